@@ -1,0 +1,2 @@
+from .basic import DiffusionModel
+from .diffusionsde import BaseDiffusionSDE, DiscreteDiffusionSDE, ContinuousDiffusionSDE, SUPPORTED_SOLVERS

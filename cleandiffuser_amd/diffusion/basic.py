@@ -1,0 +1,75 @@
+"""``DiffusionModel`` -- owner of the (diffusion, condition) networks, their EMA copy and the optimiser.
+
+Interface contract: reference diffusion/basic.py:14-103 (constructor kwargs, ``.model`` / ``.model_ema``
+``nn.ModuleDict{"diffusion","condition"}``, ``.optimizer``, ``.classifier``, ``.fix_mask[None]``,
+``.loss_weight[None]``, ``train/eval/ema_update/save/load`` with the ``{"model","model_ema"}`` checkpoint).
+"""
+from copy import deepcopy
+from typing import Optional, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ..nn_condition import BaseNNCondition, IdentityCondition
+from ..nn_diffusion import BaseNNDiffusion
+from ..utils import to_tensor
+
+
+class DiffusionModel:
+    def __init__(self, nn_diffusion: BaseNNDiffusion, nn_condition: Optional[BaseNNCondition] = None,
+                 fix_mask: Union[list, np.ndarray, torch.Tensor] = None,
+                 loss_weight: Union[list, np.ndarray, torch.Tensor] = None,
+                 classifier=None, grad_clip_norm: Optional[float] = None, diffusion_steps: int = 1000,
+                 ema_rate: float = 0.995, optim_params: Optional[dict] = None,
+                 device: Union[torch.device, str] = "cpu"):
+        self.device = device
+        self.grad_clip_norm = grad_clip_norm
+        self.diffusion_steps = diffusion_steps
+        self.ema_rate = ema_rate
+
+        nets = {"diffusion": nn_diffusion.to(device),
+                "condition": (nn_condition if nn_condition is not None else IdentityCondition()).to(device)}
+        self.model = nn.ModuleDict(nets)
+        self.model_ema = deepcopy(self.model).requires_grad_(False)
+        self.model.train()
+        self.model_ema.eval()
+
+        self.optimizer = torch.optim.AdamW(self.model.parameters(),
+                                           **(optim_params or {"lr": 2e-4, "weight_decay": 1e-5}))
+        self.classifier = classifier
+
+        self.fix_mask = 0. if fix_mask is None else to_tensor(fix_mask, device)[None, ]
+        self.loss_weight = 1. if loss_weight is None else to_tensor(loss_weight, device)[None, ]
+
+    # -- mode / EMA ---------------------------------------------------------------------------- #
+    def train(self):
+        self.model.train()
+        if self.classifier is not None:
+            self.classifier.model.train()
+
+    def eval(self):
+        self.model.eval()
+        if self.classifier is not None:
+            self.classifier.model.eval()
+
+    def ema_update(self):
+        with torch.no_grad():
+            for p, p_ema in zip(self.model.parameters(), self.model_ema.parameters()):
+                p_ema.data.mul_(self.ema_rate).add_(p.data, alpha=1. - self.ema_rate)
+
+    # -- abstract ------------------------------------------------------------------------------ #
+    def update(self, x0, condition=None, update_ema=True, **kwargs):
+        raise NotImplementedError
+
+    def sample(self, *args, **kwargs):
+        raise NotImplementedError
+
+    # -- checkpoints --------------------------------------------------------------------------- #
+    def save(self, path: str):
+        torch.save({"model": self.model.state_dict(), "model_ema": self.model_ema.state_dict()}, path)
+
+    def load(self, path: str):
+        ckpt = torch.load(path, map_location=self.device)
+        self.model.load_state_dict(ckpt["model"])
+        self.model_ema.load_state_dict(ckpt["model_ema"])

@@ -1,0 +1,386 @@
+"""VP diffusion-SDE solvers: ``DiscreteDiffusionSDE`` / ``ContinuousDiffusionSDE``.
+
+Public contract = reference diffusion/diffusionsde.py (constructor kwargs :310-347 / :665-699, ``sample`` kwargs
+:401-427 / :743-769, ``loss/update/update_classifier`` :94-149, 8 solvers :14-18, guidance semantics :153-241).
+
+Architecture (different from the reference on purpose):
+
+1. ``sample()`` first *compiles* the request into a ``SamplePlan`` (engine/plan.py): one record per denoising
+   step holding the frozen scalars of that step's affine update.
+2. The plan is executed by one of two executors that share those records:
+   * **fused gfx950 executor** (engine/dispatch.py -> C-ABI ``cdx_unet1d_run``): the *whole loop* -- every
+     U-Net forward, guidance combine, clip, solver update and fix-mask blend -- runs in ONE kernel launch with
+     one workgroup per trajectory and all activations in LDS.  Chosen when the solver lives on a ROCm device,
+     gradients are off, the backbone is one the engine can compile, and no per-step classifier guidance is asked.
+   * **PyTorch executor** (``_run_plan_torch`` below): step-by-step, calling ``model["diffusion"]`` like the
+     reference does.  Serves CPU, autograd (``requires_grad=True``, DQL), classifier guidance and user backbones.
+3. Noise is drawn in exactly the reference's order (initial draw, then one draw per stochastic step) so a CPU run
+   with the same torch seed reproduces the reference; ``noise=[z0, z1, ...]`` (kwarg) replays recorded draws,
+   which is how device runs are compared with the CPU oracle and how multi-GPU shards stay seed-consistent.
+"""
+from typing import Callable, Dict, List, Optional, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ..engine import plan as _plan
+from ..engine.plan import SUPPORTED_SOLVERS, KIND_DDPM, KIND_DDIM, V_EPS, V_XTHETA, V_MULTISTEP
+from ..nn_condition import BaseNNCondition
+from ..nn_diffusion import BaseNNDiffusion
+from ..utils import (at_least_ndim, SUPPORTED_NOISE_SCHEDULES, SUPPORTED_DISCRETIZATIONS,
+                     SUPPORTED_SAMPLING_STEP_SCHEDULE)
+from .basic import DiffusionModel
+
+
+def epstheta_to_xtheta(x, alpha, sigma, eps_theta):
+    return (x - sigma * eps_theta) / alpha
+
+
+def xtheta_to_epstheta(x, alpha, sigma, x_theta):
+    return (x - alpha * x_theta) / sigma
+
+
+class _NoiseFeed:
+    """Hands out N(0,I) draws in call order: replayed from a recorded list, or fresh ``randn_like``."""
+
+    def __init__(self, recorded=None):
+        self._rec = list(recorded) if recorded is not None else None
+        self._pos = 0
+
+    def like(self, ref: torch.Tensor) -> torch.Tensor:
+        if self._rec is None:
+            return torch.randn_like(ref)
+        if self._pos >= len(self._rec):
+            raise ValueError("`noise=` list is shorter than the number of draws this sampler needs")
+        z = torch.as_tensor(self._rec[self._pos]).to(device=ref.device, dtype=ref.dtype)
+        self._pos += 1
+        if z.shape != ref.shape:
+            raise ValueError(f"recorded noise #{self._pos - 1} has shape {tuple(z.shape)}, need {tuple(ref.shape)}")
+        return z
+
+
+class BaseDiffusionSDE(DiffusionModel):
+    def __init__(self, nn_diffusion: BaseNNDiffusion, nn_condition: Optional[BaseNNCondition] = None,
+                 fix_mask=None, loss_weight=None, classifier=None, grad_clip_norm: Optional[float] = None,
+                 ema_rate: float = 0.995, optim_params: Optional[dict] = None, epsilon: float = 1e-3,
+                 noise_schedule: Union[str, Dict[str, Callable]] = "cosine",
+                 noise_schedule_params: Optional[dict] = None,
+                 x_max: Optional[torch.Tensor] = None, x_min: Optional[torch.Tensor] = None,
+                 predict_noise: bool = True, device: Union[torch.device, str] = "cpu"):
+        super().__init__(nn_diffusion, nn_condition, fix_mask, loss_weight, classifier, grad_clip_norm,
+                         0, ema_rate, optim_params, device)
+        self.predict_noise = predict_noise
+        self.epsilon = epsilon
+        self.x_max = x_max.to(device) if isinstance(x_max, torch.Tensor) else x_max
+        self.x_min = x_min.to(device) if isinstance(x_min, torch.Tensor) else x_min
+
+    # ------------------------------------------------------------------------------------------ #
+    @property
+    def supported_solvers(self):
+        return SUPPORTED_SOLVERS
+
+    @property
+    def clip_pred(self):
+        return (self.x_max is not None) or (self.x_min is not None)
+
+    # ==================================== training ============================================ #
+    def add_noise(self, x0, t=None, eps=None):
+        raise NotImplementedError
+
+    def loss(self, x0, condition=None, **kwargs):
+        xt, t, eps = self.add_noise(x0)
+        cond = self.model["condition"](condition) if condition is not None else None
+        target = eps if self.predict_noise else x0
+        err = (self.model["diffusion"](xt, t, cond) - target) ** 2
+        err = err * self.loss_weight * (1 - self.fix_mask)
+        w = kwargs.get("weighted_regression_tensor", None)
+        if w is not None:
+            err = err * w.unsqueeze(-1)
+        return err.mean()
+
+    def update(self, x0, condition=None, update_ema=True, **kwargs):
+        loss = self.loss(x0, condition, **kwargs)
+        loss.backward()
+        grad_norm = nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_clip_norm) \
+            if self.grad_clip_norm else None
+        self.optimizer.step()
+        self.optimizer.zero_grad()
+        if update_ema:
+            self.ema_update()
+        return {"loss": loss.item(), "grad_norm": grad_norm}
+
+    def update_classifier(self, x0, condition):
+        xt, t, _ = self.add_noise(x0)
+        return self.classifier.update(xt, t, condition)
+
+    # ==================================== guidance ============================================ #
+    def classifier_guidance(self, xt, t, alpha, sigma, model, condition=None, w: float = 1.0, pred=None):
+        """eps <- eps - w*sigma*grad   |   x0 <- x0 + w*sigma^2/alpha*grad   (reference :153-173)."""
+        if pred is None:
+            pred = model["diffusion"](xt, t, None)
+        if self.classifier is None or w == 0.0:
+            return pred, None
+        log_p, grad = self.classifier.gradients(xt.clone(), t, condition)
+        if self.predict_noise:
+            pred = pred - w * sigma * grad
+        else:
+            pred = pred + w * ((sigma ** 2) / alpha) * grad
+        return pred, log_p
+
+    def classifier_free_guidance(self, xt, t, model, condition=None, w: float = 1.0, pred=None, pred_uncond=None,
+                                 requires_grad: bool = False):
+        """w*pred_c + (1-w)*pred_u with the reference's forward-count rules (Q6): w==1 -> conditional only,
+        w==0 -> unconditional only (condition=None), otherwise ONE forward at batch 2B with zeros for the
+        unconditional half (reference :175-206)."""
+        with torch.set_grad_enabled(requires_grad):
+            if w != 0.0 and w != 1.0:
+                if pred is None or pred_uncond is None:
+                    b = xt.shape[0]
+                    both = torch.cat([condition, torch.zeros_like(condition)], 0)
+                    out = model["diffusion"](xt.repeat(2, *([1] * (xt.dim() - 1))), t.repeat(2), both)
+                    pred, pred_uncond = out[:b], out[b:]
+            elif w == 0.0:
+                pred, pred_uncond = 0., model["diffusion"](xt, t, None)
+            else:
+                pred, pred_uncond = model["diffusion"](xt, t, condition), 0.
+        return w * pred + (1 - w) * pred_uncond
+
+    def clip_prediction(self, pred, xt, alpha, sigma):
+        if not self.clip_pred:
+            return pred
+        if self.predict_noise:
+            upper = (xt - alpha * self.x_min) / sigma if self.x_min is not None else None
+            lower = (xt - alpha * self.x_max) / sigma if self.x_max is not None else None
+            return pred.clip(lower, upper)
+        return pred.clip(self.x_min, self.x_max)
+
+    def guided_sampling(self, xt, t, alpha, sigma, model, condition_cfg=None, w_cfg: float = 0.0,
+                        condition_cg=None, w_cg: float = 0.0, requires_grad: bool = False):
+        pred = self.classifier_free_guidance(xt, t, model, condition_cfg, w_cfg, None, None, requires_grad)
+        return self.classifier_guidance(xt, t, alpha, sigma, model, condition_cg, w_cg, pred)
+
+    # ==================================== sampling ============================================ #
+    def _resolve_schedule(self, sample_step_schedule, domain, sample_steps):
+        if isinstance(sample_step_schedule, str):
+            if sample_step_schedule not in SUPPORTED_SAMPLING_STEP_SCHEDULE:
+                raise ValueError(f"Sampling step schedule {sample_step_schedule} is not supported.")
+            return SUPPORTED_SAMPLING_STEP_SCHEDULE[sample_step_schedule](domain, sample_steps)
+        if callable(sample_step_schedule):
+            return sample_step_schedule(domain, sample_steps)
+        raise ValueError("sample_step_schedule must be a callable or a string")
+
+    def _torch_step(self, st: "_plan.Step", xt, pred, prev_xth, feed):
+        """One affine solver update on tensors (same scalars the fused kernel receives)."""
+        k0, k1, k2, k3, k4 = st.k
+        if self.predict_noise:
+            eps, xth = pred, epstheta_to_xtheta(xt, st.alpha, st.sigma, pred)
+        else:
+            eps, xth = xtheta_to_epstheta(xt, st.alpha, st.sigma, pred), pred
+        if st.kind == KIND_DDPM:
+            new = k0 * (xt - k1 * eps) + k2 * eps
+            if st.noise:
+                new = new + k3 * feed.like(xt)
+        elif st.kind == KIND_DDIM:
+            new = k0 * ((xt - k1 * eps) / k2) + k3 * eps
+        else:
+            if st.vsel == V_EPS:
+                v = eps
+            elif st.vsel == V_XTHETA:
+                v = xth
+            else:
+                v = k3 * xth - k4 * prev_xth
+            new = k0 * xt - k1 * v
+            if st.noise:
+                new = new + k2 * feed.like(xt)
+        return new, (xth if st.push else prev_xth)
+
+    def _run_plan_torch(self, plan, xt, prior, model, cond_cfg, w_cfg, cond_cg, w_cg, requires_grad,
+                        feed, t_dtype, history):
+        n = xt.shape[0]
+        prev_xth = None
+        for st in plan.steps:
+            t = torch.full((n,), st.t, dtype=t_dtype, device=self.device)
+            pred, _ = self.guided_sampling(xt, t, st.alpha, st.sigma, model, cond_cfg, w_cfg, cond_cg, w_cg,
+                                           requires_grad)
+            pred = self.clip_prediction(pred, xt, st.alpha, st.sigma)
+            xt, prev_xth = self._torch_step(st, xt, pred, prev_xth, feed)
+            xt = xt * (1. - self.fix_mask) + prior * self.fix_mask
+            if history is not None:
+                history[:, (history.shape[1] - 1) - st.index + 1] = xt.detach().cpu().numpy()
+        return xt
+
+    def _sample_common(self, plan, xt, prior, n_samples, use_ema, condition_cfg, mask_cfg, w_cfg, condition_cg,
+                       w_cg, requires_grad, preserve_history, sample_steps, feed, t_dtype, final_logp: bool):
+        from ..engine import dispatch
+        model = self.model_ema if use_ema else self.model
+        log = {"sample_history": None}
+        if preserve_history:  # (n, S+1, *prior.shape) with broadcast writes -- reference quirk Q15 kept
+            log["sample_history"] = np.empty((n_samples, sample_steps + 1, *prior.shape))
+            log["sample_history"][:, 0] = xt.detach().cpu().numpy()
+
+        with torch.set_grad_enabled(requires_grad):
+            cond_vec = model["condition"](condition_cfg, mask_cfg) if condition_cfg is not None else None
+
+        fused = None
+        if not preserve_history:
+            fused = dispatch.try_fused_sample(self, model, plan, xt, prior, cond_vec, w_cfg, w_cg,
+                                              requires_grad, feed)
+        if fused is not None:
+            xt = fused
+        else:
+            xt = self._run_plan_torch(plan, xt, prior, model, cond_vec, w_cfg, condition_cg, w_cg, requires_grad,
+                                      feed, t_dtype, log["sample_history"])
+
+        if final_logp:
+            with torch.no_grad():
+                t0 = torch.zeros((n_samples,), dtype=torch.long, device=self.device)
+                log["log_p"] = self.classifier.logp(xt, t0, condition_cg)
+        if self.clip_pred:
+            xt = xt.clip(self.x_min, self.x_max)
+        return xt, log
+
+    def sample(self, *args, **kwargs):
+        raise NotImplementedError
+
+
+class DiscreteDiffusionSDE(BaseDiffusionSDE):
+    """Discrete-time VP-SDE: the score is learnt on T grid points ``t_diffusion = linspace(eps, 1, T)`` and the
+    samplers hop between those grid points following a sampling-step schedule of S+1 indices."""
+
+    def __init__(self, nn_diffusion: BaseNNDiffusion, nn_condition: Optional[BaseNNCondition] = None,
+                 fix_mask=None, loss_weight=None, classifier=None, grad_clip_norm: Optional[float] = None,
+                 ema_rate: float = 0.995, optim_params: Optional[dict] = None, epsilon: float = 1e-3,
+                 diffusion_steps: int = 1000, discretization: Union[str, Callable] = "uniform",
+                 noise_schedule: Union[str, Dict[str, Callable]] = "cosine",
+                 noise_schedule_params: Optional[dict] = None,
+                 x_max: Optional[torch.Tensor] = None, x_min: Optional[torch.Tensor] = None,
+                 predict_noise: bool = True, device: Union[torch.device, str] = "cpu"):
+        super().__init__(nn_diffusion, nn_condition, fix_mask, loss_weight, classifier, grad_clip_norm, ema_rate,
+                         optim_params, epsilon, noise_schedule, noise_schedule_params, x_max, x_min,
+                         predict_noise, device)
+        self.diffusion_steps = diffusion_steps
+        if 1. / diffusion_steps < epsilon:
+            raise ValueError("epsilon is too large for the number of diffusion steps")
+
+        if isinstance(discretization, str):
+            grid_fn = SUPPORTED_DISCRETIZATIONS.get(discretization, SUPPORTED_DISCRETIZATIONS["uniform"])
+        elif callable(discretization):
+            grid_fn = discretization
+        else:
+            raise ValueError("discretization must be a callable or a string")
+        self.t_diffusion = grid_fn(diffusion_steps, epsilon).to(device)
+
+        if isinstance(noise_schedule, str):
+            if noise_schedule not in SUPPORTED_NOISE_SCHEDULES:
+                raise ValueError(f"Noise schedule {noise_schedule} is not supported.")
+            fwd = SUPPORTED_NOISE_SCHEDULES[noise_schedule]["forward"]
+        elif isinstance(noise_schedule, dict):
+            fwd = noise_schedule["forward"]
+        else:
+            raise ValueError("noise_schedule must be a callable or a string")
+        self.alpha, self.sigma = fwd(self.t_diffusion, **(noise_schedule_params or {}))
+        self.logSNR = torch.log(self.alpha / self.sigma)
+
+    def add_noise(self, x0, t=None, eps=None):
+        t = torch.randint(self.diffusion_steps, (x0.shape[0],), device=self.device) if t is None else t
+        eps = torch.randn_like(x0) if eps is None else eps
+        alpha, sigma = at_least_ndim(self.alpha[t], x0.dim()), at_least_ndim(self.sigma[t], x0.dim())
+        xt = alpha * x0 + sigma * eps
+        return (1. - self.fix_mask) * xt + self.fix_mask * x0, t, eps
+
+    def sample(self, prior: torch.Tensor, solver: str = "ddpm", n_samples: int = 1, sample_steps: int = 5,
+               sample_step_schedule: Union[str, Callable] = "uniform", use_ema: bool = True,
+               temperature: float = 1.0, condition_cfg=None, mask_cfg=None, w_cfg: float = 0.0,
+               condition_cg=None, w_cg: float = 0.0, diffusion_x_sampling_steps: int = 0,
+               warm_start_reference: Optional[torch.Tensor] = None, warm_start_forward_level: float = 0.3,
+               requires_grad: bool = False, preserve_history: bool = False, **kwargs):
+        """-> (x0 (n_samples, *x_shape) on self.device, log{"sample_history", "log_p"?}).  Extra kwarg
+        ``noise=[z_init, z_step...]`` replays recorded Gaussian draws instead of calling the RNG."""
+        assert solver in SUPPORTED_SOLVERS, f"Solver {solver} is not supported."
+        feed = _NoiseFeed(kwargs.get("noise", None))
+        prior = prior.to(self.device)
+
+        if isinstance(warm_start_reference, torch.Tensor):
+            horizon_T = int(warm_start_forward_level * self.diffusion_steps)
+            xt = warm_start_reference * self.alpha[horizon_T] + self.sigma[horizon_T] * feed.like(warm_start_reference)
+        else:
+            horizon_T = self.diffusion_steps
+            xt = feed.like(prior) * temperature
+        xt = xt * (1. - self.fix_mask) + prior * self.fix_mask
+
+        sched = self._resolve_schedule(sample_step_schedule, horizon_T, sample_steps)
+        idx = sched.to(self.alpha.device)
+        plan = _plan.build_vp_plan(solver, self.alpha[idx], self.sigma[idx], sched.tolist(), sample_steps,
+                                   diffusion_x_sampling_steps, t_is_integer=True)
+        return self._sample_common(plan, xt, prior, n_samples, use_ema, condition_cfg, mask_cfg, w_cfg,
+                                   condition_cg, w_cg, requires_grad, preserve_history, sample_steps, feed,
+                                   torch.long, final_logp=self.classifier is not None)
+
+
+class ContinuousDiffusionSDE(BaseDiffusionSDE):
+    """Continuous-time VP-SDE: the score is learnt for every t in [eps, t_max]; samplers evaluate the noise
+    schedule at the S+1 sampled times directly."""
+
+    def __init__(self, nn_diffusion: BaseNNDiffusion, nn_condition: Optional[BaseNNCondition] = None,
+                 fix_mask=None, loss_weight=None, classifier=None, grad_clip_norm: Optional[float] = None,
+                 ema_rate: float = 0.995, optim_params: Optional[dict] = None, epsilon: float = 1e-3,
+                 noise_schedule: Union[str, Dict[str, Callable]] = "cosine",
+                 noise_schedule_params: Optional[dict] = None,
+                 x_max: Optional[torch.Tensor] = None, x_min: Optional[torch.Tensor] = None,
+                 predict_noise: bool = True, device: Union[torch.device, str] = "cpu"):
+        super().__init__(nn_diffusion, nn_condition, fix_mask, loss_weight, classifier, grad_clip_norm, ema_rate,
+                         optim_params, epsilon, noise_schedule, noise_schedule_params, x_max, x_min,
+                         predict_noise, device)
+        self.t_diffusion = [epsilon, 0.9946] if noise_schedule == "cosine" else [epsilon, 1.]
+        if isinstance(noise_schedule, str):
+            if noise_schedule not in SUPPORTED_NOISE_SCHEDULES:
+                raise ValueError(f"Noise schedule {noise_schedule} is not supported.")
+            self.noise_schedule_funcs = SUPPORTED_NOISE_SCHEDULES[noise_schedule]
+        elif isinstance(noise_schedule, dict):
+            self.noise_schedule_funcs = noise_schedule
+        else:
+            raise ValueError("noise_schedule must be a callable or a string")
+        self.noise_schedule_params = noise_schedule_params
+
+    def _alpha_sigma(self, t):
+        return self.noise_schedule_funcs["forward"](t, **(self.noise_schedule_params or {}))
+
+    def add_noise(self, x0, t=None, eps=None):
+        lo, hi = self.t_diffusion
+        t = (torch.rand((x0.shape[0],), device=self.device) * (hi - lo) + lo) if t is None else t
+        eps = torch.randn_like(x0) if eps is None else eps
+        alpha, sigma = self._alpha_sigma(t)
+        alpha, sigma = at_least_ndim(alpha, x0.dim()), at_least_ndim(sigma, x0.dim())
+        xt = alpha * x0 + sigma * eps
+        return (1. - self.fix_mask) * xt + self.fix_mask * x0, t, eps
+
+    def sample(self, prior: torch.Tensor, solver: str = "ddpm", n_samples: int = 1, sample_steps: int = 5,
+               sample_step_schedule: Union[str, Callable] = "uniform_continuous", use_ema: bool = True,
+               temperature: float = 1.0, condition_cfg=None, mask_cfg=None, w_cfg: float = 0.0,
+               condition_cg=None, w_cg: float = 0.0, diffusion_x_sampling_steps: int = 0,
+               warm_start_reference: Optional[torch.Tensor] = None, warm_start_forward_level: float = 0.3,
+               requires_grad: bool = False, preserve_history: bool = False, **kwargs):
+        assert solver in SUPPORTED_SOLVERS, f"Solver {solver} is not supported."
+        feed = _NoiseFeed(kwargs.get("noise", None))
+        prior = prior.to(self.device)
+
+        warm = isinstance(warm_start_reference, torch.Tensor) and warm_start_forward_level > 0.
+        if warm:
+            level = self.epsilon + warm_start_forward_level * (1. - self.epsilon)
+            fa, fs = self._alpha_sigma(torch.ones((1,), device=self.device) * level)
+            xt = warm_start_reference * fa + fs * feed.like(warm_start_reference)
+            t_range = [self.t_diffusion[0], level]
+        else:
+            xt = feed.like(prior) * temperature
+            t_range = self.t_diffusion
+        xt = xt * (1. - self.fix_mask) + prior * self.fix_mask
+
+        sched = self._resolve_schedule(sample_step_schedule, t_range, sample_steps)
+        alphas, sigmas = self._alpha_sigma(sched)
+        plan = _plan.build_vp_plan(solver, alphas, sigmas, sched, sample_steps, diffusion_x_sampling_steps,
+                                   t_is_integer=False)
+        return self._sample_common(plan, xt, prior, n_samples, use_ema, condition_cfg, mask_cfg, w_cfg,
+                                   condition_cg, w_cg, requires_grad, preserve_history, sample_steps, feed,
+                                   torch.float32,
+                                   final_logp=(self.classifier is not None and w_cg != 0.))

@@ -1,0 +1,40 @@
+"""Dispatch rules between the fused gfx950 executors and the PyTorch executor.
+
+HIP fast path  <=>  tensor lives on a ROCm device  AND  gradients are off  AND  dtype is fp32  AND
+the backbone is one the program compiler understands.  Everything else (CPU tensors, autograd, exotic
+variants such as ``attention=True``) runs the stock PyTorch modules.  On a ROCm device a *missing or
+unloadable* ``libcdx.so`` is a hard error -- there is no silent eager fallback for supported backbones.
+"""
+from typing import Optional
+
+import torch
+
+
+def _on_gpu(t: torch.Tensor) -> bool:
+    return t.is_cuda
+
+
+def try_backbone_forward(module, x, noise, condition) -> Optional[torch.Tensor]:
+    """Serve ``backbone.forward`` from the fused program kernel, or return None for the PyTorch path."""
+    if not _on_gpu(x) or torch.is_grad_enabled() and _needs_grad(module, x, condition):
+        return None
+    if x.dtype != torch.float32:
+        return None
+    from . import runtime
+    return runtime.backbone_forward(module, x, noise, condition)
+
+
+def _needs_grad(module, x, condition) -> bool:
+    if x.requires_grad or (condition is not None and condition.requires_grad):
+        return True
+    return any(p.requires_grad for p in module.parameters())
+
+
+def try_fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, requires_grad, feed):
+    """Run the whole denoising loop in one launch, or return None for the PyTorch executor."""
+    if not _on_gpu(xt) or requires_grad or xt.dtype != torch.float32:
+        return None
+    if w_cg != 0.0 and solver.classifier is not None:
+        return None                      # per-step classifier gradients need autograd
+    from . import runtime
+    return runtime.fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed)

@@ -1,0 +1,116 @@
+"""Step-plan compiler: turns (solver name, noise-schedule tables, step schedule) into a flat list of
+per-step records that BOTH executors consume --
+
+* the PyTorch executor in ``diffusion/diffusionsde.py`` (CPU, autograd, classifier guidance, unknown backbones)
+* the fused gfx950 kernel (``csrc/cdx_unet1d.hip``), which receives the same records as a ``cdx_step`` array.
+
+Every scalar is evaluated exactly the way the reference evaluates it (0-dim fp32 torch ops in the same
+association order, reference diffusionsde.py:514-589), then frozen to a Python float, so the only
+per-element arithmetic left for the device is the affine update itself.
+
+Update forms (P = clipped network output, eps/xth = noise/data prediction derived from P):
+  DDPM   x <- k0*(x - k1*eps) + k2*eps  [+ k3*z]
+  DDIM   x <- k0*((x - k1*eps)/k2) + k3*eps
+  LINEAR x <- k0*x - k1*V [+ k2*z],   V in {eps, xth, D},  D = k3*xth - k4*xth_prev   (2M multistep)
+"""
+from dataclasses import dataclass, field
+from typing import List, Sequence, Tuple
+
+import torch
+
+SUPPORTED_SOLVERS = [
+    "ddpm", "ddim",
+    "ode_dpmsolver_1", "ode_dpmsolver++_1", "ode_dpmsolver++_2M",
+    "sde_dpmsolver_1", "sde_dpmsolver++_1", "sde_dpmsolver++_2M"]
+
+KIND_DDPM, KIND_DDIM, KIND_LINEAR = 0, 1, 2
+V_EPS, V_XTHETA, V_MULTISTEP = 0, 1, 2
+
+
+@dataclass
+class Step:
+    kind: int
+    vsel: int
+    index: int                 # i in the reference loop (position in the step schedule)
+    t: float                   # schedule value fed to map_noise (int index or continuous time)
+    alpha: float
+    sigma: float
+    k: Tuple[float, float, float, float, float]
+    noise: bool = False        # consumes one fresh N(0, I) draw
+    push: bool = False         # stores xth for the next multistep update
+
+
+@dataclass
+class SamplePlan:
+    solver: str
+    steps: List[Step] = field(default_factory=list)
+    t_is_integer: bool = True
+
+    @property
+    def n_noise(self) -> int:
+        return sum(1 for s in self.steps if s.noise)
+
+
+def _f(x) -> float:
+    return float(x.item()) if isinstance(x, torch.Tensor) else float(x)
+
+
+def vp_tables(alphas: torch.Tensor, sigmas: torch.Tensor):
+    """logSNR increments h_i and posterior stds (reference diffusionsde.py:516-520)."""
+    alphas, sigmas = alphas.detach().float().cpu(), sigmas.detach().float().cpu()
+    log_snr = torch.log(alphas / sigmas)
+    hs = torch.zeros_like(log_snr)
+    hs[1:] = log_snr[:-1] - log_snr[1:]
+    stds = torch.zeros_like(log_snr)
+    stds[1:] = sigmas[:-1] / sigmas[1:] * (1 - (alphas[1:] / alphas[:-1]) ** 2).sqrt()
+    return alphas, sigmas, hs, stds
+
+
+def build_vp_plan(solver: str, alphas: torch.Tensor, sigmas: torch.Tensor, schedule: Sequence,
+                  sample_steps: int, diffusion_x_sampling_steps: int = 0, t_is_integer: bool = True) -> SamplePlan:
+    assert solver in SUPPORTED_SOLVERS, f"Solver {solver} is not supported."
+    a, s, hs, stds = vp_tables(alphas, sigmas)
+    order = list(reversed([1] * diffusion_x_sampling_steps + list(range(1, sample_steps + 1))))
+    plan = SamplePlan(solver=solver, t_is_integer=t_is_integer)
+    n_pushed = 0
+    for i in order:
+        tval = schedule[i]
+        tval = int(tval) if t_is_integer else _f(tval)
+        zero = 0.0
+        if solver == "ddpm":
+            st = Step(KIND_DDPM, V_EPS, i, tval, _f(a[i]), _f(s[i]),
+                      (_f(a[i - 1] / a[i]), _f(s[i]), _f((s[i - 1] ** 2 - stds[i] ** 2 + 1e-8).sqrt()),
+                       _f(stds[i]), zero), noise=(i > 1))
+        elif solver == "ddim":
+            st = Step(KIND_DDIM, V_EPS, i, tval, _f(a[i]), _f(s[i]),
+                      (_f(a[i - 1]), _f(s[i]), _f(a[i]), _f(s[i - 1]), zero))
+        elif solver == "ode_dpmsolver_1":
+            st = Step(KIND_LINEAR, V_EPS, i, tval, _f(a[i]), _f(s[i]),
+                      (_f(a[i - 1] / a[i]), _f(s[i - 1] * torch.expm1(hs[i])), zero, zero, zero))
+        elif solver == "sde_dpmsolver_1":
+            st = Step(KIND_LINEAR, V_EPS, i, tval, _f(a[i]), _f(s[i]),
+                      (_f(a[i - 1] / a[i]), _f(2 * s[i - 1] * torch.expm1(hs[i])),
+                       _f(s[i - 1] * torch.expm1(2 * hs[i]).sqrt()), zero, zero), noise=True)
+        else:
+            multistep = solver.endswith("2M")
+            stochastic = solver.startswith("sde")
+            if stochastic:
+                k0 = _f((s[i - 1] / s[i]) * (-hs[i]).exp())
+                k1 = _f(a[i - 1] * torch.expm1(-2 * hs[i]))
+                k2 = _f(s[i - 1] * (-torch.expm1(-2 * hs[i])).sqrt())
+            else:
+                k0 = _f(s[i - 1] / s[i])
+                k1 = _f(a[i - 1] * torch.expm1(-hs[i]))
+                k2 = zero
+            k3 = k4 = zero
+            vsel = V_XTHETA
+            # the reference tests `i < sample_steps`; with at least one stored xth that is "not the first step"
+            if multistep and i < sample_steps and n_pushed >= 1:
+                r = hs[i + 1] / hs[i]
+                k3, k4 = _f(1 + 0.5 / r), _f(0.5 / r)
+                vsel = V_MULTISTEP
+            st = Step(KIND_LINEAR, vsel, i, tval, _f(a[i]), _f(s[i]), (k0, k1, k2, k3, k4),
+                      noise=stochastic, push=multistep)
+            n_pushed += 1 if multistep else 0
+        plan.steps.append(st)
+    return plan

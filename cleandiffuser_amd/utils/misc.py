@@ -1,0 +1,116 @@
+"""Small host helpers shared by the solver and backbone mirrors (reference utils.py:11-75,236-245,401-483)."""
+import os
+import random
+from typing import Callable, Dict, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+
+def set_seed(seed: int):
+    random.seed(seed)
+    os.environ["PYTHONHASHSEED"] = str(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+def at_least_ndim(x, ndim: int, pad: int = 0):
+    """Append (pad=0) or prepend (pad=1) singleton axes until x has `ndim` axes; scalars pass through."""
+    if isinstance(x, (int, float)):
+        return x
+    if not isinstance(x, (np.ndarray, torch.Tensor)):
+        raise ValueError(f"Unsupported type {type(x)}")
+    missing = ndim - x.ndim
+    if missing <= 0:
+        return x
+    shape = tuple(x.shape) + (1,) * missing if pad == 0 else (1,) * missing + tuple(x.shape)
+    return x.reshape(shape)
+
+
+def to_tensor(x, device=None):
+    if isinstance(x, torch.Tensor):
+        return x.to(device)
+    if isinstance(x, (np.ndarray, list, tuple, int, float)):
+        return torch.tensor(x, device=device)
+    raise ValueError(f"Unsupported type {type(x)}")
+
+
+def count_parameters(model: nn.Module):
+    return sum(p.numel() for p in model.parameters() if p.requires_grad)
+
+
+def ema_update(model: nn.Module, model_ema: nn.Module, ema_rate: float):
+    with torch.no_grad():
+        for p, p_ema in zip(model.parameters(), model_ema.parameters()):
+            p_ema.data.mul_(ema_rate).add_(p.data, alpha=1 - ema_rate)
+
+
+class _ModuleStateSwitch:
+    """Context manager that flips a per-module/per-parameter flag and restores it on exit."""
+
+    def __init__(self, modules):
+        self.modules = list(modules)
+        self._saved = {}
+
+
+class FreezeModules(_ModuleStateSwitch):
+    def __enter__(self):
+        for m in self.modules:
+            for p in m.parameters():
+                self._saved[id(p)] = p.requires_grad
+                p.requires_grad = False
+
+    def __exit__(self, *exc):
+        for m in self.modules:
+            for p in m.parameters():
+                p.requires_grad = self._saved[id(p)]
+
+
+class UnfreezeModules(_ModuleStateSwitch):
+    def __enter__(self):
+        for m in self.modules:
+            for p in m.parameters():
+                self._saved[id(p)] = p.requires_grad
+                p.requires_grad = True
+
+    def __exit__(self, *exc):
+        for m in self.modules:
+            for p in m.parameters():
+                p.requires_grad = self._saved[id(p)]
+
+
+class EvalModules(_ModuleStateSwitch):
+    def __enter__(self):
+        for m in self.modules:
+            self._saved[id(m)] = m.training
+            m.eval()
+
+    def __exit__(self, *exc):
+        for m in self.modules:
+            m.train(self._saved[id(m)])
+
+
+class TrainModules(_ModuleStateSwitch):
+    def __enter__(self):
+        for m in self.modules:
+            self._saved[id(m)] = m.training
+            m.train()
+
+    def __exit__(self, *exc):
+        for m in self.modules:
+            m.train(self._saved[id(m)])
+
+
+def dict_apply(x: Dict[str, torch.Tensor], func: Callable[[torch.Tensor], torch.Tensor]):
+    out = {}
+    for k, v in x.items():
+        out[k] = dict_apply(v, func) if isinstance(v, dict) else (None if v is None else func(v))
+    return out
+
+
+def loop_dataloader(dl):
+    while True:
+        yield from dl

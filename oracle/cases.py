@@ -1,0 +1,142 @@
+"""Golden-case specifications shared by the fixture generator (run on the REAL reference) and the tests
+(run on cleandiffuser_amd and on the oracle ports).  TEST INFRASTRUCTURE -- see oracle/__init__.py.
+
+A case is pure data; ``build(lib, case)`` instantiates it with whichever library namespace is passed
+(the reference's modules or this repo's mirrors), ``make_inputs(case)`` derives every input tensor from the
+deterministic PCG64 streams in ``cleandiffuser_amd.utils.synth`` (numpy only, stable across machines).
+"""
+import contextlib
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from cleandiffuser_amd.utils.synth import synth_array, synth_state_dict
+
+JANNER_CFG2 = ("JannerUNet1d", dict(in_dim=23, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2, 2], kernel_size=5))
+JANNER_TINY = ("JannerUNet1d", dict(in_dim=6, model_dim=16, emb_dim=16, dim_mult=[1, 2], kernel_size=3))
+JANNER_H4 = ("JannerUNet1d", dict(in_dim=23, model_dim=32, emb_dim=32, dim_mult=[1, 4, 2], kernel_size=5))
+
+_ALL_SOLVERS = ["ddpm", "ddim", "ode_dpmsolver_1", "ode_dpmsolver++_1", "ode_dpmsolver++_2M",
+                "sde_dpmsolver_1", "sde_dpmsolver++_1", "sde_dpmsolver++_2M"]
+
+CASES = {
+    # BASELINE config 2 (north star) at a fixture-sized batch: x-prediction, fix-mask on obs of step 0, 20/20 DDIM
+    "janner_cfg2_ddim": dict(
+        net=JANNER_CFG2, horizon=32, batch=4, fix_obs=17,
+        solver=("DiscreteDiffusionSDE", dict(diffusion_steps=20, predict_noise=False)),
+        sample=dict(solver="ddim", sample_steps=20, temperature=0.5)),
+    # same network, stochastic DDPM with eps-prediction and prediction clipping, S < T
+    "janner_cfg2_ddpm_clip": dict(
+        net=JANNER_CFG2, horizon=32, batch=3, fix_obs=17, clip=2.0,
+        solver=("DiscreteDiffusionSDE", dict(diffusion_steps=20, predict_noise=True)),
+        sample=dict(solver="ddpm", sample_steps=10, temperature=1.0)),
+    # shipped halfcheetah Diffuser shape: horizon 4, dim_mult [1,4,2] (C*L is not constant across levels)
+    "janner_h4_ddpm": dict(
+        net=JANNER_H4, horizon=4, batch=5, fix_obs=17,
+        solver=("DiscreteDiffusionSDE", dict(diffusion_steps=20, predict_noise=False)),
+        sample=dict(solver="ddpm", sample_steps=20, temperature=0.5)),
+    # conditional backbone input (b, emb_dim) through IdentityCondition: w_cfg = 1 (one forward) ...
+    "janner_tiny_cond_w1": dict(
+        net=JANNER_TINY, horizon=8, batch=3, cond_dim=16, clip=3.0,
+        solver=("DiscreteDiffusionSDE", dict(diffusion_steps=50, predict_noise=True)),
+        sample=dict(solver="ddim", sample_steps=5, w_cfg=1.0)),
+    # ... and w_cfg = 2 (reference doubles the batch: cond | zeros)
+    "janner_tiny_cond_w2": dict(
+        net=JANNER_TINY, horizon=8, batch=3, cond_dim=16, clip=3.0,
+        solver=("DiscreteDiffusionSDE", dict(diffusion_steps=50, predict_noise=True)),
+        sample=dict(solver="ode_dpmsolver++_2M", sample_steps=5, w_cfg=2.0)),
+    # continuous-time solver: float timesteps -> full positional embedding, linear schedule, quad step schedule
+    "janner_tiny_cont_quad": dict(
+        net=JANNER_TINY, horizon=8, batch=3, clip=3.0,
+        solver=("ContinuousDiffusionSDE", dict(predict_noise=True, noise_schedule="linear")),
+        sample=dict(solver="sde_dpmsolver++_2M", sample_steps=6, sample_step_schedule="quad_continuous",
+                    temperature=0.7, diffusion_x_sampling_steps=2)),
+}
+# one small case per solver (discrete + continuous) so every update rule is pinned
+for _s in _ALL_SOLVERS:
+    CASES[f"janner_tiny_disc_{_s}"] = dict(
+        net=JANNER_TINY, horizon=8, batch=2, fix_obs=4, clip=(3.0 if _s != "ddim" else None),
+        solver=("DiscreteDiffusionSDE", dict(diffusion_steps=50, predict_noise=(_s != "ddim"))),
+        sample=dict(solver=_s, sample_steps=5, temperature=0.8))
+    CASES[f"janner_tiny_cont_{_s}"] = dict(
+        net=JANNER_TINY, horizon=8, batch=2, clip=(2.5 if _s == "ddim" else None),
+        solver=("ContinuousDiffusionSDE", dict(predict_noise=(_s == "ddim"))),
+        sample=dict(solver=_s, sample_steps=4))
+
+
+def lib_namespace(kind: str):
+    """'amd' -> this repo's mirrors; 'reference' -> the real reference (build container only)."""
+    if kind == "amd":
+        from cleandiffuser_amd import diffusion, nn_condition, nn_diffusion
+    else:
+        from .ref_import import import_reference
+        import_reference()
+        from cleandiffuser import diffusion, nn_condition, nn_diffusion
+    ns = SimpleNamespace()
+    for mod in (diffusion, nn_condition, nn_diffusion):
+        for k in dir(mod):
+            if not k.startswith("_"):
+                setattr(ns, k, getattr(mod, k))
+    return ns
+
+
+def make_inputs(name: str):
+    c = CASES[name]
+    b, h, d = c["batch"], c["horizon"], c["net"][1]["in_dim"]
+    prior = np.zeros((b, h, d), np.float32)
+    fix_mask = None
+    if c.get("fix_obs"):
+        fix_mask = np.zeros((h, d), np.float32)
+        fix_mask[0, :c["fix_obs"]] = 1.0
+        prior[:, 0, :c["fix_obs"]] = synth_array(name + "/obs", (b, c["fix_obs"]))
+    n_draws = c["sample"]["sample_steps"] + c["sample"].get("diffusion_x_sampling_steps", 0) + 2
+    noise = np.stack([synth_array(f"{name}/z{k}", (b, h, d)) for k in range(n_draws)])
+    cond = synth_array(name + "/cond", (b, c["cond_dim"])) if c.get("cond_dim") else None
+    return dict(prior=prior, fix_mask=fix_mask, noise=noise, cond=cond)
+
+
+def build(lib, name: str, device="cpu", weight_seed: int = 0):
+    """-> (solver object, backbone) with deterministic synthetic weights (identical for every library)."""
+    c = CASES[name]
+    net_cls, net_kw = c["net"]
+    net = getattr(lib, net_cls)(**net_kw)
+    net.load_state_dict(synth_state_dict(net.state_dict(), weight_seed))
+    cond_net = lib.IdentityCondition(dropout=0.0) if c.get("cond_dim") else None
+    inp = make_inputs(name)
+    kw = dict(c["solver"][1])
+    if inp["fix_mask"] is not None:
+        kw["fix_mask"] = torch.from_numpy(inp["fix_mask"])
+    if c.get("clip"):
+        d = net_kw["in_dim"]
+        kw["x_max"] = torch.full((1, c["horizon"], d), float(c["clip"]))
+        kw["x_min"] = torch.full((1, c["horizon"], d), -float(c["clip"]))
+    agent = getattr(lib, c["solver"][0])(net, cond_net, device=device, **kw)
+    agent.eval()
+    return agent, net
+
+
+@contextlib.contextmanager
+def replay_randn(noise):
+    """Make ``torch.randn_like`` return the recorded draws in order (how the reference is fed fixed noise)."""
+    it = iter(noise)
+    orig = torch.randn_like
+
+    def fake(ref, *a, **k):
+        z = torch.as_tensor(next(it)).to(device=ref.device, dtype=ref.dtype)
+        assert z.shape == ref.shape, (z.shape, ref.shape)
+        return z
+    torch.randn_like = fake
+    try:
+        yield
+    finally:
+        torch.randn_like = orig
+
+
+def sample_kwargs(name: str, inputs, device="cpu"):
+    c = CASES[name]
+    kw = dict(c["sample"])
+    kw["n_samples"] = c["batch"]
+    if inputs["cond"] is not None:
+        kw["condition_cfg"] = torch.from_numpy(inputs["cond"]).to(device)
+    return kw
