@@ -1,0 +1,383 @@
+"""Network -> device-program compiler for the fused gfx950 executor.
+
+A backbone (``nn.Module``) is lowered ONCE per weight version into
+
+* ``ops``   int32 [n_ops, OP_WORDS]   -- a flat list of layer descriptors the kernel interprets in order
+* ``blob``  float32 [n]               -- every parameter, pre-packed in the exact order the kernel streams it
+* an LDS plan (float offsets)         -- where every activation lives; nothing is ever written back to HBM
+
+Data layout contract with ``csrc/cdx_unet1d.hip`` (one workgroup = one trajectory, 8 waves):
+
+Activations (LDS):  channel-last rows with a 2-row zero halo:  ``slot[(pos + 2) * stride + c]``,
+    ``stride = pad16(C) + 4`` floats (the +4 keeps ``ds_read_b128`` of 16 different rows on different banks).
+Conv weights (HBM, streamed through L2/MALL): implicit-GEMM ``out[co][n] = sum_K W[co][K] X[K][n]`` tiled for
+    ``v_mfma_f32_16x16x4_f32``; K is enumerated as (source, tap, 16-channel chunk); per (16-row tile ct, chunk q)
+    the blob holds 64 lanes x float4 = 1 KiB contiguous so a wave fetches it with ONE ``global_load_dwordx4``:
+        ``packed[ct][q][lane][m] = W[ct*16 + (lane & 15)][src, tap, cc*16 + 4*(lane >> 4) + m]``
+    (lane>>4 is the MFMA k index; the 4 floats m feed 4 consecutive MFMAs; A and B use the same K permutation).
+Linear weights: transposed ``[n_in][n_out]`` so consecutive lanes read consecutive floats.
+
+Op words: see ``W_*`` constants below; flags ``F_*``.
+"""
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+OP_WORDS = 32
+OP_LOAD_TEMB, OP_LINEAR, OP_CONV = 0, 1, 2
+
+# ---- word indices (all ops) ---------------------------------------------------------------------- #
+W_KIND = 0
+# conv
+(W_COUT, W_COUT16, W_LOUT, W_TAPS, W_CSTRIDE, W_CPAD, W_TRANSPOSED,
+ W_SRCA, W_SRCA_STRIDE, W_CA_CHUNKS, W_SRCB, W_SRCB_STRIDE, W_CB_CHUNKS,
+ W_DST, W_DST_STRIDE, W_DST_ROWS, W_WOFF, W_BOFF, W_FLAGS, W_GROUPS, W_GAMMA, W_BETA,
+ W_EMB, W_RES, W_RES_STRIDE, W_KSPLIT, W_NCHUNKS, W_LIN) = range(1, 29)
+# linear / load_temb (reuse low word indices)
+L_NIN, L_NOUT, L_SRC, L_DST, L_WOFF, L_BOFF, L_FLAGS = range(1, 8)
+
+F_GN_MISH, F_ADD_EMB, F_ADD_RES, F_ACCUM, F_DST_PRED, F_POST_MISH = 1, 2, 4, 8, 16, 32
+
+HALO = 2
+N_WAVES = 8
+GN_EPS = 1e-5
+
+
+def pad16(c: int) -> int:
+    return (c + 15) // 16 * 16
+
+
+def slot_stride(c: int) -> int:
+    return pad16(c) + 4
+
+
+def slot_floats(length: int, c: int) -> int:
+    return (length + 2 * HALO) * slot_stride(c)
+
+
+@dataclass
+class Act:
+    """An activation tensor (L positions x C channels) living in an LDS slot."""
+    length: int
+    chans: int
+    uid: int
+    off: int = -1                     # float offset into the workgroup's LDS, assigned by the allocator
+    persistent: bool = False
+
+    @property
+    def stride(self):
+        return slot_stride(self.chans)
+
+    @property
+    def floats(self):
+        return slot_floats(self.length, self.chans)
+
+
+@dataclass
+class Program:
+    ops: np.ndarray                    # int32 [n_ops, OP_WORDS]
+    blob: torch.Tensor                 # float32 1-D (device of the module)
+    lds_floats: int
+    x_off: int
+    x_stride: int
+    pred_off: int
+    pred_stride: int
+    pred_branch_floats: int            # distance between the two CFG prediction slots
+    prev_off: int                      # dense [H*D] buffer for the multistep solvers
+    vec_off: int
+    scratch_off: int
+    scratch_floats: int
+    horizon: int
+    dim: int
+    emb_dim: int
+    macs_per_forward: int              # algorithmic MACs (conv + linear), for the roofline accounting
+    n_conv: int = 0
+    meta: dict = field(default_factory=dict)
+
+
+class _Builder:
+    def __init__(self, device):
+        self.device = device
+        self.ops: List[List[int]] = []
+        self.op_acts: List[Tuple[List[Act], Optional[Act]]] = []   # (reads, writes) per op for liveness
+        self.chunks: List[torch.Tensor] = []
+        self.blob_len = 0
+        self.acts: List[Act] = []
+        self.vec_len = 0
+        self.scratch = 0
+        self.macs = 0
+        self.n_conv = 0
+
+    # ---------------- parameter blob ---------------- #
+    def add(self, t: torch.Tensor) -> int:
+        t = t.detach().to(device=self.device, dtype=torch.float32).reshape(-1)
+        off = self.blob_len
+        pad = (-t.numel()) % 4                          # keep every record 16-byte aligned
+        if pad:
+            t = torch.cat([t, torch.zeros(pad, device=self.device)])
+        self.chunks.append(t)
+        self.blob_len += t.numel()
+        return off
+
+    def pack_conv(self, w_eff: torch.Tensor, split: Sequence[int]) -> Tuple[int, int, List[int]]:
+        """w_eff [C_out][taps][C_in_total] (implicit-GEMM view), split = channel count per source.
+        Returns (blob offset, n_chunks, chunks per source)."""
+        c_out, taps, c_in = w_eff.shape
+        assert sum(split) == c_in
+        n_ct = pad16(c_out) // 16
+        parts, per_src, lo = [], [], 0
+        for cs in split:
+            w = w_eff[:, :, lo:lo + cs]
+            lo += cs
+            cs16 = pad16(cs)
+            wp = torch.zeros(n_ct * 16, taps, cs16, device=w.device, dtype=torch.float32)
+            wp[:c_out, :, :cs] = w
+            cc = cs16 // 16
+            # [ct, i, tap, cc, k4, m] -> [ct, tap, cc, k4, i, m] -> [ct, tap*cc, 64, 4]
+            wp = wp.reshape(n_ct, 16, taps, cc, 4, 4).permute(0, 2, 3, 4, 1, 5).reshape(n_ct, taps * cc, 64, 4)
+            parts.append(wp)
+            per_src.append(cc)
+        packed = torch.cat(parts, dim=1).contiguous()
+        return self.add(packed), packed.shape[1], per_src
+
+    # ---------------- LDS objects ---------------- #
+    def act(self, length: int, chans: int, persistent=False) -> Act:
+        a = Act(length, chans, len(self.acts), persistent=persistent)
+        self.acts.append(a)
+        return a
+
+    def vec(self, n: int) -> int:
+        off = self.vec_len
+        self.vec_len += (n + 3) // 4 * 4
+        return off
+
+    # ---------------- ops ---------------- #
+    def _emit(self, words: Dict[int, int], reads, writes):
+        op = [0] * OP_WORDS
+        for k, v in words.items():
+            op[k] = int(v)
+        self.ops.append(op)
+        self.op_acts.append((list(reads), writes))
+
+    def load_temb(self, n: int, dst_vec: int):
+        self._emit({W_KIND: OP_LOAD_TEMB, L_NIN: n, L_DST: dst_vec}, [], None)
+
+    def linear(self, lin_w: torch.Tensor, lin_b: torch.Tensor, src_vec: int, dst_vec: int, post_mish=False):
+        n_out, n_in = lin_w.shape
+        self._emit({W_KIND: OP_LINEAR, L_NIN: n_in, L_NOUT: n_out, L_SRC: src_vec, L_DST: dst_vec,
+                    L_WOFF: self.add(lin_w.t().contiguous()), L_BOFF: self.add(lin_b),
+                    L_FLAGS: F_POST_MISH if post_mish else 0}, [], None)
+        self.macs += n_in * n_out
+
+    def conv(self, srcs: Sequence[Act], dst: Act, w_eff: torch.Tensor, bias: torch.Tensor, *, stride=1, pad=0,
+             transposed=False, gn: Optional[nn.Module] = None, emb_vec: int = -1, res: Optional[Act] = None,
+             accum=False, dst_pred=False):
+        c_out, taps, _ = w_eff.shape
+        assert taps <= 2 * HALO + 1 and pad <= HALO
+        woff, n_chunks, per_src = self.pack_conv(w_eff, [s.chans for s in srcs])
+        n_ct = pad16(c_out) // 16
+        ksplit = max(1, min(n_chunks, -(-N_WAVES // n_ct)))
+        flags = 0
+        words = {W_KIND: OP_CONV, W_COUT: c_out, W_COUT16: pad16(c_out), W_LOUT: dst.length, W_TAPS: taps,
+                 W_CSTRIDE: stride, W_CPAD: pad, W_TRANSPOSED: int(transposed),
+                 W_SRCA: 0, W_SRCA_STRIDE: srcs[0].stride, W_CA_CHUNKS: per_src[0],
+                 W_SRCB: 0, W_SRCB_STRIDE: 0, W_CB_CHUNKS: 0,
+                 W_DST: 0, W_DST_STRIDE: dst.stride, W_DST_ROWS: dst.length + 2 * HALO,
+                 W_WOFF: woff, W_BOFF: self.add(bias), W_KSPLIT: ksplit, W_NCHUNKS: n_chunks,
+                 W_LIN: srcs[0].length}
+        if len(srcs) == 2:
+            assert srcs[1].length == srcs[0].length
+            words[W_SRCB_STRIDE], words[W_CB_CHUNKS] = srcs[1].stride, per_src[1]
+        if gn is not None:
+            flags |= F_GN_MISH
+            assert abs(gn.eps - GN_EPS) < 1e-12 and c_out % gn.num_groups == 0
+            words[W_GROUPS] = gn.num_groups
+            words[W_GAMMA], words[W_BETA] = self.add(gn.weight), self.add(gn.bias)
+        if emb_vec >= 0:
+            flags |= F_ADD_EMB
+            words[W_EMB] = emb_vec
+        if res is not None:
+            flags |= F_ADD_RES
+            assert res.chans == c_out and res.length == dst.length
+            words[W_RES_STRIDE] = res.stride
+        if accum:
+            flags |= F_ACCUM
+        if dst_pred:
+            flags |= F_DST_PRED
+        words[W_FLAGS] = flags
+        reads = list(srcs) + ([res] if res is not None else []) + ([dst] if accum else [])
+        self._emit(words, reads, dst)
+        self.scratch = max(self.scratch, ksplit * dst.length * (pad16(c_out) + 4))
+        self.macs += c_out * dst.length * taps * sum(s.chans for s in srcs) // (2 if transposed else 1)
+        self.n_conv += 1
+
+    # ---------------- LDS planning ---------------- #
+    def plan_lds(self, fixed: Dict[str, int]) -> int:
+        """Linear-scan interval allocation of the activation arena; patches slot offsets into the ops."""
+        n = len(self.ops)
+        first, last = {}, {}
+        for i, (reads, writes) in enumerate(self.op_acts):
+            for a in reads + ([writes] if writes is not None else []):
+                first.setdefault(a.uid, i)
+                last[a.uid] = i
+        base = fixed["arena"]
+        live: List[Act] = []
+        top = base
+        for a in self.acts:
+            if a.persistent:
+                continue
+            if a.uid not in first:
+                continue
+        order = sorted((a for a in self.acts if not a.persistent and a.uid in first), key=lambda a: first[a.uid])
+        for a in order:
+            t = first[a.uid]
+            live = [b for b in live if last[b.uid] >= t]
+            # first-fit among gaps between live slots
+            spans = sorted((b.off, b.off + b.floats) for b in live)
+            pos = base
+            for lo, hi in spans:
+                if lo - pos >= a.floats:
+                    break
+                pos = max(pos, hi)
+            a.off = pos
+            live.append(a)
+            top = max(top, pos + a.floats)
+        # patch offsets
+        for op, (reads, writes) in zip(self.ops, self.op_acts):
+            if op[W_KIND] != OP_CONV:
+                continue
+            srcs = reads[:2] if op[W_CB_CHUNKS] else reads[:1]
+            op[W_SRCA] = srcs[0].off
+            if op[W_CB_CHUNKS]:
+                op[W_SRCB] = srcs[1].off
+            op[W_DST] = writes.off
+            if op[W_FLAGS] & F_ADD_RES:
+                op[W_RES] = reads[len(srcs)].off
+        return top
+
+
+# ================================================================================================== #
+# JannerUNet1d lowering                                                                              #
+# ================================================================================================== #
+
+def _conv1d_eff(conv: nn.Conv1d) -> torch.Tensor:
+    return conv.weight.detach().permute(0, 2, 1)            # (C_out, C_in, k) -> [co][tap][ci]
+
+
+def _convT1d_eff(conv: nn.ConvTranspose1d) -> torch.Tensor:
+    return conv.weight.detach().permute(1, 2, 0)            # (C_in, C_out, k) -> [co][tap][ci]
+
+
+def supports_janner(net) -> Optional[str]:
+    """None if the fused kernel can run this JannerUNet1d, else the reason it cannot."""
+    if net.attention:
+        return "attention=True (LinearAttention) is PyTorch-only"
+    if net.norm_type != "groupnorm":
+        return f"norm_type={net.norm_type!r} is PyTorch-only"
+    if net.kernel_size > 2 * HALO + 1 or net.kernel_size % 2 == 0:
+        return f"kernel_size={net.kernel_size} unsupported (odd, <=5)"
+    return None
+
+
+def compile_janner(net, horizon: int, max_lds_bytes: int = 160 * 1024) -> Program:
+    """Lower a JannerUNet1d (reference nn_diffusion/jannerunet.py:98-201 structure) for `horizon` positions."""
+    why = supports_janner(net)
+    if why is not None:
+        raise ValueError(why)
+    dev = next(net.parameters()).device
+    b = _Builder(dev)
+    d, k = net.in_dim, net.kernel_size
+    md = net.model_dim
+
+    # ---- time-embedding chain: temb(+cond) -> Linear -> Mish -> Linear -> [Mish] -> stacked per-block Linear ---- #
+    blocks = []
+    for res1, res2, _, _ in net.downs:
+        blocks += [res1, res2]
+    blocks += [net.mid_block1, net.mid_block2]
+    for res1, res2, _, _ in net.ups:
+        blocks += [res1, res2]
+    v_temb, v_hid, v_memb = b.vec(net.emb_dim), b.vec(md * 4), b.vec(md)
+    emb_slices, total = {}, 0
+    for rb in blocks:
+        emb_slices[id(rb)] = total
+        total += rb.emb_mlp[1].out_features
+    v_eall = b.vec(total)
+    b.load_temb(net.emb_dim, v_temb)
+    b.linear(net.map_emb[0].weight, net.map_emb[0].bias, v_temb, v_hid, post_mish=True)
+    # emb itself is only ever consumed through emb_mlp = Mish -> Linear, so store Mish(emb) directly
+    b.linear(net.map_emb[2].weight, net.map_emb[2].bias, v_hid, v_memb, post_mish=True)
+    b.linear(torch.cat([rb.emb_mlp[1].weight for rb in blocks], 0),
+             torch.cat([rb.emb_mlp[1].bias for rb in blocks], 0), v_memb, v_eall)
+
+    x = b.act(horizon, d, persistent=True)
+
+    def resblock(srcs: List[Act], rb) -> Act:
+        c_out = rb.conv1[0].out_channels
+        length = srcs[0].length
+        t1 = b.act(length, c_out)
+        b.conv(srcs, t1, _conv1d_eff(rb.conv1[0]), rb.conv1[0].bias, pad=k // 2, gn=rb.conv1[1],
+               emb_vec=v_eall + emb_slices[id(rb)])
+        out = b.act(length, c_out)
+        identity = isinstance(rb.residual_conv, nn.Identity)
+        if identity:
+            assert len(srcs) == 1
+        b.conv([t1], out, _conv1d_eff(rb.conv2[0]), rb.conv2[0].bias, pad=k // 2, gn=rb.conv2[1],
+               res=srcs[0] if identity else None)
+        if not identity:
+            b.conv(srcs, out, _conv1d_eff(rb.residual_conv), rb.residual_conv.bias, accum=True)
+        return out
+
+    cur, skips = x, []
+    for res1, res2, _, down in net.downs:
+        cur = resblock([resblock([cur], res1)], res2)
+        skips.append(cur)
+        if not isinstance(down, nn.Identity):
+            assert cur.length % 2 == 0, "horizon too short for the number of resolutions"
+            nxt = b.act(cur.length // 2, cur.chans)
+            b.conv([cur], nxt, _conv1d_eff(down.conv), down.conv.bias, stride=2, pad=1)
+            cur = nxt
+    cur = resblock([resblock([cur], net.mid_block1)], net.mid_block2)
+    for res1, res2, _, up in net.ups:
+        cur = resblock([resblock([cur, skips.pop()], res1)], res2)
+        if not isinstance(up, nn.Identity):
+            nxt = b.act(cur.length * 2, cur.chans)
+            b.conv([cur], nxt, _convT1d_eff(up.conv), up.conv.bias, stride=2, pad=1, transposed=True)
+            cur = nxt
+    assert cur.length == horizon
+    fc = net.final_conv
+    t = b.act(horizon, md)
+    b.conv([cur], t, _conv1d_eff(fc[0]), fc[0].bias, pad=2, gn=fc[1])
+    pred = b.act(horizon, d, persistent=True)
+    b.conv([t], pred, _conv1d_eff(fc[3]), fc[3].bias, dst_pred=True)
+
+    # ---- LDS map: [x | pred0 | pred1 | prev(dense) | vec | scratch | arena...] ---- #
+    off = 0
+    x.off, off = off, off + x.floats
+    pred.off, off = off, off + pred.floats
+    pred_branch = pred.floats
+    off += pred.floats                                    # second prediction slot (CFG unconditional branch)
+    prev_off, off = off, off + (horizon * d + 3) // 4 * 4
+    vec_off, off = off, off + b.vec_len
+    scratch_off, off = off, off + (b.scratch + 3) // 4 * 4
+    top = b.plan_lds({"arena": off})
+    if top * 4 > max_lds_bytes:
+        raise ValueError(f"LDS plan needs {top * 4} B > {max_lds_bytes} B (horizon {horizon} too long for one workgroup)")
+    ops = np.asarray(b.ops, dtype=np.int32)
+    # vec offsets were relative; make them absolute LDS offsets
+    for op in ops:
+        if op[W_KIND] == OP_LOAD_TEMB:
+            op[L_DST] += vec_off
+        elif op[W_KIND] == OP_LINEAR:
+            op[L_SRC] += vec_off
+            op[L_DST] += vec_off
+        elif op[W_FLAGS] & F_ADD_EMB:
+            op[W_EMB] += vec_off
+    blob = torch.cat(b.chunks) if b.chunks else torch.zeros(0, device=dev)
+    return Program(ops=ops, blob=blob.contiguous(), lds_floats=top, x_off=x.off, x_stride=x.stride,
+                   pred_off=pred.off, pred_stride=pred.stride, pred_branch_floats=pred_branch, prev_off=prev_off,
+                   vec_off=vec_off, scratch_off=scratch_off, scratch_floats=b.scratch, horizon=horizon, dim=d,
+                   emb_dim=net.emb_dim, macs_per_forward=b.macs, n_conv=b.n_conv,
+                   meta={"n_ops": len(ops), "blob_floats": int(blob.numel())})

@@ -1,0 +1,272 @@
+"""ctypes binding of libcdx.so (include/cdx.h) + program cache + launch helpers.
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every tensor crosses the boundary as a raw
+device pointer.  There is NO CPU or eager fallback in this module -- if the library cannot be loaded on a ROCm
+device, callers get a RuntimeError telling them to build it (``python -c "import __graft_entry__ as g; g.build()"``).
+"""
+import ctypes
+import os
+import weakref
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import program as P
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libcdx.so")
+ABI_VERSION = 1
+
+
+class CdxStep(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("vsel", ctypes.c_int32), ("noise_idx", ctypes.c_int32),
+                ("push", ctypes.c_int32), ("alpha", ctypes.c_float), ("sigma", ctypes.c_float),
+                ("k", ctypes.c_float * 5), ("_pad", ctypes.c_float)]
+
+
+class CdxUnet1dLaunch(ctypes.Structure):
+    _fields_ = [
+        ("ops", ctypes.c_void_p), ("wblob", ctypes.c_void_p),
+        ("n_ops", ctypes.c_int32), ("lds_floats", ctypes.c_int32),
+        ("x_off", ctypes.c_int32), ("x_stride", ctypes.c_int32),
+        ("pred_off", ctypes.c_int32), ("pred_stride", ctypes.c_int32), ("pred_branch_floats", ctypes.c_int32),
+        ("prev_off", ctypes.c_int32), ("scratch_off", ctypes.c_int32),
+        ("batch", ctypes.c_int32), ("horizon", ctypes.c_int32), ("dim", ctypes.c_int32), ("emb_dim", ctypes.c_int32),
+        ("temb", ctypes.c_void_p), ("steps", ctypes.c_void_p),
+        ("n_steps", ctypes.c_int32), ("temb_per_sample", ctypes.c_int32), ("predict_noise", ctypes.c_int32),
+        ("cfg_mode", ctypes.c_int32), ("cfg_w", ctypes.c_float),
+        ("cond", ctypes.c_void_p), ("x_in", ctypes.c_void_p), ("prior", ctypes.c_void_p),
+        ("fix_mask", ctypes.c_void_p), ("noise", ctypes.c_void_p), ("x_min", ctypes.c_void_p),
+        ("x_max", ctypes.c_void_p), ("x_out", ctypes.c_void_p)]
+
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None):
+    """Load libcdx.so and declare prototypes.  Raises RuntimeError (never falls back) if it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"cleandiffuser_amd: native library not found at {path}.  Build it with "
+            f"`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950).  "
+            f"There is no eager fallback for supported backbones on a ROCm device.")
+    lib = ctypes.CDLL(path)
+    lib.cdx_abi_version.restype = ctypes.c_int
+    lib.cdx_last_error.restype = ctypes.c_char_p
+    lib.cdx_unet1d_run.argtypes = [ctypes.POINTER(CdxUnet1dLaunch), ctypes.c_void_p]
+    lib.cdx_unet1d_run.restype = ctypes.c_int
+    lib.cdx_probe_mfma_layout.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.cdx_probe_mfma_layout.restype = ctypes.c_int
+    if lib.cdx_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libcdx.so ABI {lib.cdx_abi_version()} != expected {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = load_library().cdx_last_error().decode()
+        raise RuntimeError(f"{what} failed with code {rc}: {msg}")
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+# ------------------------------------------------------------------------------------------------ #
+# program cache: one compiled program per (module, horizon), invalidated when any parameter changes #
+# ------------------------------------------------------------------------------------------------ #
+class _Compiled:
+    def __init__(self, prog: P.Program, sig):
+        self.prog = prog
+        self.sig = sig
+        self.ops_dev = torch.from_numpy(prog.ops.reshape(-1).copy()).to(prog.blob.device)
+
+
+_cache = weakref.WeakKeyDictionary()
+
+
+def _signature(module):
+    return tuple((p.data_ptr(), p._version) for p in module.parameters()) + \
+        tuple((b.data_ptr(), b._version) for b in module.buffers())
+
+
+def compiled_program(module, horizon: int) -> _Compiled:
+    per_mod = _cache.setdefault(module, {})
+    sig = _signature(module)
+    hit = per_mod.get(horizon)
+    if hit is not None and hit.sig == sig:
+        return hit
+    with torch.no_grad():
+        prog = P.compile_janner(module, horizon)
+    per_mod[horizon] = _Compiled(prog, sig)
+    return per_mod[horizon]
+
+
+def _is_janner(module) -> bool:
+    from ..nn_diffusion.jannerunet import JannerUNet1d
+    return isinstance(module, JannerUNet1d)
+
+
+def supported_backbone(module, horizon: int) -> Optional[str]:
+    """None if the fused kernel can run `module` at this horizon, else a human-readable reason."""
+    if not _is_janner(module):
+        return f"{type(module).__name__} has no fused program yet"
+    why = P.supports_janner(module)
+    if why:
+        return why
+    n_down = sum(1 for lvl in module.downs if not isinstance(lvl[3], torch.nn.Identity))
+    if horizon % (1 << n_down) != 0:
+        return f"horizon {horizon} not divisible by 2^{n_down}"
+    return None
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _f32c(t: torch.Tensor, device) -> torch.Tensor:
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+def _dense_hd(v, h: int, d: int, device) -> Optional[torch.Tensor]:
+    """Broadcast a reference-style (1,H,D)/(H,D)/(D,)/scalar tensor to a dense (H, D) fp32 table; None stays None."""
+    if v is None or (not isinstance(v, torch.Tensor) and v == 0):
+        return None
+    t = torch.as_tensor(v, dtype=torch.float32, device=device)
+    if t.dim() >= 3:
+        if t.shape[0] != 1:
+            raise ValueError("per-sample bounds/masks are not supported by the fused executor")
+        t = t[0]
+    return t.expand(h, d).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ #
+# optional per-launch timing (HIP events on the launch stream) -- used by bench.py's roofline leg      #
+# ------------------------------------------------------------------------------------------------ #
+_timing = {"on": False, "events": []}
+
+
+def enable_launch_timing(on: bool):
+    _timing["on"] = bool(on)
+    _timing["events"] = []
+
+
+def drain_launch_timing():
+    """Synchronise and return the duration (ms) of every launch recorded since enable_launch_timing(True)."""
+    out = []
+    for start, end in _timing["events"]:
+        end.synchronize()
+        out.append(start.elapsed_time(end))
+    _timing["events"] = []
+    return out
+
+
+def _launch(comp: _Compiled, *, batch, x_in, x_out, temb, steps_dev=None, n_steps=0, temb_per_sample=0,
+            predict_noise=0, cfg_mode=0, cfg_w=0.0, cond=None, prior=None, fix_mask=None, noise=None,
+            x_min=None, x_max=None):
+    prog = comp.prog
+    L = CdxUnet1dLaunch(
+        ops=comp.ops_dev.data_ptr(), wblob=prog.blob.data_ptr(), n_ops=len(prog.ops), lds_floats=prog.lds_floats,
+        x_off=prog.x_off, x_stride=prog.x_stride, pred_off=prog.pred_off, pred_stride=prog.pred_stride,
+        pred_branch_floats=prog.pred_branch_floats, prev_off=prog.prev_off, scratch_off=prog.scratch_off,
+        batch=batch, horizon=prog.horizon, dim=prog.dim, emb_dim=prog.emb_dim,
+        temb=temb.data_ptr(), steps=_ptr(steps_dev), n_steps=n_steps, temb_per_sample=temb_per_sample,
+        predict_noise=int(predict_noise), cfg_mode=cfg_mode, cfg_w=float(cfg_w), cond=_ptr(cond),
+        x_in=x_in.data_ptr(), prior=_ptr(prior), fix_mask=_ptr(fix_mask), noise=_ptr(noise),
+        x_min=_ptr(x_min), x_max=_ptr(x_max), x_out=x_out.data_ptr())
+    if _timing["on"]:
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record(torch.cuda.current_stream(x_in.device))
+    _check(load_library().cdx_unet1d_run(ctypes.byref(L), _stream_ptr(x_in.device)), "cdx_unet1d_run")
+    if _timing["on"]:
+        end.record(torch.cuda.current_stream(x_in.device))
+        _timing["events"].append((start, end))
+
+
+# ------------------------------------------------------------------------------------------------ #
+# entry points used by dispatch.py                                                                   #
+# ------------------------------------------------------------------------------------------------ #
+def backbone_forward(module, x, noise, condition) -> Optional[torch.Tensor]:
+    """``BaseNNDiffusion.forward`` on the device: one launch, per-sample timesteps."""
+    if x.dim() != 3 or supported_backbone(module, x.shape[1]) is not None:
+        return None
+    load_library()
+    b, h, d = x.shape
+    with torch.no_grad():
+        comp = compiled_program(module, h)
+        temb = _f32c(module.map_noise(noise), x.device)
+        cond = _f32c(condition, x.device) if condition is not None else None
+        xin = _f32c(x, x.device)
+        out = torch.empty_like(xin)
+        _launch(comp, batch=b, x_in=xin, x_out=out, temb=temb, temb_per_sample=1,
+                cfg_mode=1 if cond is not None else 0, cond=cond)
+    return out
+
+
+def steps_to_device(plan, device) -> torch.Tensor:
+    arr = (CdxStep * len(plan.steps))()
+    k = 0
+    for i, st in enumerate(plan.steps):
+        arr[i].kind, arr[i].vsel, arr[i].push = st.kind, st.vsel, int(st.push)
+        arr[i].alpha, arr[i].sigma = st.alpha, st.sigma
+        for j in range(5):
+            arr[i].k[j] = st.k[j]
+        if st.noise:
+            arr[i].noise_idx, k = k, k + 1
+        else:
+            arr[i].noise_idx = -1
+    raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+    return torch.from_numpy(raw).to(device)
+
+
+def fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed) -> Optional[torch.Tensor]:
+    """Whole denoising loop in one launch.  Returns None when this request must take the PyTorch executor."""
+    net = model["diffusion"]
+    if xt.dim() != 3 or supported_backbone(net, xt.shape[1]) is not None:
+        return None
+    if cond_vec is None and w_cfg not in (0.0, 1.0):
+        return None                                   # the reference raises here; let the torch executor do it
+    if cond_vec is not None and (cond_vec.dim() != 2 or cond_vec.shape[1] != net.emb_dim):
+        return None
+    try:
+        b, h, d = xt.shape
+        dev = xt.device
+        fix_mask = _dense_hd(solver.fix_mask, h, d, dev)
+        x_min = _dense_hd(solver.x_min, h, d, dev)
+        x_max = _dense_hd(solver.x_max, h, d, dev)
+    except ValueError:
+        return None
+    load_library()
+    with torch.no_grad():
+        comp = compiled_program(net, h)
+        t_dtype = torch.long if plan.t_is_integer else torch.float32
+        t_vec = torch.tensor([st.t for st in plan.steps], dtype=t_dtype, device=dev)
+        temb = _f32c(net.map_noise(t_vec), dev)
+        steps_dev = steps_to_device(plan, dev)
+        noise = torch.stack([feed.like(xt) for _ in range(plan.n_noise)]).contiguous() if plan.n_noise else None
+        if cond_vec is None or w_cfg == 0.0:
+            mode, cond = 0, None
+        elif w_cfg == 1.0:
+            mode, cond = 1, _f32c(cond_vec, dev)
+        else:
+            mode, cond = 2, _f32c(cond_vec, dev)
+        xin = _f32c(xt, dev)
+        out = torch.empty_like(xin)
+        _launch(comp, batch=b, x_in=xin, x_out=out, temb=temb, steps_dev=steps_dev, n_steps=len(plan.steps),
+                predict_noise=solver.predict_noise, cfg_mode=mode, cfg_w=w_cfg, cond=cond,
+                prior=_f32c(prior, dev) if fix_mask is not None else None, fix_mask=fix_mask, noise=noise,
+                x_min=x_min, x_max=x_max)
+    return out
+
+
+def probe_mfma_layout(device="cuda:0") -> torch.Tensor:
+    out = torch.zeros(4, 64, 4, device=device)
+    _check(load_library().cdx_probe_mfma_layout(out.data_ptr(), _stream_ptr(out.device)), "cdx_probe_mfma_layout")
+    torch.cuda.synchronize(out.device)
+    return out.cpu()

@@ -1,0 +1,100 @@
+/* cdx.h -- C ABI of libcdx.so, the gfx950 (MI355X) executor behind cleandiffuser_amd.
+ *
+ * The reference (CleanDiffuser) is pure Python on PyTorch and has NO FFI for this path: its boundary is the
+ * Python protocol `DiffusionModel.sample()` -> `model["diffusion"](xt, t, cond)` once per denoising step
+ * (reference cleandiffuser/diffusion/diffusionsde.py:401-606, loop body :526-594; backbone contract
+ * cleandiffuser/nn_diffusion/base_nn_diffusion.py:31-42).  This ABI is what a maintainer would bind *below*
+ * that protocol (ctypes stub in INTEGRATION.md): plain pointers and sizes, no torch types, caller-owned memory,
+ * no allocation and no synchronisation inside, work enqueued on the caller's HIP stream.
+ *
+ * Every entry point returns 0 on success or a negative CDX_E* code; cdx_last_error() gives the text.
+ */
+#ifndef CDX_H_
+#define CDX_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CDX_ABI_VERSION 1
+
+#define CDX_OK 0
+#define CDX_EINVAL (-1)   /* bad argument (null pointer, size out of range, misaligned offset) */
+#define CDX_ELDS (-2)     /* program needs more LDS than one gfx950 workgroup owns (160 KiB) */
+#define CDX_EHIP (-3)     /* HIP runtime error at launch; text in cdx_last_error() */
+
+/* ------------------------------------------------------------------------------------------------
+ * Layer program (built by cleandiffuser_amd/engine/program.py; word layout in csrc/cdx_ops.h).
+ * ---------------------------------------------------------------------------------------------- */
+#define CDX_OP_WORDS 32
+
+/* One denoising step = one record.  Replaces the per-step scalar arithmetic of the reference loop
+ * (diffusionsde.py:539-589): the host freezes alpha_i, sigma_i and the solver coefficients, the device applies
+ *   kind 0 (ddpm)   x <- k0*(x - k1*eps) + k2*eps [+ k3*z]
+ *   kind 1 (ddim)   x <- k0*((x - k1*eps)/k2) + k3*eps
+ *   kind 2 (linear) x <- k0*x - k1*V [+ k2*z],  V = eps | x_theta | (k3*x_theta - k4*x_theta_prev)
+ * followed by the fix-mask blend (diffusionsde.py:592). */
+typedef struct cdx_step {
+    int32_t kind;        /* 0 ddpm, 1 ddim, 2 linear */
+    int32_t vsel;        /* kind 2: 0 eps, 1 x_theta, 2 multistep D */
+    int32_t noise_idx;   /* index into `noise` of this step's N(0,I) draw, or -1 */
+    int32_t push;        /* 1: remember x_theta for the next multistep update */
+    float alpha, sigma;  /* schedule at this step (for eps<->x conversion and clipping) */
+    float k[5];
+    float _pad;
+} cdx_step;
+
+/* One launch = the whole request: either a full sampling loop (n_steps >= 1) or a single backbone forward
+ * (n_steps == 0: x_out <- network(x_in), replaces BaseNNDiffusion.forward for JannerUNet1d,
+ * reference nn_diffusion/jannerunet.py:154-201).  One workgroup per trajectory, activations in LDS. */
+typedef struct cdx_unet1d_launch {
+    /* program */
+    const int32_t* ops;        /* device, [n_ops][CDX_OP_WORDS] */
+    const float* wblob;        /* device, packed parameters */
+    int32_t n_ops;
+    int32_t lds_floats;        /* total LDS floats per workgroup */
+    int32_t x_off, x_stride;   /* state slot */
+    int32_t pred_off, pred_stride, pred_branch_floats;
+    int32_t prev_off, scratch_off;
+    /* problem */
+    int32_t batch, horizon, dim, emb_dim;
+    /* per-step tables */
+    const float* temb;         /* device, [max(n_steps,1)][emb_dim]: map_noise(t_step) evaluated on the host side */
+    const cdx_step* steps;     /* device, [n_steps]; NULL when n_steps == 0 */
+    int32_t n_steps;
+    int32_t temb_per_sample;   /* 1: temb is [batch][emb_dim] (forward mode with per-sample timesteps) */
+    int32_t predict_noise;     /* 1: network predicts eps, 0: network predicts x0 */
+    /* guidance: 0 = one unconditional forward, 1 = one conditional forward, 2 = both, w*c + (1-w)*u */
+    int32_t cfg_mode;
+    float cfg_w;
+    const float* cond;         /* device, [batch][emb_dim] or NULL */
+    /* tensors, all fp32, (batch, horizon, dim) row-major unless noted */
+    const float* x_in;         /* initial state x_T (already temperature-scaled and fix-masked), or forward input */
+    const float* prior;        /* or NULL */
+    const float* fix_mask;     /* [horizon][dim] or NULL */
+    const float* noise;        /* [n_noise][batch][horizon][dim] or NULL */
+    const float* x_min;        /* [horizon][dim] or NULL */
+    const float* x_max;        /* [horizon][dim] or NULL */
+    float* x_out;
+} cdx_unet1d_launch;
+
+/* ABI version of the loaded library (== CDX_ABI_VERSION of the header it was built from). */
+int cdx_abi_version(void);
+
+/* Text of the last error on the calling thread ("" if none). */
+const char* cdx_last_error(void);
+
+/* Enqueue the fused U-Net program kernel on `hip_stream` (a hipStream_t; NULL = default stream). */
+int cdx_unet1d_run(const cdx_unet1d_launch* launch, void* hip_stream);
+
+/* Test hook: runs v_mfma_f32_16x16x4_f32 and v_mfma_f32_4x4x1_16b_f32 on fixed operands
+ * (digit-coded lane ids, see csrc/cdx_unet1d.hip) and writes out[4][64][4] so the lane->element maps the kernels
+ * rely on are checked on the actual silicon. */
+int cdx_probe_mfma_layout(float* out_device, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CDX_H_ */
