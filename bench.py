@@ -61,8 +61,7 @@ def cpu_baseline(net, budget_s=12.0):
     prior, z0 = make_inputs("cpu", 0)
     fm = torch.zeros(1, HORIZON, DIM)
     fm[0, 0, :17] = 1.0
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    cores = torch.get_num_threads()          # torch's own default = the cores this process may use
 
     def call():
         with torch.no_grad():
@@ -80,13 +79,34 @@ def cpu_baseline(net, budget_s=12.0):
                       f"{dt:.1f}s wall, torch {torch.__version__} CPU, {cores} threads"}
 
 
+def cpu_baseline_subprocess(timeout_s=120):
+    """Run the CPU leg in a child with a hard wall-clock bound so the GPU line is never held hostage."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"], capture_output=True,
+                           text=True, timeout=timeout_s)
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:  # noqa: BLE001 -- report, never fail the bench on the baseline leg
+        return {"value": None, "unit": "trajectories/s", "cores": None, "kind": "port",
+                "sample": f"cpu baseline leg failed or exceeded {timeout_s}s: {type(e).__name__}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.cpu_baseline_only:               # child process of the N=1 run: CPU oracle timing only
+        _, net = build_agent("cpu")
+        print(json.dumps(cpu_baseline(net)), flush=True)
+        return
+
+    import faulthandler
+    faulthandler.dump_traceback_later(240, exit=False)     # if anything wedges, say where (stderr)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -159,8 +179,9 @@ def main():
                          "flops_per_launch": flops_per_traj * BATCH},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(net)
+            out["cpu_baseline"] = cpu_baseline_subprocess()
         print(json.dumps(out), flush=True)
+    faulthandler.cancel_dump_traceback_later()
 
     if dist is not None:
         dist.barrier()

@@ -36,6 +36,13 @@
 #define CDX_W_KSPLIT 26
 #define CDX_W_NCHUNKS 27
 #define CDX_W_LIN 28
+#define CDX_W_MODE 29
+#define CDX_W_ITEMS 30
+#define CDX_W_NITEMS 31
+#define CDX_W_INV_CNT 32
+#define CDX_W_CG 33
+#define CDX_W_CG_SHIFT 34
+#define CDX_W_INV_COUT 35
 // ---- linear / load_temb ----
 #define CDX_L_NIN 1
 #define CDX_L_NOUT 2
@@ -51,6 +58,16 @@
 #define CDX_F_ACCUM 8
 #define CDX_F_DST_PRED 16
 #define CDX_F_POST_MISH 32
+
+#define CDX_MODE_16X16 0
+#define CDX_MODE_4X4 1
+#define CDX_ITEM_WORDS 8
+#define CDX_I_WOFF 0
+#define CDX_I_PART 1
+#define CDX_I_NQ 2
+#define CDX_I_ONB 3
+#define CDX_I_TAP 4
+#define CDX_I_CC 5
 
 #define CDX_HALO 2
 #define CDX_N_WAVES 8

@@ -32,7 +32,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define CDX_THREADS (CDX_N_WAVES * 64)
-#define CDX_PF 4  // weight records in flight per wave
+#define CDX_EPI_REGS 4  // GroupNorm elements a lane keeps in registers (groups of <= 256 elements)
 
 static thread_local char g_err[256] = "";
 static void set_err(const char* msg) {
@@ -44,129 +44,232 @@ static void set_err(const char* msg) {
 // device helpers
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float mish_f(float x) {
-    // x * tanh(softplus(x)) with tanh(log(1+e^x)) = n / (n + 2), n = e^x (e^x + 2); softplus threshold 20 as ATen
-    const float e = expf(fminf(x, 20.0f));
+    // x * tanh(softplus(x)) with tanh(log(1+e^x)) = n / (n + 2), n = e^x (e^x + 2); softplus threshold 20 as ATen.
+    // v_exp_f32 / v_rcp_f32 are 1-ulp instructions: relative error of the result ~3e-7, far inside the 1e-4 budget.
+    const float e = __expf(fminf(x, 20.0f));
     const float n = e * (e + 2.0f);
-    return x > 20.0f ? x : x * n / (n + 2.0f);
+    return x > 20.0f ? x : x * n * __builtin_amdgcn_rcpf(n + 2.0f);
 }
 
+// wave64 all-reduce (sum) on the DPP network: quad swaps, row half-mirror, row mirror, then the 4 row sums
+// are combined through SGPRs.  ~10 issue slots instead of 6 dependent ds_bpermute round trips.
+template <int CTRL>
+__device__ __forceinline__ float dpp_step(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true);
+    return v + __builtin_bit_cast(float, moved);
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v = dpp_step<0xB1>(v);    // quad_perm [1,0,3,2]
+    v = dpp_step<0x4E>(v);    // quad_perm [2,3,0,1]
+    v = dpp_step<0x141>(v);   // row_half_mirror
+    v = dpp_step<0x140>(v);   // row_mirror  -> every lane holds its 16-lane row sum
+    const int iv = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
-// LDS row (halo included) feeding output position `pos` at kernel tap `tap`, or -1 when it contributes zero.
-__device__ __forceinline__ int conv_row(int pos, int tap, int cstride, int cpad, int transposed) {
-    if (transposed) {
-        const int num = pos + cpad - tap;
-        if (num % cstride != 0) return -1;
-        return num / cstride + CDX_HALO;
-    }
-    return pos * cstride + tap - cpad + CDX_HALO;
+// Profiling stamps are written to LDS (a global store would be waited on by the next s_waitcnt vmcnt(0) and distort
+// the phase being measured) and copied out once at kernel end.
+__device__ __forceinline__ void stamp(unsigned long long* slot, int tid) {
+    if (slot && tid == 0) *slot = __builtin_amdgcn_s_memtime();
+}
+
+// LDS row (halo included) feeding output position `pos` at kernel tap `tap`.  Positions/taps that contribute
+// nothing (odd phase of a stride-2 transposed conv, columns past l_out) are pointed at row 0 -- the top halo row,
+// which is all zeros -- so the B fetch needs no predicate.  Transposed convs are stride 2 (host asserts).
+__device__ __forceinline__ int conv_row(int pos, int tap, int cstride, int cpad, int transposed, int l_out) {
+    const int fwd = pos * cstride + tap - cpad + CDX_HALO;
+    const int num = pos + cpad - tap;
+    const int bwd = (num & 1) ? 0 : (num >> 1) + CDX_HALO;
+    const int row = transposed ? bwd : fwd;
+    return pos < l_out ? row : 0;
 }
 
 struct ConvGeom {
     int taps, cstride, cpad, transposed, l_out;
+    int col0;      // first output position of this pass (long horizons are covered in passes of 2 column tiles)
     int srcA, strideA, ca, srcB, strideB, cb;
 };
 
-// K loop of one conv for the column tiles [0, NT): every wave owns work items (ct, ks).
-template <int NT>
-__device__ __forceinline__ void conv_kloop(const ConvGeom& g, const float* __restrict__ wrec, int n_ct, int ksplit,
-                                           int nchunks, float* __restrict__ lds, int scratch, int sstride,
-                                           int lane, int wave) {
-    const int j = lane & 15, k4 = lane >> 4;
-    const int qa = g.taps * g.ca;
-    for (int item = wave; item < n_ct * ksplit; item += CDX_N_WAVES) {
-        const int ct = item % n_ct, ks = item / n_ct;
-        const int q0 = ks * nchunks / ksplit, q1 = (ks + 1) * nchunks / ksplit;
+struct ChunkCursor {           // scalar (SGPR) walk over K = (source, tap, channel chunk)
+    int tap, cc, ccn, src, sstr;
+};
+
+// MFMA shape traits.  M16: v_mfma_f32_16x16x4_f32 -- 16 rows x 16 cols, a record covers 16 K values (4 per k-lane
+// group).  M4: v_mfma_f32_4x4x1_16b_f32 -- 16 blocks of 4x4 = 64 rows x 4 cols, a record covers 4 K values.
+struct M16 {
+    static constexpr int COLS = 16, KSTEP = 16, PF = 8;
+    static __device__ __forceinline__ int col(int lane) { return lane & 15; }
+    static __device__ __forceinline__ int koff(int lane) { return 4 * (lane >> 4); }   // B: which 4 of the 16 K
+    static __device__ __forceinline__ int drow(int lane) { return 4 * (lane >> 4); }   // D: first of 4 rows
+    static __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+};
+struct M4 {
+    static constexpr int COLS = 4, KSTEP = 4, PF = 8;
+    static __device__ __forceinline__ int col(int lane) { return lane & 3; }
+    static __device__ __forceinline__ int koff(int) { return 0; }
+    static __device__ __forceinline__ int drow(int lane) { return 4 * (lane >> 2); }
+    static __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+    }
+};
+
+template <class M, int NT>
+__device__ __forceinline__ void lane_rows(const ConvGeom& g, int tap, int sstr, int lane, int (&roff)[NT]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+        roff[nt] = conv_row(g.col0 + nt * M::COLS + M::col(lane), tap, g.cstride, g.cpad, g.transposed, g.l_out) *
+                       sstr + M::koff(lane);
+}
+
+template <class M, int NT>
+__device__ __forceinline__ void fetch_b(const float* __restrict__ lds, const ChunkCursor& c, const int (&roff)[NT],
+                                        f32x4 (&bv)[NT]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+        bv[nt] = *reinterpret_cast<const f32x4*>(lds + c.src + roff[nt] + c.cc * M::KSTEP);
+}
+
+// K loop of one conv: every wave walks its work items (item table built by the host: one row tile x one K range).
+// All control flow is scalar (wave index via readfirstlane, item records via s_load), the weight ring keeps M::PF
+// 1-KiB records in flight per wave with counted vmcnt, and chunk q+1's B operand is read from LDS under chunk q's
+// MFMAs.
+// Prefetched head of the next conv's weight stream: the first CDX_PRE records of this wave's first work item,
+// issued before the previous op's barrier/epilogue so that they have landed when the K loop starts.
+#define CDX_PRE 8
+struct Prefetch {
+    f32x4 rec[CDX_PRE];   // native vector type: SROA keeps these in VGPRs across the op loop
+    int ok;               // wave-uniform: rec[] belongs to (this op, item == wave)
+};
+
+#define CDX_RL(v, k) __builtin_amdgcn_readlane((v), (k))
+
+template <class M, int NT>
+__device__ __forceinline__ void conv_kloop(const ConvGeom& g, const float* __restrict__ wblob,
+                                           const int* __restrict__ ldsi, int items_at, int n_items,
+                                           float* __restrict__ lds, int scratch, int sstride, int lane, int wave,
+                                           Prefetch& pre, unsigned long long* prof) {
+    constexpr int PF = M::PF;
+    static_assert(PF >= CDX_PRE, "ring shallower than the cross-op prefetch");
+    const int tid0 = (wave == 0 && lane == 0) ? 0 : 1;       // stamp() fires for tid == 0 only
+    for (int item = wave; item < n_items; item += CDX_N_WAVES) {
+        const int iw = ldsi[items_at + item * CDX_ITEM_WORDS + (lane & 7)];   // item record: one ds_read, then SGPRs
+        const int it0 = CDX_RL(iw, CDX_I_WOFF), it1 = CDX_RL(iw, CDX_I_PART), nq = CDX_RL(iw, CDX_I_NQ);
+        const int it3 = CDX_RL(iw, CDX_I_ONB), it4 = CDX_RL(iw, CDX_I_TAP), it5 = CDX_RL(iw, CDX_I_CC);
+        if (prof && item == 0) { asm volatile("" ::"s"(nq)); stamp(prof + 4, tid0); }
+        ChunkCursor c;
+        c.tap = it4; c.cc = it5;
+        if (it3) { c.ccn = g.cb; c.src = g.srcB; c.sstr = g.strideB; }
+        else       { c.ccn = g.ca; c.src = g.srcA; c.sstr = g.strideA; }
         f32x4 acc0[NT], acc1[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             acc0[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             acc1[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        // decode the first chunk of this K range
-        int on_b, tap, cc;
-        if (q0 < qa) {
-            on_b = 0; tap = q0 / g.ca; cc = q0 % g.ca;
-        } else {
-            on_b = 1; tap = (q0 - qa) / g.cb; cc = (q0 - qa) % g.cb;
-        }
-        int src = on_b ? g.srcB : g.srcA, sstr = on_b ? g.strideB : g.strideA, ccn = on_b ? g.cb : g.ca;
         int roff[NT];
+        lane_rows<M, NT>(g, c.tap, c.sstr, lane, roff);
+
+        const f32x4* wp = reinterpret_cast<const f32x4*>(wblob + it0) + lane;
+        f32x4 wr[PF];
+        if (pre.ok && item == wave) {                      // head of the stream was fetched during the previous op
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int pos = nt * 16 + j;
-            const int row = pos < g.l_out ? conv_row(pos, tap, g.cstride, g.cpad, g.transposed) : -1;
-            roff[nt] = row >= 0 ? row * sstr + 4 * k4 : -1;
+            for (int u = 0; u < CDX_PRE; ++u) wr[u] = pre.rec[u];
+#pragma unroll
+            for (int u = CDX_PRE; u < PF; ++u) wr[u] = wp[(size_t)min(u, nq - 1) * 64];
+        } else {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) wr[u] = wp[(size_t)min(u, nq - 1) * 64];  // unconditional: vmcnt stays countable
         }
-        const float4* wp = reinterpret_cast<const float4*>(wrec) + ((size_t)ct * nchunks + q0) * 64 + lane;
-        float4 wr[CDX_PF];
+        f32x4 bcur[NT];
+        fetch_b<M, NT>(lds, c, roff, bcur);
+        if (prof && item == 0) { asm volatile("" ::"v"(wr[0][0]), "v"(bcur[0][0])); stamp(prof + 5, tid0); }
+
+        auto chunk = [&](const f32x4 a, bool more) {
+            if (++c.cc == c.ccn) {
+                c.cc = 0;
+                if (++c.tap == g.taps) {
+                    c.tap = 0; c.ccn = g.cb; c.src = g.srcB; c.sstr = g.strideB;
+                }
+                lane_rows<M, NT>(g, c.tap, c.sstr, lane, roff);
+            }
+            f32x4 bnext[NT];
+            if (more) fetch_b<M, NT>(lds, c, roff, bnext);
 #pragma unroll
-        for (int u = 0; u < CDX_PF; ++u)
-            if (q0 + u < q1) wr[u] = wp[(size_t)u * 64];
-        for (int q = q0; q < q1; q += CDX_PF) {
+            for (int nt = 0; nt < NT; ++nt) {
+                acc0[nt] = M::mfma(a[0], bcur[nt][0], acc0[nt]);
+                acc1[nt] = M::mfma(a[1], bcur[nt][1], acc1[nt]);
+                acc0[nt] = M::mfma(a[2], bcur[nt][2], acc0[nt]);
+                acc1[nt] = M::mfma(a[3], bcur[nt][3], acc1[nt]);
+            }
 #pragma unroll
-            for (int u = 0; u < CDX_PF; ++u) {
-                if (q + u < q1) {
-                    const float4 a = wr[u];
-                    if (q + u + CDX_PF < q1) wr[u] = wp[(size_t)(q + u + CDX_PF - q0) * 64];
+            for (int nt = 0; nt < NT; ++nt) bcur[nt] = bnext[nt];
+        };
+
+        // steady state: every ring slot is refilled unconditionally -> counted s_waitcnt vmcnt(PF-1)
+        int qi = 0;
+        const int n_main = (nq / PF - 1) * PF;
+        for (; qi < n_main; qi += PF) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (roff[nt] >= 0) bv = *reinterpret_cast<const float4*>(lds + src + roff[nt] + cc * 16);
-                        acc0[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bv.x, acc0[nt], 0, 0, 0);
-                        acc1[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bv.y, acc1[nt], 0, 0, 0);
-                        acc0[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bv.z, acc0[nt], 0, 0, 0);
-                        acc1[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bv.w, acc1[nt], 0, 0, 0);
-                    }
-                    // advance (source, tap, cc)
-                    if (++cc == ccn) {
-                        cc = 0;
-                        if (++tap == g.taps) {
-                            tap = 0; on_b = 1;
-                            src = g.srcB; sstr = g.strideB; ccn = g.cb;
-                        }
+            for (int u = 0; u < PF; ++u) {
+                chunk(wr[u], true);
+                wr[u] = wp[(size_t)(qi + u + PF) * 64];
+            }
+        }
+        // drain: the last (up to 2*PF - 1) chunks, refilling only while records remain
+        for (; qi < nq; qi += PF) {
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
-                            const int pos = nt * 16 + j;
-                            const int row = pos < g.l_out ? conv_row(pos, tap, g.cstride, g.cpad, g.transposed) : -1;
-                            roff[nt] = row >= 0 ? row * sstr + 4 * k4 : -1;
-                        }
-                    }
+            for (int u = 0; u < PF; ++u) {
+                if (qi + u < nq) {
+                    chunk(wr[u], qi + u + 1 < nq);
+                    if (qi + u + PF < nq) wr[u] = wp[(size_t)(qi + u + PF) * 64];
                 }
             }
         }
-        // D fragment: lane holds rows 4*k4 + r of column j  ->  scratch[ks][n][ct*16 + 4*k4 + r]
+        if (prof && item == 0) { asm volatile("" ::"v"(acc0[0][0]), "v"(acc1[0][0])); stamp(prof + 6, tid0); }
+        // D fragment: this lane holds 4 consecutive rows of one column -> scratch[k-slice][n][row tile + rows]
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int n = nt * 16 + j;
+            const int n = g.col0 + nt * M::COLS + M::col(lane);
             if (n < g.l_out) {
                 const f32x4 d = acc0[nt] + acc1[nt];
-                *reinterpret_cast<float4*>(lds + scratch + (ks * g.l_out + n) * sstride + ct * 16 + 4 * k4) =
+                *reinterpret_cast<float4*>(lds + scratch + it1 + n * sstride + M::drow(lane)) =
                     make_float4(d[0], d[1], d[2], d[3]);
             }
         }
     }
 }
 
-__device__ void conv_op(const int32_t* __restrict__ op, const float* __restrict__ wblob, float* __restrict__ lds,
-                        int scratch, int pred_branch_off, int tid) {
-    const int lane = tid & 63, wave = tid >> 6;
-    const int c_out = op[CDX_W_COUT], c16 = op[CDX_W_COUT16], l_out = op[CDX_W_LOUT];
-    const int flags = op[CDX_W_FLAGS];
-    const int dst = op[CDX_W_DST] + ((flags & CDX_F_DST_PRED) ? pred_branch_off : 0);
-    const int dstride = op[CDX_W_DST_STRIDE], drows = op[CDX_W_DST_ROWS];
-    const int ksplit = op[CDX_W_KSPLIT], nchunks = op[CDX_W_NCHUNKS];
-    const int n_ct = c16 >> 4, sstride = c16 + 4;
+// exact floor(e / d) for 0 <= e < 2^20 from a host-computed fp32 reciprocal (no integer division on the device)
+__device__ __forceinline__ int div_small(int e, int d, float inv_d) {
+    int q = (int)(((float)e + 0.5f) * inv_d);
+    const int r = e - q * d;
+    q += (r >= d) - (r < 0);
+    return q;
+}
+
+// `w` holds this op's descriptor, one word per lane (lane k = word k); `wn` the next op's.
+__device__ __forceinline__ void conv_op(const int w, const int wn, const int* __restrict__ ldsi, int desc_off,
+                        const float* __restrict__ wblob, float* __restrict__ lds,
+                        int scratch, int pred_branch_off, int tid, Prefetch& pre, unsigned long long* prof) {
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c_out = CDX_RL(w, CDX_W_COUT), c16 = CDX_RL(w, CDX_W_COUT16), l_out = CDX_RL(w, CDX_W_LOUT);
+    const int flags = CDX_RL(w, CDX_W_FLAGS);
+    const int dst = CDX_RL(w, CDX_W_DST) + ((flags & CDX_F_DST_PRED) ? pred_branch_off : 0);
+    const int dstride = CDX_RL(w, CDX_W_DST_STRIDE), drows = CDX_RL(w, CDX_W_DST_ROWS);
+    const int ksplit = CDX_RL(w, CDX_W_KSPLIT);
+    const int sstride = c16 + 4;
 
     ConvGeom g;
-    g.taps = op[CDX_W_TAPS]; g.cstride = op[CDX_W_CSTRIDE]; g.cpad = op[CDX_W_CPAD];
-    g.transposed = op[CDX_W_TRANSPOSED]; g.l_out = l_out;
-    g.srcA = op[CDX_W_SRCA]; g.strideA = op[CDX_W_SRCA_STRIDE]; g.ca = op[CDX_W_CA_CHUNKS];
-    g.srcB = op[CDX_W_SRCB]; g.strideB = op[CDX_W_SRCB_STRIDE]; g.cb = op[CDX_W_CB_CHUNKS];
+    g.taps = CDX_RL(w, CDX_W_TAPS); g.cstride = CDX_RL(w, CDX_W_CSTRIDE); g.cpad = CDX_RL(w, CDX_W_CPAD);
+    g.transposed = CDX_RL(w, CDX_W_TRANSPOSED); g.l_out = l_out; g.col0 = 0;
+    g.srcA = CDX_RL(w, CDX_W_SRCA); g.strideA = CDX_RL(w, CDX_W_SRCA_STRIDE); g.ca = CDX_RL(w, CDX_W_CA_CHUNKS);
+    g.srcB = CDX_RL(w, CDX_W_SRCB); g.strideB = CDX_RL(w, CDX_W_SRCB_STRIDE); g.cb = CDX_RL(w, CDX_W_CB_CHUNKS);
 
     // 1. clear the destination slot (halo rows + pad columns must read as zero for the consumer)
     if (!(flags & CDX_F_ACCUM)) {
@@ -176,26 +279,103 @@ __device__ void conv_op(const int32_t* __restrict__ op, const float* __restrict_
     }
 
     // 2. implicit-GEMM K loop -> split-K partials in scratch
-    const float* wrec = wblob + op[CDX_W_WOFF];
-    const int n_nt = (l_out + 15) >> 4;
-    if (n_nt == 1) conv_kloop<1>(g, wrec, n_ct, ksplit, nchunks, lds, scratch, sstride, lane, wave);
-    else if (n_nt == 2) conv_kloop<2>(g, wrec, n_ct, ksplit, nchunks, lds, scratch, sstride, lane, wave);
-    else conv_kloop<4>(g, wrec, n_ct, ksplit, nchunks, lds, scratch, sstride, lane, wave);
-    __syncthreads();
+    const int items_at = desc_off + CDX_RL(w, CDX_W_ITEMS);
+    const int n_items = CDX_RL(w, CDX_W_NITEMS);
+    if (CDX_RL(w, CDX_W_MODE) == CDX_MODE_4X4) {
+        if (l_out <= 4) conv_kloop<M4, 1>(g, wblob, ldsi, items_at, n_items, lds, scratch, sstride, lane, wave, pre, prof);
+        else conv_kloop<M4, 2>(g, wblob, ldsi, items_at, n_items, lds, scratch, sstride, lane, wave, pre, prof);
+    } else {
+        if (l_out <= 16) conv_kloop<M16, 1>(g, wblob, ldsi, items_at, n_items, lds, scratch, sstride, lane, wave, pre, prof);
+        else {
+            // 32 positions per pass; longer horizons re-stream the weights once per extra pass (rare: H = 64)
+            for (g.col0 = 0; g.col0 < l_out; g.col0 += 32) {
+                conv_kloop<M16, 2>(g, wblob, ldsi, items_at, n_items, lds, scratch, sstride, lane, wave, pre, prof);
+                pre.ok = 0;
+            }
+        }
+    }
 
-    // 3. epilogue
-    const float* bias = wblob + op[CDX_W_BOFF];
-    const int res = op[CDX_W_RES], rstride = op[CDX_W_RES_STRIDE];
-    if (flags & CDX_F_GN_MISH) {
-        const int groups = op[CDX_W_GROUPS];
-        const int cg = c_out / groups, cnt = cg * l_out;
-        const float* gamma = wblob + op[CDX_W_GAMMA];
-        const float* beta = wblob + op[CDX_W_BETA];
-        const float inv_cnt = 1.0f / (float)cnt;
+    // 2b. cross-op prefetch: start streaming the head of the NEXT conv's weights for this wave's first item now;
+    //     the loads fly through the barrier and the epilogue below.
+    pre.ok = 0;
+    if (CDX_RL(wn, CDX_W_KIND) == CDX_OP_CONV && wave < CDX_RL(wn, CDX_W_NITEMS)) {
+        const int iw = ldsi[desc_off + CDX_RL(wn, CDX_W_ITEMS) + wave * CDX_ITEM_WORDS + (lane & 7)];
+        const int nq = CDX_RL(iw, CDX_I_NQ);
+        const f32x4* wp = reinterpret_cast<const f32x4*>(wblob + CDX_RL(iw, CDX_I_WOFF)) + lane;
+#pragma unroll
+        for (int u = 0; u < CDX_PRE; ++u) pre.rec[u] = wp[(size_t)min(u, nq - 1) * 64];
+        pre.ok = 1;
+    }
+    stamp(prof ? prof + 7 : nullptr, tid);
+    // 3. epilogue.  Per-channel parameters are fetched BEFORE the barrier so their latency hides behind the wait
+    //    for the slowest wave; everything after the barrier touches only LDS.
+    const float* __restrict__ bias = wblob + CDX_RL(w, CDX_W_BOFF);
+    const int res = CDX_RL(w, CDX_W_RES), rstride = CDX_RL(w, CDX_W_RES_STRIDE), emb = CDX_RL(w, CDX_W_EMB);
+    const int groups = CDX_RL(w, CDX_W_GROUPS), cg = CDX_RL(w, CDX_W_CG), sh = CDX_RL(w, CDX_W_CG_SHIFT);
+    const int cnt = cg * l_out;
+    const bool gn = flags & CDX_F_GN_MISH;
+    const bool gn_fast = gn && sh >= 0 && cnt <= 64 * CDX_EPI_REGS && groups <= CDX_N_WAVES;
+    if (gn_fast) {
+        // one wave per group; a lane keeps its <= CDX_EPI_REGS elements in registers across the three passes
+        const float* __restrict__ gamma = wblob + CDX_RL(w, CDX_W_GAMMA);
+        const float* __restrict__ beta = wblob + CDX_RL(w, CDX_W_BETA);
+        float bi[CDX_EPI_REGS], ga[CDX_EPI_REGS], be[CDX_EPI_REGS];
+        int nn[CDX_EPI_REGS], cc[CDX_EPI_REGS];
+        const bool active = wave < groups;
+        if (active) {
+#pragma unroll
+            for (int t = 0; t < CDX_EPI_REGS; ++t) {
+                const int e = min(lane + 64 * t, cnt - 1);
+                nn[t] = e >> sh;
+                cc[t] = wave * cg + (e & (cg - 1));
+                bi[t] = bias[cc[t]]; ga[t] = gamma[cc[t]]; be[t] = beta[cc[t]];
+            }
+        }
+        stamp(prof ? prof + 1 : nullptr, tid);
+        __syncthreads();
+        stamp(prof ? prof + 2 : nullptr, tid);
+        if (active) {
+            const float inv_cnt = __int_as_float(CDX_RL(w, CDX_W_INV_CNT));
+            float v[CDX_EPI_REGS];
+            float s = 0.f;
+#pragma unroll
+            for (int t = 0; t < CDX_EPI_REGS; ++t) {
+                float acc = bi[t];
+                for (int ks = 0; ks < ksplit; ++ks) acc += lds[scratch + (ks * l_out + nn[t]) * sstride + cc[t]];
+                v[t] = acc;
+                s += (lane + 64 * t < cnt) ? acc : 0.f;
+            }
+            const float mean = wave_sum(s) * inv_cnt;
+            float s2 = 0.f;
+#pragma unroll
+            for (int t = 0; t < CDX_EPI_REGS; ++t) {
+                const float d = v[t] - mean;
+                s2 += (lane + 64 * t < cnt) ? d * d : 0.f;
+            }
+            const float rstd = __builtin_amdgcn_rsqf(wave_sum(s2) * inv_cnt + CDX_GN_EPS);
+#pragma unroll
+            for (int t = 0; t < CDX_EPI_REGS; ++t) {
+                if (lane + 64 * t < cnt) {
+                    float y = mish_f((v[t] - mean) * rstd * ga[t] + be[t]);
+                    if (flags & CDX_F_ADD_EMB) y += lds[emb + cc[t]];
+                    if (flags & CDX_F_ADD_RES) y += lds[res + (nn[t] + CDX_HALO) * rstride + cc[t]];
+                    lds[dst + (nn[t] + CDX_HALO) * dstride + cc[t]] = y;
+                }
+            }
+        }
+    } else if (gn) {
+        // general GroupNorm path (odd group sizes / long horizons): three passes through LDS
+        const float* __restrict__ gamma = wblob + CDX_RL(w, CDX_W_GAMMA);
+        const float* __restrict__ beta = wblob + CDX_RL(w, CDX_W_BETA);
+        const float inv_cnt = __int_as_float(CDX_RL(w, CDX_W_INV_CNT));
+        const float inv_cg = 1.0f / (float)cg;
+        stamp(prof ? prof + 1 : nullptr, tid);
+        __syncthreads();
+        stamp(prof ? prof + 2 : nullptr, tid);
         for (int gi = wave; gi < groups; gi += CDX_N_WAVES) {
             float s = 0.f;
             for (int e = lane; e < cnt; e += 64) {
-                const int n = e / cg, c = gi * cg + (e - n * cg);
+                const int n = div_small(e, cg, inv_cg), c = gi * cg + (e - n * cg);
                 float v = bias[c];
                 for (int ks = 0; ks < ksplit; ++ks) v += lds[scratch + (ks * l_out + n) * sstride + c];
                 lds[scratch + n * sstride + c] = v;  // owned by this lane only
@@ -204,28 +384,38 @@ __device__ void conv_op(const int32_t* __restrict__ op, const float* __restrict_
             const float mean = wave_sum(s) * inv_cnt;
             float s2 = 0.f;
             for (int e = lane; e < cnt; e += 64) {
-                const int n = e / cg, c = gi * cg + (e - n * cg);
+                const int n = div_small(e, cg, inv_cg), c = gi * cg + (e - n * cg);
                 const float d = lds[scratch + n * sstride + c] - mean;
                 s2 += d * d;
             }
-            const float var = wave_sum(s2) * inv_cnt;
-            const float rstd = 1.0f / sqrtf(var + CDX_GN_EPS);
+            const float rstd = __builtin_amdgcn_rsqf(wave_sum(s2) * inv_cnt + CDX_GN_EPS);
             for (int e = lane; e < cnt; e += 64) {
-                const int n = e / cg, c = gi * cg + (e - n * cg);
-                float v = (lds[scratch + n * sstride + c] - mean) * rstd * gamma[c] + beta[c];
-                v = mish_f(v);
-                if (flags & CDX_F_ADD_EMB) v += lds[op[CDX_W_EMB] + c];
+                const int n = div_small(e, cg, inv_cg), c = gi * cg + (e - n * cg);
+                float v = mish_f((lds[scratch + n * sstride + c] - mean) * rstd * gamma[c] + beta[c]);
+                if (flags & CDX_F_ADD_EMB) v += lds[emb + c];
                 if (flags & CDX_F_ADD_RES) v += lds[res + (n + CDX_HALO) * rstride + c];
                 lds[dst + (n + CDX_HALO) * dstride + c] = v;
             }
         }
     } else {
+        // plain conv (down/up-sample, 1x1 residual, output head): bias (+ residual / accumulate)
+        const float inv_cout = __int_as_float(CDX_RL(w, CDX_W_INV_COUT));
         const int total = c_out * l_out;
+        int n0, c0;
+        float b0;
+        {
+            const int e = min(tid, total - 1);
+            n0 = div_small(e, c_out, inv_cout); c0 = e - n0 * c_out; b0 = bias[c0];
+        }
+        stamp(prof ? prof + 1 : nullptr, tid);
+        __syncthreads();
+        stamp(prof ? prof + 2 : nullptr, tid);
         for (int e = tid; e < total; e += CDX_THREADS) {
-            const int n = e / c_out, c = e - n * c_out;
-            float v = bias[c];
+            int n = n0, c = c0;
+            float v = b0;
+            if (e != tid) { n = div_small(e, c_out, inv_cout); c = e - n * c_out; v = bias[c]; }
             for (int ks = 0; ks < ksplit; ++ks) v += lds[scratch + (ks * l_out + n) * sstride + c];
-            if (flags & CDX_F_ADD_EMB) v += lds[op[CDX_W_EMB] + c];
+            if (flags & CDX_F_ADD_EMB) v += lds[emb + c];
             if (flags & CDX_F_ADD_RES) v += lds[res + (n + CDX_HALO) * rstride + c];
             const int o = dst + (n + CDX_HALO) * dstride + c;
             if (flags & CDX_F_ACCUM) v += lds[o];
@@ -235,23 +425,71 @@ __device__ void conv_op(const int32_t* __restrict__ op, const float* __restrict_
     __syncthreads();
 }
 
-__device__ void run_program(const cdx_unet1d_launch& L, float* __restrict__ lds, int step, int branch, bool use_cond,
-                            int b, int tid) {
+__device__ __forceinline__ void run_program(const cdx_unet1d_launch& L, float* __restrict__ lds, int step, int branch, bool use_cond,
+                            int b, int tid, Prefetch& pre) {
+    const bool profiling = L.prof != nullptr && b == 0 && step == 0 && branch == 0;
+    unsigned long long* lprof = reinterpret_cast<unsigned long long*>(lds + L.prof_off);
+    const int* __restrict__ ldsi = reinterpret_cast<const int*>(lds);
+    const int lane = tid & 63;
+    const int dlane = lane < CDX_OP_WORDS ? lane : 0;
+    int wn = ldsi[L.desc_off + dlane];                       // descriptor of op 0, one word per lane
     for (int oi = 0; oi < L.n_ops; ++oi) {
-        const int32_t* op = L.ops + (size_t)oi * CDX_OP_WORDS;
-        const int kind = op[CDX_W_KIND];
+        const int w = wn;
+        const int nxt = oi + 1 < L.n_ops ? oi + 1 : 0;
+        wn = ldsi[L.desc_off + nxt * CDX_OP_WORDS + dlane];  // next descriptor: its latency hides behind this op
+        const int kind = CDX_RL(w, CDX_W_KIND);
+        const int op[8] = {kind, CDX_RL(w, 1), CDX_RL(w, 2), CDX_RL(w, 3), CDX_RL(w, 4), CDX_RL(w, 5), CDX_RL(w, 6),
+                           CDX_RL(w, 7)};                    // linear / temb ops only use words 0..7
+        unsigned long long* pslot = profiling ? lprof + (size_t)oi * 8 : nullptr;
+        stamp(pslot, tid);
         if (kind == CDX_OP_CONV) {
-            conv_op(op, L.wblob, lds, L.scratch_off, branch * L.pred_branch_floats, tid);
+            conv_op(w, oi + 1 < L.n_ops ? wn : 0, ldsi, L.desc_off, L.wblob, lds, L.scratch_off,
+                    branch * L.pred_branch_floats, tid, pre, pslot);
         } else if (kind == CDX_OP_LINEAR) {
             const int n_in = op[CDX_L_NIN], n_out = op[CDX_L_NOUT];
-            const float* w = L.wblob + op[CDX_L_WOFF];   // [n_in][n_out]
-            const float* bb = L.wblob + op[CDX_L_BOFF];
+            const float* __restrict__ w = L.wblob + op[CDX_L_WOFF];   // [n_in][n_out]
+            const float* __restrict__ bb = L.wblob + op[CDX_L_BOFF];
             const int src = op[CDX_L_SRC], dst = op[CDX_L_DST];
             const bool post = op[CDX_L_FLAGS] & CDX_F_POST_MISH;
-            for (int o = tid; o < n_out; o += CDX_THREADS) {
-                float acc = bb[o];
-                for (int i = 0; i < n_in; ++i) acc = fmaf(w[(size_t)i * n_out + o], lds[src + i], acc);
-                lds[dst + o] = post ? mish_f(acc) : acc;
+            int kparts = CDX_THREADS / n_out;
+            kparts = kparts > 16 ? 16 : kparts;
+            if (kparts > 1) {
+                // narrow output: (k-part, output) pairs across the workgroup, partials through the scratch area
+                if (tid < n_out * kparts) {
+                    const int part = tid / n_out, o = tid - part * n_out;
+                    const int i0 = part * n_in / kparts, i1 = (part + 1) * n_in / kparts;
+                    float acc = 0.f;
+#pragma unroll 8
+                    for (int i = i0; i < i1; ++i) acc = fmaf(w[(size_t)i * n_out + o], lds[src + i], acc);
+                    lds[L.scratch_off + part * n_out + o] = acc;
+                }
+                __syncthreads();
+                if (tid < n_out) {
+                    float acc = bb[tid];
+                    for (int part = 0; part < kparts; ++part) acc += lds[L.scratch_off + part * n_out + tid];
+                    lds[dst + tid] = post ? mish_f(acc) : acc;
+                }
+            } else {
+                // wide output: 4 outputs per thread so 4 x unroll independent weight loads are in flight
+                for (int o0 = tid; o0 < n_out; o0 += CDX_THREADS * 4) {
+                    int oo[4];
+                    float acc[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int o = o0 + u * CDX_THREADS;
+                        oo[u] = o < n_out ? o : o0;
+                        acc[u] = bb[oo[u]];
+                    }
+#pragma unroll 4
+                    for (int i = 0; i < n_in; ++i) {
+                        const float xi = lds[src + i];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) acc[u] = fmaf(w[(size_t)i * n_out + oo[u]], xi, acc[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (o0 + u * CDX_THREADS < n_out) lds[dst + oo[u]] = post ? mish_f(acc[u]) : acc[u];
+                }
             }
             __syncthreads();
         } else {  // CDX_OP_LOAD_TEMB
@@ -263,6 +501,7 @@ __device__ void run_program(const cdx_unet1d_launch& L, float* __restrict__ lds,
             }
             __syncthreads();
         }
+        stamp(pslot ? pslot + 3 : nullptr, tid);
     }
 }
 
@@ -272,6 +511,8 @@ __global__ __launch_bounds__(CDX_THREADS) void cdx_unet1d_kernel(const cdx_unet1
     const int b = blockIdx.x;
     const int H = L.horizon, D = L.dim, HD = H * D;
     const size_t xbase = (size_t)b * HD;
+    unsigned long long* lprof = reinterpret_cast<unsigned long long*>(lds + L.prof_off);
+    if (L.prof && b == 0) stamp(lprof + (size_t)L.n_ops * 8, tid);
 
     // ---- state slot: zero (halo + pad channels), then load x_T ----
     {
@@ -286,12 +527,21 @@ __global__ __launch_bounds__(CDX_THREADS) void cdx_unet1d_kernel(const cdx_unet1
     }
     __syncthreads();
 
+    // ---- layer descriptors + work-item tables: global -> LDS once (scalar-cache misses cost ~800 cycles per op) ----
+    {
+        int* ldsi = reinterpret_cast<int*>(lds);
+        for (int i = tid; i < L.desc_words; i += CDX_THREADS) ldsi[L.desc_off + i] = L.ops[i];
+    }
+    __syncthreads();
+    Prefetch pre;
+    pre.ok = 0;
+
     const int n_iter = L.n_steps > 0 ? L.n_steps : 1;
     for (int step = 0; step < n_iter; ++step) {
         const int n_branch = (L.cfg_mode == 2) ? 2 : 1;
         for (int br = 0; br < n_branch; ++br) {
             const bool use_cond = (L.cond != nullptr) && (L.cfg_mode == 1 || (L.cfg_mode == 2 && br == 0));
-            run_program(L, lds, step, br, use_cond, b, tid);
+            run_program(L, lds, step, br, use_cond, b, tid, pre);
         }
         if (L.n_steps == 0) {  // forward-only: emit the prediction
             for (int e = tid; e < HD; e += CDX_THREADS) {
@@ -349,6 +599,11 @@ __global__ __launch_bounds__(CDX_THREADS) void cdx_unet1d_kernel(const cdx_unet1
         const int n = e / D, c = e - n * D;
         L.x_out[xbase + e] = lds[L.x_off + (n + CDX_HALO) * L.x_stride + c];
     }
+    if (L.prof && b == 0) {
+        stamp(lprof + (size_t)L.n_ops * 8 + 1, tid);
+        __syncthreads();
+        for (int i = tid; i < L.n_ops * 8 + 2; i += CDX_THREADS) L.prof[i] = lprof[i];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -391,6 +646,12 @@ int cdx_unet1d_run(const cdx_unet1d_launch* L, void* hip_stream) {
     if (L->cfg_mode == 2 && !L->cond) { set_err("cfg_mode 2 needs cond"); return CDX_EINVAL; }
     if ((L->x_off | L->pred_off | L->prev_off | L->scratch_off | L->x_stride | L->pred_stride | L->pred_branch_floats) & 3) {
         set_err("LDS offsets/strides must be multiples of 4 floats"); return CDX_EINVAL;
+    }
+    if (L->desc_words < L->n_ops * CDX_OP_WORDS || L->desc_off < 0 || L->desc_off + L->desc_words > L->lds_floats) {
+        set_err("descriptor area does not fit the LDS plan"); return CDX_EINVAL;
+    }
+    if (L->prof && (L->prof_off <= 0 || (L->prof_off & 1) || L->prof_off + 2 * (L->n_ops * 8 + 2) > L->lds_floats)) {
+        set_err("profiling requested but the LDS plan has no stamp area"); return CDX_EINVAL;
     }
     const size_t lds_bytes = (size_t)L->lds_floats * sizeof(float);
     if (lds_bytes > 160u * 1024u) { set_err("program needs more than 160 KiB of LDS"); return CDX_ELDS; }

@@ -17,6 +17,12 @@ Conv weights (HBM, streamed through L2/MALL): implicit-GEMM ``out[co][n] = sum_K
     (lane>>4 is the MFMA k index; the 4 floats m feed 4 consecutive MFMAs; A and B use the same K permutation).
 Linear weights: transposed ``[n_in][n_out]`` so consecutive lanes read consecutive floats.
 
+Narrow layers (<= 8 positions, C_out % 64 == 0) use MODE_4X4 instead: ``v_mfma_f32_4x4x1_16b_f32`` computes 16 independent
+    4x4 outer products, i.e. 64 output channels x 4 positions per instruction with no padded columns; the record is
+        ``packed[ct64][q][lane][m] = W[ct64*64 + lane][src, tap, cc*4 + m]``   (one K value per MFMA, 4 per record).
+All integer divisions the kernel would need (work-item decode, K-range boundaries, cursor start) are done here and
+shipped as an item table behind the ops (``I_*`` words), because scalar division costs ~200 cycles on the device.
+
 Op words: see ``W_*`` constants below; flags ``F_*``.
 """
 from dataclasses import dataclass, field
@@ -26,8 +32,11 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-OP_WORDS = 32
+OP_WORDS = 40
+ITEM_WORDS = 8
 OP_LOAD_TEMB, OP_LINEAR, OP_CONV = 0, 1, 2
+MODE_16X16, MODE_4X4 = 0, 1        # MFMA shape of a conv: 16x16x4 (16 rows x 16 cols x 16 K per record) or
+                                   # 4x4x1 x16 blocks (64 rows x 4 cols x 4 K per record) for <= 8 positions
 
 # ---- word indices (all ops) ---------------------------------------------------------------------- #
 W_KIND = 0
@@ -35,7 +44,10 @@ W_KIND = 0
 (W_COUT, W_COUT16, W_LOUT, W_TAPS, W_CSTRIDE, W_CPAD, W_TRANSPOSED,
  W_SRCA, W_SRCA_STRIDE, W_CA_CHUNKS, W_SRCB, W_SRCB_STRIDE, W_CB_CHUNKS,
  W_DST, W_DST_STRIDE, W_DST_ROWS, W_WOFF, W_BOFF, W_FLAGS, W_GROUPS, W_GAMMA, W_BETA,
- W_EMB, W_RES, W_RES_STRIDE, W_KSPLIT, W_NCHUNKS, W_LIN) = range(1, 29)
+ W_EMB, W_RES, W_RES_STRIDE, W_KSPLIT, W_NCHUNKS, W_LIN,
+ W_MODE, W_ITEMS, W_NITEMS, W_INV_CNT, W_CG, W_CG_SHIFT, W_INV_COUT) = range(1, 36)
+# item record (ITEM_WORDS int32 each, appended to the ops buffer): one K-range of one row tile = one wave's job
+I_WOFF, I_PART, I_NQ, I_ONB, I_TAP, I_CC = range(6)
 # linear / load_temb (reuse low word indices)
 L_NIN, L_NOUT, L_SRC, L_DST, L_WOFF, L_BOFF, L_FLAGS = range(1, 8)
 
@@ -44,6 +56,11 @@ F_GN_MISH, F_ADD_EMB, F_ADD_RES, F_ACCUM, F_DST_PRED, F_POST_MISH = 1, 2, 4, 8, 
 HALO = 2
 N_WAVES = 8
 GN_EPS = 1e-5
+
+
+def _fbits(x: float) -> int:
+    """fp32 bit pattern as a (signed) int32 op word."""
+    return int(np.float32(x).view(np.int32))
 
 
 def pad16(c: int) -> int:
@@ -79,6 +96,7 @@ class Act:
 @dataclass
 class Program:
     ops: np.ndarray                    # int32 [n_ops, OP_WORDS]
+    ops_buffer: np.ndarray             # int32 1-D: the ops followed by the item tables (what the device gets)
     blob: torch.Tensor                 # float32 1-D (device of the module)
     lds_floats: int
     x_off: int
@@ -90,6 +108,8 @@ class Program:
     vec_off: int
     scratch_off: int
     scratch_floats: int
+    desc_off: int                      # LDS home of the kernel's copy of ops_buffer
+    prof_off: int                      # LDS home of the profiling stamps (u64, so an even float offset)
     horizon: int
     dim: int
     emb_dim: int
@@ -110,6 +130,8 @@ class _Builder:
         self.scratch = 0
         self.macs = 0
         self.n_conv = 0
+        self.op_items: List[Optional[list]] = []           # per op: item records (convs) or None
+        self.allow_4x4 = True
 
     # ---------------- parameter blob ---------------- #
     def add(self, t: torch.Tensor) -> int:
@@ -122,23 +144,28 @@ class _Builder:
         self.blob_len += t.numel()
         return off
 
-    def pack_conv(self, w_eff: torch.Tensor, split: Sequence[int]) -> Tuple[int, int, List[int]]:
+    def pack_conv(self, w_eff: torch.Tensor, split: Sequence[int], mode: int) -> Tuple[int, int, List[int]]:
         """w_eff [C_out][taps][C_in_total] (implicit-GEMM view), split = channel count per source.
-        Returns (blob offset, n_chunks, chunks per source)."""
+        Returns (blob offset, n_chunks, chunks-per-tap per source)."""
         c_out, taps, c_in = w_eff.shape
         assert sum(split) == c_in
-        n_ct = pad16(c_out) // 16
+        rows, kch = (16, 16) if mode == MODE_16X16 else (64, 4)
+        n_ct = -(-c_out // rows)
         parts, per_src, lo = [], [], 0
         for cs in split:
             w = w_eff[:, :, lo:lo + cs]
             lo += cs
-            cs16 = pad16(cs)
-            wp = torch.zeros(n_ct * 16, taps, cs16, device=w.device, dtype=torch.float32)
+            csp = -(-cs // kch) * kch
+            wp = torch.zeros(n_ct * rows, taps, csp, device=w.device, dtype=torch.float32)
             wp[:c_out, :, :cs] = w
-            cc = cs16 // 16
-            # [ct, i, tap, cc, k4, m] -> [ct, tap, cc, k4, i, m] -> [ct, tap*cc, 64, 4]
-            wp = wp.reshape(n_ct, 16, taps, cc, 4, 4).permute(0, 2, 3, 4, 1, 5).reshape(n_ct, taps * cc, 64, 4)
-            parts.append(wp)
+            cc = csp // kch
+            if mode == MODE_16X16:
+                # [ct, i, tap, cc, k4, m] -> [ct, tap, cc, k4, i, m] -> [ct, tap*cc, 64, 4]   (lane = k4*16 + i)
+                wp = wp.reshape(n_ct, 16, taps, cc, 4, 4).permute(0, 2, 3, 4, 1, 5)
+            else:
+                # [ct, i, tap, cc, m] -> [ct, tap, cc, i, m] -> [ct, tap*cc, 64, 4]           (lane = i)
+                wp = wp.reshape(n_ct, 64, taps, cc, 4).permute(0, 2, 3, 1, 4)
+            parts.append(wp.reshape(n_ct, taps * cc, 64, 4))
             per_src.append(cc)
         packed = torch.cat(parts, dim=1).contiguous()
         return self.add(packed), packed.shape[1], per_src
@@ -161,6 +188,8 @@ class _Builder:
             op[k] = int(v)
         self.ops.append(op)
         self.op_acts.append((list(reads), writes))
+        if len(self.op_items) < len(self.ops):
+            self.op_items.append(None)
 
     def load_temb(self, n: int, dst_vec: int):
         self._emit({W_KIND: OP_LOAD_TEMB, L_NIN: n, L_DST: dst_vec}, [], None)
@@ -171,15 +200,33 @@ class _Builder:
                     L_WOFF: self.add(lin_w.t().contiguous()), L_BOFF: self.add(lin_b),
                     L_FLAGS: F_POST_MISH if post_mish else 0}, [], None)
         self.macs += n_in * n_out
+        kparts = min(16, (N_WAVES * 64) // n_out)
+        if kparts > 1:
+            self.scratch = max(self.scratch, n_out * kparts)
 
     def conv(self, srcs: Sequence[Act], dst: Act, w_eff: torch.Tensor, bias: torch.Tensor, *, stride=1, pad=0,
              transposed=False, gn: Optional[nn.Module] = None, emb_vec: int = -1, res: Optional[Act] = None,
              accum=False, dst_pred=False):
         c_out, taps, _ = w_eff.shape
         assert taps <= 2 * HALO + 1 and pad <= HALO
-        woff, n_chunks, per_src = self.pack_conv(w_eff, [s.chans for s in srcs])
-        n_ct = pad16(c_out) // 16
+        assert not transposed or stride == 2, "the kernel's transposed-conv row map assumes stride 2"
+        mode = MODE_4X4 if (dst.length <= 8 and c_out % 64 == 0 and self.allow_4x4) else MODE_16X16
+        woff, n_chunks, per_src = self.pack_conv(w_eff, [s.chans for s in srcs], mode)
+        rows = 16 if mode == MODE_16X16 else 64
+        n_ct = -(-c_out // rows)
         ksplit = max(1, min(n_chunks, -(-N_WAVES // n_ct)))
+        sstride = pad16(c_out) + 4
+        items, qa = [], taps * per_src[0]
+        for item in range(n_ct * ksplit):
+            ct, ks = item % n_ct, item // n_ct
+            q0, q1 = ks * n_chunks // ksplit, (ks + 1) * n_chunks // ksplit
+            if q0 < qa:
+                onb, tap, cc = 0, q0 // per_src[0], q0 % per_src[0]
+            else:
+                onb, tap, cc = 1, (q0 - qa) // per_src[1], (q0 - qa) % per_src[1]
+            items.append([woff + (ct * n_chunks + q0) * 256, ks * dst.length * sstride + ct * rows, q1 - q0,
+                          onb, tap, cc, 0, 0])
+        self.op_items.append(items)
         flags = 0
         words = {W_KIND: OP_CONV, W_COUT: c_out, W_COUT16: pad16(c_out), W_LOUT: dst.length, W_TAPS: taps,
                  W_CSTRIDE: stride, W_CPAD: pad, W_TRANSPOSED: int(transposed),
@@ -187,7 +234,8 @@ class _Builder:
                  W_SRCB: 0, W_SRCB_STRIDE: 0, W_CB_CHUNKS: 0,
                  W_DST: 0, W_DST_STRIDE: dst.stride, W_DST_ROWS: dst.length + 2 * HALO,
                  W_WOFF: woff, W_BOFF: self.add(bias), W_KSPLIT: ksplit, W_NCHUNKS: n_chunks,
-                 W_LIN: srcs[0].length}
+                 W_LIN: srcs[0].length, W_MODE: mode, W_NITEMS: len(items),
+                 W_INV_COUT: _fbits(1.0 / c_out)}
         if len(srcs) == 2:
             assert srcs[1].length == srcs[0].length
             words[W_SRCB_STRIDE], words[W_CB_CHUNKS] = srcs[1].stride, per_src[1]
@@ -195,6 +243,9 @@ class _Builder:
             flags |= F_GN_MISH
             assert abs(gn.eps - GN_EPS) < 1e-12 and c_out % gn.num_groups == 0
             words[W_GROUPS] = gn.num_groups
+            cg = c_out // gn.num_groups
+            words[W_CG], words[W_CG_SHIFT] = cg, (cg.bit_length() - 1 if cg & (cg - 1) == 0 else -1)
+            words[W_INV_CNT] = _fbits(1.0 / (cg * dst.length))
             words[W_GAMMA], words[W_BETA] = self.add(gn.weight), self.add(gn.bias)
         if emb_vec >= 0:
             flags |= F_ADD_EMB
@@ -282,13 +333,14 @@ def supports_janner(net) -> Optional[str]:
     return None
 
 
-def compile_janner(net, horizon: int, max_lds_bytes: int = 160 * 1024) -> Program:
+def compile_janner(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x4: bool = True) -> Program:
     """Lower a JannerUNet1d (reference nn_diffusion/jannerunet.py:98-201 structure) for `horizon` positions."""
     why = supports_janner(net)
     if why is not None:
         raise ValueError(why)
     dev = next(net.parameters()).device
     b = _Builder(dev)
+    b.allow_4x4 = allow_4x4
     d, k = net.in_dim, net.kernel_size
     md = net.model_dim
 
@@ -362,9 +414,19 @@ def compile_janner(net, horizon: int, max_lds_bytes: int = 160 * 1024) -> Progra
     prev_off, off = off, off + (horizon * d + 3) // 4 * 4
     vec_off, off = off, off + b.vec_len
     scratch_off, off = off, off + (b.scratch + 3) // 4 * 4
+    desc_words = len(b.ops) * OP_WORDS + sum(len(it) * ITEM_WORDS for it in b.op_items if it)
+    desc_off, off = off, off + (desc_words + 3) // 4 * 4
+    prof_off, off = off, off + (2 * (len(b.ops) * 8 + 2) + 3) // 4 * 4
     top = b.plan_lds({"arena": off})
     if top * 4 > max_lds_bytes:
         raise ValueError(f"LDS plan needs {top * 4} B > {max_lds_bytes} B (horizon {horizon} too long for one workgroup)")
+    # item tables live behind the ops in the same buffer; W_ITEMS = word offset from the buffer start
+    tail, cursor = [], len(b.ops) * OP_WORDS
+    for op, items in zip(b.ops, b.op_items):
+        if items:
+            op[W_ITEMS] = cursor
+            tail += [w for rec in items for w in rec]
+            cursor += len(items) * ITEM_WORDS
     ops = np.asarray(b.ops, dtype=np.int32)
     # vec offsets were relative; make them absolute LDS offsets
     for op in ops:
@@ -376,8 +438,10 @@ def compile_janner(net, horizon: int, max_lds_bytes: int = 160 * 1024) -> Progra
         elif op[W_FLAGS] & F_ADD_EMB:
             op[W_EMB] += vec_off
     blob = torch.cat(b.chunks) if b.chunks else torch.zeros(0, device=dev)
-    return Program(ops=ops, blob=blob.contiguous(), lds_floats=top, x_off=x.off, x_stride=x.stride,
+    ops_buffer = np.concatenate([ops.reshape(-1), np.asarray(tail, dtype=np.int64).astype(np.int32)])
+    assert ops_buffer.size == desc_words
+    return Program(ops=ops, ops_buffer=ops_buffer, blob=blob.contiguous(), lds_floats=top, x_off=x.off, x_stride=x.stride,
                    pred_off=pred.off, pred_stride=pred.stride, pred_branch_floats=pred_branch, prev_off=prev_off,
-                   vec_off=vec_off, scratch_off=scratch_off, scratch_floats=b.scratch, horizon=horizon, dim=d,
+                   vec_off=vec_off, scratch_off=scratch_off, scratch_floats=b.scratch, desc_off=desc_off, prof_off=prof_off, horizon=horizon, dim=d,
                    emb_dim=net.emb_dim, macs_per_forward=b.macs, n_conv=b.n_conv,
                    meta={"n_ops": len(ops), "blob_floats": int(blob.numel())})

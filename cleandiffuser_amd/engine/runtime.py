@@ -32,13 +32,14 @@ class CdxUnet1dLaunch(ctypes.Structure):
         ("x_off", ctypes.c_int32), ("x_stride", ctypes.c_int32),
         ("pred_off", ctypes.c_int32), ("pred_stride", ctypes.c_int32), ("pred_branch_floats", ctypes.c_int32),
         ("prev_off", ctypes.c_int32), ("scratch_off", ctypes.c_int32),
+        ("prof_off", ctypes.c_int32), ("desc_off", ctypes.c_int32), ("desc_words", ctypes.c_int32),
         ("batch", ctypes.c_int32), ("horizon", ctypes.c_int32), ("dim", ctypes.c_int32), ("emb_dim", ctypes.c_int32),
         ("temb", ctypes.c_void_p), ("steps", ctypes.c_void_p),
         ("n_steps", ctypes.c_int32), ("temb_per_sample", ctypes.c_int32), ("predict_noise", ctypes.c_int32),
         ("cfg_mode", ctypes.c_int32), ("cfg_w", ctypes.c_float),
         ("cond", ctypes.c_void_p), ("x_in", ctypes.c_void_p), ("prior", ctypes.c_void_p),
         ("fix_mask", ctypes.c_void_p), ("noise", ctypes.c_void_p), ("x_min", ctypes.c_void_p),
-        ("x_max", ctypes.c_void_p), ("x_out", ctypes.c_void_p)]
+        ("x_max", ctypes.c_void_p), ("x_out", ctypes.c_void_p), ("prof", ctypes.c_void_p)]
 
 
 _lib = None
@@ -85,7 +86,7 @@ class _Compiled:
     def __init__(self, prog: P.Program, sig):
         self.prog = prog
         self.sig = sig
-        self.ops_dev = torch.from_numpy(prog.ops.reshape(-1).copy()).to(prog.blob.device)
+        self.ops_dev = torch.from_numpy(prog.ops_buffer.copy()).to(prog.blob.device)
 
 
 _cache = weakref.WeakKeyDictionary()
@@ -167,6 +168,14 @@ def drain_launch_timing():
     return out
 
 
+_prof = {"buf": None}
+
+
+def set_profile_buffer(buf: Optional[torch.Tensor]):
+    """int64 device tensor of n_ops*4+2 entries (or None): workgroup 0 stamps s_memtime per op (debug aid)."""
+    _prof["buf"] = buf
+
+
 def _launch(comp: _Compiled, *, batch, x_in, x_out, temb, steps_dev=None, n_steps=0, temb_per_sample=0,
             predict_noise=0, cfg_mode=0, cfg_w=0.0, cond=None, prior=None, fix_mask=None, noise=None,
             x_min=None, x_max=None):
@@ -175,11 +184,12 @@ def _launch(comp: _Compiled, *, batch, x_in, x_out, temb, steps_dev=None, n_step
         ops=comp.ops_dev.data_ptr(), wblob=prog.blob.data_ptr(), n_ops=len(prog.ops), lds_floats=prog.lds_floats,
         x_off=prog.x_off, x_stride=prog.x_stride, pred_off=prog.pred_off, pred_stride=prog.pred_stride,
         pred_branch_floats=prog.pred_branch_floats, prev_off=prog.prev_off, scratch_off=prog.scratch_off,
+        prof_off=prog.prof_off, desc_off=prog.desc_off, desc_words=int(prog.ops_buffer.size),
         batch=batch, horizon=prog.horizon, dim=prog.dim, emb_dim=prog.emb_dim,
         temb=temb.data_ptr(), steps=_ptr(steps_dev), n_steps=n_steps, temb_per_sample=temb_per_sample,
         predict_noise=int(predict_noise), cfg_mode=cfg_mode, cfg_w=float(cfg_w), cond=_ptr(cond),
         x_in=x_in.data_ptr(), prior=_ptr(prior), fix_mask=_ptr(fix_mask), noise=_ptr(noise),
-        x_min=_ptr(x_min), x_max=_ptr(x_max), x_out=x_out.data_ptr())
+        x_min=_ptr(x_min), x_max=_ptr(x_max), x_out=x_out.data_ptr(), prof=_ptr(_prof["buf"]))
     if _timing["on"]:
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         start.record(torch.cuda.current_stream(x_in.device))

@@ -28,7 +28,7 @@ extern "C" {
 /* ------------------------------------------------------------------------------------------------
  * Layer program (built by cleandiffuser_amd/engine/program.py; word layout in csrc/cdx_ops.h).
  * ---------------------------------------------------------------------------------------------- */
-#define CDX_OP_WORDS 32
+#define CDX_OP_WORDS 40
 
 /* One denoising step = one record.  Replaces the per-step scalar arithmetic of the reference loop
  * (diffusionsde.py:539-589): the host freezes alpha_i, sigma_i and the solver coefficients, the device applies
@@ -51,13 +51,15 @@ typedef struct cdx_step {
  * reference nn_diffusion/jannerunet.py:154-201).  One workgroup per trajectory, activations in LDS. */
 typedef struct cdx_unet1d_launch {
     /* program */
-    const int32_t* ops;        /* device, [n_ops][CDX_OP_WORDS] */
+    const int32_t* ops;        /* device, [n_ops][CDX_OP_WORDS] followed by the per-conv work-item tables */
     const float* wblob;        /* device, packed parameters */
     int32_t n_ops;
     int32_t lds_floats;        /* total LDS floats per workgroup */
     int32_t x_off, x_stride;   /* state slot */
     int32_t pred_off, pred_stride, pred_branch_floats;
     int32_t prev_off, scratch_off;
+    int32_t prof_off;             /* LDS float offset (even) of the (n_ops*8+2) x u64 stamp area; used only if prof != NULL */
+    int32_t desc_off, desc_words; /* where the kernel keeps its copy of `ops` in LDS, and how many words it is */
     /* problem */
     int32_t batch, horizon, dim, emb_dim;
     /* per-step tables */
@@ -78,6 +80,10 @@ typedef struct cdx_unet1d_launch {
     const float* x_min;        /* [horizon][dim] or NULL */
     const float* x_max;        /* [horizon][dim] or NULL */
     float* x_out;
+    /* optional profiling: device u64 [n_ops*8 + 2]; workgroup 0 stamps s_memtime at {op start, pre-barrier,
+     * post-barrier, op end, item record read, first operands landed, MFMAs done, K loop done} for the first forward,
+     * plus kernel start/end.  NULL = off. */
+    unsigned long long* prof;
 } cdx_unet1d_launch;
 
 /* ABI version of the loaded library (== CDX_ABI_VERSION of the header it was built from). */

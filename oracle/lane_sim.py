@@ -94,43 +94,60 @@ class LaneSim:
         dstride, drows = op[P.W_DST_STRIDE], op[P.W_DST_ROWS]
         if not flags & P.F_ACCUM:
             lds[dst:dst + drows * dstride] = 0.0           # kernel zeroes the whole slot before the K loop
-        n_nt = (l_out + 15) // 16
         sstride = c16 + 4
         scratch = p.scratch_off
         lane = np.arange(64)
-        li, lk = lane & 15, lane >> 4
-        w4 = self.blob[op[P.W_WOFF]:op[P.W_WOFF] + n_ct * n_chunks * 256].reshape(n_ct, n_chunks, 64, 4)
-        for item in range(n_ct * ksplit):                  # wave w takes items w, w+8, ...
-            ct, ks = item % n_ct, item // n_ct
-            q0, q1 = ks * n_chunks // ksplit, (ks + 1) * n_chunks // ksplit
-            acc = np.zeros((n_nt, 16, 16), np.float32)     # [nt][row i][col j]
-            for q in range(q0, q1):
-                if q < taps * ca:
-                    src, sstr, tap, cc = op[P.W_SRCA], op[P.W_SRCA_STRIDE], q // ca, q % ca
-                else:
-                    qq = q - taps * ca
-                    src, sstr, tap, cc = op[P.W_SRCB], op[P.W_SRCB_STRIDE], qq // cb, qq % cb
-                a = w4[ct, q]                               # [lane][m]
+        mode = op[P.W_MODE]
+        buf = p.ops_buffer
+        for item in range(op[P.W_NITEMS]):                 # wave w takes items w, w+8, ...
+            rec = buf[op[P.W_ITEMS] + item * P.ITEM_WORDS: op[P.W_ITEMS] + (item + 1) * P.ITEM_WORDS]
+            woff, part, nq = int(rec[P.I_WOFF]), int(rec[P.I_PART]), int(rec[P.I_NQ])
+            onb, tap, cc = int(rec[P.I_ONB]), int(rec[P.I_TAP]), int(rec[P.I_CC])
+            w4 = self.blob[woff:woff + nq * 256].reshape(nq, 64, 4)
+            if mode == P.MODE_16X16:
+                n_nt, cols, kstep = (l_out + 15) // 16, 16, 16
+                li, lk = lane & 15, lane >> 4
+            else:
+                n_nt, cols, kstep = (l_out + 3) // 4, 4, 4
+                li, lk = lane & 3, lane >> 2                # li = column j, lk = block (4 output rows each)
+            acc = np.zeros((n_nt, 64, cols), np.float32)   # [col tile][row within row tile][col]
+            for q in range(nq):
+                src, sstr, ccn = ((op[P.W_SRCB], op[P.W_SRCB_STRIDE], cb) if onb
+                                  else (op[P.W_SRCA], op[P.W_SRCA_STRIDE], ca))
+                a = w4[q]                                   # [lane][m]
                 for nt in range(n_nt):
                     bmat = np.zeros((64, 4), np.float32)
                     for l in range(64):
-                        pos = nt * 16 + li[l]
-                        row = self._row(op, pos, tap) if pos < l_out else -1
-                        if row >= 0:
-                            addr = src + row * sstr + cc * 16 + 4 * lk[l]
-                            bmat[l] = lds[addr:addr + 4]
-                    for m in range(4):                      # one MFMA per m: D[i][j] += sum_k A[i][k] B[k][j]
-                        amat = np.zeros((16, 4), np.float32)
-                        kmat = np.zeros((4, 16), np.float32)
-                        amat[li, lk] = a[:, m]
-                        kmat[lk, li] = bmat[:, m]
-                        acc[nt] += amat @ kmat
-            for nt in range(n_nt):                          # D: lane (j, k4) holds rows 4*k4 + r
-                for j in range(16):
-                    n = nt * 16 + j
+                        pos = nt * cols + li[l]
+                        row = self._row(op, pos, tap) if pos < l_out else 0
+                        row = max(row, 0)                   # non-contributing taps read the all-zero halo row 0
+                        addr = src + row * sstr + cc * kstep + (4 * lk[l] if mode == P.MODE_16X16 else 0)
+                        bmat[l] = lds[addr:addr + 4]
+                    for m in range(4):
+                        if mode == P.MODE_16X16:            # D[i][j] += sum_k A[i][k] B[k][j]
+                            amat = np.zeros((16, 4), np.float32)
+                            kmat = np.zeros((4, 16), np.float32)
+                            amat[lane & 15, lane >> 4] = a[:, m]
+                            kmat[lane >> 4, lane & 15] = bmat[:, m]
+                            acc[nt][:16] += amat @ kmat
+                        else:                               # 16 blocks: D_b[i][j] += A_b[i] * B_b[j], row = 4b + i
+                            avec = a[:, m]                  # lane = 4b + i  -> row
+                            bvec = bmat[:4, m]              # every block reads the same 4 columns (lanes 0..3)
+                            acc[nt] += np.outer(avec, bvec)
+                if q + 1 < nq:                              # cursor walk (source, tap, chunk)
+                    cc += 1
+                    if cc == ccn:
+                        cc = 0
+                        tap += 1
+                        if tap == taps:
+                            tap, onb = 0, 1
+            rows = 16 if mode == P.MODE_16X16 else 64
+            for nt in range(n_nt):
+                for j in range(cols):
+                    n = nt * cols + j
                     if n < l_out:
-                        base = scratch + (ks * l_out + n) * sstride + ct * 16
-                        lds[base:base + 16] = acc[nt][:, j]
+                        base = scratch + part + n * sstride
+                        lds[base:base + rows] = acc[nt][:rows, j]
         # ---------------- epilogue ---------------- #
         bias = self.blob[op[P.W_BOFF]:op[P.W_BOFF] + c_out]
         v = np.zeros((l_out, c_out), np.float32)
