@@ -1,0 +1,56 @@
+"""Batch-sharded sampling across the GPUs of one node (one process per GPU, ``torch.distributed``).
+
+The reference has no distributed code; sampling shards trivially because trajectories are independent and the
+weights (<= 276 MB) are replicated.  There is NO collective on the data path: rank r denoises rows
+``[r*B/N, (r+1)*B/N)`` of the request.  The only optional exchange is one ``all_gather`` of the finished (B/N, ...) fp32
+shards (RCCL over xGMI on GPUs, gloo on CPU) when every rank needs the global result, e.g. for candidate arg-max.
+
+Noise is drawn for the GLOBAL batch from a seeded CPU generator and sliced per rank, so the result is independent of the
+number of ranks (the property the world_size-2 gloo test checks).
+"""
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n: int, rank: int, world: int):
+    """Contiguous, near-equal split of n rows: the first n % world ranks get one extra row."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def global_noise(shape, n_draws: int, seed: int) -> List[torch.Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(shape, generator=g) for _ in range(n_draws)]
+
+
+def sharded_sample(agent, prior: torch.Tensor, *, gather: bool = True, seed: Optional[int] = None,
+                   condition_cfg: Optional[torch.Tensor] = None, **sample_kwargs):
+    """Run ``agent.sample`` on this rank's slice of `prior` (global tensor, identical on every rank).
+
+    Returns the global (B, ...) result on every rank if ``gather`` else the local shard.  ``seed`` draws the global
+    noise list on the CPU and slices it (rank-count independent results); without it each rank uses its own RNG.
+    """
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    n = prior.shape[0]
+    lo, hi = shard_bounds(n, rank, world)
+    kw = dict(sample_kwargs)
+    kw["n_samples"] = hi - lo
+    if condition_cfg is not None:
+        kw["condition_cfg"] = condition_cfg[lo:hi]
+    if seed is not None:
+        n_draws = kw.get("sample_steps", 5) + kw.get("diffusion_x_sampling_steps", 0) + 1
+        kw["noise"] = [z[lo:hi] for z in global_noise(tuple(prior.shape), n_draws, seed)]
+    x, _ = agent.sample(prior[lo:hi], **kw)
+    if not gather or world == 1:
+        return x
+    sizes = [shard_bounds(n, r, world) for r in range(world)]
+    biggest = max(b - a for a, b in sizes)
+    pad = torch.zeros((biggest, *x.shape[1:]), dtype=x.dtype, device=x.device)
+    pad[: x.shape[0]] = x
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)                       # the one exchange step (RCCL all-gather on GPUs)
+    return torch.cat([p[: b - a] for p, (a, b) in zip(parts, sizes)], dim=0)
