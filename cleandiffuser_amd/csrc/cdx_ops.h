@@ -5,6 +5,7 @@
 #define CDX_OP_LOAD_TEMB 0
 #define CDX_OP_LINEAR 1
 #define CDX_OP_CONV 2
+#define CDX_OP_FLATTEN 3
 
 #define CDX_W_KIND 0
 // ---- conv ----
@@ -51,6 +52,7 @@
 #define CDX_L_WOFF 5
 #define CDX_L_BOFF 6
 #define CDX_L_FLAGS 7
+#define CDX_L_DST2 8
 // ---- flags ----
 #define CDX_F_GN_MISH 1
 #define CDX_F_ADD_EMB 2
@@ -58,6 +60,7 @@
 #define CDX_F_ACCUM 8
 #define CDX_F_DST_PRED 16
 #define CDX_F_POST_MISH 32
+#define CDX_F_RAW_COPY 64
 
 #define CDX_MODE_16X16 0
 #define CDX_MODE_4X4 1

@@ -438,8 +438,8 @@ __device__ __forceinline__ void run_program(const cdx_unet1d_launch& L, float* _
         const int nxt = oi + 1 < L.n_ops ? oi + 1 : 0;
         wn = ldsi[L.desc_off + nxt * CDX_OP_WORDS + dlane];  // next descriptor: its latency hides behind this op
         const int kind = CDX_RL(w, CDX_W_KIND);
-        const int op[8] = {kind, CDX_RL(w, 1), CDX_RL(w, 2), CDX_RL(w, 3), CDX_RL(w, 4), CDX_RL(w, 5), CDX_RL(w, 6),
-                           CDX_RL(w, 7)};                    // linear / temb ops only use words 0..7
+        const int op[9] = {kind, CDX_RL(w, 1), CDX_RL(w, 2), CDX_RL(w, 3), CDX_RL(w, 4), CDX_RL(w, 5), CDX_RL(w, 6),
+                           CDX_RL(w, 7), CDX_RL(w, 8)};      // linear / flatten / temb ops only use words 0..8
         unsigned long long* pslot = profiling ? lprof + (size_t)oi * 8 : nullptr;
         stamp(pslot, tid);
         if (kind == CDX_OP_CONV) {
@@ -451,6 +451,8 @@ __device__ __forceinline__ void run_program(const cdx_unet1d_launch& L, float* _
             const float* __restrict__ bb = L.wblob + op[CDX_L_BOFF];
             const int src = op[CDX_L_SRC], dst = op[CDX_L_DST];
             const bool post = op[CDX_L_FLAGS] & CDX_F_POST_MISH;
+            const bool raw_copy = op[CDX_L_FLAGS] & CDX_F_RAW_COPY;
+            const int dst2 = op[CDX_L_DST2];
             int kparts = CDX_THREADS / n_out;
             kparts = kparts > 16 ? 16 : kparts;
             if (kparts > 1) {
@@ -467,6 +469,7 @@ __device__ __forceinline__ void run_program(const cdx_unet1d_launch& L, float* _
                 if (tid < n_out) {
                     float acc = bb[tid];
                     for (int part = 0; part < kparts; ++part) acc += lds[L.scratch_off + part * n_out + tid];
+                    if (raw_copy) lds[dst2 + tid] = acc;
                     lds[dst + tid] = post ? mish_f(acc) : acc;
                 }
             } else {
@@ -488,9 +491,19 @@ __device__ __forceinline__ void run_program(const cdx_unet1d_launch& L, float* _
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
-                        if (o0 + u * CDX_THREADS < n_out) lds[dst + oo[u]] = post ? mish_f(acc[u]) : acc[u];
+                        if (o0 + u * CDX_THREADS < n_out) {
+                            if (raw_copy) lds[dst2 + oo[u]] = acc[u];
+                            lds[dst + oo[u]] = post ? mish_f(acc[u]) : acc[u];
+                        }
                 }
             }
+            __syncthreads();
+        } else if (kind == CDX_OP_FLATTEN) {
+            // slot (channel-last rows) -> vector in torch's (C, L) flatten order: v[c*L + l] = slot[l][c]
+            const int C = op[CDX_L_NIN], Lp = op[CDX_L_NOUT], src = op[CDX_L_SRC], dst = op[CDX_L_DST];
+            const int sstr = op[CDX_L_WOFF];
+            for (int c = tid; c < C; c += CDX_THREADS)
+                for (int l = 0; l < Lp; ++l) lds[dst + c * Lp + l] = lds[src + (l + CDX_HALO) * sstr + c];
             __syncthreads();
         } else {  // CDX_OP_LOAD_TEMB
             const int n = op[CDX_L_NIN], dst = op[CDX_L_DST];
@@ -542,6 +555,11 @@ __global__ __launch_bounds__(CDX_THREADS) void cdx_unet1d_kernel(const cdx_unet1
         for (int br = 0; br < n_branch; ++br) {
             const bool use_cond = (L.cond != nullptr) && (L.cfg_mode == 1 || (L.cfg_mode == 2 && br == 0));
             run_program(L, lds, step, br, use_cond, b, tid, pre);
+        }
+        if (L.n_steps == 0 && L.out_vec_len > 0) {  // forward-only, vector head (classifier): emit the head output
+            for (int i = tid; i < L.out_vec_len; i += CDX_THREADS)
+                L.x_out[(size_t)b * L.out_vec_len + i] = lds[L.out_vec_off + i];
+            return;
         }
         if (L.n_steps == 0) {  // forward-only: emit the prediction
             for (int e = tid; e < HD; e += CDX_THREADS) {
@@ -641,6 +659,8 @@ int cdx_unet1d_run(const cdx_unet1d_launch* L, void* hip_stream) {
     if (!L || !L->ops || !L->wblob || !L->x_in || !L->x_out || !L->temb) { set_err("null pointer in launch"); return CDX_EINVAL; }
     if (L->n_ops <= 0 || L->batch <= 0 || L->horizon <= 0 || L->dim <= 0 || L->emb_dim <= 0) { set_err("non-positive size"); return CDX_EINVAL; }
     if (L->n_steps > 0 && !L->steps) { set_err("steps == NULL with n_steps > 0"); return CDX_EINVAL; }
+    if (L->out_vec_len > 0 && L->n_steps != 0) { set_err("vector-output programs run in forward mode only"); return CDX_EINVAL; }
+    if (L->n_steps > 0 && L->pred_stride == 0) { set_err("sampling needs a program with a prediction slot"); return CDX_EINVAL; }
     if (L->fix_mask && !L->prior) { set_err("fix_mask given without prior"); return CDX_EINVAL; }
     if (L->cfg_mode < 0 || L->cfg_mode > 2) { set_err("cfg_mode must be 0, 1 or 2"); return CDX_EINVAL; }
     if (L->cfg_mode == 2 && !L->cond) { set_err("cfg_mode 2 needs cond"); return CDX_EINVAL; }

@@ -34,7 +34,7 @@ import torch.nn as nn
 
 OP_WORDS = 40
 ITEM_WORDS = 8
-OP_LOAD_TEMB, OP_LINEAR, OP_CONV = 0, 1, 2
+OP_LOAD_TEMB, OP_LINEAR, OP_CONV, OP_FLATTEN = 0, 1, 2, 3
 MODE_16X16, MODE_4X4 = 0, 1        # MFMA shape of a conv: 16x16x4 (16 rows x 16 cols x 16 K per record) or
                                    # 4x4x1 x16 blocks (64 rows x 4 cols x 4 K per record) for <= 8 positions
 
@@ -49,9 +49,11 @@ W_KIND = 0
 # item record (ITEM_WORDS int32 each, appended to the ops buffer): one K-range of one row tile = one wave's job
 I_WOFF, I_PART, I_NQ, I_ONB, I_TAP, I_CC = range(6)
 # linear / load_temb (reuse low word indices)
-L_NIN, L_NOUT, L_SRC, L_DST, L_WOFF, L_BOFF, L_FLAGS = range(1, 8)
+L_NIN, L_NOUT, L_SRC, L_DST, L_WOFF, L_BOFF, L_FLAGS, L_DST2 = range(1, 9)
+# flatten (slot -> vector, channel-major like torch .flatten(1) of (b, C, L)): L_NIN = C, L_NOUT = L, L_SRC = slot,
+# L_DST = vector, L_WOFF = slot stride
 
-F_GN_MISH, F_ADD_EMB, F_ADD_RES, F_ACCUM, F_DST_PRED, F_POST_MISH = 1, 2, 4, 8, 16, 32
+F_GN_MISH, F_ADD_EMB, F_ADD_RES, F_ACCUM, F_DST_PRED, F_POST_MISH, F_RAW_COPY = 1, 2, 4, 8, 16, 32, 64
 
 HALO = 2
 N_WAVES = 8
@@ -115,6 +117,8 @@ class Program:
     emb_dim: int
     macs_per_forward: int              # algorithmic MACs (conv + linear), for the roofline accounting
     n_conv: int = 0
+    out_vec_off: int = 0               # vector-output programs (classifier heads): where the result lives
+    out_vec_len: int = 0
     meta: dict = field(default_factory=dict)
 
 
@@ -194,15 +198,22 @@ class _Builder:
     def load_temb(self, n: int, dst_vec: int):
         self._emit({W_KIND: OP_LOAD_TEMB, L_NIN: n, L_DST: dst_vec}, [], None)
 
-    def linear(self, lin_w: torch.Tensor, lin_b: torch.Tensor, src_vec: int, dst_vec: int, post_mish=False):
+    def linear(self, lin_w: torch.Tensor, lin_b: torch.Tensor, src_vec: int, dst_vec: int, post_mish=False,
+               raw_dst: Optional[int] = None):
+        """dst = [Mish](W src + b); with `raw_dst` the pre-activation value is stored there as well."""
         n_out, n_in = lin_w.shape
+        flags = (F_POST_MISH if post_mish else 0) | (F_RAW_COPY if raw_dst is not None else 0)
         self._emit({W_KIND: OP_LINEAR, L_NIN: n_in, L_NOUT: n_out, L_SRC: src_vec, L_DST: dst_vec,
                     L_WOFF: self.add(lin_w.t().contiguous()), L_BOFF: self.add(lin_b),
-                    L_FLAGS: F_POST_MISH if post_mish else 0}, [], None)
+                    L_FLAGS: flags, L_DST2: raw_dst if raw_dst is not None else 0}, [], None)
         self.macs += n_in * n_out
         kparts = min(16, (N_WAVES * 64) // n_out)
         if kparts > 1:
             self.scratch = max(self.scratch, n_out * kparts)
+
+    def flatten(self, src: Act, dst_vec: int):
+        self._emit({W_KIND: OP_FLATTEN, L_NIN: src.chans, L_NOUT: src.length, L_SRC: 0, L_DST: dst_vec,
+                    L_WOFF: src.stride}, [src], None)
 
     def conv(self, srcs: Sequence[Act], dst: Act, w_eff: torch.Tensor, bias: torch.Tensor, *, stride=1, pad=0,
              transposed=False, gn: Optional[nn.Module] = None, emb_vec: int = -1, res: Optional[Act] = None,
@@ -298,6 +309,8 @@ class _Builder:
             top = max(top, pos + a.floats)
         # patch offsets
         for op, (reads, writes) in zip(self.ops, self.op_acts):
+            if op[W_KIND] == OP_FLATTEN:
+                op[L_SRC] = reads[0].off
             if op[W_KIND] != OP_CONV:
                 continue
             srcs = reads[:2] if op[W_CB_CHUNKS] else reads[:1]
@@ -333,84 +346,59 @@ def supports_janner(net) -> Optional[str]:
     return None
 
 
-def compile_janner(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x4: bool = True) -> Program:
-    """Lower a JannerUNet1d (reference nn_diffusion/jannerunet.py:98-201 structure) for `horizon` positions."""
-    why = supports_janner(net)
-    if why is not None:
-        raise ValueError(why)
-    dev = next(net.parameters()).device
-    b = _Builder(dev)
-    b.allow_4x4 = allow_4x4
-    d, k = net.in_dim, net.kernel_size
-    md = net.model_dim
+def _resblock(b: "_Builder", srcs: List[Act], rb, k: int, emb_vec: int) -> Act:
+    """ResidualBlock (reference jannerunet.py:51-69) = 2 fused conv ops (+1 accumulate op for a 1x1 skip conv)."""
+    c_out = rb.conv1[0].out_channels
+    length = srcs[0].length
+    t1 = b.act(length, c_out)
+    b.conv(srcs, t1, _conv1d_eff(rb.conv1[0]), rb.conv1[0].bias, pad=k // 2, gn=rb.conv1[1], emb_vec=emb_vec)
+    out = b.act(length, c_out)
+    identity = isinstance(rb.residual_conv, nn.Identity)
+    if identity:
+        assert len(srcs) == 1
+    b.conv([t1], out, _conv1d_eff(rb.conv2[0]), rb.conv2[0].bias, pad=k // 2, gn=rb.conv2[1],
+           res=srcs[0] if identity else None)
+    if not identity:
+        b.conv(srcs, out, _conv1d_eff(rb.residual_conv), rb.residual_conv.bias, accum=True)
+    return out
 
-    # ---- time-embedding chain: temb(+cond) -> Linear -> Mish -> Linear -> [Mish] -> stacked per-block Linear ---- #
-    blocks = []
-    for res1, res2, _, _ in net.downs:
-        blocks += [res1, res2]
-    blocks += [net.mid_block1, net.mid_block2]
-    for res1, res2, _, _ in net.ups:
-        blocks += [res1, res2]
+
+def _downsample(b: "_Builder", cur: Act, down) -> Act:
+    nxt = b.act((cur.length - 1) // 2 + 1, cur.chans)          # Conv1d(k=3, stride=2, pad=1)
+    b.conv([cur], nxt, _conv1d_eff(down.conv), down.conv.bias, stride=2, pad=1)
+    return nxt
+
+
+def _emb_chain(b: "_Builder", net, blocks, raw_emb_vec: Optional[int] = None):
+    """temb(+cond) -> Linear -> Mish -> Linear -> Mish -> stacked per-block FiLM Linear.  Returns block -> vec offset.
+    `emb` is consumed by the blocks only through ``emb_mlp = Mish -> Linear``, so Mish(emb) is what gets stored;
+    callers that also need the raw embedding (classifier head) pass `raw_emb_vec`."""
+    md = net.model_dim
     v_temb, v_hid, v_memb = b.vec(net.emb_dim), b.vec(md * 4), b.vec(md)
-    emb_slices, total = {}, 0
+    slices, total = {}, 0
     for rb in blocks:
-        emb_slices[id(rb)] = total
+        slices[id(rb)] = total
         total += rb.emb_mlp[1].out_features
     v_eall = b.vec(total)
     b.load_temb(net.emb_dim, v_temb)
     b.linear(net.map_emb[0].weight, net.map_emb[0].bias, v_temb, v_hid, post_mish=True)
-    # emb itself is only ever consumed through emb_mlp = Mish -> Linear, so store Mish(emb) directly
-    b.linear(net.map_emb[2].weight, net.map_emb[2].bias, v_hid, v_memb, post_mish=True)
+    b.linear(net.map_emb[2].weight, net.map_emb[2].bias, v_hid, v_memb, post_mish=True, raw_dst=raw_emb_vec)
     b.linear(torch.cat([rb.emb_mlp[1].weight for rb in blocks], 0),
              torch.cat([rb.emb_mlp[1].bias for rb in blocks], 0), v_memb, v_eall)
+    return {k: v_eall + v for k, v in slices.items()}
 
-    x = b.act(horizon, d, persistent=True)
 
-    def resblock(srcs: List[Act], rb) -> Act:
-        c_out = rb.conv1[0].out_channels
-        length = srcs[0].length
-        t1 = b.act(length, c_out)
-        b.conv(srcs, t1, _conv1d_eff(rb.conv1[0]), rb.conv1[0].bias, pad=k // 2, gn=rb.conv1[1],
-               emb_vec=v_eall + emb_slices[id(rb)])
-        out = b.act(length, c_out)
-        identity = isinstance(rb.residual_conv, nn.Identity)
-        if identity:
-            assert len(srcs) == 1
-        b.conv([t1], out, _conv1d_eff(rb.conv2[0]), rb.conv2[0].bias, pad=k // 2, gn=rb.conv2[1],
-               res=srcs[0] if identity else None)
-        if not identity:
-            b.conv(srcs, out, _conv1d_eff(rb.residual_conv), rb.residual_conv.bias, accum=True)
-        return out
-
-    cur, skips = x, []
-    for res1, res2, _, down in net.downs:
-        cur = resblock([resblock([cur], res1)], res2)
-        skips.append(cur)
-        if not isinstance(down, nn.Identity):
-            assert cur.length % 2 == 0, "horizon too short for the number of resolutions"
-            nxt = b.act(cur.length // 2, cur.chans)
-            b.conv([cur], nxt, _conv1d_eff(down.conv), down.conv.bias, stride=2, pad=1)
-            cur = nxt
-    cur = resblock([resblock([cur], net.mid_block1)], net.mid_block2)
-    for res1, res2, _, up in net.ups:
-        cur = resblock([resblock([cur, skips.pop()], res1)], res2)
-        if not isinstance(up, nn.Identity):
-            nxt = b.act(cur.length * 2, cur.chans)
-            b.conv([cur], nxt, _convT1d_eff(up.conv), up.conv.bias, stride=2, pad=1, transposed=True)
-            cur = nxt
-    assert cur.length == horizon
-    fc = net.final_conv
-    t = b.act(horizon, md)
-    b.conv([cur], t, _conv1d_eff(fc[0]), fc[0].bias, pad=2, gn=fc[1])
-    pred = b.act(horizon, d, persistent=True)
-    b.conv([t], pred, _conv1d_eff(fc[3]), fc[3].bias, dst_pred=True)
-
-    # ---- LDS map: [x | pred0 | pred1 | prev(dense) | vec | scratch | arena...] ---- #
+def _finalize(b: "_Builder", net, x: Act, pred: Optional[Act], horizon: int, d: int, max_lds_bytes: int,
+              out_vec: int = -1, out_len: int = 0) -> Program:
+    """LDS map [x | pred0 | pred1 | prev(dense) | vec | scratch | descriptors | stamps | arena...], offsets patched."""
+    dev = b.device
     off = 0
     x.off, off = off, off + x.floats
-    pred.off, off = off, off + pred.floats
-    pred_branch = pred.floats
-    off += pred.floats                                    # second prediction slot (CFG unconditional branch)
+    pred_off = pred_stride = pred_branch = 0
+    if pred is not None:
+        pred.off, off = off, off + pred.floats
+        pred_off, pred_stride, pred_branch = pred.off, pred.stride, pred.floats
+        off += pred.floats                                # second prediction slot (CFG unconditional branch)
     prev_off, off = off, off + (horizon * d + 3) // 4 * 4
     vec_off, off = off, off + b.vec_len
     scratch_off, off = off, off + (b.scratch + 3) // 4 * 4
@@ -428,20 +416,115 @@ def compile_janner(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x4
             tail += [w for rec in items for w in rec]
             cursor += len(items) * ITEM_WORDS
     ops = np.asarray(b.ops, dtype=np.int32)
-    # vec offsets were relative; make them absolute LDS offsets
-    for op in ops:
+    for op in ops:                                        # vec offsets were relative; make them absolute
         if op[W_KIND] == OP_LOAD_TEMB:
             op[L_DST] += vec_off
         elif op[W_KIND] == OP_LINEAR:
             op[L_SRC] += vec_off
+            op[L_DST] += vec_off
+            if op[L_FLAGS] & F_RAW_COPY:
+                op[L_DST2] += vec_off
+        elif op[W_KIND] == OP_FLATTEN:
             op[L_DST] += vec_off
         elif op[W_FLAGS] & F_ADD_EMB:
             op[W_EMB] += vec_off
     blob = torch.cat(b.chunks) if b.chunks else torch.zeros(0, device=dev)
     ops_buffer = np.concatenate([ops.reshape(-1), np.asarray(tail, dtype=np.int64).astype(np.int32)])
     assert ops_buffer.size == desc_words
-    return Program(ops=ops, ops_buffer=ops_buffer, blob=blob.contiguous(), lds_floats=top, x_off=x.off, x_stride=x.stride,
-                   pred_off=pred.off, pred_stride=pred.stride, pred_branch_floats=pred_branch, prev_off=prev_off,
-                   vec_off=vec_off, scratch_off=scratch_off, scratch_floats=b.scratch, desc_off=desc_off, prof_off=prof_off, horizon=horizon, dim=d,
-                   emb_dim=net.emb_dim, macs_per_forward=b.macs, n_conv=b.n_conv,
+    return Program(ops=ops, ops_buffer=ops_buffer, blob=blob.contiguous(), lds_floats=top, x_off=x.off,
+                   x_stride=x.stride, pred_off=pred_off, pred_stride=pred_stride, pred_branch_floats=pred_branch,
+                   prev_off=prev_off, vec_off=vec_off, scratch_off=scratch_off, scratch_floats=b.scratch,
+                   desc_off=desc_off, prof_off=prof_off, horizon=horizon, dim=d, emb_dim=net.emb_dim,
+                   macs_per_forward=b.macs, n_conv=b.n_conv,
+                   out_vec_off=(vec_off + out_vec) if out_vec >= 0 else 0, out_vec_len=out_len,
                    meta={"n_ops": len(ops), "blob_floats": int(blob.numel())})
+
+
+def compile_janner(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x4: bool = True) -> Program:
+    """Lower a JannerUNet1d (reference nn_diffusion/jannerunet.py:98-201 structure) for `horizon` positions."""
+    why = supports_janner(net)
+    if why is not None:
+        raise ValueError(why)
+    b = _Builder(next(net.parameters()).device)
+    b.allow_4x4 = allow_4x4
+    d, k, md = net.in_dim, net.kernel_size, net.model_dim
+
+    blocks = []
+    for res1, res2, _, _ in net.downs:
+        blocks += [res1, res2]
+    blocks += [net.mid_block1, net.mid_block2]
+    for res1, res2, _, _ in net.ups:
+        blocks += [res1, res2]
+    emb_of = _emb_chain(b, net, blocks)
+
+    def resblock(srcs, rb):
+        return _resblock(b, srcs, rb, k, emb_of[id(rb)])
+
+    x = b.act(horizon, d, persistent=True)
+    cur, skips = x, []
+    for res1, res2, _, down in net.downs:
+        cur = resblock([resblock([cur], res1)], res2)
+        skips.append(cur)
+        if not isinstance(down, nn.Identity):
+            assert cur.length % 2 == 0, "horizon too short for the number of resolutions"
+            cur = _downsample(b, cur, down)
+    cur = resblock([resblock([cur], net.mid_block1)], net.mid_block2)
+    for res1, res2, _, up in net.ups:
+        cur = resblock([resblock([cur, skips.pop()], res1)], res2)
+        if not isinstance(up, nn.Identity):
+            nxt = b.act(cur.length * 2, cur.chans)
+            b.conv([cur], nxt, _convT1d_eff(up.conv), up.conv.bias, stride=2, pad=1, transposed=True)
+            cur = nxt
+    assert cur.length == horizon
+    fc = net.final_conv
+    t = b.act(horizon, md)
+    b.conv([cur], t, _conv1d_eff(fc[0]), fc[0].bias, pad=2, gn=fc[1])
+    pred = b.act(horizon, d, persistent=True)
+    b.conv([t], pred, _conv1d_eff(fc[3]), fc[3].bias, dst_pred=True)
+    return _finalize(b, net, x, pred, horizon, d, max_lds_bytes)
+
+
+def supports_half_janner(net) -> Optional[str]:
+    if net.norm_type != "groupnorm":
+        return f"norm_type={net.norm_type!r} is PyTorch-only"
+    if net.kernel_size > 2 * HALO + 1 or net.kernel_size % 2 == 0:
+        return f"kernel_size={net.kernel_size} unsupported (odd, <=5)"
+    return None
+
+
+def compile_half_janner(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x4: bool = True) -> Program:
+    """Lower a HalfJannerUNet1d classifier (reference nn_classifier/half_jannerunet.py:11-125): encoder half, two
+    k=5 mid blocks each followed by a stride-2 conv, channel-major flatten, concat with the raw time embedding,
+    Linear-Mish-Linear head.  Output = a (out_dim,) vector per trajectory (``Program.out_vec_*``)."""
+    why = supports_half_janner(net)
+    if why is not None:
+        raise ValueError(why)
+    if horizon != net.horizon:
+        raise ValueError(f"HalfJannerUNet1d was built for horizon {net.horizon}, got {horizon}")
+    b = _Builder(next(net.parameters()).device)
+    b.allow_4x4 = allow_4x4
+    d, k, md = net.in_dim, net.kernel_size, net.model_dim
+
+    blocks = []
+    for res1, res2, _ in net.downs:
+        blocks += [res1, res2]
+    blocks += [net.mid_block1[0], net.mid_block2[0]]
+    head_in = net.final_block[0].in_features
+    fc_dim = head_in - md
+    v_cat = b.vec(head_in)                                   # [flatten(x) | raw emb]
+    emb_of = _emb_chain(b, net, blocks, raw_emb_vec=v_cat + fc_dim)
+
+    x = b.act(horizon, d, persistent=True)
+    cur = x
+    for res1, res2, down in net.downs:
+        cur = _resblock(b, [_resblock(b, [cur], res1, k, emb_of[id(res1)])], res2, k, emb_of[id(res2)])
+        if not isinstance(down, nn.Identity):
+            cur = _downsample(b, cur, down)
+    for blk, down in (net.mid_block1, net.mid_block2):
+        cur = _downsample(b, _resblock(b, [cur], blk, 5, emb_of[id(blk)]), down)
+    assert cur.chans * cur.length == fc_dim, (cur.chans, cur.length, fc_dim)
+    b.flatten(cur, v_cat)
+    v_h, v_out = b.vec(net.final_block[0].out_features), b.vec(net.out_dim)
+    b.linear(net.final_block[0].weight, net.final_block[0].bias, v_cat, v_h, post_mish=True)
+    b.linear(net.final_block[2].weight, net.final_block[2].bias, v_h, v_out)
+    return _finalize(b, net, x, None, horizon, d, max_lds_bytes, out_vec=v_out, out_len=net.out_dim)

@@ -32,6 +32,7 @@ class CdxUnet1dLaunch(ctypes.Structure):
         ("x_off", ctypes.c_int32), ("x_stride", ctypes.c_int32),
         ("pred_off", ctypes.c_int32), ("pred_stride", ctypes.c_int32), ("pred_branch_floats", ctypes.c_int32),
         ("prev_off", ctypes.c_int32), ("scratch_off", ctypes.c_int32),
+        ("out_vec_off", ctypes.c_int32), ("out_vec_len", ctypes.c_int32),
         ("prof_off", ctypes.c_int32), ("desc_off", ctypes.c_int32), ("desc_words", ctypes.c_int32),
         ("batch", ctypes.c_int32), ("horizon", ctypes.c_int32), ("dim", ctypes.c_int32), ("emb_dim", ctypes.c_int32),
         ("temb", ctypes.c_void_p), ("steps", ctypes.c_void_p),
@@ -104,7 +105,7 @@ def compiled_program(module, horizon: int) -> _Compiled:
     if hit is not None and hit.sig == sig:
         return hit
     with torch.no_grad():
-        prog = P.compile_janner(module, horizon)
+        prog = (P.compile_half_janner if _is_half_janner(module) else P.compile_janner)(module, horizon)
     per_mod[horizon] = _Compiled(prog, sig)
     return per_mod[horizon]
 
@@ -114,8 +115,18 @@ def _is_janner(module) -> bool:
     return isinstance(module, JannerUNet1d)
 
 
+def _is_half_janner(module) -> bool:
+    from ..nn_classifier.half_jannerunet import HalfJannerUNet1d
+    return isinstance(module, HalfJannerUNet1d)
+
+
 def supported_backbone(module, horizon: int) -> Optional[str]:
     """None if the fused kernel can run `module` at this horizon, else a human-readable reason."""
+    if _is_half_janner(module):
+        why = P.supports_half_janner(module)
+        if why:
+            return why
+        return None if horizon == module.horizon else f"classifier was built for horizon {module.horizon}"
     if not _is_janner(module):
         return f"{type(module).__name__} has no fused program yet"
     why = P.supports_janner(module)
@@ -184,6 +195,7 @@ def _launch(comp: _Compiled, *, batch, x_in, x_out, temb, steps_dev=None, n_step
         ops=comp.ops_dev.data_ptr(), wblob=prog.blob.data_ptr(), n_ops=len(prog.ops), lds_floats=prog.lds_floats,
         x_off=prog.x_off, x_stride=prog.x_stride, pred_off=prog.pred_off, pred_stride=prog.pred_stride,
         pred_branch_floats=prog.pred_branch_floats, prev_off=prog.prev_off, scratch_off=prog.scratch_off,
+        out_vec_off=prog.out_vec_off, out_vec_len=prog.out_vec_len,
         prof_off=prog.prof_off, desc_off=prog.desc_off, desc_words=int(prog.ops_buffer.size),
         batch=batch, horizon=prog.horizon, dim=prog.dim, emb_dim=prog.emb_dim,
         temb=temb.data_ptr(), steps=_ptr(steps_dev), n_steps=n_steps, temb_per_sample=temb_per_sample,
@@ -213,7 +225,8 @@ def backbone_forward(module, x, noise, condition) -> Optional[torch.Tensor]:
         temb = _f32c(module.map_noise(noise), x.device)
         cond = _f32c(condition, x.device) if condition is not None else None
         xin = _f32c(x, x.device)
-        out = torch.empty_like(xin)
+        vec_len = comp.prog.out_vec_len
+        out = torch.empty((b, vec_len), device=x.device, dtype=torch.float32) if vec_len else torch.empty_like(xin)
         _launch(comp, batch=b, x_in=xin, x_out=out, temb=temb, temb_per_sample=1,
                 cfg_mode=1 if cond is not None else 0, cond=cond)
     return out
@@ -238,7 +251,7 @@ def steps_to_device(plan, device) -> torch.Tensor:
 def fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed) -> Optional[torch.Tensor]:
     """Whole denoising loop in one launch.  Returns None when this request must take the PyTorch executor."""
     net = model["diffusion"]
-    if xt.dim() != 3 or supported_backbone(net, xt.shape[1]) is not None:
+    if xt.dim() != 3 or not _is_janner(net) or supported_backbone(net, xt.shape[1]) is not None:
         return None
     if cond_vec is None and w_cfg not in (0.0, 1.0):
         return None                                   # the reference raises here; let the torch executor do it

@@ -58,6 +58,7 @@ typedef struct cdx_unet1d_launch {
     int32_t x_off, x_stride;   /* state slot */
     int32_t pred_off, pred_stride, pred_branch_floats;
     int32_t prev_off, scratch_off;
+    int32_t out_vec_off, out_vec_len; /* forward mode, vector-output programs (classifier heads): x_out is [batch][out_vec_len] */
     int32_t prof_off;             /* LDS float offset (even) of the (n_ops*8+2) x u64 stamp area; used only if prof != NULL */
     int32_t desc_off, desc_words; /* where the kernel keeps its copy of `ops` in LDS, and how many words it is */
     /* problem */

@@ -36,6 +36,12 @@ CASES = {
         net=JANNER_H4, horizon=4, batch=5, fix_obs=17,
         solver=("DiscreteDiffusionSDE", dict(diffusion_steps=20, predict_noise=False)),
         sample=dict(solver="ddpm", sample_steps=20, temperature=0.5)),
+    # the real Diffuser tail: a CumRewClassifier(HalfJannerUNet1d) scores the finished trajectories (log_p) and the caller
+    # picks arg-max candidates (reference diffusionsde.py:597-601, pipelines/diffuser_d4rl_mujoco.py:144-147)
+    "janner_cfg2_diffuser_logp": dict(
+        net=JANNER_CFG2, horizon=32, batch=8, fix_obs=17, classifier=dict(kernel_size=3),
+        solver=("DiscreteDiffusionSDE", dict(diffusion_steps=20, predict_noise=False)),
+        sample=dict(solver="ddpm", sample_steps=20, temperature=0.5)),
     # conditional backbone input (b, emb_dim) through IdentityCondition: w_cfg = 1 (one forward) ...
     "janner_tiny_cond_w1": dict(
         net=JANNER_TINY, horizon=8, batch=3, cond_dim=16, clip=3.0,
@@ -68,13 +74,13 @@ for _s in _ALL_SOLVERS:
 def lib_namespace(kind: str):
     """'amd' -> this repo's mirrors; 'reference' -> the real reference (build container only)."""
     if kind == "amd":
-        from cleandiffuser_amd import diffusion, nn_condition, nn_diffusion
+        from cleandiffuser_amd import classifier, diffusion, nn_classifier, nn_condition, nn_diffusion
     else:
         from .ref_import import import_reference
         import_reference()
-        from cleandiffuser import diffusion, nn_condition, nn_diffusion
+        from cleandiffuser import classifier, diffusion, nn_classifier, nn_condition, nn_diffusion
     ns = SimpleNamespace()
-    for mod in (diffusion, nn_condition, nn_diffusion):
+    for mod in (diffusion, nn_condition, nn_diffusion, classifier, nn_classifier):
         for k in dir(mod):
             if not k.startswith("_"):
                 setattr(ns, k, getattr(mod, k))
@@ -111,6 +117,12 @@ def build(lib, name: str, device="cpu", weight_seed: int = 0):
         d = net_kw["in_dim"]
         kw["x_max"] = torch.full((1, c["horizon"], d), float(c["clip"]))
         kw["x_min"] = torch.full((1, c["horizon"], d), -float(c["clip"]))
+    if c.get("classifier"):
+        nk = net_kw
+        clf_net = lib.HalfJannerUNet1d(c["horizon"], nk["in_dim"], out_dim=1, model_dim=nk["model_dim"],
+                                       emb_dim=nk["emb_dim"], dim_mult=tuple(nk["dim_mult"]), **c["classifier"])
+        clf_net.load_state_dict(synth_state_dict(clf_net.state_dict(), weight_seed + 1))
+        kw["classifier"] = lib.CumRewClassifier(clf_net, device=device)
     agent = getattr(lib, c["solver"][0])(net, cond_net, device=device, **kw)
     agent.eval()
     return agent, net

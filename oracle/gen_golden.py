@@ -48,8 +48,11 @@ def run_reference_case(lib, name: str):
     with torch.no_grad():
         cond = torch.from_numpy(inp["cond"]) if inp["cond"] is not None else None
         pred0 = agent.model_ema["diffusion"](xt0, t0, cond)
-    return dict(x_out=x.detach().numpy().astype(np.float32), pred0=pred0.numpy().astype(np.float32),
-                n_draws=np.int64(used["n"]))
+    out = dict(x_out=x.detach().numpy().astype(np.float32), pred0=pred0.numpy().astype(np.float32),
+               n_draws=np.int64(used["n"]))
+    if log.get("log_p") is not None:
+        out["log_p"] = log["log_p"].detach().numpy().astype(np.float32)
+    return out
 
 
 def main(out_dir="tests/golden", only=None):

@@ -53,9 +53,14 @@ class LaneSim:
                 self.lds[dst:dst + n] = v
             elif kind == P.OP_LINEAR:
                 self._linear(op)
+            elif kind == P.OP_FLATTEN:
+                c, n, src, dst, sstr = op[P.L_NIN], op[P.L_NOUT], op[P.L_SRC], op[P.L_DST], op[P.L_WOFF]
+                self.lds[dst:dst + c * n] = self.read_slot(src, sstr, n, c).T.reshape(-1)   # (C, L) flatten order
             else:
                 self._conv(op, branch)
         p = self.p
+        if p.out_vec_len:
+            return self.lds[p.out_vec_off:p.out_vec_off + p.out_vec_len].copy()
         return self.read_slot(p.pred_off + branch * p.pred_branch_floats, p.pred_stride, p.horizon, p.dim)
 
     def _linear(self, op):
@@ -66,6 +71,8 @@ class LaneSim:
         acc = bvec.copy()
         for i in range(n_in):                              # same i-order as the kernel's per-thread loop
             acc = acc + w[i] * x[i]
+        if op[P.L_FLAGS] & P.F_RAW_COPY:
+            self.lds[op[P.L_DST2]:op[P.L_DST2] + n_out] = acc
         if op[P.L_FLAGS] & P.F_POST_MISH:
             acc = mish(acc)
         self.lds[op[P.L_DST]:op[P.L_DST] + n_out] = acc

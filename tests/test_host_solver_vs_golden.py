@@ -18,6 +18,9 @@ def test_torch_executor_matches_reference_fixture(name, amd_lib):
     n_draws = int(gold["n_draws"])
     x, log = agent.sample(torch.from_numpy(inp["prior"]), noise=list(inp["noise"][:n_draws]), **kw)
     np.testing.assert_allclose(x.numpy(), gold["x_out"], rtol=2e-6, atol=2e-6)
+    if "log_p" in gold.files:                      # Diffuser tail: classifier score of the finished trajectories
+        np.testing.assert_allclose(log["log_p"].numpy(), gold["log_p"], rtol=2e-6, atol=2e-6)
+        assert int(log["log_p"].argmax()) == int(gold["log_p"].argmax())
 
 
 def test_seeded_rng_path_matches_replay(amd_lib):

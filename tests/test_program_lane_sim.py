@@ -57,3 +57,17 @@ def test_program_accounting_matches_survey(amd_lib):
     prog = P.compile_janner(net, 32)
     assert prog.n_conv == 47
     assert abs(prog.macs_per_forward - 19.67e6) / 19.67e6 < 0.01
+
+
+def test_lane_sim_reproduces_classifier_logp(amd_lib):
+    """HalfJannerUNet1d program (flatten op, raw-embedding copy, vector head) vs the reference's log_p fixture."""
+    name = "janner_cfg2_diffuser_logp"
+    gold = np.load(golden_path(name))
+    agent, _ = cases.build(amd_lib, name)
+    clf = agent.classifier.model_ema
+    prog = P.compile_half_janner(clf, 32)
+    temb = clf.map_noise(torch.zeros(1, dtype=torch.long))[0].numpy()
+    for b in range(3):
+        sim = LaneSim(prog)
+        sim.load_x(gold["x_out"][b])
+        np.testing.assert_allclose(sim.run_forward(temb), gold["log_p"][b], rtol=2e-5, atol=2e-5)
