@@ -134,6 +134,7 @@ class JannerUNet1d(BaseNNDiffusion):
                            Downsample1d(co) if k < n_res - 1 else nn.Identity()])
             for k, (ci, co) in enumerate(stages)])
 
+        self.ups = nn.ModuleList([])       # registered before the mid blocks, like the reference (parameter order)
         top = widths[-1]
         self.mid_block1 = block(top, top)
         self.mid_attn = attn(top)
@@ -141,7 +142,7 @@ class JannerUNet1d(BaseNNDiffusion):
 
         # NB: the loop index never reaches n_res-1, so every up stage upsamples and the
         # first skip (downs[0] output) is never consumed.
-        self.ups = nn.ModuleList([
+        self.ups.extend([
             nn.ModuleList([block(co * 2, ci), block(ci, ci), attn(ci),
                            Upsample1d(ci) if k < n_res - 1 else nn.Identity()])
             for k, (ci, co) in enumerate(reversed(stages[1:]))])

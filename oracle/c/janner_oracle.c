@@ -9,7 +9,7 @@
  *   Mish                      x * tanh(softplus(x)), softplus threshold 20 (ATen)
  *   solver step               reference cleandiffuser/diffusion/diffusionsde.py:539-592 in the three affine forms of
  *                             include/cdx.h (the host freezes the scalars exactly as engine/plan.py does)
- * Parameters arrive as ONE flat fp32 buffer in state_dict order (map_emb, downs, mid, ups, final_conv); the walker
+ * Parameters arrive as ONE flat fp32 buffer in execution order (map_emb, downs, mid blocks, ups, final_conv); the walker
  * below consumes them with a cursor, so a layout mismatch shows up as a wrong answer in tests/test_oracle_ports.py,
  * which pins this file against the fixtures produced by the real reference.
  */

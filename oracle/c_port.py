@@ -27,8 +27,14 @@ def _p(a):
 
 
 def flat_params(net) -> np.ndarray:
-    """state_dict order, fp32, one buffer (the C walker consumes it with a cursor)."""
-    return np.concatenate([v.detach().cpu().numpy().astype(np.float32).ravel() for v in net.state_dict().values()])
+    """One fp32 buffer in EXECUTION order (map_emb, downs, mid_block1, mid_block2, ups, final_conv; inside a group the
+    state_dict order) -- the C walker consumes it with a cursor.  (state_dict itself lists ``ups`` before the mid blocks.)"""
+    sd = net.state_dict()
+    out = []
+    for group in ("map_emb.", "downs.", "mid_block1.", "mid_block2.", "ups.", "final_conv."):
+        out += [v.detach().cpu().numpy().astype(np.float32).ravel() for k, v in sd.items() if k.startswith(group)]
+    assert sum(a.size for a in out) == sum(v.numel() for k, v in sd.items() if not k.startswith("map_noise"))
+    return np.concatenate(out)
 
 
 def janner_sample(net, x_init, prior, fix_mask, noise, temb, plan, predict_noise):

@@ -59,6 +59,47 @@ CASES = {
         sample=dict(solver="sde_dpmsolver++_2M", sample_steps=6, sample_step_schedule="quad_continuous",
                     temperature=0.7, diffusion_x_sampling_steps=2)),
 }
+# ---- the other BASELINE configs at fixture size (PyTorch executor today; fused paths are later rows) ----
+CASES.update({
+    # config 1: PearceMlp DBC, DDPM 100 -> 20 steps here, x-prediction with clip, w_cfg = 1, PearceObsCondition
+    "pearce_cfg1_ddpm": dict(
+        net=("PearceMlp", dict(act_dim=6, To=1, emb_dim=64, hidden_dim=256)), x_shape=(6,), batch=5, clip=1.0,
+        cond=("PearceObsCondition", dict(obs_dim=17, emb_dim=64, flatten=True, dropout=0.0), (1, 17)),
+        solver=("DiscreteDiffusionSDE", dict(diffusion_steps=20, predict_noise=False)),
+        sample=dict(solver="ddpm", sample_steps=20, temperature=0.5, w_cfg=1.0)),
+    # config 3: ChiUNet1d Diffusion Policy through the legacy DDPM class (narrow channels, 10 steps)
+    "chiunet_cfg3_legacy_ddpm": dict(
+        net=("ChiUNet1d", dict(act_dim=2, obs_dim=20, To=2, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2])),
+        x_shape=(16, 2), batch=3, clip=1.0, cond=("IdentityCondition", dict(dropout=0.0), (2, 20)),
+        solver=("DDPM", dict(diffusion_steps=10)), legacy=True,
+        sample=dict(sample_steps=10, w_cfg=1.0)),
+    # config 4: DiT1d Decision Diffuser, CFG w = 2, DPM-Solver++ 2M, continuous time, fix-mask on the first token
+    "dit_cfg4_cfg2_dpmpp2m": dict(
+        net=("DiT1d", dict(in_dim=29, emb_dim=32, d_model=64, n_heads=4, depth=2, timestep_emb_type="fourier")),
+        x_shape=(16, 29), batch=3, fix_first_token=True, clip=3.0,
+        cond=("MLPCondition", dict(in_dim=1, out_dim=32, hidden_dims=[32], act="SiLU", dropout=0.25), (1,)),
+        solver=("ContinuousDiffusionSDE", dict(predict_noise=True, noise_schedule="linear")),
+        sample=dict(solver="ode_dpmsolver++_2M", sample_steps=10, w_cfg=2.0, temperature=0.5)),
+    # config 5: IDQLMlp (SynthER ResidualMLP) through ContinuousEDM, Euler and Heun
+    "idql_cfg5_edm_euler": dict(
+        net=("IDQLMlp", dict(obs_dim=0, act_dim=15, emb_dim=32, hidden_dim=64, n_blocks=2)), x_shape=(15,), batch=6,
+        solver=("ContinuousEDM", dict()), sample=dict(solver="euler", sample_steps=16)),
+    "idql_cfg5_edm_heun": dict(
+        net=("IDQLMlp", dict(obs_dim=0, act_dim=15, emb_dim=32, hidden_dim=64, n_blocks=2)), x_shape=(15,), batch=6,
+        solver=("ContinuousEDM", dict()), sample=dict(solver="heun", sample_steps=8, diffusion_x_sampling_steps=1)),
+    # DQL / ChiTransformer backbones under the new-style discrete solver
+    "dqlmlp_ddpm": dict(
+        net=("DQLMlp", dict(obs_dim=17, act_dim=6)), x_shape=(6,), batch=4, clip=1.0,
+        cond=("IdentityCondition", dict(dropout=0.0), (17,)),
+        solver=("DiscreteDiffusionSDE", dict(diffusion_steps=5, predict_noise=True)),
+        sample=dict(solver="ddpm", sample_steps=5, w_cfg=1.0)),
+    "chitransformer_ddim": dict(
+        net=("ChiTransformer", dict(act_dim=2, obs_dim=20, Ta=16, To=2, d_model=64, nhead=4, num_layers=2)),
+        x_shape=(16, 2), batch=3, clip=1.0, cond=("IdentityCondition", dict(dropout=0.0), (2, 20)),
+        solver=("DiscreteDiffusionSDE", dict(diffusion_steps=50, predict_noise=True)),
+        sample=dict(solver="ddim", sample_steps=5, w_cfg=1.0)),
+})
+
 # one small case per solver (discrete + continuous) so every update rule is pinned
 for _s in _ALL_SOLVERS:
     CASES[f"janner_tiny_disc_{_s}"] = dict(
@@ -84,21 +125,37 @@ def lib_namespace(kind: str):
         for k in dir(mod):
             if not k.startswith("_"):
                 setattr(ns, k, getattr(mod, k))
+    import importlib
+    root = "cleandiffuser_amd" if kind == "amd" else "cleandiffuser"
+    ns.DDPM = importlib.import_module(root + ".diffusion.ddpm").DDPM      # legacy class, not exported by the package
     return ns
+
+
+def x_shape_of(c):
+    return tuple(c["x_shape"]) if "x_shape" in c else (c["horizon"], c["net"][1]["in_dim"])
 
 
 def make_inputs(name: str):
     c = CASES[name]
-    b, h, d = c["batch"], c["horizon"], c["net"][1]["in_dim"]
-    prior = np.zeros((b, h, d), np.float32)
+    b, xs = c["batch"], x_shape_of(c)
+    prior = np.zeros((b, *xs), np.float32)
     fix_mask = None
     if c.get("fix_obs"):
-        fix_mask = np.zeros((h, d), np.float32)
+        fix_mask = np.zeros(xs, np.float32)
         fix_mask[0, :c["fix_obs"]] = 1.0
         prior[:, 0, :c["fix_obs"]] = synth_array(name + "/obs", (b, c["fix_obs"]))
-    n_draws = c["sample"]["sample_steps"] + c["sample"].get("diffusion_x_sampling_steps", 0) + 2
-    noise = np.stack([synth_array(f"{name}/z{k}", (b, h, d)) for k in range(n_draws)])
-    cond = synth_array(name + "/cond", (b, c["cond_dim"])) if c.get("cond_dim") else None
+    if c.get("fix_first_token"):
+        fix_mask = np.zeros(xs, np.float32)
+        fix_mask[0] = 1.0
+        prior[:, 0] = synth_array(name + "/obs", (b, xs[1]))
+    n_draws = 2 * c["sample"]["sample_steps"] + c["sample"].get("diffusion_x_sampling_steps", 0) + 2
+    noise = np.stack([synth_array(f"{name}/z{k}", (b, *xs)) for k in range(n_draws)])
+    if c.get("cond_dim"):
+        cond = synth_array(name + "/cond", (b, c["cond_dim"]))
+    elif c.get("cond"):
+        cond = synth_array(name + "/cond", (b, *c["cond"][2]))
+    else:
+        cond = None
     return dict(prior=prior, fix_mask=fix_mask, noise=noise, cond=cond)
 
 
@@ -109,20 +166,29 @@ def build(lib, name: str, device="cpu", weight_seed: int = 0):
     net = getattr(lib, net_cls)(**net_kw)
     net.load_state_dict(synth_state_dict(net.state_dict(), weight_seed))
     cond_net = lib.IdentityCondition(dropout=0.0) if c.get("cond_dim") else None
+    if c.get("cond"):
+        ckw = dict(c["cond"][1])
+        if isinstance(ckw.get("act"), str):
+            ckw["act"] = getattr(torch.nn, ckw["act"])()
+        cond_net = getattr(lib, c["cond"][0])(**ckw)
+        cond_net.load_state_dict(synth_state_dict(cond_net.state_dict(), weight_seed + 2))
     inp = make_inputs(name)
     kw = dict(c["solver"][1])
     if inp["fix_mask"] is not None:
         kw["fix_mask"] = torch.from_numpy(inp["fix_mask"])
     if c.get("clip"):
-        d = net_kw["in_dim"]
-        kw["x_max"] = torch.full((1, c["horizon"], d), float(c["clip"]))
-        kw["x_min"] = torch.full((1, c["horizon"], d), -float(c["clip"]))
+        xs = x_shape_of(c)
+        kw["x_max"] = torch.full((1, *xs), float(c["clip"]))
+        kw["x_min"] = torch.full((1, *xs), -float(c["clip"]))
     if c.get("classifier"):
         nk = net_kw
         clf_net = lib.HalfJannerUNet1d(c["horizon"], nk["in_dim"], out_dim=1, model_dim=nk["model_dim"],
                                        emb_dim=nk["emb_dim"], dim_mult=tuple(nk["dim_mult"]), **c["classifier"])
         clf_net.load_state_dict(synth_state_dict(clf_net.state_dict(), weight_seed + 1))
         kw["classifier"] = lib.CumRewClassifier(clf_net, device=device)
+    if c.get("legacy"):
+        x_max, x_min = kw.pop("x_max", None), kw.pop("x_min", None)
+        kw.update(x_max=None if x_max is None else x_max.to(device), x_min=None if x_min is None else x_min.to(device))
     agent = getattr(lib, c["solver"][0])(net, cond_net, device=device, **kw)
     agent.eval()
     return agent, net
