@@ -6,6 +6,7 @@
 #define CDX_OP_LINEAR 1
 #define CDX_OP_CONV 2
 #define CDX_OP_FLATTEN 3
+#define CDX_OP_FILL 4
 
 #define CDX_W_KIND 0
 // ---- conv ----
@@ -44,6 +45,10 @@
 #define CDX_W_CG 33
 #define CDX_W_CG_SHIFT 34
 #define CDX_W_INV_COUT 35
+#define CDX_W_ACT 36
+#define CDX_W_NORM 37
+#define CDX_W_SCALE 38
+#define CDX_W_DST_COFF 39
 // ---- linear / load_temb ----
 #define CDX_L_NIN 1
 #define CDX_L_NOUT 2
@@ -61,6 +66,19 @@
 #define CDX_F_DST_PRED 16
 #define CDX_F_POST_MISH 32
 #define CDX_F_RAW_COPY 64
+#define CDX_F_SCALE 128
+#define CDX_F_KEEP_DST 256
+// ---- activation ids / normalisation modes ----
+#define CDX_ACT_NONE 0
+#define CDX_ACT_MISH 1
+#define CDX_ACT_GELU_ERF 2
+#define CDX_ACT_LEAKY 3
+#define CDX_ACT_SILU 4
+#define CDX_ACT_RELU 5
+#define CDX_ACT_GELU_TANH 6
+#define CDX_NORM_NONE 0
+#define CDX_NORM_SLOT_GROUP 1
+#define CDX_NORM_COLUMN 2
 
 #define CDX_MODE_16X16 0
 #define CDX_MODE_4X4 1

@@ -32,6 +32,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define CDX_THREADS (CDX_N_WAVES * 64)
+#define CDX_COLN_REGS 16  // per-column norm: channels per lane (c_out <= 1024)
 #define CDX_EPI_REGS 4  // GroupNorm elements a lane keeps in registers (groups of <= 256 elements)
 
 static thread_local char g_err[256] = "";
@@ -49,6 +50,25 @@ __device__ __forceinline__ float mish_f(float x) {
     const float e = __expf(fminf(x, 20.0f));
     const float n = e * (e + 2.0f);
     return x > 20.0f ? x : x * n * __builtin_amdgcn_rcpf(n + 2.0f);
+}
+
+// Activation ids of csrc/cdx_ops.h (CDX_ACT_*).  `act` is wave-uniform, so the switch is a scalar branch.
+__device__ __forceinline__ float act_f(float x, int act) {
+    switch (act) {
+        case CDX_ACT_MISH: return mish_f(x);
+        case CDX_ACT_GELU_ERF: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+        case CDX_ACT_LEAKY: return x > 0.f ? x : 0.01f * x;
+        case CDX_ACT_SILU: return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+        case CDX_ACT_RELU: return fmaxf(x, 0.f);
+        case CDX_ACT_GELU_TANH: return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+        default: return x;
+    }
+}
+
+// sum over aligned groups of `width` (power of two, < 64) consecutive lanes; every lane gets its group's sum
+__device__ __forceinline__ float seg_sum(float v, int width) {
+    for (int m = width >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
 }
 
 // wave64 all-reduce (sum) on the DPP network: quad swaps, row half-mirror, row mirror, then the 4 row sums
@@ -272,7 +292,7 @@ __device__ __forceinline__ void conv_op(const int w, const int wn, const int* __
     g.srcB = CDX_RL(w, CDX_W_SRCB); g.strideB = CDX_RL(w, CDX_W_SRCB_STRIDE); g.cb = CDX_RL(w, CDX_W_CB_CHUNKS);
 
     // 1. clear the destination slot (halo rows + pad columns must read as zero for the consumer)
-    if (!(flags & CDX_F_ACCUM)) {
+    if (!(flags & (CDX_F_ACCUM | CDX_F_KEEP_DST))) {
         const int total = drows * dstride;  // multiple of 4, dst 16-byte aligned
         for (int i = tid * 4; i < total; i += CDX_THREADS * 4)
             *reinterpret_cast<float4*>(lds + dst + i) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -313,7 +333,10 @@ __device__ __forceinline__ void conv_op(const int w, const int wn, const int* __
     const int res = CDX_RL(w, CDX_W_RES), rstride = CDX_RL(w, CDX_W_RES_STRIDE), emb = CDX_RL(w, CDX_W_EMB);
     const int groups = CDX_RL(w, CDX_W_GROUPS), cg = CDX_RL(w, CDX_W_CG), sh = CDX_RL(w, CDX_W_CG_SHIFT);
     const int cnt = cg * l_out;
+    const int act = CDX_RL(w, CDX_W_ACT), coff = CDX_RL(w, CDX_W_DST_COFF);
+    const float oscale = (flags & CDX_F_SCALE) ? __int_as_float(CDX_RL(w, CDX_W_SCALE)) : 1.0f;
     const bool gn = flags & CDX_F_GN_MISH;
+    const bool col_norm = CDX_RL(w, CDX_W_NORM) == CDX_NORM_COLUMN;
     const bool gn_fast = gn && sh >= 0 && cnt <= 64 * CDX_EPI_REGS && groups <= CDX_N_WAVES;
     if (gn_fast) {
         // one wave per group; a lane keeps its <= CDX_EPI_REGS elements in registers across the three passes
@@ -356,10 +379,10 @@ __device__ __forceinline__ void conv_op(const int w, const int wn, const int* __
 #pragma unroll
             for (int t = 0; t < CDX_EPI_REGS; ++t) {
                 if (lane + 64 * t < cnt) {
-                    float y = mish_f((v[t] - mean) * rstd * ga[t] + be[t]);
+                    float y = act_f((v[t] - mean) * rstd * ga[t] + be[t], act);
                     if (flags & CDX_F_ADD_EMB) y += lds[emb + cc[t]];
                     if (flags & CDX_F_ADD_RES) y += lds[res + (nn[t] + CDX_HALO) * rstride + cc[t]];
-                    lds[dst + (nn[t] + CDX_HALO) * dstride + cc[t]] = y;
+                    lds[dst + (nn[t] + CDX_HALO) * dstride + coff + cc[t]] = y * oscale;
                 }
             }
         }
@@ -391,10 +414,74 @@ __device__ __forceinline__ void conv_op(const int w, const int wn, const int* __
             const float rstd = __builtin_amdgcn_rsqf(wave_sum(s2) * inv_cnt + CDX_GN_EPS);
             for (int e = lane; e < cnt; e += 64) {
                 const int n = div_small(e, cg, inv_cg), c = gi * cg + (e - n * cg);
-                float v = mish_f((lds[scratch + n * sstride + c] - mean) * rstd * gamma[c] + beta[c]);
+                float v = act_f((lds[scratch + n * sstride + c] - mean) * rstd * gamma[c] + beta[c], act);
                 if (flags & CDX_F_ADD_EMB) v += lds[emb + c];
                 if (flags & CDX_F_ADD_RES) v += lds[res + (n + CDX_HALO) * rstride + c];
-                lds[dst + (n + CDX_HALO) * dstride + c] = v;
+                lds[dst + (n + CDX_HALO) * dstride + coff + c] = v * oscale;
+            }
+        }
+    } else if (col_norm) {
+        // per-column normalisation (GroupNorm1d on (b, C) / LayerNorm of the MLP backbones): statistics over the
+        // cg channels of ONE column (= one sample of the batch tile).  One wave per column, lane = channel.
+        const float* __restrict__ gamma = wblob + CDX_RL(w, CDX_W_GAMMA);
+        const float* __restrict__ beta = wblob + CDX_RL(w, CDX_W_BETA);
+        const float inv_cg = __int_as_float(CDX_RL(w, CDX_W_INV_CNT));
+        const int nslots = (c_out + 63) >> 6;                 // <= CDX_COLN_REGS (host asserts c_out <= 1024)
+        const int spg_sh = sh - 6;                            // cg >= 64: log2(slots per group)
+        stamp(prof ? prof + 1 : nullptr, tid);
+        __syncthreads();
+        stamp(prof ? prof + 2 : nullptr, tid);
+        for (int n = wave; n < l_out; n += CDX_N_WAVES) {
+            float v[CDX_COLN_REGS], m[CDX_COLN_REGS];
+#pragma unroll
+            for (int t = 0; t < CDX_COLN_REGS; ++t) {
+                v[t] = 0.f;
+                if (t < nslots) {
+                    const int c = lane + 64 * t;
+                    if (c < c_out) {
+                        float acc = bias[c];
+                        for (int ks = 0; ks < ksplit; ++ks) acc += lds[scratch + (ks * l_out + n) * sstride + c];
+                        v[t] = acc;
+                    }
+                }
+            }
+            // two passes (mean, then squared deviations), each reduced over the group's channels
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+                for (int t = 0; t < CDX_COLN_REGS; ++t)
+                    if (t < nslots) m[t] = cg < 64 ? seg_sum(pass ? v[t] * v[t] : v[t], cg)
+                                                   : wave_sum(pass ? v[t] * v[t] : v[t]);
+                if (cg > 64) {                                 // a group spans 2^spg_sh slots: add them up
+                    float g[CDX_COLN_REGS];
+#pragma unroll
+                    for (int t = 0; t < CDX_COLN_REGS; ++t) {
+                        g[t] = 0.f;
+#pragma unroll
+                        for (int u = 0; u < CDX_COLN_REGS; ++u)
+                            if (u < nslots && (u >> spg_sh) == (t >> spg_sh)) g[t] += m[u];
+                    }
+#pragma unroll
+                    for (int t = 0; t < CDX_COLN_REGS; ++t) m[t] = g[t];
+                }
+#pragma unroll
+                for (int t = 0; t < CDX_COLN_REGS; ++t) {
+                    if (t < nslots) {
+                        if (pass == 0) {
+                            const int c = lane + 64 * t;
+                            v[t] = c < c_out ? v[t] - m[t] * inv_cg : 0.f;          // deviation from the group mean
+                        } else {
+                            const int c = lane + 64 * t;
+                            if (c < c_out) {
+                                const float rstd = __builtin_amdgcn_rsqf(m[t] * inv_cg + CDX_GN_EPS);
+                                float y = act_f(v[t] * rstd * gamma[c] + beta[c], act);
+                                if (flags & CDX_F_ADD_EMB) y += lds[emb + c];
+                                if (flags & CDX_F_ADD_RES) y += lds[res + (n + CDX_HALO) * rstride + c];
+                                lds[dst + (n + CDX_HALO) * dstride + coff + c] = y * oscale;
+                            }
+                        }
+                    }
+                }
             }
         }
     } else {
@@ -415,9 +502,11 @@ __device__ __forceinline__ void conv_op(const int w, const int wn, const int* __
             float v = b0;
             if (e != tid) { n = div_small(e, c_out, inv_cout); c = e - n * c_out; v = bias[c]; }
             for (int ks = 0; ks < ksplit; ++ks) v += lds[scratch + (ks * l_out + n) * sstride + c];
+            v = act_f(v, act);
             if (flags & CDX_F_ADD_EMB) v += lds[emb + c];
             if (flags & CDX_F_ADD_RES) v += lds[res + (n + CDX_HALO) * rstride + c];
-            const int o = dst + (n + CDX_HALO) * dstride + c;
+            v *= oscale;
+            const int o = dst + (n + CDX_HALO) * dstride + coff + c;
             if (flags & CDX_F_ACCUM) v += lds[o];
             lds[o] = v;
         }
@@ -498,6 +587,15 @@ __device__ __forceinline__ void run_program(const cdx_unet1d_launch& L, float* _
                 }
             }
             __syncthreads();
+        } else if (kind == CDX_OP_FILL) {
+            // broadcast a vector into a channel range of every row of a slot (batch-invariant features of MLP tiles)
+            const int n = op[CDX_L_NIN], rows = op[CDX_L_NOUT], src = op[CDX_L_SRC], dst = op[CDX_L_DST];
+            const int sstr = op[CDX_L_WOFF], fcoff = op[CDX_L_BOFF];
+            for (int e = tid; e < n * rows; e += CDX_THREADS) {
+                const int r = e / n, i = e - r * n;
+                lds[dst + (r + CDX_HALO) * sstr + fcoff + i] = lds[src + i];
+            }
+            __syncthreads();
         } else if (kind == CDX_OP_FLATTEN) {
             // slot (channel-last rows) -> vector in torch's (C, L) flatten order: v[c*L + l] = slot[l][c]
             const int C = op[CDX_L_NIN], Lp = op[CDX_L_NOUT], src = op[CDX_L_SRC], dst = op[CDX_L_DST];
@@ -509,7 +607,7 @@ __device__ __forceinline__ void run_program(const cdx_unet1d_launch& L, float* _
             const int n = op[CDX_L_NIN], dst = op[CDX_L_DST];
             for (int i = tid; i < n; i += CDX_THREADS) {
                 float v = L.temb[(size_t)(L.temb_per_sample ? b : step) * L.emb_dim + i];
-                if (use_cond) v += L.cond[(size_t)b * L.emb_dim + i];
+                if (use_cond && L.tile == 0) v += L.cond[(size_t)b * L.emb_dim + i];
                 lds[dst + i] = v;
             }
             __syncthreads();
@@ -537,6 +635,20 @@ __global__ __launch_bounds__(CDX_THREADS) void cdx_unet1d_kernel(const cdx_unet1
     for (int e = tid; e < HD; e += CDX_THREADS) {
         const int n = e / D, c = e - n * D;
         lds[L.x_off + (n + CDX_HALO) * L.x_stride + c] = L.x_in[xbase + e];
+    }
+    __syncthreads();
+
+    // ---- further kernel-lifetime slots (MLP context): clear once, then (tile programs) load the per-sample
+    //      condition features into their channel range; an absent / unused condition stays zero ----
+    for (int i = tid * 4; i < L.zero_floats; i += CDX_THREADS * 4)
+        *reinterpret_cast<float4*>(lds + L.zero_off + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    if (L.tile > 0 && L.cond != nullptr && L.cfg_mode == 1) {
+        for (int e = tid; e < H * L.cond_dim; e += CDX_THREADS) {
+            const int n = e / L.cond_dim, i = e - n * L.cond_dim;
+            lds[L.cond_slot_off + (n + CDX_HALO) * L.cond_slot_stride + L.cond_coff + i] =
+                L.cond[((size_t)b * H + n) * L.cond_dim + i];
+        }
     }
     __syncthreads();
 
@@ -664,6 +776,9 @@ int cdx_unet1d_run(const cdx_unet1d_launch* L, void* hip_stream) {
     if (L->fix_mask && !L->prior) { set_err("fix_mask given without prior"); return CDX_EINVAL; }
     if (L->cfg_mode < 0 || L->cfg_mode > 2) { set_err("cfg_mode must be 0, 1 or 2"); return CDX_EINVAL; }
     if (L->cfg_mode == 2 && !L->cond) { set_err("cfg_mode 2 needs cond"); return CDX_EINVAL; }
+    if (L->tile > 0 && (L->cfg_mode == 2 || L->temb_per_sample)) { set_err("tile programs: cfg_mode 0/1 and per-step timesteps only"); return CDX_EINVAL; }
+    if (L->tile > 0 && L->tile != L->horizon) { set_err("tile programs: horizon must equal the tile size"); return CDX_EINVAL; }
+    if ((L->zero_off | L->zero_floats) & 3) { set_err("zero range must be 16-byte aligned"); return CDX_EINVAL; }
     if ((L->x_off | L->pred_off | L->prev_off | L->scratch_off | L->x_stride | L->pred_stride | L->pred_branch_floats) & 3) {
         set_err("LDS offsets/strides must be multiples of 4 floats"); return CDX_EINVAL;
     }

@@ -34,7 +34,7 @@ import torch.nn as nn
 
 OP_WORDS = 40
 ITEM_WORDS = 8
-OP_LOAD_TEMB, OP_LINEAR, OP_CONV, OP_FLATTEN = 0, 1, 2, 3
+OP_LOAD_TEMB, OP_LINEAR, OP_CONV, OP_FLATTEN, OP_FILL = 0, 1, 2, 3, 4
 MODE_16X16, MODE_4X4 = 0, 1        # MFMA shape of a conv: 16x16x4 (16 rows x 16 cols x 16 K per record) or
                                    # 4x4x1 x16 blocks (64 rows x 4 cols x 4 K per record) for <= 8 positions
 
@@ -45,7 +45,8 @@ W_KIND = 0
  W_SRCA, W_SRCA_STRIDE, W_CA_CHUNKS, W_SRCB, W_SRCB_STRIDE, W_CB_CHUNKS,
  W_DST, W_DST_STRIDE, W_DST_ROWS, W_WOFF, W_BOFF, W_FLAGS, W_GROUPS, W_GAMMA, W_BETA,
  W_EMB, W_RES, W_RES_STRIDE, W_KSPLIT, W_NCHUNKS, W_LIN,
- W_MODE, W_ITEMS, W_NITEMS, W_INV_CNT, W_CG, W_CG_SHIFT, W_INV_COUT) = range(1, 36)
+ W_MODE, W_ITEMS, W_NITEMS, W_INV_CNT, W_CG, W_CG_SHIFT, W_INV_COUT,
+ W_ACT, W_NORM, W_SCALE, W_DST_COFF) = range(1, 40)
 # item record (ITEM_WORDS int32 each, appended to the ops buffer): one K-range of one row tile = one wave's job
 I_WOFF, I_PART, I_NQ, I_ONB, I_TAP, I_CC = range(6)
 # linear / load_temb (reuse low word indices)
@@ -53,7 +54,11 @@ L_NIN, L_NOUT, L_SRC, L_DST, L_WOFF, L_BOFF, L_FLAGS, L_DST2 = range(1, 9)
 # flatten (slot -> vector, channel-major like torch .flatten(1) of (b, C, L)): L_NIN = C, L_NOUT = L, L_SRC = slot,
 # L_DST = vector, L_WOFF = slot stride
 
-F_GN_MISH, F_ADD_EMB, F_ADD_RES, F_ACCUM, F_DST_PRED, F_POST_MISH, F_RAW_COPY = 1, 2, 4, 8, 16, 32, 64
+F_GN_MISH, F_ADD_EMB, F_ADD_RES, F_ACCUM, F_DST_PRED, F_POST_MISH, F_RAW_COPY, F_SCALE, F_KEEP_DST = \
+    1, 2, 4, 8, 16, 32, 64, 128, 256
+# activation ids (W_ACT) and normalisation modes (W_NORM: statistics over the whole slot group / per column)
+ACT_NONE, ACT_MISH, ACT_GELU_ERF, ACT_LEAKY, ACT_SILU, ACT_RELU, ACT_GELU_TANH = range(7)
+NORM_NONE, NORM_SLOT_GROUP, NORM_COLUMN = 0, 1, 2
 
 HALO = 2
 N_WAVES = 8
@@ -119,6 +124,14 @@ class Program:
     n_conv: int = 0
     out_vec_off: int = 0               # vector-output programs (classifier heads): where the result lives
     out_vec_len: int = 0
+    tile: int = 0                      # > 0: batch-tiled MLP program, `horizon` = samples per workgroup
+    cond_slot_off: int = 0             # tile programs: per-sample condition features live in this slot ...
+    cond_slot_stride: int = 0
+    cond_coff: int = 0                 # ... at this channel offset ...
+    cond_dim: int = 0                  # ... this many of them per sample
+    zero_off: int = 0                  # the persist slots as one contiguous range (what the kernel clears at start)
+    zero_floats: int = 0
+    persist_slots: list = field(default_factory=list)   # (offset, floats) of extra kernel-lifetime slots to zero once
     meta: dict = field(default_factory=dict)
 
 
@@ -211,13 +224,21 @@ class _Builder:
         if kparts > 1:
             self.scratch = max(self.scratch, n_out * kparts)
 
+    def fill(self, src_vec: int, n: int, dst: Act, coff: int):
+        """Broadcast vec[src_vec : src_vec+n] into channels [coff, coff+n) of every row of a (persistent) slot."""
+        self._emit({W_KIND: OP_FILL, L_NIN: n, L_NOUT: dst.length, L_SRC: src_vec, L_DST: 0, L_WOFF: dst.stride,
+                    L_BOFF: coff}, [dst], None)
+
     def flatten(self, src: Act, dst_vec: int):
         self._emit({W_KIND: OP_FLATTEN, L_NIN: src.chans, L_NOUT: src.length, L_SRC: 0, L_DST: dst_vec,
                     L_WOFF: src.stride}, [src], None)
 
     def conv(self, srcs: Sequence[Act], dst: Act, w_eff: torch.Tensor, bias: torch.Tensor, *, stride=1, pad=0,
              transposed=False, gn: Optional[nn.Module] = None, emb_vec: int = -1, res: Optional[Act] = None,
-             accum=False, dst_pred=False):
+             accum=False, dst_pred=False, act: Optional[int] = None, col_norm: Optional[nn.Module] = None,
+             scale: Optional[float] = None, dst_coff: int = 0, keep_dst: bool = False):
+        """One fused conv/linear op.  Epilogue order: bias -> norm (slot-group `gn` | per-column `col_norm`) ->
+        activation -> +FiLM vector -> +residual -> *scale -> store at channel offset `dst_coff`."""
         c_out, taps, _ = w_eff.shape
         assert taps <= 2 * HALO + 1 and pad <= HALO
         assert not transposed or stride == 2, "the kernel's transposed-conv row map assumes stride 2"
@@ -258,12 +279,30 @@ class _Builder:
             words[W_CG], words[W_CG_SHIFT] = cg, (cg.bit_length() - 1 if cg & (cg - 1) == 0 else -1)
             words[W_INV_CNT] = _fbits(1.0 / (cg * dst.length))
             words[W_GAMMA], words[W_BETA] = self.add(gn.weight), self.add(gn.bias)
+        words[W_ACT] = (ACT_MISH if gn is not None else ACT_NONE) if act is None else act
+        words[W_NORM] = NORM_SLOT_GROUP if gn is not None else NORM_NONE
+        if col_norm is not None:
+            assert gn is None and abs(col_norm.eps - GN_EPS) < 1e-12
+            groups = getattr(col_norm, "num_groups", 1)             # nn.LayerNorm == one group over all channels
+            assert c_out % groups == 0
+            cg = c_out // groups
+            assert cg & (cg - 1) == 0 and c_out <= 1024, "per-column norm: power-of-two group size, C_out <= 1024"
+            words[W_NORM], words[W_GROUPS], words[W_CG] = NORM_COLUMN, groups, cg
+            words[W_CG_SHIFT] = cg.bit_length() - 1
+            words[W_INV_CNT] = _fbits(1.0 / cg)
+            words[W_GAMMA], words[W_BETA] = self.add(col_norm.weight), self.add(col_norm.bias)
+        if scale is not None:
+            flags |= F_SCALE
+            words[W_SCALE] = _fbits(scale)
+        if keep_dst or dst_coff:
+            flags |= F_KEEP_DST
+        words[W_DST_COFF] = dst_coff
         if emb_vec >= 0:
             flags |= F_ADD_EMB
             words[W_EMB] = emb_vec
         if res is not None:
             flags |= F_ADD_RES
-            assert res.chans == c_out and res.length == dst.length
+            assert res.chans >= c_out and res.length == dst.length
             words[W_RES_STRIDE] = res.stride
         if accum:
             flags |= F_ACCUM
@@ -311,6 +350,8 @@ class _Builder:
         for op, (reads, writes) in zip(self.ops, self.op_acts):
             if op[W_KIND] == OP_FLATTEN:
                 op[L_SRC] = reads[0].off
+            if op[W_KIND] == OP_FILL:
+                op[L_DST] = reads[0].off
             if op[W_KIND] != OP_CONV:
                 continue
             srcs = reads[:2] if op[W_CB_CHUNKS] else reads[:1]
@@ -389,7 +430,8 @@ def _emb_chain(b: "_Builder", net, blocks, raw_emb_vec: Optional[int] = None):
 
 
 def _finalize(b: "_Builder", net, x: Act, pred: Optional[Act], horizon: int, d: int, max_lds_bytes: int,
-              out_vec: int = -1, out_len: int = 0) -> Program:
+              out_vec: int = -1, out_len: int = 0, persist: Sequence[Act] = (), emb_dim: Optional[int] = None,
+              cond_slot: Optional[Tuple[Act, int, int]] = None, tile: int = 0) -> Program:
     """LDS map [x | pred0 | pred1 | prev(dense) | vec | scratch | descriptors | stamps | arena...], offsets patched."""
     dev = b.device
     off = 0
@@ -399,6 +441,8 @@ def _finalize(b: "_Builder", net, x: Act, pred: Optional[Act], horizon: int, d: 
         pred.off, off = off, off + pred.floats
         pred_off, pred_stride, pred_branch = pred.off, pred.stride, pred.floats
         off += pred.floats                                # second prediction slot (CFG unconditional branch)
+    for a in persist:                                     # further kernel-lifetime slots (MLP context etc.)
+        a.off, off = off, off + a.floats
     prev_off, off = off, off + (horizon * d + 3) // 4 * 4
     vec_off, off = off, off + b.vec_len
     scratch_off, off = off, off + (b.scratch + 3) // 4 * 4
@@ -426,7 +470,9 @@ def _finalize(b: "_Builder", net, x: Act, pred: Optional[Act], horizon: int, d: 
                 op[L_DST2] += vec_off
         elif op[W_KIND] == OP_FLATTEN:
             op[L_DST] += vec_off
-        elif op[W_FLAGS] & F_ADD_EMB:
+        elif op[W_KIND] == OP_FILL:
+            op[L_SRC] += vec_off
+        elif op[W_KIND] == OP_CONV and op[W_FLAGS] & F_ADD_EMB:
             op[W_EMB] += vec_off
     blob = torch.cat(b.chunks) if b.chunks else torch.zeros(0, device=dev)
     ops_buffer = np.concatenate([ops.reshape(-1), np.asarray(tail, dtype=np.int64).astype(np.int32)])
@@ -434,7 +480,13 @@ def _finalize(b: "_Builder", net, x: Act, pred: Optional[Act], horizon: int, d: 
     return Program(ops=ops, ops_buffer=ops_buffer, blob=blob.contiguous(), lds_floats=top, x_off=x.off,
                    x_stride=x.stride, pred_off=pred_off, pred_stride=pred_stride, pred_branch_floats=pred_branch,
                    prev_off=prev_off, vec_off=vec_off, scratch_off=scratch_off, scratch_floats=b.scratch,
-                   desc_off=desc_off, prof_off=prof_off, horizon=horizon, dim=d, emb_dim=net.emb_dim,
+                   desc_off=desc_off, prof_off=prof_off, horizon=horizon, dim=d,
+                   emb_dim=net.emb_dim if emb_dim is None else emb_dim, tile=tile,
+                   cond_slot_off=cond_slot[0].off if cond_slot else 0,
+                   cond_slot_stride=cond_slot[0].stride if cond_slot else 0,
+                   cond_coff=cond_slot[1] if cond_slot else 0, cond_dim=cond_slot[2] if cond_slot else 0,
+                   persist_slots=[(a.off, a.floats) for a in persist],
+                   zero_off=persist[0].off if persist else 0, zero_floats=sum(a.floats for a in persist),
                    macs_per_forward=b.macs, n_conv=b.n_conv,
                    out_vec_off=(vec_off + out_vec) if out_vec >= 0 else 0, out_vec_len=out_len,
                    meta={"n_ops": len(ops), "blob_floats": int(blob.numel())})
@@ -528,3 +580,71 @@ def compile_half_janner(net, horizon: int, max_lds_bytes: int = 160 * 1024, allo
     b.linear(net.final_block[0].weight, net.final_block[0].bias, v_cat, v_h, post_mish=True)
     b.linear(net.final_block[2].weight, net.final_block[2].bias, v_h, v_out)
     return _finalize(b, net, x, None, horizon, d, max_lds_bytes, out_vec=v_out, out_len=net.out_dim)
+
+
+# ================================================================================================== #
+# Batch-tiled MLP denoisers: one workgroup = `tile` samples, the sample index rides the MFMA column   #
+# axis (a Linear is a 1-tap conv over `tile` "positions"), the whole sampling loop stays in the launch #
+# ================================================================================================== #
+MLP_TILE = 16
+
+
+def _lin_eff(lin: nn.Linear, pad_in: int = 0) -> torch.Tensor:
+    """(n_out, n_in) -> [co][tap=1][ci], optionally zero-padding extra trailing input channels."""
+    w = lin.weight.detach()
+    if pad_in:
+        w = torch.cat([w, torch.zeros(w.shape[0], pad_in, device=w.device, dtype=w.dtype)], 1)
+    return w.unsqueeze(1)
+
+
+def compile_pearce_mlp(net, tile: int = MLP_TILE, max_lds_bytes: int = 160 * 1024) -> Program:
+    """PearceMlp (reference nn_diffusion/pearcemlp.py:36-79).  Slots: state [x | raw t] (D+1 channels), context
+    [t_emb | flattened condition]; FCBlock = Linear -> per-sample GroupNorm -> GELU(erf); skips are stored pre-scaled by
+    1/1.414 exactly where the reference divides (Q11)."""
+    b = _Builder(next(net.parameters()).device)
+    d, e, hd, n_cond = net.act_dim, net.emb_dim, net.hidden_dim, net.To * net.emb_dim
+    s = 1.0 / net.SKIP_SCALE
+    x = b.act(tile, d + 1, persistent=True)
+    ctx = b.act(tile, e + n_cond, persistent=True)
+    v_temb = b.vec(e + 1)                                   # [map_noise(t) | float(t)] row of the host table
+    b.load_temb(e + 1, v_temb)
+    b.fill(v_temb, e, ctx, 0)
+    b.fill(v_temb + e, 1, x, d)
+    a1, xe = b.act(tile, e), b.act(tile, e)
+    b.conv([x], a1, _lin_eff(net.act_emb[0], pad_in=1), net.act_emb[0].bias, act=ACT_LEAKY)
+    b.conv([a1], xe, _lin_eff(net.act_emb[2]), net.act_emb[2].bias)
+    h1, h2, h3 = b.act(tile, hd), b.act(tile, hd), b.act(tile, hd)
+    f = net.fcs
+    b.conv([xe, ctx], h1, _lin_eff(f[0].model[0]), f[0].model[0].bias, col_norm=f[0].model[1], act=ACT_GELU_ERF, scale=s)
+    b.conv([h1, x], h2, _lin_eff(f[1].model[0]), f[1].model[0].bias, col_norm=f[1].model[1], act=ACT_GELU_ERF,
+           res=h1, scale=s)
+    b.conv([h2, x], h3, _lin_eff(f[2].model[0]), f[2].model[0].bias, col_norm=f[2].model[1], act=ACT_GELU_ERF, res=h2)
+    pred = b.act(tile, d, persistent=True)
+    b.conv([h3, x], pred, _lin_eff(f[3]), f[3].bias, dst_pred=True)
+    return _finalize(b, net, x, pred, tile, d, max_lds_bytes, persist=[ctx], emb_dim=e + 1,
+                     cond_slot=(ctx, e, n_cond), tile=tile)
+
+
+def compile_dql_mlp(net, tile: int = MLP_TILE, max_lds_bytes: int = 160 * 1024) -> Program:
+    """DQLMlp (reference nn_diffusion/dqlmlp.py:9-52): features [x | time_mlp(map_noise(t)) | obs] -> 3 x (Linear, Mish)
+    -> Linear.  The time MLP is batch-invariant, so it runs once per step on a vector and is broadcast into the context."""
+    b = _Builder(next(net.parameters()).device)
+    d = net.final_layer.out_features
+    e = net.time_mlp[0].in_features
+    obs = net.obs_dim
+    x = b.act(tile, d, persistent=True)
+    ctx = b.act(tile, e + obs, persistent=True)
+    v0, v1, v2 = b.vec(e), b.vec(2 * e), b.vec(e)
+    b.load_temb(e, v0)
+    b.linear(net.time_mlp[0].weight, net.time_mlp[0].bias, v0, v1, post_mish=True)
+    b.linear(net.time_mlp[2].weight, net.time_mlp[2].bias, v1, v2)
+    b.fill(v2, e, ctx, 0)
+    m = net.mid_layer
+    m1, m2, m3 = b.act(tile, 256), b.act(tile, 256), b.act(tile, 256)
+    b.conv([x, ctx], m1, _lin_eff(m[0]), m[0].bias, act=ACT_MISH)
+    b.conv([m1], m2, _lin_eff(m[2]), m[2].bias, act=ACT_MISH)
+    b.conv([m2], m3, _lin_eff(m[4]), m[4].bias, act=ACT_MISH)
+    pred = b.act(tile, d, persistent=True)
+    b.conv([m3], pred, _lin_eff(net.final_layer), net.final_layer.bias, dst_pred=True)
+    return _finalize(b, net, x, pred, tile, d, max_lds_bytes, persist=[ctx], emb_dim=e,
+                     cond_slot=(ctx, e, obs), tile=tile)

@@ -33,6 +33,9 @@ class CdxUnet1dLaunch(ctypes.Structure):
         ("pred_off", ctypes.c_int32), ("pred_stride", ctypes.c_int32), ("pred_branch_floats", ctypes.c_int32),
         ("prev_off", ctypes.c_int32), ("scratch_off", ctypes.c_int32),
         ("out_vec_off", ctypes.c_int32), ("out_vec_len", ctypes.c_int32),
+        ("tile", ctypes.c_int32), ("cond_slot_off", ctypes.c_int32), ("cond_slot_stride", ctypes.c_int32),
+        ("cond_coff", ctypes.c_int32), ("cond_dim", ctypes.c_int32),
+        ("zero_off", ctypes.c_int32), ("zero_floats", ctypes.c_int32),
         ("prof_off", ctypes.c_int32), ("desc_off", ctypes.c_int32), ("desc_words", ctypes.c_int32),
         ("batch", ctypes.c_int32), ("horizon", ctypes.c_int32), ("dim", ctypes.c_int32), ("emb_dim", ctypes.c_int32),
         ("temb", ctypes.c_void_p), ("steps", ctypes.c_void_p),
@@ -105,7 +108,13 @@ def compiled_program(module, horizon: int) -> _Compiled:
     if hit is not None and hit.sig == sig:
         return hit
     with torch.no_grad():
-        prog = (P.compile_half_janner if _is_half_janner(module) else P.compile_janner)(module, horizon)
+        kind = _mlp_kind(module)
+        if kind == "pearce":
+            prog = P.compile_pearce_mlp(module, horizon)
+        elif kind == "dql":
+            prog = P.compile_dql_mlp(module, horizon)
+        else:
+            prog = (P.compile_half_janner if _is_half_janner(module) else P.compile_janner)(module, horizon)
     per_mod[horizon] = _Compiled(prog, sig)
     return per_mod[horizon]
 
@@ -113,6 +122,17 @@ def compiled_program(module, horizon: int) -> _Compiled:
 def _is_janner(module) -> bool:
     from ..nn_diffusion.jannerunet import JannerUNet1d
     return isinstance(module, JannerUNet1d)
+
+
+def _mlp_kind(module) -> Optional[str]:
+    """Batch-tiled MLP programs the compiler knows: 'pearce' | 'dql' | None."""
+    from ..nn_diffusion.mlp_backbones import DQLMlp, PearceMlp
+    from ..utils.embeddings import PositionalEmbedding
+    if type(module) is PearceMlp and module.hidden_dim % 64 == 0 and module.hidden_dim <= 1024:
+        return "pearce"
+    if type(module) is DQLMlp:
+        return "dql"
+    return None
 
 
 def _is_half_janner(module) -> bool:
@@ -196,6 +216,8 @@ def _launch(comp: _Compiled, *, batch, x_in, x_out, temb, steps_dev=None, n_step
         x_off=prog.x_off, x_stride=prog.x_stride, pred_off=prog.pred_off, pred_stride=prog.pred_stride,
         pred_branch_floats=prog.pred_branch_floats, prev_off=prog.prev_off, scratch_off=prog.scratch_off,
         out_vec_off=prog.out_vec_off, out_vec_len=prog.out_vec_len,
+        tile=prog.tile, cond_slot_off=prog.cond_slot_off, cond_slot_stride=prog.cond_slot_stride,
+        cond_coff=prog.cond_coff, cond_dim=prog.cond_dim, zero_off=prog.zero_off, zero_floats=prog.zero_floats,
         prof_off=prog.prof_off, desc_off=prog.desc_off, desc_words=int(prog.ops_buffer.size),
         batch=batch, horizon=prog.horizon, dim=prog.dim, emb_dim=prog.emb_dim,
         temb=temb.data_ptr(), steps=_ptr(steps_dev), n_steps=n_steps, temb_per_sample=temb_per_sample,
@@ -248,9 +270,58 @@ def steps_to_device(plan, device) -> torch.Tensor:
     return torch.from_numpy(raw).to(device)
 
 
+def fused_sample_mlp(solver, net, kind, plan, xt, prior, cond_vec, w_cfg, feed) -> Optional[torch.Tensor]:
+    """Batch-tiled MLP denoisers (x of shape (B, D)): one workgroup per `MLP_TILE` samples, whole loop in one launch."""
+    if w_cfg not in (0.0, 1.0):
+        return None                                   # cond/uncond pair per step: PyTorch executor for now
+    b, d = xt.shape
+    dev = xt.device
+    tile = P.MLP_TILE
+    n_tiles = -(-b // tile)
+    pad = n_tiles * tile - b
+    try:
+        fix_mask = _dense_hd(solver.fix_mask, 1, d, dev)
+        x_min = _dense_hd(solver.x_min, 1, d, dev)
+        x_max = _dense_hd(solver.x_max, 1, d, dev)
+    except (ValueError, RuntimeError):
+        return None
+
+    def rows(t):                                      # (B, D) -> (n_tiles * tile, D), zero rows appended
+        t = _f32c(t, dev)
+        return torch.cat([t, t.new_zeros(pad, *t.shape[1:])]) if pad else t
+
+    def table(t):                                     # (1, D) -> (tile, D): the kernel indexes bounds/masks per tile row
+        return None if t is None else t.expand(tile, d).contiguous()
+
+    cond = None
+    if cond_vec is not None and w_cfg == 1.0:
+        cond = rows(torch.flatten(cond_vec, 1))
+    load_library()
+    with torch.no_grad():
+        comp = compiled_program(net, tile)
+        if cond is not None and cond.shape[1] != comp.prog.cond_dim:
+            return None
+        t_dtype = torch.long if plan.t_is_integer else torch.float32
+        t_vec = torch.tensor([st.t for st in plan.steps], dtype=t_dtype, device=dev)
+        temb = _f32c(net.map_noise(t_vec), dev)
+        if kind == "pearce":                          # PearceMlp also consumes the raw timestep as a feature (Q11)
+            temb = torch.cat([temb, t_vec.to(torch.float32).unsqueeze(1)], 1).contiguous()
+        steps_dev = steps_to_device(plan, dev)
+        noise = torch.stack([rows(feed.like(xt)) for _ in range(plan.n_noise)]).contiguous() if plan.n_noise else None
+        xin = rows(xt)
+        out = torch.empty_like(xin)
+        _launch(comp, batch=n_tiles, x_in=xin, x_out=out, temb=temb, steps_dev=steps_dev, n_steps=len(plan.steps),
+                predict_noise=solver.predict_noise, cfg_mode=1 if cond is not None else 0, cfg_w=w_cfg, cond=cond,
+                prior=rows(prior) if fix_mask is not None else None, fix_mask=table(fix_mask), noise=noise,
+                x_min=table(x_min), x_max=table(x_max))
+    return out[:b]
+
+
 def fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed) -> Optional[torch.Tensor]:
     """Whole denoising loop in one launch.  Returns None when this request must take the PyTorch executor."""
     net = model["diffusion"]
+    if xt.dim() == 2 and _mlp_kind(net) is not None:
+        return fused_sample_mlp(solver, net, _mlp_kind(net), plan, xt, prior, cond_vec, w_cfg, feed)
     if xt.dim() != 3 or not _is_janner(net) or supported_backbone(net, xt.shape[1]) is not None:
         return None
     if cond_vec is None and w_cfg not in (0.0, 1.0):

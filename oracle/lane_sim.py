@@ -19,6 +19,27 @@ def mish(x):
     return np.where(x > 20.0, x, x * n / (n + 2.0)).astype(np.float32)
 
 
+def activation(v, act_id):
+    import math
+    v = np.asarray(v, np.float32)
+    if act_id == P.ACT_NONE:
+        return v
+    if act_id == P.ACT_MISH:
+        return mish(v)
+    if act_id == P.ACT_GELU_ERF:
+        erf = np.vectorize(math.erf)
+        return (0.5 * v * (1.0 + erf(v.astype(np.float64) / math.sqrt(2.0)))).astype(np.float32)
+    if act_id == P.ACT_LEAKY:
+        return np.where(v > 0, v, np.float32(0.01) * v).astype(np.float32)
+    if act_id == P.ACT_SILU:
+        return (v / (1.0 + np.exp(-v))).astype(np.float32)
+    if act_id == P.ACT_RELU:
+        return np.maximum(v, 0).astype(np.float32)
+    if act_id == P.ACT_GELU_TANH:
+        return (0.5 * v * (1.0 + np.tanh(0.7978845608028654 * (v + 0.044715 * v ** 3)))).astype(np.float32)
+    raise ValueError(act_id)
+
+
 class LaneSim:
     def __init__(self, prog: P.Program):
         self.p = prog
@@ -26,10 +47,16 @@ class LaneSim:
         self.lds = np.full(prog.lds_floats, np.nan, np.float32)   # NaN-poison: reading an unwritten word shows up
 
     # ------------------------------------------------------------------------------------------ #
-    def load_x(self, x):                                  # x [H][D] -> padded channel-last slot, halo/pad zeroed
+    def load_x(self, x, cond_rows=None):                  # x [H][D] -> padded channel-last slot, halo/pad zeroed
         p = self.p
         rows = p.horizon + 2 * P.HALO
         self.lds[p.x_off:p.x_off + rows * p.x_stride] = 0.0
+        for off, n in p.persist_slots:                    # kernel-lifetime slots are cleared once at kernel start
+            self.lds[off:off + n] = 0.0
+        if p.tile and cond_rows is not None:              # tile programs: per-sample condition features -> context slot
+            for n in range(p.horizon):
+                base = p.cond_slot_off + (n + P.HALO) * p.cond_slot_stride + p.cond_coff
+                self.lds[base:base + p.cond_dim] = cond_rows[n]
         for n in range(p.horizon):
             base = p.x_off + (n + P.HALO) * p.x_stride
             self.lds[base:base + p.dim] = x[n]
@@ -48,11 +75,17 @@ class LaneSim:
             if kind == P.OP_LOAD_TEMB:
                 n, dst = op[P.L_NIN], op[P.L_DST]
                 v = np.asarray(temb_row, np.float32).copy()
-                if cond_row is not None:
+                if cond_row is not None and not self.p.tile:
                     v = v + cond_row
                 self.lds[dst:dst + n] = v
             elif kind == P.OP_LINEAR:
                 self._linear(op)
+            elif kind == P.OP_FILL:
+                n, rows, src, dst, sstr, coff = (op[P.L_NIN], op[P.L_NOUT], op[P.L_SRC], op[P.L_DST], op[P.L_WOFF],
+                                                 op[P.L_BOFF])
+                for r in range(rows):
+                    base = dst + (r + P.HALO) * sstr + coff
+                    self.lds[base:base + n] = self.lds[src:src + n]
             elif kind == P.OP_FLATTEN:
                 c, n, src, dst, sstr = op[P.L_NIN], op[P.L_NOUT], op[P.L_SRC], op[P.L_DST], op[P.L_WOFF]
                 self.lds[dst:dst + c * n] = self.read_slot(src, sstr, n, c).T.reshape(-1)   # (C, L) flatten order
@@ -99,7 +132,7 @@ class LaneSim:
         flags = op[P.W_FLAGS]
         dst = op[P.W_DST] + (branch * p.pred_branch_floats if flags & P.F_DST_PRED else 0)
         dstride, drows = op[P.W_DST_STRIDE], op[P.W_DST_ROWS]
-        if not flags & P.F_ACCUM:
+        if not flags & (P.F_ACCUM | P.F_KEEP_DST):
             lds[dst:dst + drows * dstride] = 0.0           # kernel zeroes the whole slot before the K loop
         sstride = c16 + 4
         scratch = p.scratch_off
@@ -164,25 +197,33 @@ class LaneSim:
                 base = scratch + (ks * l_out + n) * sstride
                 row = row + lds[base:base + c_out]
             v[n] = row
-        if flags & P.F_GN_MISH:
+        norm, act_id = op[P.W_NORM], op[P.W_ACT]
+        if norm != P.NORM_NONE:
             g = op[P.W_GROUPS]
             cg = c_out // g
             gamma = self.blob[op[P.W_GAMMA]:op[P.W_GAMMA] + c_out]
             beta = self.blob[op[P.W_BETA]:op[P.W_BETA] + c_out]
             for gi in range(g):
-                blk = v[:, gi * cg:(gi + 1) * cg]
-                mean = np.float32(blk.sum(dtype=np.float32) / np.float32(blk.size))
+                cols = slice(gi * cg, (gi + 1) * cg)
+                # slot-group: statistics over (positions x channels of the group); column: per position (sample)
+                axes = None if norm == P.NORM_SLOT_GROUP else 1
+                blk = v[:, cols]
+                cnt = np.float32(blk.size if axes is None else cg)
+                mean = (blk.sum(axis=axes, keepdims=True, dtype=np.float32) / cnt).astype(np.float32)
                 dev = blk - mean
-                var = np.float32((dev * dev).sum(dtype=np.float32) / np.float32(blk.size))
-                rstd = np.float32(1.0) / np.sqrt(var + np.float32(P.GN_EPS), dtype=np.float32)
-                v[:, gi * cg:(gi + 1) * cg] = dev * rstd * gamma[gi * cg:(gi + 1) * cg] + beta[gi * cg:(gi + 1) * cg]
-            v = mish(v)
+                var = ((dev * dev).sum(axis=axes, keepdims=True, dtype=np.float32) / cnt).astype(np.float32)
+                rstd = (np.float32(1.0) / np.sqrt(var + np.float32(P.GN_EPS))).astype(np.float32)
+                v[:, cols] = dev * rstd * gamma[cols] + beta[cols]
+        v = activation(v, act_id)
         if flags & P.F_ADD_EMB:
             v = v + lds[op[P.W_EMB]:op[P.W_EMB] + c_out][None, :]
         if flags & P.F_ADD_RES:
             v = v + self.read_slot(op[P.W_RES], op[P.W_RES_STRIDE], l_out, c_out)
+        if flags & P.F_SCALE:
+            v = v * np.int32(op[P.W_SCALE]).view(np.float32)
+        coff = op[P.W_DST_COFF]
         for n in range(l_out):
-            base = dst + (n + P.HALO) * dstride
+            base = dst + (n + P.HALO) * dstride + coff
             if flags & P.F_ACCUM:
                 lds[base:base + c_out] += v[n]
             else:

@@ -80,7 +80,7 @@ def test_backbone_forward_matches_reference(name, amd_lib, monkeypatch):
     np.testing.assert_allclose(pred.cpu().numpy(), gold["pred0"], **TOL)
 
 
-FUSED_CASES = [n for n, c in cases.CASES.items() if c["net"][0] == "JannerUNet1d"]
+FUSED_CASES = [n for n, c in cases.CASES.items() if c["net"][0] in ("JannerUNet1d", "PearceMlp", "DQLMlp")]
 TORCH_EXECUTOR_CASES = [n for n in cases.CASES if n not in FUSED_CASES]
 
 
