@@ -32,7 +32,6 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define CDX_THREADS (CDX_N_WAVES * 64)
-#define CDX_COLN_REGS 16  // per-column norm: channels per lane (c_out <= 1024)
 #define CDX_EPI_REGS 4  // GroupNorm elements a lane keeps in registers (groups of <= 256 elements)
 
 static thread_local char g_err[256] = "";
@@ -53,7 +52,9 @@ __device__ __forceinline__ float mish_f(float x) {
 }
 
 // Activation ids of csrc/cdx_ops.h (CDX_ACT_*).  `act` is wave-uniform, so the switch is a scalar branch.
+template <bool FULL>
 __device__ __forceinline__ float act_f(float x, int act) {
+    if constexpr (!FULL) return act == CDX_ACT_MISH ? mish_f(x) : x;   // the U-Net programs only use Mish / identity
     switch (act) {
         case CDX_ACT_MISH: return mish_f(x);
         case CDX_ACT_GELU_ERF: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
@@ -63,12 +64,6 @@ __device__ __forceinline__ float act_f(float x, int act) {
         case CDX_ACT_GELU_TANH: return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
         default: return x;
     }
-}
-
-// sum over aligned groups of `width` (power of two, < 64) consecutive lanes; every lane gets its group's sum
-__device__ __forceinline__ float seg_sum(float v, int width) {
-    for (int m = width >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
 }
 
 // wave64 all-reduce (sum) on the DPP network: quad swaps, row half-mirror, row mirror, then the 4 row sums
@@ -274,6 +269,9 @@ __device__ __forceinline__ int div_small(int e, int d, float inv_d) {
 }
 
 // `w` holds this op's descriptor, one word per lane (lane k = word k); `wn` the next op's.
+// FULL = false compiles the lean U-Net instance (Mish only, no per-column norm / fill ops): the kernel is
+// instruction-cache sensitive, so the MLP-tile features live in a second instantiation.
+template <bool FULL>
 __device__ __forceinline__ void conv_op(const int w, const int wn, const int* __restrict__ ldsi, int desc_off,
                         const float* __restrict__ wblob, float* __restrict__ lds,
                         int scratch, int pred_branch_off, int tid, Prefetch& pre, unsigned long long* prof) {
@@ -379,7 +377,7 @@ __device__ __forceinline__ void conv_op(const int w, const int wn, const int* __
 #pragma unroll
             for (int t = 0; t < CDX_EPI_REGS; ++t) {
                 if (lane + 64 * t < cnt) {
-                    float y = act_f((v[t] - mean) * rstd * ga[t] + be[t], act);
+                    float y = act_f<FULL>((v[t] - mean) * rstd * ga[t] + be[t], act);
                     if (flags & CDX_F_ADD_EMB) y += lds[emb + cc[t]];
                     if (flags & CDX_F_ADD_RES) y += lds[res + (nn[t] + CDX_HALO) * rstride + cc[t]];
                     lds[dst + (nn[t] + CDX_HALO) * dstride + coff + cc[t]] = y * oscale;
@@ -414,74 +412,47 @@ __device__ __forceinline__ void conv_op(const int w, const int wn, const int* __
             const float rstd = __builtin_amdgcn_rsqf(wave_sum(s2) * inv_cnt + CDX_GN_EPS);
             for (int e = lane; e < cnt; e += 64) {
                 const int n = div_small(e, cg, inv_cg), c = gi * cg + (e - n * cg);
-                float v = act_f((lds[scratch + n * sstride + c] - mean) * rstd * gamma[c] + beta[c], act);
+                float v = act_f<FULL>((lds[scratch + n * sstride + c] - mean) * rstd * gamma[c] + beta[c], act);
                 if (flags & CDX_F_ADD_EMB) v += lds[emb + c];
                 if (flags & CDX_F_ADD_RES) v += lds[res + (n + CDX_HALO) * rstride + c];
                 lds[dst + (n + CDX_HALO) * dstride + coff + c] = v * oscale;
             }
         }
-    } else if (col_norm) {
+    } else if (FULL && col_norm) {
         // per-column normalisation (GroupNorm1d on (b, C) / LayerNorm of the MLP backbones): statistics over the
-        // cg channels of ONE column (= one sample of the batch tile).  One wave per column, lane = channel.
+        // cg channels of ONE column (= one sample of the batch tile).  One wave per (column, group) pair, three
+        // short passes through LDS -- deliberately compact code: these layers are tiny and the instruction cache
+        // is what the U-Net path is sensitive to.
         const float* __restrict__ gamma = wblob + CDX_RL(w, CDX_W_GAMMA);
         const float* __restrict__ beta = wblob + CDX_RL(w, CDX_W_BETA);
         const float inv_cg = __int_as_float(CDX_RL(w, CDX_W_INV_CNT));
-        const int nslots = (c_out + 63) >> 6;                 // <= CDX_COLN_REGS (host asserts c_out <= 1024)
-        const int spg_sh = sh - 6;                            // cg >= 64: log2(slots per group)
+        const float inv_groups = 1.0f / (float)groups;
         stamp(prof ? prof + 1 : nullptr, tid);
         __syncthreads();
         stamp(prof ? prof + 2 : nullptr, tid);
-        for (int n = wave; n < l_out; n += CDX_N_WAVES) {
-            float v[CDX_COLN_REGS], m[CDX_COLN_REGS];
-#pragma unroll
-            for (int t = 0; t < CDX_COLN_REGS; ++t) {
-                v[t] = 0.f;
-                if (t < nslots) {
-                    const int c = lane + 64 * t;
-                    if (c < c_out) {
-                        float acc = bias[c];
-                        for (int ks = 0; ks < ksplit; ++ks) acc += lds[scratch + (ks * l_out + n) * sstride + c];
-                        v[t] = acc;
-                    }
-                }
+        for (int pair = wave; pair < l_out * groups; pair += CDX_N_WAVES) {
+            const int n = div_small(pair, groups, inv_groups), c0 = (pair - n * groups) * cg;
+            float s = 0.f;
+            for (int e = lane; e < cg; e += 64) {
+                const int c = c0 + e;
+                float v = bias[c];
+                for (int ks = 0; ks < ksplit; ++ks) v += lds[scratch + (ks * l_out + n) * sstride + c];
+                lds[scratch + n * sstride + c] = v;  // owned by this lane only
+                s += v;
             }
-            // two passes (mean, then squared deviations), each reduced over the group's channels
-#pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-                for (int t = 0; t < CDX_COLN_REGS; ++t)
-                    if (t < nslots) m[t] = cg < 64 ? seg_sum(pass ? v[t] * v[t] : v[t], cg)
-                                                   : wave_sum(pass ? v[t] * v[t] : v[t]);
-                if (cg > 64) {                                 // a group spans 2^spg_sh slots: add them up
-                    float g[CDX_COLN_REGS];
-#pragma unroll
-                    for (int t = 0; t < CDX_COLN_REGS; ++t) {
-                        g[t] = 0.f;
-#pragma unroll
-                        for (int u = 0; u < CDX_COLN_REGS; ++u)
-                            if (u < nslots && (u >> spg_sh) == (t >> spg_sh)) g[t] += m[u];
-                    }
-#pragma unroll
-                    for (int t = 0; t < CDX_COLN_REGS; ++t) m[t] = g[t];
-                }
-#pragma unroll
-                for (int t = 0; t < CDX_COLN_REGS; ++t) {
-                    if (t < nslots) {
-                        if (pass == 0) {
-                            const int c = lane + 64 * t;
-                            v[t] = c < c_out ? v[t] - m[t] * inv_cg : 0.f;          // deviation from the group mean
-                        } else {
-                            const int c = lane + 64 * t;
-                            if (c < c_out) {
-                                const float rstd = __builtin_amdgcn_rsqf(m[t] * inv_cg + CDX_GN_EPS);
-                                float y = act_f(v[t] * rstd * gamma[c] + beta[c], act);
-                                if (flags & CDX_F_ADD_EMB) y += lds[emb + c];
-                                if (flags & CDX_F_ADD_RES) y += lds[res + (n + CDX_HALO) * rstride + c];
-                                lds[dst + (n + CDX_HALO) * dstride + coff + c] = y * oscale;
-                            }
-                        }
-                    }
-                }
+            const float mean = wave_sum(s) * inv_cg;
+            float s2 = 0.f;
+            for (int e = lane; e < cg; e += 64) {
+                const float d = lds[scratch + n * sstride + c0 + e] - mean;
+                s2 += d * d;
+            }
+            const float rstd = __builtin_amdgcn_rsqf(wave_sum(s2) * inv_cg + CDX_GN_EPS);
+            for (int e = lane; e < cg; e += 64) {
+                const int c = c0 + e;
+                float y = act_f<FULL>((lds[scratch + n * sstride + c] - mean) * rstd * gamma[c] + beta[c], act);
+                if (flags & CDX_F_ADD_EMB) y += lds[emb + c];
+                if (flags & CDX_F_ADD_RES) y += lds[res + (n + CDX_HALO) * rstride + c];
+                lds[dst + (n + CDX_HALO) * dstride + coff + c] = y * oscale;
             }
         }
     } else {
@@ -502,7 +473,7 @@ __device__ __forceinline__ void conv_op(const int w, const int wn, const int* __
             float v = b0;
             if (e != tid) { n = div_small(e, c_out, inv_cout); c = e - n * c_out; v = bias[c]; }
             for (int ks = 0; ks < ksplit; ++ks) v += lds[scratch + (ks * l_out + n) * sstride + c];
-            v = act_f(v, act);
+            v = act_f<FULL>(v, act);
             if (flags & CDX_F_ADD_EMB) v += lds[emb + c];
             if (flags & CDX_F_ADD_RES) v += lds[res + (n + CDX_HALO) * rstride + c];
             v *= oscale;
@@ -514,6 +485,7 @@ __device__ __forceinline__ void conv_op(const int w, const int wn, const int* __
     __syncthreads();
 }
 
+template <bool FULL>
 __device__ __forceinline__ void run_program(const cdx_unet1d_launch& L, float* __restrict__ lds, int step, int branch, bool use_cond,
                             int b, int tid, Prefetch& pre) {
     const bool profiling = L.prof != nullptr && b == 0 && step == 0 && branch == 0;
@@ -532,7 +504,7 @@ __device__ __forceinline__ void run_program(const cdx_unet1d_launch& L, float* _
         unsigned long long* pslot = profiling ? lprof + (size_t)oi * 8 : nullptr;
         stamp(pslot, tid);
         if (kind == CDX_OP_CONV) {
-            conv_op(w, oi + 1 < L.n_ops ? wn : 0, ldsi, L.desc_off, L.wblob, lds, L.scratch_off,
+            conv_op<FULL>(w, oi + 1 < L.n_ops ? wn : 0, ldsi, L.desc_off, L.wblob, lds, L.scratch_off,
                     branch * L.pred_branch_floats, tid, pre, pslot);
         } else if (kind == CDX_OP_LINEAR) {
             const int n_in = op[CDX_L_NIN], n_out = op[CDX_L_NOUT];
@@ -587,7 +559,7 @@ __device__ __forceinline__ void run_program(const cdx_unet1d_launch& L, float* _
                 }
             }
             __syncthreads();
-        } else if (kind == CDX_OP_FILL) {
+        } else if (FULL && kind == CDX_OP_FILL) {
             // broadcast a vector into a channel range of every row of a slot (batch-invariant features of MLP tiles)
             const int n = op[CDX_L_NIN], rows = op[CDX_L_NOUT], src = op[CDX_L_SRC], dst = op[CDX_L_DST];
             const int sstr = op[CDX_L_WOFF], fcoff = op[CDX_L_BOFF];
@@ -616,6 +588,7 @@ __device__ __forceinline__ void run_program(const cdx_unet1d_launch& L, float* _
     }
 }
 
+template <bool FULL>
 __global__ __launch_bounds__(CDX_THREADS) void cdx_unet1d_kernel(const cdx_unet1d_launch L) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -666,7 +639,7 @@ __global__ __launch_bounds__(CDX_THREADS) void cdx_unet1d_kernel(const cdx_unet1
         const int n_branch = (L.cfg_mode == 2) ? 2 : 1;
         for (int br = 0; br < n_branch; ++br) {
             const bool use_cond = (L.cond != nullptr) && (L.cfg_mode == 1 || (L.cfg_mode == 2 && br == 0));
-            run_program(L, lds, step, br, use_cond, b, tid, pre);
+            run_program<FULL>(L, lds, step, br, use_cond, b, tid, pre);
         }
         if (L.n_steps == 0 && L.out_vec_len > 0) {  // forward-only, vector head (classifier): emit the head output
             for (int i = tid; i < L.out_vec_len; i += CDX_THREADS)
@@ -790,10 +763,12 @@ int cdx_unet1d_run(const cdx_unet1d_launch* L, void* hip_stream) {
     }
     const size_t lds_bytes = (size_t)L->lds_floats * sizeof(float);
     if (lds_bytes > 160u * 1024u) { set_err("program needs more than 160 KiB of LDS"); return CDX_ELDS; }
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cdx_unet1d_kernel),
+    // two instantiations: the lean U-Net kernel and the full-featured one for batch-tiled MLP programs
+    auto kern = L->tile > 0 ? cdx_unet1d_kernel<true> : cdx_unet1d_kernel<false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) { set_err(hipGetErrorString(e)); return CDX_EHIP; }
-    hipLaunchKernelGGL(cdx_unet1d_kernel, dim3(L->batch), dim3(CDX_THREADS), lds_bytes,
+    hipLaunchKernelGGL(kern, dim3(L->batch), dim3(CDX_THREADS), lds_bytes,
                        reinterpret_cast<hipStream_t>(hip_stream), *L);
     e = hipGetLastError();
     if (e != hipSuccess) { set_err(hipGetErrorString(e)); return CDX_EHIP; }
