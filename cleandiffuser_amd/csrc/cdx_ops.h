@@ -90,6 +90,6 @@
 #define CDX_I_TAP 4
 #define CDX_I_CC 5
 
-#define CDX_HALO 2
+#define CDX_HALO 0
 #define CDX_N_WAVES 8
 #define CDX_GN_EPS 1e-5f

@@ -92,19 +92,20 @@ __device__ __forceinline__ void stamp(unsigned long long* slot, int tid) {
     if (slot && tid == 0) *slot = __builtin_amdgcn_s_memtime();
 }
 
-// LDS row (halo included) feeding output position `pos` at kernel tap `tap`.  Positions/taps that contribute
-// nothing (odd phase of a stride-2 transposed conv, columns past l_out) are pointed at row 0 -- the top halo row,
-// which is all zeros -- so the B fetch needs no predicate.  Transposed convs are stride 2 (host asserts).
-__device__ __forceinline__ int conv_row(int pos, int tap, int cstride, int cpad, int transposed, int l_out) {
-    const int fwd = pos * cstride + tap - cpad + CDX_HALO;
+// Input row feeding output position `pos` at kernel tap `tap`, or -1 when that tap contributes nothing (outside
+// [0, l_in), odd phase of a stride-2 transposed conv, column past l_out).  Such lanes are pointed at the shared
+// all-zero row, so the B fetch needs no predicate.  Transposed convs are stride 2 (host asserts).
+__device__ __forceinline__ int conv_row(int pos, int tap, int cstride, int cpad, int transposed, int l_out, int l_in) {
+    const int fwd = pos * cstride + tap - cpad;
     const int num = pos + cpad - tap;
-    const int bwd = (num & 1) ? 0 : (num >> 1) + CDX_HALO;
-    const int row = transposed ? bwd : fwd;
-    return pos < l_out ? row : 0;
+    const int bwd = (num & 1) ? -1 : (num >> 1);
+    const int q = transposed ? bwd : fwd;
+    return (pos < l_out && q >= 0 && q < l_in) ? q : -1;
 }
 
 struct ConvGeom {
-    int taps, cstride, cpad, transposed, l_out;
+    int taps, cstride, cpad, transposed, l_out, l_in;
+    int zrow;      // LDS offset of the shared all-zero row
     int col0;      // first output position of this pass (long horizons are covered in passes of 2 column tiles)
     int srcA, strideA, ca, srcB, strideB, cb;
 };
@@ -135,11 +136,13 @@ struct M4 {
 };
 
 template <class M, int NT>
-__device__ __forceinline__ void lane_rows(const ConvGeom& g, int tap, int sstr, int lane, int (&roff)[NT]) {
+__device__ __forceinline__ void lane_rows(const ConvGeom& g, int tap, int src, int sstr, int lane, int (&roff)[NT]) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-        roff[nt] = conv_row(g.col0 + nt * M::COLS + M::col(lane), tap, g.cstride, g.cpad, g.transposed, g.l_out) *
-                       sstr + M::koff(lane);
+    for (int nt = 0; nt < NT; ++nt) {
+        const int q = conv_row(g.col0 + nt * M::COLS + M::col(lane), tap, g.cstride, g.cpad, g.transposed, g.l_out,
+                               g.l_in);
+        roff[nt] = (q >= 0 ? q * sstr : g.zrow - src) + M::koff(lane);     // offset relative to the source slot
+    }
 }
 
 template <class M, int NT>
@@ -188,7 +191,7 @@ __device__ __forceinline__ void conv_kloop(const ConvGeom& g, const float* __res
             acc1[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         int roff[NT];
-        lane_rows<M, NT>(g, c.tap, c.sstr, lane, roff);
+        lane_rows<M, NT>(g, c.tap, c.src, c.sstr, lane, roff);
 
         const f32x4* wp = reinterpret_cast<const f32x4*>(wblob + it0) + lane;
         f32x4 wr[PF];
@@ -211,7 +214,7 @@ __device__ __forceinline__ void conv_kloop(const ConvGeom& g, const float* __res
                 if (++c.tap == g.taps) {
                     c.tap = 0; c.ccn = g.cb; c.src = g.srcB; c.sstr = g.strideB;
                 }
-                lane_rows<M, NT>(g, c.tap, c.sstr, lane, roff);
+                lane_rows<M, NT>(g, c.tap, c.src, c.sstr, lane, roff);
             }
             f32x4 bnext[NT];
             if (more) fetch_b<M, NT>(lds, c, roff, bnext);
@@ -274,7 +277,8 @@ __device__ __forceinline__ int div_small(int e, int d, float inv_d) {
 template <bool FULL>
 __device__ __forceinline__ void conv_op(const int w, const int wn, const int* __restrict__ ldsi, int desc_off,
                         const float* __restrict__ wblob, float* __restrict__ lds,
-                        int scratch, int pred_branch_off, int tid, Prefetch& pre, unsigned long long* prof) {
+                        int scratch, int zrow, int pred_branch_off, int tid, Prefetch& pre,
+                        unsigned long long* prof) {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c_out = CDX_RL(w, CDX_W_COUT), c16 = CDX_RL(w, CDX_W_COUT16), l_out = CDX_RL(w, CDX_W_LOUT);
     const int flags = CDX_RL(w, CDX_W_FLAGS);
@@ -286,6 +290,7 @@ __device__ __forceinline__ void conv_op(const int w, const int wn, const int* __
     ConvGeom g;
     g.taps = CDX_RL(w, CDX_W_TAPS); g.cstride = CDX_RL(w, CDX_W_CSTRIDE); g.cpad = CDX_RL(w, CDX_W_CPAD);
     g.transposed = CDX_RL(w, CDX_W_TRANSPOSED); g.l_out = l_out; g.col0 = 0;
+    g.l_in = CDX_RL(w, CDX_W_LIN); g.zrow = zrow;
     g.srcA = CDX_RL(w, CDX_W_SRCA); g.strideA = CDX_RL(w, CDX_W_SRCA_STRIDE); g.ca = CDX_RL(w, CDX_W_CA_CHUNKS);
     g.srcB = CDX_RL(w, CDX_W_SRCB); g.strideB = CDX_RL(w, CDX_W_SRCB_STRIDE); g.cb = CDX_RL(w, CDX_W_CB_CHUNKS);
 
@@ -504,8 +509,8 @@ __device__ __forceinline__ void run_program(const cdx_unet1d_launch& L, float* _
         unsigned long long* pslot = profiling ? lprof + (size_t)oi * 8 : nullptr;
         stamp(pslot, tid);
         if (kind == CDX_OP_CONV) {
-            conv_op<FULL>(w, oi + 1 < L.n_ops ? wn : 0, ldsi, L.desc_off, L.wblob, lds, L.scratch_off,
-                    branch * L.pred_branch_floats, tid, pre, pslot);
+            conv_op<FULL>(w, oi + 1 < L.n_ops ? wn : 0, ldsi, L.desc_off, L.wblob, lds, L.scratch_off, L.zrow_off,
+                          branch * L.pred_branch_floats, tid, pre, pslot);
         } else if (kind == CDX_OP_LINEAR) {
             const int n_in = op[CDX_L_NIN], n_out = op[CDX_L_NOUT];
             const float* __restrict__ w = L.wblob + op[CDX_L_WOFF];   // [n_in][n_out]

@@ -60,7 +60,7 @@ F_GN_MISH, F_ADD_EMB, F_ADD_RES, F_ACCUM, F_DST_PRED, F_POST_MISH, F_RAW_COPY, F
 ACT_NONE, ACT_MISH, ACT_GELU_ERF, ACT_LEAKY, ACT_SILU, ACT_RELU, ACT_GELU_TANH = range(7)
 NORM_NONE, NORM_SLOT_GROUP, NORM_COLUMN = 0, 1, 2
 
-HALO = 2
+HALO = 0          # slots carry no halo rows: out-of-range conv taps read a shared all-zero row (Program.zrow_off)
 N_WAVES = 8
 GN_EPS = 1e-5
 
@@ -131,6 +131,7 @@ class Program:
     cond_dim: int = 0                  # ... this many of them per sample
     zero_off: int = 0                  # the persist slots as one contiguous range (what the kernel clears at start)
     zero_floats: int = 0
+    zrow_off: int = 0                  # the shared all-zero row (inside the zero range)
     persist_slots: list = field(default_factory=list)   # (offset, floats) of extra kernel-lifetime slots to zero once
     meta: dict = field(default_factory=dict)
 
@@ -240,7 +241,6 @@ class _Builder:
         """One fused conv/linear op.  Epilogue order: bias -> norm (slot-group `gn` | per-column `col_norm`) ->
         activation -> +FiLM vector -> +residual -> *scale -> store at channel offset `dst_coff`."""
         c_out, taps, _ = w_eff.shape
-        assert taps <= 2 * HALO + 1 and pad <= HALO
         assert not transposed or stride == 2, "the kernel's transposed-conv row map assumes stride 2"
         mode = MODE_4X4 if (dst.length <= 8 and c_out % 64 == 0 and self.allow_4x4) else MODE_16X16
         woff, n_chunks, per_src = self.pack_conv(w_eff, [s.chans for s in srcs], mode)
@@ -382,8 +382,8 @@ def supports_janner(net) -> Optional[str]:
         return "attention=True (LinearAttention) is PyTorch-only"
     if net.norm_type != "groupnorm":
         return f"norm_type={net.norm_type!r} is PyTorch-only"
-    if net.kernel_size > 2 * HALO + 1 or net.kernel_size % 2 == 0:
-        return f"kernel_size={net.kernel_size} unsupported (odd, <=5)"
+    if net.kernel_size % 2 == 0:
+        return f"kernel_size={net.kernel_size} unsupported (odd only)"
     return None
 
 
@@ -443,6 +443,10 @@ def _finalize(b: "_Builder", net, x: Act, pred: Optional[Act], horizon: int, d: 
         off += pred.floats                                # second prediction slot (CFG unconditional branch)
     for a in persist:                                     # further kernel-lifetime slots (MLP context etc.)
         a.off, off = off, off + a.floats
+    # shared zero row: what a conv tap outside [0, L) reads (and columns past l_out); sized for the widest source
+    zrow_off = off
+    zrow_floats = max(pad16(a.chans) for a in b.acts) + 16
+    off += zrow_floats
     prev_off, off = off, off + (horizon * d + 3) // 4 * 4
     vec_off, off = off, off + b.vec_len
     scratch_off, off = off, off + (b.scratch + 3) // 4 * 4
@@ -486,7 +490,8 @@ def _finalize(b: "_Builder", net, x: Act, pred: Optional[Act], horizon: int, d: 
                    cond_slot_stride=cond_slot[0].stride if cond_slot else 0,
                    cond_coff=cond_slot[1] if cond_slot else 0, cond_dim=cond_slot[2] if cond_slot else 0,
                    persist_slots=[(a.off, a.floats) for a in persist],
-                   zero_off=persist[0].off if persist else 0, zero_floats=sum(a.floats for a in persist),
+                   zero_off=persist[0].off if persist else zrow_off,
+                   zero_floats=sum(a.floats for a in persist) + zrow_floats, zrow_off=zrow_off,
                    macs_per_forward=b.macs, n_conv=b.n_conv,
                    out_vec_off=(vec_off + out_vec) if out_vec >= 0 else 0, out_vec_len=out_len,
                    meta={"n_ops": len(ops), "blob_floats": int(blob.numel())})
@@ -539,8 +544,8 @@ def compile_janner(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x4
 def supports_half_janner(net) -> Optional[str]:
     if net.norm_type != "groupnorm":
         return f"norm_type={net.norm_type!r} is PyTorch-only"
-    if net.kernel_size > 2 * HALO + 1 or net.kernel_size % 2 == 0:
-        return f"kernel_size={net.kernel_size} unsupported (odd, <=5)"
+    if net.kernel_size % 2 == 0:
+        return f"kernel_size={net.kernel_size} unsupported (odd only)"
     return None
 
 

@@ -35,7 +35,7 @@ class CdxUnet1dLaunch(ctypes.Structure):
         ("out_vec_off", ctypes.c_int32), ("out_vec_len", ctypes.c_int32),
         ("tile", ctypes.c_int32), ("cond_slot_off", ctypes.c_int32), ("cond_slot_stride", ctypes.c_int32),
         ("cond_coff", ctypes.c_int32), ("cond_dim", ctypes.c_int32),
-        ("zero_off", ctypes.c_int32), ("zero_floats", ctypes.c_int32),
+        ("zero_off", ctypes.c_int32), ("zero_floats", ctypes.c_int32), ("zrow_off", ctypes.c_int32),
         ("prof_off", ctypes.c_int32), ("desc_off", ctypes.c_int32), ("desc_words", ctypes.c_int32),
         ("batch", ctypes.c_int32), ("horizon", ctypes.c_int32), ("dim", ctypes.c_int32), ("emb_dim", ctypes.c_int32),
         ("temb", ctypes.c_void_p), ("steps", ctypes.c_void_p),
@@ -217,7 +217,7 @@ def _launch(comp: _Compiled, *, batch, x_in, x_out, temb, steps_dev=None, n_step
         pred_branch_floats=prog.pred_branch_floats, prev_off=prog.prev_off, scratch_off=prog.scratch_off,
         out_vec_off=prog.out_vec_off, out_vec_len=prog.out_vec_len,
         tile=prog.tile, cond_slot_off=prog.cond_slot_off, cond_slot_stride=prog.cond_slot_stride,
-        cond_coff=prog.cond_coff, cond_dim=prog.cond_dim, zero_off=prog.zero_off, zero_floats=prog.zero_floats,
+        cond_coff=prog.cond_coff, cond_dim=prog.cond_dim, zero_off=prog.zero_off, zero_floats=prog.zero_floats, zrow_off=prog.zrow_off,
         prof_off=prog.prof_off, desc_off=prog.desc_off, desc_words=int(prog.ops_buffer.size),
         batch=batch, horizon=prog.horizon, dim=prog.dim, emb_dim=prog.emb_dim,
         temb=temb.data_ptr(), steps=_ptr(steps_dev), n_steps=n_steps, temb_per_sample=temb_per_sample,

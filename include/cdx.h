@@ -63,6 +63,7 @@ typedef struct cdx_unet1d_launch {
      * (batch*tile, dim); `cond` is (batch*tile, cond_dim) and is loaded into a context slot's channel range */
     int32_t tile, cond_slot_off, cond_slot_stride, cond_coff, cond_dim;
     int32_t zero_off, zero_floats;    /* extra kernel-lifetime LDS range cleared once at kernel start */
+    int32_t zrow_off;                 /* shared all-zero row inside that range: what out-of-range conv taps read */
     int32_t prof_off;             /* LDS float offset (even) of the (n_ops*8+2) x u64 stamp area; used only if prof != NULL */
     int32_t desc_off, desc_words; /* where the kernel keeps its copy of `ops` in LDS, and how many words it is */
     /* problem */

@@ -51,8 +51,7 @@ class LaneSim:
         p = self.p
         rows = p.horizon + 2 * P.HALO
         self.lds[p.x_off:p.x_off + rows * p.x_stride] = 0.0
-        for off, n in p.persist_slots:                    # kernel-lifetime slots are cleared once at kernel start
-            self.lds[off:off + n] = 0.0
+        self.lds[p.zero_off:p.zero_off + p.zero_floats] = 0.0   # kernel-lifetime slots + the shared zero row
         if p.tile and cond_rows is not None:              # tile programs: per-sample condition features -> context slot
             for n in range(p.horizon):
                 base = p.cond_slot_off + (n + P.HALO) * p.cond_slot_stride + p.cond_coff
@@ -119,8 +118,7 @@ class LaneSim:
             q = num // op[P.W_CSTRIDE]
         else:
             q = pos * op[P.W_CSTRIDE] + tap - op[P.W_CPAD]
-        assert -P.HALO <= q < op[P.W_LIN] + P.HALO, "conv window leaves the halo"
-        return q + P.HALO
+        return q + P.HALO if 0 <= q < op[P.W_LIN] else -1
 
     def _conv(self, op, branch):
         p, lds = self.p, self.lds
@@ -159,9 +157,9 @@ class LaneSim:
                     bmat = np.zeros((64, 4), np.float32)
                     for l in range(64):
                         pos = nt * cols + li[l]
-                        row = self._row(op, pos, tap) if pos < l_out else 0
-                        row = max(row, 0)                   # non-contributing taps read the all-zero halo row 0
-                        addr = src + row * sstr + cc * kstep + (4 * lk[l] if mode == P.MODE_16X16 else 0)
+                        row = self._row(op, pos, tap) if pos < l_out else -1
+                        base = src + row * sstr if row >= 0 else p.zrow_off   # non-contributing taps: shared zero row
+                        addr = base + cc * kstep + (4 * lk[l] if mode == P.MODE_16X16 else 0)
                         bmat[l] = lds[addr:addr + 4]
                     for m in range(4):
                         if mode == P.MODE_16X16:            # D[i][j] += sum_k A[i][k] B[k][j]
