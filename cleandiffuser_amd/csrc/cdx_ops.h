@@ -7,6 +7,7 @@
 #define CDX_OP_CONV 2
 #define CDX_OP_FLATTEN 3
 #define CDX_OP_FILL 4
+#define CDX_OP_LOAD_COND 5
 
 #define CDX_W_KIND 0
 // ---- conv ----
@@ -68,6 +69,7 @@
 #define CDX_F_RAW_COPY 64
 #define CDX_F_SCALE 128
 #define CDX_F_KEEP_DST 256
+#define CDX_F_FILM 512
 // ---- activation ids / normalisation modes ----
 #define CDX_ACT_NONE 0
 #define CDX_ACT_MISH 1

@@ -384,6 +384,7 @@ __device__ __forceinline__ void conv_op(const int w, const int wn, const int* __
                 if (lane + 64 * t < cnt) {
                     float y = act_f<FULL>((v[t] - mean) * rstd * ga[t] + be[t], act);
                     if (flags & CDX_F_ADD_EMB) y += lds[emb + cc[t]];
+                    if (flags & CDX_F_FILM) y = y * lds[emb + cc[t]] + lds[emb + c_out + cc[t]];
                     if (flags & CDX_F_ADD_RES) y += lds[res + (nn[t] + CDX_HALO) * rstride + cc[t]];
                     lds[dst + (nn[t] + CDX_HALO) * dstride + coff + cc[t]] = y * oscale;
                 }
@@ -419,6 +420,7 @@ __device__ __forceinline__ void conv_op(const int w, const int wn, const int* __
                 const int n = div_small(e, cg, inv_cg), c = gi * cg + (e - n * cg);
                 float v = act_f<FULL>((lds[scratch + n * sstride + c] - mean) * rstd * gamma[c] + beta[c], act);
                 if (flags & CDX_F_ADD_EMB) v += lds[emb + c];
+                if (flags & CDX_F_FILM) v = v * lds[emb + c] + lds[emb + c_out + c];
                 if (flags & CDX_F_ADD_RES) v += lds[res + (n + CDX_HALO) * rstride + c];
                 lds[dst + (n + CDX_HALO) * dstride + coff + c] = v * oscale;
             }
@@ -580,11 +582,17 @@ __device__ __forceinline__ void run_program(const cdx_unet1d_launch& L, float* _
             for (int c = tid; c < C; c += CDX_THREADS)
                 for (int l = 0; l < Lp; ++l) lds[dst + c * Lp + l] = lds[src + (l + CDX_HALO) * sstr + c];
             __syncthreads();
+        } else if (kind == CDX_OP_LOAD_COND) {
+            // raw per-trajectory condition features -> vec (zeros when the launch carries no condition / uncond branch)
+            const int n = op[CDX_L_NIN], dst = op[CDX_L_DST];
+            for (int i = tid; i < n; i += CDX_THREADS)
+                lds[dst + i] = use_cond ? L.cond[(size_t)b * L.cond_dim + i] : 0.f;
+            __syncthreads();
         } else {  // CDX_OP_LOAD_TEMB
             const int n = op[CDX_L_NIN], dst = op[CDX_L_DST];
             for (int i = tid; i < n; i += CDX_THREADS) {
                 float v = L.temb[(size_t)(L.temb_per_sample ? b : step) * L.emb_dim + i];
-                if (use_cond && L.tile == 0) v += L.cond[(size_t)b * L.emb_dim + i];
+                if (use_cond && L.tile == 0 && L.cond_dim == 0) v += L.cond[(size_t)b * L.emb_dim + i];
                 lds[dst + i] = v;
             }
             __syncthreads();
@@ -683,7 +691,19 @@ __global__ __launch_bounds__(CDX_THREADS) void cdx_unet1d_kernel(const cdx_unet1
                 xth = p; eps = (x - al * p) / sg;
             }
             float xn;
-            if (st.kind == 0) {
+            if (st.kind >= 3) {
+                // legacy DDPM class (reference diffusion/ddpm.py:153-164, 230-241): the fix-mask is applied to the
+                // *prediction* (eps: pred*(1-m); x0: pred*(1-m) + x*m), then the ancestral posterior mean
+                const float m = L.fix_mask ? L.fix_mask[e] : 0.f;
+                if (st.kind == 3) {
+                    p = p * (1.0f - m);
+                    xn = k0 * (x - k1 * p);
+                } else {
+                    p = p * (1.0f - m) + x * m;
+                    xn = k0 * (k1 * x + k2 * p);
+                }
+                if (st.noise_idx >= 0) xn += k3 * L.noise[((size_t)st.noise_idx * L.batch + b) * HD + e];
+            } else if (st.kind == 0) {
                 xn = k0 * (x - k1 * eps) + k2 * eps;
                 if (st.noise_idx >= 0) xn += k3 * L.noise[((size_t)st.noise_idx * L.batch + b) * HD + e];
             } else if (st.kind == 1) {

@@ -134,6 +134,18 @@ class DDPM(DiffusionModel):
         xt = xt * (1. - self.fix_mask) + prior * self.fix_mask
         with torch.set_grad_enabled(requires_grad):
             cond_cfg = model["condition"](condition_cfg, mask_cfg) if condition_cfg is not None else None
+        if not preserve_history:                                   # whole loop in one launch when the backbone compiles
+            from ..engine import dispatch, plan as _plan
+            plan = _plan.build_legacy_ddpm_plan(self.beta, self.alpha, self.bar_alpha, self.predict_noise,
+                                                extra_sample_steps)
+            fused = dispatch.try_fused_legacy_ddpm(self, model, plan, xt, prior, cond_cfg, w_cfg, w_cg, requires_grad, feed)
+            if fused is not None:
+                log = {"log_p": None}
+                if self.classifier is not None and condition_cg is not None:
+                    with torch.no_grad():
+                        t0 = torch.zeros((n_samples,), dtype=torch.long, device=self.device)
+                        log["log_p"] = self.classifier.logp(fused, t0, condition_cg)
+                return fused, log
         kw = dict(use_ema=use_ema, requires_grad=requires_grad, condition_vec_cfg=cond_cfg,
                   condition_vec_cg=condition_cg, w_cfg=w_cfg, w_cg=w_cg)
         for t in range(self.diffusion_steps - 1, -1, -1):

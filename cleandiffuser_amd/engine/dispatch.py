@@ -38,3 +38,13 @@ def try_fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, requ
         return None                      # per-step classifier gradients need autograd
     from . import runtime
     return runtime.fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed)
+
+
+def try_fused_legacy_ddpm(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, requires_grad, feed):
+    """Legacy ``DDPM`` class: same fused executor, legacy step kinds."""
+    if not _on_gpu(xt) or requires_grad or xt.dtype != torch.float32:
+        return None
+    if solver.classifier is not None and w_cg != 0.0:
+        return None
+    from . import runtime
+    return runtime.fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed)

@@ -23,7 +23,7 @@ SUPPORTED_SOLVERS = [
     "ode_dpmsolver_1", "ode_dpmsolver++_1", "ode_dpmsolver++_2M",
     "sde_dpmsolver_1", "sde_dpmsolver++_1", "sde_dpmsolver++_2M"]
 
-KIND_DDPM, KIND_DDIM, KIND_LINEAR = 0, 1, 2
+KIND_DDPM, KIND_DDIM, KIND_LINEAR, KIND_LEGACY_EPS, KIND_LEGACY_X0 = 0, 1, 2, 3, 4
 V_EPS, V_XTHETA, V_MULTISTEP = 0, 1, 2
 
 
@@ -113,4 +113,30 @@ def build_vp_plan(solver: str, alphas: torch.Tensor, sigmas: torch.Tensor, sched
                       noise=stochastic, push=multistep)
             n_pushed += 1 if multistep else 0
         plan.steps.append(st)
+    return plan
+
+
+def build_legacy_ddpm_plan(beta: torch.Tensor, alpha: torch.Tensor, bar_alpha: torch.Tensor, predict_noise: bool,
+                           extra_sample_steps: int = 0) -> SamplePlan:
+    """Legacy ``DDPM`` class (reference diffusion/ddpm.py:212-241 and the Diffusion-X tail :321-343): ancestral steps
+    t = T-1 .. 0 over ALL diffusion steps, then `extra_sample_steps` noise-free repeats of t = 0.
+      eps:  x <- 1/sqrt(alpha_t) * (x - beta_t/sqrt(1-abar_t) * P)                     [+ sqrt(beta_t (1-abar_{t-1})/(1-abar_t)) z]
+      x0 :  x <- 1/(1-abar_t) * (sqrt(alpha_t)(1-abar_{t-1}) x + beta_t sqrt(abar_{t-1}) P)   [+ same noise]
+    `alpha`/`sigma` of a record carry sqrt(abar_t), sqrt(1-abar_t): the clip bounds use them (ddpm.py:153-160)."""
+    beta, alpha, bar = (v.detach().float().cpu() for v in (beta, alpha, bar_alpha))
+    T = beta.shape[0]
+    plan = SamplePlan(solver="legacy_ddpm", t_is_integer=True)
+    one = torch.tensor(1.0)
+    order = list(range(T - 1, -1, -1)) + [0] * extra_sample_steps
+    for pos, t in enumerate(order):
+        bar_prev = bar[t - 1] if t > 0 else one
+        if predict_noise:
+            k = (_f(1 / alpha[t].sqrt()), _f(beta[t] / (1 - bar[t]).sqrt()), 0.0)
+            kind = KIND_LEGACY_EPS
+        else:
+            k = (_f(1 / (1 - bar[t])), _f(alpha[t].sqrt() * (1 - bar_prev)), _f(beta[t] * bar_prev.sqrt()))
+            kind = KIND_LEGACY_X0
+        std = _f((beta[t] * (1 - bar_prev) / (1 - bar[t])).sqrt())
+        plan.steps.append(Step(kind, V_EPS, t, int(t), _f(bar[t].sqrt()), _f((1 - bar[t]).sqrt()),
+                               (k[0], k[1], k[2], std, 0.0), noise=(t != 0 and pos < T)))
     return plan

@@ -34,7 +34,7 @@ import torch.nn as nn
 
 OP_WORDS = 40
 ITEM_WORDS = 8
-OP_LOAD_TEMB, OP_LINEAR, OP_CONV, OP_FLATTEN, OP_FILL = 0, 1, 2, 3, 4
+OP_LOAD_TEMB, OP_LINEAR, OP_CONV, OP_FLATTEN, OP_FILL, OP_LOAD_COND = 0, 1, 2, 3, 4, 5
 MODE_16X16, MODE_4X4 = 0, 1        # MFMA shape of a conv: 16x16x4 (16 rows x 16 cols x 16 K per record) or
                                    # 4x4x1 x16 blocks (64 rows x 4 cols x 4 K per record) for <= 8 positions
 
@@ -54,8 +54,8 @@ L_NIN, L_NOUT, L_SRC, L_DST, L_WOFF, L_BOFF, L_FLAGS, L_DST2 = range(1, 9)
 # flatten (slot -> vector, channel-major like torch .flatten(1) of (b, C, L)): L_NIN = C, L_NOUT = L, L_SRC = slot,
 # L_DST = vector, L_WOFF = slot stride
 
-F_GN_MISH, F_ADD_EMB, F_ADD_RES, F_ACCUM, F_DST_PRED, F_POST_MISH, F_RAW_COPY, F_SCALE, F_KEEP_DST = \
-    1, 2, 4, 8, 16, 32, 64, 128, 256
+F_GN_MISH, F_ADD_EMB, F_ADD_RES, F_ACCUM, F_DST_PRED, F_POST_MISH, F_RAW_COPY, F_SCALE, F_KEEP_DST, F_FILM = \
+    1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 # activation ids (W_ACT) and normalisation modes (W_NORM: statistics over the whole slot group / per column)
 ACT_NONE, ACT_MISH, ACT_GELU_ERF, ACT_LEAKY, ACT_SILU, ACT_RELU, ACT_GELU_TANH = range(7)
 NORM_NONE, NORM_SLOT_GROUP, NORM_COLUMN = 0, 1, 2
@@ -212,6 +212,10 @@ class _Builder:
     def load_temb(self, n: int, dst_vec: int):
         self._emit({W_KIND: OP_LOAD_TEMB, L_NIN: n, L_DST: dst_vec}, [], None)
 
+    def load_cond(self, n: int, dst_vec: int):
+        """vec[dst : dst+n] <- this trajectory's raw condition features (zeros when the launch has none)."""
+        self._emit({W_KIND: OP_LOAD_COND, L_NIN: n, L_DST: dst_vec}, [], None)
+
     def linear(self, lin_w: torch.Tensor, lin_b: torch.Tensor, src_vec: int, dst_vec: int, post_mish=False,
                raw_dst: Optional[int] = None):
         """dst = [Mish](W src + b); with `raw_dst` the pre-activation value is stored there as well."""
@@ -237,7 +241,7 @@ class _Builder:
     def conv(self, srcs: Sequence[Act], dst: Act, w_eff: torch.Tensor, bias: torch.Tensor, *, stride=1, pad=0,
              transposed=False, gn: Optional[nn.Module] = None, emb_vec: int = -1, res: Optional[Act] = None,
              accum=False, dst_pred=False, act: Optional[int] = None, col_norm: Optional[nn.Module] = None,
-             scale: Optional[float] = None, dst_coff: int = 0, keep_dst: bool = False):
+             scale: Optional[float] = None, dst_coff: int = 0, keep_dst: bool = False, film: bool = False):
         """One fused conv/linear op.  Epilogue order: bias -> norm (slot-group `gn` | per-column `col_norm`) ->
         activation -> +FiLM vector -> +residual -> *scale -> store at channel offset `dst_coff`."""
         c_out, taps, _ = w_eff.shape
@@ -298,7 +302,7 @@ class _Builder:
             flags |= F_KEEP_DST
         words[W_DST_COFF] = dst_coff
         if emb_vec >= 0:
-            flags |= F_ADD_EMB
+            flags |= F_FILM if film else F_ADD_EMB      # FiLM: y*e[c] + e[C + c]; else y + e[c]
             words[W_EMB] = emb_vec
         if res is not None:
             flags |= F_ADD_RES
@@ -465,7 +469,7 @@ def _finalize(b: "_Builder", net, x: Act, pred: Optional[Act], horizon: int, d: 
             cursor += len(items) * ITEM_WORDS
     ops = np.asarray(b.ops, dtype=np.int32)
     for op in ops:                                        # vec offsets were relative; make them absolute
-        if op[W_KIND] == OP_LOAD_TEMB:
+        if op[W_KIND] in (OP_LOAD_TEMB, OP_LOAD_COND):
             op[L_DST] += vec_off
         elif op[W_KIND] == OP_LINEAR:
             op[L_SRC] += vec_off
@@ -476,7 +480,7 @@ def _finalize(b: "_Builder", net, x: Act, pred: Optional[Act], horizon: int, d: 
             op[L_DST] += vec_off
         elif op[W_KIND] == OP_FILL:
             op[L_SRC] += vec_off
-        elif op[W_KIND] == OP_CONV and op[W_FLAGS] & F_ADD_EMB:
+        elif op[W_KIND] == OP_CONV and op[W_FLAGS] & (F_ADD_EMB | F_FILM):
             op[W_EMB] += vec_off
     blob = torch.cat(b.chunks) if b.chunks else torch.zeros(0, device=dev)
     ops_buffer = np.concatenate([ops.reshape(-1), np.asarray(tail, dtype=np.int64).astype(np.int32)])
@@ -653,3 +657,87 @@ def compile_dql_mlp(net, tile: int = MLP_TILE, max_lds_bytes: int = 160 * 1024) 
     b.conv([m3], pred, _lin_eff(net.final_layer), net.final_layer.bias, dst_pred=True)
     return _finalize(b, net, x, pred, tile, d, max_lds_bytes, persist=[ctx], emb_dim=e,
                      cond_slot=(ctx, e, obs), tile=tile)
+
+
+# ================================================================================================== #
+# ChiUNet1d lowering (Diffusion Policy)                                                               #
+# ================================================================================================== #
+def supports_chiunet(net) -> Optional[str]:
+    if not net.obs_as_global_cond:
+        return "local (per-timestep) observation conditioning is PyTorch-only"
+    k = net.final_conv[0].kernel_size[0]
+    if k % 2 == 0:
+        return f"kernel_size={k} unsupported (odd only)"
+    return None
+
+
+def compile_chiunet(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x4: bool = True) -> Program:
+    """ChiUNet1d with a global condition (reference nn_diffusion/chiunet.py:48-192).  The FiLM vector of a block
+    (Mish -> Linear(2*emb -> [2]C)) is computed just in time into one reusable vec region -- at config-3 width the
+    stacked vectors of all blocks would not fit LDS."""
+    why = supports_chiunet(net)
+    if why is not None:
+        raise ValueError(why)
+    b = _Builder(next(net.parameters()).device)
+    b.allow_4x4 = allow_4x4
+    d = net.final_conv[3].out_channels
+    k = net.final_conv[0].kernel_size[0]
+    e = net.emb_dim
+    n_cond = net.global_cond_encoder.in_features
+    blocks = []
+    for res1, res2, _ in net.downs:
+        blocks += [res1, res2]
+    blocks += list(net.mids)
+    for res1, res2, _ in net.ups:
+        blocks += [res1, res2]
+    # emb = [map_emb(temb) | global_cond_encoder(cond)]; blocks consume Mish(emb) only
+    v_temb, v_hid, v_cond, v_memb = b.vec(e), b.vec(4 * e), b.vec(n_cond), b.vec(2 * e)
+    v_film = b.vec(max(blk.cond_encoder[1].out_features for blk in blocks))
+    b.load_temb(e, v_temb)
+    b.load_cond(n_cond, v_cond)
+    b.linear(net.map_emb[0].weight, net.map_emb[0].bias, v_temb, v_hid, post_mish=True)
+    b.linear(net.map_emb[2].weight, net.map_emb[2].bias, v_hid, v_memb, post_mish=True)
+    b.linear(net.global_cond_encoder.weight, net.global_cond_encoder.bias, v_cond, v_memb + e, post_mish=True)
+
+    def resblock(srcs: List[Act], rb) -> Act:
+        c_out, length = rb.out_dim, srcs[0].length
+        enc = rb.cond_encoder[1]
+        b.linear(enc.weight, enc.bias, v_memb, v_film)
+        t1 = b.act(length, c_out)
+        b.conv(srcs, t1, _conv1d_eff(rb.conv1[0]), rb.conv1[0].bias, pad=k // 2, gn=rb.conv1[1], emb_vec=v_film,
+               film=rb.cond_predict_scale)
+        out = b.act(length, c_out)
+        identity = isinstance(rb.residual_conv, nn.Identity)
+        if identity:
+            assert len(srcs) == 1
+        b.conv([t1], out, _conv1d_eff(rb.conv2[0]), rb.conv2[0].bias, pad=k // 2, gn=rb.conv2[1],
+               res=srcs[0] if identity else None)
+        if not identity:
+            b.conv(srcs, out, _conv1d_eff(rb.residual_conv), rb.residual_conv.bias, accum=True)
+        return out
+
+    x = b.act(horizon, d, persistent=True)
+    cur, skips = x, []
+    for res1, res2, down in net.downs:
+        cur = resblock([resblock([cur], res1)], res2)
+        skips.append(cur)
+        if not isinstance(down, nn.Identity):
+            assert cur.length % 2 == 0, "horizon too short for the number of resolutions"
+            cur = _downsample(b, cur, down)
+    for mid in net.mids:
+        cur = resblock([cur], mid)
+    for res1, res2, up in net.ups:
+        cur = resblock([resblock([cur, skips.pop()], res1)], res2)
+        if not isinstance(up, nn.Identity):
+            nxt = b.act(cur.length * 2, cur.chans)
+            b.conv([cur], nxt, _convT1d_eff(up.conv), up.conv.bias, stride=2, pad=1, transposed=True)
+            cur = nxt
+    assert cur.length == horizon
+    fc = net.final_conv
+    t = b.act(horizon, net.model_dim)
+    b.conv([cur], t, _conv1d_eff(fc[0]), fc[0].bias, pad=k // 2, gn=fc[1])
+    pred = b.act(horizon, d, persistent=True)
+    b.conv([t], pred, _conv1d_eff(fc[3]), fc[3].bias, dst_pred=True)
+    prog = _finalize(b, net, x, pred, horizon, d, max_lds_bytes, emb_dim=e)
+    prog.cond_dim = n_cond
+    return prog

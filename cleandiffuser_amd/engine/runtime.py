@@ -113,6 +113,8 @@ def compiled_program(module, horizon: int) -> _Compiled:
             prog = P.compile_pearce_mlp(module, horizon)
         elif kind == "dql":
             prog = P.compile_dql_mlp(module, horizon)
+        elif _is_chiunet(module):
+            prog = P.compile_chiunet(module, horizon)
         else:
             prog = (P.compile_half_janner if _is_half_janner(module) else P.compile_janner)(module, horizon)
     per_mod[horizon] = _Compiled(prog, sig)
@@ -135,6 +137,11 @@ def _mlp_kind(module) -> Optional[str]:
     return None
 
 
+def _is_chiunet(module) -> bool:
+    from ..nn_diffusion.chiunet import ChiUNet1d
+    return type(module) is ChiUNet1d
+
+
 def _is_half_janner(module) -> bool:
     from ..nn_classifier.half_jannerunet import HalfJannerUNet1d
     return isinstance(module, HalfJannerUNet1d)
@@ -147,6 +154,18 @@ def supported_backbone(module, horizon: int) -> Optional[str]:
         if why:
             return why
         return None if horizon == module.horizon else f"classifier was built for horizon {module.horizon}"
+    if _is_chiunet(module):
+        why = P.supports_chiunet(module)
+        if why:
+            return why
+        n_down = sum(1 for lvl in module.downs if not isinstance(lvl[2], torch.nn.Identity))
+        if horizon % (1 << n_down) != 0:
+            return f"horizon {horizon} not divisible by 2^{n_down}"
+        try:
+            compiled_program(module, horizon)
+        except ValueError as e:                      # LDS plan does not fit one workgroup
+            return str(e)
+        return None
     if not _is_janner(module):
         return f"{type(module).__name__} has no fused program yet"
     why = P.supports_janner(module)
@@ -236,6 +255,20 @@ def _launch(comp: _Compiled, *, batch, x_in, x_out, temb, steps_dev=None, n_step
 # ------------------------------------------------------------------------------------------------ #
 # entry points used by dispatch.py                                                                   #
 # ------------------------------------------------------------------------------------------------ #
+def _backbone_cond(module, prog, condition, device):
+    """Condition tensor in the layout the program expects, None for "no condition", False for "cannot be fused"."""
+    if _is_chiunet(module):
+        if condition is None:
+            return False                              # the reference raises on a missing condition (Q12): keep that path
+        c = _f32c(torch.flatten(condition, 1), device)
+        return c if c.shape[1] == prog.cond_dim else False
+    if condition is None:
+        return None
+    if condition.dim() != 2 or condition.shape[1] != prog.emb_dim:
+        return False
+    return _f32c(condition, device)
+
+
 def backbone_forward(module, x, noise, condition) -> Optional[torch.Tensor]:
     """``BaseNNDiffusion.forward`` on the device: one launch, per-sample timesteps."""
     if x.dim() != 3 or supported_backbone(module, x.shape[1]) is not None:
@@ -245,7 +278,9 @@ def backbone_forward(module, x, noise, condition) -> Optional[torch.Tensor]:
     with torch.no_grad():
         comp = compiled_program(module, h)
         temb = _f32c(module.map_noise(noise), x.device)
-        cond = _f32c(condition, x.device) if condition is not None else None
+        cond = _backbone_cond(module, comp.prog, condition, x.device)
+        if cond is False:
+            return None
         xin = _f32c(x, x.device)
         vec_len = comp.prog.out_vec_len
         out = torch.empty((b, vec_len), device=x.device, dtype=torch.float32) if vec_len else torch.empty_like(xin)
@@ -322,12 +357,12 @@ def fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed) -> Optio
     net = model["diffusion"]
     if xt.dim() == 2 and _mlp_kind(net) is not None:
         return fused_sample_mlp(solver, net, _mlp_kind(net), plan, xt, prior, cond_vec, w_cfg, feed)
-    if xt.dim() != 3 or not _is_janner(net) or supported_backbone(net, xt.shape[1]) is not None:
+    if xt.dim() != 3 or not (_is_janner(net) or _is_chiunet(net)) or supported_backbone(net, xt.shape[1]) is not None:
         return None
     if cond_vec is None and w_cfg not in (0.0, 1.0):
         return None                                   # the reference raises here; let the torch executor do it
-    if cond_vec is not None and (cond_vec.dim() != 2 or cond_vec.shape[1] != net.emb_dim):
-        return None
+    if _is_chiunet(net) and (cond_vec is None or w_cfg == 0.0):
+        return None                                   # ChiUNet1d cannot run unconditionally (reference raises)
     try:
         b, h, d = xt.shape
         dev = xt.device
@@ -346,10 +381,10 @@ def fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed) -> Optio
         noise = torch.stack([feed.like(xt) for _ in range(plan.n_noise)]).contiguous() if plan.n_noise else None
         if cond_vec is None or w_cfg == 0.0:
             mode, cond = 0, None
-        elif w_cfg == 1.0:
-            mode, cond = 1, _f32c(cond_vec, dev)
         else:
-            mode, cond = 2, _f32c(cond_vec, dev)
+            mode, cond = (1 if w_cfg == 1.0 else 2), _backbone_cond(net, comp.prog, cond_vec, dev)
+            if cond is False or cond is None:
+                return None
         xin = _f32c(xt, dev)
         out = torch.empty_like(xin)
         _launch(comp, batch=b, x_in=xin, x_out=out, temb=temb, steps_dev=steps_dev, n_steps=len(plan.steps),

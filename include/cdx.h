@@ -35,9 +35,11 @@ extern "C" {
  *   kind 0 (ddpm)   x <- k0*(x - k1*eps) + k2*eps [+ k3*z]
  *   kind 1 (ddim)   x <- k0*((x - k1*eps)/k2) + k3*eps
  *   kind 2 (linear) x <- k0*x - k1*V [+ k2*z],  V = eps | x_theta | (k3*x_theta - k4*x_theta_prev)
+ *   kind 3/4 (legacy DDPM class, reference diffusion/ddpm.py:153-164,230-241; eps / x0 prediction):
+ *            P <- P*(1-mask) [+ x*mask];  x <- k0*(x - k1*P)  |  x <- k0*(k1*x + k2*P);  [+ k3*z]
  * followed by the fix-mask blend (diffusionsde.py:592). */
 typedef struct cdx_step {
-    int32_t kind;        /* 0 ddpm, 1 ddim, 2 linear */
+    int32_t kind;        /* 0 ddpm, 1 ddim, 2 linear, 3 legacy-ddpm eps, 4 legacy-ddpm x0 */
     int32_t vsel;        /* kind 2: 0 eps, 1 x_theta, 2 multistep D */
     int32_t noise_idx;   /* index into `noise` of this step's N(0,I) draw, or -1 */
     int32_t push;        /* 1: remember x_theta for the next multistep update */

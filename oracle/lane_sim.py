@@ -74,11 +74,14 @@ class LaneSim:
             if kind == P.OP_LOAD_TEMB:
                 n, dst = op[P.L_NIN], op[P.L_DST]
                 v = np.asarray(temb_row, np.float32).copy()
-                if cond_row is not None and not self.p.tile:
+                if cond_row is not None and not self.p.tile and not self.p.cond_dim:
                     v = v + cond_row
                 self.lds[dst:dst + n] = v
             elif kind == P.OP_LINEAR:
                 self._linear(op)
+            elif kind == P.OP_LOAD_COND:
+                n, dst = op[P.L_NIN], op[P.L_DST]
+                self.lds[dst:dst + n] = cond_row if cond_row is not None else 0.0
             elif kind == P.OP_FILL:
                 n, rows, src, dst, sstr, coff = (op[P.L_NIN], op[P.L_NOUT], op[P.L_SRC], op[P.L_DST], op[P.L_WOFF],
                                                  op[P.L_BOFF])
@@ -215,6 +218,9 @@ class LaneSim:
         v = activation(v, act_id)
         if flags & P.F_ADD_EMB:
             v = v + lds[op[P.W_EMB]:op[P.W_EMB] + c_out][None, :]
+        if flags & P.F_FILM:
+            e = lds[op[P.W_EMB]:op[P.W_EMB] + 2 * c_out]
+            v = v * e[None, :c_out] + e[None, c_out:]
         if flags & P.F_ADD_RES:
             v = v + self.read_slot(op[P.W_RES], op[P.W_RES_STRIDE], l_out, c_out)
         if flags & P.F_SCALE:

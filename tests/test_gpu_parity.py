@@ -80,7 +80,7 @@ def test_backbone_forward_matches_reference(name, amd_lib, monkeypatch):
     np.testing.assert_allclose(pred.cpu().numpy(), gold["pred0"], **TOL)
 
 
-FUSED_CASES = [n for n, c in cases.CASES.items() if c["net"][0] in ("JannerUNet1d", "PearceMlp", "DQLMlp")]
+FUSED_CASES = [n for n, c in cases.CASES.items() if c["net"][0] in ("JannerUNet1d", "PearceMlp", "DQLMlp", "ChiUNet1d")]
 TORCH_EXECUTOR_CASES = [n for n in cases.CASES if n not in FUSED_CASES]
 
 
@@ -185,3 +185,18 @@ def test_candidate_argmax_matches_cpu_at_diffuser_batch(amd_lib):
     assert torch.equal(lp_g.argmax(0), lp_c.argmax(0))
     top2 = lp_c.topk(2, dim=0).values
     assert float((top2[0] - top2[1]).min()) > 1e-4, "test inputs must not contain near-ties"
+
+
+def test_chiunet_forward_one_launch(amd_lib, monkeypatch):
+    """ChiUNet1d.forward (FiLM blocks, global condition) served by the program kernel with per-sample timesteps."""
+    agent, _ = cases.build(amd_lib, "chiunet_cfg3_legacy_ddpm", device=DEV)
+    cpu_agent, _ = cases.build(amd_lib, "chiunet_cfg3_legacy_ddpm", device="cpu")
+    g = torch.Generator().manual_seed(2)
+    x, c = torch.randn(5, 16, 2, generator=g), torch.randn(5, 2, 20, generator=g)
+    t = torch.tensor([0, 3, 9, 5, 1])
+    calls = _spy_launches(monkeypatch)
+    with torch.no_grad():
+        y = agent.model_ema["diffusion"](x.to(DEV), t.to(DEV), c.to(DEV))
+        y_ref = cpu_agent.model_ema["diffusion"](x, t, c)
+    assert calls["n"] == 1
+    np.testing.assert_allclose(y.cpu().numpy(), y_ref.numpy(), **TOL)

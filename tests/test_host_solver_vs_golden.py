@@ -55,3 +55,22 @@ def test_bad_solver_and_schedule_raise(amd_lib):
         agent.sample(prior, solver="ddim", n_samples=2, sample_step_schedule="nope")
     with pytest.raises(ValueError):
         amd_lib.DiscreteDiffusionSDE(amd_lib.JannerUNet1d(6, 16, 16, 3, [1, 2]), diffusion_steps=2000)
+
+
+@pytest.mark.parametrize("predict_noise", [True, False])
+def test_legacy_ddpm_plan_matches_posterior_step(predict_noise, amd_lib):
+    """engine/plan.py's legacy records reproduce DDPM._posterior_step (the arithmetic the device applies)."""
+    from cleandiffuser_amd.engine import plan as PL
+    net = amd_lib.DQLMlp(3, 2)
+    agent = amd_lib.DDPM(net, diffusion_steps=7, predict_noise=predict_noise)
+    plan = PL.build_legacy_ddpm_plan(agent.beta, agent.alpha, agent.bar_alpha, predict_noise, extra_sample_steps=2)
+    assert [s.t for s in plan.steps] == [6, 5, 4, 3, 2, 1, 0, 0, 0]
+    assert [s.noise for s in plan.steps] == [True] * 6 + [False] * 3
+    g = torch.Generator().manual_seed(0)
+    x, p = torch.randn(4, 2, generator=g), torch.randn(4, 2, generator=g)
+    for st in plan.steps[:7]:
+        mean, std = agent._posterior_step(x, p, st.t)
+        k0, k1, k2, k3, _ = st.k
+        mine = k0 * (x - k1 * p) if predict_noise else k0 * (k1 * x + k2 * p)
+        assert torch.allclose(mine, mean, rtol=1e-6, atol=1e-6)
+        assert abs(float(std) - k3) < 1e-7

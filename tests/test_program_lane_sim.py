@@ -97,3 +97,26 @@ def test_lane_sim_reproduces_mlp_tile_programs(kind, amd_lib):
     sim = LaneSim(prog)
     sim.load_x(x.numpy(), cond.flatten(1).numpy())
     np.testing.assert_allclose(sim.run_forward(temb), ref, rtol=2e-5, atol=2e-5)
+
+
+def test_lane_sim_reproduces_chiunet_forward(amd_lib):
+    """ChiUNet1d program: FiLM (scale, bias) epilogue, just-in-time per-block FiLM vectors, raw condition load."""
+    from cleandiffuser_amd.utils import load_synth
+    net = load_synth(amd_lib.ChiUNet1d(2, 20, 2, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2])).eval()
+    prog = P.compile_chiunet(net, 16)
+    g = torch.Generator().manual_seed(1)
+    x, c, t = torch.randn(2, 16, 2, generator=g), torch.randn(2, 2, 20, generator=g), torch.tensor([3, 7])
+    with torch.no_grad():
+        ref, temb = net(x, t, c).numpy(), net.map_noise(t).numpy()
+    for b in range(2):
+        sim = LaneSim(prog)
+        sim.load_x(x[b].numpy())
+        np.testing.assert_allclose(sim.run_forward(temb[b], c[b].flatten().numpy()), ref[b], rtol=2e-5, atol=2e-5)
+
+
+def test_config3_program_fits_one_workgroup(amd_lib):
+    """BASELINE config 3 (68.9 M parameters, 298.4 M MAC per forward) compiles into <= 160 KiB of LDS."""
+    net = amd_lib.ChiUNet1d(2, 20, 2, model_dim=256, emb_dim=256, dim_mult=[1, 2, 2])
+    prog = P.compile_chiunet(net, 16)
+    assert prog.lds_floats * 4 <= 160 * 1024
+    assert abs(prog.macs_per_forward - 298.4e6) / 298.4e6 < 0.01
