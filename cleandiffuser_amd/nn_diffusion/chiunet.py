@@ -2,9 +2,11 @@
 nn_diffusion/chiunet.py:13-192).  ``state_dict`` keys match (``downs.{i}.{0,1}.{conv1,conv2,cond_encoder.1,residual_conv}``,
 ``mids.{0,1}``, ``ups``, ``global_cond_encoder`` / ``local_cond_encoder``, ``final_conv``).
 
-Status: parameter container + PyTorch execution.  At config-3 size (68.9 M parameters, 276 MB > the 256 MiB Infinity
-Cache) one-workgroup-per-trajectory weight streaming is not the right shape; the gfx950 path for this backbone is a
-batch-tiled implicit-GEMM and is scheduled after the JannerUNet1d path.
+Execution: this nn.Module is the parameter container and the PyTorch (CPU / autograd / local-conditioning) path.  With
+``obs_as_global_cond=True`` on a ROCm device the forward -- and, through ``DDPM.sample`` / ``DiscreteDiffusionSDE.sample``,
+the whole denoising loop -- runs in the fused program kernel (engine/program.py:compile_chiunet): FiLM is an epilogue of
+the first conv of each block, the block's FiLM vector is computed just in time, config 3 (68.9 M parameters) fits 152 KiB
+of LDS per trajectory.
 """
 from typing import List, Optional
 
@@ -85,6 +87,10 @@ class ChiUNet1d(BaseNNDiffusion):
     def forward(self, x: torch.Tensor, noise: torch.Tensor, condition: Optional[torch.Tensor] = None):
         """x (b, Ta, act_dim), noise (b,), condition (b, To, obs_dim) [required, SURVEY Q12] -> (b, Ta, act_dim)."""
         assert x.shape[1] & (x.shape[1] - 1) == 0, "Ta dimension must be 2^n"
+        from ..engine import dispatch
+        y = dispatch.try_backbone_forward(self, x, noise, condition)      # one fused launch on a ROCm device
+        if y is not None:
+            return y
         x = x.permute(0, 2, 1)
         emb = self.map_emb(self.map_noise(noise))
         local = None

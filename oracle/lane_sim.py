@@ -232,4 +232,9 @@ class LaneSim:
                 lds[base:base + c_out] += v[n]
             else:
                 lds[base:base + c_out] = v[n]
-        assert np.isfinite(lds[dst:dst + drows * dstride]).all(), "NaN reached a destination slot"
+        if flags & P.F_KEEP_DST:                           # partial write into a longer-lived slot: check what was written
+            for n in range(l_out):
+                base = dst + (n + P.HALO) * dstride + coff
+                assert np.isfinite(lds[base:base + c_out]).all(), "NaN reached a destination slot"
+        else:
+            assert np.isfinite(lds[dst:dst + drows * dstride]).all(), "NaN reached a destination slot"
