@@ -169,14 +169,14 @@ struct Prefetch {
 
 template <class M, int NT>
 __device__ __forceinline__ void conv_kloop(const ConvGeom& g, const float* __restrict__ wblob,
-                                           const int* __restrict__ ldsi, int items_at, int n_items,
+                                           const int* __restrict__ items, int n_items,
                                            float* __restrict__ lds, int scratch, int sstride, int lane, int wave,
                                            Prefetch& pre, unsigned long long* prof) {
     constexpr int PF = M::PF;
     static_assert(PF >= CDX_PRE, "ring shallower than the cross-op prefetch");
     const int tid0 = (wave == 0 && lane == 0) ? 0 : 1;       // stamp() fires for tid == 0 only
     for (int item = wave; item < n_items; item += CDX_N_WAVES) {
-        const int iw = ldsi[items_at + item * CDX_ITEM_WORDS + (lane & 7)];   // item record: one ds_read, then SGPRs
+        const int iw = items[item * CDX_ITEM_WORDS + (lane & 7)];   // item record: one (flat) load, then SGPRs
         const int it0 = CDX_RL(iw, CDX_I_WOFF), it1 = CDX_RL(iw, CDX_I_PART), nq = CDX_RL(iw, CDX_I_NQ);
         const int it3 = CDX_RL(iw, CDX_I_ONB), it4 = CDX_RL(iw, CDX_I_TAP), it5 = CDX_RL(iw, CDX_I_CC);
         if (prof && item == 0) { asm volatile("" ::"s"(nq)); stamp(prof + 4, tid0); }
@@ -275,7 +275,7 @@ __device__ __forceinline__ int div_small(int e, int d, float inv_d) {
 // FULL = false compiles the lean U-Net instance (Mish only, no per-column norm / fill ops): the kernel is
 // instruction-cache sensitive, so the MLP-tile features live in a second instantiation.
 template <bool FULL>
-__device__ __forceinline__ void conv_op(const int w, const int wn, const int* __restrict__ ldsi, int desc_off,
+__device__ __forceinline__ void conv_op(const int w, const int wn, const int* __restrict__ itab,
                         const float* __restrict__ wblob, float* __restrict__ lds,
                         int scratch, int zrow, int pred_branch_off, int tid, Prefetch& pre,
                         unsigned long long* prof) {
@@ -302,17 +302,17 @@ __device__ __forceinline__ void conv_op(const int w, const int wn, const int* __
     }
 
     // 2. implicit-GEMM K loop -> split-K partials in scratch
-    const int items_at = desc_off + CDX_RL(w, CDX_W_ITEMS);
+    const int* __restrict__ items = itab + CDX_RL(w, CDX_W_ITEMS);
     const int n_items = CDX_RL(w, CDX_W_NITEMS);
     if (CDX_RL(w, CDX_W_MODE) == CDX_MODE_4X4) {
-        if (l_out <= 4) conv_kloop<M4, 1>(g, wblob, ldsi, items_at, n_items, lds, scratch, sstride, lane, wave, pre, prof);
-        else conv_kloop<M4, 2>(g, wblob, ldsi, items_at, n_items, lds, scratch, sstride, lane, wave, pre, prof);
+        if (l_out <= 4) conv_kloop<M4, 1>(g, wblob, items, n_items, lds, scratch, sstride, lane, wave, pre, prof);
+        else conv_kloop<M4, 2>(g, wblob, items, n_items, lds, scratch, sstride, lane, wave, pre, prof);
     } else {
-        if (l_out <= 16) conv_kloop<M16, 1>(g, wblob, ldsi, items_at, n_items, lds, scratch, sstride, lane, wave, pre, prof);
+        if (l_out <= 16) conv_kloop<M16, 1>(g, wblob, items, n_items, lds, scratch, sstride, lane, wave, pre, prof);
         else {
             // 32 positions per pass; longer horizons re-stream the weights once per extra pass (rare: H = 64)
             for (g.col0 = 0; g.col0 < l_out; g.col0 += 32) {
-                conv_kloop<M16, 2>(g, wblob, ldsi, items_at, n_items, lds, scratch, sstride, lane, wave, pre, prof);
+                conv_kloop<M16, 2>(g, wblob, items, n_items, lds, scratch, sstride, lane, wave, pre, prof);
                 pre.ok = 0;
             }
         }
@@ -322,7 +322,7 @@ __device__ __forceinline__ void conv_op(const int w, const int wn, const int* __
     //     the loads fly through the barrier and the epilogue below.
     pre.ok = 0;
     if (CDX_RL(wn, CDX_W_KIND) == CDX_OP_CONV && wave < CDX_RL(wn, CDX_W_NITEMS)) {
-        const int iw = ldsi[desc_off + CDX_RL(wn, CDX_W_ITEMS) + wave * CDX_ITEM_WORDS + (lane & 7)];
+        const int iw = itab[CDX_RL(wn, CDX_W_ITEMS) + wave * CDX_ITEM_WORDS + (lane & 7)];
         const int nq = CDX_RL(iw, CDX_I_NQ);
         const f32x4* wp = reinterpret_cast<const f32x4*>(wblob + CDX_RL(iw, CDX_I_WOFF)) + lane;
 #pragma unroll
@@ -500,6 +500,9 @@ __device__ __forceinline__ void run_program(const cdx_unet1d_launch& L, float* _
     const int* __restrict__ ldsi = reinterpret_cast<const int*>(lds);
     const int lane = tid & 63;
     const int dlane = lane < CDX_OP_WORDS ? lane : 0;
+    // work-item tables: in LDS behind the ops when they fit, else read from the global copy (large programs: the
+    // ~1 us per item is noise next to their K loops).  Generic pointer -> flat loads either way.
+    const int* __restrict__ itab = L.items_in_lds ? ldsi + L.desc_off : L.ops;
     int wn = ldsi[L.desc_off + dlane];                       // descriptor of op 0, one word per lane
     for (int oi = 0; oi < L.n_ops; ++oi) {
         const int w = wn;
@@ -511,7 +514,7 @@ __device__ __forceinline__ void run_program(const cdx_unet1d_launch& L, float* _
         unsigned long long* pslot = profiling ? lprof + (size_t)oi * 8 : nullptr;
         stamp(pslot, tid);
         if (kind == CDX_OP_CONV) {
-            conv_op<FULL>(w, oi + 1 < L.n_ops ? wn : 0, ldsi, L.desc_off, L.wblob, lds, L.scratch_off, L.zrow_off,
+            conv_op<FULL>(w, oi + 1 < L.n_ops ? wn : 0, itab, L.wblob, lds, L.scratch_off, L.zrow_off,
                           branch * L.pred_branch_floats, tid, pre, pslot);
         } else if (kind == CDX_OP_LINEAR) {
             const int n_in = op[CDX_L_NIN], n_out = op[CDX_L_NOUT];

@@ -122,6 +122,8 @@ class Program:
     emb_dim: int
     macs_per_forward: int              # algorithmic MACs (conv + linear), for the roofline accounting
     n_conv: int = 0
+    desc_words: int = 0                # how many words of ops_buffer the kernel copies into LDS
+    items_in_lds: bool = True          # False: only the ops are copied, item tables are read from the global buffer
     out_vec_off: int = 0               # vector-output programs (classifier heads): where the result lives
     out_vec_len: int = 0
     tile: int = 0                      # > 0: batch-tiled MLP program, `horizon` = samples per workgroup
@@ -450,14 +452,19 @@ def _finalize(b: "_Builder", net, x: Act, pred: Optional[Act], horizon: int, d: 
         a.off, off = off, off + a.floats
     # shared zero row: what a conv tap outside [0, L) reads (and columns past l_out); sized for the widest source
     zrow_off = off
-    zrow_floats = max(pad16(a.chans) for a in b.acts) + 16
+    sources = [a for reads, _ in b.op_acts for a in reads]
+    zrow_floats = max(pad16(a.chans) for a in sources) + 16
     off += zrow_floats
     prev_off, off = off, off + (horizon * d + 3) // 4 * 4
     vec_off, off = off, off + b.vec_len
     for a, rel in vec_alias:                              # 1-row slots that ARE vectors (Linear lowered as a 1-position conv)
         a.off = vec_off + rel
     scratch_off, off = off, off + (b.scratch + 3) // 4 * 4
-    desc_words = len(b.ops) * OP_WORDS + sum(len(it) * ITEM_WORDS for it in b.op_items if it)
+    op_words = len(b.ops) * OP_WORDS
+    all_words = op_words + sum(len(it) * ITEM_WORDS for it in b.op_items if it)
+    # the item tables ride in LDS with the ops unless that would blow the budget (big programs keep them in HBM)
+    items_in_lds = all_words <= 6144
+    desc_words = all_words if items_in_lds else op_words
     desc_off, off = off, off + (desc_words + 3) // 4 * 4
     prof_off, off = off, off + (2 * (len(b.ops) * 8 + 2) + 3) // 4 * 4
     top = b.plan_lds({"arena": off})
@@ -487,11 +494,12 @@ def _finalize(b: "_Builder", net, x: Act, pred: Optional[Act], horizon: int, d: 
             op[W_EMB] += vec_off
     blob = torch.cat(b.chunks) if b.chunks else torch.zeros(0, device=dev)
     ops_buffer = np.concatenate([ops.reshape(-1), np.asarray(tail, dtype=np.int64).astype(np.int32)])
-    assert ops_buffer.size == desc_words
+    assert ops_buffer.size == all_words
     return Program(ops=ops, ops_buffer=ops_buffer, blob=blob.contiguous(), lds_floats=top, x_off=x.off,
                    x_stride=x.stride, pred_off=pred_off, pred_stride=pred_stride, pred_branch_floats=pred_branch,
                    prev_off=prev_off, vec_off=vec_off, scratch_off=scratch_off, scratch_floats=b.scratch,
-                   desc_off=desc_off, prof_off=prof_off, horizon=horizon, dim=d,
+                   desc_off=desc_off, desc_words=desc_words, items_in_lds=items_in_lds, prof_off=prof_off,
+                   horizon=horizon, dim=d,
                    emb_dim=net.emb_dim if emb_dim is None else emb_dim, tile=tile,
                    cond_slot_off=cond_slot[0].off if cond_slot else 0,
                    cond_slot_stride=cond_slot[0].stride if cond_slot else 0,

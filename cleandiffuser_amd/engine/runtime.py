@@ -36,7 +36,8 @@ class CdxUnet1dLaunch(ctypes.Structure):
         ("tile", ctypes.c_int32), ("cond_slot_off", ctypes.c_int32), ("cond_slot_stride", ctypes.c_int32),
         ("cond_coff", ctypes.c_int32), ("cond_dim", ctypes.c_int32),
         ("zero_off", ctypes.c_int32), ("zero_floats", ctypes.c_int32), ("zrow_off", ctypes.c_int32),
-        ("prof_off", ctypes.c_int32), ("desc_off", ctypes.c_int32), ("desc_words", ctypes.c_int32),
+        ("prof_off", ctypes.c_int32), ("items_in_lds", ctypes.c_int32), ("desc_off", ctypes.c_int32),
+        ("desc_words", ctypes.c_int32),
         ("batch", ctypes.c_int32), ("horizon", ctypes.c_int32), ("dim", ctypes.c_int32), ("emb_dim", ctypes.c_int32),
         ("temb", ctypes.c_void_p), ("steps", ctypes.c_void_p),
         ("n_steps", ctypes.c_int32), ("temb_per_sample", ctypes.c_int32), ("predict_noise", ctypes.c_int32),
@@ -237,7 +238,8 @@ def _launch(comp: _Compiled, *, batch, x_in, x_out, temb, steps_dev=None, n_step
         out_vec_off=prog.out_vec_off, out_vec_len=prog.out_vec_len,
         tile=prog.tile, cond_slot_off=prog.cond_slot_off, cond_slot_stride=prog.cond_slot_stride,
         cond_coff=prog.cond_coff, cond_dim=prog.cond_dim, zero_off=prog.zero_off, zero_floats=prog.zero_floats, zrow_off=prog.zrow_off,
-        prof_off=prog.prof_off, desc_off=prog.desc_off, desc_words=int(prog.ops_buffer.size),
+        prof_off=prog.prof_off, items_in_lds=int(prog.items_in_lds), desc_off=prog.desc_off,
+        desc_words=prog.desc_words,
         batch=batch, horizon=prog.horizon, dim=prog.dim, emb_dim=prog.emb_dim,
         temb=temb.data_ptr(), steps=_ptr(steps_dev), n_steps=n_steps, temb_per_sample=temb_per_sample,
         predict_noise=int(predict_noise), cfg_mode=cfg_mode, cfg_w=float(cfg_w), cond=_ptr(cond),

@@ -67,6 +67,7 @@ typedef struct cdx_unet1d_launch {
     int32_t zero_off, zero_floats;    /* extra kernel-lifetime LDS range cleared once at kernel start */
     int32_t zrow_off;                 /* shared all-zero row inside that range: what out-of-range conv taps read */
     int32_t prof_off;             /* LDS float offset (even) of the (n_ops*8+2) x u64 stamp area; used only if prof != NULL */
+    int32_t items_in_lds;         /* 1: desc_words covers ops + item tables; 0: ops only, items are read from `ops` */
     int32_t desc_off, desc_words; /* where the kernel keeps its copy of `ops` in LDS, and how many words it is */
     /* problem */
     int32_t batch, horizon, dim, emb_dim;
