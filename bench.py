@@ -61,14 +61,26 @@ def cpu_baseline(net, budget_s=12.0):
     prior, z0 = make_inputs("cpu", 0)
     fm = torch.zeros(1, HORIZON, DIM)
     fm[0, 0, :17] = 1.0
-    cores = torch.get_num_threads()          # torch's own default = the cores this process may use
+    avail = torch.get_num_threads()           # torch's own default = the cores this process may use
 
     def call():
         with torch.no_grad():
             return torch_port.vp_sample(fwd, prior, [z0], solver="ddim", sample_steps=SAMPLE_STEPS, discrete=True,
                                         diffusion_steps=SAMPLE_STEPS, temperature=0.5, predict_noise=False,
                                         fix_mask=fm)
-    call()                                     # warm-up (thread pool, oneDNN primitives)
+    # the reference path is small-op bound: all cores of a big host oversubscribe it, so probe a few thread counts
+    # (one timed call each) and run the bounded sample at the fastest -- `cores` reports what was actually used
+    best, cores = None, avail
+    for th in sorted({t for t in (8, 16, 32, 64, avail) if t <= avail}):
+        torch.set_num_threads(th)
+        call()                                 # warm-up (thread pool, oneDNN primitives)
+        t0 = time.perf_counter()
+        call()
+        dt = time.perf_counter() - t0
+        if best is None or dt < best:
+            best, cores = dt, th
+    torch.set_num_threads(cores)
+    call()
     t0, n = time.perf_counter(), 0
     while n < 2 or time.perf_counter() - t0 < budget_s:
         call()
@@ -76,10 +88,10 @@ def cpu_baseline(net, budget_s=12.0):
     dt = time.perf_counter() - t0
     return {"value": BATCH * n / dt, "unit": "trajectories/s", "cores": cores, "kind": "port",
             "sample": f"{n} full sample() calls of B={BATCH} (20-step DDIM) through oracle/torch_port.py, "
-                      f"{dt:.1f}s wall, torch {torch.__version__} CPU, {cores} threads"}
+                      f"{dt:.1f}s wall, torch {torch.__version__} CPU, {cores} of {avail} threads (fastest of a probe)"}
 
 
-def cpu_baseline_subprocess(timeout_s=120):
+def cpu_baseline_subprocess(timeout_s=180):
     """Run the CPU leg in a child with a hard wall-clock bound so the GPU line is never held hostage."""
     import subprocess
     try:

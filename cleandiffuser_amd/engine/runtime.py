@@ -227,7 +227,13 @@ def set_profile_buffer(buf: Optional[torch.Tensor]):
     _prof["buf"] = buf
 
 
-def _launch(comp: _Compiled, *, batch, x_in, x_out, temb, steps_dev=None, n_steps=0, temb_per_sample=0,
+def _launch(comp: _Compiled, **kw):
+    if kw["batch"] <= 0:                       # empty request: nothing to launch, outputs are already empty tensors
+        return
+    _launch_nonempty(comp, **kw)
+
+
+def _launch_nonempty(comp: _Compiled, *, batch, x_in, x_out, temb, steps_dev=None, n_steps=0, temb_per_sample=0,
             predict_noise=0, cfg_mode=0, cfg_w=0.0, cond=None, prior=None, fix_mask=None, noise=None,
             x_min=None, x_max=None):
     prog = comp.prog

@@ -59,6 +59,13 @@ CASES = {
         sample=dict(solver="sde_dpmsolver++_2M", sample_steps=6, sample_step_schedule="quad_continuous",
                     temperature=0.7, diffusion_x_sampling_steps=2)),
 }
+# long horizon (64 positions = two 32-column passes of the 16x16 K loop) and a single trajectory (grid of one workgroup)
+CASES["janner_h64_single"] = dict(
+    net=("JannerUNet1d", dict(in_dim=5, model_dim=16, emb_dim=16, dim_mult=[1, 2, 2], kernel_size=5)),
+    horizon=64, batch=1, fix_obs=3,
+    solver=("DiscreteDiffusionSDE", dict(diffusion_steps=10, predict_noise=False)),
+    sample=dict(solver="ddim", sample_steps=4, temperature=0.9))
+
 # ---- the other BASELINE configs at fixture size (PyTorch executor today; fused paths are later rows) ----
 CASES.update({
     # config 1: PearceMlp DBC, DDPM 100 -> 20 steps here, x-prediction with clip, w_cfg = 1, PearceObsCondition

@@ -49,7 +49,7 @@ def test_mfma_lane_maps_on_silicon():
 
 
 FWD_CASES = ["janner_cfg2_ddim", "janner_h4_ddpm", "janner_tiny_disc_ddim", "janner_tiny_cond_w1",
-             "janner_tiny_cont_ddim"]
+             "janner_tiny_cont_ddim", "janner_h64_single"]
 
 
 @pytest.mark.parametrize("name", FWD_CASES)
@@ -200,3 +200,27 @@ def test_chiunet_forward_one_launch(amd_lib, monkeypatch):
         y_ref = cpu_agent.model_ema["diffusion"](x, t, c)
     assert calls["n"] == 1
     np.testing.assert_allclose(y.cpu().numpy(), y_ref.numpy(), **TOL)
+
+
+def test_empty_and_ragged_batches(amd_lib):
+    """Edge cases of the boundary: an empty request returns an empty tensor without launching; batch sizes that do
+    not fill the last wave of workgroups / the last MLP tile (1, 257, 17) give the same rows as a larger batch."""
+    agent, _ = cases.build(amd_lib, "janner_tiny_disc_ddim", device=DEV)
+    kw = dict(solver="ddim", sample_steps=5, temperature=0.8)
+    x, _ = agent.sample(torch.zeros(0, 8, 6, device=DEV), n_samples=0, **kw)
+    assert x.shape == (0, 8, 6)
+    g = torch.Generator().manual_seed(9)
+    z = torch.randn(257, 8, 6, generator=g)
+    prior = torch.zeros(257, 8, 6)
+    prior[:, 0, :4] = torch.randn(257, 4, generator=g)
+    big, _ = agent.sample(prior.to(DEV), n_samples=257, noise=[z], **kw)
+    one, _ = agent.sample(prior[256:].to(DEV), n_samples=1, noise=[z[256:]], **kw)
+    assert torch.equal(big[256:], one)
+    magent, _ = cases.build(amd_lib, "dqlmlp_ddpm", device=DEV)
+    obs = torch.randn(17, 17, generator=g)
+    zs = [torch.randn(17, 6, generator=g) for _ in range(5)]
+    mk = dict(solver="ddpm", sample_steps=5, w_cfg=1.0)
+    m17, _ = magent.sample(torch.zeros(17, 6, device=DEV), n_samples=17, condition_cfg=obs.to(DEV), noise=zs, **mk)
+    m3, _ = magent.sample(torch.zeros(3, 6, device=DEV), n_samples=3, condition_cfg=obs[14:].to(DEV),
+                          noise=[q[14:] for q in zs], **mk)
+    assert torch.equal(m17[14:], m3)

@@ -22,7 +22,7 @@ def _first_forward_inputs(name, agent):
 
 
 @pytest.mark.parametrize("name", ["janner_cfg2_ddim", "janner_h4_ddpm", "janner_tiny_disc_ddim",
-                                  "janner_tiny_cond_w1", "janner_tiny_cont_ddim"])
+                                  "janner_tiny_cond_w1", "janner_tiny_cont_ddim", "janner_h64_single"])
 def test_lane_sim_reproduces_reference_forward(name, amd_lib):
     gold = np.load(golden_path(name))
     agent, net = cases.build(amd_lib, name)
