@@ -1,0 +1,315 @@
+// cdx_gemm.hip -- batched fp32 "Linear" GEMM for the big-batch denoisers (DiT1d, wide MLPs) on gfx950.
+//
+//   C[m][n] = epilogue( sum_k A[m][k] * W[n][k] + bias[n] )        A: (M, K) row-major, W: (N, K) row-major
+//
+// i.e. exactly ``torch.nn.functional.linear(A, W, bias)`` with the PyTorch weight layout, so the reference
+// checkpoints' tensors are used in place (no packing).  These layers are the hot ops of
+// cleandiffuser/nn_diffusion/dit.py:31-36,49 and idqlmlp.py:12-18 when the batch is large (M = batch x tokens >> 256):
+// there the right shape is a classic tiled GEMM, not the one-workgroup-per-trajectory program kernel.
+//
+// Kernel: 128 x 128 x 16 block tile, 4 wave64, each wave a 64 x 64 sub-tile as 2 x 2 v_mfma_f32_32x32x2_f32 (exact fp32,
+// fmaf-chain numerics).  A and W tiles are fetched K-contiguous (float4 per lane), transposed through LDS into
+// [k][row] so MFMA operand reads are conflict-free ds_read_b32, next tile prefetched into registers under the MFMAs.
+// Epilogue (fused, per element): + bias[n] -> activation -> * gate[m / rows_per_gate][n] -> + residual[m][n]
+// -> + table[m % table_rows][n]  (adaLN gates, residual streams and the positional table of DiT never take a pass of
+// their own).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/cdx.h"
+#include "cdx_ops.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define GM_BM 128
+#define GM_BN 128
+#define GM_BK 16
+#define GM_LD (GM_BM + 4)
+#define GM_THREADS 256
+
+extern void cdx_set_err(const char* msg);
+
+__device__ __forceinline__ float gm_act(float x, int act) {
+    switch (act) {
+        case CDX_ACT_MISH: {
+            const float e = __expf(fminf(x, 20.0f));
+            const float n = e * (e + 2.0f);
+            return x > 20.0f ? x : x * n * __builtin_amdgcn_rcpf(n + 2.0f);
+        }
+        case CDX_ACT_GELU_ERF: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+        case CDX_ACT_LEAKY: return x > 0.f ? x : 0.01f * x;
+        case CDX_ACT_SILU: return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+        case CDX_ACT_RELU: return fmaxf(x, 0.f);
+        case CDX_ACT_GELU_TANH: return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+        default: return x;
+    }
+}
+
+// load 4 consecutive K values of one row (zero beyond the matrix edge)
+template <bool VEC>
+__device__ __forceinline__ float4 gm_load4(const float* __restrict__ base, int row, int rows, int k, int K, int ld) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < rows) {
+        const float* p = base + (size_t)row * ld + k;
+        if (VEC) {
+            if (k + 3 < K) v = *reinterpret_cast<const float4*>(p);
+            else {
+                if (k < K) v.x = p[0];
+                if (k + 1 < K) v.y = p[1];
+                if (k + 2 < K) v.z = p[2];
+            }
+        } else {
+            if (k < K) v.x = p[0];
+            if (k + 1 < K) v.y = p[1];
+            if (k + 2 < K) v.z = p[2];
+            if (k + 3 < K) v.w = p[3];
+        }
+    }
+    return v;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(GM_THREADS) void cdx_gemm_kernel(const cdx_gemm_args g) {
+    __shared__ __attribute__((aligned(16))) float As[GM_BK][GM_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[GM_BK][GM_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // column-major walk over tiles: consecutive workgroups share the W panel (small N) and stream A
+    const int tiles_m = (g.M + GM_BM - 1) / GM_BM;
+    const int bm = (blockIdx.x % tiles_m) * GM_BM, bn = (blockIdx.x / tiles_m) * GM_BN;
+    const int lrow = tid & 127, kq = tid >> 7;          // this thread stages row `lrow`, k quads kq and kq + 2
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra0 = gm_load4<VEC>(g.A, bm + lrow, g.M, kq * 4, g.K, g.lda);
+    float4 ra1 = gm_load4<VEC>(g.A, bm + lrow, g.M, 8 + kq * 4, g.K, g.lda);
+    float4 rb0 = gm_load4<VEC>(g.W, bn + lrow, g.N, kq * 4, g.K, g.ldw);
+    float4 rb1 = gm_load4<VEC>(g.W, bn + lrow, g.N, 8 + kq * 4, g.K, g.ldw);
+
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int lr = lane & 31, lk = lane >> 5;
+    for (int k0 = 0; k0 < g.K; k0 += GM_BK) {
+        __syncthreads();                                 // previous tile fully consumed
+        {
+            const int ka = kq * 4, kb = 8 + kq * 4;
+            As[ka + 0][lrow] = ra0.x; As[ka + 1][lrow] = ra0.y; As[ka + 2][lrow] = ra0.z; As[ka + 3][lrow] = ra0.w;
+            As[kb + 0][lrow] = ra1.x; As[kb + 1][lrow] = ra1.y; As[kb + 2][lrow] = ra1.z; As[kb + 3][lrow] = ra1.w;
+            Bs[ka + 0][lrow] = rb0.x; Bs[ka + 1][lrow] = rb0.y; Bs[ka + 2][lrow] = rb0.z; Bs[ka + 3][lrow] = rb0.w;
+            Bs[kb + 0][lrow] = rb1.x; Bs[kb + 1][lrow] = rb1.y; Bs[kb + 2][lrow] = rb1.z; Bs[kb + 3][lrow] = rb1.w;
+        }
+        __syncthreads();
+        const int kn = k0 + GM_BK;                       // prefetch the next tile under this tile's MFMAs
+        if (kn < g.K) {
+            ra0 = gm_load4<VEC>(g.A, bm + lrow, g.M, kn + kq * 4, g.K, g.lda);
+            ra1 = gm_load4<VEC>(g.A, bm + lrow, g.M, kn + 8 + kq * 4, g.K, g.lda);
+            rb0 = gm_load4<VEC>(g.W, bn + lrow, g.N, kn + kq * 4, g.K, g.ldw);
+            rb1 = gm_load4<VEC>(g.W, bn + lrow, g.N, kn + 8 + kq * 4, g.K, g.ldw);
+        }
+#pragma unroll
+        for (int kk = 0; kk < GM_BK; kk += 2) {
+            const float a0 = As[kk + lk][wm + lr], a1 = As[kk + lk][wm + 32 + lr];
+            const float b0 = Bs[kk + lk][wn + lr], b1 = Bs[kk + lk][wn + 32 + lr];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+
+    // epilogue: D fragment of 32x32x2 -- col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int n = bn + wn + ni * 32 + lr;
+            if (n >= g.N) continue;
+            const float bias = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = bm + wm + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (m >= g.M) continue;
+                float v = gm_act(acc[mi][ni][r] + bias, g.act);
+                if (g.gate) v *= g.gate[(size_t)(m / g.rows_per_gate) * g.ldg + n];
+                if (g.residual) v += g.residual[(size_t)m * g.ldr + n];
+                if (g.table) v += g.table[(size_t)(m % g.table_rows) * g.N + n];
+                g.C[(size_t)m * g.ldc + n] = v;
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row LayerNorm (no affine, eps) + adaLN modulation:  y[m][c] = LN(x[m])[c] * (1 + scale[b][c]) + shift[b][c]
+// (reference dit.py:10-11, 33-35, 48); b = m / rows_per_mod.  With gamma/beta instead of shift/scale it is a plain
+// affine LayerNorm (idqlmlp.py:14).  One wave per row, values in registers, DPP-free shuffles (memory-bound op).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cdx_layernorm_kernel(const cdx_ln_args a) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.M) return;
+    const float* x = a.x + (size_t)row * a.ldx;
+    float v[16];                                        // C <= 1024
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int c = lane + 64 * t;
+        v[t] = c < a.C ? x[c] : 0.f;
+        s += v[t];
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)a.C;
+    float s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const float d = (lane + 64 * t < a.C) ? v[t] - mean : 0.f;
+        v[t] = d;
+        s2 += d * d;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+    const float rstd = 1.0f / sqrtf(s2 / (float)a.C + a.eps);
+    const int b = row / a.rows_per_mod;
+    float* y = a.y + (size_t)row * a.ldy;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int c = lane + 64 * t;
+        if (c < a.C) {
+            float o = v[t] * rstd;
+            if (a.gamma) o = o * a.gamma[c] + a.beta[c];
+            if (a.scale) o = o * (1.0f + a.scale[(size_t)b * a.ldmod + c]) + a.shift[(size_t)b * a.ldmod + c];
+            y[c] = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Multi-head self-attention over short sequences (T <= 64 tokens, head_dim <= 64), full softmax, no mask
+// (reference dit.py:20,34 = nn.MultiheadAttention(batch_first) core: softmax(q k^T / sqrt(d_h)) v).
+// qkv: (B*T, 3*d_model) as produced by in_proj (q | k | v, heads contiguous inside each third).
+// One workgroup per (batch, head): K and V of the head in LDS, one thread per query row.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void cdx_attention_kernel(const cdx_attn_args a) {
+    __shared__ float Qs[64][65];
+    __shared__ float Ks[64][65];
+    __shared__ float Vs[64][65];
+    const int t = threadIdx.x;
+    const int b = blockIdx.x / a.n_heads, h = blockIdx.x % a.n_heads;
+    const int dh = a.head_dim, dm = a.n_heads * a.head_dim;
+    const size_t row0 = (size_t)b * a.T;
+    for (int i = t; i < a.T * dh; i += 64) {
+        const int tok = i / dh, d = i - tok * dh;
+        const float* base = a.qkv + (row0 + tok) * (size_t)(3 * dm) + h * dh + d;
+        Qs[tok][d] = base[0] * a.scale;
+        Ks[tok][d] = base[dm];
+        Vs[tok][d] = base[2 * dm];
+    }
+    __syncthreads();
+    if (t >= a.T) return;
+    float p[64];                                         // this query's scores; statically indexed -> registers
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) p[j] = 0.f;
+    for (int d = 0; d < dh; ++d) {
+        const float qd = Qs[t][d];
+#pragma unroll
+        for (int j = 0; j < 64; ++j) p[j] = fmaf(qd, Ks[j][d], p[j]);      // Ks[j][d]: same address for all lanes
+    }
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+        p[j] = j < a.T ? p[j] : -3.0e38f;
+        mx = fmaxf(mx, p[j]);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+        p[j] = j < a.T ? expf(p[j] - mx) : 0.f;
+        den += p[j];
+    }
+    const float inv = 1.0f / den;
+    float* op = a.out + (row0 + t) * (size_t)dm + h * dh;
+    for (int d = 0; d < dh; ++d) {
+        float o = 0.f;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) o = fmaf(p[j], Vs[j][d], o);
+        op[d] = o * inv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Elementwise unary map (SiLU / Mish / ...) for the batch-invariant embedding vectors
+// ------------------------------------------------------------------------------------------------
+__global__ void cdx_act_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, int act) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = gm_act(x[i], act);
+}
+
+extern "C" {
+
+int cdx_gemm_f32(const cdx_gemm_args* g, void* hip_stream) {
+    if (!g) { cdx_set_err("cdx_gemm_f32: null argument block"); return CDX_EINVAL; }
+    if (g->M < 0 || g->N <= 0 || g->K <= 0) { cdx_set_err("cdx_gemm_f32: bad shape"); return CDX_EINVAL; }
+    if (g->M == 0) return CDX_OK;                                   // empty batch: nothing to launch
+    if (!g->A || !g->W || !g->C) { cdx_set_err("cdx_gemm_f32: null pointer"); return CDX_EINVAL; }
+    if ((g->gate && g->rows_per_gate <= 0) || (g->table && g->table_rows <= 0)) {
+        cdx_set_err("cdx_gemm_f32: gate/table need a positive row period"); return CDX_EINVAL;
+    }
+    const int tiles = ((g->M + GM_BM - 1) / GM_BM) * ((g->N + GM_BN - 1) / GM_BN);
+    const bool vec = (g->K % 4 == 0) && (g->lda % 4 == 0) && (g->ldw % 4 == 0) &&
+                     (((uintptr_t)g->A | (uintptr_t)g->W) % 16 == 0);
+    hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+    if (vec) hipLaunchKernelGGL(cdx_gemm_kernel<true>, dim3(tiles), dim3(GM_THREADS), 0, s, *g);
+    else hipLaunchKernelGGL(cdx_gemm_kernel<false>, dim3(tiles), dim3(GM_THREADS), 0, s, *g);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
+    return CDX_OK;
+}
+
+int cdx_layernorm_f32(const cdx_ln_args* a, void* hip_stream) {
+    if (!a) { cdx_set_err("cdx_layernorm_f32: null argument block"); return CDX_EINVAL; }
+    if (a->M > 0 && (!a->x || !a->y)) { cdx_set_err("cdx_layernorm_f32: null pointer"); return CDX_EINVAL; }
+    if (a->C <= 0 || a->C > 1024 || a->M < 0) { cdx_set_err("cdx_layernorm_f32: 0 < C <= 1024 required"); return CDX_EINVAL; }
+    if ((a->scale != nullptr) != (a->shift != nullptr) || (a->gamma != nullptr) != (a->beta != nullptr)) {
+        cdx_set_err("cdx_layernorm_f32: scale/shift and gamma/beta come in pairs"); return CDX_EINVAL;
+    }
+    if (a->scale && a->rows_per_mod <= 0) { cdx_set_err("cdx_layernorm_f32: rows_per_mod must be positive"); return CDX_EINVAL; }
+    if (a->M == 0) return CDX_OK;
+    cdx_ln_args b = *a;
+    if (b.rows_per_mod <= 0) b.rows_per_mod = 1;
+    hipLaunchKernelGGL(cdx_layernorm_kernel, dim3((a->M + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), b);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
+    return CDX_OK;
+}
+
+int cdx_attention_f32(const cdx_attn_args* a, void* hip_stream) {
+    if (!a) { cdx_set_err("cdx_attention_f32: null argument block"); return CDX_EINVAL; }
+    if (a->B > 0 && (!a->qkv || !a->out)) { cdx_set_err("cdx_attention_f32: null pointer"); return CDX_EINVAL; }
+    if (a->T <= 0 || a->T > 64 || a->head_dim <= 0 || a->head_dim > 64 || a->n_heads <= 0 || a->B < 0) {
+        cdx_set_err("cdx_attention_f32: T <= 64 and head_dim <= 64 required"); return CDX_EINVAL;
+    }
+    if (a->B == 0) return CDX_OK;
+    hipLaunchKernelGGL(cdx_attention_kernel, dim3(a->B * a->n_heads), dim3(64), 0,
+                       reinterpret_cast<hipStream_t>(hip_stream), *a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
+    return CDX_OK;
+}
+
+int cdx_act_f32(const float* x, float* y, long long n, int act, void* hip_stream) {
+    if (!x || !y || n < 0) { cdx_set_err("cdx_act_f32: bad argument"); return CDX_EINVAL; }
+    if (n == 0) return CDX_OK;
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(cdx_act_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), x, y,
+                       (size_t)n, act);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
+    return CDX_OK;
+}
+
+}  // extern "C"

@@ -35,10 +35,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CDX_EPI_REGS 4  // GroupNorm elements a lane keeps in registers (groups of <= 256 elements)
 
 static thread_local char g_err[256] = "";
-static void set_err(const char* msg) {
+void cdx_set_err(const char* msg) {          // shared with the other translation units of libcdx.so
     strncpy(g_err, msg, sizeof(g_err) - 1);
     g_err[sizeof(g_err) - 1] = 0;
 }
+static void set_err(const char* msg) { cdx_set_err(msg); }
 
 // ------------------------------------------------------------------------------------------------
 // device helpers

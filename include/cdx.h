@@ -104,6 +104,52 @@ const char* cdx_last_error(void);
 /* Enqueue the fused U-Net program kernel on `hip_stream` (a hipStream_t; NULL = default stream). */
 int cdx_unet1d_run(const cdx_unet1d_launch* launch, void* hip_stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Big-batch building blocks (csrc/cdx_gemm.hip): when M = batch x tokens >> 256 the denoiser layers are classic
+ * GEMMs.  Tensors are fp32, row-major with explicit leading dimensions, weights in the PyTorch (N, K) layout.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* C[m][n] = act(sum_k A[m][k] W[n][k] + bias[n]) * gate[m / rows_per_gate][n] + residual[m][n] + table[m % table_rows][n]
+ * Replaces nn.Linear and its surrounding elementwise ops (reference nn_diffusion/dit.py:31-36,49,118; idqlmlp.py:12-18). */
+typedef struct cdx_gemm_args {
+    const float* A;        /* (M, K), leading dimension lda */
+    const float* W;        /* (N, K), leading dimension ldw */
+    const float* bias;     /* (N) or NULL */
+    const float* gate;     /* (M / rows_per_gate, ldg) or NULL: multiplies the activated value */
+    const float* residual; /* (M, ldr) or NULL: added after the gate */
+    const float* table;    /* (table_rows, N) or NULL: added last (positional table) */
+    float* C;              /* (M, ldc) */
+    int32_t M, N, K, lda, ldw, ldc, ldg, ldr;
+    int32_t rows_per_gate, table_rows;
+    int32_t act;           /* CDX_ACT_* of csrc/cdx_ops.h: 0 none, 1 mish, 2 gelu(erf), 3 leaky, 4 silu, 5 relu, 6 gelu(tanh) */
+} cdx_gemm_args;
+int cdx_gemm_f32(const cdx_gemm_args* args, void* hip_stream);
+
+/* y[m][c] = LN(x[m])[c] [* gamma[c] + beta[c]] [* (1 + scale[m / rows_per_mod][c]) + shift[...]],  C <= 1024.
+ * Replaces nn.LayerNorm(+ adaLN `modulate`) (reference dit.py:10-11,33-35,48; idqlmlp.py:14). */
+typedef struct cdx_ln_args {
+    const float* x;
+    float* y;
+    const float* gamma; const float* beta;     /* (C) or both NULL */
+    const float* scale; const float* shift;    /* (M / rows_per_mod, ldmod) or both NULL */
+    int32_t M, C, ldx, ldy, ldmod, rows_per_mod;
+    float eps;
+} cdx_ln_args;
+int cdx_layernorm_f32(const cdx_ln_args* args, void* hip_stream);
+
+/* out[b][t][h*d..] = softmax(q k^T * scale) v per (batch, head); qkv = (B*T, 3*n_heads*head_dim) from in_proj.
+ * Replaces the core of nn.MultiheadAttention(batch_first=True) (reference dit.py:20,34).  T <= 64, head_dim <= 64. */
+typedef struct cdx_attn_args {
+    const float* qkv;
+    float* out;            /* (B*T, n_heads*head_dim) */
+    int32_t B, T, n_heads, head_dim;
+    float scale;
+} cdx_attn_args;
+int cdx_attention_f32(const cdx_attn_args* args, void* hip_stream);
+
+/* y = act(x) elementwise (batch-invariant embedding vectors: SiLU before adaLN, Mish in map_emb). */
+int cdx_act_f32(const float* x, float* y, long long n, int act, void* hip_stream);
+
 /* Test hook: runs v_mfma_f32_16x16x4_f32 and v_mfma_f32_4x4x1_16b_f32 on fixed operands
  * (digit-coded lane ids, see csrc/cdx_unet1d.hip) and writes out[4][64][4] so the lane->element maps the kernels
  * rely on are checked on the actual silicon. */

@@ -1,0 +1,85 @@
+"""GPU unit tests of the big-batch building blocks (cdx_gemm_f32 / cdx_layernorm_f32 / cdx_attention_f32) against the
+plain PyTorch fp32 ops they replace -- evaluated on the CPU in fp64 as the reference, so the bar is fp32 round-off."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _ref(t):
+    return t.detach().cpu().double()
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 1, 1), (7, 29, 320), (300, 320, 29), (1024, 960, 320), (130, 129, 17),
+                                   (4096, 1280, 320), (513, 320, 1280)])
+def test_gemm_matches_linear(m, n, k):
+    from cleandiffuser_amd.engine import blocks
+    g = torch.Generator().manual_seed(m * 7 + n)
+    a, w, b = torch.randn(m, k, generator=g), torch.randn(n, k, generator=g) / k ** 0.5, torch.randn(n, generator=g)
+    out = blocks.linear(a.to(DEV), w.to(DEV), b.to(DEV))
+    ref = F.linear(_ref(a), _ref(w), _ref(b))
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=2e-5, atol=2e-5)
+
+
+def test_gemm_asymmetric_identity_catches_transposes():
+    from cleandiffuser_amd.engine import blocks
+    a = torch.eye(160)
+    w = torch.arange(96 * 160, dtype=torch.float32).reshape(96, 160) * 1e-3
+    out = blocks.linear(a.to(DEV), w.to(DEV))
+    torch.testing.assert_close(out.cpu(), w.t().contiguous(), rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("act", ["none", "mish", "gelu", "gelu_tanh", "silu", "leaky", "relu"])
+def test_gemm_fused_epilogue(act):
+    from cleandiffuser_amd.engine import blocks
+    g = torch.Generator().manual_seed(3)
+    B, T, K, N = 5, 16, 64, 96
+    a, w, b = torch.randn(B * T, K, generator=g), torch.randn(N, K, generator=g) / 8, torch.randn(N, generator=g)
+    gate, res, tab = torch.randn(B, N, generator=g), torch.randn(B * T, N, generator=g), torch.randn(T, N, generator=g)
+    out = blocks.linear(a.to(DEV), w.to(DEV), b.to(DEV), act=act, gate=gate.to(DEV), rows_per_gate=T,
+                        residual=res.to(DEV), table=tab.to(DEV))
+    y = F.linear(_ref(a), _ref(w), _ref(b))
+    fn = {"none": lambda v: v, "mish": F.mish, "gelu": F.gelu, "gelu_tanh": lambda v: F.gelu(v, approximate="tanh"),
+          "silu": F.silu, "leaky": lambda v: F.leaky_relu(v, 0.01), "relu": F.relu}[act]
+    ref = fn(y) * _ref(gate).repeat_interleave(T, 0) + _ref(res) + _ref(tab).repeat(B, 1)
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=2e-5, atol=2e-5)
+
+
+def test_gemm_strided_views_and_empty():
+    from cleandiffuser_amd.engine import blocks
+    g = torch.Generator().manual_seed(4)
+    big = torch.randn(40, 96, generator=g).to(DEV)
+    a = big[:, 32:64]                                   # row stride 96, 32 columns
+    w = torch.randn(24, 32, generator=g).to(DEV)
+    out = blocks.linear(a, w)
+    torch.testing.assert_close(out.cpu().double(), F.linear(_ref(a), _ref(w)), rtol=2e-5, atol=2e-5)
+    assert blocks.linear(torch.zeros(0, 32, device=DEV), w).shape == (0, 24)
+
+
+@pytest.mark.parametrize("c", [64, 320, 1024, 100])
+def test_layernorm_modulate(c):
+    from cleandiffuser_amd.engine import blocks
+    g = torch.Generator().manual_seed(c)
+    B, T = 3, 8
+    x = torch.randn(B * T, c, generator=g) * 3 + 1
+    sc, sh = torch.randn(B, c, generator=g), torch.randn(B, c, generator=g)
+    y = blocks.layernorm(x.to(DEV), scale=sc.to(DEV), shift=sh.to(DEV), rows_per_mod=T, eps=1e-6)
+    ref = F.layer_norm(_ref(x), (c,), eps=1e-6) * (1 + _ref(sc).repeat_interleave(T, 0)) + _ref(sh).repeat_interleave(T, 0)
+    torch.testing.assert_close(y.cpu().double(), ref, rtol=2e-5, atol=2e-5)
+    ga, be = torch.randn(c, generator=g), torch.randn(c, generator=g)
+    y2 = blocks.layernorm(x.to(DEV), gamma=ga.to(DEV), beta=be.to(DEV), eps=1e-5)
+    torch.testing.assert_close(y2.cpu().double(), F.layer_norm(_ref(x), (c,), _ref(ga), _ref(be), 1e-5), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("tokens,heads,dh", [(64, 10, 32), (16, 4, 16), (5, 2, 64), (1, 1, 8)])
+def test_attention_matches_mha_core(tokens, heads, dh):
+    from cleandiffuser_amd.engine import blocks
+    g = torch.Generator().manual_seed(tokens)
+    B, dm = 3, heads * dh
+    qkv = torch.randn(B * tokens, 3 * dm, generator=g)
+    out = blocks.attention(qkv.to(DEV), B, tokens, heads)
+    q, k, v = (_ref(qkv).reshape(B, tokens, 3, heads, dh)[:, :, i].transpose(1, 2) for i in range(3))
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B * tokens, dm)
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=2e-5, atol=2e-5)
