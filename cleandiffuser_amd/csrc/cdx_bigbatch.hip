@@ -1,0 +1,425 @@
+// cdx_bigbatch.hip -- whole sampling loops for the GEMM-shaped denoisers (DiT1d, residual MLPs) on gfx950.
+//
+// The one-workgroup-per-trajectory program kernel (cdx_unet1d.hip) is the right shape while a trajectory's
+// activations fit one CU's LDS and the batch is a few hundred.  DiT1d (64 tokens x 320..1280 features) and the
+// wide IDQLMlp (hidden 1024..4096, 10^5..10^6 samples) are the opposite regime: M = batch x tokens is huge, every layer
+// is a plain (M, K) x (K, N) GEMM, weights are re-used by every row.  Here the host sequences tiled-GEMM /
+// LayerNorm / attention launches (csrc/cdx_gemm.hip) and a fused solver-step kernel; everything is enqueued on the
+// caller's stream without synchronisation, so the loop of `sample()` (reference diffusion/diffusionsde.py:526-594,
+// newedm.py:387-401) costs one C call.  The batch is processed in independent chunks sized so that a chunk's
+// activations stay inside the 256 MiB Infinity Cache between producer and consumer launches.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cdx.h"
+#include "cdx_ops.h"
+
+extern void cdx_set_err(const char* msg);
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Embedding rows of one chunk:  out[r] = temb[row(r)] + (conditional half ? cond[b0 + r] : 0)
+// (reference dit.py:127-131: emb = map_noise(t); emb += condition | zeros)
+// ------------------------------------------------------------------------------------------------
+__global__ void emb_rows_kernel(float* __restrict__ out, const float* __restrict__ temb, const float* __restrict__ cond,
+                                int rows, int nb, int b0, int E, int rec, int per_sample, int n_cond_rows) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * E) return;
+    const int r = i / E, e = i - r * E;
+    const int s = b0 + (r % nb);
+    float v = temb[(size_t)(per_sample ? s : rec) * E + e];
+    if (cond != nullptr && r < n_cond_rows) v += cond[(size_t)s * E + e];
+    out[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Feature rows of the residual MLP:  [in_scale * x | tfeat | obs-or-zeros]   (reference idqlmlp.py:57-63)
+// ------------------------------------------------------------------------------------------------
+__global__ void mlp_features_kernel(float* __restrict__ out, const float* __restrict__ x, const float* __restrict__ temb,
+                                    const float* __restrict__ cond, int rows, int nb, int b0, int D, int E, int O,
+                                    int rec, int per_sample, int n_cond_rows, float in_scale) {
+    const int F = D + E + O;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * F) return;
+    const int r = i / F, c = i - r * F;
+    const int l = r % nb, s = b0 + l;
+    float v;
+    if (c < D) v = in_scale * x[(size_t)l * D + c];
+    else if (c < D + E) v = temb[(size_t)(per_sample ? s : rec) * E + (c - D)];
+    else v = (cond != nullptr && r < n_cond_rows) ? cond[(size_t)s * O + (c - D - E)] : 0.f;
+    out[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// One solver step on a chunk, state in HBM: guidance combine, clip, eps/x0 conversion, update, fix-mask blend.
+// Same arithmetic, in the same order, as the in-LDS step of cdx_unet1d.hip (kinds 0-4); kinds 5/6 are EDM.
+// ------------------------------------------------------------------------------------------------
+struct StepArgs {
+    float* x;             // (nb, hd) chunk state, in/out
+    const float* pred;    // (nb | 2 nb, hd)
+    float* prev;          // (nb, hd) multistep memory / EDM slope
+    float* xold;          // (nb, hd) EDM Heun: state before the predictor
+    const float* prior;   // chunk-offset already applied
+    const float* fix_mask;
+    const float* noise;   // full tensor [n_noise][batch][hd]
+    const float* x_min;
+    const float* x_max;
+    cdx_step st;
+    int nb, hd, b0, batch, predict_noise, cfg_mode;
+    float cfg_w;
+};
+
+__global__ void solver_step_kernel(const StepArgs a) {
+    const size_t n = (size_t)a.nb * a.hd;
+    const cdx_step& st = a.st;
+    const float al = st.alpha, sg = st.sigma;
+    const float k0 = st.k[0], k1 = st.k[1], k2 = st.k[2], k3 = st.k[3], k4 = st.k[4];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i % a.hd);
+        const int l = (int)(i / a.hd);
+        const float x = a.x[i];
+        float p = a.pred[i];
+        if (a.cfg_mode == 2) p = a.cfg_w * p + (1.0f - a.cfg_w) * a.pred[n + i];
+        float xn;
+        if (st.kind >= 5) {  // EDM: p is the raw network output F
+            float d = k0 * x + k1 * p;
+            if (a.x_min) d = fmaxf(d, a.x_min[e]);
+            if (a.x_max) d = fminf(d, a.x_max[e]);
+            const float s = (x - d) / k2;
+            if (st.kind == 5) {
+                xn = x - s * k3;
+                if (st.push) { a.prev[i] = s; a.xold[i] = x; }
+            } else {
+                xn = a.xold[i] - (a.prev[i] + s) / 2.0f * k3;
+            }
+        } else {
+            if (a.predict_noise) {
+                if (a.x_max) p = fmaxf(p, (x - al * a.x_max[e]) / sg);
+                if (a.x_min) p = fminf(p, (x - al * a.x_min[e]) / sg);
+            } else {
+                if (a.x_min) p = fmaxf(p, a.x_min[e]);
+                if (a.x_max) p = fminf(p, a.x_max[e]);
+            }
+            float eps, xth;
+            if (a.predict_noise) { eps = p; xth = (x - sg * p) / al; }
+            else { xth = p; eps = (x - al * p) / sg; }
+            const size_t zi = ((size_t)(st.noise_idx < 0 ? 0 : st.noise_idx) * a.batch + a.b0 + l) * a.hd + e;
+            if (st.kind >= 3) {
+                const float m = a.fix_mask ? a.fix_mask[e] : 0.f;
+                if (st.kind == 3) { p = p * (1.0f - m); xn = k0 * (x - k1 * p); }
+                else { p = p * (1.0f - m) + x * m; xn = k0 * (k1 * x + k2 * p); }
+                if (st.noise_idx >= 0) xn += k3 * a.noise[zi];
+            } else if (st.kind == 0) {
+                xn = k0 * (x - k1 * eps) + k2 * eps;
+                if (st.noise_idx >= 0) xn += k3 * a.noise[zi];
+            } else if (st.kind == 1) {
+                xn = k0 * ((x - k1 * eps) / k2) + k3 * eps;
+            } else {
+                float v = st.vsel == 0 ? eps : xth;
+                if (st.vsel == 2) v = k3 * xth - k4 * a.prev[i];
+                xn = k0 * x - k1 * v;
+                if (st.noise_idx >= 0) xn += k2 * a.noise[zi];
+            }
+            if (st.push) a.prev[i] = xth;
+        }
+        if (a.fix_mask) {
+            const float m = a.fix_mask[e];
+            xn = xn * (1.0f - m) + a.prior[i] * m;
+        }
+        a.x[i] = xn;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side helpers
+// ------------------------------------------------------------------------------------------------
+struct Arena {
+    float* base;
+    long long used, cap;
+    float* take(long long n) {
+        n = (n + 63) & ~63LL;  // 256-byte aligned blocks: every buffer stays float4-loadable
+        float* p = base ? base + used : nullptr;
+        used += n;
+        return p;
+    }
+};
+
+#define CDX_TRY(expr)            \
+    do {                         \
+        const int rc_ = (expr);  \
+        if (rc_ != CDX_OK) return rc_; \
+    } while (0)
+
+int hip_ok() {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
+    return CDX_OK;
+}
+
+int gemm(void* stream, const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M, int N,
+         int K, int act = CDX_ACT_NONE, const float* gate = nullptr, int ldg = 0, int rows_per_gate = 1,
+         const float* residual = nullptr, int ldr = 0, const float* table = nullptr, int table_rows = 0) {
+    cdx_gemm_args g;
+    g.A = A; g.W = W; g.bias = bias; g.gate = gate; g.residual = residual; g.table = table; g.C = C;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldg = ldg; g.ldr = ldr;
+    g.rows_per_gate = rows_per_gate; g.table_rows = table_rows; g.act = act;
+    return cdx_gemm_f32(&g, stream);
+}
+
+int layernorm(void* stream, const float* x, float* y, int M, int C, float eps, const float* gamma, const float* beta,
+              const float* scale, const float* shift, int ldmod, int rows_per_mod, int x_rows) {
+    cdx_ln_args a;
+    a.x = x; a.y = y; a.gamma = gamma; a.beta = beta; a.scale = scale; a.shift = shift;
+    a.M = M; a.C = C; a.ldx = C; a.ldy = C; a.ldmod = ldmod; a.rows_per_mod = rows_per_mod; a.eps = eps; a.x_rows = x_rows;
+    return cdx_layernorm_f32(&a, stream);
+}
+
+int check_request(const cdx_sampling* s, const char* who, int max_kind) {
+    if (!s || !s->x_in || !s->x_out || !s->temb) { cdx_set_err("null pointer in sampling request"); return CDX_EINVAL; }
+    if (s->batch < 0 || s->hd <= 0 || s->emb_dim <= 0 || s->n_steps < 0 || s->chunk < 0) { cdx_set_err("bad size in sampling request"); return CDX_EINVAL; }
+    if (s->n_steps > 0 && !s->steps) { cdx_set_err("steps == NULL with n_steps > 0"); return CDX_EINVAL; }
+    if (s->fix_mask && !s->prior) { cdx_set_err("fix_mask given without prior"); return CDX_EINVAL; }
+    if (s->cfg_mode < 0 || s->cfg_mode > 2) { cdx_set_err("cfg_mode must be 0, 1 or 2"); return CDX_EINVAL; }
+    if (s->cfg_mode == 2 && (!s->cond || s->n_steps == 0)) { cdx_set_err("cfg_mode 2 needs cond and a sampling loop"); return CDX_EINVAL; }
+    if (s->temb_per_sample && s->n_steps > 0) { cdx_set_err("per-sample timesteps are a forward-mode feature"); return CDX_EINVAL; }
+    for (int i = 0; i < s->n_steps; ++i) {
+        const cdx_step& st = s->steps[i];
+        if (st.kind < 0 || st.kind > max_kind) { cdx_set_err("unsupported step kind for this executor"); return CDX_EINVAL; }
+        if (st.noise_idx >= 0 && !s->noise) { cdx_set_err("step draws noise but noise == NULL"); return CDX_EINVAL; }
+    }
+    (void)who;
+    return CDX_OK;
+}
+
+int chunk_of(const cdx_sampling* s) { return (s->chunk > 0 && s->chunk < s->batch) ? s->chunk : s->batch; }
+
+int run_step(hipStream_t stream, const cdx_sampling* s, const cdx_step& st, float* x, const float* pred, float* prev,
+             float* xold, int nb, int b0) {
+    StepArgs a;
+    a.x = x; a.pred = pred; a.prev = prev; a.xold = xold;
+    a.prior = s->prior ? s->prior + (size_t)b0 * s->hd : nullptr;
+    a.fix_mask = s->fix_mask; a.noise = s->noise; a.x_min = s->x_min; a.x_max = s->x_max;
+    a.st = st; a.nb = nb; a.hd = s->hd; a.b0 = b0; a.batch = s->batch;
+    a.predict_noise = s->predict_noise; a.cfg_mode = s->cfg_mode; a.cfg_w = s->cfg_w;
+    const size_t n = (size_t)nb * s->hd;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(solver_step_kernel, dim3(blocks), dim3(256), 0, stream, a);
+    return hip_ok();
+}
+
+// ------------------------------------------------------------------------------------------------
+// DiT1d
+// ------------------------------------------------------------------------------------------------
+struct DitBuffers {
+    float *x, *prev, *emb0, *e1, *emb, *semb, *ada, *h0, *xm, *qkv, *att, *h2, *f, *h, *pred;
+};
+
+long long dit_layout(const cdx_dit1d_weights* w, const cdx_sampling* s, float* base, DitBuffers* B) {
+    const long long nb = chunk_of(s), bf = nb * (s->cfg_mode == 2 ? 2 : 1);
+    const long long T = w->tokens, d = w->d_model, rows = bf * T;
+    Arena a{base, 0, 0};
+    DitBuffers b;
+    b.x = a.take(nb * s->hd);
+    b.prev = a.take(nb * s->hd);
+    b.emb0 = a.take(bf * w->emb_dim);
+    b.e1 = a.take(bf * d);
+    b.emb = a.take(bf * d);
+    b.semb = a.take(bf * d);
+    b.ada = a.take(bf * 6 * d);
+    b.h0 = a.take(nb * T * d);
+    b.xm = a.take(rows * d);
+    b.qkv = a.take(rows * 3 * d);
+    b.att = a.take(rows * d);
+    b.h2 = a.take(rows * d);
+    b.f = a.take(rows * 4 * d);
+    b.h = a.take(rows * d);
+    b.pred = a.take(rows * w->in_dim);
+    if (B) *B = b;
+    return a.used;
+}
+
+int dit_check(const cdx_dit1d_weights* w, const cdx_sampling* s) {
+    if (!w || !w->blocks || !w->x_proj_w || !w->pos || !w->map0_w || !w->map2_w || !w->fin_ada_w || !w->fin_w) { cdx_set_err("null pointer in DiT1d weights"); return CDX_EINVAL; }
+    if (w->tokens <= 0 || w->tokens > 64 || w->d_model <= 0 || w->d_model > 1024 || w->n_heads <= 0 ||
+        w->d_model % w->n_heads != 0 || w->d_model / w->n_heads > 64 || w->depth < 0 || w->in_dim <= 0) {
+        cdx_set_err("DiT1d executor: tokens <= 64, d_model <= 1024, head_dim <= 64 required"); return CDX_EINVAL;
+    }
+    CDX_TRY(check_request(s, "cdx_dit1d_run", 4));
+    if (s->hd != w->tokens * w->in_dim || s->emb_dim != w->emb_dim || (s->cond && s->cond_dim != w->emb_dim)) {
+        cdx_set_err("DiT1d request shape does not match the weights"); return CDX_EINVAL;
+    }
+    return CDX_OK;
+}
+
+int dit_forward(const cdx_dit1d_weights* w, const cdx_sampling* s, hipStream_t st, const DitBuffers& B, const float* x,
+                float* pred, int nb, int b0, int rec) {
+    const int two = s->cfg_mode == 2 ? 2 : 1, bf = nb * two;
+    const int T = w->tokens, d = w->d_model, E = w->emb_dim, rows = bf * T;
+    const int n_cond_rows = (s->cond == nullptr || s->cfg_mode == 0) ? 0 : nb;   // conditional half comes first
+    {
+        const int n = bf * E;
+        hipLaunchKernelGGL(emb_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, st, B.emb0, s->temb, s->cond, bf, nb, b0,
+                           E, rec, s->temb_per_sample, n_cond_rows);
+        CDX_TRY(hip_ok());
+    }
+    CDX_TRY(gemm(st, B.emb0, E, w->map0_w, E, w->map0_b, B.e1, d, bf, d, E, CDX_ACT_MISH));
+    CDX_TRY(gemm(st, B.e1, d, w->map2_w, d, w->map2_b, B.emb, d, bf, d, d, CDX_ACT_MISH));
+    CDX_TRY(cdx_act_f32(B.emb, B.semb, (long long)bf * d, CDX_ACT_SILU, st));
+    // token stream: x_proj(x) + pos, computed once per trajectory (both CFG halves start from the same tokens)
+    CDX_TRY(gemm(st, x, w->in_dim, w->x_proj_w, w->in_dim, w->x_proj_b, B.h0, d, nb * T, d, w->in_dim, CDX_ACT_NONE,
+                 nullptr, 0, 1, nullptr, 0, w->pos, T));
+    const float* h = B.h0;
+    int h_rows = nb * T;
+    for (int i = 0; i < w->depth; ++i) {
+        const cdx_dit1d_block& k = w->blocks[i];
+        CDX_TRY(gemm(st, B.semb, d, k.ada_w, d, k.ada_b, B.ada, 6 * d, bf, 6 * d, d));
+        // x <- modulate(LN(x), shift_a, scale_a)   (dit.py:33: the block continues from the modulated stream, Q4)
+        CDX_TRY(layernorm(st, h, B.xm, rows, d, 1e-6f, nullptr, nullptr, B.ada + d, B.ada, 6 * d, T, h_rows == rows ? 0 : h_rows));
+        CDX_TRY(gemm(st, B.xm, d, k.qkv_w, d, k.qkv_b, B.qkv, 3 * d, rows, 3 * d, d));
+        cdx_attn_args at;
+        at.qkv = B.qkv; at.out = B.att; at.B = bf; at.T = T; at.n_heads = w->n_heads; at.head_dim = d / w->n_heads;
+        at.scale = 1.0f / sqrtf((float)at.head_dim);
+        CDX_TRY(cdx_attention_f32(&at, st));
+        CDX_TRY(gemm(st, B.att, d, k.proj_w, d, k.proj_b, B.h2, d, rows, d, d, CDX_ACT_NONE, B.ada + 2 * d, 6 * d, T, B.xm, d));
+        CDX_TRY(layernorm(st, B.h2, B.xm, rows, d, 1e-6f, nullptr, nullptr, B.ada + 4 * d, B.ada + 3 * d, 6 * d, T, 0));
+        CDX_TRY(gemm(st, B.xm, d, k.fc1_w, d, k.fc1_b, B.f, 4 * d, rows, 4 * d, d, CDX_ACT_GELU_TANH));
+        CDX_TRY(gemm(st, B.f, 4 * d, k.fc2_w, 4 * d, k.fc2_b, B.h, d, rows, d, 4 * d, CDX_ACT_NONE, B.ada + 5 * d, 6 * d, T, B.h2, d));
+        h = B.h;
+        h_rows = rows;
+    }
+    CDX_TRY(gemm(st, B.semb, d, w->fin_ada_w, d, w->fin_ada_b, B.ada, 2 * d, bf, 2 * d, d));
+    CDX_TRY(layernorm(st, h, B.xm, rows, d, 1e-6f, nullptr, nullptr, B.ada + d, B.ada, 2 * d, T, h_rows == rows ? 0 : h_rows));
+    CDX_TRY(gemm(st, B.xm, d, w->fin_w, d, w->fin_b, pred, w->in_dim, rows, w->in_dim, d));
+    return CDX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// residual MLP
+// ------------------------------------------------------------------------------------------------
+struct MlpBuffers {
+    float *x, *prev, *xold, *feat, *h, *y, *u, *pred;
+};
+
+long long mlp_layout(const cdx_resmlp_weights* w, const cdx_sampling* s, float* base, MlpBuffers* B) {
+    const long long nb = chunk_of(s), bf = nb * (s->cfg_mode == 2 ? 2 : 1);
+    const long long F = w->x_dim + w->emb_dim + w->obs_dim, H = w->hidden;
+    Arena a{base, 0, 0};
+    MlpBuffers b;
+    b.x = a.take(nb * s->hd);
+    b.prev = a.take(nb * s->hd);
+    b.xold = a.take(nb * s->hd);
+    b.feat = a.take(bf * F);
+    b.h = a.take(bf * H);
+    b.y = a.take(bf * H);
+    b.u = a.take(bf * 4 * H);
+    b.pred = a.take(bf * w->x_dim);
+    if (B) *B = b;
+    return a.used;
+}
+
+int mlp_check(const cdx_resmlp_weights* w, const cdx_sampling* s) {
+    if (!w || !w->in_w || !w->out_w || (w->n_blocks > 0 && !w->blocks)) { cdx_set_err("null pointer in residual-MLP weights"); return CDX_EINVAL; }
+    if (w->x_dim <= 0 || w->emb_dim <= 0 || w->obs_dim < 0 || w->hidden <= 0 || w->hidden > 1024 || w->n_blocks < 0) {
+        cdx_set_err("residual-MLP executor: hidden <= 1024 required (LayerNorm row in registers)"); return CDX_EINVAL;
+    }
+    CDX_TRY(check_request(s, "cdx_resmlp_run", 6));
+    if (s->hd != w->x_dim || s->emb_dim != w->emb_dim || (s->cond && s->cond_dim != w->obs_dim)) {
+        cdx_set_err("residual-MLP request shape does not match the weights"); return CDX_EINVAL;
+    }
+    return CDX_OK;
+}
+
+int mlp_forward(const cdx_resmlp_weights* w, const cdx_sampling* s, hipStream_t st, const MlpBuffers& B, const float* x,
+                float* pred, int nb, int b0, int rec, float in_scale) {
+    const int two = s->cfg_mode == 2 ? 2 : 1, bf = nb * two;
+    const int D = w->x_dim, E = w->emb_dim, O = w->obs_dim, F = D + E + O, H = w->hidden;
+    const int n_cond_rows = (s->cond == nullptr || s->cfg_mode == 0) ? 0 : nb;
+    {
+        const long long n = (long long)bf * F;
+        hipLaunchKernelGGL(mlp_features_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, B.feat, x, s->temb,
+                           s->cond, bf, nb, b0, D, E, O, rec, s->temb_per_sample, n_cond_rows, in_scale);
+        CDX_TRY(hip_ok());
+    }
+    CDX_TRY(gemm(st, B.feat, F, w->in_w, F, w->in_b, B.h, H, bf, H, F));
+    for (int i = 0; i < w->n_blocks; ++i) {
+        const cdx_resmlp_block& k = w->blocks[i];
+        CDX_TRY(layernorm(st, B.h, B.y, bf, H, 1e-5f, k.ln_g, k.ln_b, nullptr, nullptr, 0, 1, 0));
+        CDX_TRY(gemm(st, B.y, H, k.fc1_w, H, k.fc1_b, B.u, 4 * H, bf, 4 * H, H, CDX_ACT_MISH));
+        CDX_TRY(gemm(st, B.u, 4 * H, k.fc2_w, 4 * H, k.fc2_b, B.h, H, bf, H, 4 * H, CDX_ACT_NONE, nullptr, 0, 1, B.h, H));
+    }
+    const float* head_in = B.h;
+    if (w->head_mish) {
+        CDX_TRY(cdx_act_f32(B.h, B.y, (long long)bf * H, CDX_ACT_MISH, st));
+        head_in = B.y;
+    }
+    CDX_TRY(gemm(st, head_in, H, w->out_w, H, w->out_b, pred, D, bf, D, H));
+    return CDX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+long long cdx_dit1d_workspace_floats(const cdx_dit1d_weights* w, const cdx_sampling* s) {
+    if (!w || !s) return -1;
+    return dit_layout(w, s, nullptr, nullptr);
+}
+
+int cdx_dit1d_run(const cdx_dit1d_weights* w, const cdx_sampling* s, void* hip_stream) {
+    CDX_TRY(dit_check(w, s));
+    if (s->batch == 0) return CDX_OK;
+    DitBuffers B;
+    const long long need = dit_layout(w, s, s->workspace, &B);
+    if (!s->workspace || s->workspace_floats < need) { cdx_set_err("cdx_dit1d_run: workspace too small"); return CDX_EINVAL; }
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    const int chunk = chunk_of(s);
+    for (int b0 = 0; b0 < s->batch; b0 += chunk) {
+        const int nb = s->batch - b0 < chunk ? s->batch - b0 : chunk;
+        const size_t off = (size_t)b0 * s->hd, bytes = (size_t)nb * s->hd * sizeof(float);
+        if (s->n_steps == 0) {
+            CDX_TRY(dit_forward(w, s, st, B, s->x_in + off, s->x_out + off, nb, b0, 0));
+            continue;
+        }
+        if (hipMemcpyAsync(B.x, s->x_in + off, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return hip_ok();
+        for (int i = 0; i < s->n_steps; ++i) {
+            CDX_TRY(dit_forward(w, s, st, B, B.x, B.pred, nb, b0, i));
+            CDX_TRY(run_step(st, s, s->steps[i], B.x, B.pred, B.prev, nullptr, nb, b0));
+        }
+        if (hipMemcpyAsync(s->x_out + off, B.x, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return hip_ok();
+    }
+    return CDX_OK;
+}
+
+long long cdx_resmlp_workspace_floats(const cdx_resmlp_weights* w, const cdx_sampling* s) {
+    if (!w || !s) return -1;
+    return mlp_layout(w, s, nullptr, nullptr);
+}
+
+int cdx_resmlp_run(const cdx_resmlp_weights* w, const cdx_sampling* s, void* hip_stream) {
+    CDX_TRY(mlp_check(w, s));
+    if (s->batch == 0) return CDX_OK;
+    MlpBuffers B;
+    const long long need = mlp_layout(w, s, s->workspace, &B);
+    if (!s->workspace || s->workspace_floats < need) { cdx_set_err("cdx_resmlp_run: workspace too small"); return CDX_EINVAL; }
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    const int chunk = chunk_of(s);
+    for (int b0 = 0; b0 < s->batch; b0 += chunk) {
+        const int nb = s->batch - b0 < chunk ? s->batch - b0 : chunk;
+        const size_t off = (size_t)b0 * s->hd, bytes = (size_t)nb * s->hd * sizeof(float);
+        if (s->n_steps == 0) {
+            CDX_TRY(mlp_forward(w, s, st, B, s->x_in + off, s->x_out + off, nb, b0, 0, 1.0f));
+            continue;
+        }
+        if (hipMemcpyAsync(B.x, s->x_in + off, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return hip_ok();
+        for (int i = 0; i < s->n_steps; ++i) {
+            const cdx_step& rec = s->steps[i];
+            CDX_TRY(mlp_forward(w, s, st, B, B.x, B.pred, nb, b0, i, rec.kind >= 5 ? rec.alpha : 1.0f));
+            CDX_TRY(run_step(st, s, rec, B.x, B.pred, B.prev, B.xold, nb, b0));
+        }
+        if (hipMemcpyAsync(s->x_out + off, B.x, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return hip_ok();
+    }
+    return CDX_OK;
+}
+
+}  // extern "C"

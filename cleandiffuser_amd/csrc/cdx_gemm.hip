@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void cdx_layernorm_kernel(const cdx_ln_args a)
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.M) return;
-    const float* x = a.x + (size_t)row * a.ldx;
+    const float* x = a.x + (size_t)(a.x_rows > 0 ? row % a.x_rows : row) * a.ldx;
     float v[16];                                        // C <= 1024
     float s = 0.f;
 #pragma unroll

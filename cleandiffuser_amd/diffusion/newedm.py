@@ -150,6 +150,15 @@ class ContinuousEDM(DiffusionModel):
         ramp = torch.arange(sample_steps + 1, device=self.device) / sample_steps
         sigmas = (self.sigma_min ** inv_rho + ramp * (top_sigma ** inv_rho - self.sigma_min ** inv_rho)) ** self.rho
 
+        if not preserve_history:
+            from ..engine import dispatch
+            from ..engine.plan import build_edm_plan
+            plan = build_edm_plan(self.sigma_data, self.sigma_min, top_sigma, self.rho, sample_steps, solver,
+                                  diffusion_x_sampling_steps)
+            fused = dispatch.try_fused_edm(self, model, plan, xt, prior, cond_cfg, w_cfg, w_cg, requires_grad, feed)
+            if fused is not None:
+                return self._finish_sample(fused, n_samples, condition_cg, log)
+
         def denoise(x, t, sigma):
             pred, _ = self.guided_sampling(x, t, sigma, model, cond_cfg, w_cfg, condition_cg, w_cg, requires_grad)
             return pred.clip(self.x_min, self.x_max) if self.clip_pred else pred
@@ -170,6 +179,9 @@ class ContinuousEDM(DiffusionModel):
             if preserve_history:
                 log["sample_history"][:, sample_steps - i + 1] = xt.cpu().numpy()
 
+        return self._finish_sample(xt, n_samples, condition_cg, log)
+
+    def _finish_sample(self, xt, n_samples, condition_cg, log):
         if self.classifier is not None:
             with torch.no_grad():
                 t = torch.ones((n_samples,), dtype=torch.long, device=self.device) * self.sigma_min

@@ -1,0 +1,329 @@
+"""Host side of the big-batch executors (``cdx_dit1d_run`` / ``cdx_resmlp_run``, include/cdx.h, csrc/cdx_bigbatch.hip).
+
+DiT1d and IDQLMlp/NewIDQLMlp are served here: their layers are plain GEMMs over M = batch x tokens rows, so the loop of
+``sample()`` becomes a stream of tiled-GEMM / LayerNorm / attention / solver-step launches issued by ONE C call.  This
+module only marshals pointers: the checkpoint tensors are used in place (PyTorch layouts), the workspace is a cached
+device tensor, step records are the same ``plan.Step`` list the fused kernel consumes.
+"""
+import ctypes
+import weakref
+from typing import Optional
+
+import torch
+
+from .runtime import CdxStep, _check, _dense_hd, _f32c, _signature, _stream_ptr, load_library
+
+_FP = ctypes.c_void_p
+_I = ctypes.c_int32
+
+
+class CdxSampling(ctypes.Structure):
+    _fields_ = [("batch", _I), ("hd", _I), ("emb_dim", _I), ("cond_dim", _I), ("temb", _FP),
+                ("steps", ctypes.POINTER(CdxStep)), ("n_steps", _I), ("temb_per_sample", _I), ("predict_noise", _I),
+                ("cfg_mode", _I), ("cfg_w", ctypes.c_float), ("cond", _FP), ("x_in", _FP), ("prior", _FP),
+                ("fix_mask", _FP), ("noise", _FP), ("x_min", _FP), ("x_max", _FP), ("x_out", _FP), ("workspace", _FP),
+                ("workspace_floats", ctypes.c_longlong), ("chunk", _I)]
+
+
+class CdxDitBlock(ctypes.Structure):
+    _fields_ = [(n, _FP) for n in ("ada_w", "ada_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "fc1_w", "fc1_b", "fc2_w",
+                                   "fc2_b")]
+
+
+class CdxDitWeights(ctypes.Structure):
+    _fields_ = [("tokens", _I), ("in_dim", _I), ("emb_dim", _I), ("d_model", _I), ("n_heads", _I), ("depth", _I),
+                ("x_proj_w", _FP), ("x_proj_b", _FP), ("pos", _FP), ("map0_w", _FP), ("map0_b", _FP), ("map2_w", _FP),
+                ("map2_b", _FP), ("blocks", ctypes.POINTER(CdxDitBlock)), ("fin_ada_w", _FP), ("fin_ada_b", _FP),
+                ("fin_w", _FP), ("fin_b", _FP)]
+
+
+class CdxResMlpBlock(ctypes.Structure):
+    _fields_ = [(n, _FP) for n in ("ln_g", "ln_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+
+
+class CdxResMlpWeights(ctypes.Structure):
+    _fields_ = [("x_dim", _I), ("emb_dim", _I), ("obs_dim", _I), ("hidden", _I), ("n_blocks", _I), ("head_mish", _I),
+                ("in_w", _FP), ("in_b", _FP), ("blocks", ctypes.POINTER(CdxResMlpBlock)), ("out_w", _FP), ("out_b", _FP)]
+
+
+_declared = False
+
+
+def _lib():
+    global _declared
+    lib = load_library()
+    if not _declared:
+        lib.cdx_dit1d_workspace_floats.argtypes = [ctypes.POINTER(CdxDitWeights), ctypes.POINTER(CdxSampling)]
+        lib.cdx_dit1d_workspace_floats.restype = ctypes.c_longlong
+        lib.cdx_dit1d_run.argtypes = [ctypes.POINTER(CdxDitWeights), ctypes.POINTER(CdxSampling), ctypes.c_void_p]
+        lib.cdx_dit1d_run.restype = ctypes.c_int
+        lib.cdx_resmlp_workspace_floats.argtypes = [ctypes.POINTER(CdxResMlpWeights), ctypes.POINTER(CdxSampling)]
+        lib.cdx_resmlp_workspace_floats.restype = ctypes.c_longlong
+        lib.cdx_resmlp_run.argtypes = [ctypes.POINTER(CdxResMlpWeights), ctypes.POINTER(CdxSampling), ctypes.c_void_p]
+        lib.cdx_resmlp_run.restype = ctypes.c_int
+        _declared = True
+    return lib
+
+
+# ------------------------------------------------------------------------------------------------ #
+# backbone recognition + weight marshalling (cached per module, invalidated when a parameter changes)  #
+# ------------------------------------------------------------------------------------------------ #
+def is_dit1d(module) -> bool:
+    from ..nn_diffusion.dit import DiT1d
+    return type(module) is DiT1d
+
+
+def is_resmlp(module) -> bool:
+    from ..nn_diffusion.mlp_backbones import IDQLMlp, NewIDQLMlp
+    return type(module) in (IDQLMlp, NewIDQLMlp)
+
+
+class _Bound:
+    """ctypes weight struct + the tensors it points into (kept alive here)."""
+
+    def __init__(self, struct, keep, sig):
+        self.struct, self.keep, self.sig = struct, keep, sig
+
+
+_cache = weakref.WeakKeyDictionary()
+
+
+def _dev_f32(t: torch.Tensor, keep: list, device):
+    """Pointer of an fp32 contiguous tensor on `device`; parameters that already are one are used in place."""
+    if t.dtype != torch.float32 or not t.is_contiguous() or t.device != device:
+        t = t.detach().to(device=device, dtype=torch.float32).contiguous()
+    keep.append(t)
+    return t.data_ptr()
+
+
+def _bind_dit(net, tokens: int, device) -> Optional[_Bound]:
+    d = net.d_model
+    heads = net.blocks[0].attn.num_heads if len(net.blocks) else 1
+    if tokens > 64 or d > 1024 or d % heads or d // heads > 64:
+        return None
+    for blk in net.blocks:
+        a = blk.attn
+        if a.in_proj_weight is None or a.in_proj_bias is None or a.bias_k is not None or a.add_zero_attn or \
+                not a.batch_first:
+            return None
+    keep = []
+    p = lambda t: _dev_f32(t, keep, device)  # noqa: E731
+    blocks = (CdxDitBlock * max(len(net.blocks), 1))()
+    for i, blk in enumerate(net.blocks):
+        ada, fc1, fc2 = blk.adaLN_modulation[1], blk.mlp[0], blk.mlp[3]
+        blocks[i] = CdxDitBlock(p(ada.weight), p(ada.bias), p(blk.attn.in_proj_weight), p(blk.attn.in_proj_bias),
+                                p(blk.attn.out_proj.weight), p(blk.attn.out_proj.bias), p(fc1.weight), p(fc1.bias),
+                                p(fc2.weight), p(fc2.bias))
+    pos = net.pos_emb(torch.arange(tokens, device=device)).float().contiguous()     # dit.py:122-125
+    fin = net.final_layer
+    w = CdxDitWeights(tokens=tokens, in_dim=net.in_dim, emb_dim=net.emb_dim, d_model=d, n_heads=heads,
+                      depth=len(net.blocks), x_proj_w=p(net.x_proj.weight), x_proj_b=p(net.x_proj.bias), pos=p(pos),
+                      map0_w=p(net.map_emb[0].weight), map0_b=p(net.map_emb[0].bias), map2_w=p(net.map_emb[2].weight),
+                      map2_b=p(net.map_emb[2].bias), blocks=blocks, fin_ada_w=p(fin.adaLN_modulation[1].weight),
+                      fin_ada_b=p(fin.adaLN_modulation[1].bias), fin_w=p(fin.linear.weight), fin_b=p(fin.linear.bias))
+    keep.append(blocks)
+    return _Bound(w, keep, None)
+
+
+def _bind_resmlp(net, device) -> Optional[_Bound]:
+    hidden = net.affine_in.out_features
+    if hidden > 1024:
+        return None
+    keep = []
+    p = lambda t: _dev_f32(t, keep, device)  # noqa: E731
+    res = list(net.ln_resnet)
+    blocks = (CdxResMlpBlock * max(len(res), 1))()
+    for i, blk in enumerate(res):
+        ln, fc1, fc2 = blk.net[1], blk.net[2], blk.net[4]
+        blocks[i] = CdxResMlpBlock(p(ln.weight), p(ln.bias), p(fc1.weight), p(fc1.bias), p(fc2.weight), p(fc2.bias))
+    head_mish = isinstance(net.affine_out, torch.nn.Sequential)
+    head = net.affine_out[1] if head_mish else net.affine_out
+    emb_dim = net.time_mlp[2].out_features
+    x_dim = net.affine_in.in_features - emb_dim - net.obs_dim
+    w = CdxResMlpWeights(x_dim=x_dim, emb_dim=emb_dim, obs_dim=net.obs_dim, hidden=hidden, n_blocks=len(res),
+                         head_mish=int(head_mish), in_w=p(net.affine_in.weight), in_b=p(net.affine_in.bias),
+                         blocks=blocks, out_w=p(head.weight), out_b=p(head.bias))
+    keep.append(blocks)
+    return _Bound(w, keep, None)
+
+
+def _bound(net, key, make) -> Optional[_Bound]:
+    per_mod = _cache.setdefault(net, {})
+    sig = _signature(net)
+    hit = per_mod.get(key)
+    if hit is not None and hit.sig == sig:
+        return hit
+    b = make()
+    if b is not None:
+        b.sig = sig
+        per_mod[key] = b
+    return b
+
+
+_workspaces = {}
+
+
+def _workspace(device, floats: int) -> torch.Tensor:
+    ws = _workspaces.get(device)
+    if ws is None or ws.numel() < floats:
+        _workspaces[device] = ws = torch.empty(int(floats), dtype=torch.float32, device=device)
+    return ws
+
+
+def host_steps(plan):
+    """plan.Step list -> host-resident cdx_step array (the C loop reads it while enqueuing)."""
+    arr = (CdxStep * max(len(plan.steps), 1))()
+    k = 0
+    for i, st in enumerate(plan.steps):
+        arr[i].kind, arr[i].vsel, arr[i].push = st.kind, st.vsel, int(st.push)
+        arr[i].alpha, arr[i].sigma = st.alpha, st.sigma
+        for j in range(5):
+            arr[i].k[j] = st.k[j]
+        if st.noise:
+            arr[i].noise_idx, k = k, k + 1
+        else:
+            arr[i].noise_idx = -1
+    return arr
+
+
+# Chunk sizes: a chunk's widest activation (rows x 4 d_model resp. rows x 4 hidden, fp32) stays well inside the 256 MiB
+# Infinity Cache between the GEMM that writes it and the GEMM that reads it, while rows >= 16 k keeps > 256 tiles in flight.
+def _dit_chunk(batch: int, tokens: int, d_model: int, two: int) -> int:
+    rows_budget = max((96 << 20) // (4 * 4 * d_model), 4096)
+    return max(min(batch, rows_budget // (tokens * two)), 1)
+
+
+def _mlp_chunk(batch: int, hidden: int, two: int) -> int:
+    return max(min(batch, max((96 << 20) // (4 * 4 * hidden), 4096) // two), 1)
+
+
+CHUNK_OVERRIDE = {"dit": None, "mlp": None}        # tools/bench_configs.py sweeps these
+
+
+def _run(kind, bound, *, batch, hd, emb_dim, cond_dim, temb, steps, n_steps, temb_per_sample, predict_noise, cfg_mode,
+         cfg_w, cond, x_in, prior, fix_mask, noise, x_min, x_max, x_out, chunk):
+    lib = _lib()
+    pp = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    s = CdxSampling(batch=batch, hd=hd, emb_dim=emb_dim, cond_dim=cond_dim, temb=temb.data_ptr(), steps=steps,
+                    n_steps=n_steps, temb_per_sample=int(temb_per_sample), predict_noise=int(predict_noise),
+                    cfg_mode=cfg_mode, cfg_w=float(cfg_w), cond=pp(cond), x_in=x_in.data_ptr(), prior=pp(prior),
+                    fix_mask=pp(fix_mask), noise=pp(noise), x_min=pp(x_min), x_max=pp(x_max), x_out=x_out.data_ptr(),
+                    workspace=None, workspace_floats=0, chunk=chunk)
+    size_fn, run_fn = ((lib.cdx_dit1d_workspace_floats, lib.cdx_dit1d_run) if kind == "dit" else
+                       (lib.cdx_resmlp_workspace_floats, lib.cdx_resmlp_run))
+    need = size_fn(ctypes.byref(bound.struct), ctypes.byref(s))
+    ws = _workspace(x_in.device, need)
+    s.workspace, s.workspace_floats = ws.data_ptr(), ws.numel()
+    if batch:
+        _check(run_fn(ctypes.byref(bound.struct), ctypes.byref(s), _stream_ptr(x_in.device)), f"cdx_{kind}_run")
+
+
+# ------------------------------------------------------------------------------------------------ #
+# backbone.forward                                                                                     #
+# ------------------------------------------------------------------------------------------------ #
+def dit_forward(net, x, noise, condition) -> Optional[torch.Tensor]:
+    if x.dim() != 3 or x.shape[2] != net.in_dim:
+        return None
+    b, tokens, _ = x.shape
+    dev = x.device
+    bound = _bound(net, ("dit", tokens), lambda: _bind_dit(net, tokens, dev))
+    if bound is None:
+        return None
+    with torch.no_grad():
+        temb = _f32c(net.map_noise(noise), dev)
+        cond = None if condition is None else _f32c(condition, dev)
+        xin = _f32c(x, dev)
+        out = torch.empty_like(xin)
+        _run("dit", bound, batch=b, hd=tokens * net.in_dim, emb_dim=net.emb_dim, cond_dim=net.emb_dim, temb=temb,
+             steps=None, n_steps=0, temb_per_sample=1, predict_noise=0, cfg_mode=1 if cond is not None else 0, cfg_w=1.0,
+             cond=cond, x_in=xin, prior=None, fix_mask=None, noise=None, x_min=None, x_max=None, x_out=out,
+             chunk=CHUNK_OVERRIDE["dit"] or _dit_chunk(b, tokens, net.d_model, 1))
+    return out
+
+
+def _time_features(net, t_vec, dev) -> torch.Tensor:
+    """time_mlp(map_noise(t)) through the library's own GEMM (rows = number of distinct timesteps)."""
+    from . import blocks
+    e = _f32c(net.map_noise(t_vec), dev)
+    l0, l2 = net.time_mlp[0], net.time_mlp[2]
+    h = blocks.linear(e, _f32c(l0.weight, dev), _f32c(l0.bias, dev), act="mish")
+    return blocks.linear(h, _f32c(l2.weight, dev), _f32c(l2.bias, dev))
+
+
+def resmlp_forward(net, x, noise, condition) -> Optional[torch.Tensor]:
+    if x.dim() != 2:
+        return None
+    dev = x.device
+    bound = _bound(net, "mlp", lambda: _bind_resmlp(net, dev))
+    if bound is None or x.shape[1] != bound.struct.x_dim:
+        return None
+    with torch.no_grad():
+        temb = _time_features(net, noise, dev)
+        cond = None if (condition is None or net.obs_dim == 0) else _f32c(condition, dev)
+        xin = _f32c(x, dev)
+        out = torch.empty_like(xin)
+        w = bound.struct
+        _run("mlp", bound, batch=x.shape[0], hd=w.x_dim, emb_dim=w.emb_dim, cond_dim=w.obs_dim, temb=temb, steps=None,
+             n_steps=0, temb_per_sample=1, predict_noise=0, cfg_mode=1 if cond is not None else 0, cfg_w=1.0, cond=cond,
+             x_in=xin, prior=None, fix_mask=None, noise=None, x_min=None, x_max=None, x_out=out,
+             chunk=CHUNK_OVERRIDE["mlp"] or _mlp_chunk(x.shape[0], w.hidden, 1))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ #
+# sample()                                                                                             #
+# ------------------------------------------------------------------------------------------------ #
+def sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed) -> Optional[torch.Tensor]:
+    """Whole denoising loop through cdx_dit1d_run / cdx_resmlp_run.  None -> caller uses the PyTorch executor."""
+    dev = xt.device
+    if is_dit1d(net):
+        if xt.dim() != 3 or xt.shape[2] != net.in_dim:
+            return None
+        kind, (b, tokens, d) = "dit", xt.shape
+        bound = _bound(net, ("dit", tokens), lambda: _bind_dit(net, tokens, dev))
+        hd, rows_h = tokens * d, tokens
+    elif is_resmlp(net):
+        if xt.dim() != 2:
+            return None
+        kind, (b, d) = "mlp", xt.shape
+        bound = _bound(net, "mlp", lambda: _bind_resmlp(net, dev))
+        hd, rows_h = d, 1
+        if bound is not None and bound.struct.x_dim != d:
+            return None
+    else:
+        return None
+    if bound is None:
+        return None
+    if cond_vec is None and w_cfg not in (0.0, 1.0):
+        return None                                   # the reference raises here; let the torch executor do it
+    try:
+        fix_mask = _dense_hd(solver.fix_mask, rows_h, d, dev)
+        x_min = _dense_hd(getattr(solver, "x_min", None), rows_h, d, dev)
+        x_max = _dense_hd(getattr(solver, "x_max", None), rows_h, d, dev)
+    except (ValueError, RuntimeError):
+        return None
+    with torch.no_grad():
+        t_dtype = torch.long if plan.t_is_integer else torch.float32
+        t_vec = torch.tensor([st.t for st in plan.steps], dtype=t_dtype, device=dev)
+        if kind == "dit":
+            temb, emb_dim, cond_dim = _f32c(net.map_noise(t_vec), dev), net.emb_dim, net.emb_dim
+        else:
+            temb, emb_dim, cond_dim = _time_features(net, t_vec, dev), bound.struct.emb_dim, bound.struct.obs_dim
+        if cond_vec is None or w_cfg == 0.0 or (kind == "mlp" and cond_dim == 0):
+            mode, cond = 0, None
+        else:
+            mode, cond = (1 if w_cfg == 1.0 else 2), _f32c(torch.flatten(cond_vec, 1), dev)
+            if cond.shape != (b, cond_dim):
+                return None
+        two = 2 if mode == 2 else 1
+        steps = host_steps(plan)
+        noise = torch.stack([feed.like(xt) for _ in range(plan.n_noise)]).contiguous() if plan.n_noise else None
+        xin = _f32c(xt, dev)
+        out = torch.empty_like(xin)
+        chunk = CHUNK_OVERRIDE[kind] or (_dit_chunk(b, rows_h, net.d_model, two) if kind == "dit" else
+                                         _mlp_chunk(b, bound.struct.hidden, two))
+        _run(kind, bound, batch=b, hd=hd, emb_dim=emb_dim, cond_dim=cond_dim, temb=temb, steps=steps,
+             n_steps=len(plan.steps), temb_per_sample=0, predict_noise=getattr(solver, "predict_noise", False),
+             cfg_mode=mode, cfg_w=w_cfg, cond=cond, x_in=xin, prior=_f32c(prior, dev) if fix_mask is not None else None,
+             fix_mask=fix_mask, noise=noise, x_min=x_min, x_max=x_max, x_out=out, chunk=chunk)
+    return out

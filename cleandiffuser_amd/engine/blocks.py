@@ -25,7 +25,8 @@ class CdxLnArgs(ctypes.Structure):
     _fields_ = [("x", ctypes.c_void_p), ("y", ctypes.c_void_p), ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p),
                 ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p),
                 ("M", ctypes.c_int32), ("C", ctypes.c_int32), ("ldx", ctypes.c_int32), ("ldy", ctypes.c_int32),
-                ("ldmod", ctypes.c_int32), ("rows_per_mod", ctypes.c_int32), ("eps", ctypes.c_float)]
+                ("ldmod", ctypes.c_int32), ("rows_per_mod", ctypes.c_int32), ("eps", ctypes.c_float),
+                ("x_rows", ctypes.c_int32)]
 
 
 class CdxAttnArgs(ctypes.Structure):

@@ -1,5 +1,8 @@
 """Dispatch rules between the fused gfx950 executors and the PyTorch executor.
 
+Two native executors: the one-workgroup-per-trajectory program kernel (runtime.py: JannerUNet1d, ChiUNet1d, PearceMlp,
+DQLMlp, HalfJannerUNet1d) and the big-batch GEMM executors (bigbatch.py: DiT1d, IDQLMlp/NewIDQLMlp).
+
 HIP fast path  <=>  tensor lives on a ROCm device  AND  gradients are off  AND  dtype is fp32  AND
 the backbone is one the program compiler understands.  Everything else (CPU tensors, autograd, exotic
 variants such as ``attention=True``) runs the stock PyTorch modules.  On a ROCm device a *missing or
@@ -20,7 +23,11 @@ def try_backbone_forward(module, x, noise, condition) -> Optional[torch.Tensor]:
         return None
     if x.dtype != torch.float32:
         return None
-    from . import runtime
+    from . import bigbatch, runtime
+    if bigbatch.is_dit1d(module):
+        return bigbatch.dit_forward(module, x, noise, condition)
+    if bigbatch.is_resmlp(module):
+        return bigbatch.resmlp_forward(module, x, noise, condition)
     return runtime.backbone_forward(module, x, noise, condition)
 
 
@@ -36,8 +43,24 @@ def try_fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, requ
         return None
     if w_cg != 0.0 and solver.classifier is not None:
         return None                      # per-step classifier gradients need autograd
-    from . import runtime
+    from . import bigbatch, runtime
+    net = model["diffusion"]
+    if bigbatch.is_dit1d(net) or bigbatch.is_resmlp(net):
+        return bigbatch.sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed)
     return runtime.fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed)
+
+
+def try_fused_edm(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, requires_grad, feed):
+    """``ContinuousEDM.sample`` on the big-batch executors (GEMM-shaped backbones only)."""
+    if not _on_gpu(xt) or requires_grad or xt.dtype != torch.float32:
+        return None
+    if w_cg != 0.0 and solver.classifier is not None:
+        return None
+    from . import bigbatch
+    net = model["diffusion"]
+    if not bigbatch.is_resmlp(net):
+        return None
+    return bigbatch.sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed)
 
 
 def try_fused_legacy_ddpm(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, requires_grad, feed):

@@ -140,3 +140,38 @@ def build_legacy_ddpm_plan(beta: torch.Tensor, alpha: torch.Tensor, bar_alpha: t
         plan.steps.append(Step(kind, V_EPS, t, int(t), _f(bar[t].sqrt()), _f((1 - bar[t]).sqrt()),
                                (k[0], k[1], k[2], std, 0.0), noise=(t != 0 and pos < T)))
     return plan
+
+
+KIND_EDM_EULER, KIND_EDM_HEUN = 5, 6
+
+
+def build_edm_plan(sigma_data: float, sigma_min: float, top_sigma: float, rho: float, sample_steps: int, solver: str,
+                   diffusion_x_sampling_steps: int = 0) -> SamplePlan:
+    """``ContinuousEDM.sample`` (reference diffusion/newedm.py:373-401): Karras sigma ladder, Euler predictor and (Heun,
+    i > 1) trapezoid corrector.  One record per network evaluation; ``t`` is c_noise = ln(sigma)/4 as the backbone's
+    ``map_noise`` sees it, ``alpha`` carries c_in, ``k`` = (c_skip, c_out, sigma, dt, 0):
+        euler  D = clip(k0 x + k1 F);  s = (x - D)/k2;  x <- x - k3 s
+        heun   D = clip(k0 x' + k1 F); s' = (x' - D)/k2; x <- x_old - k3 (s + s')/2     (x' = Euler result)
+    Scalars are produced by the same 0-dim fp32 torch expressions as the reference."""
+    inv_rho = 1 / rho
+    ramp = torch.arange(sample_steps + 1) / sample_steps
+    sigmas = (sigma_min ** inv_rho + ramp * (top_sigma ** inv_rho - sigma_min ** inv_rho)) ** rho
+    sd2 = sigma_data ** 2
+
+    def pre(sig):                                       # sig: 0-dim fp32 tensor, as `t` reaches D() in the reference
+        return (_f(sd2 / (sd2 + sig ** 2)), _f(sig * sigma_data / (sd2 + sig ** 2).sqrt()),
+                _f(1 / (sd2 + sig ** 2).sqrt()), _f(0.25 * sig.log()))
+
+    plan = SamplePlan(solver="edm_" + solver, t_is_integer=False)
+    for i in reversed([1] * diffusion_x_sampling_steps + list(range(1, sample_steps + 1))):
+        sig, sig_prev = sigmas[i], sigmas[i - 1]
+        dt = _f(sig - sig_prev)
+        skip, out, cin, cnoise = pre(sig)
+        corrector = solver == "heun" and i > 1
+        plan.steps.append(Step(KIND_EDM_EULER, V_EPS, i, cnoise, cin, _f(sig), (skip, out, _f(sig), dt, 0.0),
+                               push=corrector))
+        if corrector:
+            sig2 = sig / sig * sig_prev                  # reference: t / sigmas[i] * sigmas[i-1]
+            skip, out, cin, cnoise = pre(sig2)
+            plan.steps.append(Step(KIND_EDM_HEUN, V_EPS, i, cnoise, cin, _f(sig2), (skip, out, _f(sig_prev), dt, 0.0)))
+    return plan

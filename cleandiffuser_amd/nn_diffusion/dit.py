@@ -5,7 +5,9 @@ Interface/checkpoint contract: reference nn_diffusion/dit.py:10-180 (``x_proj``,
 Reference quirk kept on purpose: the block overwrites ``x`` with the *modulated LayerNorm output* before
 the attention residual, i.e. ``x <- mod(LN(x)); x <- x + gate * attn(x)`` -- not the textbook DiT residual.
 
-Status: parameter container + PyTorch execution (token-tiled GEMM/attention kernels are a later row).
+Execution: on a ROCm device without autograd, ``DiT1d.forward`` and every ``sample()`` over it run through
+``engine/bigbatch.py`` -> ``cdx_dit1d_run`` (tiled fp32-MFMA GEMMs with fused epilogues, LayerNorm+modulate, small-T
+attention, csrc/cdx_gemm.hip + cdx_bigbatch.hip); the module code below is the CPU / autograd executor.
 """
 from typing import Optional
 
@@ -94,6 +96,14 @@ class DiT1d(BaseNNDiffusion):
 
     def forward(self, x: torch.Tensor, noise: torch.Tensor, condition: Optional[torch.Tensor] = None):
         """x (b, horizon, in_dim), noise (b,), condition (b, emb_dim)|None -> (b, horizon, in_dim)."""
+        if type(self) is DiT1d:
+            from ..engine import dispatch
+            y = dispatch.try_backbone_forward(self, x, noise, condition)     # GEMM/LN/attention launches on a ROCm device
+            if y is not None:
+                return y
+        return self._forward_torch(x, noise, condition)
+
+    def _forward_torch(self, x, noise, condition=None):
         h = self._tokens(x)
         emb = self._embed(noise, condition)
         for block in self.blocks:

@@ -124,6 +124,13 @@ class IDQLMlp(_ObsConditionedMlp):
         return nn.Linear(hidden_dim, act_dim)
 
     def forward(self, x: torch.Tensor, noise: torch.Tensor, condition: Optional[torch.Tensor] = None):
+        from ..engine import dispatch
+        y = dispatch.try_backbone_forward(self, x, noise, condition)         # cdx_resmlp_run on a ROCm device
+        if y is not None:
+            return y
+        return self._forward_torch(x, noise, condition)
+
+    def _forward_torch(self, x, noise, condition=None):
         return self.affine_out(self.ln_resnet(self.affine_in(self._features(x, noise, condition))))
 
 

@@ -134,6 +134,7 @@ typedef struct cdx_ln_args {
     const float* scale; const float* shift;    /* (M / rows_per_mod, ldmod) or both NULL */
     int32_t M, C, ldx, ldy, ldmod, rows_per_mod;
     float eps;
+    int32_t x_rows;        /* > 0: input row of output row m is m % x_rows (CFG pair sharing one token stream) */
 } cdx_ln_args;
 int cdx_layernorm_f32(const cdx_ln_args* args, void* hip_stream);
 
@@ -149,6 +150,77 @@ int cdx_attention_f32(const cdx_attn_args* args, void* hip_stream);
 
 /* y = act(x) elementwise (batch-invariant embedding vectors: SiLU before adaLN, Mish in map_emb). */
 int cdx_act_f32(const float* x, float* y, long long n, int act, void* hip_stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Big-batch sampling loops (csrc/cdx_bigbatch.hip): the whole `sample()` request for the GEMM-shaped denoisers.
+ * One call enqueues every kernel of every denoising step on the caller's stream (no host synchronisation, no
+ * allocation: the caller owns `workspace`).  The step records are the same cdx_step as above but live in HOST
+ * memory here, because the host sequences the launches.  Two extra kinds serve the EDM solver
+ * (reference diffusion/newedm.py:387-401); for them `alpha` carries c_in (the network sees c_in*x) and
+ *   kind 5 (edm euler)  D = clip(k0*x + k1*F); s = (x - D)/k2; x' = x - k3*s;    push: remember s and x
+ *   kind 6 (edm heun)   D = clip(k0*x + k1*F); s2 = (x - D)/k2; x' = x_old - k3*(s_old + s2)/2
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct cdx_sampling {
+    int32_t batch;             /* trajectories */
+    int32_t hd;                /* floats per trajectory (tokens*in_dim, or the MLP's x dimension) */
+    int32_t emb_dim;           /* width of one `temb` row */
+    int32_t cond_dim;          /* width of one `cond` row (DiT1d: == emb_dim; residual MLP: obs_dim) */
+    const float* temb;         /* device, [max(n_steps,1)][emb_dim] (one row per step record), or [batch][emb_dim] */
+    const cdx_step* steps;     /* HOST, [n_steps]; n_steps == 0: one backbone forward x_out <- network(x_in) */
+    int32_t n_steps, temb_per_sample, predict_noise;
+    int32_t cfg_mode;          /* 0 unconditional, 1 conditional, 2 both: w*c + (1-w)*u on a doubled batch */
+    float cfg_w;
+    const float* cond;         /* device, [batch][cond_dim] or NULL */
+    const float* x_in;         /* (batch, hd) */
+    const float* prior;        /* (batch, hd) or NULL */
+    const float* fix_mask;     /* (hd) or NULL */
+    const float* noise;        /* [n_noise][batch][hd] or NULL */
+    const float* x_min;        /* (hd) or NULL */
+    const float* x_max;        /* (hd) or NULL */
+    float* x_out;              /* (batch, hd) */
+    float* workspace;          /* device scratch, >= cdx_*_workspace_floats() floats */
+    long long workspace_floats;
+    int32_t chunk;             /* trajectories per pass through the loop (0 = whole batch); passes are independent */
+} cdx_sampling;
+
+/* DiT1d (reference nn_diffusion/dit.py:14-36 DiTBlock, :39-50 FinalLayer1d, :53-132 DiT1d): all tensors are the
+ * checkpoint's own (PyTorch layouts), `pos` is the (tokens, d_model) sinusoidal table of dit.py:122-125. */
+typedef struct cdx_dit1d_block {
+    const float *ada_w, *ada_b;       /* adaLN_modulation.1: (6d, d), (6d) */
+    const float *qkv_w, *qkv_b;       /* attn.in_proj_{weight,bias}: (3d, d), (3d) */
+    const float *proj_w, *proj_b;     /* attn.out_proj: (d, d), (d) */
+    const float *fc1_w, *fc1_b;       /* mlp.0: (4d, d), (4d) */
+    const float *fc2_w, *fc2_b;       /* mlp.3: (d, 4d), (d) */
+} cdx_dit1d_block;
+typedef struct cdx_dit1d_weights {
+    int32_t tokens, in_dim, emb_dim, d_model, n_heads, depth;
+    const float *x_proj_w, *x_proj_b; /* (d, in_dim), (d) */
+    const float* pos;                 /* (tokens, d) */
+    const float *map0_w, *map0_b;     /* map_emb.0: (d, emb_dim), (d) */
+    const float *map2_w, *map2_b;     /* map_emb.2: (d, d), (d) */
+    const cdx_dit1d_block* blocks;    /* HOST array [depth] of device pointers */
+    const float *fin_ada_w, *fin_ada_b; /* final_layer.adaLN_modulation.1: (2d, d), (2d) */
+    const float *fin_w, *fin_b;       /* final_layer.linear: (in_dim, d), (in_dim) */
+} cdx_dit1d_weights;
+long long cdx_dit1d_workspace_floats(const cdx_dit1d_weights* w, const cdx_sampling* s);
+int cdx_dit1d_run(const cdx_dit1d_weights* w, const cdx_sampling* s, void* hip_stream);
+
+/* Pre-norm residual MLP = IDQLMlp / NewIDQLMlp (reference nn_diffusion/idqlmlp.py:9-18 ResidualBlock, :21-65, :68-112):
+ * features [x | time_mlp(map_noise(t)) | obs] -> affine_in -> n x (h + fc2(mish(fc1(LN(h))))) -> [mish] -> affine_out.
+ * `temb` of the request is the table AFTER time_mlp (batch-invariant during sampling). */
+typedef struct cdx_resmlp_block {
+    const float *ln_g, *ln_b;         /* net.1: (h), (h) */
+    const float *fc1_w, *fc1_b;       /* net.2: (4h, h), (4h) */
+    const float *fc2_w, *fc2_b;       /* net.4: (h, 4h), (h) */
+} cdx_resmlp_block;
+typedef struct cdx_resmlp_weights {
+    int32_t x_dim, emb_dim, obs_dim, hidden, n_blocks, head_mish;
+    const float *in_w, *in_b;         /* affine_in: (h, x_dim+emb_dim+obs_dim), (h) */
+    const cdx_resmlp_block* blocks;   /* HOST array [n_blocks] of device pointers */
+    const float *out_w, *out_b;       /* affine_out: (x_dim, h), (x_dim) */
+} cdx_resmlp_weights;
+long long cdx_resmlp_workspace_floats(const cdx_resmlp_weights* w, const cdx_sampling* s);
+int cdx_resmlp_run(const cdx_resmlp_weights* w, const cdx_sampling* s, void* hip_stream);
 
 /* Test hook: runs v_mfma_f32_16x16x4_f32 and v_mfma_f32_4x4x1_16b_f32 on fixed operands
  * (digit-coded lane ids, see csrc/cdx_unet1d.hip) and writes out[4][64][4] so the lane->element maps the kernels

@@ -107,6 +107,41 @@ CASES.update({
         sample=dict(solver="ddim", sample_steps=5, w_cfg=1.0)),
 })
 
+# ---- big-batch executors (DiT1d, IDQLMlp/NewIDQLMlp): more solver/guidance combinations + the full-size networks ----
+DIT_SMALL = ("DiT1d", dict(in_dim=7, emb_dim=32, d_model=64, n_heads=4, depth=2, timestep_emb_type="positional"))
+CASES.update({
+    # the config-4 network at its real size (d_model 320, 10 heads of 32, 64 tokens), conditional only, SDE noise
+    "dit_full_ddpm_w1": dict(
+        net=("DiT1d", dict(in_dim=29, emb_dim=128, d_model=320, n_heads=10, depth=2, timestep_emb_type="fourier")),
+        x_shape=(64, 29), batch=2, fix_first_token=True, clip=3.0,
+        cond=("MLPCondition", dict(in_dim=1, out_dim=128, hidden_dims=[128], act="SiLU", dropout=0.25), (1,)),
+        solver=("DiscreteDiffusionSDE", dict(diffusion_steps=20, predict_noise=True)),
+        sample=dict(solver="ddpm", sample_steps=3, w_cfg=1.0, temperature=0.5)),
+    "dit_uncond_sde_dpmpp2m": dict(
+        net=DIT_SMALL, x_shape=(12, 7), batch=5, clip=2.0,
+        solver=("ContinuousDiffusionSDE", dict(predict_noise=False)),
+        sample=dict(solver="sde_dpmsolver++_2M", sample_steps=6)),
+    "dit_ddim_cfg": dict(
+        net=DIT_SMALL, x_shape=(5, 7), batch=4, clip=2.0, cond=("IdentityCondition", dict(dropout=0.0), (32,)),
+        solver=("DiscreteDiffusionSDE", dict(diffusion_steps=30, predict_noise=True)),
+        sample=dict(solver="ddim", sample_steps=5, w_cfg=1.7)),
+    "idql_obs_ddim_cfg": dict(
+        net=("IDQLMlp", dict(obs_dim=11, act_dim=3, emb_dim=16, hidden_dim=64, n_blocks=2)), x_shape=(3,), batch=7,
+        clip=1.0, cond=("IdentityCondition", dict(dropout=0.0), (11,)),
+        solver=("DiscreteDiffusionSDE", dict(diffusion_steps=20, predict_noise=True)),
+        sample=dict(solver="ddim", sample_steps=5, w_cfg=1.5)),
+    # config 5 as the reference pipeline really samples it (synther_d4rl_mujoco.py): DiscreteDiffusionSDE, DDPM steps
+    "newidql_ddpm": dict(
+        net=("NewIDQLMlp", dict(obs_dim=0, act_dim=15, emb_dim=32, hidden_dim=100, n_blocks=3)), x_shape=(15,), batch=9,
+        clip=2.0, solver=("DiscreteDiffusionSDE", dict(diffusion_steps=16, predict_noise=False)),
+        sample=dict(solver="ddpm", sample_steps=16, temperature=0.8)),
+    # the config-5 network at its real size (hidden 1024, 6 blocks, emb 128)
+    "idql_full_edm_euler": dict(
+        net=("IDQLMlp", dict(obs_dim=0, act_dim=15, emb_dim=128, hidden_dim=1024, n_blocks=6)), x_shape=(15,), batch=3,
+        solver=("ContinuousEDM", dict()), sample=dict(solver="euler", sample_steps=4)),
+})
+BIGBATCH_NETS = ("DiT1d", "IDQLMlp", "NewIDQLMlp")
+
 # one small case per solver (discrete + continuous) so every update rule is pinned
 for _s in _ALL_SOLVERS:
     CASES[f"janner_tiny_disc_{_s}"] = dict(
@@ -135,6 +170,8 @@ def lib_namespace(kind: str):
     import importlib
     root = "cleandiffuser_amd" if kind == "amd" else "cleandiffuser"
     ns.DDPM = importlib.import_module(root + ".diffusion.ddpm").DDPM      # legacy class, not exported by the package
+    mlp_mod = "cleandiffuser_amd.nn_diffusion.mlp_backbones" if kind == "amd" else "cleandiffuser.nn_diffusion.idqlmlp"
+    ns.NewIDQLMlp = importlib.import_module(mlp_mod).NewIDQLMlp           # likewise (idqlmlp.py:68)
     return ns
 
 
@@ -199,6 +236,26 @@ def build(lib, name: str, device="cpu", weight_seed: int = 0):
     agent = getattr(lib, c["solver"][0])(net, cond_net, device=device, **kw)
     agent.eval()
     return agent, net
+
+
+def forward_probe(name: str, agent, inputs, device="cpu"):
+    """Inputs of a stand-alone ``backbone.forward`` check with a different timestep per sample:
+    -> (x, t, condition embedding | None).  Used by gen_golden (reference) and the GPU tests (this repo)."""
+    c = CASES[name]
+    b = c["batch"]
+    x = torch.from_numpy(inputs["noise"][-1]).to(device)
+    kind = c["solver"][0]
+    if kind in ("DiscreteDiffusionSDE", "DDPM"):
+        t = ((torch.arange(b) * 7 + 1) % c["solver"][1]["diffusion_steps"]).long().to(device)
+    elif kind == "ContinuousEDM":
+        t = torch.linspace(-1.0, 1.0, b).to(device)
+    else:
+        t = torch.linspace(0.1, 0.9, b).to(device)
+    cond = None
+    if inputs["cond"] is not None:
+        with torch.no_grad():
+            cond = agent.model_ema["condition"](torch.from_numpy(inputs["cond"]).to(device), None)
+    return x, t, cond
 
 
 @contextlib.contextmanager

@@ -35,6 +35,10 @@ def run_reference_case(lib, name: str):
         out = dict(x_out=x.detach().numpy().astype(np.float32), n_draws=np.int64(used["n"]))
         if isinstance(log, dict) and log.get("log_p") is not None:
             out["log_p"] = log["log_p"].detach().numpy().astype(np.float32)
+        if c["net"][0] in cases.BIGBATCH_NETS:   # stand-alone forward with per-sample timesteps
+            fx, ft, fc = cases.forward_probe(name, agent, inp)
+            with torch.no_grad():
+                out["fwd_pred"] = agent.model_ema["diffusion"](fx, ft, fc).numpy().astype(np.float32)
         return out
     # first backbone forward on the initial state, at the first timestep the loop visits
     temp = c["sample"].get("temperature", 1.0)

@@ -81,7 +81,55 @@ def test_backbone_forward_matches_reference(name, amd_lib, monkeypatch):
 
 
 FUSED_CASES = [n for n, c in cases.CASES.items() if c["net"][0] in ("JannerUNet1d", "PearceMlp", "DQLMlp", "ChiUNet1d")]
-TORCH_EXECUTOR_CASES = [n for n in cases.CASES if n not in FUSED_CASES]
+BIGBATCH_CASES = [n for n, c in cases.CASES.items() if c["net"][0] in cases.BIGBATCH_NETS]
+TORCH_EXECUTOR_CASES = [n for n in cases.CASES if n not in FUSED_CASES and n not in BIGBATCH_CASES]
+
+
+def _spy_bigbatch(monkeypatch):
+    from cleandiffuser_amd.engine import bigbatch
+    calls = []
+    orig = bigbatch._run
+
+    def wrapped(kind, *a, **k):
+        calls.append((kind, k["chunk"], k["batch"]))
+        return orig(kind, *a, **k)
+    monkeypatch.setattr(bigbatch, "_run", wrapped)
+    return calls
+
+
+@pytest.mark.parametrize("chunk", [None, 2])
+@pytest.mark.parametrize("name", BIGBATCH_CASES)
+def test_bigbatch_sample_matches_reference_fixture(name, chunk, amd_lib, monkeypatch):
+    """DiT1d / IDQLMlp / NewIDQLMlp: the whole loop is ONE C call (cdx_dit1d_run / cdx_resmlp_run) that enqueues the
+    GEMM / LayerNorm / attention / solver-step kernels; `chunk=2` forces several independent passes over the batch."""
+    from cleandiffuser_amd.engine import bigbatch
+    gold = np.load(golden_path(name))
+    agent, _ = cases.build(amd_lib, name, device=DEV)
+    inp = cases.make_inputs(name)
+    kw = cases.sample_kwargs(name, inp, device=DEV)
+    calls = _spy_bigbatch(monkeypatch)
+    kind = "dit" if cases.CASES[name]["net"][0] == "DiT1d" else "mlp"
+    monkeypatch.setitem(bigbatch.CHUNK_OVERRIDE, kind, chunk)
+    x, _ = agent.sample(torch.from_numpy(inp["prior"]).to(DEV), noise=list(inp["noise"][:int(gold["n_draws"])]), **kw)
+    torch.cuda.synchronize()
+    assert [c[0] for c in calls] == [kind], "exactly one native call for the whole loop"
+    assert x.device.type == "cuda" and x.shape == gold["x_out"].shape
+    np.testing.assert_allclose(x.cpu().numpy(), gold["x_out"], **TOL)
+
+
+@pytest.mark.parametrize("name", BIGBATCH_CASES)
+def test_bigbatch_forward_matches_reference_fixture(name, amd_lib, monkeypatch):
+    """`backbone.forward` with a different timestep per sample (what training-time evaluation and custom loops call)."""
+    gold = np.load(golden_path(name))
+    agent, _ = cases.build(amd_lib, name, device=DEV)
+    inp = cases.make_inputs(name)
+    x, t, cond = cases.forward_probe(name, agent, inp, device=DEV)
+    calls = _spy_bigbatch(monkeypatch)
+    with torch.no_grad():
+        pred = agent.model_ema["diffusion"](x, t, cond)
+    torch.cuda.synchronize()
+    assert len(calls) == 1
+    np.testing.assert_allclose(pred.cpu().numpy(), gold["fwd_pred"], **TOL)
 
 
 @pytest.mark.parametrize("name", TORCH_EXECUTOR_CASES)

@@ -74,3 +74,31 @@ def test_legacy_ddpm_plan_matches_posterior_step(predict_noise, amd_lib):
         mine = k0 * (x - k1 * p) if predict_noise else k0 * (k1 * x + k2 * p)
         assert torch.allclose(mine, mean, rtol=1e-6, atol=1e-6)
         assert abs(float(std) - k3) < 1e-7
+
+
+@pytest.mark.parametrize("name", ["idql_cfg5_edm_euler", "idql_cfg5_edm_heun"])
+def test_edm_plan_records_reproduce_reference(name, amd_lib):
+    """The cdx_step records of build_edm_plan (kinds 5/6), applied with plain torch arithmetic exactly as
+    csrc/cdx_bigbatch.hip's solver_step_kernel applies them, land on the real reference's samples."""
+    from cleandiffuser_amd.engine.plan import KIND_EDM_EULER, build_edm_plan
+    gold = np.load(golden_path(name))
+    c = cases.CASES[name]
+    agent, net = cases.build(amd_lib, name)
+    inp = cases.make_inputs(name)
+    plan = build_edm_plan(agent.sigma_data, agent.sigma_min, agent.sigma_max, agent.rho, c["sample"]["sample_steps"],
+                          c["sample"]["solver"], c["sample"].get("diffusion_x_sampling_steps", 0))
+    x = torch.from_numpy(inp["noise"][0]) * agent.sigma_max * c["sample"].get("temperature", 1.0)
+    slope_old = x_old = None
+    with torch.no_grad():
+        for st in plan.steps:
+            t = torch.full((x.shape[0],), st.t, dtype=torch.float32)
+            F = net(st.alpha * x, t, None)
+            d = st.k[0] * x + st.k[1] * F
+            s = (x - d) / st.k[2]
+            if st.kind == KIND_EDM_EULER:
+                if st.push:
+                    slope_old, x_old = s, x
+                x = x - s * st.k[3]
+            else:
+                x = x_old - (slope_old + s) / 2.0 * st.k[3]
+    np.testing.assert_allclose(x.numpy(), gold["x_out"], rtol=1e-4, atol=1e-4)
