@@ -15,6 +15,7 @@
 // their own).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/cdx.h"
@@ -41,44 +42,175 @@ __device__ __forceinline__ float gm_act(float x, int act) {
         case CDX_ACT_LEAKY: return x > 0.f ? x : 0.01f * x;
         case CDX_ACT_SILU: return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
         case CDX_ACT_RELU: return fmaxf(x, 0.f);
-        case CDX_ACT_GELU_TANH: return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+        case CDX_ACT_GELU_TANH: {                        // 0.5 x (1 + tanh u) == x * sigmoid(2u): one v_exp, one v_rcp, no branches
+            const float u2 = 1.5957691216057308f * (x + 0.044715f * x * x * x);
+            return x * __builtin_amdgcn_rcpf(1.0f + __expf(-u2));
+        }
         default: return x;
     }
 }
 
-// load 4 consecutive K values of one row (zero beyond the matrix edge)
-template <bool VEC>
-__device__ __forceinline__ float4 gm_load4(const float* __restrict__ base, int row, int rows, int k, int K, int ld) {
+// load 4 consecutive K values of one row (zero beyond the matrix edge) -- general path only
+__device__ __forceinline__ float4 gm_load4_guarded(const float* __restrict__ base, int row, int rows, int k, int K, int ld) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row < rows) {
         const float* p = base + (size_t)row * ld + k;
-        if (VEC) {
-            if (k + 3 < K) v = *reinterpret_cast<const float4*>(p);
-            else {
-                if (k < K) v.x = p[0];
-                if (k + 1 < K) v.y = p[1];
-                if (k + 2 < K) v.z = p[2];
-            }
-        } else {
-            if (k < K) v.x = p[0];
-            if (k + 1 < K) v.y = p[1];
-            if (k + 2 < K) v.z = p[2];
-            if (k + 3 < K) v.w = p[3];
-        }
+        if (k < K) v.x = p[0];
+        if (k + 1 < K) v.y = p[1];
+        if (k + 2 < K) v.z = p[2];
+        if (k + 3 < K) v.w = p[3];
     }
     return v;
 }
 
-template <bool VEC>
-__global__ __launch_bounds__(GM_THREADS) void cdx_gemm_kernel(const cdx_gemm_args g) {
-    __shared__ __attribute__((aligned(16))) float As[GM_BK][GM_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[GM_BK][GM_LD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// exact m / d and m % d for 0 <= m < 2^31 from a float reciprocal (one multiply + two fix-ups instead of a ~40-instruction
+// integer division per output element)
+__device__ __forceinline__ void gm_divmod(int m, int d, float inv, int& q, int& r) {
+    q = (int)((float)m * inv);
+    r = m - q * d;
+    if (r < 0) { r += d; --q; }
+    if (r >= d) { r -= d; ++q; }
+}
+
+template <int ACT>
+__device__ __forceinline__ float gm_act_t(float x) { return gm_act(x, ACT); }
+
+// Epilogue of one wave's 64 x 64 sub-tile.  D fragment of 32x32x2: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+template <int ACT>
+__device__ __forceinline__ void gm_epilogue(const cdx_gemm_args& g, const f32x16 (&acc)[2][2], int row0, int col0, int lr, int lk) {
+    const float inv_gate = g.gate ? 1.0f / (float)g.rows_per_gate : 0.f;
+    const float inv_tab = g.table ? 1.0f / (float)g.table_rows : 0.f;
+    const int n0 = col0 + lr, n1 = n0 + 32;
+    const bool ok0 = n0 < g.N, ok1 = n1 < g.N;
+    const float bias0 = (g.bias && ok0) ? g.bias[n0] : 0.f, bias1 = (g.bias && ok1) ? g.bias[n1] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = row0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (m >= g.M) continue;
+            float v0 = gm_act_t<ACT>(acc[mi][0][r] + bias0), v1 = gm_act_t<ACT>(acc[mi][1][r] + bias1);
+            if (g.gate) {
+                int q, rem;
+                gm_divmod(m, g.rows_per_gate, inv_gate, q, rem);
+                const float* gp = g.gate + (size_t)q * g.ldg;
+                if (ok0) v0 *= gp[n0];
+                if (ok1) v1 *= gp[n1];
+            }
+            if (g.residual) {
+                const float* rp = g.residual + (size_t)m * g.ldr;
+                if (ok0) v0 += rp[n0];
+                if (ok1) v1 += rp[n1];
+            }
+            if (g.table) {
+                int q, rem;
+                gm_divmod(m, g.table_rows, inv_tab, q, rem);
+                const float* tp = g.table + (size_t)rem * g.N;
+                if (ok0) v0 += tp[n0];
+                if (ok1) v1 += tp[n1];
+            }
+            float* cp = g.C + (size_t)m * g.ldc;
+            if (ok0) cp[n0] = v0;
+            if (ok1) cp[n1] = v1;
+        }
+    }
+}
+
+// Fast epilogue (N, ldc, ldr, ldg multiples of 4; 16-byte aligned bases): each 32 x 32 MFMA block goes through a wave-private LDS
+// patch so that a lane ends up with 4 consecutive columns -> gate / residual / table are read and C is written with 16-byte
+// accesses, loads are unconditional (clamped addresses) and issued together, only the store is predicated.
+#define GM_EP_LD 36
+template <int ACT>
+__device__ __forceinline__ void gm_epilogue_fast(const cdx_gemm_args& g, const f32x16 (&acc)[2][2], float* __restrict__ patch,
+                                                 int row0, int col0, int lane) {
+    const int lr = lane & 31, lk = lane >> 5;
+    const int prow = lane >> 3, pc4 = (lane & 7) * 4;
+    const float inv_gate = g.gate ? 1.0f / (float)g.rows_per_gate : 0.f;
+    const float inv_tab = g.table ? 1.0f / (float)g.table_rows : 0.f;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int nb = col0 + ni * 32;
+        const float bias = (g.bias && nb + lr < g.N) ? g.bias[nb + lr] : 0.f;
+        const int n = nb + pc4;
+        const bool n_ok = n < g.N;
+        const int nc = n_ok ? n : 0;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                patch[((r & 3) + 8 * (r >> 2) + 4 * lk) * GM_EP_LD + lr] = gm_act_t<ACT>(acc[mi][ni][r] + bias);
+#pragma unroll
+            for (int jh = 0; jh < 4; jh += 2) {            // two rows per lane at a time keeps the epilogue under the K loop's VGPRs
+                __builtin_amdgcn_sched_barrier(0);         // and the scheduler must not hoist later blocks' loads above this one
+                float4 v[2], gt[2], rs[2], tb[2];
+                int mrow[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    mrow[j] = row0 + mi * 32 + prow + 8 * (jh + j);
+                    const int mc = min(mrow[j], g.M - 1);
+                    if (g.gate) {
+                        int q, rem;
+                        gm_divmod(mc, g.rows_per_gate, inv_gate, q, rem);
+                        gt[j] = *reinterpret_cast<const float4*>(g.gate + (size_t)q * g.ldg + nc);
+                    }
+                    if (g.residual) rs[j] = *reinterpret_cast<const float4*>(g.residual + (size_t)mc * g.ldr + nc);
+                    if (g.table) {
+                        int q, rem;
+                        gm_divmod(mc, g.table_rows, inv_tab, q, rem);
+                        tb[j] = *reinterpret_cast<const float4*>(g.table + (size_t)rem * g.N + nc);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    v[j] = *reinterpret_cast<const float4*>(patch + (prow + 8 * (jh + j)) * GM_EP_LD + pc4);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (g.gate) { v[j].x *= gt[j].x; v[j].y *= gt[j].y; v[j].z *= gt[j].z; v[j].w *= gt[j].w; }
+                    if (g.residual) { v[j].x += rs[j].x; v[j].y += rs[j].y; v[j].z += rs[j].z; v[j].w += rs[j].w; }
+                    if (g.table) { v[j].x += tb[j].x; v[j].y += tb[j].y; v[j].z += tb[j].z; v[j].w += tb[j].w; }
+                    if (n_ok && mrow[j] < g.M) *reinterpret_cast<float4*>(g.C + (size_t)mrow[j] * g.ldc + n) = v[j];
+                }
+            }
+        }
+    }
+}
+
+template <int ACT>
+__device__ __forceinline__ void gm_epilogue_any(const cdx_gemm_args& g, const f32x16 (&acc)[2][2], float* patch, int row0, int col0,
+                                                int lane, bool fast) {
+    if (fast) gm_epilogue_fast<ACT>(g, acc, patch, row0, col0, lane);
+    else gm_epilogue<ACT>(g, acc, row0, col0, lane & 31, lane >> 5);
+}
+
+// Optional timeline trace (tools/gemm_trace.py): [blockIdx][4] x u64 = {s_memtime at start, first tile landed, K loop done,
+// epilogue done}, lane 0 only; off unless cdx_gemm_set_trace() installed a buffer.
+__device__ unsigned long long* gm_trace = nullptr;
+__device__ __forceinline__ void gm_stamp(int slot) {
+    if (gm_trace != nullptr && threadIdx.x == 0) gm_trace[(size_t)blockIdx.x * 4 + slot] = __builtin_amdgcn_s_memtime();
+}
+
+// FAST: K % 16 == 0, 16-byte aligned rows -> unguarded global_load_dwordx4 (rows beyond the edge are clamped: they only
+// feed outputs that are never stored).  !FAST: fully guarded scalar loads (K = 29 input projections and the like).
+template <bool FAST>
+__global__ __launch_bounds__(GM_THREADS, 3) void cdx_gemm_kernel(const cdx_gemm_args g, const int stagger, const int fast_ep) {
+    // one LDS arena: A/B staging tiles during the K loop, then 4 wave-private 32 x 36 transposition patches
+    __shared__ __attribute__((aligned(16))) float smem[4 * GM_BK * GM_LD];   // [stage][A | B][k][row]; 33 KiB >= 4 * 32 * GM_EP_LD
+    float (*As)[GM_LD] = reinterpret_cast<float (*)[GM_LD]>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // column-major walk over tiles: consecutive workgroups share the W panel (small N) and stream A
     const int tiles_m = (g.M + GM_BM - 1) / GM_BM;
     const int bm = (blockIdx.x % tiles_m) * GM_BM, bn = (blockIdx.x / tiles_m) * GM_BN;
     const int lrow = tid & 127, kq = tid >> 7;          // this thread stages row `lrow`, k quads kq and kq + 2
 
+    // First-wave stagger: the 3 workgroups that share a CU (dispatch order: b, b + 256, b + 512) would otherwise run their
+    // K loops and their store-heavy epilogues in lockstep, leaving the MFMA pipe idle during every epilogue.  Delaying the
+    // 2nd/3rd by 1/3, 2/3 of a tile time once shifts their phases for the whole launch (later workgroups inherit the slot).
+    if (stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 768) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        const unsigned long long wait = (unsigned long long)stagger * (blockIdx.x >> 8);
+        while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+    }
+    gm_stamp(0);
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -87,60 +219,86 @@ __global__ __launch_bounds__(GM_THREADS) void cdx_gemm_kernel(const cdx_gemm_arg
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra0 = gm_load4<VEC>(g.A, bm + lrow, g.M, kq * 4, g.K, g.lda);
-    float4 ra1 = gm_load4<VEC>(g.A, bm + lrow, g.M, 8 + kq * 4, g.K, g.lda);
-    float4 rb0 = gm_load4<VEC>(g.W, bn + lrow, g.N, kq * 4, g.K, g.ldw);
-    float4 rb1 = gm_load4<VEC>(g.W, bn + lrow, g.N, 8 + kq * 4, g.K, g.ldw);
+    const int arow = FAST ? min(bm + lrow, g.M - 1) : bm + lrow, wrow = FAST ? min(bn + lrow, g.N - 1) : bn + lrow;
+    const float* ap = g.A + (size_t)arow * g.lda + kq * 4;
+    const float* wp = g.W + (size_t)wrow * g.ldw + kq * 4;
+    float4 ra0, ra1, rb0, rb1;
+    auto fetch = [&](int kt) {                           // global -> registers: k columns [kt, kt + 16) of this thread's row
+        if (FAST) {
+            ra0 = *reinterpret_cast<const float4*>(ap + kt);
+            ra1 = *reinterpret_cast<const float4*>(ap + kt + 8);
+            rb0 = *reinterpret_cast<const float4*>(wp + kt);
+            rb1 = *reinterpret_cast<const float4*>(wp + kt + 8);
+        } else {
+            ra0 = gm_load4_guarded(g.A, arow, g.M, kt + kq * 4, g.K, g.lda);
+            ra1 = gm_load4_guarded(g.A, arow, g.M, kt + 8 + kq * 4, g.K, g.lda);
+            rb0 = gm_load4_guarded(g.W, wrow, g.N, kt + kq * 4, g.K, g.ldw);
+            rb1 = gm_load4_guarded(g.W, wrow, g.N, kt + 8 + kq * 4, g.K, g.ldw);
+        }
+    };
+    auto stage = [&](int buf) {                          // registers -> LDS stage `buf`, transposed to [k][row]
+        float (*Ad)[GM_LD] = As + buf * (2 * GM_BK);
+        float (*Bd)[GM_LD] = Ad + GM_BK;
+        const int ka = kq * 4, kb = 8 + kq * 4;
+        Ad[ka + 0][lrow] = ra0.x; Ad[ka + 1][lrow] = ra0.y; Ad[ka + 2][lrow] = ra0.z; Ad[ka + 3][lrow] = ra0.w;
+        Ad[kb + 0][lrow] = ra1.x; Ad[kb + 1][lrow] = ra1.y; Ad[kb + 2][lrow] = ra1.z; Ad[kb + 3][lrow] = ra1.w;
+        Bd[ka + 0][lrow] = rb0.x; Bd[ka + 1][lrow] = rb0.y; Bd[ka + 2][lrow] = rb0.z; Bd[ka + 3][lrow] = rb0.w;
+        Bd[kb + 0][lrow] = rb1.x; Bd[kb + 1][lrow] = rb1.y; Bd[kb + 2][lrow] = rb1.z; Bd[kb + 3][lrow] = rb1.w;
+    };
 
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const int lr = lane & 31, lk = lane >> 5;
-    for (int k0 = 0; k0 < g.K; k0 += GM_BK) {
-        __syncthreads();                                 // previous tile fully consumed
-        {
-            const int ka = kq * 4, kb = 8 + kq * 4;
-            As[ka + 0][lrow] = ra0.x; As[ka + 1][lrow] = ra0.y; As[ka + 2][lrow] = ra0.z; As[ka + 3][lrow] = ra0.w;
-            As[kb + 0][lrow] = ra1.x; As[kb + 1][lrow] = ra1.y; As[kb + 2][lrow] = ra1.z; As[kb + 3][lrow] = ra1.w;
-            Bs[ka + 0][lrow] = rb0.x; Bs[ka + 1][lrow] = rb0.y; Bs[ka + 2][lrow] = rb0.z; Bs[ka + 3][lrow] = rb0.w;
-            Bs[kb + 0][lrow] = rb1.x; Bs[kb + 1][lrow] = rb1.y; Bs[kb + 2][lrow] = rb1.z; Bs[kb + 3][lrow] = rb1.w;
-        }
-        __syncthreads();
-        const int kn = k0 + GM_BK;                       // prefetch the next tile under this tile's MFMAs
-        if (kn < g.K) {
-            ra0 = gm_load4<VEC>(g.A, bm + lrow, g.M, kn + kq * 4, g.K, g.lda);
-            ra1 = gm_load4<VEC>(g.A, bm + lrow, g.M, kn + 8 + kq * 4, g.K, g.lda);
-            rb0 = gm_load4<VEC>(g.W, bn + lrow, g.N, kn + kq * 4, g.K, g.ldw);
-            rb1 = gm_load4<VEC>(g.W, bn + lrow, g.N, kn + 8 + kq * 4, g.K, g.ldw);
-        }
+    const int nk = (g.K + GM_BK - 1) / GM_BK;
+
+    // Two LDS stages, ONE barrier per 16-wide K tile: while the MFMAs of tile t run out of stage t & 1, the registers
+    // holding tile t + 1 (fetched a whole tile earlier) are written to the other stage and tile t + 2 is requested.
+    fetch(0);
+    stage(0);
+    if (nk > 1) fetch(GM_BK);
+    __syncthreads();
+    gm_stamp(1);
+    for (int t = 0; t < nk; ++t) {
+        const float (*Ac)[GM_LD] = As + (t & 1) * (2 * GM_BK);
+        const float (*Bc)[GM_LD] = Ac + GM_BK;
+        // operands of the next k pair are read from LDS before the MFMAs of the current one are issued
+        float a0 = Ac[lk][wm + lr], a1 = Ac[lk][wm + 32 + lr], b0 = Bc[lk][wn + lr], b1 = Bc[lk][wn + 32 + lr];
 #pragma unroll
         for (int kk = 0; kk < GM_BK; kk += 2) {
-            const float a0 = As[kk + lk][wm + lr], a1 = As[kk + lk][wm + 32 + lr];
-            const float b0 = Bs[kk + lk][wn + lr], b1 = Bs[kk + lk][wn + 32 + lr];
+            float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+            if (kk + 2 < GM_BK) {
+                na0 = Ac[kk + 2 + lk][wm + lr]; na1 = Ac[kk + 2 + lk][wm + 32 + lr];
+                nb0 = Bc[kk + 2 + lk][wn + lr]; nb1 = Bc[kk + 2 + lk][wn + 32 + lr];
+            }
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            if (kk == 4 && t + 1 < nk) {                 // mid-tile: park tile t + 1 in the other stage, request tile t + 2
+                stage((t + 1) & 1);
+                if (t + 2 < nk) fetch((t + 2) * GM_BK);
+            }
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
         }
+        __syncthreads();                                 // stage (t+1)&1 complete, stage t&1 free for tile t + 2
     }
 
-    // epilogue: D fragment of 32x32x2 -- col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int n = bn + wn + ni * 32 + lr;
-            if (n >= g.N) continue;
-            const float bias = g.bias ? g.bias[n] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = bm + wm + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (m >= g.M) continue;
-                float v = gm_act(acc[mi][ni][r] + bias, g.act);
-                if (g.gate) v *= g.gate[(size_t)(m / g.rows_per_gate) * g.ldg + n];
-                if (g.residual) v += g.residual[(size_t)m * g.ldr + n];
-                if (g.table) v += g.table[(size_t)(m % g.table_rows) * g.N + n];
-                g.C[(size_t)m * g.ldc + n] = v;
-            }
-        }
+    asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[1][1][15]));
+    gm_stamp(2);
+    // (the loop's last barrier already separates the final LDS reads from the patches written below)
+    // fused epilogue, one specialisation per activation (the branch is uniform; only the taken copy touches the I-cache)
+    const int row0 = bm + wm, col0 = bn + wn;
+    float* patch = smem + wave * (32 * GM_EP_LD);
+    const bool fe = fast_ep != 0;
+    switch (g.act) {
+        case CDX_ACT_MISH: gm_epilogue_any<CDX_ACT_MISH>(g, acc, patch, row0, col0, lane, fe); break;
+        case CDX_ACT_GELU_ERF: gm_epilogue_any<CDX_ACT_GELU_ERF>(g, acc, patch, row0, col0, lane, fe); break;
+        case CDX_ACT_LEAKY: gm_epilogue_any<CDX_ACT_LEAKY>(g, acc, patch, row0, col0, lane, fe); break;
+        case CDX_ACT_SILU: gm_epilogue_any<CDX_ACT_SILU>(g, acc, patch, row0, col0, lane, fe); break;
+        case CDX_ACT_RELU: gm_epilogue_any<CDX_ACT_RELU>(g, acc, patch, row0, col0, lane, fe); break;
+        case CDX_ACT_GELU_TANH: gm_epilogue_any<CDX_ACT_GELU_TANH>(g, acc, patch, row0, col0, lane, fe); break;
+        default: gm_epilogue_any<CDX_ACT_NONE>(g, acc, patch, row0, col0, lane, fe); break;
+    }
+    gm_stamp(3);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -202,12 +360,13 @@ __global__ __launch_bounds__(64) void cdx_attention_kernel(const cdx_attn_args a
     const int b = blockIdx.x / a.n_heads, h = blockIdx.x % a.n_heads;
     const int dh = a.head_dim, dm = a.n_heads * a.head_dim;
     const size_t row0 = (size_t)b * a.T;
-    for (int i = t; i < a.T * dh; i += 64) {
+    for (int i = t; i < 64 * dh; i += 64) {              // rows >= T are zero-filled: 0 * stale-LDS NaN must not leak
         const int tok = i / dh, d = i - tok * dh;
-        const float* base = a.qkv + (row0 + tok) * (size_t)(3 * dm) + h * dh + d;
-        Qs[tok][d] = base[0] * a.scale;
-        Ks[tok][d] = base[dm];
-        Vs[tok][d] = base[2 * dm];
+        const bool live = tok < a.T;
+        const float* base = a.qkv + (row0 + (live ? tok : 0)) * (size_t)(3 * dm) + h * dh + d;
+        Qs[tok][d] = live ? base[0] * a.scale : 0.f;
+        Ks[tok][d] = live ? base[dm] : 0.f;
+        Vs[tok][d] = live ? base[2 * dm] : 0.f;
     }
     __syncthreads();
     if (t >= a.T) return;
@@ -260,13 +419,25 @@ int cdx_gemm_f32(const cdx_gemm_args* g, void* hip_stream) {
         cdx_set_err("cdx_gemm_f32: gate/table need a positive row period"); return CDX_EINVAL;
     }
     const int tiles = ((g->M + GM_BM - 1) / GM_BM) * ((g->N + GM_BN - 1) / GM_BN);
-    const bool vec = (g->K % 4 == 0) && (g->lda % 4 == 0) && (g->ldw % 4 == 0) &&
+    const bool vec = (g->K % GM_BK == 0) && (g->lda % 4 == 0) && (g->ldw % 4 == 0) &&
                      (((uintptr_t)g->A | (uintptr_t)g->W) % 16 == 0);
     hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
-    if (vec) hipLaunchKernelGGL(cdx_gemm_kernel<true>, dim3(tiles), dim3(GM_THREADS), 0, s, *g);
-    else hipLaunchKernelGGL(cdx_gemm_kernel<false>, dim3(tiles), dim3(GM_THREADS), 0, s, *g);
+    static const char* env = getenv("CDX_GEMM_STAGGER");          // tuning hook: cycles per phase class, 0 = off
+    int stagger = 0;
+    if (tiles >= 2 * 768 && env) stagger = atoi(env);
+    const uintptr_t ep_ptrs = (uintptr_t)g->C | (uintptr_t)g->gate | (uintptr_t)g->residual | (uintptr_t)g->table;
+    const int fast_ep = (g->N % 4 == 0) && (g->ldc % 4 == 0) && (!g->gate || g->ldg % 4 == 0) &&
+                        (!g->residual || g->ldr % 4 == 0) && (ep_ptrs % 16 == 0);
+    if (vec) hipLaunchKernelGGL(cdx_gemm_kernel<true>, dim3(tiles), dim3(GM_THREADS), 0, s, *g, stagger, fast_ep);
+    else hipLaunchKernelGGL(cdx_gemm_kernel<false>, dim3(tiles), dim3(GM_THREADS), 0, s, *g, stagger, fast_ep);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
+    return CDX_OK;
+}
+
+int cdx_gemm_set_trace(unsigned long long* device_buffer) {
+    unsigned long long* p = device_buffer;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(gm_trace), &p, sizeof(p)) != hipSuccess) { cdx_set_err("cdx_gemm_set_trace failed"); return CDX_EHIP; }
     return CDX_OK;
 }
 

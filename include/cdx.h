@@ -222,6 +222,10 @@ typedef struct cdx_resmlp_weights {
 long long cdx_resmlp_workspace_floats(const cdx_resmlp_weights* w, const cdx_sampling* s);
 int cdx_resmlp_run(const cdx_resmlp_weights* w, const cdx_sampling* s, void* hip_stream);
 
+/* Profiling hook: device buffer of [n_workgroups][4] u64 that every following cdx_gemm_f32 launch stamps with s_memtime
+ * (start, first tile staged, K loop done, epilogue done); NULL switches it off.  Synchronise before changing it. */
+int cdx_gemm_set_trace(unsigned long long* device_buffer);
+
 /* Test hook: runs v_mfma_f32_16x16x4_f32 and v_mfma_f32_4x4x1_16b_f32 on fixed operands
  * (digit-coded lane ids, see csrc/cdx_unet1d.hip) and writes out[4][64][4] so the lane->element maps the kernels
  * rely on are checked on the actual silicon. */

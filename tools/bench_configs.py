@@ -1,5 +1,6 @@
-"""Secondary measurements: BASELINE configs 1 and 3 through the fused kernel (bench.py stays the config-2 contract).
-Usage (GPU box): python tools/bench_configs.py [cfg1|cfg3 ...]   -> one JSON line per config."""
+"""Secondary measurements: BASELINE configs 1 and 3 through the fused kernel, 4 and 5 (one GPU's shard) through the
+big-batch executors (bench.py stays the config-2 contract).
+Usage (GPU box): python tools/bench_configs.py [cfg1|cfg3|cfg4[:B]|cfg5[:B] ...]   -> one JSON line per config."""
 import json
 import os
 import sys
@@ -49,6 +50,66 @@ def cfg3():
 from cleandiffuser_amd.engine.program import MLP_TILE as P_TILE  # noqa: E402
 
 
+def _time_calls(call, reps):
+    x = call()
+    torch.cuda.synchronize()
+    assert torch.isfinite(x).all()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        call()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def cfg4(B=512):
+    """Config 4: DiT1d Decision Diffuser (d_model 320, 10 heads, depth 2, 64 tokens x 29), CFG w = 2 (doubled batch),
+    10-step DPM-Solver++(2M).  BASELINE shards B = 4096 over 8 GPUs -> 512 trajectories per GPU."""
+    from cleandiffuser_amd.diffusion import ContinuousDiffusionSDE
+    from cleandiffuser_amd.nn_condition import MLPCondition
+    from cleandiffuser_amd.nn_diffusion import DiT1d
+    T, D, d, depth, steps = 64, 29, 320, 2, 10
+    net = load_synth(DiT1d(D, emb_dim=128, d_model=d, n_heads=10, depth=depth, timestep_emb_type="fourier"))
+    cond = load_synth(MLPCondition(1, 128, [128], torch.nn.SiLU(), dropout=0.25), 2)
+    fix = torch.zeros(T, D)
+    fix[0] = 1.0
+    agent = ContinuousDiffusionSDE(net, cond, fix_mask=fix, predict_noise=True, noise_schedule="linear",
+                                   x_max=3 * torch.ones(1, T, D), x_min=-3 * torch.ones(1, T, D), device=DEV)
+    agent.eval()
+    prior = torch.zeros(B, T, D, device=DEV)
+    prior[:, 0] = torch.randn(B, D, device=DEV)
+    ret = torch.rand(B, 1, device=DEV)
+    z = [torch.randn(B, T, D, device=DEV)]
+    call = lambda: agent.sample(prior, solver="ode_dpmsolver++_2M", n_samples=B, sample_steps=steps, w_cfg=2.0,  # noqa: E731
+                                temperature=0.5, condition_cfg=ret, noise=z)[0]
+    tok_macs = D * d + depth * (3 * d * d + d * d + 8 * d * d) + depth * 2 * T * d + d * D   # per token, attention incl.
+    smp_macs = 128 * d + d * d + depth * 6 * d * d + 2 * d * d                              # per (doubled) sample
+    flops = 2.0 * (tok_macs * T + smp_macs) * 2 * steps * B
+    return f"config 4 shard: DiT1d d=320 h=10 depth=2, H=64 D=29, CFG w=2, 10-step dpmsolver++2M, B={B}", call, B, flops
+
+
+def cfg5(B=131072, steps=128):
+    """Config 5: SynthER residual MLP (IDQLMlp hidden 1024 x 6 blocks, emb 128, D = 15), 128-step EDM Euler.
+    BASELINE shards B = 1 M over 8 GPUs -> 131072 samples per GPU."""
+    from cleandiffuser_amd.diffusion import ContinuousEDM
+    from cleandiffuser_amd.nn_diffusion import IDQLMlp
+    D, H, nb = 15, 1024, 6
+    net = load_synth(IDQLMlp(0, D, emb_dim=128, hidden_dim=H, n_blocks=nb))
+    agent = ContinuousEDM(net, None, device=DEV)
+    agent.eval()
+    z = [torch.randn(B, D, device=DEV)]
+    call = lambda: agent.sample(torch.zeros(B, D, device=DEV), solver="euler", n_samples=B, sample_steps=steps,  # noqa: E731
+                                noise=z)[0]
+    macs = (D + 128) * H + nb * 8 * H * H + H * D
+    return f"config 5 shard: IDQLMlp 1024x6, D=15, {steps}-step EDM Euler, B={B}", call, B, 2.0 * macs * steps * B
+
+
+def run_big(name, fn, reps=2, **kw):
+    label, call, B, flops = fn(**kw)
+    dt = _time_calls(call, reps)
+    print(json.dumps({"config": label, "samples_per_s": B / dt, "ms_per_call": 1e3 * dt, "tflops": flops / dt / 1e12,
+                      "frac_fp32_mfma_peak": flops / dt / 1e12 / PEAK}), flush=True)
+
+
 def run(name, fn, reps=3):
     label, call, B, steps, net, horizon = fn()
     x = call()
@@ -74,4 +135,8 @@ def run(name, fn, reps=3):
 
 if __name__ == "__main__":
     for name in (sys.argv[1:] or ["cfg1", "cfg3"]):
-        run(name, {"cfg1": cfg1, "cfg3": cfg3}[name])
+        if name.startswith("cfg4") or name.startswith("cfg5"):       # e.g. cfg4, cfg4:4096, cfg5:16384
+            base, _, b = name.partition(":")
+            run_big(name, {"cfg4": cfg4, "cfg5": cfg5}[base], **({"B": int(b)} if b else {}))
+        else:
+            run(name, {"cfg1": cfg1, "cfg3": cfg3}[name])
