@@ -22,11 +22,15 @@ namespace {
 // Embedding rows of one chunk:  out[r] = temb[row(r)] + (conditional half ? cond[b0 + r] : 0)
 // (reference dit.py:127-131: emb = map_noise(t); emb += condition | zeros)
 // ------------------------------------------------------------------------------------------------
+// All step records of a chunk at once: row (rec * rows + r).  The embedding path does not depend on the state x, so the
+// whole map_emb / adaLN chain of every denoising step is evaluated BEFORE the loop as a few tall GEMMs.
 __global__ void emb_rows_kernel(float* __restrict__ out, const float* __restrict__ temb, const float* __restrict__ cond,
-                                int rows, int nb, int b0, int E, int rec, int per_sample, int n_cond_rows) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * E) return;
-    const int r = i / E, e = i - r * E;
+                                int n_rec, int rows, int nb, int b0, int E, int per_sample, int n_cond_rows) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n_rec * rows * E) return;
+    const int e = (int)(i % E);
+    const int rr = (int)(i / E);
+    const int rec = rr / rows, r = rr - rec * rows;
     const int s = b0 + (r % nb);
     float v = temb[(size_t)(per_sample ? s : rec) * E + e];
     if (cond != nullptr && r < n_cond_rows) v += cond[(size_t)s * E + e];
@@ -40,9 +44,9 @@ __global__ void mlp_features_kernel(float* __restrict__ out, const float* __rest
                                     const float* __restrict__ cond, int rows, int nb, int b0, int D, int E, int O,
                                     int rec, int per_sample, int n_cond_rows, float in_scale) {
     const int F = D + E + O;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * F) return;
-    const int r = i / F, c = i - r * F;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)rows * F) return;
+    const int r = (int)(i / F), c = (int)(i - (size_t)r * F);
     const int l = r % nb, s = b0 + l;
     float v;
     if (c < D) v = in_scale * x[(size_t)l * D + c];
@@ -218,15 +222,16 @@ struct DitBuffers {
 long long dit_layout(const cdx_dit1d_weights* w, const cdx_sampling* s, float* base, DitBuffers* B) {
     const long long nb = chunk_of(s), bf = nb * (s->cfg_mode == 2 ? 2 : 1);
     const long long T = w->tokens, d = w->d_model, rows = bf * T;
+    const long long n_rec = s->n_steps > 0 ? s->n_steps : 1, er = n_rec * bf;    // embedding rows: every record of the chunk
     Arena a{base, 0, 0};
     DitBuffers b;
     b.x = a.take(nb * s->hd);
     b.prev = a.take(nb * s->hd);
-    b.emb0 = a.take(bf * w->emb_dim);
-    b.e1 = a.take(bf * d);
-    b.emb = a.take(bf * d);
-    b.semb = a.take(bf * d);
-    b.ada = a.take(bf * 6 * d);
+    b.emb0 = a.take(er * w->emb_dim);
+    b.e1 = a.take(er * d);
+    b.emb = a.take(er * d);
+    b.semb = a.take(er * d);
+    b.ada = a.take(er * (6 * d * w->depth + 2 * d));
     b.h0 = a.take(nb * T * d);
     b.xm = a.take(rows * d);
     b.qkv = a.take(rows * 3 * d);
@@ -252,20 +257,34 @@ int dit_check(const cdx_dit1d_weights* w, const cdx_sampling* s) {
     return CDX_OK;
 }
 
-int dit_forward(const cdx_dit1d_weights* w, const cdx_sampling* s, hipStream_t st, const DitBuffers& B, const float* x,
-                float* pred, int nb, int b0, int rec) {
+// adaLN table of a chunk: for every step record, (bf, 6 d depth + 2 d) = [block 0: shift_a scale_a gate_a shift_m scale_m gate_m |
+// block 1 ... | final: shift scale]   (reference dit.py:31, 47 evaluated once per record instead of once per block call)
+int dit_prepare(const cdx_dit1d_weights* w, const cdx_sampling* s, hipStream_t st, const DitBuffers& B, int nb, int b0) {
     const int two = s->cfg_mode == 2 ? 2 : 1, bf = nb * two;
-    const int T = w->tokens, d = w->d_model, E = w->emb_dim, rows = bf * T;
+    const int d = w->d_model, E = w->emb_dim, n_rec = s->n_steps > 0 ? s->n_steps : 1, er = n_rec * bf;
+    const int ntot = 6 * d * w->depth + 2 * d;
     const int n_cond_rows = (s->cond == nullptr || s->cfg_mode == 0) ? 0 : nb;   // conditional half comes first
     {
-        const int n = bf * E;
-        hipLaunchKernelGGL(emb_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, st, B.emb0, s->temb, s->cond, bf, nb, b0,
-                           E, rec, s->temb_per_sample, n_cond_rows);
+        const long long n = (long long)er * E;
+        hipLaunchKernelGGL(emb_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, B.emb0, s->temb, s->cond, n_rec,
+                           bf, nb, b0, E, s->temb_per_sample, n_cond_rows);
         CDX_TRY(hip_ok());
     }
-    CDX_TRY(gemm(st, B.emb0, E, w->map0_w, E, w->map0_b, B.e1, d, bf, d, E, CDX_ACT_MISH));
-    CDX_TRY(gemm(st, B.e1, d, w->map2_w, d, w->map2_b, B.emb, d, bf, d, d, CDX_ACT_MISH));
-    CDX_TRY(cdx_act_f32(B.emb, B.semb, (long long)bf * d, CDX_ACT_SILU, st));
+    CDX_TRY(gemm(st, B.emb0, E, w->map0_w, E, w->map0_b, B.e1, d, er, d, E, CDX_ACT_MISH));
+    CDX_TRY(gemm(st, B.e1, d, w->map2_w, d, w->map2_b, B.emb, d, er, d, d, CDX_ACT_MISH));
+    CDX_TRY(cdx_act_f32(B.emb, B.semb, (long long)er * d, CDX_ACT_SILU, st));
+    for (int i = 0; i < w->depth; ++i)
+        CDX_TRY(gemm(st, B.semb, d, w->blocks[i].ada_w, d, w->blocks[i].ada_b, B.ada + (size_t)i * 6 * d, ntot, er, 6 * d, d));
+    CDX_TRY(gemm(st, B.semb, d, w->fin_ada_w, d, w->fin_ada_b, B.ada + (size_t)w->depth * 6 * d, ntot, er, 2 * d, d));
+    return CDX_OK;
+}
+
+int dit_forward(const cdx_dit1d_weights* w, const cdx_sampling* s, hipStream_t st, const DitBuffers& B, const float* x,
+                float* pred, int nb, int rec) {
+    const int two = s->cfg_mode == 2 ? 2 : 1, bf = nb * two;
+    const int T = w->tokens, d = w->d_model, rows = bf * T;
+    const int ntot = 6 * d * w->depth + 2 * d;
+    const float* ada_rec = B.ada + (size_t)rec * bf * ntot;
     // token stream: x_proj(x) + pos, computed once per trajectory (both CFG halves start from the same tokens)
     CDX_TRY(gemm(st, x, w->in_dim, w->x_proj_w, w->in_dim, w->x_proj_b, B.h0, d, nb * T, d, w->in_dim, CDX_ACT_NONE,
                  nullptr, 0, 1, nullptr, 0, w->pos, T));
@@ -273,23 +292,23 @@ int dit_forward(const cdx_dit1d_weights* w, const cdx_sampling* s, hipStream_t s
     int h_rows = nb * T;
     for (int i = 0; i < w->depth; ++i) {
         const cdx_dit1d_block& k = w->blocks[i];
-        CDX_TRY(gemm(st, B.semb, d, k.ada_w, d, k.ada_b, B.ada, 6 * d, bf, 6 * d, d));
+        const float* ada = ada_rec + (size_t)i * 6 * d;
         // x <- modulate(LN(x), shift_a, scale_a)   (dit.py:33: the block continues from the modulated stream, Q4)
-        CDX_TRY(layernorm(st, h, B.xm, rows, d, 1e-6f, nullptr, nullptr, B.ada + d, B.ada, 6 * d, T, h_rows == rows ? 0 : h_rows));
+        CDX_TRY(layernorm(st, h, B.xm, rows, d, 1e-6f, nullptr, nullptr, ada + d, ada, ntot, T, h_rows == rows ? 0 : h_rows));
         CDX_TRY(gemm(st, B.xm, d, k.qkv_w, d, k.qkv_b, B.qkv, 3 * d, rows, 3 * d, d));
         cdx_attn_args at;
         at.qkv = B.qkv; at.out = B.att; at.B = bf; at.T = T; at.n_heads = w->n_heads; at.head_dim = d / w->n_heads;
         at.scale = 1.0f / sqrtf((float)at.head_dim);
         CDX_TRY(cdx_attention_f32(&at, st));
-        CDX_TRY(gemm(st, B.att, d, k.proj_w, d, k.proj_b, B.h2, d, rows, d, d, CDX_ACT_NONE, B.ada + 2 * d, 6 * d, T, B.xm, d));
-        CDX_TRY(layernorm(st, B.h2, B.xm, rows, d, 1e-6f, nullptr, nullptr, B.ada + 4 * d, B.ada + 3 * d, 6 * d, T, 0));
+        CDX_TRY(gemm(st, B.att, d, k.proj_w, d, k.proj_b, B.h2, d, rows, d, d, CDX_ACT_NONE, ada + 2 * d, ntot, T, B.xm, d));
+        CDX_TRY(layernorm(st, B.h2, B.xm, rows, d, 1e-6f, nullptr, nullptr, ada + 4 * d, ada + 3 * d, ntot, T, 0));
         CDX_TRY(gemm(st, B.xm, d, k.fc1_w, d, k.fc1_b, B.f, 4 * d, rows, 4 * d, d, CDX_ACT_GELU_TANH));
-        CDX_TRY(gemm(st, B.f, 4 * d, k.fc2_w, 4 * d, k.fc2_b, B.h, d, rows, d, 4 * d, CDX_ACT_NONE, B.ada + 5 * d, 6 * d, T, B.h2, d));
+        CDX_TRY(gemm(st, B.f, 4 * d, k.fc2_w, 4 * d, k.fc2_b, B.h, d, rows, d, 4 * d, CDX_ACT_NONE, ada + 5 * d, ntot, T, B.h2, d));
         h = B.h;
         h_rows = rows;
     }
-    CDX_TRY(gemm(st, B.semb, d, w->fin_ada_w, d, w->fin_ada_b, B.ada, 2 * d, bf, 2 * d, d));
-    CDX_TRY(layernorm(st, h, B.xm, rows, d, 1e-6f, nullptr, nullptr, B.ada + d, B.ada, 2 * d, T, h_rows == rows ? 0 : h_rows));
+    const float* fin = ada_rec + (size_t)w->depth * 6 * d;
+    CDX_TRY(layernorm(st, h, B.xm, rows, d, 1e-6f, nullptr, nullptr, fin + d, fin, ntot, T, h_rows == rows ? 0 : h_rows));
     CDX_TRY(gemm(st, B.xm, d, w->fin_w, d, w->fin_b, pred, w->in_dim, rows, w->in_dim, d));
     return CDX_OK;
 }
@@ -377,13 +396,14 @@ int cdx_dit1d_run(const cdx_dit1d_weights* w, const cdx_sampling* s, void* hip_s
     for (int b0 = 0; b0 < s->batch; b0 += chunk) {
         const int nb = s->batch - b0 < chunk ? s->batch - b0 : chunk;
         const size_t off = (size_t)b0 * s->hd, bytes = (size_t)nb * s->hd * sizeof(float);
+        CDX_TRY(dit_prepare(w, s, st, B, nb, b0));
         if (s->n_steps == 0) {
-            CDX_TRY(dit_forward(w, s, st, B, s->x_in + off, s->x_out + off, nb, b0, 0));
+            CDX_TRY(dit_forward(w, s, st, B, s->x_in + off, s->x_out + off, nb, 0));
             continue;
         }
         if (hipMemcpyAsync(B.x, s->x_in + off, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return hip_ok();
         for (int i = 0; i < s->n_steps; ++i) {
-            CDX_TRY(dit_forward(w, s, st, B, B.x, B.pred, nb, b0, i));
+            CDX_TRY(dit_forward(w, s, st, B, B.x, B.pred, nb, i));
             CDX_TRY(run_step(st, s, s->steps[i], B.x, B.pred, B.prev, nullptr, nb, b0));
         }
         if (hipMemcpyAsync(s->x_out + off, B.x, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return hip_ok();

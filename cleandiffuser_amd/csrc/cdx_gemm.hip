@@ -401,6 +401,122 @@ __global__ __launch_bounds__(64) void cdx_attention_kernel(const cdx_attn_args a
 }
 
 // ------------------------------------------------------------------------------------------------
+// MFMA attention for the same problem (head_dim % 4 == 0): one WAVE per (batch, head), no workgroup barriers.
+//   S^T = K Q^T   (keys x queries, 32x32x2 MFMAs, K and scaled Q staged in wave-private LDS)
+//   softmax over keys = over the registers of a lane (+ one lane ^ 32 exchange): in the D fragment a lane owns ONE query column
+//   O^T = V^T P^T : P^T is consumed straight out of the S^T accumulators as the MFMA B operand -- the contraction index is
+//                   visited in the D fragment's own row order j(r, lane>>5) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), and the
+//                   A operand reads V[j][d] from LDS in that same order, so the probabilities never move.
+// DB = number of 32-wide blocks of the (zero-padded) head dimension.
+// ------------------------------------------------------------------------------------------------
+template <int DB>
+__global__ __launch_bounds__(256) void cdx_attention_mfma_kernel(const cdx_attn_args a) {
+    constexpr int DHP = 32 * DB, LD = DHP + 1;
+    extern __shared__ float att_lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pair = blockIdx.x * 4 + wave;
+    if (pair >= a.B * a.n_heads) return;                 // waves are independent (no barriers below)
+    const int b = pair / a.n_heads, h = pair - b * a.n_heads;
+    const int dh = a.head_dim, dm = a.n_heads * dh, T = a.T;
+    float* Ks = att_lds + (size_t)wave * (2 * 64 * LD);
+    float* QVs = Ks + 64 * LD;
+    const float* base = a.qkv + (size_t)b * T * (3 * dm) + h * dh;
+    const int lr = lane & 31, lk = lane >> 5;
+
+    for (int i = lane; i < 64 * DHP; i += 64) {          // 32*DB consecutive lanes walk one token row: coalesced
+        const int tok = i / DHP, d = i - tok * DHP;
+        const bool live = tok < T && d < dh;
+        const float* p = base + (size_t)(live ? tok : 0) * (3 * dm) + (live ? d : 0);
+        Ks[tok * LD + d] = live ? p[dm] : 0.f;
+        QVs[tok * LD + d] = live ? p[0] * a.scale : 0.f;
+    }
+    f32x16 s[2][2];                                      // [query block][key block]
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[q][k][r] = 0.f;
+#pragma unroll 4
+    for (int st = 0; st < DHP / 2; ++st) {
+        const int d = 2 * st + lk;
+        const float k0 = Ks[lr * LD + d], k1 = Ks[(32 + lr) * LD + d];
+        const float q0 = QVs[lr * LD + d], q1 = QVs[(32 + lr) * LD + d];
+        s[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(k0, q0, s[0][0], 0, 0, 0);
+        s[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(k1, q0, s[0][1], 0, 0, 0);
+        s[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(k0, q1, s[1][0], 0, 0, 0);
+        s[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(k1, q1, s[1][1], 0, 0, 0);
+    }
+    // V replaces Q in LDS (same wave: LDS operations retire in order, the reads above are done before these writes land)
+    for (int i = lane; i < 64 * DHP; i += 64) {
+        const int tok = i / DHP, d = i - tok * DHP;
+        const bool live = tok < T && d < dh;
+        QVs[tok * LD + d] = live ? base[(size_t)tok * (3 * dm) + 2 * dm + d] : 0.f;
+    }
+    float inv_den[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = k * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                s[q][k][r] = j < T ? s[q][k][r] : -3.0e38f;
+                mx = fmaxf(mx, s[q][k][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float den = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = k * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const float e = j < T ? expf(s[q][k][r] - mx) : 0.f;
+                s[q][k][r] = e;
+                den += e;
+            }
+        den += __shfl_xor(den, 32, 64);
+        inv_den[q] = 1.0f / den;
+    }
+    f32x16 o[2][DB];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[q][db][r] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = k * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const float v = QVs[j * LD + db * 32 + lr];
+                o[0][db] = __builtin_amdgcn_mfma_f32_32x32x2f32(v, s[0][k][r], o[0][db], 0, 0, 0);
+                o[1][db] = __builtin_amdgcn_mfma_f32_32x32x2f32(v, s[1][k][r], o[1][db], 0, 0, 0);
+            }
+        }
+    // O^T fragment: column = query lr of block q, rows d = db*32 + (r & 3) + 8 (r >> 2) + 4 lk -> four float4 per block
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int tok = q * 32 + lr;
+        if (tok >= T) continue;
+        float* op = a.out + ((size_t)b * T + tok) * dm + h * dh;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d0 = db * 32 + 8 * g4 + 4 * lk;
+                if (d0 < dh)
+                    *reinterpret_cast<float4*>(op + d0) = make_float4(o[q][db][4 * g4] * inv_den[q], o[q][db][4 * g4 + 1] * inv_den[q],
+                                                                       o[q][db][4 * g4 + 2] * inv_den[q], o[q][db][4 * g4 + 3] * inv_den[q]);
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Elementwise unary map (SiLU / Mish / ...) for the batch-invariant embedding vectors
 // ------------------------------------------------------------------------------------------------
 __global__ void cdx_act_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, int act) {
@@ -465,8 +581,22 @@ int cdx_attention_f32(const cdx_attn_args* a, void* hip_stream) {
         cdx_set_err("cdx_attention_f32: T <= 64 and head_dim <= 64 required"); return CDX_EINVAL;
     }
     if (a->B == 0) return CDX_OK;
-    hipLaunchKernelGGL(cdx_attention_kernel, dim3(a->B * a->n_heads), dim3(64), 0,
-                       reinterpret_cast<hipStream_t>(hip_stream), *a);
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    const int dm = a->n_heads * a->head_dim;
+    if (a->head_dim % 4 == 0 && dm % 4 == 0 && ((uintptr_t)a->out % 16) == 0) {      // MFMA path, one wave per (batch, head)
+        const int pairs = a->B * a->n_heads, grid = (pairs + 3) / 4;
+        if (a->head_dim <= 32) {
+            hipLaunchKernelGGL(cdx_attention_mfma_kernel<1>, dim3(grid), dim3(256), 4 * 2 * 64 * 33 * sizeof(float), st, *a);
+        } else {
+            static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(&cdx_attention_mfma_kernel<2>),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                            4 * 2 * 64 * 65 * sizeof(float)) == hipSuccess;
+            (void)big_lds;
+            hipLaunchKernelGGL(cdx_attention_mfma_kernel<2>, dim3(grid), dim3(256), 4 * 2 * 64 * 65 * sizeof(float), st, *a);
+        }
+    } else {
+        hipLaunchKernelGGL(cdx_attention_kernel, dim3(a->B * a->n_heads), dim3(64), 0, st, *a);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
     return CDX_OK;

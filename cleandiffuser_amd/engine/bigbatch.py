@@ -6,6 +6,7 @@ module only marshals pointers: the checkpoint tensors are used in place (PyTorch
 device tensor, step records are the same ``plan.Step`` list the fused kernel consumes.
 """
 import ctypes
+import os
 import weakref
 from typing import Optional
 
@@ -186,18 +187,21 @@ def host_steps(plan):
     return arr
 
 
-# Chunk sizes: a chunk's widest activation (rows x 4 d_model resp. rows x 4 hidden, fp32) stays well inside the 256 MiB
-# Infinity Cache between the GEMM that writes it and the GEMM that reads it, while rows >= 16 k keeps > 256 tiles in flight.
+# Chunk sizes (measured on MI355X, tools/bench_configs.py with CDX_DIT_CHUNK / CDX_MLP_CHUNK): the GEMMs are compute bound, so
+# tall chunks win -- more 128 x 128 tiles per launch means fuller last waves of workgroups and fewer launches -- until the
+# widest activation (rows x 4 width fp32) outgrows the 256 MiB Infinity Cache by much: DiT1d d=320 peaks at 64 k rows (335 MB),
+# IDQLMlp hidden 1024 at 16 k rows (268 MB); twice that is 5-8 % slower, a quarter of it 15 % slower.
 def _dit_chunk(batch: int, tokens: int, d_model: int, two: int) -> int:
-    rows_budget = max((96 << 20) // (4 * 4 * d_model), 4096)
-    return max(min(batch, rows_budget // (tokens * two)), 1)
+    rows = max((320 << 20) // (4 * 4 * d_model), 2048)
+    return max(min(batch, rows // (tokens * two)), 1)
 
 
 def _mlp_chunk(batch: int, hidden: int, two: int) -> int:
-    return max(min(batch, max((96 << 20) // (4 * 4 * hidden), 4096) // two), 1)
+    return max(min(batch, max((256 << 20) // (4 * 4 * hidden), 2048) // two), 1)
 
 
-CHUNK_OVERRIDE = {"dit": None, "mlp": None}        # tools/bench_configs.py sweeps these
+CHUNK_OVERRIDE = {"dit": int(os.environ.get("CDX_DIT_CHUNK", 0)) or None,      # tuning hooks (tools/bench_configs.py, tests)
+                  "mlp": int(os.environ.get("CDX_MLP_CHUNK", 0)) or None}
 
 
 def _run(kind, bound, *, batch, hd, emb_dim, cond_dim, temb, steps, n_steps, temb_per_sample, predict_noise, cfg_mode,

@@ -73,12 +73,13 @@ def test_layernorm_modulate(c):
     torch.testing.assert_close(y2.cpu().double(), F.layer_norm(_ref(x), (c,), _ref(ga), _ref(be), 1e-5), rtol=2e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize("tokens,heads,dh", [(64, 10, 32), (16, 4, 16), (5, 2, 64), (1, 1, 8)])
+@pytest.mark.parametrize("tokens,heads,dh", [(64, 10, 32), (16, 4, 16), (5, 2, 64), (1, 1, 8), (64, 3, 64), (33, 5, 20), (7, 3, 6)])
 def test_attention_matches_mha_core(tokens, heads, dh):
     from cleandiffuser_amd.engine import blocks
     g = torch.Generator().manual_seed(tokens)
     B, dm = 3, heads * dh
-    qkv = torch.randn(B * tokens, 3 * dm, generator=g)
+    torch.full((1 << 22,), float("nan"), device=DEV)     # whatever stale memory the kernel might touch is poisoned first
+    qkv = torch.randn(B * tokens, 3 * dm, generator=g) * 2
     out = blocks.attention(qkv.to(DEV), B, tokens, heads)
     q, k, v = (_ref(qkv).reshape(B, tokens, 3, heads, dh)[:, :, i].transpose(1, 2) for i in range(3))
     ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B * tokens, dm)
