@@ -423,13 +423,33 @@ __global__ __launch_bounds__(256) void cdx_attention_mfma_kernel(const cdx_attn_
     const float* base = a.qkv + (size_t)b * T * (3 * dm) + h * dh;
     const int lr = lane & 31, lk = lane >> 5;
 
-    for (int i = lane; i < 64 * DHP; i += 64) {          // 32*DB consecutive lanes walk one token row: coalesced
-        const int tok = i / DHP, d = i - tok * DHP;
-        const bool live = tok < T && d < dh;
-        const float* p = base + (size_t)(live ? tok : 0) * (3 * dm) + (live ? d : 0);
-        Ks[tok * LD + d] = live ? p[dm] : 0.f;
-        QVs[tok * LD + d] = live ? p[0] * a.scale : 0.f;
-    }
+    // global -> registers -> LDS with every load of a matrix in flight at once (a load-use-per-iteration loop costs one
+    // memory round trip per 64 floats and made this kernel latency bound); 8*DB lanes cover one padded token row.
+    constexpr int NV = 64 * DHP / 4 / 64;                // float4 per lane per matrix
+    auto load_mat = [&](float4 (&reg)[NV], int which, float mul) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = i * 64 + lane, tok = v / (DHP / 4), d = (v - tok * (DHP / 4)) * 4;
+            const bool live = tok < T && d < dh;         // head_dim % 4 == 0: a float4 is all live or all padding
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live) x = *reinterpret_cast<const float4*>(base + (size_t)tok * (3 * dm) + which * dm + d);
+            reg[i] = make_float4(x.x * mul, x.y * mul, x.z * mul, x.w * mul);
+        }
+    };
+    auto park = [&](float* dst, const float4 (&reg)[NV]) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = i * 64 + lane, tok = v / (DHP / 4), d = (v - tok * (DHP / 4)) * 4;
+            float* p = dst + tok * LD + d;
+            p[0] = reg[i].x; p[1] = reg[i].y; p[2] = reg[i].z; p[3] = reg[i].w;
+        }
+    };
+    float4 rq[NV], rk[NV], rv[NV];
+    load_mat(rk, 1, 1.0f);
+    load_mat(rq, 0, a.scale);
+    load_mat(rv, 2, 1.0f);                               // V is needed last: its latency hides under the S^T MFMAs
+    park(Ks, rk);
+    park(QVs, rq);
     f32x16 s[2][2];                                      // [query block][key block]
 #pragma unroll
     for (int q = 0; q < 2; ++q)
@@ -448,11 +468,7 @@ __global__ __launch_bounds__(256) void cdx_attention_mfma_kernel(const cdx_attn_
         s[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(k1, q1, s[1][1], 0, 0, 0);
     }
     // V replaces Q in LDS (same wave: LDS operations retire in order, the reads above are done before these writes land)
-    for (int i = lane; i < 64 * DHP; i += 64) {
-        const int tok = i / DHP, d = i - tok * DHP;
-        const bool live = tok < T && d < dh;
-        QVs[tok * LD + d] = live ? base[(size_t)tok * (3 * dm) + 2 * dm + d] : 0.f;
-    }
+    park(QVs, rv);
     float inv_den[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
