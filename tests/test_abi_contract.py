@@ -22,29 +22,36 @@ def lib():
 
 def test_every_declared_symbol_is_exported(lib):
     hdr = open(os.path.join(ROOT, "include", "cdx.h")).read()
-    names = re.findall(r"^(?:int|const char\*)\s+(cdx_\w+)\s*\(", hdr, flags=re.M)
-    assert set(names) >= {"cdx_abi_version", "cdx_last_error", "cdx_unet1d_run", "cdx_probe_mfma_layout"}
+    names = re.findall(r"^(?:int|long long|const char\*)\s+(cdx_\w+)\s*\(", hdr, flags=re.M)
+    assert set(names) >= {"cdx_abi_version", "cdx_last_error", "cdx_unet1d_run", "cdx_probe_mfma_layout", "cdx_gemm_f32",
+                          "cdx_layernorm_f32", "cdx_attention_f32", "cdx_act_f32", "cdx_dit1d_run", "cdx_resmlp_run",
+                          "cdx_dit1d_workspace_floats", "cdx_resmlp_workspace_floats", "cdx_gemm_set_trace"}
     for n in names:
         assert hasattr(lib, n), f"{n} declared in cdx.h but not exported by libcdx.so"
     assert lib.cdx_abi_version() == int(re.search(r"#define CDX_ABI_VERSION (\d+)", hdr).group(1))
 
 
 def test_ctypes_mirrors_have_c_layout(tmp_path):
-    from cleandiffuser_amd.engine import runtime
-    fields = [f for f, _ in runtime.CdxUnet1dLaunch._fields_]
-    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "cdx.h"', 'int main(void){',
-           'printf("%zu %zu\\n", sizeof(cdx_unet1d_launch), sizeof(cdx_step));']
-    src += [f'printf("%zu\\n", offsetof(cdx_unet1d_launch, {f}));' for f in fields]
+    from cleandiffuser_amd.engine import bigbatch, blocks, runtime
+    mirrors = {"cdx_unet1d_launch": runtime.CdxUnet1dLaunch, "cdx_step": runtime.CdxStep, "cdx_gemm_args": blocks.CdxGemmArgs,
+               "cdx_ln_args": blocks.CdxLnArgs, "cdx_attn_args": blocks.CdxAttnArgs, "cdx_sampling": bigbatch.CdxSampling,
+               "cdx_dit1d_block": bigbatch.CdxDitBlock, "cdx_dit1d_weights": bigbatch.CdxDitWeights,
+               "cdx_resmlp_block": bigbatch.CdxResMlpBlock, "cdx_resmlp_weights": bigbatch.CdxResMlpWeights}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "cdx.h"', 'int main(void){']
+    for cname, mirror in mirrors.items():
+        src.append(f'printf("%zu\\n", sizeof({cname}));')
+        src += [f'printf("%zu\\n", offsetof({cname}, {f[0]}));' for f in mirror._fields_]
     src += ['return 0;}']
     c = tmp_path / "layout.c"
     c.write_text("\n".join(src))
     exe = tmp_path / "layout"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)], check=True)
-    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
-    assert int(out[0]) == ctypes.sizeof(runtime.CdxUnet1dLaunch)
-    assert int(out[1]) == ctypes.sizeof(runtime.CdxStep) == 48
-    for f, off in zip(fields, out[2:]):
-        assert getattr(runtime.CdxUnet1dLaunch, f).offset == int(off), f
+    out = iter(subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split())
+    for cname, mirror in mirrors.items():
+        assert int(next(out)) == ctypes.sizeof(mirror), cname
+        for f in mirror._fields_:
+            assert getattr(mirror, f[0]).offset == int(next(out)), (cname, f[0])
+    assert ctypes.sizeof(runtime.CdxStep) == 48
 
 
 def test_op_word_layout_matches_header():
@@ -64,6 +71,20 @@ def test_launch_validation_fails_loudly(lib):
     L = runtime.CdxUnet1dLaunch()
     assert lib.cdx_unet1d_run(ctypes.byref(L), None) == -1
     assert b"null" in lib.cdx_last_error()
+
+
+def test_bigbatch_validation_fails_loudly(lib):
+    from cleandiffuser_amd.engine import bigbatch, blocks
+    bigbatch._lib(), blocks._lib()
+    assert lib.cdx_gemm_f32(ctypes.byref(blocks.CdxGemmArgs(M=4, N=4, K=4)), None) == -1
+    assert b"null" in lib.cdx_last_error()
+    assert lib.cdx_gemm_f32(ctypes.byref(blocks.CdxGemmArgs(M=0, N=4, K=4)), None) == 0          # empty batch is not an error
+    assert lib.cdx_attention_f32(ctypes.byref(blocks.CdxAttnArgs(B=1, T=65, n_heads=1, head_dim=8, qkv=8, out=8)), None) == -1
+    assert lib.cdx_layernorm_f32(ctypes.byref(blocks.CdxLnArgs(M=1, C=2048, x=8, y=8)), None) == -1
+    w, s = bigbatch.CdxDitWeights(), bigbatch.CdxSampling()
+    assert lib.cdx_dit1d_run(ctypes.byref(w), ctypes.byref(s), None) == -1
+    assert lib.cdx_resmlp_run(ctypes.byref(bigbatch.CdxResMlpWeights()), ctypes.byref(s), None) == -1
+    assert lib.cdx_last_error() != b""
 
 
 def test_missing_library_is_a_hard_error(tmp_path):
