@@ -120,12 +120,18 @@ __global__ void solver_step_kernel(const StepArgs a) {
             } else if (st.kind == 1) {
                 xn = k0 * ((x - k1 * eps) / k2) + k3 * eps;
             } else {
-                float v = st.vsel == 0 ? eps : xth;
+                if (st.flags & CDX_STEP_MASK_PRED) {
+                    const float m = a.fix_mask ? a.fix_mask[e] : 0.f;
+                    eps = eps * (1.0f - m);
+                    xth = xth * (1.0f - m) + x * m;
+                }
+                float v = (st.vsel & 1) ? xth : eps;
                 if (st.vsel == 2) v = k3 * xth - k4 * a.prev[i];
+                if (st.vsel == 3) v = k3 * eps - k4 * a.prev[i];
                 xn = k0 * x - k1 * v;
                 if (st.noise_idx >= 0) xn += k2 * a.noise[zi];
             }
-            if (st.push) a.prev[i] = xth;
+            if (st.push) a.prev[i] = st.push == 2 ? eps : xth;
         }
         if (a.fix_mask) {
             const float m = a.fix_mask[e];

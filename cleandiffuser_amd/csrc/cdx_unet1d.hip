@@ -651,8 +651,28 @@ __global__ __launch_bounds__(CDX_THREADS) void cdx_unet1d_kernel(const cdx_unet1
     Prefetch pre;
     pre.ok = 0;
 
+    // EDM plans (kinds 5/6; a plan is all-EDM or not at all): the network sees c_in * x, so the authoritative state lives in a
+    // dense side buffer and the state slot is rewritten with the scaled copy before every forward.
+    const int PV = (HD + 3) & ~3;                        // prev | x_old | x_true, PV floats each (program.py: prev region)
+    const bool edm = L.n_steps > 0 && L.steps[0].kind >= 5;
+    if (edm) {
+        for (int e = tid; e < HD; e += CDX_THREADS) {
+            const int n = e / D, c = e - n * D;
+            lds[L.prev_off + 2 * PV + e] = lds[L.x_off + (n + CDX_HALO) * L.x_stride + c];
+        }
+        __syncthreads();
+    }
+
     const int n_iter = L.n_steps > 0 ? L.n_steps : 1;
     for (int step = 0; step < n_iter; ++step) {
+        if (edm) {
+            const float c_in = L.steps[step].alpha;
+            for (int e = tid; e < HD; e += CDX_THREADS) {
+                const int n = e / D, c = e - n * D;
+                lds[L.x_off + (n + CDX_HALO) * L.x_stride + c] = c_in * lds[L.prev_off + 2 * PV + e];
+            }
+            __syncthreads();
+        }
         const int n_branch = (L.cfg_mode == 2) ? 2 : 1;
         for (int br = 0; br < n_branch; ++br) {
             const bool use_cond = (L.cond != nullptr) && (L.cfg_mode == 1 || (L.cfg_mode == 2 && br == 0));
@@ -678,9 +698,29 @@ __global__ __launch_bounds__(CDX_THREADS) void cdx_unet1d_kernel(const cdx_unet1
             const int n = e / D, c = e - n * D;
             const int xo = L.x_off + (n + CDX_HALO) * L.x_stride + c;
             const int po = L.pred_off + (n + CDX_HALO) * L.pred_stride + c;
-            const float x = lds[xo];
+            const float x = edm ? lds[L.prev_off + 2 * PV + e] : lds[xo];
             float p = lds[po];
             if (L.cfg_mode == 2) p = L.cfg_w * p + (1.0f - L.cfg_w) * lds[po + L.pred_branch_floats];
+            float xn;
+            if (st.kind >= 5) {
+                // EDM (newedm.py:387-401, legacy edm.py:118-160): D = clip(c_skip x + c_out F), slope = (x - D) / sigma
+                float dn = k0 * x + k1 * p;
+                if (L.x_min) dn = fmaxf(dn, L.x_min[e]);
+                if (L.x_max) dn = fminf(dn, L.x_max[e]);
+                const float sl = (x - dn) / k2;
+                if (st.kind == 5) {
+                    xn = x - sl * k3;
+                    if (st.push) { lds[L.prev_off + e] = sl; lds[L.prev_off + PV + e] = x; }
+                } else {
+                    xn = lds[L.prev_off + PV + e] - (lds[L.prev_off + e] + sl) / 2.0f * k3;
+                }
+                if (L.fix_mask) {
+                    const float m = L.fix_mask[e];
+                    xn = xn * (1.0f - m) + L.prior[xbase + e] * m;
+                }
+                lds[L.prev_off + 2 * PV + e] = xn;
+                continue;
+            }
             if (L.predict_noise) {
                 if (L.x_max) p = fmaxf(p, (x - al * L.x_max[e]) / sg);
                 if (L.x_min) p = fminf(p, (x - al * L.x_min[e]) / sg);
@@ -694,7 +734,6 @@ __global__ __launch_bounds__(CDX_THREADS) void cdx_unet1d_kernel(const cdx_unet1
             } else {
                 xth = p; eps = (x - al * p) / sg;
             }
-            float xn;
             if (st.kind >= 3) {
                 // legacy DDPM class (reference diffusion/ddpm.py:153-164, 230-241): the fix-mask is applied to the
                 // *prediction* (eps: pred*(1-m); x0: pred*(1-m) + x*m), then the ancestral posterior mean
@@ -713,8 +752,14 @@ __global__ __launch_bounds__(CDX_THREADS) void cdx_unet1d_kernel(const cdx_unet1
             } else if (st.kind == 1) {
                 xn = k0 * ((x - k1 * eps) / k2) + k3 * eps;
             } else {
-                float v = st.vsel == 0 ? eps : xth;
+                if (st.flags & CDX_STEP_MASK_PRED) {     // legacy DPMSolver (dpmsolver.py:257-264): mask on the prediction
+                    const float m = L.fix_mask ? L.fix_mask[e] : 0.f;
+                    eps = eps * (1.0f - m);
+                    xth = xth * (1.0f - m) + x * m;
+                }
+                float v = (st.vsel & 1) ? xth : eps;     // 0 eps, 1 x_theta, 2 multistep on x_theta, 3 multistep on eps
                 if (st.vsel == 2) v = k3 * xth - k4 * lds[L.prev_off + e];
+                if (st.vsel == 3) v = k3 * eps - k4 * lds[L.prev_off + e];
                 xn = k0 * x - k1 * v;
                 if (st.noise_idx >= 0) xn += k2 * L.noise[((size_t)st.noise_idx * L.batch + b) * HD + e];
             }
@@ -722,14 +767,14 @@ __global__ __launch_bounds__(CDX_THREADS) void cdx_unet1d_kernel(const cdx_unet1
                 const float m = L.fix_mask[e];
                 xn = xn * (1.0f - m) + L.prior[xbase + e] * m;
             }
-            if (st.push) lds[L.prev_off + e] = xth;
+            if (st.push) lds[L.prev_off + e] = st.push == 2 ? eps : xth;
             lds[xo] = xn;
         }
         __syncthreads();
     }
     for (int e = tid; e < HD; e += CDX_THREADS) {
         const int n = e / D, c = e - n * D;
-        L.x_out[xbase + e] = lds[L.x_off + (n + CDX_HALO) * L.x_stride + c];
+        L.x_out[xbase + e] = edm ? lds[L.prev_off + 2 * PV + e] : lds[L.x_off + (n + CDX_HALO) * L.x_stride + c];
     }
     if (L.prof && b == 0) {
         stamp(lprof + (size_t)L.n_ops * 8 + 1, tid);

@@ -176,7 +176,7 @@ def host_steps(plan):
     arr = (CdxStep * max(len(plan.steps), 1))()
     k = 0
     for i, st in enumerate(plan.steps):
-        arr[i].kind, arr[i].vsel, arr[i].push = st.kind, st.vsel, int(st.push)
+        arr[i].kind, arr[i].vsel, arr[i].push, arr[i].flags = st.kind, st.vsel, int(st.push), int(st.flags)
         arr[i].alpha, arr[i].sigma = st.alpha, st.sigma
         for j in range(5):
             arr[i].k[j] = st.k[j]

@@ -46,6 +46,8 @@ def try_fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, requ
     from . import bigbatch, runtime
     net = model["diffusion"]
     if bigbatch.is_dit1d(net) or bigbatch.is_resmlp(net):
+        if bigbatch.is_dit1d(net) and any(st.kind >= 5 for st in plan.steps):
+            return None                  # EDM input scaling is not wired into cdx_dit1d_run
         return bigbatch.sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed)
     return runtime.fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed)
 
@@ -56,11 +58,13 @@ def try_fused_edm(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, require
         return None
     if w_cg != 0.0 and solver.classifier is not None:
         return None
-    from . import bigbatch
+    from . import bigbatch, runtime
     net = model["diffusion"]
-    if not bigbatch.is_resmlp(net):
-        return None
-    return bigbatch.sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed)
+    if bigbatch.is_resmlp(net):
+        return bigbatch.sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed)
+    if bigbatch.is_dit1d(net):
+        return None                      # cdx_dit1d_run has no c_in input scaling yet
+    return runtime.fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed)
 
 
 def try_fused_legacy_ddpm(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, requires_grad, feed):

@@ -24,7 +24,8 @@ SUPPORTED_SOLVERS = [
     "sde_dpmsolver_1", "sde_dpmsolver++_1", "sde_dpmsolver++_2M"]
 
 KIND_DDPM, KIND_DDIM, KIND_LINEAR, KIND_LEGACY_EPS, KIND_LEGACY_X0 = 0, 1, 2, 3, 4
-V_EPS, V_XTHETA, V_MULTISTEP = 0, 1, 2
+V_EPS, V_XTHETA, V_MULTISTEP, V_MULTISTEP_EPS = 0, 1, 2, 3
+F_MASK_PRED = 1
 
 
 @dataclass
@@ -37,7 +38,8 @@ class Step:
     sigma: float
     k: Tuple[float, float, float, float, float]
     noise: bool = False        # consumes one fresh N(0, I) draw
-    push: bool = False         # stores xth for the next multistep update
+    push: int = 0              # 1: stores xth (2: eps) for the next multistep update; EDM: stores slope and state
+    flags: int = 0             # F_MASK_PRED: legacy DPMSolver applies the fix-mask to the prediction
 
 
 @dataclass
@@ -174,4 +176,78 @@ def build_edm_plan(sigma_data: float, sigma_min: float, top_sigma: float, rho: f
             sig2 = sig / sig * sig_prev                  # reference: t / sigmas[i] * sigmas[i-1]
             skip, out, cin, cnoise = pre(sig2)
             plan.steps.append(Step(KIND_EDM_HEUN, V_EPS, i, cnoise, cin, _f(sig2), (skip, out, _f(sig_prev), dt, 0.0)))
+    return plan
+
+
+# ------------------------------------------------------------------------------------------------ #
+# legacy classes the dp_* / dbc_* pipelines import: DPMSolver, EDM                                     #
+# ------------------------------------------------------------------------------------------------ #
+LEGACY_DPM_SAMPLERS = {          # name -> (prediction the update consumes is eps?, order)   (reference dpmsolver.py:13-49)
+    "ode_dpm_1": (True, 1), "ddim": (True, 1), "sde_dpm_1": (True, 1), "ode_dpmpp_1": (False, 1), "sde_dpmpp_1": (False, 1),
+    "ode_dpm_2": (True, 2), "sde_dpm_2": (True, 2), "ode_dpmpp_2": (False, 2), "sde_dpmpp_2": (False, 2)}
+
+
+def build_legacy_dpmsolver_plan(t: torch.Tensor, alphas: torch.Tensor, sigmas: torch.Tensor, sampler: str,
+                                sample_steps: int, extra_sample_steps: int = 0) -> SamplePlan:
+    """Legacy ``DPMSolver.sample / sample_x`` (reference diffusion/dpmsolver.py:66-89 one-step estimates, :478-520 loop,
+    :600-616 Diffusion-X tail).  Step i = 1..S evaluates the network at t[i-1] and hops to t[i]:
+        ode_dpm / ddim   x <- a_i/a_{i-1} x - s_i expm1(h_i) V                                 V eps-type
+        sde_dpm          x <- a_i/a_{i-1} x - 2 s_i expm1(h_i) V + s_i sqrt(expm1(2 h_i)) z
+        ode_dpmpp        x <- s_i/s_{i-1} x - a_i expm1(-h_i) V                                V x-type
+        sde_dpmpp        x <- s_i/s_{i-1} e^{-h_i} x - a_i expm1(-2 h_i) V + s_i sqrt(-expm1(-2 h_i)) z
+    second order (i > 1): V = (1 + 1/(2r)) P_i - 1/(2r) P_{i-1}, r = h_{i-1}/h_i, P the masked prediction (flag MASK_PRED).
+    `alpha`/`sigma` of a record are those of t[i-1] (conversion and clipping happen there)."""
+    eps_type, order = LEGACY_DPM_SAMPLERS[sampler]
+    t, alphas, sigmas = (v.detach().float().cpu() for v in (t, alphas, sigmas))
+    log_snr = (alphas / sigmas).log()
+    h = torch.zeros_like(log_snr)
+    h[1:] = log_snr[1:] - log_snr[:-1]
+    family = "ode_dpm" if sampler == "ddim" else sampler[:-2]
+    plan = SamplePlan(solver="legacy_" + sampler, t_is_integer=False)
+    order_of = list(range(1, sample_steps + 1)) + ([sample_steps] * extra_sample_steps if order == 1 else [])
+    for pos, i in enumerate(order_of):
+        if family == "ode_dpm":
+            c = (_f(alphas[i] / alphas[i - 1]), _f(sigmas[i] * torch.expm1(h[i])), 0.0)
+        elif family == "sde_dpm":
+            c = (_f(alphas[i] / alphas[i - 1]), _f(2. * sigmas[i] * torch.expm1(h[i])),
+                 _f(sigmas[i] * torch.expm1(2. * h[i]).sqrt()))
+        elif family == "ode_dpmpp":
+            c = (_f(sigmas[i] / sigmas[i - 1]), _f(alphas[i] * torch.expm1(-h[i])), 0.0)
+        else:
+            c = (_f(sigmas[i] / sigmas[i - 1] * (-h[i]).exp()), _f(alphas[i] * torch.expm1(-2. * h[i])),
+                 _f(sigmas[i] * (-1. * torch.expm1(-2. * h[i])).sqrt()))
+        k3 = k4 = 0.0
+        vsel = V_EPS if eps_type else V_XTHETA
+        if order == 2 and i > 1 and pos < sample_steps:
+            r = h[i - 1] / h[i]
+            k3, k4 = _f(1 + 0.5 / r), _f(0.5 / r)
+            vsel = V_MULTISTEP_EPS if eps_type else V_MULTISTEP
+        plan.steps.append(Step(KIND_LINEAR, vsel, i, _f(t[i - 1]), _f(alphas[i - 1]), _f(sigmas[i - 1]),
+                               (c[0], c[1], c[2], k3, k4), noise=family.startswith("sde"),
+                               push=(2 if eps_type else 1) if order == 2 else 0, flags=F_MASK_PRED))
+    return plan
+
+
+def build_legacy_edm_plan(sigma_data: float, sigma_s: torch.Tensor, solver: str, extra_sample_steps: int = 0) -> SamplePlan:
+    """Legacy ``EDM.sample / sample_x`` (reference diffusion/edm.py:118-160 dot_x, :252-268 loop, :330-341 tail) for the
+    ``EDM`` class proper (scale_s == 1, t_s == sigma_s): Euler  x <- x - (x - D)/sigma_i (sigma_i - sigma_{i+1}), Heun corrector
+    when i != N-1 and sigma_{i+1} > 0.005, `extra_sample_steps` repeats of the last Euler step.  No clipping, no temperature."""
+    sig = sigma_s.detach().float().cpu()
+    n = sig.shape[0] - 1
+    sd2 = sigma_data ** 2
+
+    def rec(kind, i, dt, push):
+        s = sig[i]
+        return Step(kind, V_EPS, i, _f(0.25 * s.log()), _f(1 / (sd2 + s ** 2).sqrt()), _f(s),
+                    (_f(sd2 / (sd2 + s ** 2)), _f(s * sigma_data / (sd2 + s ** 2).sqrt()), _f(s), dt, 0.0), push=push)
+
+    plan = SamplePlan(solver="legacy_edm_" + solver, t_is_integer=False)
+    for i in range(n):
+        dt = _f(sig[i] - sig[i + 1])
+        corrector = solver == "heun" and i != n - 1 and bool(sig[i + 1] > 0.005)
+        plan.steps.append(rec(KIND_EDM_EULER, i, dt, int(corrector)))
+        if corrector:
+            plan.steps.append(rec(KIND_EDM_HEUN, i + 1, dt, 0))
+    for _ in range(extra_sample_steps):
+        plan.steps.append(rec(KIND_EDM_EULER, n - 1, _f(sig[n - 1] - sig[n]), 0))
     return plan

@@ -455,7 +455,7 @@ def _finalize(b: "_Builder", net, x: Act, pred: Optional[Act], horizon: int, d: 
     sources = [a for reads, _ in b.op_acts for a in reads]
     zrow_floats = max(pad16(a.chans) for a in sources) + 16
     off += zrow_floats
-    prev_off, off = off, off + (horizon * d + 3) // 4 * 4
+    prev_off, off = off, off + 3 * ((horizon * d + 3) // 4 * 4)     # multistep memory / EDM slope | x_old | x_true
     vec_off, off = off, off + b.vec_len
     for a, rel in vec_alias:                              # 1-row slots that ARE vectors (Linear lowered as a 1-position conv)
         a.off = vec_off + rel

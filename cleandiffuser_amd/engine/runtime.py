@@ -16,13 +16,13 @@ from . import program as P
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libcdx.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class CdxStep(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int32), ("vsel", ctypes.c_int32), ("noise_idx", ctypes.c_int32),
                 ("push", ctypes.c_int32), ("alpha", ctypes.c_float), ("sigma", ctypes.c_float),
-                ("k", ctypes.c_float * 5), ("_pad", ctypes.c_float)]
+                ("k", ctypes.c_float * 5), ("flags", ctypes.c_int32)]
 
 
 class CdxUnet1dLaunch(ctypes.Structure):
@@ -301,7 +301,7 @@ def steps_to_device(plan, device) -> torch.Tensor:
     arr = (CdxStep * len(plan.steps))()
     k = 0
     for i, st in enumerate(plan.steps):
-        arr[i].kind, arr[i].vsel, arr[i].push = st.kind, st.vsel, int(st.push)
+        arr[i].kind, arr[i].vsel, arr[i].push, arr[i].flags = st.kind, st.vsel, int(st.push), int(st.flags)
         arr[i].alpha, arr[i].sigma = st.alpha, st.sigma
         for j in range(5):
             arr[i].k[j] = st.k[j]
@@ -324,8 +324,8 @@ def fused_sample_mlp(solver, net, kind, plan, xt, prior, cond_vec, w_cfg, feed) 
     pad = n_tiles * tile - b
     try:
         fix_mask = _dense_hd(solver.fix_mask, 1, d, dev)
-        x_min = _dense_hd(solver.x_min, 1, d, dev)
-        x_max = _dense_hd(solver.x_max, 1, d, dev)
+        x_min = _dense_hd(getattr(solver, "x_min", None), 1, d, dev)
+        x_max = _dense_hd(getattr(solver, "x_max", None), 1, d, dev)
     except (ValueError, RuntimeError):
         return None
 
@@ -354,7 +354,7 @@ def fused_sample_mlp(solver, net, kind, plan, xt, prior, cond_vec, w_cfg, feed) 
         xin = rows(xt)
         out = torch.empty_like(xin)
         _launch(comp, batch=n_tiles, x_in=xin, x_out=out, temb=temb, steps_dev=steps_dev, n_steps=len(plan.steps),
-                predict_noise=solver.predict_noise, cfg_mode=1 if cond is not None else 0, cfg_w=w_cfg, cond=cond,
+                predict_noise=getattr(solver, "predict_noise", False), cfg_mode=1 if cond is not None else 0, cfg_w=w_cfg, cond=cond,
                 prior=rows(prior) if fix_mask is not None else None, fix_mask=table(fix_mask), noise=noise,
                 x_min=table(x_min), x_max=table(x_max))
     return out[:b]
@@ -375,8 +375,8 @@ def fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed) -> Optio
         b, h, d = xt.shape
         dev = xt.device
         fix_mask = _dense_hd(solver.fix_mask, h, d, dev)
-        x_min = _dense_hd(solver.x_min, h, d, dev)
-        x_max = _dense_hd(solver.x_max, h, d, dev)
+        x_min = _dense_hd(getattr(solver, "x_min", None), h, d, dev)
+        x_max = _dense_hd(getattr(solver, "x_max", None), h, d, dev)
     except ValueError:
         return None
     load_library()
@@ -396,7 +396,7 @@ def fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed) -> Optio
         xin = _f32c(xt, dev)
         out = torch.empty_like(xin)
         _launch(comp, batch=b, x_in=xin, x_out=out, temb=temb, steps_dev=steps_dev, n_steps=len(plan.steps),
-                predict_noise=solver.predict_noise, cfg_mode=mode, cfg_w=w_cfg, cond=cond,
+                predict_noise=getattr(solver, "predict_noise", False), cfg_mode=mode, cfg_w=w_cfg, cond=cond,
                 prior=_f32c(prior, dev) if fix_mask is not None else None, fix_mask=fix_mask, noise=noise,
                 x_min=x_min, x_max=x_max)
     return out

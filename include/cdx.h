@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define CDX_ABI_VERSION 1
+#define CDX_ABI_VERSION 2
 
 #define CDX_OK 0
 #define CDX_EINVAL (-1)   /* bad argument (null pointer, size out of range, misaligned offset) */
@@ -34,18 +34,25 @@ extern "C" {
  * (diffusionsde.py:539-589): the host freezes alpha_i, sigma_i and the solver coefficients, the device applies
  *   kind 0 (ddpm)   x <- k0*(x - k1*eps) + k2*eps [+ k3*z]
  *   kind 1 (ddim)   x <- k0*((x - k1*eps)/k2) + k3*eps
- *   kind 2 (linear) x <- k0*x - k1*V [+ k2*z],  V = eps | x_theta | (k3*x_theta - k4*x_theta_prev)
+ *   kind 2 (linear) x <- k0*x - k1*V [+ k2*z],  V = eps | x_theta | (k3*x_theta - k4*x_theta_prev) | (k3*eps - k4*eps_prev)
+ *            with CDX_STEP_MASK_PRED (legacy DPMSolver class, reference diffusion/dpmsolver.py:257-264) the fix-mask is first
+ *            applied to the prediction: eps <- eps*(1-m), x_theta <- x_theta*(1-m) + x*m
  *   kind 3/4 (legacy DDPM class, reference diffusion/ddpm.py:153-164,230-241; eps / x0 prediction):
  *            P <- P*(1-mask) [+ x*mask];  x <- k0*(x - k1*P)  |  x <- k0*(k1*x + k2*P);  [+ k3*z]
+ *   kind 5/6 (EDM Euler / Heun corrector; reference diffusion/newedm.py:387-401, legacy edm.py:118-160,252-268):
+ *            `alpha` carries c_in (the network sees c_in*x), k = (c_skip, c_out, sigma, dt):
+ *            D = clip(k0*x + k1*F); s = (x - D)/k2;  kind 5: x' = x - k3*s (push: remember s and x);
+ *            kind 6: x' = x_old - k3*(s_old + s)/2.   A plan is all-EDM or not EDM at all.
  * followed by the fix-mask blend (diffusionsde.py:592). */
+#define CDX_STEP_MASK_PRED 1
 typedef struct cdx_step {
     int32_t kind;        /* 0 ddpm, 1 ddim, 2 linear, 3 legacy-ddpm eps, 4 legacy-ddpm x0 */
-    int32_t vsel;        /* kind 2: 0 eps, 1 x_theta, 2 multistep D */
+    int32_t vsel;        /* kind 2: 0 eps, 1 x_theta, 2 multistep on x_theta, 3 multistep on eps */
     int32_t noise_idx;   /* index into `noise` of this step's N(0,I) draw, or -1 */
-    int32_t push;        /* 1: remember x_theta for the next multistep update */
+    int32_t push;        /* 1: remember x_theta (2: eps) for the next multistep update; EDM: remember slope and state */
     float alpha, sigma;  /* schedule at this step (for eps<->x conversion and clipping) */
     float k[5];
-    float _pad;
+    int32_t flags;       /* CDX_STEP_* bits */
 } cdx_step;
 
 /* One launch = the whole request: either a full sampling loop (n_steps >= 1) or a single backbone forward
@@ -155,10 +162,7 @@ int cdx_act_f32(const float* x, float* y, long long n, int act, void* hip_stream
  * Big-batch sampling loops (csrc/cdx_bigbatch.hip): the whole `sample()` request for the GEMM-shaped denoisers.
  * One call enqueues every kernel of every denoising step on the caller's stream (no host synchronisation, no
  * allocation: the caller owns `workspace`).  The step records are the same cdx_step as above but live in HOST
- * memory here, because the host sequences the launches.  Two extra kinds serve the EDM solver
- * (reference diffusion/newedm.py:387-401); for them `alpha` carries c_in (the network sees c_in*x) and
- *   kind 5 (edm euler)  D = clip(k0*x + k1*F); s = (x - D)/k2; x' = x - k3*s;    push: remember s and x
- *   kind 6 (edm heun)   D = clip(k0*x + k1*F); s2 = (x - D)/k2; x' = x_old - k3*(s_old + s2)/2
+ * memory here, because the host sequences the launches (all step kinds of cdx_step, EDM kinds 5/6 included).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct cdx_sampling {
     int32_t batch;             /* trajectories */

@@ -142,6 +142,38 @@ CASES.update({
 })
 BIGBATCH_NETS = ("DiT1d", "IDQLMlp", "NewIDQLMlp")
 
+# ---- legacy solver classes the dp_* / dbc_* pipelines import (DPMSolver, EDM): every sampler family, 2nd order, sample_x ----
+_J8 = dict(net=("JannerUNet1d", dict(in_dim=6, model_dim=8, emb_dim=8, dim_mult=[1, 2], kernel_size=5)), x_shape=(8, 6),
+           batch=2, fix_obs=4, legacy=True)
+CASES.update({
+    "janner_legacy_dpm_ode2": dict(_J8, clip=3.0, solver=("DPMSolver", dict(predict_noise=True, noise_schedule="cosine")),
+                                   sample=dict(sampler="ode_dpm_2", sample_steps=5, temperature=0.8)),
+    "janner_legacy_dpm_sdepp2": dict(_J8, clip=2.0, solver=("DPMSolver", dict(predict_noise=False)),
+                                     sample=dict(sampler="sde_dpmpp_2", sample_steps=5, kappa=2.0)),
+    "janner_legacy_dpm_sde1_x": dict(_J8, clip=3.0, solver=("DPMSolver", dict(predict_noise=False)), method="sample_x",
+                                     sample=dict(sampler="sde_dpm_1", sample_steps=4, extra_sample_steps=3, temperature=0.7)),
+    "janner_legacy_dpm_odepp2_eps": dict(_J8, clip=3.0, solver=("DPMSolver", dict(predict_noise=True)),
+                                         sample=dict(sampler="ode_dpmpp_2", sample_steps=6)),
+    "janner_legacy_dpm_ddim_cfg": dict(_J8, clip=3.0, cond_dim=8, solver=("DPMSolver", dict(predict_noise=True)),
+                                       sample=dict(sampler="ddim", sample_steps=5, w_cfg=1.6)),
+    "chiunet_legacy_dpmpp1": dict(
+        net=("ChiUNet1d", dict(act_dim=2, obs_dim=20, To=2, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2])),
+        x_shape=(16, 2), batch=3, clip=1.0, cond=("IdentityCondition", dict(dropout=0.0), (2, 20)), legacy=True,
+        solver=("DPMSolver", dict(predict_noise=False)), sample=dict(sampler="ode_dpmpp_1", sample_steps=5, w_cfg=1.0)),
+    "janner_legacy_edm_euler": dict(_J8, solver=("EDM", dict()), sample=dict(solver="euler", sample_steps=6)),
+    "janner_legacy_edm_heun": dict(_J8, solver=("EDM", dict(sigma_max=20.0)), sample=dict(solver="heun", sample_steps=6)),
+    "janner_legacy_edm_x": dict(_J8, solver=("EDM", dict()), method="sample_x",
+                                sample=dict(solver="euler", sample_steps=4, extra_sample_steps=2)),
+    "idql_legacy_edm_heun_cfg": dict(
+        net=("IDQLMlp", dict(obs_dim=11, act_dim=3, emb_dim=16, hidden_dim=64, n_blocks=2)), x_shape=(3,), batch=7,
+        cond=("IdentityCondition", dict(dropout=0.0), (11,)), legacy=True,
+        solver=("EDM", dict()), sample=dict(solver="heun", sample_steps=5, w_cfg=1.3)),
+    "dql_legacy_edm_euler": dict(
+        net=("DQLMlp", dict(obs_dim=17, act_dim=6)), x_shape=(6,), batch=4, legacy=True,
+        cond=("IdentityCondition", dict(dropout=0.0), (17,)),
+        solver=("EDM", dict()), sample=dict(solver="euler", sample_steps=5, w_cfg=1.0)),
+})
+
 # one small case per solver (discrete + continuous) so every update rule is pinned
 for _s in _ALL_SOLVERS:
     CASES[f"janner_tiny_disc_{_s}"] = dict(
@@ -170,6 +202,8 @@ def lib_namespace(kind: str):
     import importlib
     root = "cleandiffuser_amd" if kind == "amd" else "cleandiffuser"
     ns.DDPM = importlib.import_module(root + ".diffusion.ddpm").DDPM      # legacy class, not exported by the package
+    ns.DPMSolver = importlib.import_module(root + ".diffusion.dpmsolver").DPMSolver
+    ns.EDM = importlib.import_module(root + ".diffusion.edm").EDM
     mlp_mod = "cleandiffuser_amd.nn_diffusion.mlp_backbones" if kind == "amd" else "cleandiffuser.nn_diffusion.idqlmlp"
     ns.NewIDQLMlp = importlib.import_module(mlp_mod).NewIDQLMlp           # likewise (idqlmlp.py:68)
     return ns
@@ -230,7 +264,9 @@ def build(lib, name: str, device="cpu", weight_seed: int = 0):
                                        emb_dim=nk["emb_dim"], dim_mult=tuple(nk["dim_mult"]), **c["classifier"])
         clf_net.load_state_dict(synth_state_dict(clf_net.state_dict(), weight_seed + 1))
         kw["classifier"] = lib.CumRewClassifier(clf_net, device=device)
-    if c.get("legacy"):
+    if c.get("legacy") and c["solver"][0] == "EDM":
+        pass                                                   # legacy EDM has no clipping bounds
+    elif c.get("legacy"):
         x_max, x_min = kw.pop("x_max", None), kw.pop("x_min", None)
         kw.update(x_max=None if x_max is None else x_max.to(device), x_min=None if x_min is None else x_min.to(device))
     agent = getattr(lib, c["solver"][0])(net, cond_net, device=device, **kw)
@@ -273,6 +309,11 @@ def replay_randn(noise):
         yield
     finally:
         torch.randn_like = orig
+
+
+def sampler_of(agent, name: str):
+    """The bound method a case calls: ``sample`` unless the case names another one (``sample_x``)."""
+    return getattr(agent, CASES[name].get("method", "sample"))
 
 
 def sample_kwargs(name: str, inputs, device="cpu"):

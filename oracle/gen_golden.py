@@ -29,7 +29,7 @@ def run_reference_case(lib, name: str):
             yield z
 
     with cases.replay_randn(counting(inp["noise"])):
-        x, log = agent.sample(prior, **kw)
+        x, log = cases.sampler_of(agent, name)(prior, **kw)
     c = cases.CASES[name]
     if "x_shape" in c:                    # non-Janner cases: the loop output alone pins them
         out = dict(x_out=x.detach().numpy().astype(np.float32), n_draws=np.int64(used["n"]))

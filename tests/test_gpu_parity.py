@@ -110,7 +110,7 @@ def test_bigbatch_sample_matches_reference_fixture(name, chunk, amd_lib, monkeyp
     calls = _spy_bigbatch(monkeypatch)
     kind = "dit" if cases.CASES[name]["net"][0] == "DiT1d" else "mlp"
     monkeypatch.setitem(bigbatch.CHUNK_OVERRIDE, kind, chunk)
-    x, _ = agent.sample(torch.from_numpy(inp["prior"]).to(DEV), noise=list(inp["noise"][:int(gold["n_draws"])]), **kw)
+    x, _ = cases.sampler_of(agent, name)(torch.from_numpy(inp["prior"]).to(DEV), noise=list(inp["noise"][:int(gold["n_draws"])]), **kw)
     torch.cuda.synchronize()
     assert [c[0] for c in calls] == [kind], "exactly one native call for the whole loop"
     assert x.device.type == "cuda" and x.shape == gold["x_out"].shape
@@ -141,7 +141,7 @@ def test_unfused_backbones_match_reference_on_device(name, amd_lib, monkeypatch)
     inp = cases.make_inputs(name)
     kw = cases.sample_kwargs(name, inp, device=DEV)
     calls = _spy_launches(monkeypatch)
-    x, log = agent.sample(torch.from_numpy(inp["prior"]).to(DEV), noise=list(inp["noise"][:int(gold["n_draws"])]), **kw)
+    x, log = cases.sampler_of(agent, name)(torch.from_numpy(inp["prior"]).to(DEV), noise=list(inp["noise"][:int(gold["n_draws"])]), **kw)
     torch.cuda.synchronize()
     assert calls["n"] == 0
     np.testing.assert_allclose(x.cpu().numpy(), gold["x_out"], **TOL)
@@ -155,7 +155,7 @@ def test_fused_sample_matches_reference_fixture(name, amd_lib, monkeypatch):
     kw = cases.sample_kwargs(name, inp, device=DEV)
     n_draws = int(gold["n_draws"])
     calls = _spy_launches(monkeypatch)
-    x, log = agent.sample(torch.from_numpy(inp["prior"]).to(DEV), noise=list(inp["noise"][:n_draws]), **kw)
+    x, log = cases.sampler_of(agent, name)(torch.from_numpy(inp["prior"]).to(DEV), noise=list(inp["noise"][:n_draws]), **kw)
     torch.cuda.synchronize()
     has_clf = "log_p" in gold.files
     assert calls["n"] == (2 if has_clf else 1), "one launch for the whole loop (+ one for the classifier score)"

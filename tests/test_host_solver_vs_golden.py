@@ -16,7 +16,7 @@ def test_torch_executor_matches_reference_fixture(name, amd_lib):
     inp = cases.make_inputs(name)
     kw = cases.sample_kwargs(name, inp)
     n_draws = int(gold["n_draws"])
-    x, log = agent.sample(torch.from_numpy(inp["prior"]), noise=list(inp["noise"][:n_draws]), **kw)
+    x, log = cases.sampler_of(agent, name)(torch.from_numpy(inp["prior"]), noise=list(inp["noise"][:n_draws]), **kw)
     np.testing.assert_allclose(x.numpy(), gold["x_out"], rtol=2e-6, atol=2e-6)
     if "log_p" in gold.files:                      # Diffuser tail: classifier score of the finished trajectories
         np.testing.assert_allclose(log["log_p"].numpy(), gold["log_p"], rtol=2e-6, atol=2e-6)
@@ -101,4 +101,46 @@ def test_edm_plan_records_reproduce_reference(name, amd_lib):
                 x = x - s * st.k[3]
             else:
                 x = x_old - (slope_old + s) / 2.0 * st.k[3]
+    np.testing.assert_allclose(x.numpy(), gold["x_out"], rtol=1e-4, atol=1e-4)
+
+
+LEGACY_PLAN_CASES = [n for n, c in cases.CASES.items() if c["solver"][0] in ("DPMSolver", "EDM")]
+
+
+@pytest.mark.parametrize("name", LEGACY_PLAN_CASES)
+def test_legacy_plan_records_reproduce_reference(name, amd_lib):
+    """build_legacy_dpmsolver_plan / build_legacy_edm_plan, interpreted with the device's step semantics (oracle/step_sim.py),
+    land on the samples of the real reference's DPMSolver / EDM classes (tests/golden)."""
+    from cleandiffuser_amd.engine import plan as P
+    from oracle import step_sim
+    gold = np.load(golden_path(name))
+    c = cases.CASES[name]
+    agent, net = cases.build(amd_lib, name)
+    inp = cases.make_inputs(name)
+    s = c["sample"]
+    prior = torch.from_numpy(inp["prior"])
+    fm = torch.from_numpy(inp["fix_mask"])[None] if inp["fix_mask"] is not None else None
+    z = [torch.from_numpy(v) for v in inp["noise"]]
+    cond = None
+    if inp["cond"] is not None:
+        with torch.no_grad():
+            cond = agent.model_ema["condition"](torch.from_numpy(inp["cond"]), None)
+    if c["solver"][0] == "DPMSolver":
+        S, kappa = s["sample_steps"], s.get("kappa", 1.0)
+        idx = torch.arange(S + 1)
+        t = ((S - idx) / S * agent.t_range[1] ** (1 / kappa) + idx / S * agent.t_range[0] ** (1 / kappa)) ** kappa
+        alphas = agent.alpha_schedule(t)
+        plan = P.build_legacy_dpmsolver_plan(t, alphas, (1 - alphas ** 2).sqrt(), s["sampler"], S, s.get("extra_sample_steps", 0))
+        x0 = z[0] * s.get("temperature", 1.0)
+        kw = dict(predict_noise=agent.predict_noise, x_min=agent.x_min, x_max=agent.x_max)
+    else:
+        agent.set_sample_steps(s["sample_steps"])
+        plan = P.build_legacy_edm_plan(agent.sigma_data, agent.sigma_s, s["solver"], s.get("extra_sample_steps", 0))
+        x0 = z[0] * agent.sigma_s[0]
+        kw = dict(predict_noise=False)
+    if fm is not None:
+        x0 = x0 * (1 - fm) + prior * fm
+    x = step_sim.run_plan(plan, net, x0, prior=prior, fix_mask=fm, noise=z[1:], cond=cond, w_cfg=s.get("w_cfg", 0.0), **kw)
+    if c.get("clip") and c["solver"][0] == "DPMSolver":
+        x = x.clip(agent.x_min, agent.x_max)
     np.testing.assert_allclose(x.numpy(), gold["x_out"], rtol=1e-4, atol=1e-4)
