@@ -90,6 +90,16 @@ __global__ void solver_step_kernel(const StepArgs a) {
             float d = k0 * x + k1 * p;
             if (a.x_min) d = fmaxf(d, a.x_min[e]);
             if (a.x_max) d = fminf(d, a.x_max[e]);
+            if (st.kind == 7) {                          // consistency model: x <- f(x) [mask], then re-noise for the next level
+                xn = d;
+                if (a.fix_mask) {
+                    const float m = a.fix_mask[e];
+                    xn = xn * (1.0f - m) + a.prior[i] * m;
+                }
+                if (st.noise_idx >= 0) xn += k3 * a.noise[((size_t)st.noise_idx * a.batch + a.b0 + l) * a.hd + e];
+                a.x[i] = xn;
+                continue;
+            }
             const float s = (x - d) / k2;
             if (st.kind == 5) {
                 xn = x - s * k3;
@@ -348,7 +358,7 @@ int mlp_check(const cdx_resmlp_weights* w, const cdx_sampling* s) {
     if (w->x_dim <= 0 || w->emb_dim <= 0 || w->obs_dim < 0 || w->hidden <= 0 || w->hidden > 1024 || w->n_blocks < 0) {
         cdx_set_err("residual-MLP executor: hidden <= 1024 required (LayerNorm row in registers)"); return CDX_EINVAL;
     }
-    CDX_TRY(check_request(s, "cdx_resmlp_run", 6));
+    CDX_TRY(check_request(s, "cdx_resmlp_run", 7));
     if (s->hd != w->x_dim || s->emb_dim != w->emb_dim || (s->cond && s->cond_dim != w->obs_dim)) {
         cdx_set_err("residual-MLP request shape does not match the weights"); return CDX_EINVAL;
     }

@@ -707,6 +707,16 @@ __global__ __launch_bounds__(CDX_THREADS) void cdx_unet1d_kernel(const cdx_unet1
                 float dn = k0 * x + k1 * p;
                 if (L.x_min) dn = fmaxf(dn, L.x_min[e]);
                 if (L.x_max) dn = fminf(dn, L.x_max[e]);
+                if (st.kind == 7) {                      // consistency model: x <- f(x) [mask], then re-noise for the next level
+                    xn = dn;
+                    if (L.fix_mask) {
+                        const float m = L.fix_mask[e];
+                        xn = xn * (1.0f - m) + L.prior[xbase + e] * m;
+                    }
+                    if (st.noise_idx >= 0) xn += k3 * L.noise[((size_t)st.noise_idx * L.batch + b) * HD + e];
+                    lds[L.prev_off + 2 * PV + e] = xn;
+                    continue;
+                }
                 const float sl = (x - dn) / k2;
                 if (st.kind == 5) {
                     xn = x - sl * k3;

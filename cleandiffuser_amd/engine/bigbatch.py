@@ -12,7 +12,7 @@ from typing import Optional
 
 import torch
 
-from .runtime import CdxStep, _check, _dense_hd, _f32c, _signature, _stream_ptr, load_library
+from .runtime import CdxStep, _check, _dense_hd, _f32c, _predicts_noise, _signature, _stream_ptr, load_library
 
 _FP = ctypes.c_void_p
 _I = ctypes.c_int32
@@ -302,8 +302,9 @@ def sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed) -> Optional[torc
         return None                                   # the reference raises here; let the torch executor do it
     try:
         fix_mask = _dense_hd(solver.fix_mask, rows_h, d, dev)
-        x_min = _dense_hd(getattr(solver, "x_min", None), rows_h, d, dev)
-        x_max = _dense_hd(getattr(solver, "x_max", None), rows_h, d, dev)
+        clip = getattr(plan, "clip_each_step", True)
+        x_min = _dense_hd(getattr(solver, "x_min", None), rows_h, d, dev) if clip else None
+        x_max = _dense_hd(getattr(solver, "x_max", None), rows_h, d, dev) if clip else None
     except (ValueError, RuntimeError):
         return None
     with torch.no_grad():
@@ -327,7 +328,7 @@ def sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed) -> Optional[torc
         chunk = CHUNK_OVERRIDE[kind] or (_dit_chunk(b, rows_h, net.d_model, two) if kind == "dit" else
                                          _mlp_chunk(b, bound.struct.hidden, two))
         _run(kind, bound, batch=b, hd=hd, emb_dim=emb_dim, cond_dim=cond_dim, temb=temb, steps=steps,
-             n_steps=len(plan.steps), temb_per_sample=0, predict_noise=getattr(solver, "predict_noise", False),
+             n_steps=len(plan.steps), temb_per_sample=0, predict_noise=_predicts_noise(plan, solver),
              cfg_mode=mode, cfg_w=w_cfg, cond=cond, x_in=xin, prior=_f32c(prior, dev) if fix_mask is not None else None,
              fix_mask=fix_mask, noise=noise, x_min=x_min, x_max=x_max, x_out=out, chunk=chunk)
     return out

@@ -47,6 +47,8 @@ class SamplePlan:
     solver: str
     steps: List[Step] = field(default_factory=list)
     t_is_integer: bool = True
+    clip_each_step: bool = True            # False: the solver has no per-step clipping (rectified flow)
+    network_predicts_noise: object = None  # None: ask the solver object; True/False: the plan decides (rectified flow)
 
     @property
     def n_noise(self) -> int:
@@ -250,4 +252,37 @@ def build_legacy_edm_plan(sigma_data: float, sigma_s: torch.Tensor, solver: str,
             plan.steps.append(rec(KIND_EDM_HEUN, i + 1, dt, 0))
     for _ in range(extra_sample_steps):
         plan.steps.append(rec(KIND_EDM_EULER, n - 1, _f(sig[n - 1] - sig[n]), 0))
+    return plan
+
+
+KIND_CONSISTENCY = 7
+
+
+def build_flow_plan(times, dts, integer_time: bool) -> SamplePlan:
+    """Rectified-flow Euler steps (reference diffusion/rectifiedflow.py:318-334, :612-628): x <- x + dt v(x, t).  As ``linear``
+    records: alpha = sigma = 1 and "predict noise" so that V is the raw network output, k0 = 1, k1 = -dt.  The per-step
+    clipping of the VP solvers does not exist here (``clip_each_step = False``); the class clips once at the end."""
+    plan = SamplePlan(solver="rectified_flow_euler", t_is_integer=integer_time)
+    plan.clip_each_step = False
+    plan.network_predicts_noise = True
+    for k, (t, dt) in enumerate(zip(times, dts)):
+        plan.steps.append(Step(KIND_LINEAR, V_EPS, k, int(t) if integer_time else _f(t), 1.0, 1.0, (1.0, -_f(dt), 0.0, 0.0, 0.0)))
+    return plan
+
+
+def build_consistency_plan(sigma_data: float, sigma_min: float, sigmas: torch.Tensor, levels) -> SamplePlan:
+    """Multistep consistency sampling (reference diffusion/consistency_model.py:412-427): record j evaluates
+    f(x, sigma_{levels[j]}) = clip(c_skip x + c_out F(c_in x, ln(sigma)/4)), applies the fix-mask, and -- unless it is the last
+    record -- re-noises for the next level: x <- f + sqrt(sigma_next^2 - sigma_min^2) z.  Kind 7: k = (c_skip, c_out, -, noise
+    scale), ``alpha`` = c_in, boundary-condition preconditioning c_skip = sd^2 / (sd^2 + (s - smin)^2), c_out = (s - smin) sd / sqrt(sd^2 + s^2)."""
+    sig = sigmas.detach().float().cpu()
+    sd2 = sigma_data ** 2
+    plan = SamplePlan(solver="consistency", t_is_integer=False)
+    for j, i in enumerate(levels):
+        s = sig[i]
+        last = j == len(levels) - 1
+        renoise = 0.0 if last else _f((sig[levels[j + 1]] ** 2 - sigma_min ** 2).sqrt())
+        plan.steps.append(Step(KIND_CONSISTENCY, V_EPS, i, _f(0.25 * s.log()), _f(1 / (sd2 + s ** 2).sqrt()), _f(s),
+                               (_f(sd2 / (sd2 + (s - sigma_min) ** 2)), _f((s - sigma_min) * sigma_data / (sd2 + s ** 2).sqrt()),
+                                1.0, renoise, 0.0), noise=not last))
     return plan

@@ -298,6 +298,12 @@ def backbone_forward(module, x, noise, condition) -> Optional[torch.Tensor]:
     return out
 
 
+def _predicts_noise(plan, solver) -> bool:
+    """What the network output means for this plan: the plan's own statement (rectified flow) or the solver's attribute."""
+    own = getattr(plan, "network_predicts_noise", None)
+    return bool(getattr(solver, "predict_noise", False) if own is None else own)
+
+
 def steps_to_device(plan, device) -> torch.Tensor:
     arr = (CdxStep * len(plan.steps))()
     k = 0
@@ -325,8 +331,9 @@ def fused_sample_mlp(solver, net, kind, plan, xt, prior, cond_vec, w_cfg, feed) 
     pad = n_tiles * tile - b
     try:
         fix_mask = _dense_hd(solver.fix_mask, 1, d, dev)
-        x_min = _dense_hd(getattr(solver, "x_min", None), 1, d, dev)
-        x_max = _dense_hd(getattr(solver, "x_max", None), 1, d, dev)
+        clip = getattr(plan, "clip_each_step", True)
+        x_min = _dense_hd(getattr(solver, "x_min", None), 1, d, dev) if clip else None
+        x_max = _dense_hd(getattr(solver, "x_max", None), 1, d, dev) if clip else None
     except (ValueError, RuntimeError):
         return None
 
@@ -355,7 +362,7 @@ def fused_sample_mlp(solver, net, kind, plan, xt, prior, cond_vec, w_cfg, feed) 
         xin = rows(xt)
         out = torch.empty_like(xin)
         _launch(comp, batch=n_tiles, x_in=xin, x_out=out, temb=temb, steps_dev=steps_dev, n_steps=len(plan.steps),
-                predict_noise=getattr(solver, "predict_noise", False), cfg_mode=1 if cond is not None else 0, cfg_w=w_cfg, cond=cond,
+                predict_noise=_predicts_noise(plan, solver), cfg_mode=1 if cond is not None else 0, cfg_w=w_cfg, cond=cond,
                 prior=rows(prior) if fix_mask is not None else None, fix_mask=table(fix_mask), noise=noise,
                 x_min=table(x_min), x_max=table(x_max))
     return out[:b]
@@ -376,8 +383,9 @@ def fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed) -> Optio
         b, h, d = xt.shape
         dev = xt.device
         fix_mask = _dense_hd(solver.fix_mask, h, d, dev)
-        x_min = _dense_hd(getattr(solver, "x_min", None), h, d, dev)
-        x_max = _dense_hd(getattr(solver, "x_max", None), h, d, dev)
+        clip = getattr(plan, "clip_each_step", True)
+        x_min = _dense_hd(getattr(solver, "x_min", None), h, d, dev) if clip else None
+        x_max = _dense_hd(getattr(solver, "x_max", None), h, d, dev) if clip else None
     except ValueError:
         return None
     load_library()
@@ -397,7 +405,7 @@ def fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed) -> Optio
         xin = _f32c(xt, dev)
         out = torch.empty_like(xin)
         _launch(comp, batch=b, x_in=xin, x_out=out, temb=temb, steps_dev=steps_dev, n_steps=len(plan.steps),
-                predict_noise=getattr(solver, "predict_noise", False), cfg_mode=mode, cfg_w=w_cfg, cond=cond,
+                predict_noise=_predicts_noise(plan, solver), cfg_mode=mode, cfg_w=w_cfg, cond=cond,
                 prior=_f32c(prior, dev) if fix_mask is not None else None, fix_mask=fix_mask, noise=noise,
                 x_min=x_min, x_max=x_max)
     return out

@@ -42,11 +42,13 @@ extern "C" {
  *   kind 5/6 (EDM Euler / Heun corrector; reference diffusion/newedm.py:387-401, legacy edm.py:118-160,252-268):
  *            `alpha` carries c_in (the network sees c_in*x), k = (c_skip, c_out, sigma, dt):
  *            D = clip(k0*x + k1*F); s = (x - D)/k2;  kind 5: x' = x - k3*s (push: remember s and x);
- *            kind 6: x' = x_old - k3*(s_old + s)/2.   A plan is all-EDM or not EDM at all.
+ *            kind 6: x' = x_old - k3*(s_old + s)/2.
+ *   kind 7 (consistency model, reference diffusion/consistency_model.py:412-427): x' = mask(D) [+ k3*z]  (re-noising for
+ *            the next level; the fix-mask is applied BEFORE the noise).   A plan is all-EDM-family (5/6/7) or not at all.
  * followed by the fix-mask blend (diffusionsde.py:592). */
 #define CDX_STEP_MASK_PRED 1
 typedef struct cdx_step {
-    int32_t kind;        /* 0 ddpm, 1 ddim, 2 linear, 3 legacy-ddpm eps, 4 legacy-ddpm x0 */
+    int32_t kind;        /* 0 ddpm, 1 ddim, 2 linear, 3 legacy-ddpm eps, 4 legacy-ddpm x0, 5 edm euler, 6 edm heun, 7 consistency */
     int32_t vsel;        /* kind 2: 0 eps, 1 x_theta, 2 multistep on x_theta, 3 multistep on eps */
     int32_t noise_idx;   /* index into `noise` of this step's N(0,I) draw, or -1 */
     int32_t push;        /* 1: remember x_theta (2: eps) for the next multistep update; EDM: remember slope and state */

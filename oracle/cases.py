@@ -174,6 +174,23 @@ CASES.update({
         solver=("EDM", dict()), sample=dict(solver="euler", sample_steps=5, w_cfg=1.0)),
 })
 
+# ---- rectified flow and consistency models (Euler transport as linear records; step kind 7) ----
+CASES.update({
+    "janner_rflow_discrete": dict(_J8, clip=2.0, solver=("DiscreteRectifiedFlow", dict(diffusion_steps=20)),
+                                  sample=dict(sample_steps=5, temperature=0.8, diffusion_x_sampling_steps=1)),
+    "janner_rflow_cont_cfg": dict(_J8, cond_dim=8, solver=("ContinuousRectifiedFlow", dict()),
+                                  sample=dict(sample_steps=6, w_cfg=1.5)),
+    "idql_rflow_cont": dict(
+        net=("IDQLMlp", dict(obs_dim=0, act_dim=15, emb_dim=32, hidden_dim=64, n_blocks=2)), x_shape=(15,), batch=6,
+        clip=2.0, legacy=True, solver=("ContinuousRectifiedFlow", dict()), sample=dict(sample_steps=5, temperature=0.9)),
+    "janner_cm": dict(_J8, clip=2.0, solver=("ContinuousConsistencyModel", dict()),
+                      sample=dict(sample_steps=4, diffusion_x_sampling_steps=1, temperature=0.9)),
+    "idql_cm_cond": dict(
+        net=("IDQLMlp", dict(obs_dim=11, act_dim=3, emb_dim=16, hidden_dim=64, n_blocks=2)), x_shape=(3,), batch=7,
+        cond=("IdentityCondition", dict(dropout=0.0), (11,)), legacy=True,
+        solver=("ContinuousConsistencyModel", dict(sigma_max=10.0)), sample=dict(sample_steps=3)),
+})
+
 # one small case per solver (discrete + continuous) so every update rule is pinned
 for _s in _ALL_SOLVERS:
     CASES[f"janner_tiny_disc_{_s}"] = dict(

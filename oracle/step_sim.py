@@ -28,6 +28,10 @@ def run_plan(plan, net, x, *, predict_noise, prior=None, fix_mask=None, noise=()
                 d = torch.maximum(d, x_min)
             if x_max is not None:
                 d = torch.minimum(d, x_max)
+            if st.kind == 7:                     # consistency model: mask first, then re-noise for the next level
+                xn = d if fix_mask is None else d * (1.0 - m) + prior * m
+                x = xn + k[3] * next(draws) if st.noise else xn
+                continue
             s = (x - d) / k[2]
             if st.kind == 5:
                 xn = x - s * k[3]

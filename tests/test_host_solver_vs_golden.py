@@ -144,3 +144,40 @@ def test_legacy_plan_records_reproduce_reference(name, amd_lib):
     if c.get("clip") and c["solver"][0] == "DPMSolver":
         x = x.clip(agent.x_min, agent.x_max)
     np.testing.assert_allclose(x.numpy(), gold["x_out"], rtol=1e-4, atol=1e-4)
+
+
+FLOW_CM_CASES = [n for n, c in cases.CASES.items()
+                 if c["solver"][0] in ("DiscreteRectifiedFlow", "ContinuousRectifiedFlow", "ContinuousConsistencyModel")]
+
+
+@pytest.mark.parametrize("name", FLOW_CM_CASES)
+def test_flow_and_consistency_plans_reproduce_reference(name, amd_lib, monkeypatch):
+    """The records the rectified-flow / consistency classes hand to the device (captured from the class itself by
+    intercepting the dispatch hook), interpreted by oracle/step_sim.py, land on the real reference's samples."""
+    from cleandiffuser_amd.engine import dispatch
+    from oracle import step_sim
+    gold = np.load(golden_path(name))
+    c = cases.CASES[name]
+    agent, net = cases.build(amd_lib, name)
+    inp = cases.make_inputs(name)
+    seen = {}
+
+    def capture(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, requires_grad, feed):
+        seen.update(plan=plan, xt=xt.clone(), cond=cond_vec, w_cfg=w_cfg)
+        return None                                        # -> the class continues on its PyTorch loop
+    monkeypatch.setattr(dispatch, "try_fused_sample", capture)
+    monkeypatch.setattr(dispatch, "try_fused_edm", capture)
+    kw = cases.sample_kwargs(name, inp)
+    n_draws = int(gold["n_draws"])
+    x_ref, _ = agent.sample(torch.from_numpy(inp["prior"]), noise=list(inp["noise"][:n_draws]), **kw)
+    plan = seen["plan"]
+    fm = torch.from_numpy(inp["fix_mask"])[None] if inp["fix_mask"] is not None else None
+    clip_d = c["solver"][0] == "ContinuousConsistencyModel"    # f() clips inside every evaluation; flows clip once at the end
+    x = step_sim.run_plan(plan, net, seen["xt"], predict_noise=bool(plan.network_predicts_noise),
+                          prior=torch.from_numpy(inp["prior"]), fix_mask=fm,
+                          noise=[torch.from_numpy(v) for v in inp["noise"][1:]], cond=seen["cond"], w_cfg=seen["w_cfg"],
+                          x_min=agent.x_min if clip_d else None, x_max=agent.x_max if clip_d else None)
+    if agent.clip_pred and not clip_d:
+        x = x.clip(agent.x_min, agent.x_max)
+    np.testing.assert_allclose(x.numpy(), gold["x_out"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(x_ref.numpy(), gold["x_out"], rtol=2e-6, atol=2e-6)
