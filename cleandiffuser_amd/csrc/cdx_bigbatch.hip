@@ -314,7 +314,7 @@ int dit_forward(const cdx_dit1d_weights* w, const cdx_sampling* s, hipStream_t s
         CDX_TRY(gemm(st, B.xm, d, k.qkv_w, d, k.qkv_b, B.qkv, 3 * d, rows, 3 * d, d));
         cdx_attn_args at;
         at.qkv = B.qkv; at.out = B.att; at.B = bf; at.T = T; at.n_heads = w->n_heads; at.head_dim = d / w->n_heads;
-        at.scale = 1.0f / sqrtf((float)at.head_dim);
+        at.scale = 1.0f / sqrtf((float)at.head_dim); at.mask = nullptr;
         CDX_TRY(cdx_attention_f32(&at, st));
         CDX_TRY(gemm(st, B.att, d, k.proj_w, d, k.proj_b, B.h2, d, rows, d, d, CDX_ACT_NONE, ada + 2 * d, ntot, T, B.xm, d));
         CDX_TRY(layernorm(st, B.h2, B.xm, rows, d, 1e-6f, nullptr, nullptr, ada + 4 * d, ada + 3 * d, ntot, T, 0));
@@ -392,6 +392,140 @@ int mlp_forward(const cdx_resmlp_weights* w, const cdx_sampling* s, hipStream_t 
     return CDX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// ChiTransformer
+// ------------------------------------------------------------------------------------------------
+// observation rows of a chunk: conditional samples copy their (To, obs_dim) block, unconditional ones are zeros
+__global__ void obs_rows_kernel(float* __restrict__ out, const float* __restrict__ cond, int rows, int nb, int b0, int width,
+                                int n_cond_rows) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)rows * width) return;
+    const int r = (int)(i / width), c = (int)(i - (size_t)r * width);
+    out[i] = (cond != nullptr && r < n_cond_rows) ? cond[(size_t)(b0 + r % nb) * width + c] : 0.f;
+}
+
+// timestep tokens: temb[row] + cond_pos_emb[0]
+__global__ void time_rows_kernel(float* __restrict__ out, const float* __restrict__ temb, const float* __restrict__ pos0,
+                                 int rows, int nb, int b0, int d, int per_sample) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)rows * d) return;
+    const int r = (int)(i / d), c = (int)(i - (size_t)r * d);
+    out[i] = temb[(size_t)(per_sample ? b0 + r % nb : r) * d + c] + pos0[c];
+}
+
+struct TfBuffers {
+    float *x, *prev, *obs, *tin, *tenc, *tmem, *oin, *oenc, *omem, *tkv, *okv, *h, *y, *qkv, *att, *f, *pred;
+};
+
+long long tf_layout(const cdx_chitf_weights* w, const cdx_sampling* s, float* base, TfBuffers* B) {
+    const long long nb = chunk_of(s), bf = nb * (s->cfg_mode == 2 ? 2 : 1);
+    const long long d = w->d_model, rows = bf * w->Ta, orow = bf * w->To;
+    const long long trow = s->temb_per_sample ? bf : (s->n_steps > 0 ? s->n_steps : 1);
+    Arena a{base, 0, 0};
+    TfBuffers b;
+    b.x = a.take(nb * s->hd);
+    b.prev = a.take(nb * s->hd);
+    b.obs = a.take(orow * w->obs_dim);
+    b.tin = a.take(trow * d);
+    b.tenc = a.take(trow * 4 * d);
+    b.tmem = a.take(trow * d);
+    b.oin = a.take(orow * d);
+    b.oenc = a.take(orow * 4 * d);
+    b.omem = a.take(orow * d);
+    b.tkv = a.take((long long)w->n_layers * trow * 2 * d);
+    b.okv = a.take((long long)w->n_layers * orow * 2 * d);
+    b.h = a.take(rows * d);
+    b.y = a.take(rows * d);
+    b.qkv = a.take(rows * 3 * d);
+    b.att = a.take(rows * d);
+    b.f = a.take(rows * 4 * d);
+    b.pred = a.take(rows * w->act_dim);
+    if (B) *B = b;
+    return a.used;
+}
+
+int tf_check(const cdx_chitf_weights* w, const cdx_sampling* s) {
+    if (!w || !w->layers || !w->act_emb_w || !w->pos_emb || !w->obs_emb_w || !w->cond_pos_emb || !w->enc0_w || !w->enc2_w ||
+        !w->lnf_g || !w->head_w || !w->self_mask || !w->memory_mask) { cdx_set_err("null pointer in ChiTransformer weights"); return CDX_EINVAL; }
+    if (w->Ta <= 0 || w->Ta > 64 || w->To < 0 || 1 + w->To > 16 || w->d_model <= 0 || w->d_model > 1024 || w->n_heads <= 0 ||
+        w->d_model % w->n_heads != 0 || w->d_model / w->n_heads > 64 || w->n_layers < 0) {
+        cdx_set_err("ChiTransformer executor: Ta <= 64, 1 + To <= 16, d_model <= 1024, head_dim <= 64 required"); return CDX_EINVAL;
+    }
+    CDX_TRY(check_request(s, "cdx_chitf_run", 4));
+    if (s->hd != w->Ta * w->act_dim || s->emb_dim != w->d_model || (s->cond && s->cond_dim != w->To * w->obs_dim)) {
+        cdx_set_err("ChiTransformer request shape does not match the weights"); return CDX_EINVAL;
+    }
+    return CDX_OK;
+}
+
+// memory tokens and their per-layer K/V projections (independent of the state x)
+int tf_prepare(const cdx_chitf_weights* w, const cdx_sampling* s, hipStream_t st, const TfBuffers& B, int nb, int b0) {
+    const int two = s->cfg_mode == 2 ? 2 : 1, bf = nb * two, d = w->d_model, To = w->To;
+    const int orow = bf * To, trow = s->temb_per_sample ? bf : (s->n_steps > 0 ? s->n_steps : 1);
+    const int n_cond_rows = (s->cond == nullptr || s->cfg_mode == 0) ? 0 : nb * To;
+    {
+        const long long n = (long long)trow * d;
+        hipLaunchKernelGGL(time_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, B.tin, s->temb, w->cond_pos_emb,
+                           trow, nb, b0, d, s->temb_per_sample);
+        CDX_TRY(hip_ok());
+    }
+    CDX_TRY(gemm(st, B.tin, d, w->enc0_w, d, w->enc0_b, B.tenc, 4 * d, trow, 4 * d, d, CDX_ACT_MISH));
+    CDX_TRY(gemm(st, B.tenc, 4 * d, w->enc2_w, 4 * d, w->enc2_b, B.tmem, d, trow, d, 4 * d));
+    if (To > 0) {
+        const long long n = (long long)orow * w->obs_dim;
+        // cond is (batch, To * obs_dim): row (b, s) of the observation table is a contiguous slice of it
+        hipLaunchKernelGGL(obs_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, B.obs, s->cond, bf, nb, b0,
+                           To * w->obs_dim, n_cond_rows / (To > 0 ? To : 1));
+        CDX_TRY(hip_ok());
+        CDX_TRY(gemm(st, B.obs, w->obs_dim, w->obs_emb_w, w->obs_dim, w->obs_emb_b, B.oin, d, orow, d, w->obs_dim, CDX_ACT_NONE,
+                     nullptr, 0, 1, nullptr, 0, w->cond_pos_emb + d, To));
+        CDX_TRY(gemm(st, B.oin, d, w->enc0_w, d, w->enc0_b, B.oenc, 4 * d, orow, 4 * d, d, CDX_ACT_MISH));
+        CDX_TRY(gemm(st, B.oenc, 4 * d, w->enc2_w, 4 * d, w->enc2_b, B.omem, d, orow, d, 4 * d));
+    }
+    for (int l = 0; l < w->n_layers; ++l) {
+        const cdx_chitf_layer& k = w->layers[l];
+        CDX_TRY(gemm(st, B.tmem, d, k.ca_in_w + (size_t)d * d, d, k.ca_in_b + d, B.tkv + (size_t)l * trow * 2 * d, 2 * d, trow, 2 * d, d));
+        if (To > 0)
+            CDX_TRY(gemm(st, B.omem, d, k.ca_in_w + (size_t)d * d, d, k.ca_in_b + d, B.okv + (size_t)l * orow * 2 * d, 2 * d, orow, 2 * d, d));
+    }
+    return CDX_OK;
+}
+
+int tf_forward(const cdx_chitf_weights* w, const cdx_sampling* s, hipStream_t st, const TfBuffers& B, const float* x, float* pred,
+               int nb, int rec) {
+    const int two = s->cfg_mode == 2 ? 2 : 1, bf = nb * two;
+    const int T = w->Ta, d = w->d_model, rows = bf * T, orow = bf * w->To;
+    const int trow = s->temb_per_sample ? bf : (s->n_steps > 0 ? s->n_steps : 1);
+    for (int half = 0; half < two; ++half)               // both CFG halves start from the same action tokens
+        CDX_TRY(gemm(st, x, w->act_dim, w->act_emb_w, w->act_dim, w->act_emb_b, B.h + (size_t)half * nb * T * d, d, nb * T, d,
+                     w->act_dim, CDX_ACT_NONE, nullptr, 0, 1, nullptr, 0, w->pos_emb, T));
+    for (int l = 0; l < w->n_layers; ++l) {
+        const cdx_chitf_layer& k = w->layers[l];
+        CDX_TRY(layernorm(st, B.h, B.y, rows, d, 1e-5f, k.ln1_g, k.ln1_b, nullptr, nullptr, 0, 1, 0));
+        CDX_TRY(gemm(st, B.y, d, k.sa_in_w, d, k.sa_in_b, B.qkv, 3 * d, rows, 3 * d, d));
+        cdx_attn_args at;
+        at.qkv = B.qkv; at.out = B.att; at.B = bf; at.T = T; at.n_heads = w->n_heads; at.head_dim = d / w->n_heads;
+        at.scale = 1.0f / sqrtf((float)at.head_dim); at.mask = w->self_mask;
+        CDX_TRY(cdx_attention_f32(&at, st));
+        CDX_TRY(gemm(st, B.att, d, k.sa_out_w, d, k.sa_out_b, B.h, d, rows, d, d, CDX_ACT_NONE, nullptr, 0, 1, B.h, d));
+        CDX_TRY(layernorm(st, B.h, B.y, rows, d, 1e-5f, k.ln2_g, k.ln2_b, nullptr, nullptr, 0, 1, 0));
+        CDX_TRY(gemm(st, B.y, d, k.ca_in_w, d, k.ca_in_b, B.qkv, d, rows, d, d));       // q projection only
+        cdx_xattn_args xa;
+        xa.q = B.qkv; xa.kv_shared = B.tkv + (size_t)l * trow * 2 * d; xa.kv_rows = B.okv + (size_t)l * orow * 2 * d;
+        xa.mask = w->memory_mask; xa.out = B.att; xa.B = bf; xa.T = T; xa.n_obs = w->To; xa.n_heads = w->n_heads;
+        xa.head_dim = d / w->n_heads; xa.shared_row = rec; xa.shared_per_sample = s->temb_per_sample;
+        xa.scale = at.scale;
+        CDX_TRY(cdx_cross_attention_f32(&xa, st));
+        CDX_TRY(gemm(st, B.att, d, k.ca_out_w, d, k.ca_out_b, B.h, d, rows, d, d, CDX_ACT_NONE, nullptr, 0, 1, B.h, d));
+        CDX_TRY(layernorm(st, B.h, B.y, rows, d, 1e-5f, k.ln3_g, k.ln3_b, nullptr, nullptr, 0, 1, 0));
+        CDX_TRY(gemm(st, B.y, d, k.ff1_w, d, k.ff1_b, B.f, 4 * d, rows, 4 * d, d, CDX_ACT_GELU_ERF));
+        CDX_TRY(gemm(st, B.f, 4 * d, k.ff2_w, 4 * d, k.ff2_b, B.h, d, rows, d, 4 * d, CDX_ACT_NONE, nullptr, 0, 1, B.h, d));
+    }
+    CDX_TRY(layernorm(st, B.h, B.y, rows, d, 1e-5f, w->lnf_g, w->lnf_b, nullptr, nullptr, 0, 1, 0));
+    CDX_TRY(gemm(st, B.y, d, w->head_w, d, w->head_b, pred, w->act_dim, rows, w->act_dim, d));
+    return CDX_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -420,6 +554,37 @@ int cdx_dit1d_run(const cdx_dit1d_weights* w, const cdx_sampling* s, void* hip_s
         if (hipMemcpyAsync(B.x, s->x_in + off, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return hip_ok();
         for (int i = 0; i < s->n_steps; ++i) {
             CDX_TRY(dit_forward(w, s, st, B, B.x, B.pred, nb, i));
+            CDX_TRY(run_step(st, s, s->steps[i], B.x, B.pred, B.prev, nullptr, nb, b0));
+        }
+        if (hipMemcpyAsync(s->x_out + off, B.x, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return hip_ok();
+    }
+    return CDX_OK;
+}
+
+long long cdx_chitf_workspace_floats(const cdx_chitf_weights* w, const cdx_sampling* s) {
+    if (!w || !s) return -1;
+    return tf_layout(w, s, nullptr, nullptr);
+}
+
+int cdx_chitf_run(const cdx_chitf_weights* w, const cdx_sampling* s, void* hip_stream) {
+    CDX_TRY(tf_check(w, s));
+    if (s->batch == 0) return CDX_OK;
+    TfBuffers B;
+    const long long need = tf_layout(w, s, s->workspace, &B);
+    if (!s->workspace || s->workspace_floats < need) { cdx_set_err("cdx_chitf_run: workspace too small"); return CDX_EINVAL; }
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    const int chunk = chunk_of(s);
+    for (int b0 = 0; b0 < s->batch; b0 += chunk) {
+        const int nb = s->batch - b0 < chunk ? s->batch - b0 : chunk;
+        const size_t off = (size_t)b0 * s->hd, bytes = (size_t)nb * s->hd * sizeof(float);
+        CDX_TRY(tf_prepare(w, s, st, B, nb, b0));
+        if (s->n_steps == 0) {
+            CDX_TRY(tf_forward(w, s, st, B, s->x_in + off, s->x_out + off, nb, 0));
+            continue;
+        }
+        if (hipMemcpyAsync(B.x, s->x_in + off, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return hip_ok();
+        for (int i = 0; i < s->n_steps; ++i) {
+            CDX_TRY(tf_forward(w, s, st, B, B.x, B.pred, nb, i));
             CDX_TRY(run_step(st, s, s->steps[i], B.x, B.pred, B.prev, nullptr, nb, b0));
         }
         if (hipMemcpyAsync(s->x_out + off, B.x, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return hip_ok();

@@ -381,7 +381,9 @@ __global__ __launch_bounds__(64) void cdx_attention_kernel(const cdx_attn_args a
     }
 #pragma unroll
     for (int j = 0; j < 64; ++j) {
-        p[j] = j < a.T ? p[j] : -3.0e38f;
+        float sc = p[j];
+        if (a.mask != nullptr && j < a.T) sc += a.mask[t * a.T + j];
+        p[j] = j < a.T ? fmaxf(sc, -3.0e38f) : -3.0e38f;
         mx = fmaxf(mx, p[j]);
     }
     float den = 0.f;
@@ -478,7 +480,9 @@ __global__ __launch_bounds__(256) void cdx_attention_mfma_kernel(const cdx_attn_
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int j = k * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                s[q][k][r] = j < T ? s[q][k][r] : -3.0e38f;
+                float sc = s[q][k][r];
+                if (a.mask != nullptr && j < T && q * 32 + lr < T) sc += a.mask[(q * 32 + lr) * T + j];
+                s[q][k][r] = j < T ? fmaxf(sc, -3.0e38f) : -3.0e38f;     // -inf entries become the finite floor: exp -> 0
                 mx = fmaxf(mx, s[q][k][r]);
             }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -529,6 +533,56 @@ __global__ __launch_bounds__(256) void cdx_attention_mfma_kernel(const cdx_attn_
                     *reinterpret_cast<float4*>(op + d0) = make_float4(o[q][db][4 * g4] * inv_den[q], o[q][db][4 * g4 + 1] * inv_den[q],
                                                                        o[q][db][4 * g4 + 2] * inv_den[q], o[q][db][4 * g4 + 3] * inv_den[q]);
             }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cross-attention against a short memory (S = 1 + n_obs <= 16 keys): one thread per (batch, head, query).  The work is
+// tiny (T x S x head_dim per head); K/V rows are shared by the T threads of a (batch, head) and come from cache.
+// ------------------------------------------------------------------------------------------------
+#define XA_MAX_S 16
+__global__ __launch_bounds__(256) void cdx_cross_attention_kernel(const cdx_xattn_args a) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = a.B * a.n_heads * a.T;
+    if (idx >= total) return;
+    const int t = idx % a.T, h = (idx / a.T) % a.n_heads, b = idx / (a.T * a.n_heads);
+    const int dh = a.head_dim, dm = a.n_heads * dh, S = 1 + a.n_obs;
+    const float* q = a.q + ((size_t)b * a.T + t) * dm + h * dh;
+    const float* kv[XA_MAX_S];
+    kv[0] = a.kv_shared + (size_t)(a.shared_per_sample ? b : a.shared_row) * (2 * dm) + h * dh;
+#pragma unroll
+    for (int s = 1; s < XA_MAX_S; ++s)
+        kv[s] = s < S ? a.kv_rows + ((size_t)b * a.n_obs + (s - 1)) * (2 * dm) + h * dh : kv[0];
+    float sc[XA_MAX_S];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int s = 0; s < XA_MAX_S; ++s) {
+        float acc = 0.f;
+        if (s < S) {
+            for (int d = 0; d < dh; ++d) acc = fmaf(q[d], kv[s][d], acc);
+            acc *= a.scale;
+            if (a.mask) acc += a.mask[t * S + s];
+            acc = fmaxf(acc, -3.0e38f);
+        } else {
+            acc = -3.0e38f;
+        }
+        sc[s] = acc;
+        mx = fmaxf(mx, acc);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int s = 0; s < XA_MAX_S; ++s) {
+        sc[s] = s < S ? expf(sc[s] - mx) : 0.f;
+        den += sc[s];
+    }
+    const float inv = 1.0f / den;
+    float* o = a.out + ((size_t)b * a.T + t) * dm + h * dh;
+    for (int d = 0; d < dh; ++d) {
+        float acc = 0.f;
+#pragma unroll
+        for (int s = 0; s < XA_MAX_S; ++s)
+            if (s < S) acc = fmaf(sc[s], kv[s][dm + d], acc);
+        o[d] = acc * inv;
     }
 }
 
@@ -613,6 +667,21 @@ int cdx_attention_f32(const cdx_attn_args* a, void* hip_stream) {
     } else {
         hipLaunchKernelGGL(cdx_attention_kernel, dim3(a->B * a->n_heads), dim3(64), 0, st, *a);
     }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
+    return CDX_OK;
+}
+
+int cdx_cross_attention_f32(const cdx_xattn_args* a, void* hip_stream) {
+    if (!a) { cdx_set_err("cdx_cross_attention_f32: null argument block"); return CDX_EINVAL; }
+    if (a->B < 0 || a->T <= 0 || a->n_obs < 0 || 1 + a->n_obs > XA_MAX_S || a->n_heads <= 0 || a->head_dim <= 0) {
+        cdx_set_err("cdx_cross_attention_f32: 1 + n_obs <= 16 memory tokens required"); return CDX_EINVAL;
+    }
+    if (a->B == 0) return CDX_OK;
+    if (!a->q || !a->kv_shared || !a->out || (a->n_obs > 0 && !a->kv_rows)) { cdx_set_err("cdx_cross_attention_f32: null pointer"); return CDX_EINVAL; }
+    const long long total = (long long)a->B * a->n_heads * a->T;
+    hipLaunchKernelGGL(cdx_cross_attention_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(hip_stream), *a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
     return CDX_OK;

@@ -47,6 +47,19 @@ class CdxResMlpWeights(ctypes.Structure):
                 ("in_w", _FP), ("in_b", _FP), ("blocks", ctypes.POINTER(CdxResMlpBlock)), ("out_w", _FP), ("out_b", _FP)]
 
 
+class CdxChitfLayer(ctypes.Structure):
+    _fields_ = [(n, _FP) for n in ("ln1_g", "ln1_b", "sa_in_w", "sa_in_b", "sa_out_w", "sa_out_b", "ln2_g", "ln2_b", "ca_in_w",
+                                   "ca_in_b", "ca_out_w", "ca_out_b", "ln3_g", "ln3_b", "ff1_w", "ff1_b", "ff2_w", "ff2_b")]
+
+
+class CdxChitfWeights(ctypes.Structure):
+    _fields_ = [("Ta", _I), ("To", _I), ("act_dim", _I), ("obs_dim", _I), ("d_model", _I), ("n_heads", _I), ("n_layers", _I),
+                ("act_emb_w", _FP), ("act_emb_b", _FP), ("pos_emb", _FP), ("obs_emb_w", _FP), ("obs_emb_b", _FP),
+                ("cond_pos_emb", _FP), ("enc0_w", _FP), ("enc0_b", _FP), ("enc2_w", _FP), ("enc2_b", _FP),
+                ("layers", ctypes.POINTER(CdxChitfLayer)), ("lnf_g", _FP), ("lnf_b", _FP), ("head_w", _FP), ("head_b", _FP),
+                ("self_mask", _FP), ("memory_mask", _FP)]
+
+
 _declared = False
 
 
@@ -58,6 +71,10 @@ def _lib():
         lib.cdx_dit1d_workspace_floats.restype = ctypes.c_longlong
         lib.cdx_dit1d_run.argtypes = [ctypes.POINTER(CdxDitWeights), ctypes.POINTER(CdxSampling), ctypes.c_void_p]
         lib.cdx_dit1d_run.restype = ctypes.c_int
+        lib.cdx_chitf_workspace_floats.argtypes = [ctypes.POINTER(CdxChitfWeights), ctypes.POINTER(CdxSampling)]
+        lib.cdx_chitf_workspace_floats.restype = ctypes.c_longlong
+        lib.cdx_chitf_run.argtypes = [ctypes.POINTER(CdxChitfWeights), ctypes.POINTER(CdxSampling), ctypes.c_void_p]
+        lib.cdx_chitf_run.restype = ctypes.c_int
         lib.cdx_resmlp_workspace_floats.argtypes = [ctypes.POINTER(CdxResMlpWeights), ctypes.POINTER(CdxSampling)]
         lib.cdx_resmlp_workspace_floats.restype = ctypes.c_longlong
         lib.cdx_resmlp_run.argtypes = [ctypes.POINTER(CdxResMlpWeights), ctypes.POINTER(CdxSampling), ctypes.c_void_p]
@@ -77,6 +94,11 @@ def is_dit1d(module) -> bool:
 def is_resmlp(module) -> bool:
     from ..nn_diffusion.mlp_backbones import IDQLMlp, NewIDQLMlp
     return type(module) in (IDQLMlp, NewIDQLMlp)
+
+
+def is_chitf(module) -> bool:
+    from ..nn_diffusion.chitransformer import ChiTransformer
+    return type(module) is ChiTransformer
 
 
 class _Bound:
@@ -148,6 +170,42 @@ def _bind_resmlp(net, device) -> Optional[_Bound]:
     return _Bound(w, keep, None)
 
 
+def _bind_chitf(net, device) -> Optional[_Bound]:
+    import torch.nn as nn
+    d = net.act_emb.out_features
+    layers = list(net.decoder.layers)
+    if not isinstance(net.encoder, nn.Sequential) or net.T > 64 or 1 + net.To > 16 or d > 1024 or net.decoder.norm is not None:
+        return None                                   # transformer condition encoder (n_cond_layers > 0): PyTorch executor
+    heads = layers[0].self_attn.num_heads if layers else 1
+    if d % heads or d // heads > 64:
+        return None
+    for lyr in layers:
+        act = lyr.activation
+        if not lyr.norm_first or getattr(act, "__name__", "") != "gelu" or lyr.self_attn.in_proj_weight is None or \
+                lyr.multihead_attn.in_proj_weight is None or not lyr.self_attn.batch_first:
+            return None
+    keep = []
+    p = lambda t: _dev_f32(t, keep, device)  # noqa: E731
+    arr = (CdxChitfLayer * max(len(layers), 1))()
+    for i, l in enumerate(layers):
+        sa, ca = l.self_attn, l.multihead_attn
+        arr[i] = CdxChitfLayer(p(l.norm1.weight), p(l.norm1.bias), p(sa.in_proj_weight), p(sa.in_proj_bias),
+                               p(sa.out_proj.weight), p(sa.out_proj.bias), p(l.norm2.weight), p(l.norm2.bias),
+                               p(ca.in_proj_weight), p(ca.in_proj_bias), p(ca.out_proj.weight), p(ca.out_proj.bias),
+                               p(l.norm3.weight), p(l.norm3.bias), p(l.linear1.weight), p(l.linear1.bias), p(l.linear2.weight),
+                               p(l.linear2.bias))
+    neg = torch.finfo(torch.float32).min               # the kernels clamp scores at -3e38; -inf entries map onto that floor
+    w = CdxChitfWeights(Ta=net.T, To=net.To, act_dim=net.act_emb.in_features, obs_dim=net.obs_dim, d_model=d, n_heads=heads,
+                        n_layers=len(layers), act_emb_w=p(net.act_emb.weight), act_emb_b=p(net.act_emb.bias),
+                        pos_emb=p(net.pos_emb[0]), obs_emb_w=p(net.obs_emb.weight), obs_emb_b=p(net.obs_emb.bias),
+                        cond_pos_emb=p(net.cond_pos_emb[0]), enc0_w=p(net.encoder[0].weight), enc0_b=p(net.encoder[0].bias),
+                        enc2_w=p(net.encoder[2].weight), enc2_b=p(net.encoder[2].bias), layers=arr, lnf_g=p(net.ln_f.weight),
+                        lnf_b=p(net.ln_f.bias), head_w=p(net.head.weight), head_b=p(net.head.bias),
+                        self_mask=p(net.mask.detach().clamp_min(neg)), memory_mask=p(net.memory_mask.detach().clamp_min(neg)))
+    keep.append(arr)
+    return _Bound(w, keep, None)
+
+
 def _bound(net, key, make) -> Optional[_Bound]:
     per_mod = _cache.setdefault(net, {})
     sig = _signature(net)
@@ -201,7 +259,8 @@ def _mlp_chunk(batch: int, hidden: int, two: int) -> int:
 
 
 CHUNK_OVERRIDE = {"dit": int(os.environ.get("CDX_DIT_CHUNK", 0)) or None,      # tuning hooks (tools/bench_configs.py, tests)
-                  "mlp": int(os.environ.get("CDX_MLP_CHUNK", 0)) or None}
+                  "mlp": int(os.environ.get("CDX_MLP_CHUNK", 0)) or None,
+                  "chitf": int(os.environ.get("CDX_CHITF_CHUNK", 0)) or None}
 
 
 def _run(kind, bound, *, batch, hd, emb_dim, cond_dim, temb, steps, n_steps, temb_per_sample, predict_noise, cfg_mode,
@@ -213,8 +272,9 @@ def _run(kind, bound, *, batch, hd, emb_dim, cond_dim, temb, steps, n_steps, tem
                     cfg_mode=cfg_mode, cfg_w=float(cfg_w), cond=pp(cond), x_in=x_in.data_ptr(), prior=pp(prior),
                     fix_mask=pp(fix_mask), noise=pp(noise), x_min=pp(x_min), x_max=pp(x_max), x_out=x_out.data_ptr(),
                     workspace=None, workspace_floats=0, chunk=chunk)
-    size_fn, run_fn = ((lib.cdx_dit1d_workspace_floats, lib.cdx_dit1d_run) if kind == "dit" else
-                       (lib.cdx_resmlp_workspace_floats, lib.cdx_resmlp_run))
+    size_fn, run_fn = {"dit": (lib.cdx_dit1d_workspace_floats, lib.cdx_dit1d_run),
+                       "mlp": (lib.cdx_resmlp_workspace_floats, lib.cdx_resmlp_run),
+                       "chitf": (lib.cdx_chitf_workspace_floats, lib.cdx_chitf_run)}[kind]
     need = size_fn(ctypes.byref(bound.struct), ctypes.byref(s))
     ws = _workspace(x_in.device, need)
     s.workspace, s.workspace_floats = ws.data_ptr(), ws.numel()
@@ -242,6 +302,28 @@ def dit_forward(net, x, noise, condition) -> Optional[torch.Tensor]:
              steps=None, n_steps=0, temb_per_sample=1, predict_noise=0, cfg_mode=1 if cond is not None else 0, cfg_w=1.0,
              cond=cond, x_in=xin, prior=None, fix_mask=None, noise=None, x_min=None, x_max=None, x_out=out,
              chunk=CHUNK_OVERRIDE["dit"] or _dit_chunk(b, tokens, net.d_model, 1))
+    return out
+
+
+def chitf_forward(net, x, noise, condition) -> Optional[torch.Tensor]:
+    if x.dim() != 3 or x.shape[1] != net.T:
+        return None
+    dev = x.device
+    bound = _bound(net, "chitf", lambda: _bind_chitf(net, dev))
+    if bound is None or x.shape[2] != bound.struct.act_dim:
+        return None
+    w = bound.struct
+    with torch.no_grad():
+        temb = _f32c(net.map_noise(noise), dev)
+        cond = None if condition is None else _f32c(torch.flatten(condition, 1), dev)
+        if cond is not None and cond.shape[1] != w.To * w.obs_dim:
+            return None
+        xin = _f32c(x, dev)
+        out = torch.empty_like(xin)
+        _run("chitf", bound, batch=x.shape[0], hd=w.Ta * w.act_dim, emb_dim=w.d_model, cond_dim=w.To * w.obs_dim, temb=temb,
+             steps=None, n_steps=0, temb_per_sample=1, predict_noise=0, cfg_mode=1 if cond is not None else 0, cfg_w=1.0,
+             cond=cond, x_in=xin, prior=None, fix_mask=None, noise=None, x_min=None, x_max=None, x_out=out,
+             chunk=CHUNK_OVERRIDE["chitf"] or _dit_chunk(x.shape[0], w.Ta, w.d_model, 1))
     return out
 
 
@@ -286,6 +368,14 @@ def sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed) -> Optional[torc
         kind, (b, tokens, d) = "dit", xt.shape
         bound = _bound(net, ("dit", tokens), lambda: _bind_dit(net, tokens, dev))
         hd, rows_h = tokens * d, tokens
+    elif is_chitf(net):
+        if xt.dim() != 3 or xt.shape[1] != net.T:
+            return None
+        kind, (b, tokens, d) = "chitf", xt.shape
+        bound = _bound(net, "chitf", lambda: _bind_chitf(net, dev))
+        hd, rows_h = tokens * d, tokens
+        if bound is not None and bound.struct.act_dim != d:
+            return None
     elif is_resmlp(net):
         if xt.dim() != 2:
             return None
@@ -312,6 +402,9 @@ def sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed) -> Optional[torc
         t_vec = torch.tensor([st.t for st in plan.steps], dtype=t_dtype, device=dev)
         if kind == "dit":
             temb, emb_dim, cond_dim = _f32c(net.map_noise(t_vec), dev), net.emb_dim, net.emb_dim
+        elif kind == "chitf":
+            temb, emb_dim = _f32c(net.map_noise(t_vec), dev), bound.struct.d_model
+            cond_dim = bound.struct.To * bound.struct.obs_dim
         else:
             temb, emb_dim, cond_dim = _time_features(net, t_vec, dev), bound.struct.emb_dim, bound.struct.obs_dim
         if cond_vec is None or w_cfg == 0.0 or (kind == "mlp" and cond_dim == 0):
@@ -325,8 +418,10 @@ def sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed) -> Optional[torc
         noise = torch.stack([feed.like(xt) for _ in range(plan.n_noise)]).contiguous() if plan.n_noise else None
         xin = _f32c(xt, dev)
         out = torch.empty_like(xin)
-        chunk = CHUNK_OVERRIDE[kind] or (_dit_chunk(b, rows_h, net.d_model, two) if kind == "dit" else
-                                         _mlp_chunk(b, bound.struct.hidden, two))
+        if kind == "mlp":
+            chunk = CHUNK_OVERRIDE[kind] or _mlp_chunk(b, bound.struct.hidden, two)
+        else:
+            chunk = CHUNK_OVERRIDE[kind] or _dit_chunk(b, rows_h, bound.struct.d_model, two)
         _run(kind, bound, batch=b, hd=hd, emb_dim=emb_dim, cond_dim=cond_dim, temb=temb, steps=steps,
              n_steps=len(plan.steps), temb_per_sample=0, predict_noise=_predicts_noise(plan, solver),
              cfg_mode=mode, cfg_w=w_cfg, cond=cond, x_in=xin, prior=_f32c(prior, dev) if fix_mask is not None else None,

@@ -31,7 +31,15 @@ class CdxLnArgs(ctypes.Structure):
 
 class CdxAttnArgs(ctypes.Structure):
     _fields_ = [("qkv", ctypes.c_void_p), ("out", ctypes.c_void_p), ("B", ctypes.c_int32), ("T", ctypes.c_int32),
-                ("n_heads", ctypes.c_int32), ("head_dim", ctypes.c_int32), ("scale", ctypes.c_float)]
+                ("n_heads", ctypes.c_int32), ("head_dim", ctypes.c_int32), ("scale", ctypes.c_float),
+                ("mask", ctypes.c_void_p)]
+
+
+class CdxXattnArgs(ctypes.Structure):
+    _fields_ = [("q", ctypes.c_void_p), ("kv_shared", ctypes.c_void_p), ("kv_rows", ctypes.c_void_p), ("mask", ctypes.c_void_p),
+                ("out", ctypes.c_void_p), ("B", ctypes.c_int32), ("T", ctypes.c_int32), ("n_obs", ctypes.c_int32),
+                ("n_heads", ctypes.c_int32), ("head_dim", ctypes.c_int32), ("shared_row", ctypes.c_int32),
+                ("shared_per_sample", ctypes.c_int32), ("scale", ctypes.c_float)]
 
 
 _declared = False
@@ -44,6 +52,8 @@ def _lib():
         lib.cdx_gemm_f32.argtypes = [ctypes.POINTER(CdxGemmArgs), ctypes.c_void_p]
         lib.cdx_layernorm_f32.argtypes = [ctypes.POINTER(CdxLnArgs), ctypes.c_void_p]
         lib.cdx_attention_f32.argtypes = [ctypes.POINTER(CdxAttnArgs), ctypes.c_void_p]
+        lib.cdx_cross_attention_f32.argtypes = [ctypes.POINTER(CdxXattnArgs), ctypes.c_void_p]
+        lib.cdx_cross_attention_f32.restype = ctypes.c_int
         lib.cdx_act_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p]
         for f in (lib.cdx_gemm_f32, lib.cdx_layernorm_f32, lib.cdx_attention_f32, lib.cdx_act_f32):
             f.restype = ctypes.c_int
@@ -91,15 +101,33 @@ def layernorm(x: torch.Tensor, out: Optional[torch.Tensor] = None, gamma=None, b
     return out
 
 
-def attention(qkv: torch.Tensor, batch: int, tokens: int, n_heads: int, out: Optional[torch.Tensor] = None):
+def attention(qkv: torch.Tensor, batch: int, tokens: int, n_heads: int, out: Optional[torch.Tensor] = None,
+              mask: Optional[torch.Tensor] = None):
     dm = qkv.shape[1] // 3
     assert qkv.is_contiguous() and qkv.shape[0] == batch * tokens
     if out is None:
         out = torch.empty((batch * tokens, dm), device=qkv.device, dtype=torch.float32)
     dh = dm // n_heads
     a = CdxAttnArgs(qkv=qkv.data_ptr(), out=out.data_ptr(), B=batch, T=tokens, n_heads=n_heads, head_dim=dh,
-                    scale=float(dh) ** -0.5)
+                    scale=float(dh) ** -0.5, mask=_p(mask))
+    if mask is not None:
+        assert mask.shape == (tokens, tokens) and mask.is_contiguous() and mask.dtype == torch.float32
     _check(_lib().cdx_attention_f32(ctypes.byref(a), _stream_ptr(qkv.device)), "cdx_attention_f32")
+    return out
+
+
+def cross_attention(q: torch.Tensor, kv_shared: torch.Tensor, kv_rows: Optional[torch.Tensor], batch: int, tokens: int,
+                    n_obs: int, n_heads: int, shared_row: int = 0, shared_per_sample: bool = False,
+                    mask: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """softmax(q [k_shared | k_rows]^T / sqrt(dh) + mask) [v_shared | v_rows] per (sample, head); kv = [k | v] columns."""
+    dm = q.shape[1]
+    dh = dm // n_heads
+    if out is None:
+        out = torch.empty_like(q)
+    a = CdxXattnArgs(q=q.data_ptr(), kv_shared=kv_shared.data_ptr(), kv_rows=_p(kv_rows), mask=_p(mask), out=out.data_ptr(),
+                     B=batch, T=tokens, n_obs=n_obs, n_heads=n_heads, head_dim=dh, shared_row=shared_row,
+                     shared_per_sample=int(shared_per_sample), scale=float(dh) ** -0.5)
+    _check(_lib().cdx_cross_attention_f32(ctypes.byref(a), _stream_ptr(q.device)), "cdx_cross_attention_f32")
     return out
 
 

@@ -28,6 +28,8 @@ def try_backbone_forward(module, x, noise, condition) -> Optional[torch.Tensor]:
         return bigbatch.dit_forward(module, x, noise, condition)
     if bigbatch.is_resmlp(module):
         return bigbatch.resmlp_forward(module, x, noise, condition)
+    if bigbatch.is_chitf(module):
+        return bigbatch.chitf_forward(module, x, noise, condition)
     return runtime.backbone_forward(module, x, noise, condition)
 
 
@@ -45,9 +47,9 @@ def try_fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, requ
         return None                      # per-step classifier gradients need autograd
     from . import bigbatch, runtime
     net = model["diffusion"]
-    if bigbatch.is_dit1d(net) or bigbatch.is_resmlp(net):
-        if bigbatch.is_dit1d(net) and any(st.kind >= 5 for st in plan.steps):
-            return None                  # EDM input scaling is not wired into cdx_dit1d_run
+    if bigbatch.is_dit1d(net) or bigbatch.is_resmlp(net) or bigbatch.is_chitf(net):
+        if not bigbatch.is_resmlp(net) and any(st.kind >= 5 for st in plan.steps):
+            return None                  # EDM input scaling is wired into cdx_resmlp_run only
         return bigbatch.sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed)
     return runtime.fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed)
 
@@ -62,8 +64,8 @@ def try_fused_edm(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, require
     net = model["diffusion"]
     if bigbatch.is_resmlp(net):
         return bigbatch.sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed)
-    if bigbatch.is_dit1d(net):
-        return None                      # cdx_dit1d_run has no c_in input scaling yet
+    if bigbatch.is_dit1d(net) or bigbatch.is_chitf(net):
+        return None                      # cdx_dit1d_run / cdx_chitf_run have no c_in input scaling yet
     return runtime.fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed)
 
 

@@ -2,7 +2,9 @@
 [timestep token | observation tokens] with a causal target mask and a staggered memory mask
 (interface/checkpoint contract: reference nn_diffusion/chitransformer.py:12-158).
 
-Status: parameter container + PyTorch execution.
+Execution: on a ROCm device without autograd, forward and every sample() over it run through engine/bigbatch.py ->
+``cdx_chitf_run`` (memory tokens and their K/V projections precomputed per request, masked MFMA self-attention, small
+cross-attention kernel, GEMMs with fused GELU / residual epilogues); the module code below is the CPU / autograd executor.
 """
 from typing import Optional
 
@@ -84,6 +86,13 @@ class ChiTransformer(BaseNNDiffusion):
 
     def forward(self, x: torch.Tensor, noise: torch.Tensor, condition: Optional[torch.Tensor] = None):
         """x (b, Ta, act_dim), noise (b,), condition (b, To, obs_dim)|None(=zeros) -> (b, Ta, act_dim)."""
+        from ..engine import dispatch
+        y = dispatch.try_backbone_forward(self, x, noise, condition)        # cdx_chitf_run on a ROCm device
+        if y is not None:
+            return y
+        return self._forward_torch(x, noise, condition)
+
+    def _forward_torch(self, x, noise, condition=None):
         if condition is None:
             condition = torch.zeros((x.shape[0], self.To, self.obs_dim)).to(x.device)
         cond_tok = torch.cat([self.map_noise(noise).unsqueeze(1), self.obs_emb(condition)], dim=1)

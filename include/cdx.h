@@ -154,8 +154,24 @@ typedef struct cdx_attn_args {
     float* out;            /* (B*T, n_heads*head_dim) */
     int32_t B, T, n_heads, head_dim;
     float scale;
+    const float* mask;     /* (T, T) additive mask on the scores, row = query (0 / -inf as nn.Transformer builds them) or NULL */
 } cdx_attn_args;
 int cdx_attention_f32(const cdx_attn_args* args, void* hip_stream);
+
+/* Cross-attention of T queries against a short memory of S = 1 + n_obs keys per sample: key 0 is a token shared by the whole
+ * batch (the timestep token: row `shared_row` of kv_shared, or row b when shared_per_sample), keys 1.. are per-sample rows of
+ * kv_rows.  q: (B*T, d); kv_*: (.., 2d) = [k | v] as in_proj[d:3d] produces them; mask: (T, S) additive or NULL.
+ * Replaces the memory attention of nn.TransformerDecoderLayer (reference nn_diffusion/chitransformer.py:101-104, 148-155). */
+typedef struct cdx_xattn_args {
+    const float* q;
+    const float* kv_shared;    /* (rows, 2d) */
+    const float* kv_rows;      /* (B * n_obs, 2d) */
+    const float* mask;
+    float* out;                /* (B*T, d) */
+    int32_t B, T, n_obs, n_heads, head_dim, shared_row, shared_per_sample;
+    float scale;
+} cdx_xattn_args;
+int cdx_cross_attention_f32(const cdx_xattn_args* args, void* hip_stream);
 
 /* y = act(x) elementwise (batch-invariant embedding vectors: SiLU before adaLN, Mish in map_emb). */
 int cdx_act_f32(const float* x, float* y, long long n, int act, void* hip_stream);
@@ -210,6 +226,32 @@ typedef struct cdx_dit1d_weights {
 } cdx_dit1d_weights;
 long long cdx_dit1d_workspace_floats(const cdx_dit1d_weights* w, const cdx_sampling* s);
 int cdx_dit1d_run(const cdx_dit1d_weights* w, const cdx_sampling* s, void* hip_stream);
+
+/* ChiTransformer (reference nn_diffusion/chitransformer.py:61-158) with the MLP condition encoder (n_cond_layers == 0):
+ * memory = encoder([map_noise(t) | obs_emb(obs)] + cond_pos_emb); decoder layers are nn.TransformerDecoderLayer(norm_first, gelu):
+ * h += SA(LN1 h, causal mask); h += CA(LN2 h, memory, memory mask); h += FF(LN3 h); out = head(LN_f h).
+ * The memory and its per-layer K/V projections do not depend on x: they are evaluated once per request (observation tokens)
+ * and once per step record (timestep token) before the loop.  `temb` rows are map_noise(t) (width d_model); `cond` is
+ * (batch, To*obs_dim) or NULL (= zero observations, as the reference substitutes). */
+typedef struct cdx_chitf_layer {
+    const float *ln1_g, *ln1_b, *sa_in_w, *sa_in_b, *sa_out_w, *sa_out_b;      /* norm1, self_attn.in_proj (3d,d), out_proj */
+    const float *ln2_g, *ln2_b, *ca_in_w, *ca_in_b, *ca_out_w, *ca_out_b;      /* norm2, multihead_attn.in_proj (3d,d), out_proj */
+    const float *ln3_g, *ln3_b, *ff1_w, *ff1_b, *ff2_w, *ff2_b;                /* norm3, linear1 (4d,d), linear2 (d,4d) */
+} cdx_chitf_layer;
+typedef struct cdx_chitf_weights {
+    int32_t Ta, To, act_dim, obs_dim, d_model, n_heads, n_layers;
+    const float *act_emb_w, *act_emb_b;      /* (d, act_dim) */
+    const float* pos_emb;                    /* (Ta, d) */
+    const float *obs_emb_w, *obs_emb_b;      /* (d, obs_dim) */
+    const float* cond_pos_emb;               /* (1 + To, d) */
+    const float *enc0_w, *enc0_b, *enc2_w, *enc2_b;   /* encoder.0 (4d, d), encoder.2 (d, 4d) */
+    const cdx_chitf_layer* layers;           /* HOST array [n_layers] of device pointers */
+    const float *lnf_g, *lnf_b, *head_w, *head_b;     /* ln_f, head (act_dim, d) */
+    const float* self_mask;                  /* (Ta, Ta) additive */
+    const float* memory_mask;                /* (Ta, 1 + To) additive */
+} cdx_chitf_weights;
+long long cdx_chitf_workspace_floats(const cdx_chitf_weights* w, const cdx_sampling* s);
+int cdx_chitf_run(const cdx_chitf_weights* w, const cdx_sampling* s, void* hip_stream);
 
 /* Pre-norm residual MLP = IDQLMlp / NewIDQLMlp (reference nn_diffusion/idqlmlp.py:9-18 ResidualBlock, :21-65, :68-112):
  * features [x | time_mlp(map_noise(t)) | obs] -> affine_in -> n x (h + fc2(mish(fc1(LN(h))))) -> [mish] -> affine_out.

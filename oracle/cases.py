@@ -140,7 +140,21 @@ CASES.update({
         net=("IDQLMlp", dict(obs_dim=0, act_dim=15, emb_dim=128, hidden_dim=1024, n_blocks=6)), x_shape=(15,), batch=3,
         solver=("ContinuousEDM", dict()), sample=dict(solver="euler", sample_steps=4)),
 })
-BIGBATCH_NETS = ("DiT1d", "IDQLMlp", "NewIDQLMlp")
+BIGBATCH_NETS = ("DiT1d", "IDQLMlp", "NewIDQLMlp", "ChiTransformer")
+CASES.update({
+    # Diffusion Policy's transformer at its pusht size (d_model 256, 4 heads of 64, 8 decoder layers), CFG with w != 1
+    "chitransformer_full_cfg": dict(
+        net=("ChiTransformer", dict(act_dim=2, obs_dim=20, Ta=16, To=2, d_model=256, nhead=4, num_layers=8)),
+        x_shape=(16, 2), batch=2, clip=1.0, cond=("IdentityCondition", dict(dropout=0.0), (2, 20)),
+        solver=("DiscreteDiffusionSDE", dict(diffusion_steps=20, predict_noise=True)),
+        sample=dict(solver="ddpm", sample_steps=3, w_cfg=1.4)),
+    "chitransformer_uncond_2m": dict(
+        net=("ChiTransformer", dict(act_dim=3, obs_dim=5, Ta=12, To=3, d_model=64, nhead=4, num_layers=2,
+                                    timestep_emb_type="fourier")),
+        x_shape=(12, 3), batch=5, clip=2.0,
+        solver=("ContinuousDiffusionSDE", dict(predict_noise=False)),
+        sample=dict(solver="ode_dpmsolver++_2M", sample_steps=6)),
+})
 
 # ---- legacy solver classes the dp_* / dbc_* pipelines import (DPMSolver, EDM): every sampler family, 2nd order, sample_x ----
 _J8 = dict(net=("JannerUNet1d", dict(in_dim=6, model_dim=8, emb_dim=8, dim_mult=[1, 2], kernel_size=5)), x_shape=(8, 6),

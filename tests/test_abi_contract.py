@@ -25,7 +25,8 @@ def test_every_declared_symbol_is_exported(lib):
     names = re.findall(r"^(?:int|long long|const char\*)\s+(cdx_\w+)\s*\(", hdr, flags=re.M)
     assert set(names) >= {"cdx_abi_version", "cdx_last_error", "cdx_unet1d_run", "cdx_probe_mfma_layout", "cdx_gemm_f32",
                           "cdx_layernorm_f32", "cdx_attention_f32", "cdx_act_f32", "cdx_dit1d_run", "cdx_resmlp_run",
-                          "cdx_dit1d_workspace_floats", "cdx_resmlp_workspace_floats", "cdx_gemm_set_trace"}
+                          "cdx_dit1d_workspace_floats", "cdx_resmlp_workspace_floats", "cdx_gemm_set_trace",
+                          "cdx_chitf_run", "cdx_chitf_workspace_floats", "cdx_cross_attention_f32"}
     for n in names:
         assert hasattr(lib, n), f"{n} declared in cdx.h but not exported by libcdx.so"
     assert lib.cdx_abi_version() == int(re.search(r"#define CDX_ABI_VERSION (\d+)", hdr).group(1))
@@ -36,7 +37,9 @@ def test_ctypes_mirrors_have_c_layout(tmp_path):
     mirrors = {"cdx_unet1d_launch": runtime.CdxUnet1dLaunch, "cdx_step": runtime.CdxStep, "cdx_gemm_args": blocks.CdxGemmArgs,
                "cdx_ln_args": blocks.CdxLnArgs, "cdx_attn_args": blocks.CdxAttnArgs, "cdx_sampling": bigbatch.CdxSampling,
                "cdx_dit1d_block": bigbatch.CdxDitBlock, "cdx_dit1d_weights": bigbatch.CdxDitWeights,
-               "cdx_resmlp_block": bigbatch.CdxResMlpBlock, "cdx_resmlp_weights": bigbatch.CdxResMlpWeights}
+               "cdx_resmlp_block": bigbatch.CdxResMlpBlock, "cdx_resmlp_weights": bigbatch.CdxResMlpWeights,
+               "cdx_chitf_layer": bigbatch.CdxChitfLayer, "cdx_chitf_weights": bigbatch.CdxChitfWeights,
+               "cdx_xattn_args": blocks.CdxXattnArgs}
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "cdx.h"', 'int main(void){']
     for cname, mirror in mirrors.items():
         src.append(f'printf("%zu\\n", sizeof({cname}));')

@@ -84,3 +84,40 @@ def test_attention_matches_mha_core(tokens, heads, dh):
     q, k, v = (_ref(qkv).reshape(B, tokens, 3, heads, dh)[:, :, i].transpose(1, 2) for i in range(3))
     ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B * tokens, dm)
     torch.testing.assert_close(out.cpu().double(), ref, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("tokens,heads,dh", [(16, 4, 64), (64, 2, 32), (12, 4, 16), (9, 3, 6)])
+def test_attention_with_additive_mask(tokens, heads, dh):
+    """Causal mask built the way nn.Transformer builds it (0 / -inf, clamped to the fp32 floor by the binding)."""
+    from cleandiffuser_amd.engine import blocks
+    g = torch.Generator().manual_seed(tokens + dh)
+    B, dm = 3, heads * dh
+    qkv = torch.randn(B * tokens, 3 * dm, generator=g) * 2
+    allowed = torch.tril(torch.ones(tokens, tokens)) == 1
+    mask = torch.zeros(tokens, tokens).masked_fill(~allowed, float("-inf"))
+    out = blocks.attention(qkv.to(DEV), B, tokens, heads, mask=mask.clamp_min(torch.finfo(torch.float32).min).to(DEV))
+    q, k, v = (_ref(qkv).reshape(B, tokens, 3, heads, dh)[:, :, i].transpose(1, 2) for i in range(3))
+    ref = F.scaled_dot_product_attention(q, k, v, attn_mask=mask.double()).transpose(1, 2).reshape(B * tokens, dm)
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("tokens,n_obs,heads,dh,per_sample", [(16, 2, 4, 64, False), (12, 3, 4, 16, True), (5, 0, 2, 8, False)])
+def test_cross_attention_against_short_memory(tokens, n_obs, heads, dh, per_sample):
+    from cleandiffuser_amd.engine import blocks
+    g = torch.Generator().manual_seed(tokens * 3 + n_obs)
+    B, dm, S = 4, heads * dh, 1 + n_obs
+    q = torch.randn(B * tokens, dm, generator=g)
+    kv_shared = torch.randn(B if per_sample else 3, 2 * dm, generator=g)
+    kv_rows = torch.randn(max(B * n_obs, 1), 2 * dm, generator=g)
+    t_idx, s_idx = torch.meshgrid(torch.arange(tokens), torch.arange(S), indexing="ij")
+    mask = torch.zeros(tokens, S).masked_fill(~(t_idx >= (s_idx - 1)), float("-inf"))
+    out = blocks.cross_attention(q.to(DEV), kv_shared.to(DEV), kv_rows.to(DEV) if n_obs else None, B, tokens, n_obs, heads,
+                                 shared_row=2, shared_per_sample=per_sample,
+                                 mask=mask.clamp_min(torch.finfo(torch.float32).min).to(DEV))
+    shared = _ref(kv_shared)[torch.arange(B)] if per_sample else _ref(kv_shared)[2].expand(B, -1)
+    mem = torch.cat([shared[:, None], _ref(kv_rows)[:B * n_obs].reshape(B, n_obs, 2 * dm)], 1)       # (B, S, 2dm)
+    k = mem[..., :dm].reshape(B, S, heads, dh).transpose(1, 2)
+    v = mem[..., dm:].reshape(B, S, heads, dh).transpose(1, 2)
+    qq = _ref(q).reshape(B, tokens, heads, dh).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(qq, k, v, attn_mask=mask.double()).transpose(1, 2).reshape(B * tokens, dm)
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=2e-5, atol=2e-5)

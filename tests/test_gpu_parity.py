@@ -108,7 +108,7 @@ def test_bigbatch_sample_matches_reference_fixture(name, chunk, amd_lib, monkeyp
     inp = cases.make_inputs(name)
     kw = cases.sample_kwargs(name, inp, device=DEV)
     calls = _spy_bigbatch(monkeypatch)
-    kind = "dit" if cases.CASES[name]["net"][0] == "DiT1d" else "mlp"
+    kind = {"DiT1d": "dit", "ChiTransformer": "chitf"}.get(cases.CASES[name]["net"][0], "mlp")
     monkeypatch.setitem(bigbatch.CHUNK_OVERRIDE, kind, chunk)
     x, _ = cases.sampler_of(agent, name)(torch.from_numpy(inp["prior"]).to(DEV), noise=list(inp["noise"][:int(gold["n_draws"])]), **kw)
     torch.cuda.synchronize()
