@@ -184,6 +184,7 @@ int gemm(void* stream, const float* A, int lda, const float* W, int ldw, const f
     g.A = A; g.W = W; g.bias = bias; g.gate = gate; g.residual = residual; g.table = table; g.C = C;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldg = ldg; g.ldr = ldr;
     g.rows_per_gate = rows_per_gate; g.table_rows = table_rows; g.act = act;
+    g.conv_taps = g.conv_cin = g.conv_lin = g.conv_lout = g.conv_stride = g.conv_pad = 0;
     return cdx_gemm_f32(&g, stream);
 }
 
@@ -526,6 +527,210 @@ int tf_forward(const cdx_chitf_weights* w, const cdx_sampling* s, hipStream_t st
     return CDX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// ChiUNet1d as implicit-GEMM convolutions (global conditioning)
+// ------------------------------------------------------------------------------------------------
+struct UNet {                     // one pass over the op list; with dry == true it only measures the workspace
+    const cdx_chiunet_weights* w;
+    const cdx_sampling* s;
+    hipStream_t st;
+    Arena a;
+    bool dry;
+    int nb, bf, b0, rec, n_rec;
+    // persistent (prepare) buffers
+    float *x, *prev, *xin, *obs, *e1, *te, *mte, *gobs, *mo, *tfilm, *ofilm, *pred;
+    long long film_total;         // sum of film_out over all blocks (row width of the film tables)
+
+    float* take(long long n) { return a.take(n); }
+
+    int conv(const float* x, int lda, const float* wp, const float* bias, int Lin, int Lout, int taps, int cin, int stride, int pad,
+             int N, float* out, int ldc, const float* residual, int ldr) {
+        if (dry) return CDX_OK;
+        cdx_gemm_args g;
+        g.A = x; g.W = wp; g.bias = bias; g.gate = nullptr; g.residual = residual; g.table = nullptr; g.C = out;
+        g.M = bf * Lout; g.N = N; g.K = taps * cin; g.lda = lda; g.ldw = taps * cin; g.ldc = ldc; g.ldg = 0; g.ldr = ldr;
+        g.rows_per_gate = 1; g.table_rows = 0; g.act = CDX_ACT_NONE;
+        g.conv_taps = taps; g.conv_cin = cin; g.conv_lin = Lin; g.conv_lout = Lout; g.conv_stride = stride; g.conv_pad = pad;
+        return cdx_gemm_f32(&g, st);
+    }
+    int gn(const float* x, float* y, int L, int C, int G, const float* gamma, const float* beta, const float* fa, int ldfa,
+           const float* fb, int ldfb, int film_mode, const float* residual) {
+        if (dry) return CDX_OK;
+        cdx_gn_args q;
+        q.x = x; q.y = y; q.gamma = gamma; q.beta = beta; q.fa = fa; q.fb = fb; q.residual = residual;
+        q.B = bf; q.L = L; q.C = C; q.G = G; q.ldx = C; q.ldy = C; q.ldr = C; q.ldfa = ldfa; q.ldfb = ldfb;
+        q.fa_row = s->temb_per_sample ? 0 : rec; q.fa_per_sample = s->temb_per_sample; q.film_mode = film_mode;
+        q.act = CDX_ACT_MISH; q.eps = 1e-5f;
+        return cdx_groupnorm_f32(&q, st);
+    }
+    // ChiResidualBlock on [xa | xb] at length L  ->  new buffer (bf * L, cout)
+    int block(const cdx_chiunet_block& k, long long film_off, const float* xa, const float* xb, int L, float** out) {
+        const int ks = w->kernel_size, pad = ks / 2, co = k.cout;
+        const long long n = (long long)bf * L * co;
+        float* h1 = take(n);
+        float* h2 = take(n);
+        float* res = (k.wra != nullptr) ? take(n) : nullptr;
+        float* o = take(n);
+        CDX_TRY(conv(xa, k.cin_a, k.w1a, k.b1, L, L, ks, k.cin_a, 1, pad, co, h1, co, nullptr, 0));
+        if (k.cin_b > 0) CDX_TRY(conv(xb, k.cin_b, k.w1b, nullptr, L, L, ks, k.cin_b, 1, pad, co, h1, co, h1, co));
+        const int fm = w->cond_predict_scale ? 1 : 2;
+        CDX_TRY(gn(h1, h2, L, co, k.groups, k.g1, k.be1, tfilm ? tfilm + film_off : nullptr, (int)film_total,
+                   ofilm ? ofilm + film_off : nullptr, (int)film_total, fm, nullptr));
+        CDX_TRY(conv(h2, co, k.w2, k.b2, L, L, ks, co, 1, pad, co, h1, co, nullptr, 0));       // h1 is free again
+        const float* skip = xa;                                                                 // identity skip
+        if (k.wra != nullptr) {
+            CDX_TRY(conv(xa, k.cin_a, k.wra, k.br, L, L, 1, k.cin_a, 1, 0, co, res, co, nullptr, 0));
+            if (k.cin_b > 0) CDX_TRY(conv(xb, k.cin_b, k.wrb, nullptr, L, L, 1, k.cin_b, 1, 0, co, res, co, res, co));
+            skip = res;
+        }
+        CDX_TRY(gn(h1, o, L, co, k.groups, k.g2, k.be2, nullptr, 0, nullptr, 0, 0, skip));
+        *out = o;
+        return CDX_OK;
+    }
+    int film_out(const cdx_chiunet_block& k) const { return (w->cond_predict_scale ? 2 : 1) * k.cout; }
+    int n_blocks() const { return 2 * w->n_levels + 2 + 2 * (w->n_levels - 1); }
+
+    // request-invariant tables: embeddings and the two halves of every block's FiLM vector
+    int prepare() {
+        const int E = w->emb_dim, trow = s->temb_per_sample ? bf : n_rec;
+        film_total = 0;
+        for (int i = 0; i < n_blocks(); ++i) film_total += film_out(w->blocks[i]);
+        x = take((long long)nb * s->hd); prev = take((long long)nb * s->hd); xin = take((long long)bf * s->hd);
+        obs = take((long long)bf * w->cond_dim);
+        e1 = take((long long)trow * 4 * E); te = take((long long)trow * E); mte = take((long long)trow * E);
+        gobs = take((long long)bf * E); mo = take((long long)bf * E);
+        tfilm = take((long long)trow * film_total); ofilm = take((long long)bf * film_total);
+        pred = take((long long)bf * s->hd);
+        if (dry) return CDX_OK;
+        const float* trows = s->temb;                    // per-sample timesteps: rows of this chunk (both CFG halves alike)
+        if (s->temb_per_sample) {
+            for (int half = 0; half < bf / nb; ++half)
+                if (hipMemcpyAsync(mte + (size_t)half * nb * E, s->temb + (size_t)b0 * E, (size_t)nb * E * sizeof(float),
+                                   hipMemcpyDeviceToDevice, st) != hipSuccess) return hip_ok();
+            trows = mte;                                 // staged in mte, consumed by the first GEMM before mte is rewritten
+        }
+        CDX_TRY(gemm(st, trows, E, w->map0_w, E, w->map0_b, e1, 4 * E, trow, 4 * E, E, CDX_ACT_MISH));
+        CDX_TRY(gemm(st, e1, 4 * E, w->map2_w, 4 * E, w->map2_b, te, E, trow, E, 4 * E));
+        CDX_TRY(cdx_act_f32(te, mte, (long long)trow * E, CDX_ACT_MISH, st));
+        {
+            const long long n = (long long)bf * w->cond_dim;
+            const int n_cond_rows = (s->cond == nullptr || s->cfg_mode == 0) ? 0 : nb;
+            hipLaunchKernelGGL(obs_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, obs, s->cond, bf, nb, b0,
+                               w->cond_dim, n_cond_rows);
+            CDX_TRY(hip_ok());
+        }
+        CDX_TRY(gemm(st, obs, w->cond_dim, w->gce_w, w->cond_dim, w->gce_b, gobs, E, bf, E, w->cond_dim));
+        CDX_TRY(cdx_act_f32(gobs, mo, (long long)bf * E, CDX_ACT_MISH, st));
+        long long off = 0;
+        for (int i = 0; i < n_blocks(); ++i) {
+            const cdx_chiunet_block& k = w->blocks[i];
+            const int fo = film_out(k);
+            CDX_TRY(gemm(st, mte, E, k.film_w, 2 * E, nullptr, tfilm + off, (int)film_total, trow, fo, E));
+            CDX_TRY(gemm(st, mo, E, k.film_w + E, 2 * E, k.film_b, ofilm + off, (int)film_total, bf, fo, E));
+            off += fo;
+        }
+        return CDX_OK;
+    }
+
+    int forward(const float* xrows, float* out_pred) {
+        const int nl = w->n_levels, Ta = w->Ta;
+        const float* skips[8];
+        const float* cur = xrows;
+        long long foff = 0;
+        int bi = 0, L = Ta;
+        float* o = nullptr;
+        for (int k = 0; k < nl; ++k) {
+            for (int j = 0; j < 2; ++j) {
+                const cdx_chiunet_block& kb = w->blocks[bi];
+                CDX_TRY(block(kb, foff, cur, nullptr, L, &o));
+                foff += film_out(kb); ++bi; cur = o;
+            }
+            skips[k] = cur;
+            if (k < nl - 1) {
+                const int C = w->blocks[bi - 1].cout;
+                float* d = take((long long)bf * (L / 2) * C);
+                CDX_TRY(conv(cur, C, w->down_w[k], w->down_b[k], L, L / 2, 3, C, 2, 1, C, d, C, nullptr, 0));
+                cur = d; L /= 2;
+            }
+        }
+        for (int j = 0; j < 2; ++j) {
+            const cdx_chiunet_block& kb = w->blocks[bi];
+            CDX_TRY(block(kb, foff, cur, nullptr, L, &o));
+            foff += film_out(kb); ++bi; cur = o;
+        }
+        for (int k = 0; k < nl - 1; ++k) {
+            const float* skip = skips[nl - 1 - k];
+            CDX_TRY(block(w->blocks[bi], foff, cur, skip, L, &o));
+            foff += film_out(w->blocks[bi]); ++bi; cur = o;
+            CDX_TRY(block(w->blocks[bi], foff, cur, nullptr, L, &o));
+            foff += film_out(w->blocks[bi]); ++bi; cur = o;
+            const int C = w->blocks[bi - 1].cout;
+            float* u = take((long long)bf * 2 * L * C);   // row (b, j) of the (bf*L, 2C) view = [out[2j] | out[2j+1]]
+            CDX_TRY(conv(cur, C, w->up_w_even[k], w->up_b[k], L, L, 2, C, 1, 1, C, u, 2 * C, nullptr, 0));
+            CDX_TRY(conv(cur, C, w->up_w_odd[k], w->up_b[k], L, L, 2, C, 1, 0, C, u + C, 2 * C, nullptr, 0));
+            cur = u; L *= 2;
+        }
+        const int md = w->model_dim, ks = w->kernel_size;
+        float* f1 = take((long long)bf * L * md);
+        float* f2 = take((long long)bf * L * md);
+        CDX_TRY(conv(cur, md, w->fin_w, w->fin_b, L, L, ks, md, 1, ks / 2, md, f1, md, nullptr, 0));
+        CDX_TRY(gn(f1, f2, L, md, w->final_groups, w->fin_g, w->fin_be, nullptr, 0, nullptr, 0, 0, nullptr));
+        CDX_TRY(conv(f2, md, w->out_w, w->out_b, L, L, 1, md, 1, 0, w->act_dim, out_pred, w->act_dim, nullptr, 0));
+        return CDX_OK;
+    }
+};
+
+int chiunet_check(const cdx_chiunet_weights* w, const cdx_sampling* s) {
+    if (!w || !w->blocks || !w->map0_w || !w->map2_w || !w->gce_w || !w->fin_w || !w->out_w ||
+        (w->n_levels > 1 && (!w->down_w || !w->down_b || !w->up_w_even || !w->up_w_odd || !w->up_b))) {
+        cdx_set_err("null pointer in ChiUNet1d weights"); return CDX_EINVAL;
+    }
+    if (w->n_levels < 1 || w->n_levels > 8 || w->Ta <= 0 || (w->Ta >> (w->n_levels - 1)) < 1 || (w->Ta & (w->Ta - 1)) ||
+        w->kernel_size < 1 || !(w->kernel_size & 1) || w->emb_dim <= 0 || w->cond_dim <= 0) {
+        cdx_set_err("ChiUNet1d executor: Ta must be a power of two >= 2^(levels-1), odd kernel size"); return CDX_EINVAL;
+    }
+    CDX_TRY(check_request(s, "cdx_chiunet_run", 4));
+    if (s->hd != w->Ta * w->act_dim || s->emb_dim != w->emb_dim || !s->cond || s->cond_dim != w->cond_dim || s->cfg_mode == 0) {
+        cdx_set_err("ChiUNet1d request: shape mismatch, or no condition (the reference requires one)"); return CDX_EINVAL;
+    }
+    return CDX_OK;
+}
+
+long long chiunet_pass(const cdx_chiunet_weights* w, const cdx_sampling* s, hipStream_t st, float* base, bool dry, int* rc) {
+    const int chunk = chunk_of(s);
+    long long need = 0;
+    *rc = CDX_OK;
+    for (int b0 = 0; b0 < s->batch; b0 += chunk) {
+        UNet u;
+        u.w = w; u.s = s; u.st = st; u.a = Arena{base, 0, 0}; u.dry = dry;
+        u.nb = s->batch - b0 < chunk ? s->batch - b0 : chunk;
+        if (dry) u.nb = chunk;
+        u.bf = u.nb * (s->cfg_mode == 2 ? 2 : 1); u.b0 = b0; u.rec = 0; u.n_rec = s->n_steps > 0 ? s->n_steps : 1;
+        if ((*rc = u.prepare()) != CDX_OK) return -1;
+        const long long mark = u.a.used;
+        const size_t off = (size_t)b0 * s->hd, bytes = (size_t)u.nb * s->hd * sizeof(float);
+        const int n_fwd = s->n_steps > 0 ? s->n_steps : 1;
+        for (int i = 0; i < n_fwd; ++i) {
+            u.a.used = mark;                              // activations of a forward are recycled every step
+            u.rec = i;
+            const float* xsrc = s->n_steps == 0 ? s->x_in + off : u.x;
+            if (!dry) {
+                if (i == 0 && s->n_steps > 0 && hipMemcpyAsync(u.x, s->x_in + off, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) { *rc = hip_ok(); return -1; }
+                for (int half = 0; half < u.bf / u.nb; ++half)
+                    if (hipMemcpyAsync(u.xin + (size_t)half * u.nb * s->hd, xsrc, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) { *rc = hip_ok(); return -1; }
+            }
+            float* dst = (s->n_steps == 0) ? s->x_out + off : u.pred;
+            if ((*rc = u.forward(u.xin, dst)) != CDX_OK) return -1;
+            if (u.a.used > need) need = u.a.used;
+            if (dry) break;
+            if (s->n_steps > 0 && (*rc = run_step(st, s, s->steps[i], u.x, u.pred, u.prev, nullptr, u.nb, b0)) != CDX_OK) return -1;
+        }
+        if (dry) break;
+        if (s->n_steps > 0 && hipMemcpyAsync(s->x_out + off, u.x, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) { *rc = hip_ok(); return -1; }
+    }
+    return need;
+}
+
 }  // namespace
 
 extern "C" {
@@ -590,6 +795,22 @@ int cdx_chitf_run(const cdx_chitf_weights* w, const cdx_sampling* s, void* hip_s
         if (hipMemcpyAsync(s->x_out + off, B.x, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return hip_ok();
     }
     return CDX_OK;
+}
+
+long long cdx_chiunet_workspace_floats(const cdx_chiunet_weights* w, const cdx_sampling* s) {
+    if (!w || !s || !w->blocks) return -1;
+    int rc;
+    return chiunet_pass(w, s, nullptr, nullptr, true, &rc);
+}
+
+int cdx_chiunet_run(const cdx_chiunet_weights* w, const cdx_sampling* s, void* hip_stream) {
+    CDX_TRY(chiunet_check(w, s));
+    if (s->batch == 0) return CDX_OK;
+    int rc;
+    const long long need = chiunet_pass(w, s, nullptr, nullptr, true, &rc);
+    if (!s->workspace || s->workspace_floats < need) { cdx_set_err("cdx_chiunet_run: workspace too small"); return CDX_EINVAL; }
+    chiunet_pass(w, s, reinterpret_cast<hipStream_t>(hip_stream), s->workspace, false, &rc);
+    return rc;
 }
 
 long long cdx_resmlp_workspace_floats(const cdx_resmlp_weights* w, const cdx_sampling* s) {

@@ -63,6 +63,24 @@ __device__ __forceinline__ float4 gm_load4_guarded(const float* __restrict__ bas
     return v;
 }
 
+// implicit-GEMM conv gather of 4 consecutive k (general path: any conv_cin; one division per element, tiny first layers only)
+__device__ __forceinline__ float4 gm_conv_load4(const cdx_gemm_args& g, int row, int k) {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (row < g.M) {
+        const int b = row / g.conv_lout, lo = row - b * g.conv_lout;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kk = k + i;
+            if (kk < g.K) {
+                const int tap = kk / g.conv_cin, c = kk - tap * g.conv_cin;
+                const int pos = lo * g.conv_stride + tap - g.conv_pad;
+                if (pos >= 0 && pos < g.conv_lin) v[i] = g.A[((size_t)b * g.conv_lin + pos) * g.lda + c];
+            }
+        }
+    }
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+
 // exact m / d and m % d for 0 <= m < 2^31 from a float reciprocal (one multiply + two fix-ups instead of a ~40-instruction
 // integer division per output element)
 __device__ __forceinline__ void gm_divmod(int m, int d, float inv, int& q, int& r) {
@@ -223,15 +241,41 @@ __global__ __launch_bounds__(GM_THREADS, 3) void cdx_gemm_kernel(const cdx_gemm_
     const float* ap = g.A + (size_t)arow * g.lda + kq * 4;
     const float* wp = g.W + (size_t)wrow * g.ldw + kq * 4;
     float4 ra0, ra1, rb0, rb1;
+    // implicit-GEMM conv (FAST: conv_cin % 16 == 0, so a 16-wide K tile never straddles two taps)
+    const bool conv = g.conv_taps > 0;
+    int conv_in0 = 0;
+    size_t conv_base = 0;
+    if (conv) {
+        const int cb = arow / g.conv_lout, clo = arow - cb * g.conv_lout;
+        conv_in0 = clo * g.conv_stride - g.conv_pad;
+        conv_base = (size_t)cb * g.conv_lin;
+    }
+    const float conv_inv_cin = conv ? 1.0f / (float)g.conv_cin : 0.f;
     auto fetch = [&](int kt) {                           // global -> registers: k columns [kt, kt + 16) of this thread's row
         if (FAST) {
-            ra0 = *reinterpret_cast<const float4*>(ap + kt);
-            ra1 = *reinterpret_cast<const float4*>(ap + kt + 8);
+            if (conv) {
+                const int tap = (int)(((float)kt + 0.5f) * conv_inv_cin), c0 = kt - tap * g.conv_cin;
+                const int pos = conv_in0 + tap;
+                const bool ok = pos >= 0 && pos < g.conv_lin;
+                const float* p = g.A + (conv_base + (ok ? pos : 0)) * g.lda + c0 + kq * 4;
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 v0 = *reinterpret_cast<const float4*>(p), v1 = *reinterpret_cast<const float4*>(p + 8);
+                ra0 = ok ? v0 : z;
+                ra1 = ok ? v1 : z;
+            } else {
+                ra0 = *reinterpret_cast<const float4*>(ap + kt);
+                ra1 = *reinterpret_cast<const float4*>(ap + kt + 8);
+            }
             rb0 = *reinterpret_cast<const float4*>(wp + kt);
             rb1 = *reinterpret_cast<const float4*>(wp + kt + 8);
         } else {
+            if (conv) {
+                ra0 = gm_conv_load4(g, arow, kt + kq * 4);
+                ra1 = gm_conv_load4(g, arow, kt + 8 + kq * 4);
+            } else {
             ra0 = gm_load4_guarded(g.A, arow, g.M, kt + kq * 4, g.K, g.lda);
             ra1 = gm_load4_guarded(g.A, arow, g.M, kt + 8 + kq * 4, g.K, g.lda);
+            }
             rb0 = gm_load4_guarded(g.W, wrow, g.N, kt + kq * 4, g.K, g.ldw);
             rb1 = gm_load4_guarded(g.W, wrow, g.N, kt + 8 + kq * 4, g.K, g.ldw);
         }
@@ -342,6 +386,90 @@ __global__ __launch_bounds__(256) void cdx_layernorm_kernel(const cdx_ln_args a)
             if (a.gamma) o = o * a.gamma[c] + a.beta[c];
             if (a.scale) o = o * (1.0f + a.scale[(size_t)b * a.ldmod + c]) + a.shift[(size_t)b * a.ldmod + c];
             y[c] = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm (+ activation, FiLM, residual) on channel-last rows: one wave per (sample, group); the group's L x C/G values stay
+// in registers when there are <= 2048 of them (two-pass variance like ATen), else they are re-read.
+// ------------------------------------------------------------------------------------------------
+#define GN_REGS 32
+__global__ __launch_bounds__(256) void cdx_groupnorm_kernel(const cdx_gn_args a) {
+    const int lane = threadIdx.x & 63;
+    const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wg >= a.B * a.G) return;
+    const int b = wg / a.G, grp = wg - b * a.G;
+    const int cg = a.C / a.G, n = a.L * cg;
+    const float inv_cg = 1.0f / (float)cg;
+    const float* xb = a.x + (size_t)b * a.L * a.ldx + grp * cg;
+    const bool in_regs = n <= 64 * GN_REGS;
+    float v[GN_REGS];
+    float s = 0.f;
+    if (in_regs) {
+#pragma unroll
+        for (int i = 0; i < GN_REGS; ++i) {
+            const int e = lane + 64 * i;
+            float x = 0.f;
+            if (e < n) {
+                const int l = (int)(((float)e + 0.5f) * inv_cg), c = e - l * cg;
+                x = xb[(size_t)l * a.ldx + c];
+            }
+            v[i] = x;
+            s += x;
+        }
+    } else {
+        for (int e = lane; e < n; e += 64) {
+            const int l = e / cg, c = e - l * cg;
+            s += xb[(size_t)l * a.ldx + c];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)n;
+    float s2 = 0.f;
+    if (in_regs) {
+#pragma unroll
+        for (int i = 0; i < GN_REGS; ++i) {
+            const float d = (lane + 64 * i < n) ? v[i] - mean : 0.f;
+            s2 += d * d;
+        }
+    } else {
+        for (int e = lane; e < n; e += 64) {
+            const int l = e / cg, c = e - l * cg;
+            const float d = xb[(size_t)l * a.ldx + c] - mean;
+            s2 += d * d;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+    const float rstd = 1.0f / sqrtf(s2 / (float)n + a.eps);
+    const float* fa = a.fa ? a.fa + (size_t)(a.fa_per_sample ? b : a.fa_row) * a.ldfa : nullptr;
+    const float* fb = a.fb ? a.fb + (size_t)b * a.ldfb : nullptr;
+    auto emit = [&](int e, float x) {
+        const int l = (int)(((float)e + 0.5f) * inv_cg), c = e - l * cg, ch = grp * cg + c;
+        float y = gm_act((x - mean) * rstd * a.gamma[ch] + a.beta[ch], a.act);
+        if (a.film_mode == 1) {
+            const float sc = (fa ? fa[ch] : 0.f) + (fb ? fb[ch] : 0.f);
+            const float bi = (fa ? fa[a.C + ch] : 0.f) + (fb ? fb[a.C + ch] : 0.f);
+            y = sc * y + bi;
+        } else if (a.film_mode == 2) {
+            y += (fa ? fa[ch] : 0.f) + (fb ? fb[ch] : 0.f);
+        }
+        const size_t row = (size_t)b * a.L + l;
+        if (a.residual) y += a.residual[row * a.ldr + ch];
+        a.y[row * a.ldy + ch] = y;
+    };
+    if (in_regs) {
+#pragma unroll
+        for (int i = 0; i < GN_REGS; ++i) {
+            const int e = lane + 64 * i;
+            if (e < n) emit(e, v[i]);
+        }
+    } else {
+        for (int e = lane; e < n; e += 64) {
+            const int l = e / cg, c = e - l * cg;
+            emit(e, xb[(size_t)l * a.ldx + c]);
         }
     }
 }
@@ -605,8 +733,12 @@ int cdx_gemm_f32(const cdx_gemm_args* g, void* hip_stream) {
         cdx_set_err("cdx_gemm_f32: gate/table need a positive row period"); return CDX_EINVAL;
     }
     const int tiles = ((g->M + GM_BM - 1) / GM_BM) * ((g->N + GM_BN - 1) / GM_BN);
+    if (g->conv_taps < 0 || (g->conv_taps > 0 && (g->conv_cin <= 0 || g->conv_lin <= 0 || g->conv_lout <= 0 || g->conv_stride <= 0 ||
+                                                   g->K != g->conv_taps * g->conv_cin || g->M % g->conv_lout != 0))) {
+        cdx_set_err("cdx_gemm_f32: inconsistent implicit-conv description"); return CDX_EINVAL;
+    }
     const bool vec = (g->K % GM_BK == 0) && (g->lda % 4 == 0) && (g->ldw % 4 == 0) &&
-                     (((uintptr_t)g->A | (uintptr_t)g->W) % 16 == 0);
+                     (((uintptr_t)g->A | (uintptr_t)g->W) % 16 == 0) && (g->conv_taps == 0 || g->conv_cin % GM_BK == 0);
     hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
     static const char* env = getenv("CDX_GEMM_STAGGER");          // tuning hook: cycles per phase class, 0 = off
     int stagger = 0;
@@ -639,6 +771,20 @@ int cdx_layernorm_f32(const cdx_ln_args* a, void* hip_stream) {
     cdx_ln_args b = *a;
     if (b.rows_per_mod <= 0) b.rows_per_mod = 1;
     hipLaunchKernelGGL(cdx_layernorm_kernel, dim3((a->M + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), b);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
+    return CDX_OK;
+}
+
+int cdx_groupnorm_f32(const cdx_gn_args* a, void* hip_stream) {
+    if (!a) { cdx_set_err("cdx_groupnorm_f32: null argument block"); return CDX_EINVAL; }
+    if (a->B < 0 || a->L <= 0 || a->C <= 0 || a->G <= 0 || a->C % a->G != 0 || a->film_mode < 0 || a->film_mode > 2) {
+        cdx_set_err("cdx_groupnorm_f32: bad shape (C must be a multiple of G)"); return CDX_EINVAL;
+    }
+    if (a->B == 0) return CDX_OK;
+    if (!a->x || !a->y || !a->gamma || !a->beta) { cdx_set_err("cdx_groupnorm_f32: null pointer"); return CDX_EINVAL; }
+    const long long waves = (long long)a->B * a->G;
+    hipLaunchKernelGGL(cdx_groupnorm_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), *a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
     return CDX_OK;

@@ -60,6 +60,20 @@ class CdxChitfWeights(ctypes.Structure):
                 ("self_mask", _FP), ("memory_mask", _FP)]
 
 
+class CdxChiUNetBlock(ctypes.Structure):
+    _fields_ = [("cin_a", _I), ("cin_b", _I), ("cout", _I), ("groups", _I)] + \
+               [(n, _FP) for n in ("w1a", "w1b", "b1", "g1", "be1", "w2", "b2", "g2", "be2", "film_w", "film_b", "wra", "wrb", "br")]
+
+
+class CdxChiUNetWeights(ctypes.Structure):
+    _fields_ = [(n, _I) for n in ("act_dim", "Ta", "cond_dim", "emb_dim", "kernel_size", "n_levels", "cond_predict_scale",
+                                  "model_dim", "final_groups")] + \
+               [(n, _FP) for n in ("map0_w", "map0_b", "map2_w", "map2_b", "gce_w", "gce_b")] + \
+               [("blocks", ctypes.POINTER(CdxChiUNetBlock))] + \
+               [(n, ctypes.POINTER(ctypes.c_void_p)) for n in ("down_w", "down_b", "up_w_even", "up_w_odd", "up_b")] + \
+               [(n, _FP) for n in ("fin_w", "fin_b", "fin_g", "fin_be", "out_w", "out_b")]
+
+
 _declared = False
 
 
@@ -75,6 +89,10 @@ def _lib():
         lib.cdx_chitf_workspace_floats.restype = ctypes.c_longlong
         lib.cdx_chitf_run.argtypes = [ctypes.POINTER(CdxChitfWeights), ctypes.POINTER(CdxSampling), ctypes.c_void_p]
         lib.cdx_chitf_run.restype = ctypes.c_int
+        lib.cdx_chiunet_workspace_floats.argtypes = [ctypes.POINTER(CdxChiUNetWeights), ctypes.POINTER(CdxSampling)]
+        lib.cdx_chiunet_workspace_floats.restype = ctypes.c_longlong
+        lib.cdx_chiunet_run.argtypes = [ctypes.POINTER(CdxChiUNetWeights), ctypes.POINTER(CdxSampling), ctypes.c_void_p]
+        lib.cdx_chiunet_run.restype = ctypes.c_int
         lib.cdx_resmlp_workspace_floats.argtypes = [ctypes.POINTER(CdxResMlpWeights), ctypes.POINTER(CdxSampling)]
         lib.cdx_resmlp_workspace_floats.restype = ctypes.c_longlong
         lib.cdx_resmlp_run.argtypes = [ctypes.POINTER(CdxResMlpWeights), ctypes.POINTER(CdxSampling), ctypes.c_void_p]
@@ -206,6 +224,75 @@ def _bind_chitf(net, device) -> Optional[_Bound]:
     return _Bound(w, keep, None)
 
 
+def _bind_chiunet(net, Ta: int, device) -> Optional[_Bound]:
+    """ChiUNet1d (global conditioning) for the implicit-GEMM executor: conv weights are re-packed (c_out, k, c_in) once."""
+    import torch.nn as nn
+    from . import blocks as B
+    if not net.obs_as_global_cond or net.global_cond_encoder is None:
+        return None
+    n_levels = len(net.downs)
+    if Ta & (Ta - 1) or (Ta >> (n_levels - 1)) < 1 or n_levels > 8:
+        return None
+    keep = []
+    p = lambda t: _dev_f32(t, keep, device)  # noqa: E731
+
+    def packed(t):                                      # derived tensors are always fresh fp32 device copies
+        t = t.to(device=device, dtype=torch.float32).contiguous()
+        keep.append(t)
+        return t.data_ptr()
+
+    def bind_block(blk, cin_a, cin_b):
+        c1, gn1, c2, gn2 = blk.conv1[0], blk.conv1[1], blk.conv2[0], blk.conv2[1]
+        w1 = B.pack_conv(c1.weight)                     # (co, k, ci)
+        has_res = isinstance(blk.residual_conv, nn.Conv1d)
+        wr = blk.residual_conv.weight.detach()[:, :, 0] if has_res else None
+        return CdxChiUNetBlock(
+            cin_a=cin_a, cin_b=cin_b, cout=c1.out_channels, groups=gn1.num_groups,
+            w1a=packed(w1[:, :, :cin_a]), w1b=packed(w1[:, :, cin_a:]) if cin_b else None, b1=p(c1.bias), g1=p(gn1.weight),
+            be1=p(gn1.bias), w2=packed(B.pack_conv(c2.weight)), b2=p(c2.bias), g2=p(gn2.weight), be2=p(gn2.bias),
+            film_w=p(blk.cond_encoder[1].weight), film_b=p(blk.cond_encoder[1].bias),
+            wra=packed(wr[:, :cin_a]) if has_res else None, wrb=packed(wr[:, cin_a:]) if (has_res and cin_b) else None,
+            br=p(blk.residual_conv.bias) if has_res else None)
+
+    blocks = []
+    for res1, res2, _ in net.downs:
+        blocks += [bind_block(res1, res1.conv1[0].in_channels, 0), bind_block(res2, res2.conv1[0].in_channels, 0)]
+    blocks += [bind_block(m, m.conv1[0].in_channels, 0) for m in net.mids]
+    for res1, res2, _ in net.ups:
+        half = res1.conv1[0].in_channels // 2
+        blocks += [bind_block(res1, half, half), bind_block(res2, res2.conv1[0].in_channels, 0)]
+    for b in blocks:                                    # identity skips need matching widths; the FAST GEMM path wants 16 | c_in
+        if b.wra is None and (b.cin_b or b.cin_a != b.cout):
+            return None
+    arr = (CdxChiUNetBlock * len(blocks))(*blocks)
+
+    def ptr_array(vals):
+        a = (ctypes.c_void_p * max(len(vals), 1))(*vals)
+        keep.append(a)
+        return a
+    downs = [lvl[2].conv for lvl in net.downs if not isinstance(lvl[2], nn.Identity)]
+    ups = [lvl[2].conv for lvl in net.ups if not isinstance(lvl[2], nn.Identity)]
+    if len(downs) != n_levels - 1 or len(ups) != n_levels - 1:
+        return None
+    up_packed = [B.pack_conv_transpose_k4s2p1(u.weight) for u in ups]
+    fin = net.final_conv
+    E = net.emb_dim
+    w = CdxChiUNetWeights()
+    w.act_dim, w.Ta, w.cond_dim, w.emb_dim = net.downs[0][0].conv1[0].in_channels, Ta, net.global_cond_encoder.in_features, E
+    w.kernel_size, w.n_levels, w.cond_predict_scale = fin[0].kernel_size[0], n_levels, int(net.downs[0][0].cond_predict_scale)
+    w.model_dim, w.final_groups = net.model_dim, fin[1].num_groups
+    w.map0_w, w.map0_b, w.map2_w, w.map2_b = p(net.map_emb[0].weight), p(net.map_emb[0].bias), p(net.map_emb[2].weight), p(net.map_emb[2].bias)
+    w.gce_w, w.gce_b = p(net.global_cond_encoder.weight), p(net.global_cond_encoder.bias)
+    w.blocks = arr
+    w.down_w, w.down_b = ptr_array([packed(B.pack_conv(d.weight)) for d in downs]), ptr_array([p(d.bias) for d in downs])
+    w.up_w_even, w.up_w_odd = ptr_array([packed(e) for e, _ in up_packed]), ptr_array([packed(o) for _, o in up_packed])
+    w.up_b = ptr_array([p(u.bias) for u in ups])
+    w.fin_w, w.fin_b, w.fin_g, w.fin_be = packed(B.pack_conv(fin[0].weight)), p(fin[0].bias), p(fin[1].weight), p(fin[1].bias)
+    w.out_w, w.out_b = packed(fin[3].weight.detach()[:, :, 0]), p(fin[3].bias)
+    keep.append(arr)
+    return _Bound(w, keep, None)
+
+
 def _bound(net, key, make) -> Optional[_Bound]:
     per_mod = _cache.setdefault(net, {})
     sig = _signature(net)
@@ -260,7 +347,44 @@ def _mlp_chunk(batch: int, hidden: int, two: int) -> int:
 
 CHUNK_OVERRIDE = {"dit": int(os.environ.get("CDX_DIT_CHUNK", 0)) or None,      # tuning hooks (tools/bench_configs.py, tests)
                   "mlp": int(os.environ.get("CDX_MLP_CHUNK", 0)) or None,
-                  "chitf": int(os.environ.get("CDX_CHITF_CHUNK", 0)) or None}
+                  "chitf": int(os.environ.get("CDX_CHITF_CHUNK", 0)) or None,
+                  "chiunet": int(os.environ.get("CDX_CHIUNET_CHUNK", 0)) or None}
+# ChiUNet1d has two native executors: the one-workgroup-per-trajectory program kernel (weights re-streamed by every CU) and the
+# implicit-GEMM executor (weights shared by all rows).  The GEMM one wins once batch x length fills the 128 x 128 tiles.
+UNET_GEMM_MIN_BATCH = int(os.environ.get("CDX_UNET_GEMM_MIN_BATCH", 512))
+
+
+def is_chiunet_gemm(module, batch: int) -> bool:
+    from ..nn_diffusion.chiunet import ChiUNet1d
+    return type(module) is ChiUNet1d and module.obs_as_global_cond and batch >= UNET_GEMM_MIN_BATCH
+
+
+def _chiunet_chunk(batch: int, Ta: int, model_dim: int, two: int) -> int:
+    rows = max((256 << 20) // (4 * model_dim), 4096)       # widest live activation ~ rows x model_dim
+    return max(min(batch, rows // (Ta * two)), 1)
+
+
+def chiunet_forward(net, x, noise, condition) -> Optional[torch.Tensor]:
+    if x.dim() != 3 or condition is None:
+        return None
+    dev = x.device
+    b, Ta, _ = x.shape
+    bound = _bound(net, ("chiunet", Ta), lambda: _bind_chiunet(net, Ta, dev))
+    if bound is None or x.shape[2] != bound.struct.act_dim:
+        return None
+    w = bound.struct
+    with torch.no_grad():
+        cond = _f32c(torch.flatten(condition, 1), dev)
+        if cond.shape[1] != w.cond_dim:
+            return None
+        temb = _f32c(net.map_noise(noise), dev)
+        xin = _f32c(x, dev)
+        out = torch.empty_like(xin)
+        _run("chiunet", bound, batch=b, hd=Ta * w.act_dim, emb_dim=w.emb_dim, cond_dim=w.cond_dim, temb=temb, steps=None,
+             n_steps=0, temb_per_sample=1, predict_noise=0, cfg_mode=1, cfg_w=1.0, cond=cond, x_in=xin, prior=None,
+             fix_mask=None, noise=None, x_min=None, x_max=None, x_out=out,
+             chunk=CHUNK_OVERRIDE["chiunet"] or _chiunet_chunk(b, Ta, net.model_dim, 1))
+    return out
 
 
 def _run(kind, bound, *, batch, hd, emb_dim, cond_dim, temb, steps, n_steps, temb_per_sample, predict_noise, cfg_mode,
@@ -274,7 +398,8 @@ def _run(kind, bound, *, batch, hd, emb_dim, cond_dim, temb, steps, n_steps, tem
                     workspace=None, workspace_floats=0, chunk=chunk)
     size_fn, run_fn = {"dit": (lib.cdx_dit1d_workspace_floats, lib.cdx_dit1d_run),
                        "mlp": (lib.cdx_resmlp_workspace_floats, lib.cdx_resmlp_run),
-                       "chitf": (lib.cdx_chitf_workspace_floats, lib.cdx_chitf_run)}[kind]
+                       "chitf": (lib.cdx_chitf_workspace_floats, lib.cdx_chitf_run),
+                       "chiunet": (lib.cdx_chiunet_workspace_floats, lib.cdx_chiunet_run)}[kind]
     need = size_fn(ctypes.byref(bound.struct), ctypes.byref(s))
     ws = _workspace(x_in.device, need)
     s.workspace, s.workspace_floats = ws.data_ptr(), ws.numel()
@@ -368,6 +493,14 @@ def sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed) -> Optional[torc
         kind, (b, tokens, d) = "dit", xt.shape
         bound = _bound(net, ("dit", tokens), lambda: _bind_dit(net, tokens, dev))
         hd, rows_h = tokens * d, tokens
+    elif is_chiunet_gemm(net, xt.shape[0]):
+        if xt.dim() != 3 or cond_vec is None or w_cfg == 0.0:
+            return None                               # ChiUNet1d cannot run unconditionally (the reference raises)
+        kind, (b, tokens, d) = "chiunet", xt.shape
+        bound = _bound(net, ("chiunet", tokens), lambda: _bind_chiunet(net, tokens, dev))
+        hd, rows_h = tokens * d, tokens
+        if bound is not None and bound.struct.act_dim != d:
+            return None
     elif is_chitf(net):
         if xt.dim() != 3 or xt.shape[1] != net.T:
             return None
@@ -405,6 +538,8 @@ def sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed) -> Optional[torc
         elif kind == "chitf":
             temb, emb_dim = _f32c(net.map_noise(t_vec), dev), bound.struct.d_model
             cond_dim = bound.struct.To * bound.struct.obs_dim
+        elif kind == "chiunet":
+            temb, emb_dim, cond_dim = _f32c(net.map_noise(t_vec), dev), bound.struct.emb_dim, bound.struct.cond_dim
         else:
             temb, emb_dim, cond_dim = _time_features(net, t_vec, dev), bound.struct.emb_dim, bound.struct.obs_dim
         if cond_vec is None or w_cfg == 0.0 or (kind == "mlp" and cond_dim == 0):
@@ -420,6 +555,8 @@ def sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed) -> Optional[torc
         out = torch.empty_like(xin)
         if kind == "mlp":
             chunk = CHUNK_OVERRIDE[kind] or _mlp_chunk(b, bound.struct.hidden, two)
+        elif kind == "chiunet":
+            chunk = CHUNK_OVERRIDE[kind] or _chiunet_chunk(b, rows_h, bound.struct.model_dim, two)
         else:
             chunk = CHUNK_OVERRIDE[kind] or _dit_chunk(b, rows_h, bound.struct.d_model, two)
         _run(kind, bound, batch=b, hd=hd, emb_dim=emb_dim, cond_dim=cond_dim, temb=temb, steps=steps,

@@ -18,7 +18,16 @@ class CdxGemmArgs(ctypes.Structure):
                 ("residual", ctypes.c_void_p), ("table", ctypes.c_void_p), ("C", ctypes.c_void_p),
                 ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("lda", ctypes.c_int32),
                 ("ldw", ctypes.c_int32), ("ldc", ctypes.c_int32), ("ldg", ctypes.c_int32), ("ldr", ctypes.c_int32),
-                ("rows_per_gate", ctypes.c_int32), ("table_rows", ctypes.c_int32), ("act", ctypes.c_int32)]
+                ("rows_per_gate", ctypes.c_int32), ("table_rows", ctypes.c_int32), ("act", ctypes.c_int32),
+                ("conv_taps", ctypes.c_int32), ("conv_cin", ctypes.c_int32), ("conv_lin", ctypes.c_int32),
+                ("conv_lout", ctypes.c_int32), ("conv_stride", ctypes.c_int32), ("conv_pad", ctypes.c_int32)]
+
+
+class CdxGnArgs(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_void_p), ("y", ctypes.c_void_p), ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p),
+                ("fa", ctypes.c_void_p), ("fb", ctypes.c_void_p), ("residual", ctypes.c_void_p)] + \
+               [(n, ctypes.c_int32) for n in ("B", "L", "C", "G", "ldx", "ldy", "ldr", "ldfa", "ldfb", "fa_row", "fa_per_sample",
+                                              "film_mode", "act")] + [("eps", ctypes.c_float)]
 
 
 class CdxLnArgs(ctypes.Structure):
@@ -52,6 +61,8 @@ def _lib():
         lib.cdx_gemm_f32.argtypes = [ctypes.POINTER(CdxGemmArgs), ctypes.c_void_p]
         lib.cdx_layernorm_f32.argtypes = [ctypes.POINTER(CdxLnArgs), ctypes.c_void_p]
         lib.cdx_attention_f32.argtypes = [ctypes.POINTER(CdxAttnArgs), ctypes.c_void_p]
+        lib.cdx_groupnorm_f32.argtypes = [ctypes.POINTER(CdxGnArgs), ctypes.c_void_p]
+        lib.cdx_groupnorm_f32.restype = ctypes.c_int
         lib.cdx_cross_attention_f32.argtypes = [ctypes.POINTER(CdxXattnArgs), ctypes.c_void_p]
         lib.cdx_cross_attention_f32.restype = ctypes.c_int
         lib.cdx_act_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p]
@@ -86,6 +97,67 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     if table is not None:
         assert table.shape[1] == n and table.is_contiguous()
     _check(_lib().cdx_gemm_f32(ctypes.byref(g), _stream_ptr(a.device)), "cdx_gemm_f32")
+    return out
+
+
+def conv1d(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], batch: int, l_in: int, stride: int = 1,
+           pad: int = 0, out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, act: str = "none",
+           l_out: Optional[int] = None):
+    """Implicit-GEMM Conv1d on channel-last rows.  x: (batch*l_in, c_in); w_packed: (c_out, taps, c_in) = weight.permute(0,2,1);
+    -> (batch*l_out, c_out), l_out = (l_in + 2 pad - taps) // stride + 1 unless given (`pad` is the LEFT padding; positions past
+    either end read zeros, so an explicit l_out expresses asymmetric padding)."""
+    n, taps, cin = w_packed.shape
+    if l_out is None:
+        l_out = (l_in + 2 * pad - taps) // stride + 1
+    m = batch * l_out
+    if out is None:
+        out = torch.empty((m, n), device=x.device, dtype=torch.float32)
+    w2 = w_packed.reshape(n, taps * cin)
+    g = CdxGemmArgs(A=x.data_ptr(), W=w2.data_ptr(), bias=_p(bias), residual=_p(residual), C=out.data_ptr(), M=m, N=n,
+                    K=taps * cin, lda=_rows(x), ldw=_rows(w2), ldc=_rows(out), ldr=_rows(residual) if residual is not None else 0,
+                    rows_per_gate=1, act=ACT[act], conv_taps=taps, conv_cin=cin, conv_lin=l_in, conv_lout=l_out,
+                    conv_stride=stride, conv_pad=pad)
+    _check(_lib().cdx_gemm_f32(ctypes.byref(g), _stream_ptr(x.device)), "cdx_gemm_f32(conv)")
+    return out
+
+
+def pack_conv(weight: torch.Tensor) -> torch.Tensor:
+    """nn.Conv1d weight (c_out, c_in, k) -> (c_out, k, c_in): K index = tap * c_in + c, contiguous in c."""
+    return weight.detach().permute(0, 2, 1).contiguous()
+
+
+def pack_conv_transpose_k4s2p1(weight: torch.Tensor):
+    """nn.ConvTranspose1d(k=4, stride=2, pad=1) weight (c_in, c_out, 4) -> two (c_out, 2, c_in) stride-1 kernels, one per output
+    parity:  out[2j]   = W[:, :, 3]^T x[j-1] + W[:, :, 1]^T x[j]     (taps at shifts -1, 0  -> pad 1)
+             out[2j+1] = W[:, :, 2]^T x[j]   + W[:, :, 0]^T x[j+1]   (taps at shifts  0, +1 -> pad 0)"""
+    w = weight.detach().permute(1, 2, 0)                      # (c_out, 4, c_in)
+    return w[:, [3, 1]].contiguous(), w[:, [2, 0]].contiguous()
+
+
+def conv_transpose1d_k4s2p1(x: torch.Tensor, packed, bias, batch: int, l_in: int, out: Optional[torch.Tensor] = None):
+    """ConvTranspose1d(k=4, s=2, p=1) as two implicit-GEMM convs writing the even / odd output rows (ldc = 2 N)."""
+    even, odd = packed
+    n = even.shape[0]
+    if out is None:
+        out = torch.empty((batch * l_in * 2, n), device=x.device, dtype=torch.float32)
+    view = out.view(batch * l_in, 2 * n)                      # row (b, j) holds [out[2j] | out[2j+1]]
+    conv1d(x, even, bias, batch, l_in, 1, 1, out=view[:, :n], l_out=l_in)
+    conv1d(x, odd, bias, batch, l_in, 1, 0, out=view[:, n:], l_out=l_in)
+    return out
+
+
+def groupnorm(x: torch.Tensor, gamma, beta, batch: int, length: int, groups: int, act: str = "none", eps: float = 1e-5,
+              fa=None, fb=None, fa_row: int = 0, fa_per_sample: bool = False, film_mode: int = 0, residual=None,
+              out: Optional[torch.Tensor] = None):
+    c = x.shape[1]
+    if out is None:
+        out = torch.empty_like(x)
+    a = CdxGnArgs(x=x.data_ptr(), y=out.data_ptr(), gamma=gamma.data_ptr(), beta=beta.data_ptr(), fa=_p(fa), fb=_p(fb),
+                  residual=_p(residual), B=batch, L=length, C=c, G=groups, ldx=_rows(x), ldy=_rows(out),
+                  ldr=_rows(residual) if residual is not None else 0, ldfa=_rows(fa) if fa is not None else 0,
+                  ldfb=_rows(fb) if fb is not None else 0, fa_row=fa_row, fa_per_sample=int(fa_per_sample), film_mode=film_mode,
+                  act=ACT[act], eps=eps)
+    _check(_lib().cdx_groupnorm_f32(ctypes.byref(a), _stream_ptr(x.device)), "cdx_groupnorm_f32")
     return out
 
 

@@ -30,6 +30,10 @@ def try_backbone_forward(module, x, noise, condition) -> Optional[torch.Tensor]:
         return bigbatch.resmlp_forward(module, x, noise, condition)
     if bigbatch.is_chitf(module):
         return bigbatch.chitf_forward(module, x, noise, condition)
+    if bigbatch.is_chiunet_gemm(module, x.shape[0]):
+        y = bigbatch.chiunet_forward(module, x, noise, condition)
+        if y is not None:
+            return y
     return runtime.backbone_forward(module, x, noise, condition)
 
 
@@ -47,6 +51,10 @@ def try_fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, requ
         return None                      # per-step classifier gradients need autograd
     from . import bigbatch, runtime
     net = model["diffusion"]
+    if bigbatch.is_chiunet_gemm(net, xt.shape[0]) and not any(st.kind >= 5 for st in plan.steps):
+        out = bigbatch.sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed)
+        if out is not None:
+            return out
     if bigbatch.is_dit1d(net) or bigbatch.is_resmlp(net) or bigbatch.is_chitf(net):
         if not bigbatch.is_resmlp(net) and any(st.kind >= 5 for st in plan.steps):
             return None                  # EDM input scaling is wired into cdx_resmlp_run only
@@ -75,5 +83,9 @@ def try_fused_legacy_ddpm(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg,
         return None
     if solver.classifier is not None and w_cg != 0.0:
         return None
-    from . import runtime
+    from . import bigbatch, runtime
+    if bigbatch.is_chiunet_gemm(model["diffusion"], xt.shape[0]):
+        out = bigbatch.sample(solver, model["diffusion"], plan, xt, prior, cond_vec, w_cfg, feed)
+        if out is not None:
+            return out
     return runtime.fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed)

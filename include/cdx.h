@@ -131,6 +131,12 @@ typedef struct cdx_gemm_args {
     int32_t M, N, K, lda, ldw, ldc, ldg, ldr;
     int32_t rows_per_gate, table_rows;
     int32_t act;           /* CDX_ACT_* of csrc/cdx_ops.h: 0 none, 1 mish, 2 gelu(erf), 3 leaky, 4 silu, 5 relu, 6 gelu(tanh) */
+    /* Implicit-GEMM Conv1d (conv_taps > 0): A is a channel-last activation tensor, rows = samples * conv_lin, row stride lda;
+     * output row m = (b, lo) = (m / conv_lout, m % conv_lout); K = conv_taps * conv_cin with k = tap * conv_cin + c;
+     * A[m][k] = X[b * conv_lin + lo * conv_stride + tap - conv_pad][c], zero outside [0, conv_lin).  W is (N, conv_taps, conv_cin).
+     * Replaces nn.Conv1d / (per output parity) nn.ConvTranspose1d of the temporal U-Nets (reference nn_diffusion/chiunet.py:19-28,
+     * jannerunet.py:22-36). */
+    int32_t conv_taps, conv_cin, conv_lin, conv_lout, conv_stride, conv_pad;
 } cdx_gemm_args;
 int cdx_gemm_f32(const cdx_gemm_args* args, void* hip_stream);
 
@@ -146,6 +152,22 @@ typedef struct cdx_ln_args {
     int32_t x_rows;        /* > 0: input row of output row m is m % x_rows (CFG pair sharing one token stream) */
 } cdx_ln_args;
 int cdx_layernorm_f32(const cdx_ln_args* args, void* hip_stream);
+
+/* GroupNorm over (C/G channels x L positions) per sample on channel-last rows (B*L, C), then activation, FiLM and residual:
+ *   y = film_scale * act(gn(x) * gamma + beta) + film_bias + residual
+ * film = fa[row_a] + fb[b] (either may be NULL) laid out [scale (C) | bias (C)] (film_mode 1) or [bias (C)] (film_mode 2); row_a is
+ * fa_row, or b when fa_per_sample.  Replaces GroupNorm1d + Mish + the FiLM modulation + the block's skip add (reference
+ * utils/building_blocks.py:60-76, nn_diffusion/chiunet.py:19-44, jannerunet.py:60-95). */
+typedef struct cdx_gn_args {
+    const float* x;
+    float* y;
+    const float *gamma, *beta;       /* (C) */
+    const float *fa, *fb;            /* FiLM tables or NULL */
+    const float* residual;           /* (B*L, ldr) or NULL */
+    int32_t B, L, C, G, ldx, ldy, ldr, ldfa, ldfb, fa_row, fa_per_sample, film_mode, act;
+    float eps;
+} cdx_gn_args;
+int cdx_groupnorm_f32(const cdx_gn_args* args, void* hip_stream);
 
 /* out[b][t][h*d..] = softmax(q k^T * scale) v per (batch, head); qkv = (B*T, 3*n_heads*head_dim) from in_proj.
  * Replaces the core of nn.MultiheadAttention(batch_first=True) (reference dit.py:20,34).  T <= 64, head_dim <= 64. */
@@ -252,6 +274,35 @@ typedef struct cdx_chitf_weights {
 } cdx_chitf_weights;
 long long cdx_chitf_workspace_floats(const cdx_chitf_weights* w, const cdx_sampling* s);
 int cdx_chitf_run(const cdx_chitf_weights* w, const cdx_sampling* s, void* hip_stream);
+
+/* ChiUNet1d with global conditioning at large batch (reference nn_diffusion/chiunet.py:13-192): every Conv1d is an implicit GEMM
+ * over (batch * L) rows, GroupNorm + Mish + FiLM + skip add is one pass (cdx_groupnorm_f32).  Conv weights are PACKED by the
+ * host once per weight version: Conv1d (c_out, c_in, k) -> (c_out, k, c_in); ConvTranspose1d(k4 s2 p1) -> two (c_out, 2, c_in)
+ * kernels, one per output parity (engine/blocks.py:pack_conv*).  FiLM = cond_encoder.1([mish(time emb) | mish(obs emb)]) is
+ * separable, so its time half is evaluated once per step record and its observation half once per request, before the loop.
+ * `temb` rows are map_noise(t) (width emb_dim); `cond` is (batch, cond_dim) and required. */
+typedef struct cdx_chiunet_block {
+    int32_t cin_a, cin_b, cout, groups;      /* input = channel concat [a | b] (cin_b == 0: single input) */
+    const float *w1a, *w1b, *b1, *g1, *be1;  /* conv1 split by input part, GroupNorm affine */
+    const float *w2, *b2, *g2, *be2;
+    const float *film_w, *film_b;            /* cond_encoder.1: (film_out, 2 emb_dim), (film_out) */
+    const float *wra, *wrb, *br;             /* residual 1x1 conv split by input part, or all NULL (identity) */
+} cdx_chiunet_block;
+typedef struct cdx_chiunet_weights {
+    int32_t act_dim, Ta, cond_dim, emb_dim, kernel_size, n_levels, cond_predict_scale, model_dim, final_groups;
+    const float *map0_w, *map0_b, *map2_w, *map2_b;     /* map_emb.0 (4E, E), map_emb.2 (E, 4E) */
+    const float *gce_w, *gce_b;                         /* global_cond_encoder (E, cond_dim) */
+    const cdx_chiunet_block* blocks;                    /* HOST [2 n_levels + 2 + 2 (n_levels - 1)]: downs, mids, ups */
+    const float* const* down_w;                         /* HOST [n_levels - 1] packed (C, 3, C) */
+    const float* const* down_b;
+    const float* const* up_w_even;                      /* HOST [n_levels - 1] packed (C, 2, C) */
+    const float* const* up_w_odd;
+    const float* const* up_b;
+    const float *fin_w, *fin_b, *fin_g, *fin_be;        /* final_conv.0 packed (md, k, md), final_conv.1 GroupNorm */
+    const float *out_w, *out_b;                         /* final_conv.3 1x1 (act_dim, md) */
+} cdx_chiunet_weights;
+long long cdx_chiunet_workspace_floats(const cdx_chiunet_weights* w, const cdx_sampling* s);
+int cdx_chiunet_run(const cdx_chiunet_weights* w, const cdx_sampling* s, void* hip_stream);
 
 /* Pre-norm residual MLP = IDQLMlp / NewIDQLMlp (reference nn_diffusion/idqlmlp.py:9-18 ResidualBlock, :21-65, :68-112):
  * features [x | time_mlp(map_noise(t)) | obs] -> affine_in -> n x (h + fc2(mish(fc1(LN(h))))) -> [mish] -> affine_out.

@@ -121,3 +121,54 @@ def test_cross_attention_against_short_memory(tokens, n_obs, heads, dh, per_samp
     qq = _ref(q).reshape(B, tokens, heads, dh).transpose(1, 2)
     ref = F.scaled_dot_product_attention(qq, k, v, attn_mask=mask.double()).transpose(1, 2).reshape(B * tokens, dm)
     torch.testing.assert_close(out.cpu().double(), ref, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,L", [(32, 64, 5, 1, 2, 16), (256, 256, 3, 2, 1, 8), (2, 48, 5, 1, 2, 16),
+                                                     (23, 32, 5, 1, 2, 32), (64, 23, 1, 1, 0, 4), (48, 40, 3, 1, 1, 1)])
+def test_implicit_gemm_conv1d(cin, cout, k, stride, pad, L):
+    from cleandiffuser_amd.engine import blocks
+    g = torch.Generator().manual_seed(cin + cout)
+    B = 5
+    x = torch.randn(B, cin, L, generator=g)
+    conv = torch.nn.Conv1d(cin, cout, k, stride, pad)
+    rows = x.permute(0, 2, 1).reshape(B * L, cin).contiguous().to(DEV)
+    out = blocks.conv1d(rows, blocks.pack_conv(conv.weight).to(DEV), conv.bias.detach().to(DEV), B, L, stride, pad)
+    ref = conv.double()(x.double()).permute(0, 2, 1).reshape(-1, cout)
+    torch.testing.assert_close(out.cpu().double(), ref.detach(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("c,L", [(64, 4), (32, 16), (20, 3)])
+def test_implicit_gemm_conv_transpose(c, L):
+    from cleandiffuser_amd.engine import blocks
+    g = torch.Generator().manual_seed(c)
+    B = 3
+    x = torch.randn(B, c, L, generator=g)
+    up = torch.nn.ConvTranspose1d(c, c, 4, 2, 1)
+    rows = x.permute(0, 2, 1).reshape(B * L, c).contiguous().to(DEV)
+    packed = tuple(t.to(DEV) for t in blocks.pack_conv_transpose_k4s2p1(up.weight))
+    out = blocks.conv_transpose1d_k4s2p1(rows, packed, up.bias.detach().to(DEV), B, L)
+    ref = up.double()(x.double()).permute(0, 2, 1).reshape(-1, c)
+    torch.testing.assert_close(out.cpu().double(), ref.detach(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("c,groups,L,film", [(256, 8, 16, 1), (1024, 8, 4, 1), (32, 8, 32, 2), (48, 4, 5, 0), (4096, 2, 16, 1)])
+def test_groupnorm_mish_film_residual(c, groups, L, film):
+    from cleandiffuser_amd.engine import blocks
+    g = torch.Generator().manual_seed(c + L)
+    B = 3
+    x = torch.randn(B, c, L, generator=g) * 2 + 0.5
+    gamma, beta = torch.randn(c, generator=g), torch.randn(c, generator=g)
+    width = {0: c, 1: 2 * c, 2: c}[film]
+    fa, fb = torch.randn(4, width, generator=g), torch.randn(B, width, generator=g)
+    res = torch.randn(B * L, c, generator=g)
+    rows = x.permute(0, 2, 1).reshape(B * L, c).contiguous()
+    out = blocks.groupnorm(rows.to(DEV), gamma.to(DEV), beta.to(DEV), B, L, groups, act="mish", fa=fa.to(DEV) if film else None,
+                           fb=fb.to(DEV) if film else None, fa_row=2, film_mode=film, residual=res.to(DEV))
+    y = F.mish(F.group_norm(_ref(x), groups, _ref(gamma), _ref(beta), 1e-5))                       # (B, C, L)
+    f = _ref(fa)[2][None] + _ref(fb)
+    if film == 1:
+        y = f[:, :c, None] * y + f[:, c:, None]
+    elif film == 2:
+        y = y + f[:, :, None]
+    ref = y.permute(0, 2, 1).reshape(B * L, c) + _ref(res)
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=3e-5, atol=3e-5)

@@ -117,6 +117,49 @@ def test_bigbatch_sample_matches_reference_fixture(name, chunk, amd_lib, monkeyp
     np.testing.assert_allclose(x.cpu().numpy(), gold["x_out"], **TOL)
 
 
+CHIUNET_CASES = [n for n, c in cases.CASES.items() if c["net"][0] == "ChiUNet1d"]
+
+
+@pytest.mark.parametrize("chunk", [None, 2])
+@pytest.mark.parametrize("name", CHIUNET_CASES)
+def test_chiunet_gemm_executor_matches_reference_fixture(name, chunk, amd_lib, monkeypatch):
+    """ChiUNet1d's second native executor (implicit-GEMM convolutions, cdx_chiunet_run) -- normally chosen for batch >= 512 --
+    forced on for the small fixtures: same reference samples, one native call."""
+    from cleandiffuser_amd.engine import bigbatch
+    gold = np.load(golden_path(name))
+    agent, _ = cases.build(amd_lib, name, device=DEV)
+    inp = cases.make_inputs(name)
+    kw = cases.sample_kwargs(name, inp, device=DEV)
+    monkeypatch.setattr(bigbatch, "UNET_GEMM_MIN_BATCH", 1)
+    monkeypatch.setitem(bigbatch.CHUNK_OVERRIDE, "chiunet", chunk)
+    calls = _spy_bigbatch(monkeypatch)
+    fused = _spy_launches(monkeypatch)
+    x, _ = cases.sampler_of(agent, name)(torch.from_numpy(inp["prior"]).to(DEV), noise=list(inp["noise"][:int(gold["n_draws"])]), **kw)
+    torch.cuda.synchronize()
+    assert [c[0] for c in calls] == ["chiunet"] and fused["n"] == 0
+    np.testing.assert_allclose(x.cpu().numpy(), gold["x_out"], **TOL)
+
+
+def test_chiunet_gemm_forward_matches_program_kernel(amd_lib, monkeypatch):
+    """backbone.forward with per-sample timesteps: the two native ChiUNet1d executors agree (and the program kernel is pinned to
+    the reference by the fixtures above)."""
+    from cleandiffuser_amd.engine import bigbatch
+    name = "chiunet_cfg3_legacy_ddpm"
+    agent, net = cases.build(amd_lib, name, device=DEV)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(37, 16, 2, generator=g).to(DEV)
+    t = torch.randint(0, 10, (37,), generator=g).to(DEV)
+    cond = torch.randn(37, 2, 20, generator=g).to(DEV)
+    with torch.no_grad():
+        a = net(x, t, cond)
+        monkeypatch.setattr(bigbatch, "UNET_GEMM_MIN_BATCH", 1)
+        calls = _spy_bigbatch(monkeypatch)
+        b = net(x, t, cond)
+    torch.cuda.synchronize()
+    assert [c[0] for c in calls] == ["chiunet"]
+    np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), **TOL)
+
+
 @pytest.mark.parametrize("name", BIGBATCH_CASES)
 def test_bigbatch_forward_matches_reference_fixture(name, amd_lib, monkeypatch):
     """`backbone.forward` with a different timestep per sample (what training-time evaluation and custom loops call)."""

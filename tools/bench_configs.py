@@ -126,6 +126,10 @@ def run(name, fn, reps=3):
     prog = runtime.compiled_program(net, horizon).prog
     per_unit = horizon if prog.tile else 1                  # tile programs: MACs are per workgroup of `tile` samples
     flops = 2.0 * prog.macs_per_forward / per_unit * steps * B
+    if not k_ms:                                            # served by the implicit-GEMM executor: no single fused launch to time
+        print(json.dumps({"config": label + " [implicit-GEMM executor]", "trajectories_per_s": B / dt, "ms_per_call": 1e3 * dt,
+                          "tflops": flops / dt / 1e12, "frac_fp32_mfma_peak": flops / dt / 1e12 / PEAK}), flush=True)
+        return
     k = sum(k_ms) / len(k_ms)
     print(json.dumps({"config": label, "trajectories_per_s": B / dt, "ms_per_call": 1e3 * dt, "kernel_ms": k,
                       "launches_per_call": len(k_ms) / reps, "tflops": flops / (k * 1e-3) / 1e12,
