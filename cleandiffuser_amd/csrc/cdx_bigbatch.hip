@@ -185,6 +185,7 @@ int gemm(void* stream, const float* A, int lda, const float* W, int ldw, const f
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldg = ldg; g.ldr = ldr;
     g.rows_per_gate = rows_per_gate; g.table_rows = table_rows; g.act = act;
     g.conv_taps = g.conv_cin = g.conv_lin = g.conv_lout = g.conv_stride = g.conv_pad = 0;
+    g.partial = nullptr; g.partial_slices = 0;
     return cdx_gemm_f32(&g, stream);
 }
 
@@ -530,6 +531,7 @@ int tf_forward(const cdx_chitf_weights* w, const cdx_sampling* s, hipStream_t st
 // ------------------------------------------------------------------------------------------------
 // ChiUNet1d as implicit-GEMM convolutions (global conditioning)
 // ------------------------------------------------------------------------------------------------
+#define UNET_SPLITK 6
 struct UNet {                     // one pass over the op list; with dry == true it only measures the workspace
     const cdx_chiunet_weights* w;
     const cdx_sampling* s;
@@ -538,8 +540,9 @@ struct UNet {                     // one pass over the op list; with dry == true
     bool dry;
     int nb, bf, b0, rec, n_rec;
     // persistent (prepare) buffers
-    float *x, *prev, *xin, *obs, *e1, *te, *mte, *gobs, *mo, *tfilm, *ofilm, *pred;
+    float *x, *prev, *xin, *obs, *e1, *te, *mte, *gobs, *mo, *tfilm, *ofilm, *pred, *splitk;
     long long film_total;         // sum of film_out over all blocks (row width of the film tables)
+    long long splitk_floats;      // split-K scratch: UNET_SPLITK slices of the largest conv output (rows x model_dim at full length)
 
     float* take(long long n) { return a.take(n); }
 
@@ -551,6 +554,8 @@ struct UNet {                     // one pass over the op list; with dry == true
         g.M = bf * Lout; g.N = N; g.K = taps * cin; g.lda = lda; g.ldw = taps * cin; g.ldc = ldc; g.ldg = 0; g.ldr = ldr;
         g.rows_per_gate = 1; g.table_rows = 0; g.act = CDX_ACT_NONE;
         g.conv_taps = taps; g.conv_cin = cin; g.conv_lin = Lin; g.conv_lout = Lout; g.conv_stride = stride; g.conv_pad = pad;
+        g.partial = splitk; g.partial_slices = (splitk && (long long)g.M * N * UNET_SPLITK <= splitk_floats) ? UNET_SPLITK : 0;
+        if (g.partial_slices == 0) g.partial = nullptr;
         return cdx_gemm_f32(&g, st);
     }
     int gn(const float* x, float* y, int L, int C, int G, const float* gamma, const float* beta, const float* fa, int ldfa,
@@ -601,6 +606,8 @@ struct UNet {                     // one pass over the op list; with dry == true
         gobs = take((long long)bf * E); mo = take((long long)bf * E);
         tfilm = take((long long)trow * film_total); ofilm = take((long long)bf * film_total);
         pred = take((long long)bf * s->hd);
+        splitk_floats = (long long)UNET_SPLITK * bf * w->Ta * w->model_dim;     // every conv output is <= bf*Ta*model_dim floats
+        splitk = take(splitk_floats);
         if (dry) return CDX_OK;
         const float* trows = s->temb;                    // per-sample timesteps: rows of this chunk (both CFG halves alike)
         if (s->temb_per_sample) {

@@ -210,14 +210,16 @@ __device__ __forceinline__ void gm_stamp(int slot) {
 // FAST: K % 16 == 0, 16-byte aligned rows -> unguarded global_load_dwordx4 (rows beyond the edge are clamped: they only
 // feed outputs that are never stored).  !FAST: fully guarded scalar loads (K = 29 input projections and the like).
 template <bool FAST>
-__global__ __launch_bounds__(GM_THREADS, 3) void cdx_gemm_kernel(const cdx_gemm_args g, const int stagger, const int fast_ep) {
+__global__ __launch_bounds__(GM_THREADS, 3) void cdx_gemm_kernel(const cdx_gemm_args g, const int stagger, const int fast_ep,
+                                                                const int k_split) {
     // one LDS arena: A/B staging tiles during the K loop, then 4 wave-private 32 x 36 transposition patches
     __shared__ __attribute__((aligned(16))) float smem[4 * GM_BK * GM_LD];   // [stage][A | B][k][row]; 33 KiB >= 4 * 32 * GM_EP_LD
     float (*As)[GM_LD] = reinterpret_cast<float (*)[GM_LD]>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // column-major walk over tiles: consecutive workgroups share the W panel (small N) and stream A
-    const int tiles_m = (g.M + GM_BM - 1) / GM_BM;
-    const int bm = (blockIdx.x % tiles_m) * GM_BM, bn = (blockIdx.x / tiles_m) * GM_BN;
+    const int tiles_m = (g.M + GM_BM - 1) / GM_BM, tiles_n = (g.N + GM_BN - 1) / GM_BN;
+    const int tile = blockIdx.x % (tiles_m * tiles_n), slice = blockIdx.x / (tiles_m * tiles_n);   // split-K: slice of the K range
+    const int bm = (tile % tiles_m) * GM_BM, bn = (tile / tiles_m) * GM_BN;
     const int lrow = tid & 127, kq = tid >> 7;          // this thread stages row `lrow`, k quads kq and kq + 2
 
     // First-wave stagger: the 3 workgroups that share a CU (dispatch order: b, b + 256, b + 512) would otherwise run their
@@ -292,13 +294,16 @@ __global__ __launch_bounds__(GM_THREADS, 3) void cdx_gemm_kernel(const cdx_gemm_
 
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const int lr = lane & 31, lk = lane >> 5;
-    const int nk = (g.K + GM_BK - 1) / GM_BK;
+    const int nk_all = (g.K + GM_BK - 1) / GM_BK;
+    const int per = (nk_all + k_split - 1) / k_split;    // K tiles per slice
+    const int kt0 = slice * per * GM_BK;                  // first k of this slice
+    const int nk = min(per, nk_all - slice * per);
 
     // Two LDS stages, ONE barrier per 16-wide K tile: while the MFMAs of tile t run out of stage t & 1, the registers
     // holding tile t + 1 (fetched a whole tile earlier) are written to the other stage and tile t + 2 is requested.
-    fetch(0);
+    fetch(kt0);
     stage(0);
-    if (nk > 1) fetch(GM_BK);
+    if (nk > 1) fetch(kt0 + GM_BK);
     __syncthreads();
     gm_stamp(1);
     for (int t = 0; t < nk; ++t) {
@@ -319,7 +324,7 @@ __global__ __launch_bounds__(GM_THREADS, 3) void cdx_gemm_kernel(const cdx_gemm_
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
             if (kk == 4 && t + 1 < nk) {                 // mid-tile: park tile t + 1 in the other stage, request tile t + 2
                 stage((t + 1) & 1);
-                if (t + 2 < nk) fetch((t + 2) * GM_BK);
+                if (t + 2 < nk) fetch(kt0 + (t + 2) * GM_BK);
             }
             a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
         }
@@ -333,6 +338,14 @@ __global__ __launch_bounds__(GM_THREADS, 3) void cdx_gemm_kernel(const cdx_gemm_
     const int row0 = bm + wm, col0 = bn + wn;
     float* patch = smem + wave * (32 * GM_EP_LD);
     const bool fe = fast_ep != 0;
+    if (k_split > 1) {                                   // raw partial tile; the epilogue runs in gm_splitk_reduce_kernel
+        cdx_gemm_args gp = g;
+        gp.C = g.partial + (size_t)slice * g.M * g.N; gp.ldc = g.N;
+        gp.bias = nullptr; gp.gate = nullptr; gp.residual = nullptr; gp.table = nullptr;
+        gm_epilogue_any<CDX_ACT_NONE>(gp, acc, patch, row0, col0, lane, (g.N % 4 == 0));
+        gm_stamp(3);
+        return;
+    }
     switch (g.act) {
         case CDX_ACT_MISH: gm_epilogue_any<CDX_ACT_MISH>(g, acc, patch, row0, col0, lane, fe); break;
         case CDX_ACT_GELU_ERF: gm_epilogue_any<CDX_ACT_GELU_ERF>(g, acc, patch, row0, col0, lane, fe); break;
@@ -343,6 +356,24 @@ __global__ __launch_bounds__(GM_THREADS, 3) void cdx_gemm_kernel(const cdx_gemm_
         default: gm_epilogue_any<CDX_ACT_NONE>(g, acc, patch, row0, col0, lane, fe); break;
     }
     gm_stamp(3);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Second pass of a split-K launch: C = epilogue(sum over slices, in slice order, of partial[slice]) -- same epilogue semantics as
+// the GEMM kernel (bias -> act -> gate -> residual -> table), one output element per thread, memory bound.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gm_splitk_reduce_kernel(const cdx_gemm_args g, const int k_split) {
+    const size_t total = (size_t)g.M * g.N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / g.N), n = (int)(i - (size_t)m * g.N);
+        float v = 0.f;
+        for (int s = 0; s < k_split; ++s) v += g.partial[(size_t)s * total + i];
+        v = gm_act(v + (g.bias ? g.bias[n] : 0.f), g.act);
+        if (g.gate) v *= g.gate[(size_t)(m / g.rows_per_gate) * g.ldg + n];
+        if (g.residual) v += g.residual[(size_t)m * g.ldr + n];
+        if (g.table) v += g.table[(size_t)(m % g.table_rows) * g.N + n];
+        g.C[(size_t)m * g.ldc + n] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -746,8 +777,24 @@ int cdx_gemm_f32(const cdx_gemm_args* g, void* hip_stream) {
     const uintptr_t ep_ptrs = (uintptr_t)g->C | (uintptr_t)g->gate | (uintptr_t)g->residual | (uintptr_t)g->table;
     const int fast_ep = (g->N % 4 == 0) && (g->ldc % 4 == 0) && (!g->gate || g->ldg % 4 == 0) &&
                         (!g->residual || g->ldr % 4 == 0) && (ep_ptrs % 16 == 0);
-    if (vec) hipLaunchKernelGGL(cdx_gemm_kernel<true>, dim3(tiles), dim3(GM_THREADS), 0, s, *g, stagger, fast_ep);
-    else hipLaunchKernelGGL(cdx_gemm_kernel<false>, dim3(tiles), dim3(GM_THREADS), 0, s, *g, stagger, fast_ep);
+    // split-K when the tile count cannot fill the chip (768 workgroup slots) and K is long enough to pay for the second pass
+    int k_split = 1;
+    if (g->partial != nullptr && g->partial_slices > 1 && tiles < 384) {
+        const int nk_all = (g->K + GM_BK - 1) / GM_BK;
+        k_split = (768 + tiles - 1) / tiles;
+        if (k_split > g->partial_slices) k_split = g->partial_slices;
+        if (k_split > nk_all / 16) k_split = nk_all / 16;           // at least 16 K tiles (256 k) per slice
+        if (k_split < 1) k_split = 1;
+        const int per = (nk_all + k_split - 1) / k_split;
+        k_split = (nk_all + per - 1) / per;                          // no empty slices
+    }
+    if (vec) hipLaunchKernelGGL(cdx_gemm_kernel<true>, dim3(tiles * k_split), dim3(GM_THREADS), 0, s, *g, stagger, fast_ep, k_split);
+    else hipLaunchKernelGGL(cdx_gemm_kernel<false>, dim3(tiles * k_split), dim3(GM_THREADS), 0, s, *g, stagger, fast_ep, k_split);
+    if (k_split > 1) {
+        const size_t total = (size_t)g->M * g->N;
+        const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL(gm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, *g, k_split);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
     return CDX_OK;

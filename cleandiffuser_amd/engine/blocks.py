@@ -20,7 +20,8 @@ class CdxGemmArgs(ctypes.Structure):
                 ("ldw", ctypes.c_int32), ("ldc", ctypes.c_int32), ("ldg", ctypes.c_int32), ("ldr", ctypes.c_int32),
                 ("rows_per_gate", ctypes.c_int32), ("table_rows", ctypes.c_int32), ("act", ctypes.c_int32),
                 ("conv_taps", ctypes.c_int32), ("conv_cin", ctypes.c_int32), ("conv_lin", ctypes.c_int32),
-                ("conv_lout", ctypes.c_int32), ("conv_stride", ctypes.c_int32), ("conv_pad", ctypes.c_int32)]
+                ("conv_lout", ctypes.c_int32), ("conv_stride", ctypes.c_int32), ("conv_pad", ctypes.c_int32),
+                ("partial", ctypes.c_void_p), ("partial_slices", ctypes.c_int32)]
 
 
 class CdxGnArgs(ctypes.Structure):
@@ -83,7 +84,8 @@ def _rows(t: torch.Tensor):
 
 def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
            act: str = "none", gate: Optional[torch.Tensor] = None, rows_per_gate: int = 1,
-           residual: Optional[torch.Tensor] = None, table: Optional[torch.Tensor] = None) -> torch.Tensor:
+           residual: Optional[torch.Tensor] = None, table: Optional[torch.Tensor] = None,
+           partial: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = act(a @ w.T + bias) * gate[row // rows_per_gate] + residual + table[row % len(table)]  (one launch)."""
     m, k = a.shape
     n = w.shape[0]
@@ -93,7 +95,8 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     g = CdxGemmArgs(A=a.data_ptr(), W=w.data_ptr(), bias=_p(bias), gate=_p(gate), residual=_p(residual),
                     table=_p(table), C=out.data_ptr(), M=m, N=n, K=k, lda=_rows(a), ldw=_rows(w), ldc=_rows(out),
                     ldg=_rows(gate) if gate is not None else 0, ldr=_rows(residual) if residual is not None else 0,
-                    rows_per_gate=rows_per_gate, table_rows=table.shape[0] if table is not None else 0, act=ACT[act])
+                    rows_per_gate=rows_per_gate, table_rows=table.shape[0] if table is not None else 0, act=ACT[act],
+                    partial=_p(partial), partial_slices=(partial.numel() // max(m * n, 1)) if partial is not None else 0)
     if table is not None:
         assert table.shape[1] == n and table.is_contiguous()
     _check(_lib().cdx_gemm_f32(ctypes.byref(g), _stream_ptr(a.device)), "cdx_gemm_f32")
@@ -102,7 +105,7 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
 
 def conv1d(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], batch: int, l_in: int, stride: int = 1,
            pad: int = 0, out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, act: str = "none",
-           l_out: Optional[int] = None):
+           l_out: Optional[int] = None, partial: Optional[torch.Tensor] = None):
     """Implicit-GEMM Conv1d on channel-last rows.  x: (batch*l_in, c_in); w_packed: (c_out, taps, c_in) = weight.permute(0,2,1);
     -> (batch*l_out, c_out), l_out = (l_in + 2 pad - taps) // stride + 1 unless given (`pad` is the LEFT padding; positions past
     either end read zeros, so an explicit l_out expresses asymmetric padding)."""
@@ -116,7 +119,8 @@ def conv1d(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor]
     g = CdxGemmArgs(A=x.data_ptr(), W=w2.data_ptr(), bias=_p(bias), residual=_p(residual), C=out.data_ptr(), M=m, N=n,
                     K=taps * cin, lda=_rows(x), ldw=_rows(w2), ldc=_rows(out), ldr=_rows(residual) if residual is not None else 0,
                     rows_per_gate=1, act=ACT[act], conv_taps=taps, conv_cin=cin, conv_lin=l_in, conv_lout=l_out,
-                    conv_stride=stride, conv_pad=pad)
+                    conv_stride=stride, conv_pad=pad, partial=_p(partial),
+                    partial_slices=(partial.numel() // (m * n)) if partial is not None else 0)
     _check(_lib().cdx_gemm_f32(ctypes.byref(g), _stream_ptr(x.device)), "cdx_gemm_f32(conv)")
     return out
 

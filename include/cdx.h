@@ -137,6 +137,11 @@ typedef struct cdx_gemm_args {
      * Replaces nn.Conv1d / (per output parity) nn.ConvTranspose1d of the temporal U-Nets (reference nn_diffusion/chiunet.py:19-28,
      * jannerunet.py:22-36). */
     int32_t conv_taps, conv_cin, conv_lin, conv_lout, conv_stride, conv_pad;
+    /* Split-K for launches that cannot fill the chip with 128 x 128 tiles (few rows, long K): with `partial` != NULL the library
+     * may cut K into k_split slices (chosen internally, <= partial_slices), each workgroup writes its raw partial tile to
+     * partial[slice][M][N] and a second pass sums the slices in a fixed order and applies the epilogue -- deterministic. */
+    float* partial;        /* device scratch of partial_slices * M * N floats, or NULL: never split */
+    int32_t partial_slices;
 } cdx_gemm_args;
 int cdx_gemm_f32(const cdx_gemm_args* args, void* hip_stream);
 

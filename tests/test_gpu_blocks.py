@@ -172,3 +172,19 @@ def test_groupnorm_mish_film_residual(c, groups, L, film):
         y = y + f[:, :, None]
     ref = y.permute(0, 2, 1).reshape(B * L, c) + _ref(res)
     torch.testing.assert_close(out.cpu().double(), ref, rtol=3e-5, atol=3e-5)
+
+
+@pytest.mark.parametrize("m,n,k,slices", [(256, 256, 4096, 6), (300, 130, 2048, 4), (128, 64, 512, 8)])
+def test_gemm_split_k_is_exact_and_deterministic(m, n, k, slices):
+    """Few tiles + long K: the library splits K over `slices` partial buffers and reduces them in slice order."""
+    from cleandiffuser_amd.engine import blocks
+    g = torch.Generator().manual_seed(k)
+    a, w, b = torch.randn(m, k, generator=g), torch.randn(n, k, generator=g) / k ** 0.5, torch.randn(n, generator=g)
+    res = torch.randn(m, n, generator=g)
+    part = torch.full((slices * m * n,), float("nan"), device=DEV)
+    kw = dict(act="mish", residual=res.to(DEV), partial=part)
+    o1 = blocks.linear(a.to(DEV), w.to(DEV), b.to(DEV), **kw)
+    o2 = blocks.linear(a.to(DEV), w.to(DEV), b.to(DEV), **kw)
+    assert torch.equal(o1, o2)
+    ref = F.mish(F.linear(_ref(a), _ref(w), _ref(b))) + _ref(res)
+    torch.testing.assert_close(o1.cpu().double(), ref, rtol=2e-5, atol=2e-5)
