@@ -123,7 +123,7 @@ CHIUNET_CASES = [n for n, c in cases.CASES.items() if c["net"][0] == "ChiUNet1d"
 @pytest.mark.parametrize("chunk", [None, 2])
 @pytest.mark.parametrize("name", CHIUNET_CASES)
 def test_chiunet_gemm_executor_matches_reference_fixture(name, chunk, amd_lib, monkeypatch):
-    """ChiUNet1d's second native executor (implicit-GEMM convolutions, cdx_chiunet_run) -- normally chosen for batch >= 512 --
+    """ChiUNet1d's second native executor (implicit-GEMM convolutions, cdx_chiunet_run) -- normally chosen for batch >= 96 --
     forced on for the small fixtures: same reference samples, one native call."""
     from cleandiffuser_amd.engine import bigbatch
     gold = np.load(golden_path(name))

@@ -34,17 +34,16 @@ def cfg1():
     return "config 1: PearceMlp DDPM act=6 obs=17, 100 steps, B=256", call, B, 100, net, P_TILE
 
 
-def cfg3():
+def cfg3(B=1024):
     net = load_synth(ChiUNet1d(2, 20, 2, model_dim=256, emb_dim=256, dim_mult=[1, 2, 2], obs_as_global_cond=True))
     agent = DDPM(net, IdentityCondition(dropout=0.0), diffusion_steps=50, x_max=torch.ones(1, 16, 2, device=DEV),
                  x_min=-torch.ones(1, 16, 2, device=DEV), device=DEV)
     agent.eval()
-    B = 1024
     cond = torch.randn(B, 2, 20, device=DEV)
     zs = [torch.randn(B, 16, 2, device=DEV) for _ in range(50)]
     call = lambda: agent.sample(torch.zeros(B, 16, 2, device=DEV), n_samples=B, sample_steps=50,  # noqa: E731
                                 condition_cfg=cond, w_cfg=1.0, noise=zs)[0]
-    return "config 3: ChiUNet1d dp_pusht H=16 act=2 obs=20, 50-step legacy DDPM, B=1024", call, B, 50, net, 16
+    return f"config 3: ChiUNet1d dp_pusht H=16 act=2 obs=20, 50-step legacy DDPM, B={B}", call, B, 50, net, 16
 
 
 from cleandiffuser_amd.engine.program import MLP_TILE as P_TILE  # noqa: E402
@@ -110,8 +109,8 @@ def run_big(name, fn, reps=2, **kw):
                       "frac_fp32_mfma_peak": flops / dt / 1e12 / PEAK}), flush=True)
 
 
-def run(name, fn, reps=3):
-    label, call, B, steps, net, horizon = fn()
+def run(name, fn, reps=3, **kw):
+    label, call, B, steps, net, horizon = fn(**kw)
     x = call()
     torch.cuda.synchronize()
     assert torch.isfinite(x).all()
@@ -143,4 +142,5 @@ if __name__ == "__main__":
             base, _, b = name.partition(":")
             run_big(name, {"cfg4": cfg4, "cfg5": cfg5}[base], **({"B": int(b)} if b else {}))
         else:
-            run(name, {"cfg1": cfg1, "cfg3": cfg3}[name])
+            base, _, b = name.partition(":")
+            run(name, {"cfg1": cfg1, "cfg3": cfg3}[base], **({"B": int(b)} if b else {}))
