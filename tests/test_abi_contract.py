@@ -26,7 +26,8 @@ def test_every_declared_symbol_is_exported(lib):
     assert set(names) >= {"cdx_abi_version", "cdx_last_error", "cdx_unet1d_run", "cdx_probe_mfma_layout", "cdx_gemm_f32",
                           "cdx_layernorm_f32", "cdx_attention_f32", "cdx_act_f32", "cdx_dit1d_run", "cdx_resmlp_run",
                           "cdx_dit1d_workspace_floats", "cdx_resmlp_workspace_floats", "cdx_gemm_set_trace",
-                          "cdx_chitf_run", "cdx_chitf_workspace_floats", "cdx_cross_attention_f32"}
+                          "cdx_chitf_run", "cdx_chitf_workspace_floats", "cdx_cross_attention_f32", "cdx_chiunet_run",
+                          "cdx_chiunet_workspace_floats", "cdx_groupnorm_f32"}
     for n in names:
         assert hasattr(lib, n), f"{n} declared in cdx.h but not exported by libcdx.so"
     assert lib.cdx_abi_version() == int(re.search(r"#define CDX_ABI_VERSION (\d+)", hdr).group(1))
@@ -39,7 +40,8 @@ def test_ctypes_mirrors_have_c_layout(tmp_path):
                "cdx_dit1d_block": bigbatch.CdxDitBlock, "cdx_dit1d_weights": bigbatch.CdxDitWeights,
                "cdx_resmlp_block": bigbatch.CdxResMlpBlock, "cdx_resmlp_weights": bigbatch.CdxResMlpWeights,
                "cdx_chitf_layer": bigbatch.CdxChitfLayer, "cdx_chitf_weights": bigbatch.CdxChitfWeights,
-               "cdx_xattn_args": blocks.CdxXattnArgs}
+               "cdx_xattn_args": blocks.CdxXattnArgs, "cdx_gn_args": blocks.CdxGnArgs,
+               "cdx_chiunet_block": bigbatch.CdxChiUNetBlock, "cdx_chiunet_weights": bigbatch.CdxChiUNetWeights}
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "cdx.h"', 'int main(void){']
     for cname, mirror in mirrors.items():
         src.append(f'printf("%zu\\n", sizeof({cname}));')
