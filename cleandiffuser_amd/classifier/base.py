@@ -46,6 +46,11 @@ class BaseClassifier:
         raise NotImplementedError
 
     def gradients(self, x: torch.Tensor, noise: torch.Tensor, c: torch.Tensor):
+        if x.is_cuda:                         # explicit forward + backward kernels (engine/classifier_grad.py); None -> autograd
+            from ..engine import classifier_grad
+            native = classifier_grad.gradients(self, x, noise, c)
+            if native is not None:
+                return native
         x.requires_grad_()
         logp = self.logp(x, noise, c)
         grad = torch.autograd.grad([logp.sum()], [x])[0]

@@ -42,6 +42,13 @@ __device__ __forceinline__ float gm_act(float x, int act) {
         case CDX_ACT_LEAKY: return x > 0.f ? x : 0.01f * x;
         case CDX_ACT_SILU: return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
         case CDX_ACT_RELU: return fmaxf(x, 0.f);
+        case CDX_ACT_MISH_GRAD: {                        // d/dx [x tanh(softplus x)] = t + x (1 - t^2) sigmoid(x)
+            const float e = __expf(fminf(x, 20.0f));
+            const float n = e * (e + 2.0f);
+            const float t = x > 20.0f ? 1.0f : n / (n + 2.0f);
+            const float sg = e / (1.0f + e);
+            return t + x * (1.0f - t * t) * sg;
+        }
         case CDX_ACT_GELU_TANH: {                        // 0.5 x (1 + tanh u) == x * sigmoid(2u): one v_exp, one v_rcp, no branches
             const float u2 = 1.5957691216057308f * (x + 0.044715f * x * x * x);
             return x * __builtin_amdgcn_rcpf(1.0f + __expf(-u2));
@@ -506,6 +513,58 @@ __global__ __launch_bounds__(256) void cdx_groupnorm_kernel(const cdx_gn_args a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Backward of act(GroupNorm(x) gamma + beta) w.r.t. x, one wave per (sample, group):
+//   dz = dy * act'(z),  g = dz * gamma,  dx = rstd * (g - mean(g) - xhat * mean(g * xhat))      (means over the group)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cdx_groupnorm_bwd_kernel(const cdx_gn_args a) {
+    const int lane = threadIdx.x & 63;
+    const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wg >= a.B * a.G) return;
+    const int b = wg / a.G, grp = wg - b * a.G;
+    const int cg = a.C / a.G, n = a.L * cg;
+    const float* xb = a.x + (size_t)b * a.L * a.ldx + grp * cg;
+    const float* db = a.residual + (size_t)b * a.L * a.ldr + grp * cg;
+    float s = 0.f;
+    for (int e = lane; e < n; e += 64) {
+        const int l = e / cg, c = e - l * cg;
+        s += xb[(size_t)l * a.ldx + c];
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)n;
+    float s2 = 0.f;
+    for (int e = lane; e < n; e += 64) {
+        const int l = e / cg, c = e - l * cg;
+        const float d = xb[(size_t)l * a.ldx + c] - mean;
+        s2 += d * d;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+    const float rstd = 1.0f / sqrtf(s2 / (float)n + a.eps);
+    float sg = 0.f, sgx = 0.f;                           // sum g, sum g * xhat
+    for (int e = lane; e < n; e += 64) {
+        const int l = e / cg, c = e - l * cg, ch = grp * cg + c;
+        const float xh = (xb[(size_t)l * a.ldx + c] - mean) * rstd;
+        const float z = xh * a.gamma[ch] + a.beta[ch];
+        const float dz = db[(size_t)l * a.ldr + c] * (a.act == CDX_ACT_MISH ? gm_act(z, CDX_ACT_MISH_GRAD) : 1.0f);
+        const float g = dz * a.gamma[ch];
+        sg += g;
+        sgx += g * xh;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { sg += __shfl_xor(sg, o, 64); sgx += __shfl_xor(sgx, o, 64); }
+    const float mg = sg / (float)n, mgx = sgx / (float)n;
+    for (int e = lane; e < n; e += 64) {
+        const int l = e / cg, c = e - l * cg, ch = grp * cg + c;
+        const float xh = (xb[(size_t)l * a.ldx + c] - mean) * rstd;
+        const float z = xh * a.gamma[ch] + a.beta[ch];
+        const float dz = db[(size_t)l * a.ldr + c] * (a.act == CDX_ACT_MISH ? gm_act(z, CDX_ACT_MISH_GRAD) : 1.0f);
+        const float g = dz * a.gamma[ch];
+        a.y[((size_t)b * a.L + l) * a.ldy + ch] = rstd * (g - mg - xh * mgx);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Multi-head self-attention over short sequences (T <= 64 tokens, head_dim <= 64), full softmax, no mask
 // (reference dit.py:20,34 = nn.MultiheadAttention(batch_first) core: softmax(q k^T / sqrt(d_h)) v).
 // qkv: (B*T, 3*d_model) as produced by in_proj (q | k | v, heads contiguous inside each third).
@@ -832,6 +891,20 @@ int cdx_groupnorm_f32(const cdx_gn_args* a, void* hip_stream) {
     if (!a->x || !a->y || !a->gamma || !a->beta) { cdx_set_err("cdx_groupnorm_f32: null pointer"); return CDX_EINVAL; }
     const long long waves = (long long)a->B * a->G;
     hipLaunchKernelGGL(cdx_groupnorm_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), *a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
+    return CDX_OK;
+}
+
+int cdx_groupnorm_bwd_f32(const cdx_gn_args* a, void* hip_stream) {
+    if (!a) { cdx_set_err("cdx_groupnorm_bwd_f32: null argument block"); return CDX_EINVAL; }
+    if (a->B < 0 || a->L <= 0 || a->C <= 0 || a->G <= 0 || a->C % a->G != 0 || (a->act != CDX_ACT_MISH && a->act != CDX_ACT_NONE)) {
+        cdx_set_err("cdx_groupnorm_bwd_f32: bad shape or unsupported activation"); return CDX_EINVAL;
+    }
+    if (a->B == 0) return CDX_OK;
+    if (!a->x || !a->y || !a->gamma || !a->beta || !a->residual) { cdx_set_err("cdx_groupnorm_bwd_f32: null pointer"); return CDX_EINVAL; }
+    const long long waves = (long long)a->B * a->G;
+    hipLaunchKernelGGL(cdx_groupnorm_bwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), *a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
     return CDX_OK;

@@ -10,7 +10,7 @@ from . import program as P
 from .runtime import _check, _stream_ptr, load_library
 
 ACT = {"none": P.ACT_NONE, "mish": P.ACT_MISH, "gelu": P.ACT_GELU_ERF, "leaky": P.ACT_LEAKY, "silu": P.ACT_SILU,
-       "relu": P.ACT_RELU, "gelu_tanh": P.ACT_GELU_TANH}
+       "relu": P.ACT_RELU, "gelu_tanh": P.ACT_GELU_TANH, "mish_grad": P.ACT_MISH_GRAD}
 
 
 class CdxGemmArgs(ctypes.Structure):
@@ -64,6 +64,8 @@ def _lib():
         lib.cdx_attention_f32.argtypes = [ctypes.POINTER(CdxAttnArgs), ctypes.c_void_p]
         lib.cdx_groupnorm_f32.argtypes = [ctypes.POINTER(CdxGnArgs), ctypes.c_void_p]
         lib.cdx_groupnorm_f32.restype = ctypes.c_int
+        lib.cdx_groupnorm_bwd_f32.argtypes = [ctypes.POINTER(CdxGnArgs), ctypes.c_void_p]
+        lib.cdx_groupnorm_bwd_f32.restype = ctypes.c_int
         lib.cdx_cross_attention_f32.argtypes = [ctypes.POINTER(CdxXattnArgs), ctypes.c_void_p]
         lib.cdx_cross_attention_f32.restype = ctypes.c_int
         lib.cdx_act_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p]
@@ -78,8 +80,9 @@ def _p(t: Optional[torch.Tensor]):
 
 
 def _rows(t: torch.Tensor):
-    assert t.dim() == 2 and t.stride(1) == 1 and t.dtype == torch.float32 and t.is_cuda, "2-D fp32 row-major device tensor"
-    return t.stride(0)
+    assert t.dim() == 2 and (t.stride(1) == 1 or t.shape[1] == 1) and t.dtype == torch.float32 and t.is_cuda, \
+        "2-D fp32 row-major device tensor"
+    return max(t.stride(0), t.shape[1]) if t.shape[0] > 1 else t.shape[1]
 
 
 def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
@@ -162,6 +165,17 @@ def groupnorm(x: torch.Tensor, gamma, beta, batch: int, length: int, groups: int
                   ldfb=_rows(fb) if fb is not None else 0, fa_row=fa_row, fa_per_sample=int(fa_per_sample), film_mode=film_mode,
                   act=ACT[act], eps=eps)
     _check(_lib().cdx_groupnorm_f32(ctypes.byref(a), _stream_ptr(x.device)), "cdx_groupnorm_f32")
+    return out
+
+
+def groupnorm_backward(dy: torch.Tensor, x: torch.Tensor, gamma, beta, batch: int, length: int, groups: int,
+                       act: str = "mish", eps: float = 1e-5, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """d loss / d x for y = act(groupnorm(x) * gamma + beta), given dy = d loss / d y (x is the saved forward input)."""
+    if out is None:
+        out = torch.empty_like(x)
+    a = CdxGnArgs(x=x.data_ptr(), y=out.data_ptr(), gamma=gamma.data_ptr(), beta=beta.data_ptr(), residual=dy.data_ptr(),
+                  B=batch, L=length, C=x.shape[1], G=groups, ldx=_rows(x), ldy=_rows(out), ldr=_rows(dy), act=ACT[act], eps=eps)
+    _check(_lib().cdx_groupnorm_bwd_f32(ctypes.byref(a), _stream_ptr(x.device)), "cdx_groupnorm_bwd_f32")
     return out
 
 

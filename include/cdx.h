@@ -173,6 +173,10 @@ typedef struct cdx_gn_args {
     float eps;
 } cdx_gn_args;
 int cdx_groupnorm_f32(const cdx_gn_args* args, void* hip_stream);
+/* Backward of y = act(gn(x) * gamma + beta) w.r.t. x (classifier guidance, reference classifier/base.py:74-79 asks autograd
+ * for d logp / d x): same argument block with `x` = the saved forward input, `residual` = d loss / d y (row stride ldr),
+ * `y` = d loss / d x; act must be CDX_ACT_MISH or CDX_ACT_NONE; the FiLM fields are ignored. */
+int cdx_groupnorm_bwd_f32(const cdx_gn_args* args, void* hip_stream);
 
 /* out[b][t][h*d..] = softmax(q k^T * scale) v per (batch, head); qkv = (B*T, 3*n_heads*head_dim) from in_proj.
  * Replaces the core of nn.MultiheadAttention(batch_first=True) (reference dit.py:20,34).  T <= 64, head_dim <= 64. */

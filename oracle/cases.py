@@ -188,6 +188,18 @@ CASES.update({
         solver=("EDM", dict()), sample=dict(solver="euler", sample_steps=5, w_cfg=1.0)),
 })
 
+# ---- classifier guidance at every step (w_cg > 0: what every shipped Diffuser configuration runs) ----
+CASES.update({
+    "janner_cfg2_guided_ddpm": dict(
+        net=JANNER_CFG2, horizon=32, batch=4, fix_obs=17, classifier=dict(kernel_size=3),
+        solver=("DiscreteDiffusionSDE", dict(diffusion_steps=20, predict_noise=False)),
+        sample=dict(solver="ddpm", sample_steps=5, temperature=0.5, w_cg=0.3)),
+    "janner_h4_guided_eps": dict(
+        net=JANNER_H4, horizon=4, batch=5, fix_obs=17, classifier=dict(kernel_size=3), clip=3.0,
+        solver=("DiscreteDiffusionSDE", dict(diffusion_steps=20, predict_noise=True)),
+        sample=dict(solver="ddim", sample_steps=6, w_cg=0.05)),
+})
+
 # ---- rectified flow and consistency models (Euler transport as linear records; step kind 7) ----
 CASES.update({
     "janner_rflow_discrete": dict(_J8, clip=2.0, solver=("DiscreteRectifiedFlow", dict(diffusion_steps=20)),

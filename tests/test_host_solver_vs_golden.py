@@ -17,7 +17,9 @@ def test_torch_executor_matches_reference_fixture(name, amd_lib):
     kw = cases.sample_kwargs(name, inp)
     n_draws = int(gold["n_draws"])
     x, log = cases.sampler_of(agent, name)(torch.from_numpy(inp["prior"]), noise=list(inp["noise"][:n_draws]), **kw)
-    np.testing.assert_allclose(x.numpy(), gold["x_out"], rtol=2e-6, atol=2e-6)
+    # autograd's conv backward sums in a thread-dependent order: guided cases get 2e-5 instead of 2e-6
+    tol = 2e-5 if cases.CASES[name]["sample"].get("w_cg") else 2e-6
+    np.testing.assert_allclose(x.numpy(), gold["x_out"], rtol=tol, atol=tol)
     if "log_p" in gold.files:                      # Diffuser tail: classifier score of the finished trajectories
         np.testing.assert_allclose(log["log_p"].numpy(), gold["log_p"], rtol=2e-6, atol=2e-6)
         assert int(log["log_p"].argmax()) == int(gold["log_p"].argmax())
