@@ -738,6 +738,150 @@ long long chiunet_pass(const cdx_chiunet_weights* w, const cdx_sampling* s, hipS
     return need;
 }
 
+// ------------------------------------------------------------------------------------------------
+// HalfJannerUNet1d forward + input-gradient backward (classifier guidance)
+// ------------------------------------------------------------------------------------------------
+__global__ void fill_kernel(float* __restrict__ p, float v, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+#define HJ_SPLITK 4
+struct HjPass {
+    const cdx_hjgrad_weights* w;
+    hipStream_t st;
+    Arena a;
+    bool dry;
+    int b;
+    float* partial = nullptr;     // split-K scratch: at batch 256 every conv has <= 64 tiles and a long serial K loop
+    long long partial_floats = 0;
+
+    int conv(const float* x, int cin, const float* wp, const float* bias, int Lin, int Lout, int taps, int stride, int pad, int N,
+             float* out, int ldc, const float* residual) {
+        if (dry) return CDX_OK;
+        cdx_gemm_args g;
+        g.A = x; g.W = wp; g.bias = bias; g.gate = nullptr; g.residual = residual; g.table = nullptr; g.C = out;
+        g.M = b * Lout; g.N = N; g.K = taps * cin; g.lda = cin; g.ldw = taps * cin; g.ldc = ldc; g.ldg = 0; g.ldr = N;
+        g.rows_per_gate = 1; g.table_rows = 0; g.act = CDX_ACT_NONE;
+        g.conv_taps = taps; g.conv_cin = cin; g.conv_lin = Lin; g.conv_lout = Lout; g.conv_stride = stride; g.conv_pad = pad;
+        const bool fits = partial && (long long)g.M * N * HJ_SPLITK <= partial_floats && ldc == N;
+        g.partial = fits ? partial : nullptr; g.partial_slices = fits ? HJ_SPLITK : 0;
+        return cdx_gemm_f32(&g, st);
+    }
+    int gn(bool backward, const float* x, float* y, int L, int C, int G, const float* gamma, const float* beta, const float* fa,
+           const float* res_or_dy) {
+        if (dry) return CDX_OK;
+        cdx_gn_args q;
+        q.x = x; q.y = y; q.gamma = gamma; q.beta = beta; q.fa = fa; q.fb = nullptr; q.residual = res_or_dy;
+        q.B = b; q.L = L; q.C = C; q.G = G; q.ldx = C; q.ldy = C; q.ldr = C; q.ldfa = C; q.ldfb = 0; q.fa_row = 0;
+        q.fa_per_sample = 1; q.film_mode = fa ? 2 : 0; q.act = CDX_ACT_MISH; q.eps = 1e-5f;
+        return backward ? cdx_groupnorm_bwd_f32(&q, st) : cdx_groupnorm_f32(&q, st);
+    }
+    int lin(const float* A, int lda, const float* W, int K, const float* bias, float* C, int M, int N, int act, const float* gate,
+            const float* residual) {
+        if (dry) return CDX_OK;
+        return gemm(st, A, lda, W, K, bias, C, N, M, N, K, act, gate, N, 1, residual, N);
+    }
+
+    int run(const float* x, const float* emb0, float* logp, float* grad) {
+        const int md = w->model_dim, H = w->horizon, D = w->in_dim;
+        {
+            long long widest = (long long)H * D;           // floats per sample of the largest conv output
+            int L = H, bi = 0, di = 0;
+            for (int s = 0; s < w->n_stages; ++s) {
+                if (w->stage_kind[s] == 0) { const long long n = (long long)L * w->blocks[bi++].cout; widest = n > widest ? n : widest; }
+                else { ++di; L = (L - 1) / 2 + 1; }
+            }
+            partial_floats = (long long)HJ_SPLITK * b * widest;
+            partial = a.take(partial_floats);
+            if (dry) partial = nullptr;
+        }
+        float* e1 = a.take((long long)b * 4 * md);
+        float* emb = a.take((long long)b * md);
+        float* memb = a.take((long long)b * md);
+        CDX_TRY(lin(emb0, w->emb_dim, w->map0_w, w->emb_dim, w->map0_b, e1, b, 4 * md, CDX_ACT_MISH, nullptr, nullptr));
+        CDX_TRY(lin(e1, 4 * md, w->map2_w, 4 * md, w->map2_b, emb, b, md, CDX_ACT_NONE, nullptr, nullptr));
+        if (!dry) CDX_TRY(cdx_act_f32(emb, memb, (long long)b * md, CDX_ACT_MISH, st));
+        // ---- forward; a1 / a2 of every block are kept for the backward
+        const float* cur = x;
+        int L = H, bi = 0, di = 0;
+        struct Saved { float *a1, *a2; int L; } saved[64];
+        if (w->n_stages > 64) { cdx_set_err("cdx_hjgrad_run: too many stages"); return CDX_EINVAL; }
+        for (int s = 0; s < w->n_stages; ++s) {
+            if (w->stage_kind[s] == 0) {
+                const cdx_hj_block& k = w->blocks[bi++];
+                const long long n = (long long)b * L * k.cout;
+                float* e = a.take((long long)b * k.cout);
+                float *a1 = a.take(n), *h1 = a.take(n), *a2 = a.take(n), *o = a.take(n);
+                float* res = k.wr ? a.take(n) : nullptr;
+                CDX_TRY(lin(memb, md, k.emb_w, md, k.emb_b, e, b, k.cout, CDX_ACT_NONE, nullptr, nullptr));
+                CDX_TRY(conv(cur, k.cin, k.w1, k.b1, L, L, k.k, 1, k.k / 2, k.cout, a1, k.cout, nullptr));
+                CDX_TRY(gn(false, a1, h1, L, k.cout, k.groups, k.g1, k.be1, e, nullptr));
+                CDX_TRY(conv(h1, k.cout, k.w2, k.b2, L, L, k.k, 1, k.k / 2, k.cout, a2, k.cout, nullptr));
+                if (k.wr) CDX_TRY(conv(cur, k.cin, k.wr, k.br, L, L, 1, 1, 0, k.cout, res, k.cout, nullptr));
+                CDX_TRY(gn(false, a2, o, L, k.cout, k.groups, k.g2, k.be2, nullptr, k.wr ? res : cur));
+                saved[s] = Saved{a1, a2, L};
+                cur = o;
+            } else {
+                const cdx_hj_down& k = w->downs[di++];
+                const int Lo = (L - 1) / 2 + 1;
+                float* o = a.take((long long)b * Lo * k.c);
+                CDX_TRY(conv(cur, k.c, k.w, k.b, L, Lo, 3, 2, 1, k.c, o, k.c, nullptr));
+                saved[s] = Saved{nullptr, nullptr, L};
+                cur = o; L = Lo;
+            }
+        }
+        const int fc_in = w->c_last * w->l_last, fh = w->fc_hidden, od = w->out_dim;
+        float *u0 = a.take((long long)b * fh), *u = a.take((long long)b * fh), *hm = a.take((long long)b * fh);
+        float *gu = a.take((long long)b * fh), *ones = a.take((long long)b * od), *du = a.take((long long)b * fh);
+        float* g = a.take((long long)b * fc_in);
+        CDX_TRY(lin(emb, md, w->fc1_we, md, w->fc1_b, u0, b, fh, CDX_ACT_NONE, nullptr, nullptr));
+        CDX_TRY(lin(cur, fc_in, w->fc1_wx, fc_in, nullptr, u, b, fh, CDX_ACT_NONE, nullptr, u0));
+        if (!dry) {
+            CDX_TRY(cdx_act_f32(u, hm, (long long)b * fh, CDX_ACT_MISH, st));
+            CDX_TRY(cdx_act_f32(u, gu, (long long)b * fh, CDX_ACT_MISH_GRAD, st));
+            const size_t n1 = (size_t)b * od;
+            hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st, ones, 1.0f, n1);
+            CDX_TRY(hip_ok());
+        }
+        CDX_TRY(lin(hm, fh, w->fc2_w, fh, w->fc2_b, logp, b, od, CDX_ACT_NONE, nullptr, nullptr));
+        // ---- backward of logp.sum()
+        CDX_TRY(lin(ones, od, w->fc2_w_t, od, nullptr, du, b, fh, CDX_ACT_NONE, gu, nullptr));
+        CDX_TRY(lin(du, fh, w->fc1_wx_t, fh, nullptr, g, b, fc_in, CDX_ACT_NONE, nullptr, nullptr));
+        const float* gcur = g;                             // (b * L, C) rows of the current gradient
+        for (int s = w->n_stages - 1; s >= 0; --s) {
+            const int Ls = saved[s].L;
+            if (w->stage_kind[s] == 1) {
+                const cdx_hj_down& k = w->downs[--di];
+                const int Lo = (Ls - 1) / 2 + 1;
+                float* full = a.take((long long)b * Ls * k.c);
+                if (Ls == 1) {
+                    CDX_TRY(conv(gcur, k.c, k.bwd_even, nullptr, 1, 1, 1, 1, 0, k.c, full, k.c, nullptr));
+                } else {                                   // row (b, m) of the (b*Lo, 2c) view = [dX[2m] | dX[2m+1]]
+                    CDX_TRY(conv(gcur, k.c, k.bwd_even, nullptr, Lo, Lo, 1, 1, 0, k.c, full, 2 * k.c, nullptr));
+                    CDX_TRY(conv(gcur, k.c, k.bwd_odd, nullptr, Lo, Lo, 2, 1, 0, k.c, full + k.c, 2 * k.c, nullptr));
+                }
+                gcur = full;
+            } else {
+                const cdx_hj_block& k = w->blocks[--bi];
+                const long long n = (long long)b * Ls * k.cout;
+                float *da2 = a.take(n), *dh1 = a.take(n), *da1 = a.take(n);
+                float* dres = k.wr ? a.take((long long)b * Ls * k.cin) : nullptr;
+                const bool last = s == 0;
+                float* dx = last ? grad : a.take((long long)b * Ls * k.cin);
+                CDX_TRY(gn(true, saved[s].a2, da2, Ls, k.cout, k.groups, k.g2, k.be2, nullptr, gcur));
+                CDX_TRY(conv(da2, k.cout, k.w2_bwd, nullptr, Ls, Ls, k.k, 1, k.k / 2, k.cout, dh1, k.cout, nullptr));
+                CDX_TRY(gn(true, saved[s].a1, da1, Ls, k.cout, k.groups, k.g1, k.be1, nullptr, dh1));
+                if (k.wr) CDX_TRY(conv(gcur, k.cout, k.wr_bwd, nullptr, Ls, Ls, 1, 1, 0, k.cin, dres, k.cin, nullptr));
+                CDX_TRY(conv(da1, k.cout, k.w1_bwd, nullptr, Ls, Ls, k.k, 1, k.k / 2, k.cin, dx, k.cin, k.wr ? dres : gcur));
+                gcur = dx;
+            }
+        }
+        if (w->n_stages > 0 && w->stage_kind[0] != 0) { cdx_set_err("cdx_hjgrad_run: the first stage must be a residual block"); return CDX_EINVAL; }
+        return CDX_OK;
+    }
+};
+
 }  // namespace
 
 extern "C" {
@@ -818,6 +962,26 @@ int cdx_chiunet_run(const cdx_chiunet_weights* w, const cdx_sampling* s, void* h
     if (!s->workspace || s->workspace_floats < need) { cdx_set_err("cdx_chiunet_run: workspace too small"); return CDX_EINVAL; }
     chiunet_pass(w, s, reinterpret_cast<hipStream_t>(hip_stream), s->workspace, false, &rc);
     return rc;
+}
+
+long long cdx_hjgrad_workspace_floats(const cdx_hjgrad_weights* w, int32_t batch) {
+    if (!w || !w->stage_kind || !w->blocks || batch < 0) return -1;
+    HjPass p{w, nullptr, Arena{nullptr, 0, 0}, true, batch};
+    if (p.run(nullptr, nullptr, nullptr, nullptr) != CDX_OK) return -1;
+    return p.a.used;
+}
+
+int cdx_hjgrad_run(const cdx_hjgrad_weights* w, const float* x, const float* emb0, int32_t batch, float* logp, float* grad,
+                   float* workspace, long long workspace_floats, void* hip_stream) {
+    if (!w || !w->stage_kind || !w->blocks || !w->map0_w || !w->fc1_wx || !w->fc2_w) { cdx_set_err("cdx_hjgrad_run: null pointer in weights"); return CDX_EINVAL; }
+    if (batch < 0 || w->horizon <= 0 || w->in_dim <= 0) { cdx_set_err("cdx_hjgrad_run: bad shape"); return CDX_EINVAL; }
+    if (batch == 0) return CDX_OK;
+    if (!x || !emb0 || !logp || !grad) { cdx_set_err("cdx_hjgrad_run: null tensor"); return CDX_EINVAL; }
+    const long long need = cdx_hjgrad_workspace_floats(w, batch);
+    if (need < 0) return CDX_EINVAL;
+    if (!workspace || workspace_floats < need) { cdx_set_err("cdx_hjgrad_run: workspace too small"); return CDX_EINVAL; }
+    HjPass p{w, reinterpret_cast<hipStream_t>(hip_stream), Arena{workspace, 0, 0}, false, batch};
+    return p.run(x, emb0, logp, grad);
 }
 
 long long cdx_resmlp_workspace_floats(const cdx_resmlp_weights* w, const cdx_sampling* s) {

@@ -10,6 +10,7 @@ writing even / odd rows; ``cdx_groupnorm_f32`` / ``cdx_groupnorm_bwd_f32`` do Gr
 keeps the two pre-normalisation tensors of every residual block (the only state the backward needs).  Only the input gradient
 is produced -- no weight gradients, no autograd graph.
 """
+import ctypes
 import weakref
 from typing import Optional, Tuple
 
@@ -17,7 +18,43 @@ import torch
 import torch.nn as nn
 
 from . import blocks as B
-from .runtime import _f32c, _signature
+from .runtime import _check, _f32c, _signature, _stream_ptr, load_library
+
+_FP, _I = ctypes.c_void_p, ctypes.c_int32
+ONE_CALL = True          # True: cdx_hjgrad_run sequences every launch in C; False: the same schedule issued from Python (debugging)
+
+
+class CdxHjBlock(ctypes.Structure):
+    _fields_ = [(n, _I) for n in ("cin", "cout", "k", "groups")] + \
+               [(n, _FP) for n in ("w1", "b1", "w1_bwd", "g1", "be1", "w2", "b2", "w2_bwd", "g2", "be2", "emb_w", "emb_b",
+                                   "wr", "br", "wr_bwd")]
+
+
+class CdxHjDown(ctypes.Structure):
+    _fields_ = [("c", _I)] + [(n, _FP) for n in ("w", "b", "bwd_even", "bwd_odd")]
+
+
+class CdxHjgradWeights(ctypes.Structure):
+    _fields_ = [(n, _I) for n in ("horizon", "in_dim", "model_dim", "emb_dim", "out_dim", "fc_hidden", "c_last", "l_last",
+                                  "n_stages")] + \
+               [("stage_kind", ctypes.POINTER(_I)), ("blocks", ctypes.POINTER(CdxHjBlock)), ("downs", ctypes.POINTER(CdxHjDown))] + \
+               [(n, _FP) for n in ("map0_w", "map0_b", "map2_w", "map2_b", "fc1_wx", "fc1_wx_t", "fc1_we", "fc1_b", "fc2_w",
+                                   "fc2_b", "fc2_w_t")]
+
+
+_declared = False
+
+
+def _lib():
+    global _declared
+    lib = load_library()
+    if not _declared:
+        lib.cdx_hjgrad_workspace_floats.argtypes = [ctypes.POINTER(CdxHjgradWeights), _I]
+        lib.cdx_hjgrad_workspace_floats.restype = ctypes.c_longlong
+        lib.cdx_hjgrad_run.argtypes = [ctypes.POINTER(CdxHjgradWeights), _FP, _FP, _I, _FP, _FP, _FP, ctypes.c_longlong, _FP]
+        lib.cdx_hjgrad_run.restype = ctypes.c_int
+        _declared = True
+    return lib
 
 
 def _bwd_conv_s1(weight: torch.Tensor) -> torch.Tensor:
@@ -84,7 +121,41 @@ class HalfJannerGrad:
         self.fc1_wx = f(wx.reshape(fc1.out_features, self.fc_in))
         self.fc1_wx_t = f(wx.reshape(fc1.out_features, self.fc_in).t())                                   # (fc_in, o)
         self.fc1_we, self.fc1_b = f(fc1.weight.detach()[:, self.fc_in:]), f(fc1.bias)
-        self.fc2_w, self.fc2_b, self.fc2_w_t = f(fc2.weight), f(fc2.bias), f(fc2.weight.detach().t())
+        self.fc2_w, self.fc2_b, self.fc2_w_t = f(fc2.weight), f(fc2.bias), f(fc2.weight.detach().t().contiguous())
+        self._struct = self._bind(net, fc1, fc2)
+        self._ws = None
+
+    def _bind(self, net, fc1, fc2) -> CdxHjgradWeights:
+        p = lambda t: t.data_ptr()  # noqa: E731
+        blocks = [st for kind, st in self.stages if kind == "block"]
+        downs = [st for kind, st in self.stages if kind == "down"]
+        self._kinds = (_I * len(self.stages))(*[0 if kind == "block" else 1 for kind, _ in self.stages])
+        self._blocks_c = (CdxHjBlock * len(blocks))(*[
+            CdxHjBlock(cin=b.w1.shape[2], cout=b.cout, k=b.k, groups=b.groups, w1=p(b.w1), b1=p(b.b1), w1_bwd=p(b.w1_b), g1=p(b.g1),
+                       be1=p(b.be1), w2=p(b.w2), b2=p(b.b2), w2_bwd=p(b.w2_b), g2=p(b.g2), be2=p(b.be2), emb_w=p(b.emb_w),
+                       emb_b=p(b.emb_b), wr=p(b.wr) if b.has_res else None, br=p(b.br) if b.has_res else None,
+                       wr_bwd=p(b.wr_b) if b.has_res else None) for b in blocks])
+        self._downs_c = (CdxHjDown * max(len(downs), 1))(*[
+            CdxHjDown(c=d.w.shape[0], w=p(d.w), b=p(d.b), bwd_even=p(d.even), bwd_odd=p(d.odd)) for d in downs])
+        return CdxHjgradWeights(
+            horizon=net.horizon, in_dim=net.in_dim, model_dim=net.model_dim, emb_dim=net.map_emb[0].in_features,
+            out_dim=fc2.out_features, fc_hidden=fc1.out_features, c_last=self.c_last, l_last=self.l_last,
+            n_stages=len(self.stages), stage_kind=self._kinds, blocks=self._blocks_c, downs=self._downs_c,
+            map0_w=p(self.map0_w), map0_b=p(self.map0_b), map2_w=p(self.map2_w), map2_b=p(self.map2_b), fc1_wx=p(self.fc1_wx),
+            fc1_wx_t=p(self.fc1_wx_t), fc1_we=p(self.fc1_we), fc1_b=p(self.fc1_b), fc2_w=p(self.fc2_w), fc2_b=p(self.fc2_b),
+            fc2_w_t=p(self.fc2_w_t))
+
+    def _one_call(self, x, emb0):
+        lib = _lib()
+        b = x.shape[0]
+        need = lib.cdx_hjgrad_workspace_floats(ctypes.byref(self._struct), b)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(int(need), dtype=torch.float32, device=self.dev)
+        logp = torch.empty((b, self._struct.out_dim), dtype=torch.float32, device=self.dev)
+        grad = torch.empty_like(x)
+        _check(lib.cdx_hjgrad_run(ctypes.byref(self._struct), x.data_ptr(), emb0.data_ptr(), b, logp.data_ptr(), grad.data_ptr(),
+                                  self._ws.data_ptr(), self._ws.numel(), _stream_ptr(self.dev)), "cdx_hjgrad_run")
+        return logp, grad
 
     @staticmethod
     def _blocks(net):
@@ -102,6 +173,8 @@ class HalfJannerGrad:
             emb0 = _f32c(net.map_noise(noise), dev)
             if condition is not None:
                 emb0 = emb0 + condition
+            if ONE_CALL and H == net.horizon:
+                return self._one_call(_f32c(x, dev), _f32c(emb0, dev))
             emb = B.linear(B.linear(emb0, self.map0_w, self.map0_b, act="mish"), self.map2_w, self.map2_b)     # (b, md)
             memb = B.activation(emb, "mish")
             cur = _f32c(x, dev).reshape(b * H, D)

@@ -313,6 +313,35 @@ typedef struct cdx_chiunet_weights {
 long long cdx_chiunet_workspace_floats(const cdx_chiunet_weights* w, const cdx_sampling* s);
 int cdx_chiunet_run(const cdx_chiunet_weights* w, const cdx_sampling* s, void* hip_stream);
 
+/* Classifier guidance: (logp, d logp.sum() / d x) of HalfJannerUNet1d by explicit forward + backward launches -- what
+ * BaseClassifier.gradients asks torch.autograd for once per denoising step (reference classifier/base.py:74-79,
+ * nn_classifier/half_jannerunet.py:102-125, diffusionsde.py:153-173).  Weights are packed by the host (engine/classifier_grad.py):
+ * forward convs (c_out, k, c_in); backward-data convs tap-flipped and transposed (c_in, k, c_out); the stride-2 downsample's
+ * backward as an even (1 tap) and an odd (2 taps) kernel.  `emb0` = map_noise(t) [+ condition], one row per sample. */
+typedef struct cdx_hj_block {
+    int32_t cin, cout, k, groups;
+    const float *w1, *b1, *w1_bwd, *g1, *be1;
+    const float *w2, *b2, *w2_bwd, *g2, *be2;
+    const float *emb_w, *emb_b;              /* emb_mlp.1: (cout, model_dim) */
+    const float *wr, *br, *wr_bwd;           /* residual 1x1 conv (cout, 1, cin) / (cin, 1, cout), or NULL: identity */
+} cdx_hj_block;
+typedef struct cdx_hj_down {
+    int32_t c;
+    const float *w, *b, *bwd_even, *bwd_odd; /* (c, 3, c), (c), (c, 1, c), (c, 2, c) */
+} cdx_hj_down;
+typedef struct cdx_hjgrad_weights {
+    int32_t horizon, in_dim, model_dim, emb_dim, out_dim, fc_hidden, c_last, l_last, n_stages;
+    const int32_t* stage_kind;               /* HOST [n_stages]: 0 = next residual block, 1 = next downsample */
+    const cdx_hj_block* blocks;              /* HOST */
+    const cdx_hj_down* downs;                /* HOST */
+    const float *map0_w, *map0_b, *map2_w, *map2_b;
+    const float *fc1_wx, *fc1_wx_t, *fc1_we, *fc1_b;   /* final_block.0 split: flattened part in [l][c] order (+ transpose), emb part */
+    const float *fc2_w, *fc2_b, *fc2_w_t;              /* final_block.2 (+ transpose) */
+} cdx_hjgrad_weights;
+long long cdx_hjgrad_workspace_floats(const cdx_hjgrad_weights* w, int32_t batch);
+int cdx_hjgrad_run(const cdx_hjgrad_weights* w, const float* x, const float* emb0, int32_t batch, float* logp, float* grad,
+                   float* workspace, long long workspace_floats, void* hip_stream);
+
 /* Pre-norm residual MLP = IDQLMlp / NewIDQLMlp (reference nn_diffusion/idqlmlp.py:9-18 ResidualBlock, :21-65, :68-112):
  * features [x | time_mlp(map_noise(t)) | obs] -> affine_in -> n x (h + fc2(mish(fc1(LN(h))))) -> [mish] -> affine_out.
  * `temb` of the request is the table AFTER time_mlp (batch-invariant during sampling). */

@@ -134,6 +134,10 @@ def test_native_classifier_gradients_match_autograd(name, amd_lib, monkeypatch):
     t = torch.randint(0, 20, (b,), generator=g).to(DEV)
     clf = agent.classifier
     logp_n, grad_n = clf.gradients(x.clone(), t, None)
+    monkeypatch.setattr(classifier_grad, "ONE_CALL", False)                          # same schedule issued op by op from Python
+    logp_p, grad_p = clf.gradients(x.clone(), t, None)
+    np.testing.assert_allclose(logp_n.cpu().numpy(), logp_p.cpu().numpy(), rtol=1e-5, atol=1e-5)     # (C path may split K)
+    np.testing.assert_allclose(grad_n.cpu().numpy(), grad_p.cpu().numpy(), rtol=1e-5, atol=1e-5 * max(float(grad_p.abs().max()), 1.0))
     monkeypatch.setattr(classifier_grad, "gradients", lambda *a, **k: None)          # force the autograd path
     logp_a, grad_a = clf.gradients(x.clone(), t, None)
     torch.cuda.synchronize()

@@ -102,6 +102,29 @@ def cfg5(B=131072, steps=128):
     return f"config 5 shard: IDQLMlp 1024x6, D=15, {steps}-step EDM Euler, B={B}", call, B, 2.0 * macs * steps * B
 
 
+def cfg2g(B=256):
+    """Config 2 with classifier guidance at every step (w_cg > 0, what the shipped Diffuser configurations run): JannerUNet1d
+    denoiser (fused forward per step) + CumRewClassifier(HalfJannerUNet1d) gradient per step, 20-step DDPM."""
+    from cleandiffuser_amd.classifier import CumRewClassifier
+    from cleandiffuser_amd.nn_classifier import HalfJannerUNet1d
+    from cleandiffuser_amd.nn_diffusion import JannerUNet1d
+    H, D = 32, 23
+    net = load_synth(JannerUNet1d(D, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2, 2], kernel_size=5))
+    clf_net = load_synth(HalfJannerUNet1d(H, D, out_dim=1, model_dim=32, emb_dim=32, dim_mult=(1, 2, 2, 2), kernel_size=3), 1)
+    fix = torch.zeros(H, D)
+    fix[0, :17] = 1.0
+    agent = DiscreteDiffusionSDE(net, None, fix_mask=fix, classifier=CumRewClassifier(clf_net, device=DEV), diffusion_steps=20,
+                                 predict_noise=False, device=DEV)
+    agent.eval()
+    prior = torch.zeros(B, H, D, device=DEV)
+    prior[:, 0, :17] = torch.randn(B, 17, device=DEV)
+    cg = torch.ones(B, 1, device=DEV)
+    call = lambda: agent.sample(prior, solver="ddpm", n_samples=B, sample_steps=20, temperature=0.5, w_cg=0.1,  # noqa: E731
+                                condition_cg=cg)[0]
+    flops = 2.0 * 19.67e6 * 20 * B              # denoiser only (the classifier's work is extra)
+    return f"config 2 + classifier guidance (w_cg=0.1, HalfJannerUNet1d), 20-step DDPM, B={B}", call, B, flops
+
+
 def run_big(name, fn, reps=2, **kw):
     label, call, B, flops = fn(**kw)
     dt = _time_calls(call, reps)
@@ -138,9 +161,9 @@ def run(name, fn, reps=3, **kw):
 
 if __name__ == "__main__":
     for name in (sys.argv[1:] or ["cfg1", "cfg3"]):
-        if name.startswith("cfg4") or name.startswith("cfg5"):       # e.g. cfg4, cfg4:4096, cfg5:16384
+        if name.startswith("cfg4") or name.startswith("cfg5") or name.startswith("cfg2g"):   # e.g. cfg4, cfg4:4096, cfg2g:3200
             base, _, b = name.partition(":")
-            run_big(name, {"cfg4": cfg4, "cfg5": cfg5}[base], **({"B": int(b)} if b else {}))
+            run_big(name, {"cfg4": cfg4, "cfg5": cfg5, "cfg2g": cfg2g}[base], **({"B": int(b)} if b else {}))
         else:
             base, _, b = name.partition(":")
             run(name, {"cfg1": cfg1, "cfg3": cfg3}[base], **({"B": int(b)} if b else {}))
