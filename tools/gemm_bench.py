@@ -9,10 +9,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cleandiffuser_amd.engine import blocks  # noqa: E402
 
 SHAPES = [  # (M, N, K, act, gate/residual)
-    ("dit qkv", 19584, 960, 320, "none", False),
-    ("dit out_proj", 19584, 320, 320, "none", True),
-    ("dit fc1", 19584, 1280, 320, "gelu_tanh", False),
-    ("dit fc2", 19584, 320, 1280, "none", True),
+    ("dit qkv", 65536, 960, 320, "none", False),
+    ("dit out_proj", 65536, 320, 320, "none", True),
+    ("dit fc1", 65536, 1280, 320, "gelu_tanh", False),
+    ("dit fc2", 65536, 320, 1280, "none", True),
     ("dit adaLN", 306, 1920, 320, "none", False),
     ("dit final", 19584, 29, 320, "none", False),
     ("dit x_proj", 9792, 320, 29, "none", False),
