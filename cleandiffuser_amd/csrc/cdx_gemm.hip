@@ -100,43 +100,36 @@ __device__ __forceinline__ void gm_divmod(int m, int d, float inv, int& q, int& 
 template <int ACT>
 __device__ __forceinline__ float gm_act_t(float x) { return gm_act(x, ACT); }
 
-// Epilogue of one wave's 64 x 64 sub-tile.  D fragment of 32x32x2: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
-template <int ACT>
-__device__ __forceinline__ void gm_epilogue(const cdx_gemm_args& g, const f32x16 (&acc)[2][2], int row0, int col0, int lr, int lk) {
+// Epilogue of one wave's (32 WT) x (32 WT) sub-tile.  D fragment of 32x32x2: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+template <int ACT, int WT>
+__device__ __forceinline__ void gm_epilogue(const cdx_gemm_args& g, const f32x16 (&acc)[WT][WT], int row0, int col0, int lr, int lk) {
     const float inv_gate = g.gate ? 1.0f / (float)g.rows_per_gate : 0.f;
     const float inv_tab = g.table ? 1.0f / (float)g.table_rows : 0.f;
-    const int n0 = col0 + lr, n1 = n0 + 32;
-    const bool ok0 = n0 < g.N, ok1 = n1 < g.N;
-    const float bias0 = (g.bias && ok0) ? g.bias[n0] : 0.f, bias1 = (g.bias && ok1) ? g.bias[n1] : 0.f;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int ni = 0; ni < WT; ++ni) {
+        const int n = col0 + ni * 32 + lr;
+        if (n >= g.N) continue;
+        const float bias = g.bias ? g.bias[n] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = row0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            if (m >= g.M) continue;
-            float v0 = gm_act_t<ACT>(acc[mi][0][r] + bias0), v1 = gm_act_t<ACT>(acc[mi][1][r] + bias1);
-            if (g.gate) {
-                int q, rem;
-                gm_divmod(m, g.rows_per_gate, inv_gate, q, rem);
-                const float* gp = g.gate + (size_t)q * g.ldg;
-                if (ok0) v0 *= gp[n0];
-                if (ok1) v1 *= gp[n1];
+        for (int mi = 0; mi < WT; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = row0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (m >= g.M) continue;
+                float v = gm_act_t<ACT>(acc[mi][ni][r] + bias);
+                if (g.gate) {
+                    int q, rem;
+                    gm_divmod(m, g.rows_per_gate, inv_gate, q, rem);
+                    v *= g.gate[(size_t)q * g.ldg + n];
+                }
+                if (g.residual) v += g.residual[(size_t)m * g.ldr + n];
+                if (g.table) {
+                    int q, rem;
+                    gm_divmod(m, g.table_rows, inv_tab, q, rem);
+                    v += g.table[(size_t)rem * g.N + n];
+                }
+                g.C[(size_t)m * g.ldc + n] = v;
             }
-            if (g.residual) {
-                const float* rp = g.residual + (size_t)m * g.ldr;
-                if (ok0) v0 += rp[n0];
-                if (ok1) v1 += rp[n1];
-            }
-            if (g.table) {
-                int q, rem;
-                gm_divmod(m, g.table_rows, inv_tab, q, rem);
-                const float* tp = g.table + (size_t)rem * g.N;
-                if (ok0) v0 += tp[n0];
-                if (ok1) v1 += tp[n1];
-            }
-            float* cp = g.C + (size_t)m * g.ldc;
-            if (ok0) cp[n0] = v0;
-            if (ok1) cp[n1] = v1;
         }
     }
 }
@@ -145,22 +138,22 @@ __device__ __forceinline__ void gm_epilogue(const cdx_gemm_args& g, const f32x16
 // patch so that a lane ends up with 4 consecutive columns -> gate / residual / table are read and C is written with 16-byte
 // accesses, loads are unconditional (clamped addresses) and issued together, only the store is predicated.
 #define GM_EP_LD 36
-template <int ACT>
-__device__ __forceinline__ void gm_epilogue_fast(const cdx_gemm_args& g, const f32x16 (&acc)[2][2], float* __restrict__ patch,
+template <int ACT, int WT>
+__device__ __forceinline__ void gm_epilogue_fast(const cdx_gemm_args& g, const f32x16 (&acc)[WT][WT], float* __restrict__ patch,
                                                  int row0, int col0, int lane) {
     const int lr = lane & 31, lk = lane >> 5;
     const int prow = lane >> 3, pc4 = (lane & 7) * 4;
     const float inv_gate = g.gate ? 1.0f / (float)g.rows_per_gate : 0.f;
     const float inv_tab = g.table ? 1.0f / (float)g.table_rows : 0.f;
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
+    for (int ni = 0; ni < WT; ++ni) {
         const int nb = col0 + ni * 32;
         const float bias = (g.bias && nb + lr < g.N) ? g.bias[nb + lr] : 0.f;
         const int n = nb + pc4;
         const bool n_ok = n < g.N;
         const int nc = n_ok ? n : 0;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < WT; ++mi) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 patch[((r & 3) + 8 * (r >> 2) + 4 * lk) * GM_EP_LD + lr] = gm_act_t<ACT>(acc[mi][ni][r] + bias);
@@ -200,11 +193,11 @@ __device__ __forceinline__ void gm_epilogue_fast(const cdx_gemm_args& g, const f
     }
 }
 
-template <int ACT>
-__device__ __forceinline__ void gm_epilogue_any(const cdx_gemm_args& g, const f32x16 (&acc)[2][2], float* patch, int row0, int col0,
+template <int ACT, int WT>
+__device__ __forceinline__ void gm_epilogue_any(const cdx_gemm_args& g, const f32x16 (&acc)[WT][WT], float* patch, int row0, int col0,
                                                 int lane, bool fast) {
-    if (fast) gm_epilogue_fast<ACT>(g, acc, patch, row0, col0, lane);
-    else gm_epilogue<ACT>(g, acc, row0, col0, lane & 31, lane >> 5);
+    if (fast) gm_epilogue_fast<ACT, WT>(g, acc, patch, row0, col0, lane);
+    else gm_epilogue<ACT, WT>(g, acc, row0, col0, lane & 31, lane >> 5);
 }
 
 // Optional timeline trace (tools/gemm_trace.py): [blockIdx][4] x u64 = {s_memtime at start, first tile landed, K loop done,
@@ -214,17 +207,23 @@ __device__ __forceinline__ void gm_stamp(int slot) {
     if (gm_trace != nullptr && threadIdx.x == 0) gm_trace[(size_t)blockIdx.x * 4 + slot] = __builtin_amdgcn_s_memtime();
 }
 
-// FAST: K % 16 == 0, 16-byte aligned rows -> unguarded global_load_dwordx4 (rows beyond the edge are clamped: they only
-// feed outputs that are never stored).  !FAST: fully guarded scalar loads (K = 29 input projections and the like).
-template <bool FAST>
-__global__ __launch_bounds__(GM_THREADS, 3) void cdx_gemm_kernel(const cdx_gemm_args g, const int stagger, const int fast_ep,
-                                                                const int k_split, const int xcd_order) {
-    // one LDS arena: A/B staging tiles during the K loop, then 4 wave-private 32 x 36 transposition patches
-    __shared__ __attribute__((aligned(16))) float smem[4 * GM_BK * GM_LD];   // [stage][A | B][k][row]; 33 KiB >= 4 * 32 * GM_EP_LD
-    float (*As)[GM_LD] = reinterpret_cast<float (*)[GM_LD]>(smem);
+// FAST: K a multiple of the K tile, 16-byte aligned rows -> unguarded global_load_dwordx4 (rows beyond the edge are clamped: they
+// only feed outputs that are never stored).  !FAST: fully guarded scalar loads (K = 29 input projections and the like).
+// WT = MFMA tiles per wave per dimension: 2 -> 128 x 128 x 16 workgroup tile (throughput shape), 1 -> 64 x 64 x 32 (few rows:
+// four times the workgroups, a quarter of the MFMA time per barrier -- the launches of classifier guidance and small batches).
+template <bool FAST, int WT, bool CONV>
+__global__ __launch_bounds__(GM_THREADS, (WT == 2 ? 3 : 4)) void cdx_gemm_kernel(const cdx_gemm_args g, const int stagger,
+                                                                                const int fast_ep, const int k_split,
+                                                                                const int xcd_order) {
+    constexpr int BMN = 64 * WT;                  // rows of A == rows of W per tile
+    constexpr int KQ = GM_THREADS / BMN;           // k quads staged per row by different threads
+    constexpr int BK = 8 * KQ;                     // each thread stages two float4 per operand: k = kq*4 and BK/2 + kq*4
+    constexpr int LD = BMN + 4;
+    // one LDS arena: two stages of A/B staging tiles [k][row] during the K loop, then 4 wave-private 32 x 36 transposition patches
+    __shared__ __attribute__((aligned(16))) float smem[(4 * BK * LD > 4 * 32 * GM_EP_LD) ? 4 * BK * LD : 4 * 32 * GM_EP_LD];
+    float (*As)[LD] = reinterpret_cast<float (*)[LD]>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // column-major walk over tiles: consecutive workgroups share the W panel (small N) and stream A
-    const int tiles_m = (g.M + GM_BM - 1) / GM_BM, tiles_n = (g.N + GM_BN - 1) / GM_BN;
+    const int tiles_m = (g.M + BMN - 1) / BMN, tiles_n = (g.N + BMN - 1) / BMN;
     const int n_tiles = tiles_m * tiles_n;
     const int lin = blockIdx.x % n_tiles, slice = blockIdx.x / n_tiles;     // split-K: slice of the K range
     // Tiles are walked n-fastest: concurrently resident workgroups share a few A row blocks across all their N tiles (the whole W
@@ -235,23 +234,20 @@ __global__ __launch_bounds__(GM_THREADS, 3) void cdx_gemm_kernel(const cdx_gemm_
         const int xcd = lin & 7, t = lin >> 3, q8 = n_tiles >> 3, r8 = n_tiles & 7;
         tile = xcd * q8 + min(xcd, r8) + t;
     }
-    const int bm = (tile / tiles_n) * GM_BM, bn = (tile % tiles_n) * GM_BN;
-    const int lrow = tid & 127, kq = tid >> 7;          // this thread stages row `lrow`, k quads kq and kq + 2
+    const int bm = (tile / tiles_n) * BMN, bn = (tile % tiles_n) * BMN;
+    const int lrow = tid % BMN, kq = tid / BMN;         // this thread stages row `lrow`, k quads kq and kq + KQ
 
-    // First-wave stagger: the 3 workgroups that share a CU (dispatch order: b, b + 256, b + 512) would otherwise run their
-    // K loops and their store-heavy epilogues in lockstep, leaving the MFMA pipe idle during every epilogue.  Delaying the
-    // 2nd/3rd by 1/3, 2/3 of a tile time once shifts their phases for the whole launch (later workgroups inherit the slot).
-    if (stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 768) {
+    if (stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 768) {     // measured no-op (kept as a tuning hook)
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
         const unsigned long long wait = (unsigned long long)stagger * (blockIdx.x >> 8);
         while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
     }
     gm_stamp(0);
-    f32x16 acc[2][2];
+    f32x16 acc[WT][WT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -259,8 +255,8 @@ __global__ __launch_bounds__(GM_THREADS, 3) void cdx_gemm_kernel(const cdx_gemm_
     const float* ap = g.A + (size_t)arow * g.lda + kq * 4;
     const float* wp = g.W + (size_t)wrow * g.ldw + kq * 4;
     float4 ra0, ra1, rb0, rb1;
-    // implicit-GEMM conv (FAST: conv_cin % 16 == 0, so a 16-wide K tile never straddles two taps)
-    const bool conv = g.conv_taps > 0;
+    // implicit-GEMM conv (FAST: conv_cin % 4 == 0, so an aligned float4 never straddles two taps)
+    constexpr bool conv = CONV;                      // compile-time: the plain-GEMM instantiations carry no conv code at all
     int conv_in0 = 0;
     size_t conv_base = 0;
     if (conv) {
@@ -269,85 +265,96 @@ __global__ __launch_bounds__(GM_THREADS, 3) void cdx_gemm_kernel(const cdx_gemm_
         conv_base = (size_t)cb * g.conv_lin;
     }
     const float conv_inv_cin = conv ? 1.0f / (float)g.conv_cin : 0.f;
-    auto fetch = [&](int kt) {                           // global -> registers: k columns [kt, kt + 16) of this thread's row
+    // The validity of a conv tap is applied when the registers are parked in LDS, NOT at load time: a select right behind the load
+    // makes hipcc wait for it (s_waitcnt vmcnt(0) in the middle of the MFMA stream: -5..-17 % measured on the large GEMMs).
+    bool cok0 = true, cok1 = true;
+    auto conv_addr = [&](int k, bool& ok) -> const float* {   // 4 consecutive channels of one tap (clamped inside the tensor)
+        const int tap = (int)(((float)k + 0.5f) * conv_inv_cin), c0 = k - tap * g.conv_cin;
+        const int pos = conv_in0 + tap;
+        ok = pos >= 0 && pos < g.conv_lin;
+        return g.A + (conv_base + (ok ? pos : 0)) * g.lda + c0;
+    };
+    auto fetch = [&](int kt) {                           // global -> registers: k columns [kt, kt + BK) of this thread's row
         if (FAST) {
+            const float *p0 = ap + kt, *p1 = ap + kt + BK / 2;
             if (conv) {
-                const int tap = (int)(((float)kt + 0.5f) * conv_inv_cin), c0 = kt - tap * g.conv_cin;
-                const int pos = conv_in0 + tap;
-                const bool ok = pos >= 0 && pos < g.conv_lin;
-                const float* p = g.A + (conv_base + (ok ? pos : 0)) * g.lda + c0 + kq * 4;
-                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                const float4 v0 = *reinterpret_cast<const float4*>(p), v1 = *reinterpret_cast<const float4*>(p + 8);
-                ra0 = ok ? v0 : z;
-                ra1 = ok ? v1 : z;
-            } else {
-                ra0 = *reinterpret_cast<const float4*>(ap + kt);
-                ra1 = *reinterpret_cast<const float4*>(ap + kt + 8);
+                p0 = conv_addr(kt + kq * 4, cok0);
+                p1 = conv_addr(kt + BK / 2 + kq * 4, cok1);
             }
+            ra0 = *reinterpret_cast<const float4*>(p0);
+            ra1 = *reinterpret_cast<const float4*>(p1);
             rb0 = *reinterpret_cast<const float4*>(wp + kt);
-            rb1 = *reinterpret_cast<const float4*>(wp + kt + 8);
+            rb1 = *reinterpret_cast<const float4*>(wp + kt + BK / 2);
         } else {
             if (conv) {
                 ra0 = gm_conv_load4(g, arow, kt + kq * 4);
-                ra1 = gm_conv_load4(g, arow, kt + 8 + kq * 4);
+                ra1 = gm_conv_load4(g, arow, kt + BK / 2 + kq * 4);
             } else {
-            ra0 = gm_load4_guarded(g.A, arow, g.M, kt + kq * 4, g.K, g.lda);
-            ra1 = gm_load4_guarded(g.A, arow, g.M, kt + 8 + kq * 4, g.K, g.lda);
+                ra0 = gm_load4_guarded(g.A, arow, g.M, kt + kq * 4, g.K, g.lda);
+                ra1 = gm_load4_guarded(g.A, arow, g.M, kt + BK / 2 + kq * 4, g.K, g.lda);
             }
             rb0 = gm_load4_guarded(g.W, wrow, g.N, kt + kq * 4, g.K, g.ldw);
-            rb1 = gm_load4_guarded(g.W, wrow, g.N, kt + 8 + kq * 4, g.K, g.ldw);
+            rb1 = gm_load4_guarded(g.W, wrow, g.N, kt + BK / 2 + kq * 4, g.K, g.ldw);
         }
     };
     auto stage = [&](int buf) {                          // registers -> LDS stage `buf`, transposed to [k][row]
-        float (*Ad)[GM_LD] = As + buf * (2 * GM_BK);
-        float (*Bd)[GM_LD] = Ad + GM_BK;
-        const int ka = kq * 4, kb = 8 + kq * 4;
+        float (*Ad)[LD] = As + buf * (2 * BK);
+        float (*Bd)[LD] = Ad + BK;
+        const int ka = kq * 4, kb = BK / 2 + kq * 4;
+        if (FAST && conv) {
+            if (!cok0) ra0 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!cok1) ra1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         Ad[ka + 0][lrow] = ra0.x; Ad[ka + 1][lrow] = ra0.y; Ad[ka + 2][lrow] = ra0.z; Ad[ka + 3][lrow] = ra0.w;
         Ad[kb + 0][lrow] = ra1.x; Ad[kb + 1][lrow] = ra1.y; Ad[kb + 2][lrow] = ra1.z; Ad[kb + 3][lrow] = ra1.w;
         Bd[ka + 0][lrow] = rb0.x; Bd[ka + 1][lrow] = rb0.y; Bd[ka + 2][lrow] = rb0.z; Bd[ka + 3][lrow] = rb0.w;
         Bd[kb + 0][lrow] = rb1.x; Bd[kb + 1][lrow] = rb1.y; Bd[kb + 2][lrow] = rb1.z; Bd[kb + 3][lrow] = rb1.w;
     };
 
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int wm = (wave >> 1) * (32 * WT), wn = (wave & 1) * (32 * WT);
     const int lr = lane & 31, lk = lane >> 5;
-    const int nk_all = (g.K + GM_BK - 1) / GM_BK;
+    const int nk_all = (g.K + BK - 1) / BK;
     const int per = (nk_all + k_split - 1) / k_split;    // K tiles per slice
-    const int kt0 = slice * per * GM_BK;                  // first k of this slice
+    const int kt0 = slice * per * BK;                     // first k of this slice
     const int nk = min(per, nk_all - slice * per);
 
-    // Two LDS stages, ONE barrier per 16-wide K tile: while the MFMAs of tile t run out of stage t & 1, the registers
+    // Two LDS stages, ONE barrier per K tile: while the MFMAs of tile t run out of stage t & 1, the registers
     // holding tile t + 1 (fetched a whole tile earlier) are written to the other stage and tile t + 2 is requested.
     fetch(kt0);
     stage(0);
-    if (nk > 1) fetch(kt0 + GM_BK);
+    if (nk > 1) fetch(kt0 + BK);
     __syncthreads();
     gm_stamp(1);
     for (int t = 0; t < nk; ++t) {
-        const float (*Ac)[GM_LD] = As + (t & 1) * (2 * GM_BK);
-        const float (*Bc)[GM_LD] = Ac + GM_BK;
+        const float (*Ac)[LD] = As + (t & 1) * (2 * BK);
+        const float (*Bc)[LD] = Ac + BK;
         // operands of the next k pair are read from LDS before the MFMAs of the current one are issued
-        float a0 = Ac[lk][wm + lr], a1 = Ac[lk][wm + 32 + lr], b0 = Bc[lk][wn + lr], b1 = Bc[lk][wn + 32 + lr];
+        float av[WT], bv[WT];
 #pragma unroll
-        for (int kk = 0; kk < GM_BK; kk += 2) {
-            float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
-            if (kk + 2 < GM_BK) {
-                na0 = Ac[kk + 2 + lk][wm + lr]; na1 = Ac[kk + 2 + lk][wm + 32 + lr];
-                nb0 = Bc[kk + 2 + lk][wn + lr]; nb1 = Bc[kk + 2 + lk][wn + 32 + lr];
+        for (int i = 0; i < WT; ++i) { av[i] = Ac[lk][wm + 32 * i + lr]; bv[i] = Bc[lk][wn + 32 * i + lr]; }
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float na[WT], nb[WT];
+#pragma unroll
+            for (int i = 0; i < WT; ++i) {
+                na[i] = 0.f; nb[i] = 0.f;
+                if (kk + 2 < BK) { na[i] = Ac[kk + 2 + lk][wm + 32 * i + lr]; nb[i] = Bc[kk + 2 + lk][wn + 32 * i + lr]; }
             }
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-            if (kk == 4 && t + 1 < nk) {                 // mid-tile: park tile t + 1 in the other stage, request tile t + 2
+#pragma unroll
+            for (int i = 0; i < WT; ++i)
+#pragma unroll
+                for (int j = 0; j < WT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            if (kk == BK / 2 - 4 && t + 1 < nk) {        // mid-tile: park tile t + 1 in the other stage, request tile t + 2
                 stage((t + 1) & 1);
-                if (t + 2 < nk) fetch(kt0 + (t + 2) * GM_BK);
+                if (t + 2 < nk) fetch(kt0 + (t + 2) * BK);
             }
-            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+#pragma unroll
+            for (int i = 0; i < WT; ++i) { av[i] = na[i]; bv[i] = nb[i]; }
         }
         __syncthreads();                                 // stage (t+1)&1 complete, stage t&1 free for tile t + 2
     }
 
-    asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[1][1][15]));
+    asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[WT - 1][WT - 1][15]));
     gm_stamp(2);
     // (the loop's last barrier already separates the final LDS reads from the patches written below)
     // fused epilogue, one specialisation per activation (the branch is uniform; only the taken copy touches the I-cache)
@@ -358,18 +365,18 @@ __global__ __launch_bounds__(GM_THREADS, 3) void cdx_gemm_kernel(const cdx_gemm_
         cdx_gemm_args gp = g;
         gp.C = g.partial + (size_t)slice * g.M * g.N; gp.ldc = g.N;
         gp.bias = nullptr; gp.gate = nullptr; gp.residual = nullptr; gp.table = nullptr;
-        gm_epilogue_any<CDX_ACT_NONE>(gp, acc, patch, row0, col0, lane, (g.N % 4 == 0));
+        gm_epilogue_any<CDX_ACT_NONE, WT>(gp, acc, patch, row0, col0, lane, (g.N % 4 == 0));
         gm_stamp(3);
         return;
     }
     switch (g.act) {
-        case CDX_ACT_MISH: gm_epilogue_any<CDX_ACT_MISH>(g, acc, patch, row0, col0, lane, fe); break;
-        case CDX_ACT_GELU_ERF: gm_epilogue_any<CDX_ACT_GELU_ERF>(g, acc, patch, row0, col0, lane, fe); break;
-        case CDX_ACT_LEAKY: gm_epilogue_any<CDX_ACT_LEAKY>(g, acc, patch, row0, col0, lane, fe); break;
-        case CDX_ACT_SILU: gm_epilogue_any<CDX_ACT_SILU>(g, acc, patch, row0, col0, lane, fe); break;
-        case CDX_ACT_RELU: gm_epilogue_any<CDX_ACT_RELU>(g, acc, patch, row0, col0, lane, fe); break;
-        case CDX_ACT_GELU_TANH: gm_epilogue_any<CDX_ACT_GELU_TANH>(g, acc, patch, row0, col0, lane, fe); break;
-        default: gm_epilogue_any<CDX_ACT_NONE>(g, acc, patch, row0, col0, lane, fe); break;
+        case CDX_ACT_MISH: gm_epilogue_any<CDX_ACT_MISH, WT>(g, acc, patch, row0, col0, lane, fe); break;
+        case CDX_ACT_GELU_ERF: gm_epilogue_any<CDX_ACT_GELU_ERF, WT>(g, acc, patch, row0, col0, lane, fe); break;
+        case CDX_ACT_LEAKY: gm_epilogue_any<CDX_ACT_LEAKY, WT>(g, acc, patch, row0, col0, lane, fe); break;
+        case CDX_ACT_SILU: gm_epilogue_any<CDX_ACT_SILU, WT>(g, acc, patch, row0, col0, lane, fe); break;
+        case CDX_ACT_RELU: gm_epilogue_any<CDX_ACT_RELU, WT>(g, acc, patch, row0, col0, lane, fe); break;
+        case CDX_ACT_GELU_TANH: gm_epilogue_any<CDX_ACT_GELU_TANH, WT>(g, acc, patch, row0, col0, lane, fe); break;
+        default: gm_epilogue_any<CDX_ACT_NONE, WT>(g, acc, patch, row0, col0, lane, fe); break;
     }
     gm_stamp(3);
 }
@@ -831,13 +838,20 @@ int cdx_gemm_f32(const cdx_gemm_args* g, void* hip_stream) {
     if ((g->gate && g->rows_per_gate <= 0) || (g->table && g->table_rows <= 0)) {
         cdx_set_err("cdx_gemm_f32: gate/table need a positive row period"); return CDX_EINVAL;
     }
-    const int tiles = ((g->M + GM_BM - 1) / GM_BM) * ((g->N + GM_BN - 1) / GM_BN);
+    // tile shape: 128 x 128 (K tile 16) unless that leaves most of the chip idle -- then 64 x 64 (K tile 32)
+    const int tiles_big = ((g->M + 127) / 128) * ((g->N + 127) / 128);
+    static const char* env_t = getenv("CDX_GEMM_SMALL_TILE_BELOW");          // tuning hook
+    const int small_below = env_t ? atoi(env_t) : 192;
+    // the 64 x 64 variant stages 32-wide K tiles: with K % 32 != 0 but K % 16 == 0 the 128 x 128 kernel keeps its unguarded loads
+    const bool small = tiles_big < small_below && (g->K % 32 == 0 || g->K % 16 != 0);
+    const int bmn = small ? 64 : 128, bk = small ? 32 : 16;
+    const int tiles = ((g->M + bmn - 1) / bmn) * ((g->N + bmn - 1) / bmn);
     if (g->conv_taps < 0 || (g->conv_taps > 0 && (g->conv_cin <= 0 || g->conv_lin <= 0 || g->conv_lout <= 0 || g->conv_stride <= 0 ||
                                                    g->K != g->conv_taps * g->conv_cin || g->M % g->conv_lout != 0))) {
         cdx_set_err("cdx_gemm_f32: inconsistent implicit-conv description"); return CDX_EINVAL;
     }
-    const bool vec = (g->K % GM_BK == 0) && (g->lda % 4 == 0) && (g->ldw % 4 == 0) &&
-                     (((uintptr_t)g->A | (uintptr_t)g->W) % 16 == 0) && (g->conv_taps == 0 || g->conv_cin % GM_BK == 0);
+    const bool vec = (g->K % bk == 0) && (g->lda % 4 == 0) && (g->ldw % 4 == 0) &&
+                     (((uintptr_t)g->A | (uintptr_t)g->W) % 16 == 0) && (g->conv_taps == 0 || g->conv_cin % 4 == 0);
     hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
     static const char* env = getenv("CDX_GEMM_STAGGER");          // tuning hook: cycles per phase class, 0 = off
     int stagger = 0;
@@ -845,21 +859,31 @@ int cdx_gemm_f32(const cdx_gemm_args* g, void* hip_stream) {
     const uintptr_t ep_ptrs = (uintptr_t)g->C | (uintptr_t)g->gate | (uintptr_t)g->residual | (uintptr_t)g->table;
     const int fast_ep = (g->N % 4 == 0) && (g->ldc % 4 == 0) && (!g->gate || g->ldg % 4 == 0) &&
                         (!g->residual || g->ldr % 4 == 0) && (ep_ptrs % 16 == 0);
-    // split-K when the tile count cannot fill the chip (768 workgroup slots) and K is long enough to pay for the second pass
+    // split-K when the tile count cannot fill the chip and K is long enough to pay for the second pass
     int k_split = 1;
-    if (g->partial != nullptr && g->partial_slices > 1 && tiles < 384) {
-        const int nk_all = (g->K + GM_BK - 1) / GM_BK;
-        k_split = (768 + tiles - 1) / tiles;
+    const int slots = small ? 1024 : 768;
+    if (g->partial != nullptr && g->partial_slices > 1 && tiles < slots / 2) {
+        const int nk_all = (g->K + bk - 1) / bk;
+        k_split = (slots + tiles - 1) / tiles;
         if (k_split > g->partial_slices) k_split = g->partial_slices;
-        if (k_split > nk_all / 16) k_split = nk_all / 16;           // at least 16 K tiles (256 k) per slice
+        if (k_split > nk_all / 8) k_split = nk_all / 8;              // at least 8 K tiles per slice
         if (k_split < 1) k_split = 1;
         const int per = (nk_all + k_split - 1) / k_split;
         k_split = (nk_all + per - 1) / per;                          // no empty slices
     }
-    static const char* env_x = getenv("CDX_GEMM_XCD_ORDER");      // tuning hook: 0 = plain row-major tile order
-    const int xcd_order = env_x ? atoi(env_x) : 0;    // measured: +-2 % either way once tiles are walked n-fastest (kept as a hook)
-    if (vec) hipLaunchKernelGGL(cdx_gemm_kernel<true>, dim3(tiles * k_split), dim3(GM_THREADS), 0, s, *g, stagger, fast_ep, k_split, xcd_order);
-    else hipLaunchKernelGGL(cdx_gemm_kernel<false>, dim3(tiles * k_split), dim3(GM_THREADS), 0, s, *g, stagger, fast_ep, k_split, xcd_order);
+    static const char* env_x = getenv("CDX_GEMM_XCD_ORDER");      // tuning hook: 1 = one contiguous tile range per XCD
+    const int xcd_order = env_x ? atoi(env_x) : 0;    // measured: +-2 % either way once tiles are walked n-fastest
+    const dim3 grid(tiles * k_split), block(GM_THREADS);
+#define GM_LAUNCH(F, W, C) hipLaunchKernelGGL((cdx_gemm_kernel<F, W, C>), grid, block, 0, s, *g, stagger, fast_ep, k_split, xcd_order)
+    const bool cv = g->conv_taps > 0;
+    if (small) {
+        if (vec) { if (cv) GM_LAUNCH(true, 1, true); else GM_LAUNCH(true, 1, false); }
+        else { if (cv) GM_LAUNCH(false, 1, true); else GM_LAUNCH(false, 1, false); }
+    } else {
+        if (vec) { if (cv) GM_LAUNCH(true, 2, true); else GM_LAUNCH(true, 2, false); }
+        else { if (cv) GM_LAUNCH(false, 2, true); else GM_LAUNCH(false, 2, false); }
+    }
+#undef GM_LAUNCH
     if (k_split > 1) {
         const size_t total = (size_t)g->M * g->N;
         const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
