@@ -385,17 +385,32 @@ __global__ __launch_bounds__(GM_THREADS, (WT == 2 ? 3 : 4)) void cdx_gemm_kernel
 // Second pass of a split-K launch: C = epilogue(sum over slices, in slice order, of partial[slice]) -- same epilogue semantics as
 // the GEMM kernel (bias -> act -> gate -> residual -> table), one output element per thread, memory bound.
 // ------------------------------------------------------------------------------------------------
+template <bool VEC4>
 __global__ __launch_bounds__(256) void gm_splitk_reduce_kernel(const cdx_gemm_args g, const int k_split) {
-    const size_t total = (size_t)g.M * g.N;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    constexpr int W = VEC4 ? 4 : 1;                      // VEC4: N, ldc, ldr, ldg multiples of 4 and 16-byte aligned bases
+    const size_t total = (size_t)g.M * g.N, groups = total / W;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < groups; q += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = q * W;
         const int m = (int)(i / g.N), n = (int)(i - (size_t)m * g.N);
-        float v = 0.f;
-        for (int s = 0; s < k_split; ++s) v += g.partial[(size_t)s * total + i];
-        v = gm_act(v + (g.bias ? g.bias[n] : 0.f), g.act);
-        if (g.gate) v *= g.gate[(size_t)(m / g.rows_per_gate) * g.ldg + n];
-        if (g.residual) v += g.residual[(size_t)m * g.ldr + n];
-        if (g.table) v += g.table[(size_t)(m % g.table_rows) * g.N + n];
-        g.C[(size_t)m * g.ldc + n] = v;
+        float v[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) v[j] = 0.f;
+        for (int s = 0; s < k_split; ++s) {
+            const float* p = g.partial + (size_t)s * total + i;
+            if (VEC4) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] += t.x; v[1 % W] += t.y; v[2 % W] += t.z; v[3 % W] += t.w; }
+            else v[0] += p[0];
+        }
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            float x = gm_act(v[j] + (g.bias ? g.bias[n + j] : 0.f), g.act);
+            if (g.gate) x *= g.gate[(size_t)(m / g.rows_per_gate) * g.ldg + n + j];
+            if (g.residual) x += g.residual[(size_t)m * g.ldr + n + j];
+            if (g.table) x += g.table[(size_t)(m % g.table_rows) * g.N + n + j];
+            v[j] = x;
+        }
+        float* c = g.C + (size_t)m * g.ldc + n;
+        if (VEC4) *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1 % W], v[2 % W], v[3 % W]);
+        else c[0] = v[0];
     }
 }
 
@@ -886,8 +901,11 @@ int cdx_gemm_f32(const cdx_gemm_args* g, void* hip_stream) {
 #undef GM_LAUNCH
     if (k_split > 1) {
         const size_t total = (size_t)g->M * g->N;
-        const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-        hipLaunchKernelGGL(gm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, *g, k_split);
+        const bool v4 = fast_ep && ((uintptr_t)g->partial % 16 == 0);
+        const size_t work = v4 ? total / 4 : total;
+        const int blocks = (int)((work + 255) / 256 < 8192 ? (work + 255) / 256 : 8192);
+        if (v4) hipLaunchKernelGGL(gm_splitk_reduce_kernel<true>, dim3(blocks), dim3(256), 0, s, *g, k_split);
+        else hipLaunchKernelGGL(gm_splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, s, *g, k_split);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
