@@ -392,3 +392,76 @@ def test_training_step_on_device_keeps_autograd(name, amd_lib, monkeypatch):
     assert native["n"] == (1 if c["solver"][0] == "ContinuousConsistencyModel" else 0)
     changed = sum(float((p.detach() - b).abs().sum()) for p, b in zip(net.parameters(), before))
     assert changed > 0.0
+
+
+def _full_size(which, B):
+    """The BASELINE config-3/4/5 solvers at their real network sizes (synthetic weights), with explicit inputs."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from cleandiffuser_amd import diffusion as DF, nn_condition as NC, nn_diffusion as ND
+    from cleandiffuser_amd.diffusion.ddpm import DDPM
+    from cleandiffuser_amd.utils import load_synth
+    g = torch.Generator().manual_seed(17)
+
+    def make(dev):
+        if which == "cfg3":
+            net = load_synth(ND.ChiUNet1d(2, 20, 2, model_dim=256, emb_dim=256, dim_mult=[1, 2, 2], obs_as_global_cond=True))
+            one = torch.ones(1, 16, 2, device=dev)
+            return DDPM(net, NC.IdentityCondition(dropout=0.0), diffusion_steps=50, x_max=one, x_min=-one, device=dev)
+        if which == "cfg4":
+            net = load_synth(ND.DiT1d(29, emb_dim=128, d_model=320, n_heads=10, depth=2, timestep_emb_type="fourier"))
+            cond = load_synth(NC.MLPCondition(1, 128, [128], torch.nn.SiLU(), dropout=0.25), 2)
+            fix = torch.zeros(64, 29)
+            fix[0] = 1.0
+            return DF.ContinuousDiffusionSDE(net, cond, fix_mask=fix, predict_noise=True, noise_schedule="linear",
+                                             x_max=3 * torch.ones(1, 64, 29), x_min=-3 * torch.ones(1, 64, 29), device=dev)
+        net = load_synth(ND.IDQLMlp(0, 15, emb_dim=128, hidden_dim=1024, n_blocks=6))
+        return DF.ContinuousEDM(net, None, device=dev)
+
+    def make_eval(dev):
+        a = make(dev)
+        a.eval()
+        return a
+
+    if which == "cfg3":
+        prior, cond = torch.zeros(B, 16, 2), torch.randn(B, 2, 20, generator=g)
+        zs = [torch.randn(B, 16, 2, generator=g) for _ in range(50)]
+        kw = dict(sample_steps=50, w_cfg=1.0)
+    elif which == "cfg4":
+        prior, cond = torch.zeros(B, 64, 29), torch.rand(B, 1, generator=g)
+        prior[:, 0] = torch.randn(B, 29, generator=g)
+        zs = [torch.randn(B, 64, 29, generator=g)]
+        kw = dict(solver="ode_dpmsolver++_2M", sample_steps=10, w_cfg=2.0, temperature=0.5)
+    else:
+        prior, cond = torch.zeros(B, 15), None
+        zs = [torch.randn(B, 15, generator=g)]
+        kw = dict(solver="euler", sample_steps=16)
+    return make_eval, prior, cond, zs, kw
+
+
+@pytest.mark.parametrize("which,B", [("cfg3", 1024), ("cfg4", 512), ("cfg5", 4096)])
+def test_bigbatch_full_size_properties(which, B, amd_lib):
+    """BASELINE configs 3, 4, 5 at their real network and batch sizes: determinism (split-K included), exact fix-mask, a
+    sample's result independent of its batch neighbours / of the executor that serves a small batch (1e-4), and agreement with
+    the CPU executor on two samples."""
+    make, prior, cond, zs, kw = _full_size(which, B)
+    agent = make(DEV)
+
+    def run(a, sl, dev):
+        p = prior[sl].to(dev)
+        c = None if cond is None else cond[sl].to(dev)
+        x, _ = a.sample(p, n_samples=p.shape[0], condition_cfg=c, noise=[z[sl] for z in zs], **kw)
+        return x
+    full = slice(0, B)
+    x1, x2 = run(agent, full, DEV), run(agent, full, DEV)
+    torch.cuda.synchronize()
+    assert torch.isfinite(x1).all() and torch.equal(x1, x2), "not deterministic"
+    if which == "cfg4":
+        assert torch.equal(x1[:, 0].cpu(), prior[:, 0].clip(-3, 3)), "fix-mask must re-impose the prior exactly (then the final clip)"
+    sl = slice(B // 2 + 3, B // 2 + 11)
+    scale = max(float(x1.abs().max()), 1.0)
+    np.testing.assert_allclose(run(agent, sl, DEV).cpu().numpy(), x1[sl].cpu().numpy(), rtol=1e-4, atol=1e-4 * scale)
+    two = slice(B // 2 + 3, B // 2 + 5)
+    x_cpu = run(make("cpu"), two, "cpu")
+    np.testing.assert_allclose(x1[two].cpu().numpy(), x_cpu.numpy(), rtol=1e-4, atol=1e-4 * scale)
