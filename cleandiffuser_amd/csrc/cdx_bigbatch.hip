@@ -72,6 +72,8 @@ struct StepArgs {
     cdx_step st;
     int nb, hd, b0, batch, predict_noise, cfg_mode;
     float cfg_w;
+    const float* grad;    // classifier gradient (nb, hd) or NULL
+    float cg_scale;       // pred += cg_scale * grad before clipping (classifier guidance)
 };
 
 __global__ void solver_step_kernel(const StepArgs a) {
@@ -85,6 +87,7 @@ __global__ void solver_step_kernel(const StepArgs a) {
         const float x = a.x[i];
         float p = a.pred[i];
         if (a.cfg_mode == 2) p = a.cfg_w * p + (1.0f - a.cfg_w) * a.pred[n + i];
+        if (a.grad) p += a.cg_scale * a.grad[i];
         float xn;
         if (st.kind >= 5) {  // EDM: p is the raw network output F
             float d = k0 * x + k1 * p;
@@ -224,6 +227,7 @@ int run_step(hipStream_t stream, const cdx_sampling* s, const cdx_step& st, floa
     a.fix_mask = s->fix_mask; a.noise = s->noise; a.x_min = s->x_min; a.x_max = s->x_max;
     a.st = st; a.nb = nb; a.hd = s->hd; a.b0 = b0; a.batch = s->batch;
     a.predict_noise = s->predict_noise; a.cfg_mode = s->cfg_mode; a.cfg_w = s->cfg_w;
+    a.grad = nullptr; a.cg_scale = 0.f;
     const size_t n = (size_t)nb * s->hd;
     const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipLaunchKernelGGL(solver_step_kernel, dim3(blocks), dim3(256), 0, stream, a);
@@ -783,7 +787,7 @@ struct HjPass {
         return gemm(st, A, lda, W, K, bias, C, N, M, N, K, act, gate, N, 1, residual, N);
     }
 
-    int run(const float* x, const float* emb0, float* logp, float* grad) {
+    int run(const float* x, const float* emb0, int emb0_ld, float* logp, float* grad) {
         const int md = w->model_dim, H = w->horizon, D = w->in_dim;
         {
             long long widest = (long long)H * D;           // floats per sample of the largest conv output
@@ -799,7 +803,7 @@ struct HjPass {
         float* e1 = a.take((long long)b * 4 * md);
         float* emb = a.take((long long)b * md);
         float* memb = a.take((long long)b * md);
-        CDX_TRY(lin(emb0, w->emb_dim, w->map0_w, w->emb_dim, w->map0_b, e1, b, 4 * md, CDX_ACT_MISH, nullptr, nullptr));
+        CDX_TRY(lin(emb0, emb0_ld, w->map0_w, w->emb_dim, w->map0_b, e1, b, 4 * md, CDX_ACT_MISH, nullptr, nullptr));
         CDX_TRY(lin(e1, 4 * md, w->map2_w, 4 * md, w->map2_b, emb, b, md, CDX_ACT_NONE, nullptr, nullptr));
         if (!dry) CDX_TRY(cdx_act_f32(emb, memb, (long long)b * md, CDX_ACT_MISH, st));
         // ---- forward; a1 / a2 of every block are kept for the backward
@@ -967,12 +971,12 @@ int cdx_chiunet_run(const cdx_chiunet_weights* w, const cdx_sampling* s, void* h
 long long cdx_hjgrad_workspace_floats(const cdx_hjgrad_weights* w, int32_t batch) {
     if (!w || !w->stage_kind || !w->blocks || batch < 0) return -1;
     HjPass p{w, nullptr, Arena{nullptr, 0, 0}, true, batch};
-    if (p.run(nullptr, nullptr, nullptr, nullptr) != CDX_OK) return -1;
+    if (p.run(nullptr, nullptr, 0, nullptr, nullptr) != CDX_OK) return -1;
     return p.a.used;
 }
 
-int cdx_hjgrad_run(const cdx_hjgrad_weights* w, const float* x, const float* emb0, int32_t batch, float* logp, float* grad,
-                   float* workspace, long long workspace_floats, void* hip_stream) {
+int cdx_hjgrad_run(const cdx_hjgrad_weights* w, const float* x, const float* emb0, int32_t emb0_ld, int32_t batch, float* logp,
+                   float* grad, float* workspace, long long workspace_floats, void* hip_stream) {
     if (!w || !w->stage_kind || !w->blocks || !w->map0_w || !w->fc1_wx || !w->fc2_w) { cdx_set_err("cdx_hjgrad_run: null pointer in weights"); return CDX_EINVAL; }
     if (batch < 0 || w->horizon <= 0 || w->in_dim <= 0) { cdx_set_err("cdx_hjgrad_run: bad shape"); return CDX_EINVAL; }
     if (batch == 0) return CDX_OK;
@@ -980,8 +984,61 @@ int cdx_hjgrad_run(const cdx_hjgrad_weights* w, const float* x, const float* emb
     const long long need = cdx_hjgrad_workspace_floats(w, batch);
     if (need < 0) return CDX_EINVAL;
     if (!workspace || workspace_floats < need) { cdx_set_err("cdx_hjgrad_run: workspace too small"); return CDX_EINVAL; }
+    if (emb0_ld != 0 && emb0_ld < w->emb_dim) { cdx_set_err("cdx_hjgrad_run: emb0_ld must be 0 (shared row) or >= emb_dim"); return CDX_EINVAL; }
     HjPass p{w, reinterpret_cast<hipStream_t>(hip_stream), Arena{workspace, 0, 0}, false, batch};
-    return p.run(x, emb0, logp, grad);
+    return p.run(x, emb0, emb0_ld, logp, grad);
+}
+
+long long cdx_guided_workspace_floats(const cdx_guided_launch* g) {
+    if (!g || !g->classifier || g->batch < 0 || g->hd <= 0) return -1;
+    const long long clf = cdx_hjgrad_workspace_floats(g->classifier, g->batch);
+    if (clf < 0) return -1;
+    const long long state = ((long long)g->batch * g->hd + 63) & ~63LL;
+    return clf + 4 * state + (((long long)g->batch * g->classifier->out_dim + 63) & ~63LL);     // x, pred, prev, grad, logp
+}
+
+int cdx_guided_run(const cdx_guided_launch* g, void* hip_stream) {
+    if (!g || !g->denoiser || !g->classifier || !g->steps || !g->cg_scale || !g->temb || !g->clf_emb0 || !g->x_in || !g->x_out) {
+        cdx_set_err("cdx_guided_run: null pointer"); return CDX_EINVAL;
+    }
+    if (g->n_steps <= 0 || g->batch < 0 || g->hd != g->denoiser->horizon * g->denoiser->dim || g->denoiser->n_steps != 0 ||
+        g->denoiser->cfg_mode == 2 || g->denoiser->tile != 0 || g->classifier->horizon * g->classifier->in_dim != g->hd) {
+        cdx_set_err("cdx_guided_run: the denoiser must be a forward-mode U-Net launch matching the classifier's (horizon, dim)"); return CDX_EINVAL;
+    }
+    if (g->fix_mask && !g->prior) { cdx_set_err("cdx_guided_run: fix_mask given without prior"); return CDX_EINVAL; }
+    for (int i = 0; i < g->n_steps; ++i)
+        if (g->steps[i].kind < 0 || g->steps[i].kind > 2 || (g->steps[i].noise_idx >= 0 && !g->noise)) {
+            cdx_set_err("cdx_guided_run: step kinds 0-2 only; stochastic steps need the noise tensor"); return CDX_EINVAL;
+        }
+    if (g->batch == 0) return CDX_OK;
+    const long long need = cdx_guided_workspace_floats(g);
+    if (!g->workspace || g->workspace_floats < need) { cdx_set_err("cdx_guided_run: workspace too small"); return CDX_EINVAL; }
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    Arena a{g->workspace, 0, 0};
+    const long long n = (long long)g->batch * g->hd;
+    float *x = a.take(n), *pred = a.take(n), *prev = a.take(n), *grad = a.take(n);
+    float* logp = a.take((long long)g->batch * g->classifier->out_dim);
+    float* clf_ws = g->workspace + a.used;
+    const long long clf_floats = g->workspace_floats - a.used;
+    if (hipMemcpyAsync(x, g->x_in, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return hip_ok();
+    for (int i = 0; i < g->n_steps; ++i) {
+        cdx_unet1d_launch L = *g->denoiser;
+        L.n_steps = 0; L.steps = nullptr; L.temb_per_sample = 0; L.batch = g->batch;
+        L.temb = g->temb + (size_t)i * L.emb_dim; L.x_in = x; L.x_out = pred;
+        CDX_TRY(cdx_unet1d_run(&L, hip_stream));
+        CDX_TRY(cdx_hjgrad_run(g->classifier, x, g->clf_emb0 + (size_t)i * g->classifier->emb_dim, 0, g->batch, logp, grad, clf_ws,
+                               clf_floats, hip_stream));
+        StepArgs sa;
+        sa.x = x; sa.pred = pred; sa.prev = prev; sa.xold = nullptr; sa.prior = g->prior; sa.fix_mask = g->fix_mask;
+        sa.noise = g->noise; sa.x_min = g->x_min; sa.x_max = g->x_max; sa.st = g->steps[i]; sa.nb = g->batch; sa.hd = g->hd;
+        sa.b0 = 0; sa.batch = g->batch; sa.predict_noise = g->predict_noise; sa.cfg_mode = 0; sa.cfg_w = 0.f;
+        sa.grad = grad; sa.cg_scale = g->cg_scale[i];
+        const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+        hipLaunchKernelGGL(solver_step_kernel, dim3(blocks), dim3(256), 0, st, sa);
+        CDX_TRY(hip_ok());
+    }
+    if (hipMemcpyAsync(g->x_out, x, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return hip_ok();
+    return CDX_OK;
 }
 
 long long cdx_resmlp_workspace_floats(const cdx_resmlp_weights* w, const cdx_sampling* s) {

@@ -51,7 +51,7 @@ def _lib():
     if not _declared:
         lib.cdx_hjgrad_workspace_floats.argtypes = [ctypes.POINTER(CdxHjgradWeights), _I]
         lib.cdx_hjgrad_workspace_floats.restype = ctypes.c_longlong
-        lib.cdx_hjgrad_run.argtypes = [ctypes.POINTER(CdxHjgradWeights), _FP, _FP, _I, _FP, _FP, _FP, ctypes.c_longlong, _FP]
+        lib.cdx_hjgrad_run.argtypes = [ctypes.POINTER(CdxHjgradWeights), _FP, _FP, _I, _I, _FP, _FP, _FP, ctypes.c_longlong, _FP]
         lib.cdx_hjgrad_run.restype = ctypes.c_int
         _declared = True
     return lib
@@ -153,7 +153,7 @@ class HalfJannerGrad:
             self._ws = torch.empty(int(need), dtype=torch.float32, device=self.dev)
         logp = torch.empty((b, self._struct.out_dim), dtype=torch.float32, device=self.dev)
         grad = torch.empty_like(x)
-        _check(lib.cdx_hjgrad_run(ctypes.byref(self._struct), x.data_ptr(), emb0.data_ptr(), b, logp.data_ptr(), grad.data_ptr(),
+        _check(lib.cdx_hjgrad_run(ctypes.byref(self._struct), x.data_ptr(), emb0.data_ptr(), emb0.shape[1], b, logp.data_ptr(), grad.data_ptr(),
                                   self._ws.data_ptr(), self._ws.numel(), _stream_ptr(self.dev)), "cdx_hjgrad_run")
         return logp, grad
 

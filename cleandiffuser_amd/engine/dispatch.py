@@ -48,7 +48,8 @@ def try_fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, requ
     if not _on_gpu(xt) or requires_grad or xt.dtype != torch.float32:
         return None
     if w_cg != 0.0 and solver.classifier is not None:
-        return None                      # per-step classifier gradients need autograd
+        from . import guided             # classifier guidance: fused backbone forward + explicit classifier backward per step
+        return guided.guided_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, feed)
     from . import bigbatch, runtime
     net = model["diffusion"]
     if bigbatch.is_chiunet_gemm(net, xt.shape[0]) and not any(st.kind >= 5 for st in plan.steps):

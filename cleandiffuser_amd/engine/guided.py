@@ -1,0 +1,109 @@
+"""Classifier-guided sampling loop in one native call (``cdx_guided_run``, include/cdx.h).
+
+Reference behaviour: ``DiscreteDiffusionSDE.sample`` / ``ContinuousDiffusionSDE.sample`` with ``w_cg > 0``
+(diffusionsde.py:526-594 + classifier_guidance :153-173) -- per step one backbone forward, one ``classifier.gradients`` call
+(autograd in the reference) and the solver update.  Here every step is: the fused program kernel in forward mode, the explicit
+classifier forward+backward (engine/classifier_grad.py) and the solver-step kernel with the guidance shift folded in; all
+launches of all steps are enqueued by a single C call.
+"""
+import ctypes
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import classifier_grad, runtime
+from .bigbatch import host_steps
+from .runtime import CdxStep, CdxUnet1dLaunch, _check, _dense_hd, _f32c, _predicts_noise, _stream_ptr, load_library
+
+_FP, _I = ctypes.c_void_p, ctypes.c_int32
+
+
+class CdxGuidedLaunch(ctypes.Structure):
+    _fields_ = [("denoiser", ctypes.POINTER(CdxUnet1dLaunch)), ("classifier", ctypes.POINTER(classifier_grad.CdxHjgradWeights)),
+                ("steps", ctypes.POINTER(CdxStep)), ("cg_scale", ctypes.POINTER(ctypes.c_float)), ("n_steps", _I), ("batch", _I),
+                ("hd", _I), ("predict_noise", _I), ("temb", _FP), ("clf_emb0", _FP), ("x_in", _FP), ("prior", _FP),
+                ("fix_mask", _FP), ("noise", _FP), ("x_min", _FP), ("x_max", _FP), ("x_out", _FP), ("workspace", _FP),
+                ("workspace_floats", ctypes.c_longlong)]
+
+
+_declared = False
+_ws = {}
+
+
+def _lib():
+    global _declared
+    lib = load_library()
+    if not _declared:
+        lib.cdx_guided_workspace_floats.argtypes = [ctypes.POINTER(CdxGuidedLaunch)]
+        lib.cdx_guided_workspace_floats.restype = ctypes.c_longlong
+        lib.cdx_guided_run.argtypes = [ctypes.POINTER(CdxGuidedLaunch), ctypes.c_void_p]
+        lib.cdx_guided_run.restype = ctypes.c_int
+        _declared = True
+    return lib
+
+
+def guided_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, feed) -> Optional[torch.Tensor]:
+    """None -> the caller steps the loop itself (PyTorch executor, which still uses the native pieces per step)."""
+    from ..classifier.rew_classifiers import CumRewClassifier
+    from ..nn_classifier.half_jannerunet import HalfJannerUNet1d
+    from ..diffusion.diffusionsde import BaseDiffusionSDE
+    net, clf = model["diffusion"], solver.classifier
+    if not isinstance(solver, BaseDiffusionSDE):        # the legacy classes shift the prediction after their own conversions
+        return None
+    if xt.dim() != 3 or type(clf) is not CumRewClassifier or type(clf.model_ema) is not HalfJannerUNet1d:
+        return None
+    b, h, d = xt.shape
+    if not (runtime._is_janner(net) or runtime._is_chiunet(net)) or runtime.supported_backbone(net, h) is not None:
+        return None
+    if any(st.kind > 2 for st in plan.steps) or (cond_vec is not None and w_cfg not in (0.0, 1.0)):
+        return None
+    if clf.model_ema.horizon != h or clf.model_ema.in_dim != d:
+        return None
+    dev = xt.device
+    bound = classifier_grad.bound_for(clf.model_ema, dev)
+    if bound is None:
+        return None
+    try:
+        clip = getattr(plan, "clip_each_step", True)
+        fix_mask = _dense_hd(solver.fix_mask, h, d, dev)
+        x_min = _dense_hd(getattr(solver, "x_min", None), h, d, dev) if clip else None
+        x_max = _dense_hd(getattr(solver, "x_max", None), h, d, dev) if clip else None
+    except ValueError:
+        return None
+    with torch.no_grad():
+        comp = runtime.compiled_program(net, h)
+        if cond_vec is None or w_cfg == 0.0:
+            mode, cond = 0, None
+        else:
+            mode, cond = 1, runtime._backbone_cond(net, comp.prog, cond_vec, dev)
+            if cond is False or cond is None:
+                return None
+        if runtime._is_chiunet(net) and cond is None:
+            return None
+        t_dtype = torch.long if plan.t_is_integer else torch.float32
+        t_vec = torch.tensor([st.t for st in plan.steps], dtype=t_dtype, device=dev)
+        temb = _f32c(net.map_noise(t_vec), dev)
+        clf_emb0 = _f32c(clf.model_ema.map_noise(t_vec), dev)
+        pn = _predicts_noise(plan, solver)
+        scale = [(-(w_cg * st.sigma)) if pn else (w_cg * ((st.sigma ** 2) / st.alpha)) for st in plan.steps]
+        cg = (ctypes.c_float * len(scale))(*[float(np.float32(v)) for v in scale])
+        steps = host_steps(plan)
+        noise = torch.stack([feed.like(xt) for _ in range(plan.n_noise)]).contiguous() if plan.n_noise else None
+        xin = _f32c(xt, dev)
+        out = torch.empty_like(xin)
+        prior_d = _f32c(prior, dev) if fix_mask is not None else None
+        den = runtime.describe_launch(comp, batch=b, cfg_mode=mode, cfg_w=w_cfg, cond=cond)
+        g = CdxGuidedLaunch(denoiser=ctypes.pointer(den), classifier=ctypes.pointer(bound._struct), steps=steps, cg_scale=cg,
+                            n_steps=len(plan.steps), batch=b, hd=h * d, predict_noise=int(pn), temb=temb.data_ptr(),
+                            clf_emb0=clf_emb0.data_ptr(), x_in=xin.data_ptr(), prior=runtime._ptr(prior_d),
+                            fix_mask=runtime._ptr(fix_mask), noise=runtime._ptr(noise), x_min=runtime._ptr(x_min),
+                            x_max=runtime._ptr(x_max), x_out=out.data_ptr())
+        lib = _lib()
+        need = lib.cdx_guided_workspace_floats(ctypes.byref(g))
+        ws = _ws.get(dev)
+        if ws is None or ws.numel() < need:
+            _ws[dev] = ws = torch.empty(int(need), dtype=torch.float32, device=dev)
+        g.workspace, g.workspace_floats = ws.data_ptr(), ws.numel()
+        _check(lib.cdx_guided_run(ctypes.byref(g), _stream_ptr(dev)), "cdx_guided_run")
+    return out

@@ -234,11 +234,12 @@ def _launch(comp: _Compiled, **kw):
     _launch_nonempty(comp, **kw)
 
 
-def _launch_nonempty(comp: _Compiled, *, batch, x_in, x_out, temb, steps_dev=None, n_steps=0, temb_per_sample=0,
-            predict_noise=0, cfg_mode=0, cfg_w=0.0, cond=None, prior=None, fix_mask=None, noise=None,
-            x_min=None, x_max=None):
+def describe_launch(comp: _Compiled, *, batch, x_in=None, x_out=None, temb=None, steps_dev=None, n_steps=0, temb_per_sample=0,
+                    predict_noise=0, cfg_mode=0, cfg_w=0.0, cond=None, prior=None, fix_mask=None, noise=None,
+                    x_min=None, x_max=None) -> CdxUnet1dLaunch:
+    """The cdx_unet1d_launch block of a request (tensors may be filled in later by a caller that sequences several launches)."""
     prog = comp.prog
-    L = CdxUnet1dLaunch(
+    return CdxUnet1dLaunch(
         ops=comp.ops_dev.data_ptr(), wblob=prog.blob.data_ptr(), n_ops=len(prog.ops), lds_floats=prog.lds_floats,
         x_off=prog.x_off, x_stride=prog.x_stride, pred_off=prog.pred_off, pred_stride=prog.pred_stride,
         pred_branch_floats=prog.pred_branch_floats, prev_off=prog.prev_off, scratch_off=prog.scratch_off,
@@ -248,10 +249,14 @@ def _launch_nonempty(comp: _Compiled, *, batch, x_in, x_out, temb, steps_dev=Non
         prof_off=prog.prof_off, items_in_lds=int(prog.items_in_lds), desc_off=prog.desc_off,
         desc_words=prog.desc_words,
         batch=batch, horizon=prog.horizon, dim=prog.dim, emb_dim=prog.emb_dim,
-        temb=temb.data_ptr(), steps=_ptr(steps_dev), n_steps=n_steps, temb_per_sample=temb_per_sample,
+        temb=_ptr(temb), steps=_ptr(steps_dev), n_steps=n_steps, temb_per_sample=temb_per_sample,
         predict_noise=int(predict_noise), cfg_mode=cfg_mode, cfg_w=float(cfg_w), cond=_ptr(cond),
-        x_in=x_in.data_ptr(), prior=_ptr(prior), fix_mask=_ptr(fix_mask), noise=_ptr(noise),
-        x_min=_ptr(x_min), x_max=_ptr(x_max), x_out=x_out.data_ptr(), prof=_ptr(_prof["buf"]))
+        x_in=_ptr(x_in), prior=_ptr(prior), fix_mask=_ptr(fix_mask), noise=_ptr(noise),
+        x_min=_ptr(x_min), x_max=_ptr(x_max), x_out=_ptr(x_out), prof=_ptr(_prof["buf"]))
+
+
+def _launch_nonempty(comp: _Compiled, *, x_in, **kw):
+    L = describe_launch(comp, x_in=x_in, **kw)
     if _timing["on"]:
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         start.record(torch.cuda.current_stream(x_in.device))

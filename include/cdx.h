@@ -339,8 +339,29 @@ typedef struct cdx_hjgrad_weights {
     const float *fc2_w, *fc2_b, *fc2_w_t;              /* final_block.2 (+ transpose) */
 } cdx_hjgrad_weights;
 long long cdx_hjgrad_workspace_floats(const cdx_hjgrad_weights* w, int32_t batch);
-int cdx_hjgrad_run(const cdx_hjgrad_weights* w, const float* x, const float* emb0, int32_t batch, float* logp, float* grad,
-                   float* workspace, long long workspace_floats, void* hip_stream);
+/* emb0_ld: row stride of emb0 in floats; 0 = one row shared by the whole batch (the sampling loop: same t for every sample). */
+int cdx_hjgrad_run(const cdx_hjgrad_weights* w, const float* x, const float* emb0, int32_t emb0_ld, int32_t batch, float* logp,
+                   float* grad, float* workspace, long long workspace_floats, void* hip_stream);
+
+/* Classifier-guided sampling loop (reference diffusionsde.py:526-594 with w_cg > 0, the configuration every shipped Diffuser
+ * pipeline runs): per step record  pred <- backbone(x, t)  [program kernel, forward mode];  (logp, g) <- classifier gradient;
+ * pred <- pred - w sigma g (eps prediction) | pred + w sigma^2/alpha g (x0 prediction)  [cg_scale[i], host-frozen];  then clip,
+ * solver update and fix-mask exactly as in the unguided loop.  All launches of all steps are enqueued by this one call. */
+typedef struct cdx_guided_launch {
+    const cdx_unet1d_launch* denoiser;   /* a forward-mode launch description (n_steps = 0); temb/x_in/x_out are set per step */
+    const cdx_hjgrad_weights* classifier;
+    const cdx_step* steps;               /* HOST [n_steps], kinds 0-2 */
+    const float* cg_scale;               /* HOST [n_steps]: factor of the gradient added to the prediction at step i */
+    int32_t n_steps, batch, hd, predict_noise;
+    const float* temb;                   /* device (n_steps, denoiser emb_dim) */
+    const float* clf_emb0;               /* device (n_steps, classifier emb_dim): classifier map_noise(t_i) */
+    const float *x_in, *prior, *fix_mask, *noise, *x_min, *x_max;
+    float* x_out;
+    float* workspace;                    /* >= cdx_guided_workspace_floats() */
+    long long workspace_floats;
+} cdx_guided_launch;
+long long cdx_guided_workspace_floats(const cdx_guided_launch* g);
+int cdx_guided_run(const cdx_guided_launch* g, void* hip_stream);
 
 /* Pre-norm residual MLP = IDQLMlp / NewIDQLMlp (reference nn_diffusion/idqlmlp.py:9-18 ResidualBlock, :21-65, :68-112):
  * features [x | time_mlp(map_noise(t)) | obs] -> affine_in -> n x (h + fc2(mish(fc1(LN(h))))) -> [mish] -> affine_out.

@@ -28,15 +28,16 @@ def test_every_declared_symbol_is_exported(lib):
                           "cdx_dit1d_workspace_floats", "cdx_resmlp_workspace_floats", "cdx_gemm_set_trace",
                           "cdx_chitf_run", "cdx_chitf_workspace_floats", "cdx_cross_attention_f32", "cdx_chiunet_run",
                           "cdx_chiunet_workspace_floats", "cdx_groupnorm_f32", "cdx_groupnorm_bwd_f32", "cdx_hjgrad_run",
-                          "cdx_hjgrad_workspace_floats"}
+                          "cdx_hjgrad_workspace_floats", "cdx_guided_run", "cdx_guided_workspace_floats"}
     for n in names:
         assert hasattr(lib, n), f"{n} declared in cdx.h but not exported by libcdx.so"
     assert lib.cdx_abi_version() == int(re.search(r"#define CDX_ABI_VERSION (\d+)", hdr).group(1))
 
 
 def test_ctypes_mirrors_have_c_layout(tmp_path):
-    from cleandiffuser_amd.engine import bigbatch, blocks, classifier_grad, runtime
-    mirrors = {"cdx_hj_block": classifier_grad.CdxHjBlock, "cdx_hj_down": classifier_grad.CdxHjDown,
+    from cleandiffuser_amd.engine import bigbatch, blocks, classifier_grad, guided, runtime
+    mirrors = {"cdx_guided_launch": guided.CdxGuidedLaunch,
+               "cdx_hj_block": classifier_grad.CdxHjBlock, "cdx_hj_down": classifier_grad.CdxHjDown,
                "cdx_hjgrad_weights": classifier_grad.CdxHjgradWeights,
                "cdx_unet1d_launch": runtime.CdxUnet1dLaunch, "cdx_step": runtime.CdxStep, "cdx_gemm_args": blocks.CdxGemmArgs,
                "cdx_ln_args": blocks.CdxLnArgs, "cdx_attn_args": blocks.CdxAttnArgs, "cdx_sampling": bigbatch.CdxSampling,

@@ -146,25 +146,36 @@ def test_native_classifier_gradients_match_autograd(name, amd_lib, monkeypatch):
     np.testing.assert_allclose(grad_n.cpu().numpy(), grad_a.cpu().numpy(), rtol=1e-4, atol=1e-4 * max(scale, 1.0))
 
 
+@pytest.mark.parametrize("one_call", [True, False])
 @pytest.mark.parametrize("name", GUIDED_CASES)
-def test_guided_sampling_matches_reference_fixture(name, amd_lib, monkeypatch):
-    """w_cg > 0: per-step loop = fused backbone forward (one launch) + native classifier forward/backward + solver update."""
-    from cleandiffuser_amd.engine import classifier_grad
+def test_guided_sampling_matches_reference_fixture(name, one_call, amd_lib, monkeypatch):
+    """w_cg > 0.  one_call: the whole guided loop is cdx_guided_run (fused backbone forward + native classifier forward/backward +
+    solver step per record).  Otherwise the host steps the loop and every step's gradient still comes from the native kernels."""
+    from cleandiffuser_amd.engine import classifier_grad, guided
     gold = np.load(golden_path(name))
     agent, _ = cases.build(amd_lib, name, device=DEV)
     inp = cases.make_inputs(name)
     kw = cases.sample_kwargs(name, inp, device=DEV)
-    used = {"n": 0}
-    orig = classifier_grad.gradients
+    used = {"grad": 0, "loop": 0}
+    orig_g, orig_l = classifier_grad.gradients, guided.guided_sample
 
     def counted(*a, **k):
-        out = orig(*a, **k)
-        used["n"] += out is not None
+        out = orig_g(*a, **k)
+        used["grad"] += out is not None
+        return out
+
+    def loop(*a, **k):
+        out = orig_l(*a, **k) if one_call else None
+        used["loop"] += out is not None
         return out
     monkeypatch.setattr(classifier_grad, "gradients", counted)
+    monkeypatch.setattr(guided, "guided_sample", loop)
     x, _ = agent.sample(torch.from_numpy(inp["prior"]).to(DEV), noise=list(inp["noise"][:int(gold["n_draws"])]), **kw)
     torch.cuda.synchronize()
-    assert used["n"] == kw["sample_steps"], "every step's classifier gradient must come from the native kernels"
+    if one_call:
+        assert used == {"grad": 0, "loop": 1}
+    else:
+        assert used["grad"] == kw["sample_steps"], "every step's classifier gradient must come from the native kernels"
     np.testing.assert_allclose(x.cpu().numpy(), gold["x_out"], **TOL)
 
 
