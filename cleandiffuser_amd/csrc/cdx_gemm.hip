@@ -212,9 +212,8 @@ __device__ __forceinline__ void gm_stamp(int slot) {
 // WT = MFMA tiles per wave per dimension: 2 -> 128 x 128 x 16 workgroup tile (throughput shape), 1 -> 64 x 64 x 32 (few rows:
 // four times the workgroups, a quarter of the MFMA time per barrier -- the launches of classifier guidance and small batches).
 template <bool FAST, int WT, bool CONV>
-__global__ __launch_bounds__(GM_THREADS, (WT == 2 ? 3 : 4)) void cdx_gemm_kernel(const cdx_gemm_args g, const int stagger,
-                                                                                const int fast_ep, const int k_split,
-                                                                                const int xcd_order) {
+__global__ __launch_bounds__(GM_THREADS, (WT == 2 ? 3 : 4)) void cdx_gemm_kernel(const cdx_gemm_args g, const int fast_ep,
+                                                                                const int k_split, const int xcd_order) {
     constexpr int BMN = 64 * WT;                  // rows of A == rows of W per tile
     constexpr int KQ = GM_THREADS / BMN;           // k quads staged per row by different threads
     constexpr int BK = 8 * KQ;                     // each thread stages two float4 per operand: k = kq*4 and BK/2 + kq*4
@@ -237,11 +236,6 @@ __global__ __launch_bounds__(GM_THREADS, (WT == 2 ? 3 : 4)) void cdx_gemm_kernel
     const int bm = (tile / tiles_n) * BMN, bn = (tile % tiles_n) * BMN;
     const int lrow = tid % BMN, kq = tid / BMN;         // this thread stages row `lrow`, k quads kq and kq + KQ
 
-    if (stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 768) {     // measured no-op (kept as a tuning hook)
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-        const unsigned long long wait = (unsigned long long)stagger * (blockIdx.x >> 8);
-        while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
-    }
     gm_stamp(0);
     f32x16 acc[WT][WT];
 #pragma unroll
@@ -868,9 +862,6 @@ int cdx_gemm_f32(const cdx_gemm_args* g, void* hip_stream) {
     const bool vec = (g->K % bk == 0) && (g->lda % 4 == 0) && (g->ldw % 4 == 0) &&
                      (((uintptr_t)g->A | (uintptr_t)g->W) % 16 == 0) && (g->conv_taps == 0 || g->conv_cin % 4 == 0);
     hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
-    static const char* env = getenv("CDX_GEMM_STAGGER");          // tuning hook: cycles per phase class, 0 = off
-    int stagger = 0;
-    if (tiles >= 2 * 768 && env) stagger = atoi(env);
     const uintptr_t ep_ptrs = (uintptr_t)g->C | (uintptr_t)g->gate | (uintptr_t)g->residual | (uintptr_t)g->table;
     const int fast_ep = (g->N % 4 == 0) && (g->ldc % 4 == 0) && (!g->gate || g->ldg % 4 == 0) &&
                         (!g->residual || g->ldr % 4 == 0) && (ep_ptrs % 16 == 0);
@@ -889,7 +880,7 @@ int cdx_gemm_f32(const cdx_gemm_args* g, void* hip_stream) {
     static const char* env_x = getenv("CDX_GEMM_XCD_ORDER");      // tuning hook: 1 = one contiguous tile range per XCD
     const int xcd_order = env_x ? atoi(env_x) : 0;    // measured: +-2 % either way once tiles are walked n-fastest
     const dim3 grid(tiles * k_split), block(GM_THREADS);
-#define GM_LAUNCH(F, W, C) hipLaunchKernelGGL((cdx_gemm_kernel<F, W, C>), grid, block, 0, s, *g, stagger, fast_ep, k_split, xcd_order)
+#define GM_LAUNCH(F, W, C) hipLaunchKernelGGL((cdx_gemm_kernel<F, W, C>), grid, block, 0, s, *g, fast_ep, k_split, xcd_order)
     const bool cv = g->conv_taps > 0;
     if (small) {
         if (vec) { if (cv) GM_LAUNCH(true, 1, true); else GM_LAUNCH(true, 1, false); }
