@@ -601,18 +601,20 @@ struct UNet {                     // one pass over the op list; with dry == true
 
     // request-invariant tables: embeddings and the two halves of every block's FiLM vector
     int prepare() {
-        const int E = w->emb_dim, trow = s->temb_per_sample ? bf : n_rec;
+        const int E = w->emb_dim, EH = w->emb_hidden, EO = w->emb_out, trow = s->temb_per_sample ? bf : n_rec;
+        const bool has_obs = w->cond_dim > 0;
         film_total = 0;
         for (int i = 0; i < n_blocks(); ++i) film_total += film_out(w->blocks[i]);
         x = take((long long)nb * s->hd); prev = take((long long)nb * s->hd); xin = take((long long)bf * s->hd);
-        obs = take((long long)bf * w->cond_dim);
-        e1 = take((long long)trow * 4 * E); te = take((long long)trow * E); mte = take((long long)trow * E);
-        gobs = take((long long)bf * E); mo = take((long long)bf * E);
-        tfilm = take((long long)trow * film_total); ofilm = take((long long)bf * film_total);
+        obs = take(has_obs ? (long long)bf * w->cond_dim : 0);
+        e1 = take((long long)trow * EH); te = take((long long)trow * (EO > E ? EO : E)); mte = take((long long)trow * (EO > E ? EO : E));
+        gobs = take(has_obs ? (long long)bf * EO : 0); mo = take(has_obs ? (long long)bf * EO : 0);
+        tfilm = take((long long)trow * film_total); ofilm = take(has_obs ? (long long)bf * film_total : 0);
         pred = take((long long)bf * s->hd);
         splitk_floats = (long long)UNET_SPLITK * bf * w->Ta * w->model_dim;     // every conv output is <= bf*Ta*model_dim floats
         splitk = take(splitk_floats);
         if (dry) return CDX_OK;
+        if (!has_obs) ofilm = nullptr;
         const float* trows = s->temb;                    // per-sample timesteps: rows of this chunk (both CFG halves alike)
         if (s->temb_per_sample) {
             for (int half = 0; half < bf / nb; ++half)
@@ -620,24 +622,26 @@ struct UNet {                     // one pass over the op list; with dry == true
                                    hipMemcpyDeviceToDevice, st) != hipSuccess) return hip_ok();
             trows = mte;                                 // staged in mte, consumed by the first GEMM before mte is rewritten
         }
-        CDX_TRY(gemm(st, trows, E, w->map0_w, E, w->map0_b, e1, 4 * E, trow, 4 * E, E, CDX_ACT_MISH));
-        CDX_TRY(gemm(st, e1, 4 * E, w->map2_w, 4 * E, w->map2_b, te, E, trow, E, 4 * E));
-        CDX_TRY(cdx_act_f32(te, mte, (long long)trow * E, CDX_ACT_MISH, st));
-        {
+        CDX_TRY(gemm(st, trows, E, w->map0_w, E, w->map0_b, e1, EH, trow, EH, E, CDX_ACT_MISH));
+        CDX_TRY(gemm(st, e1, EH, w->map2_w, EH, w->map2_b, te, EO, trow, EO, EH));
+        CDX_TRY(cdx_act_f32(te, mte, (long long)trow * EO, CDX_ACT_MISH, st));
+        if (has_obs) {
             const long long n = (long long)bf * w->cond_dim;
             const int n_cond_rows = (s->cond == nullptr || s->cfg_mode == 0) ? 0 : nb;
             hipLaunchKernelGGL(obs_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, obs, s->cond, bf, nb, b0,
                                w->cond_dim, n_cond_rows);
             CDX_TRY(hip_ok());
+            CDX_TRY(gemm(st, obs, w->cond_dim, w->gce_w, w->cond_dim, w->gce_b, gobs, EO, bf, EO, w->cond_dim));
+            CDX_TRY(cdx_act_f32(gobs, mo, (long long)bf * EO, CDX_ACT_MISH, st));
         }
-        CDX_TRY(gemm(st, obs, w->cond_dim, w->gce_w, w->cond_dim, w->gce_b, gobs, E, bf, E, w->cond_dim));
-        CDX_TRY(cdx_act_f32(gobs, mo, (long long)bf * E, CDX_ACT_MISH, st));
         long long off = 0;
         for (int i = 0; i < n_blocks(); ++i) {
             const cdx_chiunet_block& k = w->blocks[i];
             const int fo = film_out(k);
-            CDX_TRY(gemm(st, mte, E, k.film_w, 2 * E, nullptr, tfilm + off, (int)film_total, trow, fo, E));
-            CDX_TRY(gemm(st, mo, E, k.film_w + E, 2 * E, k.film_b, ofilm + off, (int)film_total, bf, fo, E));
+            // without an observation half the block's bias rides with the time half
+            CDX_TRY(gemm(st, mte, EO, k.film_w, w->film_ld, has_obs ? nullptr : k.film_b, tfilm + off, (int)film_total, trow, fo, EO));
+            if (has_obs)
+                CDX_TRY(gemm(st, mo, EO, k.film_w + EO, w->film_ld, k.film_b, ofilm + off, (int)film_total, bf, fo, EO));
             off += fo;
         }
         return CDX_OK;
@@ -692,18 +696,21 @@ struct UNet {                     // one pass over the op list; with dry == true
 };
 
 int chiunet_check(const cdx_chiunet_weights* w, const cdx_sampling* s) {
-    if (!w || !w->blocks || !w->map0_w || !w->map2_w || !w->gce_w || !w->fin_w || !w->out_w ||
+    if (!w || !w->blocks || !w->map0_w || !w->map2_w || (w->cond_dim > 0 && !w->gce_w) || !w->fin_w || !w->out_w ||
         (w->n_levels > 1 && (!w->down_w || !w->down_b || !w->up_w_even || !w->up_w_odd || !w->up_b))) {
         cdx_set_err("null pointer in ChiUNet1d weights"); return CDX_EINVAL;
     }
     if (w->n_levels < 1 || w->n_levels > 8 || w->Ta <= 0 || (w->Ta >> (w->n_levels - 1)) < 1 || (w->Ta & (w->Ta - 1)) ||
-        w->kernel_size < 1 || !(w->kernel_size & 1) || w->emb_dim <= 0 || w->cond_dim <= 0) {
+        w->kernel_size < 1 || !(w->kernel_size & 1) || w->emb_dim <= 0 || w->cond_dim < 0 || w->emb_hidden <= 0 || w->emb_out <= 0 ||
+        w->film_ld < w->emb_out) {
         cdx_set_err("ChiUNet1d executor: Ta must be a power of two >= 2^(levels-1), odd kernel size"); return CDX_EINVAL;
     }
     CDX_TRY(check_request(s, "cdx_chiunet_run", 4));
-    if (s->hd != w->Ta * w->act_dim || s->emb_dim != w->emb_dim || !s->cond || s->cond_dim != w->cond_dim || s->cfg_mode == 0) {
-        cdx_set_err("ChiUNet1d request: shape mismatch, or no condition (the reference requires one)"); return CDX_EINVAL;
+    if (s->hd != w->Ta * w->act_dim || s->emb_dim != w->emb_dim) { cdx_set_err("U-Net request: shape mismatch"); return CDX_EINVAL; }
+    if (w->cond_dim > 0 && (!s->cond || s->cond_dim != w->cond_dim || s->cfg_mode == 0)) {
+        cdx_set_err("ChiUNet1d request: no condition (the reference requires one)"); return CDX_EINVAL;
     }
+    if (w->cond_dim == 0 && (s->cond || s->cfg_mode != 0)) { cdx_set_err("unconditional U-Net: cond must be NULL, cfg_mode 0"); return CDX_EINVAL; }
     return CDX_OK;
 }
 

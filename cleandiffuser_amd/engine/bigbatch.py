@@ -67,7 +67,7 @@ class CdxChiUNetBlock(ctypes.Structure):
 
 class CdxChiUNetWeights(ctypes.Structure):
     _fields_ = [(n, _I) for n in ("act_dim", "Ta", "cond_dim", "emb_dim", "kernel_size", "n_levels", "cond_predict_scale",
-                                  "model_dim", "final_groups")] + \
+                                  "model_dim", "final_groups", "emb_hidden", "emb_out", "film_ld")] + \
                [(n, _FP) for n in ("map0_w", "map0_b", "map2_w", "map2_b", "gce_w", "gce_b")] + \
                [("blocks", ctypes.POINTER(CdxChiUNetBlock))] + \
                [(n, ctypes.POINTER(ctypes.c_void_p)) for n in ("down_w", "down_b", "up_w_even", "up_w_odd", "up_b")] + \
@@ -281,8 +281,87 @@ def _bind_chiunet(net, Ta: int, device) -> Optional[_Bound]:
     w.act_dim, w.Ta, w.cond_dim, w.emb_dim = net.downs[0][0].conv1[0].in_channels, Ta, net.global_cond_encoder.in_features, E
     w.kernel_size, w.n_levels, w.cond_predict_scale = fin[0].kernel_size[0], n_levels, int(net.downs[0][0].cond_predict_scale)
     w.model_dim, w.final_groups = net.model_dim, fin[1].num_groups
+    w.emb_hidden, w.emb_out, w.film_ld = net.map_emb[0].out_features, E, 2 * E
     w.map0_w, w.map0_b, w.map2_w, w.map2_b = p(net.map_emb[0].weight), p(net.map_emb[0].bias), p(net.map_emb[2].weight), p(net.map_emb[2].bias)
     w.gce_w, w.gce_b = p(net.global_cond_encoder.weight), p(net.global_cond_encoder.bias)
+    w.blocks = arr
+    w.down_w, w.down_b = ptr_array([packed(B.pack_conv(d.weight)) for d in downs]), ptr_array([p(d.bias) for d in downs])
+    w.up_w_even, w.up_w_odd = ptr_array([packed(e) for e, _ in up_packed]), ptr_array([packed(o) for _, o in up_packed])
+    w.up_b = ptr_array([p(u.bias) for u in ups])
+    w.fin_w, w.fin_b, w.fin_g, w.fin_be = packed(B.pack_conv(fin[0].weight)), p(fin[0].bias), p(fin[1].weight), p(fin[1].bias)
+    w.out_w, w.out_b = packed(fin[3].weight.detach()[:, :, 0]), p(fin[3].bias)
+    keep.append(arr)
+    return _Bound(w, keep, None)
+
+
+def _bind_janner_gemm(net, H: int, device) -> Optional[_Bound]:
+    """Unconditional JannerUNet1d for the same implicit-GEMM executor (bias-only FiLM from Linear(Mish(emb)), no obs half)."""
+    import torch.nn as nn
+    from . import blocks as B
+    from ..utils import GroupNorm1d
+    if getattr(net, "attention", False) or H & (H - 1):
+        return None
+    n_levels = len(net.downs)
+    if (H >> (n_levels - 1)) < 1 or n_levels > 8:
+        return None
+    keep = []
+    p = lambda t: _dev_f32(t, keep, device)  # noqa: E731
+
+    def packed(t):
+        t = t.to(device=device, dtype=torch.float32).contiguous()
+        keep.append(t)
+        return t.data_ptr()
+
+    def bind_block(blk, cin_a, cin_b):
+        c1, gn1, c2, gn2 = blk.conv1[0], blk.conv1[1], blk.conv2[0], blk.conv2[1]
+        if not isinstance(gn1, GroupNorm1d) or not isinstance(gn2, GroupNorm1d):
+            return None
+        w1 = B.pack_conv(c1.weight)
+        has_res = isinstance(blk.residual_conv, nn.Conv1d)
+        wr = blk.residual_conv.weight.detach()[:, :, 0] if has_res else None
+        return CdxChiUNetBlock(
+            cin_a=cin_a, cin_b=cin_b, cout=c1.out_channels, groups=gn1.num_groups,
+            w1a=packed(w1[:, :, :cin_a]), w1b=packed(w1[:, :, cin_a:]) if cin_b else None, b1=p(c1.bias), g1=p(gn1.weight),
+            be1=p(gn1.bias), w2=packed(B.pack_conv(c2.weight)), b2=p(c2.bias), g2=p(gn2.weight), be2=p(gn2.bias),
+            film_w=p(blk.emb_mlp[1].weight), film_b=p(blk.emb_mlp[1].bias),
+            wra=packed(wr[:, :cin_a]) if has_res else None, wrb=packed(wr[:, cin_a:]) if (has_res and cin_b) else None,
+            br=p(blk.residual_conv.bias) if has_res else None)
+
+    blocks = []
+    for res1, res2, _, _ in net.downs:
+        blocks += [bind_block(res1, res1.conv1[0].in_channels, 0), bind_block(res2, res2.conv1[0].in_channels, 0)]
+    blocks += [bind_block(m, m.conv1[0].in_channels, 0) for m in (net.mid_block1, net.mid_block2)]
+    for res1, res2, _, _ in net.ups:
+        half = res1.conv1[0].in_channels // 2
+        blocks += [bind_block(res1, half, half), bind_block(res2, res2.conv1[0].in_channels, 0)]
+    if any(b is None for b in blocks):
+        return None
+    for b in blocks:
+        if b.wra is None and (b.cin_b or b.cin_a != b.cout):
+            return None
+    arr = (CdxChiUNetBlock * len(blocks))(*blocks)
+
+    def ptr_array(vals):
+        a = (ctypes.c_void_p * max(len(vals), 1))(*vals)
+        keep.append(a)
+        return a
+    downs = [lvl[3].conv for lvl in net.downs if not isinstance(lvl[3], nn.Identity)]
+    ups = [lvl[3].conv for lvl in net.ups if not isinstance(lvl[3], nn.Identity)]
+    if len(downs) != n_levels - 1 or len(ups) != n_levels - 1:
+        return None
+    up_packed = [B.pack_conv_transpose_k4s2p1(u.weight) for u in ups]
+    fin = net.final_conv
+    if not isinstance(fin[1], GroupNorm1d):
+        return None
+    w = CdxChiUNetWeights()
+    w.act_dim, w.Ta, w.cond_dim, w.emb_dim = net.in_dim, H, 0, net.map_emb[0].in_features
+    w.kernel_size, w.n_levels, w.cond_predict_scale = net.kernel_size, n_levels, 0
+    if fin[0].kernel_size[0] != net.kernel_size:
+        return None                                   # the executor uses one kernel size for the blocks and the final conv
+    w.model_dim, w.final_groups = net.model_dim, fin[1].num_groups
+    w.emb_hidden, w.emb_out, w.film_ld = net.map_emb[0].out_features, net.map_emb[2].out_features, net.map_emb[2].out_features
+    w.map0_w, w.map0_b, w.map2_w, w.map2_b = p(net.map_emb[0].weight), p(net.map_emb[0].bias), p(net.map_emb[2].weight), p(net.map_emb[2].bias)
+    w.gce_w, w.gce_b = None, None
     w.blocks = arr
     w.down_w, w.down_b = ptr_array([packed(B.pack_conv(d.weight)) for d in downs]), ptr_array([p(d.bias) for d in downs])
     w.up_w_even, w.up_w_odd = ptr_array([packed(e) for e, _ in up_packed]), ptr_array([packed(o) for _, o in up_packed])
@@ -354,9 +433,22 @@ CHUNK_OVERRIDE = {"dit": int(os.environ.get("CDX_DIT_CHUNK", 0)) or None,      #
 UNET_GEMM_MIN_BATCH = int(os.environ.get("CDX_UNET_GEMM_MIN_BATCH", 96))   # measured: 1.45x at B=128, 1.18x at 256, 2.1x at 1024
 
 
+# JannerUNet1d's channels are narrow (32..256): its GEMM tiles are mostly padding, so the program kernel keeps small and medium
+# batches and the GEMM executor only takes over where weight re-streaming dominates (measured crossover, tools/bench_configs.py).
+JANNER_GEMM_MIN_BATCH = int(os.environ.get("CDX_JANNER_GEMM_MIN_BATCH", 2048))   # config-2 net: 0.39x at 256, 0.89x at 1024, 1.16x at 3200
+
+
 def is_chiunet_gemm(module, batch: int) -> bool:
     from ..nn_diffusion.chiunet import ChiUNet1d
+    from ..nn_diffusion.jannerunet import JannerUNet1d
+    if type(module) is JannerUNet1d:
+        return batch >= JANNER_GEMM_MIN_BATCH
     return type(module) is ChiUNet1d and module.obs_as_global_cond and batch >= UNET_GEMM_MIN_BATCH
+
+
+def _bind_unet_gemm(net, tokens: int, dev):
+    from ..nn_diffusion.jannerunet import JannerUNet1d
+    return _bind_janner_gemm(net, tokens, dev) if type(net) is JannerUNet1d else _bind_chiunet(net, tokens, dev)
 
 
 def _chiunet_chunk(batch: int, Ta: int, model_dim: int, two: int) -> int:
@@ -494,10 +586,15 @@ def sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed) -> Optional[torc
         bound = _bound(net, ("dit", tokens), lambda: _bind_dit(net, tokens, dev))
         hd, rows_h = tokens * d, tokens
     elif is_chiunet_gemm(net, xt.shape[0]):
-        if xt.dim() != 3 or cond_vec is None or w_cfg == 0.0:
-            return None                               # ChiUNet1d cannot run unconditionally (the reference raises)
+        from ..nn_diffusion.jannerunet import JannerUNet1d
+        janner = type(net) is JannerUNet1d
+        if xt.dim() != 3 or (janner and cond_vec is not None and w_cfg != 0.0) or \
+                (not janner and (cond_vec is None or w_cfg == 0.0)):
+            return None                               # ChiUNet1d needs a condition (the reference raises); Janner here: none
+        if janner:
+            cond_vec = None
         kind, (b, tokens, d) = "chiunet", xt.shape
-        bound = _bound(net, ("chiunet", tokens), lambda: _bind_chiunet(net, tokens, dev))
+        bound = _bound(net, ("chiunet", tokens), lambda: _bind_unet_gemm(net, tokens, dev))
         hd, rows_h = tokens * d, tokens
         if bound is not None and bound.struct.act_dim != d:
             return None

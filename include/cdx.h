@@ -299,8 +299,13 @@ typedef struct cdx_chiunet_block {
 } cdx_chiunet_block;
 typedef struct cdx_chiunet_weights {
     int32_t act_dim, Ta, cond_dim, emb_dim, kernel_size, n_levels, cond_predict_scale, model_dim, final_groups;
-    const float *map0_w, *map0_b, *map2_w, *map2_b;     /* map_emb.0 (4E, E), map_emb.2 (E, 4E) */
-    const float *gce_w, *gce_b;                         /* global_cond_encoder (E, cond_dim) */
+    /* The same executor serves the unconditional JannerUNet1d (reference nn_diffusion/jannerunet.py:98-201): its blocks add
+     * Linear(Mish(emb)) as a per-channel bias (cond_predict_scale = 0), the embedding MLP is emb_dim -> emb_hidden -> emb_out
+     * and there is no observation half (cond_dim = 0, film_ld = emb_out).  ChiUNet1d: emb_hidden = 4 emb_dim, emb_out = emb_dim,
+     * film_ld = 2 emb_dim. */
+    int32_t emb_hidden, emb_out, film_ld;
+    const float *map0_w, *map0_b, *map2_w, *map2_b;     /* map_emb.0 (emb_hidden, emb_dim), map_emb.2 (emb_out, emb_hidden) */
+    const float *gce_w, *gce_b;                         /* global_cond_encoder (emb_out, cond_dim), or NULL when cond_dim == 0 */
     const cdx_chiunet_block* blocks;                    /* HOST [2 n_levels + 2 + 2 (n_levels - 1)]: downs, mids, ups */
     const float* const* down_w;                         /* HOST [n_levels - 1] packed (C, 3, C) */
     const float* const* down_b;

@@ -202,6 +202,26 @@ def test_chiunet_gemm_executor_matches_reference_fixture(name, chunk, amd_lib, m
     np.testing.assert_allclose(x.cpu().numpy(), gold["x_out"], **TOL)
 
 
+@pytest.mark.parametrize("name", ["janner_cfg2_ddim", "janner_h4_ddpm", "janner_cfg2_ddpm_clip", "janner_h64_single",
+                                  "janner_legacy_dpm_sdepp2", "janner_rflow_discrete", "janner_legacy_edm_euler"])
+def test_janner_gemm_executor_matches_reference_fixture(name, amd_lib, monkeypatch):
+    """Unconditional JannerUNet1d through the implicit-GEMM U-Net executor (meant for batches in the thousands; forced here)."""
+    from cleandiffuser_amd.engine import bigbatch
+    gold = np.load(golden_path(name))
+    agent, _ = cases.build(amd_lib, name, device=DEV)
+    inp = cases.make_inputs(name)
+    kw = cases.sample_kwargs(name, inp, device=DEV)
+    monkeypatch.setattr(bigbatch, "JANNER_GEMM_MIN_BATCH", 1)
+    calls = _spy_bigbatch(monkeypatch)
+    x, _ = cases.sampler_of(agent, name)(torch.from_numpy(inp["prior"]).to(DEV), noise=list(inp["noise"][:int(gold["n_draws"])]), **kw)
+    torch.cuda.synchronize()
+    if cases.CASES[name]["solver"][0] == "EDM":
+        assert calls == []                            # EDM input scaling lives in the program kernel only
+    else:
+        assert [c[0] for c in calls] == ["chiunet"]
+    np.testing.assert_allclose(x.cpu().numpy(), gold["x_out"], **TOL)
+
+
 def test_chiunet_gemm_forward_matches_program_kernel(amd_lib, monkeypatch):
     """backbone.forward with per-sample timesteps: the two native ChiUNet1d executors agree (and the program kernel is pinned to
     the reference by the fixtures above)."""

@@ -102,6 +102,22 @@ def cfg5(B=131072, steps=128):
     return f"config 5 shard: IDQLMlp 1024x6, D=15, {steps}-step EDM Euler, B={B}", call, B, 2.0 * macs * steps * B
 
 
+def cfg2big(B=3200):
+    """Config 2's network at the real Diffuser batch (50 environments x 64 candidate plans), unguided 20-step DDIM."""
+    from cleandiffuser_amd.nn_diffusion import JannerUNet1d
+    H, D = 32, 23
+    net = load_synth(JannerUNet1d(D, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2, 2], kernel_size=5))
+    fix = torch.zeros(H, D)
+    fix[0, :17] = 1.0
+    agent = DiscreteDiffusionSDE(net, None, fix_mask=fix, diffusion_steps=20, predict_noise=False, device=DEV)
+    agent.eval()
+    prior = torch.zeros(B, H, D, device=DEV)
+    prior[:, 0, :17] = torch.randn(B, 17, device=DEV)
+    z = [torch.randn(B, H, D, device=DEV)]
+    call = lambda: agent.sample(prior, solver="ddim", n_samples=B, sample_steps=20, temperature=0.5, noise=z)[0]  # noqa: E731
+    return f"config 2 network, 20-step DDIM, B={B}", call, B, 2.0 * 19.67e6 * 20 * B
+
+
 def cfg2g(B=256):
     """Config 2 with classifier guidance at every step (w_cg > 0, what the shipped Diffuser configurations run): JannerUNet1d
     denoiser (fused forward per step) + CumRewClassifier(HalfJannerUNet1d) gradient per step, 20-step DDPM."""
@@ -161,9 +177,9 @@ def run(name, fn, reps=3, **kw):
 
 if __name__ == "__main__":
     for name in (sys.argv[1:] or ["cfg1", "cfg3"]):
-        if name.startswith("cfg4") or name.startswith("cfg5") or name.startswith("cfg2g"):   # e.g. cfg4, cfg4:4096, cfg2g:3200
+        if name.startswith(("cfg4", "cfg5", "cfg2g", "cfg2big")):    # e.g. cfg4, cfg4:4096, cfg2g:3200, cfg2big:1024
             base, _, b = name.partition(":")
-            run_big(name, {"cfg4": cfg4, "cfg5": cfg5, "cfg2g": cfg2g}[base], **({"B": int(b)} if b else {}))
+            run_big(name, {"cfg4": cfg4, "cfg5": cfg5, "cfg2g": cfg2g, "cfg2big": cfg2big}[base], **({"B": int(b)} if b else {}))
         else:
             base, _, b = name.partition(":")
             run(name, {"cfg1": cfg1, "cfg3": cfg3}[base], **({"B": int(b)} if b else {}))
