@@ -188,6 +188,21 @@ CASES.update({
         solver=("EDM", dict()), sample=dict(solver="euler", sample_steps=5, w_cfg=1.0)),
 })
 
+# ChiUNet1d with classifier-free guidance on a doubled batch (zero observations for the unconditional half), bias-only FiLM
+CASES.update({
+    "chiunet_cfg_w18_ddim": dict(
+        net=("ChiUNet1d", dict(act_dim=3, obs_dim=5, To=2, model_dim=32, emb_dim=32, dim_mult=[1, 2], kernel_size=3)),
+        x_shape=(8, 3), batch=5, clip=1.5, cond=("IdentityCondition", dict(dropout=0.0), (2, 5)),
+        solver=("DiscreteDiffusionSDE", dict(diffusion_steps=30, predict_noise=True)),
+        sample=dict(solver="ddim", sample_steps=5, w_cfg=1.8)),
+    "chiunet_nofilmscale_sde": dict(
+        net=("ChiUNet1d", dict(act_dim=2, obs_dim=4, To=1, model_dim=32, emb_dim=16, dim_mult=[1, 2, 2], kernel_size=5,
+                               cond_predict_scale=False)),
+        x_shape=(16, 2), batch=3, clip=2.0, cond=("IdentityCondition", dict(dropout=0.0), (1, 4)),
+        solver=("ContinuousDiffusionSDE", dict(predict_noise=False)),
+        sample=dict(solver="sde_dpmsolver++_1", sample_steps=4, w_cfg=1.0)),
+})
+
 # ---- classifier guidance at every step (w_cg > 0: what every shipped Diffuser configuration runs) ----
 CASES.update({
     "janner_cfg2_guided_ddpm": dict(
