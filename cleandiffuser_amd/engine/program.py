@@ -646,7 +646,7 @@ def compile_pearce_mlp(net, tile: int = MLP_TILE, max_lds_bytes: int = 160 * 102
 
 
 def compile_dql_mlp(net, tile: int = MLP_TILE, max_lds_bytes: int = 160 * 1024) -> Program:
-    """DQLMlp (reference nn_diffusion/dqlmlp.py:9-52): features [x | time_mlp(map_noise(t)) | obs] -> 3 x (Linear, Mish)
+    """DQLMlp (reference nn_diffusion/dqlmlp.py:9-52) and DVInvMlp (dvinvmlp.py:9-47, same trunk): features [x | time_mlp(map_noise(t)) | obs] -> 3 x (Linear, Mish)
     -> Linear.  The time MLP is batch-invariant, so it runs once per step on a vector and is broadcast into the context."""
     b = _Builder(next(net.parameters()).device)
     d = net.final_layer.out_features
@@ -660,7 +660,8 @@ def compile_dql_mlp(net, tile: int = MLP_TILE, max_lds_bytes: int = 160 * 1024) 
     b.linear(net.time_mlp[2].weight, net.time_mlp[2].bias, v1, v2)
     b.fill(v2, e, ctx, 0)
     m = net.mid_layer
-    m1, m2, m3 = b.act(tile, 256), b.act(tile, 256), b.act(tile, 256)
+    hid = m[0].out_features                               # 256 for DQLMlp, configurable for DVInvMlp
+    m1, m2, m3 = b.act(tile, hid), b.act(tile, hid), b.act(tile, hid)
     b.conv([x, ctx], m1, _lin_eff(m[0]), m[0].bias, act=ACT_MISH)
     b.conv([m1], m2, _lin_eff(m[2]), m[2].bias, act=ACT_MISH)
     b.conv([m2], m3, _lin_eff(m[4]), m[4].bias, act=ACT_MISH)

@@ -96,6 +96,26 @@ class DQLMlp(_ObsConditionedMlp):
         return self.final_layer(self.mid_layer(self._features(x, noise, condition)))
 
 
+class DVInvMlp(_ObsConditionedMlp):
+    """Decision-Veteran inverse-dynamics denoiser (reference nn_diffusion/dvinvmlp.py:9-47): DQLMlp's trunk with a configurable
+    width over features [x | time_mlp(map_noise(t)) | (obs, next_obs)]; the condition is REQUIRED (the reference concatenates it
+    unconditionally).  Same parameter names as DQLMlp, so the batch-tiled MLP program serves it on a ROCm device."""
+
+    def __init__(self, obs_dim: int, act_dim: int, emb_dim: int = 16, hidden_dim: int = 256,
+                 timestep_emb_type: str = "positional", timestep_emb_params: Optional[dict] = None):
+        super().__init__(emb_dim, timestep_emb_type, timestep_emb_params)
+        self.obs_dim = obs_dim * 2
+        self.time_mlp = _time_mlp(emb_dim)
+        self.mid_layer = nn.Sequential(nn.Linear(obs_dim * 2 + act_dim + emb_dim, hidden_dim), nn.Mish(),
+                                       nn.Linear(hidden_dim, hidden_dim), nn.Mish(), nn.Linear(hidden_dim, hidden_dim), nn.Mish())
+        self.final_layer = nn.Linear(hidden_dim, act_dim)
+
+    def forward(self, x: torch.Tensor, noise: torch.Tensor, condition: torch.Tensor = None):
+        if condition is None:
+            raise TypeError("DVInvMlp needs the (obs, next_obs) condition")       # reference: torch.cat fails on None
+        return self.final_layer(self.mid_layer(self._features(x, noise, condition)))
+
+
 class ResidualBlock(nn.Module):
     """x + Linear(Mish(Linear(LayerNorm(Dropout(x)))))  (pre-norm MLP block, 4x expansion)."""
 

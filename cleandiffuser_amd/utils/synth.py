@@ -39,6 +39,8 @@ def synth_state_dict(reference_sd: Dict[str, torch.Tensor], seed: int = 0) -> Di
             out[name] = t.clone()
             continue
         out[name] = torch.from_numpy(_fill(name, tuple(t.shape), seed)).to(dtype=t.dtype)
+        if name.endswith("running_var"):              # BatchNorm statistics must stay a valid variance
+            out[name] = out[name].abs() + 0.5
     return out
 
 

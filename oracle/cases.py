@@ -203,6 +203,25 @@ CASES.update({
         sample=dict(solver="sde_dpmsolver++_1", sample_steps=4, w_cfg=1.0)),
 })
 
+# remaining reference backbones: DVInvMlp runs on the batch-tiled MLP program, the other two on PyTorch
+CASES.update({
+    "dvinv_ddpm": dict(
+        net=("DVInvMlp", dict(obs_dim=7, act_dim=3, emb_dim=16, hidden_dim=128)), x_shape=(3,), batch=6, clip=1.0,
+        cond=("IdentityCondition", dict(dropout=0.0), (14,)),
+        solver=("DiscreteDiffusionSDE", dict(diffusion_steps=10, predict_noise=True)),
+        sample=dict(solver="ddpm", sample_steps=5, w_cfg=1.0)),
+    "sfbc_ode1": dict(
+        net=("SfBCUNet", dict(act_dim=6, emb_dim=32, hidden_dims=[64, 32, 16])), x_shape=(6,), batch=4, clip=2.0,
+        cond=("IdentityCondition", dict(dropout=0.0), (32,)),
+        solver=("ContinuousDiffusionSDE", dict(predict_noise=True)),
+        sample=dict(solver="ode_dpmsolver_1", sample_steps=5, w_cfg=1.3)),
+    "pearcetf_ddim": dict(
+        net=("PearceTransformer", dict(act_dim=4, To=2, emb_dim=32, trans_emb_dim=16, nhead=4)), x_shape=(4,), batch=5,
+        clip=1.0, cond=("IdentityCondition", dict(dropout=0.0), (2, 32)),
+        solver=("DiscreteDiffusionSDE", dict(diffusion_steps=20, predict_noise=False)),
+        sample=dict(solver="ddim", sample_steps=4, w_cfg=1.0)),
+})
+
 # ---- classifier guidance at every step (w_cg > 0: what every shipped Diffuser configuration runs) ----
 CASES.update({
     "janner_cfg2_guided_ddpm": dict(
