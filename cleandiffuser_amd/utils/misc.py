@@ -114,3 +114,32 @@ def dict_apply(x: Dict[str, torch.Tensor], func: Callable[[torch.Tensor], torch.
 def loop_dataloader(dl):
     while True:
         yield from dl
+
+
+def _human(n: int) -> str:
+    return f"{n / 1e6:.2f} M" if n >= 1e6 else f"{n / 1e3:.2f} k"
+
+
+def report_parameters(model, topk: int = 10) -> int:
+    """Print the trainable-parameter total and the `topk` largest tensors with their owning module; return the total
+    (what every reference pipeline prints after building its networks; reference utils/utils.py:355-376)."""
+    sizes = {name: p.numel() for name, p in model.named_parameters() if p.requires_grad}
+    total = sum(sizes.values())
+    print(f"Total parameters: {_human(total)}")
+    owners = dict(model.named_modules())
+    ranked = sorted(sizes, key=lambda k: -sizes[k])
+    for name in ranked[:topk]:
+        print(" " * 8, f"{name:10}: {_human(sizes[name])} | {owners[name.rpartition('.')[0]]}")
+    rest = ranked[topk:]
+    print(" " * 8, f"... and {len(rest)} others accounting for {_human(sum(sizes[k] for k in rest))} parameters")
+    return total
+
+
+# Return normalisers of the Decision-Diffuser pipelines (discount 0.997), keyed by D4RL dataset name (reference utils/utils.py:379-395)
+DD_RETURN_SCALE = {
+    **{f"halfcheetah-{k}-v2": v for k, v in (("medium-expert", 3600), ("medium-replay", 1600), ("medium", 1700))},
+    **{f"hopper-{k}-v2": v for k, v in (("medium-expert", 1200), ("medium-replay", 1000), ("medium", 1000))},
+    **{f"walker2d-{k}-v2": v for k, v in (("medium-expert", 1600), ("medium-replay", 1300), ("medium", 1300))},
+    "kitchen-partial-v0": 470, "kitchen-mixed-v0": 400,
+    **{f"antmaze-{k}-v2": 100 for k in ("medium-play", "medium-diverse", "large-play", "large-diverse")},
+}
