@@ -53,6 +53,10 @@ __device__ __forceinline__ float gm_act(float x, int act) {
             const float u2 = 1.5957691216057308f * (x + 0.044715f * x * x * x);
             return x * __builtin_amdgcn_rcpf(1.0f + __expf(-u2));
         }
+        case CDX_ACT_TANH: {                             // sign(x) (1 - e^{-2|x|}) / (1 + e^{-2|x|}): no overflow, no branches
+            const float t = __expf(-2.0f * fabsf(x));
+            return copysignf((1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t), x);
+        }
         default: return x;
     }
 }
@@ -370,6 +374,7 @@ __global__ __launch_bounds__(GM_THREADS, (WT == 2 ? 3 : 4)) void cdx_gemm_kernel
         case CDX_ACT_SILU: gm_epilogue_any<CDX_ACT_SILU, WT>(g, acc, patch, row0, col0, lane, fe); break;
         case CDX_ACT_RELU: gm_epilogue_any<CDX_ACT_RELU, WT>(g, acc, patch, row0, col0, lane, fe); break;
         case CDX_ACT_GELU_TANH: gm_epilogue_any<CDX_ACT_GELU_TANH, WT>(g, acc, patch, row0, col0, lane, fe); break;
+        case CDX_ACT_TANH: gm_epilogue_any<CDX_ACT_TANH, WT>(g, acc, patch, row0, col0, lane, fe); break;
         default: gm_epilogue_any<CDX_ACT_NONE, WT>(g, acc, patch, row0, col0, lane, fe); break;
     }
     gm_stamp(3);

@@ -79,6 +79,7 @@
 #define CDX_ACT_RELU 5
 #define CDX_ACT_GELU_TANH 6
 #define CDX_ACT_MISH_GRAD 7   /* d mish(x) / dx (elementwise map only: classifier-guidance backward) */
+#define CDX_ACT_TANH 8        /* critic / inverse-dynamics heads */
 #define CDX_NORM_NONE 0
 #define CDX_NORM_SLOT_GROUP 1
 #define CDX_NORM_COLUMN 2

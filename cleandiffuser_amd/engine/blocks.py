@@ -10,7 +10,7 @@ from . import program as P
 from .runtime import _check, _stream_ptr, load_library
 
 ACT = {"none": P.ACT_NONE, "mish": P.ACT_MISH, "gelu": P.ACT_GELU_ERF, "leaky": P.ACT_LEAKY, "silu": P.ACT_SILU,
-       "relu": P.ACT_RELU, "gelu_tanh": P.ACT_GELU_TANH, "mish_grad": P.ACT_MISH_GRAD}
+       "relu": P.ACT_RELU, "gelu_tanh": P.ACT_GELU_TANH, "mish_grad": P.ACT_MISH_GRAD, "tanh": P.ACT_TANH}
 
 
 class CdxGemmArgs(ctypes.Structure):

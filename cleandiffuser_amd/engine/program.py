@@ -57,7 +57,7 @@ L_NIN, L_NOUT, L_SRC, L_DST, L_WOFF, L_BOFF, L_FLAGS, L_DST2 = range(1, 9)
 F_GN_MISH, F_ADD_EMB, F_ADD_RES, F_ACCUM, F_DST_PRED, F_POST_MISH, F_RAW_COPY, F_SCALE, F_KEEP_DST, F_FILM = \
     1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 # activation ids (W_ACT) and normalisation modes (W_NORM: statistics over the whole slot group / per column)
-ACT_NONE, ACT_MISH, ACT_GELU_ERF, ACT_LEAKY, ACT_SILU, ACT_RELU, ACT_GELU_TANH, ACT_MISH_GRAD = range(8)
+ACT_NONE, ACT_MISH, ACT_GELU_ERF, ACT_LEAKY, ACT_SILU, ACT_RELU, ACT_GELU_TANH, ACT_MISH_GRAD, ACT_TANH = range(9)
 NORM_NONE, NORM_SLOT_GROUP, NORM_COLUMN = 0, 1, 2
 
 HALO = 0          # slots carry no halo rows: out-of-range conv taps read a shared all-zero row (Program.zrow_off)

@@ -116,6 +116,14 @@ def loop_dataloader(dl):
         yield from dl
 
 
+TensorDict = Dict[str, Union["TensorDict", torch.Tensor]]
+
+
+def param_to_module(param: str) -> str:
+    """'a.b.weight' -> 'a.b' (owner module path of a parameter name)."""
+    return param.rpartition(".")[0] if "." in param else param
+
+
 def _human(n: int) -> str:
     return f"{n / 1e6:.2f} M" if n >= 1e6 else f"{n / 1e3:.2f} k"
 

@@ -130,7 +130,7 @@ typedef struct cdx_gemm_args {
     float* C;              /* (M, ldc) */
     int32_t M, N, K, lda, ldw, ldc, ldg, ldr;
     int32_t rows_per_gate, table_rows;
-    int32_t act;           /* CDX_ACT_* of csrc/cdx_ops.h: 0 none, 1 mish, 2 gelu(erf), 3 leaky, 4 silu, 5 relu, 6 gelu(tanh) */
+    int32_t act;           /* CDX_ACT_* of csrc/cdx_ops.h: 0 none, 1 mish, 2 gelu(erf), 3 leaky, 4 silu, 5 relu, 6 gelu(tanh), 8 tanh */
     /* Implicit-GEMM Conv1d (conv_taps > 0): A is a channel-last activation tensor, rows = samples * conv_lin, row stride lda;
      * output row m = (b, lo) = (m / conv_lout, m % conv_lout); K = conv_taps * conv_cin with k = tap * conv_cin + c;
      * A[m][k] = X[b * conv_lin + lo * conv_stride + tap - conv_pad][c], zero outside [0, conv_lin).  W is (N, conv_taps, conv_cin).

@@ -72,6 +72,60 @@ def wrapper_outputs(root_pkg):
     return out
 
 
+def _synth(net, salt=5):
+    net.load_state_dict(synth_state_dict(net.state_dict(), salt))
+    net.eval()
+    return net
+
+
+def head_outputs(root_pkg, device="cpu"):
+    """Post-sampling heads: critics, inverse dynamics, transformer toolkit -- outputs on synthetic weights."""
+    import importlib
+    U = importlib.import_module(f"{root_pkg}.utils")
+    I = importlib.import_module(f"{root_pkg}.invdynamic.mlp")
+    n = 9
+
+    def f(name, *shape):
+        return torch.from_numpy(synth_array(f"head/{name}", shape)).to(device)
+    out = {}
+    obs, act, nxt = f("obs", n, 11), f("act", n, 3), f("next", n, 11)
+    with torch.no_grad():
+        c = _synth(U.DQLCritic(11, 3, hidden_dim=64)).to(device)
+        q1, q2 = c(obs, act)
+        out["DQLCritic/q1"], out["DQLCritic/q2"], out["DQLCritic/q_min"] = q1, q2, c.q_min(obs, act)
+        out["DQLCritic/q1_only"] = c.q1(obs, act)
+        tq = _synth(U.TwinQ(11, 3, hidden_dim=48)).to(device)
+        out["TwinQ/q1"], out["TwinQ/q2"] = tq.both(obs, act)
+        out["TwinQ/min"] = tq(obs, act)
+        out["V"] = _synth(U.V(11, hidden_dim=48)).to(device)(obs)
+        iql = _synth(U.IQL(11, 3, hidden_dim=32)).to(device)
+        out["IQL/q_targ"], out["IQL/v"] = iql.Q_targ(obs, act), iql.V(obs)
+        traj = f("traj", 4, 6, 5)
+        for norm in ("post", "pre"):
+            out[f"DVHorizonCritic/{norm}"] = _synth(U.DVHorizonCritic(5, 16, d_model=32, n_heads=4, depth=2, norm_type=norm)).to(device)(traj)
+        tr = _synth(U.Transformer(32, 4, 2, bias=True)).to(device)
+        tok = f("tok", 3, 6, 32)
+        y, maps = tr(tok, mask=U.generate_causal_mask(6, device))
+        out["Transformer/y"], out["Transformer/map1"] = y, maps[1]
+        out["SoftBounds"] = torch.stack([U.SoftLowerBound(-0.3)(obs), U.SoftUpperBound(0.4)(obs)])
+    heads = {"MlpInvDynamic": I.MlpInvDynamic(11, 3, hidden_dim=64, device=device),
+             "MlpInvDynamic/identity": I.MlpInvDynamic(11, 3, hidden_dim=40, out_activation=torch.nn.Identity(), device=device),
+             "FancyMlpInvDynamic": I.FancyMlpInvDynamic(11, 3, hidden_dim=64, add_norm=True, add_dropout=True, device=device),
+             "FancyMlpInvDynamic/plain": I.FancyMlpInvDynamic(11, 3, hidden_dim=32, device=device),
+             "EnsembleMlpInvDynamic": I.EnsembleMlpInvDynamic(11, 3, hidden_dim=32, n_models=3, device=device),
+             "EnsembleMlpInvDynamic/fancy": I.EnsembleMlpInvDynamic(11, 3, hidden_dim=32, n_models=2, mlp_type="fancy", device=device),
+             "ResInvDynamic": I.ResInvDynamic(11, 3, hidden_dim=32, add_norm=True, add_dropout=True, n_blocks=2, device=device)}
+    for name, h in heads.items():
+        net = h.mlp if hasattr(h, "mlp") else h.model
+        net.load_state_dict({k: v.to(device) for k, v in synth_state_dict(net.state_dict(), 9).items()})
+        h.eval()
+        out[name] = h(obs, nxt)
+        if name.startswith("Ensemble"):
+            with torch.no_grad():
+                out[name + "/idx1"] = h.forward(obs, nxt, 1)
+    return {k: v.detach().cpu().numpy() for k, v in out.items()}
+
+
 def main(path="tests/golden/modules.npz"):
     from .ref_import import import_reference
     import_reference()
@@ -82,6 +136,9 @@ def main(path="tests/golden/modules.npz"):
             out[name] = net(*args).numpy()
         print(f"{name:20s} out{out[name].shape} |y|max={np.abs(out[name]).max():.3f}")
     out.update(wrapper_outputs("cleandiffuser"))
+    heads = head_outputs("cleandiffuser")
+    print("heads:", ", ".join(sorted(heads)))
+    out.update({f"head/{k}": v for k, v in heads.items()})
     np.savez_compressed(path, **out)
 
 

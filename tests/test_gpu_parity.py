@@ -496,3 +496,48 @@ def test_bigbatch_full_size_properties(which, B, amd_lib):
     two = slice(B // 2 + 3, B // 2 + 5)
     x_cpu = run(make("cpu"), two, "cpu")
     np.testing.assert_allclose(x1[two].cpu().numpy(), x_cpu.numpy(), rtol=1e-4, atol=1e-4 * scale)
+
+
+@pytest.mark.gpu
+def test_post_sampling_heads_run_native_and_match_reference(amd_lib, monkeypatch):
+    """Critics / inverse-dynamics heads on the device: every Sequential goes through engine/heads.py (counted),
+    results equal the reference's CPU outputs; tanh / LayerNorm-as-GroupNorm(L=1,G=1) paths included."""
+    from cleandiffuser_amd.engine import heads
+    from oracle import gen_module_golden as G
+    calls = {"n": 0, "eager": 0}
+    real = heads.try_sequential
+
+    def counted(seq, x):
+        y = real(seq, x)
+        calls["n" if y is not None else "eager"] += 1
+        return y
+    monkeypatch.setattr(heads, "try_sequential", counted)
+    gold = np.load(golden_path("modules"))
+    out = G.head_outputs("cleandiffuser_amd", device="cuda")
+    for k, v in out.items():
+        np.testing.assert_allclose(v, gold[f"head/{k}"], rtol=1e-4, atol=2e-5, err_msg=k)
+    assert calls["eager"] == 0 and calls["n"] >= 25, calls
+
+
+@pytest.mark.gpu
+def test_heads_at_candidate_batch(amd_lib):
+    """IDQL-style re-weighting at pipeline scale: 256 states x 64 candidates through TwinQ/V and the inverse-dynamics head,
+    against the same modules run by PyTorch on the device (fp32, 1e-4)."""
+    from cleandiffuser_amd.invdynamic import MlpInvDynamic
+    from cleandiffuser_amd.utils import DQLCritic, TwinQ, V, load_synth
+    torch.manual_seed(0)
+    n, o, a = 256 * 64, 17, 6
+    obs, act, nxt = torch.randn(n, o, device="cuda"), torch.randn(n, a, device="cuda"), torch.randn(n, o, device="cuda")
+    q, v, c = load_synth(TwinQ(o, a)).cuda().eval(), load_synth(V(o)).cuda().eval(), load_synth(DQLCritic(o, a)).cuda().eval()
+    inv = MlpInvDynamic(o, a, device="cuda")
+    inv.eval()
+    with torch.no_grad():
+        got = [q(obs, act), v(obs), c.q_min(obs, act), inv(obs, nxt)]
+        x = torch.cat([obs, act], -1)
+        want = [torch.min(q.Q1(x), q.Q2(x)), v.V(obs), torch.min(c.q1_model(x), c.q2_model(x)), inv.mlp.mlp(torch.cat([obs, nxt], -1))]
+    for g, w in zip(got, want):
+        assert g.shape == w.shape
+        np.testing.assert_allclose(g.cpu().numpy(), w.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    adv = got[0] - got[1]
+    idx = torch.multinomial(torch.softmax(adv.view(256, 64) * 3.0, -1), 1)         # selection stays on the device
+    assert idx.shape == (256, 1) and idx.is_cuda

@@ -22,3 +22,33 @@ def test_classifier_wrappers_match_reference():
     out = G.wrapper_outputs("cleandiffuser_amd")
     for k, v in out.items():
         np.testing.assert_allclose(v, gold[k], rtol=2e-5, atol=2e-6, err_msg=k)
+
+
+def test_post_sampling_heads_match_reference():
+    """Critics, inverse dynamics, transformer toolkit on CPU against the reference's outputs."""
+    gold = np.load(golden_path("modules"))
+    out = G.head_outputs("cleandiffuser_amd")
+    assert {f"head/{k}" for k in out} == {k for k in gold.files if k.startswith("head/")}
+    for k, v in out.items():
+        np.testing.assert_allclose(v, gold[f"head/{k}"], rtol=2e-6, atol=2e-6, err_msg=k)
+
+
+def test_head_chain_compiler_covers_every_head():
+    """engine/heads.py must understand every Sequential the heads are made of (otherwise the GPU path silently runs eager)."""
+    import torch.nn as nn
+    from cleandiffuser_amd.engine import heads
+    from cleandiffuser_amd.invdynamic.mlp import EnsembleMlpInvDynamic, FancyMlpInvDynamic, MlpInvDynamic
+    from cleandiffuser_amd.utils import DQLCritic, TwinQ, V
+    seqs = [DQLCritic(5, 2, 16).q1_model, TwinQ(5, 2, 16).Q2, V(5, 16).V, MlpInvDynamic(5, 2, 16).mlp.mlp,
+            FancyMlpInvDynamic(5, 2, 16, add_norm=True, add_dropout=True).model.eval(),
+            EnsembleMlpInvDynamic(5, 2, 16, n_models=2, mlp_type="fancy").mlp[0].eval()]
+    for s in seqs:
+        ops = heads.compile_chain(s)
+        assert ops is not None
+        assert sum(o[0] == "linear" for o in ops) == sum(isinstance(m, nn.Linear) for m in s.modules())
+        assert not any(o[0] == "act" for o in ops), "every activation should fuse into the launch before it"
+    ops = heads.compile_chain(DQLCritic(5, 2, 16).q1_model)
+    assert [o[0] for o in ops] == ["linear", "norm"] * 3 + ["linear"] and [o[2] for o in ops[1::2]] == ["tanh", "mish", "mish"]
+    fancy = FancyMlpInvDynamic(5, 2, 16, add_dropout=True).model.train()
+    assert heads.compile_chain(fancy) is None            # active dropout: stock modules
+    assert heads.compile_chain(nn.Sequential(nn.Linear(3, 3), nn.Softplus())) is None
