@@ -1,0 +1,3 @@
+"""Module-path alias: reference nn_diffusion/idqlmlp.py (implementation in mlp_backbones.py)."""
+from .base_nn_diffusion import BaseNNDiffusion  # noqa: F401
+from .mlp_backbones import IDQLMlp, NewIDQLMlp, ResidualBlock  # noqa: F401
