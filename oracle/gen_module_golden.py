@@ -126,6 +126,27 @@ def head_outputs(root_pkg, device="cpu"):
     return {k: v.detach().cpu().numpy() for k, v in out.items()}
 
 
+def edm_variant_outputs(root_pkg):
+    """VPODE / VEODE / EDMDDIM: sampling tables, preconditioning hooks and the training loss under a fixed seed.  (Their
+    ``sample()`` raises IndexError in the reference -- N-entry tables indexed at N -- which the caller checks separately.)"""
+    import importlib
+    N = importlib.import_module(f"{root_pkg}.nn_diffusion")
+    out = {}
+    for mod, cls in (("vpode", "VPODE"), ("veode", "VEODE"), ("edmddim", "EDMDDIM")):
+        C = getattr(importlib.import_module(f"{root_pkg}.diffusion.{mod}"), cls)
+        net = N.DQLMlp(5, 3, emb_dim=16, timestep_emb_type="fourier")
+        net.load_state_dict(synth_state_dict(net.state_dict(), 3))
+        agent = C(net, None, diffusion_steps=50)
+        agent.set_sample_steps(7)
+        out[f"{cls}/tables"] = torch.stack([agent.t_s, agent.sigma_s, agent.scale_s, agent.x_weight_s, agent.D_weight_s]).numpy()
+        sig = torch.tensor([0.3, 1.2, 5.0])
+        out[f"{cls}/hooks"] = torch.stack([agent.c_skip(sig), agent.c_out(sig), agent.c_in(sig), agent.c_noise(sig).float(),
+                                           agent.loss_weighting(sig)]).numpy()
+        torch.manual_seed(1)
+        out[f"{cls}/loss"] = np.float32(agent.loss(torch.from_numpy(synth_array("mod/edmvar/x0", (6, 3)))).item())
+    return out
+
+
 def main(path="tests/golden/modules.npz"):
     from .ref_import import import_reference
     import_reference()
@@ -139,6 +160,7 @@ def main(path="tests/golden/modules.npz"):
     heads = head_outputs("cleandiffuser")
     print("heads:", ", ".join(sorted(heads)))
     out.update({f"head/{k}": v for k, v in heads.items()})
+    out.update({f"edmvar/{k}": v for k, v in edm_variant_outputs("cleandiffuser").items()})
     np.savez_compressed(path, **out)
 
 

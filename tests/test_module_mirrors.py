@@ -52,3 +52,18 @@ def test_head_chain_compiler_covers_every_head():
     fancy = FancyMlpInvDynamic(5, 2, 16, add_dropout=True).model.train()
     assert heads.compile_chain(fancy) is None            # active dropout: stock modules
     assert heads.compile_chain(nn.Sequential(nn.Linear(3, 3), nn.Softplus())) is None
+
+
+def test_edm_variants_match_reference():
+    """VPODE / VEODE / EDMDDIM: tables, preconditioning, loss equal to the reference; sample() fails the way the reference's does."""
+    import torch
+    gold = np.load(golden_path("modules"))
+    out = G.edm_variant_outputs("cleandiffuser_amd")
+    for k, v in out.items():
+        np.testing.assert_allclose(v, gold[f"edmvar/{k}"], rtol=1e-6, atol=1e-7, err_msg=k)
+    from cleandiffuser_amd.diffusion.veode import VEODE
+    from cleandiffuser_amd.nn_diffusion import DQLMlp
+    agent = VEODE(DQLMlp(5, 3, emb_dim=16), None, diffusion_steps=50)
+    agent.eval()
+    with pytest.raises(IndexError):
+        agent.sample(torch.zeros(4, 3), solver="euler", n_samples=4, sample_steps=6)
