@@ -103,6 +103,19 @@ def cpu_baseline_subprocess(timeout_s=180):
                 "sample": f"cpu baseline leg failed or exceeded {timeout_s}s: {type(e).__name__}"}
 
 
+def recorded_traffic():
+    """HBM-side bytes per launch of the fused kernel from the committed PMC pass (rocprofv3 --pmc cannot run inside this
+    process); null when the record is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        return {"traffic": rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"], "traffic_unit": "bytes/launch",
+                "traffic_source": "profiles/r01_pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE pass, gfx950-corrected)"}
+    except (OSError, KeyError, ValueError):
+        return {"traffic": None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,7 +199,7 @@ def main():
                        "batch_per_gpu": BATCH, "global_batch": BATCH * world, "horizon": HORIZON, "dim": DIM,
                        "sample_steps": SAMPLE_STEPS, "parallelism": f"batch-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, **recorded_traffic(),
                          "kernel": "cdx_unet1d_kernel", "kernel_ms": k_ms, "launches_timed": len(kernel_ms),
                          "flops_per_launch": flops_per_traj * BATCH},
         }
