@@ -1,7 +1,8 @@
 """Condition-encoder plug-in base (contract: reference nn_condition/base_nn_condition.py:7-57).
 
 Condition encoders run ONCE per ``sample()`` / ``loss()`` call (reference diffusionsde.py:499), never
-inside the denoising loop, so they stay ordinary PyTorch modules on whatever device the solver owns.
+inside the denoising loop; user-defined ones are ordinary PyTorch modules on whatever device the solver owns, the
+built-in Linear / MLP ones (mlp.py) route their matmuls through the HIP library while sampling.
 ``forward(condition, mask=None) -> (b, *cond_out_shape)``; in train mode a Bernoulli label-dropout
 mask is drawn, in eval mode ``mask=None`` means "keep everything".
 """

@@ -1,6 +1,9 @@
 """Low-dimensional condition encoders (reference nn_condition/mlp.py:10-92, pearce_obs_condition.py:10-50,
 positional.py:8-54).  Parameter names (``affine``, ``mlp.mlp.{i}.0``, ``mlp.{0,2}``, ``freqs``) match the
-reference checkpoints."""
+reference checkpoints.
+
+Execution: the Linear / activation chains run through engine/heads.py (``cdx_gemm_f32`` with bias + activation in the epilogue)
+on a ROCm device when no gradient is needed -- i.e. inside ``sample()`` -- and as stock modules otherwise (training, CPU)."""
 from typing import List, Optional
 
 import numpy as np
@@ -11,6 +14,12 @@ from ..utils import Mlp
 from .base_nn_condition import IdentityCondition
 
 
+def _rows(net: nn.Module, x: torch.Tensor) -> torch.Tensor:
+    from ..engine import heads
+    y = heads.try_sequential(net.mlp if isinstance(net, Mlp) else net, x)
+    return net(x) if y is None else y
+
+
 class LinearCondition(IdentityCondition):
     def __init__(self, in_dim: int, out_dim: int, dropout: float = 0.25):
         super().__init__(dropout)
@@ -18,7 +27,7 @@ class LinearCondition(IdentityCondition):
 
     def forward(self, condition: torch.Tensor, mask: torch.Tensor = None):
         m = self._mask(mask, condition.shape[0], condition.device, condition.dim())
-        return self.affine(condition) * m
+        return _rows(self.affine, condition) * m
 
 
 class MLPCondition(IdentityCondition):
@@ -28,7 +37,7 @@ class MLPCondition(IdentityCondition):
 
     def forward(self, condition: torch.Tensor, mask: torch.Tensor = None):
         m = self._mask(mask, condition.shape[0], condition.device, condition.dim())
-        return self.mlp(condition) * m
+        return _rows(self.mlp, condition) * m
 
 
 class MLPSieveObsCondition(IdentityCondition):
@@ -40,7 +49,7 @@ class MLPSieveObsCondition(IdentityCondition):
 
     def forward(self, obs: torch.Tensor, mask: torch.Tensor = None):
         m = self._mask(mask, obs.shape[0], obs.device, 2)
-        return torch.flatten(self.mlp(obs), 1) * m
+        return torch.flatten(_rows(self.mlp, obs), 1) * m
 
 
 class PearceObsCondition(IdentityCondition):
@@ -53,7 +62,7 @@ class PearceObsCondition(IdentityCondition):
 
     def forward(self, obs: torch.Tensor, mask: Optional[torch.Tensor] = None):
         m = self._mask(mask, obs.shape[0], obs.device, 2 if self.flatten else 3)
-        e = self.mlp(obs)
+        e = _rows(self.mlp, obs)
         return (torch.flatten(e, 1) if self.flatten else e) * m
 
 

@@ -541,3 +541,41 @@ def test_heads_at_candidate_batch(amd_lib):
     adv = got[0] - got[1]
     idx = torch.multinomial(torch.softmax(adv.view(256, 64) * 3.0, -1), 1)         # selection stays on the device
     assert idx.shape == (256, 1) and idx.is_cuda
+
+
+@pytest.mark.gpu
+def test_condition_encoders_run_native(amd_lib, monkeypatch):
+    """The built-in low-dim condition encoders go through engine/heads.py while sampling (eval, no grad) -- including
+    the K = 1 first layer of Decision Diffuser's return encoder -- and equal the same modules on CPU."""
+    from cleandiffuser_amd import nn_condition as NC
+    from cleandiffuser_amd.engine import heads
+    from cleandiffuser_amd.utils import load_synth
+    calls = {"n": 0, "eager": 0}
+    real = heads.try_sequential
+
+    def counted(seq, x):
+        y = real(seq, x)
+        if x.is_cuda:
+            calls["n" if y is not None else "eager"] += 1
+        return y
+    monkeypatch.setattr(heads, "try_sequential", counted)
+    torch.manual_seed(0)
+    cases = [(NC.MLPCondition(1, 128, [128], torch.nn.SiLU(), 0.25), torch.rand(37, 1)),
+             (NC.MLPCondition(11, 64, [96, 48]), torch.randn(300, 11)),
+             (NC.LinearCondition(9, 32), torch.randn(5, 9)),
+             (NC.MLPSieveObsCondition(7, emb_dim=16, hidden_dim=64), torch.randn(6, 3, 7)),
+             (NC.PearceObsCondition(17, 64, flatten=True, dropout=0.0), torch.randn(256, 1, 17)),
+             (NC.PearceObsCondition(5, 32, flatten=False), torch.randn(4, 2, 5)),
+             (NC.FourierCondition(32, 64), torch.rand(8, 1)),
+             (NC.PositionalCondition(32, 32), torch.rand(8))]
+    for enc, c in cases:
+        enc = load_synth(enc).eval()
+        with torch.no_grad():
+            want = enc(c)
+            got = enc.cuda()(c.cuda())
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-5, err_msg=type(enc).__name__)
+    assert calls == {"n": len(cases), "eager": 0}, calls
+    enc = cases[0][0].train()                                  # training: label-dropout mask + autograd -> stock modules
+    out = enc(cases[0][1].cuda())
+    assert out.requires_grad and calls["eager"] == 1
