@@ -659,8 +659,9 @@ __global__ __launch_bounds__(64) void cdx_attention_kernel(const cdx_attn_args a
 //                   A operand reads V[j][d] from LDS in that same order, so the probabilities never move.
 // DB = number of 32-wide blocks of the (zero-padded) head dimension.
 // ------------------------------------------------------------------------------------------------
-template <int DB>
+template <int DB, int TB>
 __global__ __launch_bounds__(256) void cdx_attention_mfma_kernel(const cdx_attn_args a) {
+    constexpr int TP = 32 * TB;                          // padded token count
     constexpr int DHP = 32 * DB, LD = DHP + 1;
     extern __shared__ float att_lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -668,14 +669,14 @@ __global__ __launch_bounds__(256) void cdx_attention_mfma_kernel(const cdx_attn_
     if (pair >= a.B * a.n_heads) return;                 // waves are independent (no barriers below)
     const int b = pair / a.n_heads, h = pair - b * a.n_heads;
     const int dh = a.head_dim, dm = a.n_heads * dh, T = a.T;
-    float* Ks = att_lds + (size_t)wave * (2 * 64 * LD);
-    float* QVs = Ks + 64 * LD;
+    float* Ks = att_lds + (size_t)wave * (2 * TP * LD);
+    float* QVs = Ks + TP * LD;
     const float* base = a.qkv + (size_t)b * T * (3 * dm) + h * dh;
     const int lr = lane & 31, lk = lane >> 5;
 
     // global -> registers -> LDS with every load of a matrix in flight at once (a load-use-per-iteration loop costs one
     // memory round trip per 64 floats and made this kernel latency bound); 8*DB lanes cover one padded token row.
-    constexpr int NV = 64 * DHP / 4 / 64;                // float4 per lane per matrix
+    constexpr int NV = TP * DHP / 4 / 64;                // float4 per lane per matrix
     auto load_mat = [&](float4 (&reg)[NV], int which, float mul) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -700,31 +701,35 @@ __global__ __launch_bounds__(256) void cdx_attention_mfma_kernel(const cdx_attn_
     load_mat(rv, 2, 1.0f);                               // V is needed last: its latency hides under the S^T MFMAs
     park(Ks, rk);
     park(QVs, rq);
-    f32x16 s[2][2];                                      // [query block][key block]
+    f32x16 s[TB][TB];                                    // [query block][key block]
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < TB; ++q)
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
+        for (int k = 0; k < TB; ++k)
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[q][k][r] = 0.f;
 #pragma unroll 4
     for (int st = 0; st < DHP / 2; ++st) {
         const int d = 2 * st + lk;
-        const float k0 = Ks[lr * LD + d], k1 = Ks[(32 + lr) * LD + d];
-        const float q0 = QVs[lr * LD + d], q1 = QVs[(32 + lr) * LD + d];
-        s[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(k0, q0, s[0][0], 0, 0, 0);
-        s[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(k1, q0, s[0][1], 0, 0, 0);
-        s[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(k0, q1, s[1][0], 0, 0, 0);
-        s[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(k1, q1, s[1][1], 0, 0, 0);
+        float kk[TB], qq[TB];
+#pragma unroll
+        for (int i = 0; i < TB; ++i) {
+            kk[i] = Ks[(32 * i + lr) * LD + d];
+            qq[i] = QVs[(32 * i + lr) * LD + d];
+        }
+#pragma unroll
+        for (int q = 0; q < TB; ++q)
+#pragma unroll
+            for (int k = 0; k < TB; ++k) s[q][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk[k], qq[q], s[q][k], 0, 0, 0);
     }
     // V replaces Q in LDS (same wave: LDS operations retire in order, the reads above are done before these writes land)
     park(QVs, rv);
-    float inv_den[2];
+    float inv_den[TB];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < TB; ++q) {
         float mx = -3.0e38f;
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
+        for (int k = 0; k < TB; ++k)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int j = k * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
@@ -736,7 +741,7 @@ __global__ __launch_bounds__(256) void cdx_attention_mfma_kernel(const cdx_attn_
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         float den = 0.f;
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
+        for (int k = 0; k < TB; ++k)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int j = k * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
@@ -747,28 +752,28 @@ __global__ __launch_bounds__(256) void cdx_attention_mfma_kernel(const cdx_attn_
         den += __shfl_xor(den, 32, 64);
         inv_den[q] = 1.0f / den;
     }
-    f32x16 o[2][DB];
+    f32x16 o[TB][DB];
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < TB; ++q)
 #pragma unroll
         for (int db = 0; db < DB; ++db)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[q][db][r] = 0.f;
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < TB; ++k)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int j = k * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
                 const float v = QVs[j * LD + db * 32 + lr];
-                o[0][db] = __builtin_amdgcn_mfma_f32_32x32x2f32(v, s[0][k][r], o[0][db], 0, 0, 0);
-                o[1][db] = __builtin_amdgcn_mfma_f32_32x32x2f32(v, s[1][k][r], o[1][db], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < TB; ++q) o[q][db] = __builtin_amdgcn_mfma_f32_32x32x2f32(v, s[q][k][r], o[q][db], 0, 0, 0);
             }
         }
     // O^T fragment: column = query lr of block q, rows d = db*32 + (r & 3) + 8 (r >> 2) + 4 lk -> four float4 per block
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < TB; ++q) {
         const int tok = q * 32 + lr;
         if (tok >= T) continue;
         float* op = a.out + ((size_t)b * T + tok) * dm + h * dh;
@@ -832,6 +837,59 @@ __global__ __launch_bounds__(256) void cdx_cross_attention_kernel(const cdx_xatt
             if (s < S) acc = fmaf(sc[s], kv[s][dm + d], acc);
         o[d] = acc * inv;
     }
+}
+
+// Coalesced variant (head_dim = 4 * GL, GL a power of two): GL adjacent lanes own one (row, head), each lane one float4 of the
+// head -- q and out move as contiguous 16-byte lane accesses (the scalar kernel above reads a 1-KiB-strided row per thread
+// and ran at ~0.3 TB/s); scores are reduced across the GL lanes with xor shuffles, the T rows of a sample hit the same K/V lines.
+template <int GL>
+__global__ __launch_bounds__(256) void cdx_cross_attention_vec_kernel(const cdx_xattn_args a) {
+    const int dh = 4 * GL, dm = a.n_heads * dh, S = 1 + a.n_obs, cpr = dm >> 2;          // float4 chunks per row
+    const long long rows = (long long)a.B * a.T;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    long long r = idx / cpr;
+    const int c = (int)(idx - r * cpr);
+    const bool live = r < rows;                     // a (row, head) group is live or dead as a whole: shuffles stay uniform
+    if (!live) r = rows - 1;
+    const int b = (int)(r / a.T), t = (int)(r - (long long)b * a.T);
+    const int d0 = c * 4;
+    const float4 q = *reinterpret_cast<const float4*>(a.q + (size_t)r * dm + d0);
+    const float* kvs = a.kv_shared + (size_t)(a.shared_per_sample ? b : a.shared_row) * (2 * dm) + d0;
+    const float* kvr = a.n_obs > 0 ? a.kv_rows + (size_t)b * a.n_obs * (2 * dm) + d0 : kvs;
+    float sc[XA_MAX_S];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int s = 0; s < XA_MAX_S; ++s) {
+        float p = -3.0e38f;
+        if (s < S) {
+            const float4 k = *reinterpret_cast<const float4*>(s == 0 ? kvs : kvr + (size_t)(s - 1) * (2 * dm));
+            p = fmaf(q.x, k.x, fmaf(q.y, k.y, fmaf(q.z, k.z, q.w * k.w)));
+#pragma unroll
+            for (int o = GL / 2; o >= 1; o >>= 1) p += __shfl_xor(p, o, 64);
+            p *= a.scale;
+            if (a.mask) p += a.mask[t * S + s];
+            p = fmaxf(p, -3.0e38f);
+        }
+        sc[s] = p;
+        mx = fmaxf(mx, p);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int s = 0; s < XA_MAX_S; ++s) {
+        sc[s] = s < S ? expf(sc[s] - mx) : 0.f;
+        den += sc[s];
+    }
+    const float inv = 1.0f / den;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int s = 0; s < XA_MAX_S; ++s)
+        if (s < S) {
+            const float4 v = *reinterpret_cast<const float4*>((s == 0 ? kvs : kvr + (size_t)(s - 1) * (2 * dm)) + dm);
+            acc.x = fmaf(sc[s], v.x, acc.x); acc.y = fmaf(sc[s], v.y, acc.y);
+            acc.z = fmaf(sc[s], v.z, acc.z); acc.w = fmaf(sc[s], v.w, acc.w);
+        }
+    if (live)
+        *reinterpret_cast<float4*>(a.out + (size_t)r * dm + d0) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -970,15 +1028,21 @@ int cdx_attention_f32(const cdx_attn_args* a, void* hip_stream) {
     const int dm = a->n_heads * a->head_dim;
     if (a->head_dim % 4 == 0 && dm % 4 == 0 && ((uintptr_t)a->out % 16) == 0) {      // MFMA path, one wave per (batch, head)
         const int pairs = a->B * a->n_heads, grid = (pairs + 3) / 4;
-        if (a->head_dim <= 32) {
-            hipLaunchKernelGGL(cdx_attention_mfma_kernel<1>, dim3(grid), dim3(256), 4 * 2 * 64 * 33 * sizeof(float), st, *a);
-        } else {
-            static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(&cdx_attention_mfma_kernel<2>),
-                                                            hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                            4 * 2 * 64 * 65 * sizeof(float)) == hipSuccess;
-            (void)big_lds;
-            hipLaunchKernelGGL(cdx_attention_mfma_kernel<2>, dim3(grid), dim3(256), 4 * 2 * 64 * 65 * sizeof(float), st, *a);
-        }
+        // <head-dim blocks, token blocks>: T <= 32 runs the single-block variant (a quarter of the MFMAs, half the LDS)
+        const int tb = a->T <= 32 ? 1 : 2, db = a->head_dim <= 32 ? 1 : 2;
+        static bool lds_raised[2][2] = {{false, false}, {false, false}};
+        auto launch = [&](auto kern, size_t lds) {
+            if (lds > 48 * 1024 && !lds_raised[db - 1][tb - 1]) {
+                lds_raised[db - 1][tb - 1] = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+            }
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, *a);
+        };
+        const size_t lds = (size_t)4 * 2 * (32 * tb) * (32 * db + 1) * sizeof(float);
+        if (db == 1 && tb == 1) launch(cdx_attention_mfma_kernel<1, 1>, lds);
+        else if (db == 1) launch(cdx_attention_mfma_kernel<1, 2>, lds);
+        else if (tb == 1) launch(cdx_attention_mfma_kernel<2, 1>, lds);
+        else launch(cdx_attention_mfma_kernel<2, 2>, lds);
     } else {
         hipLaunchKernelGGL(cdx_attention_kernel, dim3(a->B * a->n_heads), dim3(64), 0, st, *a);
     }
@@ -994,9 +1058,25 @@ int cdx_cross_attention_f32(const cdx_xattn_args* a, void* hip_stream) {
     }
     if (a->B == 0) return CDX_OK;
     if (!a->q || !a->kv_shared || !a->out || (a->n_obs > 0 && !a->kv_rows)) { cdx_set_err("cdx_cross_attention_f32: null pointer"); return CDX_EINVAL; }
-    const long long total = (long long)a->B * a->n_heads * a->T;
-    hipLaunchKernelGGL(cdx_cross_attention_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(hip_stream), *a);
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    const int gl = a->head_dim / 4;
+    const bool aligned = (((uintptr_t)a->q | (uintptr_t)a->out | (uintptr_t)a->kv_shared | (uintptr_t)a->kv_rows) % 16) == 0;
+    if (aligned && a->head_dim % 4 == 0 && gl <= 64 && (gl & (gl - 1)) == 0) {
+        const long long lanes = (long long)a->B * a->T * a->n_heads * gl;
+        const dim3 grid((unsigned)((lanes + 255) / 256));
+        switch (gl) {
+            case 1: hipLaunchKernelGGL(cdx_cross_attention_vec_kernel<1>, grid, dim3(256), 0, st, *a); break;
+            case 2: hipLaunchKernelGGL(cdx_cross_attention_vec_kernel<2>, grid, dim3(256), 0, st, *a); break;
+            case 4: hipLaunchKernelGGL(cdx_cross_attention_vec_kernel<4>, grid, dim3(256), 0, st, *a); break;
+            case 8: hipLaunchKernelGGL(cdx_cross_attention_vec_kernel<8>, grid, dim3(256), 0, st, *a); break;
+            case 16: hipLaunchKernelGGL(cdx_cross_attention_vec_kernel<16>, grid, dim3(256), 0, st, *a); break;
+            case 32: hipLaunchKernelGGL(cdx_cross_attention_vec_kernel<32>, grid, dim3(256), 0, st, *a); break;
+            default: hipLaunchKernelGGL(cdx_cross_attention_vec_kernel<64>, grid, dim3(256), 0, st, *a); break;
+        }
+    } else {
+        const long long total = (long long)a->B * a->n_heads * a->T;
+        hipLaunchKernelGGL(cdx_cross_attention_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, *a);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
     return CDX_OK;

@@ -31,7 +31,7 @@ def test_gemm_asymmetric_identity_catches_transposes():
     torch.testing.assert_close(out.cpu(), w.t().contiguous(), rtol=0, atol=1e-6)
 
 
-@pytest.mark.parametrize("act", ["none", "mish", "gelu", "gelu_tanh", "silu", "leaky", "relu"])
+@pytest.mark.parametrize("act", ["none", "mish", "gelu", "gelu_tanh", "silu", "leaky", "relu", "tanh"])
 def test_gemm_fused_epilogue(act):
     from cleandiffuser_amd.engine import blocks
     g = torch.Generator().manual_seed(3)
@@ -42,7 +42,7 @@ def test_gemm_fused_epilogue(act):
                         residual=res.to(DEV), table=tab.to(DEV))
     y = F.linear(_ref(a), _ref(w), _ref(b))
     fn = {"none": lambda v: v, "mish": F.mish, "gelu": F.gelu, "gelu_tanh": lambda v: F.gelu(v, approximate="tanh"),
-          "silu": F.silu, "leaky": lambda v: F.leaky_relu(v, 0.01), "relu": F.relu}[act]
+          "silu": F.silu, "leaky": lambda v: F.leaky_relu(v, 0.01), "relu": F.relu, "tanh": torch.tanh}[act]
     ref = fn(y) * _ref(gate).repeat_interleave(T, 0) + _ref(res) + _ref(tab).repeat(B, 1)
     torch.testing.assert_close(out.cpu().double(), ref, rtol=2e-5, atol=2e-5)
 
@@ -101,7 +101,9 @@ def test_attention_with_additive_mask(tokens, heads, dh):
     torch.testing.assert_close(out.cpu().double(), ref, rtol=2e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize("tokens,n_obs,heads,dh,per_sample", [(16, 2, 4, 64, False), (12, 3, 4, 16, True), (5, 0, 2, 8, False)])
+@pytest.mark.parametrize("tokens,n_obs,heads,dh,per_sample", [(16, 2, 4, 64, False), (12, 3, 4, 16, True), (5, 0, 2, 8, False),
+                                                              (16, 15, 2, 4, False), (7, 2, 3, 6, True), (3, 1, 1, 256, False),
+                                                              (33, 4, 5, 128, True), (1, 0, 7, 32, False)])
 def test_cross_attention_against_short_memory(tokens, n_obs, heads, dh, per_sample):
     from cleandiffuser_amd.engine import blocks
     g = torch.Generator().manual_seed(tokens * 3 + n_obs)

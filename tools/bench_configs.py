@@ -118,11 +118,11 @@ def cfg2big(B=3200):
     return f"config 2 network, 20-step DDIM, B={B}", call, B, 2.0 * 19.67e6 * 20 * B
 
 
-def cfgT(B=1024):
+def cfgT(B=1024, steps=100):
     """Diffusion Policy's transformer (dp_pusht): ChiTransformer d_model 256, 4 heads, 8 decoder layers, Ta=16, To=2, obs 20;
     100-step DDPM over DiscreteDiffusionSDE, conditional (w_cfg = 1)."""
     from cleandiffuser_amd.nn_diffusion import ChiTransformer
-    Ta, A, d, L, steps = 16, 2, 256, 8, 100
+    Ta, A, d, L = 16, 2, 256, 8
     net = load_synth(ChiTransformer(A, 20, Ta, 2, d_model=d, nhead=4, num_layers=L))
     one = torch.ones(1, Ta, A)
     agent = DiscreteDiffusionSDE(net, IdentityCondition(dropout=0.0), predict_noise=True, x_max=one, x_min=-one,
@@ -133,7 +133,7 @@ def cfgT(B=1024):
     call = lambda: agent.sample(torch.zeros(B, Ta, A, device=DEV), solver="ddpm", n_samples=B, sample_steps=steps,  # noqa: E731
                                 condition_cfg=obs, w_cfg=1.0, noise=zs)[0]
     tok = A * d + L * (3 * d * d + d * d + d * d + d * d + 8 * d * d) + L * (2 * Ta * d + 2 * 3 * d) + d * A     # MACs per token
-    return f"ChiTransformer dp_pusht d=256 h=4 L=8, Ta=16, 100-step DDPM, B={B}", call, B, 2.0 * tok * Ta * steps * B
+    return f"ChiTransformer dp_pusht d=256 h=4 L=8, Ta=16, {steps}-step DDPM, B={B}", call, B, 2.0 * tok * Ta * steps * B
 
 
 def cfg2g(B=256):
@@ -196,9 +196,10 @@ def run(name, fn, reps=3, **kw):
 if __name__ == "__main__":
     for name in (sys.argv[1:] or ["cfg1", "cfg3"]):
         if name.startswith(("cfg4", "cfg5", "cfg2g", "cfg2big", "cfgT")):    # e.g. cfg4, cfg4:4096, cfg2g:3200, cfgT:256
-            base, _, b = name.partition(":")
+            base, _, b = name.partition(":")                        # cfgT:1024:10 = batch 1024, 10 denoising steps (short profiles)
+            b, _, st = b.partition(":")
             run_big(name, {"cfg4": cfg4, "cfg5": cfg5, "cfg2g": cfg2g, "cfg2big": cfg2big, "cfgT": cfgT}[base],
-                    **({"B": int(b)} if b else {}))
+                    **({"B": int(b)} if b else {}), **({"steps": int(st)} if st else {}))
         else:
             base, _, b = name.partition(":")
             run(name, {"cfg1": cfg1, "cfg3": cfg3}[base], **({"B": int(b)} if b else {}))
