@@ -18,14 +18,14 @@ Architecture (different from the reference on purpose):
    with the same torch seed reproduces the reference; ``noise=[z0, z1, ...]`` (kwarg) replays recorded draws,
    which is how device runs are compared with the CPU oracle and how multi-GPU shards stay seed-consistent.
 """
-from typing import Callable, Dict, List, Optional, Union
+from typing import Callable, Dict, Optional, Union
 
 import numpy as np
 import torch
 import torch.nn as nn
 
 from ..engine import plan as _plan
-from ..engine.plan import SUPPORTED_SOLVERS, KIND_DDPM, KIND_DDIM, V_EPS, V_XTHETA, V_MULTISTEP
+from ..engine.plan import SUPPORTED_SOLVERS, KIND_DDPM, KIND_DDIM, V_EPS, V_XTHETA
 from ..nn_condition import BaseNNCondition
 from ..nn_diffusion import BaseNNDiffusion
 from ..utils import (at_least_ndim, SUPPORTED_NOISE_SCHEDULES, SUPPORTED_DISCRETIZATIONS,

@@ -131,7 +131,6 @@ def _is_janner(module) -> bool:
 def _mlp_kind(module) -> Optional[str]:
     """Batch-tiled MLP programs the compiler knows: 'pearce' | 'dql' | None."""
     from ..nn_diffusion.mlp_backbones import DQLMlp, DVInvMlp, PearceMlp
-    from ..utils.embeddings import PositionalEmbedding
     if type(module) is PearceMlp and module.hidden_dim % 64 == 0 and module.hidden_dim <= 1024:
         return "pearce"
     if type(module) is DQLMlp or (type(module) is DVInvMlp and module.mid_layer[0].out_features % 64 == 0

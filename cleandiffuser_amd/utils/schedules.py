@@ -5,7 +5,6 @@ The registry *names* and call signatures are the plug-in contract of the referen
 (cleandiffuser/utils/utils.py:89-233); the arithmetic is restated here so that the
 tables are bit-identical to the reference's when evaluated with torch fp32 on CPU.
 """
-import math
 from typing import Callable, Dict
 
 import numpy as np
