@@ -24,7 +24,13 @@ SHAPES = [  # (M, N, K, act, gate/residual)
 
 def main(reps=20):
     dev = "cuda:0"
-    for name, m, n, k, act, gr in SHAPES:
+    shapes = SHAPES
+    if len(sys.argv) > 1:                                  # custom shapes: M,N,K[,act[,gr]] ...
+        shapes = []
+        for spec in sys.argv[1:]:
+            f = spec.split(",")
+            shapes.append((spec, int(f[0]), int(f[1]), int(f[2]), f[3] if len(f) > 3 else "none", len(f) > 4))
+    for name, m, n, k, act, gr in shapes:
         a = torch.randn(m, k, device=dev)
         w = torch.randn(n, k, device=dev) / k ** 0.5
         b = torch.randn(n, device=dev)
