@@ -18,6 +18,19 @@ extern void cdx_set_err(const char* msg);
 
 namespace {
 
+// EDM / consistency records evaluate the network on c_in * x (reference newedm.py:142-148, edm.py:77-82): scaled copy of the state
+__global__ void scale_rows_kernel(float* __restrict__ out, const float* __restrict__ x, float c, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = c * x[i];
+}
+
+int scaled_input(hipStream_t st, const float*& x, float* scratch, float in_scale, size_t n) {
+    if (in_scale == 1.0f) return CDX_OK;
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(scale_rows_kernel, dim3(blocks), dim3(256), 0, st, scratch, x, in_scale, n);
+    x = scratch;
+    return hipGetLastError() == hipSuccess ? CDX_OK : CDX_EHIP;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Embedding rows of one chunk:  out[r] = temb[row(r)] + (conditional half ? cond[b0 + r] : 0)
 // (reference dit.py:127-131: emb = map_noise(t); emb += condition | zeros)
@@ -238,7 +251,7 @@ int run_step(hipStream_t stream, const cdx_sampling* s, const cdx_step& st, floa
 // DiT1d
 // ------------------------------------------------------------------------------------------------
 struct DitBuffers {
-    float *x, *prev, *emb0, *e1, *emb, *semb, *ada, *h0, *xm, *qkv, *att, *h2, *f, *h, *pred;
+    float *x, *prev, *xold, *emb0, *e1, *emb, *semb, *ada, *h0, *xm, *qkv, *att, *h2, *f, *h, *pred;
 };
 
 long long dit_layout(const cdx_dit1d_weights* w, const cdx_sampling* s, float* base, DitBuffers* B) {
@@ -249,6 +262,7 @@ long long dit_layout(const cdx_dit1d_weights* w, const cdx_sampling* s, float* b
     DitBuffers b;
     b.x = a.take(nb * s->hd);
     b.prev = a.take(nb * s->hd);
+    b.xold = a.take(nb * s->hd);           // EDM Heun: state before the predictor
     b.emb0 = a.take(er * w->emb_dim);
     b.e1 = a.take(er * d);
     b.emb = a.take(er * d);
@@ -272,7 +286,7 @@ int dit_check(const cdx_dit1d_weights* w, const cdx_sampling* s) {
         w->d_model % w->n_heads != 0 || w->d_model / w->n_heads > 64 || w->depth < 0 || w->in_dim <= 0) {
         cdx_set_err("DiT1d executor: tokens <= 64, d_model <= 1024, head_dim <= 64 required"); return CDX_EINVAL;
     }
-    CDX_TRY(check_request(s, "cdx_dit1d_run", 4));
+    CDX_TRY(check_request(s, "cdx_dit1d_run", 7));
     if (s->hd != w->tokens * w->in_dim || s->emb_dim != w->emb_dim || (s->cond && s->cond_dim != w->emb_dim)) {
         cdx_set_err("DiT1d request shape does not match the weights"); return CDX_EINVAL;
     }
@@ -302,9 +316,10 @@ int dit_prepare(const cdx_dit1d_weights* w, const cdx_sampling* s, hipStream_t s
 }
 
 int dit_forward(const cdx_dit1d_weights* w, const cdx_sampling* s, hipStream_t st, const DitBuffers& B, const float* x,
-                float* pred, int nb, int rec) {
+                float* pred, int nb, int rec, float in_scale = 1.0f) {
     const int two = s->cfg_mode == 2 ? 2 : 1, bf = nb * two;
     const int T = w->tokens, d = w->d_model, rows = bf * T;
+    CDX_TRY(scaled_input(st, x, pred, in_scale, (size_t)nb * T * w->in_dim));     // pred is free until the final layer writes it
     const int ntot = 6 * d * w->depth + 2 * d;
     const float* ada_rec = B.ada + (size_t)rec * bf * ntot;
     // token stream: x_proj(x) + pos, computed once per trajectory (both CFG halves start from the same tokens)
@@ -420,7 +435,7 @@ __global__ void time_rows_kernel(float* __restrict__ out, const float* __restric
 }
 
 struct TfBuffers {
-    float *x, *prev, *obs, *tin, *tenc, *tmem, *oin, *oenc, *omem, *tkv, *okv, *h, *y, *qkv, *att, *f, *pred;
+    float *x, *prev, *xold, *obs, *tin, *tenc, *tmem, *oin, *oenc, *omem, *tkv, *okv, *h, *y, *qkv, *att, *f, *pred;
 };
 
 long long tf_layout(const cdx_chitf_weights* w, const cdx_sampling* s, float* base, TfBuffers* B) {
@@ -431,6 +446,7 @@ long long tf_layout(const cdx_chitf_weights* w, const cdx_sampling* s, float* ba
     TfBuffers b;
     b.x = a.take(nb * s->hd);
     b.prev = a.take(nb * s->hd);
+    b.xold = a.take(nb * s->hd);
     b.obs = a.take(orow * w->obs_dim);
     b.tin = a.take(trow * d);
     b.tenc = a.take(trow * 4 * d);
@@ -457,7 +473,7 @@ int tf_check(const cdx_chitf_weights* w, const cdx_sampling* s) {
         w->d_model % w->n_heads != 0 || w->d_model / w->n_heads > 64 || w->n_layers < 0) {
         cdx_set_err("ChiTransformer executor: Ta <= 64, 1 + To <= 16, d_model <= 1024, head_dim <= 64 required"); return CDX_EINVAL;
     }
-    CDX_TRY(check_request(s, "cdx_chitf_run", 4));
+    CDX_TRY(check_request(s, "cdx_chitf_run", 7));
     if (s->hd != w->Ta * w->act_dim || s->emb_dim != w->d_model || (s->cond && s->cond_dim != w->To * w->obs_dim)) {
         cdx_set_err("ChiTransformer request shape does not match the weights"); return CDX_EINVAL;
     }
@@ -498,9 +514,10 @@ int tf_prepare(const cdx_chitf_weights* w, const cdx_sampling* s, hipStream_t st
 }
 
 int tf_forward(const cdx_chitf_weights* w, const cdx_sampling* s, hipStream_t st, const TfBuffers& B, const float* x, float* pred,
-               int nb, int rec) {
+               int nb, int rec, float in_scale = 1.0f) {
     const int two = s->cfg_mode == 2 ? 2 : 1, bf = nb * two;
     const int T = w->Ta, d = w->d_model, rows = bf * T, orow = bf * w->To;
+    CDX_TRY(scaled_input(st, x, pred, in_scale, (size_t)nb * T * w->act_dim));    // pred is free until the head writes it
     const int trow = s->temb_per_sample ? bf : (s->n_steps > 0 ? s->n_steps : 1);
     for (int half = 0; half < two; ++half)               // both CFG halves start from the same action tokens
         CDX_TRY(gemm(st, x, w->act_dim, w->act_emb_w, w->act_dim, w->act_emb_b, B.h + (size_t)half * nb * T * d, d, nb * T, d,
@@ -920,8 +937,8 @@ int cdx_dit1d_run(const cdx_dit1d_weights* w, const cdx_sampling* s, void* hip_s
         }
         if (hipMemcpyAsync(B.x, s->x_in + off, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return hip_ok();
         for (int i = 0; i < s->n_steps; ++i) {
-            CDX_TRY(dit_forward(w, s, st, B, B.x, B.pred, nb, i));
-            CDX_TRY(run_step(st, s, s->steps[i], B.x, B.pred, B.prev, nullptr, nb, b0));
+            CDX_TRY(dit_forward(w, s, st, B, B.x, B.pred, nb, i, s->steps[i].kind >= 5 ? s->steps[i].alpha : 1.0f));
+            CDX_TRY(run_step(st, s, s->steps[i], B.x, B.pred, B.prev, B.xold, nb, b0));
         }
         if (hipMemcpyAsync(s->x_out + off, B.x, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return hip_ok();
     }
@@ -951,8 +968,8 @@ int cdx_chitf_run(const cdx_chitf_weights* w, const cdx_sampling* s, void* hip_s
         }
         if (hipMemcpyAsync(B.x, s->x_in + off, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return hip_ok();
         for (int i = 0; i < s->n_steps; ++i) {
-            CDX_TRY(tf_forward(w, s, st, B, B.x, B.pred, nb, i));
-            CDX_TRY(run_step(st, s, s->steps[i], B.x, B.pred, B.prev, nullptr, nb, b0));
+            CDX_TRY(tf_forward(w, s, st, B, B.x, B.pred, nb, i, s->steps[i].kind >= 5 ? s->steps[i].alpha : 1.0f));
+            CDX_TRY(run_step(st, s, s->steps[i], B.x, B.pred, B.prev, B.xold, nb, b0));
         }
         if (hipMemcpyAsync(s->x_out + off, B.x, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return hip_ok();
     }

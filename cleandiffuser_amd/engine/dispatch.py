@@ -57,24 +57,20 @@ def try_fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, requ
         if out is not None:
             return out
     if bigbatch.is_dit1d(net) or bigbatch.is_resmlp(net) or bigbatch.is_chitf(net):
-        if not bigbatch.is_resmlp(net) and any(st.kind >= 5 for st in plan.steps):
-            return None                  # EDM input scaling is wired into cdx_resmlp_run only
-        return bigbatch.sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed)
+        return bigbatch.sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed)     # EDM / consistency kinds included
     return runtime.fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed)
 
 
 def try_fused_edm(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, requires_grad, feed):
-    """``ContinuousEDM.sample`` on the big-batch executors (GEMM-shaped backbones only)."""
+    """``ContinuousEDM.sample``: big-batch executors for the GEMM-shaped backbones, the program kernel for the rest."""
     if not _on_gpu(xt) or requires_grad or xt.dtype != torch.float32:
         return None
     if w_cg != 0.0 and solver.classifier is not None:
         return None
     from . import bigbatch, runtime
     net = model["diffusion"]
-    if bigbatch.is_resmlp(net):
+    if bigbatch.is_resmlp(net) or bigbatch.is_dit1d(net) or bigbatch.is_chitf(net):
         return bigbatch.sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed)
-    if bigbatch.is_dit1d(net) or bigbatch.is_chitf(net):
-        return None                      # cdx_dit1d_run / cdx_chitf_run have no c_in input scaling yet
     return runtime.fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed)
 
 

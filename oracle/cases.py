@@ -188,6 +188,27 @@ CASES.update({
         solver=("EDM", dict()), sample=dict(solver="euler", sample_steps=5, w_cfg=1.0)),
 })
 
+# EDM-family solvers over the GEMM-shaped transformers (dp_* pipelines offer `solver=edm` with every backbone): the executors
+# evaluate the network on c_in * x (scaled copy in front of the token projection) and keep x_old for the Heun corrector
+CHITF_SMALL = ("ChiTransformer", dict(act_dim=2, obs_dim=20, Ta=16, To=2, d_model=64, nhead=4, num_layers=2))
+CASES.update({
+    "dit_edm_heun_cfg": dict(
+        net=DIT_SMALL, x_shape=(5, 7), batch=4, cond=("IdentityCondition", dict(dropout=0.0), (32,)),
+        solver=("ContinuousEDM", dict()), sample=dict(solver="heun", sample_steps=5, w_cfg=1.4)),
+    "chitf_edm_euler_x": dict(
+        net=CHITF_SMALL, x_shape=(16, 2), batch=3, cond=("IdentityCondition", dict(dropout=0.0), (2, 20)),
+        solver=("ContinuousEDM", dict()), sample=dict(solver="euler", sample_steps=5, w_cfg=1.0, diffusion_x_sampling_steps=1)),
+    "dit_legacy_edm_heun": dict(
+        net=DIT_SMALL, x_shape=(6, 7), batch=3, cond=("IdentityCondition", dict(dropout=0.0), (32,)), legacy=True,
+        solver=("EDM", dict()), sample=dict(solver="heun", sample_steps=5, w_cfg=1.0)),
+    "chitf_legacy_edm_euler": dict(
+        net=CHITF_SMALL, x_shape=(16, 2), batch=3, cond=("IdentityCondition", dict(dropout=0.0), (2, 20)), legacy=True,
+        solver=("EDM", dict()), sample=dict(solver="euler", sample_steps=6, w_cfg=1.0)),
+    "dit_cm": dict(
+        net=DIT_SMALL, x_shape=(5, 7), batch=4, clip=2.0, legacy=True,
+        solver=("ContinuousConsistencyModel", dict()), sample=dict(sample_steps=3, temperature=0.9)),
+})
+
 # ChiUNet1d with classifier-free guidance on a doubled batch (zero observations for the unconditional half), bias-only FiLM
 CASES.update({
     "chiunet_cfg_w18_ddim": dict(
