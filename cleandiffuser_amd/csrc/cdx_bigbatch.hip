@@ -561,7 +561,7 @@ struct UNet {                     // one pass over the op list; with dry == true
     bool dry;
     int nb, bf, b0, rec, n_rec;
     // persistent (prepare) buffers
-    float *x, *prev, *xin, *obs, *e1, *te, *mte, *gobs, *mo, *tfilm, *ofilm, *pred, *splitk;
+    float *x, *prev, *xold, *xin, *obs, *e1, *te, *mte, *gobs, *mo, *tfilm, *ofilm, *pred, *splitk;
     long long film_total;         // sum of film_out over all blocks (row width of the film tables)
     long long splitk_floats;      // split-K scratch: UNET_SPLITK slices of the largest conv output (rows x model_dim at full length)
 
@@ -622,7 +622,8 @@ struct UNet {                     // one pass over the op list; with dry == true
         const bool has_obs = w->cond_dim > 0;
         film_total = 0;
         for (int i = 0; i < n_blocks(); ++i) film_total += film_out(w->blocks[i]);
-        x = take((long long)nb * s->hd); prev = take((long long)nb * s->hd); xin = take((long long)bf * s->hd);
+        x = take((long long)nb * s->hd); prev = take((long long)nb * s->hd); xold = take((long long)nb * s->hd);
+        xin = take((long long)bf * s->hd);
         obs = take(has_obs ? (long long)bf * w->cond_dim : 0);
         e1 = take((long long)trow * EH); te = take((long long)trow * (EO > E ? EO : E)); mte = take((long long)trow * (EO > E ? EO : E));
         gobs = take(has_obs ? (long long)bf * EO : 0); mo = take(has_obs ? (long long)bf * EO : 0);
@@ -722,7 +723,7 @@ int chiunet_check(const cdx_chiunet_weights* w, const cdx_sampling* s) {
         w->film_ld < w->emb_out) {
         cdx_set_err("ChiUNet1d executor: Ta must be a power of two >= 2^(levels-1), odd kernel size"); return CDX_EINVAL;
     }
-    CDX_TRY(check_request(s, "cdx_chiunet_run", 4));
+    CDX_TRY(check_request(s, "cdx_chiunet_run", 7));
     if (s->hd != w->Ta * w->act_dim || s->emb_dim != w->emb_dim) { cdx_set_err("U-Net request: shape mismatch"); return CDX_EINVAL; }
     if (w->cond_dim > 0 && (!s->cond || s->cond_dim != w->cond_dim || s->cfg_mode == 0)) {
         cdx_set_err("ChiUNet1d request: no condition (the reference requires one)"); return CDX_EINVAL;
@@ -751,14 +752,20 @@ long long chiunet_pass(const cdx_chiunet_weights* w, const cdx_sampling* s, hipS
             const float* xsrc = s->n_steps == 0 ? s->x_in + off : u.x;
             if (!dry) {
                 if (i == 0 && s->n_steps > 0 && hipMemcpyAsync(u.x, s->x_in + off, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) { *rc = hip_ok(); return -1; }
-                for (int half = 0; half < u.bf / u.nb; ++half)
-                    if (hipMemcpyAsync(u.xin + (size_t)half * u.nb * s->hd, xsrc, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) { *rc = hip_ok(); return -1; }
+                const float in_scale = (s->n_steps > 0 && s->steps[i].kind >= 5) ? s->steps[i].alpha : 1.0f;     // EDM: F(c_in x, ...)
+                for (int half = 0; half < u.bf / u.nb; ++half) {
+                    float* xdst = u.xin + (size_t)half * u.nb * s->hd;
+                    if (in_scale != 1.0f) {
+                        const float* src = xsrc;
+                        if ((*rc = scaled_input(st, src, xdst, in_scale, (size_t)u.nb * s->hd)) != CDX_OK) return -1;
+                    } else if (hipMemcpyAsync(xdst, xsrc, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) { *rc = hip_ok(); return -1; }
+                }
             }
             float* dst = (s->n_steps == 0) ? s->x_out + off : u.pred;
             if ((*rc = u.forward(u.xin, dst)) != CDX_OK) return -1;
             if (u.a.used > need) need = u.a.used;
             if (dry) break;
-            if (s->n_steps > 0 && (*rc = run_step(st, s, s->steps[i], u.x, u.pred, u.prev, nullptr, u.nb, b0)) != CDX_OK) return -1;
+            if (s->n_steps > 0 && (*rc = run_step(st, s, s->steps[i], u.x, u.pred, u.prev, u.xold, u.nb, b0)) != CDX_OK) return -1;
         }
         if (dry) break;
         if (s->n_steps > 0 && hipMemcpyAsync(s->x_out + off, u.x, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) { *rc = hip_ok(); return -1; }

@@ -52,7 +52,7 @@ def try_fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, requ
         return guided.guided_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, feed)
     from . import bigbatch, runtime
     net = model["diffusion"]
-    if bigbatch.is_chiunet_gemm(net, xt.shape[0]) and not any(st.kind >= 5 for st in plan.steps):
+    if bigbatch.is_chiunet_gemm(net, xt.shape[0]):
         out = bigbatch.sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed)
         if out is not None:
             return out
@@ -71,6 +71,10 @@ def try_fused_edm(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, require
     net = model["diffusion"]
     if bigbatch.is_resmlp(net) or bigbatch.is_dit1d(net) or bigbatch.is_chitf(net):
         return bigbatch.sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed)
+    if bigbatch.is_chiunet_gemm(net, xt.shape[0]):
+        out = bigbatch.sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed)
+        if out is not None:
+            return out
     return runtime.fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed)
 
 

@@ -204,6 +204,14 @@ CASES.update({
     "chitf_legacy_edm_euler": dict(
         net=CHITF_SMALL, x_shape=(16, 2), batch=3, cond=("IdentityCondition", dict(dropout=0.0), (2, 20)), legacy=True,
         solver=("EDM", dict()), sample=dict(solver="euler", sample_steps=6, w_cfg=1.0)),
+    "chiunet_legacy_edm_heun": dict(
+        net=("ChiUNet1d", dict(act_dim=2, obs_dim=20, To=2, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2])),
+        x_shape=(16, 2), batch=3, cond=("IdentityCondition", dict(dropout=0.0), (2, 20)), legacy=True,
+        solver=("EDM", dict()), sample=dict(solver="heun", sample_steps=5, w_cfg=1.0)),
+    "chiunet_edm_euler_cfg": dict(
+        net=("ChiUNet1d", dict(act_dim=2, obs_dim=20, To=2, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2])),
+        x_shape=(16, 2), batch=3, cond=("IdentityCondition", dict(dropout=0.0), (2, 20)),
+        solver=("ContinuousEDM", dict()), sample=dict(solver="euler", sample_steps=5, w_cfg=1.6)),
     "dit_cm": dict(
         net=DIT_SMALL, x_shape=(5, 7), batch=4, clip=2.0, legacy=True,
         solver=("ContinuousConsistencyModel", dict()), sample=dict(sample_steps=3, temperature=0.9)),

@@ -203,7 +203,8 @@ def test_chiunet_gemm_executor_matches_reference_fixture(name, chunk, amd_lib, m
 
 
 @pytest.mark.parametrize("name", ["janner_cfg2_ddim", "janner_h4_ddpm", "janner_cfg2_ddpm_clip", "janner_h64_single",
-                                  "janner_legacy_dpm_sdepp2", "janner_rflow_discrete", "janner_legacy_edm_euler"])
+                                  "janner_legacy_dpm_sdepp2", "janner_rflow_discrete", "janner_legacy_edm_euler",
+                                  "janner_legacy_edm_heun", "janner_legacy_edm_x", "janner_cm"])
 def test_janner_gemm_executor_matches_reference_fixture(name, amd_lib, monkeypatch):
     """Unconditional JannerUNet1d through the implicit-GEMM U-Net executor (meant for batches in the thousands; forced here)."""
     from cleandiffuser_amd.engine import bigbatch
@@ -215,10 +216,7 @@ def test_janner_gemm_executor_matches_reference_fixture(name, amd_lib, monkeypat
     calls = _spy_bigbatch(monkeypatch)
     x, _ = cases.sampler_of(agent, name)(torch.from_numpy(inp["prior"]).to(DEV), noise=list(inp["noise"][:int(gold["n_draws"])]), **kw)
     torch.cuda.synchronize()
-    if cases.CASES[name]["solver"][0] == "EDM":
-        assert calls == []                            # EDM input scaling lives in the program kernel only
-    else:
-        assert [c[0] for c in calls] == ["chiunet"]
+    assert [c[0] for c in calls] == ["chiunet"]       # EDM / consistency records included (c_in-scaled input copy)
     np.testing.assert_allclose(x.cpu().numpy(), gold["x_out"], **TOL)
 
 
