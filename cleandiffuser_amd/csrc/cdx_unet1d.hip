@@ -58,7 +58,12 @@ __device__ __forceinline__ float act_f(float x, int act) {
     if constexpr (!FULL) return act == CDX_ACT_MISH ? mish_f(x) : x;   // the U-Net programs only use Mish / identity
     switch (act) {
         case CDX_ACT_MISH: return mish_f(x);
-        case CDX_ACT_GELU_ERF: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+        case CDX_ACT_GELU_ERF: {                         // erf by Abramowitz-Stegun 7.1.26, |err| < 1.5e-7, branch-free (as in cdx_gemm.hip)
+            const float z = fabsf(x) * 0.70710678118654752f;
+            const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+            const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+            return 0.5f * x * (1.0f + copysignf(1.0f - poly * __expf(-z * z), x));
+        }
         case CDX_ACT_LEAKY: return x > 0.f ? x : 0.01f * x;
         case CDX_ACT_SILU: return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
         case CDX_ACT_RELU: return fmaxf(x, 0.f);
@@ -428,9 +433,8 @@ __device__ __forceinline__ void conv_op(const int w, const int wn, const int* __
         }
     } else if (FULL && col_norm) {
         // per-column normalisation (GroupNorm1d on (b, C) / LayerNorm of the MLP backbones): statistics over the
-        // cg channels of ONE column (= one sample of the batch tile).  One wave per (column, group) pair, three
-        // short passes through LDS -- deliberately compact code: these layers are tiny and the instruction cache
-        // is what the U-Net path is sensitive to.
+        // cg channels of ONE column (= one sample of the batch tile).  Three short passes through LDS -- deliberately compact
+        // code: these layers are tiny and the instruction cache is what the U-Net path is sensitive to.
         const float* __restrict__ gamma = wblob + CDX_RL(w, CDX_W_GAMMA);
         const float* __restrict__ beta = wblob + CDX_RL(w, CDX_W_BETA);
         const float inv_cg = __int_as_float(CDX_RL(w, CDX_W_INV_CNT));
@@ -438,30 +442,43 @@ __device__ __forceinline__ void conv_op(const int w, const int wn, const int* __
         stamp(prof ? prof + 1 : nullptr, tid);
         __syncthreads();
         stamp(prof ? prof + 2 : nullptr, tid);
-        for (int pair = wave; pair < l_out * groups; pair += CDX_N_WAVES) {
+        // A (column, group) pair is cg channels of one sample: far too little for a wave (the wave-per-pair loop spent 28 k cycles
+        // per 256-wide layer of PearceMlp, twice its K loop).  `seg` adjacent lanes own a pair instead -- the largest power of two
+        // that still keeps all CDX_THREADS lanes busy -- and reduce with xor shuffles inside their segment.
+        const int pairs = l_out * groups;
+        int seg = 64;
+        while (seg > 1 && (seg > cg || pairs * (seg >> 1) >= CDX_THREADS)) seg >>= 1;
+        const int sl = tid & (seg - 1), slot = tid / seg, per_round = CDX_THREADS / seg;
+        for (int p0 = 0; p0 < pairs; p0 += per_round) {
+            const bool live = p0 + slot < pairs;                 // dead segments shadow the last pair (uniform shuffles), never store
+            const int pair = live ? p0 + slot : pairs - 1;
             const int n = div_small(pair, groups, inv_groups), c0 = (pair - n * groups) * cg;
             float s = 0.f;
-            for (int e = lane; e < cg; e += 64) {
+            for (int e = sl; e < cg; e += seg) {
                 const int c = c0 + e;
                 float v = bias[c];
                 for (int ks = 0; ks < ksplit; ++ks) v += lds[scratch + (ks * l_out + n) * sstride + c];
-                lds[scratch + n * sstride + c] = v;  // owned by this lane only
+                if (live) lds[scratch + n * sstride + c] = v;    // owned by this lane only
                 s += v;
             }
-            const float mean = wave_sum(s) * inv_cg;
+            for (int o = seg >> 1; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+            const float mean = s * inv_cg;
             float s2 = 0.f;
-            for (int e = lane; e < cg; e += 64) {
-                const float d = lds[scratch + n * sstride + c0 + e] - mean;
-                s2 += d * d;
-            }
-            const float rstd = __builtin_amdgcn_rsqf(wave_sum(s2) * inv_cg + CDX_GN_EPS);
-            for (int e = lane; e < cg; e += 64) {
-                const int c = c0 + e;
-                float y = act_f<FULL>((lds[scratch + n * sstride + c] - mean) * rstd * gamma[c] + beta[c], act);
-                if (flags & CDX_F_ADD_EMB) y += lds[emb + c];
-                if (flags & CDX_F_ADD_RES) y += lds[res + (n + CDX_HALO) * rstride + c];
-                lds[dst + (n + CDX_HALO) * dstride + coff + c] = y * oscale;
-            }
+            if (live)
+                for (int e = sl; e < cg; e += seg) {
+                    const float d = lds[scratch + n * sstride + c0 + e] - mean;
+                    s2 += d * d;
+                }
+            for (int o = seg >> 1; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+            const float rstd = __builtin_amdgcn_rsqf(s2 * inv_cg + CDX_GN_EPS);
+            if (live)
+                for (int e = sl; e < cg; e += seg) {
+                    const int c = c0 + e;
+                    float y = act_f<FULL>((lds[scratch + n * sstride + c] - mean) * rstd * gamma[c] + beta[c], act);
+                    if (flags & CDX_F_ADD_EMB) y += lds[emb + c];
+                    if (flags & CDX_F_ADD_RES) y += lds[res + (n + CDX_HALO) * rstride + c];
+                    lds[dst + (n + CDX_HALO) * dstride + coff + c] = y * oscale;
+                }
         }
     } else {
         // plain conv (down/up-sample, 1x1 residual, output head): bias (+ residual / accumulate)
