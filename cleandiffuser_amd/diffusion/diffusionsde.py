@@ -161,6 +161,16 @@ class BaseDiffusionSDE(DiffusionModel):
         return self.classifier_guidance(xt, t, alpha, sigma, model, condition_cg, w_cg, pred)
 
     # ==================================== sampling ============================================ #
+    def _cached_plan(self, key, build):
+        """Step plans depend only on (solver, grid, step counts): keep the last few so that a control loop calling sample() with the
+        same settings re-derives nothing on the host (3 ms of scalar tensor math for 100 steps) and re-uploads nothing."""
+        plans = self.__dict__.setdefault("_plans", {})
+        if key not in plans:
+            if len(plans) >= 16:
+                plans.pop(next(iter(plans)))
+            plans[key] = build()
+        return plans[key]
+
     def _resolve_schedule(self, sample_step_schedule, domain, sample_steps):
         if isinstance(sample_step_schedule, str):
             if sample_step_schedule not in SUPPORTED_SAMPLING_STEP_SCHEDULE:
@@ -281,6 +291,9 @@ class DiscreteDiffusionSDE(BaseDiffusionSDE):
             raise ValueError("noise_schedule must be a callable or a string")
         self.alpha, self.sigma = fwd(self.t_diffusion, **(noise_schedule_params or {}))
         self.logSNR = torch.log(self.alpha / self.sigma)
+        # host images of the tables: sample() derives its step coefficients on the CPU without a device read-back (which would
+        # wait for whatever the stream is still running, e.g. the previous sample() call)
+        self._alpha_host, self._sigma_host = self.alpha.detach().float().cpu(), self.sigma.detach().float().cpu()
 
     def add_noise(self, x0, t=None, eps=None):
         t = torch.randint(self.diffusion_steps, (x0.shape[0],), device=self.device) if t is None else t
@@ -310,9 +323,10 @@ class DiscreteDiffusionSDE(BaseDiffusionSDE):
         xt = xt * (1. - self.fix_mask) + prior * self.fix_mask
 
         sched = self._resolve_schedule(sample_step_schedule, horizon_T, sample_steps)
-        idx = sched.to(self.alpha.device)
-        plan = _plan.build_vp_plan(solver, self.alpha[idx], self.sigma[idx], sched.tolist(), sample_steps,
-                                   diffusion_x_sampling_steps, t_is_integer=True)
+        grid = sched.tolist()
+        plan = self._cached_plan((solver, tuple(grid), sample_steps, diffusion_x_sampling_steps), lambda: _plan.build_vp_plan(
+            solver, self._alpha_host[sched.cpu()], self._sigma_host[sched.cpu()], grid, sample_steps,
+            diffusion_x_sampling_steps, t_is_integer=True))
         return self._sample_common(plan, xt, prior, n_samples, use_ema, condition_cfg, mask_cfg, w_cfg,
                                    condition_cg, w_cg, requires_grad, preserve_history, sample_steps, feed,
                                    torch.long, final_logp=self.classifier is not None)
@@ -377,9 +391,13 @@ class ContinuousDiffusionSDE(BaseDiffusionSDE):
         xt = xt * (1. - self.fix_mask) + prior * self.fix_mask
 
         sched = self._resolve_schedule(sample_step_schedule, t_range, sample_steps)
-        alphas, sigmas = self._alpha_sigma(sched)
-        plan = _plan.build_vp_plan(solver, alphas, sigmas, sched, sample_steps, diffusion_x_sampling_steps,
-                                   t_is_integer=False)
+        sched = sched.cpu() if isinstance(sched, torch.Tensor) else sched
+
+        def build():
+            alphas, sigmas = self._alpha_sigma(sched)
+            return _plan.build_vp_plan(solver, alphas, sigmas, sched, sample_steps, diffusion_x_sampling_steps, t_is_integer=False)
+        key = tuple(sched.tolist()) if isinstance(sched, torch.Tensor) else tuple(float(v) for v in sched)
+        plan = self._cached_plan((solver, key, sample_steps, diffusion_x_sampling_steps), build)
         return self._sample_common(plan, xt, prior, n_samples, use_ema, condition_cfg, mask_cfg, w_cfg,
                                    condition_cg, w_cg, requires_grad, preserve_history, sample_steps, feed,
                                    torch.float32,

@@ -12,6 +12,7 @@ from typing import Optional
 
 import torch
 
+from . import runtime
 from .runtime import CdxStep, _check, _dense_hd, _f32c, _predicts_noise, _signature, _stream_ptr, load_library
 
 _FP = ctypes.c_void_p
@@ -396,7 +397,12 @@ def _workspace(device, floats: int) -> torch.Tensor:
 
 
 def host_steps(plan):
-    """plan.Step list -> host-resident cdx_step array (the C loop reads it while enqueuing)."""
+    """plan.Step list -> host-resident cdx_step array (the C loop reads it while enqueuing); memoised on the plan."""
+    from .plan import cached
+    return cached(plan, ("host_steps",), lambda: _pack_host_steps(plan))
+
+
+def _pack_host_steps(plan):
     arr = (CdxStep * max(len(plan.steps), 1))()
     k = 0
     for i, st in enumerate(plan.steps):
@@ -628,8 +634,7 @@ def sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed) -> Optional[torc
     except (ValueError, RuntimeError):
         return None
     with torch.no_grad():
-        t_dtype = torch.long if plan.t_is_integer else torch.float32
-        t_vec = torch.tensor([st.t for st in plan.steps], dtype=t_dtype, device=dev)
+        t_vec = runtime.device_times(plan, dev)
         if kind == "dit":
             temb, emb_dim, cond_dim = _f32c(net.map_noise(t_vec), dev), net.emb_dim, net.emb_dim
         elif kind == "chitf":

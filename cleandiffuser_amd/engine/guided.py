@@ -81,8 +81,7 @@ def guided_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, feed) -
                 return None
         if runtime._is_chiunet(net) and cond is None:
             return None
-        t_dtype = torch.long if plan.t_is_integer else torch.float32
-        t_vec = torch.tensor([st.t for st in plan.steps], dtype=t_dtype, device=dev)
+        t_vec = runtime.device_times(plan, dev)
         temb = _f32c(net.map_noise(t_vec), dev)
         clf_emb0 = _f32c(clf.model_ema.map_noise(t_vec), dev)
         pn = _predicts_noise(plan, solver)

@@ -55,6 +55,16 @@ class SamplePlan:
         return sum(1 for s in self.steps if s.noise)
 
 
+def cached(plan: "SamplePlan", key, make):
+    """Per-plan memo for the device-side images of a plan (timestep vector, packed step records): plans are immutable once
+    built and the solvers keep them across calls, so a steady-state ``sample()`` issues no host-to-device copy for them --
+    a pageable H2D copy is stream-ordered behind the previous call's kernel and would stall the host on it."""
+    memo = plan.__dict__.setdefault("_memo", {})
+    if key not in memo:
+        memo[key] = make()
+    return memo[key]
+
+
 def _f(x) -> float:
     return float(x.item()) if isinstance(x, torch.Tensor) else float(x)
 

@@ -309,7 +309,19 @@ def _predicts_noise(plan, solver) -> bool:
     return bool(getattr(solver, "predict_noise", False) if own is None else own)
 
 
+def device_times(plan, device) -> torch.Tensor:
+    """The timestep of every step record as one device vector (int64 grid indices or fp32 times), memoised on the plan."""
+    from .plan import cached
+    dt = torch.long if plan.t_is_integer else torch.float32
+    return cached(plan, ("t", str(device)), lambda: torch.tensor([st.t for st in plan.steps], dtype=dt, device=device))
+
+
 def steps_to_device(plan, device) -> torch.Tensor:
+    from .plan import cached
+    return cached(plan, ("steps", str(device)), lambda: _pack_steps(plan, device))
+
+
+def _pack_steps(plan, device) -> torch.Tensor:
     arr = (CdxStep * len(plan.steps))()
     k = 0
     for i, st in enumerate(plan.steps):
@@ -357,8 +369,7 @@ def fused_sample_mlp(solver, net, kind, plan, xt, prior, cond_vec, w_cfg, feed) 
         comp = compiled_program(net, tile)
         if cond is not None and cond.shape[1] != comp.prog.cond_dim:
             return None
-        t_dtype = torch.long if plan.t_is_integer else torch.float32
-        t_vec = torch.tensor([st.t for st in plan.steps], dtype=t_dtype, device=dev)
+        t_vec = device_times(plan, dev)
         temb = _f32c(net.map_noise(t_vec), dev)
         if kind == "pearce":                          # PearceMlp also consumes the raw timestep as a feature (Q11)
             temb = torch.cat([temb, t_vec.to(torch.float32).unsqueeze(1)], 1).contiguous()
@@ -396,8 +407,7 @@ def fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed) -> Optio
     load_library()
     with torch.no_grad():
         comp = compiled_program(net, h)
-        t_dtype = torch.long if plan.t_is_integer else torch.float32
-        t_vec = torch.tensor([st.t for st in plan.steps], dtype=t_dtype, device=dev)
+        t_vec = device_times(plan, dev)
         temb = _f32c(net.map_noise(t_vec), dev)
         steps_dev = steps_to_device(plan, dev)
         noise = torch.stack([feed.like(xt) for _ in range(plan.n_noise)]).contiguous() if plan.n_noise else None
