@@ -136,8 +136,9 @@ class DDPM(DiffusionModel):
             cond_cfg = model["condition"](condition_cfg, mask_cfg) if condition_cfg is not None else None
         if not preserve_history:                                   # whole loop in one launch when the backbone compiles
             from ..engine import dispatch, plan as _plan
-            plan = _plan.build_legacy_ddpm_plan(self.beta, self.alpha, self.bar_alpha, self.predict_noise,
-                                                extra_sample_steps)
+            plan = self._cached_plan(("legacy_ddpm", bool(self.predict_noise), extra_sample_steps),
+                                     lambda: _plan.build_legacy_ddpm_plan(self.beta, self.alpha, self.bar_alpha,
+                                                                          self.predict_noise, extra_sample_steps))
             fused = dispatch.try_fused_legacy_ddpm(self, model, plan, xt, prior, cond_cfg, w_cfg, w_cg, requires_grad, feed)
             if fused is not None:
                 log = {"log_p": None}

@@ -161,16 +161,6 @@ class BaseDiffusionSDE(DiffusionModel):
         return self.classifier_guidance(xt, t, alpha, sigma, model, condition_cg, w_cg, pred)
 
     # ==================================== sampling ============================================ #
-    def _cached_plan(self, key, build):
-        """Step plans depend only on (solver, grid, step counts): keep the last few so that a control loop calling sample() with the
-        same settings re-derives nothing on the host (3 ms of scalar tensor math for 100 steps) and re-uploads nothing."""
-        plans = self.__dict__.setdefault("_plans", {})
-        if key not in plans:
-            if len(plans) >= 16:
-                plans.pop(next(iter(plans)))
-            plans[key] = build()
-        return plans[key]
-
     def _resolve_schedule(self, sample_step_schedule, domain, sample_steps):
         if isinstance(sample_step_schedule, str):
             if sample_step_schedule not in SUPPORTED_SAMPLING_STEP_SCHEDULE:

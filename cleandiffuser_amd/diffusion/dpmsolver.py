@@ -169,7 +169,8 @@ class DPMSolver(DiffusionModel):
         fused = None
         if not preserve_history:
             from ..engine import dispatch, plan as _plan
-            plan = _plan.build_legacy_dpmsolver_plan(t, alphas, sigmas, sampler, sample_steps, extra_sample_steps)
+            plan = self._cached_plan((sampler, sample_steps, extra_sample_steps, float(kappa)), lambda: _plan.build_legacy_dpmsolver_plan(
+                t, alphas, sigmas, sampler, sample_steps, extra_sample_steps))
             fused = dispatch.try_fused_sample(self, model, plan, xt, prior, cond_cfg, w_cfg, w_cg, requires_grad, feed)
         if fused is not None:
             xt, log = fused, {"sample_history": None, "log_p": None}

@@ -228,4 +228,5 @@ class EDM(EDMArchetecture):
         if type(self) is not EDM:
             return None
         from ..engine.plan import build_legacy_edm_plan
-        return build_legacy_edm_plan(self.sigma_data, self.sigma_s, solver, extra_sample_steps)
+        key = ("legacy_edm", solver, extra_sample_steps, self.sample_steps, self.sigma_data, self.sigma_min, self.sigma_max, self.rho)
+        return self._cached_plan(key, lambda: build_legacy_edm_plan(self.sigma_data, self.sigma_s, solver, extra_sample_steps))

@@ -183,3 +183,30 @@ def test_flow_and_consistency_plans_reproduce_reference(name, amd_lib, monkeypat
         x = x.clip(agent.x_min, agent.x_max)
     np.testing.assert_allclose(x.numpy(), gold["x_out"], rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(x_ref.numpy(), gold["x_out"], rtol=2e-6, atol=2e-6)
+
+
+def test_step_plans_are_memoised_per_settings(amd_lib):
+    """A control loop calling sample() with the same settings re-derives nothing on the host: the plan object is reused, a change
+    of solver / step count / Diffusion-X tail gets its own plan, and results stay equal to the reference fixture throughout."""
+    name = "janner_tiny_disc_ddim"
+    gold = np.load(golden_path(name))
+    agent, _ = cases.build(amd_lib, name)
+    inp = cases.make_inputs(name)
+    kw = cases.sample_kwargs(name, inp)
+    prior, zs = torch.from_numpy(inp["prior"]), list(inp["noise"][:int(gold["n_draws"])])
+    x1, _ = agent.sample(prior, noise=zs, **kw)
+    (plan1,) = agent._plans.values()
+    x2, _ = agent.sample(prior, noise=zs, **kw)
+    assert list(agent._plans.values()) == [plan1] and next(iter(agent._plans.values())) is plan1
+    assert torch.equal(x1, x2)
+    np.testing.assert_allclose(x1.numpy(), gold["x_out"], rtol=2e-6, atol=2e-6)
+    kw2 = dict(kw, sample_steps=kw["sample_steps"] - 1)
+    agent.sample(prior, noise=list(inp["noise"]), **kw2)
+    agent.sample(prior, noise=list(inp["noise"]), **dict(kw, solver="ddpm"))
+    agent.sample(prior, noise=list(inp["noise"]), **dict(kw, diffusion_x_sampling_steps=1))
+    assert len(agent._plans) == 4
+    x3, _ = agent.sample(prior, noise=zs, **kw)                       # the first plan is still the one used for the first settings
+    assert torch.equal(x1, x3)
+    for i in range(20):                                                # bounded: the oldest entries are dropped
+        agent.sample(prior, noise=list(inp["noise"]), **dict(kw, sample_steps=2, diffusion_x_sampling_steps=i))
+    assert len(agent._plans) <= 16
