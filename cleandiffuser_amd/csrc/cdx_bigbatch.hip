@@ -773,6 +773,34 @@ long long chiunet_pass(const cdx_chiunet_weights* w, const cdx_sampling* s, hipS
     return need;
 }
 
+// One helper stream + two events per device for cdx_guided_run's fork/join (created on first use, never destroyed: process lifetime)
+struct SideStream {
+    hipStream_t stream;
+    hipEvent_t fork, join;
+};
+SideStream* side_stream() {
+    static const bool enabled = [] { const char* e = getenv("CDX_GUIDED_OVERLAP"); return !(e && e[0] == '0'); }();
+    if (!enabled) return nullptr;
+    static SideStream slots[64];
+    static bool ready[64] = {};
+    static bool failed[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || failed[dev]) return nullptr;
+    if (!ready[dev]) {
+        SideStream s;
+        if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) {
+            failed[dev] = true;
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        slots[dev] = s;
+        ready[dev] = true;
+    }
+    return &slots[dev];
+}
+
 // ------------------------------------------------------------------------------------------------
 // HalfJannerUNet1d forward + input-gradient backward (classifier guidance)
 // ------------------------------------------------------------------------------------------------
@@ -1052,13 +1080,26 @@ int cdx_guided_run(const cdx_guided_launch* g, void* hip_stream) {
     float* clf_ws = g->workspace + a.used;
     const long long clf_floats = g->workspace_floats - a.used;
     if (hipMemcpyAsync(x, g->x_in, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return hip_ok();
+    // The denoiser forward and the classifier forward+backward of a step both read x_t and are independent: the fused U-Net kernel
+    // (one workgroup per CU, ~121 KB of LDS) runs on a side stream while the classifier's ~80 small GEMM launches go down the
+    // caller's stream -- a GEMM workgroup (34 KB LDS, 4 waves) fits next to the U-Net workgroup on every CU.  Fork/join with two
+    // events per step; all side-stream work is joined before the call returns.  CDX_GUIDED_OVERLAP=0 serialises (A/B hook).
+    SideStream* side = side_stream();
     for (int i = 0; i < g->n_steps; ++i) {
         cdx_unet1d_launch L = *g->denoiser;
         L.n_steps = 0; L.steps = nullptr; L.temb_per_sample = 0; L.batch = g->batch;
         L.temb = g->temb + (size_t)i * L.emb_dim; L.x_in = x; L.x_out = pred;
-        CDX_TRY(cdx_unet1d_run(&L, hip_stream));
-        CDX_TRY(cdx_hjgrad_run(g->classifier, x, g->clf_emb0 + (size_t)i * g->classifier->emb_dim, 0, g->batch, logp, grad, clf_ws,
-                               clf_floats, hip_stream));
+        if (side) {
+            if (hipEventRecord(side->fork, st) != hipSuccess || hipStreamWaitEvent(side->stream, side->fork, 0) != hipSuccess) return hip_ok();
+            CDX_TRY(cdx_unet1d_run(&L, side->stream));
+            if (hipEventRecord(side->join, side->stream) != hipSuccess) return hip_ok();
+        } else {
+            CDX_TRY(cdx_unet1d_run(&L, hip_stream));
+        }
+        const int clf_rc = cdx_hjgrad_run(g->classifier, x, g->clf_emb0 + (size_t)i * g->classifier->emb_dim, 0, g->batch, logp, grad,
+                                          clf_ws, clf_floats, hip_stream);
+        if (side && hipStreamWaitEvent(st, side->join, 0) != hipSuccess) return hip_ok();      // join even when the classifier failed
+        CDX_TRY(clf_rc);
         StepArgs sa;
         sa.x = x; sa.pred = pred; sa.prev = prev; sa.xold = nullptr; sa.prior = g->prior; sa.fix_mask = g->fix_mask;
         sa.noise = g->noise; sa.x_min = g->x_min; sa.x_max = g->x_max; sa.st = g->steps[i]; sa.nb = g->batch; sa.hd = g->hd;

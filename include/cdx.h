@@ -351,7 +351,11 @@ int cdx_hjgrad_run(const cdx_hjgrad_weights* w, const float* x, const float* emb
 /* Classifier-guided sampling loop (reference diffusionsde.py:526-594 with w_cg > 0, the configuration every shipped Diffuser
  * pipeline runs): per step record  pred <- backbone(x, t)  [program kernel, forward mode];  (logp, g) <- classifier gradient;
  * pred <- pred - w sigma g (eps prediction) | pred + w sigma^2/alpha g (x0 prediction)  [cg_scale[i], host-frozen];  then clip,
- * solver update and fix-mask exactly as in the unguided loop.  All launches of all steps are enqueued by this one call. */
+ * solver update and fix-mask exactly as in the unguided loop.  All launches of all steps are enqueued by this one call.
+ * Streams: the denoiser launch of each step is issued on a library-owned side stream (one per device, created on first use)
+ * forked from and joined back into `hip_stream` with events, so that it overlaps the classifier's launches; every side-stream
+ * launch is joined before the call returns, i.e. the caller only ever has to order against `hip_stream`.  Environment
+ * CDX_GUIDED_OVERLAP=0 keeps everything on `hip_stream`. */
 typedef struct cdx_guided_launch {
     const cdx_unet1d_launch* denoiser;   /* a forward-mode launch description (n_steps = 0); temb/x_in/x_out are set per step */
     const cdx_hjgrad_weights* classifier;
