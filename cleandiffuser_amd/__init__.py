@@ -11,7 +11,7 @@ def install_as_cleandiffuser():
     import sys
     pkg = sys.modules[__name__]
     sys.modules.setdefault("cleandiffuser", pkg)
-    for sub in ("utils", "nn_diffusion", "nn_condition", "diffusion", "classifier", "nn_classifier"):
+    for sub in ("utils", "nn_diffusion", "nn_condition", "diffusion", "classifier", "nn_classifier", "invdynamic", "dataset"):
         try:
             mod = importlib.import_module(f"{__name__}.{sub}")
         except ImportError:
