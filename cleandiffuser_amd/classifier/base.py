@@ -1,66 +1,80 @@
 """Classifier-guidance plug-in (contract: reference classifier/base.py:9-90): owns ``model`` / ``model_ema`` of a
-``BaseNNClassifier``, ``logp(x, noise, c) -> (b, 1)``, ``gradients`` = autograd of ``logp.sum()`` w.r.t. ``x``,
-Adam optimiser, EMA, ``save/load`` with the ``{"model","model_ema"}`` checkpoint."""
+``BaseNNClassifier``, ``logp(x, noise, c) -> (b, 1)``, ``gradients(x, noise, c) -> (logp, d logp.sum() / dx)``, an Adam optimiser
+(default lr 2e-4, weight decay 1e-4), an EMA copy, and ``save/load`` of the ``{"model", "model_ema"}`` checkpoint.
+
+``gradients`` on a ROCm device is served by explicit forward + backward kernels when the network is one the engine knows
+(engine/classifier_grad.py: HalfJannerUNet1d); everything else differentiates ``logp`` with autograd as the reference does.
+"""
 from copy import deepcopy
 from typing import Optional
 
 import torch
+
+_DEFAULT_ADAM = {"lr": 2e-4, "weight_decay": 1e-4}
 
 
 class BaseClassifier:
     def __init__(self, nn_classifier, ema_rate: float = 0.995, grad_clip_norm: Optional[float] = None,
                  optim_params: Optional[dict] = None, device: str = "cpu"):
         self.device = device
-        self.ema_rate, self.grad_clip_norm = ema_rate, grad_clip_norm
+        self.ema_rate = ema_rate
+        self.grad_clip_norm = grad_clip_norm
         self.model = nn_classifier.to(device)
         self.model_ema = deepcopy(self.model).eval()
-        self.optim = torch.optim.Adam(self.model.parameters(), **(optim_params or {"lr": 2e-4, "weight_decay": 1e-4}))
+        self.optim = torch.optim.Adam(self.model.parameters(), **(_DEFAULT_ADAM if optim_params is None else optim_params))
 
-    def eval(self):
-        self.model.eval()
-        self.model_ema.eval()
-
-    def train(self):
-        self.model.train()
-
-    def ema_update(self):
-        with torch.no_grad():
-            for p, p_ema in zip(self.model.parameters(), self.model_ema.parameters()):
-                p_ema.data.mul_(self.ema_rate).add_(p.data, alpha=1. - self.ema_rate)
-
+    # ---- what a concrete classifier defines ----
     def loss(self, x: torch.Tensor, noise: torch.Tensor, y: torch.Tensor):
         raise NotImplementedError
 
+    def logp(self, x: torch.Tensor, noise: torch.Tensor, c: torch.Tensor):
+        """log p(c | x_t, noise level): x (b, *x_shape), noise (b,), c (b, *c_shape) -> (b, 1)."""
+        raise NotImplementedError
+
+    # ---- guidance signal ----
+    def gradients(self, x: torch.Tensor, noise: torch.Tensor, c: torch.Tensor):
+        if x.is_cuda:
+            from ..engine import classifier_grad
+            native = classifier_grad.gradients(self, x, noise, c)        # None: not a network with hand-written backward kernels
+            if native is not None:
+                return native
+        x.requires_grad_()
+        logp = self.logp(x, noise, c)
+        (grad,) = torch.autograd.grad([logp.sum()], [x])
+        x.detach()                                                       # (no-op, as in the reference: x keeps requires_grad)
+        return logp.detach(), grad.detach()
+
+    # ---- training ----
     def update(self, x: torch.Tensor, noise: torch.Tensor, y: torch.Tensor, update_ema: bool = True):
         loss = self.loss(x, noise, y)
         self.optim.zero_grad()
         loss.backward()
-        grad_norm = torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_clip_norm).item() \
-            if isinstance(self.grad_clip_norm, float) else None
+        grad_norm = None
+        if isinstance(self.grad_clip_norm, float):
+            grad_norm = torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_clip_norm).item()
         self.optim.step()
         if update_ema:
             self.ema_update()
         return {"loss": loss.item(), "grad_norm": grad_norm}
 
-    def logp(self, x: torch.Tensor, noise: torch.Tensor, c: torch.Tensor):
-        raise NotImplementedError
+    def ema_update(self):
+        keep = self.ema_rate
+        with torch.no_grad():
+            for live, avg in zip(self.model.parameters(), self.model_ema.parameters()):
+                avg.data.mul_(keep).add_(live.data, alpha=1. - keep)
 
-    def gradients(self, x: torch.Tensor, noise: torch.Tensor, c: torch.Tensor):
-        if x.is_cuda:                         # explicit forward + backward kernels (engine/classifier_grad.py); None -> autograd
-            from ..engine import classifier_grad
-            native = classifier_grad.gradients(self, x, noise, c)
-            if native is not None:
-                return native
-        x.requires_grad_()
-        logp = self.logp(x, noise, c)
-        grad = torch.autograd.grad([logp.sum()], [x])[0]
-        x.detach()
-        return logp.detach(), grad.detach()
+    def train(self):
+        self.model.train()
 
+    def eval(self):
+        for m in (self.model, self.model_ema):
+            m.eval()
+
+    # ---- checkpoints ----
     def save(self, path):
-        torch.save({"model": self.model.state_dict(), "model_ema": self.model_ema.state_dict()}, path)
+        torch.save({name: getattr(self, name).state_dict() for name in ("model", "model_ema")}, path)
 
     def load(self, path):
         ckpt = torch.load(path, map_location=self.device)
-        self.model.load_state_dict(ckpt["model"])
-        self.model_ema.load_state_dict(ckpt["model_ema"])
+        for name in ("model", "model_ema"):
+            getattr(self, name).load_state_dict(ckpt[name])
