@@ -1,8 +1,2 @@
-class BasicInvDynamic:
-    """Protocol of an inverse-dynamics head: ``predict(...)`` and call-through (reference invdynamic/common.py:1-6)."""
-
-    def predict(self, **kwargs):
-        raise NotImplementedError
-
-    def __call__(self, **kwargs):
-        return self.predict(**kwargs)
+"""Module-path alias: reference invdynamic/common.py (the protocol class lives next to its implementations in mlp.py)."""
+from .mlp import BasicInvDynamic  # noqa: F401

@@ -18,6 +18,17 @@ def _forward_rows(net: nn.Module, x: torch.Tensor) -> torch.Tensor:
     return net(x) if y is None else y
 
 
+class BasicInvDynamic:
+    """Protocol of an inverse-dynamics head (reference invdynamic/common.py:1-6): ``predict`` with keyword arguments, and calling the
+    object is calling ``predict``."""
+
+    def predict(self, **kwargs):
+        raise NotImplementedError
+
+    def __call__(self, **kwargs):
+        return self.predict(**kwargs)
+
+
 class _MseTrainedHead:
     """update/predict/train/eval/save/load shared by the heads; subclasses provide ``forward`` and ``_net``."""
 
