@@ -60,6 +60,9 @@ def compile_chain(seq: nn.Module) -> Optional[List[Tuple]]:
 def native_ok(x: torch.Tensor, params) -> bool:
     if not x.is_cuda or x.dtype != torch.float32:
         return False
+    params = list(params)
+    if any(p.dtype != torch.float32 or p.device != x.device for p in params):
+        return False                                   # mixed precision / split placement: whatever PyTorch makes of it
     if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
         return False
     return True
