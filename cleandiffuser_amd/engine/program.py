@@ -292,9 +292,9 @@ class _Builder:
             groups = getattr(col_norm, "num_groups", 1)             # nn.LayerNorm == one group over all channels
             assert c_out % groups == 0
             cg = c_out // groups
-            assert cg & (cg - 1) == 0 and c_out <= 1024, "per-column norm: power-of-two group size, C_out <= 1024"
+            assert c_out <= 1024, "per-column norm: C_out <= 1024"       # any group size: the epilogue strides lanes over cg
             words[W_NORM], words[W_GROUPS], words[W_CG] = NORM_COLUMN, groups, cg
-            words[W_CG_SHIFT] = cg.bit_length() - 1
+            words[W_CG_SHIFT] = cg.bit_length() - 1 if cg & (cg - 1) == 0 else -1
             words[W_INV_CNT] = _fbits(1.0 / cg)
             words[W_GAMMA], words[W_BETA] = self.add(col_norm.weight), self.add(col_norm.bias)
         if scale is not None:

@@ -577,3 +577,32 @@ def test_condition_encoders_run_native(amd_lib, monkeypatch):
     enc = cases[0][0].train()                                  # training: label-dropout mask + autograd -> stock modules
     out = enc(cases[0][1].cuda())
     assert out.requires_grad and calls["eager"] == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hidden,batch", [(64, 5), (192, 37), (512, 16)])
+def test_pearce_mlp_widths_fused_vs_cpu(hidden, batch, amd_lib, monkeypatch):
+    """Batch-tiled MLP program at other widths than the config-1 fixture (group sizes 8 / 24 / 64 in the segmented GroupNorm epilogue,
+    ragged last tile): fused sample on the device against the same agent's PyTorch executor on the CPU, same noise."""
+    from cleandiffuser_amd.diffusion import DiscreteDiffusionSDE
+    from cleandiffuser_amd.nn_condition import PearceObsCondition
+    from cleandiffuser_amd.nn_diffusion import PearceMlp
+    from cleandiffuser_amd.utils import load_synth
+    steps = 8
+
+    def make(device):
+        net = load_synth(PearceMlp(6, To=1, emb_dim=32, hidden_dim=hidden), 3)
+        cond = load_synth(PearceObsCondition(11, 32, flatten=True, dropout=0.0), 4)
+        agent = DiscreteDiffusionSDE(net, cond, predict_noise=False, x_max=torch.ones(1, 6), x_min=-torch.ones(1, 6),
+                                     diffusion_steps=steps, device=device)
+        agent.eval()
+        return agent
+    g = torch.Generator().manual_seed(hidden)
+    obs = torch.randn(batch, 1, 11, generator=g)
+    zs = [torch.randn(batch, 6, generator=g) for _ in range(steps + 1)]
+    kw = dict(solver="ddpm", n_samples=batch, sample_steps=steps, temperature=0.7, w_cfg=1.0)
+    want, _ = make("cpu").sample(torch.zeros(batch, 6), condition_cfg=obs, noise=list(zs), **kw)
+    launches = _spy_launches(monkeypatch)
+    got, _ = make(DEV).sample(torch.zeros(batch, 6, device=DEV), condition_cfg=obs.to(DEV), noise=[z.to(DEV) for z in zs], **kw)
+    assert launches["n"] == 1, "whole loop in one fused launch"
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), **TOL)
