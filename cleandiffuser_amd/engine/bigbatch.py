@@ -444,12 +444,21 @@ UNET_GEMM_MIN_BATCH = int(os.environ.get("CDX_UNET_GEMM_MIN_BATCH", 96))   # mea
 JANNER_GEMM_MIN_BATCH = int(os.environ.get("CDX_JANNER_GEMM_MIN_BATCH", 2048))   # config-2 net: 0.39x at 256, 0.89x at 1024, 1.16x at 3200
 
 
-def is_chiunet_gemm(module, batch: int) -> bool:
+def is_chiunet_gemm(module, batch: int, horizon: Optional[int] = None) -> bool:
+    """Should this U-Net request go to the implicit-GEMM executor?  Yes from the measured crossover batch up, and -- when the
+    horizon is given -- for configurations the one-workgroup program kernel cannot hold at all (wide / long nets whose
+    activations exceed the LDS plan): those would otherwise drop to the PyTorch executor."""
     from ..nn_diffusion.chiunet import ChiUNet1d
     from ..nn_diffusion.jannerunet import JannerUNet1d
     if type(module) is JannerUNet1d:
-        return batch >= JANNER_GEMM_MIN_BATCH
-    return type(module) is ChiUNet1d and module.obs_as_global_cond and batch >= UNET_GEMM_MIN_BATCH
+        big = batch >= JANNER_GEMM_MIN_BATCH
+    elif type(module) is ChiUNet1d and module.obs_as_global_cond:
+        big = batch >= UNET_GEMM_MIN_BATCH
+    else:
+        return False
+    if big or horizon is None:
+        return big
+    return runtime.supported_backbone(module, horizon) is not None
 
 
 def _bind_unet_gemm(net, tokens: int, dev):
@@ -591,7 +600,7 @@ def sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed) -> Optional[torc
         kind, (b, tokens, d) = "dit", xt.shape
         bound = _bound(net, ("dit", tokens), lambda: _bind_dit(net, tokens, dev))
         hd, rows_h = tokens * d, tokens
-    elif is_chiunet_gemm(net, xt.shape[0]):
+    elif is_chiunet_gemm(net, xt.shape[0], xt.shape[1] if xt.dim() == 3 else None):
         from ..nn_diffusion.jannerunet import JannerUNet1d
         janner = type(net) is JannerUNet1d
         if xt.dim() != 3 or (janner and cond_vec is not None and w_cfg != 0.0) or \

@@ -155,7 +155,13 @@ def supported_backbone(module, horizon: int) -> Optional[str]:
         why = P.supports_half_janner(module)
         if why:
             return why
-        return None if horizon == module.horizon else f"classifier was built for horizon {module.horizon}"
+        if horizon != module.horizon:
+            return f"classifier was built for horizon {module.horizon}"
+        try:
+            compiled_program(module, horizon)
+        except ValueError as e:
+            return str(e)
+        return None
     if _is_chiunet(module):
         why = P.supports_chiunet(module)
         if why:
@@ -176,6 +182,10 @@ def supported_backbone(module, horizon: int) -> Optional[str]:
     n_down = sum(1 for lvl in module.downs if not isinstance(lvl[3], torch.nn.Identity))
     if horizon % (1 << n_down) != 0:
         return f"horizon {horizon} not divisible by 2^{n_down}"
+    try:
+        compiled_program(module, horizon)                # cached: the caller's own compiled_program() call is a hit
+    except ValueError as e:                              # wide / long configurations whose LDS plan exceeds one workgroup
+        return str(e)
     return None
 
 

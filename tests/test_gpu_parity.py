@@ -606,3 +606,35 @@ def test_pearce_mlp_widths_fused_vs_cpu(hidden, batch, amd_lib, monkeypatch):
     got, _ = make(DEV).sample(torch.zeros(batch, 6, device=DEV), condition_cfg=obs.to(DEV), noise=[z.to(DEV) for z in zs], **kw)
     assert launches["n"] == 1, "whole loop in one fused launch"
     np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), **TOL)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("horizon,dim_mult,model_dim", [(128, [1, 2, 2, 2], 32), (64, [1, 4, 2], 48)])
+def test_janner_beyond_one_workgroup_takes_gemm_executor(horizon, dim_mult, model_dim, amd_lib, monkeypatch):
+    """Long-horizon / wide JannerUNet1d (maze2d-style plans) does not fit the one-workgroup program kernel's LDS plan: small batches
+    go to the implicit-GEMM U-Net executor instead of failing or dropping to eager (the backbone itself requires 2^n horizons)."""
+    from cleandiffuser_amd.diffusion import DiscreteDiffusionSDE
+    from cleandiffuser_amd.engine import runtime
+    from cleandiffuser_amd.nn_diffusion import JannerUNet1d
+    from cleandiffuser_amd.utils import load_synth
+    D, B, steps = 6, 3, 3
+
+    def make(device):
+        net = load_synth(JannerUNet1d(D, model_dim=model_dim, emb_dim=32, dim_mult=dim_mult, kernel_size=5), 11)
+        fm = torch.zeros(horizon, D)
+        fm[0, :4] = 1.0
+        agent = DiscreteDiffusionSDE(net, None, fix_mask=fm, diffusion_steps=10, predict_noise=False, device=device)
+        agent.eval()
+        return agent
+    g = torch.Generator().manual_seed(horizon)
+    prior = torch.zeros(B, horizon, D)
+    prior[:, 0, :4] = torch.randn(B, 4, generator=g)
+    zs = [torch.randn(B, horizon, D, generator=g) for _ in range(steps + 1)]
+    kw = dict(solver="ddim", n_samples=B, sample_steps=steps, temperature=0.8)
+    want, _ = make("cpu").sample(prior, noise=list(zs), **kw)
+    dev_agent = make(DEV)
+    assert runtime.supported_backbone(dev_agent.model_ema["diffusion"], horizon) is not None       # program kernel: LDS plan too large
+    calls = _spy_bigbatch(monkeypatch)
+    got, _ = dev_agent.sample(prior.to(DEV), noise=[z.to(DEV) for z in zs], **kw)
+    assert [c[0] for c in calls] == ["chiunet"]
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), **TOL)
