@@ -376,7 +376,10 @@ def fused_sample_mlp(solver, net, kind, plan, xt, prior, cond_vec, w_cfg, feed) 
         cond = rows(torch.flatten(cond_vec, 1))
     load_library()
     with torch.no_grad():
-        comp = compiled_program(net, tile)
+        try:
+            comp = compiled_program(net, tile)
+        except ValueError:                            # very wide nets: the tile's LDS plan exceeds one workgroup -> PyTorch executor
+            return None
         if cond is not None and cond.shape[1] != comp.prog.cond_dim:
             return None
         t_vec = device_times(plan, dev)
