@@ -471,7 +471,32 @@ def _chiunet_chunk(batch: int, Ta: int, model_dim: int, two: int) -> int:
     return max(min(batch, rows // (Ta * two)), 1)
 
 
+def janner_forward(net, x, noise) -> Optional[torch.Tensor]:
+    """Unconditional JannerUNet1d.forward with per-sample timesteps through the implicit-GEMM executor (what a guided /
+    custom loop calls once per step when the net is too large for the one-workgroup program kernel)."""
+    if x.dim() != 3:
+        return None
+    dev = x.device
+    b, H, d = x.shape
+    bound = _bound(net, ("chiunet", H), lambda: _bind_janner_gemm(net, H, dev))
+    if bound is None or d != bound.struct.act_dim:
+        return None
+    w = bound.struct
+    with torch.no_grad():
+        temb = _f32c(net.map_noise(noise), dev)
+        xin = _f32c(x, dev)
+        out = torch.empty_like(xin)
+        _run("chiunet", bound, batch=b, hd=H * d, emb_dim=w.emb_dim, cond_dim=0, temb=temb, steps=None, n_steps=0,
+             temb_per_sample=1, predict_noise=0, cfg_mode=0, cfg_w=0.0, cond=None, x_in=xin, prior=None, fix_mask=None,
+             noise=None, x_min=None, x_max=None, x_out=out,
+             chunk=CHUNK_OVERRIDE["chiunet"] or _chiunet_chunk(b, H, net.model_dim if hasattr(net, "model_dim") else 32, 1))
+    return out
+
+
 def chiunet_forward(net, x, noise, condition) -> Optional[torch.Tensor]:
+    from ..nn_diffusion.jannerunet import JannerUNet1d
+    if type(net) is JannerUNet1d:
+        return janner_forward(net, x, noise) if condition is None else None
     if x.dim() != 3 or condition is None:
         return None
     dev = x.device
