@@ -697,3 +697,43 @@ def test_kitchen_size_diffuser_guided_loop_uses_native_forward_and_gradient(amd_
     assert len(calls) == steps and grads["n"] == steps, (calls, grads)
     np.testing.assert_allclose(got_g.cpu().numpy(), want_g.numpy(), rtol=2e-4, atol=2e-4)
     assert int(log_d["log_p"].argmax()) == int(log_c["log_p"].argmax())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["chitf_ta10", "dit_h10_d384", "dit_h40_depth8"])
+def test_shipped_transformer_shapes_native_vs_cpu(which, amd_lib, monkeypatch):
+    """Token counts / widths of the shipped dp_* and veteran configs that the fixtures do not cover (Ta = 10, 10 and 40 tokens,
+    head_dim 64, depth 8): whole loop native, equal to the CPU executor on the same noise."""
+    from cleandiffuser_amd.diffusion import DiscreteDiffusionSDE
+    from cleandiffuser_amd.nn_condition import IdentityCondition
+    from cleandiffuser_amd.nn_diffusion import ChiTransformer, DiT1d
+    from cleandiffuser_amd.utils import load_synth
+    B, steps = 3, 3
+    if which == "chitf_ta10":
+        mk_net = lambda: ChiTransformer(7, 23, 10, 2, d_model=256, nhead=4, num_layers=3)          # noqa: E731
+        x_shape, cond_shape, kind = (10, 7), (2, 23), "chitf"
+    elif which == "dit_h10_d384":
+        mk_net = lambda: DiT1d(7, emb_dim=64, d_model=384, n_heads=6, depth=2)                      # noqa: E731
+        x_shape, cond_shape, kind = (10, 7), (64,), "dit"
+    else:
+        mk_net = lambda: DiT1d(29, emb_dim=128, d_model=256, n_heads=8, depth=8, timestep_emb_type="fourier")   # noqa: E731
+        x_shape, cond_shape, kind = (40, 29), (128,), "dit"
+
+    def make(device):
+        agent = DiscreteDiffusionSDE(load_synth(mk_net(), 31), IdentityCondition(dropout=0.0), predict_noise=True,
+                                     x_max=2 * torch.ones(1, *x_shape), x_min=-2 * torch.ones(1, *x_shape), diffusion_steps=20,
+                                     device=device)
+        agent.eval()
+        return agent
+    g = torch.Generator().manual_seed(len(which))
+    cond = torch.randn(B, *cond_shape, generator=g)
+    zs = [torch.randn(B, *x_shape, generator=g) for _ in range(steps + 1)]
+    kw = dict(solver="ddim", n_samples=B, sample_steps=steps, w_cfg=1.3)
+    want, _ = make("cpu").sample(torch.zeros(B, *x_shape), condition_cfg=cond, noise=list(zs), **kw)
+    calls = _spy_bigbatch(monkeypatch)
+    got, _ = make(DEV).sample(torch.zeros(B, *x_shape, device=DEV), condition_cfg=cond.to(DEV), noise=[z.to(DEV) for z in zs], **kw)
+    assert [c[0] for c in calls] == [kind]
+    # depth 8 on synthetic (untrained, saturating) weights amplifies fp32 summation-order differences through eight unnormalised
+    # residual blocks and the eps-clip: 3 of 3480 elements reach 2.9e-4 there; the 2-3 block cases hold the 1e-4 bar
+    tol = dict(rtol=5e-4, atol=5e-4) if which == "dit_h40_depth8" else TOL
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), **tol)
