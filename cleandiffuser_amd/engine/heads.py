@@ -87,13 +87,14 @@ def run_chain(ops, x: torch.Tensor) -> torch.Tensor:
 
 
 def try_sequential(seq: nn.Module, x: torch.Tensor) -> Optional[torch.Tensor]:
-    """``seq(x)`` through the HIP library, or None for the PyTorch path.  The compiled chain is cached on the module and
-    rebuilt when train()/eval() flips (dropout) -- weights are read in place, so optimiser steps need no invalidation."""
+    """``seq(x)`` through the HIP library, or None for the PyTorch path.  The compiled chain is cached on the module and rebuilt
+    when train()/eval() flips (dropout) or a sub-module is replaced -- weights are read in place, so optimiser steps and
+    ``load_state_dict`` need no invalidation."""
     if not native_ok(x, seq.parameters()):
         return None
     if x.numel() == 0:
         return None
-    key = bool(seq.training)
+    key = (bool(seq.training), tuple(id(m) for m in seq.modules()))        # train/eval flips and swapped sub-modules recompile
     cached = getattr(seq, "_cdx_chain", None)
     if cached is None or cached[0] != key:
         cached = (key, compile_chain(seq))
