@@ -444,7 +444,7 @@ UNET_GEMM_MIN_BATCH = int(os.environ.get("CDX_UNET_GEMM_MIN_BATCH", 96))   # mea
 JANNER_GEMM_MIN_BATCH = int(os.environ.get("CDX_JANNER_GEMM_MIN_BATCH", 2048))   # config-2 net: 0.39x at 256, 0.89x at 1024, 1.16x at 3200
 
 
-def is_chiunet_gemm(module, batch: int, horizon: Optional[int] = None) -> bool:
+def is_chiunet_gemm(module, batch: int, horizon: Optional[int] = None, edm: bool = False) -> bool:
     """Should this U-Net request go to the implicit-GEMM executor?  Yes from the measured crossover batch up, and -- when the
     horizon is given -- for configurations the one-workgroup program kernel cannot hold at all (wide / long nets whose
     activations exceed the LDS plan): those would otherwise drop to the PyTorch executor."""
@@ -458,7 +458,7 @@ def is_chiunet_gemm(module, batch: int, horizon: Optional[int] = None) -> bool:
         return False
     if big or horizon is None:
         return big
-    return runtime.supported_backbone(module, horizon) is not None
+    return runtime.supported_backbone(module, horizon, edm) is not None
 
 
 def _bind_unet_gemm(net, tokens: int, dev):
@@ -625,7 +625,7 @@ def sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed) -> Optional[torc
         kind, (b, tokens, d) = "dit", xt.shape
         bound = _bound(net, ("dit", tokens), lambda: _bind_dit(net, tokens, dev))
         hd, rows_h = tokens * d, tokens
-    elif is_chiunet_gemm(net, xt.shape[0], xt.shape[1] if xt.dim() == 3 else None):
+    elif is_chiunet_gemm(net, xt.shape[0], xt.shape[1] if xt.dim() == 3 else None, runtime.plan_is_edm(plan)):
         from ..nn_diffusion.jannerunet import JannerUNet1d
         janner = type(net) is JannerUNet1d
         if xt.dim() != 3 or (janner and cond_vec is not None and w_cfg != 0.0) or \

@@ -52,7 +52,7 @@ def try_fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, requ
         return guided.guided_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, feed)
     from . import bigbatch, runtime
     net = model["diffusion"]
-    if bigbatch.is_chiunet_gemm(net, xt.shape[0], xt.shape[1] if xt.dim() == 3 else None):
+    if bigbatch.is_chiunet_gemm(net, xt.shape[0], xt.shape[1] if xt.dim() == 3 else None, runtime.plan_is_edm(plan)):
         out = bigbatch.sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed)
         if out is not None:
             return out
@@ -71,7 +71,7 @@ def try_fused_edm(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, require
     net = model["diffusion"]
     if bigbatch.is_resmlp(net) or bigbatch.is_dit1d(net) or bigbatch.is_chitf(net):
         return bigbatch.sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed)
-    if bigbatch.is_chiunet_gemm(net, xt.shape[0], xt.shape[1] if xt.dim() == 3 else None):
+    if bigbatch.is_chiunet_gemm(net, xt.shape[0], xt.shape[1] if xt.dim() == 3 else None, runtime.plan_is_edm(plan)):
         out = bigbatch.sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed)
         if out is not None:
             return out
@@ -85,7 +85,7 @@ def try_fused_legacy_ddpm(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg,
     if solver.classifier is not None and w_cg != 0.0:
         return None
     from . import bigbatch, runtime
-    if bigbatch.is_chiunet_gemm(model["diffusion"], xt.shape[0], xt.shape[1] if xt.dim() == 3 else None):
+    if bigbatch.is_chiunet_gemm(model["diffusion"], xt.shape[0], xt.shape[1] if xt.dim() == 3 else None, runtime.plan_is_edm(plan)):
         out = bigbatch.sample(solver, model["diffusion"], plan, xt, prior, cond_vec, w_cfg, feed)
         if out is not None:
             return out

@@ -438,8 +438,10 @@ def _emb_chain(b: "_Builder", net, blocks, raw_emb_vec: Optional[int] = None):
 def _finalize(b: "_Builder", net, x: Act, pred: Optional[Act], horizon: int, d: int, max_lds_bytes: int,
               out_vec: int = -1, out_len: int = 0, persist: Sequence[Act] = (), emb_dim: Optional[int] = None,
               cond_slot: Optional[Tuple[Act, int, int]] = None, tile: int = 0,
-              vec_alias: Sequence[Tuple[Act, int]] = ()) -> Program:
-    """LDS map [x | pred0 | pred1 | prev(dense) | vec | scratch | descriptors | stamps | arena...], offsets patched."""
+              vec_alias: Sequence[Tuple[Act, int]] = (), edm: bool = True) -> Program:
+    """LDS map [x | pred0 | pred1 | prev(dense) | vec | scratch | descriptors | stamps | arena...], offsets patched.
+    `edm`: reserve the two extra dense buffers (x_old, x_true) the EDM / consistency step kinds keep next to the multistep
+    memory; programs compiled without them are 2 x H x D floats smaller and must only be launched with step kinds 0-4."""
     dev = b.device
     off = 0
     x.off, off = off, off + x.floats
@@ -455,7 +457,7 @@ def _finalize(b: "_Builder", net, x: Act, pred: Optional[Act], horizon: int, d: 
     sources = [a for reads, _ in b.op_acts for a in reads]
     zrow_floats = max(pad16(a.chans) for a in sources) + 16
     off += zrow_floats
-    prev_off, off = off, off + 3 * ((horizon * d + 3) // 4 * 4)     # multistep memory / EDM slope | x_old | x_true
+    prev_off, off = off, off + (3 if edm else 1) * ((horizon * d + 3) // 4 * 4)     # multistep memory / EDM slope [| x_old | x_true]
     vec_off, off = off, off + b.vec_len
     for a, rel in vec_alias:                              # 1-row slots that ARE vectors (Linear lowered as a 1-position conv)
         a.off = vec_off + rel
@@ -512,7 +514,7 @@ def _finalize(b: "_Builder", net, x: Act, pred: Optional[Act], horizon: int, d: 
                    meta={"n_ops": len(ops), "blob_floats": int(blob.numel())})
 
 
-def compile_janner(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x4: bool = True) -> Program:
+def compile_janner(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x4: bool = True, edm: bool = True) -> Program:
     """Lower a JannerUNet1d (reference nn_diffusion/jannerunet.py:98-201 structure) for `horizon` positions."""
     why = supports_janner(net)
     if why is not None:
@@ -553,7 +555,7 @@ def compile_janner(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x4
     b.conv([cur], t, _conv1d_eff(fc[0]), fc[0].bias, pad=2, gn=fc[1])
     pred = b.act(horizon, d, persistent=True)
     b.conv([t], pred, _conv1d_eff(fc[3]), fc[3].bias, dst_pred=True)
-    return _finalize(b, net, x, pred, horizon, d, max_lds_bytes)
+    return _finalize(b, net, x, pred, horizon, d, max_lds_bytes, edm=edm)
 
 
 def supports_half_janner(net) -> Optional[str]:
@@ -599,7 +601,7 @@ def compile_half_janner(net, horizon: int, max_lds_bytes: int = 160 * 1024, allo
     v_h, v_out = b.vec(net.final_block[0].out_features), b.vec(net.out_dim)
     b.linear(net.final_block[0].weight, net.final_block[0].bias, v_cat, v_h, post_mish=True)
     b.linear(net.final_block[2].weight, net.final_block[2].bias, v_h, v_out)
-    return _finalize(b, net, x, None, horizon, d, max_lds_bytes, out_vec=v_out, out_len=net.out_dim)
+    return _finalize(b, net, x, None, horizon, d, max_lds_bytes, out_vec=v_out, out_len=net.out_dim, edm=False)   # forward-only
 
 
 # ================================================================================================== #
@@ -617,7 +619,7 @@ def _lin_eff(lin: nn.Linear, pad_in: int = 0) -> torch.Tensor:
     return w.unsqueeze(1)
 
 
-def compile_pearce_mlp(net, tile: int = MLP_TILE, max_lds_bytes: int = 160 * 1024) -> Program:
+def compile_pearce_mlp(net, tile: int = MLP_TILE, max_lds_bytes: int = 160 * 1024, edm: bool = True) -> Program:
     """PearceMlp (reference nn_diffusion/pearcemlp.py:36-79).  Slots: state [x | raw t] (D+1 channels), context
     [t_emb | flattened condition]; FCBlock = Linear -> per-sample GroupNorm -> GELU(erf); skips are stored pre-scaled by
     1/1.414 exactly where the reference divides (Q11)."""
@@ -642,10 +644,10 @@ def compile_pearce_mlp(net, tile: int = MLP_TILE, max_lds_bytes: int = 160 * 102
     pred = b.act(tile, d, persistent=True)
     b.conv([h3, x], pred, _lin_eff(f[3]), f[3].bias, dst_pred=True)
     return _finalize(b, net, x, pred, tile, d, max_lds_bytes, persist=[ctx], emb_dim=e + 1,
-                     cond_slot=(ctx, e, n_cond), tile=tile)
+                     cond_slot=(ctx, e, n_cond), tile=tile, edm=edm)
 
 
-def compile_dql_mlp(net, tile: int = MLP_TILE, max_lds_bytes: int = 160 * 1024) -> Program:
+def compile_dql_mlp(net, tile: int = MLP_TILE, max_lds_bytes: int = 160 * 1024, edm: bool = True) -> Program:
     """DQLMlp (reference nn_diffusion/dqlmlp.py:9-52) and DVInvMlp (dvinvmlp.py:9-47, same trunk): features [x | time_mlp(map_noise(t)) | obs] -> 3 x (Linear, Mish)
     -> Linear.  The time MLP is batch-invariant, so it runs once per step on a vector and is broadcast into the context."""
     b = _Builder(next(net.parameters()).device)
@@ -668,7 +670,7 @@ def compile_dql_mlp(net, tile: int = MLP_TILE, max_lds_bytes: int = 160 * 1024) 
     pred = b.act(tile, d, persistent=True)
     b.conv([m3], pred, _lin_eff(net.final_layer), net.final_layer.bias, dst_pred=True)
     return _finalize(b, net, x, pred, tile, d, max_lds_bytes, persist=[ctx], emb_dim=e,
-                     cond_slot=(ctx, e, obs), tile=tile)
+                     cond_slot=(ctx, e, obs), tile=tile, edm=edm)
 
 
 # ================================================================================================== #
@@ -683,7 +685,7 @@ def supports_chiunet(net) -> Optional[str]:
     return None
 
 
-def compile_chiunet(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x4: bool = True) -> Program:
+def compile_chiunet(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x4: bool = True, edm: bool = True) -> Program:
     """ChiUNet1d with a global condition (reference nn_diffusion/chiunet.py:48-192).  The FiLM vector of a block
     (Mish -> Linear(2*emb -> [2]C)) is computed just in time into one reusable vec region -- at config-3 width the
     stacked vectors of all blocks would not fit LDS."""
@@ -757,6 +759,6 @@ def compile_chiunet(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x
     pred = b.act(horizon, d, persistent=True)
     b.conv([t], pred, _conv1d_eff(fc[3]), fc[3].bias, dst_pred=True)
     prog = _finalize(b, net, x, pred, horizon, d, max_lds_bytes, emb_dim=e,
-                     vec_alias=[(memb_slot, v_memb), (film_slot, v_film)])
+                     vec_alias=[(memb_slot, v_memb), (film_slot, v_film)], edm=edm)
     prog.cond_dim = n_cond
     return prog

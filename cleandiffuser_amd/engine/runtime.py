@@ -103,24 +103,33 @@ def _signature(module):
         tuple((b.data_ptr(), b._version) for b in module.buffers())
 
 
-def compiled_program(module, horizon: int) -> _Compiled:
+def compiled_program(module, horizon: int, edm: bool = False) -> _Compiled:
+    """The module's program at this horizon.  `edm`: with the two extra dense state buffers of the EDM / consistency step kinds
+    (2 x H x D floats of LDS more -- the difference between fitting and not fitting for the shipped Diffuser kitchen net)."""
     per_mod = _cache.setdefault(module, {})
     sig = _signature(module)
-    hit = per_mod.get(horizon)
+    key = (horizon, bool(edm) and not _is_half_janner(module))
+    hit = per_mod.get(key)
     if hit is not None and hit.sig == sig:
         return hit
     with torch.no_grad():
         kind = _mlp_kind(module)
         if kind == "pearce":
-            prog = P.compile_pearce_mlp(module, horizon)
+            prog = P.compile_pearce_mlp(module, horizon, edm=edm)
         elif kind == "dql":
-            prog = P.compile_dql_mlp(module, horizon)
+            prog = P.compile_dql_mlp(module, horizon, edm=edm)
         elif _is_chiunet(module):
-            prog = P.compile_chiunet(module, horizon)
+            prog = P.compile_chiunet(module, horizon, edm=edm)
+        elif _is_half_janner(module):
+            prog = P.compile_half_janner(module, horizon)
         else:
-            prog = (P.compile_half_janner if _is_half_janner(module) else P.compile_janner)(module, horizon)
-    per_mod[horizon] = _Compiled(prog, sig)
-    return per_mod[horizon]
+            prog = P.compile_janner(module, horizon, edm=edm)
+    per_mod[key] = _Compiled(prog, sig)
+    return per_mod[key]
+
+
+def plan_is_edm(plan) -> bool:
+    return any(st.kind >= 5 for st in plan.steps)
 
 
 def _is_janner(module) -> bool:
@@ -149,7 +158,7 @@ def _is_half_janner(module) -> bool:
     return isinstance(module, HalfJannerUNet1d)
 
 
-def supported_backbone(module, horizon: int) -> Optional[str]:
+def supported_backbone(module, horizon: int, edm: bool = False) -> Optional[str]:
     """None if the fused kernel can run `module` at this horizon, else a human-readable reason."""
     if _is_half_janner(module):
         why = P.supports_half_janner(module)
@@ -170,7 +179,7 @@ def supported_backbone(module, horizon: int) -> Optional[str]:
         if horizon % (1 << n_down) != 0:
             return f"horizon {horizon} not divisible by 2^{n_down}"
         try:
-            compiled_program(module, horizon)
+            compiled_program(module, horizon, edm)
         except ValueError as e:                      # LDS plan does not fit one workgroup
             return str(e)
         return None
@@ -183,7 +192,7 @@ def supported_backbone(module, horizon: int) -> Optional[str]:
     if horizon % (1 << n_down) != 0:
         return f"horizon {horizon} not divisible by 2^{n_down}"
     try:
-        compiled_program(module, horizon)                # cached: the caller's own compiled_program() call is a hit
+        compiled_program(module, horizon, edm)           # cached: the caller's own compiled_program() call is a hit
     except ValueError as e:                              # wide / long configurations whose LDS plan exceeds one workgroup
         return str(e)
     return None
@@ -377,7 +386,7 @@ def fused_sample_mlp(solver, net, kind, plan, xt, prior, cond_vec, w_cfg, feed) 
     load_library()
     with torch.no_grad():
         try:
-            comp = compiled_program(net, tile)
+            comp = compiled_program(net, tile, plan_is_edm(plan))
         except ValueError:                            # very wide nets: the tile's LDS plan exceeds one workgroup -> PyTorch executor
             return None
         if cond is not None and cond.shape[1] != comp.prog.cond_dim:
@@ -402,7 +411,7 @@ def fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed) -> Optio
     net = model["diffusion"]
     if xt.dim() == 2 and _mlp_kind(net) is not None:
         return fused_sample_mlp(solver, net, _mlp_kind(net), plan, xt, prior, cond_vec, w_cfg, feed)
-    if xt.dim() != 3 or not (_is_janner(net) or _is_chiunet(net)) or supported_backbone(net, xt.shape[1]) is not None:
+    if xt.dim() != 3 or not (_is_janner(net) or _is_chiunet(net)) or supported_backbone(net, xt.shape[1], plan_is_edm(plan)) is not None:
         return None
     if cond_vec is None and w_cfg not in (0.0, 1.0):
         return None                                   # the reference raises here; let the torch executor do it
@@ -419,7 +428,7 @@ def fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed) -> Optio
         return None
     load_library()
     with torch.no_grad():
-        comp = compiled_program(net, h)
+        comp = compiled_program(net, h, plan_is_edm(plan))
         t_vec = device_times(plan, dev)
         temb = _f32c(net.map_noise(t_vec), dev)
         steps_dev = steps_to_device(plan, dev)

@@ -641,23 +641,26 @@ def test_janner_beyond_one_workgroup_takes_gemm_executor(horizon, dim_mult, mode
 
 
 @pytest.mark.gpu
-def test_kitchen_size_diffuser_guided_loop_uses_native_forward_and_gradient(amd_lib, monkeypatch):
-    """The shipped Diffuser kitchen configuration (JannerUNet1d model_dim 64, H = 32, D = 69) exceeds the program kernel's LDS plan:
-    unguided sampling takes the implicit-GEMM executor; the guided loop (every shipped config has w_cg > 0) runs the PyTorch step
-    logic around a native per-step forward (GEMM executor) and the native classifier gradient.  Checked against the CPU executor."""
+@pytest.mark.parametrize("size", ["kitchen", "antmaze"])
+def test_shipped_large_diffuser_configs_stay_native(size, amd_lib, monkeypatch):
+    """The two shipped Diffuser / AdaptDiffuser configurations with model_dim 64.  kitchen (H = 32, D = 69) fits the program kernel
+    once the EDM-only state buffers are left out of its LDS plan (159.7 of 160 KB): fused unguided loop, one-call guided loop.
+    antmaze (H = 64, D = 37, 242 KB) does not: unguided sampling is one implicit-GEMM executor call, the guided loop runs the PyTorch
+    step logic around a native per-step forward and the native classifier gradient.  Both against the CPU executor."""
     from cleandiffuser_amd.classifier import CumRewClassifier
     from cleandiffuser_amd.diffusion import DiscreteDiffusionSDE
-    from cleandiffuser_amd.engine import bigbatch, classifier_grad, runtime
+    from cleandiffuser_amd.engine import classifier_grad, guided, runtime
     from cleandiffuser_amd.nn_classifier import HalfJannerUNet1d
     from cleandiffuser_amd.nn_diffusion import JannerUNet1d
     from cleandiffuser_amd.utils import load_synth
-    H, D, B, steps = 32, 69, 3, 3
+    H, D, n_obs = (32, 69, 60) if size == "kitchen" else (64, 37, 29)
+    B, steps = 3, 3
 
     def make(device):
         net = load_synth(JannerUNet1d(D, model_dim=64, emb_dim=64, dim_mult=[1, 2, 2, 2], kernel_size=5), 21)
         clf_net = load_synth(HalfJannerUNet1d(H, D, out_dim=1, model_dim=64, emb_dim=64, dim_mult=(1, 2, 2, 2), kernel_size=3), 22)
         fm = torch.zeros(H, D)
-        fm[0, :60] = 1.0
+        fm[0, :n_obs] = 1.0
         agent = DiscreteDiffusionSDE(net, None, fix_mask=fm, classifier=CumRewClassifier(clf_net, device=device),
                                      diffusion_steps=10, predict_noise=False, device=device)
         agent.eval()
@@ -665,36 +668,46 @@ def test_kitchen_size_diffuser_guided_loop_uses_native_forward_and_gradient(amd_
         return agent
     g = torch.Generator().manual_seed(5)
     prior = torch.zeros(B, H, D)
-    prior[:, 0, :60] = torch.randn(B, 60, generator=g)
+    prior[:, 0, :n_obs] = torch.randn(B, n_obs, generator=g)
     zs = [torch.randn(B, H, D, generator=g) for _ in range(steps + 2)]
     cpu, dev = make("cpu"), make(DEV)
     net = dev.model_ema["diffusion"]
-    assert runtime.supported_backbone(net, H) is not None
-    # stand-alone forward with per-sample timesteps
+    fits = size == "kitchen"
+    assert (runtime.supported_backbone(net, H) is None) == fits
+    assert runtime.supported_backbone(net, H, edm=True) is not None                  # with the EDM buffers neither fits
     x, t = zs[0], torch.tensor([1, 4, 8])
-    with torch.no_grad():
+    with torch.no_grad():                                                            # stand-alone forward, per-sample timesteps
         want_f = cpu.model_ema["diffusion"](x, t, None)
         got_f = net(x.to(DEV), t.to(DEV), None)
     np.testing.assert_allclose(got_f.cpu().numpy(), want_f.numpy(), **TOL)
-    # unguided: one GEMM-executor call; guided: PyTorch loop, native forward + native gradient per step
     kw = dict(solver="ddpm", n_samples=B, sample_steps=steps, temperature=0.5)
-    calls = _spy_bigbatch(monkeypatch)
+    calls, fused = _spy_bigbatch(monkeypatch), _spy_launches(monkeypatch)
     want, _ = cpu.sample(prior, noise=list(zs), w_cg=0.0, **kw)
     got, _ = dev.sample(prior.to(DEV), noise=[z.to(DEV) for z in zs], w_cg=0.0, **kw)
-    assert len(calls) == 1
+    # program-kernel launches: the sampling loop (kitchen only) + the classifier's final logp forward (both sizes fit that one)
+    assert (len(calls), fused["n"]) == ((0, 2) if fits else (1, 1)), (calls, fused)
     np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), **TOL)
-    grads = {"n": 0}
-    real = classifier_grad.gradients
+    grads, one_call = {"n": 0}, {"n": 0}
+    real_grad, real_guided = classifier_grad.gradients, guided.guided_sample
 
     def counted(*a, **k):
-        out = real(*a, **k)
+        out = real_grad(*a, **k)
         grads["n"] += out is not None
         return out
+
+    def counted_guided(*a, **k):
+        out = real_guided(*a, **k)
+        one_call["n"] += out is not None
+        return out
     monkeypatch.setattr(classifier_grad, "gradients", counted)
+    monkeypatch.setattr(guided, "guided_sample", counted_guided)
     want_g, log_c = cpu.sample(prior, noise=list(zs), w_cg=0.2, condition_cg=None, **kw)
     del calls[:]
     got_g, log_d = dev.sample(prior.to(DEV), noise=[z.to(DEV) for z in zs], w_cg=0.2, condition_cg=None, **kw)
-    assert len(calls) == steps and grads["n"] == steps, (calls, grads)
+    if fits:
+        assert one_call["n"] == 1 and calls == []                                    # cdx_guided_run: the whole guided loop
+    else:
+        assert one_call["n"] == 0 and len(calls) == steps and grads["n"] == steps, (calls, grads)
     np.testing.assert_allclose(got_g.cpu().numpy(), want_g.numpy(), rtol=2e-4, atol=2e-4)
     assert int(log_d["log_p"].argmax()) == int(log_c["log_p"].argmax())
 
