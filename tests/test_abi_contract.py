@@ -100,3 +100,36 @@ def test_missing_library_is_a_hard_error(tmp_path):
     from cleandiffuser_amd.engine import runtime
     with pytest.raises(RuntimeError, match="native library not found"):
         runtime.load_library(str(tmp_path / "nope.so"))
+
+
+def test_newer_entries_validate_before_touching_the_device(lib):
+    """Cross-attention, GroupNorm (+ backward), ChiTransformer / U-Net / guided loops: bad requests are refused with a message and
+    no HIP call (this runs without a GPU); workspace queries are pure host arithmetic."""
+    from cleandiffuser_amd.engine import bigbatch, blocks, classifier_grad, guided
+    bigbatch._lib(), blocks._lib()
+    bad = -1
+    x = blocks.CdxXattnArgs(B=1, T=4, n_obs=16, n_heads=1, head_dim=8, q=8, kv_shared=8, kv_rows=8, out=8)
+    assert lib.cdx_cross_attention_f32(ctypes.byref(x), None) == bad and b"memory tokens" in lib.cdx_last_error()
+    assert lib.cdx_cross_attention_f32(ctypes.byref(blocks.CdxXattnArgs(B=0, T=4, n_obs=2, n_heads=1, head_dim=8)), None) == 0
+    g = blocks.CdxGnArgs(B=2, L=4, C=30, G=8, x=8, y=8, gamma=8, beta=8)
+    assert lib.cdx_groupnorm_f32(ctypes.byref(g), None) == bad and b"multiple of G" in lib.cdx_last_error()
+    g = blocks.CdxGnArgs(B=2, L=4, C=32, G=8, x=8, y=8, gamma=8, beta=8, residual=8, act=4)          # SiLU has no backward here
+    assert lib.cdx_groupnorm_bwd_f32(ctypes.byref(g), None) == bad
+    s = bigbatch.CdxSampling()
+    assert lib.cdx_chitf_run(ctypes.byref(bigbatch.CdxChitfWeights()), ctypes.byref(s), None) == bad
+    assert lib.cdx_chiunet_run(ctypes.byref(bigbatch.CdxChiUNetWeights()), ctypes.byref(s), None) == bad
+    lib.cdx_guided_run.restype = ctypes.c_int
+    assert lib.cdx_guided_run(ctypes.byref(guided.CdxGuidedLaunch()), None) == bad and b"null" in lib.cdx_last_error()
+    lib.cdx_act_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p]
+    assert lib.cdx_act_f32(None, None, 4, 1, None) == bad
+    assert lib.cdx_act_f32(8, 8, 0, 1, None) == 0                                                    # nothing to do is fine
+    # workspace sizes: host arithmetic, grows with the chunk, independent of the batch beyond the chunk
+    blk = (bigbatch.CdxDitBlock * 2)()
+    w = bigbatch.CdxDitWeights(tokens=64, in_dim=29, emb_dim=128, d_model=320, n_heads=10, depth=2, blocks=blk)
+
+    def need(batch, chunk, steps):
+        return lib.cdx_dit1d_workspace_floats(ctypes.byref(w), ctypes.byref(bigbatch.CdxSampling(batch=batch, hd=64 * 29, emb_dim=128,
+                                                                                                 n_steps=steps, cfg_mode=2, chunk=chunk)))
+    assert 0 < need(512, 128, 10) < need(512, 256, 10) < need(512, 512, 10) == need(512, 0, 10) == need(512, 4096, 10)
+    assert need(100000, 256, 10) == need(512, 256, 10) and need(512, 256, 20) > need(512, 256, 10)
+    assert lib.cdx_dit1d_workspace_floats(None, None) == -1
