@@ -26,12 +26,25 @@ def global_noise(shape, n_draws: int, seed: int) -> List[torch.Tensor]:
     return [torch.randn(shape, generator=g) for _ in range(n_draws)]
 
 
+def _all_gather_rows(local: torch.Tensor, n: int, world: int) -> torch.Tensor:
+    """Concatenate ragged (rows_r, ...) shards of an n-row tensor over the ranks: one padded all_gather."""
+    sizes = [shard_bounds(n, r, world) for r in range(world)]
+    biggest = max(b - a for a, b in sizes)
+    pad = torch.zeros((biggest, *local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)                       # the one exchange step (RCCL all-gather on GPUs)
+    return torch.cat([p[: b - a] for p, (a, b) in zip(parts, sizes)], dim=0)
+
+
 def sharded_sample(agent, prior: torch.Tensor, *, gather: bool = True, seed: Optional[int] = None,
-                   condition_cfg: Optional[torch.Tensor] = None, **sample_kwargs):
+                   condition_cfg: Optional[torch.Tensor] = None, return_logp: bool = False, **sample_kwargs):
     """Run ``agent.sample`` on this rank's slice of `prior` (global tensor, identical on every rank).
 
     Returns the global (B, ...) result on every rank if ``gather`` else the local shard.  ``seed`` draws the global
     noise list on the CPU and slices it (rank-count independent results); without it each rank uses its own RNG.
+    ``return_logp``: also return the classifier score ``log["log_p"]`` (B, 1) -- gathered like the samples -- so that candidate
+    selection (Diffuser: arg-max over the candidates of an environment) happens on the global batch after the one exchange.
     """
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
@@ -44,13 +57,12 @@ def sharded_sample(agent, prior: torch.Tensor, *, gather: bool = True, seed: Opt
     if seed is not None:
         n_draws = kw.get("sample_steps", 5) + kw.get("diffusion_x_sampling_steps", 0) + 1
         kw["noise"] = [z[lo:hi] for z in global_noise(tuple(prior.shape), n_draws, seed)]
-    x, _ = agent.sample(prior[lo:hi], **kw)
-    if not gather or world == 1:
-        return x
-    sizes = [shard_bounds(n, r, world) for r in range(world)]
-    biggest = max(b - a for a, b in sizes)
-    pad = torch.zeros((biggest, *x.shape[1:]), dtype=x.dtype, device=x.device)
-    pad[: x.shape[0]] = x
-    parts = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(parts, pad)                       # the one exchange step (RCCL all-gather on GPUs)
-    return torch.cat([p[: b - a] for p, (a, b) in zip(parts, sizes)], dim=0)
+    x, log = agent.sample(prior[lo:hi], **kw)
+    logp = log.get("log_p") if return_logp else None
+    if return_logp and logp is None:
+        raise ValueError("return_logp needs a solver with a classifier (log['log_p'] is absent)")
+    if gather and world > 1:
+        x = _all_gather_rows(x, n, world)
+        if logp is not None:
+            logp = _all_gather_rows(logp, n, world)
+    return (x, logp) if return_logp else x

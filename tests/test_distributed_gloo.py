@@ -27,8 +27,13 @@ def _worker(rank, world, port, out_path):
     agent, _ = cases.build(lib, "janner_tiny_disc_ddpm")
     prior = torch.zeros(5, 8, 6)                              # 5 rows over 2 ranks: ragged 3 + 2 split
     x = sharded_sample(agent, prior, gather=True, seed=11, solver="ddpm", sample_steps=5, temperature=0.8)
+    # Diffuser tail: classifier scores travel with the samples, candidate arg-max happens on the gathered batch
+    scorer, _ = cases.build(lib, "janner_cfg2_diffuser_logp")
+    c = cases.CASES["janner_cfg2_diffuser_logp"]
+    prior2 = torch.zeros(7, c["horizon"], c["net"][1]["in_dim"])
+    xs, logp = sharded_sample(scorer, prior2, gather=True, seed=3, return_logp=True, solver="ddim", sample_steps=3, temperature=0.5)
     if rank == 0:
-        torch.save(x, out_path)
+        torch.save({"x": x, "xs": xs, "logp": logp}, out_path)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -36,7 +41,8 @@ def _worker(rank, world, port, out_path):
 def test_two_rank_shard_and_gather_equals_single_process(tmp_path):
     out = str(tmp_path / "x.pt")
     mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
-    x2 = torch.load(out)
+    got = torch.load(out)
+    x2 = got["x"]
     sys.path.insert(0, ROOT)
     from cleandiffuser_amd.distributed import sharded_sample, shard_bounds
     from oracle import cases
@@ -46,5 +52,11 @@ def test_two_rank_shard_and_gather_equals_single_process(tmp_path):
     assert x2.shape == (5, 8, 6)
     # ATen CPU kernels block differently for batch 5 vs 3+2, so agreement is to rounding, not bitwise
     assert torch.allclose(x1, x2, rtol=1e-4, atol=1e-4)
+    scorer, _ = cases.build(cases.lib_namespace("amd"), "janner_cfg2_diffuser_logp")
+    c = cases.CASES["janner_cfg2_diffuser_logp"]
+    xs1, logp1 = sharded_sample(scorer, torch.zeros(7, c["horizon"], c["net"][1]["in_dim"]), gather=True, seed=3, return_logp=True,
+                                solver="ddim", sample_steps=3, temperature=0.5)
+    assert got["logp"].shape == (7, 1) and torch.allclose(got["xs"], xs1, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(got["logp"], logp1, rtol=1e-4, atol=1e-4) and int(got["logp"].argmax()) == int(logp1.argmax())
     assert [shard_bounds(5, r, 2) for r in range(2)] == [(0, 3), (3, 5)]
     assert [shard_bounds(0, r, 2) for r in range(2)] == [(0, 0), (0, 0)]
