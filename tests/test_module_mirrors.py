@@ -67,3 +67,45 @@ def test_edm_variants_match_reference():
     agent.eval()
     with pytest.raises(IndexError):
         agent.sample(torch.zeros(4, 3), solver="euler", n_samples=4, sample_steps=6)
+
+
+def test_head_chain_semantics_with_torch_stand_ins(monkeypatch):
+    """engine/heads.py end to end on the CPU: the three block launchers are replaced by PyTorch stand-ins with the same contract
+    (linear: act(x W^T + b); groupnorm with L = 1, G = 1: per-row LayerNorm, affine, activation), so the compiled chain, the
+    activation-name table, the leading-dimension handling and the cache invalidation are checked without a GPU."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from cleandiffuser_amd.engine import blocks, heads
+    from cleandiffuser_amd.invdynamic.mlp import EnsembleMlpInvDynamic, FancyMlpInvDynamic, MlpInvDynamic
+    from cleandiffuser_amd.nn_condition import MLPCondition, PearceObsCondition
+    from cleandiffuser_amd.utils import DQLCritic, TwinQ, V, load_synth
+    acts = {"none": lambda v: v, "relu": F.relu, "tanh": torch.tanh, "mish": F.mish, "silu": F.silu, "gelu": F.gelu,
+            "gelu_tanh": lambda v: F.gelu(v, approximate="tanh"), "leaky": lambda v: F.leaky_relu(v, 0.01)}
+    monkeypatch.setattr(blocks, "linear", lambda h, w, b=None, act="none", **k: acts[act](F.linear(h, w, b)))
+    monkeypatch.setattr(blocks, "groupnorm", lambda h, g, b, batch, length, groups, act="none", eps=1e-5, **k:
+                        acts[act](F.layer_norm(h, (h.shape[1],), g, b, eps)) if (length, groups, batch) == (1, 1, h.shape[0]) else None)
+    monkeypatch.setattr(blocks, "activation", lambda h, act, **k: acts[act](h))
+    monkeypatch.setattr(heads, "native_ok", lambda x, params: True)
+    torch.manual_seed(0)
+    with torch.no_grad():
+        for seq, x in [(load_synth(DQLCritic(5, 2, 16)).q2_model.eval(), torch.randn(9, 7)),
+                       (load_synth(TwinQ(5, 2, 24)).Q1.eval(), torch.randn(4, 3, 7)),                   # leading dims kept
+                       (load_synth(V(5, 16)).V.eval(), torch.randn(1, 5)),
+                       (MlpInvDynamic(5, 2, 16).mlp.mlp.eval(), torch.randn(6, 10)),
+                       (FancyMlpInvDynamic(5, 2, 16, add_norm=True, add_dropout=True).model.eval(), torch.randn(6, 10)),
+                       (EnsembleMlpInvDynamic(5, 2, 16, n_models=2, mlp_type="fancy").mlp[1].eval(), torch.randn(6, 10)),
+                       (load_synth(MLPCondition(1, 8, [8], nn.SiLU())).mlp.mlp.eval(), torch.rand(5, 1)),
+                       (load_synth(PearceObsCondition(4, 8)).mlp.eval(), torch.randn(3, 2, 4)),
+                       (nn.Sequential(nn.GELU(approximate="tanh"), nn.Linear(4, 3, bias=False), nn.LeakyReLU()).eval(), torch.randn(5, 4))]:
+            want, got = seq(x), heads.try_sequential(seq, x)
+            assert got is not None and got.shape == want.shape
+            np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-6, atol=1e-6)
+        seq = FancyMlpInvDynamic(5, 2, 16, add_dropout=True).model.eval()
+        x = torch.randn(6, 10)
+        assert heads.try_sequential(seq, x) is not None
+        seq.train()                                                   # dropout becomes active: recompiled, refused
+        assert heads.try_sequential(seq, x) is None
+        seq.eval()
+        seq[4] = nn.Linear(16, 16)                                    # swapped sub-module: recompiled against the new one
+        np.testing.assert_allclose(heads.try_sequential(seq, x).numpy(), seq(x).numpy(), rtol=1e-6, atol=1e-6)
+        assert heads.try_sequential(seq, torch.zeros(0, 10)) is None   # empty batch: stock modules
