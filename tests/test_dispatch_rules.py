@@ -1,0 +1,45 @@
+"""Host-side routing rules between the two native U-Net executors and the PyTorch executor (engine/dispatch.py, bigbatch.py,
+runtime.py) -- pure Python decisions, checked on the CPU."""
+import torch
+
+from cleandiffuser_amd.engine import bigbatch, plan as P, program, runtime
+from cleandiffuser_amd.nn_diffusion import ChiUNet1d, DiT1d, JannerUNet1d
+
+
+def test_unet_executor_choice(monkeypatch):
+    janner = JannerUNet1d(6, model_dim=16, emb_dim=16, dim_mult=[1, 2], kernel_size=5)
+    chi = ChiUNet1d(2, 5, 1, model_dim=32, emb_dim=32, dim_mult=[1, 2], obs_as_global_cond=True)
+    chi_local = ChiUNet1d(2, 5, 1, model_dim=32, emb_dim=32, dim_mult=[1, 2], obs_as_global_cond=False)
+    assert not bigbatch.is_chiunet_gemm(janner, 256) and bigbatch.is_chiunet_gemm(janner, bigbatch.JANNER_GEMM_MIN_BATCH)
+    assert not bigbatch.is_chiunet_gemm(chi, 8) and bigbatch.is_chiunet_gemm(chi, bigbatch.UNET_GEMM_MIN_BATCH)
+    assert not bigbatch.is_chiunet_gemm(chi_local, 10 ** 6) and not bigbatch.is_chiunet_gemm(DiT1d(4, 8, d_model=16, n_heads=2, depth=1), 10 ** 6)
+    seen = []
+
+    def fake_supported(module, horizon, edm=False):
+        seen.append((horizon, edm))
+        return "LDS plan needs 200000 B" if (horizon >= 64 or edm) else None
+    monkeypatch.setattr(runtime, "supported_backbone", fake_supported)
+    assert not bigbatch.is_chiunet_gemm(janner, 3, 32)                  # fits the program kernel: small batches stay there
+    assert bigbatch.is_chiunet_gemm(janner, 3, 64)                      # does not fit: GEMM executor at any batch
+    assert bigbatch.is_chiunet_gemm(chi, 3, 16, True)                   # fits only without the EDM buffers, plan has EDM steps
+    assert seen == [(32, False), (64, False), (16, True)]
+    assert bigbatch.is_chiunet_gemm(janner, 5000, 32) and len(seen) == 3     # large batch: no need to ask the compiler
+
+
+def test_edm_state_buffers_are_optional_in_the_lds_plan():
+    net = JannerUNet1d(23, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2, 2], kernel_size=5)
+    lean, full = program.compile_janner(net, 32, edm=False), program.compile_janner(net, 32, edm=True)
+    assert full.lds_floats - lean.lds_floats == 2 * ((32 * 23 + 3) // 4 * 4)
+    assert (lean.prev_off, lean.x_off, lean.pred_off) == (full.prev_off, full.x_off, full.pred_off)
+    assert len(lean.ops) == len(full.ops) and lean.macs_per_forward == full.macs_per_forward
+    euler = P.SamplePlan(solver="x", steps=[P.Step(P.KIND_EDM_EULER, P.V_EPS, 1, 0.1, 1.0, 1.0, (1.0, 1.0, 1.0, 0.1, 0.0))])
+    ddim = P.SamplePlan(solver="ddim", steps=[P.Step(P.KIND_DDIM, P.V_EPS, 1, 3, 0.9, 0.4, (1.0, 0.4, 0.9, 0.0, 0.0))])
+    assert runtime.plan_is_edm(euler) and not runtime.plan_is_edm(ddim)
+    # the shipped Diffuser kitchen net: 159.7 KB without, 177 KB with -- the difference between fused and not
+    kitchen = JannerUNet1d(69, model_dim=64, emb_dim=64, dim_mult=[1, 2, 2, 2], kernel_size=5)
+    assert program.compile_janner(kitchen, 32, edm=False).lds_floats * 4 <= 160 * 1024
+    try:
+        program.compile_janner(kitchen, 32, edm=True)
+        raise AssertionError("expected the EDM variant not to fit")
+    except ValueError as e:
+        assert "LDS plan" in str(e)
