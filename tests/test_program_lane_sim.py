@@ -21,13 +21,16 @@ def _first_forward_inputs(name, agent):
     return inp, xt0.astype(np.float32)
 
 
-@pytest.mark.parametrize("name", ["janner_cfg2_ddim", "janner_h4_ddpm", "janner_tiny_disc_ddim",
-                                  "janner_tiny_cond_w1", "janner_tiny_cont_ddim", "janner_h64_single"])
-def test_lane_sim_reproduces_reference_forward(name, amd_lib):
+@pytest.mark.parametrize("name,edm", [("janner_cfg2_ddim", False), ("janner_h4_ddpm", True), ("janner_tiny_disc_ddim", True),
+                                      ("janner_tiny_disc_ddim", False), ("janner_tiny_cond_w1", False),
+                                      ("janner_tiny_cont_ddim", True), ("janner_h64_single", False)])
+def test_lane_sim_reproduces_reference_forward(name, edm, amd_lib):
+    """`edm`: with / without the two EDM-only dense state buffers in the LDS plan (the runtime compiles the lean plan unless the
+    step plan needs them) -- the interpreter works off the plan's offsets, so an overlap would show up here."""
     gold = np.load(golden_path(name))
     agent, net = cases.build(amd_lib, name)
     c = cases.CASES[name]
-    prog = P.compile_janner(agent.model_ema["diffusion"], c["horizon"])
+    prog = P.compile_janner(agent.model_ema["diffusion"], c["horizon"], edm=edm)
     assert prog.lds_floats * 4 <= 160 * 1024
     inp, xt0 = _first_forward_inputs(name, agent)
     # timestep-embedding row exactly as the solver would hand it to the kernel
