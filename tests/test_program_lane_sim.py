@@ -76,7 +76,7 @@ def test_lane_sim_reproduces_classifier_logp(amd_lib):
         np.testing.assert_allclose(sim.run_forward(temb), gold["log_p"][b], rtol=2e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize("kind", ["pearce", "dql"])
+@pytest.mark.parametrize("kind", ["pearce", "pearce192", "dql"])
 def test_lane_sim_reproduces_mlp_tile_programs(kind, amd_lib):
     """Batch-tiled MLP programs (sample index on the MFMA column axis, per-sample GroupNorm, GELU/Mish/LeakyReLU,
     pre-scaled skips, context slot) against the module forward, which is bit-identical to the reference's."""
@@ -85,8 +85,8 @@ def test_lane_sim_reproduces_mlp_tile_programs(kind, amd_lib):
     g = torch.Generator().manual_seed(0)
     x = torch.randn(S, 6, generator=g)
     t = torch.full((S,), 13, dtype=torch.long)
-    if kind == "pearce":
-        net = load_synth(amd_lib.PearceMlp(6, 1, emb_dim=64, hidden_dim=256)).eval()
+    if kind.startswith("pearce"):                     # hidden 192: GroupNorm groups of 24 channels (not a power of two)
+        net = load_synth(amd_lib.PearceMlp(6, 1, emb_dim=64, hidden_dim=192 if kind == "pearce192" else 256)).eval()
         prog = P.compile_pearce_mlp(net, S)
         cond = torch.randn(S, 1, 64, generator=g)
         temb = np.concatenate([net.map_noise(t[:1])[0].numpy(), [13.0]]).astype(np.float32)
