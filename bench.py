@@ -200,7 +200,7 @@ def main():
                        "sample_steps": SAMPLE_STEPS, "parallelism": f"batch-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, **recorded_traffic(),
-                         "kernel": "cdx_unet1d_kernel", "kernel_ms": k_ms, "launches_timed": len(kernel_ms),
+                         "kernel": "cdx_unet2_kernel" if os.environ.get("CDX_UNET2", "1") != "0" else "cdx_unet1d_kernel", "kernel_ms": k_ms, "launches_timed": len(kernel_ms),
                          "flops_per_launch": flops_per_traj * BATCH},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -58,10 +58,8 @@ class BaseClassifier:
         return {"loss": loss.item(), "grad_norm": grad_norm}
 
     def ema_update(self):
-        keep = self.ema_rate
-        with torch.no_grad():
-            for live, avg in zip(self.model.parameters(), self.model_ema.parameters()):
-                avg.data.mul_(keep).add_(live.data, alpha=1. - keep)
+        from ..utils.misc import ema_update
+        ema_update(self.model, self.model_ema, self.ema_rate)
 
     def train(self):
         self.model.train()

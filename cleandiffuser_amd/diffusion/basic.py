@@ -64,9 +64,8 @@ class DiffusionModel:
             self.classifier.model.eval()
 
     def ema_update(self):
-        with torch.no_grad():
-            for p, p_ema in zip(self.model.parameters(), self.model_ema.parameters()):
-                p_ema.data.mul_(self.ema_rate).add_(p.data, alpha=1. - self.ema_rate)
+        from ..utils.misc import ema_update
+        ema_update(self.model, self.model_ema, self.ema_rate)
 
     # -- abstract ------------------------------------------------------------------------------ #
     def update(self, x0, condition=None, update_ema=True, **kwargs):

@@ -1,0 +1,355 @@
+"""Network -> device program for the second-generation fused U-Net kernel (``csrc/cdx_unet2.hip``).
+
+Same idea as ``program.py`` (one launch = the whole ``sample()`` loop, activations resident in LDS, weights streamed as
+1-KiB MFMA records) with the per-op fixed cost engineered out -- what the round-1 profile showed the north-star kernel was
+spending 60 % of its time on:
+
+* **4 wave64 per workgroup, one per SIMD**; a conv's output is cut into (row tile x column group) *tiles*; when a layer has
+  fewer than four tiles the K range is split over the spare waves.  Work items are 8-word records read with scalar loads.
+* **The 1x1 residual conv of a ResidualBlock** (reference jannerunet.py:58, :69) is a plain op whose epilogue adds into the
+  block's output slot (GroupNorm + Mish sit between the two sums, so they cannot share an accumulator).
+* **The per-block FiLM vectors** ``Linear(Mish(map_emb(temb)))`` depend only on the step, not on the trajectory: they are
+  evaluated once per (weights version, schedule) into a ``(steps, n_emb)`` table by ``cdx_unet2_embtab`` and read as
+  per-channel float4 epilogue parameters; the embedding MLP ops disappear from the per-forward program.
+* **Epilogue**: staged partial tiles -> 32 lanes per GroupNorm group, float4 of consecutive channels per lane, two-pass
+  statistics in registers, Mish, + FiLM vector, + residual slot, float4 store.
+* **T trajectories per workgroup** (1 or 2): every weight record feeds T x the MFMAs; each trajectory owns an identical
+  LDS region (``traj_floats`` apart), so all offsets below are relative to the trajectory base.
+
+Descriptor words ``W2_*`` / item words ``I2_*`` MUST mirror ``csrc/cdx_ops2.h`` (tests/test_abi_contract.py checks).
+Activations: channel-last rows ``slot[pos * stride + c]``, ``stride = pad16(C) + 4`` (as program.py); out-of-range conv
+taps read the trajectory's all-zero row.  Conv records: identical lane layouts to program.py (MODE_16X16 / MODE_4X4).
+"""
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .program import (Act, GN_EPS, MODE_16X16, MODE_4X4, _conv1d_eff, _convT1d_eff, _fbits, pad16, supports_janner)
+
+OP2_WORDS = 48
+ITEM2_WORDS = 8
+NW2 = 4                       # waves per workgroup
+RING2 = 16                    # weight records in flight per wave
+GROUPS2 = 8                   # GroupNorm groups the epilogue partition is built for (32 lanes per group)
+MAX_NK2 = 4                   # float4 items a lane may own in the epilogue
+
+(W2_KIND, W2_FLAGS, W2_COUT, W2_LOUT, W2_LIN, W2_CSTRIDE, W2_TRANSPOSED, W2_MODE, W2_NT, W2_NITEMS, W2_ITEMS,
+ W2_NSEG) = range(12)
+W2_SEG0, SEG2_WORDS = 12, 5   # 2 K segments (the sources of a channel concat) x (SRC, STRIDE, CCN, TAPS, PAD)
+S2_SRC, S2_STRIDE, S2_CCN, S2_TAPS, S2_PAD = range(5)
+(W2_DST, W2_DST_STRIDE, W2_SSTRIDE, W2_KSPLIT, W2_BOFF, W2_GAMMA, W2_BETA, W2_EMB, W2_RES, W2_RES_STRIDE, W2_CG4_SHIFT,
+ W2_INV_CNT, W2_NK, W2_COUTP) = range(22, 36)
+I2_WOFF, I2_NQ, I2_SEG, I2_TAP, I2_CC, I2_PART, I2_COL0, I2_SPARE = range(8)
+
+F2_GN, F2_EMB, F2_RES, F2_PRED = 1, 2, 4, 8
+
+
+def pad32(c: int) -> int:
+    return (c + 31) // 32 * 32
+
+
+@dataclass
+class Program2:
+    ops: np.ndarray                    # int32 [n_ops, OP2_WORDS]
+    ops_buffer: np.ndarray             # int32 1-D: ops followed by the item tables
+    blob: torch.Tensor                 # float32 1-D on the module's device
+    traj_floats: int                   # LDS floats per trajectory
+    zrow_off: int
+    x_off: int
+    x_stride: int
+    pred_off: int
+    pred_stride: int
+    prev_off: int
+    stage_off: int
+    horizon: int
+    dim: int
+    emb_dim: int                       # width of one map_noise(t) row
+    n_emb: int                         # width of one FiLM-table row
+    embtab: Dict[str, int] = field(default_factory=dict)   # blob offsets / sizes of the embedding MLP
+    macs_per_forward: int = 0
+    n_conv: int = 0
+    meta: dict = field(default_factory=dict)
+
+    def lds_bytes(self, traj_per_wg: int) -> int:
+        return 4 * self.traj_floats * traj_per_wg
+
+
+def _records(w_eff: torch.Tensor, split: Sequence[int], mode: int) -> Tuple[torch.Tensor, List[int]]:
+    """w_eff [C_out][taps][C_in_total] -> records [n_row_tiles][taps*sum(cc)][64][4] (+ chunks per tap per source).
+    Lane layouts as program.py:pack_conv: MODE_16X16 lane = k4*16 + row, 16 K per record; MODE_4X4 lane = row, 4 K."""
+    c_out, taps, c_in = w_eff.shape
+    assert sum(split) == c_in
+    rows, kch = (16, 16) if mode == MODE_16X16 else (64, 4)
+    n_ct = -(-c_out // rows)
+    parts, per_src, lo = [], [], 0
+    for cs in split:
+        w = w_eff[:, :, lo:lo + cs]
+        lo += cs
+        csp = -(-cs // kch) * kch
+        wp = torch.zeros(n_ct * rows, taps, csp, device=w.device, dtype=torch.float32)
+        wp[:c_out, :, :cs] = w
+        cc = csp // kch
+        if mode == MODE_16X16:
+            wp = wp.reshape(n_ct, 16, taps, cc, 4, 4).permute(0, 2, 3, 4, 1, 5)
+        else:
+            wp = wp.reshape(n_ct, 64, taps, cc, 4).permute(0, 2, 3, 1, 4)
+        parts.append(wp.reshape(n_ct, taps * cc, 64, 4))
+        per_src.append(cc)
+    return torch.cat(parts, dim=1).contiguous(), per_src
+
+
+class _Builder2:
+    def __init__(self, device):
+        self.device = device
+        self.ops: List[List[int]] = []
+        self.op_acts: List[Tuple[List[Act], Optional[Act]]] = []
+        self.op_items: List[list] = []
+        self.chunks: List[torch.Tensor] = []
+        self.blob_len = 0
+        self.acts: List[Act] = []
+        self.stage = 0
+        self.macs = 0
+        self.n_emb = 0
+        self.allow_4x4 = True
+
+    def add(self, t: torch.Tensor, pad_to: int = 4) -> int:
+        t = t.detach().to(device=self.device, dtype=torch.float32).reshape(-1)
+        off = self.blob_len
+        pad = (-t.numel()) % pad_to
+        if pad:
+            t = torch.cat([t, torch.zeros(pad, device=self.device)])
+        self.chunks.append(t)
+        self.blob_len += t.numel()
+        return off
+
+    def act(self, length: int, chans: int, persistent=False) -> Act:
+        a = Act(length, chans, len(self.acts), persistent=persistent)
+        self.acts.append(a)
+        return a
+
+    def emb_slot(self, c_out: int) -> int:
+        off = self.n_emb
+        self.n_emb += pad32(c_out)
+        return off
+
+    def conv(self, srcs: Sequence[Act], dst: Act, w_eff: torch.Tensor, bias: torch.Tensor, *, stride=1, pad=0,
+             transposed=False, gn: Optional[nn.Module] = None, emb_off: int = -1, res: Optional[Act] = None,
+             pred: bool = False):
+        """One fused op: conv -> [GroupNorm -> Mish] -> [+ emb] -> [+ residual slot `res` (may be `dst` itself: accumulate)] -> dst."""
+        c_out, taps, _ = w_eff.shape
+        l_out = dst.length
+        assert not transposed or stride == 2
+        assert 1 <= len(srcs) <= 2, "at most 2 K segments per op"
+        mode = MODE_4X4 if (l_out <= 8 and c_out % 64 == 0 and self.allow_4x4) else MODE_16X16
+        rows, cols = (16, 16) if mode == MODE_16X16 else (64, 4)
+        nt = 2 if (mode == MODE_4X4 and l_out > 4) else 1
+        n_rt = -(-c_out // rows)
+        n_cg = -(-l_out // (nt * cols))
+        tiles = n_rt * n_cg
+        recs, per_src = _records(w_eff, [s.chans for s in srcs], mode)
+        nqt = recs.shape[1]
+        woff = self.add(recs)
+        ksplit = max(1, min(NW2 // tiles, nqt)) if tiles < NW2 else 1
+        coutp = pad32(c_out)
+        sstride = coutp + 4
+        seg_len = [cc * taps for cc in per_src]
+
+        def cursor(q):
+            for si, n in enumerate(seg_len):
+                if q < n:
+                    return si, q // per_src[si], q % per_src[si]
+                q -= n
+            raise AssertionError("slice starts past the stream")
+
+        items = []
+        for item in range(tiles * ksplit):
+            tile, ks = item % tiles, item // tiles
+            rt, cgi = tile % n_rt, tile // n_rt
+            q0, q1 = ks * nqt // ksplit, (ks + 1) * nqt // ksplit
+            si, tap, cc = cursor(q0)
+            items.append([woff + (rt * nqt + q0) * 256, q1 - q0, si, tap, cc, ks * l_out * sstride + rt * rows,
+                          cgi * nt * cols, 0])
+        words = {W2_KIND: 0, W2_COUT: c_out, W2_LOUT: l_out, W2_LIN: srcs[0].length, W2_CSTRIDE: stride,
+                 W2_TRANSPOSED: int(transposed), W2_MODE: mode, W2_NT: nt, W2_NITEMS: len(items), W2_NSEG: len(srcs),
+                 W2_DST_STRIDE: dst.stride, W2_SSTRIDE: sstride, W2_KSPLIT: ksplit,
+                 W2_BOFF: self.add(_padded(bias, coutp)), W2_COUTP: coutp}
+        for si, (s, cc) in enumerate(zip(srcs, per_src)):
+            assert s.length == srcs[0].length
+            base = W2_SEG0 + si * SEG2_WORDS
+            words[base + S2_STRIDE], words[base + S2_CCN], words[base + S2_TAPS], words[base + S2_PAD] = s.stride, cc, taps, pad
+        cg = coutp // GROUPS2
+        cg4 = cg // 4
+        assert cg4 & (cg4 - 1) == 0 and cg4 <= 32, f"C_out {c_out}: channels per group / 4 must be a power of two <= 32"
+        nk = -(-(cg4 * l_out) // 32)
+        if nk > MAX_NK2:
+            raise ValueError(f"epilogue: {cg4 * l_out} float4 items per group > {32 * MAX_NK2} (horizon too long for v2)")
+        words[W2_CG4_SHIFT], words[W2_NK] = cg4.bit_length() - 1, nk
+        flags = 0
+        if gn is not None:
+            # the epilogue cuts pad32(C_out) channels into 8 lane groups; a real group must be exactly one of them (C_out = 16 with
+            # 4 groups of 4 is fine: lane groups 4..7 then work on pad channels that are never stored)
+            if c_out % gn.num_groups or c_out // gn.num_groups != cg or abs(gn.eps - GN_EPS) > 1e-12:
+                raise ValueError(f"v2 epilogue needs GroupNorm groups of pad32(C)/8 channels (C={c_out}, G={gn.num_groups})")
+            flags |= F2_GN
+            words[W2_INV_CNT] = _fbits(1.0 / (cg * l_out))
+            words[W2_GAMMA], words[W2_BETA] = self.add(_padded(gn.weight, coutp)), self.add(_padded(gn.bias, coutp))
+        if emb_off >= 0:
+            flags |= F2_EMB
+            words[W2_EMB] = emb_off
+        if res is not None:
+            assert res.chans == c_out and res.length == l_out
+            flags |= F2_RES
+            words[W2_RES_STRIDE] = res.stride
+        if pred:
+            flags |= F2_PRED
+        words[W2_FLAGS] = flags
+        op = [0] * OP2_WORDS
+        for k, v in words.items():
+            op[k] = int(v)
+        self.ops.append(op)
+        reads = list(srcs) + ([res] if res is not None else [])
+        self.op_acts.append((reads, dst))
+        self.op_items.append(items)
+        self.stage = max(self.stage, ksplit * l_out * sstride)
+        self.macs += c_out * l_out * taps * sum(s.chans for s in srcs) // (2 if transposed else 1)
+
+    def plan_arena(self, base: int) -> int:
+        """First-fit interval allocation over op liveness (same policy as program.py); patches slot offsets into the ops."""
+        first, last = {}, {}
+        for i, (reads, writes) in enumerate(self.op_acts):
+            for a in reads + [writes]:
+                first.setdefault(a.uid, i)
+                last[a.uid] = i
+        live: List[Act] = []
+        top = base
+        for a in sorted((a for a in self.acts if not a.persistent and a.uid in first), key=lambda a: first[a.uid]):
+            t = first[a.uid]
+            live = [b for b in live if last[b.uid] >= t]
+            pos = base
+            for lo, hi in sorted((b.off, b.off + b.floats) for b in live):
+                if lo - pos >= a.floats:
+                    break
+                pos = max(pos, hi)
+            a.off = pos
+            live.append(a)
+            top = max(top, pos + a.floats)
+        for op, (reads, writes) in zip(self.ops, self.op_acts):
+            for si in range(op[W2_NSEG]):
+                op[W2_SEG0 + si * SEG2_WORDS + S2_SRC] = reads[si].off
+            op[W2_DST] = writes.off
+            if op[W2_FLAGS] & F2_RES:
+                op[W2_RES] = reads[op[W2_NSEG]].off
+        return top
+
+
+def _padded(v: torch.Tensor, n: int) -> torch.Tensor:
+    v = v.detach().to(torch.float32).reshape(-1)
+    return torch.cat([v, torch.zeros(n - v.numel(), device=v.device)]) if v.numel() < n else v
+
+
+def supports_janner2(net, horizon: int) -> Optional[str]:
+    """None if the v2 kernel can run this JannerUNet1d at `horizon`, else the reason (the caller falls back to v1)."""
+    why = supports_janner(net)
+    if why is not None:
+        return why
+    try:
+        compile_janner2(net, horizon)
+    except (ValueError, AssertionError) as e:
+        return str(e)
+    return None
+
+
+def compile_janner2(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x4: bool = True) -> Program2:
+    """Lower a JannerUNet1d (reference nn_diffusion/jannerunet.py:98-201) for `horizon` positions."""
+    why = supports_janner(net)
+    if why is not None:
+        raise ValueError(why)
+    dev = next(net.parameters()).device
+    b = _Builder2(dev)
+    b.allow_4x4 = allow_4x4
+    d, k, md = net.in_dim, net.kernel_size, net.model_dim
+
+    blocks = []
+
+    def resblock(srcs: List[Act], rb) -> Act:
+        c_out, length = rb.conv1[0].out_channels, srcs[0].length
+        e_off = b.emb_slot(c_out)
+        blocks.append((rb, e_off))
+        t1 = b.act(length, c_out)
+        b.conv(srcs, t1, _conv1d_eff(rb.conv1[0]), rb.conv1[0].bias, pad=k // 2, gn=rb.conv1[1], emb_off=e_off)
+        out = b.act(length, c_out)
+        if isinstance(rb.residual_conv, nn.Identity):
+            assert len(srcs) == 1
+            b.conv([t1], out, _conv1d_eff(rb.conv2[0]), rb.conv2[0].bias, pad=k // 2, gn=rb.conv2[1], res=srcs[0])
+        else:
+            b.conv([t1], out, _conv1d_eff(rb.conv2[0]), rb.conv2[0].bias, pad=k // 2, gn=rb.conv2[1])
+            b.conv(srcs, out, _conv1d_eff(rb.residual_conv), rb.residual_conv.bias, res=out)     # out += W_r x + b_r
+        return out
+
+    x = b.act(horizon, d, persistent=True)
+    cur, skips = x, []
+    for res1, res2, _, down in net.downs:
+        cur = resblock([resblock([cur], res1)], res2)
+        skips.append(cur)
+        if not isinstance(down, nn.Identity):
+            if cur.length % 2:
+                raise ValueError("horizon too short for the number of resolutions")
+            nxt = b.act((cur.length - 1) // 2 + 1, cur.chans)
+            b.conv([cur], nxt, _conv1d_eff(down.conv), down.conv.bias, stride=2, pad=1)
+            cur = nxt
+    cur = resblock([resblock([cur], net.mid_block1)], net.mid_block2)
+    for res1, res2, _, up in net.ups:
+        cur = resblock([resblock([cur, skips.pop()], res1)], res2)
+        if not isinstance(up, nn.Identity):
+            nxt = b.act(cur.length * 2, cur.chans)
+            b.conv([cur], nxt, _convT1d_eff(up.conv), up.conv.bias, stride=2, pad=1, transposed=True)
+            cur = nxt
+    if cur.length != horizon:
+        raise ValueError("up path does not return to the input horizon")
+    fc = net.final_conv
+    t = b.act(horizon, md)
+    b.conv([cur], t, _conv1d_eff(fc[0]), fc[0].bias, pad=2, gn=fc[1])
+    pred = b.act(horizon, d, persistent=True)
+    b.conv([t], pred, _conv1d_eff(fc[3]), fc[3].bias, pred=True)
+
+    # embedding MLP (evaluated by cdx_unet2_embtab, once per schedule): transposed [n_in][n_out] weights
+    emb = {"emb_dim": net.emb_dim, "hidden": net.map_emb[0].out_features, "md": net.map_emb[2].out_features,
+           "n_emb": b.n_emb}
+    emb["w0"], emb["b0"] = b.add(net.map_emb[0].weight.t().contiguous()), b.add(net.map_emb[0].bias)
+    emb["w2"], emb["b2"] = b.add(net.map_emb[2].weight.t().contiguous()), b.add(net.map_emb[2].bias)
+    w_all = torch.zeros(b.n_emb, emb["md"], device=dev)
+    b_all = torch.zeros(b.n_emb, device=dev)
+    for rb, off in blocks:
+        lin = rb.emb_mlp[1]
+        w_all[off:off + lin.out_features] = lin.weight.detach().to(dev)
+        b_all[off:off + lin.out_features] = lin.bias.detach().to(dev)
+    emb["w3"], emb["b3"] = b.add(w_all.t().contiguous()), b.add(b_all)
+    b.macs += net.emb_dim * emb["hidden"] + emb["hidden"] * emb["md"] + emb["md"] * sum(rb.emb_mlp[1].out_features for rb, _ in blocks)
+
+    # ---- LDS plan of one trajectory: [zero row | x | pred | prev | stage | arena] ----
+    off = 0
+    sources = [a for reads, _ in b.op_acts for a in reads]
+    zrow_floats = max(pad16(a.chans) for a in sources) + 16
+    zrow_off, off = off, off + zrow_floats
+    x.off, off = off, off + x.floats
+    pred.off, off = off, off + pred.floats
+    prev_off, off = off, off + (horizon * d + 3) // 4 * 4
+    stage_off, off = off, off + (b.stage + 3) // 4 * 4
+    top = (b.plan_arena(off) + 3) // 4 * 4
+    if top * 4 > max_lds_bytes:
+        raise ValueError(f"LDS plan needs {top * 4} B > {max_lds_bytes} B per trajectory")
+    tail, cursor = [], len(b.ops) * OP2_WORDS
+    for op, items in zip(b.ops, b.op_items):
+        op[W2_ITEMS] = cursor
+        tail += [w for rec in items for w in rec]
+        cursor += len(items) * ITEM2_WORDS
+    ops = np.asarray(b.ops, dtype=np.int32)
+    ops_buffer = np.concatenate([ops.reshape(-1), np.asarray(tail, dtype=np.int64).astype(np.int32)])
+    blob = torch.cat(b.chunks).contiguous()
+    return Program2(ops=ops, ops_buffer=ops_buffer, blob=blob, traj_floats=top, zrow_off=zrow_off, x_off=x.off,
+                    x_stride=x.stride, pred_off=pred.off, pred_stride=pred.stride, prev_off=prev_off, stage_off=stage_off,
+                    horizon=horizon, dim=d, emb_dim=net.emb_dim, n_emb=b.n_emb, embtab=emb, macs_per_forward=b.macs,
+                    n_conv=len(b.ops), meta={"zrow_floats": zrow_floats, "blob_floats": b.blob_len})

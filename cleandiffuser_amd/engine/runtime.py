@@ -17,7 +17,7 @@ from . import program as P
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libcdx.so")
 LIB_PATH = os.environ.get("CDX_LIB", LIB_PATH)          # A/B hook: run the same process against another build
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class CdxStep(ctypes.Structure):
@@ -99,7 +99,9 @@ _cache = weakref.WeakKeyDictionary()
 
 
 def _signature(module):
-    return tuple((p.data_ptr(), p._version) for p in module.parameters()) + \
+    """Identity of a module's weights: storage pointers + autograd version counters + the explicit epoch that
+    ``utils.invalidate_weights`` / ``ema_update`` / ``load`` bump (``p.data`` writes leave ``_version`` untouched)."""
+    return (module.__dict__.get("_cdx_epoch", 0),) + tuple((p.data_ptr(), p._version) for p in module.parameters()) + \
         tuple((b.data_ptr(), b._version) for b in module.buffers())
 
 
@@ -427,6 +429,11 @@ def fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed) -> Optio
     except ValueError:
         return None
     load_library()
+    if (cond_vec is None or w_cfg == 0.0) and _is_janner(net):
+        from . import runtime2                        # unconditional temporal U-Net, non-EDM plan: second-generation kernel
+        out = runtime2.fused_sample2(solver, net, plan, xt, prior, feed, fix_mask, x_min, x_max)
+        if out is not None:
+            return out
     with torch.no_grad():
         comp = compiled_program(net, h, plan_is_edm(plan))
         t_vec = device_times(plan, dev)

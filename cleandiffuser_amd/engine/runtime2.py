@@ -1,0 +1,193 @@
+"""Binding + launch helpers of the second-generation fused U-Net kernel (``cdx_unet2_run`` / ``cdx_unet2_embtab``,
+include/cdx.h, csrc/cdx_unet2.hip).  Same contract as runtime.py: PyTorch owns device memory and the stream, tensors cross the
+boundary as raw pointers, no CPU / eager fallback -- a backbone the v2 compiler does not take simply stays on the first
+program kernel (runtime.py), which is equally native.
+
+What the host keeps per (weights version, plan): the compiled program (ops, item tables, packed blob) and the FiLM table of the
+plan's step records -- ``map_noise(t)`` -> ``cdx_unet2_embtab`` -- so a steady-state ``sample()`` call is ONE kernel launch and
+no ATen launch (the timestep-embedding glue used to run ~17 elementwise launches per call).
+"""
+import ctypes
+import os
+import weakref
+from typing import Optional
+
+import torch
+
+from . import program2 as P2
+from . import runtime as R
+
+
+class CdxUnet2EmbtabArgs(ctypes.Structure):
+    _fields_ = [("wblob", ctypes.c_void_p),
+                ("emb_dim", ctypes.c_int32), ("hidden", ctypes.c_int32), ("md", ctypes.c_int32), ("n_emb", ctypes.c_int32),
+                ("w0", ctypes.c_int32), ("b0", ctypes.c_int32), ("w2", ctypes.c_int32), ("b2", ctypes.c_int32),
+                ("w3", ctypes.c_int32), ("b3", ctypes.c_int32),
+                ("temb", ctypes.c_void_p), ("n_rows", ctypes.c_int32), ("out", ctypes.c_void_p)]
+
+
+class CdxUnet2Launch(ctypes.Structure):
+    _fields_ = [("ops", ctypes.c_void_p), ("wblob", ctypes.c_void_p),
+                ("n_ops", ctypes.c_int32), ("traj_floats", ctypes.c_int32), ("traj_per_wg", ctypes.c_int32),
+                ("zrow_off", ctypes.c_int32), ("x_off", ctypes.c_int32), ("x_stride", ctypes.c_int32),
+                ("pred_off", ctypes.c_int32), ("pred_stride", ctypes.c_int32), ("prev_off", ctypes.c_int32),
+                ("stage_off", ctypes.c_int32),
+                ("batch", ctypes.c_int32), ("horizon", ctypes.c_int32), ("dim", ctypes.c_int32),
+                ("emb", ctypes.c_void_p), ("emb_ld", ctypes.c_int32),
+                ("steps", ctypes.c_void_p), ("n_steps", ctypes.c_int32), ("predict_noise", ctypes.c_int32),
+                ("x_in", ctypes.c_void_p), ("prior", ctypes.c_void_p), ("fix_mask", ctypes.c_void_p),
+                ("noise", ctypes.c_void_p), ("x_min", ctypes.c_void_p), ("x_max", ctypes.c_void_p),
+                ("x_out", ctypes.c_void_p), ("prof", ctypes.c_void_p)]
+
+
+_declared = False
+
+
+def _lib():
+    global _declared
+    lib = R.load_library()
+    if not _declared:
+        lib.cdx_unet2_run.argtypes = [ctypes.POINTER(CdxUnet2Launch), ctypes.c_void_p]
+        lib.cdx_unet2_run.restype = ctypes.c_int
+        lib.cdx_unet2_embtab.argtypes = [ctypes.POINTER(CdxUnet2EmbtabArgs), ctypes.c_void_p]
+        lib.cdx_unet2_embtab.restype = ctypes.c_int
+        _declared = True
+    return lib
+
+
+class _Compiled2:
+    def __init__(self, prog: Optional[P2.Program2], sig, why: Optional[str] = None):
+        self.prog, self.sig, self.why = prog, sig, why
+        self.ops_dev = None if prog is None else torch.from_numpy(prog.ops_buffer.copy()).to(prog.blob.device)
+
+
+_cache = weakref.WeakKeyDictionary()
+
+
+def enabled() -> bool:
+    return os.environ.get("CDX_UNET2", "1") != "0"
+
+
+def compiled2(module, horizon: int) -> _Compiled2:
+    """The module's v2 program at this horizon (``.prog is None`` + ``.why`` when the v2 compiler does not take it)."""
+    per_mod = _cache.setdefault(module, {})
+    sig = R._signature(module)
+    hit = per_mod.get(horizon)
+    if hit is not None and hit.sig == sig:
+        return hit
+    with torch.no_grad():
+        try:
+            comp = _Compiled2(P2.compile_janner2(module, horizon), sig)
+        except (ValueError, AssertionError) as e:
+            comp = _Compiled2(None, sig, str(e))
+    per_mod[horizon] = comp
+    return comp
+
+
+def supported(module, horizon: int) -> Optional[str]:
+    """None when the v2 kernel runs `module` (an unconditional JannerUNet1d forward) at `horizon`, else the reason."""
+    if not enabled():
+        return "disabled by CDX_UNET2=0"
+    if not R._is_janner(module):
+        return f"{type(module).__name__} has no v2 program"
+    n_down = sum(1 for lvl in module.downs if not isinstance(lvl[3], torch.nn.Identity))
+    if horizon % (1 << n_down) != 0:
+        return f"horizon {horizon} not divisible by 2^{n_down}"
+    return compiled2(module, horizon).why
+
+
+def film_table(comp: _Compiled2, module, t_vec: torch.Tensor) -> torch.Tensor:
+    """(rows, n_emb) FiLM table of the timesteps in `t_vec`: map_noise (the module's own embedding, a handful of ATen ops) and
+    one cdx_unet2_embtab launch.  Callers memoise the result per plan."""
+    prog = comp.prog
+    dev = prog.blob.device
+    with torch.no_grad():
+        temb = R._f32c(module.map_noise(t_vec), dev)
+    out = torch.empty((temb.shape[0], prog.n_emb), device=dev, dtype=torch.float32)
+    e = prog.embtab
+    args = CdxUnet2EmbtabArgs(wblob=prog.blob.data_ptr(), emb_dim=e["emb_dim"], hidden=e["hidden"], md=e["md"], n_emb=e["n_emb"],
+                              w0=e["w0"], b0=e["b0"], w2=e["w2"], b2=e["b2"], w3=e["w3"], b3=e["b3"],
+                              temb=temb.data_ptr(), n_rows=temb.shape[0], out=out.data_ptr())
+    R._check(_lib().cdx_unet2_embtab(ctypes.byref(args), R._stream_ptr(dev)), "cdx_unet2_embtab")
+    return out
+
+
+def plan_film_table(comp: _Compiled2, module, plan, device) -> torch.Tensor:
+    from .plan import cached
+    return cached(plan, ("film2", str(device), id(module), comp.sig),
+                  lambda: film_table(comp, module, R.device_times(plan, device)))
+
+
+def min_batch() -> int:
+    """Smallest batch the v2 kernel takes by default.  Measured on MI355X (profiles/r02_*): with one workgroup per CU (B <= 256)
+    a 4-wave workgroup is instruction-issue bound and the 8-wave first kernel is ahead; from two co-resident workgroups per CU
+    on (B >= 512) v2 is ~1.8x faster."""
+    return int(os.environ.get("CDX_UNET2_MIN_BATCH", "384"))
+
+
+def traj_per_wg(prog: P2.Program2, batch: int) -> int:
+    """Trajectories per workgroup.  Two co-resident single-trajectory workgroups per CU currently beat one two-trajectory
+    workgroup (measured, B = 512: 6.8 vs 9.4 ms), so T = 2 is opt-in (CDX_UNET2_T=2)."""
+    forced = os.environ.get("CDX_UNET2_T")
+    t = int(forced) if forced in ("1", "2") else 1
+    if prog.lds_bytes(t) > 160 * 1024:
+        t = 1
+    return t
+
+
+def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps=0, predict_noise=0, prior=None,
+           fix_mask=None, noise=None, x_min=None, x_max=None, t_per_wg: Optional[int] = None):
+    if batch <= 0:
+        return
+    prog = comp.prog
+    t = t_per_wg or traj_per_wg(prog, batch)
+    prof = R._prof["buf"]
+    L = CdxUnet2Launch(
+        ops=comp.ops_dev.data_ptr(), wblob=prog.blob.data_ptr(), n_ops=len(prog.ops), traj_floats=prog.traj_floats,
+        traj_per_wg=t, zrow_off=prog.zrow_off, x_off=prog.x_off, x_stride=prog.x_stride, pred_off=prog.pred_off,
+        pred_stride=prog.pred_stride, prev_off=prog.prev_off, stage_off=prog.stage_off,
+        batch=batch, horizon=prog.horizon, dim=prog.dim, emb=emb.data_ptr(), emb_ld=emb.shape[1],
+        steps=R._ptr(steps_dev), n_steps=n_steps, predict_noise=int(predict_noise),
+        x_in=x_in.data_ptr(), prior=R._ptr(prior), fix_mask=R._ptr(fix_mask), noise=R._ptr(noise), x_min=R._ptr(x_min),
+        x_max=R._ptr(x_max), x_out=x_out.data_ptr(), prof=R._ptr(prof))
+    timing = R._timing
+    if timing["on"]:
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record(torch.cuda.current_stream(x_in.device))
+    R._check(_lib().cdx_unet2_run(ctypes.byref(L), R._stream_ptr(x_in.device)), "cdx_unet2_run")
+    if timing["on"]:
+        end.record(torch.cuda.current_stream(x_in.device))
+        timing["events"].append((start, end))
+
+
+def fused_sample2(solver, net, plan, xt, prior, feed, fix_mask, x_min, x_max) -> Optional[torch.Tensor]:
+    """Unconditional JannerUNet1d, step kinds 0-4: the whole loop in one cdx_unet2_run launch.  None -> caller uses v1."""
+    b, h, d = xt.shape
+    if b < min_batch() or R.plan_is_edm(plan) or supported(net, h) is not None:
+        return None
+    dev = xt.device
+    comp = compiled2(net, h)
+    with torch.no_grad():
+        emb = plan_film_table(comp, net, plan, dev)
+        steps_dev = R.steps_to_device(plan, dev)
+        noise = torch.stack([feed.like(xt) for _ in range(plan.n_noise)]).contiguous() if plan.n_noise else None
+        xin = R._f32c(xt, dev)
+        out = torch.empty_like(xin)
+        launch(comp, batch=b, x_in=xin, x_out=out, emb=emb, steps_dev=steps_dev, n_steps=len(plan.steps),
+               predict_noise=R._predicts_noise(plan, solver), prior=R._f32c(prior, dev) if fix_mask is not None else None,
+               fix_mask=fix_mask, noise=noise, x_min=x_min, x_max=x_max)
+    return out
+
+
+def backbone_forward2(module, x, noise_t) -> Optional[torch.Tensor]:
+    """One unconditional forward with ONE timestep shared by the whole batch (the sampling loops' per-step call)."""
+    b, h, d = x.shape
+    if supported(module, h) is not None:
+        return None
+    comp = compiled2(module, h)
+    with torch.no_grad():
+        emb = film_table(comp, module, noise_t.reshape(-1)[:1])
+        xin = R._f32c(x, x.device)
+        out = torch.empty_like(xin)
+        launch(comp, batch=b, x_in=xin, x_out=out, emb=emb)
+    return out

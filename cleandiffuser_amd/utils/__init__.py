@@ -11,4 +11,4 @@ from .synth import synth_state_dict, load_synth, synth_array
 from .critics import (DQLCritic, TwinQ, V, IQL, IDQLQNet, IDQLVNet, SoftLowerBound, SoftUpperBound, DVTransformerBlock,
                       DVHorizonCritic, PreNorm, Residual, FeedForward, MultiHeadAttention, Transformer, generate_causal_mask)
 from .normalizers import EmptyNormalizer, GaussianNormalizer, MinMaxNormalizer
-from .misc import param_to_module, TensorDict
+from .misc import param_to_module, TensorDict, invalidate_weights

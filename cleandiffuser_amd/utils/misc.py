@@ -43,9 +43,21 @@ def count_parameters(model: nn.Module):
 
 
 def ema_update(model: nn.Module, model_ema: nn.Module, ema_rate: float):
+    """p_ema <- rate * p_ema + (1 - rate) * p (reference diffusion/basic.py:83-86).  The update goes through the parameter
+    itself (not ``.data``): in-place ops on ``.data`` do not bump ``Tensor._version``, which the native executors' packed-weight
+    caches key on -- a stale cache would keep sampling from the first EMA weights.  The explicit epoch bump covers the caches
+    for callers that still write through ``.data`` and then call ``invalidate_weights`` themselves."""
     with torch.no_grad():
         for p, p_ema in zip(model.parameters(), model_ema.parameters()):
-            p_ema.data.mul_(ema_rate).add_(p.data, alpha=1 - ema_rate)
+            p_ema.mul_(ema_rate).add_(p.detach(), alpha=1 - ema_rate)
+    invalidate_weights(model_ema)
+
+
+def invalidate_weights(module: nn.Module):
+    """Tell the native executors that `module`'s parameters changed behind autograd's back (``p.data`` writes,
+    ``load_state_dict(assign=True)``...): every packed-weight / program cache keyed on a sub-module is rebuilt on next use."""
+    for m in module.modules():
+        m.__dict__["_cdx_epoch"] = m.__dict__.get("_cdx_epoch", 0) + 1
 
 
 class _ModuleStateSwitch:

@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define CDX_ABI_VERSION 2
+#define CDX_ABI_VERSION 3
 
 #define CDX_OK 0
 #define CDX_EINVAL (-1)   /* bad argument (null pointer, size out of range, misaligned offset) */
@@ -112,6 +112,55 @@ const char* cdx_last_error(void);
 
 /* Enqueue the fused U-Net program kernel on `hip_stream` (a hipStream_t; NULL = default stream). */
 int cdx_unet1d_run(const cdx_unet1d_launch* launch, void* hip_stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Second-generation fused U-Net program (csrc/cdx_unet2.hip; program built by engine/program2.py, word layout in
+ * csrc/cdx_ops2.h).  Same contract as cdx_unet1d_run -- the whole DiscreteDiffusionSDE / ContinuousDiffusionSDE.sample() loop
+ * (reference diffusionsde.py:526-594 over nn_diffusion/jannerunet.py:154-201) in ONE launch, step kinds 0-4 -- for
+ * unconditional JannerUNet1d-structured denoisers, re-engineered for the per-op fixed cost: 4 wave64 per workgroup,
+ * `traj_per_wg` (1 or 2) trajectories per workgroup sharing every streamed weight record, the ResidualBlock's 1x1 skip conv
+ * fused into its second conv, and the per-block FiLM vectors Linear(Mish(map_emb(map_noise(t)))) read from a per-step table
+ * that cdx_unet2_embtab evaluates once per (weights, schedule).
+ * ---------------------------------------------------------------------------------------------- */
+#define CDX2_OP_WORDS 48
+
+/* FiLM table: out[r][:] = W3^T mish(W2^T mish(W0^T temb[r] + b0) + b2) + b3, all weights transposed [n_in][n_out] inside `wblob`
+ * at the given float offsets (reference jannerunet.py:135-136 map_emb, :57 emb_mlp of every block, stacked). */
+typedef struct cdx_unet2_embtab_args {
+    const float* wblob;
+    int32_t emb_dim, hidden, md, n_emb;
+    int32_t w0, b0, w2, b2, w3, b3;
+    const float* temb;        /* device (n_rows, emb_dim): map_noise(t) per step record */
+    int32_t n_rows;
+    float* out;               /* device (n_rows, n_emb) */
+} cdx_unet2_embtab_args;
+int cdx_unet2_embtab(const cdx_unet2_embtab_args* args, void* hip_stream);
+
+typedef struct cdx_unet2_launch {
+    const int32_t* ops;        /* device, [n_ops][CDX2_OP_WORDS] followed by the work-item tables */
+    const float* wblob;        /* device, packed parameters */
+    int32_t n_ops;
+    int32_t traj_floats;       /* LDS floats of one trajectory's region; the workgroup owns traj_per_wg of them */
+    int32_t traj_per_wg;       /* 1 or 2 */
+    int32_t zrow_off, x_off, x_stride, pred_off, pred_stride, prev_off, stage_off;   /* relative to the trajectory region */
+    int32_t batch, horizon, dim;
+    const float* emb;          /* device (max(n_steps,1), emb_ld): FiLM table rows, one per step record */
+    int32_t emb_ld;
+    const cdx_step* steps;     /* device [n_steps], kinds 0-4; NULL with n_steps == 0 (one forward: x_out <- network(x_in)) */
+    int32_t n_steps, predict_noise;
+    const float* x_in;         /* (batch, horizon, dim) */
+    const float* prior;        /* or NULL */
+    const float* fix_mask;     /* (horizon, dim) or NULL */
+    const float* noise;        /* (n_noise, batch, horizon, dim) or NULL */
+    const float* x_min;        /* (horizon, dim) or NULL */
+    const float* x_max;
+    float* x_out;
+    /* optional profiling: device u64 [n_ops*8 + 2]; workgroup 0 stamps s_memtime at {op start, next-op prefetch issued, after the
+     * staging barrier, op end, item record + segment read, first operands landed, MFMAs done, partial tile staged} of the first
+     * forward, plus kernel start/end.  NULL = off. */
+    unsigned long long* prof;
+} cdx_unet2_launch;
+int cdx_unet2_run(const cdx_unet2_launch* launch, void* hip_stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Big-batch building blocks (csrc/cdx_gemm.hip): when M = batch x tokens >> 256 the denoiser layers are classic

@@ -1,0 +1,183 @@
+"""Lane-level numpy model of ``csrc/cdx_unet2.hip`` -- TEST INFRASTRUCTURE (see oracle/__init__.py).
+
+Interprets the SAME (ops, item tables, blob, LDS plan) the v2 kernel receives with the kernel's index arithmetic:
+items per wave, the (segment, tap, chunk) cursor, the 64-lane operand
+fetch of the two MFMA shapes, the staging layout, and the epilogue's thread -> (group, float4 item) partition.  It is the
+executable specification ``cdx_unet2.hip`` was transcribed from and the CPU proof that the compiler's packing / slot
+plan / item tables are right before a GPU minute is spent.  One instance = one trajectory (trajectories never interact).
+"""
+import numpy as np
+
+from cleandiffuser_amd.engine import program2 as P2
+from cleandiffuser_amd.engine.program import GN_EPS, MODE_16X16
+from .lane_sim import mish
+
+
+def emb_table(prog: P2.Program2, temb: np.ndarray) -> np.ndarray:
+    """What cdx_unet2_embtab computes: rows of Linear(Mish(map_emb(temb_row))) for every block, (steps, n_emb)."""
+    blob = prog.blob.detach().cpu().numpy()
+    e = prog.embtab
+    ed, hid, md, n = e["emb_dim"], e["hidden"], e["md"], e["n_emb"]
+    w0 = blob[e["w0"]:e["w0"] + ed * hid].reshape(ed, hid)
+    w2 = blob[e["w2"]:e["w2"] + hid * md].reshape(hid, md)
+    w3 = blob[e["w3"]:e["w3"] + md * n].reshape(md, n)
+    out = np.empty((temb.shape[0], n), np.float32)
+    for s, row in enumerate(np.asarray(temb, np.float32)):
+        h = blob[e["b0"]:e["b0"] + hid].copy()
+        for i in range(ed):
+            h = h + w0[i] * row[i]
+        h = mish(h)
+        m = blob[e["b2"]:e["b2"] + md].copy()
+        for i in range(hid):
+            m = m + w2[i] * h[i]
+        m = mish(m)
+        o = blob[e["b3"]:e["b3"] + n].copy()
+        for i in range(md):
+            o = o + w3[i] * m[i]
+        out[s] = o
+    return out
+
+
+class LaneSim2:
+    def __init__(self, prog: P2.Program2):
+        self.p = prog
+        self.blob = prog.blob.detach().cpu().numpy()
+        self.buf = prog.ops_buffer
+        self.lds = np.full(prog.traj_floats, np.nan, np.float32)        # NaN poison: an unwritten read shows up
+        # kernel start: the whole trajectory region is zeroed once (zero row, x pad channels, slot pad columns)
+        self.lds[:] = 0.0
+        self.poison_arena()
+
+    def poison_arena(self):
+        """Everything but the zero row and the x slot is (re)poisoned: ops must write before anyone reads."""
+        p = self.p
+        keep_lo, keep_hi = 0, p.x_off + p.horizon * p.x_stride
+        self.lds[keep_hi:] = np.nan
+        assert p.zrow_off == 0 and keep_lo == 0
+
+    def load_x(self, x):
+        p = self.p
+        for n in range(p.horizon):
+            self.lds[p.x_off + n * p.x_stride: p.x_off + n * p.x_stride + p.dim] = x[n]
+
+    def read_slot(self, off, stride, length, chans):
+        return np.stack([self.lds[off + n * stride: off + n * stride + chans] for n in range(length)])
+
+    # ------------------------------------------------------------------------------------------ #
+    def run_forward(self, emb_row):
+        for op in self.p.ops:
+            self._conv(op, np.asarray(emb_row, np.float32))
+        p = self.p
+        return self.read_slot(p.pred_off, p.pred_stride, p.horizon, p.dim)
+
+    @staticmethod
+    def _conv_row(op, pos, tap, pad):
+        if op[P2.W2_TRANSPOSED]:
+            num = pos + pad - tap
+            q = -1 if (num & 1) else (num >> 1)
+        else:
+            q = pos * op[P2.W2_CSTRIDE] + tap - pad
+        return q if (pos < op[P2.W2_LOUT] and 0 <= q < op[P2.W2_LIN]) else -1
+
+    def _conv(self, op, emb_row):
+        p, lds = self.p, self.lds
+        c_out, l_out, coutp = int(op[P2.W2_COUT]), int(op[P2.W2_LOUT]), int(op[P2.W2_COUTP])
+        mode, nt_n, sstride = int(op[P2.W2_MODE]), int(op[P2.W2_NT]), int(op[P2.W2_SSTRIDE])
+        flags = int(op[P2.W2_FLAGS])
+        segs = [[int(op[P2.W2_SEG0 + s * P2.SEG2_WORDS + k]) for k in range(P2.SEG2_WORDS)]
+                for s in range(int(op[P2.W2_NSEG]))]
+        lane = np.arange(64)
+        if mode == MODE_16X16:
+            cols, kstep, lcol, koff, drow, rows = 16, 16, lane & 15, 4 * (lane >> 4), 4 * (lane >> 4), 16
+        else:
+            cols, kstep, lcol, koff, drow, rows = 4, 4, lane & 3, 0 * lane, 4 * (lane >> 2), 64
+        stage = p.stage_off
+        ksplit = int(op[P2.W2_KSPLIT])
+        lds[stage:stage + ksplit * l_out * sstride] = np.nan      # stale data must not be read
+
+        for item in range(int(op[P2.W2_NITEMS])):             # wave w takes items w, w + 4, ...
+            rec = self.buf[op[P2.W2_ITEMS] + item * P2.ITEM2_WORDS: op[P2.W2_ITEMS] + (item + 1) * P2.ITEM2_WORDS]
+            woff, nq, si, tap, cc, part, col0 = (int(rec[k]) for k in range(7))
+            w4 = self.blob[woff:woff + nq * 256].reshape(nq, 64, 4)
+            acc = np.zeros((nt_n, 64, 4), np.float32)         # D fragment: [col tile][lane][4 rows]
+            for q in range(nq):
+                src, sstr, ccn, taps, pad = segs[si]
+                a = w4[q]
+                for nt in range(nt_n):
+                    bmat = np.empty((64, 4), np.float32)
+                    for l in range(64):
+                        row = self._conv_row(op, col0 + nt * cols + lcol[l], tap, pad)
+                        base = src + row * sstr if row >= 0 else p.zrow_off
+                        addr = base + cc * kstep + koff[l]
+                        bmat[l] = lds[addr:addr + 4]
+                    if mode == MODE_16X16:                     # D[i][j] += sum_k A[i][k] B[k][j]; lane = k*16 + i / k*16 + j
+                        am = a.reshape(4, 16, 4)
+                        bm = bmat.reshape(4, 16, 4)
+                        d = np.einsum("kim,kjm->ij", am, bm).astype(np.float32)        # [row i][col j]
+                    else:                                      # 16 blocks of 4x4: row = lane, the 4 columns are lanes 0..3
+                        d = (a[:, None, :] * bmat[None, :4, :]).sum(-1).astype(np.float32)   # [row 0..63][col 0..3]
+                    for l in range(64):
+                        acc[nt][l] += d[drow[l]:drow[l] + 4, lcol[l]]
+                if q + 1 < nq:                                 # cursor walk (segment, tap, chunk)
+                    cc += 1
+                    if cc == ccn:
+                        cc = 0
+                        tap += 1
+                        if tap == taps:
+                            tap, si = 0, si + 1
+            for nt in range(nt_n):                             # D fragment -> stage[k slice][position][row tile + rows]
+                for l in range(64):
+                    n = col0 + nt * cols + lcol[l]
+                    if n < l_out:
+                        a0 = stage + part + n * sstride + drow[l]
+                        lds[a0:a0 + 4] = acc[nt][l]
+
+        # ---------------- epilogue: thread -> (group, float4 item) ---------------- #
+        cg = coutp // P2.GROUPS2
+        shift, nk = int(op[P2.W2_CG4_SHIFT]), int(op[P2.W2_NK])
+        cg4 = cg // 4
+        assert cg4 == 1 << shift
+        nv = cg4 * l_out
+        dst, dstride = int(op[P2.W2_DST]), int(op[P2.W2_DST_STRIDE])
+
+        def par(word):
+            o = int(op[word])
+            return self.blob[o:o + coutp]
+
+        bias = par(P2.W2_BOFF)
+        vals = {}
+        for tid in range(256):
+            g, li = tid >> 5, tid & 31
+            for k in range(nk):
+                i = li + 32 * k
+                if i >= nv:
+                    continue
+                c, pos = g * cg + 4 * (i & (cg4 - 1)), i >> shift
+                v = bias[c:c + 4].copy()
+                for ks in range(ksplit):
+                    a = stage + (ks * l_out + pos) * sstride + c
+                    v = v + lds[a:a + 4]
+                vals[(g, pos, c)] = v
+        if flags & P2.F2_GN:
+            gamma, beta = par(P2.W2_GAMMA), par(P2.W2_BETA)
+            inv_cnt = np.int32(op[P2.W2_INV_CNT]).view(np.float32)
+            for g in range(P2.GROUPS2):
+                keys = [kk for kk in vals if kk[0] == g]
+                allv = np.concatenate([vals[kk] for kk in keys])
+                mean = np.float32(allv.sum(dtype=np.float32) * inv_cnt)
+                var = np.float32(((allv - mean) ** 2).sum(dtype=np.float32) * inv_cnt)
+                rstd = np.float32(1.0) / np.sqrt(var + np.float32(GN_EPS))
+                for kk in keys:
+                    c = kk[2]
+                    vals[kk] = mish((vals[kk] - mean) * rstd * gamma[c:c + 4] + beta[c:c + 4])
+        for (g, pos, c), v in vals.items():
+            if flags & P2.F2_EMB:
+                e0 = int(op[P2.W2_EMB]) + c
+                v = v + emb_row[e0:e0 + 4]
+            if flags & P2.F2_RES:
+                a = int(op[P2.W2_RES]) + pos * int(op[P2.W2_RES_STRIDE]) + c
+                v = v + lds[a:a + 4]
+            for j in range(4):
+                if c + j < c_out:
+                    assert np.isfinite(v[j]), "NaN reached a destination slot"
+                    lds[dst + pos * dstride + c + j] = v[j]

@@ -28,15 +28,17 @@ def test_every_declared_symbol_is_exported(lib):
                           "cdx_dit1d_workspace_floats", "cdx_resmlp_workspace_floats", "cdx_gemm_set_trace",
                           "cdx_chitf_run", "cdx_chitf_workspace_floats", "cdx_cross_attention_f32", "cdx_chiunet_run",
                           "cdx_chiunet_workspace_floats", "cdx_groupnorm_f32", "cdx_groupnorm_bwd_f32", "cdx_hjgrad_run",
-                          "cdx_hjgrad_workspace_floats", "cdx_guided_run", "cdx_guided_workspace_floats"}
+                          "cdx_hjgrad_workspace_floats", "cdx_guided_run", "cdx_guided_workspace_floats", "cdx_unet2_run",
+                          "cdx_unet2_embtab"}
     for n in names:
         assert hasattr(lib, n), f"{n} declared in cdx.h but not exported by libcdx.so"
     assert lib.cdx_abi_version() == int(re.search(r"#define CDX_ABI_VERSION (\d+)", hdr).group(1))
 
 
 def test_ctypes_mirrors_have_c_layout(tmp_path):
-    from cleandiffuser_amd.engine import bigbatch, blocks, classifier_grad, guided, runtime
-    mirrors = {"cdx_guided_launch": guided.CdxGuidedLaunch,
+    from cleandiffuser_amd.engine import bigbatch, blocks, classifier_grad, guided, runtime, runtime2
+    mirrors = {"cdx_guided_launch": guided.CdxGuidedLaunch, "cdx_unet2_launch": runtime2.CdxUnet2Launch,
+               "cdx_unet2_embtab_args": runtime2.CdxUnet2EmbtabArgs,
                "cdx_hj_block": classifier_grad.CdxHjBlock, "cdx_hj_down": classifier_grad.CdxHjDown,
                "cdx_hjgrad_weights": classifier_grad.CdxHjgradWeights,
                "cdx_unet1d_launch": runtime.CdxUnet1dLaunch, "cdx_step": runtime.CdxStep, "cdx_gemm_args": blocks.CdxGemmArgs,
@@ -73,6 +75,35 @@ def test_op_word_layout_matches_header():
         assert getattr(P, py) == int(val), (name, val, getattr(P, py))
     hdr = open(os.path.join(ROOT, "include", "cdx.h")).read()
     assert int(re.search(r"#define CDX_OP_WORDS (\d+)", hdr).group(1)) == P.OP_WORDS
+
+
+def test_op2_word_layout_matches_header():
+    """csrc/cdx_ops2.h (what cdx_unet2.hip decodes) == engine/program2.py (what the host emits)."""
+    from cleandiffuser_amd.engine import program2 as P2
+    text = open(os.path.join(ROOT, "cleandiffuser_amd", "csrc", "cdx_ops2.h")).read()
+    defs = re.findall(r"#define CDX2_(\w+) (\d+)\b", text)
+    assert len(defs) > 40
+    alias = {"OP_WORDS": "OP2_WORDS", "ITEM_WORDS": "ITEM2_WORDS"}
+    for name, val in defs:
+        name = alias.get(name, name)
+        assert hasattr(P2, name), f"program2.py lacks {name}"
+        assert getattr(P2, name) == int(val), (name, val, getattr(P2, name))
+    hdr = open(os.path.join(ROOT, "include", "cdx.h")).read()
+    assert int(re.search(r"#define CDX2_OP_WORDS (\d+)", hdr).group(1)) == P2.OP2_WORDS
+
+
+def test_unet2_validation_fails_loudly(lib):
+    from cleandiffuser_amd.engine import runtime2
+    runtime2._lib()
+    assert lib.cdx_unet2_run(ctypes.byref(runtime2.CdxUnet2Launch()), None) == -1 and b"null" in lib.cdx_last_error()
+    L = runtime2.CdxUnet2Launch(ops=8, wblob=8, x_in=8, x_out=8, emb=8, n_ops=1, batch=4, horizon=4, dim=4, traj_floats=64,
+                                traj_per_wg=3)
+    assert lib.cdx_unet2_run(ctypes.byref(L), None) == -1 and b"traj_per_wg" in lib.cdx_last_error()
+    L.traj_per_wg, L.traj_floats = 2, 30 * 1024
+    assert lib.cdx_unet2_run(ctypes.byref(L), None) == -2 and b"160 KiB" in lib.cdx_last_error()
+    L.batch = 0
+    assert lib.cdx_unet2_run(ctypes.byref(L), None) == 0                                            # empty request: nothing to do
+    assert lib.cdx_unet2_embtab(ctypes.byref(runtime2.CdxUnet2EmbtabArgs()), None) == -1
 
 
 def test_launch_validation_fails_loudly(lib):

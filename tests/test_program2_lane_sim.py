@@ -1,0 +1,72 @@
+"""v2 program compiler (engine/program2.py: tiles / K slices / item tables / record packing / slot plan / epilogue partition)
+proven on CPU: the lane-level model of csrc/cdx_unet2.hip (oracle/lane_sim2.py) interprets the compiled program and must
+reproduce the reference's first forward (``pred0`` of the fixtures, produced by the real reference).  Tolerance 2e-5: same
+fp32 math, different summation order."""
+import numpy as np
+import pytest
+import torch
+
+from cleandiffuser_amd.engine import program2 as P2
+from oracle import cases
+from oracle.lane_sim2 import LaneSim2, emb_table
+from conftest import golden_path
+from test_program_lane_sim import _first_forward_inputs
+
+
+def _first_t(agent, c):
+    from cleandiffuser_amd.utils import SUPPORTED_SAMPLING_STEP_SCHEDULE as SS
+    S = c["sample"]["sample_steps"]
+    if c["solver"][0] == "DiscreteDiffusionSDE":
+        sched = SS[c["sample"].get("sample_step_schedule", "uniform")](agent.diffusion_steps, S)
+        return torch.tensor([int(sched[S])], dtype=torch.long)
+    sched = SS[c["sample"].get("sample_step_schedule", "uniform_continuous")](agent.t_diffusion, S)
+    return torch.tensor([float(sched[S])], dtype=torch.float32)
+
+
+@pytest.mark.parametrize("name", ["janner_cfg2_ddim", "janner_h4_ddpm", "janner_tiny_disc_ddim", "janner_tiny_cont_ddim", "janner_h64_single"])
+def test_lane_sim2_reproduces_reference_forward(name, amd_lib):
+    gold = np.load(golden_path(name))
+    agent, _ = cases.build(amd_lib, name)
+    c = cases.CASES[name]
+    net = agent.model_ema["diffusion"]
+    prog = P2.compile_janner2(net, c["horizon"])
+    assert prog.lds_bytes(1) <= 160 * 1024
+    inp, xt0 = _first_forward_inputs(name, agent)
+    with torch.no_grad():
+        temb = net.map_noise(_first_t(agent, c)).numpy()
+    row = emb_table(prog, temb)[0]
+    for b in range(2 if name == "janner_cfg2_ddim" else c["batch"]):
+        sim = LaneSim2(prog)
+        sim.load_x(xt0[b])
+        np.testing.assert_allclose(sim.run_forward(row), gold["pred0"][b], rtol=2e-5, atol=2e-5)
+
+
+def test_program2_accounting_and_budget(amd_lib):
+    """North-star config: 19.67 M MAC per forward (embedding MLP included), 47 conv ops (16 blocks x 2 +
+    7 skip convs + 3 down + 3 up + 2 head), and TWO trajectories fit one workgroup's 160 KiB."""
+    _, net = cases.build(amd_lib, "janner_cfg2_ddim")
+    prog = P2.compile_janner2(net, 32)
+    assert len(prog.ops) == 47
+    assert abs(prog.macs_per_forward - 19.67e6) / 19.67e6 < 0.01
+    assert prog.lds_bytes(2) <= 160 * 1024
+    ops = prog.ops
+    assert (ops[:, P2.W2_NITEMS] >= 1).all() and (ops[:, P2.W2_NSEG] <= 2).all()
+    # every wave has work in every op of this net, and K slices exactly tile the record stream of a row tile
+    for op in ops:
+        items = prog.ops_buffer[op[P2.W2_ITEMS]: op[P2.W2_ITEMS] + op[P2.W2_NITEMS] * P2.ITEM2_WORDS].reshape(-1, P2.ITEM2_WORDS)
+        assert len(items) == P2.NW2
+        nqt = sum(int(op[P2.W2_SEG0 + s * P2.SEG2_WORDS + P2.S2_CCN]) * int(op[P2.W2_SEG0 + s * P2.SEG2_WORDS + P2.S2_TAPS])
+                  for s in range(op[P2.W2_NSEG]))
+        tiles = len(items) // op[P2.W2_KSPLIT]
+        assert items[:, P2.I2_NQ].sum() == nqt * tiles
+
+
+def test_v2_refuses_what_it_cannot_run(amd_lib):
+    """Nets outside the v2 epilogue partition report a reason: the runtime keeps them on the first kernel."""
+    from cleandiffuser_amd.engine import runtime2
+    net = amd_lib.JannerUNet1d(5, model_dim=24, emb_dim=16, dim_mult=[1, 2], kernel_size=3)      # 24 channels: groups of 4 != 32/8
+    why = runtime2.supported(net, 8)
+    assert why is not None and "GroupNorm" in why
+    agent, _ = cases.build(amd_lib, "janner_cfg2_ddim")
+    assert runtime2.supported(agent.model_ema["diffusion"], 32) is None
+    assert runtime2.supported(agent.model_ema["diffusion"], 36) is not None

@@ -1,0 +1,49 @@
+"""Per-op cycle breakdown of the v2 fused kernel (workgroup 0, first forward) -- tuning aid.
+Usage (GPU box): python tools/op_profile2.py [batch] [traj_per_wg] > gpurun_out/op_profile2.txt"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from cleandiffuser_amd.engine import program2 as P2, runtime, runtime2  # noqa: E402
+
+
+def main():
+    batch = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    if len(sys.argv) > 2:
+        os.environ["CDX_UNET2_T"] = sys.argv[2]
+    bench.BATCH = batch
+    dev = torch.device("cuda", 0)
+    agent, net = bench.build_agent(dev)
+    prior, z0 = bench.make_inputs(dev, 0)
+    kw = dict(solver="ddim", n_samples=batch, sample_steps=20, temperature=0.5)
+    for _ in range(3):
+        agent.sample(prior, noise=[z0], **kw)
+    prog = runtime2.compiled2(agent.model_ema["diffusion"], 32).prog
+    n_ops = len(prog.ops)
+    buf = torch.zeros(n_ops * 8 + 2, dtype=torch.int64, device=dev)
+    runtime.set_profile_buffer(buf)
+    agent.sample(prior, noise=[z0], **kw)
+    torch.cuda.synchronize()
+    runtime.set_profile_buffer(None)
+    t = buf.cpu().numpy()
+    total = t[n_ops * 8 + 1] - t[n_ops * 8]
+    fwd = t[(n_ops - 1) * 8 + 3] - t[0]
+    print(f"batch={batch} T={runtime2.traj_per_wg(prog, batch)} kernel cycles (wg0) = {total}  traj_bytes={prog.traj_floats * 4}")
+    print(f"first forward cycles = {fwd}  ({fwd * 20 / total:.2%} of kernel if all 20 equal)")
+    print(f"{'op':>3} {'cout':>4} {'L':>3} {'mode':>4} {'nt':>2} {'ks':>2} {'nq/item':>7} {'kloop':>7} {'sync':>6} {'epi':>6} {'total':>7}")
+    tk = ts = te = 0
+    for i, op in enumerate(prog.ops):
+        s0, s1, s2, s3, k4, k5, k6, k7 = t[i * 8:i * 8 + 8]
+        nq = int(prog.ops_buffer[op[P2.W2_ITEMS] + P2.I2_NQ])
+        k, s, e = s1 - s0, s2 - s1, s3 - s2
+        tk, ts, te = tk + k, ts + s, te + e
+        print(f"{i:3d} {op[P2.W2_COUT]:4d} {op[P2.W2_LOUT]:3d} {'4x4' if op[P2.W2_MODE] else '16':>4} {op[P2.W2_NT]:2d} {op[P2.W2_KSPLIT]:2d} "
+              f"{nq:7d} {k:7d} {s:6d} {e:6d} {s3 - s0:7d} | decode {k4 - s0:5d} operands {k5 - k4:5d} mfma {k6 - k5:6d} stage {k7 - k6:5d} prefetch {s1 - k7:5d}")
+    print(f"totals: kloop={tk} sync={ts} epilogue={te}  sum={tk + ts + te}")
+
+
+if __name__ == "__main__":
+    main()
