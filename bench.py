@@ -27,7 +27,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-BATCH, HORIZON, DIM, SAMPLE_STEPS = 256, 32, 23, 20
+BATCH, HORIZON, DIM, SAMPLE_STEPS = int(os.environ.get("BENCH_BATCH", "256")), 32, 23, 20
 PEAK_FP32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_*_f32 dense peak
 
 

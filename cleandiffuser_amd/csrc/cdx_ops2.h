@@ -3,55 +3,49 @@
 // MUST mirror cleandiffuser_amd/engine/program2.py (tests/test_abi_contract.py parses this file and compares).
 #pragma once
 
-#define CDX2_OP_WORDS 48   /* 36 used; 192 B = three 64-B scalar-cache lines */
+#define CDX2_OP_WORDS 64   /* 25 descriptor words (padded to 32) + CDX2_NW2 inline work items */
 #define CDX2_ITEM_WORDS 8
 #define CDX2_NW2 4        /* waves per workgroup, one per SIMD */
 #define CDX2_RING2 16     /* 1-KiB weight records in flight per wave */
 #define CDX2_GROUPS2 8    /* GroupNorm groups: 32 lanes per group in the epilogue */
 #define CDX2_MAX_NK2 4    /* float4 items one lane may own in the epilogue */
+#define CDX2_HALO2 2       /* zero rows on either side of an activation slot */
 
 #define CDX2_W2_KIND 0
 #define CDX2_W2_FLAGS 1
 #define CDX2_W2_COUT 2
 #define CDX2_W2_LOUT 3
-#define CDX2_W2_LIN 4
+#define CDX2_W2_LCOLS 4      /* tile columns: l_out, or l_in for the per-parity halves of a transposed conv */
 #define CDX2_W2_CSTRIDE 5
-#define CDX2_W2_TRANSPOSED 6
+#define CDX2_W2_OSTRIDE 6    /* output position = column * OSTRIDE + item offset (2 for a transposed conv) */
 #define CDX2_W2_MODE 7
 #define CDX2_W2_NT 8
 #define CDX2_W2_NITEMS 9
-#define CDX2_W2_ITEMS 10
-#define CDX2_W2_NSEG 11
-#define CDX2_W2_SEG0 12
-#define CDX2_SEG2_WORDS 5
-#define CDX2_S2_SRC 0
-#define CDX2_S2_STRIDE 1
-#define CDX2_S2_CCN 2
-#define CDX2_S2_TAPS 3
-#define CDX2_S2_PAD 4
-#define CDX2_W2_DST 22
-#define CDX2_W2_DST_STRIDE 23
-#define CDX2_W2_SSTRIDE 24
-#define CDX2_W2_KSPLIT 25
-#define CDX2_W2_BOFF 26
-#define CDX2_W2_GAMMA 27
-#define CDX2_W2_BETA 28
-#define CDX2_W2_EMB 29
-#define CDX2_W2_RES 30
-#define CDX2_W2_RES_STRIDE 31
-#define CDX2_W2_CG4_SHIFT 32
-#define CDX2_W2_INV_CNT 33
-#define CDX2_W2_NK 34
-#define CDX2_W2_COUTP 35
+#define CDX2_W2_ITEMS 10     /* word offset of items NW2.. (the first NW2 are inline at W2_ITEM0) */
+#define CDX2_W2_DST 11
+#define CDX2_W2_DST_STRIDE 12
+#define CDX2_W2_SSTRIDE 13
+#define CDX2_W2_KSPLIT 14
+#define CDX2_W2_BOFF 15
+#define CDX2_W2_GAMMA 16
+#define CDX2_W2_BETA 17
+#define CDX2_W2_EMB 18
+#define CDX2_W2_RES 19
+#define CDX2_W2_RES_STRIDE 20
+#define CDX2_W2_CG4_SHIFT 21
+#define CDX2_W2_INV_CNT 22
+#define CDX2_W2_NK 23
+#define CDX2_W2_COUTP 24
+#define CDX2_W2_ITEM0 32
 
 #define CDX2_I2_WOFF 0
 #define CDX2_I2_NQ 1
-#define CDX2_I2_SEG 2
-#define CDX2_I2_TAP 3
-#define CDX2_I2_CC 4
-#define CDX2_I2_PART 5
-#define CDX2_I2_COL0 6
-#define CDX2_I2_SPARE 7
+#define CDX2_I2_TAPCC 2      /* start cursor: tap | chunk << 8 */
+#define CDX2_I2_PART 3
+#define CDX2_I2_COL0 4
+#define CDX2_I2_PADOOFF 5    /* conv padding | output-position offset << 8 */
+#define CDX2_I2_SRCSTR 6     /* source slot: float offset | row stride << 16 */
+#define CDX2_I2_CCN 7        /* chunks per tap */
 
 #define CDX2_F2_GN 1
 #define CDX2_F2_EMB 2

@@ -88,199 +88,249 @@ struct M4 {    // v_mfma_f32_4x4x1_16b_f32: 16 blocks of 4x4 = 64 rows x 4 cols,
     }
 };
 
-struct Seg { int src, sstr, ccn, taps, pad; };
-
 struct Geom {                    // wave-uniform description of one conv op's K loop
-    int l_out, l_in, cstride, transposed, zrow;
-    const cint* segs;            // the op's segment table (descriptor words CDX2_W2_SEG0...), re-read at a segment change
-    int sstride, stage;
+    int l_cols, cstride, ostride, sstride, stage;
 };
 
-struct Cursor { int si, tap, cc; Seg s; };
+// One wave's job: (row tile, column group, K slice [, output parity of a transposed conv]) over ONE source slot.
+struct Item { int woff, nq, tap, cc, part, col0, pad, ooff, src, sstr, ccn; };
 
-// Segment `si` of the op (a K segment = one source slot of a channel concat): scalar loads from the descriptor (scalar-cache
-// hits; it changes at most once per item).  Kept as loads on purpose: selecting between register-resident structs makes the
-// compiler build a scratch array.
-__device__ __forceinline__ Seg pick(const Geom& g, int si) {
-    const cint* s = g.segs + si * CDX2_SEG2_WORDS;
-    return Seg{s[CDX2_S2_SRC], s[CDX2_S2_STRIDE], s[CDX2_S2_CCN], s[CDX2_S2_TAPS], s[CDX2_S2_PAD]};
+__device__ __forceinline__ Item make_item(int woff, int nq, int tc, int part, int col0, int po, int ss, int ccn) {
+    return Item{woff, nq, tc & 255, tc >> 8, part, col0, po & 255, po >> 8, ss & 0xffff, ss >> 16, ccn};
+}
+__device__ __forceinline__ Item load_item(const cint* it) {        // items past the inline four: scalar loads (rare)
+    return make_item(it[CDX2_I2_WOFF], it[CDX2_I2_NQ], it[CDX2_I2_TAPCC], it[CDX2_I2_PART], it[CDX2_I2_COL0],
+                     it[CDX2_I2_PADOOFF], it[CDX2_I2_SRCSTR], it[CDX2_I2_CCN]);
 }
 
-// Input row feeding output position `pos` at tap `tap`, or -1 (outside [0, l_in), odd phase of the stride-2 transposed conv,
-// column past l_out): such lanes read the trajectory's all-zero row, so the B fetch needs no predicate.
-__device__ __forceinline__ int conv_row(const Geom& g, int pos, int tap, int pad) {
-    const int fwd = pos * g.cstride + tap - pad;
-    const int num = pos + pad - tap;
-    const int bwd = (num & 1) ? -1 : (num >> 1);
-    const int q = g.transposed ? bwd : fwd;
-    return (pos < g.l_out && q >= 0 && q < g.l_in) ? q : -1;
+// An op descriptor is 64 words = ONE coalesced dword load per wave: lane k holds word k, fields come out with v_readlane.
+// (The scalar-load version of this kernel spent ~900 cycles per op waiting on dependent s_loads / spilling their results.)
+#define CDX2_DW(vd, k) __builtin_amdgcn_readlane((vd), (k))
+__device__ __forceinline__ Item inline_item(int vd, int j) {       // item j < NW of the descriptor held in `vd`
+    const int b = CDX2_W2_ITEM0 + j * CDX2_ITEM_WORDS;
+    return make_item(CDX2_DW(vd, b + CDX2_I2_WOFF), CDX2_DW(vd, b + CDX2_I2_NQ), CDX2_DW(vd, b + CDX2_I2_TAPCC),
+                     CDX2_DW(vd, b + CDX2_I2_PART), CDX2_DW(vd, b + CDX2_I2_COL0), CDX2_DW(vd, b + CDX2_I2_PADOOFF),
+                     CDX2_DW(vd, b + CDX2_I2_SRCSTR), CDX2_DW(vd, b + CDX2_I2_CCN));
 }
-
-template <class M, int NT>
-__device__ __forceinline__ void lane_rows(const Geom& g, const Cursor& c, int col0, int lane, int (&roff)[NT]) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int q = conv_row(g, col0 + nt * M::COLS + M::col(lane), c.tap, c.s.pad);
-        const int in_slot = __mul24(q, c.s.sstr);                                  // 24-bit multiply: cheap enough to stay branch-free
-        roff[nt] = (q >= 0 ? in_slot : g.zrow - c.s.src) + M::koff(lane);          // relative to the segment's source slot
-    }
-}
-
-template <class M, int NT, int T>
-__device__ __forceinline__ void fetch_b(const float* __restrict__ lds, int tf, const Cursor& c, const int (&roff)[NT],
-                                        f32x4 (&bv)[T][NT]) {
-#pragma unroll
-    for (int t = 0; t < T; ++t)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-            bv[t][nt] = *reinterpret_cast<const f32x4*>(lds + t * tf + c.s.src + roff[nt] + c.cc * M::KSTEP);
-}
-
-// ---- weight ring -------------------------------------------------------------------------------------------------------
-// PF = 16 1-KiB records in flight per wave, held as RS = 8 slots of SUB = 2 records.  The slot count matters: hipcc keeps
-// *counted* `s_waitcnt vmcnt(N)` waits only for register rings unrolled <= 8 deep (measured on this toolchain: 9, 10, 12 and
-// 16 slots all degenerate to a full drain per revolution, i.e. one L2 round trip every PF records), while 8 slots x 2 loads
-// give the same 16 loads in flight with waits vmcnt(14)/(15).
-#define RS 8
-#define SUB (PF / RS)
-struct Ring { f32x4 rec[RS][SUB]; };  // head of this wave's next weight stream, issued one op ahead
 
 // Profiling stamps go to LDS (a global store would be waited on by the next vmcnt wait and distort the phase being measured).
 __device__ __forceinline__ void stamp(unsigned long long* slot, int tid) {
     if (slot && tid == 0) *slot = __builtin_amdgcn_s_memtime();
 }
 
-// K loop of one conv op for this wave: items wave, wave + 4, ...; an item = (row tile, column group, K slice).
+// ---- weight ring -------------------------------------------------------------------------------------------------------
+// PF = 16 1-KiB records in flight per wave (a single wave per SIMD has to cover the whole L2 latency by itself).
+struct Ring { f32x4 rec[PF]; };       // head of this wave's next weight stream, issued one op ahead
+
+// K loop of one conv op for this wave: items wave, wave + 4, ...  The first item (and its ring contents) arrive from the
+// previous op; further items (layers with more than four tiles) are read from the descriptor / tail table here.
+//
+// Operand addressing.  Column m of the tile (output position n = m * ostride + ooff) reads input row m * cstride - pad + tap of
+// the item's source slot; the slot's HALO2 zero rows make that row valid for every tap, i.e. the B address is LINEAR in
+// (tap, chunk): one add per chunk (`+ KSTEP`) and, every `ccn` chunks, one per-lane add for the tap step.  Columns past l_cols
+// sit on halo row 0 with a zero tap step.  Nothing else happens per record: wait, 4 MFMAs per (trajectory, column tile), one
+// ds_read per (trajectory, column tile), one global load.
 template <class M, int NT, int T>
-__device__ __forceinline__ void conv_kloop(const Geom& g, const float* __restrict__ wblob, const cint* items,
-                                           int n_items, float* __restrict__ lds, int tf, int lane, int wave, Ring& ring,
-                                           unsigned long long* prof) {
-    const int ptid = (wave == 0 && lane == 0) ? 0 : 1;          // stamp() fires for tid == 0 only
+__device__ __forceinline__ void conv_kloop(const Geom& g, const float* __restrict__ wblob, int vd, const cint* ops,
+                                           Item it, int n_items, float* __restrict__ lds, int tf, int lane, int wave,
+                                           Ring& ring, unsigned long long* prof) {
     // operand ring depth: 8 when a chunk is only 4 short MFMAs (32 cycles), else 4
     constexpr int BD = (M::KSTEP == 4 && NT * T == 1) ? 8 : 4;
     static_assert(PF % BD == 0, "operand ring must divide the weight ring");
+    const int ptid = (wave == 0 && lane == 0) ? 0 : 1;          // stamp() fires for tid == 0 only
     for (int item = wave; item < n_items; item += NW) {
-        const cint* it = items + item * CDX2_ITEM_WORDS;                     // wave-uniform address -> scalar loads
-        const int woff = it[CDX2_I2_WOFF], nq = it[CDX2_I2_NQ], part = it[CDX2_I2_PART], col0 = it[CDX2_I2_COL0];
-        Cursor c;
-        c.si = it[CDX2_I2_SEG]; c.tap = it[CDX2_I2_TAP]; c.cc = it[CDX2_I2_CC];
-        c.s = pick(g, c.si);
-        if (prof && item == 0) { asm volatile("" ::"s"(nq), "s"(c.s.ccn)); stamp(prof + 4, ptid); }
-        f32x4 acc0[T][NT], acc1[T][NT];
+        if (item != wave) it = load_item(ops + CDX2_DW(vd, CDX2_W2_ITEMS) + (item - NW) * CDX2_ITEM_WORDS);
+        const int nq = it.nq, ccn = it.ccn;
+        int cc = it.cc;
+        int cur[NT], tstep[NT], mcol[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            mcol[nt] = it.col0 + nt * M::COLS + M::col(lane);
+            const bool valid = mcol[nt] < g.l_cols;
+            const int row = valid ? mcol[nt] * g.cstride - it.pad + CDX2_HALO2 + it.tap : 0;
+            cur[nt] = it.src + __mul24(row, it.sstr) + M::koff(lane) + cc * M::KSTEP;
+            tstep[nt] = (valid ? it.sstr : 0) - ccn * M::KSTEP;
+        }
+        if (prof && item == 0) { asm volatile("" ::"s"(nq), "v"(cur[0])); stamp(prof + 4, ptid); }
+        // four accumulators per tile, one per K value of a record: a 4x4x1 MFMA is 2 passes, and with only two accumulators the
+        // compiler has to pad every dependent pair with s_nop (seen in the ISA: ~2 per record)
+        f32x4 acc[T][NT][4];
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                acc0[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                acc1[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-        int roff[NT];
-        lane_rows<M, NT>(g, c, col0, lane, roff);
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t][nt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-        const f32x4* wp = reinterpret_cast<const f32x4*>(wblob + woff) + lane;
-        f32x4 wr[RS][SUB];
+        const f32x4* wp = reinterpret_cast<const f32x4*>(wblob + it.woff) + lane;
+        f32x4 wr[PF];
         if (item == wave) {                                    // head of the stream was issued during the previous op
 #pragma unroll
-            for (int u = 0; u < RS; ++u)
-#pragma unroll
-                for (int h = 0; h < SUB; ++h) wr[u][h] = ring.rec[u][h];
+            for (int u = 0; u < PF; ++u) wr[u] = ring.rec[u];
         } else {
 #pragma unroll
-            for (int u = 0; u < RS; ++u)
-#pragma unroll
-                for (int h = 0; h < SUB; ++h) wr[u][h] = wp[(size_t)min(u * SUB + h, nq - 1) * 64];   // unconditional: vmcnt stays countable
+            for (int u = 0; u < PF; ++u) wr[u] = wp[(size_t)u * 64];   // unconditional (the blob is padded by PF records)
         }
         // B-operand ring: with ONE wave per SIMD nothing else hides the ~100+ cycle ds_read latency, so the operand of chunk
         // q + BD - 1 is requested before chunk q's MFMAs issue (a chunk is only 32 cycles of matrix pipe in the 4x4 mode).
         f32x4 bq[BD][T][NT];
-        auto advance = [&]() {
-            if (++c.cc == c.s.ccn) {
-                c.cc = 0;
-                if (++c.tap == c.s.taps) {
-                    c.tap = 0;
-                    c.s = pick(g, ++c.si);
-                }
-                lane_rows<M, NT>(g, c, col0, lane, roff);
+        auto fetch = [&](f32x4 (&bv)[T][NT]) {
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bv[t][nt] = *reinterpret_cast<const f32x4*>(lds + t * tf + cur[nt]);
+        };
+        auto advance = [&]() {                                 // cursor -> next chunk
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) cur[nt] += M::KSTEP;
+            if (++cc == ccn) {                                 // ... -> next tap: one more add
+                cc = 0;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) cur[nt] += tstep[nt];
             }
         };
 #pragma unroll
         for (int j = 0; j < BD - 1; ++j) {
             if (j < nq) {
                 if (j > 0) advance();
-                fetch_b<M, NT, T>(lds, tf, c, roff, bq[j]);
+                fetch(bq[j]);
             }
         }
-
-        if (prof && item == 0) { asm volatile("" ::"v"(wr[0][0][0]), "v"(bq[0][0][0][0])); stamp(prof + 5, ptid); }
+        if (prof && item == 0) { asm volatile("" ::"v"(wr[0][0]), "v"(bq[0][0][0][0])); stamp(prof + 5, ptid); }
 
         // chunk at ring slot u (record index == u mod PF, PF % BD == 0 -> operand slot u % BD is static after unrolling)
         auto chunk = [&](const f32x4 a, const int u, bool more) {
             if (more) {
                 advance();
-                fetch_b<M, NT, T>(lds, tf, c, roff, bq[(u + BD - 1) % BD]);
+                fetch(bq[(u + BD - 1) % BD]);
             }
 #pragma unroll
             for (int t = 0; t < T; ++t)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    acc0[t][nt] = M::mfma(a[0], bq[u % BD][t][nt][0], acc0[t][nt]);
-                    acc1[t][nt] = M::mfma(a[1], bq[u % BD][t][nt][1], acc1[t][nt]);
-                    acc0[t][nt] = M::mfma(a[2], bq[u % BD][t][nt][2], acc0[t][nt]);
-                    acc1[t][nt] = M::mfma(a[3], bq[u % BD][t][nt][3], acc1[t][nt]);
-                }
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[t][nt][j] = M::mfma(a[j], bq[u % BD][t][nt][j], acc[t][nt][j]);
         };
 
         // The refill of a record is issued one chunk LATE (after the next chunk's MFMAs): the scheduler may hoist a load
         // over the MFMAs of its own basic block, and a refill overlapping the last reads of the value it replaces makes the
         // register allocator double-buffer the whole ring (16 v_mov_b64 + a vmcnt(0) drain per revolution, seen in the ISA).
         // Lagged by a chunk, the old value is dead a full basic block earlier and every slot keeps its registers.
-        auto refill = [&](const int slot, int q) {            // record q -> ring slot `slot` (static after unrolling)
-            wr[slot / SUB][slot % SUB] = wp[(size_t)q * 64];
-        };
-        // steady state: every slot is refilled unconditionally (except the very first lagged one) -> counted vmcnt waits
-        // (16x16 layers are short -- tens of records -- and run entirely in the drain loop: the instruction cache is 64 KiB)
+        auto refill = [&](const int slot, int q) { wr[slot] = wp[(size_t)q * 64]; };
+        // steady state (4x4 layers whose taps span a multiple of PF chunks -- C_in >= 64 -- with the K slice starting on such a
+        // boundary, which the host guarantees): a revolution of PF chunks then lies inside ONE tap, so every operand address of
+        // the revolution is `base + constant` -- the ds_read carries the chunk as an immediate offset and nothing but
+        // {wait, MFMAs, ds_read, global_load} is issued per record; the tap step is applied once per revolution.  With one wave
+        // per SIMD the instruction count IS the speed of this loop (measured: 17 instructions per record = 100 cycles for 32
+        // cycles of matrix work).  16x16 layers are short (tens of records) and take the general loop below.
         int qi = 0;
-        const int n_main = M::KSTEP == 4 ? (nq / PF - 1) * PF : 0;
-        for (; qi < n_main; qi += PF) {
+        if (M::KSTEP == 4 && (ccn % PF) == 0 && (it.cc % PF) == 0) {
+            const int n_main = (nq / PF - 1) * PF;
+            // operand base of the current revolution's first chunk (bytes from the trajectory region), and of the next one's
+            int rb[NT], rbn[NT];
 #pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                chunk(wr[u / SUB][u % SUB], u, true);
-                if (u > 0) refill(u - 1, qi + u - 1 + PF);
-                else if (qi > 0) refill(PF - 1, qi - 1 + PF);
+            for (int nt = 0; nt < NT; ++nt) rb[nt] = (cur[nt] - (nq >= BD - 1 ? BD - 2 : nq - 1) * M::KSTEP) * 4;
+            int cc0 = it.cc;                                   // chunk-in-tap of the revolution's first chunk
+            const char* ldsb = reinterpret_cast<const char*>(lds);
+            for (; qi < n_main; qi += PF) {
+                const bool wrap = cc0 + PF == ccn;             // the NEXT revolution starts the next tap
+                cc0 = wrap ? 0 : cc0 + PF;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) rbn[nt] = rb[nt] + PF * M::KSTEP * 4 + (wrap ? tstep[nt] * 4 : 0);
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    const int ua = u + BD - 1;                 // chunk whose operand is requested now
+#pragma unroll
+                    for (int t = 0; t < T; ++t)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            bq[ua % BD][t][nt] = *reinterpret_cast<const f32x4*>(
+                                ldsb + (ua < PF ? rb[nt] : rbn[nt]) + t * tf * 4 + (ua % PF) * M::KSTEP * 4);
+#pragma unroll
+                    for (int t = 0; t < T; ++t)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                acc[t][nt][j] = M::mfma(wr[u][j], bq[u % BD][t][nt][j], acc[t][nt][j]);
+                    if (u > 0) refill(u - 1, qi + u - 1 + PF);
+                    else if (qi > 0) refill(PF - 1, qi - 1 + PF);
+                    // one refill per chunk, in place: left to itself the scheduler batches the 16 loads of a revolution into
+                    // 2-3 bursts and the ring spends half of the time 6-9 deep instead of 16 (seen in the ISA and the stream rate)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) rb[nt] = rbn[nt];
+            }
+            if (qi > 0) {                                      // hand the cursor to the general loop: it sits on chunk qi + BD - 2
+                cc = cc0 + BD - 2;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) cur[nt] = rb[nt] / 4 + (BD - 2) * M::KSTEP;
             }
         }
         // drain: the last (up to 2*PF - 1) records, refilling only while records remain
         for (; qi < nq; qi += PF) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
-                if (qi + u < nq) chunk(wr[u / SUB][u % SUB], u, qi + u + BD - 1 < nq);
+                if (qi + u < nq) chunk(wr[u], u, qi + u + BD - 1 < nq);
                 const int q = qi + u - 1 + PF;                 // lagged refill of the previous position
                 if (q >= PF && q < nq) refill((u + PF - 1) % PF, q);
             }
         }
-        if (prof && item == 0) { asm volatile("" ::"v"(acc0[0][0][0]), "v"(acc1[0][0][0])); stamp(prof + 6, ptid); }
-        // D fragment: 4 consecutive rows (channels) of one column -> stage[k slice][position][row tile + rows]
+        if (prof && item == 0) { asm volatile("" ::"v"(acc[0][0][0][0]), "v"(acc[0][0][1][0])); stamp(prof + 6, ptid); }
+        // D fragment: 4 consecutive rows (channels) of one column -> stage[k slice][output position][row tile + rows]
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const int n = col0 + nt * M::COLS + M::col(lane);
-                if (n < g.l_out) {
-                    const f32x4 d = acc0[t][nt] + acc1[t][nt];
-                    *reinterpret_cast<f32x4*>(lds + t * tf + g.stage + part + n * g.sstride + M::drow(lane)) = d;
+                if (mcol[nt] < g.l_cols) {
+                    const int n = mcol[nt] * g.ostride + it.ooff;
+                    const f32x4 dd = (acc[t][nt][0] + acc[t][nt][1]) + (acc[t][nt][2] + acc[t][nt][3]);
+                    *reinterpret_cast<f32x4*>(lds + t * tf + g.stage + it.part + n * g.sstride + M::drow(lane)) = dd;
                 }
             }
     }
 }
 
+// The epilogue's view of a descriptor (decoded with v_readlane right where it is needed: SGPR live ranges stay short).
+struct EpiDesc {
+    int flags, c_out, l_out, coutp, sstride, ksplit, dst, dstride, res, rstride, shift, nk;
+    float inv_cnt;
+};
+__device__ __forceinline__ EpiDesc decode_epi(int vd) {
+    EpiDesc e;
+    e.flags = CDX2_DW(vd, CDX2_W2_FLAGS); e.c_out = CDX2_DW(vd, CDX2_W2_COUT); e.l_out = CDX2_DW(vd, CDX2_W2_LOUT);
+    e.coutp = CDX2_DW(vd, CDX2_W2_COUTP); e.sstride = CDX2_DW(vd, CDX2_W2_SSTRIDE); e.ksplit = CDX2_DW(vd, CDX2_W2_KSPLIT);
+    e.dst = CDX2_DW(vd, CDX2_W2_DST); e.dstride = CDX2_DW(vd, CDX2_W2_DST_STRIDE); e.res = CDX2_DW(vd, CDX2_W2_RES);
+    e.rstride = CDX2_DW(vd, CDX2_W2_RES_STRIDE); e.shift = CDX2_DW(vd, CDX2_W2_CG4_SHIFT); e.nk = CDX2_DW(vd, CDX2_W2_NK);
+    e.inv_cnt = __int_as_float(CDX2_DW(vd, CDX2_W2_INV_CNT));
+    return e;
+}
+
 struct EpiParams { f32x4 bi, ga, be, em; };
+
+// two half-wave sums at once (the DPP chains of a and b interleave, so the second one is almost free)
+__device__ __forceinline__ void half_sum2(float& a, float& b, int lane) {
+    a = dpp_add<0xB1>(a);  b = dpp_add<0xB1>(b);
+    a = dpp_add<0x4E>(a);  b = dpp_add<0x4E>(b);
+    a = dpp_add<0x141>(a); b = dpp_add<0x141>(b);
+    a = dpp_add<0x140>(a); b = dpp_add<0x140>(b);
+    const int ia = __builtin_bit_cast(int, a), ib = __builtin_bit_cast(int, b);
+    const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ia, 0)), a1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ia, 16));
+    const float a2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ia, 32)), a3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ia, 48));
+    const float b0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ib, 0)), b1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ib, 16));
+    const float b2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ib, 32)), b3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ib, 48));
+    a = lane < 32 ? a0 + a1 : a2 + a3;
+    b = lane < 32 ? b0 + b1 : b2 + b3;
+}
 
 // Epilogue of one op for one trajectory region `tl`.  Thread -> (group g = tid / 32, float4 item li + 32 k): 4 consecutive
 // channels c..c+3 of position pos0 + k * pstep.  NK = items per lane (compile-time so the values stay in registers).
+// GroupNorm statistics in ONE cross-lane round: sums of (x - s) and (x - s)^2 with s = the group's first element (no E[x^2] -
+// E[x]^2 cancellation; the second dependent reduction of a two-pass scheme is ~150 cycles of pure latency per op).
 template <int NK>
-__device__ __forceinline__ void epilogue(float* __restrict__ tl, const EpiParams& P, int flags, int c, int pos0, int pstep,
-                                         int li, int nv, int l_out, int c_out, int sstride, int stage, int ksplit, int dst,
-                                         int dstride, int res, int rstride, float inv_cnt, int lane) {
+__device__ __forceinline__ void epilogue(float* __restrict__ tl, const EpiParams& P, const EpiDesc& e, int stage, int c, int pos0,
+                                         int pstep, int li, int nv, int lane) {
     f32x4 v[NK];
     bool ok[NK];
 #pragma unroll
@@ -288,21 +338,26 @@ __device__ __forceinline__ void epilogue(float* __restrict__ tl, const EpiParams
         ok[k] = li + 32 * k < nv;
         const int pos = ok[k] ? pos0 + k * pstep : 0;
         f32x4 acc = P.bi;
-        for (int ks = 0; ks < ksplit; ++ks) acc += *reinterpret_cast<const f32x4*>(tl + stage + (ks * l_out + pos) * sstride + c);
+        for (int ks = 0; ks < e.ksplit; ++ks)
+            acc += *reinterpret_cast<const f32x4*>(tl + stage + (ks * e.l_out + pos) * e.sstride + c);
         v[k] = acc;
     }
-    if (flags & CDX2_F2_GN) {
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < NK; ++k) s += ok[k] ? (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]) : 0.f;
-        const float mean = half_sum(s, lane) * inv_cnt;
-        float s2 = 0.f;
+    if (e.flags & CDX2_F2_GN) {
+        const int i0 = __builtin_bit_cast(int, v[0][0]);
+        const float f0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i0, 0));
+        const float f1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i0, 32));
+        const float sh = lane < 32 ? f0 : f1;                  // first element of this half-wave's group
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
-            const f32x4 d = v[k] - mean;
-            s2 += ok[k] ? (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]) : 0.f;
+            const f32x4 dl = v[k] - sh;
+            s1 += ok[k] ? (dl[0] + dl[1]) + (dl[2] + dl[3]) : 0.f;
+            s2 += ok[k] ? (dl[0] * dl[0] + dl[1] * dl[1]) + (dl[2] * dl[2] + dl[3] * dl[3]) : 0.f;
         }
-        const float rstd = __builtin_amdgcn_rsqf(half_sum(s2, lane) * inv_cnt + CDX_GN_EPS);
+        half_sum2(s1, s2, lane);
+        const float m1 = s1 * e.inv_cnt;
+        const float mean = sh + m1;
+        const float rstd = __builtin_amdgcn_rsqf(s2 * e.inv_cnt - m1 * m1 + CDX_GN_EPS);
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             const f32x4 y = (v[k] - mean) * rstd * P.ga + P.be;
@@ -314,101 +369,89 @@ __device__ __forceinline__ void epilogue(float* __restrict__ tl, const EpiParams
         if (!ok[k]) continue;
         const int pos = pos0 + k * pstep;
         f32x4 y = v[k];
-        if (flags & CDX2_F2_EMB) y += P.em;
-        if (flags & CDX2_F2_RES) y += *reinterpret_cast<const f32x4*>(tl + res + pos * rstride + c);
-        float* o = tl + dst + pos * dstride + c;
-        if (c + 3 < c_out) {
+        if (e.flags & CDX2_F2_EMB) y += P.em;
+        if (e.flags & CDX2_F2_RES) y += *reinterpret_cast<const f32x4*>(tl + e.res + (pos + CDX2_HALO2) * e.rstride + c);
+        float* o = tl + e.dst + (pos + CDX2_HALO2) * e.dstride + c;
+        if (c + 3 < e.c_out) {
             *reinterpret_cast<f32x4*>(o) = y;
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (c + j < c_out) o[j] = y[j];
+                if (c + j < e.c_out) o[j] = y[j];
         }
     }
 }
 
-
-// Issue the first PF records of this wave's first item of op `d` (descriptor pointer, wave-uniform).
-__device__ __forceinline__ void prefetch_op(const cint* d, const cint* ops, const float* __restrict__ wblob,
-                                            int lane, int wave, Ring& ring) {
-    if (wave < d[CDX2_W2_NITEMS]) {
-        const cint* it = ops + d[CDX2_W2_ITEMS] + wave * CDX2_ITEM_WORDS;
-        const int nq = it[CDX2_I2_NQ];
-        const f32x4* wp = reinterpret_cast<const f32x4*>(wblob + it[CDX2_I2_WOFF]) + lane;
+// Issue the first PF records of item `it` (this wave's first item of the next op) into the ring.  No clamp to the item's
+// record count: the blob ends with PF records of padding, slots past `nq` are simply never consumed.
+__device__ __forceinline__ void prefetch_ring(const Item& it, const float* __restrict__ wblob, int lane, Ring& ring) {
+    const f32x4* wp = reinterpret_cast<const f32x4*>(wblob + it.woff) + lane;
 #pragma unroll
-        for (int u = 0; u < RS; ++u)
-#pragma unroll
-            for (int h = 0; h < SUB; ++h) ring.rec[u][h] = wp[(size_t)min(u * SUB + h, nq - 1) * 64];
-    }
+    for (int u = 0; u < PF; ++u) ring.rec[u] = wp[(size_t)u * 64];
 }
 
+// One op.  `vd`: this op's descriptor (one word per lane), `it`: this wave's first item, both fetched during the previous op;
+// `vdn`: the next op's descriptor, whose load was issued before this call.  Leaves the next op's first item in `it`.
 template <int T>
-__device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* ops, const cint* d, const cint* dn,
-                                       const float* __restrict__ emb_row, float* __restrict__ lds, int tid, Ring& pre,
+__device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* ops, int vd, int vdn, Item& it,
+                                       const float* __restrict__ emb_row, float* __restrict__ lds, int tid, Ring& ring,
                                        unsigned long long* prof) {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tf = L.traj_floats;
-    const int flags = d[CDX2_W2_FLAGS], c_out = d[CDX2_W2_COUT], l_out = d[CDX2_W2_LOUT], coutp = d[CDX2_W2_COUTP];
-    Geom g;
-    g.l_out = l_out; g.l_in = d[CDX2_W2_LIN]; g.cstride = d[CDX2_W2_CSTRIDE]; g.transposed = d[CDX2_W2_TRANSPOSED];
-    g.zrow = L.zrow_off;
-    g.segs = d + CDX2_W2_SEG0;
-    g.sstride = d[CDX2_W2_SSTRIDE]; g.stage = L.stage_off;
+    const int flags = CDX2_DW(vd, CDX2_W2_FLAGS), coutp = CDX2_DW(vd, CDX2_W2_COUTP), shift = CDX2_DW(vd, CDX2_W2_CG4_SHIFT);
+    const int l_out = CDX2_DW(vd, CDX2_W2_LOUT), sstride = CDX2_DW(vd, CDX2_W2_SSTRIDE);
+    const Geom g{CDX2_DW(vd, CDX2_W2_LCOLS), CDX2_DW(vd, CDX2_W2_CSTRIDE), CDX2_DW(vd, CDX2_W2_OSTRIDE), sstride, L.stage_off};
 
     // epilogue geometry + per-channel parameters: issued now, consumed after the barrier (latency hides behind the K loop)
-    const int shift = d[CDX2_W2_CG4_SHIFT];
     const int grp = tid >> 5, li = tid & 31;
     const int c = grp * (coutp >> 3) + 4 * (li & ((1 << shift) - 1));
     const int pos0 = li >> shift, pstep = 32 >> shift;
     const int nv = (coutp >> 5) * l_out;
     EpiParams P;
-    P.bi = *reinterpret_cast<const f32x4*>(L.wblob + d[CDX2_W2_BOFF] + c);
+    P.bi = *reinterpret_cast<const f32x4*>(L.wblob + CDX2_DW(vd, CDX2_W2_BOFF) + c);
     P.ga = P.be = P.em = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (flags & CDX2_F2_GN) {
-        P.ga = *reinterpret_cast<const f32x4*>(L.wblob + d[CDX2_W2_GAMMA] + c);
-        P.be = *reinterpret_cast<const f32x4*>(L.wblob + d[CDX2_W2_BETA] + c);
+        P.ga = *reinterpret_cast<const f32x4*>(L.wblob + CDX2_DW(vd, CDX2_W2_GAMMA) + c);
+        P.be = *reinterpret_cast<const f32x4*>(L.wblob + CDX2_DW(vd, CDX2_W2_BETA) + c);
     }
-    if (flags & CDX2_F2_EMB) P.em = *reinterpret_cast<const f32x4*>(emb_row + d[CDX2_W2_EMB] + c);
+    if (flags & CDX2_F2_EMB) P.em = *reinterpret_cast<const f32x4*>(emb_row + CDX2_DW(vd, CDX2_W2_EMB) + c);
 
     // K loop -> staged partial tiles
-    const cint* items = ops + d[CDX2_W2_ITEMS];
-    const int n_items = d[CDX2_W2_NITEMS];
-    if (d[CDX2_W2_MODE] == CDX_MODE_4X4) {
-        if (d[CDX2_W2_NT] == 1) conv_kloop<M4, 1, T>(g, L.wblob, items, n_items, lds, tf, lane, wave, pre, prof);
-        else conv_kloop<M4, 2, T>(g, L.wblob, items, n_items, lds, tf, lane, wave, pre, prof);
+    const int n_items = CDX2_DW(vd, CDX2_W2_NITEMS);
+    if (CDX2_DW(vd, CDX2_W2_MODE) == CDX_MODE_4X4) {
+        if (CDX2_DW(vd, CDX2_W2_NT) == 1) conv_kloop<M4, 1, T>(g, L.wblob, vd, ops, it, n_items, lds, tf, lane, wave, ring, prof);
+        else conv_kloop<M4, 2, T>(g, L.wblob, vd, ops, it, n_items, lds, tf, lane, wave, ring, prof);
     } else {
-        conv_kloop<M16, 1, T>(g, L.wblob, items, n_items, lds, tf, lane, wave, pre, prof);
+        conv_kloop<M16, 1, T>(g, L.wblob, vd, ops, it, n_items, lds, tf, lane, wave, ring, prof);
     }
-    // head of the next op's weight stream: flies through the barrier and the epilogue
     stamp(prof ? prof + 7 : nullptr, tid);
-    prefetch_op(dn, ops, L.wblob, lane, wave, pre);
+    // head of the next op's weight stream: flies through the barrier and the epilogue
+    it = inline_item(vdn, wave);
+    if (wave < CDX2_DW(vdn, CDX2_W2_NITEMS)) prefetch_ring(it, L.wblob, lane, ring);
     stamp(prof ? prof + 1 : nullptr, tid);
     __syncthreads();
     stamp(prof ? prof + 2 : nullptr, tid);
 
-    const int ksplit = d[CDX2_W2_KSPLIT];
-    const int dst = d[CDX2_W2_DST], dstride = d[CDX2_W2_DST_STRIDE], res = d[CDX2_W2_RES], rstride = d[CDX2_W2_RES_STRIDE];
-    const float inv_cnt = __int_as_float(d[CDX2_W2_INV_CNT]);
-    const int nk = d[CDX2_W2_NK];
+    const EpiDesc e = decode_epi(vd);
 #pragma unroll 1
     for (int t = 0; t < T; ++t) {
         float* tl = lds + t * tf;
-        if (nk == 1)
-            epilogue<1>(tl, P, flags, c, pos0, pstep, li, nv, l_out, c_out, g.sstride, g.stage, ksplit, dst, dstride, res, rstride,
-                        inv_cnt, lane);
-        else if (nk == 2)
-            epilogue<2>(tl, P, flags, c, pos0, pstep, li, nv, l_out, c_out, g.sstride, g.stage, ksplit, dst, dstride, res, rstride,
-                        inv_cnt, lane);
-        else
-            epilogue<CDX2_MAX_NK2>(tl, P, flags, c, pos0, pstep, li, nv, l_out, c_out, g.sstride, g.stage, ksplit, dst, dstride, res,
-                                   rstride, inv_cnt, lane);
+        if (e.nk == 1) epilogue<1>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane);
+        else if (e.nk == 2) epilogue<2>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane);
+        else epilogue<CDX2_MAX_NK2>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane);
+        // wave w rewrites halo row w of the destination (the arena hands this LDS to slots of other shapes in between)
+        const int hrow = wave < CDX2_HALO2 ? wave : e.l_out + wave;
+        for (int j = lane * 4; j < e.dstride; j += 256)
+            *reinterpret_cast<f32x4*>(tl + e.dst + hrow * e.dstride + j) = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();
     stamp(prof ? prof + 3 : nullptr, tid);
 }
 
+// T = 1: two workgroups per CU must be able to co-reside (that is what hides this latency-bound kernel's stalls from B = 512
+// on), i.e. at most 256 VGPR + AGPR per lane -- the second launch-bound argument is waves per SIMD.
 template <int T>
-__global__ __launch_bounds__(THREADS) void cdx_unet2_kernel(const cdx_unet2_launch L) {
+__global__ __launch_bounds__(THREADS, (T == 1 ? 2 : 1)) void cdx_unet2_kernel(const cdx_unet2_launch L) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -418,12 +461,14 @@ __global__ __launch_bounds__(THREADS) void cdx_unet2_kernel(const cdx_unet2_laun
     const bool profiling = L.prof != nullptr && blockIdx.x == 0;
     if (profiling) stamp(lprof + (size_t)L.n_ops * 8, tid);
 
-    // weight stream of op 0 first: it flies while the state is set up
+    // descriptor + first item + weight stream of op 0 first: they fly while the state is set up
     const cint* ops = as_const(L.ops);
-    Ring pre;
-    prefetch_op(ops, ops, L.wblob, lane, wave, pre);
+    int vd = L.ops[lane];
+    Item it = inline_item(vd, wave);
+    Ring ring;
+    if (wave < CDX2_DW(vd, CDX2_W2_NITEMS)) prefetch_ring(it, L.wblob, lane, ring);
 
-    // ---- clear the workgroup's LDS once (zero rows, pad channels of the state slots), then load x_T ----
+    // ---- clear the workgroup's LDS once (halo rows and pad channels of the state slots), then load x_T ----
     for (int i = tid * 4; i < T * tf; i += THREADS * 4)
         *reinterpret_cast<f32x4*>(lds + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads();
@@ -441,14 +486,14 @@ __global__ __launch_bounds__(THREADS) void cdx_unet2_kernel(const cdx_unet2_laun
     const int n_iter = L.n_steps > 0 ? L.n_steps : 1;
     for (int step = 0; step < n_iter; ++step) {
         const float* __restrict__ emb_row = L.emb + (size_t)step * L.emb_ld;
-        const cint* d = ops;
         for (int oi = 0; oi < L.n_ops; ++oi) {
-            const cint* dn = (oi + 1 < L.n_ops) ? d + CDX2_OP_WORDS : ops;     // last op prefetches op 0 of the next step
+            // next op's descriptor (the last op fetches op 0 of the next step): one coalesced load, needed after the K loop
+            const int vdn = L.ops[(oi + 1 < L.n_ops ? oi + 1 : 0) * CDX2_OP_WORDS + lane];
             // (profile the SECOND forward when there is one: instruction / scalar caches warm, like every later step)
             unsigned long long* pslot = (profiling && step == (L.n_steps > 1 ? 1 : 0)) ? lprof + (size_t)oi * 8 : nullptr;
             stamp(pslot, tid);
-            run_op<T>(L, ops, d, dn, emb_row, lds, tid, pre, pslot);
-            d = dn;
+            run_op<T>(L, ops, vd, vdn, it, emb_row, lds, tid, ring, pslot);
+            vd = vdn;
         }
         if (L.n_steps == 0) break;
         // ---- clip, eps/x0 conversion, solver update, fix-mask blend on the LDS-resident state (kinds 0-4) ----
@@ -588,7 +633,7 @@ int cdx_unet2_run(const cdx_unet2_launch* L, void* hip_stream) {
     if (L->n_steps > 0 && !L->steps) { cdx_set_err("steps == NULL with n_steps > 0"); return CDX_EINVAL; }
     if (L->n_steps < 0) { cdx_set_err("negative n_steps"); return CDX_EINVAL; }
     if (L->fix_mask && !L->prior) { cdx_set_err("fix_mask given without prior"); return CDX_EINVAL; }
-    if ((L->traj_floats | L->zrow_off | L->x_off | L->x_stride | L->pred_off | L->pred_stride | L->prev_off | L->stage_off | L->emb_ld) & 3) {
+    if ((L->traj_floats | L->x_off | L->x_stride | L->pred_off | L->pred_stride | L->prev_off | L->stage_off | L->emb_ld) & 3) {
         cdx_set_err("LDS offsets/strides and emb_ld must be multiples of 4 floats"); return CDX_EINVAL;
     }
     size_t lds_bytes = (size_t)L->traj_floats * L->traj_per_wg * sizeof(float);

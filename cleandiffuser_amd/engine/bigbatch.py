@@ -451,6 +451,10 @@ def is_chiunet_gemm(module, batch: int, horizon: Optional[int] = None, edm: bool
     from ..nn_diffusion.chiunet import ChiUNet1d
     from ..nn_diffusion.jannerunet import JannerUNet1d
     if type(module) is JannerUNet1d:
+        if horizon is not None and not edm:
+            from . import runtime2           # the second-generation program kernel keeps its lead at every batch size (two
+            if batch >= runtime2.min_batch() and runtime2.supported(module, horizon) is None:   # co-resident workgroups per CU)
+                return False
         big = batch >= JANNER_GEMM_MIN_BATCH
     elif type(module) is ChiUNet1d and module.obs_as_global_cond:
         big = batch >= UNET_GEMM_MIN_BATCH

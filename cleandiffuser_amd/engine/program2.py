@@ -1,48 +1,58 @@
 """Network -> device program for the second-generation fused U-Net kernel (``csrc/cdx_unet2.hip``).
 
 Same idea as ``program.py`` (one launch = the whole ``sample()`` loop, activations resident in LDS, weights streamed as
-1-KiB MFMA records) with the per-op fixed cost engineered out -- what the round-1 profile showed the north-star kernel was
-spending 60 % of its time on:
+1-KiB MFMA records).  The format is shaped by what the round-2 profiles showed: with one workgroup per CU the kernel is bound by
+per-op latency and by *instruction issue* (a wave64 issues about one instruction every four clocks), so everything the K loop
+does per weight record beyond "wait, 4 MFMAs, one LDS read, one global load" was designed out on the host side:
 
-* **4 wave64 per workgroup, one per SIMD**; a conv's output is cut into (row tile x column group) *tiles*; when a layer has
-  fewer than four tiles the K range is split over the spare waves.  Work items are 8-word records read with scalar loads.
-* **The 1x1 residual conv of a ResidualBlock** (reference jannerunet.py:58, :69) is a plain op whose epilogue adds into the
-  block's output slot (GroupNorm + Mish sit between the two sums, so they cannot share an accumulator).
+* **4 wave64 per workgroup, one per SIMD**; a conv's output is cut into (row tile x column group) *tiles*, one work item per
+  wave; a layer with fewer than four tiles splits K over the spare waves.  Items are 8-word records; a wave's first item sits
+  INSIDE the op descriptor (words ``W2_ITEM0``...), so it is found at a fixed offset without a dependent load.
+* **A work item reads ONE source slot with a row that is LINEAR in the tap.**  Slots carry a ``HALO2``-row zero halo, so zero
+  padding needs no predicate and a tap change is one per-lane add.  A channel concat (reference jannerunet.py:193
+  ``torch.cat([x, skip])``) is never materialised and never switched inside the loop: the K slices of such a layer are cut
+  at the boundary between the two sources (the layers that concatenate have at most two tiles, so K is split anyway) and the
+  item record names its source.  ``ConvTranspose1d(4, 2, 1)`` is lowered to two 2-tap convs, one per output parity (even
+  outputs use taps 3,1 on rows m-1,m; odd outputs taps 2,0 on rows m,m+1), each with its own record stream -- no half-empty
+  MFMAs and no parity test in the loop.
+* **The 1x1 skip conv of a ResidualBlock** (jannerunet.py:58, :69) is a plain op whose epilogue adds into the block's output.
 * **The per-block FiLM vectors** ``Linear(Mish(map_emb(temb)))`` depend only on the step, not on the trajectory: they are
   evaluated once per (weights version, schedule) into a ``(steps, n_emb)`` table by ``cdx_unet2_embtab`` and read as
   per-channel float4 epilogue parameters; the embedding MLP ops disappear from the per-forward program.
-* **Epilogue**: staged partial tiles -> 32 lanes per GroupNorm group, float4 of consecutive channels per lane, two-pass
-  statistics in registers, Mish, + FiLM vector, + residual slot, float4 store.
-* **T trajectories per workgroup** (1 or 2): every weight record feeds T x the MFMAs; each trajectory owns an identical
-  LDS region (``traj_floats`` apart), so all offsets below are relative to the trajectory base.
+* **Epilogue**: staged partial tiles -> 32 lanes per GroupNorm group, float4 of consecutive channels per lane, single-pass
+  shifted statistics in registers, Mish, + FiLM vector, + residual, float4 store; the producing op also rewrites the four
+  halo rows of its destination (the arena recycles LDS between slots of different shapes).
+* **T trajectories per workgroup** (1 or 2): each trajectory owns an identical LDS region (``traj_floats`` apart), so all
+  offsets below are relative to the trajectory base.
 
 Descriptor words ``W2_*`` / item words ``I2_*`` MUST mirror ``csrc/cdx_ops2.h`` (tests/test_abi_contract.py checks).
-Activations: channel-last rows ``slot[pos * stride + c]``, ``stride = pad16(C) + 4`` (as program.py); out-of-range conv
-taps read the trajectory's all-zero row.  Conv records: identical lane layouts to program.py (MODE_16X16 / MODE_4X4).
+Activations: channel-last rows ``slot[(pos + HALO2) * stride + c]``, ``stride = pad16(C) + 4``.  Conv records: identical lane
+layouts to program.py (MODE_16X16 / MODE_4X4).
 """
 from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 import torch
 import torch.nn as nn
 
-from .program import (Act, GN_EPS, MODE_16X16, MODE_4X4, _conv1d_eff, _convT1d_eff, _fbits, pad16, supports_janner)
+from .program import (GN_EPS, MODE_16X16, MODE_4X4, _conv1d_eff, _convT1d_eff, _fbits, slot_stride, supports_janner)
 
-OP2_WORDS = 48
+OP2_WORDS = 64                # 29 descriptor words (padded to 32) + NW2 inline work items
 ITEM2_WORDS = 8
 NW2 = 4                       # waves per workgroup
 RING2 = 16                    # weight records in flight per wave
 GROUPS2 = 8                   # GroupNorm groups the epilogue partition is built for (32 lanes per group)
 MAX_NK2 = 4                   # float4 items a lane may own in the epilogue
+HALO2 = 2                     # zero rows on either side of a slot: covers kernel sizes <= 5 (pad <= 2)
 
-(W2_KIND, W2_FLAGS, W2_COUT, W2_LOUT, W2_LIN, W2_CSTRIDE, W2_TRANSPOSED, W2_MODE, W2_NT, W2_NITEMS, W2_ITEMS,
- W2_NSEG) = range(12)
-W2_SEG0, SEG2_WORDS = 12, 5   # 2 K segments (the sources of a channel concat) x (SRC, STRIDE, CCN, TAPS, PAD)
-S2_SRC, S2_STRIDE, S2_CCN, S2_TAPS, S2_PAD = range(5)
-(W2_DST, W2_DST_STRIDE, W2_SSTRIDE, W2_KSPLIT, W2_BOFF, W2_GAMMA, W2_BETA, W2_EMB, W2_RES, W2_RES_STRIDE, W2_CG4_SHIFT,
- W2_INV_CNT, W2_NK, W2_COUTP) = range(22, 36)
-I2_WOFF, I2_NQ, I2_SEG, I2_TAP, I2_CC, I2_PART, I2_COL0, I2_SPARE = range(8)
+(W2_KIND, W2_FLAGS, W2_COUT, W2_LOUT, W2_LCOLS, W2_CSTRIDE, W2_OSTRIDE, W2_MODE, W2_NT, W2_NITEMS, W2_ITEMS, W2_DST,
+ W2_DST_STRIDE, W2_SSTRIDE, W2_KSPLIT, W2_BOFF, W2_GAMMA, W2_BETA, W2_EMB, W2_RES, W2_RES_STRIDE, W2_CG4_SHIFT, W2_INV_CNT,
+ W2_NK, W2_COUTP) = range(25)
+W2_ITEM0 = 32                 # items 0..NW2-1 inline; items NW2.. in the tail table at W2_ITEMS
+# item record: blob offset of the first record, record count, start cursor (tap | chunk << 8), stage offset of the partial tile,
+# first column, (pad | output-position offset << 8), source slot (float offset | row stride << 16), chunks per tap
+I2_WOFF, I2_NQ, I2_TAPCC, I2_PART, I2_COL0, I2_PADOOFF, I2_SRCSTR, I2_CCN = range(8)
 
 F2_GN, F2_EMB, F2_RES, F2_PRED = 1, 2, 4, 8
 
@@ -52,13 +62,34 @@ def pad32(c: int) -> int:
 
 
 @dataclass
+class Act:
+    """An LDS slot of (L + 2 HALO2) channel-last rows of C channels."""
+    length: int
+    chans: int
+    uid: int
+    off: int = -1                     # float offset of the slot (its first halo row) inside the trajectory region
+    persistent: bool = False
+
+    @property
+    def stride(self):
+        return slot_stride(self.chans)
+
+    @property
+    def floats(self):
+        return (self.length + 2 * HALO2) * self.stride
+
+    @property
+    def data_off(self):               # float offset of position 0
+        return self.off + HALO2 * self.stride
+
+
+@dataclass
 class Program2:
     ops: np.ndarray                    # int32 [n_ops, OP2_WORDS]
     ops_buffer: np.ndarray             # int32 1-D: ops followed by the item tables
     blob: torch.Tensor                 # float32 1-D on the module's device
     traj_floats: int                   # LDS floats per trajectory
-    zrow_off: int
-    x_off: int
+    x_off: int                         # position 0 of the state slot (halo rows lie before it)
     x_stride: int
     pred_off: int
     pred_stride: int
@@ -77,35 +108,29 @@ class Program2:
         return 4 * self.traj_floats * traj_per_wg
 
 
-def _records(w_eff: torch.Tensor, split: Sequence[int], mode: int) -> Tuple[torch.Tensor, List[int]]:
-    """w_eff [C_out][taps][C_in_total] -> records [n_row_tiles][taps*sum(cc)][64][4] (+ chunks per tap per source).
+def _records(w_eff: torch.Tensor, mode: int) -> Tuple[torch.Tensor, int]:
+    """w_eff [C_out][taps][C_in] -> records [n_row_tiles][taps * cc][64][4] and cc = chunks per tap.
     Lane layouts as program.py:pack_conv: MODE_16X16 lane = k4*16 + row, 16 K per record; MODE_4X4 lane = row, 4 K."""
-    c_out, taps, c_in = w_eff.shape
-    assert sum(split) == c_in
+    c_out, taps, cs = w_eff.shape
     rows, kch = (16, 16) if mode == MODE_16X16 else (64, 4)
     n_ct = -(-c_out // rows)
-    parts, per_src, lo = [], [], 0
-    for cs in split:
-        w = w_eff[:, :, lo:lo + cs]
-        lo += cs
-        csp = -(-cs // kch) * kch
-        wp = torch.zeros(n_ct * rows, taps, csp, device=w.device, dtype=torch.float32)
-        wp[:c_out, :, :cs] = w
-        cc = csp // kch
-        if mode == MODE_16X16:
-            wp = wp.reshape(n_ct, 16, taps, cc, 4, 4).permute(0, 2, 3, 4, 1, 5)
-        else:
-            wp = wp.reshape(n_ct, 64, taps, cc, 4).permute(0, 2, 3, 1, 4)
-        parts.append(wp.reshape(n_ct, taps * cc, 64, 4))
-        per_src.append(cc)
-    return torch.cat(parts, dim=1).contiguous(), per_src
+    csp = -(-cs // kch) * kch
+    wp = torch.zeros(n_ct * rows, taps, csp, device=w_eff.device, dtype=torch.float32)
+    wp[:c_out, :, :cs] = w_eff
+    cc = csp // kch
+    if mode == MODE_16X16:
+        wp = wp.reshape(n_ct, 16, taps, cc, 4, 4).permute(0, 2, 3, 4, 1, 5)
+    else:
+        wp = wp.reshape(n_ct, 64, taps, cc, 4).permute(0, 2, 3, 1, 4)
+    return wp.reshape(n_ct, taps * cc, 64, 4).contiguous(), cc
 
 
 class _Builder2:
     def __init__(self, device):
         self.device = device
         self.ops: List[List[int]] = []
-        self.op_acts: List[Tuple[List[Act], Optional[Act]]] = []
+        self.op_acts: List[Tuple[List[Act], Act]] = []     # (slots read: sources [+ residual], slot written) per op
+        self.op_item_src: List[List[int]] = []            # per op, per item: index of the source slot it reads
         self.op_items: List[list] = []
         self.chunks: List[torch.Tensor] = []
         self.blob_len = 0
@@ -135,51 +160,69 @@ class _Builder2:
         self.n_emb += pad32(c_out)
         return off
 
-    def conv(self, srcs: Sequence[Act], dst: Act, w_eff: torch.Tensor, bias: torch.Tensor, *, stride=1, pad=0,
-             transposed=False, gn: Optional[nn.Module] = None, emb_off: int = -1, res: Optional[Act] = None,
-             pred: bool = False):
-        """One fused op: conv -> [GroupNorm -> Mish] -> [+ emb] -> [+ residual slot `res` (may be `dst` itself: accumulate)] -> dst."""
-        c_out, taps, _ = w_eff.shape
+    def conv(self, srcs: List[Act], dst: Act, w_eff: torch.Tensor, bias: torch.Tensor, *, stride=1, pad=0, transposed=False,
+             gn: Optional[nn.Module] = None, emb_off: int = -1, res: Optional[Act] = None, pred: bool = False):
+        """One fused op: conv over the channel concat of `srcs` -> [GroupNorm -> Mish] -> [+ emb] -> [+ residual slot `res` (may be
+        `dst`: accumulate)] -> dst.  `transposed`: ConvTranspose1d(k=4, stride=2, pad=1) as two 2-tap convs, one per output parity."""
+        c_out, taps, c_in = w_eff.shape
         l_out = dst.length
-        assert not transposed or stride == 2
-        assert 1 <= len(srcs) <= 2, "at most 2 K segments per op"
-        mode = MODE_4X4 if (l_out <= 8 and c_out % 64 == 0 and self.allow_4x4) else MODE_16X16
+        assert c_in == sum(a.chans for a in srcs) and dst.chans == c_out and 1 <= len(srcs) <= 2
+        if transposed:
+            if (taps, stride, pad) != (4, 2, 1) or l_out != 2 * srcs[0].length or len(srcs) != 1:
+                raise ValueError("v2 lowers ConvTranspose1d(4, 2, 1) of one source only")
+            # (taps in row order, item pad, output offset): even outputs n = 2m read rows m-1, m with taps 3, 1; odd n = 2m+1 rows m, m+1 with 2, 0
+            phases = [(w_eff[:, [3, 1], :], 1, 0), (w_eff[:, [2, 0], :], 0, 1)]
+            l_cols, cstride, ostride = srcs[0].length, 1, 2
+        else:
+            if pad > HALO2 or (taps - 1 - pad) > HALO2:
+                raise ValueError(f"kernel size {taps} needs more than {HALO2} halo rows")
+            phases = [(w_eff, pad, 0)]
+            l_cols, cstride, ostride = l_out, stride, 1
+        mode = MODE_4X4 if (l_cols <= 8 and c_out % 64 == 0 and self.allow_4x4) else MODE_16X16
         rows, cols = (16, 16) if mode == MODE_16X16 else (64, 4)
-        nt = 2 if (mode == MODE_4X4 and l_out > 4) else 1
+        nt = 2 if (mode == MODE_4X4 and l_cols > 4) else 1
         n_rt = -(-c_out // rows)
-        n_cg = -(-l_out // (nt * cols))
-        tiles = n_rt * n_cg
-        recs, per_src = _records(w_eff, [s.chans for s in srcs], mode)
-        nqt = recs.shape[1]
-        woff = self.add(recs)
-        ksplit = max(1, min(NW2 // tiles, nqt)) if tiles < NW2 else 1
+        n_cg = -(-l_cols // (nt * cols))
+        tiles = n_rt * n_cg * len(phases)
         coutp = pad32(c_out)
         sstride = coutp + 4
-        seg_len = [cc * taps for cc in per_src]
+        # record stream of a row tile: [source 0: taps x chunks | source 1: taps x chunks]; a K slice never straddles the sources
+        streams = []
+        for w, _, _ in phases:
+            segs, lo = [], 0
+            for a in srcs:
+                segs.append(_records(w[:, :, lo:lo + a.chans], mode))
+                lo += a.chans
+            streams.append(segs)
+        seg_n = [r.shape[1] for r, _ in streams[0]]
+        nqt = sum(seg_n)
+        ksplit = max(1, min(NW2 // tiles, nqt)) if tiles < NW2 else 1
+        if len(srcs) == 2 and (ksplit % 2 or seg_n[0] != seg_n[1]):
+            raise ValueError("v2 needs the two sources of a concat to be equal halves of an evenly split K range")
+        woffs = [self.add(torch.cat([r for r, _ in segs], dim=1).contiguous()) for segs in streams]
+        # K-slice boundaries: even cuts.  (The kernel's immediate-offset steady loop needs a slice to start on a multiple of RING2
+        # chunks inside a tap that spans a multiple of RING2 chunks; the wide 4x4 layers -- C_in >= 64, K a multiple of 64 per
+        # slice -- have that by themselves, and the kernel checks it per item.)
 
-        def cursor(q):
-            for si, n in enumerate(seg_len):
-                if q < n:
-                    return si, q // per_src[si], q % per_src[si]
-                q -= n
-            raise AssertionError("slice starts past the stream")
+        def cut(ks):
+            return ks * nqt // ksplit
 
-        items = []
+        items, item_src = [], []
         for item in range(tiles * ksplit):
             tile, ks = item % tiles, item // tiles
+            ph, tile = tile % len(phases), tile // len(phases)
             rt, cgi = tile % n_rt, tile // n_rt
-            q0, q1 = ks * nqt // ksplit, (ks + 1) * nqt // ksplit
-            si, tap, cc = cursor(q0)
-            items.append([woff + (rt * nqt + q0) * 256, q1 - q0, si, tap, cc, ks * l_out * sstride + rt * rows,
-                          cgi * nt * cols, 0])
-        words = {W2_KIND: 0, W2_COUT: c_out, W2_LOUT: l_out, W2_LIN: srcs[0].length, W2_CSTRIDE: stride,
-                 W2_TRANSPOSED: int(transposed), W2_MODE: mode, W2_NT: nt, W2_NITEMS: len(items), W2_NSEG: len(srcs),
-                 W2_DST_STRIDE: dst.stride, W2_SSTRIDE: sstride, W2_KSPLIT: ksplit,
-                 W2_BOFF: self.add(_padded(bias, coutp)), W2_COUTP: coutp}
-        for si, (s, cc) in enumerate(zip(srcs, per_src)):
-            assert s.length == srcs[0].length
-            base = W2_SEG0 + si * SEG2_WORDS
-            words[base + S2_STRIDE], words[base + S2_CCN], words[base + S2_TAPS], words[base + S2_PAD] = s.stride, cc, taps, pad
+            q0, q1 = cut(ks), cut(ks + 1)
+            si = 0 if q1 <= seg_n[0] else 1
+            base = 0 if si == 0 else seg_n[0]
+            assert base <= q0 and q1 <= base + seg_n[si]
+            ccn = streams[ph][si][1]
+            items.append([woffs[ph] + (rt * nqt + q0) * 256, q1 - q0, ((q0 - base) // ccn) | (((q0 - base) % ccn) << 8),
+                          ks * l_out * sstride + rt * rows, cgi * nt * cols, phases[ph][1] | (phases[ph][2] << 8), 0, ccn])
+            item_src.append(si)
+        words = {W2_KIND: 0, W2_COUT: c_out, W2_LOUT: l_out, W2_LCOLS: l_cols, W2_CSTRIDE: cstride, W2_OSTRIDE: ostride,
+                 W2_MODE: mode, W2_NT: nt, W2_NITEMS: len(items), W2_DST_STRIDE: dst.stride, W2_SSTRIDE: sstride,
+                 W2_KSPLIT: ksplit, W2_BOFF: self.add(_padded(bias, coutp)), W2_COUTP: coutp}
         cg = coutp // GROUPS2
         cg4 = cg // 4
         assert cg4 & (cg4 - 1) == 0 and cg4 <= 32, f"C_out {c_out}: channels per group / 4 must be a power of two <= 32"
@@ -210,11 +253,11 @@ class _Builder2:
         for k, v in words.items():
             op[k] = int(v)
         self.ops.append(op)
-        reads = list(srcs) + ([res] if res is not None else [])
-        self.op_acts.append((reads, dst))
+        self.op_acts.append((list(srcs) + ([res] if res is not None else []), dst))
         self.op_items.append(items)
+        self.op_item_src.append(item_src)
         self.stage = max(self.stage, ksplit * l_out * sstride)
-        self.macs += c_out * l_out * taps * sum(s.chans for s in srcs) // (2 if transposed else 1)
+        self.macs += c_out * l_out * taps * c_in // (2 if transposed else 1)
 
     def plan_arena(self, base: int) -> int:
         """First-fit interval allocation over op liveness (same policy as program.py); patches slot offsets into the ops."""
@@ -236,30 +279,27 @@ class _Builder2:
             a.off = pos
             live.append(a)
             top = max(top, pos + a.floats)
-        for op, (reads, writes) in zip(self.ops, self.op_acts):
-            for si in range(op[W2_NSEG]):
-                op[W2_SEG0 + si * SEG2_WORDS + S2_SRC] = reads[si].off
-            op[W2_DST] = writes.off
+        for op, (reads, dst), items, item_src in zip(self.ops, self.op_acts, self.op_items, self.op_item_src):
+            op[W2_DST] = dst.off                                       # slot base = first halo row
             if op[W2_FLAGS] & F2_RES:
-                op[W2_RES] = reads[op[W2_NSEG]].off
+                op[W2_RES] = reads[-1].off
+            for rec, si in zip(items, item_src):
+                assert reads[si].off < (1 << 16) and reads[si].stride < (1 << 15)
+                rec[I2_SRCSTR] = reads[si].off | (reads[si].stride << 16)
         return top
+
+
+def op_item(ops_buffer: np.ndarray, op: np.ndarray, j: int) -> np.ndarray:
+    """Work item `j` of `op` (a row of Program2.ops): inline in the descriptor for j < NW2, else in the tail table."""
+    if j < NW2:
+        return op[W2_ITEM0 + j * ITEM2_WORDS: W2_ITEM0 + (j + 1) * ITEM2_WORDS]
+    lo = int(op[W2_ITEMS]) + (j - NW2) * ITEM2_WORDS
+    return ops_buffer[lo: lo + ITEM2_WORDS]
 
 
 def _padded(v: torch.Tensor, n: int) -> torch.Tensor:
     v = v.detach().to(torch.float32).reshape(-1)
     return torch.cat([v, torch.zeros(n - v.numel(), device=v.device)]) if v.numel() < n else v
-
-
-def supports_janner2(net, horizon: int) -> Optional[str]:
-    """None if the v2 kernel can run this JannerUNet1d at `horizon`, else the reason (the caller falls back to v1)."""
-    why = supports_janner(net)
-    if why is not None:
-        return why
-    try:
-        compile_janner2(net, horizon)
-    except (ValueError, AssertionError) as e:
-        return str(e)
-    return None
 
 
 def compile_janner2(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x4: bool = True) -> Program2:
@@ -275,6 +315,7 @@ def compile_janner2(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x
     blocks = []
 
     def resblock(srcs: List[Act], rb) -> Act:
+        """ResidualBlock (jannerunet.py:51-69) over the channel concat of `srcs`."""
         c_out, length = rb.conv1[0].out_channels, srcs[0].length
         e_off = b.emb_slot(c_out)
         blocks.append((rb, e_off))
@@ -312,7 +353,7 @@ def compile_janner2(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x
     fc = net.final_conv
     t = b.act(horizon, md)
     b.conv([cur], t, _conv1d_eff(fc[0]), fc[0].bias, pad=2, gn=fc[1])
-    pred = b.act(horizon, d, persistent=True)
+    pred = b.act(horizon, d)                 # arena slot: written by the last op, read by the solver step right after it
     b.conv([t], pred, _conv1d_eff(fc[3]), fc[3].bias, pred=True)
 
     # embedding MLP (evaluated by cdx_unet2_embtab, once per schedule): transposed [n_in][n_out] weights
@@ -329,13 +370,9 @@ def compile_janner2(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x
     emb["w3"], emb["b3"] = b.add(w_all.t().contiguous()), b.add(b_all)
     b.macs += net.emb_dim * emb["hidden"] + emb["hidden"] * emb["md"] + emb["md"] * sum(rb.emb_mlp[1].out_features for rb, _ in blocks)
 
-    # ---- LDS plan of one trajectory: [zero row | x | pred | prev | stage | arena] ----
+    # ---- LDS plan of one trajectory: [x | prev | stage | arena] ----
     off = 0
-    sources = [a for reads, _ in b.op_acts for a in reads]
-    zrow_floats = max(pad16(a.chans) for a in sources) + 16
-    zrow_off, off = off, off + zrow_floats
     x.off, off = off, off + x.floats
-    pred.off, off = off, off + pred.floats
     prev_off, off = off, off + (horizon * d + 3) // 4 * 4
     stage_off, off = off, off + (b.stage + 3) // 4 * 4
     top = (b.plan_arena(off) + 3) // 4 * 4
@@ -343,13 +380,16 @@ def compile_janner2(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x
         raise ValueError(f"LDS plan needs {top * 4} B > {max_lds_bytes} B per trajectory")
     tail, cursor = [], len(b.ops) * OP2_WORDS
     for op, items in zip(b.ops, b.op_items):
+        for j, rec in enumerate(items[:NW2]):             # a wave's first item: fixed offset inside the descriptor
+            op[W2_ITEM0 + j * ITEM2_WORDS: W2_ITEM0 + (j + 1) * ITEM2_WORDS] = rec
         op[W2_ITEMS] = cursor
-        tail += [w for rec in items for w in rec]
-        cursor += len(items) * ITEM2_WORDS
+        tail += [w for rec in items[NW2:] for w in rec]
+        cursor += len(items[NW2:]) * ITEM2_WORDS
     ops = np.asarray(b.ops, dtype=np.int32)
     ops_buffer = np.concatenate([ops.reshape(-1), np.asarray(tail, dtype=np.int64).astype(np.int32)])
+    b.add(torch.zeros(RING2 * 256))          # the ring prefetch reads RING2 records from an item's first one, whatever its length
     blob = torch.cat(b.chunks).contiguous()
-    return Program2(ops=ops, ops_buffer=ops_buffer, blob=blob, traj_floats=top, zrow_off=zrow_off, x_off=x.off,
-                    x_stride=x.stride, pred_off=pred.off, pred_stride=pred.stride, prev_off=prev_off, stage_off=stage_off,
+    return Program2(ops=ops, ops_buffer=ops_buffer, blob=blob, traj_floats=top, x_off=x.data_off,
+                    x_stride=x.stride, pred_off=pred.data_off, pred_stride=pred.stride, prev_off=prev_off, stage_off=stage_off,
                     horizon=horizon, dim=d, emb_dim=net.emb_dim, n_emb=b.n_emb, embtab=emb, macs_per_forward=b.macs,
-                    n_conv=len(b.ops), meta={"zrow_floats": zrow_floats, "blob_floats": b.blob_len})
+                    n_conv=len(b.ops), meta={"blob_floats": b.blob_len})

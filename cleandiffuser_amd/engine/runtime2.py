@@ -29,7 +29,7 @@ class CdxUnet2EmbtabArgs(ctypes.Structure):
 class CdxUnet2Launch(ctypes.Structure):
     _fields_ = [("ops", ctypes.c_void_p), ("wblob", ctypes.c_void_p),
                 ("n_ops", ctypes.c_int32), ("traj_floats", ctypes.c_int32), ("traj_per_wg", ctypes.c_int32),
-                ("zrow_off", ctypes.c_int32), ("x_off", ctypes.c_int32), ("x_stride", ctypes.c_int32),
+                ("x_off", ctypes.c_int32), ("x_stride", ctypes.c_int32),
                 ("pred_off", ctypes.c_int32), ("pred_stride", ctypes.c_int32), ("prev_off", ctypes.c_int32),
                 ("stage_off", ctypes.c_int32),
                 ("batch", ctypes.c_int32), ("horizon", ctypes.c_int32), ("dim", ctypes.c_int32),
@@ -119,17 +119,17 @@ def plan_film_table(comp: _Compiled2, module, plan, device) -> torch.Tensor:
 
 
 def min_batch() -> int:
-    """Smallest batch the v2 kernel takes by default.  Measured on MI355X (profiles/r02_*): with one workgroup per CU (B <= 256)
-    a 4-wave workgroup is instruction-issue bound and the 8-wave first kernel is ahead; from two co-resident workgroups per CU
-    on (B >= 512) v2 is ~1.8x faster."""
-    return int(os.environ.get("CDX_UNET2_MIN_BATCH", "384"))
+    """Smallest batch the v2 kernel takes (it is ahead of the first program kernel at every batch size measured on MI355X,
+    profiles/r02_*: 5.6 vs 6.3 ms at B = 256, 7.1 vs 12.5 ms at B = 512); CDX_UNET2_MIN_BATCH is an A/B hook."""
+    return int(os.environ.get("CDX_UNET2_MIN_BATCH", "1"))
 
 
 def traj_per_wg(prog: P2.Program2, batch: int) -> int:
-    """Trajectories per workgroup.  Two co-resident single-trajectory workgroups per CU currently beat one two-trajectory
-    workgroup (measured, B = 512: 6.8 vs 9.4 ms), so T = 2 is opt-in (CDX_UNET2_T=2)."""
+    """Trajectories per workgroup: two as soon as the batch exceeds one workgroup per CU -- every streamed weight record then
+    feeds twice the MFMAs (measured, B = 512: 7.05 ms against 8.0 ms for two co-resident single-trajectory workgroups per
+    CU; B = 1024: 14.0 vs 16.1 ms).  CDX_UNET2_T forces 1 or 2."""
     forced = os.environ.get("CDX_UNET2_T")
-    t = int(forced) if forced in ("1", "2") else 1
+    t = int(forced) if forced in ("1", "2") else (2 if batch > 256 else 1)
     if prog.lds_bytes(t) > 160 * 1024:
         t = 1
     return t
@@ -144,7 +144,7 @@ def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps
     prof = R._prof["buf"]
     L = CdxUnet2Launch(
         ops=comp.ops_dev.data_ptr(), wblob=prog.blob.data_ptr(), n_ops=len(prog.ops), traj_floats=prog.traj_floats,
-        traj_per_wg=t, zrow_off=prog.zrow_off, x_off=prog.x_off, x_stride=prog.x_stride, pred_off=prog.pred_off,
+        traj_per_wg=t, x_off=prog.x_off, x_stride=prog.x_stride, pred_off=prog.pred_off,
         pred_stride=prog.pred_stride, prev_off=prog.prev_off, stage_off=prog.stage_off,
         batch=batch, horizon=prog.horizon, dim=prog.dim, emb=emb.data_ptr(), emb_ld=emb.shape[1],
         steps=R._ptr(steps_dev), n_steps=n_steps, predict_noise=int(predict_noise),

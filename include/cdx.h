@@ -122,7 +122,7 @@ int cdx_unet1d_run(const cdx_unet1d_launch* launch, void* hip_stream);
  * fused into its second conv, and the per-block FiLM vectors Linear(Mish(map_emb(map_noise(t)))) read from a per-step table
  * that cdx_unet2_embtab evaluates once per (weights, schedule).
  * ---------------------------------------------------------------------------------------------- */
-#define CDX2_OP_WORDS 48
+#define CDX2_OP_WORDS 64
 
 /* FiLM table: out[r][:] = W3^T mish(W2^T mish(W0^T temb[r] + b0) + b2) + b3, all weights transposed [n_in][n_out] inside `wblob`
  * at the given float offsets (reference jannerunet.py:135-136 map_emb, :57 emb_mlp of every block, stacked). */
@@ -137,12 +137,12 @@ typedef struct cdx_unet2_embtab_args {
 int cdx_unet2_embtab(const cdx_unet2_embtab_args* args, void* hip_stream);
 
 typedef struct cdx_unet2_launch {
-    const int32_t* ops;        /* device, [n_ops][CDX2_OP_WORDS] followed by the work-item tables */
+    const int32_t* ops;        /* device, [n_ops][CDX2_OP_WORDS] (descriptor + first work items) followed by further work items */
     const float* wblob;        /* device, packed parameters */
     int32_t n_ops;
     int32_t traj_floats;       /* LDS floats of one trajectory's region; the workgroup owns traj_per_wg of them */
     int32_t traj_per_wg;       /* 1 or 2 */
-    int32_t zrow_off, x_off, x_stride, pred_off, pred_stride, prev_off, stage_off;   /* relative to the trajectory region */
+    int32_t x_off, x_stride, pred_off, pred_stride, prev_off, stage_off;   /* relative to the trajectory region; x/pred: position 0 */
     int32_t batch, horizon, dim;
     const float* emb;          /* device (max(n_steps,1), emb_ld): FiLM table rows, one per step record */
     int32_t emb_ld;

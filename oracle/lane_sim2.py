@@ -44,16 +44,17 @@ class LaneSim2:
         self.blob = prog.blob.detach().cpu().numpy()
         self.buf = prog.ops_buffer
         self.lds = np.full(prog.traj_floats, np.nan, np.float32)        # NaN poison: an unwritten read shows up
-        # kernel start: the whole trajectory region is zeroed once (zero row, x pad channels, slot pad columns)
+        # kernel start: the whole trajectory region is zeroed once (halo rows and pad channels of the state slot)
         self.lds[:] = 0.0
         self.poison_arena()
 
     def poison_arena(self):
-        """Everything but the zero row and the x slot is (re)poisoned: ops must write before anyone reads."""
+        """Everything but the x slot is (re)poisoned: ops must write (data rows AND halo rows) before anyone reads."""
         p = self.p
-        keep_lo, keep_hi = 0, p.x_off + p.horizon * p.x_stride
-        self.lds[keep_hi:] = np.nan
-        assert p.zrow_off == 0 and keep_lo == 0
+        lo = p.x_off - P2.HALO2 * p.x_stride
+        hi = p.x_off + (p.horizon + P2.HALO2) * p.x_stride
+        assert lo == 0
+        self.lds[hi:] = np.nan
 
     def load_x(self, x):
         p = self.p
@@ -70,65 +71,56 @@ class LaneSim2:
         p = self.p
         return self.read_slot(p.pred_off, p.pred_stride, p.horizon, p.dim)
 
-    @staticmethod
-    def _conv_row(op, pos, tap, pad):
-        if op[P2.W2_TRANSPOSED]:
-            num = pos + pad - tap
-            q = -1 if (num & 1) else (num >> 1)
-        else:
-            q = pos * op[P2.W2_CSTRIDE] + tap - pad
-        return q if (pos < op[P2.W2_LOUT] and 0 <= q < op[P2.W2_LIN]) else -1
-
     def _conv(self, op, emb_row):
         p, lds = self.p, self.lds
         c_out, l_out, coutp = int(op[P2.W2_COUT]), int(op[P2.W2_LOUT]), int(op[P2.W2_COUTP])
         mode, nt_n, sstride = int(op[P2.W2_MODE]), int(op[P2.W2_NT]), int(op[P2.W2_SSTRIDE])
+        l_cols, cstride, ostride = int(op[P2.W2_LCOLS]), int(op[P2.W2_CSTRIDE]), int(op[P2.W2_OSTRIDE])
         flags = int(op[P2.W2_FLAGS])
-        segs = [[int(op[P2.W2_SEG0 + s * P2.SEG2_WORDS + k]) for k in range(P2.SEG2_WORDS)]
-                for s in range(int(op[P2.W2_NSEG]))]
         lane = np.arange(64)
         if mode == MODE_16X16:
-            cols, kstep, lcol, koff, drow, rows = 16, 16, lane & 15, 4 * (lane >> 4), 4 * (lane >> 4), 16
+            cols, kstep, lcol, koff, drow = 16, 16, lane & 15, 4 * (lane >> 4), 4 * (lane >> 4)
         else:
-            cols, kstep, lcol, koff, drow, rows = 4, 4, lane & 3, 0 * lane, 4 * (lane >> 2), 64
+            cols, kstep, lcol, koff, drow = 4, 4, lane & 3, 0 * lane, 4 * (lane >> 2)
         stage = p.stage_off
         ksplit = int(op[P2.W2_KSPLIT])
         lds[stage:stage + ksplit * l_out * sstride] = np.nan      # stale data must not be read
 
         for item in range(int(op[P2.W2_NITEMS])):             # wave w takes items w, w + 4, ...
-            rec = self.buf[op[P2.W2_ITEMS] + item * P2.ITEM2_WORDS: op[P2.W2_ITEMS] + (item + 1) * P2.ITEM2_WORDS]
-            woff, nq, si, tap, cc, part, col0 = (int(rec[k]) for k in range(7))
+            rec = P2.op_item(self.buf, op, item)
+            woff, nq, part, col0, ccn = (int(rec[k]) for k in (P2.I2_WOFF, P2.I2_NQ, P2.I2_PART, P2.I2_COL0, P2.I2_CCN))
+            tap, cc = int(rec[P2.I2_TAPCC]) & 255, int(rec[P2.I2_TAPCC]) >> 8
+            pad, ooff = int(rec[P2.I2_PADOOFF]) & 255, int(rec[P2.I2_PADOOFF]) >> 8
+            src, sstr = int(rec[P2.I2_SRCSTR]) & 0xffff, int(rec[P2.I2_SRCSTR]) >> 16
             w4 = self.blob[woff:woff + nq * 256].reshape(nq, 64, 4)
             acc = np.zeros((nt_n, 64, 4), np.float32)         # D fragment: [col tile][lane][4 rows]
+            # per-lane operand offset: LINEAR in the tap thanks to the halo; columns past l_cols sit on halo row 0, step 0
+            m = np.stack([col0 + nt * cols + lcol for nt in range(nt_n)])
+            valid = m < l_cols
+            row = np.where(valid, m * cstride - pad + P2.HALO2 + tap, 0)
+            assert (row >= 0).all()
+            cur = src + row * sstr + koff[None, :] + cc * kstep
+            tstep = np.where(valid, sstr, 0) - ccn * kstep
             for q in range(nq):
-                src, sstr, ccn, taps, pad = segs[si]
                 a = w4[q]
                 for nt in range(nt_n):
-                    bmat = np.empty((64, 4), np.float32)
-                    for l in range(64):
-                        row = self._conv_row(op, col0 + nt * cols + lcol[l], tap, pad)
-                        base = src + row * sstr if row >= 0 else p.zrow_off
-                        addr = base + cc * kstep + koff[l]
-                        bmat[l] = lds[addr:addr + 4]
+                    bmat = np.stack([lds[cur[nt][l]:cur[nt][l] + 4] for l in range(64)])
+                    assert np.isfinite(bmat).all(), "B operand read an unwritten LDS word"
                     if mode == MODE_16X16:                     # D[i][j] += sum_k A[i][k] B[k][j]; lane = k*16 + i / k*16 + j
-                        am = a.reshape(4, 16, 4)
-                        bm = bmat.reshape(4, 16, 4)
-                        d = np.einsum("kim,kjm->ij", am, bm).astype(np.float32)        # [row i][col j]
+                        d = np.einsum("kim,kjm->ij", a.reshape(4, 16, 4), bmat.reshape(4, 16, 4)).astype(np.float32)
                     else:                                      # 16 blocks of 4x4: row = lane, the 4 columns are lanes 0..3
-                        d = (a[:, None, :] * bmat[None, :4, :]).sum(-1).astype(np.float32)   # [row 0..63][col 0..3]
+                        d = (a[:, None, :] * bmat[None, :4, :]).sum(-1).astype(np.float32)
                     for l in range(64):
                         acc[nt][l] += d[drow[l]:drow[l] + 4, lcol[l]]
-                if q + 1 < nq:                                 # cursor walk (segment, tap, chunk)
-                    cc += 1
-                    if cc == ccn:
-                        cc = 0
-                        tap += 1
-                        if tap == taps:
-                            tap, si = 0, si + 1
-            for nt in range(nt_n):                             # D fragment -> stage[k slice][position][row tile + rows]
+                cur = cur + kstep                              # cursor walk: chunk, then (every ccn chunks) one tap step
+                cc += 1
+                if cc == ccn:
+                    cc = 0
+                    cur = cur + tstep
+            for nt in range(nt_n):                             # D fragment -> stage[k slice][output position][row tile + rows]
                 for l in range(64):
-                    n = col0 + nt * cols + lcol[l]
-                    if n < l_out:
+                    if m[nt][l] < l_cols:
+                        n = m[nt][l] * ostride + ooff
                         a0 = stage + part + n * sstride + drow[l]
                         lds[a0:a0 + 4] = acc[nt][l]
 
@@ -138,7 +130,7 @@ class LaneSim2:
         cg4 = cg // 4
         assert cg4 == 1 << shift
         nv = cg4 * l_out
-        dst, dstride = int(op[P2.W2_DST]), int(op[P2.W2_DST_STRIDE])
+        dst, dstride, coff = int(op[P2.W2_DST]), int(op[P2.W2_DST_STRIDE]), 0
 
         def par(word):
             o = int(op[word])
@@ -164,8 +156,13 @@ class LaneSim2:
             for g in range(P2.GROUPS2):
                 keys = [kk for kk in vals if kk[0] == g]
                 allv = np.concatenate([vals[kk] for kk in keys])
-                mean = np.float32(allv.sum(dtype=np.float32) * inv_cnt)
-                var = np.float32(((allv - mean) ** 2).sum(dtype=np.float32) * inv_cnt)
+                # single pass, shifted by the group's first element (lane 0 of the half-wave, component 0): one cross-lane
+                # reduction round instead of two, without the cancellation of a raw E[x^2] - E[x]^2
+                shift = vals[(g, 0, g * cg)][0]
+                dlt = (allv - shift).astype(np.float32)
+                m1 = np.float32(dlt.sum(dtype=np.float32) * inv_cnt)
+                var = np.float32((dlt * dlt).sum(dtype=np.float32) * inv_cnt - m1 * m1)
+                mean = np.float32(shift + m1)
                 rstd = np.float32(1.0) / np.sqrt(var + np.float32(GN_EPS))
                 for kk in keys:
                     c = kk[2]
@@ -175,9 +172,11 @@ class LaneSim2:
                 e0 = int(op[P2.W2_EMB]) + c
                 v = v + emb_row[e0:e0 + 4]
             if flags & P2.F2_RES:
-                a = int(op[P2.W2_RES]) + pos * int(op[P2.W2_RES_STRIDE]) + c
+                a = int(op[P2.W2_RES]) + (pos + P2.HALO2) * int(op[P2.W2_RES_STRIDE]) + c
                 v = v + lds[a:a + 4]
             for j in range(4):
                 if c + j < c_out:
                     assert np.isfinite(v[j]), "NaN reached a destination slot"
-                    lds[dst + pos * dstride + c + j] = v[j]
+                    lds[dst + (pos + P2.HALO2) * dstride + coff + c + j] = v[j]
+        for r in (0, 1, l_out + P2.HALO2, l_out + P2.HALO2 + 1):        # wave w rewrites halo row w of the destination
+            lds[dst + r * dstride: dst + (r + 1) * dstride] = 0.0

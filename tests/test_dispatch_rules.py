@@ -2,7 +2,7 @@
 runtime.py) -- pure Python decisions, checked on the CPU."""
 import torch
 
-from cleandiffuser_amd.engine import bigbatch, plan as P, program, runtime
+from cleandiffuser_amd.engine import bigbatch, plan as P, program, runtime, runtime2
 from cleandiffuser_amd.nn_diffusion import ChiUNet1d, DiT1d, JannerUNet1d
 
 
@@ -19,11 +19,15 @@ def test_unet_executor_choice(monkeypatch):
         seen.append((horizon, edm))
         return "LDS plan needs 200000 B" if (horizon >= 64 or edm) else None
     monkeypatch.setattr(runtime, "supported_backbone", fake_supported)
+    # the second-generation program kernel has its own (smaller) LDS plan: pretend it shares the fake limit of the first
+    monkeypatch.setattr(runtime2, "supported", lambda module, horizon: "LDS plan needs 200000 B" if horizon >= 64 else None)
     assert not bigbatch.is_chiunet_gemm(janner, 3, 32)                  # fits the program kernel: small batches stay there
     assert bigbatch.is_chiunet_gemm(janner, 3, 64)                      # does not fit: GEMM executor at any batch
     assert bigbatch.is_chiunet_gemm(chi, 3, 16, True)                   # fits only without the EDM buffers, plan has EDM steps
-    assert seen == [(32, False), (64, False), (16, True)]
-    assert bigbatch.is_chiunet_gemm(janner, 5000, 32) and len(seen) == 3     # large batch: no need to ask the compiler
+    assert seen == [(64, False), (16, True)]                            # (v2 answered for the H = 32 request)
+    assert not bigbatch.is_chiunet_gemm(janner, 5000, 32)               # v2 program kernel keeps every batch size it can run
+    assert bigbatch.is_chiunet_gemm(janner, 5000, 32, True) and bigbatch.is_chiunet_gemm(janner, 5000, 64)   # EDM plans / too big: GEMM
+    assert len(seen) == 2                                               # large batch: no need to ask the v1 compiler
 
 
 def test_edm_state_buffers_are_optional_in_the_lds_plan():

@@ -32,8 +32,20 @@ def _worker(rank, world, port, out_path):
     c = cases.CASES["janner_cfg2_diffuser_logp"]
     prior2 = torch.zeros(7, c["horizon"], c["net"][1]["in_dim"])
     xs, logp = sharded_sample(scorer, prior2, gather=True, seed=3, return_logp=True, solver="ddim", sample_steps=3, temperature=0.5)
+    # per-sample tensor kwargs are sliced with the prior: CFG condition (even 4 + 4 split -> all_gather_into_tensor) and a
+    # recorded noise list
+    cond_agent, _ = cases.build(lib, "janner_tiny_cond_w2")
+    cc = cases.CASES["janner_tiny_cond_w2"]
+    inp = cases.make_inputs("janner_tiny_cond_w2")
+    reps = -(-8 // inp["prior"].shape[0])
+    prior3 = torch.from_numpy(inp["prior"]).repeat(reps, 1, 1)[:8]
+    cond3 = torch.from_numpy(inp["cond"]).repeat(reps, *([1] * (inp["cond"].ndim - 1)))[:8] * torch.linspace(0.5, 1.5, 8).view(-1, *([1] * (inp["cond"].ndim - 1)))
+    g = torch.Generator().manual_seed(5)
+    zs = [torch.randn(prior3.shape, generator=g) for _ in range(cc["sample"]["sample_steps"] + 1)]
+    kw3 = {k: v for k, v in cases.sample_kwargs("janner_tiny_cond_w2", inp).items() if k not in ("n_samples", "condition_cfg")}
+    xc = sharded_sample(cond_agent, prior3, gather=True, noise=zs, condition_cfg=cond3, **kw3)
     if rank == 0:
-        torch.save({"x": x, "xs": xs, "logp": logp}, out_path)
+        torch.save({"x": x, "xs": xs, "logp": logp, "xc": xc, "prior3": prior3, "cond3": cond3, "zs": zs}, out_path)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -58,5 +70,10 @@ def test_two_rank_shard_and_gather_equals_single_process(tmp_path):
                                 solver="ddim", sample_steps=3, temperature=0.5)
     assert got["logp"].shape == (7, 1) and torch.allclose(got["xs"], xs1, rtol=1e-4, atol=1e-4)
     assert torch.allclose(got["logp"], logp1, rtol=1e-4, atol=1e-4) and int(got["logp"].argmax()) == int(logp1.argmax())
+    cond_agent, _ = cases.build(cases.lib_namespace("amd"), "janner_tiny_cond_w2")
+    inp = cases.make_inputs("janner_tiny_cond_w2")
+    kw3 = {k: v for k, v in cases.sample_kwargs("janner_tiny_cond_w2", inp).items() if k not in ("n_samples", "condition_cfg")}
+    xc1 = sharded_sample(cond_agent, got["prior3"], gather=True, noise=got["zs"], condition_cfg=got["cond3"], **kw3)
+    assert got["xc"].shape == xc1.shape and torch.allclose(got["xc"], xc1, rtol=1e-4, atol=1e-4), "per-sample kwargs must be sliced"
     assert [shard_bounds(5, r, 2) for r in range(2)] == [(0, 3), (3, 5)]
     assert [shard_bounds(0, r, 2) for r in range(2)] == [(0, 0), (0, 0)]

@@ -50,15 +50,14 @@ def test_program2_accounting_and_budget(amd_lib):
     assert abs(prog.macs_per_forward - 19.67e6) / 19.67e6 < 0.01
     assert prog.lds_bytes(2) <= 160 * 1024
     ops = prog.ops
-    assert (ops[:, P2.W2_NITEMS] >= 1).all() and (ops[:, P2.W2_NSEG] <= 2).all()
-    # every wave has work in every op of this net, and K slices exactly tile the record stream of a row tile
+    assert (ops[:, P2.W2_NITEMS] == P2.NW2).all(), "every wave has exactly one work item in every op of this net"
     for op in ops:
-        items = prog.ops_buffer[op[P2.W2_ITEMS]: op[P2.W2_ITEMS] + op[P2.W2_NITEMS] * P2.ITEM2_WORDS].reshape(-1, P2.ITEM2_WORDS)
-        assert len(items) == P2.NW2
-        nqt = sum(int(op[P2.W2_SEG0 + s * P2.SEG2_WORDS + P2.S2_CCN]) * int(op[P2.W2_SEG0 + s * P2.SEG2_WORDS + P2.S2_TAPS])
-                  for s in range(op[P2.W2_NSEG]))
-        tiles = len(items) // op[P2.W2_KSPLIT]
-        assert items[:, P2.I2_NQ].sum() == nqt * tiles
+        items = np.stack([P2.op_item(prog.ops_buffer, op, j) for j in range(op[P2.W2_NITEMS])])
+        # K slices of one tile exactly tile its record stream: same record count per tile, slices of a tile are contiguous
+        per_tile = items[:, P2.I2_NQ].sum() * op[P2.W2_KSPLIT] // len(items)
+        assert per_tile * len(items) == items[:, P2.I2_NQ].sum() * op[P2.W2_KSPLIT]
+        assert (items[:, P2.I2_NQ] >= 1).all() and (items[:, P2.I2_CCN] >= 1).all()
+        assert ((items[:, P2.I2_SRCSTR] & 0xffff) < prog.traj_floats).all()
 
 
 def test_v2_refuses_what_it_cannot_run(amd_lib):

@@ -1,6 +1,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "unet2_agrees" 2>&1 | tail -5
+export CDX_UNET2_MIN_BATCH=1
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "unet2 or test_fused_sample_matches_reference_fixture or full_size_properties" 2>&1 | tail -12
 timeout 300 python tools/op_profile2.py 256 > gpurun_out/op2_b256.txt 2>&1; cat gpurun_out/op2_b256.txt
-timeout 300 python tools/op_profile2.py 512 2 > gpurun_out/op2_b512_t2.txt 2>&1; cat gpurun_out/op2_b512_t2.txt | head -5; grep totals gpurun_out/op2_b512_t2.txt
-timeout 300 python tools/op_profile2.py 512 1 > gpurun_out/op2_b512_t1.txt 2>&1; cat gpurun_out/op2_b512_t1.txt | head -3; grep totals gpurun_out/op2_b512_t1.txt
+for B in 256 512 1024 3200; do BENCH_BATCH=$B timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('B=$B T=1', round(d['value']), 'traj/s', 'kernel_ms', round(d['roofline']['kernel_ms'],3), 'frac', round(d['roofline']['frac'],4))"; done
+for B in 512 1024 3200; do CDX_UNET2_T=2 BENCH_BATCH=$B timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('B=$B T=2', round(d['value']), 'traj/s', 'kernel_ms', round(d['roofline']['kernel_ms'],3), 'frac', round(d['roofline']['frac'],4))"; done

@@ -37,7 +37,7 @@ def main():
     tk = ts = te = 0
     for i, op in enumerate(prog.ops):
         s0, s1, s2, s3, k4, k5, k6, k7 = t[i * 8:i * 8 + 8]
-        nq = int(prog.ops_buffer[op[P2.W2_ITEMS] + P2.I2_NQ])
+        nq = int(P2.op_item(prog.ops_buffer, op, 0)[P2.I2_NQ])
         k, s, e = s1 - s0, s2 - s1, s3 - s2
         tk, ts, te = tk + k, ts + s, te + e
         print(f"{i:3d} {op[P2.W2_COUT]:4d} {op[P2.W2_LOUT]:3d} {'4x4' if op[P2.W2_MODE] else '16':>4} {op[P2.W2_NT]:2d} {op[P2.W2_KSPLIT]:2d} "
