@@ -8,13 +8,23 @@ temperature 0.5 -- synthetic random-init weights and synthetic inputs already re
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (driver, N > 1)
 
-Multi-GPU: trajectories are independent, so each rank denoises its own 256 (weak scaling, no data-path
-collective); the only collectives are the timing barrier and the MAX reduction of the elapsed time.
+The ONE JSON line (rank 0):
 
-Prints ONE JSON line (rank 0).  ``roofline`` prices the single fused kernel against the fp32-MFMA peak using the
-algorithmic FLOPs of the reference modules (786.6 MFLOP per trajectory = 39.33 MFLOP x 20 forwards) and
-the kernel's mean duration from HIP events on the launch stream.  ``cpu_baseline`` times the CPU oracle port
-(oracle/torch_port.py, the same ATen ops the reference runs) on this host's cores -- reported baseline only.
+* ``value`` -- N = 1: trajectories/s of the B=256 call.  N > 1: WEAK scaling -- every rank denoises its own 256 trajectories
+  and the finished shards are exchanged with one RCCL all-gather INSIDE the timed region (north star: "RCCL over xGMI used only
+  to gather sampled trajectories"); ``scaling`` says "weak".
+* ``strong_scaling`` (N > 1) -- the same timed loop for a FIXED global batch sharded over the ranks through
+  ``cleandiffuser_amd.distributed.sharded_sample`` (shard, sample, all-gather): global B = 256 (the metric's batch: 256 / N
+  trajectories per GPU -- one workgroup per trajectory leaves most of a GPU idle, this is the latency floor of one launch) and
+  global B = 3200 (the batch the shipped Diffuser pipelines really sample: 50 environments x 64 candidate plans).
+* ``roofline`` prices the single fused kernel against the fp32-MFMA peak using the algorithmic FLOPs of the reference modules
+  (786.6 MFLOP per trajectory = 39.33 MFLOP x 20 forwards) and the kernel's mean duration from HIP events on the
+  launch stream.
+* ``other_configs`` (N = 1) -- the other BASELINE configs and the guided / large-batch variants of config 2, measured by the same
+  process right after the headline (short runs; builder-independent numbers for configs 1, 3, 4, 5).
+* ``cpu_baseline`` (N = 1) -- the CPU oracle port (oracle/torch_port.py, the same ATen ops the reference runs) on this host: at
+  the fastest thread count of a probe and at ONE thread, with the CPU model and torch build; plus the recorded figure of the
+  real reference measured in the build container (profiles/r02_reference_cpu.json).  Reported baseline only.
 """
 import argparse
 import json
@@ -29,6 +39,7 @@ sys.path.insert(0, ROOT)
 
 BATCH, HORIZON, DIM, SAMPLE_STEPS = int(os.environ.get("BENCH_BATCH", "256")), 32, 23, 20
 PEAK_FP32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_*_f32 dense peak
+FLOPS_PER_TRAJ = 2.0 * 19.67e6 * SAMPLE_STEPS   # SURVEY 8d (the program compilers re-derive 19.67 M MAC, asserted in tests/)
 
 
 def build_agent(device):
@@ -44,21 +55,36 @@ def build_agent(device):
     return agent, net
 
 
-def make_inputs(device, seed):
+def make_inputs(device, seed, batch=None):
+    batch = BATCH if batch is None else batch
     g = torch.Generator().manual_seed(1000 + seed)
-    prior = torch.zeros(BATCH, HORIZON, DIM)
-    prior[:, 0, :17] = torch.randn(BATCH, 17, generator=g)
-    z0 = torch.randn(BATCH, HORIZON, DIM, generator=g)
+    prior = torch.zeros(batch, HORIZON, DIM)
+    prior[:, 0, :17] = torch.randn(batch, 17, generator=g)
+    z0 = torch.randn(batch, HORIZON, DIM, generator=g)
     return prior.to(device), z0.to(device)
 
 
-def cpu_baseline(net, budget_s=12.0):
-    """Time the CPU oracle on a bounded sample of the same workload: whole sample() calls at B=256 until
-    ~budget_s of CPU work has been done (>= 2 calls)."""
+# ------------------------------------------------------------------------------------------------------------------- #
+# CPU baseline leg (child process)                                                                                      #
+# ------------------------------------------------------------------------------------------------------------------- #
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(net, budget_s=10.0):
+    """Time the CPU oracle on a bounded sample of the same workload: whole sample() calls at B=256 until ~budget_s of CPU work
+    has been done (>= 2 calls) at the fastest thread count of a probe, then >= 1 call at one thread."""
     from oracle import torch_port
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     fwd = torch_port.make_forward(sd, dict(emb_dim=32, kernel_size=5, dim_mult=[1, 2, 2, 2]))
-    prior, z0 = make_inputs("cpu", 0)
+    prior, z0 = make_inputs("cpu", 0, 256)
     fm = torch.zeros(1, HORIZON, DIM)
     fm[0, 0, :17] = 1.0
     avail = torch.get_num_threads()           # torch's own default = the cores this process may use
@@ -70,15 +96,14 @@ def cpu_baseline(net, budget_s=12.0):
                                         fix_mask=fm)
     # the reference path is small-op bound: all cores of a big host oversubscribe it, so probe a few thread counts
     # (one timed call each) and run the bounded sample at the fastest -- `cores` reports what was actually used
-    best, cores = None, avail
+    probe = {}
     for th in sorted({t for t in (8, 16, 32, 64, avail) if t <= avail}):
         torch.set_num_threads(th)
         call()                                 # warm-up (thread pool, oneDNN primitives)
         t0 = time.perf_counter()
         call()
-        dt = time.perf_counter() - t0
-        if best is None or dt < best:
-            best, cores = dt, th
+        probe[th] = time.perf_counter() - t0
+    cores = min(probe, key=probe.get)
     torch.set_num_threads(cores)
     call()
     t0, n = time.perf_counter(), 0
@@ -86,12 +111,30 @@ def cpu_baseline(net, budget_s=12.0):
         call()
         n += 1
     dt = time.perf_counter() - t0
-    return {"value": BATCH * n / dt, "unit": "trajectories/s", "cores": cores, "kind": "port",
-            "sample": f"{n} full sample() calls of B={BATCH} (20-step DDIM) through oracle/torch_port.py, "
-                      f"{dt:.1f}s wall, torch {torch.__version__} CPU, {cores} of {avail} threads (fastest of a probe)"}
+    torch.set_num_threads(1)
+    call()
+    t1, n1 = time.perf_counter(), 0
+    while n1 < 1 or time.perf_counter() - t1 < budget_s / 2:
+        call()
+        n1 += 1
+    dt1 = time.perf_counter() - t1
+    ref = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_reference_cpu.json")) as f:
+            ref = json.load(f)
+    except (OSError, ValueError):
+        pass
+    blas = [ln.strip() for ln in torch.__config__.show().splitlines() if "BLAS" in ln or "MKL" in ln or "OpenMP" in ln][:4]
+    return {"value": 256 * n / dt, "unit": "trajectories/s", "cores": cores, "kind": "port",
+            "sample": f"{n} full sample() calls of B=256 (20-step DDIM) through oracle/torch_port.py, {dt:.1f}s wall, "
+                      f"{cores} of {avail} threads (fastest of a probe over {sorted(probe)})",
+            "all_cores": {"value": 256 / probe[avail], "cores": avail, "sample": "one call after a warm-up"},
+            "one_thread": {"value": 256 * n1 / dt1, "cores": 1, "sample": f"{n1} calls, {dt1:.1f}s wall"},
+            "cpu_model": _cpu_model(), "torch": torch.__version__, "torch_build": blas,
+            "reference_in_build_container": ref}
 
 
-def cpu_baseline_subprocess(timeout_s=180):
+def cpu_baseline_subprocess(timeout_s=240):
     """Run the CPU leg in a child with a hard wall-clock bound so the GPU line is never held hostage."""
     import subprocess
     try:
@@ -106,22 +149,86 @@ def cpu_baseline_subprocess(timeout_s=180):
 def recorded_traffic():
     """HBM-side bytes per launch of the fused kernel from the committed PMC pass (rocprofv3 --pmc cannot run inside this
     process); null when the record is absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                rec = json.load(f)
+            return {"traffic": rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"], "traffic_unit": "bytes/launch",
+                    "traffic_kernel": rec.get("kernel"),
+                    "traffic_source": f"profiles/{name} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected)"}
+        except (OSError, KeyError, ValueError):
+            continue
+    return {"traffic": None}
+
+
+# ------------------------------------------------------------------------------------------------------------------- #
+# other configs (N = 1)                                                                                                 #
+# ------------------------------------------------------------------------------------------------------------------- #
+def other_configs(device):
+    """Short measurements of the other BASELINE configs / config-2 variants (tools/bench_configs.py workloads): each entry has
+    the whole-call rate, ms per sample() call, the fp32-MFMA fraction of the whole call and the kernel family that dominates."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_configs as bc
+    from cleandiffuser_amd.engine import runtime
+    out = []
+
+    def timed(call, reps):
+        x = call()
+        torch.cuda.synchronize(device)
+        assert torch.isfinite(x).all()
+        runtime.enable_launch_timing(True)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            call()
+        torch.cuda.synchronize(device)
+        dt = (time.perf_counter() - t0) / reps
+        k_ms = runtime.drain_launch_timing()
+        runtime.enable_launch_timing(False)
+        return dt, k_ms
+
+    def big(tag, fn, kernel, reps=3, **kw):
+        try:
+            label, call, b, flops = fn(**kw)
+            dt, k_ms = timed(call, reps)
+            out.append({"name": tag, "workload": label, "value": b / dt, "unit": "samples/s", "ms_per_call": 1e3 * dt,
+                        "roofline_frac": flops / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, "dominant_kernel": kernel,
+                        "fused_kernel_ms": (sum(k_ms) / len(k_ms)) if k_ms else None})
+        except Exception as e:  # noqa: BLE001 -- one broken side measurement must not take the headline down
+            out.append({"name": tag, "error": f"{type(e).__name__}: {e}"})
+
+    big("config2_B3200", bc.cfg2big, "cdx_unet2_kernel<2> (two trajectories per workgroup)", B=3200)
+    big("config2_guided_B256", bc.cfg2g, "cdx_guided_run: cdx_unet1d_kernel forward + classifier GEMM/GroupNorm kernels", B=256)
     try:
-        with open(path) as f:
-            rec = json.load(f)
-        return {"traffic": rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"], "traffic_unit": "bytes/launch",
-                "traffic_source": "profiles/r01_pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE pass, gfx950-corrected)"}
-    except (OSError, KeyError, ValueError):
-        return {"traffic": None}
+        label, call, b, steps, net, horizon = bc.cfg1()
+        dt, k_ms = timed(call, 5)
+        prog = runtime.compiled_program(net, horizon).prog
+        flops = 2.0 * prog.macs_per_forward / horizon * steps * b
+        out.append({"name": "config1", "workload": label, "value": b / dt, "unit": "samples/s", "ms_per_call": 1e3 * dt,
+                    "roofline_frac": flops / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, "dominant_kernel": "cdx_unet1d_kernel<true> (MLP tiles)",
+                    "fused_kernel_ms": (sum(k_ms) / len(k_ms)) if k_ms else None})
+    except Exception as e:  # noqa: BLE001
+        out.append({"name": "config1", "error": f"{type(e).__name__}: {e}"})
+    try:
+        label, call, b, steps, net, horizon = bc.cfg3()
+        dt, _ = timed(call, 2)
+        flops = 2.0 * 298.4e6 * steps * b
+        out.append({"name": "config3", "workload": label, "value": b / dt, "unit": "samples/s", "ms_per_call": 1e3 * dt,
+                    "roofline_frac": flops / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, "dominant_kernel": "cdx_gemm_kernel (implicit-GEMM conv)"})
+    except Exception as e:  # noqa: BLE001
+        out.append({"name": "config3", "error": f"{type(e).__name__}: {e}"})
+    big("config4_shard512", bc.cfg4, "cdx_gemm_kernel", B=512)
+    big("config5_chunk16384", bc.cfg5, "cdx_gemm_kernel", reps=1, B=16384)
+    return out
 
 
+# ------------------------------------------------------------------------------------------------------------------- #
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=400)      # ~5.6 ms per call: a >= 2 s timed region
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -131,7 +238,7 @@ def main():
         return
 
     import faulthandler
-    faulthandler.dump_traceback_later(240, exit=False)     # if anything wedges, say where (stderr)
+    faulthandler.dump_traceback_later(600, exit=False)     # if anything wedges, say where (stderr)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -145,19 +252,21 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        assert dist.get_world_size() == world == args.gpus, (dist.get_world_size(), world, args.gpus)
 
+    from cleandiffuser_amd import distributed as cdist
     from cleandiffuser_amd.engine import runtime
     runtime.load_library()
     agent, net = build_agent(device)
     prior, z0 = make_inputs(device, rank)
     kw = dict(solver="ddim", n_samples=BATCH, sample_steps=SAMPLE_STEPS, temperature=0.5)
+    gathered = torch.empty((BATCH * world, HORIZON, DIM), device=device) if dist is not None else None
 
     def step():
         x, _ = agent.sample(prior, noise=[z0], **kw)
+        if dist is not None:                  # the one exchange of the data path: all ranks end up with every trajectory
+            dist.all_gather_into_tensor(gathered, x)
         return x
-
-    for _ in range(args.warmup):
-        step()
 
     def fence():
         torch.cuda.synchronize(device)
@@ -165,27 +274,47 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
+    def timed_loop(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            x = fn()
+        fence()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, x
+
+    for _ in range(args.warmup):
+        step()
     runtime.enable_launch_timing(True)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        x = step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    elapsed, x = timed_loop(step, args.steps, 0)
     kernel_ms = runtime.drain_launch_timing()
     runtime.enable_launch_timing(False)
     assert torch.isfinite(x).all()
 
-    if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    strong = None
+    if dist is not None:                      # fixed global batch sharded over the ranks: shard -> sample -> all-gather
+        strong = {}
+        for gb in (256, 3200):
+            gp, gz = make_inputs(device, 12345, gb)      # identical on every rank
+            skw = dict(solver="ddim", sample_steps=SAMPLE_STEPS, temperature=0.5)
+            reps = max(args.steps // (4 if gb == 256 else 16), 3)
+            el, xs = timed_loop(lambda: cdist.sharded_sample(agent, gp, gather=True, noise=[gz], **skw), reps, 2)
+            assert xs.shape[0] == gb and torch.isfinite(xs).all()
+            strong[f"global_batch_{gb}"] = {"value": gb * reps / el, "unit": "trajectories/s", "ms_per_call": 1e3 * el / reps,
+                                            "trajectories_per_gpu": [cdist.shard_bounds(gb, r, world)[1] - cdist.shard_bounds(gb, r, world)[0]
+                                                                     for r in range(world)], "calls_timed": reps,
+                                            "includes": "shard, sample(), RCCL all-gather of the result"}
 
     if rank == 0:
-        prog = runtime.compiled_program(agent.model_ema["diffusion"], HORIZON).prog
-        flops_per_traj = 2.0 * prog.macs_per_forward * SAMPLE_STEPS
         k_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
-        achieved = flops_per_traj * BATCH / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        achieved = FLOPS_PER_TRAJ * BATCH / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        v2 = os.environ.get("CDX_UNET2", "1") != "0"
         out = {
             "metric": "denoised trajectories/sec @ (B=256,H=32,D=23) 20-step DDIM",
             "value": BATCH * world * args.steps / elapsed,
@@ -195,14 +324,20 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: JannerUNet1d Diffuser H=32 D=23, 20-step DDIM, "
-                                   "B=256 trajectories per GPU, whole DiscreteDiffusionSDE.sample() call",
+                                   f"B={BATCH} trajectories per GPU, whole DiscreteDiffusionSDE.sample() call"
+                                   + (", then one RCCL all-gather of the N x 256 result" if world > 1 else ""),
                        "batch_per_gpu": BATCH, "global_batch": BATCH * world, "horizon": HORIZON, "dim": DIM,
-                       "sample_steps": SAMPLE_STEPS, "parallelism": f"batch-sharded x{world}, no data-path collective"},
+                       "sample_steps": SAMPLE_STEPS, "world_size": world,
+                       "parallelism": f"batch-sharded x{world}; the only data-path collective is the all-gather of the result"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, **recorded_traffic(),
-                         "kernel": "cdx_unet2_kernel" if os.environ.get("CDX_UNET2", "1") != "0" else "cdx_unet1d_kernel", "kernel_ms": k_ms, "launches_timed": len(kernel_ms),
-                         "flops_per_launch": flops_per_traj * BATCH},
+                         "kernel": "cdx_unet2_kernel<1>" if v2 else "cdx_unet1d_kernel", "kernel_ms": k_ms,
+                         "launches_timed": len(kernel_ms), "flops_per_launch": FLOPS_PER_TRAJ * BATCH},
         }
+        if strong is not None:
+            out["strong_scaling"] = strong
+        if world == 1 and not args.no_other_configs:
+            out["other_configs"] = other_configs(device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_subprocess()
         print(json.dumps(out), flush=True)

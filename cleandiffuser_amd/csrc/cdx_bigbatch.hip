@@ -9,6 +9,7 @@
 // newedm.py:387-401) costs one C call.  The batch is processed in independent chunks sized so that a chunk's
 // activations stay inside the 256 MiB Infinity Cache between producer and consumer launches.
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <stdint.h>
 
 #include "../../include/cdx.h"
@@ -777,6 +778,7 @@ long long chiunet_pass(const cdx_chiunet_weights* w, const cdx_sampling* s, hipS
 struct SideStream {
     hipStream_t stream;
     hipEvent_t fork, join;
+    std::mutex* busy;            // held for a whole guided call: one side stream + event pair per device, one user at a time
 };
 SideStream* side_stream() {
     static const bool enabled = [] { const char* e = getenv("CDX_GUIDED_OVERLAP"); return !(e && e[0] == '0'); }();
@@ -784,8 +786,11 @@ SideStream* side_stream() {
     static SideStream slots[64];
     static bool ready[64] = {};
     static bool failed[64] = {};
+    static std::mutex init_lock, busy_locks[64];
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || failed[dev]) return nullptr;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> guard(init_lock);       // lazy creation from concurrent callers (threads / streams)
+    if (failed[dev]) return nullptr;
     if (!ready[dev]) {
         SideStream s;
         if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
@@ -795,6 +800,7 @@ SideStream* side_stream() {
             (void)hipGetLastError();
             return nullptr;
         }
+        s.busy = &busy_locks[dev];
         slots[dev] = s;
         ready[dev] = true;
     }
@@ -1085,21 +1091,31 @@ int cdx_guided_run(const cdx_guided_launch* g, void* hip_stream) {
     // caller's stream -- a GEMM workgroup (34 KB LDS, 4 waves) fits next to the U-Net workgroup on every CU.  Fork/join with two
     // events per step; all side-stream work is joined before the call returns.  CDX_GUIDED_OVERLAP=0 serialises (A/B hook).
     SideStream* side = side_stream();
+    // Two guided calls on one device (other threads, other caller streams) would race on the shared fork/join events: the second
+    // one waits here.  Every exit after a fork drains the side stream first, so that the caller may free cond / temb / workspace
+    // as soon as it has synchronised with ITS stream, error or not.
+    std::unique_lock<std::mutex> busy;
+    if (side) busy = std::unique_lock<std::mutex>(*side->busy);
+    auto bail = [&](int rc) {
+        if (side) (void)hipStreamSynchronize(side->stream);
+        return rc;
+    };
+#define CDX_TRY_SIDE(expr) do { const int rc_ = (expr); if (rc_ != CDX_OK) return bail(rc_); } while (0)
     for (int i = 0; i < g->n_steps; ++i) {
         cdx_unet1d_launch L = *g->denoiser;
         L.n_steps = 0; L.steps = nullptr; L.temb_per_sample = 0; L.batch = g->batch;
         L.temb = g->temb + (size_t)i * L.emb_dim; L.x_in = x; L.x_out = pred;
         if (side) {
-            if (hipEventRecord(side->fork, st) != hipSuccess || hipStreamWaitEvent(side->stream, side->fork, 0) != hipSuccess) return hip_ok();
-            CDX_TRY(cdx_unet1d_run(&L, side->stream));
-            if (hipEventRecord(side->join, side->stream) != hipSuccess) return hip_ok();
+            if (hipEventRecord(side->fork, st) != hipSuccess || hipStreamWaitEvent(side->stream, side->fork, 0) != hipSuccess) return bail(hip_ok());
+            CDX_TRY_SIDE(cdx_unet1d_run(&L, side->stream));
+            if (hipEventRecord(side->join, side->stream) != hipSuccess) return bail(hip_ok());
         } else {
             CDX_TRY(cdx_unet1d_run(&L, hip_stream));
         }
         const int clf_rc = cdx_hjgrad_run(g->classifier, x, g->clf_emb0 + (size_t)i * g->classifier->emb_dim, 0, g->batch, logp, grad,
                                           clf_ws, clf_floats, hip_stream);
-        if (side && hipStreamWaitEvent(st, side->join, 0) != hipSuccess) return hip_ok();      // join even when the classifier failed
-        CDX_TRY(clf_rc);
+        if (side && hipStreamWaitEvent(st, side->join, 0) != hipSuccess) return bail(hip_ok());      // join even when the classifier failed
+        CDX_TRY_SIDE(clf_rc);
         StepArgs sa;
         sa.x = x; sa.pred = pred; sa.prev = prev; sa.xold = nullptr; sa.prior = g->prior; sa.fix_mask = g->fix_mask;
         sa.noise = g->noise; sa.x_min = g->x_min; sa.x_max = g->x_max; sa.st = g->steps[i]; sa.nb = g->batch; sa.hd = g->hd;
@@ -1107,8 +1123,9 @@ int cdx_guided_run(const cdx_guided_launch* g, void* hip_stream) {
         sa.grad = grad; sa.cg_scale = g->cg_scale[i];
         const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
         hipLaunchKernelGGL(solver_step_kernel, dim3(blocks), dim3(256), 0, st, sa);
-        CDX_TRY(hip_ok());
+        CDX_TRY_SIDE(hip_ok());
     }
+#undef CDX_TRY_SIDE
     if (hipMemcpyAsync(g->x_out, x, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return hip_ok();
     return CDX_OK;
 }

@@ -390,9 +390,12 @@ _workspaces = {}
 
 
 def _workspace(device, floats: int) -> torch.Tensor:
-    ws = _workspaces.get(device)
+    """Scratch of the big-batch executors, one buffer per (device, stream): work is ordered by the stream it is enqueued on, so
+    two solvers sampling on different torch streams must not share (or regrow) one buffer."""
+    key = (device, _stream_ptr(device))
+    ws = _workspaces.get(key)
     if ws is None or ws.numel() < floats:
-        _workspaces[device] = ws = torch.empty(int(floats), dtype=torch.float32, device=device)
+        _workspaces[key] = ws = torch.empty(int(floats), dtype=torch.float32, device=device)
     return ws
 
 

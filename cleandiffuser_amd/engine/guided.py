@@ -100,9 +100,10 @@ def guided_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, feed) -
                             x_max=runtime._ptr(x_max), x_out=out.data_ptr())
         lib = _lib()
         need = lib.cdx_guided_workspace_floats(ctypes.byref(g))
-        ws = _ws.get(dev)
+        key = (dev, _stream_ptr(dev))          # scratch is ordered by the stream it is used on: one buffer per (device, stream)
+        ws = _ws.get(key)
         if ws is None or ws.numel() < need:
-            _ws[dev] = ws = torch.empty(int(need), dtype=torch.float32, device=dev)
+            _ws[key] = ws = torch.empty(int(need), dtype=torch.float32, device=dev)
         g.workspace, g.workspace_floats = ws.data_ptr(), ws.numel()
         _check(lib.cdx_guided_run(ctypes.byref(g), _stream_ptr(dev)), "cdx_guided_run")
     return out

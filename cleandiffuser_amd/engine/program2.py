@@ -58,7 +58,9 @@ F2_GN, F2_EMB, F2_RES, F2_PRED = 1, 2, 4, 8
 
 
 def pad32(c: int) -> int:
-    return (c + 31) // 32 * 32
+    """Channel count the epilogue partitions: 32 x a power of two (8 lane groups of 4 x 2^k channels each)."""
+    n = (c + 31) // 32
+    return 32 * (1 << (n - 1).bit_length())
 
 
 @dataclass
@@ -196,28 +198,24 @@ class _Builder2:
             streams.append(segs)
         seg_n = [r.shape[1] for r, _ in streams[0]]
         nqt = sum(seg_n)
-        ksplit = max(1, min(NW2 // tiles, nqt)) if tiles < NW2 else 1
-        if len(srcs) == 2 and (ksplit % 2 or seg_n[0] != seg_n[1]):
-            raise ValueError("v2 needs the two sources of a concat to be equal halves of an evenly split K range")
+        # K slices: cut every source's record range evenly; with two sources (a concat) the slices never straddle the boundary,
+        # whatever the tile count -- each source gets at least one slice and the epilogue sums the staged partials
+        per_src = max(1, (NW2 // tiles if tiles < NW2 else 1) // len(srcs))
+        per_src = [min(per_src, n) for n in seg_n]
+        ksplit = sum(per_src)
+        cuts, base = [], 0                                  # (first record, one past the last, source index) per slice
+        for si, (n, k) in enumerate(zip(seg_n, per_src)):
+            cuts += [(base + j * n // k, base + (j + 1) * n // k, si, base) for j in range(k)]
+            base += n
         woffs = [self.add(torch.cat([r for r, _ in segs], dim=1).contiguous()) for segs in streams]
-        # K-slice boundaries: even cuts.  (The kernel's immediate-offset steady loop needs a slice to start on a multiple of RING2
-        # chunks inside a tap that spans a multiple of RING2 chunks; the wide 4x4 layers -- C_in >= 64, K a multiple of 64 per
-        # slice -- have that by themselves, and the kernel checks it per item.)
-
-        def cut(ks):
-            return ks * nqt // ksplit
-
         items, item_src = [], []
         for item in range(tiles * ksplit):
             tile, ks = item % tiles, item // tiles
             ph, tile = tile % len(phases), tile // len(phases)
             rt, cgi = tile % n_rt, tile // n_rt
-            q0, q1 = cut(ks), cut(ks + 1)
-            si = 0 if q1 <= seg_n[0] else 1
-            base = 0 if si == 0 else seg_n[0]
-            assert base <= q0 and q1 <= base + seg_n[si]
+            q0, q1, si, sbase = cuts[ks]
             ccn = streams[ph][si][1]
-            items.append([woffs[ph] + (rt * nqt + q0) * 256, q1 - q0, ((q0 - base) // ccn) | (((q0 - base) % ccn) << 8),
+            items.append([woffs[ph] + (rt * nqt + q0) * 256, q1 - q0, ((q0 - sbase) // ccn) | (((q0 - sbase) % ccn) << 8),
                           ks * l_out * sstride + rt * rows, cgi * nt * cols, phases[ph][1] | (phases[ph][2] << 8), 0, ccn])
             item_src.append(si)
         words = {W2_KIND: 0, W2_COUT: c_out, W2_LOUT: l_out, W2_LCOLS: l_cols, W2_CSTRIDE: cstride, W2_OSTRIDE: ostride,

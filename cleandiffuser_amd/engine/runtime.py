@@ -436,16 +436,18 @@ def fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed) -> Optio
             return out
     with torch.no_grad():
         comp = compiled_program(net, h, plan_is_edm(plan))
-        t_vec = device_times(plan, dev)
-        temb = _f32c(net.map_noise(t_vec), dev)
-        steps_dev = steps_to_device(plan, dev)
-        noise = torch.stack([feed.like(xt) for _ in range(plan.n_noise)]).contiguous() if plan.n_noise else None
+        # every eligibility check that can still send the request to the PyTorch executor comes BEFORE the first draw from `feed`:
+        # a recorded noise list must reach that executor unconsumed
         if cond_vec is None or w_cfg == 0.0:
             mode, cond = 0, None
         else:
             mode, cond = (1 if w_cfg == 1.0 else 2), _backbone_cond(net, comp.prog, cond_vec, dev)
             if cond is False or cond is None:
                 return None
+        t_vec = device_times(plan, dev)
+        temb = _f32c(net.map_noise(t_vec), dev)
+        steps_dev = steps_to_device(plan, dev)
+        noise = torch.stack([feed.like(xt) for _ in range(plan.n_noise)]).contiguous() if plan.n_noise else None
         xin = _f32c(xt, dev)
         out = torch.empty_like(xin)
         _launch(comp, batch=b, x_in=xin, x_out=out, temb=temb, steps_dev=steps_dev, n_steps=len(plan.steps),

@@ -1,0 +1,149 @@
+"""Reference fixtures for the shapes the small ``cases.CASES`` fixtures do not reach -- TEST INFRASTRUCTURE (oracle/__init__.py).
+
+Round 1 compared these shapes (shipped widths / horizons: PearceMlp 64/192/512, long-horizon and wide JannerUNet1d, the
+model_dim-64 Diffuser nets of kitchen / antmaze with classifier guidance, ChiTransformer Ta = 10, DiT1d with 10 and 40 tokens /
+depth 8, ChiUNet1d at the config-3 width) against this repo's own PyTorch executor on the GPU box's CPU and had to widen the
+tolerance for host-BLAS summation order.  Here every scenario is a pair of pure functions of a *library namespace*
+(``cases.lib_namespace("reference" | "amd")``) and a device, so ``python -m oracle.gen_golden_extra`` (build container) runs the REAL
+reference on them and commits ``tests/golden/extra_<name>.npz``; the GPU tests build the same agents from this repo's classes on
+the device and are held to the 1e-4 bar like every other fixture.  Weights: ``load_synth`` (PCG64 streams keyed by parameter
+name); inputs: seeded ``torch.Generator`` draws -- nothing but the outputs is stored.
+"""
+from typing import Callable, Dict
+
+import torch
+
+from cleandiffuser_amd.utils import load_synth
+from . import cases
+
+
+def _sample(agent, lib_kind: str, prior, zs, **kw):
+    """agent.sample on recorded draws: this repo takes ``noise=[...]``, the reference gets them through ``torch.randn_like``."""
+    dev = prior.device
+    if lib_kind == "amd":
+        return agent.sample(prior, noise=[z.to(dev) for z in zs], **kw)
+    with cases.replay_randn([z for z in zs]):
+        return agent.sample(prior, **kw)
+
+
+# --------------------------------------------------------------------------------------------------------------------- #
+def pearce(hidden: int, batch: int):
+    steps = 8
+
+    def run(lib, kind, device):
+        net = load_synth(lib.PearceMlp(6, To=1, emb_dim=32, hidden_dim=hidden), 3)
+        cond = load_synth(lib.PearceObsCondition(11, 32, flatten=True, dropout=0.0), 4)
+        agent = lib.DiscreteDiffusionSDE(net, cond, predict_noise=False, x_max=torch.ones(1, 6), x_min=-torch.ones(1, 6),
+                                         diffusion_steps=steps, device=device)
+        agent.eval()
+        g = torch.Generator().manual_seed(hidden)
+        obs = torch.randn(batch, 1, 11, generator=g)
+        zs = [torch.randn(batch, 6, generator=g) for _ in range(steps + 1)]
+        x, _ = _sample(agent, kind, torch.zeros(batch, 6, device=device), zs, solver="ddpm", n_samples=batch, sample_steps=steps,
+                       temperature=0.7, w_cfg=1.0, condition_cfg=obs.to(device))
+        return {"x": x}
+    return run
+
+
+def janner_long(horizon: int, dim_mult, model_dim: int):
+    D, B, steps = 6, 3, 3
+
+    def run(lib, kind, device):
+        net = load_synth(lib.JannerUNet1d(D, model_dim=model_dim, emb_dim=32, dim_mult=dim_mult, kernel_size=5), 11)
+        fm = torch.zeros(horizon, D)
+        fm[0, :4] = 1.0
+        agent = lib.DiscreteDiffusionSDE(net, None, fix_mask=fm, diffusion_steps=10, predict_noise=False, device=device)
+        agent.eval()
+        g = torch.Generator().manual_seed(horizon)
+        prior = torch.zeros(B, horizon, D)
+        prior[:, 0, :4] = torch.randn(B, 4, generator=g)
+        zs = [torch.randn(B, horizon, D, generator=g) for _ in range(steps + 1)]
+        x, _ = _sample(agent, kind, prior.to(device), zs, solver="ddim", n_samples=B, sample_steps=steps, temperature=0.8)
+        return {"x": x, "_agent": agent}
+    return run
+
+
+def shipped_diffuser(size: str):
+    """kitchen (H 32, D 69) / antmaze (H 64, D 37), model_dim 64, CumRewClassifier(HalfJannerUNet1d): stand-alone forward,
+    unguided loop, guided loop (w_cg 0.2) + the classifier's log_p."""
+    H, D, n_obs = (32, 69, 60) if size == "kitchen" else (64, 37, 29)
+    B, steps = 3, 3
+
+    def run(lib, kind, device):
+        net = load_synth(lib.JannerUNet1d(D, model_dim=64, emb_dim=64, dim_mult=[1, 2, 2, 2], kernel_size=5), 21)
+        clf_net = load_synth(lib.HalfJannerUNet1d(H, D, out_dim=1, model_dim=64, emb_dim=64, dim_mult=(1, 2, 2, 2), kernel_size=3), 22)
+        fm = torch.zeros(H, D)
+        fm[0, :n_obs] = 1.0
+        agent = lib.DiscreteDiffusionSDE(net, None, fix_mask=fm, classifier=lib.CumRewClassifier(clf_net, device=device),
+                                         diffusion_steps=10, predict_noise=False, device=device)
+        agent.eval()
+        agent.classifier.eval()
+        g = torch.Generator().manual_seed(5)
+        prior = torch.zeros(B, H, D)
+        prior[:, 0, :n_obs] = torch.randn(B, n_obs, generator=g)
+        zs = [torch.randn(B, H, D, generator=g) for _ in range(steps + 2)]
+        t = torch.tensor([1, 4, 8])
+        with torch.no_grad():
+            fwd = agent.model_ema["diffusion"](zs[0].to(device), t.to(device), None)
+        kw = dict(solver="ddpm", n_samples=B, sample_steps=steps, temperature=0.5)
+        x, _ = _sample(agent, kind, prior.to(device), zs, w_cg=0.0, **kw)
+        xg, log = _sample(agent, kind, prior.to(device), zs, w_cg=0.2, condition_cg=None, **kw)
+        return {"fwd": fwd, "x": x, "x_guided": xg, "log_p": log["log_p"], "_agent": agent}
+    return run
+
+
+def transformer(which: str):
+    B, steps = 3, 3
+
+    def run(lib, kind, device):
+        if which == "chitf_ta10":
+            net, x_shape, cond_shape = lib.ChiTransformer(7, 23, 10, 2, d_model=256, nhead=4, num_layers=3), (10, 7), (2, 23)
+        elif which == "dit_h10_d384":
+            net, x_shape, cond_shape = lib.DiT1d(7, emb_dim=64, d_model=384, n_heads=6, depth=2), (10, 7), (64,)
+        else:
+            net = lib.DiT1d(29, emb_dim=128, d_model=256, n_heads=8, depth=8, timestep_emb_type="fourier")
+            x_shape, cond_shape = (40, 29), (128,)
+        agent = lib.DiscreteDiffusionSDE(load_synth(net, 31), lib.IdentityCondition(dropout=0.0), predict_noise=True,
+                                         x_max=2 * torch.ones(1, *x_shape), x_min=-2 * torch.ones(1, *x_shape), diffusion_steps=20,
+                                         device=device)
+        agent.eval()
+        g = torch.Generator().manual_seed(len(which))
+        cond = torch.randn(B, *cond_shape, generator=g)
+        zs = [torch.randn(B, *x_shape, generator=g) for _ in range(steps + 1)]
+        x, _ = _sample(agent, kind, torch.zeros(B, *x_shape, device=device), zs, solver="ddim", n_samples=B, sample_steps=steps,
+                       w_cfg=1.3, condition_cfg=cond.to(device))
+        return {"x": x}
+    return run
+
+
+def chiunet_cfg3_width():
+    """ChiUNet1d at the BASELINE config-3 width (model_dim 256, 68.9 M parameters), legacy DDPM, 4 steps, B = 2."""
+    B, steps = 2, 4
+
+    def run(lib, kind, device):
+        net = load_synth(lib.ChiUNet1d(2, 20, 2, model_dim=256, emb_dim=256, dim_mult=[1, 2, 2], obs_as_global_cond=True), 41)
+        agent = lib.DDPM(net, lib.IdentityCondition(dropout=0.0), diffusion_steps=steps, x_max=torch.ones(1, 16, 2, device=device),
+                         x_min=-torch.ones(1, 16, 2, device=device), device=device)
+        agent.eval()
+        g = torch.Generator().manual_seed(41)
+        cond = torch.randn(B, 2, 20, generator=g)
+        zs = [torch.randn(B, 16, 2, generator=g) for _ in range(steps + 1)]
+        x, _ = _sample(agent, kind, torch.zeros(B, 16, 2, device=device), zs, n_samples=B, sample_steps=steps,
+                       condition_cfg=cond.to(device), w_cfg=1.0)
+        return {"x": x, "_agent": agent}
+    return run
+
+
+SCENARIOS: Dict[str, Callable] = {
+    "pearce_h64": pearce(64, 5), "pearce_h192": pearce(192, 37), "pearce_h512": pearce(512, 16),
+    "janner_h128": janner_long(128, [1, 2, 2, 2], 32), "janner_h64_w48": janner_long(64, [1, 4, 2], 48),
+    "diffuser_kitchen": shipped_diffuser("kitchen"), "diffuser_antmaze": shipped_diffuser("antmaze"),
+    "chitf_ta10": transformer("chitf_ta10"), "dit_h10_d384": transformer("dit_h10_d384"), "dit_h40_depth8": transformer("dit_h40_depth8"),
+    "chiunet_cfg3_width": chiunet_cfg3_width(),
+}
+
+
+def run(name: str, lib_kind: str, device="cpu"):
+    """Outputs of scenario `name` as {key: tensor}; keys starting with '_' are live objects for the caller, not results."""
+    torch.manual_seed(1234)
+    return SCENARIOS[name](cases.lib_namespace(lib_kind), lib_kind, device)

@@ -1,0 +1,17 @@
+"""CPU: this repo's PyTorch executor reproduces the extra reference fixtures (oracle/extra_cases.py: shipped widths, long
+horizons, model_dim-64 Diffuser nets with classifier guidance, transformer token counts, ChiUNet1d at the config-3 width) --
+the same fixtures the GPU tests hold the native kernels to at 1e-4."""
+import numpy as np
+import pytest
+
+from conftest import golden_path
+from oracle import extra_cases
+
+
+@pytest.mark.parametrize("name", sorted(extra_cases.SCENARIOS))
+def test_cpu_executor_reproduces_extra_reference_fixture(name):
+    gold = np.load(golden_path("extra_" + name))
+    out = extra_cases.run(name, "amd", "cpu")
+    assert set(gold.files) == {k for k in out if not k.startswith("_")}
+    for k in gold.files:
+        np.testing.assert_allclose(out[k].detach().numpy(), gold[k], rtol=2e-6, atol=2e-6, err_msg=f"{name}/{k}")

@@ -41,6 +41,28 @@ def test_lane_sim2_reproduces_reference_forward(name, amd_lib):
         np.testing.assert_allclose(sim.run_forward(row), gold["pred0"][b], rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("shape", [(32, 69, 64, [1, 2, 2, 2]), (16, 6, 32, [1, 2, 4])])
+def test_lane_sim2_wide_nets_against_module_forward(shape, amd_lib):
+    """Shapes that leave the one-item-per-wave regime: the shipped kitchen Diffuser net (64 channels x 32 positions = 8 tiles, so
+    waves loop over items of the tail table; concat layers with K slices cut at the source boundary; 2 float4 items per lane in the
+    epilogue; C_out = 69 padded to 128 lanes) and a 3-level net with a x4 channel step.  Against the module's own forward (which
+    is bit-identical to the reference's, tests/test_module_mirrors.py)."""
+    from cleandiffuser_amd.utils import load_synth
+    H, D, md, dm = shape
+    net = load_synth(amd_lib.JannerUNet1d(D, model_dim=md, emb_dim=32, dim_mult=dm, kernel_size=5), 9).eval()
+    prog = P2.compile_janner2(net, H)
+    assert prog.lds_bytes(1) <= 160 * 1024
+    assert max(int(op[P2.W2_NITEMS]) for op in prog.ops) > P2.NW2 or md < 64
+    g = torch.Generator().manual_seed(2)
+    x, t = torch.randn(1, H, D, generator=g), torch.tensor([11])
+    with torch.no_grad():
+        ref = net._forward_torch(x, t, None)[0].numpy()
+        row = emb_table(prog, net.map_noise(t).numpy())[0]
+    sim = LaneSim2(prog)
+    sim.load_x(x[0].numpy())
+    np.testing.assert_allclose(sim.run_forward(row), ref, rtol=2e-5, atol=2e-5)
+
+
 def test_program2_accounting_and_budget(amd_lib):
     """North-star config: 19.67 M MAC per forward (embedding MLP included), 47 conv ops (16 blocks x 2 +
     7 skip convs + 3 down + 3 up + 2 head), and TWO trajectories fit one workgroup's 160 KiB."""
