@@ -248,9 +248,10 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST"):      # (BENCH_FORCE_DIST=1: exercise the RCCL path on a single-GPU box)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         assert dist.get_world_size() == world == args.gpus, (dist.get_world_size(), world, args.gpus)
 
@@ -325,7 +326,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: JannerUNet1d Diffuser H=32 D=23, 20-step DDIM, "
                                    f"B={BATCH} trajectories per GPU, whole DiscreteDiffusionSDE.sample() call"
-                                   + (", then one RCCL all-gather of the N x 256 result" if world > 1 else ""),
+                                   + (", then one RCCL all-gather of the N x 256 result" if dist is not None else ""),
                        "batch_per_gpu": BATCH, "global_batch": BATCH * world, "horizon": HORIZON, "dim": DIM,
                        "sample_steps": SAMPLE_STEPS, "world_size": world,
                        "parallelism": f"batch-sharded x{world}; the only data-path collective is the all-gather of the result"},

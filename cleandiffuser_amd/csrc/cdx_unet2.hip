@@ -199,11 +199,13 @@ __device__ __forceinline__ void conv_kloop(const Geom& g, const float* __restric
         if (prof && item == 0) { asm volatile("" ::"v"(wr[0][0]), "v"(bq[0][0][0][0])); stamp(prof + 5, ptid); }
 
         // chunk at ring slot u (record index == u mod PF, PF % BD == 0 -> operand slot u % BD is static after unrolling)
+        // (the operand fetch is UNconditional -- past the item's last chunk it re-reads the last valid address -- and the loop below
+        //  leaves through one exit: with a fetch on only some paths the compiler cannot count the LDS queue any more and puts an
+        //  lgkmcnt(0) in front of every chunk's MFMAs, i.e. the full ds_read latency per record: measured 255 instead of ~130
+        //  cycles per 16x16 record)
         auto chunk = [&](const f32x4 a, const int u, bool more) {
-            if (more) {
-                advance();
-                fetch(bq[(u + BD - 1) % BD]);
-            }
+            if (more) advance();
+            fetch(bq[(u + BD - 1) % BD]);
 #pragma unroll
             for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -272,7 +274,8 @@ __device__ __forceinline__ void conv_kloop(const Geom& g, const float* __restric
         for (; qi < nq; qi += PF) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
-                if (qi + u < nq) chunk(wr[u], u, qi + u + BD - 1 < nq);
+                if (qi + u >= nq) break;                       // single exit: every chunk has exactly one predecessor
+                chunk(wr[u], u, qi + u + BD - 1 < nq);
                 const int q = qi + u - 1 + PF;                 // lagged refill of the previous position
                 if (q >= PF && q < nq) refill((u + PF - 1) % PF, q);
             }

