@@ -1,12 +1,14 @@
-// cdx_ops2.h -- word layout of the v2 U-Net program (csrc/cdx_unet2.hip): op descriptors of CDX2_OP_WORDS int32 and
-// work-item records of CDX2_ITEM_WORDS int32, both read with scalar loads.
+// cdx_ops2.h -- word layout of the v2 U-Net program (csrc/cdx_unet2.hip): op descriptors of CDX2_HDR_WORDS header words followed
+// by one inline CDX2_ITEM_WORDS-word work item per wave of the workgroup shape the program was compiled for (4 or 8 waves).
 // MUST mirror cleandiffuser_amd/engine/program2.py (tests/test_abi_contract.py parses this file and compares).
 #pragma once
 
-#define CDX2_OP_WORDS 64   /* 25 descriptor words (padded to 32) + CDX2_NW2 inline work items */
+#define CDX2_HDR_WORDS 32   /* 25 descriptor words, padded; == CDX2_W2_ITEM0 */
 #define CDX2_ITEM_WORDS 8
-#define CDX2_NW2 4        /* waves per workgroup, one per SIMD */
-#define CDX2_RING2 16     /* 1-KiB weight records in flight per wave */
+#define CDX2_NW2 4         /* waves per workgroup of the default shape (one per SIMD) */
+#define CDX2_NW2_MAX 8     /* ... and of the two-waves-per-SIMD shape */
+#define CDX2_RING2 16      /* 1-KiB weight records in flight per wave, 4-wave shape */
+#define CDX2_RING2_NW8 8   /* ... 8-wave shape */
 #define CDX2_GROUPS2 8    /* GroupNorm groups: 32 lanes per group in the epilogue */
 #define CDX2_MAX_NK2 4    /* float4 items one lane may own in the epilogue */
 #define CDX2_HALO2 2       /* zero rows on either side of an activation slot */
@@ -21,7 +23,7 @@
 #define CDX2_W2_MODE 7
 #define CDX2_W2_NT 8
 #define CDX2_W2_NITEMS 9
-#define CDX2_W2_ITEMS 10     /* word offset of items NW2.. (the first NW2 are inline at W2_ITEM0) */
+#define CDX2_W2_ITEMS 10     /* word offset of items n_waves.. (the first n_waves are inline at W2_ITEM0) */
 #define CDX2_W2_DST 11
 #define CDX2_W2_DST_STRIDE 12
 #define CDX2_W2_SSTRIDE 13

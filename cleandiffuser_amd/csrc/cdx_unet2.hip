@@ -36,9 +36,17 @@ static __device__ __forceinline__ const cint* as_const(const int* p) { return (c
 
 void cdx_set_err(const char* msg);          // cdx_unet1d.hip
 
-#define NW CDX2_NW2
-#define THREADS (NW * 64)
-#define PF CDX2_RING2
+// Workgroup shapes (template parameter NWV = wave64 per workgroup):
+//   4 waves, one per SIMD, 16 weight records in flight per wave -- up to 512 VGPRs per lane;
+//   8 waves, two per SIMD,  8 weight records in flight per wave -- 256 VGPRs per lane.  A lone wave on a SIMD issues about one
+//     instruction per four clocks and cannot keep the matrix pipe busy across its own ds_read / s_waitcnt bubbles (round-2 op
+//     profile: ~62 clk per 16x16x4 MFMA, 15-22 per 4x4x1, i.e. half rate); a second wave fills those slots.  With two
+//     trajectories per workgroup waves 0-3 / 4-7 also run the two epilogues side by side.
+template <int NWV> struct WG {
+    static constexpr int THREADS = NWV * 64;
+    static constexpr int PF = NWV == 8 ? 8 : 16;                                  // weight ring depth (1-KiB records per wave)
+    static constexpr int OPW = CDX2_HDR_WORDS + NWV * CDX2_ITEM_WORDS;             // words per op descriptor
+};
 
 namespace {
 
@@ -103,11 +111,18 @@ __device__ __forceinline__ Item load_item(const cint* it) {        // items past
                      it[CDX2_I2_PADOOFF], it[CDX2_I2_SRCSTR], it[CDX2_I2_CCN]);
 }
 
-// An op descriptor is 64 words = ONE coalesced dword load per wave: lane k holds word k, fields come out with v_readlane.
+// An op descriptor is read with ONE dword load per wave: lane k holds word k, fields come out with v_readlane.
 // (The scalar-load version of this kernel spent ~900 cycles per op waiting on dependent s_loads / spilling their results.)
 #define CDX2_DW(vd, k) __builtin_amdgcn_readlane((vd), (k))
-__device__ __forceinline__ Item inline_item(int vd, int j) {       // item j < NW of the descriptor held in `vd`
-    const int b = CDX2_W2_ITEM0 + j * CDX2_ITEM_WORDS;
+template <int NWV>
+__device__ __forceinline__ int load_desc(const int* __restrict__ ops, int op, int lane, int wave) {
+    const int w = lane < CDX2_HDR_WORDS ? lane : CDX2_HDR_WORDS + wave * CDX2_ITEM_WORDS + (lane & (CDX2_ITEM_WORDS - 1));
+    return ops[op * WG<NWV>::OPW + w];
+}
+// A wave's view `vd` of an op descriptor: lanes 0-31 hold the header words, lanes 32-39 the words of THIS wave's inline item
+// (item `wave` of the op) -- see load_desc(); every field comes out with a constant-lane v_readlane.
+__device__ __forceinline__ Item inline_item(int vd) {
+    const int b = CDX2_HDR_WORDS;
     return make_item(CDX2_DW(vd, b + CDX2_I2_WOFF), CDX2_DW(vd, b + CDX2_I2_NQ), CDX2_DW(vd, b + CDX2_I2_TAPCC),
                      CDX2_DW(vd, b + CDX2_I2_PART), CDX2_DW(vd, b + CDX2_I2_COL0), CDX2_DW(vd, b + CDX2_I2_PADOOFF),
                      CDX2_DW(vd, b + CDX2_I2_SRCSTR), CDX2_DW(vd, b + CDX2_I2_CCN));
@@ -119,8 +134,8 @@ __device__ __forceinline__ void stamp(unsigned long long* slot, int tid) {
 }
 
 // ---- weight ring -------------------------------------------------------------------------------------------------------
-// PF = 16 1-KiB records in flight per wave (a single wave per SIMD has to cover the whole L2 latency by itself).
-struct Ring { f32x4 rec[PF]; };       // head of this wave's next weight stream, issued one op ahead
+// PF 1-KiB records in flight per wave (a single wave per SIMD has to cover the whole L2 latency by itself: 16; two share it: 8).
+template <int PF> struct Ring { f32x4 rec[PF]; };       // head of this wave's next weight stream, issued one op ahead
 
 // K loop of one conv op for this wave: items wave, wave + 4, ...  The first item (and its ring contents) arrive from the
 // previous op; further items (layers with more than four tiles) are read from the descriptor / tail table here.
@@ -130,12 +145,20 @@ struct Ring { f32x4 rec[PF]; };       // head of this wave's next weight stream,
 // (tap, chunk): one add per chunk (`+ KSTEP`) and, every `ccn` chunks, one per-lane add for the tap step.  Columns past l_cols
 // sit on halo row 0 with a zero tap step.  Nothing else happens per record: wait, 4 MFMAs per (trajectory, column tile), one
 // ds_read per (trajectory, column tile), one global load.
-template <class M, int NT, int T>
+template <class M, int NT, int T, int NWV>
 __device__ __forceinline__ void conv_kloop(const Geom& g, const float* __restrict__ wblob, int vd, const cint* ops,
                                            Item it, int n_items, float* __restrict__ lds, int tf, int lane, int wave,
-                                           Ring& ring, unsigned long long* prof) {
-    // operand ring depth: 8 when a chunk is only 4 short MFMAs (32 cycles), else 4
-    constexpr int BD = (M::KSTEP == 4 && NT * T == 1) ? 8 : 4;
+                                           Ring<WG<NWV>::PF>& ring, unsigned long long* prof, int tune) {
+    constexpr int PF = WG<NWV>::PF, NW = NWV;
+    // operand ring depth: one wave per SIMD has to cover the ds_read latency with its own MFMAs -- 8 chunks when a chunk is only 4
+    // short MFMAs (32 cycles), else 4; with two waves per SIMD the other wave helps and registers are half as many
+    constexpr int BD = NWV == 4 ? ((M::KSTEP == 4 && NT * T == 1) ? 8 : 4)
+                                : (NT * T == 1 ? (M::KSTEP == 4 ? 8 : 4) : (NT * T == 2 ? 4 : 2));
+    // accumulators per tile: a record's four MFMAs on one tile must not form a dependent chain (a 4x4x1 MFMA is 2 passes; the
+    // compiler pads dependent pairs with s_nop): 4 independent MFMAs between dependent ones is enough
+    // (NA must not depend on T: the summation order of a trajectory is the same whether it shares a workgroup or not)
+    // (a 16x16x4 MFMA occupies the pipe as long as its result takes: two accumulators are plenty)
+    constexpr int NA = NWV == 4 ? 4 : ((M::KSTEP == 4 && NT == 1) ? 4 : 2);
     static_assert(PF % BD == 0, "operand ring must divide the weight ring");
     const int ptid = (wave == 0 && lane == 0) ? 0 : 1;          // stamp() fires for tid == 0 only
     for (int item = wave; item < n_items; item += NW) {
@@ -152,15 +175,13 @@ __device__ __forceinline__ void conv_kloop(const Geom& g, const float* __restric
             tstep[nt] = (valid ? it.sstr : 0) - ccn * M::KSTEP;
         }
         if (prof && item == 0) { asm volatile("" ::"s"(nq), "v"(cur[0])); stamp(prof + 4, ptid); }
-        // four accumulators per tile, one per K value of a record: a 4x4x1 MFMA is 2 passes, and with only two accumulators the
-        // compiler has to pad every dependent pair with s_nop (seen in the ISA: ~2 per record)
-        f32x4 acc[T][NT][4];
+        f32x4 acc[T][NT][NA];
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[t][nt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < NA; ++j) acc[t][nt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
         const f32x4* wp = reinterpret_cast<const f32x4*>(wblob + it.woff) + lane;
         f32x4 wr[PF];
@@ -189,14 +210,30 @@ __device__ __forceinline__ void conv_kloop(const Geom& g, const float* __restric
                 for (int nt = 0; nt < NT; ++nt) cur[nt] += tstep[nt];
             }
         };
+        // steady-state eligibility (see below): 4x4 layers whose taps span a multiple of PF chunks, K slice starting on such a
+        // boundary (the host cuts long streams that way), at least one full revolution before the drain
+        const bool aligned = M::KSTEP == 4 && (ccn % PF) == 0 && (it.cc % PF) == 0 && nq >= 2 * PF;
+        if (aligned) {                                         // the first BD - 1 chunks lie inside one tap: immediate offsets
 #pragma unroll
-        for (int j = 0; j < BD - 1; ++j) {
-            if (j < nq) {
-                if (j > 0) advance();
-                fetch(bq[j]);
+            for (int j = 0; j < BD - 1; ++j)
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        bq[j][t][nt] = *reinterpret_cast<const f32x4*>(lds + t * tf + cur[nt] + j * M::KSTEP);
+        } else {
+#pragma unroll
+            for (int j = 0; j < BD - 1; ++j) {
+                if (j < nq) {
+                    if (j > 0) advance();
+                    fetch(bq[j]);
+                }
             }
         }
         if (prof && item == 0) { asm volatile("" ::"v"(wr[0][0]), "v"(bq[0][0][0][0])); stamp(prof + 5, ptid); }
+        // two waves per SIMD: the arbiter favours the older wave (0-3), which then finishes its K loop well before its
+        // SIMD-mate and leaves it running alone at the single-wave rate; raising the younger wave's priority evens them out
+        if (NWV == 8 && (tune & 1) && wave >= 4) __builtin_amdgcn_s_setprio(1);
 
         // chunk at ring slot u (record index == u mod PF, PF % BD == 0 -> operand slot u % BD is static after unrolling)
         // (the operand fetch is UNconditional -- past the item's last chunk it re-reads the last valid address -- and the loop below
@@ -207,11 +244,12 @@ __device__ __forceinline__ void conv_kloop(const Geom& g, const float* __restric
             if (more) advance();
             fetch(bq[(u + BD - 1) % BD]);
 #pragma unroll
-            for (int t = 0; t < T; ++t)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
+                for (int t = 0; t < T; ++t)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[t][nt][j] = M::mfma(a[j], bq[u % BD][t][nt][j], acc[t][nt][j]);
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[t][nt][j % NA] = M::mfma(a[j], bq[u % BD][t][nt][j], acc[t][nt][j % NA]);
         };
 
         // The refill of a record is issued one chunk LATE (after the next chunk's MFMAs): the scheduler may hoist a load
@@ -226,12 +264,12 @@ __device__ __forceinline__ void conv_kloop(const Geom& g, const float* __restric
         // per SIMD the instruction count IS the speed of this loop (measured: 17 instructions per record = 100 cycles for 32
         // cycles of matrix work).  16x16 layers are short (tens of records) and take the general loop below.
         int qi = 0;
-        if (M::KSTEP == 4 && (ccn % PF) == 0 && (it.cc % PF) == 0) {
-            const int n_main = (nq / PF - 1) * PF;
+        if (aligned) {
+            const int n_main = (nq / PF - 1) * PF;             // >= PF
             // operand base of the current revolution's first chunk (bytes from the trajectory region), and of the next one's
             int rb[NT], rbn[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) rb[nt] = (cur[nt] - (nq >= BD - 1 ? BD - 2 : nq - 1) * M::KSTEP) * 4;
+            for (int nt = 0; nt < NT; ++nt) rb[nt] = cur[nt] * 4;
             int cc0 = it.cc;                                   // chunk-in-tap of the revolution's first chunk
             const char* ldsb = reinterpret_cast<const char*>(lds);
             for (; qi < n_main; qi += PF) {
@@ -249,12 +287,12 @@ __device__ __forceinline__ void conv_kloop(const Geom& g, const float* __restric
                             bq[ua % BD][t][nt] = *reinterpret_cast<const f32x4*>(
                                 ldsb + (ua < PF ? rb[nt] : rbn[nt]) + t * tf * 4 + (ua % PF) * M::KSTEP * 4);
 #pragma unroll
-                    for (int t = 0; t < T; ++t)
+                    for (int j = 0; j < 4; ++j)
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
+                        for (int t = 0; t < T; ++t)
 #pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                acc[t][nt][j] = M::mfma(wr[u][j], bq[u % BD][t][nt][j], acc[t][nt][j]);
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[t][nt][j % NA] = M::mfma(wr[u][j], bq[u % BD][t][nt][j], acc[t][nt][j % NA]);
                     if (u > 0) refill(u - 1, qi + u - 1 + PF);
                     else if (qi > 0) refill(PF - 1, qi - 1 + PF);
                     // one refill per chunk, in place: left to itself the scheduler batches the 16 loads of a revolution into
@@ -264,11 +302,10 @@ __device__ __forceinline__ void conv_kloop(const Geom& g, const float* __restric
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) rb[nt] = rbn[nt];
             }
-            if (qi > 0) {                                      // hand the cursor to the general loop: it sits on chunk qi + BD - 2
-                cc = cc0 + BD - 2;
+            // hand the cursor to the general loop: it sits on chunk qi + BD - 2
+            cc = cc0 + BD - 2;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) cur[nt] = rb[nt] / 4 + (BD - 2) * M::KSTEP;
-            }
+            for (int nt = 0; nt < NT; ++nt) cur[nt] = rb[nt] / 4 + (BD - 2) * M::KSTEP;
         }
         // drain: the last (up to 2*PF - 1) records, refilling only while records remain
         for (; qi < nq; qi += PF) {
@@ -280,6 +317,7 @@ __device__ __forceinline__ void conv_kloop(const Geom& g, const float* __restric
                 if (q >= PF && q < nq) refill((u + PF - 1) % PF, q);
             }
         }
+        if (NWV == 8 && (tune & 1)) __builtin_amdgcn_s_setprio(0);
         if (prof && item == 0) { asm volatile("" ::"v"(acc[0][0][0][0]), "v"(acc[0][0][1][0])); stamp(prof + 6, ptid); }
         // D fragment: 4 consecutive rows (channels) of one column -> stage[k slice][output position][row tile + rows]
 #pragma unroll
@@ -288,7 +326,9 @@ __device__ __forceinline__ void conv_kloop(const Geom& g, const float* __restric
             for (int nt = 0; nt < NT; ++nt) {
                 if (mcol[nt] < g.l_cols) {
                     const int n = mcol[nt] * g.ostride + it.ooff;
-                    const f32x4 dd = (acc[t][nt][0] + acc[t][nt][1]) + (acc[t][nt][2] + acc[t][nt][3]);
+                    f32x4 dd = acc[t][nt][0];
+                    if (NA == 2) dd += acc[t][nt][NA - 1];
+                    if (NA == 4) dd = (acc[t][nt][0] + acc[t][nt][1]) + (acc[t][nt][NA / 2] + acc[t][nt][NA - 1]);
                     *reinterpret_cast<f32x4*>(lds + t * tf + g.stage + it.part + n * g.sstride + M::drow(lane)) = dd;
                 }
             }
@@ -340,9 +380,23 @@ __device__ __forceinline__ void epilogue(float* __restrict__ tl, const EpiParams
     for (int k = 0; k < NK; ++k) {
         ok[k] = li + 32 * k < nv;
         const int pos = ok[k] ? pos0 + k * pstep : 0;
+        // bias + partial 0 + partial 1 + ... in this order; the reads go out four / two at a time so that their ~130-cycle
+        // latencies overlap instead of adding up (8 waves: up to 8 K slices per tile)
         f32x4 acc = P.bi;
-        for (int ks = 0; ks < e.ksplit; ++ks)
-            acc += *reinterpret_cast<const f32x4*>(tl + stage + (ks * e.l_out + pos) * e.sstride + c);
+        const float* sp = tl + stage + pos * e.sstride + c;
+        const int kstep = e.l_out * e.sstride;
+        int ks = 0;
+        for (; ks + 4 <= e.ksplit; ks += 4, sp += 4 * kstep) {
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(sp), p1 = *reinterpret_cast<const f32x4*>(sp + kstep);
+            const f32x4 p2 = *reinterpret_cast<const f32x4*>(sp + 2 * kstep), p3 = *reinterpret_cast<const f32x4*>(sp + 3 * kstep);
+            acc += p0; acc += p1; acc += p2; acc += p3;
+        }
+        if (ks + 2 <= e.ksplit) {
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(sp), p1 = *reinterpret_cast<const f32x4*>(sp + kstep);
+            acc += p0; acc += p1;
+            ks += 2; sp += 2 * kstep;
+        }
+        if (ks < e.ksplit) acc += *reinterpret_cast<const f32x4*>(sp);
         v[k] = acc;
     }
     if (e.flags & CDX2_F2_GN) {
@@ -387,65 +441,81 @@ __device__ __forceinline__ void epilogue(float* __restrict__ tl, const EpiParams
 
 // Issue the first PF records of item `it` (this wave's first item of the next op) into the ring.  No clamp to the item's
 // record count: the blob ends with PF records of padding, slots past `nq` are simply never consumed.
-__device__ __forceinline__ void prefetch_ring(const Item& it, const float* __restrict__ wblob, int lane, Ring& ring) {
+template <int PF>
+__device__ __forceinline__ void prefetch_ring(const Item& it, const float* __restrict__ wblob, int lane, Ring<PF>& ring) {
     const f32x4* wp = reinterpret_cast<const f32x4*>(wblob + it.woff) + lane;
 #pragma unroll
     for (int u = 0; u < PF; ++u) ring.rec[u] = wp[(size_t)u * 64];
 }
 
-// One op.  `vd`: this op's descriptor (one word per lane), `it`: this wave's first item, both fetched during the previous op;
+// One op.  `vd`: this wave's view of the op's descriptor, `it`: this wave's first item, both fetched during the previous op;
 // `vdn`: the next op's descriptor, whose load was issued before this call.  Leaves the next op's first item in `it`.
-template <int T>
+// Epilogue threads: 256 per trajectory (8 GroupNorm groups x 32 lanes).  4 waves: all of them, one trajectory after the other;
+// 8 waves, T = 2: waves 0-3 take trajectory 0 while waves 4-7 take trajectory 1; 8 waves, T = 1: waves 0-3 run the epilogue,
+// waves 4-7 rewrite the destination's halo rows.
+template <int T, int NWV>
 __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* ops, int vd, int vdn, Item& it,
-                                       const float* __restrict__ emb_row, float* __restrict__ lds, int tid, Ring& ring,
-                                       unsigned long long* prof) {
+                                       const float* __restrict__ emb_row, float* __restrict__ lds, int tid,
+                                       Ring<WG<NWV>::PF>& ring, unsigned long long* prof) {
+    constexpr bool SPLIT_T = NWV == 8 && T == 2;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tf = L.traj_floats;
     const int flags = CDX2_DW(vd, CDX2_W2_FLAGS), coutp = CDX2_DW(vd, CDX2_W2_COUTP), shift = CDX2_DW(vd, CDX2_W2_CG4_SHIFT);
     const int l_out = CDX2_DW(vd, CDX2_W2_LOUT), sstride = CDX2_DW(vd, CDX2_W2_SSTRIDE);
     const Geom g{CDX2_DW(vd, CDX2_W2_LCOLS), CDX2_DW(vd, CDX2_W2_CSTRIDE), CDX2_DW(vd, CDX2_W2_OSTRIDE), sstride, L.stage_off};
+    const bool epi_wave = NWV == 4 || SPLIT_T || wave < 4;
+    const bool halo_wave = NWV == 4 || SPLIT_T || wave >= 4;
 
     // epilogue geometry + per-channel parameters: issued now, consumed after the barrier (latency hides behind the K loop)
-    const int grp = tid >> 5, li = tid & 31;
+    const int etid = tid & 255;
+    const int grp = etid >> 5, li = etid & 31;
     const int c = grp * (coutp >> 3) + 4 * (li & ((1 << shift) - 1));
     const int pos0 = li >> shift, pstep = 32 >> shift;
     const int nv = (coutp >> 5) * l_out;
     EpiParams P;
-    P.bi = *reinterpret_cast<const f32x4*>(L.wblob + CDX2_DW(vd, CDX2_W2_BOFF) + c);
-    P.ga = P.be = P.em = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (flags & CDX2_F2_GN) {
-        P.ga = *reinterpret_cast<const f32x4*>(L.wblob + CDX2_DW(vd, CDX2_W2_GAMMA) + c);
-        P.be = *reinterpret_cast<const f32x4*>(L.wblob + CDX2_DW(vd, CDX2_W2_BETA) + c);
+    P.bi = P.ga = P.be = P.em = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (epi_wave) {
+        P.bi = *reinterpret_cast<const f32x4*>(L.wblob + CDX2_DW(vd, CDX2_W2_BOFF) + c);
+        if (flags & CDX2_F2_GN) {
+            P.ga = *reinterpret_cast<const f32x4*>(L.wblob + CDX2_DW(vd, CDX2_W2_GAMMA) + c);
+            P.be = *reinterpret_cast<const f32x4*>(L.wblob + CDX2_DW(vd, CDX2_W2_BETA) + c);
+        }
+        if (flags & CDX2_F2_EMB) P.em = *reinterpret_cast<const f32x4*>(emb_row + CDX2_DW(vd, CDX2_W2_EMB) + c);
     }
-    if (flags & CDX2_F2_EMB) P.em = *reinterpret_cast<const f32x4*>(emb_row + CDX2_DW(vd, CDX2_W2_EMB) + c);
 
     // K loop -> staged partial tiles
     const int n_items = CDX2_DW(vd, CDX2_W2_NITEMS);
     if (CDX2_DW(vd, CDX2_W2_MODE) == CDX_MODE_4X4) {
-        if (CDX2_DW(vd, CDX2_W2_NT) == 1) conv_kloop<M4, 1, T>(g, L.wblob, vd, ops, it, n_items, lds, tf, lane, wave, ring, prof);
-        else conv_kloop<M4, 2, T>(g, L.wblob, vd, ops, it, n_items, lds, tf, lane, wave, ring, prof);
+        if (CDX2_DW(vd, CDX2_W2_NT) == 1) conv_kloop<M4, 1, T, NWV>(g, L.wblob, vd, ops, it, n_items, lds, tf, lane, wave, ring, prof, L.tune);
+        else conv_kloop<M4, 2, T, NWV>(g, L.wblob, vd, ops, it, n_items, lds, tf, lane, wave, ring, prof, L.tune);
     } else {
-        conv_kloop<M16, 1, T>(g, L.wblob, vd, ops, it, n_items, lds, tf, lane, wave, ring, prof);
+        conv_kloop<M16, 1, T, NWV>(g, L.wblob, vd, ops, it, n_items, lds, tf, lane, wave, ring, prof, L.tune);
     }
     stamp(prof ? prof + 7 : nullptr, tid);
     // head of the next op's weight stream: flies through the barrier and the epilogue
-    it = inline_item(vdn, wave);
+    it = inline_item(vdn);
     if (wave < CDX2_DW(vdn, CDX2_W2_NITEMS)) prefetch_ring(it, L.wblob, lane, ring);
     stamp(prof ? prof + 1 : nullptr, tid);
     __syncthreads();
     stamp(prof ? prof + 2 : nullptr, tid);
 
     const EpiDesc e = decode_epi(vd);
+    const int t_lo = SPLIT_T ? (wave >> 2) : 0, t_hi = SPLIT_T ? t_lo + 1 : T;
 #pragma unroll 1
-    for (int t = 0; t < T; ++t) {
+    for (int t = t_lo; t < t_hi; ++t) {
         float* tl = lds + t * tf;
-        if (e.nk == 1) epilogue<1>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane);
-        else if (e.nk == 2) epilogue<2>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane);
-        else epilogue<CDX2_MAX_NK2>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane);
-        // wave w rewrites halo row w of the destination (the arena hands this LDS to slots of other shapes in between)
-        const int hrow = wave < CDX2_HALO2 ? wave : e.l_out + wave;
-        for (int j = lane * 4; j < e.dstride; j += 256)
-            *reinterpret_cast<f32x4*>(tl + e.dst + hrow * e.dstride + j) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (epi_wave) {
+            if (e.nk == 1) epilogue<1>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane);
+            else if (e.nk == 2) epilogue<2>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane);
+            else epilogue<CDX2_MAX_NK2>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane);
+        }
+        if (halo_wave) {
+            // wave w (mod 4) rewrites halo row w of the destination (the arena hands this LDS to slots of other shapes in between)
+            const int hw = wave & 3;
+            const int hrow = hw < CDX2_HALO2 ? hw : e.l_out + hw;
+            for (int j = lane * 4; j < e.dstride; j += 256)
+                *reinterpret_cast<f32x4*>(tl + e.dst + hrow * e.dstride + j) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
     }
     __syncthreads();
     stamp(prof ? prof + 3 : nullptr, tid);
@@ -453,8 +523,9 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
 
 // T = 1: two workgroups per CU must be able to co-reside (that is what hides this latency-bound kernel's stalls from B = 512
 // on), i.e. at most 256 VGPR + AGPR per lane -- the second launch-bound argument is waves per SIMD.
-template <int T>
-__global__ __launch_bounds__(THREADS, (T == 1 ? 2 : 1)) void cdx_unet2_kernel(const cdx_unet2_launch L) {
+template <int T, int NWV>
+__global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_unet2_kernel(const cdx_unet2_launch L) {
+    constexpr int THREADS = WG<NWV>::THREADS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -466,9 +537,9 @@ __global__ __launch_bounds__(THREADS, (T == 1 ? 2 : 1)) void cdx_unet2_kernel(co
 
     // descriptor + first item + weight stream of op 0 first: they fly while the state is set up
     const cint* ops = as_const(L.ops);
-    int vd = L.ops[lane];
-    Item it = inline_item(vd, wave);
-    Ring ring;
+    int vd = load_desc<NWV>(L.ops, 0, lane, wave);
+    Item it = inline_item(vd);
+    Ring<WG<NWV>::PF> ring;
     if (wave < CDX2_DW(vd, CDX2_W2_NITEMS)) prefetch_ring(it, L.wblob, lane, ring);
 
     // ---- clear the workgroup's LDS once (halo rows and pad channels of the state slots), then load x_T ----
@@ -491,11 +562,11 @@ __global__ __launch_bounds__(THREADS, (T == 1 ? 2 : 1)) void cdx_unet2_kernel(co
         const float* __restrict__ emb_row = L.emb + (size_t)step * L.emb_ld;
         for (int oi = 0; oi < L.n_ops; ++oi) {
             // next op's descriptor (the last op fetches op 0 of the next step): one coalesced load, needed after the K loop
-            const int vdn = L.ops[(oi + 1 < L.n_ops ? oi + 1 : 0) * CDX2_OP_WORDS + lane];
+            const int vdn = load_desc<NWV>(L.ops, oi + 1 < L.n_ops ? oi + 1 : 0, lane, wave);
             // (profile the SECOND forward when there is one: instruction / scalar caches warm, like every later step)
             unsigned long long* pslot = (profiling && step == (L.n_steps > 1 ? 1 : 0)) ? lprof + (size_t)oi * 8 : nullptr;
             stamp(pslot, tid);
-            run_op<T>(L, ops, vd, vdn, it, emb_row, lds, tid, ring, pslot);
+            run_op<T, NWV>(L, ops, vd, vdn, it, emb_row, lds, tid, ring, pslot);
             vd = vdn;
         }
         if (L.n_steps == 0) break;
@@ -633,6 +704,7 @@ int cdx_unet2_run(const cdx_unet2_launch* L, void* hip_stream) {
     if (L->batch == 0) return CDX_OK;
     if (L->n_ops <= 0 || L->batch < 0 || L->horizon <= 0 || L->dim <= 0 || L->traj_floats <= 0) { cdx_set_err("non-positive size"); return CDX_EINVAL; }
     if (L->traj_per_wg != 1 && L->traj_per_wg != 2) { cdx_set_err("traj_per_wg must be 1 or 2"); return CDX_EINVAL; }
+    if (L->n_waves != 4 && L->n_waves != 8) { cdx_set_err("n_waves must be 4 or 8 (the program is compiled for one of them)"); return CDX_EINVAL; }
     if (L->n_steps > 0 && !L->steps) { cdx_set_err("steps == NULL with n_steps > 0"); return CDX_EINVAL; }
     if (L->n_steps < 0) { cdx_set_err("negative n_steps"); return CDX_EINVAL; }
     if (L->fix_mask && !L->prior) { cdx_set_err("fix_mask given without prior"); return CDX_EINVAL; }
@@ -642,11 +714,12 @@ int cdx_unet2_run(const cdx_unet2_launch* L, void* hip_stream) {
     size_t lds_bytes = (size_t)L->traj_floats * L->traj_per_wg * sizeof(float);
     if (L->prof) lds_bytes += (size_t)(L->n_ops * 8 + 2) * sizeof(unsigned long long);
     if (lds_bytes > 160u * 1024u) { cdx_set_err("program needs more than 160 KiB of LDS"); return CDX_ELDS; }
-    auto kern = L->traj_per_wg == 2 ? cdx_unet2_kernel<2> : cdx_unet2_kernel<1>;
+    auto kern = L->n_waves == 8 ? (L->traj_per_wg == 2 ? cdx_unet2_kernel<2, 8> : cdx_unet2_kernel<1, 8>)
+                                : (L->traj_per_wg == 2 ? cdx_unet2_kernel<2, 4> : cdx_unet2_kernel<1, 4>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
     const int grid = (L->batch + L->traj_per_wg - 1) / L->traj_per_wg;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds_bytes, reinterpret_cast<hipStream_t>(hip_stream), *L);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(L->n_waves * 64), lds_bytes, reinterpret_cast<hipStream_t>(hip_stream), *L);
     e = hipGetLastError();
     if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
     return CDX_OK;

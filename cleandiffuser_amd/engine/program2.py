@@ -5,9 +5,10 @@ Same idea as ``program.py`` (one launch = the whole ``sample()`` loop, activatio
 per-op latency and by *instruction issue* (a wave64 issues about one instruction every four clocks), so everything the K loop
 does per weight record beyond "wait, 4 MFMAs, one LDS read, one global load" was designed out on the host side:
 
-* **4 wave64 per workgroup, one per SIMD**; a conv's output is cut into (row tile x column group) *tiles*, one work item per
-  wave; a layer with fewer than four tiles splits K over the spare waves.  Items are 8-word records; a wave's first item sits
-  INSIDE the op descriptor (words ``W2_ITEM0``...), so it is found at a fixed offset without a dependent load.
+* **4 or 8 wave64 per workgroup** (one or two per SIMD; a program is compiled for ONE shape, ``Program2.nw``); a conv's output
+  is cut into (row tile x column group) *tiles*, one work item per wave; a layer with fewer tiles than waves splits K over the
+  spare waves.  Items are 8-word records; a wave's first item sits INSIDE the op descriptor (words ``W2_ITEM0 + 8 * wave``...),
+  so it is found at a fixed offset without a dependent load.
 * **A work item reads ONE source slot with a row that is LINEAR in the tap.**  Slots carry a ``HALO2``-row zero halo, so zero
   padding needs no predicate and a tap change is one per-lane add.  A channel concat (reference jannerunet.py:193
   ``torch.cat([x, skip])``) is never materialised and never switched inside the loop: the K slices of such a layer are cut
@@ -38,10 +39,12 @@ import torch.nn as nn
 
 from .program import (GN_EPS, MODE_16X16, MODE_4X4, _conv1d_eff, _convT1d_eff, _fbits, slot_stride, supports_janner)
 
-OP2_WORDS = 64                # 29 descriptor words (padded to 32) + NW2 inline work items
+HDR_WORDS = 32                # 25 descriptor words, padded
 ITEM2_WORDS = 8
-NW2 = 4                       # waves per workgroup
-RING2 = 16                    # weight records in flight per wave
+NW2 = 4                       # waves per workgroup, default shape (one per SIMD)
+NW2_MAX = 8                   # ... two per SIMD
+RING2 = 16                    # weight records in flight per wave, 4-wave shape
+RING2_NW8 = 8                 # ... 8-wave shape
 GROUPS2 = 8                   # GroupNorm groups the epilogue partition is built for (32 lanes per group)
 MAX_NK2 = 4                   # float4 items a lane may own in the epilogue
 HALO2 = 2                     # zero rows on either side of a slot: covers kernel sizes <= 5 (pad <= 2)
@@ -49,7 +52,16 @@ HALO2 = 2                     # zero rows on either side of a slot: covers kerne
 (W2_KIND, W2_FLAGS, W2_COUT, W2_LOUT, W2_LCOLS, W2_CSTRIDE, W2_OSTRIDE, W2_MODE, W2_NT, W2_NITEMS, W2_ITEMS, W2_DST,
  W2_DST_STRIDE, W2_SSTRIDE, W2_KSPLIT, W2_BOFF, W2_GAMMA, W2_BETA, W2_EMB, W2_RES, W2_RES_STRIDE, W2_CG4_SHIFT, W2_INV_CNT,
  W2_NK, W2_COUTP) = range(25)
-W2_ITEM0 = 32                 # items 0..NW2-1 inline; items NW2.. in the tail table at W2_ITEMS
+W2_ITEM0 = 32                 # items 0..nw-1 inline; items nw.. in the tail table at W2_ITEMS
+
+
+def op_words(nw: int) -> int:
+    """int32 words per op descriptor of a program compiled for `nw` waves (cdx.h: CDX2_OP_WORDS(n_waves))."""
+    return HDR_WORDS + ITEM2_WORDS * nw
+
+
+def ring_depth(nw: int) -> int:
+    return {4: RING2, 8: RING2_NW8}[nw]
 # item record: blob offset of the first record, record count, start cursor (tap | chunk << 8), stage offset of the partial tile,
 # first column, (pad | output-position offset << 8), source slot (float offset | row stride << 16), chunks per tap
 I2_WOFF, I2_NQ, I2_TAPCC, I2_PART, I2_COL0, I2_PADOOFF, I2_SRCSTR, I2_CCN = range(8)
@@ -87,7 +99,7 @@ class Act:
 
 @dataclass
 class Program2:
-    ops: np.ndarray                    # int32 [n_ops, OP2_WORDS]
+    ops: np.ndarray                    # int32 [n_ops, op_words(nw)]
     ops_buffer: np.ndarray             # int32 1-D: ops followed by the item tables
     blob: torch.Tensor                 # float32 1-D on the module's device
     traj_floats: int                   # LDS floats per trajectory
@@ -105,6 +117,7 @@ class Program2:
     macs_per_forward: int = 0
     n_conv: int = 0
     meta: dict = field(default_factory=dict)
+    nw: int = NW2                      # waves per workgroup the work items were cut for
 
     def lds_bytes(self, traj_per_wg: int) -> int:
         return 4 * self.traj_floats * traj_per_wg
@@ -128,8 +141,11 @@ def _records(w_eff: torch.Tensor, mode: int) -> Tuple[torch.Tensor, int]:
 
 
 class _Builder2:
-    def __init__(self, device):
+    def __init__(self, device, nw: int = NW2):
+        if nw not in (NW2, NW2_MAX):
+            raise ValueError(f"v2 programs are compiled for {NW2} or {NW2_MAX} waves, not {nw}")
         self.device = device
+        self.nw = nw
         self.ops: List[List[int]] = []
         self.op_acts: List[Tuple[List[Act], Act]] = []     # (slots read: sources [+ residual], slot written) per op
         self.op_item_src: List[List[int]] = []            # per op, per item: index of the source slot it reads
@@ -200,12 +216,17 @@ class _Builder2:
         nqt = sum(seg_n)
         # K slices: cut every source's record range evenly; with two sources (a concat) the slices never straddle the boundary,
         # whatever the tile count -- each source gets at least one slice and the epilogue sums the staged partials
-        per_src = max(1, (NW2 // tiles if tiles < NW2 else 1) // len(srcs))
+        nw, ring = self.nw, ring_depth(self.nw)
+        per_src = max(1, (nw // tiles if tiles < nw else 1) // len(srcs))
         per_src = [min(per_src, n) for n in seg_n]
         ksplit = sum(per_src)
         cuts, base = [], 0                                  # (first record, one past the last, source index) per slice
         for si, (n, k) in enumerate(zip(seg_n, per_src)):
-            cuts += [(base + j * n // k, base + (j + 1) * n // k, si, base) for j in range(k)]
+            # long streams are cut on multiples of the ring depth: the kernel's immediate-offset steady loop needs a slice to start
+            # on a ring-aligned chunk of its tap
+            al = ring if n >= 2 * ring * k else 1
+            edge = [min(n, (j * n // k + al // 2) // al * al) for j in range(k)] + [n]
+            cuts += [(base + edge[j], base + edge[j + 1], si, base) for j in range(k)]
             base += n
         woffs = [self.add(torch.cat([r for r, _ in segs], dim=1).contiguous()) for segs in streams]
         items, item_src = [], []
@@ -247,7 +268,7 @@ class _Builder2:
         if pred:
             flags |= F2_PRED
         words[W2_FLAGS] = flags
-        op = [0] * OP2_WORDS
+        op = [0] * op_words(self.nw)
         for k, v in words.items():
             op[k] = int(v)
         self.ops.append(op)
@@ -288,10 +309,11 @@ class _Builder2:
 
 
 def op_item(ops_buffer: np.ndarray, op: np.ndarray, j: int) -> np.ndarray:
-    """Work item `j` of `op` (a row of Program2.ops): inline in the descriptor for j < NW2, else in the tail table."""
-    if j < NW2:
+    """Work item `j` of `op` (a row of Program2.ops): inline in the descriptor for j < nw, else in the tail table."""
+    nw = (len(op) - HDR_WORDS) // ITEM2_WORDS
+    if j < nw:
         return op[W2_ITEM0 + j * ITEM2_WORDS: W2_ITEM0 + (j + 1) * ITEM2_WORDS]
-    lo = int(op[W2_ITEMS]) + (j - NW2) * ITEM2_WORDS
+    lo = int(op[W2_ITEMS]) + (j - nw) * ITEM2_WORDS
     return ops_buffer[lo: lo + ITEM2_WORDS]
 
 
@@ -300,13 +322,13 @@ def _padded(v: torch.Tensor, n: int) -> torch.Tensor:
     return torch.cat([v, torch.zeros(n - v.numel(), device=v.device)]) if v.numel() < n else v
 
 
-def compile_janner2(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x4: bool = True) -> Program2:
-    """Lower a JannerUNet1d (reference nn_diffusion/jannerunet.py:98-201) for `horizon` positions."""
+def compile_janner2(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x4: bool = True, nw: int = NW2) -> Program2:
+    """Lower a JannerUNet1d (reference nn_diffusion/jannerunet.py:98-201) for `horizon` positions and `nw` waves per workgroup."""
     why = supports_janner(net)
     if why is not None:
         raise ValueError(why)
     dev = next(net.parameters()).device
-    b = _Builder2(dev)
+    b = _Builder2(dev, nw)
     b.allow_4x4 = allow_4x4
     d, k, md = net.in_dim, net.kernel_size, net.model_dim
 
@@ -376,18 +398,18 @@ def compile_janner2(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x
     top = (b.plan_arena(off) + 3) // 4 * 4
     if top * 4 > max_lds_bytes:
         raise ValueError(f"LDS plan needs {top * 4} B > {max_lds_bytes} B per trajectory")
-    tail, cursor = [], len(b.ops) * OP2_WORDS
+    tail, cursor = [], len(b.ops) * op_words(nw)
     for op, items in zip(b.ops, b.op_items):
-        for j, rec in enumerate(items[:NW2]):             # a wave's first item: fixed offset inside the descriptor
+        for j, rec in enumerate(items[:nw]):              # a wave's first item: fixed offset inside the descriptor
             op[W2_ITEM0 + j * ITEM2_WORDS: W2_ITEM0 + (j + 1) * ITEM2_WORDS] = rec
         op[W2_ITEMS] = cursor
-        tail += [w for rec in items[NW2:] for w in rec]
-        cursor += len(items[NW2:]) * ITEM2_WORDS
+        tail += [w for rec in items[nw:] for w in rec]
+        cursor += len(items[nw:]) * ITEM2_WORDS
     ops = np.asarray(b.ops, dtype=np.int32)
     ops_buffer = np.concatenate([ops.reshape(-1), np.asarray(tail, dtype=np.int64).astype(np.int32)])
-    b.add(torch.zeros(RING2 * 256))          # the ring prefetch reads RING2 records from an item's first one, whatever its length
+    b.add(torch.zeros(RING2 * 256))          # the ring prefetch reads a ring of records from an item's first one, whatever its length
     blob = torch.cat(b.chunks).contiguous()
     return Program2(ops=ops, ops_buffer=ops_buffer, blob=blob, traj_floats=top, x_off=x.data_off,
                     x_stride=x.stride, pred_off=pred.data_off, pred_stride=pred.stride, prev_off=prev_off, stage_off=stage_off,
                     horizon=horizon, dim=d, emb_dim=net.emb_dim, n_emb=b.n_emb, embtab=emb, macs_per_forward=b.macs,
-                    n_conv=len(b.ops), meta={"blob_floats": b.blob_len})
+                    n_conv=len(b.ops), meta={"blob_floats": b.blob_len}, nw=nw)

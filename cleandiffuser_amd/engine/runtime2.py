@@ -29,6 +29,7 @@ class CdxUnet2EmbtabArgs(ctypes.Structure):
 class CdxUnet2Launch(ctypes.Structure):
     _fields_ = [("ops", ctypes.c_void_p), ("wblob", ctypes.c_void_p),
                 ("n_ops", ctypes.c_int32), ("traj_floats", ctypes.c_int32), ("traj_per_wg", ctypes.c_int32),
+                ("n_waves", ctypes.c_int32), ("tune", ctypes.c_int32),
                 ("x_off", ctypes.c_int32), ("x_stride", ctypes.c_int32),
                 ("pred_off", ctypes.c_int32), ("pred_stride", ctypes.c_int32), ("prev_off", ctypes.c_int32),
                 ("stage_off", ctypes.c_int32),
@@ -68,19 +69,20 @@ def enabled() -> bool:
     return os.environ.get("CDX_UNET2", "1") != "0"
 
 
-def compiled2(module, horizon: int) -> _Compiled2:
-    """The module's v2 program at this horizon (``.prog is None`` + ``.why`` when the v2 compiler does not take it)."""
+def compiled2(module, horizon: int, nw: int = P2.NW2) -> _Compiled2:
+    """The module's v2 program at this horizon for `nw` waves per workgroup (``.prog is None`` + ``.why`` when the v2 compiler
+    does not take it)."""
     per_mod = _cache.setdefault(module, {})
     sig = R._signature(module)
-    hit = per_mod.get(horizon)
+    hit = per_mod.get((horizon, nw))
     if hit is not None and hit.sig == sig:
         return hit
     with torch.no_grad():
         try:
-            comp = _Compiled2(P2.compile_janner2(module, horizon), sig)
+            comp = _Compiled2(P2.compile_janner2(module, horizon, nw=nw), sig)
         except (ValueError, AssertionError) as e:
             comp = _Compiled2(None, sig, str(e))
-    per_mod[horizon] = comp
+    per_mod[(horizon, nw)] = comp
     return comp
 
 
@@ -135,6 +137,34 @@ def traj_per_wg(prog: P2.Program2, batch: int) -> int:
     return t
 
 
+def n_waves(batch: int) -> int:
+    """Waves per workgroup (the program is compiled per shape): 8 = two wave64 per SIMD.  CDX_UNET2_NW forces 4 or 8."""
+    forced = os.environ.get("CDX_UNET2_NW")
+    return int(forced) if forced in ("4", "8") else DEFAULT_NW
+
+
+DEFAULT_NW = 8
+DEFAULT_TUNE = 0
+
+
+def shape_for(module, horizon: int, batch: int):
+    """(compiled program, trajectories per workgroup) the launch of `batch` trajectories uses.  The 8-wave shape stages more K
+    slices, so its LDS plan is a little larger: when two of them do not fit next to each other but two of the 4-wave plan do,
+    a batch that wants two trajectories per workgroup takes the 4-wave program."""
+    nw = n_waves(batch)
+    comp = compiled2(module, horizon, nw)
+    if comp.prog is None and nw != P2.NW2:
+        comp = compiled2(module, horizon, P2.NW2)
+    t = traj_per_wg(comp.prog, batch)
+    forced = os.environ.get("CDX_UNET2_T")
+    want = int(forced) if forced in ("1", "2") else (2 if batch > 256 else 1)
+    if t < want and comp.prog.nw != P2.NW2:
+        alt = compiled2(module, horizon, P2.NW2)
+        if alt.prog is not None and traj_per_wg(alt.prog, batch) == want:
+            return alt, want
+    return comp, t
+
+
 def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps=0, predict_noise=0, prior=None,
            fix_mask=None, noise=None, x_min=None, x_max=None, t_per_wg: Optional[int] = None):
     if batch <= 0:
@@ -144,7 +174,7 @@ def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps
     prof = R._prof["buf"]
     L = CdxUnet2Launch(
         ops=comp.ops_dev.data_ptr(), wblob=prog.blob.data_ptr(), n_ops=len(prog.ops), traj_floats=prog.traj_floats,
-        traj_per_wg=t, x_off=prog.x_off, x_stride=prog.x_stride, pred_off=prog.pred_off,
+        traj_per_wg=t, n_waves=prog.nw, tune=int(os.environ.get("CDX_UNET2_TUNE", DEFAULT_TUNE)), x_off=prog.x_off, x_stride=prog.x_stride, pred_off=prog.pred_off,
         pred_stride=prog.pred_stride, prev_off=prog.prev_off, stage_off=prog.stage_off,
         batch=batch, horizon=prog.horizon, dim=prog.dim, emb=emb.data_ptr(), emb_ld=emb.shape[1],
         steps=R._ptr(steps_dev), n_steps=n_steps, predict_noise=int(predict_noise),
@@ -166,7 +196,7 @@ def fused_sample2(solver, net, plan, xt, prior, feed, fix_mask, x_min, x_max) ->
     if b < min_batch() or R.plan_is_edm(plan) or supported(net, h) is not None:
         return None
     dev = xt.device
-    comp = compiled2(net, h)
+    comp, t = shape_for(net, h, b)
     with torch.no_grad():
         emb = plan_film_table(comp, net, plan, dev)
         steps_dev = R.steps_to_device(plan, dev)
@@ -175,7 +205,7 @@ def fused_sample2(solver, net, plan, xt, prior, feed, fix_mask, x_min, x_max) ->
         out = torch.empty_like(xin)
         launch(comp, batch=b, x_in=xin, x_out=out, emb=emb, steps_dev=steps_dev, n_steps=len(plan.steps),
                predict_noise=R._predicts_noise(plan, solver), prior=R._f32c(prior, dev) if fix_mask is not None else None,
-               fix_mask=fix_mask, noise=noise, x_min=x_min, x_max=x_max)
+               fix_mask=fix_mask, noise=noise, x_min=x_min, x_max=x_max, t_per_wg=t)
     return out
 
 
@@ -184,10 +214,10 @@ def backbone_forward2(module, x, noise_t) -> Optional[torch.Tensor]:
     b, h, d = x.shape
     if supported(module, h) is not None:
         return None
-    comp = compiled2(module, h)
+    comp, t = shape_for(module, h, b)
     with torch.no_grad():
         emb = film_table(comp, module, noise_t.reshape(-1)[:1])
         xin = R._f32c(x, x.device)
         out = torch.empty_like(xin)
-        launch(comp, batch=b, x_in=xin, x_out=out, emb=emb)
+        launch(comp, batch=b, x_in=xin, x_out=out, emb=emb, t_per_wg=t)
     return out

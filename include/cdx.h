@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define CDX_ABI_VERSION 3
+#define CDX_ABI_VERSION 4
 
 #define CDX_OK 0
 #define CDX_EINVAL (-1)   /* bad argument (null pointer, size out of range, misaligned offset) */
@@ -117,12 +117,12 @@ int cdx_unet1d_run(const cdx_unet1d_launch* launch, void* hip_stream);
  * Second-generation fused U-Net program (csrc/cdx_unet2.hip; program built by engine/program2.py, word layout in
  * csrc/cdx_ops2.h).  Same contract as cdx_unet1d_run -- the whole DiscreteDiffusionSDE / ContinuousDiffusionSDE.sample() loop
  * (reference diffusionsde.py:526-594 over nn_diffusion/jannerunet.py:154-201) in ONE launch, step kinds 0-4 -- for
- * unconditional JannerUNet1d-structured denoisers, re-engineered for the per-op fixed cost: 4 wave64 per workgroup,
+ * unconditional JannerUNet1d-structured denoisers, re-engineered for the per-op fixed cost: 4 or 8 wave64 per workgroup,
  * `traj_per_wg` (1 or 2) trajectories per workgroup sharing every streamed weight record, the ResidualBlock's 1x1 skip conv
  * fused into its second conv, and the per-block FiLM vectors Linear(Mish(map_emb(map_noise(t)))) read from a per-step table
  * that cdx_unet2_embtab evaluates once per (weights, schedule).
  * ---------------------------------------------------------------------------------------------- */
-#define CDX2_OP_WORDS 64
+#define CDX2_OP_WORDS(n_waves) (32 + 8 * (n_waves))   /* header + one inline work item per wave */
 
 /* FiLM table: out[r][:] = W3^T mish(W2^T mish(W0^T temb[r] + b0) + b2) + b3, all weights transposed [n_in][n_out] inside `wblob`
  * at the given float offsets (reference jannerunet.py:135-136 map_emb, :57 emb_mlp of every block, stacked). */
@@ -137,11 +137,14 @@ typedef struct cdx_unet2_embtab_args {
 int cdx_unet2_embtab(const cdx_unet2_embtab_args* args, void* hip_stream);
 
 typedef struct cdx_unet2_launch {
-    const int32_t* ops;        /* device, [n_ops][CDX2_OP_WORDS] (descriptor + first work items) followed by further work items */
+    const int32_t* ops;        /* device, [n_ops][CDX2_OP_WORDS(n_waves)] (descriptor + first work items) followed by further work items */
     const float* wblob;        /* device, packed parameters */
     int32_t n_ops;
     int32_t traj_floats;       /* LDS floats of one trajectory's region; the workgroup owns traj_per_wg of them */
     int32_t traj_per_wg;       /* 1 or 2 */
+    int32_t n_waves;           /* 4 or 8: wave64 per workgroup; the program (work items, K slices) is compiled for one of them */
+    int32_t tune;              /* scheduling switches (results do not depend on them); bit 0: in the 8-wave shape waves 4-7 run
+                                * their K loops at raised priority */
     int32_t x_off, x_stride, pred_off, pred_stride, prev_off, stage_off;   /* relative to the trajectory region; x/pred: position 0 */
     int32_t batch, horizon, dim;
     const float* emb;          /* device (max(n_steps,1), emb_ld): FiLM table rows, one per step record */

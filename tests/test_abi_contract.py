@@ -83,13 +83,15 @@ def test_op2_word_layout_matches_header():
     text = open(os.path.join(ROOT, "cleandiffuser_amd", "csrc", "cdx_ops2.h")).read()
     defs = re.findall(r"#define CDX2_(\w+) (\d+)\b", text)
     assert len(defs) > 40
-    alias = {"OP_WORDS": "OP2_WORDS", "ITEM_WORDS": "ITEM2_WORDS"}
+    alias = {"ITEM_WORDS": "ITEM2_WORDS"}
     for name, val in defs:
         name = alias.get(name, name)
         assert hasattr(P2, name), f"program2.py lacks {name}"
         assert getattr(P2, name) == int(val), (name, val, getattr(P2, name))
     hdr = open(os.path.join(ROOT, "include", "cdx.h")).read()
-    assert int(re.search(r"#define CDX2_OP_WORDS (\d+)", hdr).group(1)) == P2.OP2_WORDS
+    m = re.search(r"#define CDX2_OP_WORDS\(n_waves\) \((\d+) \+ (\d+) \* \(n_waves\)\)", hdr)
+    assert m and all(int(m.group(1)) + int(m.group(2)) * nw == P2.op_words(nw) for nw in (4, 8))
+    assert P2.W2_ITEM0 == P2.HDR_WORDS
 
 
 def test_unet2_validation_fails_loudly(lib):
@@ -100,6 +102,8 @@ def test_unet2_validation_fails_loudly(lib):
                                 traj_per_wg=3)
     assert lib.cdx_unet2_run(ctypes.byref(L), None) == -1 and b"traj_per_wg" in lib.cdx_last_error()
     L.traj_per_wg, L.traj_floats = 2, 30 * 1024
+    assert lib.cdx_unet2_run(ctypes.byref(L), None) == -1 and b"n_waves" in lib.cdx_last_error()
+    L.n_waves = 8
     assert lib.cdx_unet2_run(ctypes.byref(L), None) == -2 and b"160 KiB" in lib.cdx_last_error()
     L.batch = 0
     assert lib.cdx_unet2_run(ctypes.byref(L), None) == 0                                            # empty request: nothing to do

@@ -308,18 +308,20 @@ V2_CASES = [n for n in FUSED_CASES if cases.CASES[n]["net"][0] == "JannerUNet1d"
             and not cases.CASES[n]["sample"].get("w_cfg")]
 
 
+@pytest.mark.parametrize("n_waves", ["4", "8"])
 @pytest.mark.parametrize("t_per_wg", ["1", "2"])
 @pytest.mark.parametrize("name", V2_CASES)
-def test_unet2_kernel_matches_reference_fixture(name, t_per_wg, amd_lib, monkeypatch):
-    """The second-generation kernel (cdx_unet2_run) with one and with two trajectories per workgroup (the fixtures' odd batch
-    sizes exercise the half-empty last workgroup): every unconditional JannerUNet1d fixture whose plan has no EDM step kinds
-    must be served by it -- one launch -- and reproduce the reference."""
+def test_unet2_kernel_matches_reference_fixture(name, t_per_wg, n_waves, amd_lib, monkeypatch):
+    """The second-generation kernel (cdx_unet2_run) in its four workgroup shapes -- 4 or 8 waves, one or two trajectories per
+    workgroup (the fixtures' odd batch sizes exercise the half-empty last workgroup): every unconditional JannerUNet1d fixture
+    whose plan has no EDM step kinds must be served by it -- one launch -- and reproduce the reference."""
     from cleandiffuser_amd.engine import runtime, runtime2
     gold = np.load(golden_path(name))
     agent, _ = cases.build(amd_lib, name, device=DEV)
     inp = cases.make_inputs(name)
     kw = cases.sample_kwargs(name, inp, device=DEV)
     monkeypatch.setenv("CDX_UNET2_T", t_per_wg)
+    monkeypatch.setenv("CDX_UNET2_NW", n_waves)
     monkeypatch.setenv("CDX_UNET2_MIN_BATCH", "1")
     calls = _spy_launches(monkeypatch)
     seen, orig = [], runtime2.fused_sample2
@@ -350,7 +352,8 @@ def test_unet2_agrees_with_first_kernel_and_is_batch_invariant(amd_lib, monkeypa
     kw = dict(solver="ddpm", n_samples=B, sample_steps=10)
     outs = {}
     monkeypatch.setenv("CDX_UNET2_MIN_BATCH", "1")
-    for tag, env in (("v1", {"CDX_UNET2": "0"}), ("t1", {"CDX_UNET2": "1", "CDX_UNET2_T": "1"}), ("t2", {"CDX_UNET2": "1", "CDX_UNET2_T": "2"})):
+    for tag, env in (("v1", {"CDX_UNET2": "0"}), ("t1", {"CDX_UNET2": "1", "CDX_UNET2_T": "1", "CDX_UNET2_NW": "4"}),
+                     ("t2", {"CDX_UNET2_T": "2"}), ("t1w8", {"CDX_UNET2_T": "1", "CDX_UNET2_NW": "8"}), ("t2w8", {"CDX_UNET2_T": "2"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         calls = _spy_launches(monkeypatch)
@@ -358,6 +361,9 @@ def test_unet2_agrees_with_first_kernel_and_is_batch_invariant(amd_lib, monkeypa
         torch.cuda.synchronize()
         assert calls["n"] == 1 and calls["v2"] == (0 if tag == "v1" else 1)
     assert torch.equal(outs["t1"], outs["t2"]), "trajectories per workgroup must not change results"
+    assert torch.equal(outs["t1w8"], outs["t2w8"]), "trajectories per workgroup must not change results (8-wave shape)"
+    # (the 8-wave program cuts K into more slices: same math, another summation order)
+    np.testing.assert_allclose(outs["t1w8"].cpu().numpy(), outs["t1"].cpu().numpy(), rtol=2e-4, atol=2e-4)
     # (a 10-step clipped DDPM amplifies summation-order noise near the clip boundary: both kernels are pinned to the reference
     #  at 1e-4 by the fixtures; here they only have to agree with each other to within twice that)
     np.testing.assert_allclose(outs["t1"].cpu().numpy(), outs["v1"].cpu().numpy(), rtol=2e-4, atol=2e-4)

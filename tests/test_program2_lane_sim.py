@@ -23,14 +23,15 @@ def _first_t(agent, c):
     return torch.tensor([float(sched[S])], dtype=torch.float32)
 
 
+@pytest.mark.parametrize("nw", [4, 8])
 @pytest.mark.parametrize("name", ["janner_cfg2_ddim", "janner_h4_ddpm", "janner_tiny_disc_ddim", "janner_tiny_cont_ddim", "janner_h64_single"])
-def test_lane_sim2_reproduces_reference_forward(name, amd_lib):
+def test_lane_sim2_reproduces_reference_forward(name, nw, amd_lib):
     gold = np.load(golden_path(name))
     agent, _ = cases.build(amd_lib, name)
     c = cases.CASES[name]
     net = agent.model_ema["diffusion"]
-    prog = P2.compile_janner2(net, c["horizon"])
-    assert prog.lds_bytes(1) <= 160 * 1024
+    prog = P2.compile_janner2(net, c["horizon"], nw=nw)
+    assert prog.lds_bytes(1) <= 160 * 1024 and prog.nw == nw and prog.ops.shape[1] == P2.op_words(nw)
     inp, xt0 = _first_forward_inputs(name, agent)
     with torch.no_grad():
         temb = net.map_noise(_first_t(agent, c)).numpy()
@@ -41,8 +42,9 @@ def test_lane_sim2_reproduces_reference_forward(name, amd_lib):
         np.testing.assert_allclose(sim.run_forward(row), gold["pred0"][b], rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("nw", [4, 8])
 @pytest.mark.parametrize("shape", [(32, 69, 64, [1, 2, 2, 2]), (16, 6, 32, [1, 2, 4])])
-def test_lane_sim2_wide_nets_against_module_forward(shape, amd_lib):
+def test_lane_sim2_wide_nets_against_module_forward(shape, nw, amd_lib):
     """Shapes that leave the one-item-per-wave regime: the shipped kitchen Diffuser net (64 channels x 32 positions = 8 tiles, so
     waves loop over items of the tail table; concat layers with K slices cut at the source boundary; 2 float4 items per lane in the
     epilogue; C_out = 69 padded to 128 lanes) and a 3-level net with a x4 channel step.  Against the module's own forward (which
@@ -50,9 +52,9 @@ def test_lane_sim2_wide_nets_against_module_forward(shape, amd_lib):
     from cleandiffuser_amd.utils import load_synth
     H, D, md, dm = shape
     net = load_synth(amd_lib.JannerUNet1d(D, model_dim=md, emb_dim=32, dim_mult=dm, kernel_size=5), 9).eval()
-    prog = P2.compile_janner2(net, H)
+    prog = P2.compile_janner2(net, H, nw=nw)
     assert prog.lds_bytes(1) <= 160 * 1024
-    assert max(int(op[P2.W2_NITEMS]) for op in prog.ops) > P2.NW2 or md < 64
+    assert max(int(op[P2.W2_NITEMS]) for op in prog.ops) > nw or md < 64 or nw == 8
     g = torch.Generator().manual_seed(2)
     x, t = torch.randn(1, H, D, generator=g), torch.tensor([11])
     with torch.no_grad():
@@ -63,16 +65,18 @@ def test_lane_sim2_wide_nets_against_module_forward(shape, amd_lib):
     np.testing.assert_allclose(sim.run_forward(row), ref, rtol=2e-5, atol=2e-5)
 
 
-def test_program2_accounting_and_budget(amd_lib):
+@pytest.mark.parametrize("nw", [4, 8])
+def test_program2_accounting_and_budget(nw, amd_lib):
     """North-star config: 19.67 M MAC per forward (embedding MLP included), 47 conv ops (16 blocks x 2 +
     7 skip convs + 3 down + 3 up + 2 head), and TWO trajectories fit one workgroup's 160 KiB."""
     _, net = cases.build(amd_lib, "janner_cfg2_ddim")
-    prog = P2.compile_janner2(net, 32)
+    prog = P2.compile_janner2(net, 32, nw=nw)
     assert len(prog.ops) == 47
     assert abs(prog.macs_per_forward - 19.67e6) / 19.67e6 < 0.01
     assert prog.lds_bytes(2) <= 160 * 1024
     ops = prog.ops
-    assert (ops[:, P2.W2_NITEMS] == P2.NW2).all(), "every wave has exactly one work item in every op of this net"
+    assert (ops[:, P2.W2_NITEMS] == nw).all(), "every wave has exactly one work item in every op of this net"
+    ring = P2.ring_depth(nw)
     for op in ops:
         items = np.stack([P2.op_item(prog.ops_buffer, op, j) for j in range(op[P2.W2_NITEMS])])
         # K slices of one tile exactly tile its record stream: same record count per tile, slices of a tile are contiguous
@@ -80,6 +84,9 @@ def test_program2_accounting_and_budget(amd_lib):
         assert per_tile * len(items) == items[:, P2.I2_NQ].sum() * op[P2.W2_KSPLIT]
         assert (items[:, P2.I2_NQ] >= 1).all() and (items[:, P2.I2_CCN] >= 1).all()
         assert ((items[:, P2.I2_SRCSTR] & 0xffff) < prog.traj_floats).all()
+        # long K slices start on a ring-aligned chunk of their tap (the kernel's immediate-offset steady loop)
+        long = items[:, P2.I2_NQ] >= 2 * ring
+        assert (((items[long, P2.I2_TAPCC] >> 8) % ring == 0) | (items[long, P2.I2_CCN] % ring != 0)).all()
 
 
 def test_v2_refuses_what_it_cannot_run(amd_lib):

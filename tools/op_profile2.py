@@ -1,5 +1,5 @@
-"""Per-op cycle breakdown of the v2 fused kernel (workgroup 0, first forward) -- tuning aid.
-Usage (GPU box): python tools/op_profile2.py [batch] [traj_per_wg] > gpurun_out/op_profile2.txt"""
+"""Per-op cycle breakdown of the v2 fused kernel (workgroup 0, second forward) -- tuning aid.
+Usage (GPU box): python tools/op_profile2.py [batch] [traj_per_wg] [n_waves] > gpurun_out/op_profile2.txt"""
 import os
 import sys
 
@@ -14,6 +14,8 @@ def main():
     batch = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     if len(sys.argv) > 2:
         os.environ["CDX_UNET2_T"] = sys.argv[2]
+    if len(sys.argv) > 3:
+        os.environ["CDX_UNET2_NW"] = sys.argv[3]
     bench.BATCH = batch
     dev = torch.device("cuda", 0)
     agent, net = bench.build_agent(dev)
@@ -21,7 +23,8 @@ def main():
     kw = dict(solver="ddim", n_samples=batch, sample_steps=20, temperature=0.5)
     for _ in range(3):
         agent.sample(prior, noise=[z0], **kw)
-    prog = runtime2.compiled2(agent.model_ema["diffusion"], 32).prog
+    comp, tpw = runtime2.shape_for(agent.model_ema["diffusion"], 32, batch)
+    prog = comp.prog
     n_ops = len(prog.ops)
     buf = torch.zeros(n_ops * 8 + 2, dtype=torch.int64, device=dev)
     runtime.set_profile_buffer(buf)
@@ -31,7 +34,7 @@ def main():
     t = buf.cpu().numpy()
     total = t[n_ops * 8 + 1] - t[n_ops * 8]
     fwd = t[(n_ops - 1) * 8 + 3] - t[0]
-    print(f"batch={batch} T={runtime2.traj_per_wg(prog, batch)} kernel cycles (wg0) = {total}  traj_bytes={prog.traj_floats * 4}")
+    print(f"batch={batch} T={tpw} waves={prog.nw} kernel cycles (wg0) = {total}  traj_bytes={prog.traj_floats * 4}")
     print(f"first forward cycles = {fwd}  ({fwd * 20 / total:.2%} of kernel if all 20 equal)")
     print(f"{'op':>3} {'cout':>4} {'L':>3} {'mode':>4} {'nt':>2} {'ks':>2} {'nq/item':>7} {'kloop':>7} {'sync':>6} {'epi':>6} {'total':>7}")
     tk = ts = te = 0
