@@ -196,7 +196,7 @@ def other_configs(device):
         except Exception as e:  # noqa: BLE001 -- one broken side measurement must not take the headline down
             out.append({"name": tag, "error": f"{type(e).__name__}: {e}"})
 
-    big("config2_B3200", bc.cfg2big, "cdx_unet2_kernel<2> (two trajectories per workgroup)", B=3200)
+    big("config2_B3200", bc.cfg2big, "cdx_unet2_kernel<2, 8> (two trajectories, 8 wave64 per workgroup)", B=3200)
     big("config2_guided_B256", bc.cfg2g, "cdx_guided_run: cdx_unet1d_kernel forward + classifier GEMM/GroupNorm kernels", B=256)
     try:
         label, call, b, steps, net, horizon = bc.cfg1()
@@ -316,6 +316,20 @@ def main():
         k_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
         achieved = FLOPS_PER_TRAJ * BATCH / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         v2 = os.environ.get("CDX_UNET2", "1") != "0"
+        kname, l2 = "cdx_unet1d_kernel", None
+        if v2:
+            from cleandiffuser_amd.engine import runtime2
+            comp, tpw = runtime2.shape_for(agent.model_ema["diffusion"], HORIZON, BATCH)
+            kname = f"cdx_unet2_kernel<{tpw}, {comp.prog.nw}> ({tpw} trajectories, {comp.prog.nw} wave64 per workgroup)"
+            # second roofline of the same launch: every workgroup streams the whole packed weight set from L2 once per denoiser
+            # forward (activations never leave LDS).  With one trajectory per CU -- all B = 256 allows -- THIS is the binding
+            # limit: MI355X_MICROARCH.md gives 34.5 TB/s aggregate L2 bandwidth
+            wbytes = 4.0 * comp.prog.meta["blob_floats"]
+            n_wg = -(-BATCH // tpw)
+            l2_bytes = wbytes * n_wg * SAMPLE_STEPS
+            l2 = {"bound": "l2", "bytes_per_launch": l2_bytes, "achieved": l2_bytes / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0,
+                  "peak": 34.5, "unit": "TB/s", "weight_bytes_per_forward": wbytes, "workgroups": n_wg}
+            l2["frac"] = l2["achieved"] / l2["peak"]
         out = {
             "metric": "denoised trajectories/sec @ (B=256,H=32,D=23) 20-step DDIM",
             "value": BATCH * world * args.steps / elapsed,
@@ -332,8 +346,8 @@ def main():
                        "parallelism": f"batch-sharded x{world}; the only data-path collective is the all-gather of the result"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, **recorded_traffic(),
-                         "kernel": "cdx_unet2_kernel<1>" if v2 else "cdx_unet1d_kernel", "kernel_ms": k_ms,
-                         "launches_timed": len(kernel_ms), "flops_per_launch": FLOPS_PER_TRAJ * BATCH},
+                         "kernel": kname, "kernel_ms": k_ms,
+                         "launches_timed": len(kernel_ms), "flops_per_launch": FLOPS_PER_TRAJ * BATCH, "l2_stream": l2},
         }
         if strong is not None:
             out["strong_scaling"] = strong
