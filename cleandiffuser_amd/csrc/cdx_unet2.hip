@@ -552,7 +552,17 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
         const size_t xbase = (size_t)(b0 + t) * HD;
         for (int e = tid; e < HD; e += THREADS) {
             const int n = e / D, c = e - n * D;
-            lds[t * tf + L.x_off + n * L.x_stride + c] = L.x_in[xbase + e];
+            float v = L.x_in[xbase + e];
+            if (L.init_blend) {
+                // x_T = z * temperature, then the fix-mask blend with the prior (reference diffusionsde.py:509-510): the same
+                // four roundings as the ATen ops it replaces -- no fma contraction
+                v = __fmul_rn(v, L.x_scale);
+                if (L.fix_mask) {
+                    const float m = L.fix_mask[e];
+                    v = __fadd_rn(__fmul_rn(v, __fsub_rn(1.0f, m)), __fmul_rn(L.prior[xbase + e], m));
+                }
+            }
+            lds[t * tf + L.x_off + n * L.x_stride + c] = v;
         }
     }
     __syncthreads();

@@ -210,10 +210,32 @@ class BaseDiffusionSDE(DiffusionModel):
                 history[:, (history.shape[1] - 1) - st.index + 1] = xt.detach().cpu().numpy()
         return xt
 
+    def _initial_state(self, z, temperature, prior):
+        """x_T of a cold start (reference diffusionsde.py:509-510)."""
+        xt = z * temperature
+        return xt * (1. - self.fix_mask) + prior * self.fix_mask
+
+    def _raw_start_ok(self, condition_cfg, w_cfg, w_cg, requires_grad, preserve_history):
+        """Cheap host-side test: may the fused executor be offered the raw draw instead of x_T?  (unconditional, unguided,
+        no history / autograd -- everything else is checked by dispatch.try_fused_raw)"""
+        return (condition_cfg is None and w_cfg == 0.0 and (w_cg == 0.0 or self.classifier is None)
+                and not requires_grad and not preserve_history)
+
     def _sample_common(self, plan, xt, prior, n_samples, use_ema, condition_cfg, mask_cfg, w_cfg, condition_cg,
-                       w_cg, requires_grad, preserve_history, sample_steps, feed, t_dtype, final_logp: bool):
+                       w_cg, requires_grad, preserve_history, sample_steps, feed, t_dtype, final_logp: bool,
+                       raw_start=None):
         from ..engine import dispatch
         model = self.model_ema if use_ema else self.model
+        if xt is None:                     # raw_start = (z, temperature): x_T not formed yet
+            fused = dispatch.try_fused_raw(self, model, plan, raw_start[0], raw_start[1], prior, feed)
+            if fused is not None:
+                log = {"sample_history": None}
+                if final_logp:
+                    with torch.no_grad():
+                        t0 = torch.zeros((n_samples,), dtype=torch.long, device=self.device)
+                        log["log_p"] = self.classifier.logp(fused, t0, condition_cg)
+                return (fused.clip(self.x_min, self.x_max) if self.clip_pred else fused), log
+            xt = self._initial_state(raw_start[0], raw_start[1], prior)
         log = {"sample_history": None}
         if preserve_history:  # (n, S+1, *prior.shape) with broadcast writes -- reference quirk Q15 kept
             log["sample_history"] = np.empty((n_samples, sample_steps + 1, *prior.shape))
@@ -307,10 +329,13 @@ class DiscreteDiffusionSDE(BaseDiffusionSDE):
         if isinstance(warm_start_reference, torch.Tensor):
             horizon_T = int(warm_start_forward_level * self.diffusion_steps)
             xt = warm_start_reference * self.alpha[horizon_T] + self.sigma[horizon_T] * feed.like(warm_start_reference)
+            xt = xt * (1. - self.fix_mask) + prior * self.fix_mask
+            raw_start = None
         else:
             horizon_T = self.diffusion_steps
-            xt = feed.like(prior) * temperature
-        xt = xt * (1. - self.fix_mask) + prior * self.fix_mask
+            raw_start = (feed.like(prior), temperature)
+            xt = None if self._raw_start_ok(condition_cfg, w_cfg, w_cg, requires_grad, preserve_history) \
+                else self._initial_state(raw_start[0], temperature, prior)
 
         sched = self._resolve_schedule(sample_step_schedule, horizon_T, sample_steps)
         grid = sched.tolist()
@@ -319,7 +344,7 @@ class DiscreteDiffusionSDE(BaseDiffusionSDE):
             diffusion_x_sampling_steps, t_is_integer=True))
         return self._sample_common(plan, xt, prior, n_samples, use_ema, condition_cfg, mask_cfg, w_cfg,
                                    condition_cg, w_cg, requires_grad, preserve_history, sample_steps, feed,
-                                   torch.long, final_logp=self.classifier is not None)
+                                   torch.long, final_logp=self.classifier is not None, raw_start=raw_start)
 
 
 class ContinuousDiffusionSDE(BaseDiffusionSDE):
@@ -375,10 +400,13 @@ class ContinuousDiffusionSDE(BaseDiffusionSDE):
             fa, fs = self._alpha_sigma(torch.ones((1,), device=self.device) * level)
             xt = warm_start_reference * fa + fs * feed.like(warm_start_reference)
             t_range = [self.t_diffusion[0], level]
+            xt = xt * (1. - self.fix_mask) + prior * self.fix_mask
+            raw_start = None
         else:
-            xt = feed.like(prior) * temperature
+            raw_start = (feed.like(prior), temperature)
+            xt = None if self._raw_start_ok(condition_cfg, w_cfg, w_cg, requires_grad, preserve_history) \
+                else self._initial_state(raw_start[0], temperature, prior)
             t_range = self.t_diffusion
-        xt = xt * (1. - self.fix_mask) + prior * self.fix_mask
 
         sched = self._resolve_schedule(sample_step_schedule, t_range, sample_steps)
         sched = sched.cpu() if isinstance(sched, torch.Tensor) else sched
@@ -391,4 +419,4 @@ class ContinuousDiffusionSDE(BaseDiffusionSDE):
         return self._sample_common(plan, xt, prior, n_samples, use_ema, condition_cfg, mask_cfg, w_cfg,
                                    condition_cg, w_cg, requires_grad, preserve_history, sample_steps, feed,
                                    torch.float32,
-                                   final_logp=(self.classifier is not None and w_cg != 0.))
+                                   final_logp=(self.classifier is not None and w_cg != 0.), raw_start=raw_start)

@@ -61,6 +61,25 @@ def try_fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, requ
     return runtime.fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed)
 
 
+def try_fused_raw(solver, model, plan, z, temperature, prior, feed):
+    """The common unconditional request before x_T exists: `z` is the initial N(0, I) draw.  When the second-generation U-Net
+    kernel takes the request it forms x_T = (z * temperature) * (1 - fix_mask) + prior * fix_mask itself (reference
+    diffusionsde.py:509-510), so a steady-state sample() call launches that kernel and nothing else.
+    None -> the caller forms x_T with ATen ops and goes through try_fused_sample as before (no draw consumed here)."""
+    if not _on_gpu(z) or z.dtype != torch.float32 or z.dim() != 3:
+        return None
+    from . import bigbatch, runtime
+    net = model["diffusion"]
+    if not runtime._is_janner(net) or runtime.plan_is_edm(plan):
+        return None
+    from . import runtime2
+    if z.shape[0] < runtime2.min_batch() or runtime2.supported(net, z.shape[1]) is not None:
+        return None
+    if bigbatch.is_chiunet_gemm(net, z.shape[0], z.shape[1], False):
+        return None
+    return runtime.fused_sample(solver, model, plan, z, prior, None, 0.0, feed, x_scale=float(temperature))
+
+
 def try_fused_edm(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, requires_grad, feed):
     """``ContinuousEDM.sample``: big-batch executors for the GEMM-shaped backbones, the program kernel for the rest."""
     if not _on_gpu(xt) or requires_grad or xt.dtype != torch.float32:

@@ -212,12 +212,28 @@ def _dense_hd(v, h: int, d: int, device) -> Optional[torch.Tensor]:
     """Broadcast a reference-style (1,H,D)/(H,D)/(D,)/scalar tensor to a dense (H, D) fp32 table; None stays None."""
     if v is None or (not isinstance(v, torch.Tensor) and v == 0):
         return None
+    memo = None
+    if isinstance(v, torch.Tensor):
+        # a (1, 1, D) bound would otherwise cost an expand + copy launch in every sample() call; the entry pins its source tensor,
+        # so (data_ptr, _version) cannot be recycled under it
+        memo = (v.data_ptr(), v._version, tuple(v.shape), str(v.dtype), h, d, str(device))
+        hit = _dense_memo.get(memo)
+        if hit is not None:
+            return hit[1]
     t = torch.as_tensor(v, dtype=torch.float32, device=device)
     if t.dim() >= 3:
         if t.shape[0] != 1:
             raise ValueError("per-sample bounds/masks are not supported by the fused executor")
         t = t[0]
-    return t.expand(h, d).contiguous()
+    out = t.expand(h, d).contiguous()
+    if memo is not None:
+        if len(_dense_memo) >= 64:
+            _dense_memo.clear()
+        _dense_memo[memo] = (v, out)
+    return out
+
+
+_dense_memo = {}
 
 
 # ------------------------------------------------------------------------------------------------ #
@@ -408,8 +424,9 @@ def fused_sample_mlp(solver, net, kind, plan, xt, prior, cond_vec, w_cfg, feed) 
     return out[:b]
 
 
-def fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed) -> Optional[torch.Tensor]:
-    """Whole denoising loop in one launch.  Returns None when this request must take the PyTorch executor."""
+def fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed, x_scale: Optional[float] = None) -> Optional[torch.Tensor]:
+    """Whole denoising loop in one launch.  Returns None when this request must take the PyTorch executor.
+    `x_scale` given: `xt` is the raw N(0, I) draw (see dispatch.try_fused_raw); only the v2 U-Net kernel takes such a request."""
     net = model["diffusion"]
     if xt.dim() == 2 and _mlp_kind(net) is not None:
         return fused_sample_mlp(solver, net, _mlp_kind(net), plan, xt, prior, cond_vec, w_cfg, feed)
@@ -431,9 +448,11 @@ def fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed) -> Optio
     load_library()
     if (cond_vec is None or w_cfg == 0.0) and _is_janner(net):
         from . import runtime2                        # unconditional temporal U-Net, non-EDM plan: second-generation kernel
-        out = runtime2.fused_sample2(solver, net, plan, xt, prior, feed, fix_mask, x_min, x_max)
+        out = runtime2.fused_sample2(solver, net, plan, xt, prior, feed, fix_mask, x_min, x_max, x_scale=x_scale)
         if out is not None:
             return out
+    if x_scale is not None:
+        return None                                   # raw-draw requests are only taken by the v2 kernel; the caller forms x_T itself
     with torch.no_grad():
         comp = compiled_program(net, h, plan_is_edm(plan))
         # every eligibility check that can still send the request to the PyTorch executor comes BEFORE the first draw from `feed`:

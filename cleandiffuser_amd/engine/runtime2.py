@@ -38,7 +38,8 @@ class CdxUnet2Launch(ctypes.Structure):
                 ("steps", ctypes.c_void_p), ("n_steps", ctypes.c_int32), ("predict_noise", ctypes.c_int32),
                 ("x_in", ctypes.c_void_p), ("prior", ctypes.c_void_p), ("fix_mask", ctypes.c_void_p),
                 ("noise", ctypes.c_void_p), ("x_min", ctypes.c_void_p), ("x_max", ctypes.c_void_p),
-                ("x_out", ctypes.c_void_p), ("prof", ctypes.c_void_p)]
+                ("x_out", ctypes.c_void_p), ("init_blend", ctypes.c_int32), ("x_scale", ctypes.c_float),
+                ("prof", ctypes.c_void_p)]
 
 
 _declared = False
@@ -166,7 +167,7 @@ def shape_for(module, horizon: int, batch: int):
 
 
 def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps=0, predict_noise=0, prior=None,
-           fix_mask=None, noise=None, x_min=None, x_max=None, t_per_wg: Optional[int] = None):
+           fix_mask=None, noise=None, x_min=None, x_max=None, t_per_wg: Optional[int] = None, x_scale: Optional[float] = None):
     if batch <= 0:
         return
     prog = comp.prog
@@ -179,7 +180,8 @@ def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps
         batch=batch, horizon=prog.horizon, dim=prog.dim, emb=emb.data_ptr(), emb_ld=emb.shape[1],
         steps=R._ptr(steps_dev), n_steps=n_steps, predict_noise=int(predict_noise),
         x_in=x_in.data_ptr(), prior=R._ptr(prior), fix_mask=R._ptr(fix_mask), noise=R._ptr(noise), x_min=R._ptr(x_min),
-        x_max=R._ptr(x_max), x_out=x_out.data_ptr(), prof=R._ptr(prof))
+        x_max=R._ptr(x_max), x_out=x_out.data_ptr(), init_blend=0 if x_scale is None else 1,
+        x_scale=1.0 if x_scale is None else float(x_scale), prof=R._ptr(prof))
     timing = R._timing
     if timing["on"]:
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -190,8 +192,9 @@ def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps
         timing["events"].append((start, end))
 
 
-def fused_sample2(solver, net, plan, xt, prior, feed, fix_mask, x_min, x_max) -> Optional[torch.Tensor]:
-    """Unconditional JannerUNet1d, step kinds 0-4: the whole loop in one cdx_unet2_run launch.  None -> caller uses v1."""
+def fused_sample2(solver, net, plan, xt, prior, feed, fix_mask, x_min, x_max, x_scale: Optional[float] = None) -> Optional[torch.Tensor]:
+    """Unconditional JannerUNet1d, step kinds 0-4: the whole loop in one cdx_unet2_run launch.  None -> caller uses v1.
+    `x_scale` given: `xt` is the raw N(0, I) draw and the kernel forms x_T = xt * x_scale blended with the prior itself."""
     b, h, d = xt.shape
     if b < min_batch() or R.plan_is_edm(plan) or supported(net, h) is not None:
         return None
@@ -205,7 +208,7 @@ def fused_sample2(solver, net, plan, xt, prior, feed, fix_mask, x_min, x_max) ->
         out = torch.empty_like(xin)
         launch(comp, batch=b, x_in=xin, x_out=out, emb=emb, steps_dev=steps_dev, n_steps=len(plan.steps),
                predict_noise=R._predicts_noise(plan, solver), prior=R._f32c(prior, dev) if fix_mask is not None else None,
-               fix_mask=fix_mask, noise=noise, x_min=x_min, x_max=x_max, t_per_wg=t)
+               fix_mask=fix_mask, noise=noise, x_min=x_min, x_max=x_max, t_per_wg=t, x_scale=x_scale)
     return out
 
 

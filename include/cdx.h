@@ -158,6 +158,11 @@ typedef struct cdx_unet2_launch {
     const float* x_min;        /* (horizon, dim) or NULL */
     const float* x_max;
     float* x_out;
+    /* init_blend != 0: x_in holds the raw N(0, I) draw z; the kernel forms x_T = (z * x_scale) * (1 - fix_mask) + prior * fix_mask
+     * while loading it (reference diffusionsde.py:509-510 `xt = randn_like(prior) * temperature; xt = xt * (1 - mask) + prior * mask`,
+     * same roundings), so the host launches nothing but this kernel.  0: x_in is x_T itself. */
+    int32_t init_blend;
+    float x_scale;
     /* optional profiling: device u64 [n_ops*8 + 2]; workgroup 0 stamps s_memtime at {op start, next-op prefetch issued, after the
      * staging barrier, op end, item record + segment read, first operands landed, MFMAs done, partial tile staged} of the first
      * forward, plus kernel start/end.  NULL = off. */
