@@ -197,7 +197,8 @@ def other_configs(device):
             out.append({"name": tag, "error": f"{type(e).__name__}: {e}"})
 
     big("config2_B3200", bc.cfg2big, "cdx_unet2_kernel<2, 8> (two trajectories, 8 wave64 per workgroup)", B=3200)
-    big("config2_guided_B256", bc.cfg2g, "cdx_guided_run: cdx_unet1d_kernel forward + classifier GEMM/GroupNorm kernels", B=256)
+    big("config2_guided_B256", bc.cfg2g, "cdx_unet2_kernel<1, 8, true>: denoiser forward + classifier forward/backward + shifted solver step, "
+        "one launch per guided sample() call", B=256)
     try:
         label, call, b, steps, net, horizon = bc.cfg1()
         dt, k_ms = timed(call, 5)

@@ -38,6 +38,14 @@
 #define CDX2_W2_INV_CNT 22
 #define CDX2_W2_NK 23
 #define CDX2_W2_COUTP 24
+#define CDX2_W2_SAVE 25        /* slot (no halo) of the normalised pre-affine values a GroupNorm layer keeps for its backward */
+#define CDX2_W2_SAVE_STRIDE 26
+#define CDX2_W2_STATS 27       /* 8 floats: rstd per GroupNorm group */
+#define CDX2_W2_DST2 28        /* F2_DUAL: slot of the value before the backward epilogue */
+#define CDX2_W2_DST2_STRIDE 29
+#define CDX2_KIND2_CONV 0
+#define CDX2_KIND2_HEAD 1      /* classifier head, forward + backward (words: COUT hidden, LOUT/LCOLS positions/channels, RES src,
+                                * DST gradient slot, BOFF W1x [l][c][hidden], GAMMA w2, EMB table offset) */
 #define CDX2_W2_ITEM0 32
 
 #define CDX2_I2_WOFF 0
@@ -53,3 +61,6 @@
 #define CDX2_F2_EMB 2
 #define CDX2_F2_RES 4
 #define CDX2_F2_PRED 8
+#define CDX2_F2_SAVE 16      /* forward GroupNorm op also stores x_hat and rstd */
+#define CDX2_F2_GNBWD 32     /* epilogue = backward of (GroupNorm -> Mish) of the layer named by W2_SAVE / W2_STATS */
+#define CDX2_F2_DUAL 64      /* ... and the value before that backward goes to W2_DST2 */

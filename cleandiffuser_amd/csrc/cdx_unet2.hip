@@ -338,8 +338,10 @@ __device__ __forceinline__ void conv_kloop(const Geom& g, const float* __restric
 // The epilogue's view of a descriptor (decoded with v_readlane right where it is needed: SGPR live ranges stay short).
 struct EpiDesc {
     int flags, c_out, l_out, coutp, sstride, ksplit, dst, dstride, res, rstride, shift, nk;
+    int save, savestr, stats, dst2, d2stride;          // backward-pass extras (F2_SAVE / F2_GNBWD / F2_DUAL)
     float inv_cnt;
 };
+template <bool BWD>
 __device__ __forceinline__ EpiDesc decode_epi(int vd) {
     EpiDesc e;
     e.flags = CDX2_DW(vd, CDX2_W2_FLAGS); e.c_out = CDX2_DW(vd, CDX2_W2_COUT); e.l_out = CDX2_DW(vd, CDX2_W2_LOUT);
@@ -347,6 +349,11 @@ __device__ __forceinline__ EpiDesc decode_epi(int vd) {
     e.dst = CDX2_DW(vd, CDX2_W2_DST); e.dstride = CDX2_DW(vd, CDX2_W2_DST_STRIDE); e.res = CDX2_DW(vd, CDX2_W2_RES);
     e.rstride = CDX2_DW(vd, CDX2_W2_RES_STRIDE); e.shift = CDX2_DW(vd, CDX2_W2_CG4_SHIFT); e.nk = CDX2_DW(vd, CDX2_W2_NK);
     e.inv_cnt = __int_as_float(CDX2_DW(vd, CDX2_W2_INV_CNT));
+    e.save = e.savestr = e.stats = e.dst2 = e.d2stride = 0;
+    if (BWD && (e.flags & (CDX2_F2_SAVE | CDX2_F2_GNBWD))) {
+        e.save = CDX2_DW(vd, CDX2_W2_SAVE); e.savestr = CDX2_DW(vd, CDX2_W2_SAVE_STRIDE); e.stats = CDX2_DW(vd, CDX2_W2_STATS);
+        e.dst2 = CDX2_DW(vd, CDX2_W2_DST2); e.d2stride = CDX2_DW(vd, CDX2_W2_DST2_STRIDE);
+    }
     return e;
 }
 
@@ -371,9 +378,9 @@ __device__ __forceinline__ void half_sum2(float& a, float& b, int lane) {
 // channels c..c+3 of position pos0 + k * pstep.  NK = items per lane (compile-time so the values stay in registers).
 // GroupNorm statistics in ONE cross-lane round: sums of (x - s) and (x - s)^2 with s = the group's first element (no E[x^2] -
 // E[x]^2 cancellation; the second dependent reduction of a two-pass scheme is ~150 cycles of pure latency per op).
-template <int NK>
+template <int NK, bool BWD>
 __device__ __forceinline__ void epilogue(float* __restrict__ tl, const EpiParams& P, const EpiDesc& e, int stage, int c, int pos0,
-                                         int pstep, int li, int nv, int lane) {
+                                         int pstep, int li, int nv, int lane, int grp) {
     f32x4 v[NK];
     bool ok[NK];
 #pragma unroll
@@ -415,9 +422,13 @@ __device__ __forceinline__ void epilogue(float* __restrict__ tl, const EpiParams
         const float m1 = s1 * e.inv_cnt;
         const float mean = sh + m1;
         const float rstd = __builtin_amdgcn_rsqf(s2 * e.inv_cnt - m1 * m1 + CDX_GN_EPS);
+        const bool keep = BWD && (e.flags & CDX2_F2_SAVE) != 0;  // the backward pass of this layer wants x_hat and rstd
+        if (keep && li == 0) tl[e.stats + grp] = rstd;
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
-            const f32x4 y = (v[k] - mean) * rstd * P.ga + P.be;
+            const f32x4 xh = (v[k] - mean) * rstd;
+            if (keep && ok[k] && c < e.c_out) *reinterpret_cast<f32x4*>(tl + e.save + (pos0 + k * pstep) * e.savestr + c) = xh;
+            const f32x4 y = xh * P.ga + P.be;
             v[k] = (f32x4){mish2(y[0]), mish2(y[1]), mish2(y[2]), mish2(y[3])};
         }
     }
@@ -439,6 +450,95 @@ __device__ __forceinline__ void epilogue(float* __restrict__ tl, const EpiParams
     }
 }
 
+// d Mish(a) / d a with tanh(softplus(a)) = n / (n + 2), n = e^a (e^a + 2):  n/(n+2) + a * 4 e^a (e^a + 1) / (n + 2)^2
+__device__ __forceinline__ float mish2_grad(float a) {
+    const float e = __expf(fminf(a, 20.0f));
+    const float n = e * (e + 2.0f);
+    const float r = __builtin_amdgcn_rcpf(n + 2.0f);
+    return n * r + a * (4.0f * e * (e + 1.0f)) * (r * r);
+}
+
+// Backward epilogue (F2_GNBWD): v = staged conv result [+ residual slot]; [dst2 <- v]; then the backward of y = Mish(gamma x_hat +
+// beta), x_hat = (u - mean) rstd of the layer whose x_hat / rstd the forward pass saved:
+//   g_xhat = v * Mish'(gamma x_hat + beta) * gamma;   dst <- rstd (g_xhat - mean_grp(g_xhat) - x_hat mean_grp(g_xhat x_hat))
+// (torch's native_group_norm_backward for the input, reference utils/building_blocks.py:60-76 + nn.Mish under autograd).
+template <int NK>
+__device__ __forceinline__ void epilogue_bwd(float* __restrict__ tl, const EpiParams& P, const EpiDesc& e, int stage, int c, int pos0,
+                                             int pstep, int li, int nv, int lane, int grp) {
+    f32x4 gx[NK], xh[NK];
+    bool ok[NK];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        ok[k] = li + 32 * k < nv;
+        const int pos = ok[k] ? pos0 + k * pstep : 0;
+        f32x4 acc = P.bi;
+        const float* sp = tl + stage + pos * e.sstride + c;
+        const int kstep = e.l_out * e.sstride;
+        for (int ks = 0; ks < e.ksplit; ++ks) acc += *reinterpret_cast<const f32x4*>(sp + ks * kstep);
+        if (e.flags & CDX2_F2_RES) acc += *reinterpret_cast<const f32x4*>(tl + e.res + (pos + CDX2_HALO2) * e.rstride + c);
+        if ((e.flags & CDX2_F2_DUAL) && ok[k]) *reinterpret_cast<f32x4*>(tl + e.dst2 + (pos + CDX2_HALO2) * e.d2stride + c) = acc;
+        // (lane groups past C_out -- nets with fewer than 8 x 4 channels -- have nothing saved: zeros, never stored)
+        xh[k] = c < e.c_out ? *reinterpret_cast<const f32x4*>(tl + e.save + pos * e.savestr + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f32x4 a = xh[k] * P.ga + P.be;
+        const f32x4 d = (f32x4){mish2_grad(a[0]), mish2_grad(a[1]), mish2_grad(a[2]), mish2_grad(a[3])};
+        gx[k] = acc * d * P.ga;
+        const f32x4 gh = gx[k] * xh[k];
+        s1 += ok[k] ? (gx[k][0] + gx[k][1]) + (gx[k][2] + gx[k][3]) : 0.f;
+        s2 += ok[k] ? (gh[0] + gh[1]) + (gh[2] + gh[3]) : 0.f;
+    }
+    half_sum2(s1, s2, lane);
+    const float m1 = s1 * e.inv_cnt, m2 = s2 * e.inv_cnt;
+    const float rstd = tl[e.stats + grp];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        if (!ok[k]) continue;
+        const int pos = pos0 + k * pstep;
+        const f32x4 gu = (gx[k] - m1 - xh[k] * m2) * rstd;
+        float* o = tl + e.dst + (pos + CDX2_HALO2) * e.dstride + c;
+        if (c + 3 < e.c_out) {
+            *reinterpret_cast<f32x4*>(o) = gu;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (c + j < e.c_out) o[j] = gu[j];
+        }
+    }
+}
+
+// Classifier head, forward and backward in one op (KIND2_HEAD; reference nn_classifier/half_jannerunet.py:49-50, :62):
+// z_j = e_j + sum_{l,c} W1[l][c][j] x[l][c];  gz_j = w2_j Mish'(z_j);  dst[l][c] = sum_j W1[l][c][j] gz_j.
+template <int THREADS>
+__device__ __forceinline__ void run_head(const cdx_unet2_launch& L, int vd, const float* __restrict__ emb_row, float* __restrict__ tl,
+                                         int tid) {
+    const int hidden = CDX2_DW(vd, CDX2_W2_COUT), len = CDX2_DW(vd, CDX2_W2_LOUT), ch = CDX2_DW(vd, CDX2_W2_LCOLS);
+    const int src = CDX2_DW(vd, CDX2_W2_RES), sstr = CDX2_DW(vd, CDX2_W2_RES_STRIDE);
+    const int dst = CDX2_DW(vd, CDX2_W2_DST), dstr = CDX2_DW(vd, CDX2_W2_DST_STRIDE);
+    const float* __restrict__ w1 = L.wblob + CDX2_DW(vd, CDX2_W2_BOFF);
+    const float* __restrict__ w2 = L.wblob + CDX2_DW(vd, CDX2_W2_GAMMA);
+    const float* __restrict__ ev = emb_row + CDX2_DW(vd, CDX2_W2_EMB);
+    float* gz = tl + L.stage_off;
+    for (int j = tid; j < hidden; j += THREADS) {
+        float z = ev[j];
+        for (int l = 0; l < len; ++l)
+            for (int c = 0; c < ch; ++c) z = fmaf(w1[(size_t)(l * ch + c) * hidden + j], tl[src + (l + CDX2_HALO2) * sstr + c], z);
+        gz[j] = w2[j] * mish2_grad(z);
+    }
+    __syncthreads();
+    for (int i = tid; i < len * ch; i += THREADS) {
+        const int l = i / ch, c = i - l * ch;
+        const float* wr = w1 + (size_t)i * hidden;
+        float acc = 0.f;
+        for (int j = 0; j < hidden; ++j) acc = fmaf(wr[j], gz[j], acc);
+        tl[dst + (l + CDX2_HALO2) * dstr + c] = acc;
+    }
+    for (int i = tid; i < 2 * CDX2_HALO2 * dstr; i += THREADS) {       // halo rows of the gradient slot (a conv source)
+        const int r = i / dstr, col = i - r * dstr;
+        tl[dst + (r < CDX2_HALO2 ? r : len + r) * dstr + col] = 0.f;
+    }
+    __syncthreads();
+}
+
 // Issue the first PF records of item `it` (this wave's first item of the next op) into the ring.  No clamp to the item's
 // record count: the blob ends with PF records of padding, slots past `nq` are simply never consumed.
 template <int PF>
@@ -453,13 +553,20 @@ __device__ __forceinline__ void prefetch_ring(const Item& it, const float* __res
 // Epilogue threads: 256 per trajectory (8 GroupNorm groups x 32 lanes).  4 waves: all of them, one trajectory after the other;
 // 8 waves, T = 2: waves 0-3 take trajectory 0 while waves 4-7 take trajectory 1; 8 waves, T = 1: waves 0-3 run the epilogue,
 // waves 4-7 rewrite the destination's halo rows.
-template <int T, int NWV>
+template <int T, int NWV, bool BWD>
 __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* ops, int vd, int vdn, Item& it,
                                        const float* __restrict__ emb_row, float* __restrict__ lds, int tid,
                                        Ring<WG<NWV>::PF>& ring, unsigned long long* prof) {
     constexpr bool SPLIT_T = NWV == 8 && T == 2;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tf = L.traj_floats;
+    if (BWD && CDX2_DW(vd, CDX2_W2_KIND) == CDX2_KIND2_HEAD) {       // classifier head: no K loop, its own two barriers
+        it = inline_item(vdn);
+        if (wave < CDX2_DW(vdn, CDX2_W2_NITEMS)) prefetch_ring(it, L.wblob, lane, ring);
+#pragma unroll 1
+        for (int t = 0; t < T; ++t) run_head<WG<NWV>::THREADS>(L, vd, emb_row, lds + t * tf, tid);
+        return;
+    }
     const int flags = CDX2_DW(vd, CDX2_W2_FLAGS), coutp = CDX2_DW(vd, CDX2_W2_COUTP), shift = CDX2_DW(vd, CDX2_W2_CG4_SHIFT);
     const int l_out = CDX2_DW(vd, CDX2_W2_LOUT), sstride = CDX2_DW(vd, CDX2_W2_SSTRIDE);
     const Geom g{CDX2_DW(vd, CDX2_W2_LCOLS), CDX2_DW(vd, CDX2_W2_CSTRIDE), CDX2_DW(vd, CDX2_W2_OSTRIDE), sstride, L.stage_off};
@@ -476,7 +583,7 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
     P.bi = P.ga = P.be = P.em = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (epi_wave) {
         P.bi = *reinterpret_cast<const f32x4*>(L.wblob + CDX2_DW(vd, CDX2_W2_BOFF) + c);
-        if (flags & CDX2_F2_GN) {
+        if (flags & (CDX2_F2_GN | CDX2_F2_GNBWD)) {
             P.ga = *reinterpret_cast<const f32x4*>(L.wblob + CDX2_DW(vd, CDX2_W2_GAMMA) + c);
             P.be = *reinterpret_cast<const f32x4*>(L.wblob + CDX2_DW(vd, CDX2_W2_BETA) + c);
         }
@@ -499,15 +606,19 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
     __syncthreads();
     stamp(prof ? prof + 2 : nullptr, tid);
 
-    const EpiDesc e = decode_epi(vd);
+    const EpiDesc e = decode_epi<BWD>(vd);
     const int t_lo = SPLIT_T ? (wave >> 2) : 0, t_hi = SPLIT_T ? t_lo + 1 : T;
 #pragma unroll 1
     for (int t = t_lo; t < t_hi; ++t) {
         float* tl = lds + t * tf;
         if (epi_wave) {
-            if (e.nk == 1) epilogue<1>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane);
-            else if (e.nk == 2) epilogue<2>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane);
-            else epilogue<CDX2_MAX_NK2>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane);
+            if (BWD && (e.flags & CDX2_F2_GNBWD)) {
+                if (e.nk == 1) epilogue_bwd<1>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp);
+                else if (e.nk == 2) epilogue_bwd<2>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp);
+                else epilogue_bwd<CDX2_MAX_NK2>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp);
+            } else if (e.nk == 1) epilogue<1, BWD>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp);
+            else if (e.nk == 2) epilogue<2, BWD>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp);
+            else epilogue<CDX2_MAX_NK2, BWD>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp);
         }
         if (halo_wave) {
             // wave w (mod 4) rewrites halo row w of the destination (the arena hands this LDS to slots of other shapes in between)
@@ -515,6 +626,9 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
             const int hrow = hw < CDX2_HALO2 ? hw : e.l_out + hw;
             for (int j = lane * 4; j < e.dstride; j += 256)
                 *reinterpret_cast<f32x4*>(tl + e.dst + hrow * e.dstride + j) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (BWD && (e.flags & CDX2_F2_DUAL))
+                for (int j = lane * 4; j < e.d2stride; j += 256)
+                    *reinterpret_cast<f32x4*>(tl + e.dst2 + hrow * e.d2stride + j) = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     }
     __syncthreads();
@@ -523,7 +637,7 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
 
 // T = 1: two workgroups per CU must be able to co-reside (that is what hides this latency-bound kernel's stalls from B = 512
 // on), i.e. at most 256 VGPR + AGPR per lane -- the second launch-bound argument is waves per SIMD.
-template <int T, int NWV>
+template <int T, int NWV, bool BWD>
 __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_unet2_kernel(const cdx_unet2_launch L) {
     constexpr int THREADS = WG<NWV>::THREADS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -576,7 +690,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
             // (profile the SECOND forward when there is one: instruction / scalar caches warm, like every later step)
             unsigned long long* pslot = (profiling && step == (L.n_steps > 1 ? 1 : 0)) ? lprof + (size_t)oi * 8 : nullptr;
             stamp(pslot, tid);
-            run_op<T, NWV>(L, ops, vd, vdn, it, emb_row, lds, tid, ring, pslot);
+            run_op<T, NWV, BWD>(L, ops, vd, vdn, it, emb_row, lds, tid, ring, pslot);
             vd = vdn;
         }
         if (L.n_steps == 0) break;
@@ -595,6 +709,9 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
                 const int xo = L.x_off + n * L.x_stride + c;
                 const float x = tl[xo];
                 float p = tl[L.pred_off + n * L.pred_stride + c];
+                // classifier guidance (reference diffusionsde.py:153-173): the prediction is shifted along d log p / d x_t BEFORE
+                // it is clipped; cg_scale[step] = -w sigma (noise prediction) or w sigma^2 / alpha (x0 prediction), frozen by the host
+                if (BWD && L.cg_scale) p += L.cg_scale[step] * tl[L.grad_off + n * L.grad_stride + c];
                 if (L.predict_noise) {
                     if (L.x_max) p = fmaxf(p, (x - al * L.x_max[e]) / sg);
                     if (L.x_min) p = fminf(p, (x - al * L.x_min[e]) / sg);
@@ -650,7 +767,10 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
     for (int t = 0; t < T; ++t) {
         if (b0 + t >= L.batch) break;
         const size_t xbase = (size_t)(b0 + t) * HD;
-        const int off = L.n_steps == 0 ? L.pred_off : L.x_off, str = L.n_steps == 0 ? L.pred_stride : L.x_stride;
+        // one forward (n_steps == 0): the network output -- of a program with backward ops, the gradient slot
+        const bool want_grad = BWD && L.n_steps == 0 && L.grad_off >= 0 && L.with_backward;
+        const int off = L.n_steps == 0 ? (want_grad ? L.grad_off : L.pred_off) : L.x_off;
+        const int str = L.n_steps == 0 ? (want_grad ? L.grad_stride : L.pred_stride) : L.x_stride;
         for (int e = tid; e < HD; e += THREADS) {
             const int n = e / D, c = e - n * D;
             L.x_out[xbase + e] = lds[t * tf + off + n * str + c];
@@ -669,6 +789,7 @@ __global__ __launch_bounds__(256) void cdx_unet2_embtab_kernel(const cdx_unet2_e
     float* v0 = sh;
     float* h = v0 + A.emb_dim;
     float* m = h + A.hidden;
+    float* raw = m + A.md;
     const int r = blockIdx.x, tid = threadIdx.x;
     for (int i = tid; i < A.emb_dim; i += 256) v0[i] = A.temb[(size_t)r * A.emb_dim + i];
     __syncthreads();
@@ -681,13 +802,20 @@ __global__ __launch_bounds__(256) void cdx_unet2_embtab_kernel(const cdx_unet2_e
     for (int o = tid; o < A.md; o += 256) {
         float acc = A.wblob[A.b2 + o];
         for (int i = 0; i < A.hidden; ++i) acc = fmaf(A.wblob[A.w2 + (size_t)i * A.md + o], h[i], acc);
+        raw[o] = acc;
         m[o] = mish2(acc);
     }
     __syncthreads();
+    float* orow = A.out + (size_t)r * A.out_ld;
     for (int o = tid; o < A.n_emb; o += 256) {
         float acc = A.wblob[A.b3 + o];
         for (int i = 0; i < A.md; ++i) acc = fmaf(A.wblob[A.w3 + (size_t)i * A.n_emb + o], m[i], acc);
-        A.out[(size_t)r * A.n_emb + o] = acc;
+        orow[A.col0 + o] = acc;
+    }
+    for (int o = tid; o < A.n_raw; o += 256) {            // rows applied to the RAW embedding (classifier head)
+        float acc = A.wblob[A.b4 + o];
+        for (int i = 0; i < A.md; ++i) acc = fmaf(A.wblob[A.w4 + (size_t)i * A.n_raw + o], raw[i], acc);
+        orow[A.col4 + o] = acc;
     }
 }
 
@@ -699,8 +827,11 @@ int cdx_unet2_embtab(const cdx_unet2_embtab_args* A, void* hip_stream) {
     cdx_set_err("");
     if (!A || !A->wblob || !A->temb || !A->out) { cdx_set_err("null pointer in embtab args"); return CDX_EINVAL; }
     if (A->n_rows == 0) return CDX_OK;
-    if (A->n_rows < 0 || A->emb_dim <= 0 || A->hidden <= 0 || A->md <= 0 || A->n_emb <= 0) { cdx_set_err("non-positive size"); return CDX_EINVAL; }
-    const size_t sh = (size_t)(A->emb_dim + A->hidden + A->md) * sizeof(float);
+    if (A->n_rows < 0 || A->emb_dim <= 0 || A->hidden <= 0 || A->md <= 0 || A->n_emb <= 0 || A->n_raw < 0) { cdx_set_err("non-positive size"); return CDX_EINVAL; }
+    if (A->out_ld < A->col0 + A->n_emb || (A->n_raw > 0 && A->out_ld < A->col4 + A->n_raw) || A->col0 < 0 || A->col4 < 0) {
+        cdx_set_err("embedding table columns do not fit the row stride"); return CDX_EINVAL;
+    }
+    const size_t sh = (size_t)(A->emb_dim + A->hidden + 2 * A->md) * sizeof(float);
     if (sh > 64u * 1024u) { cdx_set_err("embedding MLP too wide for the table kernel"); return CDX_EINVAL; }
     hipLaunchKernelGGL(cdx_unet2_embtab_kernel, dim3(A->n_rows), dim3(256), sh, reinterpret_cast<hipStream_t>(hip_stream), *A);
     const hipError_t e = hipGetLastError();
@@ -724,8 +855,14 @@ int cdx_unet2_run(const cdx_unet2_launch* L, void* hip_stream) {
     size_t lds_bytes = (size_t)L->traj_floats * L->traj_per_wg * sizeof(float);
     if (L->prof) lds_bytes += (size_t)(L->n_ops * 8 + 2) * sizeof(unsigned long long);
     if (lds_bytes > 160u * 1024u) { cdx_set_err("program needs more than 160 KiB of LDS"); return CDX_ELDS; }
-    auto kern = L->n_waves == 8 ? (L->traj_per_wg == 2 ? cdx_unet2_kernel<2, 8> : cdx_unet2_kernel<1, 8>)
-                                : (L->traj_per_wg == 2 ? cdx_unet2_kernel<2, 4> : cdx_unet2_kernel<1, 4>);
+    const bool guided = L->cg_scale != nullptr || L->with_backward != 0;
+    if (guided && (L->n_waves != 8 || L->traj_per_wg != 1)) {
+        cdx_set_err("programs with backward ops (classifier guidance) run in the 8-wave, one-trajectory shape only"); return CDX_EINVAL;
+    }
+    if (L->cg_scale && (L->grad_off < 0 || (L->grad_off & 3) || (L->grad_stride & 3))) { cdx_set_err("cg_scale given without a gradient slot"); return CDX_EINVAL; }
+    auto kern = guided ? cdx_unet2_kernel<1, 8, true>
+              : L->n_waves == 8 ? (L->traj_per_wg == 2 ? cdx_unet2_kernel<2, 8, false> : cdx_unet2_kernel<1, 8, false>)
+                                : (L->traj_per_wg == 2 ? cdx_unet2_kernel<2, 4, false> : cdx_unet2_kernel<1, 4, false>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
     const int grid = (L->batch + L->traj_per_wg - 1) / L->traj_per_wg;

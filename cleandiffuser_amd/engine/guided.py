@@ -71,6 +71,13 @@ def guided_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, feed) -
         x_max = _dense_hd(getattr(solver, "x_max", None), h, d, dev) if clip else None
     except ValueError:
         return None
+    if (cond_vec is None or w_cfg == 0.0) and runtime._is_janner(net):
+        # unconditional temporal U-Net: the classifier's forward + backward joins the denoiser in the second-generation kernel --
+        # the whole guided loop is one launch instead of ~105 launches per step
+        from . import runtime2
+        out = runtime2.guided_sample2(solver, net, clf.model_ema, plan, xt, prior, feed, fix_mask, x_min, x_max, w_cg)
+        if out is not None:
+            return out
     with torch.no_grad():
         comp = runtime.compiled_program(net, h)
         if cond_vec is None or w_cfg == 0.0:

@@ -51,7 +51,8 @@ HALO2 = 2                     # zero rows on either side of a slot: covers kerne
 
 (W2_KIND, W2_FLAGS, W2_COUT, W2_LOUT, W2_LCOLS, W2_CSTRIDE, W2_OSTRIDE, W2_MODE, W2_NT, W2_NITEMS, W2_ITEMS, W2_DST,
  W2_DST_STRIDE, W2_SSTRIDE, W2_KSPLIT, W2_BOFF, W2_GAMMA, W2_BETA, W2_EMB, W2_RES, W2_RES_STRIDE, W2_CG4_SHIFT, W2_INV_CNT,
- W2_NK, W2_COUTP) = range(25)
+ W2_NK, W2_COUTP, W2_SAVE, W2_SAVE_STRIDE, W2_STATS, W2_DST2, W2_DST2_STRIDE) = range(30)
+KIND2_CONV, KIND2_HEAD = 0, 1
 W2_ITEM0 = 32                 # items 0..nw-1 inline; items nw.. in the tail table at W2_ITEMS
 
 
@@ -66,7 +67,10 @@ def ring_depth(nw: int) -> int:
 # first column, (pad | output-position offset << 8), source slot (float offset | row stride << 16), chunks per tap
 I2_WOFF, I2_NQ, I2_TAPCC, I2_PART, I2_COL0, I2_PADOOFF, I2_SRCSTR, I2_CCN = range(8)
 
-F2_GN, F2_EMB, F2_RES, F2_PRED = 1, 2, 4, 8
+# F2_SAVE: a GroupNorm op also stores the normalised (pre-affine) values and the group rstd for the backward pass;
+# F2_GNBWD: the epilogue is the BACKWARD of (GroupNorm -> Mish) of the layer whose saved values W2_SAVE / W2_STATS name, applied to
+# the conv result (+ residual slot); F2_DUAL: the value before that backward is also stored (slot W2_DST2)
+F2_GN, F2_EMB, F2_RES, F2_PRED, F2_SAVE, F2_GNBWD, F2_DUAL = 1, 2, 4, 8, 16, 32, 64
 
 
 def pad32(c: int) -> int:
@@ -83,6 +87,7 @@ class Act:
     uid: int
     off: int = -1                     # float offset of the slot (its first halo row) inside the trajectory region
     persistent: bool = False
+    halo: int = HALO2                 # 0: a slot that is never a conv source (saved normalised values of the backward pass)
 
     @property
     def stride(self):
@@ -90,11 +95,11 @@ class Act:
 
     @property
     def floats(self):
-        return (self.length + 2 * HALO2) * self.stride
+        return (self.length + 2 * self.halo) * self.stride
 
     @property
     def data_off(self):               # float offset of position 0
-        return self.off + HALO2 * self.stride
+        return self.off + self.halo * self.stride
 
 
 @dataclass
@@ -118,6 +123,9 @@ class Program2:
     n_conv: int = 0
     meta: dict = field(default_factory=dict)
     nw: int = NW2                      # waves per workgroup the work items were cut for
+    embtabs: List[dict] = field(default_factory=list)      # one embedding-MLP spec per network (denoiser[, classifier])
+    grad_off: int = -1                 # guided programs: position 0 of the classifier-gradient slot
+    grad_stride: int = 0
 
     def lds_bytes(self, traj_per_wg: int) -> int:
         return 4 * self.traj_floats * traj_per_wg
@@ -147,7 +155,7 @@ class _Builder2:
         self.device = device
         self.nw = nw
         self.ops: List[List[int]] = []
-        self.op_acts: List[Tuple[List[Act], Act]] = []     # (slots read: sources [+ residual], slot written) per op
+        self.op_acts: List[dict] = []                      # per op: srcs / res / dst / save / dst2 slots + reads / writes (liveness)
         self.op_item_src: List[List[int]] = []            # per op, per item: index of the source slot it reads
         self.op_items: List[list] = []
         self.chunks: List[torch.Tensor] = []
@@ -156,6 +164,7 @@ class _Builder2:
         self.stage = 0
         self.macs = 0
         self.n_emb = 0
+        self.n_stats = 0
         self.allow_4x4 = True
 
     def add(self, t: torch.Tensor, pad_to: int = 4) -> int:
@@ -168,8 +177,8 @@ class _Builder2:
         self.blob_len += t.numel()
         return off
 
-    def act(self, length: int, chans: int, persistent=False) -> Act:
-        a = Act(length, chans, len(self.acts), persistent=persistent)
+    def act(self, length: int, chans: int, persistent=False, halo: int = HALO2) -> Act:
+        a = Act(length, chans, len(self.acts), persistent=persistent, halo=halo)
         self.acts.append(a)
         return a
 
@@ -178,14 +187,33 @@ class _Builder2:
         self.n_emb += pad32(c_out)
         return off
 
-    def conv(self, srcs: List[Act], dst: Act, w_eff: torch.Tensor, bias: torch.Tensor, *, stride=1, pad=0, transposed=False,
-             gn: Optional[nn.Module] = None, emb_off: int = -1, res: Optional[Act] = None, pred: bool = False):
-        """One fused op: conv over the channel concat of `srcs` -> [GroupNorm -> Mish] -> [+ emb] -> [+ residual slot `res` (may be
-        `dst`: accumulate)] -> dst.  `transposed`: ConvTranspose1d(k=4, stride=2, pad=1) as two 2-tap convs, one per output parity."""
+    def stats_slot(self) -> int:
+        """8 floats (one rstd per GroupNorm group) in the persistent statistics area; returns the float index."""
+        off = self.n_stats
+        self.n_stats += GROUPS2
+        return off
+
+    def conv(self, srcs: List[Act], dst: Act, w_eff: torch.Tensor, bias: Optional[torch.Tensor], *, stride=1, pad=0,
+             transposed=False, phases=None, gn: Optional[nn.Module] = None, emb_off: int = -1, res: Optional[Act] = None,
+             pred: bool = False, save: Optional[Tuple[Act, int]] = None, bwd: Optional[dict] = None):
+        """One fused op: conv over the channel concat of `srcs` -> epilogue -> dst.
+
+        Forward epilogue: [GroupNorm -> Mish] -> [+ emb] -> [+ residual slot `res` (may be `dst`: accumulate)].  `save=(slot, stats)`
+        additionally stores the normalised pre-affine values and the group rstd (what the backward of this layer needs).
+        Backward epilogue (`bwd=dict(gn=<GroupNorm of the layer below>, save=<its saved slot>, stats=<its stats index>,
+        dst2=<slot or None>)`): v = conv [+ res]; dst2 <- v; dst <- d/du of Mish(GroupNorm(u)) applied to v.
+
+        `transposed`: ConvTranspose1d(k=4, stride=2, pad=1) as two 2-tap convs, one per output parity.  `phases`: explicit list of
+        (taps-in-row-order weights [C_out][taps][C_in], item pad, output offset) of a stride-2 scatter (the backward of a strided
+        conv); phases may have different tap counts."""
         c_out, taps, c_in = w_eff.shape
         l_out = dst.length
         assert c_in == sum(a.chans for a in srcs) and dst.chans == c_out and 1 <= len(srcs) <= 2
-        if transposed:
+        if phases is not None:
+            if l_out != 2 * srcs[0].length or len(srcs) != 1:
+                raise ValueError("explicit phases describe a stride-2 scatter of one source")
+            l_cols, cstride, ostride = srcs[0].length, 1, 2
+        elif transposed:
             if (taps, stride, pad) != (4, 2, 1) or l_out != 2 * srcs[0].length or len(srcs) != 1:
                 raise ValueError("v2 lowers ConvTranspose1d(4, 2, 1) of one source only")
             # (taps in row order, item pad, output offset): even outputs n = 2m read rows m-1, m with taps 3, 1; odd n = 2m+1 rows m, m+1 with 2, 0
@@ -196,6 +224,9 @@ class _Builder2:
                 raise ValueError(f"kernel size {taps} needs more than {HALO2} halo rows")
             phases = [(w_eff, pad, 0)]
             l_cols, cstride, ostride = l_out, stride, 1
+        for w, ppad, _ in phases:
+            if ppad > HALO2 or (w.shape[1] - 1 - ppad) > HALO2:
+                raise ValueError("phase reaches past the halo rows")
         mode = MODE_4X4 if (l_cols <= 8 and c_out % 64 == 0 and self.allow_4x4) else MODE_16X16
         rows, cols = (16, 16) if mode == MODE_16X16 else (64, 4)
         nt = 2 if (mode == MODE_4X4 and l_cols > 4) else 1
@@ -204,44 +235,52 @@ class _Builder2:
         tiles = n_rt * n_cg * len(phases)
         coutp = pad32(c_out)
         sstride = coutp + 4
-        # record stream of a row tile: [source 0: taps x chunks | source 1: taps x chunks]; a K slice never straddles the sources
-        streams = []
+        nw, ring = self.nw, ring_depth(self.nw)
+        # record stream of a (phase, row tile): [source 0: taps x chunks | source 1: taps x chunks]; a K slice never straddles the
+        # sources.  K slices: every source's record range is cut evenly; with two sources (a concat) each source gets at least one
+        # slice and the epilogue sums the staged partials.  Phases with fewer taps get the same NUMBER of slices (shorter ones).
+        per_src = max(1, (nw // tiles if tiles < nw else 1) // len(srcs))
+        ph_segs = []
         for w, _, _ in phases:
             segs, lo = [], 0
             for a in srcs:
                 segs.append(_records(w[:, :, lo:lo + a.chans], mode))
                 lo += a.chans
-            streams.append(segs)
-        seg_n = [r.shape[1] for r, _ in streams[0]]
-        nqt = sum(seg_n)
-        # K slices: cut every source's record range evenly; with two sources (a concat) the slices never straddle the boundary,
-        # whatever the tile count -- each source gets at least one slice and the epilogue sums the staged partials
-        nw, ring = self.nw, ring_depth(self.nw)
-        per_src = max(1, (nw // tiles if tiles < nw else 1) // len(srcs))
-        per_src = [min(per_src, n) for n in seg_n]
-        ksplit = sum(per_src)
-        cuts, base = [], 0                                  # (first record, one past the last, source index) per slice
-        for si, (n, k) in enumerate(zip(seg_n, per_src)):
-            # long streams are cut on multiples of the ring depth: the kernel's immediate-offset steady loop needs a slice to start
-            # on a ring-aligned chunk of its tap
-            al = ring if n >= 2 * ring * k else 1
-            edge = [min(n, (j * n // k + al // 2) // al * al) for j in range(k)] + [n]
-            cuts += [(base + edge[j], base + edge[j + 1], si, base) for j in range(k)]
-            base += n
-        woffs = [self.add(torch.cat([r for r, _ in segs], dim=1).contiguous()) for segs in streams]
+            ph_segs.append(segs)
+        # slices per source: the same for every phase (the epilogue sums `ksplit` staged partials of every output position)
+        per = [min([per_src] + [segs[si][0].shape[1] for segs in ph_segs]) for si in range(len(srcs))]
+        ph_info = []
+        for (w, ppad, ooff), segs in zip(phases, ph_segs):
+            seg_n = [r.shape[1] for r, _ in segs]
+            cuts, base = [], 0                              # (first record, one past the last, source index, source base) per slice
+            for si, (n, k) in enumerate(zip(seg_n, per)):
+                # long streams are cut on multiples of the ring depth: the kernel's immediate-offset steady loop needs a slice to
+                # start on a ring-aligned chunk of its tap
+                al = ring if n >= 2 * ring * k else 1
+                edge = [min(n, (j * n // k + al // 2) // al * al) for j in range(k)] + [n]
+                cuts += [(base + edge[j], base + edge[j + 1], si, base) for j in range(k)]
+                base += n
+            woff = self.add(torch.cat([r for r, _ in segs], dim=1).contiguous())
+            ph_info.append(dict(segs=segs, nqt=sum(seg_n), cuts=cuts, woff=woff, pad=ppad, ooff=ooff))
+        ksplit = max(len(pi["cuts"]) for pi in ph_info)
         items, item_src = [], []
-        for item in range(tiles * ksplit):
-            tile, ks = item % tiles, item // tiles
-            ph, tile = tile % len(phases), tile // len(phases)
-            rt, cgi = tile % n_rt, tile // n_rt
-            q0, q1, si, sbase = cuts[ks]
-            ccn = streams[ph][si][1]
-            items.append([woffs[ph] + (rt * nqt + q0) * 256, q1 - q0, ((q0 - sbase) // ccn) | (((q0 - sbase) % ccn) << 8),
-                          ks * l_out * sstride + rt * rows, cgi * nt * cols, phases[ph][1] | (phases[ph][2] << 8), 0, ccn])
-            item_src.append(si)
-        words = {W2_KIND: 0, W2_COUT: c_out, W2_LOUT: l_out, W2_LCOLS: l_cols, W2_CSTRIDE: cstride, W2_OSTRIDE: ostride,
+        for ks in range(ksplit):
+            for tile in range(n_rt * n_cg):
+                rt, cgi = tile % n_rt, tile // n_rt
+                for pi in ph_info:
+                    if ks >= len(pi["cuts"]):
+                        continue                             # this phase has fewer slices: its staged partials of slice ks must read 0
+                    q0, q1, si, sbase = pi["cuts"][ks]
+                    ccn = pi["segs"][si][1]
+                    items.append([pi["woff"] + (rt * pi["nqt"] + q0) * 256, q1 - q0, ((q0 - sbase) // ccn) | (((q0 - sbase) % ccn) << 8),
+                                  ks * l_out * sstride + rt * rows, cgi * nt * cols, pi["pad"] | (pi["ooff"] << 8), 0, ccn])
+                    item_src.append(si)
+        if any(len(pi["cuts"]) != ksplit for pi in ph_info):
+            raise ValueError("phases with different K-slice counts are not supported (stale partial tiles)")
+        words = {W2_KIND: KIND2_CONV, W2_COUT: c_out, W2_LOUT: l_out, W2_LCOLS: l_cols, W2_CSTRIDE: cstride, W2_OSTRIDE: ostride,
                  W2_MODE: mode, W2_NT: nt, W2_NITEMS: len(items), W2_DST_STRIDE: dst.stride, W2_SSTRIDE: sstride,
-                 W2_KSPLIT: ksplit, W2_BOFF: self.add(_padded(bias, coutp)), W2_COUTP: coutp}
+                 W2_KSPLIT: ksplit, W2_COUTP: coutp,
+                 W2_BOFF: self.add(_padded(bias if bias is not None else torch.zeros(c_out, device=self.device), coutp))}
         cg = coutp // GROUPS2
         cg4 = cg // 4
         assert cg4 & (cg4 - 1) == 0 and cg4 <= 32, f"C_out {c_out}: channels per group / 4 must be a power of two <= 32"
@@ -250,14 +289,30 @@ class _Builder2:
             raise ValueError(f"epilogue: {cg4 * l_out} float4 items per group > {32 * MAX_NK2} (horizon too long for v2)")
         words[W2_CG4_SHIFT], words[W2_NK] = cg4.bit_length() - 1, nk
         flags = 0
-        if gn is not None:
+        reads, writes = list(srcs), [dst]
+        norm = gn if bwd is None else bwd["gn"]
+        if norm is not None:
             # the epilogue cuts pad32(C_out) channels into 8 lane groups; a real group must be exactly one of them (C_out = 16 with
             # 4 groups of 4 is fine: lane groups 4..7 then work on pad channels that are never stored)
-            if c_out % gn.num_groups or c_out // gn.num_groups != cg or abs(gn.eps - GN_EPS) > 1e-12:
-                raise ValueError(f"v2 epilogue needs GroupNorm groups of pad32(C)/8 channels (C={c_out}, G={gn.num_groups})")
-            flags |= F2_GN
+            if c_out % norm.num_groups or c_out // norm.num_groups != cg or abs(norm.eps - GN_EPS) > 1e-12:
+                raise ValueError(f"v2 epilogue needs GroupNorm groups of pad32(C)/8 channels (C={c_out}, G={norm.num_groups})")
+            flags |= F2_GN if bwd is None else F2_GNBWD
             words[W2_INV_CNT] = _fbits(1.0 / (cg * l_out))
-            words[W2_GAMMA], words[W2_BETA] = self.add(_padded(gn.weight, coutp)), self.add(_padded(gn.bias, coutp))
+            words[W2_GAMMA], words[W2_BETA] = self.add(_padded(norm.weight, coutp)), self.add(_padded(norm.bias, coutp))
+        if bwd is not None:
+            assert gn is None and emb_off < 0 and save is None and bwd["save"].chans == c_out and bwd["save"].length == l_out
+            words[W2_SAVE_STRIDE], words[W2_STATS] = bwd["save"].stride, bwd["stats"]
+            reads.append(bwd["save"])
+            if bwd.get("dst2") is not None:
+                assert bwd["dst2"].chans == c_out and bwd["dst2"].length == l_out
+                flags |= F2_DUAL
+                words[W2_DST2_STRIDE] = bwd["dst2"].stride
+                writes.append(bwd["dst2"])
+        if save is not None:
+            assert gn is not None and save[0].chans == c_out and save[0].length == l_out and save[0].halo == 0
+            flags |= F2_SAVE
+            words[W2_SAVE_STRIDE], words[W2_STATS] = save[0].stride, save[1]
+            writes.append(save[0])
         if emb_off >= 0:
             flags |= F2_EMB
             words[W2_EMB] = emb_off
@@ -265,6 +320,7 @@ class _Builder2:
             assert res.chans == c_out and res.length == l_out
             flags |= F2_RES
             words[W2_RES_STRIDE] = res.stride
+            reads.append(res)
         if pred:
             flags |= F2_PRED
         words[W2_FLAGS] = flags
@@ -272,17 +328,40 @@ class _Builder2:
         for k, v in words.items():
             op[k] = int(v)
         self.ops.append(op)
-        self.op_acts.append((list(srcs) + ([res] if res is not None else []), dst))
+        self.op_acts.append(dict(srcs=list(srcs), res=res, dst=dst, save=(save[0] if save is not None else (bwd["save"] if bwd else None)),
+                                 dst2=(bwd.get("dst2") if bwd else None), reads=reads, writes=writes))
         self.op_items.append(items)
         self.op_item_src.append(item_src)
         self.stage = max(self.stage, ksplit * l_out * sstride)
-        self.macs += c_out * l_out * taps * c_in // (2 if transposed else 1)
+        self.macs += sum(c_out * (l_cols if len(phases) > 1 else l_out) * w.shape[1] * c_in for w, _, _ in phases)
+
+    def head(self, src: Act, dst: Act, w1: torch.Tensor, e_off: int, w2: torch.Tensor):
+        """Classifier head with its backward in one op (reference nn_classifier/half_jannerunet.py:49-50, :62):
+        z = W1x flat(src) + e (e = W1e emb + b1 comes from the per-step table at `e_off`), y = w2 . Mish(z) (+ b2, irrelevant for the
+        gradient); dst <- d y / d src = W1x^T (w2 * Mish'(z)).  `w1` = W1x as [hidden][C][L] (the reference flattens channel-major)."""
+        hidden, c, l = w1.shape
+        assert (c, l) == (src.chans, src.length) and (dst.chans, dst.length) == (c, l) and w2.numel() == hidden
+        if hidden > 256:
+            raise ValueError("classifier head wider than 256 hidden units")
+        wp = w1.permute(2, 1, 0).contiguous()                # [l][c][hidden]: the thread of hidden unit j reads consecutive j
+        words = {W2_KIND: KIND2_HEAD, W2_COUT: hidden, W2_LOUT: l, W2_LCOLS: c, W2_NITEMS: 0, W2_DST_STRIDE: dst.stride,
+                 W2_RES_STRIDE: src.stride, W2_BOFF: self.add(wp), W2_GAMMA: self.add(w2.reshape(-1)), W2_EMB: e_off,
+                 W2_COUTP: pad32(c), W2_NK: 1, W2_KSPLIT: 1}
+        op = [0] * op_words(self.nw)
+        for k, v in words.items():
+            op[k] = int(v)
+        self.ops.append(op)
+        self.op_acts.append(dict(srcs=[], res=src, dst=dst, save=None, dst2=None, reads=[src], writes=[dst]))
+        self.op_items.append([])
+        self.op_item_src.append([])
+        self.stage = max(self.stage, 2 * hidden)
+        self.macs += 2 * hidden * c * l
 
     def plan_arena(self, base: int) -> int:
         """First-fit interval allocation over op liveness (same policy as program.py); patches slot offsets into the ops."""
         first, last = {}, {}
-        for i, (reads, writes) in enumerate(self.op_acts):
-            for a in reads + [writes]:
+        for i, oa in enumerate(self.op_acts):
+            for a in oa["reads"] + oa["writes"]:
                 first.setdefault(a.uid, i)
                 last[a.uid] = i
         live: List[Act] = []
@@ -298,13 +377,18 @@ class _Builder2:
             a.off = pos
             live.append(a)
             top = max(top, pos + a.floats)
-        for op, (reads, dst), items, item_src in zip(self.ops, self.op_acts, self.op_items, self.op_item_src):
-            op[W2_DST] = dst.off                                       # slot base = first halo row
-            if op[W2_FLAGS] & F2_RES:
-                op[W2_RES] = reads[-1].off
+        for op, oa, items, item_src in zip(self.ops, self.op_acts, self.op_items, self.op_item_src):
+            op[W2_DST] = oa["dst"].off                                 # slot base = first halo row
+            if oa["res"] is not None:
+                op[W2_RES] = oa["res"].off
+            if oa["save"] is not None:
+                op[W2_SAVE] = oa["save"].off
+            if oa["dst2"] is not None:
+                op[W2_DST2] = oa["dst2"].off
             for rec, si in zip(items, item_src):
-                assert reads[si].off < (1 << 16) and reads[si].stride < (1 << 15)
-                rec[I2_SRCSTR] = reads[si].off | (reads[si].stride << 16)
+                src = oa["srcs"][si]
+                assert src.off < (1 << 16) and src.stride < (1 << 15)
+                rec[I2_SRCSTR] = src.off | (src.stride << 16)
         return top
 
 
@@ -322,16 +406,33 @@ def _padded(v: torch.Tensor, n: int) -> torch.Tensor:
     return torch.cat([v, torch.zeros(n - v.numel(), device=v.device)]) if v.numel() < n else v
 
 
-def compile_janner2(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x4: bool = True, nw: int = NW2) -> Program2:
-    """Lower a JannerUNet1d (reference nn_diffusion/jannerunet.py:98-201) for `horizon` positions and `nw` waves per workgroup."""
-    why = supports_janner(net)
-    if why is not None:
-        raise ValueError(why)
-    dev = next(net.parameters()).device
-    b = _Builder2(dev, nw)
-    b.allow_4x4 = allow_4x4
-    d, k, md = net.in_dim, net.kernel_size, net.model_dim
+def _emb_table_spec(b: "_Builder2", net, blocks, dev, raw_rows: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None) -> dict:
+    """Blob offsets of a network's embedding MLP for cdx_unet2_embtab: map_emb (Linear -> Mish -> Linear), then per block
+    emb_mlp = Mish -> Linear stacked into one matrix over Mish(map_emb(temb)); `raw_rows` = (W, bias, table offset): rows applied to
+    the RAW map_emb output (the classifier head's share of its first Linear)."""
+    emb = {"emb_dim": net.emb_dim, "hidden": net.map_emb[0].out_features, "md": net.map_emb[2].out_features}
+    emb["w0"], emb["b0"] = b.add(net.map_emb[0].weight.t().contiguous()), b.add(net.map_emb[0].bias)
+    emb["w2"], emb["b2"] = b.add(net.map_emb[2].weight.t().contiguous()), b.add(net.map_emb[2].bias)
+    lo = min(off for _, off in blocks)
+    hi = max(off + pad32(rb.emb_mlp[1].out_features) for rb, off in blocks)
+    w_all = torch.zeros(hi - lo, emb["md"], device=dev)
+    b_all = torch.zeros(hi - lo, device=dev)
+    for rb, off in blocks:
+        lin = rb.emb_mlp[1]
+        w_all[off - lo:off - lo + lin.out_features] = lin.weight.detach().to(dev)
+        b_all[off - lo:off - lo + lin.out_features] = lin.bias.detach().to(dev)
+    emb["w3"], emb["b3"], emb["col0"], emb["n_emb"] = b.add(w_all.t().contiguous()), b.add(b_all), lo, hi - lo
+    emb["w4"], emb["b4"], emb["col4"], emb["n_raw"] = 0, 0, 0, 0
+    if raw_rows is not None:
+        w, bias, col = raw_rows
+        emb["w4"], emb["b4"], emb["col4"], emb["n_raw"] = b.add(w.t().contiguous()), b.add(bias), col, w.shape[0]
+    b.macs += net.emb_dim * emb["hidden"] + emb["hidden"] * emb["md"] + emb["md"] * sum(rb.emb_mlp[1].out_features for rb, _ in blocks)
+    return emb
 
+
+def _lower_janner(b: "_Builder2", net, horizon: int, x: Act):
+    """Ops of one JannerUNet1d forward (reference nn_diffusion/jannerunet.py:154-201) reading slot `x`; returns (pred slot, blocks)."""
+    d, k, md = net.in_dim, net.kernel_size, net.model_dim
     blocks = []
 
     def resblock(srcs: List[Act], rb) -> Act:
@@ -350,7 +451,6 @@ def compile_janner2(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x
             b.conv(srcs, out, _conv1d_eff(rb.residual_conv), rb.residual_conv.bias, res=out)     # out += W_r x + b_r
         return out
 
-    x = b.act(horizon, d, persistent=True)
     cur, skips = x, []
     for res1, res2, _, down in net.downs:
         cur = resblock([resblock([cur], res1)], res2)
@@ -373,31 +473,127 @@ def compile_janner2(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x
     fc = net.final_conv
     t = b.act(horizon, md)
     b.conv([cur], t, _conv1d_eff(fc[0]), fc[0].bias, pad=2, gn=fc[1])
-    pred = b.act(horizon, d)                 # arena slot: written by the last op, read by the solver step right after it
-    b.conv([t], pred, _conv1d_eff(fc[3]), fc[3].bias, pred=True)
+    return t, fc, blocks
 
-    # embedding MLP (evaluated by cdx_unet2_embtab, once per schedule): transposed [n_in][n_out] weights
-    emb = {"emb_dim": net.emb_dim, "hidden": net.map_emb[0].out_features, "md": net.map_emb[2].out_features,
-           "n_emb": b.n_emb}
-    emb["w0"], emb["b0"] = b.add(net.map_emb[0].weight.t().contiguous()), b.add(net.map_emb[0].bias)
-    emb["w2"], emb["b2"] = b.add(net.map_emb[2].weight.t().contiguous()), b.add(net.map_emb[2].bias)
-    w_all = torch.zeros(b.n_emb, emb["md"], device=dev)
-    b_all = torch.zeros(b.n_emb, device=dev)
-    for rb, off in blocks:
-        lin = rb.emb_mlp[1]
-        w_all[off:off + lin.out_features] = lin.weight.detach().to(dev)
-        b_all[off:off + lin.out_features] = lin.bias.detach().to(dev)
-    emb["w3"], emb["b3"] = b.add(w_all.t().contiguous()), b.add(b_all)
-    b.macs += net.emb_dim * emb["hidden"] + emb["hidden"] * emb["md"] + emb["md"] * sum(rb.emb_mlp[1].out_features for rb, _ in blocks)
 
-    # ---- LDS plan of one trajectory: [x | prev | stage | arena] ----
+def _dgrad_eff(conv: nn.Conv1d) -> torch.Tensor:
+    """Weights of the backward-data conv of a stride-1 'same' Conv1d as a forward conv: [C_in][tap'][C_out], tap' = k-1-tap."""
+    return conv.weight.detach().permute(1, 2, 0).flip(1)
+
+
+def _lower_half_janner_grad(b: "_Builder2", clf, horizon: int, x: Act, grad: Act):
+    """Forward AND backward-data pass of a HalfJannerUNet1d classifier (reference nn_classifier/half_jannerunet.py:102-125) reading
+    slot `x`: d out / d x -> slot `grad` (what BaseClassifier.gradients returns, classifier/base.py:74-79, for the summed log p).
+    Every GroupNorm layer saves its normalised values + rstd on the way up; on the way down each backward-data conv's epilogue applies
+    the backward of the (GroupNorm -> Mish) below it.  Returns the (block, emb offset) list and the head's table offset."""
+    if clf.norm_type != "groupnorm" or clf.out_dim != 1:
+        raise ValueError("the fused classifier gradient needs norm_type='groupnorm' and out_dim == 1")
+    if horizon != clf.horizon:
+        raise ValueError(f"HalfJannerUNet1d was built for horizon {clf.horizon}, got {horizon}")
+    k = clf.kernel_size
+    blocks, tape = [], []                 # tape: forward records consumed in reverse
+
+    def resblock(src: Act, rb, ksz: int) -> Act:
+        c_out, length = rb.conv1[0].out_channels, src.length
+        e_off = b.emb_slot(c_out)
+        blocks.append((rb, e_off))
+        s1, s2 = (b.act(length, c_out, halo=0), b.stats_slot()), (b.act(length, c_out, halo=0), b.stats_slot())
+        t1 = b.act(length, c_out)
+        b.conv([src], t1, _conv1d_eff(rb.conv1[0]), rb.conv1[0].bias, pad=ksz // 2, gn=rb.conv1[1], emb_off=e_off, save=s1)
+        out = b.act(length, c_out)
+        ident = isinstance(rb.residual_conv, nn.Identity)
+        b.conv([t1], out, _conv1d_eff(rb.conv2[0]), rb.conv2[0].bias, pad=ksz // 2, gn=rb.conv2[1], res=src if ident else None, save=s2)
+        if not ident:
+            b.conv([src], out, _conv1d_eff(rb.residual_conv), rb.residual_conv.bias, res=out)
+        tape.append(("block", rb, ksz, src, s1, s2, ident))
+        return out
+
+    def down(src: Act, dn) -> Act:
+        if src.length % 2:
+            raise ValueError("horizon too short for the classifier's resolutions")
+        nxt = b.act(src.length // 2, src.chans)
+        b.conv([src], nxt, _conv1d_eff(dn.conv), dn.conv.bias, stride=2, pad=1)
+        tape.append(("down", dn, src))
+        return nxt
+
+    cur = x
+    for res1, res2, dn in clf.downs:
+        cur = resblock(resblock(cur, res1, k), res2, k)
+        if not isinstance(dn, nn.Identity):
+            cur = down(cur, dn)
+    for blk, dn in (clf.mid_block1, clf.mid_block2):
+        cur = down(resblock(cur, blk, 5), dn)
+    # ---- head: flatten (channel-major) ++ raw emb -> Linear -> Mish -> Linear; forward + backward in one op ----
+    lin1, lin2 = clf.final_block[0], clf.final_block[2]
+    fc = cur.chans * cur.length
+    if lin1.in_features != fc + clf.model_dim:
+        raise ValueError("classifier head does not match the flattened feature size")
+    head_off = b.emb_slot(lin1.out_features)
+    g = b.act(cur.length, cur.chans)                       # gradient w.r.t. the last downsample's output
+    b.head(cur, g, lin1.weight.detach()[:, :fc].reshape(lin1.out_features, cur.chans, cur.length), head_off, lin2.weight.detach())
+
+    # ---- backward: g = gradient w.r.t. the output of the tape entry on top ----
+    # what lies BELOW an entry decides the epilogue of the op that completes the gradient w.r.t. that entry's input: another
+    # block's output (a residual sum: keep the plain gradient for the skip path AND push it through that block's conv2 norm),
+    # a downsample's output or the network input (plain)
+    def lower_entry(idx: int):
+        return tape[idx - 1] if idx > 0 else None
+
+    def finish(idx: int, make_op):
+        """Emit the op that completes the gradient w.r.t. tape[idx]'s input; returns (plain gradient slot, pre-norm gradient slot)."""
+        below = lower_entry(idx)
+        src_act = tape[idx][3] if tape[idx][0] == "block" else tape[idx][2]
+        if below is not None and below[0] == "block":
+            _, rb_b, _, _, _, s2_b, _ = below
+            plain, gu = b.act(src_act.length, src_act.chans), b.act(src_act.length, src_act.chans)
+            make_op(gu, dict(gn=rb_b.conv2[1], save=s2_b[0], stats=s2_b[1], dst2=plain))
+            return plain, gu
+        plain = grad if below is None else b.act(src_act.length, src_act.chans)
+        make_op(plain, None)
+        return plain, None
+
+    g_plain, g_u2 = g, None
+    for idx in range(len(tape) - 1, -1, -1):
+        ent = tape[idx]
+        if ent[0] == "down":
+            _, dn, src = ent
+            wt = dn.conv.weight.detach().permute(1, 2, 0)                # [C_in][tap][C_out]
+            # y[m] = sum_k W_k x[2m - 1 + k]  =>  gx[2j] = W_1^T gy[j];  gx[2j+1] = W_2^T gy[j] + W_0^T gy[j+1]
+            phases = [(wt[:, [1], :], 0, 0), (wt[:, [2, 0], :], 0, 1)]
+            gsrc = g_plain
+            g_plain, g_u2 = finish(idx, lambda dst, bw: b.conv([gsrc], dst, wt, None, phases=phases, bwd=bw))
+            continue
+        _, rb, ksz, src, s1, s2, ident = ent
+        assert g_u2 is not None, "a block's output gradient always arrives with its conv2 norm already differentiated"
+        gu1 = b.act(src.length, rb.conv1[0].out_channels)
+        b.conv([g_u2], gu1, _dgrad_eff(rb.conv2[0]), None, pad=ksz // 2,
+               bwd=dict(gn=rb.conv1[1], save=s1[0], stats=s1[1], dst2=None))
+        gout = g_plain
+        if ident:
+            skip = gout
+        else:
+            skip = b.act(src.length, src.chans)
+            b.conv([gout], skip, rb.residual_conv.weight.detach().permute(1, 2, 0), None)    # W_r^T g_out
+        g_plain, g_u2 = finish(idx, lambda dst, bw: b.conv([gu1], dst, _dgrad_eff(rb.conv1[0]), None, pad=ksz // 2, res=skip, bwd=bw))
+    return blocks, (lin1, head_off)
+
+
+def _finalize2(b: "_Builder2", nets_emb: List[dict], x: Act, pred: Act, horizon: int, d: int, emb_dim: int, max_lds_bytes: int,
+               persistent: List[Act], grad: Optional[Act] = None) -> Program2:
+    """LDS plan of one trajectory: [x | persistent slots | prev | stats | stage | arena]; item tables; blob."""
+    nw = b.nw
     off = 0
     x.off, off = off, off + x.floats
+    for a in persistent:
+        a.off, off = off, off + a.floats
     prev_off, off = off, off + (horizon * d + 3) // 4 * 4
+    stats_off, off = off, off + (b.n_stats + 3) // 4 * 4
     stage_off, off = off, off + (b.stage + 3) // 4 * 4
     top = (b.plan_arena(off) + 3) // 4 * 4
     if top * 4 > max_lds_bytes:
         raise ValueError(f"LDS plan needs {top * 4} B > {max_lds_bytes} B per trajectory")
+    for op in b.ops:
+        op[W2_STATS] += stats_off
     tail, cursor = [], len(b.ops) * op_words(nw)
     for op, items in zip(b.ops, b.op_items):
         for j, rec in enumerate(items[:nw]):              # a wave's first item: fixed offset inside the descriptor
@@ -411,5 +607,50 @@ def compile_janner2(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x
     blob = torch.cat(b.chunks).contiguous()
     return Program2(ops=ops, ops_buffer=ops_buffer, blob=blob, traj_floats=top, x_off=x.data_off,
                     x_stride=x.stride, pred_off=pred.data_off, pred_stride=pred.stride, prev_off=prev_off, stage_off=stage_off,
-                    horizon=horizon, dim=d, emb_dim=net.emb_dim, n_emb=b.n_emb, embtab=emb, macs_per_forward=b.macs,
-                    n_conv=len(b.ops), meta={"blob_floats": b.blob_len}, nw=nw)
+                    horizon=horizon, dim=d, emb_dim=emb_dim, n_emb=b.n_emb, embtab=nets_emb[0], macs_per_forward=b.macs,
+                    n_conv=len(b.ops), meta={"blob_floats": b.blob_len, "stats_off": stats_off}, nw=nw,
+                    embtabs=nets_emb, grad_off=-1 if grad is None else grad.data_off, grad_stride=0 if grad is None else grad.stride)
+
+
+def compile_janner2(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x4: bool = True, nw: int = NW2) -> Program2:
+    """Lower a JannerUNet1d (reference nn_diffusion/jannerunet.py:98-201) for `horizon` positions and `nw` waves per workgroup."""
+    why = supports_janner(net)
+    if why is not None:
+        raise ValueError(why)
+    dev = next(net.parameters()).device
+    b = _Builder2(dev, nw)
+    b.allow_4x4 = allow_4x4
+    d = net.in_dim
+    x = b.act(horizon, d, persistent=True)
+    t, fc, blocks = _lower_janner(b, net, horizon, x)
+    pred = b.act(horizon, d)                 # arena slot: written by the last op, read by the solver step right after it
+    b.conv([t], pred, _conv1d_eff(fc[3]), fc[3].bias, pred=True)
+    emb = _emb_table_spec(b, net, blocks, dev)
+    return _finalize2(b, [emb], x, pred, horizon, d, net.emb_dim, max_lds_bytes, [])
+
+
+def compile_guided2(net, clf, horizon: int, max_lds_bytes: int = 160 * 1024, nw: int = NW2_MAX) -> Program2:
+    """Denoiser forward + classifier forward/backward as ONE op list (classifier-guided sampling, reference
+    diffusionsde.py:153-173): ops [0, n_den) write the prediction, the rest writes d log p / d x_t into the gradient slot; the
+    kernel's solver step shifts the prediction by cg_scale[step] * gradient before clipping.  Both networks read the state slot."""
+    why = supports_janner(net)
+    if why is not None:
+        raise ValueError(why)
+    if clf.in_dim != net.in_dim:
+        raise ValueError("classifier and denoiser disagree on the state dimension")
+    dev = next(net.parameters()).device
+    b = _Builder2(dev, nw)
+    d = net.in_dim
+    x = b.act(horizon, d, persistent=True)
+    pred = b.act(horizon, d, persistent=True)            # outlives the classifier ops
+    grad = b.act(horizon, d, persistent=True)
+    t, fc, blocks = _lower_janner(b, net, horizon, x)
+    b.conv([t], pred, _conv1d_eff(fc[3]), fc[3].bias, pred=True)
+    n_den = len(b.ops)
+    emb_den = _emb_table_spec(b, net, blocks, dev)
+    cblocks, (lin1, head_off) = _lower_half_janner_grad(b, clf, horizon, x, grad)
+    fcw = lin1.in_features - clf.model_dim
+    emb_clf = _emb_table_spec(b, clf, cblocks, dev, raw_rows=(lin1.weight.detach()[:, fcw:], lin1.bias.detach(), head_off))
+    prog = _finalize2(b, [emb_den, emb_clf], x, pred, horizon, d, net.emb_dim, max_lds_bytes, [pred, grad], grad=grad)
+    prog.meta["n_den"] = n_den
+    return prog

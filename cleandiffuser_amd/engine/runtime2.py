@@ -23,7 +23,9 @@ class CdxUnet2EmbtabArgs(ctypes.Structure):
                 ("emb_dim", ctypes.c_int32), ("hidden", ctypes.c_int32), ("md", ctypes.c_int32), ("n_emb", ctypes.c_int32),
                 ("w0", ctypes.c_int32), ("b0", ctypes.c_int32), ("w2", ctypes.c_int32), ("b2", ctypes.c_int32),
                 ("w3", ctypes.c_int32), ("b3", ctypes.c_int32),
-                ("temb", ctypes.c_void_p), ("n_rows", ctypes.c_int32), ("out", ctypes.c_void_p)]
+                ("temb", ctypes.c_void_p), ("n_rows", ctypes.c_int32), ("out", ctypes.c_void_p),
+                ("out_ld", ctypes.c_int32), ("col0", ctypes.c_int32),
+                ("w4", ctypes.c_int32), ("b4", ctypes.c_int32), ("n_raw", ctypes.c_int32), ("col4", ctypes.c_int32)]
 
 
 class CdxUnet2Launch(ctypes.Structure):
@@ -39,7 +41,8 @@ class CdxUnet2Launch(ctypes.Structure):
                 ("x_in", ctypes.c_void_p), ("prior", ctypes.c_void_p), ("fix_mask", ctypes.c_void_p),
                 ("noise", ctypes.c_void_p), ("x_min", ctypes.c_void_p), ("x_max", ctypes.c_void_p),
                 ("x_out", ctypes.c_void_p), ("init_blend", ctypes.c_int32), ("x_scale", ctypes.c_float),
-                ("prof", ctypes.c_void_p)]
+                ("cg_scale", ctypes.c_void_p), ("grad_off", ctypes.c_int32), ("grad_stride", ctypes.c_int32),
+                ("with_backward", ctypes.c_int32), ("prof", ctypes.c_void_p)]
 
 
 _declared = False
@@ -99,26 +102,30 @@ def supported(module, horizon: int) -> Optional[str]:
     return compiled2(module, horizon).why
 
 
-def film_table(comp: _Compiled2, module, t_vec: torch.Tensor) -> torch.Tensor:
-    """(rows, n_emb) FiLM table of the timesteps in `t_vec`: map_noise (the module's own embedding, a handful of ATen ops) and
-    one cdx_unet2_embtab launch.  Callers memoise the result per plan."""
+def film_table(comp: _Compiled2, module, t_vec: torch.Tensor, modules=None) -> torch.Tensor:
+    """(rows, n_emb) FiLM table of the timesteps in `t_vec`: per network map_noise (the module's own embedding, a handful of ATen
+    ops) and one cdx_unet2_embtab launch that fills the network's columns.  `modules`: the networks of a multi-network program
+    (denoiser, classifier), default [module].  Callers memoise the result per plan."""
     prog = comp.prog
     dev = prog.blob.device
-    with torch.no_grad():
-        temb = R._f32c(module.map_noise(t_vec), dev)
-    out = torch.empty((temb.shape[0], prog.n_emb), device=dev, dtype=torch.float32)
-    e = prog.embtab
-    args = CdxUnet2EmbtabArgs(wblob=prog.blob.data_ptr(), emb_dim=e["emb_dim"], hidden=e["hidden"], md=e["md"], n_emb=e["n_emb"],
-                              w0=e["w0"], b0=e["b0"], w2=e["w2"], b2=e["b2"], w3=e["w3"], b3=e["b3"],
-                              temb=temb.data_ptr(), n_rows=temb.shape[0], out=out.data_ptr())
-    R._check(_lib().cdx_unet2_embtab(ctypes.byref(args), R._stream_ptr(dev)), "cdx_unet2_embtab")
+    mods = list(modules) if modules is not None else [module]
+    assert len(mods) == len(prog.embtabs)
+    out = torch.zeros((t_vec.shape[0], prog.n_emb), device=dev, dtype=torch.float32)
+    for mod, e in zip(mods, prog.embtabs):
+        with torch.no_grad():
+            temb = R._f32c(mod.map_noise(t_vec), dev)
+        args = CdxUnet2EmbtabArgs(wblob=prog.blob.data_ptr(), emb_dim=e["emb_dim"], hidden=e["hidden"], md=e["md"], n_emb=e["n_emb"],
+                                  w0=e["w0"], b0=e["b0"], w2=e["w2"], b2=e["b2"], w3=e["w3"], b3=e["b3"],
+                                  temb=temb.data_ptr(), n_rows=temb.shape[0], out=out.data_ptr(), out_ld=prog.n_emb, col0=e["col0"],
+                                  w4=e["w4"], b4=e["b4"], n_raw=e["n_raw"], col4=e["col4"])
+        R._check(_lib().cdx_unet2_embtab(ctypes.byref(args), R._stream_ptr(dev)), "cdx_unet2_embtab")
     return out
 
 
-def plan_film_table(comp: _Compiled2, module, plan, device) -> torch.Tensor:
+def plan_film_table(comp: _Compiled2, module, plan, device, modules=None) -> torch.Tensor:
     from .plan import cached
-    return cached(plan, ("film2", str(device), id(module), comp.sig),
-                  lambda: film_table(comp, module, R.device_times(plan, device)))
+    return cached(plan, ("film2", str(device), id(module), comp.sig, len(comp.prog.embtabs)),
+                  lambda: film_table(comp, module, R.device_times(plan, device), modules))
 
 
 def min_batch() -> int:
@@ -167,7 +174,8 @@ def shape_for(module, horizon: int, batch: int):
 
 
 def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps=0, predict_noise=0, prior=None,
-           fix_mask=None, noise=None, x_min=None, x_max=None, t_per_wg: Optional[int] = None, x_scale: Optional[float] = None):
+           fix_mask=None, noise=None, x_min=None, x_max=None, t_per_wg: Optional[int] = None, x_scale: Optional[float] = None,
+           cg_scale=None, with_backward: bool = False):
     if batch <= 0:
         return
     prog = comp.prog
@@ -181,7 +189,8 @@ def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps
         steps=R._ptr(steps_dev), n_steps=n_steps, predict_noise=int(predict_noise),
         x_in=x_in.data_ptr(), prior=R._ptr(prior), fix_mask=R._ptr(fix_mask), noise=R._ptr(noise), x_min=R._ptr(x_min),
         x_max=R._ptr(x_max), x_out=x_out.data_ptr(), init_blend=0 if x_scale is None else 1,
-        x_scale=1.0 if x_scale is None else float(x_scale), prof=R._ptr(prof))
+        x_scale=1.0 if x_scale is None else float(x_scale), cg_scale=R._ptr(cg_scale), grad_off=prog.grad_off,
+        grad_stride=prog.grad_stride, with_backward=int(with_backward or cg_scale is not None), prof=R._ptr(prof))
     timing = R._timing
     if timing["on"]:
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -223,4 +232,76 @@ def backbone_forward2(module, x, noise_t) -> Optional[torch.Tensor]:
         xin = R._f32c(x, x.device)
         out = torch.empty_like(xin)
         launch(comp, batch=b, x_in=xin, x_out=out, emb=emb, t_per_wg=t)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------- #
+# classifier-guided sampling: denoiser forward + classifier forward/backward in the same launch                          #
+# ------------------------------------------------------------------------------------------------------------------- #
+_gcache = weakref.WeakKeyDictionary()
+
+
+def compiled_guided2(net, clf_net, horizon: int) -> _Compiled2:
+    """Guided program (denoiser ops, then the HalfJannerUNet1d classifier's forward and backward-data ops) for the 8-wave,
+    one-trajectory shape; ``.prog is None`` + ``.why`` when it does not exist (LDS plan, unsupported layers)."""
+    per = _gcache.setdefault(net, {})
+    sig = (R._signature(net), R._signature(clf_net))
+    key = (id(clf_net), horizon)
+    hit = per.get(key)
+    if hit is not None and hit.sig == sig:
+        return hit
+    with torch.no_grad():
+        try:
+            comp = _Compiled2(P2.compile_guided2(net, clf_net, horizon), sig)
+        except (ValueError, AssertionError) as e:
+            comp = _Compiled2(None, sig, str(e))
+    per[key] = comp
+    return comp
+
+
+def guided_supported(net, clf_net, horizon: int) -> Optional[str]:
+    if not enabled() or os.environ.get("CDX_UNET2_GUIDED", "1") == "0":
+        return "disabled by CDX_UNET2=0 / CDX_UNET2_GUIDED=0"
+    why = supported(net, horizon)
+    if why is not None:
+        return why
+    return compiled_guided2(net, clf_net, horizon).why
+
+
+def guided_sample2(solver, net, clf_net, plan, xt, prior, feed, fix_mask, x_min, x_max, w_cg) -> Optional[torch.Tensor]:
+    """Whole classifier-guided loop in ONE cdx_unet2_run launch (reference diffusionsde.py:526-594 with w_cg != 0): per step the
+    denoiser forward, the classifier's forward + backward-data pass and the shifted, clipped solver update, all on LDS-resident
+    state.  None -> the caller takes the per-step executor (cdx_guided_run)."""
+    b, h, d = xt.shape
+    if R.plan_is_edm(plan) or any(st.kind > 2 for st in plan.steps) or guided_supported(net, clf_net, h) is not None:
+        return None
+    dev = xt.device
+    comp = compiled_guided2(net, clf_net, h)
+    from .plan import cached
+    pn = R._predicts_noise(plan, solver)
+    with torch.no_grad():
+        emb = plan_film_table(comp, net, plan, dev, modules=[net, clf_net])
+        steps_dev = R.steps_to_device(plan, dev)
+        cg = cached(plan, ("cg2", str(dev), float(w_cg), int(pn)), lambda: torch.tensor(
+            [(-(w_cg * st.sigma)) if pn else (w_cg * ((st.sigma ** 2) / st.alpha)) for st in plan.steps], dtype=torch.float32, device=dev))
+        noise = torch.stack([feed.like(xt) for _ in range(plan.n_noise)]).contiguous() if plan.n_noise else None
+        xin = R._f32c(xt, dev)
+        out = torch.empty_like(xin)
+        launch(comp, batch=b, x_in=xin, x_out=out, emb=emb, steps_dev=steps_dev, n_steps=len(plan.steps), predict_noise=pn,
+               prior=R._f32c(prior, dev) if fix_mask is not None else None, fix_mask=fix_mask, noise=noise, x_min=x_min,
+               x_max=x_max, t_per_wg=1, cg_scale=cg)
+    return out
+
+
+def classifier_gradient2(net, clf_net, x, noise_t) -> Optional[torch.Tensor]:
+    """d classifier(x, t).sum() / d x through the guided program in forward mode (ONE timestep for the batch) -- test / probe entry."""
+    b, h, d = x.shape
+    if guided_supported(net, clf_net, h) is not None:
+        return None
+    comp = compiled_guided2(net, clf_net, h)
+    with torch.no_grad():
+        emb = film_table(comp, net, noise_t.reshape(-1)[:1], modules=[net, clf_net])
+        xin = R._f32c(x, x.device)
+        out = torch.empty_like(xin)
+        launch(comp, batch=b, x_in=xin, x_out=out, emb=emb, t_per_wg=1, with_backward=True)
     return out

@@ -132,7 +132,11 @@ typedef struct cdx_unet2_embtab_args {
     int32_t w0, b0, w2, b2, w3, b3;
     const float* temb;        /* device (n_rows, emb_dim): map_noise(t) per step record */
     int32_t n_rows;
-    float* out;               /* device (n_rows, n_emb) */
+    float* out;               /* device (n_rows, out_ld): this network's FiLM vectors go to columns [col0, col0 + n_emb) */
+    int32_t out_ld, col0;
+    /* optional rows applied to the RAW embedding W2^T mish(...) + b2 (the HalfJannerUNet1d head's share of its first Linear,
+     * reference nn_classifier/half_jannerunet.py:62 `cat([x.flatten(1), emb])`): out[r][col4 + o] = W4^T raw + b4; n_raw = 0: none */
+    int32_t w4, b4, n_raw, col4;
 } cdx_unet2_embtab_args;
 int cdx_unet2_embtab(const cdx_unet2_embtab_args* args, void* hip_stream);
 
@@ -163,6 +167,12 @@ typedef struct cdx_unet2_launch {
      * same roundings), so the host launches nothing but this kernel.  0: x_in is x_T itself. */
     int32_t init_blend;
     float x_scale;
+    /* classifier guidance (programs built by engine/program2.py:compile_guided2: the ops after the denoiser's are the classifier's
+     * forward and backward-data pass, which leaves d log p / d x_t in the gradient slot): per step the prediction is shifted by
+     * cg_scale[step] * gradient before clipping (reference diffusionsde.py:153-173).  NULL: no shift.  with_backward != 0 selects
+     * the kernel variant that understands backward ops even without a shift (one forward+backward: gradients only). */
+    const float* cg_scale;     /* device [n_steps] or NULL */
+    int32_t grad_off, grad_stride, with_backward;
     /* optional profiling: device u64 [n_ops*8 + 2]; workgroup 0 stamps s_memtime at {op start, next-op prefetch issued, after the
      * staging barrier, op end, item record + segment read, first operands landed, MFMAs done, partial tile staged} of the first
      * forward, plus kernel start/end.  NULL = off. */

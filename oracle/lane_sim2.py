@@ -13,28 +13,47 @@ from cleandiffuser_amd.engine.program import GN_EPS, MODE_16X16
 from .lane_sim import mish
 
 
-def emb_table(prog: P2.Program2, temb: np.ndarray) -> np.ndarray:
-    """What cdx_unet2_embtab computes: rows of Linear(Mish(map_emb(temb_row))) for every block, (steps, n_emb)."""
+def mish_grad(a):
+    """d Mish(a) / d a in the kernel's form: n/(n+2) + a 4 e (e+1) / (n+2)^2, e = exp(min(a, 20)), n = e (e + 2)."""
+    a = np.asarray(a, np.float32)
+    e = np.exp(np.minimum(a, np.float32(20.0))).astype(np.float32)
+    n = (e * (e + np.float32(2.0))).astype(np.float32)
+    r = (np.float32(1.0) / (n + np.float32(2.0))).astype(np.float32)
+    return (n * r + a * (np.float32(4.0) * e * (e + np.float32(1.0))) * (r * r)).astype(np.float32)
+
+
+def emb_table(prog: P2.Program2, temb, tembs=None) -> np.ndarray:
+    """What cdx_unet2_embtab computes per network of the program: rows of Linear(Mish(map_emb(temb_row))) for every block
+    (+ the rows applied to the RAW embedding: the classifier head), (steps, n_emb).  `tembs`: one map_noise(t) array per network."""
     blob = prog.blob.detach().cpu().numpy()
-    e = prog.embtab
-    ed, hid, md, n = e["emb_dim"], e["hidden"], e["md"], e["n_emb"]
-    w0 = blob[e["w0"]:e["w0"] + ed * hid].reshape(ed, hid)
-    w2 = blob[e["w2"]:e["w2"] + hid * md].reshape(hid, md)
-    w3 = blob[e["w3"]:e["w3"] + md * n].reshape(md, n)
-    out = np.empty((temb.shape[0], n), np.float32)
-    for s, row in enumerate(np.asarray(temb, np.float32)):
-        h = blob[e["b0"]:e["b0"] + hid].copy()
-        for i in range(ed):
-            h = h + w0[i] * row[i]
-        h = mish(h)
-        m = blob[e["b2"]:e["b2"] + md].copy()
-        for i in range(hid):
-            m = m + w2[i] * h[i]
-        m = mish(m)
-        o = blob[e["b3"]:e["b3"] + n].copy()
-        for i in range(md):
-            o = o + w3[i] * m[i]
-        out[s] = o
+    tembs = [temb] if tembs is None else list(tembs)
+    specs = prog.embtabs if prog.embtabs else [prog.embtab]
+    assert len(tembs) == len(specs)
+    out = np.zeros((np.asarray(tembs[0]).shape[0], prog.n_emb), np.float32)
+    for e, tb in zip(specs, tembs):
+        ed, hid, md, n = e["emb_dim"], e["hidden"], e["md"], e["n_emb"]
+        w0 = blob[e["w0"]:e["w0"] + ed * hid].reshape(ed, hid)
+        w2 = blob[e["w2"]:e["w2"] + hid * md].reshape(hid, md)
+        w3 = blob[e["w3"]:e["w3"] + md * n].reshape(md, n)
+        for s, row in enumerate(np.asarray(tb, np.float32)):
+            h = blob[e["b0"]:e["b0"] + hid].copy()
+            for i in range(ed):
+                h = h + w0[i] * row[i]
+            h = mish(h)
+            raw = blob[e["b2"]:e["b2"] + md].copy()
+            for i in range(hid):
+                raw = raw + w2[i] * h[i]
+            m = mish(raw)
+            o = blob[e["b3"]:e["b3"] + n].copy()
+            for i in range(md):
+                o = o + w3[i] * m[i]
+            out[s, e.get("col0", 0):e.get("col0", 0) + n] = o
+            if e.get("n_raw", 0):
+                w4 = blob[e["w4"]:e["w4"] + md * e["n_raw"]].reshape(md, e["n_raw"])
+                o4 = blob[e["b4"]:e["b4"] + e["n_raw"]].copy()
+                for i in range(md):
+                    o4 = o4 + w4[i] * raw[i]
+                out[s, e["col4"]:e["col4"] + e["n_raw"]] = o4
     return out
 
 
@@ -66,10 +85,41 @@ class LaneSim2:
 
     # ------------------------------------------------------------------------------------------ #
     def run_forward(self, emb_row):
+        """All ops once; returns the prediction slot (guided programs: see also grad())."""
         for op in self.p.ops:
-            self._conv(op, np.asarray(emb_row, np.float32))
+            if int(op[P2.W2_KIND]) == P2.KIND2_HEAD:
+                self._head(op, np.asarray(emb_row, np.float32))
+            else:
+                self._conv(op, np.asarray(emb_row, np.float32))
         p = self.p
         return self.read_slot(p.pred_off, p.pred_stride, p.horizon, p.dim)
+
+    def grad(self):
+        p = self.p
+        return self.read_slot(p.grad_off, p.grad_stride, p.horizon, p.dim)
+
+    def _head(self, op, emb_row):
+        """KIND2_HEAD: z = e + W1x . flat(src); gz = w2 * Mish'(z); dst = W1x^T gz; halo rows of dst zeroed."""
+        lds = self.lds
+        hidden, length, ch = int(op[P2.W2_COUT]), int(op[P2.W2_LOUT]), int(op[P2.W2_LCOLS])
+        src, sstr, dst, dstr = (int(op[k]) for k in (P2.W2_RES, P2.W2_RES_STRIDE, P2.W2_DST, P2.W2_DST_STRIDE))
+        w1 = self.blob[int(op[P2.W2_BOFF]):int(op[P2.W2_BOFF]) + length * ch * hidden].reshape(length * ch, hidden)
+        w2 = self.blob[int(op[P2.W2_GAMMA]):int(op[P2.W2_GAMMA]) + hidden]
+        z = emb_row[int(op[P2.W2_EMB]):int(op[P2.W2_EMB]) + hidden].copy()
+        for l in range(length):
+            for c in range(ch):
+                xv = lds[src + (l + P2.HALO2) * sstr + c]
+                assert np.isfinite(xv)
+                z = z + w1[l * ch + c] * xv
+        gz = (w2 * mish_grad(z)).astype(np.float32)
+        for l in range(length):
+            for c in range(ch):
+                acc = np.float32(0.0)
+                for j in range(hidden):
+                    acc = np.float32(acc + w1[l * ch + c][j] * gz[j])
+                lds[dst + (l + P2.HALO2) * dstr + c] = acc
+        for r in (0, 1, length + P2.HALO2, length + P2.HALO2 + 1):
+            lds[dst + r * dstr: dst + (r + 1) * dstr] = 0.0
 
     def _conv(self, op, emb_row):
         p, lds = self.p, self.lds
@@ -150,6 +200,9 @@ class LaneSim2:
                     a = stage + (ks * l_out + pos) * sstride + c
                     v = v + lds[a:a + 4]
                 vals[(g, pos, c)] = v
+        if flags & P2.F2_GNBWD:
+            self._epilogue_bwd(op, vals, par, cg, c_out, l_out)
+            return
         if flags & P2.F2_GN:
             gamma, beta = par(P2.W2_GAMMA), par(P2.W2_BETA)
             inv_cnt = np.int32(op[P2.W2_INV_CNT]).view(np.float32)
@@ -164,9 +217,15 @@ class LaneSim2:
                 var = np.float32((dlt * dlt).sum(dtype=np.float32) * inv_cnt - m1 * m1)
                 mean = np.float32(shift + m1)
                 rstd = np.float32(1.0) / np.sqrt(var + np.float32(GN_EPS))
+                if flags & P2.F2_SAVE:
+                    lds[int(op[P2.W2_STATS]) + g] = rstd
                 for kk in keys:
                     c = kk[2]
-                    vals[kk] = mish((vals[kk] - mean) * rstd * gamma[c:c + 4] + beta[c:c + 4])
+                    xh = ((vals[kk] - mean) * rstd).astype(np.float32)
+                    if (flags & P2.F2_SAVE) and c < c_out:  # save slot: no halo, position-major; pad lane groups save nothing
+                        a = int(op[P2.W2_SAVE]) + kk[1] * int(op[P2.W2_SAVE_STRIDE]) + c
+                        lds[a:a + 4] = xh
+                    vals[kk] = mish(xh * gamma[c:c + 4] + beta[c:c + 4])
         for (g, pos, c), v in vals.items():
             if flags & P2.F2_EMB:
                 e0 = int(op[P2.W2_EMB]) + c
@@ -180,3 +239,50 @@ class LaneSim2:
                     lds[dst + (pos + P2.HALO2) * dstride + coff + c + j] = v[j]
         for r in (0, 1, l_out + P2.HALO2, l_out + P2.HALO2 + 1):        # wave w rewrites halo row w of the destination
             lds[dst + r * dstride: dst + (r + 1) * dstride] = 0.0
+
+    def _epilogue_bwd(self, op, vals, par, cg, c_out, l_out):
+        """F2_GNBWD: v (+ residual slot) -> [dst2]; g_xhat = v Mish'(gamma x_hat + beta) gamma; dst = rstd (g_xhat - mean(g_xhat) -
+        x_hat mean(g_xhat x_hat)), means over the group."""
+        lds = self.lds
+        flags = int(op[P2.W2_FLAGS])
+        gamma, beta = par(P2.W2_GAMMA), par(P2.W2_BETA)
+        inv_cnt = np.int32(op[P2.W2_INV_CNT]).view(np.float32)
+        dst, dstride = int(op[P2.W2_DST]), int(op[P2.W2_DST_STRIDE])
+        gx, xhs = {}, {}
+        for (g, pos, c), v in vals.items():
+            if c >= c_out:                                  # pad lane group (fewer than 8 x 4 channels): never stored, skip
+                continue
+            if flags & P2.F2_RES:
+                a = int(op[P2.W2_RES]) + (pos + P2.HALO2) * int(op[P2.W2_RES_STRIDE]) + c
+                assert np.isfinite(lds[a:a + 4]).all()
+                v = v + lds[a:a + 4]
+            if flags & P2.F2_DUAL:
+                a = int(op[P2.W2_DST2]) + (pos + P2.HALO2) * int(op[P2.W2_DST2_STRIDE]) + c
+                lds[a:a + 4] = v
+            a = int(op[P2.W2_SAVE]) + pos * int(op[P2.W2_SAVE_STRIDE]) + c
+            xh = lds[a:a + 4].copy() if c < c_out else np.zeros(4, np.float32)
+            assert np.isfinite(xh).all(), "backward read an unsaved x_hat"
+            d = mish_grad(xh * gamma[c:c + 4] + beta[c:c + 4])
+            gx[(g, pos, c)] = (v * d * gamma[c:c + 4]).astype(np.float32)
+            xhs[(g, pos, c)] = xh
+        for g in range(P2.GROUPS2):
+            keys = [kk for kk in gx if kk[0] == g]
+            if not keys:
+                continue
+            s1 = np.float32(sum(np.float32(gx[kk].sum(dtype=np.float32)) for kk in keys))
+            s2 = np.float32(sum(np.float32((gx[kk] * xhs[kk]).sum(dtype=np.float32)) for kk in keys))
+            m1, m2 = np.float32(s1 * inv_cnt), np.float32(s2 * inv_cnt)
+            rstd = lds[int(op[P2.W2_STATS]) + g]
+            assert np.isfinite(rstd)
+            for kk in keys:
+                _, pos, c = kk
+                gu = ((gx[kk] - m1 - xhs[kk] * m2) * rstd).astype(np.float32)
+                for j in range(4):
+                    if c + j < c_out:
+                        assert np.isfinite(gu[j])
+                        lds[dst + (pos + P2.HALO2) * dstride + c + j] = gu[j]
+        for r in (0, 1, l_out + P2.HALO2, l_out + P2.HALO2 + 1):
+            lds[dst + r * dstride: dst + (r + 1) * dstride] = 0.0
+            if flags & P2.F2_DUAL:
+                d2, d2s = int(op[P2.W2_DST2]), int(op[P2.W2_DST2_STRIDE])
+                lds[d2 + r * d2s: d2 + (r + 1) * d2s] = 0.0

@@ -160,13 +160,36 @@ def test_native_classifier_gradients_match_autograd(name, amd_lib, monkeypatch):
     np.testing.assert_allclose(grad_n.cpu().numpy(), grad_a.cpu().numpy(), rtol=1e-4, atol=1e-4 * max(scale, 1.0))
 
 
-@pytest.mark.parametrize("one_call", [True, False])
+def test_guided_program_gradient_matches_autograd(amd_lib):
+    """The guided program's classifier part on the GPU (cdx_unet2_kernel<1, 8, true> in forward mode returns the gradient slot):
+    d classifier(x, t).sum() / d x against torch.autograd on the same module, B = 70 (more workgroups than one XCD holds)."""
+    from cleandiffuser_amd.engine import runtime2
+    agent, _ = cases.build(amd_lib, "janner_cfg2_guided_ddpm", device=DEV)
+    net, clf = agent.model_ema["diffusion"], agent.classifier.model_ema
+    assert runtime2.guided_supported(net, clf, 32) is None
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(70, 32, 23, generator=g).to(DEV)
+    t = torch.full((70,), 7, dtype=torch.long, device=DEV)
+    grad = runtime2.classifier_gradient2(net, clf, x, t)
+    xr = x.clone().requires_grad_()
+    clf._forward_torch(xr, t, None).sum().backward()
+    torch.cuda.synchronize()
+    scale = float(xr.grad.abs().max())
+    np.testing.assert_allclose(grad.cpu().numpy(), xr.grad.cpu().numpy(), rtol=1e-4, atol=1e-4 * max(scale, 1.0))
+
+
+@pytest.mark.parametrize("one_call", ["v2", True, False])
 @pytest.mark.parametrize("name", GUIDED_CASES)
 def test_guided_sampling_matches_reference_fixture(name, one_call, amd_lib, monkeypatch):
-    """w_cg > 0.  one_call: the whole guided loop is cdx_guided_run (fused backbone forward + native classifier forward/backward +
-    solver step per record).  Otherwise the host steps the loop and every step's gradient still comes from the native kernels."""
-    from cleandiffuser_amd.engine import classifier_grad, guided
+    """w_cg > 0.  "v2": the whole guided loop is ONE cdx_unet2_run launch (denoiser forward, classifier forward + backward and the
+    shifted solver step on LDS-resident state) whenever the guided program exists.  True: cdx_guided_run (fused backbone forward +
+    native classifier forward/backward + solver step per record, ~105 launches per step from one C call).  False: the host steps
+    the loop and every step's gradient still comes from the native kernels."""
+    from cleandiffuser_amd.engine import classifier_grad, guided, runtime2
     gold = np.load(golden_path(name))
+    if one_call != "v2":
+        monkeypatch.setenv("CDX_UNET2_GUIDED", "0")
+    launches = _spy_launches(monkeypatch)
     agent, _ = cases.build(amd_lib, name, device=DEV)
     inp = cases.make_inputs(name)
     kw = cases.sample_kwargs(name, inp, device=DEV)
@@ -186,8 +209,13 @@ def test_guided_sampling_matches_reference_fixture(name, one_call, amd_lib, monk
     monkeypatch.setattr(guided, "guided_sample", loop)
     x, _ = agent.sample(torch.from_numpy(inp["prior"]).to(DEV), noise=list(inp["noise"][:int(gold["n_draws"])]), **kw)
     torch.cuda.synchronize()
-    if one_call:
+    if one_call == "v2":
         assert used == {"grad": 0, "loop": 1}
+        c = cases.CASES[name]
+        if runtime2.guided_supported(agent.model_ema["diffusion"], agent.classifier.model_ema, c["horizon"]) is None:
+            assert launches["v2"] == 1, "guided loop with a guided program must be one cdx_unet2_run launch"
+    elif one_call:
+        assert used == {"grad": 0, "loop": 1} and launches["v2"] == 0
     else:
         assert used["grad"] == kw["sample_steps"], "every step's classifier gradient must come from the native kernels"
     np.testing.assert_allclose(x.cpu().numpy(), gold["x_out"], **TOL)

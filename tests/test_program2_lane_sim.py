@@ -98,3 +98,32 @@ def test_v2_refuses_what_it_cannot_run(amd_lib):
     agent, _ = cases.build(amd_lib, "janner_cfg2_ddim")
     assert runtime2.supported(agent.model_ema["diffusion"], 32) is None
     assert runtime2.supported(agent.model_ema["diffusion"], 36) is not None
+
+
+@pytest.mark.parametrize("shape", [(16, 6, [1, 2]), (32, 23, [1, 2, 2, 2])])
+def test_lane_sim2_guided_program_gradient_matches_autograd(shape, amd_lib):
+    """Guided program (engine/program2.py:compile_guided2): the denoiser's ops followed by the HalfJannerUNet1d classifier's forward
+    and backward-data ops (saved x_hat / rstd, tap-flipped transposed weights, the stride-2 scatter as two parity convs, the
+    GroupNorm -> Mish backward epilogue, the head op).  The lane-level twin of the kernel must reproduce the denoiser forward AND
+    torch.autograd's d classifier(x, t).sum() / d x of the module (bit-identical to the reference's, tests/test_module_mirrors.py)."""
+    from cleandiffuser_amd.utils import load_synth
+    H, D, dm = shape
+    net = load_synth(amd_lib.JannerUNet1d(D, model_dim=32, emb_dim=32, dim_mult=dm, kernel_size=5), 0).eval()
+    clf = load_synth(amd_lib.HalfJannerUNet1d(H, D, out_dim=1, model_dim=32, emb_dim=32, dim_mult=tuple(dm), kernel_size=3), 1).eval()
+    prog = P2.compile_guided2(net, clf, H)
+    assert prog.nw == 8 and prog.lds_bytes(1) <= 160 * 1024 and prog.grad_off > 0 and len(prog.embtabs) == 2
+    n_den = prog.meta["n_den"]
+    assert all(int(op[P2.W2_FLAGS]) & (P2.F2_SAVE | P2.F2_GNBWD | P2.F2_DUAL) == 0 for op in prog.ops[:n_den])
+    assert sum(int(op[P2.W2_KIND]) == P2.KIND2_HEAD for op in prog.ops) == 1
+    g = torch.Generator().manual_seed(3)
+    x, t = torch.randn(1, H, D, generator=g), torch.tensor([7])
+    xr = x.clone().requires_grad_()
+    clf._forward_torch(xr, t, None).sum().backward()
+    with torch.no_grad():
+        ref_pred = net._forward_torch(x, t, None)[0].numpy()
+        row = emb_table(prog, None, [net.map_noise(t).numpy(), clf.map_noise(t).numpy()])[0]
+    sim = LaneSim2(prog)
+    sim.load_x(x[0].numpy())
+    np.testing.assert_allclose(sim.run_forward(row), ref_pred, rtol=2e-5, atol=2e-5)
+    ref_grad = xr.grad[0].numpy()
+    np.testing.assert_allclose(sim.grad(), ref_grad, rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(ref_grad).max())))
