@@ -475,7 +475,18 @@ __device__ __forceinline__ void epilogue_bwd(float* __restrict__ tl, const EpiPa
         f32x4 acc = P.bi;
         const float* sp = tl + stage + pos * e.sstride + c;
         const int kstep = e.l_out * e.sstride;
-        for (int ks = 0; ks < e.ksplit; ++ks) acc += *reinterpret_cast<const f32x4*>(sp + ks * kstep);
+        int ks = 0;
+        for (; ks + 4 <= e.ksplit; ks += 4, sp += 4 * kstep) {      // same 4 / 2 / 1 cascade as the forward epilogue
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(sp), p1 = *reinterpret_cast<const f32x4*>(sp + kstep);
+            const f32x4 p2 = *reinterpret_cast<const f32x4*>(sp + 2 * kstep), p3 = *reinterpret_cast<const f32x4*>(sp + 3 * kstep);
+            acc += p0; acc += p1; acc += p2; acc += p3;
+        }
+        if (ks + 2 <= e.ksplit) {
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(sp), p1 = *reinterpret_cast<const f32x4*>(sp + kstep);
+            acc += p0; acc += p1;
+            ks += 2; sp += 2 * kstep;
+        }
+        if (ks < e.ksplit) acc += *reinterpret_cast<const f32x4*>(sp);
         if (e.flags & CDX2_F2_RES) acc += *reinterpret_cast<const f32x4*>(tl + e.res + (pos + CDX2_HALO2) * e.rstride + c);
         if ((e.flags & CDX2_F2_DUAL) && ok[k]) *reinterpret_cast<f32x4*>(tl + e.dst2 + (pos + CDX2_HALO2) * e.d2stride + c) = acc;
         // (lane groups past C_out -- nets with fewer than 8 x 4 channels -- have nothing saved: zeros, never stored)
@@ -520,8 +531,10 @@ __device__ __forceinline__ void run_head(const cdx_unet2_launch& L, int vd, cons
     float* gz = tl + L.stage_off;
     for (int j = tid; j < hidden; j += THREADS) {
         float z = ev[j];
-        for (int l = 0; l < len; ++l)
+        for (int l = 0; l < len; ++l) {
+#pragma unroll 8
             for (int c = 0; c < ch; ++c) z = fmaf(w1[(size_t)(l * ch + c) * hidden + j], tl[src + (l + CDX2_HALO2) * sstr + c], z);
+        }
         gz[j] = w2[j] * mish2_grad(z);
     }
     __syncthreads();
@@ -529,6 +542,7 @@ __device__ __forceinline__ void run_head(const cdx_unet2_launch& L, int vd, cons
         const int l = i / ch, c = i - l * ch;
         const float* wr = w1 + (size_t)i * hidden;
         float acc = 0.f;
+#pragma unroll 8
         for (int j = 0; j < hidden; ++j) acc = fmaf(wr[j], gz[j], acc);
         tl[dst + (l + CDX2_HALO2) * dstr + c] = acc;
     }
@@ -644,7 +658,8 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = L.horizon, D = L.dim, HD = H * D, tf = L.traj_floats;
-    const int b0 = blockIdx.x * T;
+    const int b0 = L.traj_first + blockIdx.x * T;
+    const int b_end = L.traj_first + L.traj_count;      // this launch covers trajectories [traj_first, traj_first + traj_count) of the batch
     unsigned long long* lprof = reinterpret_cast<unsigned long long*>(lds + T * tf);
     const bool profiling = L.prof != nullptr && blockIdx.x == 0;
     if (profiling) stamp(lprof + (size_t)L.n_ops * 8, tid);
@@ -662,7 +677,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
     __syncthreads();
 #pragma unroll 1
     for (int t = 0; t < T; ++t) {
-        if (b0 + t >= L.batch) break;
+        if (b0 + t >= b_end) break;
         const size_t xbase = (size_t)(b0 + t) * HD;
         for (int e = tid; e < HD; e += THREADS) {
             const int n = e / D, c = e - n * D;
@@ -700,7 +715,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
         const float k0 = st.k[0], k1 = st.k[1], k2 = st.k[2], k3 = st.k[3], k4 = st.k[4];
 #pragma unroll 1
         for (int t = 0; t < T; ++t) {
-            if (b0 + t >= L.batch) break;
+            if (b0 + t >= b_end) break;
             const int b = b0 + t;
             const size_t xbase = (size_t)b * HD;
             float* tl = lds + t * tf;
@@ -765,7 +780,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
     }
 #pragma unroll 1
     for (int t = 0; t < T; ++t) {
-        if (b0 + t >= L.batch) break;
+        if (b0 + t >= b_end) break;
         const size_t xbase = (size_t)(b0 + t) * HD;
         // one forward (n_steps == 0): the network output -- of a program with backward ops, the gradient slot
         const bool want_grad = BWD && L.n_steps == 0 && L.grad_off >= 0 && L.with_backward;
@@ -843,6 +858,13 @@ int cdx_unet2_run(const cdx_unet2_launch* L, void* hip_stream) {
     cdx_set_err("");
     if (!L || !L->ops || !L->wblob || !L->x_in || !L->x_out || !L->emb) { cdx_set_err("null pointer in launch"); return CDX_EINVAL; }
     if (L->batch == 0) return CDX_OK;
+    cdx_unet2_launch whole;
+    if (L->traj_first == 0 && L->traj_count == 0) {      // range left zero: the whole batch
+        whole = *L;
+        whole.traj_count = L->batch;
+        L = &whole;
+    }
+    if (L->traj_first < 0 || L->traj_count < 0 || L->traj_first + L->traj_count > L->batch) { cdx_set_err("trajectory range outside the batch"); return CDX_EINVAL; }
     if (L->n_ops <= 0 || L->batch < 0 || L->horizon <= 0 || L->dim <= 0 || L->traj_floats <= 0) { cdx_set_err("non-positive size"); return CDX_EINVAL; }
     if (L->traj_per_wg != 1 && L->traj_per_wg != 2) { cdx_set_err("traj_per_wg must be 1 or 2"); return CDX_EINVAL; }
     if (L->n_waves != 4 && L->n_waves != 8) { cdx_set_err("n_waves must be 4 or 8 (the program is compiled for one of them)"); return CDX_EINVAL; }
@@ -865,7 +887,7 @@ int cdx_unet2_run(const cdx_unet2_launch* L, void* hip_stream) {
                                 : (L->traj_per_wg == 2 ? cdx_unet2_kernel<2, 4, false> : cdx_unet2_kernel<1, 4, false>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
-    const int grid = (L->batch + L->traj_per_wg - 1) / L->traj_per_wg;
+    const int grid = (L->traj_count + L->traj_per_wg - 1) / L->traj_per_wg;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(L->n_waves * 64), lds_bytes, reinterpret_cast<hipStream_t>(hip_stream), *L);
     e = hipGetLastError();
     if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }

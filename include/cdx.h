@@ -151,6 +151,10 @@ typedef struct cdx_unet2_launch {
                                 * their K loops at raised priority */
     int32_t x_off, x_stride, pred_off, pred_stride, prev_off, stage_off;   /* relative to the trajectory region; x/pred: position 0 */
     int32_t batch, horizon, dim;
+    /* this launch denoises trajectories [traj_first, traj_first + traj_count) of the batch (all tensors keep their full-batch
+     * indexing): lets the host run the bulk of a large batch two trajectories per workgroup and the remainder one per workgroup.
+     * Both zero: the whole batch. */
+    int32_t traj_first, traj_count;
     const float* emb;          /* device (max(n_steps,1), emb_ld): FiLM table rows, one per step record */
     int32_t emb_ld;
     const cdx_step* steps;     /* device [n_steps], kinds 0-4; NULL with n_steps == 0 (one forward: x_out <- network(x_in)) */

@@ -397,6 +397,27 @@ def test_unet2_agrees_with_first_kernel_and_is_batch_invariant(amd_lib, monkeypa
     np.testing.assert_allclose(outs["t1"].cpu().numpy(), outs["v1"].cpu().numpy(), rtol=2e-4, atol=2e-4)
 
 
+def test_split_tail_launch_does_not_change_results(amd_lib, monkeypatch):
+    """B = 640: the bulk (512) runs two trajectories per workgroup, the remainder (128) one per workgroup through a second
+    cdx_unet2_run over the trajectory range [512, 640) -- bit-identical to the single two-per-workgroup launch (DDPM: per-step noise
+    is indexed with the full-batch stride in both)."""
+    name = "janner_cfg2_ddpm_clip"
+    agent, _ = cases.build(amd_lib, name, device=DEV)
+    g = torch.Generator().manual_seed(9)
+    B = 640
+    prior = torch.zeros(B, 32, 23)
+    prior[:, 0, :17] = torch.randn(B, 17, generator=g)
+    zs = [torch.randn(B, 32, 23, generator=g).to(DEV) for _ in range(4)]
+    kw = dict(solver="ddpm", n_samples=B, sample_steps=3)
+    outs = {}
+    for split in ("1", "0"):
+        monkeypatch.setenv("CDX_UNET2_SPLIT_TAIL", split)
+        outs[split], _ = agent.sample(prior.to(DEV), noise=list(zs), **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(outs["1"], outs["0"])
+    assert torch.isfinite(outs["1"]).all()
+
+
 def test_steady_state_sample_call_is_one_kernel_launch(amd_lib, monkeypatch):
     """a steady-state sample() call of the north-star config dispatches no ATen compute -- the schedule grid
     (a CPU linspace) and the output allocation are all the host does besides the one cdx_unet2_run launch: x_T = z * temperature
