@@ -96,6 +96,13 @@ struct M4 {    // v_mfma_f32_4x4x1_16b_f32: 16 blocks of 4x4 = 64 rows x 4 cols,
     }
 };
 
+typedef const cdx_unet2_launch __attribute__((address_space(4))) KArg;      // the launch struct as it lies in the kernarg segment
+
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+static __device__ __forceinline__ const KArg* kernarg() { return (const KArg*)__builtin_amdgcn_kernarg_segment_ptr(); }
+#pragma clang diagnostic pop
+
 struct Geom {                    // wave-uniform description of one conv op's K loop
     int l_cols, cstride, ostride, sstride, stage;
 };
@@ -675,24 +682,28 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
     for (int i = tid * 4; i < T * tf; i += THREADS * 4)
         *reinterpret_cast<f32x4*>(lds + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads();
+    {
+    const KArg* S = kernarg();
+    asm volatile("" : "+s"(S));
 #pragma unroll 1
     for (int t = 0; t < T; ++t) {
         if (b0 + t >= b_end) break;
         const size_t xbase = (size_t)(b0 + t) * HD;
         for (int e = tid; e < HD; e += THREADS) {
             const int n = e / D, c = e - n * D;
-            float v = L.x_in[xbase + e];
-            if (L.init_blend) {
+            float v = S->x_in[xbase + e];
+            if (S->init_blend) {
                 // x_T = z * temperature, then the fix-mask blend with the prior (reference diffusionsde.py:509-510): the same
                 // four roundings as the ATen ops it replaces -- no fma contraction
-                v = __fmul_rn(v, L.x_scale);
-                if (L.fix_mask) {
-                    const float m = L.fix_mask[e];
-                    v = __fadd_rn(__fmul_rn(v, __fsub_rn(1.0f, m)), __fmul_rn(L.prior[xbase + e], m));
+                v = __fmul_rn(v, S->x_scale);
+                if (S->fix_mask) {
+                    const float m = S->fix_mask[e];
+                    v = __fadd_rn(__fmul_rn(v, __fsub_rn(1.0f, m)), __fmul_rn(S->prior[xbase + e], m));
                 }
             }
-            lds[t * tf + L.x_off + n * L.x_stride + c] = v;
+            lds[t * tf + S->x_off + n * S->x_stride + c] = v;
         }
+    }
     }
     __syncthreads();
 
@@ -709,8 +720,14 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
             vd = vdn;
         }
         if (L.n_steps == 0) break;
+        // The solver step's pointers and offsets are read from the kernarg segment HERE, through a pointer the optimiser cannot
+        // see through across iterations: as by-value kernel arguments they would stay live in ~35 SGPRs over the whole op loop,
+        // where the descriptor fields already fill the scalar register file (each spill / reload is a VALU v_writelane /
+        // v_readlane on the critical path of every op).
+        const KArg* S = kernarg();
+        asm volatile("" : "+s"(S));
         // ---- clip, eps/x0 conversion, solver update, fix-mask blend on the LDS-resident state (kinds 0-4) ----
-        const cdx_step st = L.steps[step];
+        const cdx_step st = S->steps[step];
         const float al = st.alpha, sg = st.sigma;
         const float k0 = st.k[0], k1 = st.k[1], k2 = st.k[2], k3 = st.k[3], k4 = st.k[4];
 #pragma unroll 1
@@ -721,28 +738,28 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
             float* tl = lds + t * tf;
             for (int e = tid; e < HD; e += THREADS) {
                 const int n = e / D, c = e - n * D;
-                const int xo = L.x_off + n * L.x_stride + c;
+                const int xo = S->x_off + n * S->x_stride + c;
                 const float x = tl[xo];
-                float p = tl[L.pred_off + n * L.pred_stride + c];
+                float p = tl[S->pred_off + n * S->pred_stride + c];
                 // classifier guidance (reference diffusionsde.py:153-173): the prediction is shifted along d log p / d x_t BEFORE
                 // it is clipped; cg_scale[step] = -w sigma (noise prediction) or w sigma^2 / alpha (x0 prediction), frozen by the host
-                if (BWD && L.cg_scale) p += L.cg_scale[step] * tl[L.grad_off + n * L.grad_stride + c];
-                if (L.predict_noise) {
-                    if (L.x_max) p = fmaxf(p, (x - al * L.x_max[e]) / sg);
-                    if (L.x_min) p = fminf(p, (x - al * L.x_min[e]) / sg);
+                if (BWD && S->cg_scale) p += S->cg_scale[step] * tl[S->grad_off + n * S->grad_stride + c];
+                if (S->predict_noise) {
+                    if (S->x_max) p = fmaxf(p, (x - al * S->x_max[e]) / sg);
+                    if (S->x_min) p = fminf(p, (x - al * S->x_min[e]) / sg);
                 } else {
-                    if (L.x_min) p = fmaxf(p, L.x_min[e]);
-                    if (L.x_max) p = fminf(p, L.x_max[e]);
+                    if (S->x_min) p = fmaxf(p, S->x_min[e]);
+                    if (S->x_max) p = fminf(p, S->x_max[e]);
                 }
                 float eps, xth, xn;
-                if (L.predict_noise) {
+                if (S->predict_noise) {
                     eps = p; xth = (x - sg * p) / al;
                 } else {
                     xth = p; eps = (x - al * p) / sg;
                 }
                 if (st.kind >= 3) {
                     // legacy DDPM class (reference diffusion/ddpm.py:153-164, 230-241): fix-mask on the prediction
-                    const float m = L.fix_mask ? L.fix_mask[e] : 0.f;
+                    const float m = S->fix_mask ? S->fix_mask[e] : 0.f;
                     if (st.kind == 3) {
                         p = p * (1.0f - m);
                         xn = k0 * (x - k1 * p);
@@ -750,29 +767,29 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
                         p = p * (1.0f - m) + x * m;
                         xn = k0 * (k1 * x + k2 * p);
                     }
-                    if (st.noise_idx >= 0) xn += k3 * L.noise[((size_t)st.noise_idx * L.batch + b) * HD + e];
+                    if (st.noise_idx >= 0) xn += k3 * S->noise[((size_t)st.noise_idx * S->batch + b) * HD + e];
                 } else if (st.kind == 0) {
                     xn = k0 * (x - k1 * eps) + k2 * eps;
-                    if (st.noise_idx >= 0) xn += k3 * L.noise[((size_t)st.noise_idx * L.batch + b) * HD + e];
+                    if (st.noise_idx >= 0) xn += k3 * S->noise[((size_t)st.noise_idx * S->batch + b) * HD + e];
                 } else if (st.kind == 1) {
                     xn = k0 * ((x - k1 * eps) / k2) + k3 * eps;
                 } else {
                     if (st.flags & CDX_STEP_MASK_PRED) {     // legacy DPMSolver (dpmsolver.py:257-264)
-                        const float m = L.fix_mask ? L.fix_mask[e] : 0.f;
+                        const float m = S->fix_mask ? S->fix_mask[e] : 0.f;
                         eps = eps * (1.0f - m);
                         xth = xth * (1.0f - m) + x * m;
                     }
                     float v = (st.vsel & 1) ? xth : eps;
-                    if (st.vsel == 2) v = k3 * xth - k4 * tl[L.prev_off + e];
-                    if (st.vsel == 3) v = k3 * eps - k4 * tl[L.prev_off + e];
+                    if (st.vsel == 2) v = k3 * xth - k4 * tl[S->prev_off + e];
+                    if (st.vsel == 3) v = k3 * eps - k4 * tl[S->prev_off + e];
                     xn = k0 * x - k1 * v;
-                    if (st.noise_idx >= 0) xn += k2 * L.noise[((size_t)st.noise_idx * L.batch + b) * HD + e];
+                    if (st.noise_idx >= 0) xn += k2 * S->noise[((size_t)st.noise_idx * S->batch + b) * HD + e];
                 }
-                if (L.fix_mask) {
-                    const float m = L.fix_mask[e];
-                    xn = xn * (1.0f - m) + L.prior[xbase + e] * m;
+                if (S->fix_mask) {
+                    const float m = S->fix_mask[e];
+                    xn = xn * (1.0f - m) + S->prior[xbase + e] * m;
                 }
-                if (st.push) tl[L.prev_off + e] = st.push == 2 ? eps : xth;
+                if (st.push) tl[S->prev_off + e] = st.push == 2 ? eps : xth;
                 tl[xo] = xn;
             }
         }
@@ -783,12 +800,15 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
         if (b0 + t >= b_end) break;
         const size_t xbase = (size_t)(b0 + t) * HD;
         // one forward (n_steps == 0): the network output -- of a program with backward ops, the gradient slot
-        const bool want_grad = BWD && L.n_steps == 0 && L.grad_off >= 0 && L.with_backward;
-        const int off = L.n_steps == 0 ? (want_grad ? L.grad_off : L.pred_off) : L.x_off;
-        const int str = L.n_steps == 0 ? (want_grad ? L.grad_stride : L.pred_stride) : L.x_stride;
+        const KArg* S = kernarg();
+        asm volatile("" : "+s"(S));
+        const bool want_grad = BWD && S->n_steps == 0 && S->grad_off >= 0 && S->with_backward;
+        const int off = S->n_steps == 0 ? (want_grad ? S->grad_off : S->pred_off) : S->x_off;
+        const int str = S->n_steps == 0 ? (want_grad ? S->grad_stride : S->pred_stride) : S->x_stride;
+        float* __restrict__ xo = S->x_out;
         for (int e = tid; e < HD; e += THREADS) {
             const int n = e / D, c = e - n * D;
-            L.x_out[xbase + e] = lds[t * tf + off + n * str + c];
+            xo[xbase + e] = lds[t * tf + off + n * str + c];
         }
     }
     if (profiling) {

@@ -30,6 +30,7 @@ Descriptor words ``W2_*`` / item words ``I2_*`` MUST mirror ``csrc/cdx_ops2.h`` 
 Activations: channel-last rows ``slot[(pos + HALO2) * stride + c]``, ``stride = pad16(C) + 4``.  Conv records: identical lane
 layouts to program.py (MODE_16X16 / MODE_4X4).
 """
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
@@ -48,6 +49,7 @@ RING2_NW8 = 8                 # ... 8-wave shape
 GROUPS2 = 8                   # GroupNorm groups the epilogue partition is built for (32 lanes per group)
 MAX_NK2 = 4                   # float4 items a lane may own in the epilogue
 HALO2 = 2                     # zero rows on either side of a slot: covers kernel sizes <= 5 (pad <= 2)
+MIN_SLICE = int(os.environ.get("CDX_UNET2_MIN_SLICE", "3"))      # shortest K slice (records) worth a wave of its own
 
 (W2_KIND, W2_FLAGS, W2_COUT, W2_LOUT, W2_LCOLS, W2_CSTRIDE, W2_OSTRIDE, W2_MODE, W2_NT, W2_NITEMS, W2_ITEMS, W2_DST,
  W2_DST_STRIDE, W2_SSTRIDE, W2_KSPLIT, W2_BOFF, W2_GAMMA, W2_BETA, W2_EMB, W2_RES, W2_RES_STRIDE, W2_CG4_SHIFT, W2_INV_CNT,
@@ -248,7 +250,9 @@ class _Builder2:
                 lo += a.chans
             ph_segs.append(segs)
         # slices per source: the same for every phase (the epilogue sums `ksplit` staged partials of every output position)
-        per = [min([per_src] + [segs[si][0].shape[1] for segs in ph_segs]) for si in range(len(srcs))]
+        # ... and a slice is at least MIN_SLICE records long: below that the extra partial tile (staging, one more LDS read per
+        # epilogue item) costs more than the few MFMAs it takes off the other waves
+        per = [min([per_src] + [max(1, segs[si][0].shape[1] // MIN_SLICE) for segs in ph_segs]) for si in range(len(srcs))]
         ph_info = []
         for (w, ppad, ooff), segs in zip(phases, ph_segs):
             seg_n = [r.shape[1] for r, _ in segs]
