@@ -377,8 +377,8 @@ long long mlp_layout(const cdx_resmlp_weights* w, const cdx_sampling* s, float* 
 
 int mlp_check(const cdx_resmlp_weights* w, const cdx_sampling* s) {
     if (!w || !w->in_w || !w->out_w || (w->n_blocks > 0 && !w->blocks)) { cdx_set_err("null pointer in residual-MLP weights"); return CDX_EINVAL; }
-    if (w->x_dim <= 0 || w->emb_dim <= 0 || w->obs_dim < 0 || w->hidden <= 0 || w->hidden > 1024 || w->n_blocks < 0) {
-        cdx_set_err("residual-MLP executor: hidden <= 1024 required (LayerNorm row in registers)"); return CDX_EINVAL;
+    if (w->x_dim <= 0 || w->emb_dim <= 0 || w->obs_dim < 0 || w->hidden <= 0 || w->hidden > 4096 || w->n_blocks < 0) {
+        cdx_set_err("residual-MLP executor: hidden <= 4096 required (LayerNorm row in registers)"); return CDX_EINVAL;
     }
     CDX_TRY(check_request(s, "cdx_resmlp_run", 7));
     if (s->hd != w->x_dim || s->emb_dim != w->emb_dim || (s->cond && s->cond_dim != w->obs_dim)) {

@@ -424,15 +424,17 @@ __global__ __launch_bounds__(256) void gm_splitk_reduce_kernel(const cdx_gemm_ar
 // (reference dit.py:10-11, 33-35, 48); b = m / rows_per_mod.  With gamma/beta instead of shift/scale it is a plain
 // affine LayerNorm (idqlmlp.py:14).  One wave per row, values in registers, DPP-free shuffles (memory-bound op).
 // ------------------------------------------------------------------------------------------------
+// NT = values per lane: 16 (C <= 1024), 32 (C <= 2048) or 64 (C <= 4096; the wide IDQLMlp variants)
+template <int NT>
 __global__ __launch_bounds__(256) void cdx_layernorm_kernel(const cdx_ln_args a) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.M) return;
     const float* x = a.x + (size_t)(a.x_rows > 0 ? row % a.x_rows : row) * a.ldx;
-    float v[16];                                        // C <= 1024
+    float v[NT];                                        // C <= 64 * NT
     float s = 0.f;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
+    for (int t = 0; t < NT; ++t) {
         const int c = lane + 64 * t;
         v[t] = c < a.C ? x[c] : 0.f;
         s += v[t];
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(256) void cdx_layernorm_kernel(const cdx_ln_args a)
     const float mean = s / (float)a.C;
     float s2 = 0.f;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
+    for (int t = 0; t < NT; ++t) {
         const float d = (lane + 64 * t < a.C) ? v[t] - mean : 0.f;
         v[t] = d;
         s2 += d * d;
@@ -453,7 +455,7 @@ __global__ __launch_bounds__(256) void cdx_layernorm_kernel(const cdx_ln_args a)
     const int b = row / a.rows_per_mod;
     float* y = a.y + (size_t)row * a.ldy;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
+    for (int t = 0; t < NT; ++t) {
         const int c = lane + 64 * t;
         if (c < a.C) {
             float o = v[t] * rstd;
@@ -981,7 +983,7 @@ int cdx_gemm_set_trace(unsigned long long* device_buffer) {
 int cdx_layernorm_f32(const cdx_ln_args* a, void* hip_stream) {
     if (!a) { cdx_set_err("cdx_layernorm_f32: null argument block"); return CDX_EINVAL; }
     if (a->M > 0 && (!a->x || !a->y)) { cdx_set_err("cdx_layernorm_f32: null pointer"); return CDX_EINVAL; }
-    if (a->C <= 0 || a->C > 1024 || a->M < 0) { cdx_set_err("cdx_layernorm_f32: 0 < C <= 1024 required"); return CDX_EINVAL; }
+    if (a->C <= 0 || a->C > 4096 || a->M < 0) { cdx_set_err("cdx_layernorm_f32: 0 < C <= 4096 required"); return CDX_EINVAL; }
     if ((a->scale != nullptr) != (a->shift != nullptr) || (a->gamma != nullptr) != (a->beta != nullptr)) {
         cdx_set_err("cdx_layernorm_f32: scale/shift and gamma/beta come in pairs"); return CDX_EINVAL;
     }
@@ -989,7 +991,8 @@ int cdx_layernorm_f32(const cdx_ln_args* a, void* hip_stream) {
     if (a->M == 0) return CDX_OK;
     cdx_ln_args b = *a;
     if (b.rows_per_mod <= 0) b.rows_per_mod = 1;
-    hipLaunchKernelGGL(cdx_layernorm_kernel, dim3((a->M + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), b);
+    auto kern = a->C <= 1024 ? cdx_layernorm_kernel<16> : (a->C <= 2048 ? cdx_layernorm_kernel<32> : cdx_layernorm_kernel<64>);
+    hipLaunchKernelGGL(kern, dim3((a->M + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), b);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
     return CDX_OK;

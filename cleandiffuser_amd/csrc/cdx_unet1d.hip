@@ -693,6 +693,16 @@ __global__ __launch_bounds__(CDX_THREADS) void cdx_unet1d_kernel(const cdx_unet1
         const int n_branch = (L.cfg_mode == 2) ? 2 : 1;
         for (int br = 0; br < n_branch; ++br) {
             const bool use_cond = (L.cond != nullptr) && (L.cfg_mode == 1 || (L.cfg_mode == 2 && br == 0));
+            if (L.tile > 0 && L.cfg_mode == 2) {
+                // tile programs keep the condition features in a kernel-lifetime context slot: the CFG pair (reference
+                // diffusionsde.py:185-199, cond | zeros) rewrites that channel range before each branch
+                for (int e = tid; e < H * L.cond_dim; e += CDX_THREADS) {
+                    const int n = e / L.cond_dim, i = e - n * L.cond_dim;
+                    lds[L.cond_slot_off + (n + CDX_HALO) * L.cond_slot_stride + L.cond_coff + i] =
+                        use_cond ? L.cond[((size_t)b * H + n) * L.cond_dim + i] : 0.f;
+                }
+                __syncthreads();
+            }
             run_program<FULL>(L, lds, step, br, use_cond, b, tid, pre);
         }
         if (L.n_steps == 0 && L.out_vec_len > 0) {  // forward-only, vector head (classifier): emit the head output
@@ -850,7 +860,7 @@ int cdx_unet1d_run(const cdx_unet1d_launch* L, void* hip_stream) {
     if (L->fix_mask && !L->prior) { set_err("fix_mask given without prior"); return CDX_EINVAL; }
     if (L->cfg_mode < 0 || L->cfg_mode > 2) { set_err("cfg_mode must be 0, 1 or 2"); return CDX_EINVAL; }
     if (L->cfg_mode == 2 && !L->cond) { set_err("cfg_mode 2 needs cond"); return CDX_EINVAL; }
-    if (L->tile > 0 && (L->cfg_mode == 2 || L->temb_per_sample)) { set_err("tile programs: cfg_mode 0/1 and per-step timesteps only"); return CDX_EINVAL; }
+    if (L->tile > 0 && L->temb_per_sample) { set_err("tile programs: per-step timesteps only"); return CDX_EINVAL; }
     if (L->tile > 0 && L->tile != L->horizon) { set_err("tile programs: horizon must equal the tile size"); return CDX_EINVAL; }
     if ((L->zero_off | L->zero_floats) & 3) { set_err("zero range must be 16-byte aligned"); return CDX_EINVAL; }
     if ((L->x_off | L->pred_off | L->prev_off | L->scratch_off | L->x_stride | L->pred_stride | L->pred_branch_floats) & 3) {

@@ -169,7 +169,7 @@ def _bind_dit(net, tokens: int, device) -> Optional[_Bound]:
 
 def _bind_resmlp(net, device) -> Optional[_Bound]:
     hidden = net.affine_in.out_features
-    if hidden > 1024:
+    if hidden > 4096:                                  # cdx_layernorm_f32 keeps a row in registers: C <= 4096
         return None
     keep = []
     p = lambda t: _dev_f32(t, keep, device)  # noqa: E731

@@ -376,8 +376,6 @@ def _pack_steps(plan, device) -> torch.Tensor:
 
 def fused_sample_mlp(solver, net, kind, plan, xt, prior, cond_vec, w_cfg, feed) -> Optional[torch.Tensor]:
     """Batch-tiled MLP denoisers (x of shape (B, D)): one workgroup per `MLP_TILE` samples, whole loop in one launch."""
-    if w_cfg not in (0.0, 1.0):
-        return None                                   # cond/uncond pair per step: PyTorch executor for now
     b, d = xt.shape
     dev = xt.device
     tile = P.MLP_TILE
@@ -399,7 +397,9 @@ def fused_sample_mlp(solver, net, kind, plan, xt, prior, cond_vec, w_cfg, feed) 
         return None if t is None else t.expand(tile, d).contiguous()
 
     cond = None
-    if cond_vec is not None and w_cfg == 1.0:
+    if cond_vec is None and w_cfg not in (0.0, 1.0):
+        return None                                   # the reference raises here; let the torch executor do it
+    if cond_vec is not None and w_cfg != 0.0:         # w = 1: one conditional forward; otherwise the cond | zeros pair per step
         cond = rows(torch.flatten(cond_vec, 1))
     load_library()
     with torch.no_grad():
@@ -418,7 +418,8 @@ def fused_sample_mlp(solver, net, kind, plan, xt, prior, cond_vec, w_cfg, feed) 
         xin = rows(xt)
         out = torch.empty_like(xin)
         _launch(comp, batch=n_tiles, x_in=xin, x_out=out, temb=temb, steps_dev=steps_dev, n_steps=len(plan.steps),
-                predict_noise=_predicts_noise(plan, solver), cfg_mode=1 if cond is not None else 0, cfg_w=w_cfg, cond=cond,
+                predict_noise=_predicts_noise(plan, solver), cfg_mode=(0 if cond is None else (1 if w_cfg == 1.0 else 2)), cfg_w=w_cfg,
+                cond=cond,
                 prior=rows(prior) if fix_mask is not None else None, fix_mask=table(fix_mask), noise=noise,
                 x_min=table(x_min), x_max=table(x_max))
     return out[:b]

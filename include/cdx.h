@@ -216,7 +216,7 @@ typedef struct cdx_gemm_args {
 } cdx_gemm_args;
 int cdx_gemm_f32(const cdx_gemm_args* args, void* hip_stream);
 
-/* y[m][c] = LN(x[m])[c] [* gamma[c] + beta[c]] [* (1 + scale[m / rows_per_mod][c]) + shift[...]],  C <= 1024.
+/* y[m][c] = LN(x[m])[c] [* gamma[c] + beta[c]] [* (1 + scale[m / rows_per_mod][c]) + shift[...]],  C <= 4096.
  * Replaces nn.LayerNorm(+ adaLN `modulate`) (reference dit.py:10-11,33-35,48; idqlmlp.py:14). */
 typedef struct cdx_ln_args {
     const float* x;

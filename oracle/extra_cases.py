@@ -45,6 +45,46 @@ def pearce(hidden: int, batch: int):
     return run
 
 
+def mlp_cfg_pair(which: str):
+    """Tile-MLP denoisers with a classifier-free-guidance PAIR (w_cfg not in {0, 1}: conditional and zero-condition forward per
+    step, reference diffusionsde.py:175-206)."""
+    steps, batch = 6, 21
+
+    def run(lib, kind, device):
+        g = torch.Generator().manual_seed(77)
+        if which == "pearce":
+            net = load_synth(lib.PearceMlp(6, To=1, emb_dim=32, hidden_dim=128), 5)
+            cond = load_synth(lib.PearceObsCondition(11, 32, flatten=True, dropout=0.0), 6)
+            obs, d = torch.randn(batch, 1, 11, generator=g), 6
+        else:
+            net = load_synth(lib.DQLMlp(11, 6, emb_dim=16), 5)
+            cond = lib.IdentityCondition(dropout=0.0)
+            obs, d = torch.randn(batch, 11, generator=g), 6
+        agent = lib.DiscreteDiffusionSDE(net, cond, predict_noise=False, x_max=torch.ones(1, d), x_min=-torch.ones(1, d),
+                                         diffusion_steps=steps, device=device)
+        agent.eval()
+        zs = [torch.randn(batch, d, generator=g) for _ in range(steps + 1)]
+        x, _ = _sample(agent, kind, torch.zeros(batch, d, device=device), zs, solver="ddpm", n_samples=batch, sample_steps=steps,
+                       temperature=0.8, w_cfg=1.5, condition_cfg=obs.to(device))
+        return {"x": x}
+    return run
+
+
+def idql_wide():
+    """IDQLMlp with hidden 2048 (> the 1024 the residual-MLP executor's LayerNorm used to hold): 2 blocks, EDM Euler, B = 9."""
+    def run(lib, kind, device):
+        net = load_synth(lib.IDQLMlp(11, 6, emb_dim=32, hidden_dim=2048, n_blocks=2), 8)
+        agent = lib.ContinuousEDM(net, lib.IdentityCondition(dropout=0.0), x_max=torch.ones(1, 6), x_min=-torch.ones(1, 6), device=device)
+        agent.eval()
+        g = torch.Generator().manual_seed(8)
+        obs = torch.randn(9, 11, generator=g)
+        zs = [torch.randn(9, 6, generator=g) for _ in range(6)]
+        x, _ = _sample(agent, kind, torch.zeros(9, 6, device=device), zs, solver="euler", n_samples=9, sample_steps=5,
+                       condition_cfg=obs.to(device), w_cfg=1.0)
+        return {"x": x}
+    return run
+
+
 def janner_long(horizon: int, dim_mult, model_dim: int):
     D, B, steps = 6, 3, 3
 
@@ -140,6 +180,7 @@ SCENARIOS: Dict[str, Callable] = {
     "diffuser_kitchen": shipped_diffuser("kitchen"), "diffuser_antmaze": shipped_diffuser("antmaze"),
     "chitf_ta10": transformer("chitf_ta10"), "dit_h10_d384": transformer("dit_h10_d384"), "dit_h40_depth8": transformer("dit_h40_depth8"),
     "chiunet_cfg3_width": chiunet_cfg3_width(),
+    "pearce_cfg_pair": mlp_cfg_pair("pearce"), "dql_cfg_pair": mlp_cfg_pair("dql"), "idql_h2048": idql_wide(),
 }
 
 

@@ -892,3 +892,25 @@ def test_chiunet_config3_width_matches_reference_fixture(executor, amd_lib, monk
     torch.cuda.synchronize()
     assert ([c[0] for c in calls], fused["n"]) == ((["chiunet"], 0) if executor == "gemm" else ([], 1))
     np.testing.assert_allclose(out["x"].cpu().numpy(), gold["x"], **TOL)
+
+
+@pytest.mark.parametrize("name", ["pearce_cfg_pair", "dql_cfg_pair"])
+def test_tile_mlp_cfg_pair_is_fused(name, amd_lib, monkeypatch):
+    """w_cfg not in {0, 1} on the batch-tiled MLP programs (PearceMlp, DQLMlp) used to fall back to the PyTorch
+    executor; now the conditional / zero-condition pair of every step runs inside the one cdx_unet1d_run launch (the context slot's
+    condition channels are rewritten per branch).  Reference fixture, 1e-4."""
+    calls = _spy_launches(monkeypatch)
+    out, gold = _extra(name)
+    torch.cuda.synchronize()
+    assert calls["n"] == 1, "CFG pair on a tile-MLP denoiser must be one fused launch"
+    np.testing.assert_allclose(out["x"].cpu().numpy(), gold["x"], **TOL)
+
+
+def test_wide_idqlmlp_runs_on_the_resmlp_executor(amd_lib, monkeypatch):
+    """IDQLMlp with hidden_dim 2048 (> 1024) -- cdx_layernorm_f32 now keeps rows of up to 4096 channels in registers, so
+    cdx_resmlp_run takes the net instead of the PyTorch executor.  Reference fixture (EDM Euler), 1e-4."""
+    calls = _spy_bigbatch(monkeypatch)
+    out, gold = _extra("idql_h2048")
+    torch.cuda.synchronize()
+    assert [c[0] for c in calls] == ["mlp"], calls                   # one cdx_resmlp_run call
+    np.testing.assert_allclose(out["x"].cpu().numpy(), gold["x"], **TOL)
