@@ -199,6 +199,8 @@ def other_configs(device):
     big("config2_B3200", bc.cfg2big, "cdx_unet2_kernel<2, 8> (two trajectories, 8 wave64 per workgroup)", B=3200)
     big("config2_guided_B256", bc.cfg2g, "cdx_unet2_kernel<1, 8, true>: denoiser forward + classifier forward/backward + shifted solver step, "
         "one launch per guided sample() call", B=256)
+    big("config2_guided_B3200", bc.cfg2g, "cdx_unet2_kernel<2, 8, true>: two trajectories per workgroup, saved normalised tensors in a "
+        "global workspace; the batch the shipped Diffuser pipelines sample (50 environments x 64 plans, all with w_cg > 0)", reps=2, B=3200)
     try:
         label, call, b, steps, net, horizon = bc.cfg1()
         dt, k_ms = timed(call, 5)

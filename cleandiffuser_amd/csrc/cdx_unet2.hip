@@ -387,7 +387,7 @@ __device__ __forceinline__ void half_sum2(float& a, float& b, int lane) {
 // E[x]^2 cancellation; the second dependent reduction of a two-pass scheme is ~150 cycles of pure latency per op).
 template <int NK, bool BWD>
 __device__ __forceinline__ void epilogue(float* __restrict__ tl, const EpiParams& P, const EpiDesc& e, int stage, int c, int pos0,
-                                         int pstep, int li, int nv, int lane, int grp) {
+                                         int pstep, int li, int nv, int lane, int grp, float* __restrict__ ws) {
     f32x4 v[NK];
     bool ok[NK];
 #pragma unroll
@@ -434,7 +434,11 @@ __device__ __forceinline__ void epilogue(float* __restrict__ tl, const EpiParams
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             const f32x4 xh = (v[k] - mean) * rstd;
-            if (keep && ok[k] && c < e.c_out) *reinterpret_cast<f32x4*>(tl + e.save + (pos0 + k * pstep) * e.savestr + c) = xh;
+            if (keep && ok[k] && c < e.c_out) {
+                // (F2_SAVE_GLOBAL: the trajectory's block of the launch workspace instead of LDS -- two-trajectory guided programs)
+                float* sv = ((e.flags & CDX2_F2_SAVE_GLOBAL) ? ws : tl) + e.save + (pos0 + k * pstep) * e.savestr + c;
+                *reinterpret_cast<f32x4*>(sv) = xh;
+            }
             const f32x4 y = xh * P.ga + P.be;
             v[k] = (f32x4){mish2(y[0]), mish2(y[1]), mish2(y[2]), mish2(y[3])};
         }
@@ -471,7 +475,15 @@ __device__ __forceinline__ float mish2_grad(float a) {
 // (torch's native_group_norm_backward for the input, reference utils/building_blocks.py:60-76 + nn.Mish under autograd).
 template <int NK>
 __device__ __forceinline__ void epilogue_bwd(float* __restrict__ tl, const EpiParams& P, const EpiDesc& e, int stage, int c, int pos0,
-                                             int pstep, int li, int nv, int lane, int grp) {
+                                             int pstep, int li, int nv, int lane, int grp, const float* __restrict__ ws) {
+    f32x4 xh_pre[NK];
+    const float* __restrict__ svb = ((e.flags & CDX2_F2_SAVE_GLOBAL) ? ws : tl) + e.save;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {      // saved x_hat first: from the global workspace this is the longest latency of the epilogue
+        const bool okk = li + 32 * k < nv;
+        const int pos = okk ? pos0 + k * pstep : 0;
+        xh_pre[k] = c < e.c_out ? *reinterpret_cast<const f32x4*>(svb + pos * e.savestr + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     f32x4 gx[NK], xh[NK];
     bool ok[NK];
     float s1 = 0.f, s2 = 0.f;
@@ -497,7 +509,7 @@ __device__ __forceinline__ void epilogue_bwd(float* __restrict__ tl, const EpiPa
         if (e.flags & CDX2_F2_RES) acc += *reinterpret_cast<const f32x4*>(tl + e.res + (pos + CDX2_HALO2) * e.rstride + c);
         if ((e.flags & CDX2_F2_DUAL) && ok[k]) *reinterpret_cast<f32x4*>(tl + e.dst2 + (pos + CDX2_HALO2) * e.d2stride + c) = acc;
         // (lane groups past C_out -- nets with fewer than 8 x 4 channels -- have nothing saved: zeros, never stored)
-        xh[k] = c < e.c_out ? *reinterpret_cast<const f32x4*>(tl + e.save + pos * e.savestr + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        xh[k] = xh_pre[k];
         const f32x4 a = xh[k] * P.ga + P.be;
         const f32x4 d = (f32x4){mish2_grad(a[0]), mish2_grad(a[1]), mish2_grad(a[2]), mish2_grad(a[3])};
         gx[k] = acc * d * P.ga;
@@ -577,7 +589,7 @@ __device__ __forceinline__ void prefetch_ring(const Item& it, const float* __res
 template <int T, int NWV, bool BWD>
 __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* ops, int vd, int vdn, Item& it,
                                        const float* __restrict__ emb_row, float* __restrict__ lds, int tid,
-                                       Ring<WG<NWV>::PF>& ring, unsigned long long* prof) {
+                                       Ring<WG<NWV>::PF>& ring, unsigned long long* prof, int b0) {
     constexpr bool SPLIT_T = NWV == 8 && T == 2;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tf = L.traj_floats;
@@ -632,14 +644,17 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
 #pragma unroll 1
     for (int t = t_lo; t < t_hi; ++t) {
         float* tl = lds + t * tf;
+        // (a trajectory past the end of the range -- odd count, last workgroup -- computes on its zeroed region; its saved tensors
+        //  go to the spare block [batch] of the workspace, never into a real trajectory's block)
+        float* ws = BWD ? L.ws + (size_t)(b0 + t < L.traj_first + L.traj_count ? b0 + t : L.batch) * L.ws_floats : nullptr;
         if (epi_wave) {
             if (BWD && (e.flags & CDX2_F2_GNBWD)) {
-                if (e.nk == 1) epilogue_bwd<1>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp);
-                else if (e.nk == 2) epilogue_bwd<2>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp);
-                else epilogue_bwd<CDX2_MAX_NK2>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp);
-            } else if (e.nk == 1) epilogue<1, BWD>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp);
-            else if (e.nk == 2) epilogue<2, BWD>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp);
-            else epilogue<CDX2_MAX_NK2, BWD>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp);
+                if (e.nk == 1) epilogue_bwd<1>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
+                else if (e.nk == 2) epilogue_bwd<2>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
+                else epilogue_bwd<CDX2_MAX_NK2>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
+            } else if (e.nk == 1) epilogue<1, BWD>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
+            else if (e.nk == 2) epilogue<2, BWD>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
+            else epilogue<CDX2_MAX_NK2, BWD>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
         }
         if (halo_wave) {
             // wave w (mod 4) rewrites halo row w of the destination (the arena hands this LDS to slots of other shapes in between)
@@ -716,7 +731,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
             // (profile the SECOND forward when there is one: instruction / scalar caches warm, like every later step)
             unsigned long long* pslot = (profiling && step == (L.n_steps > 1 ? 1 : 0)) ? lprof + (size_t)oi * 8 : nullptr;
             stamp(pslot, tid);
-            run_op<T, NWV, BWD>(L, ops, vd, vdn, it, emb_row, lds, tid, ring, pslot);
+            run_op<T, NWV, BWD>(L, ops, vd, vdn, it, emb_row, lds, tid, ring, pslot, b0);
             vd = vdn;
         }
         if (L.n_steps == 0) break;
@@ -898,11 +913,11 @@ int cdx_unet2_run(const cdx_unet2_launch* L, void* hip_stream) {
     if (L->prof) lds_bytes += (size_t)(L->n_ops * 8 + 2) * sizeof(unsigned long long);
     if (lds_bytes > 160u * 1024u) { cdx_set_err("program needs more than 160 KiB of LDS"); return CDX_ELDS; }
     const bool guided = L->cg_scale != nullptr || L->with_backward != 0;
-    if (guided && (L->n_waves != 8 || L->traj_per_wg != 1)) {
-        cdx_set_err("programs with backward ops (classifier guidance) run in the 8-wave, one-trajectory shape only"); return CDX_EINVAL;
-    }
+    if (guided && L->n_waves != 8) { cdx_set_err("programs with backward ops (classifier guidance) run in the 8-wave shape only"); return CDX_EINVAL; }
+    if (guided && L->ws_floats > 0 && !L->ws) { cdx_set_err("program keeps saved tensors in a global workspace: ws == NULL"); return CDX_EINVAL; }
+    if (L->ws_floats < 0 || (L->ws_floats & 3)) { cdx_set_err("ws_floats must be a non-negative multiple of 4"); return CDX_EINVAL; }
     if (L->cg_scale && (L->grad_off < 0 || (L->grad_off & 3) || (L->grad_stride & 3))) { cdx_set_err("cg_scale given without a gradient slot"); return CDX_EINVAL; }
-    auto kern = guided ? cdx_unet2_kernel<1, 8, true>
+    auto kern = guided ? (L->traj_per_wg == 2 ? cdx_unet2_kernel<2, 8, true> : cdx_unet2_kernel<1, 8, true>)
               : L->n_waves == 8 ? (L->traj_per_wg == 2 ? cdx_unet2_kernel<2, 8, false> : cdx_unet2_kernel<1, 8, false>)
                                 : (L->traj_per_wg == 2 ? cdx_unet2_kernel<2, 4, false> : cdx_unet2_kernel<1, 4, false>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

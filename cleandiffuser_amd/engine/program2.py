@@ -71,8 +71,9 @@ I2_WOFF, I2_NQ, I2_TAPCC, I2_PART, I2_COL0, I2_PADOOFF, I2_SRCSTR, I2_CCN = rang
 
 # F2_SAVE: a GroupNorm op also stores the normalised (pre-affine) values and the group rstd for the backward pass;
 # F2_GNBWD: the epilogue is the BACKWARD of (GroupNorm -> Mish) of the layer whose saved values W2_SAVE / W2_STATS name, applied to
-# the conv result (+ residual slot); F2_DUAL: the value before that backward is also stored (slot W2_DST2)
-F2_GN, F2_EMB, F2_RES, F2_PRED, F2_SAVE, F2_GNBWD, F2_DUAL = 1, 2, 4, 8, 16, 32, 64
+# the conv result (+ residual slot); F2_DUAL: the value before that backward is also stored (slot W2_DST2); F2_SAVE_GLOBAL: the saved
+# values live in the launch's global workspace (W2_SAVE = float offset inside the trajectory's block) instead of an LDS slot
+F2_GN, F2_EMB, F2_RES, F2_PRED, F2_SAVE, F2_GNBWD, F2_DUAL, F2_SAVE_GLOBAL = 1, 2, 4, 8, 16, 32, 64, 128
 
 
 def pad32(c: int) -> int:
@@ -90,6 +91,7 @@ class Act:
     off: int = -1                     # float offset of the slot (its first halo row) inside the trajectory region
     persistent: bool = False
     halo: int = HALO2                 # 0: a slot that is never a conv source (saved normalised values of the backward pass)
+    in_global: bool = False           # saved values kept in the per-trajectory global workspace, not in LDS
 
     @property
     def stride(self):
@@ -128,6 +130,7 @@ class Program2:
     embtabs: List[dict] = field(default_factory=list)      # one embedding-MLP spec per network (denoiser[, classifier])
     grad_off: int = -1                 # guided programs: position 0 of the classifier-gradient slot
     grad_stride: int = 0
+    ws_floats: int = 0                 # floats of global workspace per trajectory (saved x_hat tensors), 0: everything in LDS
 
     def lds_bytes(self, traj_per_wg: int) -> int:
         return 4 * self.traj_floats * traj_per_wg
@@ -167,6 +170,10 @@ class _Builder2:
         self.macs = 0
         self.n_emb = 0
         self.n_stats = 0
+        self.max_stage = 1 << 30           # cap (floats) on the staging area of one op = K slices x positions x row stride (guided
+                                           # programs for two trajectories per workgroup keep it small)
+        self.save_global = False
+        self.ws_floats = 0                 # per-trajectory global workspace (saved x_hat tensors) when save_global
         self.allow_4x4 = True
 
     def add(self, t: torch.Tensor, pad_to: int = 4) -> int:
@@ -182,6 +189,16 @@ class _Builder2:
     def act(self, length: int, chans: int, persistent=False, halo: int = HALO2) -> Act:
         a = Act(length, chans, len(self.acts), persistent=persistent, halo=halo)
         self.acts.append(a)
+        return a
+
+    def save_slot(self, length: int, chans: int) -> Act:
+        """Where a GroupNorm layer keeps its normalised values for the backward pass: an LDS slot without halo, or (save_global) a
+        block of the trajectory's global workspace."""
+        a = self.act(length, chans, halo=0)
+        if self.save_global:
+            a.in_global, a.persistent = True, True       # (persistent: not part of the LDS arena)
+            a.off = self.ws_floats
+            self.ws_floats += (a.floats + 3) // 4 * 4
         return a
 
     def emb_slot(self, c_out: int) -> int:
@@ -253,6 +270,8 @@ class _Builder2:
         # ... and a slice is at least MIN_SLICE records long: below that the extra partial tile (staging, one more LDS read per
         # epilogue item) costs more than the few MFMAs it takes off the other waves
         per = [min([per_src] + [max(1, segs[si][0].shape[1] // MIN_SLICE) for segs in ph_segs]) for si in range(len(srcs))]
+        while sum(per) > len(srcs) and sum(per) * l_out * sstride > self.max_stage:
+            per[per.index(max(per))] -= 1
         ph_info = []
         for (w, ppad, ooff), segs in zip(phases, ph_segs):
             seg_n = [r.shape[1] for r, _ in segs]
@@ -306,6 +325,7 @@ class _Builder2:
         if bwd is not None:
             assert gn is None and emb_off < 0 and save is None and bwd["save"].chans == c_out and bwd["save"].length == l_out
             words[W2_SAVE_STRIDE], words[W2_STATS] = bwd["save"].stride, bwd["stats"]
+            flags |= F2_SAVE_GLOBAL if bwd["save"].in_global else 0
             reads.append(bwd["save"])
             if bwd.get("dst2") is not None:
                 assert bwd["dst2"].chans == c_out and bwd["dst2"].length == l_out
@@ -314,7 +334,7 @@ class _Builder2:
                 writes.append(bwd["dst2"])
         if save is not None:
             assert gn is not None and save[0].chans == c_out and save[0].length == l_out and save[0].halo == 0
-            flags |= F2_SAVE
+            flags |= F2_SAVE | (F2_SAVE_GLOBAL if save[0].in_global else 0)
             words[W2_SAVE_STRIDE], words[W2_STATS] = save[0].stride, save[1]
             writes.append(save[0])
         if emb_off >= 0:
@@ -501,7 +521,7 @@ def _lower_half_janner_grad(b: "_Builder2", clf, horizon: int, x: Act, grad: Act
         c_out, length = rb.conv1[0].out_channels, src.length
         e_off = b.emb_slot(c_out)
         blocks.append((rb, e_off))
-        s1, s2 = (b.act(length, c_out, halo=0), b.stats_slot()), (b.act(length, c_out, halo=0), b.stats_slot())
+        s1, s2 = (b.save_slot(length, c_out), b.stats_slot()), (b.save_slot(length, c_out), b.stats_slot())
         t1 = b.act(length, c_out)
         b.conv([src], t1, _conv1d_eff(rb.conv1[0]), rb.conv1[0].bias, pad=ksz // 2, gn=rb.conv1[1], emb_off=e_off, save=s1)
         out = b.act(length, c_out)
@@ -633,7 +653,8 @@ def compile_janner2(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x
     return _finalize2(b, [emb], x, pred, horizon, d, net.emb_dim, max_lds_bytes, [])
 
 
-def compile_guided2(net, clf, horizon: int, max_lds_bytes: int = 160 * 1024, nw: int = NW2_MAX) -> Program2:
+def compile_guided2(net, clf, horizon: int, max_lds_bytes: int = 160 * 1024, nw: int = NW2_MAX, save_global: bool = False,
+                    max_stage: Optional[int] = None) -> Program2:
     """Denoiser forward + classifier forward/backward as ONE op list (classifier-guided sampling, reference
     diffusionsde.py:153-173): ops [0, n_den) write the prediction, the rest writes d log p / d x_t into the gradient slot; the
     kernel's solver step shifts the prediction by cg_scale[step] * gradient before clipping.  Both networks read the state slot."""
@@ -644,6 +665,9 @@ def compile_guided2(net, clf, horizon: int, max_lds_bytes: int = 160 * 1024, nw:
         raise ValueError("classifier and denoiser disagree on the state dimension")
     dev = next(net.parameters()).device
     b = _Builder2(dev, nw)
+    b.save_global = save_global          # saved x_hat tensors in global memory: the LDS plan shrinks enough for two trajectories
+    if max_stage is not None:
+        b.max_stage = max_stage
     d = net.in_dim
     x = b.act(horizon, d, persistent=True)
     pred = b.act(horizon, d, persistent=True)            # outlives the classifier ops
@@ -657,4 +681,5 @@ def compile_guided2(net, clf, horizon: int, max_lds_bytes: int = 160 * 1024, nw:
     emb_clf = _emb_table_spec(b, clf, cblocks, dev, raw_rows=(lin1.weight.detach()[:, fcw:], lin1.bias.detach(), head_off))
     prog = _finalize2(b, [emb_den, emb_clf], x, pred, horizon, d, net.emb_dim, max_lds_bytes, [pred, grad], grad=grad)
     prog.meta["n_den"] = n_den
+    prog.ws_floats = b.ws_floats
     return prog

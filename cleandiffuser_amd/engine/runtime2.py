@@ -43,7 +43,8 @@ class CdxUnet2Launch(ctypes.Structure):
                 ("noise", ctypes.c_void_p), ("x_min", ctypes.c_void_p), ("x_max", ctypes.c_void_p),
                 ("x_out", ctypes.c_void_p), ("init_blend", ctypes.c_int32), ("x_scale", ctypes.c_float),
                 ("cg_scale", ctypes.c_void_p), ("grad_off", ctypes.c_int32), ("grad_stride", ctypes.c_int32),
-                ("with_backward", ctypes.c_int32), ("prof", ctypes.c_void_p)]
+                ("with_backward", ctypes.c_int32), ("ws", ctypes.c_void_p), ("ws_floats", ctypes.c_int32),
+                ("prof", ctypes.c_void_p)]
 
 
 _declared = False
@@ -191,6 +192,12 @@ def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps
             and prog.lds_bytes(1) <= 160 * 1024:
         bulk = batch - batch % rounds
         parts = [(0, bulk, 2), (bulk, batch - bulk, 1)]
+    ws = None
+    if prog.ws_floats:                     # saved tensors of a two-trajectory guided program: scratch per (device, stream)
+        key = (x_in.device, R._stream_ptr(x_in.device))
+        ws = _ws.get(key)
+        if ws is None or ws.numel() < (batch + 1) * prog.ws_floats:            # + 1: spare block of the half-empty last workgroup
+            _ws[key] = ws = torch.empty((batch + 1) * prog.ws_floats, dtype=torch.float32, device=x_in.device)
     timing = R._timing
     if timing["on"]:
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -206,7 +213,8 @@ def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps
             x_in=x_in.data_ptr(), prior=R._ptr(prior), fix_mask=R._ptr(fix_mask), noise=R._ptr(noise), x_min=R._ptr(x_min),
             x_max=R._ptr(x_max), x_out=x_out.data_ptr(), init_blend=0 if x_scale is None else 1,
             x_scale=1.0 if x_scale is None else float(x_scale), cg_scale=R._ptr(cg_scale), grad_off=prog.grad_off,
-            grad_stride=prog.grad_stride, with_backward=int(with_backward or cg_scale is not None), prof=R._ptr(prof))
+            grad_stride=prog.grad_stride, with_backward=int(with_backward or cg_scale is not None), ws=R._ptr(ws),
+            ws_floats=prog.ws_floats, prof=R._ptr(prof))
         R._check(_lib().cdx_unet2_run(ctypes.byref(L), R._stream_ptr(x_in.device)), "cdx_unet2_run")
     if timing["on"]:
         end.record(torch.cuda.current_stream(x_in.device))
@@ -214,6 +222,7 @@ def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps
 
 
 N_CUS = 256          # MI355X
+_ws = {}
 
 
 def fused_sample2(solver, net, plan, xt, prior, feed, fix_mask, x_min, x_max, x_scale: Optional[float] = None) -> Optional[torch.Tensor]:
@@ -256,22 +265,27 @@ def backbone_forward2(module, x, noise_t) -> Optional[torch.Tensor]:
 _gcache = weakref.WeakKeyDictionary()
 
 
-def compiled_guided2(net, clf_net, horizon: int) -> _Compiled2:
-    """Guided program (denoiser ops, then the HalfJannerUNet1d classifier's forward and backward-data ops) for the 8-wave,
-    one-trajectory shape; ``.prog is None`` + ``.why`` when it does not exist (LDS plan, unsupported layers)."""
+def compiled_guided2(net, clf_net, horizon: int, two: bool = False) -> _Compiled2:
+    """Guided program (denoiser ops, then the HalfJannerUNet1d classifier's forward and backward-data ops), 8-wave shape.  `two`: the
+    variant for two trajectories per workgroup -- saved tensors in a global workspace, small staging area.  ``.prog is None`` +
+    ``.why`` when it does not exist (LDS plan, unsupported layers)."""
     per = _gcache.setdefault(net, {})
     sig = (R._signature(net), R._signature(clf_net))
-    key = (id(clf_net), horizon)
+    key = (id(clf_net), horizon, bool(two))
     hit = per.get(key)
     if hit is not None and hit.sig == sig:
         return hit
     with torch.no_grad():
         try:
-            comp = _Compiled2(P2.compile_guided2(net, clf_net, horizon), sig)
+            kw = dict(save_global=True, max_stage=GUIDED_T2_STAGE, max_lds_bytes=80 * 1024) if two else {}
+            comp = _Compiled2(P2.compile_guided2(net, clf_net, horizon, **kw), sig)
         except (ValueError, AssertionError) as e:
             comp = _Compiled2(None, sig, str(e))
     per[key] = comp
     return comp
+
+
+GUIDED_T2_STAGE = 2304       # floats of staging area a two-trajectory guided program may use per op (config 2: 2 x 80.8 KB of LDS)
 
 
 def guided_supported(net, clf_net, horizon: int) -> Optional[str]:
@@ -291,7 +305,12 @@ def guided_sample2(solver, net, clf_net, plan, xt, prior, feed, fix_mask, x_min,
     if R.plan_is_edm(plan) or any(st.kind > 2 for st in plan.steps) or guided_supported(net, clf_net, h) is not None:
         return None
     dev = xt.device
-    comp = compiled_guided2(net, clf_net, h)
+    comp, t = compiled_guided2(net, clf_net, h), 1
+    forced = os.environ.get("CDX_UNET2_T")
+    if (forced == "2" or (forced is None and b > 256)):
+        alt = compiled_guided2(net, clf_net, h, two=True)
+        if alt.prog is not None:
+            comp, t = alt, 2
     from .plan import cached
     pn = R._predicts_noise(plan, solver)
     with torch.no_grad():
@@ -304,7 +323,7 @@ def guided_sample2(solver, net, clf_net, plan, xt, prior, feed, fix_mask, x_min,
         out = torch.empty_like(xin)
         launch(comp, batch=b, x_in=xin, x_out=out, emb=emb, steps_dev=steps_dev, n_steps=len(plan.steps), predict_noise=pn,
                prior=R._f32c(prior, dev) if fix_mask is not None else None, fix_mask=fix_mask, noise=noise, x_min=x_min,
-               x_max=x_max, t_per_wg=1, cg_scale=cg)
+               x_max=x_max, t_per_wg=t, cg_scale=cg)
     return out
 
 

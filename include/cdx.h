@@ -177,6 +177,10 @@ typedef struct cdx_unet2_launch {
      * the kernel variant that understands backward ops even without a shift (one forward+backward: gradients only). */
     const float* cg_scale;     /* device [n_steps] or NULL */
     int32_t grad_off, grad_stride, with_backward;
+    /* programs compiled with their saved normalised tensors in global memory (so that two trajectories share a workgroup): device
+     * scratch of (batch + 1) * ws_floats floats (one spare block), owned by the caller, ordered by the launch stream; ws_floats == 0: none */
+    float* ws;
+    int32_t ws_floats;
     /* optional profiling: device u64 [n_ops*8 + 2]; workgroup 0 stamps s_memtime at {op start, next-op prefetch issued, after the
      * staging barrier, op end, item record + segment read, first operands landed, MFMAs done, partial tile staged} of the first
      * forward, plus kernel start/end.  NULL = off. */

@@ -62,6 +62,7 @@ class LaneSim2:
         self.p = prog
         self.blob = prog.blob.detach().cpu().numpy()
         self.buf = prog.ops_buffer
+        self.ws = np.full(max(prog.ws_floats, 1), np.nan, np.float32)    # this trajectory's block of the global workspace
         self.lds = np.full(prog.traj_floats, np.nan, np.float32)        # NaN poison: an unwritten read shows up
         # kernel start: the whole trajectory region is zeroed once (halo rows and pad channels of the state slot)
         self.lds[:] = 0.0
@@ -224,7 +225,7 @@ class LaneSim2:
                     xh = ((vals[kk] - mean) * rstd).astype(np.float32)
                     if (flags & P2.F2_SAVE) and c < c_out:  # save slot: no halo, position-major; pad lane groups save nothing
                         a = int(op[P2.W2_SAVE]) + kk[1] * int(op[P2.W2_SAVE_STRIDE]) + c
-                        lds[a:a + 4] = xh
+                        (self.ws if flags & P2.F2_SAVE_GLOBAL else lds)[a:a + 4] = xh
                     vals[kk] = mish(xh * gamma[c:c + 4] + beta[c:c + 4])
         for (g, pos, c), v in vals.items():
             if flags & P2.F2_EMB:
@@ -260,7 +261,7 @@ class LaneSim2:
                 a = int(op[P2.W2_DST2]) + (pos + P2.HALO2) * int(op[P2.W2_DST2_STRIDE]) + c
                 lds[a:a + 4] = v
             a = int(op[P2.W2_SAVE]) + pos * int(op[P2.W2_SAVE_STRIDE]) + c
-            xh = lds[a:a + 4].copy() if c < c_out else np.zeros(4, np.float32)
+            xh = (self.ws if flags & P2.F2_SAVE_GLOBAL else lds)[a:a + 4].copy() if c < c_out else np.zeros(4, np.float32)
             assert np.isfinite(xh).all(), "backward read an unsaved x_hat"
             d = mish_grad(xh * gamma[c:c + 4] + beta[c:c + 4])
             gx[(g, pos, c)] = (v * d * gamma[c:c + 4]).astype(np.float32)

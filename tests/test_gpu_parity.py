@@ -178,6 +178,30 @@ def test_guided_program_gradient_matches_autograd(amd_lib):
     np.testing.assert_allclose(grad.cpu().numpy(), xr.grad.cpu().numpy(), rtol=1e-4, atol=1e-4 * max(scale, 1.0))
 
 
+def test_guided_two_trajectories_per_workgroup(amd_lib, monkeypatch):
+    """Guided program variant for two trajectories per workgroup (saved x_hat tensors in the launch's global workspace, capped staging
+    area; taken above B = 256): B = 37 (half-empty last workgroup -> spare workspace block) forced through it must agree with the
+    one-trajectory, all-in-LDS program to summation-order noise (the staging cap changes some K splits), and reproduce itself."""
+    name = "janner_cfg2_guided_ddpm"
+    agent, _ = cases.build(amd_lib, name, device=DEV)
+    g = torch.Generator().manual_seed(13)
+    B = 37
+    prior = torch.zeros(B, 32, 23)
+    prior[:, 0, :17] = torch.randn(B, 17, generator=g)
+    zs = [torch.randn(B, 32, 23, generator=g).to(DEV) for _ in range(6)]
+    kw = dict(solver="ddpm", n_samples=B, sample_steps=5, temperature=0.5, w_cg=0.3)
+    outs = {}
+    for t in ("1", "2", "2"):
+        monkeypatch.setenv("CDX_UNET2_T", t)
+        calls = _spy_launches(monkeypatch)
+        x, _ = agent.sample(prior.to(DEV), noise=list(zs), **kw)
+        torch.cuda.synchronize()
+        assert calls["v2"] == 1
+        outs.setdefault(t, []).append(x)
+    assert torch.equal(outs["2"][0], outs["2"][1])
+    np.testing.assert_allclose(outs["2"][0].cpu().numpy(), outs["1"][0].cpu().numpy(), rtol=2e-4, atol=2e-4)
+
+
 @pytest.mark.parametrize("one_call", ["v2", True, False])
 @pytest.mark.parametrize("name", GUIDED_CASES)
 def test_guided_sampling_matches_reference_fixture(name, one_call, amd_lib, monkeypatch):

@@ -102,8 +102,9 @@ def test_v2_refuses_what_it_cannot_run(amd_lib):
     assert runtime2.supported(agent.model_ema["diffusion"], 36) is not None
 
 
+@pytest.mark.parametrize("two", [False, True])
 @pytest.mark.parametrize("shape", [(16, 6, [1, 2]), (32, 23, [1, 2, 2, 2])])
-def test_lane_sim2_guided_program_gradient_matches_autograd(shape, amd_lib):
+def test_lane_sim2_guided_program_gradient_matches_autograd(shape, two, amd_lib):
     """Guided program (engine/program2.py:compile_guided2): the denoiser's ops followed by the HalfJannerUNet1d classifier's forward
     and backward-data ops (saved x_hat / rstd, tap-flipped transposed weights, the stride-2 scatter as two parity convs, the
     GroupNorm -> Mish backward epilogue, the head op).  The lane-level twin of the kernel must reproduce the denoiser forward AND
@@ -112,8 +113,10 @@ def test_lane_sim2_guided_program_gradient_matches_autograd(shape, amd_lib):
     H, D, dm = shape
     net = load_synth(amd_lib.JannerUNet1d(D, model_dim=32, emb_dim=32, dim_mult=dm, kernel_size=5), 0).eval()
     clf = load_synth(amd_lib.HalfJannerUNet1d(H, D, out_dim=1, model_dim=32, emb_dim=32, dim_mult=tuple(dm), kernel_size=3), 1).eval()
-    prog = P2.compile_guided2(net, clf, H)
-    assert prog.nw == 8 and prog.lds_bytes(1) <= 160 * 1024 and prog.grad_off > 0 and len(prog.embtabs) == 2
+    # `two`: the variant for two trajectories per workgroup -- saved tensors in the global workspace, capped staging area
+    prog = P2.compile_guided2(net, clf, H, **(dict(save_global=True, max_stage=2304) if two else {}))
+    assert prog.nw == 8 and prog.lds_bytes(2 if two else 1) <= 160 * 1024 and prog.grad_off > 0 and len(prog.embtabs) == 2
+    assert (prog.ws_floats > 0) == two
     n_den = prog.meta["n_den"]
     assert all(int(op[P2.W2_FLAGS]) & (P2.F2_SAVE | P2.F2_GNBWD | P2.F2_DUAL) == 0 for op in prog.ops[:n_den])
     assert sum(int(op[P2.W2_KIND]) == P2.KIND2_HEAD for op in prog.ops) == 1
