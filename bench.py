@@ -358,12 +358,22 @@ def main():
             out["other_configs"] = other_configs(device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_subprocess()
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
     faulthandler.cancel_dump_traceback_later()
 
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    # The JSON line is the LAST thing this process writes to stdout: RCCL prints a version banner through C stdio, which is
+    # block-buffered on a pipe and would otherwise surface after the line when the process exits.
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except (OSError, AttributeError):
+        pass
+    sys.stdout.flush()
+    if rank == 0:
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
