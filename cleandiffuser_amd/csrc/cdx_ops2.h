@@ -43,6 +43,8 @@
 #define CDX2_W2_STATS 27       /* 8 floats: rstd per GroupNorm group */
 #define CDX2_W2_DST2 28        /* F2_DUAL: slot of the value before the backward epilogue */
 #define CDX2_W2_DST2_STRIDE 29
+#define CDX2_W2_KPOST 30       /* partial tiles after the first KSPLIT that are added AFTER norm / activation (fused 1x1 skip conv) */
+#define CDX2_W2_PBIAS 31       /* blob offset of their bias */
 #define CDX2_KIND2_CONV 0
 #define CDX2_KIND2_HEAD 1      /* classifier head, forward + backward (words: COUT hidden, LOUT/LCOLS positions/channels, RES src,
                                 * DST gradient slot, BOFF W1x [l][c][hidden], GAMMA w2, EMB table offset) */

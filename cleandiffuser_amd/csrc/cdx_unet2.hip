@@ -346,6 +346,7 @@ __device__ __forceinline__ void conv_kloop(const Geom& g, const float* __restric
 struct EpiDesc {
     int flags, c_out, l_out, coutp, sstride, ksplit, dst, dstride, res, rstride, shift, nk;
     int save, savestr, stats, dst2, d2stride;          // backward-pass extras (F2_SAVE / F2_GNBWD / F2_DUAL)
+    int kpost;                                         // partial tiles (after the first ksplit) that are added AFTER norm / activation
     float inv_cnt;
 };
 template <bool BWD>
@@ -356,6 +357,7 @@ __device__ __forceinline__ EpiDesc decode_epi(int vd) {
     e.dst = CDX2_DW(vd, CDX2_W2_DST); e.dstride = CDX2_DW(vd, CDX2_W2_DST_STRIDE); e.res = CDX2_DW(vd, CDX2_W2_RES);
     e.rstride = CDX2_DW(vd, CDX2_W2_RES_STRIDE); e.shift = CDX2_DW(vd, CDX2_W2_CG4_SHIFT); e.nk = CDX2_DW(vd, CDX2_W2_NK);
     e.inv_cnt = __int_as_float(CDX2_DW(vd, CDX2_W2_INV_CNT));
+    e.kpost = CDX2_DW(vd, CDX2_W2_KPOST);
     e.save = e.savestr = e.stats = e.dst2 = e.d2stride = 0;
     if (BWD && (e.flags & (CDX2_F2_SAVE | CDX2_F2_GNBWD))) {
         e.save = CDX2_DW(vd, CDX2_W2_SAVE); e.savestr = CDX2_DW(vd, CDX2_W2_SAVE_STRIDE); e.stats = CDX2_DW(vd, CDX2_W2_STATS);
@@ -364,7 +366,7 @@ __device__ __forceinline__ EpiDesc decode_epi(int vd) {
     return e;
 }
 
-struct EpiParams { f32x4 bi, ga, be, em; };
+struct EpiParams { f32x4 bi, ga, be, em, pb; };      // bias, gamma, beta, FiLM vector, bias of the post-norm extra conv
 
 // two half-wave sums at once (the DPP chains of a and b interleave, so the second one is almost free)
 __device__ __forceinline__ void half_sum2(float& a, float& b, int lane) {
@@ -449,6 +451,14 @@ __device__ __forceinline__ void epilogue(float* __restrict__ tl, const EpiParams
         const int pos = pos0 + k * pstep;
         f32x4 y = v[k];
         if (e.flags & CDX2_F2_EMB) y += P.em;
+        if (e.kpost) {
+            // the ResidualBlock's 1x1 skip conv (reference jannerunet.py:58, :69) was computed by other waves of this op: bias + its
+            // partial tiles, added after the norm / activation
+            f32x4 pv = P.pb;
+            const float* pp = tl + stage + (e.ksplit * e.l_out + pos) * e.sstride + c;
+            for (int j = 0; j < e.kpost; ++j) pv += *reinterpret_cast<const f32x4*>(pp + j * e.l_out * e.sstride);
+            y += pv;
+        }
         if (e.flags & CDX2_F2_RES) y += *reinterpret_cast<const f32x4*>(tl + e.res + (pos + CDX2_HALO2) * e.rstride + c);
         float* o = tl + e.dst + (pos + CDX2_HALO2) * e.dstride + c;
         if (c + 3 < e.c_out) {
@@ -613,9 +623,10 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
     const int pos0 = li >> shift, pstep = 32 >> shift;
     const int nv = (coutp >> 5) * l_out;
     EpiParams P;
-    P.bi = P.ga = P.be = P.em = (f32x4){0.f, 0.f, 0.f, 0.f};
+    P.bi = P.ga = P.be = P.em = P.pb = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (epi_wave) {
         P.bi = *reinterpret_cast<const f32x4*>(L.wblob + CDX2_DW(vd, CDX2_W2_BOFF) + c);
+        if (CDX2_DW(vd, CDX2_W2_KPOST)) P.pb = *reinterpret_cast<const f32x4*>(L.wblob + CDX2_DW(vd, CDX2_W2_PBIAS) + c);
         if (flags & (CDX2_F2_GN | CDX2_F2_GNBWD)) {
             P.ga = *reinterpret_cast<const f32x4*>(L.wblob + CDX2_DW(vd, CDX2_W2_GAMMA) + c);
             P.be = *reinterpret_cast<const f32x4*>(L.wblob + CDX2_DW(vd, CDX2_W2_BETA) + c);

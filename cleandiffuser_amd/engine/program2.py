@@ -50,10 +50,11 @@ GROUPS2 = 8                   # GroupNorm groups the epilogue partition is built
 MAX_NK2 = 4                   # float4 items a lane may own in the epilogue
 HALO2 = 2                     # zero rows on either side of a slot: covers kernel sizes <= 5 (pad <= 2)
 MIN_SLICE = int(os.environ.get("CDX_UNET2_MIN_SLICE", "3"))      # shortest K slice (records) worth a wave of its own
+FUSE_SKIP = os.environ.get("CDX_UNET2_FUSE_SKIP", "1") != "0"    # 1x1 skip convs ride in their block's second conv op
 
 (W2_KIND, W2_FLAGS, W2_COUT, W2_LOUT, W2_LCOLS, W2_CSTRIDE, W2_OSTRIDE, W2_MODE, W2_NT, W2_NITEMS, W2_ITEMS, W2_DST,
  W2_DST_STRIDE, W2_SSTRIDE, W2_KSPLIT, W2_BOFF, W2_GAMMA, W2_BETA, W2_EMB, W2_RES, W2_RES_STRIDE, W2_CG4_SHIFT, W2_INV_CNT,
- W2_NK, W2_COUTP, W2_SAVE, W2_SAVE_STRIDE, W2_STATS, W2_DST2, W2_DST2_STRIDE) = range(30)
+ W2_NK, W2_COUTP, W2_SAVE, W2_SAVE_STRIDE, W2_STATS, W2_DST2, W2_DST2_STRIDE, W2_KPOST, W2_PBIAS) = range(32)
 KIND2_CONV, KIND2_HEAD = 0, 1
 W2_ITEM0 = 32                 # items 0..nw-1 inline; items nw.. in the tail table at W2_ITEMS
 
@@ -214,8 +215,14 @@ class _Builder2:
 
     def conv(self, srcs: List[Act], dst: Act, w_eff: torch.Tensor, bias: Optional[torch.Tensor], *, stride=1, pad=0,
              transposed=False, phases=None, gn: Optional[nn.Module] = None, emb_off: int = -1, res: Optional[Act] = None,
-             pred: bool = False, save: Optional[Tuple[Act, int]] = None, bwd: Optional[dict] = None):
+             pred: bool = False, save: Optional[Tuple[Act, int]] = None, bwd: Optional[dict] = None,
+             extra: Optional[List[dict]] = None):
         """One fused op: conv over the channel concat of `srcs` -> epilogue -> dst.
+
+        `extra`: further stride-1 convs with the same output shape computed by the SAME op on other waves -- dicts
+        {srcs, w_eff, pad, bias, post}.  post=False: their partial tiles are simply summed with the main conv's (the two convs of a
+        backward residual sum).  post=True: their sum (+ bias) is added AFTER the GroupNorm / Mish / FiLM of the main conv -- the
+        1x1 skip conv of a ResidualBlock (reference jannerunet.py:58, :69) rides in its second conv's op instead of costing an op.
 
         Forward epilogue: [GroupNorm -> Mish] -> [+ emb] -> [+ residual slot `res` (may be `dst`: accumulate)].  `save=(slot, stats)`
         additionally stores the normalised pre-affine values and the group rstd (what the backward of this layer needs).
@@ -258,52 +265,113 @@ class _Builder2:
         # record stream of a (phase, row tile): [source 0: taps x chunks | source 1: taps x chunks]; a K slice never straddles the
         # sources.  K slices: every source's record range is cut evenly; with two sources (a concat) each source gets at least one
         # slice and the epilogue sums the staged partials.  Phases with fewer taps get the same NUMBER of slices (shorter ones).
-        per_src = max(1, (nw // tiles if tiles < nw else 1) // len(srcs))
-        ph_segs = []
-        for w, _, _ in phases:
-            segs, lo = [], 0
+        extra = list(extra or [])
+        all_srcs = list(srcs)
+        kpost, pbias = 0, None
+        if len(phases) == 1:
+            # ---- single phase: a list of record STREAMS (one per source of the main conv and of every extra conv); every stream is
+            # cut into K slices, one work item per (slice, tile).  Slice budget = waves per tile, handed out greedily to the stream with
+            # the most records per slice (>= 1 per stream, >= MIN_SLICE records per slice, staging area <= max_stage).
+            streams = []                                     # dict(act index, records, ccn, pad, post)
+            lo = 0
             for a in srcs:
-                segs.append(_records(w[:, :, lo:lo + a.chans], mode))
+                r, ccn = _records(phases[0][0][:, :, lo:lo + a.chans], mode)
+                streams.append(dict(src=all_srcs.index(a), recs=r, ccn=ccn, pad=phases[0][1], post=False))
                 lo += a.chans
-            ph_segs.append(segs)
-        # slices per source: the same for every phase (the epilogue sums `ksplit` staged partials of every output position)
-        # ... and a slice is at least MIN_SLICE records long: below that the extra partial tile (staging, one more LDS read per
-        # epilogue item) costs more than the few MFMAs it takes off the other waves
-        per = [min([per_src] + [max(1, segs[si][0].shape[1] // MIN_SLICE) for segs in ph_segs]) for si in range(len(srcs))]
-        while sum(per) > len(srcs) and sum(per) * l_out * sstride > self.max_stage:
-            per[per.index(max(per))] -= 1
-        ph_info = []
-        for (w, ppad, ooff), segs in zip(phases, ph_segs):
-            seg_n = [r.shape[1] for r, _ in segs]
-            cuts, base = [], 0                              # (first record, one past the last, source index, source base) per slice
-            for si, (n, k) in enumerate(zip(seg_n, per)):
-                # long streams are cut on multiples of the ring depth: the kernel's immediate-offset steady loop needs a slice to
-                # start on a ring-aligned chunk of its tap
+            for ex in extra:
+                w2, lo = ex["w_eff"], 0
+                assert w2.shape[0] == c_out and w2.shape[2] == sum(a.chans for a in ex["srcs"]) and stride == 1
+                if ex["pad"] > HALO2 or (w2.shape[1] - 1 - ex["pad"]) > HALO2:
+                    raise ValueError("extra conv reaches past the halo rows")
+                for a in ex["srcs"]:
+                    if a not in all_srcs:
+                        all_srcs.append(a)
+                    r, ccn = _records(w2[:, :, lo:lo + a.chans], mode)
+                    streams.append(dict(src=all_srcs.index(a), recs=r, ccn=ccn, pad=ex["pad"], post=bool(ex.get("post"))))
+                    lo += a.chans
+                if ex.get("post"):
+                    pb = ex.get("bias")
+                    pbias = (pbias if pbias is not None else torch.zeros(c_out, device=self.device)) + \
+                        (pb.detach().to(self.device) if pb is not None else 0)
+                else:
+                    assert ex.get("bias") is None, "bias of a summed extra conv: fold it into the main bias"
+                self.macs += c_out * l_out * w2.shape[1] * w2.shape[2]
+            budget = max(len(streams), nw // tiles if tiles < nw else 1)
+            per = [1] * len(streams)
+            n_of = [st["recs"].shape[1] for st in streams]
+
+            def grow():
+                cand = [i for i in range(len(streams)) if n_of[i] // (per[i] + 1) >= MIN_SLICE]
+                return max(cand, key=lambda i: n_of[i] / per[i]) if cand else None
+            while sum(per) < budget and (sum(per) + 1) * l_out * sstride <= self.max_stage:
+                i = grow()
+                if i is None:
+                    break
+                per[i] += 1
+            order = [i for i in range(len(streams)) if not streams[i]["post"]] + [i for i in range(len(streams)) if streams[i]["post"]]
+            kpost = sum(per[i] for i in range(len(streams)) if streams[i]["post"])
+            ksplit = sum(per) - kpost                        # slices summed BEFORE the norm; the post slices follow them in the stage
+            items, item_src, ks = [], [], 0
+            for i in order:
+                st, n, k = streams[i], n_of[i], per[i]
+                woff = self.add(st["recs"].contiguous())
                 al = ring if n >= 2 * ring * k else 1
                 edge = [min(n, (j * n // k + al // 2) // al * al) for j in range(k)] + [n]
-                cuts += [(base + edge[j], base + edge[j + 1], si, base) for j in range(k)]
-                base += n
-            woff = self.add(torch.cat([r for r, _ in segs], dim=1).contiguous())
-            ph_info.append(dict(segs=segs, nqt=sum(seg_n), cuts=cuts, woff=woff, pad=ppad, ooff=ooff))
-        ksplit = max(len(pi["cuts"]) for pi in ph_info)
-        items, item_src = [], []
-        for ks in range(ksplit):
-            for tile in range(n_rt * n_cg):
-                rt, cgi = tile % n_rt, tile // n_rt
-                for pi in ph_info:
-                    if ks >= len(pi["cuts"]):
-                        continue                             # this phase has fewer slices: its staged partials of slice ks must read 0
-                    q0, q1, si, sbase = pi["cuts"][ks]
-                    ccn = pi["segs"][si][1]
-                    items.append([pi["woff"] + (rt * pi["nqt"] + q0) * 256, q1 - q0, ((q0 - sbase) // ccn) | (((q0 - sbase) % ccn) << 8),
-                                  ks * l_out * sstride + rt * rows, cgi * nt * cols, pi["pad"] | (pi["ooff"] << 8), 0, ccn])
-                    item_src.append(si)
-        if any(len(pi["cuts"]) != ksplit for pi in ph_info):
-            raise ValueError("phases with different K-slice counts are not supported (stale partial tiles)")
+                for j in range(k):
+                    q0, q1 = edge[j], edge[j + 1]
+                    for tile in range(n_rt * n_cg):
+                        rt, cgi = tile % n_rt, tile // n_rt
+                        items.append([woff + (rt * n + q0) * 256, q1 - q0, (q0 // st["ccn"]) | ((q0 % st["ccn"]) << 8),
+                                      ks * l_out * sstride + rt * rows, cgi * nt * cols, st["pad"] | (0 << 8), 0, st["ccn"]])
+                        item_src.append(st["src"])
+                    ks += 1
+            stage_slices = ksplit + kpost
+        else:
+            assert not extra, "extra convs ride on single-phase ops only"
+            # record stream of a (phase, row tile): [source 0: taps x chunks | source 1: taps x chunks]; a K slice never straddles the
+            # sources.  Phases with fewer taps get the same NUMBER of slices (shorter ones).
+            per_src = max(1, (nw // tiles if tiles < nw else 1) // len(srcs))
+            ph_segs = []
+            for w, _, _ in phases:
+                segs, lo = [], 0
+                for a in srcs:
+                    segs.append(_records(w[:, :, lo:lo + a.chans], mode))
+                    lo += a.chans
+                ph_segs.append(segs)
+            per = [min([per_src] + [max(1, segs[si][0].shape[1] // MIN_SLICE) for segs in ph_segs]) for si in range(len(srcs))]
+            while sum(per) > len(srcs) and sum(per) * l_out * sstride > self.max_stage:
+                per[per.index(max(per))] -= 1
+            ph_info = []
+            for (w, ppad, ooff), segs in zip(phases, ph_segs):
+                seg_n = [r.shape[1] for r, _ in segs]
+                cuts, base = [], 0                          # (first record, one past the last, source index, source base) per slice
+                for si, (n, k) in enumerate(zip(seg_n, per)):
+                    al = ring if n >= 2 * ring * k else 1
+                    edge = [min(n, (j * n // k + al // 2) // al * al) for j in range(k)] + [n]
+                    cuts += [(base + edge[j], base + edge[j + 1], si, base) for j in range(k)]
+                    base += n
+                woff = self.add(torch.cat([r for r, _ in segs], dim=1).contiguous())
+                ph_info.append(dict(segs=segs, nqt=sum(seg_n), cuts=cuts, woff=woff, pad=ppad, ooff=ooff))
+            ksplit = max(len(pi["cuts"]) for pi in ph_info)
+            items, item_src = [], []
+            for ks in range(ksplit):
+                for tile in range(n_rt * n_cg):
+                    rt, cgi = tile % n_rt, tile // n_rt
+                    for pi in ph_info:
+                        q0, q1, si, sbase = pi["cuts"][ks]
+                        ccn = pi["segs"][si][1]
+                        items.append([pi["woff"] + (rt * pi["nqt"] + q0) * 256, q1 - q0, ((q0 - sbase) // ccn) | (((q0 - sbase) % ccn) << 8),
+                                      ks * l_out * sstride + rt * rows, cgi * nt * cols, pi["pad"] | (pi["ooff"] << 8), 0, ccn])
+                        item_src.append(si)
+            if any(len(pi["cuts"]) != ksplit for pi in ph_info):
+                raise ValueError("phases with different K-slice counts are not supported (stale partial tiles)")
+            stage_slices = ksplit
         words = {W2_KIND: KIND2_CONV, W2_COUT: c_out, W2_LOUT: l_out, W2_LCOLS: l_cols, W2_CSTRIDE: cstride, W2_OSTRIDE: ostride,
                  W2_MODE: mode, W2_NT: nt, W2_NITEMS: len(items), W2_DST_STRIDE: dst.stride, W2_SSTRIDE: sstride,
-                 W2_KSPLIT: ksplit, W2_COUTP: coutp,
+                 W2_KSPLIT: ksplit, W2_COUTP: coutp, W2_KPOST: kpost,
                  W2_BOFF: self.add(_padded(bias if bias is not None else torch.zeros(c_out, device=self.device), coutp))}
+        if kpost:
+            words[W2_PBIAS] = self.add(_padded(pbias, coutp))
         cg = coutp // GROUPS2
         cg4 = cg // 4
         assert cg4 & (cg4 - 1) == 0 and cg4 <= 32, f"C_out {c_out}: channels per group / 4 must be a power of two <= 32"
@@ -312,8 +380,10 @@ class _Builder2:
             raise ValueError(f"epilogue: {cg4 * l_out} float4 items per group > {32 * MAX_NK2} (horizon too long for v2)")
         words[W2_CG4_SHIFT], words[W2_NK] = cg4.bit_length() - 1, nk
         flags = 0
-        reads, writes = list(srcs), [dst]
+        reads, writes = list(all_srcs), [dst]
         norm = gn if bwd is None else bwd["gn"]
+        if kpost and bwd is not None:
+            raise ValueError("post-norm extra convs exist on forward ops only")
         if norm is not None:
             # the epilogue cuts pad32(C_out) channels into 8 lane groups; a real group must be exactly one of them (C_out = 16 with
             # 4 groups of 4 is fine: lane groups 4..7 then work on pad channels that are never stored)
@@ -352,11 +422,11 @@ class _Builder2:
         for k, v in words.items():
             op[k] = int(v)
         self.ops.append(op)
-        self.op_acts.append(dict(srcs=list(srcs), res=res, dst=dst, save=(save[0] if save is not None else (bwd["save"] if bwd else None)),
+        self.op_acts.append(dict(srcs=list(all_srcs), res=res, dst=dst, save=(save[0] if save is not None else (bwd["save"] if bwd else None)),
                                  dst2=(bwd.get("dst2") if bwd else None), reads=reads, writes=writes))
         self.op_items.append(items)
         self.op_item_src.append(item_src)
-        self.stage = max(self.stage, ksplit * l_out * sstride)
+        self.stage = max(self.stage, stage_slices * l_out * sstride)
         self.macs += sum(c_out * (l_cols if len(phases) > 1 else l_out) * w.shape[1] * c_in for w, _, _ in phases)
 
     def head(self, src: Act, dst: Act, w1: torch.Tensor, e_off: int, w2: torch.Tensor):
@@ -470,6 +540,11 @@ def _lower_janner(b: "_Builder2", net, horizon: int, x: Act):
         if isinstance(rb.residual_conv, nn.Identity):
             assert len(srcs) == 1
             b.conv([t1], out, _conv1d_eff(rb.conv2[0]), rb.conv2[0].bias, pad=k // 2, gn=rb.conv2[1], res=srcs[0])
+        elif FUSE_SKIP:
+            # the 1x1 skip conv rides in the second conv's op: its work items take some of the waves, its partial tiles are added
+            # after the norm / activation (one op, two barriers and one epilogue less per block)
+            b.conv([t1], out, _conv1d_eff(rb.conv2[0]), rb.conv2[0].bias, pad=k // 2, gn=rb.conv2[1],
+                   extra=[dict(srcs=srcs, w_eff=_conv1d_eff(rb.residual_conv), pad=0, bias=rb.residual_conv.bias, post=True)])
         else:
             b.conv([t1], out, _conv1d_eff(rb.conv2[0]), rb.conv2[0].bias, pad=k // 2, gn=rb.conv2[1])
             b.conv(srcs, out, _conv1d_eff(rb.residual_conv), rb.residual_conv.bias, res=out)     # out += W_r x + b_r
@@ -526,8 +601,10 @@ def _lower_half_janner_grad(b: "_Builder2", clf, horizon: int, x: Act, grad: Act
         b.conv([src], t1, _conv1d_eff(rb.conv1[0]), rb.conv1[0].bias, pad=ksz // 2, gn=rb.conv1[1], emb_off=e_off, save=s1)
         out = b.act(length, c_out)
         ident = isinstance(rb.residual_conv, nn.Identity)
-        b.conv([t1], out, _conv1d_eff(rb.conv2[0]), rb.conv2[0].bias, pad=ksz // 2, gn=rb.conv2[1], res=src if ident else None, save=s2)
-        if not ident:
+        fuse = (not ident) and FUSE_SKIP
+        b.conv([t1], out, _conv1d_eff(rb.conv2[0]), rb.conv2[0].bias, pad=ksz // 2, gn=rb.conv2[1], res=src if ident else None, save=s2,
+               extra=[dict(srcs=[src], w_eff=_conv1d_eff(rb.residual_conv), pad=0, bias=rb.residual_conv.bias, post=True)] if fuse else None)
+        if not ident and not fuse:
             b.conv([src], out, _conv1d_eff(rb.residual_conv), rb.residual_conv.bias, res=out)
         tape.append(("block", rb, ksz, src, s1, s2, ident))
         return out
@@ -593,12 +670,17 @@ def _lower_half_janner_grad(b: "_Builder2", clf, horizon: int, x: Act, grad: Act
         b.conv([g_u2], gu1, _dgrad_eff(rb.conv2[0]), None, pad=ksz // 2,
                bwd=dict(gn=rb.conv1[1], save=s1[0], stats=s1[1], dst2=None))
         gout = g_plain
+        wrt = None if ident else rb.residual_conv.weight.detach().permute(1, 2, 0)          # W_r^T as [C_in][1][C_out]
         if ident:
-            skip = gout
+            g_plain, g_u2 = finish(idx, lambda dst, bw: b.conv([gu1], dst, _dgrad_eff(rb.conv1[0]), None, pad=ksz // 2, res=gout, bwd=bw))
+        elif FUSE_SKIP:
+            # gradient w.r.t. the block input = conv1^T g_u1 + W_r^T g_out: two convs whose partial tiles are simply summed
+            g_plain, g_u2 = finish(idx, lambda dst, bw: b.conv([gu1], dst, _dgrad_eff(rb.conv1[0]), None, pad=ksz // 2, bwd=bw,
+                                                               extra=[dict(srcs=[gout], w_eff=wrt, pad=0, bias=None, post=False)]))
         else:
             skip = b.act(src.length, src.chans)
-            b.conv([gout], skip, rb.residual_conv.weight.detach().permute(1, 2, 0), None)    # W_r^T g_out
-        g_plain, g_u2 = finish(idx, lambda dst, bw: b.conv([gu1], dst, _dgrad_eff(rb.conv1[0]), None, pad=ksz // 2, res=skip, bwd=bw))
+            b.conv([gout], skip, wrt, None)                                                 # W_r^T g_out
+            g_plain, g_u2 = finish(idx, lambda dst, bw: b.conv([gu1], dst, _dgrad_eff(rb.conv1[0]), None, pad=ksz // 2, res=skip, bwd=bw))
     return blocks, (lin1, head_off)
 
 

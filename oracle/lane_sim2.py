@@ -135,7 +135,7 @@ class LaneSim2:
             cols, kstep, lcol, koff, drow = 4, 4, lane & 3, 0 * lane, 4 * (lane >> 2)
         stage = p.stage_off
         ksplit = int(op[P2.W2_KSPLIT])
-        lds[stage:stage + ksplit * l_out * sstride] = np.nan      # stale data must not be read
+        lds[stage:stage + (ksplit + int(op[P2.W2_KPOST])) * l_out * sstride] = np.nan      # stale data must not be read
 
         for item in range(int(op[P2.W2_NITEMS])):             # wave w takes items w, w + 4, ...
             rec = P2.op_item(self.buf, op, item)
@@ -227,10 +227,17 @@ class LaneSim2:
                         a = int(op[P2.W2_SAVE]) + kk[1] * int(op[P2.W2_SAVE_STRIDE]) + c
                         (self.ws if flags & P2.F2_SAVE_GLOBAL else lds)[a:a + 4] = xh
                     vals[kk] = mish(xh * gamma[c:c + 4] + beta[c:c + 4])
+        kpost = int(op[P2.W2_KPOST])
         for (g, pos, c), v in vals.items():
             if flags & P2.F2_EMB:
                 e0 = int(op[P2.W2_EMB]) + c
                 v = v + emb_row[e0:e0 + 4]
+            if kpost:                                         # extra conv(s) added after the norm: bias + their staged partials
+                pv = par(P2.W2_PBIAS)[c:c + 4].copy()
+                for ks in range(ksplit, ksplit + kpost):
+                    a = stage + (ks * l_out + pos) * sstride + c
+                    pv = pv + lds[a:a + 4]
+                v = v + pv
             if flags & P2.F2_RES:
                 a = int(op[P2.W2_RES]) + (pos + P2.HALO2) * int(op[P2.W2_RES_STRIDE]) + c
                 v = v + lds[a:a + 4]
