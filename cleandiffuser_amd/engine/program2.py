@@ -50,7 +50,8 @@ GROUPS2 = 8                   # GroupNorm groups the epilogue partition is built
 MAX_NK2 = 4                   # float4 items a lane may own in the epilogue
 HALO2 = 2                     # zero rows on either side of a slot: covers kernel sizes <= 5 (pad <= 2)
 MIN_SLICE = int(os.environ.get("CDX_UNET2_MIN_SLICE", "3"))      # shortest K slice (records) worth a wave of its own
-FUSE_SKIP = os.environ.get("CDX_UNET2_FUSE_SKIP", "1") != "0"    # 1x1 skip convs ride in their block's second conv op
+FUSE_SKIP = os.environ.get("CDX_UNET2_FUSE_SKIP", "1") != "0"    # 1x1 skip convs ride in their block's second conv op ...
+FUSE_MAX_RECORDS = int(os.environ.get("CDX_UNET2_FUSE_MAX", "100"))   # ... unless that leaves the main conv K slices longer than this
 
 (W2_KIND, W2_FLAGS, W2_COUT, W2_LOUT, W2_LCOLS, W2_CSTRIDE, W2_OSTRIDE, W2_MODE, W2_NT, W2_NITEMS, W2_ITEMS, W2_DST,
  W2_DST_STRIDE, W2_SSTRIDE, W2_KSPLIT, W2_BOFF, W2_GAMMA, W2_BETA, W2_EMB, W2_RES, W2_RES_STRIDE, W2_CG4_SHIFT, W2_INV_CNT,
@@ -295,7 +296,6 @@ class _Builder2:
                         (pb.detach().to(self.device) if pb is not None else 0)
                 else:
                     assert ex.get("bias") is None, "bias of a summed extra conv: fold it into the main bias"
-                self.macs += c_out * l_out * w2.shape[1] * w2.shape[2]
             budget = max(len(streams), nw // tiles if tiles < nw else 1)
             per = [1] * len(streams)
             n_of = [st["recs"].shape[1] for st in streams]
@@ -308,6 +308,10 @@ class _Builder2:
                 if i is None:
                     break
                 per[i] += 1
+            if extra and max(n_of[i] / per[i] for i in range(len(srcs))) > FUSE_MAX_RECORDS:
+                # the main conv is a long, stream-bound K loop: giving waves away to the extra conv costs it more than an op of its own
+                return False
+            self.macs += sum(c_out * l_out * ex["w_eff"].shape[1] * ex["w_eff"].shape[2] for ex in extra)
             order = [i for i in range(len(streams)) if not streams[i]["post"]] + [i for i in range(len(streams)) if streams[i]["post"]]
             kpost = sum(per[i] for i in range(len(streams)) if streams[i]["post"])
             ksplit = sum(per) - kpost                        # slices summed BEFORE the norm; the post slices follow them in the stage
@@ -428,6 +432,7 @@ class _Builder2:
         self.op_item_src.append(item_src)
         self.stage = max(self.stage, stage_slices * l_out * sstride)
         self.macs += sum(c_out * (l_cols if len(phases) > 1 else l_out) * w.shape[1] * c_in for w, _, _ in phases)
+        return True
 
     def head(self, src: Act, dst: Act, w1: torch.Tensor, e_off: int, w2: torch.Tensor):
         """Classifier head with its backward in one op (reference nn_classifier/half_jannerunet.py:49-50, :62):
@@ -540,14 +545,14 @@ def _lower_janner(b: "_Builder2", net, horizon: int, x: Act):
         if isinstance(rb.residual_conv, nn.Identity):
             assert len(srcs) == 1
             b.conv([t1], out, _conv1d_eff(rb.conv2[0]), rb.conv2[0].bias, pad=k // 2, gn=rb.conv2[1], res=srcs[0])
-        elif FUSE_SKIP:
-            # the 1x1 skip conv rides in the second conv's op: its work items take some of the waves, its partial tiles are added
-            # after the norm / activation (one op, two barriers and one epilogue less per block)
-            b.conv([t1], out, _conv1d_eff(rb.conv2[0]), rb.conv2[0].bias, pad=k // 2, gn=rb.conv2[1],
-                   extra=[dict(srcs=srcs, w_eff=_conv1d_eff(rb.residual_conv), pad=0, bias=rb.residual_conv.bias, post=True)])
         else:
-            b.conv([t1], out, _conv1d_eff(rb.conv2[0]), rb.conv2[0].bias, pad=k // 2, gn=rb.conv2[1])
-            b.conv(srcs, out, _conv1d_eff(rb.residual_conv), rb.residual_conv.bias, res=out)     # out += W_r x + b_r
+            # the 1x1 skip conv rides in the second conv's op when that pays: its work items take some of the waves, its partial tiles
+            # are added after the norm / activation (one op, two barriers and one epilogue less per block)
+            fused = FUSE_SKIP and b.conv([t1], out, _conv1d_eff(rb.conv2[0]), rb.conv2[0].bias, pad=k // 2, gn=rb.conv2[1], extra=[
+                dict(srcs=srcs, w_eff=_conv1d_eff(rb.residual_conv), pad=0, bias=rb.residual_conv.bias, post=True)])
+            if not fused:
+                b.conv([t1], out, _conv1d_eff(rb.conv2[0]), rb.conv2[0].bias, pad=k // 2, gn=rb.conv2[1])
+                b.conv(srcs, out, _conv1d_eff(rb.residual_conv), rb.residual_conv.bias, res=out)     # out += W_r x + b_r
         return out
 
     cur, skips = x, []
@@ -601,11 +606,13 @@ def _lower_half_janner_grad(b: "_Builder2", clf, horizon: int, x: Act, grad: Act
         b.conv([src], t1, _conv1d_eff(rb.conv1[0]), rb.conv1[0].bias, pad=ksz // 2, gn=rb.conv1[1], emb_off=e_off, save=s1)
         out = b.act(length, c_out)
         ident = isinstance(rb.residual_conv, nn.Identity)
-        fuse = (not ident) and FUSE_SKIP
-        b.conv([t1], out, _conv1d_eff(rb.conv2[0]), rb.conv2[0].bias, pad=ksz // 2, gn=rb.conv2[1], res=src if ident else None, save=s2,
-               extra=[dict(srcs=[src], w_eff=_conv1d_eff(rb.residual_conv), pad=0, bias=rb.residual_conv.bias, post=True)] if fuse else None)
-        if not ident and not fuse:
-            b.conv([src], out, _conv1d_eff(rb.residual_conv), rb.residual_conv.bias, res=out)
+        fused = (not ident) and FUSE_SKIP and b.conv(
+            [t1], out, _conv1d_eff(rb.conv2[0]), rb.conv2[0].bias, pad=ksz // 2, gn=rb.conv2[1], save=s2,
+            extra=[dict(srcs=[src], w_eff=_conv1d_eff(rb.residual_conv), pad=0, bias=rb.residual_conv.bias, post=True)])
+        if not fused:
+            b.conv([t1], out, _conv1d_eff(rb.conv2[0]), rb.conv2[0].bias, pad=ksz // 2, gn=rb.conv2[1], res=src if ident else None, save=s2)
+            if not ident:
+                b.conv([src], out, _conv1d_eff(rb.residual_conv), rb.residual_conv.bias, res=out)
         tape.append(("block", rb, ksz, src, s1, s2, ident))
         return out
 
@@ -673,14 +680,17 @@ def _lower_half_janner_grad(b: "_Builder2", clf, horizon: int, x: Act, grad: Act
         wrt = None if ident else rb.residual_conv.weight.detach().permute(1, 2, 0)          # W_r^T as [C_in][1][C_out]
         if ident:
             g_plain, g_u2 = finish(idx, lambda dst, bw: b.conv([gu1], dst, _dgrad_eff(rb.conv1[0]), None, pad=ksz // 2, res=gout, bwd=bw))
-        elif FUSE_SKIP:
-            # gradient w.r.t. the block input = conv1^T g_u1 + W_r^T g_out: two convs whose partial tiles are simply summed
-            g_plain, g_u2 = finish(idx, lambda dst, bw: b.conv([gu1], dst, _dgrad_eff(rb.conv1[0]), None, pad=ksz // 2, bwd=bw,
-                                                               extra=[dict(srcs=[gout], w_eff=wrt, pad=0, bias=None, post=False)]))
         else:
-            skip = b.act(src.length, src.chans)
-            b.conv([gout], skip, wrt, None)                                                 # W_r^T g_out
-            g_plain, g_u2 = finish(idx, lambda dst, bw: b.conv([gu1], dst, _dgrad_eff(rb.conv1[0]), None, pad=ksz // 2, res=skip, bwd=bw))
+            # gradient w.r.t. the block input = conv1^T g_u1 + W_r^T g_out: two convs whose partial tiles are simply summed -- in one
+            # op when that pays, else the skip part first into a slot the main op adds
+            def make(dst, bw):
+                if FUSE_SKIP and b.conv([gu1], dst, _dgrad_eff(rb.conv1[0]), None, pad=ksz // 2, bwd=bw,
+                                        extra=[dict(srcs=[gout], w_eff=wrt, pad=0, bias=None, post=False)]):
+                    return
+                skip = b.act(src.length, src.chans)
+                b.conv([gout], skip, wrt, None)                                             # W_r^T g_out
+                b.conv([gu1], dst, _dgrad_eff(rb.conv1[0]), None, pad=ksz // 2, res=skip, bwd=bw)
+            g_plain, g_u2 = finish(idx, make)
     return blocks, (lin1, head_off)
 
 

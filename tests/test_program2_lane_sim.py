@@ -71,14 +71,16 @@ def test_program2_accounting_and_budget(nw, amd_lib):
     one workgroup's 160 KiB."""
     _, net = cases.build(amd_lib, "janner_cfg2_ddim")
     prog = P2.compile_janner2(net, 32, nw=nw)
-    assert len(prog.ops) == 40          # 16 blocks x 2 convs (the 7 skip convs ride in their block's second conv op) + 3 down + 3 up + 2 head
+    # 16 blocks x 2 convs + 3 down + 3 up + 2 head = 40; six of the seven 1x1 skip convs ride in their block's second conv op, the
+    # seventh (128 -> 256 channels at L = 4, next to a 320-record, stream-bound main conv) keeps an op of its own at 8 waves
+    assert len(prog.ops) == (41 if nw == 8 else 43)          # (4 waves: three long main convs keep their skip conv separate)
     assert abs(prog.macs_per_forward - 19.67e6) / 19.67e6 < 0.01
     assert prog.lds_bytes(2) <= 160 * 1024
     ops = prog.ops
     assert (ops[:, P2.W2_NITEMS] <= 8).all() and (ops[:, P2.W2_NITEMS] >= 4).all()
     if nw == 8:
         assert (ops[:, P2.W2_NITEMS] <= nw).all(), "at most one work item per wave in this net"
-    assert (ops[:, P2.W2_KPOST] > 0).sum() == 7, "seven blocks change the channel count: their 1x1 skip convs are fused"
+    assert (ops[:, P2.W2_KPOST] > 0).sum() == (6 if nw == 8 else 4), "blocks that change the channel count: fused 1x1 skip convs"
     ring = P2.ring_depth(nw)
     for op in ops:
         items = np.stack([P2.op_item(prog.ops_buffer, op, j) for j in range(op[P2.W2_NITEMS])])
