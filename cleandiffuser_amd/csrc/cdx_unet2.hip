@@ -140,6 +140,28 @@ __device__ __forceinline__ void stamp(unsigned long long* slot, int tid) {
     if (slot && tid == 0) *slot = __builtin_amdgcn_s_memtime();
 }
 
+// ---- weight records: loaded through a raw buffer descriptor (uniform byte offset in an SGPR, lane * 16 in one VGPR -- no 64-bit
+// vector address arithmetic per load: +2.4 % at two trajectories per workgroup) with a compile-time cache policy (CDX2_WPOLICY:
+// 0 default, 1 sc0, 2 nt, 16 sc1).  Measured on MI355X: sc0 / sc1 change nothing; nt is 30-40 % SLOWER -- every CU of an XCD streams
+// the same records, and non-temporal lines do not stay in the L2 for the other 31.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#ifndef CDX2_WPOLICY
+#define CDX2_WPOLICY 0
+#endif
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+struct WStream {
+    __amdgpu_buffer_rsrc_t rs;
+    int lane16;
+    __device__ __forceinline__ WStream(const float* wblob, int lane)
+        : rs(__builtin_amdgcn_make_buffer_rsrc((void*)wblob, 0, 0x7fffffff, 0x00020000)), lane16(lane * 16) {}
+    // record `q` of the stream that starts at float offset `woff`
+    __device__ __forceinline__ f32x4 load(int woff, int q) const {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, woff * 4 + q * 1024, CDX2_WPOLICY));
+    }
+};
+#pragma clang diagnostic pop
+
 // ---- weight ring -------------------------------------------------------------------------------------------------------
 // PF 1-KiB records in flight per wave (a single wave per SIMD has to cover the whole L2 latency by itself: 16; two share it: 8).
 template <int PF> struct Ring { f32x4 rec[PF]; };       // head of this wave's next weight stream, issued one op ahead
@@ -190,14 +212,16 @@ __device__ __forceinline__ void conv_kloop(const Geom& g, const float* __restric
 #pragma unroll
                 for (int j = 0; j < NA; ++j) acc[t][nt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-        const f32x4* wp = reinterpret_cast<const f32x4*>(wblob + it.woff) + lane;
+        const WStream ws(wblob, lane);
+        const int woff = it.woff;
+#define CDX2_WLOAD(q) ws.load(woff, (q))
         f32x4 wr[PF];
         if (item == wave) {                                    // head of the stream was issued during the previous op
 #pragma unroll
             for (int u = 0; u < PF; ++u) wr[u] = ring.rec[u];
         } else {
 #pragma unroll
-            for (int u = 0; u < PF; ++u) wr[u] = wp[(size_t)u * 64];   // unconditional (the blob is padded by PF records)
+            for (int u = 0; u < PF; ++u) wr[u] = CDX2_WLOAD(u);   // unconditional (the blob is padded by PF records)
         }
         // B-operand ring: with ONE wave per SIMD nothing else hides the ~100+ cycle ds_read latency, so the operand of chunk
         // q + BD - 1 is requested before chunk q's MFMAs issue (a chunk is only 32 cycles of matrix pipe in the 4x4 mode).
@@ -263,7 +287,7 @@ __device__ __forceinline__ void conv_kloop(const Geom& g, const float* __restric
         // over the MFMAs of its own basic block, and a refill overlapping the last reads of the value it replaces makes the
         // register allocator double-buffer the whole ring (16 v_mov_b64 + a vmcnt(0) drain per revolution, seen in the ISA).
         // Lagged by a chunk, the old value is dead a full basic block earlier and every slot keeps its registers.
-        auto refill = [&](const int slot, int q) { wr[slot] = wp[(size_t)q * 64]; };
+        auto refill = [&](const int slot, int q) { wr[slot] = CDX2_WLOAD(q); };
         // steady state (4x4 layers whose taps span a multiple of PF chunks -- C_in >= 64 -- with the K slice starting on such a
         // boundary, which the host guarantees): a revolution of PF chunks then lies inside ONE tap, so every operand address of
         // the revolution is `base + constant` -- the ds_read carries the chunk as an immediate offset and nothing but
@@ -586,9 +610,9 @@ __device__ __forceinline__ void run_head(const cdx_unet2_launch& L, int vd, cons
 // record count: the blob ends with PF records of padding, slots past `nq` are simply never consumed.
 template <int PF>
 __device__ __forceinline__ void prefetch_ring(const Item& it, const float* __restrict__ wblob, int lane, Ring<PF>& ring) {
-    const f32x4* wp = reinterpret_cast<const f32x4*>(wblob + it.woff) + lane;
+    const WStream ws(wblob, lane);
 #pragma unroll
-    for (int u = 0; u < PF; ++u) ring.rec[u] = wp[(size_t)u * 64];
+    for (int u = 0; u < PF; ++u) ring.rec[u] = ws.load(it.woff, u);
 }
 
 // One op.  `vd`: this wave's view of the op's descriptor, `it`: this wave's first item, both fetched during the previous op;
