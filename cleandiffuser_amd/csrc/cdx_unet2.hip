@@ -45,6 +45,7 @@ void cdx_set_err(const char* msg);          // cdx_unet1d.hip
 template <int NWV> struct WG {
     static constexpr int THREADS = NWV * 64;
     static constexpr int PF = NWV == 8 ? 8 : 16;                                  // weight ring depth (1-KiB records per wave)
+                                                                                  // (16 at 8 waves: 10 % slower, measured again in round 2)
     static constexpr int OPW = CDX2_HDR_WORDS + NWV * CDX2_ITEM_WORDS;             // words per op descriptor
 };
 
@@ -328,7 +329,9 @@ __device__ __forceinline__ void conv_kloop(const Geom& g, const float* __restric
                     else if (qi > 0) refill(PF - 1, qi - 1 + PF);
                     // one refill per chunk, in place: left to itself the scheduler batches the 16 loads of a revolution into
                     // 2-3 bursts and the ring spends half of the time 6-9 deep instead of 16 (seen in the ISA and the stream rate)
-                    __builtin_amdgcn_sched_barrier(0);
+                    // (with ONE trajectory per workgroup the scheduler's own placement is 1.2 % faster; with two, the fence is 1.3 %
+                    //  faster -- A/B on MI355X, tools/gpu_variants.sh)
+                    if (NWV == 4 || T == 2) __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) rb[nt] = rbn[nt];
