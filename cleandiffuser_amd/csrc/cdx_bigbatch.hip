@@ -1054,21 +1054,50 @@ int cdx_hjgrad_run(const cdx_hjgrad_weights* w, const float* x, const float* emb
     return p.run(x, emb0, emb0_ld, logp, grad);
 }
 
+namespace {
+// forward-mode request of the implicit-GEMM U-Net executor for one guided step (row `step` of the denoiser's timestep table)
+cdx_sampling guided_gemm_request(const cdx_guided_launch* g, int step, const float* x, float* pred, float* ws, long long ws_floats) {
+    cdx_sampling S{};
+    S.batch = g->batch; S.hd = g->hd; S.emb_dim = g->denoiser_emb_dim; S.cond_dim = 0;
+    S.temb = g->temb ? g->temb + (size_t)step * g->denoiser_emb_dim : nullptr;
+    S.n_steps = 0; S.temb_per_sample = 0; S.cfg_mode = 0;
+    S.x_in = x; S.x_out = pred; S.workspace = ws; S.workspace_floats = ws_floats; S.chunk = g->denoiser_chunk;
+    return S;
+}
+}  // namespace
+
 long long cdx_guided_workspace_floats(const cdx_guided_launch* g) {
     if (!g || !g->classifier || g->batch < 0 || g->hd <= 0) return -1;
     const long long clf = cdx_hjgrad_workspace_floats(g->classifier, g->batch);
     if (clf < 0) return -1;
     const long long state = ((long long)g->batch * g->hd + 63) & ~63LL;
-    return clf + 4 * state + (((long long)g->batch * g->classifier->out_dim + 63) & ~63LL);     // x, pred, prev, grad, logp
+    long long den = 0;
+    if (g->denoiser_gemm) {
+        const cdx_sampling S = guided_gemm_request(g, 0, nullptr, nullptr, nullptr, 0);
+        int rc;
+        den = chiunet_pass(g->denoiser_gemm, &S, nullptr, nullptr, true, &rc);
+        if (den < 0) return -1;
+        den = (den + 63) & ~63LL;
+    }
+    return clf + den + 4 * state + (((long long)g->batch * g->classifier->out_dim + 63) & ~63LL);     // x, pred, prev, grad, logp
 }
 
 int cdx_guided_run(const cdx_guided_launch* g, void* hip_stream) {
-    if (!g || !g->denoiser || !g->classifier || !g->steps || !g->cg_scale || !g->temb || !g->clf_emb0 || !g->x_in || !g->x_out) {
+    if (!g || (!g->denoiser && !g->denoiser_gemm) || !g->classifier || !g->steps || !g->cg_scale || !g->temb || !g->clf_emb0 || !g->x_in || !g->x_out) {
         cdx_set_err("cdx_guided_run: null pointer"); return CDX_EINVAL;
     }
-    if (g->n_steps <= 0 || g->batch < 0 || g->hd != g->denoiser->horizon * g->denoiser->dim || g->denoiser->n_steps != 0 ||
-        g->denoiser->cfg_mode == 2 || g->denoiser->tile != 0 || g->classifier->horizon * g->classifier->in_dim != g->hd) {
+    if (g->denoiser && g->denoiser_gemm) { cdx_set_err("cdx_guided_run: give the denoiser as a program launch OR as GEMM-executor weights"); return CDX_EINVAL; }
+    if (g->n_steps <= 0 || g->batch < 0 || g->classifier->horizon * g->classifier->in_dim != g->hd) {
+        cdx_set_err("cdx_guided_run: bad shape"); return CDX_EINVAL;
+    }
+    if (g->denoiser && (g->hd != g->denoiser->horizon * g->denoiser->dim || g->denoiser->n_steps != 0 || g->denoiser->cfg_mode == 2 ||
+                        g->denoiser->tile != 0)) {
         cdx_set_err("cdx_guided_run: the denoiser must be a forward-mode U-Net launch matching the classifier's (horizon, dim)"); return CDX_EINVAL;
+    }
+    if (g->denoiser_gemm) {
+        if (g->denoiser_emb_dim <= 0 || g->denoiser_chunk < 0) { cdx_set_err("cdx_guided_run: GEMM denoiser needs emb_dim > 0, chunk >= 0"); return CDX_EINVAL; }
+        const cdx_sampling S = guided_gemm_request(g, 0, g->x_in, g->x_out, nullptr, 0);
+        CDX_TRY(chiunet_check(g->denoiser_gemm, &S));
     }
     if (g->fix_mask && !g->prior) { cdx_set_err("cdx_guided_run: fix_mask given without prior"); return CDX_EINVAL; }
     for (int i = 0; i < g->n_steps; ++i)
@@ -1083,6 +1112,14 @@ int cdx_guided_run(const cdx_guided_launch* g, void* hip_stream) {
     const long long n = (long long)g->batch * g->hd;
     float *x = a.take(n), *pred = a.take(n), *prev = a.take(n), *grad = a.take(n);
     float* logp = a.take((long long)g->batch * g->classifier->out_dim);
+    float* den_ws = nullptr;
+    long long den_floats = 0;
+    if (g->denoiser_gemm) {
+        const cdx_sampling S = guided_gemm_request(g, 0, nullptr, nullptr, nullptr, 0);
+        int rc0;
+        den_floats = chiunet_pass(g->denoiser_gemm, &S, nullptr, nullptr, true, &rc0);
+        den_ws = a.take(den_floats);
+    }
     float* clf_ws = g->workspace + a.used;
     const long long clf_floats = g->workspace_floats - a.used;
     if (hipMemcpyAsync(x, g->x_in, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return hip_ok();
@@ -1090,7 +1127,7 @@ int cdx_guided_run(const cdx_guided_launch* g, void* hip_stream) {
     // (one workgroup per CU, ~121 KB of LDS) runs on a side stream while the classifier's ~80 small GEMM launches go down the
     // caller's stream -- a GEMM workgroup (34 KB LDS, 4 waves) fits next to the U-Net workgroup on every CU.  Fork/join with two
     // events per step; all side-stream work is joined before the call returns.  CDX_GUIDED_OVERLAP=0 serialises (A/B hook).
-    SideStream* side = side_stream();
+    SideStream* side = g->denoiser_gemm ? nullptr : side_stream();      // (the GEMM denoiser's launches stay on the caller's stream)
     // Two guided calls on one device (other threads, other caller streams) would race on the shared fork/join events: the second
     // one waits here.  Every exit after a fork drains the side stream first, so that the caller may free cond / temb / workspace
     // as soon as it has synchronised with ITS stream, error or not.
@@ -1102,10 +1139,20 @@ int cdx_guided_run(const cdx_guided_launch* g, void* hip_stream) {
     };
 #define CDX_TRY_SIDE(expr) do { const int rc_ = (expr); if (rc_ != CDX_OK) return bail(rc_); } while (0)
     for (int i = 0; i < g->n_steps; ++i) {
-        cdx_unet1d_launch L = *g->denoiser;
-        L.n_steps = 0; L.steps = nullptr; L.temb_per_sample = 0; L.batch = g->batch;
-        L.temb = g->temb + (size_t)i * L.emb_dim; L.x_in = x; L.x_out = pred;
-        if (side) {
+        if (g->denoiser_gemm) {
+            const cdx_sampling S = guided_gemm_request(g, i, x, pred, den_ws, den_floats);
+            int rcg;
+            chiunet_pass(g->denoiser_gemm, &S, st, den_ws, false, &rcg);
+            CDX_TRY(rcg);
+        }
+        cdx_unet1d_launch L;
+        if (g->denoiser) {
+            L = *g->denoiser;
+            L.n_steps = 0; L.steps = nullptr; L.temb_per_sample = 0; L.batch = g->batch;
+            L.temb = g->temb + (size_t)i * L.emb_dim; L.x_in = x; L.x_out = pred;
+        }
+        if (g->denoiser_gemm) {
+        } else if (side) {
             if (hipEventRecord(side->fork, st) != hipSuccess || hipStreamWaitEvent(side->stream, side->fork, 0) != hipSuccess) return bail(hip_ok());
             CDX_TRY_SIDE(cdx_unet1d_run(&L, side->stream));
             if (hipEventRecord(side->join, side->stream) != hipSuccess) return bail(hip_ok());

@@ -24,7 +24,7 @@ class CdxGuidedLaunch(ctypes.Structure):
                 ("steps", ctypes.POINTER(CdxStep)), ("cg_scale", ctypes.POINTER(ctypes.c_float)), ("n_steps", _I), ("batch", _I),
                 ("hd", _I), ("predict_noise", _I), ("temb", _FP), ("clf_emb0", _FP), ("x_in", _FP), ("prior", _FP),
                 ("fix_mask", _FP), ("noise", _FP), ("x_min", _FP), ("x_max", _FP), ("x_out", _FP), ("workspace", _FP),
-                ("workspace_floats", ctypes.c_longlong)]
+                ("workspace_floats", ctypes.c_longlong), ("denoiser_gemm", _FP), ("denoiser_emb_dim", _I), ("denoiser_chunk", _I)]
 
 
 _declared = False
@@ -54,8 +54,18 @@ def guided_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, feed) -
     if xt.dim() != 3 or type(clf) is not CumRewClassifier or type(clf.model_ema) is not HalfJannerUNet1d:
         return None
     b, h, d = xt.shape
-    if not (runtime._is_janner(net) or runtime._is_chiunet(net)) or runtime.supported_backbone(net, h) is not None:
+    if not (runtime._is_janner(net) or runtime._is_chiunet(net)):
         return None
+    gemm_bound = None
+    if runtime.supported_backbone(net, h) is not None:
+        # LDS plan larger than one workgroup (the shipped antmaze Diffuser): the per-step denoiser forward runs on the implicit-GEMM
+        # U-Net executor inside the same cdx_guided_run call -- unconditional JannerUNet1d only
+        from . import bigbatch
+        if not runtime._is_janner(net) or (cond_vec is not None and w_cfg != 0.0):
+            return None
+        gemm_bound = bigbatch._bound(net, ("chiunet", h), lambda: bigbatch._bind_janner_gemm(net, h, xt.device))
+        if gemm_bound is None or d != gemm_bound.struct.act_dim:
+            return None
     if any(st.kind > 2 for st in plan.steps) or (cond_vec is not None and w_cfg not in (0.0, 1.0)):
         return None
     if clf.model_ema.horizon != h or clf.model_ema.in_dim != d:
@@ -79,7 +89,7 @@ def guided_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, feed) -
         if out is not None:
             return out
     with torch.no_grad():
-        comp = runtime.compiled_program(net, h)
+        comp = None if gemm_bound is not None else runtime.compiled_program(net, h)
         if cond_vec is None or w_cfg == 0.0:
             mode, cond = 0, None
         else:
@@ -99,8 +109,16 @@ def guided_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, feed) -
         xin = _f32c(xt, dev)
         out = torch.empty_like(xin)
         prior_d = _f32c(prior, dev) if fix_mask is not None else None
-        den = runtime.describe_launch(comp, batch=b, cfg_mode=mode, cfg_w=w_cfg, cond=cond)
-        g = CdxGuidedLaunch(denoiser=ctypes.pointer(den), classifier=ctypes.pointer(bound._struct), steps=steps, cg_scale=cg,
+        if gemm_bound is not None:
+            from . import bigbatch
+            den_ptr = ctypes.POINTER(CdxUnet1dLaunch)()              # NULL: the denoiser is the GEMM executor
+            gemm_kw = dict(denoiser_gemm=ctypes.cast(ctypes.pointer(gemm_bound.struct), ctypes.c_void_p),
+                           denoiser_emb_dim=gemm_bound.struct.emb_dim,
+                           denoiser_chunk=bigbatch.CHUNK_OVERRIDE["chiunet"] or bigbatch._chiunet_chunk(b, h, getattr(net, "model_dim", 32), 1))
+        else:
+            den = runtime.describe_launch(comp, batch=b, cfg_mode=mode, cfg_w=w_cfg, cond=cond)
+            den_ptr, gemm_kw = ctypes.pointer(den), {}
+        g = CdxGuidedLaunch(denoiser=den_ptr, classifier=ctypes.pointer(bound._struct), steps=steps, cg_scale=cg, **gemm_kw,
                             n_steps=len(plan.steps), batch=b, hd=h * d, predict_noise=int(pn), temb=temb.data_ptr(),
                             clf_emb0=clf_emb0.data_ptr(), x_in=xin.data_ptr(), prior=runtime._ptr(prior_d),
                             fix_mask=runtime._ptr(fix_mask), noise=runtime._ptr(noise), x_min=runtime._ptr(x_min),

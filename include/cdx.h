@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define CDX_ABI_VERSION 4
+#define CDX_ABI_VERSION 5
 
 #define CDX_OK 0
 #define CDX_EINVAL (-1)   /* bad argument (null pointer, size out of range, misaligned offset) */
@@ -432,7 +432,8 @@ int cdx_hjgrad_run(const cdx_hjgrad_weights* w, const float* x, const float* emb
  * launch is joined before the call returns, i.e. the caller only ever has to order against `hip_stream`.  Environment
  * CDX_GUIDED_OVERLAP=0 keeps everything on `hip_stream`. */
 typedef struct cdx_guided_launch {
-    const cdx_unet1d_launch* denoiser;   /* a forward-mode launch description (n_steps = 0); temb/x_in/x_out are set per step */
+    const cdx_unet1d_launch* denoiser;   /* a forward-mode launch description (n_steps = 0); temb/x_in/x_out are set per step;
+                                          * NULL when the denoiser runs on the implicit-GEMM executor (denoiser_gemm) */
     const cdx_hjgrad_weights* classifier;
     const cdx_step* steps;               /* HOST [n_steps], kinds 0-2 */
     const float* cg_scale;               /* HOST [n_steps]: factor of the gradient added to the prediction at step i */
@@ -443,6 +444,10 @@ typedef struct cdx_guided_launch {
     float* x_out;
     float* workspace;                    /* >= cdx_guided_workspace_floats() */
     long long workspace_floats;
+    /* nets whose LDS plan exceeds one workgroup (the shipped antmaze Diffuser: model_dim 64, H = 64): the per-step denoiser forward
+     * is the implicit-GEMM U-Net executor (what cdx_chiunet_run runs in forward mode) -- the guided loop is still ONE call */
+    const cdx_chiunet_weights* denoiser_gemm;   /* or NULL */
+    int32_t denoiser_emb_dim, denoiser_chunk;   /* width of one temb row; trajectories per pass (0 = whole batch) */
 } cdx_guided_launch;
 long long cdx_guided_workspace_floats(const cdx_guided_launch* g);
 int cdx_guided_run(const cdx_guided_launch* g, void* hip_stream);
