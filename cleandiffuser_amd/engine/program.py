@@ -673,6 +673,47 @@ def compile_dql_mlp(net, tile: int = MLP_TILE, max_lds_bytes: int = 160 * 1024, 
                      cond_slot=(ctx, e, obs), tile=tile, edm=edm)
 
 
+def compile_sfbc_unet(net, tile: int = MLP_TILE, max_lds_bytes: int = 160 * 1024, edm: bool = True) -> Program:
+    """SfBCUNet (reference nn_diffusion/sfbc_unet.py:9-82): residual blocks of Linears, block(x, c) = SiLU(L2(SiLU(L1 x) + Lc c)) +
+    skip(x), a down path, a middle block, an up path over the concat with the matching down activation, one output Linear.
+    The context c = t_layer(map_noise(t)) + condition is never formed: the context slot holds [t_layer(...) | condition] side by
+    side and Lc is applied to both halves ([Lc | Lc]); the t_layer table (batch-invariant) is the launch's `temb`."""
+    b = _Builder(next(net.parameters()).device)
+    d, e = net.out_layer.out_features, net.t_layer[0].in_features
+    x = b.act(tile, d, persistent=True)
+    ctx = b.act(tile, 2 * e, persistent=True)
+    v0 = b.vec(e)
+    b.load_temb(e, v0)
+    b.fill(v0, e, ctx, 0)
+
+    def block(srcs, blk):
+        c_out = blk.linear1[0].out_features
+        h = b.act(tile, c_out)
+        b.conv(srcs, h, _lin_eff(blk.linear1[0]), blk.linear1[0].bias, act=ACT_SILU)
+        wc = blk.linearc.weight.detach()
+        b.conv([ctx], h, torch.cat([wc, wc], 1).unsqueeze(1), blk.linearc.bias, accum=True, act=ACT_NONE)      # h += Lc (t + cond)
+        o = b.act(tile, c_out)
+        ident = isinstance(blk.skip, nn.Identity)
+        b.conv([h], o, _lin_eff(blk.linear2[0]), blk.linear2[0].bias, act=ACT_SILU, res=srcs[0] if ident and len(srcs) == 1 else None)
+        if not ident:
+            b.conv(srcs, o, _lin_eff(blk.skip), blk.skip.bias, accum=True, act=ACT_NONE)
+        elif len(srcs) > 1:               # identity skip over a concat (up block whose widths happen to match): o += cat(srcs)
+            eye = torch.eye(c_out, device=b.device).unsqueeze(1)
+            b.conv(srcs, o, eye, torch.zeros(c_out, device=b.device), accum=True, act=ACT_NONE)
+        return o
+
+    cur, kept = x, []
+    for blk in net.down_blocks:
+        cur = block([cur], blk)
+        kept.append(cur)
+    cur = block([cur], net.mid_block)
+    for blk in net.up_blocks:
+        cur = block([cur, kept.pop()], blk)
+    pred = b.act(tile, d, persistent=True)
+    b.conv([cur], pred, _lin_eff(net.out_layer), net.out_layer.bias, dst_pred=True, act=ACT_NONE)
+    return _finalize(b, net, x, pred, tile, d, max_lds_bytes, persist=[ctx], emb_dim=e, cond_slot=(ctx, e, e), tile=tile, edm=edm)
+
+
 # ================================================================================================== #
 # ChiUNet1d lowering (Diffusion Policy)                                                               #
 # ================================================================================================== #

@@ -120,6 +120,8 @@ def compiled_program(module, horizon: int, edm: bool = False) -> _Compiled:
             prog = P.compile_pearce_mlp(module, horizon, edm=edm)
         elif kind == "dql":
             prog = P.compile_dql_mlp(module, horizon, edm=edm)
+        elif kind == "sfbc":
+            prog = P.compile_sfbc_unet(module, horizon, edm=edm)
         elif _is_chiunet(module):
             prog = P.compile_chiunet(module, horizon, edm=edm)
         elif _is_half_janner(module):
@@ -147,6 +149,10 @@ def _mlp_kind(module) -> Optional[str]:
     if type(module) is DQLMlp or (type(module) is DVInvMlp and module.mid_layer[0].out_features % 64 == 0
                                   and module.mid_layer[0].out_features <= 1024):
         return "dql"
+    from ..nn_diffusion.sfbc_unet import SfBCUNet
+    if type(module) is SfBCUNet and all(blk.linear1[0].out_features % 16 == 0 and blk.linear1[0].out_features <= 1024
+                                        for blk in list(module.down_blocks) + [module.mid_block] + list(module.up_blocks)):
+        return "sfbc"
     return None
 
 
@@ -411,6 +417,8 @@ def fused_sample_mlp(solver, net, kind, plan, xt, prior, cond_vec, w_cfg, feed) 
             return None
         t_vec = device_times(plan, dev)
         temb = _f32c(net.map_noise(t_vec), dev)
+        if kind == "sfbc":                            # SfBCUNet: the batch-invariant t_layer runs here, once per step record
+            temb = _f32c(net.t_layer(temb), dev)
         if kind == "pearce":                          # PearceMlp also consumes the raw timestep as a feature (Q11)
             temb = torch.cat([temb, t_vec.to(torch.float32).unsqueeze(1)], 1).contiguous()
         steps_dev = steps_to_device(plan, dev)

@@ -94,7 +94,7 @@ def test_backbone_forward_matches_reference(name, amd_lib, monkeypatch):
     np.testing.assert_allclose(pred.cpu().numpy(), gold["pred0"], **TOL)
 
 
-FUSED_CASES = [n for n, c in cases.CASES.items() if c["net"][0] in ("JannerUNet1d", "PearceMlp", "DQLMlp", "DVInvMlp", "ChiUNet1d")
+FUSED_CASES = [n for n, c in cases.CASES.items() if c["net"][0] in ("JannerUNet1d", "PearceMlp", "DQLMlp", "DVInvMlp", "ChiUNet1d", "SfBCUNet")
                and not c["sample"].get("w_cg")]
 BIGBATCH_CASES = [n for n, c in cases.CASES.items() if c["net"][0] in cases.BIGBATCH_NETS]
 TORCH_EXECUTOR_CASES = [n for n in cases.CASES if n not in FUSED_CASES and n not in BIGBATCH_CASES

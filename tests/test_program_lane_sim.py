@@ -76,7 +76,7 @@ def test_lane_sim_reproduces_classifier_logp(amd_lib):
         np.testing.assert_allclose(sim.run_forward(temb), gold["log_p"][b], rtol=2e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize("kind", ["pearce", "pearce192", "dql"])
+@pytest.mark.parametrize("kind", ["pearce", "pearce192", "dql", "sfbc"])
 def test_lane_sim_reproduces_mlp_tile_programs(kind, amd_lib):
     """Batch-tiled MLP programs (sample index on the MFMA column axis, per-sample GroupNorm, GELU/Mish/LeakyReLU,
     pre-scaled skips, context slot) against the module forward, which is bit-identical to the reference's."""
@@ -90,6 +90,12 @@ def test_lane_sim_reproduces_mlp_tile_programs(kind, amd_lib):
         prog = P.compile_pearce_mlp(net, S)
         cond = torch.randn(S, 1, 64, generator=g)
         temb = np.concatenate([net.map_noise(t[:1])[0].numpy(), [13.0]]).astype(np.float32)
+    elif kind == "sfbc":                              # Linear / SiLU residual blocks, concat skips, context = t_layer(temb) + condition
+        net = load_synth(amd_lib.SfBCUNet(6, emb_dim=32, hidden_dims=[128, 64, 32])).eval()
+        prog = P.compile_sfbc_unet(net, S)
+        cond = torch.randn(S, 32, generator=g)
+        with torch.no_grad():
+            temb = net.t_layer(net.map_noise(t[:1]))[0].numpy()
     else:
         net = load_synth(amd_lib.DQLMlp(17, 6)).eval()
         prog = P.compile_dql_mlp(net, S)
