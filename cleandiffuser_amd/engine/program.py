@@ -673,6 +673,54 @@ def compile_dql_mlp(net, tile: int = MLP_TILE, max_lds_bytes: int = 160 * 1024, 
                      cond_slot=(ctx, e, obs), tile=tile, edm=edm)
 
 
+def _act_id(m) -> Optional[int]:
+    """nn activation module -> ACT_* id of the program kernel, None when it has no native epilogue."""
+    if isinstance(m, nn.ReLU):
+        return ACT_RELU
+    if isinstance(m, nn.Mish):
+        return ACT_MISH
+    if isinstance(m, nn.SiLU):
+        return ACT_SILU
+    if isinstance(m, nn.Tanh):
+        return ACT_TANH
+    if isinstance(m, nn.GELU):
+        return ACT_GELU_TANH if getattr(m, "approximate", "none") == "tanh" else ACT_GELU_ERF
+    if isinstance(m, nn.LeakyReLU) and abs(m.negative_slope - 0.01) < 1e-12:
+        return ACT_LEAKY
+    if isinstance(m, nn.Identity):
+        return ACT_NONE
+    return None
+
+
+def compile_mlp_nn(net, tile: int = MLP_TILE, max_lds_bytes: int = 160 * 1024, edm: bool = True) -> Program:
+    """MlpNNDiffusion (reference nn_diffusion/mlps.py:10-40): Mlp(cat[x, map_noise(t) + condition]) -- hidden Linears with one
+    activation, an output Linear.  The context slot holds [map_noise(t) | condition]; the first layer's time columns are applied
+    to both halves."""
+    b = _Builder(next(net.parameters()).device)
+    layers = list(net.mlp.mlp)
+    lins = [m[0] if isinstance(m, nn.Sequential) else m for m in layers if isinstance(m, (nn.Sequential, nn.Linear))]
+    acts = [_act_id(m[1]) for m in layers if isinstance(m, nn.Sequential)] + [_act_id(layers[-1])]
+    if any(a is None for a in acts) or len(lins) != len(acts):
+        raise ValueError("MlpNNDiffusion: activation without a native epilogue")
+    d = lins[-1].out_features
+    e = lins[0].in_features - d
+    x = b.act(tile, d, persistent=True)
+    ctx = b.act(tile, 2 * e, persistent=True)
+    v0 = b.vec(e)
+    b.load_temb(e, v0)
+    b.fill(v0, e, ctx, 0)
+    w0 = lins[0].weight.detach()
+    w_first = torch.cat([w0, w0[:, d:]], 1).unsqueeze(1)          # [W_x | W_t | W_t]: the condition is ADDED to the time embedding
+    cur, srcs = None, [x, ctx]
+    for i, (lin, act) in enumerate(zip(lins[:-1], acts[:-1])):
+        nxt = b.act(tile, lin.out_features)
+        b.conv(srcs, nxt, w_first if i == 0 else _lin_eff(lin), lin.bias, act=act)
+        cur, srcs = nxt, [nxt]
+    pred = b.act(tile, d, persistent=True)
+    b.conv(srcs, pred, w_first if len(lins) == 1 else _lin_eff(lins[-1]), lins[-1].bias, dst_pred=True, act=acts[-1])
+    return _finalize(b, net, x, pred, tile, d, max_lds_bytes, persist=[ctx], emb_dim=e, cond_slot=(ctx, e, e), tile=tile, edm=edm)
+
+
 def compile_sfbc_unet(net, tile: int = MLP_TILE, max_lds_bytes: int = 160 * 1024, edm: bool = True) -> Program:
     """SfBCUNet (reference nn_diffusion/sfbc_unet.py:9-82): residual blocks of Linears, block(x, c) = SiLU(L2(SiLU(L1 x) + Lc c)) +
     skip(x), a down path, a middle block, an up path over the concat with the matching down activation, one output Linear.

@@ -122,6 +122,8 @@ def compiled_program(module, horizon: int, edm: bool = False) -> _Compiled:
             prog = P.compile_dql_mlp(module, horizon, edm=edm)
         elif kind == "sfbc":
             prog = P.compile_sfbc_unet(module, horizon, edm=edm)
+        elif kind == "mlpnn":
+            prog = P.compile_mlp_nn(module, horizon, edm=edm)
         elif _is_chiunet(module):
             prog = P.compile_chiunet(module, horizon, edm=edm)
         elif _is_half_janner(module):
@@ -153,6 +155,12 @@ def _mlp_kind(module) -> Optional[str]:
     if type(module) is SfBCUNet and all(blk.linear1[0].out_features % 16 == 0 and blk.linear1[0].out_features <= 1024
                                         for blk in list(module.down_blocks) + [module.mid_block] + list(module.up_blocks)):
         return "sfbc"
+    from ..nn_diffusion.mlp_backbones import MlpNNDiffusion
+    if type(module) is MlpNNDiffusion:
+        lins = [m[0] for m in module.mlp.mlp if isinstance(m, torch.nn.Sequential)]
+        acts = [m[1] for m in module.mlp.mlp if isinstance(m, torch.nn.Sequential)] + [module.mlp.mlp[-1]]
+        if lins and all(l.out_features % 16 == 0 and l.out_features <= 1024 for l in lins) and all(P._act_id(a) is not None for a in acts):
+            return "mlpnn"
     return None
 
 

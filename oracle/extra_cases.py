@@ -85,6 +85,22 @@ def idql_wide():
     return run
 
 
+def mlpnn():
+    """MlpNNDiffusion (reference nn_diffusion/mlps.py): ReLU MLP over [x | map_noise(t) + condition], DDIM, CFG pair w = 1.4."""
+    def run(lib, kind, device):
+        net = load_synth(lib.MlpNNDiffusion(5, emb_dim=16, hidden_dims=[64, 128]), 12)
+        agent = lib.DiscreteDiffusionSDE(net, lib.IdentityCondition(dropout=0.0), predict_noise=True, x_max=2 * torch.ones(1, 5),
+                                         x_min=-2 * torch.ones(1, 5), diffusion_steps=20, device=device)
+        agent.eval()
+        g = torch.Generator().manual_seed(12)
+        cond = torch.randn(19, 16, generator=g)
+        zs = [torch.randn(19, 5, generator=g) for _ in range(6)]
+        x, _ = _sample(agent, kind, torch.zeros(19, 5, device=device), zs, solver="ddim", n_samples=19, sample_steps=5, w_cfg=1.4,
+                       condition_cfg=cond.to(device))
+        return {"x": x}
+    return run
+
+
 def janner_long(horizon: int, dim_mult, model_dim: int):
     D, B, steps = 6, 3, 3
 
@@ -181,6 +197,7 @@ SCENARIOS: Dict[str, Callable] = {
     "chitf_ta10": transformer("chitf_ta10"), "dit_h10_d384": transformer("dit_h10_d384"), "dit_h40_depth8": transformer("dit_h40_depth8"),
     "chiunet_cfg3_width": chiunet_cfg3_width(),
     "pearce_cfg_pair": mlp_cfg_pair("pearce"), "dql_cfg_pair": mlp_cfg_pair("dql"), "idql_h2048": idql_wide(),
+    "mlpnn_cfg_pair": mlpnn(),
 }
 
 

@@ -919,7 +919,7 @@ def test_chiunet_config3_width_matches_reference_fixture(executor, amd_lib, monk
     np.testing.assert_allclose(out["x"].cpu().numpy(), gold["x"], **TOL)
 
 
-@pytest.mark.parametrize("name", ["pearce_cfg_pair", "dql_cfg_pair"])
+@pytest.mark.parametrize("name", ["pearce_cfg_pair", "dql_cfg_pair", "mlpnn_cfg_pair"])
 def test_tile_mlp_cfg_pair_is_fused(name, amd_lib, monkeypatch):
     """w_cfg not in {0, 1} on the batch-tiled MLP programs (PearceMlp, DQLMlp) used to fall back to the PyTorch
     executor; now the conditional / zero-condition pair of every step runs inside the one cdx_unet1d_run launch (the context slot's

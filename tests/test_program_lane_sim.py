@@ -76,7 +76,7 @@ def test_lane_sim_reproduces_classifier_logp(amd_lib):
         np.testing.assert_allclose(sim.run_forward(temb), gold["log_p"][b], rtol=2e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize("kind", ["pearce", "pearce192", "dql", "sfbc"])
+@pytest.mark.parametrize("kind", ["pearce", "pearce192", "dql", "sfbc", "mlpnn"])
 def test_lane_sim_reproduces_mlp_tile_programs(kind, amd_lib):
     """Batch-tiled MLP programs (sample index on the MFMA column axis, per-sample GroupNorm, GELU/Mish/LeakyReLU,
     pre-scaled skips, context slot) against the module forward, which is bit-identical to the reference's."""
@@ -96,6 +96,12 @@ def test_lane_sim_reproduces_mlp_tile_programs(kind, amd_lib):
         cond = torch.randn(S, 32, generator=g)
         with torch.no_grad():
             temb = net.t_layer(net.map_noise(t[:1]))[0].numpy()
+    elif kind == "mlpnn":                             # plain MLP over [x | map_noise(t) + condition]
+        net = load_synth(amd_lib.MlpNNDiffusion(6, emb_dim=16, hidden_dims=[64, 128], activation=torch.nn.SiLU())).eval()
+        prog = P.compile_mlp_nn(net, S)
+        cond = torch.randn(S, 16, generator=g)
+        with torch.no_grad():
+            temb = net.map_noise(t[:1])[0].numpy()
     else:
         net = load_synth(amd_lib.DQLMlp(17, 6)).eval()
         prog = P.compile_dql_mlp(net, S)
