@@ -196,7 +196,7 @@ def other_configs(device):
         except Exception as e:  # noqa: BLE001 -- one broken side measurement must not take the headline down
             out.append({"name": tag, "error": f"{type(e).__name__}: {e}"})
 
-    big("config2_B3200", bc.cfg2big, "cdx_unet2_kernel<2, 8> (two trajectories, 8 wave64 per workgroup)", B=3200)
+    big("config2_B3200", bc.cfg2big, "cdx_unet2_kernel<3, 8> (three trajectories, 8 wave64 per workgroup; the last 128 one per workgroup)", B=3200)
     big("config2_guided_B256", bc.cfg2g, "cdx_unet2_kernel<1, 8, true>: denoiser forward + classifier forward/backward + shifted solver step, "
         "one launch per guided sample() call", B=256)
     big("config2_guided_B3200", bc.cfg2g, "cdx_unet2_kernel<2, 8, true>: two trajectories per workgroup, saved normalised tensors in a "
@@ -322,13 +322,14 @@ def main():
         kname, l2 = "cdx_unet1d_kernel", None
         if v2:
             from cleandiffuser_amd.engine import runtime2
-            comp, tpw = runtime2.shape_for(agent.model_ema["diffusion"], HORIZON, BATCH)
+            comp, parts = runtime2.plan_for(agent.model_ema["diffusion"], HORIZON, BATCH)
+            tpw = parts[0][2]
             kname = f"cdx_unet2_kernel<{tpw}, {comp.prog.nw}> ({tpw} trajectories, {comp.prog.nw} wave64 per workgroup)"
             # second roofline of the same launch: every workgroup streams the whole packed weight set from L2 once per denoiser
             # forward (activations never leave LDS).  With one trajectory per CU -- all B = 256 allows -- THIS is the binding
             # limit: MI355X_MICROARCH.md gives 34.5 TB/s aggregate L2 bandwidth
             wbytes = 4.0 * comp.prog.meta["blob_floats"]
-            n_wg = -(-BATCH // tpw)
+            n_wg = sum(-(-cnt // t) for _, cnt, t in parts)
             l2_bytes = wbytes * n_wg * SAMPLE_STEPS
             l2 = {"bound": "l2", "bytes_per_launch": l2_bytes, "achieved": l2_bytes / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0,
                   "peak": 34.5, "unit": "TB/s", "weight_bytes_per_forward": wbytes, "workgroups": n_wg}

@@ -183,7 +183,7 @@ __device__ __forceinline__ void conv_kloop(const Geom& g, const float* __restric
     // operand ring depth: one wave per SIMD has to cover the ds_read latency with its own MFMAs -- 8 chunks when a chunk is only 4
     // short MFMAs (32 cycles), else 4; with two waves per SIMD the other wave helps and registers are half as many
     constexpr int BD = NWV == 4 ? ((M::KSTEP == 4 && NT * T == 1) ? 8 : 4)
-                                : (NT * T == 1 ? (M::KSTEP == 4 ? 8 : 4) : (NT * T == 2 ? 4 : 2));
+                                : (NT * T == 1 ? (M::KSTEP == 4 ? 8 : 4) : (NT * T == 2 ? 4 : 2));      // (three trajectories: 2)
     // accumulators per tile: a record's four MFMAs on one tile must not form a dependent chain (a 4x4x1 MFMA is 2 passes; the
     // compiler pads dependent pairs with s_nop): 4 independent MFMAs between dependent ones is enough
     // (NA must not depend on T: the summation order of a trajectory is the same whether it shares a workgroup or not)
@@ -331,7 +331,7 @@ __device__ __forceinline__ void conv_kloop(const Geom& g, const float* __restric
                     // 2-3 bursts and the ring spends half of the time 6-9 deep instead of 16 (seen in the ISA and the stream rate)
                     // (with ONE trajectory per workgroup the scheduler's own placement is 1.2 % faster; with two, the fence is 1.3 %
                     //  faster -- A/B on MI355X, tools/gpu_variants.sh)
-                    if (NWV == 4 || T == 2) __builtin_amdgcn_sched_barrier(0);
+                    if (NWV == 4 || T >= 2) __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) rb[nt] = rbn[nt];
@@ -627,7 +627,7 @@ template <int T, int NWV, bool BWD>
 __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* ops, int vd, int vdn, Item& it,
                                        const float* __restrict__ emb_row, float* __restrict__ lds, int tid,
                                        Ring<WG<NWV>::PF>& ring, unsigned long long* prof, int b0) {
-    constexpr bool SPLIT_T = NWV == 8 && T == 2;
+    constexpr bool SPLIT_T = NWV == 8 && T >= 2;       // waves 0-3 take trajectories 0, 2; waves 4-7 trajectory 1
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tf = L.traj_floats;
     if (BWD && CDX2_DW(vd, CDX2_W2_KIND) == CDX2_KIND2_HEAD) {       // classifier head: no K loop, its own two barriers
@@ -680,9 +680,9 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
     stamp(prof ? prof + 2 : nullptr, tid);
 
     const EpiDesc e = decode_epi<BWD>(vd);
-    const int t_lo = SPLIT_T ? (wave >> 2) : 0, t_hi = SPLIT_T ? t_lo + 1 : T;
+    const int t_lo = SPLIT_T ? (wave >> 2) : 0, t_step = SPLIT_T ? 2 : 1;
 #pragma unroll 1
-    for (int t = t_lo; t < t_hi; ++t) {
+    for (int t = t_lo; t < T; t += t_step) {
         float* tl = lds + t * tf;
         // (a trajectory past the end of the range -- odd count, last workgroup -- computes on its zeroed region; its saved tensors
         //  go to the spare block [batch] of the workspace, never into a real trajectory's block)
@@ -757,6 +757,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
                 }
             }
             lds[t * tf + S->x_off + n * S->x_stride + c] = v;
+            if (S->compact) S->x_out[xbase + e] = v;
         }
     }
     }
@@ -794,7 +795,8 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
             for (int e = tid; e < HD; e += THREADS) {
                 const int n = e / D, c = e - n * D;
                 const int xo = S->x_off + n * S->x_stride + c;
-                const float x = tl[xo];
+                // compact programs: the authoritative state lives in x_out (global), the LDS slot only feeds op 0 of the next forward
+                const float x = S->compact ? S->x_out[xbase + e] : tl[xo];
                 float p = tl[S->pred_off + n * S->pred_stride + c];
                 // classifier guidance (reference diffusionsde.py:153-173): the prediction is shifted along d log p / d x_t BEFORE
                 // it is clipped; cg_scale[step] = -w sigma (noise prediction) or w sigma^2 / alpha (x0 prediction), frozen by the host
@@ -835,8 +837,8 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
                         xth = xth * (1.0f - m) + x * m;
                     }
                     float v = (st.vsel & 1) ? xth : eps;
-                    if (st.vsel == 2) v = k3 * xth - k4 * tl[S->prev_off + e];
-                    if (st.vsel == 3) v = k3 * eps - k4 * tl[S->prev_off + e];
+                    if (st.vsel == 2) v = k3 * xth - k4 * (S->compact ? S->ws[(size_t)b * S->ws_floats + e] : tl[S->prev_off + e]);
+                    if (st.vsel == 3) v = k3 * eps - k4 * (S->compact ? S->ws[(size_t)b * S->ws_floats + e] : tl[S->prev_off + e]);
                     xn = k0 * x - k1 * v;
                     if (st.noise_idx >= 0) xn += k2 * S->noise[((size_t)st.noise_idx * S->batch + b) * HD + e];
                 }
@@ -844,8 +846,12 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
                     const float m = S->fix_mask[e];
                     xn = xn * (1.0f - m) + S->prior[xbase + e] * m;
                 }
-                if (st.push) tl[S->prev_off + e] = st.push == 2 ? eps : xth;
+                if (st.push) {
+                    if (S->compact) S->ws[(size_t)b * S->ws_floats + e] = st.push == 2 ? eps : xth;
+                    else tl[S->prev_off + e] = st.push == 2 ? eps : xth;
+                }
                 tl[xo] = xn;
+                if (S->compact) S->x_out[xbase + e] = xn;
             }
         }
         __syncthreads();
@@ -861,6 +867,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
         const int off = S->n_steps == 0 ? (want_grad ? S->grad_off : S->pred_off) : S->x_off;
         const int str = S->n_steps == 0 ? (want_grad ? S->grad_stride : S->pred_stride) : S->x_stride;
         float* __restrict__ xo = S->x_out;
+        if (S->compact && S->n_steps > 0) break;            // the state is already there
         for (int e = tid; e < HD; e += THREADS) {
             const int n = e / D, c = e - n * D;
             xo[xbase + e] = lds[t * tf + off + n * str + c];
@@ -941,7 +948,9 @@ int cdx_unet2_run(const cdx_unet2_launch* L, void* hip_stream) {
     }
     if (L->traj_first < 0 || L->traj_count < 0 || L->traj_first + L->traj_count > L->batch) { cdx_set_err("trajectory range outside the batch"); return CDX_EINVAL; }
     if (L->n_ops <= 0 || L->batch < 0 || L->horizon <= 0 || L->dim <= 0 || L->traj_floats <= 0) { cdx_set_err("non-positive size"); return CDX_EINVAL; }
-    if (L->traj_per_wg != 1 && L->traj_per_wg != 2) { cdx_set_err("traj_per_wg must be 1 or 2"); return CDX_EINVAL; }
+    if (L->traj_per_wg < 1 || L->traj_per_wg > 3) { cdx_set_err("traj_per_wg must be 1, 2 or 3"); return CDX_EINVAL; }
+    if (L->traj_per_wg == 3 && (L->n_waves != 8 || !L->compact)) { cdx_set_err("three trajectories per workgroup: 8-wave compact programs only"); return CDX_EINVAL; }
+    if (L->compact && L->n_steps > 0 && (!L->ws || L->ws_floats < L->horizon * L->dim)) { cdx_set_err("compact program: ws (multistep memory) missing"); return CDX_EINVAL; }
     if (L->n_waves != 4 && L->n_waves != 8) { cdx_set_err("n_waves must be 4 or 8 (the program is compiled for one of them)"); return CDX_EINVAL; }
     if (L->n_steps > 0 && !L->steps) { cdx_set_err("steps == NULL with n_steps > 0"); return CDX_EINVAL; }
     if (L->n_steps < 0) { cdx_set_err("negative n_steps"); return CDX_EINVAL; }
@@ -958,7 +967,8 @@ int cdx_unet2_run(const cdx_unet2_launch* L, void* hip_stream) {
     if (L->ws_floats < 0 || (L->ws_floats & 3)) { cdx_set_err("ws_floats must be a non-negative multiple of 4"); return CDX_EINVAL; }
     if (L->cg_scale && (L->grad_off < 0 || (L->grad_off & 3) || (L->grad_stride & 3))) { cdx_set_err("cg_scale given without a gradient slot"); return CDX_EINVAL; }
     auto kern = guided ? (L->traj_per_wg == 2 ? cdx_unet2_kernel<2, 8, true> : cdx_unet2_kernel<1, 8, true>)
-              : L->n_waves == 8 ? (L->traj_per_wg == 2 ? cdx_unet2_kernel<2, 8, false> : cdx_unet2_kernel<1, 8, false>)
+              : L->n_waves == 8 ? (L->traj_per_wg == 3 ? cdx_unet2_kernel<3, 8, false>
+                                   : L->traj_per_wg == 2 ? cdx_unet2_kernel<2, 8, false> : cdx_unet2_kernel<1, 8, false>)
                                 : (L->traj_per_wg == 2 ? cdx_unet2_kernel<2, 4, false> : cdx_unet2_kernel<1, 4, false>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }

@@ -132,7 +132,8 @@ class Program2:
     embtabs: List[dict] = field(default_factory=list)      # one embedding-MLP spec per network (denoiser[, classifier])
     grad_off: int = -1                 # guided programs: position 0 of the classifier-gradient slot
     grad_stride: int = 0
-    ws_floats: int = 0                 # floats of global workspace per trajectory (saved x_hat tensors), 0: everything in LDS
+    ws_floats: int = 0                 # floats of global workspace per trajectory (saved x_hat tensors / compact: multistep memory)
+    compact: bool = False              # state and multistep memory in global memory (three trajectories per workgroup)
 
     def lds_bytes(self, traj_per_wg: int) -> int:
         return 4 * self.traj_floats * traj_per_wg
@@ -174,6 +175,8 @@ class _Builder2:
         self.n_stats = 0
         self.max_stage = 1 << 30           # cap (floats) on the staging area of one op = K slices x positions x row stride (guided
                                            # programs for two trajectories per workgroup keep it small)
+        self.alias_residual = False        # write identity-residual block outputs in place over their input slot
+        self.wrap_live: List[Act] = []     # non-persistent slots that the solver step writes for op 0 of the next forward (the state)
         self.save_global = False
         self.ws_floats = 0                 # per-trajectory global workspace (saved x_hat tensors) when save_global
         self.allow_4x4 = True
@@ -457,25 +460,56 @@ class _Builder2:
         self.macs += 2 * hidden * c * l
 
     def plan_arena(self, base: int) -> int:
-        """First-fit interval allocation over op liveness (same policy as program.py); patches slot offsets into the ops."""
+        """Interval allocation of the non-persistent slots over op liveness; patches slot offsets into the ops.  `alias_residual`:
+        the output of an op whose residual slot has the same shape and dies with this op is written IN PLACE over that residual
+        (each epilogue thread reads its residual element before it stores the same element) -- one slot less at the deepest level."""
         first, last = {}, {}
         for i, oa in enumerate(self.op_acts):
             for a in oa["reads"] + oa["writes"]:
                 first.setdefault(a.uid, i)
                 last[a.uid] = i
-        live: List[Act] = []
-        top = base
-        for a in sorted((a for a in self.acts if not a.persistent and a.uid in first), key=lambda a: first[a.uid]):
-            t = first[a.uid]
-            live = [b for b in live if last[b.uid] >= t]
-            pos = base
-            for lo, hi in sorted((b.off, b.off + b.floats) for b in live):
-                if lo - pos >= a.floats:
-                    break
-                pos = max(pos, hi)
-            a.off = pos
-            live.append(a)
-            top = max(top, pos + a.floats)
+        root = {}                                            # aliased slot uid -> uid of the slot whose storage it shares
+        if self.alias_residual:
+            for i, oa in enumerate(self.op_acts):
+                r, d = oa["res"], oa["dst"]
+                if (r is not None and r is not d and not r.persistent and not d.persistent and r.uid not in root
+                        and (r.length, r.chans, r.halo) == (d.length, d.chans, d.halo) and last[r.uid] == i and first[d.uid] == i
+                        and int(self.ops[i][W2_KIND]) == KIND2_CONV and not (int(self.ops[i][W2_FLAGS]) & (F2_GNBWD | F2_DUAL))):
+                    root[d.uid] = r.uid
+                    last[r.uid] = max(last[r.uid], last[d.uid])
+        slots = [a for a in self.acts if not a.persistent and a.uid in first and a.uid not in root]
+        n_ops = len(self.op_acts)
+        wrap = {a.uid for a in self.wrap_live}               # slots written AFTER the last op (solver step) and read by op 0
+
+        def overlap(a, b):
+            if not (last[b.uid] < first[a.uid] or last[a.uid] < first[b.uid]):
+                return True
+            for w, o in ((a, b), (b, a)):                    # a wrap slot is also live at the last op (the solver step reads `pred` then)
+                if w.uid in wrap and last[o.uid] >= n_ops - 1:
+                    return True
+            return False
+
+        def place(order):
+            offs, placed = {}, []
+            for a in order:
+                busy = sorted((offs[b.uid], offs[b.uid] + b.floats) for b in placed if overlap(a, b))
+                pos = base
+                for lo, hi in busy:
+                    if lo - pos >= a.floats:
+                        break
+                    pos = max(pos, hi)
+                offs[a.uid] = pos
+                placed.append(a)
+            return offs, max([base] + [offs[a.uid] + a.floats for a in placed])
+        # two orders, keep the tighter plan: by first use (what a stack would do) and largest-first
+        best = min((place(sorted(slots, key=lambda a: first[a.uid])), place(sorted(slots, key=lambda a: (-a.floats, first[a.uid])))),
+                   key=lambda r: r[1])
+        offs, top = best
+        by_uid = {a.uid: a for a in self.acts}
+        for a in slots:
+            a.off = offs[a.uid]
+        for d, r in root.items():
+            by_uid[d].off = by_uid[r].off
         for op, oa, items, item_src in zip(self.ops, self.op_acts, self.op_items, self.op_item_src):
             op[W2_DST] = oa["dst"].off                                 # slot base = first halo row
             if oa["res"] is not None:
@@ -695,14 +729,24 @@ def _lower_half_janner_grad(b: "_Builder2", clf, horizon: int, x: Act, grad: Act
 
 
 def _finalize2(b: "_Builder2", nets_emb: List[dict], x: Act, pred: Act, horizon: int, d: int, emb_dim: int, max_lds_bytes: int,
-               persistent: List[Act], grad: Optional[Act] = None) -> Program2:
-    """LDS plan of one trajectory: [x | persistent slots | prev | stats | stage | arena]; item tables; blob."""
+               persistent: List[Act], grad: Optional[Act] = None, compact: bool = False) -> Program2:
+    """LDS plan of one trajectory: [x | persistent slots | prev | stats | stage | arena]; item tables; blob.
+    `compact`: the authoritative state x_t and the multistep memory live in GLOBAL memory (the launch's x_out / workspace); the
+    LDS state slot is an arena slot that only has to exist from the solver step to the first op of the next forward."""
     nw = b.nw
     off = 0
-    x.off, off = off, off + x.floats
+    if compact:
+        x.persistent = False
+        b.wrap_live.append(x)
+        if b.op_acts[0]["srcs"][0] is not x:
+            raise ValueError("compact programs expect the state slot to be read by op 0 only")
+    else:
+        x.off, off = off, off + x.floats
     for a in persistent:
         a.off, off = off, off + a.floats
-    prev_off, off = off, off + (horizon * d + 3) // 4 * 4
+    prev_off = -4
+    if not compact:
+        prev_off, off = off, off + (horizon * d + 3) // 4 * 4
     stats_off, off = off, off + (b.n_stats + 3) // 4 * 4
     stage_off, off = off, off + (b.stage + 3) // 4 * 4
     top = (b.plan_arena(off) + 3) // 4 * 4
@@ -725,24 +769,30 @@ def _finalize2(b: "_Builder2", nets_emb: List[dict], x: Act, pred: Act, horizon:
                     x_stride=x.stride, pred_off=pred.data_off, pred_stride=pred.stride, prev_off=prev_off, stage_off=stage_off,
                     horizon=horizon, dim=d, emb_dim=emb_dim, n_emb=b.n_emb, embtab=nets_emb[0], macs_per_forward=b.macs,
                     n_conv=len(b.ops), meta={"blob_floats": b.blob_len, "stats_off": stats_off}, nw=nw,
-                    embtabs=nets_emb, grad_off=-1 if grad is None else grad.data_off, grad_stride=0 if grad is None else grad.stride)
+                    embtabs=nets_emb, grad_off=-1 if grad is None else grad.data_off, grad_stride=0 if grad is None else grad.stride,
+                    compact=compact, ws_floats=((horizon * d + 3) // 4 * 4) if compact else 0)
 
 
-def compile_janner2(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x4: bool = True, nw: int = NW2) -> Program2:
-    """Lower a JannerUNet1d (reference nn_diffusion/jannerunet.py:98-201) for `horizon` positions and `nw` waves per workgroup."""
+def compile_janner2(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x4: bool = True, nw: int = NW2, compact: bool = False,
+                    max_stage: Optional[int] = None) -> Program2:
+    """Lower a JannerUNet1d (reference nn_diffusion/jannerunet.py:98-201) for `horizon` positions and `nw` waves per workgroup.
+    `compact`: the small-LDS variant for THREE trajectories per workgroup (in-place residual outputs, capped staging area)."""
     why = supports_janner(net)
     if why is not None:
         raise ValueError(why)
     dev = next(net.parameters()).device
     b = _Builder2(dev, nw)
     b.allow_4x4 = allow_4x4
+    b.alias_residual = compact
+    if max_stage is not None:
+        b.max_stage = max_stage
     d = net.in_dim
     x = b.act(horizon, d, persistent=True)
     t, fc, blocks = _lower_janner(b, net, horizon, x)
     pred = b.act(horizon, d)                 # arena slot: written by the last op, read by the solver step right after it
     b.conv([t], pred, _conv1d_eff(fc[3]), fc[3].bias, pred=True)
     emb = _emb_table_spec(b, net, blocks, dev)
-    return _finalize2(b, [emb], x, pred, horizon, d, net.emb_dim, max_lds_bytes, [])
+    return _finalize2(b, [emb], x, pred, horizon, d, net.emb_dim, max_lds_bytes, [], compact=compact)
 
 
 def compile_guided2(net, clf, horizon: int, max_lds_bytes: int = 160 * 1024, nw: int = NW2_MAX, save_global: bool = False,

@@ -44,7 +44,7 @@ class CdxUnet2Launch(ctypes.Structure):
                 ("x_out", ctypes.c_void_p), ("init_blend", ctypes.c_int32), ("x_scale", ctypes.c_float),
                 ("cg_scale", ctypes.c_void_p), ("grad_off", ctypes.c_int32), ("grad_stride", ctypes.c_int32),
                 ("with_backward", ctypes.c_int32), ("ws", ctypes.c_void_p), ("ws_floats", ctypes.c_int32),
-                ("prof", ctypes.c_void_p)]
+                ("compact", ctypes.c_int32), ("prof", ctypes.c_void_p)]
 
 
 _declared = False
@@ -75,21 +75,27 @@ def enabled() -> bool:
     return os.environ.get("CDX_UNET2", "1") != "0"
 
 
-def compiled2(module, horizon: int, nw: int = P2.NW2) -> _Compiled2:
+def compiled2(module, horizon: int, nw: int = P2.NW2, compact: bool = False) -> _Compiled2:
     """The module's v2 program at this horizon for `nw` waves per workgroup (``.prog is None`` + ``.why`` when the v2 compiler
-    does not take it)."""
+    does not take it).  `compact`: the small-LDS variant that lets three trajectories share a workgroup (state and multistep memory
+    in global memory, in-place residual outputs, capped staging area) -- a third of 160 KiB or it does not exist."""
     per_mod = _cache.setdefault(module, {})
     sig = R._signature(module)
-    hit = per_mod.get((horizon, nw))
+    key = (horizon, nw, bool(compact))
+    hit = per_mod.get(key)
     if hit is not None and hit.sig == sig:
         return hit
     with torch.no_grad():
         try:
-            comp = _Compiled2(P2.compile_janner2(module, horizon, nw=nw), sig)
+            kw = dict(compact=True, max_stage=COMPACT_STAGE, max_lds_bytes=(160 * 1024) // 3 // 16 * 16) if compact else {}
+            comp = _Compiled2(P2.compile_janner2(module, horizon, nw=nw, **kw), sig)
         except (ValueError, AssertionError) as e:
             comp = _Compiled2(None, sig, str(e))
-    per_mod[(horizon, nw)] = comp
+    per_mod[key] = comp
     return comp
+
+
+COMPACT_STAGE = 2304       # floats of staging area per op in a compact program
 
 
 def supported(module, horizon: int) -> Optional[str]:
@@ -157,6 +163,53 @@ DEFAULT_NW = 8
 DEFAULT_TUNE = 0
 
 
+# Cost of one round of 256 workgroups with 1 / 2 / 3 trajectories each (config 2 on MI355X, measured: 4.41 / 5.63 / 7.66 ms); only
+# the ratios matter -- they decide how a batch is cut into launches.
+ROUND_COST = {1: 4.41, 2: 5.63, 3: 7.66}
+
+
+def plan_parts(batch: int, tmax: int):
+    """Cut `batch` trajectories into launches [(first, count, trajectories per workgroup)]: full rounds of 256 x T workgroups at the
+    T that is cheapest per trajectory, then the remainder at whatever T finishes it soonest (B = 3200: 4 rounds of 768 three per
+    workgroup + 128 one per workgroup)."""
+    best = None
+    for tb in range(1, tmax + 1):
+        per_round = N_CUS * tb
+        rounds, parts = batch // per_round, []
+        cost, bulk = rounds * ROUND_COST[tb], rounds * per_round
+        if bulk:
+            parts.append((0, bulk, tb))
+        r = batch - bulk
+        if r:
+            tt = min(range(1, tmax + 1), key=lambda t: (-(-r // (N_CUS * t)) * ROUND_COST[t], t))
+            cost += -(-r // (N_CUS * tt)) * ROUND_COST[tt]
+            parts.append((bulk, r, tt))
+        if best is None or cost < best[0] - 1e-9:
+            best = (cost, parts)
+    return best[1]
+
+
+def plan_for(module, horizon: int, batch: int):
+    """(compiled program, launch parts) for an unguided request of `batch` trajectories.  CDX_UNET2_T forces one launch at 1, 2 or 3
+    trajectories per workgroup; CDX_UNET2_SPLIT_TAIL=0 keeps a single launch."""
+    comp, t = shape_for(module, horizon, batch)
+    forced = os.environ.get("CDX_UNET2_T")
+    three = compiled2(module, horizon, 8, compact=True) if (comp.prog is not None and comp.prog.nw == 8 and os.environ.get("CDX_UNET2_T3", "1") != "0") else None
+    if three is not None and three.prog is None:
+        three = None
+    if forced == "3":
+        return (three, [(0, batch, 3)]) if three is not None else (comp, [(0, batch, t)])
+    if three is not None and os.environ.get("CDX_UNET2_COMPACT") == "1":          # test hook: the compact program at the forced shape
+        return three, [(0, batch, int(forced) if forced in ("1", "2") else 1)]
+    if forced in ("1", "2") or os.environ.get("CDX_UNET2_SPLIT_TAIL", "1") == "0" or R._prof["buf"] is not None:
+        return comp, [(0, batch, t)]
+    tmax = 3 if three is not None else (2 if comp.prog.lds_bytes(2) <= 160 * 1024 else 1)
+    parts = plan_parts(batch, tmax)
+    if max(p[2] for p in parts) == 3:
+        return three, parts
+    return comp, parts
+
+
 def shape_for(module, horizon: int, batch: int):
     """(compiled program, trajectories per workgroup) the launch of `batch` trajectories uses.  The 8-wave shape stages more K
     slices, so its LDS plan is a little larger: when two of them do not fit next to each other but two of the 4-wave plan do,
@@ -177,7 +230,7 @@ def shape_for(module, horizon: int, batch: int):
 
 def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps=0, predict_noise=0, prior=None,
            fix_mask=None, noise=None, x_min=None, x_max=None, t_per_wg: Optional[int] = None, x_scale: Optional[float] = None,
-           cg_scale=None, with_backward: bool = False):
+           cg_scale=None, with_backward: bool = False, parts=None):
     if batch <= 0:
         return
     prog = comp.prog
@@ -186,9 +239,12 @@ def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps
     # Two trajectories per workgroup fill the 256 CUs in rounds of 512 trajectories; a remainder of up to 256 is cheaper one
     # trajectory per workgroup (B = 3200: 6 full rounds + 128 trajectories: 4.6 instead of 5.9 ms for the last round).  Same stream,
     # same tensors, disjoint trajectory ranges; results do not depend on the split (T never changes a bit).
+    given = parts
     parts = [(0, batch, t)]
     rounds = 2 * N_CUS
-    if t == 2 and prof is None and os.environ.get("CDX_UNET2_SPLIT_TAIL", "1") != "0" and batch > rounds and 0 < batch % rounds <= N_CUS \
+    if given is not None:
+        parts = list(given)
+    elif t == 2 and prof is None and os.environ.get("CDX_UNET2_SPLIT_TAIL", "1") != "0" and batch > rounds and 0 < batch % rounds <= N_CUS \
             and prog.lds_bytes(1) <= 160 * 1024:
         bulk = batch - batch % rounds
         parts = [(0, bulk, 2), (bulk, batch - bulk, 1)]
@@ -214,7 +270,7 @@ def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps
             x_max=R._ptr(x_max), x_out=x_out.data_ptr(), init_blend=0 if x_scale is None else 1,
             x_scale=1.0 if x_scale is None else float(x_scale), cg_scale=R._ptr(cg_scale), grad_off=prog.grad_off,
             grad_stride=prog.grad_stride, with_backward=int(with_backward or cg_scale is not None), ws=R._ptr(ws),
-            ws_floats=prog.ws_floats, prof=R._ptr(prof))
+            ws_floats=prog.ws_floats, compact=int(prog.compact), prof=R._ptr(prof))
         R._check(_lib().cdx_unet2_run(ctypes.byref(L), R._stream_ptr(x_in.device)), "cdx_unet2_run")
     if timing["on"]:
         end.record(torch.cuda.current_stream(x_in.device))
@@ -232,7 +288,7 @@ def fused_sample2(solver, net, plan, xt, prior, feed, fix_mask, x_min, x_max, x_
     if b < min_batch() or R.plan_is_edm(plan) or supported(net, h) is not None:
         return None
     dev = xt.device
-    comp, t = shape_for(net, h, b)
+    comp, parts = plan_for(net, h, b)
     with torch.no_grad():
         emb = plan_film_table(comp, net, plan, dev)
         steps_dev = R.steps_to_device(plan, dev)
@@ -241,7 +297,7 @@ def fused_sample2(solver, net, plan, xt, prior, feed, fix_mask, x_min, x_max, x_
         out = torch.empty_like(xin)
         launch(comp, batch=b, x_in=xin, x_out=out, emb=emb, steps_dev=steps_dev, n_steps=len(plan.steps),
                predict_noise=R._predicts_noise(plan, solver), prior=R._f32c(prior, dev) if fix_mask is not None else None,
-               fix_mask=fix_mask, noise=noise, x_min=x_min, x_max=x_max, t_per_wg=t, x_scale=x_scale)
+               fix_mask=fix_mask, noise=noise, x_min=x_min, x_max=x_max, parts=parts, x_scale=x_scale)
     return out
 
 

@@ -145,7 +145,7 @@ typedef struct cdx_unet2_launch {
     const float* wblob;        /* device, packed parameters */
     int32_t n_ops;
     int32_t traj_floats;       /* LDS floats of one trajectory's region; the workgroup owns traj_per_wg of them */
-    int32_t traj_per_wg;       /* 1 or 2 */
+    int32_t traj_per_wg;       /* 1, 2 or 3 (3: 8-wave compact programs) */
     int32_t n_waves;           /* 4 or 8: wave64 per workgroup; the program (work items, K slices) is compiled for one of them */
     int32_t tune;              /* scheduling switches (results do not depend on them); bit 0: in the 8-wave shape waves 4-7 run
                                 * their K loops at raised priority */
@@ -181,6 +181,9 @@ typedef struct cdx_unet2_launch {
      * scratch of (batch + 1) * ws_floats floats (one spare block), owned by the caller, ordered by the launch stream; ws_floats == 0: none */
     float* ws;
     int32_t ws_floats;
+    /* compact programs (engine/program2.py:compile_janner2(compact=True): the LDS plan that lets THREE trajectories share a
+     * workgroup): the authoritative state x_t lives in x_out and the multistep memory in ws ((batch + 1) * ws_floats floats) */
+    int32_t compact;
     /* optional profiling: device u64 [n_ops*8 + 2]; workgroup 0 stamps s_memtime at {op start, next-op prefetch issued, after the
      * staging barrier, op end, item record + segment read, first operands landed, MFMAs done, partial tile staged} of the first
      * forward, plus kernel start/end.  NULL = off. */

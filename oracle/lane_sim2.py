@@ -71,10 +71,11 @@ class LaneSim2:
     def poison_arena(self):
         """Everything but the x slot is (re)poisoned: ops must write (data rows AND halo rows) before anyone reads."""
         p = self.p
-        lo = p.x_off - P2.HALO2 * p.x_stride
+        lo = p.x_off - P2.HALO2 * p.x_stride                     # (compact programs keep the state slot inside the arena)
         hi = p.x_off + (p.horizon + P2.HALO2) * p.x_stride
-        assert lo == 0
-        self.lds[hi:] = np.nan
+        keep = self.lds[lo:hi].copy()
+        self.lds[:] = np.nan
+        self.lds[lo:hi] = keep
 
     def load_x(self, x):
         p = self.p

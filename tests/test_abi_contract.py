@@ -99,8 +99,11 @@ def test_unet2_validation_fails_loudly(lib):
     runtime2._lib()
     assert lib.cdx_unet2_run(ctypes.byref(runtime2.CdxUnet2Launch()), None) == -1 and b"null" in lib.cdx_last_error()
     L = runtime2.CdxUnet2Launch(ops=8, wblob=8, x_in=8, x_out=8, emb=8, n_ops=1, batch=4, horizon=4, dim=4, traj_floats=64,
-                                traj_per_wg=3)
+                                traj_per_wg=4)
     assert lib.cdx_unet2_run(ctypes.byref(L), None) == -1 and b"traj_per_wg" in lib.cdx_last_error()
+    L.traj_per_wg, L.n_waves = 3, 8
+    assert lib.cdx_unet2_run(ctypes.byref(L), None) == -1 and b"compact" in lib.cdx_last_error()     # three per workgroup: compact programs only
+    L.n_waves = 0
     L.traj_per_wg, L.traj_floats = 2, 30 * 1024
     assert lib.cdx_unet2_run(ctypes.byref(L), None) == -1 and b"n_waves" in lib.cdx_last_error()
     L.n_waves = 8

@@ -47,3 +47,18 @@ def test_edm_state_buffers_are_optional_in_the_lds_plan():
         raise AssertionError("expected the EDM variant not to fit")
     except ValueError as e:
         assert "LDS plan" in str(e)
+
+
+def test_launch_plan_cuts_large_batches():
+    """B = 3200 = 4 rounds of 768 trajectories three per workgroup + 128 one per workgroup; B = 512 one round of two; B = 256 one of one."""
+    from cleandiffuser_amd.engine import runtime2
+    assert runtime2.plan_parts(3200, 3) == [(0, 3072, 3), (3072, 128, 1)]
+    assert runtime2.plan_parts(512, 3) == [(0, 512, 2)]
+    assert runtime2.plan_parts(256, 3) == [(0, 256, 1)]
+    assert runtime2.plan_parts(640, 3) == [(0, 640, 3)]
+    assert runtime2.plan_parts(3200, 2) == [(0, 3072, 2), (3072, 128, 1)]
+    for b in (1, 255, 257, 700, 1000, 5000):
+        parts = runtime2.plan_parts(b, 3)
+        assert sum(c for _, c, _ in parts) == b and parts[0][0] == 0 and all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(len(parts) - 1))
+
+

@@ -421,6 +421,31 @@ def test_unet2_agrees_with_first_kernel_and_is_batch_invariant(amd_lib, monkeypa
     np.testing.assert_allclose(outs["t1"].cpu().numpy(), outs["v1"].cpu().numpy(), rtol=2e-4, atol=2e-4)
 
 
+def test_three_trajectories_per_workgroup(amd_lib, monkeypatch):
+    """The compact program (state and multistep memory in global memory, in-place residual outputs) with 1, 2 and 3 trajectories per
+    workgroup: bit-identical results (B = 40: a half-empty last workgroup in every shape; DPM-Solver++ 2M exercises the multistep
+    memory in the workspace), and within summation-order noise of the standard program."""
+    name = "janner_cfg2_ddim"
+    agent, _ = cases.build(amd_lib, name, device=DEV)
+    g = torch.Generator().manual_seed(21)
+    B = 40
+    prior = torch.zeros(B, 32, 23)
+    prior[:, 0, :17] = torch.randn(B, 17, generator=g)
+    z0 = torch.randn(B, 32, 23, generator=g).to(DEV)
+    kw = dict(solver="ode_dpmsolver++_2M", n_samples=B, sample_steps=6, temperature=0.5)
+    outs = {}
+    for tag, env in (("std", {"CDX_UNET2_T": "1", "CDX_UNET2_COMPACT": "0"}), ("c1", {"CDX_UNET2_T": "1", "CDX_UNET2_COMPACT": "1"}),
+                     ("c2", {"CDX_UNET2_T": "2", "CDX_UNET2_COMPACT": "1"}), ("c3", {"CDX_UNET2_T": "3", "CDX_UNET2_COMPACT": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        calls = _spy_launches(monkeypatch)
+        outs[tag], _ = agent.sample(prior.to(DEV), noise=[z0], **kw)
+        torch.cuda.synchronize()
+        assert calls["v2"] == 1
+    assert torch.equal(outs["c1"], outs["c2"]) and torch.equal(outs["c1"], outs["c3"])
+    np.testing.assert_allclose(outs["c3"].cpu().numpy(), outs["std"].cpu().numpy(), rtol=2e-4, atol=2e-4)
+
+
 def test_split_tail_launch_does_not_change_results(amd_lib, monkeypatch):
     """B = 640: the bulk (512) runs two trajectories per workgroup, the remainder (128) one per workgroup through a second
     cdx_unet2_run over the trajectory range [512, 640) -- bit-identical to the single two-per-workgroup launch (DDPM: per-step noise
@@ -434,6 +459,7 @@ def test_split_tail_launch_does_not_change_results(amd_lib, monkeypatch):
     zs = [torch.randn(B, 32, 23, generator=g).to(DEV) for _ in range(4)]
     kw = dict(solver="ddpm", n_samples=B, sample_steps=3)
     outs = {}
+    monkeypatch.setenv("CDX_UNET2_T3", "0")              # (with the compact program B = 640 would be one launch of three per workgroup)
     for split in ("1", "0"):
         monkeypatch.setenv("CDX_UNET2_SPLIT_TAIL", split)
         outs[split], _ = agent.sample(prior.to(DEV), noise=list(zs), **kw)

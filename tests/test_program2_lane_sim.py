@@ -135,3 +135,26 @@ def test_lane_sim2_guided_program_gradient_matches_autograd(shape, two, amd_lib)
     np.testing.assert_allclose(sim.run_forward(row), ref_pred, rtol=2e-5, atol=2e-5)
     ref_grad = xr.grad[0].numpy()
     np.testing.assert_allclose(sim.grad(), ref_grad, rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(ref_grad).max())))
+
+
+def test_lane_sim2_compact_program_for_three_trajectories(amd_lib):
+    """The compact variant of the config-2 program (state and multistep memory outside LDS, block outputs written in place over their
+    identity-residual input, capped staging area): three trajectories fit one workgroup's 160 KiB, and the lane-level twin still
+    reproduces the reference's first forward."""
+    name = "janner_cfg2_ddim"
+    gold = np.load(golden_path(name))
+    agent, _ = cases.build(amd_lib, name)
+    c = cases.CASES[name]
+    net = agent.model_ema["diffusion"]
+    prog = P2.compile_janner2(net, c["horizon"], nw=8, compact=True, max_stage=2304)
+    assert prog.compact and prog.lds_bytes(3) <= 160 * 1024 and prog.prev_off < 0 and prog.ws_floats >= 32 * 23
+    # in-place outputs: some op writes the slot it reads its residual from
+    assert any(int(op[P2.W2_FLAGS]) & P2.F2_RES and int(op[P2.W2_RES]) == int(op[P2.W2_DST]) and int(op[P2.W2_KPOST]) == 0 for op in prog.ops)
+    inp, xt0 = _first_forward_inputs(name, agent)
+    with torch.no_grad():
+        temb = net.map_noise(_first_t(agent, c)).numpy()
+    row = emb_table(prog, temb)[0]
+    for b in range(2):
+        sim = LaneSim2(prog)
+        sim.load_x(xt0[b])
+        np.testing.assert_allclose(sim.run_forward(row), gold["pred0"][b], rtol=2e-5, atol=2e-5)
