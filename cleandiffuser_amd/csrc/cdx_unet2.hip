@@ -305,6 +305,13 @@ __device__ __forceinline__ void conv_kloop(const Geom& g, const float* __restric
             int cc0 = it.cc;                                   // chunk-in-tap of the revolution's first chunk
             const char* ldsb = reinterpret_cast<const char*>(lds);
             for (; qi < n_main; qi += PF) {
+                // two waves per SIMD: the arbiter favours the older wave (0-3), which then leaves a long K loop thousands of cycles before
+                // its SIMD-mate and lets it finish alone at the single-wave rate.  Alternating the priority every revolution keeps
+                // the pair level (tune bit 1).
+                if (NWV == 8 && (tune & 2)) {
+                    if (((qi / PF) ^ (wave >> 2)) & 1) __builtin_amdgcn_s_setprio(1);
+                    else __builtin_amdgcn_s_setprio(0);
+                }
                 const bool wrap = cc0 + PF == ccn;             // the NEXT revolution starts the next tap
                 cc0 = wrap ? 0 : cc0 + PF;
 #pragma unroll
@@ -351,7 +358,7 @@ __device__ __forceinline__ void conv_kloop(const Geom& g, const float* __restric
                 if (q >= PF && q < nq) refill((u + PF - 1) % PF, q);
             }
         }
-        if (NWV == 8 && (tune & 1)) __builtin_amdgcn_s_setprio(0);
+        if (NWV == 8 && (tune & 3)) __builtin_amdgcn_s_setprio(0);
         if (prof && item == 0) { asm volatile("" ::"v"(acc[0][0][0][0]), "v"(acc[0][0][1][0])); stamp(prof + 6, ptid); }
         // D fragment: 4 consecutive rows (channels) of one column -> stage[k slice][output position][row tile + rows]
 #pragma unroll

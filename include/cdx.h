@@ -148,7 +148,8 @@ typedef struct cdx_unet2_launch {
     int32_t traj_per_wg;       /* 1, 2 or 3 (3: 8-wave compact programs) */
     int32_t n_waves;           /* 4 or 8: wave64 per workgroup; the program (work items, K slices) is compiled for one of them */
     int32_t tune;              /* scheduling switches (results do not depend on them); bit 0: in the 8-wave shape waves 4-7 run
-                                * their K loops at raised priority */
+                                * their K loops at raised priority; bit 1: the two waves of a SIMD alternate priority every ring
+                                * revolution of a long K loop */
     int32_t x_off, x_stride, pred_off, pred_stride, prev_off, stage_off;   /* relative to the trajectory region; x/pred: position 0 */
     int32_t batch, horizon, dim;
     /* this launch denoises trajectories [traj_first, traj_first + traj_count) of the batch (all tensors keep their full-batch

@@ -23,8 +23,8 @@ def main():
     kw = dict(solver="ddim", n_samples=batch, sample_steps=20, temperature=0.5)
     for _ in range(3):
         agent.sample(prior, noise=[z0], **kw)
-    comp, tpw = runtime2.shape_for(agent.model_ema["diffusion"], 32, batch)
-    prog = comp.prog
+    comp, parts = runtime2.plan_for(agent.model_ema["diffusion"], 32, batch)
+    prog, tpw = comp.prog, parts[0][2]
     n_ops = len(prog.ops)
     buf = torch.zeros(n_ops * 8 + 2, dtype=torch.int64, device=dev)
     runtime.set_profile_buffer(buf)
