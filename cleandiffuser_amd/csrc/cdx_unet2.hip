@@ -175,7 +175,7 @@ template <int PF> struct Ring { f32x4 rec[PF]; };       // head of this wave's n
 // (tap, chunk): one add per chunk (`+ KSTEP`) and, every `ccn` chunks, one per-lane add for the tap step.  Columns past l_cols
 // sit on halo row 0 with a zero tap step.  Nothing else happens per record: wait, 4 MFMAs per (trajectory, column tile), one
 // ds_read per (trajectory, column tile), one global load.
-template <class M, int NT, int T, int NWV>
+template <class M, int NT, int T, int NWV, bool PROF>
 __device__ __forceinline__ void conv_kloop(const Geom& g, const float* __restrict__ wblob, int vd, const cint* ops,
                                            Item it, int n_items, float* __restrict__ lds, int tf, int lane, int wave,
                                            Ring<WG<NWV>::PF>& ring, unsigned long long* prof, int tune) {
@@ -204,7 +204,7 @@ __device__ __forceinline__ void conv_kloop(const Geom& g, const float* __restric
             cur[nt] = it.src + __mul24(row, it.sstr) + M::koff(lane) + cc * M::KSTEP;
             tstep[nt] = (valid ? it.sstr : 0) - ccn * M::KSTEP;
         }
-        if (prof && item == 0) { asm volatile("" ::"s"(nq), "v"(cur[0])); stamp(prof + 4, ptid); }
+        if (PROF && prof && item == 0) { asm volatile("" ::"s"(nq), "v"(cur[0])); stamp(prof + 4, ptid); }
         f32x4 acc[T][NT][NA];
 #pragma unroll
         for (int t = 0; t < T; ++t)
@@ -262,7 +262,7 @@ __device__ __forceinline__ void conv_kloop(const Geom& g, const float* __restric
                 }
             }
         }
-        if (prof && item == 0) { asm volatile("" ::"v"(wr[0][0]), "v"(bq[0][0][0][0])); stamp(prof + 5, ptid); }
+        if (PROF && prof && item == 0) { asm volatile("" ::"v"(wr[0][0]), "v"(bq[0][0][0][0])); stamp(prof + 5, ptid); }
         // two waves per SIMD: the arbiter favours the older wave (0-3), which then finishes its K loop well before its
         // SIMD-mate and leaves it running alone at the single-wave rate; raising the younger wave's priority evens them out
         if (NWV == 8 && (tune & 1) && wave >= 4) __builtin_amdgcn_s_setprio(1);
@@ -359,7 +359,7 @@ __device__ __forceinline__ void conv_kloop(const Geom& g, const float* __restric
             }
         }
         if (NWV == 8 && (tune & 3)) __builtin_amdgcn_s_setprio(0);
-        if (prof && item == 0) { asm volatile("" ::"v"(acc[0][0][0][0]), "v"(acc[0][0][1][0])); stamp(prof + 6, ptid); }
+        if (PROF && prof && item == 0) { asm volatile("" ::"v"(acc[0][0][0][0]), "v"(acc[0][0][1][0])); stamp(prof + 6, ptid); }
         // D fragment: 4 consecutive rows (channels) of one column -> stage[k slice][output position][row tile + rows]
 #pragma unroll
         for (int t = 0; t < T; ++t)
@@ -630,7 +630,7 @@ __device__ __forceinline__ void prefetch_ring(const Item& it, const float* __res
 // Epilogue threads: 256 per trajectory (8 GroupNorm groups x 32 lanes).  4 waves: all of them, one trajectory after the other;
 // 8 waves, T = 2: waves 0-3 take trajectory 0 while waves 4-7 take trajectory 1; 8 waves, T = 1: waves 0-3 run the epilogue,
 // waves 4-7 rewrite the destination's halo rows.
-template <int T, int NWV, bool BWD>
+template <int T, int NWV, bool BWD, bool PROF>
 __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* ops, int vd, int vdn, Item& it,
                                        const float* __restrict__ emb_row, float* __restrict__ lds, int tid,
                                        Ring<WG<NWV>::PF>& ring, unsigned long long* prof, int b0) {
@@ -671,20 +671,20 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
     // K loop -> staged partial tiles
     const int n_items = CDX2_DW(vd, CDX2_W2_NITEMS);
     if (CDX2_DW(vd, CDX2_W2_MODE) == CDX_MODE_4X4) {
-        if (CDX2_DW(vd, CDX2_W2_NT) == 1) conv_kloop<M4, 1, T, NWV>(g, L.wblob, vd, ops, it, n_items, lds, tf, lane, wave, ring, prof, L.tune);
-        else conv_kloop<M4, 2, T, NWV>(g, L.wblob, vd, ops, it, n_items, lds, tf, lane, wave, ring, prof, L.tune);
+        if (CDX2_DW(vd, CDX2_W2_NT) == 1) conv_kloop<M4, 1, T, NWV, PROF>(g, L.wblob, vd, ops, it, n_items, lds, tf, lane, wave, ring, prof, L.tune);
+        else conv_kloop<M4, 2, T, NWV, PROF>(g, L.wblob, vd, ops, it, n_items, lds, tf, lane, wave, ring, prof, L.tune);
     } else {
-        conv_kloop<M16, 1, T, NWV>(g, L.wblob, vd, ops, it, n_items, lds, tf, lane, wave, ring, prof, L.tune);
+        conv_kloop<M16, 1, T, NWV, PROF>(g, L.wblob, vd, ops, it, n_items, lds, tf, lane, wave, ring, prof, L.tune);
     }
-    stamp(prof ? prof + 7 : nullptr, tid);
+    if (PROF) stamp(prof ? prof + 7 : nullptr, tid);
     // head of the next op's weight stream: flies through the barrier and the epilogue
     // (issued AFTER the partial tiles are staged: sending the eight loads first, while the MFMAs drain, blocks the wave on the
     //  memory pipe for ~350 cycles before it can write its tile -- measured 9 % slower)
     it = inline_item(vdn);
     if (wave < CDX2_DW(vdn, CDX2_W2_NITEMS)) prefetch_ring(it, L.wblob, lane, ring);
-    stamp(prof ? prof + 1 : nullptr, tid);
+    if (PROF) stamp(prof ? prof + 1 : nullptr, tid);
     __syncthreads();
-    stamp(prof ? prof + 2 : nullptr, tid);
+    if (PROF) stamp(prof ? prof + 2 : nullptr, tid);
 
     const EpiDesc e = decode_epi<BWD>(vd);
     const int t_lo = SPLIT_T ? (wave >> 2) : 0, t_step = SPLIT_T ? 2 : 1;
@@ -715,12 +715,14 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
         }
     }
     __syncthreads();
-    stamp(prof ? prof + 3 : nullptr, tid);
+    if (PROF) stamp(prof ? prof + 3 : nullptr, tid);
 }
 
 // T = 1: two workgroups per CU must be able to co-reside (that is what hides this latency-bound kernel's stalls from B = 512
 // on), i.e. at most 256 VGPR + AGPR per lane -- the second launch-bound argument is waves per SIMD.
-template <int T, int NWV, bool BWD>
+// PROF: the s_memtime stamps of tools/op_profile2.py exist only in the instantiations a launch with `prof != NULL` selects -- even
+// untaken, their scalar branches and the values they keep alive cost 1-3 % (A/B on MI355X).
+template <int T, int NWV, bool BWD, bool PROF>
 __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_unet2_kernel(const cdx_unet2_launch L) {
     constexpr int THREADS = WG<NWV>::THREADS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -730,7 +732,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
     const int b0 = L.traj_first + blockIdx.x * T;
     const int b_end = L.traj_first + L.traj_count;      // this launch covers trajectories [traj_first, traj_first + traj_count) of the batch
     unsigned long long* lprof = reinterpret_cast<unsigned long long*>(lds + T * tf);
-    const bool profiling = L.prof != nullptr && blockIdx.x == 0;
+    const bool profiling = PROF && L.prof != nullptr && blockIdx.x == 0;
     if (profiling) stamp(lprof + (size_t)L.n_ops * 8, tid);
 
     // descriptor + first item + weight stream of op 0 first: they fly while the state is set up
@@ -778,8 +780,8 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
             const int vdn = load_desc<NWV>(L.ops, oi + 1 < L.n_ops ? oi + 1 : 0, lane, wave);
             // (profile the SECOND forward when there is one: instruction / scalar caches warm, like every later step)
             unsigned long long* pslot = (profiling && step == (L.n_steps > 1 ? 1 : 0)) ? lprof + (size_t)oi * 8 : nullptr;
-            stamp(pslot, tid);
-            run_op<T, NWV, BWD>(L, ops, vd, vdn, it, emb_row, lds, tid, ring, pslot, b0);
+            if (PROF) stamp(pslot, tid);
+            run_op<T, NWV, BWD, PROF>(L, ops, vd, vdn, it, emb_row, lds, tid, ring, pslot, b0);
             vd = vdn;
         }
         if (L.n_steps == 0) break;
@@ -973,10 +975,18 @@ int cdx_unet2_run(const cdx_unet2_launch* L, void* hip_stream) {
     if (guided && L->ws_floats > 0 && !L->ws) { cdx_set_err("program keeps saved tensors in a global workspace: ws == NULL"); return CDX_EINVAL; }
     if (L->ws_floats < 0 || (L->ws_floats & 3)) { cdx_set_err("ws_floats must be a non-negative multiple of 4"); return CDX_EINVAL; }
     if (L->cg_scale && (L->grad_off < 0 || (L->grad_off & 3) || (L->grad_stride & 3))) { cdx_set_err("cg_scale given without a gradient slot"); return CDX_EINVAL; }
-    auto kern = guided ? (L->traj_per_wg == 2 ? cdx_unet2_kernel<2, 8, true> : cdx_unet2_kernel<1, 8, true>)
-              : L->n_waves == 8 ? (L->traj_per_wg == 3 ? cdx_unet2_kernel<3, 8, false>
-                                   : L->traj_per_wg == 2 ? cdx_unet2_kernel<2, 8, false> : cdx_unet2_kernel<1, 8, false>)
-                                : (L->traj_per_wg == 2 ? cdx_unet2_kernel<2, 4, false> : cdx_unet2_kernel<1, 4, false>);
+    void (*kern)(const cdx_unet2_launch);
+    if (L->prof) {                                       // profiling builds of the shapes tools/op_profile2*.py look at
+        if (L->n_waves != 8) { cdx_set_err("op profiling: 8-wave shapes only"); return CDX_EINVAL; }
+        kern = guided ? (L->traj_per_wg == 2 ? cdx_unet2_kernel<2, 8, true, true> : cdx_unet2_kernel<1, 8, true, true>)
+                      : (L->traj_per_wg == 3 ? cdx_unet2_kernel<3, 8, false, true>
+                         : L->traj_per_wg == 2 ? cdx_unet2_kernel<2, 8, false, true> : cdx_unet2_kernel<1, 8, false, true>);
+    } else {
+        kern = guided ? (L->traj_per_wg == 2 ? cdx_unet2_kernel<2, 8, true, false> : cdx_unet2_kernel<1, 8, true, false>)
+             : L->n_waves == 8 ? (L->traj_per_wg == 3 ? cdx_unet2_kernel<3, 8, false, false>
+                                  : L->traj_per_wg == 2 ? cdx_unet2_kernel<2, 8, false, false> : cdx_unet2_kernel<1, 8, false, false>)
+                               : (L->traj_per_wg == 2 ? cdx_unet2_kernel<2, 4, false, false> : cdx_unet2_kernel<1, 4, false, false>);
+    }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
     const int grid = (L->traj_count + L->traj_per_wg - 1) / L->traj_per_wg;
