@@ -265,7 +265,6 @@ __device__ __forceinline__ void conv_kloop(const Geom& g, const float* __restric
         if (PROF && prof && item == 0) { asm volatile("" ::"v"(wr[0][0]), "v"(bq[0][0][0][0])); stamp(prof + 5, ptid); }
         // two waves per SIMD: the arbiter favours the older wave (0-3), which then finishes its K loop well before its
         // SIMD-mate and leaves it running alone at the single-wave rate; raising the younger wave's priority evens them out
-        if (NWV == 8 && (tune & 1) && wave >= 4) __builtin_amdgcn_s_setprio(1);
 
         // chunk at ring slot u (record index == u mod PF, PF % BD == 0 -> operand slot u % BD is static after unrolling)
         // (the operand fetch is UNconditional -- past the item's last chunk it re-reads the last valid address -- and the loop below
@@ -307,8 +306,8 @@ __device__ __forceinline__ void conv_kloop(const Geom& g, const float* __restric
             for (; qi < n_main; qi += PF) {
                 // two waves per SIMD: the arbiter favours the older wave (0-3), which then leaves a long K loop thousands of cycles before
                 // its SIMD-mate and lets it finish alone at the single-wave rate.  Alternating the priority every revolution keeps
-                // the pair level (tune bit 1).
-                if (NWV == 8 && (tune & 2)) {
+                // the pair level (+0.5-1 %; raising the younger waves for the whole loop only moves the skew to the other side).
+                if (NWV == 8) {
                     if (((qi / PF) ^ (wave >> 2)) & 1) __builtin_amdgcn_s_setprio(1);
                     else __builtin_amdgcn_s_setprio(0);
                 }
@@ -358,7 +357,7 @@ __device__ __forceinline__ void conv_kloop(const Geom& g, const float* __restric
                 if (q >= PF && q < nq) refill((u + PF - 1) % PF, q);
             }
         }
-        if (NWV == 8 && (tune & 3)) __builtin_amdgcn_s_setprio(0);
+        if (NWV == 8) __builtin_amdgcn_s_setprio(0);
         if (PROF && prof && item == 0) { asm volatile("" ::"v"(acc[0][0][0][0]), "v"(acc[0][0][1][0])); stamp(prof + 6, ptid); }
         // D fragment: 4 consecutive rows (channels) of one column -> stage[k slice][output position][row tile + rows]
 #pragma unroll

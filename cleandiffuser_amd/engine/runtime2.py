@@ -160,7 +160,7 @@ def n_waves(batch: int) -> int:
 
 
 DEFAULT_NW = 8
-DEFAULT_TUNE = 2       # bit 1: the two waves of a SIMD alternate priority every ring revolution (+0.5-1 %, A/B on MI355X)
+DEFAULT_TUNE = 0
 
 
 # Cost of one round of 256 workgroups with 1 / 2 / 3 trajectories each (config 2 on MI355X, measured: 4.41 / 5.63 / 7.66 ms); only
