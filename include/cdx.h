@@ -1,35617 +1,486 @@
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-A    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-B    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-I    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-9    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-I    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-X    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-P    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-P    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-O    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-F    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-F    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-I    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-P    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
->    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-"    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-"    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-9    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-A    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-B    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-I    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-I    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-G    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-R    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-A    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-I    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-O    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-z    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-q    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-'    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-H    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-I    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-P    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-X    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-#    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-X    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-H    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-#    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-X    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-H    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-#    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-<    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
->    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-#    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-"    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-"    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-{    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-#    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-#    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-X    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-A    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-B    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-I    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-V    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-R    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-I    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-O    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-#    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-X    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-O    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-K    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-#    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-X    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-I    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-V    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-A    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-z    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-#    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-X    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-9    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-K    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-B    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-#    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-X    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-H    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-I    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-P    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-H    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-I    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-P    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-#    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-X    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-O    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-P    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-W    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-O    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-R    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-O    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-R    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-9    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-8    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-9    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-z    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-<    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-z    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-<    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-<    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-V    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-z    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-V    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-|    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-|    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-|    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-X    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-P    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-A    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-K    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-P    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-R    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-P    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-7    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-<    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-<    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-P    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-P    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-<    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-P    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-<    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-P    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-|    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-<    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-P    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-z    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-H    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-8    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-7    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-8    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-8    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-F    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-'    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-'    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-7    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-7    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-'    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-z    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-B    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-F    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-O    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-R    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-A    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-7    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-9    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-#    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-X    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-P    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-A    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-K    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-P    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-R    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-{    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-7    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-'    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-I    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-<    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
->    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-X    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-P    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-}    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-O    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-q    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
->    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-<    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-B    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-J    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-O    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-{    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-X    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-O    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-P    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-W    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-O    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-R    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-P    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
->    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-z    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-'    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-z    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-z    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-z    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-z    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-8    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-!    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-z    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-z    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-z    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-z    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-z    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-z    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-8    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-{    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-F    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-A    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-K    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-}    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-}    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-A    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-B    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-I    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-X    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-A    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-B    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-I    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-V    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-R    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-I    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-O    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-"    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-"    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-q    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-9    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-O    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-J    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-8    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-R    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-B    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-'    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-F    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-#    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-X    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-O    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-P    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-W    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-O    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-R    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-8    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-F    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-W    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-^    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-W    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-^    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-W    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-^    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-7    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-{    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-'    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-F    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-R    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-A    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-W    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-W    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-^    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-H    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-J    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-'    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-W    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-^    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-}    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-{    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-X    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-O    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-P    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-W    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-O    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-R    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-'    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-8    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-8    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-K    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-8    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-7    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-K    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-I    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-K    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-z    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-B    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-z    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-F    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-<    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-z    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-z    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-z    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-z    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-!    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-I    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-z    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-z    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-9    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-'    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-'    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-7    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-!    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-H    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-R    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-8    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-{    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-F    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-A    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-}    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-}    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-B    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
->    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
->    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-G    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-P    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-K    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-A    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-W    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-%    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-R    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-9    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-8    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-q    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-8    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-{    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-A    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-K    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-W    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-K    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-K    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-X    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-A    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-8    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-I    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-G    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
->    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-A    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-%    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-K    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-A    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-X    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-z    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-W    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-R    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-9    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-8    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-K    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-8    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-8    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-K    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-!    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-K    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-<    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-}    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-<    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-9    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-R    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-8    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-q    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-{    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
->    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-%    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-F    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-G    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-}    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-G    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-G    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-B    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-F    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-|    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-R    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-G    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-F    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-'    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-7    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-9    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-9    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-{    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-F    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-B    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-B    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-G    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-}    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-B    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-7    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-7    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-9    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-X    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-A    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-I    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-H    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-X    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-A    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-O    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-F    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-q    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-^    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-q    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-B    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-R    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-A    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-<    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-<    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-{    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-q    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-B    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-B    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-q    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-}    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-q    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-q    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-B    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-|    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-R    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-8    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-{    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-q    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-B    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-B    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-B    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-}    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-B    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-q    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-G    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-O    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-q    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-'    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-H    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-O    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-q    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-{    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-P    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-'    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-P    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-H    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-O    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-<    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
->    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-}    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-B    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-9    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-F    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-'    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-P    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-{    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-q    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-q    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-{    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-}    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-}    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-{    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-H    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-O    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-}    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-8    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-P    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-|    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-A    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-A    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-F    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-F    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-K    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-V    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-q    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-z    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-{    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-}    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-{    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-H    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-O    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-}    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-9    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-G    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-G    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-F    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-P    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-A    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-K    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
->    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
->    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-F    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-|    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-q    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-q    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-{    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-|    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-G    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-}    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-{    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-z    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-J    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-9    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-8    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-P    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
->    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
->    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-H    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-O    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-H    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-O    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-H    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-O    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-G    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-}    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-H    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-J    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-B    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-7    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-7    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-9    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-7    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-W    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-'    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-{    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-}    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-{    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-}    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-{    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-z    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-H    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-O    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-H    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-O    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-H    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-O    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-}    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-9    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
->    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-<    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-<    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-<    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-|    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-^    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-z    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-A    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-q    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-'    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-X    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-G    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-I    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-O    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-V    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-R    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-A    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-P    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-{    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-G    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-H    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-O    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-H    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-O    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
->    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-z    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-H    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-G    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-O    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-j    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-0    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-}    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-P    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-P    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-=    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-I    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-Q    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-I    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-Q    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-M    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-q    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-9    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-8    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-R    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-B    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-5    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-8    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-|    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-|    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
->    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
->    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
->    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
->    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-`    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-q    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-A    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-F    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-E    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-R    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-{    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-}    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-{    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-H    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-O    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-}    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-P    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-K    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-N    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-U    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-L    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-S    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-T    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-:    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-3    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-2    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-g    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-1    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-w    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-6    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-[    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-4    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-]    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
--    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
->    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-k    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-.    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-x    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-b    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-y    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-(    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-,    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-v    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-o    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-h    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-t    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-r    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-a    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-m    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-)    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-;    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-#    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-c    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-p    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-l    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-u    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-s    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-}    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-#    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-#    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-e    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-n    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-d    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-i    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-f    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-C    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-D    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-X    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-H    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-_    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-     int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-*    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-/    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
-
-    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
+/* cdx.h -- C ABI of libcdx.so, the gfx950 (MI355X) executor behind cleandiffuser_amd.
+ *
+ * The reference (CleanDiffuser) is pure Python on PyTorch and has NO FFI for this path: its boundary is the
+ * Python protocol `DiffusionModel.sample()` -> `model["diffusion"](xt, t, cond)` once per denoising step
+ * (reference cleandiffuser/diffusion/diffusionsde.py:401-606, loop body :526-594; backbone contract
+ * cleandiffuser/nn_diffusion/base_nn_diffusion.py:31-42).  This ABI is what a maintainer would bind *below*
+ * that protocol (ctypes stub in INTEGRATION.md): plain pointers and sizes, no torch types, caller-owned memory,
+ * no allocation and no synchronisation inside, work enqueued on the caller's HIP stream.
+ *
+ * Every entry point returns 0 on success or a negative CDX_E* code; cdx_last_error() gives the text.
+ */
+#ifndef CDX_H_
+#define CDX_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CDX_ABI_VERSION 5
+
+#define CDX_OK 0
+#define CDX_EINVAL (-1)   /* bad argument (null pointer, size out of range, misaligned offset) */
+#define CDX_ELDS (-2)     /* program needs more LDS than one gfx950 workgroup owns (160 KiB) */
+#define CDX_EHIP (-3)     /* HIP runtime error at launch; text in cdx_last_error() */
+
+/* ------------------------------------------------------------------------------------------------
+ * Layer program (built by cleandiffuser_amd/engine/program.py; word layout in csrc/cdx_ops.h).
+ * ---------------------------------------------------------------------------------------------- */
+#define CDX_OP_WORDS 40
+
+/* One denoising step = one record.  Replaces the per-step scalar arithmetic of the reference loop
+ * (diffusionsde.py:539-589): the host freezes alpha_i, sigma_i and the solver coefficients, the device applies
+ *   kind 0 (ddpm)   x <- k0*(x - k1*eps) + k2*eps [+ k3*z]
+ *   kind 1 (ddim)   x <- k0*((x - k1*eps)/k2) + k3*eps
+ *   kind 2 (linear) x <- k0*x - k1*V [+ k2*z],  V = eps | x_theta | (k3*x_theta - k4*x_theta_prev) | (k3*eps - k4*eps_prev)
+ *            with CDX_STEP_MASK_PRED (legacy DPMSolver class, reference diffusion/dpmsolver.py:257-264) the fix-mask is first
+ *            applied to the prediction: eps <- eps*(1-m), x_theta <- x_theta*(1-m) + x*m
+ *   kind 3/4 (legacy DDPM class, reference diffusion/ddpm.py:153-164,230-241; eps / x0 prediction):
+ *            P <- P*(1-mask) [+ x*mask];  x <- k0*(x - k1*P)  |  x <- k0*(k1*x + k2*P);  [+ k3*z]
+ *   kind 5/6 (EDM Euler / Heun corrector; reference diffusion/newedm.py:387-401, legacy edm.py:118-160,252-268):
+ *            `alpha` carries c_in (the network sees c_in*x), k = (c_skip, c_out, sigma, dt):
+ *            D = clip(k0*x + k1*F); s = (x - D)/k2;  kind 5: x' = x - k3*s (push: remember s and x);
+ *            kind 6: x' = x_old - k3*(s_old + s)/2.
+ *   kind 7 (consistency model, reference diffusion/consistency_model.py:412-427): x' = mask(D) [+ k3*z]  (re-noising for
+ *            the next level; the fix-mask is applied BEFORE the noise).   A plan is all-EDM-family (5/6/7) or not at all.
+ * followed by the fix-mask blend (diffusionsde.py:592). */
+#define CDX_STEP_MASK_PRED 1
+typedef struct cdx_step {
+    int32_t kind;        /* 0 ddpm, 1 ddim, 2 linear, 3 legacy-ddpm eps, 4 legacy-ddpm x0, 5 edm euler, 6 edm heun, 7 consistency */
+    int32_t vsel;        /* kind 2: 0 eps, 1 x_theta, 2 multistep on x_theta, 3 multistep on eps */
+    int32_t noise_idx;   /* index into `noise` of this step's N(0,I) draw, or -1 */
+    int32_t push;        /* 1: remember x_theta (2: eps) for the next multistep update; EDM: remember slope and state */
+    float alpha, sigma;  /* schedule at this step (for eps<->x conversion and clipping) */
+    float k[5];
+    int32_t flags;       /* CDX_STEP_* bits */
+} cdx_step;
+
+/* One launch = the whole request: either a full sampling loop (n_steps >= 1) or a single backbone forward
+ * (n_steps == 0: x_out <- network(x_in), replaces BaseNNDiffusion.forward for JannerUNet1d,
+ * reference nn_diffusion/jannerunet.py:154-201).  One workgroup per trajectory, activations in LDS. */
+typedef struct cdx_unet1d_launch {
+    /* program */
+    const int32_t* ops;        /* device, [n_ops][CDX_OP_WORDS] followed by the per-conv work-item tables */
+    const float* wblob;        /* device, packed parameters */
+    int32_t n_ops;
+    int32_t lds_floats;        /* total LDS floats per workgroup */
+    int32_t x_off, x_stride;   /* state slot */
+    int32_t pred_off, pred_stride, pred_branch_floats;
+    int32_t prev_off, scratch_off;
+    int32_t out_vec_off, out_vec_len; /* forward mode, vector-output programs (classifier heads): x_out is [batch][out_vec_len] */
+    /* batch-tiled MLP programs (tile > 0): one workgroup denoises `tile` samples; `horizon` == tile, tensors are
+     * (batch*tile, dim); `cond` is (batch*tile, cond_dim) and is loaded into a context slot's channel range */
+    int32_t tile, cond_slot_off, cond_slot_stride, cond_coff, cond_dim;
+    int32_t zero_off, zero_floats;    /* extra kernel-lifetime LDS range cleared once at kernel start */
+    int32_t zrow_off;                 /* shared all-zero row inside that range: what out-of-range conv taps read */
+    int32_t prof_off;             /* LDS float offset (even) of the (n_ops*8+2) x u64 stamp area; used only if prof != NULL */
+    int32_t items_in_lds;         /* 1: desc_words covers ops + item tables; 0: ops only, items are read from `ops` */
+    int32_t desc_off, desc_words; /* where the kernel keeps its copy of `ops` in LDS, and how many words it is */
+    /* problem */
+    int32_t batch, horizon, dim, emb_dim;
+    /* per-step tables */
+    const float* temb;         /* device, [max(n_steps,1)][emb_dim]: map_noise(t_step) evaluated on the host side */
+    const cdx_step* steps;     /* device, [n_steps]; NULL when n_steps == 0 */
+    int32_t n_steps;
+    int32_t temb_per_sample;   /* 1: temb is [batch][emb_dim] (forward mode with per-sample timesteps) */
+    int32_t predict_noise;     /* 1: network predicts eps, 0: network predicts x0 */
+    /* guidance: 0 = one unconditional forward, 1 = one conditional forward, 2 = both, w*c + (1-w)*u */
+    int32_t cfg_mode;
+    float cfg_w;
+    const float* cond;         /* device, [batch][emb_dim] or NULL */
+    /* tensors, all fp32, (batch, horizon, dim) row-major unless noted */
+    const float* x_in;         /* initial state x_T (already temperature-scaled and fix-masked), or forward input */
+    const float* prior;        /* or NULL */
+    const float* fix_mask;     /* [horizon][dim] or NULL */
+    const float* noise;        /* [n_noise][batch][horizon][dim] or NULL */
+    const float* x_min;        /* [horizon][dim] or NULL */
+    const float* x_max;        /* [horizon][dim] or NULL */
+    float* x_out;
+    /* optional profiling: device u64 [n_ops*8 + 2]; workgroup 0 stamps s_memtime at {op start, pre-barrier,
+     * post-barrier, op end, item record read, first operands landed, MFMAs done, K loop done} for the first forward,
+     * plus kernel start/end.  NULL = off. */
+    unsigned long long* prof;
+} cdx_unet1d_launch;
+
+/* ABI version of the loaded library (== CDX_ABI_VERSION of the header it was built from). */
+int cdx_abi_version(void);
+
+/* Text of the last error on the calling thread ("" if none). */
+const char* cdx_last_error(void);
+
+/* Enqueue the fused U-Net program kernel on `hip_stream` (a hipStream_t; NULL = default stream). */
+int cdx_unet1d_run(const cdx_unet1d_launch* launch, void* hip_stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Second-generation fused U-Net program (csrc/cdx_unet2.hip; program built by engine/program2.py, word layout in
+ * csrc/cdx_ops2.h).  Same contract as cdx_unet1d_run -- the whole DiscreteDiffusionSDE / ContinuousDiffusionSDE.sample() loop
+ * (reference diffusionsde.py:526-594 over nn_diffusion/jannerunet.py:154-201) in ONE launch, step kinds 0-4 -- for
+ * unconditional JannerUNet1d-structured denoisers, re-engineered for the per-op fixed cost: 4 or 8 wave64 per workgroup,
+ * `traj_per_wg` (1 or 2) trajectories per workgroup sharing every streamed weight record, the ResidualBlock's 1x1 skip conv
+ * fused into its second conv, and the per-block FiLM vectors Linear(Mish(map_emb(map_noise(t)))) read from a per-step table
+ * that cdx_unet2_embtab evaluates once per (weights, schedule).
+ * ---------------------------------------------------------------------------------------------- */
+#define CDX2_OP_WORDS(n_waves) (32 + 8 * (n_waves))   /* header + one inline work item per wave */
+
+/* FiLM table: out[r][:] = W3^T mish(W2^T mish(W0^T temb[r] + b0) + b2) + b3, all weights transposed [n_in][n_out] inside `wblob`
+ * at the given float offsets (reference jannerunet.py:135-136 map_emb, :57 emb_mlp of every block, stacked). */
+typedef struct cdx_unet2_embtab_args {
+    const float* wblob;
+    int32_t emb_dim, hidden, md, n_emb;
+    int32_t w0, b0, w2, b2, w3, b3;
+    const float* temb;        /* device (n_rows, emb_dim): map_noise(t) per step record */
+    int32_t n_rows;
+    float* out;               /* device (n_rows, out_ld): this network's FiLM vectors go to columns [col0, col0 + n_emb) */
+    int32_t out_ld, col0;
+    /* optional rows applied to the RAW embedding W2^T mish(...) + b2 (the HalfJannerUNet1d head's share of its first Linear,
+     * reference nn_classifier/half_jannerunet.py:62 `cat([x.flatten(1), emb])`): out[r][col4 + o] = W4^T raw + b4; n_raw = 0: none */
+    int32_t w4, b4, n_raw, col4;
+} cdx_unet2_embtab_args;
+int cdx_unet2_embtab(const cdx_unet2_embtab_args* args, void* hip_stream);
+
+typedef struct cdx_unet2_launch {
+    const int32_t* ops;        /* device, [n_ops][CDX2_OP_WORDS(n_waves)] (descriptor + first work items) followed by further work items */
+    const float* wblob;        /* device, packed parameters */
+    int32_t n_ops;
+    int32_t traj_floats;       /* LDS floats of one trajectory's region; the workgroup owns traj_per_wg of them */
+    int32_t traj_per_wg;       /* 1, 2 or 3 (3: 8-wave compact programs) */
+    int32_t n_waves;           /* 4 or 8: wave64 per workgroup; the program (work items, K slices) is compiled for one of them */
+    int32_t tune;              /* reserved for scheduling experiments (results never depend on it); 0 */
+    int32_t x_off, x_stride, pred_off, pred_stride, prev_off, stage_off;   /* relative to the trajectory region; x/pred: position 0 */
+    int32_t batch, horizon, dim;
+    /* this launch denoises trajectories [traj_first, traj_first + traj_count) of the batch (all tensors keep their full-batch
+     * indexing): lets the host run the bulk of a large batch two trajectories per workgroup and the remainder one per workgroup.
+     * Both zero: the whole batch. */
+    int32_t traj_first, traj_count;
+    const float* emb;          /* device (max(n_steps,1), emb_ld): FiLM table rows, one per step record */
+    int32_t emb_ld;
+    const cdx_step* steps;     /* device [n_steps], kinds 0-4; NULL with n_steps == 0 (one forward: x_out <- network(x_in)) */
+    int32_t n_steps, predict_noise;
+    const float* x_in;         /* (batch, horizon, dim) */
+    const float* prior;        /* or NULL */
+    const float* fix_mask;     /* (horizon, dim) or NULL */
+    const float* noise;        /* (n_noise, batch, horizon, dim) or NULL */
+    const float* x_min;        /* (horizon, dim) or NULL */
+    const float* x_max;
+    float* x_out;
+    /* init_blend != 0: x_in holds the raw N(0, I) draw z; the kernel forms x_T = (z * x_scale) * (1 - fix_mask) + prior * fix_mask
+     * while loading it (reference diffusionsde.py:509-510 `xt = randn_like(prior) * temperature; xt = xt * (1 - mask) + prior * mask`,
+     * same roundings), so the host launches nothing but this kernel.  0: x_in is x_T itself. */
+    int32_t init_blend;
+    float x_scale;
+    /* classifier guidance (programs built by engine/program2.py:compile_guided2: the ops after the denoiser's are the classifier's
+     * forward and backward-data pass, which leaves d log p / d x_t in the gradient slot): per step the prediction is shifted by
+     * cg_scale[step] * gradient before clipping (reference diffusionsde.py:153-173).  NULL: no shift.  with_backward != 0 selects
+     * the kernel variant that understands backward ops even without a shift (one forward+backward: gradients only). */
+    const float* cg_scale;     /* device [n_steps] or NULL */
+    int32_t grad_off, grad_stride, with_backward;
+    /* programs compiled with their saved normalised tensors in global memory (so that two trajectories share a workgroup): device
+     * scratch of (batch + 1) * ws_floats floats (one spare block), owned by the caller, ordered by the launch stream; ws_floats == 0: none */
+    float* ws;
+    int32_t ws_floats;
+    /* compact programs (engine/program2.py:compile_janner2(compact=True): the LDS plan that lets THREE trajectories share a
+     * workgroup): the authoritative state x_t lives in x_out and the multistep memory in ws ((batch + 1) * ws_floats floats) */
+    int32_t compact;
+    /* optional profiling: device u64 [n_ops*8 + 2]; workgroup 0 stamps s_memtime at {op start, next-op prefetch issued, after the
+     * staging barrier, op end, item record + segment read, first operands landed, MFMAs done, partial tile staged} of the first
+     * forward, plus kernel start/end.  NULL = off. */
+    unsigned long long* prof;
+} cdx_unet2_launch;
+int cdx_unet2_run(const cdx_unet2_launch* launch, void* hip_stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Big-batch building blocks (csrc/cdx_gemm.hip): when M = batch x tokens >> 256 the denoiser layers are classic
+ * GEMMs.  Tensors are fp32, row-major with explicit leading dimensions, weights in the PyTorch (N, K) layout.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* C[m][n] = act(sum_k A[m][k] W[n][k] + bias[n]) * gate[m / rows_per_gate][n] + residual[m][n] + table[m % table_rows][n]
+ * Replaces nn.Linear and its surrounding elementwise ops (reference nn_diffusion/dit.py:31-36,49,118; idqlmlp.py:12-18). */
+typedef struct cdx_gemm_args {
+    const float* A;        /* (M, K), leading dimension lda */
+    const float* W;        /* (N, K), leading dimension ldw */
+    const float* bias;     /* (N) or NULL */
+    const float* gate;     /* (M / rows_per_gate, ldg) or NULL: multiplies the activated value */
+    const float* residual; /* (M, ldr) or NULL: added after the gate */
+    const float* table;    /* (table_rows, N) or NULL: added last (positional table) */
+    float* C;              /* (M, ldc) */
+    int32_t M, N, K, lda, ldw, ldc, ldg, ldr;
+    int32_t rows_per_gate, table_rows;
+    int32_t act;           /* CDX_ACT_* of csrc/cdx_ops.h: 0 none, 1 mish, 2 gelu(erf), 3 leaky, 4 silu, 5 relu, 6 gelu(tanh), 8 tanh */
+    /* Implicit-GEMM Conv1d (conv_taps > 0): A is a channel-last activation tensor, rows = samples * conv_lin, row stride lda;
+     * output row m = (b, lo) = (m / conv_lout, m % conv_lout); K = conv_taps * conv_cin with k = tap * conv_cin + c;
+     * A[m][k] = X[b * conv_lin + lo * conv_stride + tap - conv_pad][c], zero outside [0, conv_lin).  W is (N, conv_taps, conv_cin).
+     * Replaces nn.Conv1d / (per output parity) nn.ConvTranspose1d of the temporal U-Nets (reference nn_diffusion/chiunet.py:19-28,
+     * jannerunet.py:22-36). */
+    int32_t conv_taps, conv_cin, conv_lin, conv_lout, conv_stride, conv_pad;
+    /* Split-K for launches that cannot fill the chip with 128 x 128 tiles (few rows, long K): with `partial` != NULL the library
+     * may cut K into k_split slices (chosen internally, <= partial_slices), each workgroup writes its raw partial tile to
+     * partial[slice][M][N] and a second pass sums the slices in a fixed order and applies the epilogue -- deterministic. */
+    float* partial;        /* device scratch of partial_slices * M * N floats, or NULL: never split */
+    int32_t partial_slices;
+} cdx_gemm_args;
+int cdx_gemm_f32(const cdx_gemm_args* args, void* hip_stream);
+
+/* y[m][c] = LN(x[m])[c] [* gamma[c] + beta[c]] [* (1 + scale[m / rows_per_mod][c]) + shift[...]],  C <= 4096.
+ * Replaces nn.LayerNorm(+ adaLN `modulate`) (reference dit.py:10-11,33-35,48; idqlmlp.py:14). */
+typedef struct cdx_ln_args {
+    const float* x;
+    float* y;
+    const float* gamma; const float* beta;     /* (C) or both NULL */
+    const float* scale; const float* shift;    /* (M / rows_per_mod, ldmod) or both NULL */
+    int32_t M, C, ldx, ldy, ldmod, rows_per_mod;
+    float eps;
+    int32_t x_rows;        /* > 0: input row of output row m is m % x_rows (CFG pair sharing one token stream) */
+} cdx_ln_args;
+int cdx_layernorm_f32(const cdx_ln_args* args, void* hip_stream);
+
+/* GroupNorm over (C/G channels x L positions) per sample on channel-last rows (B*L, C), then activation, FiLM and residual:
+ *   y = film_scale * act(gn(x) * gamma + beta) + film_bias + residual
+ * film = fa[row_a] + fb[b] (either may be NULL) laid out [scale (C) | bias (C)] (film_mode 1) or [bias (C)] (film_mode 2); row_a is
+ * fa_row, or b when fa_per_sample.  Replaces GroupNorm1d + Mish + the FiLM modulation + the block's skip add (reference
+ * utils/building_blocks.py:60-76, nn_diffusion/chiunet.py:19-44, jannerunet.py:60-95). */
+typedef struct cdx_gn_args {
+    const float* x;
+    float* y;
+    const float *gamma, *beta;       /* (C) */
+    const float *fa, *fb;            /* FiLM tables or NULL */
+    const float* residual;           /* (B*L, ldr) or NULL */
+    int32_t B, L, C, G, ldx, ldy, ldr, ldfa, ldfb, fa_row, fa_per_sample, film_mode, act;
+    float eps;
+} cdx_gn_args;
+int cdx_groupnorm_f32(const cdx_gn_args* args, void* hip_stream);
+/* Backward of y = act(gn(x) * gamma + beta) w.r.t. x (classifier guidance, reference classifier/base.py:74-79 asks autograd
+ * for d logp / d x): same argument block with `x` = the saved forward input, `residual` = d loss / d y (row stride ldr),
+ * `y` = d loss / d x; act must be CDX_ACT_MISH or CDX_ACT_NONE; the FiLM fields are ignored. */
+int cdx_groupnorm_bwd_f32(const cdx_gn_args* args, void* hip_stream);
+
+/* out[b][t][h*d..] = softmax(q k^T * scale) v per (batch, head); qkv = (B*T, 3*n_heads*head_dim) from in_proj.
+ * Replaces the core of nn.MultiheadAttention(batch_first=True) (reference dit.py:20,34).  T <= 64, head_dim <= 64. */
+typedef struct cdx_attn_args {
+    const float* qkv;
+    float* out;            /* (B*T, n_heads*head_dim) */
+    int32_t B, T, n_heads, head_dim;
+    float scale;
+    const float* mask;     /* (T, T) additive mask on the scores, row = query (0 / -inf as nn.Transformer builds them) or NULL */
+} cdx_attn_args;
+int cdx_attention_f32(const cdx_attn_args* args, void* hip_stream);
+
+/* Cross-attention of T queries against a short memory of S = 1 + n_obs keys per sample: key 0 is a token shared by the whole
+ * batch (the timestep token: row `shared_row` of kv_shared, or row b when shared_per_sample), keys 1.. are per-sample rows of
+ * kv_rows.  q: (B*T, d); kv_*: (.., 2d) = [k | v] as in_proj[d:3d] produces them; mask: (T, S) additive or NULL.
+ * Replaces the memory attention of nn.TransformerDecoderLayer (reference nn_diffusion/chitransformer.py:101-104, 148-155). */
+typedef struct cdx_xattn_args {
+    const float* q;
+    const float* kv_shared;    /* (rows, 2d) */
+    const float* kv_rows;      /* (B * n_obs, 2d) */
+    const float* mask;
+    float* out;                /* (B*T, d) */
+    int32_t B, T, n_obs, n_heads, head_dim, shared_row, shared_per_sample;
+    float scale;
+} cdx_xattn_args;
+int cdx_cross_attention_f32(const cdx_xattn_args* args, void* hip_stream);
+
+/* y = act(x) elementwise (batch-invariant embedding vectors: SiLU before adaLN, Mish in map_emb). */
+int cdx_act_f32(const float* x, float* y, long long n, int act, void* hip_stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Big-batch sampling loops (csrc/cdx_bigbatch.hip): the whole `sample()` request for the GEMM-shaped denoisers.
+ * One call enqueues every kernel of every denoising step on the caller's stream (no host synchronisation, no
+ * allocation: the caller owns `workspace`).  The step records are the same cdx_step as above but live in HOST
+ * memory here, because the host sequences the launches (all step kinds of cdx_step, EDM kinds 5/6 included).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct cdx_sampling {
+    int32_t batch;             /* trajectories */
+    int32_t hd;                /* floats per trajectory (tokens*in_dim, or the MLP's x dimension) */
+    int32_t emb_dim;           /* width of one `temb` row */
+    int32_t cond_dim;          /* width of one `cond` row (DiT1d: == emb_dim; residual MLP: obs_dim) */
+    const float* temb;         /* device, [max(n_steps,1)][emb_dim] (one row per step record), or [batch][emb_dim] */
+    const cdx_step* steps;     /* HOST, [n_steps]; n_steps == 0: one backbone forward x_out <- network(x_in) */
+    int32_t n_steps, temb_per_sample, predict_noise;
+    int32_t cfg_mode;          /* 0 unconditional, 1 conditional, 2 both: w*c + (1-w)*u on a doubled batch */
+    float cfg_w;
+    const float* cond;         /* device, [batch][cond_dim] or NULL */
+    const float* x_in;         /* (batch, hd) */
+    const float* prior;        /* (batch, hd) or NULL */
+    const float* fix_mask;     /* (hd) or NULL */
+    const float* noise;        /* [n_noise][batch][hd] or NULL */
+    const float* x_min;        /* (hd) or NULL */
+    const float* x_max;        /* (hd) or NULL */
+    float* x_out;              /* (batch, hd) */
+    float* workspace;          /* device scratch, >= cdx_*_workspace_floats() floats */
+    long long workspace_floats;
+    int32_t chunk;             /* trajectories per pass through the loop (0 = whole batch); passes are independent */
+} cdx_sampling;
+
+/* DiT1d (reference nn_diffusion/dit.py:14-36 DiTBlock, :39-50 FinalLayer1d, :53-132 DiT1d): all tensors are the
+ * checkpoint's own (PyTorch layouts), `pos` is the (tokens, d_model) sinusoidal table of dit.py:122-125. */
+typedef struct cdx_dit1d_block {
+    const float *ada_w, *ada_b;       /* adaLN_modulation.1: (6d, d), (6d) */
+    const float *qkv_w, *qkv_b;       /* attn.in_proj_{weight,bias}: (3d, d), (3d) */
+    const float *proj_w, *proj_b;     /* attn.out_proj: (d, d), (d) */
+    const float *fc1_w, *fc1_b;       /* mlp.0: (4d, d), (4d) */
+    const float *fc2_w, *fc2_b;       /* mlp.3: (d, 4d), (d) */
+} cdx_dit1d_block;
+typedef struct cdx_dit1d_weights {
+    int32_t tokens, in_dim, emb_dim, d_model, n_heads, depth;
+    const float *x_proj_w, *x_proj_b; /* (d, in_dim), (d) */
+    const float* pos;                 /* (tokens, d) */
+    const float *map0_w, *map0_b;     /* map_emb.0: (d, emb_dim), (d) */
+    const float *map2_w, *map2_b;     /* map_emb.2: (d, d), (d) */
+    const cdx_dit1d_block* blocks;    /* HOST array [depth] of device pointers */
+    const float *fin_ada_w, *fin_ada_b; /* final_layer.adaLN_modulation.1: (2d, d), (2d) */
+    const float *fin_w, *fin_b;       /* final_layer.linear: (in_dim, d), (in_dim) */
+} cdx_dit1d_weights;
+long long cdx_dit1d_workspace_floats(const cdx_dit1d_weights* w, const cdx_sampling* s);
+int cdx_dit1d_run(const cdx_dit1d_weights* w, const cdx_sampling* s, void* hip_stream);
+
+/* ChiTransformer (reference nn_diffusion/chitransformer.py:61-158) with the MLP condition encoder (n_cond_layers == 0):
+ * memory = encoder([map_noise(t) | obs_emb(obs)] + cond_pos_emb); decoder layers are nn.TransformerDecoderLayer(norm_first, gelu):
+ * h += SA(LN1 h, causal mask); h += CA(LN2 h, memory, memory mask); h += FF(LN3 h); out = head(LN_f h).
+ * The memory and its per-layer K/V projections do not depend on x: they are evaluated once per request (observation tokens)
+ * and once per step record (timestep token) before the loop.  `temb` rows are map_noise(t) (width d_model); `cond` is
+ * (batch, To*obs_dim) or NULL (= zero observations, as the reference substitutes). */
+typedef struct cdx_chitf_layer {
+    const float *ln1_g, *ln1_b, *sa_in_w, *sa_in_b, *sa_out_w, *sa_out_b;      /* norm1, self_attn.in_proj (3d,d), out_proj */
+    const float *ln2_g, *ln2_b, *ca_in_w, *ca_in_b, *ca_out_w, *ca_out_b;      /* norm2, multihead_attn.in_proj (3d,d), out_proj */
+    const float *ln3_g, *ln3_b, *ff1_w, *ff1_b, *ff2_w, *ff2_b;                /* norm3, linear1 (4d,d), linear2 (d,4d) */
+} cdx_chitf_layer;
+typedef struct cdx_chitf_weights {
+    int32_t Ta, To, act_dim, obs_dim, d_model, n_heads, n_layers;
+    const float *act_emb_w, *act_emb_b;      /* (d, act_dim) */
+    const float* pos_emb;                    /* (Ta, d) */
+    const float *obs_emb_w, *obs_emb_b;      /* (d, obs_dim) */
+    const float* cond_pos_emb;               /* (1 + To, d) */
+    const float *enc0_w, *enc0_b, *enc2_w, *enc2_b;   /* encoder.0 (4d, d), encoder.2 (d, 4d) */
+    const cdx_chitf_layer* layers;           /* HOST array [n_layers] of device pointers */
+    const float *lnf_g, *lnf_b, *head_w, *head_b;     /* ln_f, head (act_dim, d) */
+    const float* self_mask;                  /* (Ta, Ta) additive */
+    const float* memory_mask;                /* (Ta, 1 + To) additive */
+} cdx_chitf_weights;
+long long cdx_chitf_workspace_floats(const cdx_chitf_weights* w, const cdx_sampling* s);
+int cdx_chitf_run(const cdx_chitf_weights* w, const cdx_sampling* s, void* hip_stream);
+
+/* ChiUNet1d with global conditioning at large batch (reference nn_diffusion/chiunet.py:13-192): every Conv1d is an implicit GEMM
+ * over (batch * L) rows, GroupNorm + Mish + FiLM + skip add is one pass (cdx_groupnorm_f32).  Conv weights are PACKED by the
+ * host once per weight version: Conv1d (c_out, c_in, k) -> (c_out, k, c_in); ConvTranspose1d(k4 s2 p1) -> two (c_out, 2, c_in)
+ * kernels, one per output parity (engine/blocks.py:pack_conv*).  FiLM = cond_encoder.1([mish(time emb) | mish(obs emb)]) is
+ * separable, so its time half is evaluated once per step record and its observation half once per request, before the loop.
+ * `temb` rows are map_noise(t) (width emb_dim); `cond` is (batch, cond_dim) and required. */
+typedef struct cdx_chiunet_block {
+    int32_t cin_a, cin_b, cout, groups;      /* input = channel concat [a | b] (cin_b == 0: single input) */
+    const float *w1a, *w1b, *b1, *g1, *be1;  /* conv1 split by input part, GroupNorm affine */
+    const float *w2, *b2, *g2, *be2;
+    const float *film_w, *film_b;            /* cond_encoder.1: (film_out, 2 emb_dim), (film_out) */
+    const float *wra, *wrb, *br;             /* residual 1x1 conv split by input part, or all NULL (identity) */
+} cdx_chiunet_block;
+typedef struct cdx_chiunet_weights {
+    int32_t act_dim, Ta, cond_dim, emb_dim, kernel_size, n_levels, cond_predict_scale, model_dim, final_groups;
+    /* The same executor serves the unconditional JannerUNet1d (reference nn_diffusion/jannerunet.py:98-201): its blocks add
+     * Linear(Mish(emb)) as a per-channel bias (cond_predict_scale = 0), the embedding MLP is emb_dim -> emb_hidden -> emb_out
+     * and there is no observation half (cond_dim = 0, film_ld = emb_out).  ChiUNet1d: emb_hidden = 4 emb_dim, emb_out = emb_dim,
+     * film_ld = 2 emb_dim. */
+    int32_t emb_hidden, emb_out, film_ld;
+    const float *map0_w, *map0_b, *map2_w, *map2_b;     /* map_emb.0 (emb_hidden, emb_dim), map_emb.2 (emb_out, emb_hidden) */
+    const float *gce_w, *gce_b;                         /* global_cond_encoder (emb_out, cond_dim), or NULL when cond_dim == 0 */
+    const cdx_chiunet_block* blocks;                    /* HOST [2 n_levels + 2 + 2 (n_levels - 1)]: downs, mids, ups */
+    const float* const* down_w;                         /* HOST [n_levels - 1] packed (C, 3, C) */
+    const float* const* down_b;
+    const float* const* up_w_even;                      /* HOST [n_levels - 1] packed (C, 2, C) */
+    const float* const* up_w_odd;
+    const float* const* up_b;
+    const float *fin_w, *fin_b, *fin_g, *fin_be;        /* final_conv.0 packed (md, k, md), final_conv.1 GroupNorm */
+    const float *out_w, *out_b;                         /* final_conv.3 1x1 (act_dim, md) */
+} cdx_chiunet_weights;
+long long cdx_chiunet_workspace_floats(const cdx_chiunet_weights* w, const cdx_sampling* s);
+int cdx_chiunet_run(const cdx_chiunet_weights* w, const cdx_sampling* s, void* hip_stream);
+
+/* Classifier guidance: (logp, d logp.sum() / d x) of HalfJannerUNet1d by explicit forward + backward launches -- what
+ * BaseClassifier.gradients asks torch.autograd for once per denoising step (reference classifier/base.py:74-79,
+ * nn_classifier/half_jannerunet.py:102-125, diffusionsde.py:153-173).  Weights are packed by the host (engine/classifier_grad.py):
+ * forward convs (c_out, k, c_in); backward-data convs tap-flipped and transposed (c_in, k, c_out); the stride-2 downsample's
+ * backward as an even (1 tap) and an odd (2 taps) kernel.  `emb0` = map_noise(t) [+ condition], one row per sample. */
+typedef struct cdx_hj_block {
+    int32_t cin, cout, k, groups;
+    const float *w1, *b1, *w1_bwd, *g1, *be1;
+    const float *w2, *b2, *w2_bwd, *g2, *be2;
+    const float *emb_w, *emb_b;              /* emb_mlp.1: (cout, model_dim) */
+    const float *wr, *br, *wr_bwd;           /* residual 1x1 conv (cout, 1, cin) / (cin, 1, cout), or NULL: identity */
+} cdx_hj_block;
+typedef struct cdx_hj_down {
+    int32_t c;
+    const float *w, *b, *bwd_even, *bwd_odd; /* (c, 3, c), (c), (c, 1, c), (c, 2, c) */
+} cdx_hj_down;
+typedef struct cdx_hjgrad_weights {
+    int32_t horizon, in_dim, model_dim, emb_dim, out_dim, fc_hidden, c_last, l_last, n_stages;
+    const int32_t* stage_kind;               /* HOST [n_stages]: 0 = next residual block, 1 = next downsample */
+    const cdx_hj_block* blocks;              /* HOST */
+    const cdx_hj_down* downs;                /* HOST */
+    const float *map0_w, *map0_b, *map2_w, *map2_b;
+    const float *fc1_wx, *fc1_wx_t, *fc1_we, *fc1_b;   /* final_block.0 split: flattened part in [l][c] order (+ transpose), emb part */
+    const float *fc2_w, *fc2_b, *fc2_w_t;              /* final_block.2 (+ transpose) */
+} cdx_hjgrad_weights;
+long long cdx_hjgrad_workspace_floats(const cdx_hjgrad_weights* w, int32_t batch);
+/* emb0_ld: row stride of emb0 in floats; 0 = one row shared by the whole batch (the sampling loop: same t for every sample). */
+int cdx_hjgrad_run(const cdx_hjgrad_weights* w, const float* x, const float* emb0, int32_t emb0_ld, int32_t batch, float* logp,
+                   float* grad, float* workspace, long long workspace_floats, void* hip_stream);
+
+/* Classifier-guided sampling loop (reference diffusionsde.py:526-594 with w_cg > 0, the configuration every shipped Diffuser
+ * pipeline runs): per step record  pred <- backbone(x, t)  [program kernel, forward mode];  (logp, g) <- classifier gradient;
+ * pred <- pred - w sigma g (eps prediction) | pred + w sigma^2/alpha g (x0 prediction)  [cg_scale[i], host-frozen];  then clip,
+ * solver update and fix-mask exactly as in the unguided loop.  All launches of all steps are enqueued by this one call.
+ * Streams: the denoiser launch of each step is issued on a library-owned side stream (one per device, created on first use)
+ * forked from and joined back into `hip_stream` with events, so that it overlaps the classifier's launches; every side-stream
+ * launch is joined before the call returns, i.e. the caller only ever has to order against `hip_stream`.  Environment
+ * CDX_GUIDED_OVERLAP=0 keeps everything on `hip_stream`. */
+typedef struct cdx_guided_launch {
+    const cdx_unet1d_launch* denoiser;   /* a forward-mode launch description (n_steps = 0); temb/x_in/x_out are set per step;
+                                          * NULL when the denoiser runs on the implicit-GEMM executor (denoiser_gemm) */
+    const cdx_hjgrad_weights* classifier;
+    const cdx_step* steps;               /* HOST [n_steps], kinds 0-2 */
+    const float* cg_scale;               /* HOST [n_steps]: factor of the gradient added to the prediction at step i */
+    int32_t n_steps, batch, hd, predict_noise;
+    const float* temb;                   /* device (n_steps, denoiser emb_dim) */
+    const float* clf_emb0;               /* device (n_steps, classifier emb_dim): classifier map_noise(t_i) */
+    const float *x_in, *prior, *fix_mask, *noise, *x_min, *x_max;
+    float* x_out;
+    float* workspace;                    /* >= cdx_guided_workspace_floats() */
+    long long workspace_floats;
+    /* nets whose LDS plan exceeds one workgroup (the shipped antmaze Diffuser: model_dim 64, H = 64): the per-step denoiser forward
+     * is the implicit-GEMM U-Net executor (what cdx_chiunet_run runs in forward mode) -- the guided loop is still ONE call */
+    const cdx_chiunet_weights* denoiser_gemm;   /* or NULL */
+    int32_t denoiser_emb_dim, denoiser_chunk;   /* width of one temb row; trajectories per pass (0 = whole batch) */
+} cdx_guided_launch;
+long long cdx_guided_workspace_floats(const cdx_guided_launch* g);
+int cdx_guided_run(const cdx_guided_launch* g, void* hip_stream);
+
+/* Pre-norm residual MLP = IDQLMlp / NewIDQLMlp (reference nn_diffusion/idqlmlp.py:9-18 ResidualBlock, :21-65, :68-112):
+ * features [x | time_mlp(map_noise(t)) | obs] -> affine_in -> n x (h + fc2(mish(fc1(LN(h))))) -> [mish] -> affine_out.
+ * `temb` of the request is the table AFTER time_mlp (batch-invariant during sampling). */
+typedef struct cdx_resmlp_block {
+    const float *ln_g, *ln_b;         /* net.1: (h), (h) */
+    const float *fc1_w, *fc1_b;       /* net.2: (4h, h), (4h) */
+    const float *fc2_w, *fc2_b;       /* net.4: (h, 4h), (h) */
+} cdx_resmlp_block;
+typedef struct cdx_resmlp_weights {
+    int32_t x_dim, emb_dim, obs_dim, hidden, n_blocks, head_mish;
+    const float *in_w, *in_b;         /* affine_in: (h, x_dim+emb_dim+obs_dim), (h) */
+    const cdx_resmlp_block* blocks;   /* HOST array [n_blocks] of device pointers */
+    const float *out_w, *out_b;       /* affine_out: (x_dim, h), (x_dim) */
+} cdx_resmlp_weights;
+long long cdx_resmlp_workspace_floats(const cdx_resmlp_weights* w, const cdx_sampling* s);
+int cdx_resmlp_run(const cdx_resmlp_weights* w, const cdx_sampling* s, void* hip_stream);
+
+/* Profiling hook: device buffer of [n_workgroups][4] u64 that every following cdx_gemm_f32 launch stamps with s_memtime
+ * (start, first tile staged, K loop done, epilogue done); NULL switches it off.  Synchronise before changing it. */
+int cdx_gemm_set_trace(unsigned long long* device_buffer);
+
+/* Test hook: runs v_mfma_f32_16x16x4_f32 and v_mfma_f32_4x4x1_16b_f32 on fixed operands
+ * (digit-coded lane ids, see csrc/cdx_unet1d.hip) and writes out[4][64][4] so the lane->element maps the kernels
+ * rely on are checked on the actual silicon. */
+int cdx_probe_mfma_layout(float* out_device, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CDX_H_ */
