@@ -10,6 +10,9 @@ import bench  # noqa: E402
 from cleandiffuser_amd.engine import program as P, runtime  # noqa: E402
 
 
+os.environ.setdefault("CDX_UNET2", "0")      # this tool stamps the FIRST program kernel (cdx_unet1d_kernel); tools/op_profile2.py is the v2 one
+
+
 def main():
     batch = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     model_dim = int(sys.argv[2]) if len(sys.argv) > 2 else 32
