@@ -177,6 +177,7 @@ class _Builder2:
                                            # programs for two trajectories per workgroup keep it small)
         self.alias_residual = False        # write identity-residual block outputs in place over their input slot
         self.wrap_live: List[Act] = []     # non-persistent slots that the solver step writes for op 0 of the next forward (the state)
+        self.keep_to_end: List[Act] = []   # arena slots the solver step reads after the last op (prediction / gradient of a guided program)
         self.save_global = False
         self.ws_floats = 0                 # per-trajectory global workspace (saved x_hat tensors) when save_global
         self.allow_4x4 = True
@@ -468,6 +469,8 @@ class _Builder2:
             for a in oa["reads"] + oa["writes"]:
                 first.setdefault(a.uid, i)
                 last[a.uid] = i
+        for a in self.keep_to_end:
+            last[a.uid] = len(self.op_acts) - 1
         root = {}                                            # aliased slot uid -> uid of the slot whose storage it shares
         if self.alias_residual:
             for i, oa in enumerate(self.op_acts):
@@ -812,8 +815,10 @@ def compile_guided2(net, clf, horizon: int, max_lds_bytes: int = 160 * 1024, nw:
         b.max_stage = max_stage
     d = net.in_dim
     x = b.act(horizon, d, persistent=True)
-    pred = b.act(horizon, d, persistent=True)            # outlives the classifier ops
-    grad = b.act(horizon, d, persistent=True)
+    # prediction and gradient are arena slots that stay live until the solver step has read them (the prediction through all of the
+    # classifier's ops, whose own footprint is small next to the denoiser's peak): ~2 slots less than keeping them persistent
+    pred, grad = b.act(horizon, d), b.act(horizon, d)
+    b.keep_to_end += [pred, grad]
     t, fc, blocks = _lower_janner(b, net, horizon, x)
     b.conv([t], pred, _conv1d_eff(fc[3]), fc[3].bias, pred=True)
     n_den = len(b.ops)
@@ -821,7 +826,7 @@ def compile_guided2(net, clf, horizon: int, max_lds_bytes: int = 160 * 1024, nw:
     cblocks, (lin1, head_off) = _lower_half_janner_grad(b, clf, horizon, x, grad)
     fcw = lin1.in_features - clf.model_dim
     emb_clf = _emb_table_spec(b, clf, cblocks, dev, raw_rows=(lin1.weight.detach()[:, fcw:], lin1.bias.detach(), head_off))
-    prog = _finalize2(b, [emb_den, emb_clf], x, pred, horizon, d, net.emb_dim, max_lds_bytes, [pred, grad], grad=grad)
+    prog = _finalize2(b, [emb_den, emb_clf], x, pred, horizon, d, net.emb_dim, max_lds_bytes, [], grad=grad)
     prog.meta["n_den"] = n_den
     prog.ws_floats = b.ws_floats
     return prog

@@ -334,7 +334,14 @@ def compiled_guided2(net, clf_net, horizon: int, two: bool = False) -> _Compiled
     with torch.no_grad():
         try:
             kw = dict(save_global=True, max_stage=GUIDED_T2_STAGE, max_lds_bytes=80 * 1024) if two else {}
-            comp = _Compiled2(P2.compile_guided2(net, clf_net, horizon, **kw), sig)
+            try:
+                comp = _Compiled2(P2.compile_guided2(net, clf_net, horizon, **kw), sig)
+            except ValueError:
+                if two:
+                    raise
+                # wider nets (model_dim 64 at H = 32: the kitchen Diffuser): one trajectory per workgroup with the saved tensors in
+                # the global workspace
+                comp = _Compiled2(P2.compile_guided2(net, clf_net, horizon, save_global=True), sig)
         except (ValueError, AssertionError) as e:
             comp = _Compiled2(None, sig, str(e))
     per[key] = comp

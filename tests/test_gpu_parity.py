@@ -867,7 +867,8 @@ def test_janner_beyond_one_workgroup_takes_gemm_executor(name, horizon, amd_lib,
 def test_shipped_large_diffuser_configs_stay_native(size, amd_lib, monkeypatch):
     """The two shipped Diffuser / AdaptDiffuser configurations with model_dim 64, against fixtures of the real reference
     (stand-alone forward, unguided loop, guided loop, classifier log_p) at 1e-4.  kitchen (H = 32, D = 69) fits a program kernel
-    (v2: 141 KB; v1 without the EDM-only buffers: 159.7 KB): fused unguided loop, one-call guided loop.  antmaze (H = 64, D = 37)
+    (v2: 141 KB; v1 without the EDM-only buffers: 159.7 KB): fused unguided loop; the guided loop is ONE launch of the guided program
+    (denoiser + classifier forward / backward ops, saved tensors in the global workspace, one trajectory per workgroup: 141 KB).  antmaze (H = 64, D = 37)
     fits neither: unguided sampling is one implicit-GEMM executor call, and the guided loop is one cdx_guided_run call that runs the
     same executor for its per-step denoiser forward."""
     from cleandiffuser_amd.engine import classifier_grad, guided, runtime

@@ -106,20 +106,31 @@ def test_v2_refuses_what_it_cannot_run(amd_lib):
 
 
 @pytest.mark.parametrize("two", [False, True])
-@pytest.mark.parametrize("shape", [(16, 6, [1, 2]), (32, 23, [1, 2, 2, 2])])
+@pytest.mark.parametrize("shape", [(16, 6, [1, 2], 32), (32, 23, [1, 2, 2, 2], 32), (32, 69, [1, 2, 2, 2], 64)])
 def test_lane_sim2_guided_program_gradient_matches_autograd(shape, two, amd_lib):
     """Guided program (engine/program2.py:compile_guided2): the denoiser's ops followed by the HalfJannerUNet1d classifier's forward
     and backward-data ops (saved x_hat / rstd, tap-flipped transposed weights, the stride-2 scatter as two parity convs, the
     GroupNorm -> Mish backward epilogue, the head op).  The lane-level twin of the kernel must reproduce the denoiser forward AND
     torch.autograd's d classifier(x, t).sum() / d x of the module (bit-identical to the reference's, tests/test_module_mirrors.py)."""
     from cleandiffuser_amd.utils import load_synth
-    H, D, dm = shape
-    net = load_synth(amd_lib.JannerUNet1d(D, model_dim=32, emb_dim=32, dim_mult=dm, kernel_size=5), 0).eval()
-    clf = load_synth(amd_lib.HalfJannerUNet1d(H, D, out_dim=1, model_dim=32, emb_dim=32, dim_mult=tuple(dm), kernel_size=3), 1).eval()
+    H, D, dm, md = shape
+    net = load_synth(amd_lib.JannerUNet1d(D, model_dim=md, emb_dim=md, dim_mult=dm, kernel_size=5), 0).eval()
+    clf = load_synth(amd_lib.HalfJannerUNet1d(H, D, out_dim=1, model_dim=md, emb_dim=md, dim_mult=tuple(dm), kernel_size=3), 1).eval()
     # `two`: the variant for two trajectories per workgroup -- saved tensors in the global workspace, capped staging area
-    prog = P2.compile_guided2(net, clf, H, **(dict(save_global=True, max_stage=2304) if two else {}))
+    # model_dim 64 (the shipped kitchen Diffuser: H = 32, D = 69) fits ONE trajectory per workgroup, and only with the saved tensors
+    # in the global workspace
+    if md == 64:
+        if two:
+            with pytest.raises(ValueError):
+                P2.compile_guided2(net, clf, H, save_global=True, max_stage=2304, max_lds_bytes=80 * 1024)
+            return
+        with pytest.raises(ValueError):
+            P2.compile_guided2(net, clf, H)
+        prog = P2.compile_guided2(net, clf, H, save_global=True)
+    else:
+        prog = P2.compile_guided2(net, clf, H, **(dict(save_global=True, max_stage=2304) if two else {}))
     assert prog.nw == 8 and prog.lds_bytes(2 if two else 1) <= 160 * 1024 and prog.grad_off > 0 and len(prog.embtabs) == 2
-    assert (prog.ws_floats > 0) == two
+    assert (prog.ws_floats > 0) == (two or md == 64)
     n_den = prog.meta["n_den"]
     assert all(int(op[P2.W2_FLAGS]) & (P2.F2_SAVE | P2.F2_GNBWD | P2.F2_DUAL) == 0 for op in prog.ops[:n_den])
     assert sum(int(op[P2.W2_KIND]) == P2.KIND2_HEAD for op in prog.ops) == 1
