@@ -48,6 +48,8 @@
 #define CDX2_KIND2_CONV 0
 #define CDX2_KIND2_HEAD 1      /* classifier head, forward + backward (words: COUT hidden, LOUT/LCOLS positions/channels, RES src,
                                 * DST gradient slot, BOFF W1x [l][c][hidden], GAMMA w2, EMB table offset) */
+#define CDX2_KIND2_LOADX 2     /* compact guided programs: slot DST (COUT channels, LOUT positions) <- the trajectory's state x_t, read
+                                * back from the launch's x_out (where compact programs keep it); halo rows and pad channels zeroed */
 #define CDX2_W2_ITEM0 32
 
 #define CDX2_I2_WOFF 0

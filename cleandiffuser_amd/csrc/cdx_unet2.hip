@@ -643,6 +643,26 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
         for (int t = 0; t < T; ++t) run_head<WG<NWV>::THREADS>(L, vd, emb_row, lds + t * tf, tid);
         return;
     }
+    if (BWD && CDX2_DW(vd, CDX2_W2_KIND) == CDX2_KIND2_LOADX) {      // the classifier's copy of x_t, from global memory
+        it = inline_item(vdn);
+        if (wave < CDX2_DW(vdn, CDX2_W2_NITEMS)) prefetch_ring(it, L.wblob, lane, ring);
+        const int dst = CDX2_DW(vd, CDX2_W2_DST), dstr = CDX2_DW(vd, CDX2_W2_DST_STRIDE);
+        const int len = CDX2_DW(vd, CDX2_W2_LOUT), ch = CDX2_DW(vd, CDX2_W2_COUT);
+        const int b_end = L.traj_first + L.traj_count;
+        const KArg* S = kernarg();                                   // (read on demand: see the solver step)
+        asm volatile("" : "+s"(S));
+#pragma unroll 1
+        for (int t = 0; t < T; ++t) {
+            const float* __restrict__ xg = S->x_out + (size_t)(b0 + t) * len * ch;
+            const bool real = b0 + t < b_end;
+            for (int i = tid; i < (len + 2 * CDX2_HALO2) * dstr; i += WG<NWV>::THREADS) {
+                const int r = i / dstr, c = i - r * dstr, n = r - CDX2_HALO2;
+                lds[t * tf + dst + i] = (real && n >= 0 && n < len && c < ch) ? xg[n * ch + c] : 0.f;
+            }
+        }
+        __syncthreads();
+        return;
+    }
     const int flags = CDX2_DW(vd, CDX2_W2_FLAGS), coutp = CDX2_DW(vd, CDX2_W2_COUTP), shift = CDX2_DW(vd, CDX2_W2_CG4_SHIFT);
     const int l_out = CDX2_DW(vd, CDX2_W2_LOUT), sstride = CDX2_DW(vd, CDX2_W2_SSTRIDE);
     const Geom g{CDX2_DW(vd, CDX2_W2_LCOLS), CDX2_DW(vd, CDX2_W2_CSTRIDE), CDX2_DW(vd, CDX2_W2_OSTRIDE), sstride, L.stage_off};
@@ -861,6 +881,15 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
                 tl[xo] = xn;
                 if (S->compact) S->x_out[xbase + e] = xn;
             }
+            if (S->compact) {
+                // the LDS state slot of a compact program is an arena slot: other tensors lived there during the forward, so its halo
+                // rows and pad channels are rewritten with the zeros every conv source needs
+                const int xs = S->x_stride, xb = S->x_off - CDX2_HALO2 * xs;
+                for (int i = tid; i < (H + 2 * CDX2_HALO2) * xs; i += THREADS) {
+                    const int r = i / xs, c = i - r * xs;
+                    if (r < CDX2_HALO2 || r >= H + CDX2_HALO2 || c >= D) tl[xb + i] = 0.f;
+                }
+            }
         }
         __syncthreads();
     }
@@ -971,6 +1000,7 @@ int cdx_unet2_run(const cdx_unet2_launch* L, void* hip_stream) {
     if (lds_bytes > 160u * 1024u) { cdx_set_err("program needs more than 160 KiB of LDS"); return CDX_ELDS; }
     const bool guided = L->cg_scale != nullptr || L->with_backward != 0;
     if (guided && L->n_waves != 8) { cdx_set_err("programs with backward ops (classifier guidance) run in the 8-wave shape only"); return CDX_EINVAL; }
+    if (guided && L->compact && L->traj_per_wg != 1) { cdx_set_err("compact programs with backward ops: one trajectory per workgroup"); return CDX_EINVAL; }
     if (guided && L->ws_floats > 0 && !L->ws) { cdx_set_err("program keeps saved tensors in a global workspace: ws == NULL"); return CDX_EINVAL; }
     if (L->ws_floats < 0 || (L->ws_floats & 3)) { cdx_set_err("ws_floats must be a non-negative multiple of 4"); return CDX_EINVAL; }
     if (L->cg_scale && (L->grad_off < 0 || (L->grad_off & 3) || (L->grad_stride & 3))) { cdx_set_err("cg_scale given without a gradient slot"); return CDX_EINVAL; }

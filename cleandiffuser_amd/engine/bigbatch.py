@@ -447,7 +447,7 @@ UNET_GEMM_MIN_BATCH = int(os.environ.get("CDX_UNET_GEMM_MIN_BATCH", 96))   # mea
 JANNER_GEMM_MIN_BATCH = int(os.environ.get("CDX_JANNER_GEMM_MIN_BATCH", 2048))   # config-2 net: 0.39x at 256, 0.89x at 1024, 1.16x at 3200
 
 
-def is_chiunet_gemm(module, batch: int, horizon: Optional[int] = None, edm: bool = False) -> bool:
+def is_chiunet_gemm(module, batch: int, horizon: Optional[int] = None, edm: bool = False, forward: bool = False) -> bool:
     """Should this U-Net request go to the implicit-GEMM executor?  Yes from the measured crossover batch up, and -- when the
     horizon is given -- for configurations the one-workgroup program kernel cannot hold at all (wide / long nets whose
     activations exceed the LDS plan): those would otherwise drop to the PyTorch executor."""
@@ -457,7 +457,13 @@ def is_chiunet_gemm(module, batch: int, horizon: Optional[int] = None, edm: bool
         if horizon is not None and not edm:
             from . import runtime2           # the second-generation program kernel keeps its lead at every batch size (two
             if batch >= runtime2.min_batch() and runtime2.supported(module, horizon) is None:   # co-resident workgroups per CU)
-                return False
+                if not runtime2.compact_only(module, horizon):
+                    return False
+                # nets that fit only as a compact one-trajectory program (antmaze Diffuser, H = 128 plans): their sampling loops
+                # take the kernel at every batch size (measured, antmaze size: 10.9 k vs 6.0 k trajectories/s at B = 256, 13.3 k vs
+                # 11.5 k at B = 3200); stand-alone forwards (`forward`: per-sample timesteps, which that kernel does not do) stay here
+                if not forward:
+                    return False
         big = batch >= JANNER_GEMM_MIN_BATCH
     elif type(module) is ChiUNet1d and module.obs_as_global_cond:
         big = batch >= UNET_GEMM_MIN_BATCH

@@ -30,7 +30,7 @@ def try_backbone_forward(module, x, noise, condition) -> Optional[torch.Tensor]:
         return bigbatch.resmlp_forward(module, x, noise, condition)
     if bigbatch.is_chitf(module):
         return bigbatch.chitf_forward(module, x, noise, condition)
-    if bigbatch.is_chiunet_gemm(module, x.shape[0], x.shape[1] if x.dim() == 3 else None):
+    if bigbatch.is_chiunet_gemm(module, x.shape[0], x.shape[1] if x.dim() == 3 else None, forward=True):
         y = bigbatch.chiunet_forward(module, x, noise, condition)
         if y is not None:
             return y

@@ -56,7 +56,7 @@ FUSE_MAX_RECORDS = int(os.environ.get("CDX_UNET2_FUSE_MAX", "100"))   # ... unle
 (W2_KIND, W2_FLAGS, W2_COUT, W2_LOUT, W2_LCOLS, W2_CSTRIDE, W2_OSTRIDE, W2_MODE, W2_NT, W2_NITEMS, W2_ITEMS, W2_DST,
  W2_DST_STRIDE, W2_SSTRIDE, W2_KSPLIT, W2_BOFF, W2_GAMMA, W2_BETA, W2_EMB, W2_RES, W2_RES_STRIDE, W2_CG4_SHIFT, W2_INV_CNT,
  W2_NK, W2_COUTP, W2_SAVE, W2_SAVE_STRIDE, W2_STATS, W2_DST2, W2_DST2_STRIDE, W2_KPOST, W2_PBIAS) = range(32)
-KIND2_CONV, KIND2_HEAD = 0, 1
+KIND2_CONV, KIND2_HEAD, KIND2_LOADX = 0, 1, 2
 W2_ITEM0 = 32                 # items 0..nw-1 inline; items nw.. in the tail table at W2_ITEMS
 
 
@@ -460,6 +460,19 @@ class _Builder2:
         self.stage = max(self.stage, 2 * hidden)
         self.macs += 2 * hidden * c * l
 
+    def load_state(self, dst: Act):
+        """Compact guided programs: the state x_t is read back from GLOBAL memory (the launch's x_out, where compact programs keep
+        it) into a fresh slot for the classifier's first ops -- the denoiser's own copy need not stay in LDS across its peak."""
+        words = {W2_KIND: KIND2_LOADX, W2_COUT: dst.chans, W2_LOUT: dst.length, W2_NITEMS: 0, W2_DST_STRIDE: dst.stride,
+                 W2_COUTP: pad32(dst.chans), W2_NK: 1, W2_KSPLIT: 1}
+        op = [0] * op_words(self.nw)
+        for k, v in words.items():
+            op[k] = int(v)
+        self.ops.append(op)
+        self.op_acts.append(dict(srcs=[], res=None, dst=dst, save=None, dst2=None, reads=[], writes=[dst]))
+        self.op_items.append([])
+        self.op_item_src.append([])
+
     def plan_arena(self, base: int) -> int:
         """Interval allocation of the non-persistent slots over op liveness; patches slot offsets into the ops.  `alias_residual`:
         the output of an op whose residual slot has the same shape and dies with this op is written IN PLACE over that residual
@@ -799,7 +812,7 @@ def compile_janner2(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x
 
 
 def compile_guided2(net, clf, horizon: int, max_lds_bytes: int = 160 * 1024, nw: int = NW2_MAX, save_global: bool = False,
-                    max_stage: Optional[int] = None) -> Program2:
+                    max_stage: Optional[int] = None, compact: bool = False) -> Program2:
     """Denoiser forward + classifier forward/backward as ONE op list (classifier-guided sampling, reference
     diffusionsde.py:153-173): ops [0, n_den) write the prediction, the rest writes d log p / d x_t into the gradient slot; the
     kernel's solver step shifts the prediction by cg_scale[step] * gradient before clipping.  Both networks read the state slot."""
@@ -813,7 +826,10 @@ def compile_guided2(net, clf, horizon: int, max_lds_bytes: int = 160 * 1024, nw:
     b.save_global = save_global          # saved x_hat tensors in global memory: the LDS plan shrinks enough for two trajectories
     if max_stage is not None:
         b.max_stage = max_stage
+    b.alias_residual = compact
     d = net.in_dim
+    if compact:
+        b.ws_floats = (horizon * d + 3) // 4 * 4         # workspace of a trajectory: [multistep memory | saved tensors]
     x = b.act(horizon, d, persistent=True)
     # prediction and gradient are arena slots that stay live until the solver step has read them (the prediction through all of the
     # classifier's ops, whose own footprint is small next to the denoiser's peak): ~2 slots less than keeping them persistent
@@ -823,10 +839,16 @@ def compile_guided2(net, clf, horizon: int, max_lds_bytes: int = 160 * 1024, nw:
     b.conv([t], pred, _conv1d_eff(fc[3]), fc[3].bias, pred=True)
     n_den = len(b.ops)
     emb_den = _emb_table_spec(b, net, blocks, dev)
-    cblocks, (lin1, head_off) = _lower_half_janner_grad(b, clf, horizon, x, grad)
+    xc = x
+    if compact:
+        # `compact` (the largest nets that fit at all: model_dim 64 at H = 64): the state and the multistep memory live in global
+        # memory, the denoiser's LDS copy of x_t dies with its first op, and the classifier gets its own copy through a load op
+        xc = b.act(horizon, d)
+        b.load_state(xc)
+    cblocks, (lin1, head_off) = _lower_half_janner_grad(b, clf, horizon, xc, grad)
     fcw = lin1.in_features - clf.model_dim
     emb_clf = _emb_table_spec(b, clf, cblocks, dev, raw_rows=(lin1.weight.detach()[:, fcw:], lin1.bias.detach(), head_off))
-    prog = _finalize2(b, [emb_den, emb_clf], x, pred, horizon, d, net.emb_dim, max_lds_bytes, [], grad=grad)
+    prog = _finalize2(b, [emb_den, emb_clf], x, pred, horizon, d, net.emb_dim, max_lds_bytes, [], grad=grad, compact=compact)
     prog.meta["n_den"] = n_den
     prog.ws_floats = b.ws_floats
     return prog

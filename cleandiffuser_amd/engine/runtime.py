@@ -447,7 +447,11 @@ def fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed, x_scale:
     net = model["diffusion"]
     if xt.dim() == 2 and _mlp_kind(net) is not None:
         return fused_sample_mlp(solver, net, _mlp_kind(net), plan, xt, prior, cond_vec, w_cfg, feed)
-    if xt.dim() != 3 or not (_is_janner(net) or _is_chiunet(net)) or supported_backbone(net, xt.shape[1], plan_is_edm(plan)) is not None:
+    if xt.dim() != 3 or not (_is_janner(net) or _is_chiunet(net)):
+        return None
+    v1_why = supported_backbone(net, xt.shape[1], plan_is_edm(plan))
+    v2_candidate = (cond_vec is None or w_cfg == 0.0) and _is_janner(net)      # (nets too large for the first kernel's LDS plan may
+    if v1_why is not None and not v2_candidate:                               #  still fit the second one's compact program)
         return None
     if cond_vec is None and w_cfg not in (0.0, 1.0):
         return None                                   # the reference raises here; let the torch executor do it
@@ -468,7 +472,7 @@ def fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed, x_scale:
         out = runtime2.fused_sample2(solver, net, plan, xt, prior, feed, fix_mask, x_min, x_max, x_scale=x_scale)
         if out is not None:
             return out
-    if x_scale is not None:
+    if x_scale is not None or v1_why is not None:
         return None                                   # raw-draw requests are only taken by the v2 kernel; the caller forms x_T itself
     with torch.no_grad():
         comp = compiled_program(net, h, plan_is_edm(plan))

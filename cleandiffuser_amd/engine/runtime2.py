@@ -88,7 +88,14 @@ def compiled2(module, horizon: int, nw: int = P2.NW2, compact: bool = False) -> 
     with torch.no_grad():
         try:
             kw = dict(compact=True, max_stage=COMPACT_STAGE, max_lds_bytes=(160 * 1024) // 3 // 16 * 16) if compact else {}
-            comp = _Compiled2(P2.compile_janner2(module, horizon, nw=nw, **kw), sig)
+            try:
+                comp = _Compiled2(P2.compile_janner2(module, horizon, nw=nw, **kw), sig)
+            except (ValueError, AssertionError):
+                if compact or nw != P2.NW2_MAX or os.environ.get("CDX_UNET2_COMPACT_T1", "1") == "0":
+                    raise
+                # nets whose default plan does not fit 160 KiB (model_dim 64 at H = 64: the antmaze Diffuser, 193 KB) may still fit as
+                # a compact program with the whole LDS to itself: one trajectory per workgroup
+                comp = _Compiled2(P2.compile_janner2(module, horizon, nw=nw, compact=True), sig)
         except (ValueError, AssertionError) as e:
             comp = _Compiled2(None, sig, str(e))
     per_mod[key] = comp
@@ -98,8 +105,7 @@ def compiled2(module, horizon: int, nw: int = P2.NW2, compact: bool = False) -> 
 COMPACT_STAGE = 2304       # floats of staging area per op in a compact program
 
 
-def supported(module, horizon: int) -> Optional[str]:
-    """None when the v2 kernel runs `module` (an unconditional JannerUNet1d forward) at `horizon`, else the reason."""
+def _structural(module, horizon: int) -> Optional[str]:
     if not enabled():
         return "disabled by CDX_UNET2=0"
     if not R._is_janner(module):
@@ -107,7 +113,24 @@ def supported(module, horizon: int) -> Optional[str]:
     n_down = sum(1 for lvl in module.downs if not isinstance(lvl[3], torch.nn.Identity))
     if horizon % (1 << n_down) != 0:
         return f"horizon {horizon} not divisible by 2^{n_down}"
-    return compiled2(module, horizon).why
+    return None
+
+
+def supported(module, horizon: int) -> Optional[str]:
+    """None when the v2 kernel runs `module` (an unconditional JannerUNet1d forward) at `horizon`, else the reason."""
+    why = _structural(module, horizon)
+    if why is not None:
+        return why
+    first = compiled2(module, horizon, DEFAULT_NW)      # the shapes shape_for() tries, in its order
+    return None if first.prog is not None else (compiled2(module, horizon, P2.NW2).why or first.why)
+
+
+def compact_only(module, horizon: int) -> bool:
+    """True when `module` runs on the v2 kernel only as a compact one-trajectory-per-workgroup program (default LDS plan too large):
+    its sampling loops take the kernel below the GEMM executor's crossover batch; stand-alone forwards with per-sample timesteps
+    and large batches stay with the implicit-GEMM executor."""
+    comp = compiled2(module, horizon, DEFAULT_NW)
+    return comp.prog is not None and comp.prog.compact
 
 
 def film_table(comp: _Compiled2, module, t_vec: torch.Tensor, modules=None) -> torch.Tensor:
@@ -336,12 +359,16 @@ def compiled_guided2(net, clf_net, horizon: int, two: bool = False) -> _Compiled
             kw = dict(save_global=True, max_stage=GUIDED_T2_STAGE, max_lds_bytes=80 * 1024) if two else {}
             try:
                 comp = _Compiled2(P2.compile_guided2(net, clf_net, horizon, **kw), sig)
-            except ValueError:
+            except (ValueError, AssertionError):         # (AssertionError: a plan so large that slot offsets leave 16 bits)
                 if two:
                     raise
-                # wider nets (model_dim 64 at H = 32: the kitchen Diffuser): one trajectory per workgroup with the saved tensors in
-                # the global workspace
-                comp = _Compiled2(P2.compile_guided2(net, clf_net, horizon, save_global=True), sig)
+                # wider nets, one trajectory per workgroup: saved tensors in the global workspace (model_dim 64 at H = 32, the kitchen
+                # Diffuser: 141 KB), then also the state / multistep memory in global memory and in-place residual outputs (model_dim
+                # 64 at H = 64, the antmaze Diffuser: 158 KB)
+                try:
+                    comp = _Compiled2(P2.compile_guided2(net, clf_net, horizon, save_global=True), sig)
+                except (ValueError, AssertionError):
+                    comp = _Compiled2(P2.compile_guided2(net, clf_net, horizon, save_global=True, compact=True), sig)
         except (ValueError, AssertionError) as e:
             comp = _Compiled2(None, sig, str(e))
     per[key] = comp
@@ -354,8 +381,8 @@ GUIDED_T2_STAGE = 2304       # floats of staging area a two-trajectory guided pr
 def guided_supported(net, clf_net, horizon: int) -> Optional[str]:
     if not enabled() or os.environ.get("CDX_UNET2_GUIDED", "1") == "0":
         return "disabled by CDX_UNET2=0 / CDX_UNET2_GUIDED=0"
-    why = supported(net, horizon)
-    if why is not None:
+    why = _structural(net, horizon)          # (not `supported`: a net whose unguided default program does not fit may still have a
+    if why is not None:                      #  guided one -- the compact variant)
         return why
     return compiled_guided2(net, clf_net, horizon).why
 

@@ -75,10 +75,14 @@ class LaneSim2:
         hi = p.x_off + (p.horizon + P2.HALO2) * p.x_stride
         keep = self.lds[lo:hi].copy()
         self.lds[:] = np.nan
-        self.lds[lo:hi] = keep
+        if not p.compact:        # (a compact program's state slot is arena memory: nothing of it survives a forward)
+            self.lds[lo:hi] = keep
 
     def load_x(self, x):
         p = self.p
+        self.xg = np.asarray(x, np.float32).copy()      # compact programs: the authoritative state lives in global memory (x_out)
+        if p.compact:            # the solver step rewrites the slot's halo rows and pad channels too (kernel: `if (S->compact)`)
+            self.lds[p.x_off - P2.HALO2 * p.x_stride: p.x_off + (p.horizon + P2.HALO2) * p.x_stride] = 0.0
         for n in range(p.horizon):
             self.lds[p.x_off + n * p.x_stride: p.x_off + n * p.x_stride + p.dim] = x[n]
 
@@ -91,6 +95,12 @@ class LaneSim2:
         for op in self.p.ops:
             if int(op[P2.W2_KIND]) == P2.KIND2_HEAD:
                 self._head(op, np.asarray(emb_row, np.float32))
+            elif int(op[P2.W2_KIND]) == P2.KIND2_LOADX:       # slot <- state from global memory; halo rows and pad channels zero
+                dst, dstr, ln, ch = (int(op[k]) for k in (P2.W2_DST, P2.W2_DST_STRIDE, P2.W2_LOUT, P2.W2_COUT))
+                assert self.p.compact
+                self.lds[dst: dst + (ln + 2 * P2.HALO2) * dstr] = 0.0
+                for n in range(ln):
+                    self.lds[dst + (n + P2.HALO2) * dstr: dst + (n + P2.HALO2) * dstr + ch] = self.xg[n]
             else:
                 self._conv(op, np.asarray(emb_row, np.float32))
         p = self.p

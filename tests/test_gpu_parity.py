@@ -848,32 +848,46 @@ def test_pearce_mlp_widths_match_reference_fixture(hidden, amd_lib, monkeypatch)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,horizon", [("janner_h128", 128), ("janner_h64_w48", 64)])
-def test_janner_beyond_one_workgroup_takes_gemm_executor(name, horizon, amd_lib, monkeypatch):
-    """Long-horizon / wide JannerUNet1d (maze2d-style plans) fits neither program kernel's LDS plan: small batches go to the
-    implicit-GEMM U-Net executor instead of failing or dropping to eager.  Reference fixture, 1e-4."""
+@pytest.mark.parametrize("name,horizon,compact_t1", [("janner_h128", 128, True), ("janner_h128", 128, False), ("janner_h64_w48", 64, False)])
+def test_janner_beyond_one_workgroup_takes_gemm_executor(name, horizon, compact_t1, amd_lib, monkeypatch):
+    """Long-horizon / wide JannerUNet1d (maze2d-style plans) whose default LDS plan does not fit: H = 128 still fits as a compact
+    one-trajectory program (144 KB: one fused launch); without that variant (CDX_UNET2_COMPACT_T1=0), and for the 48-channel net
+    whose GroupNorm groups do not match the epilogue partition, small batches go to the implicit-GEMM U-Net executor instead of
+    failing or dropping to eager.  Reference fixture, 1e-4."""
     from cleandiffuser_amd.engine import runtime, runtime2
+    if not compact_t1:
+        monkeypatch.setenv("CDX_UNET2_COMPACT_T1", "0")
     calls = _spy_bigbatch(monkeypatch)
     out, gold = _extra(name)
     torch.cuda.synchronize()
     net = out["_agent"].model_ema["diffusion"]
-    assert runtime.supported_backbone(net, horizon) is not None and runtime2.supported(net, horizon) is not None
-    assert [c[0] for c in calls] == ["chiunet"]
+    assert runtime.supported_backbone(net, horizon) is not None
+    if compact_t1:
+        assert runtime2.supported(net, horizon) is None and runtime2.compiled2(net, horizon, 8).prog.compact and calls == []
+    else:
+        assert runtime2.supported(net, horizon) is not None
+        assert [c[0] for c in calls] == ["chiunet"]
     np.testing.assert_allclose(out["x"].cpu().numpy(), gold["x"], **TOL)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("path", ["program", "executor"])
 @pytest.mark.parametrize("size", ["kitchen", "antmaze"])
-def test_shipped_large_diffuser_configs_stay_native(size, amd_lib, monkeypatch):
+def test_shipped_large_diffuser_configs_stay_native(size, path, amd_lib, monkeypatch):
     """The two shipped Diffuser / AdaptDiffuser configurations with model_dim 64, against fixtures of the real reference
-    (stand-alone forward, unguided loop, guided loop, classifier log_p) at 1e-4.  kitchen (H = 32, D = 69) fits a program kernel
-    (v2: 141 KB; v1 without the EDM-only buffers: 159.7 KB): fused unguided loop; the guided loop is ONE launch of the guided program
-    (denoiser + classifier forward / backward ops, saved tensors in the global workspace, one trajectory per workgroup: 141 KB).  antmaze (H = 64, D = 37)
-    fits neither: unguided sampling is one implicit-GEMM executor call, and the guided loop is one cdx_guided_run call that runs the
-    same executor for its per-step denoiser forward."""
-    from cleandiffuser_amd.engine import classifier_grad, guided, runtime
+    (stand-alone forward, unguided loop, guided loop, classifier log_p) at 1e-4.
+    path "program" (the default): every call is ONE program-kernel launch.  kitchen (H = 32, D = 69): 141 KB of LDS, the guided
+    program keeps its saved tensors in the global workspace.  antmaze (H = 64, D = 37) fits only as a COMPACT program (state and
+    multistep memory in global memory, in-place residual outputs; guided: the classifier re-reads x_t from global memory): 158 KB.
+    path "executor" (CDX_UNET2_GUIDED=0, CDX_UNET2_COMPACT_T1=0 -- the round-1 route, kept for nets that fit no program): kitchen's
+    guided loop is one cdx_guided_run call around the fused denoiser; antmaze's unguided sampling is one implicit-GEMM executor
+    call and its guided loop one cdx_guided_run call that runs the same executor for its per-step denoiser forward."""
+    from cleandiffuser_amd.engine import classifier_grad, guided, runtime, runtime2
     H = 32 if size == "kitchen" else 64
     steps, fits = 3, size == "kitchen"
+    if path == "executor":
+        monkeypatch.setenv("CDX_UNET2_GUIDED", "0")
+        monkeypatch.setenv("CDX_UNET2_COMPACT_T1", "0")
     calls, fused = _spy_bigbatch(monkeypatch), _spy_launches(monkeypatch)
     grads, one_call = {"n": 0}, {"n": 0}
     real_grad, real_guided = classifier_grad.gradients, guided.guided_sample
@@ -894,7 +908,12 @@ def test_shipped_large_diffuser_configs_stay_native(size, amd_lib, monkeypatch):
     net = out["_agent"].model_ema["diffusion"]
     assert (runtime.supported_backbone(net, H) is None) == fits
     assert runtime.supported_backbone(net, H, edm=True) is not None                  # with the EDM buffers neither fits v1
-    if fits:
+    if path == "program":
+        assert runtime2.guided_supported(net, out["_agent"].classifier.model_ema, H) is None
+        # sampling loops: no executor call at all; antmaze's stand-alone forward (per-sample timesteps) is one GEMM-executor call
+        assert one_call["n"] == 1 and grads["n"] == 0 and [c[0] for c in calls] == ([] if fits else ["chiunet"]), calls
+        assert (runtime2.compiled2(net, H, 8).prog.compact) == (not fits) and runtime2.compact_only(net, H) == (not fits)
+    elif fits:
         assert one_call["n"] == 1 and calls == []                                    # cdx_guided_run: the whole guided loop
     else:
         # GEMM executor: the stand-alone forward and the unguided loop; the guided loop is ONE cdx_guided_run call whose per-step

@@ -148,6 +148,41 @@ def test_lane_sim2_guided_program_gradient_matches_autograd(shape, two, amd_lib)
     np.testing.assert_allclose(sim.grad(), ref_grad, rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(ref_grad).max())))
 
 
+@pytest.mark.parametrize("shape", [(16, 6, [1, 2], 32), (64, 37, [1, 2, 2, 2], 64)])
+def test_lane_sim2_compact_guided_program(shape, amd_lib):
+    """The largest shipped Diffuser net (antmaze: model_dim 64 over H = 64, D = 37) fits one workgroup only as a COMPACT guided
+    program: state and multistep memory in global memory, in-place residual outputs, saved tensors in the workspace behind the
+    multistep memory, and the classifier reads its own copy of x_t back from global memory (a load op) so that the denoiser's
+    copy need not survive the denoiser's LDS peak.  Prediction and gradient against the module / torch.autograd."""
+    from cleandiffuser_amd.utils import load_synth
+    H, D, dm, md = shape
+    net = load_synth(amd_lib.JannerUNet1d(D, model_dim=md, emb_dim=md, dim_mult=dm, kernel_size=5), 0).eval()
+    clf = load_synth(amd_lib.HalfJannerUNet1d(H, D, out_dim=1, model_dim=md, emb_dim=md, dim_mult=tuple(dm), kernel_size=3), 1).eval()
+    if md == 64:
+        with pytest.raises(ValueError):
+            P2.compile_guided2(net, clf, H, save_global=True)
+    prog = P2.compile_guided2(net, clf, H, save_global=True, compact=True)
+    assert prog.compact and prog.lds_bytes(1) <= 160 * 1024 and prog.prev_off < 0
+    assert sum(int(op[P2.W2_KIND]) == P2.KIND2_LOADX for op in prog.ops) == 1
+    hd4 = (H * D + 3) // 4 * 4
+    assert prog.ws_floats > hd4, "multistep memory first, saved tensors behind it"
+    assert all(int(op[P2.W2_SAVE]) >= hd4 for op in prog.ops if int(op[P2.W2_FLAGS]) & P2.F2_SAVE)
+    g = torch.Generator().manual_seed(3)
+    x, t = torch.randn(1, H, D, generator=g), torch.tensor([7])
+    xr = x.clone().requires_grad_()
+    clf._forward_torch(xr, t, None).sum().backward()
+    with torch.no_grad():
+        ref_pred = net._forward_torch(x, t, None)[0].numpy()
+        row = emb_table(prog, None, [net.map_noise(t).numpy(), clf.map_noise(t).numpy()])[0]
+    sim = LaneSim2(prog)
+    for _ in range(1 if md == 64 else 2):                   # (second pass: state slot and arena reused)
+        sim.poison_arena()
+        sim.load_x(x[0].numpy())
+        np.testing.assert_allclose(sim.run_forward(row), ref_pred, rtol=2e-5, atol=2e-5)
+        ref_grad = xr.grad[0].numpy()
+        np.testing.assert_allclose(sim.grad(), ref_grad, rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(ref_grad).max())))
+
+
 def test_lane_sim2_compact_program_for_three_trajectories(amd_lib):
     """The compact variant of the config-2 program (state and multistep memory outside LDS, block outputs written in place over their
     identity-residual input, capped staging area): three trajectories fit one workgroup's 160 KiB, and the lane-level twin still
@@ -169,3 +204,30 @@ def test_lane_sim2_compact_program_for_three_trajectories(amd_lib):
         sim = LaneSim2(prog)
         sim.load_x(xt0[b])
         np.testing.assert_allclose(sim.run_forward(row), gold["pred0"][b], rtol=2e-5, atol=2e-5)
+        # a later forward: the state slot is arena memory that other tensors used meanwhile -- the solver step's rewrite of its
+        # halo rows and pad channels is what makes it a valid conv source again
+        sim.poison_arena()
+        sim.load_x(xt0[b])
+        np.testing.assert_allclose(sim.run_forward(row), gold["pred0"][b], rtol=2e-5, atol=2e-5)
+
+
+def test_lane_sim2_compact_one_trajectory_program_long_horizon(amd_lib):
+    """H = 128 (maze2d-style plans): the default LDS plan needs 171 KB, the compact one 144 KB -- one trajectory per workgroup.  The
+    state slot sits high in the arena here and IS reused during the forward (the case that needs the halo rewrite)."""
+    from cleandiffuser_amd.utils import load_synth
+    H, D = 128, 6
+    net = load_synth(amd_lib.JannerUNet1d(D, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2, 2], kernel_size=5), 11).eval()
+    with pytest.raises(ValueError):
+        P2.compile_janner2(net, H, nw=8)
+    prog = P2.compile_janner2(net, H, nw=8, compact=True)
+    assert prog.compact and prog.lds_bytes(1) <= 160 * 1024 < prog.lds_bytes(2)
+    g = torch.Generator().manual_seed(2)
+    x, t = torch.randn(1, H, D, generator=g), torch.tensor([11])
+    with torch.no_grad():
+        ref = net._forward_torch(x, t, None)[0].numpy()
+        row = emb_table(prog, net.map_noise(t).numpy())[0]
+    sim = LaneSim2(prog)
+    for _ in range(2):
+        sim.poison_arena()
+        sim.load_x(x[0].numpy())
+        np.testing.assert_allclose(sim.run_forward(row), ref, rtol=2e-5, atol=2e-5)

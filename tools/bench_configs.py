@@ -159,13 +159,13 @@ def cfg2g(B=256):
     return f"config 2 + classifier guidance (w_cg=0.1, HalfJannerUNet1d), 20-step DDPM, B={B}", call, B, flops
 
 
-def cfgKg(B=256):
-    """The shipped kitchen Diffuser size with classifier guidance: JannerUNet1d model_dim 64 over H = 32, D = 69 (reference
-    configs/diffuser/kitchen/kitchen.yaml), HalfJannerUNet1d classifier, 20-step DDPM."""
+def _shipped_diffuser(size, B, guided):
+    """The two shipped Diffuser sizes with model_dim 64 (reference configs/diffuser/kitchen/kitchen.yaml: H = 32, D = 69;
+    configs/diffuser/antmaze/antmaze.yaml: H = 64, D = 37), HalfJannerUNet1d classifier, 20-step DDPM, with / without guidance."""
     from cleandiffuser_amd.classifier import CumRewClassifier
     from cleandiffuser_amd.nn_classifier import HalfJannerUNet1d
     from cleandiffuser_amd.nn_diffusion import JannerUNet1d
-    H, D, n_obs = 32, 69, 60
+    H, D, n_obs = (32, 69, 60) if size == "kitchen" else (64, 37, 29)
     net = load_synth(JannerUNet1d(D, model_dim=64, emb_dim=64, dim_mult=[1, 2, 2, 2], kernel_size=5))
     clf_net = load_synth(HalfJannerUNet1d(H, D, out_dim=1, model_dim=64, emb_dim=64, dim_mult=(1, 2, 2, 2), kernel_size=3), 1)
     fix = torch.zeros(H, D)
@@ -175,9 +175,23 @@ def cfgKg(B=256):
     agent.eval()
     prior = torch.zeros(B, H, D, device=DEV)
     prior[:, 0, :n_obs] = torch.randn(B, n_obs, device=DEV)
-    call = lambda: agent.sample(prior, solver="ddpm", n_samples=B, sample_steps=20, temperature=0.5, w_cg=0.1)[0]  # noqa: E731
-    macs = 4 * 19.67e6                      # denoiser only, ~4x the config-2 net (the classifier's work is extra)
-    return f"kitchen-size Diffuser (model_dim 64, H=32, D=69) + classifier guidance, 20-step DDPM, B={B}", call, B, 2.0 * macs * 20 * B
+    call = lambda: agent.sample(prior, solver="ddpm", n_samples=B, sample_steps=20, temperature=0.5,  # noqa: E731
+                                w_cg=0.1 if guided else 0.0)[0]
+    macs = 4 * 19.67e6 * H / 32             # denoiser only, ~4x the config-2 net per position (the classifier's work is extra)
+    return (f"{size}-size Diffuser (model_dim 64, H={H}, D={D}), {'classifier guidance' if guided else 'unguided'}, 20-step DDPM, "
+            f"B={B}"), call, B, 2.0 * macs * 20 * B
+
+
+def cfgKg(B=256):
+    return _shipped_diffuser("kitchen", B, True)
+
+
+def cfgAg(B=256):
+    return _shipped_diffuser("antmaze", B, True)
+
+
+def cfgAu(B=256):
+    return _shipped_diffuser("antmaze", B, False)
 
 
 def run_big(name, fn, reps=2, **kw):
@@ -216,10 +230,10 @@ def run(name, fn, reps=3, **kw):
 
 if __name__ == "__main__":
     for name in (sys.argv[1:] or ["cfg1", "cfg3"]):
-        if name.startswith(("cfg4", "cfg5", "cfg2g", "cfg2big", "cfgT", "cfgKg")):    # e.g. cfg4, cfg4:4096, cfg2g:3200, cfgT:256
+        if name.startswith(("cfg4", "cfg5", "cfg2g", "cfg2big", "cfgT", "cfgKg", "cfgAg", "cfgAu")):    # e.g. cfg4, cfg4:4096, cfg2g:3200, cfgT:256
             base, _, b = name.partition(":")                        # cfgT:1024:10 = batch 1024, 10 denoising steps (short profiles)
             b, _, st = b.partition(":")
-            run_big(name, {"cfg4": cfg4, "cfg5": cfg5, "cfg2g": cfg2g, "cfg2big": cfg2big, "cfgT": cfgT, "cfgKg": cfgKg}[base],
+            run_big(name, {"cfg4": cfg4, "cfg5": cfg5, "cfg2g": cfg2g, "cfg2big": cfg2big, "cfgT": cfgT, "cfgKg": cfgKg, "cfgAg": cfgAg, "cfgAu": cfgAu}[base],
                     **({"B": int(b)} if b else {}), **({"steps": int(st)} if st else {}))
         else:
             base, _, b = name.partition(":")
