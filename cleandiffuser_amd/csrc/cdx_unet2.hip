@@ -1000,18 +1000,19 @@ int cdx_unet2_run(const cdx_unet2_launch* L, void* hip_stream) {
     if (lds_bytes > 160u * 1024u) { cdx_set_err("program needs more than 160 KiB of LDS"); return CDX_ELDS; }
     const bool guided = L->cg_scale != nullptr || L->with_backward != 0;
     if (guided && L->n_waves != 8) { cdx_set_err("programs with backward ops (classifier guidance) run in the 8-wave shape only"); return CDX_EINVAL; }
-    if (guided && L->compact && L->traj_per_wg != 1) { cdx_set_err("compact programs with backward ops: one trajectory per workgroup"); return CDX_EINVAL; }
     if (guided && L->ws_floats > 0 && !L->ws) { cdx_set_err("program keeps saved tensors in a global workspace: ws == NULL"); return CDX_EINVAL; }
     if (L->ws_floats < 0 || (L->ws_floats & 3)) { cdx_set_err("ws_floats must be a non-negative multiple of 4"); return CDX_EINVAL; }
     if (L->cg_scale && (L->grad_off < 0 || (L->grad_off & 3) || (L->grad_stride & 3))) { cdx_set_err("cg_scale given without a gradient slot"); return CDX_EINVAL; }
     void (*kern)(const cdx_unet2_launch);
     if (L->prof) {                                       // profiling builds of the shapes tools/op_profile2*.py look at
         if (L->n_waves != 8) { cdx_set_err("op profiling: 8-wave shapes only"); return CDX_EINVAL; }
+        if (guided && L->traj_per_wg == 3) { cdx_set_err("op profiling of guided programs: one or two trajectories per workgroup"); return CDX_EINVAL; }
         kern = guided ? (L->traj_per_wg == 2 ? cdx_unet2_kernel<2, 8, true, true> : cdx_unet2_kernel<1, 8, true, true>)
                       : (L->traj_per_wg == 3 ? cdx_unet2_kernel<3, 8, false, true>
                          : L->traj_per_wg == 2 ? cdx_unet2_kernel<2, 8, false, true> : cdx_unet2_kernel<1, 8, false, true>);
     } else {
-        kern = guided ? (L->traj_per_wg == 2 ? cdx_unet2_kernel<2, 8, true, false> : cdx_unet2_kernel<1, 8, true, false>)
+        kern = guided ? (L->traj_per_wg == 3 ? cdx_unet2_kernel<3, 8, true, false>
+                         : L->traj_per_wg == 2 ? cdx_unet2_kernel<2, 8, true, false> : cdx_unet2_kernel<1, 8, true, false>)
              : L->n_waves == 8 ? (L->traj_per_wg == 3 ? cdx_unet2_kernel<3, 8, false, false>
                                   : L->traj_per_wg == 2 ? cdx_unet2_kernel<2, 8, false, false> : cdx_unet2_kernel<1, 8, false, false>)
                                : (L->traj_per_wg == 2 ? cdx_unet2_kernel<2, 4, false, false> : cdx_unet2_kernel<1, 4, false, false>);

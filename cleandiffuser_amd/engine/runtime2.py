@@ -191,10 +191,15 @@ DEFAULT_TUNE = 0
 ROUND_COST = {1: 4.41, 2: 5.63, 3: 7.66}
 
 
-def plan_parts(batch: int, tmax: int):
+# the same for the guided program of config 2 (B = 256: 10.1 ms; 13.4 ms per round of 512 at B = 3200; B = 768: 19.2 ms)
+GUIDED_ROUND_COST = {1: 10.1, 2: 13.4, 3: 19.2}
+
+
+def plan_parts(batch: int, tmax: int, round_cost=None):
     """Cut `batch` trajectories into launches [(first, count, trajectories per workgroup)]: full rounds of 256 x T workgroups at the
     T that is cheapest per trajectory, then the remainder at whatever T finishes it soonest (B = 3200: 4 rounds of 768 three per
     workgroup + 128 one per workgroup)."""
+    ROUND_COST = round_cost or globals()["ROUND_COST"]
     best = None
     for tb in range(1, tmax + 1):
         per_round = N_CUS * tb
@@ -344,23 +349,25 @@ def backbone_forward2(module, x, noise_t) -> Optional[torch.Tensor]:
 _gcache = weakref.WeakKeyDictionary()
 
 
-def compiled_guided2(net, clf_net, horizon: int, two: bool = False) -> _Compiled2:
+def compiled_guided2(net, clf_net, horizon: int, two: bool = False, three: bool = False) -> _Compiled2:
     """Guided program (denoiser ops, then the HalfJannerUNet1d classifier's forward and backward-data ops), 8-wave shape.  `two`: the
     variant for two trajectories per workgroup -- saved tensors in a global workspace, small staging area.  ``.prog is None`` +
     ``.why`` when it does not exist (LDS plan, unsupported layers)."""
     per = _gcache.setdefault(net, {})
     sig = (R._signature(net), R._signature(clf_net))
-    key = (id(clf_net), horizon, bool(two))
+    key = (id(clf_net), horizon, bool(two), bool(three))
     hit = per.get(key)
     if hit is not None and hit.sig == sig:
         return hit
     with torch.no_grad():
         try:
             kw = dict(save_global=True, max_stage=GUIDED_T2_STAGE, max_lds_bytes=80 * 1024) if two else {}
+            if three:        # compact on top: state / multistep memory in global memory, in-place residual outputs (config 2: 49.6 KB)
+                kw = dict(save_global=True, compact=True, max_stage=GUIDED_T2_STAGE, max_lds_bytes=(160 * 1024) // 3 // 16 * 16)
             try:
                 comp = _Compiled2(P2.compile_guided2(net, clf_net, horizon, **kw), sig)
             except (ValueError, AssertionError):         # (AssertionError: a plan so large that slot offsets leave 16 bits)
-                if two:
+                if two or three:
                     raise
                 # wider nets, one trajectory per workgroup: saved tensors in the global workspace (model_dim 64 at H = 32, the kitchen
                 # Diffuser: 141 KB), then also the state / multistep memory in global memory and in-place residual outputs (model_dim
@@ -397,7 +404,19 @@ def guided_sample2(solver, net, clf_net, plan, xt, prior, feed, fix_mask, x_min,
     dev = xt.device
     comp, t = compiled_guided2(net, clf_net, h), 1
     forced = os.environ.get("CDX_UNET2_T")
-    if (forced == "2" or (forced is None and b > 256)):
+    parts = None
+    if forced is None and b > 2 * N_CUS and os.environ.get("CDX_UNET2_T3", "1") != "0":
+        # rounds of 256 x 3 trajectories on the compact variant, the remainder at whatever finishes it soonest (same program)
+        alt = compiled_guided2(net, clf_net, h, three=True)
+        if alt.prog is not None:
+            cut = plan_parts(b, 3, GUIDED_ROUND_COST)
+            if max(p[2] for p in cut) == 3:
+                comp, t, parts = alt, 3, cut
+    if forced == "3":
+        alt = compiled_guided2(net, clf_net, h, three=True)
+        if alt.prog is not None:
+            comp, t = alt, 3
+    if parts is None and (forced == "2" or (forced is None and b > 256)):
         alt = compiled_guided2(net, clf_net, h, two=True)
         if alt.prog is not None:
             comp, t = alt, 2
@@ -413,7 +432,7 @@ def guided_sample2(solver, net, clf_net, plan, xt, prior, feed, fix_mask, x_min,
         out = torch.empty_like(xin)
         launch(comp, batch=b, x_in=xin, x_out=out, emb=emb, steps_dev=steps_dev, n_steps=len(plan.steps), predict_noise=pn,
                prior=R._f32c(prior, dev) if fix_mask is not None else None, fix_mask=fix_mask, noise=noise, x_min=x_min,
-               x_max=x_max, t_per_wg=t, cg_scale=cg)
+               x_max=x_max, t_per_wg=t, cg_scale=cg, parts=parts)
     return out
 
 

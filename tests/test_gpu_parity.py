@@ -191,7 +191,7 @@ def test_guided_two_trajectories_per_workgroup(amd_lib, monkeypatch):
     zs = [torch.randn(B, 32, 23, generator=g).to(DEV) for _ in range(6)]
     kw = dict(solver="ddpm", n_samples=B, sample_steps=5, temperature=0.5, w_cg=0.3)
     outs = {}
-    for t in ("1", "2", "2"):
+    for t in ("1", "2", "2", "3", "3"):
         monkeypatch.setenv("CDX_UNET2_T", t)
         calls = _spy_launches(monkeypatch)
         x, _ = agent.sample(prior.to(DEV), noise=list(zs), **kw)
@@ -200,6 +200,35 @@ def test_guided_two_trajectories_per_workgroup(amd_lib, monkeypatch):
         outs.setdefault(t, []).append(x)
     assert torch.equal(outs["2"][0], outs["2"][1])
     np.testing.assert_allclose(outs["2"][0].cpu().numpy(), outs["1"][0].cpu().numpy(), rtol=2e-4, atol=2e-4)
+    # three per workgroup: the compact variant on top (state / multistep memory in global memory, the classifier's copy of x_t
+    # re-read through a load op, in-place residual outputs): 49.6 KB of LDS per trajectory; 37 = 12 full workgroups + one with a
+    # single real trajectory
+    assert torch.equal(outs["3"][0], outs["3"][1])
+    np.testing.assert_allclose(outs["3"][0].cpu().numpy(), outs["1"][0].cpu().numpy(), rtol=2e-4, atol=2e-4)
+
+
+def test_guided_batch_is_cut_into_rounds_of_three_per_workgroup(amd_lib, monkeypatch):
+    """Above two rounds of workgroups a guided batch is cut like an unguided one (runtime2.plan_parts): rounds of 256 x 3 trajectories
+    on the compact guided program plus a remainder launch on the same program; the result agrees with the one-trajectory program
+    on the same draws."""
+    from cleandiffuser_amd.engine import runtime2
+    name = "janner_cfg2_guided_ddpm"
+    agent, _ = cases.build(amd_lib, name, device=DEV)
+    g = torch.Generator().manual_seed(14)
+    B = 1536 + 40
+    prior = torch.zeros(B, 32, 23)
+    prior[:, 0, :17] = torch.randn(B, 17, generator=g)
+    zs = [torch.randn(B, 32, 23, generator=g).to(DEV) for _ in range(4)]
+    kw = dict(solver="ddpm", n_samples=B, sample_steps=3, temperature=0.5, w_cg=0.3)
+    assert runtime2.plan_parts(B, 3, runtime2.GUIDED_ROUND_COST) == [(0, 1536, 3), (1536, 40, 1)]
+    calls = _spy_launches(monkeypatch)
+    x3, _ = agent.sample(prior.to(DEV), noise=list(zs), **kw)
+    torch.cuda.synchronize()
+    assert calls["v2"] == 1, calls
+    monkeypatch.setenv("CDX_UNET2_T", "1")
+    x1, _ = agent.sample(prior.to(DEV), noise=list(zs), **kw)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(x3.cpu().numpy(), x1.cpu().numpy(), rtol=2e-4, atol=2e-4)
 
 
 @pytest.mark.parametrize("one_call", ["v2", True, False])
