@@ -437,12 +437,32 @@ __global__ void time_rows_kernel(float* __restrict__ out, const float* __restric
 
 struct TfBuffers {
     float *x, *prev, *xold, *obs, *tin, *tenc, *tmem, *oin, *oenc, *omem, *tkv, *okv, *h, *y, *qkv, *att, *f, *pred;
+    float *mem, *my, *mqkv, *matt, *mf;      // transformer condition encoder: (samples x (1 + To)) token rows
 };
+
+// memory tokens of a transformer condition encoder: row (r, 0) = the timestep token, rows (r, 1..To) = the observation tokens
+__global__ void mem_rows_kernel(float* __restrict__ mem, const float* __restrict__ tin, const float* __restrict__ oin, int bf, int S,
+                                int d, int trow_index, int per_sample) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)bf * S * d) return;
+    const int c = (int)(i % d), j = (int)((i / d) % S), r = (int)(i / ((size_t)d * S));
+    mem[i] = j == 0 ? tin[(size_t)(per_sample ? r : trow_index) * d + c] : oin[((size_t)r * (S - 1) + (j - 1)) * d + c];
+}
+// ... and back into the two blocks the cross-attention kernel reads (token 0 per sample | observation tokens)
+__global__ void mem_split_kernel(const float* __restrict__ mem, float* __restrict__ tmem, float* __restrict__ omem, int bf, int S, int d) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)bf * S * d) return;
+    const int c = (int)(i % d), j = (int)((i / d) % S), r = (int)(i / ((size_t)d * S));
+    if (j == 0) tmem[(size_t)r * d + c] = mem[i];
+    else omem[((size_t)r * (S - 1) + (j - 1)) * d + c] = mem[i];
+}
 
 long long tf_layout(const cdx_chitf_weights* w, const cdx_sampling* s, float* base, TfBuffers* B) {
     const long long nb = chunk_of(s), bf = nb * (s->cfg_mode == 2 ? 2 : 1);
     const long long d = w->d_model, rows = bf * w->Ta, orow = bf * w->To;
     const long long trow = s->temb_per_sample ? bf : (s->n_steps > 0 ? s->n_steps : 1);
+    const long long mtrow = w->n_enc_layers > 0 ? bf : trow;       // rows of the timestep token's memory / K / V
+    const long long mrow = w->n_enc_layers > 0 ? bf * (1 + w->To) : 0;
     Arena a{base, 0, 0};
     TfBuffers b;
     b.x = a.take(nb * s->hd);
@@ -451,11 +471,11 @@ long long tf_layout(const cdx_chitf_weights* w, const cdx_sampling* s, float* ba
     b.obs = a.take(orow * w->obs_dim);
     b.tin = a.take(trow * d);
     b.tenc = a.take(trow * 4 * d);
-    b.tmem = a.take(trow * d);
+    b.tmem = a.take(mtrow * d);
     b.oin = a.take(orow * d);
     b.oenc = a.take(orow * 4 * d);
     b.omem = a.take(orow * d);
-    b.tkv = a.take((long long)w->n_layers * trow * 2 * d);
+    b.tkv = a.take((long long)w->n_layers * mtrow * 2 * d);
     b.okv = a.take((long long)w->n_layers * orow * 2 * d);
     b.h = a.take(rows * d);
     b.y = a.take(rows * d);
@@ -463,13 +483,21 @@ long long tf_layout(const cdx_chitf_weights* w, const cdx_sampling* s, float* ba
     b.att = a.take(rows * d);
     b.f = a.take(rows * 4 * d);
     b.pred = a.take(rows * w->act_dim);
+    b.mem = a.take(mrow * d);
+    b.my = a.take(mrow * d);
+    b.mqkv = a.take(mrow * 3 * d);
+    b.matt = a.take(mrow * d);
+    b.mf = a.take(mrow * 4 * d);
     if (B) *B = b;
     return a.used;
 }
 
 int tf_check(const cdx_chitf_weights* w, const cdx_sampling* s) {
-    if (!w || !w->layers || !w->act_emb_w || !w->pos_emb || !w->obs_emb_w || !w->cond_pos_emb || !w->enc0_w || !w->enc2_w ||
+    if (!w || !w->layers || !w->act_emb_w || !w->pos_emb || !w->obs_emb_w || !w->cond_pos_emb ||
         !w->lnf_g || !w->head_w || !w->self_mask || !w->memory_mask) { cdx_set_err("null pointer in ChiTransformer weights"); return CDX_EINVAL; }
+    if (w->n_enc_layers < 0 || (w->n_enc_layers > 0 && !w->enc_layers) || (w->n_enc_layers == 0 && (!w->enc0_w || !w->enc2_w))) {
+        cdx_set_err("ChiTransformer condition encoder: MLP weights (enc0 / enc2) or enc_layers required"); return CDX_EINVAL;
+    }
     if (w->Ta <= 0 || w->Ta > 64 || w->To < 0 || 1 + w->To > 16 || w->d_model <= 0 || w->d_model > 1024 || w->n_heads <= 0 ||
         w->d_model % w->n_heads != 0 || w->d_model / w->n_heads > 64 || w->n_layers < 0) {
         cdx_set_err("ChiTransformer executor: Ta <= 64, 1 + To <= 16, d_model <= 1024, head_dim <= 64 required"); return CDX_EINVAL;
@@ -492,8 +520,11 @@ int tf_prepare(const cdx_chitf_weights* w, const cdx_sampling* s, hipStream_t st
                            trow, nb, b0, d, s->temb_per_sample);
         CDX_TRY(hip_ok());
     }
-    CDX_TRY(gemm(st, B.tin, d, w->enc0_w, d, w->enc0_b, B.tenc, 4 * d, trow, 4 * d, d, CDX_ACT_MISH));
-    CDX_TRY(gemm(st, B.tenc, 4 * d, w->enc2_w, 4 * d, w->enc2_b, B.tmem, d, trow, d, 4 * d));
+    const bool tfenc = w->n_enc_layers > 0;       // transformer encoder: the memory is built per step in tf_forward
+    if (!tfenc) {
+        CDX_TRY(gemm(st, B.tin, d, w->enc0_w, d, w->enc0_b, B.tenc, 4 * d, trow, 4 * d, d, CDX_ACT_MISH));
+        CDX_TRY(gemm(st, B.tenc, 4 * d, w->enc2_w, 4 * d, w->enc2_b, B.tmem, d, trow, d, 4 * d));
+    }
     if (To > 0) {
         const long long n = (long long)orow * w->obs_dim;
         // cond is (batch, To * obs_dim): row (b, s) of the observation table is a contiguous slice of it
@@ -502,9 +533,12 @@ int tf_prepare(const cdx_chitf_weights* w, const cdx_sampling* s, hipStream_t st
         CDX_TRY(hip_ok());
         CDX_TRY(gemm(st, B.obs, w->obs_dim, w->obs_emb_w, w->obs_dim, w->obs_emb_b, B.oin, d, orow, d, w->obs_dim, CDX_ACT_NONE,
                      nullptr, 0, 1, nullptr, 0, w->cond_pos_emb + d, To));
-        CDX_TRY(gemm(st, B.oin, d, w->enc0_w, d, w->enc0_b, B.oenc, 4 * d, orow, 4 * d, d, CDX_ACT_MISH));
-        CDX_TRY(gemm(st, B.oenc, 4 * d, w->enc2_w, 4 * d, w->enc2_b, B.omem, d, orow, d, 4 * d));
+        if (!tfenc) {
+            CDX_TRY(gemm(st, B.oin, d, w->enc0_w, d, w->enc0_b, B.oenc, 4 * d, orow, 4 * d, d, CDX_ACT_MISH));
+            CDX_TRY(gemm(st, B.oenc, 4 * d, w->enc2_w, 4 * d, w->enc2_b, B.omem, d, orow, d, 4 * d));
+        }
     }
+    if (tfenc) return CDX_OK;
     for (int l = 0; l < w->n_layers; ++l) {
         const cdx_chitf_layer& k = w->layers[l];
         CDX_TRY(gemm(st, B.tmem, d, k.ca_in_w + (size_t)d * d, d, k.ca_in_b + d, B.tkv + (size_t)l * trow * 2 * d, 2 * d, trow, 2 * d, d));
@@ -519,7 +553,38 @@ int tf_forward(const cdx_chitf_weights* w, const cdx_sampling* s, hipStream_t st
     const int two = s->cfg_mode == 2 ? 2 : 1, bf = nb * two;
     const int T = w->Ta, d = w->d_model, rows = bf * T, orow = bf * w->To;
     CDX_TRY(scaled_input(st, x, pred, in_scale, (size_t)nb * T * w->act_dim));    // pred is free until the head writes it
-    const int trow = s->temb_per_sample ? bf : (s->n_steps > 0 ? s->n_steps : 1);
+    int trow = s->temb_per_sample ? bf : (s->n_steps > 0 ? s->n_steps : 1);
+    if (w->n_enc_layers > 0) {
+        // nn.TransformerEncoder over [timestep token | observation tokens] of every sample (reference chitransformer.py:146-149),
+        // then the decoder layers' K / V projections of that memory -- per step, because the timestep token takes part
+        const int S = 1 + w->To, mrow = bf * S;
+        const long long n = (long long)mrow * d;
+        hipLaunchKernelGGL(mem_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, B.mem, B.tin, B.oin, bf, S, d, rec,
+                           s->temb_per_sample);
+        CDX_TRY(hip_ok());
+        for (int l = 0; l < w->n_enc_layers; ++l) {
+            const cdx_chitf_enc_layer& k = w->enc_layers[l];
+            CDX_TRY(layernorm(st, B.mem, B.my, mrow, d, 1e-5f, k.ln1_g, k.ln1_b, nullptr, nullptr, 0, 1, 0));
+            CDX_TRY(gemm(st, B.my, d, k.sa_in_w, d, k.sa_in_b, B.mqkv, 3 * d, mrow, 3 * d, d));
+            cdx_attn_args at;
+            at.qkv = B.mqkv; at.out = B.matt; at.B = bf; at.T = S; at.n_heads = w->n_heads; at.head_dim = d / w->n_heads;
+            at.scale = 1.0f / sqrtf((float)at.head_dim); at.mask = nullptr;
+            CDX_TRY(cdx_attention_f32(&at, st));
+            CDX_TRY(gemm(st, B.matt, d, k.sa_out_w, d, k.sa_out_b, B.mem, d, mrow, d, d, CDX_ACT_NONE, nullptr, 0, 1, B.mem, d));
+            CDX_TRY(layernorm(st, B.mem, B.my, mrow, d, 1e-5f, k.ln2_g, k.ln2_b, nullptr, nullptr, 0, 1, 0));
+            CDX_TRY(gemm(st, B.my, d, k.ff1_w, d, k.ff1_b, B.mf, 4 * d, mrow, 4 * d, d, CDX_ACT_GELU_ERF));
+            CDX_TRY(gemm(st, B.mf, 4 * d, k.ff2_w, 4 * d, k.ff2_b, B.mem, d, mrow, d, 4 * d, CDX_ACT_NONE, nullptr, 0, 1, B.mem, d));
+        }
+        hipLaunchKernelGGL(mem_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, B.mem, B.tmem, B.omem, bf, S, d);
+        CDX_TRY(hip_ok());
+        trow = bf;
+        for (int l = 0; l < w->n_layers; ++l) {
+            const cdx_chitf_layer& k = w->layers[l];
+            CDX_TRY(gemm(st, B.tmem, d, k.ca_in_w + (size_t)d * d, d, k.ca_in_b + d, B.tkv + (size_t)l * trow * 2 * d, 2 * d, trow, 2 * d, d));
+            if (w->To > 0)
+                CDX_TRY(gemm(st, B.omem, d, k.ca_in_w + (size_t)d * d, d, k.ca_in_b + d, B.okv + (size_t)l * orow * 2 * d, 2 * d, orow, 2 * d, d));
+        }
+    }
     for (int half = 0; half < two; ++half)               // both CFG halves start from the same action tokens
         CDX_TRY(gemm(st, x, w->act_dim, w->act_emb_w, w->act_dim, w->act_emb_b, B.h + (size_t)half * nb * T * d, d, nb * T, d,
                      w->act_dim, CDX_ACT_NONE, nullptr, 0, 1, nullptr, 0, w->pos_emb, T));
@@ -537,7 +602,7 @@ int tf_forward(const cdx_chitf_weights* w, const cdx_sampling* s, hipStream_t st
         cdx_xattn_args xa;
         xa.q = B.qkv; xa.kv_shared = B.tkv + (size_t)l * trow * 2 * d; xa.kv_rows = B.okv + (size_t)l * orow * 2 * d;
         xa.mask = w->memory_mask; xa.out = B.att; xa.B = bf; xa.T = T; xa.n_obs = w->To; xa.n_heads = w->n_heads;
-        xa.head_dim = d / w->n_heads; xa.shared_row = rec; xa.shared_per_sample = s->temb_per_sample;
+        xa.head_dim = d / w->n_heads; xa.shared_row = rec; xa.shared_per_sample = (s->temb_per_sample || w->n_enc_layers > 0) ? 1 : 0;
         xa.scale = at.scale;
         CDX_TRY(cdx_cross_attention_f32(&xa, st));
         CDX_TRY(gemm(st, B.att, d, k.ca_out_w, d, k.ca_out_b, B.h, d, rows, d, d, CDX_ACT_NONE, nullptr, 0, 1, B.h, d));

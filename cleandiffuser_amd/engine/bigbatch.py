@@ -53,12 +53,17 @@ class CdxChitfLayer(ctypes.Structure):
                                    "ca_in_b", "ca_out_w", "ca_out_b", "ln3_g", "ln3_b", "ff1_w", "ff1_b", "ff2_w", "ff2_b")]
 
 
+class CdxChitfEncLayer(ctypes.Structure):
+    _fields_ = [(n, _FP) for n in ("ln1_g", "ln1_b", "sa_in_w", "sa_in_b", "sa_out_w", "sa_out_b", "ln2_g", "ln2_b", "ff1_w", "ff1_b",
+                                   "ff2_w", "ff2_b")]
+
+
 class CdxChitfWeights(ctypes.Structure):
     _fields_ = [("Ta", _I), ("To", _I), ("act_dim", _I), ("obs_dim", _I), ("d_model", _I), ("n_heads", _I), ("n_layers", _I),
                 ("act_emb_w", _FP), ("act_emb_b", _FP), ("pos_emb", _FP), ("obs_emb_w", _FP), ("obs_emb_b", _FP),
                 ("cond_pos_emb", _FP), ("enc0_w", _FP), ("enc0_b", _FP), ("enc2_w", _FP), ("enc2_b", _FP),
                 ("layers", ctypes.POINTER(CdxChitfLayer)), ("lnf_g", _FP), ("lnf_b", _FP), ("head_w", _FP), ("head_b", _FP),
-                ("self_mask", _FP), ("memory_mask", _FP)]
+                ("self_mask", _FP), ("memory_mask", _FP), ("n_enc_layers", _I), ("enc_layers", ctypes.POINTER(CdxChitfEncLayer))]
 
 
 class CdxChiUNetBlock(ctypes.Structure):
@@ -193,8 +198,17 @@ def _bind_chitf(net, device) -> Optional[_Bound]:
     import torch.nn as nn
     d = net.act_emb.out_features
     layers = list(net.decoder.layers)
-    if not isinstance(net.encoder, nn.Sequential) or net.T > 64 or 1 + net.To > 16 or d > 1024 or net.decoder.norm is not None:
-        return None                                   # transformer condition encoder (n_cond_layers > 0): PyTorch executor
+    if net.T > 64 or 1 + net.To > 16 or d > 1024 or net.decoder.norm is not None:
+        return None
+    enc_layers = []
+    if not isinstance(net.encoder, nn.Sequential):    # n_cond_layers > 0: nn.TransformerEncoder (reference chitransformer.py:91-95)
+        if not isinstance(net.encoder, nn.TransformerEncoder) or net.encoder.norm is not None:
+            return None
+        enc_layers = list(net.encoder.layers)
+        for lyr in enc_layers:
+            if not lyr.norm_first or getattr(lyr.activation, "__name__", "") != "gelu" or lyr.self_attn.in_proj_weight is None or \
+                    not lyr.self_attn.batch_first or lyr.self_attn.num_heads != layers[0].self_attn.num_heads:
+                return None
     heads = layers[0].self_attn.num_heads if layers else 1
     if d % heads or d // heads > 64:
         return None
@@ -213,15 +227,24 @@ def _bind_chitf(net, device) -> Optional[_Bound]:
                                p(ca.in_proj_weight), p(ca.in_proj_bias), p(ca.out_proj.weight), p(ca.out_proj.bias),
                                p(l.norm3.weight), p(l.norm3.bias), p(l.linear1.weight), p(l.linear1.bias), p(l.linear2.weight),
                                p(l.linear2.bias))
+    enc = (CdxChitfEncLayer * max(len(enc_layers), 1))()
+    for i, l in enumerate(enc_layers):
+        sa = l.self_attn
+        enc[i] = CdxChitfEncLayer(p(l.norm1.weight), p(l.norm1.bias), p(sa.in_proj_weight), p(sa.in_proj_bias), p(sa.out_proj.weight),
+                                  p(sa.out_proj.bias), p(l.norm2.weight), p(l.norm2.bias), p(l.linear1.weight), p(l.linear1.bias),
+                                  p(l.linear2.weight), p(l.linear2.bias))
+    mlp_enc = not enc_layers
     neg = torch.finfo(torch.float32).min               # the kernels clamp scores at -3e38; -inf entries map onto that floor
     w = CdxChitfWeights(Ta=net.T, To=net.To, act_dim=net.act_emb.in_features, obs_dim=net.obs_dim, d_model=d, n_heads=heads,
                         n_layers=len(layers), act_emb_w=p(net.act_emb.weight), act_emb_b=p(net.act_emb.bias),
                         pos_emb=p(net.pos_emb[0]), obs_emb_w=p(net.obs_emb.weight), obs_emb_b=p(net.obs_emb.bias),
-                        cond_pos_emb=p(net.cond_pos_emb[0]), enc0_w=p(net.encoder[0].weight), enc0_b=p(net.encoder[0].bias),
-                        enc2_w=p(net.encoder[2].weight), enc2_b=p(net.encoder[2].bias), layers=arr, lnf_g=p(net.ln_f.weight),
+                        cond_pos_emb=p(net.cond_pos_emb[0]), enc0_w=p(net.encoder[0].weight) if mlp_enc else None,
+                        enc0_b=p(net.encoder[0].bias) if mlp_enc else None, enc2_w=p(net.encoder[2].weight) if mlp_enc else None,
+                        enc2_b=p(net.encoder[2].bias) if mlp_enc else None, n_enc_layers=len(enc_layers), enc_layers=enc,
+                        layers=arr, lnf_g=p(net.ln_f.weight),
                         lnf_b=p(net.ln_f.bias), head_w=p(net.head.weight), head_b=p(net.head.bias),
                         self_mask=p(net.mask.detach().clamp_min(neg)), memory_mask=p(net.memory_mask.detach().clamp_min(neg)))
-    keep.append(arr)
+    keep += [arr, enc]
     return _Bound(w, keep, None)
 
 

@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define CDX_ABI_VERSION 5
+#define CDX_ABI_VERSION 6
 
 #define CDX_OK 0
 #define CDX_EINVAL (-1)   /* bad argument (null pointer, size out of range, misaligned offset) */
@@ -346,17 +346,28 @@ typedef struct cdx_chitf_layer {
     const float *ln2_g, *ln2_b, *ca_in_w, *ca_in_b, *ca_out_w, *ca_out_b;      /* norm2, multihead_attn.in_proj (3d,d), out_proj */
     const float *ln3_g, *ln3_b, *ff1_w, *ff1_b, *ff2_w, *ff2_b;                /* norm3, linear1 (4d,d), linear2 (d,4d) */
 } cdx_chitf_layer;
+/* One layer of the condition encoder when it is an nn.TransformerEncoder (n_cond_layers > 0, reference
+ * nn_diffusion/chitransformer.py:91-95; norm_first, GELU, no mask): self-attention over the 1 + To condition tokens, then the FFN. */
+typedef struct cdx_chitf_enc_layer {
+    const float *ln1_g, *ln1_b, *sa_in_w, *sa_in_b, *sa_out_w, *sa_out_b;      /* norm1, self_attn.in_proj (3d,d), out_proj */
+    const float *ln2_g, *ln2_b, *ff1_w, *ff1_b, *ff2_w, *ff2_b;                /* norm2, linear1 (4d,d), linear2 (d,4d) */
+} cdx_chitf_enc_layer;
 typedef struct cdx_chitf_weights {
     int32_t Ta, To, act_dim, obs_dim, d_model, n_heads, n_layers;
     const float *act_emb_w, *act_emb_b;      /* (d, act_dim) */
     const float* pos_emb;                    /* (Ta, d) */
     const float *obs_emb_w, *obs_emb_b;      /* (d, obs_dim) */
     const float* cond_pos_emb;               /* (1 + To, d) */
-    const float *enc0_w, *enc0_b, *enc2_w, *enc2_b;   /* encoder.0 (4d, d), encoder.2 (d, 4d) */
+    const float *enc0_w, *enc0_b, *enc2_w, *enc2_b;   /* encoder.0 (4d, d), encoder.2 (d, 4d) -- the MLP encoder (n_enc_layers == 0) */
     const cdx_chitf_layer* layers;           /* HOST array [n_layers] of device pointers */
     const float *lnf_g, *lnf_b, *head_w, *head_b;     /* ln_f, head (act_dim, d) */
     const float* self_mask;                  /* (Ta, Ta) additive */
     const float* memory_mask;                /* (Ta, 1 + To) additive */
+    /* Transformer condition encoder: n_enc_layers > 0 replaces the MLP encoder (enc0 / enc2 may then be NULL).  Its self-attention
+     * mixes the timestep token with the observation tokens, so the memory is per (sample, step): the encoder and the decoder
+     * layers' K/V projections then run once per denoising step instead of once per request. */
+    int32_t n_enc_layers;
+    const cdx_chitf_enc_layer* enc_layers;   /* HOST array [n_enc_layers] of device pointers, or NULL */
 } cdx_chitf_weights;
 long long cdx_chitf_workspace_floats(const cdx_chitf_weights* w, const cdx_sampling* s);
 int cdx_chitf_run(const cdx_chitf_weights* w, const cdx_sampling* s, void* hip_stream);

@@ -154,13 +154,17 @@ def transformer(which: str):
     def run(lib, kind, device):
         if which == "chitf_ta10":
             net, x_shape, cond_shape = lib.ChiTransformer(7, 23, 10, 2, d_model=256, nhead=4, num_layers=3), (10, 7), (2, 23)
+        elif which == "chitf_enc2":           # transformer condition encoder (n_cond_layers > 0, reference chitransformer.py:91-95)
+            net = lib.ChiTransformer(7, 23, 10, 2, d_model=128, nhead=4, num_layers=2, n_cond_layers=2)
+            x_shape, cond_shape = (10, 7), (2, 23)
         elif which == "dit_h10_d384":
             net, x_shape, cond_shape = lib.DiT1d(7, emb_dim=64, d_model=384, n_heads=6, depth=2), (10, 7), (64,)
         else:
             net = lib.DiT1d(29, emb_dim=128, d_model=256, n_heads=8, depth=8, timestep_emb_type="fourier")
             x_shape, cond_shape = (40, 29), (128,)
+        lim = 50.0 if which == "chitf_enc2" else 2.0          # (synthetic weights saturate a +-2 clip on most elements)
         agent = lib.DiscreteDiffusionSDE(load_synth(net, 31), lib.IdentityCondition(dropout=0.0), predict_noise=True,
-                                         x_max=2 * torch.ones(1, *x_shape), x_min=-2 * torch.ones(1, *x_shape), diffusion_steps=20,
+                                         x_max=lim * torch.ones(1, *x_shape), x_min=-lim * torch.ones(1, *x_shape), diffusion_steps=20,
                                          device=device)
         agent.eval()
         g = torch.Generator().manual_seed(len(which))
@@ -194,7 +198,7 @@ SCENARIOS: Dict[str, Callable] = {
     "pearce_h64": pearce(64, 5), "pearce_h192": pearce(192, 37), "pearce_h512": pearce(512, 16),
     "janner_h128": janner_long(128, [1, 2, 2, 2], 32), "janner_h64_w48": janner_long(64, [1, 4, 2], 48),
     "diffuser_kitchen": shipped_diffuser("kitchen"), "diffuser_antmaze": shipped_diffuser("antmaze"),
-    "chitf_ta10": transformer("chitf_ta10"), "dit_h10_d384": transformer("dit_h10_d384"), "dit_h40_depth8": transformer("dit_h40_depth8"),
+    "chitf_ta10": transformer("chitf_ta10"), "chitf_enc2": transformer("chitf_enc2"), "dit_h10_d384": transformer("dit_h10_d384"), "dit_h40_depth8": transformer("dit_h40_depth8"),
     "chiunet_cfg3_width": chiunet_cfg3_width(),
     "pearce_cfg_pair": mlp_cfg_pair("pearce"), "dql_cfg_pair": mlp_cfg_pair("dql"), "idql_h2048": idql_wide(),
     "mlpnn_cfg_pair": mlpnn(),

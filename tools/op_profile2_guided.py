@@ -1,6 +1,6 @@
 """Per-op cycle breakdown of a GUIDED v2 program (denoiser ops, then the classifier's forward + backward ops), workgroup 0, second
-step.  The config-2 guided program leaves no LDS for the stamp buffer (155.8 of 160 KB), so this profiles the same architecture one
-level shallower (H = 16, dim_mult (1, 2, 2)): per-op behaviour is the same.  Usage: python tools/op_profile2_guided.py [batch]"""
+step.  Default: the config-2 guided program (H = 32, dim_mult (1, 2, 2, 2); 131 KB of LDS + the stamp buffer); `h16`: the same
+architecture one level shallower.  Usage: python tools/op_profile2_guided.py [batch] [h16]"""
 import os
 import sys
 
@@ -18,7 +18,7 @@ from cleandiffuser_amd.utils import load_synth  # noqa: E402
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     dev = torch.device("cuda", 0)
-    H, D, dm = 16, 23, [1, 2, 2]
+    H, D, dm = (16, 23, [1, 2, 2]) if "h16" in sys.argv[2:] else (32, 23, [1, 2, 2, 2])
     net = load_synth(JannerUNet1d(D, model_dim=32, emb_dim=32, dim_mult=dm, kernel_size=5))
     clf_net = load_synth(HalfJannerUNet1d(H, D, out_dim=1, model_dim=32, emb_dim=32, dim_mult=tuple(dm), kernel_size=3), 1)
     fix = torch.zeros(H, D)
