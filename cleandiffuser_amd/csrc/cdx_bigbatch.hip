@@ -283,9 +283,9 @@ long long dit_layout(const cdx_dit1d_weights* w, const cdx_sampling* s, float* b
 
 int dit_check(const cdx_dit1d_weights* w, const cdx_sampling* s) {
     if (!w || !w->blocks || !w->x_proj_w || !w->pos || !w->map0_w || !w->map2_w || !w->fin_ada_w || !w->fin_w) { cdx_set_err("null pointer in DiT1d weights"); return CDX_EINVAL; }
-    if (w->tokens <= 0 || w->tokens > 64 || w->d_model <= 0 || w->d_model > 1024 || w->n_heads <= 0 ||
+    if (w->tokens <= 0 || w->tokens > CDX_ATTN_MAX_T || w->d_model <= 0 || w->d_model > 1024 || w->n_heads <= 0 ||
         w->d_model % w->n_heads != 0 || w->d_model / w->n_heads > 64 || w->depth < 0 || w->in_dim <= 0) {
-        cdx_set_err("DiT1d executor: tokens <= 64, d_model <= 1024, head_dim <= 64 required"); return CDX_EINVAL;
+        cdx_set_err("DiT1d executor: tokens <= 1024, d_model <= 1024, head_dim <= 64 required"); return CDX_EINVAL;
     }
     CDX_TRY(check_request(s, "cdx_dit1d_run", 7));
     if (s->hd != w->tokens * w->in_dim || s->emb_dim != w->emb_dim || (s->cond && s->cond_dim != w->emb_dim)) {

@@ -659,6 +659,87 @@ __global__ __launch_bounds__(64) void cdx_attention_kernel(const cdx_attn_args a
 }
 
 // ------------------------------------------------------------------------------------------------
+// Longer sequences (64 < T <= CDX_ATTN_MAX_T; DiT1d over horizons no shipped config uses): one wave per (batch, head, block of 64
+// queries), one thread per query row, keys / values streamed through LDS in tiles of 64 with an online softmax (running maximum,
+// running denominator, head_dim accumulators in registers).  Same math as the kernels below up to the order of the sums.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void cdx_attention_long_kernel(const cdx_attn_args a) {
+    __shared__ float Ks[64][65];
+    __shared__ float Vs[64][65];
+    const int t = threadIdx.x;
+    const int qblocks = (a.T + 63) / 64;
+    const int qb = blockIdx.x % qblocks, bh = blockIdx.x / qblocks;
+    const int b = bh / a.n_heads, h = bh % a.n_heads;
+    const int dh = a.head_dim, dm = a.n_heads * a.head_dim;
+    const size_t row0 = (size_t)b * a.T;
+    const int q = qb * 64 + t;
+    const bool live_q = q < a.T;
+    float qv[64], acc[64];
+#pragma unroll
+    for (int d = 0; d < 64; ++d) {
+        qv[d] = (live_q && d < dh) ? a.qkv[(row0 + q) * (size_t)(3 * dm) + h * dh + d] * a.scale : 0.f;
+        acc[d] = 0.f;
+    }
+    float mx = -3.0e38f, den = 0.f;
+    for (int k0 = 0; k0 < a.T; k0 += 64) {
+        __syncthreads();
+        for (int i = t; i < 64 * dh; i += 64) {
+            const int tok = i / dh, d = i - tok * dh;
+            const bool live = k0 + tok < a.T;
+            const float* base = a.qkv + (row0 + (live ? k0 + tok : 0)) * (size_t)(3 * dm) + h * dh + d;
+            Ks[tok][d] = live ? base[dm] : 0.f;
+            Vs[tok][d] = live ? base[2 * dm] : 0.f;
+        }
+        __syncthreads();
+        float p[64];
+#pragma unroll
+        for (int j = 0; j < 64; ++j) p[j] = 0.f;
+#pragma unroll
+        for (int d = 0; d < 64; ++d) {
+            if (d < dh) {
+#pragma unroll
+                for (int j = 0; j < 64; ++j) p[j] = fmaf(qv[d], Ks[j][d], p[j]);
+            }
+        }
+        float tile_mx = -3.0e38f;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            float sc = p[j];
+            const bool live = k0 + j < a.T;
+            if (a.mask != nullptr && live && live_q) sc += a.mask[(size_t)q * a.T + k0 + j];
+            p[j] = live ? fmaxf(sc, -3.0e38f) : -3.0e38f;
+            tile_mx = fmaxf(tile_mx, p[j]);
+        }
+        const float new_mx = fmaxf(mx, tile_mx);
+        const float corr = expf(mx - new_mx);                 // (first tile: exp(-3e38 - m) = 0 on den = 0, acc = 0)
+        den *= corr;
+#pragma unroll
+        for (int d = 0; d < 64; ++d) acc[d] *= corr;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            p[j] = (k0 + j < a.T) ? expf(p[j] - new_mx) : 0.f;
+            den += p[j];
+        }
+#pragma unroll
+        for (int d = 0; d < 64; ++d) {
+            if (d < dh) {
+                float o = acc[d];
+#pragma unroll
+                for (int j = 0; j < 64; ++j) o = fmaf(p[j], Vs[j][d], o);
+                acc[d] = o;
+            }
+        }
+        mx = new_mx;
+    }
+    if (!live_q) return;
+    const float inv = 1.0f / den;
+    float* op = a.out + (row0 + q) * (size_t)dm + h * dh;
+#pragma unroll
+    for (int d = 0; d < 64; ++d)
+        if (d < dh) op[d] = acc[d] * inv;
+}
+
+// ------------------------------------------------------------------------------------------------
 // MFMA attention for the same problem (head_dim % 4 == 0): one WAVE per (batch, head), no workgroup barriers.
 //   S^T = K Q^T   (keys x queries, 32x32x2 MFMAs, K and scaled Q staged in wave-private LDS)
 //   softmax over keys = over the registers of a lane (+ one lane ^ 32 exchange): in the D fragment a lane owns ONE query column
@@ -1060,13 +1141,17 @@ int cdx_groupnorm_bwd_f32(const cdx_gn_args* a, void* hip_stream) {
 int cdx_attention_f32(const cdx_attn_args* a, void* hip_stream) {
     if (!a) { cdx_set_err("cdx_attention_f32: null argument block"); return CDX_EINVAL; }
     if (a->B > 0 && (!a->qkv || !a->out)) { cdx_set_err("cdx_attention_f32: null pointer"); return CDX_EINVAL; }
-    if (a->T <= 0 || a->T > 64 || a->head_dim <= 0 || a->head_dim > 64 || a->n_heads <= 0 || a->B < 0) {
-        cdx_set_err("cdx_attention_f32: T <= 64 and head_dim <= 64 required"); return CDX_EINVAL;
+    if (a->T <= 0 || a->T > CDX_ATTN_MAX_T || a->head_dim <= 0 || a->head_dim > 64 || a->n_heads <= 0 || a->B < 0) {
+        cdx_set_err("cdx_attention_f32: T <= 1024 and head_dim <= 64 required"); return CDX_EINVAL;
     }
     if (a->B == 0) return CDX_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
     const int dm = a->n_heads * a->head_dim;
-    if (a->head_dim % 4 == 0 && dm % 4 == 0 && ((uintptr_t)a->out % 16) == 0) {      // MFMA path, one wave per (batch, head)
+    if (a->T > 64) {                                     // streamed keys / online softmax
+        const long long grid = (long long)a->B * a->n_heads * ((a->T + 63) / 64);
+        if (grid > 0x7fffffffLL) { cdx_set_err("cdx_attention_f32: batch too large for one launch"); return CDX_EINVAL; }
+        hipLaunchKernelGGL(cdx_attention_long_kernel, dim3((unsigned)grid), dim3(64), 0, st, *a);
+    } else if (a->head_dim % 4 == 0 && dm % 4 == 0 && ((uintptr_t)a->out % 16) == 0) {      // MFMA path, one wave per (batch, head)
         const int pairs = a->B * a->n_heads, grid = (pairs + 3) / 4;
         // <head-dim blocks, token blocks>: T <= 32 runs the single-block variant (a quarter of the MFMAs, half the LDS)
         const int tb = a->T <= 32 ? 1 : 2, db = a->head_dim <= 32 ? 1 : 2;

@@ -146,7 +146,7 @@ def _dev_f32(t: torch.Tensor, keep: list, device):
 def _bind_dit(net, tokens: int, device) -> Optional[_Bound]:
     d = net.d_model
     heads = net.blocks[0].attn.num_heads if len(net.blocks) else 1
-    if tokens > 64 or d > 1024 or d % heads or d // heads > 64:
+    if tokens > 1024 or d > 1024 or d % heads or d // heads > 64:          # CDX_ATTN_MAX_T
         return None
     for blk in net.blocks:
         a = blk.attn

@@ -256,7 +256,9 @@ int cdx_groupnorm_f32(const cdx_gn_args* args, void* hip_stream);
 int cdx_groupnorm_bwd_f32(const cdx_gn_args* args, void* hip_stream);
 
 /* out[b][t][h*d..] = softmax(q k^T * scale) v per (batch, head); qkv = (B*T, 3*n_heads*head_dim) from in_proj.
- * Replaces the core of nn.MultiheadAttention(batch_first=True) (reference dit.py:20,34).  T <= 64, head_dim <= 64. */
+ * Replaces the core of nn.MultiheadAttention(batch_first=True) (reference dit.py:20,34).  T <= CDX_ATTN_MAX_T, head_dim <= 64
+ * (T <= 64: one wave per (batch, head) on MFMA; longer sequences: streamed keys with an online softmax). */
+#define CDX_ATTN_MAX_T 1024
 typedef struct cdx_attn_args {
     const float* qkv;
     float* out;            /* (B*T, n_heads*head_dim) */

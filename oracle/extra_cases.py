@@ -157,6 +157,8 @@ def transformer(which: str):
         elif which == "chitf_enc2":           # transformer condition encoder (n_cond_layers > 0, reference chitransformer.py:91-95)
             net = lib.ChiTransformer(7, 23, 10, 2, d_model=128, nhead=4, num_layers=2, n_cond_layers=2)
             x_shape, cond_shape = (10, 7), (2, 23)
+        elif which == "dit_h96":              # more than 64 tokens: streamed-key attention kernel
+            net, x_shape, cond_shape = lib.DiT1d(7, emb_dim=64, d_model=128, n_heads=4, depth=2), (96, 7), (64,)
         elif which == "dit_h10_d384":
             net, x_shape, cond_shape = lib.DiT1d(7, emb_dim=64, d_model=384, n_heads=6, depth=2), (10, 7), (64,)
         else:
@@ -198,7 +200,7 @@ SCENARIOS: Dict[str, Callable] = {
     "pearce_h64": pearce(64, 5), "pearce_h192": pearce(192, 37), "pearce_h512": pearce(512, 16),
     "janner_h128": janner_long(128, [1, 2, 2, 2], 32), "janner_h64_w48": janner_long(64, [1, 4, 2], 48),
     "diffuser_kitchen": shipped_diffuser("kitchen"), "diffuser_antmaze": shipped_diffuser("antmaze"),
-    "chitf_ta10": transformer("chitf_ta10"), "chitf_enc2": transformer("chitf_enc2"), "dit_h10_d384": transformer("dit_h10_d384"), "dit_h40_depth8": transformer("dit_h40_depth8"),
+    "chitf_ta10": transformer("chitf_ta10"), "chitf_enc2": transformer("chitf_enc2"), "dit_h96": transformer("dit_h96"), "dit_h10_d384": transformer("dit_h10_d384"), "dit_h40_depth8": transformer("dit_h40_depth8"),
     "chiunet_cfg3_width": chiunet_cfg3_width(),
     "pearce_cfg_pair": mlp_cfg_pair("pearce"), "dql_cfg_pair": mlp_cfg_pair("dql"), "idql_h2048": idql_wide(),
     "mlpnn_cfg_pair": mlpnn(),

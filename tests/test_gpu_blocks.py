@@ -73,7 +73,8 @@ def test_layernorm_modulate(c):
     torch.testing.assert_close(y2.cpu().double(), F.layer_norm(_ref(x), (c,), _ref(ga), _ref(be), 1e-5), rtol=2e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize("tokens,heads,dh", [(64, 10, 32), (16, 4, 16), (5, 2, 64), (1, 1, 8), (64, 3, 64), (33, 5, 20), (7, 3, 6)])
+@pytest.mark.parametrize("tokens,heads,dh", [(64, 10, 32), (16, 4, 16), (5, 2, 64), (1, 1, 8), (64, 3, 64), (33, 5, 20), (7, 3, 6),
+                                             (65, 2, 32), (96, 4, 32), (200, 3, 64), (128, 2, 6)])     # > 64: streamed-key kernel
 def test_attention_matches_mha_core(tokens, heads, dh):
     from cleandiffuser_amd.engine import blocks
     g = torch.Generator().manual_seed(tokens)
@@ -86,7 +87,7 @@ def test_attention_matches_mha_core(tokens, heads, dh):
     torch.testing.assert_close(out.cpu().double(), ref, rtol=2e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize("tokens,heads,dh", [(16, 4, 64), (64, 2, 32), (12, 4, 16), (9, 3, 6)])
+@pytest.mark.parametrize("tokens,heads,dh", [(16, 4, 64), (64, 2, 32), (12, 4, 16), (9, 3, 6), (100, 2, 32)])
 def test_attention_with_additive_mask(tokens, heads, dh):
     """Causal mask built the way nn.Transformer builds it (0 / -inf, clamped to the fp32 floor by the binding)."""
     from cleandiffuser_amd.engine import blocks

@@ -954,10 +954,11 @@ def test_shipped_large_diffuser_configs_stay_native(size, path, amd_lib, monkeyp
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which", ["chitf_ta10", "chitf_enc2", "dit_h10_d384", "dit_h40_depth8"])
+@pytest.mark.parametrize("which", ["chitf_ta10", "chitf_enc2", "dit_h10_d384", "dit_h96", "dit_h40_depth8"])
 def test_shipped_transformer_shapes_match_reference_fixture(which, amd_lib, monkeypatch):
     """Token counts / widths of the shipped dp_* and veteran configs that the small fixtures do not cover (Ta = 10, 10 and 40
-    tokens, head_dim 64, depth 8; ChiTransformer with a transformer condition encoder, n_cond_layers = 2): whole loop native,
+    tokens, head_dim 64, depth 8; ChiTransformer with a transformer condition encoder, n_cond_layers = 2; DiT1d over 96 tokens --
+    the streamed-key attention kernel, no shipped config is that long): whole loop native,
     reference fixture at 1e-4 (depth 8 included)."""
     calls = _spy_bigbatch(monkeypatch)
     out, gold = _extra(which)
