@@ -627,7 +627,7 @@ struct UNet {                     // one pass over the op list; with dry == true
     bool dry;
     int nb, bf, b0, rec, n_rec;
     // persistent (prepare) buffers
-    float *x, *prev, *xold, *xin, *obs, *e1, *te, *mte, *gobs, *mo, *tfilm, *ofilm, *pred, *splitk;
+    float *x, *prev, *xold, *xin, *obs, *e1, *te, *mte, *gobs, *mo, *tfilm, *ofilm, *pred, *splitk, *lobs;
     long long film_total;         // sum of film_out over all blocks (row width of the film tables)
     long long splitk_floats;      // split-K scratch: UNET_SPLITK slices of the largest conv output (rows x model_dim at full length)
 
@@ -656,7 +656,10 @@ struct UNet {                     // one pass over the op list; with dry == true
         return cdx_groupnorm_f32(&q, st);
     }
     // ChiResidualBlock on [xa | xb] at length L  ->  new buffer (bf * L, cout)
-    int block(const cdx_chiunet_block& k, long long film_off, const float* xa, const float* xb, int L, float** out) {
+    // `extra` (local conditioning): a (bf * L, cout) tensor added to the block's output -- it rides in the residual 1x1 conv
+    int block(const cdx_chiunet_block& k, long long film_off, const float* xa, const float* xb, int L, float** out,
+              const float* extra = nullptr) {
+        if (extra != nullptr && k.wra == nullptr) { cdx_set_err("local conditioning joins a block with a residual conv only"); return CDX_EINVAL; }
         const int ks = w->kernel_size, pad = ks / 2, co = k.cout;
         const long long n = (long long)bf * L * co;
         float* h1 = take(n);
@@ -671,7 +674,7 @@ struct UNet {                     // one pass over the op list; with dry == true
         CDX_TRY(conv(h2, co, k.w2, k.b2, L, L, ks, co, 1, pad, co, h1, co, nullptr, 0));       // h1 is free again
         const float* skip = xa;                                                                 // identity skip
         if (k.wra != nullptr) {
-            CDX_TRY(conv(xa, k.cin_a, k.wra, k.br, L, L, 1, k.cin_a, 1, 0, co, res, co, nullptr, 0));
+            CDX_TRY(conv(xa, k.cin_a, k.wra, k.br, L, L, 1, k.cin_a, 1, 0, co, res, co, extra, co));
             if (k.cin_b > 0) CDX_TRY(conv(xb, k.cin_b, k.wrb, nullptr, L, L, 1, k.cin_b, 1, 0, co, res, co, res, co));
             skip = res;
         }
@@ -681,13 +684,15 @@ struct UNet {                     // one pass over the op list; with dry == true
     }
     int film_out(const cdx_chiunet_block& k) const { return (w->cond_predict_scale ? 2 : 1) * k.cout; }
     int n_blocks() const { return 2 * w->n_levels + 2 + 2 * (w->n_levels - 1); }
+    int n_film_blocks() const { return n_blocks() + (w->local_obs_dim > 0 ? 2 : 0); }      // + local_cond_encoder.0 / .1
 
     // request-invariant tables: embeddings and the two halves of every block's FiLM vector
     int prepare() {
         const int E = w->emb_dim, EH = w->emb_hidden, EO = w->emb_out, trow = s->temb_per_sample ? bf : n_rec;
         const bool has_obs = w->cond_dim > 0;
         film_total = 0;
-        for (int i = 0; i < n_blocks(); ++i) film_total += film_out(w->blocks[i]);
+        for (int i = 0; i < n_film_blocks(); ++i) film_total += film_out(w->blocks[i]);
+        lobs = take(w->local_obs_dim > 0 ? (long long)bf * w->Ta * w->local_obs_dim : 0);
         x = take((long long)nb * s->hd); prev = take((long long)nb * s->hd); xold = take((long long)nb * s->hd);
         xin = take((long long)bf * s->hd);
         obs = take(has_obs ? (long long)bf * w->cond_dim : 0);
@@ -718,8 +723,16 @@ struct UNet {                     // one pass over the op list; with dry == true
             CDX_TRY(gemm(st, obs, w->cond_dim, w->gce_w, w->cond_dim, w->gce_b, gobs, EO, bf, EO, w->cond_dim));
             CDX_TRY(cdx_act_f32(gobs, mo, (long long)bf * EO, CDX_ACT_MISH, st));
         }
+        if (w->local_obs_dim > 0) {                       // observation rows, one per (sample, position); unconditional samples: zeros
+            const int width = w->Ta * w->local_obs_dim;
+            const long long n = (long long)bf * width;
+            const int n_cond_rows = (s->cond == nullptr || s->cfg_mode == 0) ? 0 : nb;
+            hipLaunchKernelGGL(obs_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, lobs, s->cond, bf, nb, b0,
+                               width, n_cond_rows);
+            CDX_TRY(hip_ok());
+        }
         long long off = 0;
-        for (int i = 0; i < n_blocks(); ++i) {
+        for (int i = 0; i < n_film_blocks(); ++i) {
             const cdx_chiunet_block& k = w->blocks[i];
             const int fo = film_out(k);
             // without an observation half the block's bias rides with the time half
@@ -738,10 +751,23 @@ struct UNet {                     // one pass over the op list; with dry == true
         long long foff = 0;
         int bi = 0, L = Ta;
         float* o = nullptr;
+        const float *hl0 = nullptr, *hl1 = nullptr;      // local conditioning (reference chiunet.py:153-160)
+        if (w->local_obs_dim > 0) {
+            long long lf = 0;
+            for (int i = 0; i < n_blocks(); ++i) lf += film_out(w->blocks[i]);
+            const cdx_chiunet_block &l1 = w->blocks[n_blocks()], &l2 = w->blocks[n_blocks() + 1];
+            float *t1 = nullptr, *t2 = nullptr;
+            CDX_TRY(block(l1, lf, lobs, nullptr, Ta, &t1));
+            CDX_TRY(block(l2, lf + film_out(l1), lobs, nullptr, Ta, &t2));
+            const int md = w->model_dim;
+            float* d = take((long long)bf * (Ta / 2) * md);
+            CDX_TRY(conv(t2, md, w->lc_down_w, w->lc_down_b, Ta, Ta / 2, 3, md, 2, 1, md, d, md, nullptr, 0));
+            hl0 = t1; hl1 = d;
+        }
         for (int k = 0; k < nl; ++k) {
             for (int j = 0; j < 2; ++j) {
                 const cdx_chiunet_block& kb = w->blocks[bi];
-                CDX_TRY(block(kb, foff, cur, nullptr, L, &o));
+                CDX_TRY(block(kb, foff, cur, nullptr, L, &o, (k == 0 && j == 0) ? hl0 : nullptr));
                 foff += film_out(kb); ++bi; cur = o;
             }
             skips[k] = cur;
@@ -759,7 +785,7 @@ struct UNet {                     // one pass over the op list; with dry == true
         }
         for (int k = 0; k < nl - 1; ++k) {
             const float* skip = skips[nl - 1 - k];
-            CDX_TRY(block(w->blocks[bi], foff, cur, skip, L, &o));
+            CDX_TRY(block(w->blocks[bi], foff, cur, skip, L, &o, k == nl - 2 ? hl1 : nullptr));
             foff += film_out(w->blocks[bi]); ++bi; cur = o;
             CDX_TRY(block(w->blocks[bi], foff, cur, nullptr, L, &o));
             foff += film_out(w->blocks[bi]); ++bi; cur = o;
@@ -793,6 +819,13 @@ int chiunet_check(const cdx_chiunet_weights* w, const cdx_sampling* s) {
     if (s->hd != w->Ta * w->act_dim || s->emb_dim != w->emb_dim) { cdx_set_err("U-Net request: shape mismatch"); return CDX_EINVAL; }
     if (w->cond_dim > 0 && (!s->cond || s->cond_dim != w->cond_dim || s->cfg_mode == 0)) {
         cdx_set_err("ChiUNet1d request: no condition (the reference requires one)"); return CDX_EINVAL;
+    }
+    if (w->local_obs_dim > 0) {
+        if (w->cond_dim != 0 || !w->lc_down_w || !w->lc_down_b || w->n_levels < 2) { cdx_set_err("ChiUNet1d local conditioning: cond_dim 0, lc_down and >= 2 levels required"); return CDX_EINVAL; }
+        if (!s->cond || s->cond_dim != w->Ta * w->local_obs_dim || s->cfg_mode == 0) {
+            cdx_set_err("ChiUNet1d request: local conditioning needs cond (batch, Ta * obs_dim)"); return CDX_EINVAL;
+        }
+        return CDX_OK;
     }
     if (w->cond_dim == 0 && (s->cond || s->cfg_mode != 0)) { cdx_set_err("unconditional U-Net: cond must be NULL, cfg_mode 0"); return CDX_EINVAL; }
     return CDX_OK;

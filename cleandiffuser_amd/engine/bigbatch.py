@@ -77,7 +77,8 @@ class CdxChiUNetWeights(ctypes.Structure):
                [(n, _FP) for n in ("map0_w", "map0_b", "map2_w", "map2_b", "gce_w", "gce_b")] + \
                [("blocks", ctypes.POINTER(CdxChiUNetBlock))] + \
                [(n, ctypes.POINTER(ctypes.c_void_p)) for n in ("down_w", "down_b", "up_w_even", "up_w_odd", "up_b")] + \
-               [(n, _FP) for n in ("fin_w", "fin_b", "fin_g", "fin_be", "out_w", "out_b")]
+               [(n, _FP) for n in ("fin_w", "fin_b", "fin_g", "fin_be", "out_w", "out_b")] + \
+               [("local_obs_dim", _I), ("lc_down_w", _FP), ("lc_down_b", _FP)]
 
 
 _declared = False
@@ -252,9 +253,12 @@ def _bind_chiunet(net, Ta: int, device) -> Optional[_Bound]:
     """ChiUNet1d (global conditioning) for the implicit-GEMM executor: conv weights are re-packed (c_out, k, c_in) once."""
     import torch.nn as nn
     from . import blocks as B
-    if not net.obs_as_global_cond or net.global_cond_encoder is None:
+    local = not net.obs_as_global_cond                  # local conditioning: one observation row per position (chiunet.py:78-82)
+    if (local and net.local_cond_encoder is None) or (not local and net.global_cond_encoder is None):
         return None
     n_levels = len(net.downs)
+    if local and n_levels < 2:
+        return None
     if Ta & (Ta - 1) or (Ta >> (n_levels - 1)) < 1 or n_levels > 8:
         return None
     keep = []
@@ -285,6 +289,12 @@ def _bind_chiunet(net, Ta: int, device) -> Optional[_Bound]:
     for res1, res2, _ in net.ups:
         half = res1.conv1[0].in_channels // 2
         blocks += [bind_block(res1, half, half), bind_block(res2, res2.conv1[0].in_channels, 0)]
+    if local:
+        enc1, enc2, enc_down = net.local_cond_encoder
+        # the two places the local features join have a residual conv in every real net (act_dim != model_dim; concat input)
+        if blocks[0].wra is None or blocks[len(blocks) - 2].wra is None:
+            return None
+        blocks += [bind_block(enc1, enc1.conv1[0].in_channels, 0), bind_block(enc2, enc2.conv1[0].in_channels, 0)]
     for b in blocks:                                    # identity skips need matching widths; the FAST GEMM path wants 16 | c_in
         if b.wra is None and (b.cin_b or b.cin_a != b.cout):
             return None
@@ -302,12 +312,18 @@ def _bind_chiunet(net, Ta: int, device) -> Optional[_Bound]:
     fin = net.final_conv
     E = net.emb_dim
     w = CdxChiUNetWeights()
-    w.act_dim, w.Ta, w.cond_dim, w.emb_dim = net.downs[0][0].conv1[0].in_channels, Ta, net.global_cond_encoder.in_features, E
+    w.act_dim, w.Ta, w.emb_dim = net.downs[0][0].conv1[0].in_channels, Ta, E
+    w.cond_dim = 0 if local else net.global_cond_encoder.in_features
     w.kernel_size, w.n_levels, w.cond_predict_scale = fin[0].kernel_size[0], n_levels, int(net.downs[0][0].cond_predict_scale)
     w.model_dim, w.final_groups = net.model_dim, fin[1].num_groups
-    w.emb_hidden, w.emb_out, w.film_ld = net.map_emb[0].out_features, E, 2 * E
+    w.emb_hidden, w.emb_out, w.film_ld = net.map_emb[0].out_features, E, (E if local else 2 * E)
     w.map0_w, w.map0_b, w.map2_w, w.map2_b = p(net.map_emb[0].weight), p(net.map_emb[0].bias), p(net.map_emb[2].weight), p(net.map_emb[2].bias)
-    w.gce_w, w.gce_b = p(net.global_cond_encoder.weight), p(net.global_cond_encoder.bias)
+    if local:
+        w.gce_w, w.gce_b = None, None
+        w.local_obs_dim = net.local_cond_encoder[0].conv1[0].in_channels
+        w.lc_down_w, w.lc_down_b = packed(B.pack_conv(net.local_cond_encoder[2].conv.weight)), p(net.local_cond_encoder[2].conv.bias)
+    else:
+        w.gce_w, w.gce_b = p(net.global_cond_encoder.weight), p(net.global_cond_encoder.bias)
     w.blocks = arr
     w.down_w, w.down_b = ptr_array([packed(B.pack_conv(d.weight)) for d in downs]), ptr_array([p(d.bias) for d in downs])
     w.up_w_even, w.up_w_odd = ptr_array([packed(e) for e, _ in up_packed]), ptr_array([packed(o) for _, o in up_packed])
@@ -488,6 +504,8 @@ def is_chiunet_gemm(module, batch: int, horizon: Optional[int] = None, edm: bool
                 if not forward:
                     return False
         big = batch >= JANNER_GEMM_MIN_BATCH
+    elif type(module) is ChiUNet1d and not module.obs_as_global_cond:
+        return True                                     # local conditioning: the executor is its only native path
     elif type(module) is ChiUNet1d and module.obs_as_global_cond:
         big = batch >= UNET_GEMM_MIN_BATCH
     else:
@@ -529,6 +547,11 @@ def janner_forward(net, x, noise) -> Optional[torch.Tensor]:
     return out
 
 
+def _unet_cond_dim(w) -> int:
+    """Width of a request's flattened condition: To * obs_dim (global conditioning) or Ta * obs_dim (local: a row per position)."""
+    return w.Ta * w.local_obs_dim if w.local_obs_dim > 0 else w.cond_dim
+
+
 def chiunet_forward(net, x, noise, condition) -> Optional[torch.Tensor]:
     from ..nn_diffusion.jannerunet import JannerUNet1d
     if type(net) is JannerUNet1d:
@@ -543,12 +566,13 @@ def chiunet_forward(net, x, noise, condition) -> Optional[torch.Tensor]:
     w = bound.struct
     with torch.no_grad():
         cond = _f32c(torch.flatten(condition, 1), dev)
-        if cond.shape[1] != w.cond_dim:
+        cond_dim = _unet_cond_dim(w)
+        if cond.shape[1] != cond_dim:
             return None
         temb = _f32c(net.map_noise(noise), dev)
         xin = _f32c(x, dev)
         out = torch.empty_like(xin)
-        _run("chiunet", bound, batch=b, hd=Ta * w.act_dim, emb_dim=w.emb_dim, cond_dim=w.cond_dim, temb=temb, steps=None,
+        _run("chiunet", bound, batch=b, hd=Ta * w.act_dim, emb_dim=w.emb_dim, cond_dim=cond_dim, temb=temb, steps=None,
              n_steps=0, temb_per_sample=1, predict_noise=0, cfg_mode=1, cfg_w=1.0, cond=cond, x_in=xin, prior=None,
              fix_mask=None, noise=None, x_min=None, x_max=None, x_out=out,
              chunk=CHUNK_OVERRIDE["chiunet"] or _chiunet_chunk(b, Ta, net.model_dim, 1))
@@ -711,7 +735,7 @@ def sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed) -> Optional[torc
             temb, emb_dim = _f32c(net.map_noise(t_vec), dev), bound.struct.d_model
             cond_dim = bound.struct.To * bound.struct.obs_dim
         elif kind == "chiunet":
-            temb, emb_dim, cond_dim = _f32c(net.map_noise(t_vec), dev), bound.struct.emb_dim, bound.struct.cond_dim
+            temb, emb_dim, cond_dim = _f32c(net.map_noise(t_vec), dev), bound.struct.emb_dim, _unet_cond_dim(bound.struct)
         else:
             temb, emb_dim, cond_dim = _time_features(net, t_vec, dev), bound.struct.emb_dim, bound.struct.obs_dim
         if cond_vec is None or w_cfg == 0.0 or (kind == "mlp" and cond_dim == 0):

@@ -404,6 +404,13 @@ typedef struct cdx_chiunet_weights {
     const float* const* up_b;
     const float *fin_w, *fin_b, *fin_g, *fin_be;        /* final_conv.0 packed (md, k, md), final_conv.1 GroupNorm */
     const float *out_w, *out_b;                         /* final_conv.3 1x1 (act_dim, md) */
+    /* ChiUNet1d with LOCAL conditioning (obs_as_global_cond = False, reference nn_diffusion/chiunet.py:78-82, 153-185): cond_dim = 0,
+     * film_ld = emb_out (FiLM from the time embedding alone), the request's cond is (batch, Ta * local_obs_dim) = one observation row
+     * per position.  `blocks` then carries two more entries after the main ones -- local_cond_encoder.0 / .1 (local_obs_dim ->
+     * model_dim) --; the first one's output is added after the first block of level 0, the second one's, downsampled by lc_down
+     * (packed (md, 3, md)), after the first block of the last up level. */
+    int32_t local_obs_dim;                              /* 0: no local conditioning */
+    const float *lc_down_w, *lc_down_b;
 } cdx_chiunet_weights;
 long long cdx_chiunet_workspace_floats(const cdx_chiunet_weights* w, const cdx_sampling* s);
 int cdx_chiunet_run(const cdx_chiunet_weights* w, const cdx_sampling* s, void* hip_stream);

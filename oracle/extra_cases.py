@@ -196,12 +196,33 @@ def chiunet_cfg3_width():
     return run
 
 
+def chiunet_local_cond():
+    """ChiUNet1d with LOCAL conditioning (obs_as_global_cond=False, reference nn_diffusion/chiunet.py:78-82, 153-185): one observation
+    row per action position, two extra residual blocks whose outputs join the first down level and the last up level."""
+    B, steps, Ta = 3, 4, 16
+
+    def run(lib, kind, device):
+        net = load_synth(lib.ChiUNet1d(2, 5, Ta, model_dim=64, emb_dim=64, dim_mult=[1, 2, 2], obs_as_global_cond=False), 43)
+        agent = lib.DDPM(net, lib.IdentityCondition(dropout=0.0), diffusion_steps=steps, x_max=torch.ones(1, Ta, 2, device=device),
+                         x_min=-torch.ones(1, Ta, 2, device=device), device=device)
+        agent.eval()
+        g = torch.Generator().manual_seed(43)
+        cond = torch.randn(B, Ta, 5, generator=g)
+        zs = [torch.randn(B, Ta, 2, generator=g) for _ in range(steps + 1)]
+        with torch.no_grad():
+            fwd = agent.model_ema["diffusion"](zs[0].to(device), torch.tensor([0, 1, 3], device=device), cond.to(device))
+        x, _ = _sample(agent, kind, torch.zeros(B, Ta, 2, device=device), zs, n_samples=B, sample_steps=steps,
+                       condition_cfg=cond.to(device), w_cfg=1.0)
+        return {"fwd": fwd, "x": x, "_agent": agent}
+    return run
+
+
 SCENARIOS: Dict[str, Callable] = {
     "pearce_h64": pearce(64, 5), "pearce_h192": pearce(192, 37), "pearce_h512": pearce(512, 16),
     "janner_h128": janner_long(128, [1, 2, 2, 2], 32), "janner_h64_w48": janner_long(64, [1, 4, 2], 48),
     "diffuser_kitchen": shipped_diffuser("kitchen"), "diffuser_antmaze": shipped_diffuser("antmaze"),
     "chitf_ta10": transformer("chitf_ta10"), "chitf_enc2": transformer("chitf_enc2"), "dit_h96": transformer("dit_h96"), "dit_h10_d384": transformer("dit_h10_d384"), "dit_h40_depth8": transformer("dit_h40_depth8"),
-    "chiunet_cfg3_width": chiunet_cfg3_width(),
+    "chiunet_cfg3_width": chiunet_cfg3_width(), "chiunet_local_cond": chiunet_local_cond(),
     "pearce_cfg_pair": mlp_cfg_pair("pearce"), "dql_cfg_pair": mlp_cfg_pair("dql"), "idql_h2048": idql_wide(),
     "mlpnn_cfg_pair": mlpnn(),
 }

@@ -126,7 +126,7 @@ def test_bigbatch_validation_fails_loudly(lib):
     assert lib.cdx_gemm_f32(ctypes.byref(blocks.CdxGemmArgs(M=4, N=4, K=4)), None) == -1
     assert b"null" in lib.cdx_last_error()
     assert lib.cdx_gemm_f32(ctypes.byref(blocks.CdxGemmArgs(M=0, N=4, K=4)), None) == 0          # empty batch is not an error
-    assert lib.cdx_attention_f32(ctypes.byref(blocks.CdxAttnArgs(B=1, T=65, n_heads=1, head_dim=8, qkv=8, out=8)), None) == -1
+    assert lib.cdx_attention_f32(ctypes.byref(blocks.CdxAttnArgs(B=1, T=1025, n_heads=1, head_dim=8, qkv=8, out=8)), None) == -1
     assert lib.cdx_layernorm_f32(ctypes.byref(blocks.CdxLnArgs(M=1, C=8192, x=8, y=8)), None) == -1
     w, s = bigbatch.CdxDitWeights(), bigbatch.CdxSampling()
     assert lib.cdx_dit1d_run(ctypes.byref(w), ctypes.byref(s), None) == -1

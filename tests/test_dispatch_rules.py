@@ -12,7 +12,9 @@ def test_unet_executor_choice(monkeypatch):
     chi_local = ChiUNet1d(2, 5, 1, model_dim=32, emb_dim=32, dim_mult=[1, 2], obs_as_global_cond=False)
     assert not bigbatch.is_chiunet_gemm(janner, 256) and bigbatch.is_chiunet_gemm(janner, bigbatch.JANNER_GEMM_MIN_BATCH)
     assert not bigbatch.is_chiunet_gemm(chi, 8) and bigbatch.is_chiunet_gemm(chi, bigbatch.UNET_GEMM_MIN_BATCH)
-    assert not bigbatch.is_chiunet_gemm(chi_local, 10 ** 6) and not bigbatch.is_chiunet_gemm(DiT1d(4, 8, d_model=16, n_heads=2, depth=1), 10 ** 6)
+    # local conditioning: the implicit-GEMM executor is its only native path, at every batch size
+    assert bigbatch.is_chiunet_gemm(chi_local, 1) and bigbatch.is_chiunet_gemm(chi_local, 10 ** 6)
+    assert not bigbatch.is_chiunet_gemm(DiT1d(4, 8, d_model=16, n_heads=2, depth=1), 10 ** 6)
     seen = []
 
     def fake_supported(module, horizon, edm=False):
@@ -21,6 +23,7 @@ def test_unet_executor_choice(monkeypatch):
     monkeypatch.setattr(runtime, "supported_backbone", fake_supported)
     # the second-generation program kernel has its own (smaller) LDS plan: pretend it shares the fake limit of the first
     monkeypatch.setattr(runtime2, "supported", lambda module, horizon: "LDS plan needs 200000 B" if horizon >= 64 else None)
+    monkeypatch.setattr(runtime2, "compact_only", lambda module, horizon: False)
     assert not bigbatch.is_chiunet_gemm(janner, 3, 32)                  # fits the program kernel: small batches stay there
     assert bigbatch.is_chiunet_gemm(janner, 3, 64)                      # does not fit: GEMM executor at any batch
     assert bigbatch.is_chiunet_gemm(chi, 3, 16, True)                   # fits only without the EDM buffers, plan has EDM steps

@@ -996,6 +996,18 @@ def test_chiunet_config3_width_matches_reference_fixture(executor, amd_lib, monk
     np.testing.assert_allclose(out["x"].cpu().numpy(), gold["x"], **TOL)
 
 
+def test_chiunet_local_conditioning_runs_on_the_gemm_executor(amd_lib, monkeypatch):
+    """ChiUNet1d(obs_as_global_cond=False) -- one observation row per action position, local_cond_encoder's two blocks
+    joining the first down level and the last up level (reference chiunet.py:78-82, 153-185) -- used to take the PyTorch modules;
+    now the stand-alone forward and the whole legacy-DDPM loop are one cdx_chiunet_run call each.  Reference fixture, 1e-4."""
+    calls = _spy_bigbatch(monkeypatch)
+    out, gold = _extra("chiunet_local_cond")
+    torch.cuda.synchronize()
+    assert [c[0] for c in calls] == ["chiunet", "chiunet"], calls
+    for k in ("fwd", "x"):
+        np.testing.assert_allclose(out[k].cpu().numpy(), gold[k], err_msg=k, **TOL)
+
+
 @pytest.mark.parametrize("name", ["pearce_cfg_pair", "dql_cfg_pair", "mlpnn_cfg_pair"])
 def test_tile_mlp_cfg_pair_is_fused(name, amd_lib, monkeypatch):
     """w_cfg not in {0, 1} on the batch-tiled MLP programs (PearceMlp, DQLMlp) used to fall back to the PyTorch
