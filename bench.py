@@ -199,8 +199,14 @@ def other_configs(device):
     big("config2_B3200", bc.cfg2big, "cdx_unet2_kernel<3, 8> (three trajectories, 8 wave64 per workgroup; the last 128 one per workgroup)", B=3200)
     big("config2_guided_B256", bc.cfg2g, "cdx_unet2_kernel<1, 8, true>: denoiser forward + classifier forward/backward + shifted solver step, "
         "one launch per guided sample() call", B=256)
-    big("config2_guided_B3200", bc.cfg2g, "cdx_unet2_kernel<2, 8, true>: two trajectories per workgroup, saved normalised tensors in a "
-        "global workspace; the batch the shipped Diffuser pipelines sample (50 environments x 64 plans, all with w_cg > 0)", reps=2, B=3200)
+    big("config2_guided_B3200", bc.cfg2g, "cdx_unet2_kernel<3, 8, true>: three trajectories per workgroup (compact guided program, saved "
+        "normalised tensors in a global workspace), 4 rounds of 768 + 128 one per workgroup; the batch the shipped Diffuser pipelines "
+        "sample (50 environments x 64 plans, all with w_cg > 0)", reps=2, B=3200)
+    big("kitchen_guided_B256", bc.cfgKg, "cdx_unet2_kernel<1, 8, true>: guided program of the shipped kitchen Diffuser size (model_dim 64, "
+        "H=32, D=69), saved tensors in the global workspace", B=256)
+    big("antmaze_guided_B256", bc.cfgAg, "cdx_unet2_kernel<1, 8, true>: compact guided program of the shipped antmaze Diffuser size "
+        "(model_dim 64, H=64, D=37)", B=256)
+    big("antmaze_unguided_B3200", bc.cfgAu, "cdx_unet2_kernel<1, 8>: compact one-trajectory program (model_dim 64, H=64, D=37)", reps=2, B=3200)
     try:
         label, call, b, steps, net, horizon = bc.cfg1()
         dt, k_ms = timed(call, 5)
