@@ -180,8 +180,11 @@ typedef struct cdx_unet2_launch {
      * scratch of (batch + 1) * ws_floats floats (one spare block), owned by the caller, ordered by the launch stream; ws_floats == 0: none */
     float* ws;
     int32_t ws_floats;
-    /* compact programs (engine/program2.py:compile_janner2(compact=True): the LDS plan that lets THREE trajectories share a
-     * workgroup): the authoritative state x_t lives in x_out and the multistep memory in ws ((batch + 1) * ws_floats floats) */
+    /* compact programs (engine/program2.py:compile_janner2 / compile_guided2 with compact=True: the LDS plan that lets THREE
+     * trajectories share a workgroup, or lets the largest shipped nets fit one workgroup at all): the authoritative state x_t lives
+     * in x_out and the multistep memory in the first horizon * dim floats of the trajectory's ws block ((batch + 1) * ws_floats
+     * floats; a guided program's saved tensors follow it).  x_out must not alias x_in.  Guided compact programs re-read x_t from
+     * x_out for the classifier through a CDX2_KIND2_LOADX op. */
     int32_t compact;
     /* optional profiling: device u64 [n_ops*8 + 2]; workgroup 0 stamps s_memtime at {op start, next-op prefetch issued, after the
      * staging barrier, op end, item record + segment read, first operands landed, MFMAs done, partial tile staged} of the first
