@@ -987,6 +987,7 @@ int cdx_unet2_run(const cdx_unet2_launch* L, void* hip_stream) {
     if (L->n_ops <= 0 || L->batch < 0 || L->horizon <= 0 || L->dim <= 0 || L->traj_floats <= 0) { cdx_set_err("non-positive size"); return CDX_EINVAL; }
     if (L->traj_per_wg < 1 || L->traj_per_wg > 3) { cdx_set_err("traj_per_wg must be 1, 2 or 3"); return CDX_EINVAL; }
     if (L->traj_per_wg == 3 && (L->n_waves != 8 || !L->compact)) { cdx_set_err("three trajectories per workgroup: 8-wave compact programs only"); return CDX_EINVAL; }
+    if (L->compact && L->x_out == L->x_in) { cdx_set_err("compact program: x_out holds the state during the launch and must not alias x_in"); return CDX_EINVAL; }
     if (L->compact && L->n_steps > 0 && (!L->ws || L->ws_floats < L->horizon * L->dim)) { cdx_set_err("compact program: ws (multistep memory) missing"); return CDX_EINVAL; }
     if (L->n_waves != 4 && L->n_waves != 8) { cdx_set_err("n_waves must be 4 or 8 (the program is compiled for one of them)"); return CDX_EINVAL; }
     if (L->n_steps > 0 && !L->steps) { cdx_set_err("steps == NULL with n_steps > 0"); return CDX_EINVAL; }

@@ -103,7 +103,9 @@ def test_unet2_validation_fails_loudly(lib):
     assert lib.cdx_unet2_run(ctypes.byref(L), None) == -1 and b"traj_per_wg" in lib.cdx_last_error()
     L.traj_per_wg, L.n_waves = 3, 8
     assert lib.cdx_unet2_run(ctypes.byref(L), None) == -1 and b"compact" in lib.cdx_last_error()     # three per workgroup: compact programs only
-    L.n_waves = 0
+    L.compact = 1
+    assert lib.cdx_unet2_run(ctypes.byref(L), None) == -1 and b"alias" in lib.cdx_last_error()      # compact: x_out is the state storage
+    L.compact, L.n_waves = 0, 0
     L.traj_per_wg, L.traj_floats = 2, 30 * 1024
     assert lib.cdx_unet2_run(ctypes.byref(L), None) == -1 and b"n_waves" in lib.cdx_last_error()
     L.n_waves = 8
