@@ -536,7 +536,8 @@ class _Builder2:
                 op[W2_DST2] = oa["dst2"].off
             for rec, si in zip(items, item_src):
                 src = oa["srcs"][si]
-                assert src.off < (1 << 16) and src.stride < (1 << 15)
+                if src.off >= (1 << 16) or src.stride >= (1 << 15):     # item words pack offset | stride << 16
+                    raise ValueError(f"LDS plan beyond the 16-bit slot offsets of the item format (slot at float {src.off})")
                 rec[I2_SRCSTR] = src.off | (src.stride << 16)
         return top
 

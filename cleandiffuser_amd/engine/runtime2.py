@@ -90,7 +90,7 @@ def compiled2(module, horizon: int, nw: int = P2.NW2, compact: bool = False) -> 
             kw = dict(compact=True, max_stage=COMPACT_STAGE, max_lds_bytes=(160 * 1024) // 3 // 16 * 16) if compact else {}
             try:
                 comp = _Compiled2(P2.compile_janner2(module, horizon, nw=nw, **kw), sig)
-            except (ValueError, AssertionError):
+            except ValueError:
                 if compact or nw != P2.NW2_MAX or os.environ.get("CDX_UNET2_COMPACT_T1", "1") == "0":
                     raise
                 # nets whose default plan does not fit 160 KiB (model_dim 64 at H = 64: the antmaze Diffuser, 193 KB) may still fit as
@@ -366,7 +366,7 @@ def compiled_guided2(net, clf_net, horizon: int, two: bool = False, three: bool 
                 kw = dict(save_global=True, compact=True, max_stage=GUIDED_T2_STAGE, max_lds_bytes=(160 * 1024) // 3 // 16 * 16)
             try:
                 comp = _Compiled2(P2.compile_guided2(net, clf_net, horizon, **kw), sig)
-            except (ValueError, AssertionError):         # (AssertionError: a plan so large that slot offsets leave 16 bits)
+            except ValueError:                           # (LDS plan too large)
                 if two or three:
                     raise
                 # wider nets, one trajectory per workgroup: saved tensors in the global workspace (model_dim 64 at H = 32, the kitchen
@@ -374,7 +374,7 @@ def compiled_guided2(net, clf_net, horizon: int, two: bool = False, three: bool 
                 # 64 at H = 64, the antmaze Diffuser: 158 KB)
                 try:
                     comp = _Compiled2(P2.compile_guided2(net, clf_net, horizon, save_global=True), sig)
-                except (ValueError, AssertionError):
+                except ValueError:
                     comp = _Compiled2(P2.compile_guided2(net, clf_net, horizon, save_global=True, compact=True), sig)
         except (ValueError, AssertionError) as e:
             comp = _Compiled2(None, sig, str(e))
