@@ -1,0 +1,65 @@
+"""The bench.py output contract, checked on the committed line of this round (profiles/r02_bench_n1.json -- written by `python
+bench.py` on MI355X): every field the driver parses is there, the roofline numbers are consistent with each other and with the
+committed rocprofv3 statistics, and the line names BASELINE.json's metric and configuration."""
+import csv
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def line():
+    path = os.path.join(ROOT, "profiles", "r02_bench_n1.json")
+    return json.loads(open(path).read().strip().splitlines()[-1])
+
+
+def test_bench_line_has_the_contract_fields(line):
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["higher_is_better"] is True and line["scaling"] == "weak" and line["data"] == "synthetic"
+    assert line["dtype"] == "f32" and line["vs_baseline"] is None          # BASELINE.md has no published number for this metric
+    assert "workload" in line["config"] and "model" not in line["config"]
+    assert "trajectories" in line["unit"] and "256" in line["metric"] and "DDIM" in line["metric"]
+    assert str(base.get("metric", "")).split()[0].lower() in line["metric"].lower()
+    # value = trajectories per second of the whole call: batch / ms_per_step
+    assert abs(line["value"] - 256 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-6
+
+
+def test_roofline_block_is_self_consistent(line):
+    r = line["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms"):
+        assert key in r, key
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    # achieved = algorithmic flops of one launch / measured kernel time
+    assert abs(r["achieved"] - r["flops_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e12) / r["achieved"] < 1e-6
+    assert r["kernel_ms"] <= line["ms_per_step"] <= 1.05 * r["kernel_ms"]      # a steady-state call is that one launch
+    assert r["traffic"] is None or r["traffic"] > 0
+    l2 = r["l2_stream"]
+    assert l2["bound"] == "l2" and abs(l2["frac"] - l2["achieved"] / l2["peak"]) < 1e-9
+
+
+def test_rocprof_statistics_agree_with_the_live_measurement(line):
+    path = os.path.join(ROOT, "profiles", "r02_rocprofv3_kernel_stats.csv")
+    rows = list(csv.DictReader(open(path)))
+    kern = [r for r in rows if "cdx_unet2_kernel<1, 8, false, false>" in r["Name"]]
+    assert len(kern) == 1
+    avg_ms = float(kern[0]["AverageNs"]) * 1e-6
+    assert abs(avg_ms - line["roofline"]["kernel_ms"]) / avg_ms < 0.03          # HIP events in bench.py vs rocprofv3 --kernel-trace
+    assert float(kern[0]["Percentage"]) > 95.0
+
+
+def test_cpu_baseline_and_side_configs(line):
+    c = line["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
+    names = {o["name"] for o in line["other_configs"]}
+    assert {"config2_B3200", "config2_guided_B256", "config2_guided_B3200", "config1", "config3", "config4_shard512",
+            "config5_chunk16384"} <= names
+    assert not any("error" in o for o in line["other_configs"]), [o for o in line["other_configs"] if "error" in o]
