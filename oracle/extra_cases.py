@@ -228,6 +228,85 @@ SCENARIOS: Dict[str, Callable] = {
 }
 
 
+# --------------------------------------------------------------------------------------------------------------------- #
+# BASELINE.json's five configurations at their EXACT (network size x solver x step count x guidance) combination, small batch
+# (construction and call: BASELINE.md section 2).  Round 2 pinned these nets only at reduced width or reduced step count.
+def baseline_config(which: str, batch: int):
+    def run(lib, kind, device):
+        g = torch.Generator().manual_seed(1000 + len(which) + batch)
+        B = batch
+        if which == "cfg1":         # PearceMlp DBC (tutorials/1_...py:60-81,138-141): 100-step DDPM, w_cfg = 1
+            net = load_synth(lib.PearceMlp(6, To=1, emb_dim=64, hidden_dim=256), 51)
+            cond = load_synth(lib.PearceObsCondition(17, 64, flatten=True, dropout=0.0), 52)
+            agent = lib.DiscreteDiffusionSDE(net, cond, predict_noise=False, x_max=torch.ones(1, 6), x_min=-torch.ones(1, 6),
+                                             diffusion_steps=100, device=device)
+            agent.eval()
+            obs = torch.randn(B, 1, 17, generator=g)
+            zs = [torch.randn(B, 6, generator=g) for _ in range(101)]
+            x, _ = _sample(agent, kind, torch.zeros(B, 6, device=device), zs, solver="ddpm", n_samples=B, sample_steps=100,
+                           temperature=0.5, w_cfg=1.0, condition_cfg=obs.to(device))
+        elif which in ("cfg2", "cfg2_guided"):   # JannerUNet1d Diffuser, H = 32, D = 23, 20-step DDIM (north star)
+            net = load_synth(lib.JannerUNet1d(23, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2, 2], kernel_size=5), 53)
+            fm = torch.zeros(32, 23)
+            fm[0, :17] = 1.0
+            clf = None
+            if which == "cfg2_guided":           # what diffuser_d4rl_mujoco.py runs: DDPM steps, CumRewClassifier guidance, log_p
+                cn = load_synth(lib.HalfJannerUNet1d(32, 23, out_dim=1, model_dim=32, emb_dim=32, dim_mult=(1, 2, 2, 2),
+                                                     kernel_size=3), 54)
+                clf = lib.CumRewClassifier(cn, device=device)
+            agent = lib.DiscreteDiffusionSDE(net, None, fix_mask=fm, classifier=clf, diffusion_steps=20, predict_noise=False,
+                                             device=device)
+            agent.eval()
+            if clf is not None:
+                clf.eval()
+            prior = torch.zeros(B, 32, 23)
+            prior[:, 0, :17] = torch.randn(B, 17, generator=g)
+            zs = [torch.randn(B, 32, 23, generator=g) for _ in range(21)]
+            if which == "cfg2":
+                x, _ = _sample(agent, kind, prior.to(device), zs[:1], solver="ddim", n_samples=B, sample_steps=20, temperature=0.5)
+            else:
+                x, log = _sample(agent, kind, prior.to(device), zs, solver="ddpm", n_samples=B, sample_steps=20, temperature=0.5,
+                                 w_cg=0.1, condition_cg=None)
+                return {"x": x, "log_p": log["log_p"]}
+        elif which == "cfg3":       # ChiUNet1d Diffusion Policy (dp_pusht), model_dim 256, legacy DDPM class, 50 steps
+            net = load_synth(lib.ChiUNet1d(2, 20, 2, model_dim=256, emb_dim=256, dim_mult=[1, 2, 2], obs_as_global_cond=True), 55)
+            agent = lib.DDPM(net, lib.IdentityCondition(dropout=0.0), diffusion_steps=50, x_max=torch.ones(1, 16, 2, device=device),
+                             x_min=-torch.ones(1, 16, 2, device=device), device=device)
+            agent.eval()
+            cond = torch.randn(B, 2, 20, generator=g)
+            zs = [torch.randn(B, 16, 2, generator=g) for _ in range(51)]
+            x, _ = _sample(agent, kind, torch.zeros(B, 16, 2, device=device), zs, n_samples=B, sample_steps=50,
+                           condition_cfg=cond.to(device), w_cfg=1.0)
+        elif which == "cfg4":       # DiT1d Decision Diffuser: d 320 / 10 heads / 64 tokens, CFG w = 2, 10-step DPM-Solver++ 2M
+            net = load_synth(lib.DiT1d(29, emb_dim=128, d_model=320, n_heads=10, depth=2, timestep_emb_type="fourier"), 56)
+            cond = load_synth(lib.MLPCondition(1, 128, [128], torch.nn.SiLU(), dropout=0.25), 57)
+            fm = torch.zeros(64, 29)
+            fm[0] = 1.0
+            agent = lib.ContinuousDiffusionSDE(net, cond, fix_mask=fm, predict_noise=True, noise_schedule="linear", device=device)
+            agent.eval()
+            prior = torch.zeros(B, 64, 29)
+            prior[:, 0] = torch.randn(B, 29, generator=g)
+            zs = [torch.randn(B, 64, 29, generator=g)]
+            x, _ = _sample(agent, kind, prior.to(device), zs, solver="ode_dpmsolver++_2M", n_samples=B, sample_steps=10,
+                           condition_cfg=(0.3 * torch.ones(B, 1) + 0.1 * torch.randn(B, 1, generator=g)).to(device), w_cfg=2.0,
+                           temperature=0.5)
+        else:                       # cfg5: SynthER ResidualMLP = IDQLMlp 1024 x 6, 128-step EDM Euler
+            net = load_synth(lib.IDQLMlp(0, 15, emb_dim=128, hidden_dim=1024, n_blocks=6), 58)
+            agent = lib.ContinuousEDM(net, None, device=device)
+            agent.eval()
+            zs = [torch.randn(B, 15, generator=g)]
+            x, _ = _sample(agent, kind, torch.zeros(B, 15, device=device), zs, solver="euler", n_samples=B, sample_steps=128)
+        return {"x": x}
+    return run
+
+
+SCENARIOS.update({
+    "baseline_cfg1": baseline_config("cfg1", 5), "baseline_cfg2_b256": baseline_config("cfg2", 256),
+    "baseline_cfg2_guided": baseline_config("cfg2_guided", 8), "baseline_cfg3": baseline_config("cfg3", 2),
+    "baseline_cfg4": baseline_config("cfg4", 3), "baseline_cfg5": baseline_config("cfg5", 3),
+})
+
+
 def run(name: str, lib_kind: str, device="cpu"):
     """Outputs of scenario `name` as {key: tensor}; keys starting with '_' are live objects for the caller, not results."""
     torch.manual_seed(1234)

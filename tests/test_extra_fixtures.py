@@ -13,5 +13,7 @@ def test_cpu_executor_reproduces_extra_reference_fixture(name):
     gold = np.load(golden_path("extra_" + name))
     out = extra_cases.run(name, "amd", "cpu")
     assert set(gold.files) == {k for k in out if not k.startswith("_")}
+    # 20 guided steps through autograd's conv backward (threaded, order not fixed): 4.8e-6 observed against the reference's own run
+    tol = 2e-5 if name == "baseline_cfg2_guided" else 2e-6
     for k in gold.files:
-        np.testing.assert_allclose(out[k].detach().numpy(), gold[k], rtol=2e-6, atol=2e-6, err_msg=f"{name}/{k}")
+        np.testing.assert_allclose(out[k].detach().numpy(), gold[k], rtol=tol, atol=tol, err_msg=f"{name}/{k}")
