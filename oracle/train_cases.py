@@ -1,0 +1,147 @@
+"""loss() / update() scenarios -- TEST INFRASTRUCTURE (oracle/__init__.py).
+
+north_star names ``DiffusionModel.loss()`` as part of the surface; round 2 left it pinned by nothing but a finiteness check.
+Each scenario builds one solver class (reference diffusion/diffusionsde.py:94-141, 387-397, 725-739; newedm.py:152-190;
+ddpm.py:80-112) in TRAIN mode on synthetic weights, then under ``torch.manual_seed`` records
+
+* ``loss``        -- the value of one ``loss(x0, condition)`` call (draw order: timestep, noise, label-dropout mask),
+* ``upd_loss``    -- the ``loss`` entries of three consecutive ``update()`` calls (AdamW step + EMA each),
+* ``grad_norm``   -- the clipped-gradient norms ``update()`` reports,
+* ``p_head`` / ``ema_head`` / ``p_abs`` / ``ema_abs`` -- the first 16 entries of the first parameter and the sum of |p| over all
+  parameters of ``model`` and ``model_ema`` after the three updates.
+
+``python -m oracle.gen_train_golden`` runs them on the REAL reference (build container) and commits ``tests/golden/train_*.npz``;
+the tests run the same functions on this repo's classes (CPU, and the ROCm device with the CPU generator's draws replayed through
+``cpu_rng`` so both sides see identical timesteps / noise / masks).
+"""
+import contextlib
+from typing import Callable, Dict
+
+import numpy as np
+import torch
+
+from cleandiffuser_amd.utils import load_synth
+from . import cases
+
+
+@contextlib.contextmanager
+def cpu_rng(device):
+    """Route the random draws of loss() through the CPU generator and move them to `device`: a ROCm device has its own Philox
+    stream, so seeded draws made there can never equal the reference's CPU ones."""
+    if str(device) == "cpu":
+        yield
+        return
+    orig = {k: getattr(torch, k) for k in ("randn_like", "randn", "rand", "randint")}
+
+    def randn_like(ref, *a, **k):
+        return orig["randn"](ref.shape, dtype=ref.dtype).to(ref.device)
+
+    def _strip(fn):
+        def g(*a, **k):
+            dev = k.pop("device", None)
+            out = fn(*a, **k)
+            return out.to(dev) if dev is not None else out
+        return g
+    torch.randn_like = randn_like
+    torch.randn, torch.rand, torch.randint = _strip(orig["randn"]), _strip(orig["rand"]), _strip(orig["randint"])
+    try:
+        yield
+    finally:
+        for k, v in orig.items():
+            setattr(torch, k, v)
+
+
+def _record(agent, x0, cond, device, n_updates=3):
+    x0 = x0.to(device)
+    cond = None if cond is None else cond.to(device)
+    agent.train()
+    out = {}
+    with cpu_rng(device):
+        torch.manual_seed(4321)
+        out["loss"] = agent.loss(x0, cond).detach().reshape(1)
+        losses, norms = [], []
+        for _ in range(n_updates):
+            log = agent.update(x0, cond)
+            losses.append(float(log["loss"]))
+            gn = log.get("grad_norm")
+            norms.append(float(gn) if gn is not None else 0.0)
+    out["upd_loss"] = torch.tensor(losses)
+    out["grad_norm"] = torch.tensor(norms)
+    for tag, mod in (("p", agent.model), ("ema", agent.model_ema)):
+        ps = list(mod.parameters())
+        out[tag + "_head"] = ps[0].detach().reshape(-1)[:16].clone()
+        out[tag + "_abs"] = torch.stack([p.detach().abs().sum() for p in ps]).sum().reshape(1)
+    return out
+
+
+def _janner(lib, device, cls, **kw):
+    net = load_synth(lib.JannerUNet1d(6, model_dim=16, emb_dim=16, dim_mult=[1, 2], kernel_size=5), 61)
+    fm = torch.zeros(8, 6)
+    fm[0, :4] = 1.0
+    return getattr(lib, cls)(net, None, fix_mask=fm, grad_clip_norm=1.0, device=device, **kw)
+
+
+def discrete(predict_noise: bool):
+    def run(lib, kind, device):
+        agent = _janner(lib, device, "DiscreteDiffusionSDE", diffusion_steps=50, predict_noise=predict_noise,
+                        loss_weight=torch.linspace(0.5, 1.5, 6).expand(8, 6).contiguous())
+        g = torch.Generator().manual_seed(1)
+        return _record(agent, torch.randn(5, 8, 6, generator=g), None, device)
+    return run
+
+
+def continuous():
+    def run(lib, kind, device):
+        agent = _janner(lib, device, "ContinuousDiffusionSDE", predict_noise=True, noise_schedule="linear")
+        g = torch.Generator().manual_seed(2)
+        return _record(agent, torch.randn(5, 8, 6, generator=g), None, device)
+    return run
+
+
+def edm_conditional():
+    """ContinuousEDM over a conditional MLP denoiser; MLPCondition with label dropout 0.25 in train mode (the Bernoulli mask is a
+    third seeded draw, reference nn_condition/base_nn_condition.py:7-12)."""
+    def run(lib, kind, device):
+        net = load_synth(lib.IDQLMlp(11, 3, emb_dim=16, hidden_dim=64, n_blocks=2), 62)
+        agent = lib.ContinuousEDM(net, lib.IdentityCondition(dropout=0.25), grad_clip_norm=0.5, device=device)
+        g = torch.Generator().manual_seed(3)
+        return _record(agent, torch.randn(9, 3, generator=g), torch.randn(9, 11, generator=g), device)
+    return run
+
+
+def legacy_ddpm():
+    def run(lib, kind, device):
+        net = load_synth(lib.PearceMlp(6, To=1, emb_dim=32, hidden_dim=64), 63)
+        cond = load_synth(lib.PearceObsCondition(11, 32, flatten=True, dropout=0.0), 64)
+        agent = lib.DDPM(net, cond, diffusion_steps=20, predict_noise=False, device=device)
+        g = torch.Generator().manual_seed(4)
+        return _record(agent, torch.randn(7, 6, generator=g).clamp(-1, 1), torch.randn(7, 1, 11, generator=g), device)
+    return run
+
+
+def weighted_regression():
+    """``weighted_regression_tensor`` kwarg of the new-style loss (reference diffusionsde.py:107-110; the AWR pipelines pass it)."""
+    def run(lib, kind, device):
+        net = load_synth(lib.DQLMlp(11, 6, emb_dim=16), 65)
+        agent = lib.DiscreteDiffusionSDE(net, lib.IdentityCondition(dropout=0.0), diffusion_steps=10, predict_noise=True, device=device)
+        g = torch.Generator().manual_seed(5)
+        x0, c, w = torch.randn(6, 6, generator=g), torch.randn(6, 11, generator=g), torch.rand(6, generator=g)
+        agent.train()
+        with cpu_rng(device):
+            torch.manual_seed(99)
+            loss = agent.loss(x0.to(device), c.to(device), weighted_regression_tensor=w.to(device))
+            log = agent.update(x0.to(device), c.to(device), weighted_regression_tensor=w.to(device))
+        return {"loss": loss.detach().reshape(1), "upd_loss": torch.tensor([float(log["loss"])])}
+    return run
+
+
+SCENARIOS: Dict[str, Callable] = {
+    "discrete_eps": discrete(True), "discrete_x0": discrete(False), "continuous_eps": continuous(),
+    "edm_conditional": edm_conditional(), "legacy_ddpm": legacy_ddpm(), "weighted_regression": weighted_regression(),
+}
+
+
+def run(name: str, lib_kind: str, device="cpu"):
+    torch.manual_seed(1234)
+    out = SCENARIOS[name](cases.lib_namespace(lib_kind), lib_kind, device)
+    return {k: v.detach().cpu().numpy().astype(np.float32) for k, v in out.items()}

@@ -1048,3 +1048,18 @@ def test_exact_baseline_configuration_matches_reference_fixture(name, amd_lib, m
         np.testing.assert_allclose(out[k].cpu().numpy() / scale, gold[k] / scale, err_msg=f"{name}/{k}", **TOL)
     if name == "baseline_cfg2_guided":                               # candidate selection is index-exact
         assert int(out["log_p"].argmax()) == int(gold["log_p"].argmax())
+
+
+@pytest.mark.parametrize("name", ["discrete_eps", "discrete_x0", "continuous_eps", "edm_conditional", "legacy_ddpm",
+                                  "weighted_regression"])
+def test_loss_and_update_match_reference_fixture(name):
+    """loss() / update() on the ROCm device against what the REAL reference computed on CPU from the same seeded
+    timestep / noise / label-dropout draws (oracle/train_cases.py; the CPU generator's draws are replayed on the device): loss value,
+    three AdamW + EMA updates, clipped-gradient norms, parameter / EMA checksums.  Reference diffusionsde.py:94-141, newedm.py:152-190,
+    ddpm.py:80-112, basic.py:66,83-86."""
+    from oracle import train_cases
+    gold = np.load(golden_path("train_" + name))
+    out = train_cases.run(name, "amd", DEV)
+    assert set(gold.files) == set(out)
+    for k in gold.files:
+        np.testing.assert_allclose(out[k], gold[k], err_msg=f"{name}/{k}", **TOL)
