@@ -73,7 +73,14 @@ def sharded_sample(agent, prior: torch.Tensor, *, gather: bool = True, seed: Opt
         kw["noise"] = [z[lo:hi] if z.shape[0] == n else z for z in kw["noise"]]
     elif seed is not None:
         steps = kw.get("sample_steps")
-        steps = getattr(agent, "diffusion_steps", 5) if steps is None else steps          # legacy DDPM: None = every step
+        if steps is None:
+            # the default of the agent's own sample() signature: 5 for the SDE solvers, None = "every diffusion step" only for
+            # the legacy DDPM class (drawing diffusion_steps + 1 = 1001 global tensors for a 5-step call costs GBs of host memory)
+            import inspect
+            par = inspect.signature(agent.sample).parameters.get("sample_steps")
+            steps = par.default if par is not None and par.default is not inspect.Parameter.empty else None
+            if steps is None:
+                steps = getattr(agent, "diffusion_steps", 5)
         n_draws = steps + (kw.get("diffusion_x_sampling_steps") or 0) + 1
         ref = sample_kwargs.get("warm_start_reference")
         shape = tuple(ref.shape) if isinstance(ref, torch.Tensor) else tuple(prior.shape)   # the draws follow the tensor they perturb

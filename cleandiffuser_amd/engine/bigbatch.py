@@ -496,7 +496,9 @@ def is_chiunet_gemm(module, batch: int, horizon: Optional[int] = None, edm: bool
         if horizon is not None and not edm:
             from . import runtime2           # the second-generation program kernel keeps its lead at every batch size (two
             if batch >= runtime2.min_batch() and runtime2.supported(module, horizon) is None:   # co-resident workgroups per CU)
-                if not runtime2.compact_only(module, horizon):
+                # ... in sampling loops.  Stand-alone forwards (`forward`: per-sample timesteps) are not served by that kernel at
+                # all: they keep the crossover rule below (first program kernel under JANNER_GEMM_MIN_BATCH, GEMM executor above)
+                if not runtime2.compact_only(module, horizon) and not forward:
                     return False
                 # nets that fit only as a compact one-trajectory program (antmaze Diffuser, H = 128 plans): their sampling loops
                 # take the kernel at every batch size (measured, antmaze size: 10.9 k vs 6.0 k trajectories/s at B = 256, 13.3 k vs

@@ -96,7 +96,7 @@ def compiled2(module, horizon: int, nw: int = P2.NW2, compact: bool = False) -> 
                 # nets whose default plan does not fit 160 KiB (model_dim 64 at H = 64: the antmaze Diffuser, 193 KB) may still fit as
                 # a compact program with the whole LDS to itself: one trajectory per workgroup
                 comp = _Compiled2(P2.compile_janner2(module, horizon, nw=nw, compact=True), sig)
-        except (ValueError, AssertionError) as e:
+        except ValueError as e:                  # the documented 'does not fit / unsupported layer' signal; invariant failures propagate
             comp = _Compiled2(None, sig, str(e))
     per_mod[key] = comp
     return comp
@@ -154,9 +154,14 @@ def film_table(comp: _Compiled2, module, t_vec: torch.Tensor, modules=None) -> t
 
 
 def plan_film_table(comp: _Compiled2, module, plan, device, modules=None) -> torch.Tensor:
-    from .plan import cached
-    return cached(plan, ("film2", str(device), id(module), comp.sig, len(comp.prog.embtabs)),
-                  lambda: film_table(comp, module, R.device_times(plan, device), modules))
+    # one entry per (device, module, program variant): replaced -- not accumulated -- when the weight signature changes (a train /
+    # evaluate loop that keeps the solver's cached plan would otherwise add a device table + a long tuple key per ema_update)
+    memo = plan.__dict__.setdefault("_memo", {})
+    key = ("film2", str(device), id(module), comp.prog.nw, bool(comp.prog.compact), comp.prog.ws_floats, len(comp.prog.embtabs))
+    hit = memo.get(key)
+    if hit is None or hit[0] != comp.sig:
+        hit = memo[key] = (comp.sig, film_table(comp, module, R.device_times(plan, device), modules))
+    return hit[1]
 
 
 def min_batch() -> int:
@@ -233,7 +238,11 @@ def plan_for(module, horizon: int, batch: int):
         return comp, [(0, batch, t)]
     tmax = 3 if three is not None else (2 if comp.prog.lds_bytes(2) <= 160 * 1024 else 1)
     parts = plan_parts(batch, tmax)
-    if max(p[2] for p in parts) == 3:
+    # every part of a launch runs the SAME program: the compact one (valid at 1..3 trajectories per workgroup) as soon as any part
+    # asks for more trajectories than the default program's LDS plan holds (a cut into T = 2 parts is possible with tmax = 3 although
+    # two default plans do not fit: model_dim 32, dim_mult [1,2,4] at H = 32 is 90.7 KB -- ADVICE r2)
+    if any(comp.prog.lds_bytes(p[2]) > 160 * 1024 for p in parts) or max(p[2] for p in parts) == 3:
+        assert three is not None
         return three, parts
     return comp, parts
 
@@ -376,7 +385,7 @@ def compiled_guided2(net, clf_net, horizon: int, two: bool = False, three: bool 
                     comp = _Compiled2(P2.compile_guided2(net, clf_net, horizon, save_global=True), sig)
                 except ValueError:
                     comp = _Compiled2(P2.compile_guided2(net, clf_net, horizon, save_global=True, compact=True), sig)
-        except (ValueError, AssertionError) as e:
+        except ValueError as e:
             comp = _Compiled2(None, sig, str(e))
     per[key] = comp
     return comp

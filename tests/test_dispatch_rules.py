@@ -65,3 +65,36 @@ def test_launch_plan_cuts_large_batches():
         assert sum(c for _, c, _ in parts) == b and parts[0][0] == 0 and all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(len(parts) - 1))
 
 
+
+
+def test_every_launch_part_fits_the_program_it_runs_on():
+    """with a compact program present plan_for() cuts batches with T up to 3; a cut into T = 2 parts used to be launched on
+    the DEFAULT program even when two of its LDS plans exceed 160 KiB (model_dim 32, dim_mult [1,2,4], H = 32: 90.7 KB each)."""
+    net = JannerUNet1d(64, model_dim=32, dim_mult=[1, 2, 4])
+    for b in (1, 256, 300, 512, 600, 768, 1024, 3200):
+        comp, parts = runtime2.plan_for(net, 32, b)
+        assert sum(c for _, c, _ in parts) == b
+        assert all(comp.prog.lds_bytes(t) <= 160 * 1024 for _, _, t in parts), (b, parts)
+
+
+def test_standalone_forward_of_a_v2_net_keeps_the_gemm_crossover():
+    """the v2 kernel serves sampling loops only; a stand-alone forward (per-sample timesteps) of the same net follows the
+    batch crossover between the first program kernel and the implicit-GEMM executor."""
+    net = JannerUNet1d(23, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2, 2], kernel_size=5)
+    assert not bigbatch.is_chiunet_gemm(net, 3200, 32)                       # loop: v2 program kernel
+    assert bigbatch.is_chiunet_gemm(net, 3200, 32, forward=True)             # forward at the Diffuser batch: GEMM executor
+    assert not bigbatch.is_chiunet_gemm(net, 256, 32, forward=True)
+
+
+def test_sharded_sample_draws_the_solver_default_number_of_steps(monkeypatch):
+    """sharded_sample(seed=...) without sample_steps follows the agent's own default (5 for the SDE solvers), not
+    diffusion_steps (1000 -> 1001 global-batch draws)."""
+    from cleandiffuser_amd import distributed
+    from cleandiffuser_amd.diffusion import DiscreteDiffusionSDE
+    from cleandiffuser_amd.diffusion.ddpm import DDPM
+    seen = []
+    monkeypatch.setattr(distributed, "global_noise", lambda shape, n, seed: seen.append(n) or [torch.zeros(shape) for _ in range(n)])
+    net = JannerUNet1d(6, model_dim=16, emb_dim=16, dim_mult=[1, 2], kernel_size=5)
+    distributed.sharded_sample(DiscreteDiffusionSDE(net, None, diffusion_steps=1000), torch.zeros(2, 8, 6), seed=1, solver="ddim")
+    distributed.sharded_sample(DDPM(net, None, diffusion_steps=7), torch.zeros(2, 8, 6), seed=1)
+    assert seen == [6, 8]
