@@ -10,21 +10,22 @@ temperature 0.5 -- synthetic random-init weights and synthetic inputs already re
 
 The ONE JSON line (rank 0):
 
-* ``value`` -- N = 1: trajectories/s of the B=256 call.  N > 1: WEAK scaling -- every rank denoises its own 256 trajectories
-  and the finished shards are exchanged with one RCCL all-gather INSIDE the timed region (north star: "RCCL over xGMI used only
-  to gather sampled trajectories"); ``scaling`` says "weak".
-* ``strong_scaling`` (N > 1) -- the same timed loop for a FIXED global batch sharded over the ranks through
-  ``cleandiffuser_amd.distributed.sharded_sample`` (shard, sample, all-gather): global B = 256 (the metric's batch: 256 / N
-  trajectories per GPU -- one workgroup per trajectory leaves most of a GPU idle, this is the latency floor of one launch) and
-  global B = 3200 (the batch the shipped Diffuser pipelines really sample: 50 environments x 64 candidate plans).
+* ``value`` -- trajectories/s of the metric's GLOBAL B = 256 call exactly as a pipeline makes it (no ``noise=``: the initial draw is
+  inside the call).  N > 1: STRONG scaling -- the 256 trajectories are cut into 256 / N per rank through
+  ``cleandiffuser_amd.distributed.sharded_sample`` (shard, sample, ONE RCCL all-gather of the result inside the timed region: north
+  star "RCCL over xGMI used only to gather sampled trajectories"); ``scaling`` says "strong" (north star: ">= 6x strong scaling").
+* ``replayed_noise`` -- the same call with the recorded ``noise=[z0]`` (rounds 1-2's headline), for comparison.
+* ``weak_scaling`` (N > 1) -- every rank its own 256 trajectories + the all-gather of N x 256;  ``strong_scaling.global_batch_3200``
+  -- the batch the shipped Diffuser pipelines really sample (50 environments x 64 candidate plans) sharded the same way.
 * ``roofline`` prices the single fused kernel against the fp32-MFMA peak using the algorithmic FLOPs of the reference modules
   (786.6 MFLOP per trajectory = 39.33 MFLOP x 20 forwards) and the kernel's mean duration from HIP events on the
   launch stream.
 * ``other_configs`` (N = 1) -- the other BASELINE configs and the guided / large-batch variants of config 2, measured by the same
   process right after the headline (short runs; builder-independent numbers for configs 1, 3, 4, 5).
-* ``cpu_baseline`` (N = 1) -- the CPU oracle port (oracle/torch_port.py, the same ATen ops the reference runs) on this host: at
-  the fastest thread count of a probe and at ONE thread, with the CPU model and torch build; plus the recorded figure of the
-  real reference measured in the build container (profiles/r02_reference_cpu.json).  Reported baseline only.
+* ``cpu_baseline`` (N = 1) -- the imported reference classes when /root/reference is mounted (``kind: "reference"``; build
+  container), else the CPU oracle port (oracle/torch_port.py, the same ATen ops the reference runs; ``kind: "port"``; GPU boxes) on
+  this host: at the fastest thread count of a probe and at ONE thread, with the CPU model and torch build; plus the recorded figure
+  of the real reference measured in the build container (profiles/r02_reference_cpu.json).  Reported baseline only.
 """
 import argparse
 import json
@@ -78,9 +79,31 @@ def _cpu_model():
     return "unknown"
 
 
+def _reference_call(net):
+    """The REAL reference's sample() (imported from the read-only mount through oracle/ref_import.py) on the bench's weights, or None
+    where the mount does not exist (the GPU boxes: SURVEY 8d's "imported reference classes" are only reachable in the build
+    container)."""
+    try:
+        from oracle import cases, ref_import
+        if not ref_import.available():
+            return None
+        ref = cases.lib_namespace("reference")
+        rnet = ref.JannerUNet1d(DIM, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2, 2], kernel_size=5)
+        rnet.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()})
+        fix = torch.zeros(HORIZON, DIM)
+        fix[0, :17] = 1.0
+        agent = ref.DiscreteDiffusionSDE(rnet, None, fix_mask=fix, diffusion_steps=SAMPLE_STEPS, predict_noise=False, device="cpu")
+        agent.eval()
+        prior, _ = make_inputs("cpu", 0, 256)
+        return lambda: agent.sample(prior, solver="ddim", n_samples=256, sample_steps=SAMPLE_STEPS, temperature=0.5)[0]
+    except Exception:  # noqa: BLE001 -- any import problem: fall back to the port, which is pinned to the same fixtures
+        return None
+
+
 def cpu_baseline(net, budget_s=10.0):
-    """Time the CPU oracle on a bounded sample of the same workload: whole sample() calls at B=256 until ~budget_s of CPU work
-    has been done (>= 2 calls) at the fastest thread count of a probe, then >= 1 call at one thread."""
+    """Time the CPU path on a bounded sample of the same workload: whole sample() calls at B=256 until ~budget_s of CPU work
+    has been done (>= 2 calls) at the fastest thread count of a probe, then >= 1 call at one thread.  The imported reference
+    classes when /root/reference is mounted (``kind: "reference"``), else the oracle port (``kind: "port"``)."""
     from oracle import torch_port
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     fwd = torch_port.make_forward(sd, dict(emb_dim=32, kernel_size=5, dim_mult=[1, 2, 2, 2]))
@@ -88,9 +111,13 @@ def cpu_baseline(net, budget_s=10.0):
     fm = torch.zeros(1, HORIZON, DIM)
     fm[0, 0, :17] = 1.0
     avail = torch.get_num_threads()           # torch's own default = the cores this process may use
+    ref_call = _reference_call(net)
+    kind = "reference" if ref_call is not None else "port"
 
     def call():
         with torch.no_grad():
+            if ref_call is not None:
+                return ref_call()
             return torch_port.vp_sample(fwd, prior, [z0], solver="ddim", sample_steps=SAMPLE_STEPS, discrete=True,
                                         diffusion_steps=SAMPLE_STEPS, temperature=0.5, predict_noise=False,
                                         fix_mask=fm)
@@ -125,8 +152,9 @@ def cpu_baseline(net, budget_s=10.0):
     except (OSError, ValueError):
         pass
     blas = [ln.strip() for ln in torch.__config__.show().splitlines() if "BLAS" in ln or "MKL" in ln or "OpenMP" in ln][:4]
-    return {"value": 256 * n / dt, "unit": "trajectories/s", "cores": cores, "kind": "port",
-            "sample": f"{n} full sample() calls of B=256 (20-step DDIM) through oracle/torch_port.py, {dt:.1f}s wall, "
+    how = "the imported reference classes (/root/reference)" if kind == "reference" else "oracle/torch_port.py (no /root/reference on this box)"
+    return {"value": 256 * n / dt, "unit": "trajectories/s", "cores": cores, "kind": kind,
+            "sample": f"{n} full sample() calls of B=256 (20-step DDIM) through {how}, {dt:.1f}s wall, "
                       f"{cores} of {avail} threads (fastest of a probe over {sorted(probe)})",
             "all_cores": {"value": 256 / probe[avail], "cores": avail, "sample": "one call after a warm-up"},
             "one_thread": {"value": 256 * n1 / dt1, "cores": 1, "sample": f"{n1} calls, {dt1:.1f}s wall"},
@@ -272,10 +300,26 @@ def main():
     kw = dict(solver="ddim", n_samples=BATCH, sample_steps=SAMPLE_STEPS, temperature=0.5)
     gathered = torch.empty((BATCH * world, HORIZON, DIM), device=device) if dist is not None else None
 
+    gprior, gz = make_inputs(device, 12345, BATCH)        # the GLOBAL batch of the metric, identical on every rank
+    skw = dict(solver="ddim", sample_steps=SAMPLE_STEPS, temperature=0.5)
+
     def step():
+        # exactly what a pipeline calls (reference pipelines/diffuser_d4rl_mujoco.py:144): no `noise=`, the initial N(0, I) draw
+        # (reference diffusionsde.py:493) happens inside sample() and inside the timed region.
+        # N > 1: STRONG scaling of the metric's own batch -- the global B = 256 request is cut into 256 / N trajectories per rank,
+        # sampled, and exchanged with the one RCCL all-gather of the data path, all inside the timed region
+        if dist is not None:
+            return cdist.sharded_sample(agent, gprior, gather=True, **skw)
+        x, _ = agent.sample(prior, **kw)
+        return x
+
+    def step_replayed():
         x, _ = agent.sample(prior, noise=[z0], **kw)
-        if dist is not None:                  # the one exchange of the data path: all ranks end up with every trajectory
-            dist.all_gather_into_tensor(gathered, x)
+        return x
+
+    def step_weak():                          # every rank denoises its own 256 trajectories, then the all-gather of N x 256
+        x, _ = agent.sample(prior, **kw)
+        dist.all_gather_into_tensor(gathered, x)
         return x
 
     def fence():
@@ -305,16 +349,22 @@ def main():
     elapsed, x = timed_loop(step, args.steps, 0)
     kernel_ms = runtime.drain_launch_timing()
     runtime.enable_launch_timing(False)
-    assert torch.isfinite(x).all()
+    assert torch.isfinite(x).all() and x.shape[0] == BATCH
+    replay_reps = max(args.steps // 4, 5)
+    el_replay, _ = timed_loop(step_replayed, replay_reps, 2)
 
-    strong = None
-    if dist is not None:                      # fixed global batch sharded over the ranks: shard -> sample -> all-gather
+    strong, weak = None, None
+    if dist is not None:
+        reps = max(args.steps // 4, 3)
+        el, xw = timed_loop(step_weak, reps, 2)
+        weak = {"value": BATCH * world * reps / el, "unit": "trajectories/s", "ms_per_call": 1e3 * el / reps, "calls_timed": reps,
+                "what": f"every rank samples its own {BATCH} trajectories, then one RCCL all-gather of the {world} x {BATCH} result"}
+        # the batch the shipped Diffuser pipelines really sample (50 environments x 64 candidate plans), sharded the same way
         strong = {}
-        for gb in (256, 3200):
-            gp, gz = make_inputs(device, 12345, gb)      # identical on every rank
-            skw = dict(solver="ddim", sample_steps=SAMPLE_STEPS, temperature=0.5)
-            reps = max(args.steps // (4 if gb == 256 else 16), 3)
-            el, xs = timed_loop(lambda: cdist.sharded_sample(agent, gp, gather=True, noise=[gz], **skw), reps, 2)
+        for gb in (3200,):
+            gp, _ = make_inputs(device, 12345, gb)
+            reps = max(args.steps // 16, 3)
+            el, xs = timed_loop(lambda: cdist.sharded_sample(agent, gp, gather=True, **skw), reps, 2)
             assert xs.shape[0] == gb and torch.isfinite(xs).all()
             strong[f"global_batch_{gb}"] = {"value": gb * reps / el, "unit": "trajectories/s", "ms_per_call": 1e3 * el / reps,
                                             "trajectories_per_gpu": [cdist.shard_bounds(gb, r, world)[1] - cdist.shard_bounds(gb, r, world)[0]
@@ -323,12 +373,13 @@ def main():
 
     if rank == 0:
         k_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
-        achieved = FLOPS_PER_TRAJ * BATCH / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        launch_b = BATCH if dist is None else cdist.shard_bounds(BATCH, 0, world)[1]      # trajectories one launch of rank 0 processes
+        achieved = FLOPS_PER_TRAJ * launch_b / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         v2 = os.environ.get("CDX_UNET2", "1") != "0"
         kname, l2 = "cdx_unet1d_kernel", None
         if v2:
             from cleandiffuser_amd.engine import runtime2
-            comp, parts = runtime2.plan_for(agent.model_ema["diffusion"], HORIZON, BATCH)
+            comp, parts = runtime2.plan_for(agent.model_ema["diffusion"], HORIZON, launch_b)
             tpw = parts[0][2]
             kname = f"cdx_unet2_kernel<{tpw}, {comp.prog.nw}> ({tpw} trajectories, {comp.prog.nw} wave64 per workgroup)"
             # second roofline of the same launch: every workgroup streams the whole packed weight set from L2 once per denoiser
@@ -342,25 +393,29 @@ def main():
             l2["frac"] = l2["achieved"] / l2["peak"]
         out = {
             "metric": "denoised trajectories/sec @ (B=256,H=32,D=23) 20-step DDIM",
-            "value": BATCH * world * args.steps / elapsed,
+            "value": BATCH * args.steps / elapsed,
             "unit": "trajectories/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if dist is not None else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: JannerUNet1d Diffuser H=32 D=23, 20-step DDIM, "
-                                   f"B={BATCH} trajectories per GPU, whole DiscreteDiffusionSDE.sample() call"
-                                   + (", then one RCCL all-gather of the N x 256 result" if dist is not None else ""),
-                       "batch_per_gpu": BATCH, "global_batch": BATCH * world, "horizon": HORIZON, "dim": DIM,
+                                   f"global B={BATCH}, whole DiscreteDiffusionSDE.sample() call as a pipeline makes it (initial draw inside)"
+                                   + (f", sharded {BATCH}/{world} per GPU, then one RCCL all-gather of the result" if dist is not None else ""),
+                       "batch_per_gpu": BATCH // world, "global_batch": BATCH, "horizon": HORIZON, "dim": DIM,
                        "sample_steps": SAMPLE_STEPS, "world_size": world,
                        "parallelism": f"batch-sharded x{world}; the only data-path collective is the all-gather of the result"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, **recorded_traffic(),
                          "kernel": kname, "kernel_ms": k_ms,
-                         "launches_timed": len(kernel_ms), "flops_per_launch": FLOPS_PER_TRAJ * BATCH, "l2_stream": l2},
+                         "launches_timed": len(kernel_ms), "flops_per_launch": FLOPS_PER_TRAJ * launch_b, "trajectories_per_launch": launch_b,
+                         "l2_stream": l2},
         }
+        out["replayed_noise"] = {"value": BATCH * replay_reps / el_replay, "unit": "trajectories/s", "ms_per_call": 1e3 * el_replay / replay_reps,
+                                 "calls_timed": replay_reps, "what": "the same call on this rank's own 256 trajectories with noise=[z0] "
+                                 "(the initial draw outside the timed region): what rounds 1-2 reported as the headline"}
         if strong is not None:
-            out["strong_scaling"] = strong
+            out["strong_scaling"], out["weak_scaling"] = strong, weak
         if world == 1 and not args.no_other_configs:
             out["other_configs"] = other_configs(device)
         if world == 1 and not args.no_cpu_baseline:

@@ -136,6 +136,15 @@ def cfgT(B=1024, steps=100):
     return f"ChiTransformer dp_pusht d=256 h=4 L=8, Ta=16, {steps}-step DDPM, B={B}", call, B, 2.0 * tok * Ta * steps * B
 
 
+def _guided_macs(net, clf_net, horizon, fallback):
+    """MACs of ONE guided step per trajectory -- denoiser forward + classifier forward + classifier backward-data -- as the guided
+    program compiler counts them from the packed ops (the guided roofline fractions used to price the
+    denoiser's FLOPs only); `fallback` (denoiser only) when no guided program exists for the net."""
+    from cleandiffuser_amd.engine import runtime2
+    comp = runtime2.compiled_guided2(net.to(DEV), clf_net.to(DEV), horizon)
+    return float(comp.prog.macs_per_forward) if comp.prog is not None else float(fallback)
+
+
 def cfg2g(B=256):
     """Config 2 with classifier guidance at every step (w_cg > 0, what the shipped Diffuser configurations run): JannerUNet1d
     denoiser (fused forward per step) + CumRewClassifier(HalfJannerUNet1d) gradient per step, 20-step DDPM."""
@@ -155,7 +164,7 @@ def cfg2g(B=256):
     cg = torch.ones(B, 1, device=DEV)
     call = lambda: agent.sample(prior, solver="ddpm", n_samples=B, sample_steps=20, temperature=0.5, w_cg=0.1,  # noqa: E731
                                 condition_cg=cg)[0]
-    flops = 2.0 * 19.67e6 * 20 * B              # denoiser only (the classifier's work is extra)
+    flops = 2.0 * _guided_macs(net, clf_net, H, 19.67e6) * 20 * B      # denoiser + classifier forward + backward, 20 steps
     return f"config 2 + classifier guidance (w_cg=0.1, HalfJannerUNet1d), 20-step DDPM, B={B}", call, B, flops
 
 
@@ -177,7 +186,9 @@ def _shipped_diffuser(size, B, guided):
     prior[:, 0, :n_obs] = torch.randn(B, n_obs, device=DEV)
     call = lambda: agent.sample(prior, solver="ddpm", n_samples=B, sample_steps=20, temperature=0.5,  # noqa: E731
                                 w_cg=0.1 if guided else 0.0)[0]
-    macs = 4 * 19.67e6 * H / 32             # denoiser only, ~4x the config-2 net per position (the classifier's work is extra)
+    macs = 4 * 19.67e6 * H / 32             # denoiser only, ~4x the config-2 net per position
+    if guided:
+        macs = _guided_macs(net, clf_net, H, macs)
     return (f"{size}-size Diffuser (model_dim 64, H={H}, D={D}), {'classifier guidance' if guided else 'unguided'}, 20-step DDPM, "
             f"B={B}"), call, B, 2.0 * macs * 20 * B
 
