@@ -35,8 +35,10 @@ class DiffusionModel:
         self.model.train()
         self.model_ema.eval()
 
-        self.optimizer = torch.optim.AdamW(self.model.parameters(),
-                                           **(optim_params or {"lr": 2e-4, "weight_decay": 1e-5}))
+        # a torch.optim.AdamW (subclass): identical on the CPU; on a ROCm device step() is one multi-tensor gfx950 kernel that also
+        # clips, folds the EMA and zeroes the gradients (engine/optim.py, csrc/cdx_optim.hip)
+        from ..engine.optim import FusedAdamW
+        self.optimizer = FusedAdamW(self.model.parameters(), **(optim_params or {"lr": 2e-4, "weight_decay": 1e-5}))
         self.classifier = classifier
 
         self.fix_mask = 0. if fix_mask is None else to_tensor(fix_mask, device)[None, ]
@@ -66,6 +68,24 @@ class DiffusionModel:
     def ema_update(self):
         from ..utils.misc import ema_update
         ema_update(self.model, self.model_ema, self.ema_rate)
+
+    def _apply_gradients(self, update_ema: bool = True, zero_grad: bool = True):
+        """What every ``update()`` does after ``loss.backward()`` (reference diffusionsde.py:132-139): clip the global gradient
+        norm, AdamW step, zero the gradients, EMA.  -> the clipped-from norm (tensor) or None, as the reference logs it.
+        On a ROCm device with the library's optimiser this is <= 3 kernel launches for the whole model and no ATen optimiser launch."""
+        from ..engine.optim import FusedAdamW
+        opt = self.optimizer
+        if isinstance(opt, FusedAdamW) and opt.native():
+            opt.step(max_norm=self.grad_clip_norm or None, zero_grad=zero_grad,
+                     ema=(self.model, self.model_ema, self.ema_rate) if update_ema else None)
+            return opt.last_grad_norm if self.grad_clip_norm else None
+        grad_norm = nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_clip_norm) if self.grad_clip_norm else None
+        opt.step()
+        if zero_grad:
+            opt.zero_grad()
+        if update_ema:
+            self.ema_update()
+        return grad_norm
 
     # -- abstract ------------------------------------------------------------------------------ #
     def update(self, x0, condition=None, update_ema=True, **kwargs):

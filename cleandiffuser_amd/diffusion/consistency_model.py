@@ -186,12 +186,7 @@ class ContinuousConsistencyModel(DiffusionModel):
         else:
             raise ValueError(f"Unknown loss type: {loss_type}")
         loss.backward()
-        grad_norm = nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_clip_norm) \
-            if self.grad_clip_norm else None
-        self.optimizer.step()
-        self.optimizer.zero_grad()
-        if update_ema:
-            self.ema_update()
+        grad_norm = self._apply_gradients(update_ema)
         if loss_type == "training":
             self.cur_logger.incremental_update_k()
         return {"loss": loss.item(), "grad_norm": grad_norm, "unweighted_loss": unweighted}

@@ -102,12 +102,7 @@ class BaseDiffusionSDE(DiffusionModel):
     def update(self, x0, condition=None, update_ema=True, **kwargs):
         loss = self.loss(x0, condition, **kwargs)
         loss.backward()
-        grad_norm = nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_clip_norm) \
-            if self.grad_clip_norm else None
-        self.optimizer.step()
-        self.optimizer.zero_grad()
-        if update_ema:
-            self.ema_update()
+        grad_norm = self._apply_gradients(update_ema)
         return {"loss": loss.item(), "grad_norm": grad_norm}
 
     def update_classifier(self, x0, condition):

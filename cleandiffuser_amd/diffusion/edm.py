@@ -77,10 +77,7 @@ class EDMArchetecture(DiffusionModel):
         self.optimizer.zero_grad()
         loss = self.loss(x0, condition)
         loss.backward()
-        grad_norm = nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_clip_norm) \
-            if self.grad_clip_norm else None
-        self.optimizer.step()
-        self.ema_update()
+        grad_norm = self._apply_gradients(True, zero_grad=False)       # (this class zeroes BEFORE the backward pass, reference edm.py:101)
         return {"loss": loss.item(), "grad_norm": grad_norm}
 
     def update_classifier(self, x0, condition):

@@ -54,12 +54,7 @@ class _RectifiedFlow(DiffusionModel):
     def update(self, x0, condition=None, update_ema=True, x1=None, **kwargs):
         loss = self.loss(x0, x1, condition)
         loss.backward()
-        grad_norm = nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_clip_norm) \
-            if self.grad_clip_norm else None
-        self.optimizer.step()
-        self.optimizer.zero_grad()
-        if update_ema:
-            self.ema_update()
+        grad_norm = self._apply_gradients(update_ema)
         return {"loss": loss.item(), "grad_norm": grad_norm}
 
     def _velocity(self, model, xt, t, cond, w_cfg):

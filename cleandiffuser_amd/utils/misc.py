@@ -47,6 +47,12 @@ def ema_update(model: nn.Module, model_ema: nn.Module, ema_rate: float):
     itself (not ``.data``): in-place ops on ``.data`` do not bump ``Tensor._version``, which the native executors' packed-weight
     caches key on -- a stale cache would keep sampling from the first EMA weights.  The explicit epoch bump covers the caches
     for callers that still write through ``.data`` and then call ``invalidate_weights`` themselves."""
+    first = next(model_ema.parameters(), None)
+    if first is not None and first.is_cuda:          # ROCm device: ONE multi-tensor launch (csrc/cdx_optim.hip) instead of two per tensor
+        from ..engine.optim import ema_update_native
+        if ema_update_native(model, model_ema, ema_rate):
+            invalidate_weights(model_ema)
+            return
     with torch.no_grad():
         for p, p_ema in zip(model.parameters(), model_ema.parameters()):
             p_ema.mul_(ema_rate).add_(p.detach(), alpha=1 - ema_rate)

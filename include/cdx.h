@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define CDX_ABI_VERSION 6
+#define CDX_ABI_VERSION 7
 
 #define CDX_OK 0
 #define CDX_EINVAL (-1)   /* bad argument (null pointer, size out of range, misaligned offset) */
@@ -493,6 +493,34 @@ typedef struct cdx_resmlp_weights {
 } cdx_resmlp_weights;
 long long cdx_resmlp_workspace_floats(const cdx_resmlp_weights* w, const cdx_sampling* s);
 int cdx_resmlp_run(const cdx_resmlp_weights* w, const cdx_sampling* s, void* hip_stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimiser side of DiffusionModel.update(): multi-tensor AdamW + EMA + gradient-norm clipping.
+ * Replaces, per update() call, torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW.step() + optimizer.zero_grad() +
+ * DiffusionModel.ema_update() (reference diffusion/diffusionsde.py:114-141, diffusion/basic.py:66,83-86): one device table of
+ * tensor pointers cut into `chunk_elems`-float chunks, one workgroup per chunk.  AdamW arithmetic = torch/optim/adamw.py's
+ * single-tensor path term by term; the host passes step_size = lr / (1 - beta1^t) and bc2_sqrt = sqrt(1 - beta2^t).
+ * ---------------------------------------------------------------------------------------------- */
+#define CDX_OPT_ADAMW 0   /* g*clip; p *= 1-lr*wd; m,v; p -= step_size*m/(sqrt(v)/bc2_sqrt+eps); [ema = r*ema+(1-r)*p]; [g = 0] */
+#define CDX_OPT_EMA 1     /* ema = ema_rate*ema + (1-ema_rate)*p */
+#define CDX_OPT_SUMSQ 2   /* norm[0] = sqrt(sum g^2) (fixed-order reduction), norm[1] = min(1, max_norm/(norm[0]+1e-6)) (1 if max_norm <= 0) */
+#define CDX_OPT_ZERO 3    /* g = 0 */
+typedef struct cdx_optim_args {
+    float* const* p;          /* device [n_tensors]: parameters */
+    float* const* g;          /* device [n_tensors]: gradients */
+    float* const* m;          /* device [n_tensors]: exp_avg */
+    float* const* v;          /* device [n_tensors]: exp_avg_sq */
+    float* const* ema;        /* device [n_tensors]: EMA copies (AdamW: NULL = no EMA in this pass) */
+    const int64_t* numel;     /* device [n_tensors] */
+    const int32_t* chunks;    /* device [n_chunks][2]: (tensor index, chunk index inside the tensor) */
+    int32_t n_tensors, n_chunks, chunk_elems, mode;
+    float lr, beta1, beta2, eps, weight_decay, step_size, bc2_sqrt, ema_rate;
+    float max_norm;           /* > 0: gradients are scaled by norm[1] (written by a preceding CDX_OPT_SUMSQ call) */
+    int32_t zero_grad;        /* AdamW: leave the gradients zeroed */
+    float* partial;           /* device [n_chunks]: scratch of the norm pass */
+    float* norm;              /* device [2] */
+} cdx_optim_args;
+int cdx_optim_f32(const cdx_optim_args* args, void* hip_stream);
 
 /* Profiling hook: device buffer of [n_workgroups][4] u64 that every following cdx_gemm_f32 launch stamps with s_memtime
  * (start, first tile staged, K loop done, epilogue done); NULL switches it off.  Synchronise before changing it. */

@@ -98,11 +98,12 @@ def continuous():
     return run
 
 
-def edm_conditional():
-    """ContinuousEDM over a conditional MLP denoiser; MLPCondition with label dropout 0.25 in train mode (the Bernoulli mask is a
-    third seeded draw, reference nn_condition/base_nn_condition.py:7-12)."""
+def edm_conditional(dropout: float):
+    """ContinuousEDM over a conditional MLP denoiser; IdentityCondition with label dropout 0.25 in train mode (the Bernoulli mask is a
+    third seeded draw, reference nn_condition/base_nn_condition.py:7-12).  `dropout` = the backbone's own nn.Dropout rate: 0.1 (the
+    default) consumes the CPU generator inside ATen, which a ROCm device cannot replay -- that variant is CPU-only; 0.0 runs on both."""
     def run(lib, kind, device):
-        net = load_synth(lib.IDQLMlp(11, 3, emb_dim=16, hidden_dim=64, n_blocks=2), 62)
+        net = load_synth(lib.IDQLMlp(11, 3, emb_dim=16, hidden_dim=64, n_blocks=2, dropout=dropout), 62)
         agent = lib.ContinuousEDM(net, lib.IdentityCondition(dropout=0.25), grad_clip_norm=0.5, device=device)
         g = torch.Generator().manual_seed(3)
         return _record(agent, torch.randn(9, 3, generator=g), torch.randn(9, 11, generator=g), device)
@@ -137,7 +138,7 @@ def weighted_regression():
 
 SCENARIOS: Dict[str, Callable] = {
     "discrete_eps": discrete(True), "discrete_x0": discrete(False), "continuous_eps": continuous(),
-    "edm_conditional": edm_conditional(), "legacy_ddpm": legacy_ddpm(), "weighted_regression": weighted_regression(),
+    "edm_conditional": edm_conditional(0.1), "edm_conditional_nodrop": edm_conditional(0.0), "legacy_ddpm": legacy_ddpm(), "weighted_regression": weighted_regression(),
 }
 
 

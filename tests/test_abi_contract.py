@@ -29,15 +29,15 @@ def test_every_declared_symbol_is_exported(lib):
                           "cdx_chitf_run", "cdx_chitf_workspace_floats", "cdx_cross_attention_f32", "cdx_chiunet_run",
                           "cdx_chiunet_workspace_floats", "cdx_groupnorm_f32", "cdx_groupnorm_bwd_f32", "cdx_hjgrad_run",
                           "cdx_hjgrad_workspace_floats", "cdx_guided_run", "cdx_guided_workspace_floats", "cdx_unet2_run",
-                          "cdx_unet2_embtab"}
+                          "cdx_unet2_embtab", "cdx_optim_f32"}
     for n in names:
         assert hasattr(lib, n), f"{n} declared in cdx.h but not exported by libcdx.so"
     assert lib.cdx_abi_version() == int(re.search(r"#define CDX_ABI_VERSION (\d+)", hdr).group(1))
 
 
 def test_ctypes_mirrors_have_c_layout(tmp_path):
-    from cleandiffuser_amd.engine import bigbatch, blocks, classifier_grad, guided, runtime, runtime2
-    mirrors = {"cdx_guided_launch": guided.CdxGuidedLaunch, "cdx_unet2_launch": runtime2.CdxUnet2Launch,
+    from cleandiffuser_amd.engine import bigbatch, blocks, classifier_grad, guided, optim, runtime, runtime2
+    mirrors = {"cdx_optim_args": optim.CdxOptimArgs, "cdx_guided_launch": guided.CdxGuidedLaunch, "cdx_unet2_launch": runtime2.CdxUnet2Launch,
                "cdx_unet2_embtab_args": runtime2.CdxUnet2EmbtabArgs,
                "cdx_hj_block": classifier_grad.CdxHjBlock, "cdx_hj_down": classifier_grad.CdxHjDown,
                "cdx_hjgrad_weights": classifier_grad.CdxHjgradWeights,
@@ -173,3 +173,20 @@ def test_newer_entries_validate_before_touching_the_device(lib):
     assert 0 < need(512, 128, 10) < need(512, 256, 10) < need(512, 512, 10) == need(512, 0, 10) == need(512, 4096, 10)
     assert need(100000, 256, 10) == need(512, 256, 10) and need(512, 256, 20) > need(512, 256, 10)
     assert lib.cdx_dit1d_workspace_floats(None, None) == -1
+
+
+def test_optimiser_entry_validates_before_touching_the_device(lib):
+    """cdx_optim_f32 (multi-tensor AdamW / EMA / gradient norm): refused with a message, no HIP call, on malformed requests."""
+    from cleandiffuser_amd.engine import optim
+    optim._lib()
+    assert lib.cdx_optim_f32(None, None) == -1 and b"null" in lib.cdx_last_error()
+    assert lib.cdx_optim_f32(ctypes.byref(optim.CdxOptimArgs()), None) == 0                          # nothing to do
+    a = optim.CdxOptimArgs(n_tensors=1, n_chunks=1, chunk_elems=4095, chunks=8, numel=8)
+    assert lib.cdx_optim_f32(ctypes.byref(a), None) == -1 and b"multiple of 4" in lib.cdx_last_error()
+    a = optim.CdxOptimArgs(n_tensors=1, n_chunks=1, chunk_elems=4096, chunks=8, numel=8, mode=optim.OPT_ADAMW, p=8, g=8, m=8)
+    assert lib.cdx_optim_f32(ctypes.byref(a), None) == -1 and b"null pointer" in lib.cdx_last_error()
+    a = optim.CdxOptimArgs(n_tensors=1, n_chunks=1, chunk_elems=4096, chunks=8, numel=8, mode=optim.OPT_ADAMW, p=8, g=8, m=8, v=8,
+                           beta1=0.9, beta2=0.999, bc2_sqrt=0.0)
+    assert lib.cdx_optim_f32(ctypes.byref(a), None) == -1 and b"bc2_sqrt" in lib.cdx_last_error()
+    a = optim.CdxOptimArgs(n_tensors=1, n_chunks=1, chunk_elems=4096, chunks=8, numel=8, mode=9)
+    assert lib.cdx_optim_f32(ctypes.byref(a), None) == -1 and b"unknown mode" in lib.cdx_last_error()
