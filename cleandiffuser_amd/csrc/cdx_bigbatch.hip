@@ -252,8 +252,18 @@ int run_step(hipStream_t stream, const cdx_sampling* s, const cdx_step& st, floa
 // DiT1d
 // ------------------------------------------------------------------------------------------------
 struct DitBuffers {
-    float *x, *prev, *xold, *emb0, *e1, *emb, *semb, *ada, *h0, *xm, *qkv, *att, *h2, *f, *h, *pred;
+    float *x, *prev, *xold, *emb0, *e1, *emb, *semb, *ada, *h0, *xm, *qkv, *att, *h2, *f, *h, *pred, *r0, *hc;
 };
+
+// DiT1Ref: [x_ref | x] state rows -> the reference half of the network output is the reference half of its input (dit.py:157,180)
+__global__ void copy_ref_cols_kernel(float* __restrict__ out, const float* __restrict__ x, size_t rows, size_t x_rows, int in_dim,
+                                     int width) {
+    const size_t n = rows * (size_t)in_dim;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / in_dim, c = i - r * in_dim;
+        out[r * width + c] = x[(r % x_rows) * width + c];
+    }
+}
 
 long long dit_layout(const cdx_dit1d_weights* w, const cdx_sampling* s, float* base, DitBuffers* B) {
     const long long nb = chunk_of(s), bf = nb * (s->cfg_mode == 2 ? 2 : 1);
@@ -276,7 +286,12 @@ long long dit_layout(const cdx_dit1d_weights* w, const cdx_sampling* s, float* b
     b.h2 = a.take(rows * d);
     b.f = a.take(rows * 4 * d);
     b.h = a.take(rows * d);
-    b.pred = a.take(rows * w->in_dim);
+    b.pred = a.take(rows * w->in_dim * (w->cross ? 2 : 1));
+    b.r0 = b.hc = nullptr;
+    if (w->cross) {
+        b.r0 = a.take(nb * T * d);          // tokens of the reference half
+        b.hc = a.take(rows * d);            // cross-attention output = the block's input
+    }
     if (B) *B = b;
     return a.used;
 }
@@ -288,7 +303,11 @@ int dit_check(const cdx_dit1d_weights* w, const cdx_sampling* s) {
         cdx_set_err("DiT1d executor: tokens <= 1024, d_model <= 1024, head_dim <= 64 required"); return CDX_EINVAL;
     }
     CDX_TRY(check_request(s, "cdx_dit1d_run", 7));
-    if (s->hd != w->tokens * w->in_dim || s->emb_dim != w->emb_dim || (s->cond && s->cond_dim != w->emb_dim)) {
+    if (w->cross) {
+        for (int i = 0; i < w->depth; ++i)
+            if (!w->cross[i].in_w || !w->cross[i].in_b || !w->cross[i].out_w || !w->cross[i].out_b) { cdx_set_err("null pointer in DiT1Ref cross-attention weights"); return CDX_EINVAL; }
+    }
+    if (s->hd != w->tokens * w->in_dim * (w->cross ? 2 : 1) || s->emb_dim != w->emb_dim || (s->cond && s->cond_dim != w->emb_dim)) {
         cdx_set_err("DiT1d request shape does not match the weights"); return CDX_EINVAL;
     }
     return CDX_OK;
@@ -320,17 +339,38 @@ int dit_forward(const cdx_dit1d_weights* w, const cdx_sampling* s, hipStream_t s
                 float* pred, int nb, int rec, float in_scale = 1.0f) {
     const int two = s->cfg_mode == 2 ? 2 : 1, bf = nb * two;
     const int T = w->tokens, d = w->d_model, rows = bf * T;
-    CDX_TRY(scaled_input(st, x, pred, in_scale, (size_t)nb * T * w->in_dim));     // pred is free until the final layer writes it
+    const int xw = w->in_dim * (w->cross ? 2 : 1);                                 // width of a state row
+    CDX_TRY(scaled_input(st, x, pred, in_scale, (size_t)nb * T * xw));            // pred is free until the final layer writes it
     const int ntot = 6 * d * w->depth + 2 * d;
     const float* ada_rec = B.ada + (size_t)rec * bf * ntot;
     // token stream: x_proj(x) + pos, computed once per trajectory (both CFG halves start from the same tokens)
-    CDX_TRY(gemm(st, x, w->in_dim, w->x_proj_w, w->in_dim, w->x_proj_b, B.h0, d, nb * T, d, w->in_dim, CDX_ACT_NONE,
+    CDX_TRY(gemm(st, x + (w->cross ? w->in_dim : 0), xw, w->x_proj_w, w->in_dim, w->x_proj_b, B.h0, d, nb * T, d, w->in_dim, CDX_ACT_NONE,
                  nullptr, 0, 1, nullptr, 0, w->pos, T));
+    if (w->cross)                                                                  // DiT1Ref: the reference half through the same projection
+        CDX_TRY(gemm(st, x, xw, w->x_proj_w, w->in_dim, w->x_proj_b, B.r0, d, nb * T, d, w->in_dim, CDX_ACT_NONE, nullptr, 0, 1,
+                     nullptr, 0, w->pos, T));
     const float* h = B.h0;
     int h_rows = nb * T;
     for (int i = 0; i < w->depth; ++i) {
         const cdx_dit1d_block& k = w->blocks[i];
         const float* ada = ada_rec + (size_t)i * 6 * d;
+        if (w->cross) {
+            // x <- MHA(q = x, k = v = x_ref tokens), no residual (dit.py:176).  q lands in columns [0, d) of the packed qkv rows,
+            // k | v of the reference tokens in [d, 3d) -- the self-attention kernel then does the rest.  While both CFG halves still
+            // share one token stream (first block) the attention runs once, on nb trajectories.
+            const cdx_dit1ref_cross& c = w->cross[i];
+            const int cb = h_rows / T;
+            CDX_TRY(gemm(st, h, d, c.in_w, d, c.in_b, B.qkv, 3 * d, h_rows, d, d));
+            for (int rep = 0; rep < cb / nb; ++rep)
+                CDX_TRY(gemm(st, B.r0, d, c.in_w + (size_t)d * d, d, c.in_b + d, B.qkv + (size_t)rep * nb * T * 3 * d + d, 3 * d, nb * T,
+                             2 * d, d));
+            cdx_attn_args xa;
+            xa.qkv = B.qkv; xa.out = B.att; xa.B = cb; xa.T = T; xa.n_heads = w->n_heads; xa.head_dim = d / w->n_heads;
+            xa.scale = 1.0f / sqrtf((float)xa.head_dim); xa.mask = nullptr;
+            CDX_TRY(cdx_attention_f32(&xa, st));
+            CDX_TRY(gemm(st, B.att, d, c.out_w, d, c.out_b, B.hc, d, h_rows, d, d));
+            h = B.hc;
+        }
         // x <- modulate(LN(x), shift_a, scale_a)   (dit.py:33: the block continues from the modulated stream, Q4)
         CDX_TRY(layernorm(st, h, B.xm, rows, d, 1e-6f, nullptr, nullptr, ada + d, ada, ntot, T, h_rows == rows ? 0 : h_rows));
         CDX_TRY(gemm(st, B.xm, d, k.qkv_w, d, k.qkv_b, B.qkv, 3 * d, rows, 3 * d, d));
@@ -347,7 +387,140 @@ int dit_forward(const cdx_dit1d_weights* w, const cdx_sampling* s, hipStream_t s
     }
     const float* fin = ada_rec + (size_t)w->depth * 6 * d;
     CDX_TRY(layernorm(st, h, B.xm, rows, d, 1e-6f, nullptr, nullptr, fin + d, fin, ntot, T, h_rows == rows ? 0 : h_rows));
-    CDX_TRY(gemm(st, B.xm, d, w->fin_w, d, w->fin_b, pred, w->in_dim, rows, w->in_dim, d));
+    CDX_TRY(gemm(st, B.xm, d, w->fin_w, d, w->fin_b, pred + (w->cross ? w->in_dim : 0), xw, rows, w->in_dim, d));
+    if (w->cross) {       // (x may alias pred's first nb*T rows when the input was scaled: those rows then copy onto themselves)
+        const size_t n = (size_t)rows * w->in_dim;
+        hipLaunchKernelGGL(copy_ref_cols_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, st,
+                           pred, x, (size_t)rows, (size_t)nb * T, w->in_dim, xw);
+        CDX_TRY(hip_ok());
+    }
+    return CDX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// PearceTransformer (reference nn_diffusion/pearcetransformer.py:91-151) -- folded weights, see include/cdx.h
+// ------------------------------------------------------------------------------------------------
+struct PtfBuffers {
+    float *x, *prev, *xold, *tin, *cin, *xe1, *xe, *xi, *f, *qkv, *att, *t1, *a1, *u, *f2, *pred;
+};
+
+long long ptf_layout(const cdx_pearcetf_weights* w, const cdx_sampling* s, float* base, PtfBuffers* B) {
+    const long long nb = chunk_of(s), bf = nb * (s->cfg_mode == 2 ? 2 : 1);
+    const long long S = 2 + w->To, te = w->te, td = (long long)w->te * w->n_heads, rows = bf * S;
+    const long long n_rec = s->n_steps > 0 ? s->n_steps : 1;
+    Arena a{base, 0, 0};
+    PtfBuffers b;
+    b.x = a.take(nb * s->hd);
+    b.prev = a.take(nb * s->hd);
+    b.xold = a.take(nb * s->hd);
+    b.tin = a.take((s->temb_per_sample ? nb : n_rec) * te);
+    b.cin = a.take(nb * w->To * te);
+    b.xe1 = a.take(nb * w->emb_dim);
+    b.xe = a.take(nb * w->emb_dim);
+    b.xi = a.take(nb * te);
+    b.f = a.take(rows * te);
+    b.qkv = a.take(rows * 3 * td);
+    b.att = a.take(rows * td);
+    b.t1 = a.take(rows * te);
+    b.a1 = a.take(rows * te);
+    b.u = a.take(rows * 4 * te);
+    b.f2 = a.take(rows * te);
+    b.pred = a.take(bf * s->hd);
+    if (B) *B = b;
+    return a.used;
+}
+
+int ptf_check(const cdx_pearcetf_weights* w, const cdx_sampling* s) {
+    if (!w || !w->blocks || !w->ae0_w || !w->ae0_b || !w->ae2_w || !w->ae2_b || !w->a2i_w || !w->a2i_b || !w->t2i_w || !w->t2i_b ||
+        !w->c2i_w || !w->c2i_b || !w->cpos || !w->fin_w || !w->fin_b) { cdx_set_err("null pointer in PearceTransformer weights"); return CDX_EINVAL; }
+    if (w->act_dim <= 0 || w->To <= 0 || 2 + w->To > 64 || w->emb_dim <= 0 || w->te <= 0 || w->te > 64 || w->n_heads <= 0 || w->n_blocks < 0) {
+        cdx_set_err("PearceTransformer executor: 2 + To <= 64 tokens, trans_emb_dim (= head width) <= 64 required"); return CDX_EINVAL;
+    }
+    for (int i = 0; i < w->n_blocks; ++i) {
+        const cdx_pearcetf_block& k = w->blocks[i];
+        if (!k.qkv_w || !k.qkv_b || !k.o_w || !k.o_b || !k.r1 || !k.fc1_w || !k.fc1_b || !k.fc2_w || !k.fc2_b || !k.r2) {
+            cdx_set_err("null pointer in a PearceTransformer block"); return CDX_EINVAL;
+        }
+    }
+    CDX_TRY(check_request(s, "cdx_pearcetf_run", 7));
+    if (s->hd != w->act_dim || s->emb_dim != w->emb_dim || s->cfg_mode == 0 || !s->cond || s->cond_dim != w->To * w->emb_dim) {
+        cdx_set_err("PearceTransformer request: hd == act_dim, emb_dim, a (To, emb_dim) condition per sample (cfg_mode 1 or 2) required");
+        return CDX_EINVAL;
+    }
+    return CDX_OK;
+}
+
+// y[r][c] = x[r][c] * scale[c]   (the residual paths after the folded BatchNorm1d)
+__global__ void chan_scale_kernel(float* __restrict__ y, const float* __restrict__ x, const float* __restrict__ scale, size_t n, int C) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = x[i] * scale[i % C];
+}
+
+// token rows of one forward: f[(r, 0)] = action token of sample r % nb, f[(r, 1)] = time token of the record (or of the sample),
+// f[(r, 2 + j)] = condition token j of the sample (conditional half) or cond_to_input(0) + pos = c2i_b + cpos[j] (zero-condition half)
+__global__ void ptf_tokens_kernel(float* __restrict__ f, const float* __restrict__ xi, const float* __restrict__ tin,
+                                  const float* __restrict__ cin, const float* __restrict__ c2i_b, const float* __restrict__ cpos,
+                                  int bf, int nb, int S, int te, int t_row, int per_sample, int n_cond_rows) {
+    const size_t n = (size_t)bf * S * te;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % te);
+        const int tok = (int)((i / te) % S);
+        const int r = (int)(i / ((size_t)te * S));
+        const int l = r % nb;
+        float v;
+        if (tok == 0) v = xi[(size_t)l * te + c];
+        else if (tok == 1) v = tin[(size_t)(per_sample ? l : t_row) * te + c];
+        else if (r < n_cond_rows) v = cin[((size_t)l * (S - 2) + (tok - 2)) * te + c];
+        else v = c2i_b[c] + cpos[(size_t)(tok - 2) * te + c];
+        f[i] = v;
+    }
+}
+
+int ptf_prepare(const cdx_pearcetf_weights* w, const cdx_sampling* s, hipStream_t st, const PtfBuffers& B, int nb, int b0) {
+    const int te = w->te, E = w->emb_dim;
+    const int n_rec = s->n_steps > 0 ? s->n_steps : 1;
+    // time tokens of every step record (or of every sample in forward mode), condition tokens of the chunk: independent of x
+    if (s->temb_per_sample) CDX_TRY(gemm(st, s->temb + (size_t)b0 * E, E, w->t2i_w, E, w->t2i_b, B.tin, te, nb, te, E));
+    else CDX_TRY(gemm(st, s->temb, E, w->t2i_w, E, w->t2i_b, B.tin, te, n_rec, te, E));
+    CDX_TRY(gemm(st, s->cond + (size_t)b0 * s->cond_dim, E, w->c2i_w, E, w->c2i_b, B.cin, te, nb * w->To, te, E, CDX_ACT_NONE, nullptr, 0, 1,
+                 nullptr, 0, w->cpos, w->To));
+    return CDX_OK;
+}
+
+int ptf_forward(const cdx_pearcetf_weights* w, const cdx_sampling* s, hipStream_t st, const PtfBuffers& B, const float* x, float* pred,
+                int nb, int rec, float in_scale = 1.0f) {
+    const int two = s->cfg_mode == 2 ? 2 : 1, bf = nb * two;
+    const int S = 2 + w->To, te = w->te, td = w->te * w->n_heads, E = w->emb_dim, rows = bf * S;
+    CDX_TRY(scaled_input(st, x, pred, in_scale, (size_t)nb * w->act_dim));
+    CDX_TRY(gemm(st, x, w->act_dim, w->ae0_w, w->act_dim, w->ae0_b, B.xe1, E, nb, E, w->act_dim, CDX_ACT_LEAKY));
+    CDX_TRY(gemm(st, B.xe1, E, w->ae2_w, E, w->ae2_b, B.xe, E, nb, E, E));
+    CDX_TRY(gemm(st, B.xe, E, w->a2i_w, E, w->a2i_b, B.xi, te, nb, te, E));
+    {
+        const size_t n = (size_t)rows * te;
+        hipLaunchKernelGGL(ptf_tokens_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, st, B.f, B.xi,
+                           B.tin, B.cin, w->c2i_b, w->cpos, bf, nb, S, te, rec, s->temb_per_sample, nb /* cfg_mode >= 1: first nb rows */);
+        CDX_TRY(hip_ok());
+    }
+    float* f = B.f;
+    float* f_next = B.f2;
+    const size_t n = (size_t)rows * te;
+    const unsigned eb = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    for (int i = 0; i < w->n_blocks; ++i) {
+        const cdx_pearcetf_block& k = w->blocks[i];
+        CDX_TRY(gemm(st, f, te, k.qkv_w, te, k.qkv_b, B.qkv, 3 * td, rows, 3 * td, te));
+        cdx_attn_args at;
+        at.qkv = B.qkv; at.out = B.att; at.B = bf; at.T = S; at.n_heads = w->n_heads; at.head_dim = te;
+        at.scale = 1.0f / sqrtf((float)te); at.mask = nullptr;
+        CDX_TRY(cdx_attention_f32(&at, st));
+        hipLaunchKernelGGL(chan_scale_kernel, dim3(eb), dim3(256), 0, st, B.t1, f, k.r1, n, te);
+        CDX_TRY(hip_ok());
+        CDX_TRY(gemm(st, B.att, td, k.o_w, td, k.o_b, B.a1, te, rows, te, td, CDX_ACT_NONE, nullptr, 0, 1, B.t1, te));
+        CDX_TRY(gemm(st, B.a1, te, k.fc1_w, te, k.fc1_b, B.u, 4 * te, rows, 4 * te, te, CDX_ACT_GELU_ERF));
+        hipLaunchKernelGGL(chan_scale_kernel, dim3(eb), dim3(256), 0, st, B.t1, B.a1, k.r2, n, te);
+        CDX_TRY(hip_ok());
+        CDX_TRY(gemm(st, B.u, 4 * te, k.fc2_w, 4 * te, k.fc2_b, f_next, te, rows, te, 4 * te, CDX_ACT_NONE, nullptr, 0, 1, B.t1, te));
+        float* t = f; f = f_next; f_next = t;
+    }
+    CDX_TRY(gemm(st, f, S * te, w->fin_w, S * te, w->fin_b, pred, w->act_dim, bf, w->act_dim, S * te));
     return CDX_OK;
 }
 
@@ -1077,6 +1250,37 @@ int cdx_dit1d_run(const cdx_dit1d_weights* w, const cdx_sampling* s, void* hip_s
         if (hipMemcpyAsync(B.x, s->x_in + off, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return hip_ok();
         for (int i = 0; i < s->n_steps; ++i) {
             CDX_TRY(dit_forward(w, s, st, B, B.x, B.pred, nb, i, s->steps[i].kind >= 5 ? s->steps[i].alpha : 1.0f));
+            CDX_TRY(run_step(st, s, s->steps[i], B.x, B.pred, B.prev, B.xold, nb, b0));
+        }
+        if (hipMemcpyAsync(s->x_out + off, B.x, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return hip_ok();
+    }
+    return CDX_OK;
+}
+
+long long cdx_pearcetf_workspace_floats(const cdx_pearcetf_weights* w, const cdx_sampling* s) {
+    if (!w || !s) return -1;
+    return ptf_layout(w, s, nullptr, nullptr);
+}
+
+int cdx_pearcetf_run(const cdx_pearcetf_weights* w, const cdx_sampling* s, void* hip_stream) {
+    CDX_TRY(ptf_check(w, s));
+    if (s->batch == 0) return CDX_OK;
+    PtfBuffers B;
+    const long long need = ptf_layout(w, s, s->workspace, &B);
+    if (!s->workspace || s->workspace_floats < need) { cdx_set_err("cdx_pearcetf_run: workspace too small"); return CDX_EINVAL; }
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    const int chunk = chunk_of(s);
+    for (int b0 = 0; b0 < s->batch; b0 += chunk) {
+        const int nb = s->batch - b0 < chunk ? s->batch - b0 : chunk;
+        const size_t off = (size_t)b0 * s->hd, bytes = (size_t)nb * s->hd * sizeof(float);
+        CDX_TRY(ptf_prepare(w, s, st, B, nb, b0));
+        if (s->n_steps == 0) {
+            CDX_TRY(ptf_forward(w, s, st, B, s->x_in + off, s->x_out + off, nb, 0));
+            continue;
+        }
+        if (hipMemcpyAsync(B.x, s->x_in + off, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return hip_ok();
+        for (int i = 0; i < s->n_steps; ++i) {
+            CDX_TRY(ptf_forward(w, s, st, B, B.x, B.pred, nb, i, s->steps[i].kind >= 5 ? s->steps[i].alpha : 1.0f));
             CDX_TRY(run_step(st, s, s->steps[i], B.x, B.pred, B.prev, B.xold, nb, b0));
         }
         if (hipMemcpyAsync(s->x_out + off, B.x, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return hip_ok();

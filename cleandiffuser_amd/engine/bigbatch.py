@@ -32,11 +32,25 @@ class CdxDitBlock(ctypes.Structure):
                                    "fc2_b")]
 
 
+class CdxDitCross(ctypes.Structure):
+    _fields_ = [(n, _FP) for n in ("in_w", "in_b", "out_w", "out_b")]
+
+
 class CdxDitWeights(ctypes.Structure):
     _fields_ = [("tokens", _I), ("in_dim", _I), ("emb_dim", _I), ("d_model", _I), ("n_heads", _I), ("depth", _I),
                 ("x_proj_w", _FP), ("x_proj_b", _FP), ("pos", _FP), ("map0_w", _FP), ("map0_b", _FP), ("map2_w", _FP),
                 ("map2_b", _FP), ("blocks", ctypes.POINTER(CdxDitBlock)), ("fin_ada_w", _FP), ("fin_ada_b", _FP),
-                ("fin_w", _FP), ("fin_b", _FP)]
+                ("fin_w", _FP), ("fin_b", _FP), ("cross", ctypes.POINTER(CdxDitCross))]
+
+
+class CdxPearcetfBlock(ctypes.Structure):
+    _fields_ = [(n, _FP) for n in ("qkv_w", "qkv_b", "o_w", "o_b", "r1", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "r2")]
+
+
+class CdxPearcetfWeights(ctypes.Structure):
+    _fields_ = [("act_dim", _I), ("To", _I), ("emb_dim", _I), ("te", _I), ("n_heads", _I), ("n_blocks", _I)] + \
+               [(n, _FP) for n in ("ae0_w", "ae0_b", "ae2_w", "ae2_b", "a2i_w", "a2i_b", "t2i_w", "t2i_b", "c2i_w", "c2i_b", "cpos")] + \
+               [("blocks", ctypes.POINTER(CdxPearcetfBlock)), ("fin_w", _FP), ("fin_b", _FP)]
 
 
 class CdxResMlpBlock(ctypes.Structure):
@@ -92,6 +106,10 @@ def _lib():
         lib.cdx_dit1d_workspace_floats.restype = ctypes.c_longlong
         lib.cdx_dit1d_run.argtypes = [ctypes.POINTER(CdxDitWeights), ctypes.POINTER(CdxSampling), ctypes.c_void_p]
         lib.cdx_dit1d_run.restype = ctypes.c_int
+        lib.cdx_pearcetf_workspace_floats.argtypes = [ctypes.POINTER(CdxPearcetfWeights), ctypes.POINTER(CdxSampling)]
+        lib.cdx_pearcetf_workspace_floats.restype = ctypes.c_longlong
+        lib.cdx_pearcetf_run.argtypes = [ctypes.POINTER(CdxPearcetfWeights), ctypes.POINTER(CdxSampling), ctypes.c_void_p]
+        lib.cdx_pearcetf_run.restype = ctypes.c_int
         lib.cdx_chitf_workspace_floats.argtypes = [ctypes.POINTER(CdxChitfWeights), ctypes.POINTER(CdxSampling)]
         lib.cdx_chitf_workspace_floats.restype = ctypes.c_longlong
         lib.cdx_chitf_run.argtypes = [ctypes.POINTER(CdxChitfWeights), ctypes.POINTER(CdxSampling), ctypes.c_void_p]
@@ -114,6 +132,16 @@ def _lib():
 def is_dit1d(module) -> bool:
     from ..nn_diffusion.dit import DiT1d
     return type(module) is DiT1d
+
+
+def is_dit1ref(module) -> bool:
+    from ..nn_diffusion.dit import DiT1Ref
+    return type(module) is DiT1Ref
+
+
+def is_pearcetf(module) -> bool:
+    from ..nn_diffusion.pearcetransformer import PearceTransformer
+    return type(module) is PearceTransformer
 
 
 def is_resmlp(module) -> bool:
@@ -149,13 +177,21 @@ def _bind_dit(net, tokens: int, device) -> Optional[_Bound]:
     heads = net.blocks[0].attn.num_heads if len(net.blocks) else 1
     if tokens > 1024 or d > 1024 or d % heads or d // heads > 64:          # CDX_ATTN_MAX_T
         return None
-    for blk in net.blocks:
-        a = blk.attn
+    cross_mods = list(net.cross_attns) if is_dit1ref(net) else []
+    for a in [blk.attn for blk in net.blocks] + cross_mods:
         if a.in_proj_weight is None or a.in_proj_bias is None or a.bias_k is not None or a.add_zero_attn or \
-                not a.batch_first:
+                not a.batch_first or a.num_heads != heads:
             return None
     keep = []
     p = lambda t: _dev_f32(t, keep, device)  # noqa: E731
+    cross = None
+    if cross_mods:                                   # DiT1Ref (reference dit.py:135-180): one cross-attention in front of every block
+        if len(cross_mods) != len(net.blocks):
+            return None
+        cross = (CdxDitCross * len(cross_mods))()
+        for i, a in enumerate(cross_mods):
+            cross[i] = CdxDitCross(p(a.in_proj_weight), p(a.in_proj_bias), p(a.out_proj.weight), p(a.out_proj.bias))
+        keep.append(cross)
     blocks = (CdxDitBlock * max(len(net.blocks), 1))()
     for i, blk in enumerate(net.blocks):
         ada, fc1, fc2 = blk.adaLN_modulation[1], blk.mlp[0], blk.mlp[3]
@@ -168,8 +204,73 @@ def _bind_dit(net, tokens: int, device) -> Optional[_Bound]:
                       depth=len(net.blocks), x_proj_w=p(net.x_proj.weight), x_proj_b=p(net.x_proj.bias), pos=p(pos),
                       map0_w=p(net.map_emb[0].weight), map0_b=p(net.map_emb[0].bias), map2_w=p(net.map_emb[2].weight),
                       map2_b=p(net.map_emb[2].bias), blocks=blocks, fin_ada_w=p(fin.adaLN_modulation[1].weight),
-                      fin_ada_b=p(fin.adaLN_modulation[1].bias), fin_w=p(fin.linear.weight), fin_b=p(fin.linear.bias))
+                      fin_ada_b=p(fin.adaLN_modulation[1].bias), fin_w=p(fin.linear.weight), fin_b=p(fin.linear.bias), cross=cross)
     keep.append(blocks)
+    return _Bound(w, keep, None)
+
+
+def fold_pearcetf(net) -> Optional[dict]:
+    """PearceTransformer weights with everything linear folded, in float64 then fp32 (include/cdx.h, cdx_pearcetf_weights):
+    input_to_qkv1 into the attention's in_proj, out_proj into attn1_to_fcn, the 1/1.414 residual scaling and the eval-mode
+    BatchNorm1d affine maps into the neighbouring Linear, the sine position codes into the token biases.  None: a variant the
+    executor does not take (train mode -> BatchNorm1d batch statistics, non-default activations)."""
+    import torch.nn as nn
+    blocks_m = list(net.transformer_blocks)
+    if net.training or not blocks_m:
+        return None
+    te, td, heads = blocks_m[0].trans_emb_dim, blocks_m[0].transformer_dim, blocks_m[0].nheads
+    if te > 64 or td != te * heads or 2 + net.To > 64:
+        return None
+    if not isinstance(net.act_emb[1], nn.LeakyReLU) or net.act_emb[1].negative_slope != 0.01:
+        return None
+    f64 = lambda t: t.detach().to("cpu", torch.float64)  # noqa: E731
+    out = {"te": te, "td": td, "heads": heads, "blocks": []}
+    for blk in blocks_m:
+        mha, bn_a, bn_b = blk.multihead_attn1, blk.norm1a, blk.norm1b
+        if mha.in_proj_weight is None or mha.in_proj_bias is None or mha.bias_k is not None or mha.add_zero_attn or mha.batch_first or \
+                not isinstance(blk.attn1_fcn[1], nn.GELU) or getattr(blk.attn1_fcn[1], "approximate", "none") != "none" or \
+                not (bn_a.track_running_stats and bn_b.track_running_stats and bn_a.affine and bn_b.affine):
+            return None
+        wa, ba = f64(blk.input_to_qkv1.weight), f64(blk.input_to_qkv1.bias)
+        wi, bi = f64(mha.in_proj_weight), f64(mha.in_proj_bias)
+        sl = [slice(j * td, (j + 1) * td) for j in range(3)]
+        s1 = f64(bn_a.weight) / torch.sqrt(f64(bn_a.running_var) + bn_a.eps)
+        s2 = f64(bn_b.weight) / torch.sqrt(f64(bn_b.running_var) + bn_b.eps)
+        wf, bfc = f64(blk.attn1_to_fcn.weight), f64(blk.attn1_to_fcn.bias)
+        wo, bo = f64(mha.out_proj.weight), f64(mha.out_proj.bias)
+        r1, r2 = s1 / 1.414, s2 / 1.414
+        fc1, fc2 = blk.attn1_fcn[0], blk.attn1_fcn[2]
+        out["blocks"].append({
+            "qkv_w": torch.cat([wi[q] @ wa[q] for q in sl], 0), "qkv_b": torch.cat([wi[q] @ ba[q] + bi[q] for q in sl], 0),
+            "o_w": r1[:, None] * (wf @ wo), "o_b": r1 * (wf @ bo + bfc) + f64(bn_a.bias) - f64(bn_a.running_mean) * s1, "r1": r1,
+            "fc1_w": f64(fc1.weight), "fc1_b": f64(fc1.bias),
+            "fc2_w": r2[:, None] * f64(fc2.weight), "fc2_b": r2 * f64(fc2.bias) + f64(bn_b.bias) - f64(bn_b.running_mean) * s2, "r2": r2})
+    with torch.no_grad():
+        dev0 = net.final.weight.device
+        pos = lambda v: f64(net.pos_embed(torch.as_tensor(v, dtype=torch.float32, device=dev0).reshape(-1, 1)))  # noqa: E731
+        pos12, cpos = pos([1.0, 2.0]), pos([float(3 + j) for j in range(net.To)])
+    out.update(a2i_b=f64(net.act_to_input.bias) + pos12[0], t2i_b=f64(net.t_to_input.bias) + pos12[1], cpos=cpos)
+    to32 = lambda v: v.to(torch.float32).contiguous() if isinstance(v, torch.Tensor) else v  # noqa: E731
+    out["blocks"] = [{k: to32(v) for k, v in b.items()} for b in out["blocks"]]
+    return {k: to32(v) for k, v in out.items()}
+
+
+def _bind_pearcetf(net, device) -> Optional[_Bound]:
+    fold = fold_pearcetf(net)
+    if fold is None:
+        return None
+    keep = []
+    p = lambda t: _dev_f32(t, keep, device)  # noqa: E731
+    arr = (CdxPearcetfBlock * len(fold["blocks"]))()
+    for i, b in enumerate(fold["blocks"]):
+        arr[i] = CdxPearcetfBlock(*[p(b[k]) for k in ("qkv_w", "qkv_b", "o_w", "o_b", "r1", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "r2")])
+    ae0, ae2 = net.act_emb[0], net.act_emb[2]
+    w = CdxPearcetfWeights(act_dim=ae0.in_features, To=net.To, emb_dim=net.emb_dim, te=fold["te"], n_heads=fold["heads"],
+                           n_blocks=len(fold["blocks"]), ae0_w=p(ae0.weight), ae0_b=p(ae0.bias), ae2_w=p(ae2.weight), ae2_b=p(ae2.bias),
+                           a2i_w=p(net.act_to_input.weight), a2i_b=p(fold["a2i_b"]), t2i_w=p(net.t_to_input.weight),
+                           t2i_b=p(fold["t2i_b"]), c2i_w=p(net.cond_to_input.weight), c2i_b=p(net.cond_to_input.bias),
+                           cpos=p(fold["cpos"]), blocks=arr, fin_w=p(net.final.weight), fin_b=p(net.final.bias))
+    keep.append(arr)
     return _Bound(w, keep, None)
 
 
@@ -591,6 +692,7 @@ def _run(kind, bound, *, batch, hd, emb_dim, cond_dim, temb, steps, n_steps, tem
                     fix_mask=pp(fix_mask), noise=pp(noise), x_min=pp(x_min), x_max=pp(x_max), x_out=x_out.data_ptr(),
                     workspace=None, workspace_floats=0, chunk=chunk)
     size_fn, run_fn = {"dit": (lib.cdx_dit1d_workspace_floats, lib.cdx_dit1d_run),
+                       "pearcetf": (lib.cdx_pearcetf_workspace_floats, lib.cdx_pearcetf_run),
                        "mlp": (lib.cdx_resmlp_workspace_floats, lib.cdx_resmlp_run),
                        "chitf": (lib.cdx_chitf_workspace_floats, lib.cdx_chitf_run),
                        "chiunet": (lib.cdx_chiunet_workspace_floats, lib.cdx_chiunet_run)}[kind]
@@ -604,8 +706,27 @@ def _run(kind, bound, *, batch, hd, emb_dim, cond_dim, temb, steps, n_steps, tem
 # ------------------------------------------------------------------------------------------------ #
 # backbone.forward                                                                                     #
 # ------------------------------------------------------------------------------------------------ #
+def pearcetf_forward(net, x, noise, condition) -> Optional[torch.Tensor]:
+    if x.dim() != 2 or condition is None or condition.dim() != 3:
+        return None
+    dev = x.device
+    bound = _bound(net, "pearcetf", lambda: _bind_pearcetf(net, dev))
+    if bound is None or x.shape[1] != bound.struct.act_dim or tuple(condition.shape[1:]) != (net.To, net.emb_dim):
+        return None
+    w = bound.struct
+    with torch.no_grad():
+        temb = _f32c(net.map_noise(noise), dev)
+        cond = _f32c(torch.flatten(condition, 1), dev)
+        xin = _f32c(x, dev)
+        out = torch.empty_like(xin)
+        _run("pearcetf", bound, batch=x.shape[0], hd=w.act_dim, emb_dim=w.emb_dim, cond_dim=w.To * w.emb_dim, temb=temb, steps=None,
+             n_steps=0, temb_per_sample=1, predict_noise=0, cfg_mode=1, cfg_w=1.0, cond=cond, x_in=xin, prior=None, fix_mask=None,
+             noise=None, x_min=None, x_max=None, x_out=out, chunk=CHUNK_OVERRIDE["dit"] or _dit_chunk(x.shape[0], 2 + w.To, w.te * w.n_heads, 1))
+    return out
+
+
 def dit_forward(net, x, noise, condition) -> Optional[torch.Tensor]:
-    if x.dim() != 3 or x.shape[2] != net.in_dim:
+    if x.dim() != 3 or x.shape[2] != net.in_dim * (2 if is_dit1ref(net) else 1):
         return None
     b, tokens, _ = x.shape
     dev = x.device
@@ -617,7 +738,7 @@ def dit_forward(net, x, noise, condition) -> Optional[torch.Tensor]:
         cond = None if condition is None else _f32c(condition, dev)
         xin = _f32c(x, dev)
         out = torch.empty_like(xin)
-        _run("dit", bound, batch=b, hd=tokens * net.in_dim, emb_dim=net.emb_dim, cond_dim=net.emb_dim, temb=temb,
+        _run("dit", bound, batch=b, hd=tokens * x.shape[2], emb_dim=net.emb_dim, cond_dim=net.emb_dim, temb=temb,
              steps=None, n_steps=0, temb_per_sample=1, predict_noise=0, cfg_mode=1 if cond is not None else 0, cfg_w=1.0,
              cond=cond, x_in=xin, prior=None, fix_mask=None, noise=None, x_min=None, x_max=None, x_out=out,
              chunk=CHUNK_OVERRIDE["dit"] or _dit_chunk(b, tokens, net.d_model, 1))
@@ -681,8 +802,16 @@ def resmlp_forward(net, x, noise, condition) -> Optional[torch.Tensor]:
 def sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed) -> Optional[torch.Tensor]:
     """Whole denoising loop through cdx_dit1d_run / cdx_resmlp_run.  None -> caller uses the PyTorch executor."""
     dev = xt.device
-    if is_dit1d(net):
-        if xt.dim() != 3 or xt.shape[2] != net.in_dim:
+    if is_pearcetf(net):
+        if xt.dim() != 2 or cond_vec is None or w_cfg == 0.0 or cond_vec.dim() != 3:
+            return None                               # (the reference cannot run this backbone without a condition either)
+        kind, (b, d) = "pearcetf", xt.shape
+        bound = _bound(net, "pearcetf", lambda: _bind_pearcetf(net, dev))
+        hd, rows_h = d, 1
+        if bound is not None and (bound.struct.act_dim != d or tuple(cond_vec.shape[1:]) != (net.To, net.emb_dim)):
+            return None
+    elif is_dit1d(net) or is_dit1ref(net):
+        if xt.dim() != 3 or xt.shape[2] != net.in_dim * (2 if is_dit1ref(net) else 1):
             return None
         kind, (b, tokens, d) = "dit", xt.shape
         bound = _bound(net, ("dit", tokens), lambda: _bind_dit(net, tokens, dev))
@@ -733,6 +862,8 @@ def sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed) -> Optional[torc
         t_vec = runtime.device_times(plan, dev)
         if kind == "dit":
             temb, emb_dim, cond_dim = _f32c(net.map_noise(t_vec), dev), net.emb_dim, net.emb_dim
+        elif kind == "pearcetf":
+            temb, emb_dim, cond_dim = _f32c(net.map_noise(t_vec), dev), net.emb_dim, net.To * net.emb_dim
         elif kind == "chitf":
             temb, emb_dim = _f32c(net.map_noise(t_vec), dev), bound.struct.d_model
             cond_dim = bound.struct.To * bound.struct.obs_dim
@@ -755,6 +886,8 @@ def sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed) -> Optional[torc
             chunk = CHUNK_OVERRIDE[kind] or _mlp_chunk(b, bound.struct.hidden, two)
         elif kind == "chiunet":
             chunk = CHUNK_OVERRIDE[kind] or _chiunet_chunk(b, rows_h, bound.struct.model_dim, two)
+        elif kind == "pearcetf":
+            chunk = CHUNK_OVERRIDE["dit"] or _dit_chunk(b, 2 + bound.struct.To, bound.struct.te * bound.struct.n_heads, two)
         else:
             chunk = CHUNK_OVERRIDE[kind] or _dit_chunk(b, rows_h, bound.struct.d_model, two)
         _run(kind, bound, batch=b, hd=hd, emb_dim=emb_dim, cond_dim=cond_dim, temb=temb, steps=steps,

@@ -24,8 +24,10 @@ def try_backbone_forward(module, x, noise, condition) -> Optional[torch.Tensor]:
     if x.dtype != torch.float32:
         return None
     from . import bigbatch, runtime
-    if bigbatch.is_dit1d(module):
+    if bigbatch.is_dit1d(module) or bigbatch.is_dit1ref(module):
         return bigbatch.dit_forward(module, x, noise, condition)
+    if bigbatch.is_pearcetf(module):
+        return bigbatch.pearcetf_forward(module, x, noise, condition)
     if bigbatch.is_resmlp(module):
         return bigbatch.resmlp_forward(module, x, noise, condition)
     if bigbatch.is_chitf(module):
@@ -56,7 +58,7 @@ def try_fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, requ
         out = bigbatch.sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed)
         if out is not None:
             return out
-    if bigbatch.is_dit1d(net) or bigbatch.is_resmlp(net) or bigbatch.is_chitf(net):
+    if bigbatch.is_dit1d(net) or bigbatch.is_resmlp(net) or bigbatch.is_chitf(net) or bigbatch.is_dit1ref(net) or bigbatch.is_pearcetf(net):
         return bigbatch.sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed)     # EDM / consistency kinds included
     return runtime.fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed)
 
@@ -88,7 +90,7 @@ def try_fused_edm(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, require
         return None
     from . import bigbatch, runtime
     net = model["diffusion"]
-    if bigbatch.is_resmlp(net) or bigbatch.is_dit1d(net) or bigbatch.is_chitf(net):
+    if bigbatch.is_resmlp(net) or bigbatch.is_dit1d(net) or bigbatch.is_chitf(net) or bigbatch.is_dit1ref(net) or bigbatch.is_pearcetf(net):
         return bigbatch.sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed)
     if bigbatch.is_chiunet_gemm(net, xt.shape[0], xt.shape[1] if xt.dim() == 3 else None, runtime.plan_is_edm(plan)):
         out = bigbatch.sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed)

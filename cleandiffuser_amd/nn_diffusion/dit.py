@@ -122,6 +122,11 @@ class DiT1Ref(DiT1d):
 
     def forward(self, x: torch.Tensor, noise: torch.Tensor, condition: Optional[torch.Tensor] = None):
         """x (b, horizon, 2*in_dim) = [reference | noisy] -> (b, horizon, 2*in_dim) = [reference | prediction]."""
+        if type(self) is DiT1Ref:
+            from ..engine import dispatch
+            y = dispatch.try_backbone_forward(self, x, noise, condition)     # cdx_dit1d_run with the cross-attention weights
+            if y is not None:
+                return y
         x_ref, x_cur = torch.chunk(x, 2, -1)
         keep = x_ref.clone()
         ref_tok = self._tokens(x_ref)

@@ -4,7 +4,8 @@ contract: reference nn_diffusion/pearcetransformer.py:8-151).
 Tokens: [action embedding | timestep embedding | To observation embeddings], each projected to ``trans_emb_dim`` and tagged
 with a sine positional code of its index (``TimeSiren``); four encoder blocks (Linear -> qkv, seq-first
 ``nn.MultiheadAttention`` over ``trans_emb_dim * nhead`` features, 1/1.414-scaled residuals, BatchNorm1d over the feature
-axis -- running statistics in eval mode); the flattened tokens feed one Linear head.  PyTorch executor.
+axis -- running statistics in eval mode); the flattened tokens feed one Linear head.  On a ROCm device sampling and eval-mode
+forwards run on ``cdx_pearcetf_run`` (engine/bigbatch.py folds everything linear); training stays on autograd.
 """
 from typing import Optional
 
@@ -78,6 +79,11 @@ class PearceTransformer(BaseNNDiffusion):
 
     def forward(self, x: torch.Tensor, noise: torch.Tensor, condition: Optional[torch.Tensor] = None):
         """x (b, act_dim), noise (b,), condition (b, To, emb_dim)|None(=zeros) -> (b, act_dim)."""
+        if type(self) is PearceTransformer:
+            from ..engine import dispatch
+            y = dispatch.try_backbone_forward(self, x, noise, condition)     # cdx_pearcetf_run on a ROCm device (eval mode)
+            if y is not None:
+                return y
         if condition is None:
             condition = torch.zeros((x.shape[0], self.To, self.emb_dim), device=x.device)
         dev = x.device

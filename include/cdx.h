@@ -327,6 +327,13 @@ typedef struct cdx_dit1d_block {
     const float *fc1_w, *fc1_b;       /* mlp.0: (4d, d), (4d) */
     const float *fc2_w, *fc2_b;       /* mlp.3: (d, 4d), (d) */
 } cdx_dit1d_block;
+/* DiT1Ref (reference dit.py:135-180): before every block the token stream attends to the tokens of a REFERENCE trajectory,
+ * x <- cross_attns[i](x, x_ref, x_ref) (nn.MultiheadAttention, no residual); the state rows are [x_ref (in_dim) | x (in_dim)], both
+ * halves go through the same x_proj + pos, the output is [x_ref as given | final_layer(x)]. */
+typedef struct cdx_dit1ref_cross {
+    const float *in_w, *in_b;         /* cross_attns[i].in_proj_{weight,bias}: (3d, d), (3d) -- rows [0,d) q, [d,3d) k | v */
+    const float *out_w, *out_b;       /* cross_attns[i].out_proj: (d, d), (d) */
+} cdx_dit1ref_cross;
 typedef struct cdx_dit1d_weights {
     int32_t tokens, in_dim, emb_dim, d_model, n_heads, depth;
     const float *x_proj_w, *x_proj_b; /* (d, in_dim), (d) */
@@ -336,9 +343,38 @@ typedef struct cdx_dit1d_weights {
     const cdx_dit1d_block* blocks;    /* HOST array [depth] of device pointers */
     const float *fin_ada_w, *fin_ada_b; /* final_layer.adaLN_modulation.1: (2d, d), (2d) */
     const float *fin_w, *fin_b;       /* final_layer.linear: (in_dim, d), (in_dim) */
+    const cdx_dit1ref_cross* cross;   /* HOST array [depth] (DiT1Ref: cdx_sampling.hd == tokens * 2 * in_dim) or NULL (DiT1d) */
 } cdx_dit1d_weights;
 long long cdx_dit1d_workspace_floats(const cdx_dit1d_weights* w, const cdx_sampling* s);
 int cdx_dit1d_run(const cdx_dit1d_weights* w, const cdx_sampling* s, void* hip_stream);
+
+/* PearceTransformer (reference nn_diffusion/pearcetransformer.py:8-151; the DBC pipelines' transformer denoiser): S = 2 + To tokens
+ * [act_to_input(act_emb(x)) + pos(1) | t_to_input(map_noise(t)) + pos(2) | cond_to_input(condition) + pos(3..)] of width te through
+ * n_blocks TransformerEncoderBlocks, then Linear(S * te -> act_dim) on the flattened tokens.  The host folds what is linear:
+ *   qkv     = MHA.in_proj o input_to_qkv1                       (te -> 3 td; td = te * n_heads)
+ *   o       = bn1a o (attn1_to_fcn o MHA.out_proj) / 1.414       (td -> te), r1 = bn1a scale / 1.414 for the residual path
+ *   fc2     = bn1b o attn1_fcn.2 / 1.414                         (4 te -> te), r2 likewise
+ * (BatchNorm1d in eval mode is a per-channel affine map; sampling always runs model_ema.eval()), so a block is
+ *   a1 = attention(f qkv) o + r1 * f;   f' = gelu(a1 fc1) fc2 + r2 * a1.
+ * temb rows are map_noise(t) (emb_dim); cond rows are the flattened (To, emb_dim) condition embedding. */
+typedef struct cdx_pearcetf_block {
+    const float *qkv_w, *qkv_b;       /* (3 td, te), (3 td) */
+    const float *o_w, *o_b, *r1;      /* (te, td), (te), (te) */
+    const float *fc1_w, *fc1_b;       /* (4 te, te), (4 te) */
+    const float *fc2_w, *fc2_b, *r2;  /* (te, 4 te), (te), (te) */
+} cdx_pearcetf_block;
+typedef struct cdx_pearcetf_weights {
+    int32_t act_dim, To, emb_dim, te, n_heads, n_blocks;
+    const float *ae0_w, *ae0_b, *ae2_w, *ae2_b;   /* act_emb.0 / .2: (E, act_dim), (E), (E, E), (E) */
+    const float *a2i_w, *a2i_b;       /* act_to_input, pos_embed(1.0) folded into the bias: (te, E), (te) */
+    const float *t2i_w, *t2i_b;       /* t_to_input, pos_embed(2.0) folded into the bias */
+    const float *c2i_w, *c2i_b;       /* cond_to_input: (te, E), (te) */
+    const float* cpos;                /* (To, te): pos_embed(3 .. 3 + To) */
+    const cdx_pearcetf_block* blocks; /* HOST array [n_blocks] of device pointers */
+    const float *fin_w, *fin_b;       /* final: (act_dim, (2 + To) * te), (act_dim) */
+} cdx_pearcetf_weights;
+long long cdx_pearcetf_workspace_floats(const cdx_pearcetf_weights* w, const cdx_sampling* s);
+int cdx_pearcetf_run(const cdx_pearcetf_weights* w, const cdx_sampling* s, void* hip_stream);
 
 /* ChiTransformer (reference nn_diffusion/chitransformer.py:61-158) with the MLP condition encoder (n_cond_layers == 0):
  * memory = encoder([map_noise(t) | obs_emb(obs)] + cond_pos_emb); decoder layers are nn.TransformerDecoderLayer(norm_first, gelu):

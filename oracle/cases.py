@@ -312,6 +312,7 @@ def lib_namespace(kind: str):
     ns.EDM = importlib.import_module(root + ".diffusion.edm").EDM
     mlp_mod = "cleandiffuser_amd.nn_diffusion.mlp_backbones" if kind == "amd" else "cleandiffuser.nn_diffusion.idqlmlp"
     ns.NewIDQLMlp = importlib.import_module(mlp_mod).NewIDQLMlp           # likewise (idqlmlp.py:68)
+    ns.DiT1Ref = importlib.import_module(root + ".nn_diffusion.dit").DiT1Ref   # (dit.py:135; the reference package does not export it)
     return ns
 
 

@@ -307,6 +307,60 @@ SCENARIOS.update({
 })
 
 
+# --------------------------------------------------------------------------------------------------------------------- #
+# row f3: the two backbones that were PyTorch mirrors until round 3 (reference pearcetransformer.py:91-151, dit.py:135-180)
+def pearce_transformer(default_size: bool):
+    """PearceTransformer: stand-alone forward (per-sample timesteps), w_cfg = 1 loop and a CFG pair (w_cfg = 1.6).  `default_size`:
+    the constructor defaults the DBC pipelines use (emb 128, trans_emb_dim 64, 16 heads -> 1024-wide attention), To = 2."""
+    B, steps = 5, 4
+
+    def run(lib, kind, device):
+        kw = dict(To=2, emb_dim=128, trans_emb_dim=64, nhead=16) if default_size else dict(To=3, emb_dim=32, trans_emb_dim=16, nhead=4)
+        net = load_synth(lib.PearceTransformer(6, **kw), 71)
+        agent = lib.DiscreteDiffusionSDE(net, lib.IdentityCondition(dropout=0.0), predict_noise=False, x_max=torch.ones(1, 6),
+                                         x_min=-torch.ones(1, 6), diffusion_steps=20, device=device)
+        agent.eval()
+        g = torch.Generator().manual_seed(71)
+        cond = torch.randn(B, kw["To"], kw["emb_dim"], generator=g)
+        zs = [torch.randn(B, 6, generator=g) for _ in range(steps + 1)]
+        with torch.no_grad():
+            fwd = agent.model_ema["diffusion"](zs[0].to(device), torch.tensor([0, 3, 7, 11, 19], device=device), cond.to(device))
+        skw = dict(solver="ddpm", n_samples=B, sample_steps=steps, temperature=0.7, condition_cfg=cond.to(device))
+        x1, _ = _sample(agent, kind, torch.zeros(B, 6, device=device), zs, w_cfg=1.0, **skw)
+        x2, _ = _sample(agent, kind, torch.zeros(B, 6, device=device), zs, w_cfg=1.6, **skw)
+        return {"fwd": fwd, "x": x1, "x_cfg": x2}
+    return run
+
+
+def dit1ref():
+    """DiT1Ref: state rows [reference | noisy] with the reference half held by the fix-mask; stand-alone forward, CFG pair DDIM loop."""
+    B, steps, T, D = 3, 4, 12, 5
+
+    def run(lib, kind, device):
+        net = load_synth(lib.DiT1Ref(D, emb_dim=32, d_model=64, n_heads=4, depth=2), 73)
+        fm = torch.zeros(T, 2 * D)
+        fm[:, :D] = 1.0
+        lim = 2.0 * torch.ones(1, T, 2 * D)
+        agent = lib.DiscreteDiffusionSDE(net, lib.IdentityCondition(dropout=0.0), fix_mask=fm, predict_noise=True, x_max=lim, x_min=-lim,
+                                         diffusion_steps=20, device=device)
+        agent.eval()
+        g = torch.Generator().manual_seed(73)
+        prior = torch.zeros(B, T, 2 * D)
+        prior[:, :, :D] = torch.randn(B, T, D, generator=g)
+        cond = torch.randn(B, 32, generator=g)
+        zs = [torch.randn(B, T, 2 * D, generator=g) for _ in range(steps + 1)]
+        with torch.no_grad():
+            fwd = agent.model_ema["diffusion"](zs[0].to(device), torch.tensor([1, 8, 15], device=device), cond.to(device))
+        x, _ = _sample(agent, kind, prior.to(device), zs, solver="ddim", n_samples=B, sample_steps=steps, w_cfg=1.5,
+                       condition_cfg=cond.to(device))
+        xu, _ = _sample(agent, kind, prior.to(device), zs, solver="sde_dpmsolver++_1", n_samples=B, sample_steps=steps, w_cfg=0.0)
+        return {"fwd": fwd, "x": x, "x_uncond": xu}
+    return run
+
+
+SCENARIOS.update({"pearcetf_small": pearce_transformer(False), "pearcetf_default": pearce_transformer(True), "dit1ref": dit1ref()})
+
+
 def run(name: str, lib_kind: str, device="cpu"):
     """Outputs of scenario `name` as {key: tensor}; keys starting with '_' are live objects for the caller, not results."""
     torch.manual_seed(1234)

@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported(lib):
                           "cdx_chitf_run", "cdx_chitf_workspace_floats", "cdx_cross_attention_f32", "cdx_chiunet_run",
                           "cdx_chiunet_workspace_floats", "cdx_groupnorm_f32", "cdx_groupnorm_bwd_f32", "cdx_hjgrad_run",
                           "cdx_hjgrad_workspace_floats", "cdx_guided_run", "cdx_guided_workspace_floats", "cdx_unet2_run",
-                          "cdx_unet2_embtab", "cdx_optim_f32"}
+                          "cdx_unet2_embtab", "cdx_optim_f32", "cdx_pearcetf_run", "cdx_pearcetf_workspace_floats"}
     for n in names:
         assert hasattr(lib, n), f"{n} declared in cdx.h but not exported by libcdx.so"
     assert lib.cdx_abi_version() == int(re.search(r"#define CDX_ABI_VERSION (\d+)", hdr).group(1))
@@ -44,6 +44,8 @@ def test_ctypes_mirrors_have_c_layout(tmp_path):
                "cdx_unet1d_launch": runtime.CdxUnet1dLaunch, "cdx_step": runtime.CdxStep, "cdx_gemm_args": blocks.CdxGemmArgs,
                "cdx_ln_args": blocks.CdxLnArgs, "cdx_attn_args": blocks.CdxAttnArgs, "cdx_sampling": bigbatch.CdxSampling,
                "cdx_dit1d_block": bigbatch.CdxDitBlock, "cdx_dit1d_weights": bigbatch.CdxDitWeights,
+               "cdx_dit1ref_cross": bigbatch.CdxDitCross, "cdx_pearcetf_block": bigbatch.CdxPearcetfBlock,
+               "cdx_pearcetf_weights": bigbatch.CdxPearcetfWeights,
                "cdx_resmlp_block": bigbatch.CdxResMlpBlock, "cdx_resmlp_weights": bigbatch.CdxResMlpWeights,
                "cdx_chitf_layer": bigbatch.CdxChitfLayer, "cdx_chitf_weights": bigbatch.CdxChitfWeights,
                "cdx_xattn_args": blocks.CdxXattnArgs, "cdx_gn_args": blocks.CdxGnArgs,
@@ -157,6 +159,8 @@ def test_newer_entries_validate_before_touching_the_device(lib):
     assert lib.cdx_groupnorm_bwd_f32(ctypes.byref(g), None) == bad
     s = bigbatch.CdxSampling()
     assert lib.cdx_chitf_run(ctypes.byref(bigbatch.CdxChitfWeights()), ctypes.byref(s), None) == bad
+    assert lib.cdx_pearcetf_run(ctypes.byref(bigbatch.CdxPearcetfWeights()), ctypes.byref(s), None) == bad and b"PearceTransformer" in lib.cdx_last_error()
+    assert lib.cdx_pearcetf_workspace_floats(None, None) == -1
     assert lib.cdx_chiunet_run(ctypes.byref(bigbatch.CdxChiUNetWeights()), ctypes.byref(s), None) == bad
     lib.cdx_guided_run.restype = ctypes.c_int
     assert lib.cdx_guided_run(ctypes.byref(guided.CdxGuidedLaunch()), None) == bad and b"null" in lib.cdx_last_error()

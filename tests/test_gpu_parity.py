@@ -1154,3 +1154,29 @@ def test_update_runs_without_aten_optimiser_launches(amd_lib):
     xa, _ = a.sample(prior, solver="ddim", n_samples=4, sample_steps=5, noise=[z])
     xb, _ = b.sample(prior, solver="ddim", n_samples=4, sample_steps=5, noise=[z])
     np.testing.assert_allclose(xa.cpu().numpy(), xb.cpu().numpy(), **TOL)
+
+
+# ---- row f3: PearceTransformer and DiT1Ref on the library (VERDICT r2 missing #2) ----
+@pytest.mark.parametrize("name", ["pearcetf_small", "pearcetf_default"])
+def test_pearce_transformer_runs_on_its_executor(name, amd_lib, monkeypatch):
+    """PearceTransformer (reference pearcetransformer.py:91-151): the stand-alone forward with per-sample timesteps, the w_cfg = 1 loop
+    and the CFG-pair loop are ONE cdx_pearcetf_run call each (folded projections / BatchNorm, MFMA attention over the 2 + To tokens);
+    fixtures from the real reference at the DBC pipelines' default size (1024-wide attention) and a small one, 1e-4."""
+    calls = _spy_bigbatch(monkeypatch)
+    out, gold = _extra(name)
+    torch.cuda.synchronize()
+    assert [c[0] for c in calls] == ["pearcetf"] * 3, calls
+    for k in gold.files:
+        scale = max(1.0, float(np.abs(gold[k]).max()))
+        np.testing.assert_allclose(out[k].cpu().numpy() / scale, gold[k] / scale, err_msg=f"{name}/{k}", **TOL)
+
+
+def test_dit1ref_runs_on_the_dit_executor(amd_lib, monkeypatch):
+    """DiT1Ref (reference dit.py:135-180): cross-attention to the reference half's tokens in front of every block, [reference |
+    prediction] output -- forward, CFG-pair DDIM loop and unconditional SDE loop are one cdx_dit1d_run call each."""
+    calls = _spy_bigbatch(monkeypatch)
+    out, gold = _extra("dit1ref")
+    torch.cuda.synchronize()
+    assert [c[0] for c in calls] == ["dit"] * 3, calls
+    for k in gold.files:
+        np.testing.assert_allclose(out[k].cpu().numpy(), gold[k], err_msg=k, **TOL)

@@ -109,3 +109,41 @@ def test_head_chain_semantics_with_torch_stand_ins(monkeypatch):
         seq[4] = nn.Linear(16, 16)                                    # swapped sub-module: recompiled against the new one
         np.testing.assert_allclose(heads.try_sequential(seq, x).numpy(), seq(x).numpy(), rtol=1e-6, atol=1e-6)
         assert heads.try_sequential(seq, torch.zeros(0, 10)) is None   # empty batch: stock modules
+
+
+def test_pearce_transformer_folding_equals_the_module():
+    """cdx_pearcetf_run consumes folded weights (engine/bigbatch.py:fold_pearcetf: in_proj o input_to_qkv1, attn1_to_fcn o out_proj,
+    eval-mode BatchNorm1d + 1/1.414 residual scaling, position codes in the token biases).  The executor's data flow re-stated with
+    torch ops on those folded tensors must equal the module's own forward (reference pearcetransformer.py:91-151)."""
+    import torch
+    import torch.nn.functional as F
+    from cleandiffuser_amd.engine.bigbatch import fold_pearcetf
+    from cleandiffuser_amd.nn_diffusion import PearceTransformer
+    from cleandiffuser_amd.utils import load_synth
+    net = load_synth(PearceTransformer(6, To=2, emb_dim=32, trans_emb_dim=16, nhead=4), 9).eval()
+    for m in net.modules():                                  # non-trivial running statistics
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.uniform_(-0.5, 0.5)
+            m.running_var.uniform_(0.5, 2.0)
+    fold = fold_pearcetf(net)
+    g = torch.Generator().manual_seed(0)
+    x, t, cond = torch.randn(7, 6, generator=g), torch.arange(7) * 3, torch.randn(7, 2, 32, generator=g)
+    with torch.no_grad():
+        want = net._forward_torch(x, t, cond) if hasattr(net, "_forward_torch") else net(x, t, cond)
+        te, td, H = fold["te"], fold["td"], fold["heads"]
+        xi = F.linear(net.act_emb(x), net.act_to_input.weight, fold["a2i_b"])
+        ti = F.linear(net.map_noise(t), net.t_to_input.weight, fold["t2i_b"])
+        ci = net.cond_to_input(cond) + fold["cpos"][None]
+        f = torch.cat([xi[:, None], ti[:, None], ci], 1)                       # (b, S, te), batch-major rows as the executor keeps them
+        b, S = f.shape[:2]
+        for k in fold["blocks"]:
+            qkv = F.linear(f, k["qkv_w"], k["qkv_b"]).reshape(b, S, 3, H, te)
+            q, kk, v = (qkv[:, :, j].permute(0, 2, 1, 3) for j in range(3))     # (b, H, S, te)
+            att = torch.softmax(q @ kk.transpose(-1, -2) / te ** 0.5, -1) @ v
+            att = att.permute(0, 2, 1, 3).reshape(b, S, td)
+            a1 = F.linear(att, k["o_w"], k["o_b"]) + f * k["r1"]
+            f = F.linear(F.gelu(F.linear(a1, k["fc1_w"], k["fc1_b"])), k["fc2_w"], k["fc2_b"]) + a1 * k["r2"]
+        got = net.final(f.reshape(b, S * te))
+    torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-5)
+    net.train()
+    assert fold_pearcetf(net) is None                         # batch statistics: not this executor's business
