@@ -629,9 +629,9 @@ __device__ __forceinline__ void prefetch_ring(const Item& it, const float* __res
 // Epilogue threads: 256 per trajectory (8 GroupNorm groups x 32 lanes).  4 waves: all of them, one trajectory after the other;
 // 8 waves, T = 2: waves 0-3 take trajectory 0 while waves 4-7 take trajectory 1; 8 waves, T = 1: waves 0-3 run the epilogue,
 // waves 4-7 rewrite the destination's halo rows.
-template <int T, int NWV, bool BWD, bool PROF>
+template <int T, int NWV, bool BWD, bool PROF, bool COND>
 __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* ops, int vd, int vdn, Item& it,
-                                       const float* __restrict__ emb_row, float* __restrict__ lds, int tid,
+                                       const float* __restrict__ emb_row, int emb_tstride, float* __restrict__ lds, int tid,
                                        Ring<WG<NWV>::PF>& ring, unsigned long long* prof, int b0) {
     constexpr bool SPLIT_T = NWV == 8 && T >= 2;       // waves 0-3 take trajectories 0, 2; waves 4-7 trajectory 1
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -684,7 +684,8 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
             P.ga = *reinterpret_cast<const f32x4*>(L.wblob + CDX2_DW(vd, CDX2_W2_GAMMA) + c);
             P.be = *reinterpret_cast<const f32x4*>(L.wblob + CDX2_DW(vd, CDX2_W2_BETA) + c);
         }
-        if (flags & CDX2_F2_EMB) P.em = *reinterpret_cast<const f32x4*>(emb_row + CDX2_DW(vd, CDX2_W2_EMB) + c);
+        // (per-trajectory FiLM rows -- conditional nets: this thread's FIRST trajectory here, later ones inside the loop below)
+        if (flags & CDX2_F2_EMB) P.em = *reinterpret_cast<const f32x4*>(emb_row + (COND && SPLIT_T ? (wave >> 2) * emb_tstride : 0) + CDX2_DW(vd, CDX2_W2_EMB) + c);
     }
 
     // K loop -> staged partial tiles
@@ -713,6 +714,8 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
         // (a trajectory past the end of the range -- odd count, last workgroup -- computes on its zeroed region; its saved tensors
         //  go to the spare block [batch] of the workspace, never into a real trajectory's block)
         float* ws = BWD ? L.ws + (size_t)(b0 + t < L.traj_first + L.traj_count ? b0 + t : L.batch) * L.ws_floats : nullptr;
+        if (COND && emb_tstride != 0 && t != t_lo && epi_wave && (e.flags & CDX2_F2_EMB))
+            P.em = *reinterpret_cast<const f32x4*>(emb_row + t * emb_tstride + CDX2_DW(vd, CDX2_W2_EMB) + c);
         if (epi_wave) {
             if (BWD && (e.flags & CDX2_F2_GNBWD)) {
                 if (e.nk == 1) epilogue_bwd<1>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
@@ -741,8 +744,12 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
 // on), i.e. at most 256 VGPR + AGPR per lane -- the second launch-bound argument is waves per SIMD.
 // PROF: the s_memtime stamps of tools/op_profile2.py exist only in the instantiations a launch with `prof != NULL` selects -- even
 // untaken, their scalar branches and the values they keep alive cost 1-3 % (A/B on MI355X).
-template <int T, int NWV, bool BWD, bool PROF>
+// COND: the instantiations that understand conditional requests (per-trajectory FiLM rows, the classifier-free-guidance pair, EDM /
+// consistency step kinds).  A separate template parameter so that the unconditional kernels -- the headline path, scalar-register
+// bound -- compile to exactly the code they had before.
+template <int T, int NWV, bool BWD, bool PROF, bool COND = false>
 __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_unet2_kernel(const cdx_unet2_launch L) {
+    static_assert(!(COND && BWD), "conditional requests have no backward-op variant");
     constexpr int THREADS = WG<NWV>::THREADS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -768,6 +775,10 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
     {
     const KArg* S = kernarg();
     asm volatile("" : "+s"(S));
+    // EDM / consistency plans (kinds 5-7; reference newedm.py:130-148): the network sees c_in * x, the authoritative state lives in
+    // x_out (as for compact programs) and the LDS slot holds the scaled copy
+    const bool edm0 = COND && S->n_steps > 0 && S->edm_plan;
+    const float c_in0 = edm0 ? S->steps[0].alpha : 1.0f;
 #pragma unroll 1
     for (int t = 0; t < T; ++t) {
         if (b0 + t >= b_end) break;
@@ -784,25 +795,74 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
                     v = __fadd_rn(__fmul_rn(v, __fsub_rn(1.0f, m)), __fmul_rn(S->prior[xbase + e], m));
                 }
             }
-            lds[t * tf + S->x_off + n * S->x_stride + c] = v;
-            if (S->compact) S->x_out[xbase + e] = v;
+            lds[t * tf + S->x_off + n * S->x_stride + c] = (COND && edm0) ? c_in0 * v : v;
+            if (S->compact || (COND && edm0)) S->x_out[xbase + e] = v;
         }
     }
     }
     __syncthreads();
 
     const int n_iter = L.n_steps > 0 ? L.n_steps : 1;
+    const int HDp = (HD + 3) & ~3;                     // ws block of a trajectory: [multistep memory / EDM slope | x_old | p_cond]
     for (int step = 0; step < n_iter; ++step) {
+      int n_pass = 1;
+      if (COND) {
+          const KArg* S0 = kernarg();
+          asm volatile("" : "+s"(S0));
+          n_pass = S0->n_pass == 2 ? 2 : 1;
+      }
+#pragma unroll 1
+      for (int pass = 0; pass < n_pass; ++pass) {
+        // FiLM rows of this forward: one per step, or one per (step, trajectory) for conditional nets; the second pass of a
+        // classifier-free-guidance pair takes the zero-condition table
         const float* __restrict__ emb_row = L.emb + (size_t)step * L.emb_ld;
+        int emb_tstride = 0;
+        if (COND) {
+            const KArg* S0 = kernarg();
+            asm volatile("" : "+s"(S0));
+            if (pass == 1) emb_row = S0->emb_u + (size_t)step * L.emb_ld;
+            else if (S0->emb_per_traj) {      // (the table ends with two spare rows: a half-empty last workgroup reads past its batch)
+                emb_row = L.emb + ((size_t)step * L.batch + b0) * L.emb_ld;
+                emb_tstride = L.emb_ld;
+            }
+        }
         for (int oi = 0; oi < L.n_ops; ++oi) {
             // next op's descriptor (the last op fetches op 0 of the next step): one coalesced load, needed after the K loop
             const int vdn = load_desc<NWV>(L.ops, oi + 1 < L.n_ops ? oi + 1 : 0, lane, wave);
             // (profile the SECOND forward when there is one: instruction / scalar caches warm, like every later step)
             unsigned long long* pslot = (profiling && step == (L.n_steps > 1 ? 1 : 0)) ? lprof + (size_t)oi * 8 : nullptr;
             if (PROF) stamp(pslot, tid);
-            run_op<T, NWV, BWD, PROF>(L, ops, vd, vdn, it, emb_row, lds, tid, ring, pslot, b0);
+            run_op<T, NWV, BWD, PROF, COND>(L, ops, vd, vdn, it, emb_row, emb_tstride, lds, tid, ring, pslot, b0);
             vd = vdn;
         }
+        if (COND && n_pass == 2 && pass == 0) {
+            // conditional prediction -> the trajectory's ws block; a compact program's state slot was arena memory during the
+            // forward: rebuild it from x_out for the second forward
+            const KArg* S = kernarg();
+            asm volatile("" : "+s"(S));
+#pragma unroll 1
+            for (int t = 0; t < T; ++t) {
+                if (b0 + t >= b_end) break;
+                const size_t xbase = (size_t)(b0 + t) * HD;
+                float* tl = lds + t * tf;
+                float* wsb = S->ws + (size_t)(b0 + t) * S->ws_floats;
+                const float c_in = S->edm_plan ? S->steps[step].alpha : 1.0f;
+                for (int e = tid; e < HD; e += THREADS) {
+                    const int n = e / D, c = e - n * D;
+                    wsb[2 * HDp + e] = tl[S->pred_off + n * S->pred_stride + c];
+                    if (S->compact) tl[S->x_off + n * S->x_stride + c] = c_in * S->x_out[xbase + e];
+                }
+                if (S->compact) {
+                    const int xs = S->x_stride, xb = S->x_off - CDX2_HALO2 * xs;
+                    for (int i = tid; i < (H + 2 * CDX2_HALO2) * xs; i += THREADS) {
+                        const int r = i / xs, c = i - r * xs;
+                        if (r < CDX2_HALO2 || r >= H + CDX2_HALO2 || c >= D) tl[xb + i] = 0.f;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+      }
         if (L.n_steps == 0) break;
         // The solver step's pointers and offsets are read from the kernarg segment HERE, through a pointer the optimiser cannot
         // see through across iterations: as by-value kernel arguments they would stay live in ~35 SGPRs over the whole op loop,
@@ -814,18 +874,53 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
         const cdx_step st = S->steps[step];
         const float al = st.alpha, sg = st.sigma;
         const float k0 = st.k[0], k1 = st.k[1], k2 = st.k[2], k3 = st.k[3], k4 = st.k[4];
+        const bool edm = COND && st.kind >= 5;
+        const bool xglob = S->compact || edm;                  // the authoritative state lives in x_out, memory in the ws block
+        const float c_next = (edm && step + 1 < S->n_steps) ? S->steps[step + 1].alpha : 1.0f;   // the NEXT forward sees c_in * x
 #pragma unroll 1
         for (int t = 0; t < T; ++t) {
             if (b0 + t >= b_end) break;
             const int b = b0 + t;
             const size_t xbase = (size_t)b * HD;
             float* tl = lds + t * tf;
+            float* wsb = (COND && (xglob || n_pass == 2)) ? S->ws + (size_t)b * S->ws_floats : nullptr;
             for (int e = tid; e < HD; e += THREADS) {
                 const int n = e / D, c = e - n * D;
                 const int xo = S->x_off + n * S->x_stride + c;
                 // compact programs: the authoritative state lives in x_out (global), the LDS slot only feeds op 0 of the next forward
-                const float x = S->compact ? S->x_out[xbase + e] : tl[xo];
+                const float x = xglob ? S->x_out[xbase + e] : tl[xo];
                 float p = tl[S->pred_off + n * S->pred_stride + c];
+                if (COND && n_pass == 2) p = S->cfg_w * wsb[2 * HDp + e] + (1.0f - S->cfg_w) * p;   // w * cond + (1 - w) * uncond
+                if (edm) {
+                    // EDM (reference newedm.py:387-401, legacy edm.py:118-160): D = clip(c_skip x + c_out F), slope = (x - D) / sigma;
+                    // kind 7 = consistency model (consistency_model.py:412-427): x <- f(x) [mask], then re-noise for the next level
+                    float dn = k0 * x + k1 * p, xe;
+                    if (S->x_min) dn = fmaxf(dn, S->x_min[e]);
+                    if (S->x_max) dn = fminf(dn, S->x_max[e]);
+                    if (st.kind == 7) {
+                        xe = dn;
+                        if (S->fix_mask) {
+                            const float m = S->fix_mask[e];
+                            xe = xe * (1.0f - m) + S->prior[xbase + e] * m;
+                        }
+                        if (st.noise_idx >= 0) xe += k3 * S->noise[((size_t)st.noise_idx * S->batch + b) * HD + e];
+                    } else {
+                        const float sl = (x - dn) / k2;
+                        if (st.kind == 5) {
+                            xe = x - sl * k3;
+                            if (st.push) { wsb[e] = sl; wsb[HDp + e] = x; }
+                        } else {
+                            xe = wsb[HDp + e] - (wsb[e] + sl) / 2.0f * k3;
+                        }
+                        if (S->fix_mask) {
+                            const float m = S->fix_mask[e];
+                            xe = xe * (1.0f - m) + S->prior[xbase + e] * m;
+                        }
+                    }
+                    tl[xo] = c_next * xe;
+                    S->x_out[xbase + e] = xe;
+                    continue;
+                }
                 // classifier guidance (reference diffusionsde.py:153-173): the prediction is shifted along d log p / d x_t BEFORE
                 // it is clipped; cg_scale[step] = -w sigma (noise prediction) or w sigma^2 / alpha (x0 prediction), frozen by the host
                 if (BWD && S->cg_scale) p += S->cg_scale[step] * tl[S->grad_off + n * S->grad_stride + c];
@@ -904,7 +999,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
         const int off = S->n_steps == 0 ? (want_grad ? S->grad_off : S->pred_off) : S->x_off;
         const int str = S->n_steps == 0 ? (want_grad ? S->grad_stride : S->pred_stride) : S->x_stride;
         float* __restrict__ xo = S->x_out;
-        if (S->compact && S->n_steps > 0) break;            // the state is already there
+        if ((S->compact || (COND && S->edm_plan)) && S->n_steps > 0) break;            // the state is already there
         for (int e = tid; e < HD; e += THREADS) {
             const int n = e / D, c = e - n * D;
             xo[xbase + e] = lds[t * tf + off + n * str + c];
@@ -989,6 +1084,15 @@ int cdx_unet2_run(const cdx_unet2_launch* L, void* hip_stream) {
     if (L->traj_per_wg == 3 && (L->n_waves != 8 || !L->compact)) { cdx_set_err("three trajectories per workgroup: 8-wave compact programs only"); return CDX_EINVAL; }
     if (L->compact && L->x_out == L->x_in) { cdx_set_err("compact program: x_out holds the state during the launch and must not alias x_in"); return CDX_EINVAL; }
     if (L->compact && L->n_steps > 0 && (!L->ws || L->ws_floats < L->horizon * L->dim)) { cdx_set_err("compact program: ws (multistep memory) missing"); return CDX_EINVAL; }
+    if (L->n_pass != 0 && L->n_pass != 1 && L->n_pass != 2) { cdx_set_err("n_pass must be 1 or 2"); return CDX_EINVAL; }
+    if (L->n_pass == 2 && (!L->emb_u || L->n_steps == 0)) { cdx_set_err("classifier-free-guidance pair: emb_u and a sampling loop required"); return CDX_EINVAL; }
+    if ((L->n_pass == 2 || L->edm_plan) && (!L->ws || L->ws_floats < 3 * ((L->horizon * L->dim + 3) & ~3))) {
+        cdx_set_err("CFG pair / EDM step kinds: ws with 3 * round4(horizon * dim) floats per trajectory required"); return CDX_EINVAL;
+    }
+    if (L->edm_plan && L->x_out == L->x_in) { cdx_set_err("EDM step kinds: x_out holds the state during the launch and must not alias x_in"); return CDX_EINVAL; }
+    if ((L->n_pass == 2 || L->edm_plan || L->emb_per_traj) && (L->cg_scale != nullptr || L->with_backward != 0)) {
+        cdx_set_err("conditional / EDM requests are not available for programs with backward ops"); return CDX_EINVAL;
+    }
     if (L->n_waves != 4 && L->n_waves != 8) { cdx_set_err("n_waves must be 4 or 8 (the program is compiled for one of them)"); return CDX_EINVAL; }
     if (L->n_steps > 0 && !L->steps) { cdx_set_err("steps == NULL with n_steps > 0"); return CDX_EINVAL; }
     if (L->n_steps < 0) { cdx_set_err("negative n_steps"); return CDX_EINVAL; }
@@ -1005,7 +1109,13 @@ int cdx_unet2_run(const cdx_unet2_launch* L, void* hip_stream) {
     if (L->ws_floats < 0 || (L->ws_floats & 3)) { cdx_set_err("ws_floats must be a non-negative multiple of 4"); return CDX_EINVAL; }
     if (L->cg_scale && (L->grad_off < 0 || (L->grad_off & 3) || (L->grad_stride & 3))) { cdx_set_err("cg_scale given without a gradient slot"); return CDX_EINVAL; }
     void (*kern)(const cdx_unet2_launch);
-    if (L->prof) {                                       // profiling builds of the shapes tools/op_profile2*.py look at
+    const bool cond = L->n_pass == 2 || L->edm_plan || L->emb_per_traj;
+    if (cond) {
+        if (L->prof) { cdx_set_err("op profiling: unconditional requests only"); return CDX_EINVAL; }
+        kern = L->n_waves == 8 ? (L->traj_per_wg == 3 ? cdx_unet2_kernel<3, 8, false, false, true>
+                                  : L->traj_per_wg == 2 ? cdx_unet2_kernel<2, 8, false, false, true> : cdx_unet2_kernel<1, 8, false, false, true>)
+                               : (L->traj_per_wg == 2 ? cdx_unet2_kernel<2, 4, false, false, true> : cdx_unet2_kernel<1, 4, false, false, true>);
+    } else if (L->prof) {                                       // profiling builds of the shapes tools/op_profile2*.py look at
         if (L->n_waves != 8) { cdx_set_err("op profiling: 8-wave shapes only"); return CDX_EINVAL; }
         if (guided && L->traj_per_wg == 3) { cdx_set_err("op profiling of guided programs: one or two trajectories per workgroup"); return CDX_EINVAL; }
         kern = guided ? (L->traj_per_wg == 2 ? cdx_unet2_kernel<2, 8, true, true> : cdx_unet2_kernel<1, 8, true, true>)

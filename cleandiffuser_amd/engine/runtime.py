@@ -336,6 +336,11 @@ def _backbone_cond(module, prog, condition, device):
 
 def backbone_forward(module, x, noise, condition) -> Optional[torch.Tensor]:
     """``BaseNNDiffusion.forward`` on the device: one launch, per-sample timesteps."""
+    if x.dim() == 3 and _is_janner(module):
+        from . import runtime2                        # second-generation kernel: one FiLM row per sample
+        y = runtime2.backbone_forward2(module, x, noise, condition)
+        if y is not None:
+            return y
     if x.dim() != 3 or supported_backbone(module, x.shape[1]) is not None:
         return None
     load_library()
@@ -388,11 +393,24 @@ def _pack_steps(plan, device) -> torch.Tensor:
     return torch.from_numpy(raw).to(device)
 
 
+def mlp_tile(batch: int) -> int:
+    """Samples per workgroup of a batch-tiled MLP program: 16 (one 16x16x4 MFMA column tile) once that still gives every CU a
+    workgroup, else 8 or 4 (4x4x1 MFMA column blocks) -- BASELINE config 1 is B = 256: 16 workgroups of 16 samples leave 240 of the
+    256 CUs idle, 64 workgroups of 4 do a quarter of the work each.  CDX_MLP_TILE forces 4, 8 or 16."""
+    forced = os.environ.get("CDX_MLP_TILE")
+    if forced in ("4", "8", "16"):
+        return int(forced)
+    for tile in (16, 8):
+        if batch >= 256 * tile:
+            return tile
+    return 4 if batch <= 1024 else 8
+
+
 def fused_sample_mlp(solver, net, kind, plan, xt, prior, cond_vec, w_cfg, feed) -> Optional[torch.Tensor]:
     """Batch-tiled MLP denoisers (x of shape (B, D)): one workgroup per `MLP_TILE` samples, whole loop in one launch."""
     b, d = xt.shape
     dev = xt.device
-    tile = P.MLP_TILE
+    tile = mlp_tile(b)
     n_tiles = -(-b // tile)
     pad = n_tiles * tile - b
     try:
@@ -450,8 +468,8 @@ def fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed, x_scale:
     if xt.dim() != 3 or not (_is_janner(net) or _is_chiunet(net)):
         return None
     v1_why = supported_backbone(net, xt.shape[1], plan_is_edm(plan))
-    v2_candidate = (cond_vec is None or w_cfg == 0.0) and _is_janner(net)      # (nets too large for the first kernel's LDS plan may
-    if v1_why is not None and not v2_candidate:                               #  still fit the second one's compact program)
+    v2_candidate = _is_janner(net)                    # (nets too large for the first kernel's LDS plan may still fit the second
+    if v1_why is not None and not v2_candidate:       #  one's compact program)
         return None
     if cond_vec is None and w_cfg not in (0.0, 1.0):
         return None                                   # the reference raises here; let the torch executor do it
@@ -467,9 +485,10 @@ def fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed, x_scale:
     except ValueError:
         return None
     load_library()
-    if (cond_vec is None or w_cfg == 0.0) and _is_janner(net):
-        from . import runtime2                        # unconditional temporal U-Net, non-EDM plan: second-generation kernel
-        out = runtime2.fused_sample2(solver, net, plan, xt, prior, feed, fix_mask, x_min, x_max, x_scale=x_scale)
+    if _is_janner(net):
+        from . import runtime2                        # JannerUNet1d: the second-generation kernel (conditional / CFG / EDM included)
+        out = runtime2.fused_sample2(solver, net, plan, xt, prior, feed, fix_mask, x_min, x_max, x_scale=x_scale,
+                                     cond=cond_vec if w_cfg != 0.0 else None, w_cfg=w_cfg)
         if out is not None:
             return out
     if x_scale is not None or v1_why is not None:

@@ -44,7 +44,9 @@ class CdxUnet2Launch(ctypes.Structure):
                 ("x_out", ctypes.c_void_p), ("init_blend", ctypes.c_int32), ("x_scale", ctypes.c_float),
                 ("cg_scale", ctypes.c_void_p), ("grad_off", ctypes.c_int32), ("grad_stride", ctypes.c_int32),
                 ("with_backward", ctypes.c_int32), ("ws", ctypes.c_void_p), ("ws_floats", ctypes.c_int32),
-                ("compact", ctypes.c_int32), ("prof", ctypes.c_void_p)]
+                ("compact", ctypes.c_int32), ("prof", ctypes.c_void_p),
+                ("emb_per_traj", ctypes.c_int32), ("n_pass", ctypes.c_int32), ("emb_u", ctypes.c_void_p), ("cfg_w", ctypes.c_float),
+                ("edm_plan", ctypes.c_int32)]
 
 
 _declared = False
@@ -267,7 +269,8 @@ def shape_for(module, horizon: int, batch: int):
 
 def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps=0, predict_noise=0, prior=None,
            fix_mask=None, noise=None, x_min=None, x_max=None, t_per_wg: Optional[int] = None, x_scale: Optional[float] = None,
-           cg_scale=None, with_backward: bool = False, parts=None):
+           cg_scale=None, with_backward: bool = False, parts=None, emb_per_traj: bool = False, emb_u=None, cfg_w: float = 1.0,
+           edm: bool = False):
     if batch <= 0:
         return
     prog = comp.prog
@@ -285,12 +288,15 @@ def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps
             and prog.lds_bytes(1) <= 160 * 1024:
         bulk = batch - batch % rounds
         parts = [(0, bulk, 2), (bulk, batch - bulk, 1)]
-    ws = None
-    if prog.ws_floats:                     # saved tensors of a two-trajectory guided program: scratch per (device, stream)
+    ws, ws_floats = None, prog.ws_floats
+    if emb_u is not None or edm:           # CFG pair / EDM kinds: [multistep memory or slope | x_old | conditional prediction] per trajectory
+        assert cg_scale is None and not with_backward
+        ws_floats = max(ws_floats, 3 * ((prog.horizon * prog.dim + 3) // 4 * 4))
+    if ws_floats:                          # saved tensors of a two-trajectory guided program: scratch per (device, stream)
         key = (x_in.device, R._stream_ptr(x_in.device))
         ws = _ws.get(key)
-        if ws is None or ws.numel() < (batch + 1) * prog.ws_floats:            # + 1: spare block of the half-empty last workgroup
-            _ws[key] = ws = torch.empty((batch + 1) * prog.ws_floats, dtype=torch.float32, device=x_in.device)
+        if ws is None or ws.numel() < (batch + 1) * ws_floats:            # + 1: spare block of the half-empty last workgroup
+            _ws[key] = ws = torch.empty((batch + 1) * ws_floats, dtype=torch.float32, device=x_in.device)
     timing = R._timing
     if timing["on"]:
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -307,7 +313,8 @@ def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps
             x_max=R._ptr(x_max), x_out=x_out.data_ptr(), init_blend=0 if x_scale is None else 1,
             x_scale=1.0 if x_scale is None else float(x_scale), cg_scale=R._ptr(cg_scale), grad_off=prog.grad_off,
             grad_stride=prog.grad_stride, with_backward=int(with_backward or cg_scale is not None), ws=R._ptr(ws),
-            ws_floats=prog.ws_floats, compact=int(prog.compact), prof=R._ptr(prof))
+            ws_floats=ws_floats, compact=int(prog.compact), prof=R._ptr(prof), emb_per_traj=int(emb_per_traj),
+            n_pass=2 if emb_u is not None else 1, emb_u=R._ptr(emb_u), cfg_w=float(cfg_w), edm_plan=int(edm))
         R._check(_lib().cdx_unet2_run(ctypes.byref(L), R._stream_ptr(x_in.device)), "cdx_unet2_run")
     if timing["on"]:
         end.record(torch.cuda.current_stream(x_in.device))
@@ -318,37 +325,93 @@ N_CUS = 256          # MI355X
 _ws = {}
 
 
-def fused_sample2(solver, net, plan, xt, prior, feed, fix_mask, x_min, x_max, x_scale: Optional[float] = None) -> Optional[torch.Tensor]:
-    """Unconditional JannerUNet1d, step kinds 0-4: the whole loop in one cdx_unet2_run launch.  None -> caller uses v1.
-    `x_scale` given: `xt` is the raw N(0, I) draw and the kernel forms x_T = xt * x_scale blended with the prior itself."""
+_emb_bufs = {}
+
+
+def cond_film_table(comp: _Compiled2, module, t_vec: torch.Tensor, cond: Optional[torch.Tensor], per_sample: bool = False) -> torch.Tensor:
+    """FiLM rows of a CONDITIONAL JannerUNet1d request, one per (timestep, trajectory): the condition embedding enters the time
+    embedding before map_emb (reference jannerunet.py:160-164: emb = map_noise(t) + condition), so every block's FiLM vector is
+    per-sample.  Row s * B + b; `t_vec` (S,) with a shared condition batch (B, emb_dim), or -- `per_sample`, stand-alone forwards --
+    t_vec (B,) = one timestep per sample (S = 1).  One cdx_unet2_embtab launch over S * B rows; two zero spare rows close the table (a half-empty last
+    workgroup reads past its batch)."""
+    prog = comp.prog
+    dev = prog.blob.device
+    e = prog.embtabs[0]
+    with torch.no_grad():
+        temb = R._f32c(module.map_noise(t_vec), dev)
+        if per_sample:
+            rows = temb if cond is None else temb + cond
+        else:
+            rows = (temb[:, None, :] + cond[None, :, :]).reshape(-1, temb.shape[1])
+        rows = rows.contiguous()
+    n = rows.shape[0]
+    key = (dev, R._stream_ptr(dev))
+    buf = _emb_bufs.get(key)
+    if buf is None or buf.numel() < (n + 2) * prog.n_emb:
+        _emb_bufs[key] = buf = torch.zeros((n + 2) * prog.n_emb, device=dev, dtype=torch.float32)
+    out = buf[: (n + 2) * prog.n_emb].view(n + 2, prog.n_emb)
+    args = CdxUnet2EmbtabArgs(wblob=prog.blob.data_ptr(), emb_dim=e["emb_dim"], hidden=e["hidden"], md=e["md"], n_emb=e["n_emb"],
+                              w0=e["w0"], b0=e["b0"], w2=e["w2"], b2=e["b2"], w3=e["w3"], b3=e["b3"],
+                              temb=rows.data_ptr(), n_rows=n, out=out.data_ptr(), out_ld=prog.n_emb, col0=e["col0"],
+                              w4=e["w4"], b4=e["b4"], n_raw=e["n_raw"], col4=e["col4"])
+    R._check(_lib().cdx_unet2_embtab(ctypes.byref(args), R._stream_ptr(dev)), "cdx_unet2_embtab")
+    return out
+
+
+def fused_sample2(solver, net, plan, xt, prior, feed, fix_mask, x_min, x_max, x_scale: Optional[float] = None,
+                  cond=None, w_cfg: float = 0.0) -> Optional[torch.Tensor]:
+    """JannerUNet1d, every step kind: the whole loop in one cdx_unet2_run launch.  None -> the caller falls back.
+    `x_scale` given: `xt` is the raw N(0, I) draw and the kernel forms x_T = xt * x_scale blended with the prior itself.
+    `cond` (B, emb_dim) with w_cfg = 1: conditional forwards (per-trajectory FiLM rows); w_cfg not in {0, 1}: the classifier-free
+    guidance pair inside the launch (reference diffusionsde.py:175-206).  EDM / consistency plans (kinds 5-7) included."""
     b, h, d = xt.shape
-    if b < min_batch() or R.plan_is_edm(plan) or supported(net, h) is not None:
+    if b < min_batch() or supported(net, h) is not None:
+        return None
+    edm = R.plan_is_edm(plan)
+    use_cond = cond is not None and w_cfg != 0.0
+    if (use_cond or edm) and x_scale is not None:
         return None
     dev = xt.device
     comp, parts = plan_for(net, h, b)
+    if use_cond and (cond.dim() != 2 or cond.shape != (b, comp.prog.emb_dim)):
+        return None
     with torch.no_grad():
-        emb = plan_film_table(comp, net, plan, dev)
         steps_dev = R.steps_to_device(plan, dev)
+        emb_u = None
+        if use_cond:
+            emb = cond_film_table(comp, net, R.device_times(plan, dev), R._f32c(cond, dev))
+            if w_cfg != 1.0:
+                emb_u = plan_film_table(comp, net, plan, dev)                 # zero condition: the per-step table
+        else:
+            emb = plan_film_table(comp, net, plan, dev)
         noise = torch.stack([feed.like(xt) for _ in range(plan.n_noise)]).contiguous() if plan.n_noise else None
         xin = R._f32c(xt, dev)
         out = torch.empty_like(xin)
         launch(comp, batch=b, x_in=xin, x_out=out, emb=emb, steps_dev=steps_dev, n_steps=len(plan.steps),
                predict_noise=R._predicts_noise(plan, solver), prior=R._f32c(prior, dev) if fix_mask is not None else None,
-               fix_mask=fix_mask, noise=noise, x_min=x_min, x_max=x_max, parts=parts, x_scale=x_scale)
+               fix_mask=fix_mask, noise=noise, x_min=x_min, x_max=x_max, parts=parts, x_scale=x_scale,
+               emb_per_traj=use_cond, emb_u=emb_u, cfg_w=w_cfg, edm=edm)
     return out
 
 
-def backbone_forward2(module, x, noise_t) -> Optional[torch.Tensor]:
-    """One unconditional forward with ONE timestep shared by the whole batch (the sampling loops' per-step call)."""
+def backbone_forward2(module, x, noise_t, condition=None) -> Optional[torch.Tensor]:
+    """``JannerUNet1d.forward`` (per-sample timesteps, optional condition embedding) in one launch: one FiLM row per sample."""
     b, h, d = x.shape
     if supported(module, h) is not None:
         return None
-    comp, t = shape_for(module, h, b)
+    comp, t_wg = shape_for(module, h, b)
+    if comp.prog.compact:
+        return None                                   # (compact-only nets: stand-alone forwards stay with the implicit-GEMM executor)
+    if condition is not None and (condition.dim() != 2 or tuple(condition.shape) != (b, comp.prog.emb_dim)):
+        return None
     with torch.no_grad():
-        emb = film_table(comp, module, noise_t.reshape(-1)[:1])
+        t = noise_t.reshape(-1)
+        if t.shape[0] == 1:
+            t = t.expand(b)
+        emb = cond_film_table(comp, module, t.contiguous(), None if condition is None else R._f32c(condition, x.device), per_sample=True)
         xin = R._f32c(x, x.device)
         out = torch.empty_like(xin)
-        launch(comp, batch=b, x_in=xin, x_out=out, emb=emb, t_per_wg=t)
+        launch(comp, batch=b, x_in=xin, x_out=out, emb=emb, t_per_wg=t_wg, emb_per_traj=True)
     return out
 
 

@@ -156,7 +156,7 @@ typedef struct cdx_unet2_launch {
     int32_t traj_first, traj_count;
     const float* emb;          /* device (max(n_steps,1), emb_ld): FiLM table rows, one per step record */
     int32_t emb_ld;
-    const cdx_step* steps;     /* device [n_steps], kinds 0-4; NULL with n_steps == 0 (one forward: x_out <- network(x_in)) */
+    const cdx_step* steps;     /* device [n_steps], kinds 0-7; NULL with n_steps == 0 (one forward: x_out <- network(x_in)) */
     int32_t n_steps, predict_noise;
     const float* x_in;         /* (batch, horizon, dim) */
     const float* prior;        /* or NULL */
@@ -190,6 +190,20 @@ typedef struct cdx_unet2_launch {
      * staging barrier, op end, item record + segment read, first operands landed, MFMAs done, partial tile staged} of the first
      * forward, plus kernel start/end.  NULL = off. */
     unsigned long long* prof;
+    /* ---- conditional requests (round 3: what used to need the first program kernel) ----
+     * emb_per_traj != 0: `emb` holds one FiLM row per (step, trajectory), row = step * batch + b -- the condition embedding enters
+     * JannerUNet1d's time embedding (emb = map_noise(t) + condition, reference jannerunet.py:160-164), so its FiLM vectors are
+     * per-sample; with n_steps == 0 this is also how a stand-alone forward gets per-sample timesteps.  The table carries two spare
+     * rows at its end (a half-empty last workgroup reads the rows of trajectories past the batch).
+     * n_pass == 2: classifier-free-guidance pair (reference diffusionsde.py:175-206): per step one forward with `emb` (conditional)
+     * and one with `emb_u` (row = step: the zero-condition embedding), pred = cfg_w * p_cond + (1 - cfg_w) * p_uncond.
+     * Step kinds 5/6/7 (EDM Euler / Heun, consistency; a plan is all-EDM or not at all): the network sees c_in * x (c_in = the step's
+     * `alpha`), the authoritative state lives in x_out like a compact program's.
+     * Any of the three needs ws with ws_floats >= 3 * round4(horizon * dim): [multistep memory or EDM slope | x_old | p_cond]. */
+    int32_t emb_per_traj, n_pass;
+    const float* emb_u;
+    float cfg_w;
+    int32_t edm_plan;          /* != 0: the step records are kinds 5-7 */
 } cdx_unet2_launch;
 int cdx_unet2_run(const cdx_unet2_launch* launch, void* hip_stream);
 

@@ -1182,3 +1182,74 @@ def test_dit1ref_runs_on_the_dit_executor(amd_lib, monkeypatch):
     assert [c[0] for c in calls] == ["dit"] * 3, calls
     for k in gold.files:
         np.testing.assert_allclose(out[k].cpu().numpy(), gold[k], err_msg=k, **TOL)
+
+
+# ---- round 3: conditional / CFG / EDM JannerUNet1d requests on the second-generation kernel (VERDICT r2 "Next" #3) ----
+V2_COND_CASES = ["janner_tiny_cond_w1", "janner_tiny_cond_w2", "janner_legacy_dpm_ddim_cfg", "janner_rflow_cont_cfg",
+                 "janner_legacy_edm_euler", "janner_legacy_edm_heun", "janner_legacy_edm_x", "janner_cm"]
+
+
+@pytest.mark.parametrize("name", V2_COND_CASES)
+def test_conditional_and_edm_janner_requests_run_on_the_v2_kernel(name, amd_lib, monkeypatch):
+    """Condition embedding with w_cfg = 1, the classifier-free-guidance pair, EDM Euler / Heun / Diffusion-X and consistency plans of a
+    JannerUNet1d used to be served by the first program kernel (cdx_unet1d_run); now they are ONE cdx_unet2_run launch: per-trajectory
+    FiLM rows, both forwards of the pair and step kinds 5-7 inside the kernel.  Reference fixtures, 1e-4."""
+    gold = np.load(golden_path(name))
+    agent, _ = cases.build(amd_lib, name, device=DEV)
+    inp = cases.make_inputs(name)
+    kw = cases.sample_kwargs(name, inp, device=DEV)
+    calls = _spy_launches(monkeypatch)
+    x, _ = cases.sampler_of(agent, name)(torch.from_numpy(inp["prior"]).to(DEV), noise=list(inp["noise"][:int(gold["n_draws"])]), **kw)
+    torch.cuda.synchronize()
+    assert (calls["n"], calls["v2"]) == (1, 1), calls
+    np.testing.assert_allclose(x.cpu().numpy(), gold["x_out"], **TOL)
+
+
+@pytest.mark.parametrize("solver_kw", [dict(solver="ode_dpmsolver++_2M", w_cfg=1.7), dict(solver="ddpm", w_cfg=1.0)])
+def test_conditional_config2_net_is_independent_of_trajectories_per_workgroup(solver_kw, amd_lib, monkeypatch):
+    """The config-2 network with a condition embedding at B = 600 (three trajectories per workgroup on the compact program: the state
+    and the conditional prediction of the CFG pair live in global memory, the state slot is rebuilt between the two forwards) against
+    the same request one trajectory per workgroup: bit-identical, and equal to the PyTorch executor on a slice."""
+    from cleandiffuser_amd.utils import load_synth
+    net = load_synth(amd_lib.JannerUNet1d(23, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2, 2], kernel_size=5), 5)
+    fm = torch.zeros(32, 23)
+    fm[0, :17] = 1.0
+    lim = 3.0 * torch.ones(1, 32, 23)
+    agent = amd_lib.DiscreteDiffusionSDE(net, amd_lib.IdentityCondition(dropout=0.0), fix_mask=fm, diffusion_steps=20, predict_noise=True,
+                                         x_max=lim, x_min=-lim, device=DEV)
+    agent.eval()
+    g = torch.Generator().manual_seed(9)
+    B = 600
+    prior = torch.zeros(B, 32, 23)
+    prior[:, 0, :17] = torch.randn(B, 17, generator=g)
+    cond = torch.randn(B, 32, generator=g).to(DEV)
+    zs = [torch.randn(B, 32, 23, generator=g).to(DEV) for _ in range(7)]
+    kw = dict(n_samples=B, sample_steps=6, temperature=0.8, condition_cfg=cond, **solver_kw)
+    calls = _spy_launches(monkeypatch)
+    x3, _ = agent.sample(prior.to(DEV), noise=zs, **kw)
+    assert calls["v2"] >= 1
+    monkeypatch.setenv("CDX_UNET2_T", "1")
+    x1, _ = agent.sample(prior.to(DEV), noise=zs, **kw)
+    monkeypatch.delenv("CDX_UNET2_T")
+    assert torch.equal(x1, x3)
+    from cleandiffuser_amd.engine import dispatch
+    monkeypatch.setattr(dispatch, "try_fused_sample", lambda *a, **k: None)
+    monkeypatch.setattr(dispatch, "try_backbone_forward", lambda *a, **k: None)
+    xs, _ = agent.sample(prior[:5].to(DEV), noise=[z[:5] for z in zs], **dict(kw, n_samples=5, condition_cfg=cond[:5]))
+    np.testing.assert_allclose(x3[:5].cpu().numpy(), xs.cpu().numpy(), **TOL)
+
+
+def test_janner_forward_with_condition_and_per_sample_timesteps_is_one_v2_launch(amd_lib, monkeypatch):
+    from cleandiffuser_amd.utils import load_synth
+    net = load_synth(amd_lib.JannerUNet1d(23, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2, 2], kernel_size=5), 5).to(DEV).eval()
+    g = torch.Generator().manual_seed(1)
+    for B in (7, 300):
+        x, c = torch.randn(B, 32, 23, generator=g).to(DEV), torch.randn(B, 32, generator=g).to(DEV)
+        t = (torch.arange(B) * 7 % 20).to(DEV)
+        calls = _spy_launches(monkeypatch)
+        with torch.no_grad():
+            got, got_u = net(x, t, c), net(x, t, None)
+            want, want_u = net._forward_torch(x, t, c), net._forward_torch(x, t, None)
+        assert (calls["n"], calls["v2"]) == (2, 2)
+        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), **TOL)
+        np.testing.assert_allclose(got_u.cpu().numpy(), want_u.cpu().numpy(), **TOL)

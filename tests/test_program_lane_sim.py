@@ -76,12 +76,13 @@ def test_lane_sim_reproduces_classifier_logp(amd_lib):
         np.testing.assert_allclose(sim.run_forward(temb), gold["log_p"][b], rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("tile", [4, 8, 16])
 @pytest.mark.parametrize("kind", ["pearce", "pearce192", "dql", "sfbc", "mlpnn"])
-def test_lane_sim_reproduces_mlp_tile_programs(kind, amd_lib):
+def test_lane_sim_reproduces_mlp_tile_programs(kind, tile, amd_lib):
     """Batch-tiled MLP programs (sample index on the MFMA column axis, per-sample GroupNorm, GELU/Mish/LeakyReLU,
     pre-scaled skips, context slot) against the module forward, which is bit-identical to the reference's."""
     from cleandiffuser_amd.utils import load_synth
-    S = P.MLP_TILE
+    S = tile            # samples per workgroup: 16 = one 16x16x4 column tile; 4 / 8 = 4x4x1 column blocks (runtime.mlp_tile)
     g = torch.Generator().manual_seed(0)
     x = torch.randn(S, 6, generator=g)
     t = torch.full((S,), 13, dtype=torch.long)
