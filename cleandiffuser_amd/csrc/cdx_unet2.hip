@@ -149,6 +149,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef CDX2_WPOLICY
 #define CDX2_WPOLICY 0
 #endif
+#ifndef CDX2_PIPE_PARAMS
+#define CDX2_PIPE_PARAMS 1          // 0: fetch an op's epilogue parameters and the next descriptor at the op's start (round-2 order)
+#endif
+static __device__ __forceinline__ int wave_of(int tid) { return __builtin_amdgcn_readfirstlane(tid >> 6); }
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wold-style-cast"
 struct WStream {
@@ -624,6 +628,42 @@ __device__ __forceinline__ void prefetch_ring(const Item& it, const float* __res
     for (int u = 0; u < PF; ++u) ring.rec[u] = ws.load(it.woff, u);
 }
 
+// The five per-channel epilogue parameters of the op whose descriptor view is `vd` (bias, post-norm bias, gamma, beta, FiLM vector).
+// All five loads are issued by every wave (an unused one re-reads the bias: same line, an L2 hit): with loads on only some paths
+// hipcc cannot count the vector-memory queue any more and falls back to `s_waitcnt vmcnt(0)`.
+template <bool COND, bool SPLIT_T>
+__device__ __forceinline__ EpiParams load_params(const cdx_unet2_launch& L, int vd, const float* __restrict__ emb_row, int emb_tstride,
+                                                 int tid, int wave) {
+    const int etid = tid & 255, grp = etid >> 5, li = etid & 31;
+    const int flags = CDX2_DW(vd, CDX2_W2_FLAGS), coutp = CDX2_DW(vd, CDX2_W2_COUTP), shift = CDX2_DW(vd, CDX2_W2_CG4_SHIFT);
+    const int c = grp * (coutp >> 3) + 4 * (li & ((1 << shift) - 1));
+    const float* __restrict__ pbi = L.wblob + CDX2_DW(vd, CDX2_W2_BOFF) + c;
+    const bool gn = (flags & (CDX2_F2_GN | CDX2_F2_GNBWD)) != 0;
+    const float* __restrict__ ppb = CDX2_DW(vd, CDX2_W2_KPOST) ? L.wblob + CDX2_DW(vd, CDX2_W2_PBIAS) + c : pbi;
+    const float* __restrict__ pga = gn ? L.wblob + CDX2_DW(vd, CDX2_W2_GAMMA) + c : pbi;
+    const float* __restrict__ pbe = gn ? L.wblob + CDX2_DW(vd, CDX2_W2_BETA) + c : pbi;
+    const float* __restrict__ pem = (flags & CDX2_F2_EMB)
+        ? emb_row + (COND && SPLIT_T ? (wave >> 2) * emb_tstride : 0) + CDX2_DW(vd, CDX2_W2_EMB) + c : pbi;
+    EpiParams P;
+    P.bi = *reinterpret_cast<const f32x4*>(pbi);
+    P.pb = *reinterpret_cast<const f32x4*>(ppb);
+    P.ga = *reinterpret_cast<const f32x4*>(pga);
+    P.be = *reinterpret_cast<const f32x4*>(pbe);
+    P.em = *reinterpret_cast<const f32x4*>(pem);
+    return P;
+}
+
+// What an op needs from global memory besides its weight stream, and when it is fetched (PIPE, one and two trajectories per
+// workgroup): right after op n's K loop, together with the head of op n+1's weight stream, go out op n+1's epilogue parameters and op
+// n+2's descriptor.  They land during op n's barrier + epilogue, so an op starts with NOTHING recent in the vector-memory queue.
+// Round 2 fetched the parameters and the next descriptor at the op's start: the K loop's first use of the weight ring then waited
+// for them too (the compiler cannot order the waits apart across the item loop's header) -- ~700-900 cycles per op, the "decode"
+// column of profiles/r02_op_profile_wg0.txt.  Three trajectories per workgroup keep the old order (no registers to spare).
+struct OpFetch {
+    EpiParams P;           // parameters of the op about to run
+    int vdn2;              // descriptor view of the op after the next one
+};
+
 // One op.  `vd`: this wave's view of the op's descriptor, `it`: this wave's first item, both fetched during the previous op;
 // `vdn`: the next op's descriptor, whose load was issued before this call.  Leaves the next op's first item in `it`.
 // Epilogue threads: 256 per trajectory (8 GroupNorm groups x 32 lanes).  4 waves: all of them, one trajectory after the other;
@@ -632,20 +672,29 @@ __device__ __forceinline__ void prefetch_ring(const Item& it, const float* __res
 template <int T, int NWV, bool BWD, bool PROF, bool COND>
 __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* ops, int vd, int vdn, Item& it,
                                        const float* __restrict__ emb_row, int emb_tstride, float* __restrict__ lds, int tid,
-                                       Ring<WG<NWV>::PF>& ring, unsigned long long* prof, int b0) {
+                                       Ring<WG<NWV>::PF>& ring, unsigned long long* prof, int b0, OpFetch& F,
+                                       const float* __restrict__ emb_next, int emb_next_tstride, int op_next2) {
     constexpr bool SPLIT_T = NWV == 8 && T >= 2;       // waves 0-3 take trajectories 0, 2; waves 4-7 trajectory 1
+    constexpr bool PIPE = CDX2_PIPE_PARAMS && T < 3;
+    // everything the NEXT op needs, issued in one go (see OpFetch)
+    auto fetch_next = [&]() {
+        it = inline_item(vdn);
+        if (wave_of(tid) < CDX2_DW(vdn, CDX2_W2_NITEMS)) prefetch_ring(it, L.wblob, tid & 63, ring);
+        if (PIPE) {
+            F.P = load_params<COND, SPLIT_T>(L, vdn, emb_next, emb_next_tstride, tid, wave_of(tid));
+            F.vdn2 = load_desc<NWV>(L.ops, op_next2, tid & 63, wave_of(tid));
+        }
+    };
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tf = L.traj_floats;
     if (BWD && CDX2_DW(vd, CDX2_W2_KIND) == CDX2_KIND2_HEAD) {       // classifier head: no K loop, its own two barriers
-        it = inline_item(vdn);
-        if (wave < CDX2_DW(vdn, CDX2_W2_NITEMS)) prefetch_ring(it, L.wblob, lane, ring);
+        fetch_next();
 #pragma unroll 1
         for (int t = 0; t < T; ++t) run_head<WG<NWV>::THREADS>(L, vd, emb_row, lds + t * tf, tid);
         return;
     }
     if (BWD && CDX2_DW(vd, CDX2_W2_KIND) == CDX2_KIND2_LOADX) {      // the classifier's copy of x_t, from global memory
-        it = inline_item(vdn);
-        if (wave < CDX2_DW(vdn, CDX2_W2_NITEMS)) prefetch_ring(it, L.wblob, lane, ring);
+        fetch_next();
         const int dst = CDX2_DW(vd, CDX2_W2_DST), dstr = CDX2_DW(vd, CDX2_W2_DST_STRIDE);
         const int len = CDX2_DW(vd, CDX2_W2_LOUT), ch = CDX2_DW(vd, CDX2_W2_COUT);
         const int b_end = L.traj_first + L.traj_count;
@@ -675,18 +724,8 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
     const int c = grp * (coutp >> 3) + 4 * (li & ((1 << shift) - 1));
     const int pos0 = li >> shift, pstep = 32 >> shift;
     const int nv = (coutp >> 5) * l_out;
-    EpiParams P;
-    P.bi = P.ga = P.be = P.em = P.pb = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (epi_wave) {
-        P.bi = *reinterpret_cast<const f32x4*>(L.wblob + CDX2_DW(vd, CDX2_W2_BOFF) + c);
-        if (CDX2_DW(vd, CDX2_W2_KPOST)) P.pb = *reinterpret_cast<const f32x4*>(L.wblob + CDX2_DW(vd, CDX2_W2_PBIAS) + c);
-        if (flags & (CDX2_F2_GN | CDX2_F2_GNBWD)) {
-            P.ga = *reinterpret_cast<const f32x4*>(L.wblob + CDX2_DW(vd, CDX2_W2_GAMMA) + c);
-            P.be = *reinterpret_cast<const f32x4*>(L.wblob + CDX2_DW(vd, CDX2_W2_BETA) + c);
-        }
-        // (per-trajectory FiLM rows -- conditional nets: this thread's FIRST trajectory here, later ones inside the loop below)
-        if (flags & CDX2_F2_EMB) P.em = *reinterpret_cast<const f32x4*>(emb_row + (COND && SPLIT_T ? (wave >> 2) * emb_tstride : 0) + CDX2_DW(vd, CDX2_W2_EMB) + c);
-    }
+    // this op's epilogue parameters: fetched during the PREVIOUS op (PIPE), or here (consumed after the barrier either way)
+    EpiParams P = PIPE ? F.P : load_params<COND, SPLIT_T>(L, vd, emb_row, emb_tstride, tid, wave);
 
     // K loop -> staged partial tiles
     const int n_items = CDX2_DW(vd, CDX2_W2_NITEMS);
@@ -700,8 +739,7 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
     // head of the next op's weight stream: flies through the barrier and the epilogue
     // (issued AFTER the partial tiles are staged: sending the eight loads first, while the MFMAs drain, blocks the wave on the
     //  memory pipe for ~350 cycles before it can write its tile -- measured 9 % slower)
-    it = inline_item(vdn);
-    if (wave < CDX2_DW(vdn, CDX2_W2_NITEMS)) prefetch_ring(it, L.wblob, lane, ring);
+    fetch_next();
     if (PROF) stamp(prof ? prof + 1 : nullptr, tid);
     __syncthreads();
     if (PROF) stamp(prof ? prof + 2 : nullptr, tid);
@@ -804,36 +842,64 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
 
     const int n_iter = L.n_steps > 0 ? L.n_steps : 1;
     const int HDp = (HD + 3) & ~3;                     // ws block of a trajectory: [multistep memory / EDM slope | x_old | p_cond]
-    for (int step = 0; step < n_iter; ++step) {
-      int n_pass = 1;
-      if (COND) {
-          const KArg* S0 = kernarg();
-          asm volatile("" : "+s"(S0));
-          n_pass = S0->n_pass == 2 ? 2 : 1;
-      }
-#pragma unroll 1
-      for (int pass = 0; pass < n_pass; ++pass) {
-        // FiLM rows of this forward: one per step, or one per (step, trajectory) for conditional nets; the second pass of a
-        // classifier-free-guidance pair takes the zero-condition table
-        const float* __restrict__ emb_row = L.emb + (size_t)step * L.emb_ld;
-        int emb_tstride = 0;
+    constexpr bool PIPE = CDX2_PIPE_PARAMS && T < 3;   // (see OpFetch)
+    constexpr bool SPLIT_T0 = NWV == 8 && T >= 2;
+    int n_pass_all = 1;
+    if (COND) {
+        const KArg* S0 = kernarg();
+        asm volatile("" : "+s"(S0));
+        n_pass_all = S0->n_pass == 2 ? 2 : 1;
+    }
+    // FiLM rows of forward (step, pass): one row per step, or one per (step, trajectory) for conditional nets; the second pass of a
+    // classifier-free-guidance pair takes the zero-condition table
+    auto emb_of = [&](int step, int pass, int& tstride) -> const float* {
+        const float* row = L.emb + (size_t)step * L.emb_ld;
+        tstride = 0;
         if (COND) {
             const KArg* S0 = kernarg();
             asm volatile("" : "+s"(S0));
-            if (pass == 1) emb_row = S0->emb_u + (size_t)step * L.emb_ld;
+            if (pass == 1) row = S0->emb_u + (size_t)step * L.emb_ld;
             else if (S0->emb_per_traj) {      // (the table ends with two spare rows: a half-empty last workgroup reads past its batch)
-                emb_row = L.emb + ((size_t)step * L.batch + b0) * L.emb_ld;
-                emb_tstride = L.emb_ld;
+                row = L.emb + ((size_t)step * L.batch + b0) * L.emb_ld;
+                tstride = L.emb_ld;
             }
         }
+        return row;
+    };
+    OpFetch F;
+    int vdn_keep = 0;
+    if (PIPE) {
+        int ts0;
+        const float* row0 = emb_of(0, 0, ts0);
+        F.P = load_params<COND, SPLIT_T0>(L, vd, row0, ts0, tid, wave);
+        vdn_keep = load_desc<NWV>(L.ops, L.n_ops > 1 ? 1 : 0, lane, wave);
+    }
+    for (int step = 0; step < n_iter; ++step) {
+      const int n_pass = n_pass_all;
+#pragma unroll 1
+      for (int pass = 0; pass < n_pass; ++pass) {
+        int emb_tstride, emb_next_tstride;
+        const float* __restrict__ emb_row = emb_of(step, pass, emb_tstride);
+        // the forward after this one (its first op's parameters are fetched during this forward's last op)
+        const bool last_fwd = pass + 1 == n_pass && step + 1 >= n_iter;
+        const float* __restrict__ emb_fwd_next = last_fwd ? emb_of(step, pass, emb_next_tstride)
+                                                          : emb_of(pass + 1 < n_pass ? step : step + 1, pass + 1 < n_pass ? pass + 1 : 0, emb_next_tstride);
+        const int ts_fwd_next = emb_next_tstride;
         for (int oi = 0; oi < L.n_ops; ++oi) {
             // next op's descriptor (the last op fetches op 0 of the next step): one coalesced load, needed after the K loop
-            const int vdn = load_desc<NWV>(L.ops, oi + 1 < L.n_ops ? oi + 1 : 0, lane, wave);
+            // (PIPE: it was fetched during the previous op; this op fetches the one after it)
+            const int vdn = PIPE ? vdn_keep : load_desc<NWV>(L.ops, oi + 1 < L.n_ops ? oi + 1 : 0, lane, wave);
             // (profile the SECOND forward when there is one: instruction / scalar caches warm, like every later step)
             unsigned long long* pslot = (profiling && step == (L.n_steps > 1 ? 1 : 0)) ? lprof + (size_t)oi * 8 : nullptr;
             if (PROF) stamp(pslot, tid);
-            run_op<T, NWV, BWD, PROF, COND>(L, ops, vd, vdn, it, emb_row, emb_tstride, lds, tid, ring, pslot, b0);
+            const bool wrap = oi + 1 >= L.n_ops;
+            int on2 = oi + 2;
+            if (on2 >= L.n_ops) on2 -= L.n_ops;
+            if (on2 >= L.n_ops) on2 = 0;
+            run_op<T, NWV, BWD, PROF, COND>(L, ops, vd, vdn, it, emb_row, emb_tstride, lds, tid, ring, pslot, b0, F,
+                                            wrap ? emb_fwd_next : emb_row, wrap ? ts_fwd_next : emb_tstride, on2);
             vd = vdn;
+            if (PIPE) vdn_keep = F.vdn2;
         }
         if (COND && n_pass == 2 && pass == 0) {
             // conditional prediction -> the trajectory's ws block; a compact program's state slot was arena memory during the
