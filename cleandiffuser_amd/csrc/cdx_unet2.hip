@@ -149,6 +149,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef CDX2_WPOLICY
 #define CDX2_WPOLICY 0
 #endif
+#ifndef CDX2_PARAMS_ALL
+#define CDX2_PARAMS_ALL 0           // non-pipelined position only: 1 = every wave issues all five parameter loads (see load_params)
+#endif
 #ifndef CDX2_PIPE_PARAMS
 #define CDX2_PIPE_PARAMS 1          // 0: fetch an op's epilogue parameters and the next descriptor at the op's start (round-2 order)
 #endif
@@ -629,27 +632,38 @@ __device__ __forceinline__ void prefetch_ring(const Item& it, const float* __res
 }
 
 // The five per-channel epilogue parameters of the op whose descriptor view is `vd` (bias, post-norm bias, gamma, beta, FiLM vector).
-// All five loads are issued by every wave (an unused one re-reads the bias: same line, an L2 hit): with loads on only some paths
-// hipcc cannot count the vector-memory queue any more and falls back to `s_waitcnt vmcnt(0)`.
-template <bool COND, bool SPLIT_T>
+// ALL = false: only the waves that run epilogues load, and only what the op's flags ask for (a 64-lane float4 load is 1 KiB through the
+// CU's address path, ~16 cycles each: 8 waves x 5 unconditional loads cost ~450 cycles per op, measured).  That is the right form when
+// the loads sit after the K loop (PIPE).  ALL = true: every wave issues all five (an unused one re-reads the bias) -- for the round-2
+// position at the op's start, where loads on only some paths make hipcc fall back to `s_waitcnt vmcnt(0)` in the K loop.
+template <bool COND, bool SPLIT_T, bool ALL>
 __device__ __forceinline__ EpiParams load_params(const cdx_unet2_launch& L, int vd, const float* __restrict__ emb_row, int emb_tstride,
-                                                 int tid, int wave) {
+                                                 int tid, int wave, bool epi_wave) {
     const int etid = tid & 255, grp = etid >> 5, li = etid & 31;
     const int flags = CDX2_DW(vd, CDX2_W2_FLAGS), coutp = CDX2_DW(vd, CDX2_W2_COUTP), shift = CDX2_DW(vd, CDX2_W2_CG4_SHIFT);
     const int c = grp * (coutp >> 3) + 4 * (li & ((1 << shift) - 1));
     const float* __restrict__ pbi = L.wblob + CDX2_DW(vd, CDX2_W2_BOFF) + c;
     const bool gn = (flags & (CDX2_F2_GN | CDX2_F2_GNBWD)) != 0;
-    const float* __restrict__ ppb = CDX2_DW(vd, CDX2_W2_KPOST) ? L.wblob + CDX2_DW(vd, CDX2_W2_PBIAS) + c : pbi;
-    const float* __restrict__ pga = gn ? L.wblob + CDX2_DW(vd, CDX2_W2_GAMMA) + c : pbi;
-    const float* __restrict__ pbe = gn ? L.wblob + CDX2_DW(vd, CDX2_W2_BETA) + c : pbi;
-    const float* __restrict__ pem = (flags & CDX2_F2_EMB)
-        ? emb_row + (COND && SPLIT_T ? (wave >> 2) * emb_tstride : 0) + CDX2_DW(vd, CDX2_W2_EMB) + c : pbi;
+    const float* __restrict__ pem = emb_row + (COND && SPLIT_T ? (wave >> 2) * emb_tstride : 0) + CDX2_DW(vd, CDX2_W2_EMB) + c;
     EpiParams P;
-    P.bi = *reinterpret_cast<const f32x4*>(pbi);
-    P.pb = *reinterpret_cast<const f32x4*>(ppb);
-    P.ga = *reinterpret_cast<const f32x4*>(pga);
-    P.be = *reinterpret_cast<const f32x4*>(pbe);
-    P.em = *reinterpret_cast<const f32x4*>(pem);
+    if (ALL) {
+        P.bi = *reinterpret_cast<const f32x4*>(pbi);
+        P.pb = *reinterpret_cast<const f32x4*>(CDX2_DW(vd, CDX2_W2_KPOST) ? L.wblob + CDX2_DW(vd, CDX2_W2_PBIAS) + c : pbi);
+        P.ga = *reinterpret_cast<const f32x4*>(gn ? L.wblob + CDX2_DW(vd, CDX2_W2_GAMMA) + c : pbi);
+        P.be = *reinterpret_cast<const f32x4*>(gn ? L.wblob + CDX2_DW(vd, CDX2_W2_BETA) + c : pbi);
+        P.em = *reinterpret_cast<const f32x4*>((flags & CDX2_F2_EMB) ? pem : pbi);
+        return P;
+    }
+    P.bi = P.ga = P.be = P.em = P.pb = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (epi_wave) {
+        P.bi = *reinterpret_cast<const f32x4*>(pbi);
+        if (CDX2_DW(vd, CDX2_W2_KPOST)) P.pb = *reinterpret_cast<const f32x4*>(L.wblob + CDX2_DW(vd, CDX2_W2_PBIAS) + c);
+        if (gn) {
+            P.ga = *reinterpret_cast<const f32x4*>(L.wblob + CDX2_DW(vd, CDX2_W2_GAMMA) + c);
+            P.be = *reinterpret_cast<const f32x4*>(L.wblob + CDX2_DW(vd, CDX2_W2_BETA) + c);
+        }
+        if (flags & CDX2_F2_EMB) P.em = *reinterpret_cast<const f32x4*>(pem);
+    }
     return P;
 }
 
@@ -681,7 +695,7 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
         it = inline_item(vdn);
         if (wave_of(tid) < CDX2_DW(vdn, CDX2_W2_NITEMS)) prefetch_ring(it, L.wblob, tid & 63, ring);
         if (PIPE) {
-            F.P = load_params<COND, SPLIT_T>(L, vdn, emb_next, emb_next_tstride, tid, wave_of(tid));
+            F.P = load_params<COND, SPLIT_T, false>(L, vdn, emb_next, emb_next_tstride, tid, wave_of(tid), NWV == 4 || SPLIT_T || wave_of(tid) < 4);
             F.vdn2 = load_desc<NWV>(L.ops, op_next2, tid & 63, wave_of(tid));
         }
     };
@@ -725,7 +739,7 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
     const int pos0 = li >> shift, pstep = 32 >> shift;
     const int nv = (coutp >> 5) * l_out;
     // this op's epilogue parameters: fetched during the PREVIOUS op (PIPE), or here (consumed after the barrier either way)
-    EpiParams P = PIPE ? F.P : load_params<COND, SPLIT_T>(L, vd, emb_row, emb_tstride, tid, wave);
+    EpiParams P = PIPE ? F.P : load_params<COND, SPLIT_T, CDX2_PARAMS_ALL != 0>(L, vd, emb_row, emb_tstride, tid, wave, epi_wave);
 
     // K loop -> staged partial tiles
     const int n_items = CDX2_DW(vd, CDX2_W2_NITEMS);
@@ -871,7 +885,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
     if (PIPE) {
         int ts0;
         const float* row0 = emb_of(0, 0, ts0);
-        F.P = load_params<COND, SPLIT_T0>(L, vd, row0, ts0, tid, wave);
+        F.P = load_params<COND, SPLIT_T0, false>(L, vd, row0, ts0, tid, wave, NWV == 4 || SPLIT_T0 || wave < 4);
         vdn_keep = load_desc<NWV>(L.ops, L.n_ops > 1 ? 1 : 0, lane, wave);
     }
     for (int step = 0; step < n_iter; ++step) {

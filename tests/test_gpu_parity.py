@@ -1142,11 +1142,14 @@ def test_update_runs_without_aten_optimiser_launches(amd_lib):
         assert float((p.detach() - q.detach()).abs().max()) <= 2e-5 * max(1.0, float(q.detach().abs().max())), n
     # kernel census of one more update(): nothing of ATen's optimiser / foreach / clip machinery runs on the device
     with cpu_rng(DEV):
+        torch.manual_seed(12)
         a.loss(x0).backward()
         torch.cuda.synchronize()
         with profile(activities=[ProfilerActivity.CUDA]) as prof:
             a._apply_gradients(True)
             torch.cuda.synchronize()
+        torch.manual_seed(12)
+        b.update(x0)                                   # (the twin takes the same fourth step)
     kernels = [e.key for e in prof.key_averages() if not e.key.startswith("hip") and "Memcpy" not in e.key and "Memset" not in e.key]
     assert kernels and all("cdx_optim" in n for n in kernels), kernels      # (norm pass x 2 kernels + the fused AdamW / EMA pass)
     # and sampling right after sees the updated EMA weights (packed-weight caches key on the bumped version counters)
