@@ -3,7 +3,7 @@
 (default lr 2e-4, weight decay 1e-4), an EMA copy, and ``save/load`` of the ``{"model", "model_ema"}`` checkpoint.
 
 ``gradients`` on a ROCm device is served by explicit forward + backward kernels when the network is one the engine knows
-(engine/classifier_grad.py: HalfJannerUNet1d); everything else differentiates ``logp`` with autograd as the reference does.
+(engine/classifier_grad.py: HalfJannerUNet1d; engine/mlp_grad.py: MSEClassifier / QGPOClassifier over the MLP networks); everything else differentiates ``logp`` with autograd as the reference does.
 """
 from copy import deepcopy
 from typing import Optional
@@ -36,6 +36,9 @@ class BaseClassifier:
         if x.is_cuda:
             from ..engine import classifier_grad
             native = classifier_grad.gradients(self, x, noise, c)        # None: not a network with hand-written backward kernels
+            if native is None:
+                from ..engine import mlp_grad                            # the MLP / QGPO energy classifiers: explicit GEMM backward
+                native = mlp_grad.gradients(self, x, noise, c)
             if native is not None:
                 return native
         x.requires_grad_()

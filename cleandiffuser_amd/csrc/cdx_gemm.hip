@@ -989,6 +989,40 @@ __global__ void cdx_act_kernel(const float* __restrict__ x, float* __restrict__ 
         y[i] = gm_act(x[i], act);
 }
 
+// d act(x) / dx, the factor of an explicit backward pass through an MLP (classifier guidance without autograd for the MLP / QGPO
+// energy classifiers, reference classifier/base.py:74-79 over nn_classifier/mlp.py:10-55).  `param` is the scale s of a squashed
+// output s * tanh(x / s) (QGPO: 10 tanh(out / 10)); 1 for plain tanh.
+__device__ __forceinline__ float gm_act_grad(float x, int act, float param) {
+    switch (act) {
+        case CDX_ACT_NONE: return 1.0f;
+        case CDX_ACT_RELU: return x > 0.f ? 1.0f : 0.f;
+        case CDX_ACT_LEAKY: return x > 0.f ? 1.0f : 0.01f;
+        case CDX_ACT_SILU: {                             // s (1 + x (1 - s)), s = sigmoid(x)
+            const float sg = 1.0f / (1.0f + __expf(-x));
+            return sg * (1.0f + x * (1.0f - sg));
+        }
+        case CDX_ACT_MISH: return gm_act(x, CDX_ACT_MISH_GRAD);
+        case CDX_ACT_TANH: {
+            const float t = gm_act(x / param, CDX_ACT_TANH);
+            return 1.0f - t * t;
+        }
+        case CDX_ACT_GELU_ERF: {                         // Phi(x) + x phi(x)
+            const float z = fabsf(x) * 0.70710678118654752f;
+            const float t = 1.0f / fmaf(0.3275911f, z, 1.0f);
+            const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+            const float erf_abs = 1.0f - poly * __expf(-z * z);
+            return 0.5f * (1.0f + copysignf(erf_abs, x)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+        }
+        default: return 1.0f;
+    }
+}
+// out = g * act'(pre)
+__global__ void cdx_act_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ g, float* __restrict__ out, size_t n, int act,
+                                   float param) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = g[i] * gm_act_grad(pre[i], act, param);
+}
+
 static int gm_launch(const cdx_gemm_args* g, void* hip_stream, bool force_small);
 
 extern "C" {
@@ -1202,6 +1236,20 @@ int cdx_cross_attention_f32(const cdx_xattn_args* a, void* hip_stream) {
         const long long total = (long long)a->B * a->n_heads * a->T;
         hipLaunchKernelGGL(cdx_cross_attention_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, *a);
     }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
+    return CDX_OK;
+}
+
+int cdx_act_bwd_f32(const float* pre, const float* g, float* out, long long n, int act, float param, void* hip_stream) {
+    if (!pre || !g || !out || n < 0) { cdx_set_err("cdx_act_bwd_f32: bad argument"); return CDX_EINVAL; }
+    if (act == CDX_ACT_GELU_TANH || act == CDX_ACT_MISH_GRAD || act < 0 || act > CDX_ACT_TANH || !(param != 0.f)) {
+        cdx_set_err("cdx_act_bwd_f32: no derivative for this activation id / zero scale"); return CDX_EINVAL;
+    }
+    if (n == 0) return CDX_OK;
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(cdx_act_bwd_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), pre, g, out, (size_t)n,
+                       act, param);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
     return CDX_OK;

@@ -69,6 +69,9 @@ def _lib():
         lib.cdx_cross_attention_f32.argtypes = [ctypes.POINTER(CdxXattnArgs), ctypes.c_void_p]
         lib.cdx_cross_attention_f32.restype = ctypes.c_int
         lib.cdx_act_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p]
+        lib.cdx_act_bwd_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_float,
+                                        ctypes.c_void_p]
+        lib.cdx_act_bwd_f32.restype = ctypes.c_int
         for f in (lib.cdx_gemm_f32, lib.cdx_layernorm_f32, lib.cdx_attention_f32, lib.cdx_act_f32):
             f.restype = ctypes.c_int
         _declared = True
@@ -226,4 +229,14 @@ def activation(x: torch.Tensor, act: str, out: Optional[torch.Tensor] = None) ->
     if out is None:
         out = torch.empty_like(x)
     _check(_lib().cdx_act_f32(x.data_ptr(), out.data_ptr(), x.numel(), ACT[act], _stream_ptr(x.device)), "cdx_act_f32")
+    return out
+
+
+def activation_backward(pre: torch.Tensor, g: torch.Tensor, act: str, param: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """g * act'(pre) elementwise (one launch): the activation factor of an explicit MLP backward pass."""
+    assert pre.is_contiguous() and g.is_contiguous() and pre.shape == g.shape and pre.dtype == g.dtype == torch.float32
+    if out is None:
+        out = torch.empty_like(pre)
+    _check(_lib().cdx_act_bwd_f32(pre.data_ptr(), g.data_ptr(), out.data_ptr(), pre.numel(), ACT[act], float(param),
+                                  _stream_ptr(pre.device)), "cdx_act_bwd_f32")
     return out

@@ -302,6 +302,11 @@ int cdx_cross_attention_f32(const cdx_xattn_args* args, void* hip_stream);
 
 /* y = act(x) elementwise (batch-invariant embedding vectors: SiLU before adaLN, Mish in map_emb). */
 int cdx_act_f32(const float* x, float* y, long long n, int act, void* hip_stream);
+/* out = g * act'(pre) elementwise: one factor of an explicit backward pass through an MLP -- `d logp / d x` of the MLP / QGPO energy
+ * classifiers without autograd (reference classifier/base.py:74-79 over nn_classifier/mlp.py:10-55); the Linear layers' backward is
+ * cdx_gemm_f32 on the transposed weights.  act: none / mish / gelu(erf) / leaky / silu / relu / tanh; `param`: the scale s of a
+ * squashed output s * tanh(x / s) (QGPO: s = 10), 1 otherwise. */
+int cdx_act_bwd_f32(const float* pre, const float* g, float* out, long long n, int act, float param, void* hip_stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Big-batch sampling loops (csrc/cdx_bigbatch.hip): the whole `sample()` request for the GEMM-shaped denoisers.

@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported(lib):
                           "cdx_chitf_run", "cdx_chitf_workspace_floats", "cdx_cross_attention_f32", "cdx_chiunet_run",
                           "cdx_chiunet_workspace_floats", "cdx_groupnorm_f32", "cdx_groupnorm_bwd_f32", "cdx_hjgrad_run",
                           "cdx_hjgrad_workspace_floats", "cdx_guided_run", "cdx_guided_workspace_floats", "cdx_unet2_run",
-                          "cdx_unet2_embtab", "cdx_optim_f32", "cdx_pearcetf_run", "cdx_pearcetf_workspace_floats"}
+                          "cdx_unet2_embtab", "cdx_optim_f32", "cdx_pearcetf_run", "cdx_pearcetf_workspace_floats", "cdx_act_bwd_f32"}
     for n in names:
         assert hasattr(lib, n), f"{n} declared in cdx.h but not exported by libcdx.so"
     assert lib.cdx_abi_version() == int(re.search(r"#define CDX_ABI_VERSION (\d+)", hdr).group(1))
@@ -167,6 +167,10 @@ def test_newer_entries_validate_before_touching_the_device(lib):
     lib.cdx_act_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p]
     assert lib.cdx_act_f32(None, None, 4, 1, None) == bad
     assert lib.cdx_act_f32(8, 8, 0, 1, None) == 0                                                    # nothing to do is fine
+    blocks._lib()
+    assert lib.cdx_act_bwd_f32(8, 8, 8, 4, 6, 1.0, None) == bad and b"no derivative" in lib.cdx_last_error()   # tanh-GELU: not carried
+    assert lib.cdx_act_bwd_f32(8, 8, 8, 4, 8, 0.0, None) == bad and lib.cdx_act_bwd_f32(8, None, 8, 4, 4, 1.0, None) == bad
+    assert lib.cdx_act_bwd_f32(8, 8, 8, 0, 4, 1.0, None) == 0
     # workspace sizes: host arithmetic, grows with the chunk, independent of the batch beyond the chunk
     blk = (bigbatch.CdxDitBlock * 2)()
     w = bigbatch.CdxDitWeights(tokens=64, in_dim=29, emb_dim=128, d_model=320, n_heads=10, depth=2, blocks=blk)
