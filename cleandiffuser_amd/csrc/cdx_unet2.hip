@@ -672,7 +672,7 @@ __device__ __forceinline__ EpiParams load_params(const cdx_unet2_launch& L, int 
 // n+2's descriptor.  They land during op n's barrier + epilogue, so an op starts with NOTHING recent in the vector-memory queue.
 // Round 2 fetched the parameters and the next descriptor at the op's start: the K loop's first use of the weight ring then waited
 // for them too (the compiler cannot order the waits apart across the item loop's header) -- ~700-900 cycles per op, the "decode"
-// column of profiles/r02_op_profile_wg0.txt.  Three trajectories per workgroup keep the old order (no registers to spare).
+// column of profiles/r02_op_profile_wg0.txt.  Three trajectories per workgroup and programs with backward ops keep the old order (no registers to spare).
 struct OpFetch {
     EpiParams P;           // parameters of the op about to run
     int vdn2;              // descriptor view of the op after the next one
@@ -691,24 +691,28 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
     constexpr bool SPLIT_T = NWV == 8 && T >= 2;       // waves 0-3 take trajectories 0, 2; waves 4-7 trajectory 1
     constexpr bool PIPE = CDX2_PIPE_PARAMS && T < 3;
     // everything the NEXT op needs, issued in one go (see OpFetch)
-    auto fetch_next = [&]() {
+    // `params`: also the next op's epilogue parameters (ops without a K loop); a conv op issues those AFTER its staging barrier, where
+    // the epilogue waves wait on LDS anyway -- in front of the barrier their address arithmetic + issue (~450 cycles, measured) sat on
+    // the critical path just as it did at the op's start
+    auto fetch_next = [&](bool params) {
         it = inline_item(vdn);
         if (wave_of(tid) < CDX2_DW(vdn, CDX2_W2_NITEMS)) prefetch_ring(it, L.wblob, tid & 63, ring);
         if (PIPE) {
-            F.P = load_params<COND, SPLIT_T, false>(L, vdn, emb_next, emb_next_tstride, tid, wave_of(tid), NWV == 4 || SPLIT_T || wave_of(tid) < 4);
+            if (params)
+                F.P = load_params<COND, SPLIT_T, false>(L, vdn, emb_next, emb_next_tstride, tid, wave_of(tid), NWV == 4 || SPLIT_T || wave_of(tid) < 4);
             F.vdn2 = load_desc<NWV>(L.ops, op_next2, tid & 63, wave_of(tid));
         }
     };
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tf = L.traj_floats;
     if (BWD && CDX2_DW(vd, CDX2_W2_KIND) == CDX2_KIND2_HEAD) {       // classifier head: no K loop, its own two barriers
-        fetch_next();
+        fetch_next(true);
 #pragma unroll 1
         for (int t = 0; t < T; ++t) run_head<WG<NWV>::THREADS>(L, vd, emb_row, lds + t * tf, tid);
         return;
     }
     if (BWD && CDX2_DW(vd, CDX2_W2_KIND) == CDX2_KIND2_LOADX) {      // the classifier's copy of x_t, from global memory
-        fetch_next();
+        fetch_next(true);
         const int dst = CDX2_DW(vd, CDX2_W2_DST), dstr = CDX2_DW(vd, CDX2_W2_DST_STRIDE);
         const int len = CDX2_DW(vd, CDX2_W2_LOUT), ch = CDX2_DW(vd, CDX2_W2_COUT);
         const int b_end = L.traj_first + L.traj_count;
@@ -753,10 +757,11 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
     // head of the next op's weight stream: flies through the barrier and the epilogue
     // (issued AFTER the partial tiles are staged: sending the eight loads first, while the MFMAs drain, blocks the wave on the
     //  memory pipe for ~350 cycles before it can write its tile -- measured 9 % slower)
-    fetch_next();
+    fetch_next(false);
     if (PROF) stamp(prof ? prof + 1 : nullptr, tid);
     __syncthreads();
     if (PROF) stamp(prof ? prof + 2 : nullptr, tid);
+    const EpiParams Pnext = PIPE ? load_params<COND, SPLIT_T, false>(L, vdn, emb_next, emb_next_tstride, tid, wave, epi_wave) : P;
 
     const EpiDesc e = decode_epi<BWD>(vd);
     const int t_lo = SPLIT_T ? (wave >> 2) : 0, t_step = SPLIT_T ? 2 : 1;
@@ -788,6 +793,7 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
                     *reinterpret_cast<f32x4*>(tl + e.dst2 + hrow * e.d2stride + j) = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     }
+    if (PIPE) F.P = Pnext;
     __syncthreads();
     if (PROF) stamp(prof ? prof + 3 : nullptr, tid);
 }
@@ -856,7 +862,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
 
     const int n_iter = L.n_steps > 0 ? L.n_steps : 1;
     const int HDp = (HD + 3) & ~3;                     // ws block of a trajectory: [multistep memory / EDM slope | x_old | p_cond]
-    constexpr bool PIPE = CDX2_PIPE_PARAMS && T < 3;   // (see OpFetch)
+    constexpr bool PIPE = CDX2_PIPE_PARAMS && T < 3 && !BWD;   // (see OpFetch; guided programs: 16-20 more VGPRs, measured 2.5 % slower)
     constexpr bool SPLIT_T0 = NWV == 8 && T >= 2;
     int n_pass_all = 1;
     if (COND) {
