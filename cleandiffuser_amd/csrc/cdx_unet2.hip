@@ -1,20 +1,29 @@
 // cdx_unet2.hip -- second-generation fused "program" kernel for 1-D temporal U-Net denoisers on gfx950 (MI355X / CDNA4).
 //
-// Replaces, like cdx_unet1d.hip, the ~170 ATen launches per denoiser forward plus the solver arithmetic of the reference loop
+// Replaces the ~170 ATen launches per denoiser forward plus the solver arithmetic of the reference loop
 // (cleandiffuser/diffusion/diffusionsde.py:526-594 driving cleandiffuser/nn_diffusion/jannerunet.py:154-201) with ONE launch per
-// sample() call.  What changed against the first kernel is the per-op fixed cost (round-1 profile: 60 % of the time):
+// sample() call: one workgroup per trajectory (or per 2 / 3 trajectories), every activation in LDS, the weights streamed from L2
+// as 1-KiB MFMA records.  The kernel as it stands (what each choice bought is in DESIGN.md section 3a):
 //
-//   * 4 wave64 per workgroup, one per SIMD; the output of a conv is cut into (row tile x column group) tiles, one per wave (K is
-//     split over spare waves only when a layer has fewer than four tiles); work items are 8-word records read with s_load;
-//   * layer descriptors are read with scalar loads straight into SGPRs (no LDS copy, no v_readlane decode);
-//   * the ResidualBlock's 1x1 skip conv (jannerunet.py:58, :69) is a plain op whose epilogue adds into the block's output slot;
-//   * the per-block FiLM vectors are per-STEP constants: they come from a (steps, n_emb) table (cdx_unet2_embtab_kernel below) as
-//     float4 epilogue parameters -- the embedding MLP is gone from the per-forward program;
-//   * epilogue: 32 lanes per GroupNorm group, one float4 of consecutive channels per lane, statistics in registers (two-pass),
-//     Mish, + FiLM, + residual slot, one float4 LDS store; every per-channel parameter is fetched BEFORE the K loop;
-//   * 16 weight records (16 KiB) in flight per wave, and the head of the NEXT op's stream is issued before this op's barrier;
-//   * T = 1 or 2 trajectories per workgroup: each streamed weight record feeds T x the MFMAs (B >= 512 halves the L2->CU
-//     stream per trajectory, which is what bounds the 1.3-MB layers at L = 4).
+//   * 8 wave64 per workgroup (two per SIMD: a lone wave reaches about half the MFMA issue rate); a conv's output is cut into (row
+//     tile x column group x K slice) work items, one per wave; each wave keeps an 8-deep register ring of weight records in flight
+//     with counted s_waitcnt, the head of the NEXT op's stream is issued right after this op's K loop.  A 4-wave shape (16-deep
+//     ring) still exists for LDS plans that only fit two trajectories that way.
+//   * an op descriptor is ONE coalesced dword load per wave (lane k = word k); fields are decoded with constant-lane v_readlane --
+//     the scalar-load version spent ~900 cycles per op on dependent s_loads and SGPR spills;
+//   * activation slots carry two zero halo rows, so a work item's B-operand address is linear in (tap, chunk): per record the K loop
+//     issues {wait, 4 MFMAs per (trajectory, column tile), one ds_read_b128, one buffer_load}; ConvTranspose1d(4,2,1) is two 2-tap
+//     convs (one per output parity); the ResidualBlock's 1x1 skip conv rides as extra work items of the block's second conv;
+//   * FiLM vectors come from a per-(step[, trajectory]) table built by cdx_unet2_embtab_kernel (the embedding MLP is not part of the
+//     per-forward program);
+//   * epilogue: 32 lanes per GroupNorm group, one float4 of consecutive channels per lane, statistics in ONE shifted pass (sums of
+//     x - s and (x - s)^2, half-wave DPP reductions), Mish, + FiLM, + residual, one float4 LDS store; with T >= 2 waves 0-3 / 4-7
+//     run the trajectories' epilogues side by side;
+//   * the next op's epilogue parameters are fetched behind this op's staging barrier and the descriptor after next right after the
+//     K loop (OpFetch): an op starts with nothing recent in the vector-memory queue;
+//   * T = 1, 2 or 3 trajectories per workgroup share every streamed record (3: compact programs -- state and multistep memory in
+//     global memory); BWD instantiations add the classifier's backward-data ops (guided sampling in the same launch); COND
+//     instantiations add per-trajectory FiLM rows, the classifier-free-guidance pair and the EDM / consistency step kinds.
 //
 // Executable specification / CPU twin: oracle/lane_sim2.py.  Program format: engine/program2.py, csrc/cdx_ops2.h.
 #include <hip/hip_runtime.h>
@@ -677,6 +686,11 @@ struct OpFetch {
     EpiParams P;           // parameters of the op about to run
     int vdn2;              // descriptor view of the op after the next one
 };
+// Which instantiations pipeline the fetch: not three trajectories per workgroup and not the programs with backward ops (16-20 more
+// live VGPRs: 239 -> 256 at T = 2 guided, measured 2.5 % slower).  Measured on MI355X, same box, against the round-2 order
+// (gpurun r3e / r3f): T = 1 with the parameter loads in FRONT of the staging barrier 4.205 vs 4.227 ms (behind it: 4.264);
+// T = 2 with the loads BEHIND the barrier 5.604 vs 5.659 ms (in front: 5.72) -- hence PARAMS_AFTER_BARRIER = (T >= 2).
+template <int T, bool BWD> constexpr bool pipe_params() { return CDX2_PIPE_PARAMS && T < 3 && !BWD; }
 
 // One op.  `vd`: this wave's view of the op's descriptor, `it`: this wave's first item, both fetched during the previous op;
 // `vdn`: the next op's descriptor, whose load was issued before this call.  Leaves the next op's first item in `it`.
@@ -689,11 +703,11 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
                                        Ring<WG<NWV>::PF>& ring, unsigned long long* prof, int b0, OpFetch& F,
                                        const float* __restrict__ emb_next, int emb_next_tstride, int op_next2) {
     constexpr bool SPLIT_T = NWV == 8 && T >= 2;       // waves 0-3 take trajectories 0, 2; waves 4-7 trajectory 1
-    constexpr bool PIPE = CDX2_PIPE_PARAMS && T < 3;
+    constexpr bool PIPE = pipe_params<T, BWD>();
+    constexpr bool PARAMS_AFTER_BARRIER = PIPE && T >= 2;
     // everything the NEXT op needs, issued in one go (see OpFetch)
-    // `params`: also the next op's epilogue parameters (ops without a K loop); a conv op issues those AFTER its staging barrier, where
-    // the epilogue waves wait on LDS anyway -- in front of the barrier their address arithmetic + issue (~450 cycles, measured) sat on
-    // the critical path just as it did at the op's start
+    // `params`: also the next op's epilogue parameters (ops without a K loop; T = 1).  With two trajectories per workgroup a conv op
+    // issues those AFTER its staging barrier instead (see pipe_params)
     auto fetch_next = [&](bool params) {
         it = inline_item(vdn);
         if (wave_of(tid) < CDX2_DW(vdn, CDX2_W2_NITEMS)) prefetch_ring(it, L.wblob, tid & 63, ring);
@@ -757,11 +771,12 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
     // head of the next op's weight stream: flies through the barrier and the epilogue
     // (issued AFTER the partial tiles are staged: sending the eight loads first, while the MFMAs drain, blocks the wave on the
     //  memory pipe for ~350 cycles before it can write its tile -- measured 9 % slower)
-    fetch_next(false);
+    fetch_next(!PARAMS_AFTER_BARRIER);
     if (PROF) stamp(prof ? prof + 1 : nullptr, tid);
     __syncthreads();
     if (PROF) stamp(prof ? prof + 2 : nullptr, tid);
-    const EpiParams Pnext = PIPE ? load_params<COND, SPLIT_T, false>(L, vdn, emb_next, emb_next_tstride, tid, wave, epi_wave) : P;
+    const EpiParams Pnext = PARAMS_AFTER_BARRIER ? load_params<COND, SPLIT_T, false>(L, vdn, emb_next, emb_next_tstride, tid, wave, epi_wave)
+                                                 : (PIPE ? F.P : P);
 
     const EpiDesc e = decode_epi<BWD>(vd);
     const int t_lo = SPLIT_T ? (wave >> 2) : 0, t_step = SPLIT_T ? 2 : 1;
@@ -862,7 +877,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
 
     const int n_iter = L.n_steps > 0 ? L.n_steps : 1;
     const int HDp = (HD + 3) & ~3;                     // ws block of a trajectory: [multistep memory / EDM slope | x_old | p_cond]
-    constexpr bool PIPE = CDX2_PIPE_PARAMS && T < 3 && !BWD;   // (see OpFetch; guided programs: 16-20 more VGPRs, measured 2.5 % slower)
+    constexpr bool PIPE = pipe_params<T, BWD>();        // (see OpFetch)
     constexpr bool SPLIT_T0 = NWV == 8 && T >= 2;
     int n_pass_all = 1;
     if (COND) {
