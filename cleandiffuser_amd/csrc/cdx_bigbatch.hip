@@ -792,6 +792,53 @@ int tf_forward(const cdx_chitf_weights* w, const cdx_sampling* s, hipStream_t st
 // ChiUNet1d as implicit-GEMM convolutions (global conditioning)
 // ------------------------------------------------------------------------------------------------
 #define UNET_SPLITK 6
+// ------------------------------------------------------------------------------------------------
+// LinearAttention core (reference jannerunet.py:84-93): one workgroup per (sample, head); q, k, v of that head in LDS.
+// softmax of k runs over the POSITION axis (one thread per channel d), ctx = k v^T is dim_head x dim_head, out = ctx^T q.
+// Work is ~4 L dh^2 MACs per head -- a few hundred thousand at the shipped sizes: plain VALU, the GEMMs around it are the MFMA work.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void linattn_kernel(const float* __restrict__ qkv, float* __restrict__ out, int L, int heads, int dh,
+                                                        float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];
+    float* q = sh;                    // [L][dh]
+    float* k = q + (size_t)L * dh;    // [L][dh]
+    float* v = k + (size_t)L * dh;    // [L][dh]
+    float* ctx = v + (size_t)L * dh;  // [dh][dh]
+    const int b = blockIdx.x / heads, h = blockIdx.x - b * heads, tid = threadIdx.x;
+    const int inner = heads * dh, ld = 3 * inner;
+    const float* base = qkv + (size_t)b * L * ld + h * dh;
+    for (int i = tid; i < L * dh; i += 256) {
+        const int n = i / dh, c = i - n * dh;
+        q[i] = base[(size_t)n * ld + c] * scale;
+        k[i] = base[(size_t)n * ld + inner + c];
+        v[i] = base[(size_t)n * ld + 2 * inner + c];
+    }
+    __syncthreads();
+    for (int d = tid; d < dh; d += 256) {                 // softmax over positions, per channel
+        float m = -3.0e38f;
+        for (int n = 0; n < L; ++n) m = fmaxf(m, k[n * dh + d]);
+        float sum = 0.f;
+        for (int n = 0; n < L; ++n) { const float e = expf(k[n * dh + d] - m); k[n * dh + d] = e; sum += e; }
+        const float inv = 1.0f / sum;
+        for (int n = 0; n < L; ++n) k[n * dh + d] *= inv;
+    }
+    __syncthreads();
+    for (int i = tid; i < dh * dh; i += 256) {            // ctx[d][e] = sum_n k[n][d] v[n][e]
+        const int d = i / dh, e = i - d * dh;
+        float acc = 0.f;
+        for (int n = 0; n < L; ++n) acc = fmaf(k[n * dh + d], v[n * dh + e], acc);
+        ctx[i] = acc;
+    }
+    __syncthreads();
+    float* o = out + (size_t)b * L * inner + h * dh;
+    for (int i = tid; i < L * dh; i += 256) {             // out[n][e] = sum_d ctx[d][e] q[n][d]
+        const int n = i / dh, e = i - n * dh;
+        float acc = 0.f;
+        for (int d = 0; d < dh; ++d) acc = fmaf(ctx[d * dh + e], q[n * dh + d], acc);
+        o[(size_t)n * inner + e] = acc;
+    }
+}
+
 struct UNet {                     // one pass over the op list; with dry == true it only measures the workspace
     const cdx_chiunet_weights* w;
     const cdx_sampling* s;
@@ -853,6 +900,24 @@ struct UNet {                     // one pass over the op list; with dry == true
         }
         CDX_TRY(gn(h1, o, L, co, k.groups, k.g2, k.be2, nullptr, 0, nullptr, 0, 0, skip));
         *out = o;
+        return CDX_OK;
+    }
+    // LinearAttention site `ai` on `cur` (bf * L rows of C channels) -> new buffer; NULL table: nothing to do
+    int attention(int ai, const float** cur, int L, int C) {
+        if (w->attn == nullptr) return CDX_OK;
+        const cdx_unet_attn& A = w->attn[ai];
+        const int inner = A.heads * A.dim_head;
+        const long long rows = (long long)bf * L;
+        float* xn = take(rows * C);
+        float* qkv = take(rows * 3 * inner);
+        float* core = take(rows * inner);
+        float* y = take(rows * C);
+        if (dry) { *cur = y; return CDX_OK; }
+        CDX_TRY(layernorm(st, *cur, xn, (int)rows, C, 1e-5f, A.ln_g, A.ln_b, nullptr, nullptr, 0, 1, 0));
+        CDX_TRY(gemm(st, xn, C, A.qkv_w, C, nullptr, qkv, 3 * inner, (int)rows, 3 * inner, C));
+        CDX_TRY(cdx_linattn_f32(qkv, core, bf, L, A.heads, A.dim_head, 1.0f / sqrtf((float)A.dim_head), st));
+        CDX_TRY(gemm(st, core, inner, A.out_w, inner, A.out_b, y, C, (int)rows, C, inner, CDX_ACT_NONE, nullptr, 0, 1, xn, C));
+        *cur = y;
         return CDX_OK;
     }
     int film_out(const cdx_chiunet_block& k) const { return (w->cond_predict_scale ? 2 : 1) * k.cout; }
@@ -943,6 +1008,7 @@ struct UNet {                     // one pass over the op list; with dry == true
                 CDX_TRY(block(kb, foff, cur, nullptr, L, &o, (k == 0 && j == 0) ? hl0 : nullptr));
                 foff += film_out(kb); ++bi; cur = o;
             }
+            CDX_TRY(attention(k, &cur, L, w->blocks[bi - 1].cout));
             skips[k] = cur;
             if (k < nl - 1) {
                 const int C = w->blocks[bi - 1].cout;
@@ -955,6 +1021,7 @@ struct UNet {                     // one pass over the op list; with dry == true
             const cdx_chiunet_block& kb = w->blocks[bi];
             CDX_TRY(block(kb, foff, cur, nullptr, L, &o));
             foff += film_out(kb); ++bi; cur = o;
+            if (j == 0) CDX_TRY(attention(nl, &cur, L, kb.cout));
         }
         for (int k = 0; k < nl - 1; ++k) {
             const float* skip = skips[nl - 1 - k];
@@ -963,6 +1030,7 @@ struct UNet {                     // one pass over the op list; with dry == true
             CDX_TRY(block(w->blocks[bi], foff, cur, nullptr, L, &o));
             foff += film_out(w->blocks[bi]); ++bi; cur = o;
             const int C = w->blocks[bi - 1].cout;
+            CDX_TRY(attention(nl + 1 + k, &cur, L, C));
             float* u = take((long long)bf * 2 * L * C);   // row (b, j) of the (bf*L, 2C) view = [out[2j] | out[2j+1]]
             CDX_TRY(conv(cur, C, w->up_w_even[k], w->up_b[k], L, L, 2, C, 1, 1, C, u, 2 * C, nullptr, 0));
             CDX_TRY(conv(cur, C, w->up_w_odd[k], w->up_b[k], L, L, 2, C, 1, 0, C, u + C, 2 * C, nullptr, 0));
@@ -1317,6 +1385,22 @@ int cdx_chitf_run(const cdx_chitf_weights* w, const cdx_sampling* s, void* hip_s
         if (hipMemcpyAsync(s->x_out + off, B.x, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return hip_ok();
     }
     return CDX_OK;
+}
+
+int cdx_linattn_f32(const float* qkv, float* out, int32_t B, int32_t L, int32_t heads, int32_t dim_head, float scale, void* hip_stream) {
+    if (B < 0 || L <= 0 || L > 1024 || heads <= 0 || dim_head <= 0 || dim_head > 64) {
+        cdx_set_err("cdx_linattn_f32: L <= 1024 and dim_head <= 64 required"); return CDX_EINVAL;
+    }
+    if (B == 0) return CDX_OK;
+    if (!qkv || !out) { cdx_set_err("cdx_linattn_f32: null pointer"); return CDX_EINVAL; }
+    const size_t lds = ((size_t)3 * L * dim_head + (size_t)dim_head * dim_head) * sizeof(float);
+    if (lds > 160u * 1024u) { cdx_set_err("cdx_linattn_f32: q, k, v of one head exceed 160 KiB of LDS"); return CDX_ELDS; }
+    if (lds > 48u * 1024u &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return hip_ok();
+    hipLaunchKernelGGL(linattn_kernel, dim3((unsigned)(B * heads)), dim3(256), lds, reinterpret_cast<hipStream_t>(hip_stream), qkv, out, L,
+                       heads, dim_head, scale);
+    return hip_ok();
 }
 
 long long cdx_chiunet_workspace_floats(const cdx_chiunet_weights* w, const cdx_sampling* s) {

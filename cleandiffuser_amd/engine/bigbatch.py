@@ -85,6 +85,10 @@ class CdxChiUNetBlock(ctypes.Structure):
                [(n, _FP) for n in ("w1a", "w1b", "b1", "g1", "be1", "w2", "b2", "g2", "be2", "film_w", "film_b", "wra", "wrb", "br")]
 
 
+class CdxUnetAttn(ctypes.Structure):
+    _fields_ = [(n, _FP) for n in ("ln_g", "ln_b", "qkv_w", "out_w", "out_b")] + [("heads", _I), ("dim_head", _I)]
+
+
 class CdxChiUNetWeights(ctypes.Structure):
     _fields_ = [(n, _I) for n in ("act_dim", "Ta", "cond_dim", "emb_dim", "kernel_size", "n_levels", "cond_predict_scale",
                                   "model_dim", "final_groups", "emb_hidden", "emb_out", "film_ld")] + \
@@ -92,7 +96,7 @@ class CdxChiUNetWeights(ctypes.Structure):
                [("blocks", ctypes.POINTER(CdxChiUNetBlock))] + \
                [(n, ctypes.POINTER(ctypes.c_void_p)) for n in ("down_w", "down_b", "up_w_even", "up_w_odd", "up_b")] + \
                [(n, _FP) for n in ("fin_w", "fin_b", "fin_g", "fin_be", "out_w", "out_b")] + \
-               [("local_obs_dim", _I), ("lc_down_w", _FP), ("lc_down_b", _FP)]
+               [("local_obs_dim", _I), ("lc_down_w", _FP), ("lc_down_b", _FP), ("attn", ctypes.POINTER(CdxUnetAttn))]
 
 
 _declared = False
@@ -440,7 +444,7 @@ def _bind_janner_gemm(net, H: int, device) -> Optional[_Bound]:
     import torch.nn as nn
     from . import blocks as B
     from ..utils import GroupNorm1d
-    if getattr(net, "attention", False) or H & (H - 1):
+    if H & (H - 1):
         return None
     n_levels = len(net.downs)
     if (H >> (n_levels - 1)) < 1 or n_levels > 8:
@@ -509,6 +513,22 @@ def _bind_janner_gemm(net, H: int, device) -> Optional[_Bound]:
     w.up_b = ptr_array([p(u.bias) for u in ups])
     w.fin_w, w.fin_b, w.fin_g, w.fin_be = packed(B.pack_conv(fin[0].weight)), p(fin[0].bias), p(fin[1].weight), p(fin[1].bias)
     w.out_w, w.out_b = packed(fin[3].weight.detach()[:, :, 0]), p(fin[3].bias)
+    if getattr(net, "attention", False):
+        # LinearAttention (reference jannerunet.py:72-95) after every level's second block and between the middle blocks: channel
+        # LayerNorm -> to_qkv GEMM -> cdx_linattn_f32 -> to_out GEMM + the normalised input
+        from ..nn_diffusion.jannerunet import LinearAttention
+        sites = [lvl[2] for lvl in net.downs] + [net.mid_attn] + [lvl[2] for lvl in net.ups]
+        if len(sites) != 2 * n_levels or any(type(a) is not LinearAttention or a.to_qkv.bias is not None for a in sites):
+            return None
+        att = (CdxUnetAttn * len(sites))()
+        for i, a in enumerate(sites):
+            inner = a.to_out.in_channels
+            if inner % a.heads or inner // a.heads > 64 or abs(a.scale - (inner // a.heads) ** -0.5) > 1e-12 or abs(a.norm.eps - 1e-5) > 1e-12:
+                return None
+            att[i] = CdxUnetAttn(p(a.norm.g.reshape(-1)), p(a.norm.b.reshape(-1)), p(a.to_qkv.weight.reshape(a.to_qkv.out_channels, -1)),
+                                 p(a.to_out.weight.reshape(a.to_out.out_channels, -1)), p(a.to_out.bias), a.heads, inner // a.heads)
+        w.attn = att
+        keep.append(att)
     keep.append(arr)
     return _Bound(w, keep, None)
 

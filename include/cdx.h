@@ -445,6 +445,19 @@ typedef struct cdx_chiunet_block {
     const float *film_w, *film_b;            /* cond_encoder.1: (film_out, 2 emb_dim), (film_out) */
     const float *wra, *wrb, *br;             /* residual 1x1 conv split by input part, or all NULL (identity) */
 } cdx_chiunet_block;
+/* JannerUNet1d(attention=True): LinearAttention (reference nn_diffusion/jannerunet.py:72-95) after the second block of every down
+ * level, between the two middle blocks and after the second block of every up level:
+ *   xn = LayerNorm_channels(x);  q, k, v = to_qkv(xn) split into heads;  k <- softmax over POSITIONS;  ctx[d][e] = sum_n k[d][n] v[e][n];
+ *   out[e][n] = sum_d ctx[d][e] (q[d][n] * dim_head^-0.5);  y = to_out(out) + xn. */
+typedef struct cdx_unet_attn {
+    const float *ln_g, *ln_b;                /* norm.g / norm.b: (C) */
+    const float* qkv_w;                      /* to_qkv 1x1 conv, no bias: (3 * heads * dim_head, C) */
+    const float *out_w, *out_b;              /* to_out 1x1 conv: (C, heads * dim_head), (C) */
+    int32_t heads, dim_head;
+} cdx_unet_attn;
+/* the attention core on packed rows: qkv (B * L, 3 * heads * dim_head) = [q | k | v], channel h * dim_head + c -> out (B * L, heads * dim_head);
+ * dim_head <= 64, L <= 1024 */
+int cdx_linattn_f32(const float* qkv, float* out, int32_t B, int32_t L, int32_t heads, int32_t dim_head, float scale, void* hip_stream);
 typedef struct cdx_chiunet_weights {
     int32_t act_dim, Ta, cond_dim, emb_dim, kernel_size, n_levels, cond_predict_scale, model_dim, final_groups;
     /* The same executor serves the unconditional JannerUNet1d (reference nn_diffusion/jannerunet.py:98-201): its blocks add
@@ -469,6 +482,7 @@ typedef struct cdx_chiunet_weights {
      * (packed (md, 3, md)), after the first block of the last up level. */
     int32_t local_obs_dim;                              /* 0: no local conditioning */
     const float *lc_down_w, *lc_down_b;
+    const cdx_unet_attn* attn;                          /* HOST [2 n_levels]: down levels, middle, up levels -- or NULL (no attention) */
 } cdx_chiunet_weights;
 long long cdx_chiunet_workspace_floats(const cdx_chiunet_weights* w, const cdx_sampling* s);
 int cdx_chiunet_run(const cdx_chiunet_weights* w, const cdx_sampling* s, void* hip_stream);

@@ -361,6 +361,32 @@ def dit1ref():
 SCENARIOS.update({"pearcetf_small": pearce_transformer(False), "pearcetf_default": pearce_transformer(True), "dit1ref": dit1ref()})
 
 
+def janner_attention():
+    """JannerUNet1d(attention=True) -- what the reference's own tests/test_janner_unet.py instantiates: LinearAttention after every
+    level's second block and between the middle blocks (reference jannerunet.py:72-95, 124-152).  Stand-alone forward (per-sample
+    timesteps) and an unconditional 4-step DDIM loop."""
+    B, H, D, steps = 3, 16, 6, 4
+
+    def run(lib, kind, device):
+        net = load_synth(lib.JannerUNet1d(D, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2], kernel_size=5, attention=True), 81)
+        fm = torch.zeros(H, D)
+        fm[0, :4] = 1.0
+        agent = lib.DiscreteDiffusionSDE(net, None, fix_mask=fm, diffusion_steps=10, predict_noise=False, device=device)
+        agent.eval()
+        g = torch.Generator().manual_seed(81)
+        prior = torch.zeros(B, H, D)
+        prior[:, 0, :4] = torch.randn(B, 4, generator=g)
+        zs = [torch.randn(B, H, D, generator=g) for _ in range(steps + 1)]
+        with torch.no_grad():
+            fwd = agent.model_ema["diffusion"](zs[0].to(device), torch.tensor([0, 4, 9], device=device), None)
+        x, _ = _sample(agent, kind, prior.to(device), zs, solver="ddim", n_samples=B, sample_steps=steps, temperature=0.8)
+        return {"fwd": fwd, "x": x}
+    return run
+
+
+SCENARIOS["janner_attention"] = janner_attention()
+
+
 def run(name: str, lib_kind: str, device="cpu"):
     """Outputs of scenario `name` as {key: tensor}; keys starting with '_' are live objects for the caller, not results."""
     torch.manual_seed(1234)
