@@ -177,7 +177,7 @@ def cpu_baseline_subprocess(timeout_s=240):
 def recorded_traffic():
     """HBM-side bytes per launch of the fused kernel from the committed PMC pass (rocprofv3 --pmc cannot run inside this
     process); null when the record is absent."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f)
