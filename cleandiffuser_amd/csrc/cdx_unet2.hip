@@ -631,6 +631,33 @@ __device__ __forceinline__ void run_head(const cdx_unet2_launch& L, int vd, cons
     __syncthreads();
 }
 
+// Classifier head, forward only: y = b2 + sum_j w2_j Mish(z_j) -> out (the final log_p of a guided launch).  [w2 | b2] lie together.
+template <int THREADS>
+__device__ __forceinline__ void run_head_fwd(const cdx_unet2_launch& L, int vd, const float* __restrict__ emb_row, float* __restrict__ tl,
+                                             int tid, float* __restrict__ out) {
+    const int hidden = CDX2_DW(vd, CDX2_W2_COUT), len = CDX2_DW(vd, CDX2_W2_LOUT), ch = CDX2_DW(vd, CDX2_W2_LCOLS);
+    const int src = CDX2_DW(vd, CDX2_W2_RES), sstr = CDX2_DW(vd, CDX2_W2_RES_STRIDE);
+    const float* __restrict__ w1 = L.wblob + CDX2_DW(vd, CDX2_W2_BOFF);
+    const float* __restrict__ w2 = L.wblob + CDX2_DW(vd, CDX2_W2_GAMMA);
+    const float* __restrict__ ev = emb_row + CDX2_DW(vd, CDX2_W2_EMB);
+    float* hz = tl + L.stage_off;
+    for (int j = tid; j < hidden; j += THREADS) {
+        float z = ev[j];
+        for (int l = 0; l < len; ++l) {
+#pragma unroll 8
+            for (int c = 0; c < ch; ++c) z = fmaf(w1[(size_t)(l * ch + c) * hidden + j], tl[src + (l + CDX2_HALO2) * sstr + c], z);
+        }
+        hz[j] = w2[j] * mish2(z);
+    }
+    __syncthreads();
+    if (tid == 0 && out != nullptr) {
+        float y = w2[hidden];
+        for (int j = 0; j < hidden; ++j) y += hz[j];
+        *out = y;
+    }
+    __syncthreads();
+}
+
 // Issue the first PF records of item `it` (this wave's first item of the next op) into the ring.  No clamp to the item's
 // record count: the blob ends with PF records of padding, slots past `nq` are simply never consumed.
 template <int PF>
@@ -1089,6 +1116,26 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
         }
         __syncthreads();
     }
+    if (BWD && L.n_steps > 0) {
+        // final log_p (reference diffusionsde.py:597-601): the classifier's forward ops once more, on the final state, timestep 0
+        const KArg* S = kernarg();
+        asm volatile("" : "+s"(S));
+        if (S->logp_out != nullptr) {
+            const int first = S->logp_first_op, head = S->logp_head_op;
+            const float* __restrict__ emb_row = L.emb + (size_t)L.n_steps * L.emb_ld;
+            vd = load_desc<NWV>(L.ops, first, lane, wave);
+            it = inline_item(vd);
+            if (wave < CDX2_DW(vd, CDX2_W2_NITEMS)) prefetch_ring(it, L.wblob, lane, ring);
+            for (int oi = first; oi < head; ++oi) {
+                const int vdn = load_desc<NWV>(L.ops, oi + 1, lane, wave);
+                run_op<T, NWV, BWD, PROF, COND>(L, ops, vd, vdn, it, emb_row, 0, lds, tid, ring, nullptr, b0, F, emb_row, 0, 0);
+                vd = vdn;
+            }
+#pragma unroll 1
+            for (int t = 0; t < T; ++t)
+                run_head_fwd<THREADS>(L, vd, emb_row, lds + t * tf, tid, b0 + t < b_end ? S->logp_out + (b0 + t) : nullptr);
+        }
+    }
 #pragma unroll 1
     for (int t = 0; t < T; ++t) {
         if (b0 + t >= b_end) break;
@@ -1209,6 +1256,9 @@ int cdx_unet2_run(const cdx_unet2_launch* L, void* hip_stream) {
     if (guided && L->ws_floats > 0 && !L->ws) { cdx_set_err("program keeps saved tensors in a global workspace: ws == NULL"); return CDX_EINVAL; }
     if (L->ws_floats < 0 || (L->ws_floats & 3)) { cdx_set_err("ws_floats must be a non-negative multiple of 4"); return CDX_EINVAL; }
     if (L->cg_scale && (L->grad_off < 0 || (L->grad_off & 3) || (L->grad_stride & 3))) { cdx_set_err("cg_scale given without a gradient slot"); return CDX_EINVAL; }
+    if (L->logp_out && (!guided || L->n_steps == 0 || L->logp_first_op < 0 || L->logp_head_op <= L->logp_first_op || L->logp_head_op >= L->n_ops)) {
+        cdx_set_err("logp_out: guided sampling loops only, with 0 <= logp_first_op < logp_head_op < n_ops"); return CDX_EINVAL;
+    }
     void (*kern)(const cdx_unet2_launch);
     const bool cond = L->n_pass == 2 || L->edm_plan || L->emb_per_traj;
     if (cond) {

@@ -250,9 +250,13 @@ class BaseDiffusionSDE(DiffusionModel):
                                       feed, t_dtype, log["sample_history"])
 
         if final_logp:
-            with torch.no_grad():
-                t0 = torch.zeros((n_samples,), dtype=torch.long, device=self.device)
-                log["log_p"] = self.classifier.logp(xt, t0, condition_cg)
+            native_logp = getattr(fused, "_cdx_logp", None) if fused is not None else None
+            if native_logp is not None:            # guided launch: the final classifier forward ran inside it (same x_t, timestep 0)
+                log["log_p"] = native_logp
+            else:
+                with torch.no_grad():
+                    t0 = torch.zeros((n_samples,), dtype=torch.long, device=self.device)
+                    log["log_p"] = self.classifier.logp(xt, t0, condition_cg)
         if self.clip_pred:
             xt = xt.clip(self.x_min, self.x_max)
         return xt, log

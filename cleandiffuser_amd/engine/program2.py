@@ -438,7 +438,7 @@ class _Builder2:
         self.macs += sum(c_out * (l_cols if len(phases) > 1 else l_out) * w.shape[1] * c_in for w, _, _ in phases)
         return True
 
-    def head(self, src: Act, dst: Act, w1: torch.Tensor, e_off: int, w2: torch.Tensor):
+    def head(self, src: Act, dst: Act, w1: torch.Tensor, e_off: int, w2: torch.Tensor, b2: Optional[torch.Tensor] = None):
         """Classifier head with its backward in one op (reference nn_classifier/half_jannerunet.py:49-50, :62):
         z = W1x flat(src) + e (e = W1e emb + b1 comes from the per-step table at `e_off`), y = w2 . Mish(z) (+ b2, irrelevant for the
         gradient); dst <- d y / d src = W1x^T (w2 * Mish'(z)).  `w1` = W1x as [hidden][C][L] (the reference flattens channel-major)."""
@@ -448,12 +448,15 @@ class _Builder2:
             raise ValueError("classifier head wider than 256 hidden units")
         wp = w1.permute(2, 1, 0).contiguous()                # [l][c][hidden]: the thread of hidden unit j reads consecutive j
         words = {W2_KIND: KIND2_HEAD, W2_COUT: hidden, W2_LOUT: l, W2_LCOLS: c, W2_NITEMS: 0, W2_DST_STRIDE: dst.stride,
-                 W2_RES_STRIDE: src.stride, W2_BOFF: self.add(wp), W2_GAMMA: self.add(w2.reshape(-1)), W2_EMB: e_off,
+                 W2_RES_STRIDE: src.stride, W2_BOFF: self.add(wp),
+                 # [w2 (hidden) | b2]: the bias only matters for the final log_p forward (cdx_unet2_launch.logp_out)
+                 W2_GAMMA: self.add(torch.cat([w2.reshape(-1), (b2 if b2 is not None else w2.new_zeros(1)).reshape(-1)[:1]])), W2_EMB: e_off,
                  W2_COUTP: pad32(c), W2_NK: 1, W2_KSPLIT: 1}
         op = [0] * op_words(self.nw)
         for k, v in words.items():
             op[k] = int(v)
         self.ops.append(op)
+        self.head_index = len(self.ops) - 1
         self.op_acts.append(dict(srcs=[], res=src, dst=dst, save=None, dst2=None, reads=[src], writes=[dst]))
         self.op_items.append([])
         self.op_item_src.append([])
@@ -689,7 +692,8 @@ def _lower_half_janner_grad(b: "_Builder2", clf, horizon: int, x: Act, grad: Act
         raise ValueError("classifier head does not match the flattened feature size")
     head_off = b.emb_slot(lin1.out_features)
     g = b.act(cur.length, cur.chans)                       # gradient w.r.t. the last downsample's output
-    b.head(cur, g, lin1.weight.detach()[:, :fc].reshape(lin1.out_features, cur.chans, cur.length), head_off, lin2.weight.detach())
+    b.head(cur, g, lin1.weight.detach()[:, :fc].reshape(lin1.out_features, cur.chans, cur.length), head_off, lin2.weight.detach(),
+           lin2.bias.detach() if lin2.bias is not None else None)
 
     # ---- backward: g = gradient w.r.t. the output of the tape entry on top ----
     # what lies BELOW an entry decides the epilogue of the op that completes the gradient w.r.t. that entry's input: another
@@ -851,5 +855,6 @@ def compile_guided2(net, clf, horizon: int, max_lds_bytes: int = 160 * 1024, nw:
     emb_clf = _emb_table_spec(b, clf, cblocks, dev, raw_rows=(lin1.weight.detach()[:, fcw:], lin1.bias.detach(), head_off))
     prog = _finalize2(b, [emb_den, emb_clf], x, pred, horizon, d, net.emb_dim, max_lds_bytes, [], grad=grad, compact=compact)
     prog.meta["n_den"] = n_den
+    prog.meta["cls_first"], prog.meta["head_op"] = n_den, b.head_index      # final log_p forward: ops [cls_first, head_op] once more
     prog.ws_floats = b.ws_floats
     return prog

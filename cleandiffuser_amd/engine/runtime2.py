@@ -46,7 +46,8 @@ class CdxUnet2Launch(ctypes.Structure):
                 ("with_backward", ctypes.c_int32), ("ws", ctypes.c_void_p), ("ws_floats", ctypes.c_int32),
                 ("compact", ctypes.c_int32), ("prof", ctypes.c_void_p),
                 ("emb_per_traj", ctypes.c_int32), ("n_pass", ctypes.c_int32), ("emb_u", ctypes.c_void_p), ("cfg_w", ctypes.c_float),
-                ("edm_plan", ctypes.c_int32)]
+                ("edm_plan", ctypes.c_int32), ("logp_out", ctypes.c_void_p), ("logp_first_op", ctypes.c_int32),
+                ("logp_head_op", ctypes.c_int32)]
 
 
 _declared = False
@@ -155,14 +156,17 @@ def film_table(comp: _Compiled2, module, t_vec: torch.Tensor, modules=None) -> t
     return out
 
 
-def plan_film_table(comp: _Compiled2, module, plan, device, modules=None) -> torch.Tensor:
+def plan_film_table(comp: _Compiled2, module, plan, device, modules=None, zero_row: bool = False) -> torch.Tensor:
     # one entry per (device, module, program variant): replaced -- not accumulated -- when the weight signature changes (a train /
     # evaluate loop that keeps the solver's cached plan would otherwise add a device table + a long tuple key per ema_update)
     memo = plan.__dict__.setdefault("_memo", {})
-    key = ("film2", str(device), id(module), comp.prog.nw, bool(comp.prog.compact), comp.prog.ws_floats, len(comp.prog.embtabs))
+    key = ("film2", str(device), id(module), comp.prog.nw, bool(comp.prog.compact), comp.prog.ws_floats, len(comp.prog.embtabs), zero_row)
     hit = memo.get(key)
     if hit is None or hit[0] != comp.sig:
-        hit = memo[key] = (comp.sig, film_table(comp, module, R.device_times(plan, device), modules))
+        t_vec = R.device_times(plan, device)
+        if zero_row:            # one more row for timestep 0: the final log_p forward of a guided launch (reference diffusionsde.py:599)
+            t_vec = torch.cat([t_vec, t_vec.new_zeros(1)])
+        hit = memo[key] = (comp.sig, film_table(comp, module, t_vec, modules))
     return hit[1]
 
 
@@ -270,7 +274,7 @@ def shape_for(module, horizon: int, batch: int):
 def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps=0, predict_noise=0, prior=None,
            fix_mask=None, noise=None, x_min=None, x_max=None, t_per_wg: Optional[int] = None, x_scale: Optional[float] = None,
            cg_scale=None, with_backward: bool = False, parts=None, emb_per_traj: bool = False, emb_u=None, cfg_w: float = 1.0,
-           edm: bool = False):
+           edm: bool = False, logp_out=None):
     if batch <= 0:
         return
     prog = comp.prog
@@ -314,7 +318,9 @@ def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps
             x_scale=1.0 if x_scale is None else float(x_scale), cg_scale=R._ptr(cg_scale), grad_off=prog.grad_off,
             grad_stride=prog.grad_stride, with_backward=int(with_backward or cg_scale is not None), ws=R._ptr(ws),
             ws_floats=ws_floats, compact=int(prog.compact), prof=R._ptr(prof), emb_per_traj=int(emb_per_traj),
-            n_pass=2 if emb_u is not None else 1, emb_u=R._ptr(emb_u), cfg_w=float(cfg_w), edm_plan=int(edm))
+            n_pass=2 if emb_u is not None else 1, emb_u=R._ptr(emb_u), cfg_w=float(cfg_w), edm_plan=int(edm),
+            logp_out=R._ptr(logp_out), logp_first_op=prog.meta.get("cls_first", 0) if logp_out is not None else 0,
+            logp_head_op=prog.meta.get("head_op", 0) if logp_out is not None else 0)
         R._check(_lib().cdx_unet2_run(ctypes.byref(L), R._stream_ptr(x_in.device)), "cdx_unet2_run")
     if timing["on"]:
         end.record(torch.cuda.current_stream(x_in.device))
@@ -495,16 +501,22 @@ def guided_sample2(solver, net, clf_net, plan, xt, prior, feed, fix_mask, x_min,
     from .plan import cached
     pn = R._predicts_noise(plan, solver)
     with torch.no_grad():
-        emb = plan_film_table(comp, net, plan, dev, modules=[net, clf_net])
+        with_logp = os.environ.get("CDX_UNET2_LOGP", "1") != "0"       # (A/B hook: 0 = the classifier's own log_p launch afterwards)
+        emb = plan_film_table(comp, net, plan, dev, modules=[net, clf_net], zero_row=with_logp)
         steps_dev = R.steps_to_device(plan, dev)
         cg = cached(plan, ("cg2", str(dev), float(w_cg), int(pn)), lambda: torch.tensor(
             [(-(w_cg * st.sigma)) if pn else (w_cg * ((st.sigma ** 2) / st.alpha)) for st in plan.steps], dtype=torch.float32, device=dev))
         noise = torch.stack([feed.like(xt) for _ in range(plan.n_noise)]).contiguous() if plan.n_noise else None
         xin = R._f32c(xt, dev)
         out = torch.empty_like(xin)
+        logp = torch.empty((b, 1), dtype=torch.float32, device=dev) if with_logp else None
         launch(comp, batch=b, x_in=xin, x_out=out, emb=emb, steps_dev=steps_dev, n_steps=len(plan.steps), predict_noise=pn,
                prior=R._f32c(prior, dev) if fix_mask is not None else None, fix_mask=fix_mask, noise=noise, x_min=x_min,
-               x_max=x_max, t_per_wg=t, cg_scale=cg, parts=parts)
+               x_max=x_max, t_per_wg=t, cg_scale=cg, parts=parts, logp_out=logp)
+        if logp is not None:
+            # the classifier's score of the FINAL trajectories (timestep 0) came out of the same launch: handed to the solver's
+            # post-processing on the tensor itself (diffusionsde._sample_common reads it instead of calling classifier.logp)
+            out._cdx_logp = logp
     return out
 
 

@@ -204,6 +204,11 @@ typedef struct cdx_unet2_launch {
     const float* emb_u;
     float cfg_w;
     int32_t edm_plan;          /* != 0: the step records are kinds 5-7 */
+    /* guided programs: after the last step the classifier's forward ops [logp_first_op, logp_head_op] run once more on the FINAL
+     * state with FiLM row `n_steps` of `emb` (timestep 0) and the head writes its scalar to logp_out[b] -- the `log_p` the reference
+     * evaluates after the loop (diffusionsde.py:597-601), before the final clip.  NULL: not asked for. */
+    float* logp_out;           /* device (batch) or NULL */
+    int32_t logp_first_op, logp_head_op;
 } cdx_unet2_launch;
 int cdx_unet2_run(const cdx_unet2_launch* launch, void* hip_stream);
 

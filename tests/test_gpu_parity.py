@@ -1048,6 +1048,8 @@ def test_exact_baseline_configuration_matches_reference_fixture(name, amd_lib, m
         np.testing.assert_allclose(out[k].cpu().numpy() / scale, gold[k] / scale, err_msg=f"{name}/{k}", **TOL)
     if name == "baseline_cfg2_guided":                               # candidate selection is index-exact
         assert int(out["log_p"].argmax()) == int(gold["log_p"].argmax())
+        # ... and the classifier's final log_p forward ran INSIDE the guided launch (round 3): one kernel launch for the whole call
+        assert (fused["n"], fused["v2"]) == (1, 1), fused
 
 
 @pytest.mark.parametrize("name", ["discrete_eps", "discrete_x0", "continuous_eps", "edm_conditional_nodrop", "legacy_ddpm",
