@@ -59,6 +59,16 @@ class _NoiseFeed:
             raise ValueError(f"recorded noise #{self._pos - 1} has shape {tuple(z.shape)}, need {tuple(ref.shape)}")
         return z
 
+    def many(self, ref: torch.Tensor, n: int) -> Optional[torch.Tensor]:
+        """The next `n` draws as one (n, *ref.shape) tensor -- what a whole-loop executor hands its kernel.  Fresh draws on a device
+        come from ONE randn launch instead of n (a 100-step DDPM loop used to start with 100 tiny launches and a stack); on the CPU the
+        draws stay one randn_like per step, in order, so that a seeded CPU run keeps reproducing the reference's stream."""
+        if n <= 0:
+            return None
+        if self._rec is None and ref.is_cuda:
+            return torch.randn((n, *ref.shape), device=ref.device, dtype=ref.dtype)
+        return torch.stack([self.like(ref) for _ in range(n)]).contiguous()
+
 
 class BaseDiffusionSDE(DiffusionModel):
     def __init__(self, nn_diffusion: BaseNNDiffusion, nn_condition: Optional[BaseNNCondition] = None,

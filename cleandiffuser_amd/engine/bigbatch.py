@@ -899,7 +899,7 @@ def sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed) -> Optional[torc
                 return None
         two = 2 if mode == 2 else 1
         steps = host_steps(plan)
-        noise = torch.stack([feed.like(xt) for _ in range(plan.n_noise)]).contiguous() if plan.n_noise else None
+        noise = feed.many(xt, plan.n_noise)
         xin = _f32c(xt, dev)
         out = torch.empty_like(xin)
         if kind == "mlp":

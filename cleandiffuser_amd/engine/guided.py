@@ -105,7 +105,7 @@ def guided_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, feed) -
         scale = [(-(w_cg * st.sigma)) if pn else (w_cg * ((st.sigma ** 2) / st.alpha)) for st in plan.steps]
         cg = (ctypes.c_float * len(scale))(*[float(np.float32(v)) for v in scale])
         steps = host_steps(plan)
-        noise = torch.stack([feed.like(xt) for _ in range(plan.n_noise)]).contiguous() if plan.n_noise else None
+        noise = feed.many(xt, plan.n_noise)
         xin = _f32c(xt, dev)
         out = torch.empty_like(xin)
         prior_d = _f32c(prior, dev) if fix_mask is not None else None

@@ -198,25 +198,28 @@ class FusedAdamW(torch.optim.AdamW):
             ema_of = {id(p): e for p, e in zip(model.parameters(), model_ema.parameters())}
             if not all(id(p) in ema_of for _, ps in groups for p in ps):
                 raise RuntimeError("FusedAdamW: `ema` does not cover the optimiser's parameters")
-        for gi, (group, ps) in enumerate(groups):
-            sts = [self._state(p) for p in ps]
-            for st in sts:
+        for gi, (group, ps_all) in enumerate(groups):
+            for st in (self._state(p) for p in ps_all):
                 st["step"] += 1
-            t = float(sts[0]["step"])
-            if any(float(st["step"]) != t for st in sts):
-                raise RuntimeError("FusedAdamW: parameters of one group are at different step counts")
+            # one launch per distinct step count (torch keeps the count per parameter: a parameter that joined late, or one whose
+            # gradient was None for a while, is bias-corrected with ITS count); normally that is one launch per group
+            by_step = {}
+            for p in ps_all:
+                by_step.setdefault(float(self.state[p]["step"]), []).append(p)
             b1, b2 = group["betas"]
-            lists = [ps, [p.grad for p in ps], [st["exp_avg"] for st in sts], [st["exp_avg_sq"] for st in sts]]
-            if ema_of is not None:
-                lists.append([ema_of[id(p)].detach() for p in ps])
-            tab = _table(self._tables, f"adamw{gi}", lists, dev)
-            _call(CdxOptimArgs(p=tab.row(0), g=tab.row(1), m=tab.row(2), v=tab.row(3), ema=tab.row(4) if ema_of is not None else None,
-                               numel=tab.numel_ptr, chunks=tab.chunks.data_ptr(), n_tensors=tab.n_tensors, n_chunks=tab.n_chunks,
-                               chunk_elems=CHUNK, mode=OPT_ADAMW, lr=float(group["lr"]), beta1=float(b1), beta2=float(b2),
-                               eps=float(group["eps"]), weight_decay=float(group["weight_decay"]),
-                               step_size=float(group["lr"]) / (1.0 - b1 ** t), bc2_sqrt=math.sqrt(1.0 - b2 ** t),
-                               ema_rate=float(rate), max_norm=clip, zero_grad=int(zero_grad), norm=self._norm.data_ptr()), dev)
-            _bump_versions(ps)
-            if ema_of is not None:
-                _bump_versions([ema_of[id(p)] for p in ps])
+            for t, ps in by_step.items():
+                sts = [self.state[p] for p in ps]
+                lists = [ps, [p.grad for p in ps], [st["exp_avg"] for st in sts], [st["exp_avg_sq"] for st in sts]]
+                if ema_of is not None:
+                    lists.append([ema_of[id(p)].detach() for p in ps])
+                tab = _table(self._tables, f"adamw{gi}/{t if len(by_step) > 1 else 'all'}", lists, dev)
+                _call(CdxOptimArgs(p=tab.row(0), g=tab.row(1), m=tab.row(2), v=tab.row(3), ema=tab.row(4) if ema_of is not None else None,
+                                   numel=tab.numel_ptr, chunks=tab.chunks.data_ptr(), n_tensors=tab.n_tensors, n_chunks=tab.n_chunks,
+                                   chunk_elems=CHUNK, mode=OPT_ADAMW, lr=float(group["lr"]), beta1=float(b1), beta2=float(b2),
+                                   eps=float(group["eps"]), weight_decay=float(group["weight_decay"]),
+                                   step_size=float(group["lr"]) / (1.0 - b1 ** t), bc2_sqrt=math.sqrt(1.0 - b2 ** t),
+                                   ema_rate=float(rate), max_norm=clip, zero_grad=int(zero_grad), norm=self._norm.data_ptr()), dev)
+                _bump_versions(ps)
+                if ema_of is not None:
+                    _bump_versions([ema_of[id(p)] for p in ps])
         return loss

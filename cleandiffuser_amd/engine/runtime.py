@@ -448,7 +448,9 @@ def fused_sample_mlp(solver, net, kind, plan, xt, prior, cond_vec, w_cfg, feed) 
         if kind == "pearce":                          # PearceMlp also consumes the raw timestep as a feature (Q11)
             temb = torch.cat([temb, t_vec.to(torch.float32).unsqueeze(1)], 1).contiguous()
         steps_dev = steps_to_device(plan, dev)
-        noise = torch.stack([rows(feed.like(xt)) for _ in range(plan.n_noise)]).contiguous() if plan.n_noise else None
+        noise = feed.many(xt, plan.n_noise)
+        if noise is not None and pad:                 # zero rows behind every draw: the last tile's unused samples
+            noise = torch.cat([_f32c(noise, dev), noise.new_zeros(noise.shape[0], pad, d)], dim=1).contiguous()
         xin = rows(xt)
         out = torch.empty_like(xin)
         _launch(comp, batch=n_tiles, x_in=xin, x_out=out, temb=temb, steps_dev=steps_dev, n_steps=len(plan.steps),
@@ -506,7 +508,7 @@ def fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed, x_scale:
         t_vec = device_times(plan, dev)
         temb = _f32c(net.map_noise(t_vec), dev)
         steps_dev = steps_to_device(plan, dev)
-        noise = torch.stack([feed.like(xt) for _ in range(plan.n_noise)]).contiguous() if plan.n_noise else None
+        noise = feed.many(xt, plan.n_noise)
         xin = _f32c(xt, dev)
         out = torch.empty_like(xin)
         _launch(comp, batch=b, x_in=xin, x_out=out, temb=temb, steps_dev=steps_dev, n_steps=len(plan.steps),

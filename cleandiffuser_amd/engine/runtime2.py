@@ -390,7 +390,7 @@ def fused_sample2(solver, net, plan, xt, prior, feed, fix_mask, x_min, x_max, x_
                 emb_u = plan_film_table(comp, net, plan, dev)                 # zero condition: the per-step table
         else:
             emb = plan_film_table(comp, net, plan, dev)
-        noise = torch.stack([feed.like(xt) for _ in range(plan.n_noise)]).contiguous() if plan.n_noise else None
+        noise = feed.many(xt, plan.n_noise)
         xin = R._f32c(xt, dev)
         out = torch.empty_like(xin)
         launch(comp, batch=b, x_in=xin, x_out=out, emb=emb, steps_dev=steps_dev, n_steps=len(plan.steps),
@@ -506,7 +506,7 @@ def guided_sample2(solver, net, clf_net, plan, xt, prior, feed, fix_mask, x_min,
         steps_dev = R.steps_to_device(plan, dev)
         cg = cached(plan, ("cg2", str(dev), float(w_cg), int(pn)), lambda: torch.tensor(
             [(-(w_cg * st.sigma)) if pn else (w_cg * ((st.sigma ** 2) / st.alpha)) for st in plan.steps], dtype=torch.float32, device=dev))
-        noise = torch.stack([feed.like(xt) for _ in range(plan.n_noise)]).contiguous() if plan.n_noise else None
+        noise = feed.many(xt, plan.n_noise)
         xin = R._f32c(xt, dev)
         out = torch.empty_like(xin)
         logp = torch.empty((b, 1), dtype=torch.float32, device=dev) if with_logp else None
