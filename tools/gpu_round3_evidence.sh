@@ -9,6 +9,7 @@ for B in 32 64 128 256 512 768 3200; do
   BENCH_BATCH=$B timeout 300 python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-other-configs 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('B=$B', round(d['value']), 'traj/s', 'ms_per_call', round(d['ms_per_step'],3), 'kernel_ms', round(d['roofline']['kernel_ms'],3), 'frac', round(d['roofline']['frac'],4))"
 done | tee $E/r03_batch_sweep.txt
 for t in 4 8 16; do echo "MLP tile $t"; CDX_MLP_TILE=$t timeout 300 python tools/bench_configs.py cfg1 2>&1 | tail -1 | cut -c1-330; done | tee $E/r03_cfg1_tiles.txt
+timeout 300 python tools/optim_bench.py 2>/dev/null | tee $E/r03_optim_bench.jsonl
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$E/stats -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-other-configs > $R/$E/stats.log 2>&1
