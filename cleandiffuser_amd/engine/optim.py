@@ -125,6 +125,24 @@ class FusedAdamW(torch.optim.AdamW):
         self._tables = {}
         self._norm = None
         self.last_grad_norm = None
+        self._t = {}                # id(parameter) -> step count (python int): the per-parameter `step` TENSORS of torch's state layout
+        #                             are refreshed from it only when somebody looks (state_dict), not 196 CPU tensor ops per step
+
+    def _sync_steps(self):
+        for group in self.param_groups:
+            for p in group["params"]:
+                t = self._t.get(id(p))
+                if t is not None and p in self.state:
+                    self.state[p]["step"].fill_(float(t))
+
+    def state_dict(self):
+        self._sync_steps()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._t = {id(p): int(float(self.state[p]["step"])) for g in self.param_groups for p in g["params"] if p in self.state and "step" in self.state[p]}
+        self._tables = {}
 
     # ---- helpers ----
     @staticmethod
@@ -164,6 +182,8 @@ class FusedAdamW(torch.optim.AdamW):
     @torch.no_grad()
     def step(self, closure=None, *, max_norm: Optional[float] = None, ema=None, zero_grad: bool = False):
         if not self.native():                           # CPU / unsupported options: the reference's own sequence
+            self._sync_steps()
+            self._t = {}
             if max_norm:
                 self.last_grad_norm = torch.nn.utils.clip_grad_norm_([p for g in self.param_groups for p in g["params"]], max_norm)
             out = super().step(closure)
@@ -199,13 +219,16 @@ class FusedAdamW(torch.optim.AdamW):
             if not all(id(p) in ema_of for _, ps in groups for p in ps):
                 raise RuntimeError("FusedAdamW: `ema` does not cover the optimiser's parameters")
         for gi, (group, ps_all) in enumerate(groups):
-            for st in (self._state(p) for p in ps_all):
-                st["step"] += 1
             # one launch per distinct step count (torch keeps the count per parameter: a parameter that joined late, or one whose
             # gradient was None for a while, is bias-corrected with ITS count); normally that is one launch per group
             by_step = {}
             for p in ps_all:
-                by_step.setdefault(float(self.state[p]["step"]), []).append(p)
+                st = self._state(p)
+                t = self._t.get(id(p))
+                if t is None:
+                    t = int(float(st["step"]))
+                self._t[id(p)] = t = t + 1
+                by_step.setdefault(t, []).append(p)
             b1, b2 = group["betas"]
             for t, ps in by_step.items():
                 sts = [self.state[p] for p in ps]

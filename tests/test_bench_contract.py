@@ -1,4 +1,4 @@
-"""The bench.py output contract, checked on the committed line of this round (profiles/r02_bench_n1.json -- written by `python
+"""The bench.py output contract, checked on the committed line of this round (profiles/r03_bench_n1.json -- written by `python
 bench.py` on MI355X): every field the driver parses is there, the roofline numbers are consistent with each other and with the
 committed rocprofv3 statistics, and the line names BASELINE.json's metric and configuration."""
 import csv
@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module")
 def line():
-    path = os.path.join(ROOT, "profiles", "r02_bench_n1.json")
+    path = os.path.join(ROOT, "profiles", "r03_bench_n1.json")
     return json.loads(open(path).read().strip().splitlines()[-1])
 
 
@@ -45,9 +45,9 @@ def test_roofline_block_is_self_consistent(line):
 
 
 def test_rocprof_statistics_agree_with_the_live_measurement(line):
-    path = os.path.join(ROOT, "profiles", "r02_rocprofv3_kernel_stats.csv")
+    path = os.path.join(ROOT, "profiles", "r03_rocprofv3_kernel_stats.csv")
     rows = list(csv.DictReader(open(path)))
-    kern = [r for r in rows if "cdx_unet2_kernel<1, 8, false, false>" in r["Name"]]
+    kern = [r for r in rows if "cdx_unet2_kernel<1, 8, false, false, false>" in r["Name"]]
     assert len(kern) == 1
     avg_ms = float(kern[0]["AverageNs"]) * 1e-6
     assert abs(avg_ms - line["roofline"]["kernel_ms"]) / avg_ms < 0.03          # HIP events in bench.py vs rocprofv3 --kernel-trace

@@ -1100,6 +1100,7 @@ def test_fused_adamw_matches_torch_adamw_over_ten_steps():
             for q, e in zip(net_b.parameters(), ema_b.parameters()):
                 e.mul_(rate).add_(q.detach(), alpha=1 - rate)
         torch.testing.assert_close(opt_a.last_grad_norm, norm_b, rtol=2e-6, atol=0)
+    sd_a = opt_a.state_dict()                       # (refreshes the per-parameter `step` tensors from the python-side counters)
     for (n, p), q, ea, eb in zip(net_a.named_parameters(), net_b.parameters(), ema_a.parameters(), ema_b.parameters()):
         scale = float(q.detach().abs().max()) + 1e-12
         assert float((p - q).abs().max()) <= 1e-6 * max(scale, 1.0), n
@@ -1110,7 +1111,7 @@ def test_fused_adamw_matches_torch_adamw_over_ten_steps():
         torch.testing.assert_close(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=1e-5, atol=1e-12)
     # state_dict round trip through the stock optimiser class (pipelines checkpoint agent.optimizer)
     opt_c = torch.optim.AdamW(net_b.parameters(), **kw)
-    opt_c.load_state_dict(opt_a.state_dict())
+    opt_c.load_state_dict(sd_a)
 
 
 def test_update_runs_without_aten_optimiser_launches(amd_lib):
