@@ -1210,8 +1210,9 @@ def test_conditional_and_edm_janner_requests_run_on_the_v2_kernel(name, amd_lib,
     np.testing.assert_allclose(x.cpu().numpy(), gold["x_out"], **TOL)
 
 
+@pytest.mark.parametrize("B", [600, 604])          # 604 = 201 x 3 + 1: the last workgroup holds one real and two idle trajectories
 @pytest.mark.parametrize("solver_kw", [dict(solver="ode_dpmsolver++_2M", w_cfg=1.7), dict(solver="ddpm", w_cfg=1.0)])
-def test_conditional_config2_net_is_independent_of_trajectories_per_workgroup(solver_kw, amd_lib, monkeypatch):
+def test_conditional_config2_net_is_independent_of_trajectories_per_workgroup(solver_kw, B, amd_lib, monkeypatch):
     """The config-2 network with a condition embedding at B = 600 (three trajectories per workgroup on the compact program: the state
     and the conditional prediction of the CFG pair live in global memory, the state slot is rebuilt between the two forwards) against
     the same request one trajectory per workgroup: bit-identical, and equal to the PyTorch executor on a slice."""
@@ -1226,7 +1227,6 @@ def test_conditional_config2_net_is_independent_of_trajectories_per_workgroup(so
                                          x_max=lim, x_min=-lim, device=DEV)
     agent.eval()
     g = torch.Generator().manual_seed(9)
-    B = 600
     prior = torch.zeros(B, 32, 23)
     prior[:, 0, :17] = torch.randn(B, 17, generator=g)
     cond = torch.randn(B, 32, generator=g).to(DEV)
@@ -1246,8 +1246,42 @@ def test_conditional_config2_net_is_independent_of_trajectories_per_workgroup(so
     from cleandiffuser_amd.engine import dispatch
     monkeypatch.setattr(dispatch, "try_fused_sample", lambda *a, **k: None)
     monkeypatch.setattr(dispatch, "try_backbone_forward", lambda *a, **k: None)
-    xs, _ = agent.sample(prior[:5].to(DEV), noise=[z[:5] for z in zs], **dict(kw, n_samples=5, condition_cfg=cond[:5]))
-    np.testing.assert_allclose(x3[:5].cpu().numpy(), xs.cpu().numpy(), **TOL)
+    xs, _ = agent.sample(prior[-5:].to(DEV), noise=[z[-5:] for z in zs], **dict(kw, n_samples=5, condition_cfg=cond[-5:]))
+    np.testing.assert_allclose(x3[-5:].cpu().numpy(), xs.cpu().numpy(), **TOL)
+
+
+@pytest.mark.parametrize("edm_solver", ["euler", "heun"])
+def test_edm_config2_net_three_per_workgroup(edm_solver, amd_lib, monkeypatch):
+    """ContinuousEDM (step kinds 5 / 6: the network sees c_in x, state / slope / x_old in global memory) over the config-2 net at
+    B = 605 -- three trajectories per workgroup on the compact program, a half-empty last workgroup -- against the same program one
+    per workgroup (bit-identical) and the PyTorch executor on the last rows (1e-4)."""
+    from cleandiffuser_amd.utils import load_synth
+    net = load_synth(amd_lib.JannerUNet1d(23, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2, 2], kernel_size=5), 6)
+    fm = torch.zeros(32, 23)
+    fm[0, :17] = 1.0
+    lim = 2.0 * torch.ones(1, 32, 23)
+    agent = amd_lib.ContinuousEDM(net, None, fix_mask=fm, x_max=lim, x_min=-lim, device=DEV)
+    agent.eval()
+    g = torch.Generator().manual_seed(10)
+    B = 605
+    prior = torch.zeros(B, 32, 23)
+    prior[:, 0, :17] = torch.randn(B, 17, generator=g)
+    zs = [torch.randn(B, 32, 23, generator=g).to(DEV)]
+    kw = dict(solver=edm_solver, n_samples=B, sample_steps=5)
+    calls = _spy_launches(monkeypatch)
+    x3, _ = agent.sample(prior.to(DEV), noise=zs, **kw)
+    assert (calls["n"], calls["v2"]) == (1, 1), calls
+    monkeypatch.setenv("CDX_UNET2_T", "1")
+    monkeypatch.setenv("CDX_UNET2_COMPACT", "1")
+    x1, _ = agent.sample(prior.to(DEV), noise=zs, **kw)
+    monkeypatch.delenv("CDX_UNET2_COMPACT")
+    monkeypatch.delenv("CDX_UNET2_T")
+    assert torch.equal(x1, x3)
+    from cleandiffuser_amd.engine import dispatch
+    monkeypatch.setattr(dispatch, "try_fused_edm", lambda *a, **k: None)
+    monkeypatch.setattr(dispatch, "try_backbone_forward", lambda *a, **k: None)
+    xs, _ = agent.sample(prior[-4:].to(DEV), noise=[zs[0][-4:]], **dict(kw, n_samples=4))
+    np.testing.assert_allclose(x3[-4:].cpu().numpy(), xs.cpu().numpy(), **TOL)
 
 
 def test_janner_forward_with_condition_and_per_sample_timesteps_is_one_v2_launch(amd_lib, monkeypatch):
