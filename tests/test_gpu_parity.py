@@ -1103,7 +1103,7 @@ def test_fused_adamw_matches_torch_adamw_over_ten_steps():
     sd_a = opt_a.state_dict()                       # (refreshes the per-parameter `step` tensors from the python-side counters)
     for (n, p), q, ea, eb in zip(net_a.named_parameters(), net_b.parameters(), ema_a.parameters(), ema_b.parameters()):
         scale = float(q.detach().abs().max()) + 1e-12
-        assert float((p - q).abs().max()) <= 1e-6 * max(scale, 1.0), n
+        assert float((p.detach() - q.detach()).abs().max()) <= 1e-6 * max(scale, 1.0), n
         assert float((ea - eb).abs().max()) <= 1e-6 * max(scale, 1.0), n
         sa, sb = opt_a.state[p], opt_b.state[q]
         assert float(sa["step"]) == float(sb["step"]) == 10.0
