@@ -1335,3 +1335,59 @@ def test_janner_linear_attention_runs_on_the_gemm_executor(amd_lib, monkeypatch)
     assert [c[0] for c in calls] == ["chiunet", "chiunet"] and fused["n"] == 0, (calls, fused)
     for k in gold.files:
         np.testing.assert_allclose(out[k].cpu().numpy(), gold[k], err_msg=k, **TOL)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_conditional_v2_requests_match_the_torch_executor_on_random_configurations(seed, amd_lib, monkeypatch):
+    """Shapes / solvers the fixtures do not enumerate: a random JannerUNet1d (horizon, widths, kernel size), a random solver class and
+    solver, condition embedding with w_cfg in {1, pair}, random batch (odd sizes: half-empty workgroups) -- the ONE cdx_unet2_run launch
+    against this repo's PyTorch executor on the same device and draws (2e-4: two implementations, summation-order noise on both sides)."""
+    import random
+    rnd = random.Random(1000 + seed)
+    from cleandiffuser_amd.utils import load_synth
+    H = rnd.choice([4, 8, 16, 32, 64])
+    D = rnd.choice([3, 6, 11, 23])
+    md = rnd.choice([16, 32])
+    mult = rnd.choice([[1, 2], [1, 2, 2], [1, 4, 2]])
+    while H % (1 << (len(mult) - 1)):
+        mult = mult[:-1]
+    ks = rnd.choice([3, 5])
+    emb = rnd.choice([16, 32])
+    net = load_synth(amd_lib.JannerUNet1d(D, model_dim=md, emb_dim=emb, dim_mult=mult, kernel_size=ks), 100 + seed)
+    B = rnd.choice([1, 2, 3, 5, 9, 257, 300, 513, 601])
+    pn = rnd.random() < 0.5
+    lim = 3.0 * torch.ones(1, H, D)
+    fm = torch.zeros(H, D)
+    fm[0, : max(1, D // 2)] = 1.0
+    kind = rnd.choice(["disc", "cont", "edm"])
+    w_cfg = rnd.choice([1.0, 1.0, 1.6, 0.3])
+    g = torch.Generator().manual_seed(seed)
+    if kind == "edm":
+        agent = amd_lib.ContinuousEDM(net, amd_lib.IdentityCondition(dropout=0.0), fix_mask=fm, x_max=lim, x_min=-lim, device=DEV)
+        kw = dict(solver=rnd.choice(["euler", "heun"]), sample_steps=rnd.choice([3, 5]))
+    else:
+        cls = amd_lib.DiscreteDiffusionSDE if kind == "disc" else amd_lib.ContinuousDiffusionSDE
+        extra = dict(diffusion_steps=20) if kind == "disc" else {}
+        agent = cls(net, amd_lib.IdentityCondition(dropout=0.0), fix_mask=fm, predict_noise=pn, x_max=lim, x_min=-lim, device=DEV, **extra)
+        kw = dict(solver=rnd.choice(["ddpm", "ddim", "ode_dpmsolver_1", "ode_dpmsolver++_1", "ode_dpmsolver++_2M", "sde_dpmsolver_1",
+                                     "sde_dpmsolver++_1", "sde_dpmsolver++_2M"]), sample_steps=rnd.choice([3, 5]), temperature=0.8)
+    agent.eval()
+    prior = torch.zeros(B, H, D)
+    prior[:, 0] = torch.randn(B, D, generator=g)
+    cond = torch.randn(B, emb, generator=g).to(DEV)
+    zs = [torch.randn(B, H, D, generator=g).to(DEV) for _ in range(12)]
+    kw.update(n_samples=B, condition_cfg=cond, w_cfg=w_cfg)
+    calls = _spy_launches(monkeypatch)
+    x, _ = agent.sample(prior.to(DEV), noise=zs, **kw)
+    torch.cuda.synchronize()
+    from cleandiffuser_amd.engine import runtime2
+    if runtime2.supported(net, H) is None:
+        assert calls["v2"] >= 1 and calls["n"] == calls["v2"], (calls, H, D, md, mult, ks, kind, kw)
+    from cleandiffuser_amd.engine import dispatch
+    for fn in ("try_fused_sample", "try_fused_edm", "try_backbone_forward"):
+        monkeypatch.setattr(dispatch, fn, lambda *a, **k: None)
+    n = min(B, 6)
+    xs, _ = agent.sample(prior[-n:].to(DEV), noise=[z[-n:] for z in zs], **dict(kw, n_samples=n, condition_cfg=cond[-n:]))
+    scale = max(1.0, float(xs.abs().max()))
+    np.testing.assert_allclose(x[-n:].cpu().numpy() / scale, xs.cpu().numpy() / scale, rtol=2e-4, atol=2e-4,
+                               err_msg=str((H, D, md, mult, ks, emb, B, pn, kind, kw["solver"], w_cfg)))
