@@ -387,6 +387,55 @@ def janner_attention():
 SCENARIOS["janner_attention"] = janner_attention()
 
 
+def chitransformer_pusht_full():
+    """Diffusion Policy's transformer at the dp_pusht size AND step count (tools/bench_configs.py cfgT: d_model 256, 4 heads, 8 decoder
+    layers, Ta = 16, To = 2, obs 20; 100-step DDPM over DiscreteDiffusionSDE, w_cfg = 1), B = 2."""
+    B, steps = 2, 100
+
+    def run(lib, kind, device):
+        net = load_synth(lib.ChiTransformer(2, 20, 16, 2, d_model=256, nhead=4, num_layers=8), 91)
+        one = torch.ones(1, 16, 2)
+        agent = lib.DiscreteDiffusionSDE(net, lib.IdentityCondition(dropout=0.0), predict_noise=True, x_max=one, x_min=-one,
+                                         diffusion_steps=steps, device=device)
+        agent.eval()
+        g = torch.Generator().manual_seed(91)
+        obs = torch.randn(B, 2, 20, generator=g)
+        zs = [torch.randn(B, 16, 2, generator=g) for _ in range(steps + 1)]
+        x, _ = _sample(agent, kind, torch.zeros(B, 16, 2, device=device), zs, solver="ddpm", n_samples=B, sample_steps=steps,
+                       condition_cfg=obs.to(device), w_cfg=1.0)
+        return {"x": x}
+    return run
+
+
+def shipped_diffuser_full_steps(size: str):
+    """The shipped kitchen / antmaze Diffuser sizes at the shipped sampling setting: 20-step DDPM with classifier guidance and the final
+    log_p (configs/diffuser/{kitchen,antmaze}: solver ddpm, sampling_steps 20), B = 3 -- `shipped_diffuser` above stops after 3 steps."""
+    H, D, n_obs = (32, 69, 60) if size == "kitchen" else (64, 37, 29)
+    B, steps = 3, 20
+
+    def run(lib, kind, device):
+        net = load_synth(lib.JannerUNet1d(D, model_dim=64, emb_dim=64, dim_mult=[1, 2, 2, 2], kernel_size=5), 21)
+        clf_net = load_synth(lib.HalfJannerUNet1d(H, D, out_dim=1, model_dim=64, emb_dim=64, dim_mult=(1, 2, 2, 2), kernel_size=3), 22)
+        fm = torch.zeros(H, D)
+        fm[0, :n_obs] = 1.0
+        agent = lib.DiscreteDiffusionSDE(net, None, fix_mask=fm, classifier=lib.CumRewClassifier(clf_net, device=device),
+                                         diffusion_steps=steps, predict_noise=False, device=device)
+        agent.eval()
+        agent.classifier.eval()
+        g = torch.Generator().manual_seed(6)
+        prior = torch.zeros(B, H, D)
+        prior[:, 0, :n_obs] = torch.randn(B, n_obs, generator=g)
+        zs = [torch.randn(B, H, D, generator=g) for _ in range(steps + 1)]
+        xg, log = _sample(agent, kind, prior.to(device), zs, solver="ddpm", n_samples=B, sample_steps=steps, temperature=0.5, w_cg=0.05,
+                          condition_cg=None)
+        return {"x_guided": xg, "log_p": log["log_p"]}
+    return run
+
+
+SCENARIOS.update({"chitf_pusht_full": chitransformer_pusht_full(), "diffuser_kitchen_20": shipped_diffuser_full_steps("kitchen"),
+                  "diffuser_antmaze_20": shipped_diffuser_full_steps("antmaze")})
+
+
 def run(name: str, lib_kind: str, device="cpu"):
     """Outputs of scenario `name` as {key: tensor}; keys starting with '_' are live objects for the caller, not results."""
     torch.manual_seed(1234)

@@ -14,6 +14,6 @@ def test_cpu_executor_reproduces_extra_reference_fixture(name):
     out = extra_cases.run(name, "amd", "cpu")
     assert set(gold.files) == {k for k in out if not k.startswith("_")}
     # 20 guided steps through autograd's conv backward (threaded, order not fixed): 4.8e-6 observed against the reference's own run
-    tol = 2e-5 if name == "baseline_cfg2_guided" else 2e-6
+    tol = 2e-5 if name in ("baseline_cfg2_guided", "diffuser_kitchen_20", "diffuser_antmaze_20") else 2e-6
     for k in gold.files:
         np.testing.assert_allclose(out[k].detach().numpy(), gold[k], rtol=tol, atol=tol, err_msg=f"{name}/{k}")

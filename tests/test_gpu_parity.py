@@ -1391,3 +1391,19 @@ def test_conditional_v2_requests_match_the_torch_executor_on_random_configuratio
     scale = max(1.0, float(xs.abs().max()))
     np.testing.assert_allclose(x[-n:].cpu().numpy() / scale, xs.cpu().numpy() / scale, rtol=2e-4, atol=2e-4,
                                err_msg=str((H, D, md, mult, ks, emb, B, pn, kind, kw["solver"], w_cfg)))
+
+
+@pytest.mark.parametrize("name", ["chitf_pusht_full", "diffuser_kitchen_20", "diffuser_antmaze_20"])
+def test_full_step_count_configurations_match_reference_fixture(name, amd_lib, monkeypatch):
+    """Step counts the earlier fixtures cut short: Diffusion Policy's transformer at the dp_pusht size over all 100 DDPM steps, and the
+    shipped kitchen / antmaze Diffuser sizes over their 20 guided DDPM steps with the final log_p -- each one native call (cdx_chitf_run /
+    one guided cdx_unet2_run launch including log_p), reference fixtures, 1e-4."""
+    fused, big = _spy_launches(monkeypatch), _spy_bigbatch(monkeypatch)
+    out, gold = _extra(name)
+    torch.cuda.synchronize()
+    if name == "chitf_pusht_full":
+        assert [c[0] for c in big] == ["chitf"] and fused["n"] == 0
+    else:
+        assert (fused["n"], fused["v2"], len(big)) == (1, 1, 0), (fused, big)
+    for k in gold.files:
+        np.testing.assert_allclose(out[k].cpu().numpy(), gold[k], err_msg=f"{name}/{k}", **TOL)
