@@ -1465,7 +1465,7 @@ long long cdx_guided_workspace_floats(const cdx_guided_launch* g) {
         if (den < 0) return -1;
         den = (den + 63) & ~63LL;
     }
-    return clf + den + 4 * state + (((long long)g->batch * g->classifier->out_dim + 63) & ~63LL);     // x, pred, prev, grad, logp
+    return clf + den + 6 * state + (((long long)g->batch * g->classifier->out_dim + 63) & ~63LL);     // x, pred, prev, grad, x_old, c_in x, logp
 }
 
 int cdx_guided_run(const cdx_guided_launch* g, void* hip_stream) {
@@ -1486,17 +1486,23 @@ int cdx_guided_run(const cdx_guided_launch* g, void* hip_stream) {
         CDX_TRY(chiunet_check(g->denoiser_gemm, &S));
     }
     if (g->fix_mask && !g->prior) { cdx_set_err("cdx_guided_run: fix_mask given without prior"); return CDX_EINVAL; }
-    for (int i = 0; i < g->n_steps; ++i)
-        if (g->steps[i].kind < 0 || g->steps[i].kind > 2 || (g->steps[i].noise_idx >= 0 && !g->noise)) {
-            cdx_set_err("cdx_guided_run: step kinds 0-2 only; stochastic steps need the noise tensor"); return CDX_EINVAL;
+    // step kinds 0-2, or an all-EDM plan (kinds 5 / 6: classifier guidance under ContinuousEDM, reference newedm.py:217-284 -- the
+    // prediction D = c_skip x + c_out F is shifted by w sigma^2 grad, i.e. F by cg_scale = w sigma^2 / c_out; the network sees c_in x,
+    // the classifier x itself)
+    const bool edm = g->steps[0].kind >= 5;
+    for (int i = 0; i < g->n_steps; ++i) {
+        const int kd = g->steps[i].kind;
+        if (kd < 0 || (kd > 2 && kd != 5 && kd != 6) || (kd >= 5) != edm || (g->steps[i].noise_idx >= 0 && !g->noise)) {
+            cdx_set_err("cdx_guided_run: step kinds 0-2 or an all-EDM plan (5 / 6); stochastic steps need the noise tensor"); return CDX_EINVAL;
         }
+    }
     if (g->batch == 0) return CDX_OK;
     const long long need = cdx_guided_workspace_floats(g);
     if (!g->workspace || g->workspace_floats < need) { cdx_set_err("cdx_guided_run: workspace too small"); return CDX_EINVAL; }
     hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
     Arena a{g->workspace, 0, 0};
     const long long n = (long long)g->batch * g->hd;
-    float *x = a.take(n), *pred = a.take(n), *prev = a.take(n), *grad = a.take(n);
+    float *x = a.take(n), *pred = a.take(n), *prev = a.take(n), *grad = a.take(n), *xold = a.take(n), *xs = a.take(n);
     float* logp = a.take((long long)g->batch * g->classifier->out_dim);
     float* den_ws = nullptr;
     long long den_floats = 0;
@@ -1525,8 +1531,10 @@ int cdx_guided_run(const cdx_guided_launch* g, void* hip_stream) {
     };
 #define CDX_TRY_SIDE(expr) do { const int rc_ = (expr); if (rc_ != CDX_OK) return bail(rc_); } while (0)
     for (int i = 0; i < g->n_steps; ++i) {
+        const float* xnet = x;                          // what the denoiser sees: x_t, or c_in x_t under EDM
+        if (edm) CDX_TRY(scaled_input(st, xnet, xs, g->steps[i].alpha, (size_t)n));
         if (g->denoiser_gemm) {
-            const cdx_sampling S = guided_gemm_request(g, i, x, pred, den_ws, den_floats);
+            const cdx_sampling S = guided_gemm_request(g, i, xnet, pred, den_ws, den_floats);
             int rcg;
             chiunet_pass(g->denoiser_gemm, &S, st, den_ws, false, &rcg);
             CDX_TRY(rcg);
@@ -1535,7 +1543,7 @@ int cdx_guided_run(const cdx_guided_launch* g, void* hip_stream) {
         if (g->denoiser) {
             L = *g->denoiser;
             L.n_steps = 0; L.steps = nullptr; L.temb_per_sample = 0; L.batch = g->batch;
-            L.temb = g->temb + (size_t)i * L.emb_dim; L.x_in = x; L.x_out = pred;
+            L.temb = g->temb + (size_t)i * L.emb_dim; L.x_in = xnet; L.x_out = pred;
         }
         if (g->denoiser_gemm) {
         } else if (side) {
@@ -1550,7 +1558,7 @@ int cdx_guided_run(const cdx_guided_launch* g, void* hip_stream) {
         if (side && hipStreamWaitEvent(st, side->join, 0) != hipSuccess) return bail(hip_ok());      // join even when the classifier failed
         CDX_TRY_SIDE(clf_rc);
         StepArgs sa;
-        sa.x = x; sa.pred = pred; sa.prev = prev; sa.xold = nullptr; sa.prior = g->prior; sa.fix_mask = g->fix_mask;
+        sa.x = x; sa.pred = pred; sa.prev = prev; sa.xold = xold; sa.prior = g->prior; sa.fix_mask = g->fix_mask;
         sa.noise = g->noise; sa.x_min = g->x_min; sa.x_max = g->x_max; sa.st = g->steps[i]; sa.nb = g->batch; sa.hd = g->hd;
         sa.b0 = 0; sa.batch = g->batch; sa.predict_noise = g->predict_noise; sa.cfg_mode = 0; sa.cfg_w = 0.f;
         sa.grad = grad; sa.cg_scale = g->cg_scale[i];

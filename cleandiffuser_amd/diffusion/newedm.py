@@ -150,7 +150,8 @@ class ContinuousEDM(DiffusionModel):
             from ..engine.plan import build_edm_plan
             plan = self._cached_plan((solver, sample_steps, diffusion_x_sampling_steps, float(top_sigma)), lambda: build_edm_plan(
                 self.sigma_data, self.sigma_min, top_sigma, self.rho, sample_steps, solver, diffusion_x_sampling_steps))
-            fused = dispatch.try_fused_edm(self, model, plan, xt, prior, cond_cfg, w_cfg, w_cg, requires_grad, feed)
+            fused = dispatch.try_fused_edm(self, model, plan, xt, prior, cond_cfg, w_cfg, w_cg, requires_grad, feed,
+                                           condition_cg=condition_cg)
             if fused is not None:
                 return self._finish_sample(fused, n_samples, condition_cg, log)
 

@@ -82,12 +82,15 @@ def try_fused_raw(solver, model, plan, z, temperature, prior, feed):
     return runtime.fused_sample(solver, model, plan, z, prior, None, 0.0, feed, x_scale=float(temperature))
 
 
-def try_fused_edm(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, requires_grad, feed):
-    """``ContinuousEDM.sample``: big-batch executors for the GEMM-shaped backbones, the program kernel for the rest."""
+def try_fused_edm(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, requires_grad, feed, condition_cg=None):
+    """``ContinuousEDM.sample``: big-batch executors for the GEMM-shaped backbones, the program kernel for the rest.  Classifier
+    guidance (reference newedm.py:217-234: only with a classifier, w_cg != 0 AND a condition_cg) goes through the per-step guided
+    executor; without a condition_cg the reference applies no shift, so the request is an unguided one."""
     if not _on_gpu(xt) or requires_grad or xt.dtype != torch.float32:
         return None
-    if w_cg != 0.0 and solver.classifier is not None:
-        return None
+    if w_cg != 0.0 and solver.classifier is not None and condition_cg is not None:
+        from . import guided
+        return guided.guided_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, feed)
     from . import bigbatch, runtime
     net = model["diffusion"]
     if bigbatch.is_resmlp(net) or bigbatch.is_dit1d(net) or bigbatch.is_chitf(net) or bigbatch.is_dit1ref(net) or bigbatch.is_pearcetf(net):

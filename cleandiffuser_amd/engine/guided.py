@@ -48,8 +48,10 @@ def guided_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, feed) -
     from ..classifier.rew_classifiers import CumRewClassifier
     from ..nn_classifier.half_jannerunet import HalfJannerUNet1d
     from ..diffusion.diffusionsde import BaseDiffusionSDE
+    from ..diffusion.newedm import ContinuousEDM
     net, clf = model["diffusion"], solver.classifier
-    if not isinstance(solver, BaseDiffusionSDE):        # the legacy classes shift the prediction after their own conversions
+    edm = type(solver) is ContinuousEDM and runtime.plan_is_edm(plan)
+    if not (isinstance(solver, BaseDiffusionSDE) or edm):        # the legacy classes shift the prediction after their own conversions
         return None
     if xt.dim() != 3 or type(clf) is not CumRewClassifier or type(clf.model_ema) is not HalfJannerUNet1d:
         return None
@@ -66,7 +68,12 @@ def guided_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, feed) -
         gemm_bound = bigbatch._bound(net, ("chiunet", h), lambda: bigbatch._bind_janner_gemm(net, h, xt.device))
         if gemm_bound is None or d != gemm_bound.struct.act_dim:
             return None
-    if any(st.kind > 2 for st in plan.steps) or (cond_vec is not None and w_cfg not in (0.0, 1.0)):
+    if edm:
+        if any(st.kind not in (5, 6) for st in plan.steps):              # (consistency records have no guided form)
+            return None
+    elif any(st.kind > 2 for st in plan.steps):
+        return None
+    if cond_vec is not None and w_cfg not in (0.0, 1.0):
         return None
     if clf.model_ema.horizon != h or clf.model_ema.in_dim != d:
         return None
@@ -81,7 +88,7 @@ def guided_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, feed) -
         x_max = _dense_hd(getattr(solver, "x_max", None), h, d, dev) if clip else None
     except ValueError:
         return None
-    if (cond_vec is None or w_cfg == 0.0) and runtime._is_janner(net):
+    if (cond_vec is None or w_cfg == 0.0) and runtime._is_janner(net) and not edm:
         # unconditional temporal U-Net: the classifier's forward + backward joins the denoiser in the second-generation kernel --
         # the whole guided loop is one launch instead of ~105 launches per step
         from . import runtime2
@@ -102,7 +109,10 @@ def guided_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, feed) -
         temb = _f32c(net.map_noise(t_vec), dev)
         clf_emb0 = _f32c(clf.model_ema.map_noise(t_vec), dev)
         pn = _predicts_noise(plan, solver)
-        scale = [(-(w_cg * st.sigma)) if pn else (w_cg * ((st.sigma ** 2) / st.alpha)) for st in plan.steps]
+        if edm:       # D + w sigma^2 grad (reference newedm.py:230) as a shift of the raw network output: (w sigma^2 / c_out) grad
+            scale = [w_cg * (st.k[2] ** 2) / st.k[1] for st in plan.steps]
+        else:
+            scale = [(-(w_cg * st.sigma)) if pn else (w_cg * ((st.sigma ** 2) / st.alpha)) for st in plan.steps]
         cg = (ctypes.c_float * len(scale))(*[float(np.float32(v)) for v in scale])
         steps = host_steps(plan)
         noise = feed.many(xt, plan.n_noise)

@@ -436,6 +436,38 @@ SCENARIOS.update({"chitf_pusht_full": chitransformer_pusht_full(), "diffuser_kit
                   "diffuser_antmaze_20": shipped_diffuser_full_steps("antmaze")})
 
 
+def edm_classifier_guidance():
+    """Classifier guidance under ContinuousEDM (reference newedm.py:217-284): D + w sigma^2 grad at every network evaluation of a Heun
+    loop (predictor and corrector), the classifier fed (x_t, ln(sigma) / 4); with condition_cg = None the reference applies NO shift but
+    still scores the result -- both variants, plus the final log_p at sigma_min."""
+    B, H, D, steps = 3, 8, 6, 4
+
+    def run(lib, kind, device):
+        net = load_synth(lib.JannerUNet1d(D, model_dim=16, emb_dim=16, dim_mult=[1, 2], kernel_size=5), 95)
+        clf_net = load_synth(lib.HalfJannerUNet1d(H, D, out_dim=1, model_dim=16, emb_dim=16, dim_mult=(1, 2), kernel_size=3), 96)
+        fm = torch.zeros(H, D)
+        fm[0, :4] = 1.0
+        lim = 2.0 * torch.ones(1, H, D)
+        agent = lib.ContinuousEDM(net, None, fix_mask=fm, classifier=lib.CumRewClassifier(clf_net, device=device), x_max=lim, x_min=-lim,
+                                  device=device)
+        agent.eval()
+        agent.classifier.eval()
+        g = torch.Generator().manual_seed(95)
+        prior = torch.zeros(B, H, D)
+        prior[:, 0, :4] = torch.randn(B, 4, generator=g)
+        zs = [torch.randn(B, H, D, generator=g)]
+        kw = dict(n_samples=B, sample_steps=steps)
+        xg, lg = _sample(agent, kind, prior.to(device), zs, solver="heun", w_cg=0.3, condition_cg=torch.ones(B, 1, device=device), **kw)
+        xe, le = _sample(agent, kind, prior.to(device), zs, solver="euler", w_cg=0.5, condition_cg=torch.ones(B, 1, device=device),
+                         diffusion_x_sampling_steps=1, **kw)
+        xn, ln = _sample(agent, kind, prior.to(device), zs, solver="heun", w_cg=0.3, condition_cg=None, **kw)
+        return {"x_heun": xg, "logp_heun": lg["log_p"], "x_euler": xe, "logp_euler": le["log_p"], "x_nocond": xn, "logp_nocond": ln["log_p"]}
+    return run
+
+
+SCENARIOS["edm_classifier_guidance"] = edm_classifier_guidance()
+
+
 def run(name: str, lib_kind: str, device="cpu"):
     """Outputs of scenario `name` as {key: tensor}; keys starting with '_' are live objects for the caller, not results."""
     torch.manual_seed(1234)
