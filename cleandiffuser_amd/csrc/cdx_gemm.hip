@@ -552,8 +552,8 @@ __global__ __launch_bounds__(256) void cdx_groupnorm_kernel(const cdx_gn_args a)
 
 // float4 variant: C/G, every leading dimension and the FiLM strides multiples of 4, 16-byte aligned bases, the group's values in
 // registers (L * C/G <= 2048).  A lane owns 4 consecutive channels of a position: x, gamma, beta, the FiLM rows, the residual and y move
-// as dwordx4 (the scalar kernel issues ~8 dword loads per element: measured 1.9 TB/s on the config-3 tensors).  Same arithmetic: mean,
-// then the centred sum of squares, over the same values.
+// as dwordx4 (the scalar kernel issues ~8 dword loads per element: measured 1.9 TB/s on the config-3 tensors).  Mean, then the centred
+// sum of squares, accumulated in float64.
 #define GN_VREGS 8
 __global__ __launch_bounds__(256) void cdx_groupnorm_vec_kernel(const cdx_gn_args a) {
     const int lane = threadIdx.x & 63;
@@ -565,7 +565,8 @@ __global__ __launch_bounds__(256) void cdx_groupnorm_vec_kernel(const cdx_gn_arg
     const float* xb = a.x + (size_t)b * a.L * a.ldx + grp * cg;
     float4 v[GN_VREGS];
     int l_of[GN_VREGS], c_of[GN_VREGS];
-    float s = 0.f;
+    double s = 0.0;        // statistics in float64: the kernel is memory-bound, and the executor's deviation from the reference then is
+                           // the reference's own fp32 rounding alone (a clipped eps-prediction loop amplifies every ulp of it)
 #pragma unroll
     for (int i = 0; i < GN_VREGS; ++i) {
         const int e = lane + 64 * i;
@@ -577,22 +578,23 @@ __global__ __launch_bounds__(256) void cdx_groupnorm_vec_kernel(const cdx_gn_arg
             x = *reinterpret_cast<const float4*>(xb + (size_t)l * a.ldx + c);
         }
         v[i] = x; l_of[i] = l; c_of[i] = c;
-        s += (x.x + x.y) + (x.z + x.w);
+        s += ((double)x.x + (double)x.y) + ((double)x.z + (double)x.w);
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
-    const float mean = s / (float)n;
-    float s2 = 0.f;
+    const double mean_d = s / (double)n;
+    const float mean = (float)mean_d;
+    double s2 = 0.0;
 #pragma unroll
     for (int i = 0; i < GN_VREGS; ++i) {
         if (lane + 64 * i < n4) {
-            const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
+            const double d0 = (double)v[i].x - mean_d, d1 = (double)v[i].y - mean_d, d2 = (double)v[i].z - mean_d, d3 = (double)v[i].w - mean_d;
             s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
         }
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o, 64);
-    const float rstd = 1.0f / sqrtf(s2 / (float)n + a.eps);
+    const float rstd = (float)(1.0 / sqrt(s2 / (double)n + (double)a.eps));
     const float* fa = a.fa ? a.fa + (size_t)(a.fa_per_sample ? b : a.fa_row) * a.ldfa : nullptr;
     const float* fb = a.fb ? a.fb + (size_t)b * a.ldfb : nullptr;
     auto ld4 = [](const float* p) { return *reinterpret_cast<const float4*>(p); };
