@@ -600,11 +600,24 @@ CHUNK_OVERRIDE = {"dit": int(os.environ.get("CDX_DIT_CHUNK", 0)) or None,      #
 # ChiUNet1d has two native executors: the one-workgroup-per-trajectory program kernel (weights re-streamed by every CU) and the
 # implicit-GEMM executor (weights shared by all rows).  The GEMM one wins once batch x length fills the 128 x 128 tiles.
 UNET_GEMM_MIN_BATCH = int(os.environ.get("CDX_UNET_GEMM_MIN_BATCH", 96))   # measured: 1.45x at B=128, 1.18x at 256, 2.1x at 1024
+# ... and, at ANY batch, once the net is large: the program kernel's step time is the weight stream of one CU (~13 us per MB: 3.7 ms
+# per step for the 275 MB config-3 net, whatever the batch), the executor's is ~0.55 ms of dependent launches plus one pass over
+# the weights for the whole batch.  Measured (round 3, profiles/r03_chiunet_small_batch.txt), 50-step DDPM at B = 8 / 32 / 64:
+# model_dim 256 (68.9 M parameters) 190 / 181 / 178 ms on the program kernel vs 50 / 52 / 60 ms here; model_dim 64 (4.3 M) 16.5 vs
+# 33 ms; model_dim 32 (1.1 M) 10 vs 28 ms -- the crossover sits near 10 M parameters.
+UNET_GEMM_MIN_PARAMS = int(float(os.environ.get("CDX_UNET_GEMM_MIN_PARAMS", 10e6)))
 
 
 # JannerUNet1d's channels are narrow (32..256): its GEMM tiles are mostly padding, so the program kernel keeps small and medium
 # batches and the GEMM executor only takes over where weight re-streaming dominates (measured crossover, tools/bench_configs.py).
 JANNER_GEMM_MIN_BATCH = int(os.environ.get("CDX_JANNER_GEMM_MIN_BATCH", 2048))   # config-2 net: 0.39x at 256, 0.89x at 1024, 1.16x at 3200
+
+
+def _n_params(module) -> int:
+    n = module.__dict__.get("_cdx_n_params")
+    if n is None:
+        n = module.__dict__["_cdx_n_params"] = sum(p.numel() for p in module.parameters())
+    return n
 
 
 def is_chiunet_gemm(module, batch: int, horizon: Optional[int] = None, edm: bool = False, forward: bool = False) -> bool:
@@ -630,7 +643,7 @@ def is_chiunet_gemm(module, batch: int, horizon: Optional[int] = None, edm: bool
     elif type(module) is ChiUNet1d and not module.obs_as_global_cond:
         return True                                     # local conditioning: the executor is its only native path
     elif type(module) is ChiUNet1d and module.obs_as_global_cond:
-        big = batch >= UNET_GEMM_MIN_BATCH
+        big = batch >= UNET_GEMM_MIN_BATCH or _n_params(module) >= UNET_GEMM_MIN_PARAMS
     else:
         return False
     if big or horizon is None:

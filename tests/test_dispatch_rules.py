@@ -12,6 +12,11 @@ def test_unet_executor_choice(monkeypatch):
     chi_local = ChiUNet1d(2, 5, 1, model_dim=32, emb_dim=32, dim_mult=[1, 2], obs_as_global_cond=False)
     assert not bigbatch.is_chiunet_gemm(janner, 256) and bigbatch.is_chiunet_gemm(janner, bigbatch.JANNER_GEMM_MIN_BATCH)
     assert not bigbatch.is_chiunet_gemm(chi, 8) and bigbatch.is_chiunet_gemm(chi, bigbatch.UNET_GEMM_MIN_BATCH)
+    # a large net goes to the GEMM executor at every batch: the program kernel would re-stream its weights per trajectory
+    monkeypatch.setattr(bigbatch, "UNET_GEMM_MIN_PARAMS", sum(p.numel() for p in chi.parameters()))
+    assert bigbatch.is_chiunet_gemm(chi, 8)
+    monkeypatch.setattr(bigbatch, "UNET_GEMM_MIN_PARAMS", 10 ** 7)
+    assert not bigbatch.is_chiunet_gemm(chi, 8)
     # local conditioning: the implicit-GEMM executor is its only native path, at every batch size
     assert bigbatch.is_chiunet_gemm(chi_local, 1) and bigbatch.is_chiunet_gemm(chi_local, 10 ** 6)
     assert not bigbatch.is_chiunet_gemm(DiT1d(4, 8, d_model=16, n_heads=2, depth=1), 10 ** 6)

@@ -34,8 +34,8 @@ def cfg1():
     return "config 1: PearceMlp DDPM act=6 obs=17, 100 steps, B=256", call, B, 100, net, P_TILE
 
 
-def cfg3(B=1024):
-    net = load_synth(ChiUNet1d(2, 20, 2, model_dim=256, emb_dim=256, dim_mult=[1, 2, 2], obs_as_global_cond=True))
+def cfg3(B=1024, dim=256):
+    net = load_synth(ChiUNet1d(2, 20, 2, model_dim=dim, emb_dim=dim, dim_mult=[1, 2, 2], obs_as_global_cond=True))
     agent = DDPM(net, IdentityCondition(dropout=0.0), diffusion_steps=50, x_max=torch.ones(1, 16, 2, device=DEV),
                  x_min=-torch.ones(1, 16, 2, device=DEV), device=DEV)
     agent.eval()
@@ -43,7 +43,8 @@ def cfg3(B=1024):
     zs = [torch.randn(B, 16, 2, device=DEV) for _ in range(50)]
     call = lambda: agent.sample(torch.zeros(B, 16, 2, device=DEV), n_samples=B, sample_steps=50,  # noqa: E731
                                 condition_cfg=cond, w_cfg=1.0, noise=zs)[0]
-    return f"config 3: ChiUNet1d dp_pusht H=16 act=2 obs=20, 50-step legacy DDPM, B={B}", call, B, 50, net, 16
+    tag = "" if dim == 256 else f" (model_dim {dim})"
+    return f"config 3: ChiUNet1d dp_pusht H=16 act=2 obs=20, 50-step legacy DDPM, B={B}{tag}", call, B, 50, net, 16
 
 
 from cleandiffuser_amd.engine.program import MLP_TILE as P_TILE  # noqa: E402
@@ -247,5 +248,6 @@ if __name__ == "__main__":
             run_big(name, {"cfg4": cfg4, "cfg5": cfg5, "cfg2g": cfg2g, "cfg2big": cfg2big, "cfgT": cfgT, "cfgKg": cfgKg, "cfgAg": cfgAg, "cfgAu": cfgAu}[base],
                     **({"B": int(b)} if b else {}), **({"steps": int(st)} if st else {}))
         else:
-            base, _, b = name.partition(":")
-            run(name, {"cfg1": cfg1, "cfg3": cfg3}[base], **({"B": int(b)} if b else {}))
+            base, _, b = name.partition(":")                        # cfg3:64:32 = batch 64, model_dim 32
+            b, _, dim = b.partition(":")
+            run(name, {"cfg1": cfg1, "cfg3": cfg3}[base], **({"B": int(b)} if b else {}), **({"dim": int(dim)} if dim else {}))
