@@ -69,3 +69,4 @@
 #define CDX2_F2_GNBWD 32     /* epilogue = backward of (GroupNorm -> Mish) of the layer named by W2_SAVE / W2_STATS */
 #define CDX2_F2_DUAL 64      /* ... and the value before that backward goes to W2_DST2 */
 #define CDX2_F2_SAVE_GLOBAL 128   /* W2_SAVE is a float offset inside the trajectory's block of cdx_unet2_launch.ws, not an LDS slot */
+#define CDX2_F2_FILM 256     /* with F2_EMB: the table row holds [scale | bias] (2 x W2_COUTP floats) at W2_EMB: y <- scale * y + bias */

@@ -415,7 +415,7 @@ __device__ __forceinline__ EpiDesc decode_epi(int vd) {
     return e;
 }
 
-struct EpiParams { f32x4 bi, ga, be, em, pb; };      // bias, gamma, beta, FiLM vector, bias of the post-norm extra conv
+struct EpiParams { f32x4 bi, ga, be, em, pb, sc; };  // bias, gamma, beta, FiLM vector, bias of the post-norm extra conv, FiLM scale (F2_FILM, COND kernels)
 
 // two half-wave sums at once (the DPP chains of a and b interleave, so the second one is almost free)
 __device__ __forceinline__ void half_sum2(float& a, float& b, int lane) {
@@ -436,7 +436,7 @@ __device__ __forceinline__ void half_sum2(float& a, float& b, int lane) {
 // channels c..c+3 of position pos0 + k * pstep.  NK = items per lane (compile-time so the values stay in registers).
 // GroupNorm statistics in ONE cross-lane round: sums of (x - s) and (x - s)^2 with s = the group's first element (no E[x^2] -
 // E[x]^2 cancellation; the second dependent reduction of a two-pass scheme is ~150 cycles of pure latency per op).
-template <int NK, bool BWD>
+template <int NK, bool BWD, bool COND = false>
 __device__ __forceinline__ void epilogue(float* __restrict__ tl, const EpiParams& P, const EpiDesc& e, int stage, int c, int pos0,
                                          int pstep, int li, int nv, int lane, int grp, float* __restrict__ ws) {
     f32x4 v[NK];
@@ -499,7 +499,11 @@ __device__ __forceinline__ void epilogue(float* __restrict__ tl, const EpiParams
         if (!ok[k]) continue;
         const int pos = pos0 + k * pstep;
         f32x4 y = v[k];
-        if (e.flags & CDX2_F2_EMB) y += P.em;
+        if (COND && (e.flags & CDX2_F2_FILM)) {
+            // ChiUNet1d's FiLM (reference chiunet.py:41-45: scale * h + bias, two ATen ops): two roundings, no fma contraction
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = __fadd_rn(__fmul_rn(P.sc[j], y[j]), P.em[j]);
+        } else if (e.flags & CDX2_F2_EMB) y += P.em;
         if (e.kpost) {
             // the ResidualBlock's 1x1 skip conv (reference jannerunet.py:58, :69) was computed by other waves of this op: bias + its
             // partial tiles, added after the norm / activation
@@ -687,10 +691,12 @@ __device__ __forceinline__ EpiParams load_params(const cdx_unet2_launch& L, int 
         P.pb = *reinterpret_cast<const f32x4*>(CDX2_DW(vd, CDX2_W2_KPOST) ? L.wblob + CDX2_DW(vd, CDX2_W2_PBIAS) + c : pbi);
         P.ga = *reinterpret_cast<const f32x4*>(gn ? L.wblob + CDX2_DW(vd, CDX2_W2_GAMMA) + c : pbi);
         P.be = *reinterpret_cast<const f32x4*>(gn ? L.wblob + CDX2_DW(vd, CDX2_W2_BETA) + c : pbi);
-        P.em = *reinterpret_cast<const f32x4*>((flags & CDX2_F2_EMB) ? pem : pbi);
+        P.em = *reinterpret_cast<const f32x4*>((flags & CDX2_F2_EMB) ? pem + ((COND && (flags & CDX2_F2_FILM)) ? coutp : 0) : pbi);
+        P.sc = P.bi;
+        if (COND) P.sc = *reinterpret_cast<const f32x4*>((flags & CDX2_F2_FILM) ? pem : pbi);
         return P;
     }
-    P.bi = P.ga = P.be = P.em = P.pb = (f32x4){0.f, 0.f, 0.f, 0.f};
+    P.bi = P.ga = P.be = P.em = P.pb = P.sc = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (epi_wave) {
         P.bi = *reinterpret_cast<const f32x4*>(pbi);
         if (CDX2_DW(vd, CDX2_W2_KPOST)) P.pb = *reinterpret_cast<const f32x4*>(L.wblob + CDX2_DW(vd, CDX2_W2_PBIAS) + c);
@@ -698,7 +704,10 @@ __device__ __forceinline__ EpiParams load_params(const cdx_unet2_launch& L, int 
             P.ga = *reinterpret_cast<const f32x4*>(L.wblob + CDX2_DW(vd, CDX2_W2_GAMMA) + c);
             P.be = *reinterpret_cast<const f32x4*>(L.wblob + CDX2_DW(vd, CDX2_W2_BETA) + c);
         }
-        if (flags & CDX2_F2_EMB) P.em = *reinterpret_cast<const f32x4*>(pem);
+        if (COND && (flags & CDX2_F2_FILM)) {          // table row: [scale | bias], W2_COUTP floats apart
+            P.sc = *reinterpret_cast<const f32x4*>(pem);
+            P.em = *reinterpret_cast<const f32x4*>(pem + coutp);
+        } else if (flags & CDX2_F2_EMB) P.em = *reinterpret_cast<const f32x4*>(pem);
     }
     return P;
 }
@@ -813,16 +822,21 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
         // (a trajectory past the end of the range -- odd count, last workgroup -- computes on its zeroed region; its saved tensors
         //  go to the spare block [batch] of the workspace, never into a real trajectory's block)
         float* ws = BWD ? L.ws + (size_t)(b0 + t < L.traj_first + L.traj_count ? b0 + t : L.batch) * L.ws_floats : nullptr;
-        if (COND && emb_tstride != 0 && t != t_lo && epi_wave && (e.flags & CDX2_F2_EMB))
-            P.em = *reinterpret_cast<const f32x4*>(emb_row + t * emb_tstride + CDX2_DW(vd, CDX2_W2_EMB) + c);
+        if (COND && emb_tstride != 0 && t != t_lo && epi_wave && (e.flags & CDX2_F2_EMB)) {
+            const float* __restrict__ pe = emb_row + t * emb_tstride + CDX2_DW(vd, CDX2_W2_EMB) + c;
+            if (e.flags & CDX2_F2_FILM) {
+                P.sc = *reinterpret_cast<const f32x4*>(pe);
+                P.em = *reinterpret_cast<const f32x4*>(pe + e.coutp);
+            } else P.em = *reinterpret_cast<const f32x4*>(pe);
+        }
         if (epi_wave) {
             if (BWD && (e.flags & CDX2_F2_GNBWD)) {
                 if (e.nk == 1) epilogue_bwd<1>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
                 else if (e.nk == 2) epilogue_bwd<2>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
                 else epilogue_bwd<CDX2_MAX_NK2>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
-            } else if (e.nk == 1) epilogue<1, BWD>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
-            else if (e.nk == 2) epilogue<2, BWD>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
-            else epilogue<CDX2_MAX_NK2, BWD>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
+            } else if (e.nk == 1) epilogue<1, BWD, COND>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
+            else if (e.nk == 2) epilogue<2, BWD, COND>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
+            else epilogue<CDX2_MAX_NK2, BWD, COND>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
         }
         if (halo_wave) {
             // wave w (mod 4) rewrites halo row w of the destination (the arena hands this LDS to slots of other shapes in between)

@@ -648,6 +648,10 @@ def is_chiunet_gemm(module, batch: int, horizon: Optional[int] = None, edm: bool
         return False
     if big or horizon is None:
         return big
+    if type(module) is ChiUNet1d:
+        from . import runtime2                         # the second-generation program kernel takes ChiUNet1d too (EDM plans included)
+        if runtime2.supported(module, horizon) is None:
+            return False
     return runtime.supported_backbone(module, horizon, edm) is not None
 
 

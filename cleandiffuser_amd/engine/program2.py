@@ -75,7 +75,9 @@ I2_WOFF, I2_NQ, I2_TAPCC, I2_PART, I2_COL0, I2_PADOOFF, I2_SRCSTR, I2_CCN = rang
 # F2_GNBWD: the epilogue is the BACKWARD of (GroupNorm -> Mish) of the layer whose saved values W2_SAVE / W2_STATS name, applied to
 # the conv result (+ residual slot); F2_DUAL: the value before that backward is also stored (slot W2_DST2); F2_SAVE_GLOBAL: the saved
 # values live in the launch's global workspace (W2_SAVE = float offset inside the trajectory's block) instead of an LDS slot
-F2_GN, F2_EMB, F2_RES, F2_PRED, F2_SAVE, F2_GNBWD, F2_DUAL, F2_SAVE_GLOBAL = 1, 2, 4, 8, 16, 32, 64, 128
+# F2_FILM (with F2_EMB): the table row holds [scale (pad32(C)) | bias (pad32(C))] at W2_EMB and the epilogue applies scale * y + bias
+# (ChiUNet1d's cond_predict_scale FiLM, reference chiunet.py:41-45) instead of y + vector
+F2_GN, F2_EMB, F2_RES, F2_PRED, F2_SAVE, F2_GNBWD, F2_DUAL, F2_SAVE_GLOBAL, F2_FILM = 1, 2, 4, 8, 16, 32, 64, 128, 256
 
 
 def pad32(c: int) -> int:
@@ -207,9 +209,10 @@ class _Builder2:
             self.ws_floats += (a.floats + 3) // 4 * 4
         return a
 
-    def emb_slot(self, c_out: int) -> int:
+    def emb_slot(self, c_out: int, film: bool = False) -> int:
+        """Columns of the FiLM table for one block: pad32(C) (additive vector) or, `film`, [scale | bias] = 2 x pad32(C)."""
         off = self.n_emb
-        self.n_emb += pad32(c_out)
+        self.n_emb += pad32(c_out) * (2 if film else 1)
         return off
 
     def stats_slot(self) -> int:
@@ -221,7 +224,7 @@ class _Builder2:
     def conv(self, srcs: List[Act], dst: Act, w_eff: torch.Tensor, bias: Optional[torch.Tensor], *, stride=1, pad=0,
              transposed=False, phases=None, gn: Optional[nn.Module] = None, emb_off: int = -1, res: Optional[Act] = None,
              pred: bool = False, save: Optional[Tuple[Act, int]] = None, bwd: Optional[dict] = None,
-             extra: Optional[List[dict]] = None):
+             extra: Optional[List[dict]] = None, film: bool = False):
         """One fused op: conv over the channel concat of `srcs` -> epilogue -> dst.
 
         `extra`: further stride-1 convs with the same output shape computed by the SAME op on other waves -- dicts
@@ -229,7 +232,7 @@ class _Builder2:
         backward residual sum).  post=True: their sum (+ bias) is added AFTER the GroupNorm / Mish / FiLM of the main conv -- the
         1x1 skip conv of a ResidualBlock (reference jannerunet.py:58, :69) rides in its second conv's op instead of costing an op.
 
-        Forward epilogue: [GroupNorm -> Mish] -> [+ emb] -> [+ residual slot `res` (may be `dst`: accumulate)].  `save=(slot, stats)`
+        Forward epilogue: [GroupNorm -> Mish] -> [+ emb | `film`: scale * y + bias] -> [+ residual slot `res` (may be `dst`: accumulate)].  `save=(slot, stats)`
         additionally stores the normalised pre-affine values and the group rstd (what the backward of this layer needs).
         Backward epilogue (`bwd=dict(gn=<GroupNorm of the layer below>, save=<its saved slot>, stats=<its stats index>,
         dst2=<slot or None>)`): v = conv [+ res]; dst2 <- v; dst <- d/du of Mish(GroupNorm(u)) applied to v.
@@ -416,7 +419,7 @@ class _Builder2:
             words[W2_SAVE_STRIDE], words[W2_STATS] = save[0].stride, save[1]
             writes.append(save[0])
         if emb_off >= 0:
-            flags |= F2_EMB
+            flags |= F2_EMB | (F2_FILM if film else 0)
             words[W2_EMB] = emb_off
         if res is not None:
             assert res.chans == c_out and res.length == l_out
@@ -632,6 +635,113 @@ def _lower_janner(b: "_Builder2", net, horizon: int, x: Act):
     t = b.act(horizon, md)
     b.conv([cur], t, _conv1d_eff(fc[0]), fc[0].bias, pad=2, gn=fc[1])
     return t, fc, blocks
+
+
+def _lower_chiunet(b: "_Builder2", net, horizon: int, x: Act):
+    """Ops of one ChiUNet1d forward with a global condition (reference nn_diffusion/chiunet.py:152-192) reading slot `x`; returns
+    (last hidden slot, final_conv, [(block, table offset)]).  A block's FiLM vector Linear(Mish(emb)) (chiunet.py:36-45) is a row of
+    the launch's per-(step, trajectory) table, like JannerUNet1d's time vectors; with cond_predict_scale the row holds [scale | bias]."""
+    k = net.final_conv[0].kernel_size[0]
+    blocks = []
+
+    def resblock(srcs: List[Act], rb) -> Act:
+        c_out, length = rb.out_dim, srcs[0].length
+        film = bool(rb.cond_predict_scale)
+        e_off = b.emb_slot(c_out, film)
+        blocks.append((rb, e_off))
+        t1 = b.act(length, c_out)
+        b.conv(srcs, t1, _conv1d_eff(rb.conv1[0]), rb.conv1[0].bias, pad=k // 2, gn=rb.conv1[1], emb_off=e_off, film=film)
+        out = b.act(length, c_out)
+        if isinstance(rb.residual_conv, nn.Identity):
+            assert len(srcs) == 1
+            b.conv([t1], out, _conv1d_eff(rb.conv2[0]), rb.conv2[0].bias, pad=k // 2, gn=rb.conv2[1], res=srcs[0])
+        else:
+            fused = FUSE_SKIP and b.conv([t1], out, _conv1d_eff(rb.conv2[0]), rb.conv2[0].bias, pad=k // 2, gn=rb.conv2[1], extra=[
+                dict(srcs=srcs, w_eff=_conv1d_eff(rb.residual_conv), pad=0, bias=rb.residual_conv.bias, post=True)])
+            if not fused:
+                b.conv([t1], out, _conv1d_eff(rb.conv2[0]), rb.conv2[0].bias, pad=k // 2, gn=rb.conv2[1])
+                b.conv(srcs, out, _conv1d_eff(rb.residual_conv), rb.residual_conv.bias, res=out)
+        return out
+
+    cur, skips = x, []
+    for res1, res2, down in net.downs:
+        cur = resblock([resblock([cur], res1)], res2)
+        skips.append(cur)
+        if not isinstance(down, nn.Identity):
+            if cur.length % 2:
+                raise ValueError("horizon too short for the number of resolutions")
+            nxt = b.act((cur.length - 1) // 2 + 1, cur.chans)
+            b.conv([cur], nxt, _conv1d_eff(down.conv), down.conv.bias, stride=2, pad=1)
+            cur = nxt
+    for mid in net.mids:
+        cur = resblock([cur], mid)
+    for res1, res2, up in net.ups:
+        cur = resblock([resblock([cur, skips.pop()], res1)], res2)
+        if not isinstance(up, nn.Identity):
+            nxt = b.act(cur.length * 2, cur.chans)
+            b.conv([cur], nxt, _convT1d_eff(up.conv), up.conv.bias, stride=2, pad=1, transposed=True)
+            cur = nxt
+    if cur.length != horizon:
+        raise ValueError("up path does not return to the input horizon")
+    fc = net.final_conv
+    t = b.act(horizon, net.model_dim)
+    b.conv([cur], t, _conv1d_eff(fc[0]), fc[0].bias, pad=k // 2, gn=fc[1])
+    return t, fc, blocks
+
+
+def chiunet_film_spec(net, blocks, n_emb: int, dev) -> dict:
+    """What the host needs to fill the FiLM table of a ChiUNet1d program (runtime2.chi_film_table): the blocks' cond_encoder Linears
+    stacked in table-column order and split by input half -- row(step, trajectory) = W_t Mish(map_emb(temb_step)) + W_c
+    Mish(global_cond_encoder(cond_trajectory)) + bias (reference chiunet.py:160-163, :36: emb = [time | condition], every block
+    consumes Mish(emb)).  Pad columns (pad32) stay zero: scale 0, bias 0 on channels that are never stored."""
+    e = net.emb_dim
+    w_t, w_c = torch.zeros(n_emb, e, device=dev), torch.zeros(n_emb, e, device=dev)
+    bias = torch.zeros(n_emb, device=dev)
+    for rb, off in blocks:
+        lin, c, cp = rb.cond_encoder[1], rb.out_dim, pad32(rb.out_dim)
+        if lin.in_features != 2 * e:
+            raise ValueError("ChiUNet1d block whose FiLM input is not [time emb | encoded condition]")
+        w, bv = lin.weight.detach().to(dev, torch.float32), lin.bias.detach().to(dev, torch.float32)
+        for part in range(2 if rb.cond_predict_scale else 1):       # [scale | bias] halves sit pad32(C) apart in the table
+            rows = slice(off + part * cp, off + part * cp + c)
+            w_t[rows], w_c[rows], bias[rows] = w[part * c:(part + 1) * c, :e], w[part * c:(part + 1) * c, e:], bv[part * c:(part + 1) * c]
+    return {"w_t": w_t.contiguous(), "w_c": w_c.contiguous(), "bias": bias.contiguous()}
+
+
+def supports_chiunet2(net) -> Optional[str]:
+    if not net.obs_as_global_cond:
+        return "local (per-timestep) observation conditioning: implicit-GEMM executor only"
+    k = net.final_conv[0].kernel_size[0]
+    if k % 2 == 0 or k // 2 > HALO2:
+        return f"kernel_size={k} unsupported (odd, <= {2 * HALO2 + 1})"
+    return None
+
+
+def compile_chiunet2(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x4: bool = True, nw: int = NW2, compact: bool = False,
+                     max_stage: Optional[int] = None) -> Program2:
+    """Lower a ChiUNet1d with a global condition (reference nn_diffusion/chiunet.py:48-192) for `horizon` positions; same program
+    format and kernel as JannerUNet1d.  The FiLM table is filled by the host from ``meta["chi_film"]`` (no embedding MLP spec)."""
+    why = supports_chiunet2(net)
+    if why is not None:
+        raise ValueError(why)
+    dev = next(net.parameters()).device
+    b = _Builder2(dev, nw)
+    b.allow_4x4 = allow_4x4
+    b.alias_residual = compact
+    if max_stage is not None:
+        b.max_stage = max_stage
+    d = net.final_conv[3].out_channels
+    x = b.act(horizon, d, persistent=True)
+    t, fc, blocks = _lower_chiunet(b, net, horizon, x)
+    pred = b.act(horizon, d)
+    b.conv([t], pred, _conv1d_eff(fc[3]), fc[3].bias, pred=True)
+    e = net.emb_dim
+    b.macs += e * 4 * e + 4 * e * e + net.global_cond_encoder.in_features * e + 2 * e * sum(rb.cond_encoder[1].out_features for rb, _ in blocks)
+    prog = _finalize2(b, [{}], x, pred, horizon, d, e, max_lds_bytes, [], compact=compact)
+    prog.embtabs = []
+    prog.meta["chi_film"] = chiunet_film_spec(net, blocks, b.n_emb, dev)
+    prog.meta["cond_dim"] = net.global_cond_encoder.in_features
+    return prog
 
 
 def _dgrad_eff(conv: nn.Conv1d) -> torch.Tensor:

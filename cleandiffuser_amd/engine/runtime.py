@@ -336,7 +336,7 @@ def _backbone_cond(module, prog, condition, device):
 
 def backbone_forward(module, x, noise, condition) -> Optional[torch.Tensor]:
     """``BaseNNDiffusion.forward`` on the device: one launch, per-sample timesteps."""
-    if x.dim() == 3 and _is_janner(module):
+    if x.dim() == 3 and (_is_janner(module) or _is_chiunet(module)):
         from . import runtime2                        # second-generation kernel: one FiLM row per sample
         y = runtime2.backbone_forward2(module, x, noise, condition)
         if y is not None:
@@ -469,10 +469,8 @@ def fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed, x_scale:
         return fused_sample_mlp(solver, net, _mlp_kind(net), plan, xt, prior, cond_vec, w_cfg, feed)
     if xt.dim() != 3 or not (_is_janner(net) or _is_chiunet(net)):
         return None
-    v1_why = supported_backbone(net, xt.shape[1], plan_is_edm(plan))
-    v2_candidate = _is_janner(net)                    # (nets too large for the first kernel's LDS plan may still fit the second
-    if v1_why is not None and not v2_candidate:       #  one's compact program)
-        return None
+    v1_why = supported_backbone(net, xt.shape[1], plan_is_edm(plan))     # (nets too large for the first kernel's LDS plan may
+    #                                                                       still fit the second one's compact program)
     if cond_vec is None and w_cfg not in (0.0, 1.0):
         return None                                   # the reference raises here; let the torch executor do it
     if _is_chiunet(net) and (cond_vec is None or w_cfg == 0.0):
@@ -487,8 +485,8 @@ def fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed, x_scale:
     except ValueError:
         return None
     load_library()
-    if _is_janner(net):
-        from . import runtime2                        # JannerUNet1d: the second-generation kernel (conditional / CFG / EDM included)
+    if _is_janner(net) or _is_chiunet(net):
+        from . import runtime2                        # the second-generation kernel (conditional / CFG / EDM included)
         out = runtime2.fused_sample2(solver, net, plan, xt, prior, feed, fix_mask, x_min, x_max, x_scale=x_scale,
                                      cond=cond_vec if w_cfg != 0.0 else None, w_cfg=w_cfg)
         if out is not None:

@@ -91,14 +91,15 @@ def compiled2(module, horizon: int, nw: int = P2.NW2, compact: bool = False) -> 
     with torch.no_grad():
         try:
             kw = dict(compact=True, max_stage=COMPACT_STAGE, max_lds_bytes=(160 * 1024) // 3 // 16 * 16) if compact else {}
+            lower = P2.compile_chiunet2 if R._is_chiunet(module) else P2.compile_janner2
             try:
-                comp = _Compiled2(P2.compile_janner2(module, horizon, nw=nw, **kw), sig)
+                comp = _Compiled2(lower(module, horizon, nw=nw, **kw), sig)
             except ValueError:
                 if compact or nw != P2.NW2_MAX or os.environ.get("CDX_UNET2_COMPACT_T1", "1") == "0":
                     raise
                 # nets whose default plan does not fit 160 KiB (model_dim 64 at H = 64: the antmaze Diffuser, 193 KB) may still fit as
                 # a compact program with the whole LDS to itself: one trajectory per workgroup
-                comp = _Compiled2(P2.compile_janner2(module, horizon, nw=nw, compact=True), sig)
+                comp = _Compiled2(lower(module, horizon, nw=nw, compact=True), sig)
         except ValueError as e:                  # the documented 'does not fit / unsupported layer' signal; invariant failures propagate
             comp = _Compiled2(None, sig, str(e))
     per_mod[key] = comp
@@ -111,16 +112,19 @@ COMPACT_STAGE = 2304       # floats of staging area per op in a compact program
 def _structural(module, horizon: int) -> Optional[str]:
     if not enabled():
         return "disabled by CDX_UNET2=0"
-    if not R._is_janner(module):
+    if R._is_chiunet(module):
+        if not module.obs_as_global_cond:
+            return "ChiUNet1d with local conditioning has no v2 program"
+    elif not R._is_janner(module):
         return f"{type(module).__name__} has no v2 program"
-    n_down = sum(1 for lvl in module.downs if not isinstance(lvl[3], torch.nn.Identity))
+    n_down = sum(1 for lvl in module.downs if not isinstance(lvl[-1], torch.nn.Identity))
     if horizon % (1 << n_down) != 0:
         return f"horizon {horizon} not divisible by 2^{n_down}"
     return None
 
 
 def supported(module, horizon: int) -> Optional[str]:
-    """None when the v2 kernel runs `module` (an unconditional JannerUNet1d forward) at `horizon`, else the reason."""
+    """None when the v2 kernel runs `module` (JannerUNet1d, ChiUNet1d with a global condition) at `horizon`, else the reason."""
     why = _structural(module, horizon)
     if why is not None:
         return why
@@ -278,6 +282,8 @@ def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps
     if batch <= 0:
         return
     prog = comp.prog
+    if "chi_film" in prog.meta and not emb_per_traj:
+        raise ValueError("ChiUNet1d programs carry FiLM-scale ops: only the per-trajectory-table kernels decode them")
     t = t_per_wg or traj_per_wg(prog, batch)
     prof = R._prof["buf"]
     # Two trajectories per workgroup fill the 256 CUs in rounds of 512 trajectories; a remainder of up to 256 is cheaper one
@@ -364,6 +370,51 @@ def cond_film_table(comp: _Compiled2, module, t_vec: torch.Tensor, cond: Optiona
     return out
 
 
+def chi_film_table(comp: _Compiled2, module, t_vec: torch.Tensor, cond: Optional[torch.Tensor], per_sample: bool = False,
+                   plan=None) -> torch.Tensor:
+    """FiLM rows of a ChiUNet1d request (reference chiunet.py:160-163 + :36-45): emb = [map_emb(map_noise(t)) | global_cond_encoder(cond)],
+    every block applies Linear(Mish(emb)) -- separable into a per-step and a per-trajectory part, so the table is four GEMMs on
+    ``cdx_gemm_f32`` (time MLP with Mish epilogues; condition encoder with Mish; the stacked block Linears once over the encoded
+    conditions and once over the (step, trajectory) rows with the condition part added as the GEMM's row-periodic table).
+    `cond` (B, cond_dim): rows s * B + b (+ two zero spare rows); `cond` None: the zero-condition table of a classifier-free-guidance
+    pair, one row per step (reference diffusionsde.py:175-206 feeds zeros).  `per_sample`: t_vec (B,), one row per sample.  `plan`:
+    the solver's cached plan `t_vec` came from (memoises the time half)."""
+    from . import blocks
+    prog = comp.prog
+    dev = prog.blob.device
+    f = prog.meta["chi_film"]
+    with torch.no_grad():
+        # the time half depends on (schedule, weights) only: kept with the solver's cached plan like the JannerUNet1d tables
+        memo = plan.__dict__.setdefault("_memo", {}) if plan is not None else None
+        key_t = ("chi_te", str(dev), id(module))
+        hit = memo.get(key_t) if memo is not None else None
+        if hit is None or hit[0] != comp.sig:
+            temb = R._f32c(module.map_noise(t_vec), dev)
+            h = blocks.linear(temb, module.map_emb[0].weight, module.map_emb[0].bias, act="mish")
+            hit = (comp.sig, blocks.linear(h, module.map_emb[2].weight, module.map_emb[2].bias, act="mish"))   # Mish(map_emb(temb)), (S, E)
+            if memo is not None:
+                memo[key_t] = hit
+        te = hit[1]
+        gce = module.global_cond_encoder
+        c_in = cond if cond is not None else torch.zeros((1, gce.in_features), device=dev, dtype=torch.float32)
+        ce = blocks.linear(R._f32c(c_in, dev), gce.weight, gce.bias, act="mish")                     # Mish(encoder(cond)), (B, E)
+        cpart = blocks.linear(ce, f["w_c"], f["bias"])                                                # (B, n_emb), block biases included
+        n_b = cpart.shape[0]
+        if per_sample or cond is None:
+            rows_t, n = te, te.shape[0]
+            assert per_sample is False or n == n_b
+        else:
+            rows_t = te.repeat_interleave(n_b, dim=0)                                                 # row s * B + b reads step s
+            n = rows_t.shape[0]
+        key = (dev, R._stream_ptr(dev), "u" if cond is None else "c")
+        buf = _emb_bufs.get(key)
+        if buf is None or buf.numel() < (n + 2) * prog.n_emb:
+            _emb_bufs[key] = buf = torch.zeros((n + 2) * prog.n_emb, device=dev, dtype=torch.float32)
+        out = buf[: (n + 2) * prog.n_emb].view(n + 2, prog.n_emb)
+        blocks.linear(rows_t, f["w_t"], None, out=out[:n], table=cpart)                              # + cpart[row % B]
+    return out
+
+
 def fused_sample2(solver, net, plan, xt, prior, feed, fix_mask, x_min, x_max, x_scale: Optional[float] = None,
                   cond=None, w_cfg: float = 0.0) -> Optional[torch.Tensor]:
     """JannerUNet1d, every step kind: the whole loop in one cdx_unet2_run launch.  None -> the caller falls back.
@@ -375,16 +426,27 @@ def fused_sample2(solver, net, plan, xt, prior, feed, fix_mask, x_min, x_max, x_
         return None
     edm = R.plan_is_edm(plan)
     use_cond = cond is not None and w_cfg != 0.0
+    chi = R._is_chiunet(net)
+    if chi and not use_cond:
+        return None                                   # ChiUNet1d cannot run unconditionally (the reference raises)
     if (use_cond or edm) and x_scale is not None:
         return None
     dev = xt.device
     comp, parts = plan_for(net, h, b)
-    if use_cond and (cond.dim() != 2 or cond.shape != (b, comp.prog.emb_dim)):
+    if chi:
+        cond = torch.flatten(cond, 1)
+        if cond.shape != (b, comp.prog.meta["cond_dim"]):
+            return None
+    elif use_cond and (cond.dim() != 2 or cond.shape != (b, comp.prog.emb_dim)):
         return None
     with torch.no_grad():
         steps_dev = R.steps_to_device(plan, dev)
         emb_u = None
-        if use_cond:
+        if chi:
+            emb = chi_film_table(comp, net, R.device_times(plan, dev), R._f32c(cond, dev), plan=plan)
+            if w_cfg != 1.0:
+                emb_u = chi_film_table(comp, net, R.device_times(plan, dev), None, plan=plan)      # zero condition, one row per step
+        elif use_cond:
             emb = cond_film_table(comp, net, R.device_times(plan, dev), R._f32c(cond, dev))
             if w_cfg != 1.0:
                 emb_u = plan_film_table(comp, net, plan, dev)                 # zero condition: the per-step table
@@ -401,20 +463,30 @@ def fused_sample2(solver, net, plan, xt, prior, feed, fix_mask, x_min, x_max, x_
 
 
 def backbone_forward2(module, x, noise_t, condition=None) -> Optional[torch.Tensor]:
-    """``JannerUNet1d.forward`` (per-sample timesteps, optional condition embedding) in one launch: one FiLM row per sample."""
+    """``JannerUNet1d.forward`` / ``ChiUNet1d.forward`` (per-sample timesteps, condition) in one launch: one FiLM row per sample."""
     b, h, d = x.shape
     if supported(module, h) is not None:
         return None
     comp, t_wg = shape_for(module, h, b)
     if comp.prog.compact:
         return None                                   # (compact-only nets: stand-alone forwards stay with the implicit-GEMM executor)
-    if condition is not None and (condition.dim() != 2 or tuple(condition.shape) != (b, comp.prog.emb_dim)):
+    chi = R._is_chiunet(module)
+    if chi:
+        if condition is None:
+            return None                               # the reference raises on a missing condition (Q12): keep that path
+        condition = torch.flatten(condition, 1)
+        if tuple(condition.shape) != (b, comp.prog.meta["cond_dim"]):
+            return None
+    elif condition is not None and (condition.dim() != 2 or tuple(condition.shape) != (b, comp.prog.emb_dim)):
         return None
     with torch.no_grad():
         t = noise_t.reshape(-1)
         if t.shape[0] == 1:
             t = t.expand(b)
-        emb = cond_film_table(comp, module, t.contiguous(), None if condition is None else R._f32c(condition, x.device), per_sample=True)
+        if chi:
+            emb = chi_film_table(comp, module, t.contiguous(), R._f32c(condition, x.device), per_sample=True)
+        else:
+            emb = cond_film_table(comp, module, t.contiguous(), None if condition is None else R._f32c(condition, x.device), per_sample=True)
         xin = R._f32c(x, x.device)
         out = torch.empty_like(xin)
         launch(comp, batch=b, x_in=xin, x_out=out, emb=emb, t_per_wg=t_wg, emb_per_traj=True)

@@ -240,7 +240,10 @@ class LaneSim2:
                     vals[kk] = mish(xh * gamma[c:c + 4] + beta[c:c + 4])
         kpost = int(op[P2.W2_KPOST])
         for (g, pos, c), v in vals.items():
-            if flags & P2.F2_EMB:
+            if flags & P2.F2_FILM:                            # [scale | bias], pad32(C) apart: y <- scale * y + bias (two roundings)
+                e0 = int(op[P2.W2_EMB]) + c
+                v = (v * emb_row[e0:e0 + 4]).astype(np.float32) + emb_row[e0 + coutp:e0 + coutp + 4]
+            elif flags & P2.F2_EMB:
                 e0 = int(op[P2.W2_EMB]) + c
                 v = v + emb_row[e0:e0 + 4]
             if kpost:                                         # extra conv(s) added after the norm: bias + their staged partials
@@ -305,3 +308,16 @@ class LaneSim2:
             if flags & P2.F2_DUAL:
                 d2, d2s = int(op[P2.W2_DST2]), int(op[P2.W2_DST2_STRIDE])
                 lds[d2 + r * d2s: d2 + (r + 1) * d2s] = 0.0
+
+
+def chi_film_rows(prog: P2.Program2, net, t, cond) -> np.ndarray:
+    """FiLM table rows of a ChiUNet1d program (what runtime2.chi_film_table computes on the device): one row per (timestep, sample)
+    pair given elementwise -- t (n,), cond (n, To, obs) -> (n, n_emb)."""
+    import torch
+    import torch.nn.functional as F
+    f = prog.meta["chi_film"]
+    with torch.no_grad():
+        te = F.mish(net.map_emb(net.map_noise(t)))
+        ce = F.mish(net.global_cond_encoder(torch.flatten(cond, 1)))
+        rows = te @ f["w_t"].cpu().t() + ce @ f["w_c"].cpu().t() + f["bias"].cpu()
+    return rows.numpy().astype(np.float32)

@@ -31,8 +31,9 @@ def test_unet_executor_choice(monkeypatch):
     monkeypatch.setattr(runtime2, "compact_only", lambda module, horizon: False)
     assert not bigbatch.is_chiunet_gemm(janner, 3, 32)                  # fits the program kernel: small batches stay there
     assert bigbatch.is_chiunet_gemm(janner, 3, 64)                      # does not fit: GEMM executor at any batch
-    assert bigbatch.is_chiunet_gemm(chi, 3, 16, True)                   # fits only without the EDM buffers, plan has EDM steps
-    assert seen == [(64, False), (16, True)]                            # (v2 answered for the H = 32 request)
+    assert not bigbatch.is_chiunet_gemm(chi, 3, 16, True)               # v2 keeps EDM state in the launch workspace: no extra LDS
+    assert bigbatch.is_chiunet_gemm(chi, 3, 64, True)                   # neither program kernel holds it: GEMM executor
+    assert seen == [(64, False), (64, True)]                            # (v2 answered for the requests it takes)
     assert not bigbatch.is_chiunet_gemm(janner, 5000, 32)               # v2 program kernel keeps every batch size it can run
     assert bigbatch.is_chiunet_gemm(janner, 5000, 32, True) and bigbatch.is_chiunet_gemm(janner, 5000, 64)   # EDM plans / too big: GEMM
     assert len(seen) == 2                                               # large batch: no need to ask the v1 compiler

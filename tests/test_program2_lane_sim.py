@@ -237,3 +237,27 @@ def test_lane_sim2_compact_one_trajectory_program_long_horizon(amd_lib):
         sim.poison_arena()
         sim.load_x(x[0].numpy())
         np.testing.assert_allclose(sim.run_forward(row), ref, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("nw", [4, 8])
+@pytest.mark.parametrize("scale", [True, False])
+def test_lane_sim2_chiunet_against_module_forward(scale, nw, amd_lib):
+    """ChiUNet1d with a global condition on the v2 program format: FiLM rows [scale | bias] per (step, trajectory), the 1x1 skip convs
+    riding in their block's second conv, stride-2 down / transposed up convs -- against the module's own forward (bit-identical to the
+    reference's, tests/test_module_mirrors.py)."""
+    from cleandiffuser_amd.utils import load_synth
+    from oracle.lane_sim2 import chi_film_rows
+    H, act, obs, To = 16, 2, 5, 2
+    net = load_synth(amd_lib.ChiUNet1d(act, obs, To, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2], kernel_size=5,
+                                       cond_predict_scale=scale, obs_as_global_cond=True), 5).eval()
+    prog = P2.compile_chiunet2(net, H, nw=nw)
+    assert prog.lds_bytes(1) <= 160 * 1024 and prog.meta["cond_dim"] == To * obs
+    g = torch.Generator().manual_seed(4)
+    x, t, cond = torch.randn(2, H, act, generator=g), torch.tensor([7, 31]), torch.randn(2, To, obs, generator=g)
+    with torch.no_grad():
+        want = net(x, t, cond).numpy()
+    rows = chi_film_rows(prog, net, t, cond)
+    for b in range(2):
+        sim = LaneSim2(prog)
+        sim.load_x(x[b].numpy())
+        np.testing.assert_allclose(sim.run_forward(rows[b]), want[b], rtol=2e-5, atol=2e-5)
