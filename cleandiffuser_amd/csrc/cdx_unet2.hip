@@ -916,7 +916,15 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
     }
     __syncthreads();
 
-    const int n_iter = L.n_steps > 0 ? L.n_steps : 1;
+    // log_p pass only (programs with a classifier head, n_steps == 0 and logp_out given): no forward of the whole op list, just the
+    // block after the step loop -- one trajectory per workgroup, FiLM row b of the table for trajectory b (per-sample timesteps)
+    bool logp_only = false;
+    if (BWD) {
+        const KArg* S0 = kernarg();
+        asm volatile("" : "+s"(S0));
+        logp_only = L.n_steps == 0 && S0->logp_out != nullptr;
+    }
+    const int n_iter = logp_only ? 0 : (L.n_steps > 0 ? L.n_steps : 1);
     const int HDp = (HD + 3) & ~3;                     // ws block of a trajectory: [multistep memory / EDM slope | x_old | p_cond]
     constexpr bool PIPE = pipe_params<T, BWD>();        // (see OpFetch)
     constexpr bool SPLIT_T0 = NWV == 8 && T >= 2;
@@ -1130,13 +1138,14 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
         }
         __syncthreads();
     }
-    if (BWD && L.n_steps > 0) {
+    if (BWD && (L.n_steps > 0 || logp_only)) {
         // final log_p (reference diffusionsde.py:597-601): the classifier's forward ops once more, on the final state, timestep 0
+        // (log_p pass only: on the state just loaded, the trajectory's own row of the table)
         const KArg* S = kernarg();
         asm volatile("" : "+s"(S));
         if (S->logp_out != nullptr) {
             const int first = S->logp_first_op, head = S->logp_head_op;
-            const float* __restrict__ emb_row = L.emb + (size_t)L.n_steps * L.emb_ld;
+            const float* __restrict__ emb_row = L.emb + (size_t)(logp_only ? b0 : L.n_steps) * L.emb_ld;
             vd = load_desc<NWV>(L.ops, first, lane, wave);
             it = inline_item(vd);
             if (wave < CDX2_DW(vd, CDX2_W2_NITEMS)) prefetch_ring(it, L.wblob, lane, ring);
@@ -1162,6 +1171,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
         const int str = S->n_steps == 0 ? (want_grad ? S->grad_stride : S->pred_stride) : S->x_stride;
         float* __restrict__ xo = S->x_out;
         if ((S->compact || (COND && S->edm_plan)) && S->n_steps > 0) break;            // the state is already there
+        if (BWD && logp_only) break;                                                   // nothing but logp_out is produced
         for (int e = tid; e < HD; e += THREADS) {
             const int n = e / D, c = e - n * D;
             xo[xbase + e] = lds[t * tf + off + n * str + c];
@@ -1270,8 +1280,11 @@ int cdx_unet2_run(const cdx_unet2_launch* L, void* hip_stream) {
     if (guided && L->ws_floats > 0 && !L->ws) { cdx_set_err("program keeps saved tensors in a global workspace: ws == NULL"); return CDX_EINVAL; }
     if (L->ws_floats < 0 || (L->ws_floats & 3)) { cdx_set_err("ws_floats must be a non-negative multiple of 4"); return CDX_EINVAL; }
     if (L->cg_scale && (L->grad_off < 0 || (L->grad_off & 3) || (L->grad_stride & 3))) { cdx_set_err("cg_scale given without a gradient slot"); return CDX_EINVAL; }
-    if (L->logp_out && (!guided || L->n_steps == 0 || L->logp_first_op < 0 || L->logp_head_op <= L->logp_first_op || L->logp_head_op >= L->n_ops)) {
-        cdx_set_err("logp_out: guided sampling loops only, with 0 <= logp_first_op < logp_head_op < n_ops"); return CDX_EINVAL;
+    if (L->logp_out && (!guided || L->logp_first_op < 0 || L->logp_head_op <= L->logp_first_op || L->logp_head_op >= L->n_ops)) {
+        cdx_set_err("logp_out: programs with a classifier head only, with 0 <= logp_first_op < logp_head_op < n_ops"); return CDX_EINVAL;
+    }
+    if (L->logp_out && L->n_steps == 0 && (L->traj_per_wg != 1 || L->compact)) {
+        cdx_set_err("logp_out without a sampling loop (log_p pass of a batch): one trajectory per workgroup, state in LDS"); return CDX_EINVAL;
     }
     void (*kern)(const cdx_unet2_launch);
     const bool cond = L->n_pass == 2 || L->edm_plan || L->emb_per_traj;

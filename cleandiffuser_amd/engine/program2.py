@@ -749,11 +749,12 @@ def _dgrad_eff(conv: nn.Conv1d) -> torch.Tensor:
     return conv.weight.detach().permute(1, 2, 0).flip(1)
 
 
-def _lower_half_janner_grad(b: "_Builder2", clf, horizon: int, x: Act, grad: Act):
+def _lower_half_janner_grad(b: "_Builder2", clf, horizon: int, x: Act, grad: Optional[Act], forward_only: bool = False):
     """Forward AND backward-data pass of a HalfJannerUNet1d classifier (reference nn_classifier/half_jannerunet.py:102-125) reading
     slot `x`: d out / d x -> slot `grad` (what BaseClassifier.gradients returns, classifier/base.py:74-79, for the summed log p).
     Every GroupNorm layer saves its normalised values + rstd on the way up; on the way down each backward-data conv's epilogue applies
-    the backward of the (GroupNorm -> Mish) below it.  Returns the (block, emb offset) list and the head's table offset."""
+    the backward of the (GroupNorm -> Mish) below it.  Returns the (block, emb offset) list and the head's table offset.
+    `forward_only`: the forward ops and the head only, nothing saved (the classifier's own program: log p of a batch)."""
     if clf.norm_type != "groupnorm" or clf.out_dim != 1:
         raise ValueError("the fused classifier gradient needs norm_type='groupnorm' and out_dim == 1")
     if horizon != clf.horizon:
@@ -765,7 +766,7 @@ def _lower_half_janner_grad(b: "_Builder2", clf, horizon: int, x: Act, grad: Act
         c_out, length = rb.conv1[0].out_channels, src.length
         e_off = b.emb_slot(c_out)
         blocks.append((rb, e_off))
-        s1, s2 = (b.save_slot(length, c_out), b.stats_slot()), (b.save_slot(length, c_out), b.stats_slot())
+        s1, s2 = (None, None) if forward_only else ((b.save_slot(length, c_out), b.stats_slot()), (b.save_slot(length, c_out), b.stats_slot()))
         t1 = b.act(length, c_out)
         b.conv([src], t1, _conv1d_eff(rb.conv1[0]), rb.conv1[0].bias, pad=ksz // 2, gn=rb.conv1[1], emb_off=e_off, save=s1)
         out = b.act(length, c_out)
@@ -804,6 +805,8 @@ def _lower_half_janner_grad(b: "_Builder2", clf, horizon: int, x: Act, grad: Act
     g = b.act(cur.length, cur.chans)                       # gradient w.r.t. the last downsample's output
     b.head(cur, g, lin1.weight.detach()[:, :fc].reshape(lin1.out_features, cur.chans, cur.length), head_off, lin2.weight.detach(),
            lin2.bias.detach() if lin2.bias is not None else None)
+    if forward_only:
+        return blocks, (lin1, head_off)
 
     # ---- backward: g = gradient w.r.t. the output of the tape entry on top ----
     # what lies BELOW an entry decides the epilogue of the op that completes the gradient w.r.t. that entry's input: another
@@ -857,6 +860,23 @@ def _lower_half_janner_grad(b: "_Builder2", clf, horizon: int, x: Act, grad: Act
                 b.conv([gu1], dst, _dgrad_eff(rb.conv1[0]), None, pad=ksz // 2, res=skip, bwd=bw)
             g_plain, g_u2 = finish(idx, make)
     return blocks, (lin1, head_off)
+
+
+def compile_classifier2(clf, horizon: int, max_lds_bytes: int = 160 * 1024, nw: int = NW2_MAX) -> Program2:
+    """A HalfJannerUNet1d classifier's forward as its own program (reference nn_classifier/half_jannerunet.py:102-125): the forward
+    ops of `_lower_half_janner_grad` and the head, evaluated by the log_p pass of ``cdx_unet2_run`` (``n_steps == 0`` with
+    ``logp_out``) -- ``CumRewClassifier.logp`` of a batch with per-sample timesteps in one launch."""
+    dev = next(clf.parameters()).device
+    b = _Builder2(dev, nw)
+    d = clf.in_dim
+    x = b.act(horizon, d, persistent=True)
+    blocks, (lin1, head_off) = _lower_half_janner_grad(b, clf, horizon, x, None, forward_only=True)
+    fcw = lin1.in_features - clf.model_dim
+    emb = _emb_table_spec(b, clf, blocks, dev, raw_rows=(lin1.weight.detach()[:, fcw:], lin1.bias.detach(), head_off))
+    out = b.op_acts[b.head_index]["dst"]                   # (the head's gradient slot: never written by the log_p pass)
+    prog = _finalize2(b, [emb], x, out, horizon, d, clf.emb_dim, max_lds_bytes, [])
+    prog.meta["cls_first"], prog.meta["head_op"] = 0, b.head_index
+    return prog
 
 
 def _finalize2(b: "_Builder2", nets_emb: List[dict], x: Act, pred: Act, horizon: int, d: int, emb_dim: int, max_lds_bytes: int,

@@ -341,6 +341,11 @@ def backbone_forward(module, x, noise, condition) -> Optional[torch.Tensor]:
         y = runtime2.backbone_forward2(module, x, noise, condition)
         if y is not None:
             return y
+    if x.dim() == 3 and _is_half_janner(module) and condition is None and module.out_dim == 1:
+        from . import runtime2                        # the classifier's own v2 program: log p of the batch in one launch
+        y = runtime2.classifier_forward2(module, x, noise)
+        if y is not None:
+            return y
     if x.dim() != 3 or supported_backbone(module, x.shape[1]) is not None:
         return None
     load_library()

@@ -604,3 +604,46 @@ def classifier_gradient2(net, clf_net, x, noise_t) -> Optional[torch.Tensor]:
         out = torch.empty_like(xin)
         launch(comp, batch=b, x_in=xin, x_out=out, emb=emb, t_per_wg=1, with_backward=True)
     return out
+
+
+_ccache = weakref.WeakKeyDictionary()
+
+
+def compiled_classifier2(clf_net, horizon: int) -> _Compiled2:
+    """The classifier's own program (forward ops + head, engine/program2.py:compile_classifier2); ``.prog is None`` + ``.why`` when
+    the v2 compiler does not take it."""
+    per = _ccache.setdefault(clf_net, {})
+    sig = R._signature(clf_net)
+    hit = per.get(horizon)
+    if hit is not None and hit.sig == sig:
+        return hit
+    with torch.no_grad():
+        try:
+            comp = _Compiled2(P2.compile_classifier2(clf_net, horizon), sig)
+        except ValueError as e:
+            comp = _Compiled2(None, sig, str(e))
+    per[horizon] = comp
+    return comp
+
+
+def classifier_forward2(clf_net, x, noise_t) -> Optional[torch.Tensor]:
+    """``HalfJannerUNet1d.forward`` with out_dim 1 -- what ``CumRewClassifier.logp`` evaluates (reference classifier/base.py:62-72,
+    nn_classifier/half_jannerunet.py:102-125) -- as the log_p pass of ONE cdx_unet2_run launch: per-sample timesteps through one
+    FiLM row per trajectory.  (batch, 1), or None when the v2 compiler does not take the classifier."""
+    if not enabled() or x.dim() != 3 or os.environ.get("CDX_UNET2_CLASSIFIER", "1") == "0":
+        return None
+    b, h, d = x.shape
+    if getattr(clf_net, "in_dim", None) != d:
+        return None
+    comp = compiled_classifier2(clf_net, h)
+    if comp.prog is None:
+        return None
+    with torch.no_grad():
+        t = noise_t.reshape(-1)
+        if t.shape[0] == 1:
+            t = t.expand(b)
+        emb = film_table(comp, clf_net, t.contiguous())
+        xin = R._f32c(x, x.device)
+        out = torch.empty((b, 1), dtype=torch.float32, device=x.device)
+        launch(comp, batch=b, x_in=xin, x_out=xin, emb=emb, t_per_wg=1, with_backward=True, logp_out=out)
+    return out

@@ -206,7 +206,10 @@ typedef struct cdx_unet2_launch {
     int32_t edm_plan;          /* != 0: the step records are kinds 5-7 */
     /* guided programs: after the last step the classifier's forward ops [logp_first_op, logp_head_op] run once more on the FINAL
      * state with FiLM row `n_steps` of `emb` (timestep 0) and the head writes its scalar to logp_out[b] -- the `log_p` the reference
-     * evaluates after the loop (diffusionsde.py:597-601), before the final clip.  NULL: not asked for. */
+     * evaluates after the loop (diffusionsde.py:597-601), before the final clip.  NULL: not asked for.
+     * With n_steps == 0 (and with_backward != 0, traj_per_wg == 1) the launch is that pass ALONE on x_in -- `BaseClassifier.logp` of a
+     * batch (classifier/base.py:62-72; a classifier-only program of engine/program2.py:compile_classifier2): trajectory b reads FiLM
+     * row b of `emb` (per-sample timesteps), x_out is not written. */
     float* logp_out;           /* device (batch) or NULL */
     int32_t logp_first_op, logp_head_op;
 } cdx_unet2_launch;

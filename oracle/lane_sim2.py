@@ -123,6 +123,8 @@ class LaneSim2:
                 xv = lds[src + (l + P2.HALO2) * sstr + c]
                 assert np.isfinite(xv)
                 z = z + w1[l * ch + c] * xv
+        # the forward value (what the kernel's log_p pass writes to logp_out): w2 . Mish(z) + b2
+        self.logp = np.float32((w2 * mish(z)).sum(dtype=np.float32) + self.blob[int(op[P2.W2_GAMMA]) + hidden])
         gz = (w2 * mish_grad(z)).astype(np.float32)
         for l in range(length):
             for c in range(ch):

@@ -268,7 +268,8 @@ def test_guided_sampling_matches_reference_fixture(name, one_call, amd_lib, monk
         if runtime2.guided_supported(agent.model_ema["diffusion"], agent.classifier.model_ema, c["horizon"]) is None:
             assert launches["v2"] == 1, "guided loop with a guided program must be one cdx_unet2_run launch"
     elif one_call:
-        assert used == {"grad": 0, "loop": 1} and launches["v2"] == 0
+        # (the only v2 launch left is the classifier's own program scoring the final trajectories: the log_p pass)
+        assert used == {"grad": 0, "loop": 1} and launches["v2"] <= 1
     else:
         assert used["grad"] == kw["sample_steps"], "every step's classifier gradient must come from the native kernels"
     np.testing.assert_allclose(x.cpu().numpy(), gold["x_out"], **TOL)
@@ -416,7 +417,8 @@ def test_unet2_kernel_matches_reference_fixture(name, t_per_wg, n_waves, amd_lib
     net = agent.model_ema["diffusion"]
     assert len(seen) == 1, "unconditional JannerUNet1d requests are offered to the v2 kernel first"
     if runtime2.supported(net, x.shape[1]) is None and not runtime.plan_is_edm(seen[0]):
-        assert calls["v2"] == 1, "supported unconditional U-Net loop must run on cdx_unet2_run"
+        # (+ 1: a fixture with a classifier scores the final trajectories with the classifier's own v2 program)
+        assert calls["v2"] == 1 + ("log_p" in gold.files), "supported unconditional U-Net loop must run on cdx_unet2_run"
     np.testing.assert_allclose(x.cpu().numpy(), gold["x_out"], **TOL)
 
 
@@ -1477,3 +1479,26 @@ def test_chiunet_v2_requests_match_the_torch_executor(solver_kw, scale, amd_lib,
     torch.cuda.synchronize()
     assert (calls["n"], calls["v2"]) == (1, 1), calls
     np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), **TOL)
+
+
+@pytest.mark.parametrize("size", ["cfg2", "kitchen"])
+def test_classifier_log_p_of_a_batch_is_one_v2_launch(size, amd_lib, monkeypatch):
+    """``CumRewClassifier.logp`` (reference classifier/base.py:62-72 -> HalfJannerUNet1d forward) with a different timestep per
+    sample: the classifier's own v2 program, log_p pass only (n_steps = 0), one trajectory per workgroup, row b of the FiLM table for
+    trajectory b -- against the module's PyTorch forward on the CPU (bit-identical to the reference's, tests/test_module_mirrors.py).
+    300 samples: more workgroups than CUs."""
+    from cleandiffuser_amd.utils import load_synth
+    H, D, md = (32, 23, 32) if size == "cfg2" else (32, 69, 64)
+    mk = lambda: load_synth(amd_lib.HalfJannerUNet1d(H, D, out_dim=1, model_dim=md, emb_dim=md, dim_mult=(1, 2, 2, 2), kernel_size=3), 3).eval()  # noqa: E731
+    clf_cpu, clf = mk(), mk().to(DEV)
+    g = torch.Generator().manual_seed(8)
+    B = 300
+    x, t = torch.randn(B, H, D, generator=g), torch.randint(0, 20, (B,), generator=g)
+    calls = _spy_launches(monkeypatch)
+    with torch.no_grad():
+        want = clf_cpu(x, t, None)
+        got = clf(x.to(DEV), t.to(DEV), None)
+    torch.cuda.synchronize()
+    assert (calls["n"], calls["v2"]) == (1, 1), calls
+    assert got.shape == (B, 1)
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-4 * max(1.0, float(want.abs().max())))

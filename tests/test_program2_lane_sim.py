@@ -261,3 +261,26 @@ def test_lane_sim2_chiunet_against_module_forward(scale, nw, amd_lib):
         sim = LaneSim2(prog)
         sim.load_x(x[b].numpy())
         np.testing.assert_allclose(sim.run_forward(rows[b]), want[b], rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("shape", [(16, 6, [1, 2], 32), (32, 23, [1, 2, 2, 2], 32), (32, 69, [1, 2, 2, 2], 64)])
+def test_lane_sim2_classifier_program_reproduces_log_p(shape, amd_lib):
+    """The classifier's own program (engine/program2.py:compile_classifier2): forward ops + head, nothing saved, no backward ops;
+    the head's forward value is the module's output (what CumRewClassifier.logp returns)."""
+    from cleandiffuser_amd.utils import load_synth
+    H, D, dm, md = shape
+    clf = load_synth(amd_lib.HalfJannerUNet1d(H, D, out_dim=1, model_dim=md, emb_dim=md, dim_mult=tuple(dm), kernel_size=3), 1).eval()
+    prog = P2.compile_classifier2(clf, H)
+    assert prog.nw == 8 and prog.lds_bytes(1) <= 160 * 1024 and prog.ws_floats == 0 and len(prog.embtabs) == 1
+    assert all(int(op[P2.W2_FLAGS]) & (P2.F2_SAVE | P2.F2_GNBWD | P2.F2_DUAL) == 0 for op in prog.ops)
+    assert int(prog.ops[prog.meta["head_op"]][P2.W2_KIND]) == P2.KIND2_HEAD and prog.meta["head_op"] == len(prog.ops) - 1
+    g = torch.Generator().manual_seed(5)
+    x, t = torch.randn(2, H, D, generator=g), torch.tensor([7, 0])
+    with torch.no_grad():
+        want = clf._forward_torch(x, t, None).numpy()
+        rows = emb_table(prog, clf.map_noise(t).numpy())
+    for b in range(2):
+        sim = LaneSim2(prog)
+        sim.load_x(x[b].numpy())
+        sim.run_forward(rows[b])
+        np.testing.assert_allclose(sim.logp, want[b, 0], rtol=2e-5, atol=2e-5 * max(1.0, abs(float(want[b, 0]))))
