@@ -70,3 +70,10 @@
 #define CDX2_F2_DUAL 64      /* ... and the value before that backward goes to W2_DST2 */
 #define CDX2_F2_SAVE_GLOBAL 128   /* W2_SAVE is a float offset inside the trajectory's block of cdx_unet2_launch.ws, not an LDS slot */
 #define CDX2_F2_FILM 256     /* with F2_EMB: the table row holds [scale | bias] (2 x W2_COUTP floats) at W2_EMB: y <- scale * y + bias */
+/* batch-tiled MLP programs (MLP kernel instantiation): */
+#define CDX2_F2_COLNORM 512  /* with F2_GN: statistics per POSITION over the group's channels (per-sample GroupNorm) */
+#define CDX2_F2_BIAS_EMB 1024   /* the bias vector is read from the per-step table row at W2_BOFF */
+#define CDX2_F2_OUT_DIV 2048    /* the stored value is divided by the float in W2_ODIV */
+#define CDX2_F2_ACT_SHIFT 12    /* flags bits 12-15: activation id + 1 (CDX_ACT_* of cdx_ops.h), 0 = Mish after a GroupNorm, else none */
+#define CDX2_W2_ODIV 26         /* forward ops: alias of W2_SAVE_STRIDE */
+#define CDX2_KIND2_LOADC 3      /* context slot <- the launch's per-sample condition features (zeros: unconditional forward / no condition) */

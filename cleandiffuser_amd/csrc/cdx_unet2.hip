@@ -87,6 +87,43 @@ __device__ __forceinline__ float half_sum(float v, int lane) {
     return lane < 32 ? r0 + r1 : r2 + r3;
 }
 
+// sum over the aligned group of 2^w_log2 lanes this lane belongs to (w_log2 <= 5, wave-uniform): the per-sample GroupNorm of the
+// batch-tiled MLP programs reduces over the float4 items of ONE position
+__device__ __forceinline__ float seg_sum(float v, int w_log2, int lane) {
+    if (w_log2 >= 1) v = dpp_add<0xB1>(v);
+    if (w_log2 >= 2) v = dpp_add<0x4E>(v);
+    if (w_log2 >= 3) v = dpp_add<0x141>(v);
+    if (w_log2 >= 4) v = dpp_add<0x140>(v);
+    if (w_log2 >= 5) {
+        const int iv = __builtin_bit_cast(int, v);
+        const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0));
+        const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+        const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32));
+        const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+        v = lane < 32 ? r0 + r1 : r2 + r3;
+    }
+    return v;
+}
+
+// Activations of the batch-tiled MLP programs: id = CDX_ACT_* (cdx_ops.h) + 1, wave-uniform (a scalar branch)
+__device__ __forceinline__ float act2_f(float x, int id) {
+    switch (id) {
+        case 2: return mish2(x);                                         // CDX_ACT_MISH
+        case 3: {                                                        // CDX_ACT_GELU_ERF: erf by Abramowitz-Stegun 7.1.26, |err| < 1.5e-7
+            const float z = fabsf(x) * 0.70710678118654752f;
+            const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+            const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+            return 0.5f * x * (1.0f + copysignf(1.0f - poly * __expf(-z * z), x));
+        }
+        case 4: return x > 0.f ? x : 0.01f * x;                          // CDX_ACT_LEAKY
+        case 5: return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));     // CDX_ACT_SILU
+        case 6: return fmaxf(x, 0.f);                                    // CDX_ACT_RELU
+        case 7: return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));   // CDX_ACT_GELU_TANH
+        case 9: return tanhf(x);                                         // CDX_ACT_TANH
+        default: return x;                                               // 1 = CDX_ACT_NONE
+    }
+}
+
 struct M16 {   // v_mfma_f32_16x16x4_f32: 16 rows x 16 cols, a record = 16 K values
     static constexpr int COLS = 16, KSTEP = 16;
     static __device__ __forceinline__ int col(int lane) { return lane & 15; }
@@ -397,6 +434,7 @@ struct EpiDesc {
     int save, savestr, stats, dst2, d2stride;          // backward-pass extras (F2_SAVE / F2_GNBWD / F2_DUAL)
     int kpost;                                         // partial tiles (after the first ksplit) that are added AFTER norm / activation
     float inv_cnt;
+    float odiv;                                        // F2_OUT_DIV divisor (forward ops: the word W2_SAVE_STRIDE)
 };
 template <bool BWD>
 __device__ __forceinline__ EpiDesc decode_epi(int vd) {
@@ -407,6 +445,7 @@ __device__ __forceinline__ EpiDesc decode_epi(int vd) {
     e.rstride = CDX2_DW(vd, CDX2_W2_RES_STRIDE); e.shift = CDX2_DW(vd, CDX2_W2_CG4_SHIFT); e.nk = CDX2_DW(vd, CDX2_W2_NK);
     e.inv_cnt = __int_as_float(CDX2_DW(vd, CDX2_W2_INV_CNT));
     e.kpost = CDX2_DW(vd, CDX2_W2_KPOST);
+    e.odiv = BWD ? 1.0f : __int_as_float(CDX2_DW(vd, CDX2_W2_ODIV));
     e.save = e.savestr = e.stats = e.dst2 = e.d2stride = 0;
     if (BWD && (e.flags & (CDX2_F2_SAVE | CDX2_F2_GNBWD))) {
         e.save = CDX2_DW(vd, CDX2_W2_SAVE); e.savestr = CDX2_DW(vd, CDX2_W2_SAVE_STRIDE); e.stats = CDX2_DW(vd, CDX2_W2_STATS);
@@ -436,7 +475,7 @@ __device__ __forceinline__ void half_sum2(float& a, float& b, int lane) {
 // channels c..c+3 of position pos0 + k * pstep.  NK = items per lane (compile-time so the values stay in registers).
 // GroupNorm statistics in ONE cross-lane round: sums of (x - s) and (x - s)^2 with s = the group's first element (no E[x^2] -
 // E[x]^2 cancellation; the second dependent reduction of a two-pass scheme is ~150 cycles of pure latency per op).
-template <int NK, bool BWD, bool COND = false>
+template <int NK, bool BWD, bool COND = false, bool MLP = false>
 __device__ __forceinline__ void epilogue(float* __restrict__ tl, const EpiParams& P, const EpiDesc& e, int stage, int c, int pos0,
                                          int pstep, int li, int nv, int lane, int grp, float* __restrict__ ws) {
     f32x4 v[NK];
@@ -464,7 +503,24 @@ __device__ __forceinline__ void epilogue(float* __restrict__ tl, const EpiParams
         if (ks < e.ksplit) acc += *reinterpret_cast<const f32x4*>(sp);
         v[k] = acc;
     }
-    if (e.flags & CDX2_F2_GN) {
+    const int act_id = MLP ? (e.flags >> CDX2_F2_ACT_SHIFT) & 15 : 0;
+    if (MLP && (e.flags & CDX2_F2_COLNORM)) {
+        // per-sample GroupNorm (reference pearcemlp.py FCBlock): the statistics of ONE position over the group's channels = the
+        // 2^shift float4 items of that position, which sit in adjacent lanes; two passes (mean, centred squares)
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            float s1 = ok[k] ? (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]) : 0.f;
+            s1 = seg_sum(s1, e.shift, lane);
+            const float mean = s1 * e.inv_cnt;
+            const f32x4 dl = v[k] - mean;
+            float s2 = ok[k] ? (dl[0] * dl[0] + dl[1] * dl[1]) + (dl[2] * dl[2] + dl[3] * dl[3]) : 0.f;
+            s2 = seg_sum(s2, e.shift, lane);
+            const float rstd = __builtin_amdgcn_rsqf(s2 * e.inv_cnt + CDX_GN_EPS);
+            const f32x4 y = dl * rstd * P.ga + P.be;
+            v[k] = act_id ? (f32x4){act2_f(y[0], act_id), act2_f(y[1], act_id), act2_f(y[2], act_id), act2_f(y[3], act_id)}
+                          : (f32x4){mish2(y[0]), mish2(y[1]), mish2(y[2]), mish2(y[3])};
+        }
+    } else if (e.flags & CDX2_F2_GN) {
         const int i0 = __builtin_bit_cast(int, v[0][0]);
         const float f0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i0, 0));
         const float f1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i0, 32));
@@ -491,8 +547,13 @@ __device__ __forceinline__ void epilogue(float* __restrict__ tl, const EpiParams
                 *reinterpret_cast<f32x4*>(sv) = xh;
             }
             const f32x4 y = xh * P.ga + P.be;
-            v[k] = (f32x4){mish2(y[0]), mish2(y[1]), mish2(y[2]), mish2(y[3])};
+            v[k] = (MLP && act_id) ? (f32x4){act2_f(y[0], act_id), act2_f(y[1], act_id), act2_f(y[2], act_id), act2_f(y[3], act_id)}
+                                   : (f32x4){mish2(y[0]), mish2(y[1]), mish2(y[2]), mish2(y[3])};
         }
+    } else if (MLP && act_id > 1) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k)
+            v[k] = (f32x4){act2_f(v[k][0], act_id), act2_f(v[k][1], act_id), act2_f(v[k][2], act_id), act2_f(v[k][3], act_id)};
     }
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
@@ -513,6 +574,10 @@ __device__ __forceinline__ void epilogue(float* __restrict__ tl, const EpiParams
             y += pv;
         }
         if (e.flags & CDX2_F2_RES) y += *reinterpret_cast<const f32x4*>(tl + e.res + (pos + CDX2_HALO2) * e.rstride + c);
+        if (MLP && (e.flags & CDX2_F2_OUT_DIV)) {             // PearceMlp's h / 1.414 (reference pearcemlp.py:64), a true division
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = __fdiv_rn(y[j], e.odiv);
+        }
         float* o = tl + e.dst + (pos + CDX2_HALO2) * e.dstride + c;
         if (c + 3 < e.c_out) {
             *reinterpret_cast<f32x4*>(o) = y;
@@ -676,13 +741,14 @@ __device__ __forceinline__ void prefetch_ring(const Item& it, const float* __res
 // CU's address path, ~16 cycles each: 8 waves x 5 unconditional loads cost ~450 cycles per op, measured).  That is the right form when
 // the loads sit after the K loop (PIPE).  ALL = true: every wave issues all five (an unused one re-reads the bias) -- for the round-2
 // position at the op's start, where loads on only some paths make hipcc fall back to `s_waitcnt vmcnt(0)` in the K loop.
-template <bool COND, bool SPLIT_T, bool ALL>
+template <bool COND, bool SPLIT_T, bool ALL, bool MLP = false>
 __device__ __forceinline__ EpiParams load_params(const cdx_unet2_launch& L, int vd, const float* __restrict__ emb_row, int emb_tstride,
                                                  int tid, int wave, bool epi_wave) {
     const int etid = tid & 255, grp = etid >> 5, li = etid & 31;
     const int flags = CDX2_DW(vd, CDX2_W2_FLAGS), coutp = CDX2_DW(vd, CDX2_W2_COUTP), shift = CDX2_DW(vd, CDX2_W2_CG4_SHIFT);
     const int c = grp * (coutp >> 3) + 4 * (li & ((1 << shift) - 1));
-    const float* __restrict__ pbi = L.wblob + CDX2_DW(vd, CDX2_W2_BOFF) + c;
+    // (batch-tiled MLP programs: a layer whose input has a time-dependent part reads its bias from the step's table row)
+    const float* __restrict__ pbi = ((MLP && (flags & CDX2_F2_BIAS_EMB)) ? emb_row : L.wblob) + CDX2_DW(vd, CDX2_W2_BOFF) + c;
     const bool gn = (flags & (CDX2_F2_GN | CDX2_F2_GNBWD)) != 0;
     const float* __restrict__ pem = emb_row + (COND && SPLIT_T ? (wave >> 2) * emb_tstride : 0) + CDX2_DW(vd, CDX2_W2_EMB) + c;
     EpiParams P;
@@ -733,11 +799,11 @@ template <int T, bool BWD> constexpr bool pipe_params() { return CDX2_PIPE_PARAM
 // Epilogue threads: 256 per trajectory (8 GroupNorm groups x 32 lanes).  4 waves: all of them, one trajectory after the other;
 // 8 waves, T = 2: waves 0-3 take trajectory 0 while waves 4-7 take trajectory 1; 8 waves, T = 1: waves 0-3 run the epilogue,
 // waves 4-7 rewrite the destination's halo rows.
-template <int T, int NWV, bool BWD, bool PROF, bool COND>
+template <int T, int NWV, bool BWD, bool PROF, bool COND, bool MLP = false>
 __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* ops, int vd, int vdn, Item& it,
                                        const float* __restrict__ emb_row, int emb_tstride, float* __restrict__ lds, int tid,
                                        Ring<WG<NWV>::PF>& ring, unsigned long long* prof, int b0, OpFetch& F,
-                                       const float* __restrict__ emb_next, int emb_next_tstride, int op_next2) {
+                                       const float* __restrict__ emb_next, int emb_next_tstride, int op_next2, int pass = 0) {
     constexpr bool SPLIT_T = NWV == 8 && T >= 2;       // waves 0-3 take trajectories 0, 2; waves 4-7 trajectory 1
     constexpr bool PIPE = pipe_params<T, BWD>();
     constexpr bool PARAMS_AFTER_BARRIER = PIPE && T >= 2;
@@ -749,7 +815,7 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
         if (wave_of(tid) < CDX2_DW(vdn, CDX2_W2_NITEMS)) prefetch_ring(it, L.wblob, tid & 63, ring);
         if (PIPE) {
             if (params)
-                F.P = load_params<COND, SPLIT_T, false>(L, vdn, emb_next, emb_next_tstride, tid, wave_of(tid), NWV == 4 || SPLIT_T || wave_of(tid) < 4);
+                F.P = load_params<COND, SPLIT_T, false, MLP>(L, vdn, emb_next, emb_next_tstride, tid, wave_of(tid), NWV == 4 || SPLIT_T || wave_of(tid) < 4);
             F.vdn2 = load_desc<NWV>(L.ops, op_next2, tid & 63, wave_of(tid));
         }
     };
@@ -780,6 +846,28 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
         __syncthreads();
         return;
     }
+    if (MLP && CDX2_DW(vd, CDX2_W2_KIND) == CDX2_KIND2_LOADC) {      // context slot <- the samples' condition features (or zeros)
+        fetch_next(true);
+        const int dst = CDX2_DW(vd, CDX2_W2_DST), dstr = CDX2_DW(vd, CDX2_W2_DST_STRIDE);
+        const int len = CDX2_DW(vd, CDX2_W2_LOUT), ch = CDX2_DW(vd, CDX2_W2_COUT);
+        const int b_end = L.traj_first + L.traj_count;
+        const KArg* S = kernarg();
+        asm volatile("" : "+s"(S));
+        // (the unconditional forward of a classifier-free-guidance pair and a request without a condition see zeros: the reference
+        //  substitutes a zero tensor, e.g. pearcemlp.py:59-60)
+        const float* __restrict__ cg = pass == 0 ? S->ctx : nullptr;
+#pragma unroll 1
+        for (int t = 0; t < T; ++t) {
+            const bool real = cg != nullptr && b0 + t < b_end;
+            const float* __restrict__ cb = cg + (size_t)(b0 + t) * len * ch;
+            for (int i = tid; i < (len + 2 * CDX2_HALO2) * dstr; i += WG<NWV>::THREADS) {
+                const int r = i / dstr, c = i - r * dstr, n = r - CDX2_HALO2;
+                lds[t * tf + dst + i] = (real && n >= 0 && n < len && c < ch) ? cb[n * ch + c] : 0.f;
+            }
+        }
+        __syncthreads();
+        return;
+    }
     const int flags = CDX2_DW(vd, CDX2_W2_FLAGS), coutp = CDX2_DW(vd, CDX2_W2_COUTP), shift = CDX2_DW(vd, CDX2_W2_CG4_SHIFT);
     const int l_out = CDX2_DW(vd, CDX2_W2_LOUT), sstride = CDX2_DW(vd, CDX2_W2_SSTRIDE);
     const Geom g{CDX2_DW(vd, CDX2_W2_LCOLS), CDX2_DW(vd, CDX2_W2_CSTRIDE), CDX2_DW(vd, CDX2_W2_OSTRIDE), sstride, L.stage_off};
@@ -793,7 +881,7 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
     const int pos0 = li >> shift, pstep = 32 >> shift;
     const int nv = (coutp >> 5) * l_out;
     // this op's epilogue parameters: fetched during the PREVIOUS op (PIPE), or here (consumed after the barrier either way)
-    EpiParams P = PIPE ? F.P : load_params<COND, SPLIT_T, CDX2_PARAMS_ALL != 0>(L, vd, emb_row, emb_tstride, tid, wave, epi_wave);
+    EpiParams P = PIPE ? F.P : load_params<COND, SPLIT_T, CDX2_PARAMS_ALL != 0, MLP>(L, vd, emb_row, emb_tstride, tid, wave, epi_wave);
 
     // K loop -> staged partial tiles
     const int n_items = CDX2_DW(vd, CDX2_W2_NITEMS);
@@ -811,7 +899,7 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
     if (PROF) stamp(prof ? prof + 1 : nullptr, tid);
     __syncthreads();
     if (PROF) stamp(prof ? prof + 2 : nullptr, tid);
-    const EpiParams Pnext = PARAMS_AFTER_BARRIER ? load_params<COND, SPLIT_T, false>(L, vdn, emb_next, emb_next_tstride, tid, wave, epi_wave)
+    const EpiParams Pnext = PARAMS_AFTER_BARRIER ? load_params<COND, SPLIT_T, false, MLP>(L, vdn, emb_next, emb_next_tstride, tid, wave, epi_wave)
                                                  : (PIPE ? F.P : P);
 
     const EpiDesc e = decode_epi<BWD>(vd);
@@ -834,9 +922,9 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
                 if (e.nk == 1) epilogue_bwd<1>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
                 else if (e.nk == 2) epilogue_bwd<2>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
                 else epilogue_bwd<CDX2_MAX_NK2>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
-            } else if (e.nk == 1) epilogue<1, BWD, COND>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
-            else if (e.nk == 2) epilogue<2, BWD, COND>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
-            else epilogue<CDX2_MAX_NK2, BWD, COND>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
+            } else if (e.nk == 1) epilogue<1, BWD, COND, MLP>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
+            else if (e.nk == 2) epilogue<2, BWD, COND, MLP>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
+            else epilogue<CDX2_MAX_NK2, BWD, COND, MLP>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
         }
         if (halo_wave) {
             // wave w (mod 4) rewrites halo row w of the destination (the arena hands this LDS to slots of other shapes in between)
@@ -861,9 +949,10 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
 // COND: the instantiations that understand conditional requests (per-trajectory FiLM rows, the classifier-free-guidance pair, EDM /
 // consistency step kinds).  A separate template parameter so that the unconditional kernels -- the headline path, scalar-register
 // bound -- compile to exactly the code they had before.
-template <int T, int NWV, bool BWD, bool PROF, bool COND = false>
+template <int T, int NWV, bool BWD, bool PROF, bool COND = false, bool MLP = false>
 __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_unet2_kernel(const cdx_unet2_launch L) {
     static_assert(!(COND && BWD), "conditional requests have no backward-op variant");
+    static_assert(!MLP || (COND && T == 1 && NWV == 8), "batch-tiled MLP programs: the conditional one-trajectory 8-wave shape");
     constexpr int THREADS = WG<NWV>::THREADS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -918,13 +1007,14 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
 
     // log_p pass only (programs with a classifier head, n_steps == 0 and logp_out given): no forward of the whole op list, just the
     // block after the step loop -- one trajectory per workgroup, FiLM row b of the table for trajectory b (per-sample timesteps)
-    bool logp_only = false;
-    if (BWD) {
+    // (the flag is re-derived from the kernarg segment where it is needed: one more value live across the op loop is a scalar spill)
+    auto logp_only_f = [&]() -> bool {
+        if (!BWD) return false;
         const KArg* S0 = kernarg();
         asm volatile("" : "+s"(S0));
-        logp_only = L.n_steps == 0 && S0->logp_out != nullptr;
-    }
-    const int n_iter = logp_only ? 0 : (L.n_steps > 0 ? L.n_steps : 1);
+        return S0->n_steps == 0 && S0->logp_out != nullptr;
+    };
+    const int n_iter = logp_only_f() ? 0 : (L.n_steps > 0 ? L.n_steps : 1);
     const int HDp = (HD + 3) & ~3;                     // ws block of a trajectory: [multistep memory / EDM slope | x_old | p_cond]
     constexpr bool PIPE = pipe_params<T, BWD>();        // (see OpFetch)
     constexpr bool SPLIT_T0 = NWV == 8 && T >= 2;
@@ -955,7 +1045,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
     if (PIPE) {
         int ts0;
         const float* row0 = emb_of(0, 0, ts0);
-        F.P = load_params<COND, SPLIT_T0, false>(L, vd, row0, ts0, tid, wave, NWV == 4 || SPLIT_T0 || wave < 4);
+        F.P = load_params<COND, SPLIT_T0, false, MLP>(L, vd, row0, ts0, tid, wave, NWV == 4 || SPLIT_T0 || wave < 4);
         vdn_keep = load_desc<NWV>(L.ops, L.n_ops > 1 ? 1 : 0, lane, wave);
     }
     for (int step = 0; step < n_iter; ++step) {
@@ -980,8 +1070,8 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
             int on2 = oi + 2;
             if (on2 >= L.n_ops) on2 -= L.n_ops;
             if (on2 >= L.n_ops) on2 = 0;
-            run_op<T, NWV, BWD, PROF, COND>(L, ops, vd, vdn, it, emb_row, emb_tstride, lds, tid, ring, pslot, b0, F,
-                                            wrap ? emb_fwd_next : emb_row, wrap ? ts_fwd_next : emb_tstride, on2);
+            run_op<T, NWV, BWD, PROF, COND, MLP>(L, ops, vd, vdn, it, emb_row, emb_tstride, lds, tid, ring, pslot, b0, F,
+                                                 wrap ? emb_fwd_next : emb_row, wrap ? ts_fwd_next : emb_tstride, on2, pass);
             vd = vdn;
             if (PIPE) vdn_keep = F.vdn2;
         }
@@ -1138,6 +1228,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
         }
         __syncthreads();
     }
+    const bool logp_only = logp_only_f();
     if (BWD && (L.n_steps > 0 || logp_only)) {
         // final log_p (reference diffusionsde.py:597-601): the classifier's forward ops once more, on the final state, timestep 0
         // (log_p pass only: on the state just loaded, the trajectory's own row of the table)
@@ -1288,7 +1379,12 @@ int cdx_unet2_run(const cdx_unet2_launch* L, void* hip_stream) {
     }
     void (*kern)(const cdx_unet2_launch);
     const bool cond = L->n_pass == 2 || L->edm_plan || L->emb_per_traj;
-    if (cond) {
+    if (L->mlp) {
+        if (guided || L->traj_per_wg != 1 || L->n_waves != 8 || L->emb_per_traj || L->compact || L->prof) {
+            cdx_set_err("batch-tiled MLP program: one tile per workgroup, 8 waves, one table row per step, no backward ops"); return CDX_EINVAL;
+        }
+        kern = cdx_unet2_kernel<1, 8, false, false, true, true>;
+    } else if (cond) {
         if (L->prof) { cdx_set_err("op profiling: unconditional requests only"); return CDX_EINVAL; }
         kern = L->n_waves == 8 ? (L->traj_per_wg == 3 ? cdx_unet2_kernel<3, 8, false, false, true>
                                   : L->traj_per_wg == 2 ? cdx_unet2_kernel<2, 8, false, false, true> : cdx_unet2_kernel<1, 8, false, false, true>)

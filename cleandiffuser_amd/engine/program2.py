@@ -56,7 +56,7 @@ FUSE_MAX_RECORDS = int(os.environ.get("CDX_UNET2_FUSE_MAX", "100"))   # ... unle
 (W2_KIND, W2_FLAGS, W2_COUT, W2_LOUT, W2_LCOLS, W2_CSTRIDE, W2_OSTRIDE, W2_MODE, W2_NT, W2_NITEMS, W2_ITEMS, W2_DST,
  W2_DST_STRIDE, W2_SSTRIDE, W2_KSPLIT, W2_BOFF, W2_GAMMA, W2_BETA, W2_EMB, W2_RES, W2_RES_STRIDE, W2_CG4_SHIFT, W2_INV_CNT,
  W2_NK, W2_COUTP, W2_SAVE, W2_SAVE_STRIDE, W2_STATS, W2_DST2, W2_DST2_STRIDE, W2_KPOST, W2_PBIAS) = range(32)
-KIND2_CONV, KIND2_HEAD, KIND2_LOADX = 0, 1, 2
+KIND2_CONV, KIND2_HEAD, KIND2_LOADX, KIND2_LOADC = 0, 1, 2, 3
 W2_ITEM0 = 32                 # items 0..nw-1 inline; items nw.. in the tail table at W2_ITEMS
 
 
@@ -78,6 +78,14 @@ I2_WOFF, I2_NQ, I2_TAPCC, I2_PART, I2_COL0, I2_PADOOFF, I2_SRCSTR, I2_CCN = rang
 # F2_FILM (with F2_EMB): the table row holds [scale (pad32(C)) | bias (pad32(C))] at W2_EMB and the epilogue applies scale * y + bias
 # (ChiUNet1d's cond_predict_scale FiLM, reference chiunet.py:41-45) instead of y + vector
 F2_GN, F2_EMB, F2_RES, F2_PRED, F2_SAVE, F2_GNBWD, F2_DUAL, F2_SAVE_GLOBAL, F2_FILM = 1, 2, 4, 8, 16, 32, 64, 128, 256
+# Batch-tiled MLP programs (a "trajectory" = `tile` samples, one per position; a Linear = a 1-tap conv; MLP kernel instantiation only):
+# F2_COLNORM (with F2_GN): statistics per POSITION over the group's channels (a per-sample GroupNorm, reference pearcemlp.py FCBlock);
+# F2_BIAS_EMB: the bias vector is read from the per-step table row at W2_BOFF (bias + the time-dependent part of the layer's input);
+# F2_OUT_DIV: the stored value is divided by the float in W2_ODIV (PearceMlp's h / 1.414); bits 12-15: activation id + 1 of
+# program.py's ACT_* (0 = the default: Mish after a GroupNorm, none otherwise), applied after the norm, before + emb / + residual
+F2_COLNORM, F2_BIAS_EMB, F2_OUT_DIV = 512, 1024, 2048
+F2_ACT_SHIFT = 12
+W2_ODIV = 26                  # forward ops: alias of W2_SAVE_STRIDE (a backward-pass word)
 
 
 def pad32(c: int) -> int:
@@ -183,6 +191,7 @@ class _Builder2:
         self.save_global = False
         self.ws_floats = 0                 # per-trajectory global workspace (saved x_hat tensors) when save_global
         self.allow_4x4 = True
+        self.fuse_max = FUSE_MAX_RECORDS   # longest main-conv K slice (records) next to which an extra conv still rides in the same op
 
     def add(self, t: torch.Tensor, pad_to: int = 4) -> int:
         t = t.detach().to(device=self.device, dtype=torch.float32).reshape(-1)
@@ -224,7 +233,8 @@ class _Builder2:
     def conv(self, srcs: List[Act], dst: Act, w_eff: torch.Tensor, bias: Optional[torch.Tensor], *, stride=1, pad=0,
              transposed=False, phases=None, gn: Optional[nn.Module] = None, emb_off: int = -1, res: Optional[Act] = None,
              pred: bool = False, save: Optional[Tuple[Act, int]] = None, bwd: Optional[dict] = None,
-             extra: Optional[List[dict]] = None, film: bool = False):
+             extra: Optional[List[dict]] = None, film: bool = False, act: Optional[int] = None, col_norm: bool = False,
+             bias_row: int = -1, out_div: Optional[float] = None):
         """One fused op: conv over the channel concat of `srcs` -> epilogue -> dst.
 
         `extra`: further stride-1 convs with the same output shape computed by the SAME op on other waves -- dicts
@@ -315,7 +325,7 @@ class _Builder2:
                 if i is None:
                     break
                 per[i] += 1
-            if extra and max(n_of[i] / per[i] for i in range(len(srcs))) > FUSE_MAX_RECORDS:
+            if extra and max(n_of[i] / per[i] for i in range(len(srcs))) > self.fuse_max:
                 # the main conv is a long, stream-bound K loop: giving waves away to the extra conv costs it more than an op of its own
                 return False
             self.macs += sum(c_out * l_out * ex["w_eff"].shape[1] * ex["w_eff"].shape[2] for ex in extra)
@@ -379,8 +389,12 @@ class _Builder2:
             stage_slices = ksplit
         words = {W2_KIND: KIND2_CONV, W2_COUT: c_out, W2_LOUT: l_out, W2_LCOLS: l_cols, W2_CSTRIDE: cstride, W2_OSTRIDE: ostride,
                  W2_MODE: mode, W2_NT: nt, W2_NITEMS: len(items), W2_DST_STRIDE: dst.stride, W2_SSTRIDE: sstride,
-                 W2_KSPLIT: ksplit, W2_COUTP: coutp, W2_KPOST: kpost,
-                 W2_BOFF: self.add(_padded(bias if bias is not None else torch.zeros(c_out, device=self.device), coutp))}
+                 W2_KSPLIT: ksplit, W2_COUTP: coutp, W2_KPOST: kpost}
+        if bias_row >= 0:
+            assert bias is None, "a table-row bias replaces the static one (fold it into the row)"
+            words[W2_BOFF] = bias_row
+        else:
+            words[W2_BOFF] = self.add(_padded(bias if bias is not None else torch.zeros(c_out, device=self.device), coutp))
         if kpost:
             words[W2_PBIAS] = self.add(_padded(pbias, coutp))
         cg = coutp // GROUPS2
@@ -401,7 +415,10 @@ class _Builder2:
             if c_out % norm.num_groups or c_out // norm.num_groups != cg or abs(norm.eps - GN_EPS) > 1e-12:
                 raise ValueError(f"v2 epilogue needs GroupNorm groups of pad32(C)/8 channels (C={c_out}, G={norm.num_groups})")
             flags |= F2_GN if bwd is None else F2_GNBWD
-            words[W2_INV_CNT] = _fbits(1.0 / (cg * l_out))
+            if col_norm:
+                assert bwd is None
+                flags |= F2_COLNORM
+            words[W2_INV_CNT] = _fbits(1.0 / (cg if col_norm else cg * l_out))
             words[W2_GAMMA], words[W2_BETA] = self.add(_padded(norm.weight, coutp)), self.add(_padded(norm.bias, coutp))
         if bwd is not None:
             assert gn is None and emb_off < 0 and save is None and bwd["save"].chans == c_out and bwd["save"].length == l_out
@@ -428,6 +445,15 @@ class _Builder2:
             reads.append(res)
         if pred:
             flags |= F2_PRED
+        if bias_row >= 0:
+            flags |= F2_BIAS_EMB
+        if act is not None:
+            assert bwd is None and 0 <= act < 15
+            flags |= (act + 1) << F2_ACT_SHIFT
+        if out_div is not None:
+            assert bwd is None and save is None
+            flags |= F2_OUT_DIV
+            words[W2_ODIV] = _fbits(float(out_div))
         words[W2_FLAGS] = flags
         op = [0] * op_words(self.nw)
         for k, v in words.items():
@@ -470,6 +496,20 @@ class _Builder2:
         """Compact guided programs: the state x_t is read back from GLOBAL memory (the launch's x_out, where compact programs keep
         it) into a fresh slot for the classifier's first ops -- the denoiser's own copy need not stay in LDS across its peak."""
         words = {W2_KIND: KIND2_LOADX, W2_COUT: dst.chans, W2_LOUT: dst.length, W2_NITEMS: 0, W2_DST_STRIDE: dst.stride,
+                 W2_COUTP: pad32(dst.chans), W2_NK: 1, W2_KSPLIT: 1}
+        op = [0] * op_words(self.nw)
+        for k, v in words.items():
+            op[k] = int(v)
+        self.ops.append(op)
+        self.op_acts.append(dict(srcs=[], res=None, dst=dst, save=None, dst2=None, reads=[], writes=[dst]))
+        self.op_items.append([])
+        self.op_item_src.append([])
+
+    def load_context(self, dst: Act):
+        """Batch-tiled MLP programs: the per-sample condition features of the workgroup's samples (launch `ctx`, (batch, tile, C)) ->
+        slot `dst` at the start of every forward; zeros for the unconditional forward of a classifier-free-guidance pair and when the
+        request has no condition (the reference substitutes zeros, e.g. pearcemlp.py:59-60)."""
+        words = {W2_KIND: KIND2_LOADC, W2_COUT: dst.chans, W2_LOUT: dst.length, W2_NITEMS: 0, W2_DST_STRIDE: dst.stride,
                  W2_COUTP: pad32(dst.chans), W2_NK: 1, W2_KSPLIT: 1}
         op = [0] * op_words(self.nw)
         for k, v in words.items():
@@ -742,6 +782,191 @@ def compile_chiunet2(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4
     prog.meta["chi_film"] = chiunet_film_spec(net, blocks, b.n_emb, dev)
     prog.meta["cond_dim"] = net.global_cond_encoder.in_features
     return prog
+
+
+# ================================================================================================== #
+# Batch-tiled MLP denoisers on the v2 kernel: a "trajectory" is a tile of samples, the sample index   #
+# rides the position axis, a Linear is a 1-tap conv.  Everything that depends on the timestep only    #
+# (time embeddings through their MLPs, the raw timestep column) is folded by the HOST into per-step   #
+# bias rows of the launch's table; the per-sample condition sits in a context slot reloaded at the    #
+# start of every forward (zeros for the unconditional forward of a classifier-free-guidance pair).    #
+# ================================================================================================== #
+class _RowSpec:
+    """Table-row bookkeeping of an MLP program: row[off : off + n] = W feat(src) + bias with src in {"temb": map_noise(t),
+    "tfeat": the net's own time MLP over it, "t": the raw timestep}."""
+
+    def __init__(self, b: "_Builder2"):
+        self.b, self.terms = b, []
+
+    def row(self, c_out: int, bias: Optional[torch.Tensor], **parts) -> int:
+        off = self.b.emb_slot(c_out)
+        self.terms.append((off, c_out, bias, parts))
+        return off
+
+    def finish(self, n_emb: int, dev) -> dict:
+        out = {"bias": torch.zeros(n_emb, device=dev)}
+        for off, n, bias, parts in self.terms:
+            if bias is not None:
+                out["bias"][off:off + n] = bias.detach().to(dev, torch.float32)
+            for src, w in parts.items():
+                w = w.detach().to(dev, torch.float32).reshape(n, -1)
+                m = out.get(src)
+                if m is None:
+                    m = out[src] = torch.zeros(n_emb, w.shape[1], device=dev)
+                m[off:off + n] = w
+        return out
+
+
+def _lin_eff2(w: torch.Tensor) -> torch.Tensor:
+    """(n_out, n_in) Linear weight (slice) -> [co][tap = 1][ci]."""
+    return w.detach().unsqueeze(1)
+
+
+def _finish_mlp(b: "_Builder2", rows: _RowSpec, kind: str, x: Act, pred: Act, ctx: Optional[Act], tile: int, d: int, emb_dim: int,
+                max_lds_bytes: int, dev) -> Program2:
+    prog = _finalize2(b, [{}], x, pred, tile, d, emb_dim, max_lds_bytes, [ctx] if ctx is not None else [])
+    prog.embtabs = []
+    prog.meta["mlp"] = dict(kind=kind, tile=tile, cond_dim=0 if ctx is None else ctx.chans, rows=rows.finish(b.n_emb, dev))
+    return prog
+
+
+def compile_pearce_mlp2(net, tile: int, max_lds_bytes: int = 160 * 1024, nw: int = NW2_MAX) -> Program2:
+    """PearceMlp (reference nn_diffusion/pearcemlp.py:36-79).  fcs[0] reads [act_emb(x) | map_noise(t) | condition]: the time part
+    becomes its bias row; fcs[1..3] read [skip | x | raw t]: the t column (times the timestep) joins their bias rows.  FCBlock =
+    Linear -> per-sample GroupNorm -> GELU(erf); the skips are stored divided by 1.414 exactly where the reference divides (Q11)."""
+    from .program import ACT_GELU_ERF, ACT_LEAKY, ACT_NONE
+    dev = next(net.parameters()).device
+    b = _Builder2(dev, nw)
+    rows = _RowSpec(b)
+    d, e, hd, n_cond = net.act_dim, net.emb_dim, net.hidden_dim, net.To * net.emb_dim
+    x = b.act(tile, d, persistent=True)
+    ctx = b.act(tile, n_cond, persistent=True)
+    b.load_context(ctx)
+    a1, xe = b.act(tile, e), b.act(tile, e)
+    b.conv([x], a1, _lin_eff2(net.act_emb[0].weight), net.act_emb[0].bias, act=ACT_LEAKY)
+    b.conv([a1], xe, _lin_eff2(net.act_emb[2].weight), net.act_emb[2].bias, act=ACT_NONE)
+    f = net.fcs
+    w0 = f[0].model[0].weight.detach()
+    h1 = b.act(tile, hd)
+    b.conv([xe, ctx], h1, _lin_eff2(torch.cat([w0[:, :e], w0[:, 2 * e:]], 1)), None, gn=f[0].model[1], col_norm=True, act=ACT_GELU_ERF,
+           bias_row=rows.row(hd, f[0].model[0].bias, temb=w0[:, e:2 * e]), out_div=net.SKIP_SCALE)
+    cur = h1
+    for i in (1, 2):
+        w = f[i].model[0].weight.detach()
+        nxt = b.act(tile, hd)
+        b.conv([cur, x], nxt, _lin_eff2(w[:, :hd + d]), None, gn=f[i].model[1], col_norm=True, act=ACT_GELU_ERF, res=cur,
+               bias_row=rows.row(hd, f[i].model[0].bias, t=w[:, hd + d:]), out_div=net.SKIP_SCALE if i == 1 else None)
+        cur = nxt
+    pred = b.act(tile, d)
+    w3 = f[3].weight.detach()
+    b.conv([cur, x], pred, _lin_eff2(w3[:, :hd + d]), None, pred=True, act=ACT_NONE, bias_row=rows.row(d, f[3].bias, t=w3[:, hd + d:]))
+    return _finish_mlp(b, rows, "pearce", x, pred, ctx, tile, d, e, max_lds_bytes, dev)
+
+
+def compile_dql_mlp2(net, tile: int, max_lds_bytes: int = 160 * 1024, nw: int = NW2_MAX) -> Program2:
+    """DQLMlp (reference nn_diffusion/dqlmlp.py:9-52) and DVInvMlp (dvinvmlp.py:9-47, same trunk): features [x | time_mlp(map_noise(t))
+    | obs] -> 3 x (Linear, Mish) -> Linear; the time features are batch-invariant: they enter as the first layer's bias row."""
+    from .program import ACT_MISH, ACT_NONE
+    dev = next(net.parameters()).device
+    b = _Builder2(dev, nw)
+    rows = _RowSpec(b)
+    d, e, obs = net.final_layer.out_features, net.time_mlp[0].in_features, net.obs_dim
+    m = net.mid_layer
+    hid = m[0].out_features
+    x = b.act(tile, d, persistent=True)
+    ctx = b.act(tile, obs, persistent=True)
+    b.load_context(ctx)
+    w0 = m[0].weight.detach()
+    m1, m2, m3 = b.act(tile, hid), b.act(tile, hid), b.act(tile, hid)
+    b.conv([x, ctx], m1, _lin_eff2(torch.cat([w0[:, :d], w0[:, d + e:]], 1)), None, act=ACT_MISH,
+           bias_row=rows.row(hid, m[0].bias, tfeat=w0[:, d:d + e]))
+    b.conv([m1], m2, _lin_eff2(m[2].weight), m[2].bias, act=ACT_MISH)
+    b.conv([m2], m3, _lin_eff2(m[4].weight), m[4].bias, act=ACT_MISH)
+    pred = b.act(tile, d)
+    b.conv([m3], pred, _lin_eff2(net.final_layer.weight), net.final_layer.bias, pred=True, act=ACT_NONE)
+    return _finish_mlp(b, rows, "dql", x, pred, ctx, tile, d, e, max_lds_bytes, dev)
+
+
+def compile_mlp_nn2(net, tile: int, max_lds_bytes: int = 160 * 1024, nw: int = NW2_MAX) -> Program2:
+    """MlpNNDiffusion (reference nn_diffusion/mlps.py:10-40): Mlp(cat[x, map_noise(t) + condition]); the first Linear's embedding
+    columns act on the time embedding (bias row) and on the condition (context slot) alike."""
+    from .program import _act_id
+    dev = next(net.parameters()).device
+    b = _Builder2(dev, nw)
+    rows = _RowSpec(b)
+    layers = list(net.mlp.mlp)
+    lins = [m[0] if isinstance(m, nn.Sequential) else m for m in layers if isinstance(m, (nn.Sequential, nn.Linear))]
+    acts = [_act_id(m[1]) for m in layers if isinstance(m, nn.Sequential)] + [_act_id(layers[-1])]
+    if any(a is None for a in acts) or len(lins) != len(acts):
+        raise ValueError("MlpNNDiffusion: activation without a native epilogue")
+    d = lins[-1].out_features
+    e = lins[0].in_features - d
+    x = b.act(tile, d, persistent=True)
+    ctx = b.act(tile, e, persistent=True)
+    b.load_context(ctx)
+    cur, pred = None, None
+    for i, (lin, act) in enumerate(zip(lins, acts)):
+        last = i == len(lins) - 1
+        dst = b.act(tile, lin.out_features)
+        if i == 0:
+            w0 = lin.weight.detach()
+            b.conv([x, ctx], dst, _lin_eff2(w0), None, act=act, pred=last, bias_row=rows.row(lin.out_features, lin.bias, temb=w0[:, d:]))
+        else:
+            b.conv([cur], dst, _lin_eff2(lin.weight), lin.bias, act=act, pred=last)
+        cur = dst
+    pred = cur
+    return _finish_mlp(b, rows, "mlpnn", x, pred, ctx, tile, d, e, max_lds_bytes, dev)
+
+
+def compile_sfbc_unet2(net, tile: int, max_lds_bytes: int = 160 * 1024, nw: int = NW2_MAX) -> Program2:
+    """SfBCUNet (reference nn_diffusion/sfbc_unet.py:9-82): block(x, c) = SiLU(L2(SiLU(L1 x) + Lc c)) + skip(x) with c =
+    t_layer(map_noise(t)) + condition.  Lc t_layer(...) + bc is a per-step vector added after the first activation (table row);
+    Lc condition and the skip Linear are 1-tap convs whose partial tiles are added after the activation of the op they ride in."""
+    from .program import ACT_NONE, ACT_SILU
+    dev = next(net.parameters()).device
+    b = _Builder2(dev, nw)
+    b.fuse_max = 1 << 30                  # (Linears: the extra streams are what the block IS, not an optimisation)
+    rows = _RowSpec(b)
+    d, e = net.out_layer.out_features, net.t_layer[0].in_features
+    x = b.act(tile, d, persistent=True)
+    ctx = b.act(tile, e, persistent=True)
+    b.load_context(ctx)
+
+    def block(srcs: List[Act], blk) -> Act:
+        c_out = blk.linear1[0].out_features
+        h, o = b.act(tile, c_out), b.act(tile, c_out)
+        wc = blk.linearc.weight.detach()
+        ok = b.conv(srcs, h, _lin_eff2(blk.linear1[0].weight), blk.linear1[0].bias, act=ACT_SILU,
+                    emb_off=rows.row(c_out, blk.linearc.bias, tfeat=wc),
+                    extra=[dict(srcs=[ctx], w_eff=_lin_eff2(wc), pad=0, bias=None, post=True)])
+        if not ok:
+            raise ValueError("SfBCUNet block too wide for one op")
+        if isinstance(blk.skip, nn.Identity):
+            if len(srcs) == 1:
+                b.conv([h], o, _lin_eff2(blk.linear2[0].weight), blk.linear2[0].bias, act=ACT_SILU, res=srcs[0])
+                return o
+            skip_w, skip_b = torch.eye(c_out, device=dev), None          # identity skip over a concat whose widths happen to match
+        else:
+            skip_w, skip_b = blk.skip.weight.detach(), blk.skip.bias
+        ok = b.conv([h], o, _lin_eff2(blk.linear2[0].weight), blk.linear2[0].bias, act=ACT_SILU,
+                    extra=[dict(srcs=srcs, w_eff=_lin_eff2(skip_w), pad=0, bias=skip_b, post=True)])
+        if not ok:
+            raise ValueError("SfBCUNet block too wide for one op")
+        return o
+
+    cur, kept = x, []
+    for blk in net.down_blocks:
+        cur = block([cur], blk)
+        kept.append(cur)
+    cur = block([cur], net.mid_block)
+    for blk in net.up_blocks:
+        cur = block([cur, kept.pop()], blk)
+    pred = b.act(tile, d)
+    b.conv([cur], pred, _lin_eff2(net.out_layer.weight), net.out_layer.bias, pred=True, act=ACT_NONE)
+    return _finish_mlp(b, rows, "sfbc", x, pred, ctx, tile, d, e, max_lds_bytes, dev)
+
+
+MLP2_COMPILERS = {"pearce": compile_pearce_mlp2, "dql": compile_dql_mlp2, "mlpnn": compile_mlp_nn2, "sfbc": compile_sfbc_unet2}
 
 
 def _dgrad_eff(conv: nn.Conv1d) -> torch.Tensor:

@@ -17,7 +17,7 @@ from . import program as P
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libcdx.so")
 LIB_PATH = os.environ.get("CDX_LIB", LIB_PATH)          # A/B hook: run the same process against another build
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class CdxStep(ctypes.Structure):
@@ -471,6 +471,11 @@ def fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed, x_scale:
     `x_scale` given: `xt` is the raw N(0, I) draw (see dispatch.try_fused_raw); only the v2 U-Net kernel takes such a request."""
     net = model["diffusion"]
     if xt.dim() == 2 and _mlp_kind(net) is not None:
+        from . import runtime2                        # the second-generation kernel first (it returns None BEFORE drawing from `feed`)
+        load_library()
+        out = runtime2.fused_sample_mlp2(solver, net, _mlp_kind(net), plan, xt, prior, cond_vec, w_cfg, feed)
+        if out is not None:
+            return out
         return fused_sample_mlp(solver, net, _mlp_kind(net), plan, xt, prior, cond_vec, w_cfg, feed)
     if xt.dim() != 3 or not (_is_janner(net) or _is_chiunet(net)):
         return None

@@ -47,7 +47,7 @@ class CdxUnet2Launch(ctypes.Structure):
                 ("compact", ctypes.c_int32), ("prof", ctypes.c_void_p),
                 ("emb_per_traj", ctypes.c_int32), ("n_pass", ctypes.c_int32), ("emb_u", ctypes.c_void_p), ("cfg_w", ctypes.c_float),
                 ("edm_plan", ctypes.c_int32), ("logp_out", ctypes.c_void_p), ("logp_first_op", ctypes.c_int32),
-                ("logp_head_op", ctypes.c_int32)]
+                ("logp_head_op", ctypes.c_int32), ("ctx", ctypes.c_void_p), ("mlp", ctypes.c_int32)]
 
 
 _declared = False
@@ -278,12 +278,13 @@ def shape_for(module, horizon: int, batch: int):
 def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps=0, predict_noise=0, prior=None,
            fix_mask=None, noise=None, x_min=None, x_max=None, t_per_wg: Optional[int] = None, x_scale: Optional[float] = None,
            cg_scale=None, with_backward: bool = False, parts=None, emb_per_traj: bool = False, emb_u=None, cfg_w: float = 1.0,
-           edm: bool = False, logp_out=None):
+           edm: bool = False, logp_out=None, ctx=None):
     if batch <= 0:
         return
     prog = comp.prog
     if "chi_film" in prog.meta and not emb_per_traj:
         raise ValueError("ChiUNet1d programs carry FiLM-scale ops: only the per-trajectory-table kernels decode them")
+    mlp = "mlp" in prog.meta
     t = t_per_wg or traj_per_wg(prog, batch)
     prof = R._prof["buf"]
     # Two trajectories per workgroup fill the 256 CUs in rounds of 512 trajectories; a remainder of up to 256 is cheaper one
@@ -326,7 +327,7 @@ def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps
             ws_floats=ws_floats, compact=int(prog.compact), prof=R._ptr(prof), emb_per_traj=int(emb_per_traj),
             n_pass=2 if emb_u is not None else 1, emb_u=R._ptr(emb_u), cfg_w=float(cfg_w), edm_plan=int(edm),
             logp_out=R._ptr(logp_out), logp_first_op=prog.meta.get("cls_first", 0) if logp_out is not None else 0,
-            logp_head_op=prog.meta.get("head_op", 0) if logp_out is not None else 0)
+            logp_head_op=prog.meta.get("head_op", 0) if logp_out is not None else 0, ctx=R._ptr(ctx), mlp=int(mlp))
         R._check(_lib().cdx_unet2_run(ctypes.byref(L), R._stream_ptr(x_in.device)), "cdx_unet2_run")
     if timing["on"]:
         end.record(torch.cuda.current_stream(x_in.device))
@@ -647,3 +648,111 @@ def classifier_forward2(clf_net, x, noise_t) -> Optional[torch.Tensor]:
         out = torch.empty((b, 1), dtype=torch.float32, device=x.device)
         launch(comp, batch=b, x_in=xin, x_out=xin, emb=emb, t_per_wg=1, with_backward=True, logp_out=out)
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------- #
+# batch-tiled MLP denoisers (PearceMlp, DQLMlp / DVInvMlp, MlpNNDiffusion, SfBCUNet) on the second-generation kernel     #
+# ------------------------------------------------------------------------------------------------------------------- #
+_mcache = weakref.WeakKeyDictionary()
+
+
+def compiled_mlp2(net, kind: str, tile: int) -> _Compiled2:
+    per = _mcache.setdefault(net, {})
+    sig = R._signature(net)
+    hit = per.get(tile)
+    if hit is not None and hit.sig == sig:
+        return hit
+    with torch.no_grad():
+        try:
+            comp = _Compiled2(P2.MLP2_COMPILERS[kind](net, tile), sig)
+        except (ValueError, AssertionError) as e:      # widths the epilogue partition / GroupNorm layout does not take
+            comp = _Compiled2(None, sig, str(e))
+    per[tile] = comp
+    return comp
+
+
+def mlp_table(comp: _Compiled2, net, plan, device) -> torch.Tensor:
+    """(steps, n_emb) table of a batch-tiled MLP program: bias rows = static bias + the layer's time-dependent inputs (time embedding,
+    the net's own time MLP over it -- on ``cdx_gemm_f32`` --, the raw timestep column).  Kept with the solver's cached plan."""
+    from . import blocks
+    memo = plan.__dict__.setdefault("_memo", {})
+    key = ("mlp2", str(device), id(net), comp.prog.meta["mlp"]["tile"])
+    hit = memo.get(key)
+    if hit is not None and hit[0] == comp.sig:
+        return hit[1]
+    spec = comp.prog.meta["mlp"]
+    r = spec["rows"]
+    with torch.no_grad():
+        t_vec = R.device_times(plan, device)
+        temb = R._f32c(net.map_noise(t_vec), device)
+        out = r["bias"][None, :].repeat(temb.shape[0], 1).contiguous()
+        if "temb" in r:
+            out = blocks.linear(temb, r["temb"], None, residual=out)
+        if "tfeat" in r:
+            seq = net.time_mlp if spec["kind"] == "dql" else net.t_layer
+            act = "mish" if spec["kind"] == "dql" else "silu"
+            tf = blocks.linear(blocks.linear(temb, seq[0].weight, seq[0].bias, act=act), seq[2].weight, seq[2].bias)
+            out = blocks.linear(tf, r["tfeat"], None, residual=out)
+        if "t" in r:                                    # the raw timestep as a feature (PearceMlp, Q11): a rank-1 term
+            out = out + t_vec.to(torch.float32)[:, None] * r["t"][:, 0][None, :]
+    memo[key] = (comp.sig, out.contiguous())
+    return memo[key][1]
+
+
+def fused_sample_mlp2(solver, net, kind, plan, xt, prior, cond_vec, w_cfg, feed) -> Optional[torch.Tensor]:
+    """Batch-tiled MLP denoisers (x of shape (B, D)): one workgroup per `tile` samples, the whole loop in ONE cdx_unet2_run launch
+    (conditional forward, the classifier-free-guidance pair and EDM plans included).  None -> the caller falls back."""
+    if not enabled() or os.environ.get("CDX_UNET2_MLP", "1") == "0":
+        return None
+    b, d = xt.shape
+    dev = xt.device
+    if cond_vec is None and w_cfg not in (0.0, 1.0):
+        return None                                   # the reference raises here; let the torch executor do it
+    use_cond = cond_vec is not None and w_cfg != 0.0
+    if kind == "dql" and type(net).__name__ == "DVInvMlp" and not use_cond:
+        return None                                   # DVInvMlp requires its condition (the reference fails on None)
+    try:
+        fix_mask = R._dense_hd(solver.fix_mask, 1, d, dev)
+        clip = getattr(plan, "clip_each_step", True)
+        x_min = R._dense_hd(getattr(solver, "x_min", None), 1, d, dev) if clip else None
+        x_max = R._dense_hd(getattr(solver, "x_max", None), 1, d, dev) if clip else None
+    except (ValueError, RuntimeError):
+        return None
+    tile, comp = R.mlp_tile(b), None
+    while tile >= 4:                                  # wide nets: fewer samples per workgroup keep the epilogue partition in range
+        comp = compiled_mlp2(net, kind, tile)
+        if comp.prog is not None:
+            break
+        tile //= 2
+    if comp is None or comp.prog is None:
+        return None
+    n_tiles = -(-b // tile)
+    pad = n_tiles * tile - b
+
+    def rows(t):                                      # (B, D) -> (n_tiles * tile, D), zero rows appended
+        t = R._f32c(t, dev)
+        return torch.cat([t, t.new_zeros(pad, *t.shape[1:])]) if pad else t
+
+    def table(t):                                     # (1, D) -> (tile, D): the kernel indexes bounds / masks per tile row
+        return None if t is None else t.expand(tile, d).contiguous()
+
+    ctx = None
+    if use_cond:
+        ctx = rows(torch.flatten(cond_vec, 1))
+        if ctx.shape[1] != comp.prog.meta["mlp"]["cond_dim"]:
+            return None
+    edm = R.plan_is_edm(plan)
+    with torch.no_grad():
+        emb = mlp_table(comp, net, plan, dev)
+        steps_dev = R.steps_to_device(plan, dev)
+        noise = feed.many(xt, plan.n_noise)
+        if noise is not None and pad:                 # zero rows behind every draw: the last tile's unused samples
+            noise = torch.cat([R._f32c(noise, dev), noise.new_zeros(noise.shape[0], pad, d)], dim=1).contiguous()
+        xin = rows(xt)
+        out = torch.empty_like(xin)
+        pair = use_cond and w_cfg != 1.0
+        launch(comp, batch=n_tiles, x_in=xin, x_out=out, emb=emb, steps_dev=steps_dev, n_steps=len(plan.steps),
+               predict_noise=R._predicts_noise(plan, solver), prior=rows(prior) if fix_mask is not None else None,
+               fix_mask=table(fix_mask), noise=noise, x_min=table(x_min), x_max=table(x_max), t_per_wg=1,
+               emb_u=emb if pair else None, cfg_w=w_cfg, edm=edm, ctx=ctx)
+    return out[:b]

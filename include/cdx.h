@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define CDX_ABI_VERSION 7
+#define CDX_ABI_VERSION 8
 
 #define CDX_OK 0
 #define CDX_EINVAL (-1)   /* bad argument (null pointer, size out of range, misaligned offset) */
@@ -212,6 +212,13 @@ typedef struct cdx_unet2_launch {
      * row b of `emb` (per-sample timesteps), x_out is not written. */
     float* logp_out;           /* device (batch) or NULL */
     int32_t logp_first_op, logp_head_op;
+    /* Batch-tiled MLP programs (engine/program2.py: compile_*_mlp2; reference nn_diffusion/pearcemlp.py, dqlmlp.py, dvinvmlp.py, mlps.py,
+     * sfbc_unet.py): mlp != 0 selects the kernel instantiation that decodes their ops -- a "trajectory" is a tile of `horizon` samples
+     * of `dim` features (x_in (batch * horizon, dim)), traj_per_wg = 1, n_waves = 8, one table row per step.  `ctx`: the samples'
+     * condition features (batch * horizon, C) loaded into the program's context slot at the start of every forward, or NULL (zeros,
+     * what the reference substitutes for a missing condition); the second forward of a classifier-free-guidance pair sees zeros. */
+    const float* ctx;
+    int32_t mlp;
 } cdx_unet2_launch;
 int cdx_unet2_run(const cdx_unet2_launch* launch, void* hip_stream);
 

@@ -37,6 +37,8 @@ def activation(v, act_id):
         return np.maximum(v, 0).astype(np.float32)
     if act_id == P.ACT_GELU_TANH:
         return (0.5 * v * (1.0 + np.tanh(0.7978845608028654 * (v + 0.044715 * v ** 3)))).astype(np.float32)
+    if act_id == P.ACT_TANH:
+        return np.tanh(v).astype(np.float32)
     raise ValueError(act_id)
 
 

@@ -10,7 +10,7 @@ import numpy as np
 
 from cleandiffuser_amd.engine import program2 as P2
 from cleandiffuser_amd.engine.program import GN_EPS, MODE_16X16
-from .lane_sim import mish
+from .lane_sim import activation, mish
 
 
 def mish_grad(a):
@@ -90,10 +90,17 @@ class LaneSim2:
         return np.stack([self.lds[off + n * stride: off + n * stride + chans] for n in range(length)])
 
     # ------------------------------------------------------------------------------------------ #
-    def run_forward(self, emb_row):
-        """All ops once; returns the prediction slot (guided programs: see also grad())."""
+    def run_forward(self, emb_row, ctx=None):
+        """All ops once; returns the prediction slot (guided programs: see also grad()).  `ctx` (tile, C): the per-sample condition
+        features of a batch-tiled MLP program (None: zeros, as for the unconditional forward)."""
         for op in self.p.ops:
-            if int(op[P2.W2_KIND]) == P2.KIND2_HEAD:
+            if int(op[P2.W2_KIND]) == P2.KIND2_LOADC:         # context slot <- condition features; halo rows and pad channels zero
+                dst, dstr, ln, ch = (int(op[k]) for k in (P2.W2_DST, P2.W2_DST_STRIDE, P2.W2_LOUT, P2.W2_COUT))
+                self.lds[dst: dst + (ln + 2 * P2.HALO2) * dstr] = 0.0
+                if ctx is not None:
+                    for n in range(ln):
+                        self.lds[dst + (n + P2.HALO2) * dstr: dst + (n + P2.HALO2) * dstr + ch] = np.asarray(ctx, np.float32)[n]
+            elif int(op[P2.W2_KIND]) == P2.KIND2_HEAD:
                 self._head(op, np.asarray(emb_row, np.float32))
             elif int(op[P2.W2_KIND]) == P2.KIND2_LOADX:       # slot <- state from global memory; halo rows and pad channels zero
                 dst, dstr, ln, ch = (int(op[k]) for k in (P2.W2_DST, P2.W2_DST_STRIDE, P2.W2_LOUT, P2.W2_COUT))
@@ -200,7 +207,8 @@ class LaneSim2:
             o = int(op[word])
             return self.blob[o:o + coutp]
 
-        bias = par(P2.W2_BOFF)
+        bias = emb_row[int(op[P2.W2_BOFF]):int(op[P2.W2_BOFF]) + coutp] if flags & P2.F2_BIAS_EMB else par(P2.W2_BOFF)
+        act_id = (flags >> P2.F2_ACT_SHIFT) & 15              # 0: Mish after a GroupNorm, nothing otherwise
         vals = {}
         for tid in range(256):
             g, li = tid >> 5, tid & 31
@@ -217,7 +225,22 @@ class LaneSim2:
         if flags & P2.F2_GNBWD:
             self._epilogue_bwd(op, vals, par, cg, c_out, l_out)
             return
-        if flags & P2.F2_GN:
+        if (flags & P2.F2_GN) and (flags & P2.F2_COLNORM):
+            # per-sample GroupNorm: statistics of one POSITION over the group's channels, two passes (mean, then centred squares)
+            gamma, beta = par(P2.W2_GAMMA), par(P2.W2_BETA)
+            inv_cnt = np.int32(op[P2.W2_INV_CNT]).view(np.float32)
+            for g in range(P2.GROUPS2):
+                for pos in range(l_out):
+                    keys = [kk for kk in vals if kk[0] == g and kk[1] == pos]
+                    allv = np.concatenate([vals[kk] for kk in keys])
+                    mean = np.float32(allv.sum(dtype=np.float32) * inv_cnt)
+                    dlt = (allv - mean).astype(np.float32)
+                    rstd = np.float32(1.0) / np.sqrt(np.float32((dlt * dlt).sum(dtype=np.float32) * inv_cnt) + np.float32(GN_EPS))
+                    for kk in keys:
+                        c = kk[2]
+                        y = ((vals[kk] - mean) * rstd).astype(np.float32) * gamma[c:c + 4] + beta[c:c + 4]
+                        vals[kk] = activation(y, act_id - 1) if act_id else mish(y)
+        elif flags & P2.F2_GN:
             gamma, beta = par(P2.W2_GAMMA), par(P2.W2_BETA)
             inv_cnt = np.int32(op[P2.W2_INV_CNT]).view(np.float32)
             for g in range(P2.GROUPS2):
@@ -239,7 +262,11 @@ class LaneSim2:
                     if (flags & P2.F2_SAVE) and c < c_out:  # save slot: no halo, position-major; pad lane groups save nothing
                         a = int(op[P2.W2_SAVE]) + kk[1] * int(op[P2.W2_SAVE_STRIDE]) + c
                         (self.ws if flags & P2.F2_SAVE_GLOBAL else lds)[a:a + 4] = xh
-                    vals[kk] = mish(xh * gamma[c:c + 4] + beta[c:c + 4])
+                    y = xh * gamma[c:c + 4] + beta[c:c + 4]
+                    vals[kk] = activation(y, act_id - 1) if act_id else mish(y)
+        elif act_id:
+            for kk in vals:
+                vals[kk] = activation(vals[kk], act_id - 1)
         kpost = int(op[P2.W2_KPOST])
         for (g, pos, c), v in vals.items():
             if flags & P2.F2_FILM:                            # [scale | bias], pad32(C) apart: y <- scale * y + bias (two roundings)
@@ -257,6 +284,8 @@ class LaneSim2:
             if flags & P2.F2_RES:
                 a = int(op[P2.W2_RES]) + (pos + P2.HALO2) * int(op[P2.W2_RES_STRIDE]) + c
                 v = v + lds[a:a + 4]
+            if flags & P2.F2_OUT_DIV:
+                v = (v / np.int32(op[P2.W2_ODIV]).view(np.float32)).astype(np.float32)
             for j in range(4):
                 if c + j < c_out:
                     assert np.isfinite(v[j]), "NaN reached a destination slot"
@@ -323,3 +352,22 @@ def chi_film_rows(prog: P2.Program2, net, t, cond) -> np.ndarray:
         ce = F.mish(net.global_cond_encoder(torch.flatten(cond, 1)))
         rows = te @ f["w_t"].cpu().t() + ce @ f["w_c"].cpu().t() + f["bias"].cpu()
     return rows.numpy().astype(np.float32)
+
+
+def mlp_rows(prog: P2.Program2, net, t) -> np.ndarray:
+    """Per-step table rows of a batch-tiled MLP program (what runtime2.mlp_table computes on the device): bias + W_src feat_src(t) for
+    src in {"temb": map_noise(t), "tfeat": the net's time MLP over it, "t": the raw timestep}; t (n,) -> (n, n_emb)."""
+    import torch
+    spec = prog.meta["mlp"]
+    r = spec["rows"]
+    with torch.no_grad():
+        temb = net.map_noise(t)
+        out = r["bias"].cpu()[None, :].repeat(t.shape[0], 1)
+        if "temb" in r:
+            out = out + temb @ r["temb"].cpu().t()
+        if "tfeat" in r:
+            tf = net.time_mlp(temb) if spec["kind"] == "dql" else net.t_layer(temb)
+            out = out + tf @ r["tfeat"].cpu().t()
+        if "t" in r:
+            out = out + t.to(torch.float32)[:, None] @ r["t"].cpu().t()
+    return out.numpy().astype(np.float32)

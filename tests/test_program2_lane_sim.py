@@ -284,3 +284,44 @@ def test_lane_sim2_classifier_program_reproduces_log_p(shape, amd_lib):
         sim.load_x(x[b].numpy())
         sim.run_forward(rows[b])
         np.testing.assert_allclose(sim.logp, want[b, 0], rtol=2e-5, atol=2e-5 * max(1.0, abs(float(want[b, 0]))))
+
+
+def _mlp_nets(amd_lib):
+    from cleandiffuser_amd.utils import load_synth
+    import torch.nn as nn
+    return {
+        "pearce": (load_synth(amd_lib.PearceMlp(6, To=2, emb_dim=32, hidden_dim=64), 1), 6, 2 * 32, P2.compile_pearce_mlp2),
+        "pearce256": (load_synth(amd_lib.PearceMlp(6, To=1, emb_dim=64, hidden_dim=256), 2), 6, 64, P2.compile_pearce_mlp2),
+        "dql": (load_synth(amd_lib.DQLMlp(11, 3, emb_dim=16), 3), 3, 11, P2.compile_dql_mlp2),
+        "dvinv": (load_synth(amd_lib.DVInvMlp(5, 3, emb_dim=16, hidden_dim=128), 4), 3, 10, P2.compile_dql_mlp2),
+        "mlpnn": (load_synth(amd_lib.MlpNNDiffusion(5, emb_dim=16, hidden_dims=[64, 128], activation=nn.SiLU()), 5), 5, 16, P2.compile_mlp_nn2),
+        "sfbc": (load_synth(amd_lib.SfBCUNet(4, emb_dim=32, hidden_dims=[128, 64, 64]), 6), 4, 32, P2.compile_sfbc_unet2),
+    }
+
+
+@pytest.mark.parametrize("tile", [4, 16])
+@pytest.mark.parametrize("kind", ["pearce", "pearce256", "dql", "dvinv", "mlpnn", "sfbc"])
+def test_lane_sim2_tile_mlp_programs_against_module_forward(kind, tile, amd_lib):
+    """Batch-tiled MLP denoisers on the v2 program format (a tile of samples = the position axis, Linears = 1-tap convs, the
+    time-dependent inputs folded into per-step bias rows, the condition in a context slot): conditional and zero-condition forwards
+    against the modules' own forward (bit-identical to the reference's, tests/test_module_mirrors.py)."""
+    from oracle.lane_sim2 import mlp_rows
+    net, d, n_cond, compiler = _mlp_nets(amd_lib)[kind]
+    net = net.eval()
+    prog = compiler(net, tile)
+    assert prog.nw == 8 and prog.lds_bytes(1) <= 160 * 1024 and prog.meta["mlp"]["cond_dim"] == n_cond
+    assert int(prog.ops[0][P2.W2_KIND]) == P2.KIND2_LOADC
+    g = torch.Generator().manual_seed(6)
+    x, cond = torch.randn(tile, d, generator=g), torch.randn(tile, n_cond, generator=g)
+    t = torch.full((tile,), 7)
+    row = mlp_rows(prog, net, t[:1])[0]
+    cshape = (tile, 2, 32) if kind == "pearce" else (tile, n_cond)
+    with torch.no_grad():
+        want_c = net(x, t, cond.reshape(cshape)).numpy()
+        want_u = net(x, t, None).numpy() if kind != "dvinv" else None
+    sim = LaneSim2(prog)
+    sim.load_x(x.numpy())
+    np.testing.assert_allclose(sim.run_forward(row, cond.numpy()), want_c, rtol=2e-5, atol=2e-5)
+    if want_u is not None:
+        sim.poison_arena()
+        np.testing.assert_allclose(sim.run_forward(row, None), want_u, rtol=2e-5, atol=2e-5)
