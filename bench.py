@@ -238,10 +238,13 @@ def other_configs(device):
     try:
         label, call, b, steps, net, horizon = bc.cfg1()
         dt, k_ms = timed(call, 5)
-        prog = runtime.compiled_program(net, horizon).prog
-        flops = 2.0 * prog.macs_per_forward / horizon * steps * b
+        from cleandiffuser_amd.engine import runtime2
+        tile = runtime.mlp_tile(b)
+        prog = runtime2.compiled_mlp2(net, "pearce", tile).prog
+        flops = 2.0 * prog.macs_per_forward / tile * steps * b
         out.append({"name": "config1", "workload": label, "value": b / dt, "unit": "samples/s", "ms_per_call": 1e3 * dt,
-                    "roofline_frac": flops / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, "dominant_kernel": "cdx_unet1d_kernel<true> (MLP tiles)",
+                    "roofline_frac": flops / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                    "dominant_kernel": f"cdx_unet2_kernel<1, 8, false, false, true, true> (batch-tiled MLP program, {tile} samples per workgroup)",
                     "fused_kernel_ms": (sum(k_ms) / len(k_ms)) if k_ms else None})
     except Exception as e:  # noqa: BLE001
         out.append({"name": "config1", "error": f"{type(e).__name__}: {e}"})
@@ -375,22 +378,19 @@ def main():
         k_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
         launch_b = BATCH if dist is None else cdist.shard_bounds(BATCH, 0, world)[1]      # trajectories one launch of rank 0 processes
         achieved = FLOPS_PER_TRAJ * launch_b / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
-        v2 = os.environ.get("CDX_UNET2", "1") != "0"
-        kname, l2 = "cdx_unet1d_kernel", None
-        if v2:
-            from cleandiffuser_amd.engine import runtime2
-            comp, parts = runtime2.plan_for(agent.model_ema["diffusion"], HORIZON, launch_b)
-            tpw = parts[0][2]
-            kname = f"cdx_unet2_kernel<{tpw}, {comp.prog.nw}> ({tpw} trajectories, {comp.prog.nw} wave64 per workgroup)"
-            # second roofline of the same launch: every workgroup streams the whole packed weight set from L2 once per denoiser
-            # forward (activations never leave LDS).  With one trajectory per CU -- all B = 256 allows -- THIS is the binding
-            # limit: MI355X_MICROARCH.md gives 34.5 TB/s aggregate L2 bandwidth
-            wbytes = 4.0 * comp.prog.meta["blob_floats"]
-            n_wg = sum(-(-cnt // t) for _, cnt, t in parts)
-            l2_bytes = wbytes * n_wg * SAMPLE_STEPS
-            l2 = {"bound": "l2", "bytes_per_launch": l2_bytes, "achieved": l2_bytes / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0,
-                  "peak": 34.5, "unit": "TB/s", "weight_bytes_per_forward": wbytes, "workgroups": n_wg}
-            l2["frac"] = l2["achieved"] / l2["peak"]
+        from cleandiffuser_amd.engine import runtime2
+        comp, parts = runtime2.plan_for(agent.model_ema["diffusion"], HORIZON, launch_b)
+        tpw = parts[0][2]
+        kname = f"cdx_unet2_kernel<{tpw}, {comp.prog.nw}> ({tpw} trajectories, {comp.prog.nw} wave64 per workgroup)"
+        # second roofline of the same launch: every workgroup streams the whole packed weight set from L2 once per denoiser
+        # forward (activations never leave LDS).  With one trajectory per CU -- all B = 256 allows -- THIS is the binding
+        # limit: MI355X_MICROARCH.md gives 34.5 TB/s aggregate L2 bandwidth
+        wbytes = 4.0 * comp.prog.meta["blob_floats"]
+        n_wg = sum(-(-cnt // t) for _, cnt, t in parts)
+        l2_bytes = wbytes * n_wg * SAMPLE_STEPS
+        l2 = {"bound": "l2", "bytes_per_launch": l2_bytes, "achieved": l2_bytes / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0,
+              "peak": 34.5, "unit": "TB/s", "weight_bytes_per_forward": wbytes, "workgroups": n_wg}
+        l2["frac"] = l2["achieved"] / l2["peak"]
         out = {
             "metric": "denoised trajectories/sec @ (B=256,H=32,D=23) 20-step DDIM",
             "value": BATCH * args.steps / elapsed,

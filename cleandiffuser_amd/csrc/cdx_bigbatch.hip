@@ -1,6 +1,6 @@
 // cdx_bigbatch.hip -- whole sampling loops for the GEMM-shaped denoisers (DiT1d, residual MLPs) on gfx950.
 //
-// The one-workgroup-per-trajectory program kernel (cdx_unet1d.hip) is the right shape while a trajectory's
+// The one-workgroup-per-trajectory program kernel (cdx_unet2.hip) is the right shape while a trajectory's
 // activations fit one CU's LDS and the batch is a few hundred.  DiT1d (64 tokens x 320..1280 features) and the
 // wide IDQLMlp (hidden 1024..4096, 10^5..10^6 samples) are the opposite regime: M = batch x tokens is huge, every layer
 // is a plain (M, K) x (K, N) GEMM, weights are re-used by every row.  Here the host sequences tiled-GEMM /
@@ -13,7 +13,7 @@
 #include <stdint.h>
 
 #include "../../include/cdx.h"
-#include "cdx_ops.h"
+#include "cdx_ops2.h"
 
 extern void cdx_set_err(const char* msg);
 
@@ -71,7 +71,7 @@ __global__ void mlp_features_kernel(float* __restrict__ out, const float* __rest
 
 // ------------------------------------------------------------------------------------------------
 // One solver step on a chunk, state in HBM: guidance combine, clip, eps/x0 conversion, update, fix-mask blend.
-// Same arithmetic, in the same order, as the in-LDS step of cdx_unet1d.hip (kinds 0-4); kinds 5/6 are EDM.
+// Same arithmetic, in the same order, as the in-LDS step of cdx_unet2.hip (kinds 0-4); kinds 5/6 are EDM.
 // ------------------------------------------------------------------------------------------------
 struct StepArgs {
     float* x;             // (nb, hd) chunk state, in/out
@@ -1469,15 +1469,16 @@ long long cdx_guided_workspace_floats(const cdx_guided_launch* g) {
 }
 
 int cdx_guided_run(const cdx_guided_launch* g, void* hip_stream) {
-    if (!g || (!g->denoiser && !g->denoiser_gemm) || !g->classifier || !g->steps || !g->cg_scale || !g->temb || !g->clf_emb0 || !g->x_in || !g->x_out) {
+    if (!g || (!g->denoiser && !g->denoiser_gemm) || !g->classifier || !g->steps || !g->cg_scale || (g->denoiser_gemm && !g->temb) || !g->clf_emb0 ||
+        !g->x_in || !g->x_out) {
         cdx_set_err("cdx_guided_run: null pointer"); return CDX_EINVAL;
     }
     if (g->denoiser && g->denoiser_gemm) { cdx_set_err("cdx_guided_run: give the denoiser as a program launch OR as GEMM-executor weights"); return CDX_EINVAL; }
     if (g->n_steps <= 0 || g->batch < 0 || g->classifier->horizon * g->classifier->in_dim != g->hd) {
         cdx_set_err("cdx_guided_run: bad shape"); return CDX_EINVAL;
     }
-    if (g->denoiser && (g->hd != g->denoiser->horizon * g->denoiser->dim || g->denoiser->n_steps != 0 || g->denoiser->cfg_mode == 2 ||
-                        g->denoiser->tile != 0)) {
+    if (g->denoiser && (g->hd != g->denoiser->horizon * g->denoiser->dim || g->denoiser->n_steps != 0 || g->denoiser->n_pass == 2 ||
+                        g->denoiser->mlp != 0 || g->denoiser->compact != 0 || !g->denoiser->emb)) {
         cdx_set_err("cdx_guided_run: the denoiser must be a forward-mode U-Net launch matching the classifier's (horizon, dim)"); return CDX_EINVAL;
     }
     if (g->denoiser_gemm) {
@@ -1539,19 +1540,20 @@ int cdx_guided_run(const cdx_guided_launch* g, void* hip_stream) {
             chiunet_pass(g->denoiser_gemm, &S, st, den_ws, false, &rcg);
             CDX_TRY(rcg);
         }
-        cdx_unet1d_launch L;
+        cdx_unet2_launch L;
         if (g->denoiser) {
+            // forward mode of the program kernel: FiLM row(s) of step i -- one row, or one per trajectory (conditional denoisers)
             L = *g->denoiser;
-            L.n_steps = 0; L.steps = nullptr; L.temb_per_sample = 0; L.batch = g->batch;
-            L.temb = g->temb + (size_t)i * L.emb_dim; L.x_in = xnet; L.x_out = pred;
+            L.n_steps = 0; L.steps = nullptr; L.batch = g->batch; L.traj_first = 0; L.traj_count = g->batch;
+            L.emb = g->denoiser->emb + (size_t)i * (L.emb_per_traj ? g->batch : 1) * L.emb_ld; L.x_in = xnet; L.x_out = pred;
         }
         if (g->denoiser_gemm) {
         } else if (side) {
             if (hipEventRecord(side->fork, st) != hipSuccess || hipStreamWaitEvent(side->stream, side->fork, 0) != hipSuccess) return bail(hip_ok());
-            CDX_TRY_SIDE(cdx_unet1d_run(&L, side->stream));
+            CDX_TRY_SIDE(cdx_unet2_run(&L, side->stream));
             if (hipEventRecord(side->join, side->stream) != hipSuccess) return bail(hip_ok());
         } else {
-            CDX_TRY(cdx_unet1d_run(&L, hip_stream));
+            CDX_TRY(cdx_unet2_run(&L, hip_stream));
         }
         const int clf_rc = cdx_hjgrad_run(g->classifier, x, g->clf_emb0 + (size_t)i * g->classifier->emb_dim, 0, g->batch, logp, grad,
                                           clf_ws, clf_floats, hip_stream);

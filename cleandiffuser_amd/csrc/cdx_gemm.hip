@@ -19,7 +19,7 @@
 #include <string.h>
 
 #include "../../include/cdx.h"
-#include "cdx_ops.h"
+#include "cdx_ops2.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -3,6 +3,11 @@
 // MUST mirror cleandiffuser_amd/engine/program2.py (tests/test_abi_contract.py parses this file and compares).
 #pragma once
 
+/* shared with engine/program.py (MODE_*, GN_EPS): MFMA shape of a conv op's records, GroupNorm epsilon */
+#define CDX_MODE_16X16 0
+#define CDX_MODE_4X4 1
+#define CDX_GN_EPS 1e-5f
+
 #define CDX2_HDR_WORDS 32   /* 25 descriptor words, padded; == CDX2_W2_ITEM0 */
 #define CDX2_ITEM_WORDS 8
 #define CDX2_NW2 4         /* waves per workgroup of the default shape (one per SIMD) */
@@ -74,6 +79,6 @@
 #define CDX2_F2_COLNORM 512  /* with F2_GN: statistics per POSITION over the group's channels (per-sample GroupNorm) */
 #define CDX2_F2_BIAS_EMB 1024   /* the bias vector is read from the per-step table row at W2_BOFF */
 #define CDX2_F2_OUT_DIV 2048    /* the stored value is divided by the float in W2_ODIV */
-#define CDX2_F2_ACT_SHIFT 12    /* flags bits 12-15: activation id + 1 (CDX_ACT_* of cdx_ops.h), 0 = Mish after a GroupNorm, else none */
+#define CDX2_F2_ACT_SHIFT 12    /* flags bits 12-15: activation id + 1 (CDX_ACT_* of include/cdx.h), 0 = Mish after a GroupNorm, else none */
 #define CDX2_W2_ODIV 26         /* forward ops: alias of W2_SAVE_STRIDE */
 #define CDX2_KIND2_LOADC 3      /* context slot <- the launch's per-sample condition features (zeros: unconditional forward / no condition) */

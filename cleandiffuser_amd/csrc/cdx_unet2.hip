@@ -31,7 +31,6 @@
 #include <string.h>
 
 #include "../../include/cdx.h"
-#include "cdx_ops.h"
 #include "cdx_ops2.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -43,7 +42,7 @@ typedef const int __attribute__((address_space(4))) cint;
 static __device__ __forceinline__ const cint* as_const(const int* p) { return (const cint*)p; }
 #pragma clang diagnostic pop
 
-void cdx_set_err(const char* msg);          // cdx_unet1d.hip
+void cdx_set_err(const char* msg);          // cdx_common.hip
 
 // Workgroup shapes (template parameter NWV = wave64 per workgroup):
 //   4 waves, one per SIMD, 16 weight records in flight per wave -- up to 512 VGPRs per lane;
@@ -105,7 +104,7 @@ __device__ __forceinline__ float seg_sum(float v, int w_log2, int lane) {
     return v;
 }
 
-// Activations of the batch-tiled MLP programs: id = CDX_ACT_* (cdx_ops.h) + 1, wave-uniform (a scalar branch)
+// Activations of the batch-tiled MLP programs: id = CDX_ACT_* (include/cdx.h) + 1, wave-uniform (a scalar branch)
 __device__ __forceinline__ float act2_f(float x, int id) {
     switch (id) {
         case 2: return mish2(x);                                         // CDX_ACT_MISH

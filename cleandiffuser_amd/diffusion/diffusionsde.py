@@ -8,7 +8,7 @@ Architecture (different from the reference on purpose):
 1. ``sample()`` first *compiles* the request into a ``SamplePlan`` (engine/plan.py): one record per denoising
    step holding the frozen scalars of that step's affine update.
 2. The plan is executed by one of two executors that share those records:
-   * **fused gfx950 executor** (engine/dispatch.py -> C-ABI ``cdx_unet1d_run``): the *whole loop* -- every
+   * **fused gfx950 executor** (engine/dispatch.py -> C-ABI ``cdx_unet2_run``): the *whole loop* -- every
      U-Net forward, guidance combine, clip, solver update and fix-mask blend -- runs in ONE kernel launch with
      one workgroup per trajectory and all activations in LDS.  Chosen when the solver lives on a ROCm device,
      gradients are off, the backbone is one the engine can compile, and no per-step classifier guidance is asked.

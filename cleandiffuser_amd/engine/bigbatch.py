@@ -648,11 +648,10 @@ def is_chiunet_gemm(module, batch: int, horizon: Optional[int] = None, edm: bool
         return False
     if big or horizon is None:
         return big
-    if type(module) is ChiUNet1d:
-        from . import runtime2                         # the second-generation program kernel takes ChiUNet1d too (EDM plans included)
-        if runtime2.supported(module, horizon) is None:
-            return False
-    return runtime.supported_backbone(module, horizon, edm) is not None
+    from . import runtime2
+    if runtime.supported_backbone(module, horizon, edm) is not None:
+        return True                                    # no program holds it: the executor at any batch
+    return forward and runtime2.compact_only(module, horizon)       # (compact programs serve sampling loops only)
 
 
 def _bind_unet_gemm(net, tokens: int, dev):

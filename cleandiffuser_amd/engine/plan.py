@@ -2,7 +2,7 @@
 per-step records that BOTH executors consume --
 
 * the PyTorch executor in ``diffusion/diffusionsde.py`` (CPU, autograd, classifier guidance, unknown backbones)
-* the fused gfx950 kernel (``csrc/cdx_unet1d.hip``), which receives the same records as a ``cdx_step`` array.
+* the fused gfx950 kernel (``csrc/cdx_unet2.hip``), which receives the same records as a ``cdx_step`` array.
 
 Every scalar is evaluated exactly the way the reference evaluates it (0-dim fp32 torch ops in the same
 association order, reference diffusionsde.py:514-589), then frozen to a Python float, so the only

@@ -423,6 +423,8 @@ def fused_sample2(solver, net, plan, xt, prior, feed, fix_mask, x_min, x_max, x_
     `cond` (B, emb_dim) with w_cfg = 1: conditional forwards (per-trajectory FiLM rows); w_cfg not in {0, 1}: the classifier-free
     guidance pair inside the launch (reference diffusionsde.py:175-206).  EDM / consistency plans (kinds 5-7) included."""
     b, h, d = xt.shape
+    if b == 0:
+        return torch.empty_like(R._f32c(xt, xt.device))      # empty request: nothing to launch
     if b < min_batch() or supported(net, h) is not None:
         return None
     edm = R.plan_is_edm(plan)
@@ -468,6 +470,8 @@ def backbone_forward2(module, x, noise_t, condition=None) -> Optional[torch.Tens
     b, h, d = x.shape
     if supported(module, h) is not None:
         return None
+    if b == 0:
+        return torch.empty_like(R._f32c(x, x.device))
     comp, t_wg = shape_for(module, h, b)
     if comp.prog.compact:
         return None                                   # (compact-only nets: stand-alone forwards stay with the implicit-GEMM executor)
@@ -636,6 +640,8 @@ def classifier_forward2(clf_net, x, noise_t) -> Optional[torch.Tensor]:
     b, h, d = x.shape
     if getattr(clf_net, "in_dim", None) != d:
         return None
+    if b == 0:
+        return torch.empty((0, 1), dtype=torch.float32, device=x.device)
     comp = compiled_classifier2(clf_net, h)
     if comp.prog is None:
         return None
@@ -706,6 +712,8 @@ def fused_sample_mlp2(solver, net, kind, plan, xt, prior, cond_vec, w_cfg, feed)
         return None
     b, d = xt.shape
     dev = xt.device
+    if b == 0:
+        return torch.empty_like(R._f32c(xt, dev))
     if cond_vec is None and w_cfg not in (0.0, 1.0):
         return None                                   # the reference raises here; let the torch executor do it
     use_cond = cond_vec is not None and w_cfg != 0.0
@@ -756,3 +764,17 @@ def fused_sample_mlp2(solver, net, kind, plan, xt, prior, cond_vec, w_cfg, feed)
                fix_mask=table(fix_mask), noise=noise, x_min=table(x_min), x_max=table(x_max), t_per_wg=1,
                emb_u=emb if pair else None, cfg_w=w_cfg, edm=edm, ctx=ctx)
     return out[:b]
+
+
+def describe_forward(comp: _Compiled2, *, batch: int, emb: torch.Tensor, t_per_wg: int, emb_per_traj: bool) -> CdxUnet2Launch:
+    """A forward-mode launch description (n_steps = 0) for a caller that fills in x_in / x_out / the step's emb rows itself: the
+    denoiser slot of ``cdx_guided_run`` (engine/guided.py).  The caller keeps `comp` and `emb` alive."""
+    prog = comp.prog
+    if prog.compact or "mlp" in prog.meta:
+        raise ValueError("forward-mode descriptions exist for U-Net programs with the state in LDS")
+    return CdxUnet2Launch(
+        ops=comp.ops_dev.data_ptr(), wblob=prog.blob.data_ptr(), n_ops=len(prog.ops), traj_floats=prog.traj_floats, traj_per_wg=t_per_wg,
+        n_waves=prog.nw, tune=int(os.environ.get("CDX_UNET2_TUNE", DEFAULT_TUNE)), x_off=prog.x_off, x_stride=prog.x_stride,
+        pred_off=prog.pred_off, pred_stride=prog.pred_stride, prev_off=prog.prev_off, stage_off=prog.stage_off, batch=batch,
+        horizon=prog.horizon, dim=prog.dim, traj_first=0, traj_count=batch, emb=emb.data_ptr(), emb_ld=emb.shape[1], n_steps=0,
+        x_scale=1.0, grad_off=prog.grad_off, grad_stride=prog.grad_stride, ws_floats=0, emb_per_traj=int(emb_per_traj), n_pass=1, cfg_w=1.0)

@@ -7,7 +7,7 @@ so reference checkpoints load unchanged.
 
 Execution: this nn.Module is the *parameter container + autograd/CPU path*.  On a ROCm device with
 ``requires_grad`` off, ``forward`` is served by the fused gfx950 program kernel
-(`cleandiffuser_amd.engine`, C-ABI ``cdx_unet1d_run``) -- the whole U-Net forward in ONE launch with
+(`cleandiffuser_amd.engine`, C-ABI ``cdx_unet2_run``) -- the whole U-Net forward in ONE launch with
 activations resident in LDS -- and ``DiscreteDiffusionSDE.sample`` goes one step further and runs
 the entire denoising loop inside that launch.
 """

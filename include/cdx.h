@@ -18,17 +18,12 @@
 extern "C" {
 #endif
 
-#define CDX_ABI_VERSION 8
+#define CDX_ABI_VERSION 9
 
 #define CDX_OK 0
 #define CDX_EINVAL (-1)   /* bad argument (null pointer, size out of range, misaligned offset) */
 #define CDX_ELDS (-2)     /* program needs more LDS than one gfx950 workgroup owns (160 KiB) */
 #define CDX_EHIP (-3)     /* HIP runtime error at launch; text in cdx_last_error() */
-
-/* ------------------------------------------------------------------------------------------------
- * Layer program (built by cleandiffuser_amd/engine/program.py; word layout in csrc/cdx_ops.h).
- * ---------------------------------------------------------------------------------------------- */
-#define CDX_OP_WORDS 40
 
 /* One denoising step = one record.  Replaces the per-step scalar arithmetic of the reference loop
  * (diffusionsde.py:539-589): the host freezes alpha_i, sigma_i and the solver coefficients, the device applies
@@ -57,70 +52,31 @@ typedef struct cdx_step {
     int32_t flags;       /* CDX_STEP_* bits */
 } cdx_step;
 
-/* One launch = the whole request: either a full sampling loop (n_steps >= 1) or a single backbone forward
- * (n_steps == 0: x_out <- network(x_in), replaces BaseNNDiffusion.forward for JannerUNet1d,
- * reference nn_diffusion/jannerunet.py:154-201).  One workgroup per trajectory, activations in LDS. */
-typedef struct cdx_unet1d_launch {
-    /* program */
-    const int32_t* ops;        /* device, [n_ops][CDX_OP_WORDS] followed by the per-conv work-item tables */
-    const float* wblob;        /* device, packed parameters */
-    int32_t n_ops;
-    int32_t lds_floats;        /* total LDS floats per workgroup */
-    int32_t x_off, x_stride;   /* state slot */
-    int32_t pred_off, pred_stride, pred_branch_floats;
-    int32_t prev_off, scratch_off;
-    int32_t out_vec_off, out_vec_len; /* forward mode, vector-output programs (classifier heads): x_out is [batch][out_vec_len] */
-    /* batch-tiled MLP programs (tile > 0): one workgroup denoises `tile` samples; `horizon` == tile, tensors are
-     * (batch*tile, dim); `cond` is (batch*tile, cond_dim) and is loaded into a context slot's channel range */
-    int32_t tile, cond_slot_off, cond_slot_stride, cond_coff, cond_dim;
-    int32_t zero_off, zero_floats;    /* extra kernel-lifetime LDS range cleared once at kernel start */
-    int32_t zrow_off;                 /* shared all-zero row inside that range: what out-of-range conv taps read */
-    int32_t prof_off;             /* LDS float offset (even) of the (n_ops*8+2) x u64 stamp area; used only if prof != NULL */
-    int32_t items_in_lds;         /* 1: desc_words covers ops + item tables; 0: ops only, items are read from `ops` */
-    int32_t desc_off, desc_words; /* where the kernel keeps its copy of `ops` in LDS, and how many words it is */
-    /* problem */
-    int32_t batch, horizon, dim, emb_dim;
-    /* per-step tables */
-    const float* temb;         /* device, [max(n_steps,1)][emb_dim]: map_noise(t_step) evaluated on the host side */
-    const cdx_step* steps;     /* device, [n_steps]; NULL when n_steps == 0 */
-    int32_t n_steps;
-    int32_t temb_per_sample;   /* 1: temb is [batch][emb_dim] (forward mode with per-sample timesteps) */
-    int32_t predict_noise;     /* 1: network predicts eps, 0: network predicts x0 */
-    /* guidance: 0 = one unconditional forward, 1 = one conditional forward, 2 = both, w*c + (1-w)*u */
-    int32_t cfg_mode;
-    float cfg_w;
-    const float* cond;         /* device, [batch][emb_dim] or NULL */
-    /* tensors, all fp32, (batch, horizon, dim) row-major unless noted */
-    const float* x_in;         /* initial state x_T (already temperature-scaled and fix-masked), or forward input */
-    const float* prior;        /* or NULL */
-    const float* fix_mask;     /* [horizon][dim] or NULL */
-    const float* noise;        /* [n_noise][batch][horizon][dim] or NULL */
-    const float* x_min;        /* [horizon][dim] or NULL */
-    const float* x_max;        /* [horizon][dim] or NULL */
-    float* x_out;
-    /* optional profiling: device u64 [n_ops*8 + 2]; workgroup 0 stamps s_memtime at {op start, pre-barrier,
-     * post-barrier, op end, item record read, first operands landed, MFMAs done, K loop done} for the first forward,
-     * plus kernel start/end.  NULL = off. */
-    unsigned long long* prof;
-} cdx_unet1d_launch;
-
 /* ABI version of the loaded library (== CDX_ABI_VERSION of the header it was built from). */
 int cdx_abi_version(void);
 
 /* Text of the last error on the calling thread ("" if none). */
 const char* cdx_last_error(void);
 
-/* Enqueue the fused U-Net program kernel on `hip_stream` (a hipStream_t; NULL = default stream). */
-int cdx_unet1d_run(const cdx_unet1d_launch* launch, void* hip_stream);
+/* Activation ids (cdx_gemm_args.act, cdx_act_f32, the op flags of csrc/cdx_ops2.h; mirrored by engine/program.py). */
+#define CDX_ACT_NONE 0
+#define CDX_ACT_MISH 1
+#define CDX_ACT_GELU_ERF 2
+#define CDX_ACT_LEAKY 3
+#define CDX_ACT_SILU 4
+#define CDX_ACT_RELU 5
+#define CDX_ACT_GELU_TANH 6
+#define CDX_ACT_MISH_GRAD 7   /* d mish(x) / dx (elementwise map only: classifier-guidance backward) */
+#define CDX_ACT_TANH 8        /* critic / inverse-dynamics heads */
 
 /* ------------------------------------------------------------------------------------------------
- * Second-generation fused U-Net program (csrc/cdx_unet2.hip; program built by engine/program2.py, word layout in
- * csrc/cdx_ops2.h).  Same contract as cdx_unet1d_run -- the whole DiscreteDiffusionSDE / ContinuousDiffusionSDE.sample() loop
- * (reference diffusionsde.py:526-594 over nn_diffusion/jannerunet.py:154-201) in ONE launch, step kinds 0-4 -- for
- * unconditional JannerUNet1d-structured denoisers, re-engineered for the per-op fixed cost: 4 or 8 wave64 per workgroup,
- * `traj_per_wg` (1 or 2) trajectories per workgroup sharing every streamed weight record, the ResidualBlock's 1x1 skip conv
- * fused into its second conv, and the per-block FiLM vectors Linear(Mish(map_emb(map_noise(t)))) read from a per-step table
- * that cdx_unet2_embtab evaluates once per (weights, schedule).
+ * The fused program kernel (csrc/cdx_unet2.hip; program built by engine/program2.py, word layout in csrc/cdx_ops2.h): the whole
+ * DiscreteDiffusionSDE / ContinuousDiffusionSDE / ContinuousEDM .sample() loop (reference diffusionsde.py:526-594 over
+ * nn_diffusion/jannerunet.py:154-201, chiunet.py:152-192, the MLP denoisers) in ONE launch -- or a single backbone forward
+ * (n_steps == 0: x_out <- network(x_in), replaces BaseNNDiffusion.forward).  One workgroup per 1-3 trajectories, activations in LDS,
+ * weights streamed as 1-KiB MFMA records: 4 or 8 wave64 per workgroup, `traj_per_wg` trajectories sharing every streamed weight
+ * record, the ResidualBlock's 1x1 skip conv fused into its second conv, and the per-block FiLM vectors
+ * Linear(Mish(map_emb(map_noise(t)))) read from a per-step table that cdx_unet2_embtab evaluates once per (weights, schedule).
  * ---------------------------------------------------------------------------------------------- */
 #define CDX2_OP_WORDS(n_waves) (32 + 8 * (n_waves))   /* header + one inline work item per wave */
 
@@ -239,7 +195,7 @@ typedef struct cdx_gemm_args {
     float* C;              /* (M, ldc) */
     int32_t M, N, K, lda, ldw, ldc, ldg, ldr;
     int32_t rows_per_gate, table_rows;
-    int32_t act;           /* CDX_ACT_* of csrc/cdx_ops.h: 0 none, 1 mish, 2 gelu(erf), 3 leaky, 4 silu, 5 relu, 6 gelu(tanh), 8 tanh */
+    int32_t act;           /* CDX_ACT_*: 0 none, 1 mish, 2 gelu(erf), 3 leaky, 4 silu, 5 relu, 6 gelu(tanh), 8 tanh */
     /* Implicit-GEMM Conv1d (conv_taps > 0): A is a channel-last activation tensor, rows = samples * conv_lin, row stride lda;
      * output row m = (b, lo) = (m / conv_lout, m % conv_lout); K = conv_taps * conv_cin with k = tap * conv_cin + c;
      * A[m][k] = X[b * conv_lin + lo * conv_stride + tap - conv_pad][c], zero outside [0, conv_lin).  W is (N, conv_taps, conv_cin).
@@ -541,13 +497,14 @@ int cdx_hjgrad_run(const cdx_hjgrad_weights* w, const float* x, const float* emb
  * launch is joined before the call returns, i.e. the caller only ever has to order against `hip_stream`.  Environment
  * CDX_GUIDED_OVERLAP=0 keeps everything on `hip_stream`. */
 typedef struct cdx_guided_launch {
-    const cdx_unet1d_launch* denoiser;   /* a forward-mode launch description (n_steps = 0); temb/x_in/x_out are set per step;
-                                          * NULL when the denoiser runs on the implicit-GEMM executor (denoiser_gemm) */
+    const cdx_unet2_launch* denoiser;    /* a forward-mode launch description of the program kernel (n_steps = 0, its `emb` = the FiLM table
+                                          * of ALL steps: one row per step, or batch rows per step with emb_per_traj); emb row / x_in /
+                                          * x_out are set per step; NULL when the denoiser runs on the implicit-GEMM executor */
     const cdx_hjgrad_weights* classifier;
     const cdx_step* steps;               /* HOST [n_steps], kinds 0-2 */
     const float* cg_scale;               /* HOST [n_steps]: factor of the gradient added to the prediction at step i */
     int32_t n_steps, batch, hd, predict_noise;
-    const float* temb;                   /* device (n_steps, denoiser emb_dim) */
+    const float* temb;                   /* device (n_steps, denoiser emb_dim): map_noise(t_i) for the GEMM denoiser; NULL with `denoiser` */
     const float* clf_emb0;               /* device (n_steps, classifier emb_dim): classifier map_noise(t_i) */
     const float *x_in, *prior, *fix_mask, *noise, *x_min, *x_max;
     float* x_out;
@@ -611,7 +568,7 @@ int cdx_optim_f32(const cdx_optim_args* args, void* hip_stream);
 int cdx_gemm_set_trace(unsigned long long* device_buffer);
 
 /* Test hook: runs v_mfma_f32_16x16x4_f32 and v_mfma_f32_4x4x1_16b_f32 on fixed operands
- * (digit-coded lane ids, see csrc/cdx_unet1d.hip) and writes out[4][64][4] so the lane->element maps the kernels
+ * (digit-coded lane ids, see csrc/cdx_common.hip) and writes out[4][64][4] so the lane->element maps the kernels
  * rely on are checked on the actual silicon. */
 int cdx_probe_mfma_layout(float* out_device, void* hip_stream);
 

@@ -1,4 +1,4 @@
-"""Lane-level numpy model of ``csrc/cdx_unet2.hip`` -- TEST INFRASTRUCTURE (see oracle/__init__.py).
+"""Lane-level numpy model of the program kernel ``csrc/cdx_unet2.hip`` -- TEST INFRASTRUCTURE (see oracle/__init__.py).
 
 Interprets the SAME (ops, item tables, blob, LDS plan) the v2 kernel receives with the kernel's index arithmetic:
 items per wave, the (segment, tap, chunk) cursor, the 64-lane operand
@@ -8,9 +8,39 @@ plan / item tables are right before a GPU minute is spent.  One instance = one t
 """
 import numpy as np
 
+from cleandiffuser_amd.engine import program as P
 from cleandiffuser_amd.engine import program2 as P2
 from cleandiffuser_amd.engine.program import GN_EPS, MODE_16X16
-from .lane_sim import activation, mish
+
+
+def mish(x):
+    x = np.asarray(x, np.float32)
+    e = np.exp(np.minimum(x, 20.0).astype(np.float32))
+    n = e * (e + 2.0)
+    return np.where(x > 20.0, x, x * n / (n + 2.0)).astype(np.float32)
+
+
+def activation(v, act_id):
+    import math
+    v = np.asarray(v, np.float32)
+    if act_id == P.ACT_NONE:
+        return v
+    if act_id == P.ACT_MISH:
+        return mish(v)
+    if act_id == P.ACT_GELU_ERF:
+        erf = np.vectorize(math.erf)
+        return (0.5 * v * (1.0 + erf(v.astype(np.float64) / math.sqrt(2.0)))).astype(np.float32)
+    if act_id == P.ACT_LEAKY:
+        return np.where(v > 0, v, np.float32(0.01) * v).astype(np.float32)
+    if act_id == P.ACT_SILU:
+        return (v / (1.0 + np.exp(-v))).astype(np.float32)
+    if act_id == P.ACT_RELU:
+        return np.maximum(v, 0).astype(np.float32)
+    if act_id == P.ACT_GELU_TANH:
+        return (0.5 * v * (1.0 + np.tanh(0.7978845608028654 * (v + 0.044715 * v ** 3)))).astype(np.float32)
+    if act_id == P.ACT_TANH:
+        return np.tanh(v).astype(np.float32)
+    raise ValueError(act_id)
 
 
 def mish_grad(a):

@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE (see oracle/__init__.py).  A plain-torch interpreter of the ``cdx_step`` records exactly as the device
-applies them (csrc/cdx_bigbatch.hip:solver_step_kernel, csrc/cdx_unet1d.hip solver section): lets the CPU suite check that a
+applies them (csrc/cdx_bigbatch.hip:solver_step_kernel, csrc/cdx_unet2.hip solver section): lets the CPU suite check that a
 plan builder (engine/plan.py) reproduces the real reference's samples without a GPU.  The network is any callable."""
 import torch
 

@@ -1,5 +1,5 @@
 """CPU checks of the drop-in boundary: libcdx.so loads, exports every symbol include/cdx.h declares, the ctypes
-mirrors have the C layout, csrc/cdx_ops.h matches engine/program.py, and argument validation fails loudly."""
+mirrors have the C layout, csrc/cdx_ops2.h matches engine/program2.py, and argument validation fails loudly."""
 import ctypes
 import os
 import re
@@ -23,7 +23,7 @@ def lib():
 def test_every_declared_symbol_is_exported(lib):
     hdr = open(os.path.join(ROOT, "include", "cdx.h")).read()
     names = re.findall(r"^(?:int|long long|const char\*)\s+(cdx_\w+)\s*\(", hdr, flags=re.M)
-    assert set(names) >= {"cdx_abi_version", "cdx_last_error", "cdx_unet1d_run", "cdx_probe_mfma_layout", "cdx_gemm_f32",
+    assert set(names) >= {"cdx_abi_version", "cdx_last_error", "cdx_probe_mfma_layout", "cdx_gemm_f32",
                           "cdx_layernorm_f32", "cdx_attention_f32", "cdx_act_f32", "cdx_dit1d_run", "cdx_resmlp_run",
                           "cdx_dit1d_workspace_floats", "cdx_resmlp_workspace_floats", "cdx_gemm_set_trace",
                           "cdx_chitf_run", "cdx_chitf_workspace_floats", "cdx_cross_attention_f32", "cdx_chiunet_run",
@@ -41,7 +41,7 @@ def test_ctypes_mirrors_have_c_layout(tmp_path):
                "cdx_unet2_embtab_args": runtime2.CdxUnet2EmbtabArgs,
                "cdx_hj_block": classifier_grad.CdxHjBlock, "cdx_hj_down": classifier_grad.CdxHjDown,
                "cdx_hjgrad_weights": classifier_grad.CdxHjgradWeights,
-               "cdx_unet1d_launch": runtime.CdxUnet1dLaunch, "cdx_step": runtime.CdxStep, "cdx_gemm_args": blocks.CdxGemmArgs,
+               "cdx_step": runtime.CdxStep, "cdx_gemm_args": blocks.CdxGemmArgs,
                "cdx_ln_args": blocks.CdxLnArgs, "cdx_attn_args": blocks.CdxAttnArgs, "cdx_sampling": bigbatch.CdxSampling,
                "cdx_dit1d_block": bigbatch.CdxDitBlock, "cdx_dit1d_weights": bigbatch.CdxDitWeights,
                "cdx_dit1ref_cross": bigbatch.CdxDitCross, "cdx_pearcetf_block": bigbatch.CdxPearcetfBlock,
@@ -68,16 +68,19 @@ def test_ctypes_mirrors_have_c_layout(tmp_path):
     assert ctypes.sizeof(runtime.CdxStep) == 48
 
 
-def test_op_word_layout_matches_header():
+def test_shared_constants_match_headers():
+    """Activation ids (include/cdx.h CDX_ACT_*) and the MFMA modes / GroupNorm epsilon of csrc/cdx_ops2.h == engine/program.py."""
     from cleandiffuser_amd.engine import program as P
-    text = open(os.path.join(ROOT, "cleandiffuser_amd", "csrc", "cdx_ops.h")).read()
-    defs = {k: v for k, v in re.findall(r"#define CDX_(\w+) (\d+)\b", text)}
-    for name, val in defs.items():
-        py = name if hasattr(P, name) else name.replace("W_", "W_", 1)
-        assert hasattr(P, py), f"program.py lacks {py}"
-        assert getattr(P, py) == int(val), (name, val, getattr(P, py))
     hdr = open(os.path.join(ROOT, "include", "cdx.h")).read()
-    assert int(re.search(r"#define CDX_OP_WORDS (\d+)", hdr).group(1)) == P.OP_WORDS
+    acts = re.findall(r"#define CDX_(ACT_\w+) (\d+)\b", hdr)
+    assert len(acts) == 9
+    for name, val in acts:
+        assert getattr(P, name) == int(val), name
+    ops2 = open(os.path.join(ROOT, "cleandiffuser_amd", "csrc", "cdx_ops2.h")).read()
+    for name, val in re.findall(r"#define CDX_(MODE_\w+) (\d+)\b", ops2):
+        assert getattr(P, name) == int(val), name
+    assert abs(float(re.search(r"#define CDX_GN_EPS ([0-9.e+-]+)f", ops2).group(1)) - P.GN_EPS) < 1e-12
+    assert not os.path.exists(os.path.join(ROOT, "cleandiffuser_amd", "csrc", "cdx_unet1d.hip"))     # one program kernel
 
 
 def test_op2_word_layout_matches_header():
@@ -116,13 +119,6 @@ def test_unet2_validation_fails_loudly(lib):
     L.batch = 0
     assert lib.cdx_unet2_run(ctypes.byref(L), None) == 0                                            # empty request: nothing to do
     assert lib.cdx_unet2_embtab(ctypes.byref(runtime2.CdxUnet2EmbtabArgs()), None) == -1
-
-
-def test_launch_validation_fails_loudly(lib):
-    from cleandiffuser_amd.engine import runtime
-    L = runtime.CdxUnet1dLaunch()
-    assert lib.cdx_unet1d_run(ctypes.byref(L), None) == -1
-    assert b"null" in lib.cdx_last_error()
 
 
 def test_bigbatch_validation_fails_loudly(lib):

@@ -2,7 +2,7 @@
 runtime.py) -- pure Python decisions, checked on the CPU."""
 import torch
 
-from cleandiffuser_amd.engine import bigbatch, plan as P, program, runtime, runtime2
+from cleandiffuser_amd.engine import bigbatch, plan as P, runtime, runtime2
 from cleandiffuser_amd.nn_diffusion import ChiUNet1d, DiT1d, JannerUNet1d
 
 
@@ -20,42 +20,29 @@ def test_unet_executor_choice(monkeypatch):
     # local conditioning: the implicit-GEMM executor is its only native path, at every batch size
     assert bigbatch.is_chiunet_gemm(chi_local, 1) and bigbatch.is_chiunet_gemm(chi_local, 10 ** 6)
     assert not bigbatch.is_chiunet_gemm(DiT1d(4, 8, d_model=16, n_heads=2, depth=1), 10 ** 6)
-    seen = []
-
-    def fake_supported(module, horizon, edm=False):
-        seen.append((horizon, edm))
-        return "LDS plan needs 200000 B" if (horizon >= 64 or edm) else None
-    monkeypatch.setattr(runtime, "supported_backbone", fake_supported)
-    # the second-generation program kernel has its own (smaller) LDS plan: pretend it shares the fake limit of the first
+    # the program kernel's answer decides below the crossover batch (faked here: nothing with a horizon >= 64 fits)
     monkeypatch.setattr(runtime2, "supported", lambda module, horizon: "LDS plan needs 200000 B" if horizon >= 64 else None)
     monkeypatch.setattr(runtime2, "compact_only", lambda module, horizon: False)
     assert not bigbatch.is_chiunet_gemm(janner, 3, 32)                  # fits the program kernel: small batches stay there
     assert bigbatch.is_chiunet_gemm(janner, 3, 64)                      # does not fit: GEMM executor at any batch
-    assert not bigbatch.is_chiunet_gemm(chi, 3, 16, True)               # v2 keeps EDM state in the launch workspace: no extra LDS
-    assert bigbatch.is_chiunet_gemm(chi, 3, 64, True)                   # neither program kernel holds it: GEMM executor
-    assert seen == [(64, False), (64, True)]                            # (v2 answered for the requests it takes)
-    assert not bigbatch.is_chiunet_gemm(janner, 5000, 32)               # v2 program kernel keeps every batch size it can run
-    assert bigbatch.is_chiunet_gemm(janner, 5000, 32, True) and bigbatch.is_chiunet_gemm(janner, 5000, 64)   # EDM plans / too big: GEMM
-    assert len(seen) == 2                                               # large batch: no need to ask the v1 compiler
+    assert not bigbatch.is_chiunet_gemm(chi, 3, 16, True)               # EDM state lives in the launch workspace: no extra LDS
+    assert bigbatch.is_chiunet_gemm(chi, 3, 64, True)                   # no program holds it: GEMM executor
+    assert not bigbatch.is_chiunet_gemm(janner, 5000, 32)               # the program kernel keeps every batch size it can run
+    assert bigbatch.is_chiunet_gemm(janner, 5000, 32, True) and bigbatch.is_chiunet_gemm(janner, 5000, 64)   # large EDM batches / too big: GEMM
+    # nets that fit only as a compact program: sampling loops stay on the kernel, stand-alone forwards take the executor
+    monkeypatch.setattr(runtime2, "compact_only", lambda module, horizon: True)
+    assert not bigbatch.is_chiunet_gemm(janner, 3, 32) and bigbatch.is_chiunet_gemm(janner, 3, 32, forward=True)
 
 
-def test_edm_state_buffers_are_optional_in_the_lds_plan():
-    net = JannerUNet1d(23, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2, 2], kernel_size=5)
-    lean, full = program.compile_janner(net, 32, edm=False), program.compile_janner(net, 32, edm=True)
-    assert full.lds_floats - lean.lds_floats == 2 * ((32 * 23 + 3) // 4 * 4)
-    assert (lean.prev_off, lean.x_off, lean.pred_off) == (full.prev_off, full.x_off, full.pred_off)
-    assert len(lean.ops) == len(full.ops) and lean.macs_per_forward == full.macs_per_forward
+def test_edm_plans_do_not_change_the_lds_plan():
+    """EDM / consistency step kinds keep their state (slope, x_old) in the launch's global workspace: the same program serves EDM
+    and non-EDM plans -- the shipped Diffuser kitchen net fits one workgroup either way."""
     euler = P.SamplePlan(solver="x", steps=[P.Step(P.KIND_EDM_EULER, P.V_EPS, 1, 0.1, 1.0, 1.0, (1.0, 1.0, 1.0, 0.1, 0.0))])
     ddim = P.SamplePlan(solver="ddim", steps=[P.Step(P.KIND_DDIM, P.V_EPS, 1, 3, 0.9, 0.4, (1.0, 0.4, 0.9, 0.0, 0.0))])
     assert runtime.plan_is_edm(euler) and not runtime.plan_is_edm(ddim)
-    # the shipped Diffuser kitchen net: 159.7 KB without, 177 KB with -- the difference between fused and not
     kitchen = JannerUNet1d(69, model_dim=64, emb_dim=64, dim_mult=[1, 2, 2, 2], kernel_size=5)
-    assert program.compile_janner(kitchen, 32, edm=False).lds_floats * 4 <= 160 * 1024
-    try:
-        program.compile_janner(kitchen, 32, edm=True)
-        raise AssertionError("expected the EDM variant not to fit")
-    except ValueError as e:
-        assert "LDS plan" in str(e)
+    assert runtime2.supported(kitchen, 32) is None and runtime.supported_backbone(kitchen, 32, True) is None
+
 
 
 def test_launch_plan_cuts_large_batches():
@@ -85,7 +72,7 @@ def test_every_launch_part_fits_the_program_it_runs_on():
 
 def test_standalone_forward_of_a_v2_net_keeps_the_gemm_crossover():
     """the v2 kernel serves sampling loops only; a stand-alone forward (per-sample timesteps) of the same net follows the
-    batch crossover between the first program kernel and the implicit-GEMM executor."""
+    batch crossover between the program kernel and the implicit-GEMM executor."""
     net = JannerUNet1d(23, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2, 2], kernel_size=5)
     assert not bigbatch.is_chiunet_gemm(net, 3200, 32)                       # loop: v2 program kernel
     assert bigbatch.is_chiunet_gemm(net, 3200, 32, forward=True)             # forward at the Diffuser batch: GEMM executor

@@ -10,7 +10,16 @@ from cleandiffuser_amd.engine import program2 as P2
 from oracle import cases
 from oracle.lane_sim2 import LaneSim2, emb_table
 from conftest import golden_path
-from test_program_lane_sim import _first_forward_inputs
+
+
+def _first_forward_inputs(name, agent):
+    c = cases.CASES[name]
+    inp = cases.make_inputs(name)
+    temp = c["sample"].get("temperature", 1.0)
+    xt0 = inp["noise"][0] * np.float32(temp)
+    if inp["fix_mask"] is not None:
+        xt0 = xt0 * (1 - inp["fix_mask"][None]) + inp["prior"] * inp["fix_mask"][None]
+    return inp, xt0.astype(np.float32)
 
 
 def _first_t(agent, c):
@@ -95,7 +104,7 @@ def test_program2_accounting_and_budget(nw, amd_lib):
 
 
 def test_v2_refuses_what_it_cannot_run(amd_lib):
-    """Nets outside the v2 epilogue partition report a reason: the runtime keeps them on the first kernel."""
+    """Nets outside the v2 epilogue partition report a reason: the runtime sends them to the implicit-GEMM executor."""
     from cleandiffuser_amd.engine import runtime2
     net = amd_lib.JannerUNet1d(5, model_dim=24, emb_dim=16, dim_mult=[1, 2], kernel_size=3)      # 24 channels: groups of 4 != 32/8
     why = runtime2.supported(net, 8)
@@ -325,3 +334,34 @@ def test_lane_sim2_tile_mlp_programs_against_module_forward(kind, tile, amd_lib)
     if want_u is not None:
         sim.poison_arena()
         np.testing.assert_allclose(sim.run_forward(row, None), want_u, rtol=2e-5, atol=2e-5)
+
+
+def test_program_accounting_matches_survey(amd_lib):
+    """19.67 M MAC / sample / forward for the north-star config: 41 ops (the 1x1 skips ride in their block's second
+    conv) and, for BASELINE config 3 (68.9 M parameters), 298.4 M MAC per forward."""
+    agent, net = cases.build(amd_lib, "janner_cfg2_ddim")
+    prog = P2.compile_janner2(net, 32, nw=8)
+    assert prog.n_conv == 41
+    assert abs(prog.macs_per_forward - 19.67e6) / 19.67e6 < 0.01
+    chi = amd_lib.ChiUNet1d(2, 20, 2, model_dim=256, emb_dim=256, dim_mult=[1, 2, 2])
+    try:
+        big = P2.compile_chiunet2(chi, 16, nw=8)
+    except ValueError:
+        big = P2.compile_chiunet2(chi, 16, nw=8, compact=True)
+    assert abs(big.macs_per_forward - 298.4e6) / 298.4e6 < 0.01
+
+
+def test_lane_sim2_classifier_program_reproduces_reference_log_p(amd_lib):
+    """The classifier's own program against the reference's log_p fixture (CumRewClassifier over the final trajectories, t = 0)."""
+    name = "janner_cfg2_diffuser_logp"
+    gold = np.load(golden_path(name))
+    agent, _ = cases.build(amd_lib, name)
+    clf = agent.classifier.model_ema
+    prog = P2.compile_classifier2(clf, 32)
+    with torch.no_grad():
+        row = emb_table(prog, clf.map_noise(torch.zeros(1, dtype=torch.long)).numpy())[0]
+    for b in range(3):
+        sim = LaneSim2(prog)
+        sim.load_x(gold["x_out"][b])
+        sim.run_forward(row)
+        np.testing.assert_allclose(sim.logp, gold["log_p"][b], rtol=2e-5, atol=2e-5)

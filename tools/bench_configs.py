@@ -47,7 +47,7 @@ def cfg3(B=1024, dim=256):
     return f"config 3: ChiUNet1d dp_pusht H=16 act=2 obs=20, 50-step legacy DDPM, B={B}{tag}", call, B, 50, net, 16
 
 
-from cleandiffuser_amd.engine.program import MLP_TILE as P_TILE  # noqa: E402
+from cleandiffuser_amd.engine.program import MLP_TILE as P_TILE  # noqa: E402  (cfg1's sixth return value: unused for tile programs)
 
 
 def _time_calls(call, reps):
@@ -226,8 +226,12 @@ def run(name, fn, reps=3, **kw):
     dt = (time.perf_counter() - t0) / reps
     k_ms = runtime.drain_launch_timing()
     runtime.enable_launch_timing(False)
-    prog = runtime.compiled_program(net, horizon).prog
-    per_unit = horizon if prog.tile else 1                  # tile programs: MACs are per workgroup of `tile` samples
+    from cleandiffuser_amd.engine import runtime2
+    if runtime._mlp_kind(net) is not None:                  # tile programs: MACs are per workgroup of `tile` samples
+        per_unit = runtime.mlp_tile(B)
+        prog = runtime2.compiled_mlp2(net, runtime._mlp_kind(net), per_unit).prog
+    else:
+        per_unit, prog = 1, runtime2.shape_for(net, horizon, B)[0].prog
     flops = 2.0 * prog.macs_per_forward / per_unit * steps * B
     if not k_ms:                                            # served by the implicit-GEMM executor: no single fused launch to time
         print(json.dumps({"config": label + " [implicit-GEMM executor]", "trajectories_per_s": B / dt, "ms_per_call": 1e3 * dt,
@@ -237,7 +241,7 @@ def run(name, fn, reps=3, **kw):
     print(json.dumps({"config": label, "trajectories_per_s": B / dt, "ms_per_call": 1e3 * dt, "kernel_ms": k,
                       "launches_per_call": len(k_ms) / reps, "tflops": flops / (k * 1e-3) / 1e12,
                       "frac_fp32_mfma_peak": flops / (k * 1e-3) / 1e12 / PEAK,
-                      "lds_bytes": prog.lds_floats * 4, "weights_mb": prog.blob.numel() * 4 / 1e6}), flush=True)
+                      "lds_bytes": prog.lds_bytes(1), "weights_mb": prog.blob.numel() * 4 / 1e6}), flush=True)
 
 
 if __name__ == "__main__":
