@@ -3,7 +3,7 @@
 // MUST mirror cleandiffuser_amd/engine/program2.py (tests/test_abi_contract.py parses this file and compares).
 #pragma once
 
-/* shared with engine/program.py (MODE_*, GN_EPS): MFMA shape of a conv op's records, GroupNorm epsilon */
+/* shared with engine/consts.py (MODE_*, GN_EPS): MFMA shape of a conv op's records, GroupNorm epsilon */
 #define CDX_MODE_16X16 0
 #define CDX_MODE_4X4 1
 #define CDX_GN_EPS 1e-5f

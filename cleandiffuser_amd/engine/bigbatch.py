@@ -627,18 +627,14 @@ def is_chiunet_gemm(module, batch: int, horizon: Optional[int] = None, edm: bool
     from ..nn_diffusion.chiunet import ChiUNet1d
     from ..nn_diffusion.jannerunet import JannerUNet1d
     if type(module) is JannerUNet1d:
-        if horizon is not None and not edm:
-            from . import runtime2           # the second-generation program kernel keeps its lead at every batch size (two
-            if batch >= runtime2.min_batch() and runtime2.supported(module, horizon) is None:   # co-resident workgroups per CU)
-                # ... in sampling loops.  Stand-alone forwards (`forward`: per-sample timesteps) are not served by that kernel at
-                # all: they keep the crossover rule below (first program kernel under JANNER_GEMM_MIN_BATCH, GEMM executor above)
-                if not runtime2.compact_only(module, horizon) and not forward:
-                    return False
-                # nets that fit only as a compact one-trajectory program (antmaze Diffuser, H = 128 plans): their sampling loops
-                # take the kernel at every batch size (measured, antmaze size: 10.9 k vs 6.0 k trajectories/s at B = 256, 13.3 k vs
-                # 11.5 k at B = 3200); stand-alone forwards (`forward`: per-sample timesteps, which that kernel does not do) stay here
-                if not forward:
-                    return False
+        if horizon is not None and not edm and not forward:
+            from . import runtime2
+            # sampling loops: the program kernel keeps its lead at every batch size (two or three trajectories per workgroup), also for
+            # nets that fit only as a compact one-trajectory program (antmaze Diffuser, H = 128 plans; measured at the antmaze size: 10.9 k
+            # vs 6.0 k trajectories/s at B = 256, 13.3 k vs 11.5 k at B = 3200).  Stand-alone forwards (`forward`: per-sample timesteps)
+            # and EDM plans keep the crossover rule below
+            if batch >= runtime2.min_batch() and runtime2.supported(module, horizon) is None:
+                return False
         big = batch >= JANNER_GEMM_MIN_BATCH
     elif type(module) is ChiUNet1d and not module.obs_as_global_cond:
         return True                                     # local conditioning: the executor is its only native path

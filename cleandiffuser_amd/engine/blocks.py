@@ -6,7 +6,7 @@ from typing import Optional
 
 import torch
 
-from . import program as P
+from . import consts as P
 from .runtime import _check, _stream_ptr, load_library
 
 ACT = {"none": P.ACT_NONE, "mish": P.ACT_MISH, "gelu": P.ACT_GELU_ERF, "leaky": P.ACT_LEAKY, "silu": P.ACT_SILU,

@@ -1,7 +1,8 @@
 """Dispatch rules between the fused gfx950 executors and the PyTorch executor.
 
-Two native executors: the one-workgroup-per-trajectory program kernel (runtime.py: JannerUNet1d, ChiUNet1d, PearceMlp,
-DQLMlp, HalfJannerUNet1d) and the big-batch GEMM executors (bigbatch.py: DiT1d, IDQLMlp/NewIDQLMlp).
+Two native executors: the one-workgroup-per-trajectory program kernel (runtime2.py / program2.py: JannerUNet1d, ChiUNet1d below its
+crossover, the HalfJannerUNet1d classifier, PearceMlp / DQLMlp / DVInvMlp / MlpNNDiffusion / SfBCUNet) and the big-batch GEMM executors
+(bigbatch.py: DiT1d, DiT1Ref, ChiTransformer, PearceTransformer, IDQLMlp / NewIDQLMlp, the U-Nets at large batch or size).
 
 HIP fast path  <=>  tensor lives on a ROCm device  AND  gradients are off  AND  dtype is fp32  AND
 the backbone is one the program compiler understands.  Everything else (CPU tensors, autograd, exotic

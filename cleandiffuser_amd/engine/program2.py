@@ -38,7 +38,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .program import (GN_EPS, MODE_16X16, MODE_4X4, _conv1d_eff, _convT1d_eff, _fbits, slot_stride, supports_janner)
+from .consts import (GN_EPS, MODE_16X16, MODE_4X4, _conv1d_eff, _convT1d_eff, _fbits, slot_stride, supports_janner)
 
 HDR_WORDS = 32                # 25 descriptor words, padded
 ITEM2_WORDS = 8
@@ -834,7 +834,7 @@ def compile_pearce_mlp2(net, tile: int, max_lds_bytes: int = 160 * 1024, nw: int
     """PearceMlp (reference nn_diffusion/pearcemlp.py:36-79).  fcs[0] reads [act_emb(x) | map_noise(t) | condition]: the time part
     becomes its bias row; fcs[1..3] read [skip | x | raw t]: the t column (times the timestep) joins their bias rows.  FCBlock =
     Linear -> per-sample GroupNorm -> GELU(erf); the skips are stored divided by 1.414 exactly where the reference divides (Q11)."""
-    from .program import ACT_GELU_ERF, ACT_LEAKY, ACT_NONE
+    from .consts import ACT_GELU_ERF, ACT_LEAKY, ACT_NONE
     dev = next(net.parameters()).device
     b = _Builder2(dev, nw)
     rows = _RowSpec(b)
@@ -866,7 +866,7 @@ def compile_pearce_mlp2(net, tile: int, max_lds_bytes: int = 160 * 1024, nw: int
 def compile_dql_mlp2(net, tile: int, max_lds_bytes: int = 160 * 1024, nw: int = NW2_MAX) -> Program2:
     """DQLMlp (reference nn_diffusion/dqlmlp.py:9-52) and DVInvMlp (dvinvmlp.py:9-47, same trunk): features [x | time_mlp(map_noise(t))
     | obs] -> 3 x (Linear, Mish) -> Linear; the time features are batch-invariant: they enter as the first layer's bias row."""
-    from .program import ACT_MISH, ACT_NONE
+    from .consts import ACT_MISH, ACT_NONE
     dev = next(net.parameters()).device
     b = _Builder2(dev, nw)
     rows = _RowSpec(b)
@@ -890,7 +890,7 @@ def compile_dql_mlp2(net, tile: int, max_lds_bytes: int = 160 * 1024, nw: int = 
 def compile_mlp_nn2(net, tile: int, max_lds_bytes: int = 160 * 1024, nw: int = NW2_MAX) -> Program2:
     """MlpNNDiffusion (reference nn_diffusion/mlps.py:10-40): Mlp(cat[x, map_noise(t) + condition]); the first Linear's embedding
     columns act on the time embedding (bias row) and on the condition (context slot) alike."""
-    from .program import _act_id
+    from .consts import _act_id
     dev = next(net.parameters()).device
     b = _Builder2(dev, nw)
     rows = _RowSpec(b)
@@ -922,7 +922,7 @@ def compile_sfbc_unet2(net, tile: int, max_lds_bytes: int = 160 * 1024, nw: int 
     """SfBCUNet (reference nn_diffusion/sfbc_unet.py:9-82): block(x, c) = SiLU(L2(SiLU(L1 x) + Lc c)) + skip(x) with c =
     t_layer(map_noise(t)) + condition.  Lc t_layer(...) + bc is a per-step vector added after the first activation (table row);
     Lc condition and the skip Linear are 1-tap convs whose partial tiles are added after the activation of the op they ride in."""
-    from .program import ACT_NONE, ACT_SILU
+    from .consts import ACT_NONE, ACT_SILU
     dev = next(net.parameters()).device
     b = _Builder2(dev, nw)
     b.fuse_max = 1 << 30                  # (Linears: the extra streams are what the block IS, not an optimisation)

@@ -11,7 +11,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from .program import _act_id
+from .consts import _act_id
 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

@@ -4,9 +4,10 @@ nn_diffusion/chiunet.py:13-192).  ``state_dict`` keys match (``downs.{i}.{0,1}.{
 
 Execution: this nn.Module is the parameter container and the PyTorch (CPU / autograd / local-conditioning) path.  With
 ``obs_as_global_cond=True`` on a ROCm device the forward -- and, through ``DDPM.sample`` / ``DiscreteDiffusionSDE.sample``,
-the whole denoising loop -- runs in the fused program kernel (engine/program.py:compile_chiunet): FiLM is an epilogue of
-the first conv of each block, the block's FiLM vector is computed just in time, config 3 (68.9 M parameters) fits 152 KiB
-of LDS per trajectory.
+the whole denoising loop -- runs natively: nets below 10 M parameters at small batch in the fused program kernel
+(engine/program2.py:compile_chiunet2: FiLM is an epilogue of the first conv of each block, the blocks' FiLM vectors are rows of a
+per-(step, trajectory) table), everything else -- BASELINE config 3 (68.9 M parameters) at every batch -- on the implicit-GEMM
+executor (engine/bigbatch.py, ``cdx_chiunet_run``).
 """
 from typing import List, Optional
 

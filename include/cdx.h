@@ -58,7 +58,7 @@ int cdx_abi_version(void);
 /* Text of the last error on the calling thread ("" if none). */
 const char* cdx_last_error(void);
 
-/* Activation ids (cdx_gemm_args.act, cdx_act_f32, the op flags of csrc/cdx_ops2.h; mirrored by engine/program.py). */
+/* Activation ids (cdx_gemm_args.act, cdx_act_f32, the op flags of csrc/cdx_ops2.h; mirrored by engine/consts.py). */
 #define CDX_ACT_NONE 0
 #define CDX_ACT_MISH 1
 #define CDX_ACT_GELU_ERF 2

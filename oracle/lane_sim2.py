@@ -8,9 +8,9 @@ plan / item tables are right before a GPU minute is spent.  One instance = one t
 """
 import numpy as np
 
-from cleandiffuser_amd.engine import program as P
+from cleandiffuser_amd.engine import consts as P
 from cleandiffuser_amd.engine import program2 as P2
-from cleandiffuser_amd.engine.program import GN_EPS, MODE_16X16
+from cleandiffuser_amd.engine.consts import GN_EPS, MODE_16X16
 
 
 def mish(x):

@@ -69,8 +69,8 @@ def test_ctypes_mirrors_have_c_layout(tmp_path):
 
 
 def test_shared_constants_match_headers():
-    """Activation ids (include/cdx.h CDX_ACT_*) and the MFMA modes / GroupNorm epsilon of csrc/cdx_ops2.h == engine/program.py."""
-    from cleandiffuser_amd.engine import program as P
+    """Activation ids (include/cdx.h CDX_ACT_*) and the MFMA modes / GroupNorm epsilon of csrc/cdx_ops2.h == engine/consts.py."""
+    from cleandiffuser_amd.engine import consts as P
     hdr = open(os.path.join(ROOT, "include", "cdx.h")).read()
     acts = re.findall(r"#define CDX_(ACT_\w+) (\d+)\b", hdr)
     assert len(acts) == 9

@@ -47,7 +47,7 @@ def test_roofline_block_is_self_consistent(line):
 def test_rocprof_statistics_agree_with_the_live_measurement(line):
     path = os.path.join(ROOT, "profiles", "r03_rocprofv3_kernel_stats.csv")
     rows = list(csv.DictReader(open(path)))
-    kern = [r for r in rows if "cdx_unet2_kernel<1, 8, false, false, false>" in r["Name"]]
+    kern = [r for r in rows if "cdx_unet2_kernel<1, 8, false, false, false, false>" in r["Name"]]      # <T, waves, BWD, PROF, COND, MLP>
     assert len(kern) == 1
     avg_ms = float(kern[0]["AverageNs"]) * 1e-6
     assert abs(avg_ms - line["roofline"]["kernel_ms"]) / avg_ms < 0.03          # HIP events in bench.py vs rocprofv3 --kernel-trace

@@ -1537,3 +1537,36 @@ def test_tile_mlp_v2_batch_sizes_and_tiles(batch, amd_lib, monkeypatch):
     torch.cuda.synchronize()
     assert (calls["n"], calls["v2"]) == (1, 1), calls
     np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), **TOL)
+
+
+def test_the_binding_stub_of_integration_md_runs(amd_lib):
+    """The reference-side ctypes binding printed in INTEGRATION.md section 2 is executed as written (only the library path is made
+    absolute) and must reproduce the reference fixture of BASELINE config 2: the document cannot drift from the ABI."""
+    import os
+    import re
+    import types
+    from cleandiffuser_amd.engine import runtime
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(# cleandiffuser/diffusion/_cdx\.py.*?)```", text, re.S).group(1)
+    assert 'ctypes.CDLL("libcdx.so")' in code
+    ns = {}
+    exec(compile(code.replace('ctypes.CDLL("libcdx.so")', f'ctypes.CDLL({runtime.LIB_PATH!r})'), "INTEGRATION.md", "exec"), ns)
+    name = "janner_cfg2_ddim"
+    gold = np.load(golden_path(name))
+    agent, _ = cases.build(amd_lib, name, device=DEV)
+    inp = cases.make_inputs(name)
+    c = cases.CASES[name]
+    S = c["sample"]["sample_steps"]
+    from cleandiffuser_amd.utils import SUPPORTED_SAMPLING_STEP_SCHEDULE as SS
+    sched = SS["uniform"](agent.diffusion_steps, S)
+    temp = c["sample"].get("temperature", 1.0)
+    prior = torch.from_numpy(inp["prior"]).to(DEV)
+    mask = agent.fix_mask.to(DEV)
+    xt = torch.from_numpy(inp["noise"][0]).to(DEV) * temp
+    xt = (xt * (1.0 - mask) + prior * mask).contiguous()
+    me = types.SimpleNamespace(predict_noise=agent.predict_noise, fix_mask=mask)
+    out = ns["fused_loop"](me, agent.model_ema, xt, prior.contiguous(), agent._alpha_host[sched.cpu()], agent._sigma_host[sched.cpu()], sched,
+                           "ddim", S, None)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), gold["x_out"], **TOL)

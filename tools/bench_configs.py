@@ -47,7 +47,7 @@ def cfg3(B=1024, dim=256):
     return f"config 3: ChiUNet1d dp_pusht H=16 act=2 obs=20, 50-step legacy DDPM, B={B}{tag}", call, B, 50, net, 16
 
 
-from cleandiffuser_amd.engine.program import MLP_TILE as P_TILE  # noqa: E402  (cfg1's sixth return value: unused for tile programs)
+from cleandiffuser_amd.engine.consts import MLP_TILE as P_TILE  # noqa: E402  (cfg1's sixth return value: unused for tile programs)
 
 
 def _time_calls(call, reps):
