@@ -1570,3 +1570,46 @@ def test_the_binding_stub_of_integration_md_runs(amd_lib):
                            "ddim", S, None)
     torch.cuda.synchronize()
     np.testing.assert_allclose(out.cpu().numpy(), gold["x_out"], **TOL)
+
+
+@pytest.mark.parametrize("kind", ["janner", "chiunet"])
+def test_conditional_request_with_classifier_guidance_is_one_guided_call(kind, amd_lib, monkeypatch):
+    """A condition (w_cfg = 1) AND classifier guidance (w_cg > 0) at once: cdx_guided_run with the program kernel in forward mode as
+    its denoiser slot -- the slot reads the FiLM rows of (step i, trajectory b) from the table of all steps (`emb_per_traj`).  JannerUNet1d
+    with a condition embedding and ChiUNet1d with its observation condition, against this repo's PyTorch executor on the CPU
+    (autograd classifier gradients), x0-prediction DDPM."""
+    from cleandiffuser_amd.engine import guided
+    from cleandiffuser_amd.utils import load_synth
+    H, D, B, S = 16, 6, 9, 5
+
+    def build(dev):
+        if kind == "janner":
+            net = load_synth(amd_lib.JannerUNet1d(D, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2], kernel_size=5), 41)
+            cond = amd_lib.IdentityCondition(dropout=0.0)
+        else:
+            net = load_synth(amd_lib.ChiUNet1d(D, 7, 2, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2], kernel_size=5), 42)
+            cond = amd_lib.IdentityCondition(dropout=0.0)
+        clf_net = load_synth(amd_lib.HalfJannerUNet1d(H, D, out_dim=1, model_dim=32, emb_dim=32, dim_mult=(1, 2, 2), kernel_size=3), 43)
+        ag = amd_lib.DiscreteDiffusionSDE(net, cond, classifier=amd_lib.CumRewClassifier(clf_net, device=dev), diffusion_steps=10,
+                                          predict_noise=False, x_max=torch.full((1, H, D), 2.0), x_min=torch.full((1, H, D), -2.0), device=dev)
+        ag.eval()
+        return ag
+    g = torch.Generator().manual_seed(23)
+    c = torch.randn(B, 32, generator=g) if kind == "janner" else torch.randn(B, 2, 7, generator=g)
+    noise = [torch.randn(B, H, D, generator=g) for _ in range(S + 1)]
+    kw = dict(solver="ddpm", n_samples=B, sample_steps=S, temperature=0.6, w_cfg=1.0, w_cg=0.2)
+    want, wlog = build("cpu").sample(torch.zeros(B, H, D), condition_cfg=c, noise=list(noise), **kw)
+    n_loops = {"n": 0}
+    orig = guided.guided_sample
+
+    def counted(*a, **k):
+        out = orig(*a, **k)
+        n_loops["n"] += out is not None
+        return out
+    monkeypatch.setattr(guided, "guided_sample", counted)
+    monkeypatch.setattr(torch.autograd, "grad", lambda *a, **k: (_ for _ in ()).throw(AssertionError("autograd used")))
+    got, glog = build(DEV).sample(torch.zeros(B, H, D, device=DEV), condition_cfg=c.to(DEV), noise=[z.to(DEV) for z in noise], **kw)
+    torch.cuda.synchronize()
+    assert n_loops["n"] == 1, "the guided loop must be one cdx_guided_run call"
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), **TOL)
+    np.testing.assert_allclose(glog["log_p"].cpu().numpy(), wlog["log_p"].numpy(), rtol=1e-4, atol=1e-4 * max(1.0, float(wlog["log_p"].abs().max())))
