@@ -74,7 +74,13 @@ class FourierEmbedding(nn.Module):
 
     def forward(self, x: torch.Tensor):
         ang = _outer(x, 2 * np.pi * self.freqs)
-        return self.mlp(torch.cat([ang.cos(), ang.sin()], -1))
+        feats = torch.cat([ang.cos(), ang.sin()], -1)
+        if feats.is_cuda:
+            from ..engine import heads                   # Linear-Mish-Linear on the library's own GEMM (gradient-free calls only)
+            y = heads.try_sequential(self.mlp, feats)
+            if y is not None:
+                return y
+        return self.mlp(feats)
 
 
 class UntrainableFourierEmbedding(nn.Module):
