@@ -847,6 +847,7 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
     }
     if (MLP && CDX2_DW(vd, CDX2_W2_KIND) == CDX2_KIND2_LOADC) {      // context slot <- the samples' condition features (or zeros)
         fetch_next(true);
+        if (pass == 2) return;                                       // (single-forward steps after the first: the slot still holds them)
         const int dst = CDX2_DW(vd, CDX2_W2_DST), dstr = CDX2_DW(vd, CDX2_W2_DST_STRIDE);
         const int len = CDX2_DW(vd, CDX2_W2_LOUT), ch = CDX2_DW(vd, CDX2_W2_COUT);
         const int b_end = L.traj_first + L.traj_count;
@@ -1069,8 +1070,11 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
             int on2 = oi + 2;
             if (on2 >= L.n_ops) on2 -= L.n_ops;
             if (on2 >= L.n_ops) on2 = 0;
+            // (MLP programs: `pass` tells the context-slot op what to load -- 0 the condition, 1 zeros (unconditional forward of a
+            //  pair), 2 nothing: one forward per step and the slot was filled by step 0)
             run_op<T, NWV, BWD, PROF, COND, MLP>(L, ops, vd, vdn, it, emb_row, emb_tstride, lds, tid, ring, pslot, b0, F,
-                                                 wrap ? emb_fwd_next : emb_row, wrap ? ts_fwd_next : emb_tstride, on2, pass);
+                                                 wrap ? emb_fwd_next : emb_row, wrap ? ts_fwd_next : emb_tstride, on2,
+                                                 (MLP && n_pass == 1 && step > 0) ? 2 : pass);
             vd = vdn;
             if (PIPE) vdn_keep = F.vdn2;
         }

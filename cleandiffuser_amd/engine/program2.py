@@ -399,7 +399,8 @@ class _Builder2:
             words[W2_PBIAS] = self.add(_padded(pbias, coutp))
         cg = coutp // GROUPS2
         cg4 = cg // 4
-        assert cg4 & (cg4 - 1) == 0 and cg4 <= 32, f"C_out {c_out}: channels per group / 4 must be a power of two <= 32"
+        if cg4 & (cg4 - 1) or cg4 > 32:
+            raise ValueError(f"C_out {c_out}: the epilogue partitions at most 1024 channels (8 lane groups x 32 float4 lanes)")
         nk = -(-(cg4 * l_out) // 32)
         if nk > MAX_NK2:
             raise ValueError(f"epilogue: {cg4 * l_out} float4 items per group > {32 * MAX_NK2} (horizon too long for v2)")
