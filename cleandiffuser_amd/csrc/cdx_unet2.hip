@@ -434,6 +434,7 @@ struct EpiDesc {
     int kpost;                                         // partial tiles (after the first ksplit) that are added AFTER norm / activation
     float inv_cnt;
     float odiv;                                        // F2_OUT_DIV divisor (forward ops: the word W2_SAVE_STRIDE)
+    int cgreal4;                                       // F2_COLNORM: float4 items per lane group holding real channels, 0 = all
 };
 template <bool BWD>
 __device__ __forceinline__ EpiDesc decode_epi(int vd) {
@@ -445,6 +446,7 @@ __device__ __forceinline__ EpiDesc decode_epi(int vd) {
     e.inv_cnt = __int_as_float(CDX2_DW(vd, CDX2_W2_INV_CNT));
     e.kpost = CDX2_DW(vd, CDX2_W2_KPOST);
     e.odiv = BWD ? 1.0f : __int_as_float(CDX2_DW(vd, CDX2_W2_ODIV));
+    e.cgreal4 = BWD ? 0 : CDX2_DW(vd, CDX2_W2_CGREAL4);
     e.save = e.savestr = e.stats = e.dst2 = e.d2stride = 0;
     if (BWD && (e.flags & (CDX2_F2_SAVE | CDX2_F2_GNBWD))) {
         e.save = CDX2_DW(vd, CDX2_W2_SAVE); e.savestr = CDX2_DW(vd, CDX2_W2_SAVE_STRIDE); e.stats = CDX2_DW(vd, CDX2_W2_STATS);
@@ -512,7 +514,9 @@ __device__ __forceinline__ void epilogue(float* __restrict__ tl, const EpiParams
             s1 = seg_sum(s1, e.shift, lane);
             const float mean = s1 * e.inv_cnt;
             const f32x4 dl = v[k] - mean;
-            float s2 = ok[k] ? (dl[0] * dl[0] + dl[1] * dl[1]) + (dl[2] * dl[2] + dl[3] * dl[3]) : 0.f;
+            // (groups narrower than the lane group: the pad channels hold exact zeros and must not count as (0 - mean)^2)
+            const bool realc = e.cgreal4 == 0 || (li & ((1 << e.shift) - 1)) < e.cgreal4;
+            float s2 = (ok[k] && realc) ? (dl[0] * dl[0] + dl[1] * dl[1]) + (dl[2] * dl[2] + dl[3] * dl[3]) : 0.f;
             s2 = seg_sum(s2, e.shift, lane);
             const float rstd = __builtin_amdgcn_rsqf(s2 * e.inv_cnt + CDX_GN_EPS);
             const f32x4 y = dl * rstd * P.ga + P.be;

@@ -86,6 +86,8 @@ F2_GN, F2_EMB, F2_RES, F2_PRED, F2_SAVE, F2_GNBWD, F2_DUAL, F2_SAVE_GLOBAL, F2_F
 F2_COLNORM, F2_BIAS_EMB, F2_OUT_DIV = 512, 1024, 2048
 F2_ACT_SHIFT = 12
 W2_ODIV = 26                  # forward ops: alias of W2_SAVE_STRIDE (a backward-pass word)
+W2_CGREAL4 = 29               # F2_COLNORM ops: alias of W2_DST2_STRIDE -- float4 items of a lane group that hold REAL channels (0 = all):
+                              # a per-sample GroupNorm whose groups are narrower than the lane group keeps zero pad channels out of its variance
 
 
 def pad32(c: int) -> int:
@@ -234,7 +236,7 @@ class _Builder2:
              transposed=False, phases=None, gn: Optional[nn.Module] = None, emb_off: int = -1, res: Optional[Act] = None,
              pred: bool = False, save: Optional[Tuple[Act, int]] = None, bwd: Optional[dict] = None,
              extra: Optional[List[dict]] = None, film: bool = False, act: Optional[int] = None, col_norm: bool = False,
-             bias_row: int = -1, out_div: Optional[float] = None):
+             bias_row: int = -1, out_div: Optional[float] = None, cg_real: int = 0):
         """One fused op: conv over the channel concat of `srcs` -> epilogue -> dst.
 
         `extra`: further stride-1 convs with the same output shape computed by the SAME op on other waves -- dicts
@@ -417,9 +419,10 @@ class _Builder2:
                 raise ValueError(f"v2 epilogue needs GroupNorm groups of pad32(C)/8 channels (C={c_out}, G={norm.num_groups})")
             flags |= F2_GN if bwd is None else F2_GNBWD
             if col_norm:
-                assert bwd is None
+                assert bwd is None and cg_real % 4 == 0 and 0 <= cg_real <= cg
                 flags |= F2_COLNORM
-            words[W2_INV_CNT] = _fbits(1.0 / (cg if col_norm else cg * l_out))
+                words[W2_CGREAL4] = cg_real // 4 if 0 < cg_real < cg else 0
+            words[W2_INV_CNT] = _fbits(1.0 / ((cg_real or cg) if col_norm else cg * l_out))
             words[W2_GAMMA], words[W2_BETA] = self.add(_padded(norm.weight, coutp)), self.add(_padded(norm.bias, coutp))
         if bwd is not None:
             assert gn is None and emb_off < 0 and save is None and bwd["save"].chans == c_out and bwd["save"].length == l_out
@@ -834,12 +837,48 @@ def _finish_mlp(b: "_Builder2", rows: _RowSpec, kind: str, x: Act, pred: Act, ct
 def compile_pearce_mlp2(net, tile: int, max_lds_bytes: int = 160 * 1024, nw: int = NW2_MAX) -> Program2:
     """PearceMlp (reference nn_diffusion/pearcemlp.py:36-79).  fcs[0] reads [act_emb(x) | map_noise(t) | condition]: the time part
     becomes its bias row; fcs[1..3] read [skip | x | raw t]: the t column (times the timestep) joins their bias rows.  FCBlock =
-    Linear -> per-sample GroupNorm -> GELU(erf); the skips are stored divided by 1.414 exactly where the reference divides (Q11)."""
+    Linear -> per-sample GroupNorm -> GELU(erf); the skips are stored divided by 1.414 exactly where the reference divides (Q11).
+
+    Hidden widths whose GroupNorm groups are not a power-of-two number of float4 lanes (hidden_dim 192: 8 groups of 24 channels) get a
+    PADDED hidden layout: group g sits at channels [G g, G g + 24) of a 8 G-wide slot (G = 32), the pad channels have zero weights, bias,
+    gamma and beta -- they hold exact zeros through norm, GELU, skip and division -- and stay out of the variance (W2_CGREAL4)."""
     from .consts import ACT_GELU_ERF, ACT_LEAKY, ACT_NONE
     dev = next(net.parameters()).device
     b = _Builder2(dev, nw)
     rows = _RowSpec(b)
     d, e, hd, n_cond = net.act_dim, net.emb_dim, net.hidden_dim, net.To * net.emb_dim
+    gn0 = net.fcs[0].model[1]
+    n_grp = gn0.num_groups
+    if hd % n_grp or (hd // n_grp) % 4:
+        raise ValueError(f"PearceMlp hidden_dim {hd}: GroupNorm groups of {hd / n_grp:g} channels (a multiple of 4 needed)")
+    cg_real = hd // n_grp
+    cgl = 4
+    while cgl < cg_real:
+        cgl *= 2
+    hp = cgl * GROUPS2 if (cgl != cg_real or n_grp != GROUPS2) else hd          # slot width of the hidden activations
+    if n_grp > GROUPS2 or pad32(hp) != hp:
+        raise ValueError(f"PearceMlp hidden_dim {hd} with {n_grp} GroupNorm groups has no epilogue partition")
+    cmap = torch.tensor([cgl * g + j for g in range(n_grp) for j in range(cg_real)], device=dev)      # real channel -> slot channel
+
+    def out_rows(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:       # (hd, ...) -> (hp, ...), pad rows zero
+        if t is None or hp == hd:
+            return t
+        o = torch.zeros((hp,) + tuple(t.shape[1:]), device=dev, dtype=torch.float32)
+        o[cmap] = t.detach().to(dev, torch.float32)
+        return o
+
+    def in_cols(w: torch.Tensor) -> torch.Tensor:                            # (n, hd) -> (n, hp), pad columns zero
+        if hp == hd:
+            return w
+        o = torch.zeros(w.shape[0], hp, device=dev, dtype=torch.float32)
+        o[:, cmap] = w.detach().to(dev, torch.float32)
+        return o
+
+    class _Norm:                                                             # the GroupNorm of a block in the slot's channel layout
+        def __init__(self, gn):
+            self.num_groups, self.eps = GROUPS2 if hp != hd else gn.num_groups, gn.eps
+            self.weight, self.bias = out_rows(gn.weight.detach()), out_rows(gn.bias.detach())
+    creal = cg_real if hp != hd else 0
     x = b.act(tile, d, persistent=True)
     ctx = b.act(tile, n_cond, persistent=True)
     b.load_context(ctx)
@@ -848,19 +887,22 @@ def compile_pearce_mlp2(net, tile: int, max_lds_bytes: int = 160 * 1024, nw: int
     b.conv([a1], xe, _lin_eff2(net.act_emb[2].weight), net.act_emb[2].bias, act=ACT_NONE)
     f = net.fcs
     w0 = f[0].model[0].weight.detach()
-    h1 = b.act(tile, hd)
-    b.conv([xe, ctx], h1, _lin_eff2(torch.cat([w0[:, :e], w0[:, 2 * e:]], 1)), None, gn=f[0].model[1], col_norm=True, act=ACT_GELU_ERF,
-           bias_row=rows.row(hd, f[0].model[0].bias, temb=w0[:, e:2 * e]), out_div=net.SKIP_SCALE)
+    h1 = b.act(tile, hp)
+    b.conv([xe, ctx], h1, _lin_eff2(out_rows(torch.cat([w0[:, :e], w0[:, 2 * e:]], 1))), None, gn=_Norm(f[0].model[1]), col_norm=True,
+           act=ACT_GELU_ERF, bias_row=rows.row(hp, out_rows(f[0].model[0].bias), temb=out_rows(w0[:, e:2 * e])), out_div=net.SKIP_SCALE,
+           cg_real=creal)
     cur = h1
     for i in (1, 2):
         w = f[i].model[0].weight.detach()
-        nxt = b.act(tile, hd)
-        b.conv([cur, x], nxt, _lin_eff2(w[:, :hd + d]), None, gn=f[i].model[1], col_norm=True, act=ACT_GELU_ERF, res=cur,
-               bias_row=rows.row(hd, f[i].model[0].bias, t=w[:, hd + d:]), out_div=net.SKIP_SCALE if i == 1 else None)
+        nxt = b.act(tile, hp)
+        b.conv([cur, x], nxt, _lin_eff2(out_rows(torch.cat([in_cols(w[:, :hd]), w[:, hd:hd + d]], 1))), None, gn=_Norm(f[i].model[1]),
+               col_norm=True, act=ACT_GELU_ERF, res=cur, cg_real=creal,
+               bias_row=rows.row(hp, out_rows(f[i].model[0].bias), t=out_rows(w[:, hd + d:])), out_div=net.SKIP_SCALE if i == 1 else None)
         cur = nxt
     pred = b.act(tile, d)
     w3 = f[3].weight.detach()
-    b.conv([cur, x], pred, _lin_eff2(w3[:, :hd + d]), None, pred=True, act=ACT_NONE, bias_row=rows.row(d, f[3].bias, t=w3[:, hd + d:]))
+    b.conv([cur, x], pred, _lin_eff2(torch.cat([in_cols(w3[:, :hd]), w3[:, hd:hd + d]], 1)), None, pred=True, act=ACT_NONE,
+           bias_row=rows.row(d, f[3].bias, t=w3[:, hd + d:]))
     return _finish_mlp(b, rows, "pearce", x, pred, ctx, tile, d, e, max_lds_bytes, dev)
 
 

@@ -264,7 +264,9 @@ class LaneSim2:
                     keys = [kk for kk in vals if kk[0] == g and kk[1] == pos]
                     allv = np.concatenate([vals[kk] for kk in keys])
                     mean = np.float32(allv.sum(dtype=np.float32) * inv_cnt)
-                    dlt = (allv - mean).astype(np.float32)
+                    creal4 = int(op[P2.W2_CGREAL4])              # narrower real groups: the zero pad channels stay out of the variance
+                    real = [kk for kk in keys if not creal4 or (kk[2] - g * cg) // 4 < creal4]
+                    dlt = (np.concatenate([vals[kk] for kk in real]) - mean).astype(np.float32)
                     rstd = np.float32(1.0) / np.sqrt(np.float32((dlt * dlt).sum(dtype=np.float32) * inv_cnt) + np.float32(GN_EPS))
                     for kk in keys:
                         c = kk[2]

@@ -301,6 +301,8 @@ def _mlp_nets(amd_lib):
     return {
         "pearce": (load_synth(amd_lib.PearceMlp(6, To=2, emb_dim=32, hidden_dim=64), 1), 6, 2 * 32, P2.compile_pearce_mlp2),
         "pearce256": (load_synth(amd_lib.PearceMlp(6, To=1, emb_dim=64, hidden_dim=256), 2), 6, 64, P2.compile_pearce_mlp2),
+        # hidden 192: GroupNorm groups of 24 channels -> padded hidden layout (8 x 32), pad channels out of the variance
+        "pearce192": (load_synth(amd_lib.PearceMlp(6, To=1, emb_dim=64, hidden_dim=192), 7), 6, 64, P2.compile_pearce_mlp2),
         "dql": (load_synth(amd_lib.DQLMlp(11, 3, emb_dim=16), 3), 3, 11, P2.compile_dql_mlp2),
         "dvinv": (load_synth(amd_lib.DVInvMlp(5, 3, emb_dim=16, hidden_dim=128), 4), 3, 10, P2.compile_dql_mlp2),
         "mlpnn": (load_synth(amd_lib.MlpNNDiffusion(5, emb_dim=16, hidden_dims=[64, 128], activation=nn.SiLU()), 5), 5, 16, P2.compile_mlp_nn2),
@@ -309,7 +311,7 @@ def _mlp_nets(amd_lib):
 
 
 @pytest.mark.parametrize("tile", [4, 16])
-@pytest.mark.parametrize("kind", ["pearce", "pearce256", "dql", "dvinv", "mlpnn", "sfbc"])
+@pytest.mark.parametrize("kind", ["pearce", "pearce256", "pearce192", "dql", "dvinv", "mlpnn", "sfbc"])
 def test_lane_sim2_tile_mlp_programs_against_module_forward(kind, tile, amd_lib):
     """Batch-tiled MLP denoisers on the v2 program format (a tile of samples = the position axis, Linears = 1-tap convs, the
     time-dependent inputs folded into per-step bias rows, the condition in a context slot): conditional and zero-condition forwards
@@ -324,7 +326,7 @@ def test_lane_sim2_tile_mlp_programs_against_module_forward(kind, tile, amd_lib)
     x, cond = torch.randn(tile, d, generator=g), torch.randn(tile, n_cond, generator=g)
     t = torch.full((tile,), 7)
     row = mlp_rows(prog, net, t[:1])[0]
-    cshape = (tile, 2, 32) if kind == "pearce" else (tile, n_cond)
+    cshape = (tile, 2, 32) if kind == "pearce" else ((tile, 1, 64) if kind.startswith("pearce") else (tile, n_cond))
     with torch.no_grad():
         want_c = net(x, t, cond.reshape(cshape)).numpy()
         want_u = net(x, t, None).numpy() if kind != "dvinv" else None
