@@ -1,5 +1,6 @@
 #!/bin/bash
-# ChiUNet1d on the v2 program kernel: parity tests, then the small-batch comparison against the first kernel and the GEMM executor
+# ChiUNet1d on the program kernel: parity tests, then the small-batch A/B that produced profiles/r03_chiunet_v2_small_batch.txt (run when the
+# round-1 kernel still existed: CDX_UNET2=0 selected it; since its deletion that hook sends the request to the GEMM executor)
 mkdir -p gpurun_out/r3r
 timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "chiunet or baseline_cfg3 or fused_sample_matches or training_step" 2>&1 | tail -25 > gpurun_out/r3r/chi_tests.log
 cat gpurun_out/r3r/chi_tests.log

@@ -1,5 +1,6 @@
 #!/bin/bash
-# batch-tiled MLPs on the v2 kernel: the MLP fixtures, then config 1 both ways, then the guided entries (register pressure check)
+# batch-tiled MLPs on the program kernel: the MLP fixtures, then the config-1 A/B that produced profiles/r03_cfg1_v2_mlp.txt (run when the
+# round-1 kernel still existed: CDX_UNET2_MLP=0 selected it; now that hook means the PyTorch executor), then the guided entries
 mkdir -p gpurun_out/r3u
 timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "fused_sample_matches or tile_mlp or pearce_mlp_widths or baseline_cfg1 or training_step or empty_and_ragged" 2>&1 | tail -25 > gpurun_out/r3u/mlp_tests.log
 cat gpurun_out/r3u/mlp_tests.log
