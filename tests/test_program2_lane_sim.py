@@ -367,3 +367,83 @@ def test_lane_sim2_classifier_program_reproduces_reference_log_p(amd_lib):
         sim.load_x(gold["x_out"][b])
         sim.run_forward(row)
         np.testing.assert_allclose(sim.logp, gold["log_p"][b], rtol=2e-5, atol=2e-5)
+
+
+def _twin_network(prog, module, kind):
+    """net(x, t, cond) for oracle/step_sim.py that evaluates the program's lane-level twin: FiLM / bias rows from the step's timestep,
+    one twin instance per trajectory (U-Nets) or per tile of samples (MLP programs)."""
+    from oracle.lane_sim2 import mlp_rows
+
+    def net(x, t, cond):
+        out = np.zeros(tuple(x.shape), np.float32)
+        if kind == "mlp":
+            tile = prog.meta["mlp"]["tile"]
+            row = mlp_rows(prog, module, t[:1])[0]
+            xs = np.zeros((-(-x.shape[0] // tile) * tile, x.shape[1]), np.float32)
+            xs[:x.shape[0]] = x.numpy()
+            cs = None
+            if cond is not None:
+                cs = np.zeros((xs.shape[0], prog.meta["mlp"]["cond_dim"]), np.float32)
+                cs[:x.shape[0]] = torch.flatten(cond, 1).numpy()
+            for i in range(0, xs.shape[0], tile):
+                sim = LaneSim2(prog)
+                sim.load_x(xs[i:i + tile])
+                y = sim.run_forward(row, None if cs is None else cs[i:i + tile])
+                out[i:i + tile] = y[:min(tile, x.shape[0] - i)]
+        elif kind == "chi":
+            from oracle.lane_sim2 import chi_film_rows
+            rows = chi_film_rows(prog, module, t, cond)        # one row per (step, trajectory): the condition is part of it
+            for b in range(x.shape[0]):
+                sim = LaneSim2(prog)
+                sim.load_x(x[b].numpy())
+                out[b] = sim.run_forward(rows[b])
+        else:
+            with torch.no_grad():
+                row = emb_table(prog, module.map_noise(t[:1]).numpy())[0]
+            for b in range(x.shape[0]):
+                sim = LaneSim2(prog)
+                sim.load_x(x[b].numpy())
+                out[b] = sim.run_forward(row)
+        return torch.from_numpy(out)
+    return net
+
+
+@pytest.mark.parametrize("name", ["janner_tiny_disc_ddim", "janner_tiny_disc_ddpm", "dqlmlp_ddpm", "pearce_cfg1_ddpm", "chiunet_cfg_w18_ddim",
+                                  "chiunet_nofilmscale_sde"])
+def test_whole_sampling_loop_through_the_program_twin(name, amd_lib, monkeypatch):
+    """The complete device loop on the CPU: the step records the solver class hands to the kernel (captured at the dispatch hook)
+    interpreted by oracle/step_sim.py, with the compiled program's lane-level twin as the network -- program, tables, step records and
+    their sequencing together land on the real reference's samples (MLP programs in tiles of 4 with a ragged last tile; ChiUNet1d with
+    the classifier-free-guidance pair against the zero condition)."""
+    from cleandiffuser_amd.engine import dispatch
+    from oracle import step_sim
+    gold = np.load(golden_path(name))
+    c = cases.CASES[name]
+    agent, module = cases.build(amd_lib, name)
+    inp = cases.make_inputs(name)
+    seen = {}
+
+    def capture(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, requires_grad, feed):
+        seen.update(plan=plan, xt=xt.clone(), cond=cond_vec, w_cfg=w_cfg)
+        return None
+    monkeypatch.setattr(dispatch, "try_fused_sample", capture)
+    kw = cases.sample_kwargs(name, inp)
+    n_draws = int(gold["n_draws"])
+    agent.sample(torch.from_numpy(inp["prior"]), noise=list(inp["noise"][:n_draws]), **kw)
+    mlp = c["net"][0] in ("DQLMlp", "PearceMlp")
+    kind = "mlp" if mlp else ("chi" if c["net"][0] == "ChiUNet1d" else "unet")
+    if mlp:
+        compiler = P2.compile_dql_mlp2 if c["net"][0] == "DQLMlp" else P2.compile_pearce_mlp2
+        prog = compiler(module, 4)
+    elif kind == "chi":
+        prog = P2.compile_chiunet2(module, cases.x_shape_of(c)[0], nw=8)
+    else:
+        prog = P2.compile_janner2(module, c["horizon"], nw=8)
+    fm = torch.from_numpy(inp["fix_mask"])[None] if inp["fix_mask"] is not None else None
+    x = step_sim.run_plan(seen["plan"], _twin_network(prog, module, kind), seen["xt"],
+                          predict_noise=bool(agent.predict_noise), prior=torch.from_numpy(inp["prior"]), fix_mask=fm,
+                          noise=[torch.from_numpy(v) for v in inp["noise"][1:n_draws]], cond=seen["cond"], w_cfg=seen["w_cfg"],
+                          x_min=getattr(agent, "x_min", None), x_max=getattr(agent, "x_max", None))
+    if getattr(agent, "clip_pred", False):
+        x = x.clip(agent.x_min, agent.x_max)
+    np.testing.assert_allclose(x.numpy(), gold["x_out"], rtol=1e-4, atol=1e-4)
