@@ -86,6 +86,8 @@ F2_GN, F2_EMB, F2_RES, F2_PRED, F2_SAVE, F2_GNBWD, F2_DUAL, F2_SAVE_GLOBAL, F2_F
 F2_COLNORM, F2_BIAS_EMB, F2_OUT_DIV = 512, 1024, 2048
 F2_ACT_SHIFT = 12
 W2_ODIV = 26                  # forward ops: alias of W2_SAVE_STRIDE (a backward-pass word)
+W2_XG = 28                    # forward ops of a SPLIT program (one trajectory over k workgroups of an XCD): alias of W2_DST2 --
+                              # lane groups [lo, hi) this member computes, as lo | hi << 8 | 1 << 16; 0 = the op is not split
 W2_CGREAL4 = 29               # F2_COLNORM ops: alias of W2_DST2_STRIDE -- float4 items of a lane group that hold REAL channels (0 = all):
                               # a per-sample GroupNorm whose groups are narrower than the lane group keeps zero pad channels out of its variance
 
@@ -194,6 +196,9 @@ class _Builder2:
         self.ws_floats = 0                 # per-trajectory global workspace (saved x_hat tensors) when save_global
         self.allow_4x4 = True
         self.fuse_max = FUSE_MAX_RECORDS   # longest main-conv K slice (records) next to which an extra conv still rides in the same op
+        self.member = (0, 1)               # (m, k): this builder emits member m's view of a program split over k workgroups -- the
+                                           # member computes 1/k of the row tiles of every op that can be cut that way (conv())
+        self.xchg_floats = 0               # largest tile (positions x padded channels) a split op exchanges
 
     def add(self, t: torch.Tensor, pad_to: int = 4) -> int:
         t = t.detach().to(device=self.device, dtype=torch.float32).reshape(-1)
@@ -278,8 +283,18 @@ class _Builder2:
         nt = 2 if (mode == MODE_4X4 and l_cols > 4) else 1
         n_rt = -(-c_out // rows)
         n_cg = -(-l_cols // (nt * cols))
-        tiles = n_rt * n_cg * len(phases)
         coutp = pad32(c_out)
+        # ---- member view of a split program: which row tiles are this member's, and which lane groups of the epilogue that is ----
+        mem, ksp = self.member
+        my_rts, xg = list(range(n_rt)), 0
+        if ksp > 1 and len(phases) == 1 and n_rt > 1 and bwd is None and save is None and (n_rt % ksp == 0 or ksp % n_rt == 0):
+            cand = list(range(mem * n_rt // ksp, (mem + 1) * n_rt // ksp)) if n_rt >= ksp else [mem * n_rt // ksp]
+            cgw = coutp // GROUPS2
+            lo_c, hi_c = cand[0] * rows, (cand[-1] + 1) * rows
+            if lo_c % cgw == 0 and hi_c % cgw == 0:             # whole GroupNorm lane groups
+                my_rts, xg = cand, (lo_c // cgw) | (min(hi_c // cgw, GROUPS2) << 8) | (1 << 16)
+                self.xchg_floats = max(self.xchg_floats, l_out * coutp)
+        tiles = len(my_rts) * n_cg * len(phases)
         sstride = coutp + 4
         nw, ring = self.nw, ring_depth(self.nw)
         # record stream of a (phase, row tile): [source 0: taps x chunks | source 1: taps x chunks]; a K slice never straddles the
@@ -344,6 +359,8 @@ class _Builder2:
                     q0, q1 = edge[j], edge[j + 1]
                     for tile in range(n_rt * n_cg):
                         rt, cgi = tile % n_rt, tile // n_rt
+                        if rt not in my_rts:
+                            continue
                         items.append([woff + (rt * n + q0) * 256, q1 - q0, (q0 // st["ccn"]) | ((q0 % st["ccn"]) << 8),
                                       ks * l_out * sstride + rt * rows, cgi * nt * cols, st["pad"] | (0 << 8), 0, st["ccn"]])
                         item_src.append(st["src"])
@@ -397,6 +414,8 @@ class _Builder2:
             words[W2_BOFF] = bias_row
         else:
             words[W2_BOFF] = self.add(_padded(bias if bias is not None else torch.zeros(c_out, device=self.device), coutp))
+        if xg:
+            words[W2_XG] = xg
         if kpost:
             words[W2_PBIAS] = self.add(_padded(pbias, coutp))
         cg = coutp // GROUPS2
@@ -1193,7 +1212,7 @@ def _finalize2(b: "_Builder2", nets_emb: List[dict], x: Act, pred: Act, horizon:
 
 
 def compile_janner2(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x4: bool = True, nw: int = NW2, compact: bool = False,
-                    max_stage: Optional[int] = None) -> Program2:
+                    max_stage: Optional[int] = None, member: Tuple[int, int] = (0, 1)) -> Program2:
     """Lower a JannerUNet1d (reference nn_diffusion/jannerunet.py:98-201) for `horizon` positions and `nw` waves per workgroup.
     `compact`: the small-LDS variant for THREE trajectories per workgroup (in-place residual outputs, capped staging area)."""
     why = supports_janner(net)
@@ -1203,6 +1222,11 @@ def compile_janner2(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x
     b = _Builder2(dev, nw)
     b.allow_4x4 = allow_4x4
     b.alias_residual = compact
+    b.member = member
+    if member[1] > 1:
+        if compact or nw != NW2_MAX:
+            raise ValueError("split programs: the 8-wave, state-in-LDS form only")
+        b.fuse_max = 1 << 30                  # (a member's K slices are short: the 1x1 skips always ride in their block's second conv)
     if max_stage is not None:
         b.max_stage = max_stage
     d = net.in_dim
@@ -1211,7 +1235,41 @@ def compile_janner2(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x
     pred = b.act(horizon, d)                 # arena slot: written by the last op, read by the solver step right after it
     b.conv([t], pred, _conv1d_eff(fc[3]), fc[3].bias, pred=True)
     emb = _emb_table_spec(b, net, blocks, dev)
-    return _finalize2(b, [emb], x, pred, horizon, d, net.emb_dim, max_lds_bytes, [], compact=compact)
+    prog = _finalize2(b, [emb], x, pred, horizon, d, net.emb_dim, max_lds_bytes, [], compact=compact)
+    prog.meta["xchg_floats"] = b.xchg_floats
+    return prog
+
+
+def compile_janner2_split(net, horizon: int, k: int, max_lds_bytes: int = 160 * 1024) -> Program2:
+    """One trajectory over k workgroups of an XCD (small batches: B x k <= 256 workgroups).  Every member holds the whole activation
+    set in its own LDS and runs the whole op list, but computes only its 1/k of the row tiles (and GroupNorm groups) of the ops that
+    can be cut that way; after such an op the members all-gather the op's output through a 4 KB tile in global memory (same L2: no
+    agent-scope fence, tools/xwg_exchange_probe.hip).  The k member views share the blob, the LDS plan and the op count; their
+    descriptors are laid out [member 0 ops | member 1 ops | ... | item tails], so member m's op i is descriptor m * n_ops + i."""
+    if k not in (2, 4):
+        raise ValueError("split factor 2 or 4")
+    members = [compile_janner2(net, horizon, max_lds_bytes=max_lds_bytes, nw=NW2_MAX, member=(m, k)) for m in range(k)]
+    p0 = members[0]
+    n_ops, opw = len(p0.ops), op_words(NW2_MAX)
+    for p in members[1:]:
+        same = (len(p.ops), p.traj_floats, p.x_off, p.pred_off, p.prev_off, p.stage_off, p.n_emb, p.blob.numel()) == \
+               (n_ops, p0.traj_floats, p0.x_off, p0.pred_off, p0.prev_off, p0.stage_off, p0.n_emb, p0.blob.numel())
+        if not same or not torch.equal(p.blob, p0.blob):
+            raise ValueError("member views of a split program disagree on the LDS plan or the blob")
+    ops_all, tails, base = [], [], k * n_ops * opw
+    for p in members:
+        ops = p.ops.copy()
+        tail = p.ops_buffer[n_ops * opw:]
+        ops[:, W2_ITEMS] = ops[:, W2_ITEMS] - n_ops * opw + base        # tail cursors: re-based behind ALL members' descriptors
+        base += tail.size
+        ops_all.append(ops)
+        tails.append(tail)
+    p0.meta["split_k"] = k
+    p0.meta["member_ops"] = ops_all                      # (tail cursors re-based: what oracle/lane_sim2.py interprets per member)
+    p0.ops = ops_all[0]
+    p0.ops_buffer = np.concatenate([np.concatenate(ops_all).reshape(-1)] + tails).astype(np.int32)
+    p0.meta["xchg_floats"] = max(p.meta["xchg_floats"] for p in members)
+    return p0
 
 
 def compile_guided2(net, clf, horizon: int, max_lds_bytes: int = 160 * 1024, nw: int = NW2_MAX, save_global: bool = False,

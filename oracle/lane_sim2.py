@@ -88,10 +88,13 @@ def emb_table(prog: P2.Program2, temb, tembs=None) -> np.ndarray:
 
 
 class LaneSim2:
-    def __init__(self, prog: P2.Program2):
+    def __init__(self, prog: P2.Program2, member: int = -1):
+        """`member` >= 0: member view of a split program (one trajectory over k workgroups): this instance runs that member's
+        descriptors; `run_forward_split` steps the k instances in lockstep and performs the exchanges."""
         self.p = prog
         self.blob = prog.blob.detach().cpu().numpy()
         self.buf = prog.ops_buffer
+        self.ops = prog.ops if member < 0 else prog.meta["member_ops"][member]
         self.ws = np.full(max(prog.ws_floats, 1), np.nan, np.float32)    # this trajectory's block of the global workspace
         self.lds = np.full(prog.traj_floats, np.nan, np.float32)        # NaN poison: an unwritten read shows up
         # kernel start: the whole trajectory region is zeroed once (halo rows and pad channels of the state slot)
@@ -123,7 +126,13 @@ class LaneSim2:
     def run_forward(self, emb_row, ctx=None):
         """All ops once; returns the prediction slot (guided programs: see also grad()).  `ctx` (tile, C): the per-sample condition
         features of a batch-tiled MLP program (None: zeros, as for the unconditional forward)."""
-        for op in self.p.ops:
+        for op in self.ops:
+            self.run_op(op, emb_row, ctx)
+        p = self.p
+        return self.read_slot(p.pred_off, p.pred_stride, p.horizon, p.dim)
+
+    def run_op(self, op, emb_row, ctx=None):
+        if True:
             if int(op[P2.W2_KIND]) == P2.KIND2_LOADC:         # context slot <- condition features; halo rows and pad channels zero
                 dst, dstr, ln, ch = (int(op[k]) for k in (P2.W2_DST, P2.W2_DST_STRIDE, P2.W2_LOUT, P2.W2_COUT))
                 self.lds[dst: dst + (ln + 2 * P2.HALO2) * dstr] = 0.0
@@ -140,8 +149,6 @@ class LaneSim2:
                     self.lds[dst + (n + P2.HALO2) * dstr: dst + (n + P2.HALO2) * dstr + ch] = self.xg[n]
             else:
                 self._conv(op, np.asarray(emb_row, np.float32))
-        p = self.p
-        return self.read_slot(p.pred_off, p.pred_stride, p.horizon, p.dim)
 
     def grad(self):
         p = self.p
@@ -240,8 +247,12 @@ class LaneSim2:
         bias = emb_row[int(op[P2.W2_BOFF]):int(op[P2.W2_BOFF]) + coutp] if flags & P2.F2_BIAS_EMB else par(P2.W2_BOFF)
         act_id = (flags >> P2.F2_ACT_SHIFT) & 15              # 0: Mish after a GroupNorm, nothing otherwise
         vals = {}
+        xg = int(op[P2.W2_XG]) if not (flags & (P2.F2_GNBWD | P2.F2_SAVE)) else 0      # split programs: this member's lane groups
+        g_lo, g_hi = (xg & 255, (xg >> 8) & 255) if xg else (0, P2.GROUPS2)
         for tid in range(256):
             g, li = tid >> 5, tid & 31
+            if not g_lo <= g < g_hi:
+                continue
             for k in range(nk):
                 i = li + 32 * k
                 if i >= nv:
@@ -275,7 +286,7 @@ class LaneSim2:
         elif flags & P2.F2_GN:
             gamma, beta = par(P2.W2_GAMMA), par(P2.W2_BETA)
             inv_cnt = np.int32(op[P2.W2_INV_CNT]).view(np.float32)
-            for g in range(P2.GROUPS2):
+            for g in range(g_lo, g_hi):
                 keys = [kk for kk in vals if kk[0] == g]
                 allv = np.concatenate([vals[kk] for kk in keys])
                 # single pass, shifted by the group's first element (lane 0 of the half-wave, component 0): one cross-lane
@@ -403,3 +414,38 @@ def mlp_rows(prog: P2.Program2, net, t) -> np.ndarray:
         if "t" in r:
             out = out + t.to(torch.float32)[:, None] @ r["t"].cpu().t()
     return out.numpy().astype(np.float32)
+
+
+def run_forward_split(sims, emb_row):
+    """One forward of a SPLIT program: `sims[m]` = LaneSim2(prog, member=m), all loaded with the same state.  The members step through
+    the op list together; after an op that is cut over the members (W2_XG) every member receives the channels it did not compute from
+    the member that did -- the all-gather the kernel performs through global memory.  Returns member 0's prediction slot (all equal)."""
+    p = sims[0].p
+    k = len(sims)
+    for i in range(len(sims[0].ops)):
+        for s in sims:
+            s.run_op(s.ops[i], emb_row)
+        xgs = [int(s.ops[i][P2.W2_XG]) for s in sims]
+        if not any(xgs):
+            continue
+        assert all(xgs), "an op is split for every member or for none"
+        op = sims[0].ops[i]
+        c_out, l_out, coutp = int(op[P2.W2_COUT]), int(op[P2.W2_LOUT]), int(op[P2.W2_COUTP])
+        cg = coutp // P2.GROUPS2
+        owner = {}
+        for m, xg in enumerate(xgs):
+            for g in range(xg & 255, (xg >> 8) & 255):
+                owner.setdefault(g, m)
+        assert sorted(owner) == list(range(min(P2.GROUPS2, -(-c_out // cg)))) or len(owner) == P2.GROUPS2, owner
+        for m, s in enumerate(sims):
+            lo, hi = xgs[m] & 255, (xgs[m] >> 8) & 255
+            dst, dstr = int(s.ops[i][P2.W2_DST]), int(s.ops[i][P2.W2_DST_STRIDE])
+            for g, src_m in owner.items():
+                if lo <= g < hi:
+                    continue
+                src = sims[src_m]
+                sd, sds = int(src.ops[i][P2.W2_DST]), int(src.ops[i][P2.W2_DST_STRIDE])
+                for pos in range(l_out):
+                    for c in range(g * cg, min((g + 1) * cg, c_out)):
+                        s.lds[dst + (pos + P2.HALO2) * dstr + c] = src.lds[sd + (pos + P2.HALO2) * sds + c]
+    return sims[0].read_slot(p.pred_off, p.pred_stride, p.horizon, p.dim)

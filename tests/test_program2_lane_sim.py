@@ -447,3 +447,33 @@ def test_whole_sampling_loop_through_the_program_twin(name, amd_lib, monkeypatch
     if getattr(agent, "clip_pred", False):
         x = x.clip(agent.x_min, agent.x_max)
     np.testing.assert_allclose(x.numpy(), gold["x_out"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("k", [2, 4])
+@pytest.mark.parametrize("name", ["janner_cfg2_ddim", "janner_tiny_disc_ddim"])
+def test_lane_sim2_split_program_reproduces_reference_forward(name, k, amd_lib):
+    """One trajectory over k workgroups (small-batch mode): every member runs the whole op list on its own copy of the activations but
+    computes only its share of the row tiles / GroupNorm groups of the ops that can be cut; the twin steps the k member views in
+    lockstep and performs the all-gathers.  Must land on the reference's first forward like the unsplit program."""
+    from oracle.lane_sim2 import run_forward_split
+    gold = np.load(golden_path(name))
+    agent, _ = cases.build(amd_lib, name)
+    c = cases.CASES[name]
+    net = agent.model_ema["diffusion"]
+    prog = P2.compile_janner2_split(net, c["horizon"], k)
+    assert prog.lds_bytes(1) <= 160 * 1024 and prog.meta["split_k"] == k and len(prog.meta["member_ops"]) == k
+    assert prog.ops_buffer[:prog.meta["member_ops"][0].size].reshape(prog.meta["member_ops"][0].shape).tolist() == prog.meta["member_ops"][0].tolist()
+    n_split = sum(1 for op in prog.ops if op[P2.W2_XG])
+    assert n_split >= (len(prog.ops) // 2 if name == "janner_cfg2_ddim" else 1)          # (16-channel layers are one row tile: not cut)
+    inp, xt0 = _first_forward_inputs(name, agent)
+    with torch.no_grad():
+        temb = net.map_noise(_first_t(agent, c)).numpy()
+    row = emb_table(prog, temb)[0]
+    for b in range(2):
+        sims = [LaneSim2(prog, member=m) for m in range(k)]
+        for s in sims:
+            s.load_x(xt0[b])
+        np.testing.assert_allclose(run_forward_split(sims, row), gold["pred0"][b], rtol=2e-5, atol=2e-5)
+        for s in sims[1:]:                               # every member ends with the same prediction
+            np.testing.assert_array_equal(s.read_slot(prog.pred_off, prog.pred_stride, prog.horizon, prog.dim),
+                                          sims[0].read_slot(prog.pred_off, prog.pred_stride, prog.horizon, prog.dim))
