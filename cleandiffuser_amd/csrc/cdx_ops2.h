@@ -81,5 +81,6 @@
 #define CDX2_F2_OUT_DIV 2048    /* the stored value is divided by the float in W2_ODIV */
 #define CDX2_F2_ACT_SHIFT 12    /* flags bits 12-15: activation id + 1 (CDX_ACT_* of include/cdx.h), 0 = Mish after a GroupNorm, else none */
 #define CDX2_W2_ODIV 26         /* forward ops: alias of W2_SAVE_STRIDE */
+#define CDX2_W2_XG 28           /* forward ops of a split program: alias of W2_DST2: lane groups [lo, hi) of this member as lo | hi << 8 | 1 << 16; 0 = not cut */
 #define CDX2_W2_CGREAL4 29      /* F2_COLNORM ops: alias of W2_DST2_STRIDE: float4 items per lane group that hold real channels (0 = all) */
 #define CDX2_KIND2_LOADC 3      /* context slot <- the launch's per-sample condition features (zeros: unconditional forward / no condition) */

@@ -797,16 +797,82 @@ struct OpFetch {
 // T = 2 with the loads BEHIND the barrier 5.604 vs 5.659 ms (in front: 5.72) -- hence PARAMS_AFTER_BARRIER = (T >= 2).
 template <int T, bool BWD> constexpr bool pipe_params() { return CDX2_PIPE_PARAMS && T < 3 && !BWD; }
 
+// Split programs (one trajectory over k workgroups of one XCD; engine/program2.py:compile_janner2_split): what a member knows about
+// its group.  After an op that is cut over the members (descriptor word W2_XG) every member publishes the channels it computed into
+// the group's tile in global memory and collects the others'.  All members sit on the same XCD, i.e. behind the same L2, so no
+// agent-scope fence is needed -- and no flag either: the tile is made of 8-byte {value, tag} granules, tag = the exchange's sequence
+// number, written with plain 16-byte stores and polled with L1-bypassing 16-byte loads until both tags of a load match (one L2 round
+// trip per exchange instead of store-drain + flag + data; tools/xwg_exchange_probe.hip measured the flag form at ~0.8 k cycles on top
+// of the local traffic, in this kernel it cost ~5.7 k cycles per op with its four barriers).  The two tiles of a group alternate by
+// the parity of the sequence number: a member can only be two exchanges ahead of another after that one has finished reading.
+// Every poll is bounded: a granule that never arrives sets `err` and the launch ends with wrong numbers instead of hanging the GPU.
+// Sequence numbers keep increasing across launches on the same tiles (launch field xseq0), so nothing is cleared per launch.
+struct XState {
+    int m, k;                  // this workgroup's member index, members per trajectory
+    unsigned seq;              // exchanges done so far (the same number in every member: they run the same op list)
+    float* tiles;              // the group's two tiles, 2 * xf floats each ({value, tag} pairs)
+    unsigned* flags;           // (unused by the granule protocol; kept for the launch ABI)
+    int xf;
+    int* err;
+};
+
+template <int THREADS>
+__device__ __forceinline__ void split_exchange(XState& X, int xg, float* __restrict__ tl, int dst, int dstride, int l_out, int c_out,
+                                               int coutp, int tid) {
+    const int g_lo = xg & 255, g_hi = (xg >> 8) & 255, cg = coutp >> 3;
+    X.seq += 1;
+    float* __restrict__ tile = X.tiles + (size_t)(X.seq & 1) * 2 * X.xf;
+    const float tag = __uint_as_float(X.seq);
+    const int c4n = coutp >> 2;
+    // publish: this member's channels, read back from the destination slot the epilogue just wrote (pad channels travel along)
+    for (int i = tid; i < l_out * c4n; i += THREADS) {
+        const int pos = i / c4n, c = (i - pos * c4n) * 4, grp = c / cg;
+        if (grp >= g_lo && grp < g_hi) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(tl + dst + (pos + CDX2_HALO2) * dstride + c);
+            f32x4* o = reinterpret_cast<f32x4*>(tile + (size_t)(pos * coutp + c) * 2);
+            o[0] = (f32x4){v[0], tag, v[1], tag};
+            o[1] = (f32x4){v[2], tag, v[3], tag};
+        }
+    }
+    // collect: everybody else's channels, straight from L2 (nontemporal loads bypass this CU's L1), as soon as their tags say so
+    for (int i = tid; i < l_out * c4n; i += THREADS) {
+        const int pos = i / c4n, c = (i - pos * c4n) * 4, grp = c / cg;
+        if ((grp < g_lo || grp >= g_hi) && c < c_out) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(tile + (size_t)(pos * coutp + c) * 2);
+            f32x4 a, b;
+            int spins = 0;
+            for (;;) {
+                a = __builtin_nontemporal_load(src);
+                b = __builtin_nontemporal_load(src + 1);
+                if (__float_as_uint(a[1]) == X.seq && __float_as_uint(a[3]) == X.seq && __float_as_uint(b[1]) == X.seq &&
+                    __float_as_uint(b[3]) == X.seq)
+                    break;
+                if (++spins > 2000000) { *X.err = 1; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            float* o = tl + dst + (pos + CDX2_HALO2) * dstride + c;
+            const f32x4 v = (f32x4){a[0], a[2], b[0], b[2]};
+            if (c + 3 < c_out) *reinterpret_cast<f32x4*>(o) = v;
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (c + j < c_out) o[j] = v[j];
+            }
+        }
+    }
+}
+
 // One op.  `vd`: this wave's view of the op's descriptor, `it`: this wave's first item, both fetched during the previous op;
 // `vdn`: the next op's descriptor, whose load was issued before this call.  Leaves the next op's first item in `it`.
 // Epilogue threads: 256 per trajectory (8 GroupNorm groups x 32 lanes).  4 waves: all of them, one trajectory after the other;
 // 8 waves, T = 2: waves 0-3 take trajectory 0 while waves 4-7 take trajectory 1; 8 waves, T = 1: waves 0-3 run the epilogue,
 // waves 4-7 rewrite the destination's halo rows.
-template <int T, int NWV, bool BWD, bool PROF, bool COND, bool MLP = false>
+template <int T, int NWV, bool BWD, bool PROF, bool COND, bool MLP = false, bool SPLIT = false>
 __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* ops, int vd, int vdn, Item& it,
                                        const float* __restrict__ emb_row, int emb_tstride, float* __restrict__ lds, int tid,
                                        Ring<WG<NWV>::PF>& ring, unsigned long long* prof, int b0, OpFetch& F,
-                                       const float* __restrict__ emb_next, int emb_next_tstride, int op_next2, int pass = 0) {
+                                       const float* __restrict__ emb_next, int emb_next_tstride, int op_next2, int pass = 0,
+                                       XState* X = nullptr) {
     constexpr bool SPLIT_T = NWV == 8 && T >= 2;       // waves 0-3 take trajectories 0, 2; waves 4-7 trajectory 1
     constexpr bool PIPE = pipe_params<T, BWD>();
     constexpr bool PARAMS_AFTER_BARRIER = PIPE && T >= 2;
@@ -819,7 +885,7 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
         if (PIPE) {
             if (params)
                 F.P = load_params<COND, SPLIT_T, false, MLP>(L, vdn, emb_next, emb_next_tstride, tid, wave_of(tid), NWV == 4 || SPLIT_T || wave_of(tid) < 4);
-            F.vdn2 = load_desc<NWV>(L.ops, op_next2, tid & 63, wave_of(tid));
+            F.vdn2 = load_desc<NWV>(L.ops, op_next2 + (SPLIT ? X->m * L.n_ops : 0), tid & 63, wave_of(tid));
         }
     };
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -921,7 +987,9 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
                 P.em = *reinterpret_cast<const f32x4*>(pe + e.coutp);
             } else P.em = *reinterpret_cast<const f32x4*>(pe);
         }
-        if (epi_wave) {
+        // (split programs: the half-waves of lane groups that belong to other members sit this op's epilogue out)
+        const int xg = SPLIT ? CDX2_DW(vd, CDX2_W2_XG) : 0;
+        if (epi_wave && (!SPLIT || xg == 0 || (grp >= (xg & 255) && grp < ((xg >> 8) & 255)))) {
             if (BWD && (e.flags & CDX2_F2_GNBWD)) {
                 if (e.nk == 1) epilogue_bwd<1>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
                 else if (e.nk == 2) epilogue_bwd<2>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
@@ -942,6 +1010,10 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
         }
     }
     if (PIPE) F.P = Pnext;
+    if (SPLIT && CDX2_DW(vd, CDX2_W2_XG) != 0) {
+        __syncthreads();                                             // the epilogue's stores to the destination slot are in LDS
+        split_exchange<WG<NWV>::THREADS>(*X, CDX2_DW(vd, CDX2_W2_XG), lds, e.dst, e.dstride, e.l_out, e.c_out, e.coutp, tid);
+    }
     __syncthreads();
     if (PROF) stamp(prof ? prof + 3 : nullptr, tid);
 }
@@ -953,16 +1025,35 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
 // COND: the instantiations that understand conditional requests (per-trajectory FiLM rows, the classifier-free-guidance pair, EDM /
 // consistency step kinds).  A separate template parameter so that the unconditional kernels -- the headline path, scalar-register
 // bound -- compile to exactly the code they had before.
-template <int T, int NWV, bool BWD, bool PROF, bool COND = false, bool MLP = false>
+template <int T, int NWV, bool BWD, bool PROF, bool COND = false, bool MLP = false, bool SPLIT = false>
 __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_unet2_kernel(const cdx_unet2_launch L) {
     static_assert(!(COND && BWD), "conditional requests have no backward-op variant");
     static_assert(!MLP || (COND && T == 1 && NWV == 8), "batch-tiled MLP programs: the conditional one-trajectory 8-wave shape");
+    static_assert(!SPLIT || (T == 1 && NWV == 8 && !BWD && !COND && !PROF), "split programs: unconditional one-trajectory 8-wave shape");
     constexpr int THREADS = WG<NWV>::THREADS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = L.horizon, D = L.dim, HD = H * D, tf = L.traj_floats;
-    const int b0 = L.traj_first + blockIdx.x * T;
+    // split programs: 8 k consecutive workgroups hold 8 trajectories x k members; the members of a trajectory are 8 workgroups apart,
+    // i.e. on the same XCD (workgroup i runs on XCD i % 8)
+    XState X{0, 1, 0u, nullptr, nullptr, 0, nullptr};
+    int grp_idx = 0;
+    if (SPLIT) {
+        const KArg* S0 = kernarg();
+        asm volatile("" : "+s"(S0));
+        X.k = S0->split_k;
+        const int bid = (int)blockIdx.x, span = 8 * X.k;
+        grp_idx = (bid / span) * 8 + (bid & 7);
+        X.m = (bid % span) >> 3;
+        X.xf = S0->xchg_floats;
+        X.tiles = S0->xbuf + (size_t)grp_idx * 4 * X.xf;           // two tiles of 2 * xf floats ({value, tag} granules)
+        X.flags = S0->xflags + (size_t)grp_idx * 16 * 8;
+        X.err = S0->xerr;
+        X.seq = S0->xseq0;
+    }
+    const int moff = SPLIT ? X.m * L.n_ops : 0;           // member m's op i is descriptor m * n_ops + i
+    const int b0 = L.traj_first + (SPLIT ? grp_idx : (int)blockIdx.x * T);
     const int b_end = L.traj_first + L.traj_count;      // this launch covers trajectories [traj_first, traj_first + traj_count) of the batch
     unsigned long long* lprof = reinterpret_cast<unsigned long long*>(lds + T * tf);
     const bool profiling = PROF && L.prof != nullptr && blockIdx.x == 0;
@@ -970,7 +1061,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
 
     // descriptor + first item + weight stream of op 0 first: they fly while the state is set up
     const cint* ops = as_const(L.ops);
-    int vd = load_desc<NWV>(L.ops, 0, lane, wave);
+    int vd = load_desc<NWV>(L.ops, moff, lane, wave);
     Item it = inline_item(vd);
     Ring<WG<NWV>::PF> ring;
     if (wave < CDX2_DW(vd, CDX2_W2_NITEMS)) prefetch_ring(it, L.wblob, lane, ring);
@@ -1050,7 +1141,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
         int ts0;
         const float* row0 = emb_of(0, 0, ts0);
         F.P = load_params<COND, SPLIT_T0, false, MLP>(L, vd, row0, ts0, tid, wave, NWV == 4 || SPLIT_T0 || wave < 4);
-        vdn_keep = load_desc<NWV>(L.ops, L.n_ops > 1 ? 1 : 0, lane, wave);
+        vdn_keep = load_desc<NWV>(L.ops, moff + (L.n_ops > 1 ? 1 : 0), lane, wave);
     }
     for (int step = 0; step < n_iter; ++step) {
       const int n_pass = n_pass_all;
@@ -1066,7 +1157,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
         for (int oi = 0; oi < L.n_ops; ++oi) {
             // next op's descriptor (the last op fetches op 0 of the next step): one coalesced load, needed after the K loop
             // (PIPE: it was fetched during the previous op; this op fetches the one after it)
-            const int vdn = PIPE ? vdn_keep : load_desc<NWV>(L.ops, oi + 1 < L.n_ops ? oi + 1 : 0, lane, wave);
+            const int vdn = PIPE ? vdn_keep : load_desc<NWV>(L.ops, moff + (oi + 1 < L.n_ops ? oi + 1 : 0), lane, wave);
             // (profile the SECOND forward when there is one: instruction / scalar caches warm, like every later step)
             unsigned long long* pslot = (profiling && step == (L.n_steps > 1 ? 1 : 0)) ? lprof + (size_t)oi * 8 : nullptr;
             if (PROF) stamp(pslot, tid);
@@ -1076,9 +1167,9 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
             if (on2 >= L.n_ops) on2 = 0;
             // (MLP programs: `pass` tells the context-slot op what to load -- 0 the condition, 1 zeros (unconditional forward of a
             //  pair), 2 nothing: one forward per step and the slot was filled by step 0)
-            run_op<T, NWV, BWD, PROF, COND, MLP>(L, ops, vd, vdn, it, emb_row, emb_tstride, lds, tid, ring, pslot, b0, F,
-                                                 wrap ? emb_fwd_next : emb_row, wrap ? ts_fwd_next : emb_tstride, on2,
-                                                 (MLP && n_pass == 1 && step > 0) ? 2 : pass);
+            run_op<T, NWV, BWD, PROF, COND, MLP, SPLIT>(L, ops, vd, vdn, it, emb_row, emb_tstride, lds, tid, ring, pslot, b0, F,
+                                                        wrap ? emb_fwd_next : emb_row, wrap ? ts_fwd_next : emb_tstride, on2,
+                                                        (MLP && n_pass == 1 && step > 0) ? 2 : pass, &X);
             vd = vdn;
             if (PIPE) vdn_keep = F.vdn2;
         }
@@ -1269,6 +1360,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
         const int str = S->n_steps == 0 ? (want_grad ? S->grad_stride : S->pred_stride) : S->x_stride;
         float* __restrict__ xo = S->x_out;
         if ((S->compact || (COND && S->edm_plan)) && S->n_steps > 0) break;            // the state is already there
+        if (SPLIT && X.m != 0) break;                                                  // every member holds the result: member 0 stores it
         if (BWD && logp_only) break;                                                   // nothing but logp_out is produced
         for (int e = tid; e < HD; e += THREADS) {
             const int n = e / D, c = e - n * D;
@@ -1386,7 +1478,16 @@ int cdx_unet2_run(const cdx_unet2_launch* L, void* hip_stream) {
     }
     void (*kern)(const cdx_unet2_launch);
     const bool cond = L->n_pass == 2 || L->edm_plan || L->emb_per_traj;
-    if (L->mlp) {
+    int split_grid = 0;
+    if (L->split_k != 0) {
+        if ((L->split_k != 2 && L->split_k != 4) || guided || cond || L->mlp || L->prof || L->traj_per_wg != 1 || L->n_waves != 8 || L->compact ||
+            !L->xbuf || !L->xerr || L->xchg_floats <= 0 || (L->xchg_floats & 3)) {
+            cdx_set_err("split program: split_k 2 or 4, one trajectory per workgroup, 8 waves, unconditional, xbuf / xflags / xerr given"); return CDX_EINVAL;
+        }
+        split_grid = ((L->traj_count + 7) / 8) * 8 * L->split_k;
+        if (split_grid > 256) { cdx_set_err("split program: every workgroup of the launch must be resident (<= 256)"); return CDX_EINVAL; }
+        kern = cdx_unet2_kernel<1, 8, false, false, false, false, true>;
+    } else if (L->mlp) {
         if (guided || L->traj_per_wg != 1 || L->n_waves != 8 || L->emb_per_traj || L->compact || L->prof) {
             cdx_set_err("batch-tiled MLP program: one tile per workgroup, 8 waves, one table row per step, no backward ops"); return CDX_EINVAL;
         }
@@ -1411,7 +1512,7 @@ int cdx_unet2_run(const cdx_unet2_launch* L, void* hip_stream) {
     }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
-    const int grid = (L->traj_count + L->traj_per_wg - 1) / L->traj_per_wg;
+    const int grid = split_grid ? split_grid : (L->traj_count + L->traj_per_wg - 1) / L->traj_per_wg;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(L->n_waves * 64), lds_bytes, reinterpret_cast<hipStream_t>(hip_stream), *L);
     e = hipGetLastError();
     if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }

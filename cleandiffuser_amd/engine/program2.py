@@ -52,6 +52,9 @@ HALO2 = 2                     # zero rows on either side of a slot: covers kerne
 MIN_SLICE = int(os.environ.get("CDX_UNET2_MIN_SLICE", "3"))      # shortest K slice (records) worth a wave of its own
 FUSE_SKIP = os.environ.get("CDX_UNET2_FUSE_SKIP", "1") != "0"    # 1x1 skip convs ride in their block's second conv op ...
 FUSE_MAX_RECORDS = int(os.environ.get("CDX_UNET2_FUSE_MAX", "100"))   # ... unless that leaves the main conv K slices longer than this
+SPLIT_MIN_RECORDS = int(os.environ.get("CDX_UNET2_SPLIT_MIN", "32"))  # split programs: an op is cut over the members only if a wave of
+                                                                       # the uncut op streams at least this many records (an
+                                                                       # exchange costs ~3 k cycles, a record ~170 per wave)
 
 (W2_KIND, W2_FLAGS, W2_COUT, W2_LOUT, W2_LCOLS, W2_CSTRIDE, W2_OSTRIDE, W2_MODE, W2_NT, W2_NITEMS, W2_ITEMS, W2_DST,
  W2_DST_STRIDE, W2_SSTRIDE, W2_KSPLIT, W2_BOFF, W2_GAMMA, W2_BETA, W2_EMB, W2_RES, W2_RES_STRIDE, W2_CG4_SHIFT, W2_INV_CNT,
@@ -287,7 +290,9 @@ class _Builder2:
         # ---- member view of a split program: which row tiles are this member's, and which lane groups of the epilogue that is ----
         mem, ksp = self.member
         my_rts, xg = list(range(n_rt)), 0
-        if ksp > 1 and len(phases) == 1 and n_rt > 1 and bwd is None and save is None and (n_rt % ksp == 0 or ksp % n_rt == 0):
+        k_chunks = sum(-(-a.chans // (16 if mode == MODE_16X16 else 4)) for a in srcs) * phases[0][0].shape[1]     # records per row tile
+        worth = k_chunks * n_rt * n_cg / self.nw >= SPLIT_MIN_RECORDS
+        if ksp > 1 and worth and len(phases) == 1 and n_rt > 1 and bwd is None and save is None and (n_rt % ksp == 0 or ksp % n_rt == 0):
             cand = list(range(mem * n_rt // ksp, (mem + 1) * n_rt // ksp)) if n_rt >= ksp else [mem * n_rt // ksp]
             cgw = coutp // GROUPS2
             lo_c, hi_c = cand[0] * rows, (cand[-1] + 1) * rows
@@ -1269,6 +1274,8 @@ def compile_janner2_split(net, horizon: int, k: int, max_lds_bytes: int = 160 * 
     p0.ops = ops_all[0]
     p0.ops_buffer = np.concatenate([np.concatenate(ops_all).reshape(-1)] + tails).astype(np.int32)
     p0.meta["xchg_floats"] = max(p.meta["xchg_floats"] for p in members)
+    if p0.meta["xchg_floats"] == 0:
+        raise ValueError("split program: no op of this net streams enough weights to be cut over the members")
     return p0
 
 

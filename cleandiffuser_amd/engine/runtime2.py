@@ -47,7 +47,9 @@ class CdxUnet2Launch(ctypes.Structure):
                 ("compact", ctypes.c_int32), ("prof", ctypes.c_void_p),
                 ("emb_per_traj", ctypes.c_int32), ("n_pass", ctypes.c_int32), ("emb_u", ctypes.c_void_p), ("cfg_w", ctypes.c_float),
                 ("edm_plan", ctypes.c_int32), ("logp_out", ctypes.c_void_p), ("logp_first_op", ctypes.c_int32),
-                ("logp_head_op", ctypes.c_int32), ("ctx", ctypes.c_void_p), ("mlp", ctypes.c_int32)]
+                ("logp_head_op", ctypes.c_int32), ("ctx", ctypes.c_void_p), ("mlp", ctypes.c_int32),
+                ("split_k", ctypes.c_int32), ("xchg_floats", ctypes.c_int32), ("xbuf", ctypes.c_void_p), ("xflags", ctypes.c_void_p),
+                ("xerr", ctypes.c_void_p), ("xseq0", ctypes.c_uint32)]
 
 
 _declared = False
@@ -278,13 +280,33 @@ def shape_for(module, horizon: int, batch: int):
 def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps=0, predict_noise=0, prior=None,
            fix_mask=None, noise=None, x_min=None, x_max=None, t_per_wg: Optional[int] = None, x_scale: Optional[float] = None,
            cg_scale=None, with_backward: bool = False, parts=None, emb_per_traj: bool = False, emb_u=None, cfg_w: float = 1.0,
-           edm: bool = False, logp_out=None, ctx=None):
+           edm: bool = False, logp_out=None, ctx=None, split: int = 0):
     if batch <= 0:
         return
     prog = comp.prog
     if "chi_film" in prog.meta and not emb_per_traj:
         raise ValueError("ChiUNet1d programs carry FiLM-scale ops: only the per-trajectory-table kernels decode them")
     mlp = "mlp" in prog.meta
+    xbuf = xerr = None
+    xseq0 = 0
+    if split:
+        assert split == prog.meta.get("split_k") and parts is None and t_per_wg in (None, 1)
+        check_split_errors(x_in.device, wait=False)   # (a lost granule of an EARLIER split launch on this device surfaces here)
+        n_grp = -(-batch // 8) * 8
+        key = (x_in.device, R._stream_ptr(x_in.device))
+        need = n_grp * 4 * prog.meta["xchg_floats"]
+        n_forwards = max(n_steps, 1)
+        if "n_cut_ops" not in prog.meta:
+            prog.meta["n_cut_ops"] = int(sum(1 for op in prog.ops if op[P2.W2_XG]))
+        n_xchg = prog.meta["n_cut_ops"] * n_forwards
+        st = _split_bufs.get(key)
+        if st is None or st["buf"].numel() < need or st["seq"] + n_xchg >= 2 ** 31:
+            # tiles of {value, sequence number} granules: zeroed ONCE (and when the counter would wrap) -- the numbers keep increasing
+            # from launch to launch, so a granule left by an earlier launch never matches
+            st = _split_bufs[key] = {"buf": torch.zeros(need, dtype=torch.float32, device=x_in.device), "seq": 0,
+                                     "err": _split_err(x_in.device)}
+        xbuf, xerr, xseq0 = st["buf"], st["err"], st["seq"]
+        st["seq"] += n_xchg
     t = t_per_wg or traj_per_wg(prog, batch)
     prof = R._prof["buf"]
     # Two trajectories per workgroup fill the 256 CUs in rounds of 512 trajectories; a remainder of up to 256 is cheaper one
@@ -327,7 +349,9 @@ def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps
             ws_floats=ws_floats, compact=int(prog.compact), prof=R._ptr(prof), emb_per_traj=int(emb_per_traj),
             n_pass=2 if emb_u is not None else 1, emb_u=R._ptr(emb_u), cfg_w=float(cfg_w), edm_plan=int(edm),
             logp_out=R._ptr(logp_out), logp_first_op=prog.meta.get("cls_first", 0) if logp_out is not None else 0,
-            logp_head_op=prog.meta.get("head_op", 0) if logp_out is not None else 0, ctx=R._ptr(ctx), mlp=int(mlp))
+            logp_head_op=prog.meta.get("head_op", 0) if logp_out is not None else 0, ctx=R._ptr(ctx), mlp=int(mlp),
+            split_k=int(split), xchg_floats=prog.meta.get("xchg_floats", 0) if split else 0, xbuf=R._ptr(xbuf), xflags=None,
+            xerr=R._ptr(xerr), xseq0=int(xseq0))
         R._check(_lib().cdx_unet2_run(ctypes.byref(L), R._stream_ptr(x_in.device)), "cdx_unet2_run")
     if timing["on"]:
         end.record(torch.cuda.current_stream(x_in.device))
@@ -336,6 +360,62 @@ def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps
 
 N_CUS = 256          # MI355X
 _ws = {}
+_split_bufs = {}     # (device, stream) -> {exchange tiles, sequence numbers handed out so far, error word} of the split programs
+
+
+_split_errs = {}     # device -> one int32 in PINNED HOST memory: a member that loses a granule writes 1 there (over PCIe, on failure only)
+
+
+def _split_err(device) -> torch.Tensor:
+    t = _split_errs.get(device)
+    if t is None:
+        word = torch.zeros(1, dtype=torch.int32).pin_memory()
+        t = _split_errs[device] = (word, word.numpy())             # (the numpy view: reading it dispatches no ATen op)
+    return t[0]
+
+
+def check_split_errors(device=None, wait: bool = True):
+    """Raise if a split launch lost a granule (its polls are bounded: the launch ends, the numbers are wrong).  The error word lives in
+    pinned host memory the kernel writes directly, so looking at it costs nothing: the next split launch on the device does
+    (`wait=False`); `wait=True` (tests, explicit calls) synchronises the device first."""
+    for dev, (_, word) in list(_split_errs.items()):
+        if device is not None and dev != device:
+            continue
+        if wait:
+            torch.cuda.synchronize(dev)
+        if int(word[0]) != 0:
+            word[0] = 0
+            raise RuntimeError("cdx_unet2_run (split program): a member never received a granule; the results of that launch are invalid")
+
+
+def split_factor(batch: int) -> int:
+    """Workgroups per trajectory of an unconditional U-Net loop: 4 up to 64 trajectories, 2 up to 128 (every workgroup of the launch
+    must be resident: ceil(B / 8) * 8 * k <= 256), else 1.  CDX_UNET2_SPLIT=0 switches the mode off, 2 / 4 force a factor (tests)."""
+    forced = os.environ.get("CDX_UNET2_SPLIT", "auto")
+    if forced == "0" or (forced == "auto" and (os.environ.get("CDX_UNET2_T") or os.environ.get("CDX_UNET2_NW"))):
+        return 1                                      # (a forced workgroup shape means the ordinary program)
+    for k in (4, 2):
+        if forced in ("auto", str(k)) and -(-batch // 8) * 8 * k <= N_CUS:
+            return k
+    return 1
+
+
+_scache = weakref.WeakKeyDictionary()
+
+
+def compiled_split2(module, horizon: int, k: int) -> _Compiled2:
+    per = _scache.setdefault(module, {})
+    sig = R._signature(module)
+    hit = per.get((horizon, k))
+    if hit is not None and hit.sig == sig:
+        return hit
+    with torch.no_grad():
+        try:
+            comp = _Compiled2(P2.compile_janner2_split(module, horizon, k), sig)
+        except ValueError as e:
+            comp = _Compiled2(None, sig, str(e))
+    per[(horizon, k)] = comp
+    return comp
 
 
 _emb_bufs = {}
@@ -436,6 +516,13 @@ def fused_sample2(solver, net, plan, xt, prior, feed, fix_mask, x_min, x_max, x_
         return None
     dev = xt.device
     comp, parts = plan_for(net, h, b)
+    split = 0
+    if not chi and not use_cond and not edm and not comp.prog.compact and R._prof["buf"] is None:
+        k = split_factor(b)                           # small batches: one trajectory over k workgroups of an XCD
+        if k > 1:
+            alt = compiled_split2(net, h, k)
+            if alt.prog is not None:
+                comp, parts, split = alt, None, k
     if chi:
         cond = torch.flatten(cond, 1)
         if cond.shape != (b, comp.prog.meta["cond_dim"]):
@@ -461,7 +548,7 @@ def fused_sample2(solver, net, plan, xt, prior, feed, fix_mask, x_min, x_max, x_
         launch(comp, batch=b, x_in=xin, x_out=out, emb=emb, steps_dev=steps_dev, n_steps=len(plan.steps),
                predict_noise=R._predicts_noise(plan, solver), prior=R._f32c(prior, dev) if fix_mask is not None else None,
                fix_mask=fix_mask, noise=noise, x_min=x_min, x_max=x_max, parts=parts, x_scale=x_scale,
-               emb_per_traj=use_cond, emb_u=emb_u, cfg_w=w_cfg, edm=edm)
+               emb_per_traj=use_cond, emb_u=emb_u, cfg_w=w_cfg, edm=edm, split=split, t_per_wg=1 if split else None)
     return out
 
 

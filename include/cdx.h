@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define CDX_ABI_VERSION 9
+#define CDX_ABI_VERSION 10
 
 #define CDX_OK 0
 #define CDX_EINVAL (-1)   /* bad argument (null pointer, size out of range, misaligned offset) */
@@ -175,6 +175,20 @@ typedef struct cdx_unet2_launch {
      * what the reference substitutes for a missing condition); the second forward of a classifier-free-guidance pair sees zeros. */
     const float* ctx;
     int32_t mlp;
+    /* Split programs (engine/program2.py:compile_janner2_split; small batches): split_k = 2 or 4 workgroups per trajectory, all on one
+     * XCD (the grid is ceil(traj_count / 8) * 8 * split_k workgroups, which must all be resident: <= 256); `ops` holds the members'
+     * descriptors back to back (member m's op i = descriptor m * n_ops + i).  After an op that is cut over the members they all-gather its
+     * output through `xbuf`: per group of the launch (ceil(traj_count / 8) * 8 of them) two tiles of 2 * xchg_floats floats -- 8-byte
+     * {value, tag} granules, tag = the exchange's sequence number, polled until they match.  Sequence numbers start at `xseq0` + 1:
+     * the caller keeps them increasing from launch to launch on the same `xbuf` (a granule left by an earlier launch then never
+     * matches; zero the buffer when the 32-bit counter would wrap), so nothing has to be cleared per launch.  `xflags`: reserved.
+     * `xerr`: one int32 (device memory or pinned host memory), set to 1 if a granule never arrived (the polls are bounded; the results
+     * are then invalid).  0 / NULL: an ordinary launch. */
+    int32_t split_k, xchg_floats;
+    float* xbuf;
+    uint32_t* xflags;
+    int32_t* xerr;
+    uint32_t xseq0;
 } cdx_unet2_launch;
 int cdx_unet2_run(const cdx_unet2_launch* launch, void* hip_stream);
 
