@@ -26,8 +26,16 @@ def _extra(name):
 @pytest.fixture(scope="module", autouse=True)
 def _native_loaded():
     assert torch.cuda.is_available(), "gpu tests need a ROCm device"
-    from cleandiffuser_amd.engine import runtime
+    from cleandiffuser_amd.engine import runtime, runtime2
     runtime.load_library()          # hard failure if libcdx.so is missing -- never a silent eager fallback
+    # the small-batch mode checks itself against the ordinary program on its first use per device (two launches instead of one):
+    # get that over with before the tests that count launches
+    name = "janner_cfg2_ddim"
+    agent, _ = cases.build(cases.lib_namespace("amd"), name, device=DEV)
+    inp = cases.make_inputs(name)
+    agent.sample(torch.from_numpy(inp["prior"]).to(DEV), **cases.sample_kwargs(name, inp, device=DEV))
+    torch.cuda.synchronize()
+    assert runtime2._split_ok.get(torch.device(DEV)) is True, "small-batch mode failed its self-check on this device"
 
 
 def _spy_launches(monkeypatch):
