@@ -225,6 +225,10 @@ def other_configs(device):
             out.append({"name": tag, "error": f"{type(e).__name__}: {e}"})
 
     big("config2_B3200", bc.cfg2big, "cdx_unet2_kernel<3, 8> (three trajectories, 8 wave64 per workgroup; the last 128 one per workgroup)", B=3200)
+    # what one rank of an 8- / 2-GPU run of the metric's batch gets (and the real-time-control case): the small-batch mode
+    big("config2_B32", bc.cfg2big, "cdx_unet2_kernel<1, 8, ..., split>: one trajectory over 4 workgroups of an XCD, all-gather of the cut "
+        "ops through L2 (latency is the figure of merit: ms_per_call)", reps=10, B=32)
+    big("config2_B128", bc.cfg2big, "cdx_unet2_kernel<1, 8, ..., split>: one trajectory over 2 workgroups of an XCD", reps=10, B=128)
     big("config2_guided_B256", bc.cfg2g, "cdx_unet2_kernel<1, 8, true>: denoiser forward + classifier forward/backward + shifted solver step, "
         "one launch per guided sample() call", B=256)
     big("config2_guided_B3200", bc.cfg2g, "cdx_unet2_kernel<3, 8, true>: three trajectories per workgroup (compact guided program, saved "
