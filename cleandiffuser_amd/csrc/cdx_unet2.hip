@@ -814,6 +814,7 @@ struct XState {
     unsigned* flags;           // (unused by the granule protocol; kept for the launch ABI)
     int xf;
     int* err;
+    bool dead;                 // this thread lost a granule: no more waiting in this launch
 };
 
 template <int THREADS>
@@ -847,7 +848,9 @@ __device__ __forceinline__ void split_exchange(XState& X, int xg, float* __restr
                 if (__float_as_uint(a[1]) == X.seq && __float_as_uint(a[3]) == X.seq && __float_as_uint(b[1]) == X.seq &&
                     __float_as_uint(b[3]) == X.seq)
                     break;
-                if (++spins > 2000000) { *X.err = 1; break; }
+                // (a legitimate wait is tens of microseconds; ~10 ms of polling means the partner is not behind this L2.  Once a thread
+                //  has given up it stops waiting altogether: the launch must end, its numbers are void anyway)
+                if (X.dead || ++spins > 200000) { *X.err = 1; X.dead = true; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
             float* o = tl + dst + (pos + CDX2_HALO2) * dstride + c;
@@ -1037,7 +1040,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
     const int H = L.horizon, D = L.dim, HD = H * D, tf = L.traj_floats;
     // split programs: 8 k consecutive workgroups hold 8 trajectories x k members; the members of a trajectory are 8 workgroups apart,
     // i.e. on the same XCD (workgroup i runs on XCD i % 8)
-    XState X{0, 1, 0u, nullptr, nullptr, 0, nullptr};
+    XState X{0, 1, 0u, nullptr, nullptr, 0, nullptr, false};
     int grp_idx = 0;
     if (SPLIT) {
         const KArg* S0 = kernarg();
