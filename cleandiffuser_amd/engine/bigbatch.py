@@ -633,7 +633,7 @@ def is_chiunet_gemm(module, batch: int, horizon: Optional[int] = None, edm: bool
             # nets that fit only as a compact one-trajectory program (antmaze Diffuser, H = 128 plans; measured at the antmaze size: 10.9 k
             # vs 6.0 k trajectories/s at B = 256, 13.3 k vs 11.5 k at B = 3200).  Stand-alone forwards (`forward`: per-sample timesteps)
             # and EDM plans keep the crossover rule below
-            if batch >= runtime2.min_batch() and runtime2.supported(module, horizon) is None:
+            if runtime2.supported(module, horizon) is None:
                 return False
         big = batch >= JANNER_GEMM_MIN_BATCH
     elif type(module) is ChiUNet1d and not module.obs_as_global_cond:

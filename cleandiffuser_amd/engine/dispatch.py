@@ -76,7 +76,7 @@ def try_fused_raw(solver, model, plan, z, temperature, prior, feed):
     if not runtime._is_janner(net) or runtime.plan_is_edm(plan):
         return None
     from . import runtime2
-    if z.shape[0] < runtime2.min_batch() or runtime2.supported(net, z.shape[1]) is not None:
+    if runtime2.supported(net, z.shape[1]) is not None:
         return None
     if bigbatch.is_chiunet_gemm(net, z.shape[0], z.shape[1], False):
         return None

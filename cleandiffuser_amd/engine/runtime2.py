@@ -1,11 +1,13 @@
-"""Binding + launch helpers of the second-generation fused U-Net kernel (``cdx_unet2_run`` / ``cdx_unet2_embtab``,
-include/cdx.h, csrc/cdx_unet2.hip).  Same contract as runtime.py: PyTorch owns device memory and the stream, tensors cross the
-boundary as raw pointers, no CPU / eager fallback -- a backbone the v2 compiler does not take simply stays on the first
-program kernel (runtime.py), which is equally native.
+"""Binding + launch helpers of the fused program kernel (``cdx_unet2_run`` / ``cdx_unet2_embtab``, include/cdx.h,
+csrc/cdx_unet2.hip).  Same contract as runtime.py: PyTorch owns device memory and the stream, tensors cross the boundary as raw
+pointers, no CPU / eager fallback -- a backbone the program compiler (program2.py) does not take is served by the GEMM
+executors (bigbatch.py) or, failing that, is reported unsupported; nothing here computes in Python.
 
 What the host keeps per (weights version, plan): the compiled program (ops, item tables, packed blob) and the FiLM table of the
 plan's step records -- ``map_noise(t)`` -> ``cdx_unet2_embtab`` -- so a steady-state ``sample()`` call is ONE kernel launch and
-no ATen launch (the timestep-embedding glue used to run ~17 elementwise launches per call).
+no ATen launch.  The same launch record serves the U-Nets (Janner, Chi at small batch), the classifier's log-p pass, the
+batch-tiled MLP programs and the small-batch mode that spreads one trajectory over several workgroups of one XCD
+(DESIGN.md section 6).
 """
 import ctypes
 import os
@@ -174,12 +176,6 @@ def plan_film_table(comp: _Compiled2, module, plan, device, modules=None, zero_r
             t_vec = torch.cat([t_vec, t_vec.new_zeros(1)])
         hit = memo[key] = (comp.sig, film_table(comp, module, t_vec, modules))
     return hit[1]
-
-
-def min_batch() -> int:
-    """Smallest batch the v2 kernel takes (it is ahead of the first program kernel at every batch size measured on MI355X,
-    profiles/r02_*: 5.6 vs 6.3 ms at B = 256, 7.1 vs 12.5 ms at B = 512); CDX_UNET2_MIN_BATCH is an A/B hook."""
-    return int(os.environ.get("CDX_UNET2_MIN_BATCH", "1"))
 
 
 def traj_per_wg(prog: P2.Program2, batch: int) -> int:
@@ -505,7 +501,7 @@ def fused_sample2(solver, net, plan, xt, prior, feed, fix_mask, x_min, x_max, x_
     b, h, d = xt.shape
     if b == 0:
         return torch.empty_like(R._f32c(xt, xt.device))      # empty request: nothing to launch
-    if b < min_batch() or supported(net, h) is not None:
+    if supported(net, h) is not None:
         return None
     edm = R.plan_is_edm(plan)
     use_cond = cond is not None and w_cfg != 0.0

@@ -409,7 +409,6 @@ def test_unet2_kernel_matches_reference_fixture(name, t_per_wg, n_waves, amd_lib
     kw = cases.sample_kwargs(name, inp, device=DEV)
     monkeypatch.setenv("CDX_UNET2_T", t_per_wg)
     monkeypatch.setenv("CDX_UNET2_NW", n_waves)
-    monkeypatch.setenv("CDX_UNET2_MIN_BATCH", "1")
     calls = _spy_launches(monkeypatch)
     seen, orig = [], runtime2.fused_sample2
 
@@ -439,7 +438,6 @@ def test_program_kernel_is_batch_invariant_across_workgroup_shapes(amd_lib, monk
     zs = [torch.randn(B, 32, 23, generator=g) for _ in range(11)]
     kw = dict(solver="ddpm", n_samples=B, sample_steps=10)
     outs = {}
-    monkeypatch.setenv("CDX_UNET2_MIN_BATCH", "1")
     for tag, env in (("t1", {"CDX_UNET2_T": "1", "CDX_UNET2_NW": "4"}), ("t2", {"CDX_UNET2_T": "2"}),
                      ("t1w8", {"CDX_UNET2_T": "1", "CDX_UNET2_NW": "8"}), ("t2w8", {"CDX_UNET2_T": "2"})):
         for k, v in env.items():
