@@ -439,7 +439,7 @@ class _Builder2:
         if norm is not None:
             # the epilogue cuts pad32(C_out) channels into 8 lane groups; a real group must be exactly one of them (C_out = 16 with
             # 4 groups of 4 is fine: lane groups 4..7 then work on pad channels that are never stored)
-            if c_out % norm.num_groups or c_out // norm.num_groups != cg or abs(norm.eps - GN_EPS) > 1e-12:
+            if norm.num_groups < 1 or c_out % norm.num_groups or c_out // norm.num_groups != cg or abs(norm.eps - GN_EPS) > 1e-12:
                 raise ValueError(f"v2 epilogue needs GroupNorm groups of pad32(C)/8 channels (C={c_out}, G={norm.num_groups})")
             flags |= F2_GN if bwd is None else F2_GNBWD
             if col_norm:
@@ -700,6 +700,9 @@ def _lower_janner(b: "_Builder2", net, horizon: int, x: Act):
     if cur.length != horizon:
         raise ValueError("up path does not return to the input horizon")
     fc = net.final_conv
+    if cur.chans != fc[0].in_channels:
+        # dim_mult[0] != 1: the reference's own forward fails on this net (jannerunet.py:139-144 builds final_conv on model_dim)
+        raise ValueError(f"final conv expects {fc[0].in_channels} channels, the up path ends with {cur.chans}")
     t = b.act(horizon, md)
     b.conv([cur], t, _conv1d_eff(fc[0]), fc[0].bias, pad=2, gn=fc[1])
     return t, fc, blocks
