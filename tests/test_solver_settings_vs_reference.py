@@ -116,3 +116,43 @@ def test_random_solver_settings_three_ways(seed, amd_lib, monkeypatch):
             assert float(np.abs(x.numpy() - want).max()) < 1e-4 * scale, c
         finally:
             del cases.CASES[name]
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_classifier_guided_settings_match_the_reference(seed, amd_lib):
+    """Classifier guidance (w_cg, CumRewClassifier over a HalfJannerUNet1d) under random solver settings: samples, draws consumed and the
+    final log_p of the reference and of this package's host loop (reference diffusionsde.py:526-601)."""
+    ref = cases.lib_namespace("reference")
+    rng = random.Random(8000 + seed)
+    for i in range(5):
+        name = f"_random_cg_{seed}_{i}"
+        c = _draw(rng)
+        while c["solver"][0] == "ContinuousEDM" or c["net"][0] != "JannerUNet1d" or "cond_dim" in c:
+            c = _draw(rng)
+        c["classifier"] = dict(kernel_size=rng.choice([3, 5]))
+        c["sample"]["w_cg"] = rng.choice([0.0, 0.01, 0.1, 1.0, 3.0])
+        cases.CASES[name] = c
+        try:
+            outs = []
+            for lib in (ref, amd_lib):
+                torch.manual_seed(1234)
+                agent, _ = cases.build(lib, name)
+                inp = cases.make_inputs(name)
+                used = [0]
+
+                def counting(noise):
+                    for z in noise:
+                        used[0] += 1
+                        yield z
+                with cases.replay_randn(counting(inp["noise"])):
+                    x, log = agent.sample(torch.from_numpy(inp["prior"]), **cases.sample_kwargs(name, inp))
+                outs.append((x.detach().numpy(), used[0], log["log_p"].detach().numpy()))
+            (want, n_ref, lp_ref), (got, n_amd, lp_amd) = outs
+            assert n_ref == n_amd, c
+            if not np.isfinite(want).all():
+                assert (np.isfinite(got) == np.isfinite(want)).all(), c
+                continue
+            assert float(np.abs(got - want).max()) < 5e-5 * max(1.0, float(np.abs(want).max())), c
+            assert float(np.abs(lp_amd - lp_ref).max()) < 1e-4 * max(1.0, float(np.abs(lp_ref).max())), c
+        finally:
+            del cases.CASES[name]
