@@ -116,6 +116,21 @@ def test_unet2_validation_fails_loudly(lib):
     assert lib.cdx_unet2_run(ctypes.byref(L), None) == -1 and b"n_waves" in lib.cdx_last_error()
     L.n_waves = 8
     assert lib.cdx_unet2_run(ctypes.byref(L), None) == -2 and b"160 KiB" in lib.cdx_last_error()
+    # the launch modes added in round 3 refuse what they cannot run before anything is launched
+    M = runtime2.CdxUnet2Launch(ops=8, wblob=8, x_in=8, x_out=8, emb=8, n_ops=1, batch=4, horizon=4, dim=4, traj_floats=64,
+                                traj_per_wg=1, n_waves=8)
+    M.split_k = 3
+    assert lib.cdx_unet2_run(ctypes.byref(M), None) == -1 and b"split program" in lib.cdx_last_error()
+    M.split_k, M.xbuf, M.xerr, M.xchg_floats = 4, 8, 8, 6                                           # granules are float4 pairs
+    assert lib.cdx_unet2_run(ctypes.byref(M), None) == -1 and b"split program" in lib.cdx_last_error()
+    M.xchg_floats, M.batch = 1024, 72                                                               # 72 trajectories x 4 members > 256 workgroups
+    assert lib.cdx_unet2_run(ctypes.byref(M), None) == -1 and b"resident" in lib.cdx_last_error()
+    M.batch, M.emb_per_traj = 4, 1                                                                  # conditional programs are not split
+    assert lib.cdx_unet2_run(ctypes.byref(M), None) == -1 and b"unconditional" in lib.cdx_last_error()
+    M.split_k, M.emb_per_traj, M.mlp, M.traj_per_wg = 0, 0, 1, 2
+    assert lib.cdx_unet2_run(ctypes.byref(M), None) == -1 and b"MLP program" in lib.cdx_last_error()
+    M.mlp, M.traj_per_wg, M.logp_out = 0, 1, 8                                                      # log_p needs a program with a classifier head
+    assert lib.cdx_unet2_run(ctypes.byref(M), None) == -1 and b"logp_out" in lib.cdx_last_error()
     L.batch = 0
     assert lib.cdx_unet2_run(ctypes.byref(L), None) == 0                                            # empty request: nothing to do
     assert lib.cdx_unet2_embtab(ctypes.byref(runtime2.CdxUnet2EmbtabArgs()), None) == -1
