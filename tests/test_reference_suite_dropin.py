@@ -20,3 +20,23 @@ def test_reference_hot_path_tests_pass_against_this_package(tmp_path):
     assert " passed" in r.stdout and "failed" not in r.stdout, tail
     n = int(r.stdout.rsplit(" passed", 1)[0].split()[-1])
     assert n >= 51, tail
+
+
+def test_alias_installer_resolves_reference_import_paths(tmp_path):
+    """INTEGRATION.md's one-line switch: after ``install_as_cleandiffuser()`` the reference's import paths (package, sub-packages and the
+    per-file modules pipelines import from) resolve to this package.  In a subprocess: the alias must not leak into this test session."""
+    code = ("import cleandiffuser_amd; cleandiffuser_amd.install_as_cleandiffuser()\n"
+            "from cleandiffuser.diffusion import DiscreteDiffusionSDE, ContinuousDiffusionSDE\n"
+            "from cleandiffuser.diffusion.diffusionsde import DiscreteDiffusionSDE as D2\n"
+            "from cleandiffuser.nn_diffusion import JannerUNet1d, DiT1d, ChiUNet1d\n"
+            "import cleandiffuser.nn_diffusion.jannerunet as j\n"
+            "from cleandiffuser.nn_condition import IdentityCondition\n"
+            "from cleandiffuser.classifier import CumRewClassifier\n"
+            "from cleandiffuser.nn_classifier import HalfJannerUNet1d\n"
+            "from cleandiffuser.utils import at_least_ndim\n"
+            "assert D2 is DiscreteDiffusionSDE and j.__name__ == 'cleandiffuser_amd.nn_diffusion.jannerunet'\n"
+            "print(DiscreteDiffusionSDE.__module__)\n")
+    env = dict(os.environ, PYTHONPATH=ROOT, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+    r = subprocess.run([sys.executable, "-c", code], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.strip() == "cleandiffuser_amd.diffusion.diffusionsde"
