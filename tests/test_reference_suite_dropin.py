@@ -76,3 +76,48 @@ print("\n".join(sorted(gaps)))
     gaps = [g for g in r.stdout.split() if g]
     out_of_scope = ("cleandiffuser.dataset.", "cleandiffuser.env", "cleandiffuser.nn_condition:MultiImageObsCondition")
     assert all(g.startswith(out_of_scope) for g in gaps), [g for g in gaps if not g.startswith(out_of_scope)]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/cleandiffuser"), reason="reference tree not present on this box")
+def test_overlay_alias_keeps_the_reference_for_everything_outside_the_hot_path(tmp_path):
+    """``install_as_cleandiffuser(overlay=True)`` next to an installed reference: datasets / utils stay the reference's, the diffusion
+    model, backbones, conditions and classifiers come from this package, the image encoders this package does not mirror remain
+    importable -- and a reference-built condition module drives this package's solver to the reference's own samples."""
+    code = r'''
+import sys, numpy as np, torch
+from oracle.ref_import import import_reference        # (registers the torchvision stand-ins this container needs)
+import_reference()
+from cleandiffuser.diffusion import DiscreteDiffusionSDE as RefSDE
+from cleandiffuser.nn_condition import IdentityCondition as RefCond
+import cleandiffuser_amd
+cleandiffuser_amd.install_as_cleandiffuser(overlay=True)
+import cleandiffuser
+from cleandiffuser.diffusion import DiscreteDiffusionSDE
+from cleandiffuser.diffusion.diffusionsde import ContinuousDiffusionSDE
+from cleandiffuser.nn_diffusion import JannerUNet1d
+from cleandiffuser.nn_condition import MultiImageObsCondition, IdentityCondition
+from cleandiffuser.classifier import CumRewClassifier
+from cleandiffuser.utils import report_parameters
+from cleandiffuser.dataset.base_dataset import BaseDataset
+assert DiscreteDiffusionSDE.__module__ == "cleandiffuser_amd.diffusion.diffusionsde" and DiscreteDiffusionSDE is not RefSDE
+assert cleandiffuser.diffusion.__name__ == "cleandiffuser_amd.diffusion" and JannerUNet1d.__module__.startswith("cleandiffuser_amd.")
+assert CumRewClassifier.__module__.startswith("cleandiffuser_amd.") and IdentityCondition is not RefCond
+assert MultiImageObsCondition.__module__ == "cleandiffuser.nn_condition.multi_image_condition"
+assert report_parameters.__module__ == "cleandiffuser.utils.utils" and BaseDataset.__module__ == "cleandiffuser.dataset.base_dataset"
+# a condition module built by the REFERENCE inside this package's solver: same samples as the all-reference agent
+from cleandiffuser_amd.utils import load_synth
+torch.manual_seed(0)
+outs = []
+for sde, cond_cls in ((RefSDE, RefCond), (DiscreteDiffusionSDE, RefCond)):
+    net = load_synth(JannerUNet1d(6, model_dim=16, emb_dim=16, dim_mult=[1, 2], kernel_size=3), 3)
+    agent = sde(net, cond_cls(dropout=0.0), diffusion_steps=10, predict_noise=True, device="cpu")
+    agent.eval()
+    torch.manual_seed(7)
+    x, _ = agent.sample(torch.zeros(3, 8, 6), solver="ddim", n_samples=3, sample_steps=5, condition_cfg=torch.ones(3, 16), w_cfg=1.5)
+    outs.append(x.numpy())
+assert np.abs(outs[0] - outs[1]).max() < 1e-5
+print("overlay ok")
+'''
+    env = dict(os.environ, PYTHONPATH=ROOT, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="", PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, "-c", code], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "overlay ok" in r.stdout, r.stderr[-3000:]
