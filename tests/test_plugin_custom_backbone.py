@@ -1,0 +1,115 @@
+"""The plug-in surface: a user-defined ``BaseNNDiffusion`` / ``BaseNNCondition`` subclass -- the Mixer-style
+backbone of the reference's tutorial 4 (tutorials/4_customize_your_diffusion_network_backbone.py:19-118) restated -- dropped into the
+solver classes.  The engine has no program for it, so the request must run the host loop on the module itself (CPU here, the device's
+ATen ops on a GPU) and must not be routed into a fused executor by mistake; sample(), loss() and update() must agree with the imported
+reference (build container) under the same weights, draws and seeds."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import cases, ref_import
+
+
+def _define(lib_nn_diffusion, lib_nn_condition):
+    class Block(nn.Module):
+        def __init__(self, seq_len, hidden):
+            super().__init__()
+            self.norm1 = nn.LayerNorm(hidden, elementwise_affine=False, eps=1e-6)
+            self.norm2 = nn.LayerNorm(hidden, elementwise_affine=False, eps=1e-6)
+            self.tok = nn.Sequential(nn.Conv1d(seq_len, 2 * seq_len, 1), nn.GELU("tanh"), nn.Conv1d(2 * seq_len, seq_len, 1))
+            self.ch = nn.Sequential(nn.Linear(hidden, 2 * hidden), nn.GELU("tanh"), nn.Linear(2 * hidden, hidden))
+            self.ada = nn.Sequential(nn.SiLU(), nn.Linear(hidden, 6 * hidden))
+
+        def forward(self, x, emb):
+            s1, c1, g1, s2, c2, g2 = self.ada(emb).chunk(6, dim=1)
+            x = x + g1.unsqueeze(1) * self.tok(self.norm1(x) * (1 + c1.unsqueeze(1)) + s1.unsqueeze(1))
+            return x + g2.unsqueeze(1) * self.ch(self.norm2(x) * (1 + c2.unsqueeze(1)) + s2.unsqueeze(1))
+
+    class Mixer(lib_nn_diffusion.BaseNNDiffusion):
+        def __init__(self, act_dim, Ta=6, hidden=32, depth=2, timestep_emb_type="positional"):
+            super().__init__(hidden, timestep_emb_type)
+            self.inp, self.out = nn.Linear(act_dim, hidden), nn.Linear(hidden, act_dim)
+            self.map_emb = nn.Sequential(nn.Linear(hidden, hidden), nn.Mish(), nn.Linear(hidden, hidden), nn.Mish())
+            self.blocks = nn.ModuleList([Block(Ta, hidden) for _ in range(depth)])
+
+        def forward(self, x, noise, condition=None):
+            emb = self.map_emb(self.map_noise(noise))
+            if condition is not None:
+                emb = emb + condition
+            h = self.inp(x)
+            for blk in self.blocks:
+                h = blk(h, emb)
+            return self.out(h)
+
+    class ObsCondition(lib_nn_condition.BaseNNCondition):
+        def __init__(self, obs_dim, hidden=32, dropout=0.25):
+            super().__init__()
+            self.dropout, self.net = dropout, nn.Sequential(nn.Linear(obs_dim, hidden), nn.SiLU(), nn.Linear(hidden, hidden))
+
+        def forward(self, condition, mask=None):
+            mask = (torch.rand(condition.shape[0], device=condition.device) > self.dropout).float() if mask is None else mask
+            return self.net(condition) * mask.unsqueeze(-1)
+
+    return Mixer, ObsCondition
+
+
+def _run(lib, kind):
+    import importlib
+    root = "cleandiffuser" if kind == "reference" else "cleandiffuser_amd"
+    Mixer, ObsCondition = _define(importlib.import_module(root + ".nn_diffusion"), importlib.import_module(root + ".nn_condition"))
+    from cleandiffuser_amd.utils import load_synth
+    net, cond = load_synth(Mixer(4), 11), load_synth(ObsCondition(9), 12)
+    agent = lib.ContinuousDiffusionSDE(net, cond, predict_noise=True, ema_rate=0.9, grad_clip_norm=1.0, device="cpu")
+    g = torch.Generator().manual_seed(5)
+    x0, obs = torch.randn(7, 6, 4, generator=g), torch.randn(7, 9, generator=g)
+    agent.train()
+    torch.manual_seed(21)
+    out = {"loss": float(agent.loss(x0, obs))}
+    out["upd"] = [float(agent.update(x0, obs)["loss"]) for _ in range(2)]
+    agent.eval()
+    noise = [torch.randn(5, 6, 4, generator=g).numpy() for _ in range(12)]
+    with cases.replay_randn(iter(noise)):
+        x, _ = agent.sample(torch.zeros(5, 6, 4), solver="sde_dpmsolver++_2M", n_samples=5, sample_steps=5, condition_cfg=obs[:5], w_cfg=1.3,
+                            temperature=0.8)
+    out["x"] = x.detach().numpy()
+    return out
+
+
+def test_custom_backbone_runs_the_host_loop_and_not_a_fused_executor(amd_lib, monkeypatch):
+    from cleandiffuser_amd.engine import bigbatch, runtime
+    got = _run(amd_lib, "amd")
+    assert np.isfinite(got["x"]).all() and got["x"].shape == (5, 6, 4)
+    Mixer, _ = _define(__import__("cleandiffuser_amd.nn_diffusion", fromlist=["x"]), __import__("cleandiffuser_amd.nn_condition", fromlist=["x"]))
+    net = Mixer(4)
+    assert runtime.supported_backbone(net, 6) is not None              # no program for it ...
+    assert not bigbatch.is_chiunet_gemm(net, 4096, 6, False)             # ... and no GEMM executor claims it
+
+
+@pytest.mark.skipif(not ref_import.available(), reason="reference tree not present on this box")
+def test_custom_backbone_matches_the_reference(amd_lib):
+    want = _run(cases.lib_namespace("reference"), "reference")
+    got = _run(amd_lib, "amd")
+    assert abs(got["loss"] - want["loss"]) < 1e-5 * max(1.0, abs(want["loss"]))
+    np.testing.assert_allclose(got["upd"], want["upd"], rtol=1e-4)
+    np.testing.assert_allclose(got["x"], want["x"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_custom_backbone_on_the_device_matches_the_cpu_loop(amd_lib):
+    """On a ROCm device the same request keeps working (host loop over the user's module, ATen ops on the device, the solver steps from
+    the shared plan) and lands on the CPU result of the same draws."""
+    import importlib
+    from cleandiffuser_amd.utils import load_synth
+    Mixer, ObsCondition = _define(importlib.import_module("cleandiffuser_amd.nn_diffusion"), importlib.import_module("cleandiffuser_amd.nn_condition"))
+    g = torch.Generator().manual_seed(5)
+    obs = torch.randn(5, 9, generator=g)
+    noise = [torch.randn(5, 6, 4, generator=g) for _ in range(12)]
+    outs = []
+    for dev in ("cpu", "cuda:0"):
+        agent = amd_lib.ContinuousDiffusionSDE(load_synth(Mixer(4), 11), load_synth(ObsCondition(9), 12), predict_noise=True, device=dev)
+        agent.eval()
+        x, _ = agent.sample(torch.zeros(5, 6, 4, device=dev), solver="sde_dpmsolver++_2M", n_samples=5, sample_steps=5,
+                            condition_cfg=obs.to(dev), w_cfg=1.3, temperature=0.8, noise=[z.to(dev) for z in noise])
+        outs.append(x.detach().cpu().numpy())
+    np.testing.assert_allclose(outs[1], outs[0], rtol=1e-4, atol=1e-4)
