@@ -220,7 +220,8 @@ def other_configs(device):
             dt, k_ms = timed(call, reps)
             out.append({"name": tag, "workload": label, "value": b / dt, "unit": "samples/s", "ms_per_call": 1e3 * dt,
                         "roofline_frac": flops / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, "dominant_kernel": kernel,
-                        "fused_kernel_ms": (sum(k_ms) / len(k_ms)) if k_ms else None})
+                        # program-kernel time per CALL (a call whose batch is cut into rounds is several launches)
+                        "fused_kernel_ms": (sum(k_ms) / reps) if k_ms else None, "launches_per_call": len(k_ms) / reps})
         except Exception as e:  # noqa: BLE001 -- one broken side measurement must not take the headline down
             out.append({"name": tag, "error": f"{type(e).__name__}: {e}"})
 
