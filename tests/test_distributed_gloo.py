@@ -77,3 +77,43 @@ def test_two_rank_shard_and_gather_equals_single_process(tmp_path):
     assert got["xc"].shape == xc1.shape and torch.allclose(got["xc"], xc1, rtol=1e-4, atol=1e-4), "per-sample kwargs must be sliced"
     assert [shard_bounds(5, r, 2) for r in range(2)] == [(0, 3), (3, 5)]
     assert [shard_bounds(0, r, 2) for r in range(2)] == [(0, 0), (0, 0)]
+
+
+def _worker_small(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cleandiffuser_amd.distributed import sharded_sample
+    from oracle import cases
+    lib = cases.lib_namespace("amd")
+    agent, _ = cases.build(lib, "janner_tiny_disc_ddpm")
+    outs = {n: sharded_sample(agent, torch.zeros(n, 8, 6), gather=True, seed=11, solver="ddpm", sample_steps=5, temperature=0.8) for n in (1, 4)}
+    scorer, _ = cases.build(lib, "janner_cfg2_diffuser_logp")
+    c = cases.CASES["janner_cfg2_diffuser_logp"]
+    xs, logp = sharded_sample(scorer, torch.zeros(2, c["horizon"], c["net"][1]["in_dim"]), gather=True, seed=3, return_logp=True,
+                              solver="ddim", sample_steps=3, temperature=0.5)
+    if rank == world - 1:                                     # the rank whose shard was EMPTY for n = 1 and n = 2 reports
+        torch.save({"outs": outs, "xs": xs, "logp": logp}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_three_ranks_with_empty_shards(tmp_path):
+    """Fewer rows than ranks (the tail of a strong-scaling run): ranks with an empty shard still take part in the one all-gather and
+    every rank ends with the global result."""
+    out = str(tmp_path / "y.pt")
+    mp.spawn(_worker_small, args=(3, _free_port(), out), nprocs=3, join=True)
+    got = torch.load(out)
+    sys.path.insert(0, ROOT)
+    from cleandiffuser_amd.distributed import sharded_sample, shard_bounds
+    from oracle import cases
+    assert [shard_bounds(1, r, 3) for r in range(3)] == [(0, 1), (1, 1), (1, 1)]
+    agent, _ = cases.build(cases.lib_namespace("amd"), "janner_tiny_disc_ddpm")
+    for n in (1, 4):
+        want = sharded_sample(agent, torch.zeros(n, 8, 6), gather=True, seed=11, solver="ddpm", sample_steps=5, temperature=0.8)
+        assert got["outs"][n].shape == (n, 8, 6) and torch.allclose(got["outs"][n], want, rtol=1e-4, atol=1e-4)
+    scorer, _ = cases.build(cases.lib_namespace("amd"), "janner_cfg2_diffuser_logp")
+    c = cases.CASES["janner_cfg2_diffuser_logp"]
+    xs1, logp1 = sharded_sample(scorer, torch.zeros(2, c["horizon"], c["net"][1]["in_dim"]), gather=True, seed=3, return_logp=True,
+                                solver="ddim", sample_steps=3, temperature=0.5)
+    assert got["logp"].shape == (2, 1) and torch.allclose(got["xs"], xs1, rtol=1e-4, atol=1e-4) and torch.allclose(got["logp"], logp1, rtol=1e-4, atol=1e-4)
