@@ -14,7 +14,9 @@
 // Measured state at the end of round 3 (profiles/r03_mlp_fused_probe.txt): results exact to 1.3e-6 of a float64 reference; 0.62-0.65 ms per
 // call = 53-55 % of peak, phase 2 at 57 % of its MFMA floor -- and the ISA of THAT build shows why: the W2 staging registers were a guarded
 // float4[3] that the compiler kept in scratch, every global load followed by s_waitcnt vmcnt(0) and a scratch store.  This file carries the
-// fix (named registers, unconditional clamped loads); it compiles to 0 scratch bytes and has NOT been timed yet.
+// fix (named registers, unconditional clamped loads); it compiles to 0 scratch bytes and has NOT been timed yet.  Two compile-time knobs prepare
+// the first measurements of the next round (tools/gpu_mlp_fused_probe.sh builds and runs all four): PROBE_BK2 (W2 slab of 8 or 16 k) and
+// PROBE_UPFRONT (LDS operands of a slab requested before its first MFMA).  Every build checks itself against the float64 reference.
 //
 //   hipcc --offload-arch=gfx950 -O3 -o tools/_bin/mlp_fused_probe tools/mlp_fused_probe.hip && tools/_bin/mlp_fused_probe
 // prints: max relative error against a float64 host reference on sampled rows, time per call, TFLOP/s and the fraction of the
@@ -28,7 +30,13 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int D = 320, HID = 1280, BM = 64, CH = 128, BK = 16, BK2 = 8, THREADS = 256;
+#ifndef PROBE_BK2
+#define PROBE_BK2 8          // K slab of phase 2: 8 (79.6 KB of LDS, two workgroups per CU) or 16 (100 KB, one workgroup per CU, half the barriers)
+#endif
+#ifndef PROBE_UPFRONT
+#define PROBE_UPFRONT 0      // 1: all LDS operands of a slab are requested before its first MFMA
+#endif
+constexpr int D = 320, HID = 1280, BM = 64, CH = 128, BK = 16, BK2 = PROBE_BK2, THREADS = 256;
 constexpr int LDX = BM + 4, LDW1 = CH + 4, LDH = BM + 1, LDW2 = D + 4;
 constexpr int SMEM_FLOATS = 2 * BK * LDX + 2 * BK * LDW1 + CH * LDH + 2 * BK2 * LDW2;
 
@@ -54,7 +62,9 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_fused_kernel(const float* __re
     // staging roles
     const int xr = tid & 63, xq = tid >> 6;              // X slab: row xr, k quad xq (k = 4 xq)
     const float* xp = X + (size_t)min(bm + xr, M - 1) * D + xq * 4;
-    float4 rx, rw0, rw1, r2a, r2b, r2c;
+    constexpr int N4_2 = BK2 * D / 4, R2 = (N4_2 + THREADS - 1) / THREADS;      // float4 of a W2 slab, rounds of 256 threads
+    float4 rx, rw0, rw1, r2a, r2b, r2c, r2d, r2e;      // (named registers: a float4[R2] captured by the staging lambdas stays in scratch)
+    static_assert(R2 == 3 || R2 == 5, "W2 slab of 8 or 16 k");
 
     unsigned long long t_p1 = 0, t_gelu = 0, t_p2 = 0;          // cycles per phase (workgroups 0 and 300 report)
     f32x16 acc2[5];
@@ -81,18 +91,21 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_fused_kernel(const float* __re
             *reinterpret_cast<float4*>(&Wd[8 + (tid >> 5)][(tid & 31) * 4]) = rw1;
         };
         // W2p slab (c, u): 8 k x 320 output columns = 640 contiguous float4, three rounds of 256 threads (the last one half empty)
-        auto fetch2 = [&](int u) {                       // (unconditional loads into named registers: a guarded float4 array ends up in
-            const float4* src = reinterpret_cast<const float4*>(W2 + ((size_t)c * (CH / BK2) + u) * (BK2 * D));   // scratch, every load waited for)
+        auto fetch2 = [&](int u) {                       // (unconditional clamped loads: guarded ones left the registers in scratch)
+            const float4* src = reinterpret_cast<const float4*>(W2 + ((size_t)c * (CH / BK2) + u) * (BK2 * D));
             r2a = src[tid];
             r2b = src[tid + THREADS];
-            r2c = src[min(tid + 2 * THREADS, 2 * D - 1)];
+            r2c = src[min(tid + 2 * THREADS, N4_2 - 1)];
+            if (R2 == 5) { r2d = src[min(tid + 3 * THREADS, N4_2 - 1)]; r2e = src[min(tid + 4 * THREADS, N4_2 - 1)]; }
         };
         auto stage2 = [&](int buf) {
             float (*Wd)[LDW2] = W2s + buf * BK2;
             constexpr int Q = D / 4;                     // float4 per k row
-            *reinterpret_cast<float4*>(&Wd[tid / Q][(tid % Q) * 4]) = r2a;
-            *reinterpret_cast<float4*>(&Wd[(tid + THREADS) / Q][((tid + THREADS) % Q) * 4]) = r2b;
-            if (tid + 2 * THREADS < 2 * D) *reinterpret_cast<float4*>(&Wd[(tid + 2 * THREADS) / Q][((tid + 2 * THREADS) % Q) * 4]) = r2c;
+            auto put = [&](int idx, const float4& v) { if (idx < N4_2) *reinterpret_cast<float4*>(&Wd[idx / Q][(idx % Q) * 4]) = v; };
+            put(tid, r2a);
+            put(tid + THREADS, r2b);
+            put(tid + 2 * THREADS, r2c);
+            if (R2 == 5) { put(tid + 3 * THREADS, r2d); put(tid + 4 * THREADS, r2e); }
         };
 
         // ---------------- phase 1: chunk = X[64 x 320] . W1[chunk]^T ----------------
@@ -111,6 +124,25 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_fused_kernel(const float* __re
         for (int t = 0; t < NK1; ++t) {
             const float (*Xc)[LDX] = Xs + (t & 1) * BK;
             const float (*Wc)[LDW1] = W1s + (t & 1) * BK;
+#if PROBE_UPFRONT
+            float av[BK / 2], bv0[BK / 2], bv1[BK / 2];
+#pragma unroll
+            for (int kp = 0; kp < BK / 2; ++kp) {
+                av[kp] = Xc[2 * kp + lk][rh * 32 + lr];
+                bv0[kp] = Wc[2 * kp + lk][chh * 64 + lr];
+                bv1[kp] = Wc[2 * kp + lk][chh * 64 + 32 + lr];
+            }
+#pragma unroll
+            for (int kp = 0; kp < BK / 2; ++kp) {
+                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kp], bv0[kp], acc1[0], 0, 0, 0);
+                acc1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kp], bv1[kp], acc1[1], 0, 0, 0);
+                if (kp == BK / 4 - 1 && t + 1 < NK1) {
+                    stage1((t + 1) & 1);
+                    if (t + 2 < NK1) fetch1(c, t + 2);
+                    else fetch2(0);
+                }
+            }
+#else
             float av = Xc[lk][rh * 32 + lr], bv0 = Wc[lk][chh * 64 + lr], bv1 = Wc[lk][chh * 64 + 32 + lr];
 #pragma unroll
             for (int kk = 0; kk < BK; kk += 2) {
@@ -125,6 +157,7 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_fused_kernel(const float* __re
                 }
                 av = na; bv0 = nb0; bv1 = nb1;
             }
+#endif
             __syncthreads();
         }
         const unsigned long long s1 = clock64();
@@ -150,6 +183,26 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_fused_kernel(const float* __re
         for (int u = 0; u < NK2; ++u) {
             const float (*Wc)[LDW2] = W2s + (u & 1) * BK2;
             const float (*Hc)[LDH] = Hs + u * BK2;
+#if PROBE_UPFRONT
+            float av[BK2 / 2], bv[BK2 / 2][5];
+#pragma unroll
+            for (int kp = 0; kp < BK2 / 2; ++kp) {
+                av[kp] = Hc[2 * kp + lk][rh * 32 + lr];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) bv[kp][j] = Wc[2 * kp + lk][chh * 160 + 32 * j + lr];
+            }
+#pragma unroll
+            for (int kp = 0; kp < BK2 / 2; ++kp) {
+#pragma unroll
+                for (int j = 0; j < 5; ++j) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kp], bv[kp][j], acc2[j], 0, 0, 0);
+                if (kp == BK2 / 4 - 1) {
+                    if (u + 1 < NK2) {
+                        stage2((u + 1) & 1);
+                        if (u + 2 < NK2) fetch2(u + 2);
+                    } else if (c + 1 < HID / CH) fetch1(c + 1, 0);
+                }
+            }
+#else
 #pragma unroll
             for (int kk = 0; kk < BK2; kk += 2) {
                 const float av = Hc[kk + lk][rh * 32 + lr];
@@ -165,6 +218,7 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_fused_kernel(const float* __re
                     } else if (c + 1 < HID / CH) fetch1(c + 1, 0);
                 }
             }
+#endif
             __syncthreads();
         }
         const unsigned long long s3 = clock64();
@@ -193,8 +247,8 @@ int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 32768;      // config 4 at its 512-shard: 512 x 64 tokens
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
-    printf("%s  CUs %d   M = %d rows, d = %d, hidden = %d   LDS per workgroup %.1f KB\n", prop.name, prop.multiProcessorCount, M, D, HID,
-           SMEM_FLOATS * 4 / 1024.0);
+    printf("%s  CUs %d   M = %d rows, d = %d, hidden = %d   LDS per workgroup %.1f KB   [W2 slab k = %d, operands up front = %d]\n", prop.name,
+           prop.multiProcessorCount, M, D, HID, SMEM_FLOATS * 4 / 1024.0, BK2, PROBE_UPFRONT);
     unsigned seed = 12345u;
     std::vector<float> hX((size_t)M * D), hW1((size_t)HID * D), hW2((size_t)D * HID), hb1(HID), hb2(D);
     for (auto& v : hX) v = frand(seed);
