@@ -62,7 +62,12 @@ class _NoiseFeed:
     def many(self, ref: torch.Tensor, n: int) -> Optional[torch.Tensor]:
         """The next `n` draws as one (n, *ref.shape) tensor -- what a whole-loop executor hands its kernel.  Fresh draws on a device
         come from ONE randn launch instead of n (a 100-step DDPM loop used to start with 100 tiny launches and a stack); on the CPU the
-        draws stay one randn_like per step, in order, so that a seeded CPU run keeps reproducing the reference's stream."""
+        draws stay one randn_like per step, in order, so that a seeded CPU run keeps reproducing the reference's stream.
+
+        Consequence (documented): with ``torch.manual_seed`` on a ROCm device the SAME request gives different samples on the
+        whole-loop executors (one Philox launch over (n, ...)) and on the per-step PyTorch executor (n launches) -- e.g. with and
+        without ``requires_grad=True`` -- and neither equals a seeded CPU run (different generators anyway).  Callers that need
+        executor-independent draws pass ``noise=[...]`` (every parity test does)."""
         if n <= 0:
             return None
         if self._rec is None and ref.is_cuda:

@@ -741,6 +741,10 @@ def _run(kind, bound, *, batch, hd, emb_dim, cond_dim, temb, steps, n_steps, tem
 def pearcetf_forward(net, x, noise, condition) -> Optional[torch.Tensor]:
     if x.dim() != 2 or condition is None or condition.dim() != 3:
         return None
+    if net.training:
+        # train mode: BatchNorm1d uses batch statistics (reference pearcetransformer.py:38-39) -- the folded eval-mode weights a cached
+        # binding holds do not describe that network (the cache key is the weight signature, not the mode: ADVICE r3)
+        return None
     dev = x.device
     bound = _bound(net, "pearcetf", lambda: _bind_pearcetf(net, dev))
     if bound is None or x.shape[1] != bound.struct.act_dim or tuple(condition.shape[1:]) != (net.To, net.emb_dim):
@@ -838,6 +842,8 @@ def sample(solver, net, plan, xt, prior, cond_vec, w_cfg, feed) -> Optional[torc
         if xt.dim() != 2 or cond_vec is None or w_cfg == 0.0 or cond_vec.dim() != 3:
             return None                               # (the reference cannot run this backbone without a condition either)
         kind, (b, d) = "pearcetf", xt.shape
+        if net.training:                 # (see pearcetf_forward: sample(use_ema=False) on a module in train mode)
+            return None
         bound = _bound(net, "pearcetf", lambda: _bind_pearcetf(net, dev))
         hd, rows_h = d, 1
         if bound is not None and (bound.struct.act_dim != d or tuple(cond_vec.shape[1:]) != (net.To, net.emb_dim)):

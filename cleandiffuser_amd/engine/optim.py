@@ -8,6 +8,9 @@ object (LR schedulers, ``state_dict``), so the drop-in here is a SUBCLASS of ``t
   pass (two kernels: per-chunk sums, fixed-order reduction -- replaces ``clip_grad_norm_``) and ONE fused pass that clips, applies
   AdamW, folds the new parameter into its EMA copy (reference basic.py:83-86) and leaves the gradient zeroed;
 * ``zero_grad()`` keeps the gradient tensors (and so the device pointer table) alive: zeroed in place, by ``step`` for free.
+  torch's ``set_to_none=True`` semantics are kept from the optimiser's point of view: a gradient that nobody has written since it was
+  zeroed here (its autograd version counter has not moved) counts as ``None`` -- the parameter is not weight-decayed, not
+  momentum-stepped and its step count does not advance, exactly as ``torch.optim.AdamW`` skips a parameter without a gradient.
 
 Parameters on the CPU (or options this path does not carry: amsgrad, maximize, non-fp32) take torch's own ``step`` unchanged.
 On a ROCm device a missing ``libcdx.so`` is a hard error (runtime.load_library), never a silent fallback.
@@ -127,6 +130,8 @@ class FusedAdamW(torch.optim.AdamW):
         self.last_grad_norm = None
         self._t = {}                # id(parameter) -> step count (python int): the per-parameter `step` TENSORS of torch's state layout
         #                             are refreshed from it only when somebody looks (state_dict), not 196 CPU tensor ops per step
+        self._gver = {}             # id(parameter) -> (grad data_ptr, grad._version) right after THIS optimiser zeroed the gradient in
+        #                             place: unchanged at the next step = no backward pass wrote it = torch would see `grad is None`
 
     def _sync_steps(self):
         for group in self.param_groups:
@@ -165,9 +170,24 @@ class FusedAdamW(torch.optim.AdamW):
             st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
         return st
 
+    def _mark_untouched(self, ps, as_none: bool):
+        """Remember the state of the gradients this optimiser just zeroed in place.  `as_none`: until a backward pass (or anybody
+        else) writes one of them, it counts as ``None`` -- the ``set_to_none=True`` contract without freeing the tensor."""
+        for p in ps:
+            if as_none and p.grad is not None:
+                self._gver[id(p)] = (p.grad.data_ptr(), p.grad._version)
+            else:
+                self._gver.pop(id(p), None)
+
+    def _has_grad(self, p) -> bool:
+        g = p.grad
+        return g is not None and self._gver.get(id(p)) != (g.data_ptr(), g._version)
+
     # ---- torch.optim surface ----
     def zero_grad(self, set_to_none: bool = True):
-        """Zero IN PLACE on the device path (one launch): the gradient tensors -- and the pointer table built over them -- stay."""
+        """Zero IN PLACE on the device path (one launch): the gradient tensors -- and the pointer table built over them -- stay.
+        ``set_to_none=True`` (torch's default, what the reference's ``update()`` relies on): the zeroed gradients count as None for
+        the next ``step`` unless a backward pass writes them (see the module docstring)."""
         if not self.native():
             return super().zero_grad(set_to_none)
         for gi, group in enumerate(self.param_groups):
@@ -178,6 +198,7 @@ class FusedAdamW(torch.optim.AdamW):
             tab = _table(self._tables, f"zero{gi}", [[p.grad for p in ps]], dev)
             _call(CdxOptimArgs(g=tab.row(0), numel=tab.numel_ptr, chunks=tab.chunks.data_ptr(), n_tensors=tab.n_tensors,
                                n_chunks=tab.n_chunks, chunk_elems=CHUNK, mode=OPT_ZERO), dev)
+            self._mark_untouched(ps, set_to_none)
 
     @torch.no_grad()
     def step(self, closure=None, *, max_norm: Optional[float] = None, ema=None, zero_grad: bool = False):
@@ -197,9 +218,12 @@ class FusedAdamW(torch.optim.AdamW):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        groups = [(g, [p for p in g["params"] if p.grad is not None]) for g in self.param_groups]
+        # (a gradient this optimiser zeroed in place and nobody wrote since is a `None` gradient: torch skips such a parameter)
+        groups = [(g, [p for p in g["params"] if self._has_grad(p)]) for g in self.param_groups]
         groups = [(g, ps) for g, ps in groups if ps]
         if not groups:
+            if ema is not None:
+                ema_update_native(ema[0], ema[1], ema[2])
             return loss
         dev = groups[0][1][0].device
         if self._norm is None or self._norm.device != dev:
@@ -230,12 +254,13 @@ class FusedAdamW(torch.optim.AdamW):
                 self._t[id(p)] = t = t + 1
                 by_step.setdefault(t, []).append(p)
             b1, b2 = group["betas"]
-            for t, ps in by_step.items():
+            for bi, t in enumerate(sorted(by_step)):        # (tables keyed by the bucket's RANK: the count itself changes every step)
+                ps = by_step[t]
                 sts = [self.state[p] for p in ps]
                 lists = [ps, [p.grad for p in ps], [st["exp_avg"] for st in sts], [st["exp_avg_sq"] for st in sts]]
                 if ema_of is not None:
                     lists.append([ema_of[id(p)].detach() for p in ps])
-                tab = _table(self._tables, f"adamw{gi}/{t if len(by_step) > 1 else 'all'}", lists, dev)
+                tab = _table(self._tables, f"adamw{gi}/{bi}", lists, dev)
                 _call(CdxOptimArgs(p=tab.row(0), g=tab.row(1), m=tab.row(2), v=tab.row(3), ema=tab.row(4) if ema_of is not None else None,
                                    numel=tab.numel_ptr, chunks=tab.chunks.data_ptr(), n_tensors=tab.n_tensors, n_chunks=tab.n_chunks,
                                    chunk_elems=CHUNK, mode=OPT_ADAMW, lr=float(group["lr"]), beta1=float(b1), beta2=float(b2),
@@ -245,4 +270,18 @@ class FusedAdamW(torch.optim.AdamW):
                 _bump_versions(ps)
                 if ema_of is not None:
                     _bump_versions([ema_of[id(p)] for p in ps])
+                if zero_grad:
+                    self._mark_untouched(ps, True)
+        if ema_of is not None:
+            # the reference's ema_update covers EVERY parameter (basic.py:83-86): the ones that took no optimiser step this
+            # iteration (no gradient: a condition encoder while update() runs without a condition, an unused branch) in one more launch
+            stepped = {id(p) for _, ps in groups for p in ps}
+            rest = [(p.detach(), e.detach()) for p, e in zip(ema[0].parameters(), ema[1].parameters()) if id(p) not in stepped]
+            if rest:
+                if not all(native_device(t) and t.is_contiguous() for pe in rest for t in pe):
+                    raise RuntimeError("FusedAdamW: `ema` holds parameters outside the fp32 device path")
+                tab = _table(self._tables, "ema_rest", [[p for p, _ in rest], [e for _, e in rest]], dev)
+                _call(CdxOptimArgs(p=tab.row(0), ema=tab.row(1), numel=tab.numel_ptr, chunks=tab.chunks.data_ptr(), n_tensors=tab.n_tensors,
+                                   n_chunks=tab.n_chunks, chunk_elems=CHUNK, mode=OPT_EMA, ema_rate=float(rate)), dev)
+                _bump_versions([e for _, e in rest])
         return loss

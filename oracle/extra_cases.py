@@ -231,7 +231,13 @@ SCENARIOS: Dict[str, Callable] = {
 # --------------------------------------------------------------------------------------------------------------------- #
 # BASELINE.json's five configurations at their EXACT (network size x solver x step count x guidance) combination, small batch
 # (construction and call: BASELINE.md section 2).  Round 2 pinned these nets only at reduced width or reduced step count.
-def baseline_config(which: str, batch: int):
+def baseline_config(which: str, batch: int, variant: str = ""):
+    """`variant` "tied" (config 4): the synthetic DiT1d behaves like a TRAINED noise predictor -- its output layer is tied to the
+    input projection (final_layer.linear.weight = 0.25 x_proj.weight^T, its bias x 0.1), so the predicted noise tracks x_t and the
+    un-clipped 10-step DPM-Solver++ result stays |x| <= 6.2 (plain synthetic weights: the first step divides by alpha(1) = 0.0066
+    and the result reaches |x| = 589, which leaves a relative comparison no resolving power -- VERDICT r3 weak #1).  Same network
+    size, solver, step count and guidance; held to an ABSOLUTE 1e-4.  `variant` "d27" (config 5): the real hopper transition width
+    2 * 11 + 3 + 2 = 27 instead of BASELINE.json's 15 (report both)."""
     def run(lib, kind, device):
         g = torch.Generator().manual_seed(1000 + len(which) + batch)
         B = batch
@@ -279,6 +285,11 @@ def baseline_config(which: str, batch: int):
                            condition_cfg=cond.to(device), w_cfg=1.0)
         elif which == "cfg4":       # DiT1d Decision Diffuser: d 320 / 10 heads / 64 tokens, CFG w = 2, 10-step DPM-Solver++ 2M
             net = load_synth(lib.DiT1d(29, emb_dim=128, d_model=320, n_heads=10, depth=2, timestep_emb_type="fourier"), 56)
+            if variant == "tied":
+                with torch.no_grad():
+                    sd = dict(net.named_parameters())
+                    sd["final_layer.linear.weight"].copy_(0.25 * sd["x_proj.weight"].t())
+                    sd["final_layer.linear.bias"].mul_(0.1)
             cond = load_synth(lib.MLPCondition(1, 128, [128], torch.nn.SiLU(), dropout=0.25), 57)
             fm = torch.zeros(64, 29)
             fm[0] = 1.0
@@ -291,11 +302,12 @@ def baseline_config(which: str, batch: int):
                            condition_cfg=(0.3 * torch.ones(B, 1) + 0.1 * torch.randn(B, 1, generator=g)).to(device), w_cfg=2.0,
                            temperature=0.5)
         else:                       # cfg5: SynthER ResidualMLP = IDQLMlp 1024 x 6, 128-step EDM Euler
-            net = load_synth(lib.IDQLMlp(0, 15, emb_dim=128, hidden_dim=1024, n_blocks=6), 58)
+            D = 27 if variant == "d27" else 15
+            net = load_synth(lib.IDQLMlp(0, D, emb_dim=128, hidden_dim=1024, n_blocks=6), 58)
             agent = lib.ContinuousEDM(net, None, device=device)
             agent.eval()
-            zs = [torch.randn(B, 15, generator=g)]
-            x, _ = _sample(agent, kind, torch.zeros(B, 15, device=device), zs, solver="euler", n_samples=B, sample_steps=128)
+            zs = [torch.randn(B, D, generator=g)]
+            x, _ = _sample(agent, kind, torch.zeros(B, D, device=device), zs, solver="euler", n_samples=B, sample_steps=128)
         return {"x": x}
     return run
 
@@ -304,7 +316,16 @@ SCENARIOS.update({
     "baseline_cfg1": baseline_config("cfg1", 5), "baseline_cfg2_b256": baseline_config("cfg2", 256),
     "baseline_cfg2_guided": baseline_config("cfg2_guided", 8), "baseline_cfg3": baseline_config("cfg3", 2),
     "baseline_cfg4": baseline_config("cfg4", 3), "baseline_cfg5": baseline_config("cfg5", 3),
+    "baseline_cfg4_tied": baseline_config("cfg4", 3, "tied"), "baseline_cfg5_d27": baseline_config("cfg5", 3, "d27"),
 })
+
+# The same configurations at a batch that crosses the GEMM executors' tile / chunk boundaries (full-size behaviour
+# pinned against the REFERENCE, not against this repo's CPU executor).  Fixtures only (a few TFLOP of CPU work each in the build
+# container); the CPU suite does not re-run them, the GPU suite holds the native path to them at 1e-4.
+GPU_ONLY: Dict[str, Callable] = {
+    "baseline_cfg3_b130": baseline_config("cfg3", 130), "baseline_cfg4_tied_b96": baseline_config("cfg4", 96, "tied"),
+    "baseline_cfg5_b300": baseline_config("cfg5", 300), "baseline_cfg5_d27_b300": baseline_config("cfg5", 300, "d27"),
+}
 
 
 # --------------------------------------------------------------------------------------------------------------------- #
@@ -471,4 +492,4 @@ SCENARIOS["edm_classifier_guidance"] = edm_classifier_guidance()
 def run(name: str, lib_kind: str, device="cpu"):
     """Outputs of scenario `name` as {key: tensor}; keys starting with '_' are live objects for the caller, not results."""
     torch.manual_seed(1234)
-    return SCENARIOS[name](cases.lib_namespace(lib_kind), lib_kind, device)
+    return (SCENARIOS.get(name) or GPU_ONLY[name])(cases.lib_namespace(lib_kind), lib_kind, device)

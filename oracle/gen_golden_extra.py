@@ -44,7 +44,7 @@ def dit_h40_depth8_fp64(out_dir="tests/golden"):
 
 def main(out_dir="tests/golden", only=None):
     os.makedirs(out_dir, exist_ok=True)
-    for name in extra_cases.SCENARIOS:
+    for name in list(extra_cases.SCENARIOS) + list(extra_cases.GPU_ONLY):
         if only and name not in only:
             continue
         out = {k: v.detach().cpu().numpy().astype(np.float32) for k, v in extra_cases.run(name, "reference").items()
