@@ -82,5 +82,9 @@
 #define CDX2_F2_ACT_SHIFT 12    /* flags bits 12-15: activation id + 1 (CDX_ACT_* of include/cdx.h), 0 = Mish after a GroupNorm, else none */
 #define CDX2_W2_ODIV 26         /* forward ops: alias of W2_SAVE_STRIDE */
 #define CDX2_W2_XG 28           /* forward ops of a split program: alias of W2_DST2: lane groups [lo, hi) of this member as lo | hi << 8 | 1 << 16; 0 = not cut */
+#define CDX2_XG_XCHG 65536    /* W2_XG: the members exchange this op's output afterwards */
+#define CDX2_XG_GOP 131072     /* ... a GROUPED op: tile columns = (trajectory of the group) x position, W2_GMAP maps a column to its input row */
+#define CDX2_XG_TRAJ 262144    /* ... an ordinary op that wrote the member's trajectory into a group slot: whole trajectories are gathered */
+#define CDX2_W2_GMAP 25         /* forward ops of a grouped program: alias of W2_SAVE: log2(positions per trajectory) | rows per sub-slot << 8 */
 #define CDX2_W2_CGREAL4 29      /* F2_COLNORM ops: alias of W2_DST2_STRIDE: float4 items per lane group that hold real channels (0 = all) */
 #define CDX2_KIND2_LOADC 3      /* context slot <- the launch's per-sample condition features (zeros: unconditional forward / no condition) */

@@ -151,6 +151,8 @@ static __device__ __forceinline__ const KArg* kernarg() { return (const KArg*)__
 
 struct Geom {                    // wave-uniform description of one conv op's K loop
     int l_cols, cstride, ostride, sstride, stage;
+    int gsh, grows;              // grouped ops (GRP kernels): column m = trajectory (m >> gsh) of the group, position m & (2^gsh - 1);
+                                 // the trajectories' sub-slots lie `grows` rows apart.  grows == 0: an ordinary op
 };
 
 // One wave's job: (row tile, column group, K slice [, output parity of a transposed conv]) over ONE source slot.
@@ -227,7 +229,7 @@ template <int PF> struct Ring { f32x4 rec[PF]; };       // head of this wave's n
 // (tap, chunk): one add per chunk (`+ KSTEP`) and, every `ccn` chunks, one per-lane add for the tap step.  Columns past l_cols
 // sit on halo row 0 with a zero tap step.  Nothing else happens per record: wait, 4 MFMAs per (trajectory, column tile), one
 // ds_read per (trajectory, column tile), one global load.
-template <class M, int NT, int T, int NWV, bool PROF>
+template <class M, int NT, int T, int NWV, bool PROF, bool GRP = false>
 __device__ __forceinline__ void conv_kloop(const Geom& g, const float* __restrict__ wblob, int vd, const cint* ops,
                                            Item it, int n_items, float* __restrict__ lds, int tf, int lane, int wave,
                                            Ring<WG<NWV>::PF>& ring, unsigned long long* prof, int tune) {
@@ -252,7 +254,9 @@ __device__ __forceinline__ void conv_kloop(const Geom& g, const float* __restric
         for (int nt = 0; nt < NT; ++nt) {
             mcol[nt] = it.col0 + nt * M::COLS + M::col(lane);
             const bool valid = mcol[nt] < g.l_cols;
-            const int row = valid ? mcol[nt] * g.cstride - it.pad + CDX2_HALO2 + it.tap : 0;
+            int mrow = mcol[nt] * g.cstride;
+            if (GRP && g.grows) mrow = (mcol[nt] >> g.gsh) * g.grows + (mcol[nt] & ((1 << g.gsh) - 1)) * g.cstride;
+            const int row = valid ? mrow - it.pad + CDX2_HALO2 + it.tap : 0;
             cur[nt] = it.src + __mul24(row, it.sstr) + M::koff(lane) + cc * M::KSTEP;
             tstep[nt] = (valid ? it.sstr : 0) - ccn * M::KSTEP;
         }
@@ -296,7 +300,9 @@ __device__ __forceinline__ void conv_kloop(const Geom& g, const float* __restric
         };
         // steady-state eligibility (see below): 4x4 layers whose taps span a multiple of PF chunks, K slice starting on such a
         // boundary (the host cuts long streams that way), at least one full revolution before the drain
-        const bool aligned = M::KSTEP == 4 && (ccn % PF) == 0 && (it.cc % PF) == 0 && nq >= 2 * PF;
+        // (GRP kernels: also the 16x16 streams -- a grouped op is 40 records of 128 matrix-pipe cycles per wave, and the general loop's
+        //  conditional refills make the compiler wait for the whole vector-memory queue per record: measured 375 cycles per record)
+        const bool aligned = (M::KSTEP == 4 || GRP) && (ccn % PF) == 0 && (it.cc % PF) == 0 && nq >= 2 * PF;
         if (aligned) {                                         // the first BD - 1 chunks lie inside one tap: immediate offsets
 #pragma unroll
             for (int j = 0; j < BD - 1; ++j)
@@ -744,10 +750,15 @@ __device__ __forceinline__ void prefetch_ring(const Item& it, const float* __res
 // CU's address path, ~16 cycles each: 8 waves x 5 unconditional loads cost ~450 cycles per op, measured).  That is the right form when
 // the loads sit after the K loop (PIPE).  ALL = true: every wave issues all five (an unused one re-reads the bias) -- for the round-2
 // position at the op's start, where loads on only some paths make hipcc fall back to `s_waitcnt vmcnt(0)` in the K loop.
-template <bool COND, bool SPLIT_T, bool ALL, bool MLP = false>
+template <bool COND, bool SPLIT_T, bool ALL, bool MLP = false, bool GRP = false>
 __device__ __forceinline__ EpiParams load_params(const cdx_unet2_launch& L, int vd, const float* __restrict__ emb_row, int emb_tstride,
                                                  int tid, int wave, bool epi_wave) {
-    const int etid = tid & 255, grp = etid >> 5, li = etid & 31;
+    const int etid = tid & 255, li = etid & 31;
+    int grp = etid >> 5;
+    if (GRP) {       // grouped op: the half-waves are (trajectory, lane group of this member) pairs -- the channel comes from the lane group
+        const int xg = CDX2_DW(vd, CDX2_W2_XG);
+        if (xg & CDX2_XG_GOP) grp = (xg & 255) + (grp & ((((xg >> 8) & 255) - (xg & 255)) - 1));
+    }
     const int flags = CDX2_DW(vd, CDX2_W2_FLAGS), coutp = CDX2_DW(vd, CDX2_W2_COUTP), shift = CDX2_DW(vd, CDX2_W2_CG4_SHIFT);
     const int c = grp * (coutp >> 3) + 4 * (li & ((1 << shift) - 1));
     // (batch-tiled MLP programs: a layer whose input has a time-dependent part reads its bias from the step's table row)
@@ -808,38 +819,61 @@ template <int T, bool BWD> constexpr bool pipe_params() { return CDX2_PIPE_PARAM
 // Every poll is bounded: a granule that never arrives sets `err` and the launch ends with wrong numbers instead of hanging the GPU.
 // Sequence numbers keep increasing across launches on the same tiles (launch field xseq0), so nothing is cleared per launch.
 struct XState {
-    int m, k;                  // this workgroup's member index, members per trajectory
+    int m, k;                  // this workgroup's member index, members per trajectory / trajectories per group
     unsigned seq;              // exchanges done so far (the same number in every member: they run the same op list)
-    float* tiles;              // the group's two tiles, 2 * xf floats each ({value, tag} pairs)
-    unsigned* flags;           // (unused by the granule protocol; kept for the launch ABI)
-    int xf;
-    int* err;
     bool dead;                 // this thread lost a granule: no more waiting in this launch
+    // (the group's tiles, their size and the error word are re-read from the kernarg segment inside every exchange: five scalar
+    //  registers less that would be live -- and spilled -- across the whole op loop)
 };
 
+// The group's tile for the exchange with sequence number `seq` (two tiles of 2 * xchg_floats floats per group, alternating by parity).
+__device__ __forceinline__ float* exchange_tile(const XState& X, unsigned seq) {
+    const KArg* S0 = kernarg();
+    asm volatile("" : "+s"(S0));
+    const int bid = (int)blockIdx.x, grp_idx = ((bid >> (X.k == 4 ? 5 : 4)) << 3) + (bid & 7);       // (8 k consecutive workgroups = 8 groups)
+    const int xf = S0->xchg_floats;
+    return S0->xbuf + (size_t)grp_idx * 4 * xf + (size_t)(seq & 1) * 2 * xf;
+}
+
+// `xg` = the op's W2_XG word.  Split programs and grouped ops (XG_GOP): a member owns the lane groups [lo, hi) -- of its one trajectory,
+// or (grouped) of all k trajectories of the group, whose sub-slots lie `grows` rows apart in the destination slot; tile position =
+// trajectory * l_out + position.  XG_TRAJ: the member owns its WHOLE trajectory (sub-slot X.m; `dst` points at it) and collects the
+// other members' trajectories.
+// (Measured and dropped in round 4, gpurun r4d vs r4e: publishing straight from the epilogue's registers -- no LDS read-back, no barrier
+//  in front of the exchange -- with two collect items in flight per thread was 2.5 % SLOWER at B = 256; what an exchange costs, ~3.6 k
+//  cycles, is the wait for the slowest member of the group plus one L2 round trip, not the copy.)
 template <int THREADS>
-__device__ __forceinline__ void split_exchange(XState& X, int xg, float* __restrict__ tl, int dst, int dstride, int l_out, int c_out,
-                                               int coutp, int tid) {
-    const int g_lo = xg & 255, g_hi = (xg >> 8) & 255, cg = coutp >> 3;
+__device__ __forceinline__ void split_exchange(XState& X, int xg, int gmap, float* __restrict__ tl, int dst, int dstride, int l_out,
+                                               int c_out, int coutp, int tid) {
+    const int g_lo = xg & 255, g_hi = (xg >> 8) & 255;
+    const bool grouped = (xg & (CDX2_XG_GOP | CDX2_XG_TRAJ)) != 0, traj = (xg & CDX2_XG_TRAJ) != 0;
+    const int gsh = grouped ? (gmap & 255) : 30, grows = grouped ? (gmap >> 8) : 0;
+    const int vl = grouped ? l_out * X.k : l_out;
+    const int base = traj ? dst - X.m * grows * dstride : dst;
+    const int c4sh = 31 - __builtin_clz(coutp >> 2), cgsh = 31 - __builtin_clz(coutp >> 3);      // (pad32 channel counts: powers of two x 32)
     X.seq += 1;
-    float* __restrict__ tile = X.tiles + (size_t)(X.seq & 1) * 2 * X.xf;
+    float* __restrict__ tile = exchange_tile(X, X.seq);
     const float tag = __uint_as_float(X.seq);
-    const int c4n = coutp >> 2;
-    // publish: this member's channels, read back from the destination slot the epilogue just wrote (pad channels travel along)
-    for (int i = tid; i < l_out * c4n; i += THREADS) {
-        const int pos = i / c4n, c = (i - pos * c4n) * 4, grp = c / cg;
-        if (grp >= g_lo && grp < g_hi) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(tl + dst + (pos + CDX2_HALO2) * dstride + c);
-            f32x4* o = reinterpret_cast<f32x4*>(tile + (size_t)(pos * coutp + c) * 2);
+    const int n_items = vl << c4sh;
+    // publish: this member's part, read back from the destination slot the epilogue just wrote (pad channels travel along)
+    for (int i = tid; i < n_items; i += THREADS) {
+        const int vpos = i >> c4sh, c = (i - (vpos << c4sh)) * 4, grp = c >> cgsh;
+        const int t = vpos >> gsh, pos = vpos - (t << gsh);
+        const bool mine = traj ? t == X.m : (grp >= g_lo && grp < g_hi);
+        if (mine) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(tl + base + (t * grows + pos + CDX2_HALO2) * dstride + c);
+            f32x4* o = reinterpret_cast<f32x4*>(tile + (size_t)(vpos * coutp + c) * 2);
             o[0] = (f32x4){v[0], tag, v[1], tag};
             o[1] = (f32x4){v[2], tag, v[3], tag};
         }
     }
-    // collect: everybody else's channels, straight from L2 (nontemporal loads bypass this CU's L1), as soon as their tags say so
-    for (int i = tid; i < l_out * c4n; i += THREADS) {
-        const int pos = i / c4n, c = (i - pos * c4n) * 4, grp = c / cg;
-        if ((grp < g_lo || grp >= g_hi) && c < c_out) {
-            const f32x4* src = reinterpret_cast<const f32x4*>(tile + (size_t)(pos * coutp + c) * 2);
+    // collect: everybody else's part, straight from L2 (nontemporal loads bypass this CU's L1), as soon as their tags say so
+    for (int i = tid; i < n_items; i += THREADS) {
+        const int vpos = i >> c4sh, c = (i - (vpos << c4sh)) * 4, grp = c >> cgsh;
+        const int t = vpos >> gsh, pos = vpos - (t << gsh);
+        const bool mine = traj ? t == X.m : (grp >= g_lo && grp < g_hi);
+        if (!mine && c < c_out) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(tile + (size_t)(vpos * coutp + c) * 2);
             f32x4 a, b;
             int spins = 0;
             for (;;) {
@@ -849,11 +883,17 @@ __device__ __forceinline__ void split_exchange(XState& X, int xg, float* __restr
                     __float_as_uint(b[3]) == X.seq)
                     break;
                 // (a legitimate wait is tens of microseconds; ~10 ms of polling means the partner is not behind this L2.  Once a thread
-                //  has given up it stops waiting altogether: the launch must end, its numbers are void anyway)
-                if (X.dead || ++spins > 200000) { *X.err = 1; X.dead = true; break; }
+                //  has given up it stops waiting altogether: the launch must end; its workgroup stores NaN instead of trajectories)
+                if (X.dead || ++spins > 200000) {
+                    const KArg* S0 = kernarg();
+                    asm volatile("" : "+s"(S0));
+                    *S0->xerr = 1;
+                    X.dead = true;
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(1);
             }
-            float* o = tl + dst + (pos + CDX2_HALO2) * dstride + c;
+            float* o = tl + base + (t * grows + pos + CDX2_HALO2) * dstride + c;
             const f32x4 v = (f32x4){a[0], a[2], b[0], b[2]};
             if (c + 3 < c_out) *reinterpret_cast<f32x4*>(o) = v;
             else {
@@ -887,7 +927,7 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
         if (wave_of(tid) < CDX2_DW(vdn, CDX2_W2_NITEMS)) prefetch_ring(it, L.wblob, tid & 63, ring);
         if (PIPE) {
             if (params)
-                F.P = load_params<COND, SPLIT_T, false, MLP>(L, vdn, emb_next, emb_next_tstride, tid, wave_of(tid), NWV == 4 || SPLIT_T || wave_of(tid) < 4);
+                F.P = load_params<COND, SPLIT_T, false, MLP, SPLIT>(L, vdn, emb_next, emb_next_tstride, tid, wave_of(tid), NWV == 4 || SPLIT_T || wave_of(tid) < 4);
             F.vdn2 = load_desc<NWV>(L.ops, op_next2 + (SPLIT ? X->m * L.n_ops : 0), tid & 63, wave_of(tid));
         }
     };
@@ -943,26 +983,31 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
     }
     const int flags = CDX2_DW(vd, CDX2_W2_FLAGS), coutp = CDX2_DW(vd, CDX2_W2_COUTP), shift = CDX2_DW(vd, CDX2_W2_CG4_SHIFT);
     const int l_out = CDX2_DW(vd, CDX2_W2_LOUT), sstride = CDX2_DW(vd, CDX2_W2_SSTRIDE);
-    const Geom g{CDX2_DW(vd, CDX2_W2_LCOLS), CDX2_DW(vd, CDX2_W2_CSTRIDE), CDX2_DW(vd, CDX2_W2_OSTRIDE), sstride, L.stage_off};
+    // grouped op (SPLIT kernels, word W2_XG: XG_GOP): columns = (trajectory of the group) x position.  Only the K loop's column map is
+    // decoded here; what the epilogue and the exchange need is decoded again AFTER the K loop (nothing of it stays live across the loop)
+    int gmap0 = 0;
+    if (SPLIT && (CDX2_DW(vd, CDX2_W2_XG) & CDX2_XG_GOP)) gmap0 = CDX2_DW(vd, CDX2_W2_GMAP);
+    const Geom g{CDX2_DW(vd, CDX2_W2_LCOLS), CDX2_DW(vd, CDX2_W2_CSTRIDE), CDX2_DW(vd, CDX2_W2_OSTRIDE), sstride, L.stage_off,
+                 gmap0 & 255, gmap0 >> 8};
     const bool epi_wave = NWV == 4 || SPLIT_T || wave < 4;
     const bool halo_wave = NWV == 4 || SPLIT_T || wave >= 4;
 
     // epilogue geometry + per-channel parameters: issued now, consumed after the barrier (latency hides behind the K loop)
     const int etid = tid & 255;
     const int grp = etid >> 5, li = etid & 31;
-    const int c = grp * (coutp >> 3) + 4 * (li & ((1 << shift) - 1));
+    int c = grp * (coutp >> 3) + 4 * (li & ((1 << shift) - 1));
     const int pos0 = li >> shift, pstep = 32 >> shift;
     const int nv = (coutp >> 5) * l_out;
     // this op's epilogue parameters: fetched during the PREVIOUS op (PIPE), or here (consumed after the barrier either way)
-    EpiParams P = PIPE ? F.P : load_params<COND, SPLIT_T, CDX2_PARAMS_ALL != 0, MLP>(L, vd, emb_row, emb_tstride, tid, wave, epi_wave);
+    EpiParams P = PIPE ? F.P : load_params<COND, SPLIT_T, CDX2_PARAMS_ALL != 0, MLP, SPLIT>(L, vd, emb_row, emb_tstride, tid, wave, epi_wave);
 
     // K loop -> staged partial tiles
     const int n_items = CDX2_DW(vd, CDX2_W2_NITEMS);
     if (CDX2_DW(vd, CDX2_W2_MODE) == CDX_MODE_4X4) {
-        if (CDX2_DW(vd, CDX2_W2_NT) == 1) conv_kloop<M4, 1, T, NWV, PROF>(g, L.wblob, vd, ops, it, n_items, lds, tf, lane, wave, ring, prof, L.tune);
-        else conv_kloop<M4, 2, T, NWV, PROF>(g, L.wblob, vd, ops, it, n_items, lds, tf, lane, wave, ring, prof, L.tune);
+        if (CDX2_DW(vd, CDX2_W2_NT) == 1) conv_kloop<M4, 1, T, NWV, PROF, SPLIT>(g, L.wblob, vd, ops, it, n_items, lds, tf, lane, wave, ring, prof, L.tune);
+        else conv_kloop<M4, 2, T, NWV, PROF, SPLIT>(g, L.wblob, vd, ops, it, n_items, lds, tf, lane, wave, ring, prof, L.tune);
     } else {
-        conv_kloop<M16, 1, T, NWV, PROF>(g, L.wblob, vd, ops, it, n_items, lds, tf, lane, wave, ring, prof, L.tune);
+        conv_kloop<M16, 1, T, NWV, PROF, SPLIT>(g, L.wblob, vd, ops, it, n_items, lds, tf, lane, wave, ring, prof, L.tune);
     }
     if (PROF) stamp(prof ? prof + 7 : nullptr, tid);
     // head of the next op's weight stream: flies through the barrier and the epilogue
@@ -972,10 +1017,33 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
     if (PROF) stamp(prof ? prof + 1 : nullptr, tid);
     __syncthreads();
     if (PROF) stamp(prof ? prof + 2 : nullptr, tid);
-    const EpiParams Pnext = PARAMS_AFTER_BARRIER ? load_params<COND, SPLIT_T, false, MLP>(L, vdn, emb_next, emb_next_tstride, tid, wave, epi_wave)
+    const EpiParams Pnext = PARAMS_AFTER_BARRIER ? load_params<COND, SPLIT_T, false, MLP, SPLIT>(L, vdn, emb_next, emb_next_tstride, tid, wave, epi_wave)
                                                  : (PIPE ? F.P : P);
 
-    const EpiDesc e = decode_epi<BWD>(vd);
+    EpiDesc e = decode_epi<BWD>(vd);
+    int stage_e = g.stage;
+    int xgw = 0, gmap = 0;
+    bool gop = false;
+    if (SPLIT) {
+        int vde = vd;
+        asm volatile("" : "+v"(vde));                   // (decode from scratch: see above)
+        xgw = CDX2_DW(vde, CDX2_W2_XG);
+        gop = (xgw & CDX2_XG_GOP) != 0;
+        if (xgw & (CDX2_XG_GOP | CDX2_XG_TRAJ)) gmap = CDX2_DW(vde, CDX2_W2_GMAP);
+        if (gop) {
+            // grouped op: half-wave `grp` = trajectory grp / gpm of the group, lane group gx_lo + grp % gpm (gpm = 8 / k is 2 or 4, so the
+            // two half-waves of a wave belong to the same trajectory: g_t is wave-uniform).  This half-wave's trajectory: its sub-slot
+            // of the destination / residual slots, its columns of the staged tiles (which hold only the member's channels: relative to
+            // the first one), K slices `k x l_out` positions apart
+            const int gx_lo = xgw & 255, gpm = ((xgw >> 8) & 255) - gx_lo, grows = gmap >> 8;
+            const int g_t = __builtin_amdgcn_readfirstlane(gpm == 4 ? grp >> 2 : grp >> 1);
+            c = (gx_lo + (grp & (gpm - 1))) * (coutp >> 3) + 4 * (li & ((1 << shift) - 1));
+            e.dst += g_t * grows * e.dstride;
+            e.res += g_t * grows * e.rstride;
+            stage_e += g_t * l_out * sstride - gx_lo * (coutp >> 3);
+            e.l_out = l_out * X->k;
+        }
+    }
     const int t_lo = SPLIT_T ? (wave >> 2) : 0, t_step = SPLIT_T ? 2 : 1;
 #pragma unroll 1
     for (int t = t_lo; t < T; t += t_step) {
@@ -990,32 +1058,43 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
                 P.em = *reinterpret_cast<const f32x4*>(pe + e.coutp);
             } else P.em = *reinterpret_cast<const f32x4*>(pe);
         }
-        // (split programs: the half-waves of lane groups that belong to other members sit this op's epilogue out)
-        const int xg = SPLIT ? CDX2_DW(vd, CDX2_W2_XG) : 0;
-        if (epi_wave && (!SPLIT || xg == 0 || (grp >= (xg & 255) && grp < ((xg >> 8) & 255)))) {
+        // (split programs: the half-waves of lane groups that belong to other members sit this op's epilogue out; in a grouped op
+        //  every half-wave works -- on the member's lane groups of one of the group's trajectories)
+        const int xg = SPLIT ? xgw : 0;
+        if (epi_wave && (!SPLIT || gop || (xg & 0xffff) == 0 || (grp >= (xg & 255) && grp < ((xg >> 8) & 255)))) {
             if (BWD && (e.flags & CDX2_F2_GNBWD)) {
                 if (e.nk == 1) epilogue_bwd<1>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
                 else if (e.nk == 2) epilogue_bwd<2>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
                 else epilogue_bwd<CDX2_MAX_NK2>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
-            } else if (e.nk == 1) epilogue<1, BWD, COND, MLP>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
-            else if (e.nk == 2) epilogue<2, BWD, COND, MLP>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
-            else epilogue<CDX2_MAX_NK2, BWD, COND, MLP>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
+            } else if (e.nk == 1) epilogue<1, BWD, COND, MLP>(tl, P, e, stage_e, c, pos0, pstep, li, nv, lane, grp, ws);
+            else if (e.nk == 2) epilogue<2, BWD, COND, MLP>(tl, P, e, stage_e, c, pos0, pstep, li, nv, lane, grp, ws);
+            else epilogue<CDX2_MAX_NK2, BWD, COND, MLP>(tl, P, e, stage_e, c, pos0, pstep, li, nv, lane, grp, ws);
         }
         if (halo_wave) {
             // wave w (mod 4) rewrites halo row w of the destination (the arena hands this LDS to slots of other shapes in between)
             const int hw = wave & 3;
-            const int hrow = hw < CDX2_HALO2 ? hw : e.l_out + hw;
-            for (int j = lane * 4; j < e.dstride; j += 256)
-                *reinterpret_cast<f32x4*>(tl + e.dst + hrow * e.dstride + j) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int hrow = hw < CDX2_HALO2 ? hw : l_out + hw;
+            if (SPLIT && (xgw & (CDX2_XG_GOP | CDX2_XG_TRAJ))) {
+                // ... of every trajectory's sub-slot (XG_TRAJ: the exchange brings the other trajectories' data rows only; the descriptor's
+                // destination is this member's sub-slot)
+                const int hrows = gmap >> 8;
+                const int dbase = CDX2_DW(vd, CDX2_W2_DST) - ((xgw & CDX2_XG_TRAJ) ? X->m * hrows * e.dstride : 0);
+                for (int tt = 0; tt < X->k; ++tt)
+                    for (int j = lane * 4; j < e.dstride; j += 256)
+                        *reinterpret_cast<f32x4*>(tl + dbase + (tt * hrows + hrow) * e.dstride + j) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            } else {
+                for (int j = lane * 4; j < e.dstride; j += 256)
+                    *reinterpret_cast<f32x4*>(tl + e.dst + hrow * e.dstride + j) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
             if (BWD && (e.flags & CDX2_F2_DUAL))
                 for (int j = lane * 4; j < e.d2stride; j += 256)
                     *reinterpret_cast<f32x4*>(tl + e.dst2 + hrow * e.d2stride + j) = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     }
     if (PIPE) F.P = Pnext;
-    if (SPLIT && CDX2_DW(vd, CDX2_W2_XG) != 0) {
+    if (SPLIT && (xgw & CDX2_XG_XCHG)) {
         __syncthreads();                                             // the epilogue's stores to the destination slot are in LDS
-        split_exchange<WG<NWV>::THREADS>(*X, CDX2_DW(vd, CDX2_W2_XG), lds, e.dst, e.dstride, e.l_out, e.c_out, e.coutp, tid);
+        split_exchange<WG<NWV>::THREADS>(*X, xgw, gmap, lds, CDX2_DW(vd, CDX2_W2_DST), e.dstride, l_out, e.c_out, e.coutp, tid);
     }
     __syncthreads();
     if (PROF) stamp(prof ? prof + 3 : nullptr, tid);
@@ -1032,7 +1111,7 @@ template <int T, int NWV, bool BWD, bool PROF, bool COND = false, bool MLP = fal
 __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_unet2_kernel(const cdx_unet2_launch L) {
     static_assert(!(COND && BWD), "conditional requests have no backward-op variant");
     static_assert(!MLP || (COND && T == 1 && NWV == 8), "batch-tiled MLP programs: the conditional one-trajectory 8-wave shape");
-    static_assert(!SPLIT || (T == 1 && NWV == 8 && !BWD && !COND && !PROF), "split programs: unconditional one-trajectory 8-wave shape");
+    static_assert(!SPLIT || (T == 1 && NWV == 8 && !BWD && !COND), "split / grouped programs: unconditional one-trajectory 8-wave shape");
     constexpr int THREADS = WG<NWV>::THREADS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -1040,23 +1119,21 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
     const int H = L.horizon, D = L.dim, HD = H * D, tf = L.traj_floats;
     // split programs: 8 k consecutive workgroups hold 8 trajectories x k members; the members of a trajectory are 8 workgroups apart,
     // i.e. on the same XCD (workgroup i runs on XCD i % 8)
-    XState X{0, 1, 0u, nullptr, nullptr, 0, nullptr, false};
+    XState X{0, 1, 0u, false};
     int grp_idx = 0;
+    bool grouped = false;        // grouped program: the k members of a group own k trajectories (one each) instead of one together
     if (SPLIT) {
         const KArg* S0 = kernarg();
         asm volatile("" : "+s"(S0));
         X.k = S0->split_k;
+        grouped = S0->split_group != 0;
         const int bid = (int)blockIdx.x, span = 8 * X.k;
         grp_idx = (bid / span) * 8 + (bid & 7);
         X.m = (bid % span) >> 3;
-        X.xf = S0->xchg_floats;
-        X.tiles = S0->xbuf + (size_t)grp_idx * 4 * X.xf;           // two tiles of 2 * xf floats ({value, tag} granules)
-        X.flags = S0->xflags + (size_t)grp_idx * 16 * 8;
-        X.err = S0->xerr;
         X.seq = S0->xseq0;
     }
     const int moff = SPLIT ? X.m * L.n_ops : 0;           // member m's op i is descriptor m * n_ops + i
-    const int b0 = L.traj_first + (SPLIT ? grp_idx : (int)blockIdx.x * T);
+    const int b0 = L.traj_first + (SPLIT ? (grouped ? grp_idx * X.k + X.m : grp_idx) : (int)blockIdx.x * T);
     const int b_end = L.traj_first + L.traj_count;      // this launch covers trajectories [traj_first, traj_first + traj_count) of the batch
     unsigned long long* lprof = reinterpret_cast<unsigned long long*>(lds + T * tf);
     const bool profiling = PROF && L.prof != nullptr && blockIdx.x == 0;
@@ -1363,11 +1440,14 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
         const int str = S->n_steps == 0 ? (want_grad ? S->grad_stride : S->pred_stride) : S->x_stride;
         float* __restrict__ xo = S->x_out;
         if ((S->compact || (COND && S->edm_plan)) && S->n_steps > 0) break;            // the state is already there
-        if (SPLIT && X.m != 0) break;                                                  // every member holds the result: member 0 stores it
+        // (split programs: a thread that gave up on a granule makes its workgroup store NaN -- a failed exchange must never look
+        //  like a sample; the error word tells the host)
+        const bool poisoned = SPLIT && __syncthreads_or(X.dead ? 1 : 0) != 0;
+        if (SPLIT && !grouped && X.m != 0) break;                                      // every member holds the result: member 0 stores it
         if (BWD && logp_only) break;                                                   // nothing but logp_out is produced
         for (int e = tid; e < HD; e += THREADS) {
             const int n = e / D, c = e - n * D;
-            xo[xbase + e] = lds[t * tf + off + n * str + c];
+            xo[xbase + e] = (SPLIT && poisoned) ? __builtin_nanf("") : lds[t * tf + off + n * str + c];
         }
     }
     if (profiling) {
@@ -1483,13 +1563,17 @@ int cdx_unet2_run(const cdx_unet2_launch* L, void* hip_stream) {
     const bool cond = L->n_pass == 2 || L->edm_plan || L->emb_per_traj;
     int split_grid = 0;
     if (L->split_k != 0) {
-        if ((L->split_k != 2 && L->split_k != 4) || guided || cond || L->mlp || L->prof || L->traj_per_wg != 1 || L->n_waves != 8 || L->compact ||
+        if ((L->split_k != 2 && L->split_k != 4) || guided || cond || L->mlp || L->traj_per_wg != 1 || L->n_waves != 8 || L->compact ||
             !L->xbuf || !L->xerr || L->xchg_floats <= 0 || (L->xchg_floats & 3)) {
-            cdx_set_err("split program: split_k 2 or 4, one trajectory per workgroup, 8 waves, unconditional, xbuf / xflags / xerr given"); return CDX_EINVAL;
+            cdx_set_err("split / grouped program: split_k 2 or 4, one trajectory per workgroup, 8 waves, unconditional, xbuf / xerr given"); return CDX_EINVAL;
         }
-        split_grid = ((L->traj_count + 7) / 8) * 8 * L->split_k;
-        if (split_grid > 256) { cdx_set_err("split program: every workgroup of the launch must be resident (<= 256)"); return CDX_EINVAL; }
-        kern = cdx_unet2_kernel<1, 8, false, false, false, false, true>;
+        // split: split_k workgroups per trajectory; grouped: split_k trajectories per group of split_k workgroups (blocks of 8 groups)
+        split_grid = L->split_group ? ((L->traj_count + 8 * L->split_k - 1) / (8 * L->split_k)) * 8 * L->split_k
+                                    : ((L->traj_count + 7) / 8) * 8 * L->split_k;
+        if (split_grid > 256) { cdx_set_err("split / grouped program: every workgroup of the launch must be resident (<= 256)"); return CDX_EINVAL; }
+        kern = L->prof ? cdx_unet2_kernel<1, 8, false, true, false, false, true> : cdx_unet2_kernel<1, 8, false, false, false, false, true>;
+    } else if (L->split_group) {
+        cdx_set_err("split_group without split_k"); return CDX_EINVAL;
     } else if (L->mlp) {
         if (guided || L->traj_per_wg != 1 || L->n_waves != 8 || L->emb_per_traj || L->compact || L->prof) {
             cdx_set_err("batch-tiled MLP program: one tile per workgroup, 8 waves, one table row per step, no backward ops"); return CDX_EINVAL;

@@ -91,6 +91,14 @@ F2_ACT_SHIFT = 12
 W2_ODIV = 26                  # forward ops: alias of W2_SAVE_STRIDE (a backward-pass word)
 W2_XG = 28                    # forward ops of a SPLIT program (one trajectory over k workgroups of an XCD): alias of W2_DST2 --
                               # lane groups [lo, hi) this member computes, as lo | hi << 8 | 1 << 16; 0 = the op is not split
+# Grouped programs (k trajectories over the k workgroups of a group, one XCD; compile_janner2_group): bits of W2_XG above the lane-group
+# range.  XG_XCHG: the members exchange this op's output afterwards; XG_GOP: a GROUPED op -- the member computes its 1/k of the output
+# channels for ALL k trajectories (tile columns = trajectory x position, W2_GMAP maps a column to its input row); XG_TRAJ: an ordinary op
+# that wrote the member's own trajectory into a group slot -- the exchange gathers whole trajectories instead of channel ranges.
+XG_XCHG, XG_GOP, XG_TRAJ = 1 << 16, 1 << 17, 1 << 18
+W2_GMAP = 25                  # forward ops of a grouped program: alias of W2_SAVE -- log2(positions per trajectory) | rows per sub-slot << 8
+GROUP_MIN_BYTES = int(os.environ.get("CDX_UNET2_GROUP_MIN_KB", "400")) * 1024   # an op is grouped only if it streams at least this many
+                                                                                 # weight bytes (an exchange costs a few thousand cycles)
 W2_CGREAL4 = 29               # F2_COLNORM ops: alias of W2_DST2_STRIDE -- float4 items of a lane group that hold REAL channels (0 = all):
                               # a per-sample GroupNorm whose groups are narrower than the lane group keeps zero pad channels out of its variance
 
@@ -111,14 +119,20 @@ class Act:
     persistent: bool = False
     halo: int = HALO2                 # 0: a slot that is never a conv source (saved normalised values of the backward pass)
     in_global: bool = False           # saved values kept in the per-trajectory global workspace, not in LDS
+    gcap: bool = False                # grouped programs: short enough to hold the group's k trajectories side by side (k x length <= 16 columns)
+    gk: int = 1                       # ... and, once a grouped op touches it, it does: k sub-slots (each with its own halo rows), `sub_floats` apart
 
     @property
     def stride(self):
         return slot_stride(self.chans)
 
     @property
-    def floats(self):
+    def sub_floats(self):
         return (self.length + 2 * self.halo) * self.stride
+
+    @property
+    def floats(self):
+        return self.sub_floats * self.gk
 
     @property
     def data_off(self):               # float offset of position 0
@@ -202,6 +216,7 @@ class _Builder2:
         self.member = (0, 1)               # (m, k): this builder emits member m's view of a program split over k workgroups -- the
                                            # member computes 1/k of the row tiles of every op that can be cut that way (conv())
         self.xchg_floats = 0               # largest tile (positions x padded channels) a split op exchanges
+        self.grouped = False               # member views of a GROUPED program (k trajectories over k workgroups): see conv()
 
     def add(self, t: torch.Tensor, pad_to: int = 4) -> int:
         t = t.detach().to(device=self.device, dtype=torch.float32).reshape(-1)
@@ -215,6 +230,8 @@ class _Builder2:
 
     def act(self, length: int, chans: int, persistent=False, halo: int = HALO2) -> Act:
         a = Act(length, chans, len(self.acts), persistent=persistent, halo=halo)
+        k = self.member[1]
+        a.gcap = bool(self.grouped and k > 1 and not persistent and halo == HALO2 and length & (length - 1) == 0 and k * length <= 16)
         self.acts.append(a)
         return a
 
@@ -263,6 +280,7 @@ class _Builder2:
         c_out, taps, c_in = w_eff.shape
         l_out = dst.length
         assert c_in == sum(a.chans for a in srcs) and dst.chans == c_out and 1 <= len(srcs) <= 2
+        gop = False
         if phases is not None:
             if l_out != 2 * srcs[0].length or len(srcs) != 1:
                 raise ValueError("explicit phases describe a stride-2 scatter of one source")
@@ -278,6 +296,16 @@ class _Builder2:
                 raise ValueError(f"kernel size {taps} needs more than {HALO2} halo rows")
             phases = [(w_eff, pad, 0)]
             l_cols, cstride, ostride = l_out, stride, 1
+            # ---- grouped op (member view of a grouped program): all k trajectories of the group ride the column axis ----
+            ex_srcs = [a for ex in (extra or []) for a in ex["srcs"]]
+            w_bytes = 4 * (w_eff.numel() + sum(ex["w_eff"].numel() for ex in (extra or [])))
+            gop = (self.grouped and self.member[1] > 1 and stride == 1 and bwd is None and save is None and not col_norm
+                   and dst.gcap and all(a.gcap and a.length == l_out for a in list(srcs) + ex_srcs) and (res is None or res.gcap)
+                   and w_bytes >= GROUP_MIN_BYTES)
+            if gop:
+                l_cols = self.member[1] * l_out
+        if len(phases) != 1 or transposed:
+            gop = False
         for w, ppad, _ in phases:
             if ppad > HALO2 or (w.shape[1] - 1 - ppad) > HALO2:
                 raise ValueError("phase reaches past the halo rows")
@@ -292,7 +320,24 @@ class _Builder2:
         my_rts, xg = list(range(n_rt)), 0
         k_chunks = sum(-(-a.chans // (16 if mode == MODE_16X16 else 4)) for a in srcs) * phases[0][0].shape[1]     # records per row tile
         worth = k_chunks * n_rt * n_cg / self.nw >= SPLIT_MIN_RECORDS
-        if ksp > 1 and worth and len(phases) == 1 and n_rt > 1 and bwd is None and save is None and (n_rt % ksp == 0 or ksp % n_rt == 0):
+        if gop:
+            # the member's 1/k of the row tiles = whole GroupNorm lane groups, or the op stays an ordinary one on the member's own trajectory
+            cgw = coutp // GROUPS2
+            lo_c, hi_c = mem * n_rt // ksp * rows, (mem + 1) * n_rt // ksp * rows
+            if n_rt % ksp or n_cg != 1 or coutp != c_out or lo_c % cgw or hi_c % cgw or GROUPS2 % ksp:
+                gop, l_cols = False, l_out
+                mode = MODE_4X4 if (l_cols <= 8 and c_out % 64 == 0 and self.allow_4x4) else MODE_16X16
+                rows, cols = (16, 16) if mode == MODE_16X16 else (64, 4)
+                nt = 2 if (mode == MODE_4X4 and l_cols > 4) else 1
+                n_rt, n_cg = -(-c_out // rows), -(-l_cols // (nt * cols))
+                my_rts = list(range(n_rt))
+            else:
+                my_rts = list(range(mem * n_rt // ksp, (mem + 1) * n_rt // ksp))
+                xg = (lo_c // cgw) | ((hi_c // cgw) << 8) | XG_XCHG | XG_GOP
+                self.xchg_floats = max(self.xchg_floats, l_cols * coutp)
+                for a in list(srcs) + ex_srcs + [dst] + ([res] if res is not None else []):
+                    a.gk = ksp                               # these slots hold the group's k trajectories from now on
+        elif ksp > 1 and not self.grouped and worth and len(phases) == 1 and n_rt > 1 and bwd is None and save is None and (n_rt % ksp == 0 or ksp % n_rt == 0):
             cand = list(range(mem * n_rt // ksp, (mem + 1) * n_rt // ksp)) if n_rt >= ksp else [mem * n_rt // ksp]
             cgw = coutp // GROUPS2
             lo_c, hi_c = cand[0] * rows, (cand[-1] + 1) * rows
@@ -300,7 +345,10 @@ class _Builder2:
                 my_rts, xg = cand, (lo_c // cgw) | (min(hi_c // cgw, GROUPS2) << 8) | (1 << 16)
                 self.xchg_floats = max(self.xchg_floats, l_out * coutp)
         tiles = len(my_rts) * n_cg * len(phases)
-        sstride = coutp + 4
+        # staged partial tiles: [K slice][output position][channel]; a grouped op stages only the member's channels, for k x l_out columns
+        sstride = (len(my_rts) * rows + 4) if gop else coutp + 4
+        l_stage = l_cols if gop else l_out
+        rt0 = my_rts[0] if gop else 0
         nw, ring = self.nw, ring_depth(self.nw)
         # record stream of a (phase, row tile): [source 0: taps x chunks | source 1: taps x chunks]; a K slice never straddles the
         # sources.  K slices: every source's record range is cut evenly; with two sources (a concat) each source gets at least one
@@ -336,13 +384,15 @@ class _Builder2:
                 else:
                     assert ex.get("bias") is None, "bias of a summed extra conv: fold it into the main bias"
             budget = max(len(streams), nw // tiles if tiles < nw else 1)
+            if gop:      # the post-norm extra streams (1x1 skip) ride as second-round items: the main conv keeps every wave
+                budget = (nw // tiles if tiles < nw else 1) + sum(1 for st in streams if st["post"])
             per = [1] * len(streams)
             n_of = [st["recs"].shape[1] for st in streams]
 
             def grow():
                 cand = [i for i in range(len(streams)) if n_of[i] // (per[i] + 1) >= MIN_SLICE]
                 return max(cand, key=lambda i: n_of[i] / per[i]) if cand else None
-            while sum(per) < budget and (sum(per) + 1) * l_out * sstride <= self.max_stage:
+            while sum(per) < budget and (sum(per) + 1) * l_stage * sstride <= self.max_stage:
                 i = grow()
                 if i is None:
                     break
@@ -367,7 +417,7 @@ class _Builder2:
                         if rt not in my_rts:
                             continue
                         items.append([woff + (rt * n + q0) * 256, q1 - q0, (q0 // st["ccn"]) | ((q0 % st["ccn"]) << 8),
-                                      ks * l_out * sstride + rt * rows, cgi * nt * cols, st["pad"] | (0 << 8), 0, st["ccn"]])
+                                      ks * l_stage * sstride + (rt - rt0) * rows, cgi * nt * cols, st["pad"] | (0 << 8), 0, st["ccn"]])
                         item_src.append(st["src"])
                     ks += 1
             stage_slices = ksplit + kpost
@@ -421,6 +471,8 @@ class _Builder2:
             words[W2_BOFF] = self.add(_padded(bias if bias is not None else torch.zeros(c_out, device=self.device), coutp))
         if xg:
             words[W2_XG] = xg
+        if gop:
+            words[W2_GMAP] = (l_out.bit_length() - 1) | ((l_out + 2 * HALO2) << 8)
         if kpost:
             words[W2_PBIAS] = self.add(_padded(pbias, coutp))
         cg = coutp // GROUPS2
@@ -488,10 +540,10 @@ class _Builder2:
             op[k] = int(v)
         self.ops.append(op)
         self.op_acts.append(dict(srcs=list(all_srcs), res=res, dst=dst, save=(save[0] if save is not None else (bwd["save"] if bwd else None)),
-                                 dst2=(bwd.get("dst2") if bwd else None), reads=reads, writes=writes))
+                                 dst2=(bwd.get("dst2") if bwd else None), reads=reads, writes=writes, gop=gop))
         self.op_items.append(items)
         self.op_item_src.append(item_src)
-        self.stage = max(self.stage, stage_slices * l_out * sstride)
+        self.stage = max(self.stage, stage_slices * l_stage * sstride)
         self.macs += sum(c_out * (l_cols if len(phases) > 1 else l_out) * w.shape[1] * c_in for w, _, _ in phases)
         return True
 
@@ -600,19 +652,31 @@ class _Builder2:
             a.off = offs[a.uid]
         for d, r in root.items():
             by_uid[d].off = by_uid[r].off
+        mem = self.member[0]
         for op, oa, items, item_src in zip(self.ops, self.op_acts, self.op_items, self.op_item_src):
-            op[W2_DST] = oa["dst"].off                                 # slot base = first halo row
+            # grouped programs: an ORDINARY op works on the member's own trajectory = sub-slot `mem` of every group slot it touches
+            # (a grouped op addresses sub-slots itself: column -> trajectory)
+            own = lambda a: a.off + (mem * a.sub_floats if (a.gk > 1 and not oa.get("gop")) else 0)      # noqa: E731
+            op[W2_DST] = own(oa["dst"])                                # slot base = first halo row
             if oa["res"] is not None:
-                op[W2_RES] = oa["res"].off
+                op[W2_RES] = own(oa["res"])
             if oa["save"] is not None:
                 op[W2_SAVE] = oa["save"].off
             if oa["dst2"] is not None:
                 op[W2_DST2] = oa["dst2"].off
             for rec, si in zip(items, item_src):
                 src = oa["srcs"][si]
-                if src.off >= (1 << 16) or src.stride >= (1 << 15):     # item words pack offset | stride << 16
+                if own(src) >= (1 << 16) or src.stride >= (1 << 15):     # item words pack offset | stride << 16
                     raise ValueError(f"LDS plan beyond the 16-bit slot offsets of the item format (slot at float {src.off})")
-                rec[I2_SRCSTR] = src.off | (src.stride << 16)
+                rec[I2_SRCSTR] = own(src) | (src.stride << 16)
+            if oa["dst"].gk > 1 and not oa.get("gop"):
+                # an ordinary op wrote its trajectory into a group slot that grouped ops read: the members gather whole trajectories
+                d = oa["dst"]
+                if int(op[W2_KIND]) != KIND2_CONV or oa["res"] is d or (int(op[W2_FLAGS]) & (F2_GNBWD | F2_SAVE | F2_DUAL)):
+                    raise ValueError("grouped program: only plain forward convs may write a group slot from one trajectory")
+                op[W2_XG] = 0 | (GROUPS2 << 8) | XG_XCHG | XG_TRAJ
+                op[W2_GMAP] = (d.length.bit_length() - 1) | ((d.length + 2 * HALO2) << 8)
+                self.xchg_floats = max(self.xchg_floats, d.gk * d.length * int(op[W2_COUTP]))
         return top
 
 
@@ -1220,7 +1284,8 @@ def _finalize2(b: "_Builder2", nets_emb: List[dict], x: Act, pred: Act, horizon:
 
 
 def compile_janner2(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x4: bool = True, nw: int = NW2, compact: bool = False,
-                    max_stage: Optional[int] = None, member: Tuple[int, int] = (0, 1)) -> Program2:
+                    max_stage: Optional[int] = None, member: Tuple[int, int] = (0, 1), grouped: bool = False,
+                    alias_residual: Optional[bool] = None) -> Program2:
     """Lower a JannerUNet1d (reference nn_diffusion/jannerunet.py:98-201) for `horizon` positions and `nw` waves per workgroup.
     `compact`: the small-LDS variant for THREE trajectories per workgroup (in-place residual outputs, capped staging area)."""
     why = supports_janner(net)
@@ -1229,11 +1294,12 @@ def compile_janner2(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x
     dev = next(net.parameters()).device
     b = _Builder2(dev, nw)
     b.allow_4x4 = allow_4x4
-    b.alias_residual = compact
+    b.alias_residual = compact if alias_residual is None else alias_residual
     b.member = member
+    b.grouped = grouped
     if member[1] > 1:
         if compact or nw != NW2_MAX:
-            raise ValueError("split programs: the 8-wave, state-in-LDS form only")
+            raise ValueError("split / grouped programs: the 8-wave, state-in-LDS form only")
         b.fuse_max = 1 << 30                  # (a member's K slices are short: the 1x1 skips always ride in their block's second conv)
     if max_stage is not None:
         b.max_stage = max_stage
@@ -1245,6 +1311,7 @@ def compile_janner2(net, horizon: int, max_lds_bytes: int = 160 * 1024, allow_4x
     emb = _emb_table_spec(b, net, blocks, dev)
     prog = _finalize2(b, [emb], x, pred, horizon, d, net.emb_dim, max_lds_bytes, [], compact=compact)
     prog.meta["xchg_floats"] = b.xchg_floats
+    prog.meta["n_gops"] = sum(1 for oa in b.op_acts if oa.get("gop"))
     return prog
 
 
@@ -1257,6 +1324,11 @@ def compile_janner2_split(net, horizon: int, k: int, max_lds_bytes: int = 160 * 
     if k not in (2, 4):
         raise ValueError("split factor 2 or 4")
     members = [compile_janner2(net, horizon, max_lds_bytes=max_lds_bytes, nw=NW2_MAX, member=(m, k)) for m in range(k)]
+    return _merge_members(members, k)
+
+
+def _merge_members(members: List[Program2], k: int) -> Program2:
+    """One program out of the k member views (same blob, LDS plan and op count): descriptors [member 0 | member 1 | ... | item tails]."""
     p0 = members[0]
     n_ops, opw = len(p0.ops), op_words(NW2_MAX)
     for p in members[1:]:
@@ -1279,6 +1351,35 @@ def compile_janner2_split(net, horizon: int, k: int, max_lds_bytes: int = 160 * 
     p0.meta["xchg_floats"] = max(p.meta["xchg_floats"] for p in members)
     if p0.meta["xchg_floats"] == 0:
         raise ValueError("split program: no op of this net streams enough weights to be cut over the members")
+    return p0
+
+
+def compile_janner2_group(net, horizon: int, k: int, max_lds_bytes: int = 160 * 1024) -> Program2:
+    """k trajectories over the k workgroups of a group on one XCD -- the full-batch counterpart of `compile_janner2_split` (B = 256 on
+    256 CUs: no idle CU to give a trajectory).  Member m owns trajectory m of its group and runs the whole op list on it, EXCEPT the ops
+    that stream enough weights to be bound by the L2 -> CU path (config 2: the 0.6-1.3 MB layers at 4 positions): those are GROUPED --
+    the member computes its 1/k of the output channels (whole GroupNorm lane groups) for ALL k trajectories, whose k x 4 positions fill
+    the 16 columns of a 16x16x4 tile (instead of 4 of a 4x4x1 block), so every streamed weight record feeds k trajectories and each CU
+    streams 1/k of the layer.  The slots such ops touch hold the group's k trajectories side by side (k sub-slots); after a grouped op the
+    members all-gather its output through the group's tile in L2 (the exchange of the split programs), and an ordinary op that feeds a
+    grouped one publishes its whole trajectory the same way.  Descriptor layout as for split programs: [member 0 ops | member 1 ops | ...
+    | item tails]."""
+    if k not in (2, 4):
+        raise ValueError("group size 2 or 4")
+    members = None
+    for alias in (False, True):                       # in-place residual outputs only if the plain plan does not fit
+        try:
+            members = [compile_janner2(net, horizon, max_lds_bytes=max_lds_bytes, nw=NW2_MAX, member=(m, k), grouped=True,
+                                       alias_residual=alias) for m in range(k)]
+            break
+        except ValueError:
+            if alias:
+                raise
+    p0 = _merge_members(members, k)
+    p0.meta["group_k"] = k
+    del p0.meta["split_k"]
+    if p0.meta["n_gops"] == 0:
+        raise ValueError("grouped program: no op of this net streams enough weights to be grouped")
     return p0
 
 

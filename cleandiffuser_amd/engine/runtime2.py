@@ -51,7 +51,7 @@ class CdxUnet2Launch(ctypes.Structure):
                 ("edm_plan", ctypes.c_int32), ("logp_out", ctypes.c_void_p), ("logp_first_op", ctypes.c_int32),
                 ("logp_head_op", ctypes.c_int32), ("ctx", ctypes.c_void_p), ("mlp", ctypes.c_int32),
                 ("split_k", ctypes.c_int32), ("xchg_floats", ctypes.c_int32), ("xbuf", ctypes.c_void_p), ("xflags", ctypes.c_void_p),
-                ("xerr", ctypes.c_void_p), ("xseq0", ctypes.c_uint32)]
+                ("xerr", ctypes.c_void_p), ("xseq0", ctypes.c_uint32), ("split_group", ctypes.c_int32)]
 
 
 _declared = False
@@ -276,7 +276,7 @@ def shape_for(module, horizon: int, batch: int):
 def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps=0, predict_noise=0, prior=None,
            fix_mask=None, noise=None, x_min=None, x_max=None, t_per_wg: Optional[int] = None, x_scale: Optional[float] = None,
            cg_scale=None, with_backward: bool = False, parts=None, emb_per_traj: bool = False, emb_u=None, cfg_w: float = 1.0,
-           edm: bool = False, logp_out=None, ctx=None, split: int = 0):
+           edm: bool = False, logp_out=None, ctx=None, split: int = 0, group: bool = False):
     if batch <= 0:
         return
     prog = comp.prog
@@ -286,14 +286,15 @@ def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps
     xbuf = xerr = None
     xseq0 = 0
     if split:
-        assert split == prog.meta.get("split_k") and parts is None and t_per_wg in (None, 1)
+        assert split == prog.meta.get("group_k" if group else "split_k") and parts is None and t_per_wg in (None, 1)
         check_split_errors(x_in.device, wait=False)   # (a lost granule of an EARLIER split launch on this device surfaces here)
-        n_grp = -(-batch // 8) * 8
+        # exchange tiles: one pair per group of the launch -- a trajectory's k workgroups (split) or k trajectories' k workgroups (grouped)
+        n_grp = -(-batch // (8 * split)) * 8 if group else -(-batch // 8) * 8
         key = (x_in.device, R._stream_ptr(x_in.device))
         need = n_grp * 4 * prog.meta["xchg_floats"]
         n_forwards = max(n_steps, 1)
         if "n_cut_ops" not in prog.meta:
-            prog.meta["n_cut_ops"] = int(sum(1 for op in prog.ops if op[P2.W2_XG]))
+            prog.meta["n_cut_ops"] = int(sum(1 for op in prog.ops if int(op[P2.W2_XG]) & P2.XG_XCHG))
         n_xchg = prog.meta["n_cut_ops"] * n_forwards
         st = _split_bufs.get(key)
         if st is None or st["buf"].numel() < need or st["seq"] + n_xchg >= 2 ** 31:
@@ -347,7 +348,7 @@ def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps
             logp_out=R._ptr(logp_out), logp_first_op=prog.meta.get("cls_first", 0) if logp_out is not None else 0,
             logp_head_op=prog.meta.get("head_op", 0) if logp_out is not None else 0, ctx=R._ptr(ctx), mlp=int(mlp),
             split_k=int(split), xchg_floats=prog.meta.get("xchg_floats", 0) if split else 0, xbuf=R._ptr(xbuf), xflags=None,
-            xerr=R._ptr(xerr), xseq0=int(xseq0))
+            xerr=R._ptr(xerr), xseq0=int(xseq0), split_group=int(bool(group)))
         R._check(_lib().cdx_unet2_run(ctypes.byref(L), R._stream_ptr(x_in.device)), "cdx_unet2_run")
     if timing["on"]:
         end.record(torch.cuda.current_stream(x_in.device))
@@ -371,9 +372,11 @@ def _split_err(device) -> torch.Tensor:
 
 
 def check_split_errors(device=None, wait: bool = True):
-    """Raise if a split launch lost a granule (its polls are bounded: the launch ends, the numbers are wrong).  The error word lives in
-    pinned host memory the kernel writes directly, so looking at it costs nothing: the next split launch on the device does
-    (`wait=False`); `wait=True` (tests, explicit calls) synchronises the device first."""
+    """Raise if a split / grouped launch lost a granule (its polls are bounded: the launch ends; the workgroup that gave up stored NaN
+    instead of its trajectories, so a failed exchange never looks like a sample).  The error word lives in pinned host memory the kernel
+    writes directly, so looking at it costs nothing: the next such launch on the device does (`wait=False`); `wait=True` (tests, explicit
+    calls, the synchronous mode of the small-batch path) synchronises the device first.  A device on which this fires loses both modes
+    for the rest of the process (its workgroups are evidently not co-resident behind one L2)."""
     for dev, (_, word) in list(_split_errs.items()):
         if device is not None and dev != device:
             continue
@@ -381,7 +384,9 @@ def check_split_errors(device=None, wait: bool = True):
             torch.cuda.synchronize(dev)
         if int(word[0]) != 0:
             word[0] = 0
-            raise RuntimeError("cdx_unet2_run (split program): a member never received a granule; the results of that launch are invalid")
+            _split_ok[dev] = _group_ok[dev] = False
+            raise RuntimeError("cdx_unet2_run (split / grouped program): a member never received a granule; the trajectories of that "
+                               "launch were stored as NaN, and both modes are now off for this device")
 
 
 def split_factor(batch: int) -> int:
@@ -396,7 +401,39 @@ def split_factor(batch: int) -> int:
     return 1
 
 
+def group_factor(batch: int) -> int:
+    """Trajectories per GROUP of an unconditional U-Net loop at full batch (compile_janner2_group): 4 when the batch needs more than
+    128 workgroups but still fits one trajectory per CU (every workgroup of the launch must be resident: ceil(B / (8 k)) * 8 k <= 256),
+    else 1.  CDX_UNET2_GROUP=0 switches the mode off, 2 / 4 force a group size (tests, A/B runs)."""
+    forced = os.environ.get("CDX_UNET2_GROUP", "auto")
+    if forced == "0" or (forced == "auto" and (os.environ.get("CDX_UNET2_T") or os.environ.get("CDX_UNET2_NW"))):
+        return 1
+    if not (N_CUS // 2 < batch <= N_CUS) and forced == "auto":
+        return 1
+    for k in (4, 2):
+        if forced in ("auto", str(k)) and -(-batch // (8 * k)) * 8 * k <= N_CUS:
+            return k
+    return 1
+
+
 _scache = weakref.WeakKeyDictionary()
+_gcache2 = weakref.WeakKeyDictionary()
+
+
+def compiled_group2(module, horizon: int, k: int) -> _Compiled2:
+    per = _gcache2.setdefault(module, {})
+    sig = R._signature(module)
+    hit = per.get((horizon, k))
+    if hit is not None and hit.sig == sig:
+        return hit
+    with torch.no_grad():
+        try:
+            comp = _Compiled2(P2.compile_janner2_group(module, horizon, k), sig)
+        except ValueError as e:
+            comp = _Compiled2(None, sig, str(e))
+    per[(horizon, k)] = comp
+    return comp
+
 
 
 def compiled_split2(module, horizon: int, k: int) -> _Compiled2:
@@ -512,13 +549,19 @@ def fused_sample2(solver, net, plan, xt, prior, feed, fix_mask, x_min, x_max, x_
         return None
     dev = xt.device
     comp, parts = plan_for(net, h, b)
-    split, plain = 0, None
-    if not chi and not use_cond and not edm and not comp.prog.compact and R._prof["buf"] is None and _split_ok.get(dev, True):
-        k = split_factor(b)                           # small batches: one trajectory over k workgroups of an XCD
+    split, plain, group = 0, None, False
+    if not chi and not use_cond and not edm and not comp.prog.compact and (R._prof["buf"] is None or os.environ.get("CDX_UNET2_GROUP_PROF") == "1"):
+        k = split_factor(b) if _split_ok.get(dev, True) and R._prof["buf"] is None else 1      # small batches: one trajectory over k workgroups of an XCD
         if k > 1:
             alt = compiled_split2(net, h, k)
             if alt.prog is not None:
                 plain, (comp, parts, split) = (comp, parts), (alt, None, k)
+        elif _group_ok.get(dev, True):
+            k = group_factor(b)                       # one trajectory per CU: k trajectories over the k workgroups of a group
+            if k > 1:
+                alt = compiled_group2(net, h, k)
+                if alt.prog is not None:
+                    plain, (comp, parts, split, group) = (comp, parts), (alt, None, k, True)
     if chi:
         cond = torch.flatten(cond, 1)
         if cond.shape != (b, comp.prog.meta["cond_dim"]):
@@ -544,10 +587,11 @@ def fused_sample2(solver, net, plan, xt, prior, feed, fix_mask, x_min, x_max, x_
         kw = dict(batch=b, x_in=xin, emb=emb, steps_dev=steps_dev, n_steps=len(plan.steps), predict_noise=R._predicts_noise(plan, solver),
                   prior=R._f32c(prior, dev) if fix_mask is not None else None, fix_mask=fix_mask, noise=noise, x_min=x_min, x_max=x_max,
                   x_scale=x_scale, emb_per_traj=use_cond, emb_u=emb_u, cfg_w=w_cfg, edm=edm)
-        launch(comp, x_out=out, parts=parts, split=split, t_per_wg=1 if split else None, **kw)
-        if split and dev not in _split_ok:
-            # First split launch on this device: the mode rests on workgroups 8 apart sharing an XCD (one L2).  Check it ONCE against the
-            # ordinary program on this very request -- a partition mode or dispatcher that maps workgroups differently shows up as a lost
+        launch(comp, x_out=out, parts=parts, split=split, group=group, t_per_wg=1 if split else None, **kw)
+        ok = _group_ok if group else _split_ok
+        if split and dev not in ok:
+            # First split / grouped launch on this device: the modes rest on workgroups 8 apart sharing an XCD (one L2).  Check ONCE against
+            # the ordinary program on this very request -- a partition mode or dispatcher that maps workgroups differently shows up as a lost
             # granule or as different numbers, and the mode stays off for the process instead of failing later.
             ref = torch.empty_like(xin)
             launch(plain[0], x_out=ref, parts=plain[1], **kw)
@@ -556,13 +600,32 @@ def fused_sample2(solver, net, plan, xt, prior, feed, fix_mask, x_min, x_max, x_
                 good = bool(torch.allclose(out, ref, rtol=1e-3, atol=1e-3))
             except RuntimeError:
                 good = False
-            _split_ok[dev] = good
+            ok[dev] = good
             if not good:
+                return ref
+        elif split and _sync_check(group):
+            # The error word of THIS launch, before its result leaves the function: wait for the launch, look, and on a lost
+            # granule serve the request from the ordinary program instead.  Default for the small-batch mode -- its callers (real-time
+            # control, B <= 128) consume the result at once, so the wait costs them nothing; the full-batch grouped mode stays asynchronous
+            # by default (the host work of call n + 1 overlaps the kernel of call n): there a failed exchange stores NaN instead of
+            # trajectories, raises at the next launch / check_split_errors(), and switches the mode off.  CDX_UNET2_SPLIT_SYNC=1 / 0 forces.
+            torch.cuda.current_stream(dev).synchronize()
+            try:
+                check_split_errors(dev, wait=False)
+            except RuntimeError:
+                ref = torch.empty_like(xin)
+                launch(plain[0], x_out=ref, parts=plain[1], **kw)
                 return ref
     return out
 
 
+def _sync_check(group: bool) -> bool:
+    forced = os.environ.get("CDX_UNET2_SPLIT_SYNC")
+    return forced == "1" if forced in ("0", "1") else not group
+
+
 _split_ok = {}       # device -> did the small-batch mode pass its one-time check there (absent: not checked yet)
+_group_ok = {}       # ... the full-batch grouped mode
 
 
 def backbone_forward2(module, x, noise_t, condition=None) -> Optional[torch.Tensor]:

@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define CDX_ABI_VERSION 10
+#define CDX_ABI_VERSION 11
 
 #define CDX_OK 0
 #define CDX_EINVAL (-1)   /* bad argument (null pointer, size out of range, misaligned offset) */
@@ -189,6 +189,13 @@ typedef struct cdx_unet2_launch {
     uint32_t* xflags;
     int32_t* xerr;
     uint32_t xseq0;
+    /* Grouped programs (engine/program2.py:compile_janner2_group; full batches): split_group != 0 with split_k = 2 or 4 -- the split_k
+     * workgroups of a group (same XCD, as above) own split_k TRAJECTORIES, one each; the ops that are bound by the L2 -> CU weight stream
+     * are computed per member for 1/split_k of the output channels of all the group's trajectories (descriptor word W2_XG: CDX2_XG_GOP)
+     * and all-gathered through `xbuf` like the cut ops of a split program.  Grid = ceil(traj_count / (8 * split_k)) * 8 * split_k
+     * workgroups (<= 256, all resident); trajectory of a workgroup = traj_first + group * split_k + member.  A workgroup that loses a
+     * granule sets `xerr` AND stores NaN instead of its result (split programs likewise): a failed exchange never looks like a sample. */
+    int32_t split_group;
 } cdx_unet2_launch;
 int cdx_unet2_run(const cdx_unet2_launch* launch, void* hip_stream);
 

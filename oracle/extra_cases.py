@@ -489,7 +489,35 @@ def edm_classifier_guidance():
 SCENARIOS["edm_classifier_guidance"] = edm_classifier_guidance()
 
 
-def run(name: str, lib_kind: str, device="cpu"):
-    """Outputs of scenario `name` as {key: tensor}; keys starting with '_' are live objects for the caller, not results."""
+def _sample_fp64(agent, lib_kind: str, prior, zs, **kw):
+    """`_sample` with the agent cast to float64 first (weights, tables and draws: the float32 values, cast up) -- the yardstick that
+    tells how far the REFERENCE'S OWN fp32 result is from exact arithmetic on a scenario (gen_golden_extra.fp64_yardstick)."""
+    agent.model.double()
+    agent.model_ema.double()
+    for holder in (agent.model, agent.model_ema):          # (the solvers build their timestep vectors in float32)
+        net = holder["diffusion"]
+        net.forward = (lambda f: lambda x, noise, condition=None: f(x, noise.double(), condition))(net.forward)
+    for k, v in list(vars(agent).items()):
+        if isinstance(v, torch.Tensor) and v.is_floating_point():
+            setattr(agent, k, v.double())
+    kw = {k: (v.double() if isinstance(v, torch.Tensor) and v.is_floating_point() else v) for k, v in kw.items()}
+    torch.set_default_dtype(torch.float64)                  # (only around the call: the scenario's seeded draws are float32 draws)
+    try:
+        return _sample_fp32(agent, lib_kind, prior.double(), [z.double() for z in zs], **kw)
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
+_sample_fp32 = _sample
+
+
+def run(name: str, lib_kind: str, device="cpu", fp64: bool = False):
+    """Outputs of scenario `name` as {key: tensor}; keys starting with '_' are live objects for the caller, not results.
+    `fp64`: the same scenario evaluated in float64 (CPU)."""
+    global _sample
     torch.manual_seed(1234)
-    return (SCENARIOS.get(name) or GPU_ONLY[name])(cases.lib_namespace(lib_kind), lib_kind, device)
+    _sample = _sample_fp64 if fp64 else _sample_fp32
+    try:
+        return (SCENARIOS.get(name) or GPU_ONLY[name])(cases.lib_namespace(lib_kind), lib_kind, device)
+    finally:
+        _sample = _sample_fp32

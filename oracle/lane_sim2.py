@@ -92,6 +92,8 @@ class LaneSim2:
         """`member` >= 0: member view of a split program (one trajectory over k workgroups): this instance runs that member's
         descriptors; `run_forward_split` steps the k instances in lockstep and performs the exchanges."""
         self.p = prog
+        self.member = member
+        self.gk = int(prog.meta.get("group_k", 0))           # grouped program: k trajectories over the k members of a group
         self.blob = prog.blob.detach().cpu().numpy()
         self.buf = prog.ops_buffer
         self.ops = prog.ops if member < 0 else prog.meta["member_ops"][member]
@@ -192,7 +194,11 @@ class LaneSim2:
             cols, kstep, lcol, koff, drow = 4, 4, lane & 3, 0 * lane, 4 * (lane >> 2)
         stage = p.stage_off
         ksplit = int(op[P2.W2_KSPLIT])
-        lds[stage:stage + (ksplit + int(op[P2.W2_KPOST])) * l_out * sstride] = np.nan      # stale data must not be read
+        xg_word = int(op[P2.W2_XG]) if not (flags & (P2.F2_GNBWD | P2.F2_SAVE)) else 0
+        gop = bool(self.gk and (xg_word & P2.XG_GOP))        # grouped op: columns = trajectory x position, W2_GMAP maps them to rows
+        gsh, grows = (int(op[P2.W2_GMAP]) & 255, int(op[P2.W2_GMAP]) >> 8) if gop else (0, 0)
+        l_stage = l_cols if gop else l_out                   # positions per staged K slice
+        lds[stage:stage + (ksplit + int(op[P2.W2_KPOST])) * l_stage * sstride] = np.nan      # stale data must not be read
 
         for item in range(int(op[P2.W2_NITEMS])):             # wave w takes items w, w + 4, ...
             rec = P2.op_item(self.buf, op, item)
@@ -205,7 +211,8 @@ class LaneSim2:
             # per-lane operand offset: LINEAR in the tap thanks to the halo; columns past l_cols sit on halo row 0, step 0
             m = np.stack([col0 + nt * cols + lcol for nt in range(nt_n)])
             valid = m < l_cols
-            row = np.where(valid, m * cstride - pad + P2.HALO2 + tap, 0)
+            mrow = ((m >> gsh) * grows + (m & ((1 << gsh) - 1)) * cstride) if gop else m * cstride
+            row = np.where(valid, mrow - pad + P2.HALO2 + tap, 0)
             assert (row >= 0).all()
             cur = src + row * sstr + koff[None, :] + cc * kstep
             tstep = np.where(valid, sstr, 0) - ccn * kstep
@@ -256,8 +263,28 @@ class LaneSim2:
         bias = emb_row[int(op[P2.W2_BOFF]):int(op[P2.W2_BOFF]) + coutp] if flags & P2.F2_BIAS_EMB else par(P2.W2_BOFF)
         act_id = (flags >> P2.F2_ACT_SHIFT) & 15              # 0: Mish after a GroupNorm, nothing otherwise
         vals = {}
-        xg = int(op[P2.W2_XG]) if not (flags & (P2.F2_GNBWD | P2.F2_SAVE)) else 0      # split programs: this member's lane groups
+        xg = xg_word                                          # split / grouped programs: this member's lane groups
         g_lo, g_hi = (xg & 255, (xg >> 8) & 255) if xg else (0, P2.GROUPS2)
+        if gop:
+            # grouped op: the 8 half-waves are (trajectory, lane group of this member) pairs; everything below runs per trajectory on
+            # the member's channels, reading stage column t * l_out + pos (channels relative to the member's first one)
+            gpm = g_hi - g_lo
+            assert gpm * self.gk == P2.GROUPS2
+            for t in range(self.gk):
+                self._epilogue_rest(op, emb_row, par, bias, act_id, g_lo, g_hi, stage + t * l_out * sstride - g_lo * cg, l_stage,
+                                    dst + t * grows * dstride, int(op[P2.W2_RES]) + t * grows * int(op[P2.W2_RES_STRIDE]), {})
+            return
+        self._epilogue_rest(op, emb_row, par, bias, act_id, g_lo, g_hi, stage, l_out, dst, int(op[P2.W2_RES]), vals)
+
+    def _epilogue_rest(self, op, emb_row, par, bias, act_id, g_lo, g_hi, stage, l_stage, dst, res_off, vals):
+        p, lds = self.p, self.lds
+        c_out, l_out, coutp = int(op[P2.W2_COUT]), int(op[P2.W2_LOUT]), int(op[P2.W2_COUTP])
+        sstride, flags, ksplit = int(op[P2.W2_SSTRIDE]), int(op[P2.W2_FLAGS]), int(op[P2.W2_KSPLIT])
+        cg = coutp // P2.GROUPS2
+        shift, nk = int(op[P2.W2_CG4_SHIFT]), int(op[P2.W2_NK])
+        cg4 = cg // 4
+        nv = cg4 * l_out
+        dstride, coff = int(op[P2.W2_DST_STRIDE]), 0
         for tid in range(256):
             g, li = tid >> 5, tid & 31
             if not g_lo <= g < g_hi:
@@ -269,7 +296,7 @@ class LaneSim2:
                 c, pos = g * cg + 4 * (i & (cg4 - 1)), i >> shift
                 v = bias[c:c + 4].copy()
                 for ks in range(ksplit):
-                    a = stage + (ks * l_out + pos) * sstride + c
+                    a = stage + (ks * l_stage + pos) * sstride + c
                     v = v + lds[a:a + 4]
                 vals[(g, pos, c)] = v
         if flags & P2.F2_GNBWD:
@@ -330,11 +357,11 @@ class LaneSim2:
             if kpost:                                         # extra conv(s) added after the norm: bias + their staged partials
                 pv = par(P2.W2_PBIAS)[c:c + 4].copy()
                 for ks in range(ksplit, ksplit + kpost):
-                    a = stage + (ks * l_out + pos) * sstride + c
+                    a = stage + (ks * l_stage + pos) * sstride + c
                     pv = pv + lds[a:a + 4]
                 v = v + pv
             if flags & P2.F2_RES:
-                a = int(op[P2.W2_RES]) + (pos + P2.HALO2) * int(op[P2.W2_RES_STRIDE]) + c
+                a = res_off + (pos + P2.HALO2) * int(op[P2.W2_RES_STRIDE]) + c
                 v = v + lds[a:a + 4]
             if flags & P2.F2_OUT_DIV:
                 v = (v / np.int32(op[P2.W2_ODIV]).view(np.float32)).astype(np.float32)
@@ -344,6 +371,15 @@ class LaneSim2:
                     lds[dst + (pos + P2.HALO2) * dstride + coff + c + j] = v[j]
         for r in (0, 1, l_out + P2.HALO2, l_out + P2.HALO2 + 1):        # wave w rewrites halo row w of the destination
             lds[dst + r * dstride: dst + (r + 1) * dstride] = 0.0
+        xgw = int(op[P2.W2_XG]) if not (flags & (P2.F2_GNBWD | P2.F2_SAVE)) else 0
+        if self.gk and (xgw & P2.XG_TRAJ):
+            # an ordinary op that wrote this member's trajectory into a group slot: the halo rows of the OTHER sub-slots too (the exchange
+            # brings their data rows only)
+            grows = int(op[P2.W2_GMAP]) >> 8
+            base = dst - self.member * grows * dstride
+            for t in range(self.gk):
+                for r in (0, 1, l_out + P2.HALO2, l_out + P2.HALO2 + 1):
+                    lds[base + (t * grows + r) * dstride: base + (t * grows + r + 1) * dstride] = 0.0
 
     def _epilogue_bwd(self, op, vals, par, cg, c_out, l_out):
         """F2_GNBWD: v (+ residual slot) -> [dst2]; g_xhat = v Mish'(gamma x_hat + beta) gamma; dst = rstd (g_xhat - mean(g_xhat) -
@@ -458,3 +494,59 @@ def run_forward_split(sims, emb_row):
                     for c in range(g * cg, min((g + 1) * cg, c_out)):
                         s.lds[dst + (pos + P2.HALO2) * dstr + c] = src.lds[sd + (pos + P2.HALO2) * sds + c]
     return sims[0].read_slot(p.pred_off, p.pred_stride, p.horizon, p.dim)
+
+
+def run_forward_group(sims, emb_row):
+    """One forward of a GROUPED program (engine/program2.py:compile_janner2_group): `sims[m]` = LaneSim2(prog, member=m), member m loaded
+    with trajectory m of the group.  The members step through the op list together.  After a grouped op (XG_GOP) every member holds its
+    lane groups of ALL k trajectories and receives the other lane groups from the members that computed them; after an ordinary op that
+    wrote the member's own trajectory into a group slot (XG_TRAJ) every member receives the other members' whole trajectories -- the two
+    all-gathers the kernel performs through the group's tile in L2.  Returns the k prediction slots (member m: trajectory m)."""
+    p = sims[0].p
+    k = len(sims)
+    assert k == p.meta["group_k"]
+    for i in range(len(sims[0].ops)):
+        for s in sims:
+            s.run_op(s.ops[i], emb_row)
+        xgs = [int(s.ops[i][P2.W2_XG]) for s in sims]
+        if not any(x & P2.XG_XCHG for x in xgs):
+            continue
+        assert all(x & P2.XG_XCHG for x in xgs), "an op is exchanged by every member or by none"
+        op = sims[0].ops[i]
+        c_out, l_out, coutp = int(op[P2.W2_COUT]), int(op[P2.W2_LOUT]), int(op[P2.W2_COUTP])
+        cg = coutp // P2.GROUPS2
+        grows = int(op[P2.W2_GMAP]) >> 8
+        assert grows == l_out + 2 * P2.HALO2
+        if xgs[0] & P2.XG_GOP:
+            owner = {}
+            for m, xg in enumerate(xgs):
+                assert xg & P2.XG_GOP
+                for g in range(xg & 255, (xg >> 8) & 255):
+                    assert g not in owner
+                    owner[g] = m
+            assert sorted(owner) == list(range(P2.GROUPS2))
+            for m, s in enumerate(sims):
+                dst, dstr = int(s.ops[i][P2.W2_DST]), int(s.ops[i][P2.W2_DST_STRIDE])
+                for g, src_m in owner.items():
+                    if src_m == m:
+                        continue
+                    src = sims[src_m]
+                    sd = int(src.ops[i][P2.W2_DST])
+                    for t in range(k):
+                        for pos in range(l_out):
+                            a = (t * grows + pos + P2.HALO2) * dstr
+                            s.lds[dst + a + g * cg: dst + a + min((g + 1) * cg, c_out)] = src.lds[sd + a + g * cg: sd + a + min((g + 1) * cg, c_out)]
+        else:
+            assert all(x & P2.XG_TRAJ for x in xgs)
+            # every member's W2_DST points at ITS sub-slot: the group slot starts `m` sub-slots before it
+            dstr = int(op[P2.W2_DST_STRIDE])
+            bases = [int(s.ops[i][P2.W2_DST]) - m * grows * dstr for m, s in enumerate(sims)]
+            assert len(set(bases)) == 1
+            for m, s in enumerate(sims):
+                for t in range(k):
+                    if t == m:
+                        continue
+                    for pos in range(l_out):             # data rows only, real channels only: the receiving member zeroes the halo rows
+                        lo = bases[0] + (t * grows + pos + P2.HALO2) * dstr      # of every sub-slot itself (kernel: halo waves)
+                        s.lds[lo:lo + c_out] = sims[t].lds[lo:lo + c_out]
+    return [s.read_slot(p.pred_off, p.pred_stride, p.horizon, p.dim) for s in sims]

@@ -120,11 +120,16 @@ def test_unet2_validation_fails_loudly(lib):
     M = runtime2.CdxUnet2Launch(ops=8, wblob=8, x_in=8, x_out=8, emb=8, n_ops=1, batch=4, horizon=4, dim=4, traj_floats=64,
                                 traj_per_wg=1, n_waves=8)
     M.split_k = 3
-    assert lib.cdx_unet2_run(ctypes.byref(M), None) == -1 and b"split program" in lib.cdx_last_error()
+    assert lib.cdx_unet2_run(ctypes.byref(M), None) == -1 and b"split / grouped program" in lib.cdx_last_error()
     M.split_k, M.xbuf, M.xerr, M.xchg_floats = 4, 8, 8, 6                                           # granules are float4 pairs
-    assert lib.cdx_unet2_run(ctypes.byref(M), None) == -1 and b"split program" in lib.cdx_last_error()
+    assert lib.cdx_unet2_run(ctypes.byref(M), None) == -1 and b"split / grouped program" in lib.cdx_last_error()
     M.xchg_floats, M.batch = 1024, 72                                                               # 72 trajectories x 4 members > 256 workgroups
     assert lib.cdx_unet2_run(ctypes.byref(M), None) == -1 and b"resident" in lib.cdx_last_error()
+    M.split_group, M.batch = 1, 257                                                                 # grouped: 257 trajectories need 288 workgroups
+    assert lib.cdx_unet2_run(ctypes.byref(M), None) == -1 and b"resident" in lib.cdx_last_error()
+    M.split_k = 0                                                                                   # a group needs its size
+    assert lib.cdx_unet2_run(ctypes.byref(M), None) == -1 and b"split_group without split_k" in lib.cdx_last_error()
+    M.split_group, M.split_k = 0, 4
     M.batch, M.emb_per_traj = 4, 1                                                                  # conditional programs are not split
     assert lib.cdx_unet2_run(ctypes.byref(M), None) == -1 and b"unconditional" in lib.cdx_last_error()
     M.split_k, M.emb_per_traj, M.mlp, M.traj_per_wg = 0, 0, 1, 2

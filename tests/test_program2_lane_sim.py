@@ -9,6 +9,7 @@ import torch
 from cleandiffuser_amd.engine import program2 as P2
 from oracle import cases
 from oracle.lane_sim2 import LaneSim2, emb_table
+from cleandiffuser_amd.utils import load_synth
 from conftest import golden_path
 
 
@@ -480,3 +481,48 @@ def test_lane_sim2_split_program_reproduces_reference_forward(name, k, amd_lib, 
         for s in sims[1:]:                               # every member ends with the same prediction
             np.testing.assert_array_equal(s.read_slot(prog.pred_off, prog.pred_stride, prog.horizon, prog.dim),
                                           sims[0].read_slot(prog.pred_off, prog.pred_stride, prog.horizon, prog.dim))
+
+
+@pytest.mark.parametrize("k", [2, 4])
+def test_lane_sim2_grouped_program_reproduces_reference_forward(k, amd_lib):
+    """k trajectories over the k workgroups of a group (full-batch mode, VERDICT r3 'next' #2): the config-2 net's stream-bound layers at
+    4 positions are GROUPED ops -- a member computes its 1/k of the output channels for all k trajectories (16 or 8 tile columns), the
+    slots they touch hold the k trajectories side by side, the members all-gather after every grouped op and after the ordinary op that
+    feeds the first one.  The twin steps the k member views in lockstep on k DIFFERENT trajectories of the reference fixture (on
+    NaN-poisoned LDS: an unwritten halo row, pad channel or sub-slot shows up) and must land on the reference's first forward for each;
+    a second forward on re-poisoned LDS must reproduce the first bit for bit."""
+    from oracle.lane_sim2 import run_forward_group
+    net = load_synth(amd_lib.JannerUNet1d(23, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2, 2], kernel_size=5), 53)
+    prog = P2.compile_janner2_group(net, 32, k)
+    plain = P2.compile_janner2(net, 32, nw=8)
+    assert prog.lds_bytes(1) <= 160 * 1024 and prog.meta["group_k"] == k and len(prog.meta["member_ops"]) == k
+    n_g = sum(1 for op in prog.ops if int(op[P2.W2_XG]) & P2.XG_GOP)
+    n_t = sum(1 for op in prog.ops if int(op[P2.W2_XG]) & P2.XG_TRAJ)
+    assert n_g == 10 and n_t == 1, (n_g, n_t)            # the ten 0.6-1.3 MB layers at L = 4; the downsample conv that feeds them
+    assert prog.macs_per_forward == plain.macs_per_forward
+    g = torch.Generator().manual_seed(17)
+    xs = 0.7 * torch.randn(k, 32, 23, generator=g)
+    t = torch.tensor([11])
+    with torch.no_grad():
+        ref = net(xs, t.expand(k), None).numpy()
+        row = emb_table(prog, net.map_noise(t).numpy())[0]
+    sims = [LaneSim2(prog, member=m) for m in range(k)]
+    for m, s in enumerate(sims):
+        s.load_x(xs[m].numpy())
+    outs = run_forward_group(sims, row)
+    for m in range(k):
+        np.testing.assert_allclose(outs[m], ref[m], rtol=2e-5, atol=2e-5, err_msg=f"member {m}")
+    for s in sims:
+        s.poison_arena()
+    again = run_forward_group(sims, row)
+    assert all(np.array_equal(a, b) for a, b in zip(outs, again))
+
+
+def test_grouped_program_of_other_shapes_compiles_or_refuses_cleanly(amd_lib):
+    """Nets whose deepest level does not offer a grouped op (too few channels for whole lane groups per member, a horizon whose deepest
+    level is longer than 16 / k positions) must answer ValueError -- the signal that keeps a request on the ordinary program."""
+    small = load_synth(amd_lib.JannerUNet1d(6, model_dim=16, emb_dim=16, dim_mult=[1, 2], kernel_size=5), 3)
+    with pytest.raises(ValueError):
+        P2.compile_janner2_group(small, 32, 4)           # deepest level: 16 positions x 32 channels
+    with pytest.raises(ValueError):
+        P2.compile_janner2_group(small, 32, 3)

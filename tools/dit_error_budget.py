@@ -133,7 +133,7 @@ def part_b():
     for name in ("baseline_cfg4_tied", "baseline_cfg4"):
         nat = extra_cases.run(name, "amd", DEV)["x"].double().cpu()
         c32 = extra_cases.run(name, "amd", "cpu")["x"].double()
-        c64 = _run_fp64(name)
+        c64 = extra_cases.run(name, "amd", "cpu", fp64=True)["x"].double()
         fix = torch.from_numpy(np.load(os.path.join(golden, f"extra_{name}.npz"))["x"]).double()
         print(f"{name:28s} {float(fix.abs().max()):8.2f} {float((nat - c64).abs().max()):14.3e} {float((c32 - c64).abs().max()):16.3e} "
               f"{float((nat - c32).abs().max()):18.3e} {float((nat - fix).abs().max()):17.3e}")
@@ -158,29 +158,10 @@ def part_b():
         finally:
             torch.set_default_dtype(torch.float32)
         outs[tag] = x.double().cpu()
-    fix = torch.from_numpy(np.load(os.path.join(golden, f"{name}.npz"))["x"]).double()
+    fix = torch.from_numpy(np.load(os.path.join(golden, f"{name}.npz"))["x_out"]).double()
     print(f"{name:28s} {float(fix.abs().max()):8.2f} {float((outs['nat'] - outs['c64']).abs().max()):14.3e} "
           f"{float((outs['c32'] - outs['c64']).abs().max()):16.3e} {float((outs['nat'] - outs['c32']).abs().max()):18.3e} "
           f"{float((outs['nat'] - fix).abs().max()):17.3e}")
-
-
-def _run_fp64(name):
-    """extra_cases scenario `name` through this package's PyTorch executor in float64 (weights and draws: the fp32 values, cast up)."""
-    orig_sample = extra_cases._sample
-
-    def sample64(agent, lib_kind, prior, zs, **kw):
-        _to_fp64(agent)
-        kw = {k: (v.double() if isinstance(v, torch.Tensor) and v.is_floating_point() else v) for k, v in kw.items()}
-        torch.set_default_dtype(torch.float64)      # (only around the call: the scenario's seeded draws are made in float32 and cast up)
-        try:
-            return agent.sample(prior.double(), noise=[z.double() for z in zs], **kw)
-        finally:
-            torch.set_default_dtype(torch.float32)
-    extra_cases._sample = sample64
-    try:
-        return extra_cases.run(name, "amd", "cpu")["x"].double()
-    finally:
-        extra_cases._sample = orig_sample
 
 
 if __name__ == "__main__":

@@ -1,5 +1,7 @@
 """Per-op cycle breakdown of the v2 fused kernel (workgroup 0, second forward) -- tuning aid.
-Usage (GPU box): python tools/op_profile2.py [batch] [traj_per_wg] [n_waves] > gpurun_out/op_profile2.txt"""
+Usage (GPU box): python tools/op_profile2.py [batch] [traj_per_wg] [n_waves] > gpurun_out/op_profile2.txt
+                 python tools/op_profile2.py 256 group4    (the grouped program, k = 4: workgroup 0 = member 0 of group 0; the `epi`
+                                                            column of a grouped op includes its exchange)"""
 import os
 import sys
 
@@ -12,7 +14,12 @@ from cleandiffuser_amd.engine import program2 as P2, runtime, runtime2  # noqa: 
 
 def main():
     batch = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-    if len(sys.argv) > 2:
+    group = 0
+    if len(sys.argv) > 2 and sys.argv[2].startswith("group"):
+        group = int(sys.argv[2][5:])
+        os.environ["CDX_UNET2_GROUP"] = str(group)
+        os.environ["CDX_UNET2_GROUP_PROF"] = "1"
+    elif len(sys.argv) > 2:
         os.environ["CDX_UNET2_T"] = sys.argv[2]
     if len(sys.argv) > 3:
         os.environ["CDX_UNET2_NW"] = sys.argv[3]
@@ -25,6 +32,8 @@ def main():
         agent.sample(prior, noise=[z0], **kw)
     comp, parts = runtime2.plan_for(agent.model_ema["diffusion"], 32, batch)
     prog, tpw = comp.prog, parts[0][2]
+    if group:
+        prog, tpw = runtime2.compiled_group2(agent.model_ema["diffusion"], 32, group).prog, 1
     n_ops = len(prog.ops)
     buf = torch.zeros(n_ops * 8 + 2, dtype=torch.int64, device=dev)
     runtime.set_profile_buffer(buf)
@@ -34,7 +43,7 @@ def main():
     t = buf.cpu().numpy()
     total = t[n_ops * 8 + 1] - t[n_ops * 8]
     fwd = t[(n_ops - 1) * 8 + 3] - t[0]
-    print(f"batch={batch} T={tpw} waves={prog.nw} kernel cycles (wg0) = {total}  traj_bytes={prog.traj_floats * 4}")
+    print(f"batch={batch} T={tpw} waves={prog.nw} group={group} kernel cycles (wg0) = {total}  traj_bytes={prog.traj_floats * 4}")
     print(f"first forward cycles = {fwd}  ({fwd * 20 / total:.2%} of kernel if all 20 equal)")
     print(f"{'op':>3} {'cout':>4} {'L':>3} {'mode':>4} {'nt':>2} {'ks':>2} {'nq/item':>7} {'kloop':>7} {'sync':>6} {'epi':>6} {'total':>7}")
     tk = ts = te = 0
@@ -43,7 +52,9 @@ def main():
         nq = int(P2.op_item(prog.ops_buffer, op, 0)[P2.I2_NQ])
         k, s, e = s1 - s0, s2 - s1, s3 - s2
         tk, ts, te = tk + k, ts + s, te + e
-        print(f"{i:3d} {op[P2.W2_COUT]:4d} {op[P2.W2_LOUT]:3d} {'4x4' if op[P2.W2_MODE] else '16':>4} {op[P2.W2_NT]:2d} {op[P2.W2_KSPLIT]:2d} "
+        xg = int(op[P2.W2_XG])
+        tag = "G" if xg & P2.XG_GOP else ("X" if xg & P2.XG_XCHG else " ")
+        print(f"{i:3d}{tag}{op[P2.W2_COUT]:4d} {op[P2.W2_LOUT]:3d} {'4x4' if op[P2.W2_MODE] else '16':>4} {op[P2.W2_NT]:2d} {op[P2.W2_KSPLIT]:2d} "
               f"{nq:7d} {k:7d} {s:6d} {e:6d} {s3 - s0:7d} | decode {k4 - s0:5d} operands {k5 - k4:5d} mfma {k6 - k5:6d} stage {k7 - k6:5d} prefetch {s1 - k7:5d}")
     print(f"totals: kloop={tk} sync={ts} epilogue={te}  sum={tk + ts + te}")
 
