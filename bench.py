@@ -177,13 +177,18 @@ def cpu_baseline_subprocess(timeout_s=240):
 def recorded_traffic():
     """HBM-side bytes per launch of the fused kernel from the committed PMC pass (rocprofv3 --pmc cannot run inside this
     process); null when the record is absent."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f)
-            return {"traffic": rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"], "traffic_unit": "bytes/launch",
-                    "traffic_kernel": rec.get("kernel"),
-                    "traffic_source": f"profiles/{name} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected)"}
+            out = {"traffic": rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"], "traffic_unit": "bytes/launch",
+                   "traffic_kernel": rec.get("kernel"),
+                   "traffic_source": f"profiles/{name} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected)"}
+            # (round 4: the matrix-pipe and L2 counters of the same kernel, each from its own --pmc pass, next to the HBM-side bytes)
+            for key in ("mfma_busy_frac", "l2_bytes_per_launch", "l2_hit_frac"):
+                if key in rec:
+                    out[key] = rec[key]
+            return out
         except (OSError, KeyError, ValueError):
             continue
     return {"traffic": None}
@@ -263,6 +268,70 @@ def other_configs(device):
         out.append({"name": "config3", "error": f"{type(e).__name__}: {e}"})
     big("config4_shard512", bc.cfg4, "cdx_gemm_kernel", B=512)
     big("config5_chunk16384", bc.cfg5, "cdx_gemm_kernel", reps=1, B=16384)
+    # config 5 as one rank of the 8-GPU run sees it: 1 M samples / 8 = 125 000 rows in ONE sample() call (cdx_resmlp_run cuts it into
+    # 16 384-row chunks itself), and at the real hopper transition width D = 27 (report both)
+    big("config5_shard125000", bc.cfg5, "cdx_gemm_kernel (8 chunks of <= 16 384 rows inside one cdx_resmlp_run call)", reps=1, B=125000)
+    big("config5_D27_chunk16384", bc.cfg5, "cdx_gemm_kernel", reps=1, B=16384, D=27)
+    # row a16: Diffusion Policy's transformer at the dp_pusht size and step count
+    big("chitransformer_pusht_B1024", bc.cfgT, "cdx_gemm_kernel + cdx_attention_mfma_kernel + cross-attention (cdx_chitf_run)", reps=2, B=1024)
+    # row f4: one training step of config 2 -- which side of it is native is in the entry
+    try:
+        from cleandiffuser_amd.engine import train as native_train
+        has_native = True
+    except ImportError:
+        has_native = False
+    for native in ([True, False] if has_native else [None]):
+        try:
+            label, call, b = bc.cfgU(256, native_backward=native)
+            for _ in range(3):
+                call()
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(20):
+                call()
+            torch.cuda.synchronize(device)
+            dt = (time.perf_counter() - t0) / 20
+            how = ("forward / backward in the library's kernels (engine/train.py)" if native else
+                   "forward / backward on PyTorch autograd (ATen / MIOpen kernels)")
+            out.append({"name": "config2_update_B256" + ("" if native in (True, None) else "_autograd"), "workload": label,
+                        "value": 1.0 / dt, "unit": "update_steps/s", "ms_per_call": 1e3 * dt,
+                        "what": how + "; gradient-norm clip + AdamW + EMA: cdx_optim_f32 (3 launches)"})
+        except Exception as e:  # noqa: BLE001
+            out.append({"name": "config2_update_B256", "error": f"{type(e).__name__}: {e}"})
+    os.environ.pop("CDX_TRAIN_NATIVE", None)
+    return out
+
+
+def predicted_scaling(agent, device):
+    """What `bench.py --gpus N` should report on an N-GPU node, predicted on ONE GPU (VERDICT r3 'next' #7; the driver measures the
+    real curve when it has an 8-GPU node): the data path of N ranks is `sample()` on ceil(B / N) trajectories per rank plus ONE RCCL
+    all-gather of the result (cleandiffuser_amd/distributed.py), so value(N) = B / (latency(B / N) + all-gather(N, B)).  The
+    latencies are MEASURED here (the same call, this GPU, the batch a rank would get); the all-gather is a MODEL: 30 us of RCCL
+    launch latency + the bytes a rank receives at 60 GB/s (a conservative ring rate over one 153 GB/s xGMI link) -- under 2 % of the
+    call at either batch, the prediction hangs on the measured latencies."""
+    out = {"model": "value(N) = B / (measured sample() latency at ceil(B / N) trajectories on this GPU + 0.03 ms + received bytes / 60 GB/s)"}
+    for gb in (256, 3200):
+        rows = []
+        for n in (1, 2, 4, 8):
+            b = -(-gb // n)
+            prior, _ = make_inputs(device, 777, b)
+            kw = dict(solver="ddim", n_samples=b, sample_steps=SAMPLE_STEPS, temperature=0.5)
+            for _ in range(3):
+                agent.sample(prior, **kw)
+            torch.cuda.synchronize(device)
+            reps = 12 if b <= 800 else 4
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                agent.sample(prior, **kw)
+            torch.cuda.synchronize(device)
+            lat = 1e3 * (time.perf_counter() - t0) / reps
+            gather = 0.0 if n == 1 else 0.03 + (gb - b) * HORIZON * DIM * 4 / 60e9 * 1e3
+            rows.append({"n_gpus": n, "trajectories_per_gpu": b, "sample_ms": lat, "allgather_ms_model": gather,
+                         "value": gb / (lat + gather) * 1e3})
+        for r in rows:
+            r["speedup"] = r["value"] / rows[0]["value"]
+            r["efficiency"] = r["speedup"] / r["n_gpus"]
+        out[f"global_batch_{gb}"] = rows
     return out
 
 
@@ -384,17 +453,25 @@ def main():
         launch_b = BATCH if dist is None else cdist.shard_bounds(BATCH, 0, world)[1]      # trajectories one launch of rank 0 processes
         achieved = FLOPS_PER_TRAJ * launch_b / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         from cleandiffuser_amd.engine import runtime2
-        comp, parts = runtime2.plan_for(agent.model_ema["diffusion"], HORIZON, launch_b)
-        tpw = parts[0][2]
-        kname = f"cdx_unet2_kernel<{tpw}, {comp.prog.nw}> ({tpw} trajectories, {comp.prog.nw} wave64 per workgroup)"
-        # second roofline of the same launch: every workgroup streams the whole packed weight set from L2 once per denoiser
-        # forward (activations never leave LDS).  With one trajectory per CU -- all B = 256 allows -- THIS is the binding
-        # limit: MI355X_MICROARCH.md gives 34.5 TB/s aggregate L2 bandwidth
-        wbytes = 4.0 * comp.prog.meta["blob_floats"]
-        n_wg = sum(-(-cnt // t) for _, cnt, t in parts)
+        route = runtime2.route_info(agent.model_ema["diffusion"], HORIZON, launch_b, device)
+        comp, n_wg = route["comp"], route["workgroups"]
+        if route["mode"] == "grouped":
+            kname = (f"cdx_unet2_kernel<1, 8, ..., split> as a GROUPED program: {route['k']} trajectories over the {route['k']} workgroups of a "
+                     f"group on one XCD, the {comp.prog.meta['n_gops']} stream-bound layers computed per member for 1/{route['k']} of the output "
+                     "channels of all the group's trajectories (16 tile columns), all-gathered through L2")
+        elif route["mode"] == "split":
+            kname = f"cdx_unet2_kernel<1, 8, ..., split>: one trajectory over {route['k']} workgroups of an XCD"
+        else:
+            tpw = route["parts"][0][2]
+            kname = f"cdx_unet2_kernel<{tpw}, {comp.prog.nw}> ({tpw} trajectories, {comp.prog.nw} wave64 per workgroup)"
+        # second roofline of the same launch: what the workgroups stream from L2 (activations never leave LDS).  One trajectory per
+        # workgroup re-streams the whole packed weight set per forward and CU -- at B = 256 THAT was the binding limit through round 3
+        # (56 % of the 34.5 TB/s aggregate L2 bandwidth of MI355X_MICROARCH.md); the grouped program streams 1/k of the large layers
+        wbytes = float(route["stream_bytes_per_workgroup_forward"])
         l2_bytes = wbytes * n_wg * SAMPLE_STEPS
         l2 = {"bound": "l2", "bytes_per_launch": l2_bytes, "achieved": l2_bytes / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0,
-              "peak": 34.5, "unit": "TB/s", "weight_bytes_per_forward": wbytes, "workgroups": n_wg}
+              "peak": 34.5, "unit": "TB/s", "weight_bytes_per_workgroup_forward": wbytes,
+              "packed_weight_bytes": 4.0 * comp.prog.meta["blob_floats"], "workgroups": n_wg, "mode": route["mode"], "group": route["k"]}
         l2["frac"] = l2["achieved"] / l2["peak"]
         out = {
             "metric": "denoised trajectories/sec @ (B=256,H=32,D=23) 20-step DDIM",
@@ -422,6 +499,7 @@ def main():
         if strong is not None:
             out["strong_scaling"], out["weak_scaling"] = strong, weak
         if world == 1 and not args.no_other_configs:
+            out["predicted_scaling"] = predicted_scaling(agent, device)
             out["other_configs"] = other_configs(device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_subprocess()

@@ -97,8 +97,12 @@ W2_XG = 28                    # forward ops of a SPLIT program (one trajectory o
 # that wrote the member's own trajectory into a group slot -- the exchange gathers whole trajectories instead of channel ranges.
 XG_XCHG, XG_GOP, XG_TRAJ = 1 << 16, 1 << 17, 1 << 18
 W2_GMAP = 25                  # forward ops of a grouped program: alias of W2_SAVE -- log2(positions per trajectory) | rows per sub-slot << 8
-GROUP_MIN_BYTES = int(os.environ.get("CDX_UNET2_GROUP_MIN_KB", "400")) * 1024   # an op is grouped only if it streams at least this many
-                                                                                 # weight bytes (an exchange costs a few thousand cycles)
+GROUP_MIN_BYTES = None        # an op is grouped only if it streams at least this many weight bytes (an exchange costs ~3.6 k cycles);
+                              # None: CDX_UNET2_GROUP_MIN_KB (default 400), read when a program is compiled; tests set a number
+
+
+def group_min_bytes() -> int:
+    return GROUP_MIN_BYTES if GROUP_MIN_BYTES is not None else int(os.environ.get("CDX_UNET2_GROUP_MIN_KB", "400")) * 1024
 W2_CGREAL4 = 29               # F2_COLNORM ops: alias of W2_DST2_STRIDE -- float4 items of a lane group that hold REAL channels (0 = all):
                               # a per-sample GroupNorm whose groups are narrower than the lane group keeps zero pad channels out of its variance
 
@@ -301,7 +305,7 @@ class _Builder2:
             w_bytes = 4 * (w_eff.numel() + sum(ex["w_eff"].numel() for ex in (extra or [])))
             gop = (self.grouped and self.member[1] > 1 and stride == 1 and bwd is None and save is None and not col_norm
                    and dst.gcap and all(a.gcap and a.length == l_out for a in list(srcs) + ex_srcs) and (res is None or res.gcap)
-                   and w_bytes >= GROUP_MIN_BYTES)
+                   and w_bytes >= group_min_bytes())
             if gop:
                 l_cols = self.member[1] * l_out
         if len(phases) != 1 or transposed:

@@ -423,7 +423,8 @@ _gcache2 = weakref.WeakKeyDictionary()
 def compiled_group2(module, horizon: int, k: int) -> _Compiled2:
     per = _gcache2.setdefault(module, {})
     sig = R._signature(module)
-    hit = per.get((horizon, k))
+    key = (horizon, k, P2.group_min_bytes())
+    hit = per.get(key)
     if hit is not None and hit.sig == sig:
         return hit
     with torch.no_grad():
@@ -431,7 +432,7 @@ def compiled_group2(module, horizon: int, k: int) -> _Compiled2:
             comp = _Compiled2(P2.compile_janner2_group(module, horizon, k), sig)
         except ValueError as e:
             comp = _Compiled2(None, sig, str(e))
-    per[(horizon, k)] = comp
+    per[key] = comp
     return comp
 
 
@@ -626,6 +627,38 @@ def _sync_check(group: bool) -> bool:
 
 _split_ok = {}       # device -> did the small-batch mode pass its one-time check there (absent: not checked yet)
 _group_ok = {}       # ... the full-batch grouped mode
+
+
+def stream_bytes_per_forward(prog: P2.Program2, member: int = 0) -> int:
+    """Bytes of packed weight records ONE workgroup streams from L2 per denoiser forward: the sum of its work items' record counts
+    (1 KiB each).  An ordinary program: the whole packed set; member views of split / grouped programs: 1/k of the ops they cut."""
+    ops = prog.meta["member_ops"][member] if "member_ops" in prog.meta else prog.ops
+    return 1024 * sum(int(P2.op_item(prog.ops_buffer, op, j)[P2.I2_NQ]) for op in ops for j in range(int(op[P2.W2_NITEMS])))
+
+
+def route_info(net, horizon: int, batch: int, device) -> dict:
+    """How an unconditional JannerUNet1d sampling loop of `batch` trajectories is launched on `device` right now -- what fused_sample2
+    decides, for reporting (bench.py's `roofline`): mode "grouped" (k trajectories over the k workgroups of a group), "split" (one
+    trajectory over k workgroups) or "plain"; the program, the launch parts, the number of workgroups and the weight bytes a workgroup
+    streams per forward."""
+    comp, parts = plan_for(net, horizon, batch)
+    mode, k = "plain", 1
+    if not comp.prog.compact and R._prof["buf"] is None:
+        ks = split_factor(batch) if _split_ok.get(device, True) else 1
+        if ks > 1 and compiled_split2(net, horizon, ks).prog is not None:
+            mode, k, comp, parts = "split", ks, compiled_split2(net, horizon, ks), None
+        elif ks == 1 and _group_ok.get(device, True):
+            kg = group_factor(batch)
+            if kg > 1 and compiled_group2(net, horizon, kg).prog is not None:
+                mode, k, comp, parts = "grouped", kg, compiled_group2(net, horizon, kg), None
+    if mode == "split":
+        n_wg = -(-batch // 8) * 8 * k
+    elif mode == "grouped":
+        n_wg = -(-batch // (8 * k)) * 8 * k
+    else:
+        n_wg = sum(-(-cnt // t) for _, cnt, t in parts)
+    return {"mode": mode, "k": k, "comp": comp, "parts": parts, "workgroups": n_wg,
+            "stream_bytes_per_workgroup_forward": stream_bytes_per_forward(comp.prog)}
 
 
 def backbone_forward2(module, x, noise_t, condition=None) -> Optional[torch.Tensor]:

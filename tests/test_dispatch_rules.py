@@ -91,3 +91,42 @@ def test_sharded_sample_draws_the_solver_default_number_of_steps(monkeypatch):
     distributed.sharded_sample(DiscreteDiffusionSDE(net, None, diffusion_steps=1000), torch.zeros(2, 8, 6), seed=1, solver="ddim")
     distributed.sharded_sample(DDPM(net, None, diffusion_steps=7), torch.zeros(2, 8, 6), seed=1)
     assert seen == [6, 8]
+
+
+def test_weight_signature_sees_every_kind_of_change():
+    """runtime._signature keys every packed-weight / program cache.  It no longer walks the module tree per call (round 4: that walk was
+    1.6 of the 1.7 ms of host time of a steady-state sample() call), so every way weights can change must still move it: an in-place
+    update (version counter), a `.data` swap (pointer), a replaced Parameter object, a replaced / added submodule, a buffer update, the
+    explicit epoch -- and it must NOT move when nothing changed."""
+    import torch
+    from cleandiffuser_amd.engine import runtime as R
+    from cleandiffuser_amd.nn_diffusion import JannerUNet1d
+    from cleandiffuser_amd.utils import invalidate_weights
+    net = JannerUNet1d(6, model_dim=16, emb_dim=16, dim_mult=[1, 2], kernel_size=5)
+    s0 = R._signature(net)
+    assert R._signature(net) == s0 and len(s0) == 1 + len(list(net.parameters())) + len(list(net.buffers()))
+    seen = {s0}
+
+    def changed(what):
+        s = R._signature(net)
+        assert s not in seen, what
+        assert R._signature(net) == s, what + " (not stable)"
+        seen.add(s)
+    with torch.no_grad():
+        next(net.parameters()).add_(1.0)
+    changed("in-place update")
+    p = list(net.parameters())[3]
+    p.data = p.data.clone()
+    changed(".data swap")
+    net.final_conv[3].weight = torch.nn.Parameter(net.final_conv[3].weight.detach().clone())
+    changed("replaced Parameter")
+    net.final_conv[3] = torch.nn.Conv1d(16, 6, 1)
+    changed("replaced submodule")
+    net.extra = torch.nn.Linear(2, 2)
+    changed("added submodule")
+    net.register_buffer("stat", torch.zeros(3))
+    changed("added buffer")
+    net.stat.add_(1.0)
+    changed("buffer update")
+    invalidate_weights(net)
+    changed("explicit epoch")

@@ -87,12 +87,13 @@ def cfg4(B=512):
     return f"config 4 shard: DiT1d d=320 h=10 depth=2, H=64 D=29, CFG w=2, 10-step dpmsolver++2M, B={B}", call, B, flops
 
 
-def cfg5(B=131072, steps=128):
+def cfg5(B=131072, steps=128, D=15):
     """Config 5: SynthER residual MLP (IDQLMlp hidden 1024 x 6 blocks, emb 128, D = 15), 128-step EDM Euler.
-    BASELINE shards B = 1 M over 8 GPUs -> 131072 samples per GPU."""
+    BASELINE shards B = 1 M over 8 GPUs -> 125 000 samples per GPU (the executor cuts a request into 16 384-row chunks itself).
+    D = 27: the real hopper transition width 2 * 11 + 3 + 2 (report both)."""
     from cleandiffuser_amd.diffusion import ContinuousEDM
     from cleandiffuser_amd.nn_diffusion import IDQLMlp
-    D, H, nb = 15, 1024, 6
+    H, nb = 1024, 6
     net = load_synth(IDQLMlp(0, D, emb_dim=128, hidden_dim=H, n_blocks=nb))
     agent = ContinuousEDM(net, None, device=DEV)
     agent.eval()
@@ -100,7 +101,7 @@ def cfg5(B=131072, steps=128):
     call = lambda: agent.sample(torch.zeros(B, D, device=DEV), solver="euler", n_samples=B, sample_steps=steps,  # noqa: E731
                                 noise=z)[0]
     macs = (D + 128) * H + nb * 8 * H * H + H * D
-    return f"config 5 shard: IDQLMlp 1024x6, D=15, {steps}-step EDM Euler, B={B}", call, B, 2.0 * macs * steps * B
+    return f"config 5 shard: IDQLMlp 1024x6, D={D}, {steps}-step EDM Euler, B={B}", call, B, 2.0 * macs * steps * B
 
 
 def cfg2big(B=3200):
@@ -135,6 +136,22 @@ def cfgT(B=1024, steps=100):
                                 condition_cfg=obs, w_cfg=1.0, noise=zs)[0]
     tok = A * d + L * (3 * d * d + d * d + d * d + d * d + 8 * d * d) + L * (2 * Ta * d + 2 * 3 * d) + d * A     # MACs per token
     return f"ChiTransformer dp_pusht d=256 h=4 L=8, Ta=16, {steps}-step DDPM, B={B}", call, B, 2.0 * tok * Ta * steps * B
+
+
+def cfgU(B=256, native_backward=None):
+    """update() of config 2 (row f4): one training step on a batch of B trajectories -- forward + backward of the denoising loss,
+    gradient-norm clip, AdamW, EMA.  Returns (label, call, B): `call` runs ONE update and returns the loss tensor."""
+    from cleandiffuser_amd.nn_diffusion import JannerUNet1d
+    H, D = 32, 23
+    net = load_synth(JannerUNet1d(D, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2, 2], kernel_size=5))
+    fix = torch.zeros(H, D)
+    fix[0, :17] = 1.0
+    agent = DiscreteDiffusionSDE(net, None, fix_mask=fix, diffusion_steps=20, predict_noise=False, grad_clip_norm=1.0, device=DEV)
+    x0 = torch.randn(B, H, D, device=DEV)
+    if native_backward is not None:
+        os.environ["CDX_TRAIN_NATIVE"] = "1" if native_backward else "0"
+    call = lambda: torch.as_tensor(agent.update(x0)["loss"])  # noqa: E731
+    return f"config 2 update(): JannerUNet1d H=32 D=23, batch {B}, loss + backward + clip + AdamW + EMA", call, B
 
 
 def _guided_macs(net, clf_net, horizon, fallback):
