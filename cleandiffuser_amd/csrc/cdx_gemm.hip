@@ -656,6 +656,7 @@ __global__ __launch_bounds__(256) void cdx_groupnorm_bwd_kernel(const cdx_gn_arg
     for (int o = 32; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o, 64);
     const float rstd = 1.0f / sqrtf(s2 / (float)n + a.eps);
     float sg = 0.f, sgx = 0.f;                           // sum g, sum g * xhat
+    float pg = 0.f, pb = 0.f;                            // this lane's channel: sum dz * xhat, sum dz (training: d gamma, d beta)
     for (int e = lane; e < n; e += 64) {
         const int l = e / cg, c = e - l * cg, ch = grp * cg + c;
         const float xh = (xb[(size_t)l * a.ldx + c] - mean) * rstd;
@@ -664,6 +665,17 @@ __global__ __launch_bounds__(256) void cdx_groupnorm_bwd_kernel(const cdx_gn_arg
         const float g = dz * a.gamma[ch];
         sg += g;
         sgx += g * xh;
+        pg += dz * xh;
+        pb += dz;
+    }
+    if (a.dgamma_part != nullptr) {
+        // cg is a power of two <= 64 (checked by the host entry): a lane's channel e % cg is the same in every iteration, and the
+        // lanes that share it differ in the bits >= log2(cg)
+        for (int o = 32; o >= cg; o >>= 1) { pg += __shfl_xor(pg, o, 64); pb += __shfl_xor(pb, o, 64); }
+        if (lane < cg) {
+            a.dgamma_part[(size_t)b * a.C + grp * cg + lane] = pg;
+            a.dbeta_part[(size_t)b * a.C + grp * cg + lane] = pb;
+        }
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { sg += __shfl_xor(sg, o, 64); sgx += __shfl_xor(sgx, o, 64); }
@@ -1252,6 +1264,11 @@ int cdx_groupnorm_bwd_f32(const cdx_gn_args* a, void* hip_stream) {
     }
     if (a->B == 0) return CDX_OK;
     if (!a->x || !a->y || !a->gamma || !a->beta || !a->residual) { cdx_set_err("cdx_groupnorm_bwd_f32: null pointer"); return CDX_EINVAL; }
+    if ((a->dgamma_part == nullptr) != (a->dbeta_part == nullptr)) { cdx_set_err("cdx_groupnorm_bwd_f32: dgamma_part and dbeta_part go together"); return CDX_EINVAL; }
+    if (a->dgamma_part != nullptr) {
+        const int cg = a->C / a->G;
+        if (cg > 64 || (cg & (cg - 1)) != 0) { cdx_set_err("cdx_groupnorm_bwd_f32: parameter gradients need a power-of-two group width <= 64"); return CDX_EINVAL; }
+    }
     const long long waves = (long long)a->B * a->G;
     hipLaunchKernelGGL(cdx_groupnorm_bwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), *a);
     hipError_t e = hipGetLastError();

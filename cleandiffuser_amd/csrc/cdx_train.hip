@@ -1,0 +1,174 @@
+// cdx_train.hip -- the kernels the TRAINING step of the U-Net denoisers needs on top of the sampling library (the
+// forward / backward of DiffusionModel.update(), reference cleandiffuser/diffusion/diffusionsde.py:94-141, basic.py:66,83-86).
+//
+// The forward and the backward-DATA pass of a Conv1d / ConvTranspose1d are implicit-GEMM convolutions the library already has
+// (cdx_gemm_f32 with conv_taps: a backward-data conv is a conv with flipped, transposed weights; a strided one two parity convs), and
+// GroupNorm -> Mish forward / backward-data are cdx_groupnorm_f32 / cdx_groupnorm_bwd_f32.  What training adds is everything that sums
+// over the (batch x position) rows:
+//
+//   cdx_conv_wgrad_f32   dW[a][b][t] += sum_{n, m} P[n, m, a] * Q[n, m * stride + t - pad, b]      (a TN GEMM: both operands are read
+//                        with the contraction index -- the row -- as the SLOW dimension, which is exactly how the 32x32x2 MFMA wants its
+//                        A and B fragments: lanes 0-31 / 32-63 hold 32 consecutive columns of rows k / k + 1; no transposition anywhere).
+//                        nn.Conv1d: P = dY, Q = X -> dW[c_out][c_in][t]; nn.ConvTranspose1d(4, 2, 1): P = X, Q = dY -> dW[c_in][c_out][t].
+//   cdx_colsum_f32       out[c] += sum_r x[r][c]          (bias gradients; GroupNorm gain / shift gradients from their per-sample partials)
+//   cdx_groupnorm_bwd_f32 (csrc/cdx_gemm.hip) grew two optional outputs: per-(sample, channel) partial sums of dz * x_hat and dz.
+//
+// Sums over rows are split over workgroups and combined with float atomics into a buffer the caller zeroed (torch's own conv backward
+// does the same; the order is not fixed, gradients of two identical steps agree to ~1e-7 relative).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cdx.h"
+
+void cdx_set_err(const char* msg);          // cdx_common.hip
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int WG_BK = 16;          // rows (contraction index) per LDS stage
+constexpr int WG_T = 64;           // output tile: 64 x 64 per workgroup, 4 wave64 each a 32 x 32 MFMA accumulator
+constexpr int WG_LD = WG_T + 4;
+
+// one float4 of a row-major (rows x C) matrix at (row, col .. col + 3): zero outside; scalar path when the row stride or the column
+// offset is not 16-byte aligned (c_in = 23 for the first layer of config 2)
+__device__ __forceinline__ float4 wg_load4(const float* __restrict__ p, long row, int col, int C, int ld, bool row_ok) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!row_ok || col >= C) return v;
+    const float* q = p + row * (long)ld + col;
+    if (((ld | col) & 3) == 0 && col + 3 < C) return *reinterpret_cast<const float4*>(q);
+    v.x = q[0];
+    if (col + 1 < C) v.y = q[1];
+    if (col + 2 < C) v.z = q[2];
+    if (col + 3 < C) v.w = q[3];
+    return v;
+}
+
+__global__ __launch_bounds__(256) void cdx_conv_wgrad_kernel(const cdx_wgrad_args g) {
+    __shared__ __attribute__((aligned(16))) float Ps[2][WG_BK][WG_LD];
+    __shared__ __attribute__((aligned(16))) float Qs[2][WG_BK][WG_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_tb = (g.cb + WG_T - 1) / WG_T;
+    const int a0 = (blockIdx.x / n_tb) * WG_T, b0 = (blockIdx.x % n_tb) * WG_T;
+    const int tap = blockIdx.y, slice = blockIdx.z;
+    const long R = (long)g.batch * g.l_p;
+    const int n_chunks = (int)((R + WG_BK - 1) / WG_BK);
+    const int per = (n_chunks + g.k_split - 1) / g.k_split;
+    const int c_lo = slice * per, c_hi = min(n_chunks, c_lo + per);
+    if (c_lo >= c_hi) return;
+    // loader: thread -> (row of the chunk, float4 column)
+    const int lrow = tid >> 4, lcol = (tid & 15) * 4;
+    float4 rp, rq;
+    auto fetch = [&](int chunk) {
+        const long r = (long)chunk * WG_BK + lrow;
+        const bool ok = r < R;
+        const int n = ok ? (int)(r / g.l_p) : 0, m = ok ? (int)(r - (long)n * g.l_p) : 0;
+        rp = wg_load4(g.p, r, a0 + lcol, g.ca, g.ldp, ok);
+        const int qpos = m * g.stride + tap - g.pad;
+        rq = wg_load4(g.q, (long)n * g.l_q + qpos, b0 + lcol, g.cb, g.ldq, ok && qpos >= 0 && qpos < g.l_q);
+    };
+    // bias gradient riding along (db != NULL: p is d loss / d y): the workgroups of tap 0 / first column tile also sum the rows of
+    // their P tiles -- every chunk passes through stage() exactly once
+    const bool want_db = g.db != nullptr && tap == 0 && b0 == 0;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto stage = [&](int buf) {
+        *reinterpret_cast<float4*>(&Ps[buf][lrow][lcol]) = rp;
+        *reinterpret_cast<float4*>(&Qs[buf][lrow][lcol]) = rq;
+        if (want_db) { bsum.x += rp.x; bsum.y += rp.y; bsum.z += rp.z; bsum.w += rp.w; }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int lr = lane & 31, lk = lane >> 5;
+    fetch(c_lo);
+    stage(0);
+    if (c_lo + 1 < c_hi) fetch(c_lo + 1);
+    __syncthreads();
+    for (int c = c_lo; c < c_hi; ++c) {
+        const int buf = (c - c_lo) & 1;
+#pragma unroll
+        for (int kk = 0; kk < WG_BK; kk += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ps[buf][kk + lk][wm + lr], Qs[buf][kk + lk][wn + lr], acc, 0, 0, 0);
+        if (c + 1 < c_hi) {
+            stage(buf ^ 1);                       // (the other stage was last read before the barrier that ended chunk c - 1)
+            if (c + 2 < c_hi) fetch(c + 2);
+        }
+        __syncthreads();
+    }
+    // D fragment of 32x32x2: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int a = a0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lk, b = b0 + wn + lr;
+        if (a < g.ca && b < g.cb) atomicAdd(g.dw + ((long)a * g.cb + b) * g.taps + tap, acc[r]);
+    }
+    if (want_db) {                                  // 16 row-threads per float4 column -> one sum per column (stage 0 is free now)
+        *reinterpret_cast<float4*>(&Ps[0][lrow][lcol]) = bsum;
+        __syncthreads();
+        if (tid < WG_T && a0 + tid < g.ca) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < WG_BK; ++r) t += Ps[0][r][tid];
+            atomicAdd(g.db + a0 + tid, t);
+        }
+    }
+}
+
+// out[c] += sum_r x[r][c]: 64 columns x 64 rows per workgroup
+constexpr int CS_ROWS = 64;
+__global__ __launch_bounds__(256) void cdx_colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long R, int C, int ld) {
+    __shared__ float part[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    const long r0 = (long)blockIdx.y * CS_ROWS;
+    float s = 0.f;
+    if (c < C)
+        for (long r = r0 + ty; r < min(R, r0 + CS_ROWS); r += 4) s += x[r * ld + c];
+    part[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < C) atomicAdd(out + c, (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]));
+}
+
+}  // namespace
+
+extern "C" {
+
+int cdx_conv_wgrad_f32(const cdx_wgrad_args* a, void* hip_stream) {
+    cdx_set_err("");
+    if (!a || !a->p || !a->q || !a->dw) { cdx_set_err("cdx_conv_wgrad_f32: null pointer"); return CDX_EINVAL; }
+    if (a->batch == 0) return CDX_OK;
+    if (a->batch < 0 || a->l_p <= 0 || a->l_q <= 0 || a->ca <= 0 || a->cb <= 0 || a->taps <= 0 || a->taps > 16 || a->stride <= 0 || a->pad < 0 ||
+        a->ldp < a->ca || a->ldq < a->cb || a->k_split < 0) {
+        cdx_set_err("cdx_conv_wgrad_f32: bad shape"); return CDX_EINVAL;
+    }
+    cdx_wgrad_args g = *a;
+    const long R = (long)g.batch * g.l_p;
+    const int n_chunks = (int)((R + WG_BK - 1) / WG_BK);
+    const int tiles = ((g.ca + WG_T - 1) / WG_T) * ((g.cb + WG_T - 1) / WG_T) * g.taps;
+    if (g.k_split == 0) {
+        // ~1024 workgroups on the 256 CUs, at least 4 chunks (64 rows) per slice
+        g.k_split = (1024 + tiles - 1) / tiles;
+        if (g.k_split > n_chunks / 4) g.k_split = n_chunks / 4;
+        if (g.k_split < 1) g.k_split = 1;
+    }
+    if (g.k_split > 65535) g.k_split = 65535;
+    const dim3 grid(((g.ca + WG_T - 1) / WG_T) * ((g.cb + WG_T - 1) / WG_T), g.taps, g.k_split);
+    hipLaunchKernelGGL(cdx_conv_wgrad_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), g);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
+    return CDX_OK;
+}
+
+int cdx_colsum_f32(const float* x, float* out, long long rows, int32_t cols, int32_t ld, void* hip_stream) {
+    cdx_set_err("");
+    if (!x || !out) { cdx_set_err("cdx_colsum_f32: null pointer"); return CDX_EINVAL; }
+    if (rows < 0 || cols <= 0 || ld < cols) { cdx_set_err("cdx_colsum_f32: bad shape"); return CDX_EINVAL; }
+    if (rows == 0) return CDX_OK;
+    const dim3 grid((cols + 63) / 64, (unsigned)((rows + CS_ROWS - 1) / CS_ROWS));
+    hipLaunchKernelGGL(cdx_colsum_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), x, out, (long)rows, cols, ld);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
+    return CDX_OK;
+}
+
+}  // extern "C"

@@ -28,7 +28,14 @@ class CdxGnArgs(ctypes.Structure):
     _fields_ = [("x", ctypes.c_void_p), ("y", ctypes.c_void_p), ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p),
                 ("fa", ctypes.c_void_p), ("fb", ctypes.c_void_p), ("residual", ctypes.c_void_p)] + \
                [(n, ctypes.c_int32) for n in ("B", "L", "C", "G", "ldx", "ldy", "ldr", "ldfa", "ldfb", "fa_row", "fa_per_sample",
-                                              "film_mode", "act")] + [("eps", ctypes.c_float)]
+                                              "film_mode", "act")] + [("eps", ctypes.c_float)] + \
+               [("dgamma_part", ctypes.c_void_p), ("dbeta_part", ctypes.c_void_p)]
+
+
+class CdxWgradArgs(ctypes.Structure):
+    _fields_ = [("p", ctypes.c_void_p), ("q", ctypes.c_void_p), ("dw", ctypes.c_void_p)] + \
+               [(n, ctypes.c_int32) for n in ("batch", "l_p", "l_q", "ca", "cb", "taps", "stride", "pad", "ldp", "ldq", "k_split")] + \
+               [("db", ctypes.c_void_p)]
 
 
 class CdxLnArgs(ctypes.Structure):
@@ -72,6 +79,10 @@ def _lib():
         lib.cdx_act_bwd_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_float,
                                         ctypes.c_void_p]
         lib.cdx_act_bwd_f32.restype = ctypes.c_int
+        lib.cdx_conv_wgrad_f32.argtypes = [ctypes.POINTER(CdxWgradArgs), ctypes.c_void_p]
+        lib.cdx_conv_wgrad_f32.restype = ctypes.c_int
+        lib.cdx_colsum_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
+        lib.cdx_colsum_f32.restype = ctypes.c_int
         for f in (lib.cdx_gemm_f32, lib.cdx_layernorm_f32, lib.cdx_attention_f32, lib.cdx_act_f32):
             f.restype = ctypes.c_int
         _declared = True
@@ -172,14 +183,55 @@ def groupnorm(x: torch.Tensor, gamma, beta, batch: int, length: int, groups: int
 
 
 def groupnorm_backward(dy: torch.Tensor, x: torch.Tensor, gamma, beta, batch: int, length: int, groups: int,
-                       act: str = "mish", eps: float = 1e-5, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """d loss / d x for y = act(groupnorm(x) * gamma + beta), given dy = d loss / d y (x is the saved forward input)."""
+                       act: str = "mish", eps: float = 1e-5, out: Optional[torch.Tensor] = None, param_grads: bool = False):
+    """d loss / d x for y = act(groupnorm(x) * gamma + beta), given dy = d loss / d y (x is the saved forward input).
+    `param_grads`: also (d loss / d gamma, d loss / d beta) -- per-sample partial sums out of the same launch, summed over the batch by
+    cdx_colsum_f32 -> (dx, dgamma, dbeta)."""
     if out is None:
         out = torch.empty_like(x)
+    c = x.shape[1]
+    pg = pb = None
+    if param_grads:
+        pg = torch.empty((2, batch, c), device=x.device, dtype=torch.float32)
+        pb = pg[1]
     a = CdxGnArgs(x=x.data_ptr(), y=out.data_ptr(), gamma=gamma.data_ptr(), beta=beta.data_ptr(), residual=dy.data_ptr(),
-                  B=batch, L=length, C=x.shape[1], G=groups, ldx=_rows(x), ldy=_rows(out), ldr=_rows(dy), act=ACT[act], eps=eps)
+                  B=batch, L=length, C=c, G=groups, ldx=_rows(x), ldy=_rows(out), ldr=_rows(dy), act=ACT[act], eps=eps,
+                  dgamma_part=None if pg is None else pg[0].data_ptr(), dbeta_part=None if pb is None else pb.data_ptr())
     _check(_lib().cdx_groupnorm_bwd_f32(ctypes.byref(a), _stream_ptr(x.device)), "cdx_groupnorm_bwd_f32")
+    if not param_grads:
+        return out
+    # (the two (batch, C) partial blocks lie back to back: summed as 2 x batch rows into one zeroed (2, C) block by two launches that
+    #  share the memset)
+    g = torch.zeros((2, c), device=x.device, dtype=torch.float32)
+    colsum(pg[0], out=g[0])
+    colsum(pg[1], out=g[1])
+    return out, g[0], g[1]
+
+
+def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """sum over the rows of a (rows, cols) fp32 device matrix, ADDED to `out` (zeros when not given): one launch, float atomics."""
+    r, c = x.shape
+    if out is None:
+        out = torch.zeros(c, device=x.device, dtype=torch.float32)
+    _check(_lib().cdx_colsum_f32(x.data_ptr(), out.data_ptr(), r, c, _rows(x), _stream_ptr(x.device)), "cdx_colsum_f32")
     return out
+
+
+def conv_wgrad(p: torch.Tensor, q: torch.Tensor, batch: int, l_p: int, l_q: int, taps: int, stride: int = 1, pad: int = 0,
+               k_split: int = 0, bias_grad: bool = False):
+    """dw[a][b][t] = sum_{n, m} p[(n, m)][a] * q[(n, m * stride + t - pad)][b] -> (ca, cb, taps), the layout of nn.Conv1d.weight with
+    p = d loss / d y, q = x (and of nn.ConvTranspose1d.weight with p = x, q = d loss / d y, stride 2, pad 1).  One launch.
+    `bias_grad` (p = d loss / d y): also the column sums of p out of the same launch -> (dw, db); both live in ONE zeroed buffer."""
+    ca, cb = p.shape[1], q.shape[1]
+    assert p.shape[0] == batch * l_p and q.shape[0] == batch * l_q
+    n_w = ca * cb * taps
+    buf = torch.zeros(n_w + (ca if bias_grad else 0), device=p.device, dtype=torch.float32)
+    dw = buf[:n_w].view(ca, cb, taps)
+    db = buf[n_w:] if bias_grad else None
+    a = CdxWgradArgs(p=p.data_ptr(), q=q.data_ptr(), dw=dw.data_ptr(), batch=batch, l_p=l_p, l_q=l_q, ca=ca, cb=cb, taps=taps,
+                     stride=stride, pad=pad, ldp=_rows(p), ldq=_rows(q), k_split=k_split, db=_p(db))
+    _check(_lib().cdx_conv_wgrad_f32(ctypes.byref(a), _stream_ptr(p.device)), "cdx_conv_wgrad_f32")
+    return (dw, db) if bias_grad else dw
 
 
 def layernorm(x: torch.Tensor, out: Optional[torch.Tensor] = None, gamma=None, beta=None, scale=None, shift=None,

@@ -1,0 +1,186 @@
+"""Training step of the U-Net denoisers on the library's kernels: the forward and backward of
+``DiffusionModel.update()`` (reference cleandiffuser/diffusion/diffusionsde.py:94-141 ``loss`` / ``update``, basic.py:66,83-86).
+
+The reference trains through PyTorch autograd over ``nn.Conv1d`` / ``F.group_norm`` / ``nn.Mish``: ~170 ATen launches forward and as
+many again backward, the convolutions on MIOpen kernels that are tuned for images, not for (256 x 32 x 32)-sized temporal layers.  Here
+the network keeps its ``nn.Module`` parameters (checkpoints, optimiser, EMA unchanged) and autograd keeps the GRAPH -- but every node that
+touches a convolution or a GroupNorm is a ``torch.autograd.Function`` whose forward and backward are library launches on channel-last
+``(batch * positions, channels)`` rows (the layout the sampling executors use; the (b, H, D) trajectory tensor IS that layout, so
+nothing is transposed on the way in or out):
+
+* ``Conv1d`` / ``ConvTranspose1d(4, 2, 1)``: forward = ``cdx_gemm_f32`` implicit-GEMM conv; backward-data = the same kernel with flipped,
+  transposed weights (a stride-2 conv: two parity convs; a transposed conv: a stride-2 conv); weight gradient = ``cdx_conv_wgrad_f32``
+  (a TN GEMM over the batch x position rows); bias gradient = ``cdx_colsum_f32``.
+* ``GroupNorm -> Mish``: ``cdx_groupnorm_f32`` / ``cdx_groupnorm_bwd_f32`` (which also emits the per-sample partials of the gain / shift
+  gradients; summed by ``cdx_colsum_f32``).
+* what is left to ATen are the broadcast adds (FiLM vector, residual), the channel concat of the skip connections and the embedding MLP
+  (a few (batch, 32..128) Linears): no convolution, no group_norm.
+
+``CDX_TRAIN_NATIVE=0`` keeps the reference's autograd path (A/B runs, the fixtures' twin).  Parity: tests/test_gpu_parity.py --
+gradients of every parameter against ``torch.autograd`` of the module, and the ``train_*`` fixtures of the real reference.
+"""
+import os
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import blocks
+
+
+def enabled() -> bool:
+    return os.environ.get("CDX_TRAIN_NATIVE", "1") != "0"
+
+
+def supports(net, x: torch.Tensor) -> bool:
+    """JannerUNet1d (GroupNorm, no attention) with fp32 parameters on a ROCm device, called with autograd on."""
+    from .consts import supports_janner
+    from .runtime import _is_janner
+    if not (enabled() and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and _is_janner(net)):
+        return False
+    if supports_janner(net) is not None or net.kernel_size > 5:
+        return False
+    return all(p.dtype == torch.float32 and p.is_cuda for p in net.parameters())
+
+
+# --------------------------------------------------------------------------------------------------------------------- #
+class _Conv(torch.autograd.Function):
+    """nn.Conv1d (stride 1 'same', or k = 3 / stride 2 / pad 1) on channel-last rows."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, batch, l_in, stride, pad):
+        x = x.contiguous()
+        y = blocks.conv1d(x, blocks.pack_conv(weight), bias, batch, l_in, stride, pad)
+        ctx.save_for_backward(x, weight)
+        ctx.geom = (batch, l_in, stride, pad, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        batch, l_in, stride, pad, has_bias = ctx.geom
+        c_out, c_in, k = weight.shape
+        dy = dy.contiguous()
+        l_out = dy.shape[0] // batch
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if stride == 1:
+                # dx[l] = sum_t W[:, :, t]^T dy[l + pad - t]: a conv of dy with the flipped, transposed kernel, left padding k - 1 - pad
+                wt = weight.detach().flip(2).permute(1, 2, 0).contiguous()                 # (c_in, k, c_out)
+                dx = blocks.conv1d(dy, wt, None, batch, l_out, 1, k - 1 - pad, l_out=l_in)
+            else:
+                assert (k, stride, pad) == (3, 2, 1) and l_in == 2 * l_out
+                # y[m] = sum_t W_t x[2m - 1 + t]:  dx[2j] = W_1^T dy[j];  dx[2j + 1] = W_2^T dy[j] + W_0^T dy[j + 1]
+                w = weight.detach().permute(1, 2, 0)                                       # (c_in, k, c_out)
+                dx = torch.empty((batch * l_in, c_in), device=dy.device, dtype=torch.float32)
+                view = dx.view(batch * l_out, 2 * c_in)                                    # row (b, j) = [dx[2j] | dx[2j + 1]]
+                blocks.conv1d(dy, w[:, 1:2].contiguous(), None, batch, l_out, 1, 0, out=view[:, :c_in], l_out=l_out)
+                blocks.conv1d(dy, w[:, [2, 0]].contiguous(), None, batch, l_out, 1, 0, out=view[:, c_in:], l_out=l_out)
+        want_db = has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:
+            dw = blocks.conv_wgrad(dy, x, batch, l_out, l_in, k, stride, pad, bias_grad=want_db)       # (c_out, c_in, k)[, (c_out,)]
+            if want_db:
+                dw, db = dw
+        elif want_db:
+            db = blocks.colsum(dy)
+        return dx, dw, db, None, None, None, None
+
+
+class _ConvT(torch.autograd.Function):
+    """nn.ConvTranspose1d(C, C', 4, 2, 1) on channel-last rows: L -> 2 L."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, batch, l_in):
+        x = x.contiguous()
+        y = blocks.conv_transpose1d_k4s2p1(x, blocks.pack_conv_transpose_k4s2p1(weight), bias, batch, l_in)
+        ctx.save_for_backward(x, weight)
+        ctx.geom = (batch, l_in, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        batch, l_in, has_bias = ctx.geom
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            # y[2m - 1 + t] += W[ci, :, t] x[m, ci]  =>  dx[m, ci] = sum_t W[ci, :, t] . dy[2m - 1 + t]: a stride-2 conv of dy
+            wq = weight.detach().permute(0, 2, 1).contiguous()                             # (c_in, 4, c_out)
+            dx = blocks.conv1d(dy, wq, None, batch, 2 * l_in, 2, 1)
+        if ctx.needs_input_grad[1]:
+            dw = blocks.conv_wgrad(x, dy, batch, l_in, 2 * l_in, 4, 2, 1)                  # (c_in, c_out, 4)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = blocks.colsum(dy)
+        return dx, dw, db, None, None
+
+
+class _GroupNormMish(torch.autograd.Function):
+    """GroupNorm1d -> Mish on channel-last rows (reference utils/building_blocks.py:60-76 + nn.Mish)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, batch, length, groups, eps):
+        x = x.contiguous()
+        y = blocks.groupnorm(x, gamma, beta, batch, length, groups, act="mish", eps=eps)
+        ctx.save_for_backward(x, gamma, beta)
+        ctx.geom = (batch, length, groups, eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta = ctx.saved_tensors
+        batch, length, groups, eps = ctx.geom
+        dx, dg, db = blocks.groupnorm_backward(dy.contiguous(), x, gamma.detach(), beta.detach(), batch, length, groups, act="mish", eps=eps,
+                                               param_grads=True)
+        return dx, dg, db, None, None, None, None
+
+
+# --------------------------------------------------------------------------------------------------------------------- #
+def _conv(h, conv: nn.Conv1d, batch: int, length: int):
+    return _Conv.apply(h, conv.weight, conv.bias, batch, length, conv.stride[0], conv.padding[0])
+
+
+def _cna(h, seq: nn.Sequential, batch: int, length: int):
+    """Conv1d -> GroupNorm1d -> Mish (a `_conv_norm_act` Sequential of nn_diffusion/jannerunet.py)."""
+    conv, gn = seq[0], seq[1]
+    y = _conv(h, conv, batch, length)
+    return _GroupNormMish.apply(y, gn.weight, gn.bias, batch, length, gn.num_groups, gn.eps)
+
+
+def _resblock(rb, h, emb, batch: int, length: int):
+    """ResidualBlock (reference jannerunet.py:51-69): CNA2(CNA1(x) + Linear(Mish(emb))) + skip(x)."""
+    c_out = rb.conv1[0].out_channels
+    a1 = _cna(h, rb.conv1, batch, length)
+    a1 = (a1.view(batch, length, c_out) + rb.emb_mlp(emb)[:, None, :]).view(batch * length, c_out)
+    a2 = _cna(a1, rb.conv2, batch, length)
+    res = h if isinstance(rb.residual_conv, nn.Identity) else _conv(h, rb.residual_conv, batch, length)
+    return a2 + res
+
+
+def janner_forward(net, x: torch.Tensor, noise: torch.Tensor, condition: Optional[torch.Tensor]) -> torch.Tensor:
+    """``JannerUNet1d.forward`` (reference nn_diffusion/jannerunet.py:154-201) with autograd, every convolution and GroupNorm on the
+    library's kernels.  x (b, H, D) -> (b, H, D)."""
+    b, length, d = x.shape
+    emb = net.map_noise(noise)
+    emb = emb + (condition if condition is not None else torch.zeros_like(emb))
+    emb = net.map_emb(emb)
+    h = x.reshape(b * length, d)
+    skips = []
+    for res1, res2, _, down in net.downs:
+        h = _resblock(res2, _resblock(res1, h, emb, b, length), emb, b, length)
+        skips.append((h, length))
+        if not isinstance(down, nn.Identity):
+            h = _conv(h, down.conv, b, length)
+            length = (length - 1) // 2 + 1
+    h = _resblock(net.mid_block2, _resblock(net.mid_block1, h, emb, b, length), emb, b, length)
+    for res1, res2, _, up in net.ups:
+        skip, l_skip = skips.pop()
+        assert l_skip == length
+        h = torch.cat([h, skip], dim=1)
+        h = _resblock(res2, _resblock(res1, h, emb, b, length), emb, b, length)
+        if not isinstance(up, nn.Identity):
+            h = _ConvT.apply(h, up.conv.weight, up.conv.bias, b, length)
+            length *= 2
+    fc = net.final_conv
+    h = _cna(h, fc, b, length)
+    h = _conv(h, fc[3], b, length)
+    return h.view(b, length, d)

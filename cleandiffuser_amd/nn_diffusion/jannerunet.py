@@ -5,7 +5,9 @@ same ``state_dict`` keys (``downs.{i}.{0,1}.conv{1,2}.{0,1}``, ``emb_mlp.1``, ``
 ``downs.{i}.3.conv``, ``ups.{i}.3.conv``, ``mid_block{1,2}``, ``final_conv.{0,1,3}``, ``map_emb.{0,2}``)
 so reference checkpoints load unchanged.
 
-Execution: this nn.Module is the *parameter container + autograd/CPU path*.  On a ROCm device with
+Execution: this nn.Module is the *parameter container + CPU path*.  On a ROCm device with autograd ON (``loss()`` /
+``update()``) the forward and backward of every convolution and GroupNorm are library kernels behind
+``torch.autograd.Function`` nodes (`cleandiffuser_amd.engine.train`); with
 ``requires_grad`` off, ``forward`` is served by the fused gfx950 program kernel
 (`cleandiffuser_amd.engine`, C-ABI ``cdx_unet2_run``) -- the whole U-Net forward in ONE launch with
 activations resident in LDS -- and ``DiscreteDiffusionSDE.sample`` goes one step further and runs
@@ -173,7 +175,11 @@ class JannerUNet1d(BaseNNDiffusion):
     def forward(self, x: torch.Tensor, noise: torch.Tensor, condition: Optional[torch.Tensor] = None):
         """x (b, horizon, in_dim), noise (b,), condition (b, emb_dim)|None -> (b, horizon, in_dim)."""
         assert x.shape[1] & (x.shape[1] - 1) == 0, "Ta dimension must be 2^n"
-        from ..engine import dispatch
+        from ..engine import dispatch, train
+        if train.supports(self, x):
+            # autograd on, ROCm device (loss() / update(), sampling with requires_grad=True): the same graph, every convolution and
+            # GroupNorm node on the library's kernels forward and backward (engine/train.py; SURVEY 8(f4))
+            return train.janner_forward(self, x, noise, condition)
         y = dispatch.try_backbone_forward(self, x, noise, condition)
         if y is not None:
             return y

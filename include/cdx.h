@@ -257,12 +257,39 @@ typedef struct cdx_gn_args {
     const float* residual;           /* (B*L, ldr) or NULL */
     int32_t B, L, C, G, ldx, ldy, ldr, ldfa, ldfb, fa_row, fa_per_sample, film_mode, act;
     float eps;
+    /* backward only (training): optional (B, C) outputs -- per sample the sums over its positions of dz * x_hat and of dz
+     * (dz = d loss / d y * act'): the column sums of these over the batch are d loss / d gamma and d loss / d beta.  Both or neither;
+     * needs C / G channels per group to be a power of two <= 64. */
+    float *dgamma_part, *dbeta_part;
 } cdx_gn_args;
 int cdx_groupnorm_f32(const cdx_gn_args* args, void* hip_stream);
 /* Backward of y = act(gn(x) * gamma + beta) w.r.t. x (classifier guidance, reference classifier/base.py:74-79 asks autograd
- * for d logp / d x): same argument block with `x` = the saved forward input, `residual` = d loss / d y (row stride ldr),
+ * for d logp / d x; training): same argument block with `x` = the saved forward input, `residual` = d loss / d y (row stride ldr),
  * `y` = d loss / d x; act must be CDX_ACT_MISH or CDX_ACT_NONE; the FiLM fields are ignored. */
 int cdx_groupnorm_bwd_f32(const cdx_gn_args* args, void* hip_stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Training step (csrc/cdx_train.hip; SURVEY 8(f4): forward / backward of DiffusionModel.update(), reference diffusionsde.py:94-141).
+ * Forward and backward-DATA of the convolutions are cdx_gemm_f32 convolutions (flipped / transposed weights; parity pairs for the strided
+ * ones), GroupNorm -> Mish forward / backward-data are the two entries above; these are the sums over the (batch x position) rows.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Weight gradient of a 1-D convolution on channel-last rows:
+ *     dw[a][b][t] += sum_{n < batch, m < l_p} p[(n, m)][a] * q[(n, m * stride + t - pad)][b]        (q rows outside [0, l_q): zero)
+ * nn.Conv1d(c_in, c_out, k, stride, pad): p = d loss / d y ((batch * l_out, c_out)), q = x ((batch * l_in, c_in)) -> dw (c_out, c_in, k);
+ * nn.ConvTranspose1d(c_in, c_out, 4, 2, 1): p = x, q = d loss / d y, stride 2, pad 1 -> dw (c_in, c_out, 4); nn.Linear: taps 1, l = 1.
+ * `dw` must be ZEROED by the caller: row slices are combined with float atomics (k_split slices; 0 = chosen by the library). */
+typedef struct cdx_wgrad_args {
+    const float* p;
+    const float* q;
+    float* dw;
+    int32_t batch, l_p, l_q, ca, cb, taps, stride, pad, ldp, ldq, k_split;
+    float* db;             /* optional, zeroed by the caller: db[a] += sum over all rows of p[.][a] -- the bias gradient of an nn.Conv1d
+                            * (p = d loss / d y) out of the same launch */
+} cdx_wgrad_args;
+int cdx_conv_wgrad_f32(const cdx_wgrad_args* args, void* hip_stream);
+/* out[c] += sum_r x[r][c] (rows x cols, row stride ld); `out` zeroed by the caller (bias gradients, GroupNorm parameter gradients). */
+int cdx_colsum_f32(const float* x, float* out, long long rows, int32_t cols, int32_t ld, void* hip_stream);
 
 /* out[b][t][h*d..] = softmax(q k^T * scale) v per (batch, head); qkv = (B*T, 3*n_heads*head_dim) from in_proj.
  * Replaces the core of nn.MultiheadAttention(batch_first=True) (reference dit.py:20,34).  T <= CDX_ATTN_MAX_T, head_dim <= 64

@@ -29,7 +29,8 @@ def test_every_declared_symbol_is_exported(lib):
                           "cdx_chitf_run", "cdx_chitf_workspace_floats", "cdx_cross_attention_f32", "cdx_chiunet_run",
                           "cdx_chiunet_workspace_floats", "cdx_groupnorm_f32", "cdx_groupnorm_bwd_f32", "cdx_hjgrad_run",
                           "cdx_hjgrad_workspace_floats", "cdx_guided_run", "cdx_guided_workspace_floats", "cdx_unet2_run",
-                          "cdx_unet2_embtab", "cdx_optim_f32", "cdx_pearcetf_run", "cdx_pearcetf_workspace_floats", "cdx_act_bwd_f32", "cdx_linattn_f32"}
+                          "cdx_unet2_embtab", "cdx_optim_f32", "cdx_pearcetf_run", "cdx_pearcetf_workspace_floats", "cdx_act_bwd_f32", "cdx_linattn_f32",
+                          "cdx_conv_wgrad_f32", "cdx_colsum_f32"}
     for n in names:
         assert hasattr(lib, n), f"{n} declared in cdx.h but not exported by libcdx.so"
     assert lib.cdx_abi_version() == int(re.search(r"#define CDX_ABI_VERSION (\d+)", hdr).group(1))
@@ -50,7 +51,7 @@ def test_ctypes_mirrors_have_c_layout(tmp_path):
                "cdx_chitf_layer": bigbatch.CdxChitfLayer, "cdx_chitf_weights": bigbatch.CdxChitfWeights,
                "cdx_xattn_args": blocks.CdxXattnArgs, "cdx_gn_args": blocks.CdxGnArgs,
                "cdx_chiunet_block": bigbatch.CdxChiUNetBlock, "cdx_chiunet_weights": bigbatch.CdxChiUNetWeights,
-               "cdx_unet_attn": bigbatch.CdxUnetAttn}
+               "cdx_unet_attn": bigbatch.CdxUnetAttn, "cdx_wgrad_args": blocks.CdxWgradArgs}
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "cdx.h"', 'int main(void){']
     for cname, mirror in mirrors.items():
         src.append(f'printf("%zu\\n", sizeof({cname}));')

@@ -1234,6 +1234,90 @@ def test_fused_adamw_skips_parameters_without_a_gradient_like_torch():
     assert len(opt_a._tables) <= 8, "pointer tables must not accumulate per step count (ADVICE r3, low)"
 
 
+# ---- row f4, second slice: forward / backward of update() on the library's kernels (engine/train.py, csrc/cdx_train.hip) ----
+@pytest.mark.parametrize("shape", ["config2", "h4_dims_1_4_2", "conditional"])
+def test_native_training_graph_matches_autograd(shape, amd_lib, monkeypatch):
+    """JannerUNet1d with autograd ON on the device: the output and the gradient of EVERY parameter (conv weights / biases through the
+    TN weight-gradient GEMM and the column sums, GroupNorm gains / shifts, the FiLM and embedding Linears that stay on ATen) and of the
+    input, against torch.autograd of the module's own PyTorch forward on the same device.  config 2 (H = 32: stride-2 and transposed
+    convs at three levels, a 23-channel first layer), the shipped H = 4 / dim_mult [1, 4, 2] net, a conditional call."""
+    from cleandiffuser_amd.engine import train
+    from cleandiffuser_amd.utils import load_synth
+    if shape == "h4_dims_1_4_2":
+        net, H, D = load_synth(amd_lib.JannerUNet1d(23, model_dim=32, emb_dim=32, dim_mult=[1, 4, 2], kernel_size=5), 5), 4, 23
+    else:
+        net, H, D = load_synth(amd_lib.JannerUNet1d(23, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2, 2], kernel_size=5), 5), 32, 23
+    net = net.to(DEV)
+    g = torch.Generator().manual_seed(2)
+    B = 24
+    x = torch.randn(B, H, D, generator=g).to(DEV).requires_grad_(True)
+    t = torch.randint(0, 20, (B,), generator=g).to(DEV)
+    cond = torch.randn(B, 32, generator=g).to(DEV) if shape == "conditional" else None
+    wgt = torch.randn(B, H, D, generator=g).to(DEV)
+
+    def run(native):
+        monkeypatch.setenv("CDX_TRAIN_NATIVE", "1" if native else "0")
+        net.zero_grad(set_to_none=True)
+        x.grad = None
+        assert train.supports(net, x) == native
+        y = net(x, t, cond)
+        ((y * wgt).sum() / B).backward()
+        return y.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in net.named_parameters()}
+    y1, gx1, gp1 = run(True)
+    y0, gx0, gp0 = run(False)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(y1.cpu().numpy(), y0.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(gx1.cpu().numpy(), gx0.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(gx0.abs().max()))
+    assert set(gp1) == set(gp0)
+    for n in gp0:
+        scale = float(gp0[n].abs().max()) + 1e-12
+        err = float((gp1[n] - gp0[n]).abs().max())
+        assert err <= 2e-4 * scale, f"{n}: |d| = {err:.3e} at scale {scale:.3e}"
+        assert gp1[n].is_contiguous() and gp1[n].shape == gp0[n].shape
+
+
+def test_update_runs_without_aten_conv_or_groupnorm_kernels(amd_lib):
+    """VERDICT r3 'next' #5: update() of config 2 at B = 256 -- loss, backward, clip, AdamW, EMA -- dispatches NO ATen / MIOpen
+    convolution and no group_norm kernel, forward or backward: the profiler sees the library's GEMM / weight-gradient / GroupNorm /
+    column-sum / optimiser kernels plus ATen's elementwise glue; and three updates land on the same loss values, gradient norms and
+    weights as the reference sequence on the CPU (autograd, clip_grad_norm_, AdamW, EMA) fed the same draws.
+    (The twin runs on the CPU because ATen's own group_norm backward on THIS ROCm build returns gain / shift gradients that are off by
+    100 % once the batch reaches 255 -- tools/debug_train2.py, profiles/r04_aten_groupnorm_backward.txt: float64 on the CPU agrees with
+    the library's kernel to 5e-5 and with ATen-CPU, not with ATen-GPU.  Up to B = 128 the device twin agrees too:
+    test_native_training_graph_matches_autograd.)"""
+    from copy import deepcopy
+    from torch.profiler import profile, ProfilerActivity
+    from oracle.train_cases import cpu_rng
+    from cleandiffuser_amd.utils import load_synth
+    net = load_synth(amd_lib.JannerUNet1d(23, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2, 2], kernel_size=5), 7)
+    fm = torch.zeros(32, 23)
+    fm[0, :17] = 1.0
+    mk = lambda n, dev: amd_lib.DiscreteDiffusionSDE(n, None, fix_mask=fm, diffusion_steps=20, predict_noise=False, grad_clip_norm=1.0,  # noqa: E731
+                                                     device=dev)
+    a, b = mk(deepcopy(net), DEV), mk(deepcopy(net), "cpu")
+    b.optimizer = torch.optim.AdamW(b.model.parameters(), lr=2e-4, weight_decay=1e-5)        # the stock sequence
+    x0 = torch.randn(256, 32, 23, generator=torch.Generator().manual_seed(3))
+    with cpu_rng(DEV):
+        torch.manual_seed(11)
+        la_all = [a.update(x0.to(DEV)) for _ in range(3)]
+    torch.manual_seed(11)
+    lb_all = [b.update(x0) for _ in range(3)]
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        a.update(x0.to(DEV))
+        torch.cuda.synchronize()
+    names = [e.key for e in prof.key_averages()]
+    bad = [n for n in names if any(w in n.lower() for w in ("convolution", "conv1d", "conv_transpose", "miopen", "group_norm", "native_batch_norm"))]
+    assert not bad, f"ATen convolution / group_norm ops in a native update(): {bad}"
+    assert any("cdx_conv_wgrad_kernel" in n for n in names) and any("cdx_groupnorm_bwd_kernel" in n for n in names), names
+    for la, lb in zip(la_all, lb_all):
+        assert abs(la["loss"] - lb["loss"]) <= 1e-5 * max(1.0, abs(lb["loss"]))
+        assert abs(float(la["grad_norm"]) - float(lb["grad_norm"])) <= 1e-4 * float(lb["grad_norm"])
+    # (the profiled fourth update moved only `a`: compare the state after three through the EMA copies' distance budget instead --
+    #  the EMA moves by (1 - 0.995) of one more AdamW step of lr 2e-4)
+    for (n, p), q in zip(a.model_ema.named_parameters(), b.model_ema.parameters()):
+        assert float((p.detach().cpu() - q.detach()).abs().max()) <= 2e-5 * max(1.0, float(q.detach().abs().max())) + 1.1e-6, n
+
+
 def test_update_runs_without_aten_optimiser_launches(amd_lib):
     """config 2's update(): after loss.backward() the whole optimiser side -- gradient-norm clip, AdamW, EMA, zeroed gradients -- is
     the library's kernels (3 launches), and the result equals the PyTorch sequence (clip_grad_norm_, torch.optim.AdamW.step,
