@@ -867,7 +867,10 @@ __device__ __forceinline__ void split_exchange(XState& X, int xg, int gmap, floa
             o[1] = (f32x4){v[2], tag, v[3], tag};
         }
     }
-    // collect: everybody else's part, straight from L2 (nontemporal loads bypass this CU's L1), as soon as their tags say so
+    // collect: everybody else's part, straight from L2 (nontemporal loads bypass this CU's L1), as soon as their tags say so.
+    // (Measured and dropped, gpurun r4k / r4l: requesting a thread's two items together -- even the same loop merely WRITTEN for two
+    //  items with one of them disabled -- is 2 % slower at B = 256 than this plain loop; the poll interval, s_sleep 0 / 1 / 4 / 16, changes
+    //  nothing: the exchange waits for the slowest member of the group, not for the polls.)
     for (int i = tid; i < n_items; i += THREADS) {
         const int vpos = i >> c4sh, c = (i - (vpos << c4sh)) * 4, grp = c >> cgsh;
         const int t = vpos >> gsh, pos = vpos - (t << gsh);
@@ -910,7 +913,13 @@ __device__ __forceinline__ void split_exchange(XState& X, int xg, int gmap, floa
 // Epilogue threads: 256 per trajectory (8 GroupNorm groups x 32 lanes).  4 waves: all of them, one trajectory after the other;
 // 8 waves, T = 2: waves 0-3 take trajectory 0 while waves 4-7 take trajectory 1; 8 waves, T = 1: waves 0-3 run the epilogue,
 // waves 4-7 rewrite the destination's halo rows.
-template <int T, int NWV, bool BWD, bool PROF, bool COND, bool MLP = false, bool SPLIT = false>
+// SPLIT: THIS op is cut over the members / grouped / exchanged (descriptor word W2_XG != 0): the column map, the grouped epilogue, the
+// group-slot halo rows and the exchange are compiled in.  MEMBER: the kernel runs member programs (descriptor offset per member, a
+// parameter fetch that understands grouped ops -- the NEXT op may be one).
+// (Measured and dropped, gpurun r4m: giving the ordinary ops of a member program their own <SPLIT = false, MEMBER = true> instantiation of
+//  this function next to the <true, true> one -- two inlined copies in the op loop, 60 instead of 38 scalar spills -- is 2.6 % SLOWER at
+//  B = 256 (3.748 vs 3.650 ms) than one copy whose special paths an ordinary op merely branches around.)
+template <int T, int NWV, bool BWD, bool PROF, bool COND, bool MLP = false, bool SPLIT = false, bool MEMBER = SPLIT>
 __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* ops, int vd, int vdn, Item& it,
                                        const float* __restrict__ emb_row, int emb_tstride, float* __restrict__ lds, int tid,
                                        Ring<WG<NWV>::PF>& ring, unsigned long long* prof, int b0, OpFetch& F,
@@ -927,8 +936,8 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
         if (wave_of(tid) < CDX2_DW(vdn, CDX2_W2_NITEMS)) prefetch_ring(it, L.wblob, tid & 63, ring);
         if (PIPE) {
             if (params)
-                F.P = load_params<COND, SPLIT_T, false, MLP, SPLIT>(L, vdn, emb_next, emb_next_tstride, tid, wave_of(tid), NWV == 4 || SPLIT_T || wave_of(tid) < 4);
-            F.vdn2 = load_desc<NWV>(L.ops, op_next2 + (SPLIT ? X->m * L.n_ops : 0), tid & 63, wave_of(tid));
+                F.P = load_params<COND, SPLIT_T, false, MLP, MEMBER>(L, vdn, emb_next, emb_next_tstride, tid, wave_of(tid), NWV == 4 || SPLIT_T || wave_of(tid) < 4);
+            F.vdn2 = load_desc<NWV>(L.ops, op_next2 + (MEMBER ? X->m * L.n_ops : 0), tid & 63, wave_of(tid));
         }
     };
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -995,19 +1004,28 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
     // epilogue geometry + per-channel parameters: issued now, consumed after the barrier (latency hides behind the K loop)
     const int etid = tid & 255;
     const int grp = etid >> 5, li = etid & 31;
-    int c = grp * (coutp >> 3) + 4 * (li & ((1 << shift) - 1));
+    const int c = grp * (coutp >> 3) + 4 * (li & ((1 << shift) - 1));
     const int pos0 = li >> shift, pstep = 32 >> shift;
     const int nv = (coutp >> 5) * l_out;
     // this op's epilogue parameters: fetched during the PREVIOUS op (PIPE), or here (consumed after the barrier either way)
-    EpiParams P = PIPE ? F.P : load_params<COND, SPLIT_T, CDX2_PARAMS_ALL != 0, MLP, SPLIT>(L, vd, emb_row, emb_tstride, tid, wave, epi_wave);
+    EpiParams P = PIPE ? F.P : load_params<COND, SPLIT_T, CDX2_PARAMS_ALL != 0, MLP, MEMBER>(L, vd, emb_row, emb_tstride, tid, wave, epi_wave);
 
     // K loop -> staged partial tiles
     const int n_items = CDX2_DW(vd, CDX2_W2_NITEMS);
-    if (CDX2_DW(vd, CDX2_W2_MODE) == CDX_MODE_4X4) {
-        if (CDX2_DW(vd, CDX2_W2_NT) == 1) conv_kloop<M4, 1, T, NWV, PROF, SPLIT>(g, L.wblob, vd, ops, it, n_items, lds, tf, lane, wave, ring, prof, L.tune);
-        else conv_kloop<M4, 2, T, NWV, PROF, SPLIT>(g, L.wblob, vd, ops, it, n_items, lds, tf, lane, wave, ring, prof, L.tune);
+    // (grouped ops take their own instantiations -- column map, steady-state loop for the 16x16 streams --; the ordinary ops of a
+    //  split / grouped kernel run the very K loops of the plain kernels: r4f op profile, +150-200 cycles of item set-up per op otherwise)
+    if (SPLIT && gmap0 != 0) {
+        if (CDX2_DW(vd, CDX2_W2_MODE) == CDX_MODE_4X4) {
+            if (CDX2_DW(vd, CDX2_W2_NT) == 1) conv_kloop<M4, 1, T, NWV, PROF, SPLIT>(g, L.wblob, vd, ops, it, n_items, lds, tf, lane, wave, ring, prof, L.tune);
+            else conv_kloop<M4, 2, T, NWV, PROF, SPLIT>(g, L.wblob, vd, ops, it, n_items, lds, tf, lane, wave, ring, prof, L.tune);
+        } else {
+            conv_kloop<M16, 1, T, NWV, PROF, SPLIT>(g, L.wblob, vd, ops, it, n_items, lds, tf, lane, wave, ring, prof, L.tune);
+        }
+    } else if (CDX2_DW(vd, CDX2_W2_MODE) == CDX_MODE_4X4) {
+        if (CDX2_DW(vd, CDX2_W2_NT) == 1) conv_kloop<M4, 1, T, NWV, PROF>(g, L.wblob, vd, ops, it, n_items, lds, tf, lane, wave, ring, prof, L.tune);
+        else conv_kloop<M4, 2, T, NWV, PROF>(g, L.wblob, vd, ops, it, n_items, lds, tf, lane, wave, ring, prof, L.tune);
     } else {
-        conv_kloop<M16, 1, T, NWV, PROF, SPLIT>(g, L.wblob, vd, ops, it, n_items, lds, tf, lane, wave, ring, prof, L.tune);
+        conv_kloop<M16, 1, T, NWV, PROF>(g, L.wblob, vd, ops, it, n_items, lds, tf, lane, wave, ring, prof, L.tune);
     }
     if (PROF) stamp(prof ? prof + 7 : nullptr, tid);
     // head of the next op's weight stream: flies through the barrier and the epilogue
@@ -1017,33 +1035,35 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
     if (PROF) stamp(prof ? prof + 1 : nullptr, tid);
     __syncthreads();
     if (PROF) stamp(prof ? prof + 2 : nullptr, tid);
-    const EpiParams Pnext = PARAMS_AFTER_BARRIER ? load_params<COND, SPLIT_T, false, MLP, SPLIT>(L, vdn, emb_next, emb_next_tstride, tid, wave, epi_wave)
+    const EpiParams Pnext = PARAMS_AFTER_BARRIER ? load_params<COND, SPLIT_T, false, MLP, MEMBER>(L, vdn, emb_next, emb_next_tstride, tid, wave, epi_wave)
                                                  : (PIPE ? F.P : P);
 
-    EpiDesc e = decode_epi<BWD>(vd);
-    int stage_e = g.stage;
+    const EpiDesc e = decode_epi<BWD>(vd);
     int xgw = 0, gmap = 0;
-    bool gop = false;
     if (SPLIT) {
         int vde = vd;
         asm volatile("" : "+v"(vde));                   // (decode from scratch: see above)
         xgw = CDX2_DW(vde, CDX2_W2_XG);
-        gop = (xgw & CDX2_XG_GOP) != 0;
         if (xgw & (CDX2_XG_GOP | CDX2_XG_TRAJ)) gmap = CDX2_DW(vde, CDX2_W2_GMAP);
-        if (gop) {
-            // grouped op: half-wave `grp` = trajectory grp / gpm of the group, lane group gx_lo + grp % gpm (gpm = 8 / k is 2 or 4, so the
-            // two half-waves of a wave belong to the same trajectory: g_t is wave-uniform).  This half-wave's trajectory: its sub-slot
-            // of the destination / residual slots, its columns of the staged tiles (which hold only the member's channels: relative to
-            // the first one), K slices `k x l_out` positions apart
-            const int gx_lo = xgw & 255, gpm = ((xgw >> 8) & 255) - gx_lo, grows = gmap >> 8;
-            const int g_t = __builtin_amdgcn_readfirstlane(gpm == 4 ? grp >> 2 : grp >> 1);
-            c = (gx_lo + (grp & (gpm - 1))) * (coutp >> 3) + 4 * (li & ((1 << shift) - 1));
-            e.dst += g_t * grows * e.dstride;
-            e.res += g_t * grows * e.rstride;
-            stage_e += g_t * l_out * sstride - gx_lo * (coutp >> 3);
-            e.l_out = l_out * X->k;
-        }
     }
+    if (SPLIT && (xgw & CDX2_XG_GOP)) {
+        // ---- grouped op (T = 1): half-wave `grp` = trajectory grp / gpm of the group, lane group gx_lo + grp % gpm (gpm = 8 / k is 2 or 4,
+        // so the two half-waves of a wave belong to the same trajectory: g_t is wave-uniform).  This half-wave's trajectory: its sub-slot
+        // of the destination / residual slots, its columns of the staged tiles (which hold only the member's channels: relative to the
+        // first one), K slices `k x l_out` positions apart.  Every half-wave works.
+        const int gx_lo = xgw & 255, gpm = ((xgw >> 8) & 255) - gx_lo, grows = gmap >> 8;
+        if (epi_wave) {
+            const int g_t = __builtin_amdgcn_readfirstlane(gpm == 4 ? grp >> 2 : grp >> 1);
+            const int cgo = (gx_lo + (grp & (gpm - 1))) * (coutp >> 3) + 4 * (li & ((1 << shift) - 1));
+            EpiDesc eg = e;
+            eg.dst += g_t * grows * e.dstride;
+            eg.res += g_t * grows * e.rstride;
+            eg.l_out = l_out * X->k;
+            const int stage_g = g.stage + g_t * l_out * sstride - gx_lo * (coutp >> 3);
+            if (e.nk == 1) epilogue<1, BWD, COND, MLP>(lds, P, eg, stage_g, cgo, pos0, pstep, li, nv, lane, grp, nullptr);
+            else epilogue<2, BWD, COND, MLP>(lds, P, eg, stage_g, cgo, pos0, pstep, li, nv, lane, grp, nullptr);
+        }
+    } else {
     const int t_lo = SPLIT_T ? (wave >> 2) : 0, t_step = SPLIT_T ? 2 : 1;
 #pragma unroll 1
     for (int t = t_lo; t < T; t += t_step) {
@@ -1058,43 +1078,44 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
                 P.em = *reinterpret_cast<const f32x4*>(pe + e.coutp);
             } else P.em = *reinterpret_cast<const f32x4*>(pe);
         }
-        // (split programs: the half-waves of lane groups that belong to other members sit this op's epilogue out; in a grouped op
-        //  every half-wave works -- on the member's lane groups of one of the group's trajectories)
+        // (split programs: the half-waves of lane groups that belong to other members sit this op's epilogue out)
         const int xg = SPLIT ? xgw : 0;
-        if (epi_wave && (!SPLIT || gop || (xg & 0xffff) == 0 || (grp >= (xg & 255) && grp < ((xg >> 8) & 255)))) {
+        if (epi_wave && (!SPLIT || (xg & 0xffff) == 0 || (grp >= (xg & 255) && grp < ((xg >> 8) & 255)))) {
             if (BWD && (e.flags & CDX2_F2_GNBWD)) {
                 if (e.nk == 1) epilogue_bwd<1>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
                 else if (e.nk == 2) epilogue_bwd<2>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
                 else epilogue_bwd<CDX2_MAX_NK2>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
-            } else if (e.nk == 1) epilogue<1, BWD, COND, MLP>(tl, P, e, stage_e, c, pos0, pstep, li, nv, lane, grp, ws);
-            else if (e.nk == 2) epilogue<2, BWD, COND, MLP>(tl, P, e, stage_e, c, pos0, pstep, li, nv, lane, grp, ws);
-            else epilogue<CDX2_MAX_NK2, BWD, COND, MLP>(tl, P, e, stage_e, c, pos0, pstep, li, nv, lane, grp, ws);
+            } else if (e.nk == 1) epilogue<1, BWD, COND, MLP>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
+            else if (e.nk == 2) epilogue<2, BWD, COND, MLP>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
+            else epilogue<CDX2_MAX_NK2, BWD, COND, MLP>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
         }
-        if (halo_wave) {
+        if (halo_wave && !(SPLIT && (xgw & CDX2_XG_TRAJ))) {
             // wave w (mod 4) rewrites halo row w of the destination (the arena hands this LDS to slots of other shapes in between)
             const int hw = wave & 3;
-            const int hrow = hw < CDX2_HALO2 ? hw : l_out + hw;
-            if (SPLIT && (xgw & (CDX2_XG_GOP | CDX2_XG_TRAJ))) {
-                // ... of every trajectory's sub-slot (XG_TRAJ: the exchange brings the other trajectories' data rows only; the descriptor's
-                // destination is this member's sub-slot)
-                const int hrows = gmap >> 8;
-                const int dbase = CDX2_DW(vd, CDX2_W2_DST) - ((xgw & CDX2_XG_TRAJ) ? X->m * hrows * e.dstride : 0);
-                for (int tt = 0; tt < X->k; ++tt)
-                    for (int j = lane * 4; j < e.dstride; j += 256)
-                        *reinterpret_cast<f32x4*>(tl + dbase + (tt * hrows + hrow) * e.dstride + j) = (f32x4){0.f, 0.f, 0.f, 0.f};
-            } else {
-                for (int j = lane * 4; j < e.dstride; j += 256)
-                    *reinterpret_cast<f32x4*>(tl + e.dst + hrow * e.dstride + j) = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
+            const int hrow = hw < CDX2_HALO2 ? hw : e.l_out + hw;
+            for (int j = lane * 4; j < e.dstride; j += 256)
+                *reinterpret_cast<f32x4*>(tl + e.dst + hrow * e.dstride + j) = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (BWD && (e.flags & CDX2_F2_DUAL))
                 for (int j = lane * 4; j < e.d2stride; j += 256)
                     *reinterpret_cast<f32x4*>(tl + e.dst2 + hrow * e.d2stride + j) = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     }
+    }
+    if (SPLIT && halo_wave && (xgw & (CDX2_XG_GOP | CDX2_XG_TRAJ))) {
+        // group slots: halo row w of EVERY trajectory's sub-slot (XG_TRAJ: the exchange brings the other trajectories' data rows only;
+        // the descriptor's destination is this member's sub-slot)
+        const int hw = wave & 3;
+        const int hrow = hw < CDX2_HALO2 ? hw : l_out + hw;
+        const int hrows = gmap >> 8;
+        const int dbase = e.dst - ((xgw & CDX2_XG_TRAJ) ? X->m * hrows * e.dstride : 0);
+        for (int tt = 0; tt < X->k; ++tt)
+            for (int j = lane * 4; j < e.dstride; j += 256)
+                *reinterpret_cast<f32x4*>(lds + dbase + (tt * hrows + hrow) * e.dstride + j) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     if (PIPE) F.P = Pnext;
     if (SPLIT && (xgw & CDX2_XG_XCHG)) {
         __syncthreads();                                             // the epilogue's stores to the destination slot are in LDS
-        split_exchange<WG<NWV>::THREADS>(*X, xgw, gmap, lds, CDX2_DW(vd, CDX2_W2_DST), e.dstride, l_out, e.c_out, e.coutp, tid);
+        split_exchange<WG<NWV>::THREADS>(*X, xgw, gmap, lds, e.dst, e.dstride, l_out, e.c_out, e.coutp, tid);
     }
     __syncthreads();
     if (PROF) stamp(prof ? prof + 3 : nullptr, tid);
@@ -1247,9 +1268,9 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
             if (on2 >= L.n_ops) on2 = 0;
             // (MLP programs: `pass` tells the context-slot op what to load -- 0 the condition, 1 zeros (unconditional forward of a
             //  pair), 2 nothing: one forward per step and the slot was filled by step 0)
-            run_op<T, NWV, BWD, PROF, COND, MLP, SPLIT>(L, ops, vd, vdn, it, emb_row, emb_tstride, lds, tid, ring, pslot, b0, F,
-                                                        wrap ? emb_fwd_next : emb_row, wrap ? ts_fwd_next : emb_tstride, on2,
-                                                        (MLP && n_pass == 1 && step > 0) ? 2 : pass, &X);
+            run_op<T, NWV, BWD, PROF, COND, MLP, SPLIT, SPLIT>(L, ops, vd, vdn, it, emb_row, emb_tstride, lds, tid, ring, pslot, b0, F,
+                                                               wrap ? emb_fwd_next : emb_row, wrap ? ts_fwd_next : emb_tstride, on2,
+                                                               (MLP && n_pass == 1 && step > 0) ? 2 : pass, &X);
             vd = vdn;
             if (PIPE) vdn_keep = F.vdn2;
         }

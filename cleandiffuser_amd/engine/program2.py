@@ -328,7 +328,8 @@ class _Builder2:
             # the member's 1/k of the row tiles = whole GroupNorm lane groups, or the op stays an ordinary one on the member's own trajectory
             cgw = coutp // GROUPS2
             lo_c, hi_c = mem * n_rt // ksp * rows, (mem + 1) * n_rt // ksp * rows
-            if n_rt % ksp or n_cg != 1 or coutp != c_out or lo_c % cgw or hi_c % cgw or GROUPS2 % ksp:
+            # (... and at most two float4 items per epilogue lane: the grouped epilogue of the kernel is instantiated for 1 and 2)
+            if n_rt % ksp or n_cg != 1 or coutp != c_out or lo_c % cgw or hi_c % cgw or GROUPS2 % ksp or -(-(cgw // 4 * l_out) // 32) > 2:
                 gop, l_cols = False, l_out
                 mode = MODE_4X4 if (l_cols <= 8 and c_out % 64 == 0 and self.allow_4x4) else MODE_16X16
                 rows, cols = (16, 16) if mode == MODE_16X16 else (64, 4)
