@@ -25,7 +25,7 @@ The ONE JSON line (rank 0):
 * ``cpu_baseline`` (N = 1) -- the imported reference classes when /root/reference is mounted (``kind: "reference"``; build
   container), else the CPU oracle port (oracle/torch_port.py, the same ATen ops the reference runs; ``kind: "port"``; GPU boxes) on
   this host: at the fastest thread count of a probe and at ONE thread, with the CPU model and torch build; plus the recorded figure
-  of the real reference measured in the build container (profiles/r02_reference_cpu.json).  Reported baseline only.
+  of the real reference measured in the build container (profiles/r04_reference_cpu.json, re-measured per round by tools/measure_reference_cpu.py).  Reported baseline only.
 """
 import argparse
 import json
@@ -146,11 +146,15 @@ def cpu_baseline(net, budget_s=10.0):
         n1 += 1
     dt1 = time.perf_counter() - t1
     ref = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_reference_cpu.json")) as f:
-            ref = json.load(f)
-    except (OSError, ValueError):
-        pass
+    for name in ("r04_reference_cpu.json", "r02_reference_cpu.json"):      # the newest record of the REAL reference (build container)
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                ref = json.load(f)
+            ref["record"] = f"profiles/{name} -- a RECORDED figure (round {ref.get('round', 2)}, {ref.get('measured_on', 'date not recorded')}), " \
+                            "not measured by this run: /root/reference does not exist on the GPU box"
+            break
+        except (OSError, ValueError):
+            continue
     blas = [ln.strip() for ln in torch.__config__.show().splitlines() if "BLAS" in ln or "MKL" in ln or "OpenMP" in ln][:4]
     how = "the imported reference classes (/root/reference)" if kind == "reference" else "oracle/torch_port.py (no /root/reference on this box)"
     return {"value": 256 * n / dt, "unit": "trajectories/s", "cores": cores, "kind": kind,
@@ -159,7 +163,7 @@ def cpu_baseline(net, budget_s=10.0):
             "all_cores": {"value": 256 / probe[avail], "cores": avail, "sample": "one call after a warm-up"},
             "one_thread": {"value": 256 * n1 / dt1, "cores": 1, "sample": f"{n1} calls, {dt1:.1f}s wall"},
             "cpu_model": _cpu_model(), "torch": torch.__version__, "torch_build": blas,
-            "reference_in_build_container": ref}
+            "reference_in_build_container_recorded": ref}
 
 
 def cpu_baseline_subprocess(timeout_s=240):
@@ -280,9 +284,10 @@ def other_configs(device):
         has_native = True
     except ImportError:
         has_native = False
-    for native in ([True, False] if has_native else [None]):
+    for native, graph in ([(True, True), (True, False), (False, False)] if has_native else [(None, False)]):
+        tag = "config2_update_B256" + ("_hipgraph" if graph else "" if native in (True, None) else "_autograd")
         try:
-            label, call, b = bc.cfgU(256, native_backward=native)
+            label, call, b = bc.cfgU(256, native_backward=native, graph=graph)
             for _ in range(3):
                 call()
             torch.cuda.synchronize(device)
@@ -293,11 +298,13 @@ def other_configs(device):
             dt = (time.perf_counter() - t0) / 20
             how = ("forward / backward in the library's kernels (engine/train.py)" if native else
                    "forward / backward on PyTorch autograd (ATen / MIOpen kernels)")
-            out.append({"name": "config2_update_B256" + ("" if native in (True, None) else "_autograd"), "workload": label,
-                        "value": 1.0 / dt, "unit": "update_steps/s", "ms_per_call": 1e3 * dt,
+            if graph:
+                how += ", captured once and replayed as ONE HIP graph per step (opt-in: CDX_TRAIN_GRAPH=1)"
+            out.append({"name": tag, "workload": label, "value": 1.0 / dt, "unit": "update_steps/s", "ms_per_call": 1e3 * dt,
                         "what": how + "; gradient-norm clip + AdamW + EMA: cdx_optim_f32 (3 launches)"})
         except Exception as e:  # noqa: BLE001
-            out.append({"name": "config2_update_B256", "error": f"{type(e).__name__}: {e}"})
+            out.append({"name": tag, "error": f"{type(e).__name__}: {e}"})
+    os.environ.pop("CDX_TRAIN_GRAPH", None)
     os.environ.pop("CDX_TRAIN_NATIVE", None)
     return out
 

@@ -152,7 +152,9 @@ def pack_conv_transpose_k4s2p1(weight: torch.Tensor):
     parity:  out[2j]   = W[:, :, 3]^T x[j-1] + W[:, :, 1]^T x[j]     (taps at shifts -1, 0  -> pad 1)
              out[2j+1] = W[:, :, 2]^T x[j]   + W[:, :, 0]^T x[j+1]   (taps at shifts  0, +1 -> pad 0)"""
     w = weight.detach().permute(1, 2, 0)                      # (c_out, 4, c_in)
-    return w[:, [3, 1]].contiguous(), w[:, [2, 0]].contiguous()
+    # (stack of slices, not w[:, [3, 1]]: a list index becomes a host -> device copy of an index tensor, which a HIP-graph capture of
+    #  the training step refuses)
+    return torch.stack((w[:, 3], w[:, 1]), dim=1).contiguous(), torch.stack((w[:, 2], w[:, 0]), dim=1).contiguous()
 
 
 def conv_transpose1d_k4s2p1(x: torch.Tensor, packed, bias, batch: int, l_in: int, out: Optional[torch.Tensor] = None):

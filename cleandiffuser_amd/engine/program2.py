@@ -1,9 +1,8 @@
-"""Network -> device program for the second-generation fused U-Net kernel (``csrc/cdx_unet2.hip``).
-
-Same idea as ``program.py`` (one launch = the whole ``sample()`` loop, activations resident in LDS, weights streamed as
-1-KiB MFMA records).  The format is shaped by what the round-2 profiles showed: with one workgroup per CU the kernel is bound by
-per-op latency and by *instruction issue* (a wave64 issues about one instruction every four clocks), so everything the K loop
-does per weight record beyond "wait, 4 MFMAs, one LDS read, one global load" was designed out on the host side:
+"""Network -> device program for the fused program kernel (``csrc/cdx_unet2.hip``): one launch = the whole ``sample()`` loop,
+activations resident in LDS, weights streamed as 1-KiB MFMA records.  (The round-1 compiler ``program.py`` and its kernel were deleted
+in round 3; this is the only program format.)  The format is shaped by what the round-2 profiles showed: with one workgroup per CU the
+kernel is bound by per-op latency and by *instruction issue* (a wave64 issues about one instruction every four clocks), so everything the
+K loop does per weight record beyond "wait, 4 MFMAs, one LDS read, one global load" was designed out on the host side:
 
 * **4 or 8 wave64 per workgroup** (one or two per SIMD; a program is compiled for ONE shape, ``Program2.nw``); a conv's output
   is cut into (row tile x column group) *tiles*, one work item per wave; a layer with fewer tiles than waves splits K over the
@@ -27,8 +26,11 @@ does per weight record beyond "wait, 4 MFMAs, one LDS read, one global load" was
   offsets below are relative to the trajectory base.
 
 Descriptor words ``W2_*`` / item words ``I2_*`` MUST mirror ``csrc/cdx_ops2.h`` (tests/test_abi_contract.py checks).
-Activations: channel-last rows ``slot[(pos + HALO2) * stride + c]``, ``stride = pad16(C) + 4``.  Conv records: identical lane
-layouts to program.py (MODE_16X16 / MODE_4X4).
+Activations: channel-last rows ``slot[(pos + HALO2) * stride + c]``, ``stride = pad16(C) + 4``.  Conv records: ``_records`` below
+(MODE_16X16: lane = k4 * 16 + row, 16 K values per record; MODE_4X4: lane = row, 4 K values).
+
+Round 4 added GROUPED programs (``compile_janner2_group``): k trajectories over the k workgroups of a group, the stream-bound layers
+computed per member for 1/k of the output channels of all k trajectories -- see that function.
 """
 import os
 from dataclasses import dataclass, field
@@ -85,7 +87,7 @@ F2_GN, F2_EMB, F2_RES, F2_PRED, F2_SAVE, F2_GNBWD, F2_DUAL, F2_SAVE_GLOBAL, F2_F
 # F2_COLNORM (with F2_GN): statistics per POSITION over the group's channels (a per-sample GroupNorm, reference pearcemlp.py FCBlock);
 # F2_BIAS_EMB: the bias vector is read from the per-step table row at W2_BOFF (bias + the time-dependent part of the layer's input);
 # F2_OUT_DIV: the stored value is divided by the float in W2_ODIV (PearceMlp's h / 1.414); bits 12-15: activation id + 1 of
-# program.py's ACT_* (0 = the default: Mish after a GroupNorm, none otherwise), applied after the norm, before + emb / + residual
+# consts.ACT_* (0 = the default: Mish after a GroupNorm, none otherwise), applied after the norm, before + emb / + residual
 F2_COLNORM, F2_BIAS_EMB, F2_OUT_DIV = 512, 1024, 2048
 F2_ACT_SHIFT = 12
 W2_ODIV = 26                  # forward ops: alias of W2_SAVE_STRIDE (a backward-pass word)
@@ -176,7 +178,8 @@ class Program2:
 
 def _records(w_eff: torch.Tensor, mode: int) -> Tuple[torch.Tensor, int]:
     """w_eff [C_out][taps][C_in] -> records [n_row_tiles][taps * cc][64][4] and cc = chunks per tap.
-    Lane layouts as program.py:pack_conv: MODE_16X16 lane = k4*16 + row, 16 K per record; MODE_4X4 lane = row, 4 K."""
+    Lane layouts: MODE_16X16 lane = k4*16 + row, 16 K per record; MODE_4X4 lane = row, 4 K (asserted on silicon by
+    tests/test_gpu_parity.py::test_mfma_lane_maps_on_silicon)."""
     c_out, taps, cs = w_eff.shape
     rows, kch = (16, 16) if mode == MODE_16X16 else (64, 4)
     n_ct = -(-c_out // rows)

@@ -75,7 +75,7 @@ class _Conv(torch.autograd.Function):
                 dx = torch.empty((batch * l_in, c_in), device=dy.device, dtype=torch.float32)
                 view = dx.view(batch * l_out, 2 * c_in)                                    # row (b, j) = [dx[2j] | dx[2j + 1]]
                 blocks.conv1d(dy, w[:, 1:2].contiguous(), None, batch, l_out, 1, 0, out=view[:, :c_in], l_out=l_out)
-                blocks.conv1d(dy, w[:, [2, 0]].contiguous(), None, batch, l_out, 1, 0, out=view[:, c_in:], l_out=l_out)
+                blocks.conv1d(dy, torch.stack((w[:, 2], w[:, 0]), dim=1).contiguous(), None, batch, l_out, 1, 0, out=view[:, c_in:], l_out=l_out)
         want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             dw = blocks.conv_wgrad(dy, x, batch, l_out, l_in, k, stride, pad, bias_grad=want_db)       # (c_out, c_in, k)[, (c_out,)]
@@ -184,3 +184,65 @@ def janner_forward(net, x: torch.Tensor, noise: torch.Tensor, condition: Optiona
     h = _cna(h, fc, b, length)
     h = _conv(h, fc[3], b, length)
     return h.view(b, length, d)
+
+
+# --------------------------------------------------------------------------------------------------------------------- #
+# forward + backward of update() as ONE HIP graph (opt-in: CDX_TRAIN_GRAPH=1)                                            #
+# --------------------------------------------------------------------------------------------------------------------- #
+class GraphedStep:
+    """``loss = agent.loss(x0, condition); loss.backward()`` captured once into a HIP graph and replayed per step.
+
+    update() of config 2 is ~600 autograd nodes: ~14 ms of Python / dispatcher time per step at ANY batch size against ~8 ms of kernel
+    time (profiles/r04_update_bench.txt) -- launch-bound, which is what HIP graphs are for.  Everything inside the captured region is
+    capturable by construction: the library's launches go to the current (capturing) stream and allocate nothing, torch's allocations
+    come from the graph's private pool, the timestep / noise draws of ``add_noise`` use the graph-safe device generator.  Static
+    buffers: the batch (copied in before each replay), the loss, the parameters' ``.grad`` tensors (allocated by the warm-up steps;
+    the captured backward ACCUMULATES into them in place -- the optimiser zeroes them in place after each step).
+
+    Not captured: the optimiser step (its bias-correction scalars change per step and travel as kernel arguments), ``loss.item()``."""
+
+    def __init__(self, agent, x0: torch.Tensor, condition: Optional[torch.Tensor]):
+        dev = x0.device
+        self.x0 = x0.detach().clone()
+        self.cond = None if condition is None else condition.detach().clone()
+        params = [p for p in agent.model.parameters() if p.requires_grad]
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):                         # warm-up: lazy initialisation, allocator, the .grad tensors
+                agent.loss(self.x0, self.cond).backward()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        for p in params:                               # the warm-up gradients are not part of any step
+            if p.grad is not None:
+                p.grad.zero_()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = agent.loss(self.x0, self.cond)
+            self.loss.backward()
+        for p in params:                               # (capture does not run the kernels; keep the grads as the warm-up left them: zero)
+            if p.grad is not None:
+                p.grad.zero_()
+
+    def replay(self, x0, condition):
+        self.x0.copy_(x0)
+        if self.cond is not None:
+            self.cond.copy_(condition)
+        self.graph.replay()
+        return self.loss
+
+
+def graphed_step(agent, x0, condition, kwargs) -> Optional[GraphedStep]:
+    """The cached GraphedStep of (agent, batch shape) when CDX_TRAIN_GRAPH=1 and the request is one the native training path serves
+    (JannerUNet1d on a ROCm device, no extra loss arguments); else None."""
+    if os.environ.get("CDX_TRAIN_GRAPH", "0") != "1" or kwargs or not x0.is_cuda:
+        return None
+    net = agent.model["diffusion"]
+    with torch.enable_grad():
+        if not supports(net, x0):
+            return None
+    key = (tuple(x0.shape), None if condition is None else tuple(condition.shape))
+    cache = agent.__dict__.setdefault("_cdx_graphed", {})
+    g = cache.get(key)
+    if g is None:
+        g = cache[key] = GraphedStep(agent, x0, condition)
+    return g

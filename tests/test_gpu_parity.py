@@ -1318,6 +1318,42 @@ def test_update_runs_without_aten_conv_or_groupnorm_kernels(amd_lib):
         assert float((p.detach().cpu() - q.detach()).abs().max()) <= 2e-5 * max(1.0, float(q.detach().abs().max())) + 1.1e-6, n
 
 
+def test_graphed_update_equals_the_eager_native_update(amd_lib, monkeypatch):
+    """CDX_TRAIN_GRAPH=1: forward + backward of update() captured once into a HIP graph (engine/train.py:GraphedStep) and replayed per
+    step.  With the timestep / noise draws pinned (the graph uses the device generator's graph-safe stream, an eager step the ordinary
+    one) five replayed updates on changing batches must land on the same losses, gradient norms and weights as five eager native
+    updates of a twin -- including the optimiser's `None`-gradient bookkeeping (a replay does not move version counters)."""
+    from copy import deepcopy
+    from cleandiffuser_amd.utils import load_synth
+    net = load_synth(amd_lib.JannerUNet1d(23, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2, 2], kernel_size=5), 7)
+    fm = torch.zeros(32, 23)
+    fm[0, :17] = 1.0
+    mk = lambda n: amd_lib.DiscreteDiffusionSDE(n, None, fix_mask=fm, diffusion_steps=20, predict_noise=False, grad_clip_norm=1.0, device=DEV)  # noqa: E731
+    a, b = mk(deepcopy(net)), mk(deepcopy(net))
+    B = 64
+    g = torch.Generator().manual_seed(5)
+    t_fix = torch.randint(20, (B,), generator=g).to(DEV)
+    eps_fix = torch.randn(B, 32, 23, generator=g).to(DEV)
+    for agent in (a, b):
+        def add_noise(x0, t=None, eps=None, agent=agent):
+            alpha, sigma = agent.alpha[t_fix].view(-1, 1, 1), agent.sigma[t_fix].view(-1, 1, 1)
+            xt = alpha * x0 + sigma * eps_fix
+            return (1. - agent.fix_mask) * xt + agent.fix_mask * x0, t_fix, eps_fix
+        agent.add_noise = add_noise
+    batches = [torch.randn(B, 32, 23, generator=g).to(DEV) for _ in range(5)]
+    monkeypatch.setenv("CDX_TRAIN_GRAPH", "1")
+    la = [a.update(x) for x in batches]
+    assert len(a.__dict__.get("_cdx_graphed", {})) == 1, "one captured graph for the one batch shape"
+    monkeypatch.setenv("CDX_TRAIN_GRAPH", "0")
+    lb = [b.update(x) for x in batches]
+    for u, v in zip(la, lb):
+        assert abs(u["loss"] - v["loss"]) <= 1e-5 * max(1.0, abs(v["loss"])), (u, v)
+        assert abs(float(u["grad_norm"]) - float(v["grad_norm"])) <= 1e-4 * float(v["grad_norm"])
+    for (n, p), q in zip(list(a.model.named_parameters()) + list(a.model_ema.named_parameters()),
+                         list(b.model.parameters()) + list(b.model_ema.parameters())):
+        assert float((p.detach() - q.detach()).abs().max()) <= 2e-5 * max(1.0, float(q.detach().abs().max())), n
+
+
 def test_update_runs_without_aten_optimiser_launches(amd_lib):
     """config 2's update(): after loss.backward() the whole optimiser side -- gradient-norm clip, AdamW, EMA, zeroed gradients -- is
     the library's kernels (3 launches), and the result equals the PyTorch sequence (clip_grad_norm_, torch.optim.AdamW.step,

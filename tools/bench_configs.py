@@ -138,7 +138,7 @@ def cfgT(B=1024, steps=100):
     return f"ChiTransformer dp_pusht d=256 h=4 L=8, Ta=16, {steps}-step DDPM, B={B}", call, B, 2.0 * tok * Ta * steps * B
 
 
-def cfgU(B=256, native_backward=None):
+def cfgU(B=256, native_backward=None, graph=False):
     """update() of config 2 (row f4): one training step on a batch of B trajectories -- forward + backward of the denoising loss,
     gradient-norm clip, AdamW, EMA.  Returns (label, call, B): `call` runs ONE update and returns the loss tensor."""
     from cleandiffuser_amd.nn_diffusion import JannerUNet1d
@@ -150,6 +150,7 @@ def cfgU(B=256, native_backward=None):
     x0 = torch.randn(B, H, D, device=DEV)
     if native_backward is not None:
         os.environ["CDX_TRAIN_NATIVE"] = "1" if native_backward else "0"
+    os.environ["CDX_TRAIN_GRAPH"] = "1" if graph else "0"
     call = lambda: torch.as_tensor(agent.update(x0)["loss"])  # noqa: E731
     return f"config 2 update(): JannerUNet1d H=32 D=23, batch {B}, loss + backward + clip + AdamW + EMA", call, B
 

@@ -1,6 +1,6 @@
 """BUILD CONTAINER ONLY: time the REAL reference (/root/reference, imported through oracle/ref_import.py) on BASELINE config 2
 -- DiscreteDiffusionSDE.sample(), JannerUNet1d H=32 D=23, 20-step DDIM, B=256 -- on this container's CPU, at torch's default
-thread count and at one thread, and record it as profiles/r02_reference_cpu.json.  bench.py carries the record along as a side
+thread count and at one thread, and record it as profiles/r<NN>_reference_cpu.json (NN = the round, argv[1]; default 04) with the date of the measurement.  bench.py carries the record along as a side
 figure next to its own cpu_baseline (which has to run on the GPU box, where /root/reference does not exist).
 Usage: python tools/measure_reference_cpu.py"""
 import json
@@ -16,6 +16,7 @@ from oracle import cases  # noqa: E402
 
 
 def main():
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "04"
     ref = cases.lib_namespace("reference")
     torch.manual_seed(0)
     net = ref.JannerUNet1d(23, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2, 2], kernel_size=5)
@@ -52,8 +53,8 @@ def main():
            "where": "build container (not the GPU box)", "cpu_model": model, "torch": torch.__version__,
            "all_threads": {"value": v_all, "unit": "trajectories/s", "threads": avail, "calls": n_all},
            "one_thread": {"value": v_one, "unit": "trajectories/s", "threads": 1, "calls": n_one},
-           "script": "tools/measure_reference_cpu.py"}
-    with open(os.path.join(ROOT, "profiles", "r02_reference_cpu.json"), "w") as f:
+           "script": "tools/measure_reference_cpu.py", "round": int(rnd), "measured_on": time.strftime("%Y-%m-%d")}
+    with open(os.path.join(ROOT, "profiles", f"r{rnd}_reference_cpu.json"), "w") as f:
         json.dump(rec, f, indent=1)
     print(json.dumps(rec))
 
