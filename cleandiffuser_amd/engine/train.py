@@ -187,6 +187,80 @@ def janner_forward(net, x: torch.Tensor, noise: torch.Tensor, condition: Optiona
 
 
 # --------------------------------------------------------------------------------------------------------------------- #
+# Linear (+ Mish) nodes: the MLP denoisers under autograd -- DQL's policy update back-propagates through sample()           #
+# --------------------------------------------------------------------------------------------------------------------- #
+class _LinearMish(torch.autograd.Function):
+    """y = [Mish](x W^T + b) on (batch, features) rows: forward = ``cdx_gemm_f32`` (bias in the epilogue) [+ ``cdx_act_f32``]; backward:
+    dz = dy * Mish'(z) (``cdx_act_bwd_f32``), dx = dz W (the same GEMM on the transposed weight), dW / db = ``cdx_conv_wgrad_f32`` with
+    one tap (a TN GEMM over the batch rows) and its bias column sums."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, mish):
+        x = x.contiguous()
+        z = blocks.linear(x, weight, bias)
+        ctx.mish = mish
+        ctx.save_for_backward(x, weight, z if mish else x.new_empty(0))
+        return blocks.activation(z, "mish") if mish else z
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, z = ctx.saved_tensors
+        dz = dy.contiguous()
+        if ctx.mish:
+            dz = blocks.activation_backward(z, dz, "mish")
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = blocks.linear(dz, weight.detach().t().contiguous())
+        if ctx.needs_input_grad[1]:
+            want_db = ctx.needs_input_grad[2]
+            dw = blocks.conv_wgrad(dz, x, x.shape[0], 1, 1, 1, bias_grad=want_db)
+            if want_db:
+                dw, db = dw
+            dw = dw.view(weight.shape)
+        elif ctx.needs_input_grad[2]:
+            db = blocks.colsum(dz)
+        return dx, dw, db, None
+
+
+def supports_mlp(net, x: torch.Tensor) -> bool:
+    """DQLMlp / DVInvMlp (Linear -> Mish trunks) with fp32 parameters on a ROCm device, called with autograd on -- what
+    ``sample(..., requires_grad=True)`` of the Diffusion-QL policy update runs at every denoising step (reference
+    pipelines/dql_d4rl_mujoco.py:101, diffusionsde.py:401-427)."""
+    if not (enabled() and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2):
+        return False
+    if type(net).__name__ not in ("DQLMlp", "DVInvMlp"):
+        return False
+    return all(p.dtype == torch.float32 and p.is_cuda for p in net.parameters())
+
+
+def _sequential(seq: nn.Sequential, h):
+    """Linear [-> Mish] chains of an nn.Sequential on the library's kernels (anything else: the module itself)."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.Linear) and m.bias is not None:
+            mish = i + 1 < len(mods) and isinstance(mods[i + 1], nn.Mish)
+            h = _LinearMish.apply(h, m.weight, m.bias, mish)
+            i += 2 if mish else 1
+        else:
+            h = m(h)
+            i += 1
+    return h
+
+
+def dql_forward(net, x: torch.Tensor, noise: torch.Tensor, condition: Optional[torch.Tensor]) -> torch.Tensor:
+    """``DQLMlp.forward`` / ``DVInvMlp.forward`` (reference nn_diffusion/dqlmlp.py:30-52, dvinvmlp.py:30-47) with autograd, every Linear
+    and Mish on the library's kernels: features = [x | time_mlp(map_noise(t)) | condition], trunk, head."""
+    if condition is None:
+        condition = torch.zeros(x.shape[0], net.obs_dim, device=x.device)
+    temb = _sequential(net.time_mlp, net.map_noise(noise).contiguous())
+    h = torch.cat([x, temb, condition], -1)
+    h = _sequential(net.mid_layer, h)
+    return _LinearMish.apply(h, net.final_layer.weight, net.final_layer.bias, False)
+
+
+# --------------------------------------------------------------------------------------------------------------------- #
 # forward + backward of update() as ONE HIP graph (opt-in: CDX_TRAIN_GRAPH=1)                                            #
 # --------------------------------------------------------------------------------------------------------------------- #
 class GraphedStep:

@@ -93,6 +93,9 @@ class DQLMlp(_ObsConditionedMlp):
         self.final_layer = nn.Linear(256, act_dim)
 
     def forward(self, x: torch.Tensor, noise: torch.Tensor, condition: Optional[torch.Tensor] = None):
+        from ..engine import train
+        if train.supports_mlp(self, x):       # autograd on, ROCm device (DQL back-propagates through sample()): Linear / Mish nodes on the library
+            return train.dql_forward(self, x, noise, condition)
         return self.final_layer(self.mid_layer(self._features(x, noise, condition)))
 
 
@@ -113,6 +116,9 @@ class DVInvMlp(_ObsConditionedMlp):
     def forward(self, x: torch.Tensor, noise: torch.Tensor, condition: torch.Tensor = None):
         if condition is None:
             raise TypeError("DVInvMlp needs the (obs, next_obs) condition")       # reference: torch.cat fails on None
+        from ..engine import train
+        if train.supports_mlp(self, x):
+            return train.dql_forward(self, x, noise, condition)
         return self.final_layer(self.mid_layer(self._features(x, noise, condition)))
 
 
