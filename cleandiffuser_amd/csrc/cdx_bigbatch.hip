@@ -868,7 +868,7 @@ struct UNet {                     // one pass over the op list; with dry == true
     int gn(const float* x, float* y, int L, int C, int G, const float* gamma, const float* beta, const float* fa, int ldfa,
            const float* fb, int ldfb, int film_mode, const float* residual) {
         if (dry) return CDX_OK;
-        cdx_gn_args q;
+        cdx_gn_args q{};          // (zero-initialised: the optional training outputs dgamma_part / dbeta_part must be NULL here)
         q.x = x; q.y = y; q.gamma = gamma; q.beta = beta; q.fa = fa; q.fb = fb; q.residual = residual;
         q.B = bf; q.L = L; q.C = C; q.G = G; q.ldx = C; q.ldy = C; q.ldr = C; q.ldfa = ldfa; q.ldfb = ldfb;
         q.fa_row = s->temb_per_sample ? 0 : rec; q.fa_per_sample = s->temb_per_sample; q.film_mode = film_mode;
@@ -1179,7 +1179,7 @@ struct HjPass {
     int gn(bool backward, const float* x, float* y, int L, int C, int G, const float* gamma, const float* beta, const float* fa,
            const float* res_or_dy) {
         if (dry) return CDX_OK;
-        cdx_gn_args q;
+        cdx_gn_args q{};          // (zero-initialised: the optional training outputs dgamma_part / dbeta_part must be NULL here)
         q.x = x; q.y = y; q.gamma = gamma; q.beta = beta; q.fa = fa; q.fb = nullptr; q.residual = res_or_dy;
         q.B = b; q.L = L; q.C = C; q.G = G; q.ldx = C; q.ldy = C; q.ldr = C; q.ldfa = C; q.ldfb = 0; q.fa_row = 0;
         q.fa_per_sample = 1; q.film_mode = fa ? 2 : 0; q.act = CDX_ACT_MISH; q.eps = 1e-5f;
