@@ -18,7 +18,7 @@ def _on_gpu(t: torch.Tensor) -> bool:
     return t.is_cuda
 
 
-def try_backbone_forward(module, x, noise, condition) -> Optional[torch.Tensor]:
+def _try_backbone_forward(module, x, noise, condition) -> Optional[torch.Tensor]:
     """Serve ``backbone.forward`` from the fused program kernel, or return None for the PyTorch path."""
     if not _on_gpu(x) or torch.is_grad_enabled() and _needs_grad(module, x, condition):
         return None
@@ -46,7 +46,7 @@ def _needs_grad(module, x, condition) -> bool:
     return any(p.requires_grad for p in module.parameters())
 
 
-def try_fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, requires_grad, feed):
+def _try_fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, requires_grad, feed):
     """Run the whole denoising loop in one launch, or return None for the PyTorch executor."""
     if not _on_gpu(xt) or requires_grad or xt.dtype != torch.float32:
         return None
@@ -64,7 +64,7 @@ def try_fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, requ
     return runtime.fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed)
 
 
-def try_fused_raw(solver, model, plan, z, temperature, prior, feed):
+def _try_fused_raw(solver, model, plan, z, temperature, prior, feed):
     """The common unconditional request before x_T exists: `z` is the initial N(0, I) draw.  When the second-generation U-Net
     kernel takes the request it forms x_T = (z * temperature) * (1 - fix_mask) + prior * fix_mask itself (reference
     diffusionsde.py:509-510), so a steady-state sample() call launches that kernel and nothing else.
@@ -83,7 +83,7 @@ def try_fused_raw(solver, model, plan, z, temperature, prior, feed):
     return runtime.fused_sample(solver, model, plan, z, prior, None, 0.0, feed, x_scale=float(temperature))
 
 
-def try_fused_edm(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, requires_grad, feed, condition_cg=None):
+def _try_fused_edm(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, requires_grad, feed, condition_cg=None):
     """``ContinuousEDM.sample``: big-batch executors for the GEMM-shaped backbones, the program kernel for the rest.  Classifier
     guidance (reference newedm.py:217-234: only with a classifier, w_cg != 0 AND a condition_cg) goes through the per-step guided
     executor; without a condition_cg the reference applies no shift, so the request is an unguided one."""
@@ -103,7 +103,7 @@ def try_fused_edm(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, require
     return runtime.fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed)
 
 
-def try_fused_legacy_ddpm(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, requires_grad, feed):
+def _try_fused_legacy_ddpm(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg, requires_grad, feed):
     """Legacy ``DDPM`` class: same fused executor, legacy step kinds."""
     if not _on_gpu(xt) or requires_grad or xt.dtype != torch.float32:
         return None
@@ -115,3 +115,22 @@ def try_fused_legacy_ddpm(solver, model, plan, xt, prior, cond_vec, w_cfg, w_cg,
         if out is not None:
             return out
     return runtime.fused_sample(solver, model, plan, xt, prior, cond_vec, w_cfg, feed)
+
+
+def _scoped(fn):
+    """One request = one signature scope (runtime.signature_scope): the weight signature of a module is computed once per request."""
+    import functools
+
+    @functools.wraps(fn)
+    def entry(*a, **k):
+        from .runtime import signature_scope
+        with signature_scope():
+            return fn(*a, **k)
+    return entry
+
+
+try_backbone_forward = _scoped(_try_backbone_forward)
+try_fused_sample = _scoped(_try_fused_sample)
+try_fused_raw = _scoped(_try_fused_raw)
+try_fused_edm = _scoped(_try_fused_edm)
+try_fused_legacy_ddpm = _scoped(_try_fused_legacy_ddpm)
