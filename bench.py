@@ -306,6 +306,25 @@ def other_configs(device):
             out.append({"name": tag, "error": f"{type(e).__name__}: {e}"})
     os.environ.pop("CDX_TRAIN_GRAPH", None)
     os.environ.pop("CDX_TRAIN_NATIVE", None)
+    # row f4, third slice: where the training batch comes from -- HBM-resident dataset buffers against the reference's host-side loader
+    for resident in (True, False):
+        tag = "d4rl_batches_B64_" + ("resident" if resident else "dataloader")
+        try:
+            label, nxt, b, nbytes = bc.cfgD(64, resident=resident)
+            for _ in range(5):
+                nxt()
+            torch.cuda.synchronize(device)
+            reps = 400 if resident else 40
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                batch = nxt()
+            torch.cuda.synchronize(device)
+            dt = (time.perf_counter() - t0) / reps
+            assert batch["act"].is_cuda and batch["obs"]["state"].shape[:2] == (b, 32)
+            out.append({"name": tag, "workload": label, "value": 1.0 / dt, "unit": "batches/s", "ms_per_call": 1e3 * dt,
+                        "batch_bytes": b * (32 * (11 + 3 + 1) + 1) * 4, "resident_bytes": nbytes})
+        except Exception as e:  # noqa: BLE001
+            out.append({"name": tag, "error": f"{type(e).__name__}: {e}"})
     return out
 
 

@@ -12,6 +12,9 @@
 //                        nn.Conv1d: P = dY, Q = X -> dW[c_out][c_in][t]; nn.ConvTranspose1d(4, 2, 1): P = X, Q = dY -> dW[c_in][c_out][t].
 //   cdx_colsum_f32       out[c] += sum_r x[r][c]          (bias gradients; GroupNorm gain / shift gradients from their per-sample partials)
 //   cdx_groupnorm_bwd_f32 (csrc/cdx_gemm.hip) grew two optional outputs: per-(sample, channel) partial sums of dz * x_hat and dz.
+//   cdx_gather_windows_f32  the batch a training step consumes, gathered from episode arrays resident in HBM (reference: host-side
+//                        collation, dataset/d4rl_mujoco_dataset.py:138-151 + a DataLoader + an H2D copy per step): per field and batch item one
+//                        contiguous segment copy; HBM-bound byte movement, every field of the batch in ONE launch.
 //
 // Sums over rows are split over workgroups and combined with float atomics into a buffer the caller zeroed (torch's own conv backward
 // does the same; the order is not fixed, gradients of two identical steps agree to ~1e-7 relative).
@@ -129,6 +132,27 @@ __global__ __launch_bounds__(256) void cdx_colsum_kernel(const float* __restrict
     if (ty == 0 && c < C) atomicAdd(out + c, (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]));
 }
 
+
+// ---- batch gather ------------------------------------------------------------------------------------------------------
+// grid (segment tiles, batch items in groups of GT_ITEMS, fields): a workgroup copies, for GT_ITEMS consecutive batch items, its 1-KiB
+// slice of their segments of one field.  Segments start at arbitrary float offsets (width 17 / 11 / 23 ...), so the copy is dword-wide
+// and coalesced along the segment; the source rows of a window are consecutive, i.e. a segment is one contiguous run in HBM.
+constexpr int GT_ITEMS = 8;
+__global__ __launch_bounds__(256) void cdx_gather_kernel(const cdx_gather_args g) {
+    const cdx_gather_field f = g.field[blockIdx.z];
+    const int seg = f.width * f.steps;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= seg) return;
+    const int b0 = blockIdx.y * GT_ITEMS;
+#pragma unroll
+    for (int i = 0; i < GT_ITEMS; ++i) {
+        const int b = b0 + i;
+        if (b >= g.batch) break;
+        const long r = g.row0[b];
+        f.out[(size_t)b * seg + j] = f.src[(size_t)r * f.width + j];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -166,6 +190,31 @@ int cdx_colsum_f32(const float* x, float* out, long long rows, int32_t cols, int
     if (rows == 0) return CDX_OK;
     const dim3 grid((cols + 63) / 64, (unsigned)((rows + CS_ROWS - 1) / CS_ROWS));
     hipLaunchKernelGGL(cdx_colsum_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), x, out, (long)rows, cols, ld);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
+    return CDX_OK;
+}
+
+int cdx_gather_windows_f32(const cdx_gather_args* a, void* hip_stream) {
+    cdx_set_err("");
+    if (!a) { cdx_set_err("cdx_gather_windows_f32: null argument block"); return CDX_EINVAL; }
+    if (a->batch < 0 || a->n_fields <= 0 || a->n_fields > CDX_GATHER_MAX_FIELDS || a->rows < 0) {
+        cdx_set_err("cdx_gather_windows_f32: bad shape"); return CDX_EINVAL;
+    }
+    if (a->batch == 0) return CDX_OK;
+    if (!a->row0) { cdx_set_err("cdx_gather_windows_f32: null pointer"); return CDX_EINVAL; }
+    int seg_max = 0;
+    for (int i = 0; i < a->n_fields; ++i) {
+        const cdx_gather_field& f = a->field[i];
+        if (!f.src || !f.out) { cdx_set_err("cdx_gather_windows_f32: null pointer"); return CDX_EINVAL; }
+        if (f.width <= 0 || f.steps <= 0 || f.steps > a->rows || (long long)f.width * f.steps > (1 << 24)) {
+            cdx_set_err("cdx_gather_windows_f32: bad field shape"); return CDX_EINVAL;
+        }
+        if (f.width * f.steps > seg_max) seg_max = f.width * f.steps;
+    }
+    const dim3 grid((seg_max + 255) / 256, (a->batch + GT_ITEMS - 1) / GT_ITEMS, a->n_fields);
+    if (grid.y > 65535) { cdx_set_err("cdx_gather_windows_f32: batch too large for one launch (<= 524280 items)"); return CDX_EINVAL; }
+    hipLaunchKernelGGL(cdx_gather_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), *a);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
     return CDX_OK;

@@ -38,6 +38,18 @@ class CdxWgradArgs(ctypes.Structure):
                [("db", ctypes.c_void_p)]
 
 
+GATHER_MAX_FIELDS = 8
+
+
+class CdxGatherField(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("out", ctypes.c_void_p), ("width", ctypes.c_int32), ("steps", ctypes.c_int32)]
+
+
+class CdxGatherArgs(ctypes.Structure):
+    _fields_ = [("row0", ctypes.c_void_p), ("batch", ctypes.c_int32), ("n_fields", ctypes.c_int32), ("rows", ctypes.c_longlong),
+                ("field", CdxGatherField * GATHER_MAX_FIELDS)]
+
+
 class CdxLnArgs(ctypes.Structure):
     _fields_ = [("x", ctypes.c_void_p), ("y", ctypes.c_void_p), ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p),
                 ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p),
@@ -83,6 +95,8 @@ def _lib():
         lib.cdx_conv_wgrad_f32.restype = ctypes.c_int
         lib.cdx_colsum_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
         lib.cdx_colsum_f32.restype = ctypes.c_int
+        lib.cdx_gather_windows_f32.argtypes = [ctypes.POINTER(CdxGatherArgs), ctypes.c_void_p]
+        lib.cdx_gather_windows_f32.restype = ctypes.c_int
         for f in (lib.cdx_gemm_f32, lib.cdx_layernorm_f32, lib.cdx_attention_f32, lib.cdx_act_f32):
             f.restype = ctypes.c_int
         _declared = True
@@ -217,6 +231,25 @@ def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         out = torch.zeros(c, device=x.device, dtype=torch.float32)
     _check(_lib().cdx_colsum_f32(x.data_ptr(), out.data_ptr(), r, c, _rows(x), _stream_ptr(x.device)), "cdx_colsum_f32")
     return out
+
+
+def gather_windows(row0: torch.Tensor, fields, rows: int):
+    """One launch: for every (src, steps) in `fields` -- src a (rows, width) fp32 device matrix -- the windows
+    out[b] = src[row0[b] : row0[b] + steps] -> list of (batch, steps, width) tensors.  `row0`: int32 device vector; the caller
+    guarantees row0 + steps <= rows (reference: D4RLMuJoCoDataset.__getitem__, dataset/d4rl_mujoco_dataset.py:138-151, per item on
+    the host)."""
+    assert row0.dtype == torch.int32 and row0.is_cuda and row0.dim() == 1 and row0.is_contiguous()
+    assert 0 < len(fields) <= GATHER_MAX_FIELDS
+    batch = row0.shape[0]
+    a = CdxGatherArgs(row0=row0.data_ptr(), batch=batch, n_fields=len(fields), rows=rows)
+    outs = []
+    for i, (src, steps) in enumerate(fields):
+        assert src.dtype == torch.float32 and src.is_cuda and src.dim() == 2 and src.is_contiguous() and src.shape[0] == rows
+        out = torch.empty(batch, steps, src.shape[1], device=src.device, dtype=torch.float32)
+        a.field[i] = CdxGatherField(src=src.data_ptr(), out=out.data_ptr(), width=src.shape[1], steps=steps)
+        outs.append(out)
+    _check(_lib().cdx_gather_windows_f32(ctypes.byref(a), _stream_ptr(row0.device)), "cdx_gather_windows_f32")
+    return outs
 
 
 def conv_wgrad(p: torch.Tensor, q: torch.Tensor, batch: int, l_p: int, l_q: int, taps: int, stride: int = 1, pad: int = 0,

@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define CDX_ABI_VERSION 11
+#define CDX_ABI_VERSION 12
 
 #define CDX_OK 0
 #define CDX_EINVAL (-1)   /* bad argument (null pointer, size out of range, misaligned offset) */
@@ -290,6 +290,29 @@ typedef struct cdx_wgrad_args {
 int cdx_conv_wgrad_f32(const cdx_wgrad_args* args, void* hip_stream);
 /* out[c] += sum_r x[r][c] (rows x cols, row stride ld); `out` zeroed by the caller (bias gradients, GroupNorm parameter gradients). */
 int cdx_colsum_f32(const float* x, float* out, long long rows, int32_t cols, int32_t ld, void* hip_stream);
+
+/* Batch assembly from dataset buffers that live in HBM (third slice: the reference collates a batch on the host --
+ * D4RLMuJoCoDataset.__getitem__, cleandiffuser/dataset/d4rl_mujoco_dataset.py:138-151, per item through a torch DataLoader with four
+ * worker processes, pipelines/diffuser_d4rl_mujoco.py:34-35,79-83 -- and copies it to the device every step).  Here the padded episode
+ * arrays stay on the device and ONE launch gathers every field of a batch:
+ *     field f:  out_f[b][s][c] = src_f[row0[b] + s][c]        s < steps_f, c < width_f
+ * i.e. a window of steps_f consecutive rows (one contiguous segment of steps_f * width_f floats) per batch item; row0[b] is the item's
+ * first row in the flattened (path * max_path_length + position) row space the fields share.  steps 1 = one row per item (the Monte
+ * Carlo return of the window's first step; every field of a transition dataset, d4rl_mujoco_dataset.py:214-225).  Pure data movement:
+ * the bytes are those of the reference's batch, bit for bit. */
+#define CDX_GATHER_MAX_FIELDS 8
+typedef struct cdx_gather_field {
+    const float* src;      /* device (rows, width), row-major, rows contiguous */
+    float* out;            /* device (batch, steps, width) */
+    int32_t width, steps;
+} cdx_gather_field;
+typedef struct cdx_gather_args {
+    const int32_t* row0;   /* device [batch] */
+    int32_t batch, n_fields;
+    long long rows;        /* rows of every src: row0[b] + steps <= rows is the CALLER's contract (checked on the host side of the loader) */
+    cdx_gather_field field[CDX_GATHER_MAX_FIELDS];
+} cdx_gather_args;
+int cdx_gather_windows_f32(const cdx_gather_args* args, void* hip_stream);
 
 /* out[b][t][h*d..] = softmax(q k^T * scale) v per (batch, head); qkv = (B*T, 3*n_heads*head_dim) from in_proj.
  * Replaces the core of nn.MultiheadAttention(batch_first=True) (reference dit.py:20,34).  T <= CDX_ATTN_MAX_T, head_dim <= 64

@@ -1,0 +1,117 @@
+"""Dataset scenarios for SURVEY.md 8(f4), third slice (GPU-resident D4RL-MuJoCo buffers).  TEST INFRASTRUCTURE -- see oracle/__init__.py:
+only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this package.
+
+`synthetic(...)` draws a D4RL-shaped dictionary (no d4rl / gym here): episodes of random length ended by a terminal, a timeout, or both,
+an unfinished tail, one constant observation feature (std 0 -> 1 in the normaliser).  `restate_*` are plain-loop restatements of the
+reference constructors and `__getitem__` (cleandiffuser/dataset/d4rl_mujoco_dataset.py:76-151 and :197-236), pinned by
+tests/golden/dataset_*.npz, which `python -m oracle.gen_golden_dataset` writes from the IMPORTED reference classes."""
+import numpy as np
+
+SCENARIOS = {
+    # name: (synthetic kwargs, dataset kwargs, item indices recorded in the fixture are drawn with this seed)
+    "seq_h8": (dict(n=6000, o=11, a=3, seed=0, max_len=200), dict(horizon=8, max_path_length=200, terminal_penalty=-100.0, discount=0.99)),
+    "seq_h32_hopper": (dict(n=9000, o=11, a=3, seed=1, max_len=300), dict(horizon=32, max_path_length=300, terminal_penalty=-100.0, discount=0.997)),
+    "seq_h1_nopenalty": (dict(n=3000, o=17, a=6, seed=2, max_len=120), dict(horizon=1, max_path_length=120, terminal_penalty=None, discount=0.9)),
+    "seq_h64_short_paths": (dict(n=4000, o=5, a=2, seed=3, max_len=100), dict(horizon=64, max_path_length=100, terminal_penalty=-50.0, discount=0.99)),
+}
+TD_SCENARIOS = {
+    "td_plain": (dict(n=5000, o=17, a=6, seed=4, max_len=150), dict(normalize_reward=False)),
+    "td_normalized_reward": (dict(n=5000, o=11, a=3, seed=5, max_len=150), dict(normalize_reward=True)),
+}
+N_ITEMS = 96          # items recorded per fixture
+
+
+def synthetic(n, o, a, seed, max_len):
+    rng = np.random.default_rng(seed)
+    obs = (rng.standard_normal((n, o)) * rng.uniform(0.5, 3.0, o) + rng.uniform(-2.0, 2.0, o)).astype(np.float32)
+    obs[:, o // 2] = 1.25
+    act = np.tanh(rng.standard_normal((n, a))).astype(np.float32)
+    rew = rng.standard_normal(n).astype(np.float32)
+    term, tout = np.zeros(n, dtype=bool), np.zeros(n, dtype=bool)
+    i = 0
+    while i < n:
+        length = int(rng.integers(1, max_len + 1))
+        e = min(i + length - 1, n - 1)
+        if e == n - 1 and rng.random() < 0.5:
+            break                                       # an unfinished tail: the reference drops it
+        if length == max_len:
+            tout[e] = True
+        elif rng.random() < 0.15:
+            tout[e] = term[e] = True
+        else:
+            term[e] = True
+        i = e + 1
+    return dict(observations=obs, actions=act, rewards=rew, terminals=term, timeouts=tout,
+                next_observations=np.roll(obs, -1, axis=0).copy())
+
+
+def item_indices(n_items_total, seed):
+    rng = np.random.default_rng(1000 + seed)
+    fixed = [0, n_items_total - 1]
+    return np.concatenate([fixed, rng.integers(0, n_items_total, N_ITEMS - len(fixed))]).astype(np.int64)
+
+
+def _normaliser(x):                                     # GaussianNormalizer, reference utils/normalizers.py:47-61
+    mean, std = np.mean(x, axis=0), np.std(x, axis=0)
+    std[std == 0] = 1.0
+    return mean, std
+
+
+def restate_sequence(data, horizon, max_path_length, terminal_penalty, discount):
+    """Step-by-step restatement of D4RLMuJoCoDataset.__init__ (reference d4rl_mujoco_dataset.py:76-133)."""
+    obs = data["observations"].astype(np.float32)
+    act = data["actions"].astype(np.float32)
+    rew = data["rewards"].astype(np.float32)
+    tout, term = data["timeouts"], data["terminals"]
+    mean, std = _normaliser(obs)
+    nobs = (obs - mean[None]) / std[None]
+    n_paths = int(np.sum(np.logical_or(term, tout)))
+    seq_obs = np.zeros((n_paths, max_path_length, obs.shape[1]), np.float32)
+    seq_act = np.zeros((n_paths, max_path_length, act.shape[1]), np.float32)
+    seq_rew = np.zeros((n_paths, max_path_length, 1), np.float32)
+    seq_val = np.zeros((n_paths, max_path_length, 1), np.float32)
+    indices, ptr, p = [], 0, 0
+    for i in range(len(tout)):
+        if tout[i] or term[i]:
+            length = i - ptr + 1
+            if term[i] and not tout[i] and terminal_penalty is not None:
+                rew[i] = terminal_penalty
+            seq_obs[p, :length] = nobs[ptr:i + 1]
+            seq_act[p, :length] = act[ptr:i + 1]
+            seq_rew[p, :length, 0] = rew[ptr:i + 1]
+            for s in range(min(length - 1, max_path_length - horizon) + 1):
+                indices.append((p, s, s + horizon))
+            ptr, p = i + 1, p + 1
+    seq_val[:, -1] = seq_rew[:, -1]
+    for t in range(max_path_length - 2, -1, -1):
+        seq_val[:, t] = seq_rew[:, t] + discount * seq_val[:, t + 1]
+    return dict(seq_obs=seq_obs, seq_act=seq_act, seq_rew=seq_rew, seq_val=seq_val, indices=np.array(indices, np.int64).reshape(-1, 3))
+
+
+def restate_items(r, idx):
+    """__getitem__ + default collate (reference :138-151)."""
+    out = {k: [] for k in ("obs", "act", "rew", "val")}
+    for i in idx:
+        p, s, e = r["indices"][i]
+        out["obs"].append(r["seq_obs"][p, s:e]); out["act"].append(r["seq_act"][p, s:e])
+        out["rew"].append(r["seq_rew"][p, s:e]); out["val"].append(r["seq_val"][p, s])
+    return {k: np.stack(v) for k, v in out.items()}
+
+
+def restate_td(data, normalize_reward):
+    """D4RLMuJoCoTDDataset.__init__ (reference :197-221; reward rescaling :10-31)."""
+    data = {k: v.copy() for k, v in data.items()}
+    if normalize_reward:
+        rets, ep_ret, ep_len = [], 0.0, 0
+        for r, d in zip(data["rewards"], data["terminals"]):
+            ep_ret += float(r); ep_len += 1
+            if d or ep_len == 1000:
+                rets.append(ep_ret); ep_ret, ep_len = 0.0, 0
+        data["rewards"] /= max(rets) - min(rets)
+        data["rewards"] *= 1000
+    obs = data["observations"].astype(np.float32)
+    mean, std = _normaliser(obs)
+    return dict(obs=((obs - mean[None]) / std[None]).astype(np.float32),
+                next_obs=((data["next_observations"].astype(np.float32) - mean[None]) / std[None]).astype(np.float32),
+                act=data["actions"].astype(np.float32), rew=data["rewards"].astype(np.float32)[:, None],
+                tml=data["terminals"].astype(np.float32)[:, None])

@@ -155,6 +155,35 @@ def cfgU(B=256, native_backward=None, graph=False):
     return f"config 2 update(): JannerUNet1d H=32 D=23, batch {B}, loss + backward + clip + AdamW + EMA", call, B
 
 
+def cfgD(B=64, steps=200_000, resident=True):
+    """Batch supply of the Diffuser training loop (row f4, third slice): a hopper-sized synthetic D4RL dictionary (o = 11, a = 3), H = 32
+    windows, batch B.  resident: D4RLMuJoCoDataset.loader (buffers in HBM, one gather launch per batch); else the reference's way --
+    torch DataLoader(shuffle, drop_last) over the same dataset + .to(device) per field (num_workers = 0 here: worker processes only
+    hide part of the same host work).  Returns (label, next_batch, B, resident_bytes)."""
+    import numpy as np
+    from cleandiffuser_amd.dataset.d4rl_mujoco_dataset import D4RLMuJoCoDataset
+    from cleandiffuser_amd.utils import loop_dataloader
+    rng = np.random.default_rng(0)                             # a D4RL-shaped dictionary: episodes of 1-1000 steps
+    ends = np.minimum(np.cumsum(rng.integers(1, 1001, size=steps // 400 + 8)), steps) - 1
+    term = np.zeros(steps, dtype=bool)
+    term[ends] = True
+    data = dict(observations=rng.standard_normal((steps, 11)).astype(np.float32), actions=rng.uniform(-1, 1, (steps, 3)).astype(np.float32),
+                rewards=rng.standard_normal(steps).astype(np.float32), terminals=term, timeouts=np.zeros(steps, dtype=bool))
+    ds = D4RLMuJoCoDataset(data, horizon=32, max_path_length=1000)
+    if resident:
+        it = loop_dataloader(ds.loader(B, device=DEV))
+        nxt = lambda: next(it)  # noqa: E731
+    else:
+        from torch.utils.data import DataLoader
+        it = loop_dataloader(DataLoader(ds, batch_size=B, shuffle=True, drop_last=True))
+
+        def nxt():
+            b = next(it)
+            return {"obs": {"state": b["obs"]["state"].to(DEV)}, "act": b["act"].to(DEV), "rew": b["rew"].to(DEV), "val": b["val"].to(DEV)}
+    how = "HBM-resident buffers, one cdx_gather_windows_f32 launch per batch" if resident else "torch DataLoader + H2D copy per field"
+    return f"D4RL-MuJoCo sequence batches ({steps} steps, o=11 a=3, H=32), batch {B}: {how}", nxt, B, ds.resident_bytes()
+
+
 def _guided_macs(net, clf_net, horizon, fallback):
     """MACs of ONE guided step per trajectory -- denoiser forward + classifier forward + classifier backward-data -- as the guided
     program compiler counts them from the packed ops (the guided roofline fractions used to price the
