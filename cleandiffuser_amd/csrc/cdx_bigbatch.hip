@@ -17,6 +17,11 @@
 
 extern void cdx_set_err(const char* msg);
 
+// library-internal entries of csrc/cdx_gemm.hip (deferred split-K reduction, summed by the GroupNorm that consumes the conv)
+int cdx_gemm_partials_f32(const cdx_gemm_args* g, void* hip_stream, int* slices);
+bool cdx_groupnorm_slices_ok(int L, int C, int G);
+int cdx_groupnorm_slices_f32(const cdx_gn_args* a, int slices, long long slice_stride, const float* xbias, void* hip_stream);
+
 namespace {
 
 // EDM / consistency records evaluate the network on c_in * x (reference newedm.py:142-148, edm.py:77-82): scaled copy of the state
@@ -865,6 +870,37 @@ struct UNet {                     // one pass over the op list; with dry == true
         if (g.partial_slices == 0) g.partial = nullptr;
         return cdx_gemm_f32(&g, st);
     }
+    // conv whose K-slice sums stay in the split-K scratch, `slot` slices in (a second conv into the same GroupNorm input -- the other
+    // half of a channel concat -- appends its slices): the GroupNorm that follows adds them up (gn_slices)
+    int conv_partials(const float* x, int lda, const float* wp, int Lin, int Lout, int taps, int cin, int stride, int pad, int N,
+                      int slot, int max_slices, int* slices) {
+        *slices = 1;
+        if (dry) return CDX_OK;
+        cdx_gemm_args g;
+        g.A = x; g.W = wp; g.bias = nullptr; g.gate = nullptr; g.residual = nullptr; g.table = nullptr; g.C = nullptr;
+        g.M = bf * Lout; g.N = N; g.K = taps * cin; g.lda = lda; g.ldw = taps * cin; g.ldc = N; g.ldg = 0; g.ldr = 0;
+        g.rows_per_gate = 1; g.table_rows = 0; g.act = CDX_ACT_NONE;
+        g.conv_taps = taps; g.conv_cin = cin; g.conv_lin = Lin; g.conv_lout = Lout; g.conv_stride = stride; g.conv_pad = pad;
+        const long long mn = (long long)g.M * N;
+        g.partial = splitk + (size_t)slot * mn;
+        g.partial_slices = (int)((splitk_floats / mn) - slot);
+        if (g.partial_slices > max_slices) g.partial_slices = max_slices;
+        return cdx_gemm_partials_f32(&g, st, slices);
+    }
+    bool fold_ok(int L, int C, int G) const {
+        static const bool on = [] { const char* e = getenv("CDX_UNET_GN_FOLD"); return !(e && e[0] == '0'); }();      // A/B hook
+        return on && splitk != nullptr && cdx_groupnorm_slices_ok(L, C, G) && (long long)bf * L * C * UNET_SPLITK <= splitk_floats;
+    }
+    int gn_slices(int slices, const float* xbias, float* y, int L, int C, int G, const float* gamma, const float* beta, const float* fa,
+                  int ldfa, const float* fb, int ldfb, int film_mode, const float* residual) {
+        if (dry) return CDX_OK;
+        cdx_gn_args q{};
+        q.x = splitk; q.y = y; q.gamma = gamma; q.beta = beta; q.fa = fa; q.fb = fb; q.residual = residual;
+        q.B = bf; q.L = L; q.C = C; q.G = G; q.ldx = C; q.ldy = C; q.ldr = C; q.ldfa = ldfa; q.ldfb = ldfb;
+        q.fa_row = s->temb_per_sample ? 0 : rec; q.fa_per_sample = s->temb_per_sample; q.film_mode = film_mode;
+        q.act = CDX_ACT_MISH; q.eps = 1e-5f;
+        return cdx_groupnorm_slices_f32(&q, slices, (long long)bf * L * C, xbias, st);
+    }
     int gn(const float* x, float* y, int L, int C, int G, const float* gamma, const float* beta, const float* fa, int ldfa,
            const float* fb, int ldfb, int film_mode, const float* residual) {
         if (dry) return CDX_OK;
@@ -886,19 +922,35 @@ struct UNet {                     // one pass over the op list; with dry == true
         float* h2 = take(n);
         float* res = (k.wra != nullptr) ? take(n) : nullptr;
         float* o = take(n);
-        CDX_TRY(conv(xa, k.cin_a, k.w1a, k.b1, L, L, ks, k.cin_a, 1, pad, co, h1, co, nullptr, 0));
-        if (k.cin_b > 0) CDX_TRY(conv(xb, k.cin_b, k.w1b, nullptr, L, L, ks, k.cin_b, 1, pad, co, h1, co, h1, co));
+        // The 3 / 5-tap convs feed a GroupNorm: their K-slice sums (split-K, and the two halves of a channel concat) are added up by the
+        // GroupNorm's own load instead of a reduction pass + a round trip of the conv output (fold; CDX_UNET_GN_FOLD=0: the old order).
+        const bool fold = fold_ok(L, co, k.groups);
         const int fm = w->cond_predict_scale ? 1 : 2;
-        CDX_TRY(gn(h1, h2, L, co, k.groups, k.g1, k.be1, tfilm ? tfilm + film_off : nullptr, (int)film_total,
-                   ofilm ? ofilm + film_off : nullptr, (int)film_total, fm, nullptr));
-        CDX_TRY(conv(h2, co, k.w2, k.b2, L, L, ks, co, 1, pad, co, h1, co, nullptr, 0));       // h1 is free again
+        const float *tf = tfilm ? tfilm + film_off : nullptr, *of = ofilm ? ofilm + film_off : nullptr;
+        if (fold) {
+            int na = 1, nb2 = 0;
+            CDX_TRY(conv_partials(xa, k.cin_a, k.w1a, L, L, ks, k.cin_a, 1, pad, co, 0, k.cin_b > 0 ? UNET_SPLITK / 2 : UNET_SPLITK, &na));
+            if (k.cin_b > 0) CDX_TRY(conv_partials(xb, k.cin_b, k.w1b, L, L, ks, k.cin_b, 1, pad, co, na, UNET_SPLITK - na, &nb2));
+            CDX_TRY(gn_slices(na + nb2, k.b1, h2, L, co, k.groups, k.g1, k.be1, tf, (int)film_total, of, (int)film_total, fm, nullptr));
+        } else {
+            CDX_TRY(conv(xa, k.cin_a, k.w1a, k.b1, L, L, ks, k.cin_a, 1, pad, co, h1, co, nullptr, 0));
+            if (k.cin_b > 0) CDX_TRY(conv(xb, k.cin_b, k.w1b, nullptr, L, L, ks, k.cin_b, 1, pad, co, h1, co, h1, co));
+            CDX_TRY(gn(h1, h2, L, co, k.groups, k.g1, k.be1, tf, (int)film_total, of, (int)film_total, fm, nullptr));
+        }
         const float* skip = xa;                                                                 // identity skip
-        if (k.wra != nullptr) {
+        if (k.wra != nullptr) {                           // (before conv2: the 1 x 1 convs may split K through the same scratch)
             CDX_TRY(conv(xa, k.cin_a, k.wra, k.br, L, L, 1, k.cin_a, 1, 0, co, res, co, extra, co));
             if (k.cin_b > 0) CDX_TRY(conv(xb, k.cin_b, k.wrb, nullptr, L, L, 1, k.cin_b, 1, 0, co, res, co, res, co));
             skip = res;
         }
-        CDX_TRY(gn(h1, o, L, co, k.groups, k.g2, k.be2, nullptr, 0, nullptr, 0, 0, skip));
+        if (fold) {
+            int n2 = 1;
+            CDX_TRY(conv_partials(h2, co, k.w2, L, L, ks, co, 1, pad, co, 0, UNET_SPLITK, &n2));
+            CDX_TRY(gn_slices(n2, k.b2, o, L, co, k.groups, k.g2, k.be2, nullptr, 0, nullptr, 0, 0, skip));
+        } else {
+            CDX_TRY(conv(h2, co, k.w2, k.b2, L, L, ks, co, 1, pad, co, h1, co, nullptr, 0));   // h1 is free again
+            CDX_TRY(gn(h1, o, L, co, k.groups, k.g2, k.be2, nullptr, 0, nullptr, 0, 0, skip));
+        }
         *out = o;
         return CDX_OK;
     }

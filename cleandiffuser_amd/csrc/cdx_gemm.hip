@@ -554,8 +554,14 @@ __global__ __launch_bounds__(256) void cdx_groupnorm_kernel(const cdx_gn_args a)
 // registers (L * C/G <= 2048).  A lane owns 4 consecutive channels of a position: x, gamma, beta, the FiLM rows, the residual and y move
 // as dwordx4 (the scalar kernel issues ~8 dword loads per element: measured 1.9 TB/s on the config-3 tensors).  Mean, then the centred
 // sum of squares, accumulated in float64.
+// SLICES: x is not one tensor but the raw K-slice partial sums a split-K conv left behind (x = slice 0, the others `slice_stride`
+// floats apart, `slices` of them) plus the conv's bias: the kernel sums them in slice order, adds the bias -- the float operations of
+// gm_splitk_reduce_kernel, in its order -- and normalises; the conv's second pass and the round trip of its output are gone
+// (config 3: 36 of them per forward).
 #define GN_VREGS 8
-__global__ __launch_bounds__(256) void cdx_groupnorm_vec_kernel(const cdx_gn_args a) {
+template <bool SLICES>
+__global__ __launch_bounds__(256) void cdx_groupnorm_vec_kernel(const cdx_gn_args a, const int slices, const size_t slice_stride,
+                                                                const float* __restrict__ xbias) {
     const int lane = threadIdx.x & 63;
     const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wg >= a.B * a.G) return;
@@ -575,7 +581,18 @@ __global__ __launch_bounds__(256) void cdx_groupnorm_vec_kernel(const cdx_gn_arg
         if (e < n4) {
             l = (int)(((float)e + 0.5f) * inv_cq);
             c = 4 * (e - l * cq);
-            x = *reinterpret_cast<const float4*>(xb + (size_t)l * a.ldx + c);
+            const float* px = xb + (size_t)l * a.ldx + c;
+            x = *reinterpret_cast<const float4*>(px);
+            if (SLICES) {
+                for (int sl = 1; sl < slices; ++sl) {
+                    const float4 t = *reinterpret_cast<const float4*>(px + (size_t)sl * slice_stride);
+                    x.x += t.x; x.y += t.y; x.z += t.z; x.w += t.w;
+                }
+                if (xbias) {
+                    const float4 t = *reinterpret_cast<const float4*>(xbias + grp * cg + c);
+                    x.x += t.x; x.y += t.y; x.z += t.z; x.w += t.w;
+                }
+            }
         }
         v[i] = x; l_of[i] = l; c_of[i] = c;
         s += ((double)x.x + (double)x.y) + ((double)x.z + (double)x.w);
@@ -1111,7 +1128,7 @@ __global__ void cdx_act_bwd_kernel(const float* __restrict__ pre, const float* _
         out[i] = g[i] * gm_act_grad(pre[i], act, param);
 }
 
-static int gm_launch(const cdx_gemm_args* g, void* hip_stream, bool force_small);
+static int gm_launch(const cdx_gemm_args* g, void* hip_stream, bool force_small, int* defer_slices = nullptr);
 static bool gn_vec_enabled() {                       // CDX_GN_VEC=0: the scalar GroupNorm kernel everywhere (A/B hook)
     static const bool on = [] { const char* e = getenv("CDX_GN_VEC"); return !(e && e[0] == '0'); }();
     return on;
@@ -1146,7 +1163,8 @@ int cdx_gemm_f32(const cdx_gemm_args* g, void* hip_stream) {
 
 }  // extern "C"
 
-static int gm_launch(const cdx_gemm_args* g, void* hip_stream, bool force_small) {
+static int gm_launch(const cdx_gemm_args* g_in, void* hip_stream, bool force_small, int* defer_slices) {
+    const cdx_gemm_args* g = g_in;
     if (!g) { cdx_set_err("cdx_gemm_f32: null argument block"); return CDX_EINVAL; }
     if (g->M < 0 || g->N <= 0 || g->K <= 0) { cdx_set_err("cdx_gemm_f32: bad shape"); return CDX_EINVAL; }
     if (g->M == 0) return CDX_OK;                                   // empty batch: nothing to launch
@@ -1169,9 +1187,6 @@ static int gm_launch(const cdx_gemm_args* g, void* hip_stream, bool force_small)
     const bool vec = (g->K % bk == 0) && (g->lda % 4 == 0) && (g->ldw % 4 == 0) &&
                      (((uintptr_t)g->A | (uintptr_t)g->W) % 16 == 0) && (g->conv_taps == 0 || g->conv_cin % 4 == 0);
     hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
-    const uintptr_t ep_ptrs = (uintptr_t)g->C | (uintptr_t)g->gate | (uintptr_t)g->residual | (uintptr_t)g->table;
-    const int fast_ep = (g->N % 4 == 0) && (g->ldc % 4 == 0) && (!g->gate || g->ldg % 4 == 0) &&
-                        (!g->residual || g->ldr % 4 == 0) && (ep_ptrs % 16 == 0);
     // split-K when the tile count cannot fill the chip and K is long enough to pay for the second pass
     int k_split = 1;
     const int slots = small ? 1024 : 768;
@@ -1184,6 +1199,21 @@ static int gm_launch(const cdx_gemm_args* g, void* hip_stream, bool force_small)
         const int per = (nk_all + k_split - 1) / k_split;
         k_split = (nk_all + per - 1) / per;                          // no empty slices
     }
+    // deferred reduction (cdx_gemm_partials_f32): the raw K-slice sums stay in `partial` for the consumer to add up; an unsplit launch
+    // writes its raw sums as slice 0
+    cdx_gemm_args raw;
+    if (defer_slices != nullptr) {
+        *defer_slices = k_split;
+        if (k_split == 1) {
+            raw = *g;
+            raw.C = g->partial; raw.ldc = g->N; raw.bias = nullptr; raw.gate = nullptr; raw.residual = nullptr; raw.table = nullptr;
+            raw.act = CDX_ACT_NONE;
+            g = &raw;
+        }
+    }
+    const uintptr_t ep_ptrs = (uintptr_t)g->C | (uintptr_t)g->gate | (uintptr_t)g->residual | (uintptr_t)g->table;
+    const int fast_ep = (g->N % 4 == 0) && (g->ldc % 4 == 0) && (!g->gate || g->ldg % 4 == 0) &&
+                        (!g->residual || g->ldr % 4 == 0) && (ep_ptrs % 16 == 0);
     static const char* env_x = getenv("CDX_GEMM_XCD_ORDER");      // tuning hook: 1 = one contiguous tile range per XCD
     const int xcd_order = env_x ? atoi(env_x) : 0;    // measured: +-2 % either way once tiles are walked n-fastest
     const dim3 grid(tiles * k_split), block(GM_THREADS);
@@ -1197,7 +1227,7 @@ static int gm_launch(const cdx_gemm_args* g, void* hip_stream, bool force_small)
         else { if (cv) GM_LAUNCH(false, 2, true); else GM_LAUNCH(false, 2, false); }
     }
 #undef GM_LAUNCH
-    if (k_split > 1) {
+    if (k_split > 1 && defer_slices == nullptr) {
         const size_t total = (size_t)g->M * g->N;
         const bool v4 = fast_ep && ((uintptr_t)g->partial % 16 == 0);
         const size_t work = v4 ? total / 4 : total;
@@ -1206,6 +1236,47 @@ static int gm_launch(const cdx_gemm_args* g, void* hip_stream, bool force_small)
         else hipLaunchKernelGGL(gm_splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, s, *g, k_split);
     }
     hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
+    return CDX_OK;
+}
+
+// ---- library-internal entries (declared where they are used: csrc/cdx_bigbatch.hip) ------------------------------------------
+// The conv GEMM of `g` with its K-slice reduction DEFERRED: the raw slice sums (no bias, no epilogue) are left in g->partial
+// [slice][M][N], *slices says how many (>= 1; the split is chosen as for cdx_gemm_f32, up to g->partial_slices).  The consumer adds
+// them up: cdx_groupnorm_slices_f32.
+int cdx_gemm_partials_f32(const cdx_gemm_args* g, void* hip_stream, int* slices) {
+    if (!g || !slices || !g->partial || g->partial_slices < 1) { cdx_set_err("cdx_gemm_partials_f32: bad argument"); return CDX_EINVAL; }
+    if (g->gate || g->residual || g->table || g->act != CDX_ACT_NONE || g->N % 4 != 0) {
+        cdx_set_err("cdx_gemm_partials_f32: epilogue terms cannot be deferred"); return CDX_EINVAL;
+    }
+    cdx_gemm_args q = *g;
+    q.C = g->partial;                 // (never written in a split launch; an unsplit one writes slice 0 through it)
+    q.ldc = g->N;
+    return gm_launch(&q, hip_stream, false, slices);
+}
+
+// Shapes the slice-summing GroupNorm takes (the float4 kernel with the group in registers).
+bool cdx_groupnorm_slices_ok(int L, int C, int G) {
+    if (G <= 0 || C % G != 0) return false;
+    const int cg = C / G;
+    return gn_vec_enabled() && cg % 4 == 0 && (long long)L * cg <= 64LL * 4 * GN_VREGS && C % 4 == 0;
+}
+
+// cdx_groupnorm_f32 on x = sum over `slices` partial tensors (a->x, a->x + slice_stride, ...) + xbias[channel].
+int cdx_groupnorm_slices_f32(const cdx_gn_args* a, int slices, long long slice_stride, const float* xbias, void* hip_stream) {
+    if (!a || slices < 1 || slice_stride < 0) { cdx_set_err("cdx_groupnorm_slices_f32: bad argument"); return CDX_EINVAL; }
+    if (a->B == 0) return CDX_OK;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (!a->x || !a->y || !a->gamma || !a->beta || a->B < 0 || a->L <= 0 || !cdx_groupnorm_slices_ok(a->L, a->C, a->G) || a->ldx % 4 != 0 ||
+        a->ldy % 4 != 0 || slice_stride % 4 != 0 || !al16(a->x) || !al16(a->y) || !al16(a->gamma) || !al16(a->beta) || !al16(xbias) ||
+        (a->residual && (a->ldr % 4 != 0 || !al16(a->residual))) || (a->fa && (a->ldfa % 4 != 0 || !al16(a->fa))) ||
+        (a->fb && (a->ldfb % 4 != 0 || !al16(a->fb))) || a->film_mode < 0 || a->film_mode > 2) {
+        cdx_set_err("cdx_groupnorm_slices_f32: shape or alignment outside the float4 kernel"); return CDX_EINVAL;
+    }
+    const long long waves = (long long)a->B * a->G;
+    hipLaunchKernelGGL(cdx_groupnorm_vec_kernel<true>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(hip_stream), *a, slices, (size_t)slice_stride, xbias);
+    const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
     return CDX_OK;
 }
@@ -1250,7 +1321,7 @@ int cdx_groupnorm_f32(const cdx_gn_args* a, void* hip_stream) {
                      al16(a->x) && al16(a->y) && al16(a->gamma) && al16(a->beta) &&
                      (!a->residual || (a->ldr % 4 == 0 && al16(a->residual))) && (!a->fa || (a->ldfa % 4 == 0 && al16(a->fa))) &&
                      (!a->fb || (a->ldfb % 4 == 0 && al16(a->fb)));
-    if (vec) hipLaunchKernelGGL(cdx_groupnorm_vec_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), *a);
+    if (vec) hipLaunchKernelGGL(cdx_groupnorm_vec_kernel<false>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), *a, 1, (size_t)0, nullptr);
     else hipLaunchKernelGGL(cdx_groupnorm_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), *a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
