@@ -1190,7 +1190,9 @@ static int gm_launch(const cdx_gemm_args* g_in, void* hip_stream, bool force_sma
     // split-K when the tile count cannot fill the chip and K is long enough to pay for the second pass
     int k_split = 1;
     const int slots = small ? 1024 : 768;
-    if (g->partial != nullptr && g->partial_slices > 1 && tiles < slots / 2) {
+    static const char* env_f = getenv("CDX_GEMM_SPLITK_FILL");     // tuning hook: split K while tiles fill less than this % of the slots
+    const int fill = env_f ? atoi(env_f) : 51;      // (<= half: the GroupNorm-folded reduction made the second pass free; config 3 +1.4 %)
+    if (g->partial != nullptr && g->partial_slices > 1 && (long long)tiles * 100 < (long long)slots * fill) {
         const int nk_all = (g->K + bk - 1) / bk;
         k_split = (slots + tiles - 1) / tiles;
         if (k_split > g->partial_slices) k_split = g->partial_slices;
