@@ -199,6 +199,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef CDX2_PARAMS_ALL
 #define CDX2_PARAMS_ALL 0           // non-pipelined position only: 1 = every wave issues all five parameter loads (see load_params)
 #endif
+#define CDX2_GETREG_XCC_ID ((3 << 11) | 20)      /* s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4): the XCD this wave runs on, 0-7 */
 #ifndef CDX2_PIPE_PARAMS
 #define CDX2_PIPE_PARAMS 1          // 0: fetch an op's epilogue parameters and the next descriptor at the op's start (round-2 order)
 #endif
@@ -817,20 +818,51 @@ template <int T, bool BWD> constexpr bool pipe_params() { return CDX2_PIPE_PARAM
 // of the local traffic, in this kernel it cost ~5.7 k cycles per op with its four barriers).  The two tiles of a group alternate by
 // the parity of the sequence number: a member can only be two exchanges ahead of another after that one has finished reading.
 // Every poll is bounded: a granule that never arrives sets `err` and the launch ends with wrong numbers instead of hanging the GPU.
+// Placement is CHECKED, not assumed (HIP promises no workgroup -> XCD mapping; "workgroup i runs on XCD i % 8" is an observation): in
+// the kernel's prologue every member publishes its HW_REG_XCC_ID with an agent-scope store and reads its partners'; a group whose
+// members differ takes the placement-independent form of the same exchange for this launch -- `sc0 sc1` 16-byte stores and loads on
+// both sides, i.e. through memory instead of the shared L2 (slower per hop, never stale).
 // Sequence numbers keep increasing across launches on the same tiles (launch field xseq0), so nothing is cleared per launch.
 struct XState {
     int m, k;                  // this workgroup's member index, members per trajectory / trajectories per group
     unsigned seq;              // exchanges done so far (the same number in every member: they run the same op list)
     bool dead;                 // this thread lost a granule: no more waiting in this launch
+    // (whether the members of this group sit behind one L2 -- checked per launch in the kernel's prologue -- lives in the LDS word
+    //  behind the trajectory region, not here: one more scalar live across the op loop measured 1 % at B = 256.  Nonzero: the exchange
+    //  goes through memory -- write-through stores, an acquire in front of every poll -- instead of the shared L2)
     // (the group's tiles, their size and the error word are re-read from the kernarg segment inside every exchange: five scalar
     //  registers less that would be live -- and spilled -- across the whole op loop)
 };
+
+// The placement-independent form of the publish: 16-byte `sc0 sc1` stores (written through to memory, the line leaves this XCD's L2);
+// the collecting side pairs them with an agent-scope acquire in front of every poll (MI355X_MICROARCH.md, "Workgroup dispatch, XCD
+// placement & inter-workgroup visibility": the XCDs' L2s are not coherent with each other)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+__device__ __forceinline__ void xchg_store_sc(f32x4* p, f32x4 v) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 16, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, 0, 0, 17);
+}
+#pragma clang diagnostic pop
+// A failed wait: the error words (pinned host memory, 16 ints: [0] != 0 = failed, then what / which workgroup / sequence number / item /
+// this workgroup's XCC id / its member index / whether the group was on the through-memory path; [8] != 0: some group of a launch took
+// the through-memory path) -- written on failure / misplacement only
+__device__ __forceinline__ void xchg_report(int what, const XState& X, int seq, int item, bool slow) {
+    const KArg* S0 = kernarg();
+    asm volatile("" : "+s"(S0));
+    int* e = S0->xerr;
+    e[1] = what; e[2] = (int)blockIdx.x; e[3] = seq; e[4] = item;
+    e[5] = (int)(__builtin_amdgcn_s_getreg(CDX2_GETREG_XCC_ID) & 15); e[6] = X.m; e[7] = slow ? 1 : 0;
+    e[0] = 1;
+}
 
 // The group's tile for the exchange with sequence number `seq` (two tiles of 2 * xchg_floats floats per group, alternating by parity).
 __device__ __forceinline__ float* exchange_tile(const XState& X, unsigned seq) {
     const KArg* S0 = kernarg();
     asm volatile("" : "+s"(S0));
-    const int bid = (int)blockIdx.x, grp_idx = ((bid >> (X.k == 4 ? 5 : 4)) << 3) + (bid & 7);       // (8 k consecutive workgroups = 8 groups)
+    const int bid = (int)blockIdx.x;
+    int grp_idx = ((bid >> (X.k == 4 ? 5 : 4)) << 3) + (bid & 7);       // (8 k consecutive workgroups = 8 groups)
+    if (S0->tune & 0x200) grp_idx = bid >> (X.k == 4 ? 2 : 1);          // (test hook of the prologue: adjacent members)
     const int xf = S0->xchg_floats;
     return S0->xbuf + (size_t)grp_idx * 4 * xf + (size_t)(seq & 1) * 2 * xf;
 }
@@ -842,7 +874,8 @@ __device__ __forceinline__ float* exchange_tile(const XState& X, unsigned seq) {
 // (Measured and dropped in round 4, gpurun r4d vs r4e: publishing straight from the epilogue's registers -- no LDS read-back, no barrier
 //  in front of the exchange -- with two collect items in flight per thread was 2.5 % SLOWER at B = 256; what an exchange costs, ~3.6 k
 //  cycles, is the wait for the slowest member of the group plus one L2 round trip, not the copy.)
-template <int THREADS>
+// SLOW: the through-memory form (see XState::slow) -- its own instantiation, so that the usual one carries none of it.
+template <int THREADS, bool SLOW>
 __device__ __forceinline__ void split_exchange(XState& X, int xg, int gmap, float* __restrict__ tl, int dst, int dstride, int l_out,
                                                int c_out, int coutp, int tid) {
     const int g_lo = xg & 255, g_hi = (xg >> 8) & 255;
@@ -863,8 +896,13 @@ __device__ __forceinline__ void split_exchange(XState& X, int xg, int gmap, floa
         if (mine) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(tl + base + (t * grows + pos + CDX2_HALO2) * dstride + c);
             f32x4* o = reinterpret_cast<f32x4*>(tile + (size_t)(vpos * coutp + c) * 2);
-            o[0] = (f32x4){v[0], tag, v[1], tag};
-            o[1] = (f32x4){v[2], tag, v[3], tag};
+            if (SLOW) {
+                xchg_store_sc(o, (f32x4){v[0], tag, v[1], tag});
+                xchg_store_sc(o + 1, (f32x4){v[2], tag, v[3], tag});
+            } else {
+                o[0] = (f32x4){v[0], tag, v[1], tag};
+                o[1] = (f32x4){v[2], tag, v[3], tag};
+            }
         }
     }
     // collect: everybody else's part, straight from L2 (nontemporal loads bypass this CU's L1), as soon as their tags say so.
@@ -880,6 +918,9 @@ __device__ __forceinline__ void split_exchange(XState& X, int xg, int gmap, floa
             f32x4 a, b;
             int spins = 0;
             for (;;) {
+                // (through memory: this XCD's L2 may still hold the tile's lines as this group read them two exchanges ago -- nothing
+                //  probes them when another XCD writes -- so every poll starts with an agent-scope acquire, which drops them)
+                if (SLOW) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 a = __builtin_nontemporal_load(src);
                 b = __builtin_nontemporal_load(src + 1);
                 if (__float_as_uint(a[1]) == X.seq && __float_as_uint(a[3]) == X.seq && __float_as_uint(b[1]) == X.seq &&
@@ -888,9 +929,7 @@ __device__ __forceinline__ void split_exchange(XState& X, int xg, int gmap, floa
                 // (a legitimate wait is tens of microseconds; ~10 ms of polling means the partner is not behind this L2.  Once a thread
                 //  has given up it stops waiting altogether: the launch must end; its workgroup stores NaN instead of trajectories)
                 if (X.dead || ++spins > 200000) {
-                    const KArg* S0 = kernarg();
-                    asm volatile("" : "+s"(S0));
-                    *S0->xerr = 1;
+                    if (!X.dead) xchg_report(1, X, (int)(X.seq), i, SLOW);
                     X.dead = true;
                     break;
                 }
@@ -1115,7 +1154,8 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
     if (PIPE) F.P = Pnext;
     if (SPLIT && (xgw & CDX2_XG_XCHG)) {
         __syncthreads();                                             // the epilogue's stores to the destination slot are in LDS
-        split_exchange<WG<NWV>::THREADS>(*X, xgw, gmap, lds, e.dst, e.dstride, l_out, e.c_out, e.coutp, tid);
+        if (lds[T * tf] != 0.f) split_exchange<WG<NWV>::THREADS, true>(*X, xgw, gmap, lds, e.dst, e.dstride, l_out, e.c_out, e.coutp, tid);
+        else split_exchange<WG<NWV>::THREADS, false>(*X, xgw, gmap, lds, e.dst, e.dstride, l_out, e.c_out, e.coutp, tid);
     }
     __syncthreads();
     if (PROF) stamp(prof ? prof + 3 : nullptr, tid);
@@ -1141,6 +1181,8 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
     // split programs: 8 k consecutive workgroups hold 8 trajectories x k members; the members of a trajectory are 8 workgroups apart,
     // i.e. on the same XCD (workgroup i runs on XCD i % 8)
     XState X{0, 1, 0u, false};
+    unsigned* xids = nullptr;
+    unsigned xtag = 0, my_xcc = 0;
     int grp_idx = 0;
     bool grouped = false;        // grouped program: the k members of a group own k trajectories (one each) instead of one together
     if (SPLIT) {
@@ -1151,12 +1193,21 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
         const int bid = (int)blockIdx.x, span = 8 * X.k;
         grp_idx = (bid / span) * 8 + (bid & 7);
         X.m = (bid % span) >> 3;
+        if (S0->tune & 0x200) {                         // test hook: members in ADJACENT workgroups, i.e. on different XCDs
+            grp_idx = bid / X.k;
+            X.m = bid % X.k;
+        }
         X.seq = S0->xseq0;
+        // placement check, first half: this member's XCC id, tagged with the launch, where every XCD can read it
+        xids = reinterpret_cast<unsigned*>(S0->xbuf + (size_t)(gridDim.x / X.k) * 4 * S0->xchg_floats) + grp_idx * 32;      // (one 128-byte line per group)
+        xtag = (S0->xseq0 + 1u) & 0x0fffffffu;
+        my_xcc = __builtin_amdgcn_s_getreg(CDX2_GETREG_XCC_ID) & 15u;
+        if (tid == 0) __hip_atomic_store(xids + X.m, (xtag << 4) | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const int moff = SPLIT ? X.m * L.n_ops : 0;           // member m's op i is descriptor m * n_ops + i
     const int b0 = L.traj_first + (SPLIT ? (grouped ? grp_idx * X.k + X.m : grp_idx) : (int)blockIdx.x * T);
     const int b_end = L.traj_first + L.traj_count;      // this launch covers trajectories [traj_first, traj_first + traj_count) of the batch
-    unsigned long long* lprof = reinterpret_cast<unsigned long long*>(lds + T * tf);
+    unsigned long long* lprof = reinterpret_cast<unsigned long long*>(lds + T * tf + (SPLIT ? 4 : 0));     // (split kernels: the path word first)
     const bool profiling = PROF && L.prof != nullptr && blockIdx.x == 0;
     if (profiling) stamp(lprof + (size_t)L.n_ops * 8, tid);
 
@@ -1200,6 +1251,35 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
     }
     }
     __syncthreads();
+    if (SPLIT) {
+        // placement check, second half: lane j of wave 0 waits for member j's id (bounded) and compares it with this workgroup's
+        int differ = 0, lost = 0;
+        if (tid < X.k) {
+            unsigned v = 0;
+            int spins = 0;
+            for (;;) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // (the slot's line may sit in this XCD's L2 from a neighbour's poll)
+                v = __hip_atomic_load(xids + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((v >> 4) == xtag) break;
+                if (++spins > 2000000) { lost = 1; break; }         // a partner that is not running at all: the launch cannot work
+                __builtin_amdgcn_s_sleep(1);
+            }
+            differ = !lost && (v & 15u) != my_xcc;
+        }
+        const KArg* S0 = kernarg();
+        asm volatile("" : "+s"(S0));
+        const bool misplaced = __syncthreads_or(differ) != 0;
+        const bool slow = misplaced || (S0->tune & 0x100) != 0;                 // (0x100: test hook, force the through-memory path)
+        if (__syncthreads_or(lost)) {
+            if (tid == 0) xchg_report(2, X, (int)xtag, 0, slow);
+            X.dead = true;
+        }
+        if (tid == 0) {
+            lds[T * tf] = slow ? 1.0f : 0.f;                                    // read back by every exchange (ordered by the op loop's barriers)
+            xids[4 + X.m] = (xtag << 4) | (slow ? 1u : 0u);                     // which path this member took (host-side diagnostics)
+            if (misplaced && !(S0->tune & 0x200)) S0->xerr[8] = 1;              // ... and, without a synchronisation, THAT some group had to
+        }
+    }
 
     // log_p pass only (programs with a classifier head, n_steps == 0 and logp_out given): no forward of the whole op list, just the
     // block after the step loop -- one trajectory per workgroup, FiLM row b of the table for trajectory b (per-sample timesteps)
@@ -1567,6 +1647,7 @@ int cdx_unet2_run(const cdx_unet2_launch* L, void* hip_stream) {
         cdx_set_err("LDS offsets/strides and emb_ld must be multiples of 4 floats"); return CDX_EINVAL;
     }
     size_t lds_bytes = (size_t)L->traj_floats * L->traj_per_wg * sizeof(float);
+    if (L->split_k != 0) lds_bytes += 16;           // the exchange-path word of split / grouped launches (see the kernel's prologue)
     if (L->prof) lds_bytes += (size_t)(L->n_ops * 8 + 2) * sizeof(unsigned long long);
     if (lds_bytes > 160u * 1024u) { cdx_set_err("program needs more than 160 KiB of LDS"); return CDX_ELDS; }
     const bool guided = L->cg_scale != nullptr || L->with_backward != 0;

@@ -11,6 +11,7 @@ batch-tiled MLP programs and the small-batch mode that spreads one trajectory ov
 """
 import ctypes
 import os
+import warnings
 import weakref
 from typing import Optional
 
@@ -291,7 +292,7 @@ def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps
         # exchange tiles: one pair per group of the launch -- a trajectory's k workgroups (split) or k trajectories' k workgroups (grouped)
         n_grp = -(-batch // (8 * split)) * 8 if group else -(-batch // 8) * 8
         key = (x_in.device, R._stream_ptr(x_in.device))
-        need = n_grp * 4 * prog.meta["xchg_floats"]
+        need = n_grp * (4 * prog.meta["xchg_floats"] + 32)       # tiles, then one 128-byte line per group for the per-launch placement check
         n_forwards = max(n_steps, 1)
         if "n_cut_ops" not in prog.meta:
             prog.meta["n_cut_ops"] = int(sum(1 for op in prog.ops if int(op[P2.W2_XG]) & P2.XG_XCHG))
@@ -304,6 +305,7 @@ def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps
                                      "err": _split_err(x_in.device)}
         xbuf, xerr, xseq0 = st["buf"], st["err"], st["seq"]
         st["seq"] += n_xchg
+        st["last"] = (n_grp, prog.meta["xchg_floats"], split, (xseq0 + 1) & 0x0fffffff)
     t = t_per_wg or traj_per_wg(prog, batch)
     prof = R._prof["buf"]
     # Two trajectories per workgroup fill the 256 CUs in rounds of 512 trajectories; a remainder of up to 256 is cheaper one
@@ -360,13 +362,16 @@ _ws = {}
 _split_bufs = {}     # (device, stream) -> {exchange tiles, sequence numbers handed out so far, error word} of the split programs
 
 
+misplaced_launches = {}     # device -> launches (seen so far) in which some group's members sat on different XCDs
+MISPLACED_LIMIT = 3
+last_exchange_error = {}    # device -> what the first member that gave up reported (diagnostics; see check_split_errors)
 _split_errs = {}     # device -> one int32 in PINNED HOST memory: a member that loses a granule writes 1 there (over PCIe, on failure only)
 
 
 def _split_err(device) -> torch.Tensor:
     t = _split_errs.get(device)
     if t is None:
-        word = torch.zeros(1, dtype=torch.int32).pin_memory()
+        word = torch.zeros(16, dtype=torch.int32).pin_memory()     # [0] failed; [1..7] the first report; [8] misplaced (include/cdx.h: xerr)
         t = _split_errs[device] = (word, word.numpy())             # (the numpy view: reading it dispatches no ATen op)
     return t[0]
 
@@ -382,11 +387,40 @@ def check_split_errors(device=None, wait: bool = True):
             continue
         if wait:
             torch.cuda.synchronize(dev)
+        if int(word[8]) != 0:
+            # some launch found the members of a group on different XCDs and exchanged through memory: correct, but ~3x slower than the
+            # ordinary program.  Once may be a dispatch hiccup; a device where it keeps happening runs the ordinary program from then on.
+            word[8] = 0
+            misplaced_launches[dev] = misplaced_launches.get(dev, 0) + 1
+            if misplaced_launches[dev] >= MISPLACED_LIMIT and (_split_ok.get(dev, True) or _group_ok.get(dev, True)):
+                _split_ok[dev] = _group_ok[dev] = False
+                warnings.warn(f"cdx_unet2_run: the members of a split / grouped launch did not share an XCD {misplaced_launches[dev]} times "
+                              f"on {dev} (HIP promises no workgroup placement); such launches exchange through memory and stay correct, "
+                              "but the ordinary program is faster: both modes are off for this device from here on")
         if int(word[0]) != 0:
-            word[0] = 0
+            what, wg, seq, item, xcc, member, slow = (int(v) for v in word[1:8])
+            word[:] = 0
             _split_ok[dev] = _group_ok[dev] = False
+            last_exchange_error[dev] = {"what": "granule" if what == 1 else "placement handshake", "workgroup": wg, "sequence": seq,
+                                        "item": item, "xcc": xcc, "member": member, "through_memory": bool(slow)}
             raise RuntimeError("cdx_unet2_run (split / grouped program): a member never received a granule; the trajectories of that "
-                               "launch were stored as NaN, and both modes are now off for this device")
+                               "launch were stored as NaN, and both modes are now off for this device "
+                               f"(first report: {last_exchange_error[dev]})")
+
+
+def exchange_paths(device=None) -> dict:
+    """Which form of the exchange the members of the LAST split / grouped launch on the current stream took (synchronises): the number
+    of workgroups that found all their partners behind their own L2 (`shared_l2`) and of those that did not and went through memory
+    (`through_memory`; HIP promises no workgroup -> XCD placement, the kernel checks it per launch)."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    st = _split_bufs.get((device, R._stream_ptr(device)))
+    if st is None or "last" not in st:
+        return {"shared_l2": 0, "through_memory": 0}
+    torch.cuda.synchronize(device)
+    n_grp, xf, k, tag = st["last"]
+    ids = st["buf"][n_grp * 4 * xf: n_grp * (4 * xf + 32)].view(torch.int32).view(n_grp, 32)[:, 4:4 + k].cpu().numpy().astype("int64") & 0xffffffff
+    live = (ids >> 4) == tag
+    return {"shared_l2": int((live & ((ids & 1) == 0)).sum()), "through_memory": int((live & ((ids & 1) == 1)).sum())}
 
 
 def split_factor(batch: int) -> int:
@@ -599,7 +633,8 @@ def fused_sample2(solver, net, plan, xt, prior, feed, fix_mask, x_min, x_max, x_
             try:
                 check_split_errors(dev, wait=True)
                 good = bool(torch.allclose(out, ref, rtol=1e-3, atol=1e-3))
-            except RuntimeError:
+            except RuntimeError as e:
+                warnings.warn(f"first-use check of the {'grouped' if group else 'small-batch'} mode: {e}")
                 good = False
             ok[dev] = good
             if not good:
@@ -613,7 +648,8 @@ def fused_sample2(solver, net, plan, xt, prior, feed, fix_mask, x_min, x_max, x_
             torch.cuda.current_stream(dev).synchronize()
             try:
                 check_split_errors(dev, wait=False)
-            except RuntimeError:
+            except RuntimeError as e:
+                warnings.warn(f"{e}; this request is served by the ordinary program")
                 ref = torch.empty_like(xin)
                 launch(plain[0], x_out=ref, parts=plain[1], **kw)
                 return ref

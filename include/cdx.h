@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define CDX_ABI_VERSION 12
+#define CDX_ABI_VERSION 13
 
 #define CDX_OK 0
 #define CDX_EINVAL (-1)   /* bad argument (null pointer, size out of range, misaligned offset) */
@@ -182,8 +182,14 @@ typedef struct cdx_unet2_launch {
      * {value, tag} granules, tag = the exchange's sequence number, polled until they match.  Sequence numbers start at `xseq0` + 1:
      * the caller keeps them increasing from launch to launch on the same `xbuf` (a granule left by an earlier launch then never
      * matches; zero the buffer when the 32-bit counter would wrap), so nothing has to be cleared per launch.  `xflags`: reserved.
-     * `xerr`: one int32 (device memory or pinned host memory), set to 1 if a granule never arrived (the polls are bounded; the results
-     * are then invalid).  0 / NULL: an ordinary launch. */
+     * Behind the tiles `xbuf` holds one 128-byte line per group (ABI 13: n_groups * (4 * xchg_floats + 32) floats in all, zeroed once):
+     * in its prologue every member publishes the XCC id it runs on and reads its partners' -- a group whose members do NOT share an XCD
+     * (HIP promises no placement) runs the same exchange through memory (`sc0 sc1` stores, an agent-scope acquire in front of every
+     * poll) instead of the shared L2.
+     * `xerr`: SIXTEEN int32 (device memory or pinned host memory): [0] set to 1 if a wait ran out (the polls are bounded; the results
+     * are then invalid), [1..7] what / workgroup / sequence number / item / XCC id / member / path of the first report, [8] set to 1
+     * when a group took the through-memory path (correct, but slower than an ordinary launch: the caller may want to stop using the
+     * mode on a device where that keeps happening).  0 / NULL: an ordinary launch.  `tune` bits 0x100 / 0x200 (tests): force the through-memory path / put the members in adjacent workgroups. */
     int32_t split_k, xchg_floats;
     float* xbuf;
     uint32_t* xflags;

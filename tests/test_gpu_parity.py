@@ -1901,14 +1901,31 @@ def test_conditional_request_with_classifier_guidance_is_one_guided_call(kind, a
 
 
 # ---- round 3: small-batch mode -- one trajectory over k workgroups of an XCD (VERDICT r2 "Next" #6) ----
+# How the members of a group are placed / which form of the exchange they use: as launched (workgroups 8 apart -- observed to share an
+# XCD; the kernel checks it), the through-memory form forced, and members put into ADJACENT workgroups, i.e. on different XCDs -- the
+# per-launch placement check must notice and take the through-memory form by itself (HIP promises no placement).
+XCHG_MODES = {"as_launched": None, "through_memory_forced": "256", "members_on_different_xcds": "512"}
+
+
+def _check_exchange_paths(mode):
+    from cleandiffuser_amd.engine import runtime2
+    paths = runtime2.exchange_paths(DEV)
+    assert paths["shared_l2"] + paths["through_memory"] > 0
+    if mode != "as_launched":
+        assert paths["shared_l2"] == 0 and paths["through_memory"] > 0, (mode, paths)
+
+
+@pytest.mark.parametrize("mode", list(XCHG_MODES))
 @pytest.mark.parametrize("k", ["2", "4"])
 @pytest.mark.parametrize("name", ["janner_cfg2_ddim", "janner_cfg2_ddpm_clip", "janner_h4_ddpm", "janner_tiny_disc_ddim", "janner_tiny_cont_ddim"])
-def test_split_program_matches_reference_fixture(name, k, amd_lib, monkeypatch):
+def test_split_program_matches_reference_fixture(name, k, mode, amd_lib, monkeypatch):
     """Every member of a group holds the whole activation set, computes its share of each op's row tiles and all-gathers the rest
     through L2 (flags, no agent-scope fence): one launch of ceil(B / 8) * 8 * k workgroups, reference fixture at 1e-4, no lost flag."""
     from cleandiffuser_amd.engine import program2, runtime2
     if runtime2._split_ok.get(torch.device(DEV)) is not True:
-        pytest.skip("the small-batch mode failed its self-check on this device (workgroups 8 apart do not share an L2 here)")
+        pytest.skip("the small-batch mode failed its self-check on this device")
+    if XCHG_MODES[mode]:
+        monkeypatch.setenv("CDX_UNET2_TUNE", XCHG_MODES[mode])
     monkeypatch.setenv("CDX_UNET2_SPLIT", k)
     monkeypatch.setattr(program2, "SPLIT_MIN_RECORDS", 0)          # cut every op that can be cut (the default leaves short ops whole)
     gold = np.load(golden_path(name))
@@ -1926,6 +1943,7 @@ def test_split_program_matches_reference_fixture(name, k, amd_lib, monkeypatch):
     torch.cuda.synchronize()
     runtime2.check_split_errors()
     assert seen == [(int(k), int(k))], seen
+    _check_exchange_paths(mode)
     np.testing.assert_allclose(x.cpu().numpy(), gold["x_out"], **TOL)
 
 
@@ -1956,16 +1974,19 @@ def test_split_program_agrees_with_the_ordinary_program(B, amd_lib, monkeypatch)
 
 
 # ---- round 4: full-batch grouped mode -- k trajectories over the k workgroups of a group on one XCD (VERDICT r3 "Next" #2) ----
+@pytest.mark.parametrize("mode", list(XCHG_MODES))
 @pytest.mark.parametrize("k", ["2", "4"])
 @pytest.mark.parametrize("name", ["janner_cfg2_ddim", "janner_cfg2_ddpm_clip", "janner_h4_ddpm"])
-def test_grouped_program_matches_reference_fixture(name, k, amd_lib, monkeypatch):
+def test_grouped_program_matches_reference_fixture(name, k, mode, amd_lib, monkeypatch):
     """A member owns one trajectory of its group; the layers that are bound by the L2 -> CU weight stream are computed per member for
     1/k of the output channels of all k trajectories (k x positions tile columns) and all-gathered through L2.  Here with EVERY op that
     can be grouped grouped (threshold 0; `janner_h4_ddpm`: the levels at 2 and 1 positions), ragged last group (batch 3-5), reference
     fixture at 1e-4, one launch, no lost granule."""
     from cleandiffuser_amd.engine import program2, runtime2
     if runtime2._group_ok.get(torch.device(DEV)) is not True:
-        pytest.skip("the grouped mode failed its self-check on this device (workgroups 8 apart do not share an L2 here)")
+        pytest.skip("the grouped mode failed its self-check on this device")
+    if XCHG_MODES[mode]:
+        monkeypatch.setenv("CDX_UNET2_TUNE", XCHG_MODES[mode])
     monkeypatch.setenv("CDX_UNET2_SPLIT", "0")
     monkeypatch.setenv("CDX_UNET2_GROUP", k)
     monkeypatch.setattr(program2, "GROUP_MIN_BYTES", 0)
@@ -1984,7 +2005,27 @@ def test_grouped_program_matches_reference_fixture(name, k, amd_lib, monkeypatch
     torch.cuda.synchronize()
     runtime2.check_split_errors()
     assert len(seen) == 1 and seen[0][:3] == (int(k), True, int(k)) and seen[0][3] >= 2, seen
+    _check_exchange_paths(mode)
     np.testing.assert_allclose(x.cpu().numpy(), gold["x_out"], **TOL)
+
+
+@pytest.mark.parametrize("mode", ["through_memory_forced", "members_on_different_xcds"])
+def test_headline_batch_is_placement_independent(mode, amd_lib, monkeypatch):
+    """BASELINE config 2 at B = 256 (64 groups of four, every CU busy) with the members of every group on DIFFERENT XCDs / with the
+    through-memory exchange forced: the same trajectories as the reference's fixture, and bit-identical to the default placement (the
+    exchange moves values, it computes nothing)."""
+    from cleandiffuser_amd.engine import runtime2
+    if runtime2._group_ok.get(torch.device(DEV)) is not True:
+        pytest.skip("the grouped mode failed its self-check on this device")
+    ref, gold = _extra("baseline_cfg2_b256")
+    assert runtime2.exchange_paths(DEV)["shared_l2"] + runtime2.exchange_paths(DEV)["through_memory"] == 256
+    monkeypatch.setenv("CDX_UNET2_TUNE", XCHG_MODES[mode])
+    out, _ = _extra("baseline_cfg2_b256")
+    torch.cuda.synchronize()
+    runtime2.check_split_errors()
+    assert runtime2.exchange_paths(DEV) == {"shared_l2": 0, "through_memory": 256}
+    assert torch.equal(out["x"], ref["x"])
+    np.testing.assert_allclose(out["x"].cpu().numpy(), gold["x"], **TOL)
 
 
 def test_headline_batch_takes_the_grouped_program_and_matches_the_reference(amd_lib, monkeypatch):
