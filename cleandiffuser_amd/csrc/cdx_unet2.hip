@@ -199,6 +199,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef CDX2_PARAMS_ALL
 #define CDX2_PARAMS_ALL 0           // non-pipelined position only: 1 = every wave issues all five parameter loads (see load_params)
 #endif
+#define CDX2_N_CUS 256                            /* MI355X: 8 XCDs x 32 CUs */
 #define CDX2_GETREG_XCC_ID ((3 << 11) | 20)      /* s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4): the XCD this wave runs on, 0-7 */
 #ifndef CDX2_PIPE_PARAMS
 #define CDX2_PIPE_PARAMS 1          // 0: fetch an op's epilogue parameters and the next descriptor at the op's start (round-2 order)
@@ -818,51 +819,39 @@ template <int T, bool BWD> constexpr bool pipe_params() { return CDX2_PIPE_PARAM
 // of the local traffic, in this kernel it cost ~5.7 k cycles per op with its four barriers).  The two tiles of a group alternate by
 // the parity of the sequence number: a member can only be two exchanges ahead of another after that one has finished reading.
 // Every poll is bounded: a granule that never arrives sets `err` and the launch ends with wrong numbers instead of hanging the GPU.
-// Placement is CHECKED, not assumed (HIP promises no workgroup -> XCD mapping; "workgroup i runs on XCD i % 8" is an observation): in
-// the kernel's prologue every member publishes its HW_REG_XCC_ID with an agent-scope store and reads its partners'; a group whose
-// members differ takes the placement-independent form of the same exchange for this launch -- `sc0 sc1` 16-byte stores and loads on
-// both sides, i.e. through memory instead of the shared L2 (slower per hop, never stale).
-// Sequence numbers keep increasing across launches on the same tiles (launch field xseq0), so nothing is cleared per launch.
+// Groups are FORMED at run time, not assumed: HIP promises no workgroup -> XCD placement ("workgroup i runs on XCD i % 8" is an
+// observation, and a launch that deviates from it would exchange through two different L2s, which are not coherent with each other).
+// Every split / grouped launch has exactly 256 workgroups of one per CU (the LDS request sees to that), i.e. exactly 32 on every XCD,
+// all resident; in its prologue a workgroup reads HW_REG_XCC_ID and draws a ticket from its XCD's counter (an atomic only workgroups
+// behind that same L2 ever touch): ticket t on XCD x = member t % k of group x * (32 / k) + t / k.  The members of a group therefore
+// share an L2 by construction, whatever the dispatcher did.  The counters only ever count up (launch field xtick0 = 32 x the launches
+// so far); which trajectory a workgroup works on follows from its group, not from its blockIdx.
 struct XState {
     int m, k;                  // this workgroup's member index, members per trajectory / trajectories per group
     unsigned seq;              // exchanges done so far (the same number in every member: they run the same op list)
     bool dead;                 // this thread lost a granule: no more waiting in this launch
-    // (whether the members of this group sit behind one L2 -- checked per launch in the kernel's prologue -- lives in the LDS word
-    //  behind the trajectory region, not here: one more scalar live across the op loop measured 1 % at B = 256.  Nonzero: the exchange
-    //  goes through memory -- write-through stores, an acquire in front of every poll -- instead of the shared L2)
+    // (the group's index -- drawn in the kernel's prologue -- lives in the LDS word behind the trajectory region, not here: one more
+    //  scalar live across the op loop measured 1 % at B = 256; every exchange reads it back)
     // (the group's tiles, their size and the error word are re-read from the kernarg segment inside every exchange: five scalar
     //  registers less that would be live -- and spilled -- across the whole op loop)
 };
 
-// The placement-independent form of the publish: 16-byte `sc0 sc1` stores (written through to memory, the line leaves this XCD's L2);
-// the collecting side pairs them with an agent-scope acquire in front of every poll (MI355X_MICROARCH.md, "Workgroup dispatch, XCD
-// placement & inter-workgroup visibility": the XCDs' L2s are not coherent with each other)
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wold-style-cast"
-__device__ __forceinline__ void xchg_store_sc(f32x4* p, f32x4 v) {
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 16, 0x00020000);
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, 0, 0, 17);
-}
-#pragma clang diagnostic pop
-// A failed wait: the error words (pinned host memory, 16 ints: [0] != 0 = failed, then what / which workgroup / sequence number / item /
-// this workgroup's XCC id / its member index / whether the group was on the through-memory path; [8] != 0: some group of a launch took
-// the through-memory path) -- written on failure / misplacement only
-__device__ __forceinline__ void xchg_report(int what, const XState& X, int seq, int item, bool slow) {
+// A failed wait: the error words (pinned host memory, 8 ints: [0] != 0 = failed, then what (1 a granule never came, 2 the ticket of
+// this workgroup does not fit a group) / which workgroup / sequence number / item / this workgroup's XCC id / its member index / its
+// group) -- written on failure only
+__device__ __forceinline__ void xchg_report(int what, const XState& X, int seq, int item, int grp) {
     const KArg* S0 = kernarg();
     asm volatile("" : "+s"(S0));
     int* e = S0->xerr;
     e[1] = what; e[2] = (int)blockIdx.x; e[3] = seq; e[4] = item;
-    e[5] = (int)(__builtin_amdgcn_s_getreg(CDX2_GETREG_XCC_ID) & 15); e[6] = X.m; e[7] = slow ? 1 : 0;
+    e[5] = (int)(__builtin_amdgcn_s_getreg(CDX2_GETREG_XCC_ID) & 15); e[6] = X.m; e[7] = grp;
     e[0] = 1;
 }
 
 // The group's tile for the exchange with sequence number `seq` (two tiles of 2 * xchg_floats floats per group, alternating by parity).
-__device__ __forceinline__ float* exchange_tile(const XState& X, unsigned seq) {
+__device__ __forceinline__ float* exchange_tile(const XState& X, unsigned seq, int grp_idx) {
     const KArg* S0 = kernarg();
     asm volatile("" : "+s"(S0));
-    const int bid = (int)blockIdx.x;
-    int grp_idx = ((bid >> (X.k == 4 ? 5 : 4)) << 3) + (bid & 7);       // (8 k consecutive workgroups = 8 groups)
-    if (S0->tune & 0x200) grp_idx = bid >> (X.k == 4 ? 2 : 1);          // (test hook of the prologue: adjacent members)
     const int xf = S0->xchg_floats;
     return S0->xbuf + (size_t)grp_idx * 4 * xf + (size_t)(seq & 1) * 2 * xf;
 }
@@ -874,10 +863,9 @@ __device__ __forceinline__ float* exchange_tile(const XState& X, unsigned seq) {
 // (Measured and dropped in round 4, gpurun r4d vs r4e: publishing straight from the epilogue's registers -- no LDS read-back, no barrier
 //  in front of the exchange -- with two collect items in flight per thread was 2.5 % SLOWER at B = 256; what an exchange costs, ~3.6 k
 //  cycles, is the wait for the slowest member of the group plus one L2 round trip, not the copy.)
-// SLOW: the through-memory form (see XState::slow) -- its own instantiation, so that the usual one carries none of it.
-template <int THREADS, bool SLOW>
-__device__ __forceinline__ void split_exchange(XState& X, int xg, int gmap, float* __restrict__ tl, int dst, int dstride, int l_out,
-                                               int c_out, int coutp, int tid) {
+template <int THREADS>
+__device__ __forceinline__ void split_exchange(XState& X, int grp_idx, int xg, int gmap, float* __restrict__ tl, int dst, int dstride,
+                                               int l_out, int c_out, int coutp, int tid) {
     const int g_lo = xg & 255, g_hi = (xg >> 8) & 255;
     const bool grouped = (xg & (CDX2_XG_GOP | CDX2_XG_TRAJ)) != 0, traj = (xg & CDX2_XG_TRAJ) != 0;
     const int gsh = grouped ? (gmap & 255) : 30, grows = grouped ? (gmap >> 8) : 0;
@@ -885,7 +873,7 @@ __device__ __forceinline__ void split_exchange(XState& X, int xg, int gmap, floa
     const int base = traj ? dst - X.m * grows * dstride : dst;
     const int c4sh = 31 - __builtin_clz(coutp >> 2), cgsh = 31 - __builtin_clz(coutp >> 3);      // (pad32 channel counts: powers of two x 32)
     X.seq += 1;
-    float* __restrict__ tile = exchange_tile(X, X.seq);
+    float* __restrict__ tile = exchange_tile(X, X.seq, grp_idx);
     const float tag = __uint_as_float(X.seq);
     const int n_items = vl << c4sh;
     // publish: this member's part, read back from the destination slot the epilogue just wrote (pad channels travel along)
@@ -896,13 +884,8 @@ __device__ __forceinline__ void split_exchange(XState& X, int xg, int gmap, floa
         if (mine) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(tl + base + (t * grows + pos + CDX2_HALO2) * dstride + c);
             f32x4* o = reinterpret_cast<f32x4*>(tile + (size_t)(vpos * coutp + c) * 2);
-            if (SLOW) {
-                xchg_store_sc(o, (f32x4){v[0], tag, v[1], tag});
-                xchg_store_sc(o + 1, (f32x4){v[2], tag, v[3], tag});
-            } else {
-                o[0] = (f32x4){v[0], tag, v[1], tag};
-                o[1] = (f32x4){v[2], tag, v[3], tag};
-            }
+            o[0] = (f32x4){v[0], tag, v[1], tag};
+            o[1] = (f32x4){v[2], tag, v[3], tag};
         }
     }
     // collect: everybody else's part, straight from L2 (nontemporal loads bypass this CU's L1), as soon as their tags say so.
@@ -918,9 +901,6 @@ __device__ __forceinline__ void split_exchange(XState& X, int xg, int gmap, floa
             f32x4 a, b;
             int spins = 0;
             for (;;) {
-                // (through memory: this XCD's L2 may still hold the tile's lines as this group read them two exchanges ago -- nothing
-                //  probes them when another XCD writes -- so every poll starts with an agent-scope acquire, which drops them)
-                if (SLOW) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 a = __builtin_nontemporal_load(src);
                 b = __builtin_nontemporal_load(src + 1);
                 if (__float_as_uint(a[1]) == X.seq && __float_as_uint(a[3]) == X.seq && __float_as_uint(b[1]) == X.seq &&
@@ -929,7 +909,7 @@ __device__ __forceinline__ void split_exchange(XState& X, int xg, int gmap, floa
                 // (a legitimate wait is tens of microseconds; ~10 ms of polling means the partner is not behind this L2.  Once a thread
                 //  has given up it stops waiting altogether: the launch must end; its workgroup stores NaN instead of trajectories)
                 if (X.dead || ++spins > 200000) {
-                    if (!X.dead) xchg_report(1, X, (int)(X.seq), i, SLOW);
+                    if (!X.dead) xchg_report(1, X, (int)(X.seq), i, grp_idx);
                     X.dead = true;
                     break;
                 }
@@ -1154,8 +1134,7 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
     if (PIPE) F.P = Pnext;
     if (SPLIT && (xgw & CDX2_XG_XCHG)) {
         __syncthreads();                                             // the epilogue's stores to the destination slot are in LDS
-        if (lds[T * tf] != 0.f) split_exchange<WG<NWV>::THREADS, true>(*X, xgw, gmap, lds, e.dst, e.dstride, l_out, e.c_out, e.coutp, tid);
-        else split_exchange<WG<NWV>::THREADS, false>(*X, xgw, gmap, lds, e.dst, e.dstride, l_out, e.c_out, e.coutp, tid);
+        split_exchange<WG<NWV>::THREADS>(*X, __float_as_int(lds[T * tf]), xgw, gmap, lds, e.dst, e.dstride, l_out, e.c_out, e.coutp, tid);
     }
     __syncthreads();
     if (PROF) stamp(prof ? prof + 3 : nullptr, tid);
@@ -1181,28 +1160,36 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
     // split programs: 8 k consecutive workgroups hold 8 trajectories x k members; the members of a trajectory are 8 workgroups apart,
     // i.e. on the same XCD (workgroup i runs on XCD i % 8)
     XState X{0, 1, 0u, false};
-    unsigned* xids = nullptr;
-    unsigned xtag = 0, my_xcc = 0;
     int grp_idx = 0;
     bool grouped = false;        // grouped program: the k members of a group own k trajectories (one each) instead of one together
     if (SPLIT) {
+        // group formation (see XState): a ticket from this XCD's counter -> (group, member).  256 workgroups, 32 per XCD.
         const KArg* S0 = kernarg();
         asm volatile("" : "+s"(S0));
         X.k = S0->split_k;
         grouped = S0->split_group != 0;
-        const int bid = (int)blockIdx.x, span = 8 * X.k;
-        grp_idx = (bid / span) * 8 + (bid & 7);
-        X.m = (bid % span) >> 3;
-        if (S0->tune & 0x200) {                         // test hook: members in ADJACENT workgroups, i.e. on different XCDs
-            grp_idx = bid / X.k;
-            X.m = bid % X.k;
-        }
         X.seq = S0->xseq0;
-        // placement check, first half: this member's XCC id, tagged with the launch, where every XCD can read it
-        xids = reinterpret_cast<unsigned*>(S0->xbuf + (size_t)(gridDim.x / X.k) * 4 * S0->xchg_floats) + grp_idx * 32;      // (one 128-byte line per group)
-        xtag = (S0->xseq0 + 1u) & 0x0fffffffu;
-        my_xcc = __builtin_amdgcn_s_getreg(CDX2_GETREG_XCC_ID) & 15u;
-        if (tid == 0) __hip_atomic_store(xids + X.m, (xtag << 4) | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int per_xcd = (int)gridDim.x >> 3;                                  // workgroups per XCD: 32
+        const unsigned xcc = __builtin_amdgcn_s_getreg(CDX2_GETREG_XCC_ID) & 15u;
+        unsigned* xtick = reinterpret_cast<unsigned*>(S0->xbuf + (size_t)(gridDim.x / X.k) * 4 * S0->xchg_floats);   // behind the tiles
+        if (tid == 0) {
+            // (one 128-byte line per counter: only workgroups of XCD `xcc` ever touch line `xcc`)
+            const unsigned t = __hip_atomic_fetch_add(xtick + xcc * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - S0->xtick0;
+            const bool fits = xcc < 8u && t < (unsigned)per_xcd;
+            const int g = fits ? (int)xcc * (per_xcd / X.k) + (int)t / X.k : 0;
+            lds[T * tf] = __int_as_float(g);
+            lds[T * tf + 1] = __int_as_float(fits ? (int)t % X.k : -1);
+            // who ended up where (host-side diagnostics; read after the launch): [group][member] = launch tag | XCC id
+            if (fits) xtick[16 * 32 + g * X.k + (int)t % X.k] = ((S0->xseq0 + 1u) << 4) | xcc;
+        }
+        __syncthreads();
+        grp_idx = __builtin_amdgcn_readfirstlane(__float_as_int(lds[T * tf]));
+        X.m = __builtin_amdgcn_readfirstlane(__float_as_int(lds[T * tf + 1]));
+        if (X.m < 0) {                     // more than 32 workgroups on this XCD, or an XCC id past 7: no group for this workgroup
+            if (tid == 0) xchg_report(2, X, (int)S0->xseq0, 0, (int)xcc);
+            X.m = 0;
+            X.dead = true;
+        }
     }
     const int moff = SPLIT ? X.m * L.n_ops : 0;           // member m's op i is descriptor m * n_ops + i
     const int b0 = L.traj_first + (SPLIT ? (grouped ? grp_idx * X.k + X.m : grp_idx) : (int)blockIdx.x * T);
@@ -1251,36 +1238,6 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
     }
     }
     __syncthreads();
-    if (SPLIT) {
-        // placement check, second half: lane j of wave 0 waits for member j's id (bounded) and compares it with this workgroup's
-        int differ = 0, lost = 0;
-        if (tid < X.k) {
-            unsigned v = 0;
-            int spins = 0;
-            for (;;) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // (the slot's line may sit in this XCD's L2 from a neighbour's poll)
-                v = __hip_atomic_load(xids + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((v >> 4) == xtag) break;
-                if (++spins > 2000000) { lost = 1; break; }         // a partner that is not running at all: the launch cannot work
-                __builtin_amdgcn_s_sleep(1);
-            }
-            differ = !lost && (v & 15u) != my_xcc;
-        }
-        const KArg* S0 = kernarg();
-        asm volatile("" : "+s"(S0));
-        const bool misplaced = __syncthreads_or(differ) != 0;
-        const bool slow = misplaced || (S0->tune & 0x100) != 0;                 // (0x100: test hook, force the through-memory path)
-        if (__syncthreads_or(lost)) {
-            if (tid == 0) xchg_report(2, X, (int)xtag, 0, slow);
-            X.dead = true;
-        }
-        if (tid == 0) {
-            lds[T * tf] = slow ? 1.0f : 0.f;                                    // read back by every exchange (ordered by the op loop's barriers)
-            xids[4 + X.m] = (xtag << 4) | (slow ? 1u : 0u);                     // which path this member took (host-side diagnostics)
-            if (misplaced && !(S0->tune & 0x200)) S0->xerr[8] = 1;              // ... and, without a synchronisation, THAT some group had to
-        }
-    }
-
     // log_p pass only (programs with a classifier head, n_steps == 0 and logp_out given): no forward of the whole op list, just the
     // block after the step loop -- one trajectory per workgroup, FiLM row b of the table for trajectory b (per-sample timesteps)
     // (the flag is re-derived from the kernarg segment where it is needed: one more value live across the op loop is a scalar spill)
@@ -1647,7 +1604,10 @@ int cdx_unet2_run(const cdx_unet2_launch* L, void* hip_stream) {
         cdx_set_err("LDS offsets/strides and emb_ld must be multiples of 4 floats"); return CDX_EINVAL;
     }
     size_t lds_bytes = (size_t)L->traj_floats * L->traj_per_wg * sizeof(float);
-    if (L->split_k != 0) lds_bytes += 16;           // the exchange-path word of split / grouped launches (see the kernel's prologue)
+    if (L->split_k != 0) {
+        lds_bytes += 16;                            // group index / member index words of split / grouped launches (the kernel's prologue)
+        if (lds_bytes < 96u * 1024u) lds_bytes = 96u * 1024u;       // more than half a CU's LDS: ONE workgroup per CU, 32 per XCD
+    }
     if (L->prof) lds_bytes += (size_t)(L->n_ops * 8 + 2) * sizeof(unsigned long long);
     if (lds_bytes > 160u * 1024u) { cdx_set_err("program needs more than 160 KiB of LDS"); return CDX_ELDS; }
     const bool guided = L->cg_scale != nullptr || L->with_backward != 0;
@@ -1669,10 +1629,14 @@ int cdx_unet2_run(const cdx_unet2_launch* L, void* hip_stream) {
             !L->xbuf || !L->xerr || L->xchg_floats <= 0 || (L->xchg_floats & 3)) {
             cdx_set_err("split / grouped program: split_k 2 or 4, one trajectory per workgroup, 8 waves, unconditional, xbuf / xerr given"); return CDX_EINVAL;
         }
-        // split: split_k workgroups per trajectory; grouped: split_k trajectories per group of split_k workgroups (blocks of 8 groups)
-        split_grid = L->split_group ? ((L->traj_count + 8 * L->split_k - 1) / (8 * L->split_k)) * 8 * L->split_k
-                                    : ((L->traj_count + 7) / 8) * 8 * L->split_k;
-        if (split_grid > 256) { cdx_set_err("split / grouped program: every workgroup of the launch must be resident (<= 256)"); return CDX_EINVAL; }
+        // split: split_k workgroups per trajectory; grouped: split_k trajectories per group of split_k workgroups.  ALWAYS one workgroup
+        // per CU of the whole chip -- 256, 32 per XCD, all resident: that is what lets the workgroups form their groups from per-XCD
+        // tickets (see XState); groups past the batch compute on zeros
+        const int groups_needed = L->split_group ? (L->traj_count + L->split_k - 1) / L->split_k : L->traj_count;
+        split_grid = CDX2_N_CUS;
+        if (groups_needed > split_grid / L->split_k) {
+            cdx_set_err("split / grouped program: at most 256 / split_k groups per launch (every workgroup must be resident)"); return CDX_EINVAL;
+        }
         kern = L->prof ? cdx_unet2_kernel<1, 8, false, true, false, false, true> : cdx_unet2_kernel<1, 8, false, false, false, false, true>;
     } else if (L->split_group) {
         cdx_set_err("split_group without split_k"); return CDX_EINVAL;

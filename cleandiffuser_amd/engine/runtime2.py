@@ -52,7 +52,7 @@ class CdxUnet2Launch(ctypes.Structure):
                 ("edm_plan", ctypes.c_int32), ("logp_out", ctypes.c_void_p), ("logp_first_op", ctypes.c_int32),
                 ("logp_head_op", ctypes.c_int32), ("ctx", ctypes.c_void_p), ("mlp", ctypes.c_int32),
                 ("split_k", ctypes.c_int32), ("xchg_floats", ctypes.c_int32), ("xbuf", ctypes.c_void_p), ("xflags", ctypes.c_void_p),
-                ("xerr", ctypes.c_void_p), ("xseq0", ctypes.c_uint32), ("split_group", ctypes.c_int32)]
+                ("xerr", ctypes.c_void_p), ("xseq0", ctypes.c_uint32), ("xtick0", ctypes.c_uint32), ("split_group", ctypes.c_int32)]
 
 
 _declared = False
@@ -285,27 +285,32 @@ def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps
         raise ValueError("ChiUNet1d programs carry FiLM-scale ops: only the per-trajectory-table kernels decode them")
     mlp = "mlp" in prog.meta
     xbuf = xerr = None
-    xseq0 = 0
+    xseq0 = xtick0 = 0
     if split:
         assert split == prog.meta.get("group_k" if group else "split_k") and parts is None and t_per_wg in (None, 1)
         check_split_errors(x_in.device, wait=False)   # (a lost granule of an EARLIER split launch on this device surfaces here)
-        # exchange tiles: one pair per group of the launch -- a trajectory's k workgroups (split) or k trajectories' k workgroups (grouped)
-        n_grp = -(-batch // (8 * split)) * 8 if group else -(-batch // 8) * 8
+        # A split / grouped launch ALWAYS has one workgroup per CU (256; 32 per XCD): the workgroups form their groups from per-XCD
+        # tickets (HIP promises no workgroup -> XCD placement; include/cdx.h).  xbuf: a pair of exchange tiles per group, the ticket
+        # counters (16 lines), who-ended-up-where records (256 words).
+        n_grp = N_CUS // split
+        assert (-(-batch // split) if group else batch) <= n_grp
         key = (x_in.device, R._stream_ptr(x_in.device))
-        need = n_grp * (4 * prog.meta["xchg_floats"] + 32)       # tiles, then one 128-byte line per group for the per-launch placement check
+        xf = prog.meta["xchg_floats"]
+        need = n_grp * 4 * xf + 16 * 32 + N_CUS
         n_forwards = max(n_steps, 1)
         if "n_cut_ops" not in prog.meta:
             prog.meta["n_cut_ops"] = int(sum(1 for op in prog.ops if int(op[P2.W2_XG]) & P2.XG_XCHG))
         n_xchg = prog.meta["n_cut_ops"] * n_forwards
         st = _split_bufs.get(key)
-        if st is None or st["buf"].numel() < need or st["seq"] + n_xchg >= 2 ** 31:
-            # tiles of {value, sequence number} granules: zeroed ONCE (and when the counter would wrap) -- the numbers keep increasing
-            # from launch to launch, so a granule left by an earlier launch never matches
-            st = _split_bufs[key] = {"buf": torch.zeros(need, dtype=torch.float32, device=x_in.device), "seq": 0,
-                                     "err": _split_err(x_in.device)}
-        xbuf, xerr, xseq0 = st["buf"], st["err"], st["seq"]
+        if st is None or st["layout"] != (n_grp, xf) or st["seq"] + n_xchg >= 2 ** 31 or st["tick"] >= 2 ** 31:
+            # tiles of {value, sequence number} granules and ticket counters: zeroed ONCE per layout (and when a counter would wrap) --
+            # sequence numbers and tickets keep increasing from launch to launch, so a granule left by an earlier launch never matches
+            st = _split_bufs[key] = {"buf": torch.zeros(need, dtype=torch.float32, device=x_in.device), "seq": 0, "tick": 0,
+                                     "layout": (n_grp, xf), "err": _split_err(x_in.device)}
+        xbuf, xerr, xseq0, xtick0 = st["buf"], st["err"], st["seq"], st["tick"]
         st["seq"] += n_xchg
-        st["last"] = (n_grp, prog.meta["xchg_floats"], split, (xseq0 + 1) & 0x0fffffff)
+        st["tick"] += N_CUS // 8
+        st["last"] = (n_grp, xf, split, (xseq0 + 1) & 0x0fffffff)
     t = t_per_wg or traj_per_wg(prog, batch)
     prof = R._prof["buf"]
     # Two trajectories per workgroup fill the 256 CUs in rounds of 512 trajectories; a remainder of up to 256 is cheaper one
@@ -350,7 +355,7 @@ def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps
             logp_out=R._ptr(logp_out), logp_first_op=prog.meta.get("cls_first", 0) if logp_out is not None else 0,
             logp_head_op=prog.meta.get("head_op", 0) if logp_out is not None else 0, ctx=R._ptr(ctx), mlp=int(mlp),
             split_k=int(split), xchg_floats=prog.meta.get("xchg_floats", 0) if split else 0, xbuf=R._ptr(xbuf), xflags=None,
-            xerr=R._ptr(xerr), xseq0=int(xseq0), split_group=int(bool(group)))
+            xerr=R._ptr(xerr), xseq0=int(xseq0), xtick0=int(xtick0), split_group=int(bool(group)))
         R._check(_lib().cdx_unet2_run(ctypes.byref(L), R._stream_ptr(x_in.device)), "cdx_unet2_run")
     if timing["on"]:
         end.record(torch.cuda.current_stream(x_in.device))
@@ -362,8 +367,6 @@ _ws = {}
 _split_bufs = {}     # (device, stream) -> {exchange tiles, sequence numbers handed out so far, error word} of the split programs
 
 
-misplaced_launches = {}     # device -> launches (seen so far) in which some group's members sat on different XCDs
-MISPLACED_LIMIT = 3
 last_exchange_error = {}    # device -> what the first member that gave up reported (diagnostics; see check_split_errors)
 _split_errs = {}     # device -> one int32 in PINNED HOST memory: a member that loses a granule writes 1 there (over PCIe, on failure only)
 
@@ -371,7 +374,7 @@ _split_errs = {}     # device -> one int32 in PINNED HOST memory: a member that 
 def _split_err(device) -> torch.Tensor:
     t = _split_errs.get(device)
     if t is None:
-        word = torch.zeros(16, dtype=torch.int32).pin_memory()     # [0] failed; [1..7] the first report; [8] misplaced (include/cdx.h: xerr)
+        word = torch.zeros(8, dtype=torch.int32).pin_memory()      # [0] failed; [1..7] the first report (include/cdx.h: xerr)
         t = _split_errs[device] = (word, word.numpy())             # (the numpy view: reading it dispatches no ATen op)
     return t[0]
 
@@ -387,40 +390,37 @@ def check_split_errors(device=None, wait: bool = True):
             continue
         if wait:
             torch.cuda.synchronize(dev)
-        if int(word[8]) != 0:
-            # some launch found the members of a group on different XCDs and exchanged through memory: correct, but ~3x slower than the
-            # ordinary program.  Once may be a dispatch hiccup; a device where it keeps happening runs the ordinary program from then on.
-            word[8] = 0
-            misplaced_launches[dev] = misplaced_launches.get(dev, 0) + 1
-            if misplaced_launches[dev] >= MISPLACED_LIMIT and (_split_ok.get(dev, True) or _group_ok.get(dev, True)):
-                _split_ok[dev] = _group_ok[dev] = False
-                warnings.warn(f"cdx_unet2_run: the members of a split / grouped launch did not share an XCD {misplaced_launches[dev]} times "
-                              f"on {dev} (HIP promises no workgroup placement); such launches exchange through memory and stay correct, "
-                              "but the ordinary program is faster: both modes are off for this device from here on")
         if int(word[0]) != 0:
-            what, wg, seq, item, xcc, member, slow = (int(v) for v in word[1:8])
+            what, wg, seq, item, xcc, member, grp = (int(v) for v in word[1:8])
             word[:] = 0
             _split_ok[dev] = _group_ok[dev] = False
-            last_exchange_error[dev] = {"what": "granule" if what == 1 else "placement handshake", "workgroup": wg, "sequence": seq,
-                                        "item": item, "xcc": xcc, "member": member, "through_memory": bool(slow)}
+            last_exchange_error[dev] = {"what": "granule" if what == 1 else "ticket", "workgroup": wg, "sequence": seq,
+                                        "item": item, "xcc": xcc, "member": member, "group": grp}
             raise RuntimeError("cdx_unet2_run (split / grouped program): a member never received a granule; the trajectories of that "
                                "launch were stored as NaN, and both modes are now off for this device "
                                f"(first report: {last_exchange_error[dev]})")
 
 
-def exchange_paths(device=None) -> dict:
-    """Which form of the exchange the members of the LAST split / grouped launch on the current stream took (synchronises): the number
-    of workgroups that found all their partners behind their own L2 (`shared_l2`) and of those that did not and went through memory
-    (`through_memory`; HIP promises no workgroup -> XCD placement, the kernel checks it per launch)."""
+def group_placement(device=None) -> dict:
+    """Who ended up where in the LAST split / grouped launch on the current stream (synchronises): `workgroups` that drew a ticket,
+    `groups` = complete groups (all k members recorded), `one_xcd_per_group`: every group's members report the same XCC id -- true by
+    construction (a workgroup draws its ticket from the counter of the XCD it runs on), `per_xcd`: workgroups per XCC id."""
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     st = _split_bufs.get((device, R._stream_ptr(device)))
     if st is None or "last" not in st:
-        return {"shared_l2": 0, "through_memory": 0}
+        return {"workgroups": 0, "groups": 0, "one_xcd_per_group": True, "per_xcd": {}}
     torch.cuda.synchronize(device)
     n_grp, xf, k, tag = st["last"]
-    ids = st["buf"][n_grp * 4 * xf: n_grp * (4 * xf + 32)].view(torch.int32).view(n_grp, 32)[:, 4:4 + k].cpu().numpy().astype("int64") & 0xffffffff
-    live = (ids >> 4) == tag
-    return {"shared_l2": int((live & ((ids & 1) == 0)).sum()), "through_memory": int((live & ((ids & 1) == 1)).sum())}
+    off = n_grp * 4 * xf + 16 * 32
+    rec = (st["buf"][off: off + N_CUS].view(torch.int32).cpu().numpy().astype("int64") & 0xffffffff).reshape(n_grp, k)     # [group][member]
+    live = ((rec >> 4) & 0x0fffffff) == tag
+    xcc = rec & 15
+    full = live.all(axis=1)
+    same = bool(all((xcc[g] == xcc[g][0]).all() for g in range(n_grp) if full[g]))
+    per = {}
+    for v in xcc[live].tolist():
+        per[int(v)] = per.get(int(v), 0) + 1
+    return {"workgroups": int(live.sum()), "groups": int(full.sum()), "one_xcd_per_group": same, "per_xcd": per}
 
 
 def split_factor(batch: int) -> int:
@@ -687,10 +687,8 @@ def route_info(net, horizon: int, batch: int, device) -> dict:
             kg = group_factor(batch)
             if kg > 1 and compiled_group2(net, horizon, kg).prog is not None:
                 mode, k, comp, parts = "grouped", kg, compiled_group2(net, horizon, kg), None
-    if mode == "split":
-        n_wg = -(-batch // 8) * 8 * k
-    elif mode == "grouped":
-        n_wg = -(-batch // (8 * k)) * 8 * k
+    if mode in ("split", "grouped"):
+        n_wg = N_CUS                      # always one workgroup per CU (the groups are formed from per-XCD tickets)
     else:
         n_wg = sum(-(-cnt // t) for _, cnt, t in parts)
     return {"mode": mode, "k": k, "comp": comp, "parts": parts, "workgroups": n_wg,

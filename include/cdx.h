@@ -175,31 +175,33 @@ typedef struct cdx_unet2_launch {
      * what the reference substitutes for a missing condition); the second forward of a classifier-free-guidance pair sees zeros. */
     const float* ctx;
     int32_t mlp;
-    /* Split programs (engine/program2.py:compile_janner2_split; small batches): split_k = 2 or 4 workgroups per trajectory, all on one
-     * XCD (the grid is ceil(traj_count / 8) * 8 * split_k workgroups, which must all be resident: <= 256); `ops` holds the members'
-     * descriptors back to back (member m's op i = descriptor m * n_ops + i).  After an op that is cut over the members they all-gather its
-     * output through `xbuf`: per group of the launch (ceil(traj_count / 8) * 8 of them) two tiles of 2 * xchg_floats floats -- 8-byte
-     * {value, tag} granules, tag = the exchange's sequence number, polled until they match.  Sequence numbers start at `xseq0` + 1:
-     * the caller keeps them increasing from launch to launch on the same `xbuf` (a granule left by an earlier launch then never
-     * matches; zero the buffer when the 32-bit counter would wrap), so nothing has to be cleared per launch.  `xflags`: reserved.
-     * Behind the tiles `xbuf` holds one 128-byte line per group (ABI 13: n_groups * (4 * xchg_floats + 32) floats in all, zeroed once):
-     * in its prologue every member publishes the XCC id it runs on and reads its partners' -- a group whose members do NOT share an XCD
-     * (HIP promises no placement) runs the same exchange through memory (`sc0 sc1` stores, an agent-scope acquire in front of every
-     * poll) instead of the shared L2.
-     * `xerr`: SIXTEEN int32 (device memory or pinned host memory): [0] set to 1 if a wait ran out (the polls are bounded; the results
-     * are then invalid), [1..7] what / workgroup / sequence number / item / XCC id / member / path of the first report, [8] set to 1
-     * when a group took the through-memory path (correct, but slower than an ordinary launch: the caller may want to stop using the
-     * mode on a device where that keeps happening).  0 / NULL: an ordinary launch.  `tune` bits 0x100 / 0x200 (tests): force the through-memory path / put the members in adjacent workgroups. */
+    /* Split programs (engine/program2.py:compile_janner2_split; small batches): split_k = 2 or 4 workgroups per trajectory behind one
+     * L2; `ops` holds the members' descriptors back to back (member m's op i = descriptor m * n_ops + i).  After an op that is cut over
+     * the members they all-gather its output through `xbuf`: per group two tiles of 2 * xchg_floats floats -- 8-byte {value, tag}
+     * granules, tag = the exchange's sequence number, polled until they match.  Sequence numbers start at `xseq0` + 1: the caller keeps
+     * them increasing from launch to launch on the same `xbuf` (a granule left by an earlier launch then never matches; zero the buffer
+     * when the 32-bit counter would wrap), so nothing has to be cleared per launch.  `xflags`: reserved.
+     * Groups are formed at run time (ABI 13; HIP promises no workgroup -> XCD placement): EVERY split / grouped launch has 256
+     * workgroups, one per CU = 32 per XCD, all resident (at most 256 / split_k groups of work; the others compute on zeros); a
+     * workgroup draws a ticket from the counter of the XCD it finds itself on (HW_REG_XCC_ID) -- ticket t = member t % split_k of that
+     * XCD's group t / split_k -- so the members of a group share an L2 by construction.  Layout of `xbuf` (floats, zeroed once):
+     * (256 / split_k) * 4 * xchg_floats of tiles, then 16 x 32 words of ticket counters (one 128-byte line each), then 256 words
+     * [group][member] = (xseq0 + 1) << 4 | XCC id of who ended up where (diagnostics).  `xtick0`: tickets drawn per XCD so far on this
+     * `xbuf` = 32 x the launches so far (the counters only count up).
+     * `xerr`: EIGHT int32 (device memory or pinned host memory): [0] set to 1 if a wait ran out or a ticket did not fit (the polls are
+     * bounded; the results are then invalid -- stored as NaN), [1..7] what / workgroup / sequence number / item / XCC id / member /
+     * group of the first report.  0 / NULL: an ordinary launch. */
     int32_t split_k, xchg_floats;
     float* xbuf;
     uint32_t* xflags;
     int32_t* xerr;
     uint32_t xseq0;
+    uint32_t xtick0;
     /* Grouped programs (engine/program2.py:compile_janner2_group; full batches): split_group != 0 with split_k = 2 or 4 -- the split_k
-     * workgroups of a group (same XCD, as above) own split_k TRAJECTORIES, one each; the ops that are bound by the L2 -> CU weight stream
+     * workgroups of a group (behind one L2, as above) own split_k TRAJECTORIES, one each; the ops that are bound by the L2 -> CU weight stream
      * are computed per member for 1/split_k of the output channels of all the group's trajectories (descriptor word W2_XG: CDX2_XG_GOP)
-     * and all-gathered through `xbuf` like the cut ops of a split program.  Grid = ceil(traj_count / (8 * split_k)) * 8 * split_k
-     * workgroups (<= 256, all resident); trajectory of a workgroup = traj_first + group * split_k + member.  A workgroup that loses a
+     * and all-gathered through `xbuf` like the cut ops of a split program.  256 workgroups, groups formed from per-XCD tickets as above;
+     * trajectory of a workgroup = traj_first + group * split_k + member.  A workgroup that loses a
      * granule sets `xerr` AND stores NaN instead of its result (split programs likewise): a failed exchange never looks like a sample. */
     int32_t split_group;
 } cdx_unet2_launch;
