@@ -5,7 +5,7 @@
 cd $GRAFT_REPO_ROOT
 E=gpurun_out/ev4
 mkdir -p $E
-timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -6 > $E/gputests.log; tail -3 $E/gputests.log
+timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider -rs --tb=short -W always > $E/gputests_full.log 2>&1; grep -n "FAILED\|SKIPPED\|first report" $E/gputests_full.log | head -20; tail -4 $E/gputests_full.log > $E/gputests.log; tail -2 $E/gputests.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $E/smoke.log 2>&1; tail -5 $E/smoke.log
 timeout 900 python bench.py > $E/r04_bench_n1.json 2> $E/r04_bench_n1.err; head -c 1500 $E/r04_bench_n1.json; echo; tail -2 $E/r04_bench_n1.err
 timeout 300 python tools/op_profile2.py 256 group4 > $E/r04_op_profile_group4_wg0.txt 2>&1; tail -2 $E/r04_op_profile_group4_wg0.txt
