@@ -263,6 +263,9 @@ def dql_forward(net, x: torch.Tensor, noise: torch.Tensor, condition: Optional[t
 # --------------------------------------------------------------------------------------------------------------------- #
 # forward + backward of update() as ONE HIP graph (opt-in: CDX_TRAIN_GRAPH=1)                                            #
 # --------------------------------------------------------------------------------------------------------------------- #
+RECAPTURE_LIMIT = 3
+
+
 class GraphedStep:
     """``loss = agent.loss(x0, condition); loss.backward()`` captured once into a HIP graph and replayed per step.
 
@@ -279,7 +282,11 @@ class GraphedStep:
         dev = x0.device
         self.x0 = x0.detach().clone()
         self.cond = None if condition is None else condition.detach().clone()
-        params = [p for p in agent.model.parameters() if p.requires_grad]
+        params = self.params = [p for p in agent.model.parameters() if p.requires_grad]
+        # the warm-up steps below draw timesteps / noise like any step: put the generator back afterwards, so that the FIRST replay
+        # consumes what the first eager step would have (a replay reads the generator's offset at replay time and advances it by what
+        # the captured draws consume -- the same numbers an eager step draws from the same state)
+        rng = torch.cuda.get_rng_state(dev)
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -296,6 +303,17 @@ class GraphedStep:
         for p in params:                               # (capture does not run the kernels; keep the grads as the warm-up left them: zero)
             if p.grad is not None:
                 p.grad.zero_()
+        torch.cuda.set_rng_state(rng, dev)
+        self.sig = self._signature()
+
+    def _signature(self):
+        """The addresses the captured launches read and write: parameters and their gradient tensors."""
+        return tuple((p.data_ptr(), -1 if p.grad is None else p.grad.data_ptr()) for p in self.params)
+
+    def valid(self) -> bool:
+        """False once a parameter or a ``.grad`` tensor is no longer the one the graph was captured on (``zero_grad(set_to_none=True)``,
+        ``module.to(...)``, a re-created parameter): replaying would read or accumulate into memory that is not the model's any more."""
+        return self._signature() == self.sig
 
     def replay(self, x0, condition):
         self.x0.copy_(x0)
@@ -314,9 +332,16 @@ def graphed_step(agent, x0, condition, kwargs) -> Optional[GraphedStep]:
     with torch.enable_grad():
         if not supports(net, x0):
             return None
-    key = (tuple(x0.shape), None if condition is None else tuple(condition.shape))
+    key = (tuple(x0.shape), None if condition is None else tuple(condition.shape), agent.model.training)
     cache = agent.__dict__.setdefault("_cdx_graphed", {})
     g = cache.get(key)
+    if g is not None and not g.valid():
+        # captured on tensors that are gone: capture again -- unless that keeps happening (an optimiser that drops the gradients after
+        # every step): then the eager path serves this agent
+        agent._cdx_recaptures = getattr(agent, "_cdx_recaptures", 0) + 1
+        g = cache[key] = None
+    if getattr(agent, "_cdx_recaptures", 0) > RECAPTURE_LIMIT:
+        return None
     if g is None:
         g = cache[key] = GraphedStep(agent, x0, condition)
     return g

@@ -1394,6 +1394,36 @@ def test_graphed_update_equals_the_eager_native_update(amd_lib, monkeypatch):
         assert float((p.detach() - q.detach()).abs().max()) <= 2e-5 * max(1.0, float(q.detach().abs().max())), n
 
 
+def test_graphed_update_draws_what_the_eager_update_draws_and_survives_dropped_gradients(amd_lib, monkeypatch):
+    """CDX_TRAIN_GRAPH=1 against the eager native path from the SAME seed, draws NOT pinned: the capture's warm-up steps must not cost
+    the generator anything (the replays then draw exactly what eager steps draw), and gradients set to None between two updates
+    (``zero_grad(set_to_none=True)`` of user code) must not leave the graph accumulating into freed memory: it is captured again."""
+    from copy import deepcopy
+    from cleandiffuser_amd.utils import load_synth
+    net = load_synth(amd_lib.JannerUNet1d(23, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2, 2], kernel_size=5), 7)
+    fm = torch.zeros(32, 23)
+    fm[0, :17] = 1.0
+    mk = lambda n: amd_lib.DiscreteDiffusionSDE(n, None, fix_mask=fm, diffusion_steps=20, predict_noise=False, grad_clip_norm=1.0, device=DEV)  # noqa: E731
+    a, b = mk(deepcopy(net)), mk(deepcopy(net))
+    batches = [torch.randn(32, 32, 23, generator=torch.Generator().manual_seed(9 + i)).to(DEV) for i in range(5)]
+    logs = {}
+    for tag, agent in (("1", a), ("0", b)):
+        monkeypatch.setenv("CDX_TRAIN_GRAPH", tag)
+        torch.manual_seed(123)
+        out = []
+        for i, x in enumerate(batches):
+            if i == 3:
+                for p in agent.model.parameters():
+                    p.grad = None
+            out.append(agent.update(x))
+        logs[tag] = out
+    assert getattr(a, "_cdx_recaptures", 0) == 1
+    for u, v in zip(logs["1"], logs["0"]):
+        assert abs(u["loss"] - v["loss"]) <= 1e-5 * max(1.0, abs(v["loss"])), (u, v)
+    for (n, p), q in zip(a.model.named_parameters(), b.model.parameters()):
+        assert float((p.detach() - q.detach()).abs().max()) <= 2e-5 * max(1.0, float(q.detach().abs().max())), n
+
+
 def test_update_runs_without_aten_optimiser_launches(amd_lib):
     """config 2's update(): after loss.backward() the whole optimiser side -- gradient-norm clip, AdamW, EMA, zeroed gradients -- is
     the library's kernels (3 launches), and the result equals the PyTorch sequence (clip_grad_norm_, torch.optim.AdamW.step,
