@@ -225,9 +225,16 @@ template <bool FAST, int WT, bool CONV>
 __global__ __launch_bounds__(GM_THREADS, (WT == 2 ? 3 : 4)) void cdx_gemm_kernel(const cdx_gemm_args g, const int fast_ep,
                                                                                 const int k_split, const int xcd_order) {
     constexpr int BMN = 64 * WT;                  // rows of A == rows of W per tile
-    constexpr int KQ = GM_THREADS / BMN;           // k quads staged per row by different threads
-    constexpr int BK = 8 * KQ;                     // each thread stages two float4 per operand: k = kq*4 and BK/2 + kq*4
-    constexpr int LD = BMN + 4;
+    constexpr int BK = WT == 2 ? 16 : 32;          // K tile
+    // Global -> LDS staging map (round 4): a wave's load covers FEW rows in FULL 64 / 128-byte runs -- thread -> (row r0 + i * RPI, k
+    // quad q): 16 rows x 64 B per load instruction (128 x 128 tile), 8 rows x 128 B (64 x 64) -- instead of 64 rows x 16 B: a quarter /
+    // an eighth of the cache lines per instruction through the CU's memory pipe, which is what the co-resident workgroups' epilogue
+    // stores queue behind (profiles/r04_gemm_direct_epilogue_ab.txt).  LD: the transposed ds_write_b32 of a 32-lane half hit 32 banks.
+    constexpr int QPR = BK / 4;                    // float4 quads per row and K tile
+    constexpr int RPI = GM_THREADS / QPR;          // rows one load of the whole workgroup covers
+    constexpr int NLD = BMN / RPI;                 // loads per operand and thread
+    static_assert(NLD == 2, "two float4 per operand and thread");
+    constexpr int LD = WT == 2 ? BMN + 2 : BMN + 1;
     // one LDS arena: two stages of A/B staging tiles [k][row] during the K loop, then 4 wave-private 32 x 36 transposition patches
     __shared__ __attribute__((aligned(16))) float smem[(4 * BK * LD > 4 * 32 * GM_EP_LD) ? 4 * BK * LD : 4 * 32 * GM_EP_LD];
     float (*As)[LD] = reinterpret_cast<float (*)[LD]>(smem);
@@ -244,7 +251,7 @@ __global__ __launch_bounds__(GM_THREADS, (WT == 2 ? 3 : 4)) void cdx_gemm_kernel
         tile = xcd * q8 + min(xcd, r8) + t;
     }
     const int bm = (tile / tiles_n) * BMN, bn = (tile % tiles_n) * BMN;
-    const int lrow = tid % BMN, kq = tid / BMN;         // this thread stages row `lrow`, k quads kq and kq + KQ
+    const int q4 = (tid % QPR) * 4, r0 = tid / QPR;     // this thread stages k quad q4 / 4 of rows r0 and r0 + RPI
 
     gm_stamp(0);
     f32x16 acc[WT][WT];
@@ -255,64 +262,67 @@ __global__ __launch_bounds__(GM_THREADS, (WT == 2 ? 3 : 4)) void cdx_gemm_kernel
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int arow = FAST ? min(bm + lrow, g.M - 1) : bm + lrow, wrow = FAST ? min(bn + lrow, g.N - 1) : bn + lrow;
-    const float* ap = g.A + (size_t)arow * g.lda + kq * 4;
-    const float* wp = g.W + (size_t)wrow * g.ldw + kq * 4;
-    float4 ra0, ra1, rb0, rb1;
+    int lrow[NLD], arow[NLD], wrow[NLD];
+    const float *ap[NLD], *wp[NLD];
+    float4 ra[NLD], rb[NLD];
     // implicit-GEMM conv (FAST: conv_cin % 4 == 0, so an aligned float4 never straddles two taps)
     constexpr bool conv = CONV;                      // compile-time: the plain-GEMM instantiations carry no conv code at all
-    int conv_in0 = 0;
-    size_t conv_base = 0;
-    if (conv) {
-        const int cb = arow / g.conv_lout, clo = arow - cb * g.conv_lout;
-        conv_in0 = clo * g.conv_stride - g.conv_pad;
-        conv_base = (size_t)cb * g.conv_lin;
+    int conv_in0[NLD];
+    size_t conv_base[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        lrow[i] = r0 + i * RPI;
+        arow[i] = FAST ? min(bm + lrow[i], g.M - 1) : bm + lrow[i];
+        wrow[i] = FAST ? min(bn + lrow[i], g.N - 1) : bn + lrow[i];
+        ap[i] = g.A + (size_t)arow[i] * g.lda + q4;
+        wp[i] = g.W + (size_t)wrow[i] * g.ldw + q4;
+        conv_in0[i] = 0; conv_base[i] = 0;
+        if (conv) {
+            const int cb = arow[i] / g.conv_lout, clo = arow[i] - cb * g.conv_lout;
+            conv_in0[i] = clo * g.conv_stride - g.conv_pad;
+            conv_base[i] = (size_t)cb * g.conv_lin;
+        }
     }
     const float conv_inv_cin = conv ? 1.0f / (float)g.conv_cin : 0.f;
     // The validity of a conv tap is applied when the registers are parked in LDS, NOT at load time: a select right behind the load
     // makes hipcc wait for it (s_waitcnt vmcnt(0) in the middle of the MFMA stream: -5..-17 % measured on the large GEMMs).
-    bool cok0 = true, cok1 = true;
-    auto conv_addr = [&](int k, bool& ok) -> const float* {   // 4 consecutive channels of one tap (clamped inside the tensor)
-        const int tap = (int)(((float)k + 0.5f) * conv_inv_cin), c0 = k - tap * g.conv_cin;
-        const int pos = conv_in0 + tap;
-        ok = pos >= 0 && pos < g.conv_lin;
-        return g.A + (conv_base + (ok ? pos : 0)) * g.lda + c0;
-    };
-    auto fetch = [&](int kt) {                           // global -> registers: k columns [kt, kt + BK) of this thread's row
+    bool cok[NLD] = {true, true};
+    auto fetch = [&](int kt) {                           // global -> registers: k quad q4 of this thread's two rows
+        const int k = kt + q4;
         if (FAST) {
-            const float *p0 = ap + kt, *p1 = ap + kt + BK / 2;
-            if (conv) {
-                p0 = conv_addr(kt + kq * 4, cok0);
-                p1 = conv_addr(kt + BK / 2 + kq * 4, cok1);
+            int tap = 0, c0 = 0;
+            if (conv) {                                  // 4 consecutive channels of one tap (clamped inside the tensor)
+                tap = (int)(((float)k + 0.5f) * conv_inv_cin);
+                c0 = k - tap * g.conv_cin;
             }
-            ra0 = *reinterpret_cast<const float4*>(p0);
-            ra1 = *reinterpret_cast<const float4*>(p1);
-            rb0 = *reinterpret_cast<const float4*>(wp + kt);
-            rb1 = *reinterpret_cast<const float4*>(wp + kt + BK / 2);
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const float* pa = ap[i] + kt;
+                if (conv) {
+                    const int pos = conv_in0[i] + tap;
+                    cok[i] = pos >= 0 && pos < g.conv_lin;
+                    pa = g.A + (conv_base[i] + (cok[i] ? pos : 0)) * g.lda + c0;
+                }
+                ra[i] = *reinterpret_cast<const float4*>(pa);
+                rb[i] = *reinterpret_cast<const float4*>(wp[i] + kt);
+            }
         } else {
-            if (conv) {
-                ra0 = gm_conv_load4(g, arow, kt + kq * 4);
-                ra1 = gm_conv_load4(g, arow, kt + BK / 2 + kq * 4);
-            } else {
-                ra0 = gm_load4_guarded(g.A, arow, g.M, kt + kq * 4, g.K, g.lda);
-                ra1 = gm_load4_guarded(g.A, arow, g.M, kt + BK / 2 + kq * 4, g.K, g.lda);
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                ra[i] = conv ? gm_conv_load4(g, arow[i], k) : gm_load4_guarded(g.A, arow[i], g.M, k, g.K, g.lda);
+                rb[i] = gm_load4_guarded(g.W, wrow[i], g.N, k, g.K, g.ldw);
             }
-            rb0 = gm_load4_guarded(g.W, wrow, g.N, kt + kq * 4, g.K, g.ldw);
-            rb1 = gm_load4_guarded(g.W, wrow, g.N, kt + BK / 2 + kq * 4, g.K, g.ldw);
         }
     };
     auto stage = [&](int buf) {                          // registers -> LDS stage `buf`, transposed to [k][row]
         float (*Ad)[LD] = As + buf * (2 * BK);
         float (*Bd)[LD] = Ad + BK;
-        const int ka = kq * 4, kb = BK / 2 + kq * 4;
-        if (FAST && conv) {
-            if (!cok0) ra0 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!cok1) ra1 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            if (FAST && conv && !cok[i]) ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            Ad[q4 + 0][lrow[i]] = ra[i].x; Ad[q4 + 1][lrow[i]] = ra[i].y; Ad[q4 + 2][lrow[i]] = ra[i].z; Ad[q4 + 3][lrow[i]] = ra[i].w;
+            Bd[q4 + 0][lrow[i]] = rb[i].x; Bd[q4 + 1][lrow[i]] = rb[i].y; Bd[q4 + 2][lrow[i]] = rb[i].z; Bd[q4 + 3][lrow[i]] = rb[i].w;
         }
-        Ad[ka + 0][lrow] = ra0.x; Ad[ka + 1][lrow] = ra0.y; Ad[ka + 2][lrow] = ra0.z; Ad[ka + 3][lrow] = ra0.w;
-        Ad[kb + 0][lrow] = ra1.x; Ad[kb + 1][lrow] = ra1.y; Ad[kb + 2][lrow] = ra1.z; Ad[kb + 3][lrow] = ra1.w;
-        Bd[ka + 0][lrow] = rb0.x; Bd[ka + 1][lrow] = rb0.y; Bd[ka + 2][lrow] = rb0.z; Bd[ka + 3][lrow] = rb0.w;
-        Bd[kb + 0][lrow] = rb1.x; Bd[kb + 1][lrow] = rb1.y; Bd[kb + 2][lrow] = rb1.z; Bd[kb + 3][lrow] = rb1.w;
     };
 
     const int wm = (wave >> 1) * (32 * WT), wn = (wave & 1) * (32 * WT);
