@@ -1185,7 +1185,9 @@ static int gm_launch(const cdx_gemm_args* g_in, void* hip_stream, bool force_sma
     // tile shape: 128 x 128 (K tile 16) unless that leaves most of the chip idle -- then 64 x 64 (K tile 32)
     const int tiles_big = ((g->M + 127) / 128) * ((g->N + 127) / 128);
     static const char* env_t = getenv("CDX_GEMM_SMALL_TILE_BELOW");          // tuning hook
-    const int small_below = env_t ? atoi(env_t) : 192;
+    // (with the row-run staging map the 64 x 64 tiles pay up to ~500 big tiles when the launch cannot split K instead -- ChiTransformer
+    //  +3.5 %, DiT shards +0.5-2 %, profiles/r04_gemm_tile_threshold.txt; launches that CAN split K keep the 128 x 128 tiles: config 3 -8 %)
+    const int small_below = env_t ? atoi(env_t) : (g->partial != nullptr && g->partial_slices > 1 ? 192 : 520);
     // the 64 x 64 variant stages 32-wide K tiles: with K % 32 != 0 but K % 16 == 0 the 128 x 128 kernel keeps its unguarded loads
     const bool small = force_small || (tiles_big < small_below && (g->K % 32 == 0 || g->K % 16 != 0));
     const int bmn = small ? 64 : 128, bk = small ? 32 : 16;
