@@ -115,6 +115,17 @@ def test_loader_epochs_cover_the_dataset_like_a_dataloader():
         ds.loader(0, device="cpu")
 
 
+def test_empty_datasets_behave_like_the_reference():
+    """A horizon longer than the padded episodes, or no finished episode at all: zero items (as the reference), an empty epoch."""
+    d = dc.synthetic(n=300, o=4, a=2, seed=7, max_len=40)
+    ds = D4RLMuJoCoDataset(copy.deepcopy(d), horizon=50, max_path_length=40)
+    assert len(ds) == 0 and ds.indices.shape == (0, 3) and list(ds.loader(4, device="cpu")) == []
+    d["terminals"][:] = False
+    d["timeouts"][:] = False
+    ds = D4RLMuJoCoDataset(d, horizon=4, max_path_length=40)
+    assert len(ds) == 0 and ds.seq_obs.shape == (0, 40, 4) and len(ds.loader(4, device="cpu")) == 0
+
+
 def test_too_long_episode_is_rejected():
     d = dc.synthetic(n=500, o=3, a=2, seed=9, max_len=50)
     d["terminals"][:] = False
