@@ -308,9 +308,8 @@ def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps
             st = _split_bufs[key] = {"buf": torch.zeros(need, dtype=torch.float32, device=x_in.device), "seq": 0, "tick": 0,
                                      "layout": (n_grp, xf), "err": _split_err(x_in.device)}
         xbuf, xerr, xseq0, xtick0 = st["buf"], st["err"], st["seq"], st["tick"]
-        st["seq"] += n_xchg
-        st["tick"] += N_CUS // 8
-        st["last"] = (n_grp, xf, split, (xseq0 + 1) & 0x0fffffff)
+        # (the counters move only once the launch is enqueued -- below: a request the library rejects must not leave the host's idea of
+        #  the ticket counters ahead of the device's)
     t = t_per_wg or traj_per_wg(prog, batch)
     prof = R._prof["buf"]
     # Two trajectories per workgroup fill the 256 CUs in rounds of 512 trajectories; a remainder of up to 256 is cheaper one
@@ -357,6 +356,10 @@ def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps
             split_k=int(split), xchg_floats=prog.meta.get("xchg_floats", 0) if split else 0, xbuf=R._ptr(xbuf), xflags=None,
             xerr=R._ptr(xerr), xseq0=int(xseq0), xtick0=int(xtick0), split_group=int(bool(group)))
         R._check(_lib().cdx_unet2_run(ctypes.byref(L), R._stream_ptr(x_in.device)), "cdx_unet2_run")
+        if split:
+            st["seq"] += n_xchg
+            st["tick"] += N_CUS // 8
+            st["last"] = (n_grp, xf, split, (xseq0 + 1) & 0x0fffffff)
     if timing["on"]:
         end.record(torch.cuda.current_stream(x_in.device))
         timing["events"].append((start, end))
@@ -585,7 +588,11 @@ def fused_sample2(solver, net, plan, xt, prior, feed, fix_mask, x_min, x_max, x_
     dev = xt.device
     comp, parts = plan_for(net, h, b)
     split, plain, group = 0, None, False
-    if not chi and not use_cond and not edm and not comp.prog.compact and (R._prof["buf"] is None or os.environ.get("CDX_UNET2_GROUP_PROF") == "1"):
+    # (split / grouped launches carry per-launch sequence numbers and ticket bases as kernel arguments: a captured launch would replay
+    #  stale ones -- under stream capture the ordinary program serves the request)
+    capturing = dev.type == "cuda" and torch.cuda.is_current_stream_capturing()
+    if not chi and not use_cond and not edm and not comp.prog.compact and not capturing and \
+            (R._prof["buf"] is None or os.environ.get("CDX_UNET2_GROUP_PROF") == "1"):
         k = split_factor(b) if _split_ok.get(dev, True) and R._prof["buf"] is None else 1      # small batches: one trajectory over k workgroups of an XCD
         if k > 1:
             alt = compiled_split2(net, h, k)
