@@ -76,6 +76,11 @@ print("\n".join(sorted(gaps)))
     gaps = [g for g in r.stdout.split() if g]
     out_of_scope = ("cleandiffuser.dataset.", "cleandiffuser.env", "cleandiffuser.nn_condition:MultiImageObsCondition")
     assert all(g.startswith(out_of_scope) for g in gaps), [g for g in gaps if not g.startswith(out_of_scope)]
+    # (round 4, SURVEY 8(f4): the two D4RL-MuJoCo datasets the Diffuser / DQL / IDQL pipelines train from are mirrored, with HBM-resident
+    #  buffers -- their import statements resolve too)
+    assert not any(g.startswith(("cleandiffuser.dataset.d4rl_mujoco_dataset:D4RLMuJoCoDataset", "cleandiffuser.dataset.d4rl_mujoco_dataset:D4RLMuJoCoTDDataset",
+                                 "cleandiffuser.dataset.dataset_utils:loop_dataloader")) or g == "cleandiffuser.dataset.d4rl_mujoco_dataset"
+                   for g in gaps), gaps
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/cleandiffuser"), reason="reference tree not present on this box")
