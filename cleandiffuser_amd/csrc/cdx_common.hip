@@ -35,9 +35,41 @@ __global__ void cdx_probe_kernel(float* out) {
     }
 }
 
+// one wave per workgroup: which XCDs does the dispatcher reach from this process (cdx_device_query)
+__global__ void cdx_xcc_probe_kernel(uint32_t* mask) {
+    if (threadIdx.x == 0) atomicOr(mask, 1u << (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u));     // hwreg(HW_REG_XCC_ID, 0, 4)
+}
+
 extern "C" {
 
 int cdx_abi_version(void) { return CDX_ABI_VERSION; }
+
+int cdx_device_query(int device, uint32_t* scratch_u32, void* hip_stream, cdx_device_props* out) {
+    g_err[0] = 0;
+    if (!scratch_u32 || !out) { cdx_set_err("cdx_device_query: null argument"); return CDX_EINVAL; }
+    hipDeviceProp_t p;
+    hipError_t e = hipGetDeviceProperties(&p, device);
+    if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
+    memset(out, 0, sizeof(*out));
+    out->cu_count = p.multiProcessorCount;
+    out->lds_bytes_per_cu = (int32_t)p.maxSharedMemoryPerMultiProcessor;
+    out->wavefront = p.warpSize;
+    size_t i = 0;
+    for (; i + 1 < sizeof(out->arch) && p.gcnArchName[i] && p.gcnArchName[i] != ':'; ++i) out->arch[i] = p.gcnArchName[i];
+    out->arch[i] = 0;
+    hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+    e = hipMemsetAsync(scratch_u32, 0, sizeof(uint32_t), s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(cdx_xcc_probe_kernel, dim3(2048), dim3(64), 0, s, scratch_u32);
+        e = hipGetLastError();
+    }
+    uint32_t mask = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&mask, scratch_u32, sizeof(mask), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
+    out->xcc_count = __builtin_popcount(mask);
+    return CDX_OK;
+}
 
 const char* cdx_last_error(void) { return g_err; }
 

@@ -28,6 +28,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define GM_BK 16
 #define GM_LD (GM_BM + 4)
 #define GM_THREADS 256
+#ifndef CDX_GEMM_KBLOCK
+#define CDX_GEMM_KBLOCK 1                     // 0: one sequential fma chain over K per element (rounds 1-4; A/B builds)
+#endif
 
 extern void cdx_set_err(const char* msg);
 
@@ -210,6 +213,17 @@ __device__ __forceinline__ void gm_epilogue_any(const cdx_gemm_args& g, const f3
     else gm_epilogue<ACT, WT>(g, acc, row0, col0, lane & 31, lane >> 5);
 }
 
+// total += block sum, as 8 packed adds (v_pk_add_f32) per 32 x 32 block
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gm_flush(f32x16& total, const f32x16& blk) {
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const f32x2 t = f32x2{total[r], total[r + 1]} + f32x2{blk[r], blk[r + 1]};
+        total[r] = t[0];
+        total[r + 1] = t[1];
+    }
+}
+
 // Optional timeline trace (tools/gemm_trace.py): [blockIdx][4] x u64 = {s_memtime at start, first tile landed, K loop done,
 // epilogue done}, lane 0 only; off unless cdx_gemm_set_trace() installed a buffer.
 __device__ unsigned long long* gm_trace = nullptr;
@@ -339,9 +353,60 @@ __global__ __launch_bounds__(GM_THREADS, (WT == 2 ? 3 : 4)) void cdx_gemm_kernel
     if (nk > 1) fetch(kt0 + BK);
     __syncthreads();
     gm_stamp(1);
+#if CDX_GEMM_KBLOCK
+    f32x16 blk[WT];
+#pragma unroll
+    for (int i = 0; i < WT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) blk[i][r] = 0.f;
+#endif
     for (int t = 0; t < nk; ++t) {
         const float (*Ac)[LD] = As + (t & 1) * (2 * BK);
         const float (*Bc)[LD] = Ac + BK;
+#if CDX_GEMM_KBLOCK
+        // K-BLOCKED accumulation (round 5): the products of ONE K tile are summed in block accumulators that start at zero, and the block
+        // sums are added to the running totals -- an element's rounding error grows with sqrt(K / BK) + sqrt(BK) roundings instead of
+        // the sqrt(K) of one sequential fma chain (profiles/r05_dit_error_budget.txt: K = 320 3.1e-6 -> 0.8e-6 of the output's rms,
+        // K = 1280 with gate / residual 9.6e-7 -> 2.5e-7; ATen's CPU kernels on the same inputs: 2.0e-6 / 2.7e-7).  Registers: the
+        // wave's rows are walked in WT halves so that only WT block accumulators (32 registers at WT = 2) live next to the 64 of the
+        // total (154 VGPRs as before, three workgroups per CU).  Cost, same-box A/B against the sequential chain (profiles/
+        // r05_gemm_kblock_ab.txt): config 4 -3.3 %, config 3 -3.7 %, ChiTransformer -3.0 %, config 5 -6.1 % -- the flush (s_nop for the
+        // last MFMA + 16 v_pk_add_f32 per half) is issue time the wave's MFMAs do not get.  Two attempts to hide it were measured / built
+        // and dropped: 8-MFMA single-chain segments with the flush under the next segment (kb2: -4.5..-6.6 %), and a software-pipelined
+        // flush (hipcc renames the restarted accumulator: four live sets, 40-50 spilled VGPRs).
+#pragma unroll
+        for (int h = 0; h < WT; ++h) {
+#pragma unroll
+            for (int j = 0; j < WT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) blk[j][r] = 0.f;
+            float av = Ac[lk][wm + 32 * h + lr], bv[WT];
+#pragma unroll
+            for (int j = 0; j < WT; ++j) bv[j] = Bc[lk][wn + 32 * j + lr];
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) {
+                float na = 0.f, nb[WT];
+#pragma unroll
+                for (int j = 0; j < WT; ++j) nb[j] = 0.f;
+                if (kk + 2 < BK) {
+                    na = Ac[kk + 2 + lk][wm + 32 * h + lr];
+#pragma unroll
+                    for (int j = 0; j < WT; ++j) nb[j] = Bc[kk + 2 + lk][wn + 32 * j + lr];
+                }
+#pragma unroll
+                for (int j = 0; j < WT; ++j) blk[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[j], blk[j], 0, 0, 0);
+                if (h == 0 && kk == (WT == 2 ? BK - 4 : BK / 2 - 4) && t + 1 < nk) {   // park tile t + 1 in the other stage, request t + 2
+                    stage((t + 1) & 1);
+                    if (t + 2 < nk) fetch(kt0 + (t + 2) * BK);
+                }
+                av = na;
+#pragma unroll
+                for (int j = 0; j < WT; ++j) bv[j] = nb[j];
+            }
+#pragma unroll
+            for (int j = 0; j < WT; ++j) gm_flush(acc[h][j], blk[j]);
+        }
+#else
         // operands of the next k pair are read from LDS before the MFMAs of the current one are issued
         float av[WT], bv[WT];
 #pragma unroll
@@ -365,6 +430,7 @@ __global__ __launch_bounds__(GM_THREADS, (WT == 2 ? 3 : 4)) void cdx_gemm_kernel
 #pragma unroll
             for (int i = 0; i < WT; ++i) { av[i] = na[i]; bv[i] = nb[i]; }
         }
+#endif
         __syncthreads();                                 // stage (t+1)&1 complete, stage t&1 free for tile t + 2
     }
 
@@ -683,8 +749,13 @@ __global__ __launch_bounds__(256) void cdx_groupnorm_bwd_kernel(const cdx_gn_arg
     for (int o = 32; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o, 64);
     const float rstd = 1.0f / sqrtf(s2 / (float)n + a.eps);
     float sg = 0.f, sgx = 0.f;                           // sum g, sum g * xhat
-    float pg = 0.f, pb = 0.f;                            // this lane's channel: sum dz * xhat, sum dz (training: d gamma, d beta)
-    for (int e = lane; e < n; e += 64) {
+    // this lane's channels: sum dz * xhat, sum dz (training: d gamma, d beta).  cg is a power of two <= 256 (checked by the host entry):
+    // up to 64 a lane's channel e % cg is the same in every iteration; 128 / 256 (ChiUNet1d at 1024 / 2048 channels in 8 groups): a lane
+    // walks the channels lane + 64 j, j = iteration % (cg / 64) -- one partial pair per j
+    float pg[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f};
+    const int jmask = cg > 64 ? cg / 64 - 1 : 0;
+    int it = 0;
+    for (int e = lane; e < n; e += 64, ++it) {
         const int l = e / cg, c = e - l * cg, ch = grp * cg + c;
         const float xh = (xb[(size_t)l * a.ldx + c] - mean) * rstd;
         const float z = xh * a.gamma[ch] + a.beta[ch];
@@ -692,16 +763,25 @@ __global__ __launch_bounds__(256) void cdx_groupnorm_bwd_kernel(const cdx_gn_arg
         const float g = dz * a.gamma[ch];
         sg += g;
         sgx += g * xh;
-        pg += dz * xh;
-        pb += dz;
+        const int j = it & jmask;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q == j) { pg[q] += dz * xh; pb[q] += dz; }
     }
     if (a.dgamma_part != nullptr) {
-        // cg is a power of two <= 64 (checked by the host entry): a lane's channel e % cg is the same in every iteration, and the
-        // lanes that share it differ in the bits >= log2(cg)
-        for (int o = 32; o >= cg; o >>= 1) { pg += __shfl_xor(pg, o, 64); pb += __shfl_xor(pb, o, 64); }
-        if (lane < cg) {
-            a.dgamma_part[(size_t)b * a.C + grp * cg + lane] = pg;
-            a.dbeta_part[(size_t)b * a.C + grp * cg + lane] = pb;
+        if (cg <= 64) {       // the lanes that share a channel differ in the bits >= log2(cg)
+            for (int o = 32; o >= cg; o >>= 1) { pg[0] += __shfl_xor(pg[0], o, 64); pb[0] += __shfl_xor(pb[0], o, 64); }
+            if (lane < cg) {
+                a.dgamma_part[(size_t)b * a.C + grp * cg + lane] = pg[0];
+                a.dbeta_part[(size_t)b * a.C + grp * cg + lane] = pb[0];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (q <= jmask) {
+                    a.dgamma_part[(size_t)b * a.C + grp * cg + lane + 64 * q] = pg[q];
+                    a.dbeta_part[(size_t)b * a.C + grp * cg + lane + 64 * q] = pb[q];
+                }
         }
     }
 #pragma unroll
@@ -1352,7 +1432,7 @@ int cdx_groupnorm_bwd_f32(const cdx_gn_args* a, void* hip_stream) {
     if ((a->dgamma_part == nullptr) != (a->dbeta_part == nullptr)) { cdx_set_err("cdx_groupnorm_bwd_f32: dgamma_part and dbeta_part go together"); return CDX_EINVAL; }
     if (a->dgamma_part != nullptr) {
         const int cg = a->C / a->G;
-        if (cg > 64 || (cg & (cg - 1)) != 0) { cdx_set_err("cdx_groupnorm_bwd_f32: parameter gradients need a power-of-two group width <= 64"); return CDX_EINVAL; }
+        if (cg > 256 || (cg & (cg - 1)) != 0) { cdx_set_err("cdx_groupnorm_bwd_f32: parameter gradients need a power-of-two group width <= 256"); return CDX_EINVAL; }
     }
     const long long waves = (long long)a->B * a->G;
     hipLaunchKernelGGL(cdx_groupnorm_bwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), *a);

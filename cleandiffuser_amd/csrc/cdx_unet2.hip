@@ -876,12 +876,18 @@ __device__ __forceinline__ void split_exchange(XState& X, int grp_idx, int xg, i
     float* __restrict__ tile = exchange_tile(X, X.seq, grp_idx);
     const float tag = __uint_as_float(X.seq);
     const int n_items = vl << c4sh;
+    bool withhold;                                       // test hook (cdx_unet2_launch.fault): a lost granule on purpose
+    {
+        const KArg* S0 = kernarg();
+        asm volatile("" : "+s"(S0));
+        withhold = S0->fault != 0 && X.m == S0->fault - 1 && X.seq == S0->xseq0 + 1u;
+    }
     // publish: this member's part, read back from the destination slot the epilogue just wrote (pad channels travel along)
     for (int i = tid; i < n_items; i += THREADS) {
         const int vpos = i >> c4sh, c = (i - (vpos << c4sh)) * 4, grp = c >> cgsh;
         const int t = vpos >> gsh, pos = vpos - (t << gsh);
         const bool mine = traj ? t == X.m : (grp >= g_lo && grp < g_hi);
-        if (mine) {
+        if (mine && !withhold) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(tl + base + (t * grows + pos + CDX2_HALO2) * dstride + c);
             f32x4* o = reinterpret_cast<f32x4*>(tile + (size_t)(vpos * coutp + c) * 2);
             o[0] = (f32x4){v[0], tag, v[1], tag};
@@ -1159,6 +1165,14 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
     const int H = L.horizon, D = L.dim, HD = H * D, tf = L.traj_floats;
     // split programs: 8 k consecutive workgroups hold 8 trajectories x k members; the members of a trajectory are 8 workgroups apart,
     // i.e. on the same XCD (workgroup i runs on XCD i % 8)
+    if (!SPLIT) {
+        // REPAIR launch (cdx_unet2_launch.run_if): enqueued behind a split / grouped launch with the same tensors; it recomputes the
+        // request on this ordinary program only if that launch reported a lost granule -- otherwise every workgroup leaves here
+        const KArg* S0 = kernarg();
+        asm volatile("" : "+s"(S0));
+        const int* gate = S0->run_if;
+        if (gate != nullptr && __builtin_nontemporal_load(gate) == 0) return;
+    }
     XState X{0, 1, 0u, false};
     int grp_idx = 0;
     bool grouped = false;        // grouped program: the k members of a group own k trajectories (one each) instead of one together
@@ -1624,6 +1638,8 @@ int cdx_unet2_run(const cdx_unet2_launch* L, void* hip_stream) {
     void (*kern)(const cdx_unet2_launch);
     const bool cond = L->n_pass == 2 || L->edm_plan || L->emb_per_traj;
     int split_grid = 0;
+    if (L->split_k != 0 && L->run_if) { cdx_set_err("run_if: the repair launch is an ORDINARY launch (split_k == 0)"); return CDX_EINVAL; }
+    if (L->fault < 0 || (L->fault != 0 && L->split_k == 0)) { cdx_set_err("fault: test hook of split / grouped launches"); return CDX_EINVAL; }
     if (L->split_k != 0) {
         if ((L->split_k != 2 && L->split_k != 4) || guided || cond || L->mlp || L->traj_per_wg != 1 || L->n_waves != 8 || L->compact ||
             !L->xbuf || !L->xerr || L->xchg_floats <= 0 || (L->xchg_floats & 3)) {

@@ -175,13 +175,16 @@ class FusedAdamW(torch.optim.AdamW):
         else) writes one of them, it counts as ``None`` -- the ``set_to_none=True`` contract without freeing the tensor."""
         for p in ps:
             if as_none and p.grad is not None:
-                self._gver[id(p)] = (p.grad.data_ptr(), p.grad._version)
-            else:
+                self._gver[id(p)] = (p.grad, p.grad._version)          # the tensor ITSELF: a fresh gradient that the caching allocator put
+            else:                                                      # at the same address with the same version is another object (ADVICE r4)
                 self._gver.pop(id(p), None)
 
     def _has_grad(self, p) -> bool:
         g = p.grad
-        return g is not None and self._gver.get(id(p)) != (g.data_ptr(), g._version)
+        if g is None:
+            return False
+        mark = self._gver.get(id(p))
+        return mark is None or mark[0] is not g or mark[1] != g._version
 
     # ---- torch.optim surface ----
     def zero_grad(self, set_to_none: bool = True):

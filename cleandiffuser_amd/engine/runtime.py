@@ -17,7 +17,7 @@ from .consts import _act_id
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libcdx.so")
 LIB_PATH = os.environ.get("CDX_LIB", LIB_PATH)          # A/B hook: run the same process against another build
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class CdxStep(ctypes.Structure):
@@ -71,16 +71,25 @@ class _Flat:
         self.slots, self.tree = [], []
         seen = set()
         for mod in module.modules():
-            self.tree.append((mod, len(mod._modules), len(mod._parameters), len(mod._buffers), list(mod._modules.items())))
+            self.tree.append((mod, len(mod._modules), self._live(mod._parameters), self._live(mod._buffers), list(mod._modules.items())))
             for d in (mod._parameters, mod._buffers):
                 for name, t in d.items():
                     if t is not None and id(t) not in seen:          # (shared tensors once, like module.parameters())
                         seen.add(id(t))
                         self.slots.append((d, name))
 
+    @staticmethod
+    def _live(d) -> int:
+        """how many slots of a _parameters / _buffers dict hold a tensor: a slot that goes from None to a tensor (register_buffer(name,
+        None) filled in later) keeps the dict's length but must enter the signature"""
+        n = 0
+        for t in d.values():
+            n += t is not None
+        return n
+
     def valid(self) -> bool:
         for mod, n_mod, n_par, n_buf, children in self.tree:
-            if len(mod._modules) != n_mod or len(mod._parameters) != n_par or len(mod._buffers) != n_buf:
+            if len(mod._modules) != n_mod or self._live(mod._parameters) != n_par or self._live(mod._buffers) != n_buf:
                 return False
             for name, child in children:
                 if mod._modules.get(name) is not child:
@@ -88,7 +97,14 @@ class _Flat:
         return True
 
 
-_sig_scope = {"depth": 0, "id": 0}
+class _Scope(__import__("threading").local):
+    """per thread: a second thread entering a scope must not reuse the id under which the first one cached signatures"""
+    depth = 0
+    id = 0
+
+
+_sig_scope = _Scope()
+_scope_ids = __import__("itertools").count(1)             # process-wide: no two scopes, on whatever thread, share an id
 
 
 class signature_scope:
@@ -97,22 +113,22 @@ class signature_scope:
     0.39 ms of host time, tools/host_profile.py).  Outside a scope every call computes afresh."""
 
     def __enter__(self):
-        if _sig_scope["depth"] == 0:
-            _sig_scope["id"] += 1
-        _sig_scope["depth"] += 1
+        if _sig_scope.depth == 0:
+            _sig_scope.id = next(_scope_ids)
+        _sig_scope.depth += 1
 
     def __exit__(self, *exc):
-        _sig_scope["depth"] -= 1
+        _sig_scope.depth -= 1
         return False
 
 
 def _signature(module):
-    if _sig_scope["depth"] > 0:
+    if _sig_scope.depth > 0:
         hit = module.__dict__.get("_cdx_sig")
-        if hit is not None and hit[0] == _sig_scope["id"]:
+        if hit is not None and hit[0] == _sig_scope.id:
             return hit[1]
         sig = _signature_now(module)
-        module.__dict__["_cdx_sig"] = (_sig_scope["id"], sig)
+        module.__dict__["_cdx_sig"] = (_sig_scope.id, sig)
         return sig
     return _signature_now(module)
 
@@ -225,12 +241,13 @@ _dense_memo = {}
 # ------------------------------------------------------------------------------------------------ #
 # optional per-launch timing (HIP events on the launch stream) -- used by bench.py's roofline leg      #
 # ------------------------------------------------------------------------------------------------ #
-_timing = {"on": False, "events": []}
+_timing = {"on": False, "events": [], "repair_events": []}
 
 
 def enable_launch_timing(on: bool):
     _timing["on"] = bool(on)
     _timing["events"] = []
+    _timing["repair_events"] = []
 
 
 def drain_launch_timing():
@@ -240,6 +257,17 @@ def drain_launch_timing():
         end.synchronize()
         out.append(start.elapsed_time(end))
     _timing["events"] = []
+    return out
+
+
+def drain_repair_timing():
+    """The same for the REPAIR launches behind split / grouped launches (cdx.h: run_if) -- recorded apart: a repair launch that finds no
+    error is an empty grid, and averaging it into the kernel time would halve it."""
+    out = []
+    for start, end in _timing["repair_events"]:
+        end.synchronize()
+        out.append(start.elapsed_time(end))
+    _timing["repair_events"] = []
     return out
 
 

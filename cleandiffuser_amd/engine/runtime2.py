@@ -51,8 +51,9 @@ class CdxUnet2Launch(ctypes.Structure):
                 ("emb_per_traj", ctypes.c_int32), ("n_pass", ctypes.c_int32), ("emb_u", ctypes.c_void_p), ("cfg_w", ctypes.c_float),
                 ("edm_plan", ctypes.c_int32), ("logp_out", ctypes.c_void_p), ("logp_first_op", ctypes.c_int32),
                 ("logp_head_op", ctypes.c_int32), ("ctx", ctypes.c_void_p), ("mlp", ctypes.c_int32),
-                ("split_k", ctypes.c_int32), ("xchg_floats", ctypes.c_int32), ("xbuf", ctypes.c_void_p), ("xflags", ctypes.c_void_p),
-                ("xerr", ctypes.c_void_p), ("xseq0", ctypes.c_uint32), ("xtick0", ctypes.c_uint32), ("split_group", ctypes.c_int32)]
+                ("split_k", ctypes.c_int32), ("xchg_floats", ctypes.c_int32), ("xbuf", ctypes.c_void_p), ("run_if", ctypes.c_void_p),
+                ("xerr", ctypes.c_void_p), ("xseq0", ctypes.c_uint32), ("xtick0", ctypes.c_uint32), ("split_group", ctypes.c_int32),
+                ("fault", ctypes.c_int32)]
 
 
 _declared = False
@@ -277,7 +278,9 @@ def shape_for(module, horizon: int, batch: int):
 def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps=0, predict_noise=0, prior=None,
            fix_mask=None, noise=None, x_min=None, x_max=None, t_per_wg: Optional[int] = None, x_scale: Optional[float] = None,
            cg_scale=None, with_backward: bool = False, parts=None, emb_per_traj: bool = False, emb_u=None, cfg_w: float = 1.0,
-           edm: bool = False, logp_out=None, ctx=None, split: int = 0, group: bool = False):
+           edm: bool = False, logp_out=None, ctx=None, split: int = 0, group: bool = False, run_if=None):
+    """`run_if` (ordinary launches): the error word of the split / grouped launch enqueued just before on the same stream -- this launch
+    is its REPAIR: it recomputes the request only if that word is set when it starts (include/cdx.h)."""
     if batch <= 0:
         return
     prog = comp.prog
@@ -288,7 +291,6 @@ def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps
     xseq0 = xtick0 = 0
     if split:
         assert split == prog.meta.get("group_k" if group else "split_k") and parts is None and t_per_wg in (None, 1)
-        check_split_errors(x_in.device, wait=False)   # (a lost granule of an EARLIER split launch on this device surfaces here)
         # A split / grouped launch ALWAYS has one workgroup per CU (256; 32 per XCD): the workgroups form their groups from per-XCD
         # tickets (HIP promises no workgroup -> XCD placement; include/cdx.h).  xbuf: a pair of exchange tiles per group, the ticket
         # counters (16 lines), who-ended-up-where records (256 words).
@@ -353,8 +355,9 @@ def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps
             n_pass=2 if emb_u is not None else 1, emb_u=R._ptr(emb_u), cfg_w=float(cfg_w), edm_plan=int(edm),
             logp_out=R._ptr(logp_out), logp_first_op=prog.meta.get("cls_first", 0) if logp_out is not None else 0,
             logp_head_op=prog.meta.get("head_op", 0) if logp_out is not None else 0, ctx=R._ptr(ctx), mlp=int(mlp),
-            split_k=int(split), xchg_floats=prog.meta.get("xchg_floats", 0) if split else 0, xbuf=R._ptr(xbuf), xflags=None,
-            xerr=R._ptr(xerr), xseq0=int(xseq0), xtick0=int(xtick0), split_group=int(bool(group)))
+            split_k=int(split), xchg_floats=prog.meta.get("xchg_floats", 0) if split else 0, xbuf=R._ptr(xbuf), run_if=R._ptr(run_if),
+            xerr=R._ptr(xerr), xseq0=int(xseq0), xtick0=int(xtick0), split_group=int(bool(group)),
+            fault=int(os.environ.get("CDX_UNET2_FAULT", "0")) if split else 0)
         R._check(_lib().cdx_unet2_run(ctypes.byref(L), R._stream_ptr(x_in.device)), "cdx_unet2_run")
         if split:
             st["seq"] += n_xchg
@@ -362,12 +365,50 @@ def launch(comp: _Compiled2, *, batch, x_in, x_out, emb, steps_dev=None, n_steps
             st["last"] = (n_grp, xf, split, (xseq0 + 1) & 0x0fffffff)
     if timing["on"]:
         end.record(torch.cuda.current_stream(x_in.device))
-        timing["events"].append((start, end))
+        timing["repair_events" if run_if is not None else "events"].append((start, end))     # (an idle repair launch is not a kernel run)
 
 
-N_CUS = 256          # MI355X
+N_CUS = 256          # the part these launch shapes are cut for (MI355X: 8 XCDs x 32 CUs); the split / grouped modes REQUIRE it (whole_chip)
 _ws = {}
 _split_bufs = {}     # (device, stream) -> {exchange tiles, sequence numbers handed out so far, error word} of the split programs
+
+
+class CdxDeviceProps(ctypes.Structure):
+    _fields_ = [("cu_count", ctypes.c_int32), ("xcc_count", ctypes.c_int32), ("lds_bytes_per_cu", ctypes.c_int32),
+                ("wavefront", ctypes.c_int32), ("arch", ctypes.c_char * 32)]
+
+
+_props = {}
+
+
+def device_props(device) -> dict:
+    """What the library found out about `device` (cdx_device_query, once per device: compute units and architecture from hipDeviceProp_t,
+    the number of XCDs MEASURED by a probe launch that reads HW_REG_XCC_ID)."""
+    device = torch.device(device)
+    hit = _props.get(device)
+    if hit is None:
+        lib = _lib()
+        lib.cdx_device_query.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(CdxDeviceProps)]
+        lib.cdx_device_query.restype = ctypes.c_int
+        out = CdxDeviceProps()
+        scratch = torch.zeros(1, dtype=torch.int32, device=device)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        R._check(lib.cdx_device_query(idx, scratch.data_ptr(), R._stream_ptr(device), ctypes.byref(out)), "cdx_device_query")
+        hit = _props[device] = {"cu_count": int(out.cu_count), "xcc_count": int(out.xcc_count), "lds_bytes_per_cu": int(out.lds_bytes_per_cu),
+                                "wavefront": int(out.wavefront), "arch": out.arch.decode()}
+    return hit
+
+
+def whole_chip(device) -> bool:
+    """May the split / grouped programs run on `device`?  They launch exactly one workgroup per compute unit of a WHOLE MI355X -- 256
+    CUs behind 8 XCDs, 32 workgroups per L2 -- and form their groups from per-XCD tickets; a CPX / NPS partition (32 CUs, one XCD), a CU
+    mask or another part takes the ordinary programs instead of finding out through a lost granule.
+    CDX_UNET2_ASSUME_WHOLE_CHIP=1 skips the query (tests of the refusal itself use =0)."""
+    forced = os.environ.get("CDX_UNET2_ASSUME_WHOLE_CHIP")
+    if forced in ("0", "1"):
+        return forced == "1"
+    p = device_props(device)
+    return p["cu_count"] == N_CUS and p["xcc_count"] == 8 and p["arch"] == "gfx950" and p["wavefront"] == 64
 
 
 last_exchange_error = {}    # device -> what the first member that gave up reported (diagnostics; see check_split_errors)
@@ -382,25 +423,46 @@ def _split_err(device) -> torch.Tensor:
     return t[0]
 
 
+def _report_of(word) -> dict:
+    what, wg, seq, item, xcc, member, grp = (int(v) for v in word[1:8])
+    return {"what": "granule" if what == 1 else "ticket", "workgroup": wg, "sequence": seq, "item": item, "xcc": xcc, "member": member,
+            "group": grp}
+
+
+def note_exchange_failure(device) -> bool:
+    """Has a split / grouped launch on `device` reported a lost granule (so far -- no synchronisation)?  If so both modes go off for the
+    device for the rest of the process (its workgroups are evidently not co-resident behind one L2) and a warning says why.  The error
+    word is NOT cleared here: repair launches that are still queued behind earlier split / grouped launches read it (cdx.h: run_if), and
+    with the modes off nothing will raise it again.  Looking costs nothing (a numpy view of pinned host memory)."""
+    ent = _split_errs.get(device)
+    if ent is None or int(ent[1][0]) == 0:
+        return False
+    if _split_ok.get(device) is not False or _group_ok.get(device) is not False:
+        _split_ok[device] = _group_ok[device] = False
+        last_exchange_error[device] = _report_of(ent[1])
+        warnings.warn("cdx_unet2_run (split / grouped program): a member never received a granule; the affected request was recomputed by "
+                      "the ordinary program on the same stream (repair launch), and both modes are now off for this device "
+                      f"(first report: {last_exchange_error[device]})")
+    return True
+
+
 def check_split_errors(device=None, wait: bool = True):
     """Raise if a split / grouped launch lost a granule (its polls are bounded: the launch ends; the workgroup that gave up stored NaN
-    instead of its trajectories, so a failed exchange never looks like a sample).  The error word lives in pinned host memory the kernel
-    writes directly, so looking at it costs nothing: the next such launch on the device does (`wait=False`); `wait=True` (tests, explicit
-    calls, the synchronous mode of the small-batch path) synchronises the device first.  A device on which this fires loses both modes
-    for the rest of the process (its workgroups are evidently not co-resident behind one L2)."""
+    instead of its trajectories -- which the REPAIR launch behind it then overwrote with the ordinary program's result, so a caller of
+    sample() never sees them).  `wait=True` (tests, explicit calls) synchronises the device first and clears the error word -- nothing
+    is in flight then; `wait=False` only looks.  A device on which this fires loses both modes for the rest of the process."""
     for dev, (_, word) in list(_split_errs.items()):
         if device is not None and dev != device:
             continue
         if wait:
             torch.cuda.synchronize(dev)
         if int(word[0]) != 0:
-            what, wg, seq, item, xcc, member, grp = (int(v) for v in word[1:8])
-            word[:] = 0
             _split_ok[dev] = _group_ok[dev] = False
-            last_exchange_error[dev] = {"what": "granule" if what == 1 else "ticket", "workgroup": wg, "sequence": seq,
-                                        "item": item, "xcc": xcc, "member": member, "group": grp}
+            last_exchange_error[dev] = _report_of(word)
+            if wait:
+                word[:] = 0
             raise RuntimeError("cdx_unet2_run (split / grouped program): a member never received a granule; the trajectories of that "
-                               "launch were stored as NaN, and both modes are now off for this device "
+                               "launch were recomputed by the repair launch behind it, and both modes are now off for this device "
                                f"(first report: {last_exchange_error[dev]})")
 
 
@@ -592,7 +654,7 @@ def fused_sample2(solver, net, plan, xt, prior, feed, fix_mask, x_min, x_max, x_
     #  stale ones -- under stream capture the ordinary program serves the request)
     capturing = dev.type == "cuda" and torch.cuda.is_current_stream_capturing()
     if not chi and not use_cond and not edm and not comp.prog.compact and not capturing and \
-            (R._prof["buf"] is None or os.environ.get("CDX_UNET2_GROUP_PROF") == "1"):
+            (R._prof["buf"] is None or os.environ.get("CDX_UNET2_GROUP_PROF") == "1") and _modes_allowed(dev):
         k = split_factor(b) if _split_ok.get(dev, True) and R._prof["buf"] is None else 1      # small batches: one trajectory over k workgroups of an XCD
         if k > 1:
             alt = compiled_split2(net, h, k)
@@ -630,11 +692,16 @@ def fused_sample2(solver, net, plan, xt, prior, feed, fix_mask, x_min, x_max, x_
                   prior=R._f32c(prior, dev) if fix_mask is not None else None, fix_mask=fix_mask, noise=noise, x_min=x_min, x_max=x_max,
                   x_scale=x_scale, emb_per_traj=use_cond, emb_u=emb_u, cfg_w=w_cfg, edm=edm)
         launch(comp, x_out=out, parts=parts, split=split, group=group, t_per_wg=1 if split else None, **kw)
+        if split and _repair_on():
+            # REPAIR launch: the same request on the ordinary program, gated on the error word of the launch above (cdx.h: run_if).  Stream
+            # order puts it between that launch and every consumer of `out`: a lost granule (bounded polls -> NaN trajectories) is
+            # recomputed before anybody can observe it; when nothing failed every workgroup returns at once (~10 us of a 3.6 ms call).
+            launch(plain[0], x_out=out, parts=plain[1], run_if=_split_err(dev), **kw)
         ok = _group_ok if group else _split_ok
         if split and dev not in ok:
-            # First split / grouped launch on this device: the modes rest on workgroups 8 apart sharing an XCD (one L2).  Check ONCE against
-            # the ordinary program on this very request -- a partition mode or dispatcher that maps workgroups differently shows up as a lost
-            # granule or as different numbers, and the mode stays off for the process instead of failing later.
+            # First split / grouped launch on this device: checked ONCE against the ordinary program on this very request -- a dispatcher
+            # that does not give the launch one workgroup per CU shows up as a lost granule or as different numbers, and the mode stays
+            # off for the process instead of failing later.
             ref = torch.empty_like(xin)
             launch(plain[0], x_out=ref, parts=plain[1], **kw)
             try:
@@ -647,25 +714,27 @@ def fused_sample2(solver, net, plan, xt, prior, feed, fix_mask, x_min, x_max, x_
             if not good:
                 return ref
         elif split and _sync_check(group):
-            # The error word of THIS launch, before its result leaves the function: wait for the launch, look, and on a lost
-            # granule serve the request from the ordinary program instead.  Default for the small-batch mode -- its callers (real-time
-            # control, B <= 128) consume the result at once, so the wait costs them nothing; the full-batch grouped mode stays asynchronous
-            # by default (the host work of call n + 1 overlaps the kernel of call n): there a failed exchange stores NaN instead of
-            # trajectories, raises at the next launch / check_split_errors(), and switches the mode off.  CDX_UNET2_SPLIT_SYNC=1 / 0 forces.
+            # CDX_UNET2_SPLIT_SYNC=1: look at the error word of THIS launch before the call returns (the mode then switches off one call
+            # earlier).  Not needed for safety any more -- the repair launch has already replaced a failed result.
             torch.cuda.current_stream(dev).synchronize()
-            try:
-                check_split_errors(dev, wait=False)
-            except RuntimeError as e:
-                warnings.warn(f"{e}; this request is served by the ordinary program")
-                ref = torch.empty_like(xin)
-                launch(plain[0], x_out=ref, parts=plain[1], **kw)
-                return ref
+            note_exchange_failure(dev)
     return out
 
 
 def _sync_check(group: bool) -> bool:
-    forced = os.environ.get("CDX_UNET2_SPLIT_SYNC")
-    return forced == "1" if forced in ("0", "1") else not group
+    return os.environ.get("CDX_UNET2_SPLIT_SYNC") == "1"
+
+
+def _repair_on() -> bool:
+    return os.environ.get("CDX_UNET2_REPAIR", "1") != "0"       # (=0: A/B runs that price the repair launch; a failed exchange then hands out NaN)
+
+
+def _modes_allowed(dev) -> bool:
+    """Split / grouped launches on `dev`: a whole MI355X only (whole_chip), and not after a lost granule (looked up without a sync)."""
+    if dev.type != "cuda":
+        return False
+    note_exchange_failure(dev)
+    return whole_chip(dev)
 
 
 _split_ok = {}       # device -> did the small-batch mode pass its one-time check there (absent: not checked yet)

@@ -32,7 +32,7 @@ def enabled() -> bool:
     return os.environ.get("CDX_TRAIN_NATIVE", "1") != "0"
 
 
-def supports(net, x: torch.Tensor) -> bool:
+def supports(net, x: torch.Tensor, condition=None) -> bool:
     """JannerUNet1d (GroupNorm, no attention) with fp32 parameters on a ROCm device, called with autograd on."""
     from .consts import supports_janner
     from .runtime import _is_janner
@@ -40,7 +40,30 @@ def supports(net, x: torch.Tensor) -> bool:
         return False
     if supports_janner(net) is not None or net.kernel_size > 5:
         return False
+    if not _groupnorms_ok(net) or not _wants_grad(net, x, condition):
+        return False
     return all(p.dtype == torch.float32 and p.is_cuda for p in net.parameters())
+
+
+def _groupnorms_ok(net) -> bool:
+    """cdx_groupnorm_bwd_f32 reduces the gain / shift gradients per channel of a group of C / G channels: a power of two, at most 256
+    (model_dim 48 -- groups of 6 / 12 -- does not fit): such nets keep the reference's ATen autograd path instead of failing inside
+    backward()."""
+    for m in net.modules():
+        if isinstance(m, nn.GroupNorm) or type(m).__name__ == "GroupNorm1d":
+            c, g = m.weight.shape[0], max(int(m.num_groups), 1)
+            cg = c // g
+            if c % g or cg > 256 or cg & (cg - 1):
+                return False
+    return True
+
+
+def _wants_grad(net, *tensors) -> bool:
+    """Does anything in this forward take part in autograd?  A frozen net (model_ema) called without no_grad() on inputs that need no
+    gradient belongs to the one-launch fused forward, not to the per-layer training graph."""
+    if any(getattr(t, "requires_grad", False) for t in tensors):
+        return True
+    return any(p.requires_grad for p in net.parameters())
 
 
 # --------------------------------------------------------------------------------------------------------------------- #
@@ -186,6 +209,66 @@ def janner_forward(net, x: torch.Tensor, noise: torch.Tensor, condition: Optiona
     return h.view(b, length, d)
 
 
+def supports_chi(net, x: torch.Tensor, condition=None) -> bool:
+    """ChiUNet1d with a global condition (the dp_* configuration, BASELINE config 3) with fp32 parameters on a ROCm device, called
+    with autograd on."""
+    if not (enabled() and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and type(net).__name__ == "ChiUNet1d"):
+        return False
+    if not net.obs_as_global_cond or condition is None or net.final_conv[0].kernel_size[0] > 5:
+        return False
+    if not _groupnorms_ok(net) or not _wants_grad(net, x, condition):
+        return False
+    return all(p.dtype == torch.float32 and p.is_cuda for p in net.parameters())
+
+
+def _chi_block(rb, h, memb, batch: int, length: int):
+    """ChiResidualBlock (reference nn_diffusion/chiunet.py:13-45): CNA2(FiLM(CNA1(x), Linear(Mish(emb)))) + skip(x).  `memb` = Mish(emb),
+    evaluated once for all blocks (every block's cond_encoder starts with the same Mish); the block's Linear is a library node."""
+    c_out = rb.out_dim
+    a1 = _cna(h, rb.conv1, batch, length).view(batch, length, c_out)
+    lin = rb.cond_encoder[1]
+    film = _LinearMish.apply(memb, lin.weight, lin.bias, False)
+    if rb.cond_predict_scale:
+        film = film.view(batch, 2, c_out)
+        a1 = film[:, 0, None, :] * a1 + film[:, 1, None, :]
+    else:
+        a1 = a1 + film[:, None, :]
+    a2 = _cna(a1.reshape(batch * length, c_out), rb.conv2, batch, length)
+    res = h if isinstance(rb.residual_conv, nn.Identity) else _conv(h, rb.residual_conv, batch, length)
+    return a2 + res
+
+
+def chi_forward(net, x: torch.Tensor, noise: torch.Tensor, condition: torch.Tensor) -> torch.Tensor:
+    """``ChiUNet1d.forward`` with a global condition (reference nn_diffusion/chiunet.py:152-192) with autograd, every convolution,
+    GroupNorm and FiLM Linear on the library's kernels.  x (b, Ta, act_dim), condition (b, To, obs_dim) -> (b, Ta, act_dim)."""
+    b, length, d = x.shape
+    emb = net.map_emb(net.map_noise(noise))
+    emb = torch.cat([emb, net.global_cond_encoder(torch.flatten(condition, 1))], dim=-1)
+    memb = torch.nn.functional.mish(emb)
+    h = x.reshape(b * length, d)
+    skips = []
+    for res1, res2, down in net.downs:
+        h = _chi_block(res2, _chi_block(res1, h, memb, b, length), memb, b, length)
+        skips.append((h, length))
+        if not isinstance(down, nn.Identity):
+            h = _conv(h, down.conv, b, length)
+            length = (length - 1) // 2 + 1
+    for mid in net.mids:
+        h = _chi_block(mid, h, memb, b, length)
+    for res1, res2, up in net.ups:
+        skip, l_skip = skips.pop()
+        assert l_skip == length
+        h = torch.cat([h, skip], dim=1)
+        h = _chi_block(res2, _chi_block(res1, h, memb, b, length), memb, b, length)
+        if not isinstance(up, nn.Identity):
+            h = _ConvT.apply(h, up.conv.weight, up.conv.bias, b, length)
+            length *= 2
+    fc = net.final_conv
+    h = _cna(h, fc, b, length)
+    h = _conv(h, fc[3], b, length)
+    return h.view(b, length, d)
+
+
 # --------------------------------------------------------------------------------------------------------------------- #
 # Linear (+ Mish) nodes: the MLP denoisers under autograd -- DQL's policy update back-propagates through sample()           #
 # --------------------------------------------------------------------------------------------------------------------- #
@@ -222,13 +305,13 @@ class _LinearMish(torch.autograd.Function):
         return dx, dw, db, None
 
 
-def supports_mlp(net, x: torch.Tensor) -> bool:
+def supports_mlp(net, x: torch.Tensor, condition=None) -> bool:
     """DQLMlp / DVInvMlp (Linear -> Mish trunks) with fp32 parameters on a ROCm device, called with autograd on -- what
     ``sample(..., requires_grad=True)`` of the Diffusion-QL policy update runs at every denoising step (reference
     pipelines/dql_d4rl_mujoco.py:101, diffusionsde.py:401-427)."""
     if not (enabled() and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2):
         return False
-    if type(net).__name__ not in ("DQLMlp", "DVInvMlp"):
+    if type(net).__name__ not in ("DQLMlp", "DVInvMlp") or not _wants_grad(net, x, condition):
         return False
     return all(p.dtype == torch.float32 and p.is_cuda for p in net.parameters())
 

@@ -88,10 +88,17 @@ class ChiUNet1d(BaseNNDiffusion):
     def forward(self, x: torch.Tensor, noise: torch.Tensor, condition: Optional[torch.Tensor] = None):
         """x (b, Ta, act_dim), noise (b,), condition (b, To, obs_dim) [required, SURVEY Q12] -> (b, Ta, act_dim)."""
         assert x.shape[1] & (x.shape[1] - 1) == 0, "Ta dimension must be 2^n"
-        from ..engine import dispatch
+        from ..engine import dispatch, train
+        if train.supports_chi(self, x, condition):
+            # autograd on, ROCm device (loss() / update()): the same graph, every convolution / GroupNorm / FiLM Linear node on the
+            # library's kernels forward and backward (engine/train.py; SURVEY 8(f4))
+            return train.chi_forward(self, x, noise, condition)
         y = dispatch.try_backbone_forward(self, x, noise, condition)      # one fused launch on a ROCm device
         if y is not None:
             return y
+        return self._forward_torch(x, noise, condition)
+
+    def _forward_torch(self, x: torch.Tensor, noise: torch.Tensor, condition: Optional[torch.Tensor] = None):
         x = x.permute(0, 2, 1)
         emb = self.map_emb(self.map_noise(noise))
         local = None

@@ -176,7 +176,7 @@ class JannerUNet1d(BaseNNDiffusion):
         """x (b, horizon, in_dim), noise (b,), condition (b, emb_dim)|None -> (b, horizon, in_dim)."""
         assert x.shape[1] & (x.shape[1] - 1) == 0, "Ta dimension must be 2^n"
         from ..engine import dispatch, train
-        if train.supports(self, x):
+        if train.supports(self, x, condition):
             # autograd on, ROCm device (loss() / update(), sampling with requires_grad=True): the same graph, every convolution and
             # GroupNorm node on the library's kernels forward and backward (engine/train.py; SURVEY 8(f4))
             return train.janner_forward(self, x, noise, condition)

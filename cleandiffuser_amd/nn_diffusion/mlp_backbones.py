@@ -94,7 +94,7 @@ class DQLMlp(_ObsConditionedMlp):
 
     def forward(self, x: torch.Tensor, noise: torch.Tensor, condition: Optional[torch.Tensor] = None):
         from ..engine import train
-        if train.supports_mlp(self, x):       # autograd on, ROCm device (DQL back-propagates through sample()): Linear / Mish nodes on the library
+        if train.supports_mlp(self, x, condition):       # autograd on, ROCm device (DQL back-propagates through sample()): Linear / Mish nodes on the library
             return train.dql_forward(self, x, noise, condition)
         return self.final_layer(self.mid_layer(self._features(x, noise, condition)))
 
@@ -117,7 +117,7 @@ class DVInvMlp(_ObsConditionedMlp):
         if condition is None:
             raise TypeError("DVInvMlp needs the (obs, next_obs) condition")       # reference: torch.cat fails on None
         from ..engine import train
-        if train.supports_mlp(self, x):
+        if train.supports_mlp(self, x, condition):
             return train.dql_forward(self, x, noise, condition)
         return self.final_layer(self.mid_layer(self._features(x, noise, condition)))
 

@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define CDX_ABI_VERSION 13
+#define CDX_ABI_VERSION 14
 
 #define CDX_OK 0
 #define CDX_EINVAL (-1)   /* bad argument (null pointer, size out of range, misaligned offset) */
@@ -54,6 +54,20 @@ typedef struct cdx_step {
 
 /* ABI version of the loaded library (== CDX_ABI_VERSION of the header it was built from). */
 int cdx_abi_version(void);
+
+/* What the library needs to know about a device before it may use the launch shapes that assume a whole MI355X (ABI 14): the split /
+ * grouped programs of cdx_unet2_run need exactly 256 compute units behind 8 XCDs (one workgroup per CU, 32 per L2) -- a CPX / NPS
+ * partition, a CU mask or another gfx9 part must take the ordinary programs.  `xcc_count` is MEASURED: a probe launch of 2048 one-wave
+ * workgroups ORs 1 << HW_REG_XCC_ID into *scratch_u32 (caller-owned device word, zeroed by the call); the call synchronises
+ * `hip_stream` once (a one-time query, not a hot-path entry).  Returns CDX_OK and fills *out. */
+typedef struct cdx_device_props {
+    int32_t cu_count;          /* hipDeviceProp_t::multiProcessorCount */
+    int32_t xcc_count;         /* distinct HW_REG_XCC_ID values the probe saw */
+    int32_t lds_bytes_per_cu;  /* hipDeviceProp_t::maxSharedMemoryPerMultiProcessor */
+    int32_t wavefront;         /* hipDeviceProp_t::warpSize */
+    char arch[32];             /* hipDeviceProp_t::gcnArchName up to the first ':' ("gfx950") */
+} cdx_device_props;
+int cdx_device_query(int device, uint32_t* scratch_u32, void* hip_stream, cdx_device_props* out);
 
 /* Text of the last error on the calling thread ("" if none). */
 const char* cdx_last_error(void);
@@ -180,7 +194,12 @@ typedef struct cdx_unet2_launch {
      * the members they all-gather its output through `xbuf`: per group two tiles of 2 * xchg_floats floats -- 8-byte {value, tag}
      * granules, tag = the exchange's sequence number, polled until they match.  Sequence numbers start at `xseq0` + 1: the caller keeps
      * them increasing from launch to launch on the same `xbuf` (a granule left by an earlier launch then never matches; zero the buffer
-     * when the 32-bit counter would wrap), so nothing has to be cleared per launch.  `xflags`: reserved.
+     * when the 32-bit counter would wrap), so nothing has to be cleared per launch.
+     * `run_if` (ABI 14; ORDINARY launches only -- split_k == 0): NULL, or a device-visible int32 word: the launch does its work only if
+     * *run_if != 0 when it starts, otherwise every workgroup returns at once.  This is the REPAIR launch the host enqueues right behind
+     * a split / grouped launch, on the same stream, with the same tensors and run_if = that launch's `xerr`: if a member lost a granule
+     * (the polls are bounded) the request is recomputed by the ordinary program before anything downstream of the stream can observe
+     * x_out, so a failed exchange never reaches a caller as NaN; if nothing failed the repair costs one empty launch (~10 us).
      * Groups are formed at run time (ABI 13; HIP promises no workgroup -> XCD placement): EVERY split / grouped launch has 256
      * workgroups, one per CU = 32 per XCD, all resident (at most 256 / split_k groups of work; the others compute on zeros); a
      * workgroup draws a ticket from the counter of the XCD it finds itself on (HW_REG_XCC_ID) -- ticket t = member t % split_k of that
@@ -193,7 +212,7 @@ typedef struct cdx_unet2_launch {
      * group of the first report.  0 / NULL: an ordinary launch. */
     int32_t split_k, xchg_floats;
     float* xbuf;
-    uint32_t* xflags;
+    const int32_t* run_if;
     int32_t* xerr;
     uint32_t xseq0;
     uint32_t xtick0;
@@ -204,6 +223,9 @@ typedef struct cdx_unet2_launch {
      * trajectory of a workgroup = traj_first + group * split_k + member.  A workgroup that loses a
      * granule sets `xerr` AND stores NaN instead of its result (split programs likewise): a failed exchange never looks like a sample. */
     int32_t split_group;
+    /* TEST HOOK (ABI 14): fault = m + 1 makes member m of EVERY group withhold its granules in the first exchange of the launch -- a
+     * lost granule on purpose (tests/test_gpu_parity.py: sample() must never hand out NaN, the mode must switch itself off).  0: off. */
+    int32_t fault;
 } cdx_unet2_launch;
 int cdx_unet2_run(const cdx_unet2_launch* launch, void* hip_stream);
 
@@ -267,7 +289,7 @@ typedef struct cdx_gn_args {
     float eps;
     /* backward only (training): optional (B, C) outputs -- per sample the sums over its positions of dz * x_hat and of dz
      * (dz = d loss / d y * act'): the column sums of these over the batch are d loss / d gamma and d loss / d beta.  Both or neither;
-     * needs C / G channels per group to be a power of two <= 64. */
+     * needs C / G channels per group to be a power of two <= 256. */
     float *dgamma_part, *dbeta_part;
 } cdx_gn_args;
 int cdx_groupnorm_f32(const cdx_gn_args* args, void* hip_stream);

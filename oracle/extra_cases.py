@@ -325,7 +325,11 @@ SCENARIOS.update({
 GPU_ONLY: Dict[str, Callable] = {
     "baseline_cfg3_b130": baseline_config("cfg3", 130), "baseline_cfg4_tied_b96": baseline_config("cfg4", 96, "tied"),
     "baseline_cfg5_b300": baseline_config("cfg5", 300), "baseline_cfg5_d27_b300": baseline_config("cfg5", 300, "d27"),
+    # round 5: config 4 at its EXACT per-GPU shard (B = 4096 over 8 GPUs -> 512 trajectories = 65 536 token rows with the CFG pair)
+    "baseline_cfg4_tied_b512": baseline_config("cfg4", 512, "tied"),
 }
+# Fixtures of these scenarios keep every STRIDE-th trajectory only (trajectories are independent; the device run is the whole batch)
+SUBSAMPLED = {"baseline_cfg4_tied_b512": 4}
 
 
 # --------------------------------------------------------------------------------------------------------------------- #
@@ -496,7 +500,8 @@ def _sample_fp64(agent, lib_kind: str, prior, zs, **kw):
     agent.model_ema.double()
     for holder in (agent.model, agent.model_ema):          # (the solvers build their timestep vectors in float32)
         net = holder["diffusion"]
-        net.forward = (lambda f: lambda x, noise, condition=None: f(x, noise.double(), condition))(net.forward)
+        # (integer timesteps of the discrete solvers stay integers: the positional embedding truncates them)
+        net.forward = (lambda f: lambda x, noise, condition=None: f(x, noise.double() if noise.is_floating_point() else noise, condition))(net.forward)
     for k, v in list(vars(agent).items()):
         if isinstance(v, torch.Tensor) and v.is_floating_point():
             setattr(agent, k, v.double())

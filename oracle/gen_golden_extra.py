@@ -42,7 +42,7 @@ def dit_h40_depth8_fp64(out_dir="tests/golden"):
     print(f"dit_h40_depth8 fp64: reference fp32 vs fp64 max|d| = {np.abs(x32 - x.numpy()).max():.3e}")
 
 
-FP64_YARDSTICKS = ("baseline_cfg4_tied", "baseline_cfg4_tied_b96")
+FP64_YARDSTICKS = ("baseline_cfg4_tied", "baseline_cfg4_tied_b96", "baseline_cfg4_tied_b512", "chitf_ta10", "dit_h96")
 
 
 def fp64_yardstick(name, out_dir="tests/golden"):
@@ -50,7 +50,7 @@ def fp64_yardstick(name, out_dir="tests/golden"):
     alpha(1) = 0.0066, CFG w = 2) amplifies fp32 rounding so much that the reference's own fp32 result is ~1.8e-4 away from this one
     (and ~3e-4 away from ITSELF on another CPU: EPYC vs Xeon BLAS paths): the GPU test measures the native path against this yardstick
     next to the fp32 fixture (tools/dit_error_budget.py has the full table)."""
-    x64 = extra_cases.run(name, "reference", fp64=True)["x"].detach().cpu().numpy()
+    x64 = extra_cases.run(name, "reference", fp64=True)["x"].detach().cpu().numpy()[::extra_cases.SUBSAMPLED.get(name, 1)]
     x32 = np.load(os.path.join(out_dir, f"extra_{name}.npz"))["x"]
     np.savez_compressed(os.path.join(out_dir, f"extra_{name}_fp64.npz"), x=x64.astype(np.float32))       # (stored rounded: half the file)
     print(f"{name} fp64: reference fp32 vs fp64 max|d| = {np.abs(x32 - x64).max():.3e}  mean|d| = {np.abs(x32 - x64).mean():.3e}")
@@ -64,6 +64,10 @@ def main(out_dir="tests/golden", only=None):
         out = {k: v.detach().cpu().numpy().astype(np.float32) for k, v in extra_cases.run(name, "reference").items()
                if not k.startswith("_")}
         assert all(np.isfinite(v).all() for v in out.values()), name
+        if name in extra_cases.SUBSAMPLED:               # every stride-th trajectory (+ the stride itself)
+            st = extra_cases.SUBSAMPLED[name]
+            out = {k: v[::st] for k, v in out.items()}
+            out["stride"] = np.array([st], np.int32)
         np.savez_compressed(os.path.join(out_dir, f"extra_{name}.npz"), **out)
         print(f"{name:24s} " + " ".join(f"{k}{v.shape} |max|={np.abs(v).max():.3f}" for k, v in out.items()))
 

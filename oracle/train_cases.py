@@ -136,7 +136,22 @@ def weighted_regression():
     return run
 
 
+def chiunet(model_dim: int, batch: int):
+    """ChiUNet1d with a global condition under the legacy DDPM class -- the dp_pusht training step, BASELINE config 3 (reference
+    pipelines/dp_pusht.py, nn_diffusion/chiunet.py:152-192, ddpm.py:80-112).  model_dim 32: GroupNorm groups of 4 / 8 / 16 channels;
+    model_dim 256: the exact config-3 net (68.9 M parameters, groups of 32 / 64 / 128 channels, K up to 10 240)."""
+    def run(lib, kind, device):
+        net = load_synth(lib.ChiUNet1d(2, 5, 2, model_dim=model_dim, emb_dim=model_dim, dim_mult=[1, 2, 2], obs_as_global_cond=True), 66)
+        agent = lib.DDPM(net, lib.IdentityCondition(dropout=0.0), diffusion_steps=20, predict_noise=True, grad_clip_norm=1.0, device=device)
+        g = torch.Generator().manual_seed(6)
+        return _record(agent, torch.randn(batch, 16, 2, generator=g).clamp(-1, 1), torch.randn(batch, 2, 5, generator=g), device)
+    return run
+
+
+HEAVY = {"chiunet_cfg3"}          # minutes of CPU work: fixture from the real reference, checked on the device only
+
 SCENARIOS: Dict[str, Callable] = {
+    "chiunet_ddpm": chiunet(32, 5), "chiunet_cfg3": chiunet(256, 4),
     "discrete_eps": discrete(True), "discrete_x0": discrete(False), "continuous_eps": continuous(),
     "edm_conditional": edm_conditional(0.1), "edm_conditional_nodrop": edm_conditional(0.0), "legacy_ddpm": legacy_ddpm(), "weighted_regression": weighted_regression(),
 }

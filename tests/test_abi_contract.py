@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported(lib):
                           "cdx_chiunet_workspace_floats", "cdx_groupnorm_f32", "cdx_groupnorm_bwd_f32", "cdx_hjgrad_run",
                           "cdx_hjgrad_workspace_floats", "cdx_guided_run", "cdx_guided_workspace_floats", "cdx_unet2_run",
                           "cdx_unet2_embtab", "cdx_optim_f32", "cdx_pearcetf_run", "cdx_pearcetf_workspace_floats", "cdx_act_bwd_f32", "cdx_linattn_f32",
-                          "cdx_conv_wgrad_f32", "cdx_colsum_f32"}
+                          "cdx_conv_wgrad_f32", "cdx_colsum_f32", "cdx_device_query"}
     for n in names:
         assert hasattr(lib, n), f"{n} declared in cdx.h but not exported by libcdx.so"
     assert lib.cdx_abi_version() == int(re.search(r"#define CDX_ABI_VERSION (\d+)", hdr).group(1))
@@ -52,7 +52,8 @@ def test_ctypes_mirrors_have_c_layout(tmp_path):
                "cdx_xattn_args": blocks.CdxXattnArgs, "cdx_gn_args": blocks.CdxGnArgs,
                "cdx_chiunet_block": bigbatch.CdxChiUNetBlock, "cdx_chiunet_weights": bigbatch.CdxChiUNetWeights,
                "cdx_unet_attn": bigbatch.CdxUnetAttn, "cdx_wgrad_args": blocks.CdxWgradArgs,
-               "cdx_gather_args": blocks.CdxGatherArgs, "cdx_gather_field": blocks.CdxGatherField}
+               "cdx_gather_args": blocks.CdxGatherArgs, "cdx_gather_field": blocks.CdxGatherField,
+               "cdx_device_props": runtime2.CdxDeviceProps}
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "cdx.h"', 'int main(void){']
     for cname, mirror in mirrors.items():
         src.append(f'printf("%zu\\n", sizeof({cname}));')
@@ -138,6 +139,12 @@ def test_unet2_validation_fails_loudly(lib):
     assert lib.cdx_unet2_run(ctypes.byref(M), None) == -1 and b"MLP program" in lib.cdx_last_error()
     M.mlp, M.traj_per_wg, M.logp_out = 0, 1, 8                                                      # log_p needs a program with a classifier head
     assert lib.cdx_unet2_run(ctypes.byref(M), None) == -1 and b"logp_out" in lib.cdx_last_error()
+    # ABI 14: the repair gate belongs to ORDINARY launches, the fault hook to split / grouped ones
+    M.logp_out, M.split_k, M.xchg_floats, M.run_if = None, 4, 1024, 8
+    assert lib.cdx_unet2_run(ctypes.byref(M), None) == -1 and b"run_if" in lib.cdx_last_error()
+    M.split_k, M.run_if, M.fault = 0, None, 2
+    assert lib.cdx_unet2_run(ctypes.byref(M), None) == -1 and b"fault" in lib.cdx_last_error()
+    assert lib.cdx_device_query(0, None, None, None) == -1 and b"cdx_device_query" in lib.cdx_last_error()
     L.batch = 0
     assert lib.cdx_unet2_run(ctypes.byref(L), None) == 0                                            # empty request: nothing to do
     assert lib.cdx_unet2_embtab(ctypes.byref(runtime2.CdxUnet2EmbtabArgs()), None) == -1

@@ -37,12 +37,13 @@ def main():
             for _ in range(20):
                 agent.sample(prior, **kw)
             k_ms = runtime.drain_launch_timing()
+            r_ms = runtime.drain_repair_timing()
             runtime.enable_launch_timing(False)
             runtime2.check_split_errors()
             kern = sum(k_ms) / 20
             frac = batch * bench.FLOPS_PER_TRAJ / (kern * 1e-3) / (bench.PEAK_FP32_MFMA_TFLOPS * 1e12)
             print(f"B={batch} {envs or 'default':40s} {batch / ms * 1e3:9.0f} traj/s  ms_per_call {ms:.3f}  kernel_ms {kern:.3f}  "
-                  f"fp32-MFMA frac {frac:.3f}  finite={bool(torch.isfinite(x).all())}  modes ok: split {runtime2._split_ok.get(dev)} group {runtime2._group_ok.get(dev)}", flush=True)
+                  f"fp32-MFMA frac {frac:.3f}  idle repair launch {1e3 * sum(r_ms) / max(len(r_ms), 1):.1f} us x{len(r_ms)}  finite={bool(torch.isfinite(x).all())}  modes ok: split {runtime2._split_ok.get(dev)} group {runtime2._group_ok.get(dev)}", flush=True)
         finally:
             for k, v in old.items():
                 if v is None:
