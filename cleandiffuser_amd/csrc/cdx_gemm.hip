@@ -1197,6 +1197,11 @@ __device__ __forceinline__ float gm_act_grad(float x, int act, float param) {
             return sg * (1.0f + x * (1.0f - sg));
         }
         case CDX_ACT_MISH: return gm_act(x, CDX_ACT_MISH_GRAD);
+        case CDX_ACT_GELU_TANH: {                        // y = x s, s = sigmoid(2u), u = c (x + 0.044715 x^3):  s + x s (1 - s) 2c (1 + 0.134145 x^2)
+            const float u2 = 1.5957691216057308f * (x + 0.044715f * x * x * x);
+            const float sg = 1.0f / (1.0f + __expf(-u2));
+            return sg + x * sg * (1.0f - sg) * 1.5957691216057308f * (1.0f + 0.134145f * x * x);
+        }
         case CDX_ACT_TANH: {
             const float t = gm_act(x / param, CDX_ACT_TANH);
             return 1.0f - t * t;
@@ -1512,7 +1517,7 @@ int cdx_cross_attention_f32(const cdx_xattn_args* a, void* hip_stream) {
 
 int cdx_act_bwd_f32(const float* pre, const float* g, float* out, long long n, int act, float param, void* hip_stream) {
     if (!pre || !g || !out || n < 0) { cdx_set_err("cdx_act_bwd_f32: bad argument"); return CDX_EINVAL; }
-    if (act == CDX_ACT_GELU_TANH || act == CDX_ACT_MISH_GRAD || act < 0 || act > CDX_ACT_TANH || !(param != 0.f)) {
+    if (act == CDX_ACT_MISH_GRAD || act < 0 || act > CDX_ACT_TANH || !(param != 0.f)) {
         cdx_set_err("cdx_act_bwd_f32: no derivative for this activation id / zero scale"); return CDX_EINVAL;
     }
     if (n == 0) return CDX_OK;

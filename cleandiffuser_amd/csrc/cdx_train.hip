@@ -153,9 +153,194 @@ __global__ __launch_bounds__(256) void cdx_gather_kernel(const cdx_gather_args g
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Backward of the row LayerNorm of cdx_layernorm_f32:  y = xhat * w + b,  w = gamma (affine; idqlmlp.py:14) or 1 + scale[m / rows_per_mod]
+// (adaLN modulate; dit.py:10-11) or 1.  One wave per row, x and dy in registers:
+//   g = dy * w,   dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),   dyxhat = dy * xhat  (optional: what the gain / scale gradient sums)
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void cdx_layernorm_bwd_kernel(const cdx_ln_bwd_args a) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.M) return;
+    const float* x = a.x + (size_t)row * a.ldx;
+    const float* dy = a.dy + (size_t)row * a.lddy;
+    float v[NT], g[NT];
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int c = lane + 64 * t;
+        v[t] = c < a.C ? x[c] : 0.f;
+        s += v[t];
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)a.C;
+    float s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float d = (lane + 64 * t < a.C) ? v[t] - mean : 0.f;
+        v[t] = d;
+        s2 += d * d;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+    const float rstd = 1.0f / sqrtf(s2 / (float)a.C + a.eps);
+    const int b = row / a.rows_per_mod;
+    float sg = 0.f, sgx = 0.f;
+    float* dyx = a.dyxhat ? a.dyxhat + (size_t)row * a.C : nullptr;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int c = lane + 64 * t;
+        g[t] = 0.f;
+        if (c < a.C) {
+            v[t] *= rstd;                                  // xhat
+            const float d = dy[c];
+            const float w = a.gamma ? a.gamma[c] : (a.scale ? 1.0f + a.scale[(size_t)b * a.ldmod + c] : 1.0f);
+            g[t] = d * w;
+            sg += g[t];
+            sgx += g[t] * v[t];
+            if (dyx) dyx[c] = d * v[t];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { sg += __shfl_xor(sg, o, 64); sgx += __shfl_xor(sgx, o, 64); }
+    const float mg = sg / (float)a.C, mgx = sgx / (float)a.C;
+    float* dx = a.dx + (size_t)row * a.lddx;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int c = lane + 64 * t;
+        if (c < a.C) dx[c] = rstd * (g[t] - mg - v[t] * mgx);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of the softmax(Q K^T scale) V core of nn.MultiheadAttention (dit.py:20, 34) for T <= 64 tokens: one workgroup per
+// (sample, head); P is recomputed from the packed qkv rows, nothing but qkv is saved by the forward.
+//   dV = P^T dO,  dP = dO V^T,  dS = P o (dP - rowsum(P o dP)) scale,  dQ = dS K,  dK = dS^T Q
+// Plain fp32 FMA loops over LDS tiles (a training-only kernel: 0.66 M MAC per (sample, head) at T = 64, head_dim = 32).
+// ------------------------------------------------------------------------------------------------
+#define AB_T 64
+#define AB_D 64
+__global__ __launch_bounds__(256) void cdx_attention_bwd_kernel(const cdx_attn_bwd_args a) {
+    extern __shared__ float ab_lds[];                      // 4 x T x (dh + 1) operand tiles, 2 x T x (T + 1) score tiles
+    const int tid = threadIdx.x;
+    const int bh = blockIdx.x, b = bh / a.n_heads, h = bh - b * a.n_heads;
+    const int T = a.T, dh = a.head_dim, dm = a.n_heads * dh;
+    const int ldd = dh + 1, ldt = T + 1;
+    float* Qs = ab_lds;
+    float* Ks = Qs + T * ldd;
+    float* Vs = Ks + T * ldd;
+    float* dOs = Vs + T * ldd;
+    float* Ps = dOs + T * ldd;
+    float* dPs = Ps + T * ldt;
+#define Q(i, d) Qs[(i) * ldd + (d)]
+#define K(i, d) Ks[(i) * ldd + (d)]
+#define V(i, d) Vs[(i) * ldd + (d)]
+#define dO(i, d) dOs[(i) * ldd + (d)]
+#define P(i, j) Ps[(i) * ldt + (j)]
+#define dP(i, j) dPs[(i) * ldt + (j)]
+    const float* qkv = a.qkv + (size_t)b * T * 3 * dm + h * dh;
+    const float* dout = a.dout + (size_t)b * T * dm + h * dh;
+    float* dqkv = a.dqkv + (size_t)b * T * 3 * dm + h * dh;
+    for (int e = tid; e < T * dh; e += 256) {
+        const int i = e / dh, d = e - i * dh;
+        Q(i, d) = qkv[(size_t)i * 3 * dm + d];
+        K(i, d) = qkv[(size_t)i * 3 * dm + dm + d];
+        V(i, d) = qkv[(size_t)i * 3 * dm + 2 * dm + d];
+        dO(i, d) = dout[(size_t)i * dm + d];
+    }
+    __syncthreads();
+    for (int e = tid; e < T * T; e += 256) {               // S and dP
+        const int i = e / T, j = e - i * T;
+        float sacc = 0.f, pacc = 0.f;
+        for (int d = 0; d < dh; ++d) { sacc = fmaf(Q(i, d), K(j, d), sacc); pacc = fmaf(dO(i, d), V(j, d), pacc); }
+        P(i, j) = sacc * a.scale;
+        dP(i, j) = pacc;
+    }
+    __syncthreads();
+    {                                                      // row softmax + delta: 4 lanes per row
+        const int i = tid >> 2, q = tid & 3;
+        if (i < T) {
+            float mx = -3.0e38f;
+            for (int j = q; j < T; j += 4) mx = fmaxf(mx, P(i, j));
+            mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+            float sum = 0.f;
+            for (int j = q; j < T; j += 4) { const float ex = __expf(P(i, j) - mx); P(i, j) = ex; sum += ex; }
+            sum += __shfl_xor(sum, 1, 64);
+            sum += __shfl_xor(sum, 2, 64);
+            const float inv = 1.0f / sum;
+            float dl = 0.f;
+            for (int j = q; j < T; j += 4) { const float p = P(i, j) * inv; P(i, j) = p; dl = fmaf(p, dP(i, j), dl); }
+            dl += __shfl_xor(dl, 1, 64);
+            dl += __shfl_xor(dl, 2, 64);
+            for (int j = q; j < T; j += 4) dP(i, j) = P(i, j) * (dP(i, j) - dl) * a.scale;     // dS
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < T * dh; e += 256) {
+        const int i = e / dh, d = e - i * dh;
+        float dq = 0.f, dk = 0.f, dv = 0.f;
+        for (int j = 0; j < T; ++j) {
+            dq = fmaf(dP(i, j), K(j, d), dq);              // dQ[i] = sum_j dS[i][j] K[j]
+            dk = fmaf(dP(j, i), Q(j, d), dk);              // dK[i] = sum_j dS[j][i] Q[j]
+            dv = fmaf(P(j, i), dO(j, d), dv);              // dV[i] = sum_j P(j, i) dO[j]
+        }
+        dqkv[(size_t)i * 3 * dm + d] = dq;
+        dqkv[(size_t)i * 3 * dm + dm + d] = dk;
+        dqkv[(size_t)i * 3 * dm + 2 * dm + d] = dv;
+    }
+#undef Q
+#undef K
+#undef V
+#undef dO
+#undef P
+#undef dP
+}
+
 }  // namespace
 
 extern "C" {
+
+int cdx_layernorm_bwd_f32(const cdx_ln_bwd_args* a, void* hip_stream) {
+    cdx_set_err("");
+    if (!a) { cdx_set_err("cdx_layernorm_bwd_f32: null argument block"); return CDX_EINVAL; }
+    if (a->M < 0 || a->C <= 0 || a->C > 4096) { cdx_set_err("cdx_layernorm_bwd_f32: 0 < C <= 4096 required"); return CDX_EINVAL; }
+    if (a->M == 0) return CDX_OK;
+    if (!a->x || !a->dy || !a->dx) { cdx_set_err("cdx_layernorm_bwd_f32: null pointer"); return CDX_EINVAL; }
+    if (a->gamma && a->scale) { cdx_set_err("cdx_layernorm_bwd_f32: gamma (affine) OR scale (modulate), not both"); return CDX_EINVAL; }
+    if (a->ldx < a->C || a->lddy < a->C || a->lddx < a->C || (a->scale && (a->rows_per_mod <= 0 || a->ldmod < a->C))) {
+        cdx_set_err("cdx_layernorm_bwd_f32: bad leading dimension / rows_per_mod"); return CDX_EINVAL;
+    }
+    cdx_ln_bwd_args b = *a;
+    if (b.rows_per_mod <= 0) b.rows_per_mod = 1;
+    auto kern = a->C <= 1024 ? cdx_layernorm_bwd_kernel<16> : (a->C <= 2048 ? cdx_layernorm_bwd_kernel<32> : cdx_layernorm_bwd_kernel<64>);
+    hipLaunchKernelGGL(kern, dim3((a->M + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), b);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
+    return CDX_OK;
+}
+
+int cdx_attention_bwd_f32(const cdx_attn_bwd_args* a, void* hip_stream) {
+    cdx_set_err("");
+    if (!a) { cdx_set_err("cdx_attention_bwd_f32: null argument block"); return CDX_EINVAL; }
+    if (a->B < 0 || a->T <= 0 || a->T > AB_T || a->head_dim <= 0 || a->head_dim > AB_D || a->n_heads <= 0) {
+        cdx_set_err("cdx_attention_bwd_f32: T <= 64 and head_dim <= 64 required"); return CDX_EINVAL;
+    }
+    if (a->B == 0) return CDX_OK;
+    if (!a->qkv || !a->dout || !a->dqkv) { cdx_set_err("cdx_attention_bwd_f32: null pointer"); return CDX_EINVAL; }
+    if ((long long)a->B * a->n_heads > 0x7fffffffLL) { cdx_set_err("cdx_attention_bwd_f32: batch too large for one launch"); return CDX_EINVAL; }
+    const size_t lds = (size_t)(4 * a->T * (a->head_dim + 1) + 2 * a->T * (a->T + 1)) * sizeof(float);      // <= 100 KB
+    static size_t lds_raised = 0;
+    if (lds > 48 * 1024 && lds > lds_raised &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(cdx_attention_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
+        lds_raised = lds;
+    hipLaunchKernelGGL(cdx_attention_bwd_kernel, dim3((unsigned)(a->B * a->n_heads)), dim3(256), lds, reinterpret_cast<hipStream_t>(hip_stream), *a);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
+    return CDX_OK;
+}
 
 int cdx_conv_wgrad_f32(const cdx_wgrad_args* a, void* hip_stream) {
     cdx_set_err("");

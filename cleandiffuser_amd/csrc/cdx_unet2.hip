@@ -880,7 +880,7 @@ __device__ __forceinline__ void split_exchange(XState& X, int grp_idx, int xg, i
     {
         const KArg* S0 = kernarg();
         asm volatile("" : "+s"(S0));
-        withhold = S0->fault != 0 && X.m == S0->fault - 1 && X.seq == S0->xseq0 + 1u;
+        withhold = S0->fault != 0 && X.m == S0->fault - 1;
     }
     // publish: this member's part, read back from the destination slot the epilogue just wrote (pad channels travel along)
     for (int i = tid; i < n_items; i += THREADS) {

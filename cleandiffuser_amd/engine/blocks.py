@@ -58,6 +58,17 @@ class CdxLnArgs(ctypes.Structure):
                 ("x_rows", ctypes.c_int32)]
 
 
+class CdxLnBwdArgs(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_void_p), ("dy", ctypes.c_void_p), ("dx", ctypes.c_void_p), ("dyxhat", ctypes.c_void_p),
+                ("gamma", ctypes.c_void_p), ("scale", ctypes.c_void_p)] + \
+               [(n, ctypes.c_int32) for n in ("M", "C", "ldx", "lddy", "lddx", "ldmod", "rows_per_mod")] + [("eps", ctypes.c_float)]
+
+
+class CdxAttnBwdArgs(ctypes.Structure):
+    _fields_ = [("qkv", ctypes.c_void_p), ("dout", ctypes.c_void_p), ("dqkv", ctypes.c_void_p), ("B", ctypes.c_int32), ("T", ctypes.c_int32),
+                ("n_heads", ctypes.c_int32), ("head_dim", ctypes.c_int32), ("scale", ctypes.c_float)]
+
+
 class CdxAttnArgs(ctypes.Structure):
     _fields_ = [("qkv", ctypes.c_void_p), ("out", ctypes.c_void_p), ("B", ctypes.c_int32), ("T", ctypes.c_int32),
                 ("n_heads", ctypes.c_int32), ("head_dim", ctypes.c_int32), ("scale", ctypes.c_float),
@@ -95,6 +106,10 @@ def _lib():
         lib.cdx_conv_wgrad_f32.restype = ctypes.c_int
         lib.cdx_colsum_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
         lib.cdx_colsum_f32.restype = ctypes.c_int
+        lib.cdx_layernorm_bwd_f32.argtypes = [ctypes.POINTER(CdxLnBwdArgs), ctypes.c_void_p]
+        lib.cdx_layernorm_bwd_f32.restype = ctypes.c_int
+        lib.cdx_attention_bwd_f32.argtypes = [ctypes.POINTER(CdxAttnBwdArgs), ctypes.c_void_p]
+        lib.cdx_attention_bwd_f32.restype = ctypes.c_int
         lib.cdx_gather_windows_f32.argtypes = [ctypes.POINTER(CdxGatherArgs), ctypes.c_void_p]
         lib.cdx_gather_windows_f32.restype = ctypes.c_int
         for f in (lib.cdx_gemm_f32, lib.cdx_layernorm_f32, lib.cdx_attention_f32, lib.cdx_act_f32):
@@ -279,6 +294,31 @@ def layernorm(x: torch.Tensor, out: Optional[torch.Tensor] = None, gamma=None, b
                   rows_per_mod=rows_per_mod, eps=eps)
     _check(_lib().cdx_layernorm_f32(ctypes.byref(a), _stream_ptr(x.device)), "cdx_layernorm_f32")
     return out
+
+
+def layernorm_backward(dy: torch.Tensor, x: torch.Tensor, gamma=None, scale=None, rows_per_mod: int = 1, eps: float = 1e-5,
+                       want_dyxhat: bool = False):
+    """Backward of ``layernorm``: dx, and (optionally) dy * xhat per element -- what the gain / scale gradient sums (cdx.h)."""
+    m, c = x.shape
+    assert dy.shape == x.shape and dy.dtype == x.dtype == torch.float32
+    dx = torch.empty((m, c), device=x.device, dtype=torch.float32)
+    dyx = torch.empty((m, c), device=x.device, dtype=torch.float32) if want_dyxhat else None
+    a = CdxLnBwdArgs(x=x.data_ptr(), dy=dy.data_ptr(), dx=dx.data_ptr(), dyxhat=_p(dyx), gamma=_p(gamma), scale=_p(scale), M=m, C=c,
+                     ldx=_rows(x), lddy=_rows(dy), lddx=c, ldmod=_rows(scale) if scale is not None else 0, rows_per_mod=rows_per_mod, eps=eps)
+    _check(_lib().cdx_layernorm_bwd_f32(ctypes.byref(a), _stream_ptr(x.device)), "cdx_layernorm_bwd_f32")
+    return (dx, dyx) if want_dyxhat else dx
+
+
+def attention_backward(qkv: torch.Tensor, dout: torch.Tensor, batch: int, tokens: int, n_heads: int) -> torch.Tensor:
+    """d qkv of ``attention`` without a mask (probabilities recomputed from qkv)."""
+    dm = qkv.shape[1] // 3
+    assert qkv.is_contiguous() and dout.is_contiguous() and qkv.shape[0] == batch * tokens and dout.shape == (batch * tokens, dm)
+    dqkv = torch.empty_like(qkv)
+    dh = dm // n_heads
+    a = CdxAttnBwdArgs(qkv=qkv.data_ptr(), dout=dout.data_ptr(), dqkv=dqkv.data_ptr(), B=batch, T=tokens, n_heads=n_heads, head_dim=dh,
+                       scale=float(dh) ** -0.5)
+    _check(_lib().cdx_attention_bwd_f32(ctypes.byref(a), _stream_ptr(qkv.device)), "cdx_attention_bwd_f32")
+    return dqkv
 
 
 def attention(qkv: torch.Tensor, batch: int, tokens: int, n_heads: int, out: Optional[torch.Tensor] = None,

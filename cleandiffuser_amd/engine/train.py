@@ -305,6 +305,159 @@ class _LinearMish(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class _LinearAct(torch.autograd.Function):
+    """y = act(x W^T + b), act in {None, "mish", "gelu_tanh", ...}: ``cdx_gemm_f32`` with the bias in its epilogue (+ ``cdx_act_f32``
+    when the pre-activation must be kept); backward as ``_LinearMish``."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        x = x.contiguous()
+        z = blocks.linear(x, weight, bias)
+        ctx.act = act
+        ctx.save_for_backward(x, weight, z if act else x.new_empty(0))
+        return blocks.activation(z, act) if act else z
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, z = ctx.saved_tensors
+        dz = dy.contiguous()
+        if ctx.act:
+            dz = blocks.activation_backward(z, dz, ctx.act)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = blocks.linear(dz, weight.detach().t().contiguous())
+        want_db = bias_needed = ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:
+            dw = blocks.conv_wgrad(dz, x, x.shape[0], 1, 1, 1, bias_grad=want_db)
+            if want_db:
+                dw, db = dw
+            dw = dw.view(weight.shape)
+        elif bias_needed:
+            db = blocks.colsum(dz)
+        return dx, dw, db, None
+
+
+class _LayerNormAffine(torch.autograd.Function):
+    """nn.LayerNorm with gain and shift on (rows, C): ``cdx_layernorm_f32`` / ``cdx_layernorm_bwd_f32`` (+ column sums)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = x.contiguous()
+        ctx.save_for_backward(x, gamma)
+        ctx.eps = eps
+        return blocks.layernorm(x, gamma=gamma, beta=beta, eps=eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx, dyx = blocks.layernorm_backward(dy, x, gamma=gamma.detach(), eps=ctx.eps, want_dyxhat=True)
+        return dx, blocks.colsum(dyx), blocks.colsum(dy), None
+
+
+class _LayerNormMod(torch.autograd.Function):
+    """adaLN: LayerNorm(x) (no affine) * (1 + scale[b]) + shift[b] over `tokens` rows per sample (reference dit.py:10-11,33-35,48).
+    scale / shift: (B, C) views of one modulation tensor (same row stride)."""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift, tokens, eps):
+        x = x.contiguous()
+        assert scale.stride(0) == shift.stride(0) and scale.stride(1) == shift.stride(1) == 1
+        ctx.save_for_backward(x, scale)
+        ctx.geom = (tokens, eps)
+        return blocks.layernorm(x, scale=scale, shift=shift, rows_per_mod=tokens, eps=eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, scale = ctx.saved_tensors
+        tokens, eps = ctx.geom
+        dy = dy.contiguous()
+        dx, dyx = blocks.layernorm_backward(dy, x, scale=scale.detach(), rows_per_mod=tokens, eps=eps, want_dyxhat=True)
+        b, c = x.shape[0] // tokens, x.shape[1]
+        return dx, dyx.view(b, tokens, c).sum(1), dy.view(b, tokens, c).sum(1), None, None
+
+
+class _Attention(torch.autograd.Function):
+    """softmax(q k^T / sqrt(dh)) v per (sample, head) on packed qkv rows: ``cdx_attention_f32`` / ``cdx_attention_bwd_f32``."""
+
+    @staticmethod
+    def forward(ctx, qkv, batch, tokens, n_heads):
+        qkv = qkv.contiguous()
+        ctx.save_for_backward(qkv)
+        ctx.geom = (batch, tokens, n_heads)
+        return blocks.attention(qkv, batch, tokens, n_heads)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (qkv,) = ctx.saved_tensors
+        return blocks.attention_backward(qkv, dout.contiguous(), *ctx.geom), None, None, None
+
+
+def supports_idql(net, x: torch.Tensor, condition=None) -> bool:
+    """IDQLMlp / NewIDQLMlp (BASELINE config 5's SynthER residual MLP) with autograd on, on a ROCm device."""
+    if not (enabled() and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2):
+        return False
+    if type(net).__name__ not in ("IDQLMlp", "NewIDQLMlp") or net.affine_in.out_features > 4096 or not _wants_grad(net, x, condition):
+        return False
+    return all(p.dtype == torch.float32 and p.is_cuda for p in net.parameters())
+
+
+def idql_forward(net, x, noise, condition):
+    """``IDQLMlp.forward`` (reference nn_diffusion/idqlmlp.py:9-49): x + Linear(Mish(Linear(LayerNorm(Dropout(x))))) blocks; every Linear
+    and LayerNorm a library node, nn.Dropout (an RNG draw) and the feature concat stay ATen."""
+    h = _LinearAct.apply(net._features(x, noise, condition), net.affine_in.weight, net.affine_in.bias, None)
+    for rb in net.ln_resnet:
+        drop, ln, l1, _, l2 = rb.net
+        z = _LayerNormAffine.apply(drop(h), ln.weight, ln.bias, ln.eps)
+        z = _LinearAct.apply(z, l1.weight, l1.bias, "mish")
+        h = h + _LinearAct.apply(z, l2.weight, l2.bias, None)
+    head = net.affine_out
+    if isinstance(head, nn.Sequential):                    # NewIDQLMlp: Mish before the output projection
+        h, head = head[0](h), head[1]
+    return _LinearAct.apply(h, head.weight, head.bias, None)
+
+
+def supports_dit(net, x: torch.Tensor, condition=None) -> bool:
+    """DiT1d (BASELINE config 4) with autograd on, on a ROCm device: <= 64 tokens, head_dim <= 64, no dropout inside the blocks."""
+    if not (enabled() and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and type(net).__name__ == "DiT1d"):
+        return False
+    blk = net.blocks[0] if len(net.blocks) else None
+    if blk is None or x.shape[1] > 64 or net.d_model // blk.attn.num_heads > 64 or net.d_model > 4096 or net.d_model % blk.attn.num_heads:
+        return False
+    if any((b.attn.dropout > 0 or b.mlp[2].p > 0) and net.training for b in net.blocks) or not _wants_grad(net, x, condition):
+        return False
+    return all(p.dtype == torch.float32 and p.is_cuda for p in net.parameters())
+
+
+def dit_forward(net, x, noise, condition):
+    """``DiT1d.forward`` (reference nn_diffusion/dit.py:10-50,108-130) with autograd: x_proj / qkv / out_proj / fc1(+GELU) / fc2 / head
+    GEMMs, LayerNorm + adaLN modulate and the attention core on library nodes, forward and backward; the (batch, d) embedding /
+    modulation Linears, the gates and the residual adds stay ATen.  The block keeps the reference's quirk: the residual
+    stream continues from the MODULATED LayerNorm output."""
+    b, tokens, d_in = x.shape
+    d = net.d_model
+    if net.pos_emb_cache is None or net.pos_emb_cache.shape[0] != tokens:
+        net.pos_emb_cache = net.pos_emb(torch.arange(tokens, device=x.device))
+    emb = net._embed(noise, condition)
+    h = _LinearAct.apply(x.reshape(b * tokens, d_in), net.x_proj.weight, net.x_proj.bias, None)
+    h = (h.view(b, tokens, d) + net.pos_emb_cache[None]).view(b * tokens, d)
+    for blk in net.blocks:
+        sh_a, sc_a, g_a, sh_m, sc_m, g_m = blk.adaLN_modulation(emb).chunk(6, dim=1)
+        att = blk.attn
+        h = _LayerNormMod.apply(h, sc_a, sh_a, tokens, blk.norm1.eps)
+        qkv = _LinearAct.apply(h, att.in_proj_weight, att.in_proj_bias, None)
+        o = _LinearAct.apply(_Attention.apply(qkv, b, tokens, att.num_heads), att.out_proj.weight, att.out_proj.bias, None)
+        h = (h.view(b, tokens, d) + g_a[:, None, :] * o.view(b, tokens, d)).view(b * tokens, d)
+        m = _LayerNormMod.apply(h, sc_m, sh_m, tokens, blk.norm2.eps)
+        f = _LinearAct.apply(m, blk.mlp[0].weight, blk.mlp[0].bias, "gelu_tanh")
+        f = _LinearAct.apply(f, blk.mlp[3].weight, blk.mlp[3].bias, None)
+        h = (h.view(b, tokens, d) + g_m[:, None, :] * f.view(b, tokens, d)).view(b * tokens, d)
+    fl = net.final_layer
+    shift, scale = fl.adaLN_modulation(emb).chunk(2, dim=1)
+    m = _LayerNormMod.apply(h, scale, shift, tokens, fl.norm_final.eps)
+    return _LinearAct.apply(m, fl.linear.weight, fl.linear.bias, None).view(b, tokens, d_in)
+
+
 def supports_mlp(net, x: torch.Tensor, condition=None) -> bool:
     """DQLMlp / DVInvMlp (Linear -> Mish trunks) with fp32 parameters on a ROCm device, called with autograd on -- what
     ``sample(..., requires_grad=True)`` of the Diffusion-QL policy update runs at every denoising step (reference

@@ -97,7 +97,9 @@ class DiT1d(BaseNNDiffusion):
     def forward(self, x: torch.Tensor, noise: torch.Tensor, condition: Optional[torch.Tensor] = None):
         """x (b, horizon, in_dim), noise (b,), condition (b, emb_dim)|None -> (b, horizon, in_dim)."""
         if type(self) is DiT1d:
-            from ..engine import dispatch
+            from ..engine import dispatch, train
+            if train.supports_dit(self, x, condition):    # autograd on, ROCm device (loss() / update()): engine/train.py:dit_forward
+                return train.dit_forward(self, x, noise, condition)
             y = dispatch.try_backbone_forward(self, x, noise, condition)     # GEMM/LN/attention launches on a ROCm device
             if y is not None:
                 return y

@@ -150,7 +150,9 @@ class IDQLMlp(_ObsConditionedMlp):
         return nn.Linear(hidden_dim, act_dim)
 
     def forward(self, x: torch.Tensor, noise: torch.Tensor, condition: Optional[torch.Tensor] = None):
-        from ..engine import dispatch
+        from ..engine import dispatch, train
+        if train.supports_idql(self, x, condition):   # autograd on, ROCm device (loss() / update()): Linear / LayerNorm nodes on the library
+            return train.idql_forward(self, x, noise, condition)
         y = dispatch.try_backbone_forward(self, x, noise, condition)         # cdx_resmlp_run on a ROCm device
         if y is not None:
             return y

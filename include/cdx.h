@@ -223,7 +223,7 @@ typedef struct cdx_unet2_launch {
      * trajectory of a workgroup = traj_first + group * split_k + member.  A workgroup that loses a
      * granule sets `xerr` AND stores NaN instead of its result (split programs likewise): a failed exchange never looks like a sample. */
     int32_t split_group;
-    /* TEST HOOK (ABI 14): fault = m + 1 makes member m of EVERY group withhold its granules in the first exchange of the launch -- a
+    /* TEST HOOK (ABI 14): fault = m + 1 makes member m of EVERY group withhold its granules in every exchange of the launch -- a
      * lost granule on purpose (tests/test_gpu_parity.py: sample() must never hand out NaN, the mode must switch itself off).  0: off. */
     int32_t fault;
 } cdx_unet2_launch;
@@ -320,6 +320,35 @@ typedef struct cdx_wgrad_args {
 int cdx_conv_wgrad_f32(const cdx_wgrad_args* args, void* hip_stream);
 /* out[c] += sum_r x[r][c] (rows x cols, row stride ld); `out` zeroed by the caller (bias gradients, GroupNorm parameter gradients). */
 int cdx_colsum_f32(const float* x, float* out, long long rows, int32_t cols, int32_t ld, void* hip_stream);
+
+/* Backward of cdx_layernorm_f32 (ABI 14; training, csrc/cdx_train.hip): y = xhat * w + b with w = gamma[c] (affine LayerNorm,
+ * reference nn_diffusion/idqlmlp.py:14), 1 + scale[m / rows_per_mod][c] (adaLN modulate, dit.py:10-11,33-35,48) or 1 (both NULL).
+ *   dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w
+ * `dyxhat` (M, C; optional): dy * xhat per element -- the caller sums it over rows for the gain gradient (cdx_colsum_f32) or over the
+ * rows of a sample for the scale gradient; the shift gradient is the same sum of dy.  C <= 4096. */
+typedef struct cdx_ln_bwd_args {
+    const float* x;        /* (M, ldx): the forward's input */
+    const float* dy;       /* (M, lddy) */
+    float* dx;             /* (M, lddx) */
+    float* dyxhat;         /* (M, C) or NULL */
+    const float* gamma;    /* (C) or NULL */
+    const float* scale;    /* (M / rows_per_mod, ldmod) or NULL */
+    int32_t M, C, ldx, lddy, lddx, ldmod, rows_per_mod;
+    float eps;
+} cdx_ln_bwd_args;
+int cdx_layernorm_bwd_f32(const cdx_ln_bwd_args* args, void* hip_stream);
+
+/* Backward of cdx_attention_f32 without a mask (ABI 14; training): qkv (B * T, 3 * n_heads * head_dim) as the forward read it,
+ * dout (B * T, n_heads * head_dim) -> dqkv (B * T, 3 * n_heads * head_dim); the probabilities are recomputed.  T <= 64, head_dim <= 64
+ * (the DiT1d configurations; reference nn_diffusion/dit.py:20,34). */
+typedef struct cdx_attn_bwd_args {
+    const float* qkv;
+    const float* dout;
+    float* dqkv;
+    int32_t B, T, n_heads, head_dim;
+    float scale;
+} cdx_attn_bwd_args;
+int cdx_attention_bwd_f32(const cdx_attn_bwd_args* args, void* hip_stream);
 
 /* Batch assembly from dataset buffers that live in HBM (third slice: the reference collates a batch on the host --
  * D4RLMuJoCoDataset.__getitem__, cleandiffuser/dataset/d4rl_mujoco_dataset.py:138-151, per item through a torch DataLoader with four

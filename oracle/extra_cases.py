@@ -298,9 +298,12 @@ def baseline_config(which: str, batch: int, variant: str = ""):
             prior = torch.zeros(B, 64, 29)
             prior[:, 0] = torch.randn(B, 29, generator=g)
             zs = [torch.randn(B, 64, 29, generator=g)]
+            ccfg = 0.3 * torch.ones(B, 1) + 0.1 * torch.randn(B, 1, generator=g)
+            if _ROWS is not None:                # (a same-box yardstick on a subset of the batch: trajectories are independent)
+                prior, zs, ccfg = prior[_ROWS], [z[_ROWS] for z in zs], ccfg[_ROWS]
+                B = prior.shape[0]
             x, _ = _sample(agent, kind, prior.to(device), zs, solver="ode_dpmsolver++_2M", n_samples=B, sample_steps=10,
-                           condition_cfg=(0.3 * torch.ones(B, 1) + 0.1 * torch.randn(B, 1, generator=g)).to(device), w_cfg=2.0,
-                           temperature=0.5)
+                           condition_cfg=ccfg.to(device), w_cfg=2.0, temperature=0.5)
         else:                       # cfg5: SynthER ResidualMLP = IDQLMlp 1024 x 6, 128-step EDM Euler
             D = 27 if variant == "d27" else 15
             net = load_synth(lib.IDQLMlp(0, D, emb_dim=128, hidden_dim=1024, n_blocks=6), 58)
@@ -516,13 +519,18 @@ def _sample_fp64(agent, lib_kind: str, prior, zs, **kw):
 _sample_fp32 = _sample
 
 
-def run(name: str, lib_kind: str, device="cpu", fp64: bool = False):
+_ROWS = None
+
+
+def run(name: str, lib_kind: str, device="cpu", fp64: bool = False, rows=None):
     """Outputs of scenario `name` as {key: tensor}; keys starting with '_' are live objects for the caller, not results.
-    `fp64`: the same scenario evaluated in float64 (CPU)."""
-    global _sample
+    `fp64`: the same scenario evaluated in float64 (CPU).  `rows` (config-4 scenarios): a slice of the batch -- the same draws, only
+    those trajectories sampled."""
+    global _sample, _ROWS
     torch.manual_seed(1234)
     _sample = _sample_fp64 if fp64 else _sample_fp32
+    _ROWS = rows
     try:
         return (SCENARIOS.get(name) or GPU_ONLY[name])(cases.lib_namespace(lib_kind), lib_kind, device)
     finally:
-        _sample = _sample_fp32
+        _sample, _ROWS = _sample_fp32, None

@@ -148,10 +148,25 @@ def chiunet(model_dim: int, batch: int):
     return run
 
 
-HEAVY = {"chiunet_cfg3"}          # minutes of CPU work: fixture from the real reference, checked on the device only
+def dit(d_model: int, heads: int, tokens: int, batch: int):
+    """DiT1d under ContinuousDiffusionSDE with an MLP condition and label dropout -- the Decision-Diffuser training step, BASELINE
+    config 4 (reference pipelines/dd_d4rl_*.py, nn_diffusion/dit.py:10-130, diffusionsde.py:94-141).  d 64: 4 heads x 16; d 320 / 10
+    heads / 64 tokens: the exact config-4 net."""
+    def run(lib, kind, device):
+        net = load_synth(lib.DiT1d(7, emb_dim=32, d_model=d_model, n_heads=heads, depth=2, timestep_emb_type="fourier"), 67)
+        cond = load_synth(lib.MLPCondition(1, 32, [32], torch.nn.SiLU(), dropout=0.25), 68)
+        fm = torch.zeros(tokens, 7)
+        fm[0] = 1.0
+        agent = lib.ContinuousDiffusionSDE(net, cond, fix_mask=fm, predict_noise=True, noise_schedule="linear", grad_clip_norm=1.0, device=device)
+        g = torch.Generator().manual_seed(7)
+        return _record(agent, torch.randn(batch, tokens, 7, generator=g), torch.rand(batch, 1, generator=g), device)
+    return run
+
+
+HEAVY = {"chiunet_cfg3", "dit_cfg4"}          # minutes of CPU work: fixture from the real reference, checked on the device only
 
 SCENARIOS: Dict[str, Callable] = {
-    "chiunet_ddpm": chiunet(32, 5), "chiunet_cfg3": chiunet(256, 4),
+    "chiunet_ddpm": chiunet(32, 5), "chiunet_cfg3": chiunet(256, 4), "dit_small": dit(64, 4, 16, 5), "dit_cfg4": dit(320, 10, 64, 4),
     "discrete_eps": discrete(True), "discrete_x0": discrete(False), "continuous_eps": continuous(),
     "edm_conditional": edm_conditional(0.1), "edm_conditional_nodrop": edm_conditional(0.0), "legacy_ddpm": legacy_ddpm(), "weighted_regression": weighted_regression(),
 }

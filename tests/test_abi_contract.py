@@ -30,7 +30,8 @@ def test_every_declared_symbol_is_exported(lib):
                           "cdx_chiunet_workspace_floats", "cdx_groupnorm_f32", "cdx_groupnorm_bwd_f32", "cdx_hjgrad_run",
                           "cdx_hjgrad_workspace_floats", "cdx_guided_run", "cdx_guided_workspace_floats", "cdx_unet2_run",
                           "cdx_unet2_embtab", "cdx_optim_f32", "cdx_pearcetf_run", "cdx_pearcetf_workspace_floats", "cdx_act_bwd_f32", "cdx_linattn_f32",
-                          "cdx_conv_wgrad_f32", "cdx_colsum_f32", "cdx_device_query"}
+                          "cdx_conv_wgrad_f32", "cdx_colsum_f32", "cdx_device_query", "cdx_layernorm_bwd_f32",
+                          "cdx_attention_bwd_f32"}
     for n in names:
         assert hasattr(lib, n), f"{n} declared in cdx.h but not exported by libcdx.so"
     assert lib.cdx_abi_version() == int(re.search(r"#define CDX_ABI_VERSION (\d+)", hdr).group(1))
@@ -53,7 +54,7 @@ def test_ctypes_mirrors_have_c_layout(tmp_path):
                "cdx_chiunet_block": bigbatch.CdxChiUNetBlock, "cdx_chiunet_weights": bigbatch.CdxChiUNetWeights,
                "cdx_unet_attn": bigbatch.CdxUnetAttn, "cdx_wgrad_args": blocks.CdxWgradArgs,
                "cdx_gather_args": blocks.CdxGatherArgs, "cdx_gather_field": blocks.CdxGatherField,
-               "cdx_device_props": runtime2.CdxDeviceProps}
+               "cdx_device_props": runtime2.CdxDeviceProps, "cdx_ln_bwd_args": blocks.CdxLnBwdArgs, "cdx_attn_bwd_args": blocks.CdxAttnBwdArgs}
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "cdx.h"', 'int main(void){']
     for cname, mirror in mirrors.items():
         src.append(f'printf("%zu\\n", sizeof({cname}));')
@@ -194,7 +195,13 @@ def test_newer_entries_validate_before_touching_the_device(lib):
     assert lib.cdx_act_f32(None, None, 4, 1, None) == bad
     assert lib.cdx_act_f32(8, 8, 0, 1, None) == 0                                                    # nothing to do is fine
     blocks._lib()
-    assert lib.cdx_act_bwd_f32(8, 8, 8, 4, 6, 1.0, None) == bad and b"no derivative" in lib.cdx_last_error()   # tanh-GELU: not carried
+    assert lib.cdx_act_bwd_f32(8, 8, 8, 4, 7, 1.0, None) == bad and b"no derivative" in lib.cdx_last_error()   # the Mish-derivative id has none
+    assert lib.cdx_layernorm_bwd_f32(ctypes.byref(blocks.CdxLnBwdArgs(M=4, C=8192, x=8, dy=8, dx=8)), None) == bad
+    assert lib.cdx_layernorm_bwd_f32(ctypes.byref(blocks.CdxLnBwdArgs(M=4, C=64, x=8, dy=8, dx=8, gamma=8, scale=8, ldx=64, lddy=64, lddx=64)), None) == bad
+    assert b"not both" in lib.cdx_last_error()
+    assert lib.cdx_layernorm_bwd_f32(ctypes.byref(blocks.CdxLnBwdArgs(M=0, C=64)), None) == 0
+    assert lib.cdx_attention_bwd_f32(ctypes.byref(blocks.CdxAttnBwdArgs(B=1, T=65, n_heads=1, head_dim=8, qkv=8, dout=8, dqkv=8)), None) == bad
+    assert lib.cdx_attention_bwd_f32(ctypes.byref(blocks.CdxAttnBwdArgs(B=0, T=8, n_heads=1, head_dim=8)), None) == 0
     assert lib.cdx_act_bwd_f32(8, 8, 8, 4, 8, 0.0, None) == bad and lib.cdx_act_bwd_f32(8, None, 8, 4, 4, 1.0, None) == bad
     assert lib.cdx_act_bwd_f32(8, 8, 8, 0, 4, 1.0, None) == 0
     # workspace sizes: host arithmetic, grows with the chunk, independent of the batch beyond the chunk

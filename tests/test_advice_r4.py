@@ -69,7 +69,7 @@ def test_a_slot_that_goes_from_none_to_a_tensor_enters_the_signature():
 
 
 def test_native_training_graph_is_not_taken_for_shapes_its_groupnorm_backward_cannot_serve(monkeypatch):
-    """train.supports(): GroupNorm groups of 6 / 12 channels (model_dim 48) or 128 channels have no library backward for the gain / shift
+    """train.supports(): GroupNorm groups of 6 / 12 channels (model_dim 48) or of more than 256 channels have no library backward for the gain / shift
     gradients -- such nets keep the ATen autograd path instead of raising inside loss.backward(); a frozen net on inputs that need no
     gradient is not a training forward at all.  (Device checks are stubbed: this is the host-side rule.)"""
     from cleandiffuser_amd.nn_diffusion import JannerUNet1d
@@ -85,8 +85,9 @@ def test_native_training_graph_is_not_taken_for_shapes_its_groupnorm_backward_ca
     assert train.supports(ok, FakeX())
     odd = JannerUNet1d(23, model_dim=48, emb_dim=32, dim_mult=[1, 2], timestep_emb_type="positional", attention=False, kernel_size=5)
     assert not train.supports(odd, FakeX())
-    wide = JannerUNet1d(23, model_dim=128, emb_dim=32, dim_mult=[1, 8], timestep_emb_type="positional", attention=False, kernel_size=5)
-    assert not train.supports(wide, FakeX())          # 1024 channels / 8 groups = 128 per group
+    # (round 5: groups of up to 256 channels have a library backward -- ChiUNet1d's 1024 / 2048-channel levels; 512 do not)
+    assert train._groupnorms_ok(torch.nn.Sequential(torch.nn.GroupNorm(8, 1024), torch.nn.GroupNorm(8, 2048)))
+    assert not train._groupnorms_ok(torch.nn.Sequential(torch.nn.GroupNorm(8, 4096)))
     ok.requires_grad_(False)
     assert not train.supports(ok, FakeX())            # frozen net, input without requires_grad: the fused forward's business
     FakeX.requires_grad = True
