@@ -307,7 +307,7 @@ def other_configs(device):
             how = ("forward / backward in the library's kernels (engine/train.py)" if native else
                    "forward / backward on PyTorch autograd (ATen / MIOpen kernels)")
             if graph:
-                how += ", captured once and replayed as ONE HIP graph per step (opt-in: CDX_TRAIN_GRAPH=1)"
+                how += ", captured once and replayed as ONE HIP graph per step (the default since round 5 where the capturability probe passes)"
             out.append({"name": tag, "workload": label, "value": 1.0 / dt, "unit": "update_steps/s", "ms_per_call": 1e3 * dt,
                         "what": how + "; gradient-norm clip + AdamW + EMA: cdx_optim_f32 (3 launches)"})
         except Exception as e:  # noqa: BLE001

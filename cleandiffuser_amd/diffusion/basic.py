@@ -69,6 +69,21 @@ class DiffusionModel:
         from ..utils.misc import ema_update
         ema_update(self.model, self.model_ema, self.ema_rate)
 
+    def _loss_backward(self, x0, condition=None, **kwargs):
+        """``loss = self.loss(...); loss.backward()`` of every ``update()`` (reference diffusionsde.py:125-131, ddpm.py:98-104,
+        newedm.py:178-184).  On a ROCm device, for the denoisers the native training path serves, the pair is ONE HIP-graph replay once
+        the first step passed the capturability probe (engine/train.py:GraphedStep; CDX_TRAIN_GRAPH=0 keeps the eager pair)."""
+        from ..engine import train
+        g = train.graphed_step(self, x0, condition, kwargs)
+        if g is None:
+            loss = self.loss(x0, condition, **kwargs)
+            loss.backward()
+            return loss
+        loss = g.replay(x0, condition)
+        if hasattr(self.optimizer, "_gver"):
+            self.optimizer._gver.clear()    # a replay writes the gradients without moving their version counters: they ARE written
+        return loss
+
     def _apply_gradients(self, update_ema: bool = True, zero_grad: bool = True):
         """What every ``update()`` does after ``loss.backward()`` (reference diffusionsde.py:132-139): clip the global gradient
         norm, AdamW step, zero the gradients, EMA.  -> the clipped-from norm (tensor) or None, as the reference logs it.

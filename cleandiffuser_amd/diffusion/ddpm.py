@@ -65,8 +65,7 @@ class DDPM(DiffusionModel):
         return (err * self.loss_weight * (1 - self.fix_mask)).mean()
 
     def update(self, x0, condition=None, update_ema=True, **kwargs):
-        loss = self.loss(x0, condition)
-        loss.backward()
+        loss = self._loss_backward(x0, condition)
         grad_norm = self._apply_gradients(update_ema)
         return {"loss": loss.item(), "grad_norm": grad_norm}
 

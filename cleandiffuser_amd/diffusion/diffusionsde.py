@@ -115,16 +115,7 @@ class BaseDiffusionSDE(DiffusionModel):
         return err.mean()
 
     def update(self, x0, condition=None, update_ema=True, **kwargs):
-        from ..engine import train
-        g = train.graphed_step(self, x0, condition, kwargs)     # (opt-in, CDX_TRAIN_GRAPH=1: forward + backward as one HIP graph)
-        if g is not None:
-            loss = g.replay(x0, condition)
-            opt = self.optimizer
-            if hasattr(opt, "_gver"):
-                opt._gver.clear()           # a replay writes the gradients without moving their version counters: they ARE written
-        else:
-            loss = self.loss(x0, condition, **kwargs)
-            loss.backward()
+        loss = self._loss_backward(x0, condition, **kwargs)
         grad_norm = self._apply_gradients(update_ema)
         return {"loss": loss.item(), "grad_norm": grad_norm}
 

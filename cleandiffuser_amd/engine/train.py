@@ -66,6 +66,23 @@ def _wants_grad(net, *tensors) -> bool:
     return any(p.requires_grad for p in net.parameters())
 
 
+def _splitk_scratch(rows: int, n: int, k: int, device) -> Optional[torch.Tensor]:
+    """Scratch for a deterministic split-K launch of ``cdx_gemm_f32`` (cdx.h: partial) when the product has too few output tiles to
+    fill the chip and a long K -- the training batches (256 rows x 1024..4096 columns over K = 1024..5120 for configs 3 / 5): without it
+    a 64 x 64 tile walks the whole K alone on a quarter of the CUs.  None: the launch would not split anyway.  CDX_TRAIN_SPLITK=0: off."""
+    if os.environ.get("CDX_TRAIN_SPLITK", "1") == "0":
+        return None
+    tiles_big = -(-rows // 128) * -(-n // 128)
+    slices = min(16, k // 256)
+    if tiles_big >= 192 or slices < 2 or rows * n * slices > (1 << 26):
+        return None
+    return torch.empty(slices * rows * n, device=device, dtype=torch.float32)
+
+
+def _linear(a, w, bias=None):
+    return blocks.linear(a, w, bias, partial=_splitk_scratch(a.shape[0], w.shape[0], w.shape[1], a.device))
+
+
 # --------------------------------------------------------------------------------------------------------------------- #
 class _Conv(torch.autograd.Function):
     """nn.Conv1d (stride 1 'same', or k = 3 / stride 2 / pad 1) on channel-last rows."""
@@ -73,7 +90,8 @@ class _Conv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, batch, l_in, stride, pad):
         x = x.contiguous()
-        y = blocks.conv1d(x, blocks.pack_conv(weight), bias, batch, l_in, stride, pad)
+        y = blocks.conv1d(x, blocks.pack_conv(weight), bias, batch, l_in, stride, pad,
+                          partial=_splitk_scratch(x.shape[0] // stride, weight.shape[0], weight.shape[1] * weight.shape[2], x.device))
         ctx.save_for_backward(x, weight)
         ctx.geom = (batch, l_in, stride, pad, bias is not None)
         return y
@@ -90,7 +108,8 @@ class _Conv(torch.autograd.Function):
             if stride == 1:
                 # dx[l] = sum_t W[:, :, t]^T dy[l + pad - t]: a conv of dy with the flipped, transposed kernel, left padding k - 1 - pad
                 wt = weight.detach().flip(2).permute(1, 2, 0).contiguous()                 # (c_in, k, c_out)
-                dx = blocks.conv1d(dy, wt, None, batch, l_out, 1, k - 1 - pad, l_out=l_in)
+                dx = blocks.conv1d(dy, wt, None, batch, l_out, 1, k - 1 - pad, l_out=l_in,
+                                   partial=_splitk_scratch(batch * l_in, c_in, c_out * k, dy.device))
             else:
                 assert (k, stride, pad) == (3, 2, 1) and l_in == 2 * l_out
                 # y[m] = sum_t W_t x[2m - 1 + t]:  dx[2j] = W_1^T dy[j];  dx[2j + 1] = W_2^T dy[j] + W_0^T dy[j + 1]
@@ -280,7 +299,7 @@ class _LinearMish(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, mish):
         x = x.contiguous()
-        z = blocks.linear(x, weight, bias)
+        z = _linear(x, weight, bias)
         ctx.mish = mish
         ctx.save_for_backward(x, weight, z if mish else x.new_empty(0))
         return blocks.activation(z, "mish") if mish else z
@@ -293,7 +312,7 @@ class _LinearMish(torch.autograd.Function):
             dz = blocks.activation_backward(z, dz, "mish")
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = blocks.linear(dz, weight.detach().t().contiguous())
+            dx = _linear(dz, weight.detach().t().contiguous())
         if ctx.needs_input_grad[1]:
             want_db = ctx.needs_input_grad[2]
             dw = blocks.conv_wgrad(dz, x, x.shape[0], 1, 1, 1, bias_grad=want_db)
@@ -312,7 +331,7 @@ class _LinearAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, act):
         x = x.contiguous()
-        z = blocks.linear(x, weight, bias)
+        z = _linear(x, weight, bias)
         ctx.act = act
         ctx.save_for_backward(x, weight, z if act else x.new_empty(0))
         return blocks.activation(z, act) if act else z
@@ -325,7 +344,7 @@ class _LinearAct(torch.autograd.Function):
             dz = blocks.activation_backward(z, dz, ctx.act)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = blocks.linear(dz, weight.detach().t().contiguous())
+            dx = _linear(dz, weight.detach().t().contiguous())
         want_db = bias_needed = ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             dw = blocks.conv_wgrad(dz, x, x.shape[0], 1, 1, 1, bias_grad=want_db)
@@ -497,37 +516,67 @@ def dql_forward(net, x: torch.Tensor, noise: torch.Tensor, condition: Optional[t
 
 
 # --------------------------------------------------------------------------------------------------------------------- #
-# forward + backward of update() as ONE HIP graph (opt-in: CDX_TRAIN_GRAPH=1)                                            #
+# forward + backward of update() as ONE HIP graph (the default where a probe finds the step capturable; CDX_TRAIN_GRAPH=0 / 1)       #
 # --------------------------------------------------------------------------------------------------------------------- #
 RECAPTURE_LIMIT = 3
+SHAPE_LIMIT = 4            # captured graphs per agent (one per batch shape / train-eval state); further shapes run eagerly
+
+
+class NotCapturable(RuntimeError):
+    pass
 
 
 class GraphedStep:
     """``loss = agent.loss(x0, condition); loss.backward()`` captured once into a HIP graph and replayed per step.
 
     update() of config 2 is ~600 autograd nodes: ~14 ms of Python / dispatcher time per step at ANY batch size against ~8 ms of kernel
-    time (profiles/r04_update_bench.txt) -- launch-bound, which is what HIP graphs are for.  Everything inside the captured region is
-    capturable by construction: the library's launches go to the current (capturing) stream and allocate nothing, torch's allocations
-    come from the graph's private pool, the timestep / noise draws of ``add_noise`` use the graph-safe device generator.  Static
-    buffers: the batch (copied in before each replay), the loss, the parameters' ``.grad`` tensors (allocated by the warm-up steps;
-    the captured backward ACCUMULATES into them in place -- the optimiser zeroes them in place after each step).
+    time (profiles/r04_update_bench.txt) -- launch-bound, which is what HIP graphs are for.  Everything the LIBRARY does inside the
+    captured region is capturable by construction: its launches go to the current (capturing) stream and allocate nothing, torch's
+    allocations come from the graph's private pool, the timestep / noise draws of ``add_noise`` use the graph-safe device generator.
+    What user code wrapped around ``loss()`` does is not ours to know, so the first warm-up step is a PROBE (`probe=True`): it runs
+    eagerly under ``torch.cuda.set_sync_debug_mode("error")`` -- anything that synchronises (a draw from the CPU generator moved to the
+    device, ``.item()``, a data-dependent shape) raises there, BEFORE any capture was attempted (a capture that fails midway leaves
+    torch's generator / allocator bookkeeping in the capturing state), and the agent keeps the eager path (``NotCapturable``).
+    Static buffers: the batch (copied in before each replay), the loss, the parameters' ``.grad`` tensors (allocated by the warm-up
+    steps; the captured backward ACCUMULATES into them in place -- the optimiser zeroes them in place after each step).
 
     Not captured: the optimiser step (its bias-correction scalars change per step and travel as kernel arguments), ``loss.item()``."""
 
-    def __init__(self, agent, x0: torch.Tensor, condition: Optional[torch.Tensor]):
+    def __init__(self, agent, x0: torch.Tensor, condition: Optional[torch.Tensor], probe: bool = False):
         dev = x0.device
         self.x0 = x0.detach().clone()
         self.cond = None if condition is None else condition.detach().clone()
         params = self.params = [p for p in agent.model.parameters() if p.requires_grad]
-        # the warm-up steps below draw timesteps / noise like any step: put the generator back afterwards, so that the FIRST replay
+        had_grad = [p.grad is not None for p in params]
+        # the warm-up steps below draw timesteps / noise like any step: put the generators back afterwards, so that the FIRST replay
         # consumes what the first eager step would have (a replay reads the generator's offset at replay time and advances it by what
         # the captured draws consume -- the same numbers an eager step draws from the same state)
-        rng = torch.cuda.get_rng_state(dev)
+        rng, rng_cpu = torch.cuda.get_rng_state(dev), torch.get_rng_state()
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            for _ in range(2):                         # warm-up: lazy initialisation, allocator, the .grad tensors
-                agent.loss(self.x0, self.cond).backward()
+        try:
+            with torch.cuda.stream(side):
+                for i in range(2):                     # warm-up: lazy initialisation, allocator, the .grad tensors
+                    if probe and i == 0:
+                        mode = torch.cuda.get_sync_debug_mode()
+                        torch.cuda.set_sync_debug_mode("error")
+                        try:
+                            agent.loss(self.x0, self.cond).backward()
+                        finally:
+                            torch.cuda.set_sync_debug_mode(mode)
+                    else:
+                        agent.loss(self.x0, self.cond).backward()
+        except Exception as e:  # noqa: BLE001 -- whatever the probe step tripped over: this agent's step is not ours to capture
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            for p, had in zip(params, had_grad):       # nothing of the probe is part of any step
+                if not had:
+                    p.grad = None
+                elif p.grad is not None:
+                    p.grad.zero_()
+            torch.cuda.set_rng_state(rng, dev)
+            torch.set_rng_state(rng_cpu)
+            raise NotCapturable(f"{type(e).__name__}: {e}") from e
         torch.cuda.current_stream(dev).wait_stream(side)
         for p in params:                               # the warm-up gradients are not part of any step
             if p.grad is not None:
@@ -540,6 +589,7 @@ class GraphedStep:
             if p.grad is not None:
                 p.grad.zero_()
         torch.cuda.set_rng_state(rng, dev)
+        torch.set_rng_state(rng_cpu)
         self.sig = self._signature()
 
     def _signature(self):
@@ -559,15 +609,24 @@ class GraphedStep:
         return self.loss
 
 
+def _native_training_net(net, x0, condition) -> bool:
+    with torch.enable_grad():
+        return (supports(net, x0, condition) or supports_chi(net, x0, condition) or supports_dit(net, x0, condition) or
+                supports_idql(net, x0, condition) or supports_mlp(net, x0, condition))
+
+
 def graphed_step(agent, x0, condition, kwargs) -> Optional[GraphedStep]:
-    """The cached GraphedStep of (agent, batch shape) when CDX_TRAIN_GRAPH=1 and the request is one the native training path serves
-    (JannerUNet1d on a ROCm device, no extra loss arguments); else None."""
-    if os.environ.get("CDX_TRAIN_GRAPH", "0") != "1" or kwargs or not x0.is_cuda:
+    """The cached GraphedStep of (agent, batch shape), or None (the eager path).  CDX_TRAIN_GRAPH: "auto" (default) -- agents whose
+    denoiser the native training path serves (JannerUNet1d, ChiUNet1d, DiT1d, IDQLMlp, DQLMlp / DVInvMlp on a ROCm device), no extra
+    loss arguments, and whose first step passes the capturability probe (GraphedStep); "1": no probe; "0": never."""
+    mode = os.environ.get("CDX_TRAIN_GRAPH", "auto")
+    if mode == "0" or kwargs or not x0.is_cuda or not torch.is_grad_enabled() or torch.cuda.is_current_stream_capturing():
+        return None
+    if agent.__dict__.get("_cdx_graph_off"):
         return None
     net = agent.model["diffusion"]
-    with torch.enable_grad():
-        if not supports(net, x0):
-            return None
+    if not _native_training_net(net, x0, condition):       # (the raw condition stands in for the encoded one: only its presence matters)
+        return None
     key = (tuple(x0.shape), None if condition is None else tuple(condition.shape), agent.model.training)
     cache = agent.__dict__.setdefault("_cdx_graphed", {})
     g = cache.get(key)
@@ -579,5 +638,12 @@ def graphed_step(agent, x0, condition, kwargs) -> Optional[GraphedStep]:
     if getattr(agent, "_cdx_recaptures", 0) > RECAPTURE_LIMIT:
         return None
     if g is None:
-        g = cache[key] = GraphedStep(agent, x0, condition)
+        if key not in cache and len(cache) >= SHAPE_LIMIT:
+            return None                                # (a loop over ever-changing batch shapes: capturing each would cost more than it saves)
+        try:
+            g = cache[key] = GraphedStep(agent, x0, condition, probe=(mode != "1"))
+        except NotCapturable as e:
+            agent.__dict__["_cdx_graph_off"] = str(e)  # (kept for diagnostics: why this agent steps eagerly)
+            cache.pop(key, None)
+            return None
     return g

@@ -1461,11 +1461,12 @@ def test_layernorm_and_attention_backward_kernels_match_autograd():
         torch.testing.assert_close(got, qkv.grad, rtol=2e-4, atol=2e-5)
 
 
-def test_chiunet_update_runs_without_aten_conv_or_groupnorm_kernels(amd_lib):
+def test_chiunet_update_runs_without_aten_conv_or_groupnorm_kernels(amd_lib, monkeypatch):
     """update() of the dp_pusht configuration (ChiUNet1d under the legacy DDPM class) dispatches no ATen / MIOpen convolution and no
-    group_norm kernel, forward or backward."""
+    group_norm kernel, forward or backward.  (Eager step: the profiler does not attribute the kernels of a HIP-graph replay by name.)"""
     from torch.profiler import profile, ProfilerActivity
     from cleandiffuser_amd.utils import load_synth
+    monkeypatch.setenv("CDX_TRAIN_GRAPH", "0")
     net = load_synth(amd_lib.ChiUNet1d(2, 5, 2, model_dim=64, emb_dim=64, dim_mult=[1, 2, 2], obs_as_global_cond=True), 7)
     agent = amd_lib.DDPM(net, amd_lib.IdentityCondition(dropout=0.0), diffusion_steps=20, predict_noise=True, grad_clip_norm=1.0, device=DEV)
     agent.train()
@@ -1598,6 +1599,79 @@ def test_graphed_update_equals_the_eager_native_update(amd_lib, monkeypatch):
     for (n, p), q in zip(list(a.model.named_parameters()) + list(a.model_ema.named_parameters()),
                          list(b.model.parameters()) + list(b.model_ema.parameters())):
         assert float((p.detach() - q.detach()).abs().max()) <= 2e-5 * max(1.0, float(q.detach().abs().max())), n
+
+
+@pytest.mark.parametrize("which", ["janner_sde", "chiunet_ddpm", "dit_continuous", "idql_edm_dropout"])
+def test_default_update_is_a_graph_replay_and_equals_the_eager_step(which, amd_lib, monkeypatch):
+    """Round 5: with NOTHING set, update() of every natively trained backbone -- under DiscreteDiffusionSDE,
+    the legacy DDPM class, ContinuousDiffusionSDE and ContinuousEDM -- passes the capturability probe on its first call and is one
+    HIP-graph replay + the optimiser launches from then on; five updates from the same seed land on the losses, gradient norms and
+    weights of an eager twin (CDX_TRAIN_GRAPH=0), label dropout and nn.Dropout draws included."""
+    from copy import deepcopy
+    from cleandiffuser_amd.utils import load_synth
+    g = torch.Generator().manual_seed(21)
+    if which == "janner_sde":
+        net = load_synth(amd_lib.JannerUNet1d(23, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2, 2], kernel_size=5), 7)
+        fm = torch.zeros(32, 23)
+        fm[0, :17] = 1.0
+        mk = lambda n: amd_lib.DiscreteDiffusionSDE(n, None, fix_mask=fm, diffusion_steps=20, predict_noise=False, grad_clip_norm=1.0, device=DEV)  # noqa: E731
+        data = [(torch.randn(48, 32, 23, generator=g).to(DEV), None) for _ in range(5)]
+    elif which == "chiunet_ddpm":
+        net = load_synth(amd_lib.ChiUNet1d(2, 5, 2, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2], obs_as_global_cond=True), 7)
+        mk = lambda n: amd_lib.DDPM(n, amd_lib.IdentityCondition(dropout=0.25), diffusion_steps=20, grad_clip_norm=1.0, device=DEV)  # noqa: E731
+        data = [(torch.randn(24, 16, 2, generator=g).clamp(-1, 1).to(DEV), torch.randn(24, 2, 5, generator=g).to(DEV)) for _ in range(5)]
+    elif which == "dit_continuous":
+        net = load_synth(amd_lib.DiT1d(7, emb_dim=32, d_model=64, n_heads=4, depth=2, timestep_emb_type="fourier"), 7)
+        cnd = load_synth(amd_lib.MLPCondition(1, 32, [32], torch.nn.SiLU(), dropout=0.25), 8)
+        mk = lambda n: amd_lib.ContinuousDiffusionSDE(n, deepcopy(cnd), predict_noise=True, noise_schedule="linear", grad_clip_norm=1.0, device=DEV)  # noqa: E731
+        data = [(torch.randn(12, 16, 7, generator=g).to(DEV), torch.rand(12, 1, generator=g).to(DEV)) for _ in range(5)]
+    else:
+        net = load_synth(amd_lib.IDQLMlp(11, 3, emb_dim=16, hidden_dim=64, n_blocks=2, dropout=0.1), 7)
+        mk = lambda n: amd_lib.ContinuousEDM(n, amd_lib.IdentityCondition(dropout=0.25), grad_clip_norm=0.5, device=DEV)  # noqa: E731
+        data = [(torch.randn(40, 3, generator=g).to(DEV), torch.randn(40, 11, generator=g).to(DEV)) for _ in range(5)]
+    a, b = mk(deepcopy(net)), mk(deepcopy(net))
+    logs = {}
+    for tag, agent in (("auto", a), ("0", b)):
+        if tag == "auto":
+            monkeypatch.delenv("CDX_TRAIN_GRAPH", raising=False)
+        else:
+            monkeypatch.setenv("CDX_TRAIN_GRAPH", tag)
+        agent.train()
+        torch.manual_seed(77)
+        logs[tag] = [agent.update(x, c) if c is not None else agent.update(x) for x, c in data]
+    assert a.__dict__.get("_cdx_graph_off") is None and len(a.__dict__.get("_cdx_graphed", {})) == 1, a.__dict__.get("_cdx_graph_off")
+    assert not b.__dict__.get("_cdx_graphed")
+    for u, v in zip(logs["auto"], logs["0"]):
+        assert abs(u["loss"] - v["loss"]) <= 1e-5 * max(1.0, abs(v["loss"])), (u, v)
+        assert abs(float(u["grad_norm"]) - float(v["grad_norm"])) <= 1e-4 * float(v["grad_norm"])
+    for (n, p), q in zip(list(a.model.named_parameters()) + list(a.model_ema.named_parameters()),
+                         list(b.model.parameters()) + list(b.model_ema.parameters())):
+        assert float((p.detach() - q.detach()).abs().max()) <= 2e-5 * max(1.0, float(q.detach().abs().max())), n
+
+
+def test_update_that_cannot_be_captured_keeps_the_eager_path(amd_lib, monkeypatch):
+    """The capturability probe: an agent whose loss() synchronises (here: the suite's own shim that draws from the CPU generator and moves
+    the draws to the device) is found out on its first update() -- BEFORE any capture is attempted --, keeps the eager path for good,
+    says why, and its draws / gradients are what they would have been without the probe (same losses as with CDX_TRAIN_GRAPH=0)."""
+    from copy import deepcopy
+    from oracle.train_cases import cpu_rng
+    from cleandiffuser_amd.utils import load_synth
+    net = load_synth(amd_lib.JannerUNet1d(6, model_dim=16, emb_dim=16, dim_mult=[1, 2], kernel_size=5), 61)
+    mk = lambda n: amd_lib.DiscreteDiffusionSDE(n, None, diffusion_steps=50, grad_clip_norm=1.0, device=DEV)  # noqa: E731
+    a, b = mk(deepcopy(net)), mk(deepcopy(net))
+    x0 = torch.randn(5, 8, 6, generator=torch.Generator().manual_seed(1)).to(DEV)
+    out = {}
+    for tag, agent in (("auto", a), ("0", b)):
+        if tag == "auto":
+            monkeypatch.delenv("CDX_TRAIN_GRAPH", raising=False)
+        else:
+            monkeypatch.setenv("CDX_TRAIN_GRAPH", tag)
+        with cpu_rng(DEV):
+            torch.manual_seed(4321)
+            out[tag] = [agent.update(x0)["loss"] for _ in range(3)]
+    assert isinstance(a.__dict__.get("_cdx_graph_off"), str) and not a.__dict__.get("_cdx_graphed"), a.__dict__.get("_cdx_graph_off")
+    assert torch.cuda.get_sync_debug_mode() == 0
+    assert out["auto"] == out["0"], out
 
 
 def test_graphed_update_draws_what_the_eager_update_draws_and_survives_dropped_gradients(amd_lib, monkeypatch):

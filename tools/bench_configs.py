@@ -150,7 +150,7 @@ def cfgU(B=256, native_backward=None, graph=False):
     x0 = torch.randn(B, H, D, device=DEV)
     if native_backward is not None:
         os.environ["CDX_TRAIN_NATIVE"] = "1" if native_backward else "0"
-    os.environ["CDX_TRAIN_GRAPH"] = "1" if graph else "0"
+    os.environ["CDX_TRAIN_GRAPH"] = "auto" if graph else "0"
     call = lambda: torch.as_tensor(agent.update(x0)["loss"])  # noqa: E731
     return f"config 2 update(): JannerUNet1d H=32 D=23, batch {B}, loss + backward + clip + AdamW + EMA", call, B
 
