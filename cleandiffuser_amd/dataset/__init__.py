@@ -1,3 +1,7 @@
-"""Training-data side of the pipelines: the loader helpers and the D4RL-MuJoCo datasets with HBM-resident buffers."""
+"""Training-data side of the pipelines: the loader helpers and the D4RL datasets with HBM-resident buffers: the
+MuJoCo sequence / transition classes (d4rl_mujoco_dataset.py) and, round 5, their siblings over the same padded-episode store
+(episode_store.py): multi-horizon / Decision-Veteran MuJoCo sequences, kitchen and antmaze sequences and transitions."""
 from .base_dataset import BaseDataset  # noqa: F401
 from .d4rl_mujoco_dataset import D4RLMuJoCoDataset, D4RLMuJoCoTDDataset, ResidentLoader  # noqa: F401
+from .episode_store import (D4RLAntmazeDataset, D4RLAntmazeTDDataset, D4RLKitchenDataset, D4RLKitchenTDDataset,  # noqa: F401
+                            DV_D4RLKitchenSeqDataset, DV_D4RLMuJoCoSeqDataset, EpisodeStore, MultiHorizonD4RLMuJoCoDataset)

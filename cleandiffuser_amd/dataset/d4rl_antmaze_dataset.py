@@ -1,0 +1,2 @@
+"""Import-path alias of the reference module cleandiffuser/dataset/d4rl_antmaze_dataset.py: the classes live in episode_store.py."""
+from .episode_store import D4RLAntmazeDataset, D4RLAntmazeTDDataset  # noqa: F401

@@ -13,8 +13,9 @@ an epoch's permutation is drawn on the device, and every batch is ONE launch of 
 copies each item's window -- `horizon` consecutive rows, one contiguous segment -- for all fields at once.  The loader yields the
 dictionary a collated reference batch has, already on the device, so a pipeline's ``batch["act"].to(device)`` is a no-op.
 
-The datasets that need simulators or zarr stores to exist at all (kitchen, robomimic, push-T) stay out of
-scope; ``MultiHorizonD4RLMuJoCoDataset`` (DiffuserLite) is not rebuilt.
+The siblings over the same structure -- multi-horizon / Decision-Veteran MuJoCo sequences, the D4RL kitchen and antmaze classes -- live in
+``episode_store.py`` (round 5).  The datasets that need simulators or zarr stores to exist at all (robomimic, push-T, the relay-kitchen
+demos) stay out of scope.
 """
 from typing import Dict, Optional
 

@@ -1,0 +1,388 @@
+"""Padded-episode stores behind the sequence datasets of the D4RL family, resident in HBM (third slice; round 5).
+
+Every sequence dataset of the reference's D4RL files -- ``d4rl_mujoco_dataset.py`` (MultiHorizon / DV variants, :232-470),
+``d4rl_kitchen_dataset.py``, ``d4rl_antmaze_dataset.py`` -- is the same object: per episode one row of `T` steps of (normalised observation,
+action, reward, discounted return), an item table (episode, first step, one-past-last step), and ``__getitem__`` = a window of that row,
+possibly strided.  They differ in where an episode ends, how the row behind its last step is padded and how the return is scaled.
+``EpisodeStore`` is that object: `seq_obs / seq_act / seq_rew / seq_val` (n_paths, T, .), `indices` (n_items, 3), `stride`;
+the subclasses only fill the arrays (with the reference's numpy expressions step for step, so every float is the reference's -- the
+fixtures tests/golden/dataset_*.npz come from the imported reference classes), and inherit
+
+* the ``torch.utils.data.Dataset`` side (``len`` / ``__getitem__`` / ``get_normalizer``), and
+* ``loader(batch_size, shuffle, drop_last, device)``: the arrays are uploaded ONCE, an epoch's permutation is drawn on the device and
+  a batch is ONE ``cdx_gather_windows_f32`` launch (a strided window: the contiguous span is gathered and every stride-th row kept).
+"""
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import torch
+
+from ..utils.normalizers import GaussianNormalizer
+from .base_dataset import BaseDataset
+from .d4rl_mujoco_dataset import ResidentLoader, _ResidentMixin
+
+
+def episode_ends(timeouts, terminals, close_tail: bool) -> np.ndarray:
+    """Index of the last step of every episode: a terminal or a timeout (and, `close_tail`, the last step of the data)."""
+    done = np.logical_or(np.asarray(timeouts).astype(bool), np.asarray(terminals).astype(bool))
+    if close_tail and done.shape[0]:
+        done = done.copy()
+        done[-1] = True
+    return np.flatnonzero(done)
+
+
+def discounted_returns(seq_rew: np.ndarray, discount: float, steps: Optional[int] = None) -> np.ndarray:
+    """val[:, t] = rew[:, t] + discount * val[:, t + 1] from the last of the first `steps` columns backwards, the float32 recursion of
+    the reference (e.g. d4rl_kitchen_dataset.py:108-110); columns past `steps` keep their reward."""
+    val = np.copy(seq_rew)
+    steps = val.shape[1] if steps is None else steps
+    for t in range(steps - 2, -1, -1):
+        val[:, t] = seq_rew[:, t] + discount * val[:, t + 1]
+    return val
+
+
+def window_items(lengths: Sequence[int], last_start: Sequence[int], span: int) -> np.ndarray:
+    """(episode, start, start + span) for start = 0 .. last_start[episode] (none when negative), episodes in order."""
+    n_items = np.maximum(np.asarray(last_start, dtype=np.int64) + 1, 0)
+    path = np.repeat(np.arange(len(lengths)), n_items)
+    start = np.arange(int(n_items.sum())) - np.repeat(np.cumsum(n_items) - n_items, n_items)
+    return np.stack([path, start, start + span], axis=1).astype(np.int64) if n_items.sum() else np.zeros((0, 3), dtype=np.int64)
+
+
+class EpisodeStore(_ResidentMixin, BaseDataset):
+    """See the module docstring.  Subclasses set: normalizers, o_dim, a_dim, horizon, stride (default 1), seq_obs, seq_act, seq_rew,
+    seq_val, indices, path_lengths."""
+    stride = 1
+
+    def get_normalizer(self):
+        return self.normalizers["state"]
+
+    def __len__(self):
+        return self.indices.shape[0]
+
+    def __getitem__(self, idx: int):
+        path, start, end = self.indices[idx]
+        s = self.stride
+        return {"obs": {"state": torch.tensor(self.seq_obs[path, start:end:s])}, "act": torch.tensor(self.seq_act[path, start:end:s]),
+                "rew": torch.tensor(self.seq_rew[path, start:end:s]), "val": torch.tensor(self.seq_val[path, start])}
+
+    # ---- resident side ----
+    def _host_fields(self):
+        n_paths, T = self.seq_obs.shape[:2]
+        rows = n_paths * T
+        span = (self.horizon - 1) * self.stride + 1
+        fields = {"obs": (self.seq_obs.reshape(rows, self.o_dim), span, True), "act": (self.seq_act.reshape(rows, self.a_dim), span, True),
+                  "rew": (self.seq_rew.reshape(rows, 1), span, True), "val": (self.seq_val.reshape(rows, 1), 1, False)}
+        row0 = self.indices[:, 0] * T + self.indices[:, 1]
+        if row0.size and int((self.indices[:, 1] + span).max()) > T:
+            raise ValueError("a window leaves its episode row")
+        if rows >= 2 ** 31:
+            raise ValueError("more than 2^31 rows: row indices are int32")
+        return fields, row0, rows
+
+    def _assemble(self, f):
+        s = self.stride
+        cut = (lambda t: t[:, ::s].contiguous()) if s > 1 else (lambda t: t)
+        return {"obs": {"state": cut(f["obs"])}, "act": cut(f["act"]), "rew": cut(f["rew"]), "val": f["val"]}
+
+
+def _float_fields(dataset):
+    return (dataset["observations"].astype(np.float32), dataset["actions"].astype(np.float32), dataset["rewards"].astype(np.float32))
+
+
+class _RepeatPadded(EpisodeStore):
+    """Kitchen-style rows (reference d4rl_kitchen_dataset.py:63-111): behind an episode's last step the row repeats its last
+    observation and reward with zero actions; the return runs over the whole padded row."""
+
+    def _fill(self, dataset, row_len: int, discount: float, return_steps: Optional[int] = None):
+        observations, actions, rewards = _float_fields(dataset)
+        self.normalizers = {"state": GaussianNormalizer(observations)}
+        nobs = self.normalizers["state"].normalize(observations)
+        self.o_dim, self.a_dim = observations.shape[-1], actions.shape[-1]
+        ends = episode_ends(dataset["timeouts"], dataset["terminals"], close_tail=True)
+        starts = np.concatenate([[0], ends[:-1] + 1]).astype(np.int64) if ends.size else np.zeros(0, dtype=np.int64)
+        lengths = ends - starts + 1
+        n = ends.shape[0]
+        self.seq_obs = np.zeros((n, row_len, self.o_dim), dtype=np.float32)
+        self.seq_act = np.zeros((n, row_len, self.a_dim), dtype=np.float32)
+        self.seq_rew = np.zeros((n, row_len, 1), dtype=np.float32)
+        for p, (s, e, ln) in enumerate(zip(starts, ends, lengths)):
+            if ln > row_len:
+                raise ValueError(f"an episode of {int(ln)} steps does not fit a row of {row_len}")
+            self.seq_obs[p, :ln], self.seq_act[p, :ln], self.seq_rew[p, :ln, 0] = nobs[s:e + 1], actions[s:e + 1], rewards[s:e + 1]
+            self.seq_obs[p, ln:], self.seq_rew[p, ln:] = nobs[e], rewards[e]
+        self.seq_val = discounted_returns(self.seq_rew, discount, return_steps)
+        self.path_lengths = [int(v) for v in lengths]
+        early = np.logical_and(np.asarray(dataset["terminals"]).astype(bool)[ends], np.logical_not(np.asarray(dataset["timeouts"]).astype(bool)[ends]))
+        self.tml_and_not_timeout = np.stack([np.flatnonzero(early), lengths[early] - 1], axis=1).astype(np.int64) if early.any() \
+            else np.array([], dtype=np.int64)
+        return lengths
+
+
+class D4RLKitchenDataset(_RepeatPadded):
+    """Sequences of `horizon` steps with obs-repeat / act-zero / reward-repeat padding (reference d4rl_kitchen_dataset.py:10-135)."""
+
+    def __init__(self, dataset: Dict[str, np.ndarray], horizon: int = 1, max_path_length: int = 280, discount: float = 0.99):
+        super().__init__()
+        self.horizon = horizon
+        lengths = self._fill(dataset, max_path_length, discount)
+        self.indices = window_items(lengths, np.minimum(lengths - 1, max_path_length - horizon), horizon)
+        self.max_path_length = max_path_length
+
+
+class DV_D4RLKitchenSeqDataset(_RepeatPadded):
+    """Decision-Veteran's kitchen sequences (reference d4rl_kitchen_dataset.py:322-434): rows long enough for a strided window from
+    every real step, the return rescaled to [0, 1] (`center_mapping`: [-1, 1])."""
+
+    def __init__(self, dataset: Dict[str, np.ndarray], horizon: int = 1, max_path_length: int = 280, discount: float = 0.99,
+                 center_mapping: bool = True, stride: int = 1):
+        super().__init__()
+        self.horizon, self.stride = horizon, stride
+        span = (horizon - 1) * stride + 1
+        lengths = self._fill(dataset, max_path_length + span - 1, discount, return_steps=max_path_length)
+        if lengths.size and lengths.max() > max_path_length:
+            raise AssertionError("an episode longer than max_path_length")
+        self.indices = window_items(lengths, lengths - 1, span)
+        self.seq_val = (self.seq_val - self.seq_val.min()) / (self.seq_val.max() - self.seq_val.min())
+        if center_mapping:
+            self.seq_val = self.seq_val * 2 - 1
+        self.max_path_length = max_path_length
+
+
+class D4RLAntmazeDataset(EpisodeStore):
+    """Antmaze sequences (reference d4rl_antmaze_dataset.py:10-139): reward - 1 per step; an episode runs up to the step BEFORE the
+    one where the done flag drops again (or that follows a timeout); a short row is padded with the observation of that next step,
+    zero actions and zero rewards, a full row is an episode that never reached the goal: its last reward is `noreaching_penalty`.
+    The data after the last such boundary is dropped, like the reference does."""
+
+    def __init__(self, dataset: Dict[str, np.ndarray], horizon: int = 1, max_path_length: int = 1001, noreaching_penalty: float = -100.,
+                 discount: float = 0.99):
+        super().__init__()
+        observations, actions, rewards = _float_fields(dataset)
+        rewards -= 1
+        timeouts, terminals = np.asarray(dataset["timeouts"]).astype(bool), np.asarray(dataset["terminals"]).astype(bool)
+        dones = np.logical_or(timeouts, terminals)
+        self.normalizers = {"state": GaussianNormalizer(observations)}
+        nobs = self.normalizers["state"].normalize(observations)
+        self.horizon = horizon
+        self.o_dim, self.a_dim = observations.shape[-1], actions.shape[-1]
+        cut = np.zeros(dones.shape[0], dtype=bool)                        # cut[i]: a new episode starts at step i
+        cut[1:] = np.logical_or(np.logical_and(dones[:-1], np.logical_not(dones[1:])), timeouts[:-1])
+        bounds = np.flatnonzero(cut)
+        starts = np.concatenate([[0], bounds[:-1]]).astype(np.int64) if bounds.size else np.zeros(0, dtype=np.int64)
+        lengths = bounds - starts
+        n = bounds.shape[0]
+        if n and lengths.max() > max_path_length:
+            raise ValueError(f"path_length: {int(lengths.max())} > max_path_length: {max_path_length}")
+        self.seq_obs = np.zeros((n, max_path_length, self.o_dim), dtype=np.float32)
+        self.seq_act = np.zeros((n, max_path_length, self.a_dim), dtype=np.float32)
+        self.seq_rew = np.zeros((n, max_path_length, 1), dtype=np.float32)
+        for p, (s, b, ln) in enumerate(zip(starts, bounds, lengths)):
+            self.seq_obs[p, :ln], self.seq_act[p, :ln], self.seq_rew[p, :ln, 0] = nobs[s:b], actions[s:b], rewards[s:b]
+            if ln < max_path_length:
+                self.seq_obs[p, ln:] = nobs[b]
+            else:
+                self.seq_rew[p, -1] = noreaching_penalty
+        self.seq_val = discounted_returns(self.seq_rew, discount)
+        self.path_lengths = [int(v) for v in lengths]
+        early = np.logical_and(terminals[bounds], np.logical_not(timeouts[bounds])) if n else np.zeros(0, dtype=bool)
+        self.tml_and_not_timeout = np.stack([np.flatnonzero(early), lengths[early]], axis=1).astype(np.int64) if early.any() \
+            else np.array([], dtype=np.int64)
+        self.indices = window_items(lengths, np.minimum(lengths - 1, max_path_length - horizon), horizon)
+        self.max_path_length = max_path_length
+
+
+class DV_D4RLMuJoCoSeqDataset(EpisodeStore):
+    """Decision-Veteran's MuJoCo sequences (reference d4rl_mujoco_dataset.py:322-470): episodes end at a terminal, a timeout or the
+    last step of the data; a terminal step's reward is `terminal_penalty`, the last step of an episode that fills the row gets
+    `full_traj_bonus`; zero padding, one spare all-zero row; strided windows that stay inside the episode; the return rescaled to
+    [0, 1] (`center_mapping`: [-1, 1])."""
+
+    def __init__(self, dataset: Dict[str, np.ndarray], terminal_penalty: float = -100, horizon: int = 1, max_path_length: int = 1000,
+                 discount: float = 0.99, center_mapping: bool = True, stride: int = 1, full_traj_bonus: float = 100):
+        super().__init__()
+        observations, actions, rewards = _float_fields(dataset)
+        timeouts, terminals = np.asarray(dataset["timeouts"]).astype(bool), np.asarray(dataset["terminals"]).astype(bool)
+        self.stride, self.horizon = stride, horizon
+        self.normalizers = {"state": GaussianNormalizer(observations)}
+        nobs = self.normalizers["state"].normalize(observations)
+        self.o_dim, self.a_dim = observations.shape[-1], actions.shape[-1]
+        n_paths = int(np.sum(np.logical_or(terminals, timeouts)))
+        ends = episode_ends(timeouts, terminals, close_tail=True)
+        starts = np.concatenate([[0], ends[:-1] + 1]).astype(np.int64) if ends.size else np.zeros(0, dtype=np.int64)
+        lengths = ends - starts + 1
+        if lengths.size and lengths.max() > max_path_length:
+            raise AssertionError(f"current path length {int(lengths.max())}")
+        if terminal_penalty is not None:
+            rewards[ends[terminals[ends]]] = terminal_penalty
+        if full_traj_bonus is not None:
+            full = ends[lengths == max_path_length]
+            rewards[full] = rewards[full] + full_traj_bonus
+        self.seq_obs = np.zeros((n_paths + 1, max_path_length, self.o_dim), dtype=np.float32)
+        self.seq_act = np.zeros((n_paths + 1, max_path_length, self.a_dim), dtype=np.float32)
+        self.seq_rew = np.zeros((n_paths + 1, max_path_length, 1), dtype=np.float32)
+        if ends.shape[0] > n_paths + 1:
+            raise IndexError("more episodes than rows")                   # (cannot happen: at most one unfinished tail)
+        for p, (s, e, ln) in enumerate(zip(starts, ends, lengths)):
+            self.seq_obs[p, :ln], self.seq_act[p, :ln], self.seq_rew[p, :ln, 0] = nobs[s:e + 1], actions[s:e + 1], rewards[s:e + 1]
+        span = (horizon - 1) * stride + 1
+        self.indices = window_items(lengths, lengths - span, span)
+        val = np.zeros_like(self.seq_rew)
+        val[:, -1] = self.seq_rew[:, -1]
+        for t in range(max_path_length - 2, -1, -1):
+            val[:, t] = self.seq_rew[:, t] + discount * val[:, t + 1]
+        val = (val - val.min()) / (val.max() - val.min())
+        self.seq_val = val * 2 - 1 if center_mapping else val
+        self.path_lengths = [int(v) for v in lengths]
+        self.max_path_length = max_path_length
+
+
+class MultiHorizonLoader:
+    """``DataLoader`` stand-in of the multi-horizon datasets: per batch one gather launch PER HORIZON, yielding what the reference's
+    collated batch is -- a list of {"horizon": (B,) int64, "data": {...}} (reference d4rl_mujoco_dataset.py:296-320)."""
+
+    def __init__(self, ds, loaders, batch_size, shuffle, drop_last, generator, device):
+        self.ds, self.loaders = ds, loaders
+        self.batch_size, self.shuffle, self.drop_last, self.generator, self.device = int(batch_size), shuffle, drop_last, generator, device
+
+    def _n(self) -> int:
+        # Reference quirk (d4rl_mujoco_dataset.py:293-305): len(dataset) is the LARGEST item table, but item idx takes entry
+        # int(len_k * (idx / len_last)) of table k -- past len_last the last table is indexed out of range (IndexError in the
+        # reference's DataLoader).  The resident loader serves the items every horizon has.
+        return min(len(self.ds), self.ds.len_each_horizon[-1])
+
+    def __len__(self):
+        n = self._n()
+        return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
+
+    def batch_of(self, idx: torch.Tensor):
+        """The collated batch of dataset items `idx` (int64 on the loader's device): horizon k takes item
+        int(len_k * (idx / len_last)) of its own table -- the reference's float64 arithmetic, evaluated on the device."""
+        lens = self.ds.len_each_horizon
+        out = []
+        for k, (h, ld) in enumerate(zip(self.ds.horizons, self.loaders)):
+            sub = (lens[k] * (idx.to(torch.float64) / lens[-1])).to(torch.int64)
+            out.append({"horizon": torch.full((idx.shape[0],), h, dtype=torch.int64, device=idx.device), "data": ld.batch_of(ld.item_row0[sub])})
+        return out
+
+    def __iter__(self):
+        n, bs = self._n(), self.batch_size
+        order = torch.randperm(n, device=self.device, generator=self.generator) if self.shuffle else torch.arange(n, device=self.device)
+        for i in range(len(self)):
+            yield self.batch_of(order[i * bs:min((i + 1) * bs, n)])
+
+
+class MultiHorizonD4RLMuJoCoDataset(BaseDataset):
+    """DiffuserLite's multi-horizon sequences (reference d4rl_mujoco_dataset.py:232-320): the episode arrays of ``D4RLMuJoCoDataset``,
+    one item table per horizon; item `idx` = one window per horizon (no reward field)."""
+
+    def __init__(self, dataset, terminal_penalty=-100, horizons=(10, 20), max_path_length=1000, discount=0.99):
+        super().__init__()
+        from .d4rl_mujoco_dataset import D4RLMuJoCoDataset
+        base = D4RLMuJoCoDataset(dataset, terminal_penalty=terminal_penalty, horizon=1, max_path_length=max_path_length, discount=discount)
+        self.normalizers = base.normalizers
+        self.horizons = horizons
+        self.o_dim, self.a_dim = base.o_dim, base.a_dim
+        self.discount = discount ** np.arange(max_path_length, dtype=np.float32)
+        self.seq_obs, self.seq_act, self.seq_rew, self.seq_val = base.seq_obs, base.seq_act, base.seq_rew, base.seq_val
+        self.path_lengths = base.path_lengths
+        self.indices = [window_items(base.path_lengths, np.minimum(base.path_lengths - 1, max_path_length - h), h) for h in horizons]
+        self.len_each_horizon = [int(t.shape[0]) for t in self.indices]
+        self.max_path_length = max_path_length
+        self._views = None
+
+    def get_normalizer(self):
+        return self.normalizers["state"]
+
+    def __len__(self):
+        return max(self.len_each_horizon)
+
+    def __getitem__(self, idx: int):
+        out = []
+        for k, h in enumerate(self.horizons):
+            path, start, end = self.indices[k][int(self.len_each_horizon[k] * (idx / self.len_each_horizon[-1]))]
+            out.append({"horizon": h, "data": {"obs": {"state": torch.tensor(self.seq_obs[path, start:end])},
+                                               "act": torch.tensor(self.seq_act[path, start:end]),
+                                               "val": torch.tensor(self.seq_val[path, start])}})
+        return out
+
+    def _view(self, k: int) -> EpisodeStore:
+        """Horizon k as an EpisodeStore over the SAME arrays (they are uploaded once per view's first use; obs / act / val only)."""
+        v = EpisodeStore()
+        v.normalizers, v.o_dim, v.a_dim, v.horizon = self.normalizers, self.o_dim, self.a_dim, self.horizons[k]
+        v.seq_obs, v.seq_act, v.seq_rew, v.seq_val, v.indices = self.seq_obs, self.seq_act, self.seq_rew, self.seq_val, self.indices[k]
+        return v
+
+    def loader(self, batch_size: int, shuffle: bool = True, drop_last: bool = True, device="cuda",
+               generator: Optional[torch.Generator] = None) -> MultiHorizonLoader:
+        if self._views is None:
+            self._views = [self._view(k) for k in range(len(self.horizons))]
+            first = self._views[0].resident(device)                       # one upload; the other horizons share the device buffers
+            for v in self._views[1:]:
+                fields, row0, rows = v._host_fields()
+                v._resident = {"device": first["device"], "rows": rows, "row0": torch.from_numpy(np.ascontiguousarray(row0, dtype=np.int32)).to(device),
+                               "fields": {k: (first["fields"][k][0], fields[k][1], fields[k][2]) for k in fields}}
+
+        def strip(f):                                                     # the reference's multi-horizon items carry no reward
+            return {"obs": {"state": f["obs"]}, "act": f["act"], "val": f["val"]}
+        loaders = []
+        for v in self._views:
+            r = v.resident(device)
+            loaders.append(ResidentLoader({k: r["fields"][k] for k in ("obs", "act", "val")}, r["row0"], r["rows"], batch_size, False, False,
+                                          None, strip))
+        return MultiHorizonLoader(self, loaders, batch_size, shuffle, drop_last, generator, torch.device(device))
+
+
+class D4RLKitchenTDDataset(_ResidentMixin, BaseDataset):
+    """Kitchen transitions (reference d4rl_kitchen_dataset.py:138-216): normalised obs / next_obs, act, rew, tml."""
+
+    def __init__(self, dataset: Dict[str, np.ndarray]):
+        super().__init__()
+        self._build(dataset, dataset["rewards"].astype(np.float32))
+
+    def _build(self, dataset, rewards):
+        observations = dataset["observations"].astype(np.float32)
+        self.normalizers = {"state": GaussianNormalizer(observations)}
+        self.obs = torch.tensor(self.normalizers["state"].normalize(observations))
+        self.next_obs = torch.tensor(self.normalizers["state"].normalize(dataset["next_observations"].astype(np.float32)))
+        self.act = torch.tensor(dataset["actions"].astype(np.float32))
+        self.rew = torch.tensor(rewards)[:, None]
+        self.tml = torch.tensor(dataset["terminals"].astype(np.float32))[:, None]
+        self.size = self.obs.shape[0]
+        self.o_dim, self.a_dim = observations.shape[-1], self.act.shape[-1]
+
+    def get_normalizer(self):
+        return self.normalizers["state"]
+
+    def __len__(self):
+        return self.size
+
+    def __getitem__(self, idx: int):
+        return {"obs": {"state": self.obs[idx]}, "next_obs": {"state": self.next_obs[idx]}, "act": self.act[idx], "rew": self.rew[idx],
+                "tml": self.tml[idx]}
+
+    def _host_fields(self):
+        if self.size >= 2 ** 31:
+            raise ValueError("more than 2^31 rows: row indices are int32")
+        return {k: (getattr(self, k).numpy(), 1, False) for k in ("obs", "next_obs", "act", "rew", "tml")}, np.arange(self.size), self.size
+
+    @staticmethod
+    def _assemble(f):
+        return {"obs": {"state": f["obs"]}, "next_obs": {"state": f["next_obs"]}, "act": f["act"], "rew": f["rew"], "tml": f["tml"]}
+
+
+class D4RLAntmazeTDDataset(D4RLKitchenTDDataset):
+    """Antmaze transitions with the reward tuning of the offline-RL baselines (reference d4rl_antmaze_dataset.py:142-233)."""
+
+    def __init__(self, dataset: Dict[str, np.ndarray], reward_tune: str = "iql"):
+        BaseDataset.__init__(self)
+        rewards = dataset["rewards"].astype(np.float32)
+        if reward_tune == "iql":
+            rewards = rewards - 1.
+        elif reward_tune == "cql":
+            rewards = (rewards - 0.5) * 4.
+        elif reward_tune == "antmaze":
+            rewards = (rewards - 0.25) * 2.
+        elif reward_tune != "none":
+            raise ValueError(f"reward_tune: {reward_tune} is not supported.")
+        self._build(dataset, rewards)

@@ -438,7 +438,8 @@ def idql_forward(net, x, noise, condition):
 
 def supports_dit(net, x: torch.Tensor, condition=None) -> bool:
     """DiT1d (BASELINE config 4) with autograd on, on a ROCm device: <= 64 tokens, head_dim <= 64, no dropout inside the blocks."""
-    if not (enabled() and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and type(net).__name__ == "DiT1d"):
+    if not (enabled() and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and
+            type(net).__name__ in ("DiT1d", "HalfDiT1d")):       # (HalfDiT1d: the same trunk with a d_model / 2 wide final layer)
         return False
     blk = net.blocks[0] if len(net.blocks) else None
     if blk is None or x.shape[1] > 64 or net.d_model // blk.attn.num_heads > 64 or net.d_model > 4096 or net.d_model % blk.attn.num_heads:
@@ -474,7 +475,7 @@ def dit_forward(net, x, noise, condition):
     fl = net.final_layer
     shift, scale = fl.adaLN_modulation(emb).chunk(2, dim=1)
     m = _LayerNormMod.apply(h, scale, shift, tokens, fl.norm_final.eps)
-    return _LinearAct.apply(m, fl.linear.weight, fl.linear.bias, None).view(b, tokens, d_in)
+    return _LinearAct.apply(m, fl.linear.weight, fl.linear.bias, None).view(b, tokens, fl.linear.out_features)
 
 
 def supports_mlp(net, x: torch.Tensor, condition=None) -> bool:

@@ -1,7 +1,10 @@
 """HalfDiT1d -- DiT1d trunk as a trajectory classifier (contract: reference nn_classifier/half_dit.py:9-76): the final layer
 maps tokens to ``d_model // 2`` features (zero-initialised like every DiT head), tokens are mean-pooled and a
-LayerNorm-SiLU-Linear x2 head produces ``out_dim`` values.  The trunk is ``nn_diffusion.DiT1d`` (PyTorch executor here: the
-class is a subclass, so the native DiT1d dispatch -- which checks the exact type -- does not intercept it)."""
+LayerNorm-SiLU-Linear x2 head produces ``out_dim`` values.  The trunk is ``nn_diffusion.DiT1d``: with autograd on, on a ROCm device
+-- which is how ``BaseClassifier.gradients`` differentiates ``logp`` (reference classifier/base.py:74-79) -- its Linear / LayerNorm +
+modulate / attention nodes run forward and backward on the library's kernels (engine/train.py:dit_forward, round 5); the pooled head
+(a few (batch, d_model / 2) rows) stays ATen.  Without autograd the class is the PyTorch executor (the sampling dispatch checks the
+exact type DiT1d)."""
 from typing import Optional
 
 import torch

@@ -96,10 +96,13 @@ class DiT1d(BaseNNDiffusion):
 
     def forward(self, x: torch.Tensor, noise: torch.Tensor, condition: Optional[torch.Tensor] = None):
         """x (b, horizon, in_dim), noise (b,), condition (b, emb_dim)|None -> (b, horizon, in_dim)."""
+        from ..engine import train
+        if train.supports_dit(self, x, condition):
+            # autograd on, ROCm device: loss() / update() of DiT1d, and the classifier gradient through a HalfDiT1d trunk
+            # (reference nn_classifier/half_dit.py:9, classifier/base.py:74-79) -- engine/train.py:dit_forward
+            return train.dit_forward(self, x, noise, condition)
         if type(self) is DiT1d:
-            from ..engine import dispatch, train
-            if train.supports_dit(self, x, condition):    # autograd on, ROCm device (loss() / update()): engine/train.py:dit_forward
-                return train.dit_forward(self, x, noise, condition)
+            from ..engine import dispatch
             y = dispatch.try_backbone_forward(self, x, noise, condition)     # GEMM/LN/attention launches on a ROCm device
             if y is not None:
                 return y

@@ -115,3 +115,55 @@ def restate_td(data, normalize_reward):
                 next_obs=((data["next_observations"].astype(np.float32) - mean[None]) / std[None]).astype(np.float32),
                 act=data["actions"].astype(np.float32), rew=data["rewards"].astype(np.float32)[:, None],
                 tml=data["terminals"].astype(np.float32)[:, None])
+
+
+# ---- round 5: the siblings over the same padded-episode structure (cleandiffuser_amd/dataset/episode_store.py) -------------------------
+# name: (class name in both packages, module name in the reference, synthetic kwargs, dataset kwargs)
+SIBLING_SCENARIOS = {
+    "kitchen_h16": ("D4RLKitchenDataset", "d4rl_kitchen_dataset", dict(n=5000, o=9, a=4, seed=6, max_len=140), dict(horizon=16, max_path_length=140, discount=0.99)),
+    "kitchen_dv_h8_s3": ("DV_D4RLKitchenSeqDataset", "d4rl_kitchen_dataset", dict(n=4000, o=7, a=3, seed=7, max_len=120),
+                         dict(horizon=8, max_path_length=120, discount=0.997, center_mapping=True, stride=3)),
+    "antmaze_h12": ("D4RLAntmazeDataset", "d4rl_antmaze_dataset", dict(n=6000, o=8, a=3, seed=8, max_len=90, antmaze=True),
+                    dict(horizon=12, max_path_length=90, noreaching_penalty=-100.0, discount=0.99)),
+    "mujoco_dv_h6_s4": ("DV_D4RLMuJoCoSeqDataset", "d4rl_mujoco_dataset", dict(n=5000, o=11, a=3, seed=9, max_len=110),
+                        dict(terminal_penalty=-100, horizon=6, max_path_length=110, discount=0.99, center_mapping=True, stride=4, full_traj_bonus=100)),
+    "mujoco_dv_h4_s1_01": ("DV_D4RLMuJoCoSeqDataset", "d4rl_mujoco_dataset", dict(n=3000, o=5, a=2, seed=10, max_len=80),
+                           dict(terminal_penalty=None, horizon=4, max_path_length=80, discount=0.9, center_mapping=False, stride=1, full_traj_bonus=None)),
+}
+SIBLING_TD_SCENARIOS = {
+    "kitchen_td": ("D4RLKitchenTDDataset", "d4rl_kitchen_dataset", dict(n=4000, o=9, a=4, seed=11, max_len=140), dict()),
+    "antmaze_td_cql": ("D4RLAntmazeTDDataset", "d4rl_antmaze_dataset", dict(n=4000, o=8, a=3, seed=12, max_len=90), dict(reward_tune="cql")),
+}
+MULTI_HORIZON = {"mujoco_multi_h5_20": (dict(n=6000, o=11, a=3, seed=13, max_len=150),
+                                        dict(terminal_penalty=-100, horizons=(5, 20), max_path_length=150, discount=0.99))}
+
+
+def synthetic_antmaze(n, o, a, seed, max_len):
+    """Antmaze-shaped flags: sparse 0 / 1 rewards; an episode either fills `max_len` steps (timeout on its last step, goal never
+    reached) or reaches the goal early -- then the done flag (terminal) stays up for a few steps before the next episode starts."""
+    rng = np.random.default_rng(seed)
+    d = synthetic(n, o, a, seed, max_len)
+    term, tout, rew = np.zeros(n, dtype=bool), np.zeros(n, dtype=bool), np.zeros(n, dtype=np.float32)
+    i = 0
+    while i < n:
+        if rng.random() < 0.3:
+            e = i + max_len - 1
+            if e >= n:
+                break
+            tout[e] = True
+            i = e + 1
+        else:
+            reach = i + int(rng.integers(2, max_len - 6))
+            stay = int(rng.integers(1, 5))
+            if reach + stay >= n:
+                break
+            term[reach:reach + stay] = True
+            rew[reach:reach + stay] = 1.0
+            i = reach + stay
+    d["terminals"], d["timeouts"], d["rewards"] = term, tout, rew
+    return d
+
+
+def make_data(skw):
+    skw = dict(skw)
+    return synthetic_antmaze(**skw) if skw.pop("antmaze", False) else synthetic(**skw)

@@ -43,5 +43,50 @@ def main(out_dir="tests/golden"):
         print(f"{name:24s} items={len(ds)}")
 
 
+def siblings(out_dir="tests/golden"):
+    """Round 5: kitchen / antmaze / Decision-Veteran / multi-horizon classes (dataset_cases.SIBLING_*): the same records."""
+    import importlib
+    import_reference()
+    for name, (cls, mod, skw, dkw) in dc.SIBLING_SCENARIOS.items():
+        ds = getattr(importlib.import_module(f"cleandiffuser.dataset.{mod}"), cls)(copy.deepcopy(dc.make_data(skw)), **dkw)
+        idx = dc.item_indices(len(ds), skw["seed"])
+        b = default_collate([ds[int(i)] for i in idx])
+        out = dict(idx=idx, obs=b["obs"]["state"].numpy(), act=b["act"].numpy(), rew=b["rew"].numpy(), val=b["val"].numpy(),
+                   indices=np.array(ds.indices, dtype=np.int64).reshape(-1, 3), mean=ds.get_normalizer().mean, std=ds.get_normalizer().std,
+                   **{f"sum_{k}": _sums(getattr(ds, k)) for k in ("seq_obs", "seq_act", "seq_rew", "seq_val")})
+        if hasattr(ds, "tml_and_not_timeout"):
+            out["tml_and_not_timeout"] = np.asarray(ds.tml_and_not_timeout, dtype=np.int64)
+        np.savez_compressed(os.path.join(out_dir, f"dataset_{name}.npz"), **out)
+        print(f"{name:24s} items={len(ds)} rows={np.asarray(ds.seq_obs).shape[:2]}")
+    for name, (cls, mod, skw, dkw) in dc.SIBLING_TD_SCENARIOS.items():
+        ds = getattr(importlib.import_module(f"cleandiffuser.dataset.{mod}"), cls)(copy.deepcopy(dc.make_data(skw)), **dkw)
+        idx = dc.item_indices(len(ds), skw["seed"])
+        b = default_collate([ds[int(i)] for i in idx])
+        out = dict(idx=idx, obs=b["obs"]["state"].numpy(), next_obs=b["next_obs"]["state"].numpy(), act=b["act"].numpy(),
+                   rew=b["rew"].numpy(), tml=b["tml"].numpy(),
+                   **{f"sum_{k}": _sums(getattr(ds, k).numpy()) for k in ("obs", "next_obs", "act", "rew", "tml")})
+        np.savez_compressed(os.path.join(out_dir, f"dataset_{name}.npz"), **out)
+        print(f"{name:24s} items={len(ds)}")
+    from cleandiffuser.dataset.d4rl_mujoco_dataset import MultiHorizonD4RLMuJoCoDataset
+    for name, (skw, dkw) in dc.MULTI_HORIZON.items():
+        ds = MultiHorizonD4RLMuJoCoDataset(copy.deepcopy(dc.make_data(skw)), **dkw)
+        # (reference quirk: len() is the LARGEST table but item idx is scaled by idx / len(last table) -- items past the last horizon's
+        #  count raise IndexError there; the fixture records items every horizon can serve)
+        idx = dc.item_indices(min(ds.len_each_horizon), skw["seed"])
+        b = default_collate([ds[int(i)] for i in idx])
+        out = dict(idx=idx, len_each_horizon=np.array(ds.len_each_horizon, dtype=np.int64))
+        for k, part in enumerate(b):
+            out[f"h{k}_horizon"] = part["horizon"].numpy()
+            out[f"h{k}_obs"], out[f"h{k}_act"], out[f"h{k}_val"] = (part["data"]["obs"]["state"].numpy(), part["data"]["act"].numpy(),
+                                                                    part["data"]["val"].numpy())
+            out[f"h{k}_indices"] = np.array(ds.indices[k], dtype=np.int64)
+        np.savez_compressed(os.path.join(out_dir, f"dataset_{name}.npz"), **out)
+        print(f"{name:24s} items={len(ds)} per horizon {ds.len_each_horizon}")
+
+
 if __name__ == "__main__":
-    main()
+    import sys
+    if "siblings" not in sys.argv[1:]:
+        main()
+    if not sys.argv[1:] or "siblings" in sys.argv[1:]:
+        siblings()
