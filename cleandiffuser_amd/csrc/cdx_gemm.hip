@@ -28,6 +28,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define GM_BK 16
 #define GM_LD (GM_BM + 4)
 #define GM_THREADS 256
+#ifndef GM_STAGE_AT
+#define GM_STAGE_AT (BK - 4)                   // k pair of the first half behind which tile t + 1 is parked in LDS (A/B builds)
+#endif
 #ifndef CDX_GEMM_KBLOCK
 #define CDX_GEMM_KBLOCK 1                     // 0: one sequential fma chain over K per element (rounds 1-4; A/B builds)
 #endif
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(GM_THREADS, (WT == 2 ? 3 : 4)) void cdx_gemm_kernel
                 }
 #pragma unroll
                 for (int j = 0; j < WT; ++j) blk[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[j], blk[j], 0, 0, 0);
-                if (h == 0 && kk == (WT == 2 ? BK - 4 : BK / 2 - 4) && t + 1 < nk) {   // park tile t + 1 in the other stage, request t + 2
+                if (h == 0 && kk == (WT == 2 ? GM_STAGE_AT : BK / 2 - 4) && t + 1 < nk) {   // park tile t + 1 in the other stage, request t + 2
                     stage((t + 1) & 1);
                     if (t + 2 < nk) fetch(kt0 + (t + 2) * BK);
                 }

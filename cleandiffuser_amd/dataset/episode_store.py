@@ -244,6 +244,12 @@ class MultiHorizonLoader:
     def __init__(self, ds, loaders, batch_size, shuffle, drop_last, generator, device):
         self.ds, self.loaders = ds, loaders
         self.batch_size, self.shuffle, self.drop_last, self.generator, self.device = int(batch_size), shuffle, drop_last, generator, device
+        # item idx -> entry of horizon k's table: int(len_k * (idx / len_last)), the reference's float64 arithmetic -- evaluated ONCE on
+        # the host for every idx (numpy float64 = Python's; a GPU's float64 division need not round the same way: found on MI355X,
+        # where 1 of 96 entries came out one lower) and kept on the device as a lookup table
+        lens, n = ds.len_each_horizon, self._n()
+        self.sub = [torch.from_numpy((lens[k] * (np.arange(n, dtype=np.float64) / lens[-1])).astype(np.int64)).to(device)
+                    for k in range(len(ds.horizons))]
 
     def _n(self) -> int:
         # Reference quirk (d4rl_mujoco_dataset.py:293-305): len(dataset) is the LARGEST item table, but item idx takes entry
@@ -257,11 +263,10 @@ class MultiHorizonLoader:
 
     def batch_of(self, idx: torch.Tensor):
         """The collated batch of dataset items `idx` (int64 on the loader's device): horizon k takes item
-        int(len_k * (idx / len_last)) of its own table -- the reference's float64 arithmetic, evaluated on the device."""
-        lens = self.ds.len_each_horizon
+        int(len_k * (idx / len_last)) of its own table (the lookup table built in the constructor)."""
         out = []
         for k, (h, ld) in enumerate(zip(self.ds.horizons, self.loaders)):
-            sub = (lens[k] * (idx.to(torch.float64) / lens[-1])).to(torch.int64)
+            sub = self.sub[k][idx]
             out.append({"horizon": torch.full((idx.shape[0],), h, dtype=torch.int64, device=idx.device), "data": ld.batch_of(ld.item_row0[sub])})
         return out
 

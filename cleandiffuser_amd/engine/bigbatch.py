@@ -660,10 +660,12 @@ def _chiunet_chunk(batch: int, Ta: int, model_dim: int, two: int) -> int:
     return max(min(batch, rows // (Ta * two)), 1)
 
 
-def janner_forward(net, x, noise) -> Optional[torch.Tensor]:
-    """Unconditional JannerUNet1d.forward with per-sample timesteps through the implicit-GEMM executor (what a guided /
-    custom loop calls once per step when the net is too large for the one-workgroup program kernel)."""
-    if x.dim() != 3:
+def janner_forward(net, x, noise, condition=None) -> Optional[torch.Tensor]:
+    """JannerUNet1d.forward with per-sample timesteps through the implicit-GEMM executor (what a guided / custom loop calls once per
+    step when the net is too large for the one-workgroup program kernel, and ``attention=True`` nets at every size).  A condition
+    embedding enters the time embedding BEFORE map_emb (reference jannerunet.py:160-164: emb = map_noise(t) + condition), so a
+    conditional forward is the same launch on the per-sample rows map_noise(t) + condition (round 5: conditional attention nets)."""
+    if x.dim() != 3 or (condition is not None and (condition.dim() != 2 or condition.shape[0] != x.shape[0])):
         return None
     dev = x.device
     b, H, d = x.shape
@@ -672,7 +674,12 @@ def janner_forward(net, x, noise) -> Optional[torch.Tensor]:
         return None
     w = bound.struct
     with torch.no_grad():
-        temb = _f32c(net.map_noise(noise), dev)
+        temb = net.map_noise(noise)
+        if condition is not None:
+            if tuple(condition.shape) != (b, temb.shape[-1]):
+                return None
+            temb = temb.expand(b, -1) + condition
+        temb = _f32c(temb.expand(b, -1), dev)
         xin = _f32c(x, dev)
         out = torch.empty_like(xin)
         _run("chiunet", bound, batch=b, hd=H * d, emb_dim=w.emb_dim, cond_dim=0, temb=temb, steps=None, n_steps=0,
@@ -690,7 +697,7 @@ def _unet_cond_dim(w) -> int:
 def chiunet_forward(net, x, noise, condition) -> Optional[torch.Tensor]:
     from ..nn_diffusion.jannerunet import JannerUNet1d
     if type(net) is JannerUNet1d:
-        return janner_forward(net, x, noise) if condition is None else None
+        return janner_forward(net, x, noise, condition)
     if x.dim() != 3 or condition is None:
         return None
     dev = x.device

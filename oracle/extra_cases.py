@@ -415,6 +415,31 @@ def janner_attention():
 SCENARIOS["janner_attention"] = janner_attention()
 
 
+def janner_attention_conditional():
+    """JannerUNet1d(attention=True) WITH a condition embedding (reference jannerunet.py:160-164: emb = map_noise(t) + condition): the
+    stand-alone forward, a w_cfg = 1 DDIM loop and a classifier-free-guidance pair (w_cfg = 1.5)."""
+    B, H, D, steps = 3, 16, 6, 4
+
+    def run(lib, kind, device):
+        net = load_synth(lib.JannerUNet1d(D, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2], kernel_size=5, attention=True), 82)
+        agent = lib.DiscreteDiffusionSDE(net, lib.IdentityCondition(dropout=0.0), diffusion_steps=10, predict_noise=True,
+                                         x_max=2 * torch.ones(1, H, D), x_min=-2 * torch.ones(1, H, D), device=device)
+        agent.eval()
+        g = torch.Generator().manual_seed(82)
+        cond = 0.5 * torch.randn(B, 32, generator=g)
+        zs = [torch.randn(B, H, D, generator=g) for _ in range(steps + 1)]
+        with torch.no_grad():
+            fwd = agent.model_ema["diffusion"](zs[0].to(device), torch.tensor([1, 4, 9], device=device), cond.to(device))
+        kw = dict(solver="ddim", n_samples=B, sample_steps=steps, temperature=0.8, condition_cfg=cond.to(device))
+        x1, _ = _sample(agent, kind, torch.zeros(B, H, D, device=device), zs, w_cfg=1.0, **kw)
+        x2, _ = _sample(agent, kind, torch.zeros(B, H, D, device=device), zs, w_cfg=1.5, **kw)
+        return {"fwd": fwd, "x_w1": x1, "x_pair": x2}
+    return run
+
+
+SCENARIOS["janner_attention_conditional"] = janner_attention_conditional()
+
+
 def chitransformer_pusht_full():
     """Diffusion Policy's transformer at the dp_pusht size AND step count (tools/bench_configs.py cfgT: d_model 256, 4 heads, 8 decoder
     layers, Ta = 16, To = 2, obs 20; 100-step DDPM over DiscreteDiffusionSDE, w_cfg = 1), B = 2."""
