@@ -236,7 +236,9 @@ def live_traffic(timeout_s=150):
                             per.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
                 if not per:
                     return None
-                name = max(per, key=lambda k: len(per[k]))              # the kernel of the timed calls (the one-off self-check is another)
+                # the kernel that does the work: by counter VOLUME, not by dispatch count (the idle repair launches behind the grouped
+                # launches are as many dispatches of the ordinary program's instantiation)
+                name = max(per, key=lambda k: sum(per[k]))
                 got[counter] = (sum(per[name]) / len(per[name]), len(per[name]), name)
     except Exception:  # noqa: BLE001 -- never fail the bench on the counter leg
         return None
@@ -244,8 +246,9 @@ def live_traffic(timeout_s=150):
     write = got["WRITE_SIZE"][0] * 1024.0
     return {"traffic": fetch + write, "traffic_unit": "bytes/launch", "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
             "traffic_kernel": got["FETCH_SIZE"][2][:96], "dispatches": got["FETCH_SIZE"][1],
-            "traffic_source": "MEASURED by this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (one pass each, 8 + 3 launches, mean "
-                              "per dispatch; FETCH_SIZE x 1024 B x 2 = the guide's gfx950 correction, WRITE_SIZE x 1024 B as reported)"}
+            "traffic_source": "MEASURED by this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (one child run of this script per "
+                              "counter, mean over its dispatches of the kernel; FETCH_SIZE x 1024 B x 2 = the guide's gfx950 correction, "
+                              "WRITE_SIZE x 1024 B as reported)"}
 
 
 # ------------------------------------------------------------------------------------------------------------------- #

@@ -1,4 +1,4 @@
-"""The bench.py output contract, checked on the committed line of this round (profiles/r03_bench_n1.json -- written by `python
+"""The bench.py output contract, checked on the committed line of this round (profiles/r05_bench_n1.json -- written by `python
 bench.py` on MI355X): every field the driver parses is there, the roofline numbers are consistent with each other and with the
 committed rocprofv3 statistics, and the line names BASELINE.json's metric and configuration."""
 import csv
@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module")
 def line():
-    path = os.path.join(ROOT, "profiles", "r03_bench_n1.json")
+    path = os.path.join(ROOT, "profiles", "r05_bench_n1.json")
     return json.loads(open(path).read().strip().splitlines()[-1])
 
 
@@ -22,7 +22,7 @@ def test_bench_line_has_the_contract_fields(line):
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in line, key
-    assert line["n_gpus"] == 1 and line["higher_is_better"] is True and line["scaling"] == "weak" and line["data"] == "synthetic"
+    assert line["n_gpus"] == 1 and line["higher_is_better"] is True and line["scaling"] == "strong" and line["data"] == "synthetic"
     assert line["dtype"] == "f32" and line["vs_baseline"] is None          # BASELINE.md has no published number for this metric
     assert "workload" in line["config"] and "model" not in line["config"]
     assert "trajectories" in line["unit"] and "256" in line["metric"] and "DDIM" in line["metric"]
@@ -41,16 +41,26 @@ def test_roofline_block_is_self_consistent(line):
     assert abs(r["achieved"] - r["flops_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e12) / r["achieved"] < 1e-6
     assert r["kernel_ms"] <= line["ms_per_step"] <= 1.05 * r["kernel_ms"]      # a steady-state call is that one launch
     assert r["traffic"] is None or r["traffic"] > 0
+    # round 5: the HBM-side traffic is measured by the run itself (rocprofv3 --pmc child passes) and agrees with the committed record
+    assert r["traffic_source"].startswith("MEASURED by this run") and "cdx_unet2_kernel<1, 8, false, false, false, false, true>" in r["traffic_kernel"]
+    assert abs(r["traffic"] - r["recorded"]["traffic"]) <= 0.05 * r["recorded"]["traffic"]
+    assert abs(r["traffic"] - (r["fetch_bytes_per_launch"] + r["write_bytes_per_launch"])) < 1.0
+    # ... the repair launch behind the grouped launch is inside `value` and costs microseconds
+    assert r["repair_launch"]["launches_timed"] == r["launches_timed"] and r["repair_launch"]["mean_us"] < 30.0
+    assert line["sustained"]["seconds"] >= 1.0 and abs(line["sustained"]["value"] - line["value"]) <= 0.03 * line["value"]
     l2 = r["l2_stream"]
     assert l2["bound"] == "l2" and abs(l2["frac"] - l2["achieved"] / l2["peak"]) < 1e-9
 
 
 def test_rocprof_statistics_agree_with_the_live_measurement(line):
-    path = os.path.join(ROOT, "profiles", "r03_rocprofv3_kernel_stats.csv")
+    path = os.path.join(ROOT, "profiles", "r05_rocprofv3_kernel_stats.csv")
     rows = list(csv.DictReader(open(path)))
-    # <T, waves, BWD, PROF, COND, MLP, SPLIT>: the unconditional one-trajectory 8-wave instantiation, every feature flag off
-    kern = [r for r in rows if re.search(r"cdx_unet2_kernel<1, 8(, false)+>", r["Name"])]
+    # <T, waves, BWD, PROF, COND, MLP, SPLIT>: the member kernel of the grouped program (SPLIT); the all-false instantiation next to it is
+    # the idle repair launch behind every grouped launch (+ the one first-use self-check)
+    kern = [r for r in rows if re.search(r"cdx_unet2_kernel<1, 8, false, false, false, false, true>", r["Name"])]
     assert len(kern) == 1
+    repair = [r for r in rows if re.search(r"cdx_unet2_kernel<1, 8(, false)+>", r["Name"])]
+    assert len(repair) == 1 and int(repair[0]["Calls"]) == int(kern[0]["Calls"]) + 1 and float(repair[0]["Percentage"]) < 1.0
     avg_ms = float(kern[0]["AverageNs"]) * 1e-6
     assert abs(avg_ms - line["roofline"]["kernel_ms"]) / avg_ms < 0.03          # HIP events in bench.py vs rocprofv3 --kernel-trace
     assert float(kern[0]["Percentage"]) > 95.0
@@ -61,6 +71,9 @@ def test_cpu_baseline_and_side_configs(line):
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r05_reference_cpu.json")))
+    assert c["kind"] == "reference" or (c["port_over_reference"] == rec["port_over_reference"] and
+                                        abs(c["reference_equivalent"]["value"] - c["value"] / rec["port_over_reference"]) < 1e-6)
     names = {o["name"] for o in line["other_configs"]}
     assert {"config2_B3200", "config2_guided_B256", "config2_guided_B3200", "config1", "config3", "config4_shard512",
             "config5_chunk16384"} <= names

@@ -1519,7 +1519,7 @@ def test_update_runs_without_aten_conv_or_groupnorm_kernels(amd_lib):
     column-sum / optimiser kernels plus ATen's elementwise glue; and three updates land on the same loss values, gradient norms and
     weights as the reference sequence on the CPU (autograd, clip_grad_norm_, AdamW, EMA) fed the same draws.
     (The twin runs on the CPU because ATen's own group_norm backward on THIS ROCm build returns gain / shift gradients that are off by
-    100 % once the batch reaches 255 -- tools/debug_train2.py, profiles/r04_aten_groupnorm_backward.txt: float64 on the CPU agrees with
+    100 % once the batch reaches 255 -- tools/aten_groupnorm_backward_check.py, profiles/r04_aten_groupnorm_backward.txt: float64 on the CPU agrees with
     the library's kernel to 5e-5 and with ATen-CPU, not with ATen-GPU.  Up to B = 128 the device twin agrees too:
     test_native_training_graph_matches_autograd.)"""
     from copy import deepcopy

@@ -1,3 +1,6 @@
+"""GPU box: GroupNorm(8 groups) -> Mish backward on (B, 32, 32) inputs three ways -- the library's cdx_groupnorm_bwd_f32, ATen on the device,
+ATen on the CPU in float64 / float32.  The record profiles/r04_aten_groupnorm_backward.txt came from this script: ATen's device kernel of this
+ROCm build returns gain / shift gradients that are off by 100 % once the batch reaches 255."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cleandiffuser_amd.engine import blocks

@@ -3,7 +3,7 @@ mkdir -p gpurun_out/r4h
 cd "$(dirname "$0")/.."
 timeout 900 python -m pytest tests/test_gpu_parity.py -q -p no:cacheprovider -k "native_training or update_runs" > gpurun_out/r4h/pytest.log 2>&1
 tail -12 gpurun_out/r4h/pytest.log
-python tools/debug_train2.py > gpurun_out/r4h/aten_groupnorm_backward.txt 2>&1
+python tools/aten_groupnorm_backward_check.py > gpurun_out/r4h/aten_groupnorm_backward.txt 2>&1
 timeout 300 python - > gpurun_out/r4h/update_profile.txt 2>&1 <<'PY'
 import os, sys, time, torch, cProfile, pstats
 sys.path.insert(0, "tools"); sys.path.insert(0, ".")
