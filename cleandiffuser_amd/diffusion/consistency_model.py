@@ -223,6 +223,7 @@ class ContinuousConsistencyModel(DiffusionModel):
                 return fused, log
 
         pred = None
+        feed.reserve(xt, len(levels) - 1)              # (as the whole-loop executor draws them: _NoiseFeed.reserve)
         for k, i in enumerate(levels):
             t = torch.full((n_samples,), sigmas[i], dtype=torch.float32, device=self.device)
             if k > 0:

@@ -143,6 +143,7 @@ class DDPM(DiffusionModel):
                 return fused, log
         kw = dict(use_ema=use_ema, requires_grad=requires_grad, condition_vec_cfg=cond_cfg,
                   condition_vec_cg=condition_cg, w_cfg=w_cfg, w_cg=w_cg)
+        feed.reserve(xt, self.diffusion_steps - 1)     # (as the whole-loop executor draws them: _NoiseFeed.reserve)
         for t in range(self.diffusion_steps - 1, -1, -1):
             t_batch = torch.tensor(t, device=self.device, dtype=torch.long).repeat(n_samples)
             pred, log = self.predict_function(xt, t_batch, self.bar_alpha[t], **kw)

@@ -172,6 +172,8 @@ class DPMSolver(DiffusionModel):
         else:
             kw = dict(use_ema=use_ema, requires_grad=requires_grad, predict_noise=cfg["predict_noise"],
                       condition_vec_cfg=cond_cfg, condition_vec_cg=condition_cg, w_cfg=w_cfg, w_cg=w_cg)
+            if not preserve_history:
+                feed.reserve(xt, plan.n_noise)         # (as the whole-loop executor draws them: _NoiseFeed.reserve)
             buffer = []
             for i in range(1, sample_steps + 1):
                 pred, log_i = self.predict_function(xt, t[i - 1].repeat(n_samples), alphas[i - 1], sigmas[i - 1], **kw)

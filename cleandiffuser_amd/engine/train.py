@@ -621,8 +621,11 @@ def graphed_step(agent, x0, condition, kwargs) -> Optional[GraphedStep]:
     denoiser the native training path serves (JannerUNet1d, ChiUNet1d, DiT1d, IDQLMlp, DQLMlp / DVInvMlp on a ROCm device), no extra
     loss arguments, and whose first step passes the capturability probe (GraphedStep); "1": no probe; "0": never."""
     mode = os.environ.get("CDX_TRAIN_GRAPH", "auto")
-    if mode == "0" or kwargs or not x0.is_cuda or not torch.is_grad_enabled() or torch.cuda.is_current_stream_capturing():
+    if mode == "0" or kwargs or not torch.is_tensor(x0) or not x0.is_cuda or not torch.is_grad_enabled() or \
+            torch.cuda.is_current_stream_capturing():
         return None
+    if condition is not None and not (torch.is_tensor(condition) and condition.device == x0.device):
+        return None                                        # (dictionaries of observations, host tensors: not a static buffer -- eager)
     if agent.__dict__.get("_cdx_graph_off"):
         return None
     net = agent.model["diffusion"]

@@ -2411,6 +2411,34 @@ def test_headline_batch_takes_the_grouped_program_and_matches_the_reference(amd_
     assert runtime2.group_factor(256) == 4 and runtime2.group_factor(200) == 4 and runtime2.group_factor(128) == 1 and runtime2.group_factor(300) == 1
 
 
+def test_seeded_device_runs_do_not_depend_on_the_executor(amd_lib, monkeypatch):
+    """with torch.manual_seed on the ROCm device the same request must give the same trajectories whether the
+    whole-loop launch serves it or the per-step host loop does (``requires_grad=True``, a forced fallback): both draw the loop's noise
+    as ONE (n, ...) launch after the initial draw (_NoiseFeed.many / .reserve).  Stochastic solvers: DDPM and SDE-DPM-Solver++ steps."""
+    from cleandiffuser_amd.engine import dispatch
+    agent, _ = cases.build(amd_lib, "janner_cfg2_ddim", device=DEV)
+    prior = torch.zeros(6, 32, 23, device=DEV)
+    prior[:, 0, :17] = torch.randn(6, 17, generator=torch.Generator().manual_seed(4)).to(DEV)
+    for solver in ("ddpm", "sde_dpmsolver++_1"):
+        kw = dict(solver=solver, n_samples=6, sample_steps=8, temperature=0.7)
+        fused = _spy_launches(monkeypatch)
+        torch.manual_seed(31)
+        a, _ = agent.sample(prior, **kw)
+        assert fused["n"] == 1
+        torch.manual_seed(31)
+        b, _ = agent.sample(prior, requires_grad=True, **kw)              # the per-step executor (autograd through the loop)
+        monkeypatch.setattr(dispatch, "try_fused_raw", lambda *a_, **k_: None)
+        monkeypatch.setattr(dispatch, "try_fused_sample", lambda *a_, **k_: None)
+        torch.manual_seed(31)
+        c, _ = agent.sample(prior, **kw)                                 # the same host loop, gradients off
+        monkeypatch.undo()
+        np.testing.assert_allclose(b.detach().cpu().numpy(), a.cpu().numpy(), rtol=2e-4, atol=2e-4, err_msg=solver)
+        np.testing.assert_allclose(c.cpu().numpy(), a.cpu().numpy(), rtol=2e-4, atol=2e-4, err_msg=solver)
+        torch.manual_seed(32)
+        d, _ = agent.sample(prior, **kw)
+        assert float((d - a).abs().max()) > 1e-2                         # (another seed: other draws)
+
+
 # ---- round 5: the default route fails loudly, never NaN-ly (VERDICT r4 weak #8 / next #7, ADVICE r4) ----
 def test_device_query_reports_a_whole_mi355x(amd_lib, monkeypatch):
     """cdx_device_query: compute units / architecture from hipDeviceProp_t, the XCD count measured by a probe launch.  The split / grouped
