@@ -7,8 +7,10 @@
 // cleandiffuser/nn_diffusion/dit.py:31-36,49 and idqlmlp.py:12-18 when the batch is large (M = batch x tokens >> 256):
 // there the right shape is a classic tiled GEMM, not the one-workgroup-per-trajectory program kernel.
 //
-// Kernel: 128 x 128 x 16 block tile, 4 wave64, each wave a 64 x 64 sub-tile as 2 x 2 v_mfma_f32_32x32x2_f32 (exact fp32,
-// fmaf-chain numerics).  A and W tiles are fetched K-contiguous (float4 per lane), transposed through LDS into
+// Kernel: 128 x 128 x 16 block tile of v_mfma_f32_32x32x2_f32 blocks (exact fp32) -- 8 wave64 with 2 x 1 blocks each (round 5, the
+// default where loads are unguarded) or 4 wave64 with 2 x 2 each; 64 x 64 x 32 tiles (4 waves, one block each) for small problems.
+// K is summed in BLOCKS (16 / 32 k values per block sum, block sums added to a running total) instead of one sequential fma chain
+// (round 5: every GEMM at or below ATen's error against float64).  A and W tiles are fetched K-contiguous (float4 per lane), transposed through LDS into
 // [k][row] so MFMA operand reads are conflict-free ds_read_b32, next tile prefetched into registers under the MFMAs.
 // Epilogue (fused, per element): + bias[n] -> activation -> * gate[m / rows_per_gate][n] -> + residual[m][n]
 // -> + table[m % table_rows][n]  (adaLN gates, residual streams and the positional table of DiT never take a pass of
@@ -17,6 +19,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 #include "../../include/cdx.h"
 #include "cdx_ops2.h"
@@ -30,6 +33,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define GM_THREADS 256
 #ifndef GM_STAGE_AT
 #define GM_STAGE_AT (BK - 4)                   // k pair of the first half behind which tile t + 1 is parked in LDS (A/B builds)
+#endif
+#ifndef CDX_GEMM_W8_DEFAULT
+#define CDX_GEMM_W8_DEFAULT 1               // the 8-wave shape of the 128 x 128 tile by default (same-box A/B: profiles/r05_gemm_w8_ab.txt)
 #endif
 #ifndef CDX_GEMM_KBLOCK
 #define CDX_GEMM_KBLOCK 1                     // 0: one sequential fma chain over K per element (rounds 1-4; A/B builds)
@@ -117,17 +123,17 @@ template <int ACT>
 __device__ __forceinline__ float gm_act_t(float x) { return gm_act(x, ACT); }
 
 // Epilogue of one wave's (32 WT) x (32 WT) sub-tile.  D fragment of 32x32x2: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
-template <int ACT, int WT>
-__device__ __forceinline__ void gm_epilogue(const cdx_gemm_args& g, const f32x16 (&acc)[WT][WT], int row0, int col0, int lr, int lk) {
+template <int ACT, int WTM, int WTN>
+__device__ __forceinline__ void gm_epilogue(const cdx_gemm_args& g, const f32x16 (&acc)[WTM][WTN], int row0, int col0, int lr, int lk) {
     const float inv_gate = g.gate ? 1.0f / (float)g.rows_per_gate : 0.f;
     const float inv_tab = g.table ? 1.0f / (float)g.table_rows : 0.f;
 #pragma unroll
-    for (int ni = 0; ni < WT; ++ni) {
+    for (int ni = 0; ni < WTN; ++ni) {
         const int n = col0 + ni * 32 + lr;
         if (n >= g.N) continue;
         const float bias = g.bias ? g.bias[n] : 0.f;
 #pragma unroll
-        for (int mi = 0; mi < WT; ++mi) {
+        for (int mi = 0; mi < WTM; ++mi) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = row0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
@@ -154,22 +160,22 @@ __device__ __forceinline__ void gm_epilogue(const cdx_gemm_args& g, const f32x16
 // patch so that a lane ends up with 4 consecutive columns -> gate / residual / table are read and C is written with 16-byte
 // accesses, loads are unconditional (clamped addresses) and issued together, only the store is predicated.
 #define GM_EP_LD 36
-template <int ACT, int WT>
-__device__ __forceinline__ void gm_epilogue_fast(const cdx_gemm_args& g, const f32x16 (&acc)[WT][WT], float* __restrict__ patch,
+template <int ACT, int WTM, int WTN>
+__device__ __forceinline__ void gm_epilogue_fast(const cdx_gemm_args& g, const f32x16 (&acc)[WTM][WTN], float* __restrict__ patch,
                                                  int row0, int col0, int lane) {
     const int lr = lane & 31, lk = lane >> 5;
     const int prow = lane >> 3, pc4 = (lane & 7) * 4;
     const float inv_gate = g.gate ? 1.0f / (float)g.rows_per_gate : 0.f;
     const float inv_tab = g.table ? 1.0f / (float)g.table_rows : 0.f;
 #pragma unroll
-    for (int ni = 0; ni < WT; ++ni) {
+    for (int ni = 0; ni < WTN; ++ni) {
         const int nb = col0 + ni * 32;
         const float bias = (g.bias && nb + lr < g.N) ? g.bias[nb + lr] : 0.f;
         const int n = nb + pc4;
         const bool n_ok = n < g.N;
         const int nc = n_ok ? n : 0;
 #pragma unroll
-        for (int mi = 0; mi < WT; ++mi) {
+        for (int mi = 0; mi < WTM; ++mi) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 patch[((r & 3) + 8 * (r >> 2) + 4 * lk) * GM_EP_LD + lr] = gm_act_t<ACT>(acc[mi][ni][r] + bias);
@@ -209,11 +215,11 @@ __device__ __forceinline__ void gm_epilogue_fast(const cdx_gemm_args& g, const f
     }
 }
 
-template <int ACT, int WT>
-__device__ __forceinline__ void gm_epilogue_any(const cdx_gemm_args& g, const f32x16 (&acc)[WT][WT], float* patch, int row0, int col0,
+template <int ACT, int WTM, int WTN>
+__device__ __forceinline__ void gm_epilogue_any(const cdx_gemm_args& g, const f32x16 (&acc)[WTM][WTN], float* patch, int row0, int col0,
                                                 int lane, bool fast) {
-    if (fast) gm_epilogue_fast<ACT, WT>(g, acc, patch, row0, col0, lane);
-    else gm_epilogue<ACT, WT>(g, acc, row0, col0, lane & 31, lane >> 5);
+    if (fast) gm_epilogue_fast<ACT, WTM, WTN>(g, acc, patch, row0, col0, lane);
+    else gm_epilogue<ACT, WTM, WTN>(g, acc, row0, col0, lane & 31, lane >> 5);
 }
 
 // total += block sum, as 8 packed adds (v_pk_add_f32) per 32 x 32 block
@@ -238,9 +244,16 @@ __device__ __forceinline__ void gm_stamp(int slot) {
 // only feed outputs that are never stored).  !FAST: fully guarded scalar loads (K = 29 input projections and the like).
 // WT = MFMA tiles per wave per dimension: 2 -> 128 x 128 x 16 workgroup tile (throughput shape), 1 -> 64 x 64 x 32 (few rows:
 // four times the workgroups, a quarter of the MFMA time per barrier -- the launches of classifier guidance and small batches).
-template <bool FAST, int WT, bool CONV>
-__global__ __launch_bounds__(GM_THREADS, (WT == 2 ? 3 : 4)) void cdx_gemm_kernel(const cdx_gemm_args g, const int fast_ep,
-                                                                                const int k_split, const int xcd_order) {
+// NW = wave64 per workgroup: 4 (each wave a WT x WT grid of 32 x 32 blocks), or -- round 5, WT = 2 only -- 8: each wave 2 x 1 blocks of the
+// same 128 x 128 tile.  The 8-wave shape exists for the K-blocked accumulation: a wave's block accumulators (32 registers) AND its totals
+// (32) fit 128 registers, so two workgroups = four waves per SIMD stay resident, the block sums run over TWO K tiles (32 k values)
+// before they are flushed -- half the flushes per MFMA -- and the flush bubbles of one wave are covered by three others.
+template <bool FAST, int WT, bool CONV, int NW = 4>
+__global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (WT == 2 ? 3 : 4))) void cdx_gemm_kernel(const cdx_gemm_args g, const int fast_ep,
+                                                                                             const int k_split, const int xcd_order) {
+    static_assert(NW == 4 || (NW == 8 && WT == 2), "8 waves: the 128 x 128 tile only");
+    constexpr int THREADS = 64 * NW;
+    constexpr int WTM = WT, WTN = NW == 8 ? 1 : WT;      // 32 x 32 blocks per wave (rows x columns)
     constexpr int BMN = 64 * WT;                  // rows of A == rows of W per tile
     constexpr int BK = WT == 2 ? 16 : 32;          // K tile
     // Global -> LDS staging map (round 4): a wave's load covers FEW rows in FULL 64 / 128-byte runs -- thread -> (row r0 + i * RPI, k
@@ -248,12 +261,12 @@ __global__ __launch_bounds__(GM_THREADS, (WT == 2 ? 3 : 4)) void cdx_gemm_kernel
     // an eighth of the cache lines per instruction through the CU's memory pipe, which is what the co-resident workgroups' epilogue
     // stores queue behind (profiles/r04_gemm_direct_epilogue_ab.txt).  LD: the transposed ds_write_b32 of a 32-lane half hit 32 banks.
     constexpr int QPR = BK / 4;                    // float4 quads per row and K tile
-    constexpr int RPI = GM_THREADS / QPR;          // rows one load of the whole workgroup covers
-    constexpr int NLD = BMN / RPI;                 // loads per operand and thread
-    static_assert(NLD == 2, "two float4 per operand and thread");
+    constexpr int RPI = THREADS / QPR;             // rows one load of the whole workgroup covers
+    constexpr int NLD = BMN / RPI;                 // loads per operand and thread (2; 1 in the 8-wave shape)
+    static_assert(NLD == 2 || (NW == 8 && NLD == 1), "two float4 per operand and thread (one with 8 waves)");
     constexpr int LD = WT == 2 ? BMN + 2 : BMN + 1;
-    // one LDS arena: two stages of A/B staging tiles [k][row] during the K loop, then 4 wave-private 32 x 36 transposition patches
-    __shared__ __attribute__((aligned(16))) float smem[(4 * BK * LD > 4 * 32 * GM_EP_LD) ? 4 * BK * LD : 4 * 32 * GM_EP_LD];
+    // one LDS arena: two stages of A/B staging tiles [k][row] during the K loop, then NW wave-private 32 x 36 transposition patches
+    __shared__ __attribute__((aligned(16))) float smem[(4 * BK * LD > NW * 32 * GM_EP_LD) ? 4 * BK * LD : NW * 32 * GM_EP_LD];
     float (*As)[LD] = reinterpret_cast<float (*)[LD]>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_m = (g.M + BMN - 1) / BMN, tiles_n = (g.N + BMN - 1) / BMN;
@@ -271,11 +284,11 @@ __global__ __launch_bounds__(GM_THREADS, (WT == 2 ? 3 : 4)) void cdx_gemm_kernel
     const int q4 = (tid % QPR) * 4, r0 = tid / QPR;     // this thread stages k quad q4 / 4 of rows r0 and r0 + RPI
 
     gm_stamp(0);
-    f32x16 acc[WT][WT];
+    f32x16 acc[WTM][WTN];
 #pragma unroll
-    for (int i = 0; i < WT; ++i)
+    for (int i = 0; i < WTM; ++i)
 #pragma unroll
-        for (int j = 0; j < WT; ++j)
+        for (int j = 0; j < WTN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -303,7 +316,9 @@ __global__ __launch_bounds__(GM_THREADS, (WT == 2 ? 3 : 4)) void cdx_gemm_kernel
     const float conv_inv_cin = conv ? 1.0f / (float)g.conv_cin : 0.f;
     // The validity of a conv tap is applied when the registers are parked in LDS, NOT at load time: a select right behind the load
     // makes hipcc wait for it (s_waitcnt vmcnt(0) in the middle of the MFMA stream: -5..-17 % measured on the large GEMMs).
-    bool cok[NLD] = {true, true};
+    bool cok[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) cok[i] = true;
     auto fetch = [&](int kt) {                           // global -> registers: k quad q4 of this thread's two rows
         const int k = kt + q4;
         if (FAST) {
@@ -342,7 +357,7 @@ __global__ __launch_bounds__(GM_THREADS, (WT == 2 ? 3 : 4)) void cdx_gemm_kernel
         }
     };
 
-    const int wm = (wave >> 1) * (32 * WT), wn = (wave & 1) * (32 * WT);
+    const int wm = NW == 8 ? (wave >> 2) * 64 : (wave >> 1) * (32 * WT), wn = NW == 8 ? (wave & 3) * 32 : (wave & 1) * (32 * WT);
     const int lr = lane & 31, lk = lane >> 5;
     const int nk_all = (g.K + BK - 1) / BK;
     const int per = (nk_all + k_split - 1) / k_split;    // K tiles per slice
@@ -363,6 +378,44 @@ __global__ __launch_bounds__(GM_THREADS, (WT == 2 ? 3 : 4)) void cdx_gemm_kernel
 #pragma unroll
         for (int r = 0; r < 16; ++r) blk[i][r] = 0.f;
 #endif
+#if CDX_GEMM_KBLOCK
+    if constexpr (NW == 8) {
+        // 8-wave shape: two row blocks x one column block per wave = two independent chains; the block accumulators run over TWO K
+        // tiles (the second tile continues the chains of the first), then both are flushed into the totals
+        auto tile8 = [&](int t, auto first) {
+            const float (*Ac)[LD] = As + (t & 1) * (2 * BK);
+            const float (*Bc)[LD] = Ac + BK;
+            float av[2] = {Ac[lk][wm + lr], Ac[lk][wm + 32 + lr]}, bv = Bc[lk][wn + lr];
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) {
+                float na[2] = {0.f, 0.f}, nb = 0.f;
+                if (kk + 2 < BK) { na[0] = Ac[kk + 2 + lk][wm + lr]; na[1] = Ac[kk + 2 + lk][wm + 32 + lr]; nb = Bc[kk + 2 + lk][wn + lr]; }
+                if (decltype(first)::value && kk == 0) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) blk[i][r] = 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) blk[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv, blk[i], 0, 0, 0);
+                if (kk == BK / 2 - 2 && t + 1 < nk) {        // mid-tile: park tile t + 1 in the other stage, request tile t + 2
+                    stage((t + 1) & 1);
+                    if (t + 2 < nk) fetch(kt0 + (t + 2) * BK);
+                }
+                av[0] = na[0]; av[1] = na[1]; bv = nb;
+            }
+            __syncthreads();                             // stage (t+1)&1 complete, stage t&1 free for tile t + 2
+        };
+        for (int t = 0; t < nk; t += 2) {
+            tile8(t, std::true_type{});
+            if (t + 1 < nk) tile8(t + 1, std::false_type{});
+#pragma unroll
+            for (int i = 0; i < 2; ++i) gm_flush(acc[i][0], blk[i]);
+        }
+    } else
+#else
+    static_assert(NW == 4, "the 8-wave shape exists for the K-blocked accumulation");
+#endif
     for (int t = 0; t < nk; ++t) {
         const float (*Ac)[LD] = As + (t & 1) * (2 * BK);
         const float (*Bc)[LD] = Ac + BK;
@@ -372,11 +425,12 @@ __global__ __launch_bounds__(GM_THREADS, (WT == 2 ? 3 : 4)) void cdx_gemm_kernel
         // the sqrt(K) of one sequential fma chain (profiles/r05_dit_error_budget.txt: K = 320 3.1e-6 -> 0.8e-6 of the output's rms,
         // K = 1280 with gate / residual 9.6e-7 -> 2.5e-7; ATen's CPU kernels on the same inputs: 2.0e-6 / 2.7e-7).  Registers: the
         // wave's rows are walked in WT halves so that only WT block accumulators (32 registers at WT = 2) live next to the 64 of the
-        // total (154 VGPRs as before, three workgroups per CU).  Cost, same-box A/B against the sequential chain (profiles/
-        // r05_gemm_kblock_ab.txt): config 4 -3.3 %, config 3 -3.7 %, ChiTransformer -3.0 %, config 5 -6.1 % -- the flush (s_nop for the
-        // last MFMA + 16 v_pk_add_f32 per half) is issue time the wave's MFMAs do not get.  Two attempts to hide it were measured / built
-        // and dropped: 8-MFMA single-chain segments with the flush under the next segment (kb2: -4.5..-6.6 %), and a software-pipelined
-        // flush (hipcc renames the restarted accumulator: four live sets, 40-50 spilled VGPRs).
+        // total (154 VGPRs as before, three workgroups per CU).  In THIS 4-wave shape the flush costs 3-6 % against the sequential chain
+        // (profiles/r05_gemm_kblock_ab.txt): s_nop for the last MFMA + 16 v_pk_add_f32 per half are issue time the wave's MFMAs do not
+        // get, and three waves per SIMD do not cover it.  Hiding it inside this shape was tried twice and dropped (single-chain segments:
+        // -4.5..-6.6 %; a software-pipelined flush: hipcc renames the restarted accumulator, 40-50 spilled VGPRs); the 8-wave shape above
+        // is what won the cost back (0..-2 %, profiles/r05_gemm_w8_ab.txt).  This path serves the guarded-load (!FAST) launches and
+        // CDX_GEMM_W8=0, and -- WT = 1 -- the 64 x 64 tiles.
 #pragma unroll
         for (int h = 0; h < WT; ++h) {
 #pragma unroll
@@ -437,7 +491,7 @@ __global__ __launch_bounds__(GM_THREADS, (WT == 2 ? 3 : 4)) void cdx_gemm_kernel
         __syncthreads();                                 // stage (t+1)&1 complete, stage t&1 free for tile t + 2
     }
 
-    asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[WT - 1][WT - 1][15]));
+    asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[WTM - 1][WTN - 1][15]));
     gm_stamp(2);
     // (the loop's last barrier already separates the final LDS reads from the patches written below)
     // fused epilogue, one specialisation per activation (the branch is uniform; only the taken copy touches the I-cache)
@@ -448,19 +502,19 @@ __global__ __launch_bounds__(GM_THREADS, (WT == 2 ? 3 : 4)) void cdx_gemm_kernel
         cdx_gemm_args gp = g;
         gp.C = g.partial + (size_t)slice * g.M * g.N; gp.ldc = g.N;
         gp.bias = nullptr; gp.gate = nullptr; gp.residual = nullptr; gp.table = nullptr;
-        gm_epilogue_any<CDX_ACT_NONE, WT>(gp, acc, patch, row0, col0, lane, (g.N % 4 == 0));
+        gm_epilogue_any<CDX_ACT_NONE, WTM, WTN>(gp, acc, patch, row0, col0, lane, (g.N % 4 == 0));
         gm_stamp(3);
         return;
     }
     switch (g.act) {
-        case CDX_ACT_MISH: gm_epilogue_any<CDX_ACT_MISH, WT>(g, acc, patch, row0, col0, lane, fe); break;
-        case CDX_ACT_GELU_ERF: gm_epilogue_any<CDX_ACT_GELU_ERF, WT>(g, acc, patch, row0, col0, lane, fe); break;
-        case CDX_ACT_LEAKY: gm_epilogue_any<CDX_ACT_LEAKY, WT>(g, acc, patch, row0, col0, lane, fe); break;
-        case CDX_ACT_SILU: gm_epilogue_any<CDX_ACT_SILU, WT>(g, acc, patch, row0, col0, lane, fe); break;
-        case CDX_ACT_RELU: gm_epilogue_any<CDX_ACT_RELU, WT>(g, acc, patch, row0, col0, lane, fe); break;
-        case CDX_ACT_GELU_TANH: gm_epilogue_any<CDX_ACT_GELU_TANH, WT>(g, acc, patch, row0, col0, lane, fe); break;
-        case CDX_ACT_TANH: gm_epilogue_any<CDX_ACT_TANH, WT>(g, acc, patch, row0, col0, lane, fe); break;
-        default: gm_epilogue_any<CDX_ACT_NONE, WT>(g, acc, patch, row0, col0, lane, fe); break;
+        case CDX_ACT_MISH: gm_epilogue_any<CDX_ACT_MISH, WTM, WTN>(g, acc, patch, row0, col0, lane, fe); break;
+        case CDX_ACT_GELU_ERF: gm_epilogue_any<CDX_ACT_GELU_ERF, WTM, WTN>(g, acc, patch, row0, col0, lane, fe); break;
+        case CDX_ACT_LEAKY: gm_epilogue_any<CDX_ACT_LEAKY, WTM, WTN>(g, acc, patch, row0, col0, lane, fe); break;
+        case CDX_ACT_SILU: gm_epilogue_any<CDX_ACT_SILU, WTM, WTN>(g, acc, patch, row0, col0, lane, fe); break;
+        case CDX_ACT_RELU: gm_epilogue_any<CDX_ACT_RELU, WTM, WTN>(g, acc, patch, row0, col0, lane, fe); break;
+        case CDX_ACT_GELU_TANH: gm_epilogue_any<CDX_ACT_GELU_TANH, WTM, WTN>(g, acc, patch, row0, col0, lane, fe); break;
+        case CDX_ACT_TANH: gm_epilogue_any<CDX_ACT_TANH, WTM, WTN>(g, acc, patch, row0, col0, lane, fe); break;
+        default: gm_epilogue_any<CDX_ACT_NONE, WTM, WTN>(g, acc, patch, row0, col0, lane, fe); break;
     }
     gm_stamp(3);
 }
@@ -1318,17 +1372,29 @@ static int gm_launch(const cdx_gemm_args* g_in, void* hip_stream, bool force_sma
                         (!g->residual || g->ldr % 4 == 0) && (ep_ptrs % 16 == 0);
     static const char* env_x = getenv("CDX_GEMM_XCD_ORDER");      // tuning hook: 1 = one contiguous tile range per XCD
     const int xcd_order = env_x ? atoi(env_x) : 0;    // measured: +-2 % either way once tiles are walked n-fastest
-    const dim3 grid(tiles * k_split), block(GM_THREADS);
+    // 128 x 128 tiles with unguarded loads: the 8-wave shape (K-blocked sums over two K tiles per flush, four waves per SIMD).
+    // CDX_GEMM_W8=0: the 4-wave shape everywhere (A/B hook).
+    static const char* env_w8 = getenv("CDX_GEMM_W8");
+    const bool w8 = CDX_GEMM_KBLOCK && !small && vec && (env_w8 ? atoi(env_w8) != 0 : CDX_GEMM_W8_DEFAULT);
+    const dim3 grid(tiles * k_split), block(w8 ? 512 : GM_THREADS);
 #define GM_LAUNCH(F, W, C) hipLaunchKernelGGL((cdx_gemm_kernel<F, W, C>), grid, block, 0, s, *g, fast_ep, k_split, xcd_order)
+#if CDX_GEMM_KBLOCK
+#define GM_LAUNCH8(C) hipLaunchKernelGGL((cdx_gemm_kernel<true, 2, C, 8>), grid, block, 0, s, *g, fast_ep, k_split, xcd_order)
+#else
+#define GM_LAUNCH8(C) GM_LAUNCH(true, 2, C)
+#endif
     const bool cv = g->conv_taps > 0;
     if (small) {
         if (vec) { if (cv) GM_LAUNCH(true, 1, true); else GM_LAUNCH(true, 1, false); }
         else { if (cv) GM_LAUNCH(false, 1, true); else GM_LAUNCH(false, 1, false); }
+    } else if (w8) {
+        if (cv) GM_LAUNCH8(true); else GM_LAUNCH8(false);
     } else {
         if (vec) { if (cv) GM_LAUNCH(true, 2, true); else GM_LAUNCH(true, 2, false); }
         else { if (cv) GM_LAUNCH(false, 2, true); else GM_LAUNCH(false, 2, false); }
     }
 #undef GM_LAUNCH
+#undef GM_LAUNCH8
     if (k_split > 1 && defer_slices == nullptr) {
         const size_t total = (size_t)g->M * g->N;
         const bool v4 = fast_ep && ((uintptr_t)g->partial % 16 == 0);
