@@ -34,6 +34,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef GM_STAGE_AT
 #define GM_STAGE_AT (BK - 4)                   // k pair of the first half behind which tile t + 1 is parked in LDS (A/B builds)
 #endif
+#ifndef CDX_GEMM_W8_BK
+#define CDX_GEMM_W8_BK 16                      // K tile of the 8-wave shape: 16 (block sums over two tiles) or 32 (one tile = one block; dynamic LDS)
+#endif
 #ifndef CDX_GEMM_W8_DEFAULT
 #define CDX_GEMM_W8_DEFAULT 1               // the 8-wave shape of the 128 x 128 tile by default (same-box A/B: profiles/r05_gemm_w8_ab.txt)
 #endif
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (WT == 2 ? 3 : 4))) void cd
     constexpr int THREADS = 64 * NW;
     constexpr int WTM = WT, WTN = NW == 8 ? 1 : WT;      // 32 x 32 blocks per wave (rows x columns)
     constexpr int BMN = 64 * WT;                  // rows of A == rows of W per tile
-    constexpr int BK = WT == 2 ? 16 : 32;          // K tile
+    constexpr int BK = NW == 8 ? CDX_GEMM_W8_BK : (WT == 2 ? 16 : 32);          // K tile
     // Global -> LDS staging map (round 4): a wave's load covers FEW rows in FULL 64 / 128-byte runs -- thread -> (row r0 + i * RPI, k
     // quad q): 16 rows x 64 B per load instruction (128 x 128 tile), 8 rows x 128 B (64 x 64) -- instead of 64 rows x 16 B: a quarter /
     // an eighth of the cache lines per instruction through the CU's memory pipe, which is what the co-resident workgroups' epilogue
@@ -266,7 +269,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (WT == 2 ? 3 : 4))) void cd
     static_assert(NLD == 2 || (NW == 8 && NLD == 1), "two float4 per operand and thread (one with 8 waves)");
     constexpr int LD = WT == 2 ? BMN + 2 : BMN + 1;
     // one LDS arena: two stages of A/B staging tiles [k][row] during the K loop, then NW wave-private 32 x 36 transposition patches
-    __shared__ __attribute__((aligned(16))) float smem[(4 * BK * LD > NW * 32 * GM_EP_LD) ? 4 * BK * LD : NW * 32 * GM_EP_LD];
+    constexpr int SMEM_FLOATS = (4 * BK * LD > NW * 32 * GM_EP_LD) ? 4 * BK * LD : NW * 32 * GM_EP_LD;
+#if CDX_GEMM_W8_BK == 32
+    // (66.5 KB for the 8-wave shape with 32-wide K tiles: past the 64 KB of static LDS -- dynamic, requested by the launcher)
+    extern __shared__ __attribute__((aligned(16))) float dyn_smem[];
+    __shared__ __attribute__((aligned(16))) float sta_smem[NW == 8 ? 4 : SMEM_FLOATS];
+    float* smem = NW == 8 ? dyn_smem : sta_smem;
+#else
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+#endif
     float (*As)[LD] = reinterpret_cast<float (*)[LD]>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_m = (g.M + BMN - 1) / BMN, tiles_n = (g.N + BMN - 1) / BMN;
@@ -406,9 +417,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (WT == 2 ? 3 : 4))) void cd
             }
             __syncthreads();                             // stage (t+1)&1 complete, stage t&1 free for tile t + 2
         };
-        for (int t = 0; t < nk; t += 2) {
+        for (int t = 0; t < nk; t += (BK == 32 ? 1 : 2)) {
             tile8(t, std::true_type{});
-            if (t + 1 < nk) tile8(t + 1, std::false_type{});
+            if (BK != 32 && t + 1 < nk) tile8(t + 1, std::false_type{});
 #pragma unroll
             for (int i = 0; i < 2; ++i) gm_flush(acc[i][0], blk[i]);
         }
@@ -1332,14 +1343,20 @@ static int gm_launch(const cdx_gemm_args* g_in, void* hip_stream, bool force_sma
     const int small_below = env_t ? atoi(env_t) : (g->partial != nullptr && g->partial_slices > 1 ? 192 : 520);
     // the 64 x 64 variant stages 32-wide K tiles: with K % 32 != 0 but K % 16 == 0 the 128 x 128 kernel keeps its unguarded loads
     const bool small = force_small || (tiles_big < small_below && (g->K % 32 == 0 || g->K % 16 != 0));
-    const int bmn = small ? 64 : 128, bk = small ? 32 : 16;
+    // 128 x 128 tiles with unguarded loads take the 8-wave shape (K-blocked sums; four waves per SIMD); CDX_GEMM_W8=0: the 4-wave
+    // shape everywhere (A/B hook).  Decided HERE because the K tile (hence the split-K arithmetic below) follows the shape.
+    static const char* env_w8 = getenv("CDX_GEMM_W8");
+    const bool aligned16 = (g->lda % 4 == 0) && (g->ldw % 4 == 0) && (((uintptr_t)g->A | (uintptr_t)g->W) % 16 == 0) &&
+                           (g->conv_taps == 0 || g->conv_cin % 4 == 0);
+    const bool w8 = CDX_GEMM_KBLOCK && !small && aligned16 && g->K % CDX_GEMM_W8_BK == 0 && g->K % 16 == 0 &&
+                    (env_w8 ? atoi(env_w8) != 0 : CDX_GEMM_W8_DEFAULT);
+    const int bmn = small ? 64 : 128, bk = small ? 32 : (w8 ? CDX_GEMM_W8_BK : 16);
     const int tiles = ((g->M + bmn - 1) / bmn) * ((g->N + bmn - 1) / bmn);
     if (g->conv_taps < 0 || (g->conv_taps > 0 && (g->conv_cin <= 0 || g->conv_lin <= 0 || g->conv_lout <= 0 || g->conv_stride <= 0 ||
                                                    g->K != g->conv_taps * g->conv_cin || g->M % g->conv_lout != 0))) {
         cdx_set_err("cdx_gemm_f32: inconsistent implicit-conv description"); return CDX_EINVAL;
     }
-    const bool vec = (g->K % bk == 0) && (g->lda % 4 == 0) && (g->ldw % 4 == 0) &&
-                     (((uintptr_t)g->A | (uintptr_t)g->W) % 16 == 0) && (g->conv_taps == 0 || g->conv_cin % 4 == 0);
+    const bool vec = (g->K % bk == 0) && aligned16;
     hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
     // split-K when the tile count cannot fill the chip and K is long enough to pay for the second pass
     int k_split = 1;
@@ -1372,14 +1389,19 @@ static int gm_launch(const cdx_gemm_args* g_in, void* hip_stream, bool force_sma
                         (!g->residual || g->ldr % 4 == 0) && (ep_ptrs % 16 == 0);
     static const char* env_x = getenv("CDX_GEMM_XCD_ORDER");      // tuning hook: 1 = one contiguous tile range per XCD
     const int xcd_order = env_x ? atoi(env_x) : 0;    // measured: +-2 % either way once tiles are walked n-fastest
-    // 128 x 128 tiles with unguarded loads: the 8-wave shape (K-blocked sums over two K tiles per flush, four waves per SIMD).
-    // CDX_GEMM_W8=0: the 4-wave shape everywhere (A/B hook).
-    static const char* env_w8 = getenv("CDX_GEMM_W8");
-    const bool w8 = CDX_GEMM_KBLOCK && !small && vec && (env_w8 ? atoi(env_w8) != 0 : CDX_GEMM_W8_DEFAULT);
     const dim3 grid(tiles * k_split), block(w8 ? 512 : GM_THREADS);
+    const size_t lds8 = CDX_GEMM_W8_BK == 32 ? (size_t)4 * 32 * 130 * sizeof(float) : 0;
+    if (w8 && lds8) {
+        static bool raised[2] = {false, false};
+        const int ci = g->conv_taps > 0 ? 1 : 0;
+        if (!raised[ci]) {
+            const void* fn = ci ? reinterpret_cast<const void*>(cdx_gemm_kernel<true, 2, true, 8>) : reinterpret_cast<const void*>(cdx_gemm_kernel<true, 2, false, 8>);
+            raised[ci] = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8) == hipSuccess;
+        }
+    }
 #define GM_LAUNCH(F, W, C) hipLaunchKernelGGL((cdx_gemm_kernel<F, W, C>), grid, block, 0, s, *g, fast_ep, k_split, xcd_order)
 #if CDX_GEMM_KBLOCK
-#define GM_LAUNCH8(C) hipLaunchKernelGGL((cdx_gemm_kernel<true, 2, C, 8>), grid, block, 0, s, *g, fast_ep, k_split, xcd_order)
+#define GM_LAUNCH8(C) hipLaunchKernelGGL((cdx_gemm_kernel<true, 2, C, 8>), grid, block, lds8, s, *g, fast_ep, k_split, xcd_order)
 #else
 #define GM_LAUNCH8(C) GM_LAUNCH(true, 2, C)
 #endif
