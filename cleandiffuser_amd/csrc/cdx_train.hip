@@ -20,6 +20,7 @@
 // does the same; the order is not fixed, gradients of two identical steps agree to ~1e-7 relative).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "../../include/cdx.h"
 
@@ -215,81 +216,139 @@ __global__ __launch_bounds__(256) void cdx_layernorm_bwd_kernel(const cdx_ln_bwd
 }
 
 // ------------------------------------------------------------------------------------------------
-// Backward of the softmax(Q K^T scale) V core of nn.MultiheadAttention (dit.py:20, 34) for T <= 64 tokens: one workgroup per
-// (sample, head); P is recomputed from the packed qkv rows, nothing but qkv is saved by the forward.
-//   dV = P^T dO,  dP = dO V^T,  dS = P o (dP - rowsum(P o dP)) scale,  dQ = dS K,  dK = dS^T Q
-// Plain fp32 FMA loops over LDS tiles (a training-only kernel: 0.66 M MAC per (sample, head) at T = 64, head_dim = 32).
+// The softmax(Q K^T scale + mask) -> dropout -> . V core of nn.MultiheadAttention in TRAINING, forward and backward, for <= 64 query
+// and <= 64 key tokens: self-attention on packed qkv rows (dit.py:20,34), the causal self-attention and the memory cross-attention of
+// nn.TransformerDecoderLayer (chitransformer.py:108-121,148-154).  One workgroup per (sample, head); Q / K / V / dO come through
+// separate pointers and row strides, so packed and split projections are the same kernel.  Nothing but the operands is saved by the
+// forward: the backward recomputes P.
+//   forward:   P = softmax(S),  Pd = P o keep,  O = Pd V
+//   backward:  dV = Pd^T dO,  dPd = dO V^T,  dP = dPd o keep,  dS = P o (dP - rowsum(P o dP)) scale,  dQ = dS K,  dK = dS^T Q
+// `keep` holds 0 or 1 / (1 - p) per (sample, head, query, key): the dropout mask is DRAWN by the caller (torch's device generator, so
+// that seeding and HIP-graph replay behave as for every other draw of the training step) and applied here.
+// Plain fp32 FMA loops over LDS tiles (training-only kernels: 0.66 M MAC per (sample, head) at 64 tokens, head_dim 32).
 // ------------------------------------------------------------------------------------------------
 #define AB_T 64
 #define AB_D 64
-__global__ __launch_bounds__(256) void cdx_attention_bwd_kernel(const cdx_attn_bwd_args a) {
-    extern __shared__ float ab_lds[];                      // 4 x T x (dh + 1) operand tiles, 2 x T x (T + 1) score tiles
+struct mha_tiles {
+    float *Qs, *Ks, *Vs, *dOs, *Ps, *dPs;
+    int ldd, ldt;
+};
+__device__ __forceinline__ mha_tiles mha_carve(float* lds, int Tq, int Tk, int dh, bool bwd) {
+    mha_tiles t;
+    t.ldd = dh + 1; t.ldt = Tk + 1;
+    t.Qs = lds;
+    t.Ks = t.Qs + Tq * t.ldd;
+    t.Vs = t.Ks + Tk * t.ldd;
+    t.dOs = t.Vs + Tk * t.ldd;
+    t.Ps = t.dOs + (bwd ? Tq * t.ldd : 0);
+    t.dPs = t.Ps + Tq * t.ldt;
+    return t;
+}
+static size_t mha_lds_bytes(int Tq, int Tk, int dh, bool bwd) {
+    return (size_t)((bwd ? 2 : 1) * Tq * (dh + 1) + 2 * Tk * (dh + 1) + (bwd ? 2 : 1) * Tq * (Tk + 1)) * sizeof(float);
+}
+// P(i, .) <- softmax over the Tk scores of row i (4 lanes per row); returns with the rows normalised
+__device__ __forceinline__ void mha_row_softmax(float* Ps, int ldt, int Tq, int Tk, int tid) {
+    const int i = tid >> 2, q = tid & 3;
+    if (i < Tq) {
+        float* row = Ps + i * ldt;
+        float mx = -3.0e38f;
+        for (int j = q; j < Tk; j += 4) mx = fmaxf(mx, row[j]);
+        mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+        float sum = 0.f;
+        for (int j = q; j < Tk; j += 4) { const float ex = __expf(row[j] - mx); row[j] = ex; sum += ex; }
+        sum += __shfl_xor(sum, 1, 64);
+        sum += __shfl_xor(sum, 2, 64);
+        const float inv = 1.0f / sum;
+        for (int j = q; j < Tk; j += 4) row[j] *= inv;
+    }
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void cdx_mha_train_kernel(const cdx_mha_train_args a) {
+    extern __shared__ float ab_lds[];
     const int tid = threadIdx.x;
     const int bh = blockIdx.x, b = bh / a.n_heads, h = bh - b * a.n_heads;
-    const int T = a.T, dh = a.head_dim, dm = a.n_heads * dh;
-    const int ldd = dh + 1, ldt = T + 1;
-    float* Qs = ab_lds;
-    float* Ks = Qs + T * ldd;
-    float* Vs = Ks + T * ldd;
-    float* dOs = Vs + T * ldd;
-    float* Ps = dOs + T * ldd;
-    float* dPs = Ps + T * ldt;
-#define Q(i, d) Qs[(i) * ldd + (d)]
-#define K(i, d) Ks[(i) * ldd + (d)]
-#define V(i, d) Vs[(i) * ldd + (d)]
-#define dO(i, d) dOs[(i) * ldd + (d)]
-#define P(i, j) Ps[(i) * ldt + (j)]
-#define dP(i, j) dPs[(i) * ldt + (j)]
-    const float* qkv = a.qkv + (size_t)b * T * 3 * dm + h * dh;
-    const float* dout = a.dout + (size_t)b * T * dm + h * dh;
-    float* dqkv = a.dqkv + (size_t)b * T * 3 * dm + h * dh;
-    for (int e = tid; e < T * dh; e += 256) {
+    const int Tq = a.Tq, Tk = a.Tk, dh = a.head_dim;
+    const mha_tiles t = mha_carve(ab_lds, Tq, Tk, dh, BWD);
+    const int ldd = t.ldd, ldt = t.ldt;
+#define Q(i, d) t.Qs[(i) * ldd + (d)]
+#define K(i, d) t.Ks[(i) * ldd + (d)]
+#define V(i, d) t.Vs[(i) * ldd + (d)]
+#define dO(i, d) t.dOs[(i) * ldd + (d)]
+#define P(i, j) t.Ps[(i) * ldt + (j)]
+#define dP(i, j) t.dPs[(i) * ldt + (j)]
+    const size_t qrow = (size_t)b * Tq, krow = (size_t)b * Tk;
+    const int hc = h * dh;
+    for (int e = tid; e < Tq * dh; e += 256) {
         const int i = e / dh, d = e - i * dh;
-        Q(i, d) = qkv[(size_t)i * 3 * dm + d];
-        K(i, d) = qkv[(size_t)i * 3 * dm + dm + d];
-        V(i, d) = qkv[(size_t)i * 3 * dm + 2 * dm + d];
-        dO(i, d) = dout[(size_t)i * dm + d];
+        Q(i, d) = a.q[(qrow + i) * a.ldq + hc + d];
+        if (BWD) dO(i, d) = a.dout[(qrow + i) * a.ldo + hc + d];
+    }
+    for (int e = tid; e < Tk * dh; e += 256) {
+        const int i = e / dh, d = e - i * dh;
+        K(i, d) = a.k[(krow + i) * a.ldk + hc + d];
+        V(i, d) = a.v[(krow + i) * a.ldv + hc + d];
     }
     __syncthreads();
-    for (int e = tid; e < T * T; e += 256) {               // S and dP
-        const int i = e / T, j = e - i * T;
+    for (int e = tid; e < Tq * Tk; e += 256) {             // S (and dPd)
+        const int i = e / Tk, j = e - i * Tk;
         float sacc = 0.f, pacc = 0.f;
-        for (int d = 0; d < dh; ++d) { sacc = fmaf(Q(i, d), K(j, d), sacc); pacc = fmaf(dO(i, d), V(j, d), pacc); }
-        P(i, j) = sacc * a.scale;
-        dP(i, j) = pacc;
+        for (int d = 0; d < dh; ++d) {
+            sacc = fmaf(Q(i, d), K(j, d), sacc);
+            if (BWD) pacc = fmaf(dO(i, d), V(j, d), pacc);
+        }
+        P(i, j) = sacc * a.scale + (a.mask ? a.mask[i * Tk + j] : 0.f);
+        if (BWD) dP(i, j) = pacc;
     }
     __syncthreads();
-    {                                                      // row softmax + delta: 4 lanes per row
+    mha_row_softmax(t.Ps, ldt, Tq, Tk, tid);
+    const float* keep = a.keep ? a.keep + (size_t)bh * Tq * Tk : nullptr;
+    if (!BWD) {
+        __syncthreads();
+        for (int e = tid; e < Tq * dh; e += 256) {         // O = (P o keep) V
+            const int i = e / dh, d = e - i * dh;
+            float o = 0.f;
+            for (int j = 0; j < Tk; ++j) o = fmaf(keep ? P(i, j) * keep[i * Tk + j] : P(i, j), V(j, d), o);
+            a.out[(qrow + i) * a.ldo + hc + d] = o;
+        }
+        return;
+    }
+    {                                                      // delta + dS: the same 4 lanes per row that normalised it
         const int i = tid >> 2, q = tid & 3;
-        if (i < T) {
-            float mx = -3.0e38f;
-            for (int j = q; j < T; j += 4) mx = fmaxf(mx, P(i, j));
-            mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
-            float sum = 0.f;
-            for (int j = q; j < T; j += 4) { const float ex = __expf(P(i, j) - mx); P(i, j) = ex; sum += ex; }
-            sum += __shfl_xor(sum, 1, 64);
-            sum += __shfl_xor(sum, 2, 64);
-            const float inv = 1.0f / sum;
+        if (i < Tq) {
             float dl = 0.f;
-            for (int j = q; j < T; j += 4) { const float p = P(i, j) * inv; P(i, j) = p; dl = fmaf(p, dP(i, j), dl); }
+            for (int j = q; j < Tk; j += 4) {
+                const float g = keep ? dP(i, j) * keep[i * Tk + j] : dP(i, j);      // dP = dPd o keep
+                dP(i, j) = g;
+                dl = fmaf(P(i, j), g, dl);
+            }
             dl += __shfl_xor(dl, 1, 64);
             dl += __shfl_xor(dl, 2, 64);
-            for (int j = q; j < T; j += 4) dP(i, j) = P(i, j) * (dP(i, j) - dl) * a.scale;     // dS
+            for (int j = q; j < Tk; j += 4) {
+                const float p = P(i, j);
+                dP(i, j) = p * (dP(i, j) - dl) * a.scale;                              // dS
+                if (keep) P(i, j) = p * keep[i * Tk + j];                              // Pd, what dV reads
+            }
         }
     }
     __syncthreads();
-    for (int e = tid; e < T * dh; e += 256) {
+    for (int e = tid; e < Tq * dh; e += 256) {
         const int i = e / dh, d = e - i * dh;
-        float dq = 0.f, dk = 0.f, dv = 0.f;
-        for (int j = 0; j < T; ++j) {
-            dq = fmaf(dP(i, j), K(j, d), dq);              // dQ[i] = sum_j dS[i][j] K[j]
+        float dq = 0.f;
+        for (int j = 0; j < Tk; ++j) dq = fmaf(dP(i, j), K(j, d), dq);             // dQ[i] = sum_j dS[i][j] K[j]
+        a.dq[(qrow + i) * a.lddq + hc + d] = dq;
+    }
+    for (int e = tid; e < Tk * dh; e += 256) {
+        const int i = e / dh, d = e - i * dh;
+        float dk = 0.f, dv = 0.f;
+        for (int j = 0; j < Tq; ++j) {
             dk = fmaf(dP(j, i), Q(j, d), dk);              // dK[i] = sum_j dS[j][i] Q[j]
-            dv = fmaf(P(j, i), dO(j, d), dv);              // dV[i] = sum_j P(j, i) dO[j]
+            dv = fmaf(P(j, i), dO(j, d), dv);              // dV[i] = sum_j Pd[j][i] dO[j]
         }
-        dqkv[(size_t)i * 3 * dm + d] = dq;
-        dqkv[(size_t)i * 3 * dm + dm + d] = dk;
-        dqkv[(size_t)i * 3 * dm + 2 * dm + d] = dv;
+        a.dk[(krow + i) * a.lddk + hc + d] = dk;
+        a.dv[(krow + i) * a.lddv + hc + d] = dv;
     }
 #undef Q
 #undef K
@@ -297,6 +356,41 @@ __global__ __launch_bounds__(256) void cdx_attention_bwd_kernel(const cdx_attn_b
 #undef dO
 #undef P
 #undef dP
+}
+
+static int mha_bad(const char* who, const char* what) {
+    char msg[160];
+    snprintf(msg, sizeof(msg), "%s%s", who, what);
+    cdx_set_err(msg);
+    return CDX_EINVAL;
+}
+static int mha_train_launch(const cdx_mha_train_args* a, bool bwd, void* hip_stream, const char* who) {
+    cdx_set_err("");
+    if (!a) { return mha_bad(who, ": null argument block"); }
+    if (a->B < 0 || a->Tq <= 0 || a->Tq > AB_T || a->Tk <= 0 || a->Tk > AB_T || a->head_dim <= 0 || a->head_dim > AB_D || a->n_heads <= 0) {
+        return mha_bad(who, ": Tq <= 64, Tk <= 64 and head_dim <= 64 required");
+    }
+    if (a->B == 0) return CDX_OK;
+    const int dm = a->n_heads * a->head_dim;
+    if (!a->q || !a->k || !a->v || (bwd ? (!a->dout || !a->dq || !a->dk || !a->dv) : !a->out)) {
+        return mha_bad(who, ": null pointer");
+    }
+    if (a->ldq < dm || a->ldk < dm || a->ldv < dm || a->ldo < dm || (bwd && (a->lddq < dm || a->lddk < dm || a->lddv < dm))) {
+        return mha_bad(who, ": a row stride is shorter than n_heads * head_dim");
+    }
+    if ((long long)a->B * a->n_heads > 0x7fffffffLL) { return mha_bad(who, ": batch too large for one launch"); }
+    const size_t lds = mha_lds_bytes(a->Tq, a->Tk, a->head_dim, bwd);      // <= 100 KB
+    static size_t raised[2] = {0, 0};
+    const void* fn = bwd ? reinterpret_cast<const void*>(cdx_mha_train_kernel<true>) : reinterpret_cast<const void*>(cdx_mha_train_kernel<false>);
+    if (lds > 48 * 1024 && lds > raised[bwd] && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
+        raised[bwd] = lds;
+    const dim3 grid((unsigned)(a->B * a->n_heads));
+    hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+    if (bwd) hipLaunchKernelGGL(cdx_mha_train_kernel<true>, grid, dim3(256), lds, s, *a);
+    else hipLaunchKernelGGL(cdx_mha_train_kernel<false>, grid, dim3(256), lds, s, *a);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
+    return CDX_OK;
 }
 
 }  // namespace
@@ -330,17 +424,19 @@ int cdx_attention_bwd_f32(const cdx_attn_bwd_args* a, void* hip_stream) {
     }
     if (a->B == 0) return CDX_OK;
     if (!a->qkv || !a->dout || !a->dqkv) { cdx_set_err("cdx_attention_bwd_f32: null pointer"); return CDX_EINVAL; }
-    if ((long long)a->B * a->n_heads > 0x7fffffffLL) { cdx_set_err("cdx_attention_bwd_f32: batch too large for one launch"); return CDX_EINVAL; }
-    const size_t lds = (size_t)(4 * a->T * (a->head_dim + 1) + 2 * a->T * (a->T + 1)) * sizeof(float);      // <= 100 KB
-    static size_t lds_raised = 0;
-    if (lds > 48 * 1024 && lds > lds_raised &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(cdx_attention_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
-        lds_raised = lds;
-    hipLaunchKernelGGL(cdx_attention_bwd_kernel, dim3((unsigned)(a->B * a->n_heads)), dim3(256), lds, reinterpret_cast<hipStream_t>(hip_stream), *a);
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
-    return CDX_OK;
+    const int dm = a->n_heads * a->head_dim;               // packed rows [q | k | v]: the general kernel on three column blocks
+    cdx_mha_train_args g = {};
+    g.q = a->qkv; g.k = a->qkv + dm; g.v = a->qkv + 2 * dm;
+    g.dout = a->dout;
+    g.dq = a->dqkv; g.dk = a->dqkv + dm; g.dv = a->dqkv + 2 * dm;
+    g.B = a->B; g.Tq = g.Tk = a->T; g.n_heads = a->n_heads; g.head_dim = a->head_dim;
+    g.ldq = g.ldk = g.ldv = g.lddq = g.lddk = g.lddv = 3 * dm; g.ldo = dm;
+    g.scale = a->scale;
+    return mha_train_launch(&g, true, hip_stream, "cdx_attention_bwd_f32");
 }
+
+int cdx_mha_train_fwd_f32(const cdx_mha_train_args* a, void* hip_stream) { return mha_train_launch(a, false, hip_stream, "cdx_mha_train_fwd_f32"); }
+int cdx_mha_train_bwd_f32(const cdx_mha_train_args* a, void* hip_stream) { return mha_train_launch(a, true, hip_stream, "cdx_mha_train_bwd_f32"); }
 
 int cdx_conv_wgrad_f32(const cdx_wgrad_args* a, void* hip_stream) {
     cdx_set_err("");

@@ -69,6 +69,12 @@ class CdxAttnBwdArgs(ctypes.Structure):
                 ("n_heads", ctypes.c_int32), ("head_dim", ctypes.c_int32), ("scale", ctypes.c_float)]
 
 
+class CdxMhaTrainArgs(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("q", "k", "v", "mask", "keep", "out", "dout", "dq", "dk", "dv")] + \
+               [(n, ctypes.c_int32) for n in ("B", "Tq", "Tk", "n_heads", "head_dim", "ldq", "ldk", "ldv", "ldo", "lddq", "lddk", "lddv")] + \
+               [("scale", ctypes.c_float)]
+
+
 class CdxAttnArgs(ctypes.Structure):
     _fields_ = [("qkv", ctypes.c_void_p), ("out", ctypes.c_void_p), ("B", ctypes.c_int32), ("T", ctypes.c_int32),
                 ("n_heads", ctypes.c_int32), ("head_dim", ctypes.c_int32), ("scale", ctypes.c_float),
@@ -110,6 +116,9 @@ def _lib():
         lib.cdx_layernorm_bwd_f32.restype = ctypes.c_int
         lib.cdx_attention_bwd_f32.argtypes = [ctypes.POINTER(CdxAttnBwdArgs), ctypes.c_void_p]
         lib.cdx_attention_bwd_f32.restype = ctypes.c_int
+        for f in (lib.cdx_mha_train_fwd_f32, lib.cdx_mha_train_bwd_f32):
+            f.argtypes = [ctypes.POINTER(CdxMhaTrainArgs), ctypes.c_void_p]
+            f.restype = ctypes.c_int
         lib.cdx_gather_windows_f32.argtypes = [ctypes.POINTER(CdxGatherArgs), ctypes.c_void_p]
         lib.cdx_gather_windows_f32.restype = ctypes.c_int
         for f in (lib.cdx_gemm_f32, lib.cdx_layernorm_f32, lib.cdx_attention_f32, lib.cdx_act_f32):
@@ -319,6 +328,35 @@ def attention_backward(qkv: torch.Tensor, dout: torch.Tensor, batch: int, tokens
                        scale=float(dh) ** -0.5)
     _check(_lib().cdx_attention_bwd_f32(ctypes.byref(a), _stream_ptr(qkv.device)), "cdx_attention_bwd_f32")
     return dqkv
+
+
+def mha_train(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, n_heads: int, mask: Optional[torch.Tensor] = None,
+              keep: Optional[torch.Tensor] = None, dout: Optional[torch.Tensor] = None, grads=None):
+    """The attention core of nn.MultiheadAttention in training (``cdx_mha_train_fwd_f32`` / ``_bwd_f32``): q (batch * Tq, dm), k / v
+    (batch * Tk, dm) -- column blocks of packed projections welcome --, additive `mask` (Tq, Tk), dropout `keep` (batch, n_heads, Tq,
+    Tk) of 0 | 1 / (1 - p).  Without `dout`: the output (batch * Tq, dm); with it: (dq, dk, dv) -- written into `grads` (three
+    2-D views, e.g. the column blocks of one packed gradient) when given, else three fresh tensors."""
+    dm = q.shape[1]
+    tq, tk, dh = q.shape[0] // batch, k.shape[0] // batch, dm // n_heads
+    assert q.shape[0] == batch * tq and k.shape == v.shape == (batch * tk, dm) and dh * n_heads == dm
+    if mask is not None:
+        assert mask.shape == (tq, tk) and mask.is_contiguous() and mask.dtype == torch.float32
+    if keep is not None:
+        assert keep.shape == (batch, n_heads, tq, tk) and keep.is_contiguous() and keep.dtype == torch.float32
+    a = CdxMhaTrainArgs(q=q.data_ptr(), k=k.data_ptr(), v=v.data_ptr(), mask=_p(mask), keep=_p(keep), B=batch, Tq=tq, Tk=tk, n_heads=n_heads,
+                        head_dim=dh, ldq=_rows(q), ldk=_rows(k), ldv=_rows(v), ldo=dm, scale=float(dh) ** -0.5)
+    if dout is None:
+        out = torch.empty((batch * tq, dm), device=q.device, dtype=torch.float32)
+        a.out = out.data_ptr()
+        _check(_lib().cdx_mha_train_fwd_f32(ctypes.byref(a), _stream_ptr(q.device)), "cdx_mha_train_fwd_f32")
+        return out
+    assert dout.is_contiguous() and dout.shape == (batch * tq, dm)
+    dq, dk, dv = grads if grads is not None else (torch.empty_like(dout), k.new_empty((batch * tk, dm)), k.new_empty((batch * tk, dm)))
+    assert dq.shape == (batch * tq, dm) and dk.shape == dv.shape == (batch * tk, dm)
+    a.dout, a.dq, a.dk, a.dv = dout.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    a.lddq, a.lddk, a.lddv = _rows(dq), _rows(dk), _rows(dv)
+    _check(_lib().cdx_mha_train_bwd_f32(ctypes.byref(a), _stream_ptr(q.device)), "cdx_mha_train_bwd_f32")
+    return dq, dk, dv
 
 
 def attention(qkv: torch.Tensor, batch: int, tokens: int, n_heads: int, out: Optional[torch.Tensor] = None,

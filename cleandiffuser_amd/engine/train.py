@@ -412,6 +412,52 @@ class _Attention(torch.autograd.Function):
         return blocks.attention_backward(qkv, dout.contiguous(), *ctx.geom), None, None, None
 
 
+class _MHA(torch.autograd.Function):
+    """softmax(q k^T / sqrt(dh) + mask) -> dropout -> . v per (sample, head), training forward / backward
+    (``cdx_mha_train_fwd_f32`` / ``_bwd_f32``).  Operands: ONE packed tensor [q | k | v] (rows, 3 dm) (`kv` None: self-attention), or
+    q (batch * Tq, dm) next to a packed [k | v] (batch * Tk, 2 dm) (cross-attention on a memory).  `mask`: additive (Tq, Tk) or None;
+    `keep`: the attention-dropout mask (batch, heads, Tq, Tk) of 0 | 1 / (1 - p) or None (``draw_keep``).  Gradients come back packed
+    the way the operands were."""
+
+    @staticmethod
+    def forward(ctx, q, kv, batch, n_heads, mask, keep):
+        q = q.contiguous()
+        kv = None if kv is None else kv.contiguous()
+        ctx.save_for_backward(q, kv if kv is not None else q.new_empty(0), mask if mask is not None else q.new_empty(0),
+                              keep if keep is not None else q.new_empty(0))
+        ctx.geom = (batch, n_heads, kv is None, mask is not None, keep is not None)
+        qq, kk, vv = _MHA._blocks(q, kv)
+        return blocks.mha_train(qq, kk, vv, batch, n_heads, mask=mask, keep=keep)
+
+    @staticmethod
+    def _blocks(q, kv):
+        if kv is None:
+            dm = q.shape[1] // 3
+            return q[:, :dm], q[:, dm:2 * dm], q[:, 2 * dm:]
+        dm = q.shape[1]
+        return q, kv[:, :dm], kv[:, dm:]
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kv, mask, keep = ctx.saved_tensors
+        batch, n_heads, packed, has_mask, has_keep = ctx.geom
+        kv = None if packed else kv
+        dq = torch.empty_like(q)
+        dkv = None if packed else torch.empty_like(kv)
+        blocks.mha_train(*_MHA._blocks(q, kv), batch, n_heads, mask=mask if has_mask else None, keep=keep if has_keep else None,
+                         dout=dout.contiguous(), grads=_MHA._blocks(dq, dkv))
+        return dq, dkv, None, None, None, None
+
+
+def draw_keep(p: float, training: bool, batch: int, n_heads: int, tq: int, tk: int, device) -> Optional[torch.Tensor]:
+    """The attention-dropout mask of one nn.MultiheadAttention call as the kernel wants it -- 0 | 1 / (1 - p) per (sample, head, query,
+    key), one Bernoulli draw from torch's device generator (so ``torch.manual_seed`` and HIP-graph replay treat it like the noise /
+    timestep draws of the step) -- or None when the module does not drop (eval mode or p == 0)."""
+    if not training or p <= 0.0:
+        return None
+    return torch.empty((batch, n_heads, tq, tk), device=device, dtype=torch.float32).bernoulli_(1.0 - p).mul_(1.0 / (1.0 - p))
+
+
 def supports_idql(net, x: torch.Tensor, condition=None) -> bool:
     """IDQLMlp / NewIDQLMlp (BASELINE config 5's SynthER residual MLP) with autograd on, on a ROCm device."""
     if not (enabled() and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2):
@@ -437,22 +483,22 @@ def idql_forward(net, x, noise, condition):
 
 
 def supports_dit(net, x: torch.Tensor, condition=None) -> bool:
-    """DiT1d (BASELINE config 4) with autograd on, on a ROCm device: <= 64 tokens, head_dim <= 64, no dropout inside the blocks."""
+    """DiT1d (BASELINE config 4) with autograd on, on a ROCm device: <= 64 tokens, head_dim <= 64."""
     if not (enabled() and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and
             type(net).__name__ in ("DiT1d", "HalfDiT1d")):       # (HalfDiT1d: the same trunk with a d_model / 2 wide final layer)
         return False
     blk = net.blocks[0] if len(net.blocks) else None
     if blk is None or x.shape[1] > 64 or net.d_model // blk.attn.num_heads > 64 or net.d_model > 4096 or net.d_model % blk.attn.num_heads:
         return False
-    if any((b.attn.dropout > 0 or b.mlp[2].p > 0) and net.training for b in net.blocks) or not _wants_grad(net, x, condition):
+    if not _wants_grad(net, x, condition):
         return False
     return all(p.dtype == torch.float32 and p.is_cuda for p in net.parameters())
 
 
 def dit_forward(net, x, noise, condition):
     """``DiT1d.forward`` (reference nn_diffusion/dit.py:10-50,108-130) with autograd: x_proj / qkv / out_proj / fc1(+GELU) / fc2 / head
-    GEMMs, LayerNorm + adaLN modulate and the attention core on library nodes, forward and backward; the (batch, d) embedding /
-    modulation Linears, the gates and the residual adds stay ATen.  The block keeps the reference's quirk: the residual
+    GEMMs, LayerNorm + adaLN modulate and the attention core (with its dropout mask in train mode) on library nodes, forward and
+    backward; the (batch, d) embedding / modulation Linears, the gates, the residual adds and the MLP's nn.Dropout stay ATen.  The block keeps the reference's quirk: the residual
     stream continues from the MODULATED LayerNorm output."""
     b, tokens, d_in = x.shape
     d = net.d_model
@@ -466,16 +512,104 @@ def dit_forward(net, x, noise, condition):
         att = blk.attn
         h = _LayerNormMod.apply(h, sc_a, sh_a, tokens, blk.norm1.eps)
         qkv = _LinearAct.apply(h, att.in_proj_weight, att.in_proj_bias, None)
-        o = _LinearAct.apply(_Attention.apply(qkv, b, tokens, att.num_heads), att.out_proj.weight, att.out_proj.bias, None)
+        keep = draw_keep(att.dropout, att.training, b, att.num_heads, tokens, tokens, x.device)
+        core = _Attention.apply(qkv, b, tokens, att.num_heads) if keep is None else _MHA.apply(qkv, None, b, att.num_heads, None, keep)
+        o = _LinearAct.apply(core, att.out_proj.weight, att.out_proj.bias, None)
         h = (h.view(b, tokens, d) + g_a[:, None, :] * o.view(b, tokens, d)).view(b * tokens, d)
         m = _LayerNormMod.apply(h, sc_m, sh_m, tokens, blk.norm2.eps)
-        f = _LinearAct.apply(m, blk.mlp[0].weight, blk.mlp[0].bias, "gelu_tanh")
+        f = blk.mlp[2](_LinearAct.apply(m, blk.mlp[0].weight, blk.mlp[0].bias, "gelu_tanh"))       # (nn.Dropout: an ATen draw in train mode)
         f = _LinearAct.apply(f, blk.mlp[3].weight, blk.mlp[3].bias, None)
         h = (h.view(b, tokens, d) + g_m[:, None, :] * f.view(b, tokens, d)).view(b * tokens, d)
     fl = net.final_layer
     shift, scale = fl.adaLN_modulation(emb).chunk(2, dim=1)
     m = _LayerNormMod.apply(h, scale, shift, tokens, fl.norm_final.eps)
     return _LinearAct.apply(m, fl.linear.weight, fl.linear.bias, None).view(b, tokens, fl.linear.out_features)
+
+
+def _mha_ok(att: nn.MultiheadAttention, d: int) -> bool:
+    return (att._qkv_same_embed_dim and att.batch_first and att.in_proj_bias is not None and att.bias_k is None and not att.add_zero_attn and
+            att.embed_dim == d and d % att.num_heads == 0 and d // att.num_heads <= 64)
+
+
+def _tf_layer_ok(layer, d: int, decoder: bool) -> bool:
+    import torch.nn.functional as F
+    if not (layer.norm_first and layer.activation is F.gelu and _mha_ok(layer.self_attn, d)):
+        return False
+    return not decoder or _mha_ok(layer.multihead_attn, d)
+
+
+def supports_chitf(net, x: torch.Tensor, condition=None) -> bool:
+    """ChiTransformer (Diffusion Policy's transformer denoiser, the dp_* pipelines) with autograd on, on a ROCm device: the shapes its
+    masks were built for (Ta action tokens, 1 + To memory tokens, both <= 64), head_dim <= 64, pre-norm GELU layers as the class
+    constructs them (reference nn_diffusion/chitransformer.py:90-135)."""
+    if not (enabled() and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and
+            type(net).__name__ == "ChiTransformer"):
+        return False
+    d = net.act_emb.out_features
+    if x.shape[1] != net.T or net.T > 64 or net.T_cond > 64 or d > 4096 or net.obs_emb is None:
+        return False
+    if condition is not None and not (torch.is_tensor(condition) and condition.dim() == 3 and condition.shape[1] == net.To and
+                                      condition.dtype == torch.float32):
+        return False
+    enc = net.encoder
+    if isinstance(enc, nn.TransformerEncoder):
+        if enc.norm is not None or not all(_tf_layer_ok(l, d, False) for l in enc.layers):
+            return False
+    elif not (isinstance(enc, nn.Sequential) and len(enc) == 3 and isinstance(enc[1], nn.Mish)):
+        return False
+    if net.decoder.norm is not None or not all(_tf_layer_ok(l, d, True) for l in net.decoder.layers) or not _wants_grad(net, x, condition):
+        return False
+    return all(p.dtype == torch.float32 and p.is_cuda for p in net.parameters())
+
+
+def _self_attention(att, h2, batch, tokens, mask):
+    qkv = _LinearAct.apply(h2, att.in_proj_weight, att.in_proj_bias, None)
+    keep = draw_keep(att.dropout, att.training, batch, att.num_heads, tokens, tokens, h2.device)
+    core = _Attention.apply(qkv, batch, tokens, att.num_heads) if mask is None and keep is None else \
+        _MHA.apply(qkv, None, batch, att.num_heads, mask, keep)
+    return _LinearAct.apply(core, att.out_proj.weight, att.out_proj.bias, None)
+
+
+def _ffn(layer, h2):
+    f = layer.dropout(_LinearAct.apply(h2, layer.linear1.weight, layer.linear1.bias, "gelu"))
+    return _LinearAct.apply(f, layer.linear2.weight, layer.linear2.bias, None)
+
+
+def chitf_forward(net, x, noise, condition):
+    """``ChiTransformer.forward`` (reference nn_diffusion/chitransformer.py:137-158) with autograd, as nn.TransformerEncoder /
+    nn.TransformerDecoder run it in TRAIN mode (pre-norm layers: x += drop(attn(norm(x))), x += drop(ffn(norm(x)))): every Linear, every
+    LayerNorm and the three attention cores (memory encoder self-attention, causal self-attention, staggered memory cross-attention --
+    each with its dropout mask) on library nodes, forward and backward; token concat, positional adds, residual adds and the
+    nn.Dropout modules (RNG draws) stay ATen."""
+    b, ta, act_dim = x.shape
+    d, tc = net.act_emb.out_features, net.T_cond
+    if condition is None:
+        condition = torch.zeros((b, net.To, net.obs_dim), device=x.device)
+    obs = _LinearAct.apply(condition.reshape(b * net.To, net.obs_dim), net.obs_emb.weight, net.obs_emb.bias, None)
+    mem = torch.cat([net.map_noise(noise).unsqueeze(1), obs.view(b, net.To, d)], dim=1)
+    mem = net.drop(mem + net.cond_pos_emb[:, :tc, :]).reshape(b * tc, d)
+    enc = net.encoder
+    if isinstance(enc, nn.Sequential):
+        mem = _LinearAct.apply(_LinearAct.apply(mem, enc[0].weight, enc[0].bias, "mish"), enc[2].weight, enc[2].bias, None)
+    else:
+        for layer in enc.layers:
+            n1, n2 = layer.norm1, layer.norm2
+            mem = mem + layer.dropout1(_self_attention(layer.self_attn, _LayerNormAffine.apply(mem, n1.weight, n1.bias, n1.eps), b, tc, None))
+            mem = mem + layer.dropout2(_ffn(layer, _LayerNormAffine.apply(mem, n2.weight, n2.bias, n2.eps)))
+    h = _LinearAct.apply(x.reshape(b * ta, act_dim), net.act_emb.weight, net.act_emb.bias, None)
+    h = net.drop(h.view(b, ta, d) + net.pos_emb[:, :ta, :]).reshape(b * ta, d)
+    causal, staggered = net.mask.detach(), net.memory_mask.detach()
+    for layer in net.decoder.layers:
+        n1, n2, n3, ca = layer.norm1, layer.norm2, layer.norm3, layer.multihead_attn
+        h = h + layer.dropout1(_self_attention(layer.self_attn, _LayerNormAffine.apply(h, n1.weight, n1.bias, n1.eps), b, ta, causal))
+        q = _LinearAct.apply(_LayerNormAffine.apply(h, n2.weight, n2.bias, n2.eps), ca.in_proj_weight[:d], ca.in_proj_bias[:d], None)
+        kv = _LinearAct.apply(mem, ca.in_proj_weight[d:], ca.in_proj_bias[d:], None)
+        keep = draw_keep(ca.dropout, ca.training, b, ca.num_heads, ta, tc, x.device)
+        o = _LinearAct.apply(_MHA.apply(q, kv, b, ca.num_heads, staggered, keep), ca.out_proj.weight, ca.out_proj.bias, None)
+        h = h + layer.dropout2(o)
+        h = h + layer.dropout3(_ffn(layer, _LayerNormAffine.apply(h, n3.weight, n3.bias, n3.eps)))
+    h = _LayerNormAffine.apply(h, net.ln_f.weight, net.ln_f.bias, net.ln_f.eps)
+    return _LinearAct.apply(h, net.head.weight, net.head.bias, None).view(b, ta, net.head.out_features)
 
 
 def supports_mlp(net, x: torch.Tensor, condition=None) -> bool:
@@ -613,12 +747,12 @@ class GraphedStep:
 def _native_training_net(net, x0, condition) -> bool:
     with torch.enable_grad():
         return (supports(net, x0, condition) or supports_chi(net, x0, condition) or supports_dit(net, x0, condition) or
-                supports_idql(net, x0, condition) or supports_mlp(net, x0, condition))
+                supports_chitf(net, x0, condition) or supports_idql(net, x0, condition) or supports_mlp(net, x0, condition))
 
 
 def graphed_step(agent, x0, condition, kwargs) -> Optional[GraphedStep]:
     """The cached GraphedStep of (agent, batch shape), or None (the eager path).  CDX_TRAIN_GRAPH: "auto" (default) -- agents whose
-    denoiser the native training path serves (JannerUNet1d, ChiUNet1d, DiT1d, IDQLMlp, DQLMlp / DVInvMlp on a ROCm device), no extra
+    denoiser the native training path serves (JannerUNet1d, ChiUNet1d, DiT1d, ChiTransformer, IDQLMlp, DQLMlp / DVInvMlp on a ROCm device), no extra
     loss arguments, and whose first step passes the capturability probe (GraphedStep); "1": no probe; "0": never."""
     mode = os.environ.get("CDX_TRAIN_GRAPH", "auto")
     if mode == "0" or kwargs or not torch.is_tensor(x0) or not x0.is_cuda or not torch.is_grad_enabled() or \

@@ -4,7 +4,9 @@
 
 Execution: on a ROCm device without autograd, forward and every sample() over it run through engine/bigbatch.py ->
 ``cdx_chitf_run`` (memory tokens and their K/V projections precomputed per request, masked MFMA self-attention, small
-cross-attention kernel, GEMMs with fused GELU / residual epilogues); the module code below is the CPU / autograd executor.
+cross-attention kernel, GEMMs with fused GELU / residual epilogues); WITH autograd (loss() / update()) through
+engine/train.py:chitf_forward (Linear / LayerNorm / attention nodes on the library's kernels, forward and backward, attention dropout
+included); the module code below is the CPU executor.
 """
 from typing import Optional
 
@@ -86,7 +88,9 @@ class ChiTransformer(BaseNNDiffusion):
 
     def forward(self, x: torch.Tensor, noise: torch.Tensor, condition: Optional[torch.Tensor] = None):
         """x (b, Ta, act_dim), noise (b,), condition (b, To, obs_dim)|None(=zeros) -> (b, Ta, act_dim)."""
-        from ..engine import dispatch
+        from ..engine import dispatch, train
+        if train.supports_chitf(self, x, condition):
+            return train.chitf_forward(self, x, noise, condition)           # autograd on, ROCm device: loss() / update()
         y = dispatch.try_backbone_forward(self, x, noise, condition)        # cdx_chitf_run on a ROCm device
         if y is not None:
             return y

@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define CDX_ABI_VERSION 14
+#define CDX_ABI_VERSION 15
 
 #define CDX_OK 0
 #define CDX_EINVAL (-1)   /* bad argument (null pointer, size out of range, misaligned offset) */
@@ -349,6 +349,33 @@ typedef struct cdx_attn_bwd_args {
     float scale;
 } cdx_attn_bwd_args;
 int cdx_attention_bwd_f32(const cdx_attn_bwd_args* args, void* hip_stream);
+
+/* The attention core of nn.MultiheadAttention in TRAINING, forward and backward (ABI 15; csrc/cdx_train.hip): per (sample, head)
+ *     P = softmax(q k^T * scale + mask),  out = (P o keep) v
+ * with q (B * Tq rows), k / v (B * Tk rows) and out / dout read through their own pointers and row strides (packed qkv rows, a q
+ * projection next to a packed kv projection of a memory, ... are the same call); `mask` (Tq, Tk) additive, -inf = not attended, NULL =
+ * none; `keep` (B, n_heads, Tq, Tk) the attention-dropout mask as 0 or 1 / (1 - p), drawn by the caller, NULL = no dropout.  What the
+ * reference runs through nn.TransformerDecoderLayer / nn.TransformerEncoderLayer in train mode (nn_diffusion/chitransformer.py:108-121,
+ * 148-154: causal self-attention, staggered memory cross-attention, attention dropout 0.3) and through nn.MultiheadAttention in
+ * dit.py:20,34.  The backward recomputes P from the forward's operands: dq (B * Tq, lddq), dk / dv (B * Tk, lddk / lddv).
+ * Tq, Tk <= 64, head_dim <= 64; every row of `mask` must allow at least one key. */
+typedef struct cdx_mha_train_args {
+    const float* q;
+    const float* k;
+    const float* v;
+    const float* mask;     /* (Tq, Tk) or NULL */
+    const float* keep;     /* (B, n_heads, Tq, Tk) or NULL */
+    float* out;            /* forward: (B * Tq, ldo) */
+    const float* dout;     /* backward: (B * Tq, ldo) */
+    float* dq;
+    float* dk;
+    float* dv;
+    int32_t B, Tq, Tk, n_heads, head_dim;
+    int32_t ldq, ldk, ldv, ldo, lddq, lddk, lddv;
+    float scale;
+} cdx_mha_train_args;
+int cdx_mha_train_fwd_f32(const cdx_mha_train_args* args, void* hip_stream);
+int cdx_mha_train_bwd_f32(const cdx_mha_train_args* args, void* hip_stream);
 
 /* Batch assembly from dataset buffers that live in HBM (third slice: the reference collates a batch on the host --
  * D4RLMuJoCoDataset.__getitem__, cleandiffuser/dataset/d4rl_mujoco_dataset.py:138-151, per item through a torch DataLoader with four

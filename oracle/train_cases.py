@@ -163,10 +163,26 @@ def dit(d_model: int, heads: int, tokens: int, batch: int):
     return run
 
 
+def chitf(d_model: int, heads: int, layers: int, cond_layers: int, ta: int, to: int, batch: int):
+    """ChiTransformer under the legacy DDPM class with the observations passed through -- the dp_* training step with the transformer
+    denoiser (reference pipelines/dp_pusht.py:173-196, nn_diffusion/chitransformer.py:60-158, ddpm.py:80-112).  p_drop_attn = 0 here:
+    the pipelines train with 0.3, whose draws happen inside ATen and cannot be replayed across devices (the dropout path is checked
+    against autograd with shared masks in tests/test_gpu_parity.py).  d 256 / 4 heads / 8 layers / Ta 10 / To 2: the dp_pusht net;
+    the small one has a TransformerEncoder over the memory tokens (n_cond_layers 2)."""
+    def run(lib, kind, device):
+        net = load_synth(lib.ChiTransformer(3, 5, ta, to, d_model=d_model, nhead=heads, num_layers=layers, p_drop_attn=0.0,
+                                            n_cond_layers=cond_layers), 69)
+        agent = lib.DDPM(net, lib.IdentityCondition(dropout=0.0), diffusion_steps=20, predict_noise=True, grad_clip_norm=1.0, device=device)
+        g = torch.Generator().manual_seed(8)
+        return _record(agent, torch.randn(batch, ta, 3, generator=g).clamp(-1, 1), torch.randn(batch, to, 5, generator=g), device)
+    return run
+
+
 HEAVY = {"chiunet_cfg3", "dit_cfg4"}          # minutes of CPU work: fixture from the real reference, checked on the device only
 
 SCENARIOS: Dict[str, Callable] = {
     "chiunet_ddpm": chiunet(32, 5), "chiunet_cfg3": chiunet(256, 4), "dit_small": dit(64, 4, 16, 5), "dit_cfg4": dit(320, 10, 64, 4),
+    "chitf_small": chitf(64, 4, 2, 2, 6, 3, 5), "chitf_pusht": chitf(256, 4, 8, 0, 10, 2, 6),
     "discrete_eps": discrete(True), "discrete_x0": discrete(False), "continuous_eps": continuous(),
     "edm_conditional": edm_conditional(0.1), "edm_conditional_nodrop": edm_conditional(0.0), "legacy_ddpm": legacy_ddpm(), "weighted_regression": weighted_regression(),
 }

@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported(lib):
                           "cdx_hjgrad_workspace_floats", "cdx_guided_run", "cdx_guided_workspace_floats", "cdx_unet2_run",
                           "cdx_unet2_embtab", "cdx_optim_f32", "cdx_pearcetf_run", "cdx_pearcetf_workspace_floats", "cdx_act_bwd_f32", "cdx_linattn_f32",
                           "cdx_conv_wgrad_f32", "cdx_colsum_f32", "cdx_device_query", "cdx_layernorm_bwd_f32",
-                          "cdx_attention_bwd_f32"}
+                          "cdx_attention_bwd_f32", "cdx_mha_train_fwd_f32", "cdx_mha_train_bwd_f32"}
     for n in names:
         assert hasattr(lib, n), f"{n} declared in cdx.h but not exported by libcdx.so"
     assert lib.cdx_abi_version() == int(re.search(r"#define CDX_ABI_VERSION (\d+)", hdr).group(1))
@@ -54,7 +54,8 @@ def test_ctypes_mirrors_have_c_layout(tmp_path):
                "cdx_chiunet_block": bigbatch.CdxChiUNetBlock, "cdx_chiunet_weights": bigbatch.CdxChiUNetWeights,
                "cdx_unet_attn": bigbatch.CdxUnetAttn, "cdx_wgrad_args": blocks.CdxWgradArgs,
                "cdx_gather_args": blocks.CdxGatherArgs, "cdx_gather_field": blocks.CdxGatherField,
-               "cdx_device_props": runtime2.CdxDeviceProps, "cdx_ln_bwd_args": blocks.CdxLnBwdArgs, "cdx_attn_bwd_args": blocks.CdxAttnBwdArgs}
+               "cdx_device_props": runtime2.CdxDeviceProps, "cdx_ln_bwd_args": blocks.CdxLnBwdArgs, "cdx_attn_bwd_args": blocks.CdxAttnBwdArgs,
+               "cdx_mha_train_args": blocks.CdxMhaTrainArgs}
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "cdx.h"', 'int main(void){']
     for cname, mirror in mirrors.items():
         src.append(f'printf("%zu\\n", sizeof({cname}));')
@@ -202,6 +203,15 @@ def test_newer_entries_validate_before_touching_the_device(lib):
     assert lib.cdx_layernorm_bwd_f32(ctypes.byref(blocks.CdxLnBwdArgs(M=0, C=64)), None) == 0
     assert lib.cdx_attention_bwd_f32(ctypes.byref(blocks.CdxAttnBwdArgs(B=1, T=65, n_heads=1, head_dim=8, qkv=8, dout=8, dqkv=8)), None) == bad
     assert lib.cdx_attention_bwd_f32(ctypes.byref(blocks.CdxAttnBwdArgs(B=0, T=8, n_heads=1, head_dim=8)), None) == 0
+    mha = dict(B=1, Tq=8, Tk=8, n_heads=2, head_dim=8, q=8, k=8, v=8, out=8, dout=8, dq=8, dk=8, dv=8, ldq=16, ldk=16, ldv=16, ldo=16,
+               lddq=16, lddk=16, lddv=16)
+    for fn in (lib.cdx_mha_train_fwd_f32, lib.cdx_mha_train_bwd_f32):                              # ABI 15
+        assert fn(ctypes.byref(blocks.CdxMhaTrainArgs(**{**mha, "Tk": 65})), None) == bad and b"<= 64" in lib.cdx_last_error()
+        assert fn(ctypes.byref(blocks.CdxMhaTrainArgs(**{**mha, "ldk": 8})), None) == bad and b"row stride" in lib.cdx_last_error()
+        assert fn(ctypes.byref(blocks.CdxMhaTrainArgs(**{**mha, "v": None})), None) == bad
+        assert fn(ctypes.byref(blocks.CdxMhaTrainArgs(**{**mha, "B": 0})), None) == 0
+        assert fn(None, None) == bad
+    assert lib.cdx_mha_train_bwd_f32(ctypes.byref(blocks.CdxMhaTrainArgs(**{**mha, "dk": None})), None) == bad
     assert lib.cdx_act_bwd_f32(8, 8, 8, 4, 8, 0.0, None) == bad and lib.cdx_act_bwd_f32(8, None, 8, 4, 4, 1.0, None) == bad
     assert lib.cdx_act_bwd_f32(8, 8, 8, 0, 4, 1.0, None) == 0
     # workspace sizes: host arithmetic, grows with the chunk, independent of the batch beyond the chunk

@@ -1179,7 +1179,7 @@ def test_config4_with_resolving_power_against_the_float64_yardstick(name, amd_li
 
 
 @pytest.mark.parametrize("name", ["discrete_eps", "discrete_x0", "continuous_eps", "edm_conditional_nodrop", "legacy_ddpm",
-                                  "weighted_regression", "chiunet_ddpm", "chiunet_cfg3", "dit_small", "dit_cfg4"])      # ("edm_conditional": nn.Dropout draws inside ATen, CPU-only)
+                                  "weighted_regression", "chiunet_ddpm", "chiunet_cfg3", "dit_small", "dit_cfg4", "chitf_small", "chitf_pusht"])      # ("edm_conditional": nn.Dropout draws inside ATen, CPU-only)
 def test_loss_and_update_match_reference_fixture(name):
     """loss() / update() on the ROCm device against what the REAL reference computed on CPU from the same seeded
     timestep / noise / label-dropout draws (oracle/train_cases.py; the CPU generator's draws are replayed on the device): loss value,
@@ -1489,6 +1489,147 @@ def test_layernorm_and_attention_backward_kernels_match_autograd():
         o.backward(dout)
         got = blocks.attention_backward(qkv.detach().contiguous(), dout, B, T, H)
         torch.testing.assert_close(got, qkv.grad, rtol=2e-4, atol=2e-5)
+
+
+def _mha_reference(q, k, v, B, H, mask, keep):
+    """softmax(q k^T / sqrt(dh) + mask) o keep @ v in plain torch ops (what F.multi_head_attention_forward computes between the
+    projections in train mode, with the dropout mask given instead of drawn)."""
+    dm = q.shape[1]
+    dh = dm // H
+    qh, kh, vh = (z.reshape(B, -1, H, dh).transpose(1, 2) for z in (q, k, v))
+    sc = qh @ kh.transpose(-1, -2) / dh ** 0.5
+    p = torch.softmax(sc if mask is None else sc + mask, dim=-1)
+    return ((p if keep is None else p * keep) @ vh).transpose(1, 2).reshape(-1, dm)
+
+
+@pytest.mark.parametrize("B,Tq,Tk,H,dh,masked,drop", [(3, 10, 10, 4, 64, True, 0.3), (2, 16, 3, 4, 64, True, 0.3), (2, 64, 64, 10, 32, False, 0.1),
+                                                      (5, 6, 4, 4, 16, True, 0.0), (1, 33, 17, 3, 24, False, 0.0)])
+def test_mha_training_kernels_match_autograd_with_mask_and_dropout(B, Tq, Tk, H, dh, masked, drop):
+    """cdx_mha_train_fwd_f32 / _bwd_f32 (ABI 15): the attention core of nn.MultiheadAttention in train mode -- additive mask (causal /
+    staggered, -inf entries), dropout mask applied to the probabilities, q next to a packed [k | v] of another length (the memory
+    cross-attention of nn.TransformerDecoderLayer) and packed [q | k | v] rows -- against torch.autograd of the same arithmetic with the
+    SAME dropout mask (reference nn_diffusion/chitransformer.py:108-121,148-154)."""
+    from cleandiffuser_amd.engine import train
+    g = torch.Generator().manual_seed(B * 100 + Tq)
+    dm = H * dh
+    mask = None
+    if masked:
+        i, j = torch.meshgrid(torch.arange(Tq), torch.arange(Tk), indexing="ij")
+        mask = torch.zeros(Tq, Tk).masked_fill(~(i >= j - 1), float("-inf")).to(DEV)
+    keep = (torch.rand(B, H, Tq, Tk, generator=g) >= drop).float().div(1 - drop).to(DEV) if drop else None
+    dout = torch.randn(B * Tq, dm, generator=g).to(DEV)
+    # cross form: q (B * Tq, dm), kv packed (B * Tk, 2 dm)
+    q = torch.randn(B * Tq, dm, generator=g).to(DEV).requires_grad_(True)
+    kv = torch.randn(B * Tk, 2 * dm, generator=g).to(DEV).requires_grad_(True)
+    ref = _mha_reference(q, kv[:, :dm], kv[:, dm:], B, H, mask, keep)
+    ref.backward(dout)
+    gq, gkv = q.grad.clone(), kv.grad.clone()
+    q.grad = kv.grad = None
+    out = train._MHA.apply(q, kv, B, H, mask, keep)
+    out.backward(dout)
+    torch.testing.assert_close(out.detach(), ref.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(q.grad, gq, rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(kv.grad, gkv, rtol=2e-4, atol=2e-5)
+    if Tq == Tk:                                          # packed self-attention form
+        qkv = torch.randn(B * Tq, 3 * dm, generator=g).to(DEV).requires_grad_(True)
+        ref = _mha_reference(qkv[:, :dm], qkv[:, dm:2 * dm], qkv[:, 2 * dm:], B, H, mask, keep)
+        ref.backward(dout)
+        want = qkv.grad.clone()
+        qkv.grad = None
+        out = train._MHA.apply(qkv, None, B, H, mask, keep)
+        out.backward(dout)
+        torch.testing.assert_close(out.detach(), ref.detach(), rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(qkv.grad, want, rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("shape", ["pusht", "cond_encoder", "unconditional"])
+def test_native_chitransformer_training_graph_matches_autograd(shape, amd_lib, monkeypatch):
+    """VERDICT r4 missing #2, last backbone: ChiTransformer with autograd ON in TRAIN mode -- every Linear, LayerNorm and the three
+    attention cores (memory self-attention, causal self-attention, staggered memory cross-attention) on the library's kernels
+    (engine/train.py:chitf_forward; reference nn_diffusion/chitransformer.py:60-158): output, input gradient and the gradient of EVERY
+    parameter against torch.autograd of nn.TransformerDecoder / nn.TransformerEncoder on the same device (dropout 0 on both sides)."""
+    from cleandiffuser_amd.engine import train
+    from cleandiffuser_amd.utils import load_synth
+    g = torch.Generator().manual_seed(5)
+    d, heads, layers, cl, ta, to, B = {"pusht": (256, 4, 8, 0, 10, 2, 8), "cond_encoder": (64, 4, 2, 2, 6, 3, 5), "unconditional": (128, 2, 2, 0, 16, 1, 4)}[shape]
+    net = load_synth(amd_lib.ChiTransformer(3, 5, ta, to, d_model=d, nhead=heads, num_layers=layers, p_drop_attn=0.0, n_cond_layers=cl), 13).to(DEV)
+    net.train()
+    x = torch.randn(B, ta, 3, generator=g).to(DEV).requires_grad_(True)
+    t = torch.randint(0, 20, (B,), generator=g).to(DEV)
+    cond = None if shape == "unconditional" else torch.randn(B, to, 5, generator=g).to(DEV)
+    wgt = torch.randn(*x.shape, generator=g).to(DEV)
+
+    def run(native):
+        monkeypatch.setenv("CDX_TRAIN_NATIVE", "1" if native else "0")
+        net.zero_grad(set_to_none=True)
+        x.grad = None
+        assert train.supports_chitf(net, x, cond) == native
+        y = net(x, t, cond)
+        ((y * wgt).sum() / x.shape[0]).backward()
+        return y.detach().clone(), x.grad.clone(), {n: (None if p.grad is None else p.grad.clone()) for n, p in net.named_parameters()}
+    y1, gx1, gp1 = run(True)
+    y0, gx0, gp0 = run(False)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(y1.cpu().numpy(), y0.cpu().numpy(), rtol=1e-4, atol=1e-4 * max(1.0, float(y0.abs().max())))
+    np.testing.assert_allclose(gx1.cpu().numpy(), gx0.cpu().numpy(), rtol=1e-4, atol=2e-4 * float(gx0.abs().max()))
+    assert set(gp1) == set(gp0)
+    for n in gp0:
+        if gp0[n] is None:                               # (cond_encoder: constructed by the reference, used by nothing; the frozen masks)
+            assert gp1[n] is None, n
+            continue
+        sc = float(gp0[n].abs().max()) + 1e-12
+        err = float((gp1[n] - gp0[n]).abs().max())
+        assert err <= 3e-4 * sc, f"{n}: |d| = {err:.3e} at scale {sc:.3e}"
+        assert gp1[n].shape == gp0[n].shape
+
+
+def test_chitransformer_update_with_the_pipelines_dropout_runs_native_and_seeded(amd_lib, monkeypatch):
+    """The dp_* pipelines train ChiTransformer with p_drop_attn = 0.3 (reference pipelines/dp_pusht.py:176-180): update() in train mode
+    takes the native path (attention dropout masks drawn on the device and applied inside cdx_mha_train_*), is served by the HIP-graph
+    step, reproduces under torch.manual_seed, and its dropout is REAL (train-mode losses differ from the eval-mode loss of the same
+    draws; a module-level check pins the dropped attention against torch ops with the same mask)."""
+    import torch.nn.functional as F
+    from cleandiffuser_amd.engine import train
+    from cleandiffuser_amd.utils import load_synth
+
+    def make():
+        net = load_synth(amd_lib.ChiTransformer(3, 5, 10, 2, d_model=64, nhead=4, num_layers=2, p_drop_attn=0.3), 14)
+        return amd_lib.DDPM(net, amd_lib.IdentityCondition(dropout=0.0), diffusion_steps=20, predict_noise=True, grad_clip_norm=1.0, device=DEV)
+    g = torch.Generator().manual_seed(6)
+    x0, cond = torch.randn(16, 10, 3, generator=g).clamp(-1, 1).to(DEV), torch.randn(16, 2, 5, generator=g).to(DEV)
+    calls = []
+    orig = train.chitf_forward
+    monkeypatch.setattr(train, "chitf_forward", lambda *a: (calls.append(1), orig(*a))[1])
+    runs = []
+    for _ in range(2):
+        agent = make()
+        agent.train()
+        torch.manual_seed(77)
+        runs.append([float(agent.update(x0, cond)["loss"]) for _ in range(4)])
+    assert calls and np.isfinite(runs[0]).all()
+    # seeded: same draws (timesteps, noise, every dropout mask), eager or replayed (weight-gradient sums use float atomics: ~1e-7)
+    np.testing.assert_allclose(runs[0], runs[1], rtol=1e-3)
+    assert any(isinstance(v, train.GraphedStep) for v in agent.__dict__.get("_cdx_graphed", {}).values())
+    agent = make()
+    torch.manual_seed(77)
+    agent.train()
+    l_train = float(agent.loss(x0, cond))
+    torch.manual_seed(77)
+    agent.eval()
+    with torch.enable_grad():
+        l_eval = float(agent.loss(x0, cond))
+    assert abs(l_train - l_eval) > 1e-4 * abs(l_eval), (l_train, l_eval)
+    # one attention module of that net, dropped with a known mask
+    att = agent.model["diffusion"].decoder.layers[0].self_attn
+    att.train()
+    h2 = torch.randn(16 * 10, 64, generator=g).to(DEV).requires_grad_(True)
+    keep = (torch.rand(16, 4, 10, 10, generator=g) >= 0.3).float().div(0.7).to(DEV)
+    monkeypatch.setattr(train, "draw_keep", lambda *a: keep)
+    mask = agent.model["diffusion"].mask.detach()
+    out = train._self_attention(att, h2, 16, 10, mask)
+    qkv = F.linear(h2, att.in_proj_weight, att.in_proj_bias)
+    ref = F.linear(_mha_reference(qkv[:, :64], qkv[:, 64:128], qkv[:, 128:], 16, 4, mask, keep), att.out_proj.weight, att.out_proj.bias)
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-5)
 
 
 def test_chiunet_update_runs_without_aten_conv_or_groupnorm_kernels(amd_lib, monkeypatch):
