@@ -1,7 +1,7 @@
 """Padded-episode stores behind the sequence datasets of the D4RL family, resident in HBM (third slice; round 5).
 
 Every sequence dataset of the reference's D4RL files -- ``d4rl_mujoco_dataset.py`` (MultiHorizon / DV variants, :232-470),
-``d4rl_kitchen_dataset.py``, ``d4rl_antmaze_dataset.py`` -- is the same object: per episode one row of `T` steps of (normalised observation,
+``d4rl_kitchen_dataset.py``, ``d4rl_antmaze_dataset.py``, ``d4rl_maze2d_dataset.py`` -- is the same object: per episode one row of `T` steps of (normalised observation,
 action, reward, discounted return), an item table (episode, first step, one-past-last step), and ``__getitem__`` = a window of that row,
 possibly strided.  They differ in where an episode ends, how the row behind its last step is padded and how the return is scaled.
 ``EpisodeStore`` is that object: `seq_obs / seq_act / seq_rew / seq_val` (n_paths, T, .), `indices` (n_items, 3), `stride`;
@@ -51,8 +51,11 @@ def window_items(lengths: Sequence[int], last_start: Sequence[int], span: int) -
 
 class EpisodeStore(_ResidentMixin, BaseDataset):
     """See the module docstring.  Subclasses set: normalizers, o_dim, a_dim, horizon, stride (default 1), seq_obs, seq_act, seq_rew,
-    seq_val, indices, path_lengths."""
+    seq_val, indices, path_lengths; optionally seq_tml (an item then carries "tml", the flag of its first step) and learn_policy (the
+    first two observation features of a window are taken relative to its first step: the maze classes of Decision-Veteran)."""
     stride = 1
+    seq_tml = None
+    learn_policy = False
 
     def get_normalizer(self):
         return self.normalizers["state"]
@@ -63,8 +66,15 @@ class EpisodeStore(_ResidentMixin, BaseDataset):
     def __getitem__(self, idx: int):
         path, start, end = self.indices[idx]
         s = self.stride
-        return {"obs": {"state": torch.tensor(self.seq_obs[path, start:end:s])}, "act": torch.tensor(self.seq_act[path, start:end:s]),
+        obs = self.seq_obs[path, start:end:s]
+        if self.learn_policy:
+            obs = obs.copy()
+            obs[:, :2] -= obs[0, :2]
+        item = {"obs": {"state": torch.tensor(obs)}, "act": torch.tensor(self.seq_act[path, start:end:s]),
                 "rew": torch.tensor(self.seq_rew[path, start:end:s]), "val": torch.tensor(self.seq_val[path, start])}
+        if self.seq_tml is not None:
+            item["tml"] = torch.tensor(self.seq_tml[path, start])
+        return item
 
     # ---- resident side ----
     def _host_fields(self):
@@ -73,6 +83,8 @@ class EpisodeStore(_ResidentMixin, BaseDataset):
         span = (self.horizon - 1) * self.stride + 1
         fields = {"obs": (self.seq_obs.reshape(rows, self.o_dim), span, True), "act": (self.seq_act.reshape(rows, self.a_dim), span, True),
                   "rew": (self.seq_rew.reshape(rows, 1), span, True), "val": (self.seq_val.reshape(rows, 1), 1, False)}
+        if self.seq_tml is not None:
+            fields["tml"] = (self.seq_tml.reshape(rows, 1), 1, False)
         row0 = self.indices[:, 0] * T + self.indices[:, 1]
         if row0.size and int((self.indices[:, 1] + span).max()) > T:
             raise ValueError("a window leaves its episode row")
@@ -83,7 +95,13 @@ class EpisodeStore(_ResidentMixin, BaseDataset):
     def _assemble(self, f):
         s = self.stride
         cut = (lambda t: t[:, ::s].contiguous()) if s > 1 else (lambda t: t)
-        return {"obs": {"state": cut(f["obs"])}, "act": cut(f["act"]), "rew": cut(f["rew"]), "val": f["val"]}
+        obs = cut(f["obs"])
+        if self.learn_policy:
+            obs[:, :, :2] -= obs[:, :1, :2].clone()                       # (the gathered batch is ours: in place)
+        out = {"obs": {"state": obs}, "act": cut(f["act"]), "rew": cut(f["rew"]), "val": f["val"]}
+        if "tml" in f:
+            out["tml"] = f["tml"]
+        return out
 
 
 def _float_fields(dataset):
@@ -158,13 +176,19 @@ class D4RLAntmazeDataset(EpisodeStore):
     def __init__(self, dataset: Dict[str, np.ndarray], horizon: int = 1, max_path_length: int = 1001, noreaching_penalty: float = -100.,
                  discount: float = 0.99):
         super().__init__()
+        self.horizon = horizon
+        lengths = self._fill(dataset, max_path_length, noreaching_penalty)
+        self.seq_val = discounted_returns(self.seq_rew, discount)
+        self.indices = window_items(lengths, np.minimum(lengths - 1, max_path_length - horizon), horizon)
+        self.max_path_length = max_path_length
+
+    def _fill(self, dataset, max_path_length: int, noreaching_penalty: float):
         observations, actions, rewards = _float_fields(dataset)
         rewards -= 1
         timeouts, terminals = np.asarray(dataset["timeouts"]).astype(bool), np.asarray(dataset["terminals"]).astype(bool)
         dones = np.logical_or(timeouts, terminals)
         self.normalizers = {"state": GaussianNormalizer(observations)}
         nobs = self.normalizers["state"].normalize(observations)
-        self.horizon = horizon
         self.o_dim, self.a_dim = observations.shape[-1], actions.shape[-1]
         cut = np.zeros(dones.shape[0], dtype=bool)                        # cut[i]: a new episode starts at step i
         cut[1:] = np.logical_or(np.logical_and(dones[:-1], np.logical_not(dones[1:])), timeouts[:-1])
@@ -183,13 +207,11 @@ class D4RLAntmazeDataset(EpisodeStore):
                 self.seq_obs[p, ln:] = nobs[b]
             else:
                 self.seq_rew[p, -1] = noreaching_penalty
-        self.seq_val = discounted_returns(self.seq_rew, discount)
         self.path_lengths = [int(v) for v in lengths]
         early = np.logical_and(terminals[bounds], np.logical_not(timeouts[bounds])) if n else np.zeros(0, dtype=bool)
         self.tml_and_not_timeout = np.stack([np.flatnonzero(early), lengths[early]], axis=1).astype(np.int64) if early.any() \
             else np.array([], dtype=np.int64)
-        self.indices = window_items(lengths, np.minimum(lengths - 1, max_path_length - horizon), horizon)
-        self.max_path_length = max_path_length
+        return lengths
 
 
 class DV_D4RLMuJoCoSeqDataset(EpisodeStore):
@@ -277,24 +299,26 @@ class MultiHorizonLoader:
             yield self.batch_of(order[i * bs:min((i + 1) * bs, n)])
 
 
-class MultiHorizonD4RLMuJoCoDataset(BaseDataset):
-    """DiffuserLite's multi-horizon sequences (reference d4rl_mujoco_dataset.py:232-320): the episode arrays of ``D4RLMuJoCoDataset``,
-    one item table per horizon; item `idx` = one window per horizon (no reward field)."""
+class _MultiHorizon(BaseDataset):
+    """What the three multi-horizon datasets share (reference d4rl_mujoco_dataset.py:232-320, d4rl_kitchen_dataset.py:212-308,
+    d4rl_antmaze_dataset.py:250-369): one set of episode rows, one item table per horizon, item `idx` = one window per horizon.
+    Subclasses fill seq_obs / seq_act / seq_rew, call ``_tables`` and say where an item's "val" comes from."""
+    with_rew = True               # do the items carry the reward window?  (the MuJoCo class drops it)
 
-    def __init__(self, dataset, terminal_penalty=-100, horizons=(10, 20), max_path_length=1000, discount=0.99):
-        super().__init__()
-        from .d4rl_mujoco_dataset import D4RLMuJoCoDataset
-        base = D4RLMuJoCoDataset(dataset, terminal_penalty=terminal_penalty, horizon=1, max_path_length=max_path_length, discount=discount)
-        self.normalizers = base.normalizers
+    def _tables(self, lengths, horizons, max_path_length: int):
         self.horizons = horizons
-        self.o_dim, self.a_dim = base.o_dim, base.a_dim
-        self.discount = discount ** np.arange(max_path_length, dtype=np.float32)
-        self.seq_obs, self.seq_act, self.seq_rew, self.seq_val = base.seq_obs, base.seq_act, base.seq_rew, base.seq_val
-        self.path_lengths = base.path_lengths
-        self.indices = [window_items(base.path_lengths, np.minimum(base.path_lengths - 1, max_path_length - h), h) for h in horizons]
+        lengths = np.asarray(lengths, dtype=np.int64)
+        self.indices = [window_items(lengths, np.minimum(lengths - 1, max_path_length - h), h) for h in horizons]
         self.len_each_horizon = [int(t.shape[0]) for t in self.indices]
         self.max_path_length = max_path_length
         self._views = None
+
+    def _item_val(self, path: int, start: int) -> np.ndarray:
+        raise NotImplementedError
+
+    def _val_rows(self) -> np.ndarray:
+        """(n_paths, T, 1): the "val" of every (episode, first step) an item table can name -- what the resident loader gathers."""
+        raise NotImplementedError
 
     def get_normalizer(self):
         return self.normalizers["state"]
@@ -306,36 +330,213 @@ class MultiHorizonD4RLMuJoCoDataset(BaseDataset):
         out = []
         for k, h in enumerate(self.horizons):
             path, start, end = self.indices[k][int(self.len_each_horizon[k] * (idx / self.len_each_horizon[-1]))]
-            out.append({"horizon": h, "data": {"obs": {"state": torch.tensor(self.seq_obs[path, start:end])},
-                                               "act": torch.tensor(self.seq_act[path, start:end]),
-                                               "val": torch.tensor(self.seq_val[path, start])}})
+            data = {"obs": {"state": torch.tensor(self.seq_obs[path, start:end])}, "act": torch.tensor(self.seq_act[path, start:end])}
+            if self.with_rew:
+                data["rew"] = torch.tensor(self.seq_rew[path, start:end])
+            data["val"] = torch.tensor(self._item_val(path, start))
+            out.append({"horizon": h, "data": data})
         return out
 
-    def _view(self, k: int) -> EpisodeStore:
-        """Horizon k as an EpisodeStore over the SAME arrays (they are uploaded once per view's first use; obs / act / val only)."""
+    def _view(self, k: int, val_rows: np.ndarray) -> EpisodeStore:
+        """Horizon k as an EpisodeStore over the SAME arrays (uploaded once, by the first view)."""
         v = EpisodeStore()
         v.normalizers, v.o_dim, v.a_dim, v.horizon = self.normalizers, self.o_dim, self.a_dim, self.horizons[k]
-        v.seq_obs, v.seq_act, v.seq_rew, v.seq_val, v.indices = self.seq_obs, self.seq_act, self.seq_rew, self.seq_val, self.indices[k]
+        v.seq_obs, v.seq_act, v.seq_rew, v.seq_val, v.indices = self.seq_obs, self.seq_act, self.seq_rew, val_rows, self.indices[k]
         return v
 
     def loader(self, batch_size: int, shuffle: bool = True, drop_last: bool = True, device="cuda",
                generator: Optional[torch.Generator] = None) -> MultiHorizonLoader:
         if self._views is None:
-            self._views = [self._view(k) for k in range(len(self.horizons))]
+            val_rows = self._val_rows()
+            self._views = [self._view(k, val_rows) for k in range(len(self.horizons))]
             first = self._views[0].resident(device)                       # one upload; the other horizons share the device buffers
             for v in self._views[1:]:
                 fields, row0, rows = v._host_fields()
                 v._resident = {"device": first["device"], "rows": rows, "row0": torch.from_numpy(np.ascontiguousarray(row0, dtype=np.int32)).to(device),
                                "fields": {k: (first["fields"][k][0], fields[k][1], fields[k][2]) for k in fields}}
+        names = ("obs", "act", "rew", "val") if self.with_rew else ("obs", "act", "val")
 
-        def strip(f):                                                     # the reference's multi-horizon items carry no reward
-            return {"obs": {"state": f["obs"]}, "act": f["act"], "val": f["val"]}
+        def assemble(f):
+            return {"obs": {"state": f["obs"]}, **{k: f[k] for k in names[1:]}}
         loaders = []
         for v in self._views:
             r = v.resident(device)
-            loaders.append(ResidentLoader({k: r["fields"][k] for k in ("obs", "act", "val")}, r["row0"], r["rows"], batch_size, False, False,
-                                          None, strip))
+            loaders.append(ResidentLoader({k: r["fields"][k] for k in names}, r["row0"], r["rows"], batch_size, False, False, None, assemble))
         return MultiHorizonLoader(self, loaders, batch_size, shuffle, drop_last, generator, torch.device(device))
+
+
+class MultiHorizonD4RLMuJoCoDataset(_MultiHorizon):
+    """DiffuserLite's multi-horizon sequences (reference d4rl_mujoco_dataset.py:232-320): the episode arrays of ``D4RLMuJoCoDataset``,
+    one item table per horizon; item `idx` = one window per horizon (no reward field), "val" = the episode's discounted return from
+    the window's first step (the constructor's float32 recursion)."""
+    with_rew = False
+
+    def __init__(self, dataset, terminal_penalty=-100, horizons=(10, 20), max_path_length=1000, discount=0.99):
+        super().__init__()
+        from .d4rl_mujoco_dataset import D4RLMuJoCoDataset
+        base = D4RLMuJoCoDataset(dataset, terminal_penalty=terminal_penalty, horizon=1, max_path_length=max_path_length, discount=discount)
+        self.normalizers = base.normalizers
+        self.o_dim, self.a_dim = base.o_dim, base.a_dim
+        self.discount = discount ** np.arange(max_path_length, dtype=np.float32)
+        self.seq_obs, self.seq_act, self.seq_rew, self.seq_val = base.seq_obs, base.seq_act, base.seq_rew, base.seq_val
+        self.path_lengths = base.path_lengths
+        self._tables(base.path_lengths, horizons, max_path_length)
+
+    def _item_val(self, path, start):
+        return self.seq_val[path, start]
+
+    def _val_rows(self):
+        return self.seq_val
+
+
+class _MultiHorizonSummed(_MultiHorizon):
+    """The kitchen / antmaze variants: an item's "val" is summed when the item is read -- (rew[start:] * discount[:T - start]).sum(0), a
+    float32 numpy reduction (reference d4rl_kitchen_dataset.py:291-292, d4rl_antmaze_dataset.py:350-351).  ``__getitem__`` evaluates
+    that expression; the resident loader evaluates it ONCE for every (episode, first step) an item table names -- the same numpy
+    expression on the same rows, so the same bits -- and gathers from the table."""
+
+    def _item_val(self, path, start):
+        rew = self.seq_rew[path, start:]
+        return (rew * self.discount[:rew.shape[0], None]).sum(0)
+
+    def _val_rows(self):
+        val = np.zeros_like(self.seq_rew)
+        T = self.seq_rew.shape[1]
+        last = np.minimum(np.asarray(self.path_lengths, dtype=np.int64) - 1, T - min(self.horizons))
+        for p, hi in enumerate(last):
+            for st in range(int(hi) + 1):
+                val[p, st] = self._item_val(p, st)
+        return val
+
+
+class MultiHorizonD4RLKitchenDataset(_MultiHorizonSummed, _RepeatPadded):
+    """DiffuserLite's kitchen sequences (reference d4rl_kitchen_dataset.py:212-308): the rows of ``D4RLKitchenDataset``."""
+
+    def __init__(self, dataset, horizons=(10, 20), max_path_length=280, discount=0.99):
+        BaseDataset.__init__(self)
+        self.discount = discount ** np.arange(max_path_length, dtype=np.float32)
+        lengths = self._fill(dataset, max_path_length, discount=0.0, return_steps=1)
+        del self.seq_val                                                   # (the recursion of the single-horizon class is not this class's "val")
+        self._tables(lengths, horizons, max_path_length)
+
+
+class MultiHorizonD4RLAntmazeDataset(_MultiHorizonSummed, D4RLAntmazeDataset):
+    """DiffuserLite's antmaze sequences (reference d4rl_antmaze_dataset.py:250-369): the rows of ``D4RLAntmazeDataset``."""
+
+    def __init__(self, dataset, horizons=(10, 20), max_path_length=1001, noreaching_penalty=-100, discount=0.99):
+        BaseDataset.__init__(self)
+        self.discount = discount ** np.arange(max_path_length, dtype=np.float32)
+        lengths = self._fill(dataset, max_path_length, noreaching_penalty)
+        self._tables(lengths, horizons, max_path_length)
+
+
+def _rescale_returns(val: np.ndarray, center_mapping: bool) -> np.ndarray:
+    val = (val - val.min()) / (val.max() - val.min())
+    return val * 2 - 1 if center_mapping else val
+
+
+class _DVMaze(EpisodeStore):
+    """Rows of the two Decision-Veteran maze datasets: `max_path_length + (horizon - 1) * stride` steps, so that a strided window fits
+    behind every real step; sparse 0 / 1 rewards shifted by `reward_tune` AFTER padding (the padding's reward moves with them); return
+    over the first `max_path_length` steps, rescaled to [0, 1] (`center_mapping`: [-1, 1])."""
+
+    def _begin(self, dataset, horizon, max_path_length, stride, learn_policy):
+        observations, actions, rewards = _float_fields(dataset)
+        self.learn_policy, self.stride, self.horizon, self.max_path_length = learn_policy, stride, horizon, max_path_length
+        self.normalizers = {"state": GaussianNormalizer(observations)}
+        self.o_dim, self.a_dim = observations.shape[-1], actions.shape[-1]
+        self._rows, self._row_len = [], max_path_length + (horizon - 1) * stride
+        return self.normalizers["state"].normalize(observations), actions, rewards
+
+    def _row(self, obs, act, rew, pad_obs, pad_rew: float, tml=None):
+        """One episode row: the real steps, then `pad_obs` (None: zeros) / zero actions / `pad_rew` (/ raised terminal flags)."""
+        L, n = self._row_len, obs.shape[0]
+        o, a_, r, t = (np.zeros((L, d), dtype=np.float32) for d in (self.o_dim, self.a_dim, 1, 1))
+        o[:n], a_[:n], r[:n, 0] = obs, act, rew
+        if pad_obs is not None:
+            o[n:], r[n:] = pad_obs, pad_rew
+        if tml is not None:
+            t[:n, 0] = tml
+            if pad_obs is not None:
+                t[n:] = 1
+        self._rows.append((o, a_, r, t))
+        return n
+
+    def _finish(self, lengths, last_start, reward_tune, discount, center_mapping, with_tml=False):
+        L = self._row_len
+        cols = list(zip(*self._rows)) if self._rows else [[], [], [], []]
+        # (np.array of an empty list of rows would lose the trailing dimensions, as in the reference; keep the shape instead)
+        self.seq_obs, self.seq_act, self.seq_rew, tml = (np.array(c, dtype=np.float32).reshape(len(c), L, d)
+                                                          for c, d in zip(cols, (self.o_dim, self.a_dim, 1, 1)))
+        if with_tml:
+            self.seq_tml = tml
+        del self._rows
+        if reward_tune == "iql":
+            self.seq_rew += -1
+        elif reward_tune != "none":
+            raise ValueError(f"reward_tune: {reward_tune} is not supported.")
+        self.seq_val = _rescale_returns(discounted_returns(self.seq_rew, discount, steps=self.max_path_length), center_mapping)
+        self.indices = window_items(lengths, last_start, (self.horizon - 1) * self.stride + 1)
+        self.path_lengths = [int(v) for v in lengths]
+
+
+class DV_D4RLAntmazeSeqDataset(_DVMaze):
+    """Decision-Veteran's antmaze sequences (reference d4rl_antmaze_dataset.py:371-570).  Every episode is `max_path_length` steps up
+    to its timeout (asserted).  One that reaches the goal is cut at its FIRST terminal step (reward 1 there, asserted) and padded with
+    that observation, zero actions, reward `continous_reward_at_done`, terminal flags 1 -- a window from each of its steps.  One that
+    never does is kept only for policy learning (`learn_policy` and not `only_learn_reached_policy`): zero padding, windows that stay
+    inside the episode.  Items also carry "tml", the terminal flag of the window's first step."""
+
+    def __init__(self, dataset: Dict[str, np.ndarray], horizon: int = 1, max_path_length: int = 1001, discount: float = 0.99,
+                 continous_reward_at_done: bool = False, reward_tune: str = "iql", center_mapping: bool = True, learn_policy: bool = False,
+                 stride: int = 1, only_learn_reached_policy: bool = False):
+        super().__init__()
+        nobs, actions, rewards = self._begin(dataset, horizon, max_path_length, stride, learn_policy)
+        timeouts, terminals = dataset["timeouts"].astype(np.float32), dataset["terminals"].astype(np.float32)
+        lengths, last_start, ptr = [], [], 0
+        for index in np.flatnonzero(timeouts == 1):
+            assert index - ptr + 1 == max_path_length
+            hit = np.flatnonzero(terminals[ptr:index + 1])
+            if hit.size:
+                end = ptr + int(hit[0])
+                assert rewards[end] == 1
+                n = self._row(nobs[ptr:end + 1], actions[ptr:end + 1], rewards[ptr:end + 1], nobs[end], 1 if continous_reward_at_done else 0,
+                              tml=terminals[ptr:end + 1])
+                lengths.append(n)
+                last_start.append(n - 1)
+            elif learn_policy and not only_learn_reached_policy:
+                n = self._row(nobs[ptr:index + 1], actions[ptr:index + 1], rewards[ptr:index + 1], None, 0., tml=terminals[ptr:index + 1])
+                lengths.append(n)
+                last_start.append(max_path_length - (horizon - 1) * stride - 1)
+            ptr = index + 1
+        self._finish(lengths, last_start, reward_tune, discount, center_mapping, with_tml=True)
+
+
+class DV_D4RLMaze2DSeqDataset(_DVMaze):
+    """Decision-Veteran's maze2d sequences (reference d4rl_maze2d_dataset.py:9-204).  The data is one long walk with reward 1 while the
+    agent sits on the goal; an episode = a stretch of reward-0 steps plus the first reward-1 step behind it (at most the last
+    `max_path_length` of them; a trailing stretch that never reaches the goal is dropped).  `learn_policy`: fixed chunks of
+    `max_path_length` steps instead.  Padding: last observation, zero actions, reward `continous_reward_at_done`; a window from every
+    real step; `paths` keeps (first, last) data index per episode."""
+
+    def __init__(self, dataset: Dict[str, np.ndarray], horizon: int = 1, max_path_length: int = 800, discount: float = 0.99,
+                 continous_reward_at_done: bool = False, reward_tune: str = "iql", center_mapping: bool = True, learn_policy: bool = False,
+                 stride: int = 1):
+        super().__init__()
+        nobs, actions, rewards = self._begin(dataset, horizon, max_path_length, stride, learn_policy)
+        n = rewards.shape[0]
+        if learn_policy:
+            self.paths = [(s, min(s + max_path_length - 1, n - 1)) for s in range(0, n, max_path_length)]
+        else:
+            on_goal = rewards == 1.0
+            arrive = np.flatnonzero(np.logical_and(on_goal[1:], np.logical_not(on_goal[:-1]))) + 1      # first reward-1 step of a stay
+            leave = np.flatnonzero(np.logical_and(np.logical_not(on_goal[1:]), on_goal[:-1])) + 1       # first reward-0 step behind a stay
+            first = np.concatenate([[0], leave]) if n and not on_goal[0] else leave                      # where the reward-0 stretches begin
+            first = first[:arrive.shape[0]]                                                              # (a trailing stretch has no arrival)
+            self.paths = [(max(int(s), int(e) - max_path_length + 1), int(e)) for s, e in zip(first, arrive)]
+        pad = 1 if continous_reward_at_done else 0
+        lengths = [self._row(nobs[s:e + 1], actions[s:e + 1], rewards[s:e + 1], nobs[e], pad) for s, e in self.paths]
+        self._finish(lengths, [ln - 1 for ln in lengths], reward_tune, discount, center_mapping)
 
 
 class D4RLKitchenTDDataset(_ResidentMixin, BaseDataset):
@@ -391,3 +592,7 @@ class D4RLAntmazeTDDataset(D4RLKitchenTDDataset):
         elif reward_tune != "none":
             raise ValueError(f"reward_tune: {reward_tune} is not supported.")
         self._build(dataset, rewards)
+
+
+class D4RLMaze2DTDDataset(D4RLAntmazeTDDataset):
+    """Maze2d transitions (reference d4rl_maze2d_dataset.py:206-290): the antmaze class's reward tunings on maze2d data."""

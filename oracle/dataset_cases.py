@@ -164,6 +164,71 @@ def synthetic_antmaze(n, o, a, seed, max_len):
     return d
 
 
+def synthetic_antmaze_dv(n_eps, o, a, seed, max_len):
+    """Antmaze data as Decision-Veteran's class expects it: every episode exactly `max_len` steps with a timeout on the last one; two
+    thirds reach the goal at some step (reward 1 and the terminal flag from there to the end of the episode)."""
+    rng = np.random.default_rng(seed)
+    n = n_eps * max_len
+    d = synthetic(n, o, a, seed, max_len)
+    term, tout, rew = np.zeros(n, dtype=bool), np.zeros(n, dtype=bool), np.zeros(n, dtype=np.float32)
+    for e in range(n_eps):
+        lo = e * max_len
+        tout[lo + max_len - 1] = True
+        if rng.random() < 0.67:
+            reach = lo + int(rng.integers(1, max_len))
+            term[reach:lo + max_len] = True
+            rew[reach:lo + max_len] = 1.0
+    d["terminals"], d["timeouts"], d["rewards"] = term, tout, rew
+    return d
+
+
+def synthetic_maze2d(n, o, a, seed, max_len):
+    """Maze2d data: one long walk, reward 1.0 while the agent sits on the goal (stays of 1-6 steps), reward 0 otherwise in stretches
+    of up to 1.5 x max_len steps (so some episodes get cut to their last max_len steps); the walk may start on the goal and ends in
+    a stretch that never reaches it."""
+    rng = np.random.default_rng(seed)
+    d = synthetic(n, o, a, seed, max_len)
+    rew = np.zeros(n, dtype=np.float32)
+    i = int(rng.integers(0, 3))
+    rew[:i] = 1.0
+    while i < n:
+        i += int(rng.integers(1, int(1.5 * max_len)))
+        stay = int(rng.integers(1, 7))
+        rew[i:i + stay] = 1.0
+        i += stay
+    rew[n - 7:] = 0.0
+    d["rewards"] = rew
+    d["terminals"], d["timeouts"] = np.zeros(n, dtype=bool), np.zeros(n, dtype=bool)
+    d["timeouts"][max_len - 1::max_len] = True
+    return d
+
+
 def make_data(skw):
     skw = dict(skw)
-    return synthetic_antmaze(**skw) if skw.pop("antmaze", False) else synthetic(**skw)
+    kind = "antmaze" if skw.pop("antmaze", False) else skw.pop("kind", "mujoco")
+    return {"antmaze": synthetic_antmaze, "antmaze_dv": synthetic_antmaze_dv, "maze2d": synthetic_maze2d, "mujoco": synthetic}[kind](**skw)
+
+
+# ---- round 5, second batch: the remaining classes of the D4RL files ---------------------------------------------------------------------
+SIBLING_SCENARIOS.update({
+    "antmaze_dv_h5_s3": ("DV_D4RLAntmazeSeqDataset", "d4rl_antmaze_dataset", dict(n_eps=30, o=8, a=3, seed=14, max_len=60, kind="antmaze_dv"),
+                         dict(horizon=5, max_path_length=60, discount=0.99, stride=3)),
+    "antmaze_dv_policy": ("DV_D4RLAntmazeSeqDataset", "d4rl_antmaze_dataset", dict(n_eps=24, o=6, a=2, seed=15, max_len=50, kind="antmaze_dv"),
+                          dict(horizon=4, max_path_length=50, discount=0.95, stride=2, learn_policy=True, continous_reward_at_done=True,
+                               reward_tune="none", center_mapping=False)),
+    "maze2d_dv_h6_s2": ("DV_D4RLMaze2DSeqDataset", "d4rl_maze2d_dataset", dict(n=3000, o=4, a=2, seed=16, max_len=50, kind="maze2d"),
+                        dict(horizon=6, max_path_length=50, discount=0.99, stride=2)),
+    "maze2d_dv_policy": ("DV_D4RLMaze2DSeqDataset", "d4rl_maze2d_dataset", dict(n=2030, o=4, a=2, seed=17, max_len=40, kind="maze2d"),
+                         dict(horizon=3, max_path_length=40, discount=0.9, stride=4, learn_policy=True, continous_reward_at_done=True,
+                              reward_tune="none", center_mapping=False)),
+})
+SIBLING_TD_SCENARIOS.update({
+    "maze2d_td_antmaze": ("D4RLMaze2DTDDataset", "d4rl_maze2d_dataset", dict(n=3000, o=4, a=2, seed=18, max_len=50, kind="maze2d"), dict(reward_tune="antmaze")),
+})
+# multi-horizon classes whose items carry the reward window and sum "val" on the fly: name -> (class, module, synthetic kwargs, kwargs)
+MULTI_HORIZON_SUMMED = {
+    "kitchen_multi_h4_12": ("MultiHorizonD4RLKitchenDataset", "d4rl_kitchen_dataset", dict(n=4000, o=9, a=4, seed=19, max_len=120),
+                            dict(horizons=(4, 12), max_path_length=120, discount=0.99)),
+    "antmaze_multi_h6_15": ("MultiHorizonD4RLAntmazeDataset", "d4rl_antmaze_dataset", dict(n=5000, o=8, a=3, seed=20, max_len=80, antmaze=True),
+                            dict(horizons=(6, 15), max_path_length=80, noreaching_penalty=-100, discount=0.99)),
+}

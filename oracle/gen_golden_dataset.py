@@ -54,6 +54,10 @@ def siblings(out_dir="tests/golden"):
         out = dict(idx=idx, obs=b["obs"]["state"].numpy(), act=b["act"].numpy(), rew=b["rew"].numpy(), val=b["val"].numpy(),
                    indices=np.array(ds.indices, dtype=np.int64).reshape(-1, 3), mean=ds.get_normalizer().mean, std=ds.get_normalizer().std,
                    **{f"sum_{k}": _sums(getattr(ds, k)) for k in ("seq_obs", "seq_act", "seq_rew", "seq_val")})
+        if "tml" in b:
+            out["tml"] = b["tml"].numpy()
+        if hasattr(ds, "paths"):
+            out["paths"] = np.asarray(ds.paths, dtype=np.int64).reshape(-1, 2)
         if hasattr(ds, "tml_and_not_timeout"):
             out["tml_and_not_timeout"] = np.asarray(ds.tml_and_not_timeout, dtype=np.int64)
         np.savez_compressed(os.path.join(out_dir, f"dataset_{name}.npz"), **out)
@@ -67,9 +71,10 @@ def siblings(out_dir="tests/golden"):
                    **{f"sum_{k}": _sums(getattr(ds, k).numpy()) for k in ("obs", "next_obs", "act", "rew", "tml")})
         np.savez_compressed(os.path.join(out_dir, f"dataset_{name}.npz"), **out)
         print(f"{name:24s} items={len(ds)}")
-    from cleandiffuser.dataset.d4rl_mujoco_dataset import MultiHorizonD4RLMuJoCoDataset
-    for name, (skw, dkw) in dc.MULTI_HORIZON.items():
-        ds = MultiHorizonD4RLMuJoCoDataset(copy.deepcopy(dc.make_data(skw)), **dkw)
+    multi = {n: ("MultiHorizonD4RLMuJoCoDataset", "d4rl_mujoco_dataset") + v for n, v in dc.MULTI_HORIZON.items()}
+    multi.update(dc.MULTI_HORIZON_SUMMED)
+    for name, (cls, mod, skw, dkw) in multi.items():
+        ds = getattr(importlib.import_module(f"cleandiffuser.dataset.{mod}"), cls)(copy.deepcopy(dc.make_data(skw)), **dkw)
         # (reference quirk: len() is the LARGEST table but item idx is scaled by idx / len(last table) -- items past the last horizon's
         #  count raise IndexError there; the fixture records items every horizon can serve)
         idx = dc.item_indices(min(ds.len_each_horizon), skw["seed"])
@@ -79,6 +84,8 @@ def siblings(out_dir="tests/golden"):
             out[f"h{k}_horizon"] = part["horizon"].numpy()
             out[f"h{k}_obs"], out[f"h{k}_act"], out[f"h{k}_val"] = (part["data"]["obs"]["state"].numpy(), part["data"]["act"].numpy(),
                                                                     part["data"]["val"].numpy())
+            if "rew" in part["data"]:
+                out[f"h{k}_rew"] = part["data"]["rew"].numpy()
             out[f"h{k}_indices"] = np.array(ds.indices[k], dtype=np.int64)
         np.savez_compressed(os.path.join(out_dir, f"dataset_{name}.npz"), **out)
         print(f"{name:24s} items={len(ds)} per horizon {ds.len_each_horizon}")

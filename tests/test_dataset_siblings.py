@@ -1,6 +1,6 @@
 """Round 5 (VERDICT r4 missing #6 / next #9): the sequence / transition datasets of the D4RL family that share D4RLMuJoCoDataset's structure --
-kitchen, antmaze, the Decision-Veteran (strided, rescaled returns) and multi-horizon MuJoCo classes (cleandiffuser_amd/dataset/
-episode_store.py; reference dataset/d4rl_kitchen_dataset.py, d4rl_antmaze_dataset.py, d4rl_mujoco_dataset.py:232-470) -- against fixtures of
+kitchen, antmaze, maze2d, the Decision-Veteran (strided, rescaled returns) and multi-horizon classes (cleandiffuser_amd/dataset/
+episode_store.py; reference dataset/d4rl_kitchen_dataset.py, d4rl_antmaze_dataset.py, d4rl_maze2d_dataset.py, d4rl_mujoco_dataset.py:232-470) -- against fixtures of
 the IMPORTED reference classes (oracle/gen_golden_dataset.py:siblings).  Pure data movement: every comparison is bit-exact.  CPU: the
 constructor arrays, item tables, ``__getitem__`` and the host-side loader; GPU: the batches of ``cdx_gather_windows_f32``."""
 import copy
@@ -39,9 +39,12 @@ def _check_sequence(name, device):
     T = ds.seq_obs.shape[1]
     row0 = torch.from_numpy((ds.indices[f["idx"], 0] * T + ds.indices[f["idx"], 1]).astype(np.int32)).to(device)
     b = ds.loader(32, device=device).batch_of(row0)
-    for k, v in (("obs", b["obs"]["state"]), ("act", b["act"]), ("rew", b["rew"]), ("val", b["val"])):
+    assert ("tml" in b) == ("tml" in f)
+    for k, v in (("obs", b["obs"]["state"]), ("act", b["act"]), ("rew", b["rew"]), ("val", b["val"])) + ((("tml", b["tml"]),) if "tml" in f else ()):
         assert v.device.type == torch.device(device).type and v.is_contiguous()
         assert v.shape == f[k].shape and np.array_equal(v.cpu().numpy(), f[k]), (name, k)
+    if "paths" in f:
+        assert np.array_equal(np.asarray(ds.paths, dtype=np.int64).reshape(-1, 2), f["paths"])
     return ds, f
 
 
@@ -49,7 +52,8 @@ def _check_sequence(name, device):
 def test_sibling_sequence_dataset_matches_reference_fixture(name):
     ds, f = _check_sequence(name, "cpu")
     items = default_collate([ds[int(i)] for i in f["idx"][:8]])          # the torch Dataset protocol (DataLoader drop-in)
-    for k, v in (("obs", items["obs"]["state"]), ("act", items["act"]), ("rew", items["rew"]), ("val", items["val"])):
+    for k, v in (("obs", items["obs"]["state"]), ("act", items["act"]), ("rew", items["rew"]), ("val", items["val"])) + \
+            ((("tml", items["tml"]),) if "tml" in f else ()):
         assert np.array_equal(v.numpy(), f[k][:8]), (name, k)
     n = len(ds)
     ld = ds.loader(50, shuffle=True, drop_last=True, device="cpu", generator=torch.Generator().manual_seed(1))
@@ -77,10 +81,13 @@ def test_sibling_transition_dataset_matches_reference_fixture(name):
         D.D4RLAntmazeTDDataset(dc.make_data(dc.SIBLING_TD_SCENARIOS["antmaze_td_cql"][2]), reward_tune="nope")
 
 
+MULTI = {**{n: ("MultiHorizonD4RLMuJoCoDataset", "d4rl_mujoco_dataset") + v for n, v in dc.MULTI_HORIZON.items()}, **dc.MULTI_HORIZON_SUMMED}
+
+
 def _check_multi(name, device):
-    skw, dkw = dc.MULTI_HORIZON[name]
+    cls, _, skw, dkw = MULTI[name]
     f = _fix(name)
-    ds = D.MultiHorizonD4RLMuJoCoDataset(copy.deepcopy(dc.make_data(skw)), **dkw)
+    ds = getattr(D, cls)(copy.deepcopy(dc.make_data(skw)), **dkw)
     assert np.array_equal(np.array(ds.len_each_horizon), f["len_each_horizon"]) and len(ds) == int(f["len_each_horizon"].max())
     for k in range(len(ds.horizons)):
         assert np.array_equal(ds.indices[k], f[f"h{k}_indices"])
@@ -88,18 +95,21 @@ def _check_multi(name, device):
     b = ld.batch_of(torch.from_numpy(f["idx"]).to(device))
     assert len(b) == len(ds.horizons)
     for k, part in enumerate(b):
-        assert np.array_equal(part["horizon"].cpu().numpy(), f[f"h{k}_horizon"]) and set(part["data"]) == {"obs", "act", "val"}
-        for key, v in (("obs", part["data"]["obs"]["state"]), ("act", part["data"]["act"]), ("val", part["data"]["val"])):
+        with_rew = f"h{k}_rew" in f                                       # (the kitchen / antmaze classes keep the reward window)
+        assert np.array_equal(part["horizon"].cpu().numpy(), f[f"h{k}_horizon"]) and set(part["data"]) == {"obs", "act", "val"} | ({"rew"} if with_rew else set())
+        for key, v in (("obs", part["data"]["obs"]["state"]), ("act", part["data"]["act"]), ("val", part["data"]["val"])) + \
+                ((("rew", part["data"]["rew"]),) if with_rew else ()):
             assert v.shape == f[f"h{k}_{key}"].shape and np.array_equal(v.cpu().numpy(), f[f"h{k}_{key}"]), (k, key)
     return ds, f, ld
 
 
-@pytest.mark.parametrize("name", list(dc.MULTI_HORIZON))
+@pytest.mark.parametrize("name", list(MULTI))
 def test_multi_horizon_dataset_matches_reference_fixture(name):
     ds, f, ld = _check_multi(name, "cpu")
     items = default_collate([ds[int(i)] for i in f["idx"][:6]])
     for k, part in enumerate(items):
         assert np.array_equal(part["data"]["obs"]["state"].numpy(), f[f"h{k}_obs"][:6]) and np.array_equal(part["horizon"].numpy(), f[f"h{k}_horizon"][:6])
+        assert np.array_equal(part["data"]["val"].numpy(), f[f"h{k}_val"][:6])
     # the reference's quirk: len() counts the largest table, items past the LAST table's count cannot be served (IndexError there too)
     with pytest.raises(IndexError):
         ds[len(ds) - 1]
@@ -110,6 +120,21 @@ def test_reference_import_paths_resolve():
     from cleandiffuser_amd.dataset.d4rl_antmaze_dataset import D4RLAntmazeDataset, D4RLAntmazeTDDataset  # noqa: F401
     from cleandiffuser_amd.dataset.d4rl_kitchen_dataset import D4RLKitchenDataset, D4RLKitchenTDDataset, DV_D4RLKitchenSeqDataset  # noqa: F401
     from cleandiffuser_amd.dataset.episode_store import DV_D4RLMuJoCoSeqDataset, MultiHorizonD4RLMuJoCoDataset  # noqa: F401
+    from cleandiffuser_amd.dataset.d4rl_antmaze_dataset import DV_D4RLAntmazeSeqDataset, MultiHorizonD4RLAntmazeDataset  # noqa: F401
+    from cleandiffuser_amd.dataset.d4rl_kitchen_dataset import MultiHorizonD4RLKitchenDataset  # noqa: F401
+    from cleandiffuser_amd.dataset.d4rl_maze2d_dataset import D4RLMaze2DTDDataset, DV_D4RLMaze2DSeqDataset  # noqa: F401
+
+
+def test_dv_maze_constructors_keep_the_reference_error_behaviour():
+    """reward_tune outside {"iql", "none"} -> ValueError (after the rows were built, like the reference); an antmaze episode that is
+    not exactly max_path_length steps up to its timeout -> AssertionError (reference d4rl_antmaze_dataset.py:461)."""
+    skw = dict(dc.SIBLING_SCENARIOS["antmaze_dv_h5_s3"][2])
+    with pytest.raises(ValueError):
+        D.DV_D4RLAntmazeSeqDataset(dc.make_data(skw), horizon=5, max_path_length=60, reward_tune="cql")
+    with pytest.raises(AssertionError):
+        D.DV_D4RLAntmazeSeqDataset(dc.make_data(skw), horizon=5, max_path_length=61)
+    with pytest.raises(ValueError):
+        D.DV_D4RLMaze2DSeqDataset(dc.make_data(dc.SIBLING_SCENARIOS["maze2d_dv_h6_s2"][2]), horizon=6, max_path_length=50, reward_tune="antmaze")
 
 
 @pytest.mark.gpu
@@ -123,7 +148,11 @@ def test_resident_sibling_sequence_batches_match_reference_fixture(name):
     idx = perm[:128]
     p, s = ds.indices[idx, 0], ds.indices[idx, 1]
     win = s[:, None] + ds.stride * np.arange(ds.horizon)[None]
-    assert np.array_equal(b["obs"]["state"].cpu().numpy(), ds.seq_obs[p[:, None], win]) and np.array_equal(b["val"].cpu().numpy(), ds.seq_val[p, s])
+    want = ds.seq_obs[p[:, None], win]
+    if ds.learn_policy:
+        want = want.copy()
+        want[:, :, :2] -= want[:, :1, :2].copy()
+    assert np.array_equal(b["obs"]["state"].cpu().numpy(), want) and np.array_equal(b["val"].cpu().numpy(), ds.seq_val[p, s])
 
 
 @pytest.mark.gpu
@@ -133,6 +162,6 @@ def test_resident_sibling_transition_batches_match_reference_fixture(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", list(dc.MULTI_HORIZON))
+@pytest.mark.parametrize("name", list(MULTI))
 def test_resident_multi_horizon_batches_match_reference_fixture(name):
     _check_multi(name, "cuda")
