@@ -77,7 +77,8 @@ class DiffusionModel:
         g = train.graphed_step(self, x0, condition, kwargs)
         if g is None:
             loss = self.loss(x0, condition, **kwargs)
-            loss.backward()
+            with train.grads_in_place():               # the library's nodes add parameter gradients straight into .grad
+                loss.backward()
             return loss
         loss = g.replay(x0, condition)
         if hasattr(self.optimizer, "_gver"):

@@ -223,10 +223,12 @@ def groupnorm(x: torch.Tensor, gamma, beta, batch: int, length: int, groups: int
 
 
 def groupnorm_backward(dy: torch.Tensor, x: torch.Tensor, gamma, beta, batch: int, length: int, groups: int,
-                       act: str = "mish", eps: float = 1e-5, out: Optional[torch.Tensor] = None, param_grads: bool = False):
+                       act: str = "mish", eps: float = 1e-5, out: Optional[torch.Tensor] = None, param_grads: bool = False,
+                       grads_out=None):
     """d loss / d x for y = act(groupnorm(x) * gamma + beta), given dy = d loss / d y (x is the saved forward input).
     `param_grads`: also (d loss / d gamma, d loss / d beta) -- per-sample partial sums out of the same launch, summed over the batch by
-    cdx_colsum_f32 -> (dx, dgamma, dbeta)."""
+    cdx_colsum_f32 -> (dx, dgamma, dbeta).  `grads_out` = (tensor, tensor): the two sums are ADDED to these (the parameters'
+    ``.grad``) instead of landing in a fresh zeroed block -> (dx, None, None)."""
     if out is None:
         out = torch.empty_like(x)
     c = x.shape[1]
@@ -242,6 +244,11 @@ def groupnorm_backward(dy: torch.Tensor, x: torch.Tensor, gamma, beta, batch: in
         return out
     # (the two (batch, C) partial blocks lie back to back: summed as 2 x batch rows into one zeroed (2, C) block by two launches that
     #  share the memset)
+    if grads_out is not None:
+        assert all(t.is_contiguous() and t.numel() == c and t.dtype == torch.float32 for t in grads_out)
+        colsum(pg[0], out=grads_out[0])
+        colsum(pg[1], out=grads_out[1])
+        return out, None, None
     g = torch.zeros((2, c), device=x.device, dtype=torch.float32)
     colsum(pg[0], out=g[0])
     colsum(pg[1], out=g[1])
@@ -277,16 +284,23 @@ def gather_windows(row0: torch.Tensor, fields, rows: int):
 
 
 def conv_wgrad(p: torch.Tensor, q: torch.Tensor, batch: int, l_p: int, l_q: int, taps: int, stride: int = 1, pad: int = 0,
-               k_split: int = 0, bias_grad: bool = False):
+               k_split: int = 0, bias_grad: bool = False, dw_out: Optional[torch.Tensor] = None, db_out: Optional[torch.Tensor] = None):
     """dw[a][b][t] = sum_{n, m} p[(n, m)][a] * q[(n, m * stride + t - pad)][b] -> (ca, cb, taps), the layout of nn.Conv1d.weight with
     p = d loss / d y, q = x (and of nn.ConvTranspose1d.weight with p = x, q = d loss / d y, stride 2, pad 1).  One launch.
-    `bias_grad` (p = d loss / d y): also the column sums of p out of the same launch -> (dw, db); both live in ONE zeroed buffer."""
+    `bias_grad` (p = d loss / d y): also the column sums of p out of the same launch -> (dw, db); both live in ONE zeroed buffer.
+    `dw_out` (ca * cb * taps contiguous floats) [/ `db_out` (ca)]: ADD the sums to these tensors instead (a parameter's ``.grad``:
+    the kernel accumulates with float atomics either way) -- nothing is allocated or zeroed."""
     ca, cb = p.shape[1], q.shape[1]
     assert p.shape[0] == batch * l_p and q.shape[0] == batch * l_q
     n_w = ca * cb * taps
-    buf = torch.zeros(n_w + (ca if bias_grad else 0), device=p.device, dtype=torch.float32)
-    dw = buf[:n_w].view(ca, cb, taps)
-    db = buf[n_w:] if bias_grad else None
+    if dw_out is not None:
+        assert dw_out.is_contiguous() and dw_out.numel() == n_w and dw_out.dtype == torch.float32
+        assert not bias_grad or (db_out is not None and db_out.is_contiguous() and db_out.numel() == ca and db_out.dtype == torch.float32)
+        dw, db = dw_out, (db_out if bias_grad else None)
+    else:
+        buf = torch.zeros(n_w + (ca if bias_grad else 0), device=p.device, dtype=torch.float32)
+        dw = buf[:n_w].view(ca, cb, taps)
+        db = buf[n_w:] if bias_grad else None
     a = CdxWgradArgs(p=p.data_ptr(), q=q.data_ptr(), dw=dw.data_ptr(), batch=batch, l_p=l_p, l_q=l_q, ca=ca, cb=cb, taps=taps,
                      stride=stride, pad=pad, ldp=_rows(p), ldq=_rows(q), k_split=k_split, db=_p(db))
     _check(_lib().cdx_conv_wgrad_f32(ctypes.byref(a), _stream_ptr(p.device)), "cdx_conv_wgrad_f32")

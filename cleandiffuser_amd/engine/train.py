@@ -19,6 +19,7 @@ nothing is transposed on the way in or out):
 ``CDX_TRAIN_NATIVE=0`` keeps the reference's autograd path (A/B runs, the fixtures' twin).  Parity: tests/test_gpu_parity.py --
 gradients of every parameter against ``torch.autograd`` of the module, and the ``train_*`` fixtures of the real reference.
 """
+import contextlib
 import os
 from typing import Optional
 
@@ -66,6 +67,78 @@ def _wants_grad(net, *tensors) -> bool:
     return any(p.requires_grad for p in net.parameters())
 
 
+# --------------------------------------------------------------------------------------------------------------------- #
+# Parameter gradients of update(): accumulated where they live                                                                 #
+# --------------------------------------------------------------------------------------------------------------------- #
+# The weight / bias / gain sums of a layer come out of kernels that ADD into their output with float atomics (cdx_conv_wgrad_f32,
+# cdx_colsum_f32).  Handing such a sum to autograd costs three more launches per parameter pair: the zero-fill of a fresh buffer and one
+# `grad += new` each (AccumulateGrad) -- ~250 launches of the ~970 of a config-2 step (profiles/r05_update_census.txt).  Inside update()'s own
+# backward pass (DiffusionModel._loss_backward, and the HIP graph captured from it) the nodes therefore add straight into `p.grad` and
+# report "no gradient" to autograd.  Anywhere else -- torch.autograd.grad(), a user's own backward() over loss(), parameters with
+# hooks, views of parameters -- autograd's own accumulation runs as before.
+_in_place_depth = 0          # (module-wide, not thread-local: autograd runs the nodes of a device on its own worker thread)
+
+
+@contextlib.contextmanager
+def grads_in_place():
+    global _in_place_depth
+    _in_place_depth += 1
+    try:
+        yield
+    finally:
+        _in_place_depth -= 1
+
+
+def _grad_slot(p) -> Optional[torch.Tensor]:
+    """``p.grad`` as the tensor a kernel may add p's gradient into (created zeroed if missing), or None: autograd accumulates."""
+    if _in_place_depth <= 0 or os.environ.get("CDX_TRAIN_INPLACE_GRADS", "1") == "0":
+        return None
+    if not isinstance(p, nn.Parameter) or not p.is_leaf or p.dtype != torch.float32 or p._backward_hooks or \
+            getattr(p, "_post_accumulate_grad_hooks", None):
+        return None
+    g = p.grad
+    if g is None:
+        g = p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+    if g.dtype != torch.float32 or g.shape != p.shape or g.device != p.device or not g.is_contiguous() or g.requires_grad:
+        return None
+    return g
+
+
+def _written(*grads):
+    """The kernels wrote these ``.grad`` tensors behind autograd's back: move their version counters (FusedAdamW tells a gradient
+    somebody wrote from one it zeroed itself by them)."""
+    gs = [g for g in grads if g is not None]
+    if gs:
+        torch.autograd.graph.increment_version(gs)
+
+
+def _weight_grads(p_rows, q_rows, batch, l_p, l_q, taps, stride, pad, w_param, b_param, want_dw: bool, want_db: bool, bias_rows=None):
+    """(dw, db) of a Conv1d / ConvTranspose1d / Linear for autograd -- each None when not wanted OR when it was added straight into
+    the parameter's ``.grad`` (grads_in_place).  `bias_rows`: the matrix whose column sums are db when it is not `p_rows` (transposed
+    convolution: p = x)."""
+    dw = db = None
+    fused_db = want_db and bias_rows is None              # db out of the weight-gradient launch itself
+    if want_dw:
+        sw, sb = _grad_slot(w_param), (_grad_slot(b_param) if fused_db else None)
+        if sw is not None and (not fused_db or sb is not None):
+            blocks.conv_wgrad(p_rows, q_rows, batch, l_p, l_q, taps, stride, pad, bias_grad=fused_db, dw_out=sw, db_out=sb)
+            _written(sw, sb)
+        else:
+            dw = blocks.conv_wgrad(p_rows, q_rows, batch, l_p, l_q, taps, stride, pad, bias_grad=fused_db)
+            if fused_db:
+                dw, db = dw
+            dw = dw.view(w_param.shape)
+    if want_db and not (want_dw and fused_db):
+        rows = p_rows if bias_rows is None else bias_rows
+        sb = _grad_slot(b_param)
+        if sb is not None:
+            blocks.colsum(rows, out=sb)
+            _written(sb)
+        else:
+            db = blocks.colsum(rows)
+    return dw, db
+
+
 def _splitk_scratch(rows: int, n: int, k: int, device) -> Optional[torch.Tensor]:
     """Scratch for a deterministic split-K launch of ``cdx_gemm_f32`` (cdx.h: partial) when the product has too few output tiles to
     fill the chip and a long K -- the training batches (256 rows x 1024..4096 columns over K = 1024..5120 for configs 3 / 5): without it
@@ -94,6 +167,7 @@ class _Conv(torch.autograd.Function):
                           partial=_splitk_scratch(x.shape[0] // stride, weight.shape[0], weight.shape[1] * weight.shape[2], x.device))
         ctx.save_for_backward(x, weight)
         ctx.geom = (batch, l_in, stride, pad, bias is not None)
+        ctx.params = (weight, bias)
         return y
 
     @staticmethod
@@ -118,13 +192,8 @@ class _Conv(torch.autograd.Function):
                 view = dx.view(batch * l_out, 2 * c_in)                                    # row (b, j) = [dx[2j] | dx[2j + 1]]
                 blocks.conv1d(dy, w[:, 1:2].contiguous(), None, batch, l_out, 1, 0, out=view[:, :c_in], l_out=l_out)
                 blocks.conv1d(dy, torch.stack((w[:, 2], w[:, 0]), dim=1).contiguous(), None, batch, l_out, 1, 0, out=view[:, c_in:], l_out=l_out)
-        want_db = has_bias and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1]:
-            dw = blocks.conv_wgrad(dy, x, batch, l_out, l_in, k, stride, pad, bias_grad=want_db)       # (c_out, c_in, k)[, (c_out,)]
-            if want_db:
-                dw, db = dw
-        elif want_db:
-            db = blocks.colsum(dy)
+        dw, db = _weight_grads(dy, x, batch, l_out, l_in, k, stride, pad, ctx.params[0], ctx.params[1], ctx.needs_input_grad[1],
+                               has_bias and ctx.needs_input_grad[2])                        # (c_out, c_in, k), (c_out,)
         return dx, dw, db, None, None, None, None
 
 
@@ -137,6 +206,7 @@ class _ConvT(torch.autograd.Function):
         y = blocks.conv_transpose1d_k4s2p1(x, blocks.pack_conv_transpose_k4s2p1(weight), bias, batch, l_in)
         ctx.save_for_backward(x, weight)
         ctx.geom = (batch, l_in, bias is not None)
+        ctx.params = (weight, bias)
         return y
 
     @staticmethod
@@ -149,10 +219,8 @@ class _ConvT(torch.autograd.Function):
             # y[2m - 1 + t] += W[ci, :, t] x[m, ci]  =>  dx[m, ci] = sum_t W[ci, :, t] . dy[2m - 1 + t]: a stride-2 conv of dy
             wq = weight.detach().permute(0, 2, 1).contiguous()                             # (c_in, 4, c_out)
             dx = blocks.conv1d(dy, wq, None, batch, 2 * l_in, 2, 1)
-        if ctx.needs_input_grad[1]:
-            dw = blocks.conv_wgrad(x, dy, batch, l_in, 2 * l_in, 4, 2, 1)                  # (c_in, c_out, 4)
-        if has_bias and ctx.needs_input_grad[2]:
-            db = blocks.colsum(dy)
+        dw, db = _weight_grads(x, dy, batch, l_in, 2 * l_in, 4, 2, 1, ctx.params[0], ctx.params[1], ctx.needs_input_grad[1],
+                               has_bias and ctx.needs_input_grad[2], bias_rows=dy)           # (c_in, c_out, 4), (c_out,)
         return dx, dw, db, None, None
 
 
@@ -165,14 +233,19 @@ class _GroupNormMish(torch.autograd.Function):
         y = blocks.groupnorm(x, gamma, beta, batch, length, groups, act="mish", eps=eps)
         ctx.save_for_backward(x, gamma, beta)
         ctx.geom = (batch, length, groups, eps)
+        ctx.params = (gamma, beta)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, gamma, beta = ctx.saved_tensors
         batch, length, groups, eps = ctx.geom
+        slots = (_grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])) if ctx.needs_input_grad[1] and ctx.needs_input_grad[2] else (None, None)
+        slots = slots if slots[0] is not None and slots[1] is not None else None
         dx, dg, db = blocks.groupnorm_backward(dy.contiguous(), x, gamma.detach(), beta.detach(), batch, length, groups, act="mish", eps=eps,
-                                               param_grads=True)
+                                               param_grads=True, grads_out=slots)
+        if slots is not None:
+            _written(*slots)
         return dx, dg, db, None, None, None, None
 
 
@@ -301,6 +374,7 @@ class _LinearMish(torch.autograd.Function):
         x = x.contiguous()
         z = _linear(x, weight, bias)
         ctx.mish = mish
+        ctx.params = (weight, bias)
         ctx.save_for_backward(x, weight, z if mish else x.new_empty(0))
         return blocks.activation(z, "mish") if mish else z
 
@@ -313,14 +387,7 @@ class _LinearMish(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = _linear(dz, weight.detach().t().contiguous())
-        if ctx.needs_input_grad[1]:
-            want_db = ctx.needs_input_grad[2]
-            dw = blocks.conv_wgrad(dz, x, x.shape[0], 1, 1, 1, bias_grad=want_db)
-            if want_db:
-                dw, db = dw
-            dw = dw.view(weight.shape)
-        elif ctx.needs_input_grad[2]:
-            db = blocks.colsum(dz)
+        dw, db = _weight_grads(dz, x, x.shape[0], 1, 1, 1, 1, 0, ctx.params[0], ctx.params[1], ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         return dx, dw, db, None
 
 
@@ -333,6 +400,7 @@ class _LinearAct(torch.autograd.Function):
         x = x.contiguous()
         z = _linear(x, weight, bias)
         ctx.act = act
+        ctx.params = (weight, bias)
         ctx.save_for_backward(x, weight, z if act else x.new_empty(0))
         return blocks.activation(z, act) if act else z
 
@@ -345,14 +413,7 @@ class _LinearAct(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = _linear(dz, weight.detach().t().contiguous())
-        want_db = bias_needed = ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1]:
-            dw = blocks.conv_wgrad(dz, x, x.shape[0], 1, 1, 1, bias_grad=want_db)
-            if want_db:
-                dw, db = dw
-            dw = dw.view(weight.shape)
-        elif bias_needed:
-            db = blocks.colsum(dz)
+        dw, db = _weight_grads(dz, x, x.shape[0], 1, 1, 1, 1, 0, ctx.params[0], ctx.params[1], ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         return dx, dw, db, None
 
 
@@ -364,6 +425,7 @@ class _LayerNormAffine(torch.autograd.Function):
         x = x.contiguous()
         ctx.save_for_backward(x, gamma)
         ctx.eps = eps
+        ctx.params = (gamma, beta)
         return blocks.layernorm(x, gamma=gamma, beta=beta, eps=eps)
 
     @staticmethod
@@ -371,7 +433,10 @@ class _LayerNormAffine(torch.autograd.Function):
         x, gamma = ctx.saved_tensors
         dy = dy.contiguous()
         dx, dyx = blocks.layernorm_backward(dy, x, gamma=gamma.detach(), eps=ctx.eps, want_dyxhat=True)
-        return dx, blocks.colsum(dyx), blocks.colsum(dy), None
+        sg, sb = _grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])
+        dg, db = blocks.colsum(dyx, out=sg), blocks.colsum(dy, out=sb)
+        _written(sg, sb)
+        return dx, (None if sg is not None else dg), (None if sb is not None else db), None
 
 
 class _LayerNormMod(torch.autograd.Function):
@@ -696,11 +761,13 @@ class GraphedStep:
                         mode = torch.cuda.get_sync_debug_mode()
                         torch.cuda.set_sync_debug_mode("error")
                         try:
-                            agent.loss(self.x0, self.cond).backward()
+                            with grads_in_place():
+                                agent.loss(self.x0, self.cond).backward()
                         finally:
                             torch.cuda.set_sync_debug_mode(mode)
                     else:
-                        agent.loss(self.x0, self.cond).backward()
+                        with grads_in_place():
+                            agent.loss(self.x0, self.cond).backward()
         except Exception as e:  # noqa: BLE001 -- whatever the probe step tripped over: this agent's step is not ours to capture
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
@@ -719,7 +786,8 @@ class GraphedStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = agent.loss(self.x0, self.cond)
-            self.loss.backward()
+            with grads_in_place():                     # (the captured launches add into the static .grad tensors directly)
+                self.loss.backward()
         for p in params:                               # (capture does not run the kernels; keep the grads as the warm-up left them: zero)
             if p.grad is not None:
                 p.grad.zero_()
