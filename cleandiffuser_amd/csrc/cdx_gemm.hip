@@ -836,19 +836,22 @@ __global__ __launch_bounds__(256) void cdx_groupnorm_bwd_kernel(const cdx_gn_arg
         for (int q = 0; q < 4; ++q)
             if (q == j) { pg[q] += dz * xh; pb[q] += dz; }
     }
-    if (a.dgamma_part != nullptr) {
+    if (a.dgamma_part != nullptr || a.dgamma_sum != nullptr) {
+        const bool stage = a.dgamma_part != nullptr;      // per-sample partials, or atomics straight onto the (C) sums
         if (cg <= 64) {       // the lanes that share a channel differ in the bits >= log2(cg)
             for (int o = 32; o >= cg; o >>= 1) { pg[0] += __shfl_xor(pg[0], o, 64); pb[0] += __shfl_xor(pb[0], o, 64); }
             if (lane < cg) {
-                a.dgamma_part[(size_t)b * a.C + grp * cg + lane] = pg[0];
-                a.dbeta_part[(size_t)b * a.C + grp * cg + lane] = pb[0];
+                const int ch = grp * cg + lane;
+                if (stage) { a.dgamma_part[(size_t)b * a.C + ch] = pg[0]; a.dbeta_part[(size_t)b * a.C + ch] = pb[0]; }
+                else { atomicAdd(a.dgamma_sum + ch, pg[0]); atomicAdd(a.dbeta_sum + ch, pb[0]); }
             }
         } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (q <= jmask) {
-                    a.dgamma_part[(size_t)b * a.C + grp * cg + lane + 64 * q] = pg[q];
-                    a.dbeta_part[(size_t)b * a.C + grp * cg + lane + 64 * q] = pb[q];
+                    const int ch = grp * cg + lane + 64 * q;
+                    if (stage) { a.dgamma_part[(size_t)b * a.C + ch] = pg[q]; a.dbeta_part[(size_t)b * a.C + ch] = pb[q]; }
+                    else { atomicAdd(a.dgamma_sum + ch, pg[q]); atomicAdd(a.dbeta_sum + ch, pb[q]); }
                 }
         }
     }
@@ -1526,7 +1529,10 @@ int cdx_groupnorm_bwd_f32(const cdx_gn_args* a, void* hip_stream) {
     if (a->B == 0) return CDX_OK;
     if (!a->x || !a->y || !a->gamma || !a->beta || !a->residual) { cdx_set_err("cdx_groupnorm_bwd_f32: null pointer"); return CDX_EINVAL; }
     if ((a->dgamma_part == nullptr) != (a->dbeta_part == nullptr)) { cdx_set_err("cdx_groupnorm_bwd_f32: dgamma_part and dbeta_part go together"); return CDX_EINVAL; }
-    if (a->dgamma_part != nullptr) {
+    if ((a->dgamma_sum == nullptr) != (a->dbeta_sum == nullptr) || (a->dgamma_sum != nullptr && a->dgamma_part != nullptr)) {
+        cdx_set_err("cdx_groupnorm_bwd_f32: dgamma_sum and dbeta_sum go together, and not with the *_part pair"); return CDX_EINVAL;
+    }
+    if (a->dgamma_part != nullptr || a->dgamma_sum != nullptr) {
         const int cg = a->C / a->G;
         if (cg > 256 || (cg & (cg - 1)) != 0) { cdx_set_err("cdx_groupnorm_bwd_f32: parameter gradients need a power-of-two group width <= 256"); return CDX_EINVAL; }
     }

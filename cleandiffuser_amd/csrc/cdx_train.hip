@@ -393,9 +393,39 @@ static int mha_train_launch(const cdx_mha_train_args* a, bool bwd, void* hip_str
     return CDX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// cdx_relayout_f32: one workgroup per (job, chunk); see cdx.h.  The weights of a denoiser are a few MB in total and L2-resident right
+// after the optimiser wrote them: what this saves is launches, not bytes.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cdx_relayout_kernel(const cdx_relayout_job* __restrict__ jobs, const int32_t* __restrict__ chunks) {
+    const int j = chunks[2 * blockIdx.x], ck = chunks[2 * blockIdx.x + 1];
+    const cdx_relayout_job job = jobs[j];
+    const long n = (long)job.n0 * job.n1 * job.n2;
+    const long lo = (long)ck * CDX_RELAYOUT_CHUNK;
+    const long hi = lo + CDX_RELAYOUT_CHUNK < n ? lo + CDX_RELAYOUT_CHUNK : n;
+    const int n12 = job.n1 * job.n2;
+    for (long e = lo + threadIdx.x; e < hi; e += 256) {
+        const int i0 = (int)(e / n12), r = (int)(e - (long)i0 * n12);
+        const int i1 = r / job.n2, i2 = r - i1 * job.n2;
+        job.dst[e] = job.src[(long)i0 * job.s0 + (long)i1 * job.s1 + (long)i2 * job.s2];
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int cdx_relayout_f32(const cdx_relayout_job* jobs, const int32_t* chunks, int32_t n_chunks, void* hip_stream) {
+    cdx_set_err("");
+    if (n_chunks < 0) { cdx_set_err("cdx_relayout_f32: negative chunk count"); return CDX_EINVAL; }
+    if (n_chunks == 0) return CDX_OK;
+    if (!jobs || !chunks) { cdx_set_err("cdx_relayout_f32: null table"); return CDX_EINVAL; }
+    hipLaunchKernelGGL(cdx_relayout_kernel, dim3((unsigned)n_chunks), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), jobs, chunks);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
+    return CDX_OK;
+}
+
 
 int cdx_layernorm_bwd_f32(const cdx_ln_bwd_args* a, void* hip_stream) {
     cdx_set_err("");

@@ -29,7 +29,7 @@ class CdxGnArgs(ctypes.Structure):
                 ("fa", ctypes.c_void_p), ("fb", ctypes.c_void_p), ("residual", ctypes.c_void_p)] + \
                [(n, ctypes.c_int32) for n in ("B", "L", "C", "G", "ldx", "ldy", "ldr", "ldfa", "ldfb", "fa_row", "fa_per_sample",
                                               "film_mode", "act")] + [("eps", ctypes.c_float)] + \
-               [("dgamma_part", ctypes.c_void_p), ("dbeta_part", ctypes.c_void_p)]
+               [("dgamma_part", ctypes.c_void_p), ("dbeta_part", ctypes.c_void_p), ("dgamma_sum", ctypes.c_void_p), ("dbeta_sum", ctypes.c_void_p)]
 
 
 class CdxWgradArgs(ctypes.Structure):
@@ -38,6 +38,11 @@ class CdxWgradArgs(ctypes.Structure):
                [("db", ctypes.c_void_p)]
 
 
+class CdxRelayoutJob(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p)] + [(n, ctypes.c_int32) for n in ("n0", "n1", "n2", "s0", "s1", "s2")]
+
+
+RELAYOUT_CHUNK = 2048
 GATHER_MAX_FIELDS = 8
 
 
@@ -119,6 +124,8 @@ def _lib():
         for f in (lib.cdx_mha_train_fwd_f32, lib.cdx_mha_train_bwd_f32):
             f.argtypes = [ctypes.POINTER(CdxMhaTrainArgs), ctypes.c_void_p]
             f.restype = ctypes.c_int
+        lib.cdx_relayout_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+        lib.cdx_relayout_f32.restype = ctypes.c_int
         lib.cdx_gather_windows_f32.argtypes = [ctypes.POINTER(CdxGatherArgs), ctypes.c_void_p]
         lib.cdx_gather_windows_f32.restype = ctypes.c_int
         for f in (lib.cdx_gemm_f32, lib.cdx_layernorm_f32, lib.cdx_attention_f32, lib.cdx_act_f32):
@@ -228,26 +235,26 @@ def groupnorm_backward(dy: torch.Tensor, x: torch.Tensor, gamma, beta, batch: in
     """d loss / d x for y = act(groupnorm(x) * gamma + beta), given dy = d loss / d y (x is the saved forward input).
     `param_grads`: also (d loss / d gamma, d loss / d beta) -- per-sample partial sums out of the same launch, summed over the batch by
     cdx_colsum_f32 -> (dx, dgamma, dbeta).  `grads_out` = (tensor, tensor): the two sums are ADDED to these (the parameters'
-    ``.grad``) instead of landing in a fresh zeroed block -> (dx, None, None)."""
+    ``.grad``) by the backward kernel itself (float atomics; no staging, no column-sum launches) -> (dx, None, None)."""
     if out is None:
         out = torch.empty_like(x)
     c = x.shape[1]
     pg = pb = None
-    if param_grads:
+    if grads_out is not None:
+        assert param_grads and all(t.is_contiguous() and t.numel() == c and t.dtype == torch.float32 for t in grads_out)
+    elif param_grads:
         pg = torch.empty((2, batch, c), device=x.device, dtype=torch.float32)
         pb = pg[1]
     a = CdxGnArgs(x=x.data_ptr(), y=out.data_ptr(), gamma=gamma.data_ptr(), beta=beta.data_ptr(), residual=dy.data_ptr(),
                   B=batch, L=length, C=c, G=groups, ldx=_rows(x), ldy=_rows(out), ldr=_rows(dy), act=ACT[act], eps=eps,
-                  dgamma_part=None if pg is None else pg[0].data_ptr(), dbeta_part=None if pb is None else pb.data_ptr())
+                  dgamma_part=None if pg is None else pg[0].data_ptr(), dbeta_part=None if pb is None else pb.data_ptr(),
+                  dgamma_sum=None if grads_out is None else grads_out[0].data_ptr(), dbeta_sum=None if grads_out is None else grads_out[1].data_ptr())
     _check(_lib().cdx_groupnorm_bwd_f32(ctypes.byref(a), _stream_ptr(x.device)), "cdx_groupnorm_bwd_f32")
     if not param_grads:
         return out
     # (the two (batch, C) partial blocks lie back to back: summed as 2 x batch rows into one zeroed (2, C) block by two launches that
     #  share the memset)
-    if grads_out is not None:
-        assert all(t.is_contiguous() and t.numel() == c and t.dtype == torch.float32 for t in grads_out)
-        colsum(pg[0], out=grads_out[0])
-        colsum(pg[1], out=grads_out[1])
+    if grads_out is not None:                             # (added by the kernel itself: float atomics onto the two (C) tensors)
         return out, None, None
     g = torch.zeros((2, c), device=x.device, dtype=torch.float32)
     colsum(pg[0], out=g[0])
@@ -262,6 +269,28 @@ def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         out = torch.zeros(c, device=x.device, dtype=torch.float32)
     _check(_lib().cdx_colsum_f32(x.data_ptr(), out.data_ptr(), r, c, _rows(x), _stream_ptr(x.device)), "cdx_colsum_f32")
     return out
+
+
+def relayout_table(jobs, device):
+    """Device tables for ``relayout``: `jobs` = [(src tensor, element offset of index (0, 0, 0), dst tensor (contiguous), (n0, n1, n2),
+    (s0, s1, s2))] -> (jobs bytes on the device, chunk pairs on the device, n_chunks).  The tensors must stay alive and in place for as
+    long as the table is used (their addresses are in it)."""
+    import numpy as np
+    arr = (CdxRelayoutJob * len(jobs))()
+    chunks = []
+    for j, (src, off, dst, n, st) in enumerate(jobs):
+        assert src.dtype == dst.dtype == torch.float32 and dst.is_contiguous() and dst.numel() == n[0] * n[1] * n[2]
+        arr[j] = CdxRelayoutJob(src=src.data_ptr() + 4 * off, dst=dst.data_ptr(), n0=n[0], n1=n[1], n2=n[2], s0=st[0], s1=st[1], s2=st[2])
+        chunks += [(j, c) for c in range(-(-dst.numel() // RELAYOUT_CHUNK))]
+    raw = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(device)
+    ck = torch.tensor(chunks, dtype=torch.int32).reshape(-1, 2).to(device)
+    return raw, ck, len(chunks)
+
+
+def relayout(table):
+    """ONE launch: every job of a ``relayout_table``."""
+    raw, ck, n = table
+    _check(_lib().cdx_relayout_f32(raw.data_ptr(), ck.data_ptr(), n, _stream_ptr(raw.device)), "cdx_relayout_f32")
 
 
 def gather_windows(row0: torch.Tensor, fields, rows: int):

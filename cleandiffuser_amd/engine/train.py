@@ -20,6 +20,7 @@ nothing is transposed on the way in or out):
 gradients of every parameter against ``torch.autograd`` of the module, and the ``train_*`` fixtures of the real reference.
 """
 import contextlib
+import functools
 import os
 from typing import Optional
 
@@ -139,6 +140,150 @@ def _weight_grads(p_rows, q_rows, batch, l_p, l_q, taps, stride, pad, w_param, b
     return dw, db
 
 
+# --------------------------------------------------------------------------------------------------------------------- #
+# Weight layouts of a training step: one launch per forward pass                                                               #
+# --------------------------------------------------------------------------------------------------------------------- #
+# Every convolution / linear weight is needed in other layouts: taps-major for the implicit GEMM, flipped + transposed for the
+# backward-data convolution, transposed for a Linear's input gradient.  As ATen permute / flip / stack / contiguous calls inside the
+# nodes these were ~130 launches of a config-2 step (profiles/r05_update_census.txt).  Each is a 3-D strided gather of the weight, so a
+# denoiser's whole set is ONE ``cdx_relayout_f32`` launch at the start of its forward pass (and nothing at all while the parameters
+# have not changed): ``_WeightPacks`` keeps the job table.  A layout is registered the first time a node asks for it (that step still
+# builds it with ATen); from the next parameter change on it is refreshed by the one launch.  CDX_TRAIN_PACKS=0: ATen calls as before.
+def _geom(kind: str, w: torch.Tensor):
+    """(dst shape, (n0, n1, n2), (s0, s1, s2), element offset of index (0, 0, 0)) of layout `kind` of weight `w` (its own strides:
+    contiguous slices of a packed parameter are welcome)."""
+    if kind == "linear_t":                                 # (A, B) -> (B, A)
+        (a, b), (sa, sb) = w.shape, w.stride()
+        return (b, a), (b, a, 1), (sb, sa, 0), 0
+    (a, b, k), (sa, sb, sk) = w.shape, w.stride()
+    if kind in ("conv", "convt_bwd"):                      # (A, B, K) -> (A, K, B)
+        return (a, k, b), (a, k, b), (sa, sk, sb), 0
+    if kind == "conv_bwd":                                 # -> (B, K, A), taps reversed
+        return (b, k, a), (b, k, a), (sb, -sk, sa), (k - 1) * sk
+    if kind == "conv_s2_mid":                              # -> (B, 1, A): tap 1
+        return (b, 1, a), (b, 1, a), (sb, 0, sa), sk
+    if kind in ("conv_s2_outer", "convt_odd"):             # -> (B, 2, A): taps 2, 0
+        return (b, 2, a), (b, 2, a), (sb, -2 * sk, sa), 2 * sk
+    if kind == "convt_even":                               # -> (B, 2, A): taps 3, 1
+        return (b, 2, a), (b, 2, a), (sb, -2 * sk, sa), 3 * sk
+    raise KeyError(kind)
+
+
+def _aten_pack(kind: str, w: torch.Tensor) -> torch.Tensor:
+    """The same layouts as ATen calls (what a node runs for a layout that is not registered yet, and what the tests compare with)."""
+    w = w.detach()
+    if kind == "linear_t":
+        return w.t().contiguous()
+    if kind in ("conv", "convt_bwd"):
+        return w.permute(0, 2, 1).contiguous()
+    if kind == "conv_bwd":
+        return w.flip(2).permute(1, 2, 0).contiguous()
+    v = w.permute(1, 2, 0)                                 # (B, K, A)
+    if kind == "conv_s2_mid":
+        return v[:, 1:2].contiguous()
+    # (stack of slices, not v[:, [2, 0]]: a list index becomes a host -> device copy of an index tensor, which a HIP-graph capture of
+    #  the training step refuses)
+    if kind in ("conv_s2_outer", "convt_odd"):
+        return torch.stack((v[:, 2], v[:, 0]), dim=1).contiguous()
+    if kind == "convt_even":
+        return torch.stack((v[:, 3], v[:, 1]), dim=1).contiguous()
+    raise KeyError(kind)
+
+
+class _WeightPacks:
+    """The registered layouts of one module's weights (see above).  ``refresh`` at the start of a forward pass; nodes call ``get``."""
+
+    def __init__(self):
+        self.entries = {}          # (weight address, weight shape, kind) -> [dst, job, signature it is fresh for]
+        self.table = None          # device tables of every entry registered when it was built
+        self.in_table = 0
+        self.sig = None
+        self._listed, self._retired = [], []
+
+    def refresh(self, params):
+        sig = tuple((p.data_ptr(), p._version) for p in params)
+        dirty = self.in_table != len(self.entries)
+        if torch.cuda.is_current_stream_capturing():
+            # A capture records launches, it does not run them, and it cannot upload a table.  With a complete table the one launch
+            # is recorded (a replay then refreshes every layout from the weights of that moment); without one NOTHING counts as fresh
+            # in this pass, so every node records its own ATen calls instead.
+            if dirty or not self.entries:
+                self.sig = object()
+                return
+            self.sig = sig
+            blocks.relayout(self.table)
+        else:
+            if self.sig is not None and not isinstance(self.sig, tuple):
+                self.sig = None
+            if self.sig is not None and [a for a, _ in sig] != [a for a, _ in self.sig]:
+                # parameters moved: every address in the table is stale (the old homes stay alive: a captured graph may name them)
+                self._retired.append((self.entries, self.table))
+                self.entries, self.table, self.in_table, self._listed, dirty = {}, None, 0, [], False
+            if dirty:                                      # layouts registered since the table was built (the table of a captured
+                self._retired.append(self.table)           # graph stays alive)
+                self._listed = list(self.entries.values())
+                self.table = blocks.relayout_table([e[1] for e in self._listed], self._listed[0][0].device)
+                self.in_table = len(self._listed)
+            if sig == self.sig:
+                return
+            self.sig = sig
+            if self.table is None:
+                return
+            blocks.relayout(self.table)
+        for e in self._listed:
+            e[2] = sig
+
+    def get(self, kind: str, w: torch.Tensor) -> torch.Tensor:
+        key = (w.data_ptr(), tuple(w.shape), tuple(w.stride()), kind)
+        e = self.entries.get(key)
+        if e is not None and e[2] == self.sig:
+            return e[0]
+        t = _aten_pack(kind, w)
+        if e is None and not torch.cuda.is_current_stream_capturing():
+            # adopt this tensor as the layout's home: from the next parameter change on it is rewritten by the one launch
+            shape, n, st, off = _geom(kind, w)
+            assert tuple(t.shape) == shape
+            self.entries[key] = [t, (w.detach(), off, t, n, st), self.sig]
+        elif e is not None and not torch.cuda.is_current_stream_capturing():
+            e[0].copy_(t)                                  # (registered but stale and not refreshed: keep its home current)
+            e[2] = self.sig
+            return e[0]
+        return t
+
+
+_active_packs: Optional[_WeightPacks] = None
+
+
+@contextlib.contextmanager
+def _weight_packs(net):
+    """The forward pass of `net` on the library's nodes: its weight layouts are current inside (one launch, if anything changed)."""
+    global _active_packs
+    prev = _active_packs
+    packs = None
+    if os.environ.get("CDX_TRAIN_PACKS", "1") != "0":
+        packs = net.__dict__.get("_cdx_weight_packs")
+        if packs is None:
+            packs = net.__dict__["_cdx_weight_packs"] = _WeightPacks()
+        packs.refresh(list(net.parameters()))
+    _active_packs = packs
+    try:
+        yield
+    finally:
+        _active_packs = prev
+
+
+def _pack(kind: str, w: torch.Tensor, packs: Optional[_WeightPacks]) -> torch.Tensor:
+    return _aten_pack(kind, w) if packs is None else packs.get(kind, w)
+
+
+def _with_weight_packs(forward):
+    @functools.wraps(forward)
+    def run(net, *args, **kwargs):
+        with _weight_packs(net):
+            return forward(net, *args, **kwargs)
+    return run
+
+
 def _splitk_scratch(rows: int, n: int, k: int, device) -> Optional[torch.Tensor]:
     """Scratch for a deterministic split-K launch of ``cdx_gemm_f32`` (cdx.h: partial) when the product has too few output tiles to
     fill the chip and a long K -- the training batches (256 rows x 1024..4096 columns over K = 1024..5120 for configs 3 / 5): without it
@@ -163,7 +308,8 @@ class _Conv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, batch, l_in, stride, pad):
         x = x.contiguous()
-        y = blocks.conv1d(x, blocks.pack_conv(weight), bias, batch, l_in, stride, pad,
+        ctx.packs = _active_packs
+        y = blocks.conv1d(x, _pack("conv", weight, ctx.packs), bias, batch, l_in, stride, pad,
                           partial=_splitk_scratch(x.shape[0] // stride, weight.shape[0], weight.shape[1] * weight.shape[2], x.device))
         ctx.save_for_backward(x, weight)
         ctx.geom = (batch, l_in, stride, pad, bias is not None)
@@ -181,17 +327,16 @@ class _Conv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if stride == 1:
                 # dx[l] = sum_t W[:, :, t]^T dy[l + pad - t]: a conv of dy with the flipped, transposed kernel, left padding k - 1 - pad
-                wt = weight.detach().flip(2).permute(1, 2, 0).contiguous()                 # (c_in, k, c_out)
+                wt = _pack("conv_bwd", weight, ctx.packs)                                  # (c_in, k, c_out), taps reversed
                 dx = blocks.conv1d(dy, wt, None, batch, l_out, 1, k - 1 - pad, l_out=l_in,
                                    partial=_splitk_scratch(batch * l_in, c_in, c_out * k, dy.device))
             else:
                 assert (k, stride, pad) == (3, 2, 1) and l_in == 2 * l_out
                 # y[m] = sum_t W_t x[2m - 1 + t]:  dx[2j] = W_1^T dy[j];  dx[2j + 1] = W_2^T dy[j] + W_0^T dy[j + 1]
-                w = weight.detach().permute(1, 2, 0)                                       # (c_in, k, c_out)
                 dx = torch.empty((batch * l_in, c_in), device=dy.device, dtype=torch.float32)
                 view = dx.view(batch * l_out, 2 * c_in)                                    # row (b, j) = [dx[2j] | dx[2j + 1]]
-                blocks.conv1d(dy, w[:, 1:2].contiguous(), None, batch, l_out, 1, 0, out=view[:, :c_in], l_out=l_out)
-                blocks.conv1d(dy, torch.stack((w[:, 2], w[:, 0]), dim=1).contiguous(), None, batch, l_out, 1, 0, out=view[:, c_in:], l_out=l_out)
+                blocks.conv1d(dy, _pack("conv_s2_mid", weight, ctx.packs), None, batch, l_out, 1, 0, out=view[:, :c_in], l_out=l_out)
+                blocks.conv1d(dy, _pack("conv_s2_outer", weight, ctx.packs), None, batch, l_out, 1, 0, out=view[:, c_in:], l_out=l_out)
         dw, db = _weight_grads(dy, x, batch, l_out, l_in, k, stride, pad, ctx.params[0], ctx.params[1], ctx.needs_input_grad[1],
                                has_bias and ctx.needs_input_grad[2])                        # (c_out, c_in, k), (c_out,)
         return dx, dw, db, None, None, None, None
@@ -203,7 +348,8 @@ class _ConvT(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, batch, l_in):
         x = x.contiguous()
-        y = blocks.conv_transpose1d_k4s2p1(x, blocks.pack_conv_transpose_k4s2p1(weight), bias, batch, l_in)
+        ctx.packs = _active_packs
+        y = blocks.conv_transpose1d_k4s2p1(x, (_pack("convt_even", weight, ctx.packs), _pack("convt_odd", weight, ctx.packs)), bias, batch, l_in)
         ctx.save_for_backward(x, weight)
         ctx.geom = (batch, l_in, bias is not None)
         ctx.params = (weight, bias)
@@ -217,7 +363,7 @@ class _ConvT(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             # y[2m - 1 + t] += W[ci, :, t] x[m, ci]  =>  dx[m, ci] = sum_t W[ci, :, t] . dy[2m - 1 + t]: a stride-2 conv of dy
-            wq = weight.detach().permute(0, 2, 1).contiguous()                             # (c_in, 4, c_out)
+            wq = _pack("convt_bwd", weight, ctx.packs)                                     # (c_in, 4, c_out)
             dx = blocks.conv1d(dy, wq, None, batch, 2 * l_in, 2, 1)
         dw, db = _weight_grads(x, dy, batch, l_in, 2 * l_in, 4, 2, 1, ctx.params[0], ctx.params[1], ctx.needs_input_grad[1],
                                has_bias and ctx.needs_input_grad[2], bias_rows=dy)           # (c_in, c_out, 4), (c_out,)
@@ -271,6 +417,7 @@ def _resblock(rb, h, emb, batch: int, length: int):
     return a2 + res
 
 
+@_with_weight_packs
 def janner_forward(net, x: torch.Tensor, noise: torch.Tensor, condition: Optional[torch.Tensor]) -> torch.Tensor:
     """``JannerUNet1d.forward`` (reference nn_diffusion/jannerunet.py:154-201) with autograd, every convolution and GroupNorm on the
     library's kernels.  x (b, H, D) -> (b, H, D)."""
@@ -330,6 +477,7 @@ def _chi_block(rb, h, memb, batch: int, length: int):
     return a2 + res
 
 
+@_with_weight_packs
 def chi_forward(net, x: torch.Tensor, noise: torch.Tensor, condition: torch.Tensor) -> torch.Tensor:
     """``ChiUNet1d.forward`` with a global condition (reference nn_diffusion/chiunet.py:152-192) with autograd, every convolution,
     GroupNorm and FiLM Linear on the library's kernels.  x (b, Ta, act_dim), condition (b, To, obs_dim) -> (b, Ta, act_dim)."""
@@ -374,7 +522,7 @@ class _LinearMish(torch.autograd.Function):
         x = x.contiguous()
         z = _linear(x, weight, bias)
         ctx.mish = mish
-        ctx.params = (weight, bias)
+        ctx.params, ctx.packs = (weight, bias), _active_packs
         ctx.save_for_backward(x, weight, z if mish else x.new_empty(0))
         return blocks.activation(z, "mish") if mish else z
 
@@ -386,7 +534,7 @@ class _LinearMish(torch.autograd.Function):
             dz = blocks.activation_backward(z, dz, "mish")
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = _linear(dz, weight.detach().t().contiguous())
+            dx = _linear(dz, _pack("linear_t", weight, ctx.packs))
         dw, db = _weight_grads(dz, x, x.shape[0], 1, 1, 1, 1, 0, ctx.params[0], ctx.params[1], ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         return dx, dw, db, None
 
@@ -400,7 +548,7 @@ class _LinearAct(torch.autograd.Function):
         x = x.contiguous()
         z = _linear(x, weight, bias)
         ctx.act = act
-        ctx.params = (weight, bias)
+        ctx.params, ctx.packs = (weight, bias), _active_packs
         ctx.save_for_backward(x, weight, z if act else x.new_empty(0))
         return blocks.activation(z, act) if act else z
 
@@ -412,7 +560,7 @@ class _LinearAct(torch.autograd.Function):
             dz = blocks.activation_backward(z, dz, ctx.act)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = _linear(dz, weight.detach().t().contiguous())
+            dx = _linear(dz, _pack("linear_t", weight, ctx.packs))
         dw, db = _weight_grads(dz, x, x.shape[0], 1, 1, 1, 1, 0, ctx.params[0], ctx.params[1], ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         return dx, dw, db, None
 
@@ -532,6 +680,7 @@ def supports_idql(net, x: torch.Tensor, condition=None) -> bool:
     return all(p.dtype == torch.float32 and p.is_cuda for p in net.parameters())
 
 
+@_with_weight_packs
 def idql_forward(net, x, noise, condition):
     """``IDQLMlp.forward`` (reference nn_diffusion/idqlmlp.py:9-49): x + Linear(Mish(Linear(LayerNorm(Dropout(x))))) blocks; every Linear
     and LayerNorm a library node, nn.Dropout (an RNG draw) and the feature concat stay ATen."""
@@ -560,6 +709,7 @@ def supports_dit(net, x: torch.Tensor, condition=None) -> bool:
     return all(p.dtype == torch.float32 and p.is_cuda for p in net.parameters())
 
 
+@_with_weight_packs
 def dit_forward(net, x, noise, condition):
     """``DiT1d.forward`` (reference nn_diffusion/dit.py:10-50,108-130) with autograd: x_proj / qkv / out_proj / fc1(+GELU) / fc2 / head
     GEMMs, LayerNorm + adaLN modulate and the attention core (with its dropout mask in train mode) on library nodes, forward and
@@ -640,6 +790,7 @@ def _ffn(layer, h2):
     return _LinearAct.apply(f, layer.linear2.weight, layer.linear2.bias, None)
 
 
+@_with_weight_packs
 def chitf_forward(net, x, noise, condition):
     """``ChiTransformer.forward`` (reference nn_diffusion/chitransformer.py:137-158) with autograd, as nn.TransformerEncoder /
     nn.TransformerDecoder run it in TRAIN mode (pre-norm layers: x += drop(attn(norm(x))), x += drop(ffn(norm(x)))): every Linear, every
@@ -704,6 +855,7 @@ def _sequential(seq: nn.Sequential, h):
     return h
 
 
+@_with_weight_packs
 def dql_forward(net, x: torch.Tensor, noise: torch.Tensor, condition: Optional[torch.Tensor]) -> torch.Tensor:
     """``DQLMlp.forward`` / ``DVInvMlp.forward`` (reference nn_diffusion/dqlmlp.py:30-52, dvinvmlp.py:30-47) with autograd, every Linear
     and Mish on the library's kernels: features = [x | time_mlp(map_noise(t)) | condition], trunk, head."""

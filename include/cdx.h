@@ -291,6 +291,10 @@ typedef struct cdx_gn_args {
      * (dz = d loss / d y * act'): the column sums of these over the batch are d loss / d gamma and d loss / d beta.  Both or neither;
      * needs C / G channels per group to be a power of two <= 256. */
     float *dgamma_part, *dbeta_part;
+    /* backward only (ABI 15): optional (C) accumulators -- every (sample, group) ADDS its sums of dz * x_hat / dz to them with float
+     * atomics: d loss / d gamma and d loss / d beta themselves, on top of what the buffers held (a parameter's .grad), without the
+     * (B, C) staging and its two column-sum launches.  Both or neither, same group-width rule; exclusive with the *_part pair. */
+    float *dgamma_sum, *dbeta_sum;
 } cdx_gn_args;
 int cdx_groupnorm_f32(const cdx_gn_args* args, void* hip_stream);
 /* Backward of y = act(gn(x) * gamma + beta) w.r.t. x (classifier guidance, reference classifier/base.py:74-79 asks autograd
@@ -376,6 +380,23 @@ typedef struct cdx_mha_train_args {
 } cdx_mha_train_args;
 int cdx_mha_train_fwd_f32(const cdx_mha_train_args* args, void* hip_stream);
 int cdx_mha_train_bwd_f32(const cdx_mha_train_args* args, void* hip_stream);
+
+/* Many small strided re-layouts in ONE launch (ABI 15; training, csrc/cdx_train.hip).  A training step needs every convolution /
+ * linear weight in two or three other layouts (taps-major for the implicit GEMM, flipped and transposed for the backward-data
+ * convolution, transposed for a Linear's input gradient); as ATen permute / flip / contiguous calls these are ~130 launches of the
+ * ~800 of a config-2 step.  Job j copies a 3-D gather into a contiguous block:
+ *     dst[(i0 * n1 + i1) * n2 + i2] = src[i0 * s0 + i1 * s1 + i2 * s2]        (strides in elements, negative allowed: src points
+ *                                                                                at the element of index (0, 0, 0))
+ * `jobs` and `chunks` live on the DEVICE; chunks = n_chunks pairs (job index, chunk index within the job), one workgroup each,
+ * CDX_RELAYOUT_CHUNK elements per chunk.  Pure data movement. */
+#define CDX_RELAYOUT_CHUNK 2048
+typedef struct cdx_relayout_job {
+    const float* src;
+    float* dst;
+    int32_t n0, n1, n2;
+    int32_t s0, s1, s2;
+} cdx_relayout_job;
+int cdx_relayout_f32(const cdx_relayout_job* jobs, const int32_t* chunks, int32_t n_chunks, void* hip_stream);
 
 /* Batch assembly from dataset buffers that live in HBM (third slice: the reference collates a batch on the host --
  * D4RLMuJoCoDataset.__getitem__, cleandiffuser/dataset/d4rl_mujoco_dataset.py:138-151, per item through a torch DataLoader with four

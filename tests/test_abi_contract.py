@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported(lib):
                           "cdx_hjgrad_workspace_floats", "cdx_guided_run", "cdx_guided_workspace_floats", "cdx_unet2_run",
                           "cdx_unet2_embtab", "cdx_optim_f32", "cdx_pearcetf_run", "cdx_pearcetf_workspace_floats", "cdx_act_bwd_f32", "cdx_linattn_f32",
                           "cdx_conv_wgrad_f32", "cdx_colsum_f32", "cdx_device_query", "cdx_layernorm_bwd_f32",
-                          "cdx_attention_bwd_f32", "cdx_mha_train_fwd_f32", "cdx_mha_train_bwd_f32"}
+                          "cdx_attention_bwd_f32", "cdx_mha_train_fwd_f32", "cdx_mha_train_bwd_f32", "cdx_relayout_f32"}
     for n in names:
         assert hasattr(lib, n), f"{n} declared in cdx.h but not exported by libcdx.so"
     assert lib.cdx_abi_version() == int(re.search(r"#define CDX_ABI_VERSION (\d+)", hdr).group(1))
@@ -55,7 +55,7 @@ def test_ctypes_mirrors_have_c_layout(tmp_path):
                "cdx_unet_attn": bigbatch.CdxUnetAttn, "cdx_wgrad_args": blocks.CdxWgradArgs,
                "cdx_gather_args": blocks.CdxGatherArgs, "cdx_gather_field": blocks.CdxGatherField,
                "cdx_device_props": runtime2.CdxDeviceProps, "cdx_ln_bwd_args": blocks.CdxLnBwdArgs, "cdx_attn_bwd_args": blocks.CdxAttnBwdArgs,
-               "cdx_mha_train_args": blocks.CdxMhaTrainArgs}
+               "cdx_mha_train_args": blocks.CdxMhaTrainArgs, "cdx_relayout_job": blocks.CdxRelayoutJob}
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "cdx.h"', 'int main(void){']
     for cname, mirror in mirrors.items():
         src.append(f'printf("%zu\\n", sizeof({cname}));')
@@ -212,6 +212,10 @@ def test_newer_entries_validate_before_touching_the_device(lib):
         assert fn(ctypes.byref(blocks.CdxMhaTrainArgs(**{**mha, "B": 0})), None) == 0
         assert fn(None, None) == bad
     assert lib.cdx_mha_train_bwd_f32(ctypes.byref(blocks.CdxMhaTrainArgs(**{**mha, "dk": None})), None) == bad
+    assert lib.cdx_relayout_f32(None, None, 0, None) == 0 and lib.cdx_relayout_f32(None, 8, 3, None) == bad and lib.cdx_relayout_f32(8, 8, -1, None) == bad
+    gn = dict(B=2, L=4, C=8, G=2, x=8, y=8, gamma=8, beta=8, residual=8, ldx=8, ldy=8, ldr=8, act=1, eps=1e-5)
+    assert lib.cdx_groupnorm_bwd_f32(ctypes.byref(blocks.CdxGnArgs(**gn, dgamma_sum=8)), None) == bad and b"go together" in lib.cdx_last_error()
+    assert lib.cdx_groupnorm_bwd_f32(ctypes.byref(blocks.CdxGnArgs(**gn, dgamma_sum=8, dbeta_sum=8, dgamma_part=8, dbeta_part=8)), None) == bad
     assert lib.cdx_act_bwd_f32(8, 8, 8, 4, 8, 0.0, None) == bad and lib.cdx_act_bwd_f32(8, None, 8, 4, 4, 1.0, None) == bad
     assert lib.cdx_act_bwd_f32(8, 8, 8, 0, 4, 1.0, None) == 0
     # workspace sizes: host arithmetic, grows with the chunk, independent of the batch beyond the chunk

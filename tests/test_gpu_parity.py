@@ -1632,6 +1632,63 @@ def test_chitransformer_update_with_the_pipelines_dropout_runs_native_and_seeded
     torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-5)
 
 
+def test_relayout_kernel_builds_every_weight_layout_and_the_registry_keeps_them_current(amd_lib, monkeypatch):
+    """cdx_relayout_f32 (ABI 15): every layout a training step needs of a conv / conv-transpose / linear weight -- whole parameters and a
+    row slice of a packed one -- as ONE launch, bit-identical to the ATen permute / flip / stack expressions; and the registry around
+    it (engine/train.py:_WeightPacks): ATen calls only in the first step, one launch after every parameter change, none without one,
+    gradients equal to the CDX_TRAIN_PACKS=0 path throughout."""
+    from cleandiffuser_amd.engine import blocks, train
+    from cleandiffuser_amd.utils import load_synth
+    g = torch.Generator().manual_seed(2)
+    jobs, want = [], []
+    for kind in ("conv", "convt_bwd", "conv_bwd", "conv_s2_mid", "conv_s2_outer", "convt_even", "convt_odd", "linear_t"):
+        k = 3 if kind.startswith("conv_s2") else (4 if kind.startswith("convt") else 5)
+        full = (torch.randn(40, 24, generator=g) if kind == "linear_t" else torch.randn(40, 24, k, generator=g)).to(DEV)
+        for w in (full, full[8:32]):
+            shape, n, st, off = train._geom(kind, w)
+            dst = torch.full(shape, float("nan"), device=DEV)
+            jobs.append((w, off, dst, n, st))
+            want.append(train._aten_pack(kind, w))
+    big = torch.randn(300, 70, 5, generator=g).to(DEV)         # several chunks, a ragged last one
+    shape, n, st, off = train._geom("conv_bwd", big)
+    jobs.append((big, off, torch.empty(shape, device=DEV), n, st))
+    want.append(train._aten_pack("conv_bwd", big))
+    blocks.relayout(blocks.relayout_table(jobs, DEV))
+    for (_, _, dst, _, _), w in zip(jobs, want):
+        assert torch.equal(dst, w)
+    # the registry over three optimiser steps of a small U-Net
+    monkeypatch.setenv("CDX_TRAIN_GRAPH", "0")
+    calls = {"aten": 0, "launch": 0}
+    orig_pack, orig_launch = train._aten_pack, blocks.relayout
+    monkeypatch.setattr(train, "_aten_pack", lambda k, w: (calls.__setitem__("aten", calls["aten"] + 1), orig_pack(k, w))[1])
+    monkeypatch.setattr(blocks, "relayout", lambda t: (calls.__setitem__("launch", calls["launch"] + 1), orig_launch(t))[1])
+
+    def make():
+        net = load_synth(amd_lib.JannerUNet1d(6, model_dim=16, emb_dim=16, dim_mult=[1, 2], kernel_size=5), 3)
+        return amd_lib.DiscreteDiffusionSDE(net, None, diffusion_steps=20, grad_clip_norm=1.0, device=DEV)
+    x0 = torch.randn(12, 8, 6, generator=g).to(DEV)
+    runs = {}
+    for packs in ("1", "0"):
+        monkeypatch.setenv("CDX_TRAIN_PACKS", packs)
+        agent = make()
+        agent.train()
+        torch.manual_seed(3)
+        per_step = []
+        for step in range(3):
+            before = dict(calls)
+            log = agent.update(x0)
+            per_step.append((calls["aten"] - before["aten"], calls["launch"] - before["launch"], float(log["loss"]), float(log["grad_norm"])))
+        before = dict(calls)
+        agent.loss(x0).backward()                          # no parameter change since the last forward... (the optimiser stepped: one launch)
+        agent.loss(x0).backward()                          # ...and now really none
+        per_step.append((calls["aten"] - before["aten"], calls["launch"] - before["launch"], 0.0, 0.0))
+        runs[packs] = per_step
+    on, off = runs["1"], runs["0"]
+    assert on[0][0] > 0 and on[0][1] == 0 and on[1][:2] == (0, 1) and on[2][:2] == (0, 1) and on[3][:2] == (0, 1), on
+    assert all(r[1] == 0 and r[0] > 0 for r in off[:3]), off
+    np.testing.assert_allclose([r[2:] for r in on[:3]], [r[2:] for r in off[:3]], rtol=1e-5)
+
+
 @pytest.mark.parametrize("kind", ["janner", "chiunet", "dit"])
 def test_update_accumulates_parameter_gradients_in_place(kind, amd_lib, monkeypatch):
     """Inside update()'s backward (engine/train.py:grads_in_place) the weight / bias / gain sums are added straight into ``p.grad`` by the
