@@ -407,11 +407,13 @@ def _cna(h, seq: nn.Sequential, batch: int, length: int):
     return _GroupNormMish.apply(y, gn.weight, gn.bias, batch, length, gn.num_groups, gn.eps)
 
 
-def _resblock(rb, h, emb, batch: int, length: int):
-    """ResidualBlock (reference jannerunet.py:51-69): CNA2(CNA1(x) + Linear(Mish(emb))) + skip(x)."""
+def _resblock(rb, h, memb, batch: int, length: int):
+    """ResidualBlock (reference jannerunet.py:51-69): CNA2(CNA1(x) + Linear(Mish(emb))) + skip(x).  `memb` = Mish(emb), evaluated once
+    for all blocks (every block's emb_mlp starts with the same Mish); the block's Linear is a library node."""
     c_out = rb.conv1[0].out_channels
     a1 = _cna(h, rb.conv1, batch, length)
-    a1 = (a1.view(batch, length, c_out) + rb.emb_mlp(emb)[:, None, :]).view(batch * length, c_out)
+    lin = rb.emb_mlp[1]
+    a1 = (a1.view(batch, length, c_out) + _LinearMish.apply(memb, lin.weight, lin.bias, False)[:, None, :]).view(batch * length, c_out)
     a2 = _cna(a1, rb.conv2, batch, length)
     res = h if isinstance(rb.residual_conv, nn.Identity) else _conv(h, rb.residual_conv, batch, length)
     return a2 + res
@@ -423,8 +425,9 @@ def janner_forward(net, x: torch.Tensor, noise: torch.Tensor, condition: Optiona
     library's kernels.  x (b, H, D) -> (b, H, D)."""
     b, length, d = x.shape
     emb = net.map_noise(noise)
-    emb = emb + (condition if condition is not None else torch.zeros_like(emb))
-    emb = net.map_emb(emb)
+    if condition is not None:                              # (the reference adds zeros otherwise, jannerunet.py:183: the same numbers)
+        emb = emb + condition
+    emb = torch.nn.functional.mish(_sequential(net.map_emb, emb.contiguous()))        # Mish(emb): what every block's emb_mlp starts with
     h = x.reshape(b * length, d)
     skips = []
     for res1, res2, _, down in net.downs:
