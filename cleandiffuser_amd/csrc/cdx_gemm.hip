@@ -610,6 +610,62 @@ __global__ __launch_bounds__(256) void cdx_layernorm_kernel(const cdx_ln_args a)
     }
 }
 
+// The same LayerNorm with 16-byte accesses: a row belongs to 16 lanes (NV float4 each: C <= 64 NV), four rows per wave, sixteen per
+// workgroup.  The scalar kernel above keeps ONE 4-byte load per lane and 64 columns in flight -- 1.8 TB/s on the (32 768 x 320) token
+// rows of config 4 (profiles/r05_cfg4_512_rocprofv3_kernel_stats.csv: 47 us per call, 6.5 % of the sampling loop); here a lane has up
+// to NV independent 16-byte loads outstanding.  Same two-pass statistics (mean, then centred squares); the order of the sums differs
+// from the scalar kernel's (results agree to rounding).  Needs C % 4 == 0 and 16-byte aligned rows / parameter vectors (the host checks).
+template <int NV>
+__global__ __launch_bounds__(256) void cdx_layernorm_vec_kernel(const cdx_ln_args a) {
+    const int sub = threadIdx.x & 15;
+    const int row0 = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool live = row0 < a.M;
+    const int row = live ? row0 : a.M - 1;               // (idle lanes of the last workgroup recompute the last row and store nothing)
+    const float* x = a.x + (size_t)(a.x_rows > 0 ? row % a.x_rows : row) * a.ldx;
+    const int n4 = a.C >> 2;
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+        const int q = sub + 16 * t;
+        v[t] = q < n4 ? *reinterpret_cast<const float4*>(x + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[t].x + v[t].y) + (v[t].z + v[t].w);
+    }
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)a.C;
+    float s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+        if (sub + 16 * t < n4) {
+            v[t].x -= mean; v[t].y -= mean; v[t].z -= mean; v[t].w -= mean;
+            s2 += (v[t].x * v[t].x + v[t].y * v[t].y) + (v[t].z * v[t].z + v[t].w * v[t].w);
+        }
+    }
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+    const float rstd = 1.0f / sqrtf(s2 / (float)a.C + a.eps);
+    if (!live) return;
+    const size_t mod = (size_t)(row / a.rows_per_mod) * a.ldmod;
+    float* y = a.y + (size_t)row * a.ldy;
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+        const int q = sub + 16 * t;
+        if (q < n4) {
+            float4 o = make_float4(v[t].x * rstd, v[t].y * rstd, v[t].z * rstd, v[t].w * rstd);
+            if (a.gamma) {
+                const float4 g = *reinterpret_cast<const float4*>(a.gamma + 4 * q), be = *reinterpret_cast<const float4*>(a.beta + 4 * q);
+                o = make_float4(o.x * g.x + be.x, o.y * g.y + be.y, o.z * g.z + be.z, o.w * g.w + be.w);
+            }
+            if (a.scale) {
+                const float4 sc = *reinterpret_cast<const float4*>(a.scale + mod + 4 * q), sh = *reinterpret_cast<const float4*>(a.shift + mod + 4 * q);
+                o = make_float4(o.x * (1.0f + sc.x) + sh.x, o.y * (1.0f + sc.y) + sh.y, o.z * (1.0f + sc.z) + sh.z, o.w * (1.0f + sc.w) + sh.w);
+            }
+            *reinterpret_cast<float4*>(y + 4 * q) = o;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // GroupNorm (+ activation, FiLM, residual) on channel-last rows: one wave per (sample, group); the group's L x C/G values stay
 // in registers when there are <= 2048 of them (two-pass variance like ATen), else they are re-read.
@@ -1295,6 +1351,29 @@ __global__ void cdx_act_bwd_kernel(const float* __restrict__ pre, const float* _
 }
 
 static int gm_launch(const cdx_gemm_args* g, void* hip_stream, bool force_small, int* defer_slices = nullptr);
+// One side stream + fork / join events per device, created at first use and kept for the life of the process (cdx_gemm_f32's split-N path).
+struct gm_side {
+    hipStream_t stream;
+    hipEvent_t fork, join;
+};
+static gm_side* gm_side_stream() {
+    static gm_side table[16];
+    static bool made[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (!made[dev]) {
+        gm_side sd{};
+        if (hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        table[dev] = sd;
+        made[dev] = true;
+    }
+    return &table[dev];
+}
 static bool gn_vec_enabled() {                       // CDX_GN_VEC=0: the scalar GroupNorm kernel everywhere (A/B hook)
     static const bool on = [] { const char* e = getenv("CDX_GN_VEC"); return !(e && e[0] == '0'); }();
     return on;
@@ -1321,8 +1400,36 @@ int cdx_gemm_f32(const cdx_gemm_args* g, void* hip_stream) {
         if (g->residual) b.residual = g->residual + n1;
         a.partial = b.partial = nullptr;                 // (large M: split-K would not engage anyway)
         a.partial_slices = b.partial_slices = 0;
-        const int rc = gm_launch(&a, hip_stream, false);
-        return rc != CDX_OK ? rc : gm_launch(&b, hip_stream, true);
+        // The two launches write disjoint columns from the same inputs.  The 128-wide part is ONE full wave of workgroups on most of
+        // these shapes (M = 32 768, N = 256: 512 tiles on 512 slots of two 8-wave workgroups per CU); behind it the remainder -- 512 tiles
+        // of the 4-wave 64 x 64 kernel -- half-fills the chip for another ~50 us (11.5 % of config 4's loop,
+        // profiles/r05_cfg4_512_rocprofv3_kernel_stats.csv).  Registers and LDS leave room for one such workgroup NEXT TO the two big
+        // ones on a CU (4 x 96 + 96 of 512 VGPRs per SIMD, 2 x 36.9 + 33 KB of LDS), so the remainder goes to a side stream of the
+        // library between two events and fills the issue slots the big kernel leaves idle.  Not while the caller's stream is being
+        // captured (events of a library-owned stream inside somebody else's capture: the serial order is kept there).
+        // CDX_GEMM_SPLIT_N_SIDE=0: both launches on the caller's stream (A/B hook).
+        static const bool side_on = [] { const char* e = getenv("CDX_GEMM_SPLIT_N_SIDE"); return !(e && e[0] == '0'); }();
+        hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+        gm_side* sd = nullptr;
+        if (side_on) {
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) sd = gm_side_stream();
+            else (void)hipGetLastError();
+        }
+        if (sd == nullptr) {
+            const int rc = gm_launch(&a, hip_stream, false);
+            return rc != CDX_OK ? rc : gm_launch(&b, hip_stream, true);
+        }
+        if (hipEventRecord(sd->fork, s) != hipSuccess || hipStreamWaitEvent(sd->stream, sd->fork, 0) != hipSuccess) {
+            cdx_set_err("cdx_gemm_f32: fork to the side stream failed"); return CDX_EHIP;
+        }
+        const int rc_a = gm_launch(&a, hip_stream, false);
+        const int rc_b = gm_launch(&b, sd->stream, true);
+        // (join even if a launch was refused: the caller's stream must not run ahead of what the side stream did)
+        if (hipEventRecord(sd->join, sd->stream) != hipSuccess || hipStreamWaitEvent(s, sd->join, 0) != hipSuccess) {
+            cdx_set_err("cdx_gemm_f32: join from the side stream failed"); return CDX_EHIP;
+        }
+        return rc_a != CDX_OK ? rc_a : rc_b;
     }
     return gm_launch(g, hip_stream, false);
 }
@@ -1493,8 +1600,21 @@ int cdx_layernorm_f32(const cdx_ln_args* a, void* hip_stream) {
     if (a->M == 0) return CDX_OK;
     cdx_ln_args b = *a;
     if (b.rows_per_mod <= 0) b.rows_per_mod = 1;
-    auto kern = a->C <= 1024 ? cdx_layernorm_kernel<16> : (a->C <= 2048 ? cdx_layernorm_kernel<32> : cdx_layernorm_kernel<64>);
-    hipLaunchKernelGGL(kern, dim3((a->M + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), b);
+    // rows of up to 1024 columns with 16-byte aligned everything: the float4 kernel (CDX_LN_VEC=0: the scalar one everywhere, A/B hook)
+    static const bool vec_on = [] { const char* e = getenv("CDX_LN_VEC"); return !(e && e[0] == '0'); }();
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    const bool vec = vec_on && a->C <= 1024 && a->C % 4 == 0 && a->ldx % 4 == 0 && a->ldy % 4 == 0 && al16(a->x) && al16(a->y) &&
+                     al16(a->gamma) && al16(a->beta) && al16(a->scale) && al16(a->shift) && (!a->scale || a->ldmod % 4 == 0);
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    if (vec) {
+        const dim3 grid((a->M + 15) / 16), block(256);
+        if (a->C <= 256) hipLaunchKernelGGL(cdx_layernorm_vec_kernel<4>, grid, block, 0, st, b);
+        else if (a->C <= 512) hipLaunchKernelGGL(cdx_layernorm_vec_kernel<8>, grid, block, 0, st, b);
+        else hipLaunchKernelGGL(cdx_layernorm_vec_kernel<16>, grid, block, 0, st, b);
+    } else {
+        auto kern = a->C <= 1024 ? cdx_layernorm_kernel<16> : (a->C <= 2048 ? cdx_layernorm_kernel<32> : cdx_layernorm_kernel<64>);
+        hipLaunchKernelGGL(kern, dim3((a->M + 3) / 4), dim3(256), 0, st, b);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
     return CDX_OK;

@@ -94,7 +94,7 @@ def _grad_slot(p) -> Optional[torch.Tensor]:
     """``p.grad`` as the tensor a kernel may add p's gradient into (created zeroed if missing), or None: autograd accumulates."""
     if _in_place_depth <= 0 or os.environ.get("CDX_TRAIN_INPLACE_GRADS", "1") == "0":
         return None
-    if not isinstance(p, nn.Parameter) or not p.is_leaf or p.dtype != torch.float32 or p._backward_hooks or \
+    if not isinstance(p, nn.Parameter) or not p.is_leaf or not p.requires_grad or p.dtype != torch.float32 or p._backward_hooks or \
             getattr(p, "_post_accumulate_grad_hooks", None):
         return None
     g = p.grad
@@ -584,10 +584,18 @@ class _LayerNormAffine(torch.autograd.Function):
         x, gamma = ctx.saved_tensors
         dy = dy.contiguous()
         dx, dyx = blocks.layernorm_backward(dy, x, gamma=gamma.detach(), eps=ctx.eps, want_dyxhat=True)
-        sg, sb = _grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])
-        dg, db = blocks.colsum(dyx, out=sg), blocks.colsum(dy, out=sb)
-        _written(sg, sb)
-        return dx, (None if sg is not None else dg), (None if sb is not None else db), None
+        dg = db = None
+        if ctx.needs_input_grad[1]:
+            sg = _grad_slot(ctx.params[0])
+            dg = blocks.colsum(dyx, out=sg)
+            _written(sg)
+            dg = None if sg is not None else dg
+        if ctx.needs_input_grad[2]:
+            sb = _grad_slot(ctx.params[1])
+            db = blocks.colsum(dy, out=sb)
+            _written(sb)
+            db = None if sb is not None else db
+        return dx, dg, db, None
 
 
 class _LayerNormMod(torch.autograd.Function):
