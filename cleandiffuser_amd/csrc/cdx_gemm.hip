@@ -1351,29 +1351,6 @@ __global__ void cdx_act_bwd_kernel(const float* __restrict__ pre, const float* _
 }
 
 static int gm_launch(const cdx_gemm_args* g, void* hip_stream, bool force_small, int* defer_slices = nullptr);
-// One side stream + fork / join events per device, created at first use and kept for the life of the process (cdx_gemm_f32's split-N path).
-struct gm_side {
-    hipStream_t stream;
-    hipEvent_t fork, join;
-};
-static gm_side* gm_side_stream() {
-    static gm_side table[16];
-    static bool made[16] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    if (!made[dev]) {
-        gm_side sd{};
-        if (hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) != hipSuccess) {
-            (void)hipGetLastError();
-            return nullptr;
-        }
-        table[dev] = sd;
-        made[dev] = true;
-    }
-    return &table[dev];
-}
 static bool gn_vec_enabled() {                       // CDX_GN_VEC=0: the scalar GroupNorm kernel everywhere (A/B hook)
     static const bool on = [] { const char* e = getenv("CDX_GN_VEC"); return !(e && e[0] == '0'); }();
     return on;
@@ -1400,36 +1377,11 @@ int cdx_gemm_f32(const cdx_gemm_args* g, void* hip_stream) {
         if (g->residual) b.residual = g->residual + n1;
         a.partial = b.partial = nullptr;                 // (large M: split-K would not engage anyway)
         a.partial_slices = b.partial_slices = 0;
-        // The two launches write disjoint columns from the same inputs.  The 128-wide part is ONE full wave of workgroups on most of
-        // these shapes (M = 32 768, N = 256: 512 tiles on 512 slots of two 8-wave workgroups per CU); behind it the remainder -- 512 tiles
-        // of the 4-wave 64 x 64 kernel -- half-fills the chip for another ~50 us (11.5 % of config 4's loop,
-        // profiles/r05_cfg4_512_rocprofv3_kernel_stats.csv).  Registers and LDS leave room for one such workgroup NEXT TO the two big
-        // ones on a CU (4 x 96 + 96 of 512 VGPRs per SIMD, 2 x 36.9 + 33 KB of LDS), so the remainder goes to a side stream of the
-        // library between two events and fills the issue slots the big kernel leaves idle.  Not while the caller's stream is being
-        // captured (events of a library-owned stream inside somebody else's capture: the serial order is kept there).
-        // CDX_GEMM_SPLIT_N_SIDE=0: both launches on the caller's stream (A/B hook).
-        static const bool side_on = [] { const char* e = getenv("CDX_GEMM_SPLIT_N_SIDE"); return !(e && e[0] == '0'); }();
-        hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
-        gm_side* sd = nullptr;
-        if (side_on) {
-            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-            if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) sd = gm_side_stream();
-            else (void)hipGetLastError();
-        }
-        if (sd == nullptr) {
-            const int rc = gm_launch(&a, hip_stream, false);
-            return rc != CDX_OK ? rc : gm_launch(&b, hip_stream, true);
-        }
-        if (hipEventRecord(sd->fork, s) != hipSuccess || hipStreamWaitEvent(sd->stream, sd->fork, 0) != hipSuccess) {
-            cdx_set_err("cdx_gemm_f32: fork to the side stream failed"); return CDX_EHIP;
-        }
-        const int rc_a = gm_launch(&a, hip_stream, false);
-        const int rc_b = gm_launch(&b, sd->stream, true);
-        // (join even if a launch was refused: the caller's stream must not run ahead of what the side stream did)
-        if (hipEventRecord(sd->join, sd->stream) != hipSuccess || hipStreamWaitEvent(s, sd->join, 0) != hipSuccess) {
-            cdx_set_err("cdx_gemm_f32: join from the side stream failed"); return CDX_EHIP;
-        }
-        return rc_a != CDX_OK ? rc_a : rc_b;
+        // (Measured and dropped in round 5: the remainder on a side stream of the library NEXT TO the 128-wide launch -- registers and
+        //  LDS would let one 4-wave workgroup sit beside the two 8-wave ones on a CU -- is 2 % SLOWER on the config-4 shard than the
+        //  two launches back to back, profiles/r05_ln_vec_and_side_stream_ab.txt.)
+        const int rc = gm_launch(&a, hip_stream, false);
+        return rc != CDX_OK ? rc : gm_launch(&b, hip_stream, true);
     }
     return gm_launch(g, hip_stream, false);
 }

@@ -5,7 +5,7 @@ mkdir -p gpurun_out/r5q
 run() { timeout 300 python tools/bench_configs.py $1 2>&1 | tail -1 | python -c "import sys, json; d = json.loads(sys.stdin.read()); print(round(d['ms_per_call'], 2), 'ms', round(d.get('frac_fp32_mfma_peak', 0), 4))" 2>&1 | tail -1; }
 for v in "0 0" "1 0" "0 1" "1 1" "0 0" "1 1"; do
   set -- $v
-  export CDX_LN_VEC=$1 CDX_GEMM_SPLIT_N_SIDE=$2
+  export CDX_LN_VEC=$1 CDX_GEMM_SPLIT_N_SIDE=$2   # (the side-stream path was removed after this run)
   echo -n "ln_vec=$1 side=$2 cfg4:512: "; run cfg4:512
 done 2>&1 | tee gpurun_out/r5q/ab.txt
 export CDX_GEMM_SPLIT_N_SIDE=1
