@@ -239,6 +239,8 @@ class _WeightPacks:
         if e is not None and e[2] == self.sig:
             return e[0]
         t = _aten_pack(kind, w)
+        if t.untyped_storage().data_ptr() == w.untyped_storage().data_ptr():
+            return t                                       # (a 1-tap / 1-column weight IS its own layout: a view, no launch, nothing to keep)
         if e is None and not torch.cuda.is_current_stream_capturing():
             # adopt this tensor as the layout's home: from the next parameter change on it is rewritten by the one launch
             shape, n, st, off = _geom(kind, w)

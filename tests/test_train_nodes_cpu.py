@@ -1,0 +1,157 @@
+"""The host logic of the training path (cleandiffuser_amd/engine/train.py) on the CPU tier: with the kernel wrappers replaced by torch
+expressions of their contracts (tests/torch_blocks.py), every native training forward -- JannerUNet1d, ChiUNet1d, DiT1d, IDQLMlp,
+ChiTransformer, DQLMlp -- must give torch.autograd's output and gradients of the module's own PyTorch forward; gradients routed
+straight into ``.grad`` (grads_in_place) must equal autograd's accumulation; the weight-layout registry must stay current across
+optimiser steps with one refresh per parameter change.  (The kernels themselves: tests/test_gpu_parity.py on the MI355X.)"""
+import pytest
+import torch
+
+import cleandiffuser_amd.nn_diffusion as N
+from cleandiffuser_amd.engine import train
+from cleandiffuser_amd.utils import load_synth
+from torch_blocks import emulated
+
+
+def _case(name):
+    g = torch.Generator().manual_seed(11)
+    if name == "janner":
+        net = load_synth(N.JannerUNet1d(6, model_dim=16, emb_dim=16, dim_mult=[1, 2, 2], kernel_size=5), 3)
+        return net, train.janner_forward, (torch.randn(4, 8, 6, generator=g), torch.randint(0, 20, (4,), generator=g), None)
+    if name == "janner_cond":
+        net = load_synth(N.JannerUNet1d(6, model_dim=16, emb_dim=16, dim_mult=[1, 2], kernel_size=3), 4)
+        return net, train.janner_forward, (torch.randn(3, 8, 6, generator=g), torch.randint(0, 20, (3,), generator=g), torch.randn(3, 16, generator=g))
+    if name == "chiunet":
+        net = load_synth(N.ChiUNet1d(2, 5, 2, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2], obs_as_global_cond=True), 5)
+        return net, train.chi_forward, (torch.randn(3, 16, 2, generator=g), torch.randint(0, 20, (3,), generator=g), torch.randn(3, 2, 5, generator=g))
+    if name == "dit":
+        net = load_synth(N.DiT1d(7, emb_dim=32, d_model=64, n_heads=4, depth=2, timestep_emb_type="fourier"), 6)
+        return net, train.dit_forward, (torch.randn(3, 16, 7, generator=g), torch.rand(3, generator=g), torch.randn(3, 32, generator=g))
+    if name == "idql":
+        net = load_synth(N.IDQLMlp(11, 5, emb_dim=16, hidden_dim=64, n_blocks=2, dropout=0.0), 7)
+        return net, train.idql_forward, (torch.randn(6, 5, generator=g), torch.rand(6, generator=g), torch.randn(6, 11, generator=g))
+    if name == "chitf":
+        net = load_synth(N.ChiTransformer(3, 5, 6, 3, d_model=64, nhead=4, num_layers=2, p_drop_attn=0.0, n_cond_layers=2), 8)
+        return net, train.chitf_forward, (torch.randn(4, 6, 3, generator=g), torch.randint(0, 20, (4,), generator=g), torch.randn(4, 3, 5, generator=g))
+    if name == "dql":
+        net = load_synth(N.DQLMlp(11, 6, emb_dim=16), 9)
+        return net, train.dql_forward, (torch.randn(5, 6, generator=g), torch.randint(0, 10, (5,), generator=g), torch.randn(5, 11, generator=g))
+    raise KeyError(name)
+
+
+def _grads(net):
+    return {n: (None if p.grad is None else p.grad.clone()) for n, p in net.named_parameters()}
+
+
+def _reference(net, args, wgt):
+    net.zero_grad(set_to_none=True)
+    x = args[0].clone().requires_grad_(True)
+    y = net._forward_torch(x, *args[1:]) if hasattr(net, "_forward_torch") else None
+    if y is None:                                           # (modules whose forward() is the torch code once no device path applies)
+        y = net(x, *args[1:])
+    (y * wgt).sum().backward()
+    return y.detach(), x.grad.clone(), _grads(net)
+
+
+def _close(got, want, what, tol=2e-5):
+    if want is None:
+        assert got is None or float(got.abs().max()) == 0.0, what
+        return
+    assert got is not None, what
+    sc = float(want.abs().max()) + 1e-12
+    assert float((got - want).abs().max()) <= tol * sc + 1e-7, (what, float((got - want).abs().max()), sc)
+
+
+CASES = ["janner", "janner_cond", "chiunet", "dit", "idql", "chitf", "dql"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_native_training_forward_is_the_modules_autograd_graph(name):
+    net, fwd, args = _case(name)
+    net.train()
+    wgt = torch.randn(args[0].shape, generator=torch.Generator().manual_seed(1))
+    y0, gx0, gp0 = _reference(net, args, wgt)
+    with emulated():
+        for in_place in (False, True):
+            net.zero_grad(set_to_none=True)
+            x = args[0].clone().requires_grad_(True)
+            y = fwd(net, x, *args[1:])
+            if in_place:
+                with train.grads_in_place():
+                    (y * wgt).sum().backward()
+            else:
+                (y * wgt).sum().backward()
+            _close(y.detach(), y0, f"{name}: output")
+            _close(x.grad, gx0, f"{name}: input gradient")
+            for n, g in _grads(net).items():
+                _close(g, gp0[n], f"{name} (in place {in_place}): {n}")
+
+
+@pytest.mark.parametrize("name", ["janner", "chiunet", "chitf"])
+def test_in_place_gradient_sums_accumulate_and_leave_hooked_or_frozen_parameters_to_autograd(name):
+    net, fwd, args = _case(name)
+    net.train()
+    wgt = torch.randn(args[0].shape, generator=torch.Generator().manual_seed(2))
+    _, _, gp0 = _reference(net, args, wgt)
+    params = dict(net.named_parameters())
+    trained = [n for n, g in gp0.items() if g is not None]
+    frozen, hooked = trained[1], trained[-1]
+    params[frozen].requires_grad_(False)
+    fired = []
+    params[hooked].register_hook(lambda g: fired.append(1))
+    seeds = {n: torch.randn(p.shape, generator=torch.Generator().manual_seed(3)) for n, p in params.items()}
+    with emulated():
+        for n, p in params.items():
+            p.grad = None if n == frozen else seeds[n].clone()
+        versions = {n: p.grad._version for n, p in params.items() if p.grad is not None}
+        with train.grads_in_place():
+            (fwd(net, args[0], *args[1:]) * wgt).sum().backward()
+    assert len(fired) == 1 and params[frozen].grad is None
+    for n in trained:
+        if n != frozen:
+            _close(params[n].grad - seeds[n], gp0[n], f"{name}: {n}")
+            assert params[n].grad._version > versions[n], n          # FusedAdamW tells a written gradient by its version
+    # outside update(): nothing touches .grad, the functional API gets the tensors
+    params[frozen].requires_grad_(True)
+    net.zero_grad(set_to_none=True)
+    with emulated():
+        got = torch.autograd.grad((fwd(net, args[0], *args[1:]) * wgt).sum(), [params[n] for n in trained])
+    assert all(p.grad is None for p in params.values())
+    for n, g in zip(trained, got):
+        _close(g, gp0[n], f"{name}: autograd.grad {n}")
+
+
+@pytest.mark.parametrize("name", ["janner", "chiunet", "chitf", "dit"])
+def test_weight_layouts_are_refreshed_once_per_parameter_change(name, monkeypatch):
+    net, fwd, args = _case(name)
+    net.train()
+    wgt = torch.randn(args[0].shape, generator=torch.Generator().manual_seed(4))
+    opt = torch.optim.SGD(net.parameters(), lr=1e-3)
+    with emulated() as counts:
+        seen = []
+        for step in range(4):
+            _, _, gp0 = _reference(net, args, wgt)
+            net.zero_grad(set_to_none=True)
+            before = dict(counts)
+            with train.grads_in_place():
+                (fwd(net, args[0], *args[1:]) * wgt).sum().backward()
+            seen.append((counts["aten_pack"] - before["aten_pack"], counts["relayout"] - before["relayout"]))
+            for n, g in _grads(net).items():
+                _close(g, gp0[n], f"{name} step {step}: {n}")
+            if step != 2:
+                opt.step()                                  # (no step between passes 2 and 3: nothing at all may be launched)
+        assert seen[0][0] > 0 and seen[0][1] == 0 and seen[1] == (0, 1) and seen[2] == (0, 1) and seen[3] == (0, 0), seen
+        # moved parameters (module.to / a re-created tensor): the table is rebuilt from scratch, never read through stale addresses
+        for p in net.parameters():
+            p.data = p.data.clone()
+        _, _, gp0 = _reference(net, args, wgt)
+        net.zero_grad(set_to_none=True)
+        before = dict(counts)
+        (fwd(net, args[0], *args[1:]) * wgt).sum().backward()
+        assert counts["aten_pack"] - before["aten_pack"] == seen[0][0] and counts["relayout"] == before["relayout"]
+        for n, g in _grads(net).items():
+            _close(g, gp0[n], f"{name} after the move: {n}")
+    monkeypatch.setenv("CDX_TRAIN_PACKS", "0")
+    with emulated() as counts:
+        net.zero_grad(set_to_none=True)
+        (fwd(net, args[0], *args[1:]) * wgt).sum().backward()
+        assert counts["relayout"] == 0 and counts["aten_pack"] == seen[0][0]
