@@ -13,6 +13,7 @@ timeout 300 python tools/op_profile2.py 256 group4 > $E/r05_op_profile_group4_wg
 timeout 300 python tools/time_cfg2.py 256 32 64 128 3200 2>&1 | grep -v amdgpu.ids > $E/r05_batch_sweep.txt; cat $E/r05_batch_sweep.txt
 BENCH_FORCE_DIST=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 40 --warmup 5 --no-cpu-baseline --no-other-configs > $E/r05_bench_forced_dist.json 2> $E/r05_bench_forced_dist.err; tail -c 400 $E/r05_bench_forced_dist.json; echo
 timeout 600 python tools/update_bench.py 2>&1 | grep -v "amdgpu.ids\|Synchronization debug\|_cuda_set_sync" > $E/r05_update_bench.txt; cat $E/r05_update_bench.txt
+for c in cfg2 chitf; do timeout 200 python tools/update_census.py $c 2>&1 | grep -v "Warning\|amdgpu.ids"; echo; done > $E/r05_update_census.txt; head -6 $E/r05_update_census.txt
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$E/stats -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-other-configs --no-pmc > $R/$E/stats.log 2>&1
@@ -30,7 +31,7 @@ import os, sys, torch
 os.environ["CDX_TRAIN_GRAPH"] = "0"          # eager nodes: the kernels of a HIP-graph replay are the same ones, launched by the graph
 sys.path.insert(0, sys.argv[1] + "/tools"); sys.path.insert(0, sys.argv[1])
 import update_bench as ub
-for name in ("cfg2", "cfg3", "cfg4", "cfg5"):
+for name in ("cfg2", "cfg3", "cfg4", "cfg5", "chitf"):
     agent, x0, cond, what = ub.build(name)
     for _ in range(6):
         agent.update(x0, cond) if cond is not None else agent.update(x0)
