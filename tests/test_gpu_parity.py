@@ -1660,7 +1660,11 @@ def test_relayout_kernel_builds_every_weight_layout_and_the_registry_keeps_them_
     monkeypatch.setenv("CDX_TRAIN_GRAPH", "0")
     calls = {"aten": 0, "launch": 0}
     orig_pack, orig_launch = train._aten_pack, blocks.relayout
-    monkeypatch.setattr(train, "_aten_pack", lambda k, w: (calls.__setitem__("aten", calls["aten"] + 1), orig_pack(k, w))[1])
+    def counted_pack(k, w):                               # (a 1-tap weight is its own layout: the "pack" is a view, no launch -- not counted)
+        t = orig_pack(k, w)
+        calls["aten"] += int(t.untyped_storage().data_ptr() != w.untyped_storage().data_ptr())
+        return t
+    monkeypatch.setattr(train, "_aten_pack", counted_pack)
     monkeypatch.setattr(blocks, "relayout", lambda t: (calls.__setitem__("launch", calls["launch"] + 1), orig_launch(t))[1])
 
     def make():
@@ -1971,7 +1975,8 @@ def test_update_that_cannot_be_captured_keeps_the_eager_path(amd_lib, monkeypatc
             out[tag] = [agent.update(x0)["loss"] for _ in range(3)]
     assert isinstance(a.__dict__.get("_cdx_graph_off"), str) and not a.__dict__.get("_cdx_graphed"), a.__dict__.get("_cdx_graph_off")
     assert torch.cuda.get_sync_debug_mode() == 0
-    assert out["auto"] == out["0"], out
+    # (same draws, same gradients -- up to the order of the float atomics the weight / gain sums are combined with: ~1e-7)
+    np.testing.assert_allclose(out["auto"], out["0"], rtol=2e-6, err_msg=str(out))
 
 
 def test_graphed_update_draws_what_the_eager_update_draws_and_survives_dropped_gradients(amd_lib, monkeypatch):
