@@ -847,11 +847,25 @@ __global__ __launch_bounds__(256) void cdx_groupnorm_vec_kernel(const cdx_gn_arg
 // Backward of act(GroupNorm(x) gamma + beta) w.r.t. x, one wave per (sample, group):
 //   dz = dy * act'(z),  g = dz * gamma,  dx = rstd * (g - mean(g) - xhat * mean(g * xhat))      (means over the group)
 // ------------------------------------------------------------------------------------------------
+// SUMS (training with cdx_gn_args.dgamma_sum / dbeta_sum): the four waves of a workgroup take FOUR SAMPLES OF ONE GROUP, combine their
+// per-channel sums in LDS and issue one float atomic per channel and workgroup -- B / 4 instead of B adds per address (with one atomic
+// per sample the backward of a config-2 step spent 507 us in this kernel against 254 us without the sums, profiles/r05_update_census.txt).
+template <bool SUMS>
 __global__ __launch_bounds__(256) void cdx_groupnorm_bwd_kernel(const cdx_gn_args a) {
-    const int lane = threadIdx.x & 63;
-    const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wg >= a.B * a.G) return;
-    const int b = wg / a.G, grp = wg - b * a.G;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ float red[SUMS ? 2 * 4 * 256 : 1];
+    int b, grp;
+    if (SUMS) {
+        grp = blockIdx.x % a.G;
+        b = (blockIdx.x / a.G) * 4 + wave;
+    } else {
+        const int wg = blockIdx.x * 4 + wave;
+        b = wg / a.G;
+        grp = wg - b * a.G;
+    }
+    const bool live = b < a.B;
+    if (!SUMS && !live) return;
+    if (SUMS && !live) b = a.B - 1;                       // (an idle wave of the last workgroup recomputes the last sample, adds and stores nothing)
     const int cg = a.C / a.G, n = a.L * cg;
     const float* xb = a.x + (size_t)b * a.L * a.ldx + grp * cg;
     const float* db = a.residual + (size_t)b * a.L * a.ldr + grp * cg;
@@ -892,23 +906,33 @@ __global__ __launch_bounds__(256) void cdx_groupnorm_bwd_kernel(const cdx_gn_arg
         for (int q = 0; q < 4; ++q)
             if (q == j) { pg[q] += dz * xh; pb[q] += dz; }
     }
-    if (a.dgamma_part != nullptr || a.dgamma_sum != nullptr) {
-        const bool stage = a.dgamma_part != nullptr;      // per-sample partials, or atomics straight onto the (C) sums
+    if (SUMS || a.dgamma_part != nullptr) {
+        // per-sample partials (B, C) for the caller's column sums, or -- SUMS -- this workgroup's four samples combined in LDS
+        float* rg = SUMS ? red + wave * 256 : red;
+        float* rb = SUMS ? red + (4 + wave) * 256 : red;
         if (cg <= 64) {       // the lanes that share a channel differ in the bits >= log2(cg)
             for (int o = 32; o >= cg; o >>= 1) { pg[0] += __shfl_xor(pg[0], o, 64); pb[0] += __shfl_xor(pb[0], o, 64); }
             if (lane < cg) {
                 const int ch = grp * cg + lane;
-                if (stage) { a.dgamma_part[(size_t)b * a.C + ch] = pg[0]; a.dbeta_part[(size_t)b * a.C + ch] = pb[0]; }
-                else { atomicAdd(a.dgamma_sum + ch, pg[0]); atomicAdd(a.dbeta_sum + ch, pb[0]); }
+                if (!SUMS) { a.dgamma_part[(size_t)b * a.C + ch] = pg[0]; a.dbeta_part[(size_t)b * a.C + ch] = pb[0]; }
+                else { rg[lane] = live ? pg[0] : 0.f; rb[lane] = live ? pb[0] : 0.f; }
             }
         } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (q <= jmask) {
-                    const int ch = grp * cg + lane + 64 * q;
-                    if (stage) { a.dgamma_part[(size_t)b * a.C + ch] = pg[q]; a.dbeta_part[(size_t)b * a.C + ch] = pb[q]; }
-                    else { atomicAdd(a.dgamma_sum + ch, pg[q]); atomicAdd(a.dbeta_sum + ch, pb[q]); }
+                    const int c = lane + 64 * q, ch = grp * cg + c;
+                    if (!SUMS) { a.dgamma_part[(size_t)b * a.C + ch] = pg[q]; a.dbeta_part[(size_t)b * a.C + ch] = pb[q]; }
+                    else { rg[c] = live ? pg[q] : 0.f; rb[c] = live ? pb[q] : 0.f; }
                 }
+        }
+        if (SUMS) {
+            __syncthreads();
+            for (int c = threadIdx.x; c < cg; c += 256) {
+                atomicAdd(a.dgamma_sum + grp * cg + c, (red[c] + red[256 + c]) + (red[512 + c] + red[768 + c]));
+                atomicAdd(a.dbeta_sum + grp * cg + c, (red[1024 + c] + red[1280 + c]) + (red[1536 + c] + red[1792 + c]));
+            }
+            if (!live) return;
         }
     }
 #pragma unroll
@@ -1609,7 +1633,11 @@ int cdx_groupnorm_bwd_f32(const cdx_gn_args* a, void* hip_stream) {
         if (cg > 256 || (cg & (cg - 1)) != 0) { cdx_set_err("cdx_groupnorm_bwd_f32: parameter gradients need a power-of-two group width <= 256"); return CDX_EINVAL; }
     }
     const long long waves = (long long)a->B * a->G;
-    hipLaunchKernelGGL(cdx_groupnorm_bwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), *a);
+    if (a->dgamma_sum != nullptr)
+        hipLaunchKernelGGL(cdx_groupnorm_bwd_kernel<true>, dim3((unsigned)(((a->B + 3) / 4) * (long long)a->G)), dim3(256), 0,
+                           reinterpret_cast<hipStream_t>(hip_stream), *a);
+    else
+        hipLaunchKernelGGL(cdx_groupnorm_bwd_kernel<false>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), *a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
     return CDX_OK;

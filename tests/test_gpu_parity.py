@@ -1632,6 +1632,32 @@ def test_chitransformer_update_with_the_pipelines_dropout_runs_native_and_seeded
     torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("B,L,C,G", [(5, 8, 32, 8), (7, 4, 1024, 8), (256, 32, 64, 8), (2, 16, 512, 8), (1, 8, 16, 8)])
+def test_groupnorm_backward_adds_its_gain_and_shift_sums_onto_the_callers_buffers(B, L, C, G):
+    """cdx_gn_args.dgamma_sum / dbeta_sum (ABI 15): the backward kernel's own float atomics -- four samples of a group per workgroup,
+    combined in LDS first -- against the staged (B, C) partials + column sums of the same kernel and against torch.autograd; on top of
+    what the buffers held; batches that are not a multiple of four; groups of 2 to 128 channels."""
+    import torch.nn.functional as F
+    from cleandiffuser_amd.engine import blocks
+    g = torch.Generator().manual_seed(B * 7 + C)
+    x = torch.randn(B * L, C, generator=g).to(DEV)
+    dy = torch.randn(B * L, C, generator=g).to(DEV)
+    gamma, beta = torch.randn(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
+    dx0, dg0, db0 = blocks.groupnorm_backward(dy, x, gamma, beta, B, L, G, act="mish", param_grads=True)
+    seed_g, seed_b = torch.randn(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
+    acc_g, acc_b = seed_g.clone(), seed_b.clone()
+    dx1, none_g, none_b = blocks.groupnorm_backward(dy, x, gamma, beta, B, L, G, act="mish", param_grads=True, grads_out=(acc_g, acc_b))
+    assert none_g is None and none_b is None and torch.equal(dx1, dx0)
+    sc = float(dg0.abs().max()) + float(db0.abs().max())
+    torch.testing.assert_close(acc_g - seed_g, dg0, rtol=1e-5, atol=2e-6 * sc)
+    torch.testing.assert_close(acc_b - seed_b, db0, rtol=1e-5, atol=2e-6 * sc)
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    F.mish(F.group_norm(xr.view(B, L, C).permute(0, 2, 1), G, gr, br, 1e-5)).permute(0, 2, 1).reshape(B * L, C).backward(dy)
+    torch.testing.assert_close(acc_g - seed_g, gr.grad, rtol=2e-4, atol=2e-5 * sc)
+    torch.testing.assert_close(acc_b - seed_b, br.grad, rtol=2e-4, atol=2e-5 * sc)
+    torch.testing.assert_close(dx1, xr.grad, rtol=2e-4, atol=2e-5)
+
+
 def test_relayout_kernel_builds_every_weight_layout_and_the_registry_keeps_them_current(amd_lib, monkeypatch):
     """cdx_relayout_f32 (ABI 15): every layout a training step needs of a conv / conv-transpose / linear weight -- whole parameters and a
     row slice of a packed one -- as ONE launch, bit-identical to the ATen permute / flip / stack expressions; and the registry around
