@@ -1649,13 +1649,16 @@ def test_groupnorm_backward_adds_its_gain_and_shift_sums_onto_the_callers_buffer
     dx1, none_g, none_b = blocks.groupnorm_backward(dy, x, gamma, beta, B, L, G, act="mish", param_grads=True, grads_out=(acc_g, acc_b))
     assert none_g is None and none_b is None and torch.equal(dx1, dx0)
     sc = float(dg0.abs().max()) + float(db0.abs().max())
-    torch.testing.assert_close(acc_g - seed_g, dg0, rtol=1e-5, atol=2e-6 * sc)
-    torch.testing.assert_close(acc_b - seed_b, db0, rtol=1e-5, atol=2e-6 * sc)
-    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
-    F.mish(F.group_norm(xr.view(B, L, C).permute(0, 2, 1), G, gr, br, 1e-5)).permute(0, 2, 1).reshape(B * L, C).backward(dy)
-    torch.testing.assert_close(acc_g - seed_g, gr.grad, rtol=2e-4, atol=2e-5 * sc)
-    torch.testing.assert_close(acc_b - seed_b, br.grad, rtol=2e-4, atol=2e-5 * sc)
-    torch.testing.assert_close(dx1, xr.grad, rtol=2e-4, atol=2e-5)
+    # (two orders of the same B * L terms per channel, and the difference acc - seed rounds at the accumulator's magnitude)
+    torch.testing.assert_close(acc_g - seed_g, dg0, rtol=1e-4, atol=3e-5 * sc + 1e-6)
+    torch.testing.assert_close(acc_b - seed_b, db0, rtol=1e-4, atol=3e-5 * sc + 1e-6)
+    # autograd ON THE CPU: ATen's group_norm backward on this ROCm build returns wrong gain / shift gradients from batch 255 on
+    # (tools/aten_groupnorm_backward_check.py, profiles/r04_aten_groupnorm_backward.txt)
+    xr, gr, br = (t.cpu().clone().requires_grad_(True) for t in (x, gamma, beta))
+    F.mish(F.group_norm(xr.view(B, L, C).permute(0, 2, 1), G, gr, br, 1e-5)).permute(0, 2, 1).reshape(B * L, C).backward(dy.cpu())
+    torch.testing.assert_close((acc_g - seed_g).cpu(), gr.grad, rtol=2e-4, atol=5e-5 * sc + 1e-6)
+    torch.testing.assert_close((acc_b - seed_b).cpu(), br.grad, rtol=2e-4, atol=5e-5 * sc + 1e-6)
+    torch.testing.assert_close(dx1.cpu(), xr.grad, rtol=2e-4, atol=2e-5)
 
 
 def test_relayout_kernel_builds_every_weight_layout_and_the_registry_keeps_them_current(amd_lib, monkeypatch):
