@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/cdx.h"
 
@@ -31,6 +32,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace {
 
 constexpr int WG_BK = 16;          // rows (contraction index) per LDS stage
+constexpr int WG_MIN_CHUNKS = 4;          // rows per split-K slice >= 16 x this (host heuristic)
 constexpr int WG_T = 64;           // output tile: 64 x 64 per workgroup, 4 wave64 each a 32 x 32 MFMA accumulator
 constexpr int WG_LD = WG_T + 4;
 
@@ -481,9 +483,11 @@ int cdx_conv_wgrad_f32(const cdx_wgrad_args* a, void* hip_stream) {
     const int n_chunks = (int)((R + WG_BK - 1) / WG_BK);
     const int tiles = ((g.ca + WG_T - 1) / WG_T) * ((g.cb + WG_T - 1) / WG_T) * g.taps;
     if (g.k_split == 0) {
-        // ~1024 workgroups on the 256 CUs, at least 4 chunks (64 rows) per slice
+        // ~1024 workgroups on the 256 CUs, at least WG_MIN_CHUNKS chunks of 16 rows per slice (every slice ends in one float atomic
+        // per output element: thin slices buy parallelism with contention).  CDX_WGRAD_MIN_CHUNKS: tuning hook.
+        static const int min_chunks = [] { const char* e = getenv("CDX_WGRAD_MIN_CHUNKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : WG_MIN_CHUNKS; }();
         g.k_split = (1024 + tiles - 1) / tiles;
-        if (g.k_split > n_chunks / 4) g.k_split = n_chunks / 4;
+        if (g.k_split > n_chunks / min_chunks) g.k_split = n_chunks / min_chunks;
         if (g.k_split < 1) g.k_split = 1;
     }
     if (g.k_split > 65535) g.k_split = 65535;
