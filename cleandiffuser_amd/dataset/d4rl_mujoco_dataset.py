@@ -259,3 +259,13 @@ class D4RLMuJoCoTDDataset(_ResidentMixin, BaseDataset):
     @staticmethod
     def _assemble(f):
         return {"obs": {"state": f["obs"]}, "next_obs": {"state": f["next_obs"]}, "act": f["act"], "rew": f["rew"], "tml": f["tml"]}
+
+
+def __getattr__(name):
+    """The multi-horizon / Decision-Veteran MuJoCo classes of the reference's d4rl_mujoco_dataset.py (:232-470) live in episode_store.py
+    (which builds on this module): resolved on first use, so that ``from ...d4rl_mujoco_dataset import MultiHorizonD4RLMuJoCoDataset``
+    keeps working."""
+    if name in ("DV_D4RLMuJoCoSeqDataset", "MultiHorizonD4RLMuJoCoDataset"):
+        from . import episode_store
+        return getattr(episode_store, name)
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
