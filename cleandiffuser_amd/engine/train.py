@@ -200,6 +200,17 @@ class _WeightPacks:
         self.sig = None
         self._listed, self._retired = [], []
 
+    # The registry names ADDRESSES (of this module's parameters and of its own buffers): a copy of the module (``deepcopy(model)`` for the
+    # EMA twin, a pickled module) starts with an empty one.
+    def __deepcopy__(self, memo):
+        return _WeightPacks()
+
+    def __getstate__(self):
+        return {}
+
+    def __setstate__(self, state):
+        self.__init__()
+
     def refresh(self, params):
         sig = tuple((p.data_ptr(), p._version) for p in params)
         dirty = self.in_table != len(self.entries)

@@ -155,3 +155,22 @@ def test_weight_layouts_are_refreshed_once_per_parameter_change(name, monkeypatc
         net.zero_grad(set_to_none=True)
         (fwd(net, args[0], *args[1:]) * wgt).sum().backward()
         assert counts["relayout"] == 0 and counts["aten_pack"] == seen[0][0]
+
+
+def test_a_copied_module_starts_with_an_empty_layout_registry():
+    """``deepcopy(model)`` (how every agent builds its EMA twin) and pickling must not carry the registry over: it names addresses of the
+    ORIGINAL module's parameters and buffers."""
+    import copy
+    import pickle
+    net, fwd, args = _case("janner")
+    net.train()
+    with emulated():
+        fwd(net, args[0], *args[1:]).sum().backward()
+        assert net._cdx_weight_packs.entries
+        twin = copy.deepcopy(net)
+        assert not twin._cdx_weight_packs.entries and twin._cdx_weight_packs.sig is None
+        thawed = pickle.loads(pickle.dumps(net))
+        assert not thawed._cdx_weight_packs.entries
+        y0, y1 = fwd(net, args[0], *args[1:]), fwd(twin, args[0], *args[1:])       # and the twin builds its own
+        assert torch.equal(y0, y1) and twin._cdx_weight_packs.entries
+        assert all(k not in net._cdx_weight_packs.entries for k in twin._cdx_weight_packs.entries)
