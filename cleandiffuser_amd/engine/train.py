@@ -384,28 +384,45 @@ class _ConvT(torch.autograd.Function):
 
 
 class _GroupNormMish(torch.autograd.Function):
-    """GroupNorm1d -> Mish on channel-last rows (reference utils/building_blocks.py:60-76 + nn.Mish)."""
+    """GroupNorm1d [-> Mish] on channel-last rows (reference utils/building_blocks.py:60-76 + nn.Mish); `act` "mish" (default) or "none"."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, batch, length, groups, eps):
+    def forward(ctx, x, gamma, beta, batch, length, groups, eps, act="mish"):
         x = x.contiguous()
-        y = blocks.groupnorm(x, gamma, beta, batch, length, groups, act="mish", eps=eps)
+        y = blocks.groupnorm(x, gamma, beta, batch, length, groups, act=act, eps=eps)
         ctx.save_for_backward(x, gamma, beta)
-        ctx.geom = (batch, length, groups, eps)
+        ctx.geom = (batch, length, groups, eps, act)
         ctx.params = (gamma, beta)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, gamma, beta = ctx.saved_tensors
-        batch, length, groups, eps = ctx.geom
+        batch, length, groups, eps, act = ctx.geom
         slots = (_grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])) if ctx.needs_input_grad[1] and ctx.needs_input_grad[2] else (None, None)
         slots = slots if slots[0] is not None and slots[1] is not None else None
-        dx, dg, db = blocks.groupnorm_backward(dy.contiguous(), x, gamma.detach(), beta.detach(), batch, length, groups, act="mish", eps=eps,
+        dx, dg, db = blocks.groupnorm_backward(dy.contiguous(), x, gamma.detach(), beta.detach(), batch, length, groups, act=act, eps=eps,
                                                param_grads=True, grads_out=slots)
         if slots is not None:
             _written(*slots)
-        return dx, dg, db, None, None, None, None
+        return dx, dg, db, None, None, None, None, None
+
+
+class _Act(torch.autograd.Function):
+    """An elementwise activation on its own (``cdx_act_f32`` / ``cdx_act_bwd_f32``): behind a GroupNorm whose fused epilogue does not
+    know it (the GELU of PearceMlp's FCBlock)."""
+
+    @staticmethod
+    def forward(ctx, z, act):
+        z = z.contiguous()
+        ctx.save_for_backward(z)
+        ctx.act = act
+        return blocks.activation(z, act)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (z,) = ctx.saved_tensors
+        return blocks.activation_backward(z, dy.contiguous(), ctx.act), None
 
 
 # --------------------------------------------------------------------------------------------------------------------- #
@@ -891,6 +908,74 @@ def dql_forward(net, x: torch.Tensor, noise: torch.Tensor, condition: Optional[t
     return _LinearMish.apply(h, net.final_layer.weight, net.final_layer.bias, False)
 
 
+def supports_pearce(net, x: torch.Tensor, condition=None) -> bool:
+    """PearceMlp (BASELINE config 1, the dbc_* pipelines) with autograd on, on a ROCm device."""
+    if not (enabled() and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and
+            type(net).__name__ == "PearceMlp"):
+        return False
+    if not _groupnorms_ok(net) or not _wants_grad(net, x, condition):
+        return False
+    return all(p.dtype == torch.float32 and p.is_cuda for p in net.parameters())
+
+
+def _fc_block(block, h):
+    """FCBlock (reference nn_diffusion/pearcemlp.py:10-23): Linear -> GroupNorm1d over the features of one row -> GELU(erf)."""
+    lin, gn, _ = block.model
+    z = _LinearAct.apply(h, lin.weight, lin.bias, None)
+    z = _GroupNormMish.apply(z, gn.weight, gn.bias, z.shape[0], 1, gn.num_groups, gn.eps, "none")
+    return _Act.apply(z, "gelu")
+
+
+@_with_weight_packs
+def pearce_forward(net, x, noise, condition):
+    """``PearceMlp.forward`` (reference nn_diffusion/pearcemlp.py:26-77) with autograd: every Linear, GroupNorm1d and GELU / LeakyReLU
+    on library nodes; the feature concats, the skip scaling and the residual adds stay ATen."""
+    if condition is None:
+        condition = torch.zeros(x.shape[0], net.To, net.emb_dim, device=x.device)
+    t = noise.unsqueeze(-1)
+    e0, _, e2 = net.act_emb
+    a = _LinearAct.apply(_LinearAct.apply(x, e0.weight, e0.bias, "leaky"), e2.weight, e2.bias, None)
+    h = _fc_block(net.fcs[0], torch.cat([a, net.map_noise(noise), torch.flatten(condition, 1)], -1))
+    for block in (net.fcs[1], net.fcs[2]):
+        skip = h / net.SKIP_SCALE
+        h = _fc_block(block, torch.cat([skip, x, t], -1)) + skip
+    last = net.fcs[3]
+    return _LinearAct.apply(torch.cat([h, x, t], -1), last.weight, last.bias, None)
+
+
+def supports_sfbc(net, x: torch.Tensor, condition=None) -> bool:
+    """SfBCUNet (the sfbc_* pipelines' residual MLP) with autograd on, on a ROCm device."""
+    if not (enabled() and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and
+            type(net).__name__ == "SfBCUNet") or not _wants_grad(net, x, condition):
+        return False
+    return all(p.dtype == torch.float32 and p.is_cuda for p in net.parameters())
+
+
+def _sfbc_block(rb, h, c):
+    """SiLU(L2(SiLU(L1 x) + Lc c)) + skip(x) (reference nn_diffusion/sfbc_unet.py:9-24)."""
+    l1, l2, lc = rb.linear1[0], rb.linear2[0], rb.linearc
+    z = _LinearAct.apply(h, l1.weight, l1.bias, "silu") + _LinearAct.apply(c, lc.weight, lc.bias, None)
+    z = _LinearAct.apply(z, l2.weight, l2.bias, "silu")
+    return z + (h if isinstance(rb.skip, nn.Identity) else _LinearAct.apply(h, rb.skip.weight, rb.skip.bias, None))
+
+
+@_with_weight_packs
+def sfbc_forward(net, x, noise, condition):
+    """``SfBCUNet.forward`` (reference nn_diffusion/sfbc_unet.py:60-82) with autograd, every Linear (+ SiLU) a library node."""
+    t0, _, t2 = net.t_layer
+    c = _LinearAct.apply(_LinearAct.apply(net.map_noise(noise).contiguous(), t0.weight, t0.bias, "silu"), t2.weight, t2.bias, None)
+    if condition is not None:                              # (the reference adds zeros otherwise: the same numbers)
+        c = c + condition
+    kept = []
+    for block in net.down_blocks:
+        x = _sfbc_block(block, x, c)
+        kept.append(x)
+    x = _sfbc_block(net.mid_block, x, c)
+    for block in net.up_blocks:
+        x = _sfbc_block(block, torch.cat([x, kept.pop()], dim=-1), c)
+    return _LinearAct.apply(x, net.out_layer.weight, net.out_layer.bias, None)
+
+
 # --------------------------------------------------------------------------------------------------------------------- #
 # forward + backward of update() as ONE HIP graph (the default where a probe finds the step capturable; CDX_TRAIN_GRAPH=0 / 1)       #
 # --------------------------------------------------------------------------------------------------------------------- #
@@ -991,12 +1076,13 @@ class GraphedStep:
 def _native_training_net(net, x0, condition) -> bool:
     with torch.enable_grad():
         return (supports(net, x0, condition) or supports_chi(net, x0, condition) or supports_dit(net, x0, condition) or
-                supports_chitf(net, x0, condition) or supports_idql(net, x0, condition) or supports_mlp(net, x0, condition))
+                supports_chitf(net, x0, condition) or supports_idql(net, x0, condition) or supports_mlp(net, x0, condition) or
+                supports_pearce(net, x0, condition) or supports_sfbc(net, x0, condition))
 
 
 def graphed_step(agent, x0, condition, kwargs) -> Optional[GraphedStep]:
     """The cached GraphedStep of (agent, batch shape), or None (the eager path).  CDX_TRAIN_GRAPH: "auto" (default) -- agents whose
-    denoiser the native training path serves (JannerUNet1d, ChiUNet1d, DiT1d, ChiTransformer, IDQLMlp, DQLMlp / DVInvMlp on a ROCm device), no extra
+    denoiser the native training path serves (JannerUNet1d, ChiUNet1d, DiT1d, ChiTransformer, IDQLMlp, PearceMlp, SfBCUNet, DQLMlp / DVInvMlp on a ROCm device), no extra
     loss arguments, and whose first step passes the capturability probe (GraphedStep); "1": no probe; "0": never."""
     mode = os.environ.get("CDX_TRAIN_GRAPH", "auto")
     if mode == "0" or kwargs or not torch.is_tensor(x0) or not x0.is_cuda or not torch.is_grad_enabled() or \

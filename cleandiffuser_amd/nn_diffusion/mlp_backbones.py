@@ -56,6 +56,9 @@ class PearceMlp(BaseNNDiffusion):
 
     def forward(self, x: torch.Tensor, noise: torch.Tensor, condition: Optional[torch.Tensor] = None):
         """x (b, act_dim), noise (b,), condition (b, To, emb_dim) | (b, To*emb_dim) | None -> (b, act_dim)."""
+        from ..engine import train
+        if train.supports_pearce(self, x, condition):
+            return train.pearce_forward(self, x, noise, condition)          # autograd on, ROCm device: loss() / update()
         if condition is None:
             condition = torch.zeros(x.shape[0], self.To, self.emb_dim).to(x.device)
         t = noise.unsqueeze(-1)

@@ -43,6 +43,9 @@ class SfBCUNet(BaseNNDiffusion):
 
     def forward(self, x: torch.Tensor, noise: torch.Tensor, condition: Optional[torch.Tensor] = None):
         """x (b, [horizon,] act_dim), noise (b,), condition (b, emb_dim)|None(=zeros) -> like x."""
+        from ..engine import train
+        if train.supports_sfbc(self, x, condition):
+            return train.sfbc_forward(self, x, noise, condition)            # autograd on, ROCm device: loss() / update()
         c = self.t_layer(self.map_noise(noise))
         c = c + (condition if condition is not None else torch.zeros_like(c))
         kept = []

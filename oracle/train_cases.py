@@ -178,11 +178,23 @@ def chitf(d_model: int, heads: int, layers: int, cond_layers: int, ta: int, to: 
     return run
 
 
+def sfbc():
+    """SfBCUNet under ContinuousDiffusionSDE with the state as condition -- the behaviour-policy training step of SfBC (reference
+    pipelines/sfbc_d4rl_mujoco.py:61-70, nn_diffusion/sfbc_unet.py:9-82, diffusionsde.py:94-141)."""
+    def run(lib, kind, device):
+        net = load_synth(lib.SfBCUNet(4, emb_dim=32, hidden_dims=[64, 32, 16]), 70)
+        cond = load_synth(lib.MLPCondition(9, 32, [32], torch.nn.SiLU(), dropout=0.0), 71)
+        agent = lib.ContinuousDiffusionSDE(net, cond, predict_noise=True, noise_schedule="linear", grad_clip_norm=1.0, device=device)
+        g = torch.Generator().manual_seed(9)
+        return _record(agent, torch.randn(8, 4, generator=g), torch.randn(8, 9, generator=g), device)
+    return run
+
+
 HEAVY = {"chiunet_cfg3", "dit_cfg4"}          # minutes of CPU work: fixture from the real reference, checked on the device only
 
 SCENARIOS: Dict[str, Callable] = {
     "chiunet_ddpm": chiunet(32, 5), "chiunet_cfg3": chiunet(256, 4), "dit_small": dit(64, 4, 16, 5), "dit_cfg4": dit(320, 10, 64, 4),
-    "chitf_small": chitf(64, 4, 2, 2, 6, 3, 5), "chitf_pusht": chitf(256, 4, 8, 0, 10, 2, 6),
+    "chitf_small": chitf(64, 4, 2, 2, 6, 3, 5), "chitf_pusht": chitf(256, 4, 8, 0, 10, 2, 6), "sfbc_continuous": sfbc(),
     "discrete_eps": discrete(True), "discrete_x0": discrete(False), "continuous_eps": continuous(),
     "edm_conditional": edm_conditional(0.1), "edm_conditional_nodrop": edm_conditional(0.0), "legacy_ddpm": legacy_ddpm(), "weighted_regression": weighted_regression(),
 }

@@ -1179,7 +1179,7 @@ def test_config4_with_resolving_power_against_the_float64_yardstick(name, amd_li
 
 
 @pytest.mark.parametrize("name", ["discrete_eps", "discrete_x0", "continuous_eps", "edm_conditional_nodrop", "legacy_ddpm",
-                                  "weighted_regression", "chiunet_ddpm", "chiunet_cfg3", "dit_small", "dit_cfg4", "chitf_small", "chitf_pusht"])      # ("edm_conditional": nn.Dropout draws inside ATen, CPU-only)
+                                  "weighted_regression", "chiunet_ddpm", "chiunet_cfg3", "dit_small", "dit_cfg4", "chitf_small", "chitf_pusht", "sfbc_continuous"])      # ("edm_conditional": nn.Dropout draws inside ATen, CPU-only)
 def test_loss_and_update_match_reference_fixture(name):
     """loss() / update() on the ROCm device against what the REAL reference computed on CPU from the same seeded
     timestep / noise / label-dropout draws (oracle/train_cases.py; the CPU generator's draws are replayed on the device): loss value,
@@ -1581,6 +1581,55 @@ def test_native_chitransformer_training_graph_matches_autograd(shape, amd_lib, m
         err = float((gp1[n] - gp0[n]).abs().max())
         assert err <= 3e-4 * sc, f"{n}: |d| = {err:.3e} at scale {sc:.3e}"
         assert gp1[n].shape == gp0[n].shape
+
+
+@pytest.mark.parametrize("which", ["pearce_cfg1", "pearce_small", "sfbc"])
+def test_native_pearce_and_sfbc_training_graphs_match_autograd(which, amd_lib, monkeypatch):
+    """The last two denoisers the reference's pipelines train (dbc_*: PearceMlp = BASELINE config 1; sfbc_*: SfBCUNet) with autograd ON:
+    Linear / GroupNorm1d / GELU / LeakyReLU / SiLU on the library's nodes (engine/train.py:pearce_forward, sfbc_forward; reference
+    nn_diffusion/pearcemlp.py:10-77, sfbc_unet.py:9-82) -- output, input gradient and every parameter gradient against torch.autograd
+    of the module's own forward on the same device; update() of either takes the HIP-graph step."""
+    from cleandiffuser_amd.engine import train
+    from cleandiffuser_amd.utils import load_synth
+    g = torch.Generator().manual_seed(12)
+    if which.startswith("pearce"):
+        act, To, emb, hid, B = (6, 1, 128, 512, 64) if which == "pearce_cfg1" else (3, 2, 32, 64, 7)
+        net = load_synth(amd_lib.PearceMlp(act, To=To, emb_dim=emb, hidden_dim=hid), 15).to(DEV)
+        x, t, cond = torch.randn(B, act, generator=g), torch.randint(0, 100, (B,), generator=g), torch.randn(B, To, emb, generator=g)
+        sup = train.supports_pearce
+    else:
+        net = load_synth(amd_lib.SfBCUNet(6, emb_dim=64), 16).to(DEV)
+        x, t, cond, sup = torch.randn(33, 6, generator=g), torch.rand(33, generator=g), torch.randn(33, 64, generator=g), train.supports_sfbc
+    net.train()
+    x, t, cond = x.to(DEV).requires_grad_(True), t.to(DEV), cond.to(DEV)
+    wgt = torch.randn(*x.shape, generator=g).to(DEV)
+
+    def run(native):
+        monkeypatch.setenv("CDX_TRAIN_NATIVE", "1" if native else "0")
+        net.zero_grad(set_to_none=True)
+        x.grad = None
+        assert sup(net, x, cond) == native
+        y = net(x, t, cond)
+        ((y * wgt).sum() / x.shape[0]).backward()
+        return y.detach().clone(), x.grad.clone(), {n: (None if p.grad is None else p.grad.clone()) for n, p in net.named_parameters()}
+    y1, gx1, gp1 = run(True)
+    y0, gx0, gp0 = run(False)
+    np.testing.assert_allclose(y1.cpu().numpy(), y0.cpu().numpy(), rtol=1e-4, atol=1e-4 * max(1.0, float(y0.abs().max())))
+    np.testing.assert_allclose(gx1.cpu().numpy(), gx0.cpu().numpy(), rtol=1e-4, atol=2e-4 * float(gx0.abs().max()))
+    for n in gp0:
+        if gp0[n] is None:
+            assert gp1[n] is None, n
+            continue
+        sc = float(gp0[n].abs().max()) + 1e-12
+        assert float((gp1[n] - gp0[n]).abs().max()) <= 3e-4 * sc, n
+    monkeypatch.setenv("CDX_TRAIN_NATIVE", "1")
+    if which.startswith("pearce"):
+        agent = amd_lib.DDPM(net, amd_lib.IdentityCondition(dropout=0.0), diffusion_steps=20, predict_noise=True, device=DEV)
+    else:
+        agent = amd_lib.ContinuousDiffusionSDE(net, amd_lib.IdentityCondition(dropout=0.0), predict_noise=True, noise_schedule="linear", device=DEV)
+    agent.train()
+    logs = [agent.update(x.detach(), cond)["loss"] for _ in range(3)]
+    assert np.isfinite(logs).all() and any(isinstance(v, train.GraphedStep) for v in agent.__dict__.get("_cdx_graphed", {}).values())
 
 
 def test_chitransformer_update_with_the_pipelines_dropout_runs_native_and_seeded(amd_lib, monkeypatch):

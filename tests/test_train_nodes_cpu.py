@@ -1,6 +1,6 @@
 """The host logic of the training path (cleandiffuser_amd/engine/train.py) on the CPU tier: with the kernel wrappers replaced by torch
 expressions of their contracts (tests/torch_blocks.py), every native training forward -- JannerUNet1d, ChiUNet1d, DiT1d, IDQLMlp,
-ChiTransformer, DQLMlp -- must give torch.autograd's output and gradients of the module's own PyTorch forward; gradients routed
+ChiTransformer, DQLMlp, PearceMlp, SfBCUNet -- must give torch.autograd's output and gradients of the module's own PyTorch forward; gradients routed
 straight into ``.grad`` (grads_in_place) must equal autograd's accumulation; the weight-layout registry must stay current across
 optimiser steps with one refresh per parameter change.  (The kernels themselves: tests/test_gpu_parity.py on the MI355X.)"""
 import pytest
@@ -35,6 +35,12 @@ def _case(name):
     if name == "dql":
         net = load_synth(N.DQLMlp(11, 6, emb_dim=16), 9)
         return net, train.dql_forward, (torch.randn(5, 6, generator=g), torch.randint(0, 10, (5,), generator=g), torch.randn(5, 11, generator=g))
+    if name == "pearce":
+        net = load_synth(N.PearceMlp(6, To=2, emb_dim=32, hidden_dim=64), 10)
+        return net, train.pearce_forward, (torch.randn(7, 6, generator=g), torch.randint(0, 20, (7,), generator=g), torch.randn(7, 2, 32, generator=g))
+    if name == "sfbc":
+        net = load_synth(N.SfBCUNet(5, emb_dim=16, hidden_dims=[64, 32, 16]), 11)
+        return net, train.sfbc_forward, (torch.randn(6, 5, generator=g), torch.rand(6, generator=g), torch.randn(6, 16, generator=g))
     raise KeyError(name)
 
 
@@ -61,7 +67,7 @@ def _close(got, want, what, tol=2e-5):
     assert float((got - want).abs().max()) <= tol * sc + 1e-7, (what, float((got - want).abs().max()), sc)
 
 
-CASES = ["janner", "janner_cond", "chiunet", "dit", "idql", "chitf", "dql"]
+CASES = ["janner", "janner_cond", "chiunet", "dit", "idql", "chitf", "dql", "pearce", "sfbc"]
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -86,7 +92,7 @@ def test_native_training_forward_is_the_modules_autograd_graph(name):
                 _close(g, gp0[n], f"{name} (in place {in_place}): {n}")
 
 
-@pytest.mark.parametrize("name", ["janner", "chiunet", "chitf"])
+@pytest.mark.parametrize("name", ["janner", "chiunet", "chitf", "pearce"])
 def test_in_place_gradient_sums_accumulate_and_leave_hooked_or_frozen_parameters_to_autograd(name):
     net, fwd, args = _case(name)
     net.train()

@@ -12,7 +12,8 @@ import torch.nn.functional as F
 
 from cleandiffuser_amd.engine import blocks, train
 
-ACTS = {"mish": F.mish, "gelu": F.gelu, "gelu_tanh": lambda z: F.gelu(z, approximate="tanh"), "none": lambda z: z}
+ACTS = {"mish": F.mish, "gelu": F.gelu, "gelu_tanh": lambda z: F.gelu(z, approximate="tanh"), "none": lambda z: z, "silu": F.silu,
+        "leaky": F.leaky_relu}
 
 
 def _vjp(fn, inputs, dy):

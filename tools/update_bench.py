@@ -1,6 +1,6 @@
 """update() of BASELINE configs 2 / 3 / 4 / 5 (row f4): one training step -- loss forward + backward, gradient-norm clip, AdamW, EMA -- on
 the library's nodes (default) against the reference's ATen autograd graph (CDX_TRAIN_NATIVE=0), same box, same batch.
-Usage (GPU box): python tools/update_bench.py [cfg2 cfg3 cfg4 cfg5 chitf]   -> one line per (config, mode): ms per update()."""
+Usage (GPU box): python tools/update_bench.py [cfg1 cfg2 cfg3 cfg4 cfg5 chitf sfbc]   -> one line per (config, mode): ms per update()."""
 import os
 import sys
 import time
@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cleandiffuser_amd.diffusion import ContinuousDiffusionSDE, ContinuousEDM, DiscreteDiffusionSDE  # noqa: E402
 from cleandiffuser_amd.diffusion.ddpm import DDPM  # noqa: E402
 from cleandiffuser_amd.nn_condition import IdentityCondition, MLPCondition  # noqa: E402
-from cleandiffuser_amd.nn_diffusion import ChiTransformer, ChiUNet1d, DiT1d, IDQLMlp, JannerUNet1d  # noqa: E402
+from cleandiffuser_amd.nn_diffusion import ChiTransformer, ChiUNet1d, DiT1d, IDQLMlp, JannerUNet1d, PearceMlp, SfBCUNet  # noqa: E402
 from cleandiffuser_amd.utils import load_synth  # noqa: E402
 
 DEV = torch.device("cuda", 0)
@@ -33,6 +33,14 @@ def build(name):
         cnd = load_synth(MLPCondition(1, 128, [128], torch.nn.SiLU(), dropout=0.25), 2)
         agent = ContinuousDiffusionSDE(net, cnd, predict_noise=True, noise_schedule="linear", grad_clip_norm=1.0, device=DEV)
         x0, cond, what = torch.randn(64, 64, 29, device=DEV), torch.rand(64, 1, device=DEV), "config 4: DiT1d d=320 h=10 depth=2, 64 tokens, batch 64"
+    elif name == "cfg1":
+        net = load_synth(PearceMlp(6, To=1, emb_dim=128, hidden_dim=512))
+        agent = DDPM(net, IdentityCondition(dropout=0.0), diffusion_steps=100, grad_clip_norm=1.0, device=DEV)
+        x0, cond, what = torch.randn(256, 6, device=DEV).clamp(-1, 1), torch.randn(256, 1, 128, device=DEV), "config 1: PearceMlp act=6, hidden 512, batch 256"
+    elif name == "sfbc":
+        net = load_synth(SfBCUNet(6, emb_dim=64))
+        agent = ContinuousDiffusionSDE(net, IdentityCondition(dropout=0.0), predict_noise=True, noise_schedule="linear", grad_clip_norm=1.0, device=DEV)
+        x0, cond, what = torch.randn(256, 6, device=DEV), torch.randn(256, 64, device=DEV), "sfbc: SfBCUNet act=6 (512, 256, 128), batch 256"
     elif name == "chitf":
         net = load_synth(ChiTransformer(2, 5, 10, 2, d_model=256, nhead=4, num_layers=8, p_drop_attn=0.3))
         agent = DDPM(net, IdentityCondition(dropout=0.0), diffusion_steps=50, grad_clip_norm=1.0, device=DEV)
@@ -47,7 +55,7 @@ def build(name):
 
 
 def main():
-    for name in (sys.argv[1:] or ["cfg2", "cfg3", "cfg4", "cfg5", "chitf"]):
+    for name in (sys.argv[1:] or ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "chitf", "sfbc"]):
         res = {}
         modes = ("graph",) if os.environ.get("UPDATE_BENCH_GRAPH_ONLY") else ("graph", "graph_nosplitk", "native", "aten")
         for mode in modes:
