@@ -282,14 +282,19 @@ def relayout_table(jobs, device):
         assert src.dtype == dst.dtype == torch.float32 and dst.is_contiguous() and dst.numel() == n[0] * n[1] * n[2]
         arr[j] = CdxRelayoutJob(src=src.data_ptr() + 4 * off, dst=dst.data_ptr(), n0=n[0], n1=n[1], n2=n[2], s0=st[0], s1=st[1], s2=st[2])
         chunks += [(j, c) for c in range(-(-dst.numel() // RELAYOUT_CHUNK))]
-    raw = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(device)
-    ck = torch.tensor(chunks, dtype=torch.int32).reshape(-1, 2).to(device)
-    return raw, ck, len(chunks)
+    # pinned staging + asynchronous copies: the upload must not synchronise the stream (it may happen inside the capturability probe of
+    # a training step, which treats every synchronising call as "this step cannot be captured"); the staging tensors stay alive with
+    # the table
+    host = [torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()), torch.tensor(chunks, dtype=torch.int32).reshape(-1, 2)]
+    if torch.device(device).type == "cuda":
+        host = [h.pin_memory() for h in host]
+    raw, ck = (h.to(device, non_blocking=True) for h in host)
+    return raw, ck, len(chunks), host
 
 
 def relayout(table):
     """ONE launch: every job of a ``relayout_table``."""
-    raw, ck, n = table
+    raw, ck, n = table[:3]
     _check(_lib().cdx_relayout_f32(raw.data_ptr(), ck.data_ptr(), n, _stream_ptr(raw.device)), "cdx_relayout_f32")
 
 
