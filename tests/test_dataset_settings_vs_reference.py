@@ -149,5 +149,18 @@ def test_random_dataset_settings_against_the_imported_reference(seed):
                 _same(got.indices, np.array(want.indices, dtype=np.int64).reshape(-1, 3), tag + ": item table")
         for i, w in zip(probe, want_items):
             _cmp(_flat(got[i]), w, f"{tag}: item {i}")
+        # the resident loader's batch (host tensors here; one gather launch on the device) = the reference's collated items
+        if probe:
+            from torch.utils.data import default_collate
+            ld = got.loader(len(probe), shuffle=False, drop_last=False, device="cpu")
+            idx = torch.tensor(probe)
+            if group == "multi":
+                batch = ld.batch_of(idx)
+            elif group == "td":
+                batch = ld.batch_of(idx.int())
+            else:
+                T = got.seq_obs.shape[1]
+                batch = ld.batch_of(torch.from_numpy((got.indices[probe, 0] * T + got.indices[probe, 1]).astype(np.int32)))
+            _cmp(_flat(batch), _flat(default_collate([want[i] for i in probe])), f"{tag}: loader batch")
         outcomes.append("ok")
     assert outcomes.count("ok") >= 2, outcomes
