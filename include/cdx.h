@@ -291,9 +291,10 @@ typedef struct cdx_gn_args {
      * (dz = d loss / d y * act'): the column sums of these over the batch are d loss / d gamma and d loss / d beta.  Both or neither;
      * needs C / G channels per group to be a power of two <= 256. */
     float *dgamma_part, *dbeta_part;
-    /* backward only (ABI 15): optional (C) accumulators -- every (sample, group) ADDS its sums of dz * x_hat / dz to them with float
-     * atomics: d loss / d gamma and d loss / d beta themselves, on top of what the buffers held (a parameter's .grad), without the
-     * (B, C) staging and its two column-sum launches.  Both or neither, same group-width rule; exclusive with the *_part pair. */
+    /* backward only (ABI 15): optional (C) accumulators -- the kernel ADDS the sums of dz * x_hat / dz to them with float atomics (one
+     * per channel and workgroup: a workgroup takes four samples of one group and combines them in LDS first): d loss / d gamma and
+     * d loss / d beta themselves, on top of what the buffers held (a parameter's .grad), without the (B, C) staging and its two
+     * column-sum launches.  Both or neither, same group-width rule; exclusive with the *_part pair. */
     float *dgamma_sum, *dbeta_sum;
 } cdx_gn_args;
 int cdx_groupnorm_f32(const cdx_gn_args* args, void* hip_stream);
