@@ -201,9 +201,24 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #endif
 #define CDX2_N_CUS 256                            /* MI355X: 8 XCDs x 32 CUs */
 #define CDX2_GETREG_XCC_ID ((3 << 11) | 20)      /* s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4): the XCD this wave runs on, 0-7 */
+#ifndef CDX2_XCHG_FAST
+#define CDX2_XCHG_FAST 1            // 0: grouped ops exchange through split_exchange (epilogue -> barrier -> publish -> collect, rounds 4-5)
+#endif
+#ifndef CDX2_XCHG_NOWAIT
+#define CDX2_XCHG_NOWAIT 0          // 1 (diagnostic, WRONG results): grouped ops do not collect at all -- what a fully hidden exchange would cost
+#endif
+#ifndef CDX2_PROF_FETCH
+#define CDX2_PROF_FETCH 0           // diagnostic builds: the PROF kernels' stamps 4-6 time the parts of fetch_next (1) / of the exchange (2) instead of the K loop's
+#endif
 #ifndef CDX2_PIPE_PARAMS
 #define CDX2_PIPE_PARAMS 1          // 0: fetch an op's epilogue parameters and the next descriptor at the op's start (round-2 order)
 #endif
+#ifndef CDX2_MUL24
+#define CDX2_MUL24 1                // 0: plain 32-bit multiplies in the per-op address arithmetic (rounds 2-5)
+#endif
+// Per-lane products of small numbers (LDS offsets, positions x strides: far below 2^23): v_mul_i32_i24 / v_mad_i32_i24 run at full
+// rate, v_mul_lo_u32 / v_mad_u64_u32 at a quarter of it -- on the serial per-op path every instruction is ~7 cycles x 40 ops x 20 steps.
+static __device__ __forceinline__ int mul24i(int a, int b) { return CDX2_MUL24 ? __mul24(a, b) : a * b; }
 static __device__ __forceinline__ int wave_of(int tid) { return __builtin_amdgcn_readfirstlane(tid >> 6); }
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wold-style-cast"
@@ -256,13 +271,14 @@ __device__ __forceinline__ void conv_kloop(const Geom& g, const float* __restric
         for (int nt = 0; nt < NT; ++nt) {
             mcol[nt] = it.col0 + nt * M::COLS + M::col(lane);
             const bool valid = mcol[nt] < g.l_cols;
-            int mrow = mcol[nt] * g.cstride;
-            if (GRP && g.grows) mrow = (mcol[nt] >> g.gsh) * g.grows + (mcol[nt] & ((1 << g.gsh) - 1)) * g.cstride;
+            // (per-lane products of small numbers: v_mul_i32_i24 is full rate, v_mul_lo_u32 a quarter of it)
+            int mrow = mul24i(mcol[nt], g.cstride);
+            if (GRP && g.grows) mrow = mul24i(mcol[nt] >> g.gsh, g.grows) + mul24i(mcol[nt] & ((1 << g.gsh) - 1), g.cstride);
             const int row = valid ? mrow - it.pad + CDX2_HALO2 + it.tap : 0;
             cur[nt] = it.src + __mul24(row, it.sstr) + M::koff(lane) + cc * M::KSTEP;
             tstep[nt] = (valid ? it.sstr : 0) - ccn * M::KSTEP;
         }
-        if (PROF && prof && item == 0) { asm volatile("" ::"s"(nq), "v"(cur[0])); stamp(prof + 4, ptid); }
+        if (PROF && !CDX2_PROF_FETCH && prof && item == 0) { asm volatile("" ::"s"(nq), "v"(cur[0])); stamp(prof + 4, ptid); }
         f32x4 acc[T][NT][NA];
 #pragma unroll
         for (int t = 0; t < T; ++t)
@@ -322,7 +338,7 @@ __device__ __forceinline__ void conv_kloop(const Geom& g, const float* __restric
                 }
             }
         }
-        if (PROF && prof && item == 0) { asm volatile("" ::"v"(wr[0][0]), "v"(bq[0][0][0][0])); stamp(prof + 5, ptid); }
+        if (PROF && !CDX2_PROF_FETCH && prof && item == 0) { asm volatile("" ::"v"(wr[0][0]), "v"(bq[0][0][0][0])); stamp(prof + 5, ptid); }
         // two waves per SIMD: the arbiter favours the older wave (0-3), which then finishes its K loop well before its
         // SIMD-mate and leaves it running alone at the single-wave rate; raising the younger wave's priority evens them out
 
@@ -418,18 +434,18 @@ __device__ __forceinline__ void conv_kloop(const Geom& g, const float* __restric
             }
         }
         if (NWV == 8) __builtin_amdgcn_s_setprio(0);
-        if (PROF && prof && item == 0) { asm volatile("" ::"v"(acc[0][0][0][0]), "v"(acc[0][0][1][0])); stamp(prof + 6, ptid); }
+        if (PROF && !CDX2_PROF_FETCH && prof && item == 0) { asm volatile("" ::"v"(acc[0][0][0][0]), "v"(acc[0][0][1][0])); stamp(prof + 6, ptid); }
         // D fragment: 4 consecutive rows (channels) of one column -> stage[k slice][output position][row tile + rows]
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 if (mcol[nt] < g.l_cols) {
-                    const int n = mcol[nt] * g.ostride + it.ooff;
+                    const int n = mul24i(mcol[nt], g.ostride) + it.ooff;
                     f32x4 dd = acc[t][nt][0];
                     if (NA == 2) dd += acc[t][nt][NA - 1];
                     if (NA == 4) dd = (acc[t][nt][0] + acc[t][nt][1]) + (acc[t][nt][NA / 2] + acc[t][nt][NA - 1]);
-                    *reinterpret_cast<f32x4*>(lds + t * tf + g.stage + it.part + n * g.sstride + M::drow(lane)) = dd;
+                    *reinterpret_cast<f32x4*>(lds + t * tf + g.stage + it.part + mul24i(n, g.sstride) + M::drow(lane)) = dd;
                 }
             }
     }
@@ -484,9 +500,12 @@ __device__ __forceinline__ void half_sum2(float& a, float& b, int lane) {
 // channels c..c+3 of position pos0 + k * pstep.  NK = items per lane (compile-time so the values stay in registers).
 // GroupNorm statistics in ONE cross-lane round: sums of (x - s) and (x - s)^2 with s = the group's first element (no E[x^2] -
 // E[x]^2 cancellation; the second dependent reduction of a two-pass scheme is ~150 cycles of pure latency per op).
-template <int NK, bool BWD, bool COND = false, bool MLP = false>
+// Grouped ops, fast exchange: the epilogue thread that produced an item also publishes it -- straight from its registers into the
+// group's tile in L2 (granule format of split_exchange), tile position `vbase + pos`.
+struct Pub { float* tile; float tag; int vbase, coutp; bool on; };
+template <int NK, bool BWD, bool COND = false, bool MLP = false, bool PUBLISH = false>
 __device__ __forceinline__ void epilogue(float* __restrict__ tl, const EpiParams& P, const EpiDesc& e, int stage, int c, int pos0,
-                                         int pstep, int li, int nv, int lane, int grp, float* __restrict__ ws) {
+                                         int pstep, int li, int nv, int lane, int grp, float* __restrict__ ws, const Pub* pub = nullptr) {
     f32x4 v[NK];
     bool ok[NK];
 #pragma unroll
@@ -496,7 +515,7 @@ __device__ __forceinline__ void epilogue(float* __restrict__ tl, const EpiParams
         // bias + partial 0 + partial 1 + ... in this order; the reads go out four / two at a time so that their ~130-cycle
         // latencies overlap instead of adding up (8 waves: up to 8 K slices per tile)
         f32x4 acc = P.bi;
-        const float* sp = tl + stage + pos * e.sstride + c;
+        const float* sp = tl + stage + mul24i(pos, e.sstride) + c;
         const int kstep = e.l_out * e.sstride;
         int ks = 0;
         for (; ks + 4 <= e.ksplit; ks += 4, sp += 4 * kstep) {
@@ -554,7 +573,7 @@ __device__ __forceinline__ void epilogue(float* __restrict__ tl, const EpiParams
             const f32x4 xh = (v[k] - mean) * rstd;
             if (keep && ok[k] && c < e.c_out) {
                 // (F2_SAVE_GLOBAL: the trajectory's block of the launch workspace instead of LDS -- two-trajectory guided programs)
-                float* sv = ((e.flags & CDX2_F2_SAVE_GLOBAL) ? ws : tl) + e.save + (pos0 + k * pstep) * e.savestr + c;
+                float* sv = ((e.flags & CDX2_F2_SAVE_GLOBAL) ? ws : tl) + e.save + mul24i(pos0 + k * pstep, e.savestr) + c;
                 *reinterpret_cast<f32x4*>(sv) = xh;
             }
             const f32x4 y = xh * P.ga + P.be;
@@ -580,16 +599,21 @@ __device__ __forceinline__ void epilogue(float* __restrict__ tl, const EpiParams
             // the ResidualBlock's 1x1 skip conv (reference jannerunet.py:58, :69) was computed by other waves of this op: bias + its
             // partial tiles, added after the norm / activation
             f32x4 pv = P.pb;
-            const float* pp = tl + stage + (e.ksplit * e.l_out + pos) * e.sstride + c;
+            const float* pp = tl + stage + mul24i(e.ksplit * e.l_out + pos, e.sstride) + c;
             for (int j = 0; j < e.kpost; ++j) pv += *reinterpret_cast<const f32x4*>(pp + j * e.l_out * e.sstride);
             y += pv;
         }
-        if (e.flags & CDX2_F2_RES) y += *reinterpret_cast<const f32x4*>(tl + e.res + (pos + CDX2_HALO2) * e.rstride + c);
+        if (e.flags & CDX2_F2_RES) y += *reinterpret_cast<const f32x4*>(tl + e.res + mul24i(pos + CDX2_HALO2, e.rstride) + c);
         if (MLP && (e.flags & CDX2_F2_OUT_DIV)) {             // PearceMlp's h / 1.414 (reference pearcemlp.py:64), a true division
 #pragma unroll
             for (int j = 0; j < 4; ++j) y[j] = __fdiv_rn(y[j], e.odiv);
         }
-        float* o = tl + e.dst + (pos + CDX2_HALO2) * e.dstride + c;
+        if (PUBLISH && pub->on) {
+            f32x4* gq = reinterpret_cast<f32x4*>(pub->tile + (size_t)(mul24i(pub->vbase + pos, pub->coutp) + c) * 2);
+            gq[0] = (f32x4){y[0], pub->tag, y[1], pub->tag};
+            gq[1] = (f32x4){y[2], pub->tag, y[3], pub->tag};
+        }
+        float* o = tl + e.dst + mul24i(pos + CDX2_HALO2, e.dstride) + c;
         if (c + 3 < e.c_out) {
             *reinterpret_cast<f32x4*>(o) = y;
         } else {
@@ -621,7 +645,7 @@ __device__ __forceinline__ void epilogue_bwd(float* __restrict__ tl, const EpiPa
     for (int k = 0; k < NK; ++k) {      // saved x_hat first: from the global workspace this is the longest latency of the epilogue
         const bool okk = li + 32 * k < nv;
         const int pos = okk ? pos0 + k * pstep : 0;
-        xh_pre[k] = c < e.c_out ? *reinterpret_cast<const f32x4*>(svb + pos * e.savestr + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        xh_pre[k] = c < e.c_out ? *reinterpret_cast<const f32x4*>(svb + mul24i(pos, e.savestr) + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     f32x4 gx[NK], xh[NK];
     bool ok[NK];
@@ -631,7 +655,7 @@ __device__ __forceinline__ void epilogue_bwd(float* __restrict__ tl, const EpiPa
         ok[k] = li + 32 * k < nv;
         const int pos = ok[k] ? pos0 + k * pstep : 0;
         f32x4 acc = P.bi;
-        const float* sp = tl + stage + pos * e.sstride + c;
+        const float* sp = tl + stage + mul24i(pos, e.sstride) + c;
         const int kstep = e.l_out * e.sstride;
         int ks = 0;
         for (; ks + 4 <= e.ksplit; ks += 4, sp += 4 * kstep) {      // same 4 / 2 / 1 cascade as the forward epilogue
@@ -645,8 +669,8 @@ __device__ __forceinline__ void epilogue_bwd(float* __restrict__ tl, const EpiPa
             ks += 2; sp += 2 * kstep;
         }
         if (ks < e.ksplit) acc += *reinterpret_cast<const f32x4*>(sp);
-        if (e.flags & CDX2_F2_RES) acc += *reinterpret_cast<const f32x4*>(tl + e.res + (pos + CDX2_HALO2) * e.rstride + c);
-        if ((e.flags & CDX2_F2_DUAL) && ok[k]) *reinterpret_cast<f32x4*>(tl + e.dst2 + (pos + CDX2_HALO2) * e.d2stride + c) = acc;
+        if (e.flags & CDX2_F2_RES) acc += *reinterpret_cast<const f32x4*>(tl + e.res + mul24i(pos + CDX2_HALO2, e.rstride) + c);
+        if ((e.flags & CDX2_F2_DUAL) && ok[k]) *reinterpret_cast<f32x4*>(tl + e.dst2 + mul24i(pos + CDX2_HALO2, e.d2stride) + c) = acc;
         // (lane groups past C_out -- nets with fewer than 8 x 4 channels -- have nothing saved: zeros, never stored)
         xh[k] = xh_pre[k];
         const f32x4 a = xh[k] * P.ga + P.be;
@@ -664,7 +688,7 @@ __device__ __forceinline__ void epilogue_bwd(float* __restrict__ tl, const EpiPa
         if (!ok[k]) continue;
         const int pos = pos0 + k * pstep;
         const f32x4 gu = (gx[k] - m1 - xh[k] * m2) * rstd;
-        float* o = tl + e.dst + (pos + CDX2_HALO2) * e.dstride + c;
+        float* o = tl + e.dst + mul24i(pos + CDX2_HALO2, e.dstride) + c;
         if (c + 3 < e.c_out) {
             *reinterpret_cast<f32x4*>(o) = gu;
         } else {
@@ -762,7 +786,7 @@ __device__ __forceinline__ EpiParams load_params(const cdx_unet2_launch& L, int 
         if (xg & CDX2_XG_GOP) grp = (xg & 255) + (grp & ((((xg >> 8) & 255) - (xg & 255)) - 1));
     }
     const int flags = CDX2_DW(vd, CDX2_W2_FLAGS), coutp = CDX2_DW(vd, CDX2_W2_COUTP), shift = CDX2_DW(vd, CDX2_W2_CG4_SHIFT);
-    const int c = grp * (coutp >> 3) + 4 * (li & ((1 << shift) - 1));
+    const int c = mul24i(grp, coutp >> 3) + 4 * (li & ((1 << shift) - 1));
     // (batch-tiled MLP programs: a layer whose input has a time-dependent part reads its bias from the step's table row)
     const float* __restrict__ pbi = ((MLP && (flags & CDX2_F2_BIAS_EMB)) ? emb_row : L.wblob) + CDX2_DW(vd, CDX2_W2_BOFF) + c;
     const bool gn = (flags & (CDX2_F2_GN | CDX2_F2_GNBWD)) != 0;
@@ -865,7 +889,7 @@ __device__ __forceinline__ float* exchange_tile(const XState& X, unsigned seq, i
 //  cycles, is the wait for the slowest member of the group plus one L2 round trip, not the copy.)
 template <int THREADS>
 __device__ __forceinline__ void split_exchange(XState& X, int grp_idx, int xg, int gmap, float* __restrict__ tl, int dst, int dstride,
-                                               int l_out, int c_out, int coutp, int tid) {
+                                               int l_out, int c_out, int coutp, int tid, unsigned long long* prof = nullptr) {
     const int g_lo = xg & 255, g_hi = (xg >> 8) & 255;
     const bool grouped = (xg & (CDX2_XG_GOP | CDX2_XG_TRAJ)) != 0, traj = (xg & CDX2_XG_TRAJ) != 0;
     const int gsh = grouped ? (gmap & 255) : 30, grows = grouped ? (gmap >> 8) : 0;
@@ -888,12 +912,13 @@ __device__ __forceinline__ void split_exchange(XState& X, int grp_idx, int xg, i
         const int t = vpos >> gsh, pos = vpos - (t << gsh);
         const bool mine = traj ? t == X.m : (grp >= g_lo && grp < g_hi);
         if (mine && !withhold) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(tl + base + (t * grows + pos + CDX2_HALO2) * dstride + c);
-            f32x4* o = reinterpret_cast<f32x4*>(tile + (size_t)(vpos * coutp + c) * 2);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(tl + base + mul24i(mul24i(t, grows) + pos + CDX2_HALO2, dstride) + c);
+            f32x4* o = reinterpret_cast<f32x4*>(tile + (size_t)(mul24i(vpos, coutp) + c) * 2);
             o[0] = (f32x4){v[0], tag, v[1], tag};
             o[1] = (f32x4){v[2], tag, v[3], tag};
         }
     }
+    if (CDX2_PROF_FETCH == 2) stamp(prof ? prof + 5 : nullptr, tid);
     // collect: everybody else's part, straight from L2 (nontemporal loads bypass this CU's L1), as soon as their tags say so.
     // (Measured and dropped, gpurun r4k / r4l: requesting a thread's two items together -- even the same loop merely WRITTEN for two
     //  items with one of them disabled -- is 2 % slower at B = 256 than this plain loop; the poll interval, s_sleep 0 / 1 / 4 / 16, changes
@@ -903,7 +928,7 @@ __device__ __forceinline__ void split_exchange(XState& X, int grp_idx, int xg, i
         const int t = vpos >> gsh, pos = vpos - (t << gsh);
         const bool mine = traj ? t == X.m : (grp >= g_lo && grp < g_hi);
         if (!mine && c < c_out) {
-            const f32x4* src = reinterpret_cast<const f32x4*>(tile + (size_t)(vpos * coutp + c) * 2);
+            const f32x4* src = reinterpret_cast<const f32x4*>(tile + (size_t)(mul24i(vpos, coutp) + c) * 2);
             f32x4 a, b;
             int spins = 0;
             for (;;) {
@@ -921,13 +946,73 @@ __device__ __forceinline__ void split_exchange(XState& X, int grp_idx, int xg, i
                 }
                 __builtin_amdgcn_s_sleep(1);
             }
-            float* o = tl + base + (t * grows + pos + CDX2_HALO2) * dstride + c;
+            float* o = tl + base + mul24i(mul24i(t, grows) + pos + CDX2_HALO2, dstride) + c;
             const f32x4 v = (f32x4){a[0], a[2], b[0], b[2]};
             if (c + 3 < c_out) *reinterpret_cast<f32x4*>(o) = v;
             else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (c + j < c_out) o[j] = v[j];
+            }
+        }
+    }
+}
+
+// Fast exchange of a grouped op (CDX2_XCHG_FAST): the epilogue waves publish their items from registers (epilogue<..., PUBLISH>) while
+// the OTHER four waves -- which have nothing to do during an epilogue but halo rows -- collect the other members' parts: thread u of
+// the 256 takes tile item (position u >> nc4sh, float4 u & (nc4 - 1)) of each of the k - 1 other members' channel blocks, requests all of
+// them at once (up to six 16-byte loads in flight) and polls until every tag matches.  Round-5 form (split_exchange): epilogue ->
+// barrier -> all threads publish from LDS (1.3 k cycles) -> all threads collect, a thread's two items one after the other (1.8-2.7 k)
+// -> barrier; here the exchange ends one L2 round trip after the slowest member's epilogue.
+__device__ __forceinline__ void collect_fast(XState& X, int grp_idx, unsigned seq, const float* tile, int xg, int gmap,
+                                             float* tl, int dst, int dstride, int l_out, int coutp, int u) {
+    const int g_lo = xg & 255, w = ((xg >> 8) & 255) - g_lo;                 // lane groups per member (a power of two)
+    const int cgsh = 31 - __builtin_clz(coutp >> 3);                         // log2 channels per lane group
+    const int nc4sh = (31 - __builtin_clz(w)) + cgsh - 2;                    // log2 float4 items per position and member
+    const int gsh = gmap & 255, grows = gmap >> 8;
+    const int n_blk = (l_out * X.k) << nc4sh;                                // items of one member's block
+    const int km1 = X.k - 1;
+    for (int j = u; j < n_blk; j += 256) {
+        const int vpos = j >> nc4sh, c4 = j & ((1 << nc4sh) - 1);
+        const int t = vpos >> gsh, pos = vpos - (t << gsh);
+        const int row = mul24i(mul24i(t, grows) + pos + CDX2_HALO2, dstride);
+        const int tbase = mul24i(vpos, coutp);
+        f32x4 a[3], b[3];
+        int cc[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int mb = (X.m + 1 + (r < km1 ? r : 0)) & km1;                // (k = 2: one block; the spare slots re-read it, never stored)
+            cc[r] = ((mb * w) << cgsh) + 4 * c4;
+            const f32x4* src = reinterpret_cast<const f32x4*>(tile + (size_t)(tbase + cc[r]) * 2);
+            a[r] = __builtin_nontemporal_load(src);
+            b[r] = __builtin_nontemporal_load(src + 1);
+        }
+        int pending = (1 << km1) - 1, spins = 0;
+        while (pending) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                if (!(pending & (1 << r))) continue;
+                if (__float_as_uint(a[r][1]) == seq && __float_as_uint(a[r][3]) == seq && __float_as_uint(b[r][1]) == seq &&
+                    __float_as_uint(b[r][3]) == seq) {
+                    *reinterpret_cast<f32x4*>(tl + dst + row + cc[r]) = (f32x4){a[r][0], a[r][2], b[r][0], b[r][2]};
+                    pending &= ~(1 << r);
+                } else {
+                    // (a compiler barrier: the tile is written by OTHER workgroups -- without it the re-read below is a redundant load
+                    //  of an address nothing in this function stores to, and is folded into the first one)
+                    asm volatile("" ::: "memory");
+                    const f32x4* src = reinterpret_cast<const f32x4*>(tile + (size_t)(tbase + cc[r]) * 2);
+                    a[r] = __builtin_nontemporal_load(src);
+                    b[r] = __builtin_nontemporal_load(src + 1);
+                }
+            }
+            if (pending) {
+                // (bounded like split_exchange's polls: a thread that has given up once stops waiting altogether)
+                if (X.dead || ++spins > 200000) {
+                    if (!X.dead) xchg_report(1, X, (int)seq, j, grp_idx);
+                    X.dead = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
             }
         }
     }
@@ -958,10 +1043,13 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
     // issues those AFTER its staging barrier instead (see pipe_params)
     auto fetch_next = [&](bool params) {
         it = inline_item(vdn);
+        if (PROF && CDX2_PROF_FETCH == 1) stamp(prof ? prof + 4 : nullptr, tid);
         if (wave_of(tid) < CDX2_DW(vdn, CDX2_W2_NITEMS)) prefetch_ring(it, L.wblob, tid & 63, ring);
+        if (PROF && CDX2_PROF_FETCH == 1) stamp(prof ? prof + 5 : nullptr, tid);
         if (PIPE) {
             if (params)
                 F.P = load_params<COND, SPLIT_T, false, MLP, MEMBER>(L, vdn, emb_next, emb_next_tstride, tid, wave_of(tid), NWV == 4 || SPLIT_T || wave_of(tid) < 4);
+            if (PROF && CDX2_PROF_FETCH == 1) stamp(prof ? prof + 6 : nullptr, tid);
             F.vdn2 = load_desc<NWV>(L.ops, op_next2 + (MEMBER ? X->m * L.n_ops : 0), tid & 63, wave_of(tid));
         }
     };
@@ -1029,7 +1117,7 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
     // epilogue geometry + per-channel parameters: issued now, consumed after the barrier (latency hides behind the K loop)
     const int etid = tid & 255;
     const int grp = etid >> 5, li = etid & 31;
-    const int c = grp * (coutp >> 3) + 4 * (li & ((1 << shift) - 1));
+    const int c = mul24i(grp, coutp >> 3) + 4 * (li & ((1 << shift) - 1));
     const int pos0 = li >> shift, pstep = 32 >> shift;
     const int nv = (coutp >> 5) * l_out;
     // this op's epilogue parameters: fetched during the PREVIOUS op (PIPE), or here (consumed after the barrier either way)
@@ -1077,16 +1165,27 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
         // of the destination / residual slots, its columns of the staged tiles (which hold only the member's channels: relative to the
         // first one), K slices `k x l_out` positions apart.  Every half-wave works.
         const int gx_lo = xgw & 255, gpm = ((xgw >> 8) & 255) - gx_lo, grows = gmap >> 8;
+        // fast exchange: the epilogue threads publish, the other waves collect meanwhile (collect_fast); X->seq moves on below
+        const bool xfast = CDX2_XCHG_FAST && (xgw & CDX2_XG_XCHG) != 0;
+        const unsigned xseq = X->seq + 1;
+        float* xtile = xfast ? exchange_tile(*X, xseq, __float_as_int(lds[T * tf])) : nullptr;
         if (epi_wave) {
             const int g_t = __builtin_amdgcn_readfirstlane(gpm == 4 ? grp >> 2 : grp >> 1);
-            const int cgo = (gx_lo + (grp & (gpm - 1))) * (coutp >> 3) + 4 * (li & ((1 << shift) - 1));
+            const int cgo = mul24i(gx_lo + (grp & (gpm - 1)), coutp >> 3) + 4 * (li & ((1 << shift) - 1));
             EpiDesc eg = e;
             eg.dst += g_t * grows * e.dstride;
             eg.res += g_t * grows * e.rstride;
             eg.l_out = l_out * X->k;
             const int stage_g = g.stage + g_t * l_out * sstride - gx_lo * (coutp >> 3);
-            if (e.nk == 1) epilogue<1, BWD, COND, MLP>(lds, P, eg, stage_g, cgo, pos0, pstep, li, nv, lane, grp, nullptr);
-            else epilogue<2, BWD, COND, MLP>(lds, P, eg, stage_g, cgo, pos0, pstep, li, nv, lane, grp, nullptr);
+            bool withhold = false;                          // test hook (cdx_unet2_launch.fault): a lost granule on purpose
+            if (xfast) {
+                const KArg* S0 = kernarg();
+                asm volatile("" : "+s"(S0));
+                withhold = S0->fault != 0 && X->m == S0->fault - 1;
+            }
+            const Pub pub{xtile, __uint_as_float(xseq), g_t * l_out, e.coutp, xfast && !withhold};
+            if (e.nk == 1) epilogue<1, BWD, COND, MLP, true>(lds, P, eg, stage_g, cgo, pos0, pstep, li, nv, lane, grp, nullptr, &pub);
+            else epilogue<2, BWD, COND, MLP, true>(lds, P, eg, stage_g, cgo, pos0, pstep, li, nv, lane, grp, nullptr, &pub);
         }
     } else {
     const int t_lo = SPLIT_T ? (wave >> 2) : 0, t_step = SPLIT_T ? 2 : 1;
@@ -1138,9 +1237,21 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
                 *reinterpret_cast<f32x4*>(lds + dbase + (tt * hrows + hrow) * e.dstride + j) = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     if (PIPE) F.P = Pnext;
+    if (SPLIT && CDX2_XCHG_FAST && (xgw & CDX2_XG_GOP) && (xgw & CDX2_XG_XCHG)) {
+        // grouped op, fast exchange: the halo waves collect while the epilogue waves still compute and publish
+        const unsigned xseq = X->seq + 1;
+        if (halo_wave && !CDX2_XCHG_NOWAIT) {
+            const int gi = __float_as_int(lds[T * tf]);
+            collect_fast(*X, gi, xseq, exchange_tile(*X, xseq, gi), xgw, gmap, lds, e.dst, e.dstride, l_out, e.coutp, tid & 255);
+        }
+        X->seq = xseq;
+    } else
     if (SPLIT && (xgw & CDX2_XG_XCHG)) {
+        if (PROF && CDX2_PROF_FETCH == 2) stamp(prof ? prof + 4 : nullptr, tid);
         __syncthreads();                                             // the epilogue's stores to the destination slot are in LDS
-        split_exchange<WG<NWV>::THREADS>(*X, __float_as_int(lds[T * tf]), xgw, gmap, lds, e.dst, e.dstride, l_out, e.c_out, e.coutp, tid);
+        split_exchange<WG<NWV>::THREADS>(*X, __float_as_int(lds[T * tf]), xgw, gmap, lds, e.dst, e.dstride, l_out, e.c_out, e.coutp, tid,
+                                         (PROF && CDX2_PROF_FETCH == 2) ? prof : nullptr);
+        if (PROF && CDX2_PROF_FETCH == 2) stamp(prof ? prof + 6 : nullptr, tid);
     }
     __syncthreads();
     if (PROF) stamp(prof ? prof + 3 : nullptr, tid);

@@ -394,6 +394,8 @@ class _Builder2:
             budget = max(len(streams), nw // tiles if tiles < nw else 1)
             if gop:      # the post-norm extra streams (1x1 skip) ride as second-round items: the main conv keeps every wave
                 budget = (nw // tiles if tiles < nw else 1) + sum(1 for st in streams if st["post"])
+                if os.environ.get("CDX_DBG_LONE") == "1":       # (diagnostic: one K slice per tile -- four waves run the steady loop alone on their SIMDs)
+                    budget = 1 + sum(1 for st in streams if st["post"])
             per = [1] * len(streams)
             n_of = [st["recs"].shape[1] for st in streams]
 

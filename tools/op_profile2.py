@@ -25,6 +25,8 @@ def main():
         os.environ["CDX_UNET2_NW"] = sys.argv[3]
     bench.BATCH = batch
     dev = torch.device("cuda", 0)
+    if os.environ.get("OP_PROFILE_FORCE_GROUP") == "1":     # diagnostic builds whose results are wrong on purpose: skip the first-use check
+        runtime2._group_ok[dev] = True
     agent, net = bench.build_agent(dev)
     prior, z0 = bench.make_inputs(dev, 0)
     kw = dict(solver="ddim", n_samples=batch, sample_steps=20, temperature=0.5)
@@ -54,6 +56,13 @@ def main():
         tk, ts, te = tk + k, ts + s, te + e
         xg = int(op[P2.W2_XG])
         tag = "G" if xg & P2.XG_GOP else ("X" if xg & P2.XG_XCHG else " ")
+        if os.environ.get("OP_PROFILE_FETCH"):      # a -DCDX2_PROF_FETCH=1 build: stamps 4-6 sit inside fetch_next
+            print(f"{i:3d}{tag} kloop+stage {k7 - s0:6d} | item decode {k4 - k7:5d} ring loads {k5 - k4:5d} params {k6 - k5:5d} desc {s1 - k6:5d} | sync {s:5d} epi {e:6d}")
+            continue
+        if os.environ.get("OP_PROFILE_XCHG"):       # a -DCDX2_PROF_FETCH=2 build: stamps 4-6 sit around the exchange
+            if xg & P2.XG_XCHG:
+                print(f"{i:3d}{tag} kloop {k:6d} sync {s:5d} | epilogue {k4 - s2:5d} barrier+publish {k5 - k4:5d} collect {k6 - k5:5d} barrier {s3 - k6:5d} | epi column {e:6d}")
+            continue
         print(f"{i:3d}{tag}{op[P2.W2_COUT]:4d} {op[P2.W2_LOUT]:3d} {'4x4' if op[P2.W2_MODE] else '16':>4} {op[P2.W2_NT]:2d} {op[P2.W2_KSPLIT]:2d} "
               f"{nq:7d} {k:7d} {s:6d} {e:6d} {s3 - s0:7d} | decode {k4 - s0:5d} operands {k5 - k4:5d} mfma {k6 - k5:6d} stage {k7 - k6:5d} prefetch {s1 - k7:5d}")
     print(f"totals: kloop={tk} sync={ts} epilogue={te}  sum={tk + ts + te}")
