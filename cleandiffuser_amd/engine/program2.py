@@ -398,6 +398,9 @@ class _Builder2:
                     budget = 1 + sum(1 for st in streams if st["post"])
             per = [1] * len(streams)
             n_of = [st["recs"].shape[1] for st in streams]
+            single_round = False
+            uneven = {}                                      # stream -> explicit slice ends (see the grouped ops with a skip conv below)
+            kpost_streams = [i for i in range(len(streams)) if streams[i]["post"]]
 
             def grow():
                 cand = [i for i in range(len(streams)) if n_of[i] // (per[i] + 1) >= MIN_SLICE]
@@ -411,6 +414,30 @@ class _Builder2:
                 # the main conv is a long, stream-bound K loop: giving waves away to the extra conv costs it more than an op of its own
                 return False
             self.macs += sum(c_out * l_out * ex["w_eff"].shape[1] * ex["w_eff"].shape[2] for ex in extra)
+            if gop and kpost_streams:
+                # A grouped op whose block carries a 1x1 skip conv: its second-round items (the skip streams) start with an empty ring
+                # (~1.3 k cycles until their first MFMA) on the waves that also hold a first-round slice.  Cut the main conv so that
+                # (i) every slice is a multiple of the ring -- only such slices take the kernel's immediate-offset loop (round 5:
+                # op 24G's 13 / 13 / 14 cut ran the general loop at 310 cycles per record) -- and (ii) the slices of the waves that get
+                # a second-round item are one ring revolution shorter than the others' (r05 op profile: ops 16G / 24G waited ~3.6 k
+                # cycles at their staging barrier for the four waves that drew 48 records instead of 40).
+                n_first = nw // tiles if tiles < nw else 1
+                main = [i for i in range(len(streams)) if not streams[i]["post"]]
+                uneven_on = os.environ.get("CDX_UNET2_UNEVEN_CUT", "1") != "0"
+                if uneven_on and len(main) == 1 and n_first - len(kpost_streams) >= 2 and n_of[main[0]] >= 2 * ring * (n_first - len(kpost_streams)):
+                    # enough waves per tile for the skip streams to be FIRST-round items next to ring-aligned main slices: one round, no
+                    # empty-ring start at all (24G: 24 / 16 main + 16 / 8 skip records per tile instead of 13 / 13 / 14 + a second round)
+                    per = [1] * len(streams)
+                    per[main[0]] = n_first - len(kpost_streams)
+                    single_round = True
+                elif uneven_on and len(main) == 1 and n_first == 2 and n_of[main[0]] >= 4 * ring and n_of[main[0]] % (2 * ring) == 0:
+                    per[main[0]] = 2
+                    uneven[main[0]] = [n_of[main[0]] // 2 - ring, n_of[main[0]]]
+                    spare = budget - 2 - sum(per[i] for i in range(len(streams)) if streams[i]["post"])
+                    for i in sorted((i for i in range(len(streams)) if streams[i]["post"]), key=lambda i: -n_of[i]):
+                        while spare < 0 and per[i] > 1:
+                            per[i] -= 1
+                            spare += 1
             order = [i for i in range(len(streams)) if not streams[i]["post"]] + [i for i in range(len(streams)) if streams[i]["post"]]
             kpost = sum(per[i] for i in range(len(streams)) if streams[i]["post"])
             ksplit = sum(per) - kpost                        # slices summed BEFORE the norm; the post slices follow them in the stage
@@ -420,6 +447,8 @@ class _Builder2:
                 woff = self.add(st["recs"].contiguous())
                 al = ring if n >= 2 * ring * k else 1
                 edge = [min(n, (j * n // k + al // 2) // al * al) for j in range(k)] + [n]
+                if i in uneven:
+                    edge = [0] + uneven[i]
                 for j in range(k):
                     q0, q1 = edge[j], edge[j + 1]
                     for tile in range(n_rt * n_cg):
@@ -431,6 +460,16 @@ class _Builder2:
                         item_src.append(st["src"])
                     ks += 1
             stage_slices = ksplit + kpost
+            if single_round and len(items) == nw:
+                # waves w and w + 4 share a SIMD: deal the items so that the SIMDs' record totals come out level (largest first onto the
+                # least loaded SIMD with a free wave).  An item carries its own tile and partial-sum slot: the order changes no result.
+                load, free, place = [0] * 4, [[sm, sm + 4] for sm in range(4)], {}
+                for idx in sorted(range(nw), key=lambda t: -items[t][I2_NQ]):
+                    sm = min((q for q in range(4) if free[q]), key=lambda q: load[q])
+                    place[free[sm].pop(0)] = idx
+                    load[sm] += items[idx][I2_NQ]
+                items = [items[place[w]] for w in range(nw)]
+                item_src = [item_src[place[w]] for w in range(nw)]
         else:
             assert not extra, "extra convs ride on single-phase ops only"
             # record stream of a (phase, row tile): [source 0: taps x chunks | source 1: taps x chunks]; a K slice never straddles the
