@@ -8,7 +8,6 @@ from .misc import (set_seed, at_least_ndim, to_tensor, count_parameters, ema_upd
                    UnfreezeModules, EvalModules, TrainModules, dict_apply, loop_dataloader)
 from .blocks import GroupNorm1d, Mlp
 from .synth import synth_state_dict, load_synth, synth_array
-from .critics import (DQLCritic, TwinQ, V, IQL, IDQLQNet, IDQLVNet, SoftLowerBound, SoftUpperBound, DVTransformerBlock,
-                      DVHorizonCritic, PreNorm, Residual, FeedForward, MultiHeadAttention, Transformer, generate_causal_mask)
+from .critics import DQLCritic, TwinQ, V, IQL, IDQLQNet, IDQLVNet, SoftLowerBound, SoftUpperBound
 from .normalizers import EmptyNormalizer, GaussianNormalizer, MinMaxNormalizer
 from .misc import param_to_module, TensorDict, invalidate_weights

@@ -1,7 +1,7 @@
-"""Value heads and generic transformer pieces the pipelines evaluate on freshly sampled tensors: candidate
-re-weighting critics (``DQLCritic``, IQL's ``TwinQ`` / ``V``), Diffusion Veteran's horizon critic, and the small transformer
-toolkit.  Interface / checkpoint contract: reference utils/building_blocks.py:79-380 and utils/iql.py:7-95 (same attribute
-names, hence the same ``state_dict`` keys).
+"""Value heads the pipelines evaluate on freshly sampled tensors: the candidate re-weighting critics ``DQLCritic`` and
+IQL's ``TwinQ`` / ``V``.  Interface / checkpoint contract: reference utils/building_blocks.py:79-147 and utils/iql.py:7-95 (same
+attribute names, hence the same ``state_dict`` keys).  Diffusion Veteran's horizon critic and the reference's transformer toolkit
+(building_blocks.py:149-373) are outside the sampling path and are not mirrored.
 
 Execution: every head here is a chain of ``Linear -> [LayerNorm] -> activation`` over rows, so on a ROCm device without
 autograd the chain runs through ``engine/heads.py`` (fp32-MFMA GEMM with fused bias/activation epilogue + one fused
@@ -9,13 +9,9 @@ LayerNorm/activation launch per layer); with autograd on, or on CPU, the stock m
 """
 from copy import deepcopy
 
-import einops
-import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
-
-from .embeddings import SinusoidalEmbedding
 
 
 def _rows(seq: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
@@ -139,150 +135,3 @@ class IQL(nn.Module):
 
     def load(self, path, device):
         self.load_state_dict(torch.load(path, map_location=device))
-
-
-class DVTransformerBlock(nn.Module):
-    def __init__(self, hidden_size: int, n_heads: int, dropout: float = 0.0, norm_type="post"):
-        super().__init__()
-        self.norm_type = norm_type
-        self.norm1 = nn.LayerNorm(hidden_size, elementwise_affine=False, eps=1e-6)
-        self.attn = nn.MultiheadAttention(hidden_size, n_heads, dropout, batch_first=True)
-        self.norm2 = nn.LayerNorm(hidden_size, elementwise_affine=False, eps=1e-6)
-        self.mlp = nn.Sequential(nn.Linear(hidden_size, hidden_size * 4), nn.GELU(approximate="tanh"),
-                                 nn.Dropout(dropout), nn.Linear(hidden_size * 4, hidden_size))
-
-    def forward(self, x: torch.Tensor):
-        if self.norm_type == "post":
-            x = self.norm1(x + self.attn(x, x, x)[0])
-            return self.norm2(x + self.mlp(x))
-        if self.norm_type == "pre":
-            x = self.norm1(x)
-            x = x + self.attn(x, x, x)[0]
-            return x + self.mlp(self.norm2(x))
-        raise NotImplementedError
-
-
-class DVHorizonCritic(nn.Module):
-    """Transformer value function over a planned trajectory; the value is read from token 0."""
-
-    def __init__(self, in_dim: int, emb_dim: int, d_model: int = 384, n_heads: int = 6, depth: int = 12,
-                 dropout: float = 0.0, norm_type: str = "post"):
-        super().__init__()
-        self.in_dim, self.emb_dim, self.d_model = in_dim, emb_dim, d_model
-        self.x_proj = nn.Linear(in_dim, d_model)
-        self.pos_emb = SinusoidalEmbedding(d_model)
-        self.pos_emb_cache = None
-        self.blocks = nn.ModuleList([DVTransformerBlock(d_model, n_heads, dropout, norm_type) for _ in range(depth)])
-        self.final_layer = nn.Linear(d_model, 1)
-        self.initialize_weights()
-
-    def initialize_weights(self):
-        for m in self.modules():
-            if isinstance(m, nn.Linear):
-                nn.init.xavier_uniform_(m.weight)
-                if m.bias is not None:
-                    nn.init.constant_(m.bias, 0)
-
-    def forward(self, x: torch.Tensor):
-        """x (b, horizon, in_dim) -> (b, 1)."""
-        if self.pos_emb_cache is None or self.pos_emb_cache.shape[0] != x.shape[1]:
-            self.pos_emb_cache = self.pos_emb(torch.arange(x.shape[1], device=x.device))
-        h = self.x_proj(x) + self.pos_emb_cache[None, ]
-        for block in self.blocks:
-            h = block(h)
-        return self.final_layer(h)[:, 0, :]
-
-
-class PreNorm(nn.Module):
-    """fn(LayerNorm(x), **kwargs)"""
-
-    def __init__(self, dim, fn):
-        super().__init__()
-        self.norm = nn.LayerNorm(dim)
-        self.fn = fn
-
-    def forward(self, x, **kwargs):
-        return self.fn(self.norm(x), **kwargs)
-
-
-class Residual(nn.Module):
-    """fn(x, **kwargs) + x"""
-
-    def __init__(self, fn):
-        super().__init__()
-        self.fn = fn
-
-    def forward(self, x, **kwargs):
-        return self.fn(x, **kwargs) + x
-
-
-class FeedForward(nn.Module):
-    def __init__(self, d_model: int, hidden_scale: int = 4, dropout: float = 0.0):
-        super().__init__()
-        hidden = int(d_model * hidden_scale)
-        self.net = nn.Sequential(nn.Linear(d_model, hidden), nn.GELU(), nn.Dropout(dropout), nn.Linear(hidden, d_model),
-                                 nn.Dropout(dropout))
-
-    def forward(self, x):
-        return self.net(x)
-
-
-class MultiHeadAttention(nn.Module):
-    """Attention WITHOUT an output projection; returns (context, detached attention map laid out (b, i, j, h))."""
-
-    def __init__(self, d_model: int, nhead: int, dropout: float = 0.1, bias: bool = False):
-        super().__init__()
-        assert d_model % nhead == 0, "`d_model` must be divisible by `nhead`."
-        self.nhead, self.d_k = nhead, d_model // nhead
-        self.scale = 1 / np.sqrt(self.d_k)
-        self.q_layer = nn.Linear(d_model, d_model, bias=bias)
-        self.k_layer = nn.Linear(d_model, d_model, bias=bias)
-        self.v_layer = nn.Linear(d_model, d_model, bias=True)
-        self.dropout = nn.Dropout(dropout)
-
-    def forward(self, q, k, v, mask=None):
-        if mask is not None:
-            if mask.dim() == 2:
-                assert mask.shape == (q.shape[1], k.shape[1])
-                mask = mask.unsqueeze(0)
-            elif mask.dim() == 3:
-                assert mask.shape == (q.shape[0], q.shape[1], k.shape[1])
-            else:
-                raise ValueError("`mask` shape should be either (i, j) or (b, i, j)")
-            mask = mask.unsqueeze(-1)
-        split = "b n (h d) -> b n h d"
-        q = einops.rearrange(self.q_layer(q), split, h=self.nhead)
-        k = einops.rearrange(self.k_layer(k), split, h=self.nhead)
-        v = einops.rearrange(self.v_layer(v), split, h=self.nhead)
-        scores = torch.einsum("b i h d, b j h d -> b i j h", q, k) * self.scale
-        if mask is not None:
-            scores.masked_fill_(mask == 0, float("-inf"))
-        attn = self.dropout(torch.softmax(scores, dim=2))
-        out = torch.einsum("b i j h, b j h d -> b i h d", attn, v)
-        return einops.rearrange(out, "b i h d -> b i (h d)"), attn.detach()
-
-
-def generate_causal_mask(length: int, device: torch.device = "cpu"):
-    return torch.tril(torch.ones(length, length, device=device), diagonal=0)
-
-
-class Transformer(nn.Module):
-    """Pre-norm encoder stack; ``layers.{i}`` = [LayerNorm, MultiHeadAttention, LayerNorm, FeedForward]."""
-
-    def __init__(self, d_model: int, nhead: int, num_layers: int, hidden_scale: int = 4, attn_dropout: float = 0.0,
-                 ffn_dropout: float = 0.0, bias: bool = False):
-        super().__init__()
-        self.layers = nn.ModuleList([
-            nn.ModuleList([nn.LayerNorm(d_model), MultiHeadAttention(d_model, nhead, attn_dropout, bias),
-                           nn.LayerNorm(d_model), FeedForward(d_model, hidden_scale, ffn_dropout)])
-            for _ in range(num_layers)])
-
-    def forward(self, x, mask=None):
-        maps = []
-        for norm1, attn, norm2, ffn in self.layers:
-            h = norm1(x)
-            h, amap = attn(h, h, h, mask=mask)
-            maps.append(amap)
-            x = h + x
-            x = ffn(norm2(x)) + x
-        return x, maps

@@ -101,12 +101,13 @@ def head_outputs(root_pkg, device="cpu"):
         iql = _synth(U.IQL(11, 3, hidden_dim=32)).to(device)
         out["IQL/q_targ"], out["IQL/v"] = iql.Q_targ(obs, act), iql.V(obs)
         traj = f("traj", 4, 6, 5)
-        for norm in ("post", "pre"):
+        for norm in (("post", "pre") if hasattr(U, "DVHorizonCritic") else ()):       # (reference only: the package does not mirror these)
             out[f"DVHorizonCritic/{norm}"] = _synth(U.DVHorizonCritic(5, 16, d_model=32, n_heads=4, depth=2, norm_type=norm)).to(device)(traj)
-        tr = _synth(U.Transformer(32, 4, 2, bias=True)).to(device)
-        tok = f("tok", 3, 6, 32)
-        y, maps = tr(tok, mask=U.generate_causal_mask(6, device))
-        out["Transformer/y"], out["Transformer/map1"] = y, maps[1]
+        if hasattr(U, "Transformer"):
+            tr = _synth(U.Transformer(32, 4, 2, bias=True)).to(device)
+            tok = f("tok", 3, 6, 32)
+            y, maps = tr(tok, mask=U.generate_causal_mask(6, device))
+            out["Transformer/y"], out["Transformer/map1"] = y, maps[1]
         out["SoftBounds"] = torch.stack([U.SoftLowerBound(-0.3)(obs), U.SoftUpperBound(0.4)(obs)])
     heads = {"MlpInvDynamic": I.MlpInvDynamic(11, 3, hidden_dim=64, device=device),
              "MlpInvDynamic/identity": I.MlpInvDynamic(11, 3, hidden_dim=40, out_activation=torch.nn.Identity(), device=device),
