@@ -2,7 +2,7 @@
 ``BaseNNClassifier``, ``logp(x, noise, c) -> (b, 1)``, ``gradients(x, noise, c) -> (logp, d logp.sum() / dx)``, an Adam optimiser
 (default lr 2e-4, weight decay 1e-4), an EMA copy, and ``save/load`` of the ``{"model", "model_ema"}`` checkpoint.
 
-``gradients`` on a ROCm device is served by explicit forward + backward kernels when the network is one the engine knows
+``update`` on a ROCm device: native forward / backward nodes + ``FusedAdam`` (see the method).  ``gradients`` on a ROCm device is served by explicit forward + backward kernels when the network is one the engine knows
 (engine/classifier_grad.py: HalfJannerUNet1d; engine/mlp_grad.py: MSEClassifier / QGPOClassifier over the MLP networks); everything else differentiates ``logp`` with autograd as the reference does.
 """
 from copy import deepcopy
@@ -21,7 +21,9 @@ class BaseClassifier:
         self.grad_clip_norm = grad_clip_norm
         self.model = nn_classifier.to(device)
         self.model_ema = deepcopy(self.model).eval()
-        self.optim = torch.optim.Adam(self.model.parameters(), **(_DEFAULT_ADAM if optim_params is None else optim_params))
+        # (a torch.optim.Adam subclass: on a ROCm device its step is one multi-tensor launch of cdx_optim_f32, L2 decay as torch's)
+        from ..engine.optim import FusedAdam
+        self.optim = FusedAdam(self.model.parameters(), **(_DEFAULT_ADAM if optim_params is None else optim_params))
 
     # ---- what a concrete classifier defines ----
     def loss(self, x: torch.Tensor, noise: torch.Tensor, y: torch.Tensor):
@@ -49,15 +51,36 @@ class BaseClassifier:
 
     # ---- training ----
     def update(self, x: torch.Tensor, noise: torch.Tensor, y: torch.Tensor, update_ema: bool = True):
-        loss = self.loss(x, noise, y)
-        self.optim.zero_grad()
-        loss.backward()
+        """One training step (reference classifier/base.py:47-58): loss -> zero_grad -> backward -> [clip] -> Adam -> [EMA].  On a ROCm
+        device with a network the native training path serves (HalfJannerUNet1d) forward + backward run on the library's kernels -- one
+        HIP-graph replay once the first step passed the capturability probe -- and clip + Adam + EMA are at most three launches."""
+        from ..engine import train
+        from ..engine.optim import FusedAdam
+        opt = self.optim
+        fused = isinstance(opt, FusedAdam) and opt.native()
+        g = train.graphed_classifier_step(self, x, noise, y) if fused else None
+        if g is not None:
+            opt.zero_grad()                               # (in place: the captured backward adds into these very tensors)
+            loss = g.replay(x, (noise, y))
+            for p in g.written:
+                opt._gver.pop(id(p), None)                # a replay writes gradients without moving their version counters
+        else:
+            loss = self.loss(x, noise, y)
+            opt.zero_grad()
+            with train.grads_in_place():
+                loss.backward()
         grad_norm = None
-        if isinstance(self.grad_clip_norm, float):
-            grad_norm = torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_clip_norm).item()
-        self.optim.step()
-        if update_ema:
-            self.ema_update()
+        clip = self.grad_clip_norm if isinstance(self.grad_clip_norm, float) else None
+        if fused:
+            opt.step(max_norm=clip, ema=(self.model, self.model_ema, self.ema_rate) if update_ema else None)
+            if clip:
+                grad_norm = opt.last_grad_norm.item()
+        else:
+            if clip:
+                grad_norm = torch.nn.utils.clip_grad_norm_(self.model.parameters(), clip).item()
+            opt.step()
+            if update_ema:
+                self.ema_update()
         return {"loss": loss.item(), "grad_norm": grad_norm}
 
     def ema_update(self):

@@ -45,11 +45,12 @@ __global__ __launch_bounds__(OPT_THREADS) void cdx_optim_kernel(cdx_optim_args a
     const long long n = a.numel[t];
     const long long base = (long long)ci * a.chunk_elems;
     const int len = (int)((n - base < a.chunk_elems) ? (n - base) : a.chunk_elems);
-    float* __restrict__ p = (MODE == CDX_OPT_ADAMW || MODE == CDX_OPT_EMA) ? a.p[t] + base : nullptr;
-    float* __restrict__ g = (MODE == CDX_OPT_ADAMW || MODE == CDX_OPT_SUMSQ || MODE == CDX_OPT_ZERO) ? a.g[t] + base : nullptr;
-    float* __restrict__ m = (MODE == CDX_OPT_ADAMW) ? a.m[t] + base : nullptr;
-    float* __restrict__ v = (MODE == CDX_OPT_ADAMW) ? a.v[t] + base : nullptr;
-    float* __restrict__ e = ((MODE == CDX_OPT_ADAMW && a.ema != nullptr) || MODE == CDX_OPT_EMA) ? a.ema[t] + base : nullptr;
+    constexpr bool STEP = MODE == CDX_OPT_ADAMW || MODE == CDX_OPT_ADAM;
+    float* __restrict__ p = (STEP || MODE == CDX_OPT_EMA) ? a.p[t] + base : nullptr;
+    float* __restrict__ g = (STEP || MODE == CDX_OPT_SUMSQ || MODE == CDX_OPT_ZERO) ? a.g[t] + base : nullptr;
+    float* __restrict__ m = STEP ? a.m[t] + base : nullptr;
+    float* __restrict__ v = STEP ? a.v[t] + base : nullptr;
+    float* __restrict__ e = ((STEP && a.ema != nullptr) || MODE == CDX_OPT_EMA) ? a.ema[t] + base : nullptr;
 
     if (MODE == CDX_OPT_SUMSQ) {
         float s = 0.f;
@@ -80,16 +81,19 @@ __global__ __launch_bounds__(OPT_THREADS) void cdx_optim_kernel(cdx_optim_args a
         for (int i = threadIdx.x; i < len; i += OPT_THREADS) e[i] = e[i] * r + q * p[i];
         return;
     }
-    // ADAMW
+    // ADAMW (decoupled decay: p *= 1 - lr * wd) / ADAM (torch.optim.Adam's L2 form: g += wd * p, what the reference's classifiers
+    // train with -- classifier/base.py:24)
     const float clip = (a.max_norm > 0.f) ? a.norm[1] : 1.f;
-    const float decay = 1.f - a.lr * a.weight_decay;
+    const float decay = MODE == CDX_OPT_ADAM ? 1.f : 1.f - a.lr * a.weight_decay;
+    const float l2 = MODE == CDX_OPT_ADAM ? a.weight_decay : 0.f;
     const float w1 = 1.f - a.beta1, w2 = 1.f - a.beta2;
     const float r = a.ema_rate, q = 1.f - a.ema_rate;
     const bool vec = (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
                         reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(e)) & 15) == 0);
     auto one = [&](float pp, float gg, float& mm, float& vv) -> float {
         gg *= clip;
-        pp *= decay;
+        if (MODE == CDX_OPT_ADAM) gg = gg + l2 * pp;     // grad.add(param, alpha = weight_decay)
+        else pp *= decay;
         mm = mm + w1 * (gg - mm);                       // lerp_(grad, 1 - beta1), weight < 0.5 branch
         vv = vv * a.beta2 + w2 * gg * gg;               // mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
         const float denom = sqrtf(vv) / a.bc2_sqrt + a.eps;
@@ -163,6 +167,7 @@ extern "C" int cdx_optim_f32(const cdx_optim_args* a, void* hip_stream) {
     const dim3 grid(a->n_chunks), block(OPT_THREADS);
     switch (a->mode) {
     case CDX_OPT_ADAMW:
+    case CDX_OPT_ADAM:
         if (!a->p || !a->g || !a->m || !a->v || (a->max_norm > 0.f && !a->norm)) {
             cdx_set_error("cdx_optim_f32: AdamW needs the p / g / m / v tables (and norm when clipping): null pointer");
             return CDX_EINVAL;
@@ -171,7 +176,8 @@ extern "C" int cdx_optim_f32(const cdx_optim_args* a, void* hip_stream) {
             cdx_set_error("cdx_optim_f32: betas must lie in [0, 1) and bc2_sqrt must be positive");
             return CDX_EINVAL;
         }
-        hipLaunchKernelGGL(cdx_optim_kernel<CDX_OPT_ADAMW>, grid, block, 0, st, *a);
+        if (a->mode == CDX_OPT_ADAM) hipLaunchKernelGGL(cdx_optim_kernel<CDX_OPT_ADAM>, grid, block, 0, st, *a);
+        else hipLaunchKernelGGL(cdx_optim_kernel<CDX_OPT_ADAMW>, grid, block, 0, st, *a);
         break;
     case CDX_OPT_EMA:
         if (!a->p || !a->ema) {

@@ -82,7 +82,10 @@ class DiffusionModel:
             return loss
         loss = g.replay(x0, condition)
         if hasattr(self.optimizer, "_gver"):
-            self.optimizer._gver.clear()    # a replay writes the gradients without moving their version counters: they ARE written
+            # a replay writes gradients without moving their version counters: the ones the captured step writes ARE written (and only
+            # those: a parameter this step does not reach keeps its "untouched since zeroed" mark, as under eager autograd)
+            for p in g.written:
+                self.optimizer._gver.pop(id(p), None)
         return loss
 
     def _apply_gradients(self, update_ema: bool = True, zero_grad: bool = True):

@@ -24,7 +24,7 @@ import torch
 from . import runtime as R
 
 CHUNK = 4096                      # floats per workgroup (256 threads x 4 float4)
-OPT_ADAMW, OPT_EMA, OPT_SUMSQ, OPT_ZERO = 0, 1, 2, 3
+OPT_ADAMW, OPT_EMA, OPT_SUMSQ, OPT_ZERO, OPT_ADAM = 0, 1, 2, 3, 4
 
 
 class CdxOptimArgs(ctypes.Structure):
@@ -114,14 +114,15 @@ def ema_update_native(model: torch.nn.Module, model_ema: torch.nn.Module, rate: 
     return True
 
 
-class FusedAdamW(torch.optim.AdamW):
-    """``torch.optim.AdamW`` whose ``step`` runs as one multi-tensor gfx950 kernel when every parameter is an fp32 tensor on a ROCm
-    device (else: torch's own step).  Extra keyword arguments of ``step`` (all optional):
+class _FusedStep:
+    """The device-side ``step`` / ``zero_grad`` shared by ``FusedAdamW`` and ``FusedAdam`` (a mixin IN FRONT of the torch optimiser
+    class: ``super()`` calls reach torch's own methods).  Extra keyword arguments of ``step`` (all optional):
 
     ``max_norm``  -- clip the global gradient norm first (what ``clip_grad_norm_`` does); the norm lands in ``last_grad_norm``
     ``ema``       -- ``(model, model_ema, rate)``: fold the updated parameters into their EMA copies in the same pass
     ``zero_grad`` -- leave the gradients zeroed (the caller then skips ``zero_grad()``)
     """
+    _OPT_MODE = OPT_ADAMW
 
     def __init__(self, params, **kw):
         super().__init__(params, **kw)
@@ -158,6 +159,13 @@ class FusedAdamW(torch.optim.AdamW):
         return bool(ps) and all(native_device(p) and p.is_contiguous() and
                                 (p.grad is None or (not p.grad.is_sparse and p.grad.is_contiguous() and p.grad.dtype == torch.float32))
                                 for p in ps)
+
+    def _mode_of(self, group) -> int:
+        """Decoupled (AdamW) or L2 (Adam) decay: torch >= 2.6 carries it per group (``decoupled_weight_decay``), else the class says."""
+        dec = group.get("decoupled_weight_decay")
+        if dec is None:
+            return self._OPT_MODE
+        return OPT_ADAMW if dec else OPT_ADAM
 
     def native(self) -> bool:
         return all(self._native_group(g) for g in self.param_groups)
@@ -266,7 +274,7 @@ class FusedAdamW(torch.optim.AdamW):
                 tab = _table(self._tables, f"adamw{gi}/{bi}", lists, dev)
                 _call(CdxOptimArgs(p=tab.row(0), g=tab.row(1), m=tab.row(2), v=tab.row(3), ema=tab.row(4) if ema_of is not None else None,
                                    numel=tab.numel_ptr, chunks=tab.chunks.data_ptr(), n_tensors=tab.n_tensors, n_chunks=tab.n_chunks,
-                                   chunk_elems=CHUNK, mode=OPT_ADAMW, lr=float(group["lr"]), beta1=float(b1), beta2=float(b2),
+                                   chunk_elems=CHUNK, mode=self._mode_of(group), lr=float(group["lr"]), beta1=float(b1), beta2=float(b2),
                                    eps=float(group["eps"]), weight_decay=float(group["weight_decay"]),
                                    step_size=float(group["lr"]) / (1.0 - b1 ** t), bc2_sqrt=math.sqrt(1.0 - b2 ** t),
                                    ema_rate=float(rate), max_norm=clip, zero_grad=int(zero_grad), norm=self._norm.data_ptr()), dev)
@@ -288,3 +296,15 @@ class FusedAdamW(torch.optim.AdamW):
                                    n_chunks=tab.n_chunks, chunk_elems=CHUNK, mode=OPT_EMA, ema_rate=float(rate)), dev)
                 _bump_versions([e for _, e in rest])
         return loss
+
+
+class FusedAdamW(_FusedStep, torch.optim.AdamW):
+    """``torch.optim.AdamW`` (what ``DiffusionModel`` builds, reference diffusion/basic.py:66) whose ``step`` runs as one multi-tensor
+    gfx950 kernel when every parameter is an fp32 tensor on a ROCm device (else: torch's own step)."""
+    _OPT_MODE = OPT_ADAMW
+
+
+class FusedAdam(_FusedStep, torch.optim.Adam):
+    """``torch.optim.Adam`` -- L2 weight decay, the optimiser of the reference's classifiers (classifier/base.py:24: lr 2e-4, weight
+    decay 1e-4) -- on the same kernel (mode CDX_OPT_ADAM)."""
+    _OPT_MODE = OPT_ADAM

@@ -481,6 +481,49 @@ def janner_forward(net, x: torch.Tensor, noise: torch.Tensor, condition: Optiona
     return h.view(b, length, d)
 
 
+def supports_half_janner(net, x: torch.Tensor, condition=None) -> bool:
+    """HalfJannerUNet1d (GroupNorm) with fp32 parameters on a ROCm device, called with autograd on: the classifier's training forward
+    (``CumRewClassifier.update`` / ``update_classifier``, reference classifier/base.py:47-58, diffusionsde.py:143-149)."""
+    from ..nn_classifier.half_jannerunet import HalfJannerUNet1d
+    if not (enabled() and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and type(net) is HalfJannerUNet1d):
+        return False
+    if net.norm_type != "groupnorm" or net.kernel_size % 2 == 0 or net.kernel_size > 5 or x.dim() != 3 or x.shape[1] != net.horizon:
+        return False
+    if not _groupnorms_ok(net) or not _wants_grad(net, x, condition):
+        return False
+    length = net.horizon                       # the backward of a stride-2 conv is written for even input lengths (short horizons: ATen)
+    for down in [d for _, _, d in net.downs] + [net.mid_block1[1], net.mid_block2[1]]:
+        if not isinstance(down, nn.Identity):
+            if length % 2:
+                return False
+            length //= 2
+    return all(p.dtype == torch.float32 and p.is_cuda for p in net.parameters())
+
+
+@_with_weight_packs
+def half_janner_forward(net, x: torch.Tensor, noise: torch.Tensor, condition: Optional[torch.Tensor]) -> torch.Tensor:
+    """``HalfJannerUNet1d.forward`` (reference nn_classifier/half_jannerunet.py:52-63) with autograd, every convolution, GroupNorm and
+    Linear on the library's kernels.  x (b, H, D) -> (b, out_dim)."""
+    b, length, d = x.shape
+    emb = net.map_noise(noise)
+    if condition is not None:
+        emb = emb + condition
+    raw = _sequential(net.map_emb, emb.contiguous())       # the head concatenates map_emb's output as it is ...
+    memb = torch.nn.functional.mish(raw)                   # ... every block's emb_mlp starts with its Mish
+    h = x.reshape(b * length, d)
+    for res1, res2, down in net.downs:
+        h = _resblock(res2, _resblock(res1, h, memb, b, length), memb, b, length)
+        if not isinstance(down, nn.Identity):
+            h = _conv(h, down.conv, b, length)
+            length = (length - 1) // 2 + 1
+    for block, down in (net.mid_block1, net.mid_block2):
+        h = _conv(_resblock(block, h, memb, b, length), down.conv, b, length)
+        length = (length - 1) // 2 + 1
+    # x.flatten(1) of the reference's (b, C, L) layout: channel-major
+    flat = h.view(b, length, -1).permute(0, 2, 1).reshape(b, -1)
+    return _sequential(net.final_block, torch.cat([flat, raw], dim=-1))
+
+
 def supports_chi(net, x: torch.Tensor, condition=None) -> bool:
     """ChiUNet1d with a global condition (the dp_* configuration, BASELINE config 3) with fp32 parameters on a ROCm device, called
     with autograd on."""
@@ -1004,11 +1047,30 @@ class GraphedStep:
     Not captured: the optimiser step (its bias-correction scalars change per step and travel as kernel arguments), ``loss.item()``."""
 
     def __init__(self, agent, x0: torch.Tensor, condition: Optional[torch.Tensor], probe: bool = False):
+        """`agent`: anything with ``.model`` (the trained module) and ``.loss(x0, condition)``; `condition` may be a TUPLE of tensors --
+        the classifier step's (noise level, target) -- every member a static buffer."""
         dev = x0.device
         self.x0 = x0.detach().clone()
-        self.cond = None if condition is None else condition.detach().clone()
+        if isinstance(condition, tuple):
+            self.cond = tuple(c.detach().clone() for c in condition)
+        else:
+            self.cond = None if condition is None else condition.detach().clone()
         params = self.params = [p for p in agent.model.parameters() if p.requires_grad]
         had_grad = [p.grad is not None for p in params]
+        # gradients the caller accumulated BEFORE this first update() (an auxiliary loss.backward(), gradient accumulation): the reference's
+        # update() adds onto them, so the warm-up / capture below must hand them back exactly (ADVICE r5)
+        kept = [p.grad.detach().clone() if p.grad is not None else None for p in params]
+
+        def restore():
+            for p, had, g0 in zip(params, had_grad, kept):
+                if not had:
+                    p.grad = None
+                elif p.grad is not None:
+                    p.grad.copy_(g0)
+                else:
+                    p.grad = g0
+            torch.cuda.set_rng_state(rng, dev)
+            torch.set_rng_state(rng_cpu)
         # the warm-up steps below draw timesteps / noise like any step: put the generators back afterwards, so that the FIRST replay
         # consumes what the first eager step would have (a replay reads the generator's offset at replay time and advances it by what
         # the captured draws consume -- the same numbers an eager step draws from the same state)
@@ -1032,26 +1094,33 @@ class GraphedStep:
         except Exception as e:  # noqa: BLE001 -- whatever the probe step tripped over: this agent's step is not ours to capture
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
-            for p, had in zip(params, had_grad):       # nothing of the probe is part of any step
-                if not had:
-                    p.grad = None
-                elif p.grad is not None:
-                    p.grad.zero_()
-            torch.cuda.set_rng_state(rng, dev)
-            torch.set_rng_state(rng_cpu)
+            restore()                                  # nothing of the probe is part of any step
             raise NotCapturable(f"{type(e).__name__}: {e}") from e
         torch.cuda.current_stream(dev).wait_stream(side)
         for p in params:                               # the warm-up gradients are not part of any step
             if p.grad is not None:
                 p.grad.zero_()
+        # the parameters the step gives a gradient to: a replay marks THOSE as written for the optimiser, no others
+        self.written = [p for p in params if p.grad is not None]
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss = agent.loss(self.x0, self.cond)
-            with grads_in_place():                     # (the captured launches add into the static .grad tensors directly)
-                self.loss.backward()
-        for p in params:                               # (capture does not run the kernels; keep the grads as the warm-up left them: zero)
+        try:
+            # (thread-local error mode: a CUDA call from ANOTHER thread -- a DataLoader's pin_memory thread -- does not fail the capture)
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self.loss = agent.loss(self.x0, self.cond)
+                with grads_in_place():                 # (the captured launches add into the static .grad tensors directly)
+                    self.loss.backward()
+        except Exception as e:  # noqa: BLE001 -- something the probe did not see (it is a prototype check, and blind to pageable H2D copies)
+            # torch.cuda.graph's exit has ended the capture; whatever half-built graph exists is dropped, the eager step serves this agent
+            self.graph = None
+            torch.cuda.synchronize(dev)
+            restore()
+            raise NotCapturable(f"capture failed: {type(e).__name__}: {e}") from e
+        for p, g0 in zip(params, kept):                # (capture does not run the kernels) back to what the caller had: zero or its own sums
             if p.grad is not None:
-                p.grad.zero_()
+                if g0 is not None:
+                    p.grad.copy_(g0)
+                else:
+                    p.grad.zero_()
         torch.cuda.set_rng_state(rng, dev)
         torch.set_rng_state(rng_cpu)
         self.sig = self._signature()
@@ -1067,7 +1136,10 @@ class GraphedStep:
 
     def replay(self, x0, condition):
         self.x0.copy_(x0)
-        if self.cond is not None:
+        if isinstance(self.cond, tuple):
+            for dst, src in zip(self.cond, condition):
+                dst.copy_(src)
+        elif self.cond is not None:
             self.cond.copy_(condition)
         self.graph.replay()
         return self.loss
@@ -1112,6 +1184,46 @@ def graphed_step(agent, x0, condition, kwargs) -> Optional[GraphedStep]:
             g = cache[key] = GraphedStep(agent, x0, condition, probe=(mode != "1"))
         except NotCapturable as e:
             agent.__dict__["_cdx_graph_off"] = str(e)  # (kept for diagnostics: why this agent steps eagerly)
+            cache.pop(key, None)
+            return None
+    return g
+
+
+class _ClassifierStep:
+    """``loss = classifier.loss(x, noise, y)`` in the shape GraphedStep captures: ``.model`` and ``.loss(x0, (noise, y))``."""
+
+    def __init__(self, clf):
+        self.clf, self.model = clf, clf.model
+
+    def loss(self, x, cond):
+        return self.clf.loss(x, cond[0], cond[1])
+
+
+def graphed_classifier_step(clf, x, noise, y) -> Optional[GraphedStep]:
+    """The cached GraphedStep of a classifier's ``loss(x, noise, y); backward()`` (``BaseClassifier.update``), or None (the eager pair):
+    same rules as `graphed_step` -- a HalfJannerUNet1d on a ROCm device, tensors for all three inputs, a first step that passes the
+    capturability probe (CDX_TRAIN_GRAPH: "auto" / "1" / "0")."""
+    mode = os.environ.get("CDX_TRAIN_GRAPH", "auto")
+    if mode == "0" or not all(torch.is_tensor(t) and t.is_cuda and t.device == x.device for t in (x, noise, y)) or \
+            not torch.is_grad_enabled() or torch.cuda.is_current_stream_capturing() or clf.__dict__.get("_cdx_graph_off"):
+        return None
+    if not supports_half_janner(clf.model, x, None):
+        return None
+    key = (tuple(x.shape), tuple(noise.shape), noise.dtype, tuple(y.shape), clf.model.training)
+    cache = clf.__dict__.setdefault("_cdx_graphed", {})
+    g = cache.get(key)
+    if g is not None and not g.valid():
+        clf._cdx_recaptures = getattr(clf, "_cdx_recaptures", 0) + 1
+        g = cache[key] = None
+    if getattr(clf, "_cdx_recaptures", 0) > RECAPTURE_LIMIT:
+        return None
+    if g is None:
+        if key not in cache and len(cache) >= SHAPE_LIMIT:
+            return None
+        try:
+            g = cache[key] = GraphedStep(_ClassifierStep(clf), x, (noise, y), probe=(mode != "1"))
+        except NotCapturable as e:
+            clf.__dict__["_cdx_graph_off"] = str(e)
             cache.pop(key, None)
             return None
     return g

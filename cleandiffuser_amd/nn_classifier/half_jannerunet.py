@@ -3,8 +3,9 @@ classifier (reference nn_classifier/half_jannerunet.py:11-125).  Same parameter 
 ``mid_block{1,2}.{0,1}``, ``final_block.{0,2}``) so reference classifier checkpoints load unchanged.
 
 On a ROCm device with gradients off the forward (the ``log_p`` every ``sample()`` call ends with, reference
-diffusionsde.py:597-601) is one launch of the same program kernel as the denoiser; per-step classifier *guidance*
-needs d logp / dx and stays on PyTorch autograd.
+diffusionsde.py:597-601) is one launch of the same program kernel as the denoiser, per-step classifier *guidance* (d logp / dx) runs
+inside the guided launch (engine/guided.py), and with autograd ON -- the classifier's own ``loss()`` / ``update()`` -- every
+convolution, GroupNorm and Linear node is a library kernel forward and backward (engine/train.py:half_janner_forward).
 """
 from typing import Optional, Tuple
 
@@ -62,6 +63,9 @@ class HalfJannerUNet1d(BaseNNDiffusion):
         return self.final_block(torch.cat([x.flatten(1), emb], dim=-1))
 
     def forward(self, x: torch.Tensor, noise: torch.Tensor, condition: Optional[torch.Tensor] = None):
-        from ..engine import dispatch
+        from ..engine import dispatch, train
+        if train.supports_half_janner(self, x, condition):
+            # autograd on, ROCm device (the classifier's loss() / update()): the same graph on the library's conv / GroupNorm / Linear nodes
+            return train.half_janner_forward(self, x, noise, condition)
         y = dispatch.try_backbone_forward(self, x, noise, condition)
         return y if y is not None else self._forward_torch(x, noise, condition)

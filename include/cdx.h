@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define CDX_ABI_VERSION 15
+#define CDX_ABI_VERSION 16
 
 #define CDX_OK 0
 #define CDX_EINVAL (-1)   /* bad argument (null pointer, size out of range, misaligned offset) */
@@ -725,6 +725,8 @@ int cdx_resmlp_run(const cdx_resmlp_weights* w, const cdx_sampling* s, void* hip
 #define CDX_OPT_EMA 1     /* ema = ema_rate*ema + (1-ema_rate)*p */
 #define CDX_OPT_SUMSQ 2   /* norm[0] = sqrt(sum g^2) (fixed-order reduction), norm[1] = min(1, max_norm/(norm[0]+1e-6)) (1 if max_norm <= 0) */
 #define CDX_OPT_ZERO 3    /* g = 0 */
+#define CDX_OPT_ADAM 4    /* ABI 16: as CDX_OPT_ADAMW with torch.optim.Adam's L2 decay -- g = g*clip + wd*p, no decoupled decay -- the optimiser of
+                           * the reference's classifiers (classifier/base.py:24) */
 typedef struct cdx_optim_args {
     float* const* p;          /* device [n_tensors]: parameters */
     float* const* g;          /* device [n_tensors]: gradients */

@@ -190,12 +190,38 @@ def sfbc():
     return run
 
 
+def classifier_cumrew(horizon: int, model_dim: int, batch: int, lr: float = 3e-3):
+    """``CumRewClassifier(HalfJannerUNet1d).update`` -- the half of every Diffuser training iteration next to ``update()`` (reference
+    pipelines/diffuser_d4rl_mujoco.py:88-91 -> diffusionsde.py:143-149 -> classifier/base.py:47-58, rew_classifiers.py:16-24): MSE on
+    the return target, torch.optim.Adam (lr 2e-4, L2 weight decay 1e-4), EMA 0.995.  Records as the solver scenarios do: one loss
+    value, three updates, parameter / EMA checksums (``grad_norm``: zeros -- the class clips nothing)."""
+    def run(lib, kind, device):
+        net = load_synth(lib.HalfJannerUNet1d(horizon, 6, out_dim=1, kernel_size=3, model_dim=model_dim, emb_dim=model_dim,
+                                              dim_mult=(1, 2, 2)), 71)
+        clf = lib.CumRewClassifier(net, device=device, optim_params={"lr": lr, "weight_decay": 1e-2})     # (steps large enough to resolve)
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(batch, horizon, 6, generator=g).to(device)
+        t = torch.randint(0, 50, (batch,), generator=g).to(device)
+        r = torch.randn(batch, 1, generator=g).to(device)
+        clf.train()
+        out = {"loss": clf.loss(x, t, r).detach().reshape(1)}
+        out["upd_loss"] = torch.tensor([float(clf.update(x, t, r)["loss"]) for _ in range(3)])
+        out["grad_norm"] = torch.zeros(3)
+        for tag, mod in (("p", clf.model), ("ema", clf.model_ema)):
+            ps = list(mod.parameters())
+            out[tag + "_head"] = ps[0].detach().reshape(-1)[:16].clone()
+            out[tag + "_abs"] = torch.stack([p.detach().abs().sum() for p in ps]).sum().reshape(1)
+        return out
+    return run
+
+
 HEAVY = {"chiunet_cfg3", "dit_cfg4"}          # minutes of CPU work: fixture from the real reference, checked on the device only
 
 SCENARIOS: Dict[str, Callable] = {
     "chiunet_ddpm": chiunet(32, 5), "chiunet_cfg3": chiunet(256, 4), "dit_small": dit(64, 4, 16, 5), "dit_cfg4": dit(320, 10, 64, 4),
     "chitf_small": chitf(64, 4, 2, 2, 6, 3, 5), "chitf_pusht": chitf(256, 4, 8, 0, 10, 2, 6), "sfbc_continuous": sfbc(),
     "discrete_eps": discrete(True), "discrete_x0": discrete(False), "continuous_eps": continuous(),
+    "classifier_cumrew": classifier_cumrew(16, 16, 6), "classifier_cfg2": classifier_cumrew(32, 32, 8, lr=5e-4),
     "edm_conditional": edm_conditional(0.1), "edm_conditional_nodrop": edm_conditional(0.0), "legacy_ddpm": legacy_ddpm(), "weighted_regression": weighted_regression(),
 }
 

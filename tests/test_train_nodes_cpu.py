@@ -41,7 +41,18 @@ def _case(name):
     if name == "sfbc":
         net = load_synth(N.SfBCUNet(5, emb_dim=16, hidden_dims=[64, 32, 16]), 11)
         return net, train.sfbc_forward, (torch.randn(6, 5, generator=g), torch.rand(6, generator=g), torch.randn(6, 16, generator=g))
+    if name == "half_janner":
+        from cleandiffuser_amd.nn_classifier import HalfJannerUNet1d
+        net = load_synth(HalfJannerUNet1d(16, 6, out_dim=1, kernel_size=3, model_dim=16, emb_dim=16, dim_mult=(1, 2, 2)), 12)
+        return net, train.half_janner_forward, (torch.randn(5, 16, 6, generator=g), torch.randint(0, 20, (5,), generator=g), None)
     raise KeyError(name)
+
+
+def _wgt(net, args, seed):
+    """Weights of the scalar the tests differentiate: one per OUTPUT element (the classifier maps (b, H, D) to (b, out_dim))."""
+    with torch.no_grad():
+        shape = (net._forward_torch(*args) if hasattr(net, "_forward_torch") else net(*args)).shape
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed))
 
 
 def _grads(net):
@@ -67,14 +78,14 @@ def _close(got, want, what, tol=2e-5):
     assert float((got - want).abs().max()) <= tol * sc + 1e-7, (what, float((got - want).abs().max()), sc)
 
 
-CASES = ["janner", "janner_cond", "chiunet", "dit", "idql", "chitf", "dql", "pearce", "sfbc"]
+CASES = ["janner", "janner_cond", "chiunet", "dit", "idql", "chitf", "dql", "pearce", "sfbc", "half_janner"]
 
 
 @pytest.mark.parametrize("name", CASES)
 def test_native_training_forward_is_the_modules_autograd_graph(name):
     net, fwd, args = _case(name)
     net.train()
-    wgt = torch.randn(args[0].shape, generator=torch.Generator().manual_seed(1))
+    wgt = _wgt(net, args, 1)
     y0, gx0, gp0 = _reference(net, args, wgt)
     with emulated():
         for in_place in (False, True):
