@@ -310,6 +310,8 @@ def baseline_config(which: str, batch: int, variant: str = ""):
             agent = lib.ContinuousEDM(net, None, device=device)
             agent.eval()
             zs = [torch.randn(B, D, generator=g)]
+            if _ROWS is not None:                # (the fixture of a batch the CPU cannot afford: samples are independent, newedm.py:286-438)
+                zs, B = [z[_ROWS] for z in zs], len(_ROWS)
             x, _ = _sample(agent, kind, torch.zeros(B, D, device=device), zs, solver="euler", n_samples=B, sample_steps=128)
         return {"x": x}
     return run
@@ -330,7 +332,12 @@ GPU_ONLY: Dict[str, Callable] = {
     "baseline_cfg5_b300": baseline_config("cfg5", 300), "baseline_cfg5_d27_b300": baseline_config("cfg5", 300, "d27"),
     # round 5: config 4 at its EXACT per-GPU shard (B = 4096 over 8 GPUs -> 512 trajectories = 65 536 token rows with the CFG pair)
     "baseline_cfg4_tied_b512": baseline_config("cfg4", 512, "tied"),
+    # round 6: config 5 ACROSS the executor's real chunk boundary -- cdx_resmlp_run cuts a call into 16 384-row chunks (what one rank of
+    # the 8-GPU run does eight times per call); the fixture holds the reference's result for the rows either side of the cut
+    "baseline_cfg5_b16684": baseline_config("cfg5", 16384 + 300),
 }
+# Fixtures of these scenarios hold the listed ROWS only (the reference sampled just those: samples are independent; the device run is the whole batch)
+ROW_SUBSET = {"baseline_cfg5_b16684": [0, 1, 255, 256, 8191, 16382, 16383, 16384, 16385, 16511, 16512, 16683]}
 # Fixtures of these scenarios keep every STRIDE-th trajectory only (trajectories are independent; the device run is the whole batch)
 SUBSAMPLED = {"baseline_cfg4_tied_b512": 4}
 

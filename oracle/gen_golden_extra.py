@@ -61,8 +61,11 @@ def main(out_dir="tests/golden", only=None):
     for name in list(extra_cases.SCENARIOS) + list(extra_cases.GPU_ONLY):
         if only and name not in only:
             continue
-        out = {k: v.detach().cpu().numpy().astype(np.float32) for k, v in extra_cases.run(name, "reference").items()
+        rows = extra_cases.ROW_SUBSET.get(name)
+        out = {k: v.detach().cpu().numpy().astype(np.float32) for k, v in extra_cases.run(name, "reference", rows=rows).items()
                if not k.startswith("_")}
+        if rows is not None:
+            out["rows"] = np.asarray(rows, np.int32)
         assert all(np.isfinite(v).all() for v in out.values()), name
         if name in extra_cases.SUBSAMPLED:               # every stride-th trajectory (+ the stride itself)
             st = extra_cases.SUBSAMPLED[name]

@@ -155,6 +155,36 @@ def cfgU(B=256, native_backward=None, graph=False):
     return f"config 2 update(): JannerUNet1d H=32 D=23, batch {B}, loss + backward + clip + AdamW + EMA", call, B
 
 
+def cfgUC(B=256, native_backward=None, graph=False):
+    """One Diffuser TRAINING ITERATION at config-2 size (reference pipelines/diffuser_d4rl_mujoco.py:88-91): ``agent.update(x0)`` of the
+    denoiser next to ``agent.update_classifier(x0, R)`` of the CumRewClassifier(HalfJannerUNet1d) on the same batch.  Returns
+    (label, call, B, macs): `macs` = multiply-adds of ONE forward of denoiser + classifier per trajectory (a step is ~3x that)."""
+    from cleandiffuser_amd.classifier import CumRewClassifier
+    from cleandiffuser_amd.engine import program2
+    from cleandiffuser_amd.nn_classifier import HalfJannerUNet1d
+    from cleandiffuser_amd.nn_diffusion import JannerUNet1d
+    H, D = 32, 23
+    net = load_synth(JannerUNet1d(D, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2, 2], kernel_size=5))
+    cnet = load_synth(HalfJannerUNet1d(H, D, out_dim=1, kernel_size=3, model_dim=32, emb_dim=32, dim_mult=(1, 2, 2, 2)), 1)
+    if native_backward is not None:
+        os.environ["CDX_TRAIN_NATIVE"] = "1" if native_backward else "0"
+    os.environ["CDX_TRAIN_GRAPH"] = "auto" if graph else "0"
+    macs = program2.compile_janner2(net, H, nw=8).macs_per_forward + program2.compile_classifier2(cnet, H).macs_per_forward
+    fix = torch.zeros(H, D)
+    fix[0, :17] = 1.0
+    clf = CumRewClassifier(cnet, device=DEV)
+    if native_backward is False:                           # the stock sequence: autograd over ATen kernels, torch.optim.Adam
+        clf.optim = torch.optim.Adam(clf.model.parameters(), lr=2e-4, weight_decay=1e-4)
+    agent = DiscreteDiffusionSDE(net, None, fix_mask=fix, classifier=clf, diffusion_steps=20, predict_noise=False, grad_clip_norm=1.0, device=DEV)
+    x0, ret = torch.randn(B, H, D, device=DEV), torch.randn(B, 1, device=DEV)
+
+    def call():
+        loss = agent.update(x0)["loss"]
+        agent.update_classifier(x0, ret)
+        return torch.as_tensor(loss)
+    return f"Diffuser training iteration at config-2 size: update() + update_classifier(), batch {B}", call, B, macs
+
+
 def cfgD(B=64, steps=200_000, resident=True):
     """Batch supply of the Diffuser training loop (row f4, third slice): a hopper-sized synthetic D4RL dictionary (o = 11, a = 3), H = 32
     windows, batch B.  resident: D4RLMuJoCoDataset.loader (buffers in HBM, one gather launch per batch); else the reference's way --
