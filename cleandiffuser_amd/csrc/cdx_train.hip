@@ -50,13 +50,13 @@ __device__ __forceinline__ float4 wg_load4(const float* __restrict__ p, long row
     return v;
 }
 
-__global__ __launch_bounds__(256) void cdx_conv_wgrad_kernel(const cdx_wgrad_args g) {
+// one workgroup: output tile `tile` (64 x 64 of ca x cb), tap `tap`, row slice `slice` of product g
+__device__ __forceinline__ void wgrad_tile(const cdx_wgrad_args& g, int tile, int tap, int slice) {
     __shared__ __attribute__((aligned(16))) float Ps[2][WG_BK][WG_LD];
     __shared__ __attribute__((aligned(16))) float Qs[2][WG_BK][WG_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_tb = (g.cb + WG_T - 1) / WG_T;
-    const int a0 = (blockIdx.x / n_tb) * WG_T, b0 = (blockIdx.x % n_tb) * WG_T;
-    const int tap = blockIdx.y, slice = blockIdx.z;
+    const int a0 = (tile / n_tb) * WG_T, b0 = (tile % n_tb) * WG_T;
     const long R = (long)g.batch * g.l_p;
     const int n_chunks = (int)((R + WG_BK - 1) / WG_BK);
     const int per = (n_chunks + g.k_split - 1) / g.k_split;
@@ -118,6 +118,21 @@ __global__ __launch_bounds__(256) void cdx_conv_wgrad_kernel(const cdx_wgrad_arg
             atomicAdd(g.db + a0 + tid, t);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void cdx_conv_wgrad_kernel(const cdx_wgrad_args g) {
+    wgrad_tile(g, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
+// the products of many layers in one launch: the job table is the kernel argument (scalar loads at a wave-uniform index)
+__global__ __launch_bounds__(256) void cdx_conv_wgrad_batch_kernel(const cdx_wgrad_batch B) {
+    int j = 0;
+    while (j + 1 < B.n_jobs && (int)blockIdx.x >= B.wg_start[j + 1]) ++j;
+    const cdx_wgrad_args g = B.job[j];
+    const int local = (int)blockIdx.x - B.wg_start[j];
+    const int n_tiles = ((g.ca + WG_T - 1) / WG_T) * ((g.cb + WG_T - 1) / WG_T);
+    const int rest = local / n_tiles;
+    wgrad_tile(g, local - rest * n_tiles, rest % g.taps, rest / g.taps);
 }
 
 // out[c] += sum_r x[r][c]: 64 columns x 64 rows per workgroup
@@ -469,6 +484,27 @@ int cdx_attention_bwd_f32(const cdx_attn_bwd_args* a, void* hip_stream) {
 
 int cdx_mha_train_fwd_f32(const cdx_mha_train_args* a, void* hip_stream) { return mha_train_launch(a, false, hip_stream, "cdx_mha_train_fwd_f32"); }
 int cdx_mha_train_bwd_f32(const cdx_mha_train_args* a, void* hip_stream) { return mha_train_launch(a, true, hip_stream, "cdx_mha_train_bwd_f32"); }
+
+int cdx_conv_wgrad_batch_f32(const cdx_wgrad_batch* b, void* hip_stream) {
+    cdx_set_err("");
+    if (!b) { cdx_set_err("cdx_conv_wgrad_batch_f32: null pointer"); return CDX_EINVAL; }
+    if (b->n_jobs == 0) return CDX_OK;
+    if (b->n_jobs < 0 || b->n_jobs > CDX_WGRAD_BATCH || b->wg_start[0] != 0) { cdx_set_err("cdx_conv_wgrad_batch_f32: 1 .. CDX_WGRAD_BATCH jobs, wg_start[0] == 0"); return CDX_EINVAL; }
+    for (int j = 0; j < b->n_jobs; ++j) {
+        const cdx_wgrad_args* a = &b->job[j];
+        if (!a->p || !a->q || !a->dw) { cdx_set_err("cdx_conv_wgrad_batch_f32: null pointer in a job"); return CDX_EINVAL; }
+        if (a->batch <= 0 || a->l_p <= 0 || a->l_q <= 0 || a->ca <= 0 || a->cb <= 0 || a->taps <= 0 || a->taps > 16 || a->stride <= 0 || a->pad < 0 ||
+            a->ldp < a->ca || a->ldq < a->cb || a->k_split < 1) {
+            cdx_set_err("cdx_conv_wgrad_batch_f32: bad shape in a job (k_split >= 1 is the caller's here)"); return CDX_EINVAL;
+        }
+        const long wgs = (long)((a->ca + WG_T - 1) / WG_T) * ((a->cb + WG_T - 1) / WG_T) * a->taps * a->k_split;
+        if (b->wg_start[j + 1] - b->wg_start[j] != wgs) { cdx_set_err("cdx_conv_wgrad_batch_f32: wg_start does not match the jobs' tile counts"); return CDX_EINVAL; }
+    }
+    hipLaunchKernelGGL(cdx_conv_wgrad_batch_kernel, dim3(b->wg_start[b->n_jobs]), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), *b);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
+    return CDX_OK;
+}
 
 int cdx_conv_wgrad_f32(const cdx_wgrad_args* a, void* hip_stream) {
     cdx_set_err("");

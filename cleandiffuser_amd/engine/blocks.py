@@ -2,6 +2,7 @@
 cdx_attention_f32, cdx_act_f32).  Every tensor crosses as a raw device pointer; outputs are caller-allocated.
 These are used when M = batch x tokens >> 256 (DiT1d, wide MLPs), where the layers are classic GEMMs."""
 import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -36,6 +37,13 @@ class CdxWgradArgs(ctypes.Structure):
     _fields_ = [("p", ctypes.c_void_p), ("q", ctypes.c_void_p), ("dw", ctypes.c_void_p)] + \
                [(n, ctypes.c_int32) for n in ("batch", "l_p", "l_q", "ca", "cb", "taps", "stride", "pad", "ldp", "ldq", "k_split")] + \
                [("db", ctypes.c_void_p)]
+
+
+WGRAD_BATCH = 32
+
+
+class CdxWgradBatch(ctypes.Structure):
+    _fields_ = [("n_jobs", ctypes.c_int32), ("wg_start", ctypes.c_int32 * (WGRAD_BATCH + 1)), ("job", CdxWgradArgs * WGRAD_BATCH)]
 
 
 class CdxRelayoutJob(ctypes.Structure):
@@ -115,6 +123,8 @@ def _lib():
         lib.cdx_act_bwd_f32.restype = ctypes.c_int
         lib.cdx_conv_wgrad_f32.argtypes = [ctypes.POINTER(CdxWgradArgs), ctypes.c_void_p]
         lib.cdx_conv_wgrad_f32.restype = ctypes.c_int
+        lib.cdx_conv_wgrad_batch_f32.argtypes = [ctypes.POINTER(CdxWgradBatch), ctypes.c_void_p]
+        lib.cdx_conv_wgrad_batch_f32.restype = ctypes.c_int
         lib.cdx_colsum_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
         lib.cdx_colsum_f32.restype = ctypes.c_int
         lib.cdx_layernorm_bwd_f32.argtypes = [ctypes.POINTER(CdxLnBwdArgs), ctypes.c_void_p]
@@ -339,6 +349,42 @@ def conv_wgrad(p: torch.Tensor, q: torch.Tensor, batch: int, l_p: int, l_q: int,
                      stride=stride, pad=pad, ldp=_rows(p), ldq=_rows(q), k_split=k_split, db=_p(db))
     _check(_lib().cdx_conv_wgrad_f32(ctypes.byref(a), _stream_ptr(p.device)), "cdx_conv_wgrad_f32")
     return (dw, db) if bias_grad else dw
+
+
+# workgroups a queued product is cut into (tiles x taps x row slices), at least WGRAD_MIN_CHUNKS 16-row chunks each (tuning hooks:
+# CDX_WGRAD_JOB_WGS / CDX_WGRAD_BATCH_MIN_CHUNKS; sweep in profiles/r06_wgrad_batch_ab.txt)
+# measured on MI355X (update() as a HIP graph, ms for configs 2 / 3 / 4): 384 workgroups x >= 8 chunks 3.35 / 9.48 / 2.33; 128 x 16: 3.12 / 9.29 /
+# 2.40; 64 x 16: 3.07 / 9.48 / 2.49 -- convolutions (taps > 1) take 128, Linears (one tap, wide tiles: the transformers) 384
+WGRAD_JOB_WGS = int(os.environ.get("CDX_WGRAD_JOB_WGS", "0"))
+WGRAD_MIN_CHUNKS = int(os.environ.get("CDX_WGRAD_BATCH_MIN_CHUNKS", "16"))
+
+
+def conv_wgrad_batch(jobs) -> int:
+    """The weight-gradient products ``(p, q, batch, l_p, l_q, taps, stride, pad, dw_out, db_out | None)`` of many layers, ADDED into
+    their ``dw_out`` / ``db_out`` tensors (parameters' ``.grad``) by ceil(n / 32) launches of ``cdx_conv_wgrad_batch_f32``.  Each
+    product is cut into ~WGRAD_JOB_WGS workgroups: big layers get few, long row slices (every slice ends in one float atomic per
+    output element), small layers many.  -> launches issued."""
+    n_launch = 0
+    for lo in range(0, len(jobs), WGRAD_BATCH):
+        part = jobs[lo:lo + WGRAD_BATCH]
+        b = CdxWgradBatch()
+        b.n_jobs = len(part)
+        start = 0
+        for j, (p, q, batch, l_p, l_q, taps, stride, pad, dw, db) in enumerate(part):
+            ca, cb = p.shape[1], q.shape[1]
+            assert p.shape[0] == batch * l_p and q.shape[0] == batch * l_q and dw.is_contiguous() and dw.numel() == ca * cb * taps
+            tiles = -(-ca // 64) * -(-cb // 64) * taps
+            chunks = -(-(batch * l_p) // 16)
+            target = WGRAD_JOB_WGS or (128 if taps > 1 else 384)
+            ks = max(1, min(chunks // WGRAD_MIN_CHUNKS, -(-target // tiles)))
+            b.wg_start[j] = start
+            start += tiles * ks
+            b.job[j] = CdxWgradArgs(p=p.data_ptr(), q=q.data_ptr(), dw=dw.data_ptr(), batch=batch, l_p=l_p, l_q=l_q, ca=ca, cb=cb, taps=taps,
+                                    stride=stride, pad=pad, ldp=_rows(p), ldq=_rows(q), k_split=ks, db=_p(db))
+        b.wg_start[len(part)] = start
+        _check(_lib().cdx_conv_wgrad_batch_f32(ctypes.byref(b), _stream_ptr(part[0][0].device)), "cdx_conv_wgrad_batch_f32")
+        n_launch += 1
+    return n_launch
 
 
 def layernorm(x: torch.Tensor, out: Optional[torch.Tensor] = None, gamma=None, beta=None, scale=None, shift=None,

@@ -113,6 +113,33 @@ def _written(*grads):
         torch.autograd.graph.increment_version(gs)
 
 
+# The weight-gradient products of a step are independent of everything downstream of them (they only ADD into ``.grad``): inside
+# update()'s backward they are QUEUED by the nodes and issued when the backward pass ends, all layers in ceil(n / 32) launches of
+# cdx_conv_wgrad_batch_f32 -- round 5 issued 65 launches of 4-20 us each, 38 % of a config-2 step's device time at 3.8 % of the
+# matrix pipe's peak, none of them able to fill the chip.  CDX_TRAIN_WGRAD_BATCH=0: one launch per layer as before.
+_wgrad_queue: list = []
+
+
+def _flush_wgrads():
+    jobs = list(_wgrad_queue)
+    _wgrad_queue.clear()
+    if jobs:
+        blocks.conv_wgrad_batch(jobs)
+
+
+def _queue_wgrad(job) -> bool:
+    if _in_place_depth <= 0 or os.environ.get("CDX_TRAIN_WGRAD_BATCH", "1") == "0":
+        return False
+    try:
+        if not _wgrad_queue:
+            # (runs when this backward pass ends, on the stream it was called on -- what DDP's reducer relies on too)
+            torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrads)
+    except RuntimeError:
+        return False                                       # not inside a backward pass (a node called by hand): launch now
+    _wgrad_queue.append(job)
+    return True
+
+
 def _weight_grads(p_rows, q_rows, batch, l_p, l_q, taps, stride, pad, w_param, b_param, want_dw: bool, want_db: bool, bias_rows=None):
     """(dw, db) of a Conv1d / ConvTranspose1d / Linear for autograd -- each None when not wanted OR when it was added straight into
     the parameter's ``.grad`` (grads_in_place).  `bias_rows`: the matrix whose column sums are db when it is not `p_rows` (transposed
@@ -122,7 +149,8 @@ def _weight_grads(p_rows, q_rows, batch, l_p, l_q, taps, stride, pad, w_param, b
     if want_dw:
         sw, sb = _grad_slot(w_param), (_grad_slot(b_param) if fused_db else None)
         if sw is not None and (not fused_db or sb is not None):
-            blocks.conv_wgrad(p_rows, q_rows, batch, l_p, l_q, taps, stride, pad, bias_grad=fused_db, dw_out=sw, db_out=sb)
+            if not _queue_wgrad((p_rows, q_rows, batch, l_p, l_q, taps, stride, pad, sw, sb)):
+                blocks.conv_wgrad(p_rows, q_rows, batch, l_p, l_q, taps, stride, pad, bias_grad=fused_db, dw_out=sw, db_out=sb)
             _written(sw, sb)
         else:
             dw = blocks.conv_wgrad(p_rows, q_rows, batch, l_p, l_q, taps, stride, pad, bias_grad=fused_db)

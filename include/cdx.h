@@ -323,6 +323,18 @@ typedef struct cdx_wgrad_args {
                             * (p = d loss / d y) out of the same launch */
 } cdx_wgrad_args;
 int cdx_conv_wgrad_f32(const cdx_wgrad_args* args, void* hip_stream);
+/* ABI 16: up to CDX_WGRAD_BATCH weight-gradient products in ONE launch (the job table travels as the kernel argument: nothing to
+ * upload, capturable as it is).  job[j].k_split >= 1 is the caller's (rows per slice vs float atomics per output element);
+ * wg_start[j] = first workgroup of job j, wg_start[n_jobs] = the grid: job j owns ceil(ca / 64) * ceil(cb / 64) * taps * k_split of them.
+ * A training step queues the products of all its layers and issues them here (engine/train.py): 65 launches of 4-20 us each -- 38 % of a
+ * config-2 update() in round 5 -- become three. */
+#define CDX_WGRAD_BATCH 32
+typedef struct cdx_wgrad_batch {
+    int32_t n_jobs;
+    int32_t wg_start[CDX_WGRAD_BATCH + 1];
+    cdx_wgrad_args job[CDX_WGRAD_BATCH];
+} cdx_wgrad_batch;
+int cdx_conv_wgrad_batch_f32(const cdx_wgrad_batch* batch, void* hip_stream);
 /* out[c] += sum_r x[r][c] (rows x cols, row stride ld); `out` zeroed by the caller (bias gradients, GroupNorm parameter gradients). */
 int cdx_colsum_f32(const float* x, float* out, long long rows, int32_t cols, int32_t ld, void* hip_stream);
 

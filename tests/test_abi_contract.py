@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported(lib):
                           "cdx_chiunet_workspace_floats", "cdx_groupnorm_f32", "cdx_groupnorm_bwd_f32", "cdx_hjgrad_run",
                           "cdx_hjgrad_workspace_floats", "cdx_guided_run", "cdx_guided_workspace_floats", "cdx_unet2_run",
                           "cdx_unet2_embtab", "cdx_optim_f32", "cdx_pearcetf_run", "cdx_pearcetf_workspace_floats", "cdx_act_bwd_f32", "cdx_linattn_f32",
-                          "cdx_conv_wgrad_f32", "cdx_colsum_f32", "cdx_device_query", "cdx_layernorm_bwd_f32",
+                          "cdx_conv_wgrad_f32", "cdx_conv_wgrad_batch_f32", "cdx_colsum_f32", "cdx_device_query", "cdx_layernorm_bwd_f32",
                           "cdx_attention_bwd_f32", "cdx_mha_train_fwd_f32", "cdx_mha_train_bwd_f32", "cdx_relayout_f32"}
     for n in names:
         assert hasattr(lib, n), f"{n} declared in cdx.h but not exported by libcdx.so"
@@ -52,7 +52,7 @@ def test_ctypes_mirrors_have_c_layout(tmp_path):
                "cdx_chitf_layer": bigbatch.CdxChitfLayer, "cdx_chitf_weights": bigbatch.CdxChitfWeights,
                "cdx_xattn_args": blocks.CdxXattnArgs, "cdx_gn_args": blocks.CdxGnArgs,
                "cdx_chiunet_block": bigbatch.CdxChiUNetBlock, "cdx_chiunet_weights": bigbatch.CdxChiUNetWeights,
-               "cdx_unet_attn": bigbatch.CdxUnetAttn, "cdx_wgrad_args": blocks.CdxWgradArgs,
+               "cdx_unet_attn": bigbatch.CdxUnetAttn, "cdx_wgrad_args": blocks.CdxWgradArgs, "cdx_wgrad_batch": blocks.CdxWgradBatch,
                "cdx_gather_args": blocks.CdxGatherArgs, "cdx_gather_field": blocks.CdxGatherField,
                "cdx_device_props": runtime2.CdxDeviceProps, "cdx_ln_bwd_args": blocks.CdxLnBwdArgs, "cdx_attn_bwd_args": blocks.CdxAttnBwdArgs,
                "cdx_mha_train_args": blocks.CdxMhaTrainArgs, "cdx_relayout_job": blocks.CdxRelayoutJob}

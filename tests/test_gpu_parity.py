@@ -1927,7 +1927,9 @@ def test_update_runs_without_aten_conv_or_groupnorm_kernels(amd_lib):
     names = [e.key for e in prof.key_averages()]
     bad = [n for n in names if any(w in n.lower() for w in ("convolution", "conv1d", "conv_transpose", "miopen", "group_norm", "native_batch_norm"))]
     assert not bad, f"ATen convolution / group_norm ops in a native update(): {bad}"
-    assert any("cdx_conv_wgrad_kernel" in n for n in names) and any("cdx_groupnorm_bwd_kernel" in n for n in names), names
+    assert any("cdx_conv_wgrad" in n for n in names) and any("cdx_groupnorm_bwd_kernel" in n for n in names), names
+    # round 6: the weight-gradient products of all 65 layers leave the step's backward pass as ceil(65 / 32) = 3 batched launches
+    assert sum(int(e.count) for e in prof.key_averages() if "cdx_conv_wgrad_batch_kernel" in e.key) <= 3 or os.environ.get("CDX_TRAIN_WGRAD_BATCH") == "0"
     for la, lb in zip(la_all, lb_all):
         assert abs(la["loss"] - lb["loss"]) <= 1e-5 * max(1.0, abs(lb["loss"]))
         assert abs(float(la["grad_norm"]) - float(lb["grad_norm"])) <= 1e-4 * float(lb["grad_norm"])

@@ -91,6 +91,14 @@ def conv_wgrad(p, q, batch, l_p, l_q, taps, stride=1, pad=0, k_split=0, bias_gra
     return (dw, db) if bias_grad else dw
 
 
+def conv_wgrad_batch(jobs):
+    """blocks.conv_wgrad_batch: the queued products of a backward pass, added into their ``.grad`` homes."""
+    COUNTS["wgrad_batch"] = COUNTS.get("wgrad_batch", 0) + 1
+    for p, q, batch, l_p, l_q, taps, stride, pad, dw, db in jobs:
+        conv_wgrad(p, q, batch, l_p, l_q, taps, stride, pad, bias_grad=db is not None, dw_out=dw, db_out=db)
+    return -(-len(jobs) // 32)
+
+
 def activation(z, act, out=None):
     return ACTS[act](z)
 
@@ -160,7 +168,7 @@ def relayout(table):
 
 
 COUNTS = {"relayout": 0, "aten_pack": 0}
-_NAMES = ("linear", "conv1d", "groupnorm", "groupnorm_backward", "colsum", "conv_wgrad", "activation", "activation_backward", "layernorm",
+_NAMES = ("linear", "conv1d", "groupnorm", "groupnorm_backward", "colsum", "conv_wgrad", "conv_wgrad_batch", "activation", "activation_backward", "layernorm",
           "layernorm_backward", "mha_train", "attention", "attention_backward", "relayout_table", "relayout")
 
 
