@@ -436,6 +436,40 @@ class _GroupNormMish(torch.autograd.Function):
         return dx, dg, db, None, None, None, None, None
 
 
+class _GroupNormMishAdd(torch.autograd.Function):
+    """``Mish(GroupNorm1d(x)) [+ film[b]] [+ res]`` in ONE launch forward (cdx_groupnorm_f32: film_mode 2 and the residual operand) --
+    the two adds of a ResidualBlock (reference jannerunet.py:66-69: ``conv1(x) + emb_mlp(emb)``, ``conv2(.) + residual_conv(x)``) were
+    an ATen launch each, 32 of a config-2 step.  Each result element is still one fp32 add per term, as ATen's.  Backward: the
+    additive terms pass dy through (`res`: as it is, no launch; `film`: summed over a sample's positions)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, film, res, batch, length, groups, eps):
+        x = x.contiguous()
+        y = blocks.groupnorm(x, gamma, beta, batch, length, groups, act="mish", eps=eps,
+                             fb=None if film is None else film.contiguous(), film_mode=2 if film is not None else 0,
+                             residual=None if res is None else res.contiguous())
+        ctx.save_for_backward(x, gamma, beta)
+        ctx.geom = (batch, length, groups, eps)
+        ctx.params = (gamma, beta)
+        ctx.has = (film is not None, res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta = ctx.saved_tensors
+        batch, length, groups, eps = ctx.geom
+        dy = dy.contiguous()
+        slots = (_grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])) if ctx.needs_input_grad[1] and ctx.needs_input_grad[2] else (None, None)
+        slots = slots if slots[0] is not None and slots[1] is not None else None
+        dx, dg, db = blocks.groupnorm_backward(dy, x, gamma.detach(), beta.detach(), batch, length, groups, act="mish", eps=eps,
+                                               param_grads=True, grads_out=slots)
+        if slots is not None:
+            _written(*slots)
+        dfilm = dy.view(batch, length, -1).sum(1) if ctx.has[0] and ctx.needs_input_grad[3] else None
+        dres = dy if ctx.has[1] and ctx.needs_input_grad[4] else None
+        return dx, dg, db, dfilm, dres, None, None, None, None
+
+
 class _Act(torch.autograd.Function):
     """An elementwise activation on its own (``cdx_act_f32`` / ``cdx_act_bwd_f32``): behind a GroupNorm whose fused epilogue does not
     know it (the GELU of PearceMlp's FCBlock)."""
@@ -469,12 +503,16 @@ def _resblock(rb, h, memb, batch: int, length: int):
     """ResidualBlock (reference jannerunet.py:51-69): CNA2(CNA1(x) + Linear(Mish(emb))) + skip(x).  `memb` = Mish(emb), evaluated once
     for all blocks (every block's emb_mlp starts with the same Mish); the block's Linear is a library node."""
     c_out = rb.conv1[0].out_channels
-    a1 = _cna(h, rb.conv1, batch, length)
     lin = rb.emb_mlp[1]
-    a1 = (a1.view(batch, length, c_out) + _LinearMish.apply(memb, lin.weight, lin.bias, False)[:, None, :]).view(batch * length, c_out)
-    a2 = _cna(a1, rb.conv2, batch, length)
+    film = _LinearMish.apply(memb, lin.weight, lin.bias, False)                      # (batch, c_out)
     res = h if isinstance(rb.residual_conv, nn.Identity) else _conv(h, rb.residual_conv, batch, length)
-    return a2 + res
+    if os.environ.get("CDX_TRAIN_FUSED_ADDS", "1") == "0":                          # (the round-5 graph: one ATen add per term)
+        a1 = _cna(h, rb.conv1, batch, length)
+        a1 = (a1.view(batch, length, c_out) + film[:, None, :]).view(batch * length, c_out)
+        return _cna(a1, rb.conv2, batch, length) + res
+    (conv1, gn1), (conv2, gn2) = rb.conv1[:2], rb.conv2[:2]
+    a1 = _GroupNormMishAdd.apply(_conv(h, conv1, batch, length), gn1.weight, gn1.bias, film, None, batch, length, gn1.num_groups, gn1.eps)
+    return _GroupNormMishAdd.apply(_conv(a1, conv2, batch, length), gn2.weight, gn2.bias, None, res, batch, length, gn2.num_groups, gn2.eps)
 
 
 @_with_weight_packs

@@ -50,9 +50,16 @@ def _gn(x, gamma, beta, batch, length, groups, act, eps):
     return ACTS[act](y)
 
 
-def groupnorm(x, gamma, beta, batch, length, groups, act="none", eps=1e-5, **kw):
+def groupnorm(x, gamma, beta, batch, length, groups, act="none", eps=1e-5, fb=None, film_mode=0, residual=None, **kw):
+    """cdx_groupnorm_f32: y = act(gn(x)) [+ fb[b] (film_mode 2: a per-sample additive vector)] [+ residual]."""
     assert all(v is None or v == 0 or v is False for v in kw.values()), kw
-    return _gn(x, gamma, beta, batch, length, groups, act, eps)
+    y = _gn(x, gamma, beta, batch, length, groups, act, eps)
+    if fb is not None:
+        assert film_mode == 2 and fb.shape == (batch, x.shape[1])
+        y = (y.view(batch, length, -1) + fb[:, None, :]).reshape(batch * length, -1)
+    if residual is not None:
+        y = y + residual
+    return y
 
 
 def groupnorm_backward(dy, x, gamma, beta, batch, length, groups, act="mish", eps=1e-5, out=None, param_grads=False, grads_out=None):
