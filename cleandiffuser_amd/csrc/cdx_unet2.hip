@@ -964,36 +964,26 @@ __device__ __forceinline__ void split_exchange(XState& X, int grp_idx, int xg, i
 // them at once (up to six 16-byte loads in flight) and polls until every tag matches.  Round-5 form (split_exchange): epilogue ->
 // barrier -> all threads publish from LDS (1.3 k cycles) -> all threads collect, a thread's two items one after the other (1.8-2.7 k)
 // -> barrier; here the exchange ends one L2 round trip after the slowest member's epilogue.
-// TRAJ: the exchange behind an ordinary op that wrote the member's whole trajectory into a group slot (XG_TRAJ): the blocks are the other
-// members' TRAJECTORIES (all channels; c_out == coutp), `dst` is this member's sub-slot.
-template <bool TRAJ>
 __device__ __forceinline__ void collect_fast(XState& X, int grp_idx, unsigned seq, const float* tile, int xg, int gmap,
                                              float* tl, int dst, int dstride, int l_out, int coutp, int u) {
     const int g_lo = xg & 255, w = ((xg >> 8) & 255) - g_lo;                 // lane groups per member (a power of two)
     const int cgsh = 31 - __builtin_clz(coutp >> 3);                         // log2 channels per lane group
-    const int nc4sh = TRAJ ? 31 - __builtin_clz(coutp >> 2) : (31 - __builtin_clz(w)) + cgsh - 2;    // log2 float4 items per position of a block
-    const bool gop = (xg & CDX2_XG_GOP) != 0;                                 // (else, !TRAJ: a cut op of a SPLIT program -- one trajectory, no sub-slots)
-    const int gsh = (TRAJ || gop) ? (gmap & 255) : 30, grows = gmap >> 8;
-    const int n_blk = ((TRAJ || !gop) ? l_out : l_out * X.k) << nc4sh;       // items of one member's block
+    const int nc4sh = (31 - __builtin_clz(w)) + cgsh - 2;                    // log2 float4 items per position and member
+    const int gsh = gmap & 255, grows = gmap >> 8;
+    const int n_blk = (l_out * X.k) << nc4sh;                                // items of one member's block
     const int km1 = X.k - 1;
-    const int base = TRAJ ? dst - mul24i(mul24i(X.m, grows), dstride) : dst;
     for (int j = u; j < n_blk; j += 256) {
-        const int vp = j >> nc4sh, c4 = j & ((1 << nc4sh) - 1);
+        const int vpos = j >> nc4sh, c4 = j & ((1 << nc4sh) - 1);
+        const int t = vpos >> gsh, pos = vpos - (t << gsh);
+        const int row = mul24i(mul24i(t, grows) + pos + CDX2_HALO2, dstride);
+        const int tbase = mul24i(vpos, coutp);
         f32x4 a[3], b[3];
-        int so[3], lo[3];                                                    // tile offset (floats) and LDS offset of the block's item
+        int cc[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int mb = (X.m + 1 + (r < km1 ? r : 0)) & km1;                // (k = 2: one block; the spare slots re-read it, never stored)
-            if (TRAJ) {
-                so[r] = (mul24i(mul24i(mb, l_out) + vp, coutp) + 4 * c4) * 2;
-                lo[r] = base + mul24i(mul24i(mb, grows) + vp + CDX2_HALO2, dstride) + 4 * c4;
-            } else {
-                const int t = vp >> gsh, pos = vp - (t << gsh);
-                const int cc = ((mb * w) << cgsh) + 4 * c4;
-                so[r] = (mul24i(vp, coutp) + cc) * 2;
-                lo[r] = base + mul24i(mul24i(t, grows) + pos + CDX2_HALO2, dstride) + cc;
-            }
-            const f32x4* src = reinterpret_cast<const f32x4*>(tile + so[r]);
+            cc[r] = ((mb * w) << cgsh) + 4 * c4;
+            const f32x4* src = reinterpret_cast<const f32x4*>(tile + (size_t)(tbase + cc[r]) * 2);
             a[r] = __builtin_nontemporal_load(src);
             b[r] = __builtin_nontemporal_load(src + 1);
         }
@@ -1004,13 +994,13 @@ __device__ __forceinline__ void collect_fast(XState& X, int grp_idx, unsigned se
                 if (!(pending & (1 << r))) continue;
                 if (__float_as_uint(a[r][1]) == seq && __float_as_uint(a[r][3]) == seq && __float_as_uint(b[r][1]) == seq &&
                     __float_as_uint(b[r][3]) == seq) {
-                    *reinterpret_cast<f32x4*>(tl + lo[r]) = (f32x4){a[r][0], a[r][2], b[r][0], b[r][2]};
+                    *reinterpret_cast<f32x4*>(tl + dst + row + cc[r]) = (f32x4){a[r][0], a[r][2], b[r][0], b[r][2]};
                     pending &= ~(1 << r);
                 } else {
                     // (a compiler barrier: the tile is written by OTHER workgroups -- without it the re-read below is a redundant load
                     //  of an address nothing in this function stores to, and is folded into the first one)
                     asm volatile("" ::: "memory");
-                    const f32x4* src = reinterpret_cast<const f32x4*>(tile + so[r]);
+                    const f32x4* src = reinterpret_cast<const f32x4*>(tile + (size_t)(tbase + cc[r]) * 2);
                     a[r] = __builtin_nontemporal_load(src);
                     b[r] = __builtin_nontemporal_load(src + 1);
                 }
@@ -1214,24 +1204,7 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
         }
         // (split programs: the half-waves of lane groups that belong to other members sit this op's epilogue out)
         const int xg = SPLIT ? xgw : 0;
-        // (XG_TRAJ ops of a grouped program, fast exchange: the epilogue publishes the member's whole trajectory as it produces it)
-        // (... and the cut ops of a SPLIT program whose lane groups are dealt evenly over the members: each publishes its own)
-        const bool even_cut = (xg & 0xffff) != 0 && !(xg & (CDX2_XG_GOP | CDX2_XG_TRAJ)) && ((((xg >> 8) & 255) - (xg & 255)) * X->k == CDX2_GROUPS2);
-        const bool tfast = SPLIT && CDX2_XCHG_FAST && (xg & CDX2_XG_XCHG) && e.c_out == e.coutp && ((xg & CDX2_XG_TRAJ) || even_cut);
-        Pub pub{nullptr, 0.f, 0, 0, false};
-        if (SPLIT && tfast && epi_wave) {
-            const unsigned xseq = X->seq + 1;
-            const KArg* S0 = kernarg();
-            asm volatile("" : "+s"(S0));
-            const bool withhold = S0->fault != 0 && X->m == S0->fault - 1;
-            pub = Pub{exchange_tile(*X, xseq, __float_as_int(lds[T * tf])), __uint_as_float(xseq), (xg & CDX2_XG_TRAJ) ? X->m * l_out : 0, e.coutp, !withhold};
-        }
-        if (SPLIT && epi_wave && tfast && ((xg & CDX2_XG_TRAJ) || (grp >= (xg & 255) && grp < ((xg >> 8) & 255)))) {
-            if (e.nk == 1) epilogue<1, BWD, COND, MLP, true>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws, &pub);
-            else if (e.nk == 2) epilogue<2, BWD, COND, MLP, true>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws, &pub);
-            else epilogue<CDX2_MAX_NK2, BWD, COND, MLP, true>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws, &pub);
-        } else
-        if (epi_wave && !tfast && (!SPLIT || (xg & 0xffff) == 0 || (grp >= (xg & 255) && grp < ((xg >> 8) & 255)))) {
+        if (epi_wave && (!SPLIT || (xg & 0xffff) == 0 || (grp >= (xg & 255) && grp < ((xg >> 8) & 255)))) {
             if (BWD && (e.flags & CDX2_F2_GNBWD)) {
                 if (e.nk == 1) epilogue_bwd<1>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
                 else if (e.nk == 2) epilogue_bwd<2>(tl, P, e, g.stage, c, pos0, pstep, li, nv, lane, grp, ws);
@@ -1264,15 +1237,12 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
                 *reinterpret_cast<f32x4*>(lds + dbase + (tt * hrows + hrow) * e.dstride + j) = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     if (PIPE) F.P = Pnext;
-    const bool even_cut2 = SPLIT && (xgw & 0xffff) != 0 && !(xgw & (CDX2_XG_GOP | CDX2_XG_TRAJ)) &&
-                           ((((xgw >> 8) & 255) - (xgw & 255)) * X->k == CDX2_GROUPS2);
-    if (SPLIT && CDX2_XCHG_FAST && (xgw & CDX2_XG_XCHG) && ((xgw & CDX2_XG_GOP) || (((xgw & CDX2_XG_TRAJ) || even_cut2) && e.c_out == e.coutp))) {
-        // grouped op / whole-trajectory op, fast exchange: the halo waves collect while the epilogue waves still compute and publish
+    if (SPLIT && CDX2_XCHG_FAST && (xgw & CDX2_XG_GOP) && (xgw & CDX2_XG_XCHG)) {
+        // grouped op, fast exchange: the halo waves collect while the epilogue waves still compute and publish
         const unsigned xseq = X->seq + 1;
         if (halo_wave && !CDX2_XCHG_NOWAIT) {
             const int gi = __float_as_int(lds[T * tf]);
-            if (!(xgw & CDX2_XG_TRAJ)) collect_fast<false>(*X, gi, xseq, exchange_tile(*X, xseq, gi), xgw, gmap, lds, e.dst, e.dstride, l_out, e.coutp, tid & 255);
-            else collect_fast<true>(*X, gi, xseq, exchange_tile(*X, xseq, gi), xgw, gmap, lds, e.dst, e.dstride, l_out, e.coutp, tid & 255);
+            collect_fast(*X, gi, xseq, exchange_tile(*X, xseq, gi), xgw, gmap, lds, e.dst, e.dstride, l_out, e.coutp, tid & 255);
         }
         X->seq = xseq;
     } else
