@@ -1176,7 +1176,10 @@ class GraphedStep:
                 with grads_in_place():                 # (the captured launches add into the static .grad tensors directly)
                     self.loss.backward()
         except Exception as e:  # noqa: BLE001 -- something the probe did not see (it is a prototype check, and blind to pageable H2D copies)
-            # torch.cuda.graph's exit has ended the capture; whatever half-built graph exists is dropped, the eager step serves this agent
+            # torch.cuda.graph's exit has ended the capture; whatever half-built graph exists is dropped, the eager step serves this agent.
+            # (What this can repair is a failure ABOVE the driver -- an exception out of user code.  An illegal CUDA call under capture
+            #  invalidates the capture inside the driver and torch's capture_end throws before it un-registers its generator / allocator
+            #  pool; nothing in Python undoes that, which is why the eager probe runs first.)
             self.graph = None
             torch.cuda.synchronize(dev)
             restore()

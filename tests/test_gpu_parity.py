@@ -1939,6 +1939,127 @@ def test_update_runs_without_aten_conv_or_groupnorm_kernels(amd_lib):
         assert float((p.detach().cpu() - q.detach()).abs().max()) <= 2e-5 * max(1.0, float(q.detach().abs().max())) + 1.1e-6, n
 
 
+def test_fused_adam_matches_torch_adam_over_ten_steps():
+    """FusedAdam.step (cdx_optim_f32 mode CDX_OPT_ADAM, ABI 16: clip -> g += wd p -> moments -> bias-corrected step -> EMA) against
+    torch.optim.Adam (L2 weight decay, the optimiser of the reference's classifiers, classifier/base.py:24) + clip_grad_norm_ + the EMA
+    loop fed the SAME gradients for 10 steps; its state_dict loads into the stock class."""
+    from copy import deepcopy
+    from cleandiffuser_amd.engine.optim import FusedAdam
+    from cleandiffuser_amd.nn_classifier import HalfJannerUNet1d
+    from cleandiffuser_amd.utils import load_synth
+    torch.manual_seed(0)
+    net_a = load_synth(HalfJannerUNet1d(16, 6, out_dim=1, kernel_size=3, model_dim=16, emb_dim=16, dim_mult=(1, 2, 2)), 3).to(DEV)
+    net_b, ema_a = deepcopy(net_a), deepcopy(net_a).requires_grad_(False)
+    ema_b = deepcopy(ema_a)
+    kw = dict(lr=3e-3, weight_decay=5e-2, betas=(0.9, 0.99))
+    opt_a, opt_b = FusedAdam(net_a.parameters(), **kw), torch.optim.Adam(net_b.parameters(), **kw)
+    assert opt_a.native() and isinstance(opt_a, torch.optim.Adam) and not isinstance(opt_a, torch.optim.AdamW)
+    rate, max_norm = 0.9, 0.7
+    for step in range(10):
+        grads = [torch.randn_like(p) * (0.02 if step % 3 else 2.0) for p in net_a.parameters()]
+        for p, q, g in zip(net_a.parameters(), net_b.parameters(), grads):
+            p.grad, q.grad = g.clone(), g.clone()
+        opt_a.step(max_norm=max_norm, ema=(net_a, ema_a, rate))
+        norm_b = torch.nn.utils.clip_grad_norm_(net_b.parameters(), max_norm)
+        opt_b.step()
+        with torch.no_grad():
+            for q, e in zip(net_b.parameters(), ema_b.parameters()):
+                e.mul_(rate).add_(q.detach(), alpha=1 - rate)
+        torch.testing.assert_close(opt_a.last_grad_norm, norm_b, rtol=2e-6, atol=0)
+    for (n, p), q, ea, eb in zip(net_a.named_parameters(), net_b.parameters(), ema_a.parameters(), ema_b.parameters()):
+        scale = max(float(q.detach().abs().max()), 1.0)
+        assert float((p.detach() - q.detach()).abs().max()) <= 1e-6 * scale, n
+        assert float((ea - eb).abs().max()) <= 1e-6 * scale, n
+        torch.testing.assert_close(opt_a.state[p]["exp_avg_sq"], opt_b.state[q]["exp_avg_sq"], rtol=1e-5, atol=1e-12)
+    torch.optim.Adam(net_b.parameters(), **kw).load_state_dict(opt_a.state_dict())
+
+
+@pytest.mark.parametrize("n_jobs", [1, 5, 37])
+def test_batched_weight_gradients_equal_the_single_launches(n_jobs):
+    """cdx_conv_wgrad_batch_f32 (ABI 16): the products of many layers in ceil(n / 32) launches, job table as the kernel argument --
+    convolutions of 1-5 taps, the stride-2 downsample, a transposed conv's operand order, Linears, widths that are no tile multiple,
+    with and without the bias sum -- ADDED onto what the gradient tensors hold, against cdx_conv_wgrad_f32 per product (same kernel body)
+    and against a float64 einsum."""
+    from cleandiffuser_amd.engine import blocks
+    g = torch.Generator().manual_seed(n_jobs)
+    shapes = [(5, 1, 1, 32, 64), (3, 2, 1, 64, 64), (1, 1, 0, 23, 32), (5, 1, 2, 128, 96), (1, 1, 0, 256, 40), (3, 1, 1, 16, 16), (4, 1, 1, 32, 32)]
+    jobs, refs, singles = [], [], []
+    for j in range(n_jobs):
+        taps, stride, pad, ca, cb = shapes[j % len(shapes)]
+        batch = int(torch.randint(2, 9, (1,), generator=g))
+        l_q = 16 if stride == 1 else 32
+        l_p = (l_q + 2 * pad - taps) // stride + 1
+        p = torch.randn(batch * l_p, ca, generator=g).to(DEV)
+        q = torch.randn(batch * l_q, cb, generator=g).to(DEV)
+        seed_w, seed_b = torch.randn(ca, cb, taps, generator=g).to(DEV), torch.randn(ca, generator=g).to(DEV)
+        want_db = j % 2 == 0
+        dw, db = seed_w.clone(), (seed_b.clone() if want_db else None)
+        jobs.append((p, q, batch, l_p, l_q, taps, stride, pad, dw, db))
+        one = blocks.conv_wgrad(p, q, batch, l_p, l_q, taps, stride, pad, bias_grad=want_db)
+        singles.append((one[0] if want_db else one, one[1] if want_db else None))
+        p3, q3 = p.double().view(batch, l_p, ca).cpu(), q.double().view(batch, l_q, cb).cpu()
+        ref = torch.zeros(ca, cb, taps, dtype=torch.float64)
+        m = torch.arange(l_p)
+        for t in range(taps):
+            idx = m * stride + t - pad
+            ok = (idx >= 0) & (idx < l_q)
+            ref[:, :, t] = torch.einsum("nma,nmb->ab", p3[:, ok], q3[:, idx[ok]])
+        refs.append((seed_w.double().cpu() + ref, seed_b.double().cpu() + p.double().cpu().sum(0)))
+    assert blocks.conv_wgrad_batch(jobs) == -(-n_jobs // 32)
+    torch.cuda.synchronize()
+    for (p, q, batch, l_p, l_q, taps, stride, pad, dw, db), (rw, rb), (sw, sb) in zip(jobs, refs, singles):
+        scale = max(1.0, float(rw.abs().max()))
+        assert float((dw.double().cpu() - rw).abs().max()) <= 2e-5 * scale
+        if db is not None:
+            assert float((db.double().cpu() - rb).abs().max()) <= 2e-5 * max(1.0, float(rb.abs().max()))
+
+
+def test_a_failed_capture_falls_back_to_the_eager_step_and_keeps_earlier_gradients(amd_lib, monkeypatch):
+    """(i) a capture that fails -- here: user code that raises only while the stream is capturing, which the eager probe cannot
+    see -- must not leave update() with an exception: the agent steps eagerly from then on, generators and gradients as before the
+    attempt.  (An ILLEGAL CUDA call under capture -- a synchronisation -- invalidates the capture inside the driver; torch's
+    capture_end then throws before it un-registers its generator and allocator pool, which no Python code can repair: that class of
+    failure is what the eager probe in front of the capture exists for.)  (ii) gradients a caller accumulated BEFORE the first update() are part of that update (the reference's
+    update() adds onto them), also when the step is captured."""
+    from copy import deepcopy
+    from cleandiffuser_amd.utils import load_synth
+    monkeypatch.setenv("CDX_TRAIN_GRAPH", "auto")
+    net = load_synth(amd_lib.JannerUNet1d(6, model_dim=16, emb_dim=16, dim_mult=[1, 2], kernel_size=5), 5)
+    mk = lambda: amd_lib.DiscreteDiffusionSDE(deepcopy(net), None, diffusion_steps=20, predict_noise=False, grad_clip_norm=1.0, device=DEV)  # noqa: E731
+    x0 = torch.randn(8, 8, 6, generator=torch.Generator().manual_seed(1)).to(DEV)
+    # (i)
+    a = mk()
+    real_loss = a.loss
+
+    def loss(x, c=None, **kw):
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("this loss() cannot be captured")
+        return real_loss(x, c, **kw)
+    a.loss = loss
+    log = a.update(x0)
+    assert np.isfinite(log["loss"]) and a.__dict__.get("_cdx_graph_off", "").startswith("capture failed"), a.__dict__.get("_cdx_graph_off")
+    assert np.isfinite(a.update(x0)["loss"]) and not torch.cuda.is_current_stream_capturing()
+    # (ii) the same seeded draws with and without earlier gradients: the parameter updates must differ by what the earlier gradients add
+    b, c = mk(), mk()
+    extra = [0.05 * torch.randn_like(p) for p in b.model.parameters()]
+    for p, e in zip(b.model.parameters(), extra):
+        p.grad = e.clone()
+    for p in c.model.parameters():
+        p.grad = None
+    monkeypatch.setenv("CDX_TRAIN_GRAPH", "0")
+    for p, e in zip(c.model.parameters(), extra):
+        p.grad = e.clone()
+    torch.manual_seed(3)
+    lc = c.update(x0)                                   # eager: loss.backward() accumulates onto the earlier gradients
+    monkeypatch.setenv("CDX_TRAIN_GRAPH", "auto")
+    torch.manual_seed(3)
+    lb = b.update(x0)                                   # first update(): builds the graph, must accumulate likewise
+    assert b.__dict__.get("_cdx_graphed") and not b.__dict__.get("_cdx_graph_off")
+    assert abs(float(lb["grad_norm"]) - float(lc["grad_norm"])) <= 2e-5 * float(lc["grad_norm"]), (lb, lc)
+    for (n, p), q in zip(b.model.named_parameters(), c.model.parameters()):
+        assert float((p.detach() - q.detach()).abs().max()) <= 2e-6 * max(1.0, float(q.detach().abs().max())), n
+
+
 def test_classifier_update_runs_on_library_kernels(amd_lib):
     """VERDICT r5 'missing' #2: ``CumRewClassifier.update`` of the config-2 classifier (HalfJannerUNet1d, H = 32, D = 23) at the Diffuser
     pipeline's batch -- the call next to ``update()`` in every Diffuser training iteration (reference pipelines/diffuser_d4rl_mujoco.py:88-91,
