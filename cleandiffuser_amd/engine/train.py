@@ -117,26 +117,34 @@ def _written(*grads):
 # update()'s backward they are QUEUED by the nodes and issued when the backward pass ends, all layers in ceil(n / 32) launches of
 # cdx_conv_wgrad_batch_f32 -- round 5 issued 65 launches of 4-20 us each, 38 % of a config-2 step's device time at 3.8 % of the
 # matrix pipe's peak, none of them able to fill the chip.  CDX_TRAIN_WGRAD_BATCH=0: one launch per layer as before.
-_wgrad_queue: list = []
-
-
-def _flush_wgrads():
-    jobs = list(_wgrad_queue)
-    _wgrad_queue.clear()
-    if jobs:
-        blocks.conv_wgrad_batch(jobs)
+_wgrad_queues: dict = {}     # autograd graph-task id -> the products queued by that backward pass
 
 
 def _queue_wgrad(job) -> bool:
     if _in_place_depth <= 0 or os.environ.get("CDX_TRAIN_WGRAD_BATCH", "1") == "0":
         return False
-    try:
-        if not _wgrad_queue:
-            # (runs when this backward pass ends, on the stream it was called on -- what DDP's reducer relies on too)
-            torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrads)
-    except RuntimeError:
+    task = torch._C._current_graph_task_id()
+    if task < 0:
         return False                                       # not inside a backward pass (a node called by hand): launch now
-    _wgrad_queue.append(job)
+    q = _wgrad_queues.get(task)
+    if q is None:
+        # a new backward pass (a re-entrant one inside another keeps its own list).  Lists that an EARLIER pass left behind -- it raised
+        # before its end-of-pass callback ran -- belong to no step any more: drop them
+        for old in [t for t in _wgrad_queues if t < task - 4]:
+            del _wgrad_queues[old]
+        q = []
+
+        def flush(task=task):
+            jobs = _wgrad_queues.pop(task, None)
+            if jobs:
+                blocks.conv_wgrad_batch(jobs)
+        try:
+            # (runs when this backward pass ends, on the stream it was called on -- what DDP's reducer relies on too)
+            torch.autograd.Variable._execution_engine.queue_callback(flush)
+        except RuntimeError:
+            return False
+        _wgrad_queues[task] = q
+    q.append(job)
     return True
 
 
