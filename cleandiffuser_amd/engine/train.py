@@ -1013,6 +1013,77 @@ def _sequential(seq: nn.Sequential, h):
     return h
 
 
+# --------------------------------------------------------------------------------------------------------------------- #
+# Row-wise MLP chains under autograd: the heads trained NEXT to a denoiser                                                     #
+# --------------------------------------------------------------------------------------------------------------------- #
+# The critics of Diffusion-QL / IDQL (utils/critics.py: Linear -> LayerNorm -> Tanh / Mish towers; reference utils/iql.py:40-95,
+# building_blocks.py:111-147) and the inverse-dynamics heads (invdynamic/mlp.py:7-293) are trained by their own ``update`` methods or by the
+# pipelines' loops.  With autograd on, on a ROCm device, their nn.Sequential chains run on the same library nodes as the denoisers'
+# Linears (cdx_gemm_f32 / cdx_act_f32 / cdx_layernorm_f32 forward, cdx_gemm_f32 / cdx_conv_wgrad_f32 / cdx_layernorm_bwd_f32 backward).
+_CHAIN_ACTS = {nn.Mish: "mish", nn.ReLU: "relu", nn.Tanh: "tanh", nn.SiLU: "silu"}
+
+
+def _chain_act(m) -> Optional[str]:
+    if type(m) in _CHAIN_ACTS:
+        return _CHAIN_ACTS[type(m)]
+    if type(m) is nn.GELU:
+        return "gelu_tanh" if m.approximate == "tanh" else "gelu"
+    return None
+
+
+def _chain_plan(seq):
+    """[(kind, module, activation)] of a Sequential this path understands, or None: Linear (+ activation), LayerNorm (+ activation),
+    a lone activation, Identity, inactive Dropout."""
+    def flat(q):                               # (utils.Mlp nests one Sequential(Linear, activation) per hidden layer)
+        for m in q:
+            if isinstance(m, nn.Sequential):
+                yield from flat(m)
+            else:
+                yield m
+    mods = [m for m in flat(seq) if not isinstance(m, nn.Identity) and not (isinstance(m, nn.Dropout) and (not m.training or m.p == 0.0))]
+    plan, i = [], 0
+    while i < len(mods):
+        m = mods[i]
+        act = _chain_act(mods[i + 1]) if i + 1 < len(mods) else None
+        if type(m) is nn.Linear and m.bias is not None:
+            plan.append(("linear", m, act))
+        elif type(m) is nn.LayerNorm and m.elementwise_affine and len(m.normalized_shape) == 1 and m.bias is not None:
+            plan.append(("norm", m, act))
+        elif _chain_act(m) is not None:
+            plan.append(("act", m, _chain_act(m)))
+            act = None
+        else:
+            return None
+        i += 2 if act is not None and plan[-1][0] != "act" else 1
+    return plan
+
+
+def supports_chain(seq, x: torch.Tensor) -> bool:
+    if not (enabled() and torch.is_grad_enabled() and torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2):
+        return False
+    if not isinstance(seq, nn.Sequential) or not (x.requires_grad or any(p.requires_grad for p in seq.parameters())):
+        return False
+    if not all(p.dtype == torch.float32 and p.is_cuda for p in seq.parameters()):
+        return False
+    return _chain_plan(seq) is not None
+
+
+@_with_weight_packs
+def chain_forward(seq, x: torch.Tensor) -> torch.Tensor:
+    """``seq(x)`` for (rows, features) with autograd, every Linear / LayerNorm / activation a library node (see above)."""
+    h = x
+    for kind, m, act in _chain_plan(seq):
+        if kind == "linear":
+            h = _LinearAct.apply(h, m.weight, m.bias, act)
+        elif kind == "norm":
+            h = _LayerNormAffine.apply(h, m.weight, m.bias, m.eps)
+            if act is not None:
+                h = _Act.apply(h, act)
+        else:
+            h = _Act.apply(h, act)
+    return h
+
+
 @_with_weight_packs
 def dql_forward(net, x: torch.Tensor, noise: torch.Tensor, condition: Optional[torch.Tensor]) -> torch.Tensor:
     """``DQLMlp.forward`` / ``DVInvMlp.forward`` (reference nn_diffusion/dqlmlp.py:30-52, dvinvmlp.py:30-47) with autograd, every Linear

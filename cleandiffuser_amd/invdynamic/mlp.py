@@ -4,7 +4,8 @@ checkpoint keys as the reference (``mlp`` / ``model`` state dicts); same quirk: 
 per-class default learning rate is computed but unused (invdynamic/mlp.py:47-52).
 
 ``predict`` on a ROCm device runs the chain through engine/heads.py (fp32-MFMA GEMMs with fused bias + activation, fused
-LayerNorm); ``update`` stays on autograd.
+LayerNorm); ``update`` keeps the reference's autograd graph with every Linear / LayerNorm / activation node on the library's kernels
+(engine/train.py:chain_forward) and steps through ``FusedAdam`` (``cdx_optim_f32``).
 """
 import torch
 import torch.nn as nn
@@ -13,9 +14,19 @@ from ..utils import Mlp
 
 
 def _forward_rows(net: nn.Module, x: torch.Tensor) -> torch.Tensor:
-    from ..engine import heads
-    y = heads.try_sequential(net.mlp if isinstance(net, Mlp) else net, x)
+    from ..engine import heads, train
+    seq = net.mlp if isinstance(net, Mlp) else net
+    if train.supports_chain(seq, x):           # autograd on, ROCm device (``update``): library nodes forward and backward
+        return train.chain_forward(seq, x)
+    y = heads.try_sequential(seq, x)
     return net(x) if y is None else y
+
+
+def _adam(params, optim_params):
+    """What the reference builds with ``torch.optim.Adam`` (invdynamic/mlp.py:47-52): the same class on CPU, its one-launch subclass on a
+    ROCm device."""
+    from ..engine.optim import FusedAdam
+    return FusedAdam(params, **optim_params)
 
 
 class BasicInvDynamic:
@@ -69,7 +80,7 @@ class MlpInvDynamic(_MseTrainedHead):
         self.out_activation = out_activation
         self.optim_params = optim_params
         self.mlp = Mlp(2 * o_dim, [hidden_dim, hidden_dim], a_dim, nn.ReLU(), out_activation).to(device)
-        self.optim = torch.optim.Adam(self.mlp.parameters(), **optim_params)
+        self.optim = _adam(self.mlp.parameters(), optim_params)
         self._init_weights()
 
     def _net(self):
@@ -100,7 +111,7 @@ class FancyMlpInvDynamic(_MseTrainedHead):
             nn.Dropout(0.1) if add_dropout else nn.Identity(),
             nn.Linear(hidden_dim, hidden_dim), nn.GELU(),
             nn.Linear(hidden_dim, a_dim), out_activation).to(device)
-        self.optim = torch.optim.Adam(self.model.parameters(), **optim_params)
+        self.optim = _adam(self.model.parameters(), optim_params)
 
     def _net(self):
         return self.model
@@ -125,7 +136,7 @@ class EnsembleMlpInvDynamic(MlpInvDynamic):
                                      nn.Linear(h, h), nn.LayerNorm(h), nn.Mish(), nn.Linear(h, h), out_activation)
                        for _ in range(n_models)]
         self.mlp = nn.ModuleList(members).to(device)
-        self.optim = torch.optim.Adam(self.mlp.parameters(), **self.optim_params)
+        self.optim = _adam(self.mlp.parameters(), self.optim_params)
         self._init_weights()
 
     def forward(self, o, o_next, idx=None):
@@ -170,7 +181,7 @@ class ResInvDynamic(_MseTrainedHead):
             "post_linear": nn.Sequential(nn.Linear(hidden_dim, a_dim), out_activation).to(device)})
         for i in range(n_blocks):
             self.model[f"res_block{i}"] = ResidualBlock(hidden_dim, add_norm, add_dropout).to(device)
-        self.optim = torch.optim.Adam(self.model.parameters(), **optim_params)
+        self.optim = _adam(self.model.parameters(), optim_params)
 
     def _net(self):
         return self.model

@@ -5,7 +5,9 @@ attribute names, hence the same ``state_dict`` keys).  Diffusion Veteran's horiz
 
 Execution: every head here is a chain of ``Linear -> [LayerNorm] -> activation`` over rows, so on a ROCm device without
 autograd the chain runs through ``engine/heads.py`` (fp32-MFMA GEMM with fused bias/activation epilogue + one fused
-LayerNorm/activation launch per layer); with autograd on, or on CPU, the stock modules run.
+LayerNorm/activation launch per layer); with autograd ON (the critics' training steps) through ``engine/train.py:chain_forward`` --
+the same library nodes the denoisers train on, forward and backward --, IQL's two Adam optimisers and its Polyak target update on
+``cdx_optim_f32``; on CPU the stock modules run.
 """
 from copy import deepcopy
 
@@ -15,7 +17,9 @@ import torch.nn.functional as F
 
 
 def _rows(seq: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
-    from ..engine import heads
+    from ..engine import heads, train
+    if train.supports_chain(seq, x):           # autograd on, ROCm device (the critics' own training steps): library nodes forward and backward
+        return train.chain_forward(seq, x)
     y = heads.try_sequential(seq, x)
     return seq(x) if y is None else y
 
@@ -104,10 +108,15 @@ class IQL(nn.Module):
         self.Q = TwinQ(obs_dim, act_dim, hidden_dim)
         self.Q_targ = deepcopy(self.Q).requires_grad_(False).eval()
         self.V = V(obs_dim, hidden_dim)
-        self.optimV = torch.optim.Adam(self.V.parameters(), lr=3e-4)
-        self.optimQ = torch.optim.Adam(self.Q.parameters(), lr=3e-4)
+        # (torch.optim.Adam subclasses: one multi-tensor launch of cdx_optim_f32 per step on a ROCm device, torch's own step elsewhere)
+        from ..engine.optim import FusedAdam
+        self.optimV = FusedAdam(self.V.parameters(), lr=3e-4)
+        self.optimQ = FusedAdam(self.Q.parameters(), lr=3e-4)
 
     def update_target(self, mu=0.995):
+        from ..engine.optim import ema_update_native
+        if ema_update_native(self.Q, self.Q_targ, mu):       # targ <- mu * targ + (1 - mu) * q over every pair, one launch
+            return
         for p, p_targ in zip(self.Q.parameters(), self.Q_targ.parameters()):
             p_targ.data = mu * p_targ.data + (1 - mu) * p.data
 

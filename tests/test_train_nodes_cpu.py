@@ -41,6 +41,18 @@ def _case(name):
     if name == "sfbc":
         net = load_synth(N.SfBCUNet(5, emb_dim=16, hidden_dims=[64, 32, 16]), 11)
         return net, train.sfbc_forward, (torch.randn(6, 5, generator=g), torch.rand(6, generator=g), torch.randn(6, 16, generator=g))
+    if name == "chain_critic":                                # Linear -> LayerNorm -> Tanh / Mish towers (DQLCritic, IQL's TwinQ / V)
+        from cleandiffuser_amd.utils import DQLCritic
+        net = load_synth(DQLCritic(7, 3, hidden_dim=32), 13).q1_model
+        return net, train.chain_forward, (torch.randn(6, 10, generator=g),)
+    if name == "chain_invdyn":                                # Linear -> GELU -> LayerNorm -> Identity -> ... -> Tanh (active Dropout: the stock modules)
+        from cleandiffuser_amd.invdynamic import FancyMlpInvDynamic
+        net = FancyMlpInvDynamic(5, 3, hidden_dim=32, add_norm=True, add_dropout=False).model
+        return net, train.chain_forward, (torch.randn(6, 10, generator=g),)
+    if name == "chain_mlp":                                   # utils.Mlp: nested Sequential(Linear, ReLU) per hidden layer, Tanh output
+        from cleandiffuser_amd.utils import Mlp
+        net = load_synth(Mlp(10, [32, 32], 3, torch.nn.ReLU(), torch.nn.Tanh()), 14).mlp
+        return net, train.chain_forward, (torch.randn(6, 10, generator=g),)
     if name == "half_janner":
         from cleandiffuser_amd.nn_classifier import HalfJannerUNet1d
         net = load_synth(HalfJannerUNet1d(16, 6, out_dim=1, kernel_size=3, model_dim=16, emb_dim=16, dim_mult=(1, 2, 2)), 12)
@@ -78,7 +90,7 @@ def _close(got, want, what, tol=2e-5):
     assert float((got - want).abs().max()) <= tol * sc + 1e-7, (what, float((got - want).abs().max()), sc)
 
 
-CASES = ["janner", "janner_cond", "chiunet", "dit", "idql", "chitf", "dql", "pearce", "sfbc", "half_janner"]
+CASES = ["janner", "janner_cond", "chiunet", "dit", "idql", "chitf", "dql", "pearce", "sfbc", "half_janner", "chain_critic", "chain_invdyn", "chain_mlp"]
 
 
 @pytest.mark.parametrize("name", CASES)

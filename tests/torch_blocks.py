@@ -13,7 +13,7 @@ import torch.nn.functional as F
 from cleandiffuser_amd.engine import blocks, train
 
 ACTS = {"mish": F.mish, "gelu": F.gelu, "gelu_tanh": lambda z: F.gelu(z, approximate="tanh"), "none": lambda z: z, "silu": F.silu,
-        "leaky": F.leaky_relu}
+        "leaky": F.leaky_relu, "relu": F.relu, "tanh": torch.tanh}
 
 
 def _vjp(fn, inputs, dy):
