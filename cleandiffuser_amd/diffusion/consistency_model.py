@@ -185,7 +185,12 @@ class ContinuousConsistencyModel(DiffusionModel):
             loss, unweighted = self.distillation_loss(x0, condition)
         else:
             raise ValueError(f"Unknown loss type: {loss_type}")
-        loss.backward()
+        # (the denoiser's forward ran on the library's training nodes -- its forward() routes there under autograd --; inside this backward
+        #  they add the parameter gradients straight into .grad and issue the weight-gradient products as batched launches.  The step
+        #  itself is not captured as a HIP graph: the training loss draws from numpy and reports a Python float per call)
+        from ..engine import train
+        with train.grads_in_place():
+            loss.backward()
         grad_norm = self._apply_gradients(update_ema)
         if loss_type == "training":
             self.cur_logger.incremental_update_k()
