@@ -211,25 +211,53 @@ GUIDED_ROUND_COST = {1: 10.1, 2: 13.4, 3: 19.2}
 
 
 def plan_parts(batch: int, tmax: int, round_cost=None):
-    """Cut `batch` trajectories into launches [(first, count, trajectories per workgroup)]: full rounds of 256 x T workgroups at the
-    T that is cheapest per trajectory, then the remainder at whatever T finishes it soonest (B = 3200: 4 rounds of 768 three per
-    workgroup + 128 one per workgroup)."""
+    """Cut `batch` trajectories into launches [(first, count, trajectories per workgroup)]: ROUNDS of 256 workgroups, a round at T
+    trajectories per workgroup costing ROUND_COST[T] whether it is full or not, the set of rounds with the smallest total (larger T
+    first; ties: fewer launches).  B = 3200 is 12.5 rounds' worth at T = 1: three rounds at three per workgroup + two at two (13 x 256
+    places, 34.2 ms by the table) beat four + a half-empty round at one (35.1 ms) -- CDX_UNET2_PLAN=bulk: the older rule, full rounds at
+    the T that is cheapest per trajectory and ONE shape for the remainder."""
     ROUND_COST = round_cost or globals()["ROUND_COST"]
+    if os.environ.get("CDX_UNET2_PLAN") == "bulk":
+        best = None
+        for tb in range(1, tmax + 1):
+            per_round = N_CUS * tb
+            rounds, parts = batch // per_round, []
+            cost, bulk = rounds * ROUND_COST[tb], rounds * per_round
+            if bulk:
+                parts.append((0, bulk, tb))
+            r = batch - bulk
+            if r:
+                tt = min(range(1, tmax + 1), key=lambda t: (-(-r // (N_CUS * t)) * ROUND_COST[t], t))
+                cost += -(-r // (N_CUS * tt)) * ROUND_COST[tt]
+                parts.append((bulk, r, tt))
+            if best is None or cost < best[0] - 1e-9:
+                best = (cost, parts)
+        return best[1]
     best = None
-    for tb in range(1, tmax + 1):
-        per_round = N_CUS * tb
-        rounds, parts = batch // per_round, []
-        cost, bulk = rounds * ROUND_COST[tb], rounds * per_round
-        if bulk:
-            parts.append((0, bulk, tb))
-        r = batch - bulk
-        if r:
-            tt = min(range(1, tmax + 1), key=lambda t: (-(-r // (N_CUS * t)) * ROUND_COST[t], t))
-            cost += -(-r // (N_CUS * tt)) * ROUND_COST[tt]
-            parts.append((bulk, r, tt))
-        if best is None or cost < best[0] - 1e-9:
-            best = (cost, parts)
-    return best[1]
+
+    def walk(t: int, left: int, counts: tuple):
+        nonlocal best
+        if t == 0:
+            if left > 0:
+                return
+            cost = sum(n * ROUND_COST[tt] for tt, n in counts)
+            key = (round(cost, 6), sum(1 for _, n in counts if n), tuple(-n for _, n in counts))
+            if best is None or key < best[0]:
+                best = (key, counts)
+            return
+        for n in range(0, -(-max(left, 0) // (N_CUS * t)) + 1):
+            walk(t - 1, left - n * N_CUS * t, counts + ((t, n),))
+    # (the search is over the last few rounds only: everything before them runs at the T that is cheapest per trajectory)
+    t_bulk = min(range(1, tmax + 1), key=lambda t: (ROUND_COST[t] / t, -t))
+    n_bulk = max(0, batch // (N_CUS * t_bulk) - 4)
+    walk(tmax, batch - n_bulk * N_CUS * t_bulk, ())
+    parts, first = [], 0
+    for t, n in ((t, n + (n_bulk if t == t_bulk else 0)) for t, n in best[1]):
+        take = min(n * N_CUS * t, batch - first)
+        if take > 0:
+            parts.append((first, take, t))
+            first += take
+    return parts
 
 
 def plan_for(module, horizon: int, batch: int):

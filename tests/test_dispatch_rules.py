@@ -1,5 +1,6 @@
 """Host-side routing rules between the two native U-Net executors and the PyTorch executor (engine/dispatch.py, bigbatch.py,
 runtime.py) -- pure Python decisions, checked on the CPU."""
+import os
 import torch
 
 from cleandiffuser_amd.engine import bigbatch, plan as P, runtime, runtime2
@@ -46,15 +47,24 @@ def test_edm_plans_do_not_change_the_lds_plan():
 
 
 def test_launch_plan_cuts_large_batches():
-    """B = 3200 = 4 rounds of 768 trajectories three per workgroup + 128 one per workgroup; B = 512 one round of two; B = 256 one of one."""
+    """B = 3200 = 3 rounds of 768 trajectories three per workgroup + 2 rounds of two per workgroup (13 x 256 places; the older rule's
+    4 rounds of three + a half-empty round of one cost 2 % more on the MI355X); B = 512 one round of two; B = 256 one of one."""
     from cleandiffuser_amd.engine import runtime2
-    assert runtime2.plan_parts(3200, 3) == [(0, 3072, 3), (3072, 128, 1)]
+    assert runtime2.plan_parts(3200, 3) == [(0, 2304, 3), (2304, 896, 2)]
+    assert runtime2.plan_parts(3072, 3) == [(0, 3072, 3)] and runtime2.plan_parts(768 * 40, 3) == [(0, 768 * 40, 3)]
+    assert runtime2.plan_parts(10 ** 6, 3) == [(0, 999168, 3), (999168, 832, 2)]
     assert runtime2.plan_parts(512, 3) == [(0, 512, 2)]
     assert runtime2.plan_parts(256, 3) == [(0, 256, 1)]
     assert runtime2.plan_parts(640, 3) == [(0, 640, 3)]
     assert runtime2.plan_parts(3200, 2) == [(0, 3072, 2), (3072, 128, 1)]
-    for b in (1, 255, 257, 700, 1000, 5000):
+    cost = lambda parts: sum(-(-c // (256 * t)) * runtime2.ROUND_COST[t] for _, c, t in parts)
+    for b in (1, 255, 257, 700, 1000, 1576, 3200, 4096, 5000, 12345):
         parts = runtime2.plan_parts(b, 3)
+        os.environ["CDX_UNET2_PLAN"] = "bulk"
+        try:
+            assert cost(parts) <= cost(runtime2.plan_parts(b, 3)) + 1e-9          # never worse than the older rule by the cost table
+        finally:
+            del os.environ["CDX_UNET2_PLAN"]
         assert sum(c for _, c, _ in parts) == b and parts[0][0] == 0 and all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(len(parts) - 1))
 
 

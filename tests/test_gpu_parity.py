@@ -223,8 +223,8 @@ def test_guided_two_trajectories_per_workgroup(amd_lib, monkeypatch):
 
 def test_guided_batch_is_cut_into_rounds_of_three_per_workgroup(amd_lib, monkeypatch):
     """Above two rounds of workgroups a guided batch is cut like an unguided one (runtime2.plan_parts): rounds of 256 x 3 trajectories
-    on the compact guided program plus a remainder launch on the same program; the result agrees with the one-trajectory program
-    on the same draws."""
+    on the compact guided program plus the remaining rounds at two per workgroup on the same program; the result agrees with the
+    one-trajectory program on the same draws."""
     from cleandiffuser_amd.engine import runtime2
     name = "janner_cfg2_guided_ddpm"
     agent, _ = cases.build(amd_lib, name, device=DEV)
@@ -234,7 +234,7 @@ def test_guided_batch_is_cut_into_rounds_of_three_per_workgroup(amd_lib, monkeyp
     prior[:, 0, :17] = torch.randn(B, 17, generator=g)
     zs = [torch.randn(B, 32, 23, generator=g).to(DEV) for _ in range(4)]
     kw = dict(solver="ddpm", n_samples=B, sample_steps=3, temperature=0.5, w_cg=0.3)
-    assert runtime2.plan_parts(B, 3, runtime2.GUIDED_ROUND_COST) == [(0, 1536, 3), (1536, 40, 1)]
+    assert runtime2.plan_parts(B, 3, runtime2.GUIDED_ROUND_COST) == [(0, 768, 3), (768, 808, 2)]
     calls = _spy_launches(monkeypatch)
     x3, _ = agent.sample(prior.to(DEV), noise=list(zs), **kw)
     torch.cuda.synchronize()
