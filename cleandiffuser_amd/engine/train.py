@@ -454,7 +454,8 @@ class _GroupNormMishAdd(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, film, res, batch, length, groups, eps):
         x = x.contiguous()
         y = blocks.groupnorm(x, gamma, beta, batch, length, groups, act="mish", eps=eps,
-                             fb=None if film is None else film.contiguous(), film_mode=2 if film is not None else 0,
+                             fb=None if film is None else (film if film.stride(1) == 1 else film.contiguous()),
+                             film_mode=2 if film is not None else 0,
                              residual=None if res is None else res.contiguous())
         ctx.save_for_backward(x, gamma, beta)
         ctx.geom = (batch, length, groups, eps)
@@ -476,6 +477,94 @@ class _GroupNormMishAdd(torch.autograd.Function):
         dfilm = dy.view(batch, length, -1).sum(1) if ctx.has[0] and ctx.needs_input_grad[3] else None
         dres = dy if ctx.has[1] and ctx.needs_input_grad[4] else None
         return dx, dg, db, dfilm, dres, None, None, None, None
+
+
+class _ConvPair(torch.autograd.Function):
+    """The two paths that leave a ResidualBlock's input (reference jannerunet.py:66-69): ``(conv1(x), residual_conv(x))`` -- the skip path
+    a 1 x 1 Conv1d or the identity -- as ONE autograd node.  As two nodes autograd adds their input gradients with an ATen launch per
+    block (16 of a config-2 step); here the second backward-data product takes the first path's gradient as the residual operand of
+    its epilogue: dx = conv1^T(dy1) + [residual_conv^T](dres), one fp32 add per element as before."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, wr, br, batch, l_in, pad):
+        x = x.contiguous()
+        ctx.packs = _active_packs
+        c_out, c_in, k = w1.shape
+        y1 = blocks.conv1d(x, _pack("conv", w1, ctx.packs), b1, batch, l_in, 1, pad, partial=_splitk_scratch(x.shape[0], c_out, c_in * k, x.device))
+        if wr is None:
+            res = x.view_as(x)
+        else:
+            res = blocks.conv1d(x, _pack("conv", wr, ctx.packs), br, batch, l_in, 1, 0, partial=_splitk_scratch(x.shape[0], wr.shape[0], c_in, x.device))
+        ctx.save_for_backward(x, w1, wr if wr is not None else x.new_empty(0))
+        ctx.geom = (batch, l_in, pad, b1 is not None, wr is not None, br is not None)
+        ctx.params = (w1, b1, wr, br)
+        return y1, res
+
+    @staticmethod
+    def backward(ctx, dy1, dres):
+        x, w1, wr = ctx.saved_tensors
+        batch, l_in, pad, has_b1, has_wr, has_br = ctx.geom
+        c_out, c_in, k = w1.shape
+        dy1, dres = dy1.contiguous(), dres.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            d0 = dres
+            if has_wr:
+                d0 = blocks.conv1d(dres, _pack("conv_bwd", wr, ctx.packs), None, batch, l_in, 1, 0, l_out=l_in,
+                                   partial=_splitk_scratch(batch * l_in, c_in, wr.shape[0], dres.device))
+            dx = blocks.conv1d(dy1, _pack("conv_bwd", w1, ctx.packs), None, batch, l_in, 1, k - 1 - pad, l_out=l_in, residual=d0,
+                               partial=_splitk_scratch(batch * l_in, c_in, c_out * k, dy1.device))
+        dw1, db1 = _weight_grads(dy1, x, batch, l_in, l_in, k, 1, pad, ctx.params[0], ctx.params[1], ctx.needs_input_grad[1],
+                                 has_b1 and ctx.needs_input_grad[2])
+        dwr = dbr = None
+        if has_wr:
+            dwr, dbr = _weight_grads(dres, x, batch, l_in, l_in, 1, 1, 0, ctx.params[2], ctx.params[3], ctx.needs_input_grad[3],
+                                     has_br and ctx.needs_input_grad[4])
+        return dx, dw1, db1, dwr, dbr, None, None, None
+
+
+class _LinearMany(torch.autograd.Function):
+    """Several Linears of ONE input -- the emb_mlp Linears of every ResidualBlock of a U-Net, all fed Mish(emb) (reference
+    jannerunet.py:60-66): ``(x W_0^T + b_0, x W_1^T + b_1, ...)`` as column blocks of one GEMM on the stacked weights.  Backward: the
+    input's gradient is one GEMM on the stacked output gradients (sixteen GEMMs and fifteen ATen adds of a config-2 step as separate
+    nodes); the weight gradients join the step's batch as before.  Arguments: x, then (weight, bias) per Linear."""
+
+    @staticmethod
+    def forward(ctx, x, *wb):
+        x = x.contiguous()
+        ws, bs = wb[0::2], wb[1::2]
+        wcat = torch.cat([w.detach() for w in ws], 0)
+        y = _linear(x, wcat, torch.cat([b.detach() for b in bs], 0))
+        ctx.save_for_backward(x, wcat)
+        ctx.params = wb
+        outs, off = [], 0
+        for w in ws:
+            outs.append(y[:, off:off + w.shape[0]])
+            off += w.shape[0]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        x, wcat = ctx.saved_tensors
+        ws, bs = ctx.params[0::2], ctx.params[1::2]
+        dys = [d.contiguous() for d in dys]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _linear(torch.cat(dys, 1), wcat.t().contiguous())
+        grads = []
+        for i, (w, b, dy) in enumerate(zip(ws, bs, dys)):
+            grads += _weight_grads(dy, x, x.shape[0], 1, 1, 1, 1, 0, w, b, ctx.needs_input_grad[1 + 2 * i], ctx.needs_input_grad[2 + 2 * i])
+        return (dx, *grads)
+
+
+def _films(blocks_list, memb):
+    """{id(block): its FiLM vector (batch, c_out)} for the ResidualBlocks of a U-Net from one `_LinearMany` node (CDX_TRAIN_FILM_BATCH=0:
+    empty -- every block runs its own Linear node, the round-5 graph)."""
+    lins = [rb.emb_mlp[1] for rb in blocks_list]
+    if os.environ.get("CDX_TRAIN_FILM_BATCH", "1") == "0" or len(lins) < 2 or any(lin.bias is None for lin in lins):
+        return {}
+    outs = _LinearMany.apply(memb, *[t for lin in lins for t in (lin.weight, lin.bias)])
+    return {id(rb): o for rb, o in zip(blocks_list, outs)}
 
 
 class _Act(torch.autograd.Function):
@@ -507,19 +596,30 @@ def _cna(h, seq: nn.Sequential, batch: int, length: int):
     return _GroupNormMish.apply(y, gn.weight, gn.bias, batch, length, gn.num_groups, gn.eps)
 
 
-def _resblock(rb, h, memb, batch: int, length: int):
+def _resblock(rb, h, memb, batch: int, length: int, film=None):
     """ResidualBlock (reference jannerunet.py:51-69): CNA2(CNA1(x) + Linear(Mish(emb))) + skip(x).  `memb` = Mish(emb), evaluated once
-    for all blocks (every block's emb_mlp starts with the same Mish); the block's Linear is a library node."""
+    for all blocks (every block's emb_mlp starts with the same Mish); the block's Linear is a library node -- `film`: its output when
+    the caller ran all blocks' Linears as one node (`_films`)."""
     c_out = rb.conv1[0].out_channels
     lin = rb.emb_mlp[1]
-    film = _LinearMish.apply(memb, lin.weight, lin.bias, False)                      # (batch, c_out)
-    res = h if isinstance(rb.residual_conv, nn.Identity) else _conv(h, rb.residual_conv, batch, length)
+    if film is None:
+        film = _LinearMish.apply(memb, lin.weight, lin.bias, False)                  # (batch, c_out)
+    (conv1, gn1), (conv2, gn2), rc = rb.conv1[:2], rb.conv2[:2], rb.residual_conv
     if os.environ.get("CDX_TRAIN_FUSED_ADDS", "1") == "0":                          # (the round-5 graph: one ATen add per term)
+        res = h if isinstance(rc, nn.Identity) else _conv(h, rc, batch, length)
         a1 = _cna(h, rb.conv1, batch, length)
         a1 = (a1.view(batch, length, c_out) + film[:, None, :]).view(batch * length, c_out)
         return _cna(a1, rb.conv2, batch, length) + res
-    (conv1, gn1), (conv2, gn2) = rb.conv1[:2], rb.conv2[:2]
-    a1 = _GroupNormMishAdd.apply(_conv(h, conv1, batch, length), gn1.weight, gn1.bias, film, None, batch, length, gn1.num_groups, gn1.eps)
+    pair = conv1.stride[0] == 1 and (isinstance(rc, nn.Identity) or (isinstance(rc, nn.Conv1d) and rc.kernel_size[0] == 1 and rc.stride[0] == 1
+                                                                     and rc.padding[0] == 0))
+    if pair and os.environ.get("CDX_TRAIN_CONV_PAIR", "1") != "0":
+        ident = isinstance(rc, nn.Identity)
+        y1, res = _ConvPair.apply(h, conv1.weight, conv1.bias, None if ident else rc.weight, None if ident else rc.bias, batch, length,
+                                  conv1.padding[0])
+    else:
+        res = h if isinstance(rc, nn.Identity) else _conv(h, rc, batch, length)
+        y1 = _conv(h, conv1, batch, length)
+    a1 = _GroupNormMishAdd.apply(y1, gn1.weight, gn1.bias, film, None, batch, length, gn1.num_groups, gn1.eps)
     return _GroupNormMishAdd.apply(_conv(a1, conv2, batch, length), gn2.weight, gn2.bias, None, res, batch, length, gn2.num_groups, gn2.eps)
 
 
@@ -534,18 +634,20 @@ def janner_forward(net, x: torch.Tensor, noise: torch.Tensor, condition: Optiona
     emb = torch.nn.functional.mish(_sequential(net.map_emb, emb.contiguous()))        # Mish(emb): what every block's emb_mlp starts with
     h = x.reshape(b * length, d)
     skips = []
+    films = _films([rb for lvl in net.downs for rb in lvl[:2]] + [net.mid_block1, net.mid_block2] + [rb for lvl in net.ups for rb in lvl[:2]], emb)
+    block = lambda rb, h, length: _resblock(rb, h, emb, b, length, films.get(id(rb)))
     for res1, res2, _, down in net.downs:
-        h = _resblock(res2, _resblock(res1, h, emb, b, length), emb, b, length)
+        h = block(res2, block(res1, h, length), length)
         skips.append((h, length))
         if not isinstance(down, nn.Identity):
             h = _conv(h, down.conv, b, length)
             length = (length - 1) // 2 + 1
-    h = _resblock(net.mid_block2, _resblock(net.mid_block1, h, emb, b, length), emb, b, length)
+    h = block(net.mid_block2, block(net.mid_block1, h, length), length)
     for res1, res2, _, up in net.ups:
         skip, l_skip = skips.pop()
         assert l_skip == length
         h = torch.cat([h, skip], dim=1)
-        h = _resblock(res2, _resblock(res1, h, emb, b, length), emb, b, length)
+        h = block(res2, block(res1, h, length), length)
         if not isinstance(up, nn.Identity):
             h = _ConvT.apply(h, up.conv.weight, up.conv.bias, b, length)
             length *= 2
@@ -585,13 +687,14 @@ def half_janner_forward(net, x: torch.Tensor, noise: torch.Tensor, condition: Op
     raw = _sequential(net.map_emb, emb.contiguous())       # the head concatenates map_emb's output as it is ...
     memb = torch.nn.functional.mish(raw)                   # ... every block's emb_mlp starts with its Mish
     h = x.reshape(b * length, d)
+    films = _films([rb for lvl in net.downs for rb in lvl[:2]] + [net.mid_block1[0], net.mid_block2[0]], memb)
     for res1, res2, down in net.downs:
-        h = _resblock(res2, _resblock(res1, h, memb, b, length), memb, b, length)
+        h = _resblock(res2, _resblock(res1, h, memb, b, length, films.get(id(res1))), memb, b, length, films.get(id(res2)))
         if not isinstance(down, nn.Identity):
             h = _conv(h, down.conv, b, length)
             length = (length - 1) // 2 + 1
     for block, down in (net.mid_block1, net.mid_block2):
-        h = _conv(_resblock(block, h, memb, b, length), down.conv, b, length)
+        h = _conv(_resblock(block, h, memb, b, length, films.get(id(block))), down.conv, b, length)
         length = (length - 1) // 2 + 1
     # x.flatten(1) of the reference's (b, C, L) layout: channel-major
     flat = h.view(b, length, -1).permute(0, 2, 1).reshape(b, -1)

@@ -37,7 +37,9 @@ def conv1d(x, w_packed, bias, batch, l_in, stride=1, pad=0, out=None, residual=N
     xc = x.reshape(batch, l_in, cin).permute(0, 2, 1)
     xc = F.pad(xc, (pad, max(right, 0)))
     y = F.conv1d(xc, w_packed.permute(0, 2, 1), bias, stride=stride)[:, :, :l_out].permute(0, 2, 1).reshape(batch * l_out, n)
-    assert residual is None and act == "none"
+    assert act == "none"
+    if residual is not None:                              # epilogue operand of cdx_gemm_f32: one fp32 add per element
+        y = y + residual
     if out is not None:
         out.copy_(y)
         return out
