@@ -890,21 +890,32 @@ __global__ __launch_bounds__(256) void cdx_groupnorm_bwd_kernel(const cdx_gn_arg
     // this lane's channels: sum dz * xhat, sum dz (training: d gamma, d beta).  cg is a power of two <= 256 (checked by the host entry):
     // up to 64 a lane's channel e % cg is the same in every iteration; 128 / 256 (ChiUNet1d at 1024 / 2048 channels in 8 groups): a lane
     // walks the channels lane + 64 j, j = iteration % (cg / 64) -- one partial pair per j
-    float pg[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f};
+    float pg[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f}, pd[4] = {0.f, 0.f, 0.f, 0.f};
     const int jmask = cg > 64 ? cg / 64 - 1 : 0;
     int it = 0;
     for (int e = lane; e < n; e += 64, ++it) {
         const int l = e / cg, c = e - l * cg, ch = grp * cg + c;
         const float xh = (xb[(size_t)l * a.ldx + c] - mean) * rstd;
         const float z = xh * a.gamma[ch] + a.beta[ch];
-        const float dz = db[(size_t)l * a.ldr + c] * (a.act == CDX_ACT_MISH ? gm_act(z, CDX_ACT_MISH_GRAD) : 1.0f);
+        const float dyv = db[(size_t)l * a.ldr + c];
+        const float dz = dyv * (a.act == CDX_ACT_MISH ? gm_act(z, CDX_ACT_MISH_GRAD) : 1.0f);
         const float g = dz * a.gamma[ch];
         sg += g;
         sgx += g * xh;
         const int j = it & jmask;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            if (q == j) { pg[q] += dz * xh; pb[q] += dz; }
+            if (q == j) { pg[q] += dz * xh; pb[q] += dz; pd[q] += dyv; }
+    }
+    if (a.dy_possum != nullptr) {                        // per sample and channel: the sum over the positions of d loss / d y
+        if (cg <= 64) {
+            for (int o = 32; o >= cg; o >>= 1) pd[0] += __shfl_xor(pd[0], o, 64);
+            if (lane < cg && live) a.dy_possum[(size_t)b * a.ld_possum + grp * cg + lane] = pd[0];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (q <= jmask && live) a.dy_possum[(size_t)b * a.ld_possum + grp * cg + lane + 64 * q] = pd[q];
+        }
     }
     if (SUMS || a.dgamma_part != nullptr) {
         // per-sample partials (B, C) for the caller's column sums, or -- SUMS -- this workgroup's four samples combined in LDS
@@ -945,6 +956,143 @@ __global__ __launch_bounds__(256) void cdx_groupnorm_bwd_kernel(const cdx_gn_arg
         const float dz = db[(size_t)l * a.ldr + c] * (a.act == CDX_ACT_MISH ? gm_act(z, CDX_ACT_MISH_GRAD) : 1.0f);
         const float g = dz * a.gamma[ch];
         a.y[((size_t)b * a.L + l) * a.ldy + ch] = rstd * (g - mg - xh * mgx);
+    }
+}
+
+// The same backward with the group in REGISTERS (round 6): one wave per (sample, group) as above, but x and dy are read ONCE, as
+// dwordx4 (the scalar kernel walks x three times and dy twice with dword loads: 9.3 us per launch on the <= 1 MB tensors of a config-2
+// step, 12 % of update()'s device time in 33 launches), statistics in float64 as in the forward kernel.  Needs a power-of-two group
+// width of 4..256 channels, at most 8 float4 per lane (L * cg <= 2048) and 16-byte aligned rows.  A lane keeps ONE channel quad
+// (64 % (cg / 4) == 0): its items are the positions l0 + i * (256 / cg).
+template <bool SUMS>
+__global__ __launch_bounds__(256) void cdx_groupnorm_bwd_vec_kernel(const cdx_gn_args a, const int spw) {
+    // SUMS: a wave walks `spw` consecutive samples of its group and keeps the per-channel sums in registers across them, so that an
+    // address of dgamma_sum / dbeta_sum sees B / (4 spw) float atomics instead of B / 4
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ float red[SUMS ? 2 * 4 * 256 : 1];
+    int b0, grp;
+    if (SUMS) {
+        grp = blockIdx.x % a.G;
+        b0 = ((blockIdx.x / a.G) * 4 + wave) * spw;
+    } else {
+        const int wg = blockIdx.x * 4 + wave;
+        b0 = wg / a.G;
+        grp = wg - b0 * a.G;
+        if (b0 >= a.B) return;
+    }
+    const int cg = a.C / a.G, cq = cg >> 2, n = a.L * cg;
+    const int sh = __ffs(cq) - 1;
+    const int c4 = 4 * (lane & (cq - 1)), l0 = lane >> sh, lstep = 64 >> sh;
+    const int ch = grp * cg + c4;
+    auto ld4 = [](const float* p) { return *reinterpret_cast<const float4*>(p); };
+    const float4 ga4 = ld4(a.gamma + ch), be4 = ld4(a.beta + ch);
+    const float ga[4] = {ga4.x, ga4.y, ga4.z, ga4.w}, be[4] = {be4.x, be4.y, be4.z, be4.w};
+    const bool sums = SUMS || a.dgamma_part != nullptr;
+    float pg[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int si = 0; si < (SUMS ? spw : 1); ++si) {
+        const int b = b0 + si;
+        if (b >= a.B) break;                              // (wave-uniform)
+        const float* xb = a.x + (size_t)b * a.L * a.ldx + ch;
+        const float* db = a.residual + (size_t)b * a.L * a.ldr + ch;
+        float4 v[GN_VREGS], d[GN_VREGS];
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < GN_VREGS; ++i) {
+            v[i] = d[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i * lstep >= a.L) continue;               // (wave-uniform: an item index past the last position is empty in every lane)
+            const int l = l0 + i * lstep;
+            if (l < a.L) {
+                v[i] = ld4(xb + (size_t)l * a.ldx);
+                d[i] = ld4(db + (size_t)l * a.ldr);
+            }
+            s += ((double)v[i].x + (double)v[i].y) + ((double)v[i].z + (double)v[i].w);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+        const double mean_d = s / (double)n;
+        const float mean = (float)mean_d;
+        double s2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < GN_VREGS; ++i) {
+            if (i * lstep >= a.L) continue;
+            if (l0 + i * lstep < a.L) {
+                const double d0 = (double)v[i].x - mean_d, d1 = (double)v[i].y - mean_d, d2 = (double)v[i].z - mean_d, d3 = (double)v[i].w - mean_d;
+                s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+        const float rstd = (float)(1.0 / sqrt(s2 / (double)n + (double)a.eps));
+        float sg = 0.f, sgx = 0.f;
+        float qg[4] = {0.f, 0.f, 0.f, 0.f}, qb[4] = {0.f, 0.f, 0.f, 0.f}, pd[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < GN_VREGS; ++i) {
+            if (i * lstep >= a.L) continue;
+            float xv[4] = {v[i].x, v[i].y, v[i].z, v[i].w}, dv[4] = {d[i].x, d[i].y, d[i].z, d[i].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xh = (xv[j] - mean) * rstd;
+                const float z = xh * ga[j] + be[j];
+                const float dz = dv[j] * (a.act == CDX_ACT_MISH ? gm_act(z, CDX_ACT_MISH_GRAD) : 1.0f);
+                const float g = dz * ga[j];              // (lanes past the last position carry dy = 0: they add nothing anywhere)
+                sg += g;
+                sgx += g * xh;
+                qg[j] += dz * xh; qb[j] += dz; pd[j] += dv[j];
+                xv[j] = xh; dv[j] = g;
+            }
+            v[i] = make_float4(xv[0], xv[1], xv[2], xv[3]);   // x_hat
+            d[i] = make_float4(dv[0], dv[1], dv[2], dv[3]);   // g
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { pg[j] += qg[j]; pb[j] += qb[j]; }
+        if (a.dy_possum != nullptr || (!SUMS && sums)) {
+            for (int o = 32; o >= cq; o >>= 1) {           // the lanes that share a channel quad differ in the bits >= log2(cq)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (!SUMS && sums) { qg[j] += __shfl_xor(qg[j], o, 64); qb[j] += __shfl_xor(qb[j], o, 64); }
+                    if (a.dy_possum != nullptr) pd[j] += __shfl_xor(pd[j], o, 64);
+                }
+            }
+            if (lane < cq) {
+                if (a.dy_possum != nullptr)
+                    *reinterpret_cast<float4*>(a.dy_possum + (size_t)b * a.ld_possum + ch) = make_float4(pd[0], pd[1], pd[2], pd[3]);
+                if (!SUMS && sums) {
+                    *reinterpret_cast<float4*>(a.dgamma_part + (size_t)b * a.C + ch) = make_float4(qg[0], qg[1], qg[2], qg[3]);
+                    *reinterpret_cast<float4*>(a.dbeta_part + (size_t)b * a.C + ch) = make_float4(qb[0], qb[1], qb[2], qb[3]);
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { sg += __shfl_xor(sg, o, 64); sgx += __shfl_xor(sgx, o, 64); }
+        const float mg = sg / (float)n, mgx = sgx / (float)n;
+#pragma unroll
+        for (int i = 0; i < GN_VREGS; ++i) {
+            const int l = l0 + i * lstep;
+            if (l < a.L)
+                *reinterpret_cast<float4*>(a.y + ((size_t)b * a.L + l) * a.ldy + ch) =
+                    make_float4(rstd * (d[i].x - mg - v[i].x * mgx), rstd * (d[i].y - mg - v[i].y * mgx),
+                                rstd * (d[i].z - mg - v[i].z * mgx), rstd * (d[i].w - mg - v[i].w * mgx));
+        }
+    }
+    if (SUMS) {
+        // this wave's samples are summed in registers; combine the lanes of a channel quad, then the four waves in LDS: one float atomic
+        // per channel and workgroup
+        for (int o = 32; o >= cq; o >>= 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { pg[j] += __shfl_xor(pg[j], o, 64); pb[j] += __shfl_xor(pb[j], o, 64); }
+        }
+        if (lane < cq) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                red[wave * 256 + c4 + j] = pg[j];
+                red[(4 + wave) * 256 + c4 + j] = pb[j];
+            }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < cg; c += 256) {
+            atomicAdd(a.dgamma_sum + grp * cg + c, (red[c] + red[256 + c]) + (red[512 + c] + red[768 + c]));
+            atomicAdd(a.dbeta_sum + grp * cg + c, (red[1024 + c] + red[1280 + c]) + (red[1536 + c] + red[1792 + c]));
+        }
     }
 }
 
@@ -1628,16 +1776,35 @@ int cdx_groupnorm_bwd_f32(const cdx_gn_args* a, void* hip_stream) {
     if ((a->dgamma_sum == nullptr) != (a->dbeta_sum == nullptr) || (a->dgamma_sum != nullptr && a->dgamma_part != nullptr)) {
         cdx_set_err("cdx_groupnorm_bwd_f32: dgamma_sum and dbeta_sum go together, and not with the *_part pair"); return CDX_EINVAL;
     }
-    if (a->dgamma_part != nullptr || a->dgamma_sum != nullptr) {
-        const int cg = a->C / a->G;
-        if (cg > 256 || (cg & (cg - 1)) != 0) { cdx_set_err("cdx_groupnorm_bwd_f32: parameter gradients need a power-of-two group width <= 256"); return CDX_EINVAL; }
+    const int cg = a->C / a->G;
+    const bool pow2 = cg <= 256 && (cg & (cg - 1)) == 0;
+    if ((a->dgamma_part != nullptr || a->dgamma_sum != nullptr || a->dy_possum != nullptr) && !pow2) {
+        cdx_set_err("cdx_groupnorm_bwd_f32: parameter gradients / position sums need a power-of-two group width <= 256"); return CDX_EINVAL;
     }
+    if (a->dy_possum != nullptr && a->ld_possum < a->C) { cdx_set_err("cdx_groupnorm_bwd_f32: ld_possum < C"); return CDX_EINVAL; }
     const long long waves = (long long)a->B * a->G;
-    if (a->dgamma_sum != nullptr)
-        hipLaunchKernelGGL(cdx_groupnorm_bwd_kernel<true>, dim3((unsigned)(((a->B + 3) / 4) * (long long)a->G)), dim3(256), 0,
-                           reinterpret_cast<hipStream_t>(hip_stream), *a);
-    else
-        hipLaunchKernelGGL(cdx_groupnorm_bwd_kernel<false>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), *a);
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    // the group-in-registers kernel: power-of-two groups of 4..256 channels, at most 8 float4 per lane, 16-byte rows (CDX_GN_VEC=0: off)
+    const bool vec = gn_vec_enabled() && pow2 && cg >= 4 && (long long)a->L * cg <= 64LL * 4 * GN_VREGS && a->ldx % 4 == 0 && a->ldy % 4 == 0 &&
+                     a->ldr % 4 == 0 && al16(a->x) && al16(a->y) && al16(a->residual) && al16(a->gamma) && al16(a->beta) &&
+                     (a->dgamma_part == nullptr || (al16(a->dgamma_part) && al16(a->dbeta_part) && a->C % 4 == 0)) &&
+                     (a->dy_possum == nullptr || (al16(a->dy_possum) && a->ld_possum % 4 == 0));
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    const dim3 grid_s((unsigned)(((a->B + 3) / 4) * (long long)a->G)), grid_p((unsigned)((waves + 3) / 4));
+    if (a->dgamma_sum != nullptr) {
+        // samples per wave of the register kernel: 1 -- measured on config 2 / 3 (profiles/r06_gn_bwd_vec_ab.txt): 2 / 4 / 8 samples per wave
+        // cut the float atomics per address accordingly and are 10 / 60 / 170 % SLOWER, the launch is bound by one sample's dependent
+        // chain (load -> two reductions -> Mish' -> reduction -> store), not by the atomics.  CDX_GN_BWD_SPW: the A/B hook
+        static const char* env_spw = getenv("CDX_GN_BWD_SPW");
+        int spw = env_spw ? atoi(env_spw) : 1;
+        if (spw < 1 || spw > 64) spw = 1;
+        const dim3 grid_v((unsigned)(((a->B + 4 * spw - 1) / (4 * spw)) * (long long)a->G));
+        if (vec) hipLaunchKernelGGL(cdx_groupnorm_bwd_vec_kernel<true>, grid_v, dim3(256), 0, st, *a, spw);
+        else hipLaunchKernelGGL(cdx_groupnorm_bwd_kernel<true>, grid_s, dim3(256), 0, st, *a);
+    } else {
+        if (vec) hipLaunchKernelGGL(cdx_groupnorm_bwd_vec_kernel<false>, grid_p, dim3(256), 0, st, *a, 1);
+        else hipLaunchKernelGGL(cdx_groupnorm_bwd_kernel<false>, grid_p, dim3(256), 0, st, *a);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { cdx_set_err(hipGetErrorString(e)); return CDX_EHIP; }
     return CDX_OK;

@@ -30,7 +30,8 @@ class CdxGnArgs(ctypes.Structure):
                 ("fa", ctypes.c_void_p), ("fb", ctypes.c_void_p), ("residual", ctypes.c_void_p)] + \
                [(n, ctypes.c_int32) for n in ("B", "L", "C", "G", "ldx", "ldy", "ldr", "ldfa", "ldfb", "fa_row", "fa_per_sample",
                                               "film_mode", "act")] + [("eps", ctypes.c_float)] + \
-               [("dgamma_part", ctypes.c_void_p), ("dbeta_part", ctypes.c_void_p), ("dgamma_sum", ctypes.c_void_p), ("dbeta_sum", ctypes.c_void_p)]
+               [("dgamma_part", ctypes.c_void_p), ("dbeta_part", ctypes.c_void_p), ("dgamma_sum", ctypes.c_void_p), ("dbeta_sum", ctypes.c_void_p),
+                ("dy_possum", ctypes.c_void_p), ("ld_possum", ctypes.c_int32)]
 
 
 class CdxWgradArgs(ctypes.Structure):
@@ -241,14 +242,17 @@ def groupnorm(x: torch.Tensor, gamma, beta, batch: int, length: int, groups: int
 
 def groupnorm_backward(dy: torch.Tensor, x: torch.Tensor, gamma, beta, batch: int, length: int, groups: int,
                        act: str = "mish", eps: float = 1e-5, out: Optional[torch.Tensor] = None, param_grads: bool = False,
-                       grads_out=None):
+                       grads_out=None, possum_out: Optional[torch.Tensor] = None):
     """d loss / d x for y = act(groupnorm(x) * gamma + beta), given dy = d loss / d y (x is the saved forward input).
     `param_grads`: also (d loss / d gamma, d loss / d beta) -- per-sample partial sums out of the same launch, summed over the batch by
     cdx_colsum_f32 -> (dx, dgamma, dbeta).  `grads_out` = (tensor, tensor): the two sums are ADDED to these (the parameters'
-    ``.grad``) by the backward kernel itself (float atomics; no staging, no column-sum launches) -> (dx, None, None)."""
+    ``.grad``) by the backward kernel itself (float atomics; no staging, no column-sum launches) -> (dx, None, None).
+    `possum_out` (batch, C) [a column block of a wider matrix is fine]: the launch also writes dy summed over each sample's positions."""
     if out is None:
         out = torch.empty_like(x)
     c = x.shape[1]
+    if possum_out is not None:
+        assert possum_out.shape == (batch, c) and possum_out.stride(1) == 1 and possum_out.dtype == torch.float32
     pg = pb = None
     if grads_out is not None:
         assert param_grads and all(t.is_contiguous() and t.numel() == c and t.dtype == torch.float32 for t in grads_out)
@@ -258,7 +262,8 @@ def groupnorm_backward(dy: torch.Tensor, x: torch.Tensor, gamma, beta, batch: in
     a = CdxGnArgs(x=x.data_ptr(), y=out.data_ptr(), gamma=gamma.data_ptr(), beta=beta.data_ptr(), residual=dy.data_ptr(),
                   B=batch, L=length, C=c, G=groups, ldx=_rows(x), ldy=_rows(out), ldr=_rows(dy), act=ACT[act], eps=eps,
                   dgamma_part=None if pg is None else pg[0].data_ptr(), dbeta_part=None if pb is None else pb.data_ptr(),
-                  dgamma_sum=None if grads_out is None else grads_out[0].data_ptr(), dbeta_sum=None if grads_out is None else grads_out[1].data_ptr())
+                  dgamma_sum=None if grads_out is None else grads_out[0].data_ptr(), dbeta_sum=None if grads_out is None else grads_out[1].data_ptr(),
+                  dy_possum=_p(possum_out), ld_possum=_rows(possum_out) if possum_out is not None else 0)
     _check(_lib().cdx_groupnorm_bwd_f32(ctypes.byref(a), _stream_ptr(x.device)), "cdx_groupnorm_bwd_f32")
     if not param_grads:
         return out

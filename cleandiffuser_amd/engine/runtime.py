@@ -17,7 +17,7 @@ from .consts import _act_id
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libcdx.so")
 LIB_PATH = os.environ.get("CDX_LIB", LIB_PATH)          # A/B hook: run the same process against another build
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 
 class CdxStep(ctypes.Structure):

@@ -470,11 +470,18 @@ class _GroupNormMishAdd(torch.autograd.Function):
         dy = dy.contiguous()
         slots = (_grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])) if ctx.needs_input_grad[1] and ctx.needs_input_grad[2] else (None, None)
         slots = slots if slots[0] is not None and slots[1] is not None else None
+        # (the FiLM vector's gradient -- dy summed over a sample's positions -- out of the same launch: cdx_gn_args.dy_possum, ABI 17;
+        #  CDX_TRAIN_POSSUM=0: an ATen reduction per block as before)
+        cgw = x.shape[1] // groups
+        dfilm = None
+        if ctx.has[0] and ctx.needs_input_grad[3] and cgw & (cgw - 1) == 0 and cgw <= 256 and os.environ.get("CDX_TRAIN_POSSUM", "1") != "0":
+            dfilm = torch.empty((batch, x.shape[1]), device=x.device, dtype=torch.float32)
         dx, dg, db = blocks.groupnorm_backward(dy, x, gamma.detach(), beta.detach(), batch, length, groups, act="mish", eps=eps,
-                                               param_grads=True, grads_out=slots)
+                                               param_grads=True, grads_out=slots, possum_out=dfilm)
         if slots is not None:
             _written(*slots)
-        dfilm = dy.view(batch, length, -1).sum(1) if ctx.has[0] and ctx.needs_input_grad[3] else None
+        if dfilm is None and ctx.has[0] and ctx.needs_input_grad[3]:
+            dfilm = dy.view(batch, length, -1).sum(1)
         dres = dy if ctx.has[1] and ctx.needs_input_grad[4] else None
         return dx, dg, db, dfilm, dres, None, None, None, None
 

@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define CDX_ABI_VERSION 16
+#define CDX_ABI_VERSION 17
 
 #define CDX_OK 0
 #define CDX_EINVAL (-1)   /* bad argument (null pointer, size out of range, misaligned offset) */
@@ -296,6 +296,11 @@ typedef struct cdx_gn_args {
      * d loss / d beta themselves, on top of what the buffers held (a parameter's .grad), without the (B, C) staging and its two
      * column-sum launches.  Both or neither, same group-width rule; exclusive with the *_part pair. */
     float *dgamma_sum, *dbeta_sum;
+    /* backward only (ABI 17): optional (B, ld_possum) output -- per sample and channel the sum over the sample's positions of
+     * d loss / d y: the gradient of a per-sample additive vector behind the activation (the FiLM term of a ResidualBlock, reference
+     * jannerunet.py:66), out of the launch that reads d loss / d y anyway.  Same group-width rule. */
+    float* dy_possum;
+    int32_t ld_possum;
 } cdx_gn_args;
 int cdx_groupnorm_f32(const cdx_gn_args* args, void* hip_stream);
 /* Backward of y = act(gn(x) * gamma + beta) w.r.t. x (classifier guidance, reference classifier/base.py:74-79 asks autograd

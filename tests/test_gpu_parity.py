@@ -1740,6 +1740,42 @@ def test_groupnorm_backward_adds_its_gain_and_shift_sums_onto_the_callers_buffer
     torch.testing.assert_close(dx1.cpu(), xr.grad, rtol=2e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("B,L,C,G", [(5, 8, 32, 8), (7, 4, 1024, 8), (256, 32, 64, 8), (3, 32, 512, 8), (3, 64, 512, 8), (1, 8, 16, 8),
+                                     (6, 5, 2048, 8), (9, 3, 256, 8)])
+@pytest.mark.parametrize("act", ["mish", "none"])
+def test_groupnorm_backward_in_registers_and_its_position_sums(B, L, C, G, act):
+    """Round 6: the group-in-registers backward kernel (x and dy read once as float4, float64 statistics) on the shapes it takes --
+    power-of-two groups of 4..256 channels, L * cg <= 2048, odd lengths, batches that are not a multiple of four -- and the scalar
+    kernel on the ones it refuses (2-channel groups, 4096 elements per group), both against torch.autograd on the CPU; and
+    cdx_gn_args.dy_possum (ABI 17): dy summed over each sample's positions out of the same launch, written into a column block of a
+    wider matrix, with each of the three parameter-gradient modes."""
+    import torch.nn.functional as F
+    from cleandiffuser_amd.engine import blocks
+    g = torch.Generator().manual_seed(B * 11 + C + L)
+    x = torch.randn(B * L, C, generator=g).to(DEV)
+    dy = torch.randn(B * L, C, generator=g).to(DEV)
+    gamma, beta = torch.randn(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
+    xr, gr, br = (t.cpu().clone().requires_grad_(True) for t in (x, gamma, beta))
+    y = F.group_norm(xr.view(B, L, C).permute(0, 2, 1), G, gr, br, 1e-5)
+    (F.mish(y) if act == "mish" else y).permute(0, 2, 1).reshape(B * L, C).backward(dy.cpu())
+    want_sum = dy.view(B, L, C).sum(1).cpu()
+    for mode in ("none", "parts", "sums"):
+        wide = torch.full((B, C + 64), 7.0, device=DEV)
+        possum = wide[:, 32:32 + C]
+        acc = (torch.zeros(C, device=DEV), torch.zeros(C, device=DEV))
+        out = blocks.groupnorm_backward(dy, x, gamma, beta, B, L, G, act=act, param_grads=mode != "none",
+                                        grads_out=acc if mode == "sums" else None, possum_out=possum)
+        dx = out if mode == "none" else out[0]
+        torch.testing.assert_close(dx.cpu(), xr.grad, rtol=2e-4, atol=2e-5)
+        torch.testing.assert_close(possum.cpu(), want_sum, rtol=1e-5, atol=1e-5)
+        assert float(wide[:, :32].min()) == 7.0 and float(wide[:, 32 + C:].max()) == 7.0       # nothing outside the block
+        if mode != "none":
+            dg, db = (out[1], out[2]) if mode == "parts" else acc
+            sc = float(gr.grad.abs().max()) + float(br.grad.abs().max())
+            torch.testing.assert_close(dg.cpu(), gr.grad, rtol=2e-4, atol=5e-5 * sc + 1e-6)
+            torch.testing.assert_close(db.cpu(), br.grad, rtol=2e-4, atol=5e-5 * sc + 1e-6)
+
+
 def test_relayout_kernel_builds_every_weight_layout_and_the_registry_keeps_them_current(amd_lib, monkeypatch):
     """cdx_relayout_f32 (ABI 15): every layout a training step needs of a conv / conv-transpose / linear weight -- whole parameters and a
     row slice of a packed one -- as ONE launch, bit-identical to the ATen permute / flip / stack expressions; and the registry around
@@ -1927,7 +1963,7 @@ def test_update_runs_without_aten_conv_or_groupnorm_kernels(amd_lib):
     names = [e.key for e in prof.key_averages()]
     bad = [n for n in names if any(w in n.lower() for w in ("convolution", "conv1d", "conv_transpose", "miopen", "group_norm", "native_batch_norm"))]
     assert not bad, f"ATen convolution / group_norm ops in a native update(): {bad}"
-    assert any("cdx_conv_wgrad" in n for n in names) and any("cdx_groupnorm_bwd_kernel" in n for n in names), names
+    assert any("cdx_conv_wgrad" in n for n in names) and any("cdx_groupnorm_bwd_" in n for n in names), names
     # round 6: the weight-gradient products of all 65 layers leave the step's backward pass as ceil(65 / 32) = 3 batched launches
     assert sum(int(e.count) for e in prof.key_averages() if "cdx_conv_wgrad_batch_kernel" in e.key) <= 3 or os.environ.get("CDX_TRAIN_WGRAD_BATCH") == "0"
     for la, lb in zip(la_all, lb_all):

@@ -64,8 +64,11 @@ def groupnorm(x, gamma, beta, batch, length, groups, act="none", eps=1e-5, fb=No
     return y
 
 
-def groupnorm_backward(dy, x, gamma, beta, batch, length, groups, act="mish", eps=1e-5, out=None, param_grads=False, grads_out=None):
+def groupnorm_backward(dy, x, gamma, beta, batch, length, groups, act="mish", eps=1e-5, out=None, param_grads=False, grads_out=None,
+                       possum_out=None):
     dx, dg, db = _vjp(lambda a, g, b: _gn(a, g, b, batch, length, groups, act, eps), (x, gamma, beta), dy)
+    if possum_out is not None:                            # cdx_gn_args.dy_possum: dy summed over each sample's positions
+        possum_out.copy_(dy.view(batch, length, -1).sum(1))
     if not param_grads:
         return dx
     if grads_out is not None:
