@@ -1601,7 +1601,9 @@ static int gm_launch(const cdx_gemm_args* g_in, void* hip_stream, bool force_sma
         const int nk_all = (g->K + bk - 1) / bk;
         k_split = (slots + tiles - 1) / tiles;
         if (k_split > g->partial_slices) k_split = g->partial_slices;
-        if (k_split > nk_all / 8) k_split = nk_all / 8;              // at least 8 K tiles per slice
+        static const char* env_mt = getenv("CDX_GEMM_SPLITK_MIN_TILES");     // tuning hook
+        const int min_tiles = env_mt && atoi(env_mt) > 0 ? atoi(env_mt) : 8;
+        if (k_split > nk_all / min_tiles) k_split = nk_all / min_tiles;      // at least 8 K tiles per slice
         if (k_split < 1) k_split = 1;
         const int per = (nk_all + k_split - 1) / k_split;
         k_split = (nk_all + per - 1) / per;                          // no empty slices

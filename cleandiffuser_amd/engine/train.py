@@ -340,7 +340,7 @@ def _splitk_scratch(rows: int, n: int, k: int, device) -> Optional[torch.Tensor]
     if os.environ.get("CDX_TRAIN_SPLITK", "1") == "0":
         return None
     tiles_big = -(-rows // 128) * -(-n // 128)
-    slices = min(16, k // 256)
+    slices = min(16, k // int(os.environ.get("CDX_TRAIN_SPLITK_MINK", "256")))
     if tiles_big >= 192 or slices < 2 or rows * n * slices > (1 << 26):
         return None
     return torch.empty(slices * rows * n, device=device, dtype=torch.float32)
