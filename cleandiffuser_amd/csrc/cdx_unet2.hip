@@ -1157,6 +1157,9 @@ __device__ __forceinline__ void run_op(const cdx_unet2_launch& L, const cint* op
         int vde = vd;
         asm volatile("" : "+v"(vde));                   // (decode from scratch: see above)
         xgw = CDX2_DW(vde, CDX2_W2_XG);
+        // (W2_XG / W2_GMAP alias W2_DST2 / W2_SAVE: an op with backward extras -- the classifier's part of a grouped guided program --
+        //  is never cut or exchanged, and those words are what their names say)
+        if (BWD && (e.flags & (CDX2_F2_SAVE | CDX2_F2_GNBWD | CDX2_F2_DUAL))) xgw = 0;
         if (xgw & (CDX2_XG_GOP | CDX2_XG_TRAJ)) gmap = CDX2_DW(vde, CDX2_W2_GMAP);
     }
     if (SPLIT && (xgw & CDX2_XG_GOP)) {
@@ -1268,7 +1271,9 @@ template <int T, int NWV, bool BWD, bool PROF, bool COND = false, bool MLP = fal
 __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_unet2_kernel(const cdx_unet2_launch L) {
     static_assert(!(COND && BWD), "conditional requests have no backward-op variant");
     static_assert(!MLP || (COND && T == 1 && NWV == 8), "batch-tiled MLP programs: the conditional one-trajectory 8-wave shape");
-    static_assert(!SPLIT || (T == 1 && NWV == 8 && !BWD && !COND), "split / grouped programs: unconditional one-trajectory 8-wave shape");
+    // (SPLIT && BWD: the GROUPED GUIDED program -- the denoiser's stream-bound layers grouped, the classifier's forward / backward ops on
+    //  the member's own trajectory; round 6)
+    static_assert(!SPLIT || (T == 1 && NWV == 8 && !COND), "split / grouped programs: unconditional one-trajectory 8-wave shape");
     constexpr int THREADS = WG<NWV>::THREADS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -1598,11 +1603,12 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
         if (S->logp_out != nullptr) {
             const int first = S->logp_first_op, head = S->logp_head_op;
             const float* __restrict__ emb_row = L.emb + (size_t)(logp_only ? b0 : L.n_steps) * L.emb_ld;
-            vd = load_desc<NWV>(L.ops, first, lane, wave);
+            // (grouped guided programs: the member's own descriptors -- the classifier's ops are ordinary ops in every member's view)
+            vd = load_desc<NWV>(L.ops, moff + first, lane, wave);
             it = inline_item(vd);
             if (wave < CDX2_DW(vd, CDX2_W2_NITEMS)) prefetch_ring(it, L.wblob, lane, ring);
             for (int oi = first; oi < head; ++oi) {
-                const int vdn = load_desc<NWV>(L.ops, oi + 1, lane, wave);
+                const int vdn = load_desc<NWV>(L.ops, moff + oi + 1, lane, wave);
                 run_op<T, NWV, BWD, PROF, COND>(L, ops, vd, vdn, it, emb_row, 0, lds, tid, ring, nullptr, b0, F, emb_row, 0, 0);
                 vd = vdn;
             }
@@ -1752,10 +1758,11 @@ int cdx_unet2_run(const cdx_unet2_launch* L, void* hip_stream) {
     if (L->split_k != 0 && L->run_if) { cdx_set_err("run_if: the repair launch is an ORDINARY launch (split_k == 0)"); return CDX_EINVAL; }
     if (L->fault < 0 || (L->fault != 0 && L->split_k == 0)) { cdx_set_err("fault: test hook of split / grouped launches"); return CDX_EINVAL; }
     if (L->split_k != 0) {
-        if ((L->split_k != 2 && L->split_k != 4) || guided || cond || L->mlp || L->traj_per_wg != 1 || L->n_waves != 8 || L->compact ||
+        if ((L->split_k != 2 && L->split_k != 4) || cond || L->mlp || L->traj_per_wg != 1 || L->n_waves != 8 || L->compact ||
             !L->xbuf || !L->xerr || L->xchg_floats <= 0 || (L->xchg_floats & 3)) {
             cdx_set_err("split / grouped program: split_k 2 or 4, one trajectory per workgroup, 8 waves, unconditional, xbuf / xerr given"); return CDX_EINVAL;
         }
+        if (guided && (!L->split_group || L->prof)) { cdx_set_err("programs with backward ops: the GROUPED form only (split_group), no op profiling"); return CDX_EINVAL; }
         // split: split_k workgroups per trajectory; grouped: split_k trajectories per group of split_k workgroups.  ALWAYS one workgroup
         // per CU of the whole chip -- 256, 32 per XCD, all resident: that is what lets the workgroups form their groups from per-XCD
         // tickets (see XState); groups past the batch compute on zeros
@@ -1764,7 +1771,8 @@ int cdx_unet2_run(const cdx_unet2_launch* L, void* hip_stream) {
         if (groups_needed > split_grid / L->split_k) {
             cdx_set_err("split / grouped program: at most 256 / split_k groups per launch (every workgroup must be resident)"); return CDX_EINVAL;
         }
-        kern = L->prof ? cdx_unet2_kernel<1, 8, false, true, false, false, true> : cdx_unet2_kernel<1, 8, false, false, false, false, true>;
+        kern = guided ? cdx_unet2_kernel<1, 8, true, false, false, false, true>
+                      : L->prof ? cdx_unet2_kernel<1, 8, false, true, false, false, true> : cdx_unet2_kernel<1, 8, false, false, false, false, true>;
     } else if (L->split_group) {
         cdx_set_err("split_group without split_k"); return CDX_EINVAL;
     } else if (L->mlp) {

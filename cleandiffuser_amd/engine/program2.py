@@ -224,6 +224,7 @@ class _Builder2:
                                            # member computes 1/k of the row tiles of every op that can be cut that way (conv())
         self.xchg_floats = 0               # largest tile (positions x padded channels) a split op exchanges
         self.grouped = False               # member views of a GROUPED program (k trajectories over k workgroups): see conv()
+        self.group_on = True               # ... ops lowered while this is off stay ordinary ops (the classifier's part of a guided program)
 
     def add(self, t: torch.Tensor, pad_to: int = 4) -> int:
         t = t.detach().to(device=self.device, dtype=torch.float32).reshape(-1)
@@ -306,7 +307,7 @@ class _Builder2:
             # ---- grouped op (member view of a grouped program): all k trajectories of the group ride the column axis ----
             ex_srcs = [a for ex in (extra or []) for a in ex["srcs"]]
             w_bytes = 4 * (w_eff.numel() + sum(ex["w_eff"].numel() for ex in (extra or [])))
-            gop = (self.grouped and self.member[1] > 1 and stride == 1 and bwd is None and save is None and not col_norm
+            gop = (self.grouped and self.group_on and self.member[1] > 1 and stride == 1 and bwd is None and save is None and not col_norm
                    and dst.gcap and all(a.gcap and a.length == l_out for a in list(srcs) + ex_srcs) and (res is None or res.gcap)
                    and w_bytes >= group_min_bytes())
             if gop:
@@ -1433,7 +1434,8 @@ def compile_janner2_group(net, horizon: int, k: int, max_lds_bytes: int = 160 * 
 
 
 def compile_guided2(net, clf, horizon: int, max_lds_bytes: int = 160 * 1024, nw: int = NW2_MAX, save_global: bool = False,
-                    max_stage: Optional[int] = None, compact: bool = False) -> Program2:
+                    max_stage: Optional[int] = None, compact: bool = False, member: Tuple[int, int] = (0, 1), grouped: bool = False,
+                    alias_residual: Optional[bool] = None) -> Program2:
     """Denoiser forward + classifier forward/backward as ONE op list (classifier-guided sampling, reference
     diffusionsde.py:153-173): ops [0, n_den) write the prediction, the rest writes d log p / d x_t into the gradient slot; the
     kernel's solver step shifts the prediction by cg_scale[step] * gradient before clipping.  Both networks read the state slot."""
@@ -1447,7 +1449,12 @@ def compile_guided2(net, clf, horizon: int, max_lds_bytes: int = 160 * 1024, nw:
     b.save_global = save_global          # saved x_hat tensors in global memory: the LDS plan shrinks enough for two trajectories
     if max_stage is not None:
         b.max_stage = max_stage
-    b.alias_residual = compact
+    b.alias_residual = compact if alias_residual is None else alias_residual
+    b.member, b.grouped = member, grouped
+    if member[1] > 1:                    # member view of a GROUPED guided program (compile_guided2_group)
+        if compact or nw != NW2_MAX or not grouped:
+            raise ValueError("grouped guided programs: the 8-wave, state-in-LDS form only")
+        b.fuse_max = 1 << 30
     d = net.in_dim
     if compact:
         b.ws_floats = (horizon * d + 3) // 4 * 4         # workspace of a trajectory: [multistep memory | saved tensors]
@@ -1459,6 +1466,7 @@ def compile_guided2(net, clf, horizon: int, max_lds_bytes: int = 160 * 1024, nw:
     t, fc, blocks = _lower_janner(b, net, horizon, x)
     b.conv([t], pred, _conv1d_eff(fc[3]), fc[3].bias, pred=True)
     n_den = len(b.ops)
+    b.group_on = False                   # (grouped guided programs: the classifier's layers stay on the member's own trajectory)
     emb_den = _emb_table_spec(b, net, blocks, dev)
     xc = x
     if compact:
@@ -1473,4 +1481,31 @@ def compile_guided2(net, clf, horizon: int, max_lds_bytes: int = 160 * 1024, nw:
     prog.meta["n_den"] = n_den
     prog.meta["cls_first"], prog.meta["head_op"] = n_den, b.head_index      # final log_p forward: ops [cls_first, head_op] once more
     prog.ws_floats = b.ws_floats
+    prog.meta["xchg_floats"] = b.xchg_floats
+    prog.meta["n_gops"] = sum(1 for oa in b.op_acts if oa.get("gop"))
     return prog
+
+
+def compile_guided2_group(net, clf, horizon: int, k: int, max_lds_bytes: int = 160 * 1024, save_global: bool = False) -> Program2:
+    """The guided program with its DENOISER's stream-bound layers grouped (`compile_janner2_group`): k trajectories over the k workgroups
+    of a group, member m computes 1/k of the output channels of those layers for all k trajectories and the members all-gather through
+    L2; every other op -- the rest of the denoiser, the classifier's forward and backward ops with their saved tensors, the solver
+    step, the final log_p pass -- runs on the member's own trajectory as in the ordinary guided program (`cdx_unet2_kernel<1, 8, true,
+    ..., split>`)."""
+    if k not in (2, 4):
+        raise ValueError("group size 2 or 4")
+    members = None
+    for alias in (False, True):
+        try:
+            members = [compile_guided2(net, clf, horizon, max_lds_bytes=max_lds_bytes, member=(m, k), grouped=True, alias_residual=alias,
+                                       save_global=save_global) for m in range(k)]
+            break
+        except ValueError:
+            if alias:
+                raise
+    p0 = _merge_members(members, k)
+    p0.meta["group_k"] = k
+    del p0.meta["split_k"]
+    if p0.meta["n_gops"] == 0:
+        raise ValueError("grouped guided program: no op of the denoiser streams enough weights to be grouped")
+    return p0

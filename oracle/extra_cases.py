@@ -335,11 +335,13 @@ GPU_ONLY: Dict[str, Callable] = {
     # round 6: config 5 ACROSS the executor's real chunk boundary -- cdx_resmlp_run cuts a call into 16 384-row chunks (what one rank of
     # the 8-GPU run does eight times per call); the fixture holds the reference's result for the rows either side of the cut
     "baseline_cfg5_b16684": baseline_config("cfg5", 16384 + 300),
+    # round 6: the classifier-guided Diffuser loop at a batch the GROUPED guided program serves (128 < B <= 256; 200 = 50 groups of four)
+    "baseline_cfg2_guided_b200": baseline_config("cfg2_guided", 200),
 }
 # Fixtures of these scenarios hold the listed ROWS only (the reference sampled just those: samples are independent; the device run is the whole batch)
 ROW_SUBSET = {"baseline_cfg5_b16684": [0, 1, 255, 256, 8191, 16382, 16383, 16384, 16385, 16511, 16512, 16683]}
 # Fixtures of these scenarios keep every STRIDE-th trajectory only (trajectories are independent; the device run is the whole batch)
-SUBSAMPLED = {"baseline_cfg4_tied_b512": 4}
+SUBSAMPLED = {"baseline_cfg4_tied_b512": 4, "baseline_cfg2_guided_b200": 3}
 
 
 # --------------------------------------------------------------------------------------------------------------------- #

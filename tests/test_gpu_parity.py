@@ -3042,6 +3042,64 @@ def test_headline_batch_takes_the_grouped_program_and_matches_the_reference(amd_
     assert runtime2.group_factor(256) == 4 and runtime2.group_factor(200) == 4 and runtime2.group_factor(128) == 1 and runtime2.group_factor(300) == 1
 
 
+def test_guided_batch_of_200_takes_the_grouped_guided_program_and_matches_the_reference(amd_lib, monkeypatch):
+    """Round 6: the classifier-guided Diffuser loop at 128 < B <= 256 runs as a GROUPED guided program -- groups of four
+    workgroups share the weight stream of the denoiser's ten stream-bound layers, the classifier's forward / backward ops, the solver
+    step and the final log_p run on each member's own trajectory; one launch + its idle repair launch.  Against the fixture the real
+    reference produced for 200 such trajectories (every third one kept), x and log_p; bit-reproducible; within summation-order noise
+    of the ordinary guided program; a ragged last group (B = 130) as well."""
+    from cleandiffuser_amd.engine import runtime2
+    from oracle import extra_cases
+    dev = torch.device(DEV)
+    if runtime2._group_ok.get(dev) is not True:
+        pytest.skip("the grouped mode failed its self-check on this device")
+    seen = []
+    orig = runtime2.launch
+
+    def spy(comp, **kws):
+        if kws.get("run_if") is None:
+            seen.append((kws.get("split"), kws.get("group"), comp.prog.meta.get("n_gops"), kws.get("cg_scale") is not None))
+        return orig(comp, **kws)
+    monkeypatch.setattr(runtime2, "launch", spy)
+    out, gold = _extra("baseline_cfg2_guided_b200")
+    torch.cuda.synchronize()
+    runtime2.check_split_errors()
+    if runtime2._gguided_ok.get(dev) is not True:
+        pytest.fail("the grouped guided mode failed its first-use check against the ordinary guided program")
+    seen.clear()
+    out2, _ = _extra("baseline_cfg2_guided_b200")
+    torch.cuda.synchronize()
+    runtime2.check_split_errors()
+    assert seen == [(4, True, 10, True)], seen
+    assert torch.equal(out["x"], out2["x"]) and torch.equal(out["log_p"], out2["log_p"]), "not deterministic"
+    st = int(gold["stride"][0])
+    np.testing.assert_allclose(out["x"].cpu().numpy()[::st], gold["x"], **TOL)
+    np.testing.assert_allclose(out["log_p"].cpu().numpy()[::st], gold["log_p"], rtol=1e-4, atol=1e-4)
+    monkeypatch.setenv("CDX_UNET2_GUIDED_GROUP", "0")
+    plain, _ = _extra("baseline_cfg2_guided_b200")
+    assert seen[-1][:2] in ((0, False), (None, None)) and seen[-1][3]
+    np.testing.assert_allclose(out["x"].cpu().numpy(), plain["x"].cpu().numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(out["log_p"].cpu().numpy(), plain["log_p"].cpu().numpy(), rtol=2e-4, atol=2e-4)
+    monkeypatch.delenv("CDX_UNET2_GUIDED_GROUP")
+    # ragged: 130 trajectories = 32 groups + a group of two (its other two members compute on zeros)
+    agent, _ = cases.build(amd_lib, "janner_cfg2_guided_ddpm", device=DEV)
+    g = torch.Generator().manual_seed(41)
+    B = 130
+    prior = torch.zeros(B, 32, 23)
+    prior[:, 0, :17] = torch.randn(B, 17, generator=g)
+    zs = [torch.randn(B, 32, 23, generator=g).to(DEV) for _ in range(6)]
+    kw = dict(solver="ddpm", n_samples=B, sample_steps=5, temperature=0.5, w_cg=0.3)
+    seen.clear()
+    xg, lg = agent.sample(prior.to(DEV), noise=list(zs), **kw)
+    assert seen == [(4, True, 10, True)], seen
+    monkeypatch.setenv("CDX_UNET2_GUIDED_GROUP", "0")
+    xp, lp = agent.sample(prior.to(DEV), noise=list(zs), **kw)
+    torch.cuda.synchronize()
+    runtime2.check_split_errors()
+    np.testing.assert_allclose(xg.cpu().numpy(), xp.cpu().numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(lg["log_p"].cpu().numpy(), lp["log_p"].cpu().numpy(), rtol=2e-4, atol=2e-4)
+
+
 def test_seeded_device_runs_do_not_depend_on_the_executor(amd_lib, monkeypatch):
     """with torch.manual_seed on the ROCm device the same request must give the same trajectories whether the
     whole-loop launch serves it or the per-step host loop does (``requires_grad=True``, a forced fallback): both draw the loop's noise
@@ -3093,6 +3151,55 @@ def test_device_query_reports_a_whole_mi355x(amd_lib, monkeypatch):
     torch.cuda.synchronize()
     assert seen == [(0, False, False)], seen
     np.testing.assert_allclose(out["x"].cpu().numpy(), gold["x"], **TOL)
+
+
+def test_a_lost_granule_of_a_grouped_guided_launch_never_reaches_the_caller(amd_lib, monkeypatch):
+    """The same fault hook on the GROUPED GUIDED launch: trajectories AND log_p of the call are the ordinary guided program's, bit for
+    bit (the repair launch rewrites both), never NaN; the next guided call takes the ordinary program."""
+    from cleandiffuser_amd.engine import runtime2
+    dev = torch.device(DEV)
+    if runtime2._group_ok.get(dev) is not True:
+        pytest.skip("the grouped mode failed its self-check on this device")
+    agent, _ = cases.build(amd_lib, "janner_cfg2_guided_ddpm", device=DEV)
+    g = torch.Generator().manual_seed(12)
+    B = 160
+    prior = torch.zeros(B, 32, 23)
+    prior[:, 0, :17] = torch.randn(B, 17, generator=g)
+    zs = [torch.randn(B, 32, 23, generator=g).to(DEV) for _ in range(4)]
+    kw = dict(solver="ddpm", n_samples=B, sample_steps=3, temperature=0.5, w_cg=0.3)
+    seen = []
+    orig = runtime2.launch
+
+    def spy(comp, **kws):
+        seen.append((kws.get("split") or 0, kws.get("run_if") is not None))
+        return orig(comp, **kws)
+    try:
+        monkeypatch.setenv("CDX_UNET2_GUIDED_GROUP", "0")
+        plain, lp = agent.sample(prior.to(DEV), noise=list(zs), **kw)
+        monkeypatch.delenv("CDX_UNET2_GUIDED_GROUP")
+        agent.sample(prior.to(DEV), noise=list(zs), **kw)                      # (first use on this device: the mode's own check)
+        torch.cuda.synchronize()
+        assert runtime2._gguided_ok.get(dev) is True and runtime2.note_exchange_failure(dev) is False
+        monkeypatch.setattr(runtime2, "launch", spy)
+        monkeypatch.setenv("CDX_UNET2_FAULT", "2")
+        hurt, lh = agent.sample(prior.to(DEV), noise=list(zs), **kw)
+        monkeypatch.delenv("CDX_UNET2_FAULT")
+        assert seen == [(4, False), (0, True)], seen
+        torch.cuda.synchronize()
+        assert int(runtime2._split_errs[dev][1][0]) != 0, "the fault hook starved nobody: nothing was tested"
+        assert torch.isfinite(hurt).all() and torch.isfinite(lh["log_p"]).all(), "a failed exchange reached the caller"
+        assert torch.equal(hurt, plain) and torch.equal(lh["log_p"], lp["log_p"]), "the repair launch must leave the ordinary program's result"
+        with pytest.warns(UserWarning, match="never received a granule"):
+            after, la = agent.sample(prior.to(DEV), noise=list(zs), **kw)
+        assert seen[-1] == (0, False) and runtime2._gguided_ok[dev] is False
+        assert torch.equal(after, plain) and torch.equal(la["log_p"], lp["log_p"])
+    finally:
+        try:
+            runtime2.check_split_errors(dev, wait=True)
+        except RuntimeError:
+            pass
+        runtime2._group_ok[dev] = runtime2._split_ok[dev] = True
+        runtime2._gguided_ok.pop(dev, None)
 
 
 @pytest.mark.parametrize("B", [256, 32])
@@ -3152,6 +3259,7 @@ def test_a_lost_granule_never_reaches_the_caller(B, amd_lib, monkeypatch):
         except RuntimeError:
             pass
         runtime2._group_ok[dev] = runtime2._split_ok[dev] = True
+        runtime2._gguided_ok.pop(dev, None)              # (the grouped guided mode checks itself again on its next use)
     monkeypatch.setattr(runtime2, "launch", orig)
     again, _ = agent.sample(prior.to(DEV), noise=list(zs), **kw)
     torch.cuda.synchronize()

@@ -518,6 +518,42 @@ def test_lane_sim2_grouped_program_reproduces_reference_forward(k, amd_lib):
     assert all(np.array_equal(a, b) for a, b in zip(outs, again))
 
 
+@pytest.mark.parametrize("k", [2, 4])
+def test_lane_sim2_grouped_guided_program_prediction_and_gradient(k, amd_lib):
+    """Round 6: the GROUPED GUIDED program (P2.compile_guided2_group) -- the denoiser's ten stream-bound layers grouped as in the
+    unguided grouped program, every other op (the rest of the denoiser, the classifier's forward and backward ops with their saved
+    tensors) on the member's own trajectory.  The twin steps the k member views in lockstep on k different trajectories (NaN-poisoned
+    LDS): every member's prediction is the module's forward of ITS trajectory and its gradient slot torch.autograd's
+    d classifier(x, t).sum() / d x of that trajectory; the classifier's descriptors carry no cut / exchange words."""
+    from oracle.lane_sim2 import run_forward_group
+    H, D = 32, 23
+    net = load_synth(amd_lib.JannerUNet1d(D, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2, 2], kernel_size=5), 53).eval()
+    clf = load_synth(amd_lib.HalfJannerUNet1d(H, D, out_dim=1, model_dim=32, emb_dim=32, dim_mult=(1, 2, 2, 2), kernel_size=3), 54).eval()
+    prog = P2.compile_guided2_group(net, clf, H, k)
+    assert prog.lds_bytes(1) <= 160 * 1024 and prog.meta["group_k"] == k and len(prog.meta["member_ops"]) == k and prog.grad_off > 0
+    n_den = prog.meta["n_den"]
+    for ops in prog.meta["member_ops"]:
+        assert sum(1 for op in ops[:n_den] if int(op[P2.W2_XG]) & P2.XG_GOP) == 10
+        # behind the denoiser: ordinary ops only (W2_XG aliases W2_DST2 there: an LDS offset, none of the cut / exchange bits)
+        assert all(int(op[P2.W2_XG]) & (P2.XG_XCHG | P2.XG_GOP | P2.XG_TRAJ) == 0 for op in ops[n_den:])
+    g = torch.Generator().manual_seed(23)
+    xs = 0.7 * torch.randn(k, H, D, generator=g)
+    t = torch.tensor([9])
+    xr = xs.clone().requires_grad_()
+    clf._forward_torch(xr, t.expand(k), None).sum().backward()
+    with torch.no_grad():
+        ref = net._forward_torch(xs, t.expand(k), None).numpy()
+        row = emb_table(prog, None, [net.map_noise(t).numpy(), clf.map_noise(t).numpy()])[0]
+    sims = [LaneSim2(prog, member=m) for m in range(k)]
+    for m, s in enumerate(sims):
+        s.load_x(xs[m].numpy())
+    outs = run_forward_group(sims, row)
+    for m in range(k):
+        np.testing.assert_allclose(outs[m], ref[m], rtol=2e-5, atol=2e-5, err_msg=f"member {m}: prediction")
+        want = xr.grad[m].numpy()
+        np.testing.assert_allclose(sims[m].grad(), want, rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(want).max())), err_msg=f"member {m}: gradient")
+
+
 def test_grouped_program_of_other_shapes_compiles_or_refuses_cleanly(amd_lib):
     """Nets whose deepest level does not offer a grouped op (too few channels for whole lane groups per member, a horizon whose deepest
     level is longer than 16 / k positions) must answer ValueError -- the signal that keeps a request on the ordinary program."""
