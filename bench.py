@@ -292,8 +292,9 @@ def other_configs(device):
     big("config2_B32", bc.cfg2big, "cdx_unet2_kernel<1, 8, ..., split>: one trajectory over 4 workgroups of an XCD, all-gather of the cut "
         "ops through L2 (latency is the figure of merit: ms_per_call)", reps=10, B=32)
     big("config2_B128", bc.cfg2big, "cdx_unet2_kernel<1, 8, ..., split>: one trajectory over 2 workgroups of an XCD", reps=10, B=128)
-    big("config2_guided_B256", bc.cfg2g, "cdx_unet2_kernel<1, 8, true>: denoiser forward + classifier forward/backward + shifted solver step, "
-        "one launch per guided sample() call", B=256)
+    big("config2_guided_B256", bc.cfg2g, "cdx_unet2_kernel<1, 8, true, ..., split> as a GROUPED guided program (round 6): denoiser forward with its ten "
+        "stream-bound layers grouped over 4 workgroups + classifier forward/backward on each member's own trajectory + shifted solver step "
+        "+ final log_p, one launch per guided sample() call (and its idle repair launch)", reps=10, B=256)
     big("config2_guided_B3200", bc.cfg2g, "cdx_unet2_kernel<3, 8, true>: three trajectories per workgroup (compact guided program, saved "
         "normalised tensors in a global workspace), 4 rounds of 768 + 128 one per workgroup; the batch the shipped Diffuser pipelines "
         "sample (50 environments x 64 plans, all with w_cg > 0)", reps=2, B=3200)
