@@ -1435,6 +1435,8 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8 || T == 1) ? 2 : 1) void cdx_un
             if (on2 >= L.n_ops) on2 = 0;
             // (MLP programs: `pass` tells the context-slot op what to load -- 0 the condition, 1 zeros (unconditional forward of a
             //  pair), 2 nothing: one forward per step and the slot was filled by step 0)
+            // (grouped GUIDED programs: running the classifier's ops -- ordinary ops in every member's view -- on the instantiation without
+            //  member / exchange code changes nothing: 9.60-9.68 ms either way, profiles/r06_guided_group_ab.txt)
             run_op<T, NWV, BWD, PROF, COND, MLP, SPLIT, SPLIT>(L, ops, vd, vdn, it, emb_row, emb_tstride, lds, tid, ring, pslot, b0, F,
                                                                wrap ? emb_fwd_next : emb_row, wrap ? ts_fwd_next : emb_tstride, on2,
                                                                (MLP && n_pass == 1 && step > 0) ? 2 : pass, &X);
