@@ -1,0 +1,42 @@
+"""Stress of the GROUPED GUIDED launch (GPU box): N calls at B = 256 / 200 / 130 with fresh draws, each compared with the ordinary guided
+program on the same draws; reports the largest deviation, lost granules (none expected) and whether the mode stayed on."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cleandiffuser_amd.classifier import CumRewClassifier  # noqa: E402
+from cleandiffuser_amd.diffusion import DiscreteDiffusionSDE  # noqa: E402
+from cleandiffuser_amd.engine import runtime2  # noqa: E402
+from cleandiffuser_amd.nn_classifier import HalfJannerUNet1d  # noqa: E402
+from cleandiffuser_amd.nn_diffusion import JannerUNet1d  # noqa: E402
+from cleandiffuser_amd.utils import load_synth  # noqa: E402
+
+DEV = "cuda:0"
+net = load_synth(JannerUNet1d(23, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2, 2], kernel_size=5))
+clf_net = load_synth(HalfJannerUNet1d(32, 23, out_dim=1, model_dim=32, emb_dim=32, dim_mult=(1, 2, 2, 2), kernel_size=3), 1)
+fix = torch.zeros(32, 23)
+fix[0, :17] = 1.0
+agent = DiscreteDiffusionSDE(net, None, fix_mask=fix, classifier=CumRewClassifier(clf_net, device=DEV), diffusion_steps=20, predict_noise=False, device=DEV)
+agent.eval()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+g = torch.Generator().manual_seed(5)
+worst = 0.0
+for i in range(n):
+    B = (256, 200, 130)[i % 3]
+    prior = torch.zeros(B, 32, 23)
+    prior[:, 0, :17] = torch.randn(B, 17, generator=g)
+    zs = [torch.randn(B, 32, 23, generator=g).to(DEV) for _ in range(5)]
+    kw = dict(solver="ddpm", n_samples=B, sample_steps=4, temperature=0.5, w_cg=0.2)
+    os.environ.pop("CDX_UNET2_GUIDED_GROUP", None)
+    xg, lg = agent.sample(prior.to(DEV), noise=list(zs), **kw)
+    os.environ["CDX_UNET2_GUIDED_GROUP"] = "0"
+    xp, lp = agent.sample(prior.to(DEV), noise=list(zs), **kw)
+    d = max(float((xg - xp).abs().max()), float((lg["log_p"] - lp["log_p"]).abs().max()))
+    assert torch.isfinite(xg).all() and d < 5e-4, (i, B, d)
+    worst = max(worst, d)
+torch.cuda.synchronize()
+runtime2.check_split_errors()
+dev = torch.device(DEV)
+print(f"{n} grouped guided calls: max |grouped - ordinary| = {worst:.3e}; mode still on: {runtime2._gguided_ok.get(dev)}; lost granules: {int(runtime2._split_errs[dev][1][0]) if dev in runtime2._split_errs else 0}")
