@@ -1764,7 +1764,7 @@ int cdx_unet2_run(const cdx_unet2_launch* L, void* hip_stream) {
             !L->xbuf || !L->xerr || L->xchg_floats <= 0 || (L->xchg_floats & 3)) {
             cdx_set_err("split / grouped program: split_k 2 or 4, one trajectory per workgroup, 8 waves, unconditional, xbuf / xerr given"); return CDX_EINVAL;
         }
-        if (guided && (!L->split_group || L->prof)) { cdx_set_err("programs with backward ops: the GROUPED form only (split_group), no op profiling"); return CDX_EINVAL; }
+        if (guided && L->prof) { cdx_set_err("split / grouped programs with backward ops: no op profiling"); return CDX_EINVAL; }
         // split: split_k workgroups per trajectory; grouped: split_k trajectories per group of split_k workgroups.  ALWAYS one workgroup
         // per CU of the whole chip -- 256, 32 per XCD, all resident: that is what lets the workgroups form their groups from per-XCD
         // tickets (see XState); groups past the batch compute on zeros

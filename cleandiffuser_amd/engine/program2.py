@@ -224,7 +224,7 @@ class _Builder2:
                                            # member computes 1/k of the row tiles of every op that can be cut that way (conv())
         self.xchg_floats = 0               # largest tile (positions x padded channels) a split op exchanges
         self.grouped = False               # member views of a GROUPED program (k trajectories over k workgroups): see conv()
-        self.group_on = True               # ... ops lowered while this is off stay ordinary ops (the classifier's part of a guided program)
+        self.group_on = True               # ... ops lowered while this is off are neither grouped nor cut (the classifier's part of a guided program)
 
     def add(self, t: torch.Tensor, pad_to: int = 4) -> int:
         t = t.detach().to(device=self.device, dtype=torch.float32).reshape(-1)
@@ -346,7 +346,7 @@ class _Builder2:
                 self.xchg_floats = max(self.xchg_floats, l_cols * coutp)
                 for a in list(srcs) + ex_srcs + [dst] + ([res] if res is not None else []):
                     a.gk = ksp                               # these slots hold the group's k trajectories from now on
-        elif ksp > 1 and not self.grouped and worth and len(phases) == 1 and n_rt > 1 and bwd is None and save is None and (n_rt % ksp == 0 or ksp % n_rt == 0):
+        elif ksp > 1 and not self.grouped and self.group_on and worth and len(phases) == 1 and n_rt > 1 and bwd is None and save is None and (n_rt % ksp == 0 or ksp % n_rt == 0):
             cand = list(range(mem * n_rt // ksp, (mem + 1) * n_rt // ksp)) if n_rt >= ksp else [mem * n_rt // ksp]
             cgw = coutp // GROUPS2
             lo_c, hi_c = cand[0] * rows, (cand[-1] + 1) * rows
@@ -1451,9 +1451,9 @@ def compile_guided2(net, clf, horizon: int, max_lds_bytes: int = 160 * 1024, nw:
         b.max_stage = max_stage
     b.alias_residual = compact if alias_residual is None else alias_residual
     b.member, b.grouped = member, grouped
-    if member[1] > 1:                    # member view of a GROUPED guided program (compile_guided2_group)
-        if compact or nw != NW2_MAX or not grouped:
-            raise ValueError("grouped guided programs: the 8-wave, state-in-LDS form only")
+    if member[1] > 1:                    # member view of a GROUPED / SPLIT guided program (compile_guided2_group / _split)
+        if compact or nw != NW2_MAX:
+            raise ValueError("grouped / split guided programs: the 8-wave, state-in-LDS form only")
         b.fuse_max = 1 << 30
     d = net.in_dim
     if compact:
@@ -1484,6 +1484,16 @@ def compile_guided2(net, clf, horizon: int, max_lds_bytes: int = 160 * 1024, nw:
     prog.meta["xchg_floats"] = b.xchg_floats
     prog.meta["n_gops"] = sum(1 for oa in b.op_acts if oa.get("gop"))
     return prog
+
+
+def compile_guided2_split(net, clf, horizon: int, k: int, max_lds_bytes: int = 160 * 1024) -> Program2:
+    """The guided program for SMALL batches (B x k <= 256 workgroups): one trajectory over k workgroups of an XCD as in
+    `compile_janner2_split` -- the DENOISER's ops that can be cut by row tiles are, with an all-gather behind each; the classifier's
+    forward / backward ops, the solver step and the final log_p pass are computed by every member on its own copy of the trajectory."""
+    if k not in (2, 4):
+        raise ValueError("split factor 2 or 4")
+    members = [compile_guided2(net, clf, horizon, max_lds_bytes=max_lds_bytes, member=(m, k)) for m in range(k)]
+    return _merge_members(members, k)
 
 
 def compile_guided2_group(net, clf, horizon: int, k: int, max_lds_bytes: int = 160 * 1024, save_global: bool = False) -> Program2:

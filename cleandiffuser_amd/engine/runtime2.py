@@ -466,7 +466,7 @@ def note_exchange_failure(device) -> bool:
     if ent is None or int(ent[1][0]) == 0:
         return False
     if _split_ok.get(device) is not False or _group_ok.get(device) is not False:
-        _split_ok[device] = _group_ok[device] = _gguided_ok[device] = False
+        _split_ok[device] = _group_ok[device] = _gguided_ok[device] = _sguided_ok[device] = False
         last_exchange_error[device] = _report_of(ent[1])
         warnings.warn("cdx_unet2_run (split / grouped program): a member never received a granule; the affected request was recomputed by "
                       "the ordinary program on the same stream (repair launch), and both modes are now off for this device "
@@ -485,7 +485,7 @@ def check_split_errors(device=None, wait: bool = True):
         if wait:
             torch.cuda.synchronize(dev)
         if int(word[0]) != 0:
-            _split_ok[dev] = _group_ok[dev] = _gguided_ok[dev] = False
+            _split_ok[dev] = _group_ok[dev] = _gguided_ok[dev] = _sguided_ok[dev] = False
             last_exchange_error[dev] = _report_of(word)
             if wait:
                 word[:] = 0
@@ -873,21 +873,32 @@ def compiled_guided2(net, clf_net, horizon: int, two: bool = False, three: bool 
 
 _ggcache = weakref.WeakKeyDictionary()
 _gguided_ok = {}     # device -> did the grouped GUIDED mode pass its one-time check there (absent: not checked yet)
+_sguided_ok = {}     # ... the small-batch (split) GUIDED mode
 
 
 def compiled_guided_group2(net, clf_net, horizon: int, k: int) -> _Compiled2:
     """The GROUPED guided program (P2.compile_guided2_group): the denoiser's stream-bound layers computed per member for 1/k of the output
     channels of the group's k trajectories, everything else -- the classifier's forward / backward ops included -- on the member's own
     trajectory.  ``.prog is None`` + ``.why`` when it does not exist."""
+    return _compiled_guided_members(net, clf_net, horizon, k, True)
+
+
+def compiled_guided_split2(net, clf_net, horizon: int, k: int) -> _Compiled2:
+    """The SMALL-BATCH guided program (P2.compile_guided2_split): one trajectory over k workgroups of an XCD, the denoiser's ops cut by
+    row tiles where that pays, the classifier's ops computed by every member."""
+    return _compiled_guided_members(net, clf_net, horizon, k, False)
+
+
+def _compiled_guided_members(net, clf_net, horizon: int, k: int, group: bool) -> _Compiled2:
     per = _ggcache.setdefault(net, {})
     sig = (R._signature(net), R._signature(clf_net))
-    key = (id(clf_net), horizon, k, P2.group_min_bytes())
+    key = (id(clf_net), horizon, k, group, P2.group_min_bytes())
     hit = per.get(key)
     if hit is not None and hit.sig == sig:
         return hit
     with torch.no_grad():
         try:
-            comp = _Compiled2(P2.compile_guided2_group(net, clf_net, horizon, k), sig)
+            comp = _Compiled2((P2.compile_guided2_group if group else P2.compile_guided2_split)(net, clf_net, horizon, k), sig)
         except ValueError as e:
             comp = _Compiled2(None, sig, str(e))
     per[key] = comp
@@ -950,30 +961,37 @@ def guided_sample2(solver, net, clf_net, plan, xt, prior, feed, fix_mask, x_min,
         # GROUPED guided launch (round 6): one trajectory per CU, groups of k workgroups share the weight stream of the denoiser's
         # stream-bound layers -- the unguided grouped mode (`sample2`) with the classifier's ops on each member's own trajectory; same
         # gates (whole chip, no capture, no lost granule so far), same repair launch, same one-time check against the ordinary program
-        gk, galt = 1, None
+        # ... and below 129 trajectories the SMALL-BATCH form: one trajectory over 2 or 4 workgroups, the denoiser's ops cut by row tiles
+        # (`compile_guided2_split`), the classifier's ops computed by every member (CDX_UNET2_GUIDED_SPLIT=0: off)
+        gk, galt, ggroup = 1, None, True
         capturing = dev.type == "cuda" and torch.cuda.is_current_stream_capturing()
-        if forced is None and t == 1 and parts is None and with_logp and not capturing and R._prof["buf"] is None and \
-                os.environ.get("CDX_UNET2_GUIDED_GROUP", "1") != "0" and _modes_allowed(dev) and _gguided_ok.get(dev, True):
-            gk = group_factor(b)
-            if gk > 1:
-                galt = compiled_guided_group2(net, clf_net, h, gk)
-                if galt.prog is None or galt.prog.meta.get("cls_first") is None:
-                    gk, galt = 1, None
+        if forced is None and t == 1 and parts is None and with_logp and not capturing and R._prof["buf"] is None and _modes_allowed(dev):
+            if os.environ.get("CDX_UNET2_GUIDED_GROUP", "1") != "0" and _gguided_ok.get(dev, True):
+                gk = group_factor(b)
+                if gk > 1:
+                    galt = compiled_guided_group2(net, clf_net, h, gk)
+            if galt is None and os.environ.get("CDX_UNET2_GUIDED_SPLIT", "1") != "0" and _sguided_ok.get(dev, True):
+                gk = split_factor(b)
+                if gk > 1:
+                    galt, ggroup = compiled_guided_split2(net, clf_net, h, gk), False
+            if galt is not None and galt.prog is None:
+                gk, galt = 1, None
         if galt is not None:
+            ok_map = _gguided_ok if ggroup else _sguided_ok
             gemb = plan_film_table(galt, net, plan, dev, modules=[net, clf_net], zero_row=with_logp)
-            launch(galt, x_out=out, t_per_wg=1, split=gk, group=True, logp_out=logp, **{**kw, "emb": gemb})
+            launch(galt, x_out=out, t_per_wg=1, split=gk, group=ggroup, logp_out=logp, **{**kw, "emb": gemb})
             if _repair_on():
                 launch(comp, x_out=out, t_per_wg=t, logp_out=logp, run_if=_split_err(dev), **kw)
-            if dev not in _gguided_ok:
+            if dev not in ok_map:
                 ref, ref_logp = torch.empty_like(xin), torch.empty_like(logp)
                 launch(comp, x_out=ref, t_per_wg=t, logp_out=ref_logp, **kw)
                 try:
                     check_split_errors(dev, wait=True)
                     good = bool(torch.allclose(out, ref, rtol=1e-3, atol=1e-3)) and bool(torch.allclose(logp, ref_logp, rtol=1e-3, atol=1e-3))
                 except RuntimeError as e:
-                    warnings.warn(f"first-use check of the grouped guided mode: {e}")
+                    warnings.warn(f"first-use check of the {'grouped' if ggroup else 'small-batch'} guided mode: {e}")
                     good = False
-                _gguided_ok[dev] = good
+                ok_map[dev] = good
                 if not good:
                     out, logp = ref, ref_logp
             elif _sync_check(True):

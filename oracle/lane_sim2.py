@@ -461,6 +461,12 @@ def mlp_rows(prog: P2.Program2, net, t) -> np.ndarray:
     return out.numpy().astype(np.float32)
 
 
+def _xg(op) -> int:
+    """The op's cut / exchange word: W2_XG aliases W2_DST2, which ops with backward extras (the classifier's part of a split / grouped
+    GUIDED program) use under its own name -- they are never cut (kernel: run_op)."""
+    return 0 if int(op[P2.W2_FLAGS]) & (P2.F2_GNBWD | P2.F2_SAVE | P2.F2_DUAL) else int(op[P2.W2_XG])
+
+
 def run_forward_split(sims, emb_row):
     """One forward of a SPLIT program: `sims[m]` = LaneSim2(prog, member=m), all loaded with the same state.  The members step through
     the op list together; after an op that is cut over the members (W2_XG) every member receives the channels it did not compute from
@@ -470,7 +476,7 @@ def run_forward_split(sims, emb_row):
     for i in range(len(sims[0].ops)):
         for s in sims:
             s.run_op(s.ops[i], emb_row)
-        xgs = [int(s.ops[i][P2.W2_XG]) for s in sims]
+        xgs = [_xg(s.ops[i]) for s in sims]
         if not any(xgs):
             continue
         assert all(xgs), "an op is split for every member or for none"
@@ -508,7 +514,7 @@ def run_forward_group(sims, emb_row):
     for i in range(len(sims[0].ops)):
         for s in sims:
             s.run_op(s.ops[i], emb_row)
-        xgs = [int(s.ops[i][P2.W2_XG]) for s in sims]
+        xgs = [_xg(s.ops[i]) for s in sims]
         if not any(x & P2.XG_XCHG for x in xgs):
             continue
         assert all(x & P2.XG_XCHG for x in xgs), "an op is exchanged by every member or by none"

@@ -41,6 +41,11 @@ def _native_loaded():
     prior = torch.zeros(256, 32, 23, device=DEV)
     agent.sample(prior, n_samples=256, solver="ddim", sample_steps=2)
     torch.cuda.synchronize()
+    # ... and for the two GUIDED modes (round 6): the small-batch one at B = 8, the grouped one at B = 200
+    gagent, _ = cases.build(cases.lib_namespace("amd"), "janner_cfg2_guided_ddpm", device=DEV)
+    for nb in (8, 200):
+        gagent.sample(torch.zeros(nb, 32, 23, device=DEV), n_samples=nb, solver="ddpm", sample_steps=2, w_cg=0.1)
+    torch.cuda.synchronize()
 
 
 def _spy_launches(monkeypatch):
@@ -3100,6 +3105,56 @@ def test_guided_batch_of_200_takes_the_grouped_guided_program_and_matches_the_re
     np.testing.assert_allclose(lg["log_p"].cpu().numpy(), lp["log_p"].cpu().numpy(), rtol=2e-4, atol=2e-4)
 
 
+def test_small_guided_batch_takes_the_split_guided_program_and_matches_the_reference(amd_lib, monkeypatch):
+    """Round 6: the classifier-guided loop at B <= 128 runs as a SMALL-BATCH guided program -- one trajectory over 4 (B <= 64) or 2
+    workgroups of an XCD, the denoiser's ops cut by row tiles, the classifier's ops computed by every member; one launch + its idle
+    repair launch.  The B = 8 fixture of the real reference (x and log_p, 1e-4), bit-reproducible, within summation-order noise of the
+    ordinary guided program; B = 100 (two workgroups per trajectory) against the ordinary program."""
+    from cleandiffuser_amd.engine import runtime2
+    dev = torch.device(DEV)
+    if runtime2._split_ok.get(dev) is not True:
+        pytest.skip("the small-batch mode failed its self-check on this device")
+    assert runtime2._sguided_ok.get(dev) is True, "the small-batch guided mode failed its first-use check against the ordinary guided program"
+    seen = []
+    orig = runtime2.launch
+
+    def spy(comp, **kws):
+        if kws.get("run_if") is None:
+            seen.append((kws.get("split") or 0, bool(kws.get("group")), kws.get("cg_scale") is not None))
+        return orig(comp, **kws)
+    monkeypatch.setattr(runtime2, "launch", spy)
+    out, gold = _extra("baseline_cfg2_guided")
+    out2, _ = _extra("baseline_cfg2_guided")
+    torch.cuda.synchronize()
+    runtime2.check_split_errors()
+    assert seen == [(4, False, True)] * 2, seen
+    assert torch.equal(out["x"], out2["x"]) and torch.equal(out["log_p"], out2["log_p"]), "not deterministic"
+    np.testing.assert_allclose(out["x"].cpu().numpy(), gold["x"], **TOL)
+    np.testing.assert_allclose(out["log_p"].cpu().numpy(), gold["log_p"], rtol=1e-4, atol=1e-4)
+    monkeypatch.setenv("CDX_UNET2_GUIDED_SPLIT", "0")
+    plain, _ = _extra("baseline_cfg2_guided")
+    assert seen[-1] == (0, False, True)
+    np.testing.assert_allclose(out["x"].cpu().numpy(), plain["x"].cpu().numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(out["log_p"].cpu().numpy(), plain["log_p"].cpu().numpy(), rtol=2e-4, atol=2e-4)
+    monkeypatch.delenv("CDX_UNET2_GUIDED_SPLIT")
+    agent, _ = cases.build(amd_lib, "janner_cfg2_guided_ddpm", device=DEV)
+    g = torch.Generator().manual_seed(43)
+    B = 100
+    prior = torch.zeros(B, 32, 23)
+    prior[:, 0, :17] = torch.randn(B, 17, generator=g)
+    zs = [torch.randn(B, 32, 23, generator=g).to(DEV) for _ in range(6)]
+    kw = dict(solver="ddpm", n_samples=B, sample_steps=5, temperature=0.5, w_cg=0.3)
+    seen.clear()
+    xs, ls = agent.sample(prior.to(DEV), noise=list(zs), **kw)
+    assert seen == [(2, False, True)], seen
+    monkeypatch.setenv("CDX_UNET2_GUIDED_SPLIT", "0")
+    xp, lp = agent.sample(prior.to(DEV), noise=list(zs), **kw)
+    torch.cuda.synchronize()
+    runtime2.check_split_errors()
+    np.testing.assert_allclose(xs.cpu().numpy(), xp.cpu().numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(ls["log_p"].cpu().numpy(), lp["log_p"].cpu().numpy(), rtol=2e-4, atol=2e-4)
+
+
 def test_seeded_device_runs_do_not_depend_on_the_executor(amd_lib, monkeypatch):
     """with torch.manual_seed on the ROCm device the same request must give the same trajectories whether the
     whole-loop launch serves it or the per-step host loop does (``requires_grad=True``, a forced fallback): both draw the loop's noise
@@ -3200,6 +3255,7 @@ def test_a_lost_granule_of_a_grouped_guided_launch_never_reaches_the_caller(amd_
             pass
         runtime2._group_ok[dev] = runtime2._split_ok[dev] = True
         runtime2._gguided_ok.pop(dev, None)
+        runtime2._sguided_ok.pop(dev, None)
 
 
 @pytest.mark.parametrize("B", [256, 32])
@@ -3259,7 +3315,8 @@ def test_a_lost_granule_never_reaches_the_caller(B, amd_lib, monkeypatch):
         except RuntimeError:
             pass
         runtime2._group_ok[dev] = runtime2._split_ok[dev] = True
-        runtime2._gguided_ok.pop(dev, None)              # (the grouped guided mode checks itself again on its next use)
+        runtime2._gguided_ok.pop(dev, None)              # (the guided modes check themselves again on their next use)
+        runtime2._sguided_ok.pop(dev, None)
     monkeypatch.setattr(runtime2, "launch", orig)
     again, _ = agent.sample(prior.to(DEV), noise=list(zs), **kw)
     torch.cuda.synchronize()

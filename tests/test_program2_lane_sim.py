@@ -554,6 +554,40 @@ def test_lane_sim2_grouped_guided_program_prediction_and_gradient(k, amd_lib):
         np.testing.assert_allclose(sims[m].grad(), want, rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(want).max())), err_msg=f"member {m}: gradient")
 
 
+@pytest.mark.parametrize("k", [2, 4])
+def test_lane_sim2_split_guided_program_prediction_and_gradient(k, amd_lib):
+    """Round 6: the SMALL-BATCH guided program (P2.compile_guided2_split) -- one trajectory over k workgroups, the denoiser's ops cut by
+    row tiles exactly as in the unguided split program, the classifier's forward / backward ops computed by every member on its own
+    copy.  The twin steps the k member views in lockstep on ONE trajectory (NaN-poisoned LDS): every member ends with the module's
+    prediction and with torch.autograd's d classifier(x, t).sum() / d x."""
+    from oracle.lane_sim2 import run_forward_split
+    H, D = 32, 23
+    net = load_synth(amd_lib.JannerUNet1d(D, model_dim=32, emb_dim=32, dim_mult=[1, 2, 2, 2], kernel_size=5), 53).eval()
+    clf = load_synth(amd_lib.HalfJannerUNet1d(H, D, out_dim=1, model_dim=32, emb_dim=32, dim_mult=(1, 2, 2, 2), kernel_size=3), 54).eval()
+    prog = P2.compile_guided2_split(net, clf, H, k)
+    plain = P2.compile_janner2_split(net, H, k)
+    assert prog.lds_bytes(1) <= 160 * 1024 and prog.meta["split_k"] == k and len(prog.meta["member_ops"]) == k and prog.grad_off > 0
+    n_den = prog.meta["n_den"]
+    cut = [i for i, op in enumerate(prog.ops) if int(op[P2.W2_XG]) & P2.XG_XCHG]
+    assert cut == [i for i, op in enumerate(plain.ops) if int(op[P2.W2_XG]) & P2.XG_XCHG] and max(cut) < n_den
+    g = torch.Generator().manual_seed(29)
+    x = 0.7 * torch.randn(1, H, D, generator=g)
+    t = torch.tensor([5])
+    xr = x.clone().requires_grad_()
+    clf._forward_torch(xr, t, None).sum().backward()
+    with torch.no_grad():
+        ref = net._forward_torch(x, t, None)[0].numpy()
+        row = emb_table(prog, None, [net.map_noise(t).numpy(), clf.map_noise(t).numpy()])[0]
+    sims = [LaneSim2(prog, member=m) for m in range(k)]
+    for s in sims:
+        s.load_x(x[0].numpy())
+    np.testing.assert_allclose(run_forward_split(sims, row), ref, rtol=2e-5, atol=2e-5)
+    want = xr.grad[0].numpy()
+    for m, s in enumerate(sims):
+        np.testing.assert_allclose(s.read_slot(prog.pred_off, prog.pred_stride, H, D), ref, rtol=2e-5, atol=2e-5, err_msg=f"member {m}")
+        np.testing.assert_allclose(s.grad(), want, rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(want).max())), err_msg=f"member {m}: gradient")
+
+
 def test_grouped_program_of_other_shapes_compiles_or_refuses_cleanly(amd_lib):
     """Nets whose deepest level does not offer a grouped op (too few channels for whole lane groups per member, a horizon whose deepest
     level is longer than 16 / k positions) must answer ValueError -- the signal that keeps a request on the ordinary program."""
