@@ -67,7 +67,7 @@ class BaseClassifier:
         else:
             loss = self.loss(x, noise, y)
             opt.zero_grad()
-            with train.grads_in_place():
+            with train.grads_in_place(self.model.parameters()):
                 loss.backward()
         grad_norm = None
         clip = self.grad_clip_norm if isinstance(self.grad_clip_norm, float) else None

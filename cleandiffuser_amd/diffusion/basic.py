@@ -77,7 +77,7 @@ class DiffusionModel:
         g = train.graphed_step(self, x0, condition, kwargs)
         if g is None:
             loss = self.loss(x0, condition, **kwargs)
-            with train.grads_in_place():               # the library's nodes add parameter gradients straight into .grad
+            with train.grads_in_place(self.model.parameters()):               # the library's nodes add parameter gradients straight into .grad
                 loss.backward()
             return loss
         loss = g.replay(x0, condition)

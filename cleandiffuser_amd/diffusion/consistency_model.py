@@ -189,7 +189,7 @@ class ContinuousConsistencyModel(DiffusionModel):
         #  they add the parameter gradients straight into .grad and issue the weight-gradient products as batched launches.  The step
         #  itself is not captured as a HIP graph: the training loss draws from numpy and reports a Python float per call)
         from ..engine import train
-        with train.grads_in_place():
+        with train.grads_in_place(self.model.parameters()):
             loss.backward()
         grad_norm = self._apply_gradients(update_ema)
         if loss_type == "training":

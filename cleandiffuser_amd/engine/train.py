@@ -78,21 +78,40 @@ def _wants_grad(net, *tensors) -> bool:
 # report "no gradient" to autograd.  Anywhere else -- torch.autograd.grad(), a user's own backward() over loss(), parameters with
 # hooks, views of parameters -- autograd's own accumulation runs as before.
 _in_place_depth = 0          # (module-wide, not thread-local: autograd runs the nodes of a device on its own worker thread)
+_in_place_scopes: list = []  # one entry per open grads_in_place(): the ids of the parameters it covers, or None = every parameter
 
 
 @contextlib.contextmanager
-def grads_in_place():
+def grads_in_place(params=None):
+    """`params`: the parameters of the agent whose update() this is -- only THEY take gradients in place while the scope is
+    open (the flag is process-wide because autograd's worker threads run the nodes; another thread's backward over another net keeps
+    autograd's own accumulation).  None: every parameter (tests, a caller that owns the process)."""
     global _in_place_depth
+    scope = None if params is None else {id(p) for p in params}
     _in_place_depth += 1
+    _in_place_scopes.append(scope)
     try:
         yield
     finally:
         _in_place_depth -= 1
+        _in_place_scopes.remove(scope)
+
+
+def _reducer_may_listen() -> bool:
+    """A process group with more than one rank is up: a DistributedDataParallel / FSDP reducer may hang on the parameters' gradient
+    accumulators (C++ post hooks, invisible from Python), and those fire only when autograd itself accumulates -- no in-place sums."""
+    try:
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    except Exception:        # noqa: BLE001
+        return False
 
 
 def _grad_slot(p) -> Optional[torch.Tensor]:
     """``p.grad`` as the tensor a kernel may add p's gradient into (created zeroed if missing), or None: autograd accumulates."""
     if _in_place_depth <= 0 or os.environ.get("CDX_TRAIN_INPLACE_GRADS", "1") == "0":
+        return None
+    if not any(sc is None or id(p) in sc for sc in _in_place_scopes) or _reducer_may_listen():
         return None
     if not isinstance(p, nn.Parameter) or not p.is_leaf or not p.requires_grad or p.dtype != torch.float32 or p._backward_hooks or \
             getattr(p, "_post_accumulate_grad_hooks", None):
@@ -1339,12 +1358,12 @@ class GraphedStep:
                         mode = torch.cuda.get_sync_debug_mode()
                         torch.cuda.set_sync_debug_mode("error")
                         try:
-                            with grads_in_place():
+                            with grads_in_place(params):
                                 agent.loss(self.x0, self.cond).backward()
                         finally:
                             torch.cuda.set_sync_debug_mode(mode)
                     else:
-                        with grads_in_place():
+                        with grads_in_place(params):
                             agent.loss(self.x0, self.cond).backward()
         except Exception as e:  # noqa: BLE001 -- whatever the probe step tripped over: this agent's step is not ours to capture
             torch.cuda.current_stream(dev).wait_stream(side)
@@ -1362,7 +1381,7 @@ class GraphedStep:
             # (thread-local error mode: a CUDA call from ANOTHER thread -- a DataLoader's pin_memory thread -- does not fail the capture)
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.loss = agent.loss(self.x0, self.cond)
-                with grads_in_place():                 # (the captured launches add into the static .grad tensors directly)
+                with grads_in_place(params):                 # (the captured launches add into the static .grad tensors directly)
                     self.loss.backward()
         except Exception as e:  # noqa: BLE001 -- something the probe did not see (it is a prototype check, and blind to pageable H2D copies)
             # torch.cuda.graph's exit has ended the capture; whatever half-built graph exists is dropped, the eager step serves this agent.

@@ -115,6 +115,43 @@ def test_native_training_forward_is_the_modules_autograd_graph(name):
                 _close(g, gp0[n], f"{name} (in place {in_place}): {n}")
 
 
+def test_in_place_gradient_scope_covers_the_named_parameters_only(monkeypatch):
+    """``grads_in_place(params)`` is a process-wide switch (autograd's worker threads run the nodes), so it names the
+    parameters it is for: while agent A's update() is inside its backward, a backward over ANOTHER net -- from another thread, or a
+    nested one -- keeps autograd's own accumulation (its caller may be torch.autograd.grad(), which must see the gradients); and with a
+    multi-rank process group up nothing is summed in place (a DDP reducer listens on the gradient accumulators)."""
+    net_a, fwd, args = _case("janner")
+    net_b, _, _ = _case("janner")
+    net_a.train(), net_b.train()
+    wgt = _wgt(net_a, args, 1)
+    _, _, want = _reference(net_b, args, wgt)
+    _, _, want_a = _reference(net_a, args, wgt)
+    net_a.zero_grad(set_to_none=True), net_b.zero_grad(set_to_none=True)
+    slots = []
+    orig = train._grad_slot
+    monkeypatch.setattr(train, "_grad_slot", lambda p: (slots.append((id(p), orig(p) is not None)), orig(p))[1])
+    ids_a, ids_b = {id(p) for p in net_a.parameters()}, {id(p) for p in net_b.parameters()}
+    with emulated():
+        with train.grads_in_place(net_a.parameters()):
+            (fwd(net_b, args[0], *args[1:]) * wgt).sum().backward()          # B's backward inside A's scope: autograd accumulates
+            assert slots and all(not took for i, took in slots if i in ids_b)
+            for n, g in _grads(net_b).items():
+                _close(g, want[n], f"outside the scope: {n}")
+            slots.clear()
+            (fwd(net_a, args[0], *args[1:]) * wgt).sum().backward()          # A's own: in place
+            assert any(took for i, took in slots if i in ids_a)
+        slots.clear()
+        import torch.distributed as dist
+        monkeypatch.setattr(dist, "is_initialized", lambda: True)
+        monkeypatch.setattr(dist, "get_world_size", lambda *a, **k: 2)
+        net_a.zero_grad(set_to_none=True)
+        with train.grads_in_place(net_a.parameters()):
+            (fwd(net_a, args[0], *args[1:]) * wgt).sum().backward()
+        assert slots and not any(took for _, took in slots)
+    for n, g in _grads(net_a).items():
+        _close(g, want_a[n], f"under a process group: {n}")
+
+
 @pytest.mark.parametrize("name", ["janner", "chiunet", "chitf", "pearce"])
 def test_in_place_gradient_sums_accumulate_and_leave_hooked_or_frozen_parameters_to_autograd(name):
     net, fwd, args = _case(name)
