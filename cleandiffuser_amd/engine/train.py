@@ -22,6 +22,7 @@ gradients of every parameter against ``torch.autograd`` of the module, and the `
 import contextlib
 import functools
 import os
+import threading
 from typing import Optional
 
 import torch
@@ -319,25 +320,28 @@ class _WeightPacks:
         return t
 
 
-_active_packs: Optional[_WeightPacks] = None
+_tls = threading.local()     # .packs: the weight-layout registry of the forward pass THIS thread is in (nodes keep it on ctx for their backward)
+
+
+def _current_packs() -> Optional[_WeightPacks]:
+    return getattr(_tls, "packs", None)
 
 
 @contextlib.contextmanager
 def _weight_packs(net):
     """The forward pass of `net` on the library's nodes: its weight layouts are current inside (one launch, if anything changed)."""
-    global _active_packs
-    prev = _active_packs
+    prev = _current_packs()
     packs = None
     if os.environ.get("CDX_TRAIN_PACKS", "1") != "0":
         packs = net.__dict__.get("_cdx_weight_packs")
         if packs is None:
             packs = net.__dict__["_cdx_weight_packs"] = _WeightPacks()
         packs.refresh(list(net.parameters()))
-    _active_packs = packs
+    _tls.packs = packs
     try:
         yield
     finally:
-        _active_packs = prev
+        _tls.packs = prev
 
 
 def _pack(kind: str, w: torch.Tensor, packs: Optional[_WeightPacks]) -> torch.Tensor:
@@ -376,7 +380,7 @@ class _Conv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, batch, l_in, stride, pad):
         x = x.contiguous()
-        ctx.packs = _active_packs
+        ctx.packs = _current_packs()
         y = blocks.conv1d(x, _pack("conv", weight, ctx.packs), bias, batch, l_in, stride, pad,
                           partial=_splitk_scratch(x.shape[0] // stride, weight.shape[0], weight.shape[1] * weight.shape[2], x.device))
         ctx.save_for_backward(x, weight)
@@ -416,7 +420,7 @@ class _ConvT(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, batch, l_in):
         x = x.contiguous()
-        ctx.packs = _active_packs
+        ctx.packs = _current_packs()
         y = blocks.conv_transpose1d_k4s2p1(x, (_pack("convt_even", weight, ctx.packs), _pack("convt_odd", weight, ctx.packs)), bias, batch, l_in)
         ctx.save_for_backward(x, weight)
         ctx.geom = (batch, l_in, bias is not None)
@@ -514,7 +518,7 @@ class _ConvPair(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, wr, br, batch, l_in, pad):
         x = x.contiguous()
-        ctx.packs = _active_packs
+        ctx.packs = _current_packs()
         c_out, c_in, k = w1.shape
         y1 = blocks.conv1d(x, _pack("conv", w1, ctx.packs), b1, batch, l_in, 1, pad, partial=_splitk_scratch(x.shape[0], c_out, c_in * k, x.device))
         if wr is None:
@@ -801,7 +805,7 @@ class _LinearMish(torch.autograd.Function):
         x = x.contiguous()
         z = _linear(x, weight, bias)
         ctx.mish = mish
-        ctx.params, ctx.packs = (weight, bias), _active_packs
+        ctx.params, ctx.packs = (weight, bias), _current_packs()
         ctx.save_for_backward(x, weight, z if mish else x.new_empty(0))
         return blocks.activation(z, "mish") if mish else z
 
@@ -827,7 +831,7 @@ class _LinearAct(torch.autograd.Function):
         x = x.contiguous()
         z = _linear(x, weight, bias)
         ctx.act = act
-        ctx.params, ctx.packs = (weight, bias), _active_packs
+        ctx.params, ctx.packs = (weight, bias), _current_packs()
         ctx.save_for_backward(x, weight, z if act else x.new_empty(0))
         return blocks.activation(z, act) if act else z
 
