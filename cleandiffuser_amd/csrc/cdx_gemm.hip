@@ -40,6 +40,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef CDX_GEMM_W8_DEFAULT
 #define CDX_GEMM_W8_DEFAULT 1               // the 8-wave shape of the 128 x 128 tile by default (same-box A/B: profiles/r05_gemm_w8_ab.txt)
 #endif
+#ifndef CDX_GEMM_PERSIST
+#define CDX_GEMM_PERSIST 0                    // 1: the 8-wave kernel walks several tiles per workgroup (grid = resident slots), the next tile's first
+#endif                                        //    K tile requested before the epilogue of the current one (A/B builds; round 6)
 #ifndef CDX_GEMM_KBLOCK
 #define CDX_GEMM_KBLOCK 1                     // 0: one sequential fma chain over K per element (rounds 1-4; A/B builds)
 #endif
@@ -282,7 +285,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (WT == 2 ? 3 : 4))) void cd
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_m = (g.M + BMN - 1) / BMN, tiles_n = (g.N + BMN - 1) / BMN;
     const int n_tiles = tiles_m * tiles_n;
-    const int lin = blockIdx.x % n_tiles, slice = blockIdx.x / n_tiles;     // split-K: slice of the K range
+    constexpr bool PERSIST = CDX_GEMM_PERSIST && NW == 8 && FAST;
+    const int vb_end = PERSIST ? n_tiles * k_split : (int)blockIdx.x + 1;
+    bool prefetched = false;
+    float4 ra[NLD], rb[NLD];
+  for (int vb = blockIdx.x; vb < vb_end; vb += (PERSIST ? (int)gridDim.x : 1 << 30)) {
+    const int lin = vb % n_tiles, slice = vb / n_tiles;     // split-K: slice of the K range
     // Tiles are walked n-fastest: concurrently resident workgroups share a few A row blocks across all their N tiles (the whole W
     // fits L2), instead of re-fetching each A block N/128 times -- measured +15-17 % on the config-4/5 shapes over m-fastest.
     // Optional XCD-aware variant (workgroup b runs on XCD b % 8): one contiguous range of that list per XCD.
@@ -305,7 +313,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (WT == 2 ? 3 : 4))) void cd
 
     int lrow[NLD], arow[NLD], wrow[NLD];
     const float *ap[NLD], *wp[NLD];
-    float4 ra[NLD], rb[NLD];
     // implicit-GEMM conv (FAST: conv_cin % 4 == 0, so an aligned float4 never straddles two taps)
     constexpr bool conv = CONV;                      // compile-time: the plain-GEMM instantiations carry no conv code at all
     int conv_in0[NLD];
@@ -377,7 +384,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (WT == 2 ? 3 : 4))) void cd
 
     // Two LDS stages, ONE barrier per K tile: while the MFMAs of tile t run out of stage t & 1, the registers
     // holding tile t + 1 (fetched a whole tile earlier) are written to the other stage and tile t + 2 is requested.
-    fetch(kt0);
+    if (!(PERSIST && prefetched)) fetch(kt0);            // (persistent walk: requested before the previous tile's epilogue)
     stage(0);
     if (nk > 1) fetch(kt0 + BK);
     __syncthreads();
@@ -507,6 +514,28 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (WT == 2 ? 3 : 4))) void cd
     // (the loop's last barrier already separates the final LDS reads from the patches written below)
     // fused epilogue, one specialisation per activation (the branch is uniform; only the taken copy touches the I-cache)
     const int row0 = bm + wm, col0 = bn + wn;
+    if constexpr (PERSIST) {
+        // the NEXT tile of this workgroup: its first K tile is requested now and lands during the epilogue below (plain GEMMs only: a
+        // conv's tap validity belongs to the tile's own set-up)
+        prefetched = false;
+        const int vn = vb + (int)gridDim.x;
+        if (vn < vb_end && !conv) {
+            const int ln = vn % n_tiles, sn = vn / n_tiles;
+            int tn = ln;
+            if (xcd_order) {
+                const int xcd = ln & 7, t = ln >> 3, q8 = n_tiles >> 3, r8 = n_tiles & 7;
+                tn = xcd * q8 + min(xcd, r8) + t;
+            }
+            const int bmn_ = (tn / tiles_n) * BMN, bnn_ = (tn % tiles_n) * BMN;
+            const int ktn = sn * per * BK;
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                ra[i] = *reinterpret_cast<const float4*>(g.A + (size_t)min(bmn_ + lrow[i], g.M - 1) * g.lda + q4 + ktn);
+                rb[i] = *reinterpret_cast<const float4*>(g.W + (size_t)min(bnn_ + lrow[i], g.N - 1) * g.ldw + q4 + ktn);
+            }
+            prefetched = true;
+        }
+    }
     float* patch = smem + wave * (32 * GM_EP_LD);
     const bool fe = fast_ep != 0;
     if (k_split > 1) {                                   // raw partial tile; the epilogue runs in gm_splitk_reduce_kernel
@@ -515,6 +544,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (WT == 2 ? 3 : 4))) void cd
         gp.bias = nullptr; gp.gate = nullptr; gp.residual = nullptr; gp.table = nullptr;
         gm_epilogue_any<CDX_ACT_NONE, WTM, WTN>(gp, acc, patch, row0, col0, lane, (g.N % 4 == 0));
         gm_stamp(3);
+        if (PERSIST) { __syncthreads(); continue; }
         return;
     }
     switch (g.act) {
@@ -528,6 +558,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (WT == 2 ? 3 : 4))) void cd
         default: gm_epilogue_any<CDX_ACT_NONE, WTM, WTN>(g, acc, patch, row0, col0, lane, fe); break;
     }
     gm_stamp(3);
+    if (PERSIST) __syncthreads();                        // the patches alias the staging area of the next tile
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1625,7 +1657,13 @@ static int gm_launch(const cdx_gemm_args* g_in, void* hip_stream, bool force_sma
                         (!g->residual || g->ldr % 4 == 0) && (ep_ptrs % 16 == 0);
     static const char* env_x = getenv("CDX_GEMM_XCD_ORDER");      // tuning hook: 1 = one contiguous tile range per XCD
     const int xcd_order = env_x ? atoi(env_x) : 0;    // measured: +-2 % either way once tiles are walked n-fastest
+#if CDX_GEMM_PERSIST
+    static const char* env_ps = getenv("CDX_GEMM_PERSIST_SLOTS");    // workgroups of a persistent launch (default: two per CU)
+    const int slots_ps = env_ps && atoi(env_ps) > 0 ? atoi(env_ps) : 512;
+    const dim3 grid(w8 && vec ? (tiles * k_split < slots_ps ? tiles * k_split : slots_ps) : tiles * k_split), block(w8 ? 512 : GM_THREADS);
+#else
     const dim3 grid(tiles * k_split), block(w8 ? 512 : GM_THREADS);
+#endif
     const size_t lds8 = CDX_GEMM_W8_BK == 32 ? (size_t)4 * 32 * 130 * sizeof(float) : 0;
     if (w8 && lds8) {
         static bool raised[2] = {false, false};
