@@ -287,7 +287,7 @@ def other_configs(device):
         except Exception as e:  # noqa: BLE001 -- one broken side measurement must not take the headline down
             out.append({"name": tag, "error": f"{type(e).__name__}: {e}"})
 
-    big("config2_B3200", bc.cfg2big, "cdx_unet2_kernel<3, 8> (three trajectories, 8 wave64 per workgroup; the last 128 one per workgroup)", B=3200)
+    big("config2_B3200", bc.cfg2big, "cdx_unet2_kernel<3, 8> / <2, 8> (rounds of 256 workgroups: three rounds at three trajectories per workgroup + two at two, runtime2.plan_parts)", B=3200)
     # what one rank of an 8- / 2-GPU run of the metric's batch gets (and the real-time-control case): the small-batch mode
     big("config2_B32", bc.cfg2big, "cdx_unet2_kernel<1, 8, ..., split>: one trajectory over 4 workgroups of an XCD, all-gather of the cut "
         "ops through L2 (latency is the figure of merit: ms_per_call)", reps=10, B=32)
@@ -296,7 +296,7 @@ def other_configs(device):
         "stream-bound layers grouped over 4 workgroups + classifier forward/backward on each member's own trajectory + shifted solver step "
         "+ final log_p, one launch per guided sample() call (and its idle repair launch)", reps=10, B=256)
     big("config2_guided_B3200", bc.cfg2g, "cdx_unet2_kernel<3, 8, true>: three trajectories per workgroup (compact guided program, saved "
-        "normalised tensors in a global workspace), 4 rounds of 768 + 128 one per workgroup; the batch the shipped Diffuser pipelines "
+        "normalised tensors in a global workspace), three rounds of 768 + two rounds of two per workgroup; the batch the shipped Diffuser pipelines "
         "sample (50 environments x 64 plans, all with w_cg > 0)", reps=2, B=3200)
     big("kitchen_guided_B256", bc.cfgKg, "cdx_unet2_kernel<1, 8, true>: guided program of the shipped kitchen Diffuser size (model_dim 64, "
         "H=32, D=69), saved tensors in the global workspace", B=256)
