@@ -170,7 +170,8 @@ def plan_film_table(comp: _Compiled2, module, plan, device, modules=None, zero_r
     # one entry per (device, module, program variant): replaced -- not accumulated -- when the weight signature changes (a train /
     # evaluate loop that keeps the solver's cached plan would otherwise add a device table + a long tuple key per ema_update)
     memo = plan.__dict__.setdefault("_memo", {})
-    key = ("film2", str(device), id(module), comp.prog.nw, bool(comp.prog.compact), comp.prog.ws_floats, len(comp.prog.embtabs), zero_row)
+    key = ("film2", str(device), id(module), comp.prog.nw, bool(comp.prog.compact), comp.prog.ws_floats, len(comp.prog.embtabs), zero_row,
+           comp.prog.meta.get("group_k", 0), comp.prog.meta.get("split_k", 0))        # (member programs: their own table, built from their own blob)
     hit = memo.get(key)
     if hit is None or hit[0] != comp.sig:
         t_vec = R.device_times(plan, device)
