@@ -1,5 +1,5 @@
-"""Stress of the GROUPED GUIDED launch (GPU box): N calls at B = 256 / 200 / 130 with fresh draws, each compared with the ordinary guided
-program on the same draws; reports the largest deviation, lost granules (none expected) and whether the mode stayed on."""
+"""Stress of the GROUPED and SMALL-BATCH GUIDED launches (GPU box): N calls at B = 256 / 200 / 130 / 100 / 40 / 8 with fresh draws, each compared
+with the ordinary guided program on the same draws; reports the largest deviation, lost granules (none expected) and whether the modes stayed on."""
 import os
 import sys
 
@@ -24,14 +24,15 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 g = torch.Generator().manual_seed(5)
 worst = 0.0
 for i in range(n):
-    B = (256, 200, 130)[i % 3]
+    B = (256, 200, 130, 100, 40, 8)[i % 6]
     prior = torch.zeros(B, 32, 23)
     prior[:, 0, :17] = torch.randn(B, 17, generator=g)
     zs = [torch.randn(B, 32, 23, generator=g).to(DEV) for _ in range(5)]
     kw = dict(solver="ddpm", n_samples=B, sample_steps=4, temperature=0.5, w_cg=0.2)
     os.environ.pop("CDX_UNET2_GUIDED_GROUP", None)
+    os.environ.pop("CDX_UNET2_GUIDED_SPLIT", None)
     xg, lg = agent.sample(prior.to(DEV), noise=list(zs), **kw)
-    os.environ["CDX_UNET2_GUIDED_GROUP"] = "0"
+    os.environ["CDX_UNET2_GUIDED_GROUP"] = os.environ["CDX_UNET2_GUIDED_SPLIT"] = "0"
     xp, lp = agent.sample(prior.to(DEV), noise=list(zs), **kw)
     d = max(float((xg - xp).abs().max()), float((lg["log_p"] - lp["log_p"]).abs().max()))
     assert torch.isfinite(xg).all() and d < 5e-4, (i, B, d)
@@ -39,4 +40,4 @@ for i in range(n):
 torch.cuda.synchronize()
 runtime2.check_split_errors()
 dev = torch.device(DEV)
-print(f"{n} grouped guided calls: max |grouped - ordinary| = {worst:.3e}; mode still on: {runtime2._gguided_ok.get(dev)}; lost granules: {int(runtime2._split_errs[dev][1][0]) if dev in runtime2._split_errs else 0}")
+print(f"{n} grouped / small-batch guided calls: max |member program - ordinary| = {worst:.3e}; modes still on: {runtime2._gguided_ok.get(dev)} / {runtime2._sguided_ok.get(dev)}; lost granules: {int(runtime2._split_errs[dev][1][0]) if dev in runtime2._split_errs else 0}")
