@@ -518,7 +518,7 @@ def test_lane_sim2_grouped_program_reproduces_reference_forward(k, amd_lib):
     assert all(np.array_equal(a, b) for a, b in zip(outs, again))
 
 
-@pytest.mark.parametrize("k", [2, 4])
+@pytest.mark.parametrize("k", [4])           # (k = 2: the unguided grouped twin test above; the GPU suite runs both)
 def test_lane_sim2_grouped_guided_program_prediction_and_gradient(k, amd_lib):
     """Round 6: the GROUPED GUIDED program (P2.compile_guided2_group) -- the denoiser's ten stream-bound layers grouped as in the
     unguided grouped program, every other op (the rest of the denoiser, the classifier's forward and backward ops with their saved
@@ -554,7 +554,7 @@ def test_lane_sim2_grouped_guided_program_prediction_and_gradient(k, amd_lib):
         np.testing.assert_allclose(sims[m].grad(), want, rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(want).max())), err_msg=f"member {m}: gradient")
 
 
-@pytest.mark.parametrize("k", [2, 4])
+@pytest.mark.parametrize("k", [4])           # (k = 2: the unguided split twin test; the GPU suite runs B = 100 on two workgroups per trajectory)
 def test_lane_sim2_split_guided_program_prediction_and_gradient(k, amd_lib):
     """Round 6: the SMALL-BATCH guided program (P2.compile_guided2_split) -- one trajectory over k workgroups, the denoiser's ops cut by
     row tiles exactly as in the unguided split program, the classifier's forward / backward ops computed by every member on its own
