@@ -48,6 +48,22 @@ def _native_loaded():
     torch.cuda.synchronize()
 
 
+def _profiled(body, activities=None, rerun=True):
+    """torch.profiler over ``body()`` -> (profiler, body's result).  roctracer occasionally hands the profiler NO device activity for a
+    region (one full-suite run in ~25 this round: every kernel name missing, only the host-side ops listed).  A test that asserts on
+    kernel names then has nothing to look at: the region is profiled once more where running it again is harmless (`rerun`), else the
+    test is skipped rather than failed for a tracing dropout."""
+    from torch.profiler import profile, ProfilerActivity
+    acts = activities or [ProfilerActivity.CPU, ProfilerActivity.CUDA]
+    for attempt in range(2 if rerun else 1):
+        with profile(activities=acts) as prof:
+            out = body()
+            torch.cuda.synchronize()
+        if any(e.device_time_total > 0 for e in prof.key_averages()):
+            return prof, out
+    pytest.skip("torch.profiler recorded no device activity for this region (roctracer dropout)")
+
+
 def _spy_launches(monkeypatch):
     """Counts launches of the program kernel (cdx_unet2_run via runtime2.launch): `n` and `v2` are the same number.  `repair`: the
     gated launches behind split / grouped launches (cdx.h: run_if) -- an empty grid unless a granule was lost -- counted apart."""
@@ -1876,11 +1892,11 @@ def test_update_accumulates_parameter_gradients_in_place(kind, amd_lib, monkeypa
         for n, p in params.items():
             p.grad = None if seed_grads is None else seed_grads[n].clone()
         torch.manual_seed(5)
-        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        def region():
             loss = agent.loss(x0, cond)
             with train.grads_in_place():
                 loss.backward()
-            torch.cuda.synchronize()
+        prof, _ = _profiled(region, [ProfilerActivity.CUDA], rerun=False)      # (a second pass would accumulate onto the gradients compared below)
         launches = sum(e.count for e in prof.key_averages() if e.device_time_total > 0)
         return {n: (None if p.grad is None else p.grad.clone()) for n, p in params.items()}, launches
     g0, n0 = backward(False, None)
@@ -1926,9 +1942,7 @@ def test_chiunet_update_runs_without_aten_conv_or_groupnorm_kernels(amd_lib, mon
     g = torch.Generator().manual_seed(3)
     x0, cond = torch.randn(64, 16, 2, generator=g).clamp(-1, 1).to(DEV), torch.randn(64, 2, 5, generator=g).to(DEV)
     agent.update(x0, cond)
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
-        log = agent.update(x0, cond)
-        torch.cuda.synchronize()
+    prof, log = _profiled(lambda: agent.update(x0, cond))
     assert np.isfinite(log["loss"])
     names = [e.key for e in prof.key_averages()]
     bad = [n for n in names if any(k in n.lower() for k in ("convolution", "miopen", "group_norm", "conv1d", "conv_transpose"))]
@@ -1962,9 +1976,7 @@ def test_update_runs_without_aten_conv_or_groupnorm_kernels(amd_lib):
         la_all = [a.update(x0.to(DEV)) for _ in range(3)]
     torch.manual_seed(11)
     lb_all = [b.update(x0) for _ in range(3)]
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
-        a.update(x0.to(DEV))
-        torch.cuda.synchronize()
+    prof, _ = _profiled(lambda: a.update(x0.to(DEV)), rerun=False)       # (a fifth update would leave the state budget checked below)
     names = [e.key for e in prof.key_averages()]
     bad = [n for n in names if any(w in n.lower() for w in ("convolution", "conv1d", "conv_transpose", "miopen", "group_norm", "native_batch_norm"))]
     assert not bad, f"ATen convolution / group_norm ops in a native update(): {bad}"
@@ -2144,12 +2156,12 @@ def test_critic_and_inverse_dynamics_updates_run_on_library_kernels(amd_lib):
         for (n, p), q in zip(hg._net().named_parameters(), hc._net().parameters()):
             assert float((p.detach().cpu() - q.detach()).abs().max()) <= 5e-6 * max(1.0, float(q.detach().abs().max())), (cls.__name__, n)
         heads.append(hg)
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    def region():
         iql_g.update_V(d(obs), d(act))
         iql_g.update_Q(d(obs), d(act), d(rew), d(nxt), d(done))
         for hg in heads:
             hg.update(d(obs), d(act), d(nxt))
-        torch.cuda.synchronize()
+    prof, _ = _profiled(region)
     names = [e.key for e in prof.key_averages()]
     bad = [n for n in names if any(w in n.lower() for w in ("addmm", "aten::mm", "layer_norm", "cijk_", "aten::linear"))]
     assert not bad, f"ATen GEMM / LayerNorm ops in the native head updates: {bad}"
@@ -2177,9 +2189,7 @@ def test_classifier_update_runs_on_library_kernels(amd_lib):
     la = [a.update(x.to(DEV), t.to(DEV), r.to(DEV))["loss"] for _ in range(3)]
     lb = [b.update(x, t, r)["loss"] for _ in range(3)]
     assert a.__dict__.get("_cdx_graphed") and not a.__dict__.get("_cdx_graph_off"), a.__dict__.get("_cdx_graph_off")
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
-        a.update(x.to(DEV), t.to(DEV), r.to(DEV))
-        torch.cuda.synchronize()
+    prof, _ = _profiled(lambda: a.update(x.to(DEV), t.to(DEV), r.to(DEV)), rerun=False)     # (the EMA budget below counts four updates)
     names = [e.key for e in prof.key_averages()]
     bad = [n for n in names if any(w in n.lower() for w in ("convolution", "conv1d", "miopen", "group_norm", "native_batch_norm"))]
     assert not bad, f"ATen convolution / group_norm ops in a native classifier update(): {bad}"
@@ -2215,9 +2225,7 @@ def test_dql_backprop_through_the_sampler_runs_on_library_kernels(amd_lib, monke
                               condition_cfg=obs, w_cfg=1.0, requires_grad=True, noise=list(zs))
         (-(act * q_w).sum(-1).mean()).backward()
         return act.detach().clone(), obs.grad.clone(), {n: p.grad.clone() for n, p in agent.model.named_parameters() if p.grad is not None}
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
-        a1, go1, gp1 = run(True)
-        torch.cuda.synchronize()
+    prof, (a1, go1, gp1) = _profiled(lambda: run(True))
     names = [e.key for e in prof.key_averages()]
     assert not [n for n in names if "aten::addmm" in n or "aten::mish" in n or "Cijk_" in n], "ATen Linear / Mish kernels in the native DQL path"
     assert any("cdx_conv_wgrad_kernel" in n for n in names) and any("cdx_gemm_kernel" in n for n in names)
@@ -2404,9 +2412,7 @@ def test_update_runs_without_aten_optimiser_launches(amd_lib):
         torch.manual_seed(12)
         a.loss(x0).backward()
         torch.cuda.synchronize()
-        with profile(activities=[ProfilerActivity.CUDA]) as prof:
-            a._apply_gradients(True)
-            torch.cuda.synchronize()
+        prof, _ = _profiled(lambda: a._apply_gradients(True), [ProfilerActivity.CUDA], rerun=False)
         torch.manual_seed(12)
         b.update(x0)                                   # (the twin takes the same fourth step)
     kernels = [e.key for e in prof.key_averages() if not e.key.startswith("hip") and "Memcpy" not in e.key and "Memset" not in e.key]
