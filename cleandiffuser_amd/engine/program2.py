@@ -54,9 +54,12 @@ HALO2 = 2                     # zero rows on either side of a slot: covers kerne
 MIN_SLICE = int(os.environ.get("CDX_UNET2_MIN_SLICE", "3"))      # shortest K slice (records) worth a wave of its own
 FUSE_SKIP = os.environ.get("CDX_UNET2_FUSE_SKIP", "1") != "0"    # 1x1 skip convs ride in their block's second conv op ...
 FUSE_MAX_RECORDS = int(os.environ.get("CDX_UNET2_FUSE_MAX", "100"))   # ... unless that leaves the main conv K slices longer than this
-SPLIT_MIN_RECORDS = int(os.environ.get("CDX_UNET2_SPLIT_MIN", "32"))  # split programs: an op is cut over the members only if a wave of
+SPLIT_MIN_RECORDS = int(os.environ.get("CDX_UNET2_SPLIT_MIN", "8"))  # split programs: an op is cut over the members only if a wave of
                                                                        # the uncut op streams at least this many records (an
-                                                                       # exchange costs ~3 k cycles, a record ~170 per wave)
+                                                                       # exchange costs ~3 k cycles, a record ~170 per wave).
+                                                                       # Round 6: 32 -> 8 (config 2: 15 -> 21 cut ops; same-box sweep
+                                                                       # 0 / 4 / 8 / 12 / 16 / 24 / 32 / 48 / 64: B = 32 3.167 -> 3.133 ms,
+                                                                       # profiles/r06_split_min_sweep.txt)
 
 (W2_KIND, W2_FLAGS, W2_COUT, W2_LOUT, W2_LCOLS, W2_CSTRIDE, W2_OSTRIDE, W2_MODE, W2_NT, W2_NITEMS, W2_ITEMS, W2_DST,
  W2_DST_STRIDE, W2_SSTRIDE, W2_KSPLIT, W2_BOFF, W2_GAMMA, W2_BETA, W2_EMB, W2_RES, W2_RES_STRIDE, W2_CG4_SHIFT, W2_INV_CNT,

@@ -462,7 +462,7 @@ def test_lane_sim2_split_program_reproduces_reference_forward(name, k, amd_lib, 
     c = cases.CASES[name]
     net = agent.model_ema["diffusion"]
     if name == "janner_cfg2_ddim":                       # default threshold: only the stream-bound layers are cut (an exchange costs ~3 k cycles)
-        assert 8 <= sum(1 for op in P2.compile_janner2_split(net, c["horizon"], k).ops if op[P2.W2_XG]) <= 20
+        assert 8 <= sum(1 for op in P2.compile_janner2_split(net, c["horizon"], k).ops if op[P2.W2_XG]) <= 24
     monkeypatch.setattr(P2, "SPLIT_MIN_RECORDS", 0)      # here: cut everything that can be cut
     prog = P2.compile_janner2_split(net, c["horizon"], k)
     assert prog.lds_bytes(1) <= 160 * 1024 and prog.meta["split_k"] == k and len(prog.meta["member_ops"]) == k
