@@ -1606,7 +1606,9 @@ static int gm_launch(const cdx_gemm_args* g_in, void* hip_stream, bool force_sma
     static const char* env_t = getenv("CDX_GEMM_SMALL_TILE_BELOW");          // tuning hook
     // (with the row-run staging map the 64 x 64 tiles pay up to ~500 big tiles when the launch cannot split K instead -- ChiTransformer
     //  +3.5 %, DiT shards +0.5-2 %, profiles/r04_gemm_tile_threshold.txt; launches that CAN split K keep the 128 x 128 tiles: config 3 -8 %)
-    const int small_below = env_t ? atoi(env_t) : (g->partial != nullptr && g->partial_slices > 1 ? 192 : 520);
+    // (round 6, on the 8-wave kernel: outputs wider than 64 columns take the 128 x 128 tiles from 256 tiles on -- ChiTransformer's N = 256
+    //  projections at B = 1024: +4 %; narrow outputs (a 29-column head) keep the 64 x 64 tiles up to 520, profiles/r06_gemm_thresholds_ab.txt)
+    const int small_below = env_t ? atoi(env_t) : (g->partial != nullptr && g->partial_slices > 1 ? 192 : (g->N <= 64 ? 520 : 256));
     // the 64 x 64 variant stages 32-wide K tiles: with K % 32 != 0 but K % 16 == 0 the 128 x 128 kernel keeps its unguarded loads
     const bool small = force_small || (tiles_big < small_below && (g->K % 32 == 0 || g->K % 16 != 0));
     // 128 x 128 tiles with unguarded loads take the 8-wave shape (K-blocked sums; four waves per SIMD); CDX_GEMM_W8=0: the 4-wave
@@ -1656,7 +1658,7 @@ static int gm_launch(const cdx_gemm_args* g_in, void* hip_stream, bool force_sma
     const int fast_ep = (g->N % 4 == 0) && (g->ldc % 4 == 0) && (!g->gate || g->ldg % 4 == 0) &&
                         (!g->residual || g->ldr % 4 == 0) && (ep_ptrs % 16 == 0);
     static const char* env_x = getenv("CDX_GEMM_XCD_ORDER");      // tuning hook: 1 = one contiguous tile range per XCD
-    const int xcd_order = env_x ? atoi(env_x) : 0;    // measured: +-2 % either way once tiles are walked n-fastest
+    const int xcd_order = env_x ? atoi(env_x) : 1;    // rounds 3-5: +-2 % either way; on the round-6 build +1-2 % for DiT / ChiTransformer, neutral elsewhere
 #if CDX_GEMM_PERSIST
     static const char* env_ps = getenv("CDX_GEMM_PERSIST_SLOTS");    // workgroups of a persistent launch (default: two per CU)
     const int slots_ps = env_ps && atoi(env_ps) > 0 ? atoi(env_ps) : 512;
