@@ -1628,7 +1628,10 @@ static int gm_launch(const cdx_gemm_args* g_in, void* hip_stream, bool force_sma
     hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
     // split-K when the tile count cannot fill the chip and K is long enough to pay for the second pass
     int k_split = 1;
-    const int slots = small ? 1024 : 768;
+    // resident workgroups of the chosen shape: 4 x 256 threads per CU (64 x 64 tiles), 3 (4-wave 128 x 128), 2 x 512 threads (8-wave 128 x 128:
+    // the round-5 shape kept the 4-wave shape's 768 until round 6 -- a 256-tile conv of config 3 was cut into 3 slices = 1.5 rounds of workgroups)
+    static const char* env_sl = getenv("CDX_GEMM_SPLITK_SLOTS");  // tuning hook
+    const int slots = env_sl && atoi(env_sl) > 0 ? atoi(env_sl) : (small ? 1024 : (w8 ? 512 : 768));
     static const char* env_f = getenv("CDX_GEMM_SPLITK_FILL");     // tuning hook: split K while tiles fill less than this % of the slots
     const int fill = env_f ? atoi(env_f) : 51;      // (<= half: the GroupNorm-folded reduction made the second pass free; config 3 +1.4 %)
     if (g->partial != nullptr && g->partial_slices > 1 && (long long)tiles * 100 < (long long)slots * fill) {
