@@ -1636,7 +1636,8 @@ static int gm_launch(const cdx_gemm_args* g_in, void* hip_stream, bool force_sma
     const int fill = env_f ? atoi(env_f) : 51;      // (<= half: the GroupNorm-folded reduction made the second pass free; config 3 +1.4 %)
     if (g->partial != nullptr && g->partial_slices > 1 && (long long)tiles * 100 < (long long)slots * fill) {
         const int nk_all = (g->K + bk - 1) / bk;
-        k_split = (slots + tiles - 1) / tiles;
+        static const char* env_rd = getenv("CDX_GEMM_SPLITK_ROUND");   // tuning hook: "floor" = never more workgroups than slots
+        k_split = (env_rd && env_rd[0] == 'f') ? (slots / tiles > 1 ? slots / tiles : 2) : (slots + tiles - 1) / tiles;
         if (k_split > g->partial_slices) k_split = g->partial_slices;
         static const char* env_mt = getenv("CDX_GEMM_SPLITK_MIN_TILES");     // tuning hook
         const int min_tiles = env_mt && atoi(env_mt) > 0 ? atoi(env_mt) : 8;
